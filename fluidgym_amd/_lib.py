@@ -1,0 +1,140 @@
+"""ctypes binding of ``libfluidgym_hip.so`` (C ABI in ``include/fluidgym_hip.h``).
+
+This is the only door from Python into the solver: there is NO CPU or PyTorch fallback.  If the
+shared library is missing, or a call is made without a GPU, the error is raised loudly.
+The role this module plays in the reference is the pybind11 module
+``fluidgym.simulation.extensions.PISOtorch`` (``extensions/PISOtorch.cpp:40-670``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfluidgym_hip.so")
+
+FG_MAX_SCALARS = 4
+FG_OK = 0
+FG_ERR_NOT_CONVERGED = -5
+FG_ERR_NOT_FINITE = -6
+FG_PERIODIC, FG_FIXED = 0, 1
+FG_DIRICHLET, FG_NEUMANN = 0, 1
+FG_VELOCITY, FG_PRESSURE, FG_SCALAR, FG_VELOCITY_SOURCE = 0, 1, 2, 3
+FG_BOUND_VELOCITY, FG_BOUND_SCALAR = 8, 16
+FG_SOLVER_CG, FG_SOLVER_JACOBI, FG_SOLVER_RBGS, FG_SOLVER_MGCG = 0, 1, 2, 3
+(FG_BUF_A, FG_BUF_C_OFF, FG_BUF_ADV_RHS, FG_BUF_VEL_RESULT, FG_BUF_H, FG_BUF_DIV, FG_BUF_P_RESULT,
+ FG_BUF_SCALAR_RESULT) = range(8)
+
+
+class FgConfig(Structure):
+    _fields_ = [
+        ("dims", c_int32),
+        ("nx", c_int32),
+        ("ny", c_int32),
+        ("nz", c_int32),
+        ("batch", c_int32),
+        ("n_scalars", c_int32),
+        ("face_type", c_int32 * 6),
+        ("scalar_bc", (c_int32 * FG_MAX_SCALARS) * 6),
+        ("device", c_int32),
+    ]
+
+
+class FgSolveInfo(Structure):
+    _fields_ = [
+        ("final_residual", c_float),
+        ("used_iterations", c_int32),
+        ("converged", c_int32),
+        ("is_finite", c_int32),
+    ]
+
+    def __repr__(self):
+        return (f"FgSolveInfo(residual={self.final_residual:.3e}, iterations={self.used_iterations}, "
+                f"converged={bool(self.converged)}, finite={bool(self.is_finite)})")
+
+
+class FgStepOptions(Structure):
+    _fields_ = [
+        ("corrector_steps", c_int32),
+        ("advect_scalar", c_int32),
+        ("pressure_method", c_int32),
+        ("max_iterations", c_int32),
+        ("advection_tol", c_float),
+        ("pressure_tol", c_float),
+        ("buoyancy_axis", c_int32),
+        ("buoyancy_factor", c_float),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/fluidgym_hip.h
+SIGNATURES = {
+    "fg_abi_version": (c_int, []),
+    "fg_last_error": (c_char_p, []),
+    "fg_create": (c_int, [POINTER(FgConfig), POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_void_p)]),
+    "fg_destroy": (c_int, [c_void_p]),
+    "fg_bind": (c_int, [c_void_p, c_int, c_void_p]),
+    "fg_set_viscosity": (c_int, [c_void_p, c_float]),
+    "fg_set_scalar_viscosity": (c_int, [c_void_p, c_int, c_float]),
+    "fg_max_velocity": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fg_boundary_flux_balance": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fg_setup_advection": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fg_solve_advection": (c_int, [c_void_p, c_int, c_int, c_float, c_int, POINTER(FgSolveInfo), c_void_p]),
+    "fg_copy_scalar_result_to_blocks": (c_int, [c_void_p, c_int, c_void_p]),
+    "fg_setup_pressure_matrix": (c_int, [c_void_p, c_void_p]),
+    "fg_setup_pressure_rhs": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fg_solve_pressure": (c_int, [c_void_p, c_int, c_float, c_int, c_int, POINTER(FgSolveInfo), c_void_p]),
+    "fg_correct_velocity": (c_int, [c_void_p, c_void_p]),
+    "fg_copy_velocity_result_to_blocks": (c_int, [c_void_p, c_void_p]),
+    "fg_copy_velocity_result_from_blocks": (c_int, [c_void_p, c_void_p]),
+    "fg_piso_step": (c_int, [c_void_p, c_void_p, POINTER(FgStepOptions), POINTER(c_int32), c_void_p]),
+    "fg_make_divergence_free": (c_int, [c_void_p, c_float, c_int, POINTER(FgSolveInfo), c_void_p]),
+    "fg_get_buffer": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),
+    "fg_read_buffer": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "fg_poisson_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fg_poisson_jacobi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "fg_poisson_rbgs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "fg_poisson_cg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
+                              c_void_p]),
+    "fg_coords_to_transforms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP extension is missing or failed -- there is no fallback path."""
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fluidgym_amd/csrc`. fluidgym_amd has no CPU / PyTorch fallback."
+        )
+    # PyTorch-ROCm bundles its own libamdhip64; import it FIRST so that this library's
+    # libamdhip64.so.7 dependency resolves to the runtime already in the process (two HIP runtimes in
+    # one process do not see each other's devices/streams).
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fg_abi_version() != 1:
+        raise NativeLibraryError("libfluidgym_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, allow=()):
+    """Raise on a negative status (except those in ``allow``), with the library's message."""
+    if rc == FG_OK or rc in allow:
+        return rc
+    msg = load().fg_last_error()
+    raise NativeLibraryError(f"libfluidgym_hip call failed with status {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,436 @@
+// C-ABI entry points of libfluidgym_hip.so (declared in include/fluidgym_hip.h): handle lifetime,
+// field binding and the PISO step drivers.  Host code only; kernels live in fg_piso.hip,
+// fg_poisson.hip, fg_bicgstab.hip, fg_metrics.hip.
+#include <string.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "fg_internal.h"
+
+static thread_local std::string g_last_error;
+void fg_set_error(const std::string& msg) { g_last_error = msg; }
+
+extern "C" int fg_abi_version(void) { return FG_ABI_VERSION; }
+extern "C" const char* fg_last_error(void) { return g_last_error.c_str(); }
+
+#define FG_REQUIRE(cond, code, msg)  \
+    do {                             \
+        if (!(cond)) {               \
+            fg_set_error(msg);       \
+            return code;             \
+        }                            \
+    } while (0)
+
+static FgBounds make_bounds(const fg_state* s, int channel) {
+    FgBounds b;
+    for (int f = 0; f < 6; ++f) {
+        b.vel[f] = s->bvel[f];
+        b.scal[f] = s->bscal[f];
+        b.scalar_bc[f] = s->cfg.scalar_bc[f][channel < 0 ? 0 : channel];
+    }
+    return b;
+}
+
+static int check_bound(const fg_state* s, bool need_scalar) {
+    FG_REQUIRE(s->velocity && s->pressure, FG_ERR_NOT_BOUND, "velocity/pressure not bound (fg_bind)");
+    for (int f = 0; f < 2 * s->grid.dims; ++f) {
+        if (!s->grid.fixed[f]) continue;
+        FG_REQUIRE(s->bvel[f], FG_ERR_NOT_BOUND, "boundary velocity of a FIXED face not bound");
+        if (need_scalar) FG_REQUIRE(s->bscal[f], FG_ERR_NOT_BOUND, "boundary scalar of a FIXED face not bound");
+    }
+    if (need_scalar) FG_REQUIRE(s->scalar, FG_ERR_NOT_BOUND, "passive scalar not bound");
+    return FG_OK;
+}
+
+extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy, const float* hz, fg_handle* out) {
+    FG_REQUIRE(cfg && out && hx && hy, FG_ERR_INVALID_ARG, "fg_create: null argument");
+    FG_REQUIRE(cfg->dims == 2 || cfg->dims == 3, FG_ERR_INVALID_ARG, "dims must be 2 or 3");
+    FG_REQUIRE(cfg->dims == 2 || hz, FG_ERR_INVALID_ARG, "hz required in 3-D");
+    // minimum 3 cells per axis (domain_structs.cpp:1193-1195)
+    FG_REQUIRE(cfg->nx >= 3 && cfg->ny >= 3 && (cfg->dims == 2 ? cfg->nz == 1 : cfg->nz >= 3), FG_ERR_INVALID_ARG,
+               "block needs >= 3 cells per axis (nz = 1 in 2-D)");
+    FG_REQUIRE(cfg->batch >= 1, FG_ERR_INVALID_ARG, "batch must be >= 1");
+    FG_REQUIRE(cfg->n_scalars >= 0 && cfg->n_scalars <= FG_MAX_SCALARS, FG_ERR_INVALID_ARG, "bad n_scalars");
+    for (int a = 0; a < cfg->dims; ++a)
+        FG_REQUIRE(cfg->face_type[2 * a] == cfg->face_type[2 * a + 1], FG_ERR_INVALID_ARG,
+                   "a FIXED face needs a FIXED partner (CloseBoundary closes both, domain_structs.cpp:1981-2002)");
+    FG_REQUIRE((long long)cfg->nx * cfg->ny * cfg->nz * cfg->batch * 6 < (1LL << 31), FG_ERR_UNSUPPORTED,
+               "index space exceeds int32 (reference index_t is int32 as well)");
+    FG_HIP_CHECK(hipSetDevice(cfg->device));
+
+    fg_state* s = new fg_state();
+    memset(s, 0, sizeof(*s));
+    s->cfg = *cfg;
+    FgGrid& g = s->grid;
+    g.dims = cfg->dims; g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
+    g.n = cfg->nx * cfg->ny * cfg->nz; g.B = cfg->batch;
+    for (int f = 0; f < 6; ++f) g.fixed[f] = (f < 2 * cfg->dims) ? (cfg->face_type[f] == FG_FIXED) : 0;
+    s->vec = (cfg->nx % 4 == 0) ? 4 : 1;
+    s->viscosity = 0.f;
+
+    const float* hsrc[3] = {hx, hy, hz};
+    const int hn[3] = {cfg->nx, cfg->ny, cfg->nz};
+    for (int a = 0; a < 3; ++a) {
+        std::vector<float> h(hn[a], 1.f), rh(hn[a], 1.f);
+        if (a < cfg->dims)
+            for (int i = 0; i < hn[a]; ++i) {
+                if (!(hsrc[a][i] > 0.f)) { delete s; fg_set_error("cell widths must be positive"); return FG_ERR_INVALID_ARG; }
+                h[i] = hsrc[a][i]; rh[i] = 1.f / hsrc[a][i];
+            }
+        FG_HIP_CHECK(hipMalloc(&s->d_h[a], sizeof(float) * hn[a]));
+        FG_HIP_CHECK(hipMalloc(&s->d_rh[a], sizeof(float) * hn[a]));
+        FG_HIP_CHECK(hipMemcpy(s->d_h[a], h.data(), sizeof(float) * hn[a], hipMemcpyHostToDevice));
+        FG_HIP_CHECK(hipMemcpy(s->d_rh[a], rh.data(), sizeof(float) * hn[a], hipMemcpyHostToDevice));
+        g.h[a] = s->d_h[a]; g.rh[a] = s->d_rh[a];
+    }
+    const size_t BN = (size_t)g.B * g.n, d = g.dims;
+    auto alloc = [&](float** p, size_t count) -> hipError_t {
+        hipError_t e = hipMalloc(p, sizeof(float) * count);
+        if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * count);
+        return e;
+    };
+    FG_HIP_CHECK(alloc(&s->A, BN));
+    FG_HIP_CHECK(alloc(&s->rA, BN));
+    FG_HIP_CHECK(alloc(&s->Coff, BN * 2 * d));
+    FG_HIP_CHECK(alloc(&s->adv_rhs, BN * d));
+    FG_HIP_CHECK(alloc(&s->vel_result, BN * d));
+    FG_HIP_CHECK(alloc(&s->hvec, BN * d));
+    FG_HIP_CHECK(alloc(&s->div, BN));
+    FG_HIP_CHECK(alloc(&s->p_result, BN));
+    FG_HIP_CHECK(alloc(&s->scal_result, BN));
+    for (int i = 0; i < 7; ++i) FG_HIP_CHECK(alloc(&s->w[i], BN * d));
+    const size_t nsys = (size_t)g.B * d;
+    FG_HIP_CHECK(hipMalloc(&s->acc, sizeof(double) * nsys * FG_ACC_DOUBLES));
+    FG_HIP_CHECK(hipMemset(s->acc, 0, sizeof(double) * nsys * FG_ACC_DOUBLES));
+    FG_HIP_CHECK(hipMalloc(&s->flags, sizeof(int32_t) * nsys));
+    FG_HIP_CHECK(hipMalloc(&s->info_dev, sizeof(fg_solve_info) * nsys));
+    FG_HIP_CHECK(hipHostMalloc(&s->info_pinned, sizeof(fg_solve_info) * nsys));
+    FG_HIP_CHECK(hipHostMalloc(&s->flags_pinned, sizeof(int32_t) * nsys));
+    FG_HIP_CHECK(alloc(&s->scratch_B, (size_t)g.B * (4 + 2 * d)));
+    *out = s;
+    return FG_OK;
+}
+
+extern "C" int fg_destroy(fg_handle s) {
+    if (!s) return FG_OK;
+    for (int a = 0; a < 3; ++a) { (void)hipFree(s->d_h[a]); (void)hipFree(s->d_rh[a]); }
+    float* owned[] = {s->A, s->rA, s->Coff, s->adv_rhs, s->vel_result, s->hvec, s->div, s->p_result, s->scal_result,
+                      s->scratch_B};
+    for (float* p : owned) (void)hipFree(p);
+    for (int i = 0; i < 7; ++i) (void)hipFree(s->w[i]);
+    (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
+    (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
+    delete s;
+    return FG_OK;
+}
+
+extern "C" int fg_bind(fg_handle s, int field, float* ptr) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    if (field == FG_VELOCITY) s->velocity = ptr;
+    else if (field == FG_PRESSURE) s->pressure = ptr;
+    else if (field == FG_SCALAR) s->scalar = ptr;
+    else if (field == FG_VELOCITY_SOURCE) s->velocity_source = ptr;
+    else if (field >= FG_BOUND_VELOCITY && field < FG_BOUND_VELOCITY + 6) s->bvel[field - FG_BOUND_VELOCITY] = ptr;
+    else if (field >= FG_BOUND_SCALAR && field < FG_BOUND_SCALAR + 6) s->bscal[field - FG_BOUND_SCALAR] = ptr;
+    else FG_REQUIRE(false, FG_ERR_INVALID_ARG, "fg_bind: unknown field id");
+    return FG_OK;
+}
+
+extern "C" int fg_set_viscosity(fg_handle s, float v) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    s->viscosity = v;
+    return FG_OK;
+}
+extern "C" int fg_set_scalar_viscosity(fg_handle s, int ch, float v) {
+    FG_REQUIRE(s && ch >= 0 && ch < FG_MAX_SCALARS, FG_ERR_INVALID_ARG, "bad channel");
+    s->scalar_viscosity[ch] = v;
+    s->scalar_viscosity_set = true;
+    return FG_OK;
+}
+
+extern "C" int fg_max_velocity(fg_handle s, float* out_B, void* stream) {
+    FG_REQUIRE(s && out_B, FG_ERR_INVALID_ARG, "null argument");
+    if (int rc = check_bound(s, false)) return rc;
+    return fg_launch_max_velocity(s, make_bounds(s, 0), out_B, (hipStream_t)stream);
+}
+extern "C" int fg_boundary_flux_balance(fg_handle s, float* out_B, void* stream) {
+    FG_REQUIRE(s && out_B, FG_ERR_INVALID_ARG, "null argument");
+    if (int rc = check_bound(s, false)) return rc;
+    return fg_launch_flux_balance(s, make_bounds(s, 0), out_B, (hipStream_t)stream);
+}
+
+extern "C" int fg_setup_advection(fg_handle s, const float* dt_B, int for_scalar, int channel, void* stream) {
+    FG_REQUIRE(s && dt_B, FG_ERR_INVALID_ARG, "null argument");
+    if (int rc = check_bound(s, for_scalar != 0)) return rc;
+    FG_REQUIRE(!for_scalar || (channel >= 0 && channel < s->cfg.n_scalars), FG_ERR_INVALID_ARG, "bad scalar channel");
+    FgAdvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vel = s->velocity;
+    a.dt = dt_B;
+    a.for_scalar = for_scalar;
+    a.channel = channel;
+    a.n_scalars = s->cfg.n_scalars;
+    a.A = s->A; a.Coff = s->Coff; a.rhs = s->adv_rhs;
+    if (for_scalar) {
+        a.scal = s->scalar + (size_t)channel * s->grid.n;
+        a.scal_env_stride = (long)s->cfg.n_scalars * s->grid.n;
+        // getViscosity(domain, forPassiveScalar, ch) (PISO_multiblock_cuda_kernel.cu:1803-1815)
+        a.nu = s->scalar_viscosity_set ? s->scalar_viscosity[channel] : s->viscosity;
+    } else {
+        a.source = s->velocity_source;
+        a.nu = s->viscosity;
+    }
+    return fg_launch_adv_build(s, make_bounds(s, channel), a, (hipStream_t)stream);
+}
+
+extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, float tol, int max_iterations,
+                                  fg_solve_info* info_host, void* stream) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    FgBicgArgs a;
+    a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs;
+    a.dt = nullptr;
+    a.tol = tol; a.max_iterations = max_iterations;
+    if (for_scalar) { a.x = s->scal_result; a.nc = 1; a.use_x0 = 0; }
+    else { a.x = s->vel_result; a.nc = s->grid.dims; a.use_x0 = 1; }
+    (void)channel;
+    return fg_bicgstab_solve(s, a, info_host, (hipStream_t)stream);
+}
+
+extern "C" int fg_copy_scalar_result_to_blocks(fg_handle s, int channel, void* stream) {
+    FG_REQUIRE(s && s->scalar, FG_ERR_NOT_BOUND, "scalar not bound");
+    const int n = s->grid.n;
+    // strided destination: channel `channel` of [B,C,N]
+    FG_HIP_CHECK(hipMemcpy2DAsync(s->scalar + (size_t)channel * n, sizeof(float) * n * s->cfg.n_scalars, s->scal_result,
+                                  sizeof(float) * n, sizeof(float) * n, s->grid.B, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return FG_OK;
+}
+
+extern "C" int fg_setup_pressure_matrix(fg_handle s, void* stream) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    return fg_launch_pressure_setup(s, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int fg_setup_pressure_rhs(fg_handle s, const float* dt_B, void* stream) {
+    FG_REQUIRE(s && dt_B, FG_ERR_INVALID_ARG, "null argument");
+    if (int rc = check_bound(s, false)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
+    return fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st);
+}
+
+static int solve_pressure(fg_state* s, const float* dt, int method, float tol, int max_iterations, int use_previous,
+                          fg_solve_info* info_host, hipStream_t st) {
+    int rc = FG_OK;
+    if (method == FG_SOLVER_CG) {
+        FgCgArgs a;
+        a.rA = s->rA; a.b = s->div; a.x = s->p_result;
+        a.r = s->w[0]; a.p = s->w[1]; a.Ap = s->w[2];
+        a.dt = dt; a.tol = tol; a.max_iterations = max_iterations; a.use_x0 = use_previous;
+        a.reset_steps = 100;  // residual_reset_step=100 (PISOtorch_simulation.py:1913)
+        a.check_every = 16;
+        rc = fg_cg_solve(s, a, info_host, st);
+    } else {
+        fg_set_error("fg_solve_pressure: only FG_SOLVER_CG drives the PISO step (Jacobi/RBGS are smoothers)");
+        return FG_ERR_UNSUPPORTED;
+    }
+    if (rc != FG_OK && rc != FG_ERR_NOT_CONVERGED) return rc;
+    // p -= mean(p); setPressureResult; CopyPressureResultToBlocks (PISOtorch_simulation.py:1817-1821, 1953)
+    if (int rc2 = fg_launch_mean_sub(s, dt, s->p_result, s->pressure, st)) return rc2;
+    return rc;
+}
+
+extern "C" int fg_solve_pressure(fg_handle s, int method, float tol, int max_iterations, int use_previous,
+                                 fg_solve_info* info_host, void* stream) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    if (int rc = check_bound(s, false)) return rc;
+    return solve_pressure(s, nullptr, method, tol, max_iterations, use_previous, info_host, (hipStream_t)stream);
+}
+
+extern "C" int fg_correct_velocity(fg_handle s, void* stream) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    if (int rc = check_bound(s, false)) return rc;
+    return fg_launch_correct(s, nullptr, s->rA, s->hvec, s->pressure, s->vel_result, (hipStream_t)stream);
+}
+
+extern "C" int fg_copy_velocity_result_to_blocks(fg_handle s, void* stream) {
+    FG_REQUIRE(s && s->velocity, FG_ERR_NOT_BOUND, "velocity not bound");
+    return fg_launch_copy_active(s, nullptr, s->vel_result, s->velocity, s->grid.dims, (hipStream_t)stream);
+}
+extern "C" int fg_copy_velocity_result_from_blocks(fg_handle s, void* stream) {
+    FG_REQUIRE(s && s->velocity, FG_ERR_NOT_BOUND, "velocity not bound");
+    return fg_launch_copy_active(s, nullptr, s->velocity, s->vel_result, s->grid.dims, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused driver: _PISO_split_step, orthogonal branch (PISOtorch_simulation.py:1431-2002)
+// ---------------------------------------------------------------------------------------------
+static int max_iters(const fg_solve_info* info, int n) {
+    int m = -1;
+    for (int i = 0; i < n; ++i) m = info[i].used_iterations > m ? info[i].used_iterations : m;
+    return m;
+}
+
+extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
+                            void* stream) {
+    FG_REQUIRE(s && dt_B && opt, FG_ERR_INVALID_ARG, "null argument");
+    const bool scalar = opt->advect_scalar && s->cfg.n_scalars > 0;
+    if (int rc = check_bound(s, scalar)) return rc;
+    FG_REQUIRE(opt->buoyancy_axis < s->grid.dims, FG_ERR_INVALID_ARG, "bad buoyancy axis");
+    FG_REQUIRE(opt->buoyancy_axis < 0 || (s->velocity_source && s->scalar), FG_ERR_NOT_BOUND,
+               "buoyancy needs velocity source and scalar bound");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->grid.B, d = s->grid.dims;
+    std::vector<fg_solve_info> info((size_t)B * d);
+    int32_t stats[4] = {-1, -1, -1, -1};
+    int status = FG_OK;
+    auto soft = [&](int rc) {  // non-convergence is reported, not fatal (pressure_return_best_result=True)
+        if (rc == FG_ERR_NOT_CONVERGED) { status = rc; return FG_OK; }
+        return rc;
+    };
+    // ---- passive scalars (:1471-1644)
+    if (scalar) {
+        for (int ch = 0; ch < s->cfg.n_scalars; ++ch) {
+            if (int rc = fg_setup_advection(s, dt_B, 1, ch, stream)) return rc;
+            FgBicgArgs a;
+            a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->scal_result; a.nc = 1;
+            a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 0;
+            if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
+            const int m = max_iters(info.data(), B);
+            stats[0] = m > stats[0] ? m : stats[0];
+            // CopyScalarResultToBlocks for active envs
+            const int n = s->grid.n;
+            if (s->cfg.n_scalars == 1) {
+                if (int rc = fg_launch_copy_active(s, dt_B, s->scal_result, s->scalar, 1, st)) return rc;
+            } else {
+                (void)n;
+                fg_set_error("multi-channel scalar copy with inactive envs not implemented");
+                return FG_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    // ---- PRE_VELOCITY_SETUP hook fused: RBC buoyancy (rbc_env_base.py:285-297)
+    if (opt->buoyancy_axis >= 0) {
+        if (int rc = fg_launch_buoyancy(s, dt_B, s->scalar, (long)s->cfg.n_scalars * s->grid.n, s->velocity_source,
+                                        opt->buoyancy_axis, opt->buoyancy_factor, st))
+            return rc;
+    }
+    // ---- velocity predictor (:1646-1762)
+    if (int rc = fg_setup_advection(s, dt_B, 0, 0, stream)) return rc;
+    {
+        FgBicgArgs a;
+        a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->vel_result; a.nc = d;
+        a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 1;
+        if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
+        stats[1] = max_iters(info.data(), B * d);
+    }
+    // ---- correctors (:1777-1972)
+    if (int rc = fg_launch_pressure_setup(s, dt_B, st)) return rc;
+    for (int c = 0; c < opt->corrector_steps; ++c) {
+        if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
+        if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st)) return rc;
+        if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations, 0,
+                                         info.data(), st)))
+            return rc;
+        if (c < 2) stats[2 + c] = max_iters(info.data(), B);
+        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, s->pressure, s->vel_result, st)) return rc;
+    }
+    // CopyVelocityResultToBlocks (:1974)
+    if (int rc = fg_launch_copy_active(s, dt_B, s->vel_result, s->velocity, d, st)) return rc;
+    if (stats_host) memcpy(stats_host, stats, sizeof(stats));
+    return status;
+}
+
+extern "C" int fg_make_divergence_free(fg_handle s, float tol, int max_iterations, fg_solve_info* info_host,
+                                       void* stream) {
+    // make_divergence_free (PISOtorch_simulation.py:1320-1429): A := 1, dt := 1, h := u
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    if (int rc = check_bound(s, false)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t BN = (size_t)s->grid.B * s->grid.n;
+    std::vector<float> ones(BN, 1.f);
+    FG_HIP_CHECK(hipMemcpyAsync(s->rA, ones.data(), sizeof(float) * BN, hipMemcpyHostToDevice, st));
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    if (int rc = fg_launch_copy_active(s, nullptr, s->velocity, s->hvec, s->grid.dims, st)) return rc;
+    if (int rc = fg_launch_div(s, make_bounds(s, 0), nullptr, s->hvec, s->div, st)) return rc;
+    int rc = solve_pressure(s, nullptr, FG_SOLVER_CG, tol, max_iterations, 0, info_host, st);
+    if (rc != FG_OK && rc != FG_ERR_NOT_CONVERGED) return rc;
+    if (int rc2 = fg_launch_correct(s, nullptr, s->rA, s->hvec, s->pressure, s->vel_result, st)) return rc2;
+    if (int rc2 = fg_launch_copy_active(s, nullptr, s->vel_result, s->velocity, s->grid.dims, st)) return rc2;
+    return rc;
+}
+
+extern "C" int fg_get_buffer(fg_handle s, int which, float** out_ptr, int64_t* out_count) {
+    FG_REQUIRE(s && out_ptr && out_count, FG_ERR_INVALID_ARG, "null argument");
+    const int64_t BN = (int64_t)s->grid.B * s->grid.n, d = s->grid.dims;
+    switch (which) {
+        case FG_BUF_A: *out_ptr = s->A; *out_count = BN; break;
+        case FG_BUF_C_OFF: *out_ptr = s->Coff; *out_count = BN * 2 * d; break;
+        case FG_BUF_ADV_RHS: *out_ptr = s->adv_rhs; *out_count = BN * d; break;
+        case FG_BUF_VEL_RESULT: *out_ptr = s->vel_result; *out_count = BN * d; break;
+        case FG_BUF_H: *out_ptr = s->hvec; *out_count = BN * d; break;
+        case FG_BUF_DIV: *out_ptr = s->div; *out_count = BN; break;
+        case FG_BUF_P_RESULT: *out_ptr = s->p_result; *out_count = BN; break;
+        case FG_BUF_SCALAR_RESULT: *out_ptr = s->scal_result; *out_count = BN; break;
+        default: FG_REQUIRE(false, FG_ERR_INVALID_ARG, "unknown buffer id");
+    }
+    return FG_OK;
+}
+
+extern "C" int fg_read_buffer(fg_handle s, int which, float* dst, void* stream) {
+    float* src = nullptr;
+    int64_t count = 0;
+    if (int rc = fg_get_buffer(s, which, &src, &count)) return rc;
+    FG_REQUIRE(dst, FG_ERR_INVALID_ARG, "null destination");
+    FG_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(float) * count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FG_OK;
+}
+
+// ---- standalone Poisson entry points ------------------------------------------------------------
+extern "C" int fg_poisson_apply(fg_handle s, const float* rA, const float* x, float* y, void* stream) {
+    FG_REQUIRE(s && rA && x && y, FG_ERR_INVALID_ARG, "null argument");
+    return fg_poisson_apply_launch(s, rA, x, y, (hipStream_t)stream);
+}
+
+extern "C" int fg_poisson_jacobi(fg_handle s, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+                                 void* stream) {
+    FG_REQUIRE(s && rA && b && x && n_sweeps >= 0, FG_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    float* buf[2] = {x, s->w[5]};
+    for (int i = 0; i < n_sweeps; ++i)
+        if (int rc = fg_poisson_jacobi_launch(s, rA, b, buf[i & 1], buf[(i + 1) & 1], omega, st)) return rc;
+    if (n_sweeps & 1)
+        FG_HIP_CHECK(hipMemcpyAsync(x, s->w[5], sizeof(float) * (size_t)s->grid.B * s->grid.n, hipMemcpyDeviceToDevice, st));
+    return FG_OK;
+}
+
+extern "C" int fg_poisson_rbgs(fg_handle s, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+                               void* stream) {
+    FG_REQUIRE(s && rA && b && x && n_sweeps >= 0, FG_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n_sweeps; ++i) {
+        if (int rc = fg_poisson_rbgs_launch(s, rA, b, x, omega, 0, st)) return rc;
+        if (int rc = fg_poisson_rbgs_launch(s, rA, b, x, omega, 1, st)) return rc;
+    }
+    return FG_OK;
+}
+
+extern "C" int fg_poisson_cg(fg_handle s, const float* rA, const float* b, float* x, float tol, int max_iterations,
+                             int use_x0, fg_solve_info* info_host, void* stream) {
+    FG_REQUIRE(s && rA && b && x, FG_ERR_INVALID_ARG, "null argument");
+    FgCgArgs a;
+    a.rA = rA; a.b = b; a.x = x;
+    a.r = s->w[0]; a.p = s->w[1]; a.Ap = s->w[2];
+    a.dt = nullptr; a.tol = tol; a.max_iterations = max_iterations; a.use_x0 = use_x0;
+    a.reset_steps = 100;
+    a.check_every = (tol > 0.f) ? 16 : (1 << 30);  // tol <= 0: run exactly max_iterations without polling
+    return fg_cg_solve(s, a, info_host, (hipStream_t)stream);
+}
+
+extern "C" int fg_coords_to_transforms(const float* coords, float* transforms, int dims, int nx, int ny, int nz,
+                                       void* stream) {
+    FG_REQUIRE(coords && transforms && (dims == 2 || dims == 3), FG_ERR_INVALID_ARG, "bad argument");
+    return fg_metrics_launch(coords, transforms, dims, nx, ny, nz, (hipStream_t)stream);
+}

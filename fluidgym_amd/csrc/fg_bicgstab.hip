@@ -1,0 +1,381 @@
+// Batched, multi-RHS BiCGStab on the stencil-form advection-diffusion matrix, gfx950.
+//
+// Replaces bicgstabSolveGPU (bicgstab_solver_kernel.cu:63-411): same un-preconditioned recurrence
+// and the same RMS-residual criterion (cg_solver_kernel.cu:100-106), but all B*nc systems (env x
+// velocity component, one shared matrix per env) advance in lock-step inside 5 kernels per
+// iteration, with the scalars (rho, alpha, omega, ...) living in device accumulators.  The
+// reference loops the right-hand sides sequentially and reads every scalar back to the host.
+//
+// accumulators per system (fp64): 0,1 rho ring | 2 rw.v | 3 s.s | 4 t.s | 5 t.t | 6 r.r
+// derived scalars per system (fp32, `sc`): 0 alpha | 1 omega
+#include <math.h>
+
+#include "fg_internal.h"
+
+namespace {
+
+constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6;
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgVec<VEC> fg_spmv(const float* __restrict__ diag, const float* __restrict__ off,
+                                              const float* __restrict__ x, const FgCtx<DIMS, VEC>& c, size_t N) {
+    // diag/off already offset to the env; x offset to the system
+    const FgNbr<DIMS, VEC> X = fg_gather<DIMS, VEC>(x, c);
+    const FgVec<VEC> d = fg_load<VEC>(diag + c.idx);
+    FgVec<VEC> o[2 * DIMS];
+#pragma unroll
+    for (int f = 0; f < 2 * DIMS; ++f) o[f] = fg_load<VEC>(off + f * N + c.idx);
+    FgVec<VEC> y;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        float v = d.v[e] * X.c.v[e] + o[0].v[e] * X.xm.v[e] + o[1].v[e] * X.xp.v[e] + o[2].v[e] * X.ym.v[e] +
+                  o[3].v[e] * X.yp.v[e];
+        if constexpr (DIMS == 3) v += o[4].v[e] * X.zm.v[e] + o[5].v[e] * X.zp.v[e];
+        y.v[e] = v;
+    }
+    return y;
+}
+
+struct SysCtx {
+    int sys;       // b * nc + comp
+    int comp;
+    bool leader;
+};
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ SysCtx fg_sys(const FgCtx<DIMS, VEC>& c, int nc, int tiles) {
+    SysCtx s;
+    s.comp = blockIdx.y;
+    s.sys = c.b * nc + s.comp;
+    s.leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
+    return s;
+}
+
+__device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
+
+__device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int sys, float crit, int it) {
+    const bool finite = isfinite(crit);
+    flags[sys] = finite ? 1 : 2;
+    info[sys].final_residual = crit;
+    info[sys].used_iterations = it;
+    info[sys].converged = finite ? 1 : 0;
+    info[sys].is_finite = finite ? 1 : 0;
+}
+
+struct BicgPtrs {
+    const float* diag; const float* off; const float* rhs;
+    float* x; float* r; float* rw; float* p; float* v; float* t;
+    double* acc; float* sc; int32_t* flags; fg_solve_info* info;
+    int nc; float tol;
+};
+
+// init: r = rhs - C x0 ; rw = r ; p = r ; rho_0 = rr = r.r
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicg_init(FgGrid g, BicgPtrs q, int use_x0, int tiles_x, int tiles_y,
+                                                         int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
+    if (q.flags[s.sys] != 0) return;
+    const size_t N = g.n, vb = (size_t)s.sys * N;
+    __shared__ float lds[4];
+    float part[1] = {0.f};
+    if (c.valid) {
+        FgVec<VEC> r = fg_load<VEC>(q.rhs + vb + c.idx);
+        if (use_x0) {
+            const FgVec<VEC> y = fg_spmv<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N,
+                                                    q.x + vb, c, N);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.v[e] -= y.v[e];
+        } else {
+            FgVec<VEC> z;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) z.v[e] = 0.f;
+            fg_store<VEC>(q.x + vb + c.idx, z);
+        }
+        fg_store<VEC>(q.r + vb + c.idx, r);
+        fg_store<VEC>(q.rw + vb + c.idx, r);
+        fg_store<VEC>(q.p + vb + c.idx, r);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) part[0] += r.v[e] * r.v[e];
+    }
+    fg_block_sum<1>(part, lds);
+    if (threadIdx.x == 0) {
+        double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+        atomicAdd(a + A_RHO, (double)part[0]);
+        atomicAdd(a + A_RR, (double)part[0]);
+    }
+}
+
+// Kp_i: convergence check on r of iteration i-1, then p = r + beta (p - omega v)   (i > 0)
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int it, int tiles_x, int tiles_y,
+                                                      int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
+    const int f = q.flags[s.sys];
+    if (f == 4) {  // converged on s in the previous iteration: K5 has applied x += alpha p, finalise
+        if (s.leader) q.flags[s.sys] = 1;
+        return;
+    }
+    if (f != 0) return;
+    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    const float crit = fg_rms(a[A_RR], g.n);
+    if (!(crit >= q.tol)) {
+        if (s.leader) fg_mark(q.flags, q.info, s.sys, crit, it == 0 ? -1 : it);
+        return;
+    }
+    if (s.leader) {
+        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0;
+        q.info[s.sys].final_residual = crit;
+        q.info[s.sys].used_iterations = it - 1;
+    }
+    if (it == 0 || !c.valid) return;
+    const float alpha = q.sc[s.sys * 2 + 0], omega = q.sc[s.sys * 2 + 1];
+    const float beta = (float)(a[A_RHO + (it & 1)] / a[A_RHO + ((it + 1) & 1)]) * (alpha / omega);
+    const size_t vb = (size_t)s.sys * g.n;
+    const FgVec<VEC> r = fg_load<VEC>(q.r + vb + c.idx);
+    const FgVec<VEC> v = fg_load<VEC>(q.v + vb + c.idx);
+    FgVec<VEC> p = fg_load<VEC>(q.p + vb + c.idx);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) p.v[e] = r.v[e] + beta * (p.v[e] - omega * v.v[e]);
+    fg_store<VEC>(q.p + vb + c.idx, p);
+}
+
+// K2_i: v = C p ; rv += rw.v
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicg_v(FgGrid g, BicgPtrs q, int it, int tiles_x, int tiles_y,
+                                                      int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
+    if (q.flags[s.sys] != 0) return;
+    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    const size_t N = g.n, vb = (size_t)s.sys * N;
+    __shared__ float lds[4];
+    float part[1] = {0.f};
+    if (c.valid) {
+        const FgVec<VEC> y = fg_spmv<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, q.p + vb,
+                                                c, N);
+        const FgVec<VEC> rw = fg_load<VEC>(q.rw + vb + c.idx);
+        fg_store<VEC>(q.v + vb + c.idx, y);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) part[0] += rw.v[e] * y.v[e];
+    }
+    fg_block_sum<1>(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + A_RV, (double)part[0]);
+}
+
+// K3_i: alpha = rho_i / rv ; s = r - alpha v (stored in r) ; ss += s.s
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicg_s(FgGrid g, BicgPtrs q, int it, int tiles_x, int tiles_y,
+                                                      int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
+    if (q.flags[s.sys] != 0) return;
+    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_RV]);
+    if (s.leader) {
+        q.sc[s.sys * 2 + 0] = alpha;
+        a[A_RHO + ((it + 1) & 1)] = 0.0;  // rho slot of the next iteration
+        a[A_RR] = 0.0;                    // read by Kp_i / K2_i, re-accumulated by K5_i
+    }
+    const size_t vb = (size_t)s.sys * g.n;
+    __shared__ float lds[4];
+    float part[1] = {0.f};
+    if (c.valid) {
+        FgVec<VEC> r = fg_load<VEC>(q.r + vb + c.idx);
+        const FgVec<VEC> v = fg_load<VEC>(q.v + vb + c.idx);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            r.v[e] -= alpha * v.v[e];
+            part[0] += r.v[e] * r.v[e];
+        }
+        fg_store<VEC>(q.r + vb + c.idx, r);
+    }
+    fg_block_sum<1>(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + A_SS, (double)part[0]);
+}
+
+// K4_i: t = C s ; ts += t.s ; tt += t.t        (skipped when ||s|| already meets the tolerance)
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int it, int tiles_x, int tiles_y,
+                                                      int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
+    if (q.flags[s.sys] != 0) return;
+    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    const float crit_s = fg_rms(a[A_SS], g.n);
+    if (!(crit_s >= q.tol)) {
+        // converged on s (bicgstab_solver_kernel.cu:305-329): flag 4 = "K5 applies x += alpha p, then done".
+        // Nothing in THIS launch depends on the flag value written here (all workgroups take this branch).
+        if (s.leader) {
+            fg_mark(q.flags, q.info, s.sys, crit_s, it);
+            if (isfinite(crit_s)) q.flags[s.sys] = 4;
+        }
+        return;
+    }
+    const size_t N = g.n, vb = (size_t)s.sys * N;
+    __shared__ float lds[8];
+    float part[2] = {0.f, 0.f};
+    if (c.valid) {
+        const FgVec<VEC> t = fg_spmv<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, q.r + vb,
+                                                c, N);
+        const FgVec<VEC> sv = fg_load<VEC>(q.r + vb + c.idx);
+        fg_store<VEC>(q.t + vb + c.idx, t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            part[0] += t.v[e] * sv.v[e];
+            part[1] += t.v[e] * t.v[e];
+        }
+    }
+    fg_block_sum<2>(part, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_TS, (double)part[0]);
+        atomicAdd(a + A_TT, (double)part[1]);
+    }
+}
+
+// K5_i: x += alpha p (+ omega s) ; r = s - omega t ; rr += r.r ; rho_{i+1} += rw.r
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int it, int tiles_x, int tiles_y,
+                                                      int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
+    const int f = q.flags[s.sys];  // stable during this launch: K5 never writes flags
+    if (f != 0 && f != 4) return;
+    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    const float alpha = q.sc[s.sys * 2 + 0];
+    const bool half = (f == 4);
+    const float omega = half ? 0.f : (float)(a[A_TS] / a[A_TT]);
+    if (s.leader) {
+        q.sc[s.sys * 2 + 1] = omega;
+        a[A_RV] = 0.0;
+    }
+    const size_t vb = (size_t)s.sys * g.n;
+    __shared__ float lds[8];
+    float part[2] = {0.f, 0.f};
+    if (c.valid) {
+        FgVec<VEC> x = fg_load<VEC>(q.x + vb + c.idx);
+        const FgVec<VEC> p = fg_load<VEC>(q.p + vb + c.idx);
+        FgVec<VEC> r = fg_load<VEC>(q.r + vb + c.idx);
+        if (half) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) x.v[e] += alpha * p.v[e];
+            fg_store<VEC>(q.x + vb + c.idx, x);
+        } else {
+            const FgVec<VEC> t = fg_load<VEC>(q.t + vb + c.idx);
+            const FgVec<VEC> rw = fg_load<VEC>(q.rw + vb + c.idx);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                x.v[e] += alpha * p.v[e] + omega * r.v[e];
+                r.v[e] -= omega * t.v[e];
+                part[0] += r.v[e] * r.v[e];
+                part[1] += rw.v[e] * r.v[e];
+            }
+            fg_store<VEC>(q.x + vb + c.idx, x);
+            fg_store<VEC>(q.r + vb + c.idx, r);
+        }
+    }
+    if (half) return;
+    fg_block_sum<2>(part, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_RR, (double)part[0]);
+        atomicAdd(a + A_RHO + ((it + 1) & 1), (double)part[1]);
+    }
+}
+
+__global__ void k_bicg_begin(const float* __restrict__ dt, double* __restrict__ acc, float* __restrict__ sc,
+                             int32_t* __restrict__ flags, fg_solve_info* __restrict__ info, int nsys, int nc) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    for (int q = 0; q < FG_ACC_DOUBLES; ++q) acc[(size_t)s * FG_ACC_DOUBLES + q] = 0.0;
+    sc[s * 2] = 1.f; sc[s * 2 + 1] = 1.f;
+    const bool active = (dt == nullptr) || (dt[s / nc] > 0.f);
+    flags[s] = active ? 0 : 3;
+    info[s].final_residual = 0.f;
+    info[s].used_iterations = -1;
+    info[s].converged = active ? 0 : 1;
+    info[s].is_finite = 1;
+}
+
+__global__ void k_bicg_check(double* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+                             float tol, int it, int n, int nsys, int final_pass) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    if (flags[s] == 4) flags[s] = 1;
+    if (flags[s] != 0) return;
+    const float crit = (float)sqrt(acc[(size_t)s * FG_ACC_DOUBLES + A_RR] / (double)n);
+    info[s].final_residual = crit;
+    info[s].used_iterations = it + 1;
+    if (!(crit >= tol)) {
+        const bool finite = isfinite(crit);
+        flags[s] = finite ? 1 : 2;
+        info[s].converged = finite ? 1 : 0;
+        info[s].is_finite = finite ? 1 : 0;
+    } else if (final_pass) {
+        info[s].converged = 0;
+    }
+}
+
+}  // namespace
+
+int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st) {
+    const int B = s->grid.B, n = s->grid.n, nsys = B * a.nc;
+    BicgPtrs q;
+    q.diag = a.diag; q.off = a.off; q.rhs = a.rhs; q.x = a.x;
+    q.r = s->w[0]; q.rw = s->w[1]; q.p = s->w[2]; q.v = s->w[3]; q.t = s->w[4];
+    q.acc = s->acc; q.sc = s->scratch_B + 4 * B;  // scratch_B holds 4*B floats of env scalars first
+    q.flags = s->flags; q.info = s->info_dev; q.nc = a.nc; q.tol = a.tol;
+    const dim3 sg((nsys + 63) / 64), sb(64);
+    hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
+
+#define FG_BICG_LAUNCH(KERNEL, ...)                                                                          \
+    do {                                                                                                     \
+        if (s->grid.dims == 2) {                                                                             \
+            if (s->vec == 4) {                                                                               \
+                FgLaunch L = fg_launch_geometry<2, 4>(s->grid); L.grid.y = a.nc;                             \
+                hipLaunchKernelGGL((KERNEL<2, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+            } else {                                                                                         \
+                FgLaunch L = fg_launch_geometry<2, 1>(s->grid); L.grid.y = a.nc;                             \
+                hipLaunchKernelGGL((KERNEL<2, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+            }                                                                                                \
+        } else {                                                                                             \
+            if (s->vec == 4) {                                                                               \
+                FgLaunch L = fg_launch_geometry<3, 4>(s->grid); L.grid.y = a.nc;                             \
+                hipLaunchKernelGGL((KERNEL<3, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+            } else {                                                                                         \
+                FgLaunch L = fg_launch_geometry<3, 1>(s->grid); L.grid.y = a.nc;                             \
+                hipLaunchKernelGGL((KERNEL<3, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+
+    FG_BICG_LAUNCH(k_bicg_init, a.use_x0);
+    bool done = false;
+    const int check_every = 2;
+    for (int it = 0; it < a.max_iterations && !done; ++it) {
+        FG_BICG_LAUNCH(k_bicg_p, it);
+        FG_BICG_LAUNCH(k_bicg_v, it);
+        FG_BICG_LAUNCH(k_bicg_s, it);
+        FG_BICG_LAUNCH(k_bicg_t, it);
+        FG_BICG_LAUNCH(k_bicg_x, it);
+        if ((it + 1) % check_every == 0 || it + 1 == a.max_iterations) {
+            const int final_pass = (it + 1 == a.max_iterations);
+            hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, a.tol, it, n, nsys, final_pass);
+            FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));
+            FG_HIP_CHECK(hipStreamSynchronize(st));
+            done = true;
+            for (int i = 0; i < nsys; ++i) done = done && (s->flags_pinned[i] != 0);
+        }
+    }
+#undef FG_BICG_LAUNCH
+    FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    int rc = FG_OK;
+    for (int i = 0; i < nsys; ++i) {
+        if (info_host) info_host[i] = s->info_pinned[i];
+        if (!s->info_pinned[i].is_finite) rc = FG_ERR_NOT_FINITE;
+        else if (!s->info_pinned[i].converged && rc == FG_OK) rc = FG_ERR_NOT_CONVERGED;
+    }
+    FG_HIP_CHECK(hipGetLastError());
+    return rc;
+}

@@ -1,0 +1,387 @@
+// Internal definitions shared by the HIP translation units of libfluidgym_hip.so.
+// gfx950 / wave64 only.  Public C ABI: include/fluidgym_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/fluidgym_hip.h"
+
+#define FG_BLOCK 256  // threads per workgroup = 4 waves of 64
+
+// ------------------------------------------------------------------------------------------------
+// Grid description handed to every kernel by value (lives in SGPRs / kernarg, no LDS struct copy as
+// in the reference's KERNEL_PER_CELL_LOOP, PISO_multiblock_cuda_kernel.cu:3590-3610).
+// ------------------------------------------------------------------------------------------------
+struct FgGrid {
+    int dims;
+    int nx, ny, nz;
+    int n;        // cells per env
+    int B;        // env batch
+    int fixed[6]; // 1 = FIXED (prescribed) face, 0 = periodic
+    const float* h[3];  // cell widths per axis (device), length nx / ny / nz
+    const float* rh[3]; // reciprocals
+};
+
+struct FgBounds {
+    const float* vel[6];    // [B,d,slab] or nullptr (periodic)
+    const float* scal[6];   // [B,C,slab] or nullptr
+    int scalar_bc[6];       // FG_DIRICHLET / FG_NEUMANN for the channel being processed
+};
+
+// Tile geometry: a workgroup covers 64 cells in x (16 lanes x float4, or 64 scalar lanes) and the
+// remaining 256/BX threads are spread over y (and z in 3-D), so x accesses are 256-B coalesced rows.
+template <int DIMS, int VEC>
+struct FgTile {
+    static constexpr int BX = 64 / VEC;
+    static constexpr int BZ = (DIMS == 3) ? ((VEC == 4) ? 4 : 2) : 1;
+    static constexpr int BY = FG_BLOCK / (BX * BZ);
+    static constexpr int TX = 64;
+};
+
+struct FgLaunch {
+    dim3 grid;
+    int tiles_x, tiles_y, tiles_z, tiles; // per env
+};
+
+template <int DIMS, int VEC>
+inline FgLaunch fg_launch_geometry(const FgGrid& g) {
+    using T = FgTile<DIMS, VEC>;
+    FgLaunch L;
+    L.tiles_x = (g.nx + T::TX - 1) / T::TX;
+    L.tiles_y = (g.ny + T::BY - 1) / T::BY;
+    L.tiles_z = (g.nz + T::BZ - 1) / T::BZ;
+    L.tiles = L.tiles_x * L.tiles_y * L.tiles_z;
+    L.grid = dim3((unsigned)(L.tiles * g.B), 1, 1);
+    return L;
+}
+
+#ifdef __HIPCC__
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+struct FgVec {
+    float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ FgVec<VEC> fg_load(const float* __restrict__ p) {
+    FgVec<VEC> r;
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void fg_store(float* __restrict__ p, const FgVec<VEC>& r) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    } else {
+        *p = r.v[0];
+    }
+}
+
+// XCD-aware block remap (cdna_hip_programming.md T1, bijective form): hardware places block b on
+// XCD b % 8; give every XCD a contiguous chunk of the logical grid so that one env's tiles (and its
+// y/z halo re-reads) stay in one XCD's 4 MiB L2 across the kernels of a solver iteration.
+__device__ __forceinline__ unsigned fg_xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned nxcd = 8;
+    if (nwg < nxcd * 2) return bid;
+    const unsigned q = nwg / nxcd, r = nwg % nxcd;
+    const unsigned xcd = bid % nxcd, k = bid / nxcd;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+// Per-thread stencil context: where the thread's VEC cells and their 2*DIMS neighbours live.
+template <int DIMS, int VEC>
+struct FgCtx {
+    int b;          // env
+    int i0, j, k;   // first cell of the vector
+    bool valid;
+    int idx;        // linear index of cell i0 inside the env
+    int ixm, ixp;   // linear index of the -x neighbour of element 0 / +x neighbour of element VEC-1
+    int iym, iyp, izm, izp; // linear index of the vector start in the neighbouring rows
+    // face masks (1 = face has a neighbour: interior or periodic; 0 = prescribed face)
+    float mxm, mxp, mym, myp, mzm, mzp;
+};
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgCtx<DIMS, VEC> fg_make_ctx(const FgGrid& g, int tiles_x, int tiles_y, int tiles) {
+    using T = FgTile<DIMS, VEC>;
+    FgCtx<DIMS, VEC> c;
+    const unsigned bid = fg_xcd_remap(blockIdx.x, gridDim.x);
+    c.b = bid / tiles;
+    int t = bid - c.b * tiles;
+    const int tix = t % tiles_x;
+    t /= tiles_x;
+    const int tiy = t % tiles_y;
+    const int tiz = t / tiles_y;
+    const int tid = threadIdx.x;
+    const int lx = tid % T::BX;
+    const int ly = (tid / T::BX) % T::BY;
+    const int lz = tid / (T::BX * T::BY);
+    c.i0 = (tix * T::BX + lx) * VEC;
+    c.j = tiy * T::BY + ly;
+    c.k = tiz * T::BZ + lz;
+    c.valid = (c.i0 < g.nx) && (c.j < g.ny) && (c.k < g.nz);
+    if (!c.valid) { c.i0 = 0; c.j = 0; c.k = 0; }
+    const int row = (c.k * g.ny + c.j) * g.nx;
+    c.idx = row + c.i0;
+    // x neighbours
+    const bool at_xm = (c.i0 == 0), at_xp = (c.i0 + VEC == g.nx);
+    c.mxm = (at_xm && g.fixed[0]) ? 0.f : 1.f;
+    c.mxp = (at_xp && g.fixed[1]) ? 0.f : 1.f;
+    c.ixm = at_xm ? (g.fixed[0] ? c.idx : row + g.nx - 1) : c.idx - 1;
+    c.ixp = at_xp ? (g.fixed[1] ? c.idx + VEC - 1 : row) : c.idx + VEC;
+    // y neighbours
+    const bool at_ym = (c.j == 0), at_yp = (c.j == g.ny - 1);
+    c.mym = (at_ym && g.fixed[2]) ? 0.f : 1.f;
+    c.myp = (at_yp && g.fixed[3]) ? 0.f : 1.f;
+    c.iym = at_ym ? (g.fixed[2] ? c.idx : c.idx + (g.ny - 1) * g.nx) : c.idx - g.nx;
+    c.iyp = at_yp ? (g.fixed[3] ? c.idx : c.idx - (g.ny - 1) * g.nx) : c.idx + g.nx;
+    if constexpr (DIMS == 3) {
+        const int sz = g.nx * g.ny;
+        const bool at_zm = (c.k == 0), at_zp = (c.k == g.nz - 1);
+        c.mzm = (at_zm && g.fixed[4]) ? 0.f : 1.f;
+        c.mzp = (at_zp && g.fixed[5]) ? 0.f : 1.f;
+        c.izm = at_zm ? (g.fixed[4] ? c.idx : c.idx + (g.nz - 1) * sz) : c.idx - sz;
+        c.izp = at_zp ? (g.fixed[5] ? c.idx : c.idx - (g.nz - 1) * sz) : c.idx + sz;
+    } else {
+        c.mzm = c.mzp = 0.f;
+        c.izm = c.izp = c.idx;
+    }
+    return c;
+}
+
+// A field value at the thread's cells and at their face neighbours.  At a prescribed face the
+// "neighbour" is the cell itself (so one-sided differences fall out) and the mask is 0.
+template <int DIMS, int VEC>
+struct FgNbr {
+    FgVec<VEC> c, xm, xp, ym, yp, zm, zp;
+};
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgNbr<DIMS, VEC> fg_gather(const float* __restrict__ q, const FgCtx<DIMS, VEC>& c) {
+    FgNbr<DIMS, VEC> n;
+    n.c = fg_load<VEC>(q + c.idx);
+    const float left = q[c.ixm];
+    const float right = q[c.ixp];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        n.xm.v[e] = (e == 0) ? left : n.c.v[e - 1];
+        n.xp.v[e] = (e == VEC - 1) ? right : n.c.v[e + 1];
+    }
+    n.ym = fg_load<VEC>(q + c.iym);
+    n.yp = fg_load<VEC>(q + c.iyp);
+    if constexpr (DIMS == 3) {
+        n.zm = fg_load<VEC>(q + c.izm);
+        n.zp = fg_load<VEC>(q + c.izp);
+    }
+    return n;
+}
+
+// only the neighbours along one axis (used for fluxes of one velocity component)
+template <int DIMS, int VEC>
+__device__ __forceinline__ void fg_gather_axis(const float* __restrict__ q, const FgCtx<DIMS, VEC>& c, int axis,
+                                               FgVec<VEC>& ctr, FgVec<VEC>& lo, FgVec<VEC>& hi) {
+    ctr = fg_load<VEC>(q + c.idx);
+    if (axis == 0) {
+        const float left = q[c.ixm];
+        const float right = q[c.ixp];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            lo.v[e] = (e == 0) ? left : ctr.v[e - 1];
+            hi.v[e] = (e == VEC - 1) ? right : ctr.v[e + 1];
+        }
+    } else if (axis == 1) {
+        lo = fg_load<VEC>(q + c.iym);
+        hi = fg_load<VEC>(q + c.iyp);
+    } else {
+        lo = fg_load<VEC>(q + c.izm);
+        hi = fg_load<VEC>(q + c.izp);
+    }
+}
+
+// Rectilinear metrics of the thread's cells: alpha_a = det*Minv_aa^2 = J/h_a^2
+// (getLaplaceCoefficientOrthogonal, PISO_multiblock_cuda_kernel.cu:1224-1239) and of the neighbours
+// across each face.
+template <int DIMS, int VEC>
+struct FgMetric {
+    float hx[VEC], rhx[VEC];
+    float rhx_m, rhx_p;   // 1/hx of the -x neighbour of element 0 / +x neighbour of element VEC-1
+    float hy, rhy, rhy_m, rhy_p;
+    float hz, rhz, rhz_m, rhz_p;
+};
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgMetric<DIMS, VEC> fg_metrics(const FgGrid& g, const FgCtx<DIMS, VEC>& c) {
+    FgMetric<DIMS, VEC> m;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        m.hx[e] = g.h[0][c.i0 + e];
+        m.rhx[e] = g.rh[0][c.i0 + e];
+    }
+    m.rhx_m = g.rh[0][(c.i0 == 0) ? g.nx - 1 : c.i0 - 1];
+    m.rhx_p = g.rh[0][(c.i0 + VEC == g.nx) ? 0 : c.i0 + VEC];
+    m.hy = g.h[1][c.j];
+    m.rhy = g.rh[1][c.j];
+    m.rhy_m = g.rh[1][(c.j == 0) ? g.ny - 1 : c.j - 1];
+    m.rhy_p = g.rh[1][(c.j == g.ny - 1) ? 0 : c.j + 1];
+    if constexpr (DIMS == 3) {
+        m.hz = g.h[2][c.k];
+        m.rhz = g.rh[2][c.k];
+        m.rhz_m = g.rh[2][(c.k == 0) ? g.nz - 1 : c.k - 1];
+        m.rhz_p = g.rh[2][(c.k == g.nz - 1) ? 0 : c.k + 1];
+    } else {
+        m.hz = m.rhz = m.rhz_m = m.rhz_p = 1.f;
+    }
+    return m;
+}
+
+// wave64 + workgroup sum; result valid in thread 0
+__device__ __forceinline__ float fg_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float fg_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ void fg_block_sum(float (&v)[NV], float* lds /* >= NV*4 floats */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float s = fg_wave_sum(v[q]);
+        if (lane == 0) lds[q * 4 + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = lds[q * 4] + lds[q * 4 + 1] + lds[q * 4 + 2] + lds[q * 4 + 3];
+    }
+}
+#endif  // __HIPCC__
+
+// ------------------------------------------------------------------------------------------------
+// host-side state
+// ------------------------------------------------------------------------------------------------
+#define FG_ACC_DOUBLES 16  // reduction accumulators per linear system (see solver kernels)
+
+struct fg_state {
+    fg_config cfg;
+    FgGrid grid;
+    int vec;  // 4 if nx % 4 == 0 else 1
+    float viscosity;
+    float scalar_viscosity[FG_MAX_SCALARS];
+    bool scalar_viscosity_set;
+    // metrics (owned)
+    float* d_h[3];
+    float* d_rh[3];
+    // bound (borrowed) fields
+    float* velocity;
+    float* pressure;
+    float* scalar;
+    float* velocity_source;
+    float* bvel[6];
+    float* bscal[6];
+    // owned solver workspace
+    float* A;          // [B,N]
+    float* rA;         // [B,N]
+    float* Coff;       // [B,2d,N]
+    float* adv_rhs;    // [B,d,N]
+    float* vel_result; // [B,d,N]
+    float* hvec;       // [B,d,N]   pressureRHS
+    float* div;        // [B,N]     pressureRHSdiv
+    float* p_result;   // [B,N]
+    float* scal_result;// [B,N]
+    float* w[7];       // Krylov work vectors, each [B,d,N]
+    double* acc;       // [B*d][FG_ACC_DOUBLES] reduction accumulators
+    int32_t* flags;    // [B*d] convergence flags (device)
+    fg_solve_info* info_dev;   // [B*d]
+    fg_solve_info* info_pinned;// [B*d] host-pinned mirror
+    int32_t* flags_pinned;
+    float* scratch_B;  // [B*4] small per-env floats
+    size_t n_cells() const { return (size_t)grid.n; }
+};
+
+void fg_set_error(const std::string& msg);
+#define FG_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            fg_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                      \
+            return FG_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+// dims / vector-width dispatch for templated launches; the body sees constexpr DIMS and VEC
+#define FG_DISPATCH(s, ...)                                                       \
+    do {                                                                          \
+        if ((s)->grid.dims == 2) {                                                \
+            if ((s)->vec == 4) { constexpr int DIMS = 2, VEC = 4; __VA_ARGS__; }  \
+            else { constexpr int DIMS = 2, VEC = 1; __VA_ARGS__; }                \
+        } else {                                                                  \
+            if ((s)->vec == 4) { constexpr int DIMS = 3, VEC = 4; __VA_ARGS__; }  \
+            else { constexpr int DIMS = 3, VEC = 1; __VA_ARGS__; }                \
+        }                                                                         \
+    } while (0)
+
+// launchers implemented in the kernel translation units -----------------------------------------
+struct FgAdvArgs {
+    const float* vel;      // u^n [B,d,N]
+    const float* scal;     // T channel [B,?] base of the channel being advected (stride given)
+    long scal_env_stride;  // elements between envs in `scal`
+    const float* source;   // velocity source [B,d,N] or nullptr
+    const float* dt;       // [B]
+    float nu;              // viscosity (or scalar diffusivity)
+    int for_scalar;
+    int channel, n_scalars;
+    float* A; float* Coff; float* rhs;
+};
+int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
+int fg_launch_pressure_setup(const fg_state* s, const float* dt, hipStream_t st);  // rA = 1/A
+int fg_launch_h(const fg_state* s, const float* dt, const float* vel_result, hipStream_t st);
+int fg_launch_div(const fg_state* s, const FgBounds& bnd, const float* dt, const float* hvec, float* div, hipStream_t st);
+int fg_launch_correct(const fg_state* s, const float* dt, const float* rA, const float* hvec, const float* p,
+                      float* vel_out, hipStream_t st);
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st);
+int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st);
+int fg_launch_copy_active(const fg_state* s, const float* dt, const float* src, float* dst, int comps, hipStream_t st);
+int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long t_env_stride, float* source, int axis,
+                       float factor, hipStream_t st);
+int fg_launch_mean_sub(const fg_state* s, const float* active_dt, float* p, float* p_copy, hipStream_t st);
+
+// Poisson / CG (fg_poisson.hip)
+int fg_poisson_apply_launch(const fg_state* s, const float* rA, const float* x, float* y, hipStream_t st);
+int fg_poisson_jacobi_launch(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew,
+                             float omega, hipStream_t st);
+int fg_poisson_rbgs_launch(const fg_state* s, const float* rA, const float* b, float* x, float omega, int color,
+                           hipStream_t st);
+struct FgCgArgs {
+    const float* rA; const float* b; float* x;
+    float* r; float* p; float* Ap;
+    const float* dt;   // [B] activity mask (nullptr = all active)
+    float tol; int max_iterations; int use_x0; int reset_steps;
+    int check_every;
+};
+int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st);
+
+// BiCGStab on the stencil-form advection matrix (fg_bicgstab.hip)
+struct FgBicgArgs {
+    const float* diag; const float* off;  // [B,N], [B,2d,N]
+    const float* rhs; float* x;           // [B,nc,N]
+    int nc;
+    const float* dt;
+    float tol; int max_iterations; int use_x0;
+};
+int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
+
+int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

@@ -1,0 +1,544 @@
+// PISO assembly / correction stencils for gfx950 (wave64, 256-thread workgroups, float4 rows).
+//
+// One workgroup = one 64-wide x tile of one env; fields are [B, C, (Z,) Y, X] so every global
+// access is a 256-byte coalesced row segment.  Matrices are never written as CSR (the reference
+// writes value+index arrays, PISO_multiblock_cuda_kernel.cu:3861-3877): the advection matrix C is
+// kept as diag (= A) + 2d off-diagonal fields in face order, and the pressure matrix is applied
+// matrix-free from rA = 1/A (fg_poisson.hip).
+#include "fg_internal.h"
+
+namespace {
+
+template <int VEC>
+__device__ __forceinline__ float fg_elem_mask(int e, float lo_mask_or_hi, bool is_edge_elem) {
+    return is_edge_elem ? lo_mask_or_hi : 1.f;
+}
+
+// boundary-slab index of the thread's vector for face axis `a`
+template <int DIMS, int VEC>
+__device__ __forceinline__ int fg_slab_index(const FgGrid& g, const FgCtx<DIMS, VEC>& c, int a) {
+    if (a == 0) return c.k * g.ny + c.j;           // slab [nz, ny, 1]
+    if (a == 1) return c.k * g.nx + c.i0;          // slab [nz, 1, nx]
+    return c.j * g.nx + c.i0;                      // slab [1, ny, nx]
+}
+__device__ __forceinline__ int fg_slab_size(const FgGrid& g, int a) {
+    return (a == 0) ? g.ny * g.nz : (a == 1) ? g.nx * g.nz : g.nx * g.ny;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Advection-diffusion matrix (stencil form) + RHS.
+//   reference: PISO_build_matrix (PISO_multiblock_cuda_kernel.cu:3616-3880),
+//              kPISO_build_advection_RHS (:4296-4400), kPISO_build_scalar_advection_RHS (:4094-4198)
+//   diag  = J/dt + sum_f [ s_f F_f/2 + (alpha_P + alpha_N) nu/2 ]     non-prescribed faces
+//                + sum_f (1-slip) 2 nu alpha_P                         prescribed faces (:3846)
+//   off_f = s_f F_f/2 - (alpha_P + alpha_N) nu/2 ;  row /= J ; A = diag/J
+//   rhs_c = [ J q_c/dt + sum_FIXED q_b,c ( -s_f U_b + (1-slip) nu 2 alpha_b ) ]/J + S_c
+// Rectilinear grid: U_a = u_a * (J/h_a), alpha_a = (J/h_a)/h_a, boundary transform == adjacent cell.
+// ---------------------------------------------------------------------------------------------
+template <int DIMS, int VEC, bool SCALAR>
+__global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, FgAdvArgs a, int tiles_x,
+                                                         int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const float dt = a.dt[c.b];
+    if (!(dt > 0.f) || !c.valid) return;
+    const size_t N = g.n;
+    const float* __restrict__ vel = a.vel + (size_t)c.b * DIMS * N;
+    const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
+    const float nu = a.nu;
+    const float rdt = 1.f / dt;
+
+    float J[VEC], diag[VEC], off[2 * DIMS][VEC];
+    float bsum[SCALAR ? 1 : DIMS][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        J[e] = m.hx[e] * m.hy * m.hz;
+        diag[e] = J[e] * rdt;
+#pragma unroll
+        for (int q = 0; q < (SCALAR ? 1 : DIMS); ++q) bsum[q][e] = 0.f;
+    }
+    FgVec<VEC> u[DIMS];
+
+#pragma unroll
+    for (int ax = 0; ax < DIMS; ++ax) {
+        FgVec<VEC> lo, hi;
+        fg_gather_axis<DIMS, VEC>(vel + ax * N, c, ax, u[ax], lo, hi);
+        const int f_lo = 2 * ax, f_hi = 2 * ax + 1;
+        const int slab = fg_slab_index<DIMS, VEC>(g, c, ax);
+        const int slab_n = fg_slab_size(g, ax);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float area, rh_p, rh_lo, rh_hi, mask_lo, mask_hi;
+            if (ax == 0) {
+                area = m.hy * m.hz;
+                rh_p = m.rhx[e];
+                rh_lo = (e == 0) ? m.rhx_m : m.rhx[e > 0 ? e - 1 : 0];
+                rh_hi = (e == VEC - 1) ? m.rhx_p : m.rhx[e < VEC - 1 ? e + 1 : VEC - 1];
+                mask_lo = (e == 0) ? c.mxm : 1.f;
+                mask_hi = (e == VEC - 1) ? c.mxp : 1.f;
+            } else if (ax == 1) {
+                area = m.hx[e] * m.hz;
+                rh_p = m.rhy; rh_lo = m.rhy_m; rh_hi = m.rhy_p;
+                mask_lo = c.mym; mask_hi = c.myp;
+            } else {
+                area = m.hx[e] * m.hy;
+                rh_p = m.rhz; rh_lo = m.rhz_m; rh_hi = m.rhz_p;
+                mask_lo = c.mzm; mask_hi = c.mzp;
+            }
+            const float Uc = u[ax].v[e] * area;
+            const float al_p = area * rh_p;
+            // ---- lower face (s = -1)
+            if (mask_lo != 0.f) {
+                const float ff = -0.25f * (Uc + lo.v[e] * area);
+                const float visc = 0.5f * nu * (al_p + area * rh_lo);
+                diag[e] += ff + visc;
+                off[f_lo][e] = ff - visc;
+            } else {
+                off[f_lo][e] = 0.f;
+                const int bi = slab + ((ax == 0) ? 0 : e);
+                const float* bv = bnd.vel[f_lo] + (size_t)c.b * DIMS * slab_n;
+                const float Ub = bv[ax * slab_n + bi] * area;  // boundary contravariant flux (:1593-1599)
+                if constexpr (SCALAR) {
+                    const float tb = bnd.scal[f_lo][((size_t)c.b * a.n_scalars + a.channel) * slab_n + bi];
+                    const bool dir = bnd.scalar_bc[f_lo] == FG_DIRICHLET;
+                    if (dir) diag[e] += 2.f * nu * al_p;
+                    bsum[0][e] += tb * Ub + (dir ? tb * nu * 2.f * al_p : tb * nu);  // -T_b*(s U_b), s=-1
+                } else {
+                    diag[e] += 2.f * nu * al_p;
+#pragma unroll
+                    for (int q = 0; q < DIMS; ++q) {
+                        const float ub = bv[q * slab_n + bi];
+                        bsum[q][e] += ub * Ub + ub * nu * 2.f * al_p;
+                    }
+                }
+            }
+            // ---- upper face (s = +1)
+            if (mask_hi != 0.f) {
+                const float ff = 0.25f * (Uc + hi.v[e] * area);
+                const float visc = 0.5f * nu * (al_p + area * rh_hi);
+                diag[e] += ff + visc;
+                off[f_hi][e] = ff - visc;
+            } else {
+                off[f_hi][e] = 0.f;
+                const int bi = slab + ((ax == 0) ? 0 : e);
+                const float* bv = bnd.vel[f_hi] + (size_t)c.b * DIMS * slab_n;
+                const float Ub = bv[ax * slab_n + bi] * area;
+                if constexpr (SCALAR) {
+                    const float tb = bnd.scal[f_hi][((size_t)c.b * a.n_scalars + a.channel) * slab_n + bi];
+                    const bool dir = bnd.scalar_bc[f_hi] == FG_DIRICHLET;
+                    if (dir) diag[e] += 2.f * nu * al_p;
+                    bsum[0][e] += -tb * Ub + (dir ? tb * nu * 2.f * al_p : tb * nu);
+                } else {
+                    diag[e] += 2.f * nu * al_p;
+#pragma unroll
+                    for (int q = 0; q < DIMS; ++q) {
+                        const float ub = bv[q * slab_n + bi];
+                        bsum[q][e] += -ub * Ub + ub * nu * 2.f * al_p;
+                    }
+                }
+            }
+        }
+    }
+    // ---- write A, off-diagonals, RHS
+    FgVec<VEC> out;
+    float rJ[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { rJ[e] = 1.f / J[e]; out.v[e] = diag[e] * rJ[e]; }
+    fg_store<VEC>(a.A + (size_t)c.b * N + c.idx, out);
+#pragma unroll
+    for (int f = 0; f < 2 * DIMS; ++f) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out.v[e] = off[f][e] * rJ[e];
+        fg_store<VEC>(a.Coff + ((size_t)c.b * 2 * DIMS + f) * N + c.idx, out);
+    }
+    if constexpr (SCALAR) {
+        const FgVec<VEC> T = fg_load<VEC>(a.scal + (size_t)c.b * a.scal_env_stride + c.idx);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out.v[e] = (J[e] * T.v[e] * rdt + bsum[0][e]) * rJ[e];
+        fg_store<VEC>(a.rhs + (size_t)c.b * N + c.idx, out);
+    } else {
+#pragma unroll
+        for (int q = 0; q < DIMS; ++q) {
+            FgVec<VEC> S;
+            if (a.source) S = fg_load<VEC>(a.source + ((size_t)c.b * DIMS + q) * N + c.idx);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                out.v[e] = (J[e] * u[q].v[e] * rdt + bsum[q][e]) * rJ[e] + (a.source ? S.v[e] : 0.f);
+            fg_store<VEC>(a.rhs + ((size_t)c.b * DIMS + q) * N + c.idx, out);
+        }
+    }
+}
+
+// rA = 1/A  (PISO_build_pressure_matrix reads Adiag, :4839,4871; we keep the reciprocal so the
+// Poisson operator needs no divisions)
+__global__ __launch_bounds__(FG_BLOCK) void k_reciprocal(const float* __restrict__ A, float* __restrict__ rA,
+                                                          const float* __restrict__ dt, int n, int n4) {
+    const int b = blockIdx.y;
+    if (dt && !(dt[b] > 0.f)) return;
+    const float4* src = reinterpret_cast<const float4*>(A + (size_t)b * n);
+    float4* dst = reinterpret_cast<float4*>(rA + (size_t)b * n);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        dst[i] = make_float4(1.f / v.x, 1.f / v.y, 1.f / v.z, 1.f / v.w);
+    }
+    if (blockIdx.x == 0) {
+        for (int i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) rA[(size_t)b * n + i] = 1.f / A[(size_t)b * n + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// H operator: h_c = rA [ rhs_c - sum_f off_f u~_{N_f,c} ]
+//   reference PISO_build_pressure_rhs (:5136-5255): rDiag*(u^n_c/dt - H + S_bnd/J + S_c); our
+//   velocity RHS already holds u^n_c/dt + S_bnd/J + S_c (same terms, :4314-4387 vs :5165-5249).
+// ---------------------------------------------------------------------------------------------
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const float* __restrict__ dt,
+                                                 const float* __restrict__ rA_, const float* __restrict__ Coff,
+                                                 const float* __restrict__ rhs, const float* __restrict__ velr,
+                                                 float* __restrict__ hvec, int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if (!(dt[c.b] > 0.f) || !c.valid) return;
+    const size_t N = g.n;
+    const FgVec<VEC> rA = fg_load<VEC>(rA_ + (size_t)c.b * N + c.idx);
+    FgVec<VEC> off[2 * DIMS];
+#pragma unroll
+    for (int f = 0; f < 2 * DIMS; ++f) off[f] = fg_load<VEC>(Coff + ((size_t)c.b * 2 * DIMS + f) * N + c.idx);
+#pragma unroll
+    for (int q = 0; q < DIMS; ++q) {
+        const size_t base = ((size_t)c.b * DIMS + q) * N;
+        const FgNbr<DIMS, VEC> u = fg_gather<DIMS, VEC>(velr + base, c);
+        const FgVec<VEC> r = fg_load<VEC>(rhs + base + c.idx);
+        FgVec<VEC> out;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float H = off[0].v[e] * u.xm.v[e] + off[1].v[e] * u.xp.v[e] + off[2].v[e] * u.ym.v[e] +
+                      off[3].v[e] * u.yp.v[e];
+            if constexpr (DIMS == 3) H += off[4].v[e] * u.zm.v[e] + off[5].v[e] * u.zp.v[e];
+            out.v[e] = rA.v[e] * (r.v[e] - H);
+        }
+        fg_store<VEC>(hvec + base + c.idx, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// div of the fluxes of h: b = sum_a F_{a+} - F_{a-},  F = (U_P + U_N)/2, prescribed faces use the
+// boundary-velocity flux (computeFluxesNDLoop :1567-1645; k_computePressureRHSdivergenceFromFlux
+// :5389-5434; timeStepNorm = false)
+// ---------------------------------------------------------------------------------------------
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const float* __restrict__ dt,
+                                                   const float* __restrict__ hvec, float* __restrict__ div,
+                                                   int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if ((dt && !(dt[c.b] > 0.f)) || !c.valid) return;
+    const size_t N = g.n;
+    const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ax = 0; ax < DIMS; ++ax) {
+        FgVec<VEC> ctr, lo, hi;
+        fg_gather_axis<DIMS, VEC>(hvec + ((size_t)c.b * DIMS + ax) * N, c, ax, ctr, lo, hi);
+        const int slab = fg_slab_index<DIMS, VEC>(g, c, ax);
+        const int slab_n = fg_slab_size(g, ax);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float area, mask_lo, mask_hi;
+            if (ax == 0) { area = m.hy * m.hz; mask_lo = (e == 0) ? c.mxm : 1.f; mask_hi = (e == VEC - 1) ? c.mxp : 1.f; }
+            else if (ax == 1) { area = m.hx[e] * m.hz; mask_lo = c.mym; mask_hi = c.myp; }
+            else { area = m.hx[e] * m.hy; mask_lo = c.mzm; mask_hi = c.mzp; }
+            const int bi = slab + ((ax == 0) ? 0 : e);
+            float F_hi, F_lo;
+            if (mask_hi != 0.f) F_hi = 0.5f * (ctr.v[e] + hi.v[e]) * area;
+            else F_hi = bnd.vel[2 * ax + 1][((size_t)c.b * DIMS + ax) * slab_n + bi] * area;
+            if (mask_lo != 0.f) F_lo = 0.5f * (ctr.v[e] + lo.v[e]) * area;
+            else F_lo = bnd.vel[2 * ax][((size_t)c.b * DIMS + ax) * slab_n + bi] * area;
+            acc[e] += F_hi - F_lo;
+        }
+    }
+    FgVec<VEC> out;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out.v[e] = acc[e];
+    fg_store<VEC>(div + (size_t)c.b * N + c.idx, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// u_c = h_c - rA (grad p)_c ; grad: central difference * 1/2, one-sided * 1 at a prescribed face,
+// times Minv (PISO_update_velocity :5962-5995; getPressureGradient :816-849)
+// ---------------------------------------------------------------------------------------------
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const float* __restrict__ dt,
+                                                       const float* __restrict__ rA_, const float* __restrict__ hvec,
+                                                       const float* __restrict__ p, float* __restrict__ vel_out,
+                                                       int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if ((dt && !(dt[c.b] > 0.f)) || !c.valid) return;
+    const size_t N = g.n;
+    const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
+    const FgVec<VEC> rA = fg_load<VEC>(rA_ + (size_t)c.b * N + c.idx);
+    const FgNbr<DIMS, VEC> P = fg_gather<DIMS, VEC>(p + (size_t)c.b * N, c);
+#pragma unroll
+    for (int q = 0; q < DIMS; ++q) {
+        const size_t base = ((size_t)c.b * DIMS + q) * N;
+        const FgVec<VEC> h = fg_load<VEC>(hvec + base + c.idx);
+        FgVec<VEC> out;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float lo, hi, fac, rh;
+            if (q == 0) {
+                lo = P.xm.v[e]; hi = P.xp.v[e]; rh = m.rhx[e];
+                const float ml = (e == 0) ? c.mxm : 1.f, mh = (e == VEC - 1) ? c.mxp : 1.f;
+                fac = (ml == 0.f || mh == 0.f) ? 1.f : 0.5f;
+            } else if (q == 1) {
+                lo = P.ym.v[e]; hi = P.yp.v[e]; rh = m.rhy;
+                fac = (c.mym == 0.f || c.myp == 0.f) ? 1.f : 0.5f;
+            } else {
+                lo = P.zm.v[e]; hi = P.zp.v[e]; rh = m.rhz;
+                fac = (c.mzm == 0.f || c.mzp == 0.f) ? 1.f : 0.5f;
+            }
+            out.v[e] = h.v[e] - rA.v[e] * ((hi - lo) * fac * rh);
+        }
+        fg_store<VEC>(vel_out + base + c.idx, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CFL velocity: max over components of |u_c / h_c| over cells and FIXED boundaries
+// (Domain::getMaxVelocity(withBounds, computational), domain_structs.cpp:1360-1366, 1580-1611).
+// Non-negative floats order like their bit patterns, so the reduction finishes with one integer
+// atomicMax per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bnd, const float* __restrict__ vel,
+                                                            float* __restrict__ out_B) {
+    const int b = blockIdx.y;
+    const size_t N = g.n;
+    float mx = 0.f;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < g.n; idx += gridDim.x * blockDim.x) {
+        const int i = idx % g.nx;
+        const int j = (idx / g.nx) % g.ny;
+        const int k = idx / (g.nx * g.ny);
+        const float rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
+#pragma unroll
+        for (int q = 0; q < DIMS; ++q) mx = fmaxf(mx, fabsf(vel[((size_t)b * DIMS + q) * N + idx] * rh[q]));
+    }
+    if (blockIdx.x == 0) {
+        for (int f = 0; f < 2 * DIMS; ++f) {
+            if (!g.fixed[f]) continue;
+            const int ax = f >> 1;
+            const int slab_n = fg_slab_size(g, ax);
+            const int edge = (f & 1) ? ((ax == 0) ? g.nx - 1 : (ax == 1) ? g.ny - 1 : g.nz - 1) : 0;
+            for (int s = threadIdx.x; s < slab_n; s += blockDim.x) {
+                int i, j, k;
+                if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
+                else if (ax == 1) { j = edge; i = s % g.nx; k = s / g.nx; }
+                else { k = edge; i = s % g.nx; j = s / g.nx; }
+                const float rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
+#pragma unroll
+                for (int q = 0; q < DIMS; ++q)
+                    mx = fmaxf(mx, fabsf(bnd.vel[f][((size_t)b * DIMS + q) * slab_n + s] * rh[q]));
+            }
+        }
+    }
+    __shared__ float lds[4];
+    mx = fg_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+        atomicMax(reinterpret_cast<int*>(out_B) + b, __float_as_int(mx));
+    }
+}
+
+// sum of FIXED-boundary contravariant fluxes, lower faces negated
+// (Domain::GetGlobalFluxBalance, domain_structs.cpp:2476-2509).  One workgroup per env, fp64 sum.
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bnd, float* __restrict__ out_B) {
+    const int b = blockIdx.x;
+    double acc = 0.0;
+    for (int f = 0; f < 2 * DIMS; ++f) {
+        if (!g.fixed[f]) continue;
+        const int ax = f >> 1;
+        const int slab_n = fg_slab_size(g, ax);
+        const double sgn = (f & 1) ? 1.0 : -1.0;
+        for (int s = threadIdx.x; s < slab_n; s += blockDim.x) {
+            int i = 0, j = 0, k = 0;
+            if (ax == 0) { j = s % g.ny; k = s / g.ny; }
+            else if (ax == 1) { i = s % g.nx; k = s / g.nx; }
+            else { i = s % g.nx; j = s / g.nx; }
+            float area;
+            if (ax == 0) area = g.h[1][j] * (DIMS == 3 ? g.h[2][k] : 1.f);
+            else if (ax == 1) area = g.h[0][i] * (DIMS == 3 ? g.h[2][k] : 1.f);
+            else area = g.h[0][i] * g.h[1][j];
+            acc += sgn * (double)(bnd.vel[f][((size_t)b * DIMS + ax) * slab_n + s] * area);
+        }
+    }
+    __shared__ double lds[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out_B[b] = (float)(lds[0] + lds[1] + lds[2] + lds[3]);
+}
+
+// dst = src for active envs (Copy*ResultTo/FromBlocks, :6558-6746); float4 grid-stride rows
+__global__ __launch_bounds__(FG_BLOCK) void k_copy_active(const float* __restrict__ dt, const float* __restrict__ src,
+                                                           float* __restrict__ dst, long per_env) {
+    const int b = blockIdx.y;
+    if (dt && !(dt[b] > 0.f)) return;
+    const float* s = src + (size_t)b * per_env;
+    float* d = dst + (size_t)b * per_env;
+    const long n4 = (per_env % 4 == 0) ? per_env / 4 : 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < per_env; i += blockDim.x) d[i] = s[i];
+}
+
+// RBC buoyancy hook fused natively: source[axis] = factor * T, other components 0
+// (rbc_env_base.py:285-297: velocitySource = cat([0, T*buoyancy_factor(, 0)]))
+__global__ __launch_bounds__(FG_BLOCK) void k_buoyancy(const float* __restrict__ dt, const float* __restrict__ T,
+                                                        long t_env_stride, float* __restrict__ source, int dims,
+                                                        int n, int axis, float factor) {
+    const int b = blockIdx.y;
+    if (dt && !(dt[b] > 0.f)) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float t = T[(size_t)b * t_env_stride + i];
+        for (int q = 0; q < dims; ++q) source[((size_t)b * dims + q) * n + i] = (q == axis) ? factor * t : 0.f;
+    }
+}
+
+// p -= mean(p) per env (PISOtorch_simulation.py:1817-1820), written to pressureResult and the block
+__global__ __launch_bounds__(FG_BLOCK) void k_sum_env(const float* __restrict__ dt, const float* __restrict__ p,
+                                                       double* __restrict__ sums, int n) {
+    const int b = blockIdx.y;
+    if (dt && !(dt[b] > 0.f)) return;
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += p[(size_t)b * n + i];
+    __shared__ float lds[4];
+    float v[1] = {acc};
+    fg_block_sum<1>(v, lds);
+    if (threadIdx.x == 0) atomicAdd(sums + b, (double)v[0]);
+}
+__global__ __launch_bounds__(FG_BLOCK) void k_sub_mean(const float* __restrict__ dt, float* __restrict__ p,
+                                                        float* __restrict__ p_copy, const double* __restrict__ sums,
+                                                        int n) {
+    const int b = blockIdx.y;
+    if (dt && !(dt[b] > 0.f)) return;
+    const float mean = (float)(sums[b] / (double)n);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v = p[(size_t)b * n + i] - mean;
+        p[(size_t)b * n + i] = v;
+        if (p_copy) p_copy[(size_t)b * n + i] = v;
+    }
+}
+
+inline dim3 stride_grid(const fg_state* s, long per_env_elems) {
+    long blocks = (per_env_elems / 4 + FG_BLOCK - 1) / FG_BLOCK;
+    const long cap = (2048 + s->grid.B - 1) / s->grid.B;  // ~8 workgroups per CU over the batch
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks, (unsigned)s->grid.B, 1);
+}
+
+}  // namespace
+
+
+int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st) {
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        if (a.for_scalar)
+            hipLaunchKernelGGL((k_adv_build<DIMS, VEC, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
+                               L.tiles_y, L.tiles);
+        else
+            hipLaunchKernelGGL((k_adv_build<DIMS, VEC, false>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
+                               L.tiles_y, L.tiles);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_pressure_setup(const fg_state* s, const float* dt, hipStream_t st) {
+    const int n = s->grid.n;
+    hipLaunchKernelGGL(k_reciprocal, stride_grid(s, n), dim3(FG_BLOCK), 0, st, s->A, s->rA, dt, n, (n % 4 == 0) ? n / 4 : 0);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_h(const fg_state* s, const float* dt, const float* vel_result, hipStream_t st) {
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        hipLaunchKernelGGL((k_h<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, s->rA, s->Coff, s->adv_rhs,
+                           vel_result, s->hvec, L.tiles_x, L.tiles_y, L.tiles);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_div(const fg_state* s, const FgBounds& bnd, const float* dt, const float* hvec, float* div,
+                  hipStream_t st) {
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        hipLaunchKernelGGL((k_div<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, dt, hvec, div, L.tiles_x,
+                           L.tiles_y, L.tiles);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_correct(const fg_state* s, const float* dt, const float* rA, const float* hvec, const float* p,
+                      float* vel_out, hipStream_t st) {
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out,
+                           L.tiles_x, L.tiles_y, L.tiles);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st) {
+    FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(float) * s->grid.B, st));
+    dim3 grid = stride_grid(s, (long)s->grid.n * 4);
+    if (s->grid.dims == 2)
+        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B);
+    else
+        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st) {
+    if (s->grid.dims == 2)
+        hipLaunchKernelGGL(k_flux_balance<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, out_B);
+    else
+        hipLaunchKernelGGL(k_flux_balance<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, out_B);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_copy_active(const fg_state* s, const float* dt, const float* src, float* dst, int comps,
+                          hipStream_t st) {
+    const long per_env = (long)comps * s->grid.n;
+    hipLaunchKernelGGL(k_copy_active, stride_grid(s, per_env), dim3(FG_BLOCK), 0, st, dt, src, dst, per_env);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long t_env_stride, float* source, int axis,
+                       float factor, hipStream_t st) {
+    hipLaunchKernelGGL(k_buoyancy, stride_grid(s, (long)s->grid.n * 4), dim3(FG_BLOCK), 0, st, dt, T, t_env_stride,
+                       source, s->grid.dims, s->grid.n, axis, factor);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_mean_sub(const fg_state* s, const float* dt, float* p, float* p_copy, hipStream_t st) {
+    double* sums = s->acc;  // first B doubles of the accumulator pool are free between solves
+    FG_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * s->grid.B, st));
+    dim3 grid = stride_grid(s, (long)s->grid.n * 4);
+    hipLaunchKernelGGL(k_sum_env, grid, dim3(FG_BLOCK), 0, st, dt, p, sums, s->grid.n);
+    hipLaunchKernelGGL(k_sub_mean, grid, dim3(FG_BLOCK), 0, st, dt, p, p_copy, sums, s->grid.n);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}

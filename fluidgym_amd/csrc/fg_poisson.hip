@@ -1,0 +1,389 @@
+// Pressure-Poisson kernels for gfx950: matrix-free operator, Jacobi, red-black Gauss-Seidel and a
+// device-resident batched conjugate-gradient solver (2 kernels / iteration, no host scalar reads).
+//
+// Operator (PISO_build_pressure_matrix, PISO_multiblock_cuda_kernel.cu:4842-4889):
+//     (P x)_c = sum_f off_f (x_{N_f} - x_c),   off_f = (alpha_a(c) rA_c + alpha_a(N) rA_N) / 2,
+// no entry at a prescribed (FIXED) face; alpha_a = J / h_a^2.  P is negative semi-definite; like the
+// reference's CG (cg_solver_kernel.cu:250-442) we iterate on P itself (alpha, pAp < 0).
+//
+// Algorithmic HBM bytes per cell per launch (fp32): apply 12 (x, rA, y); Jacobi 20 (x, b, rA, xnew
+// + x again is the same stream) -> 16; CG kernel 1 (r, p, rA -> p, Ap) 20; CG kernel 2 (p, Ap, x, r
+// -> x, r) 24.  See DESIGN.md "roofline".
+#include <math.h>
+
+#include "fg_internal.h"
+
+namespace {
+
+// face coefficients of the thread's cells from rA (+ neighbours) and rectilinear metrics
+template <int DIMS, int VEC>
+struct FgCoef {
+    float xm[VEC], xp[VEC], ym[VEC], yp[VEC], zm[VEC], zp[VEC];
+};
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgCoef<DIMS, VEC> fg_poisson_coef(const FgCtx<DIMS, VEC>& c, const FgMetric<DIMS, VEC>& m,
+                                                             const FgNbr<DIMS, VEC>& rA) {
+    FgCoef<DIMS, VEC> k;
+    const float ayz = m.hy * m.hz;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float rh_lo = (e == 0) ? m.rhx_m : m.rhx[e > 0 ? e - 1 : 0];
+        const float rh_hi = (e == VEC - 1) ? m.rhx_p : m.rhx[e < VEC - 1 ? e + 1 : VEC - 1];
+        const float ml = (e == 0) ? c.mxm : 1.f, mh = (e == VEC - 1) ? c.mxp : 1.f;
+        const float apx = ayz * m.rhx[e] * rA.c.v[e];
+        k.xm[e] = ml * 0.5f * (apx + ayz * rh_lo * rA.xm.v[e]);
+        k.xp[e] = mh * 0.5f * (apx + ayz * rh_hi * rA.xp.v[e]);
+        const float axz = m.hx[e] * m.hz;
+        const float apy = axz * m.rhy * rA.c.v[e];
+        k.ym[e] = c.mym * 0.5f * (apy + axz * m.rhy_m * rA.ym.v[e]);
+        k.yp[e] = c.myp * 0.5f * (apy + axz * m.rhy_p * rA.yp.v[e]);
+        if constexpr (DIMS == 3) {
+            const float axy = m.hx[e] * m.hy;
+            const float apz = axy * m.rhz * rA.c.v[e];
+            k.zm[e] = c.mzm * 0.5f * (apz + axy * m.rhz_m * rA.zm.v[e]);
+            k.zp[e] = c.mzp * 0.5f * (apz + axy * m.rhz_p * rA.zp.v[e]);
+        } else {
+            k.zm[e] = k.zp[e] = 0.f;
+        }
+    }
+    return k;
+}
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ float fg_apply_elem(const FgCoef<DIMS, VEC>& k, const FgNbr<DIMS, VEC>& x, int e) {
+    float y = k.xm[e] * (x.xm.v[e] - x.c.v[e]) + k.xp[e] * (x.xp.v[e] - x.c.v[e]) +
+              k.ym[e] * (x.ym.v[e] - x.c.v[e]) + k.yp[e] * (x.yp.v[e] - x.c.v[e]);
+    if constexpr (DIMS == 3) y += k.zm[e] * (x.zm.v[e] - x.c.v[e]) + k.zp[e] * (x.zp.v[e] - x.c.v[e]);
+    return y;
+}
+
+// y = P x
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_poisson_apply(FgGrid g, const float* __restrict__ rA_,
+                                                             const float* __restrict__ x_, float* __restrict__ y_,
+                                                             int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if (!c.valid) return;
+    const size_t base = (size_t)c.b * g.n;
+    const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
+    const FgNbr<DIMS, VEC> rA = fg_gather<DIMS, VEC>(rA_ + base, c);
+    const FgNbr<DIMS, VEC> x = fg_gather<DIMS, VEC>(x_ + base, c);
+    const FgCoef<DIMS, VEC> k = fg_poisson_coef<DIMS, VEC>(c, m, rA);
+    FgVec<VEC> y;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) y.v[e] = fg_apply_elem<DIMS, VEC>(k, x, e);
+    fg_store<VEC>(y_ + base + c.idx, y);
+}
+
+// damped Jacobi sweep: xnew = x + omega (b - P x) / diag,  diag = -sum_f off_f
+// RBGS (COLOR >= 0): same update, in place, only for cells with (i+j+k)&1 == COLOR
+template <int DIMS, int VEC, bool RB>
+__global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const float* __restrict__ rA_,
+                                                             const float* __restrict__ b_, const float* x_,
+                                                             float* xnew_, float omega, int color,
+                                                             int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if (!c.valid) return;
+    const size_t base = (size_t)c.b * g.n;
+    const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
+    const FgNbr<DIMS, VEC> rA = fg_gather<DIMS, VEC>(rA_ + base, c);
+    const FgNbr<DIMS, VEC> x = fg_gather<DIMS, VEC>(x_ + base, c);
+    const FgVec<VEC> b = fg_load<VEC>(b_ + base + c.idx);
+    const FgCoef<DIMS, VEC> k = fg_poisson_coef<DIMS, VEC>(c, m, rA);
+    FgVec<VEC> out;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float diag = -(k.xm[e] + k.xp[e] + k.ym[e] + k.yp[e] + k.zm[e] + k.zp[e]);
+        const float res = b.v[e] - fg_apply_elem<DIMS, VEC>(k, x, e);
+        float v = x.c.v[e] + omega * res / diag;
+        if constexpr (RB) {
+            if (((c.i0 + e + c.j + c.k) & 1) != color) v = x.c.v[e];
+        }
+        out.v[e] = v;
+    }
+    fg_store<VEC>(xnew_ + base + c.idx, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched CG.  Per-env reduction accumulators (fp64, one atomicAdd per workgroup):
+//   acc[b][0..2]  rr ring   (rr_i lives in slot i % 3)
+//   acc[b][3..4]  pAp ring  (pAp_i in slot 3 + i % 2)
+// Every workgroup derives alpha / beta / the convergence decision itself from the accumulators, so
+// no scalar ever travels to the host inside the loop (the reference reads 3-4 scalars per
+// iteration through cublasTdot/nrm2, cg_solver_kernel.cu:277,317,332,431).
+// flags[b]: 0 running, 1 converged, 2 non-finite residual, 3 inactive env.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
+
+// r = b - P x (or r = b when x0 == 0), accumulates rr into `slot`
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float* __restrict__ rA_,
+                                                           const float* __restrict__ b_, float* __restrict__ x_,
+                                                           float* __restrict__ r_, double* __restrict__ acc,
+                                                           const int32_t* __restrict__ flags, int use_x0, int slot,
+                                                           int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if (flags[c.b] != 0) return;
+    __shared__ float lds[4];
+    const size_t base = (size_t)c.b * g.n;
+    float part[1] = {0.f};
+    if (c.valid) {
+        FgVec<VEC> r = fg_load<VEC>(b_ + base + c.idx);
+        if (use_x0) {
+            const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
+            const FgNbr<DIMS, VEC> rA = fg_gather<DIMS, VEC>(rA_ + base, c);
+            const FgNbr<DIMS, VEC> x = fg_gather<DIMS, VEC>(x_ + base, c);
+            const FgCoef<DIMS, VEC> k = fg_poisson_coef<DIMS, VEC>(c, m, rA);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.v[e] -= fg_apply_elem<DIMS, VEC>(k, x, e);
+        } else {
+            FgVec<VEC> z;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) z.v[e] = 0.f;
+            fg_store<VEC>(x_ + base + c.idx, z);
+        }
+        fg_store<VEC>(r_ + base + c.idx, r);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) part[0] += r.v[e] * r.v[e];
+    }
+    fg_block_sum<1>(part, lds);
+    if (threadIdx.x == 0) atomicAdd(acc + (size_t)c.b * FG_ACC_DOUBLES + slot, (double)part[0]);
+}
+
+// CG kernel 1 of iteration `it`:  p = r + beta p ; Ap = P p ; pAp += p.Ap
+// The p update is fused into the operator by recomputing it on the halo (r and p are gathered
+// with neighbours), which removes one full pass over p per iteration.  Because the halo cells
+// belong to other workgroups that rewrite p in this same launch, p is double-buffered:
+// pin_ = p of iteration it-1 (read with halo), pout_ = p of iteration it (written, centre only).
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __restrict__ rA_,
+                                                     const float* __restrict__ r_, const float* __restrict__ pin_,
+                                                     float* __restrict__ pout_,
+                                                     float* __restrict__ Ap_, double* __restrict__ acc,
+                                                     int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+                                                     float tol, int it, int first, int tiles_x, int tiles_y,
+                                                     int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if (flags[c.b] != 0) return;
+    double* a = acc + (size_t)c.b * FG_ACC_DOUBLES;
+    const double rr_new = a[it % 3];
+    const float crit = fg_rms(rr_new, g.n);
+    const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
+    if (!(crit >= tol)) {  // converged (crit < tol) or NaN
+        if (leader) {
+            const bool finite = isfinite(crit);
+            flags[c.b] = finite ? 1 : 2;
+            info[c.b].final_residual = crit;
+            info[c.b].used_iterations = it - 1;
+            info[c.b].converged = finite ? 1 : 0;
+            info[c.b].is_finite = finite ? 1 : 0;
+        }
+        return;
+    }
+    if (leader) {
+        a[(it + 1) % 3] = 0.0;  // rr slot of the next iteration (last read one kernel ago)
+        info[c.b].final_residual = crit;
+        info[c.b].used_iterations = it - 1;
+    }
+    const float beta = first ? 0.f : (float)(rr_new / a[(it + 2) % 3]);
+    __shared__ float lds[4];
+    const size_t base = (size_t)c.b * g.n;
+    float part[1] = {0.f};
+    if (c.valid) {
+        const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
+        const FgNbr<DIMS, VEC> rA = fg_gather<DIMS, VEC>(rA_ + base, c);
+        FgNbr<DIMS, VEC> p = fg_gather<DIMS, VEC>(r_ + base, c);
+        if (!first) {
+            const FgNbr<DIMS, VEC> po = fg_gather<DIMS, VEC>(pin_ + base, c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                p.c.v[e] += beta * po.c.v[e];
+                p.xm.v[e] += beta * po.xm.v[e];
+                p.xp.v[e] += beta * po.xp.v[e];
+                p.ym.v[e] += beta * po.ym.v[e];
+                p.yp.v[e] += beta * po.yp.v[e];
+                if constexpr (DIMS == 3) {
+                    p.zm.v[e] += beta * po.zm.v[e];
+                    p.zp.v[e] += beta * po.zp.v[e];
+                }
+            }
+        }
+        const FgCoef<DIMS, VEC> k = fg_poisson_coef<DIMS, VEC>(c, m, rA);
+        FgVec<VEC> Ap;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            Ap.v[e] = fg_apply_elem<DIMS, VEC>(k, p, e);
+            part[0] += p.c.v[e] * Ap.v[e];
+        }
+        fg_store<VEC>(Ap_ + base + c.idx, Ap);
+        fg_store<VEC>(pout_ + base + c.idx, p.c);
+    }
+    fg_block_sum<1>(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + 3 + (it & 1), (double)part[0]);
+}
+
+// CG kernel 2:  alpha = rr / pAp ; x += alpha p ; r -= alpha Ap ; rr_next += r.r
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* __restrict__ p_,
+                                                         const float* __restrict__ Ap_, float* __restrict__ x_,
+                                                         float* __restrict__ r_, double* __restrict__ acc,
+                                                         const int32_t* __restrict__ flags, float tol, int it,
+                                                         int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if (flags[c.b] != 0) return;
+    double* a = acc + (size_t)c.b * FG_ACC_DOUBLES;
+    const double rr = a[it % 3];
+    const double pAp = a[3 + (it & 1)];
+    const float alpha = (float)(rr / pAp);
+    const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
+    if (leader) a[3 + ((it + 1) & 1)] = 0.0;  // pAp slot of the next iteration
+    __shared__ float lds[4];
+    const size_t base = (size_t)c.b * g.n;
+    float part[1] = {0.f};
+    if (c.valid) {
+        const FgVec<VEC> p = fg_load<VEC>(p_ + base + c.idx);
+        const FgVec<VEC> Ap = fg_load<VEC>(Ap_ + base + c.idx);
+        FgVec<VEC> x = fg_load<VEC>(x_ + base + c.idx);
+        FgVec<VEC> r = fg_load<VEC>(r_ + base + c.idx);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            x.v[e] += alpha * p.v[e];
+            r.v[e] -= alpha * Ap.v[e];
+            part[0] += r.v[e] * r.v[e];
+        }
+        fg_store<VEC>(x_ + base + c.idx, x);
+        fg_store<VEC>(r_ + base + c.idx, r);
+    }
+    fg_block_sum<1>(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + (it + 1) % 3, (double)part[0]);
+}
+
+// Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one thread per env.
+__global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+                           float tol, int it, int n, int B, int final_pass) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || flags[b] != 0) return;
+    const float crit = fg_rms(acc[(size_t)b * FG_ACC_DOUBLES + (it + 1) % 3], n);
+    info[b].final_residual = crit;
+    info[b].used_iterations = it;
+    if (!(crit >= tol)) {
+        const bool finite = isfinite(crit);
+        flags[b] = finite ? 1 : 2;
+        info[b].converged = finite ? 1 : 0;
+        info[b].is_finite = finite ? 1 : 0;
+    } else if (final_pass) {
+        info[b].converged = 0;
+        info[b].is_finite = 1;
+    }
+}
+
+__global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ acc, int32_t* __restrict__ flags,
+                           fg_solve_info* __restrict__ info, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int q = 0; q < FG_ACC_DOUBLES; ++q) acc[(size_t)b * FG_ACC_DOUBLES + q] = 0.0;
+    const bool active = (dt == nullptr) || (dt[b] > 0.f);
+    flags[b] = active ? 0 : 3;
+    info[b].final_residual = 0.f;
+    info[b].used_iterations = -1;
+    info[b].converged = active ? 0 : 1;
+    info[b].is_finite = 1;
+}
+
+__global__ void k_zero_slot(double* __restrict__ acc, int slot, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) acc[(size_t)b * FG_ACC_DOUBLES + slot] = 0.0;
+}
+
+}  // namespace
+
+
+int fg_poisson_apply_launch(const fg_state* s, const float* rA, const float* x, float* y, hipStream_t st) {
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        hipLaunchKernelGGL((k_poisson_apply<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, rA, x, y, L.tiles_x,
+                           L.tiles_y, L.tiles);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_poisson_jacobi_launch(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew,
+                             float omega, hipStream_t st) {
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        hipLaunchKernelGGL((k_poisson_relax<DIMS, VEC, false>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, rA, b, x, xnew,
+                           omega, 0, L.tiles_x, L.tiles_y, L.tiles);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_poisson_rbgs_launch(const fg_state* s, const float* rA, const float* b, float* x, float omega, int color,
+                           hipStream_t st) {
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        hipLaunchKernelGGL((k_poisson_relax<DIMS, VEC, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, rA, b, x, x,
+                           omega, color, L.tiles_x, L.tiles_y, L.tiles);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+// Host driver of the batched CG.  p is double-buffered: a.p is buffer 0, s->w[6] buffer 1.
+int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st) {
+    const int B = s->grid.B, n = s->grid.n;
+    const dim3 sg((B + 63) / 64), sb(64);
+    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->acc, s->flags, s->info_dev, B);
+    float* pbuf[2] = {a.p, s->w[6]};
+    FG_DISPATCH(s, {
+        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+        hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,
+                           s->acc, s->flags, a.use_x0, 0, L.tiles_x, L.tiles_y, L.tiles);
+    });
+    const int check_every = a.check_every > 0 ? a.check_every : 16;
+    bool done = false;
+    int it = 0;
+    for (; it < a.max_iterations && !done; ++it) {
+        int first = (it == 0);
+        if (a.reset_steps > 0 && it > 0 && (it + 1) % a.reset_steps == 0) {
+            // residual restart (cg_solver_kernel.cu:281-302): r = b - P x, p = r
+            hipLaunchKernelGGL(k_zero_slot, sg, sb, 0, st, s->acc, it % 3, B);
+            FG_DISPATCH(s, {
+                const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+                hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x,
+                                   a.r, s->acc, s->flags, 1, it % 3, L.tiles_x, L.tiles_y, L.tiles);
+            });
+            first = 1;
+        }
+        // p double buffer: read p_{it-1} from pbuf[(it+1)&1], write p_it to pbuf[it&1]
+        const float* p_in = pbuf[(it + 1) & 1];
+        float* p_out = pbuf[it & 1];
+        FG_DISPATCH(s, {
+            const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+            hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.r, p_in, p_out,
+                               a.Ap, s->acc, s->flags, s->info_dev, a.tol, it, first, L.tiles_x, L.tiles_y, L.tiles);
+            hipLaunchKernelGGL((k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x, a.r,
+                               s->acc, s->flags, a.tol, it, L.tiles_x, L.tiles_y, L.tiles);
+        });
+        if ((it + 1) % check_every == 0 || it + 1 == a.max_iterations) {
+            const int final_pass = (it + 1 == a.max_iterations);
+            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->acc, s->flags, s->info_dev, a.tol, it, n, B, final_pass);
+            FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+            FG_HIP_CHECK(hipStreamSynchronize(st));
+            done = true;
+            for (int b = 0; b < B; ++b) done = done && (s->flags_pinned[b] != 0);
+        }
+    }
+    FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    int rc = FG_OK;
+    for (int b = 0; b < B; ++b) {
+        if (info_host) info_host[b] = s->info_pinned[b];
+        if (!s->info_pinned[b].is_finite) rc = FG_ERR_NOT_FINITE;
+        else if (!s->info_pinned[b].converged && rc == FG_OK) rc = FG_ERR_NOT_CONVERGED;
+    }
+    FG_HIP_CHECK(hipGetLastError());
+    return rc;
+}

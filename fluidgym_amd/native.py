@@ -1,0 +1,277 @@
+"""Thin object wrapper over the C ABI: one :class:`NativeSolver` per (grid, batch) on one GPU.
+
+PyTorch-ROCm tensors are used only as device-memory owners (zero-copy ``data_ptr()``) and for the
+current HIP stream; all arithmetic happens in ``libfluidgym_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class LinsolveError(RuntimeError):
+    """A linear solve failed (reference: ``PISOtorch_diff.LinsolveError``, PISOtorch_diff.py:262)."""
+
+
+class NativeSolver:
+    """Owns an ``fg_handle`` and the field tensors bound to it.
+
+    Parameters mirror ``fg_config``: ``faces`` maps face index (0..2d-1 = -x,+x,-y,+y,-z,+z) to
+    ``"periodic"`` / ``"fixed"``; ``scalar_bc[face][channel]`` is ``FG_DIRICHLET``/``FG_NEUMANN``.
+    ``widths`` = per-axis cell widths ``[hx, hy(, hz)]`` (rectilinear grid).
+    """
+
+    def __init__(self, widths: Sequence[np.ndarray], batch: int, fixed_faces: Sequence[int] = (),
+                 n_scalars: int = 0, scalar_bc: Optional[Dict[int, Sequence[int]]] = None,
+                 device: Optional[torch.device] = None, allocate: bool = True):
+        if not torch.cuda.is_available():
+            raise L.NativeLibraryError("fluidgym_amd needs a ROCm GPU (MI355X); there is no CPU path")
+        self.lib = L.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dims = len(widths)
+        assert self.dims in (2, 3)
+        self.widths = [np.ascontiguousarray(w, dtype=np.float32) for w in widths]
+        self.nx = len(self.widths[0])
+        self.ny = len(self.widths[1])
+        self.nz = len(self.widths[2]) if self.dims == 3 else 1
+        self.n = self.nx * self.ny * self.nz
+        self.B = int(batch)
+        self.n_scalars = int(n_scalars)
+        self.fixed = [f in fixed_faces for f in range(6)]
+        cfg = L.FgConfig()
+        cfg.dims, cfg.nx, cfg.ny, cfg.nz = self.dims, self.nx, self.ny, self.nz
+        cfg.batch, cfg.n_scalars = self.B, self.n_scalars
+        cfg.device = self.device.index or 0
+        for f in range(6):
+            cfg.face_type[f] = L.FG_FIXED if self.fixed[f] else L.FG_PERIODIC
+            for ch in range(L.FG_MAX_SCALARS):
+                cfg.scalar_bc[f][ch] = L.FG_DIRICHLET
+            if scalar_bc and f in scalar_bc:
+                for ch, t in enumerate(scalar_bc[f]):
+                    cfg.scalar_bc[f][ch] = int(t)
+        fp = ctypes.POINTER(ctypes.c_float)
+        hz = self.widths[2].ctypes.data_as(fp) if self.dims == 3 else None
+        handle = ctypes.c_void_p()
+        L.check(self.lib.fg_create(ctypes.byref(cfg), self.widths[0].ctypes.data_as(fp),
+                                   self.widths[1].ctypes.data_as(fp), hz, ctypes.byref(handle)))
+        self.handle = handle
+        self._bound: Dict[int, torch.Tensor] = {}
+        self.viscosity = 0.0
+        # fields
+        self.velocity = self.pressure = self.scalar = self.velocity_source = None
+        self.bvel: Dict[int, torch.Tensor] = {}
+        self.bscal: Dict[int, torch.Tensor] = {}
+        self._dt = torch.zeros(self.B, dtype=torch.float32, device=self.device)
+        self._dt_host = torch.zeros(self.B, dtype=torch.float32).pin_memory()
+        self._out_B = torch.zeros(self.B, dtype=torch.float32, device=self.device)
+        if allocate:
+            self.allocate_fields()
+
+    # ------------------------------------------------------------------ shapes
+    @property
+    def spatial(self):
+        return (self.ny, self.nx) if self.dims == 2 else (self.nz, self.ny, self.nx)
+
+    def slab(self, face: int):
+        s = list(self.spatial)
+        s[len(s) - 1 - (face >> 1)] = 1
+        return tuple(s)
+
+    # ------------------------------------------------------------------ binding
+    def bind(self, field: int, t: Optional[torch.Tensor]):
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "fields must be contiguous fp32 CUDA"
+            self._bound[field] = t  # keep alive
+        else:
+            self._bound.pop(field, None)
+        L.check(self.lib.fg_bind(self.handle, field, _ptr(t)))
+
+    def allocate_fields(self):
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self.set_velocity(z(self.B, self.dims, *self.spatial))
+        self.set_pressure(z(self.B, 1, *self.spatial))
+        if self.n_scalars:
+            self.set_scalar(z(self.B, self.n_scalars, *self.spatial))
+        for f in range(2 * self.dims):
+            if self.fixed[f]:
+                self.set_boundary_velocity(f, z(self.B, self.dims, *self.slab(f)))
+                if self.n_scalars:
+                    self.set_boundary_scalar(f, z(self.B, self.n_scalars, *self.slab(f)))
+
+    def set_velocity(self, t):
+        self.velocity = t
+        self.bind(L.FG_VELOCITY, t)
+
+    def set_pressure(self, t):
+        self.pressure = t
+        self.bind(L.FG_PRESSURE, t)
+
+    def set_scalar(self, t):
+        self.scalar = t
+        self.bind(L.FG_SCALAR, t)
+
+    def set_velocity_source(self, t):
+        self.velocity_source = t
+        self.bind(L.FG_VELOCITY_SOURCE, t)
+
+    def set_boundary_velocity(self, face, t):
+        self.bvel[face] = t
+        self.bind(L.FG_BOUND_VELOCITY + face, t)
+
+    def set_boundary_scalar(self, face, t):
+        self.bscal[face] = t
+        self.bind(L.FG_BOUND_SCALAR + face, t)
+
+    def set_viscosity(self, nu: float):
+        self.viscosity = float(nu)
+        L.check(self.lib.fg_set_viscosity(self.handle, float(nu)))
+
+    def set_scalar_viscosity(self, ch: int, k: float):
+        L.check(self.lib.fg_set_scalar_viscosity(self.handle, ch, float(k)))
+
+    # ------------------------------------------------------------------ helpers
+    def dt_tensor(self, dt) -> torch.Tensor:
+        """Per-env time steps on the device; ``dt`` may be a float or a length-B sequence
+        (``<= 0`` = env inactive for the call)."""
+        if isinstance(dt, torch.Tensor) and dt.is_cuda:
+            return dt
+        self._dt_host.copy_(torch.as_tensor(np.broadcast_to(np.asarray(dt, dtype=np.float32), (self.B,)).copy()))
+        self._dt.copy_(self._dt_host, non_blocking=True)
+        return self._dt
+
+    def buffer(self, which: int, shape) -> torch.Tensor:
+        """Copy of an internal solver vector (tests only)."""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        L.check(self.lib.fg_get_buffer(self.handle, which, ctypes.byref(p), ctypes.byref(n)))
+        out = torch.empty(int(n.value), dtype=torch.float32, device=self.device)
+        L.check(self.lib.fg_read_buffer(self.handle, which, _ptr(out), _stream(self.device)))
+        return out.view(*shape)
+
+    def _infos(self, n):
+        return (L.FgSolveInfo * n)()
+
+    # ------------------------------------------------------------------ reductions
+    def max_velocity(self) -> torch.Tensor:
+        L.check(self.lib.fg_max_velocity(self.handle, _ptr(self._out_B), _stream(self.device)))
+        return self._out_B.clone()
+
+    def boundary_flux_balance(self) -> torch.Tensor:
+        L.check(self.lib.fg_boundary_flux_balance(self.handle, _ptr(self._out_B), _stream(self.device)))
+        return self._out_B.clone()
+
+    # ------------------------------------------------------------------ PISO pieces
+    def setup_advection(self, dt, for_scalar=False, channel=0):
+        L.check(self.lib.fg_setup_advection(self.handle, _ptr(self.dt_tensor(dt)), int(for_scalar), channel,
+                                            _stream(self.device)))
+
+    def solve_advection(self, for_scalar=False, channel=0, tol=1e-5, max_iterations=5000) -> List[L.FgSolveInfo]:
+        n = self.B * (1 if for_scalar else self.dims)
+        info = self._infos(n)
+        rc = self.lib.fg_solve_advection(self.handle, int(for_scalar), channel, tol, max_iterations, info,
+                                         _stream(self.device))
+        L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
+        return list(info)
+
+    def copy_scalar_result_to_blocks(self, channel=0):
+        L.check(self.lib.fg_copy_scalar_result_to_blocks(self.handle, channel, _stream(self.device)))
+
+    def setup_pressure_matrix(self):
+        L.check(self.lib.fg_setup_pressure_matrix(self.handle, _stream(self.device)))
+
+    def setup_pressure_rhs(self, dt):
+        L.check(self.lib.fg_setup_pressure_rhs(self.handle, _ptr(self.dt_tensor(dt)), _stream(self.device)))
+
+    def solve_pressure(self, tol=1e-5, max_iterations=5000, method=L.FG_SOLVER_CG, use_previous=False):
+        info = self._infos(self.B)
+        rc = self.lib.fg_solve_pressure(self.handle, method, tol, max_iterations, int(use_previous), info,
+                                        _stream(self.device))
+        L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
+        return list(info)
+
+    def correct_velocity(self):
+        L.check(self.lib.fg_correct_velocity(self.handle, _stream(self.device)))
+
+    def copy_velocity_result_to_blocks(self):
+        L.check(self.lib.fg_copy_velocity_result_to_blocks(self.handle, _stream(self.device)))
+
+    def copy_velocity_result_from_blocks(self):
+        L.check(self.lib.fg_copy_velocity_result_from_blocks(self.handle, _stream(self.device)))
+
+    def piso_step(self, dt, corrector_steps=2, advect_scalar=True, advection_tol=1e-5, pressure_tol=1e-5,
+                  max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0, method=L.FG_SOLVER_CG):
+        opt = L.FgStepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol,
+                              pressure_tol, buoyancy_axis, buoyancy_factor)
+        stats = (ctypes.c_int32 * 4)()
+        rc = self.lib.fg_piso_step(self.handle, _ptr(self.dt_tensor(dt)), ctypes.byref(opt), stats,
+                                   _stream(self.device))
+        if rc == L.FG_ERR_NOT_FINITE:
+            raise LinsolveError("linear solve produced a non-finite residual")
+        L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED,))
+        return rc == L.FG_OK, list(stats)
+
+    def make_divergence_free(self, tol=1e-5, max_iterations=1000):
+        info = self._infos(self.B)
+        rc = self.lib.fg_make_divergence_free(self.handle, tol, max_iterations, info, _stream(self.device))
+        L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED,))
+        return list(info)
+
+    # ------------------------------------------------------------------ standalone Poisson
+    def poisson_apply(self, rA, x, y=None):
+        y = torch.empty_like(x) if y is None else y
+        L.check(self.lib.fg_poisson_apply(self.handle, _ptr(rA), _ptr(x), _ptr(y), _stream(self.device)))
+        return y
+
+    def poisson_jacobi(self, rA, b, x, sweeps, omega=1.0):
+        L.check(self.lib.fg_poisson_jacobi(self.handle, _ptr(rA), _ptr(b), _ptr(x), sweeps, omega, _stream(self.device)))
+        return x
+
+    def poisson_rbgs(self, rA, b, x, sweeps, omega=1.0):
+        L.check(self.lib.fg_poisson_rbgs(self.handle, _ptr(rA), _ptr(b), _ptr(x), sweeps, omega, _stream(self.device)))
+        return x
+
+    def poisson_cg(self, rA, b, x, tol=1e-5, max_iterations=5000, use_x0=False):
+        info = self._infos(self.B)
+        rc = self.lib.fg_poisson_cg(self.handle, _ptr(rA), _ptr(b), _ptr(x), tol, max_iterations, int(use_x0), info,
+                                    _stream(self.device))
+        L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
+        return list(info)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.fg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def coords_to_transforms(coords: torch.Tensor) -> torch.Tensor:
+    """``PISOtorch.CoordsToTransforms`` (grid_gen.cu:356-390): coords ``[1,d,(Z+1,)Y+1,X+1]`` ->
+    transforms ``[1,(Z,)Y,X,2d^2+1]``."""
+    lib = L.load()
+    assert coords.is_cuda and coords.dtype == torch.float32
+    coords = coords.contiguous()
+    d = coords.shape[1]
+    sp = [s - 1 for s in coords.shape[2:]]
+    nx, ny = sp[-1], sp[-2]
+    nz = sp[0] if d == 3 else 1
+    out = torch.empty([1] + sp + [2 * d * d + 1], dtype=torch.float32, device=coords.device)
+    L.check(lib.fg_coords_to_transforms(_ptr(coords), _ptr(out), d, nx, ny, nz, _stream(coords.device)))
+    return out

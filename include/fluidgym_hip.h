@@ -1,0 +1,201 @@
+/*
+ * fluidgym_hip.h -- C ABI of libfluidgym_hip.so, the MI355X (gfx950) native replacement for the
+ * simulation hot path of safe-autonomous-systems/fluidgym (module `PISOtorch`,
+ * reference: src/fluidgym/simulation/extensions/PISOtorch.cpp:40-670).
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / scalars (no torch types),
+ * returns an int status (FG_OK = 0, negative = error, never aborts -- the reference `exit(10)`s on a
+ * CUDA error, PISO_multiblock_cuda_kernel.cu:40-46) and is asynchronous on the `stream` it is
+ * given (a hipStream_t passed as void*; the reference synchronises the device around every kernel,
+ * PISO_multiblock_cuda_kernel.cu:4512,4520).  All `float*` arguments are DEVICE pointers unless
+ * the name ends in `_host`.
+ *
+ * Differences from the reference object model:
+ *   - an ENV BATCH axis B is the outermost axis of every field (the reference asserts N == 1,
+ *     domain_structs.cpp:2020); per-env time steps are a device array dt[B]; dt[b] <= 0 marks env b
+ *     inactive for that call (its state is left untouched);
+ *   - one block, rectilinear (tensor-product) orthogonal grid: metrics are per-axis cell widths;
+ *     faces are PERIODIC or FIXED (Dirichlet velocity; Dirichlet/Neumann passive scalar);
+ *   - matrices are never materialised as CSR: C is kept in stencil form (diag + 2d off-diagonals),
+ *     P is applied matrix-free from 1/A;
+ *   - the caller owns all field memory and binds it with fg_bind(); the handle owns solver
+ *     workspace allocated once in fg_create() -- nothing is allocated on the step path.
+ *
+ * Layouts (fp32, C-contiguous): velocity [B,d,(Z,)Y,X]; pressure [B,1,(Z,)Y,X];
+ * passive scalar [B,C,(Z,)Y,X]; velocity source [B,d,(Z,)Y,X]; boundary velocity of face f
+ * [B,d,slab(f)] and boundary scalar [B,C,slab(f)] where slab(f) is the cell shape with extent 1
+ * on the face axis.  Faces: 0..5 = -x,+x,-y,+y,-z,+z (PISO_multiblock_cuda_kernel.cu:211-236).
+ */
+#ifndef FLUIDGYM_HIP_H
+#define FLUIDGYM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_ABI_VERSION 1
+#define FG_MAX_SCALARS 4
+
+/* status codes */
+#define FG_OK 0
+#define FG_ERR_INVALID_ARG (-1)
+#define FG_ERR_NOT_BOUND (-2)
+#define FG_ERR_HIP (-3)
+#define FG_ERR_UNSUPPORTED (-4)
+#define FG_ERR_NOT_CONVERGED (-5) /* informational: a solve hit max_iterations */
+#define FG_ERR_NOT_FINITE (-6)   /* a solver residual became NaN/Inf */
+
+/* boundary type of a face (reference BoundaryType::PERIODIC / FIXED, domain_structs_gpu.h:120-135) */
+#define FG_PERIODIC 0
+#define FG_FIXED 1
+/* passive-scalar boundary condition (reference BoundaryConditionType) */
+#define FG_DIRICHLET 0
+#define FG_NEUMANN 1
+
+/* bindable fields (fg_bind) */
+enum fg_field {
+    FG_VELOCITY = 0,       /* block.velocity           [B,d,N]                      */
+    FG_PRESSURE = 1,       /* block.pressure           [B,N]                        */
+    FG_SCALAR = 2,         /* block.passiveScalar      [B,C,N]                      */
+    FG_VELOCITY_SOURCE = 3,/* block.velocitySource     [B,d,N] (NULL = none)        */
+    FG_BOUND_VELOCITY = 8, /* + face: FixedBoundary.velocity      [B,d,slab]        */
+    FG_BOUND_SCALAR = 16   /* + face: FixedBoundary.passiveScalar [B,C,slab]        */
+};
+
+/* pressure solver variants (the reference only has CG, cg_solver_kernel.cu:129-471) */
+#define FG_SOLVER_CG 0
+#define FG_SOLVER_JACOBI 1
+#define FG_SOLVER_RBGS 2
+#define FG_SOLVER_MGCG 3
+
+typedef struct fg_state* fg_handle;
+
+typedef struct fg_config {
+    int32_t dims;                 /* 2 or 3 */
+    int32_t nx, ny, nz;           /* cells; nz = 1 in 2-D; >= 3 per used axis (domain_structs.cpp:1193) */
+    int32_t batch;                /* B */
+    int32_t n_scalars;            /* passive scalar channels C (0..FG_MAX_SCALARS) */
+    int32_t face_type[6];         /* FG_PERIODIC / FG_FIXED; a FIXED face needs a FIXED partner */
+    int32_t scalar_bc[6][FG_MAX_SCALARS]; /* FG_DIRICHLET / FG_NEUMANN per FIXED face & channel */
+    int32_t device;               /* HIP device ordinal */
+} fg_config;
+
+/* result of a batched linear solve, one entry per system (reference LinearSolverResultInfo,
+ * bicgstab_solver.h) */
+typedef struct fg_solve_info {
+    float final_residual;   /* RMS residual ||r||_2/sqrt(n) (cg_solver_kernel.cu:100-106) */
+    int32_t used_iterations;
+    int32_t converged;
+    int32_t is_finite;
+} fg_solve_info;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int fg_abi_version(void);
+const char* fg_last_error(void);                 /* thread-local message of the last failure */
+
+/* Domain()+CreateBlock()+PrepareSolve() (PISOtorch.cpp:420-500; domain_structs.cpp:2570-2693).
+ * hx/hy/hz_host: per-axis cell widths (host arrays of nx/ny/nz floats; hz may be NULL in 2-D). */
+int fg_create(const fg_config* cfg, const float* hx_host, const float* hy_host, const float* hz_host,
+              fg_handle* out);
+int fg_destroy(fg_handle h);
+
+/* Block.setVelocity()/setPressure()/... + Domain.UpdateDomainData() (domain_structs.cpp:3047-3283):
+ * bind (borrow) a caller-owned device buffer.  field = enum fg_field (+ face for boundaries). */
+int fg_bind(fg_handle h, int field, float* ptr);
+/* Domain.viscosity / Domain.setScalarViscosity (domain_structs.cpp:3070) */
+int fg_set_viscosity(fg_handle h, float viscosity);
+int fg_set_scalar_viscosity(fg_handle h, int channel, float viscosity);
+
+/* ---- reductions used by the drivers --------------------------------------------------------- */
+/* Domain.getMaxVelocity(withBounds=True, computational=True) (domain_structs.cpp:1580-1611) */
+int fg_max_velocity(fg_handle h, float* out_B, void* stream);
+/* Domain.GetBoundaryFluxBalance (domain_structs.cpp:2476-2509) */
+int fg_boundary_flux_balance(fg_handle h, float* out_B, void* stream);
+
+/* ---- PISO building blocks (one call = the reference free function of the same role) --------- */
+/* SetupAdvectionMatrix (PISO_multiblock_cuda_kernel.cu:4525-4546, kernel :3616-3880) fused with
+ * SetupAdvectionVelocity (:4692-4708, kernel :4296-4400) or, when for_scalar != 0, with
+ * SetupAdvectionScalar (:4620-4637, kernel :4094-4198) for `channel`. */
+int fg_setup_advection(fg_handle h, const float* dt_B, int for_scalar, int channel, void* stream);
+/* SolveLinear(C, RHS, x, useBiCG=True) (:7085-7118; bicgstab_solver_kernel.cu:63-411) for the
+ * velocity components (for_scalar = 0; x0 = previous velocityResult) or a scalar channel.
+ * info_host: d (or 1) * B entries, written after an internal stream sync. */
+int fg_solve_advection(fg_handle h, int for_scalar, int channel, float tol, int max_iterations,
+                       fg_solve_info* info_host, void* stream);
+/* CopyScalarResultToBlocks (:6558-6746) */
+int fg_copy_scalar_result_to_blocks(fg_handle h, int channel, void* stream);
+/* SetupPressureMatrix (:5599-5615, kernel :4812-4978): rA = 1/A */
+int fg_setup_pressure_matrix(fg_handle h, void* stream);
+/* SetupPressureRHS (:5655-5672, kernels :5136-5255 + :5389-5434): h = H(u~), b = div h */
+int fg_setup_pressure_rhs(fg_handle h, const float* dt_B, void* stream);
+/* SolveLinear(P, div, x, useBiCG=False) + `p -= mean(p)` (PISOtorch_simulation.py:1804-1821) +
+ * CopyPressureResultToBlocks.  method = FG_SOLVER_*.  info_host: B entries. */
+int fg_solve_pressure(fg_handle h, int method, float tol, int max_iterations, int use_previous,
+                      fg_solve_info* info_host, void* stream);
+/* CorrectVelocity(version=1) (:6220-6236, kernel :5962-5995 + :816-849) */
+int fg_correct_velocity(fg_handle h, void* stream);
+/* CopyVelocityResultToBlocks / FromBlocks (:6558-6746) */
+int fg_copy_velocity_result_to_blocks(fg_handle h, void* stream);
+int fg_copy_velocity_result_from_blocks(fg_handle h, void* stream);
+
+/* ---- fused driver: one _PISO_split_step without Python hooks --------------------------------
+ * (PISOtorch_simulation.py:1431-2002, orthogonal branch).  buoyancy_axis >= 0 fuses the RBC
+ * PRE_VELOCITY_SETUP hook: velocitySource[axis] = buoyancy_factor * T (rbc_env_base.py:285-297).
+ * stats_host (optional, 4 ints): max iterations of {scalar, velocity, pressure0, pressure1}. */
+typedef struct fg_step_options {
+    int32_t corrector_steps;      /* 2 */
+    int32_t advect_scalar;        /* solve passive scalars first */
+    int32_t pressure_method;      /* FG_SOLVER_* */
+    int32_t max_iterations;       /* 5000 (PISOtorch_simulation.py:564) */
+    float advection_tol;          /* RMS residual, 1e-5 default (PISOtorch_diff.py:247-253) */
+    float pressure_tol;
+    int32_t buoyancy_axis;        /* -1 = none */
+    float buoyancy_factor;
+} fg_step_options;
+int fg_piso_step(fg_handle h, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
+                 void* stream);
+/* make_divergence_free (PISOtorch_simulation.py:1320-1429) */
+int fg_make_divergence_free(fg_handle h, float tol, int max_iterations, fg_solve_info* info_host,
+                            void* stream);
+
+/* ---- access to solver vectors (tests / fixtures) -------------------------------------------- */
+enum fg_buffer {
+    FG_BUF_A = 0,          /* Adiag [B,N]                               */
+    FG_BUF_C_OFF = 1,      /* C off-diagonals [B,2d,N] (face order)     */
+    FG_BUF_ADV_RHS = 2,    /* velocityRHS [B,d,N] / scalarRHS [B,N]     */
+    FG_BUF_VEL_RESULT = 3, /* velocityResult [B,d,N]                    */
+    FG_BUF_H = 4,          /* pressureRHS (h) [B,d,N]                   */
+    FG_BUF_DIV = 5,        /* pressureRHSdiv [B,N]                      */
+    FG_BUF_P_RESULT = 6,   /* pressureResult [B,N]                      */
+    FG_BUF_SCALAR_RESULT = 7 /* scalarResult [B,N] (one channel)        */
+};
+int fg_get_buffer(fg_handle h, int which, float** out_ptr, int64_t* out_count);
+/* device-to-device copy of a solver vector into a caller buffer of fg_get_buffer's count */
+int fg_read_buffer(fg_handle h, int which, float* dst, void* stream);
+
+/* ---- standalone pressure-Poisson kernels on caller arrays (micro-benchmark / tests) ----------
+ * Operator: (P x)_c = sum_f off_f (x_N - x_c), off_f = (alpha_P rA_P + alpha_N rA_N)/2, no entry at
+ * FIXED faces (PISO_multiblock_cuda_kernel.cu:4842-4889).  All arrays [B,N]. */
+int fg_poisson_apply(fg_handle h, const float* rA, const float* x, float* y, void* stream);
+/* n_sweeps damped-Jacobi / red-black Gauss-Seidel sweeps on P x = b (x updated in place; Jacobi
+ * uses the handle's scratch vector).  omega = relaxation factor. */
+int fg_poisson_jacobi(fg_handle h, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+                      void* stream);
+int fg_poisson_rbgs(fg_handle h, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+                    void* stream);
+/* n_iterations of CG without convergence polling (timing) -- or a full solve when tol > 0. */
+int fg_poisson_cg(fg_handle h, const float* rA, const float* b, float* x, float tol, int max_iterations,
+                  int use_x0, fg_solve_info* info_host, void* stream);
+
+/* ---- grid metrics --------------------------------------------------------------------------- */
+/* CoordsToTransforms (grid_gen.cu:298-390): vertex coords [d,(nz+1,)ny+1,nx+1] ->
+ * transforms [(nz,)ny,nx, 2 d^2 + 1] = M | Minv | det per cell. */
+int fg_coords_to_transforms(const float* coords, float* transforms, int dims, int nx, int ny, int nz,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDGYM_HIP_H */
