@@ -1,0 +1,218 @@
+"""Headline benchmark: batched env-steps/s of the PISO hot path + pressure-Poisson roofline.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): "2D cylinder Re=100, 256x128, batch=64 on one GPU", run on the
+single-block stand-in ``ChannelJet2D-v0`` (the reference has no Cartesian cylinder; mapping in
+SURVEY.md section 8d / fluidgym_amd/envs/channel.py).  One bench "step" = one ``env.step()`` of all
+envs = 25 PISO steps each (dt 0.01, step_length 0.25) with adaptive CFL, outflow BC update, actions,
+observations and reward.  Scaling is WEAK: every GPU carries 64 envs; actions are broadcast and
+observations gathered over RCCL by ``ParallelFluidEnv``.
+
+The JSON line also carries
+  * ``roofline``: CG kernel 1 (p-update + matrix-free P*p + dot) timed live with HIP events inside the
+    timed region (fg_profile_*), algorithmic bytes = 20 B/cell x cells per launch;
+  * ``poisson_256``: the 256^3 pressure-Poisson micro-benchmark (Jacobi sweep / CG kernels), the
+    north-star's ">= 60 % of HBM roofline" target (working set > 256 MiB Infinity Cache);
+  * ``cpu_baseline``: the NumPy/SciPy oracle (a port, not reference code: the reference has no CPU
+    path) stepping ONE env of the same workload on the host, single thread.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+ENVS_PER_GPU = 64
+ENV_ID = "ChannelJet2D-v0"
+
+
+def poisson_micro(device, n=256, iters=20):
+    """256^3 matrix-free Poisson kernels, B=1, periodic x/z + walls y, wall-refined y."""
+    import numpy as np
+    import torch
+
+    from fluidgym_amd.native import NativeSolver
+    from fluidgym_amd.simulation import grids
+
+    hx = np.full(n, 1.0 / n, np.float32)
+    hy = np.diff(grids.weights_exp(n, 1.02, "BOTH")).astype(np.float32)
+    ns = NativeSolver([hx, hy, hx.copy()], 1, fixed_faces=(2, 3), device=device, allocate=False)
+    g = torch.Generator(device=device).manual_seed(0)
+    shape = (1, n, n, n)
+    rA = 1.0 / (100.0 * (1.0 + 0.1 * torch.rand(shape, device=device, generator=g)))
+    b = torch.randn(shape, device=device, generator=g)
+    b -= b.mean()
+    x = torch.zeros(shape, device=device)
+    cells = float(n) ** 3
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) / reps
+
+    ms = timed(lambda: ns.poisson_jacobi(rA, b, x, iters, 0.8), 3) / iters
+    out["jacobi_sweep"] = {"ms": ms, "bytes_per_cell": 16, "GBps": 16 * cells / ms / 1e6,
+                           "frac": 16 * cells / ms / 1e6 / HBM_PEAK_GBS}
+    y = torch.empty_like(x)
+    ms = timed(lambda: ns.poisson_apply(rA, b, y), 10)
+    out["apply"] = {"ms": ms, "bytes_per_cell": 12, "GBps": 12 * cells / ms / 1e6, "frac": 12 * cells / ms / 1e6 / HBM_PEAK_GBS}
+    x.zero_()
+    ms = timed(lambda: ns.poisson_cg(rA, b, x, tol=0.0, max_iterations=iters), 3) / iters
+    out["cg_iteration"] = {"ms": ms, "bytes_per_cell": 44, "GBps": 44 * cells / ms / 1e6,
+                           "frac": 44 * cells / ms / 1e6 / HBM_PEAK_GBS}
+    ns.close()
+    return out
+
+
+def cpu_baseline(budget_s=20.0):
+    """Oracle (NumPy/SciPy port of the reference algorithm) on one env of the bench workload."""
+    import numpy as np
+
+    from fluidgym_amd.envs.channel import CHANNEL_JET_2D_DEFAULT_CONFIG as CFG, inflow_profile
+    from oracle import piso_oracle as O
+
+    nx, ny, L, H = CFG["resolution_x"], CFG["resolution_y"], 22.0, 4.1
+    g = O.Grid(O.rectilinear_coords([np.linspace(0, L, nx + 1), np.linspace(-H / 2, H / 2, ny + 1)]))
+    prof = inflow_profile(H, ny)
+    u = np.zeros((2, ny, nx))
+    u[0] = prof[:, None]
+    rng = np.random.default_rng(0)
+    u += 0.05 * rng.standard_normal(u.shape)
+    inflow = np.zeros((2, ny, 1))
+    inflow[0, :, 0] = prof
+    bc = {0: O.FixedBC(inflow.copy()), 1: O.FixedBC(inflow.copy()), 2: O.FixedBC(np.zeros(2)), 3: O.FixedBC(np.zeros(2))}
+    dom = O.Domain(g, 1.0 / CFG["reynolds_number"], u, np.zeros((ny, nx)), bc)
+    opts = O.SolverOptions(direct=False, pressure_tol=1e-5, advection_tol=1e-5, pressure_return_best_result=True)
+    O.make_divergence_free(dom, O.SolverOptions(direct=False, pressure_tol=1e-5))
+    velm = np.array([1.0, 0.0])
+    n_sim = max(1, int(CFG["step_length"] / CFG["dt"]))
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        O.update_advective_boundaries(dom, [1], velm, CFG["dt"], tol=1e-5)
+        O.piso_split_step(dom, CFG["dt"], opts)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / n_sim / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"1 env of the {nx}x{ny} channel, {steps} PISO steps ({steps / n_sim:.2f} env steps) in {dt:.1f} s, "
+                      "NumPy/SciPy oracle with the reference's CG/BiCGStab recurrences, fp64"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--env-id", default=ENV_ID)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-micro", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import fluidgym_amd  # noqa: F401
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    n_total = args.envs_per_gpu * world
+    penv = ParallelFluidEnv(args.env_id, num_envs=n_total)
+    env = penv.local_env
+    penv.reset(seed=1234, randomize=True)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    a_shape = (n_total,) + tuple(env.action_space.shape)
+
+    def actions():
+        return (torch.rand(a_shape, generator=gen) * 2 - 1).to(device) if penv.is_driver else None
+
+    for _ in range(args.warmup):
+        penv.step(actions())
+    solver = env._domain.solver
+    solver.profile_enable(True)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        penv.step(actions())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_sum, samples = solver.profile_read()
+    solver.profile_enable(False)
+    stats = list(env._sim.last_stats)
+
+    if rank == 0:
+        cells = float(solver.B * solver.n)
+        roof = None
+        if samples[0] > 0:
+            ms_ap = ms_sum[0] / samples[0]
+            ach = 20.0 * cells / ms_ap / 1e6  # GB/s: r, p_in, rA read + p_out, Ap written = 20 B/cell
+            roof = {"bound": "hbm", "kernel": "k_cg_ap", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms_ap, "samples": samples[0],
+                    "bytes_per_launch": 20.0 * cells,
+                    "k_cg_update_avg_launch_ms": (ms_sum[1] / samples[1]) if samples[1] else None,
+                    "note": "working set of this workload (B*N*4 B*~8 fields = 67 MB) is Infinity-Cache resident; "
+                            "see poisson_256 for the HBM-resident 256^3 case"}
+        out = {
+            "metric": "env-steps/sec (batched) + pressure-Poisson HBM GB/s vs roofline, 1/2/4/8 GPUs",
+            "value": n_total * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.env_id}: 2D channel stand-in for 'cylinder Re=100 256x128', "
+                                   f"{args.envs_per_gpu} envs/GPU, {env._n_sim_steps} PISO steps per env step",
+                       "global_batch": n_total, "grid": [solver.nx, solver.ny, solver.nz],
+                       "parallelism": f"env-sharded x{world} (RCCL bcast/all_gather of actions/obs only)",
+                       "solver_iterations_last_step": stats},
+            "roofline": roof,
+        }
+        if not args.no_micro:
+            out["poisson_256"] = poisson_micro(device)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    penv.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,72 @@
 
 Only what the hot path needs lives here: ``csrc/`` (HIP kernels + C ABI), ``_lib`` (ctypes
 binding), ``native`` (handle wrapper), ``simulation`` (PISO driver mirroring the reference's
-``Simulation``), ``envs`` (FluidEnv / ParallelFluidEnv surface).  Importing the package never
-touches the GPU; the shared library is loaded on first use and its absence is an error.
+``Simulation``), ``envs`` (FluidEnv / ParallelFluidEnv surface) and the registry
+(``fluidgym.make``-compatible).  Importing the package never touches the GPU; the shared library is
+loaded on first use and its absence is an error (there is no CPU / PyTorch fallback).
+
+Registered ids: the reference registers 39 ids (``fluidgym/__init__.py:28-352``).  The RBC and TCF
+families (single block, orthogonal) are registered under the reference's ids with the reference's
+defaults; the cylinder / airfoil families need multi-block curvilinear meshes and
+raise ``NotImplementedError`` pointing at the single-block stand-in ``ChannelJet2D-*``.
 """
+from __future__ import annotations
+
+import numpy as np
+
+from .registry import make, register, registry  # noqa: F401
+
 __version__ = "0.1.0"
+
+
+def _lazy(module: str, cls: str):
+    def ctor(**kw):
+        import importlib
+
+        return getattr(importlib.import_module(module, __name__), cls)(**kw)
+
+    return ctor
+
+
+def _not_built(family: str):
+    def ctor(**kw):
+        raise NotImplementedError(
+            f"{family} envs use multi-block body-fitted curvilinear meshes (reference envs/{family.lower()}/grid.py); "
+            "the HIP path covers single-block rectilinear grids this round. Use 'ChannelJet2D-v0' "
+            "(same boundary-condition set on one block) -- see SURVEY.md section 8f-3."
+        )
+
+    return ctor
+
+
+def _register_all():
+    from .envs.channel import CHANNEL_JET_2D_DEFAULT_CONFIG as CH
+    from .envs.rbc import RBC_2D_DEFAULT_CONFIG as R2, RBC_3D_DEFAULT_CONFIG as R3
+    from .envs.tcf import LARGE_TCF_3D_DEFAULT_CONFIG as TL, SMALL_TCF_3D_DEFAULT_CONFIG as TS
+
+    ch = _lazy(".envs.channel", "ChannelJetEnv2D")
+    register("ChannelJet2D-v0", ch, CH)                                         # BASELINE config 2 stand-in
+    register("ChannelJet2D-gate-v0", ch, CH, resolution_x=128, resolution_y=64)  # BASELINE config 1
+    register("ChannelJet2D-large-v0", ch, CH, resolution_x=512, resolution_y=256)  # BASELINE config 5
+    r2, r3 = _lazy(".envs.rbc", "RBCEnv2D"), _lazy(".envs.rbc", "RBCEnv3D")
+    # reference ids (fluidgym/__init__.py): easy/medium/hard = Ra 8e4 / 4e5 / 8e5, CFL 0.8 / 0.5 / 0.5
+    register("RBC2D-easy-v0", r2, R2)
+    register("RBC2D-medium-v0", r2, R2, rayleigh_number=4e5, adaptive_cfl=0.5)
+    register("RBC2D-hard-v0", r2, R2, rayleigh_number=8e5, adaptive_cfl=0.5)
+    register("RBC2D-wide-easy-v0", r2, R2, n_heaters=24, aspect_ratio=2.0)
+    register("RBC2D-baseline-v0", r2, R2, n_heaters=64, resolution=8, aspect_ratio=2.55)  # 512x128 (BASELINE config 3)
+    register("RBC3D-easy-v0", r3, R3)
+    t = _lazy(".envs.tcf", "TCF3DBottomEnv")
+    register("TCFSmall3D-both-easy-v0", t, TS)
+    register("TCFLarge3D-both-easy-v0", t, TL)
+    register("TCF3D-baseline-v0", t, TS, resolution_x=128, resolution_z=64, resolution_y=64, L=2 * np.pi, D=np.pi)
+    for fam, ids in {
+        "Cylinder": ["CylinderJet2D-easy-v0", "CylinderJet2D-medium-v0", "CylinderJet2D-hard-v0",
+                     "CylinderRot2D-easy-v0", "CylinderJet3D-easy-v0"],
+        "Airfoil": ["Airfoil2D-easy-v0", "Airfoil2D-medium-v0", "Airfoil2D-hard-v0", "Airfoil3D-easy-v0"],
+    }.items():
+        for i in ids:
+            register(i, _not_built(fam), {})
+
+
+_register_all()

@@ -96,6 +96,8 @@ SIGNATURES = {
     "fg_poisson_rbgs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "fg_poisson_cg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
                               c_void_p]),
+    "fg_profile_enable": (c_int, [c_void_p, c_int]),
+    "fg_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
     "fg_coords_to_transforms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

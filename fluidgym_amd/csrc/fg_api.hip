@@ -109,7 +109,21 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipHostMalloc(&s->info_pinned, sizeof(fg_solve_info) * nsys));
     FG_HIP_CHECK(hipHostMalloc(&s->flags_pinned, sizeof(int32_t) * nsys));
     FG_HIP_CHECK(alloc(&s->scratch_B, (size_t)g.B * (4 + 2 * d)));
+    for (int i = 0; i < 4; ++i) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[i]));
     *out = s;
+    return FG_OK;
+}
+
+extern "C" int fg_profile_enable(fg_handle s, int on) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    s->prof_on = on;
+    s->prof_ms[0] = s->prof_ms[1] = 0.0;
+    s->prof_n[0] = s->prof_n[1] = 0;
+    return FG_OK;
+}
+extern "C" int fg_profile_read(fg_handle s, double* ms, int64_t* n) {
+    FG_REQUIRE(s && ms && n, FG_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < 2; ++i) { ms[i] = s->prof_ms[i]; n[i] = s->prof_n[i]; s->prof_ms[i] = 0.0; s->prof_n[i] = 0; }
     return FG_OK;
 }
 
@@ -122,6 +136,7 @@ extern "C" int fg_destroy(fg_handle s) {
     for (int i = 0; i < 7; ++i) (void)hipFree(s->w[i]);
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(s->prof_ev[i]);
     delete s;
     return FG_OK;
 }
@@ -165,6 +180,7 @@ extern "C" int fg_setup_advection(fg_handle s, const float* dt_B, int for_scalar
     FG_REQUIRE(s && dt_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, for_scalar != 0)) return rc;
     FG_REQUIRE(!for_scalar || (channel >= 0 && channel < s->cfg.n_scalars), FG_ERR_INVALID_ARG, "bad scalar channel");
+    s->cur_dt = dt_B;
     FgAdvArgs a;
     memset(&a, 0, sizeof(a));
     a.vel = s->velocity;
@@ -190,7 +206,7 @@ extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, floa
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     FgBicgArgs a;
     a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs;
-    a.dt = nullptr;
+    a.dt = s->cur_dt;
     a.tol = tol; a.max_iterations = max_iterations;
     if (for_scalar) { a.x = s->scal_result; a.nc = 1; a.use_x0 = 0; }
     else { a.x = s->vel_result; a.nc = s->grid.dims; a.use_x0 = 1; }
@@ -201,7 +217,8 @@ extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, floa
 extern "C" int fg_copy_scalar_result_to_blocks(fg_handle s, int channel, void* stream) {
     FG_REQUIRE(s && s->scalar, FG_ERR_NOT_BOUND, "scalar not bound");
     const int n = s->grid.n;
-    // strided destination: channel `channel` of [B,C,N]
+    if (s->cfg.n_scalars == 1) return fg_launch_copy_active(s, s->cur_dt, s->scal_result, s->scalar, 1, (hipStream_t)stream);
+    // strided destination: channel `channel` of [B,C,N] (all envs)
     FG_HIP_CHECK(hipMemcpy2DAsync(s->scalar + (size_t)channel * n, sizeof(float) * n * s->cfg.n_scalars, s->scal_result,
                                   sizeof(float) * n, sizeof(float) * n, s->grid.B, hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
@@ -210,7 +227,7 @@ extern "C" int fg_copy_scalar_result_to_blocks(fg_handle s, int channel, void* s
 
 extern "C" int fg_setup_pressure_matrix(fg_handle s, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
-    return fg_launch_pressure_setup(s, nullptr, (hipStream_t)stream);
+    return fg_launch_pressure_setup(s, s->cur_dt, (hipStream_t)stream);
 }
 
 extern "C" int fg_setup_pressure_rhs(fg_handle s, const float* dt_B, void* stream) {
@@ -246,18 +263,18 @@ extern "C" int fg_solve_pressure(fg_handle s, int method, float tol, int max_ite
                                  fg_solve_info* info_host, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (int rc = check_bound(s, false)) return rc;
-    return solve_pressure(s, nullptr, method, tol, max_iterations, use_previous, info_host, (hipStream_t)stream);
+    return solve_pressure(s, s->cur_dt, method, tol, max_iterations, use_previous, info_host, (hipStream_t)stream);
 }
 
 extern "C" int fg_correct_velocity(fg_handle s, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (int rc = check_bound(s, false)) return rc;
-    return fg_launch_correct(s, nullptr, s->rA, s->hvec, s->pressure, s->vel_result, (hipStream_t)stream);
+    return fg_launch_correct(s, s->cur_dt, s->rA, s->hvec, s->pressure, s->vel_result, (hipStream_t)stream);
 }
 
 extern "C" int fg_copy_velocity_result_to_blocks(fg_handle s, void* stream) {
     FG_REQUIRE(s && s->velocity, FG_ERR_NOT_BOUND, "velocity not bound");
-    return fg_launch_copy_active(s, nullptr, s->vel_result, s->velocity, s->grid.dims, (hipStream_t)stream);
+    return fg_launch_copy_active(s, s->cur_dt, s->vel_result, s->velocity, s->grid.dims, (hipStream_t)stream);
 }
 extern "C" int fg_copy_velocity_result_from_blocks(fg_handle s, void* stream) {
     FG_REQUIRE(s && s->velocity, FG_ERR_NOT_BOUND, "velocity not bound");
@@ -348,6 +365,7 @@ extern "C" int fg_make_divergence_free(fg_handle s, float tol, int max_iteration
     // make_divergence_free (PISOtorch_simulation.py:1320-1429): A := 1, dt := 1, h := u
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (int rc = check_bound(s, false)) return rc;
+    s->cur_dt = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const size_t BN = (size_t)s->grid.B * s->grid.n;
     std::vector<float> ones(BN, 1.f);

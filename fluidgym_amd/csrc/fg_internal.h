@@ -308,7 +308,13 @@ struct fg_state {
     fg_solve_info* info_dev;   // [B*d]
     fg_solve_info* info_pinned;// [B*d] host-pinned mirror
     int32_t* flags_pinned;
-    float* scratch_B;  // [B*4] small per-env floats
+    float* scratch_B;  // [B*(4+2d)] small per-env floats
+    // live kernel timing (bench.py roofline): one sampled launch of each CG kernel per solve
+    int prof_on;
+    hipEvent_t prof_ev[4];
+    double prof_ms[2];
+    long long prof_n[2];
+    const float* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     size_t n_cells() const { return (size_t)grid.n; }
 };
 

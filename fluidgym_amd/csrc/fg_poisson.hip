@@ -343,7 +343,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                            s->acc, s->flags, a.use_x0, 0, L.tiles_x, L.tiles_y, L.tiles);
     });
     const int check_every = a.check_every > 0 ? a.check_every : 16;
-    bool done = false;
+    bool done = false, sampled = false;
     int it = 0;
     for (; it < a.max_iterations && !done; ++it) {
         int first = (it == 0);
@@ -360,13 +360,18 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         // p double buffer: read p_{it-1} from pbuf[(it+1)&1], write p_it to pbuf[it&1]
         const float* p_in = pbuf[(it + 1) & 1];
         float* p_out = pbuf[it & 1];
+        const bool sample = s->prof_on && it == 1;
         FG_DISPATCH(s, {
             const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+            if (sample) (void)hipEventRecord(s->prof_ev[0], st);
             hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.r, p_in, p_out,
                                a.Ap, s->acc, s->flags, s->info_dev, a.tol, it, first, L.tiles_x, L.tiles_y, L.tiles);
+            if (sample) { (void)hipEventRecord(s->prof_ev[1], st); (void)hipEventRecord(s->prof_ev[2], st); }
             hipLaunchKernelGGL((k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x, a.r,
                                s->acc, s->flags, a.tol, it, L.tiles_x, L.tiles_y, L.tiles);
+            if (sample) (void)hipEventRecord(s->prof_ev[3], st);
         });
+        sampled = sampled || sample;
         if ((it + 1) % check_every == 0 || it + 1 == a.max_iterations) {
             const int final_pass = (it + 1 == a.max_iterations);
             hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->acc, s->flags, s->info_dev, a.tol, it, n, B, final_pass);
@@ -378,6 +383,11 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     }
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
+    if (sampled) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->prof_ev[0], s->prof_ev[1]) == hipSuccess) { s->prof_ms[0] += ms; s->prof_n[0]++; }
+        if (hipEventElapsedTime(&ms, s->prof_ev[2], s->prof_ev[3]) == hipSuccess) { s->prof_ms[1] += ms; s->prof_n[1]++; }
+    }
     int rc = FG_OK;
     for (int b = 0; b < B; ++b) {
         if (info_host) info_host[b] = s->info_pinned[b];

@@ -1,0 +1,278 @@
+"""Rayleigh-Benard convection envs (2-D / 3-D), batched.
+
+Follows ``envs/rbc/rbc_env_base.py`` and ``envs/rbc/rbc_env_2d.py`` / ``rbc_env_3d.py`` of the
+reference:
+
+* grid: wall-refined orthogonal, ``x = resolution * n_heaters``, ``y = round(2 x / (aspect pi))``,
+  ``L = H aspect pi`` with ``H = 1``, base 1.02 (``rbc_env_base.py:114-117, 176-198``); periodic in x
+  (and z), FIXED plates at ``+-y`` with Dirichlet temperature ``T_hot = 1`` / ``T_cold = 0``;
+* ``nu = sqrt(Pr/Ra)``, ``kappa = 1/sqrt(Ra Pr)`` (``:181-186``); temperature is passive scalar 0 and
+  acts back through the Boussinesq source ``S = [0, T, (0)]`` set in the ``PRE_VELOCITY_SETUP`` hook
+  (``:285-297``) -- here the fused native form (``fg_step_options.buoyancy_*``);
+* solver settings ``:301-325`` (adaptive CFL, 2 correctors, pressure tol 1e-5, best-result);
+* initial state: linear conduction profile + 0.1 N(0,1) clamped to [T_cold, T_hot], velocity
+  0.05 N(0,1) (``:216-267``); randomisation = flip / roll / noise / 1-2 time units of simulation
+  (``:335-398``);
+* action -> bottom-plate temperature: zero-mean shift, ``T / max(|T|,1) * heater_limit`` limiter
+  and cubic blending between heaters (``rbc_env_2d.py:196-276``);
+* reward ``nu_ref - Nu`` with ``Nu = 1 + sqrt(Ra Pr) <u_y T>_V`` (``rbc_env_base.py:491-513, 579-595``).
+
+Deviation ("next" row): observations are read at the sensor lattice by nearest-cell
+lookup on the simulation grid instead of going through the reference's scatter-resampling to the
+render grid (``resampling.cu:297-609``) first.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import numpy as np
+import torch
+
+from .. import spaces
+from ..simulation import grids
+from ..simulation.domain import Domain
+from ..simulation.simulation import Simulation
+from .fluid_env import FluidEnv
+
+RBC_2D_DEFAULT_CONFIG = {
+    "rayleigh_number": 8e4,
+    "prandtl_number": 0.7,
+    "n_heaters": 12,
+    "resolution": 8,
+    "dt": 0.05,
+    "adaptive_cfl": 0.8,
+    "step_length": 1.0,
+    "episode_length": 200,
+    "local_obs_window": 11,
+    "local_reward_weight": 0.2,
+    "uniform_grid": False,
+    "aspect_ratio": 1.0,
+    "use_marl": False,
+    "dtype": torch.float32,
+    "load_initial_domain": False,
+    "load_domain_statistics": False,
+    "randomize_initial_state": True,
+    "enable_actions": True,
+    "differentiable": False,
+}
+
+RBC_3D_DEFAULT_CONFIG = {
+    **RBC_2D_DEFAULT_CONFIG,
+    "rayleigh_number": 2.5e3,
+    "n_heaters": 8,
+    "resolution": 4,
+    "adaptive_cfl": 0.5,
+    "dt": 0.05,
+}
+
+
+class RBCEnvBase(FluidEnv):
+    _supports_marl = False  # MARL windows (obs_extraction.py) are a "next" item
+    _resolution_scale_y: float = 2.0
+    _non_uniform_grid_base = 1.02
+    _H: float = 1.0
+    _T_hot: float = 1.0
+    _T_cold: float = 0.0
+    _heater_limit: float = 0.75
+    _buoyancy_factor: float = 1.0
+    _n_sensors_per_heater: int = 4
+    _n_sensors_y: int = 8
+    _metrics = ["nusselt"]
+
+    def __init__(self, rayleigh_number, prandtl_number, n_heaters, resolution, dt, adaptive_cfl, step_length,
+                 episode_length, ndims, local_obs_window=11, local_reward_weight=None, uniform_grid=False,
+                 aspect_ratio=1.0, **kw):
+        self._rayleigh_number = rayleigh_number
+        self._prandtl_number = prandtl_number
+        self._heater_width = int(resolution)
+        self._n_heaters = int(n_heaters)
+        self._uniform_grid = uniform_grid
+        self._aspect_ratio = aspect_ratio * np.pi
+        self._x = int(resolution * n_heaters)
+        self._y = round(self._resolution_scale_y * self._x / self._aspect_ratio)
+        self._L = self._H * self._aspect_ratio
+        self._nu = float((prandtl_number / rayleigh_number) ** 0.5)
+        self._kappa = float((rayleigh_number * prandtl_number) ** -0.5)
+        super().__init__(dt=dt, adaptive_cfl=adaptive_cfl, step_length=step_length, episode_length=episode_length,
+                         ndims=ndims, **kw)
+
+    # ---- spaces ---------------------------------------------------------------------------
+    @property
+    def _n_sensors_x(self) -> int:
+        return self._n_heaters * self._n_sensors_per_heater
+
+    def _get_action_space(self):
+        shape = (self._n_heaters,) if self._ndims == 2 else (self._n_heaters, self._n_heaters)
+        return spaces.Box(low=-1.0, high=1.0, shape=shape, dtype=np.float32)
+
+    def _get_observation_space(self):
+        if self._ndims == 2:
+            shape = (self._n_sensors_y, self._n_sensors_x)
+        else:
+            shape = (self._n_sensors_x, self._n_sensors_y, self._n_sensors_x)
+        return spaces.Dict({
+            "temperature": spaces.Box(low=self._T_cold, high=self._T_hot + self._heater_limit, shape=shape, dtype=np.float32),
+            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(self._ndims,) + shape, dtype=np.float32),
+            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=shape, dtype=np.float32),
+        })
+
+    # ---- domain ---------------------------------------------------------------------------
+    def _edges(self):
+        base = 1.0 if self._uniform_grid else self._non_uniform_grid_base
+        e = grids.wall_refined_edges(self._x, self._y, (0, -self._H / 2), (self._L, self._H / 2), ["-y", "+y"], base)
+        if self._ndims == 3:
+            e.append(grids.lerp_edges(0.0, self._L, grids.weights_linear(self._x)))
+        return e
+
+    def _get_domain(self) -> Domain:
+        coords = grids.vertex_grid(self._edges())
+        dom = Domain(self._ndims, torch.tensor([self._nu]), passiveScalarChannels=1, name="RBCDomain",
+                     device=self._cuda_device, dtype=self._dtype, batch=self._num_envs)
+        dom.setScalarViscosity(torch.tensor([self._kappa]))
+        blk = dom.CreateBlock(vertexCoordinates=coords, name="RBCBlock")
+        blk.CloseBoundary("-y")
+        blk.CloseBoundary("+y")
+        dom.PrepareSolve()
+        blk.getBoundary("-y").setPassiveScalar(torch.tensor([[self._T_hot]]))
+        blk.getBoundary("+y").setPassiveScalar(torch.tensor([[self._T_cold]]))
+        blk.setVelocitySource(torch.zeros(1, self._ndims, *dom.solver.spatial))
+        return dom
+
+    def _get_simulation(self, domain: Domain, prep_fn: Dict[str, Any]) -> Simulation:
+        return Simulation(
+            domain=domain, prep_fn=prep_fn, substeps="ADAPTIVE", adaptive_CFL=self._adaptive_cfl, dt=self._dt,
+            corrector_steps=2, pressure_tol=1e-5, advect_non_ortho_steps=1, pressure_non_ortho_steps=1,
+            pressure_return_best_result=True, velocity_corrector="FD", non_orthogonal=False,
+            buoyancy=(1, self._buoyancy_factor),  # native PRE_VELOCITY_SETUP hook (rbc_env_base.py:285-297)
+        )
+
+    def _additional_initialization(self) -> None:
+        self._block = self._domain.getBlock(0)
+        self._bottom_plate = self._block.getBoundary("-y")
+        self._top_plate = self._block.getBoundary("+y")
+        dev = self._cuda_device
+        self._cell_size = self._block.getCellSizes()[0, 0]  # [(Z,)Y,X]
+        # sensor lattice (cell-centred), nearest-cell lookup
+        ix = ((np.arange(self._n_sensors_x) + 0.5) * self._x / self._n_sensors_x).astype(np.int64)
+        ycen = 0.5 * (self._block.edges[1][1:] + self._block.edges[1][:-1])
+        ytar = -self._H / 2 + (np.arange(self._n_sensors_y) + 0.5) * self._H / self._n_sensors_y
+        iy = np.abs(ycen[None, :] - ytar[:, None]).argmin(axis=1)
+        if self._ndims == 2:
+            flat = iy[:, None] * self._x + ix[None, :]  # [sy, sx]
+        else:
+            flat = (ix[:, None, None] * self._y + iy[None, :, None]) * self._x + ix[None, None, :]  # [sz, sy, sx]
+        self._sensor_shape = flat.shape
+        self._sensor_idx = torch.from_numpy(flat.reshape(-1)).to(dev)
+        seg = torch.arange(self._x, device=dev)
+        self._seg_id = seg // self._heater_width
+        self._x_pos = seg % self._heater_width
+
+    def _fill_initial_fields(self) -> None:
+        dev, B = self._cuda_device, self._num_envs
+        grad = torch.linspace(self._T_hot, self._T_cold, steps=self._y, device=dev)
+        shape = [1] * (self._ndims + 2)
+        shape[-2] = self._y
+        T = grad.view(shape).expand(B, 1, *self._domain.solver.spatial).clone()
+        T += torch.randn(T.shape, device=dev, generator=self._torch_rng_cuda) * 0.1 * (self._T_hot - self._T_cold)
+        T.clamp_(self._T_cold, self._T_hot)
+        self._block.setPassiveScalar(T)
+        u = torch.randn(self._block.velocity.shape, device=dev, generator=self._torch_rng_cuda) * 0.05
+        self._block.setVelocity(u)
+        self._block.pressure.zero_()
+        self._domain.solver.copy_velocity_result_from_blocks()
+
+    def _randomize_domain(self) -> None:
+        """rbc_env_base.py:335-398 (flip, roll, noise, 1..2 time units of simulation), per batch."""
+        T, u = self._block.passiveScalar, self._block.velocity
+        if self._np_rng.uniform(0.0, 1.0) > 0.5:
+            T.copy_(torch.flip(T, dims=[-1]))
+            u.copy_(torch.flip(u, dims=[-1]))
+            u[:, 0] *= -1.0
+        shift = int(self._np_rng.integers(0, self._x))
+        T.copy_(torch.roll(T, shifts=shift, dims=-1))
+        u.copy_(torch.roll(u, shifts=shift, dims=-1))
+        T.add_(torch.randn(T.shape, device=T.device, generator=self._torch_rng_cuda) * 0.05).clamp_(self._T_cold, self._T_hot)
+        u.add_(torch.randn(u.shape, device=u.device, generator=self._torch_rng_cuda) * 0.05)
+        sim_time = self._np_rng.uniform(1.0, 2.0)
+        for _ in range(int(sim_time / self._dt)):
+            self._sim.single_step()
+
+    # ---- control --------------------------------------------------------------------------
+    def _smooth_profile(self, T_action: torch.Tensor) -> torch.Tensor:
+        """Cubic blending between neighbouring heaters over 10 % of the heater width
+        (rbc_env_2d.py:196-237); ``T_action``: ``[B, n_heaters]`` -> ``[B, x]``."""
+        hw = self._heater_width
+        bw = round(hw * 0.1)
+        T1 = T_action[:, self._seg_id]
+        if bw == 0:
+            return T1
+        T0 = torch.roll(T_action, 1, dims=1)[:, self._seg_id]
+        T2 = torch.roll(T_action, -1, dims=1)[:, self._seg_id]
+        tL = (self._x_pos.float() / bw + 0.5).clamp(0.0, 1.0)
+        tR = 1 - torch.roll(tL, shifts=hw - bw + 1, dims=0)
+        blend = lambda t, A, Bv: (1 - t * t * (3 - 2 * t)) * A + (t * t * (3 - 2 * t)) * Bv
+        left = self._x_pos < bw
+        right = self._x_pos >= hw - bw
+        return torch.where(left, blend(tL, T0, T1), torch.where(right, blend(tR, T1, T2), T1))
+
+    def _action_to_control(self, action: torch.Tensor) -> torch.Tensor:
+        a = action.reshape(self._num_envs, -1)
+        shifted = a - a.mean(dim=1, keepdim=True)  # eq. (8) of Vignon et al. 2023
+        T = shifted / (torch.clamp(shifted.abs(), min=1.0) / self._heater_limit) + self._T_hot  # eq. (9)
+        return T
+
+    def _apply_action(self, action: torch.Tensor) -> None:
+        T = self._action_to_control(action)
+        if self._ndims == 2:
+            control = self._smooth_profile(T).view(self._num_envs, 1, 1, self._x)
+        else:
+            Th = T.view(self._num_envs, self._n_heaters, self._n_heaters)
+            control = Th[:, self._seg_id][:, :, self._seg_id].view(self._num_envs, 1, self._x, 1, self._x)
+        self._bottom_plate.setPassiveScalar(control)
+
+    # ---- observation / reward -------------------------------------------------------------
+    def _get_global_obs(self):
+        B = self._num_envs
+        sel = lambda t, c: t.reshape(B, c, -1).index_select(2, self._sensor_idx).reshape(B, c, *self._sensor_shape)
+        return {
+            "temperature": sel(self._block.passiveScalar, 1)[:, 0],
+            "velocity": sel(self._block.velocity, self._ndims),
+            "pressure": sel(self._block.pressure, 1)[:, 0],
+        }
+
+    def compute_global_nusselt(self) -> torch.Tensor:
+        """``Nu = 1 + sqrt(Ra Pr) * <u_y T>_V`` (rbc_env_base.py:491-536), per env ``[B]``."""
+        T = self._block.passiveScalar[:, 0]
+        uy = self._block.velocity[:, 1]
+        dims = tuple(range(1, self._ndims + 1))
+        mean = (uy * T * self._cell_size).sum(dim=dims) / self._cell_size.sum()
+        return 1.0 + float(np.sqrt(self._rayleigh_number * self._prandtl_number)) * mean
+
+    @property
+    def nu_ref(self) -> float:
+        return float(self._metrics_stats.get("nusselt", 0.0))
+
+    def _step_impl(self, action: torch.Tensor):
+        if self._enable_actions:
+            self._apply_action(action)
+        for _ in range(self._n_sim_steps):
+            if not self._sim.single_step():
+                raise RuntimeError("simulation step failed")
+        nu = self.compute_global_nusselt()
+        obs = self._get_global_obs()
+        return obs, self.nu_ref - nu, False, {"nusselt": nu}
+
+    @property
+    def id(self) -> str:
+        return (f"RBC{self._ndims}d_Ra{self._rayleigh_number}_Pr{self._prandtl_number}"
+                f"_NH{self._n_heaters}_HW{self._heater_width}")
+
+
+class RBCEnv2D(RBCEnvBase):
+    def __init__(self, **kw):
+        super().__init__(ndims=2, **kw)
+
+
+class RBCEnv3D(RBCEnvBase):
+    def __init__(self, **kw):
+        super().__init__(ndims=3, **kw)

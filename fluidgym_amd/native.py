@@ -249,6 +249,16 @@ class NativeSolver:
         L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
         return list(info)
 
+    def profile_enable(self, on: bool = True):
+        L.check(self.lib.fg_profile_enable(self.handle, int(on)))
+
+    def profile_read(self):
+        """(ms_sum[2], samples[2]) of the two CG kernels since the last read."""
+        ms = (ctypes.c_double * 2)()
+        n = (ctypes.c_int64 * 2)()
+        L.check(self.lib.fg_profile_read(self.handle, ms, n))
+        return [ms[0], ms[1]], [int(n[0]), int(n[1])]
+
     def close(self):
         if getattr(self, "handle", None):
             torch.cuda.synchronize(self.device)

@@ -1,0 +1,2 @@
+from .domain import Block, BoundaryConditionType, Domain, FixedBoundary  # noqa: F401
+from .simulation import Simulation, balance_boundary_fluxes, update_advective_boundaries  # noqa: F401

@@ -189,6 +189,13 @@ int fg_poisson_rbgs(fg_handle h, const float* rA, const float* b, float* x, int 
 int fg_poisson_cg(fg_handle h, const float* rA, const float* b, float* x, float tol, int max_iterations,
                   int use_x0, fg_solve_info* info_host, void* stream);
 
+/* ---- live kernel timing for bench.py's roofline -----------------------------------------------
+ * When enabled, every CG solve brackets ONE launch of each of its two kernels (iteration 1) with HIP
+ * events on the solve's stream; fg_profile_read returns accumulated milliseconds and sample counts
+ * for {0: CG kernel 1 (p update + P p + dot), 1: CG kernel 2 (x, r update + dot)} and resets them. */
+int fg_profile_enable(fg_handle h, int on);
+int fg_profile_read(fg_handle h, double* ms_sum_2, int64_t* samples_2);
+
 /* ---- grid metrics --------------------------------------------------------------------------- */
 /* CoordsToTransforms (grid_gen.cu:298-390): vertex coords [d,(nz+1,)ny+1,nx+1] ->
  * transforms [(nz,)ny,nx, 2 d^2 + 1] = M | Minv | det per cell. */
