@@ -64,6 +64,7 @@ class FgStepOptions(Structure):
         ("pressure_tol", c_float),
         ("buoyancy_axis", c_int32),
         ("buoyancy_factor", c_float),
+        ("pressure_warm_start", c_int32),
     ]
 
 
@@ -89,6 +90,7 @@ SIGNATURES = {
     "fg_copy_velocity_result_from_blocks": (c_int, [c_void_p, c_void_p]),
     "fg_piso_step": (c_int, [c_void_p, c_void_p, POINTER(FgStepOptions), POINTER(c_int32), c_void_p]),
     "fg_make_divergence_free": (c_int, [c_void_p, c_float, c_int, POINTER(FgSolveInfo), c_void_p]),
+    "fg_reset_solver_state": (c_int, [c_void_p, c_void_p]),
     "fg_get_buffer": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),
     "fg_read_buffer": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "fg_poisson_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -97,7 +99,8 @@ SIGNATURES = {
     "fg_poisson_cg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
                               c_void_p]),
     "fg_profile_enable": (c_int, [c_void_p, c_int]),
-    "fg_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
+    "fg_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), POINTER(ctypes.c_double),
+                                POINTER(ctypes.c_double), POINTER(c_int64)]),
     "fg_coords_to_transforms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

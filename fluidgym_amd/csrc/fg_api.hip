@@ -109,7 +109,11 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipHostMalloc(&s->info_pinned, sizeof(fg_solve_info) * nsys));
     FG_HIP_CHECK(hipHostMalloc(&s->flags_pinned, sizeof(int32_t) * nsys));
     FG_HIP_CHECK(alloc(&s->scratch_B, (size_t)g.B * (4 + 2 * d)));
-    for (int i = 0; i < 4; ++i) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[i]));
+    for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[i]));
+    FG_HIP_CHECK(hipMalloc(&s->prof_active, sizeof(int32_t) * FG_PROF_SAMPLES));
+    FG_HIP_CHECK(hipHostMalloc(&s->prof_active_pinned, sizeof(int32_t) * FG_PROF_SAMPLES));
+    FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 5 * 64));
+    FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 5 * 64));
     *out = s;
     return FG_OK;
 }
@@ -117,13 +121,16 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
 extern "C" int fg_profile_enable(fg_handle s, int on) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     s->prof_on = on;
-    s->prof_ms[0] = s->prof_ms[1] = 0.0;
-    s->prof_n[0] = s->prof_n[1] = 0;
+    for (int i = 0; i < 2; ++i) { s->prof_ms[i] = s->prof_cells[i] = s->prof_full_ms[i] = 0.0; s->prof_n[i] = s->prof_full_n[i] = 0; }
     return FG_OK;
 }
-extern "C" int fg_profile_read(fg_handle s, double* ms, int64_t* n) {
-    FG_REQUIRE(s && ms && n, FG_ERR_INVALID_ARG, "null argument");
-    for (int i = 0; i < 2; ++i) { ms[i] = s->prof_ms[i]; n[i] = s->prof_n[i]; s->prof_ms[i] = 0.0; s->prof_n[i] = 0; }
+extern "C" int fg_profile_read(fg_handle s, double* ms, int64_t* n, double* cells, double* full_ms, int64_t* full_n) {
+    FG_REQUIRE(s && ms && n && cells && full_ms && full_n, FG_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < 2; ++i) {
+        ms[i] = s->prof_ms[i]; n[i] = s->prof_n[i]; cells[i] = s->prof_cells[i];
+        full_ms[i] = s->prof_full_ms[i]; full_n[i] = s->prof_full_n[i];
+        s->prof_ms[i] = s->prof_cells[i] = s->prof_full_ms[i] = 0.0; s->prof_n[i] = s->prof_full_n[i] = 0;
+    }
     return FG_OK;
 }
 
@@ -136,7 +143,8 @@ extern "C" int fg_destroy(fg_handle s) {
     for (int i = 0; i < 7; ++i) (void)hipFree(s->w[i]);
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
-    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(s->prof_ev[i]);
+    for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) (void)hipEventDestroy(s->prof_ev[i]);
+    (void)hipFree(s->prof_active); (void)hipHostFree(s->prof_active_pinned); (void)hipFree(s->cg_acc);
     delete s;
     return FG_OK;
 }
@@ -348,7 +356,8 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
     for (int c = 0; c < opt->corrector_steps; ++c) {
         if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
         if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st)) return rc;
-        if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations, 0,
+        if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations,
+                                         opt->pressure_warm_start ? 1 : 0,
                                          info.data(), st)))
             return rc;
         if (c < 2) stats[2 + c] = max_iters(info.data(), B);
@@ -378,6 +387,12 @@ extern "C" int fg_make_divergence_free(fg_handle s, float tol, int max_iteration
     if (int rc2 = fg_launch_correct(s, nullptr, s->rA, s->hvec, s->pressure, s->vel_result, st)) return rc2;
     if (int rc2 = fg_launch_copy_active(s, nullptr, s->vel_result, s->velocity, s->grid.dims, st)) return rc2;
     return rc;
+}
+
+extern "C" int fg_reset_solver_state(fg_handle s, void* stream) {
+    FG_REQUIRE(s && s->velocity, FG_ERR_NOT_BOUND, "velocity not bound");
+    FG_HIP_CHECK(hipMemsetAsync(s->p_result, 0, sizeof(float) * (size_t)s->grid.B * s->grid.n, (hipStream_t)stream));
+    return fg_launch_copy_active(s, nullptr, s->velocity, s->vel_result, s->grid.dims, (hipStream_t)stream);
 }
 
 extern "C" int fg_get_buffer(fg_handle s, int which, float** out_ptr, int64_t* out_count) {

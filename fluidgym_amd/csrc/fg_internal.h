@@ -273,6 +273,7 @@ __device__ __forceinline__ void fg_block_sum(float (&v)[NV], float* lds /* >= NV
 // ------------------------------------------------------------------------------------------------
 // host-side state
 // ------------------------------------------------------------------------------------------------
+#define FG_PROF_SAMPLES 16
 #define FG_ACC_DOUBLES 16  // reduction accumulators per linear system (see solver kernels)
 
 struct fg_state {
@@ -311,9 +312,15 @@ struct fg_state {
     float* scratch_B;  // [B*(4+2d)] small per-env floats
     // live kernel timing (bench.py roofline): one sampled launch of each CG kernel per solve
     int prof_on;
-    hipEvent_t prof_ev[4];
-    double prof_ms[2];
+    hipEvent_t prof_ev[4 * FG_PROF_SAMPLES];
+    int32_t* prof_active;         // device: active envs of each sampled launch
+    int32_t* prof_active_pinned;
+    double prof_ms[2];            // sum of sampled launch durations {k_cg_ap, k_cg_update}
     long long prof_n[2];
+    double prof_cells[2];         // sum over samples of cells actually processed (active envs * n)
+    double prof_full_ms[2];       // same, restricted to launches with every env active
+    long long prof_full_n[2];
+    double* cg_acc;               // [B][FG_CG_NAMES=5][FG_CG_SLOTS=64] slotted CG accumulators
     const float* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     size_t n_cells() const { return (size_t)grid.n; }
 };

@@ -106,23 +106,49 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// Batched CG.  Per-env reduction accumulators (fp64, one atomicAdd per workgroup):
-//   acc[b][0..2]  rr ring   (rr_i lives in slot i % 3)
-//   acc[b][3..4]  pAp ring  (pAp_i in slot 3 + i % 2)
+// Batched CG.  Per-env reduction accumulators (fp64).  To keep same-address atomic traffic off the
+// critical path on big grids (256^3 = 16384 workgroups per kernel) every accumulator is spread over
+// `ns` slots (power of two <= FG_CG_SLOTS); workgroup w adds into slot w & (ns-1) and every wave of a
+// consuming kernel re-sums the ns slots itself with one coalesced load + wave64 shuffle reduction:
+//   acc[b][0..2][slot]  rr ring   (rr_i in name i % 3)
+//   acc[b][3..4][slot]  pAp ring  (pAp_i in name 3 + i % 2)
 // Every workgroup derives alpha / beta / the convergence decision itself from the accumulators, so
 // no scalar ever travels to the host inside the loop (the reference reads 3-4 scalars per
 // iteration through cublasTdot/nrm2, cg_solver_kernel.cu:277,317,332,431).
 // flags[b]: 0 running, 1 converged, 2 non-finite residual, 3 inactive env.
 // ---------------------------------------------------------------------------------------------
+#define FG_CG_SLOTS 64
+#define FG_CG_NAMES 5
+
 __device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
 
-// r = b - P x (or r = b when x0 == 0), accumulates rr into `slot`
+__device__ __forceinline__ double* fg_acc_ptr(double* acc, int b, int name) {
+    return acc + ((size_t)b * FG_CG_NAMES + name) * FG_CG_SLOTS;
+}
+// total of an accumulator; every lane of the calling wave gets the result
+__device__ __forceinline__ double fg_acc_total(const double* a, int ns) {
+    if (ns == 1) return a[0];
+    const int lane = threadIdx.x & 63;
+    double v = (lane < ns) ? a[lane] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void fg_acc_zero(double* a, int ns) {  // called by the first wave of the leader block
+    const int lane = threadIdx.x & 63;
+    if (lane < ns) a[lane] = 0.0;
+}
+__device__ __forceinline__ void fg_acc_add(double* a, int ns, unsigned tile, double v) {
+    atomicAdd(a + (tile & (unsigned)(ns - 1)), v);
+}
+
+// r = b - P x (or r = b when x0 == 0), accumulates rr into ring name `name`
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float* __restrict__ rA_,
                                                            const float* __restrict__ b_, float* __restrict__ x_,
                                                            float* __restrict__ r_, double* __restrict__ acc,
-                                                           const int32_t* __restrict__ flags, int use_x0, int slot,
-                                                           int tiles_x, int tiles_y, int tiles) {
+                                                           const int32_t* __restrict__ flags, int use_x0, int name,
+                                                           int ns, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flags[c.b] != 0) return;
     __shared__ float lds[4];
@@ -148,7 +174,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float*
         for (int e = 0; e < VEC; ++e) part[0] += r.v[e] * r.v[e];
     }
     fg_block_sum<1>(part, lds);
-    if (threadIdx.x == 0) atomicAdd(acc + (size_t)c.b * FG_ACC_DOUBLES + slot, (double)part[0]);
+    if (threadIdx.x == 0) {
+        const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
+        fg_acc_add(fg_acc_ptr(acc, c.b, name), ns, tile, (double)part[0]);
+    }
 }
 
 // CG kernel 1 of iteration `it`:  p = r + beta p ; Ap = P p ; pAp += p.Ap
@@ -159,19 +188,19 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float*
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __restrict__ rA_,
                                                      const float* __restrict__ r_, const float* __restrict__ pin_,
-                                                     float* __restrict__ pout_,
-                                                     float* __restrict__ Ap_, double* __restrict__ acc,
-                                                     int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                                                     float tol, int it, int first, int tiles_x, int tiles_y,
+                                                     float* __restrict__ pout_, float* __restrict__ Ap_,
+                                                     double* __restrict__ acc, int32_t* __restrict__ flags,
+                                                     fg_solve_info* __restrict__ info, int32_t* __restrict__ prof_active,
+                                                     float tol, int it, int first, int ns, int tiles_x, int tiles_y,
                                                      int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flags[c.b] != 0) return;
-    double* a = acc + (size_t)c.b * FG_ACC_DOUBLES;
-    const double rr_new = a[it % 3];
+    const double rr_new = fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns);
     const float crit = fg_rms(rr_new, g.n);
-    const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
+    const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
+    const bool lead_block = (tile == 0);
     if (!(crit >= tol)) {  // converged (crit < tol) or NaN
-        if (leader) {
+        if (lead_block && threadIdx.x == 0) {
             const bool finite = isfinite(crit);
             flags[c.b] = finite ? 1 : 2;
             info[c.b].final_residual = crit;
@@ -181,12 +210,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
         }
         return;
     }
-    if (leader) {
-        a[(it + 1) % 3] = 0.0;  // rr slot of the next iteration (last read one kernel ago)
-        info[c.b].final_residual = crit;
-        info[c.b].used_iterations = it - 1;
+    const double rr_old = first ? 1.0 : fg_acc_total(fg_acc_ptr(acc, c.b, (it + 2) % 3), ns);
+    if (lead_block && threadIdx.x < 64) {
+        fg_acc_zero(fg_acc_ptr(acc, c.b, (it + 1) % 3), ns);  // rr ring entry of the next iteration
+        if (threadIdx.x == 0) {
+            info[c.b].final_residual = crit;
+            info[c.b].used_iterations = it - 1;
+            if (prof_active) atomicAdd(prof_active, 1);
+        }
     }
-    const float beta = first ? 0.f : (float)(rr_new / a[(it + 2) % 3]);
+    const float beta = first ? 0.f : (float)(rr_new / rr_old);
     __shared__ float lds[4];
     const size_t base = (size_t)c.b * g.n;
     float part[1] = {0.f};
@@ -220,7 +253,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
         fg_store<VEC>(pout_ + base + c.idx, p.c);
     }
     fg_block_sum<1>(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + 3 + (it & 1), (double)part[0]);
+    if (threadIdx.x == 0) fg_acc_add(fg_acc_ptr(acc, c.b, 3 + (it & 1)), ns, tile, (double)part[0]);
 }
 
 // CG kernel 2:  alpha = rr / pAp ; x += alpha p ; r -= alpha Ap ; rr_next += r.r
@@ -228,16 +261,15 @@ template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* __restrict__ p_,
                                                          const float* __restrict__ Ap_, float* __restrict__ x_,
                                                          float* __restrict__ r_, double* __restrict__ acc,
-                                                         const int32_t* __restrict__ flags, float tol, int it,
+                                                         const int32_t* __restrict__ flags, float tol, int it, int ns,
                                                          int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flags[c.b] != 0) return;
-    double* a = acc + (size_t)c.b * FG_ACC_DOUBLES;
-    const double rr = a[it % 3];
-    const double pAp = a[3 + (it & 1)];
+    const double rr = fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns);
+    const double pAp = fg_acc_total(fg_acc_ptr(acc, c.b, 3 + (it & 1)), ns);
     const float alpha = (float)(rr / pAp);
-    const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
-    if (leader) a[3 + ((it + 1) & 1)] = 0.0;  // pAp slot of the next iteration
+    const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
+    if (tile == 0 && threadIdx.x < 64) fg_acc_zero(fg_acc_ptr(acc, c.b, 3 + ((it + 1) & 1)), ns);  // next pAp
     __shared__ float lds[4];
     const size_t base = (size_t)c.b * g.n;
     float part[1] = {0.f};
@@ -256,15 +288,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
         fg_store<VEC>(r_ + base + c.idx, r);
     }
     fg_block_sum<1>(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + (it + 1) % 3, (double)part[0]);
+    if (threadIdx.x == 0) fg_acc_add(fg_acc_ptr(acc, c.b, (it + 1) % 3), ns, tile, (double)part[0]);
 }
 
-// Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one thread per env.
+// Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one wave per env.
 __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                           float tol, int it, int n, int B, int final_pass) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+                           float tol, int it, int n, int B, int final_pass, int ns) {
+    const int b = blockIdx.x;
     if (b >= B || flags[b] != 0) return;
-    const float crit = fg_rms(acc[(size_t)b * FG_ACC_DOUBLES + (it + 1) % 3], n);
+    const float crit = fg_rms(fg_acc_total(fg_acc_ptr(acc, b, (it + 1) % 3), ns), n);
+    if (threadIdx.x != 0) return;
     info[b].final_residual = crit;
     info[b].used_iterations = it;
     if (!(crit >= tol)) {
@@ -280,9 +313,11 @@ __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags
 
 __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ acc, int32_t* __restrict__ flags,
                            fg_solve_info* __restrict__ info, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x;
     if (b >= B) return;
-    for (int q = 0; q < FG_ACC_DOUBLES; ++q) acc[(size_t)b * FG_ACC_DOUBLES + q] = 0.0;
+    for (int q = threadIdx.x; q < FG_CG_NAMES * FG_CG_SLOTS; q += blockDim.x)
+        acc[(size_t)b * FG_CG_NAMES * FG_CG_SLOTS + q] = 0.0;
+    if (threadIdx.x != 0) return;
     const bool active = (dt == nullptr) || (dt[b] > 0.f);
     flags[b] = active ? 0 : 3;
     info[b].final_residual = 0.f;
@@ -291,9 +326,9 @@ __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ ac
     info[b].is_finite = 1;
 }
 
-__global__ void k_zero_slot(double* __restrict__ acc, int slot, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) acc[(size_t)b * FG_ACC_DOUBLES + slot] = 0.0;
+__global__ void k_zero_name(double* __restrict__ acc, int name, int B) {
+    const int b = blockIdx.x;
+    if (b < B && threadIdx.x < FG_CG_SLOTS) fg_acc_ptr(acc, b, name)[threadIdx.x] = 0.0;
 }
 
 }  // namespace
@@ -334,47 +369,59 @@ int fg_poisson_rbgs_launch(const fg_state* s, const float* rA, const float* b, f
 // Host driver of the batched CG.  p is double-buffered: a.p is buffer 0, s->w[6] buffer 1.
 int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st) {
     const int B = s->grid.B, n = s->grid.n;
-    const dim3 sg((B + 63) / 64), sb(64);
-    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->acc, s->flags, s->info_dev, B);
+    const dim3 sg(B), sb(64);
     float* pbuf[2] = {a.p, s->w[6]};
+    int tiles_per_env = 1;
+    FG_DISPATCH(s, { tiles_per_env = fg_launch_geometry<DIMS, VEC>(s->grid).tiles; });
+    int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
+    while (ns < FG_CG_SLOTS && tiles_per_env / ns > 256) ns *= 2;
+    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, B);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,
-                           s->acc, s->flags, a.use_x0, 0, L.tiles_x, L.tiles_y, L.tiles);
+                           s->cg_acc, s->flags, a.use_x0, 0, ns, L.tiles_x, L.tiles_y, L.tiles);
     });
     const int check_every = a.check_every > 0 ? a.check_every : 16;
-    bool done = false, sampled = false;
+    bool done = false;
+    int n_samples = 0;
+    if (s->prof_on) FG_HIP_CHECK(hipMemsetAsync(s->prof_active, 0, sizeof(int32_t) * FG_PROF_SAMPLES, st));
     int it = 0;
     for (; it < a.max_iterations && !done; ++it) {
         int first = (it == 0);
         if (a.reset_steps > 0 && it > 0 && (it + 1) % a.reset_steps == 0) {
             // residual restart (cg_solver_kernel.cu:281-302): r = b - P x, p = r
-            hipLaunchKernelGGL(k_zero_slot, sg, sb, 0, st, s->acc, it % 3, B);
+            hipLaunchKernelGGL(k_zero_name, sg, sb, 0, st, s->cg_acc, it % 3, B);
             FG_DISPATCH(s, {
                 const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
                 hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x,
-                                   a.r, s->acc, s->flags, 1, it % 3, L.tiles_x, L.tiles_y, L.tiles);
+                                   a.r, s->cg_acc, s->flags, 1, it % 3, ns, L.tiles_x, L.tiles_y, L.tiles);
             });
             first = 1;
         }
         // p double buffer: read p_{it-1} from pbuf[(it+1)&1], write p_it to pbuf[it&1]
         const float* p_in = pbuf[(it + 1) & 1];
         float* p_out = pbuf[it & 1];
-        const bool sample = s->prof_on && it == 1;
+        // live timing samples: iteration 1 and every 8th iteration, both kernels bracketed by events
+        const bool sample = s->prof_on && !first && n_samples < FG_PROF_SAMPLES && (it == 1 || (it & 7) == 0);
+        int32_t* pa = sample ? s->prof_active + n_samples : nullptr;
         FG_DISPATCH(s, {
             const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-            if (sample) (void)hipEventRecord(s->prof_ev[0], st);
+            if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 0], st);
             hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.r, p_in, p_out,
-                               a.Ap, s->acc, s->flags, s->info_dev, a.tol, it, first, L.tiles_x, L.tiles_y, L.tiles);
-            if (sample) { (void)hipEventRecord(s->prof_ev[1], st); (void)hipEventRecord(s->prof_ev[2], st); }
+                               a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it, first, ns, L.tiles_x, L.tiles_y,
+                               L.tiles);
+            if (sample) {
+                (void)hipEventRecord(s->prof_ev[4 * n_samples + 1], st);
+                (void)hipEventRecord(s->prof_ev[4 * n_samples + 2], st);
+            }
             hipLaunchKernelGGL((k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x, a.r,
-                               s->acc, s->flags, a.tol, it, L.tiles_x, L.tiles_y, L.tiles);
-            if (sample) (void)hipEventRecord(s->prof_ev[3], st);
+                               s->cg_acc, s->flags, a.tol, it, ns, L.tiles_x, L.tiles_y, L.tiles);
+            if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 3], st);
         });
-        sampled = sampled || sample;
+        if (sample) ++n_samples;
         if ((it + 1) % check_every == 0 || it + 1 == a.max_iterations) {
             const int final_pass = (it + 1 == a.max_iterations);
-            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->acc, s->flags, s->info_dev, a.tol, it, n, B, final_pass);
+            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, it, n, B, final_pass, ns);
             FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
             FG_HIP_CHECK(hipStreamSynchronize(st));
             done = true;
@@ -382,11 +429,22 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         }
     }
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
+    if (n_samples)
+        FG_HIP_CHECK(hipMemcpyAsync(s->prof_active_pinned, s->prof_active, sizeof(int32_t) * FG_PROF_SAMPLES,
+                                    hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
-    if (sampled) {
+    for (int i = 0; i < n_samples; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s->prof_ev[0], s->prof_ev[1]) == hipSuccess) { s->prof_ms[0] += ms; s->prof_n[0]++; }
-        if (hipEventElapsedTime(&ms, s->prof_ev[2], s->prof_ev[3]) == hipSuccess) { s->prof_ms[1] += ms; s->prof_n[1]++; }
+        const int act = s->prof_active_pinned[i];
+        if (act <= 0) continue;  // every env had converged: the launch did no work
+        if (hipEventElapsedTime(&ms, s->prof_ev[4 * i], s->prof_ev[4 * i + 1]) == hipSuccess) {
+            s->prof_ms[0] += ms; s->prof_n[0]++; s->prof_cells[0] += (double)act * n;
+            if (act == B) { s->prof_full_ms[0] += ms; s->prof_full_n[0]++; }
+        }
+        if (hipEventElapsedTime(&ms, s->prof_ev[4 * i + 2], s->prof_ev[4 * i + 3]) == hipSuccess) {
+            s->prof_ms[1] += ms; s->prof_n[1]++; s->prof_cells[1] += (double)act * n;
+            if (act == B) { s->prof_full_ms[1] += ms; s->prof_full_n[1]++; }
+        }
     }
     int rc = FG_OK;
     for (int b = 0; b < B; ++b) {

@@ -151,7 +151,7 @@ class ChannelJetEnv2D(FluidEnv):
         self._block.setVelocity(u0)
         self._block.pressure.zero_()
         self._outflow.setVelocity(self._inflow)
-        self._domain.solver.copy_velocity_result_from_blocks()
+        self._domain.solver.reset_solver_state()
         self._current_action = torch.zeros(self._num_envs, 1, device=self._cuda_device)
         self._apply_action(self._current_action)
 

@@ -179,7 +179,7 @@ class RBCEnvBase(FluidEnv):
         u = torch.randn(self._block.velocity.shape, device=dev, generator=self._torch_rng_cuda) * 0.05
         self._block.setVelocity(u)
         self._block.pressure.zero_()
-        self._domain.solver.copy_velocity_result_from_blocks()
+        self._domain.solver.reset_solver_state()
 
     def _randomize_domain(self) -> None:
         """rbc_env_base.py:335-398 (flip, roll, noise, 1..2 time units of simulation), per batch."""

@@ -140,7 +140,7 @@ class TCF3DBottomEnv(FluidEnv):
         self._block.pressure.zero_()
         self._block.getBoundary("-y").velocity.zero_()
         self._block.getBoundary("+y").velocity.zero_()
-        self._domain.solver.copy_velocity_result_from_blocks()
+        self._domain.solver.reset_solver_state()
         self._sim.make_divergence_free()
 
     def _wall_stress(self) -> torch.Tensor:

@@ -211,9 +211,10 @@ class NativeSolver:
         L.check(self.lib.fg_copy_velocity_result_from_blocks(self.handle, _stream(self.device)))
 
     def piso_step(self, dt, corrector_steps=2, advect_scalar=True, advection_tol=1e-5, pressure_tol=1e-5,
-                  max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0, method=L.FG_SOLVER_CG):
+                  max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0, method=L.FG_SOLVER_CG,
+                  pressure_warm_start=False):
         opt = L.FgStepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol,
-                              pressure_tol, buoyancy_axis, buoyancy_factor)
+                              pressure_tol, buoyancy_axis, buoyancy_factor, int(pressure_warm_start))
         stats = (ctypes.c_int32 * 4)()
         rc = self.lib.fg_piso_step(self.handle, _ptr(self.dt_tensor(dt)), ctypes.byref(opt), stats,
                                    _stream(self.device))
@@ -221,6 +222,9 @@ class NativeSolver:
             raise LinsolveError("linear solve produced a non-finite residual")
         L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED,))
         return rc == L.FG_OK, list(stats)
+
+    def reset_solver_state(self):
+        L.check(self.lib.fg_reset_solver_state(self.handle, _stream(self.device)))
 
     def make_divergence_free(self, tol=1e-5, max_iterations=1000):
         info = self._infos(self.B)
@@ -253,11 +257,11 @@ class NativeSolver:
         L.check(self.lib.fg_profile_enable(self.handle, int(on)))
 
     def profile_read(self):
-        """(ms_sum[2], samples[2]) of the two CG kernels since the last read."""
-        ms = (ctypes.c_double * 2)()
-        n = (ctypes.c_int64 * 2)()
-        L.check(self.lib.fg_profile_read(self.handle, ms, n))
-        return [ms[0], ms[1]], [int(n[0]), int(n[1])]
+        """Per CG kernel {k_cg_ap, k_cg_update}: dict(ms, samples, cells, full_ms, full_samples)."""
+        ms, cells, fms = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
+        n, fn = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
+        L.check(self.lib.fg_profile_read(self.handle, ms, n, cells, fms, fn))
+        return [dict(ms=ms[i], samples=int(n[i]), cells=cells[i], full_ms=fms[i], full_samples=int(fn[i])) for i in (0, 1)]
 
     def close(self):
         if getattr(self, "handle", None):

@@ -79,6 +79,7 @@ class Simulation:
         output_resampling_shape=None,
         output_resampling_fill_max_steps: int = 0,
         buoyancy: Optional[tuple] = None,
+        pressure_warm_start: bool = True,
         **_ignored: Any,
     ):
         if not isinstance(domain, Domain):
@@ -112,6 +113,10 @@ class Simulation:
         self.advect_passive_scalar = advect_passive_scalar
         self.non_orthogonal = non_orthogonal  # identical results on orthogonal grids
         self.buoyancy = buoyancy  # (axis, factor): native form of the RBC PRE_VELOCITY_SETUP hook
+        # start pressure solves from the previous pressureResult (the reference's non-orthogonal branch does,
+        # its orthogonal branch starts from zero: PISOtorch_simulation.py:1878-1882 vs 1804-1812); the solve
+        # converges to the same tolerance either way, in fewer iterations
+        self.pressure_warm_start = bool(pressure_warm_start)
         self.output_resampling_shape = output_resampling_shape
         self.output_resampling_fill_max_steps = output_resampling_fill_max_steps
         self.total_step = 0
@@ -205,7 +210,8 @@ class Simulation:
                                         advect_scalar=self.advect_passive_scalar and self.domain.hasPassiveScalar(),
                                         advection_tol=adv_tol, pressure_tol=p_tol,
                                         max_iterations=self.linear_solve_max_iterations,
-                                        buoyancy_axis=bax, buoyancy_factor=bfac)
+                                        buoyancy_axis=bax, buoyancy_factor=bfac,
+                                        pressure_warm_start=self.pressure_warm_start)
                 self.last_stats = stats
                 if not ok and not self.pressure_return_best_result:
                     raise LinsolveError(f"linear solve did not converge (iterations {stats})")
@@ -242,7 +248,8 @@ class Simulation:
         for _ in range(self.corrector_steps):
             s.setup_pressure_rhs(dt)
             self._run_prep_fn("POST_PRESSURE_SETUP", local_step=step, **hook_kw)
-            self._check(s.solve_pressure(tol=p_tol, max_iterations=maxit), self.pressure_return_best_result)
+            self._check(s.solve_pressure(tol=p_tol, max_iterations=maxit, use_previous=self.pressure_warm_start),
+                        self.pressure_return_best_result)
             self._run_prep_fn("POST_PRESSURE_RESULT", local_step=step, **hook_kw)
             self._run_prep_fn("POST_PRESSURE_NON_ORTHO", local_step=step, **hook_kw)
             s.correct_velocity()

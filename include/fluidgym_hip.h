@@ -153,6 +153,10 @@ typedef struct fg_step_options {
     float pressure_tol;
     int32_t buoyancy_axis;        /* -1 = none */
     float buoyancy_factor;
+    int32_t pressure_warm_start;  /* 1: start each pressure solve from the previous pressureResult (the
+                                     reference passes x=None in its orthogonal branch and pressureResult
+                                     in its non-orthogonal branch, PISOtorch_simulation.py:1804-1812 vs
+                                     :1878-1882; the converged answer is the same) */
 } fg_step_options;
 int fg_piso_step(fg_handle h, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
                  void* stream);
@@ -171,6 +175,8 @@ enum fg_buffer {
     FG_BUF_P_RESULT = 6,   /* pressureResult [B,N]                      */
     FG_BUF_SCALAR_RESULT = 7 /* scalarResult [B,N] (one channel)        */
 };
+/* velocityResult := block velocity, pressureResult := 0 (call after re-initialising the fields) */
+int fg_reset_solver_state(fg_handle h, void* stream);
 int fg_get_buffer(fg_handle h, int which, float** out_ptr, int64_t* out_count);
 /* device-to-device copy of a solver vector into a caller buffer of fg_get_buffer's count */
 int fg_read_buffer(fg_handle h, int which, float* dst, void* stream);
@@ -190,11 +196,15 @@ int fg_poisson_cg(fg_handle h, const float* rA, const float* b, float* x, float 
                   int use_x0, fg_solve_info* info_host, void* stream);
 
 /* ---- live kernel timing for bench.py's roofline -----------------------------------------------
- * When enabled, every CG solve brackets ONE launch of each of its two kernels (iteration 1) with HIP
- * events on the solve's stream; fg_profile_read returns accumulated milliseconds and sample counts
- * for {0: CG kernel 1 (p update + P p + dot), 1: CG kernel 2 (x, r update + dot)} and resets them. */
+ * When enabled, every CG solve brackets up to 16 launches of each of its two kernels (iteration 1 and
+ * every 8th iteration) with HIP events on the solve's stream and has the kernel count the envs that
+ * were still iterating in that launch.  fg_profile_read returns, per kernel {0: CG kernel 1 (p update
+ * + P p + dot), 1: CG kernel 2 (x, r update + dot)}: summed milliseconds, sample count, summed cells
+ * actually processed (active envs x cells/env), and the same restricted to launches in which every
+ * env was active; then resets the counters. */
 int fg_profile_enable(fg_handle h, int on);
-int fg_profile_read(fg_handle h, double* ms_sum_2, int64_t* samples_2);
+int fg_profile_read(fg_handle h, double* ms_sum_2, int64_t* samples_2, double* cells_sum_2, double* full_ms_sum_2,
+                    int64_t* full_samples_2);
 
 /* ---- grid metrics --------------------------------------------------------------------------- */
 /* CoordsToTransforms (grid_gen.cu:298-390): vertex coords [d,(nz+1,)ny+1,nx+1] ->

@@ -1,0 +1,110 @@
+"""CPU-side checks of the boundary: the shared library loads and exports every symbol that
+include/fluidgym_hip.h declares (no compute calls without a GPU), error paths return codes instead
+of aborting, the registry has the reference's semantics, and the product refuses to run without the
+HIP extension / GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import fluidgym_amd
+from fluidgym_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fluidgym_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in fluidgym_hip.h but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature in fluidgym_amd/_lib.py"
+    assert set(L.SIGNATURES) <= set(declared)
+    assert lib.fg_abi_version() == 1
+
+
+def test_invalid_arguments_return_status_codes():
+    lib = L.load()
+    cfg = L.FgConfig()
+    cfg.dims, cfg.nx, cfg.ny, cfg.nz, cfg.batch = 4, 8, 8, 1, 1
+    h = ctypes.c_void_p()
+    fp = ctypes.POINTER(ctypes.c_float)
+    w = np.ones(8, np.float32)
+    rc = lib.fg_create(ctypes.byref(cfg), w.ctypes.data_as(fp), w.ctypes.data_as(fp), None, ctypes.byref(h))
+    assert rc == -1 and b"dims" in lib.fg_last_error()
+    cfg.dims, cfg.nx = 2, 2  # fewer than 3 cells (domain_structs.cpp:1193-1195)
+    assert lib.fg_create(ctypes.byref(cfg), w.ctypes.data_as(fp), w.ctypes.data_as(fp), None, ctypes.byref(h)) == -1
+    cfg.nx = 8
+    cfg.face_type[2] = L.FG_FIXED  # -y fixed but +y periodic
+    assert lib.fg_create(ctypes.byref(cfg), w.ctypes.data_as(fp), w.ctypes.data_as(fp), None, ctypes.byref(h)) == -1
+    assert lib.fg_bind(None, 0, None) == -1
+    assert lib.fg_destroy(None) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_silent_cpu_fallback():
+    from fluidgym_amd.native import NativeSolver
+
+    with pytest.raises(L.NativeLibraryError):
+        NativeSolver([np.ones(8, np.float32), np.ones(8, np.float32)], 1)
+    env = fluidgym_amd.make("ChannelJet2D-gate-v0", cuda_device=torch.device("cuda", 0))
+    with pytest.raises(RuntimeError, match="CUDA is not available"):
+        env.reset(seed=0)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libfluidgym_hip.so")
+    with pytest.raises(L.NativeLibraryError):
+        L.load()
+
+
+def test_registry_semantics():
+    from fluidgym_amd.registry import EnvRegistry
+
+    r = EnvRegistry()
+    r.register("A-v0", lambda **kw: kw, {"a": 1, "b": 2}, b=3)
+    assert r.make("A-v0", a=5) == {"a": 5, "b": 3}  # kwargs override defaults (registry.py:72)
+    with pytest.raises(ValueError):
+        r.register("A-v0", dict, {})
+    with pytest.raises(ValueError):
+        r.make("missing")
+    ids = fluidgym_amd.registry.ids
+    for must in ("RBC2D-easy-v0", "TCFSmall3D-both-easy-v0", "ChannelJet2D-v0"):
+        assert must in ids
+    with pytest.raises(NotImplementedError):
+        fluidgym_amd.make("CylinderJet2D-easy-v0")
+
+
+def test_env_contract_errors_without_gpu():
+    env = fluidgym_amd.make("ChannelJet2D-gate-v0", cuda_device=torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="must be reset"):
+        env.step(torch.zeros(1))
+    with pytest.raises(ValueError, match="Seed"):
+        env.seed(None)
+    assert env._n_sim_steps == 25  # max(1, int(step_length/dt)) (fluid_env.py:840-842)
+    assert env.action_space.shape == (1,)
+    assert set(env.observation_space.keys()) == {"velocity", "pressure"}
+    rbc = fluidgym_amd.make("RBC2D-easy-v0", cuda_device=torch.device("cpu"))
+    assert (rbc._x, rbc._y) == (96, 61)  # rbc_env_base.py:177-178
+    assert rbc._n_sim_steps == 20
+
+
+def test_oracle_is_not_imported_by_the_product():
+    import subprocess
+    import sys
+
+    code = ("import sys, fluidgym_amd, fluidgym_amd.native, fluidgym_amd.simulation, fluidgym_amd.envs, "
+            "fluidgym_amd.envs.channel, fluidgym_amd.envs.rbc, fluidgym_amd.envs.tcf; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle leaked'")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
