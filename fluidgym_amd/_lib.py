@@ -22,7 +22,7 @@ FG_PERIODIC, FG_FIXED = 0, 1
 FG_DIRICHLET, FG_NEUMANN = 0, 1
 FG_VELOCITY, FG_PRESSURE, FG_SCALAR, FG_VELOCITY_SOURCE = 0, 1, 2, 3
 FG_BOUND_VELOCITY, FG_BOUND_SCALAR = 8, 16
-FG_SOLVER_CG, FG_SOLVER_JACOBI, FG_SOLVER_RBGS, FG_SOLVER_MGCG = 0, 1, 2, 3
+FG_SOLVER_CG, FG_SOLVER_JACOBI, FG_SOLVER_RBGS, FG_SOLVER_MGCG, FG_SOLVER_FDCG = 0, 1, 2, 3, 4
 (FG_BUF_A, FG_BUF_C_OFF, FG_BUF_ADV_RHS, FG_BUF_VEL_RESULT, FG_BUF_H, FG_BUF_DIV, FG_BUF_P_RESULT,
  FG_BUF_SCALAR_RESULT) = range(8)
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     "fg_bind": (c_int, [c_void_p, c_int, c_void_p]),
     "fg_set_viscosity": (c_int, [c_void_p, c_float]),
     "fg_set_scalar_viscosity": (c_int, [c_void_p, c_int, c_float]),
+    "fg_set_fd_preconditioner": (c_int, [c_void_p] + [POINTER(c_float)] * 7),
     "fg_max_velocity": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fg_boundary_flux_balance": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fg_setup_advection": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -98,6 +99,8 @@ SIGNATURES = {
     "fg_poisson_rbgs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "fg_poisson_cg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
                               c_void_p]),
+    "fg_poisson_fdcg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
+                                c_void_p]),
     "fg_profile_enable": (c_int, [c_void_p, c_int]),
     "fg_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), POINTER(ctypes.c_double),
                                 POINTER(ctypes.c_double), POINTER(c_int64)]),

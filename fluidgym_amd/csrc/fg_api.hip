@@ -112,8 +112,8 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[i]));
     FG_HIP_CHECK(hipMalloc(&s->prof_active, sizeof(int32_t) * FG_PROF_SAMPLES));
     FG_HIP_CHECK(hipHostMalloc(&s->prof_active_pinned, sizeof(int32_t) * FG_PROF_SAMPLES));
-    FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 5 * 64));
-    FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 5 * 64));
+    FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 8 * 64));
+    FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 8 * 64));
     *out = s;
     return FG_OK;
 }
@@ -144,6 +144,8 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
     for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) (void)hipEventDestroy(s->prof_ev[i]);
+    float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
+    for (float* p : fd) if (p) (void)hipFree(p);
     (void)hipFree(s->prof_active); (void)hipHostFree(s->prof_active_pinned); (void)hipFree(s->cg_acc);
     delete s;
     return FG_OK;
@@ -170,6 +172,30 @@ extern "C" int fg_set_scalar_viscosity(fg_handle s, int ch, float v) {
     FG_REQUIRE(s && ch >= 0 && ch < FG_MAX_SCALARS, FG_ERR_INVALID_ARG, "bad channel");
     s->scalar_viscosity[ch] = v;
     s->scalar_viscosity_set = true;
+    return FG_OK;
+}
+
+extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const float* QxT, const float* Qz, const float* QzT,
+                                        const float* lower, const float* inv, const float* cp) {
+    FG_REQUIRE(s && Qx && QxT && lower && inv && cp, FG_ERR_INVALID_ARG, "null argument");
+    FG_REQUIRE(s->grid.fixed[2] && s->grid.fixed[3], FG_ERR_UNSUPPORTED, "FD preconditioner needs FIXED y faces");
+    FG_REQUIRE(s->grid.dims == 2 || (Qz && QzT), FG_ERR_INVALID_ARG, "Qz required in 3-D");
+    const size_t nx = s->grid.nx, ny = s->grid.ny, nz = s->grid.nz;
+    auto up = [&](float** dst, const float* src, size_t count) -> hipError_t {
+        if (*dst) (void)hipFree(*dst);
+        hipError_t e = hipMalloc(dst, sizeof(float) * count);
+        if (e == hipSuccess) e = hipMemcpy(*dst, src, sizeof(float) * count, hipMemcpyHostToDevice);
+        return e;
+    };
+    FG_HIP_CHECK(up(&s->fd_Qx, Qx, nx * nx));
+    FG_HIP_CHECK(up(&s->fd_QxT, QxT, nx * nx));
+    if (s->grid.dims == 3) {
+        FG_HIP_CHECK(up(&s->fd_Qz, Qz, nz * nz));
+        FG_HIP_CHECK(up(&s->fd_QzT, QzT, nz * nz));
+    }
+    FG_HIP_CHECK(up(&s->fd_lower, lower, ny));
+    FG_HIP_CHECK(up(&s->fd_inv, inv, nx * ny * nz));
+    FG_HIP_CHECK(up(&s->fd_cp, cp, nx * ny * nz));
     return FG_OK;
 }
 
@@ -249,13 +275,14 @@ extern "C" int fg_setup_pressure_rhs(fg_handle s, const float* dt_B, void* strea
 static int solve_pressure(fg_state* s, const float* dt, int method, float tol, int max_iterations, int use_previous,
                           fg_solve_info* info_host, hipStream_t st) {
     int rc = FG_OK;
-    if (method == FG_SOLVER_CG) {
+    if (method == FG_SOLVER_CG || method == FG_SOLVER_FDCG) {
         FgCgArgs a;
         a.rA = s->rA; a.b = s->div; a.x = s->p_result;
         a.r = s->w[0]; a.p = s->w[1]; a.Ap = s->w[2];
         a.dt = dt; a.tol = tol; a.max_iterations = max_iterations; a.use_x0 = use_previous;
         a.reset_steps = 100;  // residual_reset_step=100 (PISOtorch_simulation.py:1913)
-        a.check_every = 16;
+        a.precond = (method == FG_SOLVER_FDCG);
+        a.check_every = a.precond ? 2 : 16;
         rc = fg_cg_solve(s, a, info_host, st);
     } else {
         fg_set_error("fg_solve_pressure: only FG_SOLVER_CG drives the PISO step (Jacobi/RBGS are smoothers)");
@@ -458,7 +485,21 @@ extern "C" int fg_poisson_cg(fg_handle s, const float* rA, const float* b, float
     a.r = s->w[0]; a.p = s->w[1]; a.Ap = s->w[2];
     a.dt = nullptr; a.tol = tol; a.max_iterations = max_iterations; a.use_x0 = use_x0;
     a.reset_steps = 100;
+    a.precond = 0;
     a.check_every = (tol > 0.f) ? 16 : (1 << 30);  // tol <= 0: run exactly max_iterations without polling
+    return fg_cg_solve(s, a, info_host, (hipStream_t)stream);
+}
+
+extern "C" int fg_poisson_fdcg(fg_handle s, const float* rA, const float* b, float* x, float tol, int max_iterations,
+                               int use_x0, fg_solve_info* info_host, void* stream) {
+    FG_REQUIRE(s && rA && b && x, FG_ERR_INVALID_ARG, "null argument");
+    FgCgArgs a;
+    a.rA = rA; a.b = b; a.x = x;
+    a.r = s->w[0]; a.p = s->w[1]; a.Ap = s->w[2];
+    a.dt = nullptr; a.tol = tol; a.max_iterations = max_iterations; a.use_x0 = use_x0;
+    a.reset_steps = 0;
+    a.precond = 1;
+    a.check_every = (tol > 0.f) ? 2 : (1 << 30);
     return fg_cg_solve(s, a, info_host, (hipStream_t)stream);
 }
 

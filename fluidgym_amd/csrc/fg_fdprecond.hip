@@ -1,0 +1,205 @@
+// Fast-diagonalisation preconditioner for the pressure CG (see simulation/fd_precond.py for the
+// maths): z = M^-1 r with M = the constant-coefficient (A = 1) pressure operator, applied as
+//     r^ = (Qx^T (x) Qz^T) r  ->  one tridiagonal solve along y per mode  ->  z = (Qx (x) Qz) u .
+// The two basis changes are genuinely GEMM-shaped (tall-skinny field matrix times a small dense
+// eigenbasis) and run on the matrix cores with the exact-fp32 MFMA v_mfma_f32_32x32x2_f32 (gfx950:
+// 64 cycles / 4096 MACs per wave, bitwise an fmaf chain, cdna_hip_programming.md section 3); the
+// tridiagonal sweep streams the per-mode LU factors precomputed on the host.
+#include "fg_internal.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA_S = BM + 4;  // LDS row pitch (floats) of the k-major A tile; +4 keeps 16-B alignment
+constexpr int LDB_S = BN + 4;
+
+struct GemmArgs {
+    const float* A; long lda; long strideA;   // [M x K] row-major, per batch (stride 0 = shared)
+    const float* B; long ldb; long strideB;   // [K x N]
+    float* C; long ldc; long strideC;         // [M x N]
+    int M, N, K;
+    const int32_t* flags;                     // batch b is skipped when flags[b] != 0
+    const float* dot_with; long strideW;      // optional: acc[b] += sum C .* W  (W laid out like C)
+    double* dot_acc; int dot_stride; int dot_ns;  // slotted accumulator: dot_acc[b * dot_stride + (block & (ns-1))]
+};
+
+// C = A * B, fp32 in / fp32 accumulate on MFMA 32x32x2.  256 threads = 4 waves in a 2 x 2 arrangement,
+// each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles (64 accumulator registers).
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    const int b = blockIdx.z;
+    if (g.flags && g.flags[b] != 0) return;
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+    const float* __restrict__ A = g.A + (size_t)b * g.strideA;
+    const float* __restrict__ B = g.B + (size_t)b * g.strideB;
+    float* __restrict__ C = g.C + (size_t)b * g.strideC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // global -> register staging: A tile 128 x 16 (thread: row tid/2, 8 consecutive k), B tile 16 x 128
+    const int a_row = tid >> 1, a_k = (tid & 1) * 8;
+    const int b_k = tid >> 4, b_n = (tid & 15) * 8;
+    float ra[8], rb[8];
+    auto load_tiles = [&](int k0) {
+        const int gm = m0 + a_row;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int gk = k0 + a_k + q;
+            ra[q] = (gm < g.M && gk < g.K) ? A[(size_t)gm * g.lda + gk] : 0.f;
+        }
+        const int gk = k0 + b_k;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int gn = n0 + b_n + q;
+            rb[q] = (gk < g.K && gn < g.N) ? B[(size_t)gk * g.ldb + gn] : 0.f;
+        }
+    };
+    load_tiles(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int q = 0; q < 8; ++q) As[(a_k + q) * LDA_S + a_row] = ra[q];
+        *reinterpret_cast<float4*>(&Bs[b_k * LDB_S + b_n]) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+        *reinterpret_cast<float4*>(&Bs[b_k * LDB_S + b_n + 4]) = make_float4(rb[4], rb[5], rb[6], rb[7]);
+        __syncthreads();
+        if (k0 + BK < g.K) load_tiles(k0 + BK);  // overlaps with the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            float a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[kr * LDA_S + wm + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = Bs[kr * LDB_S + wn + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float dot = 0.f;
+    const float* __restrict__ W = g.dot_with ? g.dot_with + (size_t)b * g.strideW : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = n0 + wn + j * 32 + (lane & 31);
+                if (row < g.M && col < g.N) {
+                    const float v = acc[i][j][r];
+                    C[(size_t)row * g.ldc + col] = v;
+                    if (W) dot += v * W[(size_t)row * g.ldc + col];
+                }
+            }
+    if (W) {
+        __shared__ float lds[4];
+        float part[1] = {dot};
+        fg_block_sum<1>(part, lds);
+        if (tid == 0)
+            atomicAdd(g.dot_acc + (size_t)b * g.dot_stride + ((blockIdx.x + blockIdx.y * gridDim.x) & (unsigned)(g.dot_ns - 1)),
+                      (double)part[0]);
+    }
+}
+
+// Thomas sweep along y for every mode, in place: forward y_j = (b_j - l_j y_{j-1}) inv_j, backward
+// x_j = y_j - c'_j x_{j+1}.  One thread per (env, z-mode, x-mode); x-mode is the fastest index so every
+// step is a coalesced row access.
+__global__ __launch_bounds__(256) void k_tridiag_y(float* __restrict__ x, const float* __restrict__ inv,
+                                                    const float* __restrict__ cp, const float* __restrict__ lower,
+                                                    const int32_t* __restrict__ flags, int nx, int ny, int nz) {
+    const int b = blockIdx.y;
+    if (flags && flags[b] != 0) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nx * nz) return;
+    const int a = t % nx, c = t / nx;
+    const size_t col = (size_t)c * ny * nx + a;
+    float* __restrict__ xb = x + (size_t)b * nx * ny * nz + col;
+    const float* __restrict__ iv = inv + col;
+    const float* __restrict__ cpp = cp + col;
+    float prev = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < ny; ++j) {
+        const size_t o = (size_t)j * nx;
+        prev = (xb[o] - lower[j] * prev) * iv[o];
+        xb[o] = prev;
+    }
+#pragma unroll 4
+    for (int j = ny - 2; j >= 0; --j) {
+        const size_t o = (size_t)j * nx;
+        prev = xb[o] - cpp[o] * prev;
+        xb[o] = prev;
+    }
+}
+
+}  // namespace
+
+static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, g);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+// z = M^-1 r for all envs with flags == 0; optionally rz_acc[b * rz_stride] += r . z
+int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, hipStream_t st) {
+    const FgGrid& G = s->grid;
+    const int nx = G.nx, ny = G.ny, nz = G.nz, B = G.B;
+    const long N = G.n;
+    float* t1 = s->w[3];
+    float* t2 = s->w[4];
+    GemmArgs g;
+    // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]
+    g.A = r; g.lda = nx; g.strideA = N;
+    g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0;
+    g.C = t1; g.ldc = nx; g.strideC = N;
+    g.M = ny * nz; g.N = nx; g.K = nx;
+    g.flags = s->flags; g.dot_with = nullptr; g.strideW = 0; g.dot_acc = nullptr; g.dot_stride = 0; g.dot_ns = 1;
+    if (int rc = launch_gemm(g, B, st)) return rc;
+    float* cur = t1;
+    if (G.dims == 3) {
+        // forward z: t2[c, m] = sum_k QzT[c, k] t1[k, m]   (m over ny*nx)
+        g.A = s->fd_QzT; g.lda = nz; g.strideA = 0;
+        g.B = t1; g.ldb = (long)ny * nx; g.strideB = N;
+        g.C = t2; g.ldc = (long)ny * nx; g.strideC = N;
+        g.M = nz; g.N = ny * nx; g.K = nz;
+        if (int rc = launch_gemm(g, B, st)) return rc;
+        cur = t2;
+    }
+    {
+        dim3 grid((nx * nz + 255) / 256, B);
+        hipLaunchKernelGGL(k_tridiag_y, grid, dim3(256), 0, st, cur, s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz);
+    }
+    if (G.dims == 3) {
+        // inverse z: t1[k, m] = sum_c Qz[k, c] t2[c, m]
+        g.A = s->fd_Qz; g.lda = nz; g.strideA = 0;
+        g.B = t2; g.ldb = (long)ny * nx; g.strideB = N;
+        g.C = t1; g.ldc = (long)ny * nx; g.strideC = N;
+        g.M = nz; g.N = ny * nx; g.K = nz;
+        if (int rc = launch_gemm(g, B, st)) return rc;
+        cur = t1;
+    }
+    // inverse x: z[rows, i] = sum_a cur[rows, a] QxT[a, i], fused r.z
+    g.A = cur; g.lda = nx; g.strideA = N;
+    g.B = s->fd_QxT; g.ldb = nx; g.strideB = 0;
+    g.C = z; g.ldc = nx; g.strideC = N;
+    g.M = ny * nz; g.N = nx; g.K = nx;
+    g.dot_with = rz_acc ? r : nullptr; g.strideW = N; g.dot_acc = rz_acc; g.dot_stride = rz_stride; g.dot_ns = rz_ns;
+    if (int rc = launch_gemm(g, B, st)) return rc;
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}

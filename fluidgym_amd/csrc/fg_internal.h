@@ -320,7 +320,9 @@ struct fg_state {
     double prof_cells[2];         // sum over samples of cells actually processed (active envs * n)
     double prof_full_ms[2];       // same, restricted to launches with every env active
     long long prof_full_n[2];
-    double* cg_acc;               // [B][FG_CG_NAMES=5][FG_CG_SLOTS=64] slotted CG accumulators
+    double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
+    // fast-diagonalisation preconditioner factors (device copies; null = not configured)
+    float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
     const float* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     size_t n_cells() const { return (size_t)grid.n; }
 };
@@ -384,6 +386,7 @@ struct FgCgArgs {
     const float* dt;   // [B] activity mask (nullptr = all active)
     float tol; int max_iterations; int use_x0; int reset_steps;
     int check_every;
+    int precond;   // 1: fast-diagonalisation preconditioned CG (needs fg_set_fd_preconditioner)
 };
 int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st);
 
@@ -397,4 +400,5 @@ struct FgBicgArgs {
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
 
+int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const floa
 // flags[b]: 0 running, 1 converged, 2 non-finite residual, 3 inactive env.
 // ---------------------------------------------------------------------------------------------
 #define FG_CG_SLOTS 64
-#define FG_CG_NAMES 5
+#define FG_CG_NAMES 8  // rr ring 0..2 | pAp ring 3..4 | r.z ring 5..7 (preconditioned CG)
 
 __device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
 
@@ -187,12 +187,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float*
 // pin_ = p of iteration it-1 (read with halo), pout_ = p of iteration it (written, centre only).
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __restrict__ rA_,
-                                                     const float* __restrict__ r_, const float* __restrict__ pin_,
+                                                     const float* __restrict__ z_, const float* __restrict__ pin_,
                                                      float* __restrict__ pout_, float* __restrict__ Ap_,
                                                      double* __restrict__ acc, int32_t* __restrict__ flags,
                                                      fg_solve_info* __restrict__ info, int32_t* __restrict__ prof_active,
-                                                     float tol, int it, int first, int ns, int tiles_x, int tiles_y,
-                                                     int tiles) {
+                                                     float tol, int it, int first, int ns, int num_base, int tiles_x,
+                                                     int tiles_y, int tiles) {
+    // z_ = preconditioned residual (= r when num_base == 0); beta = num_it / num_{it-1} with the numerator
+    // ring num_base (0: r.r, 5: r.z).  Convergence is always judged on the r.r ring (RMS residual).
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flags[c.b] != 0) return;
     const double rr_new = fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns);
@@ -210,23 +212,25 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
         }
         return;
     }
-    const double rr_old = first ? 1.0 : fg_acc_total(fg_acc_ptr(acc, c.b, (it + 2) % 3), ns);
+    const double num_new = (num_base == 0) ? rr_new : fg_acc_total(fg_acc_ptr(acc, c.b, num_base + it % 3), ns);
+    const double num_old = first ? 1.0 : fg_acc_total(fg_acc_ptr(acc, c.b, num_base + (it + 2) % 3), ns);
     if (lead_block && threadIdx.x < 64) {
         fg_acc_zero(fg_acc_ptr(acc, c.b, (it + 1) % 3), ns);  // rr ring entry of the next iteration
+        if (num_base) fg_acc_zero(fg_acc_ptr(acc, c.b, num_base + (it + 1) % 3), ns);
         if (threadIdx.x == 0) {
             info[c.b].final_residual = crit;
             info[c.b].used_iterations = it - 1;
             if (prof_active) atomicAdd(prof_active, 1);
         }
     }
-    const float beta = first ? 0.f : (float)(rr_new / rr_old);
+    const float beta = first ? 0.f : (float)(num_new / num_old);
     __shared__ float lds[4];
     const size_t base = (size_t)c.b * g.n;
     float part[1] = {0.f};
     if (c.valid) {
         const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
         const FgNbr<DIMS, VEC> rA = fg_gather<DIMS, VEC>(rA_ + base, c);
-        FgNbr<DIMS, VEC> p = fg_gather<DIMS, VEC>(r_ + base, c);
+        FgNbr<DIMS, VEC> p = fg_gather<DIMS, VEC>(z_ + base, c);
         if (!first) {
             const FgNbr<DIMS, VEC> po = fg_gather<DIMS, VEC>(pin_ + base, c);
 #pragma unroll
@@ -262,10 +266,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
                                                          const float* __restrict__ Ap_, float* __restrict__ x_,
                                                          float* __restrict__ r_, double* __restrict__ acc,
                                                          const int32_t* __restrict__ flags, float tol, int it, int ns,
-                                                         int tiles_x, int tiles_y, int tiles) {
+                                                         int num_base, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flags[c.b] != 0) return;
-    const double rr = fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns);
+    const double rr = fg_acc_total(fg_acc_ptr(acc, c.b, num_base + it % 3), ns);  // r.r or r.z
     const double pAp = fg_acc_total(fg_acc_ptr(acc, c.b, 3 + (it & 1)), ns);
     const float alpha = (float)(rr / pAp);
     const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
@@ -382,6 +386,15 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                            s->cg_acc, s->flags, a.use_x0, 0, ns, L.tiles_x, L.tiles_y, L.tiles);
     });
     const int check_every = a.check_every > 0 ? a.check_every : 16;
+    const int nb = a.precond ? 5 : 0;
+    const int acc_stride = FG_CG_NAMES * FG_CG_SLOTS;
+    float* zvec = a.precond ? s->w[5] : a.r;
+    if (a.precond) {
+        if (!s->fd_Qx) { fg_set_error("preconditioned CG requested but fg_set_fd_preconditioner was not called"); return FG_ERR_INVALID_ARG; }
+        // residual check of x0 (sets flags for already-converged envs), then z0 = M^-1 r0, r0.z0
+        hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, -1, n, B, 0, ns);
+        if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, st)) return rc;
+    }
     bool done = false;
     int n_samples = 0;
     if (s->prof_on) FG_HIP_CHECK(hipMemsetAsync(s->prof_active, 0, sizeof(int32_t) * FG_PROF_SAMPLES, st));
@@ -407,21 +420,29 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         FG_DISPATCH(s, {
             const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
             if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 0], st);
-            hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.r, p_in, p_out,
-                               a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it, first, ns, L.tiles_x, L.tiles_y,
-                               L.tiles);
+            hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, zvec, p_in, p_out,
+                               a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it, first, ns, nb, L.tiles_x,
+                               L.tiles_y, L.tiles);
             if (sample) {
                 (void)hipEventRecord(s->prof_ev[4 * n_samples + 1], st);
                 (void)hipEventRecord(s->prof_ev[4 * n_samples + 2], st);
             }
             hipLaunchKernelGGL((k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x, a.r,
-                               s->cg_acc, s->flags, a.tol, it, ns, L.tiles_x, L.tiles_y, L.tiles);
+                               s->cg_acc, s->flags, a.tol, it, ns, nb, L.tiles_x, L.tiles_y, L.tiles);
             if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 3], st);
         });
         if (sample) ++n_samples;
-        if ((it + 1) % check_every == 0 || it + 1 == a.max_iterations) {
+        const bool poll = ((it + 1) % check_every == 0 || it + 1 == a.max_iterations);
+        if (a.precond || poll) {
             const int final_pass = (it + 1 == a.max_iterations);
             hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, it, n, B, final_pass, ns);
+        }
+        if (a.precond && it + 1 < a.max_iterations) {
+            // z = M^-1 r and r.z of the next iteration (envs that just converged are skipped via flags)
+            if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + (it + 1) % 3) * FG_CG_SLOTS, acc_stride, ns, st))
+                return rc;
+        }
+        if (poll) {
             FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
             FG_HIP_CHECK(hipStreamSynchronize(st));
             done = true;

@@ -77,6 +77,17 @@ class NativeSolver:
         self._dt = torch.zeros(self.B, dtype=torch.float32, device=self.device)
         self._dt_host = torch.zeros(self.B, dtype=torch.float32).pin_memory()
         self._out_B = torch.zeros(self.B, dtype=torch.float32, device=self.device)
+        # fast-diagonalisation preconditioner (needs FIXED y faces); default pressure solver when available
+        self.has_fd = bool(self.fixed[2] and self.fixed[3])
+        if self.has_fd:
+            from .simulation.fd_precond import FDPreconditioner
+
+            fd = FDPreconditioner(self.widths, [f for f in range(6) if self.fixed[f]])
+            fpp = lambda a: a.ctypes.data_as(fp)
+            qz, qzt = (fpp(fd.Qz), fpp(fd.QzT)) if self.dims == 3 else (None, None)
+            L.check(self.lib.fg_set_fd_preconditioner(self.handle, fpp(fd.Qx), fpp(fd.QxT), qz, qzt, fpp(fd.lower),
+                                                      fpp(fd.inv), fpp(fd.cp)))
+        self.default_method = L.FG_SOLVER_FDCG if self.has_fd else L.FG_SOLVER_CG
         if allocate:
             self.allocate_fields()
 
@@ -194,7 +205,8 @@ class NativeSolver:
     def setup_pressure_rhs(self, dt):
         L.check(self.lib.fg_setup_pressure_rhs(self.handle, _ptr(self.dt_tensor(dt)), _stream(self.device)))
 
-    def solve_pressure(self, tol=1e-5, max_iterations=5000, method=L.FG_SOLVER_CG, use_previous=False):
+    def solve_pressure(self, tol=1e-5, max_iterations=5000, method=None, use_previous=False):
+        method = self.default_method if method is None else method
         info = self._infos(self.B)
         rc = self.lib.fg_solve_pressure(self.handle, method, tol, max_iterations, int(use_previous), info,
                                         _stream(self.device))
@@ -211,8 +223,9 @@ class NativeSolver:
         L.check(self.lib.fg_copy_velocity_result_from_blocks(self.handle, _stream(self.device)))
 
     def piso_step(self, dt, corrector_steps=2, advect_scalar=True, advection_tol=1e-5, pressure_tol=1e-5,
-                  max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0, method=L.FG_SOLVER_CG,
+                  max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0, method=None,
                   pressure_warm_start=False):
+        method = self.default_method if method is None else method
         opt = L.FgStepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol,
                               pressure_tol, buoyancy_axis, buoyancy_factor, int(pressure_warm_start))
         stats = (ctypes.c_int32 * 4)()
@@ -262,6 +275,13 @@ class NativeSolver:
         n, fn = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
         L.check(self.lib.fg_profile_read(self.handle, ms, n, cells, fms, fn))
         return [dict(ms=ms[i], samples=int(n[i]), cells=cells[i], full_ms=fms[i], full_samples=int(fn[i])) for i in (0, 1)]
+
+    def poisson_fdcg(self, rA, b, x, tol=1e-5, max_iterations=500, use_x0=False):
+        info = self._infos(self.B)
+        rc = self.lib.fg_poisson_fdcg(self.handle, _ptr(rA), _ptr(b), _ptr(x), tol, max_iterations, int(use_x0), info,
+                                      _stream(self.device))
+        L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
+        return list(info)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -68,7 +68,8 @@ enum fg_field {
 #define FG_SOLVER_CG 0
 #define FG_SOLVER_JACOBI 1
 #define FG_SOLVER_RBGS 2
-#define FG_SOLVER_MGCG 3
+#define FG_SOLVER_MGCG 3   /* reserved */
+#define FG_SOLVER_FDCG 4   /* CG preconditioned by the separable constant-coefficient operator (fast diagonalisation) */
 
 typedef struct fg_state* fg_handle;
 
@@ -107,6 +108,16 @@ int fg_bind(fg_handle h, int field, float* ptr);
 /* Domain.viscosity / Domain.setScalarViscosity (domain_structs.cpp:3070) */
 int fg_set_viscosity(fg_handle h, float viscosity);
 int fg_set_scalar_viscosity(fg_handle h, int channel, float viscosity);
+
+/* Fast-diagonalisation preconditioner factors for FG_SOLVER_FDCG (host arrays, copied to the device):
+ * Qx [nx,nx] / QxT: H-orthonormal eigenbasis of the 1-D x operator and its transpose, Qz / QzT the same
+ * for z (NULL in 2-D), lower [ny]: sub-diagonal of the y operator, inv / cp [(nz,) ny, nx]: per-mode
+ * reciprocal pivots and modified super-diagonal of the tridiagonal LU along y.  Built by
+ * fluidgym_amd/simulation/fd_precond.py; requires FIXED y faces.  No reference counterpart (the
+ * reference runs un-preconditioned CG, cg_solver_kernel.cu:129-471). */
+int fg_set_fd_preconditioner(fg_handle h, const float* Qx_host, const float* QxT_host, const float* Qz_host,
+                             const float* QzT_host, const float* lower_host, const float* inv_host,
+                             const float* cp_host);
 
 /* ---- reductions used by the drivers --------------------------------------------------------- */
 /* Domain.getMaxVelocity(withBounds=True, computational=True) (domain_structs.cpp:1580-1611) */
@@ -194,6 +205,9 @@ int fg_poisson_rbgs(fg_handle h, const float* rA, const float* b, float* x, int 
 /* n_iterations of CG without convergence polling (timing) -- or a full solve when tol > 0. */
 int fg_poisson_cg(fg_handle h, const float* rA, const float* b, float* x, float tol, int max_iterations,
                   int use_x0, fg_solve_info* info_host, void* stream);
+/* same with the fast-diagonalisation preconditioner (FG_SOLVER_FDCG) */
+int fg_poisson_fdcg(fg_handle h, const float* rA, const float* b, float* x, float tol, int max_iterations,
+                    int use_x0, fg_solve_info* info_host, void* stream);
 
 /* ---- live kernel timing for bench.py's roofline -----------------------------------------------
  * When enabled, every CG solve brackets up to 16 launches of each of its two kernels (iteration 1 and
