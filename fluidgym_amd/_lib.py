@@ -80,6 +80,9 @@ SIGNATURES = {
     "fg_set_fd_preconditioner": (c_int, [c_void_p] + [POINTER(c_float)] * 7),
     "fg_max_velocity": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fg_boundary_flux_balance": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fg_step_diagnostics": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
+    "fg_update_advective_boundary": (c_int, [c_void_p, c_int, POINTER(c_float), c_void_p, c_void_p]),
+    "fg_balance_boundary_fluxes": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "fg_setup_advection": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fg_solve_advection": (c_int, [c_void_p, c_int, c_int, c_float, c_int, POINTER(FgSolveInfo), c_void_p]),
     "fg_copy_scalar_result_to_blocks": (c_int, [c_void_p, c_int, c_void_p]),

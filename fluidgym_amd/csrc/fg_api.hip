@@ -109,6 +109,10 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipHostMalloc(&s->info_pinned, sizeof(fg_solve_info) * nsys));
     FG_HIP_CHECK(hipHostMalloc(&s->flags_pinned, sizeof(int32_t) * nsys));
     FG_HIP_CHECK(alloc(&s->scratch_B, (size_t)g.B * (4 + 2 * d)));
+    FG_HIP_CHECK(hipMalloc(&s->d_bvel_ptrs, sizeof(float*) * 6));
+    FG_HIP_CHECK(hipMemset(s->d_bvel_ptrs, 0, sizeof(float*) * 6));
+    FG_HIP_CHECK(hipHostMalloc(&s->diag_pinned, sizeof(float) * 2 * g.B));
+    s->pred_bicg = 2; s->pred_cg = 1;
     for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[i]));
     FG_HIP_CHECK(hipMalloc(&s->prof_active, sizeof(int32_t) * FG_PROF_SAMPLES));
     FG_HIP_CHECK(hipHostMalloc(&s->prof_active_pinned, sizeof(int32_t) * FG_PROF_SAMPLES));
@@ -144,6 +148,7 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
     for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) (void)hipEventDestroy(s->prof_ev[i]);
+    (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned);
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
     (void)hipFree(s->prof_active); (void)hipHostFree(s->prof_active_pinned); (void)hipFree(s->cg_acc);
@@ -151,13 +156,17 @@ extern "C" int fg_destroy(fg_handle s) {
     return FG_OK;
 }
 
+static int sync_bvel_ptrs(fg_state* s);
 extern "C" int fg_bind(fg_handle s, int field, float* ptr) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (field == FG_VELOCITY) s->velocity = ptr;
     else if (field == FG_PRESSURE) s->pressure = ptr;
     else if (field == FG_SCALAR) s->scalar = ptr;
     else if (field == FG_VELOCITY_SOURCE) s->velocity_source = ptr;
-    else if (field >= FG_BOUND_VELOCITY && field < FG_BOUND_VELOCITY + 6) s->bvel[field - FG_BOUND_VELOCITY] = ptr;
+    else if (field >= FG_BOUND_VELOCITY && field < FG_BOUND_VELOCITY + 6) {
+        s->bvel[field - FG_BOUND_VELOCITY] = ptr;
+        return sync_bvel_ptrs(s);
+    }
     else if (field >= FG_BOUND_SCALAR && field < FG_BOUND_SCALAR + 6) s->bscal[field - FG_BOUND_SCALAR] = ptr;
     else FG_REQUIRE(false, FG_ERR_INVALID_ARG, "fg_bind: unknown field id");
     return FG_OK;
@@ -208,6 +217,39 @@ extern "C" int fg_boundary_flux_balance(fg_handle s, float* out_B, void* stream)
     FG_REQUIRE(s && out_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, false)) return rc;
     return fg_launch_flux_balance(s, make_bounds(s, 0), out_B, (hipStream_t)stream);
+}
+
+extern "C" int fg_step_diagnostics(fg_handle s, float* out_host, void* stream) {
+    FG_REQUIRE(s && out_host, FG_ERR_INVALID_ARG, "null argument");
+    if (int rc = check_bound(s, false)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->grid.B;
+    float* d = s->scratch_B;  // [0..B) flux balance, [B..2B) max velocity
+    const FgBounds bnd = make_bounds(s, 0);
+    if (int rc = fg_launch_flux_balance(s, bnd, d, st)) return rc;
+    if (int rc = fg_launch_max_velocity(s, bnd, d + B, st)) return rc;
+    FG_HIP_CHECK(hipMemcpyAsync(s->diag_pinned, d, sizeof(float) * 2 * B, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(out_host, s->diag_pinned, sizeof(float) * 2 * B);
+    return FG_OK;
+}
+
+static int sync_bvel_ptrs(fg_state* s) {
+    FG_HIP_CHECK(hipMemcpy(s->d_bvel_ptrs, s->bvel, sizeof(float*) * 6, hipMemcpyHostToDevice));
+    return FG_OK;
+}
+
+extern "C" int fg_update_advective_boundary(fg_handle s, int face, const float* velm, const float* dt_B, void* stream) {
+    FG_REQUIRE(s && velm && dt_B && face >= 0 && face < 2 * s->grid.dims, FG_ERR_INVALID_ARG, "bad argument");
+    FG_REQUIRE(s->grid.fixed[face] && s->bvel[face], FG_ERR_INVALID_ARG, "face is not a bound FIXED face");
+    if (int rc = check_bound(s, false)) return rc;
+    return fg_launch_outflow(s, face, velm[face >> 1], dt_B, (hipStream_t)stream);
+}
+
+extern "C" int fg_balance_boundary_fluxes(fg_handle s, int free_face_mask, float atol, const float* dt_B, void* stream) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    if (int rc = check_bound(s, false)) return rc;
+    return fg_launch_balance(s, make_bounds(s, 0), free_face_mask, atol, dt_B, (hipStream_t)stream);
 }
 
 extern "C" int fg_setup_advection(fg_handle s, const float* dt_B, int for_scalar, int channel, void* stream) {

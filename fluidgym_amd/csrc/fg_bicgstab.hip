@@ -351,14 +351,17 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
 
     FG_BICG_LAUNCH(k_bicg_init, a.use_x0);
     bool done = false;
-    const int check_every = 2;
+    // first convergence poll where the previous solve finished (kernels of converged systems exit at once,
+    // so over-launching costs ~2 us per kernel while every poll costs a stream sync), then every 2 iterations
+    int next_poll = s->pred_bicg > 1 ? s->pred_bicg : 1;
     for (int it = 0; it < a.max_iterations && !done; ++it) {
         FG_BICG_LAUNCH(k_bicg_p, it);
         FG_BICG_LAUNCH(k_bicg_v, it);
         FG_BICG_LAUNCH(k_bicg_s, it);
         FG_BICG_LAUNCH(k_bicg_t, it);
         FG_BICG_LAUNCH(k_bicg_x, it);
-        if ((it + 1) % check_every == 0 || it + 1 == a.max_iterations) {
+        if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
+            next_poll = it + 1 + 2;
             const int final_pass = (it + 1 == a.max_iterations);
             hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, a.tol, it, n, nsys, final_pass);
             FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));
@@ -371,6 +374,9 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
     int rc = FG_OK;
+    int used_max = 0;
+    for (int i = 0; i < nsys; ++i) used_max = s->info_pinned[i].used_iterations > used_max ? s->info_pinned[i].used_iterations : used_max;
+    s->pred_bicg = used_max;
     for (int i = 0; i < nsys; ++i) {
         if (info_host) info_host[i] = s->info_pinned[i];
         if (!s->info_pinned[i].is_finite) rc = FG_ERR_NOT_FINITE;

@@ -11,9 +11,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDA_S = BM + 4;  // LDS row pitch (floats) of the k-major A tile; +4 keeps 16-B alignment
-constexpr int LDB_S = BN + 4;
+constexpr int BK = 16;
 
 struct GemmArgs {
     const float* A; long lda; long strideA;   // [M x K] row-major, per batch (stride 0 = shared)
@@ -26,8 +24,13 @@ struct GemmArgs {
 };
 
 // C = A * B, fp32 in / fp32 accumulate on MFMA 32x32x2.  256 threads = 4 waves in a 2 x 2 arrangement,
-// each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles (64 accumulator registers).
+// each wave owns TM x TN MFMA tiles of 32 x 32 (TM = TN = 2: 128 x 128 block tile, 64 accumulator
+// registers; TM = TN = 1: 64 x 64 block tile for launches that would otherwise leave CUs idle).
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int LDA_S = BM + 4, LDB_S = BN + 4;  // LDS row pitch; +4 floats keeps 16-B alignment, breaks conflicts
+    constexpr int PA = BM * BK / 256, PB = BN * BK / 256;  // floats staged per thread (8 or 4)
     const int b = blockIdx.z;
     if (g.flags && g.flags[b] != 0) return;
     __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
@@ -37,30 +40,32 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     float* __restrict__ C = g.C + (size_t)b * g.strideC;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // global -> register staging: A tile 128 x 16 (thread: row tid/2, 8 consecutive k), B tile 16 x 128
-    const int a_row = tid >> 1, a_k = (tid & 1) * 8;
-    const int b_k = tid >> 4, b_n = (tid & 15) * 8;
-    float ra[8], rb[8];
+    // global -> register staging: A tile BM x 16 (thread: PA consecutive k of one row), B tile 16 x BN
+    constexpr int A_TPR = BK / PA;  // threads per A row
+    constexpr int B_TPR = BN / PB;  // threads per B row
+    const int a_row = tid / A_TPR, a_k = (tid % A_TPR) * PA;
+    const int b_k = tid / B_TPR, b_n = (tid % B_TPR) * PB;
+    float ra[PA], rb[PB];
     auto load_tiles = [&](int k0) {
         const int gm = m0 + a_row;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < PA; ++q) {
             const int gk = k0 + a_k + q;
             ra[q] = (gm < g.M && gk < g.K) ? A[(size_t)gm * g.lda + gk] : 0.f;
         }
         const int gk = k0 + b_k;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < PB; ++q) {
             const int gn = n0 + b_n + q;
             rb[q] = (gk < g.K && gn < g.N) ? B[(size_t)gk * g.ldb + gn] : 0.f;
         }
@@ -69,23 +74,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
-        for (int q = 0; q < 8; ++q) As[(a_k + q) * LDA_S + a_row] = ra[q];
-        *reinterpret_cast<float4*>(&Bs[b_k * LDB_S + b_n]) = make_float4(rb[0], rb[1], rb[2], rb[3]);
-        *reinterpret_cast<float4*>(&Bs[b_k * LDB_S + b_n + 4]) = make_float4(rb[4], rb[5], rb[6], rb[7]);
+        for (int q = 0; q < PA; ++q) As[(a_k + q) * LDA_S + a_row] = ra[q];
+#pragma unroll
+        for (int q = 0; q < PB; q += 4)
+            *reinterpret_cast<float4*>(&Bs[b_k * LDB_S + b_n + q]) = make_float4(rb[q], rb[q + 1], rb[q + 2], rb[q + 3]);
         __syncthreads();
         if (k0 + BK < g.K) load_tiles(k0 + BK);  // overlaps with the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int kr = kk + (lane >> 5);
-            float a[2], bb[2];
+            float a[TM], bb[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[kr * LDA_S + wm + i * 32 + (lane & 31)];
+            for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA_S + wm + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bb[j] = Bs[kr * LDB_S + wn + j * 32 + (lane & 31)];
+            for (int j = 0; j < TN; ++j) bb[j] = Bs[kr * LDB_S + wn + j * 32 + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -93,9 +99,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     float dot = 0.f;
     const float* __restrict__ W = g.dot_with ? g.dot_with + (size_t)b * g.strideW : nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -118,7 +124,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 
 // Thomas sweep along y for every mode, in place: forward y_j = (b_j - l_j y_{j-1}) inv_j, backward
 // x_j = y_j - c'_j x_{j+1}.  One thread per (env, z-mode, x-mode); x-mode is the fastest index so every
-// step is a coalesced row access.
+// step is a coalesced row access.  The recurrence is latency-bound (one wave per CU at batch 64), so rows
+// are fetched in chunks of TRI_CH one chunk ahead of the arithmetic (register double buffer).
+constexpr int TRI_CH = 8;
 __global__ __launch_bounds__(256) void k_tridiag_y(float* __restrict__ x, const float* __restrict__ inv,
                                                     const float* __restrict__ cp, const float* __restrict__ lower,
                                                     const int32_t* __restrict__ flags, int nx, int ny, int nz) {
@@ -128,29 +136,66 @@ __global__ __launch_bounds__(256) void k_tridiag_y(float* __restrict__ x, const 
     if (t >= nx * nz) return;
     const int a = t % nx, c = t / nx;
     const size_t col = (size_t)c * ny * nx + a;
-    float* __restrict__ xb = x + (size_t)b * nx * ny * nz + col;
+    float* xb = x + (size_t)b * nx * ny * nz + col;
     const float* __restrict__ iv = inv + col;
     const float* __restrict__ cpp = cp + col;
+    float cx[TRI_CH], ci[TRI_CH], nxv[TRI_CH], niv[TRI_CH];
+    auto fetch = [&](int j0, float (&vx)[TRI_CH], float (&vi)[TRI_CH], const float* __restrict__ coef) {
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) {
+            const int j = j0 + q;
+            const bool ok = (j >= 0) && (j < ny);
+            const size_t o = (size_t)(ok ? j : 0) * nx;
+            vx[q] = ok ? xb[o] : 0.f;
+            vi[q] = ok ? coef[o] : 0.f;
+        }
+    };
+    // ---- forward elimination
     float prev = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < ny; ++j) {
-        const size_t o = (size_t)j * nx;
-        prev = (xb[o] - lower[j] * prev) * iv[o];
-        xb[o] = prev;
+    fetch(0, cx, ci, iv);
+    for (int j0 = 0; j0 < ny; j0 += TRI_CH) {
+        fetch(j0 + TRI_CH, nxv, niv, iv);
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) {
+            const int j = j0 + q;
+            if (j < ny) {
+                prev = (cx[q] - lower[j] * prev) * ci[q];
+                xb[(size_t)j * nx] = prev;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) { cx[q] = nxv[q]; ci[q] = niv[q]; }
     }
-#pragma unroll 4
-    for (int j = ny - 2; j >= 0; --j) {
-        const size_t o = (size_t)j * nx;
-        prev = xb[o] - cpp[o] * prev;
-        xb[o] = prev;
+    // ---- back substitution (prev = x_{ny-1}); chunks walk downwards, element q of a chunk is row j0 + q
+    const int last = ny - 2;
+    int j0 = (last / TRI_CH) * TRI_CH;
+    if (last >= 0) fetch(j0, cx, ci, cpp);
+    for (; j0 >= 0; j0 -= TRI_CH) {
+        fetch(j0 - TRI_CH, nxv, niv, cpp);
+#pragma unroll
+        for (int q = TRI_CH - 1; q >= 0; --q) {
+            const int j = j0 + q;
+            if (j <= last) {
+                prev = cx[q] - ci[q] * prev;
+                xb[(size_t)j * nx] = prev;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) { cx[q] = nxv[q]; ci[q] = niv[q]; }
     }
 }
 
 }  // namespace
 
 static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
-    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, g);
+    const long big_blocks = (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * batch;
+    if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
+        hipLaunchKernelGGL((k_gemm_f32<2, 2>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
+        hipLaunchKernelGGL((k_gemm_f32<1, 1>), grid, dim3(256), 0, st, g);
+    }
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

@@ -323,6 +323,9 @@ struct fg_state {
     double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
+    float** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
+    float* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
+    int pred_bicg, pred_cg; // iterations the last solves needed (first convergence poll is scheduled there)
     const float* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     size_t n_cells() const { return (size_t)grid.n; }
 };
@@ -372,6 +375,8 @@ int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, float* out_B,
 int fg_launch_copy_active(const fg_state* s, const float* dt, const float* src, float* dst, int comps, hipStream_t st);
 int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long t_env_stride, float* source, int axis,
                        float factor, hipStream_t st);
+int fg_launch_outflow(const fg_state* s, int face, float velm_axis, const float* dt, hipStream_t st);
+int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, float atol, const float* dt, hipStream_t st);
 int fg_launch_mean_sub(const fg_state* s, const float* active_dt, float* p, float* p_copy, hipStream_t st);
 
 // Poisson / CG (fg_poisson.hip)

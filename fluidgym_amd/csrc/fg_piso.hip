@@ -433,6 +433,89 @@ __global__ __launch_bounds__(FG_BLOCK) void k_sub_mean(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Convective outflow boundary (update_advective_boundaries, PISOtorch_simulation.py:282-389):
+//   t = 1 - 1/(1 + 2 dt (Minv_row_n . u_m)),  phi_b <- phi_b - t (phi_b - phi_cell)
+// for the velocity (all components) and every passive scalar channel of one FIXED face.
+// Rectilinear grid: Minv_row_n . u_m = u_m[axis] / h_axis(boundary cell).
+// ---------------------------------------------------------------------------------------------
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_outflow(FgGrid g, int face, float velm_axis, const float* __restrict__ dt,
+                                                       const float* __restrict__ vel, float* __restrict__ bvel,
+                                                       const float* __restrict__ scal, float* __restrict__ bscal,
+                                                       int n_scalars) {
+    const int b = blockIdx.y;
+    const float dtb = dt[b];
+    if (!(dtb > 0.f)) return;
+    const int ax = face >> 1;
+    const int slab_n = fg_slab_size(g, ax);
+    const int edge = (face & 1) ? ((ax == 0) ? g.nx - 1 : (ax == 1) ? g.ny - 1 : g.nz - 1) : 0;
+    const float tcoef = 1.f - 1.f / (1.f + 2.f * dtb * velm_axis * g.rh[ax][edge]);
+    const size_t N = g.n;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < slab_n; s += gridDim.x * blockDim.x) {
+        int i, j, k;
+        if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
+        else if (ax == 1) { j = edge; i = s % g.nx; k = s / g.nx; }
+        else { k = edge; i = s % g.nx; j = s / g.nx; }
+        const size_t cell = ((size_t)k * g.ny + j) * g.nx + i;
+#pragma unroll
+        for (int q = 0; q < DIMS; ++q) {
+            float* pb = bvel + ((size_t)b * DIMS + q) * slab_n + s;
+            const float vb = *pb;
+            *pb = vb - tcoef * (vb - vel[((size_t)b * DIMS + q) * N + cell]);
+        }
+        for (int ch = 0; ch < n_scalars; ++ch) {
+            float* pb = bscal + ((size_t)b * n_scalars + ch) * slab_n + s;
+            const float sb = *pb;
+            *pb = sb - tcoef * (sb - scal[((size_t)b * n_scalars + ch) * N + cell]);
+        }
+    }
+}
+
+// balance_boundary_fluxes (PISOtorch_simulation.py:188-224): per env, if |flux_fixed + flux_free| exceeds
+// atol scale the whole velocity of the free faces by -flux_fixed / flux_free.  One workgroup per env.
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds bnd, float* const* bvel_rw, int free_mask,
+                                                              float atol, const float* __restrict__ dt) {
+    const int b = blockIdx.x;
+    if (dt && !(dt[b] > 0.f)) return;
+    double fixed = 0.0, freef = 0.0;
+    for (int f = 0; f < 2 * DIMS; ++f) {
+        if (!g.fixed[f]) continue;
+        const int ax = f >> 1;
+        const int slab_n = fg_slab_size(g, ax);
+        const double sgn = (f & 1) ? 1.0 : -1.0;
+        double acc = 0.0;
+        for (int s = threadIdx.x; s < slab_n; s += blockDim.x) {
+            int i = 0, j = 0, k = 0;
+            if (ax == 0) { j = s % g.ny; k = s / g.ny; }
+            else if (ax == 1) { i = s % g.nx; k = s / g.nx; }
+            else { i = s % g.nx; j = s / g.nx; }
+            float area;
+            if (ax == 0) area = g.h[1][j] * (DIMS == 3 ? g.h[2][k] : 1.f);
+            else if (ax == 1) area = g.h[0][i] * (DIMS == 3 ? g.h[2][k] : 1.f);
+            else area = g.h[0][i] * g.h[1][j];
+            acc += sgn * (double)(bnd.vel[f][((size_t)b * DIMS + ax) * slab_n + s] * area);
+        }
+        if ((free_mask >> f) & 1) freef += acc; else fixed += acc;
+    }
+    __shared__ double lds[8];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { fixed += __shfl_down(fixed, o, 64); freef += __shfl_down(freef, o, 64); }
+    if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = fixed; lds[4 + (threadIdx.x >> 6)] = freef; }
+    __syncthreads();
+    fixed = lds[0] + lds[1] + lds[2] + lds[3];
+    freef = lds[4] + lds[5] + lds[6] + lds[7];
+    if (!(fabs(fixed + freef) > (double)atol)) return;
+    const float scale = (float)(-fixed / freef);
+    for (int f = 0; f < 2 * DIMS; ++f) {
+        if (!((free_mask >> f) & 1) || !g.fixed[f]) continue;
+        const int slab_n = fg_slab_size(g, f >> 1);
+        float* v = bvel_rw[f] + (size_t)b * DIMS * slab_n;
+        for (int s = threadIdx.x; s < DIMS * slab_n; s += blockDim.x) v[s] *= scale;
+    }
+}
+
 inline dim3 stride_grid(const fg_state* s, long per_env_elems) {
     long blocks = (per_env_elems / 4 + FG_BLOCK - 1) / FG_BLOCK;
     const long cap = (2048 + s->grid.B - 1) / s->grid.B;  // ~8 workgroups per CU over the batch
@@ -539,6 +622,29 @@ int fg_launch_mean_sub(const fg_state* s, const float* dt, float* p, float* p_co
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
     hipLaunchKernelGGL(k_sum_env, grid, dim3(FG_BLOCK), 0, st, dt, p, sums, s->grid.n);
     hipLaunchKernelGGL(k_sub_mean, grid, dim3(FG_BLOCK), 0, st, dt, p, p_copy, sums, s->grid.n);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_outflow(const fg_state* s, int face, float velm_axis, const float* dt, hipStream_t st) {
+    const int slab_n = (face >> 1) == 0 ? s->grid.ny * s->grid.nz : (face >> 1) == 1 ? s->grid.nx * s->grid.nz : s->grid.nx * s->grid.ny;
+    dim3 grid((slab_n + FG_BLOCK - 1) / FG_BLOCK, s->grid.B);
+    const int nsc = (s->scalar && s->bscal[face]) ? s->cfg.n_scalars : 0;
+    if (s->grid.dims == 2)
+        hipLaunchKernelGGL(k_outflow<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, face, velm_axis, dt, s->velocity, s->bvel[face],
+                           s->scalar, s->bscal[face], nsc);
+    else
+        hipLaunchKernelGGL(k_outflow<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, face, velm_axis, dt, s->velocity, s->bvel[face],
+                           s->scalar, s->bscal[face], nsc);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, float atol, const float* dt, hipStream_t st) {
+    if (s->grid.dims == 2)
+        hipLaunchKernelGGL(k_balance_fluxes<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt);
+    else
+        hipLaunchKernelGGL(k_balance_fluxes<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

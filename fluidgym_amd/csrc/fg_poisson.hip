@@ -396,6 +396,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, st)) return rc;
     }
     bool done = false;
+    int next_poll = a.precond ? (s->pred_cg + 1 > 1 ? s->pred_cg + 1 : 1) : check_every;
     int n_samples = 0;
     if (s->prof_on) FG_HIP_CHECK(hipMemsetAsync(s->prof_active, 0, sizeof(int32_t) * FG_PROF_SAMPLES, st));
     int it = 0;
@@ -432,7 +433,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 3], st);
         });
         if (sample) ++n_samples;
-        const bool poll = ((it + 1) % check_every == 0 || it + 1 == a.max_iterations);
+        const bool poll = (it + 1 >= next_poll || it + 1 == a.max_iterations);
+        if (poll) next_poll = it + 1 + check_every;
         if (a.precond || poll) {
             const int final_pass = (it + 1 == a.max_iterations);
             hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, it, n, B, final_pass, ns);
@@ -468,6 +470,11 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         }
     }
     int rc = FG_OK;
+    if (a.precond) {
+        int used_max = 0;
+        for (int b = 0; b < B; ++b) used_max = s->info_pinned[b].used_iterations > used_max ? s->info_pinned[b].used_iterations : used_max;
+        s->pred_cg = used_max;
+    }
     for (int b = 0; b < B; ++b) {
         if (info_host) info_host[b] = s->info_pinned[b];
         if (!s->info_pinned[b].is_finite) rc = FG_ERR_NOT_FINITE;

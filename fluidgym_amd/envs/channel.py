@@ -122,7 +122,7 @@ class ChannelJetEnv2D(FluidEnv):
         jp = torch.from_numpy(jet_profile(self._jet_cells).astype(np.float32)).to(dev) * self._jet_max
         self._jet_shape = torch.zeros(1, 2, 1, self._x, device=dev)
         self._jet_shape[0, 1, 0, self._jet_start: self._jet_start + self._jet_cells] = jp
-        self._velm = torch.tensor([[self._U_mean, 0.0]], device=dev)
+        self._velm = np.array([self._U_mean, 0.0], dtype=np.float32)  # host: characteristic outflow velocity
         # sensor probes: nearest cell centre of a regular lattice in the downstream 3/4 of the channel
         ix = np.linspace(self._x // 4, self._x - 1, self._n_sensors_x).round().astype(np.int64)
         iy = np.linspace(0, self._y - 1, self._n_sensors_y + 2).round().astype(np.int64)[1:-1]

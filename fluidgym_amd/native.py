@@ -183,6 +183,25 @@ class NativeSolver:
         L.check(self.lib.fg_boundary_flux_balance(self.handle, _ptr(self._out_B), _stream(self.device)))
         return self._out_B.clone()
 
+    def step_diagnostics(self):
+        """(flux_balance[B], max_velocity[B]) as NumPy arrays with a single device->host sync."""
+        buf = np.empty(2 * self.B, dtype=np.float32)
+        L.check(self.lib.fg_step_diagnostics(self.handle, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                             _stream(self.device)))
+        return buf[: self.B], buf[self.B:]
+
+    def update_advective_boundary(self, face: int, velm, dt):
+        v = np.ascontiguousarray(velm, dtype=np.float32).reshape(-1)
+        L.check(self.lib.fg_update_advective_boundary(self.handle, face, v.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                      _ptr(self.dt_tensor(dt)), _stream(self.device)))
+
+    def balance_boundary_fluxes(self, free_faces, atol: float, dt):
+        mask = 0
+        for f in free_faces:
+            mask |= 1 << int(f)
+        L.check(self.lib.fg_balance_boundary_fluxes(self.handle, mask, float(atol), _ptr(self.dt_tensor(dt)),
+                                                    _stream(self.device)))
+
     # ------------------------------------------------------------------ PISO pieces
     def setup_advection(self, dt, for_scalar=False, channel=0):
         L.check(self.lib.fg_setup_advection(self.handle, _ptr(self.dt_tensor(dt)), int(for_scalar), channel,

@@ -123,6 +123,7 @@ class Simulation:
         self.total_time = np.zeros(domain.batch, dtype=np.float64)
         self.last_stats: List[int] = []
         self.substep_count = 0
+        self._max_vel_hint = None
         if not verbose:
             _LOG.setLevel("ERROR")
 
@@ -143,13 +144,16 @@ class Simulation:
         """``Simulation.single_step`` (simulation.py:206-280)."""
         if static:
             raise NotImplementedError("advect_static is not on the env path")
-        balance = self.domain.GetBoundaryFluxBalance()
-        worst = float(balance.abs().max())
-        if worst > self.flux_balance_tol:
+        # one device->host transfer for both per-step scalars (flux balance guard, simulation.py:223-231, and the
+        # CFL velocity of the first substep, PISOtorch_simulation.py:2013-2014)
+        balance, max_vel = self._solver.step_diagnostics()
+        worst = float(np.abs(balance).max())
+        if not (worst <= self.flux_balance_tol):
             raise RuntimeError(
                 f"Domain boundary fluxes not balanced, cannot proceed with simulation step. "
                 f"Flux balance: {balance.tolist()}, flux_balance_tol: {self.flux_balance_tol}"
             )
+        self._max_vel_hint = max_vel
         try:
             if self.substeps > 0:
                 ok = self._PISO_split_step(self.substeps, None)
@@ -173,7 +177,10 @@ class Simulation:
             active = (t_rem > 0) & ~np.isclose(t_rem, 0)
             if not active.any():
                 break
-            max_vel = self.domain.getMaxVelocity(True, True).cpu().numpy().astype(np.float64)
+            if self._max_vel_hint is not None:
+                max_vel, self._max_vel_hint = self._max_vel_hint.astype(np.float64), None
+            else:
+                max_vel = self._solver.step_diagnostics()[1].astype(np.float64)
             ts = np.zeros(B, dtype=np.float64)
             for b in np.nonzero(active)[0]:
                 mv = max_vel[b]
@@ -306,27 +313,14 @@ def balance_boundary_fluxes(domain: Domain, free_bounds: Sequence[FixedBoundary]
         b.velocity.mul_(scale.view(-1, *([1] * (b.velocity.dim() - 1))))
 
 
-def update_advective_boundaries(domain: Domain, bounds: Sequence[FixedBoundary], velms, dt: torch.Tensor,
-                                tol: Optional[float] = None):
+def update_advective_boundaries(domain: Domain, bounds: Sequence[FixedBoundary], velms, dt, tol: Optional[float] = None):
     """Convective outflow: ``phi_b <- phi_b - t (phi_b - phi_cell)``, ``t = 1 - 1/(1 + 2 dt (Minv_n . u_m))``
-    (PISOtorch_simulation.py:282-389), then flux balancing (:393).  ``dt``: per-env ``[B]`` tensor;
-    ``velms``: one ``[1|B, d]`` characteristic velocity (or a list, one per boundary)."""
-    blk = domain.getBlock(0)
-    d = domain.dims
+    (PISOtorch_simulation.py:282-389), then flux balancing (:393) -- two small native kernels per call.
+    ``dt``: per-env ``[B]`` device tensor (or anything ``NativeSolver.dt_tensor`` accepts); ``velms``: one
+    static characteristic velocity ``[1, d]`` / ``[d]`` on the HOST (or a list, one per boundary)."""
+    s = domain.solver
     for i, b in enumerate(bounds):
         velm = velms[i] if isinstance(velms, (list, tuple)) else velms
-        velm = velm.to(domain.device, torch.float32)
-        axis = b.face >> 1
-        tr = b.transform  # [1, slab, T]
-        minv_row = tr[..., d * d + axis * d: d * d + axis * d + d]  # [1, slab, d]
-        adv = (minv_row * velm.view(velm.shape[0], *([1] * d), d)).sum(-1).unsqueeze(1)  # [1|B,1,slab]
-        alpha = dt.view(-1, *([1] * (d + 1))) * 2.0 * adv
-        t = 1.0 - 1.0 / (1.0 + alpha)
-        active = (dt > 0).view(-1, *([1] * (d + 1)))
-        t = torch.where(active, t, torch.zeros_like(t))
-        vb = b.velocity
-        vb.sub_(t * (vb - _cell_slab(blk.velocity, b.face)))
-        if domain.hasPassiveScalar():
-            sb = b.passiveScalar
-            sb.sub_(t * (sb - _cell_slab(blk.passiveScalar, b.face)))
-    balance_boundary_fluxes(domain, bounds, tol)
+        velm = velm.detach().cpu().numpy() if isinstance(velm, torch.Tensor) else np.asarray(velm)
+        s.update_advective_boundary(b.face, velm.reshape(-1)[: domain.dims], dt)
+    s.balance_boundary_fluxes([b.face for b in bounds], get_solver_tolerance(tol) * 0.01, dt)

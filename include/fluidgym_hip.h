@@ -125,6 +125,16 @@ int fg_max_velocity(fg_handle h, float* out_B, void* stream);
 /* Domain.GetBoundaryFluxBalance (domain_structs.cpp:2476-2509) */
 int fg_boundary_flux_balance(fg_handle h, float* out_B, void* stream);
 
+/* Both reductions with ONE device->host transfer and one stream sync: out_host[0..B) = flux balance,
+ * out_host[B..2B) = max velocity (what Simulation.single_step + _PISO_adaptive_step read per substep,
+ * simulation.py:223-231 and PISOtorch_simulation.py:2013-2014). */
+int fg_step_diagnostics(fg_handle h, float* out_host_2B, void* stream);
+/* update_advective_boundaries for one FIXED face with characteristic velocity velm (host, d floats)
+ * (PISOtorch_simulation.py:282-389); envs with dt_B[b] <= 0 are skipped. */
+int fg_update_advective_boundary(fg_handle h, int face, const float* velm_host, const float* dt_B, void* stream);
+/* balance_boundary_fluxes (PISOtorch_simulation.py:188-224): free_face_mask bit f = face f is free. */
+int fg_balance_boundary_fluxes(fg_handle h, int free_face_mask, float atol, const float* dt_B, void* stream);
+
 /* ---- PISO building blocks (one call = the reference free function of the same role) --------- */
 /* SetupAdvectionMatrix (PISO_multiblock_cuda_kernel.cu:4525-4546, kernel :3616-3880) fused with
  * SetupAdvectionVelocity (:4692-4708, kernel :4296-4400) or, when for_scalar != 0, with

@@ -11,7 +11,7 @@ def main(db):
            join rocpd_info_kernel_symbol s on d.kernel_id = s.id
            group by s.display_name, p.name order by 1, 2"""
     for name, ctr, n, avg in c.execute(q):
-        short = name.replace("void (anonymous namespace)::", "").split("(")[0][:70]
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
         print(f"{short},{ctr},{n},{avg:.1f}")
 
 

@@ -15,7 +15,7 @@ def main(db, out=None):
     total = sum(r[2] for r in rows) or 1
     lines = ["kernel,calls,total_ms,avg_us,min_us,max_us,pct,vgpr,sgpr,max_workgroups"]
     for name, n, tot, avg, mn, mx, vg, sg, wgs in rows:
-        short = name.replace("void (anonymous namespace)::", "").replace("void ", "").split("(")[0][:90].replace(",", ";")
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90].replace(",", ";")
         lines.append(f"{short},{n},{tot/1e6:.3f},{avg/1e3:.2f},{mn/1e3:.2f},{mx/1e3:.2f},{100*tot/total:.1f},{vg},{sg},{wgs}")
     text = "\n".join(lines)
     if out:

@@ -1,0 +1,155 @@
+"""Env-level tests on the GPU: the reset()/step() contract (reference tests/envs/test_all_envs.py:52-100
+check shapes / types / metric keys the same way), the native outflow-boundary + adaptive-CFL driver
+against the oracle, batching semantics, get_state / set_state."""
+import numpy as np
+import pytest
+import torch
+
+import fluidgym_amd
+from fluidgym_amd.simulation import Domain, Simulation, grids, update_advective_boundaries
+from oracle import piso_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+SMALL = {
+    "ChannelJet2D-v0": dict(resolution_x=64, resolution_y=32),
+    "RBC2D-easy-v0": dict(n_heaters=4, resolution=8),
+    "RBC3D-easy-v0": dict(n_heaters=2, resolution=4),
+    "TCFSmall3D-both-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.06, dt=0.03),
+}
+
+
+@pytest.mark.parametrize("env_id", list(SMALL))
+@pytest.mark.parametrize("num_envs", [None, 3])
+def test_env_contract(env_id, num_envs):
+    env = fluidgym_amd.make(env_id, num_envs=num_envs, randomize_initial_state=False, episode_length=3, **SMALL[env_id])
+    with pytest.raises(RuntimeError, match="must be reset"):
+        env.step(env._zero_action)
+    with pytest.raises(ValueError, match="Seed"):
+        env.reset()
+    obs, info = env.reset(seed=3)
+    lead = () if num_envs is None else (num_envs,)
+    for k, sp in env.observation_space.items():
+        assert tuple(obs[k].shape) == lead + tuple(sp.shape), k
+        assert obs[k].dtype == torch.float32 and obs[k].is_cuda
+    with pytest.raises(ValueError, match="Action shape"):
+        env.step(torch.zeros(lead + (99,), device="cuda"))
+    for i in range(3):
+        obs, reward, term, trunc, info = env.step(env.sample_action())
+        assert tuple(reward.shape) == lead
+        assert torch.isfinite(reward).all()
+        for m in env._metrics:
+            assert m in info and tuple(info[m].shape) == lead
+        assert term is False and trunc == (i == 2)
+    with pytest.raises(RuntimeError, match="already terminated"):
+        env.step(env.sample_action())
+    env.close()
+
+
+def test_reset_is_reproducible_and_state_roundtrip():
+    env = fluidgym_amd.make("ChannelJet2D-v0", num_envs=2, resolution_x=64, resolution_y=32)
+    o1, _ = env.reset(seed=11)
+    a = env.sample_action()
+    s0 = env.get_state()
+    r1 = env.step(a)
+    env.set_state(s0)
+    r2 = env.step(a)
+    assert torch.allclose(r1[1], r2[1], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(r1[0]["velocity"], r2[0]["velocity"], rtol=1e-4, atol=1e-6)
+    o2, _ = env.reset(seed=11)
+    assert torch.allclose(o1["velocity"], o2["velocity"], rtol=1e-4, atol=1e-6)
+    env.close()
+
+
+def test_batched_env_equals_independent_envs():
+    """Env b of a batch evolves exactly as if it were alone (no cross-talk through the batched solvers)."""
+    kw = dict(resolution_x=64, resolution_y=32, randomize_initial_state=False)
+    envB = fluidgym_amd.make("ChannelJet2D-v0", num_envs=2, **kw)
+    env1 = fluidgym_amd.make("ChannelJet2D-v0", num_envs=1, **kw)
+    envB.reset(seed=0)
+    env1.reset(seed=0)
+    acts = torch.tensor([[0.7], [-0.4]], device="cuda")
+    for _ in range(2):
+        oB, rB, *_ = envB.step(acts)
+        o1, r1, *_ = env1.step(acts[1:2])
+    assert torch.allclose(oB["velocity"][1], o1["velocity"][0], rtol=2e-4, atol=2e-5)
+    assert torch.allclose(rB[1], r1[0], rtol=2e-4, atol=1e-6)
+    assert not torch.allclose(oB["velocity"][0], oB["velocity"][1])
+    envB.close()
+    env1.close()
+
+
+def test_channel_driver_with_outflow_matches_oracle():
+    """Simulation.single_step (flux guard, adaptive CFL, native advective outflow + flux re-balancing, fused
+    PISO step) against the oracle's restatement of the same sequence, 6 steps, per-env different inflow."""
+    nx, ny, L, H, nu, dt, B = 48, 24, 6.0, 2.0, 0.02, 0.06, 2
+    edges = [np.linspace(0, L, nx + 1), np.linspace(-H / 2, H / 2, ny + 1)]
+    dom = Domain(2, torch.tensor([nu]), batch=B)
+    blk = dom.CreateBlock(grids.vertex_grid(edges))
+    blk.CloseBoundary("-x")
+    blk.CloseBoundary("-y")
+    dom.PrepareSolve()
+    rng = np.random.default_rng(0)
+    yc = 0.5 * (edges[1][1:] + edges[1][:-1])
+    inflow = np.zeros((B, 2, ny, 1))
+    for b in range(B):
+        inflow[b, 0, :, 0] = (1.0 + 0.3 * b) * 1.5 * (1 - (2 * yc / H) ** 2)
+    u0 = np.broadcast_to(inflow, (B, 2, ny, nx)).copy() + 0.05 * rng.standard_normal((B, 2, ny, nx))
+    blk.setVelocity(torch.from_numpy(u0).float())
+    blk.getBoundary("-x").setVelocity(torch.from_numpy(inflow).float())
+    out = blk.getBoundary("+x")
+    out.setVelocity(torch.from_numpy(inflow).float())
+    dom.solver.reset_solver_state()
+    velm = np.array([1.0, 0.0], dtype=np.float32)
+
+    def pre(domain, time_step, **kw):
+        update_advective_boundaries(domain, [out], velm, time_step, tol=1e-5)
+
+    sim = Simulation(dom, dt=dt, substeps="ADAPTIVE", adaptive_CFL=0.5, prep_fn={"PRE": [pre]}, pressure_tol=1e-7,
+                     advection_tol=1e-7, pressure_return_best_result=True)
+    g = O.Grid(O.rectilinear_coords(edges))
+    doms = []
+    for b in range(B):
+        bc = {0: O.FixedBC(inflow[b].copy()), 1: O.FixedBC(inflow[b].copy()), 2: O.FixedBC(np.zeros(2)), 3: O.FixedBC(np.zeros(2))}
+        doms.append(O.Domain(g, nu, u0[b].astype(np.float32).astype(np.float64), np.zeros((ny, nx)), bc))
+    hooks = {"PRE": [lambda d, ts: O.update_advective_boundaries(d, [1], velm.astype(np.float64), ts, tol=1e-5)]}
+    n_sub = []
+    for step in range(6):
+        assert sim.single_step()
+        n_sub.append(sim.substep_count)
+        for d in doms:
+            O.piso_adaptive_step(d, dt, 0.5, prep_fn=hooks)
+    assert max(n_sub) >= 2, "the case should exercise adaptive substepping"
+    vel = dom.solver.velocity.cpu().numpy().astype(np.float64)
+    bv = out.velocity.cpu().numpy().astype(np.float64)
+    for b in range(B):
+        assert rel_err(vel[b], doms[b].velocity) < 2e-4
+        assert rel_err(bv[b], np.asarray(doms[b].bvel(1))) < 2e-4
+        assert abs(O.boundary_flux_balance(doms[b])) < 1e-6
+    fb = dom.GetBoundaryFluxBalance().cpu().numpy()
+    assert np.abs(fb).max() < 1e-5
+
+
+def test_unbalanced_boundary_flux_is_rejected():
+    env = fluidgym_amd.make("ChannelJet2D-v0", num_envs=1, resolution_x=64, resolution_y=32, randomize_initial_state=False)
+    env.reset(seed=0)
+    env._block.getBoundary("-x").velocity.mul_(1.5)  # break the inflow/outflow balance behind the env's back
+    env._sim.prep_fn = {}
+    with pytest.raises(RuntimeError, match="not balanced"):
+        env._sim.single_step()
+    env.close()
+
+
+def test_rbc_heating_drives_convection():
+    env = fluidgym_amd.make("RBC2D-easy-v0", num_envs=2, n_heaters=4, resolution=8, randomize_initial_state=False,
+                            step_length=0.5)
+    env.reset(seed=1)
+    nus = []
+    for _ in range(4):
+        _, reward, _, _, info = env.step(torch.zeros(2, 4, device="cuda"))
+        nus.append(info["nusselt"].cpu().numpy())
+    assert np.isfinite(nus).all()
+    T = env._block.passiveScalar
+    assert float(T.min()) > -0.2 and float(T.max()) < 1.9
+    env.close()
