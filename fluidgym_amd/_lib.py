@@ -18,6 +18,7 @@ FG_MAX_SCALARS = 4
 FG_OK = 0
 FG_ERR_NOT_CONVERGED = -5
 FG_ERR_NOT_FINITE = -6
+FG_ERR_FLUX_BALANCE = -7
 FG_PERIODIC, FG_FIXED = 0, 1
 FG_DIRICHLET, FG_NEUMANN = 0, 1
 FG_VELOCITY, FG_PRESSURE, FG_SCALAR, FG_VELOCITY_SOURCE = 0, 1, 2, 3
@@ -68,6 +69,21 @@ class FgStepOptions(Structure):
     ]
 
 
+class FgSimOptions(Structure):
+    _fields_ = [
+        ("step", FgStepOptions),
+        ("time_step", c_float),
+        ("cfl", c_float),
+        ("adaptive", c_int32),
+        ("substeps", c_int32),
+        ("flux_balance_tol", c_float),
+        ("outflow_mask", c_int32),
+        ("outflow_velm", c_float * 3),
+        ("outflow_tol", c_float),
+        ("max_substeps", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/fluidgym_hip.h
 SIGNATURES = {
     "fg_abi_version": (c_int, []),
@@ -93,6 +109,7 @@ SIGNATURES = {
     "fg_copy_velocity_result_to_blocks": (c_int, [c_void_p, c_void_p]),
     "fg_copy_velocity_result_from_blocks": (c_int, [c_void_p, c_void_p]),
     "fg_piso_step": (c_int, [c_void_p, c_void_p, POINTER(FgStepOptions), POINTER(c_int32), c_void_p]),
+    "fg_single_step": (c_int, [c_void_p, POINTER(FgSimOptions), POINTER(c_int32), POINTER(c_float), c_void_p]),
     "fg_make_divergence_free": (c_int, [c_void_p, c_float, c_int, POINTER(FgSolveInfo), c_void_p]),
     "fg_reset_solver_state": (c_int, [c_void_p, c_void_p]),
     "fg_get_buffer": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),

@@ -112,6 +112,8 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipMalloc(&s->d_bvel_ptrs, sizeof(float*) * 6));
     FG_HIP_CHECK(hipMemset(s->d_bvel_ptrs, 0, sizeof(float*) * 6));
     FG_HIP_CHECK(hipHostMalloc(&s->diag_pinned, sizeof(float) * 2 * g.B));
+    FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(float) * g.B));
+    FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
     for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[i]));
     FG_HIP_CHECK(hipMalloc(&s->prof_active, sizeof(int32_t) * FG_PROF_SAMPLES));
@@ -148,7 +150,7 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
     for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) (void)hipEventDestroy(s->prof_ev[i]);
-    (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned);
+    (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned); (void)hipHostFree(s->dt_pinned); (void)hipFree(s->dt_dev);
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
     (void)hipFree(s->prof_active); (void)hipHostFree(s->prof_active_pinned); (void)hipFree(s->cg_acc);
@@ -436,6 +438,89 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
     if (int rc = fg_launch_copy_active(s, dt_B, s->vel_result, s->velocity, d, st)) return rc;
     if (stats_host) memcpy(stats_host, stats, sizeof(stats));
     return status;
+}
+
+// np.isclose(a, 0) with the default rtol=1e-5, atol=1e-8
+static inline bool is_close_zero(double a) { return std::fabs(a) <= 1e-8; }
+
+extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out, float* flux_host, void* stream) {
+    FG_REQUIRE(s && o && out, FG_ERR_INVALID_ARG, "null argument");
+    if (int rc = check_bound(s, o->step.advect_scalar && s->cfg.n_scalars > 0)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->grid.B;
+    const FgBounds bnd = make_bounds(s, 0);
+    std::vector<double> t_rem(B, (double)o->time_step);
+    int32_t stats[4] = {-1, -1, -1, -1};
+    int substeps = 0, all_ok = 1;
+    bool first = true;
+    int fixed_left = o->adaptive ? 0 : (o->substeps > 0 ? o->substeps : 1);
+    for (;;) {
+        bool any = false;
+        if (o->adaptive) {
+            for (int b = 0; b < B; ++b) any = any || (t_rem[b] > 0 && !is_close_zero(t_rem[b]));
+        } else {
+            any = fixed_left > 0;
+        }
+        if (!any) break;
+        if (o->adaptive || first) {
+            // one transfer: [0..B) boundary flux balance, [B..2B) max |Minv u| (CFL velocity)
+            float* d = s->scratch_B;
+            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, d, st)) return rc; }
+            if (o->adaptive) { if (int rc = fg_launch_max_velocity(s, bnd, d + B, st)) return rc; }
+            FG_HIP_CHECK(hipMemcpyAsync(s->diag_pinned, d, sizeof(float) * 2 * B, hipMemcpyDeviceToHost, st));
+            FG_HIP_CHECK(hipStreamSynchronize(st));
+            if (first) {
+                float worst = 0.f;
+                for (int b = 0; b < B; ++b) {
+                    if (flux_host) flux_host[b] = s->diag_pinned[b];
+                    const float a = std::fabs(s->diag_pinned[b]);
+                    worst = (a > worst || a != a) ? a : worst;
+                }
+                if (!(worst <= o->flux_balance_tol)) {
+                    fg_set_error("Domain boundary fluxes not balanced, cannot proceed with simulation step.");
+                    return FG_ERR_FLUX_BALANCE;
+                }
+            }
+        }
+        for (int b = 0; b < B; ++b) {
+            float ts = 0.f;
+            if (!o->adaptive) {
+                ts = o->time_step;
+            } else if (t_rem[b] > 0 && !is_close_zero(t_rem[b])) {
+                const double mv = (double)s->diag_pinned[B + b];
+                const double max_ts = is_close_zero(mv) ? t_rem[b] : (double)o->cfl / mv;
+                double tsd;
+                if (max_ts >= t_rem[b]) tsd = t_rem[b];
+                else tsd = t_rem[b] / (double)(long long)std::ceil(t_rem[b] / max_ts);
+                t_rem[b] -= tsd;
+                ts = (float)tsd;  // the reference rounds ts through the domain dtype (PISOtorch_simulation.py:2029-2031)
+            }
+            s->dt_pinned[b] = ts;
+        }
+        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * B, hipMemcpyHostToDevice, st));
+        // PRE hook: advective outflow + flux re-balancing (cylinder_env_base.py:280-300)
+        if (o->outflow_mask) {
+            for (int f = 0; f < 2 * s->grid.dims; ++f)
+                if ((o->outflow_mask >> f) & 1) {
+                    FG_REQUIRE(s->grid.fixed[f], FG_ERR_INVALID_ARG, "outflow face is not FIXED");
+                    if (int rc = fg_launch_outflow(s, f, o->outflow_velm[f >> 1], s->dt_dev, st)) return rc;
+                }
+            if (int rc = fg_launch_balance(s, bnd, o->outflow_mask, 0.01f * o->outflow_tol, s->dt_dev, st)) return rc;
+        }
+        int rc = fg_piso_step(s, s->dt_dev, &o->step, stats, stream);
+        if (rc == FG_ERR_NOT_CONVERGED) all_ok = 0;
+        else if (rc != FG_OK) return rc;
+        // dt_pinned must not be rewritten before the H2D copy above has executed: fg_piso_step's solver polls
+        // synchronise the stream, so the copy is complete here.
+        ++substeps;
+        first = false;
+        if (!o->adaptive) --fixed_left;
+        if (substeps >= (o->max_substeps > 0 ? o->max_substeps : 100000)) break;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = stats[i];
+    out[4] = substeps;
+    out[5] = all_ok;
+    return FG_OK;
 }
 
 extern "C" int fg_make_divergence_free(fg_handle s, float tol, int max_iterations, fg_solve_info* info_host,

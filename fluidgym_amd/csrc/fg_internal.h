@@ -325,6 +325,8 @@ struct fg_state {
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
     float** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
     float* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
+    float* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
+    float* dt_dev;         // [B]
     int pred_bicg, pred_cg; // iterations the last solves needed (first convergence poll is scheduled there)
     const float* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     size_t n_cells() const { return (size_t)grid.n; }

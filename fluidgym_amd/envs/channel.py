@@ -130,20 +130,22 @@ class ChannelJetEnv2D(FluidEnv):
         self._sensor_idx = torch.from_numpy(flat).to(dev)
         self._hy = float(self.H / self._y)
 
-    def _get_prep_fn(self, domain: Domain) -> Dict[str, Any]:
-        def outflow(domain, time_step, **kw):
-            # advective outflow + flux re-balancing every substep (cylinder_env_base.py:280-300)
-            update_advective_boundaries(domain, [self._outflow], self._velm, time_step, tol=1e-5)
-
-        return {"PRE": [outflow]}
-
     def _get_simulation(self, domain: Domain, prep_fn: Dict[str, Any]) -> Simulation:
         return Simulation(
             domain=domain, prep_fn=prep_fn, substeps="ADAPTIVE", adaptive_CFL=self._adaptive_cfl, dt=self._dt,
             corrector_steps=2, pressure_tol=1e-5, advect_non_ortho_steps=1, pressure_non_ortho_steps=1,
             pressure_return_best_result=True, velocity_corrector="FD", non_orthogonal=True,
             solver_double_fallback=True,
+            # advective outflow + flux re-balancing every substep (cylinder_env_base.py:280-300)
+            outflow=([self._block_outflow(domain)], self._velm_host(), 1e-5),
         )
+
+    @staticmethod
+    def _block_outflow(domain):
+        return domain.getBlock(0).getBoundary("+x")
+
+    def _velm_host(self):
+        return np.array([self._U_mean, 0.0], dtype=np.float32)
 
     def _fill_initial_fields(self) -> None:
         """Developed-profile initial state: inflow profile everywhere, zero pressure, outflow = inflow."""

@@ -255,6 +255,37 @@ class NativeSolver:
         L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED,))
         return rc == L.FG_OK, list(stats)
 
+    def single_step(self, time_step, cfl, adaptive=True, substeps=1, flux_balance_tol=1e-5, outflow_faces=(),
+                    outflow_velm=(0.0, 0.0, 0.0), outflow_tol=1e-5, corrector_steps=2, advect_scalar=True,
+                    advection_tol=1e-5, pressure_tol=1e-5, max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0,
+                    method=None, pressure_warm_start=True, max_substeps=1000):
+        """Native ``Simulation.single_step``; returns (all_converged, solver_stats[4], substeps)."""
+        method = self.default_method if method is None else method
+        o = L.FgSimOptions()
+        o.step = L.FgStepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol, pressure_tol,
+                                 buoyancy_axis, buoyancy_factor, int(pressure_warm_start))
+        o.time_step, o.cfl, o.adaptive, o.substeps = float(time_step), float(cfl), int(adaptive), int(substeps)
+        o.flux_balance_tol = float(flux_balance_tol)
+        mask = 0
+        for f in outflow_faces:
+            mask |= 1 << int(f)
+        o.outflow_mask = mask
+        for i in range(3):
+            o.outflow_velm[i] = float(outflow_velm[i]) if i < len(outflow_velm) else 0.0
+        o.outflow_tol = float(outflow_tol)
+        o.max_substeps = int(max_substeps)
+        out = (ctypes.c_int32 * 6)()
+        flux = (ctypes.c_float * self.B)()
+        rc = self.lib.fg_single_step(self.handle, ctypes.byref(o), out, flux, _stream(self.device))
+        if rc == L.FG_ERR_FLUX_BALANCE:
+            raise RuntimeError(
+                "Domain boundary fluxes not balanced, cannot proceed with simulation step. "
+                f"Flux balance: {list(flux)}, flux_balance_tol: {flux_balance_tol}")
+        if rc == L.FG_ERR_NOT_FINITE:
+            raise LinsolveError("linear solve produced a non-finite residual")
+        L.check(rc)
+        return bool(out[5]), [int(out[i]) for i in range(4)], int(out[4])
+
     def reset_solver_state(self):
         L.check(self.lib.fg_reset_solver_state(self.handle, _stream(self.device)))
 

@@ -80,6 +80,7 @@ class Simulation:
         output_resampling_fill_max_steps: int = 0,
         buoyancy: Optional[tuple] = None,
         pressure_warm_start: bool = True,
+        outflow: Optional[tuple] = None,
         **_ignored: Any,
     ):
         if not isinstance(domain, Domain):
@@ -117,6 +118,19 @@ class Simulation:
         # its orthogonal branch starts from zero: PISOtorch_simulation.py:1878-1882 vs 1804-1812); the solve
         # converges to the same tolerance either way, in fewer iterations
         self.pressure_warm_start = bool(pressure_warm_start)
+        # (bounds, velm, tol): advective-outflow PRE hook of the cylinder/airfoil envs (PISOtorch_simulation.py:
+        # 228-393, wired in cylinder_env_base.py:280-300), kept as data so the native driver can run it
+        self.outflow = outflow
+        if outflow is not None:
+            bounds, velm, otol = outflow
+
+            def _outflow_hook(domain, time_step, **kw):
+                update_advective_boundaries(domain, list(bounds), velm, time_step, tol=otol)
+
+            self.prep_fn = {**self.prep_fn, "PRE": [_outflow_hook] + list(self.prep_fn.get("PRE", []))}
+            self._native_pre = _outflow_hook
+        else:
+            self._native_pre = None
         self.output_resampling_shape = output_resampling_shape
         self.output_resampling_fill_max_steps = output_resampling_fill_max_steps
         self.total_step = 0
@@ -144,6 +158,8 @@ class Simulation:
         """``Simulation.single_step`` (simulation.py:206-280)."""
         if static:
             raise NotImplementedError("advect_static is not on the env path")
+        if self._native_ok():
+            return self._single_step_native()
         # one device->host transfer for both per-step scalars (flux balance guard, simulation.py:223-231, and the
         # CFL velocity of the first substep, PISOtorch_simulation.py:2013-2014)
         balance, max_vel = self._solver.step_diagnostics()
@@ -165,6 +181,43 @@ class Simulation:
             _LOG.exception("Simulation failed in step (total step %d):", self.total_step)
             return False
         return ok
+
+    def _native_ok(self) -> bool:
+        """True when every registered hook has a native equivalent, i.e. the whole ``single_step`` (guard,
+        adaptive substeps, outflow hook, PISO step) can run inside ``fg_single_step`` without the interpreter."""
+        for k, fns in self.prep_fn.items():
+            for fn in fns:
+                if fn is not self._native_pre:
+                    return False
+        return self.substeps == -1 or self.substeps > 0
+
+    def _single_step_native(self) -> bool:
+        s = self._solver
+        bax, bfac = self.buoyancy if self.buoyancy is not None else (-1, 0.0)
+        faces, velm, otol = (), (0.0, 0.0, 0.0), 1e-5
+        if self.outflow is not None:
+            bounds, velm_t, otol = self.outflow
+            faces = [b.face for b in bounds]
+            velm = np.asarray(velm_t.detach().cpu() if isinstance(velm_t, torch.Tensor) else velm_t, dtype=np.float64).reshape(-1)
+        try:
+            ok, stats, n_sub = s.single_step(
+                self.time_step, self.adaptive_CFL, adaptive=(self.substeps == -1), substeps=max(self.substeps, 1),
+                flux_balance_tol=self.flux_balance_tol, outflow_faces=faces, outflow_velm=velm,
+                outflow_tol=get_solver_tolerance(otol), corrector_steps=self.corrector_steps,
+                advect_scalar=self.advect_passive_scalar and self.domain.hasPassiveScalar(),
+                advection_tol=get_solver_tolerance(self.advection_tol), pressure_tol=get_solver_tolerance(self.pressure_tol),
+                max_iterations=self.linear_solve_max_iterations, buoyancy_axis=bax, buoyancy_factor=bfac,
+                pressure_warm_start=self.pressure_warm_start)
+        except LinsolveError:
+            _LOG.exception("Simulation failed in step (total step %d):", self.total_step)
+            return False
+        self.last_stats, self.substep_count = stats, n_sub
+        self.total_step += n_sub
+        self.total_time += self.time_step if self.substeps == -1 else self.time_step * max(self.substeps, 1)
+        if not ok and not self.pressure_return_best_result:
+            _LOG.error("linear solve did not converge (iterations %s)", stats)
+            return False
+        return True
 
     def _PISO_adaptive_step(self, CFL_cond: Optional[float] = None, max_substeps: int = 1000) -> bool:
         """Per-env version of ``_PISO_adaptive_step`` (PISOtorch_simulation.py:2004-2064): before every

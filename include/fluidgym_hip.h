@@ -46,6 +46,7 @@ extern "C" {
 #define FG_ERR_UNSUPPORTED (-4)
 #define FG_ERR_NOT_CONVERGED (-5) /* informational: a solve hit max_iterations */
 #define FG_ERR_NOT_FINITE (-6)   /* a solver residual became NaN/Inf */
+#define FG_ERR_FLUX_BALANCE (-7) /* |sum of boundary fluxes| > flux_balance_tol (simulation.py:223-231) */
 
 /* boundary type of a face (reference BoundaryType::PERIODIC / FIXED, domain_structs_gpu.h:120-135) */
 #define FG_PERIODIC 0
@@ -181,6 +182,28 @@ typedef struct fg_step_options {
 } fg_step_options;
 int fg_piso_step(fg_handle h, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
                  void* stream);
+/* Simulation.single_step entirely on the native side (simulation.py:206-280 + _PISO_adaptive_step,
+ * PISOtorch_simulation.py:2004-2064): flux-balance guard, per-env adaptive substeps
+ * ts = t_rem / ceil(t_rem / (CFL / max_vel)) recomputed before every substep, the advective-outflow PRE
+ * hook (update_advective_boundaries + balance_boundary_fluxes, :228-393) and fg_piso_step per substep.
+ * One device->host read per substep (flux balance + max velocity), as in the reference, but no
+ * interpreter in the loop.  out_host: [0..3] max solver iterations {scalar, velocity, pressure0,
+ * pressure1} of the last substep, [4] substeps taken, [5] 1 if every solve converged;
+ * flux_balance_host (optional, B floats) receives the guard values. */
+typedef struct fg_sim_options {
+    fg_step_options step;
+    float time_step;          /* physical time advanced per call */
+    float cfl;                /* adaptive_CFL */
+    int32_t adaptive;         /* 1: substeps == -1 ("ADAPTIVE"); 0: `substeps` fixed steps of time_step */
+    int32_t substeps;
+    float flux_balance_tol;   /* 1e-5 */
+    int32_t outflow_mask;     /* bit f: FIXED face f is an advective outflow (0 = none) */
+    float outflow_velm[3];    /* characteristic velocity u_m */
+    float outflow_tol;        /* flux re-balancing triggers above 0.01 * outflow_tol */
+    int32_t max_substeps;     /* safety cap (reference warns above 1000) */
+} fg_sim_options;
+int fg_single_step(fg_handle h, const fg_sim_options* opt, int32_t* out_host_6, float* flux_balance_host,
+                   void* stream);
 /* make_divergence_free (PISOtorch_simulation.py:1320-1429) */
 int fg_make_divergence_free(fg_handle h, float tol, int max_iterations, fg_solve_info* info_host,
                             void* stream);

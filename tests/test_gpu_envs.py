@@ -80,7 +80,8 @@ def test_batched_env_equals_independent_envs():
     env1.close()
 
 
-def test_channel_driver_with_outflow_matches_oracle():
+@pytest.mark.parametrize("driver", ["native", "python_hooks"])
+def test_channel_driver_with_outflow_matches_oracle(driver):
     """Simulation.single_step (flux guard, adaptive CFL, native advective outflow + flux re-balancing, fused
     PISO step) against the oracle's restatement of the same sequence, 6 steps, per-env different inflow."""
     nx, ny, L, H, nu, dt, B = 48, 24, 6.0, 2.0, 0.02, 0.06, 2
@@ -106,8 +107,14 @@ def test_channel_driver_with_outflow_matches_oracle():
     def pre(domain, time_step, **kw):
         update_advective_boundaries(domain, [out], velm, time_step, tol=1e-5)
 
-    sim = Simulation(dom, dt=dt, substeps="ADAPTIVE", adaptive_CFL=0.5, prep_fn={"PRE": [pre]}, pressure_tol=1e-7,
-                     advection_tol=1e-7, pressure_return_best_result=True)
+    if driver == "native":  # whole single_step inside fg_single_step
+        sim = Simulation(dom, dt=dt, substeps="ADAPTIVE", adaptive_CFL=0.5, outflow=([out], velm, 1e-5), pressure_tol=1e-7,
+                         advection_tol=1e-7, pressure_return_best_result=True)
+        assert sim._native_ok()
+    else:  # interpreter-driven: hook closure + fused fg_piso_step per substep
+        sim = Simulation(dom, dt=dt, substeps="ADAPTIVE", adaptive_CFL=0.5, prep_fn={"PRE": [pre]}, pressure_tol=1e-7,
+                         advection_tol=1e-7, pressure_return_best_result=True)
+        assert not sim._native_ok()
     g = O.Grid(O.rectilinear_coords(edges))
     doms = []
     for b in range(B):
