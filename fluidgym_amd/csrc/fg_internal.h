@@ -117,10 +117,25 @@ __device__ __forceinline__ FgCtx<DIMS, VEC> fg_make_ctx(const FgGrid& g, int til
     const unsigned bid = fg_xcd_remap(blockIdx.x, gridDim.x);
     c.b = bid / tiles;
     int t = bid - c.b * tiles;
-    const int tix = t % tiles_x;
-    t /= tiles_x;
-    const int tiy = t % tiles_y;
-    const int tiz = t / tiles_y;
+    int tix, tiy, tiz;
+    if (DIMS == 3 && (tiles_y & 7) == 0 && gridDim.x == (unsigned)tiles) {
+        // One big env (e.g. 256^3): the XCD remap hands each XCD a contiguous eighth of the tile ids.  Order the
+        // ids [y-slab][z][y in slab][x] so that an XCD sweeps z inside a thin y-slab: the z-halo planes it
+        // re-reads one layer later are still in its 4 MiB L2 (PMC: 27 % over-fetch with the plain x,y,z order).
+        const int ys = tiles_y >> 3;
+        const int per_slab = tiles / 8, per_layer = tiles_x * ys;
+        const int slab = t / per_slab;
+        int r = t - slab * per_slab;
+        tiz = r / per_layer;
+        r -= tiz * per_layer;
+        tiy = slab * ys + r / tiles_x;
+        tix = r % tiles_x;
+    } else {
+        tix = t % tiles_x;
+        t /= tiles_x;
+        tiy = t % tiles_y;
+        tiz = t / tiles_y;
+    }
     const int tid = threadIdx.x;
     const int lx = tid % T::BX;
     const int ly = (tid / T::BX) % T::BY;
@@ -317,7 +332,7 @@ struct fg_state {
     int32_t* prof_active_pinned;
     double prof_ms[2];            // sum of sampled launch durations {k_cg_ap, k_cg_update}
     long long prof_n[2];
-    double prof_cells[2];         // sum over samples of cells actually processed (active envs * n)
+    double prof_cells[2];         // sum over samples of ALGORITHMIC BYTES actually processed (active envs * n * B/cell)
     double prof_full_ms[2];       // same, restricted to launches with every env active
     long long prof_full_n[2];
     double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
@@ -407,5 +422,13 @@ struct FgBicgArgs {
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
 
+// z-marching 3-D variants (fg_poisson3d.hip)
+bool fg_zmarch_ok(const fg_state* s, int* zc_out);
+int fg_zmarch_apply(const fg_state* s, const float* rA, const float* x, float* y, int zc, hipStream_t st);
+int fg_zmarch_relax(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew, float omega,
+                    int color, int zc, hipStream_t st);
+int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const float* p_in, float* p_out, float* Ap,
+                    double* acc, int32_t* flags, fg_solve_info* info, int32_t* prof_active, float tol, int it, int first,
+                    int ns, int num_base, int zc, hipStream_t st);
 int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

@@ -339,6 +339,8 @@ __global__ void k_zero_name(double* __restrict__ acc, int name, int B) {
 
 
 int fg_poisson_apply_launch(const fg_state* s, const float* rA, const float* x, float* y, hipStream_t st) {
+    int zc;
+    if (fg_zmarch_ok(s, &zc)) return fg_zmarch_apply(s, rA, x, y, zc, st);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_poisson_apply<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, rA, x, y, L.tiles_x,
@@ -350,6 +352,8 @@ int fg_poisson_apply_launch(const fg_state* s, const float* rA, const float* x, 
 
 int fg_poisson_jacobi_launch(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew,
                              float omega, hipStream_t st) {
+    int zc;
+    if (fg_zmarch_ok(s, &zc)) return fg_zmarch_relax(s, rA, b, x, xnew, omega, -1, zc, st);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_poisson_relax<DIMS, VEC, false>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, rA, b, x, xnew,
@@ -361,6 +365,8 @@ int fg_poisson_jacobi_launch(const fg_state* s, const float* rA, const float* b,
 
 int fg_poisson_rbgs_launch(const fg_state* s, const float* rA, const float* b, float* x, float omega, int color,
                            hipStream_t st) {
+    int zc;
+    if (fg_zmarch_ok(s, &zc)) return fg_zmarch_relax(s, rA, b, x, x, omega, color, zc, st);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_poisson_relax<DIMS, VEC, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, rA, b, x, x,
@@ -377,6 +383,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     float* pbuf[2] = {a.p, s->w[6]};
     int tiles_per_env = 1;
     FG_DISPATCH(s, { tiles_per_env = fg_launch_geometry<DIMS, VEC>(s->grid).tiles; });
+    int zc = 0;
+    const bool zmarch = fg_zmarch_ok(s, &zc);
     int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
     while (ns < FG_CG_SLOTS && tiles_per_env / ns > 256) ns *= 2;
     hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, B);
@@ -396,6 +404,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, st)) return rc;
     }
     bool done = false;
+    int sample_first[FG_PROF_SAMPLES] = {0};
     int next_poll = a.precond ? (s->pred_cg + 1 > 1 ? s->pred_cg + 1 : 1) : check_every;
     int n_samples = 0;
     if (s->prof_on) FG_HIP_CHECK(hipMemsetAsync(s->prof_active, 0, sizeof(int32_t) * FG_PROF_SAMPLES, st));
@@ -416,22 +425,32 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         const float* p_in = pbuf[(it + 1) & 1];
         float* p_out = pbuf[it & 1];
         // live timing samples: iteration 1 and every 8th iteration, both kernels bracketed by events
-        const bool sample = s->prof_on && !first && n_samples < FG_PROF_SAMPLES && (it == 1 || (it & 7) == 0);
+        const bool sample = s->prof_on && n_samples < FG_PROF_SAMPLES && (it <= 1 || (it & 7) == 0);
+        if (sample) sample_first[n_samples] = first;
         int32_t* pa = sample ? s->prof_active + n_samples : nullptr;
+        if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 0], st);
+        if (zmarch) {
+            if (int rc = fg_zmarch_cg_ap(s, a.rA, zvec, p_in, p_out, a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it,
+                                         first, ns, nb, zc, st))
+                return rc;
+        } else {
+            FG_DISPATCH(s, {
+                const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+                hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, zvec, p_in, p_out,
+                                   a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it, first, ns, nb, L.tiles_x,
+                                   L.tiles_y, L.tiles);
+            });
+        }
+        if (sample) {
+            (void)hipEventRecord(s->prof_ev[4 * n_samples + 1], st);
+            (void)hipEventRecord(s->prof_ev[4 * n_samples + 2], st);
+        }
         FG_DISPATCH(s, {
             const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-            if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 0], st);
-            hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, zvec, p_in, p_out,
-                               a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it, first, ns, nb, L.tiles_x,
-                               L.tiles_y, L.tiles);
-            if (sample) {
-                (void)hipEventRecord(s->prof_ev[4 * n_samples + 1], st);
-                (void)hipEventRecord(s->prof_ev[4 * n_samples + 2], st);
-            }
             hipLaunchKernelGGL((k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x, a.r,
                                s->cg_acc, s->flags, a.tol, it, ns, nb, L.tiles_x, L.tiles_y, L.tiles);
-            if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 3], st);
         });
+        if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 3], st);
         if (sample) ++n_samples;
         const bool poll = (it + 1 >= next_poll || it + 1 == a.max_iterations);
         if (poll) next_poll = it + 1 + check_every;
@@ -461,11 +480,12 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         const int act = s->prof_active_pinned[i];
         if (act <= 0) continue;  // every env had converged: the launch did no work
         if (hipEventElapsedTime(&ms, s->prof_ev[4 * i], s->prof_ev[4 * i + 1]) == hipSuccess) {
-            s->prof_ms[0] += ms; s->prof_n[0]++; s->prof_cells[0] += (double)act * n;
+            // algorithmic bytes of k_cg_ap: z, rA read + p, Ap written (+ p_in read unless it is the first iteration)
+            s->prof_ms[0] += ms; s->prof_n[0]++; s->prof_cells[0] += (double)act * n * (sample_first[i] ? 16.0 : 20.0);
             if (act == B) { s->prof_full_ms[0] += ms; s->prof_full_n[0]++; }
         }
         if (hipEventElapsedTime(&ms, s->prof_ev[4 * i + 2], s->prof_ev[4 * i + 3]) == hipSuccess) {
-            s->prof_ms[1] += ms; s->prof_n[1]++; s->prof_cells[1] += (double)act * n;
+            s->prof_ms[1] += ms; s->prof_n[1]++; s->prof_cells[1] += (double)act * n * 24.0;
             if (act == B) { s->prof_full_ms[1] += ms; s->prof_full_n[1]++; }
         }
     }

@@ -1,0 +1,453 @@
+// 3-D pressure-Poisson kernels with z-marching register planes + LDS x/y halo tiles (gfx950).
+//
+// The generic kernels of fg_poisson.hip give every workgroup a 64 x 4 x 4 brick; at 256^3 rocprofv3 PMC
+// showed 27-45 % more bytes fetched than the algorithm needs (profiles/r01_b_poisson256_pmc.csv): with
+// bricks 4 planes thick the z-halo planes are re-fetched after they have left the XCD's 4 MiB L2.
+// Here a workgroup owns a 64 (x) x 16 (y) tile and MARCHES over a chunk of ZC planes:
+//   * each field element is loaded from global memory once per workgroup (float4 per lane) and kept in
+//     registers for the three planes k-1, k, k+1 it contributes to (z neighbours never touch memory);
+//   * x / y neighbours of the current plane go through an LDS tile (18 x 68 floats per field, double
+//     buffered -> one barrier per plane); only the tile's 2 halo rows + 2 halo columns are extra loads;
+//   * the loads of plane k+2 are issued before plane k is consumed (software prefetch).
+// z-halo over-fetch drops from 2/4 to 2/ZC planes per brick.
+#include <math.h>
+#include <stdlib.h>
+
+#include "fg_internal.h"
+
+namespace {
+
+// Buffer-resource addressing (cdna_hip_programming.md T8): one 128-bit SGPR descriptor per field, a per-thread
+// 32-bit byte offset that never changes (vo_*) and the plane offset as the scalar soffset.  The flat-pointer
+// form needed a 64-bit VGPR pair + v_lshl_add_u64 per distinct address (48 of them in the ISA) and pushed the
+// kernel to 160+ VGPRs.
+#ifndef Z_STORE_AUX
+#define Z_STORE_AUX 0  // 2 = nt stores: +8 % on the one-shot apply but -12 % on Jacobi ping-pong (measured at 256^3)
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t z_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ FgVec<4> z_bload4(rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    FgVec<4> o;
+    o.v[0] = __uint_as_float(v.x); o.v[1] = __uint_as_float(v.y); o.v[2] = __uint_as_float(v.z); o.v[3] = __uint_as_float(v.w);
+    return o;
+}
+__device__ __forceinline__ float z_bload1(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void z_bstore4(rsrc_t r, unsigned voff, unsigned soff, const FgVec<4>& v) {
+    u32x4_t u;
+    u.x = __float_as_uint(v.v[0]); u.y = __float_as_uint(v.v[1]); u.z = __float_as_uint(v.v[2]); u.w = __float_as_uint(v.v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, Z_STORE_AUX);
+}
+
+// Tile shape: BXL lanes (x float4) along x, 256 / BXL rows along y.  64 x 16, 128 x 8 or 256 x 4 cells: wider
+// tiles make each wave-level access a longer contiguous run (256 B / 512 B / 1 KiB per row) at the price of
+// more y-halo rows per cell.
+template <int BXL>
+struct ZT {
+    static constexpr int TX = BXL * 4, TY = FG_BLOCK / BXL;
+    static constexpr int LP = TX + 8;     // LDS row pitch in floats: [3] left halo, [4 .. TX+3] cells (16-B aligned), [TX+4] right halo
+    static constexpr int LROWS = TY + 2;
+};
+
+struct FgCoefZ {
+    float xm[4], xp[4], ym[4], yp[4], zm[4], zp[4];
+};
+
+struct ZCtx {
+    int b, i0, j, k0, k1;                 // env, first cell of the vector, row, z range [k0, k1)
+    int lx, ly;
+    bool valid;                           // (i0, j) inside the grid
+    float mxm, mxp, mym, myp;             // x/y face masks of this thread's cells
+    int row_c, row_ym, row_yp;            // in-plane offsets (j * nx + i0) of the centre / y-neighbour rows
+    int col_xm, col_xp;                   // in-plane offsets of the x-halo cells (row j)
+};
+
+template <int BXL>
+__device__ __forceinline__ ZCtx z_make_ctx(const FgGrid& g, int tiles_x, int tiles_y, int zchunks, int ZC) {
+    constexpr int TX = ZT<BXL>::TX, TY = ZT<BXL>::TY;
+    ZCtx c;
+    const unsigned per_env = tiles_x * tiles_y * zchunks;
+    const unsigned bid = fg_xcd_remap(blockIdx.x, gridDim.x);
+    c.b = bid / per_env;
+    unsigned t = bid - c.b * per_env;
+    const int tix = t % tiles_x; t /= tiles_x;
+    const int tiy = t % tiles_y;
+    const int tz = t / tiles_y;
+    c.lx = threadIdx.x % BXL; c.ly = threadIdx.x / BXL;
+    c.i0 = tix * TX + c.lx * 4;
+    c.j = tiy * TY + c.ly;
+    c.k0 = tz * ZC;
+    c.k1 = min(c.k0 + ZC, g.nz);
+    c.valid = (c.i0 < g.nx) && (c.j < g.ny);
+    const int i0 = c.valid ? c.i0 : 0, j = c.valid ? c.j : 0;
+    const bool at_xm = (i0 == 0), at_xp = (i0 + 4 == g.nx), at_ym = (j == 0), at_yp = (j == g.ny - 1);
+    c.mxm = (at_xm && g.fixed[0]) ? 0.f : 1.f;
+    c.mxp = (at_xp && g.fixed[1]) ? 0.f : 1.f;
+    c.mym = (at_ym && g.fixed[2]) ? 0.f : 1.f;
+    c.myp = (at_yp && g.fixed[3]) ? 0.f : 1.f;
+    c.row_c = j * g.nx + i0;
+    c.row_ym = (at_ym ? (g.fixed[2] ? j : g.ny - 1) : j - 1) * g.nx + i0;
+    c.row_yp = (at_yp ? (g.fixed[3] ? j : 0) : j + 1) * g.nx + i0;
+    c.col_xm = j * g.nx + (at_xm ? (g.fixed[0] ? i0 : g.nx - 1) : i0 - 1);
+    c.col_xp = j * g.nx + (at_xp ? (g.fixed[1] ? i0 + 3 : 0) : i0 + 4);
+    return c;
+}
+
+__device__ __forceinline__ int z_plane(const FgGrid& g, int k) {  // plane index with periodic wrap / clamp
+    if (k < 0) return g.fixed[4] ? 0 : g.nz - 1;
+    if (k >= g.nz) return g.fixed[5] ? g.nz - 1 : 0;
+    return k;
+}
+
+// Halo duty of a thread: ly == 0 / TY-1 fetch the y-halo row segment above / below the tile, lx == 0 / 15 the
+// x-halo cell left / right of their row.  Halos are PREFETCHED one plane ahead into registers (Halo), so the
+// LDS fill of plane k never waits on memory.
+struct Halo {
+    FgVec<4> y;   // valid when ly == 0 or ly == TY-1
+    float x;      // valid when lx == 0 or lx == 15
+};
+
+template <int BXL>
+__device__ __forceinline__ Halo z_load_halo(const ZCtx& c, rsrc_t r, unsigned vo_hy, unsigned vo_hx, unsigned soff) {
+    constexpr int TY = ZT<BXL>::TY;
+    Halo h;
+    h.x = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h.y.v[e] = 0.f;
+    if (c.ly == 0 || c.ly == TY - 1) h.y = z_bload4(r, vo_hy, soff);
+    if (c.lx == 0 || c.lx == BXL - 1) h.x = z_bload1(r, vo_hx, soff);
+    return h;
+}
+template <int BXL>
+__device__ __forceinline__ void z_fill_tile(float* __restrict__ tile, const ZCtx& c, const FgVec<4>& ctr, const Halo& h) {
+    constexpr int TY = ZT<BXL>::TY, LP = ZT<BXL>::LP;
+    float* row = tile + (c.ly + 1) * LP + 4 + c.lx * 4;
+    *reinterpret_cast<float4*>(row) = make_float4(ctr.v[0], ctr.v[1], ctr.v[2], ctr.v[3]);
+    if (c.ly == 0) *reinterpret_cast<float4*>(row - LP) = make_float4(h.y.v[0], h.y.v[1], h.y.v[2], h.y.v[3]);
+    if (c.ly == TY - 1) *reinterpret_cast<float4*>(row + LP) = make_float4(h.y.v[0], h.y.v[1], h.y.v[2], h.y.v[3]);
+    if (c.lx == 0) row[-1] = h.x;
+    if (c.lx == BXL - 1) row[4] = h.x;
+}
+
+// metrics of the thread's cells for plane k (x/y parts are loop invariant)
+__device__ __forceinline__ void z_metrics(const FgGrid& g, const ZCtx& c, FgMetric<3, 4>& m) {
+    const int i0 = c.valid ? c.i0 : 0, j = c.valid ? c.j : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m.hx[e] = g.h[0][i0 + e]; m.rhx[e] = g.rh[0][i0 + e]; }
+    m.rhx_m = g.rh[0][(i0 == 0) ? g.nx - 1 : i0 - 1];
+    m.rhx_p = g.rh[0][(i0 + 4 == g.nx) ? 0 : i0 + 4];
+    m.hy = g.h[1][j]; m.rhy = g.rh[1][j];
+    m.rhy_m = g.rh[1][(j == 0) ? g.ny - 1 : j - 1];
+    m.rhy_p = g.rh[1][(j == g.ny - 1) ? 0 : j + 1];
+}
+__device__ __forceinline__ void z_metrics_plane(const FgGrid& g, int k, FgMetric<3, 4>& m, FgCtx<3, 4>& fc) {
+    m.hz = g.h[2][k]; m.rhz = g.rh[2][k];
+    m.rhz_m = g.rh[2][(k == 0) ? g.nz - 1 : k - 1];
+    m.rhz_p = g.rh[2][(k == g.nz - 1) ? 0 : k + 1];
+    fc.mzm = (k == 0 && g.fixed[4]) ? 0.f : 1.f;
+    fc.mzp = (k == g.nz - 1 && g.fixed[5]) ? 0.f : 1.f;
+}
+
+enum { MODE_APPLY = 0, MODE_RELAX = 1, MODE_CG_AP = 2 };
+
+struct Z3Args {
+    const float* rA;      // [B,N]
+    const float* x;       // apply/relax: x ; cg_ap: z (preconditioned residual or r)
+    const float* x2;      // relax: b ; cg_ap: p_prev
+    float* y;             // apply: y ; relax: xnew ; cg_ap: p_out
+    float* y2;            // cg_ap: Ap
+    float omega; int color;           // relax (color < 0: Jacobi)
+    // cg_ap
+    double* acc; int32_t* flags; fg_solve_info* info; int32_t* prof_active;
+    float tol; int it; int first; int ns; int num_base;
+};
+
+__device__ __forceinline__ double* z_acc_ptr(double* acc, int b, int name) { return acc + ((size_t)b * 8 + name) * 64; }
+__device__ __forceinline__ double z_acc_total(const double* a, int ns) {
+    if (ns == 1) return a[0];
+    const int lane = threadIdx.x & 63;
+    double v = (lane < ns) ? a[lane] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int MODE, int BXL>
+__global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
+                                                              int ZC) {
+    constexpr int TY = ZT<BXL>::TY, LP = ZT<BXL>::LP, LROWS = ZT<BXL>::LROWS;
+    const ZCtx c = z_make_ctx<BXL>(g, tiles_x, tiles_y, zchunks, ZC);
+    float beta = 0.f;
+    bool use_prev = false;
+    unsigned tile_id = 0;
+    if constexpr (MODE == MODE_CG_AP) {
+        if (a.flags[c.b] != 0) return;
+        const unsigned per_env = tiles_x * tiles_y * zchunks;
+        tile_id = fg_xcd_remap(blockIdx.x, gridDim.x) % per_env;
+        const double rr_new = z_acc_total(z_acc_ptr(a.acc, c.b, a.it % 3), a.ns);
+        const float crit = (float)sqrt(rr_new / (double)g.n);
+        if (!(crit >= a.tol)) {
+            if (tile_id == 0 && threadIdx.x == 0) {
+                const bool finite = isfinite(crit);
+                a.flags[c.b] = finite ? 1 : 2;
+                a.info[c.b].final_residual = crit;
+                a.info[c.b].used_iterations = a.it - 1;
+                a.info[c.b].converged = finite ? 1 : 0;
+                a.info[c.b].is_finite = finite ? 1 : 0;
+            }
+            return;
+        }
+        const double num_new = (a.num_base == 0) ? rr_new : z_acc_total(z_acc_ptr(a.acc, c.b, a.num_base + a.it % 3), a.ns);
+        const double num_old = a.first ? 1.0 : z_acc_total(z_acc_ptr(a.acc, c.b, a.num_base + (a.it + 2) % 3), a.ns);
+        if (tile_id == 0 && threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            if (lane < a.ns) {
+                z_acc_ptr(a.acc, c.b, (a.it + 1) % 3)[lane] = 0.0;
+                if (a.num_base) z_acc_ptr(a.acc, c.b, a.num_base + (a.it + 1) % 3)[lane] = 0.0;
+            }
+            if (lane == 0) {
+                a.info[c.b].final_residual = crit;
+                a.info[c.b].used_iterations = a.it - 1;
+                if (a.prof_active) atomicAdd(a.prof_active, 1);
+            }
+        }
+        beta = a.first ? 0.f : (float)(num_new / num_old);
+        use_prev = !a.first;
+    }
+
+    // LDS ring of 3 planes per stencil field: planes k-1, k, k+1 are resident while plane k is computed, so the
+    // z neighbours are LDS reads too and a thread only holds the in-flight loads of plane k+2 in registers
+    // (register pressure decides occupancy here: the register-plane variant needed 164 VGPRs = 3 waves/SIMD).
+    __shared__ __attribute__((aligned(16))) float ring_p[3][LROWS * LP];
+    __shared__ __attribute__((aligned(16))) float ring_a[3][LROWS * LP];
+    __shared__ float red[4];
+
+    const size_t env = (size_t)c.b * g.n;
+    const unsigned plane_b = (unsigned)(g.nx * g.ny) * 4u;   // bytes per plane
+    const unsigned env_b = (unsigned)g.n * 4u;
+    const rsrc_t R_a = z_rsrc(a.rA + env, env_b);
+    const rsrc_t R_x = z_rsrc(a.x + env, env_b);
+    const rsrc_t R_x2 = z_rsrc(a.x2 ? a.x2 + env : a.x + env, env_b);
+    const rsrc_t R_y = z_rsrc(a.y + env, env_b);
+    const rsrc_t R_y2 = z_rsrc(a.y2 ? a.y2 + env : a.y + env, env_b);
+    const unsigned vo_c = (unsigned)c.row_c * 4u;
+    const unsigned vo_hy = (unsigned)((c.ly == 0) ? c.row_ym : c.row_yp) * 4u;
+    const unsigned vo_hx = (unsigned)((c.lx == 0) ? c.col_xm : c.col_xp) * 4u;
+    (void)TY;
+
+    FgMetric<3, 4> m;
+    z_metrics(g, c, m);
+    FgCtx<3, 4> fc;  // only the mask members are used
+    fc.mxm = c.mxm; fc.mxp = c.mxp; fc.mym = c.mym; fc.myp = c.myp;
+
+    struct Staged { FgVec<4> p, a; Halo hp, ha; };
+    auto stage = [&](int k) -> Staged {  // global loads of one plane (centre + this thread's halo duty)
+        Staged r;
+        const unsigned so = (unsigned)z_plane(g, k) * plane_b;
+        r.p = z_bload4(R_x, vo_c, so);
+        r.hp = z_load_halo<BXL>(c, R_x, vo_hy, vo_hx, so);
+        if constexpr (MODE == MODE_CG_AP) {
+            if (use_prev) {
+                const FgVec<4> w = z_bload4(R_x2, vo_c, so);
+                const Halo hw = z_load_halo<BXL>(c, R_x2, vo_hy, vo_hx, so);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r.p.v[e] += beta * w.v[e]; r.hp.y.v[e] += beta * hw.y.v[e]; }
+                r.hp.x += beta * hw.x;
+            }
+        }
+        r.a = z_bload4(R_a, vo_c, so);
+        r.ha = z_load_halo<BXL>(c, R_a, vo_hy, vo_hx, so);
+        return r;
+    };
+    auto commit = [&](int slot, const Staged& r) {
+        z_fill_tile<BXL>(ring_p[slot], c, r.p, r.hp);
+        z_fill_tile<BXL>(ring_a[slot], c, r.a, r.ha);
+    };
+    // prologue: planes k0-1, k0, k0+1 -> slots 0, 1, 2
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        const Staged sq = stage(c.k0 - 1 + q);
+        commit(q, sq);
+    }
+    FgVec<4> bvec;
+    if constexpr (MODE == MODE_RELAX) bvec = z_bload4(R_x2, vo_c, (unsigned)c.k0 * plane_b);
+    __syncthreads();
+    float dot = 0.f;
+    const int cen = (c.ly + 1) * LP + 4 + c.lx * 4;  // LDS offset of this thread's centre vector
+    int sm = 0, sc = 1, sp = 2;                       // ring slots of planes k-1, k, k+1
+#pragma unroll 1
+    for (int k = c.k0; k < c.k1; ++k) {
+        // ---- prefetch plane k+2 (consumed after this plane's arithmetic) and b of plane k+1
+        const bool more = (k + 1 < c.k1);
+        Staged nxt;
+        FgVec<4> bnext;
+        if (more) {
+            nxt = stage(k + 2);
+            if constexpr (MODE == MODE_RELAX) bnext = z_bload4(R_x2, vo_c, (unsigned)(k + 1) * plane_b);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- plane k from the LDS ring
+        z_metrics_plane(g, k, m, fc);
+        const float4 P_c = *reinterpret_cast<const float4*>(&ring_p[sc][cen]);
+        const float4 A_c = *reinterpret_cast<const float4*>(&ring_a[sc][cen]);
+        float pcv[4] = {P_c.x, P_c.y, P_c.z, P_c.w};
+        float acv[4] = {A_c.x, A_c.y, A_c.z, A_c.w};
+        float y[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
+        {   // x faces
+            const float pl = ring_p[sc][cen - 1], pr = ring_p[sc][cen + 4];
+            const float al = ring_a[sc][cen - 1], ar = ring_a[sc][cen + 4];
+            const float ayz = m.hy * m.hz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float rh_lo = (e == 0) ? m.rhx_m : m.rhx[e > 0 ? e - 1 : 0];
+                const float rh_hi = (e == 3) ? m.rhx_p : m.rhx[e < 3 ? e + 1 : 3];
+                const float ml = (e == 0) ? fc.mxm : 1.f, mh = (e == 3) ? fc.mxp : 1.f;
+                const float apx = ayz * m.rhx[e] * acv[e];
+                const float cl = ml * 0.5f * (apx + ayz * rh_lo * ((e == 0) ? al : acv[e > 0 ? e - 1 : 0]));
+                const float cr = mh * 0.5f * (apx + ayz * rh_hi * ((e == 3) ? ar : acv[e < 3 ? e + 1 : 3]));
+                y[e] += cl * (((e == 0) ? pl : pcv[e > 0 ? e - 1 : 0]) - pcv[e]) + cr * (((e == 3) ? pr : pcv[e < 3 ? e + 1 : 3]) - pcv[e]);
+                dg[e] -= cl + cr;
+            }
+        }
+        {   // y faces
+            const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sc][cen - LP]);
+            const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sc][cen + LP]);
+            const float4 Am = *reinterpret_cast<const float4*>(&ring_a[sc][cen - LP]);
+            const float4 Ap = *reinterpret_cast<const float4*>(&ring_a[sc][cen + LP]);
+            const float pm_[4] = {Pm.x, Pm.y, Pm.z, Pm.w}, pp_[4] = {Pp.x, Pp.y, Pp.z, Pp.w};
+            const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float axz = m.hx[e] * m.hz;
+                const float apy = axz * m.rhy * acv[e];
+                const float cl = fc.mym * 0.5f * (apy + axz * m.rhy_m * am_[e]);
+                const float cr = fc.myp * 0.5f * (apy + axz * m.rhy_p * ap_[e]);
+                y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
+                dg[e] -= cl + cr;
+            }
+        }
+        {   // z faces
+            const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sm][cen]);
+            const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sp][cen]);
+            const float4 Am = *reinterpret_cast<const float4*>(&ring_a[sm][cen]);
+            const float4 Ap = *reinterpret_cast<const float4*>(&ring_a[sp][cen]);
+            const float pm_[4] = {Pm.x, Pm.y, Pm.z, Pm.w}, pp_[4] = {Pp.x, Pp.y, Pp.z, Pp.w};
+            const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float axy = m.hx[e] * m.hy;
+                const float apz = axy * m.rhz * acv[e];
+                const float cl = fc.mzm * 0.5f * (apz + axy * m.rhz_m * am_[e]);
+                const float cr = fc.mzp * 0.5f * (apz + axy * m.rhz_p * ap_[e]);
+                y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
+                dg[e] -= cl + cr;
+            }
+        }
+        FgVec<4> out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (MODE == MODE_RELAX) {
+                float v = pcv[e] + a.omega * (bvec.v[e] - y[e]) / dg[e];
+                if (a.color >= 0 && (((c.i0 + e + c.j + k) & 1) != a.color)) v = pcv[e];
+                out.v[e] = v;
+            } else {
+                out.v[e] = y[e];
+                if constexpr (MODE == MODE_CG_AP) dot += pcv[e] * y[e];
+            }
+        }
+        if (c.valid) {
+            const unsigned so = (unsigned)k * plane_b;
+            if constexpr (MODE == MODE_CG_AP) {
+                z_bstore4(R_y2, vo_c, so, out);  // Ap
+                FgVec<4> pc_;
+                pc_.v[0] = pcv[0]; pc_.v[1] = pcv[1]; pc_.v[2] = pcv[2]; pc_.v[3] = pcv[3];
+                z_bstore4(R_y, vo_c, so, pc_);   // p
+            } else {
+                z_bstore4(R_y, vo_c, so, out);
+            }
+        }
+        if (!more) break;
+        __syncthreads();            // every wave is done reading slot sm (plane k-1)
+        commit(sm, nxt);            // plane k+2 takes its place
+        __syncthreads();
+        const int t3 = sm; sm = sc; sc = sp; sp = t3;
+        if constexpr (MODE == MODE_RELAX) bvec = bnext;
+    }
+    if constexpr (MODE == MODE_CG_AP) {
+        float part[1] = {c.valid ? dot : 0.f};
+        fg_block_sum<1>(part, red);
+        if (threadIdx.x == 0) atomicAdd(z_acc_ptr(a.acc, c.b, 3 + (a.it & 1)) + (tile_id & (unsigned)(a.ns - 1)), (double)part[0]);
+    }
+}
+
+}  // namespace
+
+// geometry -----------------------------------------------------------------------------------------
+static int z_shape() {  // lanes along x: 16 (64 x 16 tile), 32 (128 x 8), 64 (256 x 4); FG_ZMARCH_BXL overrides
+    static const int v = [] { const char* e = getenv("FG_ZMARCH_BXL"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static int z_pick_bxl(const FgGrid& g) {
+    const int forced = z_shape();
+    if (forced == 16 || forced == 32 || forced == 64) return forced;
+    // widest tile the grid is a multiple of: 256 x 4 measured best at 256^3 (1 KiB contiguous per wave access)
+    if (g.nx % 256 == 0 && g.ny % 4 == 0) return 64;
+    if (g.nx % 128 == 0 && g.ny % 8 == 0) return 32;
+    return 16;
+}
+
+bool fg_zmarch_ok(const fg_state* s, int* zc_out) {
+    const FgGrid& g = s->grid;
+    const int bxl = z_pick_bxl(g);
+    const int TX = bxl * 4, TY = FG_BLOCK / bxl;
+    // tiles must coincide with the grid (every thread valid; halo loaders handle wrap / clamp at tile edges)
+    if (g.dims != 3 || s->vec != 4 || g.nz < 32 || (g.nx % TX) != 0 || (g.ny % TY) != 0) return false;
+    const int tiles = (g.nx / TX) * (g.ny / TY);
+    static const int force = [] { const char* e = getenv("FG_FORCE_ZMARCH"); return e ? atoi(e) : 0; }();
+    if (force < 0) return false;            // FG_FORCE_ZMARCH=-1: always use the generic brick kernels
+    if (force > 0) { *zc_out = force; return true; }  // FG_FORCE_ZMARCH=ZC: tests exercise small grids
+    int zc = 32;
+    while (zc > 8 && (long)tiles * ((g.nz + zc - 1) / zc) * g.B < 2048) zc /= 2;  // >= 8 workgroups per CU
+    if ((long)tiles * ((g.nz + zc - 1) / zc) * g.B < 512) return false;
+    *zc_out = zc;
+    return true;
+}
+
+template <int MODE>
+static int launch_march(const fg_state* s, const Z3Args& a, int zc, hipStream_t st) {
+    const FgGrid& g = s->grid;
+    const int bxl = z_pick_bxl(g);
+    const int tx = g.nx / (bxl * 4), ty = g.ny / (FG_BLOCK / bxl), zch = (g.nz + zc - 1) / zc;
+    dim3 grid((unsigned)(tx * ty * zch * g.B));
+    if (bxl == 16) hipLaunchKernelGGL((k_poisson3_march<MODE, 16>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    else if (bxl == 32) hipLaunchKernelGGL((k_poisson3_march<MODE, 32>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    else hipLaunchKernelGGL((k_poisson3_march<MODE, 64>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_zmarch_apply(const fg_state* s, const float* rA, const float* x, float* y, int zc, hipStream_t st) {
+    Z3Args a = {};
+    a.rA = rA; a.x = x; a.y = y;
+    return launch_march<MODE_APPLY>(s, a, zc, st);
+}
+int fg_zmarch_relax(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew, float omega,
+                    int color, int zc, hipStream_t st) {
+    Z3Args a = {};
+    a.rA = rA; a.x = x; a.x2 = b; a.y = xnew; a.omega = omega; a.color = color;
+    return launch_march<MODE_RELAX>(s, a, zc, st);
+}
+int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const float* p_in, float* p_out, float* Ap,
+                    double* acc, int32_t* flags, fg_solve_info* info, int32_t* prof_active, float tol, int it, int first,
+                    int ns, int num_base, int zc, hipStream_t st) {
+    Z3Args a = {};
+    a.rA = rA; a.x = z; a.x2 = p_in; a.y = p_out; a.y2 = Ap;
+    a.acc = acc; a.flags = flags; a.info = info; a.prof_active = prof_active;
+    a.tol = tol; a.it = it; a.first = first; a.ns = ns; a.num_base = num_base;
+    return launch_march<MODE_CG_AP>(s, a, zc, st);
+}

@@ -320,11 +320,11 @@ class NativeSolver:
         L.check(self.lib.fg_profile_enable(self.handle, int(on)))
 
     def profile_read(self):
-        """Per CG kernel {k_cg_ap, k_cg_update}: dict(ms, samples, cells, full_ms, full_samples)."""
+        """Per CG kernel {k_cg_ap, k_cg_update}: dict(ms, samples, bytes (algorithmic), full_ms, full_samples)."""
         ms, cells, fms = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
         n, fn = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
         L.check(self.lib.fg_profile_read(self.handle, ms, n, cells, fms, fn))
-        return [dict(ms=ms[i], samples=int(n[i]), cells=cells[i], full_ms=fms[i], full_samples=int(fn[i])) for i in (0, 1)]
+        return [dict(ms=ms[i], samples=int(n[i]), bytes=cells[i], full_ms=fms[i], full_samples=int(fn[i])) for i in (0, 1)]
 
     def poisson_fdcg(self, rA, b, x, tol=1e-5, max_iterations=500, use_x0=False):
         info = self._infos(self.B)

@@ -246,11 +246,11 @@ int fg_poisson_fdcg(fg_handle h, const float* rA, const float* b, float* x, floa
  * When enabled, every CG solve brackets up to 16 launches of each of its two kernels (iteration 1 and
  * every 8th iteration) with HIP events on the solve's stream and has the kernel count the envs that
  * were still iterating in that launch.  fg_profile_read returns, per kernel {0: CG kernel 1 (p update
- * + P p + dot), 1: CG kernel 2 (x, r update + dot)}: summed milliseconds, sample count, summed cells
- * actually processed (active envs x cells/env), and the same restricted to launches in which every
- * env was active; then resets the counters. */
+ * + P p + dot), 1: CG kernel 2 (x, r update + dot)}: summed milliseconds, sample count, summed algorithmic
+ * bytes actually processed (active envs x cells/env x 16|20 resp. 24 B/cell), and the time restricted to
+ * launches in which every env was active; then resets the counters. */
 int fg_profile_enable(fg_handle h, int on);
-int fg_profile_read(fg_handle h, double* ms_sum_2, int64_t* samples_2, double* cells_sum_2, double* full_ms_sum_2,
+int fg_profile_read(fg_handle h, double* ms_sum_2, int64_t* samples_2, double* bytes_sum_2, double* full_ms_sum_2,
                     int64_t* full_samples_2);
 
 /* ---- grid metrics --------------------------------------------------------------------------- */

@@ -326,3 +326,53 @@ def test_fd_preconditioner_matches_numpy_application():
         z = fd.apply(r[b].astype(np.float64)) / 0.5
         got = _np(x[b])
         assert rel_err(got - got.mean(), z - z.mean()) < 2e-5
+
+
+@pytest.mark.parametrize("shape,fixed,zc", [((64, 32, 32), (1,), 8), ((128, 16, 40), (0, 1, 2), 16), ((64, 16, 33), (1, 2), 32)])
+def test_zmarch_3d_kernels_match_brick_kernels_and_oracle(shape, fixed, zc):
+    """The z-marching LDS/register-plane variants (fg_poisson3d.hip) against the oracle matrix: apply, Jacobi,
+    RB-GS and the CG solve.  FG_FORCE_ZMARCH makes small grids take the path that 256^3 takes by itself."""
+    import os
+    import subprocess
+    import sys
+
+    code = f"""
+import numpy as np, torch, sys
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from oracle import piso_oracle as O
+from tests.helpers import make_case, rel_err
+case = make_case(dims=3, n={shape}, fixed_axes={fixed}, B=2, seed=5, stretch=0.3)
+ns = case.native(); g = case.grid()
+rng = np.random.default_rng(1)
+rA = rng.uniform(0.6, 1.4, size=(2,) + case.shape).astype(np.float32)
+x0 = rng.standard_normal((2,) + case.shape).astype(np.float32)
+b_ = rng.standard_normal((2,) + case.shape); b_ -= b_.mean(axis=(1,2,3), keepdims=True); b_ = b_.astype(np.float32)
+d = lambda a: torch.from_numpy(a).cuda()
+y = ns.poisson_apply(d(rA), d(x0))
+xj = d(x0.copy()); ns.poisson_jacobi(d(rA), d(b_), xj, sweeps=3, omega=0.8)
+xg = d(x0.copy()); ns.poisson_rbgs(d(rA), d(b_), xg, sweeps=2, omega=1.0)
+xc = torch.zeros_like(xj); info = ns.poisson_cg(d(rA), d(b_), xc, tol=1e-6)
+torch.cuda.synchronize()
+idx = np.indices(case.shape).sum(axis=0).ravel()
+for b in range(2):
+    dom = case.oracle_domain(0, g)
+    P, _, _ = O.build_pressure_matrix(dom, 1.0 / rA[b].astype(np.float64)); P = P.tocsr(); D = P.diagonal()
+    ref = P @ x0[b].astype(np.float64).ravel()
+    assert rel_err(y[b].cpu().numpy().astype(np.float64).ravel(), ref) < 1e-5, "apply"
+    x = x0[b].astype(np.float64).ravel(); bb = b_[b].astype(np.float64).ravel()
+    for _ in range(3): x = x + 0.8 * (bb - P @ x) / D
+    assert rel_err(xj[b].cpu().numpy().astype(np.float64).ravel(), x) < 1e-5, "jacobi"
+    x = x0[b].astype(np.float64).ravel()
+    for _ in range(2):
+        for color in (0, 1):
+            m = (idx & 1) == color; r = (bb - P @ x) / D; x[m] = x[m] + r[m]
+    assert rel_err(xg[b].cpu().numpy().astype(np.float64).ravel(), x) < 1e-5, "rbgs"
+    assert info[b].converged
+    got = xc[b].cpu().numpy().astype(np.float64).ravel()
+    res = bb - P @ got   # (no 3-D direct solve: residual of the GPU solution under the ORACLE's matrix)
+    assert np.sqrt((res ** 2).mean()) < 1e-5, "cg"
+print("OK")
+"""
+    env = dict(os.environ, FG_FORCE_ZMARCH=str(zc))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
