@@ -11,7 +11,6 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 16;
 
 struct GemmArgs {
     const float* A; long lda; long strideA;   // [M x K] row-major, per batch (stride 0 = shared)
@@ -26,8 +25,11 @@ struct GemmArgs {
 // C = A * B, fp32 in / fp32 accumulate on MFMA 32x32x2.  256 threads = 4 waves in a 2 x 2 arrangement,
 // each wave owns TM x TN MFMA tiles of 32 x 32 (TM = TN = 2: 128 x 128 block tile, 64 accumulator
 // registers; TM = TN = 1: 64 x 64 block tile for launches that would otherwise leave CUs idle).
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    // BK = K-depth staged per barrier pair.  The small launches of the batched 2-D case are latency-bound
+    // (one L2 round trip per K-step, only 8 MFMAs per wave to cover it), so they use BK = 64: 4x fewer steps,
+    // 4x more bytes in flight per step.
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int LDA_S = BM + 4, LDB_S = BN + 4;  // LDS row pitch; +4 floats keeps 16-B alignment, breaks conflicts
     constexpr int PA = BM * BK / 256, PB = BN * BK / 256;  // floats staged per thread (8 or 4)
@@ -56,7 +58,25 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     const int a_row = tid / A_TPR, a_k = (tid % A_TPR) * PA;
     const int b_k = tid / B_TPR, b_n = (tid % B_TPR) * PB;
     float ra[PA], rb[PB];
+    // fast path: tile fully inside the matrices and rows 16-B aligned -> float4 loads
+    const bool vec_ok = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (g.K % BK == 0) && ((g.lda & 3) == 0) && ((g.ldb & 3) == 0) &&
+                        ((reinterpret_cast<size_t>(A) & 15) == 0) && ((reinterpret_cast<size_t>(B) & 15) == 0);
     auto load_tiles = [&](int k0) {
+        if (vec_ok) {
+            const float4* pa = reinterpret_cast<const float4*>(A + (size_t)(m0 + a_row) * g.lda + k0 + a_k);
+#pragma unroll
+            for (int q = 0; q < PA; q += 4) {
+                const float4 v = pa[q >> 2];
+                ra[q] = v.x; ra[q + 1] = v.y; ra[q + 2] = v.z; ra[q + 3] = v.w;
+            }
+            const float4* pb = reinterpret_cast<const float4*>(B + (size_t)(k0 + b_k) * g.ldb + n0 + b_n);
+#pragma unroll
+            for (int q = 0; q < PB; q += 4) {
+                const float4 v = pb[q >> 2];
+                rb[q] = v.x; rb[q + 1] = v.y; rb[q + 2] = v.z; rb[q + 3] = v.w;
+            }
+            return;
+        }
         const int gm = m0 + a_row;
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
@@ -122,66 +142,73 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     }
 }
 
-// Thomas sweep along y for every mode, in place: forward y_j = (b_j - l_j y_{j-1}) inv_j, backward
+// Thomas sweep along y for every mode: forward y_j = (b_j - l_j y_{j-1}) inv_j, backward
 // x_j = y_j - c'_j x_{j+1}.  One thread per (env, z-mode, x-mode); x-mode is the fastest index so every
-// step is a coalesced row access.  The recurrence is latency-bound (one wave per CU at batch 64), so rows
-// are fetched in chunks of TRI_CH one chunk ahead of the arithmetic (register double buffer).
-constexpr int TRI_CH = 8;
-__global__ __launch_bounds__(256) void k_tridiag_y(float* __restrict__ x, const float* __restrict__ inv,
-                                                    const float* __restrict__ cp, const float* __restrict__ lower,
-                                                    const int32_t* __restrict__ flags, int nx, int ny, int nz) {
+// step is a coalesced row access.  The intermediate y_j stay in LDS ([j][lane], conflict-free), so the global
+// traffic is: read b, inv, c' once (prefetched TRI_CH rows ahead of the recurrence), write x once -- no global
+// store sits between a load and its use (the in-place global variant spent ~170 ns per recurrence step).
+constexpr int TRI_CH = 16;
+// Row indices are CLAMPED instead of branched on: every load of a chunk is straight-line code, so the compiler
+// can keep the next chunk in flight with counted s_waitcnt (the branchy form compiled to 36 x vmcnt(0) drains).
+__global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const float* __restrict__ inv,
+                                                   const float* __restrict__ cp, const float* __restrict__ lower,
+                                                   const int32_t* __restrict__ flags, int nx, int ny, int nz) {
+    extern __shared__ __attribute__((aligned(16))) float ybuf[];  // [ny_padded][64]
     const int b = blockIdx.y;
     if (flags && flags[b] != 0) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nx * nz) return;
+    const int lane = threadIdx.x;
+    int t = blockIdx.x * 64 + lane;
+    const bool live = t < nx * nz;
+    if (!live) t = nx * nz - 1;
     const int a = t % nx, c = t / nx;
     const size_t col = (size_t)c * ny * nx + a;
-    float* xb = x + (size_t)b * nx * ny * nz + col;
+    float* __restrict__ xb = x + (size_t)b * nx * ny * nz + col;
     const float* __restrict__ iv = inv + col;
     const float* __restrict__ cpp = cp + col;
-    float cx[TRI_CH], ci[TRI_CH], nxv[TRI_CH], niv[TRI_CH];
-    auto fetch = [&](int j0, float (&vx)[TRI_CH], float (&vi)[TRI_CH], const float* __restrict__ coef) {
+    const int last = ny - 1;
+    float cx[TRI_CH], ci[TRI_CH], cl[TRI_CH], nxv[TRI_CH], niv[TRI_CH], nlv[TRI_CH];
+    // ---- forward elimination: y_j = (b_j - l_j y_{j-1}) inv_j ; y to LDS
 #pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) {
-            const int j = j0 + q;
-            const bool ok = (j >= 0) && (j < ny);
-            const size_t o = (size_t)(ok ? j : 0) * nx;
-            vx[q] = ok ? xb[o] : 0.f;
-            vi[q] = ok ? coef[o] : 0.f;
-        }
-    };
-    // ---- forward elimination
-    float prev = 0.f;
-    fetch(0, cx, ci, iv);
-    for (int j0 = 0; j0 < ny; j0 += TRI_CH) {
-        fetch(j0 + TRI_CH, nxv, niv, iv);
-#pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) {
-            const int j = j0 + q;
-            if (j < ny) {
-                prev = (cx[q] - lower[j] * prev) * ci[q];
-                xb[(size_t)j * nx] = prev;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) { cx[q] = nxv[q]; ci[q] = niv[q]; }
+    for (int q = 0; q < TRI_CH; ++q) {
+        const int j = min(q, last);
+        cx[q] = xb[(size_t)j * nx]; ci[q] = iv[(size_t)j * nx]; cl[q] = lower[j];
     }
-    // ---- back substitution (prev = x_{ny-1}); chunks walk downwards, element q of a chunk is row j0 + q
-    const int last = ny - 2;
-    int j0 = (last / TRI_CH) * TRI_CH;
-    if (last >= 0) fetch(j0, cx, ci, cpp);
-    for (; j0 >= 0; j0 -= TRI_CH) {
-        fetch(j0 - TRI_CH, nxv, niv, cpp);
+    float prev = 0.f;
+    for (int j0 = 0; j0 < ny; j0 += TRI_CH) {
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) {
+            const int j = min(j0 + TRI_CH + q, last);
+            nxv[q] = xb[(size_t)j * nx]; niv[q] = iv[(size_t)j * nx]; nlv[q] = lower[j];
+        }
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) {
+            const float v = (cx[q] - cl[q] * prev) * ci[q];
+            prev = (j0 + q <= last) ? v : prev;     // rows past the end keep the last value (select, no branch)
+            ybuf[(j0 + q) * 64 + lane] = prev;      // LDS is padded to a multiple of TRI_CH rows
+        }
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) { cx[q] = nxv[q]; ci[q] = niv[q]; cl[q] = nlv[q]; }
+    }
+    // ---- back substitution: x_last = y_last ; x_j = y_j - c'_j x_{j+1}
+    // (c'_last = 0 in the factor table, so starting one row early with prev = 0 reproduces x_last = y_last)
+    prev = 0.f;
+    const int top = ((ny + TRI_CH - 1) / TRI_CH) * TRI_CH - TRI_CH;  // first row of the last chunk
+#pragma unroll
+    for (int q = 0; q < TRI_CH; ++q) ci[q] = cpp[(size_t)min(top + q, last) * nx];
+    for (int j0 = top; j0 >= 0; j0 -= TRI_CH) {
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) niv[q] = cpp[(size_t)max(j0 - TRI_CH + q, 0) * nx];
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) cx[q] = ybuf[(j0 + q) * 64 + lane];
 #pragma unroll
         for (int q = TRI_CH - 1; q >= 0; --q) {
             const int j = j0 + q;
-            if (j <= last) {
-                prev = cx[q] - ci[q] * prev;
-                xb[(size_t)j * nx] = prev;
-            }
+            const float v = cx[q] - ci[q] * prev;
+            prev = (j <= last) ? v : prev;
+            if (live && j <= last) xb[(size_t)j * nx] = prev;
         }
 #pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) { cx[q] = nxv[q]; ci[q] = niv[q]; }
+        for (int q = 0; q < TRI_CH; ++q) ci[q] = niv[q];
     }
 }
 
@@ -191,10 +218,10 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     const long big_blocks = (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * batch;
     if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
-        hipLaunchKernelGGL((k_gemm_f32<2, 2>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
-        hipLaunchKernelGGL((k_gemm_f32<1, 1>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((k_gemm_f32<1, 1, 64>), grid, dim3(256), 0, st, g);
     }
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
@@ -226,8 +253,10 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
         cur = t2;
     }
     {
-        dim3 grid((nx * nz + 255) / 256, B);
-        hipLaunchKernelGGL(k_tridiag_y, grid, dim3(256), 0, st, cur, s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz);
+        // one wave per workgroup: at batch 64 x 256 modes this spreads the sweep over 256 CUs instead of 64 (the
+        // sweep is bound by per-CU load/store throughput, not by arithmetic)
+        dim3 grid((nx * nz + 63) / 64, B);
+        hipLaunchKernelGGL(k_tridiag_y, grid, dim3(64), (size_t)((ny + 15) / 16 * 16) * 64 * sizeof(float), st, cur, s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz);
     }
     if (G.dims == 3) {
         // inverse z: t1[k, m] = sum_c Qz[k, c] t2[c, m]
