@@ -122,8 +122,11 @@ SIGNATURES = {
     "fg_poisson_fdcg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
                                 c_void_p]),
     "fg_profile_enable": (c_int, [c_void_p, c_int]),
-    "fg_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), POINTER(ctypes.c_double),
-                                POINTER(ctypes.c_double), POINTER(c_int64)]),
+    "fg_profile_kinds": (c_int, []),
+    "fg_profile_kind_name": (ctypes.c_char_p, [c_int]),
+    "fg_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64), POINTER(ctypes.c_double),
+                                POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                POINTER(c_int64), POINTER(c_int64)]),
     "fg_coords_to_transforms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

@@ -115,28 +115,9 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(float) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
-    for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[i]));
-    FG_HIP_CHECK(hipMalloc(&s->prof_active, sizeof(int32_t) * FG_PROF_SAMPLES));
-    FG_HIP_CHECK(hipHostMalloc(&s->prof_active_pinned, sizeof(int32_t) * FG_PROF_SAMPLES));
     FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 8 * 64));
     *out = s;
-    return FG_OK;
-}
-
-extern "C" int fg_profile_enable(fg_handle s, int on) {
-    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
-    s->prof_on = on;
-    for (int i = 0; i < 2; ++i) { s->prof_ms[i] = s->prof_cells[i] = s->prof_full_ms[i] = 0.0; s->prof_n[i] = s->prof_full_n[i] = 0; }
-    return FG_OK;
-}
-extern "C" int fg_profile_read(fg_handle s, double* ms, int64_t* n, double* cells, double* full_ms, int64_t* full_n) {
-    FG_REQUIRE(s && ms && n && cells && full_ms && full_n, FG_ERR_INVALID_ARG, "null argument");
-    for (int i = 0; i < 2; ++i) {
-        ms[i] = s->prof_ms[i]; n[i] = s->prof_n[i]; cells[i] = s->prof_cells[i];
-        full_ms[i] = s->prof_full_ms[i]; full_n[i] = s->prof_full_n[i];
-        s->prof_ms[i] = s->prof_cells[i] = s->prof_full_ms[i] = 0.0; s->prof_n[i] = s->prof_full_n[i] = 0;
-    }
     return FG_OK;
 }
 
@@ -149,11 +130,11 @@ extern "C" int fg_destroy(fg_handle s) {
     for (int i = 0; i < 7; ++i) (void)hipFree(s->w[i]);
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
-    for (int i = 0; i < 4 * FG_PROF_SAMPLES; ++i) (void)hipEventDestroy(s->prof_ev[i]);
+    fg_prof_destroy(s);
     (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned); (void)hipHostFree(s->dt_pinned); (void)hipFree(s->dt_dev);
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
-    (void)hipFree(s->prof_active); (void)hipHostFree(s->prof_active_pinned); (void)hipFree(s->cg_acc);
+    (void)hipFree(s->cg_acc);
     delete s;
     return FG_OK;
 }

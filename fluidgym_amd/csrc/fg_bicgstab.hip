@@ -328,38 +328,43 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     const dim3 sg((nsys + 63) / 64), sb(64);
     hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
 
-#define FG_BICG_LAUNCH(KERNEL, ...)                                                                          \
+#define FG_BICG_LAUNCH(SLOT, KERNEL, ...)                                                                          \
     do {                                                                                                     \
         if (s->grid.dims == 2) {                                                                             \
             if (s->vec == 4) {                                                                               \
                 FgLaunch L = fg_launch_geometry<2, 4>(s->grid); L.grid.y = a.nc;                             \
-                hipLaunchKernelGGL((KERNEL<2, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<2, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             } else {                                                                                         \
                 FgLaunch L = fg_launch_geometry<2, 1>(s->grid); L.grid.y = a.nc;                             \
-                hipLaunchKernelGGL((KERNEL<2, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<2, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             }                                                                                                \
         } else {                                                                                             \
             if (s->vec == 4) {                                                                               \
                 FgLaunch L = fg_launch_geometry<3, 4>(s->grid); L.grid.y = a.nc;                             \
-                hipLaunchKernelGGL((KERNEL<3, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<3, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             } else {                                                                                         \
                 FgLaunch L = fg_launch_geometry<3, 1>(s->grid); L.grid.y = a.nc;                             \
-                hipLaunchKernelGGL((KERNEL<3, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<3, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             }                                                                                                \
         }                                                                                                    \
     } while (0)
 
-    FG_BICG_LAUNCH(k_bicg_init, a.use_x0);
+    FG_BICG_LAUNCH(-1, k_bicg_init, a.use_x0);
     bool done = false;
     // first convergence poll where the previous solve finished (kernels of converged systems exit at once,
     // so over-launching costs ~2 us per kernel while every poll costs a stream sync), then every 2 iterations
     int next_poll = s->pred_bicg > 1 ? s->pred_bicg : 1;
     for (int it = 0; it < a.max_iterations && !done; ++it) {
-        FG_BICG_LAUNCH(k_bicg_p, it);
-        FG_BICG_LAUNCH(k_bicg_v, it);
-        FG_BICG_LAUNCH(k_bicg_s, it);
-        FG_BICG_LAUNCH(k_bicg_t, it);
-        FG_BICG_LAUNCH(k_bicg_x, it);
+        // algorithmic bytes per system and cell: Kp r,v,p -> p (16; the first iteration only checks) | Kv p,rw -> v + the
+        // (1 + 2d) matrix fields shared by the nc right-hand sides | Ks r,v -> s (12) | Kt s -> t + matrix |
+        // Kx x,p,s,t,rw -> x,r (28)
+        const double cells = (double)n, mat = 4.0 * (1 + 2 * s->grid.dims) / a.nc, fl = 2.0 * (1 + 2 * s->grid.dims);
+        if (it > 0) FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_P, q.flags, nsys, cells * 16.0, cells * 4.0, st), k_bicg_p, it);
+        else FG_BICG_LAUNCH(-1, k_bicg_p, it);
+        FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_V, q.flags, nsys, cells * (12.0 + mat), cells * (fl + 2.0), st), k_bicg_v, it);
+        FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_S, q.flags, nsys, cells * 12.0, cells * 4.0, st), k_bicg_s, it);
+        FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_T, q.flags, nsys, cells * (8.0 + mat), cells * (fl + 4.0), st), k_bicg_t, it);
+        FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_X, q.flags, nsys, cells * 28.0, cells * 10.0, st), k_bicg_x, it);
         if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
             next_poll = it + 1 + 2;
             const int final_pass = (it + 1 == a.max_iterations);
@@ -373,6 +378,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
 #undef FG_BICG_LAUNCH
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
+    if (int prc = fg_prof_collect(s, st)) return prc;
     int rc = FG_OK;
     int used_max = 0;
     for (int i = 0; i < nsys; ++i) used_max = s->info_pinned[i].used_iterations > used_max ? s->info_pinned[i].used_iterations : used_max;

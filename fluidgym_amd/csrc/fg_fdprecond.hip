@@ -15,6 +15,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 struct GemmArgs {
     const float* A; long lda; long strideA;   // [M x K] row-major, per batch (stride 0 = shared)
     const float* B; long ldb; long strideB;   // [K x N]
+    const float* Bt; long ldbt;               // optional: the same matrix stored transposed [N x K] (shared, stride 0)
     float* C; long ldc; long strideC;         // [M x N]
     int M, N, K;
     const int32_t* flags;                     // batch b is skipped when flags[b] != 0
@@ -142,18 +143,132 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     }
 }
 
+// Split-K variant for the batched 2-D / small 3-D launches: one 32 x 32 output tile per workgroup, its four waves
+// each own a quarter of K.  No operand is shared between the waves of a workgroup, so there is no LDS staging
+// and no barrier in the K loop: every wave issues ALL its global loads up front (one exposed memory round trip),
+// runs its MFMAs, and the four partial tiles meet in LDS once.  Versus the 64 x 64 tile this gives 4x the
+// workgroups (the launches carry 10-64 active envs: 160-512 big tiles left most of the 256 CUs with <= 1 wave
+// per SIMD) at the price of 2x the L2 reads, which the XCD remap keeps local (an env's tiles share one L2).
+// MFMA 32x32x2 operand layout: lane l feeds A[row l%32][k-slot l/32], B[k-slot l/32][col l%32]; the k order inside
+// a wave's slab is free as long as A and B agree, so lane half h takes the h-th half of the slab CONTIGUOUSLY
+// (float4 loads from a row-major A, and from B when its transpose is available).
+template <bool BT>
+__global__ __launch_bounds__(256) void k_gemm_sk(GemmArgs g, int tiles_n, int tiles_m) {
+    const unsigned id = fg_xcd_remap(blockIdx.x, gridDim.x);
+    const int per_b = tiles_n * tiles_m;
+    const int b = id / per_b;
+    if (g.flags && g.flags[b] != 0) return;
+    const int rem = id - b * per_b, tm = rem / tiles_n, tn = rem - tm * tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const float* __restrict__ A = g.A + (size_t)b * g.strideA;
+    const float* __restrict__ B = BT ? g.Bt : g.B + (size_t)b * g.strideB;
+    const long ldb = BT ? g.ldbt : g.ldb;
+    const int arow = min(m0 + l31, g.M - 1), bcol = min(n0 + l31, g.N - 1);
+    const bool a_ok = m0 + l31 < g.M;
+    const int KS = ((g.K + 7) >> 3) << 1;  // K slab per wave (even)
+    const int kbeg = wave * KS, kend = min(g.K, kbeg + KS);
+    const bool aligned = ((g.lda & 3) == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0) &&
+                         (!BT || (((ldb & 3) == 0) && ((reinterpret_cast<size_t>(B) & 15) == 0)));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kc = kbeg; kc < kend; kc += 64) {
+        const int L = min(64, kend - kc), Lh = (L + 1) >> 1;
+        const int k0 = kc + h * Lh, kstop = h ? kc + L : kc + Lh;
+        float a[32], bb[32];
+        if (L == 64 && aligned && (kc & 3) == 0) {
+            const float4* pa = reinterpret_cast<const float4*>(A + (size_t)arow * g.lda + k0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = pa[q];
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+            if (BT) {
+                const float4* pb = reinterpret_cast<const float4*>(B + (size_t)bcol * ldb + k0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 v = pb[q];
+                    bb[4 * q] = v.x; bb[4 * q + 1] = v.y; bb[4 * q + 2] = v.z; bb[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) bb[j] = B[(size_t)(k0 + j) * ldb + bcol];
+            }
+            // keep ALL loads ahead of the MFMAs (left alone, the scheduler interleaves them 2-3 loads at a time to save
+            // registers, which exposes a memory round trip every few MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
+            if (!a_ok) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) a[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int k = min(k0 + j, g.K - 1);
+                const bool ok = k0 + j < kstop;
+                const float av = A[(size_t)arow * g.lda + k];
+                const float bv = BT ? B[(size_t)bcol * ldb + k] : B[(size_t)k * ldb + bcol];
+                a[j] = (ok && a_ok) ? av : 0.f;
+                bb[j] = ok ? bv : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j < Lh) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc, 0, 0, 0);
+        }
+    }
+    // combine the four K-partials: red[wave][reg][lane], then thread (wave w, lane) finishes regs 4w .. 4w+3
+    __shared__ float red[4][16][64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    float* __restrict__ C = g.C + (size_t)b * g.strideC;
+    const float* __restrict__ W = g.dot_with ? g.dot_with + (size_t)b * g.strideW : nullptr;
+    float dot = 0.f;
+    const int col = n0 + l31;
+    float wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // dot operand first: its loads must not queue behind the stores below
+        const int row = m0 + q + 8 * wave + 4 * h;
+        wv[q] = (W && row < g.M && col < g.N) ? W[(size_t)row * g.ldc + col] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
+        const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+        const int row = m0 + q + 8 * wave + 4 * h;  // C/D layout: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        if (row < g.M && col < g.N) {
+            C[(size_t)row * g.ldc + col] = v;
+            dot += v * wv[q];
+        }
+    }
+    if (W) {
+        __shared__ float lds[4];
+        float part[1] = {dot};
+        fg_block_sum<1>(part, lds);
+        if (tid == 0)
+            atomicAdd(g.dot_acc + (size_t)b * g.dot_stride + ((unsigned)rem & (unsigned)(g.dot_ns - 1)), (double)part[0]);
+    }
+}
+
 // Thomas sweep along y for every mode: forward y_j = (b_j - l_j y_{j-1}) inv_j, backward
 // x_j = y_j - c'_j x_{j+1}.  One thread per (env, z-mode, x-mode); x-mode is the fastest index so every
 // step is a coalesced row access.  The intermediate y_j stay in LDS ([j][lane], conflict-free), so the global
 // traffic is: read b, inv, c' once (prefetched TRI_CH rows ahead of the recurrence), write x once -- no global
 // store sits between a load and its use (the in-place global variant spent ~170 ns per recurrence step).
-constexpr int TRI_CH = 16;
-// Row indices are CLAMPED instead of branched on: every load of a chunk is straight-line code, so the compiler
-// can keep the next chunk in flight with counted s_waitcnt (the branchy form compiled to 36 x vmcnt(0) drains).
+constexpr int TRI_CH = 16;   // rows per register chunk
+constexpr int TRI_NB = 4;    // chunk buffers: TRI_NB - 1 chunks (48 rows) of loads in flight ahead of the recurrence
+// The sweep is a serial chain per mode, so its duration is (number of chunks) x max(memory round trip / chunks in
+// flight, chunk arithmetic): with one chunk in flight it sat at ~0.7 us per 16 rows whatever the batch (17-21 us for
+// ny = 128, B = 4 .. 128).  The chunk loop is unrolled by TRI_NB so the rotating buffers keep static register indices.
+// Row indices are CLAMPED instead of branched on: every load is straight-line code and the compiler can keep the
+// later chunks in flight with counted s_waitcnt (a branchy form compiled to 36 x vmcnt(0) drains).
 __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const float* __restrict__ inv,
                                                    const float* __restrict__ cp, const float* __restrict__ lower,
                                                    const int32_t* __restrict__ flags, int nx, int ny, int nz) {
-    extern __shared__ __attribute__((aligned(16))) float ybuf[];  // [ny_padded][64]
+    extern __shared__ __attribute__((aligned(16))) float ybuf[];  // [ny padded to TRI_CH * TRI_NB][64]
     const int b = blockIdx.y;
     if (flags && flags[b] != 0) return;
     const int lane = threadIdx.x;
@@ -166,62 +281,193 @@ __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const f
     const float* __restrict__ iv = inv + col;
     const float* __restrict__ cpp = cp + col;
     const int last = ny - 1;
-    float cx[TRI_CH], ci[TRI_CH], cl[TRI_CH], nxv[TRI_CH], niv[TRI_CH], nlv[TRI_CH];
+    constexpr int SPAN = TRI_CH * TRI_NB;
+    const int nyp = (ny + SPAN - 1) / SPAN * SPAN;
+    float bx[TRI_NB][TRI_CH], bi[TRI_NB][TRI_CH], bl[TRI_NB][TRI_CH];
     // ---- forward elimination: y_j = (b_j - l_j y_{j-1}) inv_j ; y to LDS
 #pragma unroll
-    for (int q = 0; q < TRI_CH; ++q) {
-        const int j = min(q, last);
-        cx[q] = xb[(size_t)j * nx]; ci[q] = iv[(size_t)j * nx]; cl[q] = lower[j];
-    }
+    for (int u = 0; u < TRI_NB - 1; ++u)
+#pragma unroll
+        for (int q = 0; q < TRI_CH; ++q) {
+            const int j = min(u * TRI_CH + q, last);
+            bx[u][q] = xb[(size_t)j * nx]; bi[u][q] = iv[(size_t)j * nx]; bl[u][q] = lower[j];
+        }
     float prev = 0.f;
-    for (int j0 = 0; j0 < ny; j0 += TRI_CH) {
+    for (int j0 = 0; j0 < nyp; j0 += SPAN) {
 #pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) {
-            const int j = min(j0 + TRI_CH + q, last);
-            nxv[q] = xb[(size_t)j * nx]; niv[q] = iv[(size_t)j * nx]; nlv[q] = lower[j];
+        for (int u = 0; u < TRI_NB; ++u) {
+            constexpr int dummy = 0; (void)dummy;
+            const int jc = j0 + u * TRI_CH;              // chunk computed now (buffer u)
+            const int jl = jc + (TRI_NB - 1) * TRI_CH;   // chunk loaded now (buffer (u + TRI_NB - 1) % TRI_NB)
+#pragma unroll
+            for (int q = 0; q < TRI_CH; ++q) {
+                const int j = min(jl + q, last);
+                bx[(u + TRI_NB - 1) % TRI_NB][q] = xb[(size_t)j * nx];
+                bi[(u + TRI_NB - 1) % TRI_NB][q] = iv[(size_t)j * nx];
+                bl[(u + TRI_NB - 1) % TRI_NB][q] = lower[j];
+            }
+#pragma unroll
+            for (int q = 0; q < TRI_CH; ++q) {
+                const float v = (bx[u][q] - bl[u][q] * prev) * bi[u][q];
+                prev = (jc + q <= last) ? v : prev;      // rows past the end keep the last value (select, no branch)
+                ybuf[(jc + q) * 64 + lane] = prev;
+            }
         }
-#pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) {
-            const float v = (cx[q] - cl[q] * prev) * ci[q];
-            prev = (j0 + q <= last) ? v : prev;     // rows past the end keep the last value (select, no branch)
-            ybuf[(j0 + q) * 64 + lane] = prev;      // LDS is padded to a multiple of TRI_CH rows
-        }
-#pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) { cx[q] = nxv[q]; ci[q] = niv[q]; cl[q] = nlv[q]; }
     }
-    // ---- back substitution: x_last = y_last ; x_j = y_j - c'_j x_{j+1}
-    // (c'_last = 0 in the factor table, so starting one row early with prev = 0 reproduces x_last = y_last)
+    // ---- back substitution: x_last = y_last ; x_j = y_j - c'_j x_{j+1}   (prev = 0 makes the first row x = y)
     prev = 0.f;
-    const int top = ((ny + TRI_CH - 1) / TRI_CH) * TRI_CH - TRI_CH;  // first row of the last chunk
 #pragma unroll
-    for (int q = 0; q < TRI_CH; ++q) ci[q] = cpp[(size_t)min(top + q, last) * nx];
-    for (int j0 = top; j0 >= 0; j0 -= TRI_CH) {
+    for (int u = 0; u < TRI_NB - 1; ++u)
 #pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) niv[q] = cpp[(size_t)max(j0 - TRI_CH + q, 0) * nx];
+        for (int q = 0; q < TRI_CH; ++q) bx[u][q] = cpp[(size_t)min(nyp - (u + 1) * TRI_CH + q, last) * nx];
+    for (int j0 = nyp - SPAN; j0 >= 0; j0 -= SPAN) {
 #pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) cx[q] = ybuf[(j0 + q) * 64 + lane];
+        for (int u = 0; u < TRI_NB; ++u) {
+            const int jc = j0 + (TRI_NB - 1 - u) * TRI_CH;   // chunks go top-down: buffer u holds chunk jc
+            const int jl = jc - (TRI_NB - 1) * TRI_CH;
 #pragma unroll
-        for (int q = TRI_CH - 1; q >= 0; --q) {
-            const int j = j0 + q;
-            const float v = cx[q] - ci[q] * prev;
-            prev = (j <= last) ? v : prev;
-            if (live && j <= last) xb[(size_t)j * nx] = prev;
+            for (int q = 0; q < TRI_CH; ++q)
+                bx[(u + TRI_NB - 1) % TRI_NB][q] = cpp[(size_t)min(max(jl + q, 0), last) * nx];
+#pragma unroll
+            for (int q = 0; q < TRI_CH; ++q) bi[0][q] = ybuf[(jc + q) * 64 + lane];
+#pragma unroll
+            for (int q = TRI_CH - 1; q >= 0; --q) {
+                const int j = jc + q;
+                const float v = bi[0][q] - bx[u][q] * prev;
+                prev = (j <= last) ? v : prev;
+                if (live && j <= last) xb[(size_t)j * nx] = prev;
+            }
+        }
+    }
+}
+
+// Cooperative variant (whole column block in LDS).  Two things bound the streaming kernel above, both per wave and
+// independent of the batch (16-19 us for ny = 128 at B = 4 .. 128): a wave keeps at most 64 loads in flight, and a lone
+// wave issues about one instruction per 4-5 cycles, so ~20 instructions per row (clamps, selects, addresses) cost
+// ~100 cycles per row.  Here the four waves of a workgroup share one 64-column block:
+//   1. float4 loads along the mode index (a wave instruction covers 4 rows x 64 columns; 24 loads per wave for
+//      ny = 128), folded on the way into LDS to  bs = b inv,  ms = l inv,  cs = c'  with zero padding rows;
+//   2. wave 0 runs  y_j = bs_j - ms_j y_{j-1}  and  x_j = y_j - cs_j x_{j+1}  out of LDS in 16-row register chunks:
+//      one dependent FMA and four instructions per row, no clamps or selects (the zero padding rows are neutral);
+//   3. all four waves store the result with float4s.
+// Measured 7.8 us at B = 64 (256 x 128), 4.5k / 6.1k / 1.5k clocks for the three phases.  Needs nx % 4 == 0 and
+// 3 x roundup(ny, 16) x 256 B of LDS (ny <= 208).
+__global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, const float* __restrict__ inv,
+                                                       const float* __restrict__ cp, const float* __restrict__ lower,
+                                                       const int32_t* __restrict__ flags, int nx, int ny, int nz) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]
+    const int b = blockIdx.y;
+    if (flags && flags[b] != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int CH = 16;
+    const int nyp = (ny + CH - 1) / CH * CH, last = ny - 1;
+    float* bs = tbuf;
+    float* ms = tbuf + (size_t)nyp * 64;
+    float* cs = tbuf + (size_t)2 * nyp * 64;
+    const int lc = 4 * (lane & 15), rsub = lane >> 4;
+    int t4 = blockIdx.x * 64 + lc;
+    const bool live = t4 < nx * nz;
+    if (!live) t4 = nx * nz - 4;
+    const int a4 = t4 % nx, c4 = t4 / nx;
+    const size_t col4 = (size_t)c4 * ny * nx + a4;
+    float* __restrict__ xb4 = x + (size_t)b * nx * ny * nz + col4;
+    const float* __restrict__ iv4 = inv + col4;
+    const float* __restrict__ cp4 = cp + col4;
+    for (int jb = wave * 32; jb < nyp; jb += 128) {  // 32 rows per wave per round = 8 instructions per array
+        float4 vx[8], vi[8], vc[8];
+        float vl[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = min(jb + 4 * q + rsub, last);
+            vx[q] = *reinterpret_cast<const float4*>(xb4 + (size_t)j * nx);
+            vi[q] = *reinterpret_cast<const float4*>(iv4 + (size_t)j * nx);
+            vc[q] = *reinterpret_cast<const float4*>(cp4 + (size_t)j * nx);
+            vl[q] = lower[j];
         }
 #pragma unroll
-        for (int q = 0; q < TRI_CH; ++q) ci[q] = niv[q];
+        for (int q = 0; q < 8; ++q) {
+            const int j = jb + 4 * q + rsub;
+            if (j < nyp) {
+                const float m = (j > last) ? 0.f : 1.f;
+                const float l = vl[q] * m;
+                const int o = j * 64 + lc;
+                *reinterpret_cast<float4*>(bs + o) =
+                    make_float4(vx[q].x * vi[q].x * m, vx[q].y * vi[q].y * m, vx[q].z * vi[q].z * m, vx[q].w * vi[q].w * m);
+                *reinterpret_cast<float4*>(ms + o) = make_float4(l * vi[q].x, l * vi[q].y, l * vi[q].z, l * vi[q].w);
+                *reinterpret_cast<float4*>(cs + o) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
+            }
+        }
     }
+    __syncthreads();
+    if (wave == 0) {
+        float prev = 0.f;
+        float* px = bs + lane;
+        const float* pm = ms + lane;
+        for (int j0 = 0; j0 < nyp; j0 += CH, px += CH * 64, pm += CH * 64) {
+            float ax[CH], am[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { ax[q] = px[q * 64]; am[q] = pm[q * 64]; }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { prev = fmaf(-am[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) px[q * 64] = ax[q];
+        }
+        prev = 0.f;
+        px = bs + (size_t)(nyp - CH) * 64 + lane;
+        const float* pc = cs + (size_t)(nyp - CH) * 64 + lane;
+        for (int j0 = nyp - CH; j0 >= 0; j0 -= CH, px -= CH * 64, pc -= CH * 64) {
+            float ax[CH], ac[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { ax[q] = px[q * 64]; ac[q] = pc[q * 64]; }
+#pragma unroll
+            for (int q = CH - 1; q >= 0; --q) { prev = fmaf(-ac[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) px[q * 64] = ax[q];
+        }
+    }
+    __syncthreads();
+    if (live)
+        for (int jb = wave * 32; jb < ny; jb += 128) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + 4 * q + rsub;
+                if (j <= last)
+                    *reinterpret_cast<float4*>(xb4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * 64 + lc);
+            }
+        }
 }
 
 }  // namespace
 
-static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+// dynamic LDS above 64 KB needs an explicit opt-in per kernel (once per process and size class)
+static bool tridiag_lds_ready(size_t bytes) {
+    static size_t granted = 0;
+    static bool failed = false;
+    if (bytes <= granted) return true;
+    if (failed) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tridiag_y_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        failed = true;
+        return false;
+    }
+    granted = bytes;
+    return true;
+}
+
+static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, hipStream_t st) {
+    // algorithmic traffic per env: A read + C written (+ the dot operand); the transform matrix stays in L2
+    const double bytes = 4.0 * ((double)g.M * g.K + (double)g.M * g.N + (g.dot_with ? (double)g.M * g.N : 0.0));
+    const int slot = fg_prof_slot(s, FG_PK_GEMM, g.flags, batch, bytes, 2.0 * g.M * g.N * g.K, st);
     const long big_blocks = (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * batch;
     if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
-        hipLaunchKernelGGL((k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, st, g);
+        FG_LAUNCH_P(s, slot, (k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, st, g);
     } else {
-        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
-        hipLaunchKernelGGL((k_gemm_f32<1, 1, 64>), grid, dim3(256), 0, st, g);
+        const int tn = (g.N + 31) / 32, tm = (g.M + 31) / 32;
+        dim3 grid((unsigned)(tn * tm * batch));
+        if (g.Bt) FG_LAUNCH_P(s, slot, (k_gemm_sk<true>), grid, dim3(256), 0, st, g, tn, tm);
+        else FG_LAUNCH_P(s, slot, (k_gemm_sk<false>), grid, dim3(256), 0, st, g, tn, tm);
     }
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
@@ -237,43 +483,50 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
     GemmArgs g;
     // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]
     g.A = r; g.lda = nx; g.strideA = N;
-    g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0;
+    g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_QxT; g.ldbt = nx;
     g.C = t1; g.ldc = nx; g.strideC = N;
     g.M = ny * nz; g.N = nx; g.K = nx;
     g.flags = s->flags; g.dot_with = nullptr; g.strideW = 0; g.dot_acc = nullptr; g.dot_stride = 0; g.dot_ns = 1;
-    if (int rc = launch_gemm(g, B, st)) return rc;
+    if (int rc = launch_gemm(s, g, B, st)) return rc;
     float* cur = t1;
     if (G.dims == 3) {
         // forward z: t2[c, m] = sum_k QzT[c, k] t1[k, m]   (m over ny*nx)
         g.A = s->fd_QzT; g.lda = nz; g.strideA = 0;
-        g.B = t1; g.ldb = (long)ny * nx; g.strideB = N;
+        g.B = t1; g.ldb = (long)ny * nx; g.strideB = N; g.Bt = nullptr; g.ldbt = 0;
         g.C = t2; g.ldc = (long)ny * nx; g.strideC = N;
         g.M = nz; g.N = ny * nx; g.K = nz;
-        if (int rc = launch_gemm(g, B, st)) return rc;
+        if (int rc = launch_gemm(s, g, B, st)) return rc;
         cur = t2;
     }
     {
-        // one wave per workgroup: at batch 64 x 256 modes this spreads the sweep over 256 CUs instead of 64 (the
-        // sweep is bound by per-CU load/store throughput, not by arithmetic)
+        // per env: x read + written, inv + c' read (shared by all envs, so they come from L2 after the first env)
         dim3 grid((nx * nz + 63) / 64, B);
-        hipLaunchKernelGGL(k_tridiag_y, grid, dim3(64), (size_t)((ny + 15) / 16 * 16) * 64 * sizeof(float), st, cur, s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz);
+        const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
+        const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
+        if ((nx & 3) == 0 && lds_coop <= 160 * 1024 && tridiag_lds_ready(lds_coop)) {
+            FG_LAUNCH_P(s, slot, k_tridiag_y_lds, grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                        s->flags, nx, ny, nz);
+        } else {
+            FG_LAUNCH_P(s, slot, k_tridiag_y, grid, dim3(64), (size_t)((ny + 63) / 64 * 64) * 64 * sizeof(float), st, cur,
+                        s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz);
+        }
     }
     if (G.dims == 3) {
         // inverse z: t1[k, m] = sum_c Qz[k, c] t2[c, m]
         g.A = s->fd_Qz; g.lda = nz; g.strideA = 0;
-        g.B = t2; g.ldb = (long)ny * nx; g.strideB = N;
+        g.B = t2; g.ldb = (long)ny * nx; g.strideB = N; g.Bt = nullptr; g.ldbt = 0;
         g.C = t1; g.ldc = (long)ny * nx; g.strideC = N;
         g.M = nz; g.N = ny * nx; g.K = nz;
-        if (int rc = launch_gemm(g, B, st)) return rc;
+        if (int rc = launch_gemm(s, g, B, st)) return rc;
         cur = t1;
     }
     // inverse x: z[rows, i] = sum_a cur[rows, a] QxT[a, i], fused r.z
     g.A = cur; g.lda = nx; g.strideA = N;
-    g.B = s->fd_QxT; g.ldb = nx; g.strideB = 0;
+    g.B = s->fd_QxT; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_Qx; g.ldbt = nx;
     g.C = z; g.ldc = nx; g.strideC = N;
     g.M = ny * nz; g.N = nx; g.K = nx;
     g.dot_with = rz_acc ? r : nullptr; g.strideW = N; g.dot_acc = rz_acc; g.dot_stride = rz_stride; g.dot_ns = rz_ns;
-    if (int rc = launch_gemm(g, B, st)) return rc;
+    if (int rc = launch_gemm(s, g, B, st)) return rc;
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

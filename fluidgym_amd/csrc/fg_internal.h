@@ -2,6 +2,7 @@
 // gfx950 / wave64 only.  Public C ABI: include/fluidgym_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 
@@ -288,7 +289,25 @@ __device__ __forceinline__ void fg_block_sum(float (&v)[NV], float* lds /* >= NV
 // ------------------------------------------------------------------------------------------------
 // host-side state
 // ------------------------------------------------------------------------------------------------
-#define FG_PROF_SAMPLES 16
+// ---- live per-kernel timing (bench.py roofline) ---------------------------------------------------
+// Sampled launches go through hipExtLaunchKernelGGL with a start/stop event pair, which timestamps the
+// kernel's own dispatch packet (no inter-kernel gap, agrees with rocprofv3 --kernel-trace); a one-wave helper
+// kernel snapshots how many systems were still iterating so the algorithmic bytes count only work done.
+enum FgProfKind {
+    FG_PK_CG_AP = 0, FG_PK_CG_UPDATE, FG_PK_BICG_P, FG_PK_BICG_V, FG_PK_BICG_S, FG_PK_BICG_T, FG_PK_BICG_X,
+    FG_PK_GEMM, FG_PK_TRIDIAG, FG_PK_COUNT
+};
+#define FG_PROF_POOL 256
+struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };
+struct FgProf {
+    int on, used, period;
+    hipEvent_t ev[2 * FG_PROF_POOL];
+    FgProfMeta meta[FG_PROF_POOL];
+    int32_t* active_dev;      // [FG_PROF_POOL] active systems of each sampled launch
+    int32_t* active_pinned;
+    double ms[FG_PK_COUNT], bytes[FG_PK_COUNT], flops[FG_PK_COUNT], full_ms[FG_PK_COUNT], full_bytes[FG_PK_COUNT];
+    long long n[FG_PK_COUNT], full_n[FG_PK_COUNT], launches[FG_PK_COUNT];
+};
 #define FG_ACC_DOUBLES 16  // reduction accumulators per linear system (see solver kernels)
 
 struct fg_state {
@@ -325,16 +344,7 @@ struct fg_state {
     fg_solve_info* info_pinned;// [B*d] host-pinned mirror
     int32_t* flags_pinned;
     float* scratch_B;  // [B*(4+2d)] small per-env floats
-    // live kernel timing (bench.py roofline): one sampled launch of each CG kernel per solve
-    int prof_on;
-    hipEvent_t prof_ev[4 * FG_PROF_SAMPLES];
-    int32_t* prof_active;         // device: active envs of each sampled launch
-    int32_t* prof_active_pinned;
-    double prof_ms[2];            // sum of sampled launch durations {k_cg_ap, k_cg_update}
-    long long prof_n[2];
-    double prof_cells[2];         // sum over samples of ALGORITHMIC BYTES actually processed (active envs * n * B/cell)
-    double prof_full_ms[2];       // same, restricted to launches with every env active
-    long long prof_full_n[2];
+    FgProf prof;
     double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
@@ -428,7 +438,25 @@ int fg_zmarch_apply(const fg_state* s, const float* rA, const float* x, float* y
 int fg_zmarch_relax(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew, float omega,
                     int color, int zc, hipStream_t st);
 int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const float* p_in, float* p_out, float* Ap,
-                    double* acc, int32_t* flags, fg_solve_info* info, int32_t* prof_active, float tol, int it, int first,
+                    double* acc, int32_t* flags, fg_solve_info* info, int prof_slot, float tol, int it, int first,
                     int ns, int num_base, int zc, hipStream_t st);
+// profiler (fg_profile.hip).  fg_prof_slot returns an event-pair slot when this launch is to be sampled (-1 otherwise);
+// flags == nullptr means all nsys systems are active; flags == FG_PROF_SELF means the sampled kernel itself adds
+// its active systems to prof.active_dev[slot] (kernels that retire systems in the same launch).  fg_prof_collect folds finished samples into the sums and
+// must be called with the stream idle.
+#define FG_PROF_SELF ((const int32_t*)(uintptr_t)1)
+int fg_prof_slot(const fg_state* s, int kind, const int32_t* flags, int nsys, double bytes_per_sys,
+                 double flops_per_sys, hipStream_t st);
+int fg_prof_collect(fg_state* s, hipStream_t st);
+void fg_prof_destroy(fg_state* s);
+#define FG_LAUNCH_P(s, slot, kernel, grid, block, shmem, st, ...)                                              \
+    do {                                                                                                       \
+        const int slot__ = (slot);                                                                             \
+        if (slot__ >= 0)                                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, (s)->prof.ev[2 * slot__],                    \
+                                  (s)->prof.ev[2 * slot__ + 1], 0, __VA_ARGS__);                               \
+        else                                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                   \
+    } while (0)
 int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

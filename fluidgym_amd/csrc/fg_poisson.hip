@@ -404,10 +404,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, st)) return rc;
     }
     bool done = false;
-    int sample_first[FG_PROF_SAMPLES] = {0};
     int next_poll = a.precond ? (s->pred_cg + 1 > 1 ? s->pred_cg + 1 : 1) : check_every;
-    int n_samples = 0;
-    if (s->prof_on) FG_HIP_CHECK(hipMemsetAsync(s->prof_active, 0, sizeof(int32_t) * FG_PROF_SAMPLES, st));
     int it = 0;
     for (; it < a.max_iterations && !done; ++it) {
         int first = (it == 0);
@@ -424,34 +421,29 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         // p double buffer: read p_{it-1} from pbuf[(it+1)&1], write p_it to pbuf[it&1]
         const float* p_in = pbuf[(it + 1) & 1];
         float* p_out = pbuf[it & 1];
-        // live timing samples: iteration 1 and every 8th iteration, both kernels bracketed by events
-        const bool sample = s->prof_on && n_samples < FG_PROF_SAMPLES && (it <= 1 || (it & 7) == 0);
-        if (sample) sample_first[n_samples] = first;
-        int32_t* pa = sample ? s->prof_active + n_samples : nullptr;
-        if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 0], st);
+        // algorithmic bytes per env of k_cg_ap: z, rA read + p, Ap written (+ p_in read unless first); 2d+1-point
+        // stencil = (4d + 1) flops + 2 (p update) + 2 (dot) per cell.  k_cg_update: x, r, p, Ap read + x, r written.
+        const int slot_ap = fg_prof_slot(s, FG_PK_CG_AP, FG_PROF_SELF, B, (double)n * (first ? 16.0 : 20.0),
+                                         (double)n * (4.0 * s->grid.dims + 5.0), st);
         if (zmarch) {
-            if (int rc = fg_zmarch_cg_ap(s, a.rA, zvec, p_in, p_out, a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it,
-                                         first, ns, nb, zc, st))
+            if (int rc = fg_zmarch_cg_ap(s, a.rA, zvec, p_in, p_out, a.Ap, s->cg_acc, s->flags, s->info_dev, slot_ap,
+                                         a.tol, it, first, ns, nb, zc, st))
                 return rc;
         } else {
             FG_DISPATCH(s, {
                 const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-                hipLaunchKernelGGL((k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, zvec, p_in, p_out,
-                                   a.Ap, s->cg_acc, s->flags, s->info_dev, pa, a.tol, it, first, ns, nb, L.tiles_x,
-                                   L.tiles_y, L.tiles);
+                FG_LAUNCH_P(s, slot_ap, (k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, zvec, p_in,
+                            p_out, a.Ap, s->cg_acc, s->flags, s->info_dev,
+                            slot_ap >= 0 ? s->prof.active_dev + slot_ap : nullptr, a.tol, it, first, ns, nb,
+                            L.tiles_x, L.tiles_y, L.tiles);
             });
         }
-        if (sample) {
-            (void)hipEventRecord(s->prof_ev[4 * n_samples + 1], st);
-            (void)hipEventRecord(s->prof_ev[4 * n_samples + 2], st);
-        }
+        const int slot_up = fg_prof_slot(s, FG_PK_CG_UPDATE, s->flags, B, (double)n * 24.0, (double)n * 6.0, st);
         FG_DISPATCH(s, {
             const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-            hipLaunchKernelGGL((k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x, a.r,
-                               s->cg_acc, s->flags, a.tol, it, ns, nb, L.tiles_x, L.tiles_y, L.tiles);
+            FG_LAUNCH_P(s, slot_up, (k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x,
+                        a.r, s->cg_acc, s->flags, a.tol, it, ns, nb, L.tiles_x, L.tiles_y, L.tiles);
         });
-        if (sample) (void)hipEventRecord(s->prof_ev[4 * n_samples + 3], st);
-        if (sample) ++n_samples;
         const bool poll = (it + 1 >= next_poll || it + 1 == a.max_iterations);
         if (poll) next_poll = it + 1 + check_every;
         if (a.precond || poll) {
@@ -471,24 +463,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         }
     }
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
-    if (n_samples)
-        FG_HIP_CHECK(hipMemcpyAsync(s->prof_active_pinned, s->prof_active, sizeof(int32_t) * FG_PROF_SAMPLES,
-                                    hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
-    for (int i = 0; i < n_samples; ++i) {
-        float ms = 0.f;
-        const int act = s->prof_active_pinned[i];
-        if (act <= 0) continue;  // every env had converged: the launch did no work
-        if (hipEventElapsedTime(&ms, s->prof_ev[4 * i], s->prof_ev[4 * i + 1]) == hipSuccess) {
-            // algorithmic bytes of k_cg_ap: z, rA read + p, Ap written (+ p_in read unless it is the first iteration)
-            s->prof_ms[0] += ms; s->prof_n[0]++; s->prof_cells[0] += (double)act * n * (sample_first[i] ? 16.0 : 20.0);
-            if (act == B) { s->prof_full_ms[0] += ms; s->prof_full_n[0]++; }
-        }
-        if (hipEventElapsedTime(&ms, s->prof_ev[4 * i + 2], s->prof_ev[4 * i + 3]) == hipSuccess) {
-            s->prof_ms[1] += ms; s->prof_n[1]++; s->prof_cells[1] += (double)act * n * 24.0;
-            if (act == B) { s->prof_full_ms[1] += ms; s->prof_full_n[1]++; }
-        }
-    }
+    if (int prc = fg_prof_collect(s, st)) return prc;
     int rc = FG_OK;
     if (a.precond) {
         int used_max = 0;

@@ -419,14 +419,14 @@ bool fg_zmarch_ok(const fg_state* s, int* zc_out) {
 }
 
 template <int MODE>
-static int launch_march(const fg_state* s, const Z3Args& a, int zc, hipStream_t st) {
+static int launch_march(const fg_state* s, const Z3Args& a, int zc, hipStream_t st, int slot = -1) {
     const FgGrid& g = s->grid;
     const int bxl = z_pick_bxl(g);
     const int tx = g.nx / (bxl * 4), ty = g.ny / (FG_BLOCK / bxl), zch = (g.nz + zc - 1) / zc;
     dim3 grid((unsigned)(tx * ty * zch * g.B));
-    if (bxl == 16) hipLaunchKernelGGL((k_poisson3_march<MODE, 16>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-    else if (bxl == 32) hipLaunchKernelGGL((k_poisson3_march<MODE, 32>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-    else hipLaunchKernelGGL((k_poisson3_march<MODE, 64>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
@@ -443,11 +443,11 @@ int fg_zmarch_relax(const fg_state* s, const float* rA, const float* b, const fl
     return launch_march<MODE_RELAX>(s, a, zc, st);
 }
 int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const float* p_in, float* p_out, float* Ap,
-                    double* acc, int32_t* flags, fg_solve_info* info, int32_t* prof_active, float tol, int it, int first,
+                    double* acc, int32_t* flags, fg_solve_info* info, int prof_slot, float tol, int it, int first,
                     int ns, int num_base, int zc, hipStream_t st) {
     Z3Args a = {};
     a.rA = rA; a.x = z; a.x2 = p_in; a.y = p_out; a.y2 = Ap;
-    a.acc = acc; a.flags = flags; a.info = info; a.prof_active = prof_active;
+    a.acc = acc; a.flags = flags; a.info = info; a.prof_active = prof_slot >= 0 ? s->prof.active_dev + prof_slot : nullptr;
     a.tol = tol; a.it = it; a.first = first; a.ns = ns; a.num_base = num_base;
-    return launch_march<MODE_CG_AP>(s, a, zc, st);
+    return launch_march<MODE_CG_AP>(s, a, zc, st, prof_slot);
 }

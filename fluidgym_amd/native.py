@@ -320,11 +320,19 @@ class NativeSolver:
         L.check(self.lib.fg_profile_enable(self.handle, int(on)))
 
     def profile_read(self):
-        """Per CG kernel {k_cg_ap, k_cg_update}: dict(ms, samples, bytes (algorithmic), full_ms, full_samples)."""
-        ms, cells, fms = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
-        n, fn = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
-        L.check(self.lib.fg_profile_read(self.handle, ms, n, cells, fms, fn))
-        return [dict(ms=ms[i], samples=int(n[i]), bytes=cells[i], full_ms=fms[i], full_samples=int(fn[i])) for i in (0, 1)]
+        """{kernel name: dict(ms, samples, bytes, flops, full_ms, full_bytes, full_samples, launches)} of the sampled
+        solver-kernel launches since profile_enable (see fg_profile_read in include/fluidgym_hip.h)."""
+        out = {}
+        for k in range(self.lib.fg_profile_kinds()):
+            ms, by, fl, fms, fby = (ctypes.c_double() for _ in range(5))
+            n, fn, nl = (ctypes.c_int64() for _ in range(3))
+            L.check(self.lib.fg_profile_read(self.handle, k, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by),
+                                             ctypes.byref(fl), ctypes.byref(fms), ctypes.byref(fby), ctypes.byref(fn),
+                                             ctypes.byref(nl)))
+            out[self.lib.fg_profile_kind_name(k).decode()] = dict(
+                ms=ms.value, samples=n.value, bytes=by.value, flops=fl.value, full_ms=fms.value,
+                full_bytes=fby.value, full_samples=fn.value, launches=nl.value)
+        return out
 
     def poisson_fdcg(self, rA, b, x, tol=1e-5, max_iterations=500, use_x0=False):
         info = self._infos(self.B)

@@ -376,3 +376,25 @@ print("OK")
     env = dict(os.environ, FG_FORCE_ZMARCH=str(zc))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_live_profiler_samples_solver_kernels():
+    """fg_profile_*: sampled launches carry kernel-accurate durations and only count systems still iterating."""
+    case = make_case(**CASES["2d_walls_y"], B=3, seed=5, with_source=True)
+    ns = case.native()
+    ns.profile_enable(True)
+    for _ in range(3):
+        ns.piso_step([0.05, 0.04, 0.03])
+    prof = ns.profile_read()
+    ns.profile_enable(False)
+    assert set(prof) >= {"k_cg_ap", "k_cg_update", "k_bicg_v", "k_bicg_t", "k_bicg_x"}
+    n = int(np.prod(case.shape))
+    for name in ("k_bicg_v", "k_bicg_x"):
+        r = prof[name]
+        assert r["launches"] >= r["samples"] > 0
+        assert 0.0 < r["ms"] / r["samples"] < 5.0
+        # never more than the full batch of systems per launch
+        per_launch = r["bytes"] / r["samples"]
+        assert 0 < per_launch <= 3 * 2 * n * 28.0 + 1
+    ns.close()
