@@ -126,7 +126,7 @@ SIGNATURES = {
     "fg_profile_kind_name": (ctypes.c_char_p, [c_int]),
     "fg_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64), POINTER(ctypes.c_double),
                                 POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
-                                POINTER(c_int64), POINTER(c_int64)]),
+                                POINTER(c_int64), POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "fg_coords_to_transforms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

@@ -141,27 +141,67 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int i
     fg_store<VEC>(q.p + vb + c.idx, p);
 }
 
-// K2_i: v = C p ; rv += rw.v
+// SpMV with the matrix held in registers: the (1 + 2 DIMS) coefficient fields belong to the env, not to the system,
+// so one workgroup applies them to ALL nc right-hand sides of its tile.  With one workgroup per (tile, component) the
+// two/three component workgroups usually sat on different XCDs and each pulled the matrix through its own L2
+// (rocprofv3 FETCH_SIZE of k_bicg_v: 86 MB per launch against 56 MB of algorithmic reads).
+template <int DIMS, int VEC>
+struct FgStencilRow {
+    FgVec<VEC> d, o[2 * DIMS];
+};
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgStencilRow<DIMS, VEC> fg_load_row(const float* __restrict__ diag,
+                                                              const float* __restrict__ off,
+                                                              const FgCtx<DIMS, VEC>& c, size_t N) {
+    FgStencilRow<DIMS, VEC> m;
+    m.d = fg_load<VEC>(diag + c.idx);
+#pragma unroll
+    for (int f = 0; f < 2 * DIMS; ++f) m.o[f] = fg_load<VEC>(off + f * N + c.idx);
+    return m;
+}
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgVec<VEC> fg_apply_row(const FgStencilRow<DIMS, VEC>& m, const float* __restrict__ x,
+                                                   const FgCtx<DIMS, VEC>& c) {
+    const FgNbr<DIMS, VEC> X = fg_gather<DIMS, VEC>(x, c);
+    FgVec<VEC> y;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        float v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
+                  m.o[3].v[e] * X.yp.v[e];
+        if constexpr (DIMS == 3) v += m.o[4].v[e] * X.zm.v[e] + m.o[5].v[e] * X.zp.v[e];
+        y.v[e] = v;
+    }
+    return y;
+}
+
+// K2_i: v = C p ; rv += rw.v        (grid.y = 1: loops over the nc systems of the env)
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_bicg_v(FgGrid g, BicgPtrs q, int it, int tiles_x, int tiles_y,
                                                       int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
-    if (q.flags[s.sys] != 0) return;
-    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const size_t N = g.n, vb = (size_t)s.sys * N;
+    const size_t N = g.n;
+    bool any = false;
+    for (int comp = 0; comp < q.nc; ++comp) any = any || (q.flags[c.b * q.nc + comp] == 0);
+    if (!any) return;
+    FgStencilRow<DIMS, VEC> m;
+    if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
     __shared__ float lds[4];
-    float part[1] = {0.f};
-    if (c.valid) {
-        const FgVec<VEC> y = fg_spmv<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, q.p + vb,
-                                                c, N);
-        const FgVec<VEC> rw = fg_load<VEC>(q.rw + vb + c.idx);
-        fg_store<VEC>(q.v + vb + c.idx, y);
+    for (int comp = 0; comp < q.nc; ++comp) {
+        const int sys = c.b * q.nc + comp;
+        if (q.flags[sys] != 0) continue;  // uniform over the workgroup
+        const size_t vb = (size_t)sys * N;
+        float part[1] = {0.f};
+        if (c.valid) {
+            const FgVec<VEC> y = fg_apply_row<DIMS, VEC>(m, q.p + vb, c);
+            const FgVec<VEC> rw = fg_load<VEC>(q.rw + vb + c.idx);
+            fg_store<VEC>(q.v + vb + c.idx, y);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) part[0] += rw.v[e] * y.v[e];
+            for (int e = 0; e < VEC; ++e) part[0] += rw.v[e] * y.v[e];
+        }
+        fg_block_sum<1>(part, lds);
+        if (threadIdx.x == 0) atomicAdd(q.acc + (size_t)sys * FG_ACC_DOUBLES + A_RV, (double)part[0]);
+        __syncthreads();  // lds reused by the next component
     }
-    fg_block_sum<1>(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + A_RV, (double)part[0]);
 }
 
 // K3_i: alpha = rho_i / rv ; s = r - alpha v (stored in r) ; ss += s.s
@@ -195,42 +235,63 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_s(FgGrid g, BicgPtrs q, int i
     if (threadIdx.x == 0) atomicAdd(a + A_SS, (double)part[0]);
 }
 
-// K4_i: t = C s ; ts += t.s ; tt += t.t        (skipped when ||s|| already meets the tolerance)
+// K4_i: t = C s ; ts += t.s ; tt += t.t        (skipped when ||s|| already meets the tolerance; grid.y = 1)
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int it, int tiles_x, int tiles_y,
                                                       int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
-    if (q.flags[s.sys] != 0) return;
-    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float crit_s = fg_rms(a[A_SS], g.n);
-    if (!(crit_s >= q.tol)) {
-        // converged on s (bicgstab_solver_kernel.cu:305-329): flag 4 = "K5 applies x += alpha p, then done".
-        // Nothing in THIS launch depends on the flag value written here (all workgroups take this branch).
-        if (s.leader) {
-            fg_mark(q.flags, q.info, s.sys, crit_s, it);
-            if (isfinite(crit_s)) q.flags[s.sys] = 4;
+    const size_t N = g.n;
+    const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
+    bool work[3] = {false, false, false};
+    bool any = false;
+    for (int comp = 0; comp < q.nc; ++comp) {
+        const int sys = c.b * q.nc + comp;
+        if (q.flags[sys] != 0) continue;
+        double* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+        const float crit_s = fg_rms(a[A_SS], g.n);
+        if (!(crit_s >= q.tol)) {
+            // converged on s (bicgstab_solver_kernel.cu:305-329): flag 4 = "K5 applies x += alpha p, then done".
+            // Nothing in THIS launch depends on the flag value written here (every workgroup of the env takes this
+            // branch from the same accumulator value, and reads flags only above).
+            if (leader) {
+                fg_mark(q.flags, q.info, sys, crit_s, it);
+                if (isfinite(crit_s)) q.flags[sys] = 4;
+            }
+            continue;
         }
-        return;
+        work[comp] = true;
+        any = true;
     }
-    const size_t N = g.n, vb = (size_t)s.sys * N;
+    // every workgroup must have read flags before a leader of the same env may overwrite them: flags of an env are
+    // only written by that env's leader workgroup, after its own reads; other workgroups read either value and then
+    // decide by the accumulator, which is stable -> same decision.  (Same protocol as before, per system.)
+    if (!any) return;
+    FgStencilRow<DIMS, VEC> m;
+    if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
     __shared__ float lds[8];
-    float part[2] = {0.f, 0.f};
-    if (c.valid) {
-        const FgVec<VEC> t = fg_spmv<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, q.r + vb,
-                                                c, N);
-        const FgVec<VEC> sv = fg_load<VEC>(q.r + vb + c.idx);
-        fg_store<VEC>(q.t + vb + c.idx, t);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            part[0] += t.v[e] * sv.v[e];
-            part[1] += t.v[e] * t.v[e];
+    for (int comp = 0; comp < 3; ++comp) {
+        if (comp >= q.nc || !work[comp]) continue;
+        const int sys = c.b * q.nc + comp;
+        const size_t vb = (size_t)sys * N;
+        float part[2] = {0.f, 0.f};
+        if (c.valid) {
+            const FgVec<VEC> t = fg_apply_row<DIMS, VEC>(m, q.r + vb, c);
+            const FgVec<VEC> sv = fg_load<VEC>(q.r + vb + c.idx);
+            fg_store<VEC>(q.t + vb + c.idx, t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                part[0] += t.v[e] * sv.v[e];
+                part[1] += t.v[e] * t.v[e];
+            }
         }
-    }
-    fg_block_sum<2>(part, lds);
-    if (threadIdx.x == 0) {
-        atomicAdd(a + A_TS, (double)part[0]);
-        atomicAdd(a + A_TT, (double)part[1]);
+        fg_block_sum<2>(part, lds);
+        if (threadIdx.x == 0) {
+            double* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+            atomicAdd(a + A_TS, (double)part[0]);
+            atomicAdd(a + A_TT, (double)part[1]);
+        }
+        __syncthreads();
     }
 }
 
@@ -328,27 +389,28 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     const dim3 sg((nsys + 63) / 64), sb(64);
     hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
 
-#define FG_BICG_LAUNCH(SLOT, KERNEL, ...)                                                                          \
+#define FG_BICG_LAUNCH_Y(NY, SLOT, KERNEL, ...)                                                                          \
     do {                                                                                                     \
         if (s->grid.dims == 2) {                                                                             \
             if (s->vec == 4) {                                                                               \
-                FgLaunch L = fg_launch_geometry<2, 4>(s->grid); L.grid.y = a.nc;                             \
+                FgLaunch L = fg_launch_geometry<2, 4>(s->grid); L.grid.y = (NY);                             \
                 FG_LAUNCH_P(s, SLOT, (KERNEL<2, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             } else {                                                                                         \
-                FgLaunch L = fg_launch_geometry<2, 1>(s->grid); L.grid.y = a.nc;                             \
+                FgLaunch L = fg_launch_geometry<2, 1>(s->grid); L.grid.y = (NY);                             \
                 FG_LAUNCH_P(s, SLOT, (KERNEL<2, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             }                                                                                                \
         } else {                                                                                             \
             if (s->vec == 4) {                                                                               \
-                FgLaunch L = fg_launch_geometry<3, 4>(s->grid); L.grid.y = a.nc;                             \
+                FgLaunch L = fg_launch_geometry<3, 4>(s->grid); L.grid.y = (NY);                             \
                 FG_LAUNCH_P(s, SLOT, (KERNEL<3, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             } else {                                                                                         \
-                FgLaunch L = fg_launch_geometry<3, 1>(s->grid); L.grid.y = a.nc;                             \
+                FgLaunch L = fg_launch_geometry<3, 1>(s->grid); L.grid.y = (NY);                             \
                 FG_LAUNCH_P(s, SLOT, (KERNEL<3, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             }                                                                                                \
         }                                                                                                    \
     } while (0)
 
+#define FG_BICG_LAUNCH(SLOT, KERNEL, ...) FG_BICG_LAUNCH_Y(a.nc, SLOT, KERNEL, __VA_ARGS__)
     FG_BICG_LAUNCH(-1, k_bicg_init, a.use_x0);
     bool done = false;
     // first convergence poll where the previous solve finished (kernels of converged systems exit at once,
@@ -361,9 +423,9 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         const double cells = (double)n, mat = 4.0 * (1 + 2 * s->grid.dims) / a.nc, fl = 2.0 * (1 + 2 * s->grid.dims);
         if (it > 0) FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_P, q.flags, nsys, cells * 16.0, cells * 4.0, st), k_bicg_p, it);
         else FG_BICG_LAUNCH(-1, k_bicg_p, it);
-        FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_V, q.flags, nsys, cells * (12.0 + mat), cells * (fl + 2.0), st), k_bicg_v, it);
+        FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICG_V, q.flags, nsys, cells * (12.0 + mat), cells * (fl + 2.0), st), k_bicg_v, it);
         FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_S, q.flags, nsys, cells * 12.0, cells * 4.0, st), k_bicg_s, it);
-        FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_T, q.flags, nsys, cells * (8.0 + mat), cells * (fl + 4.0), st), k_bicg_t, it);
+        FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICG_T, q.flags, nsys, cells * (8.0 + mat), cells * (fl + 4.0), st), k_bicg_t, it);
         FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_X, q.flags, nsys, cells * 28.0, cells * 10.0, st), k_bicg_x, it);
         if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
             next_poll = it + 1 + 2;
@@ -376,6 +438,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         }
     }
 #undef FG_BICG_LAUNCH
+#undef FG_BICG_LAUNCH_Y
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
     if (int prc = fg_prof_collect(s, st)) return prc;

@@ -455,14 +455,20 @@ static bool tridiag_lds_ready(size_t bytes) {
     return true;
 }
 
-static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, hipStream_t st) {
+static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expect_active, hipStream_t st) {
     // algorithmic traffic per env: A read + C written (+ the dot operand); the transform matrix stays in L2
     const double bytes = 4.0 * ((double)g.M * g.K + (double)g.M * g.N + (g.dot_with ? (double)g.M * g.N : 0.0));
-    const int slot = fg_prof_slot(s, FG_PK_GEMM, g.flags, batch, bytes, 2.0 * g.M * g.N * g.K, st);
     const long big_blocks = (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * batch;
+    const bool tiled = big_blocks >= 512 || (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * expect_active >= 384;
+    const int slot = fg_prof_slot(s, tiled ? FG_PK_GEMM : FG_PK_GEMM_SK, g.flags, batch, bytes, 2.0 * g.M * g.N * g.K, st);
     if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
         FG_LAUNCH_P(s, slot, (k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, st, g);
+    } else if ((long)((g.N + 63) / 64) * ((g.M + 63) / 64) * expect_active >= 384) {
+        // enough live 64 x 64 tiles for ~1.5 workgroups per CU: the LDS-staged tile reads each operand half as often
+        // (measured at 256 x 128, all envs live: B = 64 17.5 us vs 27 us split-K; B = 16 10.1 vs 8.8; B = 4 9.6 vs 6.5)
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
+        FG_LAUNCH_P(s, slot, (k_gemm_f32<1, 1, 64>), grid, dim3(256), 0, st, g);
     } else {
         const int tn = (g.N + 31) / 32, tm = (g.M + 31) / 32;
         dim3 grid((unsigned)(tn * tm * batch));
@@ -474,7 +480,9 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, hipStrea
 }
 
 // z = M^-1 r for all envs with flags == 0; optionally rz_acc[b * rz_stride] += r . z
-int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, hipStream_t st) {
+int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, int expect_active,
+                hipStream_t st) {
+    if (expect_active <= 0 || expect_active > s->grid.B) expect_active = s->grid.B;
     const FgGrid& G = s->grid;
     const int nx = G.nx, ny = G.ny, nz = G.nz, B = G.B;
     const long N = G.n;
@@ -487,7 +495,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
     g.C = t1; g.ldc = nx; g.strideC = N;
     g.M = ny * nz; g.N = nx; g.K = nx;
     g.flags = s->flags; g.dot_with = nullptr; g.strideW = 0; g.dot_acc = nullptr; g.dot_stride = 0; g.dot_ns = 1;
-    if (int rc = launch_gemm(s, g, B, st)) return rc;
+    if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
     float* cur = t1;
     if (G.dims == 3) {
         // forward z: t2[c, m] = sum_k QzT[c, k] t1[k, m]   (m over ny*nx)
@@ -495,7 +503,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
         g.B = t1; g.ldb = (long)ny * nx; g.strideB = N; g.Bt = nullptr; g.ldbt = 0;
         g.C = t2; g.ldc = (long)ny * nx; g.strideC = N;
         g.M = nz; g.N = ny * nx; g.K = nz;
-        if (int rc = launch_gemm(s, g, B, st)) return rc;
+        if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
         cur = t2;
     }
     {
@@ -517,7 +525,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
         g.B = t2; g.ldb = (long)ny * nx; g.strideB = N; g.Bt = nullptr; g.ldbt = 0;
         g.C = t1; g.ldc = (long)ny * nx; g.strideC = N;
         g.M = nz; g.N = ny * nx; g.K = nz;
-        if (int rc = launch_gemm(s, g, B, st)) return rc;
+        if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
         cur = t1;
     }
     // inverse x: z[rows, i] = sum_a cur[rows, a] QxT[a, i], fused r.z
@@ -526,7 +534,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
     g.C = z; g.ldc = nx; g.strideC = N;
     g.M = ny * nz; g.N = nx; g.K = nx;
     g.dot_with = rz_acc ? r : nullptr; g.strideW = N; g.dot_acc = rz_acc; g.dot_stride = rz_stride; g.dot_ns = rz_ns;
-    if (int rc = launch_gemm(s, g, B, st)) return rc;
+    if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

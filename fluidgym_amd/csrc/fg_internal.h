@@ -295,7 +295,7 @@ __device__ __forceinline__ void fg_block_sum(float (&v)[NV], float* lds /* >= NV
 // kernel snapshots how many systems were still iterating so the algorithmic bytes count only work done.
 enum FgProfKind {
     FG_PK_CG_AP = 0, FG_PK_CG_UPDATE, FG_PK_BICG_P, FG_PK_BICG_V, FG_PK_BICG_S, FG_PK_BICG_T, FG_PK_BICG_X,
-    FG_PK_GEMM, FG_PK_TRIDIAG, FG_PK_COUNT
+    FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_COUNT
 };
 #define FG_PROF_POOL 256
 struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };
@@ -307,6 +307,8 @@ struct FgProf {
     int32_t* active_pinned;
     double ms[FG_PK_COUNT], bytes[FG_PK_COUNT], flops[FG_PK_COUNT], full_ms[FG_PK_COUNT], full_bytes[FG_PK_COUNT];
     long long n[FG_PK_COUNT], full_n[FG_PK_COUNT], launches[FG_PK_COUNT];
+    double all_ms[FG_PK_COUNT];   // every sampled launch, including those that found all systems converged
+    long long all_n[FG_PK_COUNT];
 };
 #define FG_ACC_DOUBLES 16  // reduction accumulators per linear system (see solver kernels)
 
@@ -458,5 +460,7 @@ void fg_prof_destroy(fg_state* s);
         else                                                                                                   \
             hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                   \
     } while (0)
-int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, hipStream_t st);
+// expect_active: the caller's estimate of envs still iterating (<= 0: all) -- only picks the GEMM tile shape
+int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, int expect_active,
+                hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

@@ -401,9 +401,10 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         if (!s->fd_Qx) { fg_set_error("preconditioned CG requested but fg_set_fd_preconditioner was not called"); return FG_ERR_INVALID_ARG; }
         // residual check of x0 (sets flags for already-converged envs), then z0 = M^-1 r0, r0.z0
         hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, -1, n, B, 0, ns);
-        if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, st)) return rc;
+        if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, B, st)) return rc;
     }
     bool done = false;
+    int active_est = (B + 3) / 4;  // envs expected to still iterate after the first iteration, refreshed by every poll
     int next_poll = a.precond ? (s->pred_cg + 1 > 1 ? s->pred_cg + 1 : 1) : check_every;
     int it = 0;
     for (; it < a.max_iterations && !done; ++it) {
@@ -452,14 +453,19 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         }
         if (a.precond && it + 1 < a.max_iterations) {
             // z = M^-1 r and r.z of the next iteration (envs that just converged are skipped via flags)
-            if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + (it + 1) % 3) * FG_CG_SLOTS, acc_stride, ns, st))
+            if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + (it + 1) % 3) * FG_CG_SLOTS, acc_stride, ns, active_est, st))
                 return rc;
         }
         if (poll) {
             FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
             FG_HIP_CHECK(hipStreamSynchronize(st));
             done = true;
-            for (int b = 0; b < B; ++b) done = done && (s->flags_pinned[b] != 0);
+            active_est = 0;
+            for (int b = 0; b < B; ++b) {
+                done = done && (s->flags_pinned[b] != 0);
+                active_est += (s->flags_pinned[b] == 0);
+            }
+            if (active_est < 1) active_est = 1;
         }
     }
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));

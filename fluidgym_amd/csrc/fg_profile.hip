@@ -26,7 +26,7 @@ __global__ void k_prof_count(const int32_t* __restrict__ flags, int nsys, int32_
     if (threadIdx.x == 0) *out = c;
 }
 const char* const kNames[FG_PK_COUNT] = {"k_cg_ap", "k_cg_update", "k_bicg_p", "k_bicg_v", "k_bicg_s", "k_bicg_t",
-                                         "k_bicg_x", "k_gemm_f32", "k_tridiag_y"};
+                                         "k_bicg_x", "k_gemm_f32", "k_gemm_sk", "k_tridiag_y"};
 }  // namespace
 
 int fg_prof_slot(const fg_state* cs, int kind, const int32_t* flags, int nsys, double bytes_per_sys,
@@ -52,8 +52,9 @@ int fg_prof_collect(fg_state* s, hipStream_t st) {
         const FgProfMeta& m = P.meta[i];
         const int act = P.active_pinned[i] < 0 ? m.nsys : P.active_pinned[i];
         float ms = 0.f;
-        if (act <= 0) continue;  // every system had converged: the launch did no work
         if (hipEventElapsedTime(&ms, P.ev[2 * i], P.ev[2 * i + 1]) != hipSuccess) continue;
+        P.all_ms[m.kind] += ms; P.all_n[m.kind]++;
+        if (act <= 0) continue;  // every system had converged: the launch did no work
         P.ms[m.kind] += ms; P.n[m.kind]++;
         P.bytes[m.kind] += act * m.bytes_per_sys; P.flops[m.kind] += act * m.flops_per_sys;
         if (act == m.nsys) { P.full_ms[m.kind] += ms; P.full_bytes[m.kind] += act * m.bytes_per_sys; P.full_n[m.kind]++; }
@@ -73,10 +74,11 @@ extern "C" int fg_profile_enable(fg_handle s, int on) {
     FG_HIP_CHECK(hipDeviceSynchronize());
     P.on = on; P.used = 0;
     const char* e = getenv("FG_PROF_PERIOD");
-    P.period = e && atoi(e) > 0 ? atoi(e) : 3;
+    P.period = e && atoi(e) > 0 ? atoi(e) : 8;
     for (int k = 0; k < FG_PK_COUNT; ++k) {
         P.ms[k] = P.bytes[k] = P.flops[k] = P.full_ms[k] = P.full_bytes[k] = 0.0;
-        P.n[k] = P.full_n[k] = P.launches[k] = 0;
+        P.n[k] = P.full_n[k] = P.launches[k] = P.all_n[k] = 0;
+        P.all_ms[k] = 0.0;
     }
     return FG_OK;
 }
@@ -86,7 +88,7 @@ extern "C" const char* fg_profile_kind_name(int kind) { return kind >= 0 && kind
 
 extern "C" int fg_profile_read(fg_handle s, int kind, double* ms_sum, int64_t* samples, double* bytes_sum,
                                double* flops_sum, double* full_ms_sum, double* full_bytes_sum, int64_t* full_samples,
-                               int64_t* launches) {
+                               int64_t* launches, double* all_ms_sum, int64_t* all_samples) {
     FG_REQUIRE(s && kind >= 0 && kind < FG_PK_COUNT, FG_ERR_INVALID_ARG, "bad handle or kernel kind");
     FG_HIP_CHECK(hipDeviceSynchronize());
     if (int rc = fg_prof_collect(s, nullptr)) return rc;
@@ -99,6 +101,8 @@ extern "C" int fg_profile_read(fg_handle s, int kind, double* ms_sum, int64_t* s
     if (full_bytes_sum) *full_bytes_sum = P.full_bytes[kind];
     if (full_samples) *full_samples = P.full_n[kind];
     if (launches) *launches = P.launches[kind];
+    if (all_ms_sum) *all_ms_sum = P.all_ms[kind];
+    if (all_samples) *all_samples = P.all_n[kind];
     return FG_OK;
 }
 

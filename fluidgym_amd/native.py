@@ -324,14 +324,15 @@ class NativeSolver:
         solver-kernel launches since profile_enable (see fg_profile_read in include/fluidgym_hip.h)."""
         out = {}
         for k in range(self.lib.fg_profile_kinds()):
-            ms, by, fl, fms, fby = (ctypes.c_double() for _ in range(5))
-            n, fn, nl = (ctypes.c_int64() for _ in range(3))
+            ms, by, fl, fms, fby, ams = (ctypes.c_double() for _ in range(6))
+            n, fn, nl, an = (ctypes.c_int64() for _ in range(4))
             L.check(self.lib.fg_profile_read(self.handle, k, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by),
                                              ctypes.byref(fl), ctypes.byref(fms), ctypes.byref(fby), ctypes.byref(fn),
-                                             ctypes.byref(nl)))
+                                             ctypes.byref(nl), ctypes.byref(ams), ctypes.byref(an)))
             out[self.lib.fg_profile_kind_name(k).decode()] = dict(
                 ms=ms.value, samples=n.value, bytes=by.value, flops=fl.value, full_ms=fms.value,
-                full_bytes=fby.value, full_samples=fn.value, launches=nl.value)
+                full_bytes=fby.value, full_samples=fn.value, launches=nl.value, all_ms=ams.value,
+                all_samples=an.value)
         return out
 
     def poisson_fdcg(self, rA, b, x, tol=1e-5, max_iterations=500, use_x0=False):

@@ -243,19 +243,22 @@ int fg_poisson_fdcg(fg_handle h, const float* rA, const float* b, float* x, floa
                     int use_x0, fg_solve_info* info_host, void* stream);
 
 /* ---- live kernel timing for bench.py's roofline -----------------------------------------------
- * When enabled, every FG_PROF_PERIOD-th launch (default 3) of each solver kernel kind is issued with a
+ * When enabled, every FG_PROF_PERIOD-th launch (default 8) of each solver kernel kind is issued with a
  * start/stop event pair on the solve's stream (kernel-accurate timestamps), and the systems still
  * iterating in that launch are counted on the device.  Kinds are 0 .. fg_profile_kinds()-1, named by
- * fg_profile_kind_name (k_cg_ap, k_cg_update, k_bicg_p/v/s/t/x, k_gemm_f32, k_tridiag_y).
+ * fg_profile_kind_name (k_cg_ap, k_cg_update, k_bicg_p/v/s/t/x, k_gemm_f32, k_gemm_sk, k_tridiag_y).
  * fg_profile_read returns for one kind: summed milliseconds and count of the sampled launches that did
  * work, their summed ALGORITHMIC bytes and flops (active systems x per-system figure),
  * the same restricted to launches in which every system was active, and the total launches of that kind
- * (sampled or not) since fg_profile_enable.  Any output pointer may be NULL.  Synchronises the device. */
+ * (sampled or not) since fg_profile_enable, and milliseconds / count over ALL sampled launches including
+ * those that found every system converged (the figure rocprofv3 --stats averages).  Any output pointer
+ * may be NULL.  Synchronises the device. */
 int fg_profile_enable(fg_handle h, int on);
 int fg_profile_kinds(void);
 const char* fg_profile_kind_name(int kind);
 int fg_profile_read(fg_handle h, int kind, double* ms_sum, int64_t* samples, double* bytes_sum, double* flops_sum,
-                    double* full_ms_sum, double* full_bytes_sum, int64_t* full_samples, int64_t* launches);
+                    double* full_ms_sum, double* full_bytes_sum, int64_t* full_samples, int64_t* launches,
+                    double* all_ms_sum, int64_t* all_samples);
 
 /* ---- grid metrics --------------------------------------------------------------------------- */
 /* CoordsToTransforms (grid_gen.cu:298-390): vertex coords [d,(nz+1,)ny+1,nx+1] ->
