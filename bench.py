@@ -96,6 +96,29 @@ KERNEL_DOC = {
 }
 
 
+def pmc_traffic(kernel):
+    """Memory-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
+    fetch counter as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so this
+    is the last profiled run, not this run; None when the file has no row for the kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    key = {"k_tridiag_y": "k_tridiag_y_lds"}.get(kernel, kernel)
+    row = t["kernels"].get(key)
+    if row is None:
+        return None
+    if isinstance(row, list):
+        row = row[0]
+    return {"fetch_bytes_per_launch": row["fetch_bytes"], "write_bytes_per_launch": row["write_bytes"],
+            "launches_averaged": row["launches"], "unit": "B", "source": "profiles/r01_traffic.json (rocprofv3 --pmc, "
+            "separate FETCH_SIZE and WRITE_SIZE passes of bench.py; averages include launches that found every "
+            "system converged; Infinity-Cache hits are counted)"}
+
+
 def roofline_from_profile(prof, solver):
     """``roofline`` object for the kernel that took the largest share of the timed region.
 
@@ -126,7 +149,7 @@ def roofline_from_profile(prof, solver):
     else:
         ach, peak, unit, bound = d["GBps"], HBM_PEAK_GBS, "GB/s", "hbm"
     return {"bound": bound, "kernel": f"{dom}: {KERNEL_DOC.get(dom, '')}", "achieved": ach, "peak": peak, "unit": unit,
-            "frac": ach / peak, "traffic": None, "avg_launch_ms": d["avg_launch_ms"],
+            "frac": ach / peak, "traffic": pmc_traffic(dom), "avg_launch_ms": d["avg_launch_ms"],
             "avg_busy_launch_ms": d["avg_busy_launch_ms"], "samples": d["samples"],
             "launches": d["launches"], "avg_bytes_per_launch": d["avg_bytes_per_launch"],
             "kernels": rows,

@@ -27,21 +27,27 @@ struct GemmArgs {
 // each wave owns TM x TN MFMA tiles of 32 x 32 (TM = TN = 2: 128 x 128 block tile, 64 accumulator
 // registers; TM = TN = 1: 64 x 64 block tile for launches that would otherwise leave CUs idle).
 template <int TM, int TN, int BK>
-__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g, int tiles_n, int tiles_m) {
     // BK = K-depth staged per barrier pair.  The small launches of the batched 2-D case are latency-bound
     // (one L2 round trip per K-step, only 8 MFMAs per wave to cover it), so they use BK = 64: 4x fewer steps,
     // 4x more bytes in flight per step.
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int LDA_S = BM + 4, LDB_S = BN + 4;  // LDS row pitch; +4 floats keeps 16-B alignment, breaks conflicts
     constexpr int PA = BM * BK / 256, PB = BN * BK / 256;  // floats staged per thread (8 or 4)
-    const int b = blockIdx.z;
+    // 1-D grid, logical tile id = (env, m-tile, n-tile) with n fastest; the XCD remap hands every XCD a contiguous
+    // range of ids, so the n-tiles that re-read one A row block (and an env's tiles) share one L2 (PMC before:
+    // 13 MB fetched per launch against 6.4 MB algorithmic, each n-tile pulling A through a different XCD)
+    const unsigned id = fg_xcd_remap(blockIdx.x, gridDim.x);
+    const int per_b = tiles_n * tiles_m;
+    const int b = id / per_b;
     if (g.flags && g.flags[b] != 0) return;
+    const int rem = id - b * per_b, tile_m = rem / tiles_n, tile_n = rem - tile_m * tiles_n;
     __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
     const float* __restrict__ A = g.A + (size_t)b * g.strideA;
     const float* __restrict__ B = g.B + (size_t)b * g.strideB;
     float* __restrict__ C = g.C + (size_t)b * g.strideC;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
 
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
         float part[1] = {dot};
         fg_block_sum<1>(part, lds);
         if (tid == 0)
-            atomicAdd(g.dot_acc + (size_t)b * g.dot_stride + ((blockIdx.x + blockIdx.y * gridDim.x) & (unsigned)(g.dot_ns - 1)),
+            atomicAdd(g.dot_acc + (size_t)b * g.dot_stride + ((unsigned)rem & (unsigned)(g.dot_ns - 1)),
                       (double)part[0]);
     }
 }
@@ -462,13 +468,13 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expe
     const bool tiled = big_blocks >= 512 || (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * expect_active >= 384;
     const int slot = fg_prof_slot(s, tiled ? FG_PK_GEMM : FG_PK_GEMM_SK, g.flags, batch, bytes, 2.0 * g.M * g.N * g.K, st);
     if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
-        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
-        FG_LAUNCH_P(s, slot, (k_gemm_f32<2, 2, 16>), grid, dim3(256), 0, st, g);
+        const int tn = (g.N + 127) / 128, tm = (g.M + 127) / 128;
+        FG_LAUNCH_P(s, slot, (k_gemm_f32<2, 2, 16>), dim3((unsigned)(tn * tm * batch)), dim3(256), 0, st, g, tn, tm);
     } else if ((long)((g.N + 63) / 64) * ((g.M + 63) / 64) * expect_active >= 384) {
         // enough live 64 x 64 tiles for ~1.5 workgroups per CU: the LDS-staged tile reads each operand half as often
         // (measured at 256 x 128, all envs live: B = 64 17.5 us vs 27 us split-K; B = 16 10.1 vs 8.8; B = 4 9.6 vs 6.5)
-        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
-        FG_LAUNCH_P(s, slot, (k_gemm_f32<1, 1, 64>), grid, dim3(256), 0, st, g);
+        const int tn = (g.N + 63) / 64, tm = (g.M + 63) / 64;
+        FG_LAUNCH_P(s, slot, (k_gemm_f32<1, 1, 64>), dim3((unsigned)(tn * tm * batch)), dim3(256), 0, st, g, tn, tm);
     } else {
         const int tn = (g.N + 31) / 32, tm = (g.M + 31) / 32;
         dim3 grid((unsigned)(tn * tm * batch));
