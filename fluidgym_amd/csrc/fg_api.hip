@@ -298,7 +298,7 @@ extern "C" int fg_setup_pressure_rhs(fg_handle s, const float* dt_B, void* strea
 }
 
 static int solve_pressure(fg_state* s, const float* dt, int method, float tol, int max_iterations, int use_previous,
-                          fg_solve_info* info_host, hipStream_t st) {
+                          fg_solve_info* info_host, hipStream_t st, bool finalize = true) {
     int rc = FG_OK;
     if (method == FG_SOLVER_CG || method == FG_SOLVER_FDCG) {
         FgCgArgs a;
@@ -314,8 +314,11 @@ static int solve_pressure(fg_state* s, const float* dt, int method, float tol, i
         return FG_ERR_UNSUPPORTED;
     }
     if (rc != FG_OK && rc != FG_ERR_NOT_CONVERGED) return rc;
-    // p -= mean(p); setPressureResult; CopyPressureResultToBlocks (PISOtorch_simulation.py:1817-1821, 1953)
-    if (int rc2 = fg_launch_mean_sub(s, dt, s->p_result, s->pressure, st)) return rc2;
+    // p -= mean(p); setPressureResult; CopyPressureResultToBlocks (PISOtorch_simulation.py:1817-1821, 1953).
+    // finalize == false (inner correctors of the fused step): the velocity corrector only needs grad p and the next
+    // solve starts from p_result, both blind to the constant, so the two passes over p are left to the last corrector.
+    if (finalize)
+        if (int rc2 = fg_launch_mean_sub(s, dt, s->p_result, s->pressure, st)) return rc2;
     return rc;
 }
 
@@ -406,14 +409,16 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
     // ---- correctors (:1777-1972)
     if (int rc = fg_launch_pressure_setup(s, dt_B, st)) return rc;
     for (int c = 0; c < opt->corrector_steps; ++c) {
+        const bool last = (c + 1 == opt->corrector_steps);
         if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
         if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st)) return rc;
         if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations,
                                          opt->pressure_warm_start ? 1 : 0,
-                                         info.data(), st)))
+                                         info.data(), st, last)))
             return rc;
         if (c < 2) stats[2 + c] = max_iters(info.data(), B);
-        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, s->pressure, s->vel_result, st)) return rc;
+        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, last ? s->pressure : s->p_result, s->vel_result, st))
+            return rc;
     }
     // CopyVelocityResultToBlocks (:1974)
     if (int rc = fg_launch_copy_active(s, dt_B, s->vel_result, s->velocity, d, st)) return rc;

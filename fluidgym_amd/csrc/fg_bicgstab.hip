@@ -412,7 +412,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
 
 #define FG_BICG_LAUNCH(SLOT, KERNEL, ...) FG_BICG_LAUNCH_Y(a.nc, SLOT, KERNEL, __VA_ARGS__)
     FG_BICG_LAUNCH(-1, k_bicg_init, a.use_x0);
-    bool done = false;
+    bool done = false, info_fresh = false;
     // first convergence poll where the previous solve finished (kernels of converged systems exit at once,
     // so over-launching costs ~2 us per kernel while every poll costs a stream sync), then every 2 iterations
     int next_poll = s->pred_bicg > 1 ? s->pred_bicg : 1;
@@ -431,16 +431,20 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
             next_poll = it + 1 + 2;
             const int final_pass = (it + 1 == a.max_iterations);
             hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, a.tol, it, n, nsys, final_pass);
-            FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));
+            // one read-back serves the poll and the result (nothing is launched after the last poll)
+            FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
             FG_HIP_CHECK(hipStreamSynchronize(st));
+            info_fresh = true;
             done = true;
-            for (int i = 0; i < nsys; ++i) done = done && (s->flags_pinned[i] != 0);
+            for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
         }
     }
 #undef FG_BICG_LAUNCH
 #undef FG_BICG_LAUNCH_Y
-    FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
-    FG_HIP_CHECK(hipStreamSynchronize(st));
+    if (!info_fresh) {
+        FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
+        FG_HIP_CHECK(hipStreamSynchronize(st));
+    }
     if (int prc = fg_prof_collect(s, st)) return prc;
     int rc = FG_OK;
     int used_max = 0;

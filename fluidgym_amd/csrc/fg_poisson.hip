@@ -403,7 +403,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, -1, n, B, 0, ns);
         if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, B, st)) return rc;
     }
-    bool done = false;
+    bool done = false, info_fresh = false;
     int active_est = (B + 3) / 4;  // envs expected to still iterate after the first iteration, refreshed by every poll
     int next_poll = a.precond ? (s->pred_cg + 1 > 1 ? s->pred_cg + 1 : 1) : check_every;
     int it = 0;
@@ -457,19 +457,25 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 return rc;
         }
         if (poll) {
-            FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->flags, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+            // one read-back serves the poll and the result: info carries converged / is_finite of every env, and nothing
+            // is launched between the last poll and the end of the solve
+            FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
             FG_HIP_CHECK(hipStreamSynchronize(st));
+            info_fresh = true;
             done = true;
             active_est = 0;
             for (int b = 0; b < B; ++b) {
-                done = done && (s->flags_pinned[b] != 0);
-                active_est += (s->flags_pinned[b] == 0);
+                const bool fin = s->info_pinned[b].converged || !s->info_pinned[b].is_finite;
+                done = done && fin;
+                active_est += !fin;
             }
             if (active_est < 1) active_est = 1;
         }
     }
-    FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
-    FG_HIP_CHECK(hipStreamSynchronize(st));
+    if (!info_fresh) {
+        FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
+        FG_HIP_CHECK(hipStreamSynchronize(st));
+    }
     if (int prc = fg_prof_collect(s, st)) return prc;
     int rc = FG_OK;
     if (a.precond) {
