@@ -256,6 +256,7 @@ extern "C" int fg_setup_advection(fg_handle s, const float* dt_B, int for_scalar
     } else {
         a.source = s->velocity_source;
         a.nu = s->viscosity;
+        a.rA = s->rA;
     }
     return fg_launch_adv_build(s, make_bounds(s, channel), a, (hipStream_t)stream);
 }
@@ -406,8 +407,7 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
         if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
         stats[1] = max_iters(info.data(), B * d);
     }
-    // ---- correctors (:1777-1972)
-    if (int rc = fg_launch_pressure_setup(s, dt_B, st)) return rc;
+    // ---- correctors (:1777-1972); rA = 1/A was written by the velocity fg_setup_advection above
     for (int c = 0; c < opt->corrector_steps; ++c) {
         const bool last = (c + 1 == opt->corrector_steps);
         if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;

@@ -69,40 +69,81 @@ struct BicgPtrs {
     int nc; float tol;
 };
 
-// init: r = rhs - C x0 ; rw = r ; p = r ; rho_0 = rr = r.r
+// SpMV with the matrix held in registers: the (1 + 2 DIMS) coefficient fields belong to the env, not to the system,
+// so one workgroup applies them to ALL nc right-hand sides of its tile.  With one workgroup per (tile, component) the
+// two/three component workgroups usually sat on different XCDs and each pulled the matrix through its own L2
+// (rocprofv3 FETCH_SIZE of k_bicg_v: 86 MB per launch against 56 MB of algorithmic reads).
+template <int DIMS, int VEC>
+struct FgStencilRow {
+    FgVec<VEC> d, o[2 * DIMS];
+};
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgStencilRow<DIMS, VEC> fg_load_row(const float* __restrict__ diag,
+                                                              const float* __restrict__ off,
+                                                              const FgCtx<DIMS, VEC>& c, size_t N) {
+    FgStencilRow<DIMS, VEC> m;
+    m.d = fg_load<VEC>(diag + c.idx);
+#pragma unroll
+    for (int f = 0; f < 2 * DIMS; ++f) m.o[f] = fg_load<VEC>(off + f * N + c.idx);
+    return m;
+}
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgVec<VEC> fg_apply_row(const FgStencilRow<DIMS, VEC>& m, const float* __restrict__ x,
+                                                   const FgCtx<DIMS, VEC>& c) {
+    const FgNbr<DIMS, VEC> X = fg_gather<DIMS, VEC>(x, c);
+    FgVec<VEC> y;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        float v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
+                  m.o[3].v[e] * X.yp.v[e];
+        if constexpr (DIMS == 3) v += m.o[4].v[e] * X.zm.v[e] + m.o[5].v[e] * X.zp.v[e];
+        y.v[e] = v;
+    }
+    return y;
+}
+
+// init: r = rhs - C x0 ; rw = r ; p = r ; rho_0 = rr = r.r        (grid.y = 1: loops over the nc systems of the env)
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_bicg_init(FgGrid g, BicgPtrs q, int use_x0, int tiles_x, int tiles_y,
                                                          int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
-    if (q.flags[s.sys] != 0) return;
-    const size_t N = g.n, vb = (size_t)s.sys * N;
+    const size_t N = g.n;
+    bool any = false;
+    for (int comp = 0; comp < q.nc; ++comp) any = any || (q.flags[c.b * q.nc + comp] == 0);
+    if (!any) return;
+    FgStencilRow<DIMS, VEC> m;
+    if (use_x0 && c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
     __shared__ float lds[4];
-    float part[1] = {0.f};
-    if (c.valid) {
-        FgVec<VEC> r = fg_load<VEC>(q.rhs + vb + c.idx);
-        if (use_x0) {
-            const FgVec<VEC> y = fg_spmv<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N,
-                                                    q.x + vb, c, N);
+    for (int comp = 0; comp < q.nc; ++comp) {
+        const int sys = c.b * q.nc + comp;
+        if (q.flags[sys] != 0) continue;
+        const size_t vb = (size_t)sys * N;
+        float part[1] = {0.f};
+        if (c.valid) {
+            FgVec<VEC> r = fg_load<VEC>(q.rhs + vb + c.idx);
+            if (use_x0) {
+                const FgVec<VEC> y = fg_apply_row<DIMS, VEC>(m, q.x + vb, c);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) r.v[e] -= y.v[e];
-        } else {
-            FgVec<VEC> z;
+                for (int e = 0; e < VEC; ++e) r.v[e] -= y.v[e];
+            } else {
+                FgVec<VEC> z;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) z.v[e] = 0.f;
-            fg_store<VEC>(q.x + vb + c.idx, z);
+                for (int e = 0; e < VEC; ++e) z.v[e] = 0.f;
+                fg_store<VEC>(q.x + vb + c.idx, z);
+            }
+            fg_store<VEC>(q.r + vb + c.idx, r);
+            fg_store<VEC>(q.rw + vb + c.idx, r);
+            fg_store<VEC>(q.p + vb + c.idx, r);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) part[0] += r.v[e] * r.v[e];
         }
-        fg_store<VEC>(q.r + vb + c.idx, r);
-        fg_store<VEC>(q.rw + vb + c.idx, r);
-        fg_store<VEC>(q.p + vb + c.idx, r);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) part[0] += r.v[e] * r.v[e];
-    }
-    fg_block_sum<1>(part, lds);
-    if (threadIdx.x == 0) {
-        double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-        atomicAdd(a + A_RHO, (double)part[0]);
-        atomicAdd(a + A_RR, (double)part[0]);
+        fg_block_sum<1>(part, lds);
+        if (threadIdx.x == 0) {
+            double* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+            atomicAdd(a + A_RHO, (double)part[0]);
+            atomicAdd(a + A_RR, (double)part[0]);
+        }
+        __syncthreads();
     }
 }
 
@@ -139,39 +180,6 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int i
 #pragma unroll
     for (int e = 0; e < VEC; ++e) p.v[e] = r.v[e] + beta * (p.v[e] - omega * v.v[e]);
     fg_store<VEC>(q.p + vb + c.idx, p);
-}
-
-// SpMV with the matrix held in registers: the (1 + 2 DIMS) coefficient fields belong to the env, not to the system,
-// so one workgroup applies them to ALL nc right-hand sides of its tile.  With one workgroup per (tile, component) the
-// two/three component workgroups usually sat on different XCDs and each pulled the matrix through its own L2
-// (rocprofv3 FETCH_SIZE of k_bicg_v: 86 MB per launch against 56 MB of algorithmic reads).
-template <int DIMS, int VEC>
-struct FgStencilRow {
-    FgVec<VEC> d, o[2 * DIMS];
-};
-template <int DIMS, int VEC>
-__device__ __forceinline__ FgStencilRow<DIMS, VEC> fg_load_row(const float* __restrict__ diag,
-                                                              const float* __restrict__ off,
-                                                              const FgCtx<DIMS, VEC>& c, size_t N) {
-    FgStencilRow<DIMS, VEC> m;
-    m.d = fg_load<VEC>(diag + c.idx);
-#pragma unroll
-    for (int f = 0; f < 2 * DIMS; ++f) m.o[f] = fg_load<VEC>(off + f * N + c.idx);
-    return m;
-}
-template <int DIMS, int VEC>
-__device__ __forceinline__ FgVec<VEC> fg_apply_row(const FgStencilRow<DIMS, VEC>& m, const float* __restrict__ x,
-                                                   const FgCtx<DIMS, VEC>& c) {
-    const FgNbr<DIMS, VEC> X = fg_gather<DIMS, VEC>(x, c);
-    FgVec<VEC> y;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        float v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
-                  m.o[3].v[e] * X.yp.v[e];
-        if constexpr (DIMS == 3) v += m.o[4].v[e] * X.zm.v[e] + m.o[5].v[e] * X.zp.v[e];
-        y.v[e] = v;
-    }
-    return y;
 }
 
 // K2_i: v = C p ; rv += rw.v        (grid.y = 1: loops over the nc systems of the env)
@@ -411,7 +419,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     } while (0)
 
 #define FG_BICG_LAUNCH(SLOT, KERNEL, ...) FG_BICG_LAUNCH_Y(a.nc, SLOT, KERNEL, __VA_ARGS__)
-    FG_BICG_LAUNCH(-1, k_bicg_init, a.use_x0);
+    FG_BICG_LAUNCH_Y(1, -1, k_bicg_init, a.use_x0);
     bool done = false, info_fresh = false;
     // first convergence poll where the previous solve finished (kernels of converged systems exit at once,
     // so over-launching costs ~2 us per kernel while every poll costs a stream sync), then every 2 iterations

@@ -392,6 +392,7 @@ struct FgAdvArgs {
     int for_scalar;
     int channel, n_scalars;
     float* A; float* Coff; float* rhs;
+    float* rA;             // optional: 1/A written alongside A (velocity system only)
 };
 int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
 int fg_launch_pressure_setup(const fg_state* s, const float* dt, hipStream_t st);  // rA = 1/A

@@ -144,6 +144,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { rJ[e] = 1.f / J[e]; out.v[e] = diag[e] * rJ[e]; }
     fg_store<VEC>(a.A + (size_t)c.b * N + c.idx, out);
+    if (a.rA) {  // rA = 1/A for the pressure system, same expression as k_reciprocal (saves its pass over A)
+        FgVec<VEC> r;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r.v[e] = 1.f / out.v[e];
+        fg_store<VEC>(a.rA + (size_t)c.b * N + c.idx, r);
+    }
 #pragma unroll
     for (int f = 0; f < 2 * DIMS; ++f) {
 #pragma unroll
@@ -617,8 +623,7 @@ int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long 
 }
 
 int fg_launch_mean_sub(const fg_state* s, const float* dt, float* p, float* p_copy, hipStream_t st) {
-    double* sums = s->acc;  // first B doubles of the accumulator pool are free between solves
-    FG_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * s->grid.B, st));
+    double* sums = s->acc;  // first B doubles of the accumulator pool: free between solves, zeroed by k_cg_begin
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
     hipLaunchKernelGGL(k_sum_env, grid, dim3(FG_BLOCK), 0, st, dt, p, sums, s->grid.n);
     hipLaunchKernelGGL(k_sub_mean, grid, dim3(FG_BLOCK), 0, st, dt, p, p_copy, sums, s->grid.n);

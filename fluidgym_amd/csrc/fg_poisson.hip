@@ -316,12 +316,13 @@ __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags
 }
 
 __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ acc, int32_t* __restrict__ flags,
-                           fg_solve_info* __restrict__ info, int B) {
+                           fg_solve_info* __restrict__ info, double* __restrict__ mean_sums, int B) {
     const int b = blockIdx.x;
     if (b >= B) return;
     for (int q = threadIdx.x; q < FG_CG_NAMES * FG_CG_SLOTS; q += blockDim.x)
         acc[(size_t)b * FG_CG_NAMES * FG_CG_SLOTS + q] = 0.0;
     if (threadIdx.x != 0) return;
+    mean_sums[b] = 0.0;  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
     const bool active = (dt == nullptr) || (dt[b] > 0.f);
     flags[b] = active ? 0 : 3;
     info[b].final_residual = 0.f;
@@ -387,7 +388,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const bool zmarch = fg_zmarch_ok(s, &zc);
     int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
     while (ns < FG_CG_SLOTS && tiles_per_env / ns > 256) ns *= 2;
-    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, B);
+    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, B);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,
