@@ -128,6 +128,10 @@ SIGNATURES = {
                                 POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                 POINTER(c_int64), POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_int64)]),
     "fg_coords_to_transforms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fg_resampler_create": (c_int, [c_int, POINTER(ctypes.c_int32), POINTER(ctypes.c_int32), POINTER(ctypes.c_int32),
+                                    POINTER(ctypes.c_float), c_int, c_int, POINTER(c_void_p)]),
+    "fg_resampler_destroy": (c_int, [c_void_p]),
+    "fg_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -260,6 +260,23 @@ int fg_profile_read(fg_handle h, int kind, double* ms_sum, int64_t* samples, dou
                     double* full_ms_sum, double* full_bytes_sum, int64_t* full_samples, int64_t* launches,
                     double* all_ms_sum, int64_t* all_samples);
 
+/* ---- observation resampling -------------------------------------------------------
+ * SampleTransformedGridLocalToGlobalMulti + _FillEmptyCells (extensions/resampling.cu:191-609; Python entry
+ * sample_multi_coords_to_uniform_grid, pict/data/resample.py:254-358) for ONE rectilinear block, as a gather.
+ * The caller supplies, per axis x, y(, z), the continuous output index of every source cell centre split into
+ * floor (base) and fraction (frac), concatenated over the axes (lengths n_src[0] + n_src[1] (+ n_src[2])); the
+ * index map must be non-decreasing along each axis (it is for the reference's AABB transforms on a rectilinear
+ * block).  quirk3d != 0 reproduces the compiled kernel's 6-of-8 corner loop in 3-D (resampling.cu:320), 0 is the
+ * full multilinear splat of the reference's pure-torch implementation (resample.py:361-548).
+ * fg_resample: src [batch, channels, (nz,) ny, nx] -> dst [batch, channels, (oz,) oy, ox], both fp32 device
+ * pointers, channels <= 8; fill_max_steps as fillMaxSteps (resampling.cu:242-290). */
+typedef struct fg_resampler_state* fg_resampler;
+int fg_resampler_create(int dims, const int32_t* n_src, const int32_t* n_out, const int32_t* base_cat,
+                        const float* frac_cat, int quirk3d, int device, fg_resampler* out);
+int fg_resampler_destroy(fg_resampler r);
+int fg_resample(fg_resampler r, const float* src, int batch, int channels, float* dst, int fill_max_steps,
+                void* stream);
+
 /* ---- grid metrics --------------------------------------------------------------------------- */
 /* CoordsToTransforms (grid_gen.cu:298-390): vertex coords [d,(nz+1,)ny+1,nx+1] ->
  * transforms [(nz,)ny,nx, 2 d^2 + 1] = M | Minv | det per cell. */
