@@ -17,9 +17,10 @@ reference:
   and cubic blending between heaters (``rbc_env_2d.py:196-276``);
 * reward ``nu_ref - Nu`` with ``Nu = 1 + sqrt(Ra Pr) <u_y T>_V`` (``rbc_env_base.py:491-513, 579-595``).
 
-Deviation ("next" row): observations are read at the sensor lattice by nearest-cell
-lookup on the simulation grid instead of going through the reference's scatter-resampling to the
-render grid (``resampling.cu:297-609``) first.
+Observations follow the reference path: fields are resampled to the render grid
+(``_resample_block_data`` -> ``SampleTransformedGridLocalToGlobalMulti``, here ``fg_resample`` through
+``fluidgym_amd.simulation.resample.UniformResampler``, fill 16 passes as ``rbc_env_base.py:324-325``) and read at
+the integer sensor positions of ``_get_sensor_locations_2d`` / ``rbc_env_3d.py:182-199``.
 """
 from __future__ import annotations
 
@@ -31,6 +32,7 @@ import torch
 from .. import spaces
 from ..simulation import grids
 from ..simulation.domain import Domain
+from ..simulation.resample import UniformResampler
 from ..simulation.simulation import Simulation
 from .fluid_env import FluidEnv
 
@@ -152,17 +154,10 @@ class RBCEnvBase(FluidEnv):
         self._top_plate = self._block.getBoundary("+y")
         dev = self._cuda_device
         self._cell_size = self._block.getCellSizes()[0, 0]  # [(Z,)Y,X]
-        # sensor lattice (cell-centred), nearest-cell lookup
-        ix = ((np.arange(self._n_sensors_x) + 0.5) * self._x / self._n_sensors_x).astype(np.int64)
-        ycen = 0.5 * (self._block.edges[1][1:] + self._block.edges[1][:-1])
-        ytar = -self._H / 2 + (np.arange(self._n_sensors_y) + 0.5) * self._H / self._n_sensors_y
-        iy = np.abs(ycen[None, :] - ytar[:, None]).argmin(axis=1)
-        if self._ndims == 2:
-            flat = iy[:, None] * self._x + ix[None, :]  # [sy, sx]
-        else:
-            flat = (ix[:, None, None] * self._y + iy[None, :, None]) * self._x + ix[None, None, :]  # [sz, sy, sx]
-        self._sensor_shape = flat.shape
-        self._sensor_idx = torch.from_numpy(flat.reshape(-1)).to(dev)
+        # observation path: render-grid resampling + integer sensor positions (rbc_env_base.py:324-325, 445-470)
+        self._resampler = UniformResampler(self._block.edges, self.render_shape[: self._ndims], fill_max_steps=16,
+                                           device=dev)
+        self._sensor_locations = self._get_sensor_locations().to(dev)
         seg = torch.arange(self._x, device=dev)
         self._seg_id = seg // self._heater_width
         self._x_pos = seg % self._heater_width
@@ -231,13 +226,57 @@ class RBCEnvBase(FluidEnv):
         self._bottom_plate.setPassiveScalar(control)
 
     # ---- observation / reward -------------------------------------------------------------
+    @property
+    def render_shape(self):
+        """(nx, height, nx) of the rendered / resampled domain (rbc_env_base.py:399-405)."""
+        nx = self._n_heaters * 20
+        return (nx, round(nx / self._aspect_ratio), nx)
+
+    def _get_sensor_locations(self) -> torch.Tensor:
+        """Integer render-grid positions of the sensors, ``[ndims, n]`` with x fastest-varying last
+        (rbc_env_base.py:445-470; rbc_env_3d.py:182-199)."""
+        nx, ny = self.render_shape[:2]
+        sx = torch.linspace(0, nx, self._n_sensors_x + 1)[:-1] + nx / (2 * self._n_sensors_x)
+        sy = torch.linspace(0, ny, self._n_sensors_y + 1)[:-1] + ny / (2 * self._n_sensors_y)
+        gx, gy = torch.meshgrid(sx, sy, indexing="ij")
+        loc = torch.stack([gx, gy], dim=-1).reshape(-1, 2).T.round().to(torch.int64)
+        if self._ndims == 2:
+            return loc
+        nz = self.render_shape[-1]
+        nsz = self._n_sensors_per_heater * self._n_heaters
+        sz = (torch.linspace(0, nz, nsz + 1)[:-1] + nz / (2 * nsz)).round().to(torch.int64)
+        return torch.stack([loc[0].repeat_interleave(nsz), loc[1].repeat_interleave(nsz), sz.repeat(loc.shape[1])], dim=0)
+
+    def get_temperature(self) -> torch.Tensor:
+        """Temperature on the render grid ``[B, (oz,) oy, ox]`` (rbc_env_base.py:472-489, batched)."""
+        return self._resampler(self._block.passiveScalar)[:, 0]
+
+    def get_velocity(self) -> torch.Tensor:
+        """Velocity on the render grid ``[B, d, (oz,) oy, ox]`` (fluid_env.py:658-681, batched)."""
+        return self._resampler(self._block.velocity)
+
+    def get_pressure(self) -> torch.Tensor:
+        """Pressure on the render grid ``[B, (oz,) oy, ox]`` (fluid_env.py:683-706, batched)."""
+        return self._resampler(self._block.pressure)[:, 0]
+
     def _get_global_obs(self):
-        B = self._num_envs
-        sel = lambda t, c: t.reshape(B, c, -1).index_select(2, self._sensor_idx).reshape(B, c, *self._sensor_shape)
+        """rbc_env_2d.py:175-194 / rbc_env_3d.py:291-330 with a leading env axis."""
+        B, d = self._num_envs, self._ndims
+        sl = self._sensor_locations
+        T, u, p = self.get_temperature(), self.get_velocity(), self.get_pressure()
+        nsx, nsy = self._n_sensors_x, self._n_sensors_y
+        if d == 2:
+            pick = lambda t: t[..., sl[1], sl[0]]
+            return {
+                "temperature": pick(T).reshape(B, nsx, nsy).transpose(1, 2),
+                "velocity": pick(u).reshape(B, 2, nsx, nsy).transpose(2, 3),
+                "pressure": pick(p).reshape(B, nsx, nsy).transpose(1, 2),
+            }
+        pick = lambda t: t[..., sl[2], sl[1], sl[0]]
         return {
-            "temperature": sel(self._block.passiveScalar, 1)[:, 0],
-            "velocity": sel(self._block.velocity, self._ndims),
-            "pressure": sel(self._block.pressure, 1)[:, 0],
+            "temperature": pick(T).reshape(B, nsx, nsy, nsx).permute(0, 3, 2, 1),
+            "velocity": pick(u).reshape(B, 3, nsx, nsy, nsx).permute(0, 1, 4, 3, 2),
+            "pressure": pick(p).reshape(B, nsx, nsy, nsx).permute(0, 3, 2, 1),
         }
 
     def compute_global_nusselt(self) -> torch.Tensor:

@@ -160,3 +160,31 @@ def test_rbc_heating_drives_convection():
     T = env._block.passiveScalar
     assert float(T.min()) > -0.2 and float(T.max()) < 1.9
     env.close()
+
+
+@pytest.mark.parametrize("env_id", ["RBC2D-easy-v0", "RBC3D-easy-v0"])
+def test_rbc_observations_follow_the_reference_resampling_path(env_id):
+    """Observations = fields resampled to the render grid (compiled-kernel corner rule, 16 fill passes) read at the
+    integer sensor positions, exactly the indexing of rbc_env_2d.py:175-194 / rbc_env_3d.py:291-330."""
+    from oracle import resample_oracle as R
+
+    env = fluidgym_amd.make(env_id, num_envs=2, randomize_initial_state=True, **SMALL[env_id])
+    env.reset(seed=5)
+    obs, *_ = env.step(env.sample_action())
+    d = env._ndims
+    edges = env._block.edges
+    oshape = env.render_shape[:d]
+    sl = env._sensor_locations.cpu().numpy()
+    nsx, nsy = env._n_sensors_x, env._n_sensors_y
+    for b in range(2):
+        T = R.resample_to_uniform(env._block.passiveScalar[b].cpu().numpy(), edges, oshape, 16, corners_3d_quirk=True)[0]
+        u = R.resample_to_uniform(env._block.velocity[b].cpu().numpy(), edges, oshape, 16, corners_3d_quirk=True)
+        if d == 2:
+            Ts = T[sl[1], sl[0]].reshape(nsx, nsy).T
+            us = np.transpose(np.transpose(u, (1, 2, 0))[sl[1], sl[0], :].reshape(nsx, nsy, 2), (2, 1, 0))
+        else:
+            Ts = np.transpose(T[sl[2], sl[1], sl[0]].reshape(nsx, nsy, nsx), (2, 1, 0))
+            us = np.transpose(np.transpose(u, (1, 2, 3, 0))[sl[2], sl[1], sl[0], :].reshape(nsx, nsy, nsx, 3), (3, 2, 1, 0))
+        assert np.abs(obs["temperature"][b].cpu().numpy() - Ts).max() < 1e-5 * max(1.0, np.abs(Ts).max())
+        assert np.abs(obs["velocity"][b].cpu().numpy() - us).max() < 1e-5 * max(1e-3, np.abs(us).max())
+    env.close()
