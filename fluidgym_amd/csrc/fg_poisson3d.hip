@@ -268,11 +268,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
         z_fill_tile<BXL>(ring_p[slot], c, r.p, r.hp);
         z_fill_tile<BXL>(ring_a[slot], c, r.a, r.ha);
     };
-    // prologue: planes k0-1, k0, k0+1 -> slots 0, 1, 2
-#pragma unroll 1
-    for (int q = 0; q < 3; ++q) {
-        const Staged sq = stage(c.k0 - 1 + q);
-        commit(q, sq);
+    // prologue: planes k0-1, k0, k0+1 -> slots 0, 1, 2.  All three planes are requested before the first commit: done
+    // one after the other the prologue cost three exposed memory round trips per z-chunk.
+    {
+        const Staged s0 = stage(c.k0 - 1);
+        const Staged s1 = stage(c.k0);
+        const Staged s2 = stage(c.k0 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        commit(0, s0);
+        commit(1, s1);
+        commit(2, s2);
     }
     FgVec<4> bvec;
     if constexpr (MODE == MODE_RELAX) bvec = z_bload4(R_x2, vo_c, (unsigned)c.k0 * plane_b);
