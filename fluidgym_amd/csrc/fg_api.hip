@@ -15,14 +15,6 @@ void fg_set_error(const std::string& msg) { g_last_error = msg; }
 extern "C" int fg_abi_version(void) { return FG_ABI_VERSION; }
 extern "C" const char* fg_last_error(void) { return g_last_error.c_str(); }
 
-#define FG_REQUIRE(cond, code, msg)  \
-    do {                             \
-        if (!(cond)) {               \
-            fg_set_error(msg);       \
-            return code;             \
-        }                            \
-    } while (0)
-
 static FgBounds make_bounds(const fg_state* s, int channel) {
     FgBounds b;
     for (int f = 0; f < 6; ++f) {

@@ -360,6 +360,14 @@ struct fg_state {
 };
 
 void fg_set_error(const std::string& msg);
+// argument / state check of an extern "C" entry point: record the message for fg_last_error() and return the status
+#define FG_REQUIRE(cond, code, msg)  \
+    do {                             \
+        if (!(cond)) {               \
+            fg_set_error(msg);       \
+            return code;             \
+        }                            \
+    } while (0)
 #define FG_HIP_CHECK(expr)                                                                        \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \

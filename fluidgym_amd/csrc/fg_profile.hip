@@ -10,14 +10,6 @@
 
 #include "fg_internal.h"
 
-#define FG_REQUIRE(cond, code, msg)  \
-    do {                             \
-        if (!(cond)) {               \
-            fg_set_error(msg);       \
-            return code;             \
-        }                            \
-    } while (0)
-
 namespace {
 __global__ void k_prof_count(const int32_t* __restrict__ flags, int nsys, int32_t* __restrict__ out) {
     int c = 0;

@@ -18,14 +18,6 @@
 
 #include "fg_internal.h"
 
-#define FG_REQUIRE(cond, code, msg)  \
-    do {                             \
-        if (!(cond)) {               \
-            fg_set_error(msg);       \
-            return code;             \
-        }                            \
-    } while (0)
-
 struct fg_resampler_state {
     int dims, quirk3d, device;
     int n_src[3], n_out[3];
