@@ -244,6 +244,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
     z_metrics(g, c, m);
     FgCtx<3, 4> fc;  // only the mask members are used
     fc.mxm = c.mxm; fc.mxp = c.mxp; fc.mym = c.mym; fc.myp = c.myp;
+    // thread-invariant factors of the face coefficients (see the plane loop)
+    float hyx[4], hxy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hyx[e] = m.hy * m.rhx[e]; hxy[e] = m.hx[e] * m.hy; }
+    const float hyx_m = m.hy * m.rhx_m, hyx_p = m.hy * m.rhx_p;
+    const float s_ycl = c.mym * m.rhy, s_ynl = c.mym * m.rhy_m, s_ycr = c.myp * m.rhy, s_ynr = c.myp * m.rhy_p;
 
     struct Staged { FgVec<4> p, a; Halo hp, ha; };
     auto stage = [&](int k) -> Staged {  // global loads of one plane (centre + this thread's halo duty)
@@ -303,22 +309,34 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
         float pcv[4] = {P_c.x, P_c.y, P_c.z, P_c.w};
         float acv[4] = {A_c.x, A_c.y, A_c.z, A_c.w};
         float y[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
+        // Face coefficients  c_f = mask_f * 0.5 * area_f * (rh_c a_c + rh_n a_n)  (fg_poisson_coef).  The kernels are
+        // VALU-limited (PMC: Jacobi 24 % VALU-active per wave at 4 waves per SIMD), so the products are arranged to
+        // share work: every cell's half coefficient g = 0.5 area rh a is formed once per direction and an x face is
+        // the sum of the two cells it separates (5 faces for 4 cells instead of 8 one-sided evaluations); thread- and
+        // plane-invariant factors are hoisted (s_y*, hyx*, hxy below; no -ffast-math, so the compiler may not).
+        const float hh = 0.5f * m.hz;
         {   // x faces
-            const float pl = ring_p[sc][cen - 1], pr = ring_p[sc][cen + 4];
             const float al = ring_a[sc][cen - 1], ar = ring_a[sc][cen + 4];
-            const float ayz = m.hy * m.hz;
+            const float pl = ring_p[sc][cen - 1], pr = ring_p[sc][cen + 4];
+            float gx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gx[e] = hh * (hyx[e] * acv[e]);
+            float face[5];
+            face[0] = fc.mxm * (hh * (hyx_m * al) + gx[0]);
+#pragma unroll
+            for (int e = 1; e < 4; ++e) face[e] = gx[e - 1] + gx[e];
+            face[4] = fc.mxp * (gx[3] + hh * (hyx_p * ar));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float rh_lo = (e == 0) ? m.rhx_m : m.rhx[e > 0 ? e - 1 : 0];
-                const float rh_hi = (e == 3) ? m.rhx_p : m.rhx[e < 3 ? e + 1 : 3];
-                const float ml = (e == 0) ? fc.mxm : 1.f, mh = (e == 3) ? fc.mxp : 1.f;
-                const float apx = ayz * m.rhx[e] * acv[e];
-                const float cl = ml * 0.5f * (apx + ayz * rh_lo * ((e == 0) ? al : acv[e > 0 ? e - 1 : 0]));
-                const float cr = mh * 0.5f * (apx + ayz * rh_hi * ((e == 3) ? ar : acv[e < 3 ? e + 1 : 3]));
-                y[e] += cl * (((e == 0) ? pl : pcv[e > 0 ? e - 1 : 0]) - pcv[e]) + cr * (((e == 3) ? pr : pcv[e < 3 ? e + 1 : 3]) - pcv[e]);
-                dg[e] -= cl + cr;
+                const float pm_ = (e == 0) ? pl : pcv[e > 0 ? e - 1 : 0];
+                const float pp_ = (e == 3) ? pr : pcv[e < 3 ? e + 1 : 3];
+                y[e] += face[e] * (pm_ - pcv[e]) + face[e + 1] * (pp_ - pcv[e]);
+                dg[e] -= face[e] + face[e + 1];
             }
         }
+        float hxa[4];  // hx a_c, shared by the y and z directions
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hxa[e] = m.hx[e] * acv[e];
         {   // y faces
             const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sc][cen - LP]);
             const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sc][cen + LP]);
@@ -328,10 +346,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
             const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float axz = m.hx[e] * m.hz;
-                const float apy = axz * m.rhy * acv[e];
-                const float cl = fc.mym * 0.5f * (apy + axz * m.rhy_m * am_[e]);
-                const float cr = fc.myp * 0.5f * (apy + axz * m.rhy_p * ap_[e]);
+                const float tc = hh * hxa[e], hhx = hh * m.hx[e];
+                const float cl = s_ycl * tc + s_ynl * (hhx * am_[e]);
+                const float cr = s_ycr * tc + s_ynr * (hhx * ap_[e]);
                 y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
                 dg[e] -= cl + cr;
             }
@@ -343,12 +360,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
             const float4 Ap = *reinterpret_cast<const float4*>(&ring_a[sp][cen]);
             const float pm_[4] = {Pm.x, Pm.y, Pm.z, Pm.w}, pp_[4] = {Pp.x, Pp.y, Pp.z, Pp.w};
             const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
+            const float zcl = fc.mzm * 0.5f * m.rhz, znl = fc.mzm * 0.5f * m.rhz_m;
+            const float zcr = fc.mzp * 0.5f * m.rhz, znr = fc.mzp * 0.5f * m.rhz_p;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float axy = m.hx[e] * m.hy;
-                const float apz = axy * m.rhz * acv[e];
-                const float cl = fc.mzm * 0.5f * (apz + axy * m.rhz_m * am_[e]);
-                const float cr = fc.mzp * 0.5f * (apz + axy * m.rhz_p * ap_[e]);
+                const float uc = m.hy * hxa[e];
+                const float cl = zcl * uc + znl * (hxy[e] * am_[e]);
+                const float cr = zcr * uc + znr * (hxy[e] * ap_[e]);
                 y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
                 dg[e] -= cl + cr;
             }
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if constexpr (MODE == MODE_RELAX) {
-                float v = pcv[e] + a.omega * (bvec.v[e] - y[e]) / dg[e];
+                float v = pcv[e] + a.omega * (bvec.v[e] - y[e]) * __builtin_amdgcn_rcpf(dg[e]);  // v_rcp_f32 (1 ulp): the IEEE division was ~10 VALU ops per cell in a VALU-bound kernel
                 if (a.color >= 0 && (((c.i0 + e + c.j + k) & 1) != a.color)) v = pcv[e];
                 out.v[e] = v;
             } else {
