@@ -57,10 +57,14 @@ def _register_all():
     register("RBC2D-wide-easy-v0", r2, R2, n_heaters=24, aspect_ratio=2.0)
     register("RBC2D-baseline-v0", r2, R2, n_heaters=64, resolution=8, aspect_ratio=2.55)  # 512x128 (BASELINE config 3)
     register("RBC3D-easy-v0", r3, R3)
-    t = _lazy(".envs.tcf", "TCF3DBottomEnv")
-    register("TCFSmall3D-both-easy-v0", t, TS)
-    register("TCFLarge3D-both-easy-v0", t, TL)
-    register("TCF3D-baseline-v0", t, TS, resolution_x=128, resolution_z=64, resolution_y=64, L=2 * np.pi, D=np.pi)
+    # reference ids (fluidgym/__init__.py:215-300): Small/Large x bottom/both x easy/medium/hard = Re_tau 180 / 330 / 550
+    tcf = {"bottom": _lazy(".envs.tcf", "TCF3DBottomEnv"), "both": _lazy(".envs.tcf", "TCF3DBothEnv")}
+    for size, cfg in (("Small", TS), ("Large", TL)):
+        for act, ctor in tcf.items():
+            for level, re_tau in (("easy", 180), ("medium", 330), ("hard", 550)):
+                register(f"TCF{size}3D-{act}-{level}-v0", ctor, cfg, reynolds_number_wall=re_tau)
+    register("TCF3D-baseline-v0", tcf["both"], TS, resolution_x=128, resolution_z=64, resolution_y=64, L=2 * np.pi,
+             D=np.pi)  # 128 x 64 x 64 (BASELINE config 4)
     for fam, ids in {
         "Cylinder": ["CylinderJet2D-easy-v0", "CylinderJet2D-medium-v0", "CylinderJet2D-hard-v0",
                      "CylinderRot2D-easy-v0", "CylinderJet3D-easy-v0"],

@@ -1,21 +1,27 @@
 """3-D turbulent channel flow with wall blowing/suction, batched.
 
-Follows ``envs/tcf/tcf_env.py`` and ``envs/tcf/grid.py``:
+Mirrors ``envs/tcf/tcf_env.py`` (``TCF3DBottomEnv`` :94-1063, ``TCF3DBothEnv`` :1065-1200) and ``envs/tcf/grid.py``:
 
-* grid ``x`` x ``2*(y_half//N)`` x ``z`` with geometric wall refinement (``grid.py:15-81``), channel
-  half-height ``delta = 1``, ``L`` x ``2`` x ``D``; periodic in x and z, FIXED no-slip walls at ``+-y``
-  (``grid.py:222-227``);
-* ``nu = 1 / Re_tau`` with ``u_tau = 1`` (``tcf_env.py:268-275``); initial velocity = Reichardt profile
-  (``grid.py:91-112``) + noise;
-* dynamic forcing in the ``PRE`` hook: ``G_x = mean wall shear`` of both walls (``grid.py:147-163``);
-* action: wall-normal velocity on the ``-y`` wall per actuator patch, zero-mean over the wall so the
-  boundary fluxes stay balanced (``tcf_env.py:521-555``); reward = relative wall-shear reduction
-  (``tcf_env.py:788-824``);
-* solver: adaptive CFL 0.1, pressure tol 1e-6, 2 correctors (``tcf_env.py:478-500``).
+* units as in the reference: ``Re_cl = (Re_tau / 0.116)^(1/0.88)`` (``TCF_tools.py:36-41``), ``nu = delta / Re_cl``,
+  ``u_tau = Re_tau / Re_cl`` (``tcf_env.py:246-249``); ``step_length`` is given in wall units and converted with
+  ``t* = nu / u_tau^2`` (``:262``), ``dt = step_length / 10`` (``:265``);
+* grid ``x`` x ``2 * y_half`` x ``z`` with the geometric wall refinement of ``_make_y_weights`` (``grid.py:15-31``,
+  strength 2 below 64 cells in x, ``tcf_env.py:253``), ``L x 2 x D`` centred on the origin; periodic in x and z, no-slip
+  FIXED walls at ``+-y`` (``grid.py:222-227``); initial velocity = Reichardt profile in wall units times ``u_tau``
+  (``grid.py:84-100``);
+* dynamic forcing in the ``PRE`` hook: ``G_x`` = mean of the two wall shear stresses (``grid.py:147-176``);
+* action ``[n_agents, 1]``: wall-normal velocity per ``actor_size`` x ``actor_size`` patch, made zero-mean and clamped
+  to ``u_tau`` (``_action_to_control`` :521-547); "both" drives the top wall with the second half of the agents,
+  sign flipped (``:1143-1154``);
+* observation: fluctuation velocity ``u - <u>_V`` (components x, y) and pressure on the plane ``y+ = 15``
+  (``_get_global_obs`` :646-677), stacked bottom/top for "both" (``:1166-1180``);
+* reward ``1 - tau / tau_ref`` with the wall stress averaged over the sim steps of the env step (``:788-824``),
+  ``tau_ref`` = 1 without domain statistics (``:556-562``);
+* solver: adaptive CFL 0.1, advection and pressure tol 1e-6, 2 correctors (``:478-500``).
 
-Deviations: the reference's curl-simplex-noise initial perturbation (a separate CUDA extension,
-``extensions/noise``) is replaced by Gaussian noise made discretely divergence-free; MARL windows
-are a "next" item.
+Deviations: the reference's curl-simplex-noise initial perturbation (a separate CUDA extension, ``extensions/noise``)
+is replaced by Gaussian noise made discretely divergence-free; Smagorinsky SGS viscosity (``C_smag != 0``, off in every
+registered id) and the MARL windows are not built; no published initial domains / statistics (no network).
 """
 from __future__ import annotations
 
@@ -38,8 +44,7 @@ SMALL_TCF_3D_DEFAULT_CONFIG = {
     "D": np.pi / 2,
     "reynolds_number_wall": 180,
     "adaptive_cfl": 0.1,
-    "dt": 0.06,
-    "step_length": 0.6,
+    "step_length": 0.6,   # wall units (tcf_env.py:69); dt = step_length / 10 in physical units
     "episode_length": 1000,
     "use_marl": False,
     "init_with_noise": True,
@@ -62,38 +67,78 @@ def reichardt_profile(y_plus: torch.Tensor) -> torch.Tensor:
 
 class TCF3DBottomEnv(FluidEnv):
     _supports_marl = False
-    _metrics = ["wall_stress"]
-    _max_action_velocity: float = 1.0  # in units of u_tau
+    _actuation = "bottom"
+    _scale_actions = True
+    _delta: float = 1.0
+    _H: float = 2.0
+    _y_obs_wall: float = 15.0
+    _metrics = ["wall_stress", "wall_stress_bottom", "wall_stress_top"]
 
     def __init__(self, resolution_y, resolution_x_z, actor_size, L, D, reynolds_number_wall, adaptive_cfl, step_length,
-                 episode_length, dt=0.06, init_with_noise=True, resolution_x=None, resolution_z=None,
-                 refinement_strength: int = 1, **kw):
+                 episode_length, init_with_noise=True, resolution_x=None, resolution_z=None, C_smag: float = 0.0,
+                 use_van_driest: bool = False, local_obs_window: int = 1, local_reward_weight: float = 0.0, dt=None, **kw):
+        if C_smag != 0.0 or use_van_driest:
+            raise NotImplementedError("Smagorinsky SGS viscosity (tcf_env.py:441-474) is not built")
+        self._L, self._D = float(L), float(D)
+        self._re_wall = float(reynolds_number_wall)
+        self._re_center = (self._re_wall / 0.116) ** (1 / 0.88)   # TCF_tools.Re_wall_to_cl
+        self._nu = self._delta / self._re_center
+        self._u_wall = self._re_wall / self._re_center
         self._x = int(resolution_x if resolution_x is not None else resolution_x_z)
         self._z = int(resolution_z if resolution_z is not None else resolution_x_z)
         self._y_half = int(resolution_y) // 2
-        self._N = int(refinement_strength)
-        self._y = 2 * (self._y_half // self._N)
-        self._actor = int(actor_size)
-        self._L, self._D = float(L), float(D)
-        self._re_tau = float(reynolds_number_wall)
-        self._nu = 1.0 / self._re_tau
+        self._y = 2 * self._y_half
+        self._grid_refinement_strength = 2 if self._x < 64 else 1
         self._init_with_noise = init_with_noise
-        assert self._x % self._actor == 0 and self._z % self._actor == 0
-        super().__init__(dt=dt, adaptive_cfl=adaptive_cfl, step_length=step_length, episode_length=episode_length,
-                         ndims=3, **kw)
+        self._actor_size = int(actor_size)
+        assert self._x % 4 == 0 and self._x % self._actor_size == 0 and self._z % self._actor_size == 0
+        step_length = self._t_wall_to_t(step_length)  # wall units -> physical (tcf_env.py:262)
+        super().__init__(dt=(step_length / 10 if dt is None else dt), adaptive_cfl=adaptive_cfl, step_length=step_length,
+                         episode_length=episode_length, ndims=3, **kw)
+
+    # ---- unit conversions (tcf_env.py:323-341) ---------------------------------------------
+    def _t_wall_to_t(self, t_wall: float) -> float:
+        return t_wall * self._nu / self._u_wall ** 2
+
+    def _t_to_t_wall(self, t: float) -> float:
+        return t / (self._nu / self._u_wall ** 2)
+
+    def _y_wall_to_y(self, pos_wall: float) -> float:
+        return -self._delta + pos_wall / (self._u_wall / self._nu)
+
+    def _y_to_y_wall(self, pos: float) -> float:
+        return (pos + self._delta) * (self._u_wall / self._nu)
+
+    # ---- spaces -----------------------------------------------------------------------------
+    @property
+    def _n_actors_x(self) -> int:
+        return self._x // self._actor_size
+
+    @property
+    def _n_actors_z(self) -> int:
+        return self._z // self._actor_size
+
+    @property
+    def n_agents(self) -> int:
+        return self._n_actors_x * self._n_actors_z
 
     def _get_action_space(self):
-        return spaces.Box(low=-1.0, high=1.0, shape=(self._z // self._actor, self._x // self._actor), dtype=np.float32)
+        return spaces.Box(low=-1.0, high=1.0, shape=(self.n_agents, 1), dtype=np.float32)
 
     def _get_observation_space(self):
-        shape = (self._z // self._actor, self._x // self._actor)
-        return spaces.Dict({"velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(3,) + shape, dtype=np.float32)})
+        return spaces.Dict({
+            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(2, self._z, self._x), dtype=np.float32),
+            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=(self._z, self._x), dtype=np.float32),
+        })
 
+    # ---- domain / simulation ----------------------------------------------------------------
     def _get_domain(self) -> Domain:
-        yw = grids.tcf_y_weights(N=self._N, ny_half=self._y_half)
+        N = self._grid_refinement_strength
+        yw = grids.tcf_y_weights(N=N, ny_half=self._y_half * N)  # _make_grid passes ny_half = y_half * yN (grid.py:56)
         edges = [grids.lerp_edges(-self._L / 2, self._L / 2, grids.weights_linear(self._x)),
-                 grids.lerp_edges(-1.0, 1.0, yw),
+                 grids.lerp_edges(-self._delta, self._delta, yw),
                  grids.lerp_edges(-self._D / 2, self._D / 2, grids.weights_linear(self._z))]
+        assert len(edges[1]) - 1 == self._y
         dom = Domain(3, torch.tensor([self._nu]), passiveScalarChannels=0, name="ChannelDomain",
                      device=self._cuda_device, dtype=self._dtype, batch=self._num_envs)
         blk = dom.CreateBlock(vertexCoordinates=grids.vertex_grid(edges), name="ChannelBlock")
@@ -104,74 +149,150 @@ class TCF3DBottomEnv(FluidEnv):
 
     def _additional_initialization(self) -> None:
         self._block = self._domain.getBlock(0)
+        self._bottom_plate = self._block.getBoundary("-y")
+        self._top_plate = self._block.getBoundary("+y")
         e = self._block.edges[1]
-        self._d_wall = (float(0.5 * (e[0] + e[1]) + 1.0), float(1.0 - 0.5 * (e[-1] + e[-2])))
-        ycen = torch.from_numpy(0.5 * (e[1:] + e[:-1])).float().to(self._cuda_device)
-        self._y_plus = (1 - ycen.abs()) * self._re_tau
-        # observation plane: first cell layer with y+ >= 15 (tcf_env.py sensing plane)
-        self._obs_j = int(torch.nonzero(self._y_plus >= 15.0)[0]) if bool((self._y_plus >= 15.0).any()) else 1
-        self._tau_ref = None
+        ycen = 0.5 * (e[1:] + e[:-1])
+        self._d_wall = (float(1.0 + ycen[0]), float(1.0 - ycen[-1]))   # grid.py:149-150
+        self._y_centers = torch.from_numpy(ycen).float().to(self._cuda_device)
+        # sensing plane: cell layer closest to y+ = 15 (tcf_env.py:343-352)
+        self._y_obs_bottom_idx = int(np.abs(ycen - self._y_wall_to_y(self._y_obs_wall)).argmin())
+        self._cell_size = self._block.getCellSizes()[0, 0]   # [Z, Y, X]
 
     def _get_prep_fn(self, domain: Domain) -> Dict[str, Any]:
         def forcing(domain, **kw):
-            # dynamic forcing G_x = mean of the two wall shear stresses (grid.py:147-163)
-            u = self._block.velocity[:, 0]  # [B,Z,Y,X]
-            mean_u = u.mean(dim=(1, 3))  # [B,Y]
-            G = 0.5 * self._nu * (mean_u[:, 0] / self._d_wall[0] + mean_u[:, -1] / self._d_wall[1])
-            src = self._block.velocitySource
-            src[:, 0] = G.view(-1, 1, 1, 1)
+            tau_b, tau_t = self._get_wall_stress()   # [B] each
+            self._block.velocitySource[:, 0] = (0.5 * (tau_b + tau_t)).view(-1, 1, 1, 1)
 
         return {"PRE": [forcing]}
 
     def _get_simulation(self, domain, prep_fn) -> Simulation:
         return Simulation(domain=domain, prep_fn=prep_fn, substeps="ADAPTIVE", adaptive_CFL=self._adaptive_cfl,
-                          dt=self._dt, corrector_steps=2, pressure_tol=1e-6, advect_non_ortho_steps=1,
+                          dt=self._dt, corrector_steps=2, advection_tol=1e-6, pressure_tol=1e-6, advect_non_ortho_steps=1,
                           pressure_non_ortho_steps=1, pressure_return_best_result=True, velocity_corrector="FD",
                           non_orthogonal=True, solver_double_fallback=False)
 
     def _fill_initial_fields(self) -> None:
         B = self._num_envs
-        u_prof = reichardt_profile(self._y_plus)  # u_tau = 1
+        y_plus = (1 - self._y_centers.abs()) * self._u_wall / self._nu
+        u_prof = reichardt_profile(y_plus) * self._u_wall   # grid.py:84-100
         u = torch.zeros(B, 3, self._z, self._y, self._x, device=self._cuda_device)
         u[:, 0] = u_prof.view(1, 1, -1, 1)
         if self._init_with_noise:
             u += 0.1 * u_prof.view(1, 1, 1, -1, 1) * torch.randn(u.shape, device=u.device, generator=self._torch_rng_cuda)
         self._block.setVelocity(u)
         self._block.pressure.zero_()
-        self._block.getBoundary("-y").velocity.zero_()
-        self._block.getBoundary("+y").velocity.zero_()
+        self._bottom_plate.velocity.zero_()
+        self._top_plate.velocity.zero_()
         self._domain.solver.reset_solver_state()
         self._sim.make_divergence_free()
 
-    def _wall_stress(self) -> torch.Tensor:
-        u = self._block.velocity[:, 0]
-        return self._nu * u[:, :, 0, :].mean(dim=(1, 2)) / self._d_wall[0]
+    def _randomize_domain(self) -> None:
+        """tcf_env.py:879-916: 1 % Gaussian noise on u and p, then a random number of sim steps."""
+        max_n = int(0.01 * self._episode_length)
+        n_steps = int(self._np_rng.integers(int(0.5 * max_n), max(max_n, int(0.5 * max_n) + 1))) + 1
+        u, p = self._block.velocity, self._block.pressure
+        u += 0.01 * torch.randn(u.shape, device=u.device, generator=self._torch_rng_cuda)
+        p += 0.01 * torch.randn(p.shape, device=p.device, generator=self._torch_rng_cuda)
+        self._domain.solver.reset_solver_state()
+        for _ in range(n_steps):
+            self._sim.single_step()
 
-    def _apply_action(self, action: torch.Tensor) -> None:
-        a = action.reshape(self._num_envs, self._z // self._actor, self._x // self._actor)
-        a = a - a.mean(dim=(1, 2), keepdim=True)  # zero net mass flux (tcf_env.py:538-545)
-        v = a.repeat_interleave(self._actor, dim=1).repeat_interleave(self._actor, dim=2) * self._max_action_velocity
-        bv = self._block.getBoundary("-y").velocity  # [B,3,Z,1,X]
+    # ---- actions ----------------------------------------------------------------------------
+    def _action_to_control(self, action: torch.Tensor) -> torch.Tensor:
+        """``action [B, nax, naz]`` -> wall-normal velocity ``[B, Z, X]`` (tcf_env.py:521-547)."""
+        a = action
+        if self._scale_actions:
+            a = a - a.mean(dim=(1, 2), keepdim=True)                 # zero net mass flux
+            a = self._u_wall * a / torch.clamp(a.abs(), min=1.0)     # |v| <= u_tau
+            a = a - a.mean(dim=(1, 2), keepdim=True)
+        v = a.repeat_interleave(self._actor_size, dim=1).repeat_interleave(self._actor_size, dim=2)   # [B, X, Z]
+        return v.transpose(1, 2)
+
+    def _set_wall(self, plate, v: torch.Tensor) -> None:
+        bv = plate.velocity   # [B, 3, Z, 1, X]
         bv.zero_()
         bv[:, 1, :, 0, :] = v
 
+    def _apply_action(self, action: torch.Tensor) -> None:
+        a = action.reshape(self._num_envs, self._n_actors_x, self._n_actors_z)
+        self._set_wall(self._bottom_plate, self._action_to_control(a))
+
+    # ---- metrics / observations -----------------------------------------------------------
+    @property
+    def tau_ref(self) -> float:
+        return float(self._metrics_stats.get("wall_stress_bottom", 1.0))
+
+    def _get_wall_stress(self):
+        """(bottom, top) wall shear stress per env ``[B]`` (tcf_env.py:564-584)."""
+        mean_u = self._block.velocity[:, 0].mean(dim=(1, 3))   # [B, Y]
+        return self._nu * mean_u[:, 0] / self._d_wall[0], self._nu * mean_u[:, -1] / self._d_wall[1]
+
+    def _plane_obs(self, y_idx: int):
+        u = self._block.velocity                                   # [B, 3, Z, Y, X]
+        cs = self._cell_size
+        mean_u = (u * cs).sum(dim=(2, 3, 4), keepdim=True) / cs.sum()
+        return {"velocity": (u - mean_u)[:, :2, :, y_idx, :], "pressure": self._block.pressure[:, 0, :, y_idx, :]}
+
     def _get_global_obs(self):
-        u = self._block.velocity[:, :, :, self._obs_j, :]  # [B,3,Z,X]
-        u = u.reshape(self._num_envs, 3, self._z // self._actor, self._actor, self._x // self._actor, self._actor)
-        return {"velocity": u.mean(dim=(3, 5))}
+        return self._plane_obs(self._y_obs_bottom_idx)
+
+    def _get_reward(self, tau_total, tau_bottom):
+        return 1 - tau_bottom / self.tau_ref
 
     def _step_impl(self, action: torch.Tensor):
-        if self._tau_ref is None:
-            self._tau_ref = self._wall_stress().clone()
         if self._enable_actions:
             self._apply_action(action)
+        tb, tt = [], []
         for _ in range(self._n_sim_steps):
             if not self._sim.single_step():
                 raise RuntimeError("simulation step failed")
-        tau = self._wall_stress()
-        reward = 1.0 - tau / self._tau_ref
-        return self._get_global_obs(), reward, False, {"wall_stress": tau}
+            b, t = self._get_wall_stress()
+            tb.append(b)
+            tt.append(t)
+        tau_bottom, tau_top = torch.stack(tb).mean(dim=0), torch.stack(tt).mean(dim=0)
+        tau_total = 0.5 * (tau_bottom + tau_top)
+        info = {"wall_stress": tau_total, "wall_stress_bottom": tau_bottom, "wall_stress_top": tau_top}
+        return self._get_global_obs(), self._get_reward(tau_total, tau_bottom), False, info
 
     @property
     def id(self) -> str:
-        return f"TCF3D_Re{self._re_tau}_{self._x}x{self._y}x{self._z}"
+        return f"TCF3D_{self._actuation}_Re{self._re_wall}_{self._x}x{self._y}x{self._z}"
+
+
+class TCF3DBothEnv(TCF3DBottomEnv):
+    """Both walls actuated: the first half of the agents drives the bottom wall, the second half the top wall
+    (tcf_env.py:1065-1200)."""
+
+    _actuation = "both"
+
+    @property
+    def n_agents(self) -> int:
+        return 2 * self._n_actors_x * self._n_actors_z
+
+    def _get_observation_space(self):
+        return spaces.Dict({
+            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(2, 2, self._z, self._x), dtype=np.float32),
+            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=(2, self._z, self._x), dtype=np.float32),
+        })
+
+    @property
+    def tau_ref(self) -> float:
+        return float(self._metrics_stats.get("wall_stress", 1.0))
+
+    def _additional_initialization(self) -> None:
+        super()._additional_initialization()
+        self._y_obs_top_idx = self._y - self._y_obs_bottom_idx   # tcf_env.py:1141 (sic: not y - 1 - idx)
+
+    def _apply_action(self, action: torch.Tensor) -> None:
+        a = action.reshape(self._num_envs, 2, self._n_actors_x, self._n_actors_z)
+        self._set_wall(self._bottom_plate, self._action_to_control(a[:, 0]))
+        self._set_wall(self._top_plate, -self._action_to_control(a[:, 1]))
+
+    def _get_reward(self, tau_total, tau_bottom):
+        return 1 - tau_total / self.tau_ref
+
+    def _get_global_obs(self):
+        lo, hi = self._plane_obs(self._y_obs_bottom_idx), self._plane_obs(min(self._y_obs_top_idx, self._y - 1))
+        return {"velocity": torch.stack((lo["velocity"], hi["velocity"]), dim=1),
+                "pressure": torch.stack((lo["pressure"], hi["pressure"]), dim=1)}

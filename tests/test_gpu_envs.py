@@ -16,7 +16,8 @@ SMALL = {
     "ChannelJet2D-v0": dict(resolution_x=64, resolution_y=32),
     "RBC2D-easy-v0": dict(n_heaters=4, resolution=8),
     "RBC3D-easy-v0": dict(n_heaters=2, resolution=4),
-    "TCFSmall3D-both-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.06, dt=0.03),
+    "TCFSmall3D-both-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6),
+    "TCFSmall3D-bottom-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6),
 }
 
 
@@ -187,4 +188,42 @@ def test_rbc_observations_follow_the_reference_resampling_path(env_id):
             us = np.transpose(np.transpose(u, (1, 2, 3, 0))[sl[2], sl[1], sl[0], :].reshape(nsx, nsy, nsx, 3), (3, 2, 1, 0))
         assert np.abs(obs["temperature"][b].cpu().numpy() - Ts).max() < 1e-5 * max(1.0, np.abs(Ts).max())
         assert np.abs(obs["velocity"][b].cpu().numpy() - us).max() < 1e-5 * max(1e-3, np.abs(us).max())
+    env.close()
+
+
+def test_tcf_units_actions_and_observations_follow_the_reference():
+    """tcf_env.py: unit conversions (:246-265), _action_to_control (:521-547), the y+ = 15 sensing plane (:343-352),
+    fluctuation-velocity observations (:646-677) and the both-walls stacking / sign flip (:1143-1180)."""
+    env = fluidgym_amd.make("TCFSmall3D-both-easy-v0", num_envs=2, randomize_initial_state=False, resolution_x_z=16,
+                            resolution_y=16, step_length=0.6)
+    re_cl = (180 / 0.116) ** (1 / 0.88)
+    assert abs(env._nu - 1 / re_cl) < 1e-12 and abs(env._u_wall - 180 / re_cl) < 1e-12
+    assert abs(env.step_length - 0.6 * env._nu / env._u_wall ** 2) < 1e-12 and abs(env.dt - env.step_length / 10) < 1e-12
+    assert env._grid_refinement_strength == 2 and env._y == 16
+    env.reset(seed=2)
+    ycen = env._y_centers.cpu().numpy()
+    y15 = -1 + 15.0 / (env._u_wall / env._nu)
+    assert env._y_obs_bottom_idx == int(np.abs(ycen - y15).argmin()) and env._y_obs_top_idx == 16 - env._y_obs_bottom_idx
+    a = env.sample_action()
+    assert tuple(a.shape) == (2, env.n_agents, 1) and env.n_agents == 2 * 8 * 8
+    obs, reward, _, _, info = env.step(a)
+    # control on the walls: zero mean, |v| <= u_tau, top wall = minus the second half of the agents
+    ab = a.reshape(2, 2, 8, 8)
+    for half, plate, sign in ((0, env._bottom_plate, 1.0), (1, env._top_plate, -1.0)):
+        x = ab[:, half] - ab[:, half].mean(dim=(1, 2), keepdim=True)
+        x = env._u_wall * x / torch.clamp(x.abs(), min=1.0)
+        x = x - x.mean(dim=(1, 2), keepdim=True)
+        v = sign * x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).transpose(1, 2)
+        bv = plate.velocity
+        assert torch.allclose(bv[:, 1, :, 0, :], v, atol=1e-7) and float(bv[:, 0].abs().max()) == 0.0
+        assert float(bv[:, 1].sum().abs()) < 1e-4
+    # observation: u' = u - <u>_V on the two planes, pressure alongside
+    u, p, cs = env._block.velocity, env._block.pressure, env._cell_size
+    up = u - (u * cs).sum(dim=(2, 3, 4), keepdim=True) / cs.sum()
+    jb, jt = env._y_obs_bottom_idx, min(env._y_obs_top_idx, 15)
+    assert tuple(obs["velocity"].shape) == (2, 2, 2, 16, 16) and tuple(obs["pressure"].shape) == (2, 2, 16, 16)
+    assert torch.allclose(obs["velocity"][:, 0], up[:, :2, :, jb, :]) and torch.allclose(obs["velocity"][:, 1], up[:, :2, :, jt, :])
+    assert torch.allclose(obs["pressure"][:, 1], p[:, 0, :, jt, :])
+    assert set(info) >= {"wall_stress", "wall_stress_bottom", "wall_stress_top"}
+    assert torch.allclose(reward, 1 - info["wall_stress"])  # tau_ref = 1 without domain statistics
     env.close()
