@@ -269,8 +269,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.env_id}: 2D channel stand-in for 'cylinder Re=100 256x128', "
-                                   f"{args.envs_per_gpu} envs/GPU, {env._n_sim_steps} PISO steps per env step",
+            "config": {"workload": f"{args.env_id}"
+                                   + (": 2D channel stand-in for 'cylinder Re=100 256x128'" if args.env_id == ENV_ID else "")
+                                   + f", {args.envs_per_gpu} envs/GPU, {env._n_sim_steps} PISO steps per env step",
                        "global_batch": n_total, "grid": [solver.nx, solver.ny, solver.nz],
                        "parallelism": f"env-sharded x{world} (RCCL bcast/all_gather of actions/obs only)",
                        "solver_iterations_last_step": stats},
