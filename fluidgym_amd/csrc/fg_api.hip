@@ -442,10 +442,10 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
         if (!any) break;
         if (o->adaptive || first) {
             // one transfer: [0..B) boundary flux balance, [B..2B) max |Minv u| (CFL velocity)
-            float* d = s->scratch_B;
-            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, d, st)) return rc; }
-            if (o->adaptive) { if (int rc = fg_launch_max_velocity(s, bnd, d + B, st)) return rc; }
-            FG_HIP_CHECK(hipMemcpyAsync(s->diag_pinned, d, sizeof(float) * 2 * B, hipMemcpyDeviceToHost, st));
+            // both kernels publish straight into the host-pinned diag_pinned (one workgroup per env writes the flux
+            // balance; the last workgroup of each env mirrors the max velocity): the read-back is a stream synchronise
+            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st)) return rc; }
+            if (o->adaptive) { if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B)) return rc; }
             FG_HIP_CHECK(hipStreamSynchronize(st));
             if (first) {
                 float worst = 0.f;

@@ -367,22 +367,24 @@ __global__ void k_bicg_begin(const float* __restrict__ dt, double* __restrict__ 
 }
 
 __global__ void k_bicg_check(double* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                             float tol, int it, int n, int nsys, int final_pass) {
+                             fg_solve_info* __restrict__ mirror, float tol, int it, int n, int nsys, int final_pass) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     if (flags[s] == 4) flags[s] = 1;
-    if (flags[s] != 0) return;
-    const float crit = (float)sqrt(acc[(size_t)s * FG_ACC_DOUBLES + A_RR] / (double)n);
-    info[s].final_residual = crit;
-    info[s].used_iterations = it + 1;
-    if (!(crit >= tol)) {
-        const bool finite = isfinite(crit);
-        flags[s] = finite ? 1 : 2;
-        info[s].converged = finite ? 1 : 0;
-        info[s].is_finite = finite ? 1 : 0;
-    } else if (final_pass) {
-        info[s].converged = 0;
+    if (flags[s] == 0) {
+        const float crit = (float)sqrt(acc[(size_t)s * FG_ACC_DOUBLES + A_RR] / (double)n);
+        info[s].final_residual = crit;
+        info[s].used_iterations = it + 1;
+        if (!(crit >= tol)) {
+            const bool finite = isfinite(crit);
+            flags[s] = finite ? 1 : 2;
+            info[s].converged = finite ? 1 : 0;
+            info[s].is_finite = finite ? 1 : 0;
+        } else if (final_pass) {
+            info[s].converged = 0;
+        }
     }
+    mirror[s] = info[s];  // host-pinned copy: the poll that follows is a stream synchronise, no device-to-host copy
 }
 
 }  // namespace
@@ -438,9 +440,8 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
             next_poll = it + 1 + 2;
             const int final_pass = (it + 1 == a.max_iterations);
-            hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, a.tol, it, n, nsys, final_pass);
+            hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass);
             // one read-back serves the poll and the result (nothing is launched after the last poll)
-            FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
             FG_HIP_CHECK(hipStreamSynchronize(st));
             info_fresh = true;
             done = true;

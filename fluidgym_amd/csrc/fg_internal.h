@@ -408,7 +408,9 @@ int fg_launch_h(const fg_state* s, const float* dt, const float* vel_result, hip
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const float* dt, const float* hvec, float* div, hipStream_t st);
 int fg_launch_correct(const fg_state* s, const float* dt, const float* rA, const float* hvec, const float* p,
                       float* vel_out, hipStream_t st);
-int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st);
+// mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be
+// scratch_B + B, whose next row holds the arrival counters)
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st, float* mirror_B = nullptr);
 int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st);
 int fg_launch_copy_active(const fg_state* s, const float* dt, const float* src, float* dst, int comps, hipStream_t st);
 int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long t_env_stride, float* source, int axis,

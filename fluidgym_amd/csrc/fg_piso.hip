@@ -314,9 +314,21 @@ __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const float* __r
 // Non-negative floats order like their bit patterns, so the reduction finishes with one integer
 // atomicMax per workgroup.
 // ---------------------------------------------------------------------------------------------
+// Per-env maximum across workgroups: atomicMax on the (non-negative) float bit pattern; the workgroup that arrives last
+// (per-env arrival counter, zeroed with out_B) copies the final value into the host-pinned mirror, so the host reads the
+// CFL velocity after a stream synchronise without a device-to-host copy.  mirror_B == nullptr: plain atomicMax.
+__device__ __forceinline__ void fg_publish_max(float* out_B, int32_t* done_B, float* mirror_B, int b, float mx) {
+    atomicMax(reinterpret_cast<int*>(out_B) + b, __float_as_int(mx));
+    if (!mirror_B) return;
+    __threadfence();
+    if (atomicAdd(done_B + b, 1) == (int)gridDim.x - 1)
+        mirror_B[b] = __int_as_float(atomicMax(reinterpret_cast<int*>(out_B) + b, 0));  // atomic read of the final value
+}
+
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bnd, const float* __restrict__ vel,
-                                                            float* __restrict__ out_B) {
+                                                            float* __restrict__ out_B, int32_t* __restrict__ done_B,
+                                                            float* __restrict__ mirror_B) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     float mx = 0.f;
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
     __syncthreads();
     if (threadIdx.x == 0) {
         mx = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
-        atomicMax(reinterpret_cast<int*>(out_B) + b, __float_as_int(mx));
+        fg_publish_max(out_B, done_B, mirror_B, b, mx);
     }
 }
 
@@ -361,7 +373,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
 // 14 us on 16.8 MB at B = 64, 256 x 128).  Workgroup 0 of each env also scans the boundary slabs, as above.
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBounds bnd, const float* __restrict__ vel,
-                                                                 float* __restrict__ out_B, int rows_per_block) {
+                                                                 float* __restrict__ out_B, int32_t* __restrict__ done_B,
+                                                                 float* __restrict__ mirror_B, int rows_per_block) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
     __syncthreads();
     if (threadIdx.x == 0) {
         mx = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
-        atomicMax(reinterpret_cast<int*>(out_B) + b, __float_as_int(mx));
+        fg_publish_max(out_B, done_B, mirror_B, b, mx);
     }
 }
 
@@ -642,25 +655,30 @@ int fg_launch_correct(const fg_state* s, const float* dt, const float* rA, const
     return FG_OK;
 }
 
-int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st) {
-    FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(float) * s->grid.B, st));
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st, float* mirror_B) {
+    // out_B [B] and the arrival counters right behind it (scratch_B rows 1 and 2) are zeroed together
+    int32_t* done_B = reinterpret_cast<int32_t*>(out_B + s->grid.B);
+    FG_REQUIRE(!mirror_B || out_B == s->scratch_B + s->grid.B, FG_ERR_INVALID_ARG, "mirror needs the scratch row as out_B");
+    FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(float) * s->grid.B * (mirror_B ? 2 : 1), st));
     if ((s->grid.nx & 3) == 0) {
         const int rows = s->grid.ny * s->grid.nz;
         int rpb = 4;  // rows per workgroup: one per wave, more when that still leaves >= 8 workgroups per CU
         while ((long)((rows + 2 * rpb - 1) / (2 * rpb)) * s->grid.B >= 2048) rpb *= 2;
         dim3 grid((rows + rpb - 1) / rpb, s->grid.B);
         if (s->grid.dims == 2)
-            hipLaunchKernelGGL(k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, rpb);
+            hipLaunchKernelGGL(k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
+                               mirror_B, rpb);
         else
-            hipLaunchKernelGGL(k_max_velocity_rows<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, rpb);
+            hipLaunchKernelGGL(k_max_velocity_rows<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
+                               mirror_B, rpb);
         FG_HIP_CHECK(hipGetLastError());
         return FG_OK;
     }
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
     if (s->grid.dims == 2)
-        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B);
+        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B);
     else
-        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B);
+        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

@@ -295,24 +295,30 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
     if (threadIdx.x == 0) fg_acc_add(fg_acc_ptr(acc, c.b, (it + 1) % 3), ns, tile, (double)part[0]);
 }
 
-// Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one wave per env.
+// Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one wave per env.  `mirror` (optional) is the
+// host-pinned copy of info: thread 0 of every env writes its entry there, so a convergence poll is a stream
+// synchronise without a device-to-host copy (the copy kernel + its launch cost ~6 us per poll, 4-5 polls per PISO step).
 __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                           float tol, int it, int n, int B, int final_pass, int ns) {
+                           fg_solve_info* __restrict__ mirror, float tol, int it, int n, int B, int final_pass, int ns) {
     const int b = blockIdx.x;
-    if (b >= B || flags[b] != 0) return;
-    const float crit = fg_rms(fg_acc_total(fg_acc_ptr(acc, b, (it + 1) % 3), ns), n);
-    if (threadIdx.x != 0) return;
-    info[b].final_residual = crit;
-    info[b].used_iterations = it;
-    if (!(crit >= tol)) {
-        const bool finite = isfinite(crit);
-        flags[b] = finite ? 1 : 2;
-        info[b].converged = finite ? 1 : 0;
-        info[b].is_finite = finite ? 1 : 0;
-    } else if (final_pass) {
-        info[b].converged = 0;
-        info[b].is_finite = 1;
+    if (b >= B) return;
+    if (flags[b] == 0) {
+        const float crit = fg_rms(fg_acc_total(fg_acc_ptr(acc, b, (it + 1) % 3), ns), n);
+        if (threadIdx.x == 0) {
+            info[b].final_residual = crit;
+            info[b].used_iterations = it;
+            if (!(crit >= tol)) {
+                const bool finite = isfinite(crit);
+                flags[b] = finite ? 1 : 2;
+                info[b].converged = finite ? 1 : 0;
+                info[b].is_finite = finite ? 1 : 0;
+            } else if (final_pass) {
+                info[b].converged = 0;
+                info[b].is_finite = 1;
+            }
+        }
     }
+    if (mirror && threadIdx.x == 0) mirror[b] = info[b];
 }
 
 __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ acc, int32_t* __restrict__ flags,
@@ -401,7 +407,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     if (a.precond) {
         if (!s->fd_Qx) { fg_set_error("preconditioned CG requested but fg_set_fd_preconditioner was not called"); return FG_ERR_INVALID_ARG; }
         // residual check of x0 (sets flags for already-converged envs), then z0 = M^-1 r0, r0.z0
-        hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, -1, n, B, 0, ns);
+        hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, (fg_solve_info*)nullptr, a.tol, -1, n, B, 0, ns);
         if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, B, st)) return rc;
     }
     bool done = false, info_fresh = false;
@@ -450,7 +456,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         if (poll) next_poll = it + 1 + check_every;
         if (a.precond || poll) {
             const int final_pass = (it + 1 == a.max_iterations);
-            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, a.tol, it, n, B, final_pass, ns);
+            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, poll ? s->info_pinned : nullptr, a.tol, it,
+                               n, B, final_pass, ns);
         }
         if (a.precond && it + 1 < a.max_iterations) {
             // z = M^-1 r and r.z of the next iteration (envs that just converged are skipped via flags)
@@ -458,9 +465,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 return rc;
         }
         if (poll) {
-            // one read-back serves the poll and the result: info carries converged / is_finite of every env, and nothing
-            // is launched between the last poll and the end of the solve
-            FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
+            // one read-back serves the poll and the result: k_cg_check above mirrored info (converged / is_finite of every
+            // env) into the pinned host copy, and nothing is launched between the last poll and the end of the solve
             FG_HIP_CHECK(hipStreamSynchronize(st));
             info_fresh = true;
             done = true;
