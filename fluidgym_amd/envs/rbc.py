@@ -34,6 +34,7 @@ from ..simulation import grids
 from ..simulation.domain import Domain
 from ..simulation.resample import UniformResampler
 from ..simulation.simulation import Simulation
+from . import obs_extraction as X
 from .fluid_env import FluidEnv
 
 RBC_2D_DEFAULT_CONFIG = {
@@ -69,7 +70,7 @@ RBC_3D_DEFAULT_CONFIG = {
 
 
 class RBCEnvBase(FluidEnv):
-    _supports_marl = False  # MARL windows (obs_extraction.py) are a "next" item
+    _supports_marl = True
     _resolution_scale_y: float = 2.0
     _non_uniform_grid_base = 1.02
     _H: float = 1.0
@@ -86,6 +87,8 @@ class RBCEnvBase(FluidEnv):
                  aspect_ratio=1.0, **kw):
         self._rayleigh_number = rayleigh_number
         self._prandtl_number = prandtl_number
+        self._local_obs_window = int(local_obs_window)
+        self._local_reward_weight = local_reward_weight
         self._heater_width = int(resolution)
         self._n_heaters = int(n_heaters)
         self._uniform_grid = uniform_grid
@@ -103,15 +106,25 @@ class RBCEnvBase(FluidEnv):
     def _n_sensors_x(self) -> int:
         return self._n_heaters * self._n_sensors_per_heater
 
+    @property
+    def n_agents(self) -> int:
+        """rbc_env_base.py:418-428."""
+        if not self._use_marl:
+            return 1
+        return self._n_heaters if self._ndims == 2 else self._n_heaters ** 2
+
     def _get_action_space(self):
-        shape = (self._n_heaters,) if self._ndims == 2 else (self._n_heaters, self._n_heaters)
+        """Per-agent action space (rbc_env_2d.py:112-129, rbc_env_3d.py:120-134)."""
+        if self._use_marl:
+            shape = (1,)
+        else:
+            shape = (self._n_heaters, 1) if self._ndims == 2 else (self._n_heaters, self._n_heaters, 1)
         return spaces.Box(low=-1.0, high=1.0, shape=shape, dtype=np.float32)
 
     def _get_observation_space(self):
-        if self._ndims == 2:
-            shape = (self._n_sensors_y, self._n_sensors_x)
-        else:
-            shape = (self._n_sensors_x, self._n_sensors_y, self._n_sensors_x)
+        """Per-agent observation space (rbc_env_2d.py:131-166, rbc_env_3d.py:136-172)."""
+        nx = self._n_sensors_per_heater * (self._local_obs_window if self._use_marl else self._n_heaters)
+        shape = (self._n_sensors_y, nx) if self._ndims == 2 else (nx, self._n_sensors_y, nx)
         return spaces.Dict({
             "temperature": spaces.Box(low=self._T_cold, high=self._T_hot + self._heater_limit, shape=shape, dtype=np.float32),
             "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(self._ndims,) + shape, dtype=np.float32),
@@ -194,15 +207,15 @@ class RBCEnvBase(FluidEnv):
 
     # ---- control --------------------------------------------------------------------------
     def _smooth_profile(self, T_action: torch.Tensor) -> torch.Tensor:
-        """Cubic blending between neighbouring heaters over 10 % of the heater width
-        (rbc_env_2d.py:196-237); ``T_action``: ``[B, n_heaters]`` -> ``[B, x]``."""
+        """Cubic blending between neighbouring heaters over 10 % of the heater width along the LAST axis
+        (rbc_env_2d.py:196-237, rbc_env_3d.py:201-239); ``T_action [..., n_heaters] -> [..., x]``."""
         hw = self._heater_width
         bw = round(hw * 0.1)
-        T1 = T_action[:, self._seg_id]
+        T1 = T_action[..., self._seg_id]
         if bw == 0:
             return T1
-        T0 = torch.roll(T_action, 1, dims=1)[:, self._seg_id]
-        T2 = torch.roll(T_action, -1, dims=1)[:, self._seg_id]
+        T0 = torch.roll(T_action, 1, dims=-1)[..., self._seg_id]
+        T2 = torch.roll(T_action, -1, dims=-1)[..., self._seg_id]
         tL = (self._x_pos.float() / bw + 0.5).clamp(0.0, 1.0)
         tR = 1 - torch.roll(tL, shifts=hw - bw + 1, dims=0)
         blend = lambda t, A, Bv: (1 - t * t * (3 - 2 * t)) * A + (t * t * (3 - 2 * t)) * Bv
@@ -221,8 +234,10 @@ class RBCEnvBase(FluidEnv):
         if self._ndims == 2:
             control = self._smooth_profile(T).view(self._num_envs, 1, 1, self._x)
         else:
+            # [z-heater, x-heater] (rbc_env_3d.py:246-268): smooth along z, then along x
             Th = T.view(self._num_envs, self._n_heaters, self._n_heaters)
-            control = Th[:, self._seg_id][:, :, self._seg_id].view(self._num_envs, 1, self._x, 1, self._x)
+            sz = self._smooth_profile(Th.transpose(1, 2)).transpose(1, 2)     # [B, Z, x-heater]
+            control = self._smooth_profile(sz).view(self._num_envs, 1, self._x, 1, self._x)
         self._bottom_plate.setPassiveScalar(control)
 
     # ---- observation / reward -------------------------------------------------------------
@@ -290,6 +305,49 @@ class RBCEnvBase(FluidEnv):
     @property
     def nu_ref(self) -> float:
         return float(self._metrics_stats.get("nusselt", 0.0))
+
+    def _local_nusselt(self, T, u_y, cell_size):
+        """``_compute_nusselt`` on per-agent windows (rbc_env_base.py:491-513): ``T, u_y [B, n_agents, *win]``."""
+        dims = tuple(range(2, T.dim()))
+        mean = (u_y * T * cell_size).sum(dim=dims) / cell_size.sum()
+        return 1.0 + float(np.sqrt(self._rayleigh_number * self._prandtl_number)) * mean
+
+    def _get_local_obs(self):
+        """rbc_env_2d.py:280-325 / rbc_env_3d.py:330-385 with a leading env axis: ``[B, n_agents, ...]``."""
+        g = self._get_global_obs()
+        nh, w, W = (self._n_heaters, self._n_sensors_per_heater, self._local_obs_window)
+        win = (lambda f: X.extract_moving_window_2d(f, nh, w, W)) if self._ndims == 2 else \
+              (lambda f: X.extract_moving_window_3d(f, nh, w, W))
+        u = torch.stack([win(g["velocity"][:, c]) for c in range(self._ndims)], dim=2)
+        return {"temperature": win(g["temperature"]), "velocity": u, "pressure": win(g["pressure"])}
+
+    def _get_local_rewards(self) -> torch.Tensor:
+        """Local Nusselt numbers over each agent's window of the simulation grid (rbc_env_2d.py:327-358,
+        rbc_env_3d.py:387-424), ``[B, n_agents]``."""
+        nh, hw, W = self._n_heaters, self._heater_width, self._local_obs_window
+        T, uy, cs = self._block.passiveScalar[:, 0], self._block.velocity[:, 1], self._cell_size
+        if self._ndims == 2:
+            lc = cs[:, : W * hw]
+            lT, lu = X.extract_moving_window_2d(T, nh, hw, W), X.extract_moving_window_2d(uy, nh, hw, W)
+        else:
+            lc = cs[: W * hw, :, : W * hw]
+            lT, lu = X.extract_moving_window_3d(T, nh, hw, W), X.extract_moving_window_3d(uy, nh, hw, W)
+        return self.nu_ref - self._local_nusselt(lT, lu, lc)
+
+    def _step_marl_impl(self, action: torch.Tensor):
+        """rbc_env_base.py:613-636."""
+        if self._local_reward_weight is None:
+            raise ValueError("local_reward_weight must be set for multi-agent step.")
+        _, global_reward, terminated, info = self._step_impl(action)
+        local_obs = self._get_local_obs()
+        if self._local_reward_weight > 0:
+            local_rewards = self._get_local_rewards()
+        else:
+            local_rewards = torch.zeros((self._num_envs, self.n_agents), dtype=self._dtype, device=self._cuda_device)
+        w = self._local_reward_weight
+        agent_rewards = w * local_rewards + (1 - w) * global_reward.unsqueeze(1)
+        info["global_reward"] = global_reward
+        return local_obs, agent_rewards, terminated, info
 
     def _step_impl(self, action: torch.Tensor):
         if self._enable_actions:

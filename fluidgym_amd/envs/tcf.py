@@ -16,12 +16,13 @@ Mirrors ``envs/tcf/tcf_env.py`` (``TCF3DBottomEnv`` :94-1063, ``TCF3DBothEnv`` :
 * observation: fluctuation velocity ``u - <u>_V`` (components x, y) and pressure on the plane ``y+ = 15``
   (``_get_global_obs`` :646-677), stacked bottom/top for "both" (``:1166-1180``);
 * reward ``1 - tau / tau_ref`` with the wall stress averaged over the sim steps of the env step (``:788-824``),
-  ``tau_ref`` = 1 without domain statistics (``:556-562``);
+  ``tau_ref`` = 1 without domain statistics (``:556-562``); multi-agent mode: per-actuator windows of patch means
+  (``_get_local_obs`` :918-992, ``:1182-1195``) and the global reward for every agent (``:994-1010``);
 * solver: adaptive CFL 0.1, advection and pressure tol 1e-6, 2 correctors (``:478-500``).
 
 Deviations: the reference's curl-simplex-noise initial perturbation (a separate CUDA extension, ``extensions/noise``)
 is replaced by Gaussian noise made discretely divergence-free; Smagorinsky SGS viscosity (``C_smag != 0``, off in every
-registered id) and the MARL windows are not built; no published initial domains / statistics (no network).
+registered id) is not built; no published initial domains / statistics (no network).
 """
 from __future__ import annotations
 
@@ -34,6 +35,7 @@ from .. import spaces
 from ..simulation import grids
 from ..simulation.domain import Domain
 from ..simulation.simulation import Simulation
+from . import obs_extraction as X
 from .fluid_env import FluidEnv
 
 SMALL_TCF_3D_DEFAULT_CONFIG = {
@@ -66,7 +68,7 @@ def reichardt_profile(y_plus: torch.Tensor) -> torch.Tensor:
 
 
 class TCF3DBottomEnv(FluidEnv):
-    _supports_marl = False
+    _supports_marl = True
     _actuation = "bottom"
     _scale_actions = True
     _delta: float = 1.0
@@ -91,6 +93,8 @@ class TCF3DBottomEnv(FluidEnv):
         self._grid_refinement_strength = 2 if self._x < 64 else 1
         self._init_with_noise = init_with_noise
         self._actor_size = int(actor_size)
+        self._local_obs_window = int(local_obs_window)
+        self._local_reward_weight = local_reward_weight
         assert self._x % 4 == 0 and self._x % self._actor_size == 0 and self._z % self._actor_size == 0
         step_length = self._t_wall_to_t(step_length)  # wall units -> physical (tcf_env.py:262)
         super().__init__(dt=(step_length / 10 if dt is None else dt), adaptive_cfl=adaptive_cfl, step_length=step_length,
@@ -123,13 +127,21 @@ class TCF3DBottomEnv(FluidEnv):
         return self._n_actors_x * self._n_actors_z
 
     def _get_action_space(self):
-        return spaces.Box(low=-1.0, high=1.0, shape=(self.n_agents, 1), dtype=np.float32)
+        """Per-agent action space (tcf_env.py:367-384)."""
+        return spaces.Box(low=-1.0, high=1.0, shape=(1,) if self._use_marl else (self.n_agents, 1), dtype=np.float32)
+
+    def _obs_space(self, velocity_shape, pressure_shape):
+        return spaces.Dict({
+            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=velocity_shape, dtype=np.float32),
+            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=pressure_shape, dtype=np.float32),
+        })
 
     def _get_observation_space(self):
-        return spaces.Dict({
-            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(2, self._z, self._x), dtype=np.float32),
-            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=(self._z, self._x), dtype=np.float32),
-        })
+        """tcf_env.py:386-428."""
+        W = self._local_obs_window
+        if self._use_marl:
+            return self._obs_space((W, W, 2), (W, W))
+        return self._obs_space((2, self._z, self._x), (self._z, self._x))
 
     # ---- domain / simulation ----------------------------------------------------------------
     def _get_domain(self) -> Domain:
@@ -237,6 +249,33 @@ class TCF3DBottomEnv(FluidEnv):
     def _get_global_obs(self):
         return self._plane_obs(self._y_obs_bottom_idx)
 
+    def _local_plane_obs(self, y_idx: int, flip_obs: bool):
+        """Per-actuator windows of patch-mean fluctuations on one plane (tcf_env.py:918-992; the plane mean is taken
+        over the slice here, and the x padding of u_x is one less than that of u_y / p, both as in the reference)."""
+        u = self._block.velocity[:, :2, :, y_idx, :]                     # [B, 2, Z, X]
+        p = self._block.pressure[:, 0, :, y_idx, :]
+        up = u - u.mean(dim=(2, 3), keepdim=True)
+        W, nax, naz, aw = self._local_obs_window, self._n_actors_x, self._n_actors_z, self._actor_size
+        win = lambda f, pad_x: X.extract_moving_window_2d_x_z(f, nax, naz, aw, W, W, pad_x, W // 2)   # [B, n, Wz, Wx]
+        ux, uy, pw = win(up[:, 0], W - 1), win(up[:, 1], W), win(p, W)
+        if flip_obs:   # top wall: consistent orientation (tcf_env.py:957-985)
+            ux = torch.flip(ux, dims=[3])
+            uy = -torch.flip(uy, dims=[3])
+            pw = torch.flip(pw, dims=[2])
+        return {"velocity": torch.stack((ux, uy), dim=-1), "pressure": pw}
+
+    def _get_local_obs(self):
+        return self._local_plane_obs(self._y_obs_bottom_idx, False)
+
+    def _step_marl_impl(self, action: torch.Tensor):
+        """tcf_env.py:994-1010: every agent receives the global reward."""
+        if self._local_reward_weight is None:
+            raise ValueError("local_reward_weight must be set for multi-agent step.")
+        _, global_reward, terminated, info = self._step_impl(action)
+        agent_rewards = global_reward.unsqueeze(1).expand(-1, self.n_agents).contiguous()
+        info["global_reward"] = global_reward
+        return self._get_local_obs(), agent_rewards, terminated, info
+
     def _get_reward(self, tau_total, tau_bottom):
         return 1 - tau_bottom / self.tau_ref
 
@@ -271,10 +310,17 @@ class TCF3DBothEnv(TCF3DBottomEnv):
         return 2 * self._n_actors_x * self._n_actors_z
 
     def _get_observation_space(self):
-        return spaces.Dict({
-            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(2, 2, self._z, self._x), dtype=np.float32),
-            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=(2, self._z, self._x), dtype=np.float32),
-        })
+        """tcf_env.py:1081-1124."""
+        W = self._local_obs_window
+        if self._use_marl:
+            return self._obs_space((W, W, 2), (W, W))
+        return self._obs_space((2, 2, self._z, self._x), (2, self._z, self._x))
+
+    def _get_local_obs(self):
+        """Bottom-wall agents first, then the top-wall agents with flipped orientation (tcf_env.py:1182-1195)."""
+        lo = self._local_plane_obs(self._y_obs_bottom_idx, False)
+        hi = self._local_plane_obs(min(self._y_obs_top_idx, self._y - 1), True)
+        return {k: torch.cat((lo[k], hi[k]), dim=1) for k in lo}
 
     @property
     def tau_ref(self) -> float:

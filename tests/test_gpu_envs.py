@@ -155,7 +155,7 @@ def test_rbc_heating_drives_convection():
     env.reset(seed=1)
     nus = []
     for _ in range(4):
-        _, reward, _, _, info = env.step(torch.zeros(2, 4, device="cuda"))
+        _, reward, _, _, info = env.step(torch.zeros(2, 4, 1, device="cuda"))  # (n_heaters, 1) per env, rbc_env_2d.py:112-129
         nus.append(info["nusselt"].cpu().numpy())
     assert np.isfinite(nus).all()
     T = env._block.passiveScalar
@@ -226,4 +226,39 @@ def test_tcf_units_actions_and_observations_follow_the_reference():
     assert torch.allclose(obs["pressure"][:, 1], p[:, 0, :, jt, :])
     assert set(info) >= {"wall_stress", "wall_stress_bottom", "wall_stress_top"}
     assert torch.allclose(reward, 1 - info["wall_stress"])  # tau_ref = 1 without domain statistics
+    env.close()
+
+
+MARL = {
+    "RBC2D-easy-v0": dict(n_heaters=4, resolution=8, local_obs_window=3, local_reward_weight=0.2),
+    "RBC3D-easy-v0": dict(n_heaters=2, resolution=4, local_obs_window=1, local_reward_weight=0.2),
+    "TCFSmall3D-bottom-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6, local_obs_window=3, local_reward_weight=0.0),
+    "TCFSmall3D-both-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6, local_obs_window=1, local_reward_weight=0.0),
+}
+
+
+@pytest.mark.parametrize("env_id", list(MARL))
+@pytest.mark.parametrize("num_envs", [None, 2])
+def test_multi_agent_contract(env_id, num_envs):
+    """use_marl=True: per-agent action (1,), observations [n_agents, *per-agent space], rewards [n_agents]
+    (reference fluid_env.py:249-251, 787-788; rbc_env_base.py:613-636; tcf_env.py:994-1010)."""
+    env = fluidgym_amd.make(env_id, num_envs=num_envs, use_marl=True, randomize_initial_state=False, episode_length=2,
+                            **MARL[env_id])
+    lead = () if num_envs is None else (num_envs,)
+    assert tuple(env.action_space.shape) == (1,)
+    obs, _ = env.reset(seed=1)
+    for k, sp in env.observation_space.items():
+        assert tuple(obs[k].shape) == lead + (env.n_agents,) + tuple(sp.shape), k
+    a = env.sample_action()
+    assert tuple(a.shape) == lead + (env.n_agents, 1)
+    obs, reward, term, trunc, info = env.step(a)
+    assert tuple(reward.shape) == lead + (env.n_agents,) and torch.isfinite(reward).all()
+    assert tuple(info["global_reward"].shape) == lead
+    if env_id.startswith("TCF"):
+        assert torch.allclose(reward, info["global_reward"].unsqueeze(-1).expand_as(reward))
+    else:  # RBC: weighted sum of local and global rewards, local = nu_ref - local Nusselt of the agent's window
+        w = MARL[env_id]["local_reward_weight"]
+        local = env._get_local_rewards()
+        g = info["global_reward"].reshape(-1, 1)
+        assert torch.allclose(reward.reshape(local.shape), w * local + (1 - w) * g, atol=1e-6)
     env.close()
