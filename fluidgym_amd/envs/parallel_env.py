@@ -195,13 +195,16 @@ class ParallelFluidEnv:
         obs, info = self._env.reset(seed=None if seed is None else int(seed) + self.rank, randomize=randomize)
         flat = self._all_gather(self._pack(obs, None))
         obs_all, _ = self._unpack(flat, obs, with_reward=False)
-        return obs_all, [info for _ in range(self.world)]
+        return self._agents_to_rows(obs_all), [info for _ in range(self.world)]
 
     def step(self, action: Optional[torch.Tensor] = None):
         """Driver: ``action [num_envs, ...]``.  Other ranks in SPMD mode pass ``None``."""
         if self.is_driver:
-            if action is None or action.shape[0] != self._n_total:
-                raise ValueError(f"Expected action batch size {self._n_total}, but got "
+            # multi-agent: one row per agent of every env, envs concatenated (what sample_action returns, reference
+            # parallel_env.py:356-359), or [num_envs, n_agents, ...]
+            ok = (self._n_total, self._n_total * self._env.n_agents) if self._env.use_marl else (self._n_total,)
+            if action is None or action.shape[0] not in ok:
+                raise ValueError(f"Expected action batch size {ok[-1]}, but got "
                                  f"{None if action is None else action.shape[0]}")
         self._bcast_cmd(Command.STEP)
         return self._do_step(action)
@@ -218,12 +221,20 @@ class ParallelFluidEnv:
         obs, reward, term, trunc, info = self._env.step(mine)
         flat = self._all_gather(self._pack(obs, reward))  # observations + rewards: one collective
         obs_all, reward_all = self._unpack(flat, obs, with_reward=True)
+        obs_all = self._agents_to_rows(obs_all)
         infos = [{k: v for k, v in info.items()} for _ in range(1)]
         return obs_all, reward_all, [term] * self._n_total, [trunc] * self._n_total, infos
 
+    def _agents_to_rows(self, obs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Multi-agent observations are concatenated over envs, ``[num_envs * n_agents, ...]`` (reference
+        ``__aggregate_obs``, parallel_env.py:192-200); single-agent ones stay stacked ``[num_envs, ...]``."""
+        if not self._env.use_marl:
+            return obs
+        return {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in obs.items()}
+
     def sample_action(self) -> torch.Tensor:
-        a = self._env.sample_action()
-        return self._all_gather(a)
+        a = self._all_gather(self._env.sample_action())
+        return a.reshape((-1,) + tuple(a.shape[2:])) if self._env.use_marl else a
 
     def train(self) -> None:
         self._bcast_cmd(Command.TRAIN)

@@ -18,6 +18,7 @@ class ToyEnv:
     """Deterministic pure-torch stand-in with the attributes ParallelFluidEnv touches."""
 
     n_agents = 1
+    use_marl = False
 
     def __init__(self, num_envs=1, cuda_device=None, gain=2.0, **kw):
         self._num_envs = num_envs
@@ -165,4 +166,56 @@ def test_num_envs_must_divide_world():
     os.environ.pop("RANK", None)
     penv = ParallelFluidEnv("ToyCPU-v0", num_envs=5, backend="gloo")
     assert penv.num_envs == 5 and penv.world == 1
+    penv.close()
+
+
+class ToyMarlEnv(ToyEnv):
+    """Two agents per env: actions [B, 2, 3], observations [B, 2, ...], rewards [B, 2]."""
+
+    n_agents = 2
+    use_marl = True
+
+    def __init__(self, num_envs=1, **kw):
+        super().__init__(num_envs=num_envs, **kw)
+        self._zero_action = torch.zeros(num_envs, 2, 3)
+        self.state = torch.zeros(num_envs, 2, 3)
+
+    def _obs(self):
+        return {"a": self.state[..., :2].unsqueeze(-1).expand(-1, -1, 2, 2).contiguous(),
+                "b": torch.cat([self.state, self.state[..., :2] * 3], dim=-1)}
+
+    def reset(self, seed=None, randomize=None):
+        self.state = torch.arange(self._num_envs * 6, dtype=torch.float32).reshape(self._num_envs, 2, 3) + (seed or 0)
+        return self._obs(), {}
+
+    def step(self, action):
+        assert action.shape == (self._num_envs, 2, 3)
+        self.state = self.state + self.gain * action
+        return self._obs(), self.state.sum(dim=-1), False, False, {}
+
+    def sample_action(self):
+        return torch.ones(self._num_envs, 2, 3)
+
+
+def test_multi_agent_rows_follow_the_reference_aggregation():
+    """Multi-agent observations / sampled actions are concatenated over envs ([num_envs * n_agents, ...], reference
+    parallel_env.py:192-200, 356-359), rewards stay [num_envs, n_agents]; both action layouts are accepted."""
+    import fluidgym_amd
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    if "ToyMarlCPU-v0" not in fluidgym_amd.registry.ids:
+        fluidgym_amd.register("ToyMarlCPU-v0", ToyMarlEnv, {"gain": 1.0})
+    os.environ.pop("RANK", None)
+    penv = ParallelFluidEnv("ToyMarlCPU-v0", num_envs=3, backend="gloo")
+    assert penv.n_agents == 6
+    obs, _ = penv.reset(seed=0)
+    assert obs["b"].shape == (6, 5) and obs["a"].shape == (6, 2, 2)
+    a = penv.sample_action()
+    assert a.shape == (6, 3)
+    o1, r1, *_ = penv.step(a)                      # rows
+    o2, r2, *_ = penv.step(a.reshape(3, 2, 3))     # [num_envs, n_agents, ...]
+    assert r1.shape == (3, 2) and o1["b"].shape == (6, 5)
+    assert torch.allclose(o2["b"][:, :3] - o1["b"][:, :3], torch.ones(6, 3))
+    with pytest.raises(ValueError, match="Expected action batch size"):
+        penv.step(torch.zeros(4, 3))
     penv.close()
