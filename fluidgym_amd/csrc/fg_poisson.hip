@@ -459,14 +459,12 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, poll ? s->info_pinned : nullptr, a.tol, it,
                                n, B, final_pass, ns);
         }
-        if (a.precond && it + 1 < a.max_iterations) {
-            // z = M^-1 r and r.z of the next iteration (envs that just converged are skipped via flags)
-            if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + (it + 1) % 3) * FG_CG_SLOTS, acc_stride, ns, active_est, st))
-                return rc;
-        }
         if (poll) {
             // one read-back serves the poll and the result: k_cg_check above mirrored info (converged / is_finite of every
-            // env) into the pinned host copy, and nothing is launched between the last poll and the end of the solve
+            // env) into the pinned host copy, and nothing is launched between the last poll and the end of the solve.
+            // The poll comes BEFORE the preconditioner of the next iteration: polls are scheduled where the previous solve
+            // finished, so they usually end the solve, and three kernels of M^-1 that would find every env converged
+            // cost more than the idle round trip of a poll that does not.
             FG_HIP_CHECK(hipStreamSynchronize(st));
             info_fresh = true;
             done = true;
@@ -477,6 +475,12 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 active_est += !fin;
             }
             if (active_est < 1) active_est = 1;
+            if (done) break;
+        }
+        if (a.precond && it + 1 < a.max_iterations) {
+            // z = M^-1 r and r.z of the next iteration (envs that just converged are skipped via flags)
+            if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + (it + 1) % 3) * FG_CG_SLOTS, acc_stride, ns, active_est, st))
+                return rc;
         }
     }
     if (!info_fresh) {
