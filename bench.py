@@ -224,7 +224,7 @@ def main():
     env = penv.local_env
     penv.reset(seed=1234, randomize=True)
     gen = torch.Generator(device="cpu").manual_seed(7)
-    a_shape = (n_total,) + tuple(env.action_space.shape)
+    a_shape = (n_total,) + tuple(env._zero_action.shape[1:])  # [envs, (agents,) *per-agent action shape]
 
     def actions():
         return (torch.rand(a_shape, generator=gen) * 2 - 1).to(device) if penv.is_driver else None

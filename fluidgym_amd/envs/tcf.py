@@ -48,7 +48,9 @@ SMALL_TCF_3D_DEFAULT_CONFIG = {
     "adaptive_cfl": 0.1,
     "step_length": 0.6,   # wall units (tcf_env.py:69); dt = step_length / 10 in physical units
     "episode_length": 1000,
-    "use_marl": False,
+    "local_obs_window": 1,
+    "local_reward_weight": 0.0,
+    "use_marl": True,   # tcf_env.py:73
     "init_with_noise": True,
     "dtype": torch.float32,
     "load_initial_domain": False,

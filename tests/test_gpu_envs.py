@@ -16,8 +16,8 @@ SMALL = {
     "ChannelJet2D-v0": dict(resolution_x=64, resolution_y=32),
     "RBC2D-easy-v0": dict(n_heaters=4, resolution=8),
     "RBC3D-easy-v0": dict(n_heaters=2, resolution=4),
-    "TCFSmall3D-both-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6),
-    "TCFSmall3D-bottom-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6),
+    "TCFSmall3D-both-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False),
+    "TCFSmall3D-bottom-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False),
 }
 
 
@@ -195,7 +195,7 @@ def test_tcf_units_actions_and_observations_follow_the_reference():
     """tcf_env.py: unit conversions (:246-265), _action_to_control (:521-547), the y+ = 15 sensing plane (:343-352),
     fluctuation-velocity observations (:646-677) and the both-walls stacking / sign flip (:1143-1180)."""
     env = fluidgym_amd.make("TCFSmall3D-both-easy-v0", num_envs=2, randomize_initial_state=False, resolution_x_z=16,
-                            resolution_y=16, step_length=0.6)
+                            resolution_y=16, step_length=0.6, use_marl=False)
     re_cl = (180 / 0.116) ** (1 / 0.88)
     assert abs(env._nu - 1 / re_cl) < 1e-12 and abs(env._u_wall - 180 / re_cl) < 1e-12
     assert abs(env.step_length - 0.6 * env._nu / env._u_wall ** 2) < 1e-12 and abs(env.dt - env.step_length / 10) < 1e-12
@@ -261,4 +261,80 @@ def test_multi_agent_contract(env_id, num_envs):
         local = env._get_local_rewards()
         g = info["global_reward"].reshape(-1, 1)
         assert torch.allclose(reward.reshape(local.shape), w * local + (1 - w) * g, atol=1e-6)
+    env.close()
+
+
+# ---- the reference's own env tests (tests/env_utils/test_fluid_env.py, tests/envs/test_all_envs.py), restated for the
+# ids that are built here; grids shrunk through kwargs so the whole file stays within seconds -----------------------------
+REDUCED = {"ChannelJet": dict(resolution_x=64, resolution_y=32), "RBC2D": dict(n_heaters=4, resolution=8, local_obs_window=3),
+           "RBC3D": dict(n_heaters=2, resolution=4, local_obs_window=1), "TCF": dict(resolution_x_z=16, resolution_y=16, resolution_x=None, resolution_z=None)}
+
+
+def _built_ids():
+    return [i for i in fluidgym_amd.registry.ids if not i.startswith(("Cylinder", "Airfoil", "Toy"))]
+
+
+def _reduced(env_id):
+    for k, v in REDUCED.items():
+        if env_id.startswith(k):
+            return dict(v, randomize_initial_state=False)
+    raise KeyError(env_id)
+
+
+def test_sampling_before_reset():
+    env = fluidgym_amd.make("RBC2D-easy-v0", **_reduced("RBC2D-easy-v0"))
+    with pytest.raises(RuntimeError) as excinfo:
+        env.step(env.sample_action())
+    assert "Environment must be seeded before sampling actions" in str(excinfo.value)
+
+
+def test_step_before_reset():
+    env = fluidgym_amd.make("RBC2D-easy-v0", **_reduced("RBC2D-easy-v0"))
+    with pytest.raises(RuntimeError) as excinfo:
+        env.step(torch.zeros(env.action_space.shape, device=env.cuda_device))
+    assert "Environment must be reset before stepping" in str(excinfo.value)
+
+
+def _check_obs(env, obs, marl):
+    assert isinstance(env.observation_space, fluidgym_amd.spaces.Dict)
+    for key, space in env.observation_space.spaces.items():
+        assert key in obs, f"Observation missing key: {key}"
+        o = obs[key][0] if marl else obs[key]
+        assert isinstance(o, torch.Tensor) and tuple(o.shape) == tuple(space.shape), key
+
+
+def _check_action(env, action, marl):
+    a = action[0] if marl else action
+    assert isinstance(env.action_space, fluidgym_amd.spaces.Box)
+    assert isinstance(a, torch.Tensor) and tuple(a.shape) == tuple(env.action_space.shape)
+
+
+@pytest.mark.parametrize("env_id", _built_ids())
+def test_env_sarl(env_id):
+    env = fluidgym_amd.make(env_id, use_marl=False, **_reduced(env_id))
+    env.seed(42)
+    obs, info = env.reset()
+    _check_action(env, env.sample_action(), marl=False)
+    obs, reward, terminated, truncated, info = env.step(env.sample_action())
+    _check_obs(env, obs, marl=False)
+    assert isinstance(reward, torch.Tensor) and isinstance(terminated, bool) and isinstance(truncated, bool)
+    assert isinstance(info, dict)
+    for metric in env.metrics:
+        assert metric in info and isinstance(info[metric], torch.Tensor), metric
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", _built_ids())
+def test_env_marl(env_id):
+    try:
+        env = fluidgym_amd.make(env_id, use_marl=True, **_reduced(env_id))
+    except ValueError:
+        return  # env does not support MARL
+    env.seed(42)
+    obs, info = env.reset()
+    _check_action(env, env.sample_action(), marl=True)
+    obs, reward, terminated, truncated, info = env.step(env.sample_action())
+    _check_obs(env, obs, marl=True)
+    assert reward.shape[0] == env.n_agents
+    assert "global_reward" in info and isinstance(info["global_reward"], torch.Tensor)
     env.close()
