@@ -364,6 +364,12 @@ class RBCEnvBase(FluidEnv):
         return (f"RBC{self._ndims}d_Ra{self._rayleigh_number}_Pr{self._prandtl_number}"
                 f"_NH{self._n_heaters}_HW{self._heater_width}")
 
+    @property
+    def initial_domain_id(self) -> str:
+        """rbc_env_base.py:605-611."""
+        return (f"rbc_{self._ndims}d_Ra{self._rayleigh_number}_Pr{self._prandtl_number}"
+                f"_NH{self._n_heaters}_HW{self._heater_width}")
+
 
 class RBCEnv2D(RBCEnvBase):
     def __init__(self, **kw):

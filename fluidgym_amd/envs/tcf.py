@@ -298,7 +298,12 @@ class TCF3DBottomEnv(FluidEnv):
 
     @property
     def id(self) -> str:
-        return f"TCF3D_{self._actuation}_Re{self._re_wall}_{self._x}x{self._y}x{self._z}"
+        return f"ChannelFlow3D_Re{int(self._re_wall)}_L{self._L:.2f}"   # tcf_env.py:874-877
+
+    @property
+    def initial_domain_id(self) -> str:
+        """tcf_env.py:866-872."""
+        return f"channel_flow3D_L{self._L:.2f}_Re{int(self._re_wall)}_Res{self._x}_Ref{self._grid_refinement_strength}"
 
 
 class TCF3DBothEnv(TCF3DBottomEnv):

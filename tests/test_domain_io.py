@@ -1,0 +1,123 @@
+"""Reference on-disk domain format (pict/util/domain_io.py:64-327): a file laid out the way the reference's writer
+lays it out loads into the batched Domain, and save -> load is the identity."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fluidgym_amd.simulation import grids
+from fluidgym_amd.simulation.domain import BoundaryConditionType
+from fluidgym_amd.simulation.domain_io import load_domain, save_domain
+
+
+def _write_reference_style(path, nx=8, ny=6, with_connected=False):
+    """What ``save_domain`` of the reference emits for a 2-D single-block RBC-like domain: tensors flat in the npz
+    under "0".."n", string indices in the json, FIXED y faces (Dirichlet / Neumann scalar), PERIODIC x faces."""
+    rng = np.random.default_rng(0)
+    edges = [np.linspace(0, 2, nx + 1), np.linspace(-1, 1, ny + 1) ** 3]
+    data = [np.array([0.01], np.float32),                                   # 0 viscosity
+            np.array([0.02], np.float32),                                   # 1 passiveScalarViscosity
+            rng.standard_normal((1, 2, ny, nx)).astype(np.float32),         # 2 velocity
+            rng.standard_normal((1, 1, ny, nx)).astype(np.float32),         # 3 pressure
+            rng.standard_normal((1, 1, ny, nx)).astype(np.float32),         # 4 scalar
+            np.array([[0.3, 0.0]], np.float32),                             # 5 static velocity source [N, C]
+            grids.vertex_grid(edges).numpy().astype(np.float32),            # 6 vertexCoordinates
+            np.zeros((1, 2), np.float32),                                   # 7 static wall velocity [N, C]
+            np.ones((1, 1, 1, nx), np.float32),                             # 8 varying wall scalar
+            np.zeros((1, 1), np.float32)]                                   # 9 static wall scalar
+    periodic = {"type": "PERIODIC"}
+    if with_connected:
+        periodic = {"type": "CONNECTED", "connectedBlock": 0, "axes": [1]}
+    dd = {"name": "RBCDomain", "spatialDims": 2, "viscosity": "0", "passiveScalarChannels": 1, "passiveScalarViscosity": "1",
+          "blocks": [{"name": "RBCBlock", "velocity": "2", "pressure": "3", "scalar": "4", "velocitySource": "5",
+                      "vertexCoordinates": "6",
+                      "boundaries": [periodic, {"type": "PERIODIC"},
+                                     {"type": "FIXED", "velocityType": "DIRICHLET", "velocity": "7",
+                                      "passiveScalarType": ["DIRICHLET"], "scalar": "8"},
+                                     {"type": "FIXED", "velocityType": "DIRICHLET", "velocity": "7",
+                                      "passiveScalarType": ["NEUMANN"], "scalar": "9"}]}],
+          "data_info": {str(i): {"shape": list(d.shape), "dtype": "float32", "device": "cuda"} for i, d in enumerate(data)}}
+    np.savez_compressed(path + ".npz", **{str(i): d for i, d in enumerate(data)})
+    with open(path + ".json", "w") as fh:
+        json.dump(dd, fh)
+    return data, edges
+
+
+def test_reference_layout_parses_without_a_gpu(tmp_path):
+    p = str(tmp_path / "dom")
+    data, edges = _write_reference_style(p)
+    dom = load_domain(p, prepare=False, batch=3)
+    blk = dom.getBlock(0)
+    assert dom.dims == 2 and dom.n_scalars == 1 and dom.batch == 3 and dom.name == "RBCDomain"
+    assert abs(float(dom.viscosity) - 0.01) < 1e-9
+    assert [blk.isFixed(f) for f in range(4)] == [False, False, True, True]
+    assert blk.getBoundary("-y").passiveScalarTypes == [BoundaryConditionType.DIRICHLET]
+    assert blk.getBoundary("+y").passiveScalarTypes == [BoundaryConditionType.NEUMANN]
+    assert np.allclose(blk.edges[1], edges[1], atol=1e-6)
+    with pytest.raises(NotImplementedError, match="CONNECTED"):
+        _write_reference_style(p, with_connected=True)
+        load_domain(p, prepare=False)
+    os.remove(p + ".json")
+
+
+@pytest.mark.gpu
+def test_reference_layout_loads_and_round_trips(tmp_path):
+    p = str(tmp_path / "dom")
+    data, _ = _write_reference_style(p)
+    dom = load_domain(p, batch=2)
+    blk = dom.getBlock(0)
+    for b in range(2):  # one stored env replicated over the batch
+        assert np.array_equal(blk.velocity[b].cpu().numpy(), data[2][0])
+        assert np.array_equal(blk.passiveScalar[b].cpu().numpy(), data[4][0])
+        assert np.allclose(blk.velocitySource[b, 0].cpu().numpy(), 0.3) and np.allclose(blk.velocitySource[b, 1].cpu().numpy(), 0.0)
+        assert np.allclose(blk.getBoundary("-y").passiveScalar[b].cpu().numpy(), 1.0)
+    blk.velocity[1] *= 2.0  # make env 1 differ, save it, load it back as a batch of 3
+    q = str(tmp_path / "dom2")
+    save_domain(dom, q, env=1)
+    with open(q + ".json") as fh:
+        dd = json.load(fh)
+    assert [e["type"] for e in dd["blocks"][0]["boundaries"]] == ["PERIODIC", "PERIODIC", "FIXED", "FIXED"]
+    assert dd["blocks"][0]["boundaries"][3]["passiveScalarType"] == ["NEUMANN"]
+    dom2 = load_domain(q, batch=3)
+    b2 = dom2.getBlock(0)
+    assert np.array_equal(b2.velocity[2].cpu().numpy(), 2.0 * data[2][0])
+    assert np.array_equal(b2.pressure[0].cpu().numpy(), data[3][0])
+    assert dom2._scalar_viscosity is not None and abs(dom2._scalar_viscosity[0] - 0.02) < 1e-9
+    # both domains step identically from the loaded state
+    from fluidgym_amd.simulation import Simulation
+    blk.velocity[0] *= 2.0
+    s1 = Simulation(dom, dt=0.01, substeps=1)
+    s2 = Simulation(dom2, dt=0.01, substeps=1)
+    assert s1.single_step() and s2.single_step()
+    assert torch.allclose(blk.velocity[1], b2.velocity[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_env_initial_domain_round_trip(tmp_path, monkeypatch):
+    """FluidEnv._save_initial_domain / load_initial_domain use the reference's directory layout
+    (<data>/initial_domains/<initial_domain_id>/<idx>/<mode>.json|npz, fluid_env.py:1044-1112)."""
+    import fluidgym_amd
+    from fluidgym_amd.types import EnvMode
+
+    monkeypatch.setenv("FLUIDGYM_DATA_PATH", str(tmp_path))
+    kw = dict(n_heaters=4, resolution=8, randomize_initial_state=False)
+    a = fluidgym_amd.make("RBC2D-easy-v0", num_envs=2, **kw)
+    a.reset(seed=3)
+    a.step(a.sample_action())
+    a._save_initial_domain(EnvMode.VAL, 7, env=1)
+    base = tmp_path / "initial_domains" / a.initial_domain_id / "7"
+    assert (base / "val.json").exists() and (base / "val.npz").exists()
+    assert a.initial_domain_id.startswith("rbc_2d_Ra")
+    b = fluidgym_amd.make("RBC2D-easy-v0", num_envs=3, **kw)
+    b.seed(0)
+    b.load_initial_domain(7, EnvMode.VAL)
+    b.reset()   # resets start from the loaded state
+    for e in range(3):
+        assert torch.equal(b._block.velocity[e], a._block.velocity[1])
+        assert torch.equal(b._block.passiveScalar[e], a._block.passiveScalar[1])
+    # a missing file falls back to the deterministic regeneration
+    b.load_initial_domain(99, EnvMode.TEST)
+    assert b._loaded_initial is None
+    a.close(); b.close()
