@@ -223,9 +223,10 @@ def test_reductions_and_inactive_envs():
     assert not torch.equal(ns.velocity[0], before[0])
 
 
-def test_buoyancy_fused_rbc_like_step():
-    """Scalar advection + fused buoyancy source (RBC PRE_VELOCITY_SETUP hook)."""
-    case = make_case(dims=2, n=(32, 16), fixed_axes=(1,), B=2, seed=14, n_scalars=1, wall_motion=0.0, vel_scale=0.1)
+@pytest.mark.parametrize("dims,n", [(2, (32, 16)), (3, (16, 10, 12))])
+def test_buoyancy_fused_rbc_like_step(dims, n):
+    """Scalar advection + fused buoyancy source (RBC PRE_VELOCITY_SETUP hook), 2-D and 3-D."""
+    case = make_case(dims=dims, n=n, fixed_axes=(1,), B=2, seed=14, n_scalars=1, wall_motion=0.0, vel_scale=0.1)
     ns = case.native()
     g = case.grid()
     src = torch.zeros_like(ns.velocity)
