@@ -346,15 +346,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
 #pragma unroll
         for (int q = 0; q < DIMS; ++q) mx = fmaxf(mx, fabsf(vel[((size_t)b * DIMS + q) * N + idx] * rh[q]));
     }
-    if (blockIdx.x == 0) {
-        // one wave per boundary face (faces w, w + 4): the faces' dependent load chains (pointer -> metric -> value) run
-        // side by side instead of one after the other -- the env's workgroup 0 was the critical path of the kernel
-        for (int f = threadIdx.x >> 6; f < 2 * DIMS; f += FG_BLOCK / 64) {
+    {
+        // boundary slabs: spread over ALL workgroups of the env.  With workgroup 0 scanning them alone the kernel's
+        // duration was that one workgroup's chain of dependent loads: 14 us in 2-D (256-cell slabs) and 99 us at
+        // 128 x 64 x 64 (8192-cell slabs), for a reduction that otherwise takes a few microseconds.
+#pragma unroll
+        for (int f = 0; f < 2 * DIMS; ++f) {
             if (!g.fixed[f]) continue;
             const int ax = f >> 1;
             const int slab_n = fg_slab_size(g, ax);
             const int edge = (f & 1) ? ((ax == 0) ? g.nx - 1 : (ax == 1) ? g.ny - 1 : g.nz - 1) : 0;
-            for (int s = threadIdx.x & 63; s < slab_n; s += 64) {
+            for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < slab_n; s += gridDim.x * blockDim.x) {
                 int i, j, k;
                 if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
                 else if (ax == 1) { j = edge; i = s % g.nx; k = s / g.nx; }
@@ -405,15 +407,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
             }
         }
     }
-    if (blockIdx.x == 0) {
-        // one wave per boundary face (faces w, w + 4): the faces' dependent load chains (pointer -> metric -> value) run
-        // side by side instead of one after the other -- the env's workgroup 0 was the critical path of the kernel
-        for (int f = threadIdx.x >> 6; f < 2 * DIMS; f += FG_BLOCK / 64) {
+    {
+        // boundary slabs: spread over ALL workgroups of the env.  With workgroup 0 scanning them alone the kernel's
+        // duration was that one workgroup's chain of dependent loads: 14 us in 2-D (256-cell slabs) and 99 us at
+        // 128 x 64 x 64 (8192-cell slabs), for a reduction that otherwise takes a few microseconds.
+#pragma unroll
+        for (int f = 0; f < 2 * DIMS; ++f) {
             if (!g.fixed[f]) continue;
             const int ax = f >> 1;
             const int slab_n = fg_slab_size(g, ax);
             const int edge = (f & 1) ? ((ax == 0) ? g.nx - 1 : (ax == 1) ? g.ny - 1 : g.nz - 1) : 0;
-            for (int s = threadIdx.x & 63; s < slab_n; s += 64) {
+            for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < slab_n; s += gridDim.x * blockDim.x) {
                 int i, j, k;
                 if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
                 else if (ax == 1) { j = edge; i = s % g.nx; k = s / g.nx; }
@@ -441,21 +445,24 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bnd, float* __restrict__ out_B) {
     const int b = blockIdx.x;
     double acc = 0.0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int f = 0; f < 2 * DIMS; ++f) {
         if (!g.fixed[f]) continue;
         const int ax = f >> 1;
         const int slab_n = fg_slab_size(g, ax);
         const double sgn = (f & 1) ? 1.0 : -1.0;
-        for (int s = threadIdx.x; s < slab_n; s += blockDim.x) {
-            int i = 0, j = 0, k = 0;
-            if (ax == 0) { j = s % g.ny; k = s / g.ny; }
-            else if (ax == 1) { i = s % g.nx; k = s / g.nx; }
-            else { i = s % g.nx; j = s / g.nx; }
-            float area;
-            if (ax == 0) area = g.h[1][j] * (DIMS == 3 ? g.h[2][k] : 1.f);
-            else if (ax == 1) area = g.h[0][i] * (DIMS == 3 ? g.h[2][k] : 1.f);
-            else area = g.h[0][i] * g.h[1][j];
-            acc += sgn * (double)(bnd.vel[f][((size_t)b * DIMS + ax) * slab_n + s] * area);
+        // slab index s = i0 + n0 * i1 over the two tangential axes; waves take rows i1, lanes run along i0: no integer
+        // division per cell and the loads of a row are independent (the s % n, s / n form cost 26 us at 128 x 64 x 64)
+        const int n0 = (ax == 0) ? g.ny : g.nx;
+        const int n1 = (DIMS == 3) ? ((ax == 2) ? g.ny : g.nz) : 1;
+        const float* __restrict__ h0 = (ax == 0) ? g.h[1] : g.h[0];
+        const float* __restrict__ h1 = (DIMS == 3) ? ((ax == 2) ? g.h[1] : g.h[2]) : nullptr;
+        const float* __restrict__ v = bnd.vel[f] + ((size_t)b * DIMS + ax) * slab_n;
+        for (int i1 = wave; i1 < n1; i1 += FG_BLOCK / 64) {
+            const float a1 = h1 ? h1[i1] : 1.f;
+            double row = 0.0;  // per-cell products in fp32 like the reference's flux, sums in fp64
+            for (int i0 = lane; i0 < n0; i0 += 64) row += (double)(v[(size_t)i1 * n0 + i0] * (h0[i0] * a1));
+            acc += sgn * row;
         }
     }
     __shared__ double lds[4];
@@ -498,8 +505,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_sum_env(const float* __restrict__ 
                                                        double* __restrict__ sums, int n) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
+    const float* __restrict__ pb = p + (size_t)b * n;
     float acc = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += p[(size_t)b * n + i];
+    const int n4 = ((n & 3) == 0 && (reinterpret_cast<size_t>(pb) & 15) == 0) ? n >> 2 : 0;  // float4 body, scalar tail
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(pb)[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = n4 * 4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += pb[i];
     __shared__ float lds[4];
     float v[1] = {acc};
     fg_block_sum<1>(v, lds);
@@ -511,10 +524,20 @@ __global__ __launch_bounds__(FG_BLOCK) void k_sub_mean(const float* __restrict__
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
     const float mean = (float)(sums[b] / (double)n);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float v = p[(size_t)b * n + i] - mean;
-        p[(size_t)b * n + i] = v;
-        if (p_copy) p_copy[(size_t)b * n + i] = v;
+    float* __restrict__ pb = p + (size_t)b * n;
+    float* __restrict__ cb = p_copy ? p_copy + (size_t)b * n : nullptr;
+    const bool al = (n & 3) == 0 && (reinterpret_cast<size_t>(pb) & 15) == 0 && (!cb || (reinterpret_cast<size_t>(cb) & 15) == 0);
+    const int n4 = al ? n >> 2 : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<float4*>(pb)[i];
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        reinterpret_cast<float4*>(pb)[i] = v;
+        if (cb) reinterpret_cast<float4*>(cb)[i] = v;
+    }
+    for (int i = n4 * 4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v = pb[i] - mean;
+        pb[i] = v;
+        if (cb) cb[i] = v;
     }
 }
 
@@ -601,6 +624,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds 
     }
 }
 
+// Workgroups per env in the reduction kernels (sum, max).  Each ends in same-address atomics, which serialise at ~0.1 us
+// apiece, so fewer, fatter workgroups win as long as the chip still has a few hundred of them in total
+// (measured: B = 64, 256 x 128: 32 -> 8 per env takes the max-velocity pass 18.5 -> 7.3 us; B = 8, 128 x 64 x 64:
+// 256 -> 32 per env 31 -> 21 us, 8 per env 66 us).
+inline unsigned fg_reduce_wgs(const fg_state* s) {
+    const unsigned per_env = (512 + s->grid.B - 1) / s->grid.B;
+    return per_env < 8 ? 8 : (per_env > 64 ? 64 : per_env);
+}
+
 inline dim3 stride_grid(const fg_state* s, long per_env_elems) {
     long blocks = (per_env_elems / 4 + FG_BLOCK - 1) / FG_BLOCK;
     const long cap = (2048 + s->grid.B - 1) / s->grid.B;  // ~8 workgroups per CU over the batch
@@ -672,8 +704,9 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B,
     FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(float) * s->grid.B * (mirror_B ? 2 : 1), st));
     if ((s->grid.nx & 3) == 0) {
         const int rows = s->grid.ny * s->grid.nz;
-        int rpb = 4;  // rows per workgroup: one per wave, more when that still leaves >= 8 workgroups per CU
+        int rpb = 4;  // rows per workgroup: one per wave, more when that still leaves >= 8 workgroups per CU ...
         while ((long)((rows + 2 * rpb - 1) / (2 * rpb)) * s->grid.B >= 2048) rpb *= 2;
+        while ((rows + rpb - 1) / rpb > (int)fg_reduce_wgs(s)) rpb *= 2;  // ... and few per env: they meet in same-address atomics
         dim3 grid((rows + rpb - 1) / rpb, s->grid.B);
         if (s->grid.dims == 2)
             hipLaunchKernelGGL(k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
@@ -721,7 +754,10 @@ int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long 
 int fg_launch_mean_sub(const fg_state* s, const float* dt, float* p, float* p_copy, hipStream_t st) {
     double* sums = s->acc;  // first B doubles of the accumulator pool: free between solves, zeroed by k_cg_begin
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
-    hipLaunchKernelGGL(k_sum_env, grid, dim3(FG_BLOCK), 0, st, dt, p, sums, s->grid.n);
+    // every workgroup ends in one fp64 atomicAdd on its env's sum and same-address atomics serialise (~0.1 us each):
+    // few workgroups per env for the reduction pass (fg_reduce_wgs)
+    dim3 rgrid(grid.x > fg_reduce_wgs(s) ? fg_reduce_wgs(s) : grid.x, grid.y);
+    hipLaunchKernelGGL(k_sum_env, rgrid, dim3(FG_BLOCK), 0, st, dt, p, sums, s->grid.n);
     hipLaunchKernelGGL(k_sub_mean, grid, dim3(FG_BLOCK), 0, st, dt, p, p_copy, sums, s->grid.n);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
