@@ -109,6 +109,10 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     s->pred_bicg = 2; s->pred_cg = 1;
     FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 8 * 64));
+    FG_HIP_CHECK(hipMalloc(&s->cg_best.best_crit, sizeof(float) * g.B * 2));
+    FG_HIP_CHECK(hipMalloc(&s->cg_best.saved_crit, sizeof(float) * g.B));
+    FG_HIP_CHECK(hipMalloc(&s->cg_best.save_at, sizeof(int32_t) * g.B));
+    FG_HIP_CHECK(alloc(&s->cg_best.best_x, BN));
     *out = s;
     return FG_OK;
 }
@@ -126,7 +130,9 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned); (void)hipHostFree(s->dt_pinned); (void)hipFree(s->dt_dev);
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
+    if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc);
+    (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
     return FG_OK;
 }
@@ -180,6 +186,7 @@ extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const floa
     FG_HIP_CHECK(up(&s->fd_lower, lower, ny));
     FG_HIP_CHECK(up(&s->fd_inv, inv, nx * ny * nz));
     FG_HIP_CHECK(up(&s->fd_cp, cp, nx * ny * nz));
+    s->fd_dct_x = 0;  // fg_set_fd_fast_transform marks the axis again for the new basis
     return FG_OK;
 }
 

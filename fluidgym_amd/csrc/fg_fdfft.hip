@@ -1,0 +1,184 @@
+// Fast cosine transforms for the fast-diagonalisation preconditioner (uniform FIXED x axis).
+//
+// On an axis with uniform cell width h and FIXED (pressure-Neumann) ends the generalised eigenvectors of the 1-D
+// operator are the orthonormal DCT-II basis scaled by 1/sqrt(h) (simulation/fd_precond.py checks this against
+// numpy's eigh), so the two basis changes of M^-1 are a DCT-II and a DCT-III of every grid row -- O(n log n) instead
+// of the dense n x n GEMM of fg_fdprecond.hip (131 kflop per 256-cell row there, ~7 kflop here; both memory-bound
+// after that).  Makhoul's mapping onto ONE n-point complex FFT per row:
+//     v_j = x_{2j},  v_{n-1-j} = x_{2j+1};   V = FFT_n(v);   X_k = s_k Re(e^{-i pi k / 2n} V_k)
+// and backwards  V_k = (Y_k - i Y_{n-k}) e^{+i pi k / 2n},  v = FFT^-1(V),  x_{2j} = v_j, x_{2j+1} = v_{n-1-j}.
+// One wave per row, four rows per workgroup, radix-2 Stockham stages ping-ponging between two LDS buffers; twiddles
+// come from tables built in double precision on the host (fg_set_fd_fast_transform).
+#include <math.h>
+
+#include <vector>
+
+#include "fg_internal.h"
+
+namespace {
+
+struct DctArgs {
+    const float* src; float* dst;           // [B, rows, n] contiguous rows
+    const float2* tw;                       // [n/2]  (cos, sin)(2 pi j / n)
+    const float2* rot;                      // [n]    (cos, sin)(pi k / 2n)
+    float scale0, scale;                    // forward: s_k / sqrt(h); inverse: 1 / (s_k n sqrt(h))   (k = 0 | k > 0)
+    const int32_t* flags;                   // env b skipped when flags[b] != 0
+    const float* dot_with; double* dot_acc; int dot_stride, dot_ns;   // inverse only: acc[b] += sum dst .* dot_with
+    long env_stride; int rows;
+};
+
+template <int N, bool INVERSE>
+__global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
+    constexpr int EPL = N / 64;             // elements per lane
+    constexpr int LOG2N = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : 9;
+    __shared__ float2 buf[2][4][N];
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    if (a.flags && a.flags[b] != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    const bool live = row < a.rows;
+    const size_t off = (size_t)b * a.env_stride + (size_t)(live ? row : 0) * N + lane * EPL;
+    float2* x = buf[0][wave];
+    float2* y = buf[1][wave];
+    float xin[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) xin[e] = a.src[off + e];
+    if (!INVERSE) {
+        // v_j = x_2j, v_{n-1-j} = x_{2j+1}
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = lane * EPL + e;
+            const int j = (i & 1) ? N - 1 - (i >> 1) : (i >> 1);
+            x[j] = make_float2(xin[e], 0.f);
+        }
+    } else {
+        // stage the row so that Y_{n-k} is reachable, then V_k = g_k (Y_k - i Y_{n-k}) e^{+i theta_k},  Y_n := 0
+        float* stage = reinterpret_cast<float*>(y);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) stage[lane * EPL + e] = xin[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int k = lane * EPL + e;
+            const float yk = stage[k], ym = (k == 0) ? 0.f : stage[N - k];
+            const float2 r = a.rot[k];
+            const float g = (k == 0) ? a.scale0 : a.scale;
+            x[k] = make_float2(g * (yk * r.x + ym * r.y), g * (yk * r.y - ym * r.x));
+        }
+    }
+    __syncthreads();
+    // radix-2 Stockham autosort: stage with sub-transform length n = N >> st, stride s = 1 << st
+#pragma unroll
+    for (int st = 0; st < LOG2N; ++st) {
+        const int s = 1 << st;
+#pragma unroll
+        for (int e = 0; e < EPL / 2 + (EPL == 1); ++e) {
+            const int t = (EPL == 1) ? lane : lane * (EPL / 2) + e;   // butterfly index in [0, N/2)
+            if (EPL > 1 || lane < N / 2) {
+                const int q = t & (s - 1), ps = t - q;                // ps = p * s = twiddle index
+                const float2 u = x[t], v = x[t + N / 2];
+                float2 w = a.tw[ps];
+                if (!INVERSE) w.y = -w.y;
+                const float dr = u.x - v.x, di = u.y - v.y;
+                y[2 * ps + q] = make_float2(u.x + v.x, u.y + v.y);
+                y[2 * ps + q + s] = make_float2(dr * w.x - di * w.y, dr * w.y + di * w.x);
+            }
+        }
+        __syncthreads();
+        float2* tmp = x; x = y; y = tmp;
+    }
+    float out[EPL];
+    if (!INVERSE) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int k = lane * EPL + e;
+            const float2 r = a.rot[k], V = x[k];
+            out[e] = ((k == 0) ? a.scale0 : a.scale) * (r.x * V.x + r.y * V.y);   // Re(e^{-i theta} V)
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = lane * EPL + e;
+            out[e] = x[(i & 1) ? N - 1 - (i >> 1) : (i >> 1)].x;
+        }
+    }
+    float dot = 0.f;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) a.dst[off + e] = out[e];
+        if (INVERSE && a.dot_with) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dot += out[e] * a.dot_with[off + e];
+        }
+    }
+    if (INVERSE && a.dot_with) {
+        float part[1] = {dot};
+        fg_block_sum<1>(part, red);
+        if (threadIdx.x == 0)
+            atomicAdd(a.dot_acc + (size_t)b * a.dot_stride + (blockIdx.x & (unsigned)(a.dot_ns - 1)), (double)part[0]);
+    }
+}
+
+template <bool INVERSE>
+int launch_dct(const fg_state* s, int n, const DctArgs& a, int slot, hipStream_t st) {
+    const dim3 grid((a.rows + 3) / 4, s->grid.B);
+    switch (n) {
+        case 64: FG_LAUNCH_P(s, slot, (k_dct_rows<64, INVERSE>), grid, dim3(256), 0, st, a); break;
+        case 128: FG_LAUNCH_P(s, slot, (k_dct_rows<128, INVERSE>), grid, dim3(256), 0, st, a); break;
+        case 256: FG_LAUNCH_P(s, slot, (k_dct_rows<256, INVERSE>), grid, dim3(256), 0, st, a); break;
+        case 512: FG_LAUNCH_P(s, slot, (k_dct_rows<512, INVERSE>), grid, dim3(256), 0, st, a); break;
+        default: fg_set_error("fast cosine transform: unsupported length"); return FG_ERR_UNSUPPORTED;
+    }
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+}  // namespace
+
+bool fg_fd_dct_supported(int n) { return n == 64 || n == 128 || n == 256 || n == 512; }
+
+// x-axis transforms of fg_fd_apply when the axis is marked as DCT (fd_dct_x): rows = ny * nz per env, length nx.
+int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st) {
+    const FgGrid& G = s->grid;
+    DctArgs a = {};
+    a.src = r; a.dst = out; a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot;
+    a.scale0 = s->fd_dct_fwd[0]; a.scale = s->fd_dct_fwd[1];
+    a.flags = s->flags; a.env_stride = G.n; a.rows = G.ny * G.nz;
+    // per env: the row read + written; ~5 n log2 n flops per row
+    const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, G.B, 8.0 * G.n, 5.0 * G.n * log2((double)G.nx), st);
+    return launch_dct<false>(s, G.nx, a, slot, st);
+}
+int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, double* dot_acc, int dot_stride,
+                      int dot_ns, hipStream_t st) {
+    const FgGrid& G = s->grid;
+    DctArgs a = {};
+    a.src = u; a.dst = z; a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot;
+    a.scale0 = s->fd_dct_inv[0]; a.scale = s->fd_dct_inv[1];
+    a.flags = s->flags; a.env_stride = G.n; a.rows = G.ny * G.nz;
+    a.dot_with = dot_acc ? dot_with : nullptr; a.dot_acc = dot_acc; a.dot_stride = dot_stride; a.dot_ns = dot_ns;
+    const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, G.B, (dot_acc ? 12.0 : 8.0) * G.n, 5.0 * G.n * log2((double)G.nx), st);
+    return launch_dct<true>(s, G.nx, a, slot, st);
+}
+
+extern "C" int fg_set_fd_fast_transform(fg_handle s, int axis, float cell_width) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    FG_REQUIRE(axis == 0, FG_ERR_UNSUPPORTED, "fast transforms are built for the x axis only");
+    const int n = s->grid.nx;
+    FG_REQUIRE(fg_fd_dct_supported(n), FG_ERR_UNSUPPORTED, "fast cosine transform needs nx in {64, 128, 256, 512}");
+    FG_REQUIRE(s->grid.fixed[0] && s->grid.fixed[1] && cell_width > 0.f, FG_ERR_INVALID_ARG,
+               "fast cosine transform needs FIXED x faces and a uniform positive cell width");
+    std::vector<float2> tw(n / 2), rot(n);
+    for (int j = 0; j < n / 2; ++j) tw[j] = make_float2((float)cos(2.0 * M_PI * j / n), (float)sin(2.0 * M_PI * j / n));
+    for (int k = 0; k < n; ++k) rot[k] = make_float2((float)cos(M_PI * k / (2.0 * n)), (float)sin(M_PI * k / (2.0 * n)));
+    if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
+    FG_HIP_CHECK(hipMalloc(&s->fd_dct_tw, sizeof(float2) * (n / 2)));
+    FG_HIP_CHECK(hipMalloc(&s->fd_dct_rot, sizeof(float2) * n));
+    FG_HIP_CHECK(hipMemcpy(s->fd_dct_tw, tw.data(), sizeof(float2) * (n / 2), hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->fd_dct_rot, rot.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    const double rs = 1.0 / sqrt((double)cell_width);
+    s->fd_dct_fwd[0] = (float)(sqrt(1.0 / n) * rs); s->fd_dct_fwd[1] = (float)(sqrt(2.0 / n) * rs);
+    s->fd_dct_inv[0] = (float)(rs / (sqrt(1.0 / n) * n)); s->fd_dct_inv[1] = (float)(rs / (sqrt(2.0 / n) * n));
+    s->fd_dct_x = 1;
+    return FG_OK;
+}

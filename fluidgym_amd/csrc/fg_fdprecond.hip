@@ -495,13 +495,18 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
     float* t1 = s->w[3];
     float* t2 = s->w[4];
     GemmArgs g;
-    // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]
-    g.A = r; g.lda = nx; g.strideA = N;
-    g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_QxT; g.ldbt = nx;
-    g.C = t1; g.ldc = nx; g.strideC = N;
-    g.M = ny * nz; g.N = nx; g.K = nx;
     g.flags = s->flags; g.dot_with = nullptr; g.strideW = 0; g.dot_acc = nullptr; g.dot_stride = 0; g.dot_ns = 1;
-    if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
+    if (s->fd_dct_x) {
+        // uniform FIXED x axis: the basis is the DCT-II basis, applied as an FFT per row (fg_fdfft.hip)
+        if (int rc = fg_fd_dct_forward(s, r, t1, st)) return rc;
+    } else {
+        // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]
+        g.A = r; g.lda = nx; g.strideA = N;
+        g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_QxT; g.ldbt = nx;
+        g.C = t1; g.ldc = nx; g.strideC = N;
+        g.M = ny * nz; g.N = nx; g.K = nx;
+        if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
+    }
     float* cur = t1;
     if (G.dims == 3) {
         // forward z: t2[c, m] = sum_k QzT[c, k] t1[k, m]   (m over ny*nx)
@@ -534,6 +539,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_st
         if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
         cur = t1;
     }
+    if (s->fd_dct_x) return fg_fd_dct_inverse(s, cur, z, r, rz_acc, rz_stride, rz_ns, st);
     // inverse x: z[rows, i] = sum_a cur[rows, a] QxT[a, i], fused r.z
     g.A = cur; g.lda = nx; g.strideA = N;
     g.B = s->fd_QxT; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_Qx; g.ldbt = nx;

@@ -295,7 +295,7 @@ __device__ __forceinline__ void fg_block_sum(float (&v)[NV], float* lds /* >= NV
 // kernel snapshots how many systems were still iterating so the algorithmic bytes count only work done.
 enum FgProfKind {
     FG_PK_CG_AP = 0, FG_PK_CG_UPDATE, FG_PK_BICG_P, FG_PK_BICG_V, FG_PK_BICG_S, FG_PK_BICG_T, FG_PK_BICG_X,
-    FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_COUNT
+    FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_DCT, FG_PK_COUNT
 };
 #define FG_PROF_POOL 256
 struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };
@@ -311,6 +311,18 @@ struct FgProf {
     long long all_n[FG_PK_COUNT];
 };
 #define FG_ACC_DOUBLES 16  // reduction accumulators per linear system (see solver kernels)
+
+// Best-iterate tracking (the reference's returnBestResult, cg_solver_kernel.cu:345-361): whenever the RMS residual of
+// iterate x_it is the lowest so far (it >= 1), the kernel that is about to overwrite x (k_cg_update of iteration it,
+// which derives that residual from the accumulators like every other scalar) writes the old x to best_x -- no extra read, one extra store per cell for the envs concerned.  A solve that ends
+// unconverged (max iterations, or fp32 stagnation followed by divergence) gets its best iterate back.
+struct FgBest {
+    float* best_crit;   // [B][2] lowest residual seen so far, ring by iteration parity (readers and the writer of one
+                        //        launch use different entries)
+    float* saved_crit;  // [B] residual of the iterate held in best_x (+inf: none)
+    int32_t* save_at;   // unused slot kept for layout stability
+    float* best_x;      // [B, N]
+};
 
 struct fg_state {
     fg_config cfg;
@@ -348,8 +360,11 @@ struct fg_state {
     float* scratch_B;  // [B*(4+2d)] small per-env floats
     FgProf prof;
     double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
+    FgBest cg_best;               // best-iterate tracking of the CG (returnBestResult, cg_solver_kernel.cu:345-361)
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
+    // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs
+    int fd_dct_x; float2* fd_dct_tw; float2* fd_dct_rot; float fd_dct_fwd[2]; float fd_dct_inv[2];
     float** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
     float* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
     float* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
@@ -462,6 +477,10 @@ int fg_prof_slot(const fg_state* s, int kind, const int32_t* flags, int nsys, do
                  double flops_per_sys, hipStream_t st);
 int fg_prof_collect(fg_state* s, hipStream_t st);
 void fg_prof_destroy(fg_state* s);
+bool fg_fd_dct_supported(int n);
+int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st);
+int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, double* dot_acc, int dot_stride,
+                      int dot_ns, hipStream_t st);
 #define FG_LAUNCH_P(s, slot, kernel, grid, block, shmem, st, ...)                                              \
     do {                                                                                                       \
         const int slot__ = (slot);                                                                             \

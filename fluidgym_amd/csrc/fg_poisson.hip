@@ -265,15 +265,25 @@ template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* __restrict__ p_,
                                                          const float* __restrict__ Ap_, float* __restrict__ x_,
                                                          float* __restrict__ r_, double* __restrict__ acc,
-                                                         const int32_t* __restrict__ flags, float tol, int it, int ns,
-                                                         int num_base, int tiles_x, int tiles_y, int tiles) {
+                                                         const int32_t* __restrict__ flags, FgBest best, float tol, int it,
+                                                         int ns, int num_base, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flags[c.b] != 0) return;
     const double rr = fg_acc_total(fg_acc_ptr(acc, c.b, num_base + it % 3), ns);  // r.r or r.z
+    // best-iterate tracking (FgBest): x on entry is x_it with RMS residual crit_it; keep it if it is the best so far
+    const float crit_it = fg_rms(num_base ? fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns) : rr, g.n);
+    const float best_prev = best.best_crit[c.b * 2 + ((it + 1) & 1)];
+    const bool save = (it >= 1) && (crit_it < best_prev);
     const double pAp = fg_acc_total(fg_acc_ptr(acc, c.b, 3 + (it & 1)), ns);
     const float alpha = (float)(rr / pAp);
     const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
-    if (tile == 0 && threadIdx.x < 64) fg_acc_zero(fg_acc_ptr(acc, c.b, 3 + ((it + 1) & 1)), ns);  // next pAp
+    if (tile == 0 && threadIdx.x < 64) {
+        fg_acc_zero(fg_acc_ptr(acc, c.b, 3 + ((it + 1) & 1)), ns);  // next pAp
+        if (threadIdx.x == 0) {
+            best.best_crit[c.b * 2 + (it & 1)] = save ? crit_it : best_prev;
+            if (save) best.saved_crit[c.b] = crit_it;
+        }
+    }
     __shared__ float lds[4];
     const size_t base = (size_t)c.b * g.n;
     float part[1] = {0.f};
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
         const FgVec<VEC> Ap = fg_load<VEC>(Ap_ + base + c.idx);
         FgVec<VEC> x = fg_load<VEC>(x_ + base + c.idx);
         FgVec<VEC> r = fg_load<VEC>(r_ + base + c.idx);
+        if (save) fg_store<VEC>(best.best_x + base + c.idx, x);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             x.v[e] += alpha * p.v[e];
@@ -322,13 +333,15 @@ __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags
 }
 
 __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ acc, int32_t* __restrict__ flags,
-                           fg_solve_info* __restrict__ info, double* __restrict__ mean_sums, int B) {
+                           fg_solve_info* __restrict__ info, double* __restrict__ mean_sums, FgBest best, int B) {
     const int b = blockIdx.x;
     if (b >= B) return;
     for (int q = threadIdx.x; q < FG_CG_NAMES * FG_CG_SLOTS; q += blockDim.x)
         acc[(size_t)b * FG_CG_NAMES * FG_CG_SLOTS + q] = 0.0;
     if (threadIdx.x != 0) return;
     mean_sums[b] = 0.0;  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
+    best.best_crit[b * 2] = best.best_crit[b * 2 + 1] = INFINITY;
+    best.saved_crit[b] = INFINITY;
     const bool active = (dt == nullptr) || (dt[b] > 0.f);
     flags[b] = active ? 0 : 3;
     info[b].final_residual = 0.f;
@@ -340,6 +353,22 @@ __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ ac
 __global__ void k_zero_name(double* __restrict__ acc, int name, int B) {
     const int b = blockIdx.x;
     if (b < B && threadIdx.x < FG_CG_SLOTS) fg_acc_ptr(acc, b, name)[threadIdx.x] = 0.0;
+}
+
+// Unconverged envs get the best iterate seen back (returnBestResult): x = best_x where its residual beats the final one.
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_restore_best(float* __restrict__ x, fg_solve_info* __restrict__ info,
+                                                               fg_solve_info* __restrict__ mirror, FgBest best, int n) {
+    const int b = blockIdx.y;
+    const fg_solve_info I = info[b];
+    const float have = best.saved_crit[b];
+    const bool worse = !(I.final_residual <= have);   // also true for a NaN final residual
+    if (I.converged || !worse || !isfinite(have)) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        x[(size_t)b * n + i] = best.best_x[(size_t)b * n + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        mirror[b].final_residual = have;   // info itself is read by the other workgroups of this launch: leave it alone
+        mirror[b].is_finite = 1;
+    }
 }
 
 }  // namespace
@@ -394,7 +423,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const bool zmarch = fg_zmarch_ok(s, &zc);
     int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
     while (ns < FG_CG_SLOTS && tiles_per_env / ns > 256) ns *= 2;
-    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, B);
+    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, s->cg_best, B);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,
@@ -450,7 +479,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         FG_DISPATCH(s, {
             const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
             FG_LAUNCH_P(s, slot_up, (k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x,
-                        a.r, s->cg_acc, s->flags, a.tol, it, ns, nb, L.tiles_x, L.tiles_y, L.tiles);
+                        a.r, s->cg_acc, s->flags, s->cg_best, a.tol, it, ns, nb, L.tiles_x, L.tiles_y, L.tiles);
         });
         const bool poll = (it + 1 >= next_poll || it + 1 == a.max_iterations);
         if (poll) next_poll = it + 1 + check_every;
@@ -488,6 +517,12 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         FG_HIP_CHECK(hipStreamSynchronize(st));
     }
     if (int prc = fg_prof_collect(s, st)) return prc;
+    bool failed = false;
+    for (int b = 0; b < B; ++b) failed = failed || !s->info_pinned[b].converged;
+    if (failed) {  // rare path: hand back the best iterate instead of the last one (results land in the pinned mirror)
+        hipLaunchKernelGGL(k_cg_restore_best, dim3(32, B), dim3(FG_BLOCK), 0, st, a.x, s->info_dev, s->info_pinned, s->cg_best, n);
+        FG_HIP_CHECK(hipStreamSynchronize(st));
+    }
     int rc = FG_OK;
     if (a.precond) {
         int used_max = 0;

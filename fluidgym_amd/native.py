@@ -6,6 +6,7 @@ current HIP stream; all arithmetic happens in ``libfluidgym_hip.so``.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -87,6 +88,9 @@ class NativeSolver:
             qz, qzt = (fpp(fd.Qz), fpp(fd.QzT)) if self.dims == 3 else (None, None)
             L.check(self.lib.fg_set_fd_preconditioner(self.handle, fpp(fd.Qx), fpp(fd.QxT), qz, qzt, fpp(fd.lower),
                                                       fpp(fd.inv), fpp(fd.cp)))
+            if fd.x_cosine_width is not None and os.environ.get("FG_FD_NO_FFT", "0") == "0":
+                # the x basis is the DCT-II basis: apply it as a fast cosine transform instead of the dense GEMM
+                L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_cosine_width))
         self.default_method = L.FG_SOLVER_FDCG if self.has_fd else L.FG_SOLVER_CG
         if allocate:
             self.allocate_fields()

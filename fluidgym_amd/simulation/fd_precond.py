@@ -49,6 +49,25 @@ def axis_operator(h: np.ndarray, fixed: bool) -> np.ndarray:
     return T
 
 
+def cosine_basis(n: int, h: float):
+    """Eigenpairs of a FIXED axis with uniform width ``h``, in DCT order: ``Q[i, k] = s_k cos(pi (i + 1/2) k / n) /
+    sqrt(h)`` (orthonormal DCT-II basis; ``Q^T H Q = I``) and ``lam_k = -(2 - 2 cos(pi k / n)) / h^2``.  Same subspace
+    decomposition as :func:`generalized_eig` gives (tests/test_abi_and_host.py), but in an order and sign the device
+    can apply as a fast cosine transform (``csrc/fg_fdfft.hip``)."""
+    i = np.arange(n)[:, None]
+    k = np.arange(n)[None, :]
+    s = np.full(n, np.sqrt(2.0 / n))
+    s[0] = np.sqrt(1.0 / n)
+    Q = s[None, :] * np.cos(np.pi * (i + 0.5) * k / n) / np.sqrt(h)
+    lam = -(2.0 - 2.0 * np.cos(np.pi * np.arange(n) / n)) / (h * h)
+    return Q, lam
+
+
+def is_uniform(h: np.ndarray, rtol: float = 1e-6) -> bool:
+    h = np.asarray(h, dtype=np.float64)
+    return bool(np.abs(h - h[0]).max() <= rtol * abs(h[0]))
+
+
 def generalized_eig(T: np.ndarray, h: np.ndarray):
     """``T Q = H Q Lambda`` with ``Q^T H Q = I`` via the symmetric standard problem
     ``H^-1/2 T H^-1/2``; returns ``Q [n,n]`` (columns = modes) and ``lam [n]`` (<= 0)."""
@@ -70,7 +89,13 @@ class FDPreconditioner:
         h = [np.asarray(w, dtype=np.float64) for w in widths]
         nx, ny = len(h[0]), len(h[1])
         nz = len(h[2]) if d == 3 else 1
-        Qx, lx = generalized_eig(axis_operator(h[0], fixed_axis[0]), h[0])
+        # uniform FIXED x axis of a power-of-two length: cosine basis in DCT order, the device applies it as an FFT
+        self.x_cosine_width: Optional[float] = None
+        if fixed_axis[0] and is_uniform(h[0]) and nx in (64, 128, 256, 512):
+            self.x_cosine_width = float(np.float32(widths[0][0]))
+            Qx, lx = cosine_basis(nx, float(h[0][0]))
+        else:
+            Qx, lx = generalized_eig(axis_operator(h[0], fixed_axis[0]), h[0])
         if d == 3:
             Qz, lz = generalized_eig(axis_operator(h[2], fixed_axis[2]), h[2])
         else:

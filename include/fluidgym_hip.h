@@ -119,6 +119,11 @@ int fg_set_scalar_viscosity(fg_handle h, int channel, float viscosity);
 int fg_set_fd_preconditioner(fg_handle h, const float* Qx_host, const float* QxT_host, const float* Qz_host,
                              const float* QzT_host, const float* lower_host, const float* inv_host,
                              const float* cp_host);
+/* Marks the x axis as a cosine-transform axis: uniform cell width `cell_width`, FIXED faces, nx in {64, 128, 256, 512}.
+ * The caller must have passed the orthonormal DCT-II basis / sqrt(cell_width) (modes in DCT order) as Qx to
+ * fg_set_fd_preconditioner; the library then applies it as one FFT per row (csrc/fg_fdfft.hip) instead of a dense
+ * GEMM.  Returns FG_ERR_UNSUPPORTED for other lengths / axes (the GEMM path stays in place). */
+int fg_set_fd_fast_transform(fg_handle h, int axis, float cell_width);
 
 /* ---- reductions used by the drivers --------------------------------------------------------- */
 /* Domain.getMaxVelocity(withBounds=True, computational=True) (domain_structs.cpp:1580-1611) */

@@ -399,3 +399,54 @@ def test_live_profiler_samples_solver_kernels():
         per_launch = r["bytes"] / r["samples"]
         assert 0 < per_launch <= 3 * 2 * n * 28.0 + 1
     ns.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,n", [(2, (64, 12)), (2, (256, 16)), (2, (512, 6)), (3, (128, 8, 6))])
+def test_fd_preconditioner_fast_cosine_transform(dims, n):
+    """Uniform FIXED x axis of length 64..512: the eigenbasis is the DCT-II basis and the device applies it as an FFT per
+    row (fg_fdfft.hip).  One PCG iteration with rA = const returns M^-1 r exactly: compare with the NumPy application of
+    the same factors, and a solve with variable rA with the direct solution."""
+    from fluidgym_amd.simulation.fd_precond import FDPreconditioner, axis_operator, cosine_basis, generalized_eig
+
+    case = make_case(dims=dims, n=n, fixed_axes=(0, 1), B=2, seed=8, stretch=0.0)
+    fd = FDPreconditioner(case.widths, case.fixed_faces)
+    assert fd.x_cosine_width is not None
+    # the cosine basis spans the eigenspaces numpy finds (eigh returns them ascending = reversed DCT order)
+    h = np.asarray(case.widths[0], np.float64)
+    Q, lam = generalized_eig(axis_operator(h, True), h)
+    Qc, lamc = cosine_basis(len(h), float(h[0]))
+    assert np.allclose(lam[::-1], lamc, rtol=1e-9, atol=1e-9 * np.abs(lamc).max())
+    assert np.allclose(np.abs((Q[:, ::-1] * h[:, None] * Qc).sum(axis=0)), 1.0, atol=1e-6)
+    ns = case.native()
+    rng = np.random.default_rng(0)
+    r = rng.standard_normal((case.B,) + case.shape).astype(np.float32)
+    r -= r.mean(axis=tuple(range(1, r.ndim)), keepdims=True)
+    rA = np.full_like(r, 0.5)
+    x = torch.zeros_like(torch.from_numpy(r)).cuda()
+    info = ns.poisson_fdcg(torch.from_numpy(rA).cuda(), torch.from_numpy(r).cuda(), x, tol=1e-6)
+    torch.cuda.synchronize()
+    for b in range(case.B):
+        assert info[b].used_iterations <= 1
+        z = fd.apply(r[b].astype(np.float64)) / 0.5
+        got = _np(x[b])
+        assert rel_err(got - got.mean(), z - z.mean()) < 2e-5
+    if dims == 2 and n[0] <= 256:   # variable coefficient: full solve against the direct solution
+        g = case.grid()
+        rA2 = rng.uniform(0.6, 1.4, size=r.shape).astype(np.float32)
+        x2 = torch.zeros_like(x)
+        # 1e-7 is below what fp32 CG can reach on the 256 x 16 grid: the recurrence stagnates near 1e-6 and then
+        # drifts away.  The solve must come back unconverged WITH ITS BEST ITERATE (returnBestResult,
+        # cg_solver_kernel.cu:345-361), not with the last one.
+        info = ns.poisson_fdcg(torch.from_numpy(rA2).cuda(), torch.from_numpy(r).cuda(), x2, tol=1e-7, max_iterations=60)
+        torch.cuda.synchronize()
+        for b in range(case.B):
+            assert info[b].final_residual < 1e-5 and info[b].is_finite
+            assert info[b].converged or n[0] == 256
+            P = _oracle_poisson(case, g, rA2[b].astype(np.float64))
+            ref = O.solve_direct(P, r[b].astype(np.float64).ravel(), singular=True).reshape(case.shape)
+            got = _np(x2[b])
+            assert rel_err(got - got.mean(), ref - ref.mean()) < 1e-4
+            res = r[b].astype(np.float64).ravel() - P @ got.astype(np.float64).ravel()
+            assert np.sqrt((res ** 2).mean()) < 1e-4   # true residual of what came back (fp32 x under the fp64 oracle matrix; the last iterate would give ~1)
+    ns.close()
