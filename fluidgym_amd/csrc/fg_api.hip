@@ -107,9 +107,10 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(float) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
+    s->cg_return_best = 1;
     FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 8 * 64));
-    FG_HIP_CHECK(hipMalloc(&s->cg_best.best_crit, sizeof(float) * g.B * 2));
+    FG_HIP_CHECK(hipMalloc(&s->cg_best.best_crit, sizeof(float) * g.B));
     FG_HIP_CHECK(hipMalloc(&s->cg_best.saved_crit, sizeof(float) * g.B));
     FG_HIP_CHECK(hipMalloc(&s->cg_best.save_at, sizeof(int32_t) * g.B));
     FG_HIP_CHECK(alloc(&s->cg_best.best_x, BN));
@@ -187,6 +188,12 @@ extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const floa
     FG_HIP_CHECK(up(&s->fd_inv, inv, nx * ny * nz));
     FG_HIP_CHECK(up(&s->fd_cp, cp, nx * ny * nz));
     s->fd_dct_x = 0;  // fg_set_fd_fast_transform marks the axis again for the new basis
+    return FG_OK;
+}
+
+extern "C" int fg_set_return_best(fg_handle s, int on) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    s->cg_return_best = on ? 1 : 0;
     return FG_OK;
 }
 

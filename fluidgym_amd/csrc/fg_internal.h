@@ -313,16 +313,28 @@ struct FgProf {
 #define FG_ACC_DOUBLES 16  // reduction accumulators per linear system (see solver kernels)
 
 // Best-iterate tracking (the reference's returnBestResult, cg_solver_kernel.cu:345-361): whenever the RMS residual of
-// iterate x_it is the lowest so far (it >= 1), the kernel that is about to overwrite x (k_cg_update of iteration it,
-// which derives that residual from the accumulators like every other scalar) writes the old x to best_x -- no extra read, one extra store per cell for the envs concerned.  A solve that ends
-// unconverged (max iterations, or fp32 stagnation followed by divergence) gets its best iterate back.
+// iterate x_it is less than half that of the last kept iterate (it >= 1), the kernel that is about to overwrite x
+// (k_cg_update of iteration it) writes the old x to best_x -- no extra read, one extra store per cell for the envs concerned.  A solve that ends
+// unconverged (max iterations, or fp32 stagnation followed by divergence) gets the kept iterate back (within 2x of the lowest residual reached).
 struct FgBest {
-    float* best_crit;   // [B][2] lowest residual seen so far, ring by iteration parity (readers and the writer of one
-                        //        launch use different entries)
+    float* best_crit;   // [B] residual of the last kept iterate (leader-only state)
     float* saved_crit;  // [B] residual of the iterate held in best_x (+inf: none)
-    int32_t* save_at;   // unused slot kept for layout stability
+    int32_t* save_at;   // [B] iteration whose k_cg_update stores x before updating it
     float* best_x;      // [B, N]
 };
+#ifdef __HIPCC__
+// Called by the ONE leader thread of the stencil kernel of iteration `it`, which has just derived crit = RMS residual of
+// x_it: keep x_it when it beats the last kept iterate by a factor of two (a healthy solve then pays one extra store pass
+// every few iterations, not every iteration -- at 256^3 the every-improvement rule cost 11 % of the CG iteration -- and a
+// failed solve gets back an iterate within 2x of the lowest residual it reached).
+__device__ __forceinline__ void fg_best_decide(const FgBest& best, int b, float crit, int it) {
+    if (it >= 1 && crit < 0.5f * best.best_crit[b]) {
+        best.best_crit[b] = crit;
+        best.saved_crit[b] = crit;
+        best.save_at[b] = it;
+    }
+}
+#endif
 
 struct fg_state {
     fg_config cfg;
@@ -361,6 +373,7 @@ struct fg_state {
     FgProf prof;
     double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
     FgBest cg_best;               // best-iterate tracking of the CG (returnBestResult, cg_solver_kernel.cu:345-361)
+    int cg_return_best;           // 1 (default): track; 0: never keep an iterate (fg_set_return_best)
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs

@@ -191,8 +191,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
                                                      float* __restrict__ pout_, float* __restrict__ Ap_,
                                                      double* __restrict__ acc, int32_t* __restrict__ flags,
                                                      fg_solve_info* __restrict__ info, int32_t* __restrict__ prof_active,
-                                                     float tol, int it, int first, int ns, int num_base, int tiles_x,
-                                                     int tiles_y, int tiles) {
+                                                     FgBest best, float tol, int it, int first, int ns, int num_base,
+                                                     int tiles_x, int tiles_y, int tiles) {
     // z_ = preconditioned residual (= r when num_base == 0); beta = num_it / num_{it-1} with the numerator
     // ring num_base (0: r.r, 5: r.z).  Convergence is always judged on the r.r ring (RMS residual).
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
             info[c.b].final_residual = crit;
             info[c.b].used_iterations = it - 1;
             if (prof_active) atomicAdd(prof_active, 1);
+            fg_best_decide(best, c.b, crit, it);
         }
     }
     const float beta = first ? 0.f : (float)(num_new / num_old);
@@ -270,19 +271,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flags[c.b] != 0) return;
     const double rr = fg_acc_total(fg_acc_ptr(acc, c.b, num_base + it % 3), ns);  // r.r or r.z
-    // best-iterate tracking (FgBest): x on entry is x_it with RMS residual crit_it; keep it if it is the best so far
-    const float crit_it = fg_rms(num_base ? fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns) : rr, g.n);
-    const float best_prev = best.best_crit[c.b * 2 + ((it + 1) & 1)];
-    const bool save = (it >= 1) && (crit_it < best_prev);
+    // best-iterate tracking (FgBest): the leader of k_cg_ap decided whether x_it (x on entry) is worth keeping
+    const bool save = best.save_at[c.b] == it;
     const double pAp = fg_acc_total(fg_acc_ptr(acc, c.b, 3 + (it & 1)), ns);
     const float alpha = (float)(rr / pAp);
     const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
     if (tile == 0 && threadIdx.x < 64) {
         fg_acc_zero(fg_acc_ptr(acc, c.b, 3 + ((it + 1) & 1)), ns);  // next pAp
-        if (threadIdx.x == 0) {
-            best.best_crit[c.b * 2 + (it & 1)] = save ? crit_it : best_prev;
-            if (save) best.saved_crit[c.b] = crit_it;
-        }
     }
     __shared__ float lds[4];
     const size_t base = (size_t)c.b * g.n;
@@ -333,15 +328,17 @@ __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags
 }
 
 __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ acc, int32_t* __restrict__ flags,
-                           fg_solve_info* __restrict__ info, double* __restrict__ mean_sums, FgBest best, int B) {
+                           fg_solve_info* __restrict__ info, double* __restrict__ mean_sums, FgBest best, int track_best,
+                           int B) {
     const int b = blockIdx.x;
     if (b >= B) return;
     for (int q = threadIdx.x; q < FG_CG_NAMES * FG_CG_SLOTS; q += blockDim.x)
         acc[(size_t)b * FG_CG_NAMES * FG_CG_SLOTS + q] = 0.0;
     if (threadIdx.x != 0) return;
     mean_sums[b] = 0.0;  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
-    best.best_crit[b * 2] = best.best_crit[b * 2 + 1] = INFINITY;
+    best.best_crit[b] = track_best ? INFINITY : 0.f;  // 0: no residual ever beats it, nothing is kept
     best.saved_crit[b] = INFINITY;
+    best.save_at[b] = -1;
     const bool active = (dt == nullptr) || (dt[b] > 0.f);
     flags[b] = active ? 0 : 3;
     info[b].final_residual = 0.f;
@@ -423,7 +420,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const bool zmarch = fg_zmarch_ok(s, &zc);
     int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
     while (ns < FG_CG_SLOTS && tiles_per_env / ns > 256) ns *= 2;
-    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, s->cg_best, B);
+    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, s->cg_best, s->cg_return_best, B);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,
@@ -471,8 +468,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
                 FG_LAUNCH_P(s, slot_ap, (k_cg_ap<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, zvec, p_in,
                             p_out, a.Ap, s->cg_acc, s->flags, s->info_dev,
-                            slot_ap >= 0 ? s->prof.active_dev + slot_ap : nullptr, a.tol, it, first, ns, nb,
-                            L.tiles_x, L.tiles_y, L.tiles);
+                            slot_ap >= 0 ? s->prof.active_dev + slot_ap : nullptr, s->cg_best, a.tol, it, first, ns,
+                            nb, L.tiles_x, L.tiles_y, L.tiles);
             });
         }
         const int slot_up = fg_prof_slot(s, FG_PK_CG_UPDATE, s->flags, B, (double)n * 24.0, (double)n * 6.0, st);

@@ -163,7 +163,7 @@ struct Z3Args {
     float* y2;            // cg_ap: Ap
     float omega; int color;           // relax (color < 0: Jacobi)
     // cg_ap
-    double* acc; int32_t* flags; fg_solve_info* info; int32_t* prof_active;
+    double* acc; int32_t* flags; fg_solve_info* info; int32_t* prof_active; FgBest best;
     float tol; int it; int first; int ns; int num_base;
 };
 
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
                 a.info[c.b].final_residual = crit;
                 a.info[c.b].used_iterations = a.it - 1;
                 if (a.prof_active) atomicAdd(a.prof_active, 1);
+                fg_best_decide(a.best, c.b, crit, a.it);
             }
         }
         beta = a.first ? 0.f : (float)(num_new / num_old);
@@ -471,6 +472,7 @@ int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const fl
     Z3Args a = {};
     a.rA = rA; a.x = z; a.x2 = p_in; a.y = p_out; a.y2 = Ap;
     a.acc = acc; a.flags = flags; a.info = info; a.prof_active = prof_slot >= 0 ? s->prof.active_dev + prof_slot : nullptr;
+    a.best = s->cg_best;
     a.tol = tol; a.it = it; a.first = first; a.ns = ns; a.num_base = num_base;
     return launch_march<MODE_CG_AP>(s, a, zc, st, prof_slot);
 }

@@ -320,6 +320,10 @@ class NativeSolver:
         L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
         return list(info)
 
+    def set_return_best(self, on: bool = True):
+        """``pressure_return_best_result`` of the reference's Simulation: keep / hand back the best CG iterate."""
+        L.check(self.lib.fg_set_return_best(self.handle, int(on)))
+
     def profile_enable(self, on: bool = True):
         L.check(self.lib.fg_profile_enable(self.handle, int(on)))
 

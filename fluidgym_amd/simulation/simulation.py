@@ -111,6 +111,8 @@ class Simulation:
         self.flux_balance_tol = float(flux_balance_tol)
         self.linear_solve_max_iterations = 5000  # PISOtorch_simulation.py:564
         self.pressure_return_best_result = pressure_return_best_result
+        # returnBestResult of the pressure solve (PISOtorch_simulation.py:1913): the native CG keeps / restores it
+        domain.solver.set_return_best(bool(pressure_return_best_result))
         self.advect_passive_scalar = advect_passive_scalar
         self.non_orthogonal = non_orthogonal  # identical results on orthogonal grids
         self.buoyancy = buoyancy  # (axis, factor): native form of the RBC PRE_VELOCITY_SETUP hook

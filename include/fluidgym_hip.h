@@ -124,6 +124,10 @@ int fg_set_fd_preconditioner(fg_handle h, const float* Qx_host, const float* QxT
  * fg_set_fd_preconditioner; the library then applies it as one FFT per row (csrc/fg_fdfft.hip) instead of a dense
  * GEMM.  Returns FG_ERR_UNSUPPORTED for other lengths / axes (the GEMM path stays in place). */
 int fg_set_fd_fast_transform(fg_handle h, int axis, float cell_width);
+/* returnBestResult of the pressure CG (SolveLinear(..., returnBestResult), cg_solver_kernel.cu:345-361): on (default), a
+ * solve that ends unconverged hands back the best iterate it kept (within 2x of the lowest residual reached) instead
+ * of the last one; off saves the occasional extra store pass over x. */
+int fg_set_return_best(fg_handle h, int on);
 
 /* ---- reductions used by the drivers --------------------------------------------------------- */
 /* Domain.getMaxVelocity(withBounds=True, computational=True) (domain_structs.cpp:1580-1611) */
