@@ -69,6 +69,22 @@ class FgStepOptions(Structure):
     ]
 
 
+class FgMbStepOptions(Structure):
+    _fields_ = [
+        ("corrector_steps", c_int32),
+        ("advect_non_ortho_steps", c_int32),
+        ("pressure_non_ortho_steps", c_int32),
+        ("max_iterations", c_int32),
+        ("advection_tol", c_float),
+        ("pressure_tol", c_float),
+        ("pressure_use_bicgstab", c_int32),
+    ]
+
+
+(FG_MB_BUF_A, FG_MB_BUF_C_OFF, FG_MB_BUF_RHS, FG_MB_BUF_H, FG_MB_BUF_DIV, FG_MB_BUF_P_DIAG, FG_MB_BUF_P_OFF,
+ FG_MB_BUF_VELOCITY_RESULT) = range(8)
+
+
 class FgSimOptions(Structure):
     _fields_ = [
         ("step", FgStepOptions),
@@ -134,6 +150,22 @@ SIGNATURES = {
                                     POINTER(ctypes.c_float), c_int, c_int, POINTER(c_void_p)]),
     "fg_resampler_destroy": (c_int, [c_void_p]),
     "fg_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "fg_mb_create": (c_int, [c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "fg_mb_destroy": (c_int, [c_void_p]),
+    "fg_mb_add_block": (c_int, [c_void_p, POINTER(c_float), c_int32, c_int32, c_int32, POINTER(c_int32)]),
+    "fg_mb_connect": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "fg_mb_make_periodic": (c_int, [c_void_p, c_int32, c_int32]),
+    "fg_mb_set_reference_quirks": (c_int, [c_void_p, c_int32, c_int32]),
+    "fg_mb_finalize": (c_int, [c_void_p]),
+    "fg_mb_sizes": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
+    "fg_mb_block_info": (c_int, [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    "fg_mb_get_neighbors": (c_int, [c_void_p, POINTER(c_int32)]),
+    "fg_mb_bind": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fg_mb_set_viscosity": (c_int, [c_void_p, c_float]),
+    "fg_mb_piso_step": (c_int, [c_void_p, c_void_p, POINTER(FgMbStepOptions), POINTER(c_int32), c_void_p]),
+    "fg_mb_max_velocity": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
+    "fg_mb_get_buffer": (c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64)]),
+    "fg_mb_read_buffer": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,94 @@
+// Multi-block, non-orthogonal PISO path: state shared by fg_mb_topo.hip (host-side
+// topology / coefficient tables, built once per mesh) and fg_mb_step.hip (kernels + solvers).
+//
+// The reference resolves block connections, corner walks and metric interpolation inside every kernel for every cell
+// on every call (PISO_multiblock_cuda_kernel.cu:329-492, 1926-2001, 2757-2874).  All of that depends on the mesh only,
+// and one mesh serves the whole env batch, so here it is done ONCE on the host at fg_mb_finalize and the kernels read
+// flat tables that are shared by all envs of the batch (they stay in L2 while the per-env fields stream from HBM):
+//   nbr[f][i]          neighbour cell across face f (global index), or -1 - slot for a prescribed (FIXED) face
+//   fcode[f][i]        which contravariant component of the neighbour continues this face's flux, and its sign
+//   T[i]               Minv (row major) | det of the cell;  Tb[slot] the same for a boundary face
+//   Vdiag, Voff        viscous part of the advection-diffusion matrix for nu = 1 (orthogonal + centre/direct cross terms)
+//   KPp, KPn           pressure matrix entries as (coefficient of 1/A_P, coefficient of 1/A_N(f)) per slot and face
+//   SV*, SP*           lagged corner terms of velocity / pressure as ELL operators on cells and boundary slots
+#pragma once
+#include <vector>
+
+#include "fg_internal.h"
+
+#define FG_MB_FIXED 0
+#define FG_MB_CONNECTED 1
+#define FG_MB_PERIODIC 2
+
+struct MbBound {
+    int type = FG_MB_FIXED;
+    int other = -1;
+    int axes[3] = {0, 0, 0};
+    int slot0 = -1;  // first boundary slot of a FIXED face (slots run over the face cells, lowest axis fastest)
+};
+
+struct MbBlock {
+    int size[3] = {1, 1, 1};
+    int offset = 0;
+    int ncells = 0;
+    std::vector<double> coords;  // [d][(nz+1)][ny+1][nx+1]
+    MbBound bounds[6];
+    std::vector<double> Minv;    // [ncells][d*d]
+    std::vector<double> det;     // [ncells]
+};
+
+// device view handed to kernels by value
+struct MbDev {
+    int d, F, N, NB, B;
+    int KC, KB, KPN;                // ELL widths: velocity corner terms over cells / boundary slots, pressure corner terms
+    const int32_t* nbr;             // [F][N]
+    const int32_t* fcode;           // [F][N]  (axis of the neighbour's component) | (negate << 2)
+    const float* T;                 // [N][d*d+1]
+    const float* Tb;                // [NB][d*d+1]
+    const int32_t* bcell;           // [NB] owner cell
+    const int32_t* bface;           // [NB] face of the owner cell
+    const float* Vdiag;             // [N]
+    const float* Voff;              // [F][N]
+    const float* KPp;               // [(F+1)][F][N]   slot 0 = diagonal, slot 1+g = face g
+    const float* KPn;               // [(F+1)][F][N]
+    const int32_t* SVc_idx;         // [KC][N]
+    const float* SVc_w;             // [KC][N]
+    const int32_t* SVb_idx;         // [KB][N]
+    const float* SVb_w;             // [KB][N]
+    const int32_t* SP_idx;          // [KPN][N]
+    const int32_t* SP_face;         // [KPN][N]
+    const float* SP_wp;             // [KPN][N]
+    const float* SP_wn;             // [KPN][N]
+};
+
+struct fg_mb_state {
+    int d = 2, B = 1, N = 0, NB = 0, F = 4;
+    float nu = 0.f;
+    int quirk_diag_offset = 1;  // computeConnectedPos(..., borderOffset = 1) on diagonal walks (K.cu:2152, 2658, 2825)
+    int quirk_first_layer = 1;  // K.cu:1952
+    bool finalized = false;
+    std::vector<MbBlock> blocks;
+    // host copies of the tables (also exported for tests)
+    std::vector<int32_t> h_nbr, h_fcode, h_bcell, h_bface;
+    std::vector<float> h_T, h_Tb;
+    MbDev dev{};
+    std::vector<void*> owned;  // device allocations
+    // bound fields (caller-owned device memory)
+    float* velocity = nullptr;   // [B][d][N]
+    float* pressure = nullptr;   // [B][N]   pressure of the last solve (lagged corner terms read it)
+    float* bvel = nullptr;       // [B][d][NB]
+    const float* source = nullptr;  // [B][d][N] or null
+    // work buffers
+    float *cc, *fb, *Cdiag, *Coff, *rA, *rhs, *ures, *hvec, *div, *Pdiag, *Poff, *pres;
+    float* w[6];
+    double* acc;
+    float* sc;
+    int32_t *flags, *best_it;
+    int32_t* flags_pinned = nullptr;
+    fg_solve_info *info_dev, *info_pinned = nullptr;
+    float* red;        // [B] reductions (mean, max)
+    float* red_pinned = nullptr;
+    std::string err;
+};
+
+int fg_mb_build_tables(fg_mb_state* s);  // fg_mb_topo.hip

@@ -1,0 +1,955 @@
+// Multi-block, non-orthogonal PISO step on gfx950: assembly kernels, ELL Krylov solvers and the C ABI (fg_mb_*).
+//
+// One thread per (env, cell); the env batch is the slow grid axis, so consecutive lanes read consecutive cells of one
+// env's fields (coalesced) while the mesh tables (fg_mb.h) are shared by all envs and stay cached.  Replaces, for
+// meshes with connected blocks and cross metrics, the same reference calls as the single-block path:
+//   PISO_build_matrix (K.cu:3616-3880), kPISO_build_advection_RHS (:4296-4400), PISO_build_pressure_matrix (:4812-4978),
+//   PISO_build_pressure_rhs (:5136-5255), k_computePressureRHSdivergenceFromFlux (:5389-5434),
+//   k_pressureRHSaddNonOrthoComponents (:5471-5493), PISO_update_velocity (:5962-5995),
+//   bicgstabSolveGPU / cgSolveGPU (bicgstab_solver_kernel.cu:63-411, cg_solver_kernel.cu:129-471),
+// driven in the order of _PISO_split_step's non-orthogonal branch (PISOtorch_simulation.py:1707-1972).
+// "K.cu" = extensions/PISO_multiblock_cuda_kernel.cu.
+#include <math.h>
+
+#include <algorithm>
+
+#include "fg_mb.h"
+
+namespace {
+
+constexpr int MB_ACC = 8;  // doubles per system
+constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6, A_PAP = 7;
+
+#define MB_CELL                                         \
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x;  \
+    const int b = blockIdx.y;                           \
+    const int N = D.N;                                  \
+    const bool valid = i < N;
+
+__device__ __forceinline__ bool mb_active(const float* dt, int b) { return dt == nullptr || dt[b] > 0.f; }
+
+template <int DIMS>
+__device__ __forceinline__ void mb_load_T(const float* __restrict__ T, int i, float (&mi)[DIMS * DIMS], float& det) {
+    const float* t = T + (size_t)i * (DIMS * DIMS + 1);
+#pragma unroll
+    for (int q = 0; q < DIMS * DIMS; ++q) mi[q] = t[q];
+    det = t[DIMS * DIMS];
+}
+
+// contravariant components det * Minv u of the cells, and of the boundary faces along their own axis
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_contra(MbDev D, const float* __restrict__ dt, const float* __restrict__ u,
+                                                         const float* __restrict__ ub, float* __restrict__ cc,
+                                                         float* __restrict__ fb) {
+    MB_CELL
+    if (!mb_active(dt, b)) return;
+    if (valid) {
+        float mi[DIMS * DIMS], det;
+        mb_load_T<DIMS>(D.T, i, mi, det);
+        float v[DIMS];
+#pragma unroll
+        for (int c = 0; c < DIMS; ++c) v[c] = u[((size_t)b * DIMS + c) * N + i];
+#pragma unroll
+        for (int a = 0; a < DIMS; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DIMS; ++c) s += mi[a * DIMS + c] * v[c];
+            cc[((size_t)b * DIMS + a) * N + i] = det * s;
+        }
+    }
+    if (fb != nullptr && i < D.NB) {
+        float mi[DIMS * DIMS], det;
+        mb_load_T<DIMS>(D.Tb, i, mi, det);
+        const int axis = D.bface[i] >> 1;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DIMS; ++c) s += mi[axis * DIMS + c] * ub[((size_t)b * DIMS + c) * D.NB + i];
+        fb[(size_t)b * D.NB + i] = det * s;
+    }
+}
+
+// face flux, not multiplied by the face sign (computeFluxesNDLoop, K.cu:1568-1645)
+template <int DIMS>
+__device__ __forceinline__ float mb_flux(const MbDev& D, const float* __restrict__ cc_b, const float* __restrict__ fb_b,
+                                         int f, int i) {
+    const int n = D.nbr[(size_t)f * D.N + i];
+    if (n < 0) return fb_b[-1 - n];
+    const int code = D.fcode[(size_t)f * D.N + i];
+    const float vn = cc_b[(size_t)(code & 3) * D.N + n];
+    return 0.5f * (((code & 4) ? -vn : vn) + cc_b[(size_t)(f >> 1) * D.N + i]);
+}
+
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_matrix(MbDev D, const float* __restrict__ dt, float nu,
+                                                         const float* __restrict__ cc, const float* __restrict__ fb,
+                                                         float* __restrict__ Cdiag, float* __restrict__ Coff,
+                                                         float* __restrict__ rA) {
+    MB_CELL
+    if (!valid || !mb_active(dt, b)) return;
+    constexpr int F = 2 * DIMS;
+    const float det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
+    const float* cc_b = cc + (size_t)b * DIMS * N;
+    const float* fb_b = fb + (size_t)b * D.NB;
+    float diag = det / dt[b] + nu * D.Vdiag[i];
+    const float rdet = 1.f / det;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float o = 0.f;
+        if (D.nbr[(size_t)f * N + i] >= 0) {
+            const float ff = ((f & 1) ? 0.5f : -0.5f) * mb_flux<DIMS>(D, cc_b, fb_b, f, i);
+            diag += ff;
+            o = (ff + nu * D.Voff[(size_t)f * N + i]) * rdet;
+        }
+        Coff[((size_t)b * F + f) * N + i] = o;
+    }
+    diag *= rdet;
+    Cdiag[(size_t)b * N + i] = diag;
+    rA[(size_t)b * N + i] = 1.f / diag;
+}
+
+// boundary sources of one cell and component: -u_b flux_b n + 2 nu alpha_b u_b over its prescribed faces
+template <int DIMS>
+__device__ __forceinline__ float mb_boundary_source(const MbDev& D, const float* __restrict__ ub_c,
+                                                    const float* __restrict__ fb_b, float nu, int i) {
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < 2 * DIMS; ++f) {
+        const int n = D.nbr[(size_t)f * D.N + i];
+        if (n >= 0) continue;
+        const int k = -1 - n;
+        const float* t = D.Tb + (size_t)k * (DIMS * DIMS + 1);
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < DIMS; ++q) a += t[(f >> 1) * DIMS + q] * t[(f >> 1) * DIMS + q];
+        a *= t[DIMS * DIMS];
+        const float vel = ub_c[k];
+        s += vel * (2.f * nu * a - ((f & 1) ? fb_b[k] : -fb_b[k]));
+    }
+    return s;
+}
+
+// velocity right-hand side (kPISO_build_advection_RHS): grid.z = component
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_vrhs(MbDev D, const float* __restrict__ dt, float nu,
+                                                       const float* __restrict__ u_old, const float* __restrict__ u_res,
+                                                       const float* __restrict__ ub, const float* __restrict__ fb,
+                                                       const float* __restrict__ src, float* __restrict__ rhs) {
+    MB_CELL
+    if (!valid || !mb_active(dt, b)) return;
+    const int c = blockIdx.z;
+    const size_t vb = ((size_t)b * DIMS + c) * N;
+    const float* ub_c = ub + ((size_t)b * DIMS + c) * D.NB;
+    const float det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
+    float r = det * u_old[vb + i] / dt[b];
+    r += mb_boundary_source<DIMS>(D, ub_c, fb + (size_t)b * D.NB, nu, i);
+    float S = 0.f;
+    for (int k = 0; k < D.KC; ++k) S += D.SVc_w[(size_t)k * N + i] * u_res[vb + D.SVc_idx[(size_t)k * N + i]];
+    for (int k = 0; k < D.KB; ++k) S += D.SVb_w[(size_t)k * N + i] * ub_c[D.SVb_idx[(size_t)k * N + i]];
+    r -= nu * S;
+    r /= det;
+    if (src) r += src[vb + i];
+    rhs[vb + i] = r;
+}
+
+// pressure matrix from the coefficient pairs (PISO_build_pressure_matrix)
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* __restrict__ dt, const float* __restrict__ rA,
+                                                          float* __restrict__ Pdiag, float* __restrict__ Poff) {
+    MB_CELL
+    if (!valid || !mb_active(dt, b)) return;
+    constexpr int F = 2 * DIMS;
+    const float* ra = rA + (size_t)b * N;
+    const float rp = ra[i];
+    float rn[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int n = D.nbr[(size_t)f * N + i];
+        rn[f] = n >= 0 ? ra[n] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g <= F; ++g) {
+        float v = 0.f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const size_t q = ((size_t)g * F + f) * N + i;
+            v += D.KPp[q] * rp + D.KPn[q] * rn[f];
+        }
+        if (g == 0) Pdiag[(size_t)b * N + i] = v;
+        else Poff[((size_t)b * F + (g - 1)) * N + i] = (D.nbr[(size_t)(g - 1) * N + i] >= 0) ? v : 0.f;
+    }
+}
+
+// h = (u_old/dt - H u* + S) / A   (PISO_build_pressure_rhs): grid.z = component
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_h(MbDev D, const float* __restrict__ dt, float nu,
+                                                    const float* __restrict__ rA, const float* __restrict__ Coff,
+                                                    const float* __restrict__ u_old, const float* __restrict__ u_star,
+                                                    const float* __restrict__ ub, const float* __restrict__ fb,
+                                                    const float* __restrict__ src, float* __restrict__ h) {
+    MB_CELL
+    if (!valid || !mb_active(dt, b)) return;
+    constexpr int F = 2 * DIMS;
+    const int c = blockIdx.z;
+    const size_t vb = ((size_t)b * DIMS + c) * N;
+    const float det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
+    float H = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int n = D.nbr[(size_t)f * N + i];
+        if (n >= 0) H += Coff[((size_t)b * F + f) * N + i] * u_star[vb + n];
+    }
+    float S = mb_boundary_source<DIMS>(D, ub + ((size_t)b * DIMS + c) * D.NB, fb + (size_t)b * D.NB, nu, i) / det;
+    if (src) S += src[vb + i];
+    h[vb + i] = rA[(size_t)b * N + i] * (u_old[vb + i] / dt[b] - H + S);
+}
+
+// div of the flux of h, plus the lagged corner terms of the pressure (add_corner != 0)
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_div(MbDev D, const float* __restrict__ dt, const float* __restrict__ cc,
+                                                      const float* __restrict__ fb, const float* __restrict__ rA,
+                                                      const float* __restrict__ p, int add_corner,
+                                                      float* __restrict__ div) {
+    MB_CELL
+    if (!valid || !mb_active(dt, b)) return;
+    const float* cc_b = cc + (size_t)b * DIMS * N;
+    const float* fb_b = fb + (size_t)b * D.NB;
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < DIMS; ++a) s += mb_flux<DIMS>(D, cc_b, fb_b, 2 * a + 1, i) - mb_flux<DIMS>(D, cc_b, fb_b, 2 * a, i);
+    if (add_corner) {
+        const float* ra = rA + (size_t)b * N;
+        const float* pb = p + (size_t)b * N;
+        const float rp = ra[i];
+        for (int k = 0; k < D.KPN; ++k) {
+            const size_t q = (size_t)k * N + i;
+            const float wp = D.SP_wp[q], wn = D.SP_wn[q];
+            if (wp == 0.f && wn == 0.f) continue;
+            const int n = D.nbr[(size_t)D.SP_face[q] * N + i];
+            s += (wp * rp + wn * (n >= 0 ? ra[n] : 0.f)) * pb[D.SP_idx[q]];
+        }
+    }
+    div[(size_t)b * N + i] = s;
+}
+
+// u = h - (1/A) Minv^T grad_xi p   (PISO_update_velocity + getPressureGradient, K.cu:816-849)
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_correct(MbDev D, const float* __restrict__ dt, const float* __restrict__ rA,
+                                                          const float* __restrict__ h, const float* __restrict__ p,
+                                                          float* __restrict__ u) {
+    MB_CELL
+    if (!valid || !mb_active(dt, b)) return;
+    const float* pb = p + (size_t)b * N;
+    float mi[DIMS * DIMS], det;
+    mb_load_T<DIMS>(D.T, i, mi, det);
+    float g[DIMS];
+#pragma unroll
+    for (int a = 0; a < DIMS; ++a) {
+        const int nl = D.nbr[(size_t)(2 * a) * N + i], nh = D.nbr[(size_t)(2 * a + 1) * N + i];
+        const float fac = (nl < 0 || nh < 0) ? 1.f : 0.5f;
+        g[a] = (pb[nh < 0 ? i : nh] - pb[nl < 0 ? i : nl]) * fac;
+    }
+    const float ra = rA[(size_t)b * N + i];
+#pragma unroll
+    for (int c = 0; c < DIMS; ++c) {
+        float gp = 0.f;
+#pragma unroll
+        for (int a = 0; a < DIMS; ++a) gp += g[a] * mi[a * DIMS + c];
+        const size_t q = ((size_t)b * DIMS + c) * N + i;
+        u[q] = h[q] - ra * gp;
+    }
+}
+
+__device__ __forceinline__ float mb_block_sum(float v, float* lds) {
+    v = fg_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return r;
+}
+
+// max |Minv u| over cells and boundary faces (Block::getMaxVelocity, domain_structs.cpp:1580-1611)
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_maxvel(MbDev D, const float* __restrict__ u, const float* __restrict__ ub,
+                                                         float* __restrict__ out) {
+    MB_CELL
+    float m = 0.f;
+    if (valid) {
+        const float* t = D.T + (size_t)i * (DIMS * DIMS + 1);
+#pragma unroll
+        for (int a = 0; a < DIMS; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DIMS; ++c) s += t[a * DIMS + c] * u[((size_t)b * DIMS + c) * N + i];
+            m = fmaxf(m, fabsf(s));
+        }
+    }
+    if (i < D.NB) {
+        const float* t = D.Tb + (size_t)i * (DIMS * DIMS + 1);
+#pragma unroll
+        for (int a = 0; a < DIMS; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DIMS; ++c) s += t[a * DIMS + c] * ub[((size_t)b * DIMS + c) * D.NB + i];
+            m = fmaxf(m, fabsf(s));
+        }
+    }
+    m = fg_wave_max(m);
+    __shared__ float lds[4];
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+        atomicMax(reinterpret_cast<int*>(out) + b, __float_as_int(m));  // non-negative floats order like ints
+    }
+}
+
+__global__ void k_mb_sum(int N, const float* __restrict__ dt, const float* __restrict__ x, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    if (!mb_active(dt, b)) return;
+    float s = 0.f;
+    for (int i = blockIdx.x * FG_BLOCK + threadIdx.x; i < N; i += gridDim.x * FG_BLOCK) s += x[(size_t)b * N + i];
+    __shared__ float lds[4];
+    s = mb_block_sum(s, lds);
+    if (threadIdx.x == 0) atomicAdd(out + b, s);
+}
+__global__ void k_mb_sub_mean(int N, const float* __restrict__ dt, const float* __restrict__ sum, float* __restrict__ x,
+                              float* __restrict__ copy) {
+    const int b = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (i >= N || !mb_active(dt, b)) return;
+    const float v = x[(size_t)b * N + i] - sum[b] / (float)N;
+    x[(size_t)b * N + i] = v;
+    if (copy) copy[(size_t)b * N + i] = v;
+}
+__global__ void k_mb_copy(size_t per_env, const float* __restrict__ dt, const float* __restrict__ src, float* __restrict__ dst) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (i >= per_env || !mb_active(dt, b)) return;
+    dst[(size_t)b * per_env + i] = src[(size_t)b * per_env + i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Krylov solvers on the ELL matrix (diag [B][N], off [B][F][N], shared neighbour table).  System sys = b * nc + comp
+// is blockIdx.y; the scalars of the recurrences live in device accumulators (fp64) exactly as in the single-block
+// solvers (fg_bicgstab.hip, fg_poisson.hip), so the host only polls convergence.
+// ---------------------------------------------------------------------------------------------------------------
+struct MbSolve {
+    const float* diag; const float* off; const float* rhs;
+    float* x; float* r; float* rw; float* p; float* v; float* t;
+    double* acc; float* sc; int32_t* flags; fg_solve_info* info;
+    int nc; float tol;
+    // best-iterate tracking of the CG pressure solve (returnBestResult, cg_solver_kernel.cu:345-361): sc[2 sys] holds the
+    // residual of the kept iterate, best_it the iteration it belongs to, best_x the iterate itself
+    float* best_x; int32_t* best_it; int stall_limit;
+};
+
+template <int DIMS>
+__device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b, const float* __restrict__ x, int i) {
+    constexpr int F = 2 * DIMS;
+    float y = q.diag[(size_t)b * D.N + i] * x[i];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int n = D.nbr[(size_t)f * D.N + i];
+        if (n >= 0) y += q.off[((size_t)b * F + f) * D.N + i] * x[n];
+    }
+    return y;
+}
+
+#define MB_SYS                                          \
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x;  \
+    const int sys = blockIdx.y;                         \
+    const int b = sys / q.nc;                           \
+    const int N = D.N;                                  \
+    const bool valid = i < N;                           \
+    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0); \
+    const size_t vb = (size_t)sys * N;                  \
+    double* a = q.acc + (size_t)sys * MB_ACC;           \
+    __shared__ float lds[4];                            \
+    (void)b; (void)leader; (void)a; (void)lds; (void)valid;
+
+__device__ __forceinline__ float mb_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
+__device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, float crit, int it) {
+    const bool finite = isfinite(crit);
+    q.flags[sys] = finite ? 1 : 2;
+    q.info[sys].final_residual = crit;
+    q.info[sys].used_iterations = it;
+    q.info[sys].converged = finite ? 1 : 0;
+    q.info[sys].is_finite = finite ? 1 : 0;
+}
+
+__global__ void k_mbs_begin(const float* __restrict__ dt, MbSolve q, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    for (int k = 0; k < MB_ACC; ++k) q.acc[(size_t)s * MB_ACC + k] = 0.0;
+    q.sc[s * 2] = 1.f; q.sc[s * 2 + 1] = 1.f;
+    const bool active = mb_active(dt, s / q.nc);
+    q.flags[s] = active ? 0 : 3;
+    q.info[s].final_residual = 0.f;
+    q.info[s].used_iterations = -1;
+    q.info[s].converged = active ? 0 : 1;
+    q.info[s].is_finite = 1;
+}
+
+// r = rhs - M x0 (x0 = 0 unless use_x0); rw = p = r; rho0 = rr = r.r
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int use_x0) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    float r = 0.f;
+    if (valid) {
+        r = q.rhs[vb + i];
+        if (use_x0) r -= mb_spmv<DIMS>(D, q, b, q.x + vb, i);
+        else q.x[vb + i] = 0.f;
+        q.r[vb + i] = r;
+        if (q.rw) q.rw[vb + i] = r;
+        q.p[vb + i] = r;
+    }
+    const float s = mb_block_sum(r * r, lds);
+    if (threadIdx.x == 0) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
+}
+
+// ---- BiCGStab (same five-kernel recurrence as fg_bicgstab.hip)
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    const int f = q.flags[sys];
+    if (f == 4) { if (leader) q.flags[sys] = 1; return; }
+    if (f != 0) return;
+    const float crit = mb_rms(a[A_RR], N);
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it == 0 ? -1 : it); return; }
+    if (leader) {
+        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0;
+        q.info[sys].final_residual = crit;
+        q.info[sys].used_iterations = it - 1;
+    }
+    if (it == 0 || !valid) return;
+    const float alpha = q.sc[sys * 2], omega = q.sc[sys * 2 + 1];
+    const float beta = (float)(a[A_RHO + (it & 1)] / a[A_RHO + ((it + 1) & 1)]) * (alpha / omega);
+    q.p[vb + i] = q.r[vb + i] + beta * (q.p[vb + i] - omega * q.v[vb + i]);
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    float part = 0.f;
+    if (valid) {
+        const float y = mb_spmv<DIMS>(D, q, b, q.p + vb, i);
+        q.v[vb + i] = y;
+        part = q.rw[vb + i] * y;
+    }
+    part = mb_block_sum(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + A_RV, (double)part);
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_RV]);
+    if (leader) { q.sc[sys * 2] = alpha; a[A_RHO + ((it + 1) & 1)] = 0.0; a[A_RR] = 0.0; }
+    float part = 0.f;
+    if (valid) {
+        const float r = q.r[vb + i] - alpha * q.v[vb + i];
+        q.r[vb + i] = r;
+        part = r * r;
+    }
+    part = mb_block_sum(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + A_SS, (double)part);
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    const float crit_s = mb_rms(a[A_SS], N);
+    if (!(crit_s >= q.tol)) {  // converged on s (bicgstab_solver_kernel.cu:305-329): k_mbb_x applies x += alpha p
+        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) q.flags[sys] = 4; }
+        return;
+    }
+    float pt = 0.f, ptt = 0.f;
+    if (valid) {
+        const float t = mb_spmv<DIMS>(D, q, b, q.r + vb, i);
+        q.t[vb + i] = t;
+        pt = t * q.r[vb + i];
+        ptt = t * t;
+    }
+    pt = mb_block_sum(pt, lds);
+    ptt = mb_block_sum(ptt, lds);
+    if (threadIdx.x == 0) { atomicAdd(a + A_TS, (double)pt); atomicAdd(a + A_TT, (double)ptt); }
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    const int f = q.flags[sys];
+    if (f != 0 && f != 4) return;
+    const float alpha = q.sc[sys * 2];
+    const bool half = (f == 4);
+    const float omega = half ? 0.f : (float)(a[A_TS] / a[A_TT]);
+    if (leader) { q.sc[sys * 2 + 1] = omega; a[A_RV] = 0.0; }
+    float prr = 0.f, prho = 0.f;
+    if (valid) {
+        if (half) {
+            q.x[vb + i] += alpha * q.p[vb + i];
+        } else {
+            const float sv = q.r[vb + i];
+            q.x[vb + i] += alpha * q.p[vb + i] + omega * sv;
+            const float r = sv - omega * q.t[vb + i];
+            q.r[vb + i] = r;
+            prr = r * r;
+            prho = q.rw[vb + i] * r;
+        }
+    }
+    if (half) return;
+    prr = mb_block_sum(prr, lds);
+    prho = mb_block_sum(prho, lds);
+    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
+}
+
+// ---- CG (cgSolveGPU recurrence; residual r, search direction p, accumulators rr ring in A_RHO, pAp)
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    const float crit = mb_rms(a[A_RR], N);
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
+    if (leader) {
+        q.info[sys].final_residual = crit; q.info[sys].used_iterations = it; a[A_RHO + ((it + 1) & 1)] = 0.0;
+        // keep x_it when it beats the kept iterate by 2x: k_mbc_update of this iteration stores it before updating x
+        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2])) { q.sc[sys * 2] = crit; q.best_it[sys] = it; }
+    }
+    float part = 0.f;
+    if (valid) {
+        // p_it = r + beta p_{it-1} was written by k_mbc_dir; here: v = M p, pAp
+        const float y = mb_spmv<DIMS>(D, q, b, q.p + vb, i);
+        q.v[vb + i] = y;
+        part = q.p[vb + i] * y;
+    }
+    part = mb_block_sum(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + A_PAP, (double)part);
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_PAP]);
+    float part = 0.f;
+    if (valid) {
+        if (q.best_x && q.best_it[sys] == it) q.best_x[vb + i] = q.x[vb + i];
+        q.x[vb + i] += alpha * q.p[vb + i];
+        const float r = q.r[vb + i] - alpha * q.v[vb + i];
+        q.r[vb + i] = r;
+        part = r * r;
+    }
+    part = mb_block_sum(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + A_RHO + ((it + 1) & 1), (double)part);
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_dir(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    const double rr_new = a[A_RHO + ((it + 1) & 1)], rr_old = a[A_RHO + (it & 1)];
+    if (leader) { a[A_RR] = rr_new; a[A_PAP] = 0.0; }
+    if (valid) q.p[vb + i] = q.r[vb + i] + (float)(rr_new / rr_old) * q.p[vb + i];
+}
+
+__global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32_t* __restrict__ flag_mirror, int rr_slot,
+                            int it, int n, int nsys, int final_pass) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    if (q.flags[s] == 4) q.flags[s] = 1;
+    if (q.flags[s] == 0) {
+        const float crit = (float)sqrt(q.acc[(size_t)s * MB_ACC + rr_slot] / (double)n);
+        q.info[s].final_residual = crit;
+        q.info[s].used_iterations = it + 1;
+        if (!(crit >= q.tol)) {
+            const bool finite = isfinite(crit);
+            q.flags[s] = finite ? 1 : 2;
+            q.info[s].converged = finite ? 1 : 0;
+            q.info[s].is_finite = finite ? 1 : 0;
+        } else if (final_pass || (q.best_x && q.stall_limit > 0 && it - q.best_it[s] > q.stall_limit)) {
+            // out of iterations, or no iterate has halved the best residual for stall_limit iterations (the reference
+            // would run on to max_iterations and then hand back its best iterate, too)
+            q.info[s].converged = 0;
+            q.flags[s] = 1;
+        }
+    }
+    mirror[s] = q.info[s];
+    flag_mirror[s] = q.flags[s];
+}
+
+// hand back the kept iterate of the systems that ended unconverged
+__global__ void k_mbs_restore_best(int N, MbSolve q) {
+    const int sys = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (i >= N || q.info[sys].converged || q.flags[sys] == 3) return;
+    q.x[(size_t)sys * N + i] = q.best_x[(size_t)sys * N + i];
+    if (i == 0) { q.info[sys].final_residual = q.sc[sys * 2]; q.info[sys].used_iterations = q.best_it[sys]; }
+}
+
+#define MB_DISPATCH(s, ...)                    \
+    do {                                       \
+        if ((s)->d == 2) { constexpr int DIMS = 2; __VA_ARGS__ } \
+        else { constexpr int DIMS = 3; __VA_ARGS__ }            \
+    } while (0)
+
+int mb_poll(fg_mb_state* s, int nsys, hipStream_t st, bool& done) {
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    done = true;
+    for (int i = 0; i < nsys; ++i) done = done && s->flags_pinned[i] != 0;
+    return FG_OK;
+}
+
+int mb_finish(fg_mb_state* s, int nsys, fg_solve_info* info_host, int* max_it) {
+    int rc = FG_OK, m = 0;
+    for (int i = 0; i < nsys; ++i) {
+        if (info_host) info_host[i] = s->info_pinned[i];
+        m = std::max(m, (int)s->info_pinned[i].used_iterations);
+        if (!s->info_pinned[i].is_finite) rc = FG_ERR_NOT_FINITE;
+        else if (!s->info_pinned[i].converged && rc == FG_OK) rc = FG_ERR_NOT_CONVERGED;
+    }
+    if (max_it) *max_it = m;
+    FG_HIP_CHECK(hipGetLastError());
+    return rc;
+}
+
+MbSolve mb_solve_ptrs(fg_mb_state* s, const float* diag, const float* off, const float* rhs, float* x, int nc, float tol) {
+    MbSolve q;
+    q.diag = diag; q.off = off; q.rhs = rhs; q.x = x;
+    q.r = s->w[0]; q.rw = s->w[1]; q.p = s->w[2]; q.v = s->w[3]; q.t = s->w[4];
+    q.acc = s->acc; q.sc = s->sc; q.flags = s->flags; q.info = s->info_dev; q.nc = nc; q.tol = tol;
+    q.best_x = nullptr; q.best_it = nullptr; q.stall_limit = 0;
+    return q;
+}
+
+int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, int nc,
+                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st) {
+    const int nsys = s->B * nc, n = s->N;
+    const MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
+    const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
+    hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0););
+    bool done = false;
+    int next_poll = 2;
+    for (int it = 0; it < max_iterations && !done; ++it) {
+        MB_DISPATCH(s, {
+            hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, it);
+        });
+        if (it + 1 >= next_poll || it + 1 == max_iterations) {
+            next_poll = it + 1 + 2;
+            hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
+            if (int rc = mb_poll(s, nsys, st, done)) return rc;
+        }
+    }
+    return mb_finish(s, nsys, nullptr, max_it);
+}
+
+int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
+          int max_iterations, int use_x0, int* max_it, hipStream_t st) {
+    const int nsys = s->B, n = s->N;
+    MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);
+    q.rw = nullptr;
+    q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = 400;
+    const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
+    hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0););
+    bool done = false;
+    int next_poll = 16;
+    for (int it = 0; it < max_iterations && !done; ++it) {
+        MB_DISPATCH(s, {
+            hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            hipLaunchKernelGGL(k_mbc_dir<DIMS>, grid, blk, 0, st, s->dev, q, it);
+        });
+        if (it + 1 >= next_poll || it + 1 == max_iterations) {
+            next_poll = it + 1 + 16;
+            hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
+            if (int rc = mb_poll(s, nsys, st, done)) return rc;
+        }
+    }
+    bool failed = false;
+    for (int i = 0; i < nsys; ++i) failed = failed || !s->info_pinned[i].converged;
+    if (failed) {
+        hipLaunchKernelGGL(k_mbs_restore_best, grid, blk, 0, st, n, q);
+        FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
+        FG_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return mb_finish(s, nsys, nullptr, max_it);
+}
+
+template <typename T>
+int mb_alloc(fg_mb_state* s, T** p, size_t count) {
+    void* q = nullptr;
+    FG_HIP_CHECK(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+    FG_HIP_CHECK(hipMemset(q, 0, (count ? count : 1) * sizeof(T)));
+    s->owned.push_back(q);
+    *p = (T*)q;
+    return FG_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_handle* out) {
+    FG_REQUIRE(out != nullptr, FG_ERR_INVALID_ARG, "fg_mb_create: out is null");
+    FG_REQUIRE(dims == 2 || dims == 3, FG_ERR_INVALID_ARG, "fg_mb_create: dims must be 2 or 3");
+    FG_REQUIRE(batch >= 1, FG_ERR_INVALID_ARG, "fg_mb_create: batch must be >= 1");
+    FG_HIP_CHECK(hipSetDevice(device));
+    fg_mb_state* s = new fg_mb_state();
+    s->d = dims; s->F = 2 * dims; s->B = batch;
+    *out = s;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_destroy(fg_mb_handle s) {
+    if (!s) return FG_OK;
+    for (void* p : s->owned) (void)hipFree(p);
+    if (s->info_pinned) (void)hipHostFree(s->info_pinned);
+    if (s->red_pinned) (void)hipHostFree(s->red_pinned);
+    if (s->flags_pinned) (void)hipHostFree(s->flags_pinned);
+    delete s;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_add_block(fg_mb_handle s, const float* coords, int32_t nx, int32_t ny, int32_t nz, int32_t* block_id) {
+    FG_REQUIRE(s && coords, FG_ERR_INVALID_ARG, "fg_mb_add_block: null argument");
+    FG_REQUIRE(!s->finalized, FG_ERR_INVALID_ARG, "fg_mb_add_block: domain already finalized");
+    if (s->d == 2) nz = 1;
+    FG_REQUIRE(nx >= 3 && ny >= 3 && (s->d == 2 || nz >= 3), FG_ERR_INVALID_ARG,
+               "fg_mb_add_block: every spatial dimension must be at least 3 cells (domain_structs.cpp Block::Block)");
+    MbBlock b;
+    b.size[0] = nx; b.size[1] = ny; b.size[2] = nz;
+    b.ncells = nx * ny * nz;
+    const size_t nv = (size_t)(nx + 1) * (ny + 1) * (s->d == 3 ? nz + 1 : 1) * s->d;
+    b.coords.resize(nv);
+    for (size_t k = 0; k < nv; ++k) b.coords[k] = (double)coords[k];
+    s->blocks.push_back(std::move(b));
+    if (block_id) *block_id = (int32_t)s->blocks.size() - 1;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_connect(fg_mb_handle s, int32_t b1, int32_t face1, int32_t b2, int32_t face2, int32_t axis1, int32_t axis2) {
+    FG_REQUIRE(s && !s->finalized, FG_ERR_INVALID_ARG, "fg_mb_connect: null or finalized handle");
+    const int nb = (int)s->blocks.size(), d = s->d;
+    FG_REQUIRE(b1 >= 0 && b1 < nb && b2 >= 0 && b2 < nb, FG_ERR_INVALID_ARG, "fg_mb_connect: block index out of range");
+    FG_REQUIRE(face1 >= 0 && face1 < 2 * d && face2 >= 0 && face2 < 2 * d && axis1 >= 0 && axis1 < 2 * d, FG_ERR_INVALID_ARG,
+               "fg_mb_connect: face / axis index out of range");
+    // ConnectBlocks (domain_structs.cpp:1080-1113)
+    int axes1[3] = {face2, 0, 0}, axes2[3] = {face1, 0, 0};
+    if (d > 1) {
+        axes1[1] = axis1;
+        const int f1d = face1 >> 1, f2d = face2 >> 1;
+        bool swapped = false;
+        if (d == 2 || (axis1 >> 1) == (f2d + 1) % d) {
+            axes2[1] = (((f1d + 1) % d) << 1) | (axis1 & 1);
+        } else {
+            FG_REQUIRE((axis2 >> 1) == (f2d + 1) % d, FG_ERR_INVALID_ARG, "fg_mb_connect: invalid connection");
+            axes2[1] = (((f1d + 2) % d) << 1) | (axis2 & 1);
+            swapped = true;
+        }
+        if (d > 2) {
+            axes1[2] = axis2;
+            axes2[2] = !swapped ? ((((f1d + 2) % d) << 1) | (axis2 & 1)) : ((((f1d + 1) % d) << 1) | (axis1 & 1));
+        }
+    }
+    // the connected faces must have matching extents
+    for (int k = 1; k < d; ++k) {
+        const int a1 = ((face1 >> 1) + k) % d, a2 = axes1[k] >> 1;
+        FG_REQUIRE(s->blocks[b1].size[a1] == s->blocks[b2].size[a2], FG_ERR_INVALID_ARG,
+                   "fg_mb_connect: the connected faces differ in resolution");
+    }
+    MbBound& x = s->blocks[b1].bounds[face1];
+    x.type = FG_MB_CONNECTED; x.other = b2;
+    MbBound& y = s->blocks[b2].bounds[face2];
+    y.type = FG_MB_CONNECTED; y.other = b1;
+    for (int k = 0; k < 3; ++k) { x.axes[k] = axes1[k]; y.axes[k] = axes2[k]; }
+    return FG_OK;
+}
+
+extern "C" int fg_mb_make_periodic(fg_mb_handle s, int32_t block, int32_t axis) {
+    FG_REQUIRE(s && !s->finalized, FG_ERR_INVALID_ARG, "fg_mb_make_periodic: null or finalized handle");
+    FG_REQUIRE(block >= 0 && block < (int)s->blocks.size() && axis >= 0 && axis < s->d, FG_ERR_INVALID_ARG,
+               "fg_mb_make_periodic: index out of range");
+    s->blocks[block].bounds[2 * axis].type = FG_MB_PERIODIC;
+    s->blocks[block].bounds[2 * axis + 1].type = FG_MB_PERIODIC;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_set_reference_quirks(fg_mb_handle s, int32_t connected_diagonal_offset, int32_t first_layer_rule) {
+    FG_REQUIRE(s && !s->finalized, FG_ERR_INVALID_ARG, "fg_mb_set_reference_quirks: null or finalized handle");
+    s->quirk_diag_offset = connected_diagonal_offset ? 1 : 0;
+    s->quirk_first_layer = first_layer_rule ? 1 : 0;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_finalize(fg_mb_handle s) {
+    FG_REQUIRE(s && !s->finalized && !s->blocks.empty(), FG_ERR_INVALID_ARG, "fg_mb_finalize: nothing to finalize");
+    if (int rc = fg_mb_build_tables(s)) return rc;
+    const size_t B = s->B, N = s->N, NB = s->NB, d = s->d, F = s->F;
+    if (int rc = mb_alloc(s, &s->cc, B * d * N)) return rc;
+    if (int rc = mb_alloc(s, &s->fb, B * NB)) return rc;
+    if (int rc = mb_alloc(s, &s->Cdiag, B * N)) return rc;
+    if (int rc = mb_alloc(s, &s->Coff, B * F * N)) return rc;
+    if (int rc = mb_alloc(s, &s->rA, B * N)) return rc;
+    if (int rc = mb_alloc(s, &s->rhs, B * d * N)) return rc;
+    if (int rc = mb_alloc(s, &s->ures, B * d * N)) return rc;
+    if (int rc = mb_alloc(s, &s->hvec, B * d * N)) return rc;
+    if (int rc = mb_alloc(s, &s->div, B * N)) return rc;
+    if (int rc = mb_alloc(s, &s->Pdiag, B * N)) return rc;
+    if (int rc = mb_alloc(s, &s->Poff, B * F * N)) return rc;
+    if (int rc = mb_alloc(s, &s->pres, B * N)) return rc;
+    for (int k = 0; k < 5; ++k)
+        if (int rc = mb_alloc(s, &s->w[k], B * d * N)) return rc;
+    if (int rc = mb_alloc(s, &s->acc, B * d * MB_ACC)) return rc;
+    if (int rc = mb_alloc(s, &s->sc, B * d * 2)) return rc;
+    if (int rc = mb_alloc(s, &s->flags, B * d)) return rc;
+    if (int rc = mb_alloc(s, &s->info_dev, B * d)) return rc;
+    if (int rc = mb_alloc(s, &s->red, B)) return rc;
+    if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(float) * B, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->flags_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
+    s->finalized = true;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_sizes(fg_mb_handle s, int32_t* n_cells, int32_t* n_boundary_faces) {
+    FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_sizes: domain not finalized");
+    if (n_cells) *n_cells = s->N;
+    if (n_boundary_faces) *n_boundary_faces = s->NB;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_block_info(fg_mb_handle s, int32_t block, int32_t* cell_offset, int32_t* boundary_slot0 /*[2d]*/) {
+    FG_REQUIRE(s && s->finalized && block >= 0 && block < (int)s->blocks.size(), FG_ERR_INVALID_ARG, "fg_mb_block_info: bad argument");
+    if (cell_offset) *cell_offset = s->blocks[block].offset;
+    if (boundary_slot0)
+        for (int f = 0; f < s->F; ++f)
+            boundary_slot0[f] = s->blocks[block].bounds[f].type == FG_MB_FIXED ? s->blocks[block].bounds[f].slot0 : -1;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_bind(fg_mb_handle s, float* velocity, float* pressure_result, float* boundary_velocity, const float* source) {
+    FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_bind: domain not finalized");
+    FG_REQUIRE(velocity && pressure_result && (boundary_velocity || s->NB == 0), FG_ERR_INVALID_ARG, "fg_mb_bind: null field");
+    s->velocity = velocity; s->pressure = pressure_result; s->bvel = boundary_velocity; s->source = source;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_set_viscosity(fg_mb_handle s, float nu) {
+    FG_REQUIRE(s && nu > 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_viscosity: viscosity must be positive");
+    s->nu = nu;
+    return FG_OK;
+}
+
+extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity, FG_ERR_NOT_BOUND, "fg_mb_piso_step: fields not bound");
+    FG_REQUIRE(dt_B && opt, FG_ERR_INVALID_ARG, "fg_mb_piso_step: null argument");
+    FG_REQUIRE(s->nu > 0.f, FG_ERR_INVALID_ARG, "fg_mb_piso_step: viscosity not set");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->B, N = s->N, d = s->d, NB = s->NB;
+    const int cells = std::max(N, NB);
+    const dim3 blk(FG_BLOCK), gc((cells + FG_BLOCK - 1) / FG_BLOCK, B), gn((N + FG_BLOCK - 1) / FG_BLOCK, B),
+        gv((N + FG_BLOCK - 1) / FG_BLOCK, B, d);
+    const MbDev& D = s->dev;
+    int soft_rc = FG_OK;
+    auto soft = [&](int rc) {  // non-convergence is reported, everything else aborts the step
+        if (rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) { if (soft_rc == FG_OK || rc == FG_ERR_NOT_FINITE) soft_rc = rc; return FG_OK; }
+        return rc;
+    };
+    int its[4] = {0, 0, 0, 0};
+    const size_t vel_env = (size_t)d * N;
+    const dim3 gcopy((unsigned)((vel_env + FG_BLOCK - 1) / FG_BLOCK), B);
+    MB_DISPATCH(s, {
+        // ---- predictor (SIM.py:1646-1762, non-orthogonal branch)
+        hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, dt_B, s->velocity, s->bvel, s->cc, s->fb);
+        hipLaunchKernelGGL(k_mb_matrix<DIMS>, gn, blk, 0, st, D, dt_B, s->nu, s->cc, s->fb, s->Cdiag, s->Coff, s->rA);
+        hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, dt_B, s->velocity, s->ures);  // CopyVelocityResultFromBlocks
+        for (int no = 0; no < opt->advect_non_ortho_steps; ++no) {
+            hipLaunchKernelGGL(k_mb_vrhs<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->velocity, s->ures, s->bvel, s->fb, s->source, s->rhs);
+            int m = 0;
+            if (int rc = soft(mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
+                                          opt->max_iterations, no > 0, &m, st)))
+                return rc;
+            its[1] = std::max(its[1], m);
+        }
+        // ---- correctors (SIM.py:1777-1972)
+        for (int c = 0; c < opt->corrector_steps; ++c) {
+            hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff);
+            for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
+                if (ps == 0) {
+                    hipLaunchKernelGGL(k_mb_h<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->rA, s->Coff, s->velocity, s->ures,
+                                       s->bvel, s->fb, s->source, s->hvec);
+                    hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, dt_B, s->hvec, s->bvel, s->cc, (float*)nullptr);
+                }
+                hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, dt_B, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
+                int m = 0;
+                const int prc = opt->pressure_use_bicgstab
+                                    ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol,
+                                                  opt->max_iterations, ps > 0, &m, st)
+                                    : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol,
+                                            opt->max_iterations, ps > 0, &m, st);
+                if (int rc = soft(prc)) return rc;
+                if (c < 2) its[2 + c] = std::max(its[2 + c], m);
+                FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
+                hipLaunchKernelGGL(k_mb_sum, dim3(8, B), blk, 0, st, N, dt_B, s->pres, s->red);
+                hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, dt_B, s->red, s->pres, s->pressure);
+            }
+            hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->hvec, s->pressure, s->ures);
+        }
+        hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, dt_B, s->ures, s->velocity);  // CopyVelocityResultToBlocks
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    if (stats_host) for (int k = 0; k < 4; ++k) stats_host[k] = its[k];
+    return soft_rc;
+}
+
+extern "C" int fg_mb_max_velocity(fg_mb_handle s, float* out_B_host, void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_max_velocity: fields not bound");
+    hipStream_t st = (hipStream_t)stream;
+    const int cells = std::max(s->N, s->NB);
+    FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * s->B, st));
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_maxvel<DIMS>, dim3((cells + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st,
+                                      s->dev, s->velocity, s->bvel, s->red););
+    FG_HIP_CHECK(hipMemcpyAsync(s->red_pinned, s->red, sizeof(float) * s->B, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < s->B; ++b) out_B_host[b] = s->red_pinned[b];
+    return FG_OK;
+}
+
+// intermediate buffers for the parity tests
+extern "C" int fg_mb_get_buffer(fg_mb_handle s, int32_t which, const float** ptr, int64_t* count) {
+    FG_REQUIRE(s && s->finalized && ptr && count, FG_ERR_INVALID_ARG, "fg_mb_get_buffer: bad argument");
+    const int64_t B = s->B, N = s->N, d = s->d, F = s->F;
+    switch (which) {
+        case FG_MB_BUF_A: *ptr = s->Cdiag; *count = B * N; break;
+        case FG_MB_BUF_C_OFF: *ptr = s->Coff; *count = B * F * N; break;
+        case FG_MB_BUF_RHS: *ptr = s->rhs; *count = B * d * N; break;
+        case FG_MB_BUF_H: *ptr = s->hvec; *count = B * d * N; break;
+        case FG_MB_BUF_DIV: *ptr = s->div; *count = B * N; break;
+        case FG_MB_BUF_P_DIAG: *ptr = s->Pdiag; *count = B * N; break;
+        case FG_MB_BUF_P_OFF: *ptr = s->Poff; *count = B * F * N; break;
+        case FG_MB_BUF_VELOCITY_RESULT: *ptr = s->ures; *count = B * d * N; break;
+        default: fg_set_error("fg_mb_get_buffer: unknown buffer id"); return FG_ERR_INVALID_ARG;
+    }
+    return FG_OK;
+}
+
+extern "C" int fg_mb_read_buffer(fg_mb_handle s, int32_t which, float* dst_device, void* stream) {
+    const float* p = nullptr;
+    int64_t n = 0;
+    if (int rc = fg_mb_get_buffer(s, which, &p, &n)) return rc;
+    FG_REQUIRE(dst_device != nullptr, FG_ERR_INVALID_ARG, "fg_mb_read_buffer: null destination");
+    FG_HIP_CHECK(hipMemcpyAsync(dst_device, p, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    FG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return FG_OK;
+}
+
+// host copy of the neighbour table [2d][N] (global index, or -1 - boundary slot)
+extern "C" int fg_mb_get_neighbors(fg_mb_handle s, int32_t* out /*[2d*N]*/) {
+    FG_REQUIRE(s && s->finalized && out, FG_ERR_INVALID_ARG, "fg_mb_get_neighbors: bad argument");
+    std::copy(s->h_nbr.begin(), s->h_nbr.end(), out);
+    return FG_OK;
+}

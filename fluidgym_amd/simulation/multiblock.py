@@ -1,0 +1,219 @@
+"""Multi-block, non-orthogonal domains on the HIP library.
+
+Host-side mirror of the reference's ``PISOtorch.Domain`` / ``Block`` construction calls for meshes made of several
+structured, curvilinear blocks (``Domain.CreateBlock(vertexCoordinates=...)``, ``Block.CloseBoundary``,
+``Block.ConnectBlock``, ``Block.MakePeriodic``, ``Domain.PrepareSolve``; ``extensions/PISOtorch.cpp:420-500``,
+``domain_structs.cpp:1940-2002``) and of ``Simulation``'s non-orthogonal PISO step
+(``pict/PISOtorch_simulation.py:1707-1972``).  What differs by design: every field carries a leading env batch
+``B``; cells of all blocks live in ONE flat array per env (block order, x fastest) and all FIXED boundary faces in one
+flat slot array, so the kernels of ``csrc/fg_mb_step.hip`` need no per-block launches; the mesh tables are built once
+at ``prepare_solve`` on the host (``csrc/fg_mb_topo.hip``).  There is no CPU path: everything below calls the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+_FACES = {"-x": 0, "+x": 1, "-y": 2, "+y": 3, "-z": 4, "+z": 5}
+_AXES = {"x": 0, "y": 1, "z": 2}
+
+
+def face_index(face) -> int:
+    """``BoundarySideToIndex``: "-x", "+x", ... or the index itself."""
+    return _FACES[face] if isinstance(face, str) else int(face)
+
+
+class MBBlock:
+    """One structured block; mirrors the construction-time API of ``PISOtorch.Block``."""
+
+    def __init__(self, domain: "MultiBlockDomain", index: int, coords: np.ndarray, name: str):
+        self.domain, self.index, self.name = domain, index, name
+        self.coords = coords  # [d, (nz+1,) ny+1, nx+1] float32
+        d = coords.shape[0]
+        self.size = tuple(coords.shape[-1 - a] - 1 for a in range(d))  # (nx, ny[, nz])
+        self.cell_offset = -1
+        self.boundary_slot0: List[int] = [-1] * (2 * d)
+        self._pending_velocity: Dict[int, np.ndarray] = {}
+
+    # ---- construction (before prepare_solve)
+    def CloseBoundary(self, face, velocity=None):
+        """FIXED Dirichlet boundary (``Block::CloseBoundary``); ``velocity`` is [d] (static) or [d, face cells...]."""
+        f = face_index(face)
+        if velocity is not None:
+            self._pending_velocity[f] = np.asarray(
+                velocity.detach().cpu().numpy() if isinstance(velocity, torch.Tensor) else velocity, dtype=np.float32)
+
+    def ConnectBlock(self, face, other: "MBBlock", other_face, axis1, axis2="-z"):
+        lib = self.domain.lib
+        L.check(lib.fg_mb_connect(self.domain.handle, self.index, face_index(face), other.index, face_index(other_face),
+                                  face_index(axis1), face_index(axis2) if self.domain.dims == 3 else 0))
+
+    def MakePeriodic(self, axis):
+        a = _AXES[axis] if isinstance(axis, str) else int(axis)
+        L.check(self.domain.lib.fg_mb_make_periodic(self.domain.handle, self.index, a))
+
+    # ---- views (after prepare_solve)
+    @property
+    def n_cells(self) -> int:
+        return int(np.prod(self.size))
+
+    def face_cells(self, face) -> int:
+        f = face_index(face)
+        return self.n_cells // self.size[f >> 1]
+
+    def cells(self, field: torch.Tensor) -> torch.Tensor:
+        """View of this block's cells of a flat field [B, C, N] as [B, C, (nz,) ny, nx]."""
+        v = field[..., self.cell_offset:self.cell_offset + self.n_cells]
+        return v.reshape(*field.shape[:-1], *reversed(self.size))
+
+    def boundary(self, face, field: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """View of one FIXED face of the boundary-velocity array [B, d, NB] as [B, d, face cells] (lowest remaining axis
+        fastest, i.e. the reference's boundary tensor flattened)."""
+        f = face_index(face)
+        s0 = self.boundary_slot0[f]
+        if s0 < 0:
+            raise ValueError(f"face {face} of block {self.name} is not a FIXED boundary")
+        field = self.domain.boundary_velocity if field is None else field
+        return field[..., s0:s0 + self.face_cells(f)]
+
+    def getCellCoordinates(self) -> np.ndarray:
+        """Cell centres = mean of the cell's vertices (``Block::getCellCoordinates``)."""
+        c = self.coords
+        d = c.shape[0]
+        out = c
+        for a in range(d):
+            ax = out.ndim - 1 - a
+            n = out.shape[ax] - 1
+            out = 0.5 * (np.take(out, range(0, n), axis=ax) + np.take(out, range(1, n + 1), axis=ax))
+        return out
+
+
+class MultiBlockDomain:
+    """``PISOtorch.Domain`` for connected curvilinear blocks, batched over envs."""
+
+    def __init__(self, dims: int, viscosity: float, batch: int = 1, device: Optional[torch.device] = None,
+                 reference_quirks: bool = True):
+        if not torch.cuda.is_available():
+            raise L.NativeLibraryError("fluidgym_amd needs a GPU: the multi-block path has no CPU fallback")
+        self.lib = L.load()
+        self.dims, self.batch = int(dims), int(batch)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.viscosity = float(viscosity)
+        self.handle = ctypes.c_void_p()
+        L.check(self.lib.fg_mb_create(self.dims, self.batch, self.device.index or 0, ctypes.byref(self.handle)))
+        if not reference_quirks:
+            L.check(self.lib.fg_mb_set_reference_quirks(self.handle, 0, 0))
+        self.blocks: List[MBBlock] = []
+        self.prepared = False
+        self.velocity = self.pressure = self.boundary_velocity = self.velocity_source = None
+        self.n_cells = self.n_boundary_faces = 0
+        self._dt = None
+
+    def CreateBlock(self, vertexCoordinates, name: str = "") -> MBBlock:
+        c = vertexCoordinates.detach().cpu().numpy() if isinstance(vertexCoordinates, torch.Tensor) else np.asarray(vertexCoordinates)
+        if c.ndim == self.dims + 2:  # reference layout [1, d, ...]
+            c = c[0]
+        c = np.ascontiguousarray(c, dtype=np.float32)
+        if c.shape[0] != self.dims or c.ndim != self.dims + 1:
+            raise ValueError("vertexCoordinates must be [d, (nz+1,) ny+1, nx+1]")
+        size = [c.shape[-1 - a] - 1 for a in range(self.dims)] + [1] * (3 - self.dims)
+        bid = ctypes.c_int32(-1)
+        L.check(self.lib.fg_mb_add_block(self.handle, c.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), size[0], size[1],
+                                         size[2], ctypes.byref(bid)))
+        blk = MBBlock(self, bid.value, c, name or f"block{bid.value}")
+        self.blocks.append(blk)
+        return blk
+
+    def PrepareSolve(self):
+        """Build the mesh tables and allocate the fields (``Domain::PrepareSolve``, domain_structs.cpp:2570-2693)."""
+        L.check(self.lib.fg_mb_finalize(self.handle))
+        n, nb = ctypes.c_int32(), ctypes.c_int32()
+        L.check(self.lib.fg_mb_sizes(self.handle, ctypes.byref(n), ctypes.byref(nb)))
+        self.n_cells, self.n_boundary_faces = n.value, nb.value
+        for blk in self.blocks:
+            off = ctypes.c_int32()
+            slots = (ctypes.c_int32 * 6)()
+            L.check(self.lib.fg_mb_block_info(self.handle, blk.index, ctypes.byref(off), slots))
+            blk.cell_offset = off.value
+            blk.boundary_slot0 = [slots[f] for f in range(2 * self.dims)]
+        B, d = self.batch, self.dims
+        kw = dict(dtype=torch.float32, device=self.device)
+        self.velocity = torch.zeros(B, d, self.n_cells, **kw)
+        self.pressure = torch.zeros(B, self.n_cells, **kw)
+        self.boundary_velocity = torch.zeros(B, d, max(self.n_boundary_faces, 1), **kw)
+        self._dt = torch.zeros(B, **kw)
+        for blk in self.blocks:
+            for f, v in blk._pending_velocity.items():
+                if blk.boundary_slot0[f] < 0:
+                    raise ValueError(f"face {f} of {blk.name} was given a velocity but is connected or periodic")
+                view = blk.boundary(f)
+                t = torch.as_tensor(v, **kw).reshape(d, -1)
+                view.copy_(t.expand(d, view.shape[-1]) if t.shape[-1] == 1 else t)
+        L.check(self.lib.fg_mb_set_viscosity(self.handle, self.viscosity))
+        self._bind()
+        self.prepared = True
+
+    def _bind(self):
+        src = self.velocity_source
+        L.check(self.lib.fg_mb_bind(self.handle, ctypes.c_void_p(self.velocity.data_ptr()),
+                                    ctypes.c_void_p(self.pressure.data_ptr()),
+                                    ctypes.c_void_p(self.boundary_velocity.data_ptr()),
+                                    ctypes.c_void_p(src.data_ptr()) if src is not None else None))
+
+    def set_velocity_source(self, source: Optional[torch.Tensor]):
+        self.velocity_source = None if source is None else source.to(self.device, torch.float32).contiguous()
+        self._bind()
+
+    def neighbors(self) -> np.ndarray:
+        out = np.zeros((2 * self.dims, self.n_cells), dtype=np.int32)
+        L.check(self.lib.fg_mb_get_neighbors(self.handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        return out
+
+    # ---- stepping
+    def piso_step(self, dt, corrector_steps: int = 2, advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1,
+                  advection_tol: float = 1e-5, pressure_tol: float = 1e-5, max_iterations: int = 5000,
+                  raise_on_failure: bool = True, pressure_use_bicgstab: bool = False):
+        """One PISO step of every env (``dt``: scalar or [B]; ``dt <= 0`` leaves an env untouched).  Returns the max
+        solver iterations (velocity, pressure corrector 0, pressure corrector 1)."""
+        if not self.prepared:
+            raise RuntimeError("PrepareSolve() first")
+        self._dt.copy_(torch.as_tensor(dt, dtype=torch.float32).expand(self.batch))
+        opt = L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
+                                advection_tol, pressure_tol, int(pressure_use_bicgstab))
+        stats = (ctypes.c_int32 * 4)()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.fg_mb_piso_step(self.handle, ctypes.c_void_p(self._dt.data_ptr()), ctypes.byref(opt), stats,
+                                      ctypes.c_void_p(st))
+        L.check(rc, allow=() if raise_on_failure else (L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
+        return stats[1], stats[2], stats[3]
+
+    def max_velocity(self) -> np.ndarray:
+        out = (ctypes.c_float * self.batch)()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fg_mb_max_velocity(self.handle, out, ctypes.c_void_p(st)))
+        return np.array(out[:], dtype=np.float32)
+
+    def buffer(self, which: int) -> torch.Tensor:
+        """Copy of an intermediate buffer of the last step (tests)."""
+        ptr, cnt = ctypes.c_void_p(), ctypes.c_int64()
+        L.check(self.lib.fg_mb_get_buffer(self.handle, which, ctypes.byref(ptr), ctypes.byref(cnt)))
+        out = torch.empty(cnt.value, dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fg_mb_read_buffer(self.handle, which, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st)))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.fg_mb_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -286,6 +286,69 @@ int fg_resampler_destroy(fg_resampler r);
 int fg_resample(fg_resampler r, const float* src, int batch, int channels, float* dst, int fill_max_steps,
                 void* stream);
 
+/* ---- multi-block, non-orthogonal domains -------------------------------------------
+ * The reference's general Domain: several structured blocks of curvilinear cells (vertex coordinates ->
+ * CoordsToTransforms, grid_gen.cu:298-390), joined by ConnectedBoundary with shuffled / inverted axes
+ * (Block::ConnectBlock, domain_structs.cpp:1940-1950; ConnectBlocks :1080-1113), closed by FIXED Dirichlet
+ * boundaries (Block::CloseBoundary :1995-2002) or periodic (Block::MakePeriodic :1952-1971), stepped by
+ * _PISO_split_step's non-orthogonal branch (PISOtorch_simulation.py:1707-1972) with
+ * nonOrthoFlags = CENTER_MATRIX | DIRECT_MATRIX | DIAGONAL_RHS (:479-487).  This is what the cylinder and airfoil
+ * environments run on (envs/cylinder/grid.py:232-418).
+ *
+ * Build: fg_mb_create -> fg_mb_add_block per block (HOST vertex coordinates [d,(nz+1,)ny+1,nx+1], float32;
+ * every face starts FIXED with zero velocity) -> fg_mb_connect / fg_mb_make_periodic -> fg_mb_finalize (builds the
+ * mesh tables on the host once, allocates work space).  Faces are numbered -x,+x,-y,+y,-z,+z = 0..2d-1; the
+ * connected-axis arguments use the same numbering with the low bit meaning "inverted", exactly as ConnectBlock.
+ * Cells of all blocks are concatenated (block order, x fastest): N = fg_mb_sizes; the FIXED faces of all blocks are
+ * concatenated into NB boundary slots (block order, face order, lowest remaining axis fastest); fg_mb_block_info
+ * gives the offsets.  Fields are caller-owned fp32 device arrays: velocity [B,d,N] (updated in place), pressure
+ * result [B,N] (read for the lagged corner terms, overwritten with the new mean-free pressure), boundary velocity
+ * [B,d,NB] (Dirichlet values, may change between steps), optional velocity source [B,d,N].
+ * fg_mb_set_reference_quirks (before finalize; default 1,1) keeps two behaviours of the reference that are not
+ * geometrically motivated: diagonal walks over a connection land one layer inside the connected block
+ * (PISO_multiblock_cuda_kernel.cu:2152, 2658, 2825), and the matrices drop the cross-metric terms on the inner face
+ * of a first-layer cell when the far side of the block is a wall (:1952). */
+typedef struct fg_mb_state* fg_mb_handle;
+int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_handle* out);
+int fg_mb_destroy(fg_mb_handle h);
+int fg_mb_add_block(fg_mb_handle h, const float* vertex_coords_host, int32_t nx, int32_t ny, int32_t nz, int32_t* block_id);
+int fg_mb_connect(fg_mb_handle h, int32_t block1, int32_t face1, int32_t block2, int32_t face2, int32_t axis1, int32_t axis2);
+int fg_mb_make_periodic(fg_mb_handle h, int32_t block, int32_t axis);
+int fg_mb_set_reference_quirks(fg_mb_handle h, int32_t connected_diagonal_offset, int32_t first_layer_rule);
+int fg_mb_finalize(fg_mb_handle h);
+int fg_mb_sizes(fg_mb_handle h, int32_t* n_cells, int32_t* n_boundary_faces);
+int fg_mb_block_info(fg_mb_handle h, int32_t block, int32_t* cell_offset, int32_t* boundary_slot0 /* [2d], -1 = not FIXED */);
+int fg_mb_get_neighbors(fg_mb_handle h, int32_t* out_host /* [2d*N]: neighbour cell, or -1 - boundary slot */);
+int fg_mb_bind(fg_mb_handle h, float* velocity, float* pressure_result, float* boundary_velocity, const float* source);
+int fg_mb_set_viscosity(fg_mb_handle h, float nu);
+typedef struct fg_mb_step_options {
+    int32_t corrector_steps;           /* 2 */
+    int32_t advect_non_ortho_steps;    /* 1 (airfoil 2) */
+    int32_t pressure_non_ortho_steps;  /* 1 (cylinder 3-D and airfoil 4) */
+    int32_t max_iterations;            /* 5000 */
+    float advection_tol;               /* RMS residual */
+    float pressure_tol;
+    int32_t pressure_use_bicgstab;     /* 0: CG as the reference (pressure_use_BiCG=False, simulation.py:136) -- with the
+                                          cross-metric terms the pressure matrix is not symmetric, CG only works while the
+                                          mesh is close to orthogonal; 1: BiCGStab */
+} fg_mb_step_options;
+/* dt_B: device array [B]; dt <= 0 leaves that env untouched.  stats_host (optional, 4 ints): max iterations of
+ * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
+ * solve failed (fields still updated, as with returnBestResult), other negative codes on errors. */
+int fg_mb_piso_step(fg_mb_handle h, const float* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream);
+/* max |Minv u| over cells and boundary faces per env (Domain.getMaxVelocity(True, True)); synchronises */
+int fg_mb_max_velocity(fg_mb_handle h, float* out_B_host, void* stream);
+#define FG_MB_BUF_A 0               /* [B,N]   diagonal of C */
+#define FG_MB_BUF_C_OFF 1           /* [B,2d,N] */
+#define FG_MB_BUF_RHS 2             /* [B,d,N] velocity right-hand side of the last solve */
+#define FG_MB_BUF_H 3               /* [B,d,N] */
+#define FG_MB_BUF_DIV 4             /* [B,N]   pressure right-hand side of the last solve */
+#define FG_MB_BUF_P_DIAG 5
+#define FG_MB_BUF_P_OFF 6
+#define FG_MB_BUF_VELOCITY_RESULT 7
+int fg_mb_get_buffer(fg_mb_handle h, int32_t which, const float** ptr, int64_t* count);
+int fg_mb_read_buffer(fg_mb_handle h, int32_t which, float* dst_device, void* stream); /* device copy, synchronises */
+
 /* ---- grid metrics --------------------------------------------------------------------------- */
 /* CoordsToTransforms (grid_gen.cu:298-390): vertex coords [d,(nz+1,)ny+1,nx+1] ->
  * transforms [(nz,)ny,nx, 2 d^2 + 1] = M | Minv | det per cell. */

@@ -1,0 +1,119 @@
+"""Mesh specifications shared by the multi-block tests: one description builds the oracle domain (CPU) and the HIP
+domain (GPU), so both see the same blocks, connections and boundary values."""
+import numpy as np
+
+from oracle import mb_oracle as mbo
+
+
+class Spec:
+    def __init__(self, dims, nu):
+        self.dims, self.nu = dims, nu
+        self.blocks = []      # vertex coordinate arrays [d, ny+1, nx+1]
+        self.fixed = []       # (block, face, velocity [d, face cells])
+        self.connections = [] # (b1, face1, b2, face2, axis1)
+        self.periodic = []    # (block, axis)
+
+    def oracle(self):
+        d = mbo.Domain(self.dims, self.nu)
+        for c in self.blocks:
+            d.add_block(c)
+        for b, f, v in self.fixed:
+            d.close(b, f, v)
+        for b, a in self.periodic:
+            d.make_periodic(b, a)
+        for c in self.connections:
+            d.connect(*c)
+        d.finalize()
+        return d
+
+    def native(self, batch=1, reference_quirks=True):
+        from fluidgym_amd.simulation.multiblock import MultiBlockDomain
+
+        dom = MultiBlockDomain(self.dims, self.nu, batch=batch, reference_quirks=reference_quirks)
+        blks = [dom.CreateBlock(c.astype(np.float32)) for c in self.blocks]
+        for b, f, v in self.fixed:
+            blks[b].CloseBoundary(f, v)
+        for b, a in self.periodic:
+            blks[b].MakePeriodic(a)
+        for b1, f1, b2, f2, a1 in self.connections:
+            blks[b1].ConnectBlock(f1, blks[b2], f2, a1)
+        dom.PrepareSolve()
+        return dom
+
+
+def rot90(c):
+    """Same cells stored with xi' = +eta, eta' = -xi (right-handed)."""
+    return np.ascontiguousarray(c[:, :, ::-1].transpose(0, 2, 1))
+
+
+def split_rotated_channel(nx=12, ny=8, cut=5, nu=0.02):
+    x = np.linspace(0.0, 3.0, nx + 1) ** 1.15
+    t = np.linspace(-1.0, 1.0, ny + 1)
+    y = 0.5 * (np.tanh(1.3 * t) / np.tanh(1.3) + 1.0)
+    X, Y = np.meshgrid(x, y)
+    coords = np.stack([X, Y])
+    yc = 0.5 * (y[1:] + y[:-1])
+    inflow = np.stack([4.0 * yc * (1.0 - yc), np.zeros(ny)])
+    s = Spec(2, nu)
+    s.blocks = [coords[:, :, :cut + 1].copy(), rot90(coords[:, :, cut:])]
+    s.fixed = [(0, 0, inflow), (1, 2, inflow)]
+    s.connections = [(0, 1, 1, 3, 0)]
+    return s
+
+
+def skewed_pair(nu=0.03, shear=0.3, wobble=0.05, stretch=1.1):
+    """Two skewed blocks joined over a shuffled connection, moving lid on top, through-flow left to right."""
+    xi = np.linspace(0.0, 1.0, 6)
+    eta = np.linspace(0.0, 1.0, 7) ** stretch
+    X = xi[None, :] + shear * eta[:, None]
+    Y = eta[:, None] + 0.5 * shear * xi[None, :] + wobble * np.sin(3.0 * xi[None, :]) * eta[:, None]
+    c1 = np.stack([X, Y])
+    X2 = 1.0 + xi[None, :] + shear * eta[:, None]
+    Y2 = eta[:, None] + 0.5 * shear * (1.0 + xi[None, :]) + wobble * np.sin(3.0 * (1.0 + xi[None, :])) * eta[:, None]
+    # make the two blocks share their interface vertices exactly
+    c2 = np.stack([X2, Y2])
+    c2[:, :, 0] = c1[:, :, -1]
+    ny, nx = len(eta) - 1, len(xi) - 1
+    yc = 0.5 * (eta[1:] + eta[:-1])
+    through = np.stack([0.5 + 0.2 * yc, 0.05 * yc])
+    lid = np.stack([np.full(nx, 0.7), np.zeros(nx)])
+    s = Spec(2, nu)
+    s.blocks = [c1, rot90(c2)]
+    # block 1 is rotated: its -y face is the original +x side (cells run along xi' = original eta),
+    # its +x face is the original top (cells run along eta' = reversed original xi)
+    s.fixed = [(0, 0, through), (1, 2, through), (0, 3, lid), (1, 1, lid)]
+    s.connections = [(0, 1, 1, 3, 0)]
+    return s
+
+
+def twisted_ring(nr=5, nt=8, nu=0.05, twist=0.25, parts=3):
+    """An annulus cut into `parts` blocks connected in a ring (xi = angle, eta = radius), radial lines twisted so the
+    cells are non-orthogonal; the inner wall rotates."""
+    s = Spec(2, nu)
+    r = np.linspace(0.5, 1.5, nr + 1) ** 1.0
+    for k in range(parts):
+        th = np.linspace(2 * np.pi * k / parts, 2 * np.pi * (k + 1) / parts, nt + 1)
+        # right-handed with xi = -theta (clockwise), eta = r
+        TH = -th[None, :] + twist * (r[:, None] - 0.5)
+        X = r[:, None] * np.cos(TH)
+        Y = r[:, None] * np.sin(TH)
+        s.blocks.append(np.stack([X, Y]))
+    for k in range(parts):
+        s.connections.append((k, 1, (k + 1) % parts, 0, 2))
+        c = s.blocks[k]
+        # inner wall (-y face): tangential velocity of a rotating cylinder, evaluated at the face centres
+        xm = 0.5 * (c[0, 0, 1:] + c[0, 0, :-1])
+        ym = 0.5 * (c[1, 0, 1:] + c[1, 0, :-1])
+        s.fixed.append((k, 2, np.stack([-0.8 * ym, 0.8 * xm])))
+    return s
+
+
+def mild_skewed_pair():
+    """Same topology, cells within a few degrees of orthogonal: the regime of the reference's meshes, where its CG
+    pressure solve converges although the matrix is not exactly symmetric."""
+    return skewed_pair(shear=0.04, wobble=0.01)
+
+
+def polar_ring():
+    """Orthogonal O-grid (the cylinder mesh's inner ring is one): curved cells, three connections in a cycle."""
+    return twisted_ring(twist=0.0)

@@ -1,0 +1,171 @@
+"""Parity of the HIP multi-block / non-orthogonal PISO path with the CPU oracle (oracle/mb_oracle.py), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers_mb as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(d, seed, scale=0.2):
+    rng = np.random.default_rng(seed)
+    u = scale * rng.standard_normal((2, d.N))
+    p = 0.1 * rng.standard_normal(d.N)
+    return u, p - p.mean()
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+
+
+@pytest.mark.parametrize("spec_fn", [H.split_rotated_channel, H.skewed_pair, H.twisted_ring, H.polar_ring])
+def test_neighbor_table_matches_oracle_walk(spec_fn):
+    spec = spec_fn()
+    d = spec.oracle()
+    dom = spec.native()
+    nbr = dom.neighbors()
+    for b, pos in d.cells():
+        g = d.gidx(b, pos)
+        for f in range(4):
+            if d.at_bound(b, pos, f) and d.is_empty(b, f):
+                assert nbr[f, g] < 0
+                blk = dom.blocks[b]
+                assert -1 - nbr[f, g] == blk.boundary_slot0[f] + d.face_flat(b, f, pos)
+            else:
+                _, b2, p2, _ = d.resolve_neighbor(b, pos, f)[:4]
+                assert nbr[f, g] == d.gidx(b2, p2)
+    dom.close()
+
+
+def _load(dom, states):
+    for b, (u, p) in enumerate(states):
+        dom.velocity[b] = torch.as_tensor(u, dtype=torch.float32)
+        dom.pressure[b] = torch.as_tensor(p, dtype=torch.float32)
+
+
+def _assembly_parity(dom, d, states, dt, B, check_div):
+    from fluidgym_amd import _lib as L
+
+    A = dom.buffer(L.FG_MB_BUF_A).view(B, -1).cpu().numpy()
+    Coff = dom.buffer(L.FG_MB_BUF_C_OFF).view(B, 4, -1).cpu().numpy()
+    rhs = dom.buffer(L.FG_MB_BUF_RHS).view(B, 2, -1).cpu().numpy()
+    Pd = dom.buffer(L.FG_MB_BUF_P_DIAG).view(B, -1).cpu().numpy()
+    Po = dom.buffer(L.FG_MB_BUF_P_OFF).view(B, 4, -1).cpu().numpy()
+    h = dom.buffer(L.FG_MB_BUF_H).view(B, 2, -1).cpu().numpy()
+    div = dom.buffer(L.FG_MB_BUF_DIV).view(B, -1).cpu().numpy()
+    out = []
+    for b in range(B):
+        trace = {}
+        u_ref, p_ref = d.piso_step(states[b][0], states[b][1], dt[b], trace=trace, corrector_steps=1 if check_div else 2)
+        assert _rel(A[b], trace["C"][0]) < 2e-5
+        assert _rel(Coff[b], trace["C"][1]) < 2e-5
+        assert _rel(rhs[b], trace["rhs"]) < 5e-5
+        assert _rel(Pd[b], trace["P"][0]) < 5e-5
+        assert _rel(Po[b], trace["P"][1]) < 5e-5
+        if check_div:  # single corrector: h and the pressure right-hand side are those of corrector 0
+            assert _rel(h[b], trace["h"]) < 1e-4
+            assert _rel(div[b], trace["prhs"]) < 2e-4
+        out.append((u_ref, p_ref))
+    return out
+
+
+@pytest.mark.parametrize("spec_fn,bicg", [(H.split_rotated_channel, False), (H.polar_ring, False), (H.skewed_pair, True)])
+def test_piso_step_matches_oracle(spec_fn, bicg):
+    """Whole step against the oracle's direct solves.  The pressure solver is CG as in the reference where the mesh is
+    orthogonal (symmetric matrix); with strong cross metrics the matrix is not symmetric, CG stalls (there as here, see
+    test_cg_on_a_skewed_mesh_returns_its_best_iterate) and the same system is solved with BiCGStab."""
+    spec = spec_fn()
+    d = spec.oracle()
+    B = 2
+    dom = spec.native(batch=B)
+    dt = [0.05, 0.03]
+    states = [_state(d, 10 + b) for b in range(B)]
+    _load(dom, states)
+    its = dom.piso_step(dt, advection_tol=1e-7, pressure_tol=2e-6, pressure_use_bicgstab=bicg)
+    assert all(i > 0 for i in its)
+    u_gpu = dom.velocity.cpu().numpy()
+    p_gpu = dom.pressure.cpu().numpy()
+    refs = _assembly_parity(dom, d, states, dt, B, check_div=False)
+    for b in range(B):
+        assert _rel(u_gpu[b], refs[b][0]) < 2e-4, (spec_fn.__name__, b)
+        assert _rel(p_gpu[b], refs[b][1]) < 2e-3, (spec_fn.__name__, b)
+    mv = dom.max_velocity()
+    for b in range(B):
+        assert np.isclose(mv[b], d.max_cfl_velocity(refs[b][0]), rtol=1e-3)
+    dom.close()
+
+
+@pytest.mark.parametrize("spec_fn", [H.skewed_pair, H.twisted_ring])
+def test_assembly_matches_oracle_on_strongly_skewed_meshes(spec_fn):
+    """Matrices, right-hand sides, predictor, h and the pressure right-hand side with its lagged corner terms, on meshes
+    where every cross-metric branch is active (walls with moving Dirichlet values, connections with shuffled axes, a
+    cycle of connections).  Independent of how well the pressure solve converges."""
+    from fluidgym_amd import _lib as L
+
+    spec = spec_fn()
+    d = spec.oracle()
+    B = 2
+    dom = spec.native(batch=B)
+    dt = [0.05, 0.03]
+    states = [_state(d, 20 + b) for b in range(B)]
+    _load(dom, states)
+    dom.piso_step(dt, corrector_steps=1, advection_tol=1e-7, pressure_tol=1e-5, raise_on_failure=False, max_iterations=600)
+    _assembly_parity(dom, d, states, dt, B, check_div=True)
+    dom.close()
+
+
+def test_cg_on_a_skewed_mesh_returns_its_best_iterate():
+    """pressure_return_best_result=True (cylinder_env_base.py:318): a CG solve that stalls on the non-symmetric matrix ends
+    with the best iterate it saw, not with whatever the recurrence drifted to."""
+    spec = H.twisted_ring()
+    d = spec.oracle()
+    dom = spec.native(batch=1)
+    st = [_state(d, 3)]
+    _load(dom, st)
+    with pytest.raises(Exception, match="status -5"):
+        dom.piso_step(0.05, pressure_tol=1e-7, max_iterations=3000)
+    assert torch.isfinite(dom.velocity).all() and torch.isfinite(dom.pressure).all()
+    u_ref, _ = d.piso_step(st[0][0], st[0][1], 0.05)
+    assert float(dom.velocity.abs().max()) < 3.0 * np.abs(u_ref).max()
+    dom.close()
+
+
+def test_inactive_env_is_untouched_and_batch_is_independent():
+    spec = H.skewed_pair()
+    d = spec.oracle()
+    dom = spec.native(batch=3)
+    st = [_state(d, 5 + b) for b in range(3)]
+    for b in range(3):
+        dom.velocity[b] = torch.as_tensor(st[b][0], dtype=torch.float32)
+        dom.pressure[b] = torch.as_tensor(st[b][1], dtype=torch.float32)
+    before = dom.velocity.clone()
+    dom.piso_step([0.04, 0.0, 0.04], advection_tol=1e-7, pressure_tol=2e-6, pressure_use_bicgstab=True)
+    assert torch.equal(dom.velocity[1], before[1])
+    solo = spec.native(batch=1)
+    solo.velocity[0] = torch.as_tensor(st[2][0], dtype=torch.float32)
+    solo.pressure[0] = torch.as_tensor(st[2][1], dtype=torch.float32)
+    solo.piso_step(0.04, advection_tol=1e-7, pressure_tol=2e-6, pressure_use_bicgstab=True)
+    assert _rel(dom.velocity[2].cpu().numpy(), solo.velocity[0].cpu().numpy()) < 1e-5
+    dom.close(); solo.close()
+
+
+def test_reference_quirks_can_be_switched_off():
+    """Without the reference's first-layer rule the predictor keeps a uniform stream on a skewed mesh (see
+    tests/test_mb_oracle.py::test_flux_balance_of_a_uniform_stream_over_connections)."""
+    from fluidgym_amd import _lib as L
+
+    spec = H.skewed_pair(wobble=0.0, stretch=1.0)  # uniform parallelograms: cell and boundary-face metrics coincide
+    uc = np.array([0.6, -0.25])
+    spec.fixed = []
+    o = spec.oracle()
+    for b, blk in enumerate(o.blocks):
+        for f in range(4):
+            if blk.bounds[f].type == "fixed":
+                spec.fixed.append((b, f, np.repeat(uc[:, None], blk.bounds[f].velocity.shape[1], axis=1)))
+    dom = spec.native(batch=1, reference_quirks=False)
+    dom.velocity[0] = torch.as_tensor(np.repeat(uc[:, None], dom.n_cells, axis=1), dtype=torch.float32)
+    dom.piso_step(0.05, corrector_steps=0, advection_tol=1e-8)
+    ustar = dom.buffer(L.FG_MB_BUF_VELOCITY_RESULT).view(2, -1).cpu().numpy()
+    assert np.abs(ustar - uc[:, None]).max() < 2e-5
+    dom.close()
