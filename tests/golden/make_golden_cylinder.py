@@ -1,0 +1,114 @@
+"""Golden fixture of the reference's cylinder (vortex street) mesh: vertex coordinates of the five blocks, the
+connection / boundary calls and the inflow profile, recorded from the reference's own
+``envs/cylinder/grid.py::make_vortex_street_domain`` running HERE against a recording stand-in for the CUDA-only
+``PISOtorch`` module (the stand-in only logs the construction calls; no reference source is copied).
+
+    python tests/golden/make_golden_cylinder.py
+
+Pins ``fluidgym_amd/envs/cylinder_grid.py`` (tests/test_cylinder_grid.py).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Bound:
+    def __init__(self, log, block, face):
+        self.log, self.block, self.face = log, block, face
+
+    def setVelocity(self, v):
+        self.log.append(("velocity", self.block, self.face, v.detach().cpu().numpy().copy()))
+
+    def makeVelocityVarying(self):
+        self.log.append(("varying", self.block, self.face))
+
+
+class _Block:
+    def __init__(self, log, idx, coords, name):
+        self.log, self.idx, self.name = log, idx, name
+        log.append(("block", idx, name, coords.detach().cpu().numpy().copy()))
+
+    def CloseBoundary(self, face):
+        self.log.append(("close", self.idx, face))
+
+    def getBoundary(self, face):
+        return _Bound(self.log, self.idx, face)
+
+    def ConnectBlock(self, face, other, other_face, *axes):
+        self.log.append(("connect", self.idx, face, other.idx, other_face) + tuple(axes))
+
+    def MakePeriodic(self, axis):
+        self.log.append(("periodic", self.idx, axis))
+
+
+class _Domain:
+    def __init__(self, ndims, viscosity, name="", device=None, dtype=None, passiveScalarChannels=0):
+        self.log = []
+        self.n = 0
+
+    def CreateBlock(self, vertexCoordinates=None, name=""):
+        b = _Block(self.log, self.n, vertexCoordinates, name)
+        self.n += 1
+        return b
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    # package skeleton so that the reference file's absolute imports resolve without running fluidgym/__init__
+    for pkg in ["fluidgym", "fluidgym.simulation", "fluidgym.simulation.pict", "fluidgym.simulation.pict.data",
+                "fluidgym.simulation.pict.util", "fluidgym.envs", "fluidgym.envs.util"]:
+        _stub(pkg).__path__ = []
+    _stub("fluidgym.simulation.extensions", PISOtorch=types.SimpleNamespace(Domain=_Domain))
+    _stub("fluidgym.simulation.pict.util.output", plot_grids=lambda *a, **k: None)
+    shapes = _load(f"{REF}/fluidgym/simulation/pict/data/shapes.py", "fluidgym.simulation.pict.data.shapes")
+    sys.modules["fluidgym.simulation.pict.data"].shapes = shapes
+    _load(f"{REF}/fluidgym/envs/util/profiles.py", "fluidgym.envs.util.profiles")
+    grid = _load(f"{REF}/fluidgym/envs/cylinder/grid.py", "ref_cylinder_grid")
+
+    out = {}
+    for res in (8, 24):
+        # arguments of CylinderEnvBase._get_domain (envs/cylinder/cylinder_env_base.py:233-252)
+        dom = grid.make_vortex_street_domain(
+            ndims=2, viscosity=torch.tensor([0.01]), domain_height=4.1, domain_length=22.0, cylinder_radius=0.5,
+            cylinder_offset_y=0.05, circle_thickness=0.5, quad_thickness_x=1.0, circle_resolution_angular=res,
+            vortex_street_refinement_base=0.95, vortex_street_refinement_axes=["+y", "-y"],
+            cuda_device=torch.device("cpu"), dtype=torch.float32)
+        calls = []
+        for rec in dom.log:
+            if rec[0] == "block":
+                out[f"r{res}_block{rec[1]}"] = rec[3][0]
+                calls.append(f"block {rec[1]} {rec[2]}")
+            elif rec[0] == "velocity":
+                out[f"r{res}_velocity_{rec[1]}_{rec[2]}"] = rec[3]
+                calls.append(f"velocity {rec[1]} {rec[2]}")
+            else:
+                calls.append(" ".join(str(x) for x in rec))
+        out[f"r{res}_calls"] = np.array(calls)
+    np.savez_compressed(os.path.join(OUT, "reference_cylinder_grid.npz"), **out)
+    for k, v in out.items():
+        print(k, v.shape if v.dtype.kind != "U" else list(v))
+
+
+if __name__ == "__main__":
+    main()

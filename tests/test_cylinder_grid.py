@@ -1,0 +1,46 @@
+"""The cylinder mesh builder against vectors recorded from the reference's own make_vortex_street_domain
+(tests/golden/make_golden_cylinder.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from fluidgym_amd.envs.cylinder_grid import make_vortex_street_mesh
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_cylinder_grid.npz"))
+
+
+@pytest.mark.parametrize("res", [8, 24])
+def test_vertex_coordinates_match_reference(res):
+    m = make_vortex_street_mesh(res)
+    for b in range(5):
+        ref = G[f"r{res}_block{b}"]
+        assert m.coords[b].shape == ref.shape, (b, m.coords[b].shape, ref.shape)
+        assert np.abs(m.coords[b] - ref).max() < 2e-6, b
+    # neighbouring blocks share their interface vertices exactly enough for a watertight mesh
+    left, top = m.coords[0], m.coords[1]
+    assert np.abs(left[:, -1, :] - top[:, ::-1, 0]).max() < 1e-6
+
+
+@pytest.mark.parametrize("res", [8, 24])
+def test_boundaries_and_connections_match_reference_calls(res):
+    m = make_vortex_street_mesh(res)
+    calls = [str(c) for c in G[f"r{res}_calls"]]
+    closed = {(int(c.split()[1]), c.split()[2]) for c in calls if c.startswith("close")}
+    assert closed == set(m.fixed.keys())
+    conns = [tuple(c.split()[1:]) for c in calls if c.startswith("connect")]
+    assert conns == [(str(a), fa, str(b), fb, ax) for a, fa, b, fb, ax in m.connections]
+    assert [c.split()[2] for c in calls if c.startswith("block")] == m.names
+    assert "varying 4 +x" in calls and m.outflow == (4, "+x")
+    inflow = G[f"r{res}_velocity_0_-x"][0, :, :, 0]
+    assert np.abs(m.fixed[(0, "-x")] - inflow).max() < 1e-6
+    assert np.abs(m.fixed[(4, "+x")] - G[f"r{res}_velocity_4_+x"][0, :, :, 0]).max() < 1e-6
+
+
+def test_cells_are_right_handed():
+    from oracle.piso_oracle import coords_to_transforms
+
+    m = make_vortex_street_mesh(8)
+    for c in m.coords:
+        _, _, det = coords_to_transforms(c.astype(np.float64))
+        assert det.min() > 0
