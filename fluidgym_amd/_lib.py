@@ -81,6 +81,22 @@ class FgMbStepOptions(Structure):
     ]
 
 
+class FgMbSimOptions(Structure):
+    _fields_ = [
+        ("step", FgMbStepOptions),
+        ("time_step", c_float),
+        ("cfl", c_float),
+        ("adaptive", c_int32),
+        ("substeps", c_int32),
+        ("flux_balance_tol", c_float),
+        ("outflow_slot0", c_int32),
+        ("outflow_count", c_int32),
+        ("outflow_velm", c_float * 3),
+        ("outflow_tol", c_float),
+        ("max_substeps", c_int32),
+    ]
+
+
 (FG_MB_BUF_A, FG_MB_BUF_C_OFF, FG_MB_BUF_RHS, FG_MB_BUF_H, FG_MB_BUF_DIV, FG_MB_BUF_P_DIAG, FG_MB_BUF_P_OFF,
  FG_MB_BUF_VELOCITY_RESULT) = range(8)
 
@@ -166,6 +182,12 @@ SIGNATURES = {
     "fg_mb_max_velocity": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
     "fg_mb_get_buffer": (c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64)]),
     "fg_mb_read_buffer": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "fg_mb_single_step": (c_int, [c_void_p, POINTER(FgMbSimOptions), POINTER(c_int32), POINTER(c_float), c_void_p]),
+    "fg_mb_update_advective_boundary": (c_int, [c_void_p, c_float, c_int32, c_int32, POINTER(c_float), c_float, c_void_p]),
+    "fg_mb_make_divergence_free": (c_int, [c_void_p, POINTER(FgMbStepOptions), c_void_p]),
+    "fg_mb_boundary_flux_balance": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
+    "fg_mb_get_boundary_tables": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float)]),
+    "fg_mb_get_cell_transforms": (c_int, [c_void_p, POINTER(c_float)]),
 }
 
 _lib = None

@@ -88,6 +88,8 @@ struct fg_mb_state {
     fg_solve_info *info_dev, *info_pinned = nullptr;
     float* red;        // [B] reductions (mean, max)
     float* red_pinned = nullptr;
+    float *red2, *dt_dev;          // [2B] boundary flux sums, [B] time steps of the running substep
+    float *red2_pinned = nullptr, *dt_pinned = nullptr;
     std::string err;
 };
 

@@ -583,6 +583,65 @@ __global__ void k_mbs_restore_best(int N, MbSolve q) {
     if (i == 0) { q.info[sys].final_residual = q.sc[sys * 2]; q.info[sys].used_iterations = q.best_it[sys]; }
 }
 
+// ---- boundary bookkeeping of Simulation.single_step (simulation.py:206-280) on the flat boundary slots --------------
+// update_advective_boundaries (PISOtorch_simulation.py:228-393): u_b <- u_b - t (u_b - u_cell), t = 1 - 1/(1 + 2 dt Minv_b[axis].velm)
+template <int DIMS>
+__global__ void k_mb_outflow(MbDev D, const float* __restrict__ dt, const float* __restrict__ u, float* __restrict__ ub,
+                             int slot0, int count, float v0, float v1, float v2) {
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count || !mb_active(dt, b)) return;
+    const int sl = slot0 + k;
+    const float* t = D.Tb + (size_t)sl * (DIMS * DIMS + 1);
+    const int axis = D.bface[sl] >> 1;
+    const float velm[3] = {v0, v1, v2};
+    float adv = 0.f;
+#pragma unroll
+    for (int c = 0; c < DIMS; ++c) adv += t[axis * DIMS + c] * velm[c];
+    const float w = 1.f - 1.f / (1.f + 2.f * dt[b] * adv);
+    const int cell = D.bcell[sl];
+#pragma unroll
+    for (int c = 0; c < DIMS; ++c) {
+        const size_t q = ((size_t)b * DIMS + c) * D.NB + sl;
+        ub[q] -= w * (ub[q] - u[((size_t)b * DIMS + c) * D.N + cell]);
+    }
+}
+// signed boundary fluxes (get_fixed_boundary_fluxes, :88-105): out[b][0] = slots outside [slot0, slot0+count), out[b][1] = inside
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_bflux(MbDev D, const float* __restrict__ ub, int slot0, int count,
+                                                        float* __restrict__ out) {
+    const int b = blockIdx.x;
+    float fx = 0.f, fr = 0.f;
+    for (int sl = threadIdx.x; sl < D.NB; sl += FG_BLOCK) {
+        const float* t = D.Tb + (size_t)sl * (DIMS * DIMS + 1);
+        const int f = D.bface[sl], axis = f >> 1;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DIMS; ++c) s += t[axis * DIMS + c] * ub[((size_t)b * DIMS + c) * D.NB + sl];
+        s *= t[DIMS * DIMS] * ((f & 1) ? 1.f : -1.f);
+        if (sl >= slot0 && sl < slot0 + count) fr += s; else fx += s;
+    }
+    __shared__ float lds[4];
+    fx = mb_block_sum(fx, lds);
+    fr = mb_block_sum(fr, lds);
+    if (threadIdx.x == 0) { out[2 * b] = fx; out[2 * b + 1] = fr; }
+}
+// balance_boundary_fluxes (:188-224): scale the free boundary so that the total flux vanishes
+template <int DIMS>
+__global__ void k_mb_balance(MbDev D, const float* __restrict__ dt, const float* __restrict__ sums, float atol,
+                             float* __restrict__ ub, int slot0, int count) {
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count || !mb_active(dt, b)) return;
+    const float fx = sums[2 * b], fr = sums[2 * b + 1];
+    if (fabsf(fx + fr) <= atol) return;
+    const float scale = -fx / fr;
+#pragma unroll
+    for (int c = 0; c < DIMS; ++c) ub[((size_t)b * DIMS + c) * D.NB + slot0 + k] *= scale;
+}
+__global__ void k_mb_fill(size_t n, float v, float* __restrict__ x) {
+    const size_t i = (size_t)blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
 #define MB_DISPATCH(s, ...)                    \
     do {                                       \
         if ((s)->d == 2) { constexpr int DIMS = 2; __VA_ARGS__ } \
@@ -709,6 +768,8 @@ extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (s->info_pinned) (void)hipHostFree(s->info_pinned);
     if (s->red_pinned) (void)hipHostFree(s->red_pinned);
     if (s->flags_pinned) (void)hipHostFree(s->flags_pinned);
+    if (s->red2_pinned) (void)hipHostFree(s->red2_pinned);
+    if (s->dt_pinned) (void)hipHostFree(s->dt_pinned);
     delete s;
     return FG_OK;
 }
@@ -808,8 +869,12 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->info_dev, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->red, B)) return rc;
     if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
+    if (int rc = mb_alloc(s, &s->red2, 2 * B)) return rc;
+    if (int rc = mb_alloc(s, &s->dt_dev, B)) return rc;
     FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(float) * B, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->red2_pinned, sizeof(float) * 2 * B, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(float) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->flags_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
     s->finalized = true;
     return FG_OK;
@@ -916,6 +981,158 @@ extern "C" int fg_mb_max_velocity(fg_mb_handle s, float* out_B_host, void* strea
     FG_HIP_CHECK(hipMemcpyAsync(s->red_pinned, s->red, sizeof(float) * s->B, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < s->B; ++b) out_B_host[b] = s->red_pinned[b];
+    return FG_OK;
+}
+
+static int mb_outflow_pre(fg_mb_state* s, const float* dt_dev, int slot0, int count, const float* velm, float tol, hipStream_t st) {
+    const dim3 g((count + 63) / 64, s->B);
+    MB_DISPATCH(s, {
+        hipLaunchKernelGGL(k_mb_outflow<DIMS>, g, dim3(64), 0, st, s->dev, dt_dev, s->velocity, s->bvel, slot0, count, velm[0], velm[1], velm[2]);
+        hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, slot0, count, s->red2);
+        hipLaunchKernelGGL(k_mb_balance<DIMS>, g, dim3(64), 0, st, s->dev, dt_dev, s->red2, 0.01f * tol, s->bvel, slot0, count);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+// update_advective_boundaries + balance_boundary_fluxes for one FIXED face with the same dt for every env (the PRE hook as
+// make_divergence_free runs it, with time_step = 1: PISOtorch_simulation.py:1334-1345)
+extern "C" int fg_mb_update_advective_boundary(fg_mb_handle s, float dt, int32_t slot0, int32_t count, const float* velm, float tol,
+                                               void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity && velm, FG_ERR_NOT_BOUND, "fg_mb_update_advective_boundary: fields not bound");
+    FG_REQUIRE(slot0 >= 0 && count > 0 && slot0 + count <= s->NB, FG_ERR_INVALID_ARG, "fg_mb_update_advective_boundary: slots out of range");
+    hipStream_t st = (hipStream_t)stream;
+    for (int b = 0; b < s->B; ++b) s->dt_pinned[b] = dt;
+    FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * s->B, hipMemcpyHostToDevice, st));
+    if (int rc = mb_outflow_pre(s, s->dt_dev, slot0, count, velm, tol, st)) return rc;
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    return FG_OK;
+}
+
+static bool mb_close_zero(double v) { return std::fabs(v) <= 1e-8; }  // np.isclose(v, 0) defaults
+
+extern "C" int fg_mb_boundary_flux_balance(fg_mb_handle s, float* out_B_host, void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_boundary_flux_balance: fields not bound");
+    hipStream_t st = (hipStream_t)stream;
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, 0, 0, s->red2););
+    FG_HIP_CHECK(hipMemcpyAsync(s->red2_pinned, s->red2, sizeof(float) * 2 * s->B, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < s->B; ++b) out_B_host[b] = s->red2_pinned[2 * b] + s->red2_pinned[2 * b + 1];
+    return FG_OK;
+}
+
+extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int32_t* out, float* flux_host, void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity, FG_ERR_NOT_BOUND, "fg_mb_single_step: fields not bound");
+    FG_REQUIRE(o && out, FG_ERR_INVALID_ARG, "fg_mb_single_step: null argument");
+    FG_REQUIRE(o->outflow_count == 0 || (o->outflow_slot0 >= 0 && o->outflow_slot0 + o->outflow_count <= s->NB), FG_ERR_INVALID_ARG,
+               "fg_mb_single_step: outflow slots out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->B;
+    // flux-balance guard (simulation.py:221-229)
+    {
+        std::vector<float> fl(B);
+        if (int rc = fg_mb_boundary_flux_balance(s, fl.data(), stream)) return rc;
+        float worst = 0.f;
+        for (int b = 0; b < B; ++b) {
+            if (flux_host) flux_host[b] = fl[b];
+            const float a = std::fabs(fl[b]);
+            worst = (a > worst || a != a) ? a : worst;
+        }
+        if (!(worst <= o->flux_balance_tol)) {
+            fg_set_error("Domain boundary fluxes not balanced, cannot proceed with simulation step.");
+            return FG_ERR_FLUX_BALANCE;
+        }
+    }
+    std::vector<double> t_rem(B, (double)o->time_step);
+    std::vector<float> mv(B, 0.f);
+    int32_t stats[4] = {-1, -1, -1, -1};
+    int substeps = 0, all_ok = 1;
+    int fixed_left = o->adaptive ? 0 : (o->substeps > 0 ? o->substeps : 1);
+    for (;;) {
+        bool any = false;
+        if (o->adaptive) for (int b = 0; b < B; ++b) any = any || (t_rem[b] > 0 && !mb_close_zero(t_rem[b]));
+        else any = fixed_left > 0;
+        if (!any) break;
+        if (o->adaptive)
+            if (int rc = fg_mb_max_velocity(s, mv.data(), stream)) return rc;
+        // _PISO_adaptive_step (PISOtorch_simulation.py:2004-2064): ts = t_rem / ceil(t_rem / (CFL / max_vel)), per env
+        for (int b = 0; b < B; ++b) {
+            float ts = 0.f;
+            if (!o->adaptive) {
+                ts = o->time_step / (float)(o->substeps > 0 ? o->substeps : 1);
+            } else if (t_rem[b] > 0 && !mb_close_zero(t_rem[b])) {
+                const double max_ts = mb_close_zero(mv[b]) ? t_rem[b] : (double)o->cfl / (double)mv[b];
+                const double tsd = (max_ts >= t_rem[b]) ? t_rem[b] : t_rem[b] / (double)(long long)std::ceil(t_rem[b] / max_ts);
+                t_rem[b] -= tsd;
+                ts = (float)tsd;
+            }
+            s->dt_pinned[b] = ts;
+        }
+        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * B, hipMemcpyHostToDevice, st));
+        if (o->outflow_count > 0)  // PRE hook of the cylinder / airfoil envs (cylinder_env_base.py:280-300)
+            if (int rc = mb_outflow_pre(s, s->dt_dev, o->outflow_slot0, o->outflow_count, o->outflow_velm, o->outflow_tol, st)) return rc;
+        const int rc = fg_mb_piso_step(s, s->dt_dev, &o->step, stats, stream);
+        if (rc == FG_ERR_NOT_CONVERGED) all_ok = 0;
+        else if (rc != FG_OK) return rc;
+        FG_HIP_CHECK(hipStreamSynchronize(st));  // dt_pinned is rewritten next round
+        ++substeps;
+        if (!o->adaptive) --fixed_left;
+        if (substeps >= (o->max_substeps > 0 ? o->max_substeps : 100000)) break;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = stats[i];
+    out[4] = substeps;
+    out[5] = all_ok;
+    return FG_OK;
+}
+
+// Simulation.make_divergence_free (PISOtorch_simulation.py:1318-1429): one projection with A = 1, dt = 1, h = u
+extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_options* opt, void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity && opt, FG_ERR_NOT_BOUND, "fg_mb_make_divergence_free: fields not bound");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->B, N = s->N, d = s->d, NB = s->NB;
+    const int cells = std::max(N, NB);
+    const dim3 blk(FG_BLOCK), gc((cells + FG_BLOCK - 1) / FG_BLOCK, B), gn((N + FG_BLOCK - 1) / FG_BLOCK, B);
+    const size_t vel_env = (size_t)d * N, BN = (size_t)B * N;
+    const dim3 gcopy((unsigned)((vel_env + FG_BLOCK - 1) / FG_BLOCK), B);
+    const MbDev& D = s->dev;
+    int soft_rc = FG_OK;
+    hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), blk, 0, st, BN, 1.f, s->rA);
+    hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, (const float*)nullptr, s->velocity, s->hvec);
+    MB_DISPATCH(s, {
+        hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, (const float*)nullptr, s->hvec, s->bvel, s->cc, s->fb);
+        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->Pdiag, s->Poff);
+        for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
+            hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
+            int m = 0;
+            const int prc = opt->pressure_use_bicgstab
+                                ? mb_bicgstab(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st)
+                                : mb_cg(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st);
+            if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;
+            else if (prc != FG_OK) return prc;
+            FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
+            hipLaunchKernelGGL(k_mb_sum, dim3(8, B), blk, 0, st, N, (const float*)nullptr, s->pres, s->red);
+            hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, (const float*)nullptr, s->red, s->pres, s->pressure);
+        }
+        hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->hvec, s->pressure, s->velocity);
+    });
+    FG_HIP_CHECK(hipGetLastError());
+    return soft_rc;
+}
+
+// host copies of the boundary-slot tables: owner cell, face, Minv | det
+extern "C" int fg_mb_get_boundary_tables(fg_mb_handle s, int32_t* cell, int32_t* face, float* transform) {
+    FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_get_boundary_tables: domain not finalized");
+    const int tw = s->d * s->d + 1;
+    for (int k = 0; k < s->NB; ++k) {
+        if (cell) cell[k] = s->h_bcell[k];
+        if (face) face[k] = s->h_bface[k];
+        if (transform) for (int q = 0; q < tw; ++q) transform[(size_t)k * tw + q] = s->h_Tb[(size_t)k * tw + q];
+    }
+    return FG_OK;
+}
+extern "C" int fg_mb_get_cell_transforms(fg_mb_handle s, float* transform /* [N][d*d+1] Minv | det */) {
+    FG_REQUIRE(s && s->finalized && transform, FG_ERR_INVALID_ARG, "fg_mb_get_cell_transforms: bad argument");
+    std::copy(s->h_T.begin(), s->h_T.end(), transform);
     return FG_OK;
 }
 

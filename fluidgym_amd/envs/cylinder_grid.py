@@ -160,3 +160,17 @@ def make_vortex_street_mesh(resolution: int, domain_height: float = 4.1, domain_
                    (RIGHT, "-y", BOTTOM, "+x", "+y"), (RIGHT, "+x", WAKE, "-x", "-y")]
     names = ["BlockCylinderLeft", "BlockCylinderTop", "BlockCylinderRight", "BlockCylinderBottom", "BlockVortexStreet"]
     return CylinderMesh([f32(left), f32(top), f32(right), f32(bottom), wake], names, fixed, connections)
+
+
+def build_domain(mesh: CylinderMesh, viscosity: float, batch: int = 1, device=None, reference_quirks: bool = True):
+    """The mesh as a ``MultiBlockDomain`` on the GPU (``make_vortex_street_domain`` + ``PrepareSolve``)."""
+    from ..simulation.multiblock import MultiBlockDomain
+
+    dom = MultiBlockDomain(2, viscosity, batch=batch, device=device, reference_quirks=reference_quirks)
+    blocks = [dom.CreateBlock(c, name=n) for c, n in zip(mesh.coords, mesh.names)]
+    for (b, face), vel in mesh.fixed.items():
+        blocks[b].CloseBoundary(face, vel)
+    for b1, f1, b2, f2, ax in mesh.connections:
+        blocks[b1].ConnectBlock(f1, blocks[b2], f2, ax)
+    dom.PrepareSolve()
+    return dom

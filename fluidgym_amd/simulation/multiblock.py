@@ -207,6 +207,82 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_read_buffer(self.handle, which, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st)))
         return out
 
+    # ---- Simulation.single_step / make_divergence_free
+    def boundary_flux_balance(self) -> np.ndarray:
+        out = (ctypes.c_float * self.batch)()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fg_mb_boundary_flux_balance(self.handle, out, ctypes.c_void_p(st)))
+        return np.array(out[:], dtype=np.float32)
+
+    def boundary_tables(self):
+        """(owner cell [NB], face [NB], Minv|det [NB, d*d+1]) of the boundary slots (host arrays)."""
+        nb, tw = self.n_boundary_faces, self.dims * self.dims + 1
+        cell = np.zeros(max(nb, 1), np.int32)
+        face = np.zeros(max(nb, 1), np.int32)
+        T = np.zeros((max(nb, 1), tw), np.float32)
+        i32, f32 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)
+        L.check(self.lib.fg_mb_get_boundary_tables(self.handle, cell.ctypes.data_as(i32), face.ctypes.data_as(i32),
+                                                   T.ctypes.data_as(f32)))
+        return cell[:nb], face[:nb], T[:nb]
+
+    def cell_transforms(self) -> np.ndarray:
+        T = np.zeros((self.n_cells, self.dims * self.dims + 1), np.float32)
+        L.check(self.lib.fg_mb_get_cell_transforms(self.handle, T.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return T
+
+    def _step_options(self, corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
+                      pressure_tol, max_iterations, pressure_use_bicgstab):
+        return L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
+                                 advection_tol, pressure_tol, int(pressure_use_bicgstab))
+
+    def _outflow_slots(self, outflow):
+        blk, face = outflow
+        blk = blk if isinstance(blk, MBBlock) else self.blocks[blk]
+        f = face_index(face)
+        if blk.boundary_slot0[f] < 0:
+            raise ValueError("the outflow face must be a FIXED boundary")
+        return blk.boundary_slot0[f], blk.face_cells(f)
+
+    def update_advective_boundary(self, dt: float, outflow, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
+                                  tol: float = 5e-6):
+        """``update_advective_boundaries`` + ``balance_boundary_fluxes`` for one face (the envs' PRE hook)."""
+        s0, n = self._outflow_slots(outflow)
+        v = (ctypes.c_float * 3)(*(list(outflow_velocity) + [0.0] * 3)[:3])
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fg_mb_update_advective_boundary(self.handle, float(dt), s0, n, v, float(tol), ctypes.c_void_p(st)))
+
+    def make_divergence_free(self, pressure_tol: float = 1e-5, max_iterations: int = 1000, pressure_non_ortho_steps: int = 1,
+                             pressure_use_bicgstab: bool = False, outflow=None,
+                             outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0), outflow_tol: float = 5e-6) -> bool:
+        if outflow is not None:  # PRE hook with time_step = 1 (PISOtorch_simulation.py:1334-1345)
+            self.update_advective_boundary(1.0, outflow, outflow_velocity, outflow_tol)
+        opt = self._step_options(1, 1, pressure_non_ortho_steps, 1e-5, pressure_tol, max_iterations, pressure_use_bicgstab)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.fg_mb_make_divergence_free(self.handle, ctypes.byref(opt), ctypes.c_void_p(st))
+        L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED,))
+        return rc == L.FG_OK
+
+    def single_step(self, time_step: float, cfl: float = 0.8, adaptive: bool = True, substeps: int = 1, outflow=None,
+                    outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0), outflow_tol: float = 5e-6,
+                    flux_balance_tol: float = 1e-5, corrector_steps: int = 2, advect_non_ortho_steps: int = 1,
+                    pressure_non_ortho_steps: int = 1, advection_tol: float = 1e-5, pressure_tol: float = 1e-5,
+                    max_iterations: int = 5000, pressure_use_bicgstab: bool = False, max_substeps: int = 0):
+        """``Simulation.single_step`` on the native side.  ``outflow``: (block, face) of the FIXED face that follows the
+        convective outflow condition.  Returns (substeps, all solves converged, max iterations of the last substep)."""
+        o = L.FgMbSimOptions()
+        o.step = self._step_options(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
+                                    pressure_tol, max_iterations, pressure_use_bicgstab)
+        o.time_step, o.cfl, o.adaptive, o.substeps = float(time_step), float(cfl), int(adaptive), int(substeps)
+        o.flux_balance_tol, o.outflow_tol, o.max_substeps = float(flux_balance_tol), float(outflow_tol), int(max_substeps)
+        if outflow is not None:
+            o.outflow_slot0, o.outflow_count = self._outflow_slots(outflow)
+        v = list(outflow_velocity) + [0.0] * 3
+        o.outflow_velm[0], o.outflow_velm[1], o.outflow_velm[2] = v[0], v[1], v[2]
+        out = (ctypes.c_int32 * 6)()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fg_mb_single_step(self.handle, ctypes.byref(o), out, None, ctypes.c_void_p(st)))
+        return out[4], bool(out[5]), (out[1], out[2], out[3])
+
     def close(self):
         if self.handle:
             self.lib.fg_mb_destroy(self.handle)

@@ -336,6 +336,35 @@ typedef struct fg_mb_step_options {
  * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
  * solve failed (fields still updated, as with returnBestResult), other negative codes on errors. */
 int fg_mb_piso_step(fg_mb_handle h, const float* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream);
+/* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps
+ * (_PISO_adaptive_step, PISOtorch_simulation.py:2004-2064), the advective-outflow PRE hook on ONE FIXED face given as
+ * a range of boundary slots (update_advective_boundaries + balance_boundary_fluxes, :188-393; count 0 = none) and
+ * fg_mb_piso_step per substep.  out_host as for fg_single_step: [0..3] max solver iterations of the last substep,
+ * [4] substeps taken, [5] 1 if every solve converged; flux_host (optional, [B]) the boundary flux balance found. */
+typedef struct fg_mb_sim_options {
+    fg_mb_step_options step;
+    float time_step;
+    float cfl;
+    int32_t adaptive;          /* 1: substeps from the CFL condition; 0: `substeps` equal steps */
+    int32_t substeps;
+    float flux_balance_tol;
+    int32_t outflow_slot0;
+    int32_t outflow_count;
+    float outflow_velm[3];     /* characteristic velocity of the convective condition */
+    float outflow_tol;         /* tol of update_advective_boundaries (balance threshold = 0.01 tol) */
+    int32_t max_substeps;      /* safety bound, 0 = none */
+} fg_mb_sim_options;
+int fg_mb_single_step(fg_mb_handle h, const fg_mb_sim_options* opt, int32_t* out_host, float* flux_host, void* stream);
+/* the PRE hook alone, same dt for every env (make_divergence_free runs it with dt = 1, PISOtorch_simulation.py:1334-1345) */
+int fg_mb_update_advective_boundary(fg_mb_handle h, float dt, int32_t slot0, int32_t count, const float* velm, float tol, void* stream);
+/* Simulation.make_divergence_free (PISOtorch_simulation.py:1318-1429), without its PRE hook */
+int fg_mb_make_divergence_free(fg_mb_handle h, const fg_mb_step_options* opt, void* stream);
+/* Domain.GetBoundaryFluxBalance per env; synchronises */
+int fg_mb_boundary_flux_balance(fg_mb_handle h, float* out_B_host, void* stream);
+/* host copies of the mesh tables: per boundary slot the owner cell, its face and Minv | det of the face
+ * (k_CoordsToFaceTransforms, grid_gen.cu:398-470); per cell Minv | det (k_CoordsToTransforms, :298-354) */
+int fg_mb_get_boundary_tables(fg_mb_handle h, int32_t* cell, int32_t* face, float* transform);
+int fg_mb_get_cell_transforms(fg_mb_handle h, float* transform);
 /* max |Minv u| over cells and boundary faces per env (Domain.getMaxVelocity(True, True)); synchronises */
 int fg_mb_max_velocity(fg_mb_handle h, float* out_B_host, void* stream);
 #define FG_MB_BUF_A 0               /* [B,N]   diagonal of C */
