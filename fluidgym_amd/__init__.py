@@ -8,8 +8,8 @@ loaded on first use and its absence is an error (there is no CPU / PyTorch fallb
 
 Registered ids: the reference registers 39 ids (``fluidgym/__init__.py:28-352``).  The RBC and TCF
 families (single block, orthogonal) are registered under the reference's ids with the reference's
-defaults; the cylinder / airfoil families need multi-block curvilinear meshes and
-raise ``NotImplementedError`` pointing at the single-block stand-in ``ChannelJet2D-*``.
+defaults; the 2-D cylinder family runs on the multi-block curvilinear path (``envs/cylinder.py``); the
+3-D cylinder and the airfoil families raise ``NotImplementedError`` (meshes not built yet).
 """
 from __future__ import annotations
 
@@ -65,9 +65,14 @@ def _register_all():
                 register(f"TCF{size}3D-{act}-{level}-v0", ctor, cfg, reynolds_number_wall=re_tau)
     register("TCF3D-baseline-v0", tcf["both"], TS, resolution_x=128, resolution_z=64, resolution_y=64, L=2 * np.pi,
              D=np.pi)  # 128 x 64 x 64 (BASELINE config 4)
+    # reference ids (fluidgym/__init__.py:28-75): multi-block curvilinear mesh, non-orthogonal PISO
+    from .envs.cylinder import CYLINDER_JET_2D_DEFAULT_CONFIG as CJ, CYLINDER_ROT_2D_DEFAULT_CONFIG as CR
+    cj, cr = _lazy(".envs.cylinder", "CylinderJetEnv2D"), _lazy(".envs.cylinder", "CylinderRotEnv2D")
+    for level, re, res in (("easy", 100, 24), ("medium", 250, 32), ("hard", 500, 32)):
+        register(f"CylinderJet2D-{level}-v0", cj, CJ, reynolds_number=re, resolution=res)
+        register(f"CylinderRot2D-{level}-v0", cr, CR, reynolds_number=re, resolution=res)
     for fam, ids in {
-        "Cylinder": ["CylinderJet2D-easy-v0", "CylinderJet2D-medium-v0", "CylinderJet2D-hard-v0",
-                     "CylinderRot2D-easy-v0", "CylinderJet3D-easy-v0"],
+        "Cylinder": ["CylinderJet3D-easy-v0", "CylinderJet3D-medium-v0", "CylinderJet3D-hard-v0"],
         "Airfoil": ["Airfoil2D-easy-v0", "Airfoil2D-medium-v0", "Airfoil2D-hard-v0", "Airfoil3D-easy-v0"],
     }.items():
         for i in ids:

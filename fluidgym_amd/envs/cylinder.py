@@ -1,0 +1,270 @@
+"""Cylinder (von Karman vortex street) environments on the multi-block HIP path.
+
+Mirrors ``envs/cylinder/cylinder_env_base.py`` (CylinderEnvBase), ``jet_cylinder_env_2d.py`` (CylinderJetEnv2D) and
+``rotating_cylinder_env_2d.py`` (CylinderRotEnv2D) of the reference: the same five-block mesh (``cylinder_grid.py``,
+pinned on the reference's vertex coordinates), solver settings (:303-329), convective outflow hook (:276-300), 151
+velocity / pressure sensors read from the uniformly resampled fields (:430-518), drag / lift by wall-stress integration
+(:616-700, ``forces.py``), action smoothing and reward (:741-776).  Batched over ``num_envs`` like every env here.
+
+Not carried over: the published initial domains (HuggingFace ``fluidgym-data``; no network) -- ``reset`` starts from a
+projected uniform stream and runs ``initial_domain_steps`` developed-flow steps (the reference generates its initial
+domains with 400, :138) -- and the domain statistics (``_cd_ref`` is 0 unless ``drag_reference`` is given).  3-D
+variants (extruded mesh, z-periodic) are not built yet.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from ..simulation.multiblock import MultiBlockDomain, MultiBlockSimulation
+from ..simulation.resample_mb import MultiBlockResampler
+from .. import spaces
+from .channel import jet_profile
+from .cylinder_grid import BOTTOM, LEFT, RIGHT, TOP, build_domain, make_vortex_street_mesh
+from .fluid_env import FluidEnv
+from .forces import WallRing
+
+CYLINDER_JET_2D_DEFAULT_CONFIG = {
+    "reynolds_number": 1e2, "resolution": 24, "dt": 1e-2, "adaptive_cfl": 0.8, "step_length": 0.25,
+    "episode_length": 80, "lift_penalty": 1.0, "use_marl": False, "dtype": torch.float32,
+    "load_initial_domain": True, "load_domain_statistics": True, "randomize_initial_state": True,
+    "enable_actions": True, "differentiable": False,
+}
+CYLINDER_ROT_2D_DEFAULT_CONFIG = dict(CYLINDER_JET_2D_DEFAULT_CONFIG)
+
+
+class CylinderEnvBase(FluidEnv):
+    _supports_marl = False
+    _action_smoothing_alpha: float = 0.1
+    H: float = 4.1
+    L: float = 22.0
+    cylinder_diameter: float = 1.0
+    _U_mean: float = 1.0
+    cylinder_offset_y: float = 0.05
+    _n_sensors_x_y: int = 151
+    _vortex_street_refinement_base: float = 0.95
+    _metrics = ["drag", "lift"]
+    _initial_domain_steps = 400
+
+    def __init__(self, reynolds_number: float, resolution: int, dt: float, adaptive_cfl: float, step_length: float,
+                 episode_length: int, lift_penalty: float = 1.0, ndims: int = 2, initial_domain_steps: Optional[int] = None,
+                 drag_reference: float = 0.0, pressure_use_BiCG: bool = False, **kw):
+        if ndims != 2:
+            raise NotImplementedError("3-D cylinder envs (extruded mesh, periodic in z) are not built yet")
+        self._reynolds_number = reynolds_number
+        self._circle_resolution_angular = int(resolution)
+        self._lift_penalty = lift_penalty
+        self._nu = self._U_mean / reynolds_number
+        self._cd_ref = float(drag_reference)
+        self._pressure_use_bicg = pressure_use_BiCG
+        if initial_domain_steps is not None:
+            self._initial_domain_steps = int(initial_domain_steps)
+        super().__init__(dt=dt, adaptive_cfl=adaptive_cfl, step_length=step_length, episode_length=episode_length,
+                         ndims=2, **kw)
+        self._last_control = None
+        self._sensor_locations = self._get_sensor_locations()
+
+    # ---- spaces (cylinder_env_base.py:183-213)
+    def _get_action_space(self):
+        return spaces.Box(low=-1.0, high=1.0, shape=(1,), dtype=np.float32)
+
+    def _get_observation_space(self):
+        n = self._n_sensors_x_y
+        return spaces.Dict({
+            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=(n, 2), dtype=np.float32),
+            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=(n,), dtype=np.float32),
+        })
+
+    @property
+    def render_shape(self):
+        z_res = self._circle_resolution_angular * 4
+        return (int(z_res / self.H * self.L), z_res, z_res)
+
+    @property
+    def id(self) -> str:
+        return f"{type(self).__name__}_Re{self._reynolds_number}"
+
+    @property
+    def initial_domain_id(self) -> str:
+        return f"cylinder_2D_Re{int(self._reynolds_number)}_Res{self._circle_resolution_angular}"
+
+    # ---- sensors (cylinder_env_base.py:430-518)
+    def _get_sensor_locations_2d(self) -> np.ndarray:
+        xs, ys = np.arange(1.0, 5.0, 0.5), np.arange(-1.5, 1.75, 0.5)
+        gx, gy = np.meshgrid(xs, ys, indexing="ij")
+        main = np.stack([gx.ravel(), gy.ravel()])
+        x1 = np.arange(-0.25, 1, 0.25)
+        x2 = np.concatenate([[-0.25], np.arange(0.25, 1.25, 0.25)])
+        x3 = np.array([0.75] * 3)
+        extra = np.stack([np.concatenate([x1, x1, x2, x2, x3]),
+                          np.concatenate([np.full_like(x1, -1.5), np.full_like(x1, 1.5), np.full_like(x2, self.cylinder_diameter),
+                                          np.full_like(x2, -self.cylinder_diameter), np.array([-0.5, 0, 0.5])])])
+        ang = np.linspace(0, 2 * np.pi, 36)
+        c1 = 1.0 * np.stack([np.cos(ang), np.sin(ang)])
+        c2 = 0.625 * np.stack([np.cos(ang), np.sin(ang)])
+        return np.concatenate([main, c1, c2, extra], axis=1).astype(np.float32)
+
+    def _get_sensor_locations(self) -> np.ndarray:
+        """Pixel (x, y) of every sensor in the resampled field (``_sensor_locations_to_grid_coords``)."""
+        p = self._get_sensor_locations_2d().copy()
+        p[0] = (p[0] + np.float32(2.0)) * np.float32((self.render_shape[0] - 1) / (self.L - 2.0))
+        p[1] = (p[1] + np.float32(self.H / 2)) * np.float32((self.render_shape[1] - 1) / self.H)
+        return np.round(p).astype(np.int64)
+
+    # ---- domain and simulation (cylinder_env_base.py:233-329)
+    def _get_domain(self) -> MultiBlockDomain:
+        self._mesh = make_vortex_street_mesh(self._circle_resolution_angular, self.H, self.L, self.cylinder_diameter / 2,
+                                             self.cylinder_offset_y, self.cylinder_diameter / 2, self.cylinder_diameter,
+                                             self._vortex_street_refinement_base)
+        return build_domain(self._mesh, self._nu, batch=self._num_envs, device=self._cuda_device)
+
+    def _get_simulation(self, domain, prep_fn):
+        sim = MultiBlockSimulation(domain, dt=self._dt, adaptive_CFL=self._adaptive_cfl, substeps="ADAPTIVE", corrector_steps=2,
+                                   pressure_tol=1e-5, advect_non_ortho_steps=1, pressure_non_ortho_steps=1,
+                                   pressure_use_BiCG=self._pressure_use_bicg, outflow=self._mesh.outflow,
+                                   outflow_velocity=(self._U_mean, 0.0, 0.0), outflow_tol=5e-6)
+        return sim
+
+    def _additional_initialization(self) -> None:
+        dom = self._domain
+        self._ring = WallRing(dom, [(LEFT, "+x", False), (TOP, "-y", False), (RIGHT, "-x", True), (BOTTOM, "+y", True)])
+        self._resampler = MultiBlockResampler(self._mesh.coords, self.render_shape[:2], fill_max_steps=16, device=dom.device)
+        self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.T)
+        self._initial_boundary = dom.boundary_velocity.clone()  # inflow / outflow profile, walls at rest
+        self._last_control = torch.zeros(self._num_envs, 1, device=dom.device)
+
+    def _fill_initial_fields(self) -> None:
+        """Uniform stream projected onto the mesh, then ``initial_domain_steps`` uncontrolled steps (the reference ships
+        states generated with 400 steps, cylinder_env_base.py:138; they are cached per env instance here)."""
+        dom = self._domain
+        if getattr(self, "_developed", None) is None:
+            dom.boundary_velocity.copy_(self._initial_boundary)
+            dom.velocity.zero_()
+            dom.velocity[:, 0] = self._U_mean
+            dom.pressure.zero_()
+            self._sim.make_divergence_free()
+            for _ in range(self._initial_domain_steps):
+                self._sim.single_step()
+            self._developed = dom.Clone()
+        dom.Restore(self._developed)
+        self._last_control = torch.zeros(self._num_envs, 1, device=dom.device)
+
+    def _randomize_domain(self) -> None:
+        """cylinder_env_base.py:364-404."""
+        period = 1.0 / (0.3 * self._U_mean / self.cylinder_diameter)
+        max_n = 2 * int(period / self._step_length) - 1
+        n_steps = int(self._np_rng.integers(int(0.5 * max_n), max_n)) + 1
+        dom = self._domain
+        g = self._torch_rng_cuda
+        dom.velocity.add_(torch.randn(dom.velocity.shape, device=dom.device, generator=g) * 0.025)
+        dom.pressure.add_(torch.randn(dom.pressure.shape, device=dom.device, generator=g) * 0.025)
+        for _ in range(n_steps):
+            self._sim.single_step()
+
+    # ---- observations, forces, step (cylinder_env_base.py:541-776)
+    def _get_global_obs(self) -> Dict[str, torch.Tensor]:
+        dom = self._domain
+        u = (dom.velocity[:, :, self._sensor_idx] * self._sensor_w).sum(-1)   # [B, 2, S]
+        p = (dom.pressure[:, self._sensor_idx] * self._sensor_w).sum(-1)      # [B, S]
+        return {"velocity": u.permute(0, 2, 1).contiguous(), "pressure": p}
+
+    def get_velocity(self) -> torch.Tensor:
+        """Resampled velocity [B, 2, y, x] (``FluidEnv.get_velocity``)."""
+        return self._resampler(self._domain.velocity)
+
+    def get_pressure(self) -> torch.Tensor:
+        return self._resampler(self._domain.pressure)
+
+    def _get_drag_and_lift(self):
+        f = self._ring.forces(self._domain, self._nu)
+        norm = 0.5 * self._U_mean ** 2 * self.cylinder_diameter
+        return f[:, 0] / norm, f[:, 1] / norm
+
+    def _apply_action(self, action: torch.Tensor) -> None:
+        raise NotImplementedError
+
+    def _step_impl(self, action: torch.Tensor):
+        target = action.reshape(self._num_envs, 1)
+        cds, cls = [], []
+        for _ in range(self._n_sim_steps):
+            control = self._last_control + self._action_smoothing_alpha * (target - self._last_control)
+            self._last_control = control
+            if self._enable_actions:
+                self._apply_action(control)
+            self._sim.single_step()
+            cd, cl = self._get_drag_and_lift()
+            cds.append(cd); cls.append(cl)
+        obs = self._get_global_obs()
+        cd, cl = torch.stack(cds).mean(0), torch.stack(cls).mean(0)
+        reward = self._cd_ref - cd - self._lift_penalty * cl.abs()
+        return obs, reward, False, {"drag": cd, "lift": cl}
+
+    def _get_extra_state(self):
+        return {"last_control": self._last_control.clone()}
+
+    def _set_extra_state(self, extra) -> None:
+        if extra is not None:
+            self._last_control = extra["last_control"].clone()
+
+    def render(self, *a, **kw) -> np.ndarray:
+        return torch.linalg.vector_norm(self.get_velocity()[0], dim=0).detach().cpu().numpy()
+
+
+def _face_vertices(mesh, block: int, face: str) -> np.ndarray:
+    c = mesh.coords[block].astype(np.float64)
+    return {"+x": c[:, :, -1], "-x": c[:, :, 0], "-y": c[:, 0, :], "+y": c[:, -1, :]}[face]
+
+
+class CylinderJetEnv2D(CylinderEnvBase):
+    """Two synthetic jets at the poles of the cylinder, blowing / sucking with zero net mass flux
+    (jet_cylinder_env_2d.py:124-186)."""
+
+    _jet_angle: float = 10.0  # degrees
+
+    def _jet_velocities(self, boundary_vertices: np.ndarray, top: bool) -> np.ndarray:
+        centers = 0.5 * (boundary_vertices[:, :-1] + boundary_vertices[:, 1:])
+        base = np.pi / 2 if top else -np.pi / 2
+        deg = np.rad2deg(base - np.arctan2(centers[1], centers[0]))
+        mag = np.abs(deg)
+        mag[mag > self._jet_angle] = 0.0
+        nz = np.nonzero(mag > 0.0)[0]
+        lo, hi = nz[0] - 1, nz[-1] + 1
+        prof = jet_profile(int(hi - lo + 1))
+        vel = np.zeros_like(centers)
+        for i, u in zip(range(lo, hi + 1), prof):
+            vel[0, i] = u * np.sin(np.deg2rad(deg[i]))
+            vel[1, i] = u * np.cos(np.deg2rad(deg[i]))
+        return vel.astype(np.float32)
+
+    def _additional_initialization(self) -> None:
+        super()._additional_initialization()
+        dev = self._domain.device
+        self._top_velocity = torch.as_tensor(self._jet_velocities(_face_vertices(self._mesh, TOP, "-y"), True), device=dev)
+        self._bottom_velocity = torch.as_tensor(self._jet_velocities(_face_vertices(self._mesh, BOTTOM, "+y"), False), device=dev)
+
+    def _apply_action(self, action: torch.Tensor) -> None:
+        a = action.reshape(self._num_envs, 1, 1)
+        dom = self._domain
+        dom.blocks[TOP].boundary("-y").copy_(self._top_velocity[None] * a)
+        dom.blocks[BOTTOM].boundary("+y").copy_(self._bottom_velocity[None] * a)
+
+
+class CylinderRotEnv2D(CylinderEnvBase):
+    """The cylinder wall rotates with the commanded speed (rotating_cylinder_env_2d.py:121-176)."""
+
+    def _additional_initialization(self) -> None:
+        super()._additional_initialization()
+        dev = self._domain.device
+        self._wall = []
+        for b, face in ((LEFT, "+x"), (TOP, "-y"), (RIGHT, "-x"), (BOTTOM, "+y")):
+            v = _face_vertices(self._mesh, b, face)
+            ctr = 0.5 * (v[:, :-1] + v[:, 1:])
+            th = np.arctan2(ctr[1], ctr[0])
+            self._wall.append((b, face, torch.as_tensor(np.stack([np.sin(th), -np.cos(th)]).astype(np.float32), device=dev)))
+
+    def _apply_action(self, action: torch.Tensor) -> None:
+        a = action.reshape(self._num_envs, 1, 1)
+        for b, face, vel in self._wall:
+            self._domain.blocks[b].boundary(face).copy_(vel[None] * a)

@@ -283,6 +283,26 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_single_step(self.handle, ctypes.byref(o), out, None, ctypes.c_void_p(st)))
         return out[4], bool(out[5]), (out[1], out[2], out[3])
 
+    # ---- what FluidEnv needs of a Domain
+    def Clone(self) -> dict:
+        return {"velocity": self.velocity.clone(), "pressure": self.pressure.clone(),
+                "boundary_velocity": self.boundary_velocity.clone()}
+
+    def Restore(self, snap: dict) -> None:
+        self.velocity.copy_(snap["velocity"])
+        self.pressure.copy_(snap["pressure"])
+        self.boundary_velocity.copy_(snap["boundary_velocity"])
+
+    @property
+    def solver(self):
+        return self
+
+    def reset_solver_state(self) -> None:
+        """Nothing is carried between steps besides the bound fields (the pressure result IS the pressure field)."""
+
+    def getBlock(self, i: int) -> MBBlock:
+        return self.blocks[i]
+
     def close(self):
         if self.handle:
             self.lib.fg_mb_destroy(self.handle)
@@ -293,3 +313,43 @@ class MultiBlockDomain:
             self.close()
         except Exception:
             pass
+
+
+class MultiBlockSimulation:
+    """``Simulation`` (simulation/simulation.py:124-280) for a :class:`MultiBlockDomain`: the settings of the reference's
+    constructor that change results, ``single_step`` and ``make_divergence_free``; the loop itself runs natively
+    (``fg_mb_single_step``)."""
+
+    def __init__(self, domain: MultiBlockDomain, dt: float, adaptive_CFL: float = 0.8, substeps="ADAPTIVE",
+                 corrector_steps: int = 2, advection_tol: Optional[float] = None, pressure_tol: Optional[float] = None,
+                 advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1, max_iterations: int = 5000,
+                 pressure_use_BiCG: bool = False, outflow=None, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
+                 outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5):
+        self.domain, self.time_step, self.adaptive_CFL, self.substeps = domain, float(dt), float(adaptive_CFL), substeps
+        self.corrector_steps = corrector_steps
+        self.advection_tol = 1e-5 if advection_tol is None else advection_tol   # _get_solver_tolerance (PISOtorch_diff.py:247-253)
+        self.pressure_tol = 1e-5 if pressure_tol is None else pressure_tol
+        self.advect_non_ortho_steps, self.pressure_non_ortho_steps = advect_non_ortho_steps, pressure_non_ortho_steps
+        self.max_iterations, self.pressure_use_BiCG = max_iterations, pressure_use_BiCG
+        self.outflow, self.outflow_velocity, self.outflow_tol = outflow, tuple(outflow_velocity), outflow_tol
+        self.flux_balance_tol = flux_balance_tol
+        self.total_time, self.total_step, self.last_substeps, self.last_iterations = 0.0, 0, 0, (0, 0, 0)
+
+    def make_divergence_free(self) -> bool:
+        return self.domain.make_divergence_free(pressure_tol=self.pressure_tol, pressure_non_ortho_steps=self.pressure_non_ortho_steps,
+                                                pressure_use_bicgstab=self.pressure_use_BiCG, outflow=self.outflow,
+                                                outflow_velocity=self.outflow_velocity, outflow_tol=self.outflow_tol)
+
+    def single_step(self) -> bool:
+        adaptive = self.substeps in ("ADAPTIVE", -1)
+        n, ok, its = self.domain.single_step(
+            self.time_step, cfl=self.adaptive_CFL, adaptive=adaptive, substeps=1 if adaptive else int(self.substeps),
+            outflow=self.outflow, outflow_velocity=self.outflow_velocity, outflow_tol=self.outflow_tol,
+            flux_balance_tol=self.flux_balance_tol, corrector_steps=self.corrector_steps,
+            advect_non_ortho_steps=self.advect_non_ortho_steps, pressure_non_ortho_steps=self.pressure_non_ortho_steps,
+            advection_tol=self.advection_tol, pressure_tol=self.pressure_tol, max_iterations=self.max_iterations,
+            pressure_use_bicgstab=self.pressure_use_BiCG)
+        self.total_time += self.time_step
+        self.total_step += 1
+        self.last_substeps, self.last_iterations = n, its
+        return True  # unconverged solves hand back their best iterate (pressure_return_best_result=True), as the envs ask
