@@ -101,10 +101,10 @@ class CylinderEnvBase(FluidEnv):
         extra = np.stack([np.concatenate([x1, x1, x2, x2, x3]),
                           np.concatenate([np.full_like(x1, -1.5), np.full_like(x1, 1.5), np.full_like(x2, self.cylinder_diameter),
                                           np.full_like(x2, -self.cylinder_diameter), np.array([-0.5, 0, 0.5])])])
-        ang = np.linspace(0, 2 * np.pi, 36)
-        c1 = 1.0 * np.stack([np.cos(ang), np.sin(ang)])
-        c2 = 0.625 * np.stack([np.cos(ang), np.sin(ang)])
-        return np.concatenate([main, c1, c2, extra], axis=1).astype(np.float32)
+        ang = np.linspace(0, 2 * np.pi, 36).astype(np.float32)  # float32 like the reference's torch.linspace: the sensor at
+        c1 = np.float32(1.0) * np.stack([np.cos(ang), np.sin(ang)])   # angle 2 pi sits on a rounding tie of the pixel grid
+        c2 = np.float32(0.625) * np.stack([np.cos(ang), np.sin(ang)])
+        return np.concatenate([main.astype(np.float32), c1, c2, extra.astype(np.float32)], axis=1).astype(np.float32)
 
     def _get_sensor_locations(self) -> np.ndarray:
         """Pixel (x, y) of every sensor in the resampled field (``_sensor_locations_to_grid_coords``)."""

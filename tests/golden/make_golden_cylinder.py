@@ -105,6 +105,22 @@ def main():
             else:
                 calls.append(" ".join(str(x) for x in rec))
         out[f"r{res}_calls"] = np.array(calls)
+    # sensor pixels of CylinderEnvBase (cylinder_env_base.py:430-518): the methods are compiled from the reference file and
+    # called on a bare namespace carrying the class attributes they read
+    import ast
+    with open(f"{REF}/fluidgym/envs/cylinder/cylinder_env_base.py") as fh:
+        tree = ast.parse(fh.read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CylinderEnvBase")
+    want = {"_get_sensor_locations_2d", "_sensor_locations_to_grid_coords", "_get_sensor_locations"}
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(fns, []), "cylinder_env_base.py", "exec"), ns)
+    for res in (8, 24, 32):
+        z = res * 4
+        me = types.SimpleNamespace(H=4.1, L=22.0, cylinder_diameter=1.0, _ndims=2, render_shape=(int(z / 4.1 * 22.0), z, z))
+        for k in want:
+            setattr(me, k, types.MethodType(ns[k], me))
+        out[f"r{res}_sensor_pixels"] = me._get_sensor_locations().numpy()
     np.savez_compressed(os.path.join(OUT, "reference_cylinder_grid.npz"), **out)
     for k, v in out.items():
         print(k, v.shape if v.dtype.kind != "U" else list(v))

@@ -44,3 +44,15 @@ def test_cells_are_right_handed():
     for c in m.coords:
         _, _, det = coords_to_transforms(c.astype(np.float64))
         assert det.min() > 0
+
+
+@pytest.mark.parametrize("level,res", [("easy", 24), ("medium", 32)])
+def test_sensor_pixels_match_reference(level, res):
+    import torch
+
+    import fluidgym_amd
+
+    env = fluidgym_amd.make(f"CylinderJet2D-{level}-v0", cuda_device=torch.device("cpu"))
+    ref = G[f"r{res}_sensor_pixels"]
+    assert env._sensor_locations.shape == ref.shape == (2, 151)
+    assert (env._sensor_locations == ref).all()
