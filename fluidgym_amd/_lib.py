@@ -66,6 +66,7 @@ class FgStepOptions(Structure):
         ("buoyancy_axis", c_int32),
         ("buoyancy_factor", c_float),
         ("pressure_warm_start", c_int32),
+        ("pressure_project_mean", c_int32),
     ]
 
 
@@ -78,6 +79,8 @@ class FgMbStepOptions(Structure):
         ("advection_tol", c_float),
         ("pressure_tol", c_float),
         ("pressure_use_bicgstab", c_int32),
+        ("pressure_warm_start", c_int32),
+        ("pressure_project_mean", c_int32),
     ]
 
 

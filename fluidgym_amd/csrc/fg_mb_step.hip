@@ -17,8 +17,8 @@
 
 namespace {
 
-constexpr int MB_ACC = 8;  // doubles per system
-constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6, A_PAP = 7;
+constexpr int MB_ACC = 12;  // doubles per system
+constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6;
 
 #define MB_CELL                                         \
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x;  \
@@ -392,7 +392,7 @@ __global__ void k_mbs_begin(const float* __restrict__ dt, MbSolve q, int nsys) {
 
 // r = rhs - M x0 (x0 = 0 unless use_x0); rw = p = r; rho0 = rr = r.r
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int use_x0) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int use_x0, int sum_slot) {
     MB_SYS
     if (q.flags[sys] != 0) return;
     float r = 0.f;
@@ -405,7 +405,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int u
         q.p[vb + i] = r;
     }
     const float s = mb_block_sum(r * r, lds);
-    if (threadIdx.x == 0) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
+    const float s1 = sum_slot >= 0 ? mb_block_sum(r, lds) : 0.f;
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_RHO, (double)s);
+        atomicAdd(a + A_RR, (double)s);
+        if (sum_slot >= 0) atomicAdd(a + sum_slot, (double)s1);
+    }
 }
 
 // ---- BiCGStab (same five-kernel recurrence as fg_bicgstab.hip)
@@ -503,60 +508,88 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
 }
 
-// ---- CG (cgSolveGPU recurrence; residual r, search direction p, accumulators rr ring in A_RHO, pAp)
+// ---- CG (cgSolveGPU recurrence, cg_solver_kernel.cu:129-471) in two kernels per iteration.  The search direction is
+// never read back through a third pass: k_mbc_ap forms p_it = r_it + beta p_{it-1} for the cell AND for its neighbours
+// on the fly (p ping-pongs between two buffers so that the neighbours' old values are still there), which removes one
+// launch per iteration from a solve that is launch-bound at these mesh sizes (14 k cells x 64 envs).
+// accumulators: rho ring 0..2 (r_k.r_k in slot k % 3) | pAp ping-pong 3,4
+constexpr int C_RHO = 0, C_PAP = 3, C_SUM = 8;  // C_SUM ring 8..10: sum of r_k (mean projection, see mb_cg)
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, int it) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, const float* __restrict__ p_old, float* __restrict__ p_new, int it,
+                                                      int project_mean) {
     MB_SYS
     if (q.flags[sys] != 0) return;
-    const float crit = mb_rms(a[A_RR], N);
+    // residual with its mean removed (project_mean): rho = |r|^2 - (sum r)^2 / N
+    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
+    const float mean_r = (float)(sum_r / (double)N);
+    const double rho = a[C_RHO + it % 3] - sum_r * sum_r / (double)N;
+    const float crit = mb_rms(rho, N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
+    double rho_prev = 1.0;
+    if (it > 0) {
+        const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
+        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp / (double)N;
+    }
+    const float beta = it == 0 ? 0.f : (float)(rho / rho_prev);
     if (leader) {
-        q.info[sys].final_residual = crit; q.info[sys].used_iterations = it; a[A_RHO + ((it + 1) & 1)] = 0.0;
+        q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
+        a[C_RHO + (it + 1) % 3] = 0.0;  // accumulated by k_mbc_update of this iteration; nobody reads it here
+        a[C_SUM + (it + 1) % 3] = 0.0;
         // keep x_it when it beats the kept iterate by 2x: k_mbc_update of this iteration stores it before updating x
         if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2])) { q.sc[sys * 2] = crit; q.best_it[sys] = it; }
     }
     float part = 0.f;
     if (valid) {
-        // p_it = r + beta p_{it-1} was written by k_mbc_dir; here: v = M p, pAp
-        const float y = mb_spmv<DIMS>(D, q, b, q.p + vb, i);
+        constexpr int F = 2 * DIMS;
+        const float* r = q.r + vb;
+        const float* po = p_old + vb;
+        const float pi = it == 0 ? r[i] - mean_r : r[i] - mean_r + beta * po[i];
+        float y = q.diag[(size_t)b * N + i] * pi;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int n = D.nbr[(size_t)f * N + i];
+            if (n >= 0) y += q.off[((size_t)b * F + f) * N + i] * (it == 0 ? r[n] - mean_r : r[n] - mean_r + beta * po[n]);
+        }
+        p_new[vb + i] = pi;
         q.v[vb + i] = y;
-        part = q.p[vb + i] * y;
+        part = pi * y;
     }
     part = mb_block_sum(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + A_PAP, (double)part);
+    if (threadIdx.x == 0) atomicAdd(a + C_PAP + (it & 1), (double)part);
 }
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, int it) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, const float* __restrict__ p, int it, int project_mean) {
     MB_SYS
     if (q.flags[sys] != 0) return;
-    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_PAP]);
-    float part = 0.f;
+    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
+    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r / (double)N) / a[C_PAP + (it & 1)]);
+    if (leader) a[C_PAP + ((it + 1) & 1)] = 0.0;  // k_mbc_ap of the next iteration accumulates it; not read here
+    float part = 0.f, psum = 0.f;
     if (valid) {
         if (q.best_x && q.best_it[sys] == it) q.best_x[vb + i] = q.x[vb + i];
-        q.x[vb + i] += alpha * q.p[vb + i];
+        q.x[vb + i] += alpha * p[vb + i];
         const float r = q.r[vb + i] - alpha * q.v[vb + i];
         q.r[vb + i] = r;
         part = r * r;
+        psum = r;
     }
     part = mb_block_sum(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + A_RHO + ((it + 1) & 1), (double)part);
-}
-template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_dir(MbDev D, MbSolve q, int it) {
-    MB_SYS
-    if (q.flags[sys] != 0) return;
-    const double rr_new = a[A_RHO + ((it + 1) & 1)], rr_old = a[A_RHO + (it & 1)];
-    if (leader) { a[A_RR] = rr_new; a[A_PAP] = 0.0; }
-    if (valid) q.p[vb + i] = q.r[vb + i] + (float)(rr_new / rr_old) * q.p[vb + i];
+    if (project_mean) psum = mb_block_sum(psum, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + C_RHO + (it + 1) % 3, (double)part);
+        if (project_mean) atomicAdd(a + C_SUM + (it + 1) % 3, (double)psum);
+    }
 }
 
 __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32_t* __restrict__ flag_mirror, int rr_slot,
-                            int it, int n, int nsys, int final_pass) {
+                            int it, int n, int nsys, int final_pass, int sum_slot = -1) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     if (q.flags[s] == 4) q.flags[s] = 1;
     if (q.flags[s] == 0) {
-        const float crit = (float)sqrt(q.acc[(size_t)s * MB_ACC + rr_slot] / (double)n);
+        double rr = q.acc[(size_t)s * MB_ACC + rr_slot];
+        if (sum_slot >= 0) { const double sr = q.acc[(size_t)s * MB_ACC + sum_slot]; rr -= sr * sr / (double)n; }
+        const float crit = (float)sqrt(rr / (double)n);
         q.info[s].final_residual = crit;
         q.info[s].used_iterations = it + 1;
         if (!(crit >= q.tol)) {
@@ -683,7 +716,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     const MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
-    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0););
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, -1););
     bool done = false;
     int next_poll = 2;
     for (int it = 0; it < max_iterations && !done; ++it) {
@@ -703,26 +736,31 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     return mb_finish(s, nsys, nullptr, max_it);
 }
 
+// project_mean: every residual is used with its mean removed.  For a symmetric matrix with the constant null space (an
+// orthogonal mesh) that changes nothing; with cross-metric terms 1^T P != 0, the plain recurrence accumulates a constant
+// residual component that no search direction can reduce (the solve stalls just above the envs' tolerance and cannot be
+// warm-started), and removing it is what makes the singular system consistent.
 int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
-          int max_iterations, int use_x0, int* max_it, hipStream_t st) {
+          int max_iterations, int use_x0, int project_mean, int* max_it, hipStream_t st) {
     const int nsys = s->B, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);
     q.rw = nullptr;
     q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = 400;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
-    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0););
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project_mean ? C_SUM : -1););
     bool done = false;
     int next_poll = 16;
     for (int it = 0; it < max_iterations && !done; ++it) {
         MB_DISPATCH(s, {
-            hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, it);
-            hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, it);
-            hipLaunchKernelGGL(k_mbc_dir<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            float* p_old = (it & 1) ? s->w[1] : s->w[2];
+            float* p_new = (it & 1) ? s->w[2] : s->w[1];
+            hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)p_old, p_new, it, project_mean);
+            hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)p_new, it, project_mean);
         });
         if (it + 1 >= next_poll || it + 1 == max_iterations) {
             next_poll = it + 1 + 16;
-            hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
+            hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, C_RHO + (it + 1) % 3, it, n, nsys, (int)(it + 1 == max_iterations), project_mean ? C_SUM + (it + 1) % 3 : -1);
             if (int rc = mb_poll(s, nsys, st, done)) return rc;
         }
     }
@@ -951,11 +989,14 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 }
                 hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, dt_B, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
                 int m = 0;
+                const int warm = (ps > 0 || opt->pressure_warm_start) ? 1 : 0;
+                if (ps == 0 && warm)  // start from the pressure field (the previous solve's result, or a restored state)
+                    hipLaunchKernelGGL(k_mb_copy, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B), blk, 0, st, (size_t)N, dt_B, s->pressure, s->pres);
                 const int prc = opt->pressure_use_bicgstab
                                     ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol,
-                                                  opt->max_iterations, ps > 0, &m, st)
+                                                  opt->max_iterations, warm, &m, st)
                                     : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol,
-                                            opt->max_iterations, ps > 0, &m, st);
+                                            opt->max_iterations, warm, opt->pressure_project_mean, &m, st);
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) its[2 + c] = std::max(its[2 + c], m);
                 FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
@@ -1106,7 +1147,8 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
             int m = 0;
             const int prc = opt->pressure_use_bicgstab
                                 ? mb_bicgstab(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st)
-                                : mb_cg(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st);
+                                : mb_cg(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, ps > 0,
+                                        opt->pressure_project_mean, &m, st);
             if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;
             else if (prc != FG_OK) return prc;
             FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));

@@ -177,14 +177,16 @@ class MultiBlockDomain:
     # ---- stepping
     def piso_step(self, dt, corrector_steps: int = 2, advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1,
                   advection_tol: float = 1e-5, pressure_tol: float = 1e-5, max_iterations: int = 5000,
-                  raise_on_failure: bool = True, pressure_use_bicgstab: bool = False):
+                  raise_on_failure: bool = True, pressure_use_bicgstab: bool = False, pressure_warm_start: bool = False,
+                  pressure_project_mean: bool = False):
         """One PISO step of every env (``dt``: scalar or [B]; ``dt <= 0`` leaves an env untouched).  Returns the max
         solver iterations (velocity, pressure corrector 0, pressure corrector 1)."""
         if not self.prepared:
             raise RuntimeError("PrepareSolve() first")
         self._dt.copy_(torch.as_tensor(dt, dtype=torch.float32).expand(self.batch))
         opt = L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
-                                advection_tol, pressure_tol, int(pressure_use_bicgstab))
+                                advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
+                                int(pressure_project_mean))
         stats = (ctypes.c_int32 * 4)()
         st = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.fg_mb_piso_step(self.handle, ctypes.c_void_p(self._dt.data_ptr()), ctypes.byref(opt), stats,
@@ -231,9 +233,11 @@ class MultiBlockDomain:
         return T
 
     def _step_options(self, corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
-                      pressure_tol, max_iterations, pressure_use_bicgstab):
+                      pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start=False,
+                      pressure_project_mean=False):
         return L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
-                                 advection_tol, pressure_tol, int(pressure_use_bicgstab))
+                                 advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
+                                 int(pressure_project_mean))
 
     def _outflow_slots(self, outflow):
         blk, face = outflow
@@ -266,12 +270,14 @@ class MultiBlockDomain:
                     outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0), outflow_tol: float = 5e-6,
                     flux_balance_tol: float = 1e-5, corrector_steps: int = 2, advect_non_ortho_steps: int = 1,
                     pressure_non_ortho_steps: int = 1, advection_tol: float = 1e-5, pressure_tol: float = 1e-5,
-                    max_iterations: int = 5000, pressure_use_bicgstab: bool = False, max_substeps: int = 0):
+                    max_iterations: int = 5000, pressure_use_bicgstab: bool = False, max_substeps: int = 0,
+                    pressure_warm_start: bool = False, pressure_project_mean: bool = False):
         """``Simulation.single_step`` on the native side.  ``outflow``: (block, face) of the FIXED face that follows the
         convective outflow condition.  Returns (substeps, all solves converged, max iterations of the last substep)."""
         o = L.FgMbSimOptions()
         o.step = self._step_options(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
-                                    pressure_tol, max_iterations, pressure_use_bicgstab)
+                                    pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start,
+                                    pressure_project_mean)
         o.time_step, o.cfl, o.adaptive, o.substeps = float(time_step), float(cfl), int(adaptive), int(substeps)
         o.flux_balance_tol, o.outflow_tol, o.max_substeps = float(flux_balance_tol), float(outflow_tol), int(max_substeps)
         if outflow is not None:
@@ -324,7 +330,9 @@ class MultiBlockSimulation:
                  corrector_steps: int = 2, advection_tol: Optional[float] = None, pressure_tol: Optional[float] = None,
                  advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1, max_iterations: int = 5000,
                  pressure_use_BiCG: bool = False, outflow=None, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
-                 outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5):
+                 outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5, pressure_warm_start: bool = True,
+                 pressure_project_mean: bool = True):
+        self.pressure_warm_start, self.pressure_project_mean = pressure_warm_start, pressure_project_mean
         self.domain, self.time_step, self.adaptive_CFL, self.substeps = domain, float(dt), float(adaptive_CFL), substeps
         self.corrector_steps = corrector_steps
         self.advection_tol = 1e-5 if advection_tol is None else advection_tol   # _get_solver_tolerance (PISOtorch_diff.py:247-253)
@@ -348,7 +356,8 @@ class MultiBlockSimulation:
             flux_balance_tol=self.flux_balance_tol, corrector_steps=self.corrector_steps,
             advect_non_ortho_steps=self.advect_non_ortho_steps, pressure_non_ortho_steps=self.pressure_non_ortho_steps,
             advection_tol=self.advection_tol, pressure_tol=self.pressure_tol, max_iterations=self.max_iterations,
-            pressure_use_bicgstab=self.pressure_use_BiCG)
+            pressure_use_bicgstab=self.pressure_use_BiCG, pressure_warm_start=self.pressure_warm_start,
+            pressure_project_mean=self.pressure_project_mean)
         self.total_time += self.time_step
         self.total_step += 1
         self.last_substeps, self.last_iterations = n, its

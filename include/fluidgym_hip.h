@@ -331,6 +331,12 @@ typedef struct fg_mb_step_options {
     int32_t pressure_use_bicgstab;     /* 0: CG as the reference (pressure_use_BiCG=False, simulation.py:136) -- with the
                                           cross-metric terms the pressure matrix is not symmetric, CG only works while the
                                           mesh is close to orthogonal; 1: BiCGStab */
+    int32_t pressure_warm_start;       /* 1: the first pressure solve of a corrector starts from the current pressure field
+                                          instead of zero (the reference passes x=None there, PISOtorch_simulation.py:1878;
+                                          same converged answer, fewer iterations) */
+    int32_t pressure_project_mean;     /* 1: CG works on residuals with their mean removed -- identical on orthogonal meshes,
+                                          and what keeps the solve from stalling on the constant residual component that the
+                                          cross-metric terms feed (1^T P != 0); 0: the reference's plain recurrence */
 } fg_mb_step_options;
 /* dt_B: device array [B]; dt <= 0 leaves that env untouched.  stats_host (optional, 4 ints): max iterations of
  * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
