@@ -163,6 +163,35 @@ def roofline_from_profile(prof, solver):
                     "resident kernels can exceed the HBM figure; poisson_256 is the HBM-resident case"}
 
 
+def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
+    """The reference's own cylinder env (CylinderJet2D-easy-v0: five-block curvilinear mesh, 14 232 cells, Re 100, 25 PISO
+    steps per env step) on the multi-block path, batched like the headline workload.  Reported next to the headline,
+    which stays on the 256x128 single-block stand-in SURVEY 8d maps the BASELINE config to."""
+    import torch
+
+    import fluidgym_amd
+
+    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=num_envs, initial_domain_steps=10,
+                            randomize_initial_state=False, cuda_device=device)
+    try:
+        env.reset(seed=0)
+        a = torch.zeros(num_envs, 1, device=device)
+        env.step(a)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, _, _, _, info = env.step(a)
+        torch.cuda.synchronize(device)
+        el = (time.perf_counter() - t0) / steps
+        return {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "cells_per_env": env._domain.n_cells,
+                "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el,
+                "unit": "env-steps/s", "pressure_iterations_last_step": list(env._sim.last_iterations[1:]),
+                "drag_coefficient_env0": float(info["drag"][0]),
+                "note": "state 10 sim steps after an impulsive start (no published initial domains offline)"}
+    finally:
+        env.close()
+
+
 def cpu_baseline(budget_s=20.0):
     """Oracle (NumPy/SciPy port of the reference algorithm) on one env of the bench workload."""
     import numpy as np
@@ -281,6 +310,11 @@ def main():
         }
         if not args.no_micro:
             out["poisson_256"] = poisson_micro(device)
+        if not args.no_micro and world == 1:
+            try:
+                out["cylinder_env"] = cylinder_env_leg(device)
+            except Exception as exc:  # the headline line must survive a failure of the extra leg
+                out["cylinder_env"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -66,7 +66,6 @@ class FgStepOptions(Structure):
         ("buoyancy_axis", c_int32),
         ("buoyancy_factor", c_float),
         ("pressure_warm_start", c_int32),
-        ("pressure_project_mean", c_int32),
     ]
 
 

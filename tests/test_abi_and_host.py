@@ -114,3 +114,23 @@ def test_oracle_is_not_imported_by_the_product():
             "fluidgym_amd.envs.channel, fluidgym_amd.envs.rbc, fluidgym_amd.envs.tcf; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle leaked'")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_ctypes_structs_match_the_header_layout():
+    """Field-by-field comparison of every ctypes Structure with the typedef of the same role in include/fluidgym_hip.h
+    (a struct that drifts shifts every later field silently)."""
+    import re
+
+    from fluidgym_amd import _lib as L
+
+    text = open(os.path.join(os.path.dirname(__file__), "..", "include", "fluidgym_hip.h")).read()
+    pairs = {"fg_step_options": L.FgStepOptions, "fg_sim_options": L.FgSimOptions, "fg_mb_step_options": L.FgMbStepOptions,
+             "fg_mb_sim_options": L.FgMbSimOptions, "fg_solve_info": L.FgSolveInfo, "fg_config": L.FgConfig}
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            if decl.strip():
+                names += [re.match(r"\s*(\w+)", x).group(1) for x in decl.strip().split(None, 1)[1].split(",")]
+        assert names == [f[0] for f in cls._fields_], cname
