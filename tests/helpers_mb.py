@@ -22,7 +22,7 @@ class Spec:
         for b, a in self.periodic:
             d.make_periodic(b, a)
         for c in self.connections:
-            d.connect(*c)
+            d.connect(*c)  # (b1, face1, b2, face2, axis1[, axis2])
         d.finalize()
         return d
 
@@ -35,8 +35,8 @@ class Spec:
             blks[b].CloseBoundary(f, v)
         for b, a in self.periodic:
             blks[b].MakePeriodic(a)
-        for b1, f1, b2, f2, a1 in self.connections:
-            blks[b1].ConnectBlock(f1, blks[b2], f2, a1)
+        for b1, f1, b2, f2, a1, *rest in self.connections:
+            blks[b1].ConnectBlock(f1, blks[b2], f2, a1, *(rest or [4]))
         dom.PrepareSolve()
         return dom
 
@@ -117,3 +117,33 @@ def mild_skewed_pair():
 def polar_ring():
     """Orthogonal O-grid (the cylinder mesh's inner ring is one): curved cells, three connections in a cycle."""
     return twisted_ring(twist=0.0)
+
+
+def extrude(c2, z):
+    """[2, ny+1, nx+1] -> [3, nz+1, ny+1, nx+1]"""
+    nzv = len(z)
+    xy = np.broadcast_to(c2[:, None], (2, nzv) + c2.shape[1:])
+    zz = np.broadcast_to(np.asarray(z)[None, :, None, None], (1, nzv) + c2.shape[1:])
+    return np.ascontiguousarray(np.concatenate([xy, zz], axis=0))
+
+
+def skewed_pair_3d(nu=0.03, nz=3):
+    """The skewed two-block mesh extruded along z (periodic), blocks joined +x -> -x; a lid moves in x and z."""
+    s2 = skewed_pair(nu)
+    c1 = s2.blocks[0]
+    # undo the storage rotation of the second block: 3-D keeps both blocks in the same orientation
+    c2 = np.ascontiguousarray(s2.blocks[1].transpose(0, 2, 1)[:, :, ::-1])
+    z = np.linspace(0.0, 0.9, nz + 1)
+    s = Spec(3, nu)
+    s.blocks = [extrude(c1, z), extrude(c2, z)]
+    ny, nx = c1.shape[1] - 1, c1.shape[2] - 1
+    eta = 0.5 * (np.linspace(0.0, 1.0, ny + 1)[1:] + np.linspace(0.0, 1.0, ny + 1)[:-1])
+    through = np.zeros((3, nz, ny))
+    through[0] = 0.5 + 0.2 * eta[None, :]
+    through[2] = 0.1
+    lid = np.zeros((3, nz, nx))
+    lid[0], lid[2] = 0.7, 0.2
+    s.fixed = [(0, 0, through.reshape(3, -1)), (1, 1, through.reshape(3, -1)), (0, 3, lid.reshape(3, -1)), (1, 3, lid.reshape(3, -1))]
+    s.periodic = [(0, 2), (1, 2)]
+    s.connections = [(0, 1, 1, 0, 2, 4)]
+    return s

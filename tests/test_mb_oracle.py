@@ -189,3 +189,51 @@ def test_flux_balance_of_a_uniform_stream_over_connections():
     assert np.abs(d.apply(C, u) - rhs).max() < 1e-12
     Cq = d.build_matrix(u, 0.05)
     assert np.abs(d.apply(Cq, u) - rhs).max() > 1e-6  # the reference's rule is visible at the domain-corner cells
+
+
+def _channel3d(nx=6, ny=5, nz=4, nu=0.03, seed=1):
+    x = np.linspace(0.0, 2.0, nx + 1) ** 1.1
+    y = np.linspace(0.0, 1.0, ny + 1) ** 1.2
+    z = np.linspace(0.0, 1.5, nz + 1)
+    coords = po.rectilinear_coords([x, y, z])
+    g = po.Grid(coords)
+    rng = np.random.default_rng(seed)
+    u = 0.3 * rng.standard_normal((3, nz, ny, nx))
+    u[0] += 1.0
+    inflow = np.zeros((3, nz, ny, 1))
+    inflow[0] = 1.0
+    bc = {0: po.FixedBC(velocity=inflow.copy()), 1: po.FixedBC(velocity=inflow.copy()),
+          2: po.FixedBC(velocity=np.zeros(3)), 3: po.FixedBC(velocity=np.zeros(3)), 4: None, 5: None}
+    dom = po.Domain(grid=g, viscosity=nu, velocity=u.copy(), pressure=np.zeros((nz, ny, nx)), bc=bc)
+    return dom, coords, u
+
+
+def test_3d_two_blocks_periodic_z_equal_single_block():
+    """3-D: a channel (inflow / outflow in x, walls in y, periodic in z) cut in x into two connected blocks."""
+    dom, coords, u = _channel3d()
+    dt = 0.04
+    po.piso_split_step(dom, dt)
+    nz, ny, nx = u.shape[1:]
+    cut = 2
+    d = mb.Domain(3, dom.viscosity)
+    A = d.add_block(coords[:, :, :, : cut + 1])
+    B = d.add_block(coords[:, :, :, cut:])
+    one = np.zeros((3, nz * ny))
+    one[0] = 1.0
+    d.close(A, 0, one)
+    d.close(B, 1, one)
+    d.make_periodic(A, 2)
+    d.make_periodic(B, 2)
+    d.connect(A, 1, B, 0, 2, 4)  # +x of A to -x of B, y -> y, z -> z
+    d.finalize()
+    gmap = np.zeros((nz, ny, nx), dtype=np.int64)
+    for zz in range(nz):
+        for yy in range(ny):
+            for xx in range(nx):
+                gmap[zz, yy, xx] = d.gidx(A, [xx, yy, zz]) if xx < cut else d.gidx(B, [xx - cut, yy, zz])
+    ug = np.zeros((3, d.N))
+    ug[:, gmap.reshape(-1)] = u.reshape(3, -1)
+    u_new, p_new = d.piso_step(ug, np.zeros(d.N), dt)
+    ref_p = dom.pressure.reshape(-1)
+    assert np.allclose(u_new[:, gmap.reshape(-1)], dom.velocity.reshape(3, -1), rtol=1e-8, atol=1e-10)
+    assert np.allclose(p_new[gmap.reshape(-1)], ref_p - ref_p.mean(), rtol=1e-7, atol=1e-9)
