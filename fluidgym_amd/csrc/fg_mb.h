@@ -83,7 +83,10 @@ struct fg_mb_state {
     float* w[6];
     double* acc;
     float* sc;
-    int32_t *flags, *best_it;
+    int32_t *flags, *best_it, *it_ctr;
+    hipStream_t capture_stream = nullptr;
+    hipGraphExec_t cg_graph_exec = nullptr;   // one chunk of CG iterations + convergence check (fg_mb_step.hip::mb_cg)
+    unsigned char cg_graph_key_storage[256] = {0};
     int32_t* flags_pinned = nullptr;
     fg_solve_info *info_dev, *info_pinned = nullptr;
     float* red;        // [B] reductions (mean, max)

@@ -10,6 +10,8 @@
 // driven in the order of _PISO_split_step's non-orthogonal branch (PISOtorch_simulation.py:1707-1972).
 // "K.cu" = extensions/PISO_multiblock_cuda_kernel.cu.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -341,7 +343,11 @@ struct MbSolve {
     // best-iterate tracking of the CG pressure solve (returnBestResult, cg_solver_kernel.cu:345-361): sc[2 sys] holds the
     // residual of the kept iterate, best_it the iteration it belongs to, best_x the iterate itself
     float* best_x; int32_t* best_it; int stall_limit;
+    // device-side iteration index of the graph-replayed CG: ctr[0] read by k_mbc_ap*, ctr[1] - 1 by k_mbc_update*
+    int32_t* it_ctr; int max_iterations;
 };
+
+struct MbGraphKey { MbSolve q; int vec4, project_mean; hipStream_t stream; };
 
 template <int DIMS>
 __device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b, const float* __restrict__ x, int i) {
@@ -515,9 +521,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
 // accumulators: rho ring 0..2 (r_k.r_k in slot k % 3) | pAp ping-pong 3,4
 constexpr int C_RHO = 0, C_PAP = 3, C_SUM = 8;  // C_SUM ring 8..10: sum of r_k (mean projection, see mb_cg)
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, const float* __restrict__ p_old, float* __restrict__ p_new, int it,
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* __restrict__ pA, float* __restrict__ pB, int it_arg,
                                                       int project_mean) {
     MB_SYS
+    const int it = it_arg >= 0 ? it_arg : q.it_ctr[0];
+    if (leader && sys == 0) q.it_ctr[1] = it + 1;
+    const float* p_old = (it & 1) ? pA : pB;
+    float* p_new = (it & 1) ? pB : pA;
     if (q.flags[sys] != 0) return;
     // residual with its mean removed (project_mean): rho = |r|^2 - (sum r)^2 / N
     const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
@@ -558,8 +568,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, const f
     if (threadIdx.x == 0) atomicAdd(a + C_PAP + (it & 1), (double)part);
 }
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, const float* __restrict__ p, int it, int project_mean) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, const float* __restrict__ pA, const float* __restrict__ pB,
+                                                          int it_arg, int project_mean) {
     MB_SYS
+    const int it = it_arg >= 0 ? it_arg : q.it_ctr[1] - 1;
+    if (leader && sys == 0) q.it_ctr[0] = it + 1;
+    const float* p = (it & 1) ? pB : pA;
     if (q.flags[sys] != 0) return;
     const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
     const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r / (double)N) / a[C_PAP + (it & 1)]);
@@ -581,10 +595,121 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
     }
 }
 
+// ---- the same two kernels with four consecutive cells per thread (N % 4 == 0): own-cell data moves as 128-bit loads, the
+// 2 x 2d x 4 neighbour gathers of a thread are independent and overlap, and a quarter of the workgroups is launched --
+// at 14 k cells x 64 envs the scalar kernels were bound by gather latency and workgroup turnover, not by bytes.
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float* __restrict__ pA, float* __restrict__ pB,
+                                                       int it_arg, int project_mean) {
+    const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;
+    const int sys = blockIdx.y, b = sys, N = D.N;
+    const bool valid = i < N, leader = (blockIdx.x == 0 && threadIdx.x == 0);
+    const size_t vb = (size_t)sys * N;
+    double* a = q.acc + (size_t)sys * MB_ACC;
+    __shared__ float lds[4];
+    const int it = it_arg >= 0 ? it_arg : q.it_ctr[0];
+    if (leader && sys == 0) q.it_ctr[1] = it + 1;
+    const float* p_old = (it & 1) ? pA : pB;
+    float* p_new = (it & 1) ? pB : pA;
+    if (q.flags[sys] != 0) return;
+    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
+    const float mean_r = (float)(sum_r / (double)N);
+    const double rho = a[C_RHO + it % 3] - sum_r * sum_r / (double)N;
+    const float crit = mb_rms(rho, N);
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
+    double rho_prev = 1.0;
+    if (it > 0) {
+        const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
+        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp / (double)N;
+    }
+    const float beta = it == 0 ? 0.f : (float)(rho / rho_prev);
+    if (leader) {
+        q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
+        a[C_RHO + (it + 1) % 3] = 0.0;
+        a[C_SUM + (it + 1) % 3] = 0.0;
+        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2])) { q.sc[sys * 2] = crit; q.best_it[sys] = it; }
+    }
+    float part = 0.f;
+    if (valid) {
+        constexpr int F = 2 * DIMS;
+        const float* r = q.r + vb;
+        const float* po = p_old + vb;
+        const float4 r4 = *reinterpret_cast<const float4*>(r + i);
+        float pi[4] = {r4.x - mean_r, r4.y - mean_r, r4.z - mean_r, r4.w - mean_r};
+        if (it > 0) {
+            const float4 p4 = *reinterpret_cast<const float4*>(po + i);
+            pi[0] += beta * p4.x; pi[1] += beta * p4.y; pi[2] += beta * p4.z; pi[3] += beta * p4.w;
+        }
+        const float4 d4 = *reinterpret_cast<const float4*>(q.diag + (size_t)b * N + i);
+        float y[4] = {d4.x * pi[0], d4.y * pi[1], d4.z * pi[2], d4.w * pi[3]};
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int4 n4 = *reinterpret_cast<const int4*>(D.nbr + (size_t)f * N + i);
+            const float4 o4 = *reinterpret_cast<const float4*>(q.off + ((size_t)b * F + f) * N + i);
+            const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+            const float oo[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
+                float pn = r[n] - mean_r;
+                if (it > 0) pn += beta * po[n];
+                y[e] += oo[e] * pn;
+            }
+        }
+        *reinterpret_cast<float4*>(p_new + vb + i) = make_float4(pi[0], pi[1], pi[2], pi[3]);
+        *reinterpret_cast<float4*>(q.v + vb + i) = make_float4(y[0], y[1], y[2], y[3]);
+        part = pi[0] * y[0] + pi[1] * y[1] + pi[2] * y[2] + pi[3] * y[3];
+    }
+    part = mb_block_sum(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + C_PAP + (it & 1), (double)part);
+}
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, const float* __restrict__ pA, const float* __restrict__ pB,
+                                                           int it_arg, int project_mean) {
+    const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;
+    const int sys = blockIdx.y;
+    const bool valid = i < N, leader = (blockIdx.x == 0 && threadIdx.x == 0);
+    const size_t vb = (size_t)sys * N;
+    double* a = q.acc + (size_t)sys * MB_ACC;
+    __shared__ float lds[4];
+    const int it = it_arg >= 0 ? it_arg : q.it_ctr[1] - 1;
+    if (leader && sys == 0) q.it_ctr[0] = it + 1;
+    const float* p = (it & 1) ? pB : pA;
+    if (q.flags[sys] != 0) return;
+    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
+    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r / (double)N) / a[C_PAP + (it & 1)]);
+    if (leader) a[C_PAP + ((it + 1) & 1)] = 0.0;
+    float part = 0.f, psum = 0.f;
+    if (valid) {
+        float4 x4 = *reinterpret_cast<const float4*>(q.x + vb + i);
+        if (q.best_x && q.best_it[sys] == it) *reinterpret_cast<float4*>(q.best_x + vb + i) = x4;
+        const float4 p4 = *reinterpret_cast<const float4*>(p + vb + i);
+        const float4 v4 = *reinterpret_cast<const float4*>(q.v + vb + i);
+        float4 r4 = *reinterpret_cast<const float4*>(q.r + vb + i);
+        x4.x += alpha * p4.x; x4.y += alpha * p4.y; x4.z += alpha * p4.z; x4.w += alpha * p4.w;
+        r4.x -= alpha * v4.x; r4.y -= alpha * v4.y; r4.z -= alpha * v4.z; r4.w -= alpha * v4.w;
+        *reinterpret_cast<float4*>(q.x + vb + i) = x4;
+        *reinterpret_cast<float4*>(q.r + vb + i) = r4;
+        part = r4.x * r4.x + r4.y * r4.y + r4.z * r4.z + r4.w * r4.w;
+        psum = r4.x + r4.y + r4.z + r4.w;
+    }
+    part = mb_block_sum(part, lds);
+    if (project_mean) psum = mb_block_sum(psum, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + C_RHO + (it + 1) % 3, (double)part);
+        if (project_mean) atomicAdd(a + C_SUM + (it + 1) % 3, (double)psum);
+    }
+}
+
 __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32_t* __restrict__ flag_mirror, int rr_slot,
                             int it, int n, int nsys, int final_pass, int sum_slot = -1) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
+    if (it < 0) {  // graph-replayed CG: iteration index and accumulator slots from the device counter
+        it = q.it_ctr[0] - 1;
+        rr_slot = C_RHO + (it + 1) % 3;
+        if (sum_slot != -1) sum_slot = C_SUM + (it + 1) % 3;
+        final_pass = (it + 1 >= q.max_iterations);
+    }
     if (q.flags[s] == 4) q.flags[s] = 1;
     if (q.flags[s] == 0) {
         double rr = q.acc[(size_t)s * MB_ACC + rr_slot];
@@ -703,10 +828,12 @@ int mb_finish(fg_mb_state* s, int nsys, fg_solve_info* info_host, int* max_it) {
 
 MbSolve mb_solve_ptrs(fg_mb_state* s, const float* diag, const float* off, const float* rhs, float* x, int nc, float tol) {
     MbSolve q;
+    memset(&q, 0, sizeof(q));  // the struct doubles as (part of) the key of the cached CG graph: no stray padding bytes
     q.diag = diag; q.off = off; q.rhs = rhs; q.x = x;
     q.r = s->w[0]; q.rw = s->w[1]; q.p = s->w[2]; q.v = s->w[3]; q.t = s->w[4];
     q.acc = s->acc; q.sc = s->sc; q.flags = s->flags; q.info = s->info_dev; q.nc = nc; q.tol = tol;
     q.best_x = nullptr; q.best_it = nullptr; q.stall_limit = 0;
+    q.it_ctr = s->it_ctr; q.max_iterations = 0;
     return q;
 }
 
@@ -747,22 +874,59 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     q.rw = nullptr;
     q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = 400;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
+    const bool vec4 = (n % 4 == 0) && !getenv("FG_MB_SCALAR_CG");
+    const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project_mean ? C_SUM : -1););
     bool done = false;
-    int next_poll = 16;
-    for (int it = 0; it < max_iterations && !done; ++it) {
+    // CG_CHUNK iterations + the convergence check are one hipGraph: at 14 k cells x 64 envs a kernel runs 5-10 us, about
+    // what the host needs to enqueue it, so the loop was launch-bound.  The kernels take their iteration index from a
+    // device counter (q.it_ctr) so that one captured chunk serves every replay.
+    constexpr int CG_CHUNK = 16;
+    q.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
+    FG_HIP_CHECK(hipMemsetAsync(s->it_ctr, 0, 2 * sizeof(int32_t), st));
+    auto enqueue_chunk = [&]() {
         MB_DISPATCH(s, {
-            float* p_old = (it & 1) ? s->w[1] : s->w[2];
-            float* p_new = (it & 1) ? s->w[2] : s->w[1];
-            hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)p_old, p_new, it, project_mean);
-            hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)p_new, it, project_mean);
+            for (int k = 0; k < CG_CHUNK; ++k) {
+                if (vec4) {
+                    hipLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                    hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                } else {
+                    hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                    hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                }
+            }
         });
-        if (it + 1 >= next_poll || it + 1 == max_iterations) {
-            next_poll = it + 1 + 16;
-            hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, C_RHO + (it + 1) % 3, it, n, nsys, (int)(it + 1 == max_iterations), project_mean ? C_SUM + (it + 1) % 3 : -1);
-            if (int rc = mb_poll(s, nsys, st, done)) return rc;
+        hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, 0, -1, n, nsys, 0, project_mean ? 0 : -1);
+    };
+    const bool use_graph = !getenv("FG_MB_NO_GRAPH");
+    if (use_graph) {
+        MbGraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.q = q; key.vec4 = vec4; key.project_mean = project_mean; key.stream = st;
+        static_assert(sizeof(MbGraphKey) <= sizeof(s->cg_graph_key_storage), "graph key storage too small");
+        MbGraphKey& stored = *reinterpret_cast<MbGraphKey*>(s->cg_graph_key_storage);
+        if (!s->cg_graph_exec || memcmp(&key, &stored, sizeof(key)) != 0) {
+            if (s->cg_graph_exec) { (void)hipGraphExecDestroy(s->cg_graph_exec); s->cg_graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            // captured on a private stream (the caller's may be the legacy default stream, which cannot capture); the
+            // instantiated graph is then launched on the caller's stream
+            if (!s->capture_stream) FG_HIP_CHECK(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
+            const hipStream_t run_stream = st;
+            st = s->capture_stream;
+            FG_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            enqueue_chunk();
+            FG_HIP_CHECK(hipStreamEndCapture(st, &graph));
+            st = run_stream;
+            FG_HIP_CHECK(hipGraphInstantiate(&s->cg_graph_exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            memcpy(&stored, &key, sizeof(key));
         }
+    }
+    for (int it = 0; it < q.max_iterations && !done; it += CG_CHUNK) {
+        if (use_graph) FG_HIP_CHECK(hipGraphLaunch(s->cg_graph_exec, st));
+        else enqueue_chunk();
+        if (int rc = mb_poll(s, nsys, st, done)) return rc;
     }
     bool failed = false;
     for (int i = 0; i < nsys; ++i) failed = failed || !s->info_pinned[i].converged;
@@ -802,6 +966,8 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
 
 extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (!s) return FG_OK;
+    if (s->cg_graph_exec) (void)hipGraphExecDestroy(s->cg_graph_exec);
+    if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->info_pinned) (void)hipHostFree(s->info_pinned);
     if (s->red_pinned) (void)hipHostFree(s->red_pinned);
@@ -908,6 +1074,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->red, B)) return rc;
     if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->red2, 2 * B)) return rc;
+    if (int rc = mb_alloc(s, &s->it_ctr, 2)) return rc;
     if (int rc = mb_alloc(s, &s->dt_dev, B)) return rc;
     FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(float) * B, hipHostMallocDefault));
