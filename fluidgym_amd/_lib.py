@@ -80,6 +80,7 @@ class FgMbStepOptions(Structure):
         ("pressure_use_bicgstab", c_int32),
         ("pressure_warm_start", c_int32),
         ("pressure_project_mean", c_int32),
+        ("pressure_stall_accept", c_float),
     ]
 
 

@@ -10,6 +10,7 @@
 // driven in the order of _PISO_split_step's non-orthogonal branch (PISOtorch_simulation.py:1707-1972).
 // "K.cu" = extensions/PISO_multiblock_cuda_kernel.cu.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -345,6 +346,9 @@ struct MbSolve {
     float* best_x; int32_t* best_it; int stall_limit;
     // device-side iteration index of the graph-replayed CG: ctr[0] read by k_mbc_ap*, ctr[1] - 1 by k_mbc_update*
     int32_t* it_ctr; int max_iterations;
+    // stall acceptance (off when 0): a system whose kept iterate is within accept_factor * tol and has not improved for
+    // accept_window iterations ends with that iterate and counts as converged
+    float accept_factor; int accept_window;
 };
 
 struct MbGraphKey { MbSolve q; int vec4, project_mean; hipStream_t stream; };
@@ -540,25 +544,28 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
         const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
         rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp / (double)N;
     }
-    const float beta = it == 0 ? 0.f : (float)(rho / rho_prev);
+    const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
+    const float beta = fresh ? 0.f : (float)(rho / rho_prev);
     if (leader) {
         q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
         a[C_RHO + (it + 1) % 3] = 0.0;  // accumulated by k_mbc_update of this iteration; nobody reads it here
         a[C_SUM + (it + 1) % 3] = 0.0;
         // keep x_it when it beats the kept iterate by 2x: k_mbc_update of this iteration stores it before updating x
-        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2])) { q.sc[sys * 2] = crit; q.best_it[sys] = it; }
+        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2] || (crit < q.accept_factor * q.tol && crit < q.sc[sys * 2]))) {
+            q.sc[sys * 2] = crit; q.best_it[sys] = it;
+        }
     }
     float part = 0.f;
     if (valid) {
         constexpr int F = 2 * DIMS;
         const float* r = q.r + vb;
         const float* po = p_old + vb;
-        const float pi = it == 0 ? r[i] - mean_r : r[i] - mean_r + beta * po[i];
+        const float pi = fresh ? r[i] - mean_r : r[i] - mean_r + beta * po[i];
         float y = q.diag[(size_t)b * N + i] * pi;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int n = D.nbr[(size_t)f * N + i];
-            if (n >= 0) y += q.off[((size_t)b * F + f) * N + i] * (it == 0 ? r[n] - mean_r : r[n] - mean_r + beta * po[n]);
+            if (n >= 0) y += q.off[((size_t)b * F + f) * N + i] * (fresh ? r[n] - mean_r : r[n] - mean_r + beta * po[n]);
         }
         p_new[vb + i] = pi;
         q.v[vb + i] = y;
@@ -622,12 +629,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
         const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
         rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp / (double)N;
     }
-    const float beta = it == 0 ? 0.f : (float)(rho / rho_prev);
+    const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
+    const float beta = fresh ? 0.f : (float)(rho / rho_prev);
     if (leader) {
         q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
         a[C_RHO + (it + 1) % 3] = 0.0;
         a[C_SUM + (it + 1) % 3] = 0.0;
-        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2])) { q.sc[sys * 2] = crit; q.best_it[sys] = it; }
+        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2] || (crit < q.accept_factor * q.tol && crit < q.sc[sys * 2]))) {
+            q.sc[sys * 2] = crit; q.best_it[sys] = it;
+        }
     }
     float part = 0.f;
     if (valid) {
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
         const float* po = p_old + vb;
         const float4 r4 = *reinterpret_cast<const float4*>(r + i);
         float pi[4] = {r4.x - mean_r, r4.y - mean_r, r4.z - mean_r, r4.w - mean_r};
-        if (it > 0) {
+        if (!fresh) {
             const float4 p4 = *reinterpret_cast<const float4*>(po + i);
             pi[0] += beta * p4.x; pi[1] += beta * p4.y; pi[2] += beta * p4.z; pi[3] += beta * p4.w;
         }
@@ -652,7 +662,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
             for (int e = 0; e < 4; ++e) {
                 const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
                 float pn = r[n] - mean_r;
-                if (it > 0) pn += beta * po[n];
+                if (!fresh) pn += beta * po[n];
                 y[e] += oo[e] * pn;
             }
         }
@@ -700,6 +710,32 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, cons
     }
 }
 
+// restart of the CG recurrence (the reference recomputes r = b - A x and resets p = r every residualResetSteps = 100
+// iterations, cg_solver_kernel.cu:281-300): slots of iteration `it` are cleared by k_mbc_clear, then refilled here
+__global__ void k_mbc_clear(MbSolve q, int nsys, int it) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) q.it_ctr[2] = it;
+    if (s >= nsys) return;
+    q.acc[(size_t)s * MB_ACC + C_RHO + it % 3] = 0.0;
+    q.acc[(size_t)s * MB_ACC + C_SUM + it % 3] = 0.0;
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, int it, int project_mean) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    float r = 0.f;
+    if (valid) {
+        r = q.rhs[vb + i] - mb_spmv<DIMS>(D, q, b, q.x + vb, i);
+        q.r[vb + i] = r;
+    }
+    const float s2 = mb_block_sum(r * r, lds);
+    const float s1 = project_mean ? mb_block_sum(r, lds) : 0.f;
+    if (threadIdx.x == 0) {
+        atomicAdd(a + C_RHO + it % 3, (double)s2);
+        if (project_mean) atomicAdd(a + C_SUM + it % 3, (double)s1);
+    }
+}
+
 __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32_t* __restrict__ flag_mirror, int rr_slot,
                             int it, int n, int nsys, int final_pass, int sum_slot = -1) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -722,6 +758,11 @@ __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32
             q.flags[s] = finite ? 1 : 2;
             q.info[s].converged = finite ? 1 : 0;
             q.info[s].is_finite = finite ? 1 : 0;
+        } else if (q.best_x && q.accept_factor > 0.f && q.sc[s * 2] <= q.accept_factor * q.tol && it - q.best_it[s] >= q.accept_window) {
+            // hovering just above the tolerance (the residual of CG is not monotone, least of all on the non-symmetric
+            // matrix): take the kept iterate instead of waiting for a lucky dip
+            q.info[s].converged = 1;
+            q.flags[s] = 5;
         } else if (final_pass || (q.best_x && q.stall_limit > 0 && it - q.best_it[s] > q.stall_limit)) {
             // out of iterations, or no iterate has halved the best residual for stall_limit iterations (the reference
             // would run on to max_iterations and then hand back its best iterate, too)
@@ -736,7 +777,7 @@ __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32
 // hand back the kept iterate of the systems that ended unconverged
 __global__ void k_mbs_restore_best(int N, MbSolve q) {
     const int sys = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
-    if (i >= N || q.info[sys].converged || q.flags[sys] == 3) return;
+    if (i >= N || (q.info[sys].converged && q.flags[sys] != 5) || q.flags[sys] == 3) return;
     q.x[(size_t)sys * N + i] = q.best_x[(size_t)sys * N + i];
     if (i == 0) { q.info[sys].final_residual = q.sc[sys * 2]; q.info[sys].used_iterations = q.best_it[sys]; }
 }
@@ -834,6 +875,7 @@ MbSolve mb_solve_ptrs(fg_mb_state* s, const float* diag, const float* off, const
     q.acc = s->acc; q.sc = s->sc; q.flags = s->flags; q.info = s->info_dev; q.nc = nc; q.tol = tol;
     q.best_x = nullptr; q.best_it = nullptr; q.stall_limit = 0;
     q.it_ctr = s->it_ctr; q.max_iterations = 0;
+    q.accept_factor = 0.f; q.accept_window = 0;
     return q;
 }
 
@@ -868,11 +910,12 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
 // residual component that no search direction can reduce (the solve stalls just above the envs' tolerance and cannot be
 // warm-started), and removing it is what makes the singular system consistent.
 int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
-          int max_iterations, int use_x0, int project_mean, int* max_it, hipStream_t st) {
+          int max_iterations, int use_x0, int project_mean, float stall_accept, int* max_it, hipStream_t st) {
     const int nsys = s->B, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);
     q.rw = nullptr;
     q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = 400;
+    q.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; q.accept_window = 20;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     const bool vec4 = (n % 4 == 0) && !getenv("FG_MB_SCALAR_CG");
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
@@ -882,9 +925,9 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     // CG_CHUNK iterations + the convergence check are one hipGraph: at 14 k cells x 64 envs a kernel runs 5-10 us, about
     // what the host needs to enqueue it, so the loop was launch-bound.  The kernels take their iteration index from a
     // device counter (q.it_ctr) so that one captured chunk serves every replay.
-    constexpr int CG_CHUNK = 16;
+    constexpr int CG_CHUNK = 20, CG_RESTART = 100;
     q.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
-    FG_HIP_CHECK(hipMemsetAsync(s->it_ctr, 0, 2 * sizeof(int32_t), st));
+    FG_HIP_CHECK(hipMemsetAsync(s->it_ctr, 0, 3 * sizeof(int32_t), st));
     auto enqueue_chunk = [&]() {
         MB_DISPATCH(s, {
             for (int k = 0; k < CG_CHUNK; ++k) {
@@ -900,6 +943,7 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
         hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, 0, -1, n, nsys, 0, project_mean ? 0 : -1);
     };
     const bool use_graph = !getenv("FG_MB_NO_GRAPH");
+    const bool trace = getenv("FG_MB_TRACE") != nullptr;
     if (use_graph) {
         MbGraphKey key;
         memset(&key, 0, sizeof(key));
@@ -924,12 +968,21 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
         }
     }
     for (int it = 0; it < q.max_iterations && !done; it += CG_CHUNK) {
+        if (it > 0 && it % CG_RESTART == 0) {
+            hipLaunchKernelGGL(k_mbc_clear, sg, sb, 0, st, q, nsys, it);
+            MB_DISPATCH(s, hipLaunchKernelGGL(k_mbc_restart<DIMS>, grid, blk, 0, st, s->dev, q, it, project_mean););
+        }
         if (use_graph) FG_HIP_CHECK(hipGraphLaunch(s->cg_graph_exec, st));
         else enqueue_chunk();
         if (int rc = mb_poll(s, nsys, st, done)) return rc;
+        if (trace) {
+            float lo = 1e30f, hi = 0.f; int active = 0;
+            for (int i = 0; i < nsys; ++i) { const float c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
+            fprintf(stderr, "[mb_cg] it %4d residual min %.3e max %.3e active %d\n", it + CG_CHUNK, lo, hi, active);
+        }
     }
     bool failed = false;
-    for (int i = 0; i < nsys; ++i) failed = failed || !s->info_pinned[i].converged;
+    for (int i = 0; i < nsys; ++i) failed = failed || !s->info_pinned[i].converged || s->flags_pinned[i] == 5;
     if (failed) {
         hipLaunchKernelGGL(k_mbs_restore_best, grid, blk, 0, st, n, q);
         FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
@@ -1074,7 +1127,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->red, B)) return rc;
     if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->red2, 2 * B)) return rc;
-    if (int rc = mb_alloc(s, &s->it_ctr, 2)) return rc;
+    if (int rc = mb_alloc(s, &s->it_ctr, 4)) return rc;
     if (int rc = mb_alloc(s, &s->dt_dev, B)) return rc;
     FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(float) * B, hipHostMallocDefault));
@@ -1163,7 +1216,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                                     ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol,
                                                   opt->max_iterations, warm, &m, st)
                                     : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol,
-                                            opt->max_iterations, warm, opt->pressure_project_mean, &m, st);
+                                            opt->max_iterations, warm, opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) its[2 + c] = std::max(its[2 + c], m);
                 FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
@@ -1315,7 +1368,7 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
             const int prc = opt->pressure_use_bicgstab
                                 ? mb_bicgstab(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st)
                                 : mb_cg(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, ps > 0,
-                                        opt->pressure_project_mean, &m, st);
+                                        opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
             if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;
             else if (prc != FG_OK) return prc;
             FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));

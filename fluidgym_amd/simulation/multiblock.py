@@ -186,7 +186,7 @@ class MultiBlockDomain:
         self._dt.copy_(torch.as_tensor(dt, dtype=torch.float32).expand(self.batch))
         opt = L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
                                 advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
-                                int(pressure_project_mean))
+                                int(pressure_project_mean), 0.0)
         stats = (ctypes.c_int32 * 4)()
         st = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.fg_mb_piso_step(self.handle, ctypes.c_void_p(self._dt.data_ptr()), ctypes.byref(opt), stats,
@@ -234,10 +234,10 @@ class MultiBlockDomain:
 
     def _step_options(self, corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
                       pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start=False,
-                      pressure_project_mean=False):
+                      pressure_project_mean=False, pressure_stall_accept=0.0):
         return L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
                                  advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
-                                 int(pressure_project_mean))
+                                 int(pressure_project_mean), float(pressure_stall_accept))
 
     def _outflow_slots(self, outflow):
         blk, face = outflow
@@ -271,13 +271,14 @@ class MultiBlockDomain:
                     flux_balance_tol: float = 1e-5, corrector_steps: int = 2, advect_non_ortho_steps: int = 1,
                     pressure_non_ortho_steps: int = 1, advection_tol: float = 1e-5, pressure_tol: float = 1e-5,
                     max_iterations: int = 5000, pressure_use_bicgstab: bool = False, max_substeps: int = 0,
-                    pressure_warm_start: bool = False, pressure_project_mean: bool = False):
+                    pressure_warm_start: bool = False, pressure_project_mean: bool = False,
+                    pressure_stall_accept: float = 0.0):
         """``Simulation.single_step`` on the native side.  ``outflow``: (block, face) of the FIXED face that follows the
         convective outflow condition.  Returns (substeps, all solves converged, max iterations of the last substep)."""
         o = L.FgMbSimOptions()
         o.step = self._step_options(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
                                     pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start,
-                                    pressure_project_mean)
+                                    pressure_project_mean, pressure_stall_accept)
         o.time_step, o.cfl, o.adaptive, o.substeps = float(time_step), float(cfl), int(adaptive), int(substeps)
         o.flux_balance_tol, o.outflow_tol, o.max_substeps = float(flux_balance_tol), float(outflow_tol), int(max_substeps)
         if outflow is not None:
@@ -331,8 +332,9 @@ class MultiBlockSimulation:
                  advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1, max_iterations: int = 5000,
                  pressure_use_BiCG: bool = False, outflow=None, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
                  outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5, pressure_warm_start: bool = True,
-                 pressure_project_mean: bool = True):
+                 pressure_project_mean: bool = True, pressure_stall_accept: float = 1.25):
         self.pressure_warm_start, self.pressure_project_mean = pressure_warm_start, pressure_project_mean
+        self.pressure_stall_accept = pressure_stall_accept
         self.domain, self.time_step, self.adaptive_CFL, self.substeps = domain, float(dt), float(adaptive_CFL), substeps
         self.corrector_steps = corrector_steps
         self.advection_tol = 1e-5 if advection_tol is None else advection_tol   # _get_solver_tolerance (PISOtorch_diff.py:247-253)
@@ -357,7 +359,7 @@ class MultiBlockSimulation:
             advect_non_ortho_steps=self.advect_non_ortho_steps, pressure_non_ortho_steps=self.pressure_non_ortho_steps,
             advection_tol=self.advection_tol, pressure_tol=self.pressure_tol, max_iterations=self.max_iterations,
             pressure_use_bicgstab=self.pressure_use_BiCG, pressure_warm_start=self.pressure_warm_start,
-            pressure_project_mean=self.pressure_project_mean)
+            pressure_project_mean=self.pressure_project_mean, pressure_stall_accept=self.pressure_stall_accept)
         self.total_time += self.time_step
         self.total_step += 1
         self.last_substeps, self.last_iterations = n, its

@@ -337,6 +337,9 @@ typedef struct fg_mb_step_options {
     int32_t pressure_project_mean;     /* 1: CG works on residuals with their mean removed -- identical on orthogonal meshes,
                                           and what keeps the solve from stalling on the constant residual component that the
                                           cross-metric terms feed (1^T P != 0); 0: the reference's plain recurrence */
+    float pressure_stall_accept;       /* > 1: a CG solve whose best iterate is within this factor of pressure_tol and has
+                                          not improved for 16 iterations ends with that iterate (the residual of CG is not
+                                          monotone and hovers around the tolerance on these meshes); 0: off */
 } fg_mb_step_options;
 /* dt_B: device array [B]; dt <= 0 leaves that env untouched.  stats_host (optional, 4 ints): max iterations of
  * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
