@@ -201,6 +201,35 @@ class CylinderEnvBase(FluidEnv):
         reward = self._cd_ref - cd - self._lift_penalty * cl.abs()
         return obs, reward, False, {"drag": cd, "lift": cl}
 
+    # ---- on-disk initial domains in the reference's format (fluid_env.py:1044-1112)
+    def _save_initial_domain(self, mode, idx: int, env: int = 0) -> None:
+        from ..simulation.domain_io import save_multiblock_domain
+
+        out_dir = self._get_domain_dir(idx)
+        out_dir.mkdir(parents=True, exist_ok=True)
+        save_multiblock_domain(self._domain, str(out_dir / mode.value), env=env, name="CylinderDomain")
+
+    def load_initial_domain(self, idx: int, mode=None) -> None:
+        from pathlib import Path
+
+        from ..simulation.domain_io import load_multiblock_domain
+
+        mode = self._mode if mode is None else mode
+        path = self._get_domain_dir(idx) / mode.value
+        if not Path(str(path) + ".json").exists():
+            return super().load_initial_domain(idx, mode)
+        if self._domain is None:
+            self._set_initial_state(randomize=False)
+        loaded = load_multiblock_domain(str(path), device=self._cuda_device, batch=self._num_envs)
+        try:
+            if loaded.n_cells != self._domain.n_cells or [b.size for b in loaded.blocks] != [b.size for b in self._domain.blocks]:
+                raise ValueError(f"initial domain {path} does not match this environment's mesh")
+            snap = loaded.Clone()
+        finally:
+            loaded.close()
+        self._loaded_initial = snap
+        self._domain.Restore(snap)
+
     def _get_extra_state(self):
         return {"last_control": self._last_control.clone()}
 

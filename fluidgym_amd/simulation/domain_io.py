@@ -138,3 +138,94 @@ def load_domain(path: str, dtype=None, device=None, with_scalar: bool = True, ba
         blk.setVelocitySource(get(bd, "velocitySource"))
     dom.solver.reset_solver_state()
     return dom
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# multi-block curvilinear domains (cylinder / airfoil initial states): same file layout, CONNECTED boundaries carry
+# ``connectedBlock`` and ``axes`` (domain_io.py:157-160, 306-312)
+# --------------------------------------------------------------------------------------------------------------------
+_FACE_STR = ["-x", "+x", "-y", "+y", "-z", "+z"]
+
+
+def save_multiblock_domain(domain, path: str, env: int = 0, name: str = "Domain") -> None:
+    """``save_domain`` for env ``env`` of a prepared :class:`~fluidgym_amd.simulation.multiblock.MultiBlockDomain`."""
+    data = []
+
+    def add(t, d: dict, key: str):
+        d[key] = str(len(data))
+        data.append(torch.as_tensor(t).detach().cpu().contiguous().to(torch.float32))
+
+    dims = domain.dims
+    dd = {"name": name, "spatialDims": dims}
+    add(torch.tensor([domain.viscosity]), dd, "viscosity")
+    dd["passiveScalarChannels"] = 0
+    dd["blocks"] = []
+    for blk in domain.blocks:
+        bd = {"name": blk.name}
+        add(blk.cells(domain.velocity[env: env + 1]), bd, "velocity")
+        add(blk.cells(domain.pressure[env: env + 1, None]), bd, "pressure")
+        add(blk.coords[None], bd, "vertexCoordinates")
+        bd["boundaries"] = []
+        for f in range(2 * dims):
+            if f in blk.connections:
+                other, axes = blk.connections[f]
+                e = {"type": "CONNECTED", "connectedBlock": int(other), "axes": [int(a) for a in axes]}
+            elif (f >> 1) in blk.periodic_axes:
+                e = {"type": "PERIODIC"}
+            else:
+                e = {"type": "FIXED", "velocityType": "DIRICHLET"}
+                shape = [1, dims] + [1 if a == (f >> 1) else blk.size[a] for a in reversed(range(dims))]
+                add(blk.boundary(f)[env: env + 1].reshape(shape), e, "velocity")
+            bd["boundaries"].append(e)
+        dd["blocks"].append(bd)
+    dd["data_info"] = {str(i): {"shape": list(t.shape), "dtype": "float32", "device": "cpu"} for i, t in enumerate(data)}
+    np.savez_compressed(path + ".npz", **{str(i): t.numpy() for i, t in enumerate(data)})
+    with open(path + ".json", "w") as fh:
+        json.dump(dd, fh)
+
+
+def load_multiblock_domain(path: str, device=None, batch: int = 1, reference_quirks: bool = True):
+    """``load_domain`` for a domain with CONNECTED boundaries: builds and prepares a ``MultiBlockDomain`` holding the stored
+    state replicated over ``batch`` envs."""
+    from .multiblock import MultiBlockDomain
+
+    with open(path + ".json") as fh:
+        dd = json.load(fh)
+    with np.load(path + ".npz") as z:
+        data = [np.asarray(z[str(i)], dtype=np.float32) for i in range(len(z.files))]
+    get = lambda d, key: data[int(d[key])] if key in d else None
+    dims = int(dd["spatialDims"])
+    if dd.get("passiveScalarChannels", 0):
+        raise NotImplementedError("passive scalars on multi-block domains are not built")
+    nu = float(np.asarray(get(dd, "viscosity")).reshape(-1)[0])
+    dom = MultiBlockDomain(dims, nu, batch=batch, device=device, reference_quirks=reference_quirks)
+    blocks = []
+    for bd in dd["blocks"]:
+        if "vertexCoordinates" not in bd:
+            raise NotImplementedError("blocks stored by transform only (no vertex coordinates)")
+        if "viscosity" in bd:
+            raise NotImplementedError("per-block viscosity fields (SGS) are not built")
+        blocks.append(dom.CreateBlock(get(bd, "vertexCoordinates"), name=bd["name"]))
+    for bi, bd in enumerate(dd["blocks"]):
+        for f, e in enumerate(bd["boundaries"]):
+            t = e["type"]
+            if t in ("FIXED", "DIRICHLET", "DIRICHLET_VARYING"):
+                v = np.asarray(get(e, "velocity"))
+                blocks[bi].CloseBoundary(f, v.reshape(dims, -1) if v.size > dims else v.reshape(dims, 1))
+            elif t == "CONNECTED":
+                other = int(e["connectedBlock"])
+                if f in blocks[bi].connections:      # made from the other side already
+                    continue
+                axes = [int(a) for a in e["axes"]]
+                blocks[bi].ConnectBlock(f, blocks[other], axes[0], axes[1] if dims > 1 else 0, axes[2] if dims > 2 else 0)
+            elif t == "PERIODIC":
+                blocks[bi].MakePeriodic(f >> 1)
+            else:
+                raise TypeError("Unknown boundary type: " + t)
+    dom.PrepareSolve()
+    for blk, bd in zip(blocks, dd["blocks"]):
+        u = torch.as_tensor(get(bd, "velocity"), device=dom.device).reshape(dims, -1)
+        p = torch.as_tensor(get(bd, "pressure"), device=dom.device).reshape(-1)
+        dom.velocity[:, :, blk.cell_offset: blk.cell_offset + blk.n_cells] = u[None]
+        dom.pressure[:, blk.cell_offset: blk.cell_offset + blk.n_cells] = p[None]
+    return dom

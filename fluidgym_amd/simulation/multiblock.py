@@ -39,6 +39,8 @@ class MBBlock:
         self.cell_offset = -1
         self.boundary_slot0: List[int] = [-1] * (2 * d)
         self._pending_velocity: Dict[int, np.ndarray] = {}
+        self.connections: Dict[int, tuple] = {}   # face -> (other block index, ConnectedBoundary.axes)
+        self.periodic_axes: set = set()
 
     # ---- construction (before prepare_solve)
     def CloseBoundary(self, face, velocity=None):
@@ -50,12 +52,28 @@ class MBBlock:
 
     def ConnectBlock(self, face, other: "MBBlock", other_face, axis1, axis2="-z"):
         lib = self.domain.lib
-        L.check(lib.fg_mb_connect(self.domain.handle, self.index, face_index(face), other.index, face_index(other_face),
-                                  face_index(axis1), face_index(axis2) if self.domain.dims == 3 else 0))
+        d = self.domain.dims
+        f1, f2, a1, a2 = face_index(face), face_index(other_face), face_index(axis1), (face_index(axis2) if d == 3 else 0)
+        L.check(lib.fg_mb_connect(self.domain.handle, self.index, f1, other.index, f2, a1, a2))
+        # the axes vectors both ConnectedBoundary objects get (ConnectBlocks, domain_structs.cpp:1080-1113), kept for domain I/O
+        axes1, axes2 = [f2, a1], [f1]
+        f1d, f2d = f1 >> 1, f2 >> 1
+        if d == 2 or (a1 >> 1) == (f2d + 1) % d:
+            axes2.append((((f1d + 1) % d) << 1) | (a1 & 1))
+            swapped = False
+        else:
+            axes2.append((((f1d + 2) % d) << 1) | (a2 & 1))
+            swapped = True
+        if d == 3:
+            axes1.append(a2)
+            axes2.append(((((f1d + 2) % d) << 1) | (a2 & 1)) if not swapped else ((((f1d + 1) % d) << 1) | (a1 & 1)))
+        self.connections[f1] = (other.index, axes1)
+        other.connections[f2] = (self.index, axes2)
 
     def MakePeriodic(self, axis):
         a = _AXES[axis] if isinstance(axis, str) else int(axis)
         L.check(self.domain.lib.fg_mb_make_periodic(self.domain.handle, self.index, a))
+        self.periodic_axes.add(a)
 
     # ---- views (after prepare_solve)
     @property
