@@ -95,6 +95,8 @@ KERNEL_DOC = {
     "k_gemm_sk": "fast-diagonalisation preconditioner: eigenbasis transform, split-K 32x32 tiles (few live envs)",
     "k_dct_rows": "fast-diagonalisation preconditioner: cosine transform of every grid row (one FFT per row in LDS)",
     "k_tridiag_y": "fast-diagonalisation preconditioner: per-mode tridiagonal sweep along y",
+    "k_mbc_ap": "multi-block CG: p = r + beta p on the fly, v = P p over the neighbour table, p.Pp",
+    "k_mbc_update": "multi-block CG: x/r update + r.r + sum r",
 }
 
 
@@ -165,29 +167,45 @@ def roofline_from_profile(prof, solver):
 
 def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
     """The reference's own cylinder env (CylinderJet2D-easy-v0: five-block curvilinear mesh, 14 232 cells, Re 100, 25 PISO
-    steps per env step) on the multi-block path, batched like the headline workload.  Reported next to the headline,
-    which stays on the 256x128 single-block stand-in SURVEY 8d maps the BASELINE config to."""
+    steps per env step) on the multi-block path, batched like the headline workload and driven by the same random policy,
+    with the live roofline of its dominant kernel pair (fg_mb_profile_*).  Reported next to the headline, which stays on the
+    256x128 single-block stand-in SURVEY 8d maps the BASELINE config to."""
     import torch
 
     import fluidgym_amd
 
-    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=num_envs, initial_domain_steps=10,
+    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=num_envs, initial_domain_steps=100,
                             randomize_initial_state=False, cuda_device=device)
     try:
         env.reset(seed=0)
-        a = torch.zeros(num_envs, 1, device=device)
-        env.step(a)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        act = lambda: (torch.rand(num_envs, 1, generator=gen) * 2 - 1).to(device)
+        env.step(act())
+        dom = env._domain
+        dom.profile_enable(True)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(steps):
-            _, _, _, _, info = env.step(a)
+            _, _, _, _, info = env.step(act())
         torch.cuda.synchronize(device)
         el = (time.perf_counter() - t0) / steps
-        return {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "cells_per_env": env._domain.n_cells,
+        prof = dom.profile_read()
+        dom.profile_enable(False)
+        rows = {}
+        for name, r in prof.items():
+            if r["samples"] > 0:
+                avg = r["ms"] / r["samples"]
+                rows[name] = {"doc": KERNEL_DOC.get(name, ""), "avg_busy_launch_ms": avg, "samples": r["samples"],
+                              "launches": r["launches"], "est_total_ms": avg * r["launches"],
+                              "GBps": r["bytes"] / r["ms"] / 1e6, "frac_of_hbm_peak": r["bytes"] / r["ms"] / 1e6 / HBM_PEAK_GBS}
+        return {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "cells_per_env": dom.n_cells,
                 "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el,
-                "unit": "env-steps/s", "pressure_iterations_last_step": list(env._sim.last_iterations[1:]),
-                "drag_coefficient_env0": float(info["drag"][0]),
-                "note": "state 10 sim steps after an impulsive start (no published initial domains offline)"}
+                "unit": "env-steps/s", "policy": "uniform random jets in [-1, 1] (as the headline)",
+                "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
+                "drag_coefficient_env0": float(info["drag"][0]), "kernels": rows,
+                "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline); kernel "
+                        "rows: live start/stop events on the first CG kernel pair of every fourth 20-iteration chunk, algorithmic "
+                        "bytes = 4 (5 + 2d) B (stencil kernel) / 24 B (update kernel) x cells x systems still iterating"}
     finally:
         env.close()
 

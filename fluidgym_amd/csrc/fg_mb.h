@@ -93,6 +93,13 @@ struct fg_mb_state {
     float* red_pinned = nullptr;
     float *red2, *dt_dev;          // [2B] boundary flux sums, [B] time steps of the running substep
     float *red2_pinned = nullptr, *dt_pinned = nullptr;
+    // live timing of the CG pair for bench.py's roofline (fg_mb_profile_*): the first iteration of sampled chunks is issued
+    // with start/stop events on the kernels' own dispatch packets; active systems are known from the poll before the chunk
+    int prof_on = 0, prof_used = 0, prof_chunk = 0;
+    hipEvent_t prof_ev[2 * 32] = {nullptr};
+    int prof_kind[32] = {0}, prof_active[32] = {0};
+    double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0};
+    long long prof_n[2] = {0, 0}, prof_launches[2] = {0, 0};
     std::string err;
 };
 

@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int MB_ACC = 12;  // doubles per system
-constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6;
+constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6, A_SV = 7, A_ST = 8;  // A_SV, A_ST: sum v, sum t (projection)
 
 #define MB_CELL                                         \
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x;  \
@@ -349,6 +349,9 @@ struct MbSolve {
     // stall acceptance (off when 0): a system whose kept iterate is within accept_factor * tol and has not improved for
     // accept_window iterations ends with that iterate and counts as converged
     float accept_factor; int accept_window;
+    // BiCGStab on the singular pressure system: 1 = iterate on Q P with Q = I - 1 1^T / N (all vectors mean-free), which removes
+    // the null space the plain recurrence breaks down on
+    int project;
 };
 
 struct MbGraphKey { MbSolve q; int vec4, project_mean; hipStream_t stream; };
@@ -402,7 +405,7 @@ __global__ void k_mbs_begin(const float* __restrict__ dt, MbSolve q, int nsys) {
 
 // r = rhs - M x0 (x0 = 0 unless use_x0); rw = p = r; rho0 = rr = r.r
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int use_x0, int sum_slot) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int use_x0, int sum_slot, int defer_rho) {
     MB_SYS
     if (q.flags[sys] != 0) return;
     float r = 0.f;
@@ -417,10 +420,26 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int u
     const float s = mb_block_sum(r * r, lds);
     const float s1 = sum_slot >= 0 ? mb_block_sum(r, lds) : 0.f;
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RHO, (double)s);
-        atomicAdd(a + A_RR, (double)s);
+        if (!defer_rho) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
         if (sum_slot >= 0) atomicAdd(a + sum_slot, (double)s1);
     }
+}
+
+// second half of the start of a projected BiCGStab solve: r <- r - mean r, rw = p = r, rho0 = rr = |r|^2
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q) {
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
+    if (q.flags[sys] != 0) return;
+    double* a = q.acc + (size_t)sys * MB_ACC;
+    const size_t vb = (size_t)sys * N;
+    __shared__ float lds[4];
+    const float m = (float)(a[A_ST] / (double)N);  // k_mbs_init left sum r in A_ST
+    float r = 0.f;
+    if (i < N) {
+        r = q.r[vb + i] - m;
+        q.r[vb + i] = r; q.rw[vb + i] = r; q.p[vb + i] = r;
+    }
+    const float s = mb_block_sum(r * r, lds);
+    if (threadIdx.x == 0) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
 }
 
 // ---- BiCGStab (same five-kernel recurrence as fg_bicgstab.hip)
@@ -433,37 +452,44 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) 
     const float crit = mb_rms(a[A_RR], N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it == 0 ? -1 : it); return; }
     if (leader) {
-        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0;
+        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0; a[A_ST] = 0.0;
         q.info[sys].final_residual = crit;
         q.info[sys].used_iterations = it - 1;
     }
     if (it == 0 || !valid) return;
     const float alpha = q.sc[sys * 2], omega = q.sc[sys * 2 + 1];
     const float beta = (float)(a[A_RHO + (it & 1)] / a[A_RHO + ((it + 1) & 1)]) * (alpha / omega);
-    q.p[vb + i] = q.r[vb + i] + beta * (q.p[vb + i] - omega * q.v[vb + i]);
+    const float mv = q.project ? (float)(a[A_SV + 2 * ((it + 1) & 1)] / (double)N) : 0.f;  // sum v of the previous iteration (slots 7 / 9 alternate)
+    q.p[vb + i] = q.r[vb + i] + beta * (q.p[vb + i] - omega * (q.v[vb + i] - mv));
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) {
     MB_SYS
     if (q.flags[sys] != 0) return;
-    float part = 0.f;
+    float part = 0.f, psum = 0.f;
     if (valid) {
         const float y = mb_spmv<DIMS>(D, q, b, q.p + vb, i);
         q.v[vb + i] = y;
-        part = q.rw[vb + i] * y;
+        part = q.rw[vb + i] * y;  // rw is mean-free: rw . (v - mean v) = rw . v
+        psum = y;
     }
     part = mb_block_sum(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + A_RV, (double)part);
+    if (q.project) psum = mb_block_sum(psum, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_RV, (double)part);
+        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+    }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) {
     MB_SYS
     if (q.flags[sys] != 0) return;
     const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_RV]);
-    if (leader) { q.sc[sys * 2] = alpha; a[A_RHO + ((it + 1) & 1)] = 0.0; a[A_RR] = 0.0; }
+    if (leader) { q.sc[sys * 2] = alpha; a[A_RHO + ((it + 1) & 1)] = 0.0; a[A_RR] = 0.0; a[A_SV + 2 * ((it + 1) & 1)] = 0.0; }
+    const float mv = q.project ? (float)(a[A_SV + 2 * (it & 1)] / (double)N) : 0.f;
     float part = 0.f;
     if (valid) {
-        const float r = q.r[vb + i] - alpha * q.v[vb + i];
+        const float r = q.r[vb + i] - alpha * (q.v[vb + i] - mv);
         q.r[vb + i] = r;
         part = r * r;
     }
@@ -479,16 +505,22 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
         if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) q.flags[sys] = 4; }
         return;
     }
-    float pt = 0.f, ptt = 0.f;
+    float pt = 0.f, ptt = 0.f, pst = 0.f;
     if (valid) {
         const float t = mb_spmv<DIMS>(D, q, b, q.r + vb, i);
         q.t[vb + i] = t;
-        pt = t * q.r[vb + i];
+        pt = t * q.r[vb + i];  // s is mean-free: (t - mean t) . s = t . s
         ptt = t * t;
+        pst = t;
     }
     pt = mb_block_sum(pt, lds);
     ptt = mb_block_sum(ptt, lds);
-    if (threadIdx.x == 0) { atomicAdd(a + A_TS, (double)pt); atomicAdd(a + A_TT, (double)ptt); }
+    if (q.project) pst = mb_block_sum(pst, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_TS, (double)pt);
+        atomicAdd(a + A_TT, (double)ptt);
+        if (q.project) atomicAdd(a + A_ST, (double)pst);
+    }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) {
@@ -497,7 +529,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     if (f != 0 && f != 4) return;
     const float alpha = q.sc[sys * 2];
     const bool half = (f == 4);
-    const float omega = half ? 0.f : (float)(a[A_TS] / a[A_TT]);
+    const double st = q.project ? a[A_ST] : 0.0;
+    const float mt = (float)(st / (double)N);
+    const float omega = half ? 0.f : (float)(a[A_TS] / (a[A_TT] - st * st / (double)N));
     if (leader) { q.sc[sys * 2 + 1] = omega; a[A_RV] = 0.0; }
     float prr = 0.f, prho = 0.f;
     if (valid) {
@@ -506,7 +540,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
         } else {
             const float sv = q.r[vb + i];
             q.x[vb + i] += alpha * q.p[vb + i] + omega * sv;
-            const float r = sv - omega * q.t[vb + i];
+            const float r = sv - omega * (q.t[vb + i] - mt);
             q.r[vb + i] = r;
             prr = r * r;
             prho = q.rw[vb + i] * r;
@@ -876,16 +910,19 @@ MbSolve mb_solve_ptrs(fg_mb_state* s, const float* diag, const float* off, const
     q.best_x = nullptr; q.best_it = nullptr; q.stall_limit = 0;
     q.it_ctr = s->it_ctr; q.max_iterations = 0;
     q.accept_factor = 0.f; q.accept_window = 0;
+    q.project = 0;
     return q;
 }
 
 int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, int nc,
-                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st) {
+                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0) {
     const int nsys = s->B * nc, n = s->N;
-    const MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
+    MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
+    q.project = project ? 1 : 0;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
-    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, -1););
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project ? A_ST : -1, project ? 1 : 0););
+    if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
     bool done = false;
     int next_poll = 2;
     for (int it = 0; it < max_iterations && !done; ++it) {
@@ -920,7 +957,7 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     const bool vec4 = (n % 4 == 0) && !getenv("FG_MB_SCALAR_CG");
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
-    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project_mean ? C_SUM : -1););
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project_mean ? C_SUM : -1, 0););
     bool done = false;
     // CG_CHUNK iterations + the convergence check are one hipGraph: at 14 k cells x 64 envs a kernel runs 5-10 us, about
     // what the host needs to enqueue it, so the loop was launch-bound.  The kernels take their iteration index from a
@@ -928,21 +965,59 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     constexpr int CG_CHUNK = 20, CG_RESTART = 100;
     q.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
     FG_HIP_CHECK(hipMemsetAsync(s->it_ctr, 0, 3 * sizeof(int32_t), st));
-    auto enqueue_chunk = [&]() {
+    int active_now = 0;  // systems still iterating, from the poll before this chunk (all active ones at chunk 0)
+    auto prof_collect = [&]() -> int {
+        for (int k = 0; k < s->prof_used; ++k) {
+            float ms = 0.f;
+            FG_HIP_CHECK(hipEventElapsedTime(&ms, s->prof_ev[2 * k], s->prof_ev[2 * k + 1]));
+            const int kind = s->prof_kind[k];
+            if (s->prof_active[k] > 0) {
+                // algorithmic bytes per cell: stencil kernel r, p_old, diag, 2d off, p_new, v (+ the neighbour table, shared
+                // by the env batch); update kernel x (r/w), p, v, r (r/w)
+                const double per_cell = kind == 0 ? 4.0 * (5 + 2 * s->d) + 4.0 * 2 * s->d / (double)s->B : 24.0;
+                s->prof_ms[kind] += ms;
+                s->prof_bytes[kind] += per_cell * (double)n * s->prof_active[k];
+                s->prof_n[kind] += 1;
+            }
+        }
+        s->prof_used = 0;
+        return FG_OK;
+    };
+    auto enqueue_chunk = [&](bool sample) {
         MB_DISPATCH(s, {
             for (int k = 0; k < CG_CHUNK; ++k) {
+                const bool ev = sample && k == 0 && s->prof_used + 2 <= 32;
+                const int e0 = s->prof_used;
+                if (ev) {
+                    s->prof_kind[e0] = 0; s->prof_kind[e0 + 1] = 1;
+                    s->prof_active[e0] = s->prof_active[e0 + 1] = active_now;
+                    s->prof_used += 2;
+                }
+                s->prof_launches[0] += 1; s->prof_launches[1] += 1;
                 if (vec4) {
-                    hipLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                    hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                    if (ev) {
+                        hipExtLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipExtLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                    } else {
+                        hipLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                    }
                 } else {
-                    hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                    hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                    if (ev) {
+                        hipExtLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipExtLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                    } else {
+                        hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                    }
                 }
             }
         });
         hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, 0, -1, n, nsys, 0, project_mean ? 0 : -1);
     };
-    const bool use_graph = !getenv("FG_MB_NO_GRAPH");
+    // the chunk can be replayed as a hipGraph (FG_MB_GRAPH=1); since the four-cells-per-thread kernels the loop is no
+    // longer enqueue-bound and plain launches are as fast, so that is the default (and what the live profiler samples)
+    const bool use_graph = getenv("FG_MB_GRAPH") != nullptr && !s->prof_on;
     const bool trace = getenv("FG_MB_TRACE") != nullptr;
     if (use_graph) {
         MbGraphKey key;
@@ -959,7 +1034,7 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
             const hipStream_t run_stream = st;
             st = s->capture_stream;
             FG_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            enqueue_chunk();
+            enqueue_chunk(false);
             FG_HIP_CHECK(hipStreamEndCapture(st, &graph));
             st = run_stream;
             FG_HIP_CHECK(hipGraphInstantiate(&s->cg_graph_exec, graph, nullptr, nullptr, 0));
@@ -972,9 +1047,13 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
             hipLaunchKernelGGL(k_mbc_clear, sg, sb, 0, st, q, nsys, it);
             MB_DISPATCH(s, hipLaunchKernelGGL(k_mbc_restart<DIMS>, grid, blk, 0, st, s->dev, q, it, project_mean););
         }
+        if (it == 0) { active_now = 0; for (int i = 0; i < nsys; ++i) active_now += 1; }  // inactive envs exit in k_mbs_begin's flags; counted below after the first poll
         if (use_graph) FG_HIP_CHECK(hipGraphLaunch(s->cg_graph_exec, st));
-        else enqueue_chunk();
+        else enqueue_chunk(s->prof_on && (s->prof_chunk++ % 4 == 0));
         if (int rc = mb_poll(s, nsys, st, done)) return rc;
+        active_now = 0;
+        for (int i = 0; i < nsys; ++i) active_now += s->flags_pinned[i] == 0;
+        if (s->prof_used) if (int rc = prof_collect()) return rc;
         if (trace) {
             float lo = 1e30f, hi = 0.f; int active = 0;
             for (int i = 0; i < nsys; ++i) { const float c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
@@ -1020,6 +1099,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
 extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (!s) return FG_OK;
     if (s->cg_graph_exec) (void)hipGraphExecDestroy(s->cg_graph_exec);
+    if (s->prof_ev[0]) for (int k = 0; k < 64; ++k) (void)hipEventDestroy(s->prof_ev[k]);
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->info_pinned) (void)hipHostFree(s->info_pinned);
@@ -1214,7 +1294,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                     hipLaunchKernelGGL(k_mb_copy, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B), blk, 0, st, (size_t)N, dt_B, s->pressure, s->pres);
                 const int prc = opt->pressure_use_bicgstab
                                     ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol,
-                                                  opt->max_iterations, warm, &m, st)
+                                                  opt->max_iterations, warm, &m, st, opt->pressure_project_mean)
                                     : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol,
                                             opt->max_iterations, warm, opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
                 if (int rc = soft(prc)) return rc;
@@ -1366,7 +1446,8 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
             hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
             int m = 0;
             const int prc = opt->pressure_use_bicgstab
-                                ? mb_bicgstab(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st)
+                                ? mb_bicgstab(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st,
+                                              opt->pressure_project_mean)
                                 : mb_cg(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, ps > 0,
                                         opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
             if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;
@@ -1395,6 +1476,25 @@ extern "C" int fg_mb_get_boundary_tables(fg_mb_handle s, int32_t* cell, int32_t*
 extern "C" int fg_mb_get_cell_transforms(fg_mb_handle s, float* transform /* [N][d*d+1] Minv | det */) {
     FG_REQUIRE(s && s->finalized && transform, FG_ERR_INVALID_ARG, "fg_mb_get_cell_transforms: bad argument");
     std::copy(s->h_T.begin(), s->h_T.end(), transform);
+    return FG_OK;
+}
+
+extern "C" int fg_mb_profile_enable(fg_mb_handle s, int32_t on) {
+    FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_profile_enable: domain not finalized");
+    if (on && !s->prof_ev[0])
+        for (int k = 0; k < 64; ++k) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[k]));
+    s->prof_on = on ? 1 : 0;
+    s->prof_used = 0; s->prof_chunk = 0;
+    for (int k = 0; k < 2; ++k) { s->prof_ms[k] = 0; s->prof_bytes[k] = 0; s->prof_n[k] = 0; s->prof_launches[k] = 0; }
+    return FG_OK;
+}
+extern "C" const char* fg_mb_profile_kind_name(int32_t kind) { return kind == 0 ? "k_mbc_ap" : (kind == 1 ? "k_mbc_update" : nullptr); }
+extern "C" int fg_mb_profile_read(fg_mb_handle s, int32_t kind, double* ms_sum, int64_t* samples, double* bytes_sum, int64_t* launches) {
+    FG_REQUIRE(s && kind >= 0 && kind < 2, FG_ERR_INVALID_ARG, "fg_mb_profile_read: bad argument");
+    if (ms_sum) *ms_sum = s->prof_ms[kind];
+    if (samples) *samples = s->prof_n[kind];
+    if (bytes_sum) *bytes_sum = s->prof_bytes[kind];
+    if (launches) *launches = s->prof_launches[kind];
     return FG_OK;
 }
 

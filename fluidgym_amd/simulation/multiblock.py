@@ -308,6 +308,21 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_single_step(self.handle, ctypes.byref(o), out, None, ctypes.c_void_p(st)))
         return out[4], bool(out[5]), (out[1], out[2], out[3])
 
+    # ---- live kernel timing (bench.py)
+    def profile_enable(self, on: bool = True) -> None:
+        L.check(self.lib.fg_mb_profile_enable(self.handle, int(on)))
+
+    def profile_read(self) -> dict:
+        out = {}
+        for kind in range(2):
+            ms, nb = ctypes.c_double(), ctypes.c_double()
+            n, launches = ctypes.c_int64(), ctypes.c_int64()
+            L.check(self.lib.fg_mb_profile_read(self.handle, kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(nb),
+                                                ctypes.byref(launches)))
+            out[self.lib.fg_mb_profile_kind_name(kind).decode()] = {"ms": ms.value, "samples": n.value, "bytes": nb.value,
+                                                                    "launches": launches.value}
+        return out
+
     # ---- what FluidEnv needs of a Domain
     def Clone(self) -> dict:
         return {"velocity": self.velocity.clone(), "pressure": self.pressure.clone(),

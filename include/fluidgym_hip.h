@@ -338,8 +338,11 @@ typedef struct fg_mb_step_options {
                                           and what keeps the solve from stalling on the constant residual component that the
                                           cross-metric terms feed (1^T P != 0); 0: the reference's plain recurrence */
     float pressure_stall_accept;       /* > 1: a CG solve whose best iterate is within this factor of pressure_tol and has
-                                          not improved for 16 iterations ends with that iterate (the residual of CG is not
-                                          monotone and hovers around the tolerance on these meshes); 0: off */
+                                          not improved for 20 iterations ends with that iterate: the reference's
+                                          pressure matrix has a near-null LEFT vector y that is not constant, so a
+                                          flux-balanced right-hand side keeps a component (y.b) y no iteration can remove
+                                          -- a residual floor |y.b| / sqrt(N) that sits at 1.1e-5 on the reference's own
+                                          cylinder mesh, right at its 1e-5 tolerance; 0: off */
 } fg_mb_step_options;
 /* dt_B: device array [B]; dt <= 0 leaves that env untouched.  stats_host (optional, 4 ints): max iterations of
  * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
@@ -376,6 +379,12 @@ int fg_mb_get_boundary_tables(fg_mb_handle h, int32_t* cell, int32_t* face, floa
 int fg_mb_get_cell_transforms(fg_mb_handle h, float* transform);
 /* max |Minv u| over cells and boundary faces per env (Domain.getMaxVelocity(True, True)); synchronises */
 int fg_mb_max_velocity(fg_mb_handle h, float* out_B_host, void* stream);
+/* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
+ * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their
+ * ALGORITHMIC bytes (active systems x cells x per-cell figure) and the total launches since enable */
+int fg_mb_profile_enable(fg_mb_handle h, int32_t on);
+const char* fg_mb_profile_kind_name(int32_t kind);
+int fg_mb_profile_read(fg_mb_handle h, int32_t kind, double* ms_sum, int64_t* samples, double* bytes_sum, int64_t* launches);
 #define FG_MB_BUF_A 0               /* [B,N]   diagonal of C */
 #define FG_MB_BUF_C_OFF 1           /* [B,2d,N] */
 #define FG_MB_BUF_RHS 2             /* [B,d,N] velocity right-hand side of the last solve */
