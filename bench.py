@@ -195,7 +195,8 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
         for name, r in prof.items():
             if r["samples"] > 0:
                 avg = r["ms"] / r["samples"]
-                rows[name] = {"doc": KERNEL_DOC.get(name, ""), "avg_busy_launch_ms": avg, "samples": r["samples"],
+                rows[name] = {"doc": KERNEL_DOC.get(name, ""), "traffic": pmc_traffic(name + "4"), "avg_busy_launch_ms": avg,
+                              "samples": r["samples"],
                               "launches": r["launches"], "est_total_ms": avg * r["launches"],
                               "GBps": r["bytes"] / r["ms"] / 1e6, "frac_of_hbm_peak": r["bytes"] / r["ms"] / 1e6 / HBM_PEAK_GBS}
         return {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "cells_per_env": dom.n_cells,
