@@ -752,6 +752,25 @@ __global__ void k_mbc_clear(MbSolve q, int nsys, int it) {
     if (s >= nsys) return;
     q.acc[(size_t)s * MB_ACC + C_RHO + it % 3] = 0.0;
     q.acc[(size_t)s * MB_ACC + C_SUM + it % 3] = 0.0;
+    q.acc[(size_t)s * MB_ACC + C_PAP] = 0.0;      // both idle between iterations; a recovered system left NaN here
+    q.acc[(size_t)s * MB_ACC + C_PAP + 1] = 0.0;
+}
+// a system whose recurrence broke down (p.Pp <= 0 or overflow on the non-symmetric matrix: flag 2) goes back to its kept
+// iterate and rejoins the iteration at the restart that follows
+__global__ void k_mbs_recover(int N, MbSolve q) {
+    const int sys = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (q.flags[sys] != 2) return;
+    if (i < N) {
+        const float v = q.best_x[(size_t)sys * N + i];
+        q.x[(size_t)sys * N + i] = isfinite(v) ? v : 0.f;
+    }
+}
+__global__ void k_mbs_recover_flags(MbSolve q, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys || q.flags[s] != 2) return;
+    q.flags[s] = 0;
+    q.info[s].is_finite = 1;
+    q.info[s].converged = 0;
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, int it, int project_mean) {
@@ -1042,8 +1061,11 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
             memcpy(&stored, &key, sizeof(key));
         }
     }
+    int recoveries = 0;
+    bool need_restart = false;
     for (int it = 0; it < q.max_iterations && !done; it += CG_CHUNK) {
-        if (it > 0 && it % CG_RESTART == 0) {
+        if (it > 0 && (it % CG_RESTART == 0 || need_restart)) {
+            need_restart = false;
             hipLaunchKernelGGL(k_mbc_clear, sg, sb, 0, st, q, nsys, it);
             MB_DISPATCH(s, hipLaunchKernelGGL(k_mbc_restart<DIMS>, grid, blk, 0, st, s->dev, q, it, project_mean););
         }
@@ -1054,6 +1076,15 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
         active_now = 0;
         for (int i = 0; i < nsys; ++i) active_now += s->flags_pinned[i] == 0;
         if (s->prof_used) if (int rc = prof_collect()) return rc;
+        bool broke = false;
+        for (int i = 0; i < nsys; ++i) broke = broke || s->flags_pinned[i] == 2;
+        if (broke && recoveries < 3 && it + CG_CHUNK < q.max_iterations) {
+            hipLaunchKernelGGL(k_mbs_recover, grid, blk, 0, st, n, q);
+            hipLaunchKernelGGL(k_mbs_recover_flags, sg, sb, 0, st, q, nsys);
+            ++recoveries;
+            need_restart = true;
+            done = false;
+        }
         if (trace) {
             float lo = 1e30f, hi = 0.f; int active = 0;
             for (int i = 0; i < nsys; ++i) { const float c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
@@ -1273,9 +1304,10 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         for (int no = 0; no < opt->advect_non_ortho_steps; ++no) {
             hipLaunchKernelGGL(k_mb_vrhs<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->velocity, s->ures, s->bvel, s->fb, s->source, s->rhs);
             int m = 0;
-            if (int rc = soft(mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
-                                          opt->max_iterations, no > 0, &m, st)))
-                return rc;
+            const int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
+                                        opt->max_iterations, no > 0, &m, st);
+            if (vrc == FG_ERR_NOT_FINITE) fg_set_error("fg_mb_piso_step: the velocity (BiCGStab) solve produced a non-finite residual");
+            if (int rc = soft(vrc)) return rc;
             its[1] = std::max(its[1], m);
         }
         // ---- correctors (SIM.py:1777-1972)
@@ -1297,6 +1329,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                                                   opt->max_iterations, warm, &m, st, opt->pressure_project_mean)
                                     : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol,
                                             opt->max_iterations, warm, opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
+                if (prc == FG_ERR_NOT_FINITE) fg_set_error("fg_mb_piso_step: the pressure solve produced a non-finite residual");
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) its[2 + c] = std::max(its[2 + c], m);
                 FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));

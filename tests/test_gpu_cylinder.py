@@ -102,3 +102,22 @@ def test_initial_domain_files_roundtrip_in_the_reference_layout(tmp_path, monkey
         out = env2._domain.blocks[4].boundary("+x")[b]
         assert torch.equal(out, env._domain.blocks[4].boundary("+x", want["boundary_velocity"])[1])
     env.close(); env2.close()
+
+
+def test_uncontrolled_wake_sheds_like_the_benchmark_flow():
+    """The env's geometry is the Schaefer-Turek 2D-2 benchmark (Re 100; published C_D,max 3.22-3.24, C_L,max 0.99-1.01,
+    St 0.295-0.305) up to the reference's choice of inflow profile height and this coarse mesh: a periodic wake with those
+    magnitudes must develop (measured at resolution 24: C_D 3.39, C_L +-1.25, St 0.274; profiles/r01_cylinder_shedding_*)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "..", "profiles", "cylinder_shedding.py")
+    spec = importlib.util.spec_from_file_location("cylinder_shedding", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist, _ = mod.run(resolution=24, t_end=40.0)
+    a = mod.analyse(hist, 20.0)
+    assert a["periods"] >= 4
+    assert 0.24 < a["strouhal"] < 0.32
+    assert 3.0 < a["cd_mean"] < 3.7 and a["cd_max"] - a["cd_mean"] < 0.2
+    assert 0.8 < a["cl_max"] < 1.6 and -1.6 < a["cl_min"] < -0.8
