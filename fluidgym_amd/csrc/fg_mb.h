@@ -59,6 +59,7 @@ struct MbDev {
     const int32_t* SP_face;         // [KPN][N]
     const float* SP_wp;             // [KPN][N]
     const float* SP_wn;             // [KPN][N]
+    const float* yproj;             // [N] unit vector the CG residuals are kept orthogonal to (constant by default)
 };
 
 struct fg_mb_state {
@@ -89,6 +90,7 @@ struct fg_mb_state {
     unsigned char cg_graph_key_storage[256] = {0};
     int32_t* flags_pinned = nullptr;
     fg_solve_info *info_dev, *info_pinned = nullptr;
+    float* yproj = nullptr;
     float* red;        // [B] reductions (mean, max)
     float* red_pinned = nullptr;
     float *red2, *dt_dev;          // [2B] boundary flux sums, [B] time steps of the running substep

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int u
         q.p[vb + i] = r;
     }
     const float s = mb_block_sum(r * r, lds);
-    const float s1 = sum_slot >= 0 ? mb_block_sum(r, lds) : 0.f;
+    const float s1 = sum_slot >= 0 ? mb_block_sum(valid ? r * (q.project ? 1.f : D.yproj[i]) : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
         if (!defer_rho) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
         if (sum_slot >= 0) atomicAdd(a + sum_slot, (double)s1);
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
 // on the fly (p ping-pongs between two buffers so that the neighbours' old values are still there), which removes one
 // launch per iteration from a solve that is launch-bound at these mesh sizes (14 k cells x 64 envs).
 // accumulators: rho ring 0..2 (r_k.r_k in slot k % 3) | pAp ping-pong 3,4
-constexpr int C_RHO = 0, C_PAP = 3, C_SUM = 8;  // C_SUM ring 8..10: sum of r_k (mean projection, see mb_cg)
+constexpr int C_RHO = 0, C_PAP = 3, C_SUM = 8;  // C_SUM ring 8..10: yp . r_k (residual projection, see mb_cg)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* __restrict__ pA, float* __restrict__ pB, int it_arg,
                                                       int project_mean) {
@@ -568,15 +568,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
     float* p_new = (it & 1) ? pB : pA;
     if (q.flags[sys] != 0) return;
     // residual with its mean removed (project_mean): rho = |r|^2 - (sum r)^2 / N
+    // residual with its component along the projection vector yp removed (|yp| = 1): rho = |r|^2 - (yp.r)^2
     const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
-    const float mean_r = (float)(sum_r / (double)N);
-    const double rho = a[C_RHO + it % 3] - sum_r * sum_r / (double)N;
+    const float cy = (float)sum_r;
+    const double rho = a[C_RHO + it % 3] - sum_r * sum_r;
     const float crit = mb_rms(rho, N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
     double rho_prev = 1.0;
     if (it > 0) {
         const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
-        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp / (double)N;
+        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp;
     }
     const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
     const float beta = fresh ? 0.f : (float)(rho / rho_prev);
@@ -594,12 +595,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
         constexpr int F = 2 * DIMS;
         const float* r = q.r + vb;
         const float* po = p_old + vb;
-        const float pi = fresh ? r[i] - mean_r : r[i] - mean_r + beta * po[i];
+        const float* yp = D.yproj;
+        const float pi = fresh ? r[i] - cy * yp[i] : r[i] - cy * yp[i] + beta * po[i];
         float y = q.diag[(size_t)b * N + i] * pi;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int n = D.nbr[(size_t)f * N + i];
-            if (n >= 0) y += q.off[((size_t)b * F + f) * N + i] * (fresh ? r[n] - mean_r : r[n] - mean_r + beta * po[n]);
+            if (n >= 0) y += q.off[((size_t)b * F + f) * N + i] * (fresh ? r[n] - cy * yp[n] : r[n] - cy * yp[n] + beta * po[n]);
         }
         p_new[vb + i] = pi;
         q.v[vb + i] = y;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
     const float* p = (it & 1) ? pB : pA;
     if (q.flags[sys] != 0) return;
     const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
-    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r / (double)N) / a[C_PAP + (it & 1)]);
+    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r) / a[C_PAP + (it & 1)]);
     if (leader) a[C_PAP + ((it + 1) & 1)] = 0.0;  // k_mbc_ap of the next iteration accumulates it; not read here
     float part = 0.f, psum = 0.f;
     if (valid) {
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
         const float r = q.r[vb + i] - alpha * q.v[vb + i];
         q.r[vb + i] = r;
         part = r * r;
-        psum = r;
+        psum = r * D.yproj[i];
     }
     part = mb_block_sum(part, lds);
     if (project_mean) psum = mb_block_sum(psum, lds);
@@ -653,15 +655,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
     const float* p_old = (it & 1) ? pA : pB;
     float* p_new = (it & 1) ? pB : pA;
     if (q.flags[sys] != 0) return;
+    // residual with its component along the projection vector yp removed (|yp| = 1): rho = |r|^2 - (yp.r)^2
     const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
-    const float mean_r = (float)(sum_r / (double)N);
-    const double rho = a[C_RHO + it % 3] - sum_r * sum_r / (double)N;
+    const float cy = (float)sum_r;
+    const double rho = a[C_RHO + it % 3] - sum_r * sum_r;
     const float crit = mb_rms(rho, N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
     double rho_prev = 1.0;
     if (it > 0) {
         const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
-        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp / (double)N;
+        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp;
     }
     const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
     const float beta = fresh ? 0.f : (float)(rho / rho_prev);
@@ -679,7 +682,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
         const float* r = q.r + vb;
         const float* po = p_old + vb;
         const float4 r4 = *reinterpret_cast<const float4*>(r + i);
-        float pi[4] = {r4.x - mean_r, r4.y - mean_r, r4.z - mean_r, r4.w - mean_r};
+        const float* yp = D.yproj;
+        const float4 y4 = *reinterpret_cast<const float4*>(yp + i);
+        float pi[4] = {r4.x - cy * y4.x, r4.y - cy * y4.y, r4.z - cy * y4.z, r4.w - cy * y4.w};
         if (!fresh) {
             const float4 p4 = *reinterpret_cast<const float4*>(po + i);
             pi[0] += beta * p4.x; pi[1] += beta * p4.y; pi[2] += beta * p4.z; pi[3] += beta * p4.w;
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
-                float pn = r[n] - mean_r;
+                float pn = r[n] - cy * yp[n];
                 if (!fresh) pn += beta * po[n];
                 y[e] += oo[e] * pn;
             }
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
     if (threadIdx.x == 0) atomicAdd(a + C_PAP + (it & 1), (double)part);
 }
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, const float* __restrict__ pA, const float* __restrict__ pB,
-                                                           int it_arg, int project_mean) {
+                                                           int it_arg, int project_mean, const float* __restrict__ yp) {
     const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;
     const int sys = blockIdx.y;
     const bool valid = i < N, leader = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, cons
     const float* p = (it & 1) ? pB : pA;
     if (q.flags[sys] != 0) return;
     const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
-    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r / (double)N) / a[C_PAP + (it & 1)]);
+    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r) / a[C_PAP + (it & 1)]);
     if (leader) a[C_PAP + ((it + 1) & 1)] = 0.0;
     float part = 0.f, psum = 0.f;
     if (valid) {
@@ -734,7 +739,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, cons
         *reinterpret_cast<float4*>(q.x + vb + i) = x4;
         *reinterpret_cast<float4*>(q.r + vb + i) = r4;
         part = r4.x * r4.x + r4.y * r4.y + r4.z * r4.z + r4.w * r4.w;
-        psum = r4.x + r4.y + r4.z + r4.w;
+        const float4 y4 = *reinterpret_cast<const float4*>(yp + i);
+        psum = r4.x * y4.x + r4.y * y4.y + r4.z * y4.z + r4.w * y4.w;
     }
     part = mb_block_sum(part, lds);
     if (project_mean) psum = mb_block_sum(psum, lds);
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, in
         q.r[vb + i] = r;
     }
     const float s2 = mb_block_sum(r * r, lds);
-    const float s1 = project_mean ? mb_block_sum(r, lds) : 0.f;
+    const float s1 = project_mean ? mb_block_sum(valid ? r * D.yproj[i] : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
         atomicAdd(a + C_RHO + it % 3, (double)s2);
         if (project_mean) atomicAdd(a + C_SUM + it % 3, (double)s1);
@@ -802,7 +808,7 @@ __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32
     if (q.flags[s] == 4) q.flags[s] = 1;
     if (q.flags[s] == 0) {
         double rr = q.acc[(size_t)s * MB_ACC + rr_slot];
-        if (sum_slot >= 0) { const double sr = q.acc[(size_t)s * MB_ACC + sum_slot]; rr -= sr * sr / (double)n; }
+        if (sum_slot >= 0) { const double sr = q.acc[(size_t)s * MB_ACC + sum_slot]; rr -= sr * sr; }
         const float crit = (float)sqrt(rr / (double)n);
         q.info[s].final_residual = crit;
         q.info[s].used_iterations = it + 1;
@@ -1016,10 +1022,10 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
                 if (vec4) {
                     if (ev) {
                         hipExtLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                        hipExtLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                        hipExtLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean, s->dev.yproj);
                     } else {
                         hipLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                        hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                        hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean, s->dev.yproj);
                     }
                 } else {
                     if (ev) {
@@ -1237,6 +1243,12 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->info_dev, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->red, B)) return rc;
     if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
+    if (int rc = mb_alloc(s, &s->yproj, N)) return rc;
+    {
+        std::vector<float> ones(N, 1.f / std::sqrt((float)N));
+        FG_HIP_CHECK(hipMemcpy(s->yproj, ones.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        s->dev.yproj = s->yproj;
+    }
     if (int rc = mb_alloc(s, &s->red2, 2 * B)) return rc;
     if (int rc = mb_alloc(s, &s->it_ctr, 4)) return rc;
     if (int rc = mb_alloc(s, &s->dt_dev, B)) return rc;
@@ -1509,6 +1521,32 @@ extern "C" int fg_mb_get_boundary_tables(fg_mb_handle s, int32_t* cell, int32_t*
 extern "C" int fg_mb_get_cell_transforms(fg_mb_handle s, float* transform /* [N][d*d+1] Minv | det */) {
     FG_REQUIRE(s && s->finalized && transform, FG_ERR_INVALID_ARG, "fg_mb_get_cell_transforms: bad argument");
     std::copy(s->h_T.begin(), s->h_T.end(), transform);
+    return FG_OK;
+}
+
+// Vector the CG residuals are kept orthogonal to (pressure_project_mean): default the constant; the left near-null vector of
+// the pressure matrix removes the residual floor the constant leaves on non-orthogonal meshes.  Host array [N].
+extern "C" int fg_mb_set_residual_projection(fg_mb_handle s, const float* y_host) {
+    FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_set_residual_projection: domain not finalized");
+    std::vector<float> y(s->N);
+    double nrm = 0.0;
+    for (int i = 0; i < s->N; ++i) { y[i] = y_host ? y_host[i] : 1.f; nrm += (double)y[i] * y[i]; }
+    FG_REQUIRE(nrm > 0.0 && std::isfinite(nrm), FG_ERR_INVALID_ARG, "fg_mb_set_residual_projection: zero or non-finite vector");
+    const float sc = (float)(1.0 / std::sqrt(nrm));
+    for (int i = 0; i < s->N; ++i) y[i] *= sc;
+    FG_HIP_CHECK(hipMemcpy(s->yproj, y.data(), sizeof(float) * s->N, hipMemcpyHostToDevice));
+    return FG_OK;
+}
+// builds the pressure matrix for A = 1 into the P buffers (FG_MB_BUF_P_DIAG / P_OFF): the geometry-only matrix whose left
+// near-null vector fg_mb_set_residual_projection wants
+extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
+    FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_unit_pressure_matrix: domain not finalized");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t BN = (size_t)s->B * s->N;
+    hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), dim3(FG_BLOCK), 0, st, BN, 1.f, s->rA);
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, dim3((s->N + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st, s->dev,
+                                      (const float*)nullptr, s->rA, s->Pdiag, s->Poff););
+    FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }
 

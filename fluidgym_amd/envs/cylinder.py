@@ -50,7 +50,7 @@ class CylinderEnvBase(FluidEnv):
 
     def __init__(self, reynolds_number: float, resolution: int, dt: float, adaptive_cfl: float, step_length: float,
                  episode_length: int, lift_penalty: float = 1.0, ndims: int = 2, initial_domain_steps: Optional[int] = None,
-                 drag_reference: float = 0.0, pressure_use_BiCG: bool = False, **kw):
+                 drag_reference: float = 0.0, pressure_use_BiCG: bool = False, pressure_deflation: bool = False, **kw):
         if ndims != 2:
             raise NotImplementedError("3-D cylinder envs (extruded mesh, periodic in z) are not built yet")
         self._reynolds_number = reynolds_number
@@ -59,6 +59,7 @@ class CylinderEnvBase(FluidEnv):
         self._nu = self._U_mean / reynolds_number
         self._cd_ref = float(drag_reference)
         self._pressure_use_bicg = pressure_use_BiCG
+        self._pressure_deflation = pressure_deflation
         if initial_domain_steps is not None:
             self._initial_domain_steps = int(initial_domain_steps)
         super().__init__(dt=dt, adaptive_cfl=adaptive_cfl, step_length=step_length, episode_length=episode_length,
@@ -132,6 +133,7 @@ class CylinderEnvBase(FluidEnv):
         self._ring = WallRing(dom, [(LEFT, "+x", False), (TOP, "-y", False), (RIGHT, "-x", True), (BOTTOM, "+y", True)])
         self._resampler = MultiBlockResampler(self._mesh.coords, self.render_shape[:2], fill_max_steps=16, device=dom.device)
         self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.T)
+        self._deflation_cos = dom.set_pressure_deflation() if self._pressure_deflation else 1.0
         self._initial_boundary = dom.boundary_velocity.clone()  # inflow / outflow profile, walls at rest
         self._last_control = torch.zeros(self._num_envs, 1, device=dom.device)
 

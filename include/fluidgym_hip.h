@@ -379,6 +379,11 @@ int fg_mb_get_boundary_tables(fg_mb_handle h, int32_t* cell, int32_t* face, floa
 int fg_mb_get_cell_transforms(fg_mb_handle h, float* transform);
 /* max |Minv u| over cells and boundary faces per env (Domain.getMaxVelocity(True, True)); synchronises */
 int fg_mb_max_velocity(fg_mb_handle h, float* out_B_host, void* stream);
+/* pressure_project_mean keeps the CG residuals orthogonal to a unit vector: the constant by default, or y_host [N] (any scale).
+ * fg_mb_unit_pressure_matrix leaves the pressure matrix for A = 1 in the P buffers so that a host routine can compute its left
+ * near-null vector, the choice that removes the residual floor of non-orthogonal meshes */
+int fg_mb_set_residual_projection(fg_mb_handle h, const float* y_host);
+int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their
  * ALGORITHMIC bytes (active systems x cells x per-cell figure) and the total launches since enable */
