@@ -1336,11 +1336,16 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 const int warm = (ps > 0 || opt->pressure_warm_start) ? 1 : 0;
                 if (ps == 0 && warm)  // start from the pressure field (the previous solve's result, or a restored state)
                     hipLaunchKernelGGL(k_mb_copy, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B), blk, 0, st, (size_t)N, dt_B, s->pressure, s->pres);
-                const int prc = opt->pressure_use_bicgstab
-                                    ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol,
-                                                  opt->max_iterations, warm, &m, st, opt->pressure_project_mean)
-                                    : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol,
-                                            opt->max_iterations, warm, opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
+                auto solve = [&](int use_x0) {
+                    return opt->pressure_use_bicgstab
+                               ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations,
+                                             use_x0, &m, st, opt->pressure_project_mean)
+                               : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, use_x0,
+                                       opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
+                };
+                int prc = solve(warm);
+                // a warm-started solve that ends unconverged falls back to the reference's start from zero
+                if (prc == FG_ERR_NOT_CONVERGED && ps == 0 && warm) prc = solve(0);
                 if (prc == FG_ERR_NOT_FINITE) fg_set_error("fg_mb_piso_step: the pressure solve produced a non-finite residual");
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) its[2 + c] = std::max(its[2 + c], m);
