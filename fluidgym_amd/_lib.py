@@ -97,6 +97,8 @@ class FgMbSimOptions(Structure):
         ("outflow_velm", c_float * 3),
         ("outflow_tol", c_float),
         ("max_substeps", c_int32),
+        ("outflow_slot0_b", c_int32),
+        ("outflow_count_b", c_int32),
     ]
 
 
@@ -192,7 +194,7 @@ SIGNATURES = {
     "fg_mb_get_buffer": (c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64)]),
     "fg_mb_read_buffer": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "fg_mb_single_step": (c_int, [c_void_p, POINTER(FgMbSimOptions), POINTER(c_int32), POINTER(c_float), c_void_p]),
-    "fg_mb_update_advective_boundary": (c_int, [c_void_p, c_float, c_int32, c_int32, POINTER(c_float), c_float, c_void_p]),
+    "fg_mb_update_advective_boundary": (c_int, [c_void_p, c_float, c_int32, c_int32, c_int32, c_int32, POINTER(c_float), c_float, c_void_p]),
     "fg_mb_make_divergence_free": (c_int, [c_void_p, POINTER(FgMbStepOptions), c_void_p]),
     "fg_mb_boundary_flux_balance": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
     "fg_mb_get_boundary_tables": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float)]),

@@ -865,7 +865,7 @@ __global__ void k_mb_outflow(MbDev D, const float* __restrict__ dt, const float*
 }
 // signed boundary fluxes (get_fixed_boundary_fluxes, :88-105): out[b][0] = slots outside [slot0, slot0+count), out[b][1] = inside
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_bflux(MbDev D, const float* __restrict__ ub, int slot0, int count,
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_bflux(MbDev D, const float* __restrict__ ub, int slot0, int count, int slot0b, int countb,
                                                         float* __restrict__ out) {
     const int b = blockIdx.x;
     float fx = 0.f, fr = 0.f;
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_bflux(MbDev D, const float* __r
 #pragma unroll
         for (int c = 0; c < DIMS; ++c) s += t[axis * DIMS + c] * ub[((size_t)b * DIMS + c) * D.NB + sl];
         s *= t[DIMS * DIMS] * ((f & 1) ? 1.f : -1.f);
-        if (sl >= slot0 && sl < slot0 + count) fr += s; else fx += s;
+        if ((sl >= slot0 && sl < slot0 + count) || (sl >= slot0b && sl < slot0b + countb)) fr += s; else fx += s;
     }
     __shared__ float lds[4];
     fx = mb_block_sum(fx, lds);
@@ -1375,12 +1375,19 @@ extern "C" int fg_mb_max_velocity(fg_mb_handle s, float* out_B_host, void* strea
     return FG_OK;
 }
 
-static int mb_outflow_pre(fg_mb_state* s, const float* dt_dev, int slot0, int count, const float* velm, float tol, hipStream_t st) {
-    const dim3 g((count + 63) / 64, s->B);
+static int mb_outflow_pre(fg_mb_state* s, const float* dt_dev, int slot0, int count, int slot0b, int countb, const float* velm,
+                          float tol, hipStream_t st) {
+    const int r0[2] = {slot0, slot0b}, rn[2] = {count, countb};
     MB_DISPATCH(s, {
-        hipLaunchKernelGGL(k_mb_outflow<DIMS>, g, dim3(64), 0, st, s->dev, dt_dev, s->velocity, s->bvel, slot0, count, velm[0], velm[1], velm[2]);
-        hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, slot0, count, s->red2);
-        hipLaunchKernelGGL(k_mb_balance<DIMS>, g, dim3(64), 0, st, s->dev, dt_dev, s->red2, 0.01f * tol, s->bvel, slot0, count);
+        for (int k = 0; k < 2; ++k)
+            if (rn[k] > 0)
+                hipLaunchKernelGGL(k_mb_outflow<DIMS>, dim3((rn[k] + 63) / 64, s->B), dim3(64), 0, st, s->dev, dt_dev, s->velocity, s->bvel,
+                                   r0[k], rn[k], velm[0], velm[1], velm[2]);
+        hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, slot0, count, slot0b, countb, s->red2);
+        for (int k = 0; k < 2; ++k)
+            if (rn[k] > 0)
+                hipLaunchKernelGGL(k_mb_balance<DIMS>, dim3((rn[k] + 63) / 64, s->B), dim3(64), 0, st, s->dev, dt_dev, s->red2, 0.01f * tol,
+                                   s->bvel, r0[k], rn[k]);
     });
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
@@ -1388,14 +1395,15 @@ static int mb_outflow_pre(fg_mb_state* s, const float* dt_dev, int slot0, int co
 
 // update_advective_boundaries + balance_boundary_fluxes for one FIXED face with the same dt for every env (the PRE hook as
 // make_divergence_free runs it, with time_step = 1: PISOtorch_simulation.py:1334-1345)
-extern "C" int fg_mb_update_advective_boundary(fg_mb_handle s, float dt, int32_t slot0, int32_t count, const float* velm, float tol,
-                                               void* stream) {
+extern "C" int fg_mb_update_advective_boundary(fg_mb_handle s, float dt, int32_t slot0, int32_t count, int32_t slot0_b, int32_t count_b,
+                                               const float* velm, float tol, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity && velm, FG_ERR_NOT_BOUND, "fg_mb_update_advective_boundary: fields not bound");
-    FG_REQUIRE(slot0 >= 0 && count > 0 && slot0 + count <= s->NB, FG_ERR_INVALID_ARG, "fg_mb_update_advective_boundary: slots out of range");
+    FG_REQUIRE(slot0 >= 0 && count > 0 && slot0 + count <= s->NB && count_b >= 0 && (count_b == 0 || (slot0_b >= 0 && slot0_b + count_b <= s->NB)),
+               FG_ERR_INVALID_ARG, "fg_mb_update_advective_boundary: slots out of range");
     hipStream_t st = (hipStream_t)stream;
     for (int b = 0; b < s->B; ++b) s->dt_pinned[b] = dt;
     FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * s->B, hipMemcpyHostToDevice, st));
-    if (int rc = mb_outflow_pre(s, s->dt_dev, slot0, count, velm, tol, st)) return rc;
+    if (int rc = mb_outflow_pre(s, s->dt_dev, slot0, count, slot0_b, count_b, velm, tol, st)) return rc;
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }
@@ -1405,7 +1413,7 @@ static bool mb_close_zero(double v) { return std::fabs(v) <= 1e-8; }  // np.iscl
 extern "C" int fg_mb_boundary_flux_balance(fg_mb_handle s, float* out_B_host, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_boundary_flux_balance: fields not bound");
     hipStream_t st = (hipStream_t)stream;
-    MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, 0, 0, s->red2););
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, 0, 0, 0, 0, s->red2););
     FG_HIP_CHECK(hipMemcpyAsync(s->red2_pinned, s->red2, sizeof(float) * 2 * s->B, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < s->B; ++b) out_B_host[b] = s->red2_pinned[2 * b] + s->red2_pinned[2 * b + 1];
@@ -1415,7 +1423,9 @@ extern "C" int fg_mb_boundary_flux_balance(fg_mb_handle s, float* out_B_host, vo
 extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int32_t* out, float* flux_host, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity, FG_ERR_NOT_BOUND, "fg_mb_single_step: fields not bound");
     FG_REQUIRE(o && out, FG_ERR_INVALID_ARG, "fg_mb_single_step: null argument");
-    FG_REQUIRE(o->outflow_count == 0 || (o->outflow_slot0 >= 0 && o->outflow_slot0 + o->outflow_count <= s->NB), FG_ERR_INVALID_ARG,
+    FG_REQUIRE((o->outflow_count == 0 || (o->outflow_slot0 >= 0 && o->outflow_slot0 + o->outflow_count <= s->NB)) &&
+                   (o->outflow_count_b == 0 || (o->outflow_count > 0 && o->outflow_slot0_b >= 0 && o->outflow_slot0_b + o->outflow_count_b <= s->NB)),
+               FG_ERR_INVALID_ARG,
                "fg_mb_single_step: outflow slots out of range");
     hipStream_t st = (hipStream_t)stream;
     const int B = s->B;
@@ -1461,7 +1471,9 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
         }
         FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * B, hipMemcpyHostToDevice, st));
         if (o->outflow_count > 0)  // PRE hook of the cylinder / airfoil envs (cylinder_env_base.py:280-300)
-            if (int rc = mb_outflow_pre(s, s->dt_dev, o->outflow_slot0, o->outflow_count, o->outflow_velm, o->outflow_tol, st)) return rc;
+            if (int rc = mb_outflow_pre(s, s->dt_dev, o->outflow_slot0, o->outflow_count, o->outflow_slot0_b, o->outflow_count_b,
+                                        o->outflow_velm, o->outflow_tol, st))
+                return rc;
         const int rc = fg_mb_piso_step(s, s->dt_dev, &o->step, stats, stream);
         if (rc == FG_ERR_NOT_CONVERGED) all_ok = 0;
         else if (rc != FG_OK) return rc;

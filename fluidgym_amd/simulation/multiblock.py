@@ -257,6 +257,14 @@ class MultiBlockDomain:
                                  advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
                                  int(pressure_project_mean), float(pressure_stall_accept))
 
+    def _outflow_ranges(self, outflow):
+        """``outflow``: one (block, face) or a list of up to two; returns [(slot0, count), (slot0_b, count_b)]."""
+        faces = outflow if (isinstance(outflow, (list, tuple)) and isinstance(outflow[0], (list, tuple))) else [outflow]
+        if len(faces) > 2:
+            raise NotImplementedError("at most two outflow faces")
+        r = [self._outflow_slots(f) for f in faces]
+        return r + [(0, 0)] * (2 - len(r))
+
     def _outflow_slots(self, outflow):
         blk, face = outflow
         blk = blk if isinstance(blk, MBBlock) else self.blocks[blk]
@@ -268,10 +276,10 @@ class MultiBlockDomain:
     def update_advective_boundary(self, dt: float, outflow, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
                                   tol: float = 5e-6):
         """``update_advective_boundaries`` + ``balance_boundary_fluxes`` for one face (the envs' PRE hook)."""
-        s0, n = self._outflow_slots(outflow)
+        (s0, n), (s1, n1) = self._outflow_ranges(outflow)
         v = (ctypes.c_float * 3)(*(list(outflow_velocity) + [0.0] * 3)[:3])
         st = torch.cuda.current_stream(self.device).cuda_stream
-        L.check(self.lib.fg_mb_update_advective_boundary(self.handle, float(dt), s0, n, v, float(tol), ctypes.c_void_p(st)))
+        L.check(self.lib.fg_mb_update_advective_boundary(self.handle, float(dt), s0, n, s1, n1, v, float(tol), ctypes.c_void_p(st)))
 
     def make_divergence_free(self, pressure_tol: float = 1e-5, max_iterations: int = 1000, pressure_non_ortho_steps: int = 1,
                              pressure_use_bicgstab: bool = False, outflow=None,
@@ -300,7 +308,7 @@ class MultiBlockDomain:
         o.time_step, o.cfl, o.adaptive, o.substeps = float(time_step), float(cfl), int(adaptive), int(substeps)
         o.flux_balance_tol, o.outflow_tol, o.max_substeps = float(flux_balance_tol), float(outflow_tol), int(max_substeps)
         if outflow is not None:
-            o.outflow_slot0, o.outflow_count = self._outflow_slots(outflow)
+            (o.outflow_slot0, o.outflow_count), (o.outflow_slot0_b, o.outflow_count_b) = self._outflow_ranges(outflow)
         v = list(outflow_velocity) + [0.0] * 3
         o.outflow_velm[0], o.outflow_velm[1], o.outflow_velm[2] = v[0], v[1], v[2]
         out = (ctypes.c_int32 * 6)()

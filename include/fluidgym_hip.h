@@ -365,10 +365,13 @@ typedef struct fg_mb_sim_options {
     float outflow_velm[3];     /* characteristic velocity of the convective condition */
     float outflow_tol;         /* tol of update_advective_boundaries (balance threshold = 0.01 tol) */
     int32_t max_substeps;      /* safety bound, 0 = none */
+    int32_t outflow_slot0_b;   /* a second outflow face (the airfoil mesh has two: airfoil/grid.py:708-714); count 0 = none */
+    int32_t outflow_count_b;
 } fg_mb_sim_options;
 int fg_mb_single_step(fg_mb_handle h, const fg_mb_sim_options* opt, int32_t* out_host, float* flux_host, void* stream);
 /* the PRE hook alone, same dt for every env (make_divergence_free runs it with dt = 1, PISOtorch_simulation.py:1334-1345) */
-int fg_mb_update_advective_boundary(fg_mb_handle h, float dt, int32_t slot0, int32_t count, const float* velm, float tol, void* stream);
+int fg_mb_update_advective_boundary(fg_mb_handle h, float dt, int32_t slot0, int32_t count, int32_t slot0_b, int32_t count_b,
+                                    const float* velm, float tol, void* stream);
 /* Simulation.make_divergence_free (PISOtorch_simulation.py:1318-1429), without its PRE hook */
 int fg_mb_make_divergence_free(fg_mb_handle h, const fg_mb_step_options* opt, void* stream);
 /* Domain.GetBoundaryFluxBalance per env; synchronises */

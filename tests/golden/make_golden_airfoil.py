@@ -1,0 +1,80 @@
+"""Golden fixture of the reference's AIRFOIL mesh (not built yet in fluidgym_amd: pins the next round's mesh builder).
+
+Vertex coordinates of the six blocks, boundary / connection calls and boundary velocities recorded from the reference's
+own ``envs/airfoil/grid.py::make_airfoil_domain`` running HERE against the recording stand-in for the CUDA-only
+``PISOtorch`` module used by ``make_golden_cylinder.py`` (the stand-in only logs construction calls; no reference source is
+copied).  Arguments as ``AirfoilEnvBase._get_domain`` passes them (airfoil_env_base.py:209-229).
+
+    python tests/golden/make_golden_airfoil.py  ->  tests/golden/reference_airfoil_grid.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden_cylinder as M  # noqa: E402  (recording Domain / Block / Boundary, stub helpers)
+
+REF = M.REF
+OUT = M.OUT
+
+
+def main():
+    for pkg in ["fluidgym", "fluidgym.simulation", "fluidgym.simulation.pict", "fluidgym.simulation.pict.data",
+                "fluidgym.simulation.pict.util", "fluidgym.envs", "fluidgym.envs.util", "fluidgym.envs.airfoil"]:
+        M._stub(pkg).__path__ = []
+
+    class _Dom(M._Domain):
+        def getBlocks(self):
+            return []
+
+    class _Blk(M._Block):
+        def CloseBoundary(self, face, *vel):
+            self.log.append(("close", self.idx, face))
+            if vel and vel[0] is not None:
+                self.log.append(("velocity", self.idx, face, vel[0].detach().cpu().numpy().copy()))
+
+    def create(self, vertexCoordinates=None, name=""):
+        b = _Blk(self.log, self.n, vertexCoordinates, name)
+        self.n += 1
+        return b
+
+    _Dom.CreateBlock = create
+    M._stub("fluidgym.simulation.extensions", PISOtorch=types.SimpleNamespace(Domain=_Dom))
+    M._stub("fluidgym.simulation.pict.util.output", plot_grids=lambda *a, **k: None)
+    shapes = M._load(f"{REF}/fluidgym/simulation/pict/data/shapes.py", "fluidgym.simulation.pict.data.shapes")
+    sys.modules["fluidgym.simulation.pict.data"].shapes = shapes
+    M._load(f"{REF}/fluidgym/envs/util/profiles.py", "fluidgym.envs.util.profiles")
+    M._load(f"{REF}/fluidgym/envs/airfoil/coords.py", "fluidgym.envs.airfoil.coords")
+    # the generator ends with balance_boundary_fluxes(domain, out_bounds) (grid.py:714), which needs the compiled backend:
+    # recorded as a call, the balancing itself is the product's job
+    M._stub("fluidgym.simulation.pict.PISOtorch_simulation",
+            balance_boundary_fluxes=lambda domain, bounds: domain.log.append(("balance",) + tuple(f"{b.block}{b.face}" for b in bounds)))
+    grid = M._load(f"{REF}/fluidgym/envs/airfoil/grid.py", "ref_airfoil_grid")
+
+    out = {}
+    for aoa in (20.0, 0.0):
+        dom = grid.make_airfoil_domain(n_dims=2, res_z=0, H=1.4, L=4.5, vel_in=0.3, attack_angle_deg=aoa,
+                                       viscosity=torch.tensor([0.3 / 1e3]), resolution_div=1, tail_grow_mul=1.01,
+                                       cpu_device=torch.device("cpu"), cuda_device=torch.device("cpu"))
+        tag = f"aoa{int(aoa)}"
+        calls = []
+        for rec in dom.log:
+            if rec[0] == "block":
+                out[f"{tag}_block{rec[1]}"] = rec[3][0] if rec[3].ndim == 4 else rec[3]
+                calls.append(f"block {rec[1]} {rec[2]}")
+            elif rec[0] == "velocity":
+                out[f"{tag}_velocity_{rec[1]}_{rec[2]}"] = rec[3]
+                calls.append(f"velocity {rec[1]} {rec[2]}")
+            else:
+                calls.append(" ".join(str(x) for x in rec))
+        out[f"{tag}_calls"] = np.array(calls)
+        print(tag, [(k, v.shape) for k, v in out.items() if k.startswith(tag) and v.dtype.kind != "U"])
+        print(calls)
+    np.savez_compressed(os.path.join(OUT, "reference_airfoil_grid.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
