@@ -180,6 +180,7 @@ SIGNATURES = {
     "fg_mb_finalize": (c_int, [c_void_p]),
     "fg_mb_sizes": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     "fg_mb_block_info": (c_int, [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    "fg_mb_get_host_table": (c_int, [c_void_p, c_int32, c_void_p, POINTER(c_int64)]),
     "fg_mb_get_neighbors": (c_int, [c_void_p, POINTER(c_int32)]),
     "fg_mb_bind": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fg_mb_set_viscosity": (c_int, [c_void_p, c_float]),

@@ -72,6 +72,9 @@ struct fg_mb_state {
     // host copies of the tables (also exported for tests)
     std::vector<int32_t> h_nbr, h_fcode, h_bcell, h_bface;
     std::vector<float> h_T, h_Tb;
+    std::vector<float> h_Vdiag, h_Voff, h_KPp, h_KPn, h_SVc_w, h_SVb_w, h_SP_wp, h_SP_wn;
+    std::vector<int32_t> h_SVc_idx, h_SVb_idx, h_SP_idx, h_SP_face;
+    bool host_only = false;  // created with device < 0: tables are built and readable, nothing touches a GPU (CPU tests)
     MbDev dev{};
     std::vector<void*> owned;  // device allocations
     // bound fields (caller-owned device memory)

@@ -1126,9 +1126,10 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
     FG_REQUIRE(out != nullptr, FG_ERR_INVALID_ARG, "fg_mb_create: out is null");
     FG_REQUIRE(dims == 2 || dims == 3, FG_ERR_INVALID_ARG, "fg_mb_create: dims must be 2 or 3");
     FG_REQUIRE(batch >= 1, FG_ERR_INVALID_ARG, "fg_mb_create: batch must be >= 1");
-    FG_HIP_CHECK(hipSetDevice(device));
+    if (device >= 0) FG_HIP_CHECK(hipSetDevice(device));
     fg_mb_state* s = new fg_mb_state();
     s->d = dims; s->F = 2 * dims; s->B = batch;
+    s->host_only = device < 0;
     *out = s;
     return FG_OK;
 }
@@ -1222,6 +1223,7 @@ extern "C" int fg_mb_set_reference_quirks(fg_mb_handle s, int32_t connected_diag
 extern "C" int fg_mb_finalize(fg_mb_handle s) {
     FG_REQUIRE(s && !s->finalized && !s->blocks.empty(), FG_ERR_INVALID_ARG, "fg_mb_finalize: nothing to finalize");
     if (int rc = fg_mb_build_tables(s)) return rc;
+    if (s->host_only) { s->finalized = true; return FG_OK; }
     const size_t B = s->B, N = s->N, NB = s->NB, d = s->d, F = s->F;
     if (int rc = mb_alloc(s, &s->cc, B * d * N)) return rc;
     if (int rc = mb_alloc(s, &s->fb, B * NB)) return rc;
@@ -1279,6 +1281,7 @@ extern "C" int fg_mb_block_info(fg_mb_handle s, int32_t block, int32_t* cell_off
 
 extern "C" int fg_mb_bind(fg_mb_handle s, float* velocity, float* pressure_result, float* boundary_velocity, const float* source) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_bind: domain not finalized");
+    FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_bind: this handle was created host-only (device < 0): tables only, no compute");
     FG_REQUIRE(velocity && pressure_result && (boundary_velocity || s->NB == 0), FG_ERR_INVALID_ARG, "fg_mb_bind: null field");
     s->velocity = velocity; s->pressure = pressure_result; s->bvel = boundary_velocity; s->source = source;
     return FG_OK;
@@ -1545,6 +1548,7 @@ extern "C" int fg_mb_get_cell_transforms(fg_mb_handle s, float* transform /* [N]
 // the pressure matrix removes the residual floor the constant leaves on non-orthogonal meshes.  Host array [N].
 extern "C" int fg_mb_set_residual_projection(fg_mb_handle s, const float* y_host) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_set_residual_projection: domain not finalized");
+    FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_set_residual_projection: host-only handle");
     std::vector<float> y(s->N);
     double nrm = 0.0;
     for (int i = 0; i < s->N; ++i) { y[i] = y_host ? y_host[i] : 1.f; nrm += (double)y[i] * y[i]; }
@@ -1558,6 +1562,7 @@ extern "C" int fg_mb_set_residual_projection(fg_mb_handle s, const float* y_host
 // near-null vector fg_mb_set_residual_projection wants
 extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_unit_pressure_matrix: domain not finalized");
+    FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_unit_pressure_matrix: host-only handle");
     hipStream_t st = (hipStream_t)stream;
     const size_t BN = (size_t)s->B * s->N;
     hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), dim3(FG_BLOCK), 0, st, BN, 1.f, s->rA);
@@ -1569,6 +1574,7 @@ extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
 
 extern "C" int fg_mb_profile_enable(fg_mb_handle s, int32_t on) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_profile_enable: domain not finalized");
+    FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_profile_enable: host-only handle");
     if (on && !s->prof_ev[0])
         for (int k = 0; k < 64; ++k) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[k]));
     s->prof_on = on ? 1 : 0;
@@ -1589,6 +1595,7 @@ extern "C" int fg_mb_profile_read(fg_mb_handle s, int32_t kind, double* ms_sum, 
 // intermediate buffers for the parity tests
 extern "C" int fg_mb_get_buffer(fg_mb_handle s, int32_t which, const float** ptr, int64_t* count) {
     FG_REQUIRE(s && s->finalized && ptr && count, FG_ERR_INVALID_ARG, "fg_mb_get_buffer: bad argument");
+    FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_get_buffer: host-only handle");
     const int64_t B = s->B, N = s->N, d = s->d, F = s->F;
     switch (which) {
         case FG_MB_BUF_A: *ptr = s->Cdiag; *count = B * N; break;
@@ -1611,6 +1618,25 @@ extern "C" int fg_mb_read_buffer(fg_mb_handle s, int32_t which, float* dst_devic
     FG_REQUIRE(dst_device != nullptr, FG_ERR_INVALID_ARG, "fg_mb_read_buffer: null destination");
     FG_HIP_CHECK(hipMemcpyAsync(dst_device, p, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     FG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return FG_OK;
+}
+
+// host copies of the mesh tables (fg_mb.h) for tests: which = FG_MB_TABLE_*; *count receives the number of 4-byte elements,
+// out may be NULL to query it
+extern "C" int fg_mb_get_host_table(fg_mb_handle s, int32_t which, void* out, int64_t* count) {
+    FG_REQUIRE(s && s->finalized && count, FG_ERR_INVALID_ARG, "fg_mb_get_host_table: bad argument");
+    const void* src = nullptr;
+    size_t n = 0;
+#define T_(id, v) case id: src = s->v.data(); n = s->v.size(); break;
+    switch (which) {
+        T_(0, h_nbr) T_(1, h_fcode) T_(2, h_T) T_(3, h_Tb) T_(4, h_bcell) T_(5, h_bface) T_(6, h_Vdiag) T_(7, h_Voff) T_(8, h_KPp)
+        T_(9, h_KPn) T_(10, h_SVc_idx) T_(11, h_SVc_w) T_(12, h_SVb_idx) T_(13, h_SVb_w) T_(14, h_SP_idx) T_(15, h_SP_face)
+        T_(16, h_SP_wp) T_(17, h_SP_wn)
+        default: fg_set_error("fg_mb_get_host_table: unknown table id"); return FG_ERR_INVALID_ARG;
+    }
+#undef T_
+    *count = (int64_t)n;
+    if (out && n) memcpy(out, src, n * 4);
     return FG_OK;
 }
 

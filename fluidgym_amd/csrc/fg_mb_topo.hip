@@ -310,8 +310,9 @@ int fg_mb_build_tables(fg_mb_state* s) {
     s->h_bcell.assign(NB ? NB : 1, 0);
     s->h_bface.assign(NB ? NB : 1, 0);
     std::vector<double> Tb_d((size_t)(NB ? NB : 1) * tw, 0.0);
-    std::vector<float> Vdiag(N, 0.f), Voff((size_t)F * N, 0.f);
-    std::vector<float> KPp((size_t)(F + 1) * F * N, 0.f), KPn((size_t)(F + 1) * F * N, 0.f);
+    std::vector<float>&Vdiag = s->h_Vdiag, &Voff = s->h_Voff, &KPp = s->h_KPp, &KPn = s->h_KPn;
+    Vdiag.assign(N, 0.f); Voff.assign((size_t)F * N, 0.f);
+    KPp.assign((size_t)(F + 1) * F * N, 0.f); KPn.assign((size_t)(F + 1) * F * N, 0.f);
     struct CellTerm { int idx; double w; };
     struct PTerm { int idx, face; double wp, wn; };
     std::vector<std::vector<CellTerm>> svc(N), svb(N);
@@ -472,8 +473,10 @@ int fg_mb_build_tables(fg_mb_state* s) {
         KB = std::max(KB, (int)svb[g].size());
         KPN = std::max(KPN, (int)spn[g].size());
     }
-    std::vector<int32_t> c_idx((size_t)KC * N, 0), b_idx((size_t)KB * N, 0), p_idx((size_t)KPN * N, 0), p_face((size_t)KPN * N, 0);
-    std::vector<float> c_w((size_t)KC * N, 0.f), b_w((size_t)KB * N, 0.f), p_wp((size_t)KPN * N, 0.f), p_wn((size_t)KPN * N, 0.f);
+    std::vector<int32_t>&c_idx = s->h_SVc_idx, &b_idx = s->h_SVb_idx, &p_idx = s->h_SP_idx, &p_face = s->h_SP_face;
+    std::vector<float>&c_w = s->h_SVc_w, &b_w = s->h_SVb_w, &p_wp = s->h_SP_wp, &p_wn = s->h_SP_wn;
+    c_idx.assign((size_t)KC * N, 0); b_idx.assign((size_t)KB * N, 0); p_idx.assign((size_t)KPN * N, 0); p_face.assign((size_t)KPN * N, 0);
+    c_w.assign((size_t)KC * N, 0.f); b_w.assign((size_t)KB * N, 0.f); p_wp.assign((size_t)KPN * N, 0.f); p_wn.assign((size_t)KPN * N, 0.f);
     for (int g = 0; g < N; ++g) {
         for (size_t k = 0; k < svc[g].size(); ++k) { c_idx[k * N + g] = svc[g][k].idx; c_w[k * N + g] = (float)svc[g][k].w; }
         for (size_t k = 0; k < svb[g].size(); ++k) { b_idx[k * N + g] = svb[g][k].idx; b_w[k * N + g] = (float)svb[g][k].w; }
@@ -484,6 +487,7 @@ int fg_mb_build_tables(fg_mb_state* s) {
     }
     MbDev& D = s->dev;
     D.d = d; D.F = F; D.N = N; D.NB = NB; D.B = s->B; D.KC = KC; D.KB = KB; D.KPN = KPN;
+    if (s->host_only) return FG_OK;
     if (int rc = upload(s, s->h_nbr, &D.nbr)) return rc;
     if (int rc = upload(s, s->h_fcode, &D.fcode)) return rc;
     if (int rc = upload(s, s->h_T, &D.T)) return rc;

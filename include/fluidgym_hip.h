@@ -319,6 +319,11 @@ int fg_mb_finalize(fg_mb_handle h);
 int fg_mb_sizes(fg_mb_handle h, int32_t* n_cells, int32_t* n_boundary_faces);
 int fg_mb_block_info(fg_mb_handle h, int32_t block, int32_t* cell_offset, int32_t* boundary_slot0 /* [2d], -1 = not FIXED */);
 int fg_mb_get_neighbors(fg_mb_handle h, int32_t* out_host /* [2d*N]: neighbour cell, or -1 - boundary slot */);
+/* Every mesh table the kernels read (csrc/fg_mb.h), as built on the host: 0 nbr, 1 fcode, 2 T, 3 Tb, 4 bcell, 5 bface, 6 Vdiag,
+ * 7 Voff, 8 KPp, 9 KPn, 10 SVc_idx, 11 SVc_w, 12 SVb_idx, 13 SVb_w, 14 SP_idx, 15 SP_face, 16 SP_wp, 17 SP_wn (4-byte elements;
+ * out may be NULL to query the count).  A handle created with device < 0 is host-only: it builds and serves these tables
+ * without touching a GPU (CPU parity tests of the topology code), every compute entry point refuses it. */
+int fg_mb_get_host_table(fg_mb_handle h, int32_t which, void* out, int64_t* count);
 int fg_mb_bind(fg_mb_handle h, float* velocity, float* pressure_result, float* boundary_velocity, const float* source);
 int fg_mb_set_viscosity(fg_mb_handle h, float nu);
 typedef struct fg_mb_step_options {
