@@ -93,9 +93,9 @@ class MultiBlockResampler:
         self.out_shape = (int(out_shape[0]), int(out_shape[1]))
         self.W_host = build_operator(coords_list, out_shape, fill_max_steps)
         self.device = torch.device("cuda") if device is None else torch.device(device)
-        W = self.W_host
-        self._W = torch.sparse_csr_tensor(torch.as_tensor(W.indptr, dtype=torch.int64), torch.as_tensor(W.indices, dtype=torch.int64),
-                                          torch.as_tensor(W.data, dtype=torch.float32), size=W.shape).to(self.device)
+        W = self.W_host.tocoo()
+        idx = torch.as_tensor(np.stack([W.row, W.col]), dtype=torch.int64)
+        self._W = torch.sparse_coo_tensor(idx, torch.as_tensor(W.data, dtype=torch.float32), size=W.shape).coalesce().to(self.device)
 
     def __call__(self, field: torch.Tensor) -> torch.Tensor:
         """field [..., N] -> [..., oy, ox]."""
