@@ -177,6 +177,7 @@ SIGNATURES = {
     "fg_mb_connect": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "fg_mb_make_periodic": (c_int, [c_void_p, c_int32, c_int32]),
     "fg_mb_set_reference_quirks": (c_int, [c_void_p, c_int32, c_int32]),
+    "fg_mb_set_nonortho_flags": (c_int, [c_void_p, c_int32]),
     "fg_mb_finalize": (c_int, [c_void_p]),
     "fg_mb_sizes": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     "fg_mb_block_info": (c_int, [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32)]),

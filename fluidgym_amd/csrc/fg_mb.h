@@ -67,6 +67,7 @@ struct fg_mb_state {
     float nu = 0.f;
     int quirk_diag_offset = 1;  // computeConnectedPos(..., borderOffset = 1) on diagonal walks (K.cu:2152, 2658, 2825)
     int quirk_first_layer = 1;  // K.cu:1952
+    int nonortho_flags = 25;    // CENTER_MATRIX | DIRECT_MATRIX | DIAGONAL_RHS (the simulation's mode) or 10 = DIRECT_RHS | DIAGONAL_RHS
     bool finalized = false;
     std::vector<MbBlock> blocks;
     // host copies of the tables (also exported for tests)

@@ -1220,6 +1220,14 @@ extern "C" int fg_mb_set_reference_quirks(fg_mb_handle s, int32_t connected_diag
     return FG_OK;
 }
 
+extern "C" int fg_mb_set_nonortho_flags(fg_mb_handle s, int32_t flags) {
+    FG_REQUIRE(s && !s->finalized, FG_ERR_INVALID_ARG, "fg_mb_set_nonortho_flags: null or finalized handle");
+    FG_REQUIRE(flags == 25 || flags == 10, FG_ERR_UNSUPPORTED,
+               "fg_mb_set_nonortho_flags: 25 (CENTER_MATRIX | DIRECT_MATRIX | DIAGONAL_RHS) or 10 (DIRECT_RHS | DIAGONAL_RHS)");
+    s->nonortho_flags = flags;
+    return FG_OK;
+}
+
 extern "C" int fg_mb_finalize(fg_mb_handle s) {
     FG_REQUIRE(s && !s->finalized && !s->blocks.empty(), FG_ERR_INVALID_ARG, "fg_mb_finalize: nothing to finalize");
     if (int rc = fg_mb_build_tables(s)) return rc;

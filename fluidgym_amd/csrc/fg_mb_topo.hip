@@ -103,6 +103,8 @@ struct Topo {
         int num;            // cells counted; 0: value comes from a Dirichlet boundary
         int ncell;          // depth-2 cells collected
         int cell[2];
+        int n1;             // depth-1 cells (the two face neighbours next to the corner), for NON_ORTHO_DIRECT_RHS
+        int cell1[2];
         int nslot;          // boundary slots (value = mean of them)
         int slotv[2];
     };
@@ -117,7 +119,7 @@ struct Topo {
                 if (at_bound(c.b, c.p, c.d1)) {
                     const MbBound& bd = blk(c.b).bounds[c.d1];
                     if (bd.type == FG_MB_FIXED) {
-                        r.num = 0; r.ncell = 0;
+                        r.num = 0; r.ncell = 0; r.n1 = 0;
                         r.nslot = 1;
                         r.slotv[0] = slot(c.b, c.d1, c.p);
                         if (!at_bound(c.b, c.p, c.d2)) {
@@ -150,10 +152,25 @@ struct Topo {
                 const Cyc& o = cyc[k ^ 1];
                 if (c.b == o.b && c.p.a[0] == o.p.a[0] && c.p.a[1] == o.p.a[1] && c.p.a[2] == o.p.a[2]) return r;
                 if (depth > 1) r.cell[r.ncell++] = gidx(c.b, c.p);
+                else r.cell1[r.n1++] = gidx(c.b, c.p);
                 ++r.num;
             }
         }
         return r;
+    }
+    // getBlockDataNeighbor (K.cu:2534-2578): -1 at a prescribed boundary; over a connection it lands borderOffset = 1 inside
+    int neighbor_data(int b, const Pos& p, int dir) const {
+        const int dim = dir >> 1;
+        Pos q = p;
+        if (at_bound(b, p, dir)) {
+            const MbBound& bd = blk(b).bounds[dir];
+            if (bd.type == FG_MB_FIXED) return -1;
+            if (bd.type == FG_MB_CONNECTED) return gidx(bd.other, connected_pos(p, dim, bd, s->quirk_diag_offset));
+            q.a[dim] = (dir & 1) ? 0 : blk(b).size[dim] - 1;
+        } else {
+            q.a[dim] += (dir & 1) ? 1 : -1;
+        }
+        return gidx(b, q);
     }
     // getBlockDataNeighborDiagonal: -1 if the walk ends on a prescribed boundary
     int neighbor_diagonal(int b, const Pos& p, int dir1, int dir2) const {
@@ -404,7 +421,8 @@ int fg_mb_build_tables(fg_mb_state* s) {
                 const int t = (dim + i) % d;
                 // ---- matrices: centre + direct neighbours (K.cu:3749-3805, 4887-4936)
                 double xP, xN;
-                if (tp.cross_matrix(b, p, f, t, xP, xN) && (xP != 0.0 || xN != 0.0)) {
+                const bool in_matrix = (s->nonortho_flags & (1 | 16)) != 0, direct_rhs = (s->nonortho_flags & 2) != 0;
+                if (in_matrix && tp.cross_matrix(b, p, f, t, xP, xN) && (xP != 0.0 || xN != 0.0)) {
                     const double a = 0.5 * (xP + xN);
                     for (int tu = 0; tu < 2; ++tu) {
                         const int tf = 2 * t + tu;
@@ -444,10 +462,16 @@ int fg_mb_build_tables(fg_mb_state* s) {
                         for (int q = 0; q < c.nslot; ++q) svb[g].push_back({c.slotv[q], -fs * fa * tfs / c.nslot});
                         const int dg = tp.neighbor_diagonal(b, p, f, tf ^ 1);
                         if (dg >= 0) spn[g].push_back({dg, f, -fs * 0.5 * rP * (-tfs) * 0.25, -fs * 0.5 * rN * (-tfs) * 0.25});
+                        if (direct_rhs) {  // one-sided difference through the face neighbour and the opposite tangential one (K.cu:3176-3179)
+                            const int nf = tp.neighbor_data(b, p, f), nt = tp.neighbor_data(b, p, tf ^ 1);
+                            if (nf >= 0) spn[g].push_back({nf, f, -fs * 0.5 * rP * tfs * 0.75, -fs * 0.5 * rN * tfs * 0.75});
+                            if (nt >= 0) spn[g].push_back({nt, f, -fs * 0.5 * rP * (-tfs) * 0.25, -fs * 0.5 * rN * (-tfs) * 0.25});
+                        }
                     } else {
-                        for (int q = 0; q < c.ncell; ++q) {
-                            svc[g].push_back({c.cell[q], -fs * fa * tfs / c.num});
-                            spn[g].push_back({c.cell[q], f, -fs * 0.5 * rP * tfs / c.num, -fs * 0.5 * rN * tfs / c.num});
+                        for (int q = 0; q < c.ncell + (direct_rhs ? c.n1 : 0); ++q) {
+                            const int cq = q < c.ncell ? c.cell[q] : c.cell1[q - c.ncell];
+                            svc[g].push_back({cq, -fs * fa * tfs / c.num});
+                            spn[g].push_back({cq, f, -fs * 0.5 * rP * tfs / c.num, -fs * 0.5 * rN * tfs / c.num});
                         }
                     }
                 }

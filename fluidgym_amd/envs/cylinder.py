@@ -50,7 +50,8 @@ class CylinderEnvBase(FluidEnv):
 
     def __init__(self, reynolds_number: float, resolution: int, dt: float, adaptive_cfl: float, step_length: float,
                  episode_length: int, lift_penalty: float = 1.0, ndims: int = 2, initial_domain_steps: Optional[int] = None,
-                 drag_reference: float = 0.0, pressure_use_BiCG: bool = False, pressure_deflation: bool = False, **kw):
+                 drag_reference: float = 0.0, pressure_use_BiCG: bool = False, pressure_deflation: bool = False,
+                 non_ortho_mode: str = "matrix", **kw):
         if ndims != 2:
             raise NotImplementedError("3-D cylinder envs (extruded mesh, periodic in z) are not built yet")
         self._reynolds_number = reynolds_number
@@ -60,6 +61,9 @@ class CylinderEnvBase(FluidEnv):
         self._cd_ref = float(drag_reference)
         self._pressure_use_bicg = pressure_use_BiCG
         self._pressure_deflation = pressure_deflation
+        if non_ortho_mode not in ("matrix", "rhs"):
+            raise ValueError("non_ortho_mode: 'matrix' (the reference's nonOrthoFlags) or 'rhs' (every cross-metric term lagged)")
+        self._non_ortho_flags = 25 if non_ortho_mode == "matrix" else 10
         if initial_domain_steps is not None:
             self._initial_domain_steps = int(initial_domain_steps)
         super().__init__(dt=dt, adaptive_cfl=adaptive_cfl, step_length=step_length, episode_length=episode_length,
@@ -119,7 +123,8 @@ class CylinderEnvBase(FluidEnv):
         self._mesh = make_vortex_street_mesh(self._circle_resolution_angular, self.H, self.L, self.cylinder_diameter / 2,
                                              self.cylinder_offset_y, self.cylinder_diameter / 2, self.cylinder_diameter,
                                              self._vortex_street_refinement_base)
-        return build_domain(self._mesh, self._nu, batch=self._num_envs, device=self._cuda_device)
+        return build_domain(self._mesh, self._nu, batch=self._num_envs, device=self._cuda_device,
+                            non_ortho_flags=self._non_ortho_flags)
 
     def _get_simulation(self, domain, prep_fn):
         sim = MultiBlockSimulation(domain, dt=self._dt, adaptive_CFL=self._adaptive_cfl, substeps="ADAPTIVE", corrector_steps=2,

@@ -162,11 +162,13 @@ def make_vortex_street_mesh(resolution: int, domain_height: float = 4.1, domain_
     return CylinderMesh([f32(left), f32(top), f32(right), f32(bottom), wake], names, fixed, connections)
 
 
-def build_domain(mesh: CylinderMesh, viscosity: float, batch: int = 1, device=None, reference_quirks: bool = True):
+def build_domain(mesh: CylinderMesh, viscosity: float, batch: int = 1, device=None, reference_quirks: bool = True,
+                 non_ortho_flags: int = 25):
     """The mesh as a ``MultiBlockDomain`` on the GPU (``make_vortex_street_domain`` + ``PrepareSolve``)."""
     from ..simulation.multiblock import MultiBlockDomain
 
-    dom = MultiBlockDomain(2, viscosity, batch=batch, device=device, reference_quirks=reference_quirks)
+    dom = MultiBlockDomain(2, viscosity, batch=batch, device=device, reference_quirks=reference_quirks,
+                           non_ortho_flags=non_ortho_flags)
     blocks = [dom.CreateBlock(c, name=n) for c, n in zip(mesh.coords, mesh.names)]
     for (b, face), vel in mesh.fixed.items():
         blocks[b].CloseBoundary(face, vel)

@@ -115,7 +115,7 @@ class MultiBlockDomain:
     """``PISOtorch.Domain`` for connected curvilinear blocks, batched over envs."""
 
     def __init__(self, dims: int, viscosity: float, batch: int = 1, device: Optional[torch.device] = None,
-                 reference_quirks: bool = True):
+                 reference_quirks: bool = True, non_ortho_flags: int = 25):
         if not torch.cuda.is_available():
             raise L.NativeLibraryError("fluidgym_amd needs a GPU: the multi-block path has no CPU fallback")
         self.lib = L.load()
@@ -126,6 +126,9 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_create(self.dims, self.batch, self.device.index or 0, ctypes.byref(self.handle)))
         if not reference_quirks:
             L.check(self.lib.fg_mb_set_reference_quirks(self.handle, 0, 0))
+        if non_ortho_flags != 25:
+            L.check(self.lib.fg_mb_set_nonortho_flags(self.handle, int(non_ortho_flags)))
+        self.non_ortho_flags = int(non_ortho_flags)
         self.blocks: List[MBBlock] = []
         self.prepared = False
         self.velocity = self.pressure = self.boundary_velocity = self.velocity_source = None

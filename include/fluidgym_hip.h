@@ -315,6 +315,10 @@ int fg_mb_add_block(fg_mb_handle h, const float* vertex_coords_host, int32_t nx,
 int fg_mb_connect(fg_mb_handle h, int32_t block1, int32_t face1, int32_t block2, int32_t face2, int32_t axis1, int32_t axis2);
 int fg_mb_make_periodic(fg_mb_handle h, int32_t block, int32_t axis);
 int fg_mb_set_reference_quirks(fg_mb_handle h, int32_t connected_diagonal_offset, int32_t first_layer_rule);
+/* nonOrthoFlags of the reference (PISOtorch_simulation.py:479-487), before finalize: 25 = CENTER_MATRIX | DIRECT_MATRIX |
+ * DIAGONAL_RHS, what Simulation(non_orthogonal=True) runs (default); 10 = DIRECT_RHS | DIAGONAL_RHS: every cross-metric term
+ * lagged on the right-hand side, which leaves the pressure matrix symmetric with the exact constant null space */
+int fg_mb_set_nonortho_flags(fg_mb_handle h, int32_t flags);
 int fg_mb_finalize(fg_mb_handle h);
 int fg_mb_sizes(fg_mb_handle h, int32_t* n_cells, int32_t* n_boundary_faces);
 int fg_mb_block_info(fg_mb_handle h, int32_t block, int32_t* cell_offset, int32_t* boundary_slot0 /* [2d], -1 = not FIXED */);

@@ -317,6 +317,22 @@ class Domain:
                 num += 1
         return data / num, num
 
+    def neighbor_data(self, b, pos, direction, cell_get, bound_get):
+        """getBlockDataNeighbor (K.cu:2534-2578); over a connection it lands borderOffset = 1 inside the other block."""
+        dim = direction >> 1
+        if self.at_bound(b, pos, direction):
+            bd = self.blocks[b].bounds[direction]
+            if bd.type == FIXED:
+                return bound_get(b, direction, pos)
+            if bd.type == CONNECTED:
+                return cell_get(self.gidx(bd.other, self.connected_pos(b, pos, dim, bd, CONNECTED_DIAGONAL_OFFSET)))
+            q = list(pos)
+            q[dim] = 0 if direction & 1 else self.blocks[b].size[dim] - 1
+            return cell_get(self.gidx(b, q))
+        q = list(pos)
+        q[dim] += 1 if direction & 1 else -1
+        return cell_get(self.gidx(b, q))
+
     def neighbor_diagonal(self, b, pos, dir1, dir2, cell_get, bound_get):
         """getBlockDataNeighborDiagonal (K.cu:2630-2678); directions are NOT remapped across a connection there."""
         first_empty = self.is_empty(b, dir1)
@@ -468,7 +484,8 @@ class Domain:
                     if num == 0 and pressure:
                         to, tos = tf ^ 1, -tfs
                         if flags & NON_ORTHO_DIRECT_RHS:
-                            raise NotImplementedError("NON_ORTHO_DIRECT_RHS is not used by the simulation")
+                            grad += tfs * self.neighbor_data(b, pos, face, field_get, bound_get) * 0.75
+                            grad += tos * self.neighbor_data(b, pos, to, field_get, bound_get) * 0.25
                         if flags & NON_ORTHO_DIAGONAL_RHS:
                             grad += tos * self.neighbor_diagonal(b, pos, face, to, field_get, bound_get) * 0.25
                     else:

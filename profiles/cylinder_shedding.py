@@ -18,9 +18,9 @@ import torch
 import fluidgym_amd
 
 
-def run(resolution=24, t_end=120.0, kick=True):
+def run(resolution=24, t_end=120.0, kick=True, non_ortho_mode="matrix"):
     env = fluidgym_amd.make("CylinderRot2D-easy-v0", num_envs=1, resolution=resolution, initial_domain_steps=0,
-                            randomize_initial_state=False)
+                            randomize_initial_state=False, non_ortho_mode=non_ortho_mode)
     env.reset(seed=0)
     dt = env.dt
     n = int(round(t_end / dt))
@@ -54,8 +54,9 @@ def analyse(hist, t_from):
 if __name__ == "__main__":
     res = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     t_end = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
-    hist, wall = run(res, t_end)
-    out = os.path.join(ROOT, "gpurun_out", f"r01_cylinder_shedding_res{res}.csv")
+    mode = sys.argv[3] if len(sys.argv) > 3 else "matrix"
+    hist, wall = run(res, t_end, non_ortho_mode=mode)
+    out = os.path.join(ROOT, "gpurun_out", f"r01_cylinder_shedding_res{res}" + ("" if mode == "matrix" else f"_{mode}") + ".csv")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     np.savetxt(out, hist[::5], delimiter=",", header="t,cd,cl", comments="", fmt="%.5f")
-    print("resolution", res, "sim steps", len(hist), "wall s", round(wall, 1), analyse(hist, t_end - 30.0))
+    print("mode", mode, "resolution", res, "sim steps", len(hist), "wall s", round(wall, 1), analyse(hist, t_end - 30.0))

@@ -26,10 +26,10 @@ class Spec:
         d.finalize()
         return d
 
-    def native(self, batch=1, reference_quirks=True):
+    def native(self, batch=1, reference_quirks=True, non_ortho_flags=25):
         from fluidgym_amd.simulation.multiblock import MultiBlockDomain
 
-        dom = MultiBlockDomain(self.dims, self.nu, batch=batch, reference_quirks=reference_quirks)
+        dom = MultiBlockDomain(self.dims, self.nu, batch=batch, reference_quirks=reference_quirks, non_ortho_flags=non_ortho_flags)
         blks = [dom.CreateBlock(c.astype(np.float32)) for c in self.blocks]
         for b, f, v in self.fixed:
             blks[b].CloseBoundary(f, v)

@@ -28,10 +28,12 @@ def _cylinder_spec():
 
 
 class HostTables:
-    def __init__(self, spec):
+    def __init__(self, spec, flags=25):
         self.lib = L.load()
         self.h = ctypes.c_void_p()
         L.check(self.lib.fg_mb_create(spec.dims, 1, -1, ctypes.byref(self.h)))
+        if flags != 25:
+            L.check(self.lib.fg_mb_set_nonortho_flags(self.h, flags))
         for c in spec.blocks:
             c32 = np.ascontiguousarray(c, np.float32)
             size = [c.shape[-1 - a] - 1 for a in range(spec.dims)] + [1] * (3 - spec.dims)
@@ -59,11 +61,13 @@ class HostTables:
 SPECS = [H.split_rotated_channel, H.skewed_pair, H.twisted_ring, H.skewed_pair_3d, _cylinder_spec]
 
 
+@pytest.mark.parametrize("flags", [25, 10])
 @pytest.mark.parametrize("spec_fn", SPECS)
-def test_tables_reproduce_the_oracle(spec_fn):
+def test_tables_reproduce_the_oracle(spec_fn, flags):
+    """flags: the reference's nonOrthoFlags -- 25 what the simulation runs, 10 every cross-metric term on the right-hand side."""
     spec = spec_fn()
     d = spec.oracle()
-    t = HostTables(spec)
+    t = HostTables(spec, flags)
     N, NB, dm, F = t.N, t.NB, spec.dims, 2 * spec.dims
     assert N == d.N
     nbr = t.table(0, np.int32).reshape(F, N)
@@ -97,7 +101,7 @@ def test_tables_reproduce_the_oracle(spec_fn):
             if bd.type == mbo.FIXED:
                 bd.velocity[:] = 0.0
     dt = 0.07
-    diag, off, onbr = d.build_matrix(np.zeros((dm, N)), dt)
+    diag, off, onbr = d.build_matrix(np.zeros((dm, N)), dt, flags)
     det = T[:, dm * dm].astype(np.float64)
     assert np.array_equal(np.where(onbr >= 0, onbr, -1), np.where(nbr >= 0, nbr, -1))
     assert np.allclose((diag * det - det / dt) / nu, Vdiag, rtol=3e-5, atol=3e-5 * np.abs(Vdiag).max())
@@ -106,7 +110,7 @@ def test_tables_reproduce_the_oracle(spec_fn):
     # ---- pressure matrix from the coefficient pairs
     A = 1.0 + rng.random(N)
     rA = 1.0 / A
-    Pd, Po, _ = d.build_pressure_matrix(A)
+    Pd, Po, _ = d.build_pressure_matrix(A, flags)
     rn = np.where(nbr >= 0, rA[np.maximum(nbr, 0)], 0.0)          # [F, N]
     mine = (KPp * rA[None, None, :] + KPn * rn[None, :, :]).sum(axis=1)   # [F + 1, N]
     scale = np.abs(Pd).max()
@@ -130,12 +134,14 @@ def test_tables_reproduce_the_oracle(spec_fn):
                 bd.velocity[0] = ub[s0: s0 + bd.velocity.shape[1]]
     S_mine = (cw * u[ci]).sum(0) + ((bw * ub[bi]).sum(0) if KB else 0.0)
     S_ref = np.array([d.nonortho_rhs(b, pos, 0, lambda q: u[q], lambda bb, ff, pp: d.bound_value(bb, ff, pp, 0),
-                                     mbo.NON_ORTHO_MODE, False) for b, pos in d.cells()]) / nu
+                                     flags, False) for b, pos in d.cells()]) / nu
     assert np.allclose(S_mine, S_ref, rtol=1e-4, atol=1e-5 * max(np.abs(S_ref).max(), 1e-12))
     p = rng.standard_normal(N)
     rface = np.where(np.take_along_axis(nbr, pf, axis=0) >= 0, rA[np.maximum(np.take_along_axis(nbr, pf, axis=0), 0)], 0.0)
     N_mine = ((pwp * rA[None, :] + pwn * rface) * p[pi]).sum(0) if KPN else np.zeros(N)
-    N_ref = d.pressure_nonortho(p, A)
+    N_ref = d.pressure_nonortho(p, A, flags)
+    if flags == 10:  # nothing but the orthogonal Laplacian in the matrix: symmetric, rows sum to zero
+        assert np.abs(mine[0] + np.where(nbr >= 0, mine[1:], 0.0).sum(0)).max() < 1e-5 * scale
     assert np.allclose(N_mine, N_ref, rtol=1e-4, atol=1e-5 * max(np.abs(N_ref).max(), 1e-12))
     t.close()
 
