@@ -147,3 +147,8 @@ def skewed_pair_3d(nu=0.03, nz=3):
     s.periodic = [(0, 2), (1, 2)]
     s.connections = [(0, 1, 1, 0, 2, 4)]
     return s
+
+
+def odd_channel():
+    """Cell count not divisible by four: the solvers' one-cell-per-thread kernels instead of the four-cell ones."""
+    return split_rotated_channel(nx=11, ny=7, cut=4)

@@ -75,7 +75,8 @@ def _assembly_parity(dom, d, states, dt, B, check_div):
                                                       (H.skewed_pair, True, 2e-6, False), (H.skewed_pair_3d, True, 3e-7, False),
                                                       # mean projection is an exact no-op on orthogonal meshes, for CG and BiCGStab
                                                       (H.polar_ring, False, 2e-6, True), (H.polar_ring, True, 2e-6, True),
-                                                      (H.split_rotated_channel, True, 2e-6, True)])
+                                                      (H.split_rotated_channel, True, 2e-6, True),
+                                                      (H.odd_channel, False, 2e-6, False), (H.odd_channel, False, 2e-6, True)])
 def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     """Whole step against the oracle's direct solves.  The pressure solver is CG as in the reference where the mesh is
     orthogonal (symmetric matrix); with strong cross metrics the matrix is not symmetric, CG stalls (there as here, see
