@@ -91,12 +91,14 @@ def ring_sector(res: int, r1: float, r2: float, start_deg: float, sweep_deg: flo
 
 @dataclass
 class CylinderMesh:
-    coords: List[np.ndarray]                       # per block [2, ny+1, nx+1] float32
+    coords: List[np.ndarray]                       # per block [d, (nz+1,) ny+1, nx+1] float32
     names: List[str]
-    fixed: Dict[Tuple[int, str], np.ndarray]       # (block, face) -> Dirichlet velocity [2, face cells] (zeros = wall)
-    connections: List[Tuple[int, str, int, str, str]]
+    fixed: Dict[Tuple[int, str], np.ndarray]       # (block, face) -> Dirichlet velocity [d, face cells] (zeros = wall)
+    connections: List[Tuple]                       # (b1, face1, b2, face2, axis1[, axis2])
     outflow: Tuple[int, str] = (WAKE, "+x")
     cylinder_faces: List[Tuple[int, str]] = field(default_factory=lambda: [(LEFT, "+x"), (TOP, "-y"), (RIGHT, "-x"), (BOTTOM, "+y")])
+    dims: int = 2
+    periodic: List[Tuple[int, str]] = field(default_factory=list)
 
 
 def make_vortex_street_mesh(resolution: int, domain_height: float = 4.1, domain_length: float = 22.0,
@@ -162,17 +164,41 @@ def make_vortex_street_mesh(resolution: int, domain_height: float = 4.1, domain_
     return CylinderMesh([f32(left), f32(top), f32(right), f32(bottom), wake], names, fixed, connections)
 
 
+def extrude_mesh(mesh: CylinderMesh, res_z: int, z0: float = -2.0, z1: float = 2.0) -> CylinderMesh:
+    """The 3-D variant of the reference (``extrude_grid_z(g, res_z=res, start_z=-2, end_z=2)``, z-periodic blocks,
+    connections with the z axes aligned; envs/cylinder/grid.py:281-294, 330-343, 395-416)."""
+    z = (z0 * (1.0 - np.arange(res_z + 1) / res_z) + z1 * (np.arange(res_z + 1) / res_z)).astype(np.float32)
+    coords = []
+    for c in mesh.coords:
+        xy = np.broadcast_to(c[:, None], (2, res_z + 1) + c.shape[1:])
+        zz = np.broadcast_to(z[None, :, None, None], (1, res_z + 1) + c.shape[1:])
+        coords.append(np.ascontiguousarray(np.concatenate([xy, zz], axis=0), dtype=np.float32))
+    fixed = {}
+    for key, v in mesh.fixed.items():          # [2, n] -> [3, res_z * n], the face cells run (t, z) with t fastest
+        v3 = np.zeros((3, res_z, v.shape[1]), np.float32)
+        v3[:2] = v[:, None, :]
+        fixed[key] = v3.reshape(3, -1)
+    conns = []
+    for b1, f1, b2, f2, ax in mesh.connections:
+        # 2-D: the one remaining axis; 3-D: the axes after the face axis in cyclic order -- z first if the face is a y face
+        conns.append((b1, f1, b2, f2, "-z", ax) if f1[1] == "y" else (b1, f1, b2, f2, ax, "-z"))
+    return CylinderMesh(coords, list(mesh.names), fixed, conns, mesh.outflow, list(mesh.cylinder_faces), dims=3,
+                        periodic=[(b, "z") for b in range(len(coords))])
+
+
 def build_domain(mesh: CylinderMesh, viscosity: float, batch: int = 1, device=None, reference_quirks: bool = True,
                  non_ortho_flags: int = 25):
     """The mesh as a ``MultiBlockDomain`` on the GPU (``make_vortex_street_domain`` + ``PrepareSolve``)."""
     from ..simulation.multiblock import MultiBlockDomain
 
-    dom = MultiBlockDomain(2, viscosity, batch=batch, device=device, reference_quirks=reference_quirks,
+    dom = MultiBlockDomain(mesh.dims, viscosity, batch=batch, device=device, reference_quirks=reference_quirks,
                            non_ortho_flags=non_ortho_flags)
     blocks = [dom.CreateBlock(c, name=n) for c, n in zip(mesh.coords, mesh.names)]
     for (b, face), vel in mesh.fixed.items():
         blocks[b].CloseBoundary(face, vel)
-    for b1, f1, b2, f2, ax in mesh.connections:
-        blocks[b1].ConnectBlock(f1, blocks[b2], f2, ax)
+    for b, axis in mesh.periodic:
+        blocks[b].MakePeriodic(axis)
+    for b1, f1, b2, f2, *axes in mesh.connections:
+        blocks[b1].ConnectBlock(f1, blocks[b2], f2, *axes)
     dom.PrepareSolve()
     return dom

@@ -105,6 +105,24 @@ def main():
             else:
                 calls.append(" ".join(str(x) for x in rec))
         out[f"r{res}_calls"] = np.array(calls)
+    # the 3-D variant (extruded along z, z-periodic; grid.py:281-294, 330-343, 395-416) at resolution 8
+    dom = grid.make_vortex_street_domain(
+        ndims=3, viscosity=torch.tensor([0.01]), domain_height=4.1, domain_length=22.0, cylinder_radius=0.5,
+        cylinder_offset_y=0.05, circle_thickness=0.5, quad_thickness_x=1.0, circle_resolution_angular=8,
+        vortex_street_refinement_base=0.95, vortex_street_refinement_axes=["+y", "-y"],
+        cuda_device=torch.device("cpu"), dtype=torch.float32)
+    calls = []
+    for rec in dom.log:
+        if rec[0] == "block":
+            out[f"r8_3d_block{rec[1]}"] = rec[3][0]
+            calls.append(f"block {rec[1]} {rec[2]}")
+        elif rec[0] == "velocity":
+            out[f"r8_3d_velocity_{rec[1]}_{rec[2]}"] = rec[3]
+            calls.append(f"velocity {rec[1]} {rec[2]}")
+        else:
+            calls.append(" ".join(str(x) for x in rec))
+    out["r8_3d_calls"] = np.array(calls)
+
     # sensor pixels of CylinderEnvBase (cylinder_env_base.py:430-518): the methods are compiled from the reference file and
     # called on a bare namespace carrying the class attributes they read
     import ast

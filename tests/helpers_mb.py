@@ -152,3 +152,19 @@ def skewed_pair_3d(nu=0.03, nz=3):
 def odd_channel():
     """Cell count not divisible by four: the solvers' one-cell-per-thread kernels instead of the four-cell ones."""
     return split_rotated_channel(nx=11, ny=7, cut=4)
+
+
+def cylinder_3d_small(res=4, res_z=3, nu=0.01):
+    """The reference's 3-D cylinder mesh (extruded, z-periodic, connections carry two axes) at a small resolution, with
+    perturbed Dirichlet values so that walls and inflow exercise every boundary branch."""
+    from fluidgym_amd.envs.cylinder_grid import extrude_mesh, make_vortex_street_mesh
+
+    m = extrude_mesh(make_vortex_street_mesh(res), res_z)
+    F = {"-x": 0, "+x": 1, "-y": 2, "+y": 3, "-z": 4, "+z": 5}
+    s = Spec(3, nu)
+    s.blocks = [c.astype(np.float64) for c in m.coords]
+    rng = np.random.default_rng(6)
+    s.fixed = [(b, F[f], v.astype(np.float64) + 0.1 * rng.standard_normal(v.shape)) for (b, f), v in m.fixed.items()]
+    s.connections = [(b1, F[f1], b2, F[f2], F[a1], F[a2]) for b1, f1, b2, f2, a1, a2 in m.connections]
+    s.periodic = [(b, 2) for b, _ in m.periodic]
+    return s

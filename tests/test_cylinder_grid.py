@@ -56,3 +56,19 @@ def test_sensor_pixels_match_reference(level, res):
     ref = G[f"r{res}_sensor_pixels"]
     assert env._sensor_locations.shape == ref.shape == (2, 151)
     assert (env._sensor_locations == ref).all()
+
+
+def test_extruded_mesh_matches_reference_3d():
+    from fluidgym_amd.envs.cylinder_grid import extrude_mesh
+
+    m = extrude_mesh(make_vortex_street_mesh(8), 8)
+    for b in range(5):
+        ref = G[f"r8_3d_block{b}"]
+        assert m.coords[b].shape == ref.shape
+        assert np.abs(m.coords[b] - ref).max() < 2e-6
+    calls = [str(c) for c in G["r8_3d_calls"]]
+    conns = [tuple(c.split()[1:]) for c in calls if c.startswith("connect")]
+    assert conns == [(str(c[0]), c[1], str(c[2]), c[3], c[4], c[5]) for c in m.connections]
+    assert [tuple(c.split()[1:]) for c in calls if c.startswith("periodic")] == [(str(b), a) for b, a in m.periodic]
+    inflow = G["r8_3d_velocity_0_-x"][0, :, :, :, 0].reshape(3, -1)      # [3, z, y] -> y fastest
+    assert np.abs(m.fixed[(0, "-x")] - inflow).max() < 1e-6

@@ -121,3 +121,33 @@ def test_uncontrolled_wake_sheds_like_the_benchmark_flow():
     assert 0.24 < a["strouhal"] < 0.32
     assert 3.0 < a["cd_mean"] < 3.7 and a["cd_max"] - a["cd_mean"] < 0.2
     assert 0.8 < a["cl_max"] < 1.6 and -1.6 < a["cl_min"] < -0.8
+
+
+def test_3d_cylinder_mesh_runs_and_stays_uniform_along_the_span():
+    """The reference's 3-D variant of the mesh (five blocks extruded over z in [-2, 2], z-periodic, 15.9 k cells at
+    resolution 8): divergence-free start, a few adaptive steps, and -- inflow and walls being constant along z -- a flow
+    that stays constant along z.  The 3-D cylinder ENV (3-D sensors, forces, multi-agent split) is not built yet."""
+    from fluidgym_amd.envs.cylinder_grid import build_domain, extrude_mesh, make_vortex_street_mesh
+
+    mesh = extrude_mesh(make_vortex_street_mesh(8), 8)
+    dom = build_domain(mesh, 0.01, batch=2)
+    assert dom.n_cells == 8 * 1984
+    assert dom.cell_transforms()[:, -1].min() > 0
+    dom.velocity[:, 0] = 1.0
+    out = [mesh.outflow]
+    dom.make_divergence_free(outflow=out, outflow_velocity=(1.0, 0.0, 0.0))
+    assert np.abs(dom.boundary_flux_balance()).max() < 1e-5
+    for _ in range(5):
+        dom.single_step(0.01, cfl=0.8, outflow=out, outflow_velocity=(1.0, 0.0, 0.0), advect_non_ortho_steps=2,
+                        pressure_non_ortho_steps=4, advection_tol=1e-6, pressure_tol=1e-5, pressure_project_mean=True,
+                        pressure_warm_start=True, pressure_stall_accept=1.25)
+    assert torch.isfinite(dom.velocity).all()
+    assert np.abs(dom.boundary_flux_balance()).max() < 1e-5
+    assert torch.allclose(dom.velocity[0], dom.velocity[1], atol=1e-4)
+    for blk in dom.blocks:
+        u = blk.cells(dom.velocity)[0]                       # [3, nz, ny, nx]
+        assert float((u - u[:, :1]).abs().max()) < 2e-3      # spanwise uniform
+        assert float(u[2].abs().max()) < 2e-3                # no spanwise velocity
+    speed = torch.linalg.vector_norm(dom.velocity, dim=1)
+    assert 1.0 < float(speed.max()) < 3.0                    # accelerates around the cylinder, no blow-up
+    dom.close()

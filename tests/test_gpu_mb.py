@@ -102,7 +102,7 @@ def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     dom.close()
 
 
-@pytest.mark.parametrize("spec_fn", [H.skewed_pair, H.twisted_ring])
+@pytest.mark.parametrize("spec_fn", [H.skewed_pair, H.twisted_ring, H.cylinder_3d_small])
 def test_assembly_matches_oracle_on_strongly_skewed_meshes(spec_fn):
     """Matrices, right-hand sides, predictor, h and the pressure right-hand side with its lagged corner terms, on meshes
     where every cross-metric branch is active (walls with moving Dirichlet values, connections with shuffled axes, a

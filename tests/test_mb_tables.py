@@ -58,7 +58,7 @@ class HostTables:
         self.lib.fg_mb_destroy(self.h)
 
 
-SPECS = [H.split_rotated_channel, H.skewed_pair, H.twisted_ring, H.skewed_pair_3d, _cylinder_spec]
+SPECS = [H.split_rotated_channel, H.skewed_pair, H.twisted_ring, H.skewed_pair_3d, _cylinder_spec, H.cylinder_3d_small]
 
 
 @pytest.mark.parametrize("flags", [25, 10])
