@@ -48,6 +48,17 @@ def compute_forces_2d(u_cell, u_boundary, p_cell, wall_normals, tangent_lengths,
     return torch.stack([(fx * wall_face_lengths).sum(-1), (fy * wall_face_lengths).sum(-1)], dim=-1)
 
 
+def compute_forces_3d(u_cell, u_boundary, p_cell, wall_normals, tangent_lengths, wall_distances, wall_face_areas,
+                      viscosity) -> torch.Tensor:
+    """Force [..., 2, NZ] per spanwise layer on a wall extruded along z (``compute_forces_3d``, forces.py:278-377): the
+    2-D traction of every layer from its in-plane velocity components, times the face area (edge length x layer
+    height).  u_cell, u_boundary [..., 3, NZ, N]; p_cell [..., NZ, N]; the ring geometry as in the 2-D function."""
+    uc = u_cell[..., :2, :, :].transpose(-3, -2)      # [..., NZ, 2, N]
+    ub = u_boundary[..., :2, :, :].transpose(-3, -2)
+    f = compute_forces_2d(uc, ub, p_cell, wall_normals, tangent_lengths, wall_distances, wall_face_areas, viscosity)
+    return f.transpose(-1, -2)                         # [..., NZ, 2] -> [..., 2, NZ]
+
+
 class WallRing:
     """Index tables of a closed wall made of one face of several blocks, in the reference's traversal order.
 
@@ -59,11 +70,14 @@ class WallRing:
         from ..simulation.multiblock import face_index
 
         cells, slots, verts, centers = [], [], [], []
+        self.dims = domain.dims
+        self.nz = domain.blocks[segments[0][0]].size[2] if self.dims == 3 else 1
+        layer_cells, layer_slots = [], []
         for k, (b, face, reverse) in enumerate(segments):
             blk = domain.blocks[b]
             f = face_index(face)
             axis, upper = f >> 1, f & 1
-            nx, ny = blk.size
+            nx, ny = blk.size[0], blk.size[1]
             n_t = ny if axis == 0 else nx
             t = np.arange(n_t)
             fixed = (blk.size[axis] - 1) if upper else 0
@@ -75,16 +89,27 @@ class WallRing:
             vt = np.arange(n_t + 1)
             vx = np.full(n_t + 1, vfix) if axis == 0 else vt
             vy = vt if axis == 0 else np.full(n_t + 1, vfix)
-            v = blk.coords[:, vy, vx].astype(np.float64)
-            cc = blk.getCellCoordinates()[:, y, x].astype(np.float64)
+            if self.dims == 3:   # the ring geometry is that of the first layer (cylinder_env_base.py:633-638)
+                v = blk.coords[:2, 0, vy, vx].astype(np.float64)
+                cc = blk.getCellCoordinates()[:2, 0, y, x].astype(np.float64)
+            else:
+                v = blk.coords[:, vy, vx].astype(np.float64)
+                cc = blk.getCellCoordinates()[:, y, x].astype(np.float64)
+            layer_cells += [nx * ny] * n_t      # one spanwise layer further: cells by nx*ny, face slots by the face width
+            layer_slots += [n_t] * n_t
             if reverse:
                 cell, slot, v, cc = cell[::-1], slot[::-1], v[:, ::-1], cc[:, ::-1]
             if k != len(segments) - 1:
                 v = v[:, :-1]  # shared vertex with the next segment
             cells.append(cell); slots.append(slot); verts.append(v); centers.append(cc)
         dev = domain.device
-        self.cell_index = torch.as_tensor(np.concatenate(cells), dtype=torch.long, device=dev)
-        self.slot_index = torch.as_tensor(np.concatenate(slots), dtype=torch.long, device=dev)
+        cells, slots = np.concatenate(cells), np.concatenate(slots)
+        if self.dims == 3:
+            z = np.arange(self.nz)[:, None]
+            cells = cells[None, :] + z * np.asarray(layer_cells)[None, :]      # [NZ, N]
+            slots = slots[None, :] + z * np.asarray(layer_slots)[None, :]
+        self.cell_index = torch.as_tensor(cells, dtype=torch.long, device=dev)
+        self.slot_index = torch.as_tensor(slots, dtype=torch.long, device=dev)
         vc = torch.as_tensor(np.concatenate(verts, axis=1))
         ctr = torch.as_tensor(np.concatenate(centers, axis=1))
         dist, normals = wall_distance_from_vertices(vc, ctr)
@@ -95,10 +120,13 @@ class WallRing:
         self.wall_distances, self.wall_normals = dist.to(**f32), normals.to(**f32)
         self.tangent_lengths, self.face_lengths = tl.to(**f32), fl.to(**f32)
 
-    def forces(self, domain, viscosity: float) -> torch.Tensor:
-        """[B, 2] force on the wall from the domain's current fields."""
+    def forces(self, domain, viscosity: float, layer_height: float = 1.0) -> torch.Tensor:
+        """[B, 2] force on the wall from the domain's current fields; [B, 2, NZ] per spanwise layer in 3-D."""
         u_cell = domain.velocity[:, :, self.cell_index]
         u_b = domain.boundary_velocity[:, :, self.slot_index]
         p = domain.pressure[:, self.cell_index]
+        if self.dims == 3:
+            return compute_forces_3d(u_cell, u_b, p, self.wall_normals, self.tangent_lengths, self.wall_distances,
+                                     self.face_lengths * layer_height, viscosity)
         return compute_forces_2d(u_cell, u_b, p, self.wall_normals, self.tangent_lengths, self.wall_distances,
                                  self.face_lengths, viscosity)

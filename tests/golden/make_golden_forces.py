@@ -47,7 +47,19 @@ def main():
     nu = torch.tensor([0.01], dtype=torch.float64)
     f = forces.compute_forces_2d(u_cell=u_cell, u_boundary=u_b, p_cell=p, wall_normals=nrm, tangent_lengths=tangent_lengths,
                                  wall_distances=d, wall_face_lengths=face_len, viscosity=nu)
-    np.savez_compressed(os.path.join(OUT, "reference_forces.npz"), vc=vc.numpy(), centers=centers.numpy(), dist=d.numpy(),
+    # 3-D: the same ring extruded over nz spanwise layers (compute_forces_3d, shapes as CylinderEnvBase hands them over:
+    # u_cell / u_boundary [3, NZ, N], p_cell [NZ, N], normals [2, N, 1], distances / tangent lengths [N, 1], areas [N])
+    nz = 5
+    u3 = torch.randn(3, nz, n, generator=g, dtype=torch.float64)
+    ub3 = 0.3 * torch.randn(3, nz, n, generator=g, dtype=torch.float64)
+    p3 = torch.randn(nz, n, generator=g, dtype=torch.float64)
+    areas = face_len * (4.0 / nz)
+    f3 = forces.compute_forces_3d(u_cell=u3, u_boundary=ub3, p_cell=p3, wall_normals=nrm[..., None],
+                                  tangent_lengths=tangent_lengths[:, None], wall_distances=d[..., None],
+                                  wall_face_areas=areas, viscosity=nu)
+    print("force 3d", f3)
+    np.savez_compressed(os.path.join(OUT, "reference_forces.npz"), u3=u3.numpy(), ub3=ub3.numpy(), p3=p3.numpy(),
+                        areas=areas.numpy(), force3=f3.numpy(), vc=vc.numpy(), centers=centers.numpy(), dist=d.numpy(),
                         normals=nrm.numpy(), tangent_lengths=tangent_lengths.numpy(), face_len=face_len.numpy(),
                         u_cell=u_cell.numpy(), u_b=u_b.numpy(), p=p.numpy(), nu=nu.numpy(), force=f.numpy())
     print("force", f)

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from fluidgym_amd.simulation.resample_mb import build_operator
+from fluidgym_amd.simulation.resample_mb import ResamplePlan, build_operator
 from oracle.resample_oracle import resample_blocks_to_uniform
 
 HERE = os.path.dirname(__file__)
@@ -37,3 +37,45 @@ def test_folded_operator_matches_reference(case):
     rs = np.asarray(W.sum(axis=1)).reshape(-1)
     assert np.all((np.abs(rs - 1.0) < 1e-5) | (rs == 0.0))
     assert W.data.min() >= 0.0
+
+
+COORDS3 = [M[f"r8_3d_block{b}"] for b in range(5)]
+
+
+@pytest.mark.parametrize("case", ["3d_c3_f16", "3d_c1_f0"])
+def test_oracle_matches_reference_3d(case):
+    """Extruded mesh, 8-corner form (what the reference's torch implementation computes)."""
+    fill = int(case.split("_f")[1])
+    data = [G[f"{case}/data{b}"][0] for b in range(5)]
+    out = resample_blocks_to_uniform(data, COORDS3, G["out_shape3"], fill)
+    exp = G[f"{case}/expected"][0]
+    assert out.shape == exp.shape
+    assert np.abs(out - exp).max() < 1e-4   # fp32 accumulation order; values are O(4)
+    assert ((out == 0) == (exp == 0)).all()
+
+
+@pytest.mark.parametrize("quirk", [False, True])
+def test_factored_plan_matches_oracle_3d(quirk):
+    """The product's 3-D form (splat table + fill schedule): whole field and sensor rows, with the torch
+    implementation's 8 corners (also against the reference vector) and with the compiled kernel's 6."""
+    case = "3d_c3_f16"
+    data = [G[f"{case}/data{b}"][0] for b in range(5)]
+    flat = np.concatenate([d.reshape(3, -1) for d in data], axis=1)
+    plan = ResamplePlan(COORDS3, G["out_shape3"], 16, corners_3d_quirk=quirk)
+    assert plan.pix.shape[0] == (6 if quirk else 8)
+    out = plan.apply_numpy(flat)
+    ref = resample_blocks_to_uniform(data, COORDS3, G["out_shape3"], 16, corners_3d_quirk=quirk)
+    assert np.abs(out - ref).max() < 2e-5
+    if not quirk:
+        assert np.abs(out - G[f"{case}/expected"][0]).max() < 1e-4
+    px = np.random.default_rng(3).integers(0, plan.n_pixels, 300)
+    idx, w = plan.rows_ell(px)
+    assert np.abs((flat[:, idx] * w).sum(-1) - out.reshape(3, -1)[:, px]).max() < 1e-5
+    assert np.allclose(w.sum(-1), 1.0, atol=1e-5) and w.min() >= 0.0
+
+
+def test_factored_plan_equals_folded_operator_2d():
+    plan = ResamplePlan(COORDS, G["out_shape"], 16)
+    W = build_operator(COORDS, G["out_shape"], 16)
+    x = np.random.default_rng(4).standard_normal((2, plan.n_cells))
+    assert np.abs(plan.apply_numpy(x).reshape(2, -1) - (W @ x.T).T).max() < 1e-6
