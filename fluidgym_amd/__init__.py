@@ -71,8 +71,11 @@ def _register_all():
     for level, re, res in (("easy", 100, 24), ("medium", 250, 32), ("hard", 500, 32)):
         register(f"CylinderJet2D-{level}-v0", cj, CJ, reynolds_number=re, resolution=res)
         register(f"CylinderRot2D-{level}-v0", cr, CR, reynolds_number=re, resolution=res)
+    from .envs.cylinder import CYLINDER_JET_3D_DEFAULT_CONFIG as CJ3
+    cj3 = _lazy(".envs.cylinder", "CylinderJetEnv3D")
+    for level, re, res in (("easy", 100, 24), ("medium", 250, 32), ("hard", 500, 48)):   # fluidgym/__init__.py:79-102
+        register(f"CylinderJet3D-{level}-v0", cj3, CJ3, reynolds_number=re, resolution=res)
     for fam, ids in {
-        "Cylinder": ["CylinderJet3D-easy-v0", "CylinderJet3D-medium-v0", "CylinderJet3D-hard-v0"],
         "Airfoil": ["Airfoil2D-easy-v0", "Airfoil2D-medium-v0", "Airfoil2D-hard-v0", "Airfoil3D-easy-v0"],
     }.items():
         for i in ids:

@@ -8,8 +8,11 @@ velocity / pressure sensors read from the uniformly resampled fields (:430-518),
 
 Not carried over: the published initial domains (HuggingFace ``fluidgym-data``; no network) -- ``reset`` starts from a
 projected uniform stream and runs ``initial_domain_steps`` developed-flow steps (the reference generates its initial
-domains with 400, :138) -- and the domain statistics (``_cd_ref`` is 0 unless ``drag_reference`` is given).  3-D
-variants (extruded mesh, z-periodic) are not built yet.
+domains with 400, :138) -- and the domain statistics (``_cd_ref`` is 0 unless ``drag_reference`` is given).
+
+``CylinderJetEnv3D`` (``jet_cylinder_env_3d.py``) runs the same mesh extruded over the span (z-periodic): ``n_jets``
+spanwise jet segments, 151 x ``n_jets * 2`` sensors read from the 3-D resampled fields, drag / lift per spanwise layer,
+single-agent and multi-agent (one agent per segment, windows of neighbouring segments) interfaces.
 """
 from __future__ import annotations
 
@@ -19,10 +22,10 @@ import numpy as np
 import torch
 
 from ..simulation.multiblock import MultiBlockDomain, MultiBlockSimulation
-from ..simulation.resample_mb import MultiBlockResampler
+from ..simulation.resample_mb import MultiBlockResampler, MultiBlockResampler3D
 from .. import spaces
 from .channel import jet_profile
-from .cylinder_grid import BOTTOM, LEFT, RIGHT, TOP, build_domain, make_vortex_street_mesh
+from .cylinder_grid import BOTTOM, LEFT, RIGHT, TOP, build_domain, extrude_mesh, make_vortex_street_mesh
 from .fluid_env import FluidEnv
 from .forces import WallRing
 
@@ -39,6 +42,7 @@ class CylinderEnvBase(FluidEnv):
     _supports_marl = False
     _action_smoothing_alpha: float = 0.1
     H: float = 4.1
+    D: float = 4.0  # span of the 3-D variants
     L: float = 22.0
     cylinder_diameter: float = 1.0
     _U_mean: float = 1.0
@@ -52,8 +56,8 @@ class CylinderEnvBase(FluidEnv):
                  episode_length: int, lift_penalty: float = 1.0, ndims: int = 2, initial_domain_steps: Optional[int] = None,
                  drag_reference: float = 0.0, pressure_use_BiCG: bool = False, pressure_deflation: bool = False,
                  non_ortho_mode: str = "matrix", **kw):
-        if ndims != 2:
-            raise NotImplementedError("3-D cylinder envs (extruded mesh, periodic in z) are not built yet")
+        if ndims not in (2, 3):
+            raise ValueError("ndims must be 2 or 3")
         self._reynolds_number = reynolds_number
         self._circle_resolution_angular = int(resolution)
         self._lift_penalty = lift_penalty
@@ -67,7 +71,7 @@ class CylinderEnvBase(FluidEnv):
         if initial_domain_steps is not None:
             self._initial_domain_steps = int(initial_domain_steps)
         super().__init__(dt=dt, adaptive_cfl=adaptive_cfl, step_length=step_length, episode_length=episode_length,
-                         ndims=2, **kw)
+                         ndims=ndims, **kw)
         self._last_control = None
         self._sensor_locations = self._get_sensor_locations()
 
@@ -93,7 +97,7 @@ class CylinderEnvBase(FluidEnv):
 
     @property
     def initial_domain_id(self) -> str:
-        return f"cylinder_2D_Re{int(self._reynolds_number)}_Res{self._circle_resolution_angular}"
+        return f"cylinder_{self._ndims}D_Re{int(self._reynolds_number)}_Res{self._circle_resolution_angular}"
 
     # ---- sensors (cylinder_env_base.py:430-518)
     def _get_sensor_locations_2d(self) -> np.ndarray:
@@ -123,12 +127,15 @@ class CylinderEnvBase(FluidEnv):
         self._mesh = make_vortex_street_mesh(self._circle_resolution_angular, self.H, self.L, self.cylinder_diameter / 2,
                                              self.cylinder_offset_y, self.cylinder_diameter / 2, self.cylinder_diameter,
                                              self._vortex_street_refinement_base)
+        if self._ndims == 3:   # grid.py:281-294: res_z = resolution, z in [-2, 2]
+            self._mesh = extrude_mesh(self._mesh, self._circle_resolution_angular, -self.D / 2, self.D / 2)
         return build_domain(self._mesh, self._nu, batch=self._num_envs, device=self._cuda_device,
                             non_ortho_flags=self._non_ortho_flags)
 
     def _get_simulation(self, domain, prep_fn):
         sim = MultiBlockSimulation(domain, dt=self._dt, adaptive_CFL=self._adaptive_cfl, substeps="ADAPTIVE", corrector_steps=2,
-                                   pressure_tol=1e-5, advect_non_ortho_steps=1, pressure_non_ortho_steps=1,
+                                   pressure_tol=1e-5 if self._ndims == 2 else 5e-7, advect_non_ortho_steps=1,
+                                   pressure_non_ortho_steps=1 if self._ndims == 2 else 4,
                                    pressure_use_BiCG=self._pressure_use_bicg, outflow=self._mesh.outflow,
                                    outflow_velocity=(self._U_mean, 0.0, 0.0), outflow_tol=5e-6)
         return sim
@@ -136,11 +143,17 @@ class CylinderEnvBase(FluidEnv):
     def _additional_initialization(self) -> None:
         dom = self._domain
         self._ring = WallRing(dom, [(LEFT, "+x", False), (TOP, "-y", False), (RIGHT, "-x", True), (BOTTOM, "+y", True)])
-        self._resampler = MultiBlockResampler(self._mesh.coords, self.render_shape[:2], fill_max_steps=16, device=dom.device)
-        self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.T)
+        if self._ndims == 3:
+            self._resampler = MultiBlockResampler3D(self._mesh.coords, self.render_shape, fill_max_steps=16, device=dom.device)
+            self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.reshape(3, -1).T)
+        else:
+            self._resampler = MultiBlockResampler(self._mesh.coords, self.render_shape[:2], fill_max_steps=16, device=dom.device)
+            self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.T)
         self._deflation_cos = dom.set_pressure_deflation() if self._pressure_deflation else 1.0
         self._initial_boundary = dom.boundary_velocity.clone()  # inflow / outflow profile, walls at rest
-        self._last_control = torch.zeros(self._num_envs, 1, device=dom.device)
+        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
+
+    _n_controls = 1
 
     def _fill_initial_fields(self) -> None:
         """Uniform stream projected onto the mesh, then ``initial_domain_steps`` uncontrolled steps (the reference ships
@@ -156,7 +169,7 @@ class CylinderEnvBase(FluidEnv):
                 self._sim.single_step()
             self._developed = dom.Clone()
         dom.Restore(self._developed)
-        self._last_control = torch.zeros(self._num_envs, 1, device=dom.device)
+        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
 
     def _randomize_domain(self) -> None:
         """cylinder_env_base.py:364-404."""
@@ -185,7 +198,8 @@ class CylinderEnvBase(FluidEnv):
         return self._resampler(self._domain.pressure)
 
     def _get_drag_and_lift(self):
-        f = self._ring.forces(self._domain, self._nu)
+        """[B] in 2-D; [B, NZ] per spanwise layer in 3-D (face area = edge length x D / resolution, :676-689)."""
+        f = self._ring.forces(self._domain, self._nu, layer_height=self.D / self._circle_resolution_angular)
         norm = 0.5 * self._U_mean ** 2 * self.cylinder_diameter
         return f[:, 0] / norm, f[:, 1] / norm
 
@@ -193,7 +207,7 @@ class CylinderEnvBase(FluidEnv):
         raise NotImplementedError
 
     def _step_impl(self, action: torch.Tensor):
-        target = action.reshape(self._num_envs, 1)
+        target = action.reshape(self._num_envs, self._n_controls)
         cds, cls = [], []
         for _ in range(self._n_sim_steps):
             control = self._last_control + self._action_smoothing_alpha * (target - self._last_control)
@@ -205,7 +219,10 @@ class CylinderEnvBase(FluidEnv):
             cds.append(cd); cls.append(cl)
         obs = self._get_global_obs()
         cd, cl = torch.stack(cds).mean(0), torch.stack(cls).mean(0)
-        reward = self._cd_ref - cd - self._lift_penalty * cl.abs()
+        if self._ndims == 3:   # summed over the span here; CylinderJetEnv3D divides by D (:765-768)
+            reward = self._cd_ref - cd.sum(-1) - self._lift_penalty * cl.sum(-1).abs()
+        else:
+            reward = self._cd_ref - cd - self._lift_penalty * cl.abs()
         return obs, reward, False, {"drag": cd, "lift": cl}
 
     # ---- on-disk initial domains in the reference's format (fluid_env.py:1044-1112)
@@ -245,11 +262,16 @@ class CylinderEnvBase(FluidEnv):
             self._last_control = extra["last_control"].clone()
 
     def render(self, *a, **kw) -> np.ndarray:
-        return torch.linalg.vector_norm(self.get_velocity()[0], dim=0).detach().cpu().numpy()
+        speed = torch.linalg.vector_norm(self.get_velocity()[0], dim=0)
+        if self._ndims == 3:
+            speed = speed[speed.shape[0] // 2]      # mid-span slice
+        return speed.detach().cpu().numpy()
 
 
 def _face_vertices(mesh, block: int, face: str) -> np.ndarray:
     c = mesh.coords[block].astype(np.float64)
+    if c.shape[0] == 3:
+        c = c[:2, 0]          # the first spanwise layer ("we set z = 0", jet_cylinder_env_3d.py:378-381)
     return {"+x": c[:, :, -1], "-x": c[:, :, 0], "-y": c[:, 0, :], "+y": c[:, -1, :]}[face]
 
 
@@ -304,3 +326,161 @@ class CylinderRotEnv2D(CylinderEnvBase):
         a = action.reshape(self._num_envs, 1, 1)
         for b, face, vel in self._wall:
             self._domain.blocks[b].boundary(face).copy_(vel[None] * a)
+
+
+CYLINDER_JET_3D_DEFAULT_CONFIG = {
+    "n_jets": 8, "reynolds_number": 1e2, "resolution": 24, "dt": 1e-2, "adaptive_cfl": 0.8, "step_length": 0.25,
+    "lift_penalty": 1.0, "episode_length": 80, "local_obs_window": 3, "local_reward_weight": 0.8, "local_2d_obs": False,
+    "use_marl": False, "dtype": torch.float32, "load_initial_domain": True, "load_domain_statistics": True,
+    "randomize_initial_state": True, "enable_actions": True, "differentiable": False,
+}
+
+
+class CylinderJetEnv3D(CylinderJetEnv2D):
+    """``CylinderJetEnv3D`` (jet_cylinder_env_3d.py:44-480): the cylinder spans z in [-2, 2] (periodic), the two jet slots
+    are cut into ``n_jets`` spanwise segments, each driven by one action (single agent: all of them; multi-agent: one
+    agent per segment, observing ``local_obs_window`` neighbouring segments).
+
+    Observation layout: the reference gathers the sensors as ``[z, sensor, component]`` and then *views* that memory as
+    ``[z, component, sensor]`` (obs_extraction.py:127-135, ``view`` where a ``permute`` was meant), so the velocity
+    observation interleaves sensors and components.  Policies trained on the reference see that layout; it is kept
+    (pinned on the recorded reference output, tests/test_cylinder_grid.py)."""
+
+    _supports_marl = True
+    _n_sensors_per_agent: int = 2
+
+    def __init__(self, n_jets: int, reynolds_number: float, resolution: int, dt: float, adaptive_cfl: float,
+                 step_length: float, episode_length: int, lift_penalty: float, local_obs_window: int, use_marl: bool,
+                 local_reward_weight: Optional[float], local_2d_obs: bool = False, **kw):
+        if n_jets < 1 or resolution % n_jets != 0:
+            raise ValueError("n_agents must be a positive integer that evenly divides circle_resolution_angular.")
+        if local_2d_obs and not use_marl:
+            raise ValueError("Local 2D observations are only supported in multi-agent mode.")
+        self._local_2d_obs = bool(local_2d_obs)
+        self._n_jets = int(n_jets)
+        self._n_controls = self._n_jets
+        self._local_obs_window = int(local_obs_window)
+        self._local_reward_weight = local_reward_weight
+        if local_2d_obs:
+            self._n_sensors_per_agent = 1
+            self._local_obs_window = 1
+        kw.pop("ndims", None)
+        super().__init__(reynolds_number=reynolds_number, resolution=resolution, dt=dt, adaptive_cfl=adaptive_cfl,
+                         step_length=step_length, episode_length=episode_length, lift_penalty=lift_penalty, ndims=3,
+                         use_marl=use_marl, **kw)
+
+    # ---- spaces (jet_cylinder_env_3d.py:188-258)
+    def _get_action_space(self):
+        shape = (1,) if self._use_marl else (self._n_jets, 1)
+        return spaces.Box(low=-1.0, high=1.0, shape=shape, dtype=np.float32)
+
+    def _get_observation_space(self):
+        n, spa = self._n_sensors_x_y, self._n_sensors_per_agent
+        if self._use_marl and self._local_2d_obs:
+            v_shape, p_shape = (n, 2), (n,)
+        else:
+            lead = self._local_obs_window if self._use_marl else self._n_jets
+            v_shape, p_shape = (lead, spa, 3, n), (lead, spa, n)
+        return spaces.Dict({
+            "velocity": spaces.Box(low=-np.inf, high=np.inf, shape=v_shape, dtype=np.float32),
+            "pressure": spaces.Box(low=-np.inf, high=np.inf, shape=p_shape, dtype=np.float32),
+        })
+
+    @property
+    def n_agents(self) -> int:
+        return self._n_jets if self._use_marl else 1
+
+    @property
+    def _n_sensors_z(self) -> int:
+        return self._n_jets * self._n_sensors_per_agent
+
+    @property
+    def id(self) -> str:
+        return f"JetCylinder3D_Re{self._reynolds_number}"
+
+    # ---- sensors (jet_cylinder_env_3d.py:277-304; cylinder_env_base.py:436-449)
+    def _get_sensor_locations(self) -> np.ndarray:
+        """Pixel (x, y, z) of every sensor, [3, n_sensors_z, 151].  The spanwise positions are spread over H (not D) and
+        scaled with the y resolution, as in the reference."""
+        xy = super()._get_sensor_locations()                                     # [2, 151]
+        nz = self._n_sensors_z
+        z = np.linspace(-self.H / 2, self.H / 2, nz + 1, dtype=np.float32)[:-1] + np.float32(self.H / (2 * nz))
+        pz = (z.astype(np.float32) + np.float32(self.H / 2)) * np.float32((self.render_shape[1] - 1) / self.H)
+        pz = np.round(pz).astype(np.int64)
+        out = np.empty((3, nz, xy.shape[1]), np.int64)
+        out[0], out[1], out[2] = xy[0][None, :], xy[1][None, :], pz[:, None]
+        return out
+
+    # ---- observations (obs_extraction.py:60-151; jet_cylinder_env_3d.py:306-339)
+    def _get_global_obs(self) -> Dict[str, torch.Tensor]:
+        dom = self._domain
+        B, nz, n = self._num_envs, self._n_sensors_z, self._n_sensors_x_y
+        u = (dom.velocity[:, :, self._sensor_idx] * self._sensor_w).sum(-1)       # [B, 3, nz * 151]
+        p = (dom.pressure[:, self._sensor_idx] * self._sensor_w).sum(-1)          # [B, nz * 151]
+        if self._local_2d_obs:
+            u = u[:, :2]
+        vd = u.shape[1]
+        u = u.permute(0, 2, 1).contiguous()                                       # [B, nz * 151, vd], as gathered there
+        u = u.reshape(B, nz, vd, n).reshape(B, self._n_jets, self._n_sensors_per_agent, vd, n)   # the reference's view
+        if self._local_2d_obs:
+            u = u.permute(0, 1, 2, 4, 3)
+        return {"velocity": u, "pressure": p.reshape(B, self._n_jets, self._n_sensors_per_agent, n)}
+
+    def _get_local_obs(self) -> Dict[str, torch.Tensor]:
+        """Agent a sees the segments a - w//2 ... a + w//2 (periodic): [B, n_agents, window, ...]."""
+        g = self._get_global_obs()
+        W, nj = self._local_obs_window, self._n_jets
+        seg = (torch.arange(nj)[:, None] + torch.arange(W)[None, :] - W // 2) % nj    # [agent, window]
+        out = {}
+        for k, v in g.items():
+            win = v[:, seg.to(v.device)]                                           # [B, nj, W, ...]
+            if self._local_2d_obs:
+                win = win.reshape(self._num_envs, nj, *win.shape[4:])            # window 1, one sensor layer: squeeze
+            out[k] = win
+        return out
+
+    # ---- actuation (jet_cylinder_env_3d.py:341-421)
+    def _additional_initialization(self) -> None:
+        super()._additional_initialization()
+        nz = self._circle_resolution_angular
+        self._nz_per_agent = nz // self._n_jets
+        z3 = lambda v: torch.cat([v, torch.zeros_like(v[:1])], dim=0)[:, None, :].expand(3, nz, v.shape[1])
+        self._top_velocity3 = z3(self._top_velocity).contiguous()                 # [3, nz, nx]
+        self._bottom_velocity3 = z3(self._bottom_velocity).contiguous()
+
+    def _apply_action(self, action: torch.Tensor) -> None:
+        """One amplitude per spanwise segment, repeated over the segment's layers.  (The reference then rebalances the
+        boundary fluxes over both jet faces and the outflow with tol 1e-7; the jets are flux-neutral by construction and
+        the outflow is rebalanced by every step's PRE hook here, so that call is not repeated.)"""
+        B = self._num_envs
+        a = action.reshape(B, self._n_jets).repeat_interleave(self._nz_per_agent, dim=1)[:, None, :, None]   # [B, 1, nz, 1]
+        dom = self._domain
+        dom.blocks[TOP].boundary("-y").copy_((self._top_velocity3[None] * a).reshape(B, 3, -1))
+        dom.blocks[BOTTOM].boundary("+y").copy_((self._bottom_velocity3[None] * a).reshape(B, 3, -1))
+
+    # ---- step (jet_cylinder_env_3d.py:427-480)
+    def _step_impl(self, action: torch.Tensor):
+        obs, _, term, info = super()._step_impl(action)
+        all_cds, all_cls = info.pop("drag"), info.pop("lift")                     # [B, NZ]
+        cd, cl = all_cds.sum(-1) / self.D, all_cls.sum(-1) / self.D
+        reward = self._cd_ref - cd - self._lift_penalty * cl.abs()
+        return obs, reward, term, {"drag": cd, "lift": cl, "all_cds": all_cds, "all_cls": all_cls}
+
+    def _step_marl_impl(self, actions: torch.Tensor):
+        if self._local_reward_weight is None:
+            raise ValueError("local_reward_weight must be set for multi-agent step.")
+        _, global_reward, terminated, info = self._step_impl(actions)
+        local_obs = self._get_local_obs()
+        all_cds, all_cls = info.pop("all_cds"), info.pop("all_cls")
+        B, nj = self._num_envs, self._n_jets
+        local_cd = all_cds.reshape(B, nj, -1).sum(-1) / (self.D / nj)
+        local_cl = all_cls.reshape(B, nj, -1).sum(-1) / (self.D / nj)
+        local_rewards = self._cd_ref - local_cd - self._lift_penalty * local_cl.abs()
+        w = self._local_reward_weight
+        agent_rewards = w * local_rewards + (1 - w) * global_reward[:, None]
+        info["global_reward"] = global_reward
+        return local_obs, agent_rewards, terminated, info
+
+    def get_velocity(self) -> torch.Tensor:
+        """Resampled velocity [B, 3, z, y, x]."""
+        return self._resampler(self._domain.velocity)

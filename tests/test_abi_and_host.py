@@ -88,8 +88,15 @@ def test_registry_semantics():
     assert (cyl._reynolds_number, cyl._circle_resolution_angular) == (250, 32)
     assert cyl.render_shape == (686, 128, 128) and cyl._n_sim_steps == 25
     assert cyl._sensor_locations.shape == (2, 151)
-    with pytest.raises(NotImplementedError):
-        fluidgym_amd.make("CylinderJet2D-easy-v0", ndims=3)
+    c3 = fluidgym_amd.make("CylinderJet3D-hard-v0", cuda_device=torch.device("cpu"))
+    assert (c3._reynolds_number, c3._circle_resolution_angular, c3._ndims, c3.n_agents) == (500, 48, 3, 1)
+    assert c3.action_space.shape == (8, 1) and c3.observation_space["velocity"].shape == (8, 2, 3, 151)
+    m3 = fluidgym_amd.make("CylinderJet3D-easy-v0", cuda_device=torch.device("cpu"), use_marl=True)
+    assert m3.n_agents == 8 and m3.action_space.shape == (1,) and m3.observation_space["pressure"].shape == (3, 2, 151)
+    with pytest.raises(ValueError, match="evenly divides"):
+        fluidgym_amd.make("CylinderJet3D-easy-v0", cuda_device=torch.device("cpu"), n_jets=5)
+    with pytest.raises(ValueError, match="multi-agent"):
+        fluidgym_amd.make("CylinderJet3D-easy-v0", cuda_device=torch.device("cpu"), local_2d_obs=True)
 
 
 def test_env_contract_errors_without_gpu():

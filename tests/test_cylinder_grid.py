@@ -72,3 +72,67 @@ def test_extruded_mesh_matches_reference_3d():
     assert [tuple(c.split()[1:]) for c in calls if c.startswith("periodic")] == [(str(b), a) for b, a in m.periodic]
     inflow = G["r8_3d_velocity_0_-x"][0, :, :, :, 0].reshape(3, -1)      # [3, z, y] -> y fastest
     assert np.abs(m.fixed[(0, "-x")] - inflow).max() < 1e-6
+
+
+@pytest.mark.parametrize("res,n_jets", [(8, 4), (24, 8)])
+def test_3d_sensor_pixels_match_reference(res, n_jets):
+    import torch
+    import fluidgym_amd
+
+    env = fluidgym_amd.make("CylinderJet3D-easy-v0", cuda_device=torch.device("cpu"), resolution=res, n_jets=n_jets)
+    assert np.array_equal(env._sensor_locations, G[f"r{res}_3d_sensor_pixels"])
+
+
+class _FakeDomain:
+    """Index ramps in place of the fields: with one-hot sensor rows the env's gather returns the flat pixel index of
+    every sensor, which is what the golden generator fed the reference's observation code."""
+
+    def __init__(self, rs):
+        import torch
+        P = rs[0] * rs[1] * rs[2]
+        self.velocity = torch.arange(3 * P, dtype=torch.float32).reshape(1, 3, P)
+        self.pressure = -torch.arange(P, dtype=torch.float32).reshape(1, P)
+
+
+def _obs_env(use_marl):
+    import torch
+    import fluidgym_amd
+
+    env = fluidgym_amd.make("CylinderJet3D-easy-v0", cuda_device=torch.device("cpu"), resolution=8, n_jets=4, use_marl=use_marl)
+    rs = env.render_shape
+    env._domain = _FakeDomain(rs)
+    px = env._sensor_locations.reshape(3, -1)
+    env._sensor_idx = torch.as_tensor(px[0] + rs[0] * (px[1] + rs[1] * px[2]))[:, None]
+    env._sensor_w = torch.ones(px.shape[1], 1)
+    return env
+
+
+def test_3d_global_observation_layout_matches_reference():
+    env = _obs_env(False)
+    obs = env._get_global_obs()
+    assert np.array_equal(obs["velocity"][0].numpy(), G["r8_3d_obs_global_velocity"])
+    assert np.array_equal(obs["pressure"][0].numpy(), G["r8_3d_obs_global_pressure"])
+
+
+def test_3d_local_observation_windows_match_reference():
+    env = _obs_env(True)
+    obs = env._get_local_obs()
+    assert np.array_equal(obs["velocity"][0].numpy(), G["r8_3d_obs_local_velocity"])
+    assert np.array_equal(obs["pressure"][0].numpy(), G["r8_3d_obs_local_pressure"])
+
+
+def test_3d_jet_wall_velocities_match_reference():
+    import torch
+    import fluidgym_amd
+    from fluidgym_amd.envs.cylinder import _face_vertices
+    from fluidgym_amd.envs.cylinder_grid import BOTTOM, TOP, extrude_mesh
+
+    env = fluidgym_amd.make("CylinderJet3D-easy-v0", cuda_device=torch.device("cpu"), resolution=8, n_jets=4)
+    mesh = extrude_mesh(make_vortex_street_mesh(8), 8)
+    top = env._jet_velocities(_face_vertices(mesh, TOP, "-y"), True)        # [2, nx]
+    bottom = env._jet_velocities(_face_vertices(mesh, BOTTOM, "+y"), False)
+    ref_t, ref_b = G["r8_3d_jet_top"][0, :, :, 0, :], G["r8_3d_jet_bottom"][0, :, :, 0, :]   # [2?, nz, nx]
+    assert ref_t.shape[0] == 3 and int(G["r8_3d_nz_per_agent"]) == 2
+    assert np.abs(ref_t[2]).max() == 0 and np.abs(ref_b[2]).max() == 0
+    assert np.abs(ref_t[:2] - top[:, None, :]).max() < 1e-6 and np.abs(ref_b[:2] - bottom[:, None, :]).max() < 1e-6
+    assert np.abs(top).max() > 0.5

@@ -151,3 +151,52 @@ def test_3d_cylinder_mesh_runs_and_stays_uniform_along_the_span():
     speed = torch.linalg.vector_norm(dom.velocity, dim=1)
     assert 1.0 < float(speed.max()) < 3.0                    # accelerates around the cylinder, no blow-up
     dom.close()
+
+
+KW3 = dict(resolution=8, n_jets=4, initial_domain_steps=4, randomize_initial_state=False, step_length=0.03, dt=0.01,
+           episode_length=2)
+
+
+def test_3d_env_contract_single_agent():
+    env = fluidgym_amd.make("CylinderJet3D-easy-v0", num_envs=2, **KW3)
+    obs, _ = env.reset(seed=0)
+    assert obs["velocity"].shape == (2, 4, 2, 3, 151) and obs["pressure"].shape == (2, 4, 2, 151)
+    assert torch.isfinite(obs["velocity"]).all()
+    a = env.sample_action()
+    assert a.shape == (2, 4, 1)
+    obs, reward, term, trunc, info = env.step(a)
+    assert reward.shape == (2,) and torch.isfinite(reward).all()
+    assert set(info) == {"drag", "lift", "all_cds", "all_cls"}
+    assert info["drag"].shape == (2,) and info["all_cds"].shape == (2, 8)
+    assert torch.allclose(info["all_cds"].sum(-1) / 4.0, info["drag"], rtol=1e-5)
+    assert (info["drag"] > 0).all()
+    assert abs(float(env._domain.boundary_flux_balance().max())) < 1e-5        # the jet segments are flux neutral
+    # sensors = the 3-D resampled fields at the sensor pixels
+    full = env.get_velocity()                                                  # [B, 3, z, y, x]
+    px = env._sensor_locations.reshape(3, -1)
+    at = full[:, :, px[2], px[1], px[0]]                                       # [B, 3, S]
+    u = (env._domain.velocity[:, :, env._sensor_idx] * env._sensor_w).sum(-1)
+    assert torch.allclose(at, u, atol=1e-5)
+    assert env.render().shape == (32, 171)
+    env.close()
+
+
+def test_3d_env_multi_agent_rewards_and_windows():
+    env = fluidgym_amd.make("CylinderJet3D-easy-v0", num_envs=1, use_marl=True, **KW3)
+    obs, _ = env.reset(seed=1)
+    assert obs["velocity"].shape == (1, 4, 3, 2, 3, 151) and obs["pressure"].shape == (1, 4, 3, 2, 151)
+    # agent a's middle window is its own segment; its neighbours' middle windows are its side windows
+    p = obs["pressure"][0]
+    assert torch.equal(p[1, 0], p[0, 1]) and torch.equal(p[1, 2], p[2, 1])
+    a = torch.tensor([[[1.0], [0.0], [0.0], [-1.0]]], device="cuda")
+    obs, reward, term, trunc, info = env.step(a)
+    reward = reward[0]
+    assert reward.shape == (4,) and set(info) == {"drag", "lift", "global_reward"}
+    assert torch.isfinite(reward).all()
+    # different segment actions -> the spanwise layers differ -> so do the local rewards
+    assert float((reward.max() - reward.min()).abs()) > 1e-6
+    # the mean of the local rewards' local parts is the global one: sum_a local_cd_a * (D/n) = sum cds
+    w = 0.8
+    local = (reward - (1 - w) * info["global_reward"]) / w
+    assert local.shape == (4,)
+    env.close()
