@@ -558,7 +558,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
 // launch per iteration from a solve that is launch-bound at these mesh sizes (14 k cells x 64 envs).
 // accumulators: rho ring 0..2 (r_k.r_k in slot k % 3) | pAp ping-pong 3,4
 constexpr int C_RHO = 0, C_PAP = 3, C_SUM = 8;  // C_SUM ring 8..10: yp . r_k (residual projection, see mb_cg)
-template <int DIMS>
+// PM: how the residual is projected -- 0 not at all, 1 onto the complement of the constant (yp = 1/sqrt(N): no loads of
+// yp at all), 2 onto the complement of a general unit vector yp (gathered with every neighbour)
+template <int PM>
+__device__ __forceinline__ float mb_yp(const float* __restrict__ yp, int i, float yc) { return PM == 2 ? yp[i] : yc; }
+template <int DIMS, int PM>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* __restrict__ pA, float* __restrict__ pB, int it_arg,
                                                       int project_mean) {
     MB_SYS
@@ -596,12 +600,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
         const float* r = q.r + vb;
         const float* po = p_old + vb;
         const float* yp = D.yproj;
-        const float pi = fresh ? r[i] - cy * yp[i] : r[i] - cy * yp[i] + beta * po[i];
+        const float yc = PM == 1 ? cy * rsqrtf((float)N) : 0.f;   // cy * yp for the constant vector
+        auto proj = [&](int c) { return PM == 0 ? r[c] : (PM == 1 ? r[c] - yc : r[c] - cy * yp[c]); };
+        const float pi = fresh ? proj(i) : proj(i) + beta * po[i];
         float y = q.diag[(size_t)b * N + i] * pi;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int n = D.nbr[(size_t)f * N + i];
-            if (n >= 0) y += q.off[((size_t)b * F + f) * N + i] * (fresh ? r[n] - cy * yp[n] : r[n] - cy * yp[n] + beta * po[n]);
+            if (n >= 0) y += q.off[((size_t)b * F + f) * N + i] * (fresh ? proj(n) : proj(n) + beta * po[n]);
         }
         p_new[vb + i] = pi;
         q.v[vb + i] = y;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
 // ---- the same two kernels with four consecutive cells per thread (N % 4 == 0): own-cell data moves as 128-bit loads, the
 // 2 x 2d x 4 neighbour gathers of a thread are independent and overlap, and a quarter of the workgroups is launched --
 // at 14 k cells x 64 envs the scalar kernels were bound by gather latency and workgroup turnover, not by bytes.
-template <int DIMS>
+template <int DIMS, int PM>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float* __restrict__ pA, float* __restrict__ pB,
                                                        int it_arg, int project_mean) {
     const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;
@@ -683,8 +689,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
         const float* po = p_old + vb;
         const float4 r4 = *reinterpret_cast<const float4*>(r + i);
         const float* yp = D.yproj;
-        const float4 y4 = *reinterpret_cast<const float4*>(yp + i);
-        float pi[4] = {r4.x - cy * y4.x, r4.y - cy * y4.y, r4.z - cy * y4.z, r4.w - cy * y4.w};
+        const float yc = PM == 1 ? cy * rsqrtf((float)N) : 0.f;   // cy * yp for the constant vector
+        float pi[4] = {r4.x - yc, r4.y - yc, r4.z - yc, r4.w - yc};
+        if (PM == 2) {
+            const float4 y4 = *reinterpret_cast<const float4*>(yp + i);
+            pi[0] = r4.x - cy * y4.x; pi[1] = r4.y - cy * y4.y; pi[2] = r4.z - cy * y4.z; pi[3] = r4.w - cy * y4.w;
+        }
         if (!fresh) {
             const float4 p4 = *reinterpret_cast<const float4*>(po + i);
             pi[0] += beta * p4.x; pi[1] += beta * p4.y; pi[2] += beta * p4.z; pi[3] += beta * p4.w;
@@ -700,7 +710,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
-                float pn = r[n] - cy * yp[n];
+                float pn = PM == 2 ? r[n] - cy * yp[n] : r[n] - yc;
                 if (!fresh) pn += beta * po[n];
                 y[e] += oo[e] * pn;
             }
@@ -906,6 +916,13 @@ __global__ void k_mb_fill(size_t n, float v, float* __restrict__ x) {
         else { constexpr int DIMS = 3; __VA_ARGS__ }            \
     } while (0)
 
+#define MB_DISPATCH_PM(s, pm, ...)                                             \
+    do {                                                                        \
+        if ((pm) == 0) { constexpr int PM = 0; MB_DISPATCH(s, __VA_ARGS__); }   \
+        else if ((pm) == 1) { constexpr int PM = 1; MB_DISPATCH(s, __VA_ARGS__); } \
+        else { constexpr int PM = 2; MB_DISPATCH(s, __VA_ARGS__); }              \
+    } while (0)
+
 int mb_poll(fg_mb_state* s, int nsys, hipStream_t st, bool& done) {
     FG_HIP_CHECK(hipStreamSynchronize(st));
     done = true;
@@ -1008,8 +1025,9 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
         s->prof_used = 0;
         return FG_OK;
     };
+    const int pm_mode = project_mean ? (s->yproj_const ? 1 : 2) : 0;
     auto enqueue_chunk = [&](bool sample) {
-        MB_DISPATCH(s, {
+        MB_DISPATCH_PM(s, pm_mode, {
             for (int k = 0; k < CG_CHUNK; ++k) {
                 const bool ev = sample && k == 0 && s->prof_used + 2 <= 32;
                 const int e0 = s->prof_used;
@@ -1021,18 +1039,18 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
                 s->prof_launches[0] += 1; s->prof_launches[1] += 1;
                 if (vec4) {
                     if (ev) {
-                        hipExtLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap4<DIMS, PM>), grid4, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
                         hipExtLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean, s->dev.yproj);
                     } else {
-                        hipLaunchKernelGGL(k_mbc_ap4<DIMS>, grid4, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap4<DIMS, PM>), grid4, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
                         hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean, s->dev.yproj);
                     }
                 } else {
                     if (ev) {
-                        hipExtLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap<DIMS, PM>), grid, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
                         hipExtLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
                     } else {
-                        hipLaunchKernelGGL(k_mbc_ap<DIMS>, grid, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap<DIMS, PM>), grid, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
                         hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
                     }
                 }
@@ -1047,7 +1065,7 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     if (use_graph) {
         MbGraphKey key;
         memset(&key, 0, sizeof(key));
-        key.q = q; key.vec4 = vec4; key.project_mean = project_mean; key.stream = st;
+        key.q = q; key.vec4 = vec4; key.project_mean = pm_mode; key.stream = st;
         static_assert(sizeof(MbGraphKey) <= sizeof(s->cg_graph_key_storage), "graph key storage too small");
         MbGraphKey& stored = *reinterpret_cast<MbGraphKey*>(s->cg_graph_key_storage);
         if (!s->cg_graph_exec || memcmp(&key, &stored, sizeof(key)) != 0) {
@@ -1564,6 +1582,7 @@ extern "C" int fg_mb_set_residual_projection(fg_mb_handle s, const float* y_host
     const float sc = (float)(1.0 / std::sqrt(nrm));
     for (int i = 0; i < s->N; ++i) y[i] *= sc;
     FG_HIP_CHECK(hipMemcpy(s->yproj, y.data(), sizeof(float) * s->N, hipMemcpyHostToDevice));
+    s->yproj_const = (y_host == nullptr);
     return FG_OK;
 }
 // builds the pressure matrix for A = 1 into the P buffers (FG_MB_BUF_P_DIAG / P_OFF): the geometry-only matrix whose left
