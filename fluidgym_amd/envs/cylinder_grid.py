@@ -31,7 +31,7 @@ def _lerp_points(a, b, w):
     return np.asarray(a, np.float64)[None, :] * (1.0 - w) + np.asarray(b, np.float64)[None, :] * w
 
 
-def patch_from_borders(corners, borders, res_y: int, res_x: int, y_weights=None) -> np.ndarray:
+def patch_from_borders(corners, borders, res_y: int, res_x: int, y_weights=None, x_weights=None) -> np.ndarray:
     """Vertices ``[2, res_y, res_x]`` of a quadrilateral patch with prescribed borders.
 
     corners: (-x-y, +x-y, -x+y, +x+y); borders: [-x, +x, -y, +y] as ``[n, 2]`` arrays or None (straight line between the
@@ -41,17 +41,18 @@ def patch_from_borders(corners, borders, res_y: int, res_x: int, y_weights=None)
     """
     wy = np.arange(res_y) / (res_y - 1) if y_weights is None else np.asarray(y_weights, np.float64)
     wx = np.arange(res_x) / (res_x - 1)
-    if len(wy) != res_y:
-        raise ValueError("y_weights must have one entry per vertex row")
-    b = list(borders)
+    wxb = wx if x_weights is None else np.asarray(x_weights, np.float64)   # spacing of straight -y/+y borders only
+    if len(wy) != res_y or len(wxb) != res_x:
+        raise ValueError("weights must have one entry per vertex row / column")
+    b = list(borders) if borders is not None else [None] * 4
     if b[0] is None:
         b[0] = _lerp_points(corners[0], corners[2], wy)
     if b[1] is None:
         b[1] = _lerp_points(corners[1], corners[3], wy)
     if b[2] is None:
-        b[2] = _lerp_points(corners[0], corners[1], wx)
+        b[2] = _lerp_points(corners[0], corners[1], wxb)
     if b[3] is None:
-        b[3] = _lerp_points(corners[2], corners[3], wx)
+        b[3] = _lerp_points(corners[2], corners[3], wxb)
     b = [np.asarray(x, np.float64) for x in b]
     out = np.zeros((2, res_y, res_x))
     for j in range(res_y):

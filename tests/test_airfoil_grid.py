@@ -1,0 +1,61 @@
+"""The airfoil mesh construction against the reference's recorded meshes (tests/golden/make_golden_airfoil.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from fluidgym_amd.envs.airfoil_grid import make_airfoil_mesh, naca0012_sharp, surface_from_blocks
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_airfoil_grid.npz"))
+
+
+def _surface(tag, aoa):
+    return surface_from_blocks(G[f"{tag}_block1"], G[f"{tag}_block2"], G[f"{tag}_block3"], aoa)
+
+
+@pytest.mark.parametrize("aoa", [20, 0])
+def test_mesh_reproduces_the_recorded_reference_mesh(aoa):
+    """Fed with the surface polyline the recorded mesh contains, the construction returns that mesh: split indices,
+    block sizes, spacing laws, transfinite patches, inflow profile, connections."""
+    tag = f"aoa{aoa}"
+    m = make_airfoil_mesh(attack_angle_deg=float(aoa), surface=_surface(tag, float(aoa)))
+    for b in range(6):
+        ref = G[f"{tag}_block{b}"]
+        assert m.coords[b].shape == ref.shape
+        assert np.abs(m.coords[b] - ref).max() < 2e-7
+    calls = [str(c).split() for c in G[f"{tag}_calls"]]
+    assert [c[2] for c in calls if c[0] == "block"] == m.names
+    conns = [(int(c[1]), c[2], int(c[3]), c[4], c[5]) for c in calls if c[0] == "connect"]
+    assert conns == m.connections
+    closed = sorted((int(c[1]), c[2]) for c in calls if c[0] == "close")
+    assert closed == sorted(m.fixed)
+    inflow = G[f"{tag}_velocity_0_-x"][0, :, :, 0]
+    assert np.abs(m.fixed[(0, "-x")] - inflow).max() < 1e-6
+    for b in (4, 5):
+        assert np.allclose(m.fixed[(b, "+x")], G[f"{tag}_velocity_{b}_+x"].reshape(2, 1))
+    assert m.outflows == [(4, "+x"), (5, "+x")]
+
+
+@pytest.mark.parametrize("div,aoa", [(1, 10.0), (2, 10.0), (4, 10.0), (2, 0.0)])
+def test_own_section_gives_a_valid_mesh_at_every_resolution(div, aoa):
+    """With the closed-form section (no table): right-handed cells everywhere, blocks meet along shared vertices."""
+    m = make_airfoil_mesh(attack_angle_deg=aoa, resolution_div=div)
+    for c in m.coords:
+        c = c.astype(np.float64)
+        ex = c[:, :-1, 1:] - c[:, :-1, :-1]
+        ey = c[:, 1:, :-1] - c[:, :-1, :-1]
+        assert (ex[0] * ey[1] - ex[1] * ey[0]).min() > 0
+    left, front, top, bot, tu, tl = m.coords
+    assert np.allclose(left[:, :, -1], front[:, :, 0], atol=1e-6)
+    assert np.allclose(front[:, -1, :], top[:, :, 0][:, ::1], atol=1e-6) or np.allclose(front[:, -1, :], top[:, ::-1, 0], atol=1e-6)
+    assert np.allclose(top[:, :, -1], tu[:, :, 0], atol=1e-6) and np.allclose(bot[:, :, -1], tl[:, :, 0], atol=1e-6)
+    assert np.allclose(tu[:, 0, :], tl[:, -1, :], atol=1e-6)
+    assert top.shape[1] == 96 // div
+
+
+def test_closed_form_section():
+    s = naca0012_sharp()
+    assert s.shape == (160, 2) and np.allclose(s[0], [1, 0]) and np.allclose(s[-1], [1, 0])
+    assert np.allclose(s[1:80, 1], -s[-2:79:-1, 1]) and abs(s[:, 1].max() - 0.06) < 5e-4   # symmetric, 12 % thick
+    ref = _surface("aoa0", 0.0)
+    assert np.abs(np.interp(ref[:80, 0][::-1], s[:80, 0][::-1], s[:80, 1][::-1]) - ref[:80, 1][::-1]).max() < 1e-3
