@@ -75,8 +75,12 @@ def _register_all():
     cj3 = _lazy(".envs.cylinder", "CylinderJetEnv3D")
     for level, re, res in (("easy", 100, 24), ("medium", 250, 32), ("hard", 500, 48)):   # fluidgym/__init__.py:79-102
         register(f"CylinderJet3D-{level}-v0", cj3, CJ3, reynolds_number=re, resolution=res)
+    from .envs.airfoil import AIRFOIL_2D_DEFAULT_CONFIG as AF2
+    af2 = _lazy(".envs.airfoil", "AirfoilEnv2D")
+    for level, re in (("easy", 1e3), ("medium", 3e3), ("hard", 5e3)):                     # fluidgym/__init__.py:307-328
+        register(f"Airfoil2D-{level}-v0", af2, AF2, reynolds_number=re)
     for fam, ids in {
-        "Airfoil": ["Airfoil2D-easy-v0", "Airfoil2D-medium-v0", "Airfoil2D-hard-v0", "Airfoil3D-easy-v0"],
+        "Airfoil": ["Airfoil3D-easy-v0", "Airfoil3D-medium-v0", "Airfoil3D-hard-v0"],
     }.items():
         for i in ids:
             register(i, _not_built(fam), {})

@@ -993,7 +993,7 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     const int nsys = s->B, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);
     q.rw = nullptr;
-    q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = 400;
+    q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = s->cg_stall_limit;
     q.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; q.accept_window = 20;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     const bool vec4 = (n % 4 == 0) && !getenv("FG_MB_SCALAR_CG");
@@ -1583,6 +1583,15 @@ extern "C" int fg_mb_set_residual_projection(fg_mb_handle s, const float* y_host
     for (int i = 0; i < s->N; ++i) y[i] *= sc;
     FG_HIP_CHECK(hipMemcpy(s->yproj, y.data(), sizeof(float) * s->N, hipMemcpyHostToDevice));
     s->yproj_const = (y_host == nullptr);
+    return FG_OK;
+}
+// CG solves end with their best iterate once no iterate has improved on it (by 2x, or at all below the acceptance band) for
+// this many iterations; default 400.  Meshes whose pressure system has a residual floor above the tolerance
+// spend that many iterations per solve for nothing, so their envs lower it.
+extern "C" int fg_mb_set_stall_limit(fg_mb_handle s, int32_t iterations) {
+    FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_set_stall_limit: null handle");
+    FG_REQUIRE(iterations >= 20, FG_ERR_INVALID_ARG, "fg_mb_set_stall_limit: at least one chunk of 20 iterations");
+    s->cg_stall_limit = iterations;
     return FG_OK;
 }
 // builds the pressure matrix for A = 1 into the P buffers (FG_MB_BUF_P_DIAG / P_OFF): the geometry-only matrix whose left

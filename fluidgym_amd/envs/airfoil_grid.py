@@ -29,13 +29,21 @@ LEFT, FRONT, TOP, BOTTOM, TAIL_UPPER, TAIL_LOWER = range(6)
 
 def naca0012_sharp(n_points: int = 160) -> np.ndarray:
     """Closed polyline ``[n, 2]`` of the NACA 0012 with a sharp trailing edge (the 4-digit thickness form with the last
-    coefficient -0.1036), chord 1: from the trailing edge over the upper surface to the nose and back underneath."""
-    theta = 2.0 * math.pi * np.arange(n_points) / (n_points - 1)
-    x = 0.5 * (1.0 + np.cos(theta))
+    coefficient -0.1036), chord 1: from the trailing edge over the upper surface to the nose and back underneath.
+
+    Chordwise distribution x(t) = 0.65 t^2 + 2.04 t^3 - 1.69 t^4, t uniform from nose to trailing edge: quadratic at the
+    nose (uniform arc length ~1.9e-3 around the leading-edge circle, which also sets the first tail cell), spacing
+    ~8e-3 at the trailing edge -- the resolution the reference's tabulated section has at both ends, so that the mesh
+    sizes (tail blocks ~160 columns) and the time-step restriction come out as there."""
+    half = n_points // 2
+    t = (np.arange(half) + 0.5) / (half - 0.5)            # nose straddled by the two middle points, t = 1 at the edge
+    x = 0.65 * t ** 2 + 2.04 * t ** 3 - 1.69 * t ** 4
+    x[-1] = 1.0
     yt = 0.6 * (0.2969 * np.sqrt(x) - 0.1260 * x - 0.3516 * x ** 2 + 0.2843 * x ** 3 - 0.1036 * x ** 4)
-    y = np.where(theta <= math.pi, yt, -yt)
-    y[0] = y[-1] = 0.0
-    return np.stack([x, y], axis=1)
+    yt[-1] = 0.0
+    upper = np.stack([x[::-1], yt[::-1]], axis=1)           # trailing edge -> nose
+    lower = np.stack([x, -yt], axis=1)                      # nose -> trailing edge
+    return np.concatenate([upper, lower], axis=0)
 
 
 def weights_exp(res: int, base: float, refinement: str) -> np.ndarray:

@@ -237,6 +237,10 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_boundary_flux_balance(self.handle, out, ctypes.c_void_p(st)))
         return np.array(out[:], dtype=np.float32)
 
+    def set_stall_limit(self, iterations: int) -> None:
+        """Iterations a CG solve may go without improving its kept iterate before it ends with it (default 400)."""
+        L.check(self.lib.fg_mb_set_stall_limit(self.handle, int(iterations)))
+
     def boundary_tables(self):
         """(owner cell [NB], face [NB], Minv|det [NB, d*d+1]) of the boundary slots (host arrays)."""
         nb, tw = self.n_boundary_faces, self.dims * self.dims + 1

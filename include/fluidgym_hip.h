@@ -395,6 +395,10 @@ int fg_mb_max_velocity(fg_mb_handle h, float* out_B_host, void* stream);
  * fg_mb_unit_pressure_matrix leaves the pressure matrix for A = 1 in the P buffers so that a host routine can compute its left
  * near-null vector, the choice that removes the residual floor of non-orthogonal meshes */
 int fg_mb_set_residual_projection(fg_mb_handle h, const float* y_host);
+/* Iterations a CG solve may go without improving its kept iterate before it ends with that iterate (default 400;
+ * the reference has no such limit: its solves run to maxIterations and return the best result,
+ * cg_solver_kernel.cu:345-361, PISOtorch_diff.py:266-371). */
+int fg_mb_set_stall_limit(fg_mb_handle h, int32_t iterations);
 int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their

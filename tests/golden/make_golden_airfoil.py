@@ -73,6 +73,34 @@ def main():
         out[f"{tag}_calls"] = np.array(calls)
         print(tag, [(k, v.shape) for k, v in out.items() if k.startswith(tag) and v.dtype.kind != "U"])
         print(calls)
+    # ---- env-level geometry of AirfoilEnvBase (airfoil_env_base.py:175-214, 559-660): section mask on the render grid,
+    # sensor pixels left after masking, jet cell ranges on the top block -- the reference's own methods run on a bare
+    # namespace; the default angle of attack (10 degrees) and the recorded ones
+    import ast
+    with open(f"{REF}/fluidgym/envs/airfoil/airfoil_env_base.py") as fh:
+        tree = ast.parse(fh.read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "AirfoilEnvBase")
+    want = {"_get_airfoil_mask", "_physical_locations_to_grid_coords", "_get_sensor_locations", "_get_sensor_locations_2d"}
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(fns, []), "airfoil_env_base.py", "exec"), ns)
+    for aoa in (10.0, 20.0, 0.0):
+        me = types.SimpleNamespace(H=1.4, L=4.5, D=1.4, airfoil_length=1.0, _ndims=2, render_shape=(600, 150, 150))
+        _, c = grid.read_airfoil(attack_angle_deg=aoa, cpu_device=torch.device("cpu"), dtype=torch.float32)
+        me._airfoil_coords = c.squeeze()
+        for k in want:
+            setattr(me, k, types.MethodType(ns[k], me))
+        me._airfoil_mask = me._get_airfoil_mask()
+        tag = f"aoa{int(aoa)}"
+        out[f"{tag}_mask_rows"] = np.packbits(me._airfoil_mask, axis=1)          # [150, 75] bits of the [150, 600] mask
+        out[f"{tag}_sensor_pixels"] = me._get_sensor_locations().numpy()
+        print(tag, "mask pixels", int(me._airfoil_mask.sum()), "sensors", out[f"{tag}_sensor_pixels"].shape)
+    for aoa in (20.0, 0.0):
+        tag = f"aoa{int(aoa)}"
+        coords = [torch.from_numpy(out[f"{tag}_block{b}"])[None] for b in range(6)]
+        dom = types.SimpleNamespace(getVertexCoordinates=lambda: coords, getSpatialDims=lambda: 2)
+        out[f"{tag}_jet_locations"] = np.asarray(grid.get_jet_locations(dom), np.int32)
+        print(tag, "jets", out[f"{tag}_jet_locations"].tolist())
     np.savez_compressed(os.path.join(OUT, "reference_airfoil_grid.npz"), **out)
 
 

@@ -83,7 +83,7 @@ def test_registry_semantics():
     for must in ("RBC2D-easy-v0", "TCFSmall3D-both-easy-v0", "ChannelJet2D-v0"):
         assert must in ids
     with pytest.raises(NotImplementedError):
-        fluidgym_amd.make("Airfoil2D-easy-v0")
+        fluidgym_amd.make("Airfoil3D-easy-v0")
     cyl = fluidgym_amd.make("CylinderJet2D-medium-v0", cuda_device=torch.device("cpu"))  # construction touches no GPU
     assert (cyl._reynolds_number, cyl._circle_resolution_angular) == (250, 32)
     assert cyl.render_shape == (686, 128, 128) and cyl._n_sim_steps == 25

@@ -59,3 +59,48 @@ def test_closed_form_section():
     assert np.allclose(s[1:80, 1], -s[-2:79:-1, 1]) and abs(s[:, 1].max() - 0.06) < 5e-4   # symmetric, 12 % thick
     ref = _surface("aoa0", 0.0)
     assert np.abs(np.interp(ref[:80, 0][::-1], s[:80, 0][::-1], s[:80, 1][::-1]) - ref[:80, 1][::-1]).max() < 1e-3
+
+
+@pytest.mark.parametrize("aoa", [10, 20, 0])
+def test_env_mask_and_sensor_pixels_match_reference(aoa):
+    """Section mask on the render grid (the tie rules of the reference's polygon test matter: pixel centres and polygon
+    vertices are integers) and the sensors left after masking, from the surface the recorded meshes contain."""
+    import torch
+    import fluidgym_amd
+
+    tag = f"aoa{aoa}"
+    env = fluidgym_amd.make("Airfoil2D-easy-v0", cuda_device=torch.device("cpu"), attack_angle_deg=float(aoa),
+                            surface=_surface("aoa0", 0.0))
+    mask = np.unpackbits(G[f"{tag}_mask_rows"], axis=1)[:, :600].astype(bool)
+    assert np.array_equal(env._airfoil_mask, mask)
+    assert np.array_equal(env._sensor_locations, G[f"{tag}_sensor_pixels"])
+    assert env.observation_space["velocity"].shape == (G[f"{tag}_sensor_pixels"].shape[1], 2)
+    assert env.action_space.shape == (3,) and env._n_sim_steps == 5
+    # the closed-form section gives the same sensors (its mask differs by a few edge pixels only)
+    own = fluidgym_amd.make("Airfoil2D-easy-v0", cuda_device=torch.device("cpu"), attack_angle_deg=float(aoa))
+    assert np.array_equal(own._sensor_locations, env._sensor_locations)
+    assert int((own._airfoil_mask != mask).sum()) < 50
+
+
+@pytest.mark.parametrize("aoa", [20, 0])
+def test_jet_cell_ranges_match_reference(aoa):
+    from fluidgym_amd.envs.airfoil import jet_locations
+
+    tag = f"aoa{aoa}"
+    assert jet_locations(G[f"{tag}_block2"]) == G[f"{tag}_jet_locations"].tolist()
+    m = make_airfoil_mesh(attack_angle_deg=float(aoa), surface=_surface(tag, float(aoa)))
+    assert jet_locations(m.coords[2]) == G[f"{tag}_jet_locations"].tolist()
+
+
+def test_airfoil_registry_and_argument_checks():
+    import torch
+    import fluidgym_amd
+
+    for level, re in (("easy", 1e3), ("medium", 3e3), ("hard", 5e3)):
+        env = fluidgym_amd.make(f"Airfoil2D-{level}-v0", cuda_device=torch.device("cpu"))
+        assert env._reynolds_number == re and env._attack_angle_deg == 10.0 and env.render_shape == (600, 150, 150)
+        assert abs(env._nu - 0.3 / re) < 1e-12
+    with pytest.raises(ValueError, match="between 0 and 20"):
+        fluidgym_amd.make("Airfoil2D-easy-v0", cuda_device=torch.device("cpu"), attack_angle_deg=25.0)
+    with pytest.raises(NotImplementedError):
+        fluidgym_amd.make("Airfoil3D-easy-v0")
