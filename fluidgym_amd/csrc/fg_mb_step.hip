@@ -996,7 +996,8 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = s->cg_stall_limit;
     q.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; q.accept_window = 20;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
-    const bool vec4 = (n % 4 == 0) && !getenv("FG_MB_SCALAR_CG");
+    const char* scalar_env = getenv("FG_MB_SCALAR_CG");   // "1" forces the one-cell-per-thread kernels (debugging)
+    const bool vec4 = (n % 4 == 0) && !(scalar_env && scalar_env[0] == '1');
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project_mean ? C_SUM : -1, 0););
