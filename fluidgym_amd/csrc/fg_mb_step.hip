@@ -701,6 +701,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
         }
         const float4 d4 = *reinterpret_cast<const float4*>(q.diag + (size_t)b * N + i);
         float y[4] = {d4.x * pi[0], d4.y * pi[1], d4.z * pi[2], d4.w * pi[3]};
+        // the direction value of a neighbour is the same expression as the cell's own (pi): inside a block row the -x / +x
+        // neighbours are the adjacent cells, i.e. this thread's other three cells or the first / last cell of the adjacent
+        // lane -- taken from registers / a lane shuffle instead of two gathers each (a third to a half of all gathers)
+        const int lane = threadIdx.x & 63;
+        const float from_prev = __shfl_up(pi[3], 1), from_next = __shfl_down(pi[0], 1);
+        auto gather = [&](int n) {
+            float pn = PM == 2 ? r[n] - cy * yp[n] : r[n] - yc;
+            if (!fresh) pn += beta * po[n];
+            return pn;
+        };
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int4 n4 = *reinterpret_cast<const int4*>(D.nbr + (size_t)f * N + i);
@@ -710,8 +720,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
-                float pn = PM == 2 ? r[n] - cy * yp[n] : r[n] - yc;
-                if (!fresh) pn += beta * po[n];
+                float pn;
+                if (f == 0 && n == i + e - 1 && (e > 0 || lane > 0)) pn = e > 0 ? pi[e > 0 ? e - 1 : 0] : from_prev;
+                else if (f == 1 && n == i + e + 1 && (e < 3 || lane < 63)) pn = e < 3 ? pi[e < 3 ? e + 1 : 3] : from_next;
+                else pn = gather(n);
                 y[e] += oo[e] * pn;
             }
         }
