@@ -346,6 +346,7 @@ struct MbSolve {
     float* best_x; int32_t* best_it; int stall_limit;
     // device-side iteration index of the graph-replayed CG: ctr[0] read by k_mbc_ap*, ctr[1] - 1 by k_mbc_update*
     int32_t* it_ctr; int max_iterations;
+    int it_base;  // BiCGStab: iteration index of the last restart (kernels run on the index since then, reports add this)
     // stall acceptance (off when 0): a system whose kept iterate is within accept_factor * tol and has not improved for
     // accept_window iterations ends with that iterate and counts as converged
     float accept_factor; int accept_window;
@@ -425,6 +426,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int u
     }
 }
 
+// restart of the BiCGStab recurrence from the current iterate (the reference's residualResetSteps, bicgstab_solver_kernel.cu):
+// accumulators and scalars of the systems still iterating are reset, then k_mbs_init recomputes r = b - A x and r^ = p = r.
+// In fp32 the recurrence of the nearly singular, non-symmetric pressure systems drifts and finally diverges without it.
+__global__ void k_mbb_restart(MbSolve q, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys || q.flags[s] != 0) return;
+    for (int k = 0; k < MB_ACC; ++k) q.acc[(size_t)s * MB_ACC + k] = 0.0;
+    q.sc[s * 2] = 1.f; q.sc[s * 2 + 1] = 1.f;
+}
+
 // second half of the start of a projected BiCGStab solve: r <- r - mean r, rw = p = r, rho0 = rr = |r|^2
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
@@ -450,11 +461,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) 
     if (f == 4) { if (leader) q.flags[sys] = 1; return; }
     if (f != 0) return;
     const float crit = mb_rms(a[A_RR], N);
-    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it == 0 ? -1 : it); return; }
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
         a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0; a[A_ST] = 0.0;
         q.info[sys].final_residual = crit;
-        q.info[sys].used_iterations = it - 1;
+        q.info[sys].used_iterations = it + q.it_base - 1;
     }
     if (it == 0 || !valid) return;
     const float alpha = q.sc[sys * 2], omega = q.sc[sys * 2 + 1];
@@ -979,18 +990,31 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
     bool done = false;
     int next_poll = 2;
+    constexpr int BICG_RESTART = 200;
     for (int it = 0; it < max_iterations && !done; ++it) {
+        if (it > 0 && it % BICG_RESTART == 0) {
+            q.it_base = it;
+            hipLaunchKernelGGL(k_mbb_restart, sg, sb, 0, st, q, nsys);
+            MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, 1, project ? A_ST : -1, project ? 1 : 0););
+            if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
+        }
+        const int li = it - q.it_base;
         MB_DISPATCH(s, {
-            hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, it);
-            hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, it);
-            hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, it);
-            hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, it);
-            hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, it);
+            hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
         });
         if (it + 1 >= next_poll || it + 1 == max_iterations) {
-            next_poll = it + 1 + 2;
+            next_poll = it + 1 + (it < 20 ? 2 : 10);   // long (pressure) solves: fewer host round trips
             hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
             if (int rc = mb_poll(s, nsys, st, done)) return rc;
+            if (nc == 1 && getenv("FG_MB_TRACE")) {
+                float lo = 1e30f, hi = 0.f; int active = 0;
+                for (int i = 0; i < nsys; ++i) { const float c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
+                fprintf(stderr, "[mb_bicg] it %4d residual min %.3e max %.3e active %d\n", it + 1, lo, hi, active);
+            }
         }
     }
     return mb_finish(s, nsys, nullptr, max_it);

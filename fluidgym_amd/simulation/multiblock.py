@@ -290,10 +290,12 @@ class MultiBlockDomain:
 
     def make_divergence_free(self, pressure_tol: float = 1e-5, max_iterations: int = 1000, pressure_non_ortho_steps: int = 1,
                              pressure_use_bicgstab: bool = False, outflow=None,
-                             outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0), outflow_tol: float = 5e-6) -> bool:
+                             outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0), outflow_tol: float = 5e-6,
+                             pressure_project_mean: bool = False) -> bool:
         if outflow is not None:  # PRE hook with time_step = 1 (PISOtorch_simulation.py:1334-1345)
             self.update_advective_boundary(1.0, outflow, outflow_velocity, outflow_tol)
-        opt = self._step_options(1, 1, pressure_non_ortho_steps, 1e-5, pressure_tol, max_iterations, pressure_use_bicgstab)
+        opt = self._step_options(1, 1, pressure_non_ortho_steps, 1e-5, pressure_tol, max_iterations, pressure_use_bicgstab,
+                                 pressure_project_mean=pressure_project_mean)
         st = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.fg_mb_make_divergence_free(self.handle, ctypes.byref(opt), ctypes.c_void_p(st))
         L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED,))
@@ -439,7 +441,8 @@ class MultiBlockSimulation:
     def make_divergence_free(self) -> bool:
         return self.domain.make_divergence_free(pressure_tol=self.pressure_tol, pressure_non_ortho_steps=self.pressure_non_ortho_steps,
                                                 pressure_use_bicgstab=self.pressure_use_BiCG, outflow=self.outflow,
-                                                outflow_velocity=self.outflow_velocity, outflow_tol=self.outflow_tol)
+                                                outflow_velocity=self.outflow_velocity, outflow_tol=self.outflow_tol,
+                                                pressure_project_mean=self.pressure_use_BiCG and self.pressure_project_mean)
 
     def single_step(self) -> bool:
         adaptive = self.substeps in ("ADAPTIVE", -1)
