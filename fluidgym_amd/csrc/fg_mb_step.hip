@@ -436,6 +436,47 @@ __global__ void k_mbb_restart(MbSolve q, int nsys) {
     q.sc[s * 2] = 1.f; q.sc[s * 2 + 1] = 1.f;
 }
 
+// ---- fp64 iterative refinement around the fp32 BiCGStab (pressure_use_bicgstab = 2).  On the nearly singular pressure
+// systems of strongly non-orthogonal meshes the solution carries a large near-null component, and fp32 round-off of P x
+// (and of x itself) puts the TRUE residual at 1e-5 while the recurrence residual keeps falling.  The reference answers
+// that with an fp64 solve (solver_double_fallback, PISOtorch_diff.py:266-371); here the iterate is kept in fp64 (x64), every
+// restart folds the fp32 correction into it and recomputes r = b - P x64 in fp64, and the fp32 solver always works on a
+// correction that starts from zero -- its round-off scales with the correction, not with the solution.
+__global__ __launch_bounds__(FG_BLOCK) void k_mbr_fold(int N, MbSolve q, double* __restrict__ x64, int mode) {
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
+    if (i >= N || q.flags[sys] == 3) return;      // inactive envs untouched; converged ones fold their last correction once
+    const size_t k = (size_t)sys * N + i;
+    if (mode == 0) { x64[k] = 0.0; return; }                        // cold start
+    if (mode == 1) { x64[k] = (double)q.x[k]; q.x[k] = 0.f; return; }  // warm start from the caller's x
+    if (mode == 2) { if (q.flags[sys] == 0) { x64[k] += (double)q.x[k]; q.x[k] = 0.f; } return; }  // restart
+    q.x[k] = (float)(x64[k] + (double)q.x[k]);                       // mode 3: hand back the sum
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbr_residual(MbDev D, MbSolve q, const double* __restrict__ x64, int sum_slot, int defer_rho) {
+    MB_SYS
+    if (q.flags[sys] != 0) return;
+    float r = 0.f;
+    if (valid) {
+        constexpr int F = 2 * DIMS;
+        const double* x = x64 + vb;
+        double y = (double)q.diag[(size_t)b * N + i] * x[i];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int n = D.nbr[(size_t)f * N + i];
+            if (n >= 0) y += (double)q.off[((size_t)b * F + f) * N + i] * x[n];
+        }
+        r = (float)((double)q.rhs[vb + i] - y);
+        q.x[vb + i] = 0.f;
+        q.r[vb + i] = r; q.rw[vb + i] = r; q.p[vb + i] = r;
+    }
+    const float s = mb_block_sum(r * r, lds);
+    const float s1 = sum_slot >= 0 ? mb_block_sum(valid ? r : 0.f, lds) : 0.f;
+    if (threadIdx.x == 0) {
+        if (!defer_rho) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
+        if (sum_slot >= 0) atomicAdd(a + sum_slot, (double)s1);
+    }
+}
+
 // second half of the start of a projected BiCGStab solve: r <- r - mean r, rw = p = r, rho0 = rr = |r|^2
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
@@ -979,23 +1020,38 @@ MbSolve mb_solve_ptrs(fg_mb_state* s, const float* diag, const float* off, const
     return q;
 }
 
+template <typename T>
+int mb_alloc(fg_mb_state* s, T** p, size_t count);
+
 int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, int nc,
-                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0) {
+                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0) {
     const int nsys = s->B * nc, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     q.project = project ? 1 : 0;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
+    refine = refine && nc == 1;
+    if (refine && !s->x64) { if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc; }
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
-    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project ? A_ST : -1, project ? 1 : 0););
+    if (refine) {
+        hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, use_x0 ? 1 : 0);
+        MB_DISPATCH(s, hipLaunchKernelGGL(k_mbr_residual<DIMS>, grid, blk, 0, st, s->dev, q, (const double*)s->x64, project ? A_ST : -1, project ? 1 : 0););
+    } else {
+        MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project ? A_ST : -1, project ? 1 : 0););
+    }
     if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
     bool done = false;
     int next_poll = 2;
-    constexpr int BICG_RESTART = 200;
+    const int BICG_RESTART = refine ? 100 : 200;
     for (int it = 0; it < max_iterations && !done; ++it) {
         if (it > 0 && it % BICG_RESTART == 0) {
             q.it_base = it;
             hipLaunchKernelGGL(k_mbb_restart, sg, sb, 0, st, q, nsys);
-            MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, 1, project ? A_ST : -1, project ? 1 : 0););
+            if (refine) {
+                hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, 2);
+                MB_DISPATCH(s, hipLaunchKernelGGL(k_mbr_residual<DIMS>, grid, blk, 0, st, s->dev, q, (const double*)s->x64, project ? A_ST : -1, project ? 1 : 0););
+            } else {
+                MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, 1, project ? A_ST : -1, project ? 1 : 0););
+            }
             if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
         }
         const int li = it - q.it_base;
@@ -1017,6 +1073,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             }
         }
     }
+    if (refine) hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, 3);
     return mb_finish(s, nsys, nullptr, max_it);
 }
 
@@ -1402,16 +1459,19 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 const int warm = (ps > 0 || opt->pressure_warm_start) ? 1 : 0;
                 if (ps == 0 && warm)  // start from the pressure field (the previous solve's result, or a restored state)
                     hipLaunchKernelGGL(k_mb_copy, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B), blk, 0, st, (size_t)N, dt_B, s->pressure, s->pres);
-                auto solve = [&](int use_x0) {
-                    return opt->pressure_use_bicgstab
+                auto solve = [&](int use_x0, int force_cg = 0) {
+                    return (opt->pressure_use_bicgstab && !force_cg)
                                ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations,
-                                             use_x0, &m, st, opt->pressure_project_mean)
+                                             use_x0, &m, st, opt->pressure_project_mean, opt->pressure_use_bicgstab == 2)
                                : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, use_x0,
                                        opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
                 };
                 int prc = solve(warm);
                 // a warm-started solve that ends unconverged falls back to the reference's start from zero
                 if (prc == FG_ERR_NOT_CONVERGED && ps == 0 && warm) prc = solve(0);
+                // BiCGStab keeps no best iterate: a solve of it that broke down or ran out of iterations is repeated with CG,
+                // which hands back its best iterate (the reference's chain runs the other way round, PISOtorch_diff.py:266-371)
+                if (opt->pressure_use_bicgstab && (prc == FG_ERR_NOT_FINITE || prc == FG_ERR_NOT_CONVERGED)) prc = solve(0, 1);
                 if (prc == FG_ERR_NOT_FINITE) fg_set_error("fg_mb_piso_step: the pressure solve produced a non-finite residual");
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) its[2 + c] = std::max(its[2 + c], m);
@@ -1575,7 +1635,7 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
             int m = 0;
             const int prc = opt->pressure_use_bicgstab
                                 ? mb_bicgstab(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st,
-                                              opt->pressure_project_mean)
+                                              opt->pressure_project_mean, opt->pressure_use_bicgstab == 2)
                                 : mb_cg(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, ps > 0,
                                         opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
             if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;

@@ -7,10 +7,11 @@ advection and four pressure iterations, tolerances 1e-6 / 1e-7), convective outf
 sensors in the wake and under the section with those inside the section dropped (:559-660), drag / lift by wall-stress
 integration over the front / top / bottom faces (:334-461), reward = lift / drag - reference (:744-776).
 
-STATUS: experimental.  Mesh, mask, sensors and jet ranges are pinned on the reference; the env contract, actuation, flux
-balancing, forces and observations run and are tested; but on this mesh the pressure solves stop at a residual floor of
-2-4e-5 (tolerance 1e-7), so the flow that develops depends on where the solves are cut (``stall_limit``) and the
-forces are NOT validated.
+Pressure solver: the reference asks for CG and relies on its fallback chain (fp64, then preconditioned BiCGStab,
+``solver_double_fallback`` / ``BiCG_precondition_fallback``, :313-315) -- on this mesh the pressure matrix is 3.7 % non-symmetric
+and CG stagnates at 2-4e-5 against the tolerance of 1e-7.  The default here is the path's BiCGStab with fp64 iterative
+refinement (``pressure_use_BiCG=2``, DESIGN.md 4b), which reaches the tolerance in ~30 iterations per warm-started solve;
+``pressure_use_BiCG=False`` selects the stagnating CG (with ``stall_limit`` deciding where its solves are cut).
 
 Batched over ``num_envs`` like every env here.  Not carried over: the published initial domains / statistics (no network:
 ``reset`` develops the flow from a projected uniform stream), ``AirfoilEnv3D``.  The section is the closed-form NACA 0012
@@ -81,7 +82,7 @@ class AirfoilEnvBase(CylinderEnvBase):
     def __init__(self, ndims: int, reynolds_number: float, adaptive_cfl: float, step_length: float, episode_length: int,
                  dt: float, attack_angle_deg: float, initial_domain_steps: Optional[int] = None,
                  lift_drag_reference: float = 0.0, resolution_div: int = 1, surface: Optional[np.ndarray] = None,
-                 pressure_use_BiCG: bool = False, non_ortho_mode: str = "matrix", stall_limit: int = 400,
+                 pressure_use_BiCG=2, non_ortho_mode: str = "matrix", stall_limit: int = 400,
                  pressure_deflation: bool = False, debug: bool = False, **kw):
         if attack_angle_deg < 0.0 or attack_angle_deg > 20.0:
             raise ValueError("Attack angle must be between 0 and 20 degrees.")

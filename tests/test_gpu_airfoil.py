@@ -71,7 +71,19 @@ def test_sensor_gather_equals_masked_resampling_and_state_roundtrip():
     r1 = env.step(a)
     env.set_state(s0)
     r2 = env.step(a)
-    # the pressure solves end at their residual floor on this mesh (module docstring of envs/airfoil.py), so a replay
-    # from the same state agrees in the forces only to a few per cent
-    assert torch.allclose(r1[4]["drag"], r2[4]["drag"], rtol=0.1) and torch.allclose(r1[4]["lift"], r2[4]["lift"], rtol=0.1, atol=0.02)
+    # six steps after the impulsive start the forces still change by tens of per cent per step; a replay from the saved
+    # state (whose solver warm-start buffers are not part of the state) agrees to a per cent
+    assert torch.allclose(r1[4]["drag"], r2[4]["drag"], rtol=3e-2) and torch.allclose(r1[4]["lift"], r2[4]["lift"], rtol=3e-2, atol=1e-3)
+    env.close()
+
+
+def test_pressure_solves_reach_the_reference_tolerance_and_envs_stay_identical():
+    """With the refined BiCGStab every pressure solve of a step converges to 1e-7 (CG stagnates at 2-4e-5 on this mesh),
+    so identical envs stay identical and the forces do not depend on where a solve is cut."""
+    env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=2, **dict(KW, initial_domain_steps=12))
+    env.reset(seed=3)
+    obs, reward, _, _, info = env.step(torch.zeros(2, 3, device="cuda"))
+    assert max(env._sim.last_iterations) < 400
+    assert torch.allclose(info["drag"][0], info["drag"][1], rtol=1e-2) and torch.allclose(info["lift"][0], info["lift"][1], rtol=1e-2)
+    assert 0.1 < float(info["drag"][0]) < 2.0 and 0.2 < float(info["lift"][0]) < 2.0
     env.close()
