@@ -79,11 +79,10 @@ def _register_all():
     af2 = _lazy(".envs.airfoil", "AirfoilEnv2D")
     for level, re in (("easy", 1e3), ("medium", 3e3), ("hard", 5e3)):                     # fluidgym/__init__.py:307-328
         register(f"Airfoil2D-{level}-v0", af2, AF2, reynolds_number=re)
-    for fam, ids in {
-        "Airfoil": ["Airfoil3D-easy-v0", "Airfoil3D-medium-v0", "Airfoil3D-hard-v0"],
-    }.items():
-        for i in ids:
-            register(i, _not_built(fam), {})
+    from .envs.airfoil import AIRFOIL_3D_DEFAULT_CONFIG as AF3
+    af3 = _lazy(".envs.airfoil", "AirfoilEnv3D")
+    for level, re in (("easy", 1e3), ("medium", 3e3), ("hard", 5e3)):                     # fluidgym/__init__.py:333-352
+        register(f"Airfoil3D-{level}-v0", af3, AF3, reynolds_number=re)
 
 
 _register_all()

@@ -183,8 +183,11 @@ def extrude_mesh(mesh: CylinderMesh, res_z: int, z0: float = -2.0, z1: float = 2
     for b1, f1, b2, f2, ax in mesh.connections:
         # 2-D: the one remaining axis; 3-D: the axes after the face axis in cyclic order -- z first if the face is a y face
         conns.append((b1, f1, b2, f2, "-z", ax) if f1[1] == "y" else (b1, f1, b2, f2, ax, "-z"))
-    return CylinderMesh(coords, list(mesh.names), fixed, conns, mesh.outflow, list(mesh.cylinder_faces), dims=3,
-                        periodic=[(b, "z") for b in range(len(coords))])
+    out = CylinderMesh(coords, list(mesh.names), fixed, conns, mesh.outflow, list(mesh.cylinder_faces), dims=3,
+                       periodic=[(b, "z") for b in range(len(coords))])
+    if hasattr(mesh, "outflows"):
+        out.outflows = list(mesh.outflows)
+    return out
 
 
 def build_domain(mesh: CylinderMesh, viscosity: float, batch: int = 1, device=None, reference_quirks: bool = True,

@@ -95,6 +95,22 @@ def main():
         out[f"{tag}_mask_rows"] = np.packbits(me._airfoil_mask, axis=1)          # [150, 75] bits of the [150, 600] mask
         out[f"{tag}_sensor_pixels"] = me._get_sensor_locations().numpy()
         print(tag, "mask pixels", int(me._airfoil_mask.sum()), "sensors", out[f"{tag}_sensor_pixels"].shape)
+    # 3-D env: sensor pixels (x, y, z) on the n_agents * n_sensors_per_agent spanwise planes (airfoil_env_3d.py:303-344)
+    with open(f"{REF}/fluidgym/envs/airfoil/airfoil_env_3d.py") as fh:
+        tree3 = ast.parse(fh.read())
+    cls3 = next(n for n in tree3.body if isinstance(n, ast.ClassDef) and n.name == "AirfoilEnv3D")
+    fns3 = [n for n in cls3.body if isinstance(n, ast.FunctionDef) and n.name in {"_get_sensor_locations", "_get_sensor_locations_3d"}]
+    ns3 = {"torch": torch, "np": np}
+    exec(compile(ast.Module(fns3, []), "airfoil_env_3d.py", "exec"), ns3)
+    me = types.SimpleNamespace(H=1.4, L=4.5, D=1.4, airfoil_length=1.0, _ndims=3, render_shape=(600, 150, 150), _n_sensors_z=4)
+    _, c = grid.read_airfoil(attack_angle_deg=10.0, cpu_device=torch.device("cpu"), dtype=torch.float32)
+    me._airfoil_coords = c.squeeze()
+    for k in ("_get_airfoil_mask", "_physical_locations_to_grid_coords", "_get_sensor_locations_2d"):
+        setattr(me, k, types.MethodType(ns[k], me))
+    me._airfoil_mask = me._get_airfoil_mask()          # [150, 150, 600] in 3-D
+    me._get_sensor_locations_3d = types.MethodType(ns3["_get_sensor_locations_3d"], me)
+    out["aoa10_3d_sensor_pixels"] = ns3["_get_sensor_locations"](me).numpy()
+    print("3d sensors", out["aoa10_3d_sensor_pixels"].shape)
     for aoa in (20.0, 0.0):
         tag = f"aoa{int(aoa)}"
         coords = [torch.from_numpy(out[f"{tag}_block{b}"])[None] for b in range(6)]

@@ -102,5 +102,31 @@ def test_airfoil_registry_and_argument_checks():
         assert abs(env._nu - 0.3 / re) < 1e-12
     with pytest.raises(ValueError, match="between 0 and 20"):
         fluidgym_amd.make("Airfoil2D-easy-v0", cuda_device=torch.device("cpu"), attack_angle_deg=25.0)
-    with pytest.raises(NotImplementedError):
-        fluidgym_amd.make("Airfoil3D-easy-v0")
+    e3 = fluidgym_amd.make("Airfoil3D-hard-v0", cuda_device=torch.device("cpu"))
+    assert (e3._reynolds_number, e3._ndims, e3._res_z, e3.n_agents) == (5e3, 3, 96, 1)
+    assert e3.action_space.shape == (4, 3) and e3.observation_space["velocity"].shape == (4, 1, 3, 209)
+    m3 = fluidgym_amd.make("Airfoil3D-easy-v0", cuda_device=torch.device("cpu"), use_marl=True, local_obs_window=3)
+    assert m3.n_agents == 4 and m3.action_space.shape == (3,) and m3.observation_space["pressure"].shape == (3, 1, 209)
+    with pytest.raises(ValueError, match="evenly divides"):
+        fluidgym_amd.make("Airfoil3D-easy-v0", cuda_device=torch.device("cpu"), n_agents=5)
+
+
+def test_3d_sensor_pixels_match_reference():
+    import torch
+    import fluidgym_amd
+
+    env = fluidgym_amd.make("Airfoil3D-easy-v0", cuda_device=torch.device("cpu"), surface=_surface("aoa0", 0.0))
+    assert np.array_equal(env._sensor_locations, G["aoa10_3d_sensor_pixels"])
+    own = fluidgym_amd.make("Airfoil3D-easy-v0", cuda_device=torch.device("cpu"))
+    assert np.array_equal(own._sensor_locations, G["aoa10_3d_sensor_pixels"])
+
+
+def test_extruded_airfoil_mesh_connections_follow_the_reference_calls():
+    """grid.py:690-706: x faces connect with (in-plane axis, -z), y faces with (-z, in-plane axis); all blocks z-periodic."""
+    from fluidgym_amd.envs.cylinder_grid import extrude_mesh
+
+    m = extrude_mesh(make_airfoil_mesh(resolution_div=4), 4, -0.7, 0.7)
+    assert m.connections == [(0, "+x", 1, "-x", "-y", "-z"), (1, "+y", 2, "-x", "-z", "+y"), (1, "-y", 3, "-x", "-z", "-y"),
+                             (2, "+x", 4, "-x", "-y", "-z"), (3, "+x", 5, "-x", "-y", "-z"), (4, "-y", 5, "+y", "-z", "-x")]
+    assert m.periodic == [(b, "z") for b in range(6)] and m.outflows == [(4, "+x"), (5, "+x")]
+    assert m.coords[2].shape[1] == 5 and np.allclose(m.coords[2][2, 0], -0.7) and np.allclose(m.coords[2][2, -1], 0.7)

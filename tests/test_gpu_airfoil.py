@@ -87,3 +87,43 @@ def test_pressure_solves_reach_the_reference_tolerance_and_envs_stay_identical()
     assert torch.allclose(info["drag"][0], info["drag"][1], rtol=1e-2) and torch.allclose(info["lift"][0], info["lift"][1], rtol=1e-2)
     assert 0.1 < float(info["drag"][0]) < 2.0 and 0.2 < float(info["lift"][0]) < 2.0
     env.close()
+
+
+KW3 = dict(initial_domain_steps=4, randomize_initial_state=False, episode_length=2, resolution_div=4, res_z=8, n_agents=4)
+
+
+def test_3d_env_single_and_multi_agent():
+    env = fluidgym_amd.make("Airfoil3D-easy-v0", num_envs=2, **KW3)
+    obs, _ = env.reset(seed=0)
+    n = env._sensor_locations.shape[-1]
+    assert obs["velocity"].shape == (2, 4, 1, 3, n) and obs["pressure"].shape == (2, 4, 1, n)
+    # started from the 2-D development extruded over the span: still uniform along z, no spanwise velocity
+    for blk in env._domain.blocks:
+        u = blk.cells(env._domain.velocity)[0]
+        assert float((u - u[:, :1]).abs().max()) < 5e-3 and float(u[2].abs().max()) < 5e-3
+    a = env.sample_action()
+    assert a.shape == (2, 4, 3)
+    obs, reward, term, trunc, info = env.step(a)
+    assert reward.shape == (2,) and torch.isfinite(reward).all()
+    assert set(info) == {"drag", "lift", "all_cds", "all_cls"} and info["all_cds"].shape == (2, 8)
+    assert torch.allclose(info["all_cds"].sum(-1) / env.D, info["drag"], rtol=1e-5) and (info["drag"] > 0).all()
+    assert torch.allclose(reward, info["lift"] / info["drag"], rtol=1e-5)
+    assert np.abs(env._domain.boundary_flux_balance()).max() < 1e-5
+    full = env.get_velocity()
+    assert full.shape == (2, 3, 150, 150, 600)
+    px = env._sensor_locations.reshape(3, -1)
+    u = (env._domain.velocity[:, :, env._sensor_idx] * env._sensor_w).sum(-1)
+    assert torch.allclose(full[:, :, px[2], px[1], px[0]], u, atol=1e-5)
+    env.close()
+
+    menv = fluidgym_amd.make("Airfoil3D-easy-v0", num_envs=1, use_marl=True, local_obs_window=3, **KW3)
+    obs, _ = menv.reset(seed=1)
+    assert obs["velocity"].shape == (1, 4, 3, 1, 3, n)
+    act = torch.zeros(1, 4, 3, device="cuda")
+    act[0, 0] = torch.tensor([1.0, 0.0, -1.0])
+    obs, reward, _, _, info = menv.step(act)
+    assert reward.shape == (1, 4) and set(info) == {"drag", "lift", "global_reward"} and torch.isfinite(reward).all()
+    # only agent 0 blows: its spanwise layers carry wall velocity, the others none
+    wall = menv._domain.blocks[2].boundary("-y").reshape(1, 3, 8, -1)
+    assert float(wall[0, :, :2].abs().max()) > 1e-3 and float(wall[0, :, 2:].abs().max()) < 1e-6
+    menv.close()
