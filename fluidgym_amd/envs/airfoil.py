@@ -14,7 +14,7 @@ refinement (``pressure_use_BiCG=2``), which reaches the tolerance 
 ``pressure_use_BiCG=False`` selects the stagnating CG (with ``stall_limit`` deciding where its solves are cut).
 
 Batched over ``num_envs`` like every env here.  Not carried over: the published initial domains / statistics (no network:
-``reset`` develops the flow from a projected uniform stream), ``AirfoilEnv3D``.  The section is the closed-form NACA 0012
+``reset`` develops the flow from a projected uniform stream).  The section is the closed-form NACA 0012
 (``airfoil_grid.naca0012_sharp``) unless a ``surface`` polyline is given; states saved by the reference carry their mesh.
 """
 from __future__ import annotations
