@@ -82,8 +82,11 @@ def test_registry_semantics():
     ids = fluidgym_amd.registry.ids
     for must in ("RBC2D-easy-v0", "TCFSmall3D-both-easy-v0", "ChannelJet2D-v0"):
         assert must in ids
-    with pytest.raises(NotImplementedError):
-        fluidgym_amd.make("Airfoil3D-easy-v0")
+    # every env id of the reference is registered (fluidgym/__init__.py:28-352)
+    for fam, n in (("CylinderJet2D", 3), ("CylinderRot2D", 3), ("CylinderJet3D", 3), ("Airfoil2D", 3), ("Airfoil3D", 3), ("TCF", 12)):
+        assert sum(i.startswith(fam) and "baseline" not in i for i in ids) == n, fam
+    a3 = fluidgym_amd.make("Airfoil3D-easy-v0", cuda_device=torch.device("cpu"))
+    assert a3._ndims == 3 and a3.action_space.shape == (4, 3)
     cyl = fluidgym_amd.make("CylinderJet2D-medium-v0", cuda_device=torch.device("cpu"))  # construction touches no GPU
     assert (cyl._reynolds_number, cyl._circle_resolution_angular) == (250, 32)
     assert cyl.render_shape == (686, 128, 128) and cyl._n_sim_steps == 25
