@@ -211,6 +211,37 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
         env.close()
 
 
+def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
+    """The reference's Airfoil2D-easy-v0 (six-block C-mesh around a NACA 0012 at 10 degrees, 46.7 k cells, Re 1000, 5 PISO
+    steps per env step) on the multi-block path, batched; the pressure systems are solved by the fp64-refined BiCGStab
+    (DESIGN.md 4b).  Reported next to the headline like the cylinder leg."""
+    import torch
+
+    import fluidgym_amd
+
+    env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=num_envs, initial_domain_steps=develop,
+                            randomize_initial_state=False, cuda_device=device)
+    try:
+        env.reset(seed=0)
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        act = lambda: (torch.rand((num_envs, 3), generator=gen) * 2 - 1).to(device)
+        env.step(act())
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, _, _, _, info = env.step(act())
+        torch.cuda.synchronize(device)
+        el = (time.perf_counter() - t0) / steps
+        return {"env_id": "Airfoil2D-easy-v0", "envs": num_envs, "cells_per_env": env._domain.n_cells,
+                "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
+                "pressure_solver": "BiCGStab (fp32, mean-projected) with fp64 iterative refinement, tolerance 1e-7",
+                "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
+                "drag_lift_env0": [float(info["drag"][0]), float(info["lift"][0])],
+                "note": f"state {develop} uncontrolled sim steps after an impulsive start; uniform random jets in [-1, 1]"}
+    finally:
+        env.close()
+
+
 def cpu_baseline(budget_s=20.0):
     """Oracle (NumPy/SciPy port of the reference algorithm) on one env of the bench workload."""
     import numpy as np
@@ -334,6 +365,10 @@ def main():
                 out["cylinder_env"] = cylinder_env_leg(device)
             except Exception as exc:  # the headline line must survive a failure of the extra leg
                 out["cylinder_env"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            try:
+                out["airfoil_env"] = airfoil_env_leg(device)
+            except Exception as exc:
+                out["airfoil_env"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
