@@ -200,3 +200,16 @@ def test_3d_env_multi_agent_rewards_and_windows():
     local = (reward - (1 - w) * info["global_reward"]) / w
     assert local.shape == (4,)
     env.close()
+
+
+def test_refined_bicgstab_gives_the_same_wake_as_cg():
+    """The reference's solver for this env is CG (hovering at its tolerance on the non-symmetric matrix, best iterate
+    returned); BiCGStab with fp64 refinement converges.  Both give the same developing flow."""
+    cds = []
+    for mode in (False, 2):
+        env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=1, **dict(KW, initial_domain_steps=40, pressure_use_BiCG=mode))
+        env.reset(seed=5)
+        _, _, _, _, info = env.step(torch.zeros(1, 1, device="cuda"))
+        cds.append(float(info["drag"][0]))
+        env.close()
+    assert abs(cds[0] - cds[1]) < 0.03 * abs(cds[0]), cds

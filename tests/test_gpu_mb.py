@@ -76,7 +76,14 @@ def _assembly_parity(dom, d, states, dt, B, check_div):
                                                       # mean projection is an exact no-op on orthogonal meshes, for CG and BiCGStab
                                                       (H.polar_ring, False, 2e-6, True), (H.polar_ring, True, 2e-6, True),
                                                       (H.split_rotated_channel, True, 2e-6, True),
-                                                      (H.odd_channel, False, 2e-6, False), (H.odd_channel, False, 2e-6, True)])
+                                                      (H.odd_channel, False, 2e-6, False), (H.odd_channel, False, 2e-6, True),
+                                                      # BiCGStab with fp64 iterative refinement (pressure_use_bicgstab = 2): tighter
+                                                      # tolerance than fp32 residuals allow, on meshes where CG stalls
+                                                      # (unprojected like the oracle's direct solve: on these meshes the constant is
+                                                      # not a null vector of the matrix, so the mean projection the envs use changes
+                                                      # the system)
+                                                      (H.skewed_pair, 2, 2e-7, False), (H.skewed_pair_3d, 2, 2e-7, False),
+                                                      (H.polar_ring, 2, 2e-7, True)])
 def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     """Whole step against the oracle's direct solves.  The pressure solver is CG as in the reference where the mesh is
     orthogonal (symmetric matrix); with strong cross metrics the matrix is not symmetric, CG stalls (there as here, see
