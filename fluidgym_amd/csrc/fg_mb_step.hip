@@ -604,6 +604,166 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
 }
 
+// ---- the same five kernels with four consecutive cells per thread (N % 4 == 0): 128-bit loads / stores of the cell's own
+// data, the -x / +x neighbours of the stencil from the thread's own cells or a lane shuffle (as in k_mbc_ap4).  At
+// 16 envs x 46.7 k cells the one-cell kernels took 51 us per iteration, 2-3x what their bytes need.
+#define MB_SYS4                                                   \
+    const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;      \
+    const int sys = blockIdx.y;                                   \
+    const int b = sys / q.nc;                                     \
+    const int N = D.N;                                            \
+    const bool valid = i < N;                                     \
+    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);    \
+    const size_t vb = (size_t)sys * N;                            \
+    double* a = q.acc + (size_t)sys * MB_ACC;                     \
+    __shared__ float lds[4];                                      \
+    (void)b; (void)leader; (void)a; (void)lds; (void)valid;
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+template <int DIMS>
+__device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b, const float* __restrict__ x, int i, float y[4]) {
+    constexpr int F = 2 * DIMS;
+    const int N = D.N;
+    const float4 x4 = ld4(x + i), d4 = ld4(q.diag + (size_t)b * N + i);
+    const float xi[4] = {x4.x, x4.y, x4.z, x4.w};
+    y[0] = d4.x * xi[0]; y[1] = d4.y * xi[1]; y[2] = d4.z * xi[2]; y[3] = d4.w * xi[3];
+    const int lane = threadIdx.x & 63;
+    const float from_prev = __shfl_up(xi[3], 1), from_next = __shfl_down(xi[0], 1);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int4 n4 = *reinterpret_cast<const int4*>(D.nbr + (size_t)f * N + i);
+        const float4 o4 = ld4(q.off + ((size_t)b * F + f) * N + i);
+        const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
+        const float oo[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
+            float xn;
+            if (f == 0 && n == i + e - 1 && (e > 0 || lane > 0)) xn = e > 0 ? xi[e > 0 ? e - 1 : 0] : from_prev;
+            else if (f == 1 && n == i + e + 1 && (e < 3 || lane < 63)) xn = e < 3 ? xi[e < 3 ? e + 1 : 3] : from_next;
+            else xn = x[n];
+            y[e] += oo[e] * xn;
+        }
+    }
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_p4(MbDev D, MbSolve q, int it) {
+    MB_SYS4
+    const int f = q.flags[sys];
+    if (f == 4) { if (leader) q.flags[sys] = 1; return; }
+    if (f != 0) return;
+    const float crit = mb_rms(a[A_RR], N);
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
+    if (leader) {
+        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0; a[A_ST] = 0.0;
+        q.info[sys].final_residual = crit;
+        q.info[sys].used_iterations = it + q.it_base - 1;
+    }
+    if (it == 0 || !valid) return;
+    const float alpha = q.sc[sys * 2], omega = q.sc[sys * 2 + 1];
+    const float beta = (float)(a[A_RHO + (it & 1)] / a[A_RHO + ((it + 1) & 1)]) * (alpha / omega);
+    const float mv = q.project ? (float)(a[A_SV + 2 * ((it + 1) & 1)] / (double)N) : 0.f;
+    const float4 r = ld4(q.r + vb + i), p = ld4(q.p + vb + i), v = ld4(q.v + vb + i);
+    st4(q.p + vb + i, r.x + beta * (p.x - omega * (v.x - mv)), r.y + beta * (p.y - omega * (v.y - mv)),
+        r.z + beta * (p.z - omega * (v.z - mv)), r.w + beta * (p.w - omega * (v.w - mv)));
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_v4(MbDev D, MbSolve q, int it) {
+    MB_SYS4
+    if (q.flags[sys] != 0) return;
+    float part = 0.f, psum = 0.f;
+    if (valid) {
+        float y[4];
+        mb_spmv4<DIMS>(D, q, b, q.p + vb, i, y);
+        st4(q.v + vb + i, y[0], y[1], y[2], y[3]);
+        const float4 w = ld4(q.rw + vb + i);
+        part = w.x * y[0] + w.y * y[1] + w.z * y[2] + w.w * y[3];
+        psum = y[0] + y[1] + y[2] + y[3];
+    }
+    part = mb_block_sum(part, lds);
+    if (q.project) psum = mb_block_sum(psum, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_RV, (double)part);
+        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+    }
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_s4(MbDev D, MbSolve q, int it) {
+    MB_SYS4
+    if (q.flags[sys] != 0) return;
+    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_RV]);
+    if (leader) { q.sc[sys * 2] = alpha; a[A_RHO + ((it + 1) & 1)] = 0.0; a[A_RR] = 0.0; a[A_SV + 2 * ((it + 1) & 1)] = 0.0; }
+    const float mv = q.project ? (float)(a[A_SV + 2 * (it & 1)] / (double)N) : 0.f;
+    float part = 0.f;
+    if (valid) {
+        const float4 r = ld4(q.r + vb + i), v = ld4(q.v + vb + i);
+        const float s0 = r.x - alpha * (v.x - mv), s1 = r.y - alpha * (v.y - mv), s2 = r.z - alpha * (v.z - mv), s3 = r.w - alpha * (v.w - mv);
+        st4(q.r + vb + i, s0, s1, s2, s3);
+        part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
+    }
+    part = mb_block_sum(part, lds);
+    if (threadIdx.x == 0) atomicAdd(a + A_SS, (double)part);
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it) {
+    MB_SYS4
+    if (q.flags[sys] != 0) return;
+    const float crit_s = mb_rms(a[A_SS], N);
+    if (!(crit_s >= q.tol)) {
+        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) q.flags[sys] = 4; }
+        return;
+    }
+    float pt = 0.f, ptt = 0.f, pst = 0.f;
+    if (valid) {
+        float t[4];
+        mb_spmv4<DIMS>(D, q, b, q.r + vb, i, t);
+        st4(q.t + vb + i, t[0], t[1], t[2], t[3]);
+        const float4 sv = ld4(q.r + vb + i);
+        pt = t[0] * sv.x + t[1] * sv.y + t[2] * sv.z + t[3] * sv.w;
+        ptt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+        pst = t[0] + t[1] + t[2] + t[3];
+    }
+    pt = mb_block_sum(pt, lds);
+    ptt = mb_block_sum(ptt, lds);
+    if (q.project) pst = mb_block_sum(pst, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_TS, (double)pt);
+        atomicAdd(a + A_TT, (double)ptt);
+        if (q.project) atomicAdd(a + A_ST, (double)pst);
+    }
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it) {
+    MB_SYS4
+    const int f = q.flags[sys];
+    if (f != 0 && f != 4) return;
+    const float alpha = q.sc[sys * 2];
+    const bool half = (f == 4);
+    const double st = q.project ? a[A_ST] : 0.0;
+    const float mt = (float)(st / (double)N);
+    const float omega = half ? 0.f : (float)(a[A_TS] / (a[A_TT] - st * st / (double)N));
+    if (leader) { q.sc[sys * 2 + 1] = omega; a[A_RV] = 0.0; }
+    float prr = 0.f, prho = 0.f;
+    if (valid) {
+        const float4 x = ld4(q.x + vb + i), p = ld4(q.p + vb + i);
+        if (half) {
+            st4(q.x + vb + i, x.x + alpha * p.x, x.y + alpha * p.y, x.z + alpha * p.z, x.w + alpha * p.w);
+        } else {
+            const float4 sv = ld4(q.r + vb + i), t = ld4(q.t + vb + i), w = ld4(q.rw + vb + i);
+            st4(q.x + vb + i, x.x + alpha * p.x + omega * sv.x, x.y + alpha * p.y + omega * sv.y, x.z + alpha * p.z + omega * sv.z,
+                x.w + alpha * p.w + omega * sv.w);
+            const float r0 = sv.x - omega * (t.x - mt), r1 = sv.y - omega * (t.y - mt), r2 = sv.z - omega * (t.z - mt), r3 = sv.w - omega * (t.w - mt);
+            st4(q.r + vb + i, r0, r1, r2, r3);
+            prr = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+            prho = w.x * r0 + w.y * r1 + w.z * r2 + w.w * r3;
+        }
+    }
+    if (half) return;
+    prr = mb_block_sum(prr, lds);
+    prho = mb_block_sum(prho, lds);
+    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
+}
+
 // ---- CG (cgSolveGPU recurrence, cg_solver_kernel.cu:129-471) in two kernels per iteration.  The search direction is
 // never read back through a third pass: k_mbc_ap forms p_it = r_it + beta p_{it-1} for the cell AND for its neighbours
 // on the fly (p ping-pongs between two buffers so that the neighbours' old values are still there), which removes one
@@ -1030,6 +1190,9 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     q.project = project ? 1 : 0;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     refine = refine && nc == 1;
+    const char* scalar_env = getenv("FG_MB_SCALAR_CG");   // "1" forces the one-cell-per-thread kernels (debugging)
+    const bool vec4 = (n % 4 == 0) && !(scalar_env && scalar_env[0] == '1');
+    const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     if (refine && !s->x64) { if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc; }
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
     if (refine) {
@@ -1055,13 +1218,23 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
         }
         const int li = it - q.it_base;
-        MB_DISPATCH(s, {
-            hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
-        });
+        if (vec4) {
+            MB_DISPATCH(s, {
+                hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
+            });
+        } else {
+            MB_DISPATCH(s, {
+                hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            });
+        }
         if (it + 1 >= next_poll || it + 1 == max_iterations) {
             next_poll = it + 1 + (it < 20 ? 2 : 10);   // long (pressure) solves: fewer host round trips
             hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
