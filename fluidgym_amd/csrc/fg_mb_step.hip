@@ -1190,8 +1190,15 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     q.project = project ? 1 : 0;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     refine = refine && nc == 1;
-    const char* scalar_env = getenv("FG_MB_SCALAR_CG");   // "1" forces the one-cell-per-thread kernels (debugging)
-    const bool vec4 = (n % 4 == 0) && !(scalar_env && scalar_env[0] == '1');
+    // a refined solve that has not converged after 1500 iterations is not going to: hand over to the caller's CG fallback
+    // instead of spending the reference's 5000 (one hard env would stall the whole batch)
+    if (refine && max_iterations > 1500) max_iterations = 1500;
+    // The four-cells-per-thread BiCGStab kernels (k_mbb_*4) run the airfoil env 1.5x faster but are OFF by default: with them
+    // batches of 16 airfoil envs end in a non-finite or non-converging solve in about one run out of three, with the
+    // one-cell kernels in none (same seeds, so a race or an uninitialised lane that has not been found yet).
+    // FG_MB_BICG_VEC4=1 enables them.
+    const char* vec_env = getenv("FG_MB_BICG_VEC4");
+    const bool vec4 = (n % 4 == 0) && vec_env && vec_env[0] == '1';
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     if (refine && !s->x64) { if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc; }
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
