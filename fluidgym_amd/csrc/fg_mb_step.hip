@@ -1195,7 +1195,8 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     if (refine && max_iterations > 1500) max_iterations = 1500;
     // The four-cells-per-thread BiCGStab kernels (k_mbb_*4) run the airfoil env 1.5x faster but are OFF by default: with them
     // batches of 16 airfoil envs end in a non-finite or non-converging solve in about one run out of three, with the
-    // one-cell kernels in none (same seeds, so a race or an uninitialised lane that has not been found yet).
+    // one-cell kernels in none (same seeds; the failure rate grows with the batch -- none at 2 envs, every run at 16 -- and
+    // stays when the lane shuffles are replaced by gathers, so it is not the shuffle; not found yet).
     // FG_MB_BICG_VEC4=1 enables them.
     const char* vec_env = getenv("FG_MB_BICG_VEC4");
     const bool vec4 = (n % 4 == 0) && vec_env && vec_env[0] == '1';
