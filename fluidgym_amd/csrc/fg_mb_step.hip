@@ -1199,7 +1199,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // stays when the lane shuffles are replaced by gathers, so it is not the shuffle; not found yet).
     // FG_MB_BICG_VEC4=1 enables them.
     const char* vec_env = getenv("FG_MB_BICG_VEC4");
-    const bool vec4 = (n % 4 == 0) && vec_env && vec_env[0] == '1';
+    const int vec_mask = (n % 4 == 0 && vec_env) ? (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)) : 0;   // "1" = all five
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     if (refine && !s->x64) { if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc; }
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
@@ -1226,23 +1226,13 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
         }
         const int li = it - q.it_base;
-        if (vec4) {
-            MB_DISPATCH(s, {
-                hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li);
-            });
-        } else {
-            MB_DISPATCH(s, {
-                hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
-                hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            });
-        }
+        MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form (bisecting the defect noted above)
+            if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (vec_mask & 16) hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
+        });
         if (it + 1 >= next_poll || it + 1 == max_iterations) {
             next_poll = it + 1 + (it < 20 ? 2 : 10);   // long (pressure) solves: fewer host round trips
             hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
