@@ -1196,7 +1196,11 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // The four-cells-per-thread BiCGStab kernels (k_mbb_*4) run the airfoil env 1.5x faster but are OFF by default: with them
     // batches of 16 airfoil envs end in a non-finite or non-converging solve in about one run out of three, with the
     // one-cell kernels in none (same seeds; the failure rate grows with the batch -- none at 2 envs, every run at 16 -- and
-    // stays when the lane shuffles are replaced by gathers, so it is not the shuffle; not found yet).
+    // stays when the lane shuffles are replaced by gathers, so it is not the shuffle.  Bisecting with the per-kernel mask
+    // below: each of p4 / v4 / s4 / x4 alone reproduces it, t4 alone does not, and the residual history of the first
+    // pressure solve is bit-identical to the one-cell kernels' for its first 50 iterations -- so the four-cell arithmetic
+    // is right and what breaks is elsewhere (the velocity solves with two systems per env, or an ordering assumption that
+    // the launch geometry changes).  Not found yet.)
     // FG_MB_BICG_VEC4=1 enables them.
     const char* vec_env = getenv("FG_MB_BICG_VEC4");
     const int vec_mask = (n % 4 == 0 && vec_env) ? (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)) : 0;   // "1" = all five
