@@ -1203,7 +1203,8 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // the launch geometry changes).  Not found yet.)
     // FG_MB_BICG_VEC4=1 enables them.
     const char* vec_env = getenv("FG_MB_BICG_VEC4");
-    const int vec_mask = (n % 4 == 0 && vec_env) ? (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)) : 0;   // "1" = all five
+    int vec_mask = (n % 4 == 0 && vec_env) ? (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)) : 0;   // "1" = all five
+    if (vec_mask >= 64) vec_mask = (nc == 1) ? (vec_mask & 31) : 0;   // + 64: pressure solves only (one system per env)
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     if (refine && !s->x64) { if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc; }
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
