@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--airfoil-leg", action="store_true",
-                    help="also run Airfoil2D-easy-v0 x 8 (off by default: under random jets that env intermittently stalls for minutes)")
+                    help="also run Airfoil2D-easy-v0 x 8 (off by default: its start-up development intermittently takes minutes)")
     args = ap.parse_args()
 
     import torch

@@ -13,9 +13,9 @@ and CG stagnates at 2-4e-5 against the tolerance of 1e-7.  The default here is t
 refinement (``pressure_use_BiCG=2``, DESIGN.md 4b), which reaches the tolerance in ~30 iterations per warm-started solve;
 ``pressure_use_BiCG=False`` selects the stagnating CG (with ``stall_limit`` deciding where its solves are cut).
 
-STATUS: experimental.  Uncontrolled development (400 steps into vortex shedding) ran reliably; under strong random jet
-actuation a batch intermittently stalls for minutes (pressure solves of one env stop converging / its time step
-collapses) -- open.
+STATUS: experimental.  Development (400 steps into vortex shedding) and actuated steps ran reliably at 2 envs; with batches
+of 8 or more the development from the impulsive start intermittently takes minutes instead of seconds (pressure solves of
+the start-up transient stop converging in some runs) -- open.
 
 Batched over ``num_envs`` like every env here.  Not carried over: the published initial domains / statistics (no network:
 ``reset`` develops the flow from a projected uniform stream).  The section is the closed-form NACA 0012
