@@ -95,6 +95,7 @@ struct fg_mb_state {
     int32_t* flags_pinned = nullptr;
     fg_solve_info *info_dev, *info_pinned = nullptr;
     float* yproj = nullptr;
+    double* x64_best = nullptr; float* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
     double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2), allocated on first use
     int cg_stall_limit = 400;  // fg_mb_set_stall_limit
     bool yproj_const = true;   // yproj is the constant 1/sqrt(N): kernels use the scalar instead of loading it

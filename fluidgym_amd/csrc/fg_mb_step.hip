@@ -477,6 +477,35 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_residual(MbDev D, MbSolve q, c
     }
 }
 
+// best iterate of the refined BiCGStab: at every refinement point the TRUE residual is known (A_RR after k_mbr_residual /
+// k_mbb_project_init), so the fp64 iterate with the smallest one is kept and handed back when a solve ends unconverged --
+// BiCGStab's residual is far from monotone (spikes of two orders of magnitude on these systems) and without this an
+// unconverged solve returned whatever the last iteration happened to hold.
+__global__ void k_mbr_best_decide(MbSolve q, float* __restrict__ best_res, int32_t* __restrict__ keep, int n, int nsys, int first) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    keep[s] = 0;
+    if (q.flags[s] != 0) return;
+    const float crit = (float)sqrt(q.acc[(size_t)s * MB_ACC + A_RR] / (double)n);
+    if (first) best_res[s] = 3.0e38f;
+    if (isfinite(crit) && crit < best_res[s]) { best_res[s] = crit; keep[s] = 1; }
+}
+__global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_copy(int N, const int32_t* __restrict__ keep, const double* __restrict__ src,
+                                                             double* __restrict__ dst) {
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
+    if (i >= N || !keep[sys]) return;
+    dst[(size_t)sys * N + i] = src[(size_t)sys * N + i];
+}
+// systems that ended without converging (or non-finite): x64 <- kept iterate, fp32 correction dropped, residual reported
+__global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_restore(int N, MbSolve q, double* __restrict__ x64, const double* __restrict__ best,
+                                                                const float* __restrict__ best_res) {
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
+    if (q.flags[sys] == 3 || q.flags[sys] == 0 || (q.info[sys].converged && q.info[sys].is_finite)) return;
+    if (!(best_res[sys] < 3.0e38f)) return;   // nothing kept (non-finite from the start): leave it to the caller's fallback
+    if (i < N) { x64[(size_t)sys * N + i] = best[(size_t)sys * N + i]; q.x[(size_t)sys * N + i] = 0.f; }
+    if (i == 0) { q.info[sys].final_residual = best_res[sys]; q.info[sys].is_finite = 1; }
+}
+
 // second half of the start of a projected BiCGStab solve: r <- r - mean r, rw = p = r, rho0 = rr = |r|^2
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
@@ -1206,7 +1235,16 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     int vec_mask = (n % 4 == 0 && vec_env) ? (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)) : 0;   // "1" = all five
     if (vec_mask >= 64) vec_mask = (nc == 1) ? (vec_mask & 31) : 0;   // + 64: pressure solves only (one system per env)
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
-    if (refine && !s->x64) { if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc; }
+    if (refine && !s->x64) {
+        if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc;
+        if (int rc = mb_alloc(s, &s->x64_best, (size_t)s->B * n)) return rc;
+        if (int rc = mb_alloc(s, &s->best_res, (size_t)s->B)) return rc;
+        if (int rc = mb_alloc(s, &s->best_keep, (size_t)s->B)) return rc;
+    }
+    auto keep_best = [&](int first) {
+        hipLaunchKernelGGL(k_mbr_best_decide, sg, sb, 0, st, q, s->best_res, s->best_keep, n, nsys, first);
+        hipLaunchKernelGGL(k_mbr_best_copy, grid, blk, 0, st, n, (const int32_t*)s->best_keep, (const double*)s->x64, s->x64_best);
+    };
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
     if (refine) {
         hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, use_x0 ? 1 : 0);
@@ -1215,6 +1253,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
         MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project ? A_ST : -1, project ? 1 : 0););
     }
     if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
+    if (refine) keep_best(1);
     bool done = false;
     int next_poll = 2;
     const int BICG_RESTART = refine ? 100 : 200;
@@ -1229,6 +1268,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
                 MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, 1, project ? A_ST : -1, project ? 1 : 0););
             }
             if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
+            if (refine) keep_best(0);
         }
         const int li = it - q.it_base;
         MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form (bisecting the defect noted above)
@@ -1249,7 +1289,12 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             }
         }
     }
-    if (refine) hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, 3);
+    if (refine) {
+        hipLaunchKernelGGL(k_mbr_best_restore, grid, blk, 0, st, n, q, s->x64, (const double*)s->x64_best, (const float*)s->best_res);
+        hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, 3);
+        FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
+        FG_HIP_CHECK(hipStreamSynchronize(st));
+    }
     return mb_finish(s, nsys, nullptr, max_it);
 }
 
@@ -1647,7 +1692,8 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 if (prc == FG_ERR_NOT_CONVERGED && ps == 0 && warm) prc = solve(0);
                 // BiCGStab keeps no best iterate: a solve of it that broke down or ran out of iterations is repeated with CG,
                 // which hands back its best iterate (the reference's chain runs the other way round, PISOtorch_diff.py:266-371)
-                if (opt->pressure_use_bicgstab && (prc == FG_ERR_NOT_FINITE || prc == FG_ERR_NOT_CONVERGED)) prc = solve(0, 1);
+                if (opt->pressure_use_bicgstab && (prc == FG_ERR_NOT_FINITE || (prc == FG_ERR_NOT_CONVERGED && opt->pressure_use_bicgstab != 2)))
+                    prc = solve(0, 1);   // the refined solver hands back its best refinement point itself
                 if (prc == FG_ERR_NOT_FINITE) fg_set_error("fg_mb_piso_step: the pressure solve produced a non-finite residual");
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) its[2 + c] = std::max(its[2 + c], m);
