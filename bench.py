@@ -211,7 +211,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
         env.close()
 
 
-def airfoil_env_leg(device, num_envs=8, steps=2, develop=40):
+def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
     """The reference's Airfoil2D-easy-v0 (six-block C-mesh around a NACA 0012 at 10 degrees, 46.7 k cells, Re 1000, 5 PISO
     steps per env step) on the multi-block path, batched; the pressure systems are solved by the fp64-refined BiCGStab
     (DESIGN.md 4b).  Reported next to the headline like the cylinder leg."""
@@ -285,8 +285,7 @@ def main():
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
-    ap.add_argument("--airfoil-leg", action="store_true",
-                    help="also run Airfoil2D-easy-v0 x 8 (off by default: its start-up development intermittently takes minutes)")
+    ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 16 leg (about 10 s)")
     args = ap.parse_args()
 
     import torch
@@ -367,7 +366,7 @@ def main():
                 out["cylinder_env"] = cylinder_env_leg(device)
             except Exception as exc:  # the headline line must survive a failure of the extra leg
                 out["cylinder_env"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-            if args.airfoil_leg:
+            if not args.no_airfoil_leg:
                 try:
                     out["airfoil_env"] = airfoil_env_leg(device)
                 except Exception as exc:

@@ -1222,17 +1222,13 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // a refined solve that has not converged after 1500 iterations is not going to: hand over to the caller's CG fallback
     // instead of spending the reference's 5000 (one hard env would stall the whole batch)
     if (refine && max_iterations > 1500) max_iterations = 1500;
-    // The four-cells-per-thread BiCGStab kernels (k_mbb_*4) run the airfoil env 1.5x faster but are OFF by default: with them
-    // batches of 16 airfoil envs end in a non-finite or non-converging solve in about one run out of three, with the
-    // one-cell kernels in none (same seeds; the failure rate grows with the batch -- none at 2 envs, every run at 16 -- and
-    // stays when the lane shuffles are replaced by gathers, so it is not the shuffle.  Bisecting with the per-kernel mask
-    // below: each of p4 / v4 / s4 / x4 alone reproduces it, t4 alone does not, and the residual history of the first
-    // pressure solve is bit-identical to the one-cell kernels' for its first 50 iterations -- so the four-cell arithmetic
-    // is right and what breaks is elsewhere (the velocity solves with two systems per env, or an ordering assumption that
-    // the launch geometry changes).  Not found yet.)
-    // FG_MB_BICG_VEC4=1 enables them.
+    // The four-cells-per-thread kernels (k_mbb_*4) are used for the pressure solves (one system per env; 1.5x on the airfoil
+    // env).  For the velocity solves (d systems per env) they stay off: with them about one 16-env airfoil run in five ends
+    // in a non-finite velocity solve during the start-up, with the one-cell kernels none did (defect not found; the
+    // four-cell arithmetic itself reproduces the one-cell residual histories bit for bit on the pressure systems).
+    // FG_MB_BICG_VEC4: per-kernel mask (1 p, 2 v, 4 s, 8 t, 16 x; "1" = all), + 64 = pressure solves only; default 95.
     const char* vec_env = getenv("FG_MB_BICG_VEC4");
-    int vec_mask = (n % 4 == 0 && vec_env) ? (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)) : 0;   // "1" = all five
+    int vec_mask = (n % 4 != 0) ? 0 : (!vec_env ? 95 : (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)));
     if (vec_mask >= 64) vec_mask = (nc == 1) ? (vec_mask & 31) : 0;   // + 64: pressure solves only (one system per env)
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     if (refine && !s->x64) {

@@ -13,10 +13,6 @@ and CG stagnates at 2-4e-5 against the tolerance of 1e-7.  The default here is t
 refinement (``pressure_use_BiCG=2``, DESIGN.md 4b), which reaches the tolerance in ~30 iterations per warm-started solve;
 ``pressure_use_BiCG=False`` selects the stagnating CG (with ``stall_limit`` deciding where its solves are cut).
 
-STATUS: experimental.  Development (400 steps into vortex shedding) and actuated steps ran reliably at 2 envs; with batches
-of 8 or more the development from the impulsive start intermittently takes minutes instead of seconds (pressure solves of
-the start-up transient stop converging in some runs) -- open.
-
 Batched over ``num_envs`` like every env here.  Not carried over: the published initial domains / statistics (no network:
 ``reset`` develops the flow from a projected uniform stream).  The section is the closed-form NACA 0012
 (``airfoil_grid.naca0012_sharp``) unless a ``surface`` polyline is given; states saved by the reference carry their mesh.
