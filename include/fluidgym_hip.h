@@ -341,7 +341,8 @@ typedef struct fg_mb_step_options {
                                           cross-metric terms the pressure matrix is not symmetric, CG only works while the
                                           mesh is close to orthogonal; 1: BiCGStab (restarted every 200 iterations);
                                           2: BiCGStab with the iterate kept in fp64 and the residual recomputed in fp64 at every
-                                          restart (iterative refinement) -- the role of the reference's solver_double_fallback */
+                                          restart (iterative refinement), best refinement point returned when unconverged -- the role of
+                                          the reference's solver_double_fallback */
     int32_t pressure_warm_start;       /* 1: the first pressure solve of a corrector starts from the current pressure field
                                           instead of zero (the reference passes x=None there, PISOtorch_simulation.py:1878;
                                           same converged answer, fewer iterations) */
