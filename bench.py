@@ -288,6 +288,19 @@ def main():
     ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 16 leg (about 10 s)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): start one rank per GPU as CHILD processes through the standard
+        # launcher and relay rank 0's JSON line.  This process has not touched the GPU (no HIP call yet) and never will.
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
 

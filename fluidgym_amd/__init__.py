@@ -8,14 +8,16 @@ loaded on first use and its absence is an error (there is no CPU / PyTorch fallb
 
 Registered ids: the reference registers 39 ids (``fluidgym/__init__.py:28-352``).  The RBC and TCF
 families (single block, orthogonal) are registered under the reference's ids with the reference's
-defaults; the 2-D cylinder family runs on the multi-block curvilinear path (``envs/cylinder.py``); the
-3-D cylinder and the airfoil families raise ``NotImplementedError`` (meshes not built yet).
+defaults; the cylinder (2-D, 3-D) and airfoil (2-D, 3-D) families run on the multi-block curvilinear path
+(``envs/cylinder.py``, ``envs/airfoil.py``) on the reference's own meshes.  ``ChannelJet2D-*`` are
+single-block stand-ins for the BASELINE configs named on grid sizes the reference's meshes do not have.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from .registry import make, register, registry  # noqa: F401
+from .simulation.policy import get_solver_policy, set_solver_policy  # noqa: F401
 
 __version__ = "0.1.0"
 
@@ -25,17 +27,6 @@ def _lazy(module: str, cls: str):
         import importlib
 
         return getattr(importlib.import_module(module, __name__), cls)(**kw)
-
-    return ctor
-
-
-def _not_built(family: str):
-    def ctor(**kw):
-        raise NotImplementedError(
-            f"{family} envs use multi-block body-fitted curvilinear meshes (reference envs/{family.lower()}/grid.py); "
-            "the HIP path covers single-block rectilinear grids this round. Use 'ChannelJet2D-v0' "
-            "(same boundary-condition set on one block) -- see SURVEY.md section 8f-3."
-        )
 
     return ctor
 

@@ -96,7 +96,17 @@ struct fg_mb_state {
     fg_solve_info *info_dev, *info_pinned = nullptr;
     float* yproj = nullptr;
     double* x64_best = nullptr; float* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
-    double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2), allocated on first use
+    double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2)
+    // debug switches, read ONCE from the environment at fg_mb_create (never on the step path): FG_MB_BICG_VEC4 (per-kernel mask
+    // of the four-cell BiCGStab kernels: 1 p, 2 v, 4 s, 8 t, 16 x; + 64 = pressure solves only), FG_MB_SCALAR_CG=1 (one-cell
+    // CG kernels), FG_MB_GRAPH (CG chunks replayed as a hipGraph), FG_MB_TRACE (residual trace on stderr)
+    int dbg_vec_mask = 0, dbg_scalar_cg = 0, dbg_graph = 0, dbg_trace = 0;
+    // per-env outcome of the last fg_mb_piso_step / fg_mb_single_step: 0 ok, 1 a solve ended unconverged (best iterate used),
+    // 2 a solve was non-finite: that env's step was NOT committed (state as before the step), the other envs completed
+    float* dt_step = nullptr;          // [B] working copy of the caller's dt; failed envs are masked out (dt = 0) in it
+    int32_t* env_fail = nullptr;       // [B] device
+    int32_t* env_fail_pinned = nullptr;
+    std::vector<int32_t> env_status;   // [B] host, what fg_mb_env_status reports
     int cg_stall_limit = 400;  // fg_mb_set_stall_limit
     bool yproj_const = true;   // yproj is the constant 1/sqrt(N): kernels use the scalar instead of loading it
     float* red;        // [B] reductions (mean, max)

@@ -666,7 +666,8 @@ __device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b
         const float oo[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
+            const int n = nn[e];
+            if (n < 0) continue;  // prescribed face: no matrix entry (as mb_spmv; 0 * x would turn a non-finite x into NaN)
             float xn;
             if (f == 0 && n == i + e - 1 && (e > 0 || lane > 0)) xn = e > 0 ? xi[e > 0 ? e - 1 : 0] : from_prev;
             else if (f == 1 && n == i + e + 1 && (e < 3 || lane < 63)) xn = e < 3 ? xi[e < 3 ? e + 1 : 3] : from_next;
@@ -1163,6 +1164,16 @@ __global__ void k_mb_fill(size_t n, float v, float* __restrict__ x) {
     if (i < n) x[i] = v;
 }
 
+// envs with a non-finite system leave the step: dt = 0 masks them out of every later kernel of the call (incl. the final
+// copy of the velocity result), so their state stays what it was before the step; status 2 is recorded
+__global__ void k_mb_mask_failed(int B, int nc, const fg_solve_info* __restrict__ info, float* __restrict__ dt, int32_t* __restrict__ fail) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || !(dt[b] > 0.f)) return;
+    bool bad = false;
+    for (int c = 0; c < nc; ++c) bad = bad || !info[b * nc + c].is_finite;
+    if (bad) { dt[b] = 0.f; fail[b] = 2; }
+}
+
 #define MB_DISPATCH(s, ...)                    \
     do {                                       \
         if ((s)->d == 2) { constexpr int DIMS = 2; __VA_ARGS__ } \
@@ -1222,21 +1233,10 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // a refined solve that has not converged after 1500 iterations is not going to: hand over to the caller's CG fallback
     // instead of spending the reference's 5000 (one hard env would stall the whole batch)
     if (refine && max_iterations > 1500) max_iterations = 1500;
-    // The four-cells-per-thread kernels (k_mbb_*4) are used for the pressure solves (one system per env; 1.5x on the airfoil
-    // env).  For the velocity solves (d systems per env) they stay off: with them about one 16-env airfoil run in five ends
-    // in a non-finite velocity solve during the start-up, with the one-cell kernels none did (defect not found; the
-    // four-cell arithmetic itself reproduces the one-cell residual histories bit for bit on the pressure systems).
-    // FG_MB_BICG_VEC4: per-kernel mask (1 p, 2 v, 4 s, 8 t, 16 x; "1" = all), + 64 = pressure solves only; default 95.
-    const char* vec_env = getenv("FG_MB_BICG_VEC4");
-    int vec_mask = (n % 4 != 0) ? 0 : (!vec_env ? 95 : (vec_env[0] == '1' && vec_env[1] == 0 ? 31 : atoi(vec_env)));
+    // Four-cells-per-thread kernels (k_mbb_*4): s->dbg_vec_mask selects them per kernel (FG_MB_BICG_VEC4, read at create).
+    int vec_mask = (n % 4 != 0) ? 0 : s->dbg_vec_mask;
     if (vec_mask >= 64) vec_mask = (nc == 1) ? (vec_mask & 31) : 0;   // + 64: pressure solves only (one system per env)
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
-    if (refine && !s->x64) {
-        if (int rc = mb_alloc(s, &s->x64, (size_t)s->B * n)) return rc;
-        if (int rc = mb_alloc(s, &s->x64_best, (size_t)s->B * n)) return rc;
-        if (int rc = mb_alloc(s, &s->best_res, (size_t)s->B)) return rc;
-        if (int rc = mb_alloc(s, &s->best_keep, (size_t)s->B)) return rc;
-    }
     auto keep_best = [&](int first) {
         hipLaunchKernelGGL(k_mbr_best_decide, sg, sb, 0, st, q, s->best_res, s->best_keep, n, nsys, first);
         hipLaunchKernelGGL(k_mbr_best_copy, grid, blk, 0, st, n, (const int32_t*)s->best_keep, (const double*)s->x64, s->x64_best);
@@ -1278,7 +1278,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             next_poll = it + 1 + (it < 20 ? 2 : 10);   // long (pressure) solves: fewer host round trips
             hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
             if (int rc = mb_poll(s, nsys, st, done)) return rc;
-            if (nc == 1 && getenv("FG_MB_TRACE")) {
+            if (nc == 1 && s->dbg_trace) {
                 float lo = 1e30f, hi = 0.f; int active = 0;
                 for (int i = 0; i < nsys; ++i) { const float c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
                 fprintf(stderr, "[mb_bicg] it %4d residual min %.3e max %.3e active %d\n", it + 1, lo, hi, active);
@@ -1306,8 +1306,7 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = s->cg_stall_limit;
     q.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; q.accept_window = 20;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
-    const char* scalar_env = getenv("FG_MB_SCALAR_CG");   // "1" forces the one-cell-per-thread kernels (debugging)
-    const bool vec4 = (n % 4 == 0) && !(scalar_env && scalar_env[0] == '1');
+    const bool vec4 = (n % 4 == 0) && !s->dbg_scalar_cg;   // FG_MB_SCALAR_CG=1 forces the one-cell-per-thread kernels
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mbs_init<DIMS>, grid, blk, 0, st, s->dev, q, use_x0, project_mean ? C_SUM : -1, 0););
@@ -1371,8 +1370,8 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     };
     // the chunk can be replayed as a hipGraph (FG_MB_GRAPH=1); since the four-cells-per-thread kernels the loop is no
     // longer enqueue-bound and plain launches are as fast, so that is the default (and what the live profiler samples)
-    const bool use_graph = getenv("FG_MB_GRAPH") != nullptr && !s->prof_on;
-    const bool trace = getenv("FG_MB_TRACE") != nullptr;
+    const bool use_graph = s->dbg_graph && !s->prof_on;
+    const bool trace = s->dbg_trace != 0;
     if (use_graph) {
         MbGraphKey key;
         memset(&key, 0, sizeof(key));
@@ -1459,6 +1458,14 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
     fg_mb_state* s = new fg_mb_state();
     s->d = dims; s->F = 2 * dims; s->B = batch;
     s->host_only = device < 0;
+    {   // debug switches: the only getenv calls of this path, never on the step path
+        const char* e = getenv("FG_MB_BICG_VEC4");
+        // default: four-cell kernels in the pressure solves only (one system per env)
+        s->dbg_vec_mask = !e ? 95 : ((e[0] == '1' && e[1] == 0) ? 31 : atoi(e));
+        e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
+        s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
+        s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
+    }
     *out = s;
     return FG_OK;
 }
@@ -1474,6 +1481,7 @@ extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (s->flags_pinned) (void)hipHostFree(s->flags_pinned);
     if (s->red2_pinned) (void)hipHostFree(s->red2_pinned);
     if (s->dt_pinned) (void)hipHostFree(s->dt_pinned);
+    if (s->env_fail_pinned) (void)hipHostFree(s->env_fail_pinned);
     delete s;
     return FG_OK;
 }
@@ -1591,6 +1599,15 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->red2, 2 * B)) return rc;
     if (int rc = mb_alloc(s, &s->it_ctr, 4)) return rc;
     if (int rc = mb_alloc(s, &s->dt_dev, B)) return rc;
+    if (int rc = mb_alloc(s, &s->dt_step, B)) return rc;
+    if (int rc = mb_alloc(s, &s->env_fail, B)) return rc;
+    // fp64 iterate + best refinement point of the refined BiCGStab: allocated here, nothing is allocated on the step path
+    if (int rc = mb_alloc(s, &s->x64, B * N)) return rc;
+    if (int rc = mb_alloc(s, &s->x64_best, B * N)) return rc;
+    if (int rc = mb_alloc(s, &s->best_res, B)) return rc;
+    if (int rc = mb_alloc(s, &s->best_keep, B)) return rc;
+    s->env_status.assign(B, 0);
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->env_fail_pinned, sizeof(int32_t) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(float) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red2_pinned, sizeof(float) * 2 * B, hipHostMallocDefault));
@@ -1646,6 +1663,13 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         return rc;
     };
     int its[4] = {0, 0, 0, 0};
+    // working copy of dt: envs whose solve turns out non-finite are masked out of the rest of the step (k_mb_mask_failed)
+    FG_HIP_CHECK(hipMemcpyAsync(s->dt_step, dt_B, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
+    FG_HIP_CHECK(hipMemsetAsync(s->env_fail, 0, sizeof(int32_t) * B, st));
+    dt_B = s->dt_step;
+    auto mask_failed = [&](int nc) {
+        hipLaunchKernelGGL(k_mb_mask_failed, dim3((B + 63) / 64), dim3(64), 0, st, B, nc, (const fg_solve_info*)s->info_dev, s->dt_step, s->env_fail);
+    };
     const size_t vel_env = (size_t)d * N;
     const dim3 gcopy((unsigned)((vel_env + FG_BLOCK - 1) / FG_BLOCK), B);
     MB_DISPATCH(s, {
@@ -1658,7 +1682,10 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
             int m = 0;
             const int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
                                         opt->max_iterations, no > 0, &m, st);
-            if (vrc == FG_ERR_NOT_FINITE) fg_set_error("fg_mb_piso_step: the velocity (BiCGStab) solve produced a non-finite residual");
+            if (vrc == FG_ERR_NOT_FINITE) {
+                fg_set_error("fg_mb_piso_step: the velocity (BiCGStab) solve produced a non-finite residual");
+                mask_failed(d);   // solve_ok = False before CopyVelocityResultToBlocks (PISOtorch_simulation.py:1752-1757): state intact
+            }
             if (int rc = soft(vrc)) return rc;
             its[1] = std::max(its[1], m);
         }
@@ -1690,7 +1717,10 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 // which hands back its best iterate (the reference's chain runs the other way round, PISOtorch_diff.py:266-371)
                 if (opt->pressure_use_bicgstab && (prc == FG_ERR_NOT_FINITE || (prc == FG_ERR_NOT_CONVERGED && opt->pressure_use_bicgstab != 2)))
                     prc = solve(0, 1);   // the refined solver hands back its best refinement point itself
-                if (prc == FG_ERR_NOT_FINITE) fg_set_error("fg_mb_piso_step: the pressure solve produced a non-finite residual");
+                if (prc == FG_ERR_NOT_FINITE) {
+                    fg_set_error("fg_mb_piso_step: the pressure solve produced a non-finite residual");
+                    mask_failed(1);
+                }
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) its[2 + c] = std::max(its[2 + c], m);
                 FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
@@ -1703,8 +1733,24 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
     });
     FG_HIP_CHECK(hipGetLastError());
     if (stats_host) for (int k = 0; k < 4; ++k) stats_host[k] = its[k];
+    for (int b = 0; b < B; ++b) s->env_status[b] = 0;
+    if (soft_rc == FG_ERR_NOT_FINITE) {   // rare path: which envs were dropped
+        FG_HIP_CHECK(hipMemcpyAsync(s->env_fail_pinned, s->env_fail, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+        FG_HIP_CHECK(hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) s->env_status[b] = s->env_fail_pinned[b];
+    } else if (soft_rc == FG_ERR_NOT_CONVERGED) {
+        for (int b = 0; b < B; ++b) s->env_status[b] = 1;   // some solve of the batch ended on its best iterate
+    }
     return soft_rc;
 }
+
+extern "C" int fg_mb_env_status(fg_mb_handle s, int32_t* out_B_host) {
+    FG_REQUIRE(s && s->finalized && out_B_host, FG_ERR_INVALID_ARG, "fg_mb_env_status: bad argument");
+    for (int b = 0; b < s->B; ++b) out_B_host[b] = s->env_status[b];
+    return FG_OK;
+}
+
+
 
 extern "C" int fg_mb_max_velocity(fg_mb_handle s, float* out_B_host, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_max_velocity: fields not bound");
@@ -1790,6 +1836,7 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
     }
     std::vector<double> t_rem(B, (double)o->time_step);
     std::vector<float> mv(B, 0.f);
+    std::vector<int32_t> status(B, 0);
     int32_t stats[4] = {-1, -1, -1, -1};
     int substeps = 0, all_ok = 1;
     int fixed_left = o->adaptive ? 0 : (o->substeps > 0 ? o->substeps : 1);
@@ -1803,8 +1850,12 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
         // _PISO_adaptive_step (PISOtorch_simulation.py:2004-2064): ts = t_rem / ceil(t_rem / (CFL / max_vel)), per env
         for (int b = 0; b < B; ++b) {
             float ts = 0.f;
-            if (!o->adaptive) {
+            if (status[b] == 2) {
+                ts = 0.f;   // dropped out of this step (non-finite solve or state)
+            } else if (!o->adaptive) {
                 ts = o->time_step / (float)(o->substeps > 0 ? o->substeps : 1);
+            } else if (t_rem[b] > 0 && !mb_close_zero(t_rem[b]) && !std::isfinite(mv[b])) {
+                status[b] = 2; t_rem[b] = 0.0;   // a state that is already non-finite: nothing to step
             } else if (t_rem[b] > 0 && !mb_close_zero(t_rem[b])) {
                 const double max_ts = mb_close_zero(mv[b]) ? t_rem[b] : (double)o->cfl / (double)mv[b];
                 const double tsd = (max_ts >= t_rem[b]) ? t_rem[b] : t_rem[b] / (double)(long long)std::ceil(t_rem[b] / max_ts);
@@ -1819,8 +1870,15 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
                                         o->outflow_velm, o->outflow_tol, st))
                 return rc;
         const int rc = fg_mb_piso_step(s, s->dt_dev, &o->step, stats, stream);
-        if (rc == FG_ERR_NOT_CONVERGED) all_ok = 0;
-        else if (rc != FG_OK) return rc;
+        if (rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) {
+            all_ok = 0;
+            for (int b = 0; b < B; ++b) {
+                status[b] = std::max(status[b], s->env_status[b]);
+                // a non-finite solve: that env's substep was not committed; it sits out the rest of this step with its
+                // state intact (Simulation.single_step returns False there, simulation.py:259-280), the others finish
+                if (s->env_status[b] == 2) t_rem[b] = 0.0;
+            }
+        } else if (rc != FG_OK) return rc;
         FG_HIP_CHECK(hipStreamSynchronize(st));  // dt_pinned is rewritten next round
         ++substeps;
         if (!o->adaptive) --fixed_left;
@@ -1829,6 +1887,7 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
     for (int i = 0; i < 4; ++i) out[i] = stats[i];
     out[4] = substeps;
     out[5] = all_ok;
+    s->env_status = status;
     return FG_OK;
 }
 

@@ -6,9 +6,12 @@ parent (``:115-200, 233-287``); no collective library anywhere.
 
 MI355X design: one process per GPU in a ``torch.distributed`` group (backend ``nccl`` = RCCL over
 xGMI); every rank owns ``num_envs / world`` envs *batched inside one solver handle*.  Per step the
-driver rank broadcasts the action block (a few KB) and one ``all_gather`` returns the packed
-observation + reward block of every shard; no field data ever leaves a GPU.  Messages are
-latency-bound (KBs against 7 x ~153 GB/s links), so each direction is exactly one collective.
+driver rank broadcasts ONE message (command header + action block, a few KB) and ONE ``all_gather`` returns
+the packed observation | reward | terminated | truncated | info block of every shard; no field data ever
+leaves a GPU.  Messages are latency-bound (KBs against 7 x ~153 GB/s links), so each direction is exactly one
+collective; the collectives run on RCCL's own stream, ranks that already know the command (SPMD callers) never
+read the header back to the host, and the only host read of a step is the per-env terminated / truncated
+flags the reference's return type (Python lists) asks for.
 
 Two ways to run it:
 
@@ -31,6 +34,7 @@ import torch
 import torch.distributed as dist
 
 from ..registry import make
+from ..types import EnvMode
 
 
 class Command(IntEnum):
@@ -105,7 +109,14 @@ class ParallelFluidEnv:
             kw["cuda_device"] = self._device
         self._env = make(env_id, num_envs=self._n_local, **kw)
         self._obs_keys = sorted(self._env.observation_space.keys())
-        self._cmd = torch.zeros(4, dtype=torch.int64, device=self._device)
+        # ONE message per command: int32 header [cmd, a, b, c] followed by the action block bit-cast to int32, so that a
+        # step costs one broadcast (header + actions) and one all_gather (obs | reward | terminated | truncated | info)
+        self._a_shape = (self._n_total,) + tuple(self._env._zero_action.shape[1:])
+        self._a_numel = int(np.prod(self._a_shape))
+        self._msg = torch.zeros(self._HDR + self._a_numel, dtype=torch.int32, device=self._device)
+        self._info_layout: Optional[List] = None
+
+    _HDR = 4
 
     # ------------------------------------------------------------------ introspection
     def __getattr__(self, name: str) -> Any:
@@ -140,13 +151,25 @@ class ParallelFluidEnv:
         return self._env
 
     # ------------------------------------------------------------------ collectives
-    def _bcast_cmd(self, cmd: Optional[Command] = None, a: int = 0, b: int = 0, c: int = 0) -> List[int]:
-        if self.world == 1:
-            return [int(cmd), a, b, c]
+    def _send(self, cmd: Optional[Command] = None, a: int = 0, b: int = 0, c: int = 0,
+              action: Optional[torch.Tensor] = None, read_header: bool = True) -> List[int]:
+        """The one broadcast of a command.  Driver: fills header (+ actions).  ``read_header=False`` (SPMD ranks that
+        already know the command because they made the same call) skips the device->host read of the header."""
         if self.is_driver:
-            self._cmd.copy_(torch.tensor([int(cmd), int(a), int(b), int(c)], dtype=torch.int64))
-        dist.broadcast(self._cmd, src=0)
-        return [int(v) for v in self._cmd.tolist()]
+            hdr = torch.tensor([int(cmd), int(a), int(b), int(c)], dtype=torch.int32)
+            self._msg[: self._HDR].copy_(hdr, non_blocking=True)
+            if action is not None:
+                self._msg[self._HDR:].copy_(action.to(self._device, torch.float32).reshape(-1).view(torch.int32))
+            if self.world > 1:
+                dist.broadcast(self._msg, src=0)
+            return [int(cmd), int(a), int(b), int(c)]
+        dist.broadcast(self._msg, src=0)
+        if not read_header:
+            return [int(cmd) if cmd is not None else -1, a, b, c]
+        return [int(v) for v in self._msg[: self._HDR].tolist()]
+
+    def _actions_from_msg(self) -> torch.Tensor:
+        return self._msg[self._HDR:].view(torch.float32).reshape(self._a_shape)
 
     def _all_gather(self, local: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
@@ -160,10 +183,26 @@ class ParallelFluidEnv:
             out = torch.stack(parts)
         return out.reshape((-1,) + tuple(local.shape[1:]))
 
-    def _pack(self, obs: Dict[str, torch.Tensor], reward: Optional[torch.Tensor]) -> torch.Tensor:
+    def _per_env(self, v) -> torch.Tensor:
+        """A per-shard scalar / bool or a per-env tensor as one float row per local env."""
+        t = torch.as_tensor(v, device=self._device).float()
+        if t.dim() == 0 or t.shape[0] != self._n_local:
+            t = t.reshape(1, -1).expand(self._n_local, -1)
+        return t.reshape(self._n_local, -1)
+
+    def _pack(self, obs: Dict[str, torch.Tensor], reward: Optional[torch.Tensor], term=None, trunc=None,
+              info: Optional[Dict[str, Any]] = None) -> torch.Tensor:
         parts = [obs[k].reshape(self._n_local, -1).float() for k in self._obs_keys]
         if reward is not None:
             parts.append(reward.reshape(self._n_local, -1).float())
+            parts.append(self._per_env(term))
+            parts.append(self._per_env(trunc))
+            if self._info_layout is None:   # same keys / shapes on every rank (same env class and config)
+                self._info_layout = [(k, tuple(self._per_env(info[k]).shape[1:]),
+                                      tuple(torch.as_tensor(info[k]).shape[1:]) if torch.as_tensor(info[k]).dim() > 0
+                                      and torch.as_tensor(info[k]).shape[0] == self._n_local else None)
+                                     for k in sorted(info or {})]
+            parts += [self._per_env(info[k]) for k, _, _ in self._info_layout]
         return torch.cat(parts, dim=1)
 
     def _unpack(self, flat: torch.Tensor, obs_like: Dict[str, torch.Tensor], with_reward: bool):
@@ -174,31 +213,46 @@ class ParallelFluidEnv:
             size = int(np.prod(shp)) if len(shp) else 1
             out[k] = flat[:, off: off + size].reshape((n,) + tuple(shp))
             off += size
-        reward = flat[:, off:].reshape(n, *(() if flat.shape[1] - off == 1 else (-1,))) if with_reward else None
-        return out, reward
+        if not with_reward:
+            return out, None, None, None, None
+        info_w = sum(int(np.prod(w)) for _, w, _ in self._info_layout)
+        r_w = flat.shape[1] - off - 2 - info_w
+        reward = flat[:, off: off + r_w].reshape(n, *(() if r_w == 1 else (-1,)))
+        off += r_w
+        term, trunc = flat[:, off] != 0, flat[:, off + 1] != 0
+        off += 2
+        info = {}
+        for k, w, shp in self._info_layout:
+            size = int(np.prod(w))
+            v = flat[:, off: off + size]
+            info[k] = v.reshape((n,) + shp) if shp is not None else v.reshape(n, -1)
+            off += size
+        return out, reward, term, trunc, info
 
     # ------------------------------------------------------------------ env API (collective)
     # Every public method is a COLLECTIVE call: all ranks that are not inside serve() must call it; the
     # driver's arguments win (they travel in the command broadcast).
     def seed(self, seed: int = 0) -> None:
-        _, a, _, _ = self._bcast_cmd(Command.SEED, int(seed))
+        _, a, _, _ = self._send(Command.SEED, int(seed))
         self._env.seed(a + self.rank)
 
     def reset(self, seed: Optional[int] = None, randomize: Optional[bool] = None):
         """All shards reset with seeds ``seed + rank`` (independent envs); returns the observations of
         all ``num_envs`` envs stacked along dim 0 and a list of per-shard info dicts."""
-        _, a, b, _ = self._bcast_cmd(Command.RESET, -1 if seed is None else int(seed),
-                                     -1 if randomize is None else int(randomize))
+        _, a, b, _ = self._send(Command.RESET, -1 if seed is None else int(seed),
+                                -1 if randomize is None else int(randomize))
         return self._do_reset(None if a < 0 else a, None if b < 0 else bool(b))
 
     def _do_reset(self, seed, randomize):
         obs, info = self._env.reset(seed=None if seed is None else int(seed) + self.rank, randomize=randomize)
         flat = self._all_gather(self._pack(obs, None))
-        obs_all, _ = self._unpack(flat, obs, with_reward=False)
-        return self._agents_to_rows(obs_all), [info for _ in range(self.world)]
+        obs_all = self._unpack(flat, obs, with_reward=False)[0]
+        return self._agents_to_rows(obs_all), [info for _ in range(self._n_total)]
 
     def step(self, action: Optional[torch.Tensor] = None):
-        """Driver: ``action [num_envs, ...]``.  Other ranks in SPMD mode pass ``None``."""
+        """Driver: ``action [num_envs, ...]``.  Other ranks in SPMD mode pass ``None``.  Returns the reference's tuple
+        (``parallel_env.py:233-287``): observations of all envs, rewards ``[num_envs, ...]``, and per-env LISTS of
+        terminated / truncated flags and info dicts (the flags come back as one host read of the gathered block)."""
         if self.is_driver:
             # multi-agent: one row per agent of every env, envs concatenated (what sample_action returns, reference
             # parallel_env.py:356-359), or [num_envs, n_agents, ...]
@@ -206,24 +260,19 @@ class ParallelFluidEnv:
             if action is None or action.shape[0] not in ok:
                 raise ValueError(f"Expected action batch size {ok[-1]}, but got "
                                  f"{None if action is None else action.shape[0]}")
-        self._bcast_cmd(Command.STEP)
-        return self._do_step(action)
+        self._send(Command.STEP, action=action, read_header=False)
+        return self._do_step()
 
-    def _do_step(self, action: Optional[torch.Tensor]):
-        a_shape = (self._n_total,) + tuple(self._env._zero_action.shape[1:])
-        if self.is_driver:
-            full = action.to(self._device, torch.float32).reshape(a_shape).contiguous()
-        else:
-            full = torch.empty(a_shape, dtype=torch.float32, device=self._device)
-        if self.world > 1:
-            dist.broadcast(full, src=0)  # actions: one small collective
+    def _do_step(self):
+        full = self._actions_from_msg()
         mine = full[self.rank * self._n_local: (self.rank + 1) * self._n_local]
         obs, reward, term, trunc, info = self._env.step(mine)
-        flat = self._all_gather(self._pack(obs, reward))  # observations + rewards: one collective
-        obs_all, reward_all = self._unpack(flat, obs, with_reward=True)
+        flat = self._all_gather(self._pack(obs, reward, term, trunc, info))  # everything a step returns: one collective
+        obs_all, reward_all, term_all, trunc_all, info_all = self._unpack(flat, obs, with_reward=True)
         obs_all = self._agents_to_rows(obs_all)
-        infos = [{k: v for k, v in info.items()} for _ in range(1)]
-        return obs_all, reward_all, [term] * self._n_total, [trunc] * self._n_total, infos
+        flags = torch.stack([term_all, trunc_all]).cpu().tolist()
+        infos = [{k: v[i] for k, v in info_all.items()} for i in range(self._n_total)]
+        return obs_all, reward_all, [bool(x) for x in flags[0]], [bool(x) for x in flags[1]], infos
 
     def _agents_to_rows(self, obs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Multi-agent observations are concatenated over envs, ``[num_envs * n_agents, ...]`` (reference
@@ -233,33 +282,55 @@ class ParallelFluidEnv:
         return {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in obs.items()}
 
     def sample_action(self) -> torch.Tensor:
-        a = self._all_gather(self._env.sample_action())
+        """Collective like every other call: each shard samples from its own generator, one all_gather."""
+        self._send(Command.SAMPLE_ACTION, read_header=False)
+        return self._do_sample()
+
+    def _do_sample(self) -> torch.Tensor:
+        a = self._all_gather(self._env.sample_action().to(self._device))
         return a.reshape((-1,) + tuple(a.shape[2:])) if self._env.use_marl else a
 
     def train(self) -> None:
-        self._bcast_cmd(Command.TRAIN)
+        self._send(Command.TRAIN, read_header=False)
         self._env.train()
 
     def val(self) -> None:
-        self._bcast_cmd(Command.VAL)
+        self._send(Command.VAL, read_header=False)
         self._env.val()
 
     def test(self) -> None:
-        self._bcast_cmd(Command.TEST)
+        self._send(Command.TEST, read_header=False)
         self._env.test()
 
+    _MODES = (None, EnvMode.TRAIN, EnvMode.VAL, EnvMode.TEST)
+
     def load_initial_domain(self, idx: int = 0, mode=None) -> None:
-        _, a, _, _ = self._bcast_cmd(Command.LOAD_INITIAL_DOMAIN, int(idx))
-        self._env.load_initial_domain(a * self.world + self.rank, mode)
+        _, a, b, _ = self._send(Command.LOAD_INITIAL_DOMAIN, int(idx), self._MODES.index(mode))
+        self._env.load_initial_domain(a * self.world + self.rank, self._MODES[b])
+
+    def get_state(self) -> Any:
+        raise NotImplementedError("get_state is not implemented for ParallelFluidEnv.")   # parallel_env.py:370-378
+
+    def set_state(self, state: Any) -> None:
+        raise NotImplementedError("set_state is not implemented for ParallelFluidEnv.")
+
+    def save_gif(self, filename: str, output_path=None) -> None:
+        raise NotImplementedError("save_gif is not implemented for ParallelFluidEnv.")
+
+    def get_uncontrolled_episode_metrics(self):
+        raise NotImplementedError("get_uncontrolled_episode_metrics is not implemented for ParallelFluidEnv.")
+
+    def detach(self) -> None:
+        raise NotImplementedError("detach is not implemented for ParallelFluidEnv.")
 
     # ------------------------------------------------------------------ worker loop
     def serve(self) -> None:
         """Follow the driver's commands until CLOSE (the reference's ``_worker``, parallel_env.py:115-160)."""
         assert not self.is_driver
         while True:
-            cmd, a, b, _ = self._bcast_cmd()
+            cmd, a, b, _ = self._send()
             if cmd == Command.STEP:
-                self._do_step(None)
+                self._do_step()
             elif cmd == Command.RESET:
                 self._do_reset(None if a < 0 else a, None if b < 0 else bool(b))
             elif cmd == Command.SEED:
@@ -270,15 +341,17 @@ class ParallelFluidEnv:
                 self._env.val()
             elif cmd == Command.TEST:
                 self._env.test()
+            elif cmd == Command.SAMPLE_ACTION:
+                self._do_sample()
             elif cmd == Command.LOAD_INITIAL_DOMAIN:
-                self._env.load_initial_domain(a * self.world + self.rank, None)
+                self._env.load_initial_domain(a * self.world + self.rank, self._MODES[b])
             elif cmd == Command.CLOSE:
                 break
         self._shutdown()
 
     def close(self) -> None:
         if self.world > 1:
-            self._bcast_cmd(Command.CLOSE)
+            self._send(Command.CLOSE, read_header=False)
         self._shutdown()
         for p in self._workers:
             p.join(timeout=30)

@@ -262,7 +262,7 @@ class NativeSolver:
     def single_step(self, time_step, cfl, adaptive=True, substeps=1, flux_balance_tol=1e-5, outflow_faces=(),
                     outflow_velm=(0.0, 0.0, 0.0), outflow_tol=1e-5, corrector_steps=2, advect_scalar=True,
                     advection_tol=1e-5, pressure_tol=1e-5, max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0,
-                    method=None, pressure_warm_start=True, max_substeps=1000):
+                    method=None, pressure_warm_start=False, max_substeps=1000):
         """Native ``Simulation.single_step``; returns (all_converged, solver_stats[4], substeps)."""
         method = self.default_method if method is None else method
         o = L.FgSimOptions()

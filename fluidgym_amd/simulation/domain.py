@@ -256,7 +256,7 @@ class Domain:
         self.name = name
         self.dtype = dtype
         self.device = torch.device("cuda") if device is None else torch.device(device)
-        if self.device.index is None:
+        if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         self.batch = int(batch)
         self.n_scalars = int(passiveScalarChannels)

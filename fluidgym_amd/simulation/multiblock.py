@@ -325,6 +325,13 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_single_step(self.handle, ctypes.byref(o), out, None, ctypes.c_void_p(st)))
         return out[4], bool(out[5]), (out[1], out[2], out[3])
 
+    def env_status(self) -> np.ndarray:
+        """Per-env outcome of the last step: 0 ok, 1 a solve ended on its best iterate, 2 non-finite solve -- that env's step
+        was not committed (``fg_mb_env_status``)."""
+        out = (ctypes.c_int32 * self.batch)()
+        L.check(self.lib.fg_mb_env_status(self.handle, out))
+        return np.array(out[:], dtype=np.int32)
+
     # ---- residual projection of the pressure CG
     def unit_pressure_matrix(self):
         """The pressure matrix for A = 1 (geometry only) of env 0 as a SciPy CSR matrix."""
@@ -424,10 +431,14 @@ class MultiBlockSimulation:
                  corrector_steps: int = 2, advection_tol: Optional[float] = None, pressure_tol: Optional[float] = None,
                  advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1, max_iterations: int = 5000,
                  pressure_use_BiCG: bool = False, outflow=None, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
-                 outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5, pressure_warm_start: bool = True,
-                 pressure_project_mean: bool = True, pressure_stall_accept: float = 1.25):
-        self.pressure_warm_start, self.pressure_project_mean = pressure_warm_start, pressure_project_mean
-        self.pressure_stall_accept = pressure_stall_accept
+                 outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5, pressure_warm_start: Optional[bool] = None,
+                 pressure_project_mean: bool = True, pressure_stall_accept: Optional[float] = None):
+        from .policy import get_solver_policy
+
+        pol = get_solver_policy()   # reference behaviour unless asked otherwise: cold start, no stall acceptance
+        self.pressure_warm_start = bool(pol["pressure_warm_start"] if pressure_warm_start is None else pressure_warm_start)
+        self.pressure_stall_accept = float(pol["pressure_stall_accept"] if pressure_stall_accept is None else pressure_stall_accept)
+        self.pressure_project_mean = pressure_project_mean
         self.domain, self.time_step, self.adaptive_CFL, self.substeps = domain, float(dt), float(adaptive_CFL), substeps
         self.corrector_steps = corrector_steps
         self.advection_tol = 1e-5 if advection_tol is None else advection_tol   # _get_solver_tolerance (PISOtorch_diff.py:247-253)
@@ -457,4 +468,14 @@ class MultiBlockSimulation:
         self.total_time += self.time_step
         self.total_step += 1
         self.last_substeps, self.last_iterations = n, its
-        return True  # unconverged solves hand back their best iterate (pressure_return_best_result=True), as the envs ask
+        # unconverged solves hand back their best iterate (pressure_return_best_result=True), as the envs ask; an env whose
+        # solve was NON-FINITE keeps its pre-step state while the rest of the batch completes, and the step reports False
+        # like the reference's (simulation.py:259-280) -- the reference's envs carry on regardless (cylinder_env_base.py:755)
+        self.last_env_status = self.domain.env_status() if not ok else np.zeros(self.domain.batch, np.int32)
+        if (self.last_env_status == 2).any():
+            import logging
+            logging.getLogger("PISOsim").error("Simulation failed in step (total step %d): non-finite linear solve in envs %s; "
+                                               "their state was left unchanged", self.total_step,
+                                               np.nonzero(self.last_env_status == 2)[0].tolist())
+            return False
+        return True

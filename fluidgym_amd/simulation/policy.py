@@ -1,0 +1,42 @@
+"""Solver policy switches that change HOW a converged answer is reached, never WHICH equations are solved.
+
+The defaults are the reference's behaviour.  Everything that departs from it is opt-in and named here so that a
+benchmark line can say which mode it ran in:
+
+``pressure_warm_start``  (default False)
+    The reference starts the first pressure solve of every corrector from zero (``x=None``: orthogonal branch
+    ``PISOtorch_simulation.py:1804-1807``; non-orthogonal branch ``x = None if (pstep == 0 or not pressure_reuse_result)``,
+    ``:1877-1881``) and re-uses the previous result only for the later non-orthogonal pressure iterations of the same
+    corrector.  ``True`` starts from the pressure field of the previous solve instead: same tolerance, same criterion,
+    fewer iterations -- a performance mode, reported separately by ``bench.py``.
+``pressure_stall_accept`` (default 0 = off)
+    Multi-block CG only: a solve whose kept iterate is within this factor of the tolerance and has not improved for 20
+    iterations ends with that iterate.  This loosens the effective tolerance by the factor, so it
+    is off unless asked for.
+
+Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` /
+``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` (read once at import).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict
+
+_POLICY: Dict[str, Any] = {
+    "pressure_warm_start": os.environ.get("FLUIDGYM_AMD_PRESSURE_WARM_START", "0") not in ("0", "", "false", "False"),
+    "pressure_stall_accept": float(os.environ.get("FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT", "0") or 0.0),
+}
+
+
+def get_solver_policy() -> Dict[str, Any]:
+    return dict(_POLICY)
+
+
+def set_solver_policy(**kw: Any) -> Dict[str, Any]:
+    """Change policy switches for simulations created AFTER the call; returns the previous values."""
+    old = dict(_POLICY)
+    for k, v in kw.items():
+        if k not in _POLICY:
+            raise KeyError(f"unknown solver policy {k!r} (known: {sorted(_POLICY)})")
+        _POLICY[k] = type(_POLICY[k])(v)
+    return old

@@ -27,6 +27,7 @@ import torch
 from .. import _lib as L
 from ..native import LinsolveError
 from .domain import Domain, FixedBoundary
+from .policy import get_solver_policy
 
 _LOG = logging.getLogger("PISOsim")
 
@@ -79,7 +80,7 @@ class Simulation:
         output_resampling_shape=None,
         output_resampling_fill_max_steps: int = 0,
         buoyancy: Optional[tuple] = None,
-        pressure_warm_start: bool = True,
+        pressure_warm_start: Optional[bool] = None,
         outflow: Optional[tuple] = None,
         **_ignored: Any,
     ):
@@ -116,10 +117,17 @@ class Simulation:
         self.advect_passive_scalar = advect_passive_scalar
         self.non_orthogonal = non_orthogonal  # identical results on orthogonal grids
         self.buoyancy = buoyancy  # (axis, factor): native form of the RBC PRE_VELOCITY_SETUP hook
-        # start pressure solves from the previous pressureResult (the reference's non-orthogonal branch does,
-        # its orthogonal branch starts from zero: PISOtorch_simulation.py:1878-1882 vs 1804-1812); the solve
-        # converges to the same tolerance either way, in fewer iterations
-        self.pressure_warm_start = bool(pressure_warm_start)
+        # the reference starts every pressure solve of this path from zero (orthogonal branch x=None,
+        # PISOtorch_simulation.py:1804-1807; non-orthogonal branch x=None at pstep 0, :1877-1881, and this path runs
+        # pressure_non_ortho_steps == 1): that is the default.  Starting from the previous pressure is the opt-in
+        # performance mode of simulation/policy.py
+        self.pressure_warm_start = bool(get_solver_policy()["pressure_warm_start"] if pressure_warm_start is None
+                                        else pressure_warm_start)
+        if solver_double_fallback or not BiCG_precondition_fallback or preconditionBiCG:
+            # accepted for signature compatibility; the orthogonal single-block systems of this path are solved by a
+            # preconditioned CG / BiCGStab whose failure handling is native (returnBestResult), see DESIGN.md a19
+            _LOG.debug("solver_double_fallback=%s BiCG_precondition_fallback=%s preconditionBiCG=%s", solver_double_fallback,
+                       BiCG_precondition_fallback, preconditionBiCG)
         # (bounds, velm, tol): advective-outflow PRE hook of the cylinder/airfoil envs (PISOtorch_simulation.py:
         # 228-393, wired in cylinder_env_base.py:280-300), kept as data so the native driver can run it
         self.outflow = outflow

@@ -358,8 +358,14 @@ typedef struct fg_mb_step_options {
 } fg_mb_step_options;
 /* dt_B: device array [B]; dt <= 0 leaves that env untouched.  stats_host (optional, 4 ints): max iterations of
  * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
- * solve failed (fields still updated, as with returnBestResult), other negative codes on errors. */
+ * solve failed (unconverged: fields updated from the best iterate, as with returnBestResult; non-finite: the envs concerned
+ * are left as they were, see fg_mb_env_status), other negative codes on errors. */
 int fg_mb_piso_step(fg_mb_handle h, const float* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream);
+/* Per-env outcome of the last fg_mb_piso_step / fg_mb_single_step, host array [B]: 0 ok; 1 a solve of the batch ended
+ * unconverged (best iterate used, returnBestResult); 2 a solve of THIS env was non-finite -- its step was not committed
+ * (velocity as before the step, like solve_ok=False before CopyVelocityResultToBlocks, PISOtorch_simulation.py:1752-1757,
+ * and Simulation.single_step -> False, simulation.py:259-280) while the other envs of the batch completed. */
+int fg_mb_env_status(fg_mb_handle h, int32_t* out_B_host);
 /* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps
  * (_PISO_adaptive_step, PISOtorch_simulation.py:2004-2064), the advective-outflow PRE hook on ONE FIXED face given as
  * a range of boundary slots (update_advective_boundaries + balance_boundary_fluxes, :188-393; count 0 = none) and

@@ -207,3 +207,38 @@ def test_all_cross_terms_on_the_right_hand_side_mode(spec_fn):
         assert _rel(u_gpu[b], u_ref) < 1e-3, (spec_fn.__name__, b)
         assert _rel(p_gpu[b], p_ref) < 5e-3, (spec_fn.__name__, b)
     dom.close()
+
+
+def test_non_finite_solve_drops_only_that_env_and_leaves_its_state_intact():
+    """A non-finite velocity solve in ONE env of a batch (here forced through a NaN in its velocity source): the reference
+    returns solve_ok=False before CopyVelocityResultToBlocks (PISOtorch_simulation.py:1752-1757) and Simulation.single_step
+    returns False with the state intact (simulation.py:259-280).  Batched: that env keeps its pre-step state and is
+    reported with status 2, the other env completes exactly as it does alone; nothing raises."""
+    from fluidgym_amd.simulation.multiblock import MultiBlockSimulation
+
+    spec = H.split_rotated_channel()
+    d = spec.oracle()
+    u0, p0 = _state(d, 3)
+    u1, p1 = _state(d, 4)
+    # env 0 alone
+    ref = spec.native(batch=1)
+    _load(ref, [(u0, p0)])
+    sim_ref = MultiBlockSimulation(ref, dt=0.05, substeps=2, pressure_tol=1e-6, advection_tol=1e-6)
+    assert sim_ref.single_step()
+    u_ref = ref.velocity[0].cpu().numpy().copy()
+    ref.close()
+    dom = spec.native(batch=2)
+    _load(dom, [(u0, p0), (u1, p1)])
+    src = torch.zeros(2, d.d, d.N, device=dom.device)
+    src[1, 0, d.N // 2] = float("nan")
+    dom.set_velocity_source(src)
+    before = dom.velocity[1].cpu().numpy().copy()
+    sim = MultiBlockSimulation(dom, dt=0.05, substeps=2, pressure_tol=1e-6, advection_tol=1e-6)
+    ok = sim.single_step()
+    assert ok is False
+    assert sim.last_env_status.tolist() == [0, 2]
+    after = dom.velocity.cpu().numpy()
+    assert np.isfinite(after).all()
+    assert np.array_equal(after[1], before)              # not committed
+    assert _rel(after[0], u_ref) < 1e-5                   # the healthy env is not disturbed by its neighbour in the batch
+    dom.close()

@@ -50,10 +50,13 @@ class ToyEnv:
     def step(self, action):
         assert action.shape == (self._num_envs, 3)
         self.state = self.state + self.gain * action
-        return self._obs(), self.state.sum(dim=1), False, False, {"m": self.state.mean(dim=1)}
+        # env 0 of every shard "terminates" once its state sum exceeds 5: per-env flags must survive the gather
+        term = self.state.sum(dim=1) > 5.0
+        return self._obs(), self.state.sum(dim=1), term, False, {"m": self.state.mean(dim=1), "v": self.state[:, :2]}
 
     def sample_action(self):
-        return torch.zeros(self._num_envs, 3)
+        g = torch.Generator().manual_seed(self._seed)
+        return torch.rand(self._num_envs, 3, generator=g)
 
     def train(self):
         self.mode = "train"
@@ -65,6 +68,7 @@ class ToyEnv:
         self.mode = "test"
 
     def load_initial_domain(self, idx, mode=None):
+        self.loaded = (idx, mode)
         self.reset(seed=1000 + idx)
 
     def close(self):
@@ -97,20 +101,27 @@ def _worker(rank, world, port, mode, q):
     actions = torch.arange(12, dtype=torch.float32).reshape(4, 3) * 0.1
     if mode == "serve" and not penv.is_driver:
         penv.serve()
-        q.put((rank, "served", penv.local_env.mode))
+        q.put((rank, "served", penv.local_env.mode, penv.local_env.loaded))
         return
+    from fluidgym_amd.types import EnvMode
+
     penv.seed(5)
-    obs0, _ = penv.reset(seed=11)
+    sampled = penv.sample_action()          # a collective: hung in serve() mode before the command existed
+    penv.load_initial_domain(3, EnvMode.TEST)
+    loaded = penv.local_env.loaded
+    obs0, infos0 = penv.reset(seed=11)
     penv.val()
     out = penv.step(actions if penv.is_driver else None)
     out2 = penv.step(actions * 2 if penv.is_driver else None)
     mode_seen = penv.local_env.mode
     penv.close()
     if penv.is_driver:
+        extra = {"sampled": sampled.numpy().copy(), "loaded": loaded, "n_infos0": len(infos0), "term2": out2[2], "trunc2": out2[3],
+                 "info_m": np.array([float(i["m"]) for i in out2[4]]), "info_v": np.stack([i["v"].numpy() for i in out2[4]])}
         q.put((rank, {k: v.numpy().copy() for k, v in obs0.items()}, out[1].numpy().copy(), out2[1].numpy().copy(),
-               {k: v.numpy().copy() for k, v in out2[0].items()}, mode_seen))
+               {k: v.numpy().copy() for k, v in out2[0].items()}, mode_seen, extra))
     else:
-        q.put((rank, "spmd", mode_seen))
+        q.put((rank, "spmd", mode_seen, loaded))
 
 
 def _expected():
@@ -120,7 +131,15 @@ def _expected():
     r1 = [e.step(actions[2 * r: 2 * r + 2])[1] for r, e in enumerate(envs)]
     o2r2 = [e.step(2 * actions[2 * r: 2 * r + 2]) for r, e in enumerate(envs)]
     cat = lambda ds: {k: torch.cat([d[k] for d in ds]) for k in ds[0]}
-    return cat(obs0), torch.cat(r1), torch.cat([x[1] for x in o2r2]), cat([x[0] for x in o2r2])
+    extra = {"term2": torch.cat([x[2] for x in o2r2]).tolist(), "info_m": torch.cat([x[4]["m"] for x in o2r2]).numpy(),
+             "info_v": torch.cat([x[4]["v"] for x in o2r2]).numpy()}
+    samp = []
+    for r in range(2):
+        e = ToyEnv(num_envs=2)
+        e.seed(5 + r)
+        samp.append(e.sample_action())
+    extra["sampled"] = torch.cat(samp).numpy()
+    return cat(obs0), torch.cat(r1), torch.cat([x[1] for x in o2r2]), cat([x[0] for x in o2r2]), extra
 
 
 @pytest.mark.parametrize("mode", ["spmd", "serve"])
@@ -137,12 +156,20 @@ def test_two_rank_gloo_matches_single_process(mode):
         assert p.exitcode == 0
     drv = [r for r in results if r[0] == 0][0]
     other = [r for r in results if r[0] == 1][0]
-    obs0, r1, r2, o2 = _expected()
+    obs0, r1, r2, o2, exp = _expected()
     for k in obs0:
         assert np.allclose(drv[1][k], obs0[k].numpy())
         assert np.allclose(drv[4][k], o2[k].numpy())
     assert np.allclose(drv[2], r1.numpy()) and np.allclose(drv[3], r2.numpy())
     assert drv[5] == "val" and other[2] == "val"  # mode command reached every shard
+    got = drv[6]
+    # per-env terminated flags and info entries of EVERY shard (reference parallel_env.py:276-287), not the driver's copy
+    assert got["term2"] == exp["term2"] and any(got["term2"]) and not all(got["term2"])
+    assert got["trunc2"] == [False] * 4 and got["n_infos0"] == 4
+    assert np.allclose(got["info_m"], exp["info_m"]) and np.allclose(got["info_v"], exp["info_v"])
+    assert np.allclose(got["sampled"], exp["sampled"])           # each shard sampled from its own generator (seed + rank)
+    from fluidgym_amd.types import EnvMode
+    assert got["loaded"] == (3 * 2 + 0, EnvMode.TEST) and other[3] == (3 * 2 + 1, EnvMode.TEST)   # idx and MODE reach the workers
 
 
 def test_single_process_world_of_one():
@@ -219,3 +246,81 @@ def test_multi_agent_rows_follow_the_reference_aggregation():
     with pytest.raises(ValueError, match="Expected action batch size"):
         penv.step(torch.zeros(4, 3))
     penv.close()
+
+
+# ---- a REAL registry env (ChannelJet2D: action smoothing, jets -> boundary data, sensors, reward, Simulation driver) with the
+# solver stubbed at its boundary (tests/stub_solver.py), sharded over two gloo ranks and compared with one 4-env process
+def _stub_env_patches():
+    import fluidgym_amd.simulation.domain as D
+    from tests.stub_solver import StubSolver
+
+    D.NativeSolver = StubSolver
+    torch.cuda.is_available = lambda: True   # FluidEnv.reset's "FluidGym requires CUDA" guard; nothing here touches a GPU
+
+
+_STUB_KW = dict(cuda_device="cpu", randomize_initial_state=False, resolution_x=32, resolution_y=16, step_length=0.05)
+
+
+def _stub_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _stub_env_patches()
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    penv = ParallelFluidEnv("ChannelJet2D-v0", num_envs=4, backend="gloo", **_STUB_KW)
+    if not penv.is_driver:
+        penv.serve()
+        q.put((rank, penv.local_env._sim is None))
+        return
+    obs0, _ = penv.reset(seed=3)
+    g = torch.Generator().manual_seed(0)
+    outs = []
+    for _ in range(3):
+        a = torch.rand(4, 1, generator=g) * 2 - 1
+        o, r, term, trunc, info = penv.step(a)
+        outs.append(({k: v.numpy().copy() for k, v in o.items()}, r.numpy().copy(), term, trunc,
+                     np.array([float(i["wall_shear"]) for i in info])))
+    penv.close()
+    q.put((rank, {k: v.numpy().copy() for k, v in obs0.items()}, outs))
+
+
+def test_real_env_with_stubbed_solver_sharded_over_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stub_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    drv = [r for r in results if r[0] == 0][0]
+    # single process, the same four envs in one batch
+    real_avail = torch.cuda.is_available
+    import fluidgym_amd.simulation.domain as D
+    real_solver = D.NativeSolver
+    try:
+        _stub_env_patches()
+        import fluidgym_amd
+
+        env = fluidgym_amd.make("ChannelJet2D-v0", num_envs=4, **_STUB_KW)
+        obs0, _ = env.reset(seed=3)
+        for k in obs0:
+            assert np.allclose(drv[1][k], obs0[k].numpy())
+        g = torch.Generator().manual_seed(0)
+        for step in range(3):
+            a = torch.rand(4, 1, generator=g) * 2 - 1
+            o, r, term, trunc, info = env.step(a)
+            po, pr, pterm, ptrunc, pshear = drv[2][step]
+            for k in o:
+                assert np.allclose(po[k], o[k].numpy(), atol=1e-6), k
+            assert np.allclose(pr, r.numpy(), atol=1e-6)
+            assert pterm == [bool(term)] * 4 and ptrunc == [bool(trunc)] * 4
+            assert np.allclose(pshear, info["wall_shear"].numpy(), atol=1e-6)
+        assert np.abs(drv[2][2][1]).max() > 0   # the actions reached the boundary data and the reward saw them
+        env.close()
+    finally:
+        torch.cuda.is_available = real_avail
+        D.NativeSolver = real_solver
