@@ -190,6 +190,7 @@ SIGNATURES = {
     "fg_mb_set_residual_projection": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_mb_set_stall_limit": (c_int, [c_void_p, c_int32]),
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),
+    "fg_mb_profile_iterations": (c_int, [c_void_p, POINTER(c_int64)]),
     "fg_mb_unit_pressure_matrix": (c_int, [c_void_p, c_void_p]),
     "fg_mb_profile_enable": (c_int, [c_void_p, c_int32]),
     "fg_mb_profile_kind_name": (c_char_p, [c_int32]),

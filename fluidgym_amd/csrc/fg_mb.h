@@ -95,12 +95,16 @@ struct fg_mb_state {
     int32_t* flags_pinned = nullptr;
     fg_solve_info *info_dev, *info_pinned = nullptr;
     float* yproj = nullptr;
+    // on-chip CG (fg_mb_step.hip::k_mbc_onchip): neighbour table packed to 16 bits per face, [F/2][N] words (low half = even
+    // face, high half = odd face, 0xFFFF = prescribed face); built when N < 65535
+    uint32_t* nbr16 = nullptr;
+    int onchip_mode = 1;       // FG_MB_ONCHIP: 0 never, 1 when the mesh fits one workgroup's LDS / registers (default)
     double* x64_best = nullptr; float* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
     double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2)
     // debug switches, read ONCE from the environment at fg_mb_create (never on the step path): FG_MB_BICG_VEC4 (per-kernel mask
     // of the four-cell BiCGStab kernels: 1 p, 2 v, 4 s, 8 t, 16 x; + 64 = pressure solves only), FG_MB_SCALAR_CG=1 (one-cell
     // CG kernels), FG_MB_GRAPH (CG chunks replayed as a hipGraph), FG_MB_TRACE (residual trace on stderr)
-    int dbg_vec_mask = 0, dbg_scalar_cg = 0, dbg_graph = 0, dbg_trace = 0;
+    int dbg_vec_mask = 0, dbg_scalar_cg = 0, dbg_graph = 0, dbg_trace = 0, dbg_fail = 0;   // dbg_fail: FG_MB_TRACE_FAIL
     // per-env outcome of the last fg_mb_piso_step / fg_mb_single_step: 0 ok, 1 a solve ended unconverged (best iterate used),
     // 2 a solve was non-finite: that env's step was NOT committed (state as before the step), the other envs completed
     float* dt_step = nullptr;          // [B] working copy of the caller's dt; failed envs are masked out (dt = 0) in it
@@ -118,8 +122,10 @@ struct fg_mb_state {
     int prof_on = 0, prof_used = 0, prof_chunk = 0;
     hipEvent_t prof_ev[2 * 32] = {nullptr};
     int prof_kind[32] = {0}, prof_active[32] = {0};
-    double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0};
-    long long prof_n[2] = {0, 0}, prof_launches[2] = {0, 0};
+    // kind 0 / 1: the chunked CG's kernel pair; kind 2: the on-chip CG (one launch per solve; prof_its = its iterations)
+    double prof_ms[3] = {0, 0, 0}, prof_bytes[3] = {0, 0, 0};
+    long long prof_n[3] = {0, 0, 0}, prof_launches[3] = {0, 0, 0}, prof_its = 0;
+    hipEvent_t prof_ev_oc[2] = {nullptr, nullptr};
     std::string err;
 };
 

@@ -1105,6 +1105,220 @@ __global__ void k_mbs_restore_best(int N, MbSolve q) {
     if (i == 0) { q.info[sys].final_residual = q.sc[sys * 2]; q.info[sys].used_iterations = q.best_it[sys]; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// On-chip CG: ONE workgroup of 1024 threads runs the WHOLE pressure solve of one env.  The cylinder meshes have 14-25 k
+// cells; at that size a CG iteration of the two-kernel form above lasts as long as its launches and streams the
+// five matrix fields plus five vectors of every env through the memory system every iteration.  Here the solver state of
+// an env lives in the CU: r, x, P p (and the matrix diagonal) in registers -- CPT cells per thread, cell i = thread + k 1024,
+// so global accesses coalesce and LDS accesses are conflict-free -- and the search direction p in LDS, where the
+// neighbour gathers of the stencil hit it.  What still streams per iteration is the off-diagonal part of the matrix (4 B
+// per face and cell, from L2 / Infinity Cache) and the packed neighbour table (2 B per face and cell, shared by all envs).
+// No kernel launches, no device-scope atomics, no host polls inside a solve: envs are independent, so are the workgroups.
+// Same recurrence, same projection of the residual, same restart / best-iterate / stall rules as mb_cg's kernels; only
+// the summation order of the dot products differs (per-thread partials, wave shuffle, 16 wave sums added in fp64).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int OC_THREADS = 1024, OC_WAVES = OC_THREADS / 64;
+
+struct OcParams {
+    const uint32_t* nbr16;   // [F/2][N]
+    const float* dt;         // [B] or null
+    const float* yp;         // [N] projection vector (PM == 2)
+    int use_x0, project_mean, restart_every, check_every, max_iterations, stall_limit, accept_window;
+    float accept_factor, tol;
+};
+
+__device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[OC_WAVES], double& A, double& B) {
+    a = fg_wave_sum(a);
+    b = fg_wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = (double)a; red[1][threadIdx.x >> 6] = (double)b; }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int w = 0; w < OC_WAVES; ++w) { sa += red[0][w]; sb += red[1][w]; }
+    __syncthreads();
+    A = sa; B = sb;
+}
+
+// y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory
+template <int DIMS, int CPT, bool DG_REGS>
+__device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int sys, int N, const float* __restrict__ v_lds,
+                                        const float (&dg)[CPT], float (&y)[CPT]) {
+    constexpr int F = 2 * DIMS;
+    const float* off = q.off + (size_t)sys * F * N;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int i = threadIdx.x + k * OC_THREADS;
+        float acc = 0.f;
+        if (i < N) {
+            acc = (DG_REGS ? dg[k] : q.diag[(size_t)sys * N + i]) * v_lds[i];
+#pragma unroll
+            for (int w = 0; w < DIMS; ++w) {
+                const uint32_t u = o.nbr16[(size_t)w * N + i];
+                const uint32_t n0 = u & 0xffffu, n1 = u >> 16;
+                const float c0 = off[(size_t)(2 * w) * N + i], c1 = off[(size_t)(2 * w + 1) * N + i];
+                // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
+                const float v0 = v_lds[n0 != 0xffffu ? n0 : (uint32_t)i], v1 = v_lds[n1 != 0xffffu ? n1 : (uint32_t)i];
+                acc += n0 != 0xffffu ? c0 * v0 : 0.f;
+                acc += n1 != 0xffffu ? c1 * v1 : 0.f;
+            }
+        }
+        y[k] = acc;
+    }
+}
+
+template <int DIMS, int CPT, int PM, bool DG_REGS>
+__global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
+    __shared__ float v_lds[CPT * OC_THREADS];
+    __shared__ double red[2][OC_WAVES];
+    const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
+    const size_t vb = (size_t)sys * N;
+    if (!mb_active(o.dt, sys)) {
+        if (t == 0) {
+            q.flags[sys] = 3;
+            q.info[sys].final_residual = 0.f; q.info[sys].used_iterations = -1; q.info[sys].converged = 1; q.info[sys].is_finite = 1;
+        }
+        return;
+    }
+    float r[CPT], x[CPT], ap[CPT], dg[CPT];
+    const float rsqn = rsqrtf((float)N);
+    // ---- start: x = x0 or 0, r = rhs - M x0
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int i = t + k * OC_THREADS;
+        x[k] = (i < N && o.use_x0) ? q.x[vb + i] : 0.f;
+        r[k] = i < N ? q.rhs[vb + i] : 0.f;
+        dg[k] = (DG_REGS && i < N) ? q.diag[vb + i] : 0.f;
+        ap[k] = 0.f;
+    }
+    double rr = 0.0, sr = 0.0;
+    // true residual r = rhs - M x (start from x0, restarts, recoveries); leaves rr = |r|^2 and sr = yp . r
+    auto true_residual = [&]() {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const int i = t + k * OC_THREADS; if (i < N) v_lds[i] = x[k]; }
+        __syncthreads();
+        oc_spmv<DIMS, CPT, DG_REGS>(q, o, sys, N, v_lds, dg, ap);
+        float s2 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int i = t + k * OC_THREADS;
+            if (i < N) {
+                r[k] = q.rhs[vb + i] - ap[k];
+                s2 += r[k] * r[k];
+                s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
+            }
+        }
+        oc_reduce2(s2, s1, red, rr, sr);   // its barriers also separate the reads of v_lds from the next writes
+    };
+    if (o.use_x0) {
+        true_residual();
+    } else {
+        float s2 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int i = t + k * OC_THREADS;
+            if (i < N) { s2 += r[k] * r[k]; s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn); }
+        }
+        oc_reduce2(s2, s1, red, rr, sr);
+    }
+    if (PM == 0) sr = 0.0;
+    int it = 0, best_it = 0, recoveries = 0, outcome = 0;   // outcome: 1 converged, 2 non-finite, 3 accepted on the kept iterate, 4 out of iterations / stalled
+    float best = 3.0e38f, crit = 0.f;
+    bool fresh = true, restarted = true;
+    double rho_prev = 1.0;
+    for (;;) {
+        const double rho = rr - sr * sr;   // |r - (yp.r) yp|^2
+        crit = mb_rms(rho, N);
+        if (!(crit >= o.tol)) {
+            if (isfinite(crit)) { outcome = 1; break; }
+            // the recurrence broke down (p.Pp <= 0 or overflow on the non-symmetric matrix): back to the kept iterate
+            if (recoveries < 3 && it + o.check_every < o.max_iterations) {
+                ++recoveries;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int i = t + k * OC_THREADS;
+                    if (i < N) { const float v = q.best_x[vb + i]; x[k] = isfinite(v) ? v : 0.f; }
+                }
+                true_residual();
+                if (PM == 0) sr = 0.0;
+                fresh = true; restarted = true;
+                if (!isfinite(mb_rms(rr - sr * sr, N))) { outcome = 2; break; }
+                continue;
+            }
+            outcome = 2; break;
+        }
+        // keep x_it when it beats the kept iterate by 2x (or at all inside the acceptance band): returnBestResult
+        if (it == 0 || crit < 0.5f * best || (crit < o.accept_factor * o.tol && crit < best)) {
+            best = crit; best_it = it;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) { const int i = t + k * OC_THREADS; if (i < N) q.best_x[vb + i] = x[k]; }
+        }
+        if (it > 0 && it % o.check_every == 0) {   // the cadence of k_mbs_check in the chunked solver
+            if (o.accept_factor > 0.f && best <= o.accept_factor * o.tol && (it - 1) - best_it >= o.accept_window) { outcome = 3; break; }
+            if (o.stall_limit > 0 && (it - 1) - best_it > o.stall_limit) { outcome = 4; break; }
+        }
+        if (it >= o.max_iterations) { outcome = 4; break; }
+        if (it > 0 && it % o.restart_every == 0 && !restarted) {   // residualResetSteps (cg_solver_kernel.cu:281-300)
+            true_residual();
+            if (PM == 0) sr = 0.0;
+            fresh = true; restarted = true;
+            continue;
+        }
+        restarted = false;
+        const float beta = fresh ? 0.f : (float)(rho / rho_prev);
+        const float cy = (float)sr;
+        // p = (r - (yp.r) yp) + beta p: every thread rewrites its own cells of the LDS vector
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int i = t + k * OC_THREADS;
+            if (i < N) {
+                float v = PM == 0 ? r[k] : (PM == 1 ? r[k] - cy * rsqn : r[k] - cy * o.yp[i]);
+                if (!fresh) v += beta * v_lds[i];
+                v_lds[i] = v;
+            }
+        }
+        __syncthreads();
+        oc_spmv<DIMS, CPT, DG_REGS>(q, o, sys, N, v_lds, dg, ap);
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const int i = t + k * OC_THREADS; if (i < N) part += v_lds[i] * ap[k]; }
+        double pap, unused;
+        oc_reduce2(part, 0.f, red, pap, unused);
+        const float alpha = (float)(rho / pap);
+        float s2 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int i = t + k * OC_THREADS;
+            if (i < N) {
+                x[k] += alpha * v_lds[i];
+                r[k] -= alpha * ap[k];
+                s2 += r[k] * r[k];
+                s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
+            }
+        }
+        oc_reduce2(s2, s1, red, rr, sr);
+        if (PM == 0) sr = 0.0;
+        rho_prev = rho;
+        fresh = false;
+        ++it;
+    }
+    // ---- hand back: the last iterate when converged, the kept one otherwise (k_mbs_restore_best)
+    const bool use_best = (outcome == 3 || outcome == 4 || (outcome == 2 && best < 3.0e38f));
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int i = t + k * OC_THREADS;
+        if (i < N) q.x[vb + i] = use_best ? q.best_x[vb + i] : x[k];
+    }
+    if (t == 0) {
+        const bool finite = outcome != 2;
+        q.flags[sys] = outcome == 1 ? 1 : (outcome == 2 ? 2 : (outcome == 3 ? 5 : 1));
+        q.info[sys].final_residual = use_best ? best : crit;
+        q.info[sys].used_iterations = use_best ? best_it : it;
+        q.info[sys].converged = (outcome == 1 || outcome == 3) ? 1 : 0;
+        q.info[sys].is_finite = finite ? 1 : 0;
+        q.best_it[sys] = it;   // total iterations run (the host reports the maximum over the batch)
+    }
+}
+
 // ---- boundary bookkeeping of Simulation.single_step (simulation.py:206-280) on the flat boundary slots --------------
 // update_advective_boundaries (PISOtorch_simulation.py:228-393): u_b <- u_b - t (u_b - u_cell), t = 1 - 1/(1 + 2 dt Minv_b[axis].velm)
 template <int DIMS>
@@ -1235,7 +1449,8 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     if (refine && max_iterations > 1500) max_iterations = 1500;
     // Four-cells-per-thread kernels (k_mbb_*4): s->dbg_vec_mask selects them per kernel (FG_MB_BICG_VEC4, read at create).
     int vec_mask = (n % 4 != 0) ? 0 : s->dbg_vec_mask;
-    if (vec_mask >= 64) vec_mask = (nc == 1) ? (vec_mask & 31) : 0;   // + 64: pressure solves only (one system per env)
+    if (vec_mask & 128) vec_mask = (nc > 1) ? (vec_mask & 31) : 0;        // + 128: velocity solves only (d systems per env)
+    else if (vec_mask & 64) vec_mask = (nc == 1) ? (vec_mask & 31) : 0;   // + 64: pressure solves only (one system per env)
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     auto keep_best = [&](int first) {
         hipLaunchKernelGGL(k_mbr_best_decide, sg, sb, 0, st, q, s->best_res, s->best_keep, n, nsys, first);
@@ -1291,6 +1506,71 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
         FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
         FG_HIP_CHECK(hipStreamSynchronize(st));
     }
+    const int frc = mb_finish(s, nsys, nullptr, max_it);
+    if (frc == FG_ERR_NOT_FINITE && s->dbg_fail) {   // rare path, FG_MB_TRACE_FAIL only: the recurrence scalars of the systems that broke down
+        std::vector<double> acc((size_t)nsys * MB_ACC);
+        std::vector<float> sc((size_t)nsys * 2);
+        (void)hipMemcpy(acc.data(), s->acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sc.data(), s->sc, sc.size() * sizeof(float), hipMemcpyDeviceToHost);
+        for (int i = 0; i < nsys; ++i) {
+            if (s->info_pinned[i].is_finite) continue;
+            fprintf(stderr, "[mb_bicg] non-finite system %d (nc %d, vec_mask %d, project %d, refine %d): it %d residual %g alpha %g omega %g acc",
+                    i, nc, vec_mask, project, refine, (int)s->info_pinned[i].used_iterations, s->info_pinned[i].final_residual, sc[2 * i], sc[2 * i + 1]);
+            for (int k = 0; k < MB_ACC; ++k) fprintf(stderr, " %g", acc[(size_t)i * MB_ACC + k]);
+            fprintf(stderr, "\n");
+        }
+    }
+    return frc;
+}
+
+#define OC_LAUNCH(CPT_, PM_, DGR_)                                                                                             \
+    do {                                                                                                                       \
+        if (ev) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_onchip<2, CPT_, PM_, DGR_>), dim3(nsys), dim3(OC_THREADS), 0, st,   \
+                                      s->prof_ev_oc[0], s->prof_ev_oc[1], 0, s->dev, q, o);                                        \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_onchip<2, CPT_, PM_, DGR_>), dim3(nsys), dim3(OC_THREADS), 0, st, s->dev, q, o); \
+    } while (0)
+#define OC_LAUNCH_PM(CPT_, DGR_) do { if (pm_mode == 0) OC_LAUNCH(CPT_, 0, DGR_); else OC_LAUNCH(CPT_, 1, DGR_); } while (0)
+
+constexpr int OC_MAX_CELLS = 28 * OC_THREADS;
+
+bool mb_onchip_ok(const fg_mb_state* s, int pm_mode) {
+    return s->onchip_mode && s->d == 2 && s->nbr16 != nullptr && s->N <= OC_MAX_CELLS && pm_mode != 2;
+}
+
+// the whole CG solve of every env in one launch (k_mbc_onchip); same arguments and results as mb_cg
+int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
+                 int max_iterations, int use_x0, int pm_mode, float stall_accept, int* max_it, hipStream_t st) {
+    const int nsys = s->B, n = s->N;
+    MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);
+    q.best_x = s->w[4]; q.best_it = s->best_it;
+    constexpr int CG_CHUNK = 20, CG_RESTART = 100;
+    OcParams o;
+    o.nbr16 = s->nbr16; o.dt = dt; o.yp = s->dev.yproj;
+    o.use_x0 = use_x0; o.project_mean = pm_mode; o.restart_every = CG_RESTART; o.check_every = CG_CHUNK;
+    o.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
+    o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
+    o.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; o.tol = tol;
+    const bool ev = s->prof_on != 0;
+    if (n <= 4 * OC_THREADS) OC_LAUNCH_PM(4, true);
+    else if (n <= 8 * OC_THREADS) OC_LAUNCH_PM(8, true);
+    else if (n <= 16 * OC_THREADS) OC_LAUNCH_PM(16, true);
+    else if (n <= 24 * OC_THREADS) OC_LAUNCH_PM(24, false);
+    else OC_LAUNCH_PM(28, false);
+    FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->best_it, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));  // iterations run
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    if (ev) {
+        float ms = 0.f;
+        FG_HIP_CHECK(hipEventElapsedTime(&ms, s->prof_ev_oc[0], s->prof_ev_oc[1]));
+        long long its = 0;
+        for (int i = 0; i < nsys; ++i) its += s->flags_pinned[i] > 0 ? s->flags_pinned[i] : 0;
+        // bytes the kernel streams: per iteration and cell the off-diagonals (4 F) and the packed neighbour table (2 F);
+        // per solve and cell rhs, x0 / x, diagonal, kept iterate (about 20 B)
+        s->prof_ms[2] += ms;
+        s->prof_bytes[2] += (double)its * n * (6.0 * s->F) + (double)nsys * n * 20.0;
+        s->prof_n[2] += 1; s->prof_launches[2] += 1;
+        s->prof_its += its;
+    }
     return mb_finish(s, nsys, nullptr, max_it);
 }
 
@@ -1301,6 +1581,10 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
 int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
           int max_iterations, int use_x0, int project_mean, float stall_accept, int* max_it, hipStream_t st) {
     const int nsys = s->B, n = s->N;
+    {
+        const int pm = project_mean ? (s->yproj_const ? 1 : 2) : 0;
+        if (mb_onchip_ok(s, pm)) return mb_cg_onchip(s, dt, diag, off, rhs, x, tol, max_iterations, use_x0, pm, stall_accept, max_it, st);
+    }
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);
     q.rw = nullptr;
     q.best_x = s->w[4]; q.best_it = s->best_it; q.stall_limit = s->cg_stall_limit;
@@ -1465,6 +1749,8 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
+        s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
+        e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
     }
     *out = s;
     return FG_OK;
@@ -1474,6 +1760,7 @@ extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (!s) return FG_OK;
     if (s->cg_graph_exec) (void)hipGraphExecDestroy(s->cg_graph_exec);
     if (s->prof_ev[0]) for (int k = 0; k < 64; ++k) (void)hipEventDestroy(s->prof_ev[k]);
+    if (s->prof_ev_oc[0]) for (int k = 0; k < 2; ++k) (void)hipEventDestroy(s->prof_ev_oc[k]);
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->info_pinned) (void)hipHostFree(s->info_pinned);
@@ -1606,6 +1893,16 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->x64_best, B * N)) return rc;
     if (int rc = mb_alloc(s, &s->best_res, B)) return rc;
     if (int rc = mb_alloc(s, &s->best_keep, B)) return rc;
+    if (N < 65535) {   // packed neighbour table of the on-chip CG
+        std::vector<uint32_t> packed((size_t)(F / 2) * N);
+        for (size_t w = 0; w < F / 2; ++w)
+            for (size_t i = 0; i < N; ++i) {
+                const int32_t n0 = s->h_nbr[(2 * w) * N + i], n1 = s->h_nbr[(2 * w + 1) * N + i];
+                packed[w * N + i] = (uint32_t)(n0 >= 0 ? n0 : 0xffff) | ((uint32_t)(n1 >= 0 ? n1 : 0xffff) << 16);
+            }
+        if (int rc = mb_alloc(s, &s->nbr16, packed.size())) return rc;
+        FG_HIP_CHECK(hipMemcpy(s->nbr16, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice));
+    }
     s->env_status.assign(B, 0);
     FG_HIP_CHECK(hipHostMalloc((void**)&s->env_fail_pinned, sizeof(int32_t) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
@@ -1985,16 +2282,25 @@ extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
 extern "C" int fg_mb_profile_enable(fg_mb_handle s, int32_t on) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_profile_enable: domain not finalized");
     FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_profile_enable: host-only handle");
-    if (on && !s->prof_ev[0])
+    if (on && !s->prof_ev[0]) {
         for (int k = 0; k < 64; ++k) FG_HIP_CHECK(hipEventCreate(&s->prof_ev[k]));
+        for (int k = 0; k < 2; ++k) FG_HIP_CHECK(hipEventCreate(&s->prof_ev_oc[k]));
+    }
     s->prof_on = on ? 1 : 0;
-    s->prof_used = 0; s->prof_chunk = 0;
-    for (int k = 0; k < 2; ++k) { s->prof_ms[k] = 0; s->prof_bytes[k] = 0; s->prof_n[k] = 0; s->prof_launches[k] = 0; }
+    s->prof_used = 0; s->prof_chunk = 0; s->prof_its = 0;
+    for (int k = 0; k < 3; ++k) { s->prof_ms[k] = 0; s->prof_bytes[k] = 0; s->prof_n[k] = 0; s->prof_launches[k] = 0; }
     return FG_OK;
 }
-extern "C" const char* fg_mb_profile_kind_name(int32_t kind) { return kind == 0 ? "k_mbc_ap" : (kind == 1 ? "k_mbc_update" : nullptr); }
+extern "C" const char* fg_mb_profile_kind_name(int32_t kind) {
+    return kind == 0 ? "k_mbc_ap" : (kind == 1 ? "k_mbc_update" : (kind == 2 ? "k_mbc_onchip" : nullptr));
+}
+extern "C" int fg_mb_profile_iterations(fg_mb_handle s, int64_t* iterations) {
+    FG_REQUIRE(s && iterations, FG_ERR_INVALID_ARG, "fg_mb_profile_iterations: bad argument");
+    *iterations = s->prof_its;
+    return FG_OK;
+}
 extern "C" int fg_mb_profile_read(fg_mb_handle s, int32_t kind, double* ms_sum, int64_t* samples, double* bytes_sum, int64_t* launches) {
-    FG_REQUIRE(s && kind >= 0 && kind < 2, FG_ERR_INVALID_ARG, "fg_mb_profile_read: bad argument");
+    FG_REQUIRE(s && kind >= 0 && kind < 3, FG_ERR_INVALID_ARG, "fg_mb_profile_read: bad argument");
     if (ms_sum) *ms_sum = s->prof_ms[kind];
     if (samples) *samples = s->prof_n[kind];
     if (bytes_sum) *bytes_sum = s->prof_bytes[kind];

@@ -381,13 +381,16 @@ class MultiBlockDomain:
 
     def profile_read(self) -> dict:
         out = {}
-        for kind in range(2):
+        for kind in range(3):
             ms, nb = ctypes.c_double(), ctypes.c_double()
             n, launches = ctypes.c_int64(), ctypes.c_int64()
             L.check(self.lib.fg_mb_profile_read(self.handle, kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(nb),
                                                 ctypes.byref(launches)))
             out[self.lib.fg_mb_profile_kind_name(kind).decode()] = {"ms": ms.value, "samples": n.value, "bytes": nb.value,
                                                                     "launches": launches.value}
+        its = ctypes.c_int64()
+        L.check(self.lib.fg_mb_profile_iterations(self.handle, ctypes.byref(its)))
+        out["k_mbc_onchip"]["iterations"] = its.value
         return out
 
     # ---- what FluidEnv needs of a Domain

@@ -415,6 +415,10 @@ int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 int fg_mb_profile_enable(fg_mb_handle h, int32_t on);
 const char* fg_mb_profile_kind_name(int32_t kind);
 int fg_mb_profile_read(fg_mb_handle h, int32_t kind, double* ms_sum, int64_t* samples, double* bytes_sum, int64_t* launches);
+/* kind 2 = k_mbc_onchip, the CG that runs a whole solve of one env inside one workgroup (meshes up to 28 672 cells, 2-D):
+ * every launch is timed; bytes = what it streams from L2 / Infinity Cache (off-diagonals + packed neighbour table per
+ * iteration and cell); fg_mb_profile_iterations = CG iterations summed over envs and solves since enable */
+int fg_mb_profile_iterations(fg_mb_handle h, int64_t* iterations);
 #define FG_MB_BUF_A 0               /* [B,N]   diagonal of C */
 #define FG_MB_BUF_C_OFF 1           /* [B,2d,N] */
 #define FG_MB_BUF_RHS 2             /* [B,d,N] velocity right-hand side of the last solve */

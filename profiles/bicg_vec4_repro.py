@@ -30,6 +30,7 @@ from fluidgym_amd import _lib as L  # noqa: E402
 summary = {}
 for mask in masks:
     os.environ["FG_MB_BICG_VEC4"] = str(mask)     # read once per handle at fg_mb_create
+    os.environ["FG_MB_TRACE_FAIL"] = "1"          # recurrence scalars of a system that breaks down, on stderr
     fails = 0
     for rep in range(reps):
         env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=B, initial_domain_steps=0, randomize_initial_state=False)
@@ -45,8 +46,9 @@ for mask in masks:
                 if first_fail is None:
                     st = sim.last_env_status
                     bad = int(np.nonzero(st == 2)[0][0])
+                    msg = L.load().fg_last_error()
                     first_fail = {"step": step, "envs": np.nonzero(st == 2)[0].tolist(), "iterations": list(sim.last_iterations),
-                                  "substeps": sim.last_substeps}
+                                  "substeps": sim.last_substeps, "last_error": msg.decode() if msg else ""}
                     N, d = dom.n_cells, dom.dims
                     np.savez_compressed(
                         os.path.join(out_dir, f"bicg_fail_{mask}_{rep}.npz"),
