@@ -1139,30 +1139,37 @@ __device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[OC_WA
     A = sa; B = sb;
 }
 
-// y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory
+// y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory.
+// Addresses are (uniform base pointer) + (32-bit cell index): 64-bit per-cell addresses are loop invariants of the CG loop,
+// get hoisted out of it and cost hundreds of spilled registers.
 template <int DIMS, int CPT, bool DG_REGS>
-__device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int sys, int N, const float* __restrict__ v_lds,
+__device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int sys, int N, unsigned tl, const float* __restrict__ v_lds,
                                         const float (&dg)[CPT], float (&y)[CPT]) {
     constexpr int F = 2 * DIMS;
-    const float* off = q.off + (size_t)sys * F * N;
+    const float* __restrict__ off = q.off + (size_t)sys * F * N;
+    const float* __restrict__ diag = q.diag + (size_t)sys * N;
+    const uint32_t* __restrict__ nb = o.nbr16;
+    const unsigned un = (unsigned)N;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int i = threadIdx.x + k * OC_THREADS;
+        const unsigned i = tl + (unsigned)k * OC_THREADS;
         float acc = 0.f;
-        if (i < N) {
-            acc = (DG_REGS ? dg[k] : q.diag[(size_t)sys * N + i]) * v_lds[i];
+        if (i < un) {
+            acc = (DG_REGS ? dg[k] : diag[i]) * v_lds[i];
 #pragma unroll
             for (int w = 0; w < DIMS; ++w) {
-                const uint32_t u = o.nbr16[(size_t)w * N + i];
+                const uint32_t u = nb[(unsigned)w * un + i];
                 const uint32_t n0 = u & 0xffffu, n1 = u >> 16;
-                const float c0 = off[(size_t)(2 * w) * N + i], c1 = off[(size_t)(2 * w + 1) * N + i];
+                const float c0 = off[(unsigned)(2 * w) * un + i], c1 = off[(unsigned)(2 * w + 1) * un + i];
                 // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
-                const float v0 = v_lds[n0 != 0xffffu ? n0 : (uint32_t)i], v1 = v_lds[n1 != 0xffffu ? n1 : (uint32_t)i];
+                const float v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
                 acc += n0 != 0xffffu ? c0 * v0 : 0.f;
                 acc += n1 != 0xffffu ? c1 * v1 : 0.f;
             }
         }
         y[k] = acc;
+        // at most four cells' loads in flight (24 registers): left alone, the scheduler issues all CPT x 6 loads first
+        if ((k & 3) == 3) asm volatile("" ::: "memory");
     }
 }
 
@@ -1181,114 +1188,117 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
     }
     float r[CPT], x[CPT], ap[CPT], dg[CPT];
     const float rsqn = rsqrtf((float)N);
-    // ---- start: x = x0 or 0, r = rhs - M x0
+    const float* __restrict__ rhs = q.rhs + vb;
+    float* __restrict__ bestx = q.best_x + vb;
+    // ---- start: x = x0 or 0, r = rhs (- M x0 through a residual pass)
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int i = t + k * OC_THREADS;
-        x[k] = (i < N && o.use_x0) ? q.x[vb + i] : 0.f;
-        r[k] = i < N ? q.rhs[vb + i] : 0.f;
-        dg[k] = (DG_REGS && i < N) ? q.diag[vb + i] : 0.f;
+        const unsigned i = t + (unsigned)k * OC_THREADS;
+        x[k] = (i < (unsigned)N && o.use_x0) ? q.x[vb + i] : 0.f;
+        r[k] = i < (unsigned)N ? rhs[i] : 0.f;
+        dg[k] = (DG_REGS && i < (unsigned)N) ? q.diag[vb + i] : 0.f;
         ap[k] = 0.f;
     }
     double rr = 0.0, sr = 0.0;
-    // true residual r = rhs - M x (start from x0, restarts, recoveries); leaves rr = |r|^2 and sr = yp . r
-    auto true_residual = [&]() {
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) { const int i = t + k * OC_THREADS; if (i < N) v_lds[i] = x[k]; }
-        __syncthreads();
-        oc_spmv<DIMS, CPT, DG_REGS>(q, o, sys, N, v_lds, dg, ap);
+    if (!o.use_x0) {
         float s2 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const int i = t + k * OC_THREADS;
-            if (i < N) {
-                r[k] = q.rhs[vb + i] - ap[k];
-                s2 += r[k] * r[k];
-                s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
-            }
-        }
-        oc_reduce2(s2, s1, red, rr, sr);   // its barriers also separate the reads of v_lds from the next writes
-    };
-    if (o.use_x0) {
-        true_residual();
-    } else {
-        float s2 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int i = t + k * OC_THREADS;
-            if (i < N) { s2 += r[k] * r[k]; s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn); }
+            const unsigned i = t + (unsigned)k * OC_THREADS;
+            if (i < (unsigned)N) { s2 += r[k] * r[k]; s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn); }
         }
         oc_reduce2(s2, s1, red, rr, sr);
+        if (PM == 0) sr = 0.0;
     }
-    if (PM == 0) sr = 0.0;
+    // One loop, ONE stencil pass per trip: a trip is either a CG iteration (vector in LDS = the new search direction) or a
+    // residual pass r = rhs - M x (vector in LDS = x: start from x0, the restart every 100 iterations, a recovery).
     int it = 0, best_it = 0, recoveries = 0, outcome = 0;   // outcome: 1 converged, 2 non-finite, 3 accepted on the kept iterate, 4 out of iterations / stalled
     float best = 3.0e38f, crit = 0.f;
-    bool fresh = true, restarted = true;
-    double rho_prev = 1.0;
+    bool fresh = true, restarted = true, residual_pass = o.use_x0 != 0, recovering = false;
+    double rho = 0.0, rho_prev = 1.0;
     for (;;) {
-        const double rho = rr - sr * sr;   // |r - (yp.r) yp|^2
-        crit = mb_rms(rho, N);
-        if (!(crit >= o.tol)) {
-            if (isfinite(crit)) { outcome = 1; break; }
-            // the recurrence broke down (p.Pp <= 0 or overflow on the non-symmetric matrix): back to the kept iterate
-            if (recoveries < 3 && it + o.check_every < o.max_iterations) {
+        // the thread index is laundered once per trip: per-cell 64-bit addresses are invariants of this loop, and the
+        // compiler otherwise hoists all of them out of it (CPT x 8 register pairs) and spills them
+        unsigned tl = t;
+        asm volatile("" : "+v"(tl));
+        float beta = 0.f, cy = 0.f;
+        if (!residual_pass) {
+            rho = rr - sr * sr;   // |r - (yp.r) yp|^2
+            crit = mb_rms(rho, N);
+            if (!(crit >= o.tol)) {
+                if (isfinite(crit)) { outcome = 1; break; }
+                // the recurrence broke down (p.Pp <= 0 or overflow on the non-symmetric matrix): back to the kept iterate
+                if (recovering || recoveries >= 3 || it + o.check_every >= o.max_iterations) { outcome = 2; break; }
                 ++recoveries;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
-                    const int i = t + k * OC_THREADS;
-                    if (i < N) { const float v = q.best_x[vb + i]; x[k] = isfinite(v) ? v : 0.f; }
+                    const unsigned i = tl + (unsigned)k * OC_THREADS;
+                    if (i < (unsigned)N) { const float v = bestx[i]; x[k] = isfinite(v) ? v : 0.f; }
                 }
-                true_residual();
-                if (PM == 0) sr = 0.0;
-                fresh = true; restarted = true;
-                if (!isfinite(mb_rms(rr - sr * sr, N))) { outcome = 2; break; }
-                continue;
-            }
-            outcome = 2; break;
-        }
-        // keep x_it when it beats the kept iterate by 2x (or at all inside the acceptance band): returnBestResult
-        if (it == 0 || crit < 0.5f * best || (crit < o.accept_factor * o.tol && crit < best)) {
-            best = crit; best_it = it;
+                residual_pass = true; recovering = true;
+            } else {
+                recovering = false;
+                // keep x_it when it beats the kept iterate by 2x (or at all inside the acceptance band): returnBestResult
+                if (it == 0 || crit < 0.5f * best || (crit < o.accept_factor * o.tol && crit < best)) {
+                    best = crit; best_it = it;
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) { const int i = t + k * OC_THREADS; if (i < N) q.best_x[vb + i] = x[k]; }
+                    for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * OC_THREADS; if (i < (unsigned)N) bestx[i] = x[k]; }
+                }
+                if (it > 0 && it % o.check_every == 0) {   // the cadence of k_mbs_check in the chunked solver
+                    if (o.accept_factor > 0.f && best <= o.accept_factor * o.tol && (it - 1) - best_it >= o.accept_window) { outcome = 3; break; }
+                    if (o.stall_limit > 0 && (it - 1) - best_it > o.stall_limit) { outcome = 4; break; }
+                }
+                if (it >= o.max_iterations) { outcome = 4; break; }
+                if (it > 0 && it % o.restart_every == 0 && !restarted) residual_pass = true;   // residualResetSteps (cg_solver_kernel.cu:281-300)
+            }
         }
-        if (it > 0 && it % o.check_every == 0) {   // the cadence of k_mbs_check in the chunked solver
-            if (o.accept_factor > 0.f && best <= o.accept_factor * o.tol && (it - 1) - best_it >= o.accept_window) { outcome = 3; break; }
-            if (o.stall_limit > 0 && (it - 1) - best_it > o.stall_limit) { outcome = 4; break; }
+        if (!residual_pass) {
+            restarted = false;
+            beta = fresh ? 0.f : (float)(rho / rho_prev);
+            cy = (float)sr;
         }
-        if (it >= o.max_iterations) { outcome = 4; break; }
-        if (it > 0 && it % o.restart_every == 0 && !restarted) {   // residualResetSteps (cg_solver_kernel.cu:281-300)
-            true_residual();
-            if (PM == 0) sr = 0.0;
-            fresh = true; restarted = true;
-            continue;
-        }
-        restarted = false;
-        const float beta = fresh ? 0.f : (float)(rho / rho_prev);
-        const float cy = (float)sr;
-        // p = (r - (yp.r) yp) + beta p: every thread rewrites its own cells of the LDS vector
+        // ---- the vector the stencil is applied to: x, or p = (r - (yp.r) yp) + beta p (every thread rewrites its own cells)
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const int i = t + k * OC_THREADS;
-            if (i < N) {
-                float v = PM == 0 ? r[k] : (PM == 1 ? r[k] - cy * rsqn : r[k] - cy * o.yp[i]);
-                if (!fresh) v += beta * v_lds[i];
+            const unsigned i = tl + (unsigned)k * OC_THREADS;
+            if (i < (unsigned)N) {
+                float v;
+                if (residual_pass) v = x[k];
+                else {
+                    v = PM == 0 ? r[k] : (PM == 1 ? r[k] - cy * rsqn : r[k] - cy * o.yp[i]);
+                    if (!fresh) v += beta * v_lds[i];
+                }
                 v_lds[i] = v;
             }
         }
         __syncthreads();
-        oc_spmv<DIMS, CPT, DG_REGS>(q, o, sys, N, v_lds, dg, ap);
+        oc_spmv<DIMS, CPT, DG_REGS>(q, o, sys, N, tl, v_lds, dg, ap);
+        float s2 = 0.f, s1 = 0.f;
+        if (residual_pass) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const unsigned i = tl + (unsigned)k * OC_THREADS;
+                if (i < (unsigned)N) {
+                    r[k] = rhs[i] - ap[k];
+                    s2 += r[k] * r[k];
+                    s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
+                }
+            }
+            oc_reduce2(s2, s1, red, rr, sr);   // its barriers also separate the stencil's LDS reads from the next writes
+            if (PM == 0) sr = 0.0;
+            residual_pass = false; fresh = true; restarted = true;
+            continue;
+        }
         float part = 0.f;
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { const int i = t + k * OC_THREADS; if (i < N) part += v_lds[i] * ap[k]; }
+        for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * OC_THREADS; if (i < (unsigned)N) part += v_lds[i] * ap[k]; }
         double pap, unused;
         oc_reduce2(part, 0.f, red, pap, unused);
         const float alpha = (float)(rho / pap);
-        float s2 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const int i = t + k * OC_THREADS;
-            if (i < N) {
+            const unsigned i = tl + (unsigned)k * OC_THREADS;
+            if (i < (unsigned)N) {
                 x[k] += alpha * v_lds[i];
                 r[k] -= alpha * ap[k];
                 s2 += r[k] * r[k];
@@ -1305,17 +1315,16 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
     const bool use_best = (outcome == 3 || outcome == 4 || (outcome == 2 && best < 3.0e38f));
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int i = t + k * OC_THREADS;
-        if (i < N) q.x[vb + i] = use_best ? q.best_x[vb + i] : x[k];
+        const unsigned i = t + (unsigned)k * OC_THREADS;
+        if (i < (unsigned)N) q.x[vb + i] = use_best ? bestx[i] : x[k];
     }
     if (t == 0) {
-        const bool finite = outcome != 2;
-        q.flags[sys] = outcome == 1 ? 1 : (outcome == 2 ? 2 : (outcome == 3 ? 5 : 1));
+        q.flags[sys] = outcome == 2 ? 2 : (outcome == 3 ? 5 : 1);
         q.info[sys].final_residual = use_best ? best : crit;
         q.info[sys].used_iterations = use_best ? best_it : it;
         q.info[sys].converged = (outcome == 1 || outcome == 3) ? 1 : 0;
-        q.info[sys].is_finite = finite ? 1 : 0;
-        q.best_it[sys] = it;   // total iterations run (the host reports the maximum over the batch)
+        q.info[sys].is_finite = outcome != 2 ? 1 : 0;
+        q.best_it[sys] = it;   // total iterations run (profiling: the host sums them)
     }
 }
 
@@ -1553,7 +1562,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     const bool ev = s->prof_on != 0;
     if (n <= 4 * OC_THREADS) OC_LAUNCH_PM(4, true);
     else if (n <= 8 * OC_THREADS) OC_LAUNCH_PM(8, true);
-    else if (n <= 16 * OC_THREADS) OC_LAUNCH_PM(16, true);
+    else if (n <= 16 * OC_THREADS) OC_LAUNCH_PM(16, false);
     else if (n <= 24 * OC_THREADS) OC_LAUNCH_PM(24, false);
     else OC_LAUNCH_PM(28, false);
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));

@@ -242,3 +242,35 @@ def test_non_finite_solve_drops_only_that_env_and_leaves_its_state_intact():
     assert np.array_equal(after[1], before)              # not committed
     assert _rel(after[0], u_ref) < 1e-5                   # the healthy env is not disturbed by its neighbour in the batch
     dom.close()
+
+
+def test_onchip_cg_matches_the_chunked_cg(monkeypatch):
+    """The one-workgroup-per-env CG (k_mbc_onchip) runs the same recurrence as the two-kernel chunked CG; on the reference's
+    cylinder mesh (14 232 cells, 16 cells per thread) both reach the tolerance in the same number of iterations (the dot
+    products are summed in a different order) and the steps they produce agree to solver tolerance."""
+    from fluidgym_amd.envs.cylinder_grid import build_domain, make_vortex_street_mesh
+
+    mesh = make_vortex_street_mesh(24)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FG_MB_ONCHIP", mode)      # read once per handle at fg_mb_create
+        dom = build_domain(mesh, 0.01, batch=3)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        dom.velocity.copy_((0.3 * torch.randn(dom.velocity.shape, generator=g)).to(dom.device))
+        dom.velocity[:, 0] += 1.0
+        dom.make_divergence_free(pressure_tol=1e-6, pressure_project_mean=True)
+        its = []
+        for _ in range(3):
+            its.append(dom.piso_step([0.01, 0.02, 0.0], pressure_tol=1e-6, advection_tol=1e-6, pressure_project_mean=True,
+                                     raise_on_failure=False))
+        out[mode] = (dom.velocity.cpu().numpy().copy(), dom.pressure.cpu().numpy().copy(), its)
+        dom.close()
+    u0, p0, it0 = out["0"]
+    u1, p1, it1 = out["1"]
+    assert np.isfinite(u1).all() and np.isfinite(p1).all()
+    assert _rel(u1[:2], u0[:2]) < 2e-4 and _rel(p1[:2], p0[:2]) < 2e-3
+    assert np.array_equal(u1[2], u0[2])                        # dt = 0: that env is left alone by both
+    for a, b in zip(it0, it1):
+        for k in (1, 2):                                       # pressure solves: same iteration counts within a few per cent
+            assert abs(a[k] - b[k]) <= max(3, 0.1 * a[k]), (it0, it1)
+    assert max(max(i) for i in it1) > 20                       # the solves did iterate
