@@ -104,6 +104,7 @@ class FgMbSimOptions(Structure):
 
 (FG_MB_BUF_A, FG_MB_BUF_C_OFF, FG_MB_BUF_RHS, FG_MB_BUF_H, FG_MB_BUF_DIV, FG_MB_BUF_P_DIAG, FG_MB_BUF_P_OFF,
  FG_MB_BUF_VELOCITY_RESULT) = range(8)
+FG_MB_BUF_KRYLOV0 = 8
 
 
 class FgSimOptions(Structure):
@@ -160,6 +161,7 @@ SIGNATURES = {
                               c_void_p]),
     "fg_poisson_fdcg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
                                 c_void_p]),
+    "fg_stream_triad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, POINTER(c_float), c_void_p]),
     "fg_profile_enable": (c_int, [c_void_p, c_int]),
     "fg_profile_kinds": (c_int, []),
     "fg_profile_kind_name": (ctypes.c_char_p, [c_int]),
@@ -190,6 +192,8 @@ SIGNATURES = {
     "fg_mb_set_residual_projection": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_mb_set_stall_limit": (c_int, [c_void_p, c_int32]),
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),
+    "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
+    "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_profile_iterations": (c_int, [c_void_p, POINTER(c_int64)]),
     "fg_mb_unit_pressure_matrix": (c_int, [c_void_p, c_void_p]),
     "fg_mb_profile_enable": (c_int, [c_void_p, c_int32]),

@@ -387,6 +387,7 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
             if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
             const int m = max_iters(info.data(), B);
             stats[0] = m > stats[0] ? m : stats[0];
+            s->ctr.add(0, info.data(), B);
             // CopyScalarResultToBlocks for active envs
             const int n = s->grid.n;
             if (s->cfg.n_scalars == 1) {
@@ -412,6 +413,7 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
         a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 1;
         if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
         stats[1] = max_iters(info.data(), B * d);
+        s->ctr.add(1, info.data(), B * d);
     }
     // ---- correctors (:1777-1972); rA = 1/A was written by the velocity fg_setup_advection above
     for (int c = 0; c < opt->corrector_steps; ++c) {
@@ -422,14 +424,22 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
                                          opt->pressure_warm_start ? 1 : 0,
                                          info.data(), st, last)))
             return rc;
-        if (c < 2) stats[2 + c] = max_iters(info.data(), B);
+        if (c < 2) { stats[2 + c] = max_iters(info.data(), B); s->ctr.add(2 + c, info.data(), B); }
         if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, last ? s->pressure : s->p_result, s->vel_result, st))
             return rc;
     }
     // CopyVelocityResultToBlocks (:1974)
     if (int rc = fg_launch_copy_active(s, dt_B, s->vel_result, s->velocity, d, st)) return rc;
     if (stats_host) memcpy(stats_host, stats, sizeof(stats));
+    s->ctr.piso_steps += 1;
     return status;
+}
+
+extern "C" int fg_solver_counters(fg_handle s, int64_t* out13, int32_t reset) {
+    FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_solver_counters: null handle");
+    if (out13) s->ctr.write(out13);
+    if (reset) s->ctr.reset();
+    return FG_OK;
 }
 
 // np.isclose(a, 0) with the default rtol=1e-5, atol=1e-8

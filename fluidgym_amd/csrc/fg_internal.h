@@ -336,6 +336,26 @@ __device__ __forceinline__ void fg_best_decide(const FgBest& best, int b, float 
 }
 #endif
 
+// Iteration statistics of the linear solves since the last reset: kind 0 scalar, 1 velocity, 2 / 3 pressure corrector 0 / 1.
+// sum / n = mean iterations per SYSTEM (env x component) that took part in a solve; piso_steps counts fg_piso_step calls.
+struct FgCounters {
+    long long sum[4] = {0, 0, 0, 0}, n[4] = {0, 0, 0, 0}, piso_steps = 0;
+    int max[4] = {0, 0, 0, 0};
+    void add(int kind, const fg_solve_info* info, int count) {
+        for (int i = 0; i < count; ++i) {
+            const int it = info[i].used_iterations;
+            if (it < 0 && info[i].final_residual == 0.f) continue;   // masked-out env (dt <= 0)
+            const int v = it < 0 ? 0 : it;                           // -1: converged before the first iteration
+            sum[kind] += v; n[kind] += 1; max[kind] = v > max[kind] ? v : max[kind];
+        }
+    }
+    void reset() { *this = FgCounters(); }
+    void write(int64_t* out) const {   // [13]: sum[4] | n[4] | max[4] | piso_steps
+        for (int k = 0; k < 4; ++k) { out[k] = sum[k]; out[4 + k] = n[k]; out[8 + k] = max[k]; }
+        out[12] = piso_steps;
+    }
+};
+
 struct fg_state {
     fg_config cfg;
     FgGrid grid;
@@ -383,6 +403,7 @@ struct fg_state {
     float* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
     float* dt_dev;         // [B]
     int pred_bicg, pred_cg; // iterations the last solves needed (first convergence poll is scheduled there)
+    FgCounters ctr;         // iterations per solve kind since the last reset (fg_solver_counters)
     const float* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     size_t n_cells() const { return (size_t)grid.n; }
 };

@@ -95,9 +95,11 @@ struct fg_mb_state {
     int32_t* flags_pinned = nullptr;
     fg_solve_info *info_dev, *info_pinned = nullptr;
     float* yproj = nullptr;
-    // on-chip CG (fg_mb_step.hip::k_mbc_onchip): neighbour table packed to 16 bits per face, [F/2][N] words (low half = even
-    // face, high half = odd face, 0xFFFF = prescribed face); built when N < 65535
+    // on-chip CG (fg_mb_step.hip::k_mbc_onchip): neighbour table packed to 16 bits per face, (low half = even
+    // face, high half = odd face, 0xFFFF = prescribed face); [N][F/2] words, built when N < 65535
     uint32_t* nbr16 = nullptr;
+    float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
+    int oc_variant = 0;        // FG_MB_OC_VARIANT (tuning switches of the on-chip CG)
     int onchip_mode = 1;       // FG_MB_ONCHIP: 0 never, 1 when the mesh fits one workgroup's LDS / registers (default)
     double* x64_best = nullptr; float* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
     double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2)
@@ -126,6 +128,7 @@ struct fg_mb_state {
     double prof_ms[3] = {0, 0, 0}, prof_bytes[3] = {0, 0, 0};
     long long prof_n[3] = {0, 0, 0}, prof_launches[3] = {0, 0, 0}, prof_its = 0;
     hipEvent_t prof_ev_oc[2] = {nullptr, nullptr};
+    FgCounters ctr;    // iterations per solve kind since the last reset (fg_mb_solver_counters)
     std::string err;
 };
 

@@ -157,11 +157,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_vrhs(MbDev D, const float* __re
 // pressure matrix from the coefficient pairs (PISO_build_pressure_matrix)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* __restrict__ dt, const float* __restrict__ rA,
-                                                          float* __restrict__ Pdiag, float* __restrict__ Poff) {
+                                                          float* __restrict__ Pdiag, float* __restrict__ Poff,
+                                                          float* __restrict__ Poff4) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     constexpr int F = 2 * DIMS;
     const float* ra = rA + (size_t)b * N;
+    float o4[4] = {0.f, 0.f, 0.f, 0.f};
     const float rp = ra[i];
     float rn[F];
 #pragma unroll
@@ -178,8 +180,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* _
             v += D.KPp[q] * rp + D.KPn[q] * rn[f];
         }
         if (g == 0) Pdiag[(size_t)b * N + i] = v;
-        else Poff[((size_t)b * F + (g - 1)) * N + i] = (D.nbr[(size_t)(g - 1) * N + i] >= 0) ? v : 0.f;
+        else {
+            const float o = (D.nbr[(size_t)(g - 1) * N + i] >= 0) ? v : 0.f;
+            Poff[((size_t)b * F + (g - 1)) * N + i] = o;
+            if (DIMS == 2) o4[(g - 1) & 3] = o;
+        }
     }
+    // the same off-diagonals once more, interleaved per cell: the on-chip CG fetches a cell's four with one 16-byte load
+    if (DIMS == 2 && Poff4) *reinterpret_cast<float4*>(Poff4 + ((size_t)b * N + i) * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
 }
 
 // h = (u_old/dt - H u* + S) / A   (PISO_build_pressure_rhs): grid.z = component
@@ -1120,7 +1128,9 @@ __global__ void k_mbs_restore_best(int N, MbSolve q) {
 constexpr int OC_THREADS = 1024, OC_WAVES = OC_THREADS / 64;
 
 struct OcParams {
-    const uint32_t* nbr16;   // [F/2][N]
+    const uint32_t* nbr16;   // [N][F/2] words: one 8-byte load per cell in 2-D
+    const float* off4;       // [B][N][4] off-diagonals interleaved per cell (2-D), or null: q.off [B][F][N] is read instead
+    int fence;               // compiler fence every four cells of the stencil pass (bounds the loads in flight)
     const float* dt;         // [B] or null
     const float* yp;         // [N] projection vector (PM == 2)
     int use_x0, project_mean, restart_every, check_every, max_iterations, stall_limit, accept_window;
@@ -1139,17 +1149,42 @@ __device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[OC_WA
     A = sa; B = sb;
 }
 
-// y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory.
-// Addresses are (uniform base pointer) + (32-bit cell index): 64-bit per-cell addresses are loop invariants of the CG loop,
-// get hoisted out of it and cost hundreds of spilled registers.
+// y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory: per cell
+// one 8-byte load (four packed neighbour indices) and one 16-byte load (four coefficients) in 2-D.
 template <int DIMS, int CPT, bool DG_REGS>
 __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int sys, int N, unsigned tl, const float* __restrict__ v_lds,
                                         const float (&dg)[CPT], float (&y)[CPT]) {
     constexpr int F = 2 * DIMS;
     const float* __restrict__ off = q.off + (size_t)sys * F * N;
     const float* __restrict__ diag = q.diag + (size_t)sys * N;
-    const uint32_t* __restrict__ nb = o.nbr16;
     const unsigned un = (unsigned)N;
+    if (DIMS == 2 && o.off4 != nullptr) {
+        const float4* __restrict__ off4 = reinterpret_cast<const float4*>(o.off4) + (size_t)sys * N;
+        const uint2* __restrict__ nb2 = reinterpret_cast<const uint2*>(o.nbr16);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const unsigned i = tl + (unsigned)k * OC_THREADS;
+            float acc = 0.f;
+            if (i < un) {
+                const uint2 u = nb2[i];
+                const float4 c = off4[i];
+                const float d = DG_REGS ? dg[k] : diag[i];
+                const uint32_t n0 = u.x & 0xffffu, n1 = u.x >> 16, n2 = u.y & 0xffffu, n3 = u.y >> 16;
+                // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
+                const float v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
+                const float v2 = v_lds[n2 != 0xffffu ? n2 : i], v3 = v_lds[n3 != 0xffffu ? n3 : i];
+                acc = d * v_lds[i];
+                acc += n0 != 0xffffu ? c.x * v0 : 0.f;
+                acc += n1 != 0xffffu ? c.y * v1 : 0.f;
+                acc += n2 != 0xffffu ? c.z * v2 : 0.f;
+                acc += n3 != 0xffffu ? c.w * v3 : 0.f;
+            }
+            y[k] = acc;
+            if ((k & 3) == 3 && o.fence) asm volatile("" ::: "memory");
+        }
+        return;
+    }
+    const uint32_t* __restrict__ nb = o.nbr16;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const unsigned i = tl + (unsigned)k * OC_THREADS;
@@ -1158,18 +1193,16 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
             acc = (DG_REGS ? dg[k] : diag[i]) * v_lds[i];
 #pragma unroll
             for (int w = 0; w < DIMS; ++w) {
-                const uint32_t u = nb[(unsigned)w * un + i];
+                const uint32_t u = nb[i * (unsigned)DIMS + (unsigned)w];
                 const uint32_t n0 = u & 0xffffu, n1 = u >> 16;
                 const float c0 = off[(unsigned)(2 * w) * un + i], c1 = off[(unsigned)(2 * w + 1) * un + i];
-                // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
                 const float v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
                 acc += n0 != 0xffffu ? c0 * v0 : 0.f;
                 acc += n1 != 0xffffu ? c1 * v1 : 0.f;
             }
         }
         y[k] = acc;
-        // at most four cells' loads in flight (24 registers): left alone, the scheduler issues all CPT x 6 loads first
-        if ((k & 3) == 3) asm volatile("" ::: "memory");
+        if ((k & 3) == 3 && o.fence) asm volatile("" ::: "memory");
     }
 }
 
@@ -1555,6 +1588,8 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     constexpr int CG_CHUNK = 20, CG_RESTART = 100;
     OcParams o;
     o.nbr16 = s->nbr16; o.dt = dt; o.yp = s->dev.yproj;
+    o.off4 = (off == s->Poff && !(s->oc_variant & 2)) ? s->Poff4 : nullptr;
+    o.fence = (s->oc_variant & 1) ? 0 : 1;
     o.use_x0 = use_x0; o.project_mean = pm_mode; o.restart_every = CG_RESTART; o.check_every = CG_CHUNK;
     o.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
     o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
@@ -1760,6 +1795,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_OC_VARIANT"); s->oc_variant = e ? atoi(e) : 0;   // bit 0: no compiler fences in the stencil pass; bit 1: split [F][N] coefficient layout
     }
     *out = s;
     return FG_OK;
@@ -1907,10 +1943,12 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
         for (size_t w = 0; w < F / 2; ++w)
             for (size_t i = 0; i < N; ++i) {
                 const int32_t n0 = s->h_nbr[(2 * w) * N + i], n1 = s->h_nbr[(2 * w + 1) * N + i];
-                packed[w * N + i] = (uint32_t)(n0 >= 0 ? n0 : 0xffff) | ((uint32_t)(n1 >= 0 ? n1 : 0xffff) << 16);
+                packed[i * (F / 2) + w] = (uint32_t)(n0 >= 0 ? n0 : 0xffff) | ((uint32_t)(n1 >= 0 ? n1 : 0xffff) << 16);
             }
         if (int rc = mb_alloc(s, &s->nbr16, packed.size())) return rc;
         FG_HIP_CHECK(hipMemcpy(s->nbr16, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice));
+        if (d == 2 && N <= (size_t)28 * 1024)
+            if (int rc = mb_alloc(s, &s->Poff4, B * N * 4)) return rc;
     }
     s->env_status.assign(B, 0);
     FG_HIP_CHECK(hipHostMalloc((void**)&s->env_fail_pinned, sizeof(int32_t) * B, hipHostMallocDefault));
@@ -1994,10 +2032,11 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
             }
             if (int rc = soft(vrc)) return rc;
             its[1] = std::max(its[1], m);
+            s->ctr.add(1, s->info_pinned, B * d);
         }
         // ---- correctors (SIM.py:1777-1972)
         for (int c = 0; c < opt->corrector_steps; ++c) {
-            hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff);
+            hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4);
             for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
                 if (ps == 0) {
                     hipLaunchKernelGGL(k_mb_h<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->rA, s->Coff, s->velocity, s->ures,
@@ -2028,7 +2067,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                     mask_failed(1);
                 }
                 if (int rc = soft(prc)) return rc;
-                if (c < 2) its[2 + c] = std::max(its[2 + c], m);
+                if (c < 2) { its[2 + c] = std::max(its[2 + c], m); s->ctr.add(2 + c, s->info_pinned, B); }
                 FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
                 hipLaunchKernelGGL(k_mb_sum, dim3(8, B), blk, 0, st, N, dt_B, s->pres, s->red);
                 hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, dt_B, s->red, s->pres, s->pressure);
@@ -2039,6 +2078,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
     });
     FG_HIP_CHECK(hipGetLastError());
     if (stats_host) for (int k = 0; k < 4; ++k) stats_host[k] = its[k];
+    s->ctr.piso_steps += 1;
     for (int b = 0; b < B; ++b) s->env_status[b] = 0;
     if (soft_rc == FG_ERR_NOT_FINITE) {   // rare path: which envs were dropped
         FG_HIP_CHECK(hipMemcpyAsync(s->env_fail_pinned, s->env_fail, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
@@ -2048,6 +2088,13 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         for (int b = 0; b < B; ++b) s->env_status[b] = 1;   // some solve of the batch ended on its best iterate
     }
     return soft_rc;
+}
+
+extern "C" int fg_mb_solver_counters(fg_mb_handle s, int64_t* out13, int32_t reset) {
+    FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_solver_counters: null handle");
+    if (out13) s->ctr.write(out13);
+    if (reset) s->ctr.reset();
+    return FG_OK;
 }
 
 extern "C" int fg_mb_env_status(fg_mb_handle s, int32_t* out_B_host) {
@@ -2212,7 +2259,7 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
     hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, (const float*)nullptr, s->velocity, s->hvec);
     MB_DISPATCH(s, {
         hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, (const float*)nullptr, s->hvec, s->bvel, s->cc, s->fb);
-        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->Pdiag, s->Poff);
+        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4);
         for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
             hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
             int m = 0;
@@ -2283,7 +2330,7 @@ extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
     const size_t BN = (size_t)s->B * s->N;
     hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), dim3(FG_BLOCK), 0, st, BN, 1.f, s->rA);
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, dim3((s->N + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st, s->dev,
-                                      (const float*)nullptr, s->rA, s->Pdiag, s->Poff););
+                                      (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4););
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }
@@ -2331,6 +2378,8 @@ extern "C" int fg_mb_get_buffer(fg_mb_handle s, int32_t which, const float** ptr
         case FG_MB_BUF_P_DIAG: *ptr = s->Pdiag; *count = B * N; break;
         case FG_MB_BUF_P_OFF: *ptr = s->Poff; *count = B * F * N; break;
         case FG_MB_BUF_VELOCITY_RESULT: *ptr = s->ures; *count = B * d * N; break;
+        case FG_MB_BUF_KRYLOV0: case FG_MB_BUF_KRYLOV0 + 1: case FG_MB_BUF_KRYLOV0 + 2: case FG_MB_BUF_KRYLOV0 + 3: case FG_MB_BUF_KRYLOV0 + 4:
+            *ptr = s->w[which - FG_MB_BUF_KRYLOV0]; *count = B * d * N; break;
         default: fg_set_error("fg_mb_get_buffer: unknown buffer id"); return FG_ERR_INVALID_ARG;
     }
     return FG_OK;

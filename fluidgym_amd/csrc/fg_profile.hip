@@ -8,6 +8,8 @@
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "fg_internal.h"
 
 namespace {
@@ -104,4 +106,38 @@ void fg_prof_destroy(fg_state* s) {
     for (int i = 0; i < 2 * FG_PROF_POOL; ++i) (void)hipEventDestroy(P.ev[i]);
     (void)hipFree(P.active_dev); (void)hipHostFree(P.active_pinned);
     P.active_dev = nullptr;
+}
+
+// ---- measured practical roof: STREAM triad a = b + s c on caller-provided device arrays ("use the measured triad
+// number as the practical roof too").  One 16-byte access per lane and array, grid sized to 16 workgroups per CU.
+namespace {
+__global__ __launch_bounds__(FG_BLOCK) void k_stream_triad(float4* __restrict__ a, const float4* __restrict__ b,
+                                                           const float4* __restrict__ c, float s, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * FG_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * FG_BLOCK) {
+        const float4 x = b[i], y = c[i];
+        a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+    }
+}
+}  // namespace
+
+extern "C" int fg_stream_triad(float* a, const float* b, const float* c, float scalar, int64_t n, int32_t reps, float* ms_per_launch,
+                               void* stream) {
+    FG_REQUIRE(a && b && c && n > 0 && n % 4 == 0 && reps > 0 && ms_per_launch, FG_ERR_INVALID_ARG, "fg_stream_triad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    FG_HIP_CHECK(hipEventCreate(&e0));
+    FG_HIP_CHECK(hipEventCreate(&e1));
+    const size_t n4 = (size_t)n / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((n4 + FG_BLOCK - 1) / FG_BLOCK, 256 * 16);
+    hipLaunchKernelGGL(k_stream_triad, dim3(grid), dim3(FG_BLOCK), 0, st, (float4*)a, (const float4*)b, (const float4*)c, scalar, n4);
+    FG_HIP_CHECK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(k_stream_triad, dim3(grid), dim3(FG_BLOCK), 0, st, (float4*)a, (const float4*)b, (const float4*)c, scalar, n4);
+    FG_HIP_CHECK(hipEventRecord(e1, st));
+    FG_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / (float)reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return FG_OK;
 }

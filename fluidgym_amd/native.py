@@ -320,6 +320,18 @@ class NativeSolver:
         L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED, L.FG_ERR_NOT_FINITE))
         return list(info)
 
+
+    def solver_counters(self, reset: bool = False) -> dict:
+        """Iterations of the linear solves since the last reset: per kind (scalar, velocity, pressure corrector 0 / 1) the
+        mean and max per system (env x component) and the number of PISO steps (``fg_solver_counters``)."""
+        out = (ctypes.c_int64 * 13)()
+        L.check(self.lib.fg_solver_counters(self.handle, out, int(reset)))
+        names = ("scalar", "velocity", "pressure0", "pressure1")
+        res = {n: {"mean": (out[k] / out[4 + k]) if out[4 + k] else None, "max": int(out[8 + k]), "systems": int(out[4 + k])}
+               for k, n in enumerate(names)}
+        res["piso_steps"] = int(out[12])
+        return res
+
     def set_return_best(self, on: bool = True):
         """``pressure_return_best_result`` of the reference's Simulation: keep / hand back the best CG iterate."""
         L.check(self.lib.fg_set_return_best(self.handle, int(on)))

@@ -375,6 +375,17 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_set_residual_projection(self.handle, y32.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
         return float(y.sum() / np.sqrt(N))
 
+    def solver_counters(self, reset: bool = False) -> dict:
+        """Iterations of the linear solves since the last reset: per kind (scalar, velocity, pressure corrector 0 / 1) the
+        mean and max per system (env x component) and the number of PISO steps (``fg_mb_solver_counters``)."""
+        out = (ctypes.c_int64 * 13)()
+        L.check(self.lib.fg_mb_solver_counters(self.handle, out, int(reset)))
+        names = ("scalar", "velocity", "pressure0", "pressure1")
+        res = {n: {"mean": (out[k] / out[4 + k]) if out[4 + k] else None, "max": int(out[8 + k]), "systems": int(out[4 + k])}
+               for k, n in enumerate(names)}
+        res["piso_steps"] = int(out[12])
+        return res
+
     # ---- live kernel timing (bench.py)
     def profile_enable(self, on: bool = True) -> None:
         L.check(self.lib.fg_mb_profile_enable(self.handle, int(on)))

@@ -191,6 +191,11 @@ typedef struct fg_step_options {
 } fg_step_options;
 int fg_piso_step(fg_handle h, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
                  void* stream);
+/* Iteration statistics of the linear solves since the last reset (host bookkeeping of the LinearSolverResultInfo every
+ * SolveLinear call returns, bicgstab_solver.h): out13 = sum of iterations [4] | systems solved [4] | max iterations [4] |
+ * PISO steps, kinds = {passive scalar, velocity, pressure corrector 0, pressure corrector 1}; a system = env x component.
+ * reset != 0 clears them after the read. */
+int fg_solver_counters(fg_handle h, int64_t* out13_host, int32_t reset);
 /* Simulation.single_step entirely on the native side (simulation.py:206-280 + _PISO_adaptive_step,
  * PISOtorch_simulation.py:2004-2064): flux-balance guard, per-env adaptive substeps
  * ts = t_rem / ceil(t_rem / (CFL / max_vel)) recomputed before every substep, the advective-outflow PRE
@@ -262,6 +267,9 @@ int fg_poisson_fdcg(fg_handle h, const float* rA, const float* b, float* x, floa
  * (sampled or not) since fg_profile_enable, and milliseconds / count over ALL sampled launches including
  * those that found every system converged (the figure rocprofv3 --stats averages).  Any output pointer
  * may be NULL.  Synchronises the device. */
+/* STREAM triad a = b + scalar * c over n floats (n % 4 == 0), `reps` launches timed with events on `stream`: the measured
+ * practical HBM roof beside the spec figure (bytes per launch = 12 n).  Synchronises. */
+int fg_stream_triad(float* a, const float* b, const float* c, float scalar, int64_t n, int32_t reps, float* ms_per_launch, void* stream);
 int fg_profile_enable(fg_handle h, int on);
 int fg_profile_kinds(void);
 const char* fg_profile_kind_name(int kind);
@@ -366,6 +374,8 @@ int fg_mb_piso_step(fg_mb_handle h, const float* dt_B, const fg_mb_step_options*
  * (velocity as before the step, like solve_ok=False before CopyVelocityResultToBlocks, PISOtorch_simulation.py:1752-1757,
  * and Simulation.single_step -> False, simulation.py:259-280) while the other envs of the batch completed. */
 int fg_mb_env_status(fg_mb_handle h, int32_t* out_B_host);
+/* as fg_solver_counters, for the multi-block path */
+int fg_mb_solver_counters(fg_mb_handle h, int64_t* out13_host, int32_t reset);
 /* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps
  * (_PISO_adaptive_step, PISOtorch_simulation.py:2004-2064), the advective-outflow PRE hook on ONE FIXED face given as
  * a range of boundary slots (update_advective_boundaries + balance_boundary_fluxes, :188-393; count 0 = none) and
@@ -427,6 +437,7 @@ int fg_mb_profile_iterations(fg_mb_handle h, int64_t* iterations);
 #define FG_MB_BUF_P_DIAG 5
 #define FG_MB_BUF_P_OFF 6
 #define FG_MB_BUF_VELOCITY_RESULT 7
+#define FG_MB_BUF_KRYLOV0 8          /* 8..12: the five Krylov work vectors [B,d,N] as the last solve left them (debugging) */
 int fg_mb_get_buffer(fg_mb_handle h, int32_t which, const float** ptr, int64_t* count);
 int fg_mb_read_buffer(fg_mb_handle h, int32_t which, float* dst_device, void* stream); /* device copy, synchronises */
 

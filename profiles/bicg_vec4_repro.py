@@ -55,7 +55,13 @@ for mask in masks:
                         A=dom.buffer(L.FG_MB_BUF_A).view(B, N)[bad].cpu().numpy(),
                         Coff=dom.buffer(L.FG_MB_BUF_C_OFF).view(B, 2 * d, N)[bad].cpu().numpy(),
                         rhs=dom.buffer(L.FG_MB_BUF_RHS).view(B, d, N)[bad].cpu().numpy(),
-                        x0=dom.velocity[bad].cpu().numpy(), nbr=dom.neighbors(), env=bad, step=step)
+                        x0=dom.velocity[bad].cpu().numpy(), nbr=dom.neighbors(), env=bad, step=step,
+                        # Krylov vectors of the failing env's systems as the solve left them (r, rw, p, v, t): the masked env is
+                        # skipped by every later kernel of the step, so they are exactly what the failing iteration produced
+                        krylov=np.stack([dom.buffer(L.FG_MB_BUF_KRYLOV0 + k).view(B, d, N)[bad].cpu().numpy() for k in range(5)]))
+                    kr = np.stack([dom.buffer(L.FG_MB_BUF_KRYLOV0 + k).view(B, d, N)[bad].cpu().numpy() for k in range(5)])
+                    bad_cells = {nm: np.nonzero(~np.isfinite(kr[k]).all(0))[0] for k, nm in enumerate(("r", "rw", "p", "v", "t"))}
+                    first_fail["nonfinite_cells"] = {nm: {"count": int(len(c)), "first": c[:8].tolist(), "last": c[-4:].tolist()} for nm, c in bad_cells.items()}
         torch.cuda.synchronize()
         finite = bool(torch.isfinite(dom.velocity).all())
         fails += first_fail is not None
