@@ -3,21 +3,27 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+(`python bench.py --gpus N` started plainly launches that line itself, as child processes.)
 
 Workload (BASELINE.json configs[1]): "2D cylinder Re=100, 256x128, batch=64 on one GPU", run on the
 single-block stand-in ``ChannelJet2D-v0`` (the reference has no Cartesian cylinder; mapping in
 SURVEY.md section 8d / fluidgym_amd/envs/channel.py).  One bench "step" = one ``env.step()`` of all
 envs = 25 PISO steps each (dt 0.01, step_length 0.25) with adaptive CFL, outflow BC update, actions,
-observations and reward.  Scaling is WEAK: every GPU carries 64 envs; actions are broadcast and
-observations gathered over RCCL by ``ParallelFluidEnv``.
+observations and reward, under uniform random jet actions (the flow is unsteady).  Pressure solves are
+COLD-STARTED as in the reference (PISOtorch_simulation.py:1804-1807, 1877-1881); ``config.solver_iterations``
+holds mean / max iterations per solve over the whole timed region, ``warm_start_mode`` the opt-in
+warm-start performance mode next to it.  Scaling is WEAK: every GPU carries 64 envs; one broadcast and one
+all_gather per step by ``ParallelFluidEnv``.
 
 The JSON line also carries
   * ``roofline``: the solver kernel with the largest share of the timed region, timed live with kernel-accurate
-    HIP events inside the timed region (fg_profile_*, see roofline_from_profile), plus the table of all kinds;
-  * ``poisson_256``: the 256^3 pressure-Poisson micro-benchmark (Jacobi sweep / CG kernels), the
+    HIP events inside the timed region (fg_profile_*), the table of all kinds, and the measured STREAM-triad roof;
+  * ``poisson_256``: the 256^3 pressure-Poisson micro-benchmark (Jacobi sweep / apply / CG iteration), the
     north-star's ">= 60 % of HBM roofline" target (working set > 256 MiB Infinity Cache);
+  * ``rbc_env`` / ``tcf_env``: BASELINE configs 2 and 3 at full size on one GPU (RBC 512x128 x 32 envs, TCF 128x64x64 x 8);
+  * ``cylinder_env`` / ``airfoil_env``: the reference's own multi-block envs;
   * ``cpu_baseline``: the NumPy/SciPy oracle (a port, not reference code: the reference has no CPU
-    path) stepping ONE env of the same workload on the host, single thread.
+    path) stepping the same workload on the host: all cores (one env per process) and one thread, fp32.
 """
 from __future__ import annotations
 
@@ -102,10 +108,10 @@ KERNEL_DOC = {
 
 def pmc_traffic(kernel):
     """Memory-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
+    (profiles/r02_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
     fetch counter as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so this
     is the last profiled run, not this run; None when the file has no row for the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -118,7 +124,7 @@ def pmc_traffic(kernel):
     if isinstance(row, list):
         row = row[0]
     return {"fetch_bytes_per_launch": row["fetch_bytes"], "write_bytes_per_launch": row["write_bytes"],
-            "launches_averaged": row["launches"], "unit": "B", "source": "profiles/r01_traffic.json (rocprofv3 --pmc, "
+            "launches_averaged": row["launches"], "unit": "B", "source": "profiles/r02_traffic.json (rocprofv3 --pmc, "
             "separate FETCH_SIZE and WRITE_SIZE passes of bench.py; averages include launches that found every "
             "system converged; Infinity-Cache hits are counted)"}
 
@@ -167,48 +173,73 @@ def roofline_from_profile(prof, solver):
 
 def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
     """The reference's own cylinder env (CylinderJet2D-easy-v0: five-block curvilinear mesh, 14 232 cells, Re 100, 25 PISO
-    steps per env step) on the multi-block path, batched like the headline workload and driven by the same random policy,
-    with the live roofline of its dominant kernel pair (fg_mb_profile_*).  Reported next to the headline, which stays on the
-    256x128 single-block stand-in SURVEY 8d maps the BASELINE config to."""
+    steps per env step) on the multi-block path, batched like the headline workload and driven by the same random policy.
+    Pressure solves: CG, cold-started as in the reference; at this mesh size the whole solve of an env runs inside one
+    workgroup (k_mbc_onchip).  ``warm_start_mode`` = the opt-in performance mode (previous pressure as initial guess,
+    stall acceptance 1.25) of the same leg."""
     import torch
 
     import fluidgym_amd
 
-    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=num_envs, initial_domain_steps=100,
-                            randomize_initial_state=False, cuda_device=device)
+    def run(n_steps):
+        env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=num_envs, initial_domain_steps=100,
+                                randomize_initial_state=False, cuda_device=device)
+        try:
+            env.reset(seed=0)
+            gen = torch.Generator(device="cpu").manual_seed(7)
+            act = lambda: (torch.rand(num_envs, 1, generator=gen) * 2 - 1).to(device)
+            env.step(act())
+            dom = env._domain
+            dom.solver_counters(reset=True)
+            dom.profile_enable(True)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                _, _, _, _, info = env.step(act())
+            torch.cuda.synchronize(device)
+            el = (time.perf_counter() - t0) / n_steps
+            prof = dom.profile_read()
+            dom.profile_enable(False)
+            its = solver_iterations(dom)
+            rows = {}
+            for name, r in prof.items():
+                if r["samples"] <= 0:
+                    continue
+                if name == "k_mbc_onchip":
+                    per_it = r["ms"] / max(r["iterations"] / num_envs, 1)
+                    rows[name] = {"doc": "whole CG solve of one env per workgroup: r, x, P p in registers, p in LDS; off-diagonals and "
+                                         "packed neighbour table streamed from L2 every iteration",
+                                  "launches": r["launches"], "total_ms": r["ms"], "avg_launch_ms": r["ms"] / r["samples"],
+                                  "iterations_per_env_and_solve": r["iterations"] / num_envs / r["launches"],
+                                  "us_per_iteration": 1e3 * per_it,
+                                  "L2_side_streamed_GBps": r["bytes"] / r["ms"] / 1e6,
+                                  "note": "bytes = iterations x cells x 24 B (16 B coefficients + 8 B neighbours) + 20 B per cell and solve; "
+                                          "they come from L2 / Infinity Cache, not HBM: this kernel is bound by per-CU load latency and "
+                                          "L2 bandwidth (64 of 256 CUs busy at 64 envs), not by the HBM roofline"}
+                else:
+                    avg = r["ms"] / r["samples"]
+                    rows[name] = {"doc": KERNEL_DOC.get(name, ""), "traffic": pmc_traffic(name + "4"), "avg_busy_launch_ms": avg,
+                                  "samples": r["samples"], "launches": r["launches"], "est_total_ms": avg * r["launches"],
+                                  "GBps": r["bytes"] / r["ms"] / 1e6, "frac_of_hbm_peak": r["bytes"] / r["ms"] / 1e6 / HBM_PEAK_GBS}
+            return {"ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
+                    "pressure_warm_start": bool(env._sim.pressure_warm_start), "pressure_stall_accept": env._sim.pressure_stall_accept,
+                    "solver_iterations": its, "mean_substeps_per_sim_step": round(its["piso_steps"] / max(n_steps * env.n_sim_steps, 1), 2),
+                    "drag_coefficient_env0": float(info["drag"][0]), "kernels": rows, "cells_per_env": dom.n_cells,
+                    "piso_steps_per_env_step": env.n_sim_steps}
+        finally:
+            env.close()
+
+    out = {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "policy": "uniform random jets in [-1, 1] (as the headline)",
+           "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline)"}
+    out.update(run(steps))
+    old = fluidgym_amd.set_solver_policy(pressure_warm_start=True, pressure_stall_accept=1.25)
     try:
-        env.reset(seed=0)
-        gen = torch.Generator(device="cpu").manual_seed(7)
-        act = lambda: (torch.rand(num_envs, 1, generator=gen) * 2 - 1).to(device)
-        env.step(act())
-        dom = env._domain
-        dom.profile_enable(True)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            _, _, _, _, info = env.step(act())
-        torch.cuda.synchronize(device)
-        el = (time.perf_counter() - t0) / steps
-        prof = dom.profile_read()
-        dom.profile_enable(False)
-        rows = {}
-        for name, r in prof.items():
-            if r["samples"] > 0:
-                avg = r["ms"] / r["samples"]
-                rows[name] = {"doc": KERNEL_DOC.get(name, ""), "traffic": pmc_traffic(name + "4"), "avg_busy_launch_ms": avg,
-                              "samples": r["samples"],
-                              "launches": r["launches"], "est_total_ms": avg * r["launches"],
-                              "GBps": r["bytes"] / r["ms"] / 1e6, "frac_of_hbm_peak": r["bytes"] / r["ms"] / 1e6 / HBM_PEAK_GBS}
-        return {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "cells_per_env": dom.n_cells,
-                "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el,
-                "unit": "env-steps/s", "policy": "uniform random jets in [-1, 1] (as the headline)",
-                "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
-                "drag_coefficient_env0": float(info["drag"][0]), "kernels": rows,
-                "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline); kernel "
-                        "rows: live start/stop events on the first CG kernel pair of every fourth 20-iteration chunk, algorithmic "
-                        "bytes = 4 (5 + 2d) B (stencil kernel) / 24 B (update kernel) x cells x systems still iterating"}
+        warm = run(steps)
     finally:
-        env.close()
+        fluidgym_amd.set_solver_policy(**old)
+    out["warm_start_mode"] = {k: warm[k] for k in ("value", "ms_per_step", "pressure_warm_start", "pressure_stall_accept",
+                                                    "solver_iterations", "drag_coefficient_env0")}
+    return out
 
 
 def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
@@ -226,6 +257,7 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
         gen = torch.Generator(device="cpu").manual_seed(11)
         act = lambda: (torch.rand((num_envs, 3), generator=gen) * 2 - 1).to(device)
         env.step(act())
+        env._domain.solver_counters(reset=True)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -235,6 +267,7 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
         return {"env_id": "Airfoil2D-easy-v0", "envs": num_envs, "cells_per_env": env._domain.n_cells,
                 "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_solver": "BiCGStab (fp32, mean-projected) with fp64 iterative refinement, tolerance 1e-7",
+                "pressure_warm_start": bool(env._sim.pressure_warm_start), "solver_iterations": solver_iterations(env._domain),
                 "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
                 "drag_lift_env0": [float(info["drag"][0]), float(info["lift"][0])],
                 "note": f"state {develop} uncontrolled sim steps after an impulsive start; uniform random jets in [-1, 1]"}
@@ -242,38 +275,85 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
         env.close()
 
 
-def cpu_baseline(budget_s=20.0):
-    """Oracle (NumPy/SciPy port of the reference algorithm) on one env of the bench workload."""
-    import numpy as np
+def solver_iterations(solver) -> dict:
+    c = solver.solver_counters()
+    out = {k: {"mean": (round(v["mean"], 2) if v["mean"] is not None else None), "max": v["max"]}
+           for k, v in c.items() if isinstance(v, dict) and v["systems"]}
+    out["piso_steps"] = c["piso_steps"]
+    return out
 
-    from fluidgym_amd.envs.channel import CHANNEL_JET_2D_DEFAULT_CONFIG as CFG, inflow_profile
-    from oracle import piso_oracle as O
 
-    nx, ny, L, H = CFG["resolution_x"], CFG["resolution_y"], 22.0, 4.1
-    g = O.Grid(O.rectilinear_coords([np.linspace(0, L, nx + 1), np.linspace(-H / 2, H / 2, ny + 1)]))
-    prof = inflow_profile(H, ny)
-    u = np.zeros((2, ny, nx))
-    u[0] = prof[:, None]
-    rng = np.random.default_rng(0)
-    u += 0.05 * rng.standard_normal(u.shape)
-    inflow = np.zeros((2, ny, 1))
-    inflow[0, :, 0] = prof
-    bc = {0: O.FixedBC(inflow.copy()), 1: O.FixedBC(inflow.copy()), 2: O.FixedBC(np.zeros(2)), 3: O.FixedBC(np.zeros(2))}
-    dom = O.Domain(g, 1.0 / CFG["reynolds_number"], u, np.zeros((ny, nx)), bc)
-    opts = O.SolverOptions(direct=False, pressure_tol=1e-5, advection_tol=1e-5, pressure_return_best_result=True)
-    O.make_divergence_free(dom, O.SolverOptions(direct=False, pressure_tol=1e-5))
-    velm = np.array([1.0, 0.0])
+def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", **env_kw):
+    """One single-block env at full size, batched on this GPU: env-steps/s, iterations per solve over the timed region,
+    substeps, the live roofline table of its solver kernels."""
+    import torch
+
+    import fluidgym_amd
+
+    env = fluidgym_amd.make(env_id, num_envs=num_envs, cuda_device=device, **env_kw)
+    try:
+        env.reset(seed=seed)
+        env.seed(seed)
+        for _ in range(warmup):
+            env.step(env.sample_action())
+        solver = env._domain.solver
+        solver.solver_counters(reset=True)
+        solver.profile_enable(True)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.step(env.sample_action())
+        torch.cuda.synchronize(device)
+        el = (time.perf_counter() - t0) / steps
+        prof = solver.profile_read()
+        solver.profile_enable(False)
+        its = solver_iterations(solver)
+        roof = roofline_from_profile(prof, solver)
+        sim_steps = env.n_sim_steps
+        return {"env_id": env_id, "envs": num_envs, "grid": [solver.nx, solver.ny, solver.nz], "doc": doc,
+                "piso_steps_per_env_step": sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
+                "pressure_warm_start": bool(env._sim.pressure_warm_start), "solver_iterations": its,
+                "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
+                "policy": "uniform samples of the action space",
+                "dominant_kernel": None if roof is None else {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
+                "kernels": None if roof is None else {k: {kk: v[kk] for kk in ("avg_busy_launch_ms", "launches", "est_total_ms", "GBps", "TFLOPps")}
+                                                      for k, v in roof["kernels"].items()}}
+    finally:
+        env.close()
+
+
+def stream_triad(device, n=1 << 28, reps=10):
+    """Measured practical HBM roof: a = b + s c over 3 x 1 GiB (working set >> 256 MiB Infinity Cache)."""
+    import ctypes
+
+    import torch
+
+    from fluidgym_amd import _lib as L
+
+    a, b, c = (torch.empty(n, device=device, dtype=torch.float32) for _ in range(3))
+    b.fill_(1.0), c.fill_(2.0)
+    ms = ctypes.c_float()
+    st = torch.cuda.current_stream(device).cuda_stream
+    L.check(L.load().fg_stream_triad(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(c.data_ptr()),
+                                     ctypes.c_float(0.5), n, reps, ctypes.byref(ms), ctypes.c_void_p(st)))
+    gbps = 12.0 * n / ms.value / 1e6
+    return {"GBps": gbps, "frac_of_spec_peak": gbps / HBM_PEAK_GBS, "ms_per_launch": ms.value, "bytes_per_launch": 12 * n,
+            "note": "STREAM triad, 16 B per lane, 3 x 1 GiB arrays, mean of 10 launches (HIP events)"}
+
+
+def cpu_baseline():
+    """Oracle (NumPy/SciPy port of the reference algorithm: test infrastructure, the reference has no CPU path) on the bench
+    workload: one env per host core, all cores at once, and one thread alone; fp32 fields like the GPU path."""
+    from fluidgym_amd.envs.channel import CHANNEL_JET_2D_DEFAULT_CONFIG as CFG
+    from oracle import cpu_bench
+
     n_sim = max(1, int(CFG["step_length"] / CFG["dt"]))
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < budget_s:
-        O.update_advective_boundaries(dom, [1], velm, CFG["dt"], tol=1e-5)
-        O.piso_split_step(dom, CFG["dt"], opts)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": steps / n_sim / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"1 env of the {nx}x{ny} channel, {steps} PISO steps ({steps / n_sim:.2f} env steps) in {dt:.1f} s, "
-                      "NumPy/SciPy oracle with the reference's CG/BiCGStab recurrences, fp64"}
+    r1, rall, cores, dtype, steps_all = cpu_bench.run(budget_1=8.0, budget_all=12.0, dtype="float32")
+    return {"value": rall / n_sim, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "one_thread_value": r1 / n_sim, "cpu_model": cpu_bench.cpu_model(), "dtype": dtype,
+            "sample": f"{cores} envs of the {CFG['resolution_x']}x{CFG['resolution_y']} channel, one per core for 12 s "
+                      f"({steps_all} PISO steps = {steps_all / n_sim:.1f} env steps in total), and one env on one thread for 8 s; "
+                      "NumPy/SciPy oracle with the reference's CG / BiCGStab recurrences (cold-started, tolerance 1e-5)"}
 
 
 def main():
@@ -327,6 +407,7 @@ def main():
     for _ in range(args.warmup):
         penv.step(actions())
     solver = env._domain.solver
+    solver.solver_counters(reset=True)
     solver.profile_enable(True)
 
     def fence():
@@ -347,10 +428,21 @@ def main():
         elapsed = float(t.item())
     prof = solver.profile_read()
     solver.profile_enable(False)
-    stats = list(env._sim.last_stats)
+    its = solver_iterations(solver)
+    n_sim = env._n_sim_steps
 
     if rank == 0:
         roof = roofline_from_profile(prof, solver)
+        triad = None
+        if not args.no_micro:
+            try:
+                triad = stream_triad(device)
+            except Exception as exc:
+                triad = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if roof is not None:
+            roof["measured_stream_triad"] = triad
+            if triad and "GBps" in triad and roof["bound"] == "hbm":
+                roof["frac_of_measured_triad"] = roof["achieved"] / triad["GBps"]
         out = {
             "metric": "env-steps/sec (batched) + pressure-Poisson HBM GB/s vs roofline, 1/2/4/8 GPUs",
             "value": n_total * args.steps / elapsed,
@@ -366,28 +458,45 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.env_id}"
                                    + (": 2D channel stand-in for 'cylinder Re=100 256x128'" if args.env_id == ENV_ID else "")
-                                   + f", {args.envs_per_gpu} envs/GPU, {env._n_sim_steps} PISO steps per env step",
+                                   + f", {args.envs_per_gpu} envs/GPU, {n_sim} PISO steps per env step, uniform random jet actions",
                        "global_batch": n_total, "grid": [solver.nx, solver.ny, solver.nz],
-                       "parallelism": f"env-sharded x{world} (RCCL bcast/all_gather of actions/obs only)",
-                       "solver_iterations_last_step": stats},
+                       "parallelism": f"env-sharded x{world} (RCCL: one broadcast + one all_gather per step, actions/obs only)",
+                       "pressure_warm_start": bool(env._sim.pressure_warm_start),
+                       "pressure_solver": "CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)",
+                       "solver_iterations": its,
+                       "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2)},
             "roofline": roof,
         }
         if not args.no_micro:
             out["poisson_256"] = poisson_micro(device)
-        if not args.no_micro and world == 1:
+    penv.close()
+    if rank == 0 and world == 1 and not args.no_micro:
+        def leg(name, fn, *a, **kw):
+            t_leg = time.perf_counter()
             try:
-                out["cylinder_env"] = cylinder_env_leg(device)
-            except Exception as exc:  # the headline line must survive a failure of the extra leg
-                out["cylinder_env"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-            if not args.no_airfoil_leg:
-                try:
-                    out["airfoil_env"] = airfoil_env_leg(device)
-                except Exception as exc:
-                    out["airfoil_env"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                out[name] = fn(*a, **kw)
+            except Exception as exc:  # the headline line must survive a failure of an extra leg
+                out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            out[name]["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+
+        import fluidgym_amd
+
+        # the same workload in the opt-in performance mode: pressure solves started from the previous pressure
+        old = fluidgym_amd.set_solver_policy(pressure_warm_start=True)
+        leg("warm_start_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=max(2, args.steps // 2), warmup=2, seed=1234,
+            doc="headline workload with pressure_warm_start=True (not the reference's policy; reported separately)")
+        fluidgym_amd.set_solver_policy(**old)
+        leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=2, warmup=1,
+            doc="BASELINE config 2 on one GPU: Rayleigh-Benard 512x128, 32 envs (256 across 8 GPUs)")
+        leg("tcf_env", env_leg, "TCF3D-baseline-v0", 8, device, steps=2, warmup=1,
+            doc="BASELINE config 3: turbulent channel 128x64x64, 8 envs")
+        leg("cylinder_env", cylinder_env_leg, device)
+        if not args.no_airfoil_leg:
+            leg("airfoil_env", airfoil_env_leg, device)
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    penv.close()
 
 
 if __name__ == "__main__":

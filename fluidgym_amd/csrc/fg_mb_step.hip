@@ -1125,7 +1125,7 @@ __global__ void k_mbs_restore_best(int N, MbSolve q) {
 // Same recurrence, same projection of the residual, same restart / best-iterate / stall rules as mb_cg's kernels; only
 // the summation order of the dot products differs (per-thread partials, wave shuffle, 16 wave sums added in fp64).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int OC_THREADS = 1024, OC_WAVES = OC_THREADS / 64;
+constexpr int OC_MAX_WAVES = 16;   // workgroups of 1024 or 512 threads (NT): 512 threads get 256 registers each
 
 struct OcParams {
     const uint32_t* nbr16;   // [N][F/2] words: one 8-byte load per cell in 2-D
@@ -1137,23 +1137,29 @@ struct OcParams {
     float accept_factor, tol;
 };
 
-__device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[OC_WAVES], double& A, double& B) {
+// block sum of two values in fp64.  `red` is a ring of three slot pairs used in turn (`phase` advances per call): a wave that
+// already runs ahead into the next reduction writes another slot, so ONE barrier per reduction is enough (a slot is rewritten
+// three reductions later, with two barriers in between).
+template <int NT, bool RING = true>
+__device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[2][OC_MAX_WAVES], int& phase, double& A, double& B) {
     a = fg_wave_sum(a);
     b = fg_wave_sum(b);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = (double)a; red[1][threadIdx.x >> 6] = (double)b; }
+    double(*slot)[OC_MAX_WAVES] = red[RING ? phase : 0];
+    if (RING) phase = phase == 2 ? 0 : phase + 1;
+    if ((threadIdx.x & 63) == 0) { slot[0][threadIdx.x >> 6] = (double)a; slot[1][threadIdx.x >> 6] = (double)b; }
     __syncthreads();
     double sa = 0.0, sb = 0.0;
 #pragma unroll
-    for (int w = 0; w < OC_WAVES; ++w) { sa += red[0][w]; sb += red[1][w]; }
-    __syncthreads();
+    for (int w = 0; w < NT / 64; ++w) { sa += slot[0][w]; sb += slot[1][w]; }
+    if (!RING) __syncthreads();   // single slot: nobody may rewrite it before everybody has read it
     A = sa; B = sb;
 }
 
 // y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory: per cell
 // one 8-byte load (four packed neighbour indices) and one 16-byte load (four coefficients) in 2-D.
-template <int DIMS, int CPT, bool DG_REGS>
+template <int DIMS, int CPT, bool DG_REGS, bool NB_REGS, int NT>
 __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int sys, int N, unsigned tl, const float* __restrict__ v_lds,
-                                        const float (&dg)[CPT], float (&y)[CPT]) {
+                                        const float (&dg)[CPT], const uint2 (&nbk)[NB_REGS ? CPT : 1], float (&y)[CPT]) {
     constexpr int F = 2 * DIMS;
     const float* __restrict__ off = q.off + (size_t)sys * F * N;
     const float* __restrict__ diag = q.diag + (size_t)sys * N;
@@ -1163,10 +1169,10 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
         const uint2* __restrict__ nb2 = reinterpret_cast<const uint2*>(o.nbr16);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const unsigned i = tl + (unsigned)k * OC_THREADS;
+            const unsigned i = tl + (unsigned)k * NT;
             float acc = 0.f;
             if (i < un) {
-                const uint2 u = nb2[i];
+                const uint2 u = NB_REGS ? nbk[NB_REGS ? k : 0] : nb2[i];
                 const float4 c = off4[i];
                 const float d = DG_REGS ? dg[k] : diag[i];
                 const uint32_t n0 = u.x & 0xffffu, n1 = u.x >> 16, n2 = u.y & 0xffffu, n3 = u.y >> 16;
@@ -1187,7 +1193,7 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
     const uint32_t* __restrict__ nb = o.nbr16;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const unsigned i = tl + (unsigned)k * OC_THREADS;
+        const unsigned i = tl + (unsigned)k * NT;
         float acc = 0.f;
         if (i < un) {
             acc = (DG_REGS ? dg[k] : diag[i]) * v_lds[i];
@@ -1206,10 +1212,11 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
     }
 }
 
-template <int DIMS, int CPT, int PM, bool DG_REGS>
-__global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
-    __shared__ float v_lds[CPT * OC_THREADS];
-    __shared__ double red[2][OC_WAVES];
+template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true>
+__global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
+    __shared__ float v_lds[CPT * NT];
+    __shared__ double red[3][2][OC_MAX_WAVES];
+    int phase = 0;
     const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
     const size_t vb = (size_t)sys * N;
     if (!mb_active(o.dt, sys)) {
@@ -1220,13 +1227,24 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
         return;
     }
     float r[CPT], x[CPT], ap[CPT], dg[CPT];
+    // the packed neighbour indices of the thread's cells never change: kept in registers when they fit (2-D, interleaved
+    // coefficient layout), which also takes the index load out of the stencil's dependency chain (index -> LDS address)
+    constexpr bool NB_REGS = NBR && (DIMS == 2 && CPT * (NT / 512) <= 32);   // 2 registers per cell: up to 16 (32) cells at 1024 (512) threads
+    uint2 nbk[NB_REGS ? CPT : 1];
+    if (NB_REGS) {
+#pragma unroll
+        for (int k = 0; k < (NB_REGS ? CPT : 1); ++k) {
+            const unsigned i = t + (unsigned)k * NT;
+            nbk[k] = i < (unsigned)N ? reinterpret_cast<const uint2*>(o.nbr16)[i] : make_uint2(0xffffffffu, 0xffffffffu);
+        }
+    }
     const float rsqn = rsqrtf((float)N);
     const float* __restrict__ rhs = q.rhs + vb;
     float* __restrict__ bestx = q.best_x + vb;
     // ---- start: x = x0 or 0, r = rhs (- M x0 through a residual pass)
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const unsigned i = t + (unsigned)k * OC_THREADS;
+        const unsigned i = t + (unsigned)k * NT;
         x[k] = (i < (unsigned)N && o.use_x0) ? q.x[vb + i] : 0.f;
         r[k] = i < (unsigned)N ? rhs[i] : 0.f;
         dg[k] = (DG_REGS && i < (unsigned)N) ? q.diag[vb + i] : 0.f;
@@ -1237,10 +1255,10 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
         float s2 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const unsigned i = t + (unsigned)k * OC_THREADS;
+            const unsigned i = t + (unsigned)k * NT;
             if (i < (unsigned)N) { s2 += r[k] * r[k]; s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn); }
         }
-        oc_reduce2(s2, s1, red, rr, sr);
+        oc_reduce2<NT, RING>(s2, s1, red, phase, rr, sr);
         if (PM == 0) sr = 0.0;
     }
     // One loop, ONE stencil pass per trip: a trip is either a CG iteration (vector in LDS = the new search direction) or a
@@ -1265,7 +1283,7 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
                 ++recoveries;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
-                    const unsigned i = tl + (unsigned)k * OC_THREADS;
+                    const unsigned i = tl + (unsigned)k * NT;
                     if (i < (unsigned)N) { const float v = bestx[i]; x[k] = isfinite(v) ? v : 0.f; }
                 }
                 residual_pass = true; recovering = true;
@@ -1275,7 +1293,7 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
                 if (it == 0 || crit < 0.5f * best || (crit < o.accept_factor * o.tol && crit < best)) {
                     best = crit; best_it = it;
 #pragma unroll
-                    for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * OC_THREADS; if (i < (unsigned)N) bestx[i] = x[k]; }
+                    for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (i < (unsigned)N) bestx[i] = x[k]; }
                 }
                 if (it > 0 && it % o.check_every == 0) {   // the cadence of k_mbs_check in the chunked solver
                     if (o.accept_factor > 0.f && best <= o.accept_factor * o.tol && (it - 1) - best_it >= o.accept_window) { outcome = 3; break; }
@@ -1293,7 +1311,7 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
         // ---- the vector the stencil is applied to: x, or p = (r - (yp.r) yp) + beta p (every thread rewrites its own cells)
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const unsigned i = tl + (unsigned)k * OC_THREADS;
+            const unsigned i = tl + (unsigned)k * NT;
             if (i < (unsigned)N) {
                 float v;
                 if (residual_pass) v = x[k];
@@ -1305,32 +1323,32 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
             }
         }
         __syncthreads();
-        oc_spmv<DIMS, CPT, DG_REGS>(q, o, sys, N, tl, v_lds, dg, ap);
+        oc_spmv<DIMS, CPT, DG_REGS, NB_REGS, NT>(q, o, sys, N, tl, v_lds, dg, nbk, ap);
         float s2 = 0.f, s1 = 0.f;
         if (residual_pass) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
-                const unsigned i = tl + (unsigned)k * OC_THREADS;
+                const unsigned i = tl + (unsigned)k * NT;
                 if (i < (unsigned)N) {
                     r[k] = rhs[i] - ap[k];
                     s2 += r[k] * r[k];
                     s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
                 }
             }
-            oc_reduce2(s2, s1, red, rr, sr);   // its barriers also separate the stencil's LDS reads from the next writes
+            oc_reduce2<NT, RING>(s2, s1, red, phase, rr, sr);   // its barrier also separates the stencil's LDS reads from the next writes
             if (PM == 0) sr = 0.0;
             residual_pass = false; fresh = true; restarted = true;
             continue;
         }
         float part = 0.f;
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * OC_THREADS; if (i < (unsigned)N) part += v_lds[i] * ap[k]; }
+        for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (i < (unsigned)N) part += v_lds[i] * ap[k]; }
         double pap, unused;
-        oc_reduce2(part, 0.f, red, pap, unused);
+        oc_reduce2<NT, RING>(part, 0.f, red, phase, pap, unused);
         const float alpha = (float)(rho / pap);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const unsigned i = tl + (unsigned)k * OC_THREADS;
+            const unsigned i = tl + (unsigned)k * NT;
             if (i < (unsigned)N) {
                 x[k] += alpha * v_lds[i];
                 r[k] -= alpha * ap[k];
@@ -1338,7 +1356,7 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
                 s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
             }
         }
-        oc_reduce2(s2, s1, red, rr, sr);
+        oc_reduce2<NT, RING>(s2, s1, red, phase, rr, sr);
         if (PM == 0) sr = 0.0;
         rho_prev = rho;
         fresh = false;
@@ -1348,7 +1366,7 @@ __global__ __launch_bounds__(OC_THREADS) void k_mbc_onchip(MbDev D, MbSolve q, O
     const bool use_best = (outcome == 3 || outcome == 4 || (outcome == 2 && best < 3.0e38f));
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const unsigned i = t + (unsigned)k * OC_THREADS;
+        const unsigned i = t + (unsigned)k * NT;
         if (i < (unsigned)N) q.x[vb + i] = use_best ? bestx[i] : x[k];
     }
     if (t == 0) {
@@ -1565,15 +1583,17 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     return frc;
 }
 
-#define OC_LAUNCH(CPT_, PM_, DGR_)                                                                                             \
+#define OC_FIRST(a, ...) a
+#define OC_LAUNCH(CPT_, PM_, DGR_, ...)                                                                                        \
     do {                                                                                                                       \
-        if (ev) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_onchip<2, CPT_, PM_, DGR_>), dim3(nsys), dim3(OC_THREADS), 0, st,   \
-                                      s->prof_ev_oc[0], s->prof_ev_oc[1], 0, s->dev, q, o);                                        \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_onchip<2, CPT_, PM_, DGR_>), dim3(nsys), dim3(OC_THREADS), 0, st, s->dev, q, o); \
+        if (ev) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_onchip<2, CPT_, PM_, DGR_, __VA_ARGS__>), dim3(nsys), dim3(OC_FIRST(__VA_ARGS__)), 0, st, \
+                                      s->prof_ev_oc[0], s->prof_ev_oc[1], 0, s->dev, q, o);                                    \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_onchip<2, CPT_, PM_, DGR_, __VA_ARGS__>), dim3(nsys), dim3(OC_FIRST(__VA_ARGS__)), 0, st, s->dev, q, o); \
     } while (0)
-#define OC_LAUNCH_PM(CPT_, DGR_) do { if (pm_mode == 0) OC_LAUNCH(CPT_, 0, DGR_); else OC_LAUNCH(CPT_, 1, DGR_); } while (0)
+#define OC_STREAM_NBR 1024, false
+#define OC_LAUNCH_PM(CPT_, DGR_, ...) do { if (pm_mode == 0) OC_LAUNCH(CPT_, 0, DGR_, __VA_ARGS__); else OC_LAUNCH(CPT_, 1, DGR_, __VA_ARGS__); } while (0)
 
-constexpr int OC_MAX_CELLS = 28 * OC_THREADS;
+constexpr int OC_MAX_CELLS = 28 * 1024;
 
 bool mb_onchip_ok(const fg_mb_state* s, int pm_mode) {
     return s->onchip_mode && s->d == 2 && s->nbr16 != nullptr && s->N <= OC_MAX_CELLS && pm_mode != 2;
@@ -1595,11 +1615,24 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
     o.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; o.tol = tol;
     const bool ev = s->prof_on != 0;
-    if (n <= 4 * OC_THREADS) OC_LAUNCH_PM(4, true);
-    else if (n <= 8 * OC_THREADS) OC_LAUNCH_PM(8, true);
-    else if (n <= 16 * OC_THREADS) OC_LAUNCH_PM(16, false);
-    else if (n <= 24 * OC_THREADS) OC_LAUNCH_PM(24, false);
-    else OC_LAUNCH_PM(28, false);
+    // workgroup shape: FG_MB_OC_VARIANT bit 2 selects 512 threads x 256 registers for the mid-size meshes
+    const bool wide = (s->oc_variant & 4) != 0;
+    if (n <= 4 * 1024) OC_LAUNCH_PM(4, true, 1024);
+    else if (n <= 8 * 1024) OC_LAUNCH_PM(8, true, 1024);
+    else if (n <= 14 * 1024) {
+        if (wide) OC_LAUNCH_PM(28, true, 512);
+        else if (s->oc_variant & 8) OC_LAUNCH_PM(14, false, 1024);          // neighbour indices in registers
+        else if (s->oc_variant & 16) OC_LAUNCH_PM(16, false, 1024, false, false);   // 16 cells per thread, two barriers per reduction
+        else if (s->oc_variant & 32) OC_LAUNCH_PM(16, false, 1024, false, true);    // 16 cells per thread, one barrier
+        else if (s->oc_variant & 64) OC_LAUNCH_PM(14, false, 1024, false, false);   // 14 cells per thread, two barriers
+        else OC_LAUNCH_PM(14, false, OC_STREAM_NBR);                         // ... streamed
+    } else if (n <= 16 * 1024) {
+        if (wide) OC_LAUNCH_PM(32, true, 512);
+        else if (s->oc_variant & 8) OC_LAUNCH_PM(16, false, 1024);
+        else OC_LAUNCH_PM(16, false, OC_STREAM_NBR);
+    }
+    else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024);
+    else OC_LAUNCH_PM(28, false, 1024);
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->best_it, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));  // iterations run
     FG_HIP_CHECK(hipStreamSynchronize(st));

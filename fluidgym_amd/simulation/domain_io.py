@@ -88,13 +88,26 @@ def save_domain(domain: Domain, path: str, env: int = 0) -> None:
         json.dump(dd, fh)
 
 
-def load_domain(path: str, dtype=None, device=None, with_scalar: bool = True, batch: int = 1, prepare: bool = True) -> Domain:
-    """``load_domain`` (domain_io.py:188-327).  Returns a prepared domain (the reference leaves ``PrepareSolve`` to the
-    caller because it allocates; here the field tensors only exist afterwards) unless ``prepare=False``."""
+def read_domain_file(path: str):
+    """The two files of a stored domain as ``(dict, [numpy arrays])`` -- the pure-CPU half of ``load_domain``
+    (domain_io.py:188-205): the JSON tree holds npz keys wherever the reference's writer stored a tensor."""
     with open(path + ".json") as fh:
         dd = json.load(fh)
     with np.load(path + ".npz") as z:
-        data = [torch.from_numpy(np.asarray(z[str(i)])).to(torch.float32) for i in range(len(z.files))]
+        data = [np.asarray(z[str(i)]) for i in range(len(z.files))]
+    info = dd.get("data_info", {})
+    for i, a in enumerate(data):          # the writer records shape / dtype per tensor (:172-180): cross-check
+        meta = info.get(str(i))
+        if meta is not None and list(meta["shape"]) != list(a.shape):
+            raise ValueError(f"{path}: tensor {i} has shape {list(a.shape)} but data_info says {meta['shape']}")
+    return dd, data
+
+
+def load_domain(path: str, dtype=None, device=None, with_scalar: bool = True, batch: int = 1, prepare: bool = True) -> Domain:
+    """``load_domain`` (domain_io.py:188-327).  Returns a prepared domain (the reference leaves ``PrepareSolve`` to the
+    caller because it allocates; here the field tensors only exist afterwards) unless ``prepare=False``."""
+    dd, arrays = read_domain_file(path)
+    data = [torch.from_numpy(a).to(torch.float32) for a in arrays]
     if dtype not in (None, torch.float32):
         raise NotImplementedError("the HIP path computes in fp32")
     get = lambda d, name: data[int(d[name])] if name in d else None
@@ -189,10 +202,8 @@ def load_multiblock_domain(path: str, device=None, batch: int = 1, reference_qui
     state replicated over ``batch`` envs."""
     from .multiblock import MultiBlockDomain
 
-    with open(path + ".json") as fh:
-        dd = json.load(fh)
-    with np.load(path + ".npz") as z:
-        data = [np.asarray(z[str(i)], dtype=np.float32) for i in range(len(z.files))]
+    dd, arrays = read_domain_file(path)
+    data = [np.asarray(a, dtype=np.float32) for a in arrays]
     get = lambda d, key: data[int(d[key])] if key in d else None
     dims = int(dd["spatialDims"])
     if dd.get("passiveScalarChannels", 0):

@@ -889,14 +889,15 @@ def update_advective_boundaries(dom: Domain, faces: Sequence[int], velm: np.ndar
     """``phi_b <- phi_b - t (phi_b - phi_cell)``, ``t = 1 - 1/(1 + 2 dt (Minv_row_n . u_m))``
     for each free FIXED face, then ``balance_boundary_fluxes``."""
     g = dom.grid
-    for f in faces:
+    for k, f in enumerate(faces):
         a = f >> 1
         bc = dom.bc[f]
         vb = np.array(dom.bvel(f))
         Mi = g.b_Minv[f]
         adv = np.zeros(Mi.shape[:-2], dtype=vb.dtype)
+        vm = velm[k] if isinstance(velm, (list, tuple)) else velm   # one characteristic velocity per face, or a global one (:146-147)
         for c in range(g.dims):
-            adv = adv + Mi[..., a, c] * velm[c]
+            adv = adv + Mi[..., a, c] * vm[c]
         t = 1.0 - 1.0 / (1.0 + dt * 2.0 * adv)
         bc.velocity = vb - t * (vb - _cells_slab(g, f, dom.velocity))
         if dom.scalar is not None and bc.scalar is not None:

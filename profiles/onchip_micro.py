@@ -14,7 +14,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 res = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 mesh = make_vortex_street_mesh(res)
-for onchip, variant in (("0", "0"), ("1", "0"), ("1", "1"), ("1", "2"), ("1", "3")):
+for onchip, variant in [("0", "0")] + [("1", v) for v in (sys.argv[4] if len(sys.argv) > 4 else "0,16,32,64").split(",")]:
     os.environ["FG_MB_ONCHIP"], os.environ["FG_MB_OC_VARIANT"] = onchip, variant
     dom = build_domain(mesh, 0.01, batch=B)
     dom.set_stall_limit(100000)

@@ -121,3 +121,82 @@ def test_env_initial_domain_round_trip(tmp_path, monkeypatch):
     b.load_initial_domain(99, EnvMode.TEST)
     assert b._loaded_initial is None
     a.close(); b.close()
+
+
+# ---- files written by the reference's own save_domain (tests/golden/make_golden_domain_io.py) -----------------------------------
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_reader_parses_files_written_by_the_reference():
+    """CPU half of the loader on the reference-written fixtures: key layout, flat tensor numbering, data_info, type strings."""
+    from fluidgym_amd.simulation.domain_io import read_domain_file
+
+    exp = np.load(os.path.join(GOLD, "reference_domain_expected.npz"))
+    dd, data = read_domain_file(os.path.join(GOLD, "reference_domain_single"))
+    assert dd["spatialDims"] == 2 and dd["passiveScalarChannels"] == 1 and len(dd["blocks"]) == 1
+    get = lambda d, k: data[int(d[k])]
+    assert np.allclose(get(dd, "viscosity"), exp["single_viscosity"]) and np.allclose(get(dd, "passiveScalarViscosity"), exp["single_scalar_viscosity"])
+    b = dd["blocks"][0]
+    assert np.array_equal(get(b, "velocity"), exp["single_velocity"]) and np.array_equal(get(b, "scalar"), exp["single_scalar"])
+    assert np.array_equal(get(b, "vertexCoordinates"), exp["single_coords"])
+    types_ = [e["type"] for e in b["boundaries"]]
+    assert types_ == ["PERIODIC", "PERIODIC", "FIXED", "FIXED"]
+    assert b["boundaries"][2]["passiveScalarType"] == ["DIRICHLET"] and b["boundaries"][3]["passiveScalarType"] == ["NEUMANN"]
+    assert np.array_equal(get(b["boundaries"][3], "velocity"), exp["single_bvel3"]) and get(b["boundaries"][3], "velocity").shape == (1, 2)
+    dd2, data2 = read_domain_file(os.path.join(GOLD, "reference_domain_mb"))
+    conn = [[bi, f, e["connectedBlock"]] + e["axes"] for bi, blk in enumerate(dd2["blocks"]) for f, e in enumerate(blk["boundaries"])
+            if e["type"] == "CONNECTED"]
+    assert np.array_equal(np.array(conn), exp["mb_connections"])
+
+
+@pytest.mark.gpu
+def test_load_domain_reads_the_reference_written_single_block_file():
+    import torch
+
+    from fluidgym_amd.simulation.domain_io import load_domain, save_domain
+    from fluidgym_amd.simulation.domain import BoundaryConditionType
+
+    exp = np.load(os.path.join(GOLD, "reference_domain_expected.npz"))
+    dom = load_domain(os.path.join(GOLD, "reference_domain_single"), batch=2)
+    blk = dom.getBlock(0)
+    for e in range(2):
+        assert np.array_equal(blk.velocity[e].cpu().numpy(), exp["single_velocity"][0])
+        assert np.array_equal(blk.pressure[e].cpu().numpy(), exp["single_pressure"][0])
+        assert np.array_equal(blk.passiveScalar[e].cpu().numpy(), exp["single_scalar"][0])
+        assert np.array_equal(blk.getBoundary("-y").velocity[e].cpu().numpy(), exp["single_bvel2"][0])
+        assert np.array_equal(blk.getBoundary("-y").passiveScalar[e].cpu().numpy(), exp["single_bscal2"][0])
+        assert float(blk.getBoundary("+y").velocity[e].abs().max()) == 0.0            # static [1, d] zero velocity, broadcast
+    assert blk.getBoundary("-y").passiveScalarTypes == [BoundaryConditionType.DIRICHLET]
+    assert blk.getBoundary("+y").passiveScalarTypes == [BoundaryConditionType.NEUMANN]
+    assert not blk.isFixed(0) and not blk.isFixed(1)
+    assert abs(float(dom.viscosity) - float(exp["single_viscosity"])) < 1e-9
+    # what we write is what the reference wrote (same keys, same numbering of the tensors that exist in both)
+    import json, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        save_domain(dom, os.path.join(tmp, "again"), env=1)
+        mine = json.load(open(os.path.join(tmp, "again.json")))
+        ref = json.load(open(os.path.join(GOLD, "reference_domain_single.json")))
+        assert set(mine.keys()) == set(ref.keys())
+        assert [b["type"] for b in mine["blocks"][0]["boundaries"]] == [b["type"] for b in ref["blocks"][0]["boundaries"]]
+        assert set(mine["blocks"][0].keys()) == set(ref["blocks"][0].keys())
+    dom.solver.close()
+
+
+@pytest.mark.gpu
+def test_load_multiblock_domain_reads_the_reference_written_file():
+    from fluidgym_amd.simulation.domain_io import load_multiblock_domain
+    from tests import helpers_mb as H
+
+    exp = np.load(os.path.join(GOLD, "reference_domain_expected.npz"))
+    dom = load_multiblock_domain(os.path.join(GOLD, "reference_domain_mb"), batch=2)
+    ref = H.split_rotated_channel().native(batch=1)          # the same mesh built through the construction calls
+    assert np.array_equal(dom.neighbors(), ref.neighbors())   # connections (block, face, axes) decoded as the reference encodes them
+    for k, blk in enumerate(dom.blocks):
+        for e in range(2):
+            assert np.array_equal(blk.cells(dom.velocity)[e].cpu().numpy(), exp[f"mb_velocity{k}"][0])
+            assert np.array_equal(blk.cells(dom.pressure[:, None])[e, 0].cpu().numpy(), exp[f"mb_pressure{k}"][0, 0])
+        for f in range(4):
+            if f"mb_bvel{k}_{f}" in exp:
+                assert np.array_equal(blk.boundary(f)[0].cpu().numpy().reshape(-1), exp[f"mb_bvel{k}_{f}"][0].reshape(2, -1).reshape(-1))
+    ref.close()
+    dom.close()
