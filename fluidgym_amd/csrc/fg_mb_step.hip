@@ -1590,7 +1590,6 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
                                       s->prof_ev_oc[0], s->prof_ev_oc[1], 0, s->dev, q, o);                                    \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_onchip<2, CPT_, PM_, DGR_, __VA_ARGS__>), dim3(nsys), dim3(OC_FIRST(__VA_ARGS__)), 0, st, s->dev, q, o); \
     } while (0)
-#define OC_STREAM_NBR 1024, false
 #define OC_LAUNCH_PM(CPT_, DGR_, ...) do { if (pm_mode == 0) OC_LAUNCH(CPT_, 0, DGR_, __VA_ARGS__); else OC_LAUNCH(CPT_, 1, DGR_, __VA_ARGS__); } while (0)
 
 constexpr int OC_MAX_CELLS = 28 * 1024;
@@ -1615,24 +1614,15 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
     o.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; o.tol = tol;
     const bool ev = s->prof_on != 0;
-    // workgroup shape: FG_MB_OC_VARIANT bit 2 selects 512 threads x 256 registers for the mid-size meshes
-    const bool wide = (s->oc_variant & 4) != 0;
-    if (n <= 4 * 1024) OC_LAUNCH_PM(4, true, 1024);
-    else if (n <= 8 * 1024) OC_LAUNCH_PM(8, true, 1024);
-    else if (n <= 14 * 1024) {
-        if (wide) OC_LAUNCH_PM(28, true, 512);
-        else if (s->oc_variant & 8) OC_LAUNCH_PM(14, false, 1024);          // neighbour indices in registers
-        else if (s->oc_variant & 16) OC_LAUNCH_PM(16, false, 1024, false, false);   // 16 cells per thread, two barriers per reduction
-        else if (s->oc_variant & 32) OC_LAUNCH_PM(16, false, 1024, false, true);    // 16 cells per thread, one barrier
-        else if (s->oc_variant & 64) OC_LAUNCH_PM(14, false, 1024, false, false);   // 14 cells per thread, two barriers
-        else OC_LAUNCH_PM(14, false, OC_STREAM_NBR);                         // ... streamed
-    } else if (n <= 16 * 1024) {
-        if (wide) OC_LAUNCH_PM(32, true, 512);
-        else if (s->oc_variant & 8) OC_LAUNCH_PM(16, false, 1024);
-        else OC_LAUNCH_PM(16, false, OC_STREAM_NBR);
-    }
-    else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024);
-    else OC_LAUNCH_PM(28, false, 1024);
+    // Instances, chosen by measurement on the cylinder mesh (profiles/r02_onchip_variants.txt; 64 envs x 14 232 cells, us per
+    // iteration): 16 cells per thread with the two-barrier reduction 11.7-11.8; the same with the one-barrier ring 14.5; 14
+    // cells per thread 15.8-16.3; neighbour indices in registers 17.4; 512 threads x 256 registers 18.3 -- what the
+    // compiler's schedule makes of each form decides, not the instruction count.  Small meshes keep the indices in registers.
+    if (n <= 4 * 1024) OC_LAUNCH_PM(4, true, 1024, true, false);
+    else if (n <= 8 * 1024) OC_LAUNCH_PM(8, true, 1024, true, false);
+    else if (n <= 16 * 1024) OC_LAUNCH_PM(16, false, 1024, false, false);
+    else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024, false, false);
+    else OC_LAUNCH_PM(28, false, 1024, false, false);
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->best_it, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));  // iterations run
     FG_HIP_CHECK(hipStreamSynchronize(st));
