@@ -109,13 +109,26 @@ void fg_prof_destroy(fg_state* s) {
 }
 
 // ---- measured practical roof: STREAM triad a = b + s c on caller-provided device arrays ("use the measured triad
-// number as the practical roof too").  One 16-byte access per lane and array, grid sized to 16 workgroups per CU.
+// number as the practical roof too").  Four 16-byte accesses per lane and array in flight, one workgroup per 16 KiB of each array.
 namespace {
 __global__ __launch_bounds__(FG_BLOCK) void k_stream_triad(float4* __restrict__ a, const float4* __restrict__ b,
                                                            const float4* __restrict__ c, float s, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * FG_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * FG_BLOCK) {
-        const float4 x = b[i], y = c[i];
-        a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+    // one workgroup streams 4 x 256 consecutive float4 per array: all eight loads of a lane are issued before the first use
+    const size_t base = (size_t)blockIdx.x * (FG_BLOCK * 4) + threadIdx.x;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f* bv = reinterpret_cast<const v4f*>(b);
+    const v4f* cv = reinterpret_cast<const v4f*>(c);
+    v4f* av = reinterpret_cast<v4f*>(a);
+    v4f x[4], y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = base + (size_t)k * FG_BLOCK;
+        if (i < n4) { x[k] = __builtin_nontemporal_load(bv + i); y[k] = __builtin_nontemporal_load(cv + i); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = base + (size_t)k * FG_BLOCK;
+        if (i < n4) __builtin_nontemporal_store(x[k] + s * y[k], av + i);
     }
 }
 }  // namespace
@@ -128,7 +141,7 @@ extern "C" int fg_stream_triad(float* a, const float* b, const float* c, float s
     FG_HIP_CHECK(hipEventCreate(&e0));
     FG_HIP_CHECK(hipEventCreate(&e1));
     const size_t n4 = (size_t)n / 4;
-    const unsigned grid = (unsigned)std::min<size_t>((n4 + FG_BLOCK - 1) / FG_BLOCK, 256 * 16);
+    const unsigned grid = (unsigned)((n4 + FG_BLOCK * 4 - 1) / (FG_BLOCK * 4));
     hipLaunchKernelGGL(k_stream_triad, dim3(grid), dim3(FG_BLOCK), 0, st, (float4*)a, (const float4*)b, (const float4*)c, scalar, n4);
     FG_HIP_CHECK(hipEventRecord(e0, st));
     for (int r = 0; r < reps; ++r)
