@@ -81,6 +81,8 @@ class FgMbStepOptions(Structure):
         ("pressure_warm_start", c_int32),
         ("pressure_project_mean", c_int32),
         ("pressure_stall_accept", c_float),
+        ("solver_double_fallback", c_int32),
+        ("bicg_precondition_fallback", c_int32),
     ]
 
 
@@ -192,6 +194,7 @@ SIGNATURES = {
     "fg_mb_set_residual_projection": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_mb_set_stall_limit": (c_int, [c_void_p, c_int32]),
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),
+    "fg_mb_ladder": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_profile_iterations": (c_int, [c_void_p, POINTER(c_int64)]),

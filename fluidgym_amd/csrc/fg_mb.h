@@ -84,7 +84,7 @@ struct fg_mb_state {
     float* bvel = nullptr;       // [B][d][NB]
     const float* source = nullptr;  // [B][d][N] or null
     // work buffers
-    float *cc, *fb, *Cdiag, *Coff, *rA, *rhs, *ures, *hvec, *div, *Pdiag, *Poff, *pres;
+    float *cc, *fb, *Cdiag, *Coff, *rA, *rhs, *ures, *hvec, *div, *Pdiag, *Poff, *pres, *Sdiag, *Soff;
     float* w[6];
     double* acc;
     float* sc;
@@ -129,6 +129,8 @@ struct fg_mb_state {
     long long prof_n[3] = {0, 0, 0}, prof_launches[3] = {0, 0, 0}, prof_its = 0;
     hipEvent_t prof_ev_oc[2] = {nullptr, nullptr};
     FgCounters ctr;    // iterations per solve kind since the last reset (fg_mb_solver_counters)
+    long long ladder[4] = {0, 0, 0, 0};   // fg_mb_ladder: velocity fp64 rung, velocity preconditioned rung, pressure fp64 rung, pressure CG
+    int ladder_force = 0;
     std::string err;
 };
 

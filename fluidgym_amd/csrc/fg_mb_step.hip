@@ -1448,6 +1448,26 @@ __global__ void k_mb_mask_failed(int B, int nc, const fg_solve_info* __restrict_
     if (bad) { dt[b] = 0.f; fail[b] = 2; }
 }
 
+// right diagonal scaling for the preconditioned BiCGStab rung: M' = M D^-1 (unit diagonal), solved for y = D x
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_scale_cols(MbDev D, const float* __restrict__ dt, const float* __restrict__ diag,
+                                                             const float* __restrict__ off, float* __restrict__ diag_s, float* __restrict__ off_s) {
+    MB_CELL
+    if (!valid || !mb_active(dt, b)) return;
+    constexpr int F = 2 * DIMS;
+    diag_s[(size_t)b * N + i] = 1.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int n = D.nbr[(size_t)f * N + i];
+        off_s[((size_t)b * F + f) * N + i] = n >= 0 ? off[((size_t)b * F + f) * N + i] / diag[(size_t)b * N + n] : 0.f;
+    }
+}
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_unscale(int N, int nc, const float* __restrict__ dt, const float* __restrict__ diag, float* __restrict__ x) {
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y, b = sys / nc;
+    if (i >= N || !mb_active(dt, b)) return;
+    x[(size_t)sys * N + i] /= diag[(size_t)b * N + i];
+}
+
 #define MB_DISPATCH(s, ...)                    \
     do {                                       \
         if ((s)->d == 2) { constexpr int DIMS = 2; __VA_ARGS__ } \
@@ -1503,7 +1523,6 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     q.project = project ? 1 : 0;
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
-    refine = refine && nc == 1;
     // a refined solve that has not converged after 1500 iterations is not going to: hand over to the caller's CG fallback
     // instead of spending the reference's 5000 (one hard env would stall the whole batch)
     if (refine && max_iterations > 1500) max_iterations = 1500;
@@ -1937,6 +1956,8 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->Pdiag, B * N)) return rc;
     if (int rc = mb_alloc(s, &s->Poff, B * F * N)) return rc;
     if (int rc = mb_alloc(s, &s->pres, B * N)) return rc;
+    if (int rc = mb_alloc(s, &s->Sdiag, B * N)) return rc;      // column-scaled matrix of the preconditioned BiCGStab rung
+    if (int rc = mb_alloc(s, &s->Soff, B * F * N)) return rc;
     for (int k = 0; k < 5; ++k)
         if (int rc = mb_alloc(s, &s->w[k], B * d * N)) return rc;
     if (int rc = mb_alloc(s, &s->acc, B * d * MB_ACC)) return rc;
@@ -1957,10 +1978,10 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->dt_step, B)) return rc;
     if (int rc = mb_alloc(s, &s->env_fail, B)) return rc;
     // fp64 iterate + best refinement point of the refined BiCGStab: allocated here, nothing is allocated on the step path
-    if (int rc = mb_alloc(s, &s->x64, B * N)) return rc;
-    if (int rc = mb_alloc(s, &s->x64_best, B * N)) return rc;
-    if (int rc = mb_alloc(s, &s->best_res, B)) return rc;
-    if (int rc = mb_alloc(s, &s->best_keep, B)) return rc;
+    if (int rc = mb_alloc(s, &s->x64, B * d * N)) return rc;        // B * d systems: the fp64 rung also serves the velocity solves
+    if (int rc = mb_alloc(s, &s->x64_best, B * d * N)) return rc;
+    if (int rc = mb_alloc(s, &s->best_res, B * d)) return rc;
+    if (int rc = mb_alloc(s, &s->best_keep, B * d)) return rc;
     if (N < 65535) {   // packed neighbour table of the on-chip CG
         std::vector<uint32_t> packed((size_t)(F / 2) * N);
         for (size_t w = 0; w < F / 2; ++w)
@@ -2047,8 +2068,24 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         for (int no = 0; no < opt->advect_non_ortho_steps; ++no) {
             hipLaunchKernelGGL(k_mb_vrhs<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->velocity, s->ures, s->bvel, s->fb, s->source, s->rhs);
             int m = 0;
-            const int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
-                                        opt->max_iterations, no > 0, &m, st);
+            int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
+                                  opt->max_iterations, no > 0, &m, st);
+            // ---- the reference's retry ladder (_linear_solve, PISOtorch_diff.py:410-476).  The advection solve runs without
+            // returnBestResult, so "not solved" = any system unconverged (or non-finite); every rung starts from zero
+            // ("do not start with a possibly corrupted result tensor", :429-431)
+            auto v_failed = [](int rc) { return rc == FG_ERR_NOT_FINITE || rc == FG_ERR_NOT_CONVERGED; };
+            if ((s->ladder_force & 1) && vrc == FG_OK) vrc = FG_ERR_NOT_CONVERGED;
+            if (v_failed(vrc) && opt->solver_double_fallback) {   // fp64 rung: fp64 iterate, residual b - C x recomputed in fp64
+                ++s->ladder[0];
+                vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol, opt->max_iterations, 0, &m, st, 0, 1);
+                if ((s->ladder_force & 4) && vrc == FG_OK) vrc = FG_ERR_NOT_CONVERGED;
+            }
+            if (v_failed(vrc) && opt->bicg_precondition_fallback) {   // preconditioned rung: (C D^-1) y = b, x = D^-1 y
+                ++s->ladder[1];
+                hipLaunchKernelGGL(k_mb_scale_cols<DIMS>, gn, blk, 0, st, D, dt_B, s->Cdiag, s->Coff, s->Sdiag, s->Soff);
+                vrc = mb_bicgstab(s, dt_B, s->Sdiag, s->Soff, s->rhs, s->ures, d, opt->advection_tol, opt->max_iterations, 0, &m, st);
+                hipLaunchKernelGGL(k_mb_unscale, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B * d), blk, 0, st, N, d, dt_B, (const float*)s->Cdiag, s->ures);
+            }
             if (vrc == FG_ERR_NOT_FINITE) {
                 fg_set_error("fg_mb_piso_step: the velocity (BiCGStab) solve produced a non-finite residual");
                 mask_failed(d);   // solve_ok = False before CopyVelocityResultToBlocks (PISOtorch_simulation.py:1752-1757): state intact
@@ -2079,12 +2116,23 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                                        opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
                 };
                 int prc = solve(warm);
+                if ((s->ladder_force & 2) && prc == FG_OK) prc = FG_ERR_NOT_FINITE;
                 // a warm-started solve that ends unconverged falls back to the reference's start from zero
                 if (prc == FG_ERR_NOT_CONVERGED && ps == 0 && warm) prc = solve(0);
+                // ---- retry ladder (PISOtorch_diff.py:410-476): pressure solves run with returnBestResult, so only a NON-FINITE
+                // residual counts as "not solved".  fp64 rung: the refined BiCGStab (fp64 iterate and residual) from zero -- the
+                // reference repeats CG in fp64, which on the non-symmetric matrix stalls exactly like fp32 CG
+                if (prc == FG_ERR_NOT_FINITE && opt->solver_double_fallback && opt->pressure_use_bicgstab != 2) {
+                    ++s->ladder[2];
+                    prc = mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, 0, &m, st,
+                                      opt->pressure_project_mean, 1);
+                }
                 // BiCGStab keeps no best iterate: a solve of it that broke down or ran out of iterations is repeated with CG,
-                // which hands back its best iterate (the reference's chain runs the other way round, PISOtorch_diff.py:266-371)
-                if (opt->pressure_use_bicgstab && (prc == FG_ERR_NOT_FINITE || (prc == FG_ERR_NOT_CONVERGED && opt->pressure_use_bicgstab != 2)))
-                    prc = solve(0, 1);   // the refined solver hands back its best refinement point itself
+                // which hands back its best iterate (last resort; the refined solver hands back its best refinement point itself)
+                if (opt->pressure_use_bicgstab && (prc == FG_ERR_NOT_FINITE || (prc == FG_ERR_NOT_CONVERGED && opt->pressure_use_bicgstab != 2))) {
+                    ++s->ladder[3];
+                    prc = solve(0, 1);
+                }
                 if (prc == FG_ERR_NOT_FINITE) {
                     fg_set_error("fg_mb_piso_step: the pressure solve produced a non-finite residual");
                     mask_failed(1);
@@ -2117,6 +2165,13 @@ extern "C" int fg_mb_solver_counters(fg_mb_handle s, int64_t* out13, int32_t res
     FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_solver_counters: null handle");
     if (out13) s->ctr.write(out13);
     if (reset) s->ctr.reset();
+    return FG_OK;
+}
+
+extern "C" int fg_mb_ladder(fg_mb_handle s, int64_t* out4, int32_t force_mask) {
+    FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_ladder: null handle");
+    if (out4) for (int k = 0; k < 4; ++k) out4[k] = s->ladder[k];
+    s->ladder_force = force_mask;
     return FG_OK;
 }
 

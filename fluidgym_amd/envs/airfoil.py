@@ -186,7 +186,8 @@ class AirfoilEnvBase(CylinderEnvBase):
         return MultiBlockSimulation(domain, dt=self._dt, adaptive_CFL=self._adaptive_cfl, substeps="ADAPTIVE", corrector_steps=2,
                                     advection_tol=1e-6, pressure_tol=1e-7 if self._ndims == 2 else 1e-8, advect_non_ortho_steps=2,
                                     pressure_non_ortho_steps=4, pressure_use_BiCG=self._pressure_use_bicg,
-                                    outflow=list(self._mesh.outflows), outflow_velocity=(self.U_mean, 0.0, 0.0))
+                                    outflow=list(self._mesh.outflows), outflow_velocity=(self.U_mean, 0.0, 0.0),
+                                    solver_double_fallback=True, BiCG_precondition_fallback=True)   # airfoil_env_base.py:283-285
 
     def _additional_initialization(self) -> None:
         dom = self._domain

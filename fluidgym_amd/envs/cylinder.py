@@ -137,7 +137,8 @@ class CylinderEnvBase(FluidEnv):
                                    pressure_tol=1e-5 if self._ndims == 2 else 5e-7, advect_non_ortho_steps=1,
                                    pressure_non_ortho_steps=1 if self._ndims == 2 else 4,
                                    pressure_use_BiCG=self._pressure_use_bicg, outflow=self._mesh.outflow,
-                                   outflow_velocity=(self._U_mean, 0.0, 0.0), outflow_tol=5e-6)
+                                   outflow_velocity=(self._U_mean, 0.0, 0.0), outflow_tol=5e-6,
+                                   solver_double_fallback=True, BiCG_precondition_fallback=True)   # cylinder_env_base.py:326-328
         return sim
 
     def _additional_initialization(self) -> None:

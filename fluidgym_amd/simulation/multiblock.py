@@ -199,7 +199,8 @@ class MultiBlockDomain:
     def piso_step(self, dt, corrector_steps: int = 2, advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1,
                   advection_tol: float = 1e-5, pressure_tol: float = 1e-5, max_iterations: int = 5000,
                   raise_on_failure: bool = True, pressure_use_bicgstab: bool = False, pressure_warm_start: bool = False,
-                  pressure_project_mean: bool = False):
+                  pressure_project_mean: bool = False, solver_double_fallback: bool = False,
+                  bicg_precondition_fallback: bool = False):
         """One PISO step of every env (``dt``: scalar or [B]; ``dt <= 0`` leaves an env untouched).  Returns the max
         solver iterations (velocity, pressure corrector 0, pressure corrector 1)."""
         if not self.prepared:
@@ -207,7 +208,7 @@ class MultiBlockDomain:
         self._dt.copy_(torch.as_tensor(dt, dtype=torch.float32).expand(self.batch))
         opt = L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
                                 advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
-                                int(pressure_project_mean), 0.0)
+                                int(pressure_project_mean), 0.0, int(solver_double_fallback), int(bicg_precondition_fallback))
         stats = (ctypes.c_int32 * 4)()
         st = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.fg_mb_piso_step(self.handle, ctypes.c_void_p(self._dt.data_ptr()), ctypes.byref(opt), stats,
@@ -259,10 +260,12 @@ class MultiBlockDomain:
 
     def _step_options(self, corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
                       pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start=False,
-                      pressure_project_mean=False, pressure_stall_accept=0.0):
+                      pressure_project_mean=False, pressure_stall_accept=0.0, solver_double_fallback=False,
+                      bicg_precondition_fallback=False):
         return L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
                                  advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
-                                 int(pressure_project_mean), float(pressure_stall_accept))
+                                 int(pressure_project_mean), float(pressure_stall_accept), int(solver_double_fallback),
+                                 int(bicg_precondition_fallback))
 
     def _outflow_ranges(self, outflow):
         """``outflow``: one (block, face) or a list of up to two; returns [(slot0, count), (slot0_b, count_b)]."""
@@ -307,13 +310,15 @@ class MultiBlockDomain:
                     pressure_non_ortho_steps: int = 1, advection_tol: float = 1e-5, pressure_tol: float = 1e-5,
                     max_iterations: int = 5000, pressure_use_bicgstab: bool = False, max_substeps: int = 0,
                     pressure_warm_start: bool = False, pressure_project_mean: bool = False,
-                    pressure_stall_accept: float = 0.0):
+                    pressure_stall_accept: float = 0.0, solver_double_fallback: bool = False,
+                    bicg_precondition_fallback: bool = False):
         """``Simulation.single_step`` on the native side.  ``outflow``: (block, face) of the FIXED face that follows the
         convective outflow condition.  Returns (substeps, all solves converged, max iterations of the last substep)."""
         o = L.FgMbSimOptions()
         o.step = self._step_options(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
                                     pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start,
-                                    pressure_project_mean, pressure_stall_accept)
+                                    pressure_project_mean, pressure_stall_accept, solver_double_fallback,
+                                    bicg_precondition_fallback)
         o.time_step, o.cfl, o.adaptive, o.substeps = float(time_step), float(cfl), int(adaptive), int(substeps)
         o.flux_balance_tol, o.outflow_tol, o.max_substeps = float(flux_balance_tol), float(outflow_tol), int(max_substeps)
         if outflow is not None:
@@ -324,6 +329,13 @@ class MultiBlockDomain:
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_single_step(self.handle, ctypes.byref(o), out, None, ctypes.c_void_p(st)))
         return out[4], bool(out[5]), (out[1], out[2], out[3])
+
+    def ladder(self, force_mask: int = 0) -> dict:
+        """How often each rung of the reference's retry ladder ran (``fg_mb_ladder``); ``force_mask`` (tests) makes first attempts
+        count as failed: 1 velocity, 2 pressure, 4 also the velocity fp64 rung."""
+        out = (ctypes.c_int64 * 4)()
+        L.check(self.lib.fg_mb_ladder(self.handle, out, int(force_mask)))
+        return {"velocity_fp64": out[0], "velocity_preconditioned": out[1], "pressure_fp64": out[2], "pressure_cg": out[3]}
 
     def env_status(self) -> np.ndarray:
         """Per-env outcome of the last step: 0 ok, 1 a solve ended on its best iterate, 2 non-finite solve -- that env's step
@@ -446,7 +458,10 @@ class MultiBlockSimulation:
                  advect_non_ortho_steps: int = 1, pressure_non_ortho_steps: int = 1, max_iterations: int = 5000,
                  pressure_use_BiCG: bool = False, outflow=None, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
                  outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5, pressure_warm_start: Optional[bool] = None,
-                 pressure_project_mean: bool = True, pressure_stall_accept: Optional[float] = None):
+                 pressure_project_mean: bool = True, pressure_stall_accept: Optional[float] = None,
+                 solver_double_fallback: bool = False, BiCG_precondition_fallback: bool = True):
+        # the reference's retry ladder (Simulation attributes set by the envs, e.g. cylinder_env_base.py:326-328)
+        self.solver_double_fallback, self.BiCG_precondition_fallback = bool(solver_double_fallback), bool(BiCG_precondition_fallback)
         from .policy import get_solver_policy
 
         pol = get_solver_policy()   # reference behaviour unless asked otherwise: cold start, no stall acceptance
@@ -478,7 +493,8 @@ class MultiBlockSimulation:
             advect_non_ortho_steps=self.advect_non_ortho_steps, pressure_non_ortho_steps=self.pressure_non_ortho_steps,
             advection_tol=self.advection_tol, pressure_tol=self.pressure_tol, max_iterations=self.max_iterations,
             pressure_use_bicgstab=self.pressure_use_BiCG, pressure_warm_start=self.pressure_warm_start,
-            pressure_project_mean=self.pressure_project_mean, pressure_stall_accept=self.pressure_stall_accept)
+            pressure_project_mean=self.pressure_project_mean, pressure_stall_accept=self.pressure_stall_accept,
+            solver_double_fallback=self.solver_double_fallback, bicg_precondition_fallback=self.BiCG_precondition_fallback)
         self.total_time += self.time_step
         self.total_step += 1
         self.last_substeps, self.last_iterations = n, its

@@ -363,6 +363,14 @@ typedef struct fg_mb_step_options {
                                           flux-balanced right-hand side keeps a component (y.b) y no iteration can remove
                                           -- a residual floor |y.b| / sqrt(N) that sits at 1.1e-5 on the reference's own
                                           cylinder mesh, right at its 1e-5 tolerance; 0: off */
+    int32_t solver_double_fallback;    /* the reference's retry ladder (_linear_solve, PISOtorch_diff.py:410-476).  A solve counts as failed
+                                          like there: the velocity solve when it did not converge, a pressure solve (returnBestResult)
+                                          when its residual is non-finite.  1: a failed solve is repeated from zero with the iterate
+                                          kept in fp64 and the residual b - M x recomputed in fp64 at every restart (the reference
+                                          repeats it with matrix and vectors cast to fp64) */
+    int32_t bicg_precondition_fallback; /* 1: a BiCGStab solve that (still) failed is repeated from zero with a preconditioner: here
+                                          right diagonal scaling (M D^-1) y = b, x = D^-1 y -- same residual, same criterion; the
+                                          reference's rung is cuSPARSE ILU(0), whose triangular solves are sequential */
 } fg_mb_step_options;
 /* dt_B: device array [B]; dt <= 0 leaves that env untouched.  stats_host (optional, 4 ints): max iterations of
  * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
@@ -374,6 +382,10 @@ int fg_mb_piso_step(fg_mb_handle h, const float* dt_B, const fg_mb_step_options*
  * (velocity as before the step, like solve_ok=False before CopyVelocityResultToBlocks, PISOtorch_simulation.py:1752-1757,
  * and Simulation.single_step -> False, simulation.py:259-280) while the other envs of the batch completed. */
 int fg_mb_env_status(fg_mb_handle h, int32_t* out_B_host);
+/* How often each rung of the retry ladder ran since the handle was created: out4 = {velocity fp64 rung, velocity preconditioned
+ * rung, pressure fp64 rung, pressure last-resort CG}.  force_mask (tests): bit 0 / bit 1 make the FIRST attempt of every
+ * velocity / pressure solve count as failed, so that the rungs can be exercised on systems that do not fail. */
+int fg_mb_ladder(fg_mb_handle h, int64_t* out4_host, int32_t force_mask);
 /* as fg_solver_counters, for the multi-block path */
 int fg_mb_solver_counters(fg_mb_handle h, int64_t* out13_host, int32_t reset);
 /* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps

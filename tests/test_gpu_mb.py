@@ -275,3 +275,43 @@ def test_onchip_cg_matches_the_chunked_cg(monkeypatch):
         for k in (1, 2):                                       # pressure solves: same iteration counts within a few per cent
             assert abs(a[k] - b[k]) <= max(3, 0.1 * a[k]), (it0, it1)
     assert max(max(i) for i in it1) > 20                       # the solves did iterate
+
+
+@pytest.mark.parametrize("rungs", ["fp64", "preconditioned", "fp64_then_preconditioned", "pressure_fp64"])
+def test_retry_ladder_rungs_reproduce_the_plain_solve(rungs):
+    """The reference's retry ladder (_linear_solve, PISOtorch_diff.py:410-476): a failed fp32 solve is repeated in fp64
+    (solver_double_fallback), a failed BiCGStab solve with a preconditioner (BiCG_precondition_fallback).  The first attempt is
+    forced to count as failed (fg_mb_ladder's test mask); each rung, starting from zero, must land on the same step as the
+    plain solve and the oracle (skewed two-block mesh, 2 envs)."""
+    spec = H.skewed_pair()
+    d = spec.oracle()
+    states = [_state(d, 11), _state(d, 12)]
+    dt = [0.02, 0.03]
+    kw = dict(advection_tol=1e-7, pressure_tol=2e-7, pressure_use_bicgstab=True, raise_on_failure=False)
+    plain = spec.native(batch=2)
+    _load(plain, states)
+    plain.piso_step(dt, **kw)
+    u_plain = plain.velocity.cpu().numpy().copy()
+    assert plain.ladder() == {"velocity_fp64": 0, "velocity_preconditioned": 0, "pressure_fp64": 0, "pressure_cg": 0}
+    plain.close()
+    dom = spec.native(batch=2)
+    _load(dom, states)
+    force, opts, expect = {
+        "fp64": (1, dict(solver_double_fallback=True), ("velocity_fp64",)),
+        "preconditioned": (1, dict(bicg_precondition_fallback=True), ("velocity_preconditioned",)),
+        "fp64_then_preconditioned": (1 | 4, dict(solver_double_fallback=True, bicg_precondition_fallback=True),
+                                     ("velocity_fp64", "velocity_preconditioned")),
+        "pressure_fp64": (2, dict(solver_double_fallback=True), ("pressure_fp64",)),
+    }[rungs]
+    dom.ladder(force_mask=force)
+    dom.piso_step(dt, **dict(kw, **opts))
+    used = dom.ladder(force_mask=0)
+    for k, v in used.items():
+        assert (v > 0) == (k in expect), used
+    u = dom.velocity.cpu().numpy()
+    assert np.isfinite(u).all()
+    for b in range(2):
+        assert _rel(u[b], u_plain[b]) < 5e-5, rungs
+        u_ref, _ = d.piso_step(states[b][0], states[b][1], dt[b])
+        assert _rel(u[b], u_ref) < 2e-4, rungs
+    dom.close()
