@@ -283,7 +283,7 @@ def solver_iterations(solver) -> dict:
     return out
 
 
-def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", noise=0.0, **env_kw):
+def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing=0.0, **env_kw):
     """One single-block env at full size, batched on this GPU: env-steps/s, iterations per solve over the timed region,
     substeps, the live roofline table of its solver kernels."""
     import torch
@@ -294,12 +294,14 @@ def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", noise=0
     try:
         env.reset(seed=seed)
         env.seed(seed)
-        u_field = env._domain.getBlock(0).velocity
-        noise_gen = torch.Generator(device=device).manual_seed(4321)
+        blk0 = env._domain.getBlock(0)
+        if forcing > 0:
+            blk0.setVelocitySource(torch.zeros_like(blk0.velocity))
+        force_gen = torch.Generator(device=device).manual_seed(4321)
 
         def perturb():
-            if noise > 0:
-                u_field.add_(torch.randn(u_field.shape, device=device, generator=noise_gen), alpha=noise)
+            if forcing > 0:
+                blk0.velocitySource.normal_(0.0, forcing, generator=force_gen)
 
         for _ in range(warmup):
             perturb()
@@ -375,8 +377,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 16 leg (about 10 s)")
-    ap.add_argument("--noise", type=float, default=0.05,
-                    help="velocity noise N(0, noise) added to every env's field before each env step (0 = quiescent channel)")
+    ap.add_argument("--forcing", type=float, default=2.0,
+                    help="amplitude of the random body force (velocity source N(0, forcing), redrawn every env step); 0 = quiescent channel")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -417,15 +419,17 @@ def main():
 
     # Synthetic unsteadiness.  The laminar Re = 100 channel settles to a state whose pressure right-hand side sits AT the
     # reference's absolute tolerance (RMS 1e-5 of the volume-integrated divergence), so its projections take 0-1 iterations
-    # (`quiescent_mode` below).  To time the path the metric is named after, every env step starts from the current state
-    # plus N(0, 0.05) velocity noise -- the amplitude the cylinder envs randomise their initial states with
-    # (cylinder_env_base.py:364-404) -- so that both pressure solves of every PISO step have work to do.
-    noise_gen = torch.Generator(device=device).manual_seed(4321 + rank)
-    u_field = env._domain.getBlock(0).velocity
+    # (`quiescent_mode` below).  To time the path the metric is named after, the flow is stirred: a random body force
+    # (block.velocitySource, a feature of the reference's solver: PISO_multiblock_cuda_kernel.cu:2256-2267) ~ N(0, forcing) per
+    # cell and component, redrawn every env step, so that BOTH pressure solves of EVERY PISO step have a divergence to remove.
+    blk0 = env._domain.getBlock(0)
+    if args.forcing > 0:
+        blk0.setVelocitySource(torch.zeros_like(blk0.velocity))
+    force_gen = torch.Generator(device=device).manual_seed(4321 + rank)
 
     def perturb():
-        if args.noise > 0:
-            u_field.add_(torch.randn(u_field.shape, device=device, generator=noise_gen), alpha=args.noise)
+        if args.forcing > 0:
+            blk0.velocitySource.normal_(0.0, args.forcing, generator=force_gen)
 
     def one_step():
         perturb()
@@ -486,8 +490,8 @@ def main():
             "config": {"workload": f"{args.env_id}"
                                    + (": 2D channel stand-in for 'cylinder Re=100 256x128'" if args.env_id == ENV_ID else "")
                                    + f", {args.envs_per_gpu} envs/GPU, {n_sim} PISO steps per env step, uniform random jet actions"
-                                   + (f", N(0, {args.noise}) velocity noise injected before every env step" if args.noise > 0 else ", quiescent"),
-                       "noise_amplitude": args.noise,
+                                   + (f", stirred by a random body force N(0, {args.forcing}) redrawn every env step" if args.forcing > 0 else ", quiescent"),
+                       "forcing_amplitude": args.forcing,
                        "global_batch": n_total, "grid": [solver.nx, solver.ny, solver.nz],
                        "parallelism": f"env-sharded x{world} (RCCL: one broadcast + one all_gather per step, actions/obs only)",
                        "pressure_warm_start": bool(env._sim.pressure_warm_start),
@@ -511,12 +515,12 @@ def main():
         import fluidgym_amd
 
         leg("quiescent_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=max(2, args.steps // 2), warmup=2, seed=1234,
-            doc="headline workload without the injected noise: the laminar channel's pressure right-hand side sits at the "
+            doc="headline workload without the body force: the laminar channel's pressure right-hand side sits at the "
                 "reference's absolute tolerance, the projections take 0-1 iterations")
         # the same workload in the opt-in performance mode: pressure solves started from the previous pressure
         old = fluidgym_amd.set_solver_policy(pressure_warm_start=True)
         leg("warm_start_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=max(2, args.steps // 2), warmup=2, seed=1234,
-            noise=args.noise, doc="headline workload with pressure_warm_start=True (not the reference's policy; reported separately)")
+            forcing=args.forcing, doc="headline workload with pressure_warm_start=True (not the reference's policy; reported separately)")
         fluidgym_amd.set_solver_policy(**old)
         leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=2, warmup=1,
             doc="BASELINE config 2 on one GPU: Rayleigh-Benard 512x128, 32 envs (256 across 8 GPUs)")
