@@ -163,6 +163,8 @@ SIGNATURES = {
                               c_void_p]),
     "fg_poisson_fdcg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, POINTER(FgSolveInfo),
                                 c_void_p]),
+    "fg_sparse_apply_ell": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "fg_sparse_apply_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fg_stream_triad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, POINTER(c_float), c_void_p]),
     "fg_profile_enable": (c_int, [c_void_p, c_int]),
     "fg_profile_kinds": (c_int, []),

@@ -237,3 +237,55 @@ extern "C" int fg_resample(fg_resampler r, const float* src, int batch, int chan
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-block resampling (curvilinear blocks -> uniform render grid / sensor pixels).  For a fixed mesh the reference's chain
+// splat + normalise + FillFromNeighbors (resampling.cu:191-609; sample_multi_coords_to_uniform_grid_diff) is one linear
+// operator; simulation/resample_mb.py folds it on the host once.  Applying it is a sparse gather: the two kernels below are
+// the whole device side (round 1 went through torch.sparse.mm / fancy indexing).
+//   k_sparse_ell: rows of equal length K (the sensors' rows: 151 x <= 9 cells in 2-D) -- one thread per (row, field)
+//   k_sparse_csr: the full operator -- eight lanes per row stride over its entries (coalesced index / weight reads for
+//                 the long rows that hole filling produces), then reduce with three shuffles
+// field x: [M][N] (M = envs x components, row stride N); out y: [M][rows].
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_sparse_ell(const int32_t* __restrict__ idx, const float* __restrict__ w, int rows, int K,
+                                                     const float* __restrict__ x, size_t n, float* __restrict__ y) {
+    const int r = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (r >= rows) return;
+    const float* xm = x + (size_t)m * n;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += w[(size_t)r * K + k] * xm[idx[(size_t)r * K + k]];
+    y[(size_t)m * rows + r] = acc;
+}
+__global__ __launch_bounds__(256) void k_sparse_csr(const int32_t* __restrict__ indptr, const int32_t* __restrict__ col,
+                                                     const float* __restrict__ val, int rows, const float* __restrict__ x, size_t n,
+                                                     float* __restrict__ y) {
+    const int r = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7, m = blockIdx.y;
+    float acc = 0.f;
+    if (r < rows) {
+        const float* xm = x + (size_t)m * n;
+        for (int k = indptr[r] + sub; k < indptr[r + 1]; k += 8) acc += val[k] * xm[col[k]];
+    }
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    if (r < rows && sub == 0) y[(size_t)m * rows + r] = acc;
+}
+}  // namespace
+
+extern "C" int fg_sparse_apply_ell(const int32_t* idx, const float* w, int32_t rows, int32_t K, const float* x, int64_t n, int32_t m,
+                                   float* y, void* stream) {
+    FG_REQUIRE(idx && w && x && y && rows > 0 && K > 0 && n > 0 && m > 0, FG_ERR_INVALID_ARG, "fg_sparse_apply_ell: bad argument");
+    hipLaunchKernelGGL(k_sparse_ell, dim3((rows + 255) / 256, m), dim3(256), 0, (hipStream_t)stream, idx, w, rows, K, x, (size_t)n, y);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+extern "C" int fg_sparse_apply_csr(const int32_t* indptr, const int32_t* col, const float* val, int32_t rows, const float* x, int64_t n,
+                                   int32_t m, float* y, void* stream) {
+    FG_REQUIRE(indptr && col && val && x && y && rows > 0 && n > 0 && m > 0, FG_ERR_INVALID_ARG, "fg_sparse_apply_csr: bad argument");
+    hipLaunchKernelGGL(k_sparse_csr, dim3((rows * 8 + 255) / 256, m), dim3(256), 0, (hipStream_t)stream, indptr, col, val, rows, x,
+                       (size_t)n, y);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}

@@ -194,10 +194,10 @@ class AirfoilEnvBase(CylinderEnvBase):
         self._ring = WallRing(dom, [(FRONT, "+x", False), (TOP, "-y", False), (BOTTOM, "+y", True)])
         if self._ndims == 3:
             self._resampler = MultiBlockResampler3D(self._mesh.coords, self.render_shape, fill_max_steps=128, device=dom.device)
-            self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.reshape(3, -1).T)
+            self._sensors = self._resampler.sensor_gather(self._sensor_locations.reshape(3, -1).T)
         else:
             self._resampler = MultiBlockResampler(self._mesh.coords, self.render_shape[:2], fill_max_steps=128, device=dom.device)
-            self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.T)
+            self._sensors = self._resampler.sensor_gather(self._sensor_locations.T)
         self._deflation_cos = dom.set_pressure_deflation() if self._pressure_deflation else 1.0
         self._initial_boundary = dom.boundary_velocity.clone()
         self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
@@ -423,8 +423,8 @@ class AirfoilEnv3D(AirfoilEnvBase):
     def _get_global_obs(self) -> Dict[str, torch.Tensor]:
         dom = self._domain
         B, nz, n = self._num_envs, self._n_sensors_z, self._sensor_locations.shape[-1]
-        u = (dom.velocity[:, :, self._sensor_idx] * self._sensor_w).sum(-1)      # [B, 3, nz * n]
-        p = (dom.pressure[:, self._sensor_idx] * self._sensor_w).sum(-1)
+        u = self._sensors(dom.velocity)      # [B, 3, nz * n]
+        p = self._sensors(dom.pressure)
         if self._local_2d_obs:
             u = u[:, :2]
         vd = u.shape[1]

@@ -146,10 +146,10 @@ class CylinderEnvBase(FluidEnv):
         self._ring = WallRing(dom, [(LEFT, "+x", False), (TOP, "-y", False), (RIGHT, "-x", True), (BOTTOM, "+y", True)])
         if self._ndims == 3:
             self._resampler = MultiBlockResampler3D(self._mesh.coords, self.render_shape, fill_max_steps=16, device=dom.device)
-            self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.reshape(3, -1).T)
+            self._sensors = self._resampler.sensor_gather(self._sensor_locations.reshape(3, -1).T)
         else:
             self._resampler = MultiBlockResampler(self._mesh.coords, self.render_shape[:2], fill_max_steps=16, device=dom.device)
-            self._sensor_idx, self._sensor_w = self._resampler.sensor_gather(self._sensor_locations.T)
+            self._sensors = self._resampler.sensor_gather(self._sensor_locations.T)
         self._deflation_cos = dom.set_pressure_deflation() if self._pressure_deflation else 1.0
         self._initial_boundary = dom.boundary_velocity.clone()  # inflow / outflow profile, walls at rest
         self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
@@ -187,8 +187,8 @@ class CylinderEnvBase(FluidEnv):
     # ---- observations, forces, step (cylinder_env_base.py:541-776)
     def _get_global_obs(self) -> Dict[str, torch.Tensor]:
         dom = self._domain
-        u = (dom.velocity[:, :, self._sensor_idx] * self._sensor_w).sum(-1)   # [B, 2, S]
-        p = (dom.pressure[:, self._sensor_idx] * self._sensor_w).sum(-1)      # [B, S]
+        u = self._sensors(dom.velocity)   # [B, 2, S]
+        p = self._sensors(dom.pressure)      # [B, S]
         return {"velocity": u.permute(0, 2, 1).contiguous(), "pressure": p}
 
     def get_velocity(self) -> torch.Tensor:
@@ -416,8 +416,8 @@ class CylinderJetEnv3D(CylinderJetEnv2D):
     def _get_global_obs(self) -> Dict[str, torch.Tensor]:
         dom = self._domain
         B, nz, n = self._num_envs, self._n_sensors_z, self._n_sensors_x_y
-        u = (dom.velocity[:, :, self._sensor_idx] * self._sensor_w).sum(-1)       # [B, 3, nz * 151]
-        p = (dom.pressure[:, self._sensor_idx] * self._sensor_w).sum(-1)          # [B, nz * 151]
+        u = self._sensors(dom.velocity)       # [B, 3, nz * 151]
+        p = self._sensors(dom.pressure)          # [B, nz * 151]
         if self._local_2d_obs:
             u = u[:, :2]
         vd = u.shape[1]

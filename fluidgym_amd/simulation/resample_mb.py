@@ -253,6 +253,40 @@ def build_operator(coords_list: Sequence[np.ndarray], out_shape: Sequence[int], 
     return W.tocsr()
 
 
+def _ptr(t: torch.Tensor):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class SensorGather:
+    """Rows of the resampling operator for a set of pixels, applied on the GPU by ``fg_sparse_apply_ell`` (csrc/fg_resample.hip):
+    ``gather(field [..., N]) -> [..., S]``.  Indexable like the ``(idx, w)`` pair it replaces."""
+
+    def __init__(self, idx: torch.Tensor, w: torch.Tensor):
+        self.idx, self.w = idx, w
+        self._idx32 = idx.to(torch.int32).contiguous()
+        self._w = w.to(torch.float32).contiguous()
+
+    def __iter__(self):
+        return iter((self.idx, self.w))
+
+    def __call__(self, field: torch.Tensor) -> torch.Tensor:
+        from .. import _lib as L
+
+        if not field.is_cuda:   # stubbed-solver CPU tests: the same sum written with torch
+            return (field[..., self.idx] * self.w).sum(-1)
+        lead = field.shape[:-1]
+        flat = field.reshape(-1, field.shape[-1])
+        if not flat.is_contiguous():
+            flat = flat.contiguous()
+        S, K = self._idx32.shape
+        out = torch.empty(flat.shape[0], S, dtype=torch.float32, device=field.device)
+        st = torch.cuda.current_stream(field.device).cuda_stream
+        L.check(L.load().fg_sparse_apply_ell(_ptr(self._idx32), _ptr(self._w), S, K, _ptr(flat), flat.shape[1], flat.shape[0], _ptr(out),
+                                             __import__("ctypes").c_void_p(st)))
+        return out.reshape(*lead, S)
+
+
 class MultiBlockResampler3D:
     """The factored plan replayed on the GPU: one scatter-add for the splat, one gather per fill pass."""
 
@@ -291,7 +325,7 @@ class MultiBlockResampler3D:
         pix = np.asarray(pixel_xyz, np.int64)
         ox, oy, _ = self.out_shape
         idx, w = self.plan.rows_ell(pix[:, 0] + ox * (pix[:, 1] + oy * pix[:, 2]))
-        return torch.as_tensor(idx, device=self.device), torch.as_tensor(w, device=self.device)
+        return SensorGather(torch.as_tensor(idx, device=self.device), torch.as_tensor(w, device=self.device))
 
 
 class MultiBlockResampler:
@@ -301,16 +335,27 @@ class MultiBlockResampler:
         self.out_shape = (int(out_shape[0]), int(out_shape[1]))
         self.W_host = build_operator(coords_list, out_shape, fill_max_steps)
         self.device = torch.device("cuda") if device is None else torch.device(device)
-        W = self.W_host.tocoo()
-        idx = torch.as_tensor(np.stack([W.row, W.col]), dtype=torch.int64)
-        self._W = torch.sparse_coo_tensor(idx, torch.as_tensor(W.data, dtype=torch.float32), size=W.shape).coalesce().to(self.device)
+        W = self.W_host.tocsr()
+        W.sort_indices()
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
+        self._indptr, self._col, self._val = t(W.indptr, torch.int32), t(W.indices, torch.int32), t(W.data, torch.float32)
+        self._rows = W.shape[0]
 
     def __call__(self, field: torch.Tensor) -> torch.Tensor:
-        """field [..., N] -> [..., oy, ox]."""
+        """field [..., N] -> [..., oy, ox]: one native sparse gather (``fg_sparse_apply_csr``, csrc/fg_resample.hip)."""
+        import ctypes
+
+        from .. import _lib as L
+
         lead = field.shape[:-1]
-        flat = field.reshape(-1, field.shape[-1]).t().contiguous()  # [N, M]
-        out = torch.sparse.mm(self._W, flat)                      # [pixels, M]
-        return out.t().reshape(*lead, self.out_shape[1], self.out_shape[0])
+        flat = field.reshape(-1, field.shape[-1]).to(torch.float32)
+        if not flat.is_contiguous():
+            flat = flat.contiguous()
+        out = torch.empty(flat.shape[0], self._rows, dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(L.load().fg_sparse_apply_csr(_ptr(self._indptr), _ptr(self._col), _ptr(self._val), self._rows, _ptr(flat), flat.shape[1],
+                                             flat.shape[0], _ptr(out), ctypes.c_void_p(st)))
+        return out.reshape(*lead, self.out_shape[1], self.out_shape[0])
 
     def sensor_gather(self, pixel_xy: np.ndarray):
         """ELL rows of the operator for pixels ``[(x, y), ...]``: (cell index [S, K] long, weight [S, K] float32)."""
@@ -324,4 +369,4 @@ class MultiBlockResampler:
             a, b = sub.indptr[r], sub.indptr[r + 1]
             idx[r, : b - a] = sub.indices[a:b]
             w[r, : b - a] = sub.data[a:b]
-        return torch.as_tensor(idx, device=self.device), torch.as_tensor(w, device=self.device)
+        return SensorGather(torch.as_tensor(idx, device=self.device), torch.as_tensor(w, device=self.device))

@@ -287,6 +287,14 @@ int fg_profile_read(fg_handle h, int kind, double* ms_sum, int64_t* samples, dou
  * full multilinear splat of the reference's pure-torch implementation (resample.py:361-548).
  * fg_resample: src [batch, channels, (nz,) ny, nx] -> dst [batch, channels, (oz,) oy, ox], both fp32 device
  * pointers, channels <= 8; fill_max_steps as fillMaxSteps (resampling.cu:242-290). */
+/* Multi-block resampling = a fixed sparse operator per mesh (the folded splat + normalise + hole-fill chain of
+ * SampleTransformedGridLocalToGlobalMulti + _FillEmptyCells, resampling.cu:191-609, built on the host once).  y[m][r] = sum_k w * x[m][idx]:
+ * ELL rows of equal length K (sensor pixels: the observation of every env step) or CSR (whole render grid).  x: [m][n] device,
+ * y: [m][rows] device; index / weight arrays on the device. */
+int fg_sparse_apply_ell(const int32_t* idx, const float* w, int32_t rows, int32_t K, const float* x, int64_t n, int32_t m, float* y,
+                        void* stream);
+int fg_sparse_apply_csr(const int32_t* indptr, const int32_t* col, const float* val, int32_t rows, const float* x, int64_t n, int32_t m,
+                        float* y, void* stream);
 typedef struct fg_resampler_state* fg_resampler;
 int fg_resampler_create(int dims, const int32_t* n_src, const int32_t* n_out, const int32_t* base_cat,
                         const float* frac_cat, int quirk3d, int device, fg_resampler* out);

@@ -69,6 +69,15 @@ def test_sensor_gather_equals_full_resampling():
     ref = full[:, torch.as_tensor(sy), torch.as_tensor(sx)].t()
     assert torch.allclose(obs["velocity"][0], ref, rtol=1e-5, atol=1e-6)
     assert full.shape == (2, env.render_shape[1], env.render_shape[0])
+    # the native sparse kernels (fg_sparse_apply_csr / _ell, csrc/fg_resample.hip) against the host operator they apply, which is
+    # pinned on the reference's own resampling (tests/test_resample_mb.py, reference_resample_mb.npz)
+    import numpy as np
+    W = env._resampler.W_host
+    u = env._domain.velocity[0].cpu().numpy().astype(np.float64)                 # [2, N]
+    host = (W @ u.T).T.reshape(2, env.render_shape[1], env.render_shape[0])
+    assert np.abs(full.cpu().numpy() - host).max() <= 1e-5 * max(np.abs(host).max(), 1.0)
+    rows = np.asarray(sy) * env.render_shape[0] + np.asarray(sx)
+    assert np.abs(obs["velocity"][0].cpu().numpy() - (W[rows] @ u.T)).max() <= 1e-5 * max(np.abs(host).max(), 1.0)
     env.close()
 
 
