@@ -102,8 +102,8 @@ def _obs_env(use_marl):
     rs = env.render_shape
     env._domain = _FakeDomain(rs)
     px = env._sensor_locations.reshape(3, -1)
-    env._sensor_idx = torch.as_tensor(px[0] + rs[0] * (px[1] + rs[1] * px[2]))[:, None]
-    env._sensor_w = torch.ones(px.shape[1], 1)
+    from fluidgym_amd.simulation.resample_mb import SensorGather
+    env._sensors = SensorGather(torch.as_tensor(px[0] + rs[0] * (px[1] + rs[1] * px[2]))[:, None], torch.ones(px.shape[1], 1))
     return env
 
 

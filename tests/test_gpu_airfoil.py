@@ -117,7 +117,7 @@ def test_3d_env_single_and_multi_agent():
     full = env.get_velocity()
     assert full.shape == (2, 3, 150, 150, 600)
     px = env._sensor_locations.reshape(3, -1)
-    u = (env._domain.velocity[:, :, env._sensor_idx] * env._sensor_w).sum(-1)
+    u = env._sensors(env._domain.velocity)
     assert torch.allclose(full[:, :, px[2], px[1], px[0]], u, atol=1e-5)
     env.close()
 

@@ -184,7 +184,7 @@ def test_3d_env_contract_single_agent():
     full = env.get_velocity()                                                  # [B, 3, z, y, x]
     px = env._sensor_locations.reshape(3, -1)
     at = full[:, :, px[2], px[1], px[0]]                                       # [B, 3, S]
-    u = (env._domain.velocity[:, :, env._sensor_idx] * env._sensor_w).sum(-1)
+    u = env._sensors(env._domain.velocity)
     assert torch.allclose(at, u, atol=1e-5)
     assert env.render().shape == (32, 171)
     env.close()
