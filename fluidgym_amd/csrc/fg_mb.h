@@ -98,6 +98,9 @@ struct fg_mb_state {
     // on-chip CG (fg_mb_step.hip::k_mbc_onchip): neighbour table packed to 16 bits per face, (low half = even
     // face, high half = odd face, 0xFFFF = prescribed face); [N][F/2] words, built when N < 65535
     uint32_t* nbr16 = nullptr;
+    // multilevel preconditioner of the on-chip CG (fg_mb_set_multilevel)
+    uint16_t *ml_a4 = nullptr, *ml_parent4 = nullptr; float *ml_d4g = nullptr, *ml_aci8 = nullptr;
+    int ml_n4 = 0, ml_n8 = 0; float ml_geom_diag_sum = 0.f; bool ml_on = false;
     float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
     int oc_variant = 0;        // FG_MB_OC_VARIANT (tuning switches of the on-chip CG)
     int onchip_mode = 1;       // FG_MB_ONCHIP: 0 never, 1 when the mesh fits one workgroup's LDS / registers (default)

@@ -1127,7 +1127,21 @@ __global__ void k_mbs_restore_best(int N, MbSolve q) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int OC_MAX_WAVES = 16;   // workgroups of 1024 or 512 threads (NT): 512 threads get 256 registers each
 
+// Two-level-plus additive preconditioner of the on-chip CG (fg_mb_set_multilevel): M r = D^-1 r + 1/2 Z4 D4^-1 Z4^T r + Z8 A8^+ Z8^T r with
+// piecewise-constant aggregates of 4 x 4 and 8 x 8 cells inside the blocks, D4 the diagonal of the Galerkin operator Z4^T S Z4 and
+// A8^+ the (dense) pseudo-inverse of Z8^T S Z8, S = symmetric part of the pressure matrix for A = 1 (geometry only), scaled per env.
+constexpr int OC_N4 = 2048, OC_N8 = 512;
+struct OcPre {
+    const uint16_t* a4;        // [N]   4 x 4 aggregate of every cell
+    const uint16_t* parent4;   // [n4]  8 x 8 aggregate of every 4 x 4 aggregate
+    const float* d4g;          // [n4]  diag(Z4^T S Z4)
+    const float* aci8;         // [n8][n8] pseudo-inverse of Z8^T S Z8
+    int n4, n8;
+    float geom_diag_sum;       // sum_i S_ii: the env's scale is sum_i P_ii / geom_diag_sum (P = S / A with A nearly constant)
+};
+
 struct OcParams {
+    OcPre pre;
     const uint32_t* nbr16;   // [N][F/2] words: one 8-byte load per cell in 2-D
     const float* off4;       // [B][N][4] off-diagonals interleaved per cell (2-D), or null: q.off [B][F][N] is read instead
     int fence;               // compiler fence every four cells of the stencil pass (bounds the loads in flight)
@@ -1212,10 +1226,11 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
     }
 }
 
-template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true>
+template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true, bool PRE = false>
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
     __shared__ float v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
+    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1];
     int phase = 0;
     const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
     const size_t vb = (size_t)sys * N;
@@ -1251,6 +1266,15 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         ap[k] = 0.f;
     }
     double rr = 0.0, sr = 0.0;
+    float inv_s = 1.f;   // 1 / (scale of this env's matrix against the geometry-only one)
+    if (PRE) {
+        float sd = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const unsigned i = t + (unsigned)k * NT; if (i < (unsigned)N) sd += q.diag[vb + i]; }
+        double dsum, unused0;
+        oc_reduce2<NT, RING>(sd, 0.f, red, phase, dsum, unused0);
+        inv_s = (float)((double)o.pre.geom_diag_sum / dsum);
+    }
     if (!o.use_x0) {
         float s2 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -1261,6 +1285,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         oc_reduce2<NT, RING>(s2, s1, red, phase, rr, sr);
         if (PM == 0) sr = 0.0;
     }
+    double rz = 0.0, rz_prev = 1.0;
     // One loop, ONE stencil pass per trip: a trip is either a CG iteration (vector in LDS = the new search direction) or a
     // residual pass r = rhs - M x (vector in LDS = x: start from x0, the restart every 100 iterations, a recovery).
     int it = 0, best_it = 0, recoveries = 0, outcome = 0;   // outcome: 1 converged, 2 non-finite, 3 accepted on the kept iterate, 4 out of iterations / stalled
@@ -1303,10 +1328,51 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 if (it > 0 && it % o.restart_every == 0 && !restarted) residual_pass = true;   // residualResetSteps (cg_solver_kernel.cu:281-300)
             }
         }
+        float zbar = 0.f;
         if (!residual_pass) {
             restarted = false;
             beta = fresh ? 0.f : (float)(rho / rho_prev);
             cy = (float)sr;
+            if (PRE) {
+                // ---- z = M (r - mean r): restrict to the 4 x 4 and 8 x 8 aggregates (LDS atomics), dense coarse solve by the
+                // waves (one row per wave and pass, lanes over the columns), corrections summed top-down into l_r4
+                const float rm = PM == 1 ? cy * rsqn : 0.f;
+                const int n4 = o.pre.n4, n8 = o.pre.n8;
+                for (int a = t; a < n4; a += NT) l_r4[a] = 0.f;
+                for (int a = t; a < n8; a += NT) l_r8[a] = 0.f;
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const unsigned i = tl + (unsigned)k * NT;
+                    if (i < (unsigned)N) atomicAdd(&l_r4[o.pre.a4[i]], r[k] - rm);
+                }
+                __syncthreads();
+                for (int a = t; a < n4; a += NT) atomicAdd(&l_r8[o.pre.parent4[a]], l_r4[a]);
+                __syncthreads();
+                for (int row = t >> 6; row < n8; row += NT / 64) {
+                    float acc = 0.f;
+                    for (int j = t & 63; j < n8; j += 64) acc += o.pre.aci8[(unsigned)row * (unsigned)n8 + j] * l_r8[j];
+                    acc = fg_wave_sum(acc);
+                    if ((t & 63) == 0) l_e8[row] = acc * inv_s;
+                }
+                __syncthreads();
+                for (int a = t; a < n4; a += NT) l_r4[a] = 0.5f * inv_s * l_r4[a] / o.pre.d4g[a] + l_e8[o.pre.parent4[a]];
+                __syncthreads();
+                float s_rz = 0.f, s_z = 0.f;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const unsigned i = tl + (unsigned)k * NT;
+                    if (i < (unsigned)N) {
+                        const float rt = r[k] - rm;
+                        const float z = rt / (DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]];
+                        s_rz += rt * z; s_z += z;
+                    }
+                }
+                double zsum;
+                oc_reduce2<NT, RING>(s_rz, s_z, red, phase, rz, zsum);
+                zbar = PM == 1 ? (float)(zsum / (double)N) : 0.f;
+                beta = fresh ? 0.f : (float)(rz / rz_prev);
+            }
         }
         // ---- the vector the stencil is applied to: x, or p = (r - (yp.r) yp) + beta p (every thread rewrites its own cells)
 #pragma unroll
@@ -1317,6 +1383,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 if (residual_pass) v = x[k];
                 else {
                     v = PM == 0 ? r[k] : (PM == 1 ? r[k] - cy * rsqn : r[k] - cy * o.yp[i]);
+                    if (PRE) v = v / (DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]] - zbar;   // z of this cell, recomputed
                     if (!fresh) v += beta * v_lds[i];
                 }
                 v_lds[i] = v;
@@ -1345,7 +1412,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (i < (unsigned)N) part += v_lds[i] * ap[k]; }
         double pap, unused;
         oc_reduce2<NT, RING>(part, 0.f, red, phase, pap, unused);
-        const float alpha = (float)(rho / pap);
+        const float alpha = (float)((PRE ? rz : rho) / pap);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = tl + (unsigned)k * NT;
@@ -1359,6 +1426,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         oc_reduce2<NT, RING>(s2, s1, red, phase, rr, sr);
         if (PM == 0) sr = 0.0;
         rho_prev = rho;
+        rz_prev = rz;
         fresh = false;
         ++it;
     }
@@ -1637,11 +1705,16 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     // iteration): 16 cells per thread with the two-barrier reduction 11.7-11.8; the same with the one-barrier ring 14.5; 14
     // cells per thread 15.8-16.3; neighbour indices in registers 17.4; 512 threads x 256 registers 18.3 -- what the
     // compiler's schedule makes of each form decides, not the instruction count.  Small meshes keep the indices in registers.
-    if (n <= 4 * 1024) OC_LAUNCH_PM(4, true, 1024, true, false);
-    else if (n <= 8 * 1024) OC_LAUNCH_PM(8, true, 1024, true, false);
-    else if (n <= 16 * 1024) OC_LAUNCH_PM(16, false, 1024, false, false);
-    else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024, false, false);
-    else OC_LAUNCH_PM(28, false, 1024, false, false);
+    const bool pre = s->ml_on && s->ml_a4 != nullptr;
+    o.pre.a4 = s->ml_a4; o.pre.parent4 = s->ml_parent4; o.pre.d4g = s->ml_d4g; o.pre.aci8 = s->ml_aci8;
+    o.pre.n4 = s->ml_n4; o.pre.n8 = s->ml_n8; o.pre.geom_diag_sum = s->ml_geom_diag_sum;
+#define OC_LAUNCH_PRE(CPT_, DGR_, NBR_) do { if (pre) OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, true); else OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, false); } while (0)
+    if (n <= 4 * 1024) OC_LAUNCH_PRE(4, true, true);
+    else if (n <= 8 * 1024) OC_LAUNCH_PRE(8, true, true);
+    else if (n <= 16 * 1024) OC_LAUNCH_PRE(16, false, false);
+    else if (n <= 24 * 1024) OC_LAUNCH_PRE(24, false, false);
+    else OC_LAUNCH_PRE(28, false, false);
+#undef OC_LAUNCH_PRE
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->best_it, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));  // iterations run
     FG_HIP_CHECK(hipStreamSynchronize(st));
@@ -2165,6 +2238,31 @@ extern "C" int fg_mb_solver_counters(fg_mb_handle s, int64_t* out13, int32_t res
     FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_solver_counters: null handle");
     if (out13) s->ctr.write(out13);
     if (reset) s->ctr.reset();
+    return FG_OK;
+}
+
+// Tables of the multilevel preconditioner of the on-chip pressure CG (built on the host from the geometry-only pressure matrix,
+// simulation/multiblock.py::set_pressure_multilevel); a4 / parent4 as int32 on the host, stored as 16-bit on the device.
+extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, const int32_t* a4_host, const int32_t* parent4_host,
+                                    const float* d4g_host, const float* aci8_host, float geom_diag_sum, int32_t enable) {
+    FG_REQUIRE(s && s->finalized && !s->host_only, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: domain not finalized (or host-only)");
+    if (!a4_host) { s->ml_on = enable && s->ml_a4 != nullptr; return FG_OK; }   // switch only
+    FG_REQUIRE(s->d == 2 && n4 > 0 && n4 <= OC_N4 && n8 > 0 && n8 <= OC_N8 && parent4_host && d4g_host && aci8_host && geom_diag_sum != 0.f,
+               FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: 2-D meshes with at most 2048 / 512 aggregates");
+    std::vector<uint16_t> a4(s->N), p4(n4);
+    for (int i = 0; i < s->N; ++i) { FG_REQUIRE(a4_host[i] >= 0 && a4_host[i] < n4, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: aggregate id out of range"); a4[i] = (uint16_t)a4_host[i]; }
+    for (int a = 0; a < n4; ++a) { FG_REQUIRE(parent4_host[a] >= 0 && parent4_host[a] < n8, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: parent id out of range"); p4[a] = (uint16_t)parent4_host[a]; }
+    if (!s->ml_a4) {
+        if (int rc = mb_alloc(s, &s->ml_a4, (size_t)s->N)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_parent4, (size_t)OC_N4)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_d4g, (size_t)OC_N4)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_aci8, (size_t)OC_N8 * OC_N8)) return rc;
+    }
+    FG_HIP_CHECK(hipMemcpy(s->ml_a4, a4.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_parent4, p4.data(), sizeof(uint16_t) * n4, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_d4g, d4g_host, sizeof(float) * n4, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_aci8, aci8_host, sizeof(float) * (size_t)n8 * n8, hipMemcpyHostToDevice));
+    s->ml_n4 = n4; s->ml_n8 = n8; s->ml_geom_diag_sum = geom_diag_sum; s->ml_on = enable != 0;
     return FG_OK;
 }
 

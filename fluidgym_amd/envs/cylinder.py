@@ -151,6 +151,9 @@ class CylinderEnvBase(FluidEnv):
             self._resampler = MultiBlockResampler(self._mesh.coords, self.render_shape[:2], fill_max_steps=16, device=dom.device)
             self._sensors = self._resampler.sensor_gather(self._sensor_locations.T)
         self._deflation_cos = dom.set_pressure_deflation() if self._pressure_deflation else 1.0
+        from ..simulation.policy import get_solver_policy
+        self._multilevel = dom.set_pressure_multilevel() if (get_solver_policy()["pressure_multilevel"] and not self._pressure_deflation
+                                                              and not self._pressure_use_bicg) else None
         self._initial_boundary = dom.boundary_velocity.clone()  # inflow / outflow profile, walls at rest
         self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
 

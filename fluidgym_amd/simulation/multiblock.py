@@ -111,6 +111,53 @@ class MBBlock:
         return out
 
 
+def multilevel_tables(P, blocks, max_n4: int = 2048, max_n8: int = 512):
+    """Host tables of the multilevel pressure preconditioner (pure NumPy / SciPy, no GPU).  ``P``: pressure matrix for ``A = 1``
+    (SciPy sparse, cells of all blocks in flat order); ``blocks``: ``(nx, ny, cell_offset)`` per block.  Aggregates are tiles
+    inside the blocks: about 8 x 8 cells (balanced when the size is not a multiple), each split into 2 x 2 sub-tiles of about
+    4 x 4.  Returns ``a4`` [N], ``parent4`` [n4], ``d4`` = diag(Z4^T S Z4), ``aci8`` = pinv(Z8^T S Z8), ``geom_diag_sum`` =
+    trace(S), with ``S`` the symmetric part of ``P``; None when the aggregate counts exceed the kernel's LDS tables."""
+    import scipy.sparse as sp
+
+    S = (0.5 * (P + P.T)).tocsr()
+    N = S.shape[0]
+    a4 = np.zeros(N, np.int64)
+    parent4: List[int] = []
+    n4 = n8 = 0
+    for nx, ny, offset in blocks:
+        g8x, g8y = max(1, -(-nx // 8)), max(1, -(-ny // 8))
+        t8x, t8y = (np.arange(nx) * g8x) // nx, (np.arange(ny) * g8y) // ny          # balanced 8-tile index per cell column / row
+
+        def halves(t8):
+            h = np.zeros(len(t8), np.int64)
+            for tile in np.unique(t8):
+                idx = np.nonzero(t8 == tile)[0]
+                h[idx[(len(idx) + 1) // 2:]] = 1                                      # second half of the tile
+            return h
+
+        t4x, t4y = 2 * t8x + halves(t8x), 2 * t8y + halves(t8y)
+        local4 = (t4y[:, None] * (2 * g8x) + t4x[None, :]).reshape(-1)
+        a4[offset: offset + nx * ny] = n4 + local4
+        par = np.full(4 * g8x * g8y, -1, np.int64)
+        par[local4] = (n8 + t8y[:, None] * g8x + t8x[None, :]).reshape(-1)
+        parent4.extend(par.tolist())
+        n4 += 4 * g8x * g8y
+        n8 += g8x * g8y
+    parent4 = np.asarray(parent4, np.int64)
+    used = np.zeros(n4, bool)
+    used[a4] = True                                                                   # sub-tiles no cell fell into (tiles 1 cell wide)
+    remap = np.cumsum(used) - 1
+    a4, parent4, n4 = remap[a4], parent4[used], int(used.sum())
+    if n4 > max_n4 or n8 > max_n8:
+        return None
+    Z4 = sp.csr_matrix((np.ones(N), (np.arange(N), a4)), shape=(N, n4))
+    Z8 = sp.csr_matrix((np.ones(n4), (np.arange(n4), parent4)), shape=(n4, n8))
+    A4 = (Z4.T @ S @ Z4).tocsr()
+    A8 = (Z8.T @ A4 @ Z8).toarray()
+    return {"a4": a4, "parent4": parent4, "n4": n4, "n8": n8, "d4": A4.diagonal(), "aci8": np.linalg.pinv(A8, rcond=1e-10, hermitian=True),
+            "geom_diag_sum": float(S.diagonal().sum())}
+
+
 class MultiBlockDomain:
     """``PISOtorch.Domain`` for connected curvilinear blocks, batched over envs."""
 
@@ -134,6 +181,7 @@ class MultiBlockDomain:
         self.velocity = self.pressure = self.boundary_velocity = self.velocity_source = None
         self.n_cells = self.n_boundary_faces = 0
         self._dt = None
+        self.multilevel = None   # aggregate counts once set_pressure_multilevel has installed the preconditioner
 
     def CreateBlock(self, vertexCoordinates, name: str = "") -> MBBlock:
         c = vertexCoordinates.detach().cpu().numpy() if isinstance(vertexCoordinates, torch.Tensor) else np.asarray(vertexCoordinates)
@@ -360,6 +408,32 @@ class MultiBlockDomain:
             ok = nbr[f] >= 0
             rows.append(np.nonzero(ok)[0]); cols.append(nbr[f][ok]); vals.append(off[f][ok])
         return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N))
+
+    def set_pressure_multilevel(self, enable: bool = True) -> Optional[dict]:
+        """Build and install the additive multilevel preconditioner of the on-chip pressure CG (``fg_mb_set_multilevel``): Jacobi on
+        the cells + half-weighted Jacobi on 4 x 4 aggregates + the exact (pseudo-)inverse on 8 x 8 aggregates, aggregates being
+        tiles inside the blocks (:func:`multilevel_tables`).  Everything comes from the symmetric part ``S`` of the pressure matrix
+        for ``A = 1`` -- geometry only, so it is built ONCE per mesh and shared by all envs; a per-env scale accounts for
+        ``P = S / A`` with ``A`` nearly constant (the same argument as the single-block path's constant-coefficient
+        preconditioner, DESIGN.md section 4).  The reference runs CG without a preconditioner (cg_solver_kernel.cu:129-471);
+        converged answers agree to the solver tolerance, iteration counts drop 3-4x (profiles/r02_*).  2-D meshes that run the
+        on-chip solver only; returns the aggregate counts, or None when the mesh does not qualify (nothing is installed)."""
+        if self.dims != 2 or self.n_cells > 28 * 1024 or self.n_cells >= 65535:
+            return None
+        if not enable:
+            L.check(self.lib.fg_mb_set_multilevel(self.handle, 0, 0, None, None, None, None, 0.0, 0))
+            return None
+        P = self.unit_pressure_matrix().astype(np.float64)
+        tab = multilevel_tables(P, [(b.size[0], b.size[1], b.cell_offset) for b in self.blocks])
+        if tab is None:
+            return None
+        i32, f32 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)
+        a4_32, p4_32 = np.ascontiguousarray(tab["a4"], np.int32), np.ascontiguousarray(tab["parent4"], np.int32)
+        d4_32, aci_32 = np.ascontiguousarray(tab["d4"], np.float32), np.ascontiguousarray(tab["aci8"], np.float32)
+        L.check(self.lib.fg_mb_set_multilevel(self.handle, tab["n4"], tab["n8"], a4_32.ctypes.data_as(i32), p4_32.ctypes.data_as(i32),
+                                              d4_32.ctypes.data_as(f32), aci_32.ctypes.data_as(f32), float(tab["geom_diag_sum"]), 1))
+        self.multilevel = {"n4": tab["n4"], "n8": tab["n8"]}
+        return self.multilevel
 
     def set_pressure_deflation(self) -> float:
         """Keep the pressure-CG residuals orthogonal to the LEFT near-null vector of the pressure matrix instead of the

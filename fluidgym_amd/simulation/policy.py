@@ -14,8 +14,13 @@ benchmark line can say which mode it ran in:
     iterations ends with that iterate.  This loosens the effective tolerance by the factor, so it
     is off unless asked for.
 
+``pressure_multilevel`` (default True)
+    Multi-block 2-D envs whose pressure CG runs on-chip (the cylinder family): the additive multilevel preconditioner of
+    ``MultiBlockDomain.set_pressure_multilevel``.  It changes the Krylov trajectory, not the system or its tolerance (the
+    single-block path is preconditioned in the same spirit); ``False`` gives the reference's plain CG.
+
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` /
-``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` (read once at import).
+``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` (read once at import).
 """
 from __future__ import annotations
 
@@ -25,6 +30,7 @@ from typing import Any, Dict
 _POLICY: Dict[str, Any] = {
     "pressure_warm_start": os.environ.get("FLUIDGYM_AMD_PRESSURE_WARM_START", "0") not in ("0", "", "false", "False"),
     "pressure_stall_accept": float(os.environ.get("FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT", "0") or 0.0),
+    "pressure_multilevel": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL", "1") not in ("0", "", "false", "False"),
 }
 
 
