@@ -1230,7 +1230,8 @@ template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
     __shared__ float v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
-    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1];
+    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1], l_part[4][PRE ? OC_N8 : 1];
+    static_assert(!PRE || NT == 1024, "the coarse solve of the preconditioner splits its columns over four groups of 256 threads");
     int phase = 0;
     const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
     const size_t vb = (size_t)sys * N;
@@ -1349,12 +1350,21 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 __syncthreads();
                 for (int a = t; a < n4; a += NT) atomicAdd(&l_r8[o.pre.parent4[a]], l_r4[a]);
                 __syncthreads();
-                for (int row = t >> 6; row < n8; row += NT / 64) {
-                    float acc = 0.f;
-                    for (int j = t & 63; j < n8; j += 64) acc += o.pre.aci8[(unsigned)row * (unsigned)n8 + j] * l_r8[j];
-                    acc = fg_wave_sum(acc);
-                    if ((t & 63) == 0) l_e8[row] = acc * inv_s;
+                // e8 = A8^+ r8, 4 x 256 threads: thread (row, quarter) sums its quarter of the columns; A8^+ is symmetric, so the
+                // entries a thread needs are read as column `row` of consecutive rows -- consecutive threads, consecutive
+                // addresses, and the n8 / 4 loads of a thread are independent (a wave-per-row version spent 14 dependent
+                // load -> reduce round trips here, 18 us per application)
+                {
+                    const int qn = (n8 + 3) >> 2;
+                    for (int row = t & 255; row < n8; row += 256) {
+                        const int qtr = t >> 8, c0 = qtr * qn, c1 = min(c0 + qn, n8);
+                        float acc = 0.f;
+                        for (int c = c0; c < c1; ++c) acc += o.pre.aci8[(unsigned)c * (unsigned)n8 + row] * l_r8[c];
+                        l_part[qtr][row] = acc;
+                    }
                 }
+                __syncthreads();
+                for (int row = t; row < n8; row += NT) l_e8[row] = inv_s * (l_part[0][row] + l_part[1][row] + l_part[2][row] + l_part[3][row]);
                 __syncthreads();
                 for (int a = t; a < n4; a += NT) l_r4[a] = 0.5f * inv_s * l_r4[a] / o.pre.d4g[a] + l_e8[o.pre.parent4[a]];
                 __syncthreads();
@@ -1365,6 +1375,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     if (i < (unsigned)N) {
                         const float rt = r[k] - rm;
                         const float z = rt / (DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]];
+                        ap[k] = z;   // ap is free until the stencil pass rewrites it
                         s_rz += rt * z; s_z += z;
                     }
                 }
@@ -1383,7 +1394,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 if (residual_pass) v = x[k];
                 else {
                     v = PM == 0 ? r[k] : (PM == 1 ? r[k] - cy * rsqn : r[k] - cy * o.yp[i]);
-                    if (PRE) v = v / (DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]] - zbar;   // z of this cell, recomputed
+                    if (PRE) v = ap[k] - zbar;   // z of this cell, parked in ap by the preconditioner pass
                     if (!fresh) v += beta * v_lds[i];
                 }
                 v_lds[i] = v;
