@@ -1134,8 +1134,8 @@ constexpr int OC_N4 = 2048, OC_N8 = 512;
 struct OcPre {
     const uint16_t* a4;        // [N]   4 x 4 aggregate of every cell
     const uint16_t* parent4;   // [n4]  8 x 8 aggregate of every 4 x 4 aggregate
-    const float* d4g;          // [n4]  diag(Z4^T S Z4)
-    const float* aci8;         // [n8][n8] pseudo-inverse of Z8^T S Z8
+    const float* d4g;          // [n4]  1 / diag(Z4^T S Z4)
+    const float* aci8;         // [n8][ld] pseudo-inverse of Z8^T S Z8, row pitch ld = n8 rounded up to a multiple of 4
     int n4, n8;
     float geom_diag_sum;       // sum_i S_ii: the env's scale is sum_i P_ii / geom_diag_sum (P = S / A with A nearly constant)
 };
@@ -1230,8 +1230,8 @@ template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
     __shared__ float v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
-    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1], l_part[4][PRE ? OC_N8 : 1];
-    static_assert(!PRE || NT == 1024, "the coarse solve of the preconditioner splits its columns over four groups of 256 threads");
+    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1], l_part[OC_MAX_WAVES][PRE ? OC_N8 : 4];
+    static_assert(!PRE || NT == 1024, "the coarse solve of the preconditioner gives every one of the 16 waves its own set of columns");
     int phase = 0;
     const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
     const size_t vb = (size_t)sys * N;
@@ -1350,23 +1350,33 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 __syncthreads();
                 for (int a = t; a < n4; a += NT) atomicAdd(&l_r8[o.pre.parent4[a]], l_r4[a]);
                 __syncthreads();
-                // e8 = A8^+ r8, 4 x 256 threads: thread (row, quarter) sums its quarter of the columns; A8^+ is symmetric, so the
-                // entries a thread needs are read as column `row` of consecutive rows -- consecutive threads, consecutive
-                // addresses, and the n8 / 4 loads of a thread are independent (a wave-per-row version spent 14 dependent
-                // load -> reduce round trips here, 18 us per application)
+                // e8 = A8^+ r8.  A8^+ is symmetric, so row r is read as column r of consecutive rows: wave g takes the columns
+                // c = g, g + 16, ..., lane q the four rows 4q .. 4q+3 -- every load is a 16-byte access, a wave reads 1 KiB
+                // contiguous, and the ~15 loads of a lane are independent (128 KiB in flight per workgroup: the matrix, 208 KB
+                // at 228 aggregates, streams from L2 once per iteration).  A wave-per-row version spent 14 dependent
+                // load -> reduce round trips here (18 us), one thread per (row, quarter of the columns) 10 us.
                 {
-                    const int qn = (n8 + 3) >> 2;
-                    for (int row = t & 255; row < n8; row += 256) {
-                        const int qtr = t >> 8, c0 = qtr * qn, c1 = min(c0 + qn, n8);
-                        float acc = 0.f;
-                        for (int c = c0; c < c1; ++c) acc += o.pre.aci8[(unsigned)c * (unsigned)n8 + row] * l_r8[c];
-                        l_part[qtr][row] = acc;
+                    const int ld = (n8 + 3) & ~3, nq = ld >> 2, grp = t >> 6;
+                    for (int qd = t & 63; qd < nq; qd += 64) {
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                        for (int c = grp; c < n8; c += OC_MAX_WAVES) {
+                            const float4 a = *reinterpret_cast<const float4*>(o.pre.aci8 + (unsigned)c * (unsigned)ld + 4u * (unsigned)qd);
+                            const float rc = l_r8[c];
+                            acc.x += a.x * rc; acc.y += a.y * rc; acc.z += a.z * rc; acc.w += a.w * rc;
+                        }
+                        *reinterpret_cast<float4*>(&l_part[grp][4 * qd]) = acc;
                     }
                 }
                 __syncthreads();
-                for (int row = t; row < n8; row += NT) l_e8[row] = inv_s * (l_part[0][row] + l_part[1][row] + l_part[2][row] + l_part[3][row]);
+                for (int row = t; row < n8; row += NT) {
+                    float e = 0.f;
+#pragma unroll
+                    for (int g = 0; g < OC_MAX_WAVES; ++g) e += l_part[g][row];
+                    l_e8[row] = inv_s * e;
+                }
                 __syncthreads();
-                for (int a = t; a < n4; a += NT) l_r4[a] = 0.5f * inv_s * l_r4[a] / o.pre.d4g[a] + l_e8[o.pre.parent4[a]];
+                for (int a = t; a < n4; a += NT) l_r4[a] = 0.5f * inv_s * l_r4[a] * o.pre.d4g[a] + l_e8[o.pre.parent4[a]];   // d4g holds reciprocals
                 __syncthreads();
                 float s_rz = 0.f, s_z = 0.f;
 #pragma unroll
@@ -1374,7 +1384,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     const unsigned i = tl + (unsigned)k * NT;
                     if (i < (unsigned)N) {
                         const float rt = r[k] - rm;
-                        const float z = rt / (DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]];
+                        const float z = rt * __builtin_amdgcn_rcpf(DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]];   // v_rcp_f32: a preconditioner needs no IEEE division
                         ap[k] = z;   // ap is free until the stencil pass rewrites it
                         s_rz += rt * z; s_z += z;
                     }
@@ -2271,8 +2281,14 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
     }
     FG_HIP_CHECK(hipMemcpy(s->ml_a4, a4.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_parent4, p4.data(), sizeof(uint16_t) * n4, hipMemcpyHostToDevice));
-    FG_HIP_CHECK(hipMemcpy(s->ml_d4g, d4g_host, sizeof(float) * n4, hipMemcpyHostToDevice));
-    FG_HIP_CHECK(hipMemcpy(s->ml_aci8, aci8_host, sizeof(float) * (size_t)n8 * n8, hipMemcpyHostToDevice));
+    std::vector<float> rd4(n4);
+    for (int a = 0; a < n4; ++a) { FG_REQUIRE(d4g_host[a] != 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: zero Galerkin diagonal"); rd4[a] = 1.f / d4g_host[a]; }
+    const int ld = (n8 + 3) & ~3;
+    std::vector<float> padded((size_t)n8 * ld, 0.f);
+    for (int r = 0; r < n8; ++r)
+        for (int c = 0; c < n8; ++c) padded[(size_t)r * ld + c] = aci8_host[(size_t)r * n8 + c];
+    FG_HIP_CHECK(hipMemcpy(s->ml_d4g, rd4.data(), sizeof(float) * n4, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_aci8, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
     s->ml_n4 = n4; s->ml_n8 = n8; s->ml_geom_diag_sum = geom_diag_sum; s->ml_on = enable != 0;
     return FG_OK;
 }
