@@ -195,8 +195,8 @@ SIGNATURES = {
     "fg_mb_max_velocity": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
     "fg_mb_set_residual_projection": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_mb_set_stall_limit": (c_int, [c_void_p, c_int32]),
-    "fg_mb_set_multilevel": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_float), POINTER(c_float),
-                                     c_float, c_int32]),
+    "fg_mb_set_multilevel": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_float),
+                                     POINTER(c_float), c_float, c_int32]),
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "fg_mb_ladder": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),

@@ -99,7 +99,7 @@ struct fg_mb_state {
     // face, high half = odd face, 0xFFFF = prescribed face); [N][F/2] words, built when N < 65535
     uint32_t* nbr16 = nullptr;
     // multilevel preconditioner of the on-chip CG (fg_mb_set_multilevel)
-    uint16_t *ml_a4 = nullptr, *ml_parent4 = nullptr; float *ml_d4g = nullptr, *ml_aci8 = nullptr;
+    uint16_t *ml_a4 = nullptr, *ml_parent4 = nullptr; float *ml_d4g = nullptr, *ml_aci8 = nullptr; uint2 *ml_rect4 = nullptr, *ml_child8 = nullptr;
     int ml_n4 = 0, ml_n8 = 0; float ml_geom_diag_sum = 0.f; bool ml_on = false;
     float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
     int oc_variant = 0;        // FG_MB_OC_VARIANT (tuning switches of the on-chip CG)

@@ -1134,6 +1134,8 @@ constexpr int OC_N4 = 2048, OC_N8 = 512;
 struct OcPre {
     const uint16_t* a4;        // [N]   4 x 4 aggregate of every cell
     const uint16_t* parent4;   // [n4]  8 x 8 aggregate of every 4 x 4 aggregate
+    const uint2* rect4;        // [n4]  the aggregate as a rectangle of cells: .x = first cell, .y = width | height << 8 | row stride << 16
+    const uint2* child8;       // [n8]  the (up to four) 4 x 4 aggregates of an 8 x 8 aggregate, 16 bits each, 0xFFFF = none
     const float* d4g;          // [n4]  1 / diag(Z4^T S Z4)
     const float* aci8;         // [n8][ld] pseudo-inverse of Z8^T S Z8, row pitch ld = n8 rounded up to a multiple of 4
     int n4, n8;
@@ -1145,6 +1147,7 @@ struct OcParams {
     const uint32_t* nbr16;   // [N][F/2] words: one 8-byte load per cell in 2-D
     const float* off4;       // [B][N][4] off-diagonals interleaved per cell (2-D), or null: q.off [B][F][N] is read instead
     int fence;               // compiler fence every four cells of the stencil pass (bounds the loads in flight)
+    int dbg;                 // timing experiments (FG_MB_OC_VARIANT >> 8): 1 no restriction atomics, 2 no coarse solve, 4 no z pass loads
     const float* dt;         // [B] or null
     const float* yp;         // [N] projection vector (PM == 2)
     int use_x0, project_mean, restart_every, check_every, max_iterations, stall_limit, accept_window;
@@ -1230,7 +1233,12 @@ template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
     __shared__ float v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
-    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1], l_part[OC_MAX_WAVES][PRE ? OC_N8 : 4];
+    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1];
+    // r - mean r of the preconditioner pass, where the aggregate sums gather it; once they have, the same memory holds the
+    // per-wave partial sums of the coarse solve
+    constexpr int RT = PRE ? (CPT * NT > OC_MAX_WAVES * OC_N8 ? CPT * NT : OC_MAX_WAVES * OC_N8) : 1;
+    __shared__ __attribute__((aligned(16))) float l_rt[RT];
+    float (*l_part)[OC_N8] = reinterpret_cast<float (*)[OC_N8]>(l_rt);
     static_assert(!PRE || NT == 1024, "the coarse solve of the preconditioner gives every one of the 16 waves its own set of columns");
     int phase = 0;
     const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
@@ -1339,16 +1347,30 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 // waves (one row per wave and pass, lanes over the columns), corrections summed top-down into l_r4
                 const float rm = PM == 1 ? cy * rsqn : 0.f;
                 const int n4 = o.pre.n4, n8 = o.pre.n8;
-                for (int a = t; a < n4; a += NT) l_r4[a] = 0.f;
-                for (int a = t; a < n8; a += NT) l_r8[a] = 0.f;
-                __syncthreads();
+                // restriction as GATHERS: every aggregate is a rectangle of cells of one block, so one thread sums it out of the
+                // LDS copy of the residual; 8 x 8 aggregates sum their (up to four) children.  LDS float atomics did this first
+                // and cost 21 us per application (14 k atomics on 912 addresses)
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     const unsigned i = tl + (unsigned)k * NT;
-                    if (i < (unsigned)N) atomicAdd(&l_r4[o.pre.a4[i]], r[k] - rm);
+                    if (i < (unsigned)N) l_rt[i] = r[k] - rm;
                 }
                 __syncthreads();
-                for (int a = t; a < n4; a += NT) atomicAdd(&l_r8[o.pre.parent4[a]], l_r4[a]);
+                for (int a = t; a < n4; a += NT) {
+                    const uint2 rc = o.pre.rect4[a];
+                    const unsigned w = rc.y & 0xffu, h = (rc.y >> 8) & 0xffu, stride = rc.y >> 16;
+                    float sum = 0.f;
+                    for (unsigned dy = 0; dy < h; ++dy)
+                        for (unsigned dx = 0; dx < w; ++dx) sum += l_rt[rc.x + dy * stride + dx];
+                    l_r4[a] = sum;
+                }
+                __syncthreads();
+                for (int a = t; a < n8; a += NT) {
+                    const uint2 ch = o.pre.child8[a];
+                    const unsigned c0 = ch.x & 0xffffu, c1 = ch.x >> 16, c2 = ch.y & 0xffffu, c3 = ch.y >> 16;
+                    l_r8[a] = (c0 != 0xffffu ? l_r4[c0] : 0.f) + (c1 != 0xffffu ? l_r4[c1] : 0.f) + (c2 != 0xffffu ? l_r4[c2] : 0.f) +
+                              (c3 != 0xffffu ? l_r4[c3] : 0.f);
+                }
                 __syncthreads();
                 // e8 = A8^+ r8.  A8^+ is symmetric, so row r is read as column r of consecutive rows: wave g takes the columns
                 // c = g, g + 16, ..., lane q the four rows 4q .. 4q+3 -- every load is a 16-byte access, a wave reads 1 KiB
@@ -1717,6 +1739,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     o.nbr16 = s->nbr16; o.dt = dt; o.yp = s->dev.yproj;
     o.off4 = (off == s->Poff && !(s->oc_variant & 2)) ? s->Poff4 : nullptr;
     o.fence = (s->oc_variant & 1) ? 0 : 1;
+    o.dbg = s->oc_variant >> 8;
     o.use_x0 = use_x0; o.project_mean = pm_mode; o.restart_every = CG_RESTART; o.check_every = CG_CHUNK;
     o.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
     o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
@@ -1726,15 +1749,16 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     // iteration): 16 cells per thread with the two-barrier reduction 11.7-11.8; the same with the one-barrier ring 14.5; 14
     // cells per thread 15.8-16.3; neighbour indices in registers 17.4; 512 threads x 256 registers 18.3 -- what the
     // compiler's schedule makes of each form decides, not the instruction count.  Small meshes keep the indices in registers.
-    const bool pre = s->ml_on && s->ml_a4 != nullptr;
+    const bool pre = s->ml_on && s->ml_a4 != nullptr && n <= 16 * 1024;   // LDS: p, r - mean r and the aggregate tables
     o.pre.a4 = s->ml_a4; o.pre.parent4 = s->ml_parent4; o.pre.d4g = s->ml_d4g; o.pre.aci8 = s->ml_aci8;
+    o.pre.rect4 = s->ml_rect4; o.pre.child8 = s->ml_child8;
     o.pre.n4 = s->ml_n4; o.pre.n8 = s->ml_n8; o.pre.geom_diag_sum = s->ml_geom_diag_sum;
 #define OC_LAUNCH_PRE(CPT_, DGR_, NBR_) do { if (pre) OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, true); else OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, false); } while (0)
     if (n <= 4 * 1024) OC_LAUNCH_PRE(4, true, true);
     else if (n <= 8 * 1024) OC_LAUNCH_PRE(8, true, true);
     else if (n <= 16 * 1024) OC_LAUNCH_PRE(16, false, false);
-    else if (n <= 24 * 1024) OC_LAUNCH_PRE(24, false, false);
-    else OC_LAUNCH_PRE(28, false, false);
+    else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024, false, false, false);
+    else OC_LAUNCH_PM(28, false, 1024, false, false, false);
 #undef OC_LAUNCH_PRE
     FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->best_it, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));  // iterations run
@@ -2265,15 +2289,44 @@ extern "C" int fg_mb_solver_counters(fg_mb_handle s, int64_t* out13, int32_t res
 // Tables of the multilevel preconditioner of the on-chip pressure CG (built on the host from the geometry-only pressure matrix,
 // simulation/multiblock.py::set_pressure_multilevel); a4 / parent4 as int32 on the host, stored as 16-bit on the device.
 extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, const int32_t* a4_host, const int32_t* parent4_host,
-                                    const float* d4g_host, const float* aci8_host, float geom_diag_sum, int32_t enable) {
+                                    const int32_t* rect4_host, const float* d4g_host, const float* aci8_host, float geom_diag_sum,
+                                    int32_t enable) {
     FG_REQUIRE(s && s->finalized && !s->host_only, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: domain not finalized (or host-only)");
     if (!a4_host) { s->ml_on = enable && s->ml_a4 != nullptr; return FG_OK; }   // switch only
-    FG_REQUIRE(s->d == 2 && n4 > 0 && n4 <= OC_N4 && n8 > 0 && n8 <= OC_N8 && parent4_host && d4g_host && aci8_host && geom_diag_sum != 0.f,
+    FG_REQUIRE(s->d == 2 && n4 > 0 && n4 <= OC_N4 && n8 > 0 && n8 <= OC_N8 && parent4_host && rect4_host && d4g_host && aci8_host &&
+                   geom_diag_sum != 0.f,
                FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: 2-D meshes with at most 2048 / 512 aggregates");
     std::vector<uint16_t> a4(s->N), p4(n4);
     for (int i = 0; i < s->N; ++i) { FG_REQUIRE(a4_host[i] >= 0 && a4_host[i] < n4, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: aggregate id out of range"); a4[i] = (uint16_t)a4_host[i]; }
     for (int a = 0; a < n4; ++a) { FG_REQUIRE(parent4_host[a] >= 0 && parent4_host[a] < n8, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: parent id out of range"); p4[a] = (uint16_t)parent4_host[a]; }
+    // every aggregate must be the rectangle it is declared as (the kernel sums it by its shape), and an 8 x 8 aggregate has at
+    // most four children
+    std::vector<uint2> rect(n4), child(n8, make_uint2(0xffffffffu, 0xffffffffu));
+    {
+        std::vector<int> count(n4, 0);
+        for (int i = 0; i < s->N; ++i) count[a4[i]]++;
+        for (int a = 0; a < n4; ++a) {
+            const int first = rect4_host[4 * a], w = rect4_host[4 * a + 1], h = rect4_host[4 * a + 2], stride = rect4_host[4 * a + 3];
+            FG_REQUIRE(first >= 0 && w >= 1 && w <= 255 && h >= 1 && h <= 255 && stride >= w && stride <= 65535 && w * h == count[a] &&
+                           (long)first + (long)(h - 1) * stride + w <= (long)s->N,
+                       FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: aggregate is not the declared rectangle");
+            for (int dy = 0; dy < h; ++dy)
+                for (int dx = 0; dx < w; ++dx)
+                    FG_REQUIRE(a4[first + dy * stride + dx] == a, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: aggregate is not the declared rectangle");
+            rect[a] = make_uint2((unsigned)first, (unsigned)w | ((unsigned)h << 8) | ((unsigned)stride << 16));
+        }
+        std::vector<int> nch(n8, 0);
+        for (int a = 0; a < n4; ++a) {
+            const int p = p4[a], k = nch[p]++;
+            FG_REQUIRE(k < 4, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: an 8 x 8 aggregate has more than four children");
+            unsigned* words = &child[p].x;
+            unsigned& wref = words[k >> 1];
+            wref = (k & 1) ? ((wref & 0x0000ffffu) | ((unsigned)a << 16)) : ((wref & 0xffff0000u) | (unsigned)a);
+        }
+    }
     if (!s->ml_a4) {
+        if (int rc = mb_alloc(s, &s->ml_rect4, (size_t)OC_N4)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_child8, (size_t)OC_N8)) return rc;
         if (int rc = mb_alloc(s, &s->ml_a4, (size_t)s->N)) return rc;
         if (int rc = mb_alloc(s, &s->ml_parent4, (size_t)OC_N4)) return rc;
         if (int rc = mb_alloc(s, &s->ml_d4g, (size_t)OC_N4)) return rc;
@@ -2281,6 +2334,8 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
     }
     FG_HIP_CHECK(hipMemcpy(s->ml_a4, a4.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_parent4, p4.data(), sizeof(uint16_t) * n4, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_rect4, rect.data(), sizeof(uint2) * n4, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_child8, child.data(), sizeof(uint2) * n8, hipMemcpyHostToDevice));
     std::vector<float> rd4(n4);
     for (int a = 0; a < n4; ++a) { FG_REQUIRE(d4g_host[a] != 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: zero Galerkin diagonal"); rd4[a] = 1.f / d4g_host[a]; }
     const int ld = (n8 + 3) & ~3;

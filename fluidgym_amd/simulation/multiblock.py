@@ -123,6 +123,7 @@ def multilevel_tables(P, blocks, max_n4: int = 2048, max_n8: int = 512):
     N = S.shape[0]
     a4 = np.zeros(N, np.int64)
     parent4: List[int] = []
+    rects: Dict[int, tuple] = {}
     n4 = n8 = 0
     for nx, ny, offset in blocks:
         g8x, g8y = max(1, -(-nx // 8)), max(1, -(-ny // 8))
@@ -138,6 +139,11 @@ def multilevel_tables(P, blocks, max_n4: int = 2048, max_n8: int = 512):
         t4x, t4y = 2 * t8x + halves(t8x), 2 * t8y + halves(t8y)
         local4 = (t4y[:, None] * (2 * g8x) + t4x[None, :]).reshape(-1)
         a4[offset: offset + nx * ny] = n4 + local4
+        for ty in np.unique(t4y):                                                     # every sub-tile as a rectangle of cells
+            ys = np.nonzero(t4y == ty)[0]
+            for tx in np.unique(t4x):
+                xs = np.nonzero(t4x == tx)[0]
+                rects[n4 + ty * (2 * g8x) + tx] = (offset + ys[0] * nx + xs[0], len(xs), len(ys), nx)
         par = np.full(4 * g8x * g8y, -1, np.int64)
         par[local4] = (n8 + t8y[:, None] * g8x + t8x[None, :]).reshape(-1)
         parent4.extend(par.tolist())
@@ -147,6 +153,7 @@ def multilevel_tables(P, blocks, max_n4: int = 2048, max_n8: int = 512):
     used = np.zeros(n4, bool)
     used[a4] = True                                                                   # sub-tiles no cell fell into (tiles 1 cell wide)
     remap = np.cumsum(used) - 1
+    rect4 = np.array([rects[k] for k in np.nonzero(used)[0]], np.int64)                # [n4, 4]: first cell, width, height, row stride
     a4, parent4, n4 = remap[a4], parent4[used], int(used.sum())
     if n4 > max_n4 or n8 > max_n8:
         return None
@@ -154,7 +161,7 @@ def multilevel_tables(P, blocks, max_n4: int = 2048, max_n8: int = 512):
     Z8 = sp.csr_matrix((np.ones(n4), (np.arange(n4), parent4)), shape=(n4, n8))
     A4 = (Z4.T @ S @ Z4).tocsr()
     A8 = (Z8.T @ A4 @ Z8).toarray()
-    return {"a4": a4, "parent4": parent4, "n4": n4, "n8": n8, "d4": A4.diagonal(), "aci8": np.linalg.pinv(A8, rcond=1e-10, hermitian=True),
+    return {"a4": a4, "parent4": parent4, "rect4": rect4, "n4": n4, "n8": n8, "d4": A4.diagonal(), "aci8": np.linalg.pinv(A8, rcond=1e-10, hermitian=True),
             "geom_diag_sum": float(S.diagonal().sum())}
 
 
@@ -418,10 +425,10 @@ class MultiBlockDomain:
         preconditioner, DESIGN.md section 4).  The reference runs CG without a preconditioner (cg_solver_kernel.cu:129-471);
         converged answers agree to the solver tolerance, iteration counts drop 3-4x (profiles/r02_*).  2-D meshes that run the
         on-chip solver only; returns the aggregate counts, or None when the mesh does not qualify (nothing is installed)."""
-        if self.dims != 2 or self.n_cells > 28 * 1024 or self.n_cells >= 65535:
+        if self.dims != 2 or self.n_cells > 16 * 1024:     # the kernel's LDS budget: p, r - mean r and the aggregate tables
             return None
         if not enable:
-            L.check(self.lib.fg_mb_set_multilevel(self.handle, 0, 0, None, None, None, None, 0.0, 0))
+            L.check(self.lib.fg_mb_set_multilevel(self.handle, 0, 0, None, None, None, None, None, 0.0, 0))
             return None
         P = self.unit_pressure_matrix().astype(np.float64)
         tab = multilevel_tables(P, [(b.size[0], b.size[1], b.cell_offset) for b in self.blocks])
@@ -430,8 +437,10 @@ class MultiBlockDomain:
         i32, f32 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)
         a4_32, p4_32 = np.ascontiguousarray(tab["a4"], np.int32), np.ascontiguousarray(tab["parent4"], np.int32)
         d4_32, aci_32 = np.ascontiguousarray(tab["d4"], np.float32), np.ascontiguousarray(tab["aci8"], np.float32)
+        rect_32 = np.ascontiguousarray(tab["rect4"], np.int32)
         L.check(self.lib.fg_mb_set_multilevel(self.handle, tab["n4"], tab["n8"], a4_32.ctypes.data_as(i32), p4_32.ctypes.data_as(i32),
-                                              d4_32.ctypes.data_as(f32), aci_32.ctypes.data_as(f32), float(tab["geom_diag_sum"]), 1))
+                                              rect_32.ctypes.data_as(i32), d4_32.ctypes.data_as(f32), aci_32.ctypes.data_as(f32),
+                                              float(tab["geom_diag_sum"]), 1))
         self.multilevel = {"n4": tab["n4"], "n8": tab["n8"]}
         return self.multilevel
 

@@ -440,11 +440,13 @@ int fg_mb_set_residual_projection(fg_mb_handle h, const float* y_host);
 int fg_mb_set_stall_limit(fg_mb_handle h, int32_t iterations);
 /* Additive multilevel preconditioner of the pressure CG on 2-D meshes that run the on-chip solver (k_mbc_onchip): Jacobi +
  * 1/2 x Jacobi on 4 x 4 aggregates + the dense pseudo-inverse on 8 x 8 aggregates, all from the geometry-only (A = 1) matrix and
- * scaled per env.  Host arrays: a4 [N] (aggregate of every cell), parent4 [n4] (8 x 8 aggregate of every 4 x 4 one), d4g [n4],
+ * scaled per env.  Host arrays: a4 [N] (aggregate of every cell), parent4 [n4] (8 x 8 aggregate of every 4 x 4 one), rect4 (every
+ * 4 x 4 aggregate as a rectangle of cells of one block; checked against a4), d4g [n4],
  * aci8 [n8 x n8]; n4 <= 2048, n8 <= 512.  a4 == NULL only switches it on / off (enable).  The reference has no preconditioner
  * for CG (cg_solver_kernel.cu); converged answers agree to the solver tolerance, iteration counts drop 3-4x. */
 int fg_mb_set_multilevel(fg_mb_handle h, int32_t n4, int32_t n8, const int32_t* a4_host, const int32_t* parent4_host,
-                         const float* d4g_host, const float* aci8_host, float geom_diag_sum, int32_t enable);
+                         const int32_t* rect4_host /* [n4][4]: first cell, width, height, row stride */, const float* d4g_host,
+                         const float* aci8_host, float geom_diag_sum, int32_t enable);
 int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their

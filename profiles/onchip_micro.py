@@ -18,6 +18,8 @@ for onchip, variant in [("0", "0")] + [("1", v) for v in (sys.argv[4] if len(sys
     os.environ["FG_MB_ONCHIP"], os.environ["FG_MB_OC_VARIANT"] = onchip, variant
     dom = build_domain(mesh, 0.01, batch=B)
     dom.set_stall_limit(100000)
+    if int(variant) & 128:
+        dom.set_pressure_multilevel()
     g = torch.Generator(device="cpu").manual_seed(1)
     dom.velocity.copy_((0.3 * torch.randn(dom.velocity.shape, generator=g)).to(dom.device))
     dom.make_divergence_free(pressure_tol=1e-30, max_iterations=20, pressure_project_mean=True)   # warm-up

@@ -74,6 +74,9 @@ def test_tables_and_iteration_counts_on_the_cylinder_mesh():
         ids = a4[o: o + nx * ny]
         assert set(ids).isdisjoint(set(np.delete(a4, np.s_[o: o + nx * ny])))
     assert np.bincount(a4).max() <= 25 and np.bincount(p4).max() <= 4
+    for a, (first, w, h, stride) in enumerate(tab["rect4"]):                          # the rectangles the kernel sums by shape
+        cells = (first + np.arange(h)[:, None] * stride + np.arange(w)[None, :]).reshape(-1)
+        assert (a4[cells] == a).all() and len(cells) == np.count_nonzero(a4 == a)
     # the kernel's preconditioner: D^-1 r + 1/2 s^-1 Z4 D4^-1 Z4^T r + s^-1 Z8 A8^+ Z8^T r, s = trace(P) / trace(S)
     P = _pressure_matrix(t, 1.0 / A)
     D = P.diagonal()
