@@ -230,15 +230,22 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
             env.close()
 
     out = {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "policy": "uniform random jets in [-1, 1] (as the headline)",
+           "pressure_solver": "CG, cold-started (reference policy), additive multilevel preconditioner, whole solve per env on-chip",
            "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline)"}
     out.update(run(steps))
-    old = fluidgym_amd.set_solver_policy(pressure_warm_start=True, pressure_stall_accept=1.25)
-    try:
-        warm = run(steps)
-    finally:
-        fluidgym_amd.set_solver_policy(**old)
-    out["warm_start_mode"] = {k: warm[k] for k in ("value", "ms_per_step", "pressure_warm_start", "pressure_stall_accept",
-                                                    "solver_iterations", "drag_coefficient_env0")}
+    keep = ("value", "ms_per_step", "pressure_warm_start", "pressure_stall_accept", "solver_iterations", "drag_coefficient_env0")
+
+    def mode(**policy):
+        old = fluidgym_amd.set_solver_policy(**policy)
+        try:
+            r = run(steps)
+        finally:
+            fluidgym_amd.set_solver_policy(**old)
+        return {k: r[k] for k in keep}
+
+    # the reference's own recurrence (plain CG, cold start) and the opt-in warm start, same env, same policy of actions
+    out["plain_cg_mode"] = mode(pressure_multilevel=False)
+    out["warm_start_mode"] = mode(pressure_warm_start=True, pressure_stall_accept=1.25)
     return out
 
 

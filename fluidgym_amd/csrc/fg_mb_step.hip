@@ -1233,7 +1233,7 @@ template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
     __shared__ float v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
-    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1], l_e8[PRE ? OC_N8 : 1];
+    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1];
     // r - mean r of the preconditioner pass, where the aggregate sums gather it; once they have, the same memory holds the
     // per-wave partial sums of the coarse solve
     constexpr int RT = PRE ? (CPT * NT > OC_MAX_WAVES * OC_N8 ? CPT * NT : OC_MAX_WAVES * OC_N8) : 1;
@@ -1391,14 +1391,15 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     }
                 }
                 __syncthreads();
-                for (int row = t; row < n8; row += NT) {
+                // corrections summed top-down into the 4 x 4 table: its own half-weighted Jacobi term + the coarse solution of its
+                // parent (the 16 per-wave partial sums are added here, by every child: one barrier less than a separate pass)
+                for (int a = t; a < n4; a += NT) {
+                    const int row = o.pre.parent4[a];
                     float e = 0.f;
 #pragma unroll
                     for (int g = 0; g < OC_MAX_WAVES; ++g) e += l_part[g][row];
-                    l_e8[row] = inv_s * e;
+                    l_r4[a] = inv_s * (0.5f * l_r4[a] * o.pre.d4g[a] + e);   // d4g holds reciprocals
                 }
-                __syncthreads();
-                for (int a = t; a < n4; a += NT) l_r4[a] = 0.5f * inv_s * l_r4[a] * o.pre.d4g[a] + l_e8[o.pre.parent4[a]];   // d4g holds reciprocals
                 __syncthreads();
                 float s_rz = 0.f, s_z = 0.f;
 #pragma unroll
