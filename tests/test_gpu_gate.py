@@ -3,10 +3,14 @@ single-block channel stand-in that carries the cylinder env's boundary set (SURV
 advective outflow with flux re-balancing, no-slip walls, nu = 1/100, 200 PISO steps at fixed dt.
 
 GPU (fp32, solver tolerance 1e-7, the whole step native) against the oracle (fp64, direct solves) from identical
-initial state.  The gate the task states is rtol 1e-5 per step from identical state (covered by
-test_gpu_parity.py::test_full_piso_step_intermediates); a 200-step trajectory of a nonlinear flow amplifies fp32
-round-off, so here the DRIFT CURVE is recorded (profiles/r01_gate_128x64_drift.csv when FG_WRITE_DRIFT is set) and
-bounded: max |du| / max |u| stays below 2e-4 over the whole run."""
+initial state.  The gate the task states is rtol 1e-5 per step from identical state: asserted here on the first step (and, with
+every intermediate quantity, in test_gpu_parity.py::test_full_piso_step_intermediates).  Over 200 steps of a nonlinear flow the
+difference grows to a plateau of 1.3-1.5e-4 (velocity) / 2.4e-3 (pressure); the DRIFT CURVE is recorded
+(profiles/r01_gate_128x64_drift.csv when FG_WRITE_DRIFT is set) and bounded.  Where the plateau comes from is measured on the
+CPU by profiles/gate_drift_decomposition.py (profiles/r02_gate_oracle_drift.csv): fp32 fields with direct solves drift by only
+1.3e-6, fp64 with the Krylov solves stopped at this test's 1e-7 by 6.8e-6 after one step and 1-2.6e-5 later (pressure 1-5e-3) --
+the first-step figure and the pressure difference are Krylov truncation, the rest is fp32 arithmetic inside the iterative
+solves."""
 import os
 
 import numpy as np
@@ -60,6 +64,6 @@ def test_200_step_channel_gate_drift_curve():
             fh.write("step,max_abs_du_over_max_abs_u,max_abs_dp_over_max_abs_p\n")
             for s, eu, ep in curve:
                 fh.write(f"{s},{eu:.3e},{ep:.3e}\n")
-    assert curve[0][1] < 2e-5            # one step from identical state
+    assert curve[0][1] < 1e-5            # THE GATE: one step from identical state, rtol 1e-5 (measured 4.9e-6)
     assert max(c[1] for c in curve) < 2e-4
     assert max(c[2] for c in curve) < 5e-3   # p ~ (h / dt) x velocity difference: measured 2.4e-3 at its peak
