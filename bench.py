@@ -171,7 +171,7 @@ def roofline_from_profile(prof, solver):
                     "resident kernels can exceed the HBM figure; poisson_256 is the HBM-resident case"}
 
 
-def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
+def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
     """The reference's own cylinder env (CylinderJet2D-easy-v0: five-block curvilinear mesh, 14 232 cells, Re 100, 25 PISO
     steps per env step) on the multi-block path, batched like the headline workload and driven by the same random policy.
     Pressure solves: CG, cold-started as in the reference; at this mesh size the whole solve of an env runs inside one
@@ -234,6 +234,8 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2):
            "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline)"}
     out.update(run(steps))
     keep = ("value", "ms_per_step", "pressure_warm_start", "pressure_stall_accept", "solver_iterations", "drag_coefficient_env0")
+    if not extra_modes:
+        return out
 
     def mode(**policy):
         old = fluidgym_amd.set_solver_policy(**policy)
@@ -534,6 +536,8 @@ def main():
         leg("tcf_env", env_leg, "TCF3D-baseline-v0", 8, device, steps=2, warmup=1,
             doc="BASELINE config 3: turbulent channel 128x64x64, 8 envs")
         leg("cylinder_env", cylinder_env_leg, device)
+        # one workgroup per env: 64 envs keep 64 of the 256 CUs busy during the pressure solves -- the same leg with every CU fed
+        leg("cylinder_env_256", cylinder_env_leg, device, num_envs=256, steps=2, extra_modes=False)
         if not args.no_airfoil_leg:
             leg("airfoil_env", airfoil_env_leg, device)
     if rank == 0:

