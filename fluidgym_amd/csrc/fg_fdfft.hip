@@ -30,7 +30,6 @@ struct DctArgs {
 template <int N, bool INVERSE>
 __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     constexpr int EPL = N / 64;             // elements per lane
-    constexpr int LOG2N = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : 9;
     __shared__ float2 buf[2][4][N];
     __shared__ float2 twl[N];                // W^k = (cos, sin)(2 pi k / N), k < N
     __shared__ float red[4];
@@ -75,6 +74,14 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     // Butterfly t of a stage with stride s: q = t mod s, ps = t - q; inputs x[t + j N/4], outputs y[4 ps + q + j s] with
     //   b1 = (a0 + rot a1 - a2 - rot a3) W^ps,  b2 = (a0 - a1 + a2 - a3) W^2ps,  b3 = (a0 - rot a1 - a2 + rot a3) W^3ps,
     // rot = -i (forward) / +i (inverse)  (formulas checked against numpy.fft for all four lengths).
+    // every wave works on its own row: between stages only the lanes of ONE wave exchange data through LDS, whose operations a wave
+    // issues in order -- a wave-level barrier (no instruction, a scheduling fence for the compiler) replaces the block barrier and
+    // lets the four waves of a workgroup drift apart
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto cmul = [](float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); };
     auto twid = [&](int k) { float2 w = twl[k & (N - 1)]; if (!INVERSE) w.y = -w.y; return w; };
     int sft = 0;   // log2 of the stride s
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
             o[2 << sft] = cmul(c2, twid(2 * ps));
             o[3 << sft] = cmul(c3, twid(3 * ps));
         }
-        __syncthreads();
+        wave_sync();
         float2* tmp = x; x = y; y = tmp;
         sft += 2; rem /= 4;
     }
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
             y[2 * ps + q] = make_float2(u.x + v.x, u.y + v.y);
             y[2 * ps + q + (1 << sft)] = cmul(make_float2(u.x - v.x, u.y - v.y), twid(ps));
         }
-        __syncthreads();
+        wave_sync();
         float2* tmp = x; x = y; y = tmp;
     }
     float out[EPL];

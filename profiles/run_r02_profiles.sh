@@ -14,7 +14,7 @@ rocprofv3 --pmc WRITE_SIZE -d $O/p_write -o bench -- $BENCH > $O/p_write.log 2>&
 python3 $R/profiles/summarize_pmc.py "$(find $O/p_write -name '*.db' | head -1)" > $O/r02_a_bench_pmc_write.csv
 rocprofv3 --kernel-trace --stats -d $O/p_p256 -o p256 -- python3 $R/profiles/micro_poisson.py > $O/p_p256.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_p256 -name '*.db' | head -1)" $O/r02_b_poisson256_kernel_stats.csv > /dev/null
-rocprofv3 --kernel-trace --stats -d $O/p_cyl -o cyl -- python3 $R/profiles/cylinder_modes.py 64 2 1-0 > $O/p_cyl.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/p_cyl -o cyl -- python3 $R/profiles/cylinder_modes.py 64 2 1-0-1 > $O/p_cyl.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_cyl -name '*.db' | head -1)" $O/r02_c_cylinder_kernel_stats.csv > /dev/null
 rm -rf $O/p_stats $O/p_fetch $O/p_write $O/p_p256 $O/p_cyl
 ls -la $O/r02_*
