@@ -199,6 +199,7 @@ SIGNATURES = {
                                      POINTER(c_float), c_float, c_int32]),
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "fg_mb_ladder": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
+    "fg_mb_debug_cycles": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_profile_iterations": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -103,6 +103,7 @@ struct fg_mb_state {
     int ml_n4 = 0, ml_n8 = 0; float ml_geom_diag_sum = 0.f; bool ml_on = false;
     float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
     int oc_variant = 0;        // FG_MB_OC_VARIANT (tuning switches of the on-chip CG)
+    unsigned long long* oc_dbg = nullptr;   // per-phase cycle counts (fg_mb_debug_cycles)
     int onchip_mode = 1;       // FG_MB_ONCHIP: 0 never, 1 when the mesh fits one workgroup's LDS / registers (default)
     double* x64_best = nullptr; float* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
     double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2)

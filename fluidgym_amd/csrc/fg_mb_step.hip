@@ -1147,7 +1147,8 @@ struct OcParams {
     const uint32_t* nbr16;   // [N][F/2] words: one 8-byte load per cell in 2-D
     const float* off4;       // [B][N][4] off-diagonals interleaved per cell (2-D), or null: q.off [B][F][N] is read instead
     int fence;               // compiler fence every four cells of the stencil pass (bounds the loads in flight)
-    int dbg;                 // timing experiments (FG_MB_OC_VARIANT >> 8): 1 no restriction atomics, 2 no coarse solve, 4 no z pass loads
+    int dbg;                 // FG_MB_OC_VARIANT >> 8: bit 0 = per-phase cycle counts of workgroup 0 into dbg_out (fg_mb_debug_cycles)
+    unsigned long long* dbg_out;   // [16] cycles per phase, summed over the iterations of the launch
     const float* dt;         // [B] or null
     const float* yp;         // [N] projection vector (PM == 2)
     int use_x0, project_mean, restart_every, check_every, max_iterations, stall_limit, accept_window;
@@ -1301,6 +1302,9 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     float best = 3.0e38f, crit = 0.f;
     bool fresh = true, restarted = true, residual_pass = o.use_x0 != 0, recovering = false;
     double rho = 0.0, rho_prev = 1.0;
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tph = 0;
+#define OC_PHASE(k) do { if (o.dbg & 1) { const unsigned long long now_ = clock64(); ph[k] += now_ - tph; tph = now_; } } while (0)
+    if (o.dbg & 1) tph = clock64();
     for (;;) {
         // the thread index is laundered once per trip: per-cell 64-bit addresses are invariants of this loop, and the
         // compiler otherwise hoists all of them out of it (CPT x 8 register pairs) and spills them
@@ -1338,6 +1342,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
             }
         }
         float zbar = 0.f;
+        OC_PHASE(0);   // checks, best-iterate store
         if (!residual_pass) {
             restarted = false;
             beta = fresh ? 0.f : (float)(rho / rho_prev);
@@ -1356,6 +1361,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     if (i < (unsigned)N) l_rt[i] = r[k] - rm;
                 }
                 __syncthreads();
+                OC_PHASE(1);   // residual copy to LDS
                 for (int a = t; a < n4; a += NT) {
                     const uint2 rc = o.pre.rect4[a];
                     const unsigned w = rc.y & 0xffu, h = (rc.y >> 8) & 0xffu, stride = rc.y >> 16;
@@ -1365,6 +1371,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     l_r4[a] = sum;
                 }
                 __syncthreads();
+                OC_PHASE(2);   // 4 x 4 sums
                 for (int a = t; a < n8; a += NT) {
                     const uint2 ch = o.pre.child8[a];
                     const unsigned c0 = ch.x & 0xffffu, c1 = ch.x >> 16, c2 = ch.y & 0xffffu, c3 = ch.y >> 16;
@@ -1372,6 +1379,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                               (c3 != 0xffffu ? l_r4[c3] : 0.f);
                 }
                 __syncthreads();
+                OC_PHASE(3);   // 8 x 8 sums
                 // e8 = A8^+ r8.  A8^+ is symmetric, so row r is read as column r of consecutive rows: wave g takes the columns
                 // c = g, g + 16, ..., lane q the four rows 4q .. 4q+3 -- every load is a 16-byte access, a wave reads 1 KiB
                 // contiguous, and the ~15 loads of a lane are independent (128 KiB in flight per workgroup: the matrix, 208 KB
@@ -1391,6 +1399,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     }
                 }
                 __syncthreads();
+                OC_PHASE(4);   // coarse solve
                 // corrections summed top-down into the 4 x 4 table: its own half-weighted Jacobi term + the coarse solution of its
                 // parent (the 16 per-wave partial sums are added here, by every child: one barrier less than a separate pass)
                 for (int a = t; a < n4; a += NT) {
@@ -1401,6 +1410,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     l_r4[a] = inv_s * (0.5f * l_r4[a] * o.pre.d4g[a] + e);   // d4g holds reciprocals
                 }
                 __syncthreads();
+                OC_PHASE(5);   // correction table
                 float s_rz = 0.f, s_z = 0.f;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
@@ -1416,6 +1426,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 oc_reduce2<NT, RING>(s_rz, s_z, red, phase, rz, zsum);
                 zbar = PM == 1 ? (float)(zsum / (double)N) : 0.f;
                 beta = fresh ? 0.f : (float)(rz / rz_prev);
+                OC_PHASE(6);   // z pass + r.z reduction
             }
         }
         // ---- the vector the stencil is applied to: x, or p = (r - (yp.r) yp) + beta p (every thread rewrites its own cells)
@@ -1434,7 +1445,9 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
             }
         }
         __syncthreads();
+        OC_PHASE(7);   // direction update
         oc_spmv<DIMS, CPT, DG_REGS, NB_REGS, NT>(q, o, sys, N, tl, v_lds, dg, nbk, ap);
+        OC_PHASE(8);   // stencil pass
         float s2 = 0.f, s1 = 0.f;
         if (residual_pass) {
 #pragma unroll
@@ -1456,6 +1469,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (i < (unsigned)N) part += v_lds[i] * ap[k]; }
         double pap, unused;
         oc_reduce2<NT, RING>(part, 0.f, red, phase, pap, unused);
+        OC_PHASE(9);   // p.Pp reduction
         const float alpha = (float)((PRE ? rz : rho) / pap);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
@@ -1473,7 +1487,13 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         rz_prev = rz;
         fresh = false;
         ++it;
+        OC_PHASE(10);  // x, r update + r.r reduction
     }
+    if ((o.dbg & 1) && sys == 0 && t == 0 && o.dbg_out) {
+        for (int k = 0; k < 11; ++k) o.dbg_out[k] = ph[k];
+        o.dbg_out[11] = (unsigned long long)it;
+    }
+#undef OC_PHASE
     // ---- hand back: the last iterate when converged, the kept one otherwise (k_mbs_restore_best)
     const bool use_best = (outcome == 3 || outcome == 4 || (outcome == 2 && best < 3.0e38f));
 #pragma unroll
@@ -1741,6 +1761,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     o.off4 = (off == s->Poff && !(s->oc_variant & 2)) ? s->Poff4 : nullptr;
     o.fence = (s->oc_variant & 1) ? 0 : 1;
     o.dbg = s->oc_variant >> 8;
+    o.dbg_out = s->oc_dbg;
     o.use_x0 = use_x0; o.project_mean = pm_mode; o.restart_every = CG_RESTART; o.check_every = CG_CHUNK;
     o.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
     o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
@@ -2095,6 +2116,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->it_ctr, 4)) return rc;
     if (int rc = mb_alloc(s, &s->dt_dev, B)) return rc;
     if (int rc = mb_alloc(s, &s->dt_step, B)) return rc;
+    if (int rc = mb_alloc(s, &s->oc_dbg, (size_t)16)) return rc;
     if (int rc = mb_alloc(s, &s->env_fail, B)) return rc;
     // fp64 iterate + best refinement point of the refined BiCGStab: allocated here, nothing is allocated on the step path
     if (int rc = mb_alloc(s, &s->x64, B * d * N)) return rc;        // B * d systems: the fp64 rung also serves the velocity solves
@@ -2346,6 +2368,13 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
     FG_HIP_CHECK(hipMemcpy(s->ml_d4g, rd4.data(), sizeof(float) * n4, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_aci8, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
     s->ml_n4 = n4; s->ml_n8 = n8; s->ml_geom_diag_sum = geom_diag_sum; s->ml_on = enable != 0;
+    return FG_OK;
+}
+
+// cycle counts per phase of the on-chip CG (workgroup 0 of the last launch; FG_MB_OC_VARIANT=256): [0..10] phases, [11] iterations
+extern "C" int fg_mb_debug_cycles(fg_mb_handle s, uint64_t* out12) {
+    FG_REQUIRE(s && s->oc_dbg && out12, FG_ERR_INVALID_ARG, "fg_mb_debug_cycles: not available");
+    FG_HIP_CHECK(hipMemcpy(out12, s->oc_dbg, sizeof(uint64_t) * 12, hipMemcpyDeviceToHost));
     return FG_OK;
 }
 

@@ -394,6 +394,9 @@ int fg_mb_env_status(fg_mb_handle h, int32_t* out_B_host);
  * rung, pressure fp64 rung, pressure last-resort CG}.  force_mask (tests): bit 0 / bit 1 make the FIRST attempt of every
  * velocity / pressure solve count as failed, so that the rungs can be exercised on systems that do not fail. */
 int fg_mb_ladder(fg_mb_handle h, int64_t* out4_host, int32_t force_mask);
+/* Tuning aid: with FG_MB_OC_VARIANT=256 in the environment at fg_mb_create, workgroup 0 of the on-chip CG counts shader-clock
+ * cycles per phase of its loop; out12 = 11 phases + iterations of the last launch. */
+int fg_mb_debug_cycles(fg_mb_handle h, uint64_t* out12_host);
 /* as fg_solver_counters, for the multi-block path */
 int fg_mb_solver_counters(fg_mb_handle h, int64_t* out13_host, int32_t reset);
 /* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps

@@ -37,5 +37,13 @@ for onchip, variant in [("0", "0")] + [("1", v) for v in (sys.argv[4] if len(sys
         a, u = p["k_mbc_ap"], p["k_mbc_update"]
         row.update(us_per_iteration=round(1e3 * (a["ms"] / max(a["samples"], 1) + u["ms"] / max(u["samples"], 1)), 3),
                    ap_us=round(1e3 * a["ms"] / max(a["samples"], 1), 3), update_us=round(1e3 * u["ms"] / max(u["samples"], 1), 3))
+    if int(variant) & 256:
+        import ctypes
+        from fluidgym_amd import _lib as L
+        cyc = (ctypes.c_uint64 * 12)()
+        L.check(dom.lib.fg_mb_debug_cycles(dom.handle, cyc))
+        names = ["checks", "r_to_lds", "sum4", "sum8", "coarse", "table4", "z+rz", "p_update", "stencil", "pAp", "x_r_update"]
+        its = max(int(cyc[11]), 1)
+        row["cycles_per_iteration"] = {n: round(cyc[k] / its) for k, n in enumerate(names)}
     print(json.dumps(row), flush=True)
     dom.close()
