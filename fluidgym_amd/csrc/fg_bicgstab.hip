@@ -55,7 +55,7 @@ __device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(r
 
 __device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int sys, float crit, int it) {
     const bool finite = isfinite(crit);
-    flags[sys] = finite ? 1 : 2;
+    flag_st(flags + (sys), finite ? 1 : 2);
     info[sys].final_residual = crit;
     info[sys].used_iterations = it;
     info[sys].converged = finite ? 1 : 0;
@@ -109,14 +109,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_init(FgGrid g, BicgPtrs q, in
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     const size_t N = g.n;
     bool any = false;
-    for (int comp = 0; comp < q.nc; ++comp) any = any || (q.flags[c.b * q.nc + comp] == 0);
+    for (int comp = 0; comp < q.nc; ++comp) any = any || (flag_ld(q.flags + (c.b * q.nc + comp)) == 0);
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (use_x0 && c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
     __shared__ float lds[4];
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
-        if (q.flags[sys] != 0) continue;
+        if (flag_ld(q.flags + (sys)) != 0) continue;
         const size_t vb = (size_t)sys * N;
         float part[1] = {0.f};
         if (c.valid) {
@@ -153,26 +153,26 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int i
                                                       int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
-    const int f = q.flags[s.sys];
+    const int f = flag_ld(q.flags + (s.sys));
     if (f == 4) {  // converged on s in the previous iteration: K5 has applied x += alpha p, finalise
-        if (s.leader) q.flags[s.sys] = 1;
+        if (s.leader) flag_st(q.flags + (s.sys), 1);
         return;
     }
     if (f != 0) return;
     double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float crit = fg_rms(a[A_RR], g.n);
+    const float crit = fg_rms(acc_ld(a + (A_RR)), g.n);
     if (!(crit >= q.tol)) {
         if (s.leader) fg_mark(q.flags, q.info, s.sys, crit, it == 0 ? -1 : it);
         return;
     }
     if (s.leader) {
-        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0;
+        acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0);
         q.info[s.sys].final_residual = crit;
         q.info[s.sys].used_iterations = it - 1;
     }
     if (it == 0 || !c.valid) return;
-    const float alpha = q.sc[s.sys * 2 + 0], omega = q.sc[s.sys * 2 + 1];
-    const float beta = (float)(a[A_RHO + (it & 1)] / a[A_RHO + ((it + 1) & 1)]) * (alpha / omega);
+    const float alpha = sc_ld(q.sc + (s.sys * 2 + 0)), omega = sc_ld(q.sc + (s.sys * 2 + 1));
+    const float beta = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RHO + ((it + 1) & 1)))) * (alpha / omega);
     const size_t vb = (size_t)s.sys * g.n;
     const FgVec<VEC> r = fg_load<VEC>(q.r + vb + c.idx);
     const FgVec<VEC> v = fg_load<VEC>(q.v + vb + c.idx);
@@ -189,14 +189,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_v(FgGrid g, BicgPtrs q, int i
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     const size_t N = g.n;
     bool any = false;
-    for (int comp = 0; comp < q.nc; ++comp) any = any || (q.flags[c.b * q.nc + comp] == 0);
+    for (int comp = 0; comp < q.nc; ++comp) any = any || (flag_ld(q.flags + (c.b * q.nc + comp)) == 0);
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
     __shared__ float lds[4];
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
-        if (q.flags[sys] != 0) continue;  // uniform over the workgroup
+        if (flag_ld(q.flags + (sys)) != 0) continue;  // uniform over the workgroup
         const size_t vb = (size_t)sys * N;
         float part[1] = {0.f};
         if (c.valid) {
@@ -218,13 +218,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_s(FgGrid g, BicgPtrs q, int i
                                                       int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
-    if (q.flags[s.sys] != 0) return;
+    if (flag_ld(q.flags + (s.sys)) != 0) return;
     double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_RV]);
+    const float alpha = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RV)));
     if (s.leader) {
-        q.sc[s.sys * 2 + 0] = alpha;
-        a[A_RHO + ((it + 1) & 1)] = 0.0;  // rho slot of the next iteration
-        a[A_RR] = 0.0;                    // read by Kp_i / K2_i, re-accumulated by K5_i
+        sc_st(q.sc + (s.sys * 2 + 0), alpha);
+        acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0);  // rho slot of the next iteration
+        acc_st(a + (A_RR), 0.0);                    // read by Kp_i / K2_i, re-accumulated by K5_i
     }
     const size_t vb = (size_t)s.sys * g.n;
     __shared__ float lds[4];
@@ -254,16 +254,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int i
     bool any = false;
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
-        if (q.flags[sys] != 0) continue;
+        if (flag_ld(q.flags + (sys)) != 0) continue;
         double* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-        const float crit_s = fg_rms(a[A_SS], g.n);
+        const float crit_s = fg_rms(acc_ld(a + (A_SS)), g.n);
         if (!(crit_s >= q.tol)) {
             // converged on s (bicgstab_solver_kernel.cu:305-329): flag 4 = "K5 applies x += alpha p, then done".
             // Nothing in THIS launch depends on the flag value written here (every workgroup of the env takes this
             // branch from the same accumulator value, and reads flags only above).
             if (leader) {
                 fg_mark(q.flags, q.info, sys, crit_s, it);
-                if (isfinite(crit_s)) q.flags[sys] = 4;
+                if (isfinite(crit_s)) flag_st(q.flags + (sys), 4);
             }
             continue;
         }
@@ -309,15 +309,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
                                                       int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
-    const int f = q.flags[s.sys];  // stable during this launch: K5 never writes flags
+    const int f = flag_ld(q.flags + (s.sys));  // stable during this launch: K5 never writes flags
     if (f != 0 && f != 4) return;
     double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float alpha = q.sc[s.sys * 2 + 0];
+    const float alpha = sc_ld(q.sc + (s.sys * 2 + 0));
     const bool half = (f == 4);
-    const float omega = half ? 0.f : (float)(a[A_TS] / a[A_TT]);
+    const float omega = half ? 0.f : (float)(acc_ld(a + (A_TS)) / acc_ld(a + (A_TT)));
     if (s.leader) {
-        q.sc[s.sys * 2 + 1] = omega;
-        a[A_RV] = 0.0;
+        sc_st(q.sc + (s.sys * 2 + 1), omega);
+        acc_st(a + (A_RV), 0.0);
     }
     const size_t vb = (size_t)s.sys * g.n;
     __shared__ float lds[8];
@@ -356,10 +356,10 @@ __global__ void k_bicg_begin(const float* __restrict__ dt, double* __restrict__ 
                              int32_t* __restrict__ flags, fg_solve_info* __restrict__ info, int nsys, int nc) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
-    for (int q = 0; q < FG_ACC_DOUBLES; ++q) acc[(size_t)s * FG_ACC_DOUBLES + q] = 0.0;
-    sc[s * 2] = 1.f; sc[s * 2 + 1] = 1.f;
+    for (int q = 0; q < FG_ACC_DOUBLES; ++q) acc_st(acc + ((size_t)s * FG_ACC_DOUBLES + q), 0.0);
+    sc_st(sc + (s * 2), 1.f); sc_st(sc + (s * 2 + 1), 1.f);
     const bool active = (dt == nullptr) || (dt[s / nc] > 0.f);
-    flags[s] = active ? 0 : 3;
+    flag_st(flags + (s), active ? 0 : 3);
     info[s].final_residual = 0.f;
     info[s].used_iterations = -1;
     info[s].converged = active ? 0 : 1;
@@ -370,14 +370,14 @@ __global__ void k_bicg_check(double* __restrict__ acc, int32_t* __restrict__ fla
                              fg_solve_info* __restrict__ mirror, float tol, int it, int n, int nsys, int final_pass) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
-    if (flags[s] == 4) flags[s] = 1;
-    if (flags[s] == 0) {
-        const float crit = (float)sqrt(acc[(size_t)s * FG_ACC_DOUBLES + A_RR] / (double)n);
+    if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
+    if (flag_ld(flags + (s)) == 0) {
+        const float crit = (float)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + A_RR)) / (double)n);
         info[s].final_residual = crit;
         info[s].used_iterations = it + 1;
         if (!(crit >= tol)) {
             const bool finite = isfinite(crit);
-            flags[s] = finite ? 1 : 2;
+            flag_st(flags + (s), finite ? 1 : 2);
             info[s].converged = finite ? 1 : 0;
             info[s].is_finite = finite ? 1 : 0;
         } else if (final_pass) {

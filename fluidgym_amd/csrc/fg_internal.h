@@ -8,6 +8,19 @@
 
 #include "../../include/fluidgym_hip.h"
 
+// The recurrence scalars (accumulators, alpha / omega, flags) are shared by workgroups on all eight XCDs, whose L2s are not
+// coherent with each other.  Round 1 zeroed accumulator slots and read them back with PLAIN stores / loads while the sums were
+// accumulated with device-scope atomics (which bypass L2): once in ~10^4 solves a kernel read the zero its predecessor's leader had
+// stored instead of the sum the kernel in between had accumulated (rw.v == 0 exactly with v finite in every cell -> alpha = -inf;
+// profiles/r02_bicg_failure_trace.txt) -- the intermittent "non-finite BiCGStab solve".  Every access to these words now takes
+// the ONE path the atomics take: 8-byte / 4-byte agent-scope atomic loads and stores (global_load / store ... sc1).
+__device__ __forceinline__ double acc_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void acc_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sc_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sc_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t flag_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_st(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 #define FG_BLOCK 256  // threads per workgroup = 4 waves of 64
 
 // ------------------------------------------------------------------------------------------------

@@ -389,10 +389,11 @@ __device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b
     __shared__ float lds[4];                            \
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
 
+// accumulator / scalar / flag words: only through acc_ld / acc_st, sc_ld / sc_st, flag_ld / flag_st (fg_internal.h)
 __device__ __forceinline__ float mb_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
 __device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, float crit, int it) {
     const bool finite = isfinite(crit);
-    q.flags[sys] = finite ? 1 : 2;
+    flag_st(q.flags + (sys), finite ? 1 : 2);
     q.info[sys].final_residual = crit;
     q.info[sys].used_iterations = it;
     q.info[sys].converged = finite ? 1 : 0;
@@ -402,10 +403,10 @@ __device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, float crit, i
 __global__ void k_mbs_begin(const float* __restrict__ dt, MbSolve q, int nsys) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
-    for (int k = 0; k < MB_ACC; ++k) q.acc[(size_t)s * MB_ACC + k] = 0.0;
-    q.sc[s * 2] = 1.f; q.sc[s * 2 + 1] = 1.f;
+    for (int k = 0; k < MB_ACC; ++k) acc_st(q.acc + ((size_t)s * MB_ACC + k), 0.0);
+    sc_st(q.sc + (s * 2), 1.f); sc_st(q.sc + (s * 2 + 1), 1.f);
     const bool active = mb_active(dt, s / q.nc);
-    q.flags[s] = active ? 0 : 3;
+    flag_st(q.flags + (s), active ? 0 : 3);
     q.info[s].final_residual = 0.f;
     q.info[s].used_iterations = -1;
     q.info[s].converged = active ? 0 : 1;
@@ -416,7 +417,7 @@ __global__ void k_mbs_begin(const float* __restrict__ dt, MbSolve q, int nsys) {
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int use_x0, int sum_slot, int defer_rho) {
     MB_SYS
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     float r = 0.f;
     if (valid) {
         r = q.rhs[vb + i];
@@ -439,9 +440,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int u
 // In fp32 the recurrence of the nearly singular, non-symmetric pressure systems drifts and finally diverges without it.
 __global__ void k_mbb_restart(MbSolve q, int nsys) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsys || q.flags[s] != 0) return;
-    for (int k = 0; k < MB_ACC; ++k) q.acc[(size_t)s * MB_ACC + k] = 0.0;
-    q.sc[s * 2] = 1.f; q.sc[s * 2 + 1] = 1.f;
+    if (s >= nsys || flag_ld(q.flags + (s)) != 0) return;
+    for (int k = 0; k < MB_ACC; ++k) acc_st(q.acc + ((size_t)s * MB_ACC + k), 0.0);
+    sc_st(q.sc + (s * 2), 1.f); sc_st(q.sc + (s * 2 + 1), 1.f);
 }
 
 // ---- fp64 iterative refinement around the fp32 BiCGStab (pressure_use_bicgstab = 2).  On the nearly singular pressure
@@ -452,17 +453,17 @@ __global__ void k_mbb_restart(MbSolve q, int nsys) {
 // correction that starts from zero -- its round-off scales with the correction, not with the solution.
 __global__ __launch_bounds__(FG_BLOCK) void k_mbr_fold(int N, MbSolve q, double* __restrict__ x64, int mode) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
-    if (i >= N || q.flags[sys] == 3) return;      // inactive envs untouched; converged ones fold their last correction once
+    if (i >= N || flag_ld(q.flags + (sys)) == 3) return;      // inactive envs untouched; converged ones fold their last correction once
     const size_t k = (size_t)sys * N + i;
     if (mode == 0) { x64[k] = 0.0; return; }                        // cold start
     if (mode == 1) { x64[k] = (double)q.x[k]; q.x[k] = 0.f; return; }  // warm start from the caller's x
-    if (mode == 2) { if (q.flags[sys] == 0) { x64[k] += (double)q.x[k]; q.x[k] = 0.f; } return; }  // restart
+    if (mode == 2) { if (flag_ld(q.flags + (sys)) == 0) { x64[k] += (double)q.x[k]; q.x[k] = 0.f; } return; }  // restart
     q.x[k] = (float)(x64[k] + (double)q.x[k]);                       // mode 3: hand back the sum
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbr_residual(MbDev D, MbSolve q, const double* __restrict__ x64, int sum_slot, int defer_rho) {
     MB_SYS
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     float r = 0.f;
     if (valid) {
         constexpr int F = 2 * DIMS;
@@ -493,8 +494,8 @@ __global__ void k_mbr_best_decide(MbSolve q, float* __restrict__ best_res, int32
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     keep[s] = 0;
-    if (q.flags[s] != 0) return;
-    const float crit = (float)sqrt(q.acc[(size_t)s * MB_ACC + A_RR] / (double)n);
+    if (flag_ld(q.flags + (s)) != 0) return;
+    const float crit = (float)sqrt(acc_ld(q.acc + ((size_t)s * MB_ACC + A_RR)) / (double)n);
     if (first) best_res[s] = 3.0e38f;
     if (isfinite(crit) && crit < best_res[s]) { best_res[s] = crit; keep[s] = 1; }
 }
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_copy(int N, const int32_t
 __global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_restore(int N, MbSolve q, double* __restrict__ x64, const double* __restrict__ best,
                                                                 const float* __restrict__ best_res) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
-    if (q.flags[sys] == 3 || q.flags[sys] == 0 || (q.info[sys].converged && q.info[sys].is_finite)) return;
+    if (flag_ld(q.flags + (sys)) == 3 || flag_ld(q.flags + (sys)) == 0 || (q.info[sys].converged && q.info[sys].is_finite)) return;
     if (!(best_res[sys] < 3.0e38f)) return;   // nothing kept (non-finite from the start): leave it to the caller's fallback
     if (i < N) { x64[(size_t)sys * N + i] = best[(size_t)sys * N + i]; q.x[(size_t)sys * N + i] = 0.f; }
     if (i == 0) { q.info[sys].final_residual = best_res[sys]; q.info[sys].is_finite = 1; }
@@ -517,11 +518,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_restore(int N, MbSolve q,
 // second half of the start of a projected BiCGStab solve: r <- r - mean r, rw = p = r, rho0 = rr = |r|^2
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     double* a = q.acc + (size_t)sys * MB_ACC;
     const size_t vb = (size_t)sys * N;
     __shared__ float lds[4];
-    const float m = (float)(a[A_ST] / (double)N);  // k_mbs_init left sum r in A_ST
+    const float m = (float)(acc_ld(a + (A_ST)) / (double)N);  // k_mbs_init left sum r in A_ST
     float r = 0.f;
     if (i < N) {
         r = q.r[vb + i] - m;
@@ -535,26 +536,26 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) {
     MB_SYS
-    const int f = q.flags[sys];
-    if (f == 4) { if (leader) q.flags[sys] = 1; return; }
+    const int f = flag_ld(q.flags + (sys));
+    if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
     if (f != 0) return;
-    const float crit = mb_rms(a[A_RR], N);
+    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
-        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0; a[A_ST] = 0.0;
+        acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
         q.info[sys].final_residual = crit;
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
     if (it == 0 || !valid) return;
-    const float alpha = q.sc[sys * 2], omega = q.sc[sys * 2 + 1];
-    const float beta = (float)(a[A_RHO + (it & 1)] / a[A_RHO + ((it + 1) & 1)]) * (alpha / omega);
-    const float mv = q.project ? (float)(a[A_SV + 2 * ((it + 1) & 1)] / (double)N) : 0.f;  // sum v of the previous iteration (slots 7 / 9 alternate)
+    const float alpha = sc_ld(q.sc + (sys * 2)), omega = sc_ld(q.sc + (sys * 2 + 1));
+    const float beta = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RHO + ((it + 1) & 1)))) * (alpha / omega);
+    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;  // sum v of the previous iteration (slots 7 / 9 alternate)
     q.p[vb + i] = q.r[vb + i] + beta * (q.p[vb + i] - omega * (q.v[vb + i] - mv));
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) {
     MB_SYS
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     float part = 0.f, psum = 0.f;
     if (valid) {
         const float y = mb_spmv<DIMS>(D, q, b, q.p + vb, i);
@@ -572,10 +573,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) 
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) {
     MB_SYS
-    if (q.flags[sys] != 0) return;
-    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_RV]);
-    if (leader) { q.sc[sys * 2] = alpha; a[A_RHO + ((it + 1) & 1)] = 0.0; a[A_RR] = 0.0; a[A_SV + 2 * ((it + 1) & 1)] = 0.0; }
-    const float mv = q.project ? (float)(a[A_SV + 2 * (it & 1)] / (double)N) : 0.f;
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const float alpha = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RV)));
+    if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
+    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
     float part = 0.f;
     if (valid) {
         const float r = q.r[vb + i] - alpha * (q.v[vb + i] - mv);
@@ -588,10 +589,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) 
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) {
     MB_SYS
-    if (q.flags[sys] != 0) return;
-    const float crit_s = mb_rms(a[A_SS], N);
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);
     if (!(crit_s >= q.tol)) {  // converged on s (bicgstab_solver_kernel.cu:305-329): k_mbb_x applies x += alpha p
-        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) q.flags[sys] = 4; }
+        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) flag_st(q.flags + (sys), 4); }
         return;
     }
     float pt = 0.f, ptt = 0.f, pst = 0.f;
@@ -614,14 +615,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) {
     MB_SYS
-    const int f = q.flags[sys];
+    const int f = flag_ld(q.flags + (sys));
     if (f != 0 && f != 4) return;
-    const float alpha = q.sc[sys * 2];
+    const float alpha = sc_ld(q.sc + (sys * 2));
     const bool half = (f == 4);
-    const double st = q.project ? a[A_ST] : 0.0;
+    const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
     const float mt = (float)(st / (double)N);
-    const float omega = half ? 0.f : (float)(a[A_TS] / (a[A_TT] - st * st / (double)N));
-    if (leader) { q.sc[sys * 2 + 1] = omega; a[A_RV] = 0.0; }
+    const float omega = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
     float prr = 0.f, prho = 0.f;
     if (valid) {
         if (half) {
@@ -687,20 +688,20 @@ __device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p4(MbDev D, MbSolve q, int it) {
     MB_SYS4
-    const int f = q.flags[sys];
-    if (f == 4) { if (leader) q.flags[sys] = 1; return; }
+    const int f = flag_ld(q.flags + (sys));
+    if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
     if (f != 0) return;
-    const float crit = mb_rms(a[A_RR], N);
+    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
-        a[A_SS] = 0.0; a[A_TS] = 0.0; a[A_TT] = 0.0; a[A_ST] = 0.0;
+        acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
         q.info[sys].final_residual = crit;
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
     if (it == 0 || !valid) return;
-    const float alpha = q.sc[sys * 2], omega = q.sc[sys * 2 + 1];
-    const float beta = (float)(a[A_RHO + (it & 1)] / a[A_RHO + ((it + 1) & 1)]) * (alpha / omega);
-    const float mv = q.project ? (float)(a[A_SV + 2 * ((it + 1) & 1)] / (double)N) : 0.f;
+    const float alpha = sc_ld(q.sc + (sys * 2)), omega = sc_ld(q.sc + (sys * 2 + 1));
+    const float beta = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RHO + ((it + 1) & 1)))) * (alpha / omega);
+    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
     const float4 r = ld4(q.r + vb + i), p = ld4(q.p + vb + i), v = ld4(q.v + vb + i);
     st4(q.p + vb + i, r.x + beta * (p.x - omega * (v.x - mv)), r.y + beta * (p.y - omega * (v.y - mv)),
         r.z + beta * (p.z - omega * (v.z - mv)), r.w + beta * (p.w - omega * (v.w - mv)));
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p4(MbDev D, MbSolve q, int it)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v4(MbDev D, MbSolve q, int it) {
     MB_SYS4
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     float part = 0.f, psum = 0.f;
     if (valid) {
         float y[4];
@@ -728,10 +729,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v4(MbDev D, MbSolve q, int it)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s4(MbDev D, MbSolve q, int it) {
     MB_SYS4
-    if (q.flags[sys] != 0) return;
-    const float alpha = (float)(a[A_RHO + (it & 1)] / a[A_RV]);
-    if (leader) { q.sc[sys * 2] = alpha; a[A_RHO + ((it + 1) & 1)] = 0.0; a[A_RR] = 0.0; a[A_SV + 2 * ((it + 1) & 1)] = 0.0; }
-    const float mv = q.project ? (float)(a[A_SV + 2 * (it & 1)] / (double)N) : 0.f;
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const float alpha = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RV)));
+    if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
+    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
     float part = 0.f;
     if (valid) {
         const float4 r = ld4(q.r + vb + i), v = ld4(q.v + vb + i);
@@ -745,10 +746,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s4(MbDev D, MbSolve q, int it)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it) {
     MB_SYS4
-    if (q.flags[sys] != 0) return;
-    const float crit_s = mb_rms(a[A_SS], N);
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);
     if (!(crit_s >= q.tol)) {
-        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) q.flags[sys] = 4; }
+        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) flag_st(q.flags + (sys), 4); }
         return;
     }
     float pt = 0.f, ptt = 0.f, pst = 0.f;
@@ -773,14 +774,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it) {
     MB_SYS4
-    const int f = q.flags[sys];
+    const int f = flag_ld(q.flags + (sys));
     if (f != 0 && f != 4) return;
-    const float alpha = q.sc[sys * 2];
+    const float alpha = sc_ld(q.sc + (sys * 2));
     const bool half = (f == 4);
-    const double st = q.project ? a[A_ST] : 0.0;
+    const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
     const float mt = (float)(st / (double)N);
-    const float omega = half ? 0.f : (float)(a[A_TS] / (a[A_TT] - st * st / (double)N));
-    if (leader) { q.sc[sys * 2 + 1] = omega; a[A_RV] = 0.0; }
+    const float omega = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
     float prr = 0.f, prho = 0.f;
     if (valid) {
         const float4 x = ld4(q.x + vb + i), p = ld4(q.p + vb + i);
@@ -820,28 +821,28 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
     if (leader && sys == 0) q.it_ctr[1] = it + 1;
     const float* p_old = (it & 1) ? pA : pB;
     float* p_new = (it & 1) ? pB : pA;
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     // residual with its mean removed (project_mean): rho = |r|^2 - (sum r)^2 / N
     // residual with its component along the projection vector yp removed (|yp| = 1): rho = |r|^2 - (yp.r)^2
-    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
+    const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
     const float cy = (float)sum_r;
-    const double rho = a[C_RHO + it % 3] - sum_r * sum_r;
+    const double rho = acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r;
     const float crit = mb_rms(rho, N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
     double rho_prev = 1.0;
     if (it > 0) {
-        const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
-        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp;
+        const double sp = project_mean ? acc_ld(a + (C_SUM + (it + 2) % 3)) : 0.0;
+        rho_prev = acc_ld(a + (C_RHO + (it + 2) % 3)) - sp * sp;
     }
     const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
     const float beta = fresh ? 0.f : (float)(rho / rho_prev);
     if (leader) {
         q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
-        a[C_RHO + (it + 1) % 3] = 0.0;  // accumulated by k_mbc_update of this iteration; nobody reads it here
-        a[C_SUM + (it + 1) % 3] = 0.0;
+        acc_st(a + (C_RHO + (it + 1) % 3), 0.0);  // accumulated by k_mbc_update of this iteration; nobody reads it here
+        acc_st(a + (C_SUM + (it + 1) % 3), 0.0);
         // keep x_it when it beats the kept iterate by 2x: k_mbc_update of this iteration stores it before updating x
-        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2] || (crit < q.accept_factor * q.tol && crit < q.sc[sys * 2]))) {
-            q.sc[sys * 2] = crit; q.best_it[sys] = it;
+        if (q.best_x && (it == 0 || crit < 0.5f * sc_ld(q.sc + (sys * 2)) || (crit < q.accept_factor * q.tol && crit < sc_ld(q.sc + (sys * 2))))) {
+            sc_st(q.sc + (sys * 2), crit); q.best_it[sys] = it;
         }
     }
     float part = 0.f;
@@ -873,10 +874,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[1] - 1;
     if (leader && sys == 0) q.it_ctr[0] = it + 1;
     const float* p = (it & 1) ? pB : pA;
-    if (q.flags[sys] != 0) return;
-    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
-    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r) / a[C_PAP + (it & 1)]);
-    if (leader) a[C_PAP + ((it + 1) & 1)] = 0.0;  // k_mbc_ap of the next iteration accumulates it; not read here
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
+    const float alpha = (float)((acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r) / acc_ld(a + (C_PAP + (it & 1))));
+    if (leader) acc_st(a + (C_PAP + ((it + 1) & 1)), 0.0);  // k_mbc_ap of the next iteration accumulates it; not read here
     float part = 0.f, psum = 0.f;
     if (valid) {
         if (q.best_x && q.best_it[sys] == it) q.best_x[vb + i] = q.x[vb + i];
@@ -910,26 +911,26 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
     if (leader && sys == 0) q.it_ctr[1] = it + 1;
     const float* p_old = (it & 1) ? pA : pB;
     float* p_new = (it & 1) ? pB : pA;
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     // residual with its component along the projection vector yp removed (|yp| = 1): rho = |r|^2 - (yp.r)^2
-    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
+    const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
     const float cy = (float)sum_r;
-    const double rho = a[C_RHO + it % 3] - sum_r * sum_r;
+    const double rho = acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r;
     const float crit = mb_rms(rho, N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
     double rho_prev = 1.0;
     if (it > 0) {
-        const double sp = project_mean ? a[C_SUM + (it + 2) % 3] : 0.0;
-        rho_prev = a[C_RHO + (it + 2) % 3] - sp * sp;
+        const double sp = project_mean ? acc_ld(a + (C_SUM + (it + 2) % 3)) : 0.0;
+        rho_prev = acc_ld(a + (C_RHO + (it + 2) % 3)) - sp * sp;
     }
     const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
     const float beta = fresh ? 0.f : (float)(rho / rho_prev);
     if (leader) {
         q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
-        a[C_RHO + (it + 1) % 3] = 0.0;
-        a[C_SUM + (it + 1) % 3] = 0.0;
-        if (q.best_x && (it == 0 || crit < 0.5f * q.sc[sys * 2] || (crit < q.accept_factor * q.tol && crit < q.sc[sys * 2]))) {
-            q.sc[sys * 2] = crit; q.best_it[sys] = it;
+        acc_st(a + (C_RHO + (it + 1) % 3), 0.0);
+        acc_st(a + (C_SUM + (it + 1) % 3), 0.0);
+        if (q.best_x && (it == 0 || crit < 0.5f * sc_ld(q.sc + (sys * 2)) || (crit < q.accept_factor * q.tol && crit < sc_ld(q.sc + (sys * 2))))) {
+            sc_st(q.sc + (sys * 2), crit); q.best_it[sys] = it;
         }
     }
     float part = 0.f;
@@ -995,10 +996,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, cons
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[1] - 1;
     if (leader && sys == 0) q.it_ctr[0] = it + 1;
     const float* p = (it & 1) ? pB : pA;
-    if (q.flags[sys] != 0) return;
-    const double sum_r = project_mean ? a[C_SUM + it % 3] : 0.0;
-    const float alpha = (float)((a[C_RHO + it % 3] - sum_r * sum_r) / a[C_PAP + (it & 1)]);
-    if (leader) a[C_PAP + ((it + 1) & 1)] = 0.0;
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
+    const float alpha = (float)((acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r) / acc_ld(a + (C_PAP + (it & 1))));
+    if (leader) acc_st(a + (C_PAP + ((it + 1) & 1)), 0.0);
     float part = 0.f, psum = 0.f;
     if (valid) {
         float4 x4 = *reinterpret_cast<const float4*>(q.x + vb + i);
@@ -1028,16 +1029,16 @@ __global__ void k_mbc_clear(MbSolve q, int nsys, int it) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0) q.it_ctr[2] = it;
     if (s >= nsys) return;
-    q.acc[(size_t)s * MB_ACC + C_RHO + it % 3] = 0.0;
-    q.acc[(size_t)s * MB_ACC + C_SUM + it % 3] = 0.0;
-    q.acc[(size_t)s * MB_ACC + C_PAP] = 0.0;      // both idle between iterations; a recovered system left NaN here
-    q.acc[(size_t)s * MB_ACC + C_PAP + 1] = 0.0;
+    acc_st(q.acc + ((size_t)s * MB_ACC + C_RHO + it % 3), 0.0);
+    acc_st(q.acc + ((size_t)s * MB_ACC + C_SUM + it % 3), 0.0);
+    acc_st(q.acc + ((size_t)s * MB_ACC + C_PAP), 0.0);      // both idle between iterations; a recovered system left NaN here
+    acc_st(q.acc + ((size_t)s * MB_ACC + C_PAP + 1), 0.0);
 }
 // a system whose recurrence broke down (p.Pp <= 0 or overflow on the non-symmetric matrix: flag 2) goes back to its kept
 // iterate and rejoins the iteration at the restart that follows
 __global__ void k_mbs_recover(int N, MbSolve q) {
     const int sys = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
-    if (q.flags[sys] != 2) return;
+    if (flag_ld(q.flags + (sys)) != 2) return;
     if (i < N) {
         const float v = q.best_x[(size_t)sys * N + i];
         q.x[(size_t)sys * N + i] = isfinite(v) ? v : 0.f;
@@ -1045,15 +1046,15 @@ __global__ void k_mbs_recover(int N, MbSolve q) {
 }
 __global__ void k_mbs_recover_flags(MbSolve q, int nsys) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsys || q.flags[s] != 2) return;
-    q.flags[s] = 0;
+    if (s >= nsys || flag_ld(q.flags + (s)) != 2) return;
+    flag_st(q.flags + (s), 0);
     q.info[s].is_finite = 1;
     q.info[s].converged = 0;
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, int it, int project_mean) {
     MB_SYS
-    if (q.flags[sys] != 0) return;
+    if (flag_ld(q.flags + (sys)) != 0) return;
     float r = 0.f;
     if (valid) {
         r = q.rhs[vb + i] - mb_spmv<DIMS>(D, q, b, q.x + vb, i);
@@ -1077,40 +1078,40 @@ __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32
         if (sum_slot != -1) sum_slot = C_SUM + (it + 1) % 3;
         final_pass = (it + 1 >= q.max_iterations);
     }
-    if (q.flags[s] == 4) q.flags[s] = 1;
-    if (q.flags[s] == 0) {
-        double rr = q.acc[(size_t)s * MB_ACC + rr_slot];
-        if (sum_slot >= 0) { const double sr = q.acc[(size_t)s * MB_ACC + sum_slot]; rr -= sr * sr; }
+    if (flag_ld(q.flags + (s)) == 4) flag_st(q.flags + (s), 1);
+    if (flag_ld(q.flags + (s)) == 0) {
+        double rr = acc_ld(q.acc + ((size_t)s * MB_ACC + rr_slot));
+        if (sum_slot >= 0) { const double sr = acc_ld(q.acc + ((size_t)s * MB_ACC + sum_slot)); rr -= sr * sr; }
         const float crit = (float)sqrt(rr / (double)n);
         q.info[s].final_residual = crit;
         q.info[s].used_iterations = it + 1;
         if (!(crit >= q.tol)) {
             const bool finite = isfinite(crit);
-            q.flags[s] = finite ? 1 : 2;
+            flag_st(q.flags + (s), finite ? 1 : 2);
             q.info[s].converged = finite ? 1 : 0;
             q.info[s].is_finite = finite ? 1 : 0;
-        } else if (q.best_x && q.accept_factor > 0.f && q.sc[s * 2] <= q.accept_factor * q.tol && it - q.best_it[s] >= q.accept_window) {
+        } else if (q.best_x && q.accept_factor > 0.f && sc_ld(q.sc + (s * 2)) <= q.accept_factor * q.tol && it - q.best_it[s] >= q.accept_window) {
             // hovering just above the tolerance (the residual of CG is not monotone, least of all on the non-symmetric
             // matrix): take the kept iterate instead of waiting for a lucky dip
             q.info[s].converged = 1;
-            q.flags[s] = 5;
+            flag_st(q.flags + (s), 5);
         } else if (final_pass || (q.best_x && q.stall_limit > 0 && it - q.best_it[s] > q.stall_limit)) {
             // out of iterations, or no iterate has halved the best residual for stall_limit iterations (the reference
             // would run on to max_iterations and then hand back its best iterate, too)
             q.info[s].converged = 0;
-            q.flags[s] = 1;
+            flag_st(q.flags + (s), 1);
         }
     }
     mirror[s] = q.info[s];
-    flag_mirror[s] = q.flags[s];
+    flag_mirror[s] = flag_ld(q.flags + (s));
 }
 
 // hand back the kept iterate of the systems that ended unconverged
 __global__ void k_mbs_restore_best(int N, MbSolve q) {
     const int sys = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
-    if (i >= N || (q.info[sys].converged && q.flags[sys] != 5) || q.flags[sys] == 3) return;
+    if (i >= N || (q.info[sys].converged && flag_ld(q.flags + (sys)) != 5) || flag_ld(q.flags + (sys)) == 3) return;
     q.x[(size_t)sys * N + i] = q.best_x[(size_t)sys * N + i];
-    if (i == 0) { q.info[sys].final_residual = q.sc[sys * 2]; q.info[sys].used_iterations = q.best_it[sys]; }
+    if (i == 0) { q.info[sys].final_residual = sc_ld(q.sc + (sys * 2)); q.info[sys].used_iterations = q.best_it[sys]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     const size_t vb = (size_t)sys * N;
     if (!mb_active(o.dt, sys)) {
         if (t == 0) {
-            q.flags[sys] = 3;
+            flag_st(q.flags + (sys), 3);
             q.info[sys].final_residual = 0.f; q.info[sys].used_iterations = -1; q.info[sys].converged = 1; q.info[sys].is_finite = 1;
         }
         return;
@@ -1502,7 +1503,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         if (i < (unsigned)N) q.x[vb + i] = use_best ? bestx[i] : x[k];
     }
     if (t == 0) {
-        q.flags[sys] = outcome == 2 ? 2 : (outcome == 3 ? 5 : 1);
+        flag_st(q.flags + (sys), outcome == 2 ? 2 : (outcome == 3 ? 5 : 1));
         q.info[sys].final_residual = use_best ? best : crit;
         q.info[sys].used_iterations = use_best ? best_it : it;
         q.info[sys].converged = (outcome == 1 || outcome == 3) ? 1 : 0;

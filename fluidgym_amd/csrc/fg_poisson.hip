@@ -127,16 +127,16 @@ __device__ __forceinline__ double* fg_acc_ptr(double* acc, int b, int name) {
 }
 // total of an accumulator; every lane of the calling wave gets the result
 __device__ __forceinline__ double fg_acc_total(const double* a, int ns) {
-    if (ns == 1) return a[0];
+    if (ns == 1) return acc_ld(a + (0));
     const int lane = threadIdx.x & 63;
-    double v = (lane < ns) ? a[lane] : 0.0;
+    double v = (lane < ns) ? acc_ld(a + (lane)) : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ void fg_acc_zero(double* a, int ns) {  // called by the first wave of the leader block
     const int lane = threadIdx.x & 63;
-    if (lane < ns) a[lane] = 0.0;
+    if (lane < ns) acc_st(a + (lane), 0.0);
 }
 __device__ __forceinline__ void fg_acc_add(double* a, int ns, unsigned tile, double v) {
     atomicAdd(a + (tile & (unsigned)(ns - 1)), v);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float*
                                                            const int32_t* __restrict__ flags, int use_x0, int name,
                                                            int ns, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    if (flags[c.b] != 0) return;
+    if (flag_ld(flags + (c.b)) != 0) return;
     __shared__ float lds[4];
     const size_t base = (size_t)c.b * g.n;
     float part[1] = {0.f};
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
     // z_ = preconditioned residual (= r when num_base == 0); beta = num_it / num_{it-1} with the numerator
     // ring num_base (0: r.r, 5: r.z).  Convergence is always judged on the r.r ring (RMS residual).
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    if (flags[c.b] != 0) return;
+    if (flag_ld(flags + (c.b)) != 0) return;
     const double rr_new = fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns);
     const float crit = fg_rms(rr_new, g.n);
     const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
     if (!(crit >= tol)) {  // converged (crit < tol) or NaN
         if (lead_block && threadIdx.x == 0) {
             const bool finite = isfinite(crit);
-            flags[c.b] = finite ? 1 : 2;
+            flag_st(flags + (c.b), finite ? 1 : 2);
             info[c.b].final_residual = crit;
             info[c.b].used_iterations = it - 1;
             info[c.b].converged = finite ? 1 : 0;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
                                                          const int32_t* __restrict__ flags, FgBest best, float tol, int it,
                                                          int ns, int num_base, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    if (flags[c.b] != 0) return;
+    if (flag_ld(flags + (c.b)) != 0) return;
     const double rr = fg_acc_total(fg_acc_ptr(acc, c.b, num_base + it % 3), ns);  // r.r or r.z
     // best-iterate tracking (FgBest): the leader of k_cg_ap decided whether x_it (x on entry) is worth keeping
     const bool save = best.save_at[c.b] == it;
@@ -308,14 +308,14 @@ __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags
                            fg_solve_info* __restrict__ mirror, float tol, int it, int n, int B, int final_pass, int ns) {
     const int b = blockIdx.x;
     if (b >= B) return;
-    if (flags[b] == 0) {
+    if (flag_ld(flags + (b)) == 0) {
         const float crit = fg_rms(fg_acc_total(fg_acc_ptr(acc, b, (it + 1) % 3), ns), n);
         if (threadIdx.x == 0) {
             info[b].final_residual = crit;
             info[b].used_iterations = it;
             if (!(crit >= tol)) {
                 const bool finite = isfinite(crit);
-                flags[b] = finite ? 1 : 2;
+                flag_st(flags + (b), finite ? 1 : 2);
                 info[b].converged = finite ? 1 : 0;
                 info[b].is_finite = finite ? 1 : 0;
             } else if (final_pass) {
@@ -333,14 +333,14 @@ __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ ac
     const int b = blockIdx.x;
     if (b >= B) return;
     for (int q = threadIdx.x; q < FG_CG_NAMES * FG_CG_SLOTS; q += blockDim.x)
-        acc[(size_t)b * FG_CG_NAMES * FG_CG_SLOTS + q] = 0.0;
+        acc_st(acc + ((size_t)b * FG_CG_NAMES * FG_CG_SLOTS + q), 0.0);
     if (threadIdx.x != 0) return;
     mean_sums[b] = 0.0;  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
     best.best_crit[b] = track_best ? INFINITY : 0.f;  // 0: no residual ever beats it, nothing is kept
     best.saved_crit[b] = INFINITY;
     best.save_at[b] = -1;
     const bool active = (dt == nullptr) || (dt[b] > 0.f);
-    flags[b] = active ? 0 : 3;
+    flag_st(flags + (b), active ? 0 : 3);
     info[b].final_residual = 0.f;
     info[b].used_iterations = -1;
     info[b].converged = active ? 0 : 1;

@@ -169,9 +169,9 @@ struct Z3Args {
 
 __device__ __forceinline__ double* z_acc_ptr(double* acc, int b, int name) { return acc + ((size_t)b * 8 + name) * 64; }
 __device__ __forceinline__ double z_acc_total(const double* a, int ns) {
-    if (ns == 1) return a[0];
+    if (ns == 1) return acc_ld(a + (0));
     const int lane = threadIdx.x & 63;
-    double v = (lane < ns) ? a[lane] : 0.0;
+    double v = (lane < ns) ? acc_ld(a + (lane)) : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
     bool use_prev = false;
     unsigned tile_id = 0;
     if constexpr (MODE == MODE_CG_AP) {
-        if (a.flags[c.b] != 0) return;
+        if (flag_ld(a.flags + (c.b)) != 0) return;
         const unsigned per_env = tiles_x * tiles_y * zchunks;
         tile_id = fg_xcd_remap(blockIdx.x, gridDim.x) % per_env;
         const double rr_new = z_acc_total(z_acc_ptr(a.acc, c.b, a.it % 3), a.ns);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
         if (!(crit >= a.tol)) {
             if (tile_id == 0 && threadIdx.x == 0) {
                 const bool finite = isfinite(crit);
-                a.flags[c.b] = finite ? 1 : 2;
+                flag_st(a.flags + (c.b), finite ? 1 : 2);
                 a.info[c.b].final_residual = crit;
                 a.info[c.b].used_iterations = a.it - 1;
                 a.info[c.b].converged = finite ? 1 : 0;
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
         if (tile_id == 0 && threadIdx.x < 64) {
             const int lane = threadIdx.x;
             if (lane < a.ns) {
-                z_acc_ptr(a.acc, c.b, (a.it + 1) % 3)[lane] = 0.0;
-                if (a.num_base) z_acc_ptr(a.acc, c.b, a.num_base + (a.it + 1) % 3)[lane] = 0.0;
+                acc_st(z_acc_ptr(a.acc, c.b, (a.it + 1) % 3) + lane, 0.0);
+                if (a.num_base) acc_st(z_acc_ptr(a.acc, c.b, a.num_base + (a.it + 1) % 3) + lane, 0.0);
             }
             if (lane == 0) {
                 a.info[c.b].final_residual = crit;
