@@ -369,3 +369,16 @@ def test_multilevel_preconditioned_step_matches_the_oracle(spec_fn):
         assert _rel(u_gpu[b], refs[b][0]) < 2e-4, (spec_fn.__name__, b)
         assert _rel(p_gpu[b], refs[b][1]) < 2e-3, (spec_fn.__name__, b)
     dom.close()
+
+
+def test_recurrence_words_read_back_exactly_under_agent_scope_access():
+    """Regression for the intermittent non-finite BiCGStab solve of round 1: sums accumulated with device-scope
+    atomics, zeroed by a leader workgroup and read by every wave of the next kernel must read back exactly, launch after launch,
+    when the zeroing / reading goes through agent-scope atomic stores / loads as the solvers do (fg_internal.h acc_st / acc_ld).
+    The shape is the Airfoil2D batch the failure was captured on (16 envs x 2 components, 46664 cells)."""
+    import ctypes
+    from fluidgym_amd import _lib as L
+    bad = (ctypes.c_int64 * 12)()
+    val = (ctypes.c_double * 12)()
+    L.check(L.load().fg_coherence_litmus(1, 32, 46664, 4000, bad, val, None))
+    assert sum(bad) == 0, (list(bad), list(val))
