@@ -101,6 +101,9 @@ struct fg_mb_state {
     // multilevel preconditioner of the on-chip CG (fg_mb_set_multilevel)
     uint16_t *ml_a4 = nullptr, *ml_parent4 = nullptr; float *ml_d4g = nullptr, *ml_aci8 = nullptr; uint2 *ml_rect4 = nullptr, *ml_child8 = nullptr;
     int ml_n4 = 0, ml_n8 = 0; float ml_geom_diag_sum = 0.f; bool ml_on = false;
+    int ml_cap4 = 0, ml_cap8 = 0;   // capacity of the tables above (the on-chip CG takes at most 2048 / 512 aggregates, the kernel form 65535 / 2048)
+    // work arrays of the kernel form (mb_ml_apply): aggregate sums [B][n4], coarse solution [B][n8], 1 / scale [B], M p and M s [B][N]
+    float *ml_r4 = nullptr, *ml_z8 = nullptr, *ml_scale = nullptr, *ml_mp = nullptr, *ml_ms = nullptr;
     float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
     int oc_variant = 0;        // FG_MB_OC_VARIANT (tuning switches of the on-chip CG)
     unsigned long long* oc_dbg = nullptr;   // per-phase cycle counts (fg_mb_debug_cycles)

@@ -361,6 +361,9 @@ struct MbSolve {
     // BiCGStab on the singular pressure system: 1 = iterate on Q P with Q = I - 1 1^T / N (all vectors mean-free), which removes
     // the null space the plain recurrence breaks down on
     int project;
+    // right preconditioning (multilevel, mb_ml_apply): when set, v = A mp with mp = M p, t = A ms with ms = M s, and the iterate
+    // advances along mp / ms; the recurrence itself (p, s, r and all dot products) is the one of A M
+    const float* mp; const float* ms;
 };
 
 struct MbGraphKey { MbSolve q; int vec4, project_mean; hipStream_t stream; };
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) 
     if (flag_ld(q.flags + (sys)) != 0) return;
     float part = 0.f, psum = 0.f;
     if (valid) {
-        const float y = mb_spmv<DIMS>(D, q, b, q.p + vb, i);
+        const float y = mb_spmv<DIMS>(D, q, b, (q.mp ? q.mp : q.p) + vb, i);
         q.v[vb + i] = y;
         part = q.rw[vb + i] * y;  // rw is mean-free: rw . (v - mean v) = rw . v
         psum = y;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
     }
     float pt = 0.f, ptt = 0.f, pst = 0.f;
     if (valid) {
-        const float t = mb_spmv<DIMS>(D, q, b, q.r + vb, i);
+        const float t = mb_spmv<DIMS>(D, q, b, (q.ms ? q.ms : q.r) + vb, i);
         q.t[vb + i] = t;
         pt = t * q.r[vb + i];  // s is mean-free: (t - mean t) . s = t . s
         ptt = t * t;
@@ -625,11 +628,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
     float prr = 0.f, prho = 0.f;
     if (valid) {
+        const float pd = (q.mp ? q.mp : q.p)[vb + i];
         if (half) {
-            q.x[vb + i] += alpha * q.p[vb + i];
+            q.x[vb + i] += alpha * pd;
         } else {
             const float sv = q.r[vb + i];
-            q.x[vb + i] += alpha * q.p[vb + i] + omega * sv;
+            q.x[vb + i] += alpha * pd + omega * (q.ms ? q.ms[vb + i] : sv);
             const float r = sv - omega * (q.t[vb + i] - mt);
             q.r[vb + i] = r;
             prr = r * r;
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v4(MbDev D, MbSolve q, int it)
     float part = 0.f, psum = 0.f;
     if (valid) {
         float y[4];
-        mb_spmv4<DIMS>(D, q, b, q.p + vb, i, y);
+        mb_spmv4<DIMS>(D, q, b, (q.mp ? q.mp : q.p) + vb, i, y);
         st4(q.v + vb + i, y[0], y[1], y[2], y[3]);
         const float4 w = ld4(q.rw + vb + i);
         part = w.x * y[0] + w.y * y[1] + w.z * y[2] + w.w * y[3];
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it)
     float pt = 0.f, ptt = 0.f, pst = 0.f;
     if (valid) {
         float t[4];
-        mb_spmv4<DIMS>(D, q, b, q.r + vb, i, t);
+        mb_spmv4<DIMS>(D, q, b, (q.ms ? q.ms : q.r) + vb, i, t);
         st4(q.t + vb + i, t[0], t[1], t[2], t[3]);
         const float4 sv = ld4(q.r + vb + i);
         pt = t[0] * sv.x + t[1] * sv.y + t[2] * sv.z + t[3] * sv.w;
@@ -784,13 +788,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
     float prr = 0.f, prho = 0.f;
     if (valid) {
-        const float4 x = ld4(q.x + vb + i), p = ld4(q.p + vb + i);
+        const float4 x = ld4(q.x + vb + i), p = ld4((q.mp ? q.mp : q.p) + vb + i);
         if (half) {
             st4(q.x + vb + i, x.x + alpha * p.x, x.y + alpha * p.y, x.z + alpha * p.z, x.w + alpha * p.w);
         } else {
             const float4 sv = ld4(q.r + vb + i), t = ld4(q.t + vb + i), w = ld4(q.rw + vb + i);
-            st4(q.x + vb + i, x.x + alpha * p.x + omega * sv.x, x.y + alpha * p.y + omega * sv.y, x.z + alpha * p.z + omega * sv.z,
-                x.w + alpha * p.w + omega * sv.w);
+            const float4 sd = q.ms ? ld4(q.ms + vb + i) : sv;
+            st4(q.x + vb + i, x.x + alpha * p.x + omega * sd.x, x.y + alpha * p.y + omega * sd.y, x.z + alpha * p.z + omega * sd.z,
+                x.w + alpha * p.w + omega * sd.w);
             const float r0 = sv.x - omega * (t.x - mt), r1 = sv.y - omega * (t.y - mt), r2 = sv.z - omega * (t.z - mt), r3 = sv.w - omega * (t.w - mt);
             st4(q.r + vb + i, r0, r1, r2, r3);
             prr = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
@@ -801,6 +806,86 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     prr = mb_block_sum(prr, lds);
     prho = mb_block_sum(prho, lds);
     if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
+}
+
+// ---- the additive multilevel preconditioner as kernels (meshes too large for the on-chip CG; right preconditioner of the
+// pressure BiCGStab):  z = D^-1 r + 1/2 s^-1 Z4 D4^-1 Z4^T r + s^-1 Z8 A8^+ Z8^T r  with the tables of fg_mb_set_multilevel
+// (aggregates = rectangles of cells inside the blocks, geometry-only Galerkin operators) and s = trace(P_env) / trace(S_geom)
+// the per-env scale of the pressure matrix against the geometry-only one.  Three launches per application:
+//   k_ml_restrict  one thread per 4 x 4 aggregate sums its rectangle of r                                   -> r4 [sys][n4]
+//   k_ml_coarse    r8 = sums over the (at most four) children; z8 = A8^+ r8 / s, A8^+ symmetric so the matrix is read by
+//                  columns (coalesced across the threads of a row block)                                    -> z8 [sys][n8]
+//   k_ml_prolong   z = r / diag + (1/2s) r4 / d4 + z8 at the cell's aggregates                              -> z  [sys][N]
+struct MlDev {
+    const uint16_t* a4; const uint16_t* parent4; const uint2* rect4; const uint2* child8; const float* rd4; const float* aci8;
+    int n4, n8, ld8;
+    float* r4; float* z8; const float* scale_inv;   // work arrays [nsys][n4], [nsys][n8]; 1 / s per env
+};
+// 1 / s per env: trace(S_geom) / trace(P_env); one workgroup per env
+__global__ __launch_bounds__(1024) void k_ml_scale(const float* __restrict__ diag, int N, float geom_diag_sum, float* __restrict__ scale_inv) {
+    const int b = blockIdx.x;
+    __shared__ double part[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N; i += 1024) acc += (double)diag[(size_t)b * N + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        scale_inv[b] = (float)((double)geom_diag_sum / t);
+    }
+}
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* __restrict__ in, int N, const int32_t* __restrict__ flags) {
+    const int a = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
+    if (a >= M.n4 || flag_ld(flags + sys) != 0) return;
+    const uint2 rc = M.rect4[a];
+    const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
+    const float* src = in + (size_t)sys * N + rc.x;
+    float sum = 0.f;
+    for (int dy = 0; dy < h; ++dy)
+        for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
+    M.r4[(size_t)sys * M.n4 + a] = sum;
+}
+constexpr int ML_N8_MAX = 2048;
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_coarse(MlDev M, int nc, const int32_t* __restrict__ flags) {
+    const int sys = blockIdx.y;
+    if (flag_ld(flags + sys) != 0) return;
+    __shared__ float l_r8[ML_N8_MAX];
+    const float* r4 = M.r4 + (size_t)sys * M.n4;
+    for (int g = threadIdx.x; g < M.n8; g += FG_BLOCK) {
+        const uint2 ch = M.child8[g];
+        const unsigned ids[4] = {ch.x & 0xffffu, ch.x >> 16, ch.y & 0xffffu, ch.y >> 16};
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (ids[k] != 0xffffu) sum += r4[ids[k]];
+        l_r8[g] = sum;
+    }
+    __syncthreads();
+    const int row = blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (row >= M.n8) return;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    const float* col = M.aci8 + row;
+    int j = 0;
+    for (; j + 4 <= M.n8; j += 4) {
+        acc0 += col[(size_t)j * M.ld8] * l_r8[j];
+        acc1 += col[(size_t)(j + 1) * M.ld8] * l_r8[j + 1];
+        acc2 += col[(size_t)(j + 2) * M.ld8] * l_r8[j + 2];
+        acc3 += col[(size_t)(j + 3) * M.ld8] * l_r8[j + 3];
+    }
+    for (; j < M.n8; ++j) acc0 += col[(size_t)j * M.ld8] * l_r8[j];
+    M.z8[(size_t)sys * M.n8 + row] = ((acc0 + acc1) + (acc2 + acc3)) * M.scale_inv[sys / nc];
+}
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const float* __restrict__ in, const float* __restrict__ diag, int N, int nc,
+                                                         const int32_t* __restrict__ flags, float* __restrict__ out) {
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
+    if (i >= N || flag_ld(flags + sys) != 0) return;
+    const int b = sys / nc;
+    const unsigned a = M.a4[i];
+    const float half_s = 0.5f * M.scale_inv[b];
+    out[(size_t)sys * N + i] = in[(size_t)sys * N + i] * __builtin_amdgcn_rcpf(diag[(size_t)b * N + i]) +
+                               half_s * M.rd4[a] * M.r4[(size_t)sys * M.n4 + a] + M.z8[(size_t)sys * M.n8 + M.parent4[a]];
 }
 
 // ---- CG (cgSolveGPU recurrence, cg_solver_kernel.cu:129-471) in two kernels per iteration.  The search direction is
@@ -1650,11 +1735,29 @@ MbSolve mb_solve_ptrs(fg_mb_state* s, const float* diag, const float* off, const
 template <typename T>
 int mb_alloc(fg_mb_state* s, T** p, size_t count);
 
+// z = M in for every system still iterating (kernel form of the multilevel preconditioner; pressure systems, nc == 1)
+void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st) {
+    MlDev M;
+    M.a4 = s->ml_a4; M.parent4 = s->ml_parent4; M.rect4 = s->ml_rect4; M.child8 = s->ml_child8; M.rd4 = s->ml_d4g; M.aci8 = s->ml_aci8;
+    M.n4 = s->ml_n4; M.n8 = s->ml_n8; M.ld8 = (s->ml_n8 + 3) & ~3;
+    M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale;
+    const int nsys = s->B * q.nc, n = s->N;
+    hipLaunchKernelGGL(k_ml_restrict, dim3((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
+    hipLaunchKernelGGL(k_ml_coarse, dim3((M.n8 + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, q.nc, (const int32_t*)q.flags);
+    hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out);
+}
+
 int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, int nc,
-                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0) {
+                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0, int multilevel = 0) {
     const int nsys = s->B * nc, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     q.project = project ? 1 : 0;
+    // multilevel right preconditioning of the pressure solve: the recurrence runs on P M, the iterate advances along M p, M s
+    const bool ml = multilevel && nc == 1 && s->ml_on && s->ml_a4 != nullptr && s->ml_mp != nullptr;
+    if (ml) {
+        q.mp = s->ml_mp; q.ms = s->ml_ms;
+        hipLaunchKernelGGL(k_ml_scale, dim3(s->B), dim3(1024), 0, st, diag, n, s->ml_geom_diag_sum, s->ml_scale);
+    }
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     // a refined solve that has not converged after 1500 iterations is not going to: hand over to the caller's CG fallback
     // instead of spending the reference's 5000 (one hard env would stall the whole batch)
@@ -1696,8 +1799,10 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
         const int li = it - q.it_base;
         MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form (bisecting the defect noted above)
             if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st);
             if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
             if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st);
             if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
             if (vec_mask & 16) hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
         });
@@ -1772,7 +1877,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     // iteration): 16 cells per thread with the two-barrier reduction 11.7-11.8; the same with the one-barrier ring 14.5; 14
     // cells per thread 15.8-16.3; neighbour indices in registers 17.4; 512 threads x 256 registers 18.3 -- what the
     // compiler's schedule makes of each form decides, not the instruction count.  Small meshes keep the indices in registers.
-    const bool pre = s->ml_on && s->ml_a4 != nullptr && n <= 16 * 1024;   // LDS: p, r - mean r and the aggregate tables
+    const bool pre = s->ml_on && s->ml_a4 != nullptr && n <= 16 * 1024 && s->ml_n4 <= OC_N4 && s->ml_n8 <= OC_N8;   // LDS: p, r - mean r and the aggregate tables
     o.pre.a4 = s->ml_a4; o.pre.parent4 = s->ml_parent4; o.pre.d4g = s->ml_d4g; o.pre.aci8 = s->ml_aci8;
     o.pre.rect4 = s->ml_rect4; o.pre.child8 = s->ml_child8;
     o.pre.n4 = s->ml_n4; o.pre.n8 = s->ml_n8; o.pre.geom_diag_sum = s->ml_geom_diag_sum;
@@ -2253,7 +2358,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 auto solve = [&](int use_x0, int force_cg = 0) {
                     return (opt->pressure_use_bicgstab && !force_cg)
                                ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations,
-                                             use_x0, &m, st, opt->pressure_project_mean, opt->pressure_use_bicgstab == 2)
+                                             use_x0, &m, st, opt->pressure_project_mean, opt->pressure_use_bicgstab == 2, 1)
                                : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, use_x0,
                                        opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
                 };
@@ -2317,9 +2422,9 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
                                     int32_t enable) {
     FG_REQUIRE(s && s->finalized && !s->host_only, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: domain not finalized (or host-only)");
     if (!a4_host) { s->ml_on = enable && s->ml_a4 != nullptr; return FG_OK; }   // switch only
-    FG_REQUIRE(s->d == 2 && n4 > 0 && n4 <= OC_N4 && n8 > 0 && n8 <= OC_N8 && parent4_host && rect4_host && d4g_host && aci8_host &&
+    FG_REQUIRE(s->d == 2 && n4 > 0 && n4 < 65535 && n8 > 0 && n8 <= ML_N8_MAX && parent4_host && rect4_host && d4g_host && aci8_host &&
                    geom_diag_sum != 0.f,
-               FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: 2-D meshes with at most 2048 / 512 aggregates");
+               FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: 2-D meshes with at most 65534 / 2048 aggregates");
     std::vector<uint16_t> a4(s->N), p4(n4);
     for (int i = 0; i < s->N; ++i) { FG_REQUIRE(a4_host[i] >= 0 && a4_host[i] < n4, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: aggregate id out of range"); a4[i] = (uint16_t)a4_host[i]; }
     for (int a = 0; a < n4; ++a) { FG_REQUIRE(parent4_host[a] >= 0 && parent4_host[a] < n8, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: parent id out of range"); p4[a] = (uint16_t)parent4_host[a]; }
@@ -2348,13 +2453,22 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
             wref = (k & 1) ? ((wref & 0x0000ffffu) | ((unsigned)a << 16)) : ((wref & 0xffff0000u) | (unsigned)a);
         }
     }
-    if (!s->ml_a4) {
-        if (int rc = mb_alloc(s, &s->ml_rect4, (size_t)OC_N4)) return rc;
-        if (int rc = mb_alloc(s, &s->ml_child8, (size_t)OC_N8)) return rc;
-        if (int rc = mb_alloc(s, &s->ml_a4, (size_t)s->N)) return rc;
-        if (int rc = mb_alloc(s, &s->ml_parent4, (size_t)OC_N4)) return rc;
-        if (int rc = mb_alloc(s, &s->ml_d4g, (size_t)OC_N4)) return rc;
-        if (int rc = mb_alloc(s, &s->ml_aci8, (size_t)OC_N8 * OC_N8)) return rc;
+    if (!s->ml_a4 || n4 > s->ml_cap4 || n8 > s->ml_cap8) {   // (a second, larger table set leaves the first to fg_mb_destroy)
+        const int c4 = n4 > OC_N4 ? n4 : OC_N4, c8 = n8 > OC_N8 ? n8 : OC_N8;
+        if (int rc = mb_alloc(s, &s->ml_rect4, (size_t)c4)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_child8, (size_t)c8)) return rc;
+        if (!s->ml_a4) if (int rc = mb_alloc(s, &s->ml_a4, (size_t)s->N)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_parent4, (size_t)c4)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_d4g, (size_t)c4)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_aci8, (size_t)c8 * c8)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_r4, (size_t)s->B * c4)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_z8, (size_t)s->B * c8)) return rc;
+        if (!s->ml_scale) {
+            if (int rc = mb_alloc(s, &s->ml_scale, (size_t)s->B)) return rc;
+            if (int rc = mb_alloc(s, &s->ml_mp, (size_t)s->B * s->N)) return rc;
+            if (int rc = mb_alloc(s, &s->ml_ms, (size_t)s->B * s->N)) return rc;
+        }
+        s->ml_cap4 = c4; s->ml_cap8 = c8;
     }
     FG_HIP_CHECK(hipMemcpy(s->ml_a4, a4.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_parent4, p4.data(), sizeof(uint16_t) * n4, hipMemcpyHostToDevice));
@@ -2554,7 +2668,7 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
             int m = 0;
             const int prc = opt->pressure_use_bicgstab
                                 ? mb_bicgstab(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st,
-                                              opt->pressure_project_mean, opt->pressure_use_bicgstab == 2)
+                                              opt->pressure_project_mean, opt->pressure_use_bicgstab == 2, 1)
                                 : mb_cg(s, nullptr, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, ps > 0,
                                         opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
             if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;

@@ -177,8 +177,16 @@ __device__ __forceinline__ double z_acc_total(const double* a, int ns) {
     return v;
 }
 
-template <int MODE, int BXL>
-__global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
+#ifndef FG_ZMARCH_OCC      // tuning switch for profiles/zmarch_sweep.sh: pin the register budget to the LDS-limited residency
+#define FG_ZMARCH_OCC 1
+#endif
+#if FG_ZMARCH_OCC
+#define FG_ZMARCH_OCC_ATTR(PPB) __attribute__((amdgpu_waves_per_eu(PPB == 1 ? 4 : 3, PPB == 1 ? 4 : 3)))
+#else
+#define FG_ZMARCH_OCC_ATTR(PPB)
+#endif
+template <int MODE, int BXL, int PPB>
+__global__ __launch_bounds__(FG_BLOCK) FG_ZMARCH_OCC_ATTR(PPB) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
                                                               int ZC) {
     constexpr int TY = ZT<BXL>::TY, LP = ZT<BXL>::LP, LROWS = ZT<BXL>::LROWS;
     const ZCtx c = z_make_ctx<BXL>(g, tiles_x, tiles_y, zchunks, ZC);
@@ -221,11 +229,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
         use_prev = !a.first;
     }
 
-    // LDS ring of 3 planes per stencil field: planes k-1, k, k+1 are resident while plane k is computed, so the
-    // z neighbours are LDS reads too and a thread only holds the in-flight loads of plane k+2 in registers
-    // (register pressure decides occupancy here: the register-plane variant needed 164 VGPRs = 3 waves/SIMD).
-    __shared__ __attribute__((aligned(16))) float ring_p[3][LROWS * LP];
-    __shared__ __attribute__((aligned(16))) float ring_a[3][LROWS * LP];
+    // LDS ring of PPB + 2 planes per stencil field: planes k-1 .. k+PPB are resident while planes k .. k+PPB-1 are computed,
+    // so the z neighbours are LDS reads too and a thread only holds the in-flight loads of the next PPB planes in registers
+    // (register pressure decides occupancy here: the register-plane variant needed 164 VGPRs = 3 waves/SIMD).  PPB = 2 halves
+    // the barriers per plane and doubles the bytes a thread has in flight; plane q of a chunk lives in slot (q - k0 + 1) % NS.
+    constexpr int NS = PPB + 2;
+    __shared__ __attribute__((aligned(16))) float ring_p[NS][LROWS * LP];
+    __shared__ __attribute__((aligned(16))) float ring_a[NS][LROWS * LP];
     __shared__ float red[4];
 
     const size_t env = (size_t)c.b * g.n;
@@ -275,35 +285,31 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
         z_fill_tile<BXL>(ring_p[slot], c, r.p, r.hp);
         z_fill_tile<BXL>(ring_a[slot], c, r.a, r.ha);
     };
-    // prologue: planes k0-1, k0, k0+1 -> slots 0, 1, 2.  All three planes are requested before the first commit: done
-    // one after the other the prologue cost three exposed memory round trips per z-chunk.
+    // prologue: planes k0-1 .. k0+PPB -> slots 0 .. NS-1.  All planes are requested before the first commit: done one after
+    // the other the prologue cost one exposed memory round trip per plane and z-chunk.
     {
-        const Staged s0 = stage(c.k0 - 1);
-        const Staged s1 = stage(c.k0);
-        const Staged s2 = stage(c.k0 + 1);
+        Staged s0[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) s0[q] = stage(c.k0 - 1 + q);
         __builtin_amdgcn_sched_barrier(0);
-        commit(0, s0);
-        commit(1, s1);
-        commit(2, s2);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) commit(q, s0[q]);
     }
-    FgVec<4> bvec;
-    if constexpr (MODE == MODE_RELAX) bvec = z_bload4(R_x2, vo_c, (unsigned)c.k0 * plane_b);
+    FgVec<4> bvec[PPB];
+    if constexpr (MODE == MODE_RELAX) {
+#pragma unroll
+        for (int u = 0; u < PPB; ++u) bvec[u] = z_bload4(R_x2, vo_c, (unsigned)min(c.k0 + u, g.nz - 1) * plane_b);
+    }
     __syncthreads();
     float dot = 0.f;
     const int cen = (c.ly + 1) * LP + 4 + c.lx * 4;  // LDS offset of this thread's centre vector
-    int sm = 0, sc = 1, sp = 2;                       // ring slots of planes k-1, k, k+1
-#pragma unroll 1
-    for (int k = c.k0; k < c.k1; ++k) {
-        // ---- prefetch plane k+2 (consumed after this plane's arithmetic) and b of plane k+1
-        const bool more = (k + 1 < c.k1);
-        Staged nxt;
-        FgVec<4> bnext;
-        if (more) {
-            nxt = stage(k + 2);
-            if constexpr (MODE == MODE_RELAX) bnext = z_bload4(R_x2, vo_c, (unsigned)(k + 1) * plane_b);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- plane k from the LDS ring
+    int s_first = 0;                                  // ring slot of plane k-1
+    // z faces: every cell's half coefficient gz = (0.5 rh_z) (hx hy a) is formed once, a face is the sum of the two cells it
+    // separates, and a thread marching in z carries gz of the plane above and the face it shares with it: exactly one face
+    // evaluation per cell and plane, and both sides of a face use the same bits.
+    float gz_c[4], face_zm[4];
+    bool have_carry = false;
+    auto plane = [&](int k, int sm, int sc, int sp, const FgVec<4>& bv) {
         z_metrics_plane(g, k, m, fc);
         const float4 P_c = *reinterpret_cast<const float4*>(&ring_p[sc][cen]);
         const float4 A_c = *reinterpret_cast<const float4*>(&ring_a[sc][cen]);
@@ -335,9 +341,6 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
                 dg[e] -= face[e] + face[e + 1];
             }
         }
-        float hxa[4];  // hx a_c, shared by the y and z directions
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hxa[e] = m.hx[e] * acv[e];
         {   // y faces
             const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sc][cen - LP]);
             const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sc][cen + LP]);
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
             const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float tc = hh * hxa[e], hhx = hh * m.hx[e];
+                const float hhx = hh * m.hx[e], tc = hhx * acv[e];
                 const float cl = s_ycl * tc + s_ynl * (hhx * am_[e]);
                 const float cr = s_ycr * tc + s_ynr * (hhx * ap_[e]);
                 y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
@@ -357,26 +360,35 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
         {   // z faces
             const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sm][cen]);
             const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sp][cen]);
-            const float4 Am = *reinterpret_cast<const float4*>(&ring_a[sm][cen]);
             const float4 Ap = *reinterpret_cast<const float4*>(&ring_a[sp][cen]);
             const float pm_[4] = {Pm.x, Pm.y, Pm.z, Pm.w}, pp_[4] = {Pp.x, Pp.y, Pp.z, Pp.w};
-            const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
-            const float zcl = fc.mzm * 0.5f * m.rhz, znl = fc.mzm * 0.5f * m.rhz_m;
-            const float zcr = fc.mzp * 0.5f * m.rhz, znr = fc.mzp * 0.5f * m.rhz_p;
+            const float ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
+            const float wz_p = 0.5f * m.rhz_p;
+            if (!have_carry) {       // first plane of the chunk (uniform branch): the face below from plane k-1 in the ring
+                const float4 Am = *reinterpret_cast<const float4*>(&ring_a[sm][cen]);
+                const float am_[4] = {Am.x, Am.y, Am.z, Am.w};
+                const float wz_c = 0.5f * m.rhz, wz_m = 0.5f * m.rhz_m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gz_c[e] = wz_c * (hxy[e] * acv[e]);
+                    face_zm[e] = fc.mzm * (wz_m * (hxy[e] * am_[e]) + gz_c[e]);
+                }
+                have_carry = true;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float uc = m.hy * hxa[e];
-                const float cl = zcl * uc + znl * (hxy[e] * am_[e]);
-                const float cr = zcr * uc + znr * (hxy[e] * ap_[e]);
-                y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
-                dg[e] -= cl + cr;
+                const float gz_p = wz_p * (hxy[e] * ap_[e]);
+                const float face_zp = fc.mzp * (gz_c[e] + gz_p);
+                y[e] += face_zm[e] * (pm_[e] - pcv[e]) + face_zp * (pp_[e] - pcv[e]);
+                dg[e] -= face_zm[e] + face_zp;
+                gz_c[e] = gz_p; face_zm[e] = face_zp;      // the plane above: its centre half coefficient and lower face
             }
         }
         FgVec<4> out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if constexpr (MODE == MODE_RELAX) {
-                float v = pcv[e] + a.omega * (bvec.v[e] - y[e]) * __builtin_amdgcn_rcpf(dg[e]);  // v_rcp_f32 (1 ulp): the IEEE division was ~10 VALU ops per cell in a VALU-bound kernel
+                float v = pcv[e] + a.omega * (bv.v[e] - y[e]) * __builtin_amdgcn_rcpf(dg[e]);  // v_rcp_f32 (1 ulp): the IEEE division was ~10 VALU ops per cell in a VALU-bound kernel
                 if (a.color >= 0 && (((c.i0 + e + c.j + k) & 1) != a.color)) v = pcv[e];
                 out.v[e] = v;
             } else {
@@ -395,12 +407,45 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
                 z_bstore4(R_y, vo_c, so, out);
             }
         }
+    };
+#pragma unroll 1
+    for (int k = c.k0; k < c.k1; k += PPB) {
+        // ---- prefetch the next PPB planes (consumed after this step's arithmetic) and their b
+        const bool more = (k + PPB < c.k1);
+        Staged nxt[PPB];
+        FgVec<4> bnext[PPB];
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PPB; ++u) {
+                nxt[u] = stage(k + PPB + 1 + u);
+                if constexpr (MODE == MODE_RELAX) bnext[u] = z_bload4(R_x2, vo_c, (unsigned)min(k + PPB + u, g.nz - 1) * plane_b);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- planes k .. k+PPB-1 from the LDS ring
+#pragma unroll
+        for (int u = 0; u < PPB; ++u) {
+            if (u == 0 || k + u < c.k1) {
+                int sm = s_first + u, sc = s_first + u + 1, sp = s_first + u + 2;
+                sm = sm >= NS ? sm - NS : sm; sc = sc >= NS ? sc - NS : sc; sp = sp >= NS ? sp - NS : sp;
+                plane(k + u, sm, sc, sp, bvec[u]);
+            }
+        }
         if (!more) break;
-        __syncthreads();            // every wave is done reading slot sm (plane k-1)
-        commit(sm, nxt);            // plane k+2 takes its place
+        __syncthreads();            // every wave is done reading the slots of planes k-1 .. k+PPB-2
+#pragma unroll
+        for (int u = 0; u < PPB; ++u) {   // planes k+PPB+1+u take their place
+            int sl = s_first + u;
+            sl = sl >= NS ? sl - NS : sl;
+            commit(sl, nxt[u]);
+        }
         __syncthreads();
-        const int t3 = sm; sm = sc; sc = sp; sp = t3;
-        if constexpr (MODE == MODE_RELAX) bvec = bnext;
+        s_first += PPB;
+        s_first = s_first >= NS ? s_first - NS : s_first;
+        if constexpr (MODE == MODE_RELAX) {
+#pragma unroll
+            for (int u = 0; u < PPB; ++u) bvec[u] = bnext[u];
+        }
     }
     if constexpr (MODE == MODE_CG_AP) {
         float part[1] = {c.valid ? dot : 0.f};
@@ -448,9 +493,16 @@ static int launch_march(const fg_state* s, const Z3Args& a, int zc, hipStream_t 
     const int bxl = z_pick_bxl(g);
     const int tx = g.nx / (bxl * 4), ty = g.ny / (FG_BLOCK / bxl), zch = (g.nz + zc - 1) / zc;
     dim3 grid((unsigned)(tx * ty * zch * g.B));
-    if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-    else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-    else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    static const int ppb = [] { const char* e = getenv("FG_ZMARCH_PPB"); return e ? atoi(e) : 1; }();
+    if (ppb == 2) {
+        if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16, 2>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+        else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32, 2>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+        else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64, 2>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    } else {
+        if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16, 1>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+        else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32, 1>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+        else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64, 1>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    }
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

@@ -423,15 +423,18 @@ class MultiBlockDomain:
         for ``A = 1`` -- geometry only, so it is built ONCE per mesh and shared by all envs; a per-env scale accounts for
         ``P = S / A`` with ``A`` nearly constant (the same argument as the single-block path's constant-coefficient
         preconditioner, DESIGN.md section 4).  The reference runs CG without a preconditioner (cg_solver_kernel.cu:129-471);
-        converged answers agree to the solver tolerance, iteration counts drop 3-4x (profiles/r02_*).  2-D meshes that run the
-        on-chip solver only; returns the aggregate counts, or None when the mesh does not qualify (nothing is installed)."""
-        if self.dims != 2 or self.n_cells > 16 * 1024:     # the kernel's LDS budget: p, r - mean r and the aggregate tables
+        converged answers agree to the solver tolerance, iteration counts drop 3-4x (profiles/r02_*).  Two consumers: the on-chip
+        CG (meshes up to 16 k cells, 2048 / 512 aggregates: its LDS budget) applies it inside the persistent kernel; the pressure
+        BiCGStab of larger 2-D meshes (Airfoil2D: 46.7 k cells) takes it as a right preconditioner in kernel form (three launches
+        per application, csrc/fg_mb_step.hip::mb_ml_apply), up to 2048 coarse aggregates.  Returns the aggregate counts, or None
+        when the mesh does not qualify (3-D, or too many aggregates; nothing is installed)."""
+        if self.dims != 2:
             return None
         if not enable:
             L.check(self.lib.fg_mb_set_multilevel(self.handle, 0, 0, None, None, None, None, None, 0.0, 0))
             return None
         P = self.unit_pressure_matrix().astype(np.float64)
-        tab = multilevel_tables(P, [(b.size[0], b.size[1], b.cell_offset) for b in self.blocks])
+        tab = multilevel_tables(P, [(b.size[0], b.size[1], b.cell_offset) for b in self.blocks], max_n4=65534, max_n8=2048)
         if tab is None:
             return None
         i32, f32 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)
