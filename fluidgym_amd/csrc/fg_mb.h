@@ -111,7 +111,7 @@ struct fg_mb_state {
     double* x64_best = nullptr; float* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
     double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2)
     // debug switches, read ONCE from the environment at fg_mb_create (never on the step path): FG_MB_BICG_VEC4 (per-kernel mask
-    // of the four-cell BiCGStab kernels: 1 p, 2 v, 4 s, 8 t, 16 x; + 64 = pressure solves only), FG_MB_SCALAR_CG=1 (one-cell
+    // of the four-cell BiCGStab kernels: 1 p, 2 v, 4 s, 8 t, 16 x; default all), FG_MB_SCALAR_CG=1 (one-cell
     // CG kernels), FG_MB_GRAPH (CG chunks replayed as a hipGraph), FG_MB_TRACE (residual trace on stderr)
     int dbg_vec_mask = 0, dbg_scalar_cg = 0, dbg_graph = 0, dbg_trace = 0, dbg_fail = 0;   // dbg_fail: FG_MB_TRACE_FAIL
     // per-env outcome of the last fg_mb_piso_step / fg_mb_single_step: 0 ok, 1 a solve ended unconverged (best iterate used),

@@ -848,34 +848,54 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* 
         for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
     M.r4[(size_t)sys * M.n4 + a] = sum;
 }
-constexpr int ML_N8_MAX = 2048;
-__global__ __launch_bounds__(FG_BLOCK) void k_ml_coarse(MlDev M, int nc, const int32_t* __restrict__ flags) {
-    const int sys = blockIdx.y;
-    if (flag_ld(flags + sys) != 0) return;
-    __shared__ float l_r8[ML_N8_MAX];
-    const float* r4 = M.r4 + (size_t)sys * M.n4;
-    for (int g = threadIdx.x; g < M.n8; g += FG_BLOCK) {
-        const uint2 ch = M.child8[g];
-        const unsigned ids[4] = {ch.x & 0xffffu, ch.x >> 16, ch.y & 0xffffu, ch.y >> 16};
-        float sum = 0.f;
+constexpr int ML_N8_MAX = 2048, ML_SB = 4, ML_CW = 16;   // coarse solve: systems per workgroup (they share every matrix element read), waves
+// One workgroup = 64 rows of A8^+ x ML_SB systems; its 16 waves split the column range (each lane streams its row's slice of the
+// symmetric matrix by columns, coalesced across the wave, 16-deep), partial sums meet in LDS.  At Airfoil2D's 771 aggregates x 16
+// envs: 13 x 4 workgroups, 2.4 MB of matrix read 4 times from L2 instead of 16.
+__global__ __launch_bounds__(64 * ML_CW) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags) {
+    __shared__ float l_r8[ML_SB][ML_N8_MAX];
+    __shared__ float l_part[ML_CW][ML_SB][64];
+    const int sys0 = blockIdx.y * ML_SB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool on[ML_SB], any = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (ids[k] != 0xffffu) sum += r4[ids[k]];
-        l_r8[g] = sum;
+    for (int k = 0; k < ML_SB; ++k) { on[k] = sys0 + k < nsys && flag_ld(flags + sys0 + k) == 0; any = any || on[k]; }
+    if (!any) return;
+#pragma unroll
+    for (int k = 0; k < ML_SB; ++k) {
+        const float* r4 = M.r4 + (size_t)(sys0 + k) * M.n4;
+        for (int g = threadIdx.x; g < M.n8; g += 64 * ML_CW) {
+            float sum = 0.f;
+            if (on[k]) {
+                const uint2 ch = M.child8[g];
+                const unsigned ids[4] = {ch.x & 0xffffu, ch.x >> 16, ch.y & 0xffffu, ch.y >> 16};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (ids[c] != 0xffffu) sum += r4[ids[c]];
+            }
+            l_r8[k][g] = sum;
+        }
     }
     __syncthreads();
-    const int row = blockIdx.x * FG_BLOCK + threadIdx.x;
-    if (row >= M.n8) return;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    const float* col = M.aci8 + row;
-    int j = 0;
-    for (; j + 4 <= M.n8; j += 4) {
-        acc0 += col[(size_t)j * M.ld8] * l_r8[j];
-        acc1 += col[(size_t)(j + 1) * M.ld8] * l_r8[j + 1];
-        acc2 += col[(size_t)(j + 2) * M.ld8] * l_r8[j + 2];
-        acc3 += col[(size_t)(j + 3) * M.ld8] * l_r8[j + 3];
+    const int row = blockIdx.x * 64 + lane;
+    const int chunk = (M.n8 + ML_CW - 1) / ML_CW, j0 = wave * chunk, j1 = min(j0 + chunk, M.n8);
+    float acc[ML_SB] = {0.f, 0.f, 0.f, 0.f};
+    if (row < M.n8) {
+        const float* col = M.aci8 + row;
+#pragma unroll 16
+        for (int j = j0; j < j1; ++j) {
+            const float m = col[(size_t)j * M.ld8];
+#pragma unroll
+            for (int k = 0; k < ML_SB; ++k) acc[k] += m * l_r8[k][j];
+        }
     }
-    for (; j < M.n8; ++j) acc0 += col[(size_t)j * M.ld8] * l_r8[j];
-    M.z8[(size_t)sys * M.n8 + row] = ((acc0 + acc1) + (acc2 + acc3)) * M.scale_inv[sys / nc];
+#pragma unroll
+    for (int k = 0; k < ML_SB; ++k) l_part[wave][k][lane] = acc[k];
+    __syncthreads();
+    if (wave < ML_SB && row < M.n8 && on[wave]) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < ML_CW; ++w) t += l_part[w][wave][lane];
+        M.z8[(size_t)(sys0 + wave) * M.n8 + row] = t * M.scale_inv[(sys0 + wave) / nc];
+    }
 }
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const float* __restrict__ in, const float* __restrict__ diag, int N, int nc,
                                                          const int32_t* __restrict__ flags, float* __restrict__ out) {
@@ -1743,7 +1763,7 @@ void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, 
     M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale;
     const int nsys = s->B * q.nc, n = s->N;
     hipLaunchKernelGGL(k_ml_restrict, dim3((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
-    hipLaunchKernelGGL(k_ml_coarse, dim3((M.n8 + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, q.nc, (const int32_t*)q.flags);
+    hipLaunchKernelGGL(k_ml_coarse, dim3((M.n8 + 63) / 64, (nsys + ML_SB - 1) / ML_SB), dim3(64 * ML_CW), 0, st, M, q.nc, nsys, (const int32_t*)q.flags);
     hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out);
 }
 
@@ -1762,10 +1782,10 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // a refined solve that has not converged after 1500 iterations is not going to: hand over to the caller's CG fallback
     // instead of spending the reference's 5000 (one hard env would stall the whole batch)
     if (refine && max_iterations > 1500) max_iterations = 1500;
-    // Four-cells-per-thread kernels (k_mbb_*4): s->dbg_vec_mask selects them per kernel (FG_MB_BICG_VEC4, read at create).
-    int vec_mask = (n % 4 != 0) ? 0 : s->dbg_vec_mask;
-    if (vec_mask & 128) vec_mask = (nc > 1) ? (vec_mask & 31) : 0;        // + 128: velocity solves only (d systems per env)
-    else if (vec_mask & 64) vec_mask = (nc == 1) ? (vec_mask & 31) : 0;   // + 64: pressure solves only (one system per env)
+    // Four-cells-per-thread kernels (k_mbb_*4) whenever the cell count allows; FG_MB_BICG_VEC4 (read at create) is the repro
+    // harness's per-kernel switch (profiles/bicg_vec4_repro.py), not a workaround: the defect it once bisected was the
+    // accumulator access pattern (fg_internal.h acc_ld / acc_st), in both kernel forms.
+    const int vec_mask = (n % 4 != 0) ? 0 : (s->dbg_vec_mask & 31);
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     auto keep_best = [&](int first) {
         hipLaunchKernelGGL(k_mbr_best_decide, sg, sb, 0, st, q, s->best_res, s->best_keep, n, nsys, first);
@@ -1797,7 +1817,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             if (refine) keep_best(0);
         }
         const int li = it - q.it_base;
-        MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form (bisecting the defect noted above)
+        MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form
             if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
             if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st);
             if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
@@ -2076,8 +2096,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
     s->host_only = device < 0;
     {   // debug switches: the only getenv calls of this path, never on the step path
         const char* e = getenv("FG_MB_BICG_VEC4");
-        // default: four-cell kernels in the pressure solves only (one system per env)
-        s->dbg_vec_mask = !e ? 95 : ((e[0] == '1' && e[1] == 0) ? 31 : atoi(e));
+        s->dbg_vec_mask = !e ? 31 : ((e[0] == '1' && e[1] == 0) ? 31 : atoi(e));   // bit per kernel: 1 p, 2 v, 4 s, 8 t, 16 x
         e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;

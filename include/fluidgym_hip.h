@@ -448,12 +448,14 @@ int fg_mb_set_residual_projection(fg_mb_handle h, const float* y_host);
  * the reference has no such limit: its solves run to maxIterations and return the best result,
  * cg_solver_kernel.cu:345-361, PISOtorch_diff.py:266-371). */
 int fg_mb_set_stall_limit(fg_mb_handle h, int32_t iterations);
-/* Additive multilevel preconditioner of the pressure CG on 2-D meshes that run the on-chip solver (k_mbc_onchip): Jacobi +
- * 1/2 x Jacobi on 4 x 4 aggregates + the dense pseudo-inverse on 8 x 8 aggregates, all from the geometry-only (A = 1) matrix and
- * scaled per env.  Host arrays: a4 [N] (aggregate of every cell), parent4 [n4] (8 x 8 aggregate of every 4 x 4 one), rect4 (every
- * 4 x 4 aggregate as a rectangle of cells of one block; checked against a4), d4g [n4],
- * aci8 [n8 x n8]; n4 <= 2048, n8 <= 512.  a4 == NULL only switches it on / off (enable).  The reference has no preconditioner
- * for CG (cg_solver_kernel.cu); converged answers agree to the solver tolerance, iteration counts drop 3-4x. */
+/* Additive multilevel preconditioner of the pressure solves on 2-D meshes: Jacobi + 1/2 x Jacobi on 4 x 4 aggregates + the
+ * dense pseudo-inverse on 8 x 8 aggregates, all from the geometry-only (A = 1) matrix and scaled per env.  Host arrays: a4 [N]
+ * (aggregate of every cell), parent4 [n4] (8 x 8 aggregate of every 4 x 4 one), rect4 (every 4 x 4 aggregate as a rectangle of
+ * cells of one block; checked against a4), d4g [n4], aci8 [n8 x n8]; n4 < 65535, n8 <= 2048.  Consumers: the on-chip CG
+ * (k_mbc_onchip; up to 16 k cells, n4 <= 2048, n8 <= 512) applies it inside the persistent kernel, the pressure BiCGStab of any
+ * mesh takes it as right preconditioner in kernel form (three launches per application).  a4 == NULL only switches it on / off
+ * (enable).  The reference's CG / BiCGStab run without one (cg_solver_kernel.cu; its ILU0 is the fallback rung only); converged
+ * answers agree to the solver tolerance, iteration counts drop 3-9x. */
 int fg_mb_set_multilevel(fg_mb_handle h, int32_t n4, int32_t n8, const int32_t* a4_host, const int32_t* parent4_host,
                          const int32_t* rect4_host /* [n4][4]: first cell, width, height, row stride */, const float* d4g_host,
                          const float* aci8_host, float geom_diag_sum, int32_t enable);
