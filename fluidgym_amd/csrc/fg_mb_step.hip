@@ -1408,9 +1408,15 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     float best = 3.0e38f, crit = 0.f;
     bool fresh = true, restarted = true, residual_pass = o.use_x0 != 0, recovering = false;
     double rho = 0.0, rho_prev = 1.0;
+    // per-phase cycle counters: a BUILD switch (-DFG_MB_OC_CYCLES, profiles/onchip_micro.py variant 256) -- as a run-time switch
+    // the 24 extra registers pushed every instance of this kernel into scratch (30 -> 60 us per preconditioned iteration)
+#ifdef FG_MB_OC_CYCLES
     unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tph = 0;
 #define OC_PHASE(k) do { if (o.dbg & 1) { const unsigned long long now_ = clock64(); ph[k] += now_ - tph; tph = now_; } } while (0)
     if (o.dbg & 1) tph = clock64();
+#else
+#define OC_PHASE(k) do { } while (0)
+#endif
     for (;;) {
         // the thread index is laundered once per trip: per-cell 64-bit addresses are invariants of this loop, and the
         // compiler otherwise hoists all of them out of it (CPT x 8 register pairs) and spills them
@@ -1595,10 +1601,12 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         ++it;
         OC_PHASE(10);  // x, r update + r.r reduction
     }
+#ifdef FG_MB_OC_CYCLES
     if ((o.dbg & 1) && sys == 0 && t == 0 && o.dbg_out) {
         for (int k = 0; k < 11; ++k) o.dbg_out[k] = ph[k];
         o.dbg_out[11] = (unsigned long long)it;
     }
+#endif
 #undef OC_PHASE
     // ---- hand back: the last iterate when converged, the kept one otherwise (k_mbs_restore_best)
     const bool use_best = (outcome == 3 || outcome == 4 || (outcome == 2 && best < 3.0e38f));

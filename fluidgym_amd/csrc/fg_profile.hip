@@ -136,16 +136,19 @@ __global__ __launch_bounds__(FG_BLOCK) void k_stream_triad(float4* __restrict__ 
 // The access pattern of the multi-kernel BiCGStab recurrence reduced to its skeleton: per iteration five launches (p, v, s, t, x)
 // over `nsys` systems x `G` workgroups; every workgroup adds 1.0 to a sum slot with a device-scope atomic, the NEXT kernel reads
 // the slot in every wave and expects exactly G, and the system's leader workgroup zeroes slots for later kernels -- seven sums in
-// one 96-byte record per system, as in fg_mb_step.hip / fg_bicgstab.hip.  ATOMIC = false zeroes and reads the slots with plain
-// stores / loads (round 1), ATOMIC = true with agent-scope atomic stores / loads (acc_st / acc_ld).  A read that is not G is
+// one 96-byte record per system, as in fg_mb_step.hip / fg_bicgstab.hip.  LD / ST select how the slots are read and zeroed:
+// plain (round 1), agent-scope atomic load / store, or an atomic exchange for the zeroing.  A read that is not G is
 // counted per slot and the first wrong value kept.
 enum { L_RHO = 0, L_RV = 2, L_SS = 3, L_TS = 4, L_TT = 5, L_RR = 6, L_REC = 12 };
-template <bool ATOMIC> __device__ __forceinline__ double lit_ld(const double* p) {
-    if constexpr (ATOMIC) return acc_ld(p);
+// LD: 0 plain load, 1 agent-scope atomic load.  ST: 0 plain store, 1 agent-scope atomic store, 2 atomic exchange (the path of the adds)
+template <int LD> __device__ __forceinline__ double lit_ld(const double* p) {
+    if constexpr (LD == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <bool ATOMIC> __device__ __forceinline__ void lit_st(double* p, double v) {
-    if constexpr (ATOMIC) acc_st(p, v); else *p = v;
+template <int ST> __device__ __forceinline__ void lit_st(double* p, double v) {
+    if constexpr (ST == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if constexpr (ST == 2) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 struct LitArgs { double* acc; float* vec; int64_t* bad; double* bad_value; int n; int it; };
 __device__ __forceinline__ void lit_check(const LitArgs& q, int slot, double got) {
@@ -153,7 +156,7 @@ __device__ __forceinline__ void lit_check(const LitArgs& q, int slot, double got
         if (atomicAdd((unsigned long long*)(q.bad + slot), 1ull) == 0ull) q.bad_value[slot] = got;
     }
 }
-template <bool ATOMIC, int K>
+template <int LD, int ST, int K>
 __global__ __launch_bounds__(FG_BLOCK) void k_litmus(LitArgs q) {
     const int sys = blockIdx.y;
     double* a = q.acc + (size_t)sys * L_REC;
@@ -162,51 +165,51 @@ __global__ __launch_bounds__(FG_BLOCK) void k_litmus(LitArgs q) {
     float* v = q.vec + (size_t)sys * q.n;
     const int it = q.it;
     if constexpr (K == 0) {          // p: reads rr, both rho; leader zeroes ss, ts, tt
-        const double rr = lit_ld<ATOMIC>(a + L_RR), r0 = lit_ld<ATOMIC>(a + L_RHO + (it & 1));
+        const double rr = lit_ld<LD>(a + L_RR), r0 = lit_ld<LD>(a + L_RHO + (it & 1));
         lit_check(q, L_RR, rr); lit_check(q, L_RHO + (it & 1), r0);
-        if (leader) { lit_st<ATOMIC>(a + L_SS, 0.0); lit_st<ATOMIC>(a + L_TS, 0.0); lit_st<ATOMIC>(a + L_TT, 0.0); }
+        if (leader) { lit_st<ST>(a + L_SS, 0.0); lit_st<ST>(a + L_TS, 0.0); lit_st<ST>(a + L_TT, 0.0); }
         if (i < q.n) v[i] = v[i] * 0.5f + (float)(rr - r0);
     } else if constexpr (K == 1) {   // v: accumulates rw.v
         if (i < q.n) v[i] += 1.f;
         if (threadIdx.x == 0) atomicAdd(a + L_RV, 1.0);
     } else if constexpr (K == 2) {   // s: reads rho, rw.v; leader zeroes next rho, rr; accumulates ss
-        const double rv = lit_ld<ATOMIC>(a + L_RV), r0 = lit_ld<ATOMIC>(a + L_RHO + (it & 1));
+        const double rv = lit_ld<LD>(a + L_RV), r0 = lit_ld<LD>(a + L_RHO + (it & 1));
         lit_check(q, L_RV, rv); lit_check(q, L_RHO + (it & 1), r0);
-        if (leader) { lit_st<ATOMIC>(a + L_RHO + ((it + 1) & 1), 0.0); lit_st<ATOMIC>(a + L_RR, 0.0); }
+        if (leader) { lit_st<ST>(a + L_RHO + ((it + 1) & 1), 0.0); lit_st<ST>(a + L_RR, 0.0); }
         if (i < q.n) v[i] -= (float)(rv / r0);
         if (threadIdx.x == 0) atomicAdd(a + L_SS, 1.0);
     } else if constexpr (K == 3) {   // t: reads ss; accumulates ts, tt
-        const double ss = lit_ld<ATOMIC>(a + L_SS);
+        const double ss = lit_ld<LD>(a + L_SS);
         lit_check(q, L_SS, ss);
         if (i < q.n) v[i] += (float)ss * 1e-3f;
         if (threadIdx.x == 0) { atomicAdd(a + L_TS, 1.0); atomicAdd(a + L_TT, 1.0); }
     } else {                         // x: reads ts, tt; leader zeroes rw.v; accumulates rr and next rho
-        const double ts = lit_ld<ATOMIC>(a + L_TS), tt = lit_ld<ATOMIC>(a + L_TT);
+        const double ts = lit_ld<LD>(a + L_TS), tt = lit_ld<LD>(a + L_TT);
         lit_check(q, L_TS, ts); lit_check(q, L_TT, tt);
-        if (leader) lit_st<ATOMIC>(a + L_RV, 0.0);
+        if (leader) lit_st<ST>(a + L_RV, 0.0);
         if (i < q.n) v[i] -= (float)(ts / tt);
         if (threadIdx.x == 0) { atomicAdd(a + L_RR, 1.0); atomicAdd(a + L_RHO + ((it + 1) & 1), 1.0); }
     }
 }
-template <bool ATOMIC>
+template <int LD, int ST>
 __global__ void k_litmus_init(LitArgs q, int nsys, double g) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
-    for (int k = 0; k < L_REC; ++k) lit_st<ATOMIC>(q.acc + (size_t)s * L_REC + k, 0.0);
-    lit_st<ATOMIC>(q.acc + (size_t)s * L_REC + L_RR, g);
-    lit_st<ATOMIC>(q.acc + (size_t)s * L_REC + L_RHO, g);
+    for (int k = 0; k < L_REC; ++k) lit_st<ST>(q.acc + (size_t)s * L_REC + k, 0.0);
+    lit_st<ST>(q.acc + (size_t)s * L_REC + L_RR, g);
+    lit_st<ST>(q.acc + (size_t)s * L_REC + L_RHO, g);
 }
-template <bool ATOMIC>
+template <int LD, int ST>
 void litmus_run(LitArgs q, int nsys, int G, int iters, hipStream_t st) {
-    hipLaunchKernelGGL(k_litmus_init<ATOMIC>, dim3((nsys + 63) / 64), dim3(64), 0, st, q, nsys, (double)G);
+    hipLaunchKernelGGL((k_litmus_init<LD, ST>), dim3((nsys + 63) / 64), dim3(64), 0, st, q, nsys, (double)G);
     const dim3 grid(G, nsys), blk(FG_BLOCK);
     for (int it = 0; it < iters; ++it) {
         q.it = it;
-        hipLaunchKernelGGL((k_litmus<ATOMIC, 0>), grid, blk, 0, st, q);
-        hipLaunchKernelGGL((k_litmus<ATOMIC, 1>), grid, blk, 0, st, q);
-        hipLaunchKernelGGL((k_litmus<ATOMIC, 2>), grid, blk, 0, st, q);
-        hipLaunchKernelGGL((k_litmus<ATOMIC, 3>), grid, blk, 0, st, q);
-        hipLaunchKernelGGL((k_litmus<ATOMIC, 4>), grid, blk, 0, st, q);
+        hipLaunchKernelGGL((k_litmus<LD, ST, 0>), grid, blk, 0, st, q);
+        hipLaunchKernelGGL((k_litmus<LD, ST, 1>), grid, blk, 0, st, q);
+        hipLaunchKernelGGL((k_litmus<LD, ST, 2>), grid, blk, 0, st, q);
+        hipLaunchKernelGGL((k_litmus<LD, ST, 3>), grid, blk, 0, st, q);
+        hipLaunchKernelGGL((k_litmus<LD, ST, 4>), grid, blk, 0, st, q);
     }
 }
 }  // namespace
@@ -247,7 +250,16 @@ extern "C" int fg_coherence_litmus(int32_t atomic_access, int32_t nsys, int32_t 
     FG_HIP_CHECK(hipMemsetAsync(q.vec, 0, sizeof(float) * (size_t)cells * nsys, st));
     FG_HIP_CHECK(hipMemsetAsync(q.bad, 0, sizeof(int64_t) * L_REC, st));
     FG_HIP_CHECK(hipMemsetAsync(q.bad_value, 0, sizeof(double) * L_REC, st));
-    if (atomic_access) litmus_run<true>(q, nsys, G, iterations, st); else litmus_run<false>(q, nsys, G, iterations, st);
+    switch (atomic_access) {   // 10 * store + load
+        case 0: litmus_run<0, 0>(q, nsys, G, iterations, st); break;
+        case 1: litmus_run<1, 0>(q, nsys, G, iterations, st); break;
+        case 10: litmus_run<0, 1>(q, nsys, G, iterations, st); break;
+        case 11: litmus_run<1, 1>(q, nsys, G, iterations, st); break;
+        case 20: litmus_run<0, 2>(q, nsys, G, iterations, st); break;
+        case 21: litmus_run<1, 2>(q, nsys, G, iterations, st); break;
+        default: (void)hipFree(q.acc); (void)hipFree(q.vec); (void)hipFree(q.bad); (void)hipFree(q.bad_value);
+                 FG_REQUIRE(false, FG_ERR_INVALID_ARG, "fg_coherence_litmus: access must be 0, 1, 10, 11, 20 or 21");
+    }
     FG_HIP_CHECK(hipMemcpyAsync(bad_reads, q.bad, sizeof(int64_t) * L_REC, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipMemcpyAsync(bad_value, q.bad_value, sizeof(double) * L_REC, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));

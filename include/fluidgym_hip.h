@@ -272,8 +272,8 @@ int fg_poisson_fdcg(fg_handle h, const float* rA, const float* b, float* x, floa
 int fg_stream_triad(float* a, const float* b, const float* c, float scalar, int64_t n, int32_t reps, float* ms_per_launch, void* stream);
 /* Litmus for the access pattern of the multi-kernel Krylov recurrences: `iterations` x five launches over
  * `nsys` systems of `cells` cells; sums accumulated with device-scope atomics are read by the following kernel and zeroed by a
- * leader workgroup, either with plain loads / stores (atomic_access = 0, the round-1 pattern) or with agent-scope atomic loads /
- * stores (1, what the solvers use).  bad_reads[12] counts, per slot of the record, reads that did not return the full sum,
+ * leader workgroup; atomic_access = 10 x store + load with load 0 plain / 1 agent-scope atomic load and store 0 plain / 1
+ * agent-scope atomic store / 2 atomic exchange (0 = the round-1 pattern).  bad_reads[12] counts, per slot of the record, reads that did not return the full sum,
  * bad_value[12] keeps the first wrong value.  Synchronises. */
 int fg_coherence_litmus(int32_t atomic_access, int32_t nsys, int32_t cells, int32_t iterations, int64_t* bad_reads, double* bad_value,
                         void* stream);

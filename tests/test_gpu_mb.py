@@ -434,5 +434,5 @@ def test_recurrence_words_read_back_exactly_under_agent_scope_access():
     from fluidgym_amd import _lib as L
     bad = (ctypes.c_int64 * 12)()
     val = (ctypes.c_double * 12)()
-    L.check(L.load().fg_coherence_litmus(1, 32, 46664, 4000, bad, val, None))
+    L.check(L.load().fg_coherence_litmus(11, 32, 46664, 4000, bad, val, None))
     assert sum(bad) == 0, (list(bad), list(val))
