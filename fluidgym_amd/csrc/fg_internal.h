@@ -14,12 +14,26 @@
 // stored instead of the sum the kernel in between had accumulated (rw.v == 0 exactly with v finite in every cell -> alpha = -inf;
 // profiles/r02_bicg_failure_trace.txt) -- the intermittent "non-finite BiCGStab solve".  Every access to these words now takes
 // the ONE path the atomics take: 8-byte / 4-byte agent-scope atomic loads and stores (global_load / store ... sc1).
-__device__ __forceinline__ double acc_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void acc_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float sc_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void sc_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t flag_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void flag_st(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// FG_ACC_ACCESS / FG_FLAG_ACCESS (build switches of profiles/bicg_stress.sh): bit 0 = agent-scope atomic loads, bit 1 = agent-scope
+// atomic stores, for the accumulators and for the scalar / flag words
+#ifndef FG_ACC_ACCESS
+#define FG_ACC_ACCESS 3
+#endif
+#ifndef FG_FLAG_ACCESS
+#define FG_FLAG_ACCESS 3
+#endif
+template <typename T> __device__ __forceinline__ T fg_word_ld(const T* p, bool atomic) {
+    return atomic ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <typename T> __device__ __forceinline__ void fg_word_st(T* p, T v, bool atomic) {
+    if (atomic) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ double acc_ld(const double* p) { return fg_word_ld(p, (FG_ACC_ACCESS & 1) != 0); }
+__device__ __forceinline__ void acc_st(double* p, double v) { fg_word_st(p, v, (FG_ACC_ACCESS & 2) != 0); }
+__device__ __forceinline__ float sc_ld(const float* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
+__device__ __forceinline__ void sc_st(float* p, float v) { fg_word_st(p, v, (FG_FLAG_ACCESS & 2) != 0); }
+__device__ __forceinline__ int32_t flag_ld(const int32_t* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
+__device__ __forceinline__ void flag_st(int32_t* p, int32_t v) { fg_word_st(p, v, (FG_FLAG_ACCESS & 2) != 0); }
 
 #define FG_BLOCK 256  // threads per workgroup = 4 waves of 64
 

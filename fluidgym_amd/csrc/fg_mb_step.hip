@@ -2487,7 +2487,7 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
         if (!s->ml_a4) if (int rc = mb_alloc(s, &s->ml_a4, (size_t)s->N)) return rc;
         if (int rc = mb_alloc(s, &s->ml_parent4, (size_t)c4)) return rc;
         if (int rc = mb_alloc(s, &s->ml_d4g, (size_t)c4)) return rc;
-        if (int rc = mb_alloc(s, &s->ml_aci8, (size_t)c8 * c8)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_aci8, (size_t)c8 * ((c8 + 3) & ~3))) return rc;   // rows padded to a multiple of four
         if (int rc = mb_alloc(s, &s->ml_r4, (size_t)s->B * c4)) return rc;
         if (int rc = mb_alloc(s, &s->ml_z8, (size_t)s->B * c8)) return rc;
         if (!s->ml_scale) {
@@ -2517,6 +2517,25 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
 extern "C" int fg_mb_debug_cycles(fg_mb_handle s, uint64_t* out12) {
     FG_REQUIRE(s && s->oc_dbg && out12, FG_ERR_INVALID_ARG, "fg_mb_debug_cycles: not available");
     FG_HIP_CHECK(hipMemcpy(out12, s->oc_dbg, sizeof(uint64_t) * 12, hipMemcpyDeviceToHost));
+    return FG_OK;
+}
+
+// Stress harness of the velocity BiCGStab (profiles/bicg_stress.py): solves the systems currently held in the assembly buffers
+// (diagonal, off-diagonals, right-hand side; FG_MB_BUF_A / _C_OFF / _RHS) `reps` times from zero, exactly as fg_mb_piso_step's first
+// attempt does, and counts the outcomes: [0] solves, [1] with a non-finite system, [2] unconverged, [3] max iterations seen.
+extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, float tol, int32_t max_iterations, int32_t reps, int64_t* out4, void* stream) {
+    FG_REQUIRE(s && s->finalized && !s->host_only && out4 && reps > 0, FG_ERR_INVALID_ARG, "fg_mb_debug_bicgstab: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (int r = 0; r < reps; ++r) {
+        int m = 0;
+        const int rc = mb_bicgstab(s, nullptr, s->Cdiag, s->Coff, s->rhs, s->ures, s->d, tol, max_iterations, 0, &m, st);
+        out4[0] += 1;
+        if (rc == FG_ERR_NOT_FINITE) { out4[1] += 1; if (out4[1] > 20) break; }
+        else if (rc == FG_ERR_NOT_CONVERGED) out4[2] += 1;
+        else if (rc != FG_OK) return rc;
+        if (m > out4[3]) out4[3] = m;
+    }
     return FG_OK;
 }
 

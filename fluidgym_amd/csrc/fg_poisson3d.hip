@@ -177,16 +177,8 @@ __device__ __forceinline__ double z_acc_total(const double* a, int ns) {
     return v;
 }
 
-#ifndef FG_ZMARCH_OCC      // tuning switch for profiles/zmarch_sweep.sh: pin the register budget to the LDS-limited residency
-#define FG_ZMARCH_OCC 1
-#endif
-#if FG_ZMARCH_OCC
-#define FG_ZMARCH_OCC_ATTR(PPB) __attribute__((amdgpu_waves_per_eu(PPB == 1 ? 4 : 3, PPB == 1 ? 4 : 3)))
-#else
-#define FG_ZMARCH_OCC_ATTR(PPB)
-#endif
 template <int MODE, int BXL, int PPB>
-__global__ __launch_bounds__(FG_BLOCK) FG_ZMARCH_OCC_ATTR(PPB) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
+__global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
                                                               int ZC) {
     constexpr int TY = ZT<BXL>::TY, LP = ZT<BXL>::LP, LROWS = ZT<BXL>::LROWS;
     const ZCtx c = z_make_ctx<BXL>(g, tiles_x, tiles_y, zchunks, ZC);
@@ -307,6 +299,8 @@ __global__ __launch_bounds__(FG_BLOCK) FG_ZMARCH_OCC_ATTR(PPB) void k_poisson3_m
     // z faces: every cell's half coefficient gz = (0.5 rh_z) (hx hy a) is formed once, a face is the sum of the two cells it
     // separates, and a thread marching in z carries gz of the plane above and the face it shares with it: exactly one face
     // evaluation per cell and plane, and both sides of a face use the same bits.
+    // (not in the CG kernel: the eight carried registers cost it a wave of occupancy, 156 -> 169 us per CG iteration at 256^3)
+    constexpr bool CARRY = (MODE != MODE_CG_AP);
     float gz_c[4], face_zm[4];
     bool have_carry = false;
     auto plane = [&](int k, int sm, int sc, int sp, const FgVec<4>& bv) {
@@ -364,7 +358,7 @@ __global__ __launch_bounds__(FG_BLOCK) FG_ZMARCH_OCC_ATTR(PPB) void k_poisson3_m
             const float pm_[4] = {Pm.x, Pm.y, Pm.z, Pm.w}, pp_[4] = {Pp.x, Pp.y, Pp.z, Pp.w};
             const float ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
             const float wz_p = 0.5f * m.rhz_p;
-            if (!have_carry) {       // first plane of the chunk (uniform branch): the face below from plane k-1 in the ring
+            if (!CARRY || !have_carry) {   // first plane of the chunk (uniform branch): the face below from plane k-1 in the ring
                 const float4 Am = *reinterpret_cast<const float4*>(&ring_a[sm][cen]);
                 const float am_[4] = {Am.x, Am.y, Am.z, Am.w};
                 const float wz_c = 0.5f * m.rhz, wz_m = 0.5f * m.rhz_m;
@@ -373,7 +367,7 @@ __global__ __launch_bounds__(FG_BLOCK) FG_ZMARCH_OCC_ATTR(PPB) void k_poisson3_m
                     gz_c[e] = wz_c * (hxy[e] * acv[e]);
                     face_zm[e] = fc.mzm * (wz_m * (hxy[e] * am_[e]) + gz_c[e]);
                 }
-                have_carry = true;
+                have_carry = CARRY;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -491,18 +485,18 @@ template <int MODE>
 static int launch_march(const fg_state* s, const Z3Args& a, int zc, hipStream_t st, int slot = -1) {
     const FgGrid& g = s->grid;
     const int bxl = z_pick_bxl(g);
-    const int tx = g.nx / (bxl * 4), ty = g.ny / (FG_BLOCK / bxl), zch = (g.nz + zc - 1) / zc;
+    const int tx = g.nx / (bxl * 4), ty = g.ny / (FG_BLOCK / bxl);
+    // apply carries the least per-plane state and gains from longer chunks (two halo planes per chunk): twice the planes while
+    // that leaves >= 4 workgroups per CU (256^3: 16 planes, 43.7 us against 46.3 with 8)
+    if (MODE == MODE_APPLY && zc < 32 && (long)tx * ty * ((g.nz + 2 * zc - 1) / (2 * zc)) * g.B >= 1024) zc *= 2;
+    const int zch = (g.nz + zc - 1) / zc;
     dim3 grid((unsigned)(tx * ty * zch * g.B));
-    static const int ppb = [] { const char* e = getenv("FG_ZMARCH_PPB"); return e ? atoi(e) : 1; }();
-    if (ppb == 2) {
-        if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16, 2>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-        else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32, 2>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-        else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64, 2>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-    } else {
-        if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16, 1>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-        else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32, 1>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-        else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64, 1>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
-    }
+    // measured at 256^3 (profiles/zmarch_sweep.sh, r02): the Jacobi / RB-GS sweep is fastest with two planes per barrier pair
+    // (55.5 us against 58.8), apply and the CG kernel with one (registers: 152-170 with two)
+    constexpr int PPB = (MODE == MODE_RELAX) ? 2 : 1;
+    if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16, PPB>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32, PPB>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+    else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64, PPB>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

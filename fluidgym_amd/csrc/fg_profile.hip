@@ -150,10 +150,25 @@ template <int ST> __device__ __forceinline__ void lit_st(double* p, double v) {
     else if constexpr (ST == 2) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
-struct LitArgs { double* acc; float* vec; int64_t* bad; double* bad_value; int n; int it; };
+template <int LD> __device__ __forceinline__ int32_t lit_ldf(const int32_t* p) {
+    if constexpr (LD == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <int ST> __device__ __forceinline__ void lit_stf(int32_t* p, int32_t v) {
+    if constexpr (ST != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+struct LitArgs { double* acc; float* vec; int64_t* bad; double* bad_value; int32_t* flag; int n; int it; };
 __device__ __forceinline__ void lit_check(const LitArgs& q, int slot, double got) {
     if (threadIdx.x == 0 && got != (double)gridDim.x) {
         if (atomicAdd((unsigned long long*)(q.bad + slot), 1ull) == 0ull) q.bad_value[slot] = got;
+    }
+}
+// the flag / scalar protocol of the same solvers: a word stored by the system's leader workgroup in kernel t (plain or atomic
+// store) is read by every workgroup of the four kernels that follow; slot 11 counts reads that did not return it
+__device__ __forceinline__ void lit_check_flag(const LitArgs& q, int got, int want) {
+    if (threadIdx.x == 0 && got != want) {
+        if (atomicAdd((unsigned long long*)(q.bad + 11), 1ull) == 0ull) q.bad_value[11] = (double)got;
     }
 }
 template <int LD, int ST, int K>
@@ -164,6 +179,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_litmus(LitArgs q) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x;
     float* v = q.vec + (size_t)sys * q.n;
     const int it = q.it;
+    {   // systems store at different rates (every 1 / 2 / 3 iterations), as systems converge at different times in the solvers:
+        // the 32 flags of a batch share one 128-byte line that is partially rewritten from different XCDs at different times
+        const int m = 1 + sys % 3;
+        if constexpr (K == 3) { if (leader && it % m == 0) lit_stf<ST>(q.flag + sys, it + 1); }
+        else {
+            const int last = (K == 4) ? it : it - 1;   // iteration of the latest t kernel before this one
+            lit_check_flag(q, lit_ldf<LD>(q.flag + sys), last < 0 ? 0 : (last / m) * m + 1);
+        }
+    }
     if constexpr (K == 0) {          // p: reads rr, both rho; leader zeroes ss, ts, tt
         const double rr = lit_ld<LD>(a + L_RR), r0 = lit_ld<LD>(a + L_RHO + (it & 1));
         lit_check(q, L_RR, rr); lit_check(q, L_RHO + (it & 1), r0);
@@ -246,6 +270,8 @@ extern "C" int fg_coherence_litmus(int32_t atomic_access, int32_t nsys, int32_t 
     FG_HIP_CHECK(hipMalloc(&q.acc, sizeof(double) * L_REC * nsys));
     FG_HIP_CHECK(hipMalloc(&q.vec, sizeof(float) * (size_t)cells * nsys));
     FG_HIP_CHECK(hipMalloc(&q.bad, sizeof(int64_t) * L_REC));
+    FG_HIP_CHECK(hipMalloc(&q.flag, sizeof(int32_t) * nsys));
+    FG_HIP_CHECK(hipMemsetAsync(q.flag, 0, sizeof(int32_t) * nsys, st));
     FG_HIP_CHECK(hipMalloc(&q.bad_value, sizeof(double) * L_REC));
     FG_HIP_CHECK(hipMemsetAsync(q.vec, 0, sizeof(float) * (size_t)cells * nsys, st));
     FG_HIP_CHECK(hipMemsetAsync(q.bad, 0, sizeof(int64_t) * L_REC, st));
@@ -257,12 +283,12 @@ extern "C" int fg_coherence_litmus(int32_t atomic_access, int32_t nsys, int32_t 
         case 11: litmus_run<1, 1>(q, nsys, G, iterations, st); break;
         case 20: litmus_run<0, 2>(q, nsys, G, iterations, st); break;
         case 21: litmus_run<1, 2>(q, nsys, G, iterations, st); break;
-        default: (void)hipFree(q.acc); (void)hipFree(q.vec); (void)hipFree(q.bad); (void)hipFree(q.bad_value);
+        default: (void)hipFree(q.acc); (void)hipFree(q.vec); (void)hipFree(q.bad); (void)hipFree(q.bad_value); (void)hipFree(q.flag);
                  FG_REQUIRE(false, FG_ERR_INVALID_ARG, "fg_coherence_litmus: access must be 0, 1, 10, 11, 20 or 21");
     }
     FG_HIP_CHECK(hipMemcpyAsync(bad_reads, q.bad, sizeof(int64_t) * L_REC, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipMemcpyAsync(bad_value, q.bad_value, sizeof(double) * L_REC, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
-    (void)hipFree(q.acc); (void)hipFree(q.vec); (void)hipFree(q.bad); (void)hipFree(q.bad_value);
+    (void)hipFree(q.acc); (void)hipFree(q.vec); (void)hipFree(q.bad); (void)hipFree(q.bad_value); (void)hipFree(q.flag);
     return FG_OK;
 }

@@ -273,8 +273,9 @@ int fg_stream_triad(float* a, const float* b, const float* c, float scalar, int6
 /* Litmus for the access pattern of the multi-kernel Krylov recurrences: `iterations` x five launches over
  * `nsys` systems of `cells` cells; sums accumulated with device-scope atomics are read by the following kernel and zeroed by a
  * leader workgroup; atomic_access = 10 x store + load with load 0 plain / 1 agent-scope atomic load and store 0 plain / 1
- * agent-scope atomic store / 2 atomic exchange (0 = the round-1 pattern).  bad_reads[12] counts, per slot of the record, reads that did not return the full sum,
- * bad_value[12] keeps the first wrong value.  Synchronises. */
+ * agent-scope atomic store / 2 atomic exchange (0 = the round-1 pattern).  bad_reads[12] counts, per slot of the record, reads that did not return the full sum
+ * ([11]: reads of a flag word stored by the leader one to four kernels earlier that did not return it), bad_value[12] keeps the
+ * first wrong value.  Synchronises. */
 int fg_coherence_litmus(int32_t atomic_access, int32_t nsys, int32_t cells, int32_t iterations, int64_t* bad_reads, double* bad_value,
                         void* stream);
 int fg_profile_enable(fg_handle h, int on);
@@ -459,6 +460,10 @@ int fg_mb_set_stall_limit(fg_mb_handle h, int32_t iterations);
 int fg_mb_set_multilevel(fg_mb_handle h, int32_t n4, int32_t n8, const int32_t* a4_host, const int32_t* parent4_host,
                          const int32_t* rect4_host /* [n4][4]: first cell, width, height, row stride */, const float* d4g_host,
                          const float* aci8_host, float geom_diag_sum, int32_t enable);
+/* Stress harness of the multi-block velocity BiCGStab: solves the d systems per env held in the assembly buffers (FG_MB_BUF_A,
+ * _C_OFF, _RHS, e.g. loaded from a dumped failing step) `reps` times from zero; out4 = solves, solves with a non-finite system,
+ * unconverged solves, max iterations.  Debugging aid (profiles/bicg_stress.py), not on any step path. */
+int fg_mb_debug_bicgstab(fg_mb_handle h, float tol, int32_t max_iterations, int32_t reps, int64_t* out4, void* stream);
 int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their

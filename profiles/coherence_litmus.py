@@ -20,7 +20,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 lib = L.load()
 torch.cuda.init()
 torch.zeros(1, device="cuda")
-SLOTS = {0: "rho0", 1: "rho1", 2: "rw.v", 3: "ss", 4: "ts", 5: "tt", 6: "rr"}
+SLOTS = {0: "rho0", 1: "rho1", 2: "rw.v", 3: "ss", 4: "ts", 5: "tt", 6: "rr", 11: "flag"}
 NAMES = {0: "plain load, plain store (round 1)", 1: "atomic load, plain store", 10: "plain load, atomic store", 20: "plain load, atomic exchange",
          11: "atomic load, atomic store", 21: "atomic load, atomic exchange"}
 shapes = ((32, 46664), (16, 46664), (48, 11776), (3, 262144), (256, 2048))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/r02_*: kernel statistics and the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no
-# tracing domains mixed in) of the headline bench command, plus kernel statistics of the 256^3 micro-benchmark and the cylinder leg.
+# tracing domains mixed in) of the headline bench command, plus kernel statistics (and the PMC passes) of the 256^3 micro-benchmark and kernel statistics of the cylinder and airfoil legs.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
@@ -16,5 +16,11 @@ rocprofv3 --kernel-trace --stats -d $O/p_p256 -o p256 -- python3 $R/profiles/mic
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_p256 -name '*.db' | head -1)" $O/r02_b_poisson256_kernel_stats.csv > /dev/null
 rocprofv3 --kernel-trace --stats -d $O/p_cyl -o cyl -- python3 $R/profiles/cylinder_modes.py 64 2 1-0-1 > $O/p_cyl.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_cyl -name '*.db' | head -1)" $O/r02_c_cylinder_kernel_stats.csv > /dev/null
-rm -rf $O/p_stats $O/p_fetch $O/p_write $O/p_p256 $O/p_cyl
+rocprofv3 --pmc FETCH_SIZE -d $O/p_p256f -o p256 -- python3 $R/profiles/micro_poisson.py > $O/p_p256f.log 2>&1
+python3 $R/profiles/summarize_pmc.py "$(find $O/p_p256f -name '*.db' | head -1)" > $O/r02_b_poisson256_pmc_fetch.csv
+rocprofv3 --pmc WRITE_SIZE -d $O/p_p256w -o p256 -- python3 $R/profiles/micro_poisson.py > $O/p_p256w.log 2>&1
+python3 $R/profiles/summarize_pmc.py "$(find $O/p_p256w -name '*.db' | head -1)" > $O/r02_b_poisson256_pmc_write.csv
+rocprofv3 --kernel-trace --stats -d $O/p_air -o air -- python3 $R/profiles/airfoil_bench.py 16 1 40 > $O/p_air.log 2>&1
+python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air -name '*.db' | head -1)" $O/r02_d_airfoil_kernel_stats.csv > /dev/null
+rm -rf $O/p_stats $O/p_fetch $O/p_write $O/p_p256 $O/p_cyl $O/p_p256f $O/p_p256w $O/p_air
 ls -la $O/r02_*
