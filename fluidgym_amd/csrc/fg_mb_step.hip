@@ -2520,10 +2520,25 @@ extern "C" int fg_mb_debug_cycles(fg_mb_handle s, uint64_t* out12) {
     return FG_OK;
 }
 
+// z = M r with the kernel form of the multilevel preconditioner, for every env, on the pressure matrix currently assembled
+// (fg_mb_unit_pressure_matrix or the last step): the unit test of mb_ml_apply (tests/test_gpu_mb.py), not on any step path.
+extern "C" int fg_mb_multilevel_apply(fg_mb_handle s, const float* r_BN, float* z_BN, void* stream) {
+    FG_REQUIRE(s && s->finalized && !s->host_only && r_BN && z_BN, FG_ERR_INVALID_ARG, "fg_mb_multilevel_apply: bad argument");
+    FG_REQUIRE(s->ml_a4 != nullptr && s->ml_mp != nullptr, FG_ERR_UNSUPPORTED, "fg_mb_multilevel_apply: no tables installed (fg_mb_set_multilevel)");
+    hipStream_t st = (hipStream_t)stream;
+    MbSolve q = mb_solve_ptrs(s, s->Pdiag, s->Poff, nullptr, nullptr, 1, 0.f);
+    FG_HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int32_t) * s->B, st));
+    hipLaunchKernelGGL(k_ml_scale, dim3(s->B), dim3(1024), 0, st, (const float*)s->Pdiag, s->N, s->ml_geom_diag_sum, s->ml_scale);
+    mb_ml_apply(s, q, r_BN, z_BN, st);
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    return FG_OK;
+}
+
 // Stress harness of the velocity BiCGStab (profiles/bicg_stress.py): solves the systems currently held in the assembly buffers
 // (diagonal, off-diagonals, right-hand side; FG_MB_BUF_A / _C_OFF / _RHS) `reps` times from zero, exactly as fg_mb_piso_step's first
 // attempt does, and counts the outcomes: [0] solves, [1] with a non-finite system, [2] unconverged, [3] max iterations seen.
-extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, float tol, int32_t max_iterations, int32_t reps, int64_t* out4, void* stream) {
+extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, float tol, int32_t max_iterations, int32_t reps, int64_t* out4, double* acc_out,
+                                    float* sc_out, void* stream) {
     FG_REQUIRE(s && s->finalized && !s->host_only && out4 && reps > 0, FG_ERR_INVALID_ARG, "fg_mb_debug_bicgstab: bad argument");
     hipStream_t st = (hipStream_t)stream;
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
@@ -2536,6 +2551,10 @@ extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, float tol, int32_t max_itera
         else if (rc != FG_OK) return rc;
         if (m > out4[3]) out4[3] = m;
     }
+    // the recurrence words as the last solve left them ([B d][12] accumulators, [B d][2] alpha / omega): with max_iterations = k
+    // for k = 1, 2, ... this is the history of a (deterministic) solve
+    if (acc_out) FG_HIP_CHECK(hipMemcpy(acc_out, s->acc, sizeof(double) * MB_ACC * s->B * s->d, hipMemcpyDeviceToHost));
+    if (sc_out) FG_HIP_CHECK(hipMemcpy(sc_out, s->sc, sizeof(float) * 2 * s->B * s->d, hipMemcpyDeviceToHost));
     return FG_OK;
 }
 

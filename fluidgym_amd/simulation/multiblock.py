@@ -445,7 +445,16 @@ class MultiBlockDomain:
                                               rect_32.ctypes.data_as(i32), d4_32.ctypes.data_as(f32), aci_32.ctypes.data_as(f32),
                                               float(tab["geom_diag_sum"]), 1))
         self.multilevel = {"n4": tab["n4"], "n8": tab["n8"]}
+        self._multilevel_tables = tab
         return self.multilevel
+
+    def multilevel_apply(self, r: torch.Tensor) -> torch.Tensor:
+        """``z = M r`` [B, N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled."""
+        r = r.to(self.device, torch.float32).contiguous()
+        z = torch.empty_like(r)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fg_mb_multilevel_apply(self.handle, ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(st)))
+        return z
 
     def set_pressure_deflation(self) -> float:
         """Keep the pressure-CG residuals orthogonal to the LEFT near-null vector of the pressure matrix instead of the

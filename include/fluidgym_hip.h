@@ -462,8 +462,13 @@ int fg_mb_set_multilevel(fg_mb_handle h, int32_t n4, int32_t n8, const int32_t* 
                          const float* aci8_host, float geom_diag_sum, int32_t enable);
 /* Stress harness of the multi-block velocity BiCGStab: solves the d systems per env held in the assembly buffers (FG_MB_BUF_A,
  * _C_OFF, _RHS, e.g. loaded from a dumped failing step) `reps` times from zero; out4 = solves, solves with a non-finite system,
- * unconverged solves, max iterations.  Debugging aid (profiles/bicg_stress.py), not on any step path. */
-int fg_mb_debug_bicgstab(fg_mb_handle h, float tol, int32_t max_iterations, int32_t reps, int64_t* out4, void* stream);
+ * unconverged solves, max iterations; acc_out / sc_out receive the recurrence words (accumulators, alpha / omega) as the last solve
+ * left them.  Debugging aid (profiles/bicg_stress.py), not on any step path. */
+int fg_mb_debug_bicgstab(fg_mb_handle h, float tol, int32_t max_iterations, int32_t reps, int64_t* out4,
+                         double* acc_out /* [B d][12] or NULL */, float* sc_out /* [B d][2] or NULL */, void* stream);
+/* z = M r [B,N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled (unit test of
+ * the three kernels behind the preconditioned pressure BiCGStab; synchronises). */
+int fg_mb_multilevel_apply(fg_mb_handle h, const float* r_BN, float* z_BN, void* stream);
 int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their

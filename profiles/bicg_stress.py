@@ -56,7 +56,7 @@ for path in dumps:
     t0 = time.time()
     reps = 200
     while time.time() - t0 < seconds and tot[1] <= 20:
-        L.check(lib.fg_mb_debug_bicgstab(dom.handle, 1e-6, 5000, reps, out, None))
+        L.check(lib.fg_mb_debug_bicgstab(dom.handle, 1e-6, 5000, reps, out, None, None, None))
         for k in range(3):
             tot[k] += out[k]
         tot[3] = max(tot[3], out[3])

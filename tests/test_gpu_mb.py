@@ -372,6 +372,31 @@ def test_multilevel_preconditioned_step_matches_the_oracle(spec_fn):
 
 
 @pytest.mark.parametrize("spec_fn", [H.polar_ring, H.split_rotated_channel, H.odd_channel])
+def test_multilevel_kernel_form_applies_the_tables(spec_fn):
+    """mb_ml_apply (k_ml_restrict / k_ml_coarse / k_ml_prolong) against the NumPy formula on the same tables:
+    z = r / diag + (1 / 2s) Z4 D4^-1 Z4^T r + (1 / s) Z8 A8^+ Z8^T r with s = trace(P) / trace(S)."""
+    spec = spec_fn()
+    B = 3
+    dom = spec.native(batch=B)
+    assert dom.set_pressure_multilevel() is not None
+    tab = dom._multilevel_tables
+    P = dom.unit_pressure_matrix()           # leaves the A = 1 matrix assembled on the device
+    N = dom.n_cells
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal((B, N)).astype(np.float32)
+    z = dom.multilevel_apply(torch.from_numpy(r)).cpu().numpy().astype(np.float64)
+    a4, p4 = tab["a4"], tab["parent4"]
+    scale_inv = tab["geom_diag_sum"] / P.diagonal().sum()
+    for b in range(B):
+        rb = r[b].astype(np.float64)
+        r4 = np.bincount(a4, weights=rb, minlength=tab["n4"])
+        r8 = np.bincount(p4, weights=r4, minlength=tab["n8"])
+        ref = rb / P.diagonal() + 0.5 * scale_inv * (r4 / tab["d4"])[a4] + scale_inv * (tab["aci8"] @ r8)[p4[a4]]
+        assert _rel(z[b], ref) < 2e-5, (spec_fn.__name__, b)
+    dom.close()
+
+
+@pytest.mark.parametrize("spec_fn", [H.polar_ring, H.split_rotated_channel, H.odd_channel])
 @pytest.mark.parametrize("bicg", [1, 2])
 def test_multilevel_preconditioned_bicgstab_step_matches_the_oracle(spec_fn, bicg):
     """The kernel form of the multilevel preconditioner (mb_ml_apply: restrict / coarse / prolong launches) as RIGHT preconditioner
