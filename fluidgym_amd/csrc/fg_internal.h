@@ -8,19 +8,21 @@
 
 #include "../../include/fluidgym_hip.h"
 
-// The recurrence scalars (accumulators, alpha / omega, flags) are shared by workgroups on all eight XCDs, whose L2s are not
-// coherent with each other.  Round 1 zeroed accumulator slots and read them back with PLAIN stores / loads while the sums were
-// accumulated with device-scope atomics (which bypass L2): once in ~10^4 solves a kernel read the zero its predecessor's leader had
-// stored instead of the sum the kernel in between had accumulated (rw.v == 0 exactly with v finite in every cell -> alpha = -inf;
-// profiles/r02_bicg_failure_trace.txt) -- the intermittent "non-finite BiCGStab solve".  Every access to these words now takes
-// the ONE path the atomics take: 8-byte / 4-byte agent-scope atomic loads and stores (global_load / store ... sc1).
-// FG_ACC_ACCESS / FG_FLAG_ACCESS (build switches of profiles/bicg_stress.sh): bit 0 = agent-scope atomic loads, bit 1 = agent-scope
-// atomic stores, for the accumulators and for the scalar / flag words
+// The recurrence words of the multi-kernel Krylov solvers (accumulators, alpha / omega, flags) are read and zeroed through
+// acc_ld / acc_st, sc_ld / sc_st, flag_ld / flag_st.  They are plain loads / stores: sums are accumulated with device-scope atomics
+// in one kernel and read in the next, zeroed by a leader workgroup for a later one -- kernel boundaries order all of it.  While the
+// "intermittent non-finite BiCGStab solve" of round 1 was hunted, the suspicion that plain accesses to these words are not
+// coherent across the per-XCD L2s was tested and REJECTED: fg_coherence_litmus reads back 3.2e7 sums exactly under every
+// combination of plain / agent-scope atomic loads and stores, and the captured failures reproduce identically under all of them
+// (they are exact breakdowns of the fp32 recurrence, fg_mb_step.hip MB_BETA).  Agent-scope loads by every wave
+// cost 4-45 % of env-steps/s (same-address requests serialise at the memory side), so the build switches stay at 0:
+// FG_ACC_ACCESS / FG_FLAG_ACCESS (profiles/bicg_stress.sh): bit 0 = agent-scope atomic loads, bit 1 = agent-scope atomic stores,
+// for the accumulators and for the scalar / flag words.
 #ifndef FG_ACC_ACCESS
-#define FG_ACC_ACCESS 3
+#define FG_ACC_ACCESS 0
 #endif
 #ifndef FG_FLAG_ACCESS
-#define FG_FLAG_ACCESS 3
+#define FG_FLAG_ACCESS 0
 #endif
 template <typename T> __device__ __forceinline__ T fg_word_ld(const T* p, bool atomic) {
     return atomic ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;

@@ -22,6 +22,8 @@ namespace {
 
 constexpr int MB_ACC = 12;  // doubles per system
 constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6, A_SV = 7, A_ST = 8;  // A_SV, A_ST: sum v, sum t (projection)
+// A_RHOE + (it & 1): the rho the recurrence of iteration `it` actually uses -- rw.r, or r.r after a breakdown restart (k_mbb_p)
+constexpr int A_RHOE = 10;
 
 #define MB_CELL                                         \
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x;  \
@@ -536,6 +538,18 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q)
 }
 
 // ---- BiCGStab (same five-kernel recurrence as fg_bicgstab.hip)
+// beta of iteration `it` and the breakdown guard.  In fp32 the last iterations of a solve whose tolerance sits at the rounding
+// level of its right-hand side run on sums (rw.r, rw.v) that cancel to their rounding lattice -- which contains 0: an exact
+// rho = 0 or rw.v = 0 turned alpha / beta into inf or NaN about once in 10^5-10^6 system solves (deterministic for
+// given inputs, profiles/bicg_history.py).  rw.v == 0 makes k_mbb_s take alpha = 0 (the iteration degenerates to its minimal-
+// residual half); a non-finite beta (rho of the previous iteration 0, omega 0) restarts the recurrence HERE from the current
+// residual: rw = p = r, rho = r.r.  Every workgroup of a system decides from the same words, so the decision is uniform.
+#define MB_BETA                                                                                                                   \
+    const float alpha = sc_ld(q.sc + (sys * 2)), omega = sc_ld(q.sc + (sys * 2 + 1));                                             \
+    const double rho_now = acc_ld(a + (A_RHO + (it & 1)));                                                                         \
+    const float beta = it == 0 ? 0.f : (float)(rho_now / acc_ld(a + (A_RHOE + ((it + 1) & 1)))) * (alpha / omega);                \
+    const bool restart = it > 0 && !isfinite(beta);                                                                                \
+    if (leader) acc_st(a + (A_RHOE + (it & 1)), restart ? acc_ld(a + (A_RR)) : rho_now);
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) {
     MB_SYS
@@ -549,11 +563,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) 
         q.info[sys].final_residual = crit;
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
+    MB_BETA
     if (it == 0 || !valid) return;
-    const float alpha = sc_ld(q.sc + (sys * 2)), omega = sc_ld(q.sc + (sys * 2 + 1));
-    const float beta = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RHO + ((it + 1) & 1)))) * (alpha / omega);
     const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;  // sum v of the previous iteration (slots 7 / 9 alternate)
-    q.p[vb + i] = q.r[vb + i] + beta * (q.p[vb + i] - omega * (q.v[vb + i] - mv));
+    if (restart) { const float r = q.r[vb + i]; q.rw[vb + i] = r; q.p[vb + i] = r; }
+    else q.p[vb + i] = q.r[vb + i] + beta * (q.p[vb + i] - omega * (q.v[vb + i] - mv));
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) {
@@ -577,7 +591,8 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) {
     MB_SYS
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float alpha = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
     const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
     float part = 0.f;
@@ -624,7 +639,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     const bool half = (f == 4);
     const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
     const float mt = (float)(st / (double)N);
-    const float omega = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    const float omega = isfinite(omega_raw) ? omega_raw : 0.f;
     if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
     float prr = 0.f, prho = 0.f;
     if (valid) {
@@ -702,11 +718,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p4(MbDev D, MbSolve q, int it)
         q.info[sys].final_residual = crit;
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
+    MB_BETA
     if (it == 0 || !valid) return;
-    const float alpha = sc_ld(q.sc + (sys * 2)), omega = sc_ld(q.sc + (sys * 2 + 1));
-    const float beta = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RHO + ((it + 1) & 1)))) * (alpha / omega);
     const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
-    const float4 r = ld4(q.r + vb + i), p = ld4(q.p + vb + i), v = ld4(q.v + vb + i);
+    const float4 r = ld4(q.r + vb + i);
+    if (restart) { st4(q.rw + vb + i, r.x, r.y, r.z, r.w); st4(q.p + vb + i, r.x, r.y, r.z, r.w); return; }
+    const float4 p = ld4(q.p + vb + i), v = ld4(q.v + vb + i);
     st4(q.p + vb + i, r.x + beta * (p.x - omega * (v.x - mv)), r.y + beta * (p.y - omega * (v.y - mv)),
         r.z + beta * (p.z - omega * (v.z - mv)), r.w + beta * (p.w - omega * (v.w - mv)));
 }
@@ -734,7 +751,8 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s4(MbDev D, MbSolve q, int it) {
     MB_SYS4
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float alpha = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
     const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
     float part = 0.f;
@@ -784,7 +802,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     const bool half = (f == 4);
     const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
     const float mt = (float)(st / (double)N);
-    const float omega = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    const float omega = isfinite(omega_raw) ? omega_raw : 0.f;
     if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
     float prr = 0.f, prho = 0.f;
     if (valid) {
@@ -1790,9 +1809,9 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // a refined solve that has not converged after 1500 iterations is not going to: hand over to the caller's CG fallback
     // instead of spending the reference's 5000 (one hard env would stall the whole batch)
     if (refine && max_iterations > 1500) max_iterations = 1500;
-    // Four-cells-per-thread kernels (k_mbb_*4) whenever the cell count allows; FG_MB_BICG_VEC4 (read at create) is the repro
-    // harness's per-kernel switch (profiles/bicg_vec4_repro.py), not a workaround: the defect it once bisected was the
-    // accumulator access pattern (fg_internal.h acc_ld / acc_st), in both kernel forms.
+    // Four-cells-per-thread kernels (k_mbb_*4) whenever the cell count allows; FG_MB_BICG_VEC4 (read at create) is the test /
+    // harness switch between the two kernel forms, not a workaround: the failures it once bisected were exact breakdowns of the
+    // recurrence (MB_BETA), deterministic per kernel form because the two forms sum in different orders.
     const int vec_mask = (n % 4 != 0) ? 0 : (s->dbg_vec_mask & 31);
     const dim3 grid4((n / 4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
     auto keep_best = [&](int first) {

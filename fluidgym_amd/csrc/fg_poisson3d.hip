@@ -335,6 +335,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
                 dg[e] -= face[e] + face[e + 1];
             }
         }
+        float hxa[4];  // hx a_c, shared by the y and z directions
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hxa[e] = m.hx[e] * acv[e];
         {   // y faces
             const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sc][cen - LP]);
             const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sc][cen + LP]);
@@ -344,21 +347,38 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
             const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float hhx = hh * m.hx[e], tc = hhx * acv[e];
+                const float tc = hh * hxa[e], hhx = hh * m.hx[e];
                 const float cl = s_ycl * tc + s_ynl * (hhx * am_[e]);
                 const float cr = s_ycr * tc + s_ynr * (hhx * ap_[e]);
                 y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
                 dg[e] -= cl + cr;
             }
         }
-        {   // z faces
+        if constexpr (!CARRY) {   // z faces, both evaluated from the ring (the CG kernel: no registers to spare for the carry)
+            const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sm][cen]);
+            const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sp][cen]);
+            const float4 Am = *reinterpret_cast<const float4*>(&ring_a[sm][cen]);
+            const float4 Ap = *reinterpret_cast<const float4*>(&ring_a[sp][cen]);
+            const float pm_[4] = {Pm.x, Pm.y, Pm.z, Pm.w}, pp_[4] = {Pp.x, Pp.y, Pp.z, Pp.w};
+            const float am_[4] = {Am.x, Am.y, Am.z, Am.w}, ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
+            const float zcl = fc.mzm * 0.5f * m.rhz, znl = fc.mzm * 0.5f * m.rhz_m;
+            const float zcr = fc.mzp * 0.5f * m.rhz, znr = fc.mzp * 0.5f * m.rhz_p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float uc = m.hy * hxa[e];
+                const float cl = zcl * uc + znl * (hxy[e] * am_[e]);
+                const float cr = zcr * uc + znr * (hxy[e] * ap_[e]);
+                y[e] += cl * (pm_[e] - pcv[e]) + cr * (pp_[e] - pcv[e]);
+                dg[e] -= cl + cr;
+            }
+        } else {   // z faces with the carried half coefficients
             const float4 Pm = *reinterpret_cast<const float4*>(&ring_p[sm][cen]);
             const float4 Pp = *reinterpret_cast<const float4*>(&ring_p[sp][cen]);
             const float4 Ap = *reinterpret_cast<const float4*>(&ring_a[sp][cen]);
             const float pm_[4] = {Pm.x, Pm.y, Pm.z, Pm.w}, pp_[4] = {Pp.x, Pp.y, Pp.z, Pp.w};
             const float ap_[4] = {Ap.x, Ap.y, Ap.z, Ap.w};
             const float wz_p = 0.5f * m.rhz_p;
-            if (!CARRY || !have_carry) {   // first plane of the chunk (uniform branch): the face below from plane k-1 in the ring
+            if (!have_carry) {   // first plane of the chunk (uniform branch): the face below from plane k-1 in the ring
                 const float4 Am = *reinterpret_cast<const float4*>(&ring_a[sm][cen]);
                 const float am_[4] = {Am.x, Am.y, Am.z, Am.w};
                 const float wz_c = 0.5f * m.rhz, wz_m = 0.5f * m.rhz_m;
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
                     gz_c[e] = wz_c * (hxy[e] * acv[e]);
                     face_zm[e] = fc.mzm * (wz_m * (hxy[e] * am_[e]) + gz_c[e]);
                 }
-                have_carry = CARRY;
+                have_carry = true;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

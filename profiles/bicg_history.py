@@ -1,4 +1,4 @@
-"""Scalar history of the multi-block velocity BiCGStab on a dumped failing step (profiles/data/bicg_fail_*.npz), DESIGN.md 4b.
+"""Scalar history of the multi-block velocity BiCGStab on a dumped failing step (tests/golden/bicg_breakdown_*.npz), DESIGN.md 4b.
 
     python profiles/bicg_history.py dump.npz [system] [iterations]
 

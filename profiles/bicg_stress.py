@@ -24,7 +24,7 @@ from fluidgym_amd.envs.airfoil_grid import make_airfoil_mesh  # noqa: E402
 from fluidgym_amd.envs.cylinder_grid import build_domain  # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-dumps = sys.argv[2:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "data", "bicg_fail_*.npz")))
+dumps = sys.argv[2:] or sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bicg_breakdown_*.npz")))
 B = 16
 lib = L.load()
 hip = ctypes.CDLL("libamdhip64.so")

@@ -450,14 +450,62 @@ def test_multilevel_preconditioned_bicgstab_needs_fewer_iterations_on_the_airfoi
     assert c_m["pressure0"]["mean"] > 3
 
 
-def test_recurrence_words_read_back_exactly_under_agent_scope_access():
-    """Regression for the intermittent non-finite BiCGStab solve of round 1: sums accumulated with device-scope
-    atomics, zeroed by a leader workgroup and read by every wave of the next kernel must read back exactly, launch after launch,
-    when the zeroing / reading goes through agent-scope atomic stores / loads as the solvers do (fg_internal.h acc_st / acc_ld).
-    The shape is the Airfoil2D batch the failure was captured on (16 envs x 2 components, 46664 cells)."""
+@pytest.mark.parametrize("dump,vec4", [("a", 31), ("a", 0), ("b", 0), ("b", 31), ("c", 0), ("c", 31)])
+def test_captured_bicgstab_breakdowns_now_converge(dump, vec4, monkeypatch):
+    """The "intermittent non-finite BiCGStab solve" of round 1: three velocity systems of developing Airfoil2D
+    batches on which the fp32 recurrence hit an EXACT breakdown (rho = rw.r or rw.v summing to 0.0 at the rounding level) --
+    deterministically, a with the four-cell kernels, b and c with the one-cell kernels (21 of 21 repeats each before the guard,
+    profiles/bicg_stress.py).  With the breakdown guard (k_mbb_p: restart from the current residual; k_mbb_s: alpha = 0) the
+    plain solve -- no retry ladder -- converges on all of them in both kernel forms, and the answer solves the dumped system."""
+    import ctypes
+    import os
+    from fluidgym_amd import _lib as L
+    from fluidgym_amd.envs.airfoil_grid import make_airfoil_mesh
+    from fluidgym_amd.envs.cylinder_grid import build_domain
+
+    monkeypatch.setenv("FG_MB_BICG_VEC4", str(vec4))      # read once per handle, at fg_mb_create
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"bicg_breakdown_{dump}.npz"))
+    B = 2
+    dom = build_domain(make_airfoil_mesh(attack_angle_deg=10.0), 0.001, batch=B)
+    N, d = dom.n_cells, dom.dims
+    assert z["A"].shape == (N,)
+    lib, hip = L.load(), ctypes.CDLL("libamdhip64.so")
+    for which, host in ((L.FG_MB_BUF_A, np.repeat(z["A"][None], B, 0)), (L.FG_MB_BUF_C_OFF, np.repeat(z["Coff"][None], B, 0)),
+                        (L.FG_MB_BUF_RHS, np.repeat(z["rhs"][None], B, 0))):
+        ptr, cnt = ctypes.c_void_p(), ctypes.c_int64()
+        L.check(lib.fg_mb_get_buffer(dom.handle, which, ctypes.byref(ptr), ctypes.byref(cnt)))
+        t = torch.from_numpy(np.ascontiguousarray(host, np.float32)).cuda()
+        assert t.numel() == cnt.value
+        assert hip.hipMemcpy(ptr, ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(4 * t.numel()), 3) == 0
+    torch.cuda.synchronize()
+    out = (ctypes.c_int64 * 4)()
+    L.check(lib.fg_mb_debug_bicgstab(dom.handle, 1e-6, 5000, 3, out, None, None, None))
+    assert (out[0], out[1], out[2]) == (3, 0, 0), list(out)          # three solves, none non-finite, none unconverged
+    assert out[3] < 60                                                # (18-22 iterations without the breakdown)
+    x = dom.buffer(L.FG_MB_BUF_VELOCITY_RESULT).view(B, d, N).cpu().numpy().astype(np.float64)
+    nbr = dom.neighbors()
+    A, C = z["A"].astype(np.float64), z["Coff"].astype(np.float64)
+    for b in range(B):
+        for c in range(d):
+            y = A * x[b, c]
+            for f in range(2 * d):
+                ok = nbr[f] >= 0
+                y[ok] += C[f][ok] * x[b, c][nbr[f][ok]]
+            res = z["rhs"][c].astype(np.float64) - y
+            assert np.sqrt((res ** 2).mean()) < 5e-6, (dump, vec4, b, c)   # criterion 1e-6 on the fp32 recurrence residual
+    dom.close()
+
+
+def test_recurrence_words_read_back_exactly():
+    """The access pattern of the multi-kernel Krylov recurrences in isolation (fg_coherence_litmus): sums accumulated with
+    device-scope atomics, zeroed by a leader workgroup and read by every wave of the next kernel, plus a flag word stored by the
+    leader and read by the four kernels that follow, must read back exactly, launch after launch, with the plain loads / stores
+    the solvers use (and with agent-scope atomic ones).  The shape is the Airfoil2D batch the round-1 failures were captured on
+    (16 envs x 2 components, 46664 cells); they turned out to be breakdowns of the recurrence, not lost updates."""
     import ctypes
     from fluidgym_amd import _lib as L
-    bad = (ctypes.c_int64 * 12)()
-    val = (ctypes.c_double * 12)()
-    L.check(L.load().fg_coherence_litmus(11, 32, 46664, 4000, bad, val, None))
-    assert sum(bad) == 0, (list(bad), list(val))
+    for access in (0, 11):
+        bad = (ctypes.c_int64 * 12)()
+        val = (ctypes.c_double * 12)()
+        L.check(L.load().fg_coherence_litmus(access, 32, 46664, 3000, bad, val, None))
+        assert sum(bad) == 0, (access, list(bad), list(val))
