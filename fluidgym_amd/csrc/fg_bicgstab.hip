@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6;
+// A_RHOE + (it & 1): the rho iteration `it` actually uses -- rw.r, or r.r after a breakdown restart (k_bicg_p; the guard of
+// fg_mb_step.hip MB_BETA: an exact rho = 0 or rw.v = 0 at the fp32 rounding level must not turn into inf / NaN)
+constexpr int A_RHOE = 10;
 
 template <int DIMS, int VEC>
 __device__ __forceinline__ FgVec<VEC> fg_spmv(const float* __restrict__ diag, const float* __restrict__ off,
@@ -170,11 +173,19 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int i
         q.info[s.sys].final_residual = crit;
         q.info[s.sys].used_iterations = it - 1;
     }
-    if (it == 0 || !c.valid) return;
     const float alpha = sc_ld(q.sc + (s.sys * 2 + 0)), omega = sc_ld(q.sc + (s.sys * 2 + 1));
-    const float beta = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RHO + ((it + 1) & 1)))) * (alpha / omega);
+    const double rho_now = acc_ld(a + (A_RHO + (it & 1)));
+    const float beta = it == 0 ? 0.f : (float)(rho_now / acc_ld(a + (A_RHOE + ((it + 1) & 1)))) * (alpha / omega);
+    const bool restart = it > 0 && !isfinite(beta);   // rho of the previous iteration exactly 0, or omega 0: rw = p = r, rho = r.r
+    if (s.leader) acc_st(a + (A_RHOE + (it & 1)), restart ? acc_ld(a + (A_RR)) : rho_now);
+    if (it == 0 || !c.valid) return;
     const size_t vb = (size_t)s.sys * g.n;
     const FgVec<VEC> r = fg_load<VEC>(q.r + vb + c.idx);
+    if (restart) {
+        fg_store<VEC>(q.rw + vb + c.idx, r);
+        fg_store<VEC>(q.p + vb + c.idx, r);
+        return;
+    }
     const FgVec<VEC> v = fg_load<VEC>(q.v + vb + c.idx);
     FgVec<VEC> p = fg_load<VEC>(q.p + vb + c.idx);
 #pragma unroll
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_s(FgGrid g, BicgPtrs q, int i
     const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
     if (flag_ld(q.flags + (s.sys)) != 0) return;
     double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float alpha = (float)(acc_ld(a + (A_RHO + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
     if (s.leader) {
         sc_st(q.sc + (s.sys * 2 + 0), alpha);
         acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0);  // rho slot of the next iteration
@@ -314,7 +326,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
     double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
     const float alpha = sc_ld(q.sc + (s.sys * 2 + 0));
     const bool half = (f == 4);
-    const float omega = half ? 0.f : (float)(acc_ld(a + (A_TS)) / acc_ld(a + (A_TT)));
+    const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / acc_ld(a + (A_TT)));
+    const float omega = isfinite(omega_raw) ? omega_raw : 0.f;
     if (s.leader) {
         sc_st(q.sc + (s.sys * 2 + 1), omega);
         acc_st(a + (A_RV), 0.0);

@@ -93,6 +93,7 @@ struct fg_mb_state {
     hipGraphExec_t cg_graph_exec = nullptr;   // one chunk of CG iterations + convergence check (fg_mb_step.hip::mb_cg)
     unsigned char cg_graph_key_storage[256] = {0};
     int32_t* flags_pinned = nullptr;
+    int32_t* verified = nullptr;   // [B d] BiCGStab convergence verification (mb_bicgstab): 0 open, 1 true residual checked, 2 being checked
     fg_solve_info *info_dev, *info_pinned = nullptr;
     float* yproj = nullptr;
     // on-chip CG (fg_mb_step.hip::k_mbc_onchip): neighbour table packed to 16 bits per face, (low half = even
