@@ -1766,10 +1766,12 @@ __global__ void k_mbb_verify(MbSolve q, int32_t* __restrict__ verified, int n, i
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys || verified[s] != 2) return;
     const float crit = (float)sqrt(acc_ld(q.acc + ((size_t)s * MB_ACC + A_RR)) / (double)n);   // the recomputed residual
-    if (crit < q.tol || (last_round && isfinite(crit))) {
+    if (crit < q.tol || last_round) {   // last round: ends here either way, reported as what it is
         verified[s] = 1;
         q.info[s].final_residual = crit;
-        flag_st(q.flags + s, 1);
+        q.info[s].converged = crit < q.tol ? 1 : 0;
+        q.info[s].is_finite = isfinite(crit) ? 1 : 0;
+        flag_st(q.flags + s, isfinite(crit) ? 1 : 2);
     } else {
         verified[s] = 0;          // iterates on (flag 0) from the recomputed residual; checked again when it reports convergence
         q.info[s].converged = 0;

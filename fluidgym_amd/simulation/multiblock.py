@@ -161,8 +161,12 @@ def multilevel_tables(P, blocks, max_n4: int = 2048, max_n8: int = 512):
     Z8 = sp.csr_matrix((np.ones(n4), (np.arange(n4), parent4)), shape=(n4, n8))
     A4 = (Z4.T @ S @ Z4).tocsr()
     A8 = (Z8.T @ A4 @ Z8).toarray()
-    return {"a4": a4, "parent4": parent4, "rect4": rect4, "n4": n4, "n8": n8, "d4": A4.diagonal(), "aci8": np.linalg.pinv(A8, rcond=1e-10, hermitian=True),
-            "geom_diag_sum": float(S.diagonal().sum())}
+    # The coarse operator inherits the constant null vector of the all-Neumann pressure matrix -- but only to the precision P was
+    # assembled in: the GPU's fp32 matrix leaves that eigenvalue at 1e-8..1e-7 of the largest, with either sign.  Inverted, it
+    # becomes a 1e7-fold amplification of the coarse constant (eigenvalues of P M of -2.2 .. +0.03 where 0 belongs) that wrecks the
+    # fp32 BiCGStab; 1e-6 cuts it and is three orders below the smallest genuine eigenvalue (~ 1 / n8).
+    aci8 = np.linalg.pinv(A8, rcond=1e-6, hermitian=True)
+    return {"a4": a4, "parent4": parent4, "rect4": rect4, "n4": n4, "n8": n8, "d4": A4.diagonal(), "aci8": aci8, "geom_diag_sum": float(S.diagonal().sum())}
 
 
 class MultiBlockDomain:
