@@ -161,11 +161,19 @@ def multilevel_tables(P, blocks, max_n4: int = 2048, max_n8: int = 512):
     Z8 = sp.csr_matrix((np.ones(n4), (np.arange(n4), parent4)), shape=(n4, n8))
     A4 = (Z4.T @ S @ Z4).tocsr()
     A8 = (Z8.T @ A4 @ Z8).toarray()
-    # The coarse operator inherits the constant null vector of the all-Neumann pressure matrix -- but only to the precision P was
-    # assembled in: the GPU's fp32 matrix leaves that eigenvalue at 1e-8..1e-7 of the largest, with either sign.  Inverted, it
-    # becomes a 1e7-fold amplification of the coarse constant (eigenvalues of P M of -2.2 .. +0.03 where 0 belongs) that wrecks the
-    # fp32 BiCGStab; 1e-6 cuts it and is three orders below the smallest genuine eigenvalue (~ 1 / n8).
-    aci8 = np.linalg.pinv(A8, rcond=1e-6, hermitian=True)
+    # The constant is the null vector of the all-Neumann pressure matrix (P 1 = 0), and the coarse operator inherits it only
+    # approximately: to the precision P was assembled in on orthogonal meshes (the GPU's fp32 matrix leaves that eigenvalue at
+    # 1e-8..1e-7 of the largest, with either sign), and to 1e-5..1e-6 on non-orthogonal ones, where S = sym(P) has no exact null
+    # vector at all (Airfoil2D: -2e-3 against -9e2).  Inverted, that eigenvalue becomes a 1e5..1e7-fold amplification of the coarse
+    # constant -- eigenvalues of P M of -2.2 .. +0.03 where 0 belongs -- which wrecks the fp32 BiCGStab.  The coarse problem is
+    # therefore solved on the complement of the coarse constant (Z 1_coarse = 1): Q A8^+ Q with Q = I - 1 1^T / n8, and what is
+    # left below 1e-6 of the largest eigenvalue is cut (three orders under the smallest genuine one, ~ 1 / n8).
+    singular = np.abs(P @ np.ones(N)).max() < 1e-3 * np.abs(P.diagonal()).max()
+    if singular and n8 > 1:
+        Q = np.eye(n8) - np.full((n8, n8), 1.0 / n8)
+        aci8 = Q @ np.linalg.pinv(Q @ A8 @ Q, rcond=1e-6, hermitian=True) @ Q
+    else:
+        aci8 = np.linalg.pinv(A8, rcond=1e-6, hermitian=True)
     return {"a4": a4, "parent4": parent4, "rect4": rect4, "n4": n4, "n8": n8, "d4": A4.diagonal(), "aci8": aci8, "geom_diag_sum": float(S.diagonal().sum())}
 
 

@@ -96,7 +96,9 @@ def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     states = [_state(d, 10 + b) for b in range(B)]
     _load(dom, states)
     its = dom.piso_step(dt, advection_tol=1e-7, pressure_tol=ptol, pressure_use_bicgstab=bicg, pressure_project_mean=project)
-    assert all(i > 0 for i in its)
+    # (the refined solver verifies convergence on the true fp64 residual: after such a first projection the second corrector's
+    # right-hand side can already meet the tolerance -- 0 iterations)
+    assert its[0] > 0 and its[1] > 0 and (its[2] > 0 or bicg == 2)
     u_gpu = dom.velocity.cpu().numpy()
     p_gpu = dom.pressure.cpu().numpy()
     refs = _assembly_parity(dom, d, states, dt, B, check_div=False)
