@@ -26,7 +26,6 @@ import torch
 
 from .. import spaces
 from ..simulation.multiblock import MultiBlockSimulation
-from ..simulation.policy import get_solver_policy
 from ..simulation.resample_mb import MultiBlockResampler, MultiBlockResampler3D
 from .airfoil_grid import BOTTOM, FRONT, TAIL_LOWER, TAIL_UPPER, TOP, make_airfoil_mesh, naca0012_sharp
 from .channel import jet_profile
@@ -181,8 +180,8 @@ class AirfoilEnvBase(CylinderEnvBase):
         # the pressure system of this mesh has a residual floor (2-4e-5) far above the reference's tolerance (1e-7): every
         # solve ends on its best iterate after ``stall_limit`` iterations without improvement ("Airfoil")
         dom.set_stall_limit(self._stall_limit)
-        # 2-D: multilevel right preconditioner of the pressure BiCGStab (solver policy; geometry-only tables, built once)
-        self._multilevel = dom.set_pressure_multilevel() if (self._ndims == 2 and get_solver_policy()["pressure_multilevel"]) else None
+        # (the multilevel preconditioner is NOT installed here: as right preconditioner of the pressure BiCGStab it cuts the
+        # iterations 3x on this mesh but is not robust on it -- DESIGN.md 4b, "kernel form")
         return dom
 
     def _get_simulation(self, domain, prep_fn):
