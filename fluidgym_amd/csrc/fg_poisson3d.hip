@@ -178,7 +178,7 @@ __device__ __forceinline__ double z_acc_total(const double* a, int ns) {
 }
 
 template <int MODE, int BXL, int PPB>
-__global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
+__global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 2 && PPB == 1 ? 4 : 1))) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
                                                               int ZC) {
     constexpr int TY = ZT<BXL>::TY, LP = ZT<BXL>::LP, LROWS = ZT<BXL>::LROWS;
     const ZCtx c = z_make_ctx<BXL>(g, tiles_x, tiles_y, zchunks, ZC);
@@ -422,6 +422,27 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson3_march(FgGrid g, Z3Args a,
             }
         }
     };
+    if constexpr (PPB == 1) {   // one plane per barrier pair: three rotating slot indices, one staged plane
+        int sm = 0, sc = 1, sp = 2;
+#pragma unroll 1
+        for (int k = c.k0; k < c.k1; ++k) {
+            const bool more = (k + 1 < c.k1);
+            Staged nxt;
+            FgVec<4> bnext;
+            if (more) {
+                nxt = stage(k + 2);
+                if constexpr (MODE == MODE_RELAX) bnext = z_bload4(R_x2, vo_c, (unsigned)(k + 1) * plane_b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            plane(k, sm, sc, sp, bvec[0]);
+            if (!more) break;
+            __syncthreads();            // every wave is done reading slot sm (plane k-1)
+            commit(sm, nxt);            // plane k+2 takes its place
+            __syncthreads();
+            const int t3 = sm; sm = sc; sc = sp; sp = t3;
+            if constexpr (MODE == MODE_RELAX) bvec[0] = bnext;
+        }
+    } else
 #pragma unroll 1
     for (int k = c.k0; k < c.k1; k += PPB) {
         // ---- prefetch the next PPB planes (consumed after this step's arithmetic) and their b
