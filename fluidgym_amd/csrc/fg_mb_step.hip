@@ -2426,8 +2426,10 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         for (int no = 0; no < opt->advect_non_ortho_steps; ++no) {
             hipLaunchKernelGGL(k_mb_vrhs<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->velocity, s->ures, s->bvel, s->fb, s->source, s->rhs);
             int m = 0;
+            // initial guess: the velocity result buffer, i.e. the current velocity on the first non-orthogonal pass and the previous
+            // pass's result after that (advect_use_prev_result, PISOtorch_simulation.py:1436, 1689-1697)
             int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
-                                  opt->max_iterations, no > 0, &m, st);
+                                  opt->max_iterations, 1, &m, st);
             // ---- the reference's retry ladder (_linear_solve, PISOtorch_diff.py:410-476).  The advection solve runs without
             // returnBestResult, so "not solved" = any system unconverged (or non-finite); every rung starts from zero
             // ("do not start with a possibly corrupted result tensor", :429-431)
