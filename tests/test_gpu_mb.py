@@ -298,13 +298,20 @@ def test_retry_ladder_rungs_reproduce_the_plain_solve(rungs):
     plain.close()
     dom = spec.native(batch=2)
     _load(dom, states)
-    force, opts, expect = {
-        "fp64": (1, dict(solver_double_fallback=True), ("velocity_fp64",)),
-        "preconditioned": (1, dict(bicg_precondition_fallback=True), ("velocity_preconditioned",)),
-        "fp64_then_preconditioned": (1 | 4, dict(solver_double_fallback=True, bicg_precondition_fallback=True),
-                                     ("velocity_fp64", "velocity_preconditioned")),
-        "pressure_fp64": (2, dict(solver_double_fallback=True), ("pressure_fp64",)),
+    # which rungs the REFERENCE tries for the same scripted outcomes (tests/golden/reference_control.json, produced by its own
+    # _linear_solve_wrapper): the advection solve runs without returnBestResult ("unconverged" fails it), the pressure solve
+    # with it (only a non-finite residual does)
+    from tests.test_control_golden import ladder_attempts
+    force, opts, kind, outcomes = {
+        "fp64": (1, dict(solver_double_fallback=True), "velocity", ["unconverged", "converged"]),
+        "preconditioned": (1, dict(bicg_precondition_fallback=True), "velocity", ["unconverged", "converged"]),
+        "fp64_then_preconditioned": (1 | 4, dict(solver_double_fallback=True, bicg_precondition_fallback=True), "velocity",
+                                     ["unconverged", "unconverged", "converged"]),
+        "pressure_fp64": (2, dict(solver_double_fallback=True), "pressure", ["non_finite", "converged"]),
     }[rungs]
+    ref = ladder_attempts(True, kind == "pressure", bool(opts.get("solver_double_fallback")), bool(opts.get("bicg_precondition_fallback")), outcomes)
+    expect = tuple(f"{kind}_fp64" if a["dtype"] == "float64" else f"{kind}_preconditioned" for a in ref["attempts"][1:])
+    assert expect, ref
     dom.ladder(force_mask=force)
     dom.piso_step(dt, **dict(kw, **opts))
     used = dom.ladder(force_mask=0)
