@@ -405,6 +405,33 @@ def test_multilevel_kernel_form_applies_the_tables(spec_fn):
     dom.close()
 
 
+@pytest.mark.parametrize("div", [4, 2])
+def test_multilevel_kernel_form_on_the_airfoil_mesh(div):
+    """The same check on the six-block Airfoil2D mesh (blocks of 19 x 71 ... 95 x 159 cells at full resolution; balanced tiles of
+    unequal sizes, the coarse constant deflated): kernel form against the NumPy formula on the tables."""
+    from fluidgym_amd.envs.airfoil_grid import make_airfoil_mesh
+    from fluidgym_amd.envs.cylinder_grid import build_domain
+
+    B = 2
+    dom = build_domain(make_airfoil_mesh(attack_angle_deg=10.0, resolution_div=div), 0.001, batch=B)
+    assert dom.set_pressure_multilevel() is not None
+    tab = dom._multilevel_tables
+    P = dom.unit_pressure_matrix()
+    N = dom.n_cells
+    rng = np.random.default_rng(5)
+    r = rng.standard_normal((B, N)).astype(np.float32)
+    z = dom.multilevel_apply(torch.from_numpy(r)).cpu().numpy().astype(np.float64)
+    a4, p4 = tab["a4"], tab["parent4"]
+    scale_inv = tab["geom_diag_sum"] / P.diagonal().sum()
+    for b in range(B):
+        rb = r[b].astype(np.float64)
+        r4 = np.bincount(a4, weights=rb, minlength=tab["n4"])
+        r8 = np.bincount(p4, weights=r4, minlength=tab["n8"])
+        ref = rb / P.diagonal() + 0.5 * scale_inv * (r4 / tab["d4"])[a4] + scale_inv * (tab["aci8"] @ r8)[p4[a4]]
+        assert _rel(z[b], ref) < 5e-5, (div, b)
+    dom.close()
+
+
 @pytest.mark.parametrize("spec_fn", [H.polar_ring, H.split_rotated_channel, H.odd_channel])
 @pytest.mark.parametrize("bicg", [1, 2])
 def test_multilevel_preconditioned_bicgstab_step_matches_the_oracle(spec_fn, bicg):
