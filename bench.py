@@ -540,6 +540,9 @@ def main():
         leg("cylinder_env_256", cylinder_env_leg, device, num_envs=256, steps=2, extra_modes=False)
         if not args.no_airfoil_leg:
             leg("airfoil_env", airfoil_env_leg, device)
+            # the same with four times the envs: the BiCGStab kernels of 16 x 46.7 k cells run 5-9 us each (launch-bound), the
+            # batch is what fills the GPU (one slow env still holds the batch back: iterations are per-env, launches are not)
+            leg("airfoil_env_64", airfoil_env_leg, device, num_envs=64, steps=1)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
