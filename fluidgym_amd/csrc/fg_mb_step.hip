@@ -366,6 +366,9 @@ struct MbSolve {
     // right preconditioning (multilevel, mb_ml_apply): when set, v = A mp with mp = M p, t = A ms with ms = M s, and the iterate
     // advances along mp / ms; the recurrence itself (p, s, r and all dot products) is the one of A M
     const float* mp; const float* ms;
+    // fused s / t kernel (k_mbb_st*): s lives in its own buffer (the neighbours' s is recomputed from r and v, which must still be
+    // there), k_mbb_x reads it from here and takes over the convergence-on-s decision; null = the separate s and t kernels
+    float* sbuf;
 };
 
 struct MbGraphKey { MbSolve q; int vec4, project_mean; hipStream_t stream; };
@@ -630,13 +633,33 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
         if (q.project) atomicAdd(a + A_ST, (double)pst);
     }
 }
+// "converged on s" (x += alpha p only, bicgstab_solver_kernel.cu:305-329).  With separate s and t kernels the t kernel has decided
+// (flag 4).  With the fused kernel the decision is taken HERE from the complete s.s -- every workgroup of the system computes the
+// same value; the leader publishes flag 4, which k_mbb_p of the next iteration (or k_mbs_check) turns into "converged".  A
+// workgroup that starts after the leader's store reads 4 instead of 0 and decides the same from s.s.  Non-finite s.s: flagged,
+// nothing is added to x.
+#define MB_HALF                                                                                                           \
+    bool half = (f == 4);                                                                                                 \
+    if (q.sbuf) {                                                                                                         \
+        const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);                                                               \
+        half = !(crit_s >= q.tol);                                                                                        \
+        if (half) {                                                                                                       \
+            const bool fin = isfinite(crit_s);                                                                            \
+            if (leader) {                                                                                                 \
+                q.info[sys].final_residual = crit_s; q.info[sys].used_iterations = it + q.it_base;                        \
+                q.info[sys].converged = fin ? 1 : 0; q.info[sys].is_finite = fin ? 1 : 0;                                 \
+                flag_st(q.flags + (sys), fin ? 4 : 2);                                                                    \
+            }                                                                                                             \
+            if (!fin) return;                                                                                             \
+        }                                                                                                                 \
+    }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) {
     MB_SYS
     const int f = flag_ld(q.flags + (sys));
     if (f != 0 && f != 4) return;
     const float alpha = sc_ld(q.sc + (sys * 2));
-    const bool half = (f == 4);
+    MB_HALF
     const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
     const float mt = (float)(st / (double)N);
     const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
         if (half) {
             q.x[vb + i] += alpha * pd;
         } else {
-            const float sv = q.r[vb + i];
+            const float sv = (q.sbuf ? q.sbuf : q.r)[vb + i];
             q.x[vb + i] += alpha * pd + omega * (q.ms ? q.ms[vb + i] : sv);
             const float r = sv - omega * (q.t[vb + i] - mt);
             q.r[vb + i] = r;
@@ -678,12 +701,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
-template <int DIMS>
-__device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b, const float* __restrict__ x, int i, float y[4]) {
+// y = A x for the thread's four cells: xi = the vector at the own cells, gather(n) = the vector at any other cell
+template <int DIMS, typename G>
+__device__ __forceinline__ void mb_spmv4_core(const MbDev& D, const MbSolve& q, int b, int i, const float xi[4], G gather, float y[4]) {
     constexpr int F = 2 * DIMS;
     const int N = D.N;
-    const float4 x4 = ld4(x + i), d4 = ld4(q.diag + (size_t)b * N + i);
-    const float xi[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float4 d4 = ld4(q.diag + (size_t)b * N + i);
     y[0] = d4.x * xi[0]; y[1] = d4.y * xi[1]; y[2] = d4.z * xi[2]; y[3] = d4.w * xi[3];
     const int lane = threadIdx.x & 63;
     const float from_prev = __shfl_up(xi[3], 1), from_next = __shfl_down(xi[0], 1);
@@ -700,10 +723,16 @@ __device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b
             float xn;
             if (f == 0 && n == i + e - 1 && (e > 0 || lane > 0)) xn = e > 0 ? xi[e > 0 ? e - 1 : 0] : from_prev;
             else if (f == 1 && n == i + e + 1 && (e < 3 || lane < 63)) xn = e < 3 ? xi[e < 3 ? e + 1 : 3] : from_next;
-            else xn = x[n];
+            else xn = gather(n);
             y[e] += oo[e] * xn;
         }
     }
+}
+template <int DIMS>
+__device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b, const float* __restrict__ x, int i, float y[4]) {
+    const float4 x4 = ld4(x + i);
+    const float xi[4] = {x4.x, x4.y, x4.z, x4.w};
+    mb_spmv4_core<DIMS>(D, q, b, i, xi, [x](int n) { return x[n]; }, y);
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p4(MbDev D, MbSolve q, int it) {
@@ -799,7 +828,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     const int f = flag_ld(q.flags + (sys));
     if (f != 0 && f != 4) return;
     const float alpha = sc_ld(q.sc + (sys * 2));
-    const bool half = (f == 4);
+    MB_HALF
     const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
     const float mt = (float)(st / (double)N);
     const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
@@ -811,7 +840,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
         if (half) {
             st4(q.x + vb + i, x.x + alpha * p.x, x.y + alpha * p.y, x.z + alpha * p.z, x.w + alpha * p.w);
         } else {
-            const float4 sv = ld4(q.r + vb + i), t = ld4(q.t + vb + i), w = ld4(q.rw + vb + i);
+            const float4 sv = ld4((q.sbuf ? q.sbuf : q.r) + vb + i), t = ld4(q.t + vb + i), w = ld4(q.rw + vb + i);
             const float4 sd = q.ms ? ld4(q.ms + vb + i) : sv;
             st4(q.x + vb + i, x.x + alpha * p.x + omega * sd.x, x.y + alpha * p.y + omega * sd.y, x.z + alpha * p.z + omega * sd.z,
                 x.w + alpha * p.w + omega * sd.w);
@@ -825,6 +854,80 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     prr = mb_block_sum(prr, lds);
     prho = mb_block_sum(prho, lds);
     if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
+}
+
+// ---- s and t in one launch (five kernels per iteration -> four): s = r - alpha (v - mean v) for the own cell and, recomputed
+// from r and v, for its neighbours; t = A s; s goes to its own buffer (q.sbuf) because the neighbours' r must survive the launch.
+// The convergence-on-s test (bicgstab_solver_kernel.cu:305-329) needs the complete s.s and moves into k_mbb_x.  At 16 x 46.7 k
+// cells every one of these kernels is launch-bound (5-9 us); not used with the right-preconditioned recurrence (t = A M s).
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_st(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    constexpr int F = 2 * DIMS;
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
+    if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
+    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    float pss = 0.f, pts = 0.f, ptt = 0.f, pst = 0.f;
+    if (valid) {
+        const float* __restrict__ r = q.r + vb;
+        const float* __restrict__ v = q.v + vb;
+        const float sv = r[i] - alpha * (v[i] - mv);
+        float t = q.diag[(size_t)b * N + i] * sv;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int n = D.nbr[(size_t)f * N + i];
+            if (n >= 0) t += q.off[((size_t)b * F + f) * N + i] * (r[n] - alpha * (v[n] - mv));
+        }
+        q.sbuf[vb + i] = sv;
+        q.t[vb + i] = t;
+        pss = sv * sv; pts = t * sv; ptt = t * t; pst = t;
+    }
+    pss = mb_block_sum(pss, lds);
+    pts = mb_block_sum(pts, lds);
+    ptt = mb_block_sum(ptt, lds);
+    if (q.project) pst = mb_block_sum(pst, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_SS, (double)pss);
+        atomicAdd(a + A_TS, (double)pts);
+        atomicAdd(a + A_TT, (double)ptt);
+        if (q.project) atomicAdd(a + A_ST, (double)pst);
+    }
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it) {
+    MB_SYS4
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;
+    if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
+    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    float pss = 0.f, pts = 0.f, ptt = 0.f, pst = 0.f;
+    if (valid) {
+        const float* __restrict__ r = q.r + vb;
+        const float* __restrict__ v = q.v + vb;
+        const float4 r4 = ld4(r + i), v4 = ld4(v + i);
+        const float sv[4] = {r4.x - alpha * (v4.x - mv), r4.y - alpha * (v4.y - mv), r4.z - alpha * (v4.z - mv), r4.w - alpha * (v4.w - mv)};
+        float t[4];
+        mb_spmv4_core<DIMS>(D, q, b, i, sv, [r, v, alpha, mv](int n) { return r[n] - alpha * (v[n] - mv); }, t);
+        st4(q.sbuf + vb + i, sv[0], sv[1], sv[2], sv[3]);
+        st4(q.t + vb + i, t[0], t[1], t[2], t[3]);
+        pss = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2] + sv[3] * sv[3];
+        pts = t[0] * sv[0] + t[1] * sv[1] + t[2] * sv[2] + t[3] * sv[3];
+        ptt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+        pst = t[0] + t[1] + t[2] + t[3];
+    }
+    pss = mb_block_sum(pss, lds);
+    pts = mb_block_sum(pts, lds);
+    ptt = mb_block_sum(ptt, lds);
+    if (q.project) pst = mb_block_sum(pst, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_SS, (double)pss);
+        atomicAdd(a + A_TS, (double)pts);
+        atomicAdd(a + A_TT, (double)ptt);
+        if (q.project) atomicAdd(a + A_ST, (double)pst);
+    }
 }
 
 // ---- the additive multilevel preconditioner as kernels (meshes too large for the on-chip CG; right preconditioner of the
@@ -1853,6 +1956,10 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     };
     // a preconditioned or refined solve verifies convergence on the true residual (k_mbb_reopen); the plain fp32 recurrence stays
     // the reference's (bicgstab_solver_kernel.cu declares convergence on the recurrence residual)
+    // s and t in one launch unless the recurrence is right-preconditioned (t = A M s needs all of s first); FG_MB_BICG_FUSE=0
+    // (read at create) keeps the two kernels
+    const bool fused_st = !ml && s->dbg_fuse_st;
+    if (fused_st) q.sbuf = s->w[5];
     const bool verify = ml || refine;
     int verify_rounds = 0;
     if (verify) FG_HIP_CHECK(hipMemsetAsync(s->verified, 0, sizeof(int32_t) * nsys, st));
@@ -1886,9 +1993,13 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
             if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st);
             if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st);
-            if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (fused_st) {
+                if ((vec_mask & 12) == 12) hipLaunchKernelGGL(k_mbb_st4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_st<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            } else {
+                if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st);
+                if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            }
             if (vec_mask & 16) hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
         });
         if (it + 1 >= next_poll || it + 1 == max_iterations) {
@@ -2189,6 +2300,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         const char* e = getenv("FG_MB_BICG_VEC4");
         s->dbg_vec_mask = !e ? 31 : ((e[0] == '1' && e[1] == 0) ? 31 : atoi(e));   // bit per kernel: 1 p, 2 v, 4 s, 8 t, 16 x
         e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
+        e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = (e && e[0] == '0') ? 0 : 1;
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
@@ -2314,7 +2426,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->pres, B * N)) return rc;
     if (int rc = mb_alloc(s, &s->Sdiag, B * N)) return rc;      // column-scaled matrix of the preconditioned BiCGStab rung
     if (int rc = mb_alloc(s, &s->Soff, B * F * N)) return rc;
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 6; ++k)
         if (int rc = mb_alloc(s, &s->w[k], B * d * N)) return rc;
     if (int rc = mb_alloc(s, &s->acc, B * d * MB_ACC)) return rc;
     if (int rc = mb_alloc(s, &s->sc, B * d * 2)) return rc;

@@ -320,7 +320,9 @@ def test_retry_ladder_rungs_reproduce_the_plain_solve(rungs):
     u = dom.velocity.cpu().numpy()
     assert np.isfinite(u).all()
     for b in range(2):
-        assert _rel(u[b], u_plain[b]) < 5e-5, rungs
+        # (the plain fp32 recurrence declares convergence on its recurrence residual, whose gap to the true residual depends on
+        # the trajectory -- 1e-5 .. 3e-4 against the oracle at this tolerance; the rungs are held to the oracle bound)
+        assert _rel(u[b], u_plain[b]) < 5e-4, rungs
         u_ref, _ = d.piso_step(states[b][0], states[b][1], dt[b])
         assert _rel(u[b], u_ref) < 2e-4, rungs
     dom.close()
