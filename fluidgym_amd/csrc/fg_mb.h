@@ -85,7 +85,7 @@ struct fg_mb_state {
     const float* source = nullptr;  // [B][d][N] or null
     // work buffers
     float *cc, *fb, *Cdiag, *Coff, *rA, *rhs, *ures, *hvec, *div, *Pdiag, *Poff, *pres, *Sdiag, *Soff;
-    float* w[6];
+    float* w[8];   // Krylov work vectors: r, rw, p, v, t | s of the fused BiCGStab kernels | second p and v of their ping-pong pairs
     double* acc;
     float* sc;
     int32_t *flags, *best_it, *it_ctr;

@@ -369,6 +369,9 @@ struct MbSolve {
     // fused s / t kernel (k_mbb_st*): s lives in its own buffer (the neighbours' s is recomputed from r and v, which must still be
     // there), k_mbb_x reads it from here and takes over the convergence-on-s decision; null = the separate s and t kernels
     float* sbuf;
+    // fused p / v kernel (k_mbb_pv*): p and v of the previous iteration (the neighbours' new p is recomputed from them, so the new p
+    // and v go to the other buffer of a pair); q.p / q.v are the current ones.  Null = the separate p and v kernels
+    const float* p_prev; const float* v_prev;
 };
 
 struct MbGraphKey { MbSolve q; int vec4, project_mean; hipStream_t stream; };
@@ -854,6 +857,112 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     prr = mb_block_sum(prr, lds);
     prho = mb_block_sum(prho, lds);
     if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
+}
+
+// ---- p and v in one launch: p_new = r + beta (p - omega (v - mean v)) for the own cell and, recomputed from r, p, v of the
+// previous iteration, for its neighbours; v_new = A p_new.  p and v ping-pong between two buffers each (the neighbours' old
+// values must survive the launch); the convergence test on r, the breakdown restart and the leader's bookkeeping are k_mbb_p's.
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv(MbDev D, MbSolve q, int it) {
+    MB_SYS
+    constexpr int F = 2 * DIMS;
+    const int f = flag_ld(q.flags + (sys));
+    if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
+    if (f != 0) return;
+    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
+    if (leader) {
+        acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
+        q.info[sys].final_residual = crit;
+        q.info[sys].used_iterations = it + q.it_base - 1;
+    }
+    MB_BETA
+    const float mv = (q.project && it > 0) ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
+    float part = 0.f, psum = 0.f;
+    if (valid) {
+        const float* __restrict__ r = q.r + vb;
+        const float* __restrict__ pp = q.p_prev + vb;
+        const float* __restrict__ vp = q.v_prev + vb;
+        // it == 0: p = r was laid down by the initialisation in the CURRENT p buffer
+        auto pnew = [&](int c) -> float {
+            if (it == 0) return q.p[vb + c];
+            if (restart) return r[c];
+            return r[c] + beta * (pp[c] - omega * (vp[c] - mv));
+        };
+        const float pc = pnew(i);
+        float y = q.diag[(size_t)b * N + i] * pc;
+#pragma unroll
+        for (int ff = 0; ff < F; ++ff) {
+            const int n = D.nbr[(size_t)ff * N + i];
+            if (n >= 0) y += q.off[((size_t)b * F + ff) * N + i] * pnew(n);
+        }
+        float rwv = q.rw[vb + i];
+        if (restart) { rwv = r[i]; q.rw[vb + i] = rwv; }
+        if (it > 0) q.p[vb + i] = pc;
+        q.v[vb + i] = y;
+        part = rwv * y;
+        psum = y;
+    }
+    part = mb_block_sum(part, lds);
+    if (q.project) psum = mb_block_sum(psum, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_RV, (double)part);
+        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+    }
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it) {
+    MB_SYS4
+    const int f = flag_ld(q.flags + (sys));
+    if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
+    if (f != 0) return;
+    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
+    if (leader) {
+        acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
+        q.info[sys].final_residual = crit;
+        q.info[sys].used_iterations = it + q.it_base - 1;
+    }
+    MB_BETA
+    const float mv = (q.project && it > 0) ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
+    float part = 0.f, psum = 0.f;
+    if (valid) {
+        const float* __restrict__ r = q.r + vb;
+        const float* __restrict__ pp = q.p_prev + vb;
+        const float* __restrict__ vp = q.v_prev + vb;
+        const float* __restrict__ pcur = q.p + vb;
+        float pc[4];
+        if (it == 0) {
+            const float4 p4 = ld4(pcur + i);
+            pc[0] = p4.x; pc[1] = p4.y; pc[2] = p4.z; pc[3] = p4.w;
+        } else {
+            const float4 r4 = ld4(r + i);
+            if (restart) { pc[0] = r4.x; pc[1] = r4.y; pc[2] = r4.z; pc[3] = r4.w; }
+            else {
+                const float4 p4 = ld4(pp + i), v4 = ld4(vp + i);
+                pc[0] = r4.x + beta * (p4.x - omega * (v4.x - mv)); pc[1] = r4.y + beta * (p4.y - omega * (v4.y - mv));
+                pc[2] = r4.z + beta * (p4.z - omega * (v4.z - mv)); pc[3] = r4.w + beta * (p4.w - omega * (v4.w - mv));
+            }
+        }
+        float y[4];
+        mb_spmv4_core<DIMS>(D, q, b, i, pc, [=](int n) -> float {
+            if (it == 0) return pcur[n];
+            if (restart) return r[n];
+            return r[n] + beta * (pp[n] - omega * (vp[n] - mv));
+        }, y);
+        float4 w = ld4(q.rw + vb + i);
+        if (restart) { w = make_float4(pc[0], pc[1], pc[2], pc[3]); st4(q.rw + vb + i, w.x, w.y, w.z, w.w); }
+        if (it > 0) st4(q.p + vb + i, pc[0], pc[1], pc[2], pc[3]);
+        st4(q.v + vb + i, y[0], y[1], y[2], y[3]);
+        part = w.x * y[0] + w.y * y[1] + w.z * y[2] + w.w * y[3];
+        psum = y[0] + y[1] + y[2] + y[3];
+    }
+    part = mb_block_sum(part, lds);
+    if (q.project) psum = mb_block_sum(psum, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(a + A_RV, (double)part);
+        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+    }
 }
 
 // ---- s and t in one launch (five kernels per iteration -> four): s = r - alpha (v - mean v) for the own cell and, recomputed
@@ -1978,6 +2087,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     for (int it = 0; it < max_iterations && !done; ++it) {
         if (it > 0 && it % BICG_RESTART == 0) {
             q.it_base = it;
+            q.p = s->w[2]; q.v = s->w[3];   // the re-initialisation lays p = r down in buffer 0 of the pair (iteration index 0)
             hipLaunchKernelGGL(k_mbb_restart, sg, sb, 0, st, q, nsys);
             if (refine) {
                 hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, 2);
@@ -1989,10 +2099,18 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             if (refine) keep_best(0);
         }
         const int li = it - q.it_base;
+        if (fused_st) {   // (and fused p / v): p and v of iteration li live in buffer li & 1 of their pair
+            q.p = (li & 1) ? s->w[6] : s->w[2]; q.p_prev = (li & 1) ? s->w[2] : s->w[6];
+            q.v = (li & 1) ? s->w[7] : s->w[3]; q.v_prev = (li & 1) ? s->w[3] : s->w[7];
+        }
         MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form
+            if (fused_st) {
+                if ((vec_mask & 3) == 3) hipLaunchKernelGGL(k_mbb_pv4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_pv<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            } else {
             if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
             if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st);
             if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            }
             if (fused_st) {
                 if ((vec_mask & 12) == 12) hipLaunchKernelGGL(k_mbb_st4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_st<DIMS>, grid, blk, 0, st, s->dev, q, li);
             } else {
@@ -2018,6 +2136,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
                     ++verify_rounds;
                     hipLaunchKernelGGL(k_mbb_reopen, sg, sb, 0, st, q, s->verified, nsys);
                     q.it_base = it + 1;
+                    q.p = s->w[2]; q.v = s->w[3];
                     if (refine) {
                         hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, 2);
                         MB_DISPATCH(s, hipLaunchKernelGGL(k_mbr_residual<DIMS>, grid, blk, 0, st, s->dev, q, (const double*)s->x64, project ? A_ST : -1, project ? 1 : 0););
@@ -2426,7 +2545,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->pres, B * N)) return rc;
     if (int rc = mb_alloc(s, &s->Sdiag, B * N)) return rc;      // column-scaled matrix of the preconditioned BiCGStab rung
     if (int rc = mb_alloc(s, &s->Soff, B * F * N)) return rc;
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 8; ++k)
         if (int rc = mb_alloc(s, &s->w[k], B * d * N)) return rc;
     if (int rc = mb_alloc(s, &s->acc, B * d * MB_ACC)) return rc;
     if (int rc = mb_alloc(s, &s->sc, B * d * 2)) return rc;
