@@ -25,7 +25,7 @@ from fluidgym_amd.envs.cylinder_grid import build_domain  # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 dumps = sys.argv[2:] or sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bicg_breakdown_*.npz")))
-B = 16
+B = int(os.environ.get("STRESS_ENVS", "16"))   # 16 envs x 2 components = the velocity solve of the airfoil leg; 8 envs = its pressure-solve size
 lib = L.load()
 hip = ctypes.CDLL("libamdhip64.so")
 dom = build_domain(make_airfoil_mesh(attack_angle_deg=10.0), 0.001, batch=B)
