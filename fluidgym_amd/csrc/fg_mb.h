@@ -115,6 +115,9 @@ struct fg_mb_state {
     // of the four-cell BiCGStab kernels: 1 p, 2 v, 4 s, 8 t, 16 x; default all), FG_MB_SCALAR_CG=1 (one-cell
     // CG kernels), FG_MB_GRAPH (CG chunks replayed as a hipGraph), FG_MB_TRACE (residual trace on stderr)
     int dbg_vec_mask = 0, dbg_scalar_cg = 0, dbg_graph = 0, dbg_trace = 0, dbg_fail = 0;   // dbg_fail: FG_MB_TRACE_FAIL
+    // iterations the last BiCGStab solve of the same place in the step took -- [0..3] velocity non-orthogonal pass, [4 + 8 c + ps]
+    // pressure solve ps of corrector c, [31] anything else: where the next solve of that place polls first
+    int pred_bicg[32] = {0};
     int dbg_fuse_st = 1;   // FG_MB_BICG_FUSE=0: separate s and t kernels in the BiCGStab (default: fused, k_mbb_st)
     // per-env outcome of the last fg_mb_piso_step / fg_mb_single_step: 0 ok, 1 a solve ended unconverged (best iterate used),
     // 2 a solve was non-finite: that env's step was NOT committed (state as before the step), the other envs completed

@@ -2040,7 +2040,8 @@ void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, 
 }
 
 int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, int nc,
-                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0, int multilevel = 0) {
+                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0, int multilevel = 0,
+                int pred_slot = 31) {
     const int nsys = s->B * nc, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     q.project = project ? 1 : 0;
@@ -2082,7 +2083,11 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
     if (refine) keep_best(1);
     bool done = false;
-    int next_poll = 2;
+    // first convergence poll where the previous solve of this kind finished (kernels of converged systems exit at once, so running
+    // a few launches past convergence costs ~2 us each, while every poll is a stream synchronisation: 10-20 us of idle GPU), then
+    // every 2 (every 10 beyond 20) iterations
+    int& pred = s->pred_bicg[pred_slot & 31];
+    int next_poll = pred > 2 ? pred : 2;
     const int BICG_RESTART = refine ? 100 : 200;
     for (int it = 0; it < max_iterations && !done; ++it) {
         if (it > 0 && it % BICG_RESTART == 0) {
@@ -2165,6 +2170,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
         FG_HIP_CHECK(hipStreamSynchronize(st));
     }
     const int frc = mb_finish(s, nsys, nullptr, max_it);
+    if (max_it && frc == FG_OK) pred = *max_it < 200 ? *max_it : 200;
     if (frc == FG_ERR_NOT_FINITE && s->dbg_fail) {   // rare path, FG_MB_TRACE_FAIL only: the recurrence scalars of the systems that broke down
         std::vector<double> acc((size_t)nsys * MB_ACC);
         std::vector<float> sc((size_t)nsys * 2);
@@ -2660,7 +2666,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
             // initial guess: the velocity result buffer, i.e. the current velocity on the first non-orthogonal pass and the previous
             // pass's result after that (advect_use_prev_result, PISOtorch_simulation.py:1436, 1689-1697)
             int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
-                                  opt->max_iterations, 1, &m, st);
+                                  opt->max_iterations, 1, &m, st, 0, 0, 0, no & 3);
             // ---- the reference's retry ladder (_linear_solve, PISOtorch_diff.py:410-476).  The advection solve runs without
             // returnBestResult, so "not solved" = any system unconverged (or non-finite); every rung starts from zero
             // ("do not start with a possibly corrupted result tensor", :429-431)
@@ -2702,7 +2708,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 auto solve = [&](int use_x0, int force_cg = 0) {
                     return (opt->pressure_use_bicgstab && !force_cg)
                                ? mb_bicgstab(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, 1, opt->pressure_tol, opt->max_iterations,
-                                             use_x0, &m, st, opt->pressure_project_mean, opt->pressure_use_bicgstab == 2, 1)
+                                             use_x0, &m, st, opt->pressure_project_mean, opt->pressure_use_bicgstab == 2, 1, 4 + 8 * (c & 1) + (ps & 7))
                                : mb_cg(s, dt_B, s->Pdiag, s->Poff, s->div, s->pres, opt->pressure_tol, opt->max_iterations, use_x0,
                                        opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
                 };
