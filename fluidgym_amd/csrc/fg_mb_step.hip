@@ -280,6 +280,21 @@ __device__ __forceinline__ float mb_block_sum(float v, float* lds) {
     __syncthreads();
     return r;
 }
+// NV sums with ONE barrier pair (lds: NV * 4 floats): in the launch-bound Krylov kernels the reduction tail is a visible
+// share of the run time, and four sums one after the other are eight barriers
+template <int NV>
+__device__ __forceinline__ void mb_block_sums(float (&v)[NV], float* lds) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = fg_wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds[k * 4 + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = lds[k * 4] + lds[k * 4 + 1] + lds[k * 4 + 2] + lds[k * 4 + 3];
+    __syncthreads();
+}
 
 // max |Minv u| over cells and boundary faces (Block::getMaxVelocity, domain_structs.cpp:1580-1611)
 template <int DIMS>
@@ -397,7 +412,7 @@ __device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0); \
     const size_t vb = (size_t)sys * N;                  \
     double* a = q.acc + (size_t)sys * MB_ACC;           \
-    __shared__ float lds[4];                            \
+    __shared__ float lds[16];                           \
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
 
 // accumulator / scalar / flag words: only through acc_ld / acc_st, sc_ld / sc_st, flag_ld / flag_st (fg_internal.h)
@@ -683,9 +698,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
         }
     }
     if (half) return;
-    prr = mb_block_sum(prr, lds);
-    prho = mb_block_sum(prho, lds);
-    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
+    float sums[2] = {prr, prho};
+    mb_block_sums<2>(sums, lds);
+    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)sums[0]); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
 }
 
 // ---- the same five kernels with four consecutive cells per thread (N % 4 == 0): 128-bit loads / stores of the cell's own
@@ -700,7 +715,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);    \
     const size_t vb = (size_t)sys * N;                            \
     double* a = q.acc + (size_t)sys * MB_ACC;                     \
-    __shared__ float lds[4];                                      \
+    __shared__ float lds[16];                                     \
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
@@ -854,9 +869,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
         }
     }
     if (half) return;
-    prr = mb_block_sum(prr, lds);
-    prho = mb_block_sum(prho, lds);
-    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)prr); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)prho); }
+    float sums[2] = {prr, prho};
+    mb_block_sums<2>(sums, lds);
+    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)sums[0]); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
 }
 
 // ---- p and v in one launch: p_new = r + beta (p - omega (v - mean v)) for the own cell and, recomputed from r, p, v of the
@@ -903,11 +918,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv(MbDev D, MbSolve q, int it)
         part = rwv * y;
         psum = y;
     }
-    part = mb_block_sum(part, lds);
-    if (q.project) psum = mb_block_sum(psum, lds);
+    float sums[2] = {part, psum};
+    mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RV, (double)part);
-        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+        atomicAdd(a + A_RV, (double)sums[0]);
+        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)sums[1]);
     }
 }
 template <int DIMS>
@@ -957,11 +972,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it
         part = w.x * y[0] + w.y * y[1] + w.z * y[2] + w.w * y[3];
         psum = y[0] + y[1] + y[2] + y[3];
     }
-    part = mb_block_sum(part, lds);
-    if (q.project) psum = mb_block_sum(psum, lds);
+    float sums[2] = {part, psum};
+    mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RV, (double)part);
-        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+        atomicAdd(a + A_RV, (double)sums[0]);
+        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)sums[1]);
     }
 }
 
@@ -993,15 +1008,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st(MbDev D, MbSolve q, int it)
         q.t[vb + i] = t;
         pss = sv * sv; pts = t * sv; ptt = t * t; pst = t;
     }
-    pss = mb_block_sum(pss, lds);
-    pts = mb_block_sum(pts, lds);
-    ptt = mb_block_sum(ptt, lds);
-    if (q.project) pst = mb_block_sum(pst, lds);
+    float sums[4] = {pss, pts, ptt, pst};
+    mb_block_sums<4>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_SS, (double)pss);
-        atomicAdd(a + A_TS, (double)pts);
-        atomicAdd(a + A_TT, (double)ptt);
-        if (q.project) atomicAdd(a + A_ST, (double)pst);
+        atomicAdd(a + A_SS, (double)sums[0]);
+        atomicAdd(a + A_TS, (double)sums[1]);
+        atomicAdd(a + A_TT, (double)sums[2]);
+        if (q.project) atomicAdd(a + A_ST, (double)sums[3]);
     }
 }
 template <int DIMS>
@@ -1027,15 +1040,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it
         ptt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
         pst = t[0] + t[1] + t[2] + t[3];
     }
-    pss = mb_block_sum(pss, lds);
-    pts = mb_block_sum(pts, lds);
-    ptt = mb_block_sum(ptt, lds);
-    if (q.project) pst = mb_block_sum(pst, lds);
+    float sums[4] = {pss, pts, ptt, pst};
+    mb_block_sums<4>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_SS, (double)pss);
-        atomicAdd(a + A_TS, (double)pts);
-        atomicAdd(a + A_TT, (double)ptt);
-        if (q.project) atomicAdd(a + A_ST, (double)pst);
+        atomicAdd(a + A_SS, (double)sums[0]);
+        atomicAdd(a + A_TS, (double)sums[1]);
+        atomicAdd(a + A_TT, (double)sums[2]);
+        if (q.project) atomicAdd(a + A_ST, (double)sums[3]);
     }
 }
 
