@@ -166,6 +166,7 @@ SIGNATURES = {
     "fg_sparse_apply_ell": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fg_sparse_apply_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fg_stream_triad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, POINTER(c_float), c_void_p]),
+    "fg_mb_multilevel_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "fg_mb_multilevel_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fg_mb_debug_bicgstab": (c_int, [c_void_p, c_float, c_int32, c_int32, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_float), c_void_p]),
     "fg_coherence_litmus": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_int64), POINTER(ctypes.c_double), c_void_p]),

@@ -102,6 +102,9 @@ struct fg_mb_state {
     // multilevel preconditioner of the on-chip CG (fg_mb_set_multilevel)
     uint16_t *ml_a4 = nullptr, *ml_parent4 = nullptr; float *ml_d4g = nullptr, *ml_aci8 = nullptr; uint2 *ml_rect4 = nullptr, *ml_child8 = nullptr;
     int ml_n4 = 0, ml_n8 = 0; float ml_geom_diag_sum = 0.f; bool ml_on = false;
+    // right-preconditioned pressure BiCGStab (kernel form): a trial with exponential back-off (mb_pressure_bicgstab): after a failed
+    // attempt the next ml_bicg_skip solves run plain, the back-off doubles with every failure (up to 256) and halves with every success
+    int ml_bicg_attempts = 0, ml_bicg_failures = 0, ml_bicg_skip = 0, ml_bicg_backoff = 4;
     int ml_cap4 = 0, ml_cap8 = 0;   // capacity of the tables above (the on-chip CG takes at most 2048 / 512 aggregates, the kernel form 65535 / 2048)
     // work arrays of the kernel form (mb_ml_apply): aggregate sums [B][n4], coarse solution [B][n8], 1 / scale [B], M p and M s [B][N]
     float *ml_r4 = nullptr, *ml_z8 = nullptr, *ml_scale = nullptr, *ml_mp = nullptr, *ml_ms = nullptr;

@@ -26,6 +26,7 @@ import torch
 
 from .. import spaces
 from ..simulation.multiblock import MultiBlockSimulation
+from ..simulation.policy import get_solver_policy
 from ..simulation.resample_mb import MultiBlockResampler, MultiBlockResampler3D
 from .airfoil_grid import BOTTOM, FRONT, TAIL_LOWER, TAIL_UPPER, TOP, make_airfoil_mesh, naca0012_sharp
 from .channel import jet_profile
@@ -180,8 +181,11 @@ class AirfoilEnvBase(CylinderEnvBase):
         # the pressure system of this mesh has a residual floor (2-4e-5) far above the reference's tolerance (1e-7): every
         # solve ends on its best iterate after ``stall_limit`` iterations without improvement ("Airfoil")
         dom.set_stall_limit(self._stall_limit)
-        # (the multilevel preconditioner is NOT installed here: as right preconditioner of the pressure BiCGStab it cuts the
-        # iterations 3x on this mesh but is not robust on it -- DESIGN.md 4b, "kernel form")
+        # 2-D: the multilevel preconditioner as a TRIAL of the pressure BiCGStab (solver policy; geometry-only tables, built once):
+        # attempts are capped and verified on the true residual, one that fails is repeated with the plain recurrence and makes
+        # the domain back off exponentially (developed flow at full resolution: 3x fewer iterations; half resolution: one capped
+        # attempt per 256 solves)
+        self._multilevel = dom.set_pressure_multilevel() if (self._ndims == 2 and get_solver_policy()["pressure_multilevel"]) else None
         return dom
 
     def _get_simulation(self, domain, prep_fn):

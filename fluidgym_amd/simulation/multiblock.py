@@ -460,6 +460,13 @@ class MultiBlockDomain:
         self._multilevel_tables = tab
         return self.multilevel
 
+    def multilevel_status(self) -> dict:
+        """The pressure BiCGStab's trial of the multilevel right preconditioner: current back-off (solves run plain after a failed
+        attempt; 4 = every attempt converges, 0 = no tables), attempts, failed attempts."""
+        out = (ctypes.c_int32 * 3)()
+        L.check(self.lib.fg_mb_multilevel_status(self.handle, out))
+        return {"backoff": int(out[0]), "attempts": int(out[1]), "failed_attempts": int(out[2])}
+
     def multilevel_apply(self, r: torch.Tensor) -> torch.Tensor:
         """``z = M r`` [B, N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled."""
         r = r.to(self.device, torch.float32).contiguous()

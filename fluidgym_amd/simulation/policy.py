@@ -15,10 +15,11 @@ benchmark line can say which mode it ran in:
     is off unless asked for.
 
 ``pressure_multilevel`` (default True)
-    Multi-block 2-D envs whose pressure CG runs on-chip (the cylinder family): the additive multilevel preconditioner of
-    ``MultiBlockDomain.set_pressure_multilevel``.  It changes the Krylov trajectory, not the system or its tolerance (the
-    single-block path is preconditioned in the same spirit); ``False`` gives the reference's plain CG.  (A domain with the
-    tables installed also right-preconditions its pressure BiCGStab with them, in kernel form; no registered env does that.)
+    Multi-block 2-D envs: the additive multilevel preconditioner of ``MultiBlockDomain.set_pressure_multilevel`` -- inside the
+    on-chip pressure CG (the cylinder family) and, in kernel form, as right preconditioner of the pressure BiCGStab (Airfoil2D),
+    there as a trial: every attempt is capped and verified on the true residual, a failed one is repeated with the plain
+    recurrence and makes the domain back off.  It changes the Krylov trajectory, not the system or its tolerance (the
+    single-block path is preconditioned in the same spirit); ``False`` gives the reference's plain CG / BiCGStab.
 
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` /
 ``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` (read once at import).

@@ -469,6 +469,10 @@ int fg_mb_debug_bicgstab(fg_mb_handle h, float tol, int32_t max_iterations, int3
 /* z = M r [B,N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled (unit test of
  * the three kernels behind the preconditioned pressure BiCGStab; synchronises). */
 int fg_mb_multilevel_apply(fg_mb_handle h, const float* r_BN, float* z_BN, void* stream);
+/* The multilevel right preconditioner of the pressure BiCGStab is a trial with exponential back-off per handle:
+ * out3 = current back-off in solves (0: no tables; 4: every attempt converges; up to 256), attempts, failed attempts (each repeated
+ * with the plain recurrence). */
+int fg_mb_multilevel_status(fg_mb_handle h, int32_t* out3);
 int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their

@@ -13,4 +13,4 @@ torch.cuda.synchronize(); t0 = time.time()
 for _ in range(steps):
     obs, r, _, _, info = env.step(a)
 torch.cuda.synchronize(); dt = (time.time() - t0) / steps
-print(f"B={B} ms_per_env_step={dt*1e3:.1f} env_steps_per_s={B/dt:.2f} substeps_last={env._sim.last_substeps} its={env._sim.last_iterations} cd={info['drag'][0].item():.3f} cl={info['lift'][0].item():.3f}")
+print(f"B={B} ms_per_env_step={dt*1e3:.1f} env_steps_per_s={B/dt:.2f} substeps_last={env._sim.last_substeps} its={env._sim.last_iterations} cd={info['drag'][0].item():.3f} cl={info['lift'][0].item():.3f} multilevel={env._domain.multilevel_status()} counters={ {k: v['mean'] for k, v in env._domain.solver_counters().items() if isinstance(v, dict)} }")
