@@ -2198,20 +2198,19 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     return frc;
 }
 
-// Pressure BiCGStab with the multilevel right preconditioner as a TRIAL.  Where it fits (Airfoil2D at full resolution once the
-// flow has developed: 16 iterations per solve against 55-60) the attempt converges, verified on the true residual.  Where it does
-// not (the same mesh at half resolution; the stiff solves right after an impulsive start) it does not converge -- so the attempt
-// is capped, a failed attempt is repeated with the plain recurrence (from the kept iterate; from zero after a non-finite one), and
-// the handle backs off: the next `backoff` solves run plain, the back-off doubles with every failure (4 ... 256) and halves with
-// every success.  A mesh the preconditioner never fits pays one capped attempt per 256 solves.
-constexpr int ML_TRY_CAP = 200;
+// Pressure BiCGStab with the multilevel right preconditioner as a TRIAL.  On the Airfoil2D mesh the attempt converges in a third
+// of the plain iterations (17 against 55-63), verified on the true residual -- but a geometry-only symmetric coarse operator is no
+// safe preconditioner for that non-symmetric matrix in every state (the stiff solves right after an impulsive start exceed any
+// sensible cap), so the attempt is capped (200 iterations), a failed attempt is repeated with the plain recurrence (from the kept
+// iterate; from zero after a non-finite one), and the handle backs off: the next `backoff` solves run plain, the back-off doubles
+// with every failure (4 ... 256) and halves with every success.
 int mb_pressure_bicgstab(fg_mb_state* s, const float* dt, float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project,
                          int refine, int pred_slot) {
     const bool have_ml = s->ml_on && s->ml_a4 != nullptr && s->ml_mp != nullptr && s->d == 2;
     if (have_ml && s->ml_bicg_skip > 0) --s->ml_bicg_skip;
     else if (have_ml) {
         ++s->ml_bicg_attempts;
-        const int cap = max_iterations < ML_TRY_CAP ? max_iterations : ML_TRY_CAP;
+        const int cap = max_iterations < s->dbg_ml_cap ? max_iterations : s->dbg_ml_cap;
         const int rc = mb_bicgstab(s, dt, s->Pdiag, s->Poff, s->div, s->pres, 1, tol, cap, use_x0, max_it, st, project, refine, 1, (pred_slot + 16) & 31);
         if (rc == FG_OK) { s->ml_bicg_backoff = s->ml_bicg_backoff > 4 ? s->ml_bicg_backoff / 2 : 4; return rc; }
         if (rc != FG_ERR_NOT_CONVERGED && rc != FG_ERR_NOT_FINITE) return rc;
@@ -2462,6 +2461,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         s->dbg_vec_mask = !e ? 31 : ((e[0] == '1' && e[1] == 0) ? 31 : atoi(e));   // bit per kernel: 1 p, 2 v, 4 s, 8 t, 16 x
         e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
         e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_ML_TRY_CAP"); if (e && atoi(e) > 0) s->dbg_ml_cap = atoi(e);
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;

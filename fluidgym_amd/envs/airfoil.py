@@ -183,8 +183,7 @@ class AirfoilEnvBase(CylinderEnvBase):
         dom.set_stall_limit(self._stall_limit)
         # 2-D: the multilevel preconditioner as a TRIAL of the pressure BiCGStab (solver policy; geometry-only tables, built once):
         # attempts are capped and verified on the true residual, one that fails is repeated with the plain recurrence and makes
-        # the domain back off exponentially (developed flow at full resolution: 3x fewer iterations; half resolution: one capped
-        # attempt per 256 solves)
+        # the domain back off exponentially (3x fewer pressure iterations; the stiff start-up solves are the ones that fail)
         self._multilevel = dom.set_pressure_multilevel() if (self._ndims == 2 and get_solver_policy()["pressure_multilevel"]) else None
         return dom
 

@@ -94,6 +94,36 @@ def test_pressure_solves_reach_the_reference_tolerance_and_envs_stay_identical()
     env.close()
 
 
+def test_multilevel_trial_of_the_pressure_bicgstab(monkeypatch):
+    """The multilevel right preconditioner of the pressure BiCGStab runs as a trial.  Normal run: attempts converge
+    (verified on the true residual) in a fraction of the plain iterations.  With the attempt cap forced to 2 iterations every
+    attempt fails: the solves must be repeated with the plain recurrence, the handle must back off exponentially, and the step
+    must be as good as without the tables."""
+    def run(cap=None):
+        if cap is not None:
+            monkeypatch.setenv("FG_MB_ML_TRY_CAP", str(cap))      # read once per handle, at fg_mb_create
+        else:
+            monkeypatch.delenv("FG_MB_ML_TRY_CAP", raising=False)
+        env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=2, **dict(KW, initial_domain_steps=4))
+        env.reset(seed=3)
+        env._domain.solver_counters(reset=True)
+        obs, reward, _, _, info = env.step(torch.zeros(2, 3, device="cuda"))
+        out = (env._domain.multilevel_status(), env._domain.solver_counters(), info["drag"].cpu().numpy().copy(), info["lift"].cpu().numpy().copy(),
+               env._domain.env_status().copy(), max(env._sim.last_iterations))
+        env.close()
+        return out
+
+    st, ctr, drag, lift, status, its = run()
+    assert st["attempts"] >= 10 and st["failed_attempts"] <= 2 and st["backoff"] <= 16, st
+    assert (status != 2).all() and its < 1500
+    st2, ctr2, drag2, lift2, status2, its2 = run(cap=2)
+    assert st2["failed_attempts"] == st2["attempts"] >= 3 and st2["backoff"] >= 32, st2
+    assert st2["attempts"] <= 16, st2                    # exponential back-off: a handful of attempts among the ~400 solves
+    assert (status2 != 2).all() and its2 < 1500
+    assert ctr["pressure0"]["mean"] < 0.6 * ctr2["pressure0"]["mean"], (ctr["pressure0"], ctr2["pressure0"])   # the trial pays
+    assert np.allclose(drag, drag2, rtol=1e-1) and np.allclose(lift, lift2, rtol=1e-1)
+
+
 KW3 = dict(initial_domain_steps=4, randomize_initial_state=False, episode_length=2, resolution_div=4, res_z=8, n_agents=4)
 
 
