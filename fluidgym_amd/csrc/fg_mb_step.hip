@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it
 // the per-env scale of the pressure matrix against the geometry-only one.  Three launches per application:
 //   k_ml_restrict  one thread per 4 x 4 aggregate sums its rectangle of r                                   -> r4 [sys][n4]
 //   k_ml_coarse    r8 = sums over the (at most four) children; z8 = A8^+ r8 / s, A8^+ symmetric so the matrix is read by
-//                  columns (coalesced across the threads of a row block)                                    -> z8 [sys][n8]
+//                  columns; 16 rows x 64 column groups x 4 systems per workgroup                             -> z8 [sys][n8]
 //   k_ml_prolong   z = r / diag + (1/2s) r4 / d4 + z8 at the cell's aggregates                              -> z  [sys][N]
 struct MlDev {
     const uint16_t* a4; const uint16_t* parent4; const uint2* rect4; const uint2* child8; const float* rd4; const float* aci8;
@@ -1090,14 +1090,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* 
         for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
     M.r4[(size_t)sys * M.n4 + a] = sum;
 }
-constexpr int ML_N8_MAX = 2048, ML_SB = 4, ML_CW = 16;   // coarse solve: systems per workgroup (they share every matrix element read), waves
-// One workgroup = 64 rows of A8^+ x ML_SB systems; its 16 waves split the column range (each lane streams its row's slice of the
-// symmetric matrix by columns, coalesced across the wave, 16-deep), partial sums meet in LDS.  At Airfoil2D's 771 aggregates x 16
-// envs: 13 x 4 workgroups, 2.4 MB of matrix read 4 times from L2 instead of 16.
-__global__ __launch_bounds__(64 * ML_CW) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags) {
+constexpr int ML_N8_MAX = 2048, ML_SB = 4, ML_ROWS = 16, ML_CG = 64;   // coarse solve: systems and rows per workgroup, column groups
+// One workgroup = 16 rows of A8^+ x ML_SB systems; its 1024 threads are 16 rows x 64 column groups (a thread streams 1 / 64 of its
+// row -- by columns, the matrix is symmetric --: 12 loads at Airfoil2D's 771 aggregates, all in flight at once), partial sums meet
+// in LDS.  49 x 4 workgroups at 771 aggregates x 16 envs; with 64 rows per workgroup (13 x 4 workgroups, 49 dependent-latency
+// loads per thread) the kernel took 12.3 us and was the largest single item of the preconditioned airfoil step.
+__global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags) {
     __shared__ float l_r8[ML_SB][ML_N8_MAX];
-    __shared__ float l_part[ML_CW][ML_SB][64];
-    const int sys0 = blockIdx.y * ML_SB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float l_part[ML_CG][ML_SB][ML_ROWS];
+    const int sys0 = blockIdx.y * ML_SB, r = threadIdx.x & (ML_ROWS - 1), cg = threadIdx.x / ML_ROWS;
     bool on[ML_SB], any = false;
 #pragma unroll
     for (int k = 0; k < ML_SB; ++k) { on[k] = sys0 + k < nsys && flag_ld(flags + sys0 + k) == 0; any = any || on[k]; }
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(64 * ML_CW) void k_ml_coarse(MlDev M, int nc, int n
 #pragma unroll
     for (int k = 0; k < ML_SB; ++k) {
         const float* r4 = M.r4 + (size_t)(sys0 + k) * M.n4;
-        for (int g = threadIdx.x; g < M.n8; g += 64 * ML_CW) {
+        for (int g = threadIdx.x; g < M.n8; g += ML_ROWS * ML_CG) {
             float sum = 0.f;
             if (on[k]) {
                 const uint2 ch = M.child8[g];
@@ -1117,26 +1118,36 @@ __global__ __launch_bounds__(64 * ML_CW) void k_ml_coarse(MlDev M, int nc, int n
         }
     }
     __syncthreads();
-    const int row = blockIdx.x * 64 + lane;
-    const int chunk = (M.n8 + ML_CW - 1) / ML_CW, j0 = wave * chunk, j1 = min(j0 + chunk, M.n8);
+    const int row = blockIdx.x * ML_ROWS + r;
     float acc[ML_SB] = {0.f, 0.f, 0.f, 0.f};
     if (row < M.n8) {
         const float* col = M.aci8 + row;
-#pragma unroll 16
-        for (int j = j0; j < j1; ++j) {
+#pragma unroll 4
+        for (int j = cg; j < M.n8; j += ML_CG) {      // column groups interleave: a wave's four groups read four adjacent matrix rows
             const float m = col[(size_t)j * M.ld8];
 #pragma unroll
             for (int k = 0; k < ML_SB; ++k) acc[k] += m * l_r8[k][j];
         }
     }
 #pragma unroll
-    for (int k = 0; k < ML_SB; ++k) l_part[wave][k][lane] = acc[k];
+    for (int k = 0; k < ML_SB; ++k) l_part[cg][k][r] = acc[k];
     __syncthreads();
-    if (wave < ML_SB && row < M.n8 && on[wave]) {
+    // 64 partial sums per (system, row), folded in two stages: thread t < 256 = (quarter t / 64, system t / 16 % 4, row t % 16)
+    if (threadIdx.x < ML_SB * ML_ROWS * 4) {
+        const int rr = threadIdx.x & (ML_ROWS - 1), k = (threadIdx.x / ML_ROWS) & (ML_SB - 1), quarter = threadIdx.x / (ML_SB * ML_ROWS);
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < ML_CW; ++w) t += l_part[w][wave][lane];
-        M.z8[(size_t)(sys0 + wave) * M.n8 + row] = t * M.scale_inv[(sys0 + wave) / nc];
+        for (int w = 0; w < ML_CG / 4; ++w) t += l_part[quarter * (ML_CG / 4) + w][k][rr];
+        l_r8[0][threadIdx.x] = t;     // second stage in the (now free) r8 buffer: [quarter][system][row] = thread index
+    }
+    __syncthreads();
+    if (threadIdx.x < ML_SB * ML_ROWS) {
+        const int rr = threadIdx.x & (ML_ROWS - 1), k = threadIdx.x / ML_ROWS;
+        const int orow = blockIdx.x * ML_ROWS + rr;
+        constexpr int Q = ML_SB * ML_ROWS;
+        if (orow < M.n8 && on[k])
+            M.z8[(size_t)(sys0 + k) * M.n8 + orow] =
+                (l_r8[0][threadIdx.x] + l_r8[0][Q + threadIdx.x] + l_r8[0][2 * Q + threadIdx.x] + l_r8[0][3 * Q + threadIdx.x]) * M.scale_inv[(sys0 + k) / nc];
     }
 }
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const float* __restrict__ in, const float* __restrict__ diag, int N, int nc,
@@ -2046,7 +2057,7 @@ void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, 
     M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale;
     const int nsys = s->B * q.nc, n = s->N;
     hipLaunchKernelGGL(k_ml_restrict, dim3((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
-    hipLaunchKernelGGL(k_ml_coarse, dim3((M.n8 + 63) / 64, (nsys + ML_SB - 1) / ML_SB), dim3(64 * ML_CW), 0, st, M, q.nc, nsys, (const int32_t*)q.flags);
+    hipLaunchKernelGGL(k_ml_coarse, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + ML_SB - 1) / ML_SB), dim3(ML_ROWS * ML_CG), 0, st, M, q.nc, nsys, (const int32_t*)q.flags);
     hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out);
 }
 
