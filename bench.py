@@ -251,16 +251,21 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
     return out
 
 
-def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
+def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=False):
     """The reference's Airfoil2D-easy-v0 (six-block C-mesh around a NACA 0012 at 10 degrees, 46.7 k cells, Re 1000, 5 PISO
     steps per env step) on the multi-block path, batched; the pressure systems are solved by the fp64-refined BiCGStab
-    (DESIGN.md 4b).  Reported next to the headline like the cylinder leg."""
+    (DESIGN.md 4b).  Reported next to the headline like the cylinder leg.  ``multilevel_trial``: the opt-in policy
+    ``pressure_multilevel_bicgstab`` (off by default, see fluidgym_amd/simulation/policy.py for why)."""
     import torch
 
     import fluidgym_amd
 
-    env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=num_envs, initial_domain_steps=develop,
-                            randomize_initial_state=False, cuda_device=device)
+    old_policy = fluidgym_amd.set_solver_policy(pressure_multilevel_bicgstab=bool(multilevel_trial))
+    try:
+        env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=num_envs, initial_domain_steps=develop,
+                                randomize_initial_state=False, cuda_device=device)
+    finally:
+        fluidgym_amd.set_solver_policy(**old_policy)
     try:
         env.reset(seed=0)
         gen = torch.Generator(device="cpu").manual_seed(11)
@@ -275,7 +280,9 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60):
         el = (time.perf_counter() - t0) / steps
         return {"env_id": "Airfoil2D-easy-v0", "envs": num_envs, "cells_per_env": env._domain.n_cells,
                 "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
-                "pressure_solver": "BiCGStab (fp32, mean-projected) with fp64 iterative refinement, tolerance 1e-7",
+                "pressure_solver": "BiCGStab (fp32, mean-projected) with fp64 iterative refinement, tolerance 1e-7"
+                                   + (" + multilevel right preconditioner as a capped, verified trial (opt-in policy)" if multilevel_trial else ""),
+                "multilevel_trial": env._domain.multilevel_status() if multilevel_trial else None,
                 "pressure_warm_start": bool(env._sim.pressure_warm_start), "solver_iterations": solver_iterations(env._domain),
                 "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
                 "drag_lift_env0": [float(info["drag"][0]), float(info["lift"][0])],
@@ -543,6 +550,8 @@ def main():
             # the same with four times the envs: the BiCGStab kernels of 16 x 46.7 k cells run 5-9 us each (launch-bound), the
             # batch is what fills the GPU (one slow env still holds the batch back: iterations are per-env, launches are not)
             leg("airfoil_env_64", airfoil_env_leg, device, num_envs=64, steps=1)
+            # opt-in performance mode (NOT the default: identical envs of a batch come apart in one run out of five with it)
+            leg("airfoil_env_multilevel_trial_mode", airfoil_env_leg, device, multilevel_trial=True)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

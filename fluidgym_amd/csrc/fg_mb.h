@@ -122,7 +122,8 @@ struct fg_mb_state {
     // pressure solve ps of corrector c, [31] anything else: where the next solve of that place polls first
     int pred_bicg[32] = {0};
     int dbg_ml_cap = 200;   // FG_MB_ML_TRY_CAP: iteration cap of a multilevel-preconditioned pressure BiCGStab attempt (tests: a tiny cap makes every attempt fail)
-    int dbg_fuse_st = 1;   // FG_MB_BICG_FUSE=0: separate s and t kernels in the BiCGStab (default: fused, k_mbb_st)
+    int dbg_fuse_st = 2;   // FG_MB_BICG_FUSE: 0 five BiCGStab kernels, 1 s / t fused (k_mbb_st), 2 also p / v (k_mbb_pv; default)
+    int dbg_pred = 1;      // FG_MB_PRED=0: first convergence poll after two iterations instead of where the previous solve finished
     // per-env outcome of the last fg_mb_piso_step / fg_mb_single_step: 0 ok, 1 a solve ended unconverged (best iterate used),
     // 2 a solve was non-finite: that env's step was NOT committed (state as before the step), the other envs completed
     float* dt_step = nullptr;          // [B] working copy of the caller's dt; failed envs are masked out (dt = 0) in it

@@ -2090,7 +2090,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // the reference's (bicgstab_solver_kernel.cu declares convergence on the recurrence residual)
     // s and t in one launch unless the recurrence is right-preconditioned (t = A M s needs all of s first); FG_MB_BICG_FUSE=0
     // (read at create) keeps the two kernels
-    const bool fused_st = !ml && s->dbg_fuse_st;
+    const bool fused_st = !ml && s->dbg_fuse_st >= 1, fused_pv = !ml && s->dbg_fuse_st >= 2;
     if (fused_st) q.sbuf = s->w[5];
     const bool verify = ml || refine;
     int verify_rounds = 0;
@@ -2109,7 +2109,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // a few launches past convergence costs ~2 us each, while every poll is a stream synchronisation: 10-20 us of idle GPU), then
     // every 2 (every 10 beyond 20) iterations
     int& pred = s->pred_bicg[pred_slot & 31];
-    int next_poll = pred > 2 ? pred : 2;
+    int next_poll = (pred > 2 && s->dbg_pred) ? pred : 2;
     const int BICG_RESTART = refine ? 100 : 200;
     for (int it = 0; it < max_iterations && !done; ++it) {
         if (it > 0 && it % BICG_RESTART == 0) {
@@ -2126,12 +2126,12 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             if (refine) keep_best(0);
         }
         const int li = it - q.it_base;
-        if (fused_st) {   // (and fused p / v): p and v of iteration li live in buffer li & 1 of their pair
+        if (fused_pv) {   // p and v of iteration li live in buffer li & 1 of their pair
             q.p = (li & 1) ? s->w[6] : s->w[2]; q.p_prev = (li & 1) ? s->w[2] : s->w[6];
             q.v = (li & 1) ? s->w[7] : s->w[3]; q.v_prev = (li & 1) ? s->w[3] : s->w[7];
         }
         MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form
-            if (fused_st) {
+            if (fused_pv) {
                 if ((vec_mask & 3) == 3) hipLaunchKernelGGL(k_mbb_pv4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_pv<DIMS>, grid, blk, 0, st, s->dev, q, li);
             } else {
             if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
@@ -2471,7 +2471,8 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         const char* e = getenv("FG_MB_BICG_VEC4");
         s->dbg_vec_mask = !e ? 31 : ((e[0] == '1' && e[1] == 0) ? 31 : atoi(e));   // bit per kernel: 1 p, 2 v, 4 s, 8 t, 16 x
         e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
-        e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = e ? atoi(e) : 2;   // 0 five kernels, 1 s / t fused, 2 also p / v (default)
+        e = getenv("FG_MB_PRED"); s->dbg_pred = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_ML_TRY_CAP"); if (e && atoi(e) > 0) s->dbg_ml_cap = atoi(e);
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;

@@ -15,14 +15,19 @@ benchmark line can say which mode it ran in:
     is off unless asked for.
 
 ``pressure_multilevel`` (default True)
-    Multi-block 2-D envs: the additive multilevel preconditioner of ``MultiBlockDomain.set_pressure_multilevel`` -- inside the
-    on-chip pressure CG (the cylinder family) and, in kernel form, as right preconditioner of the pressure BiCGStab (Airfoil2D),
-    there as a trial: every attempt is capped and verified on the true residual, a failed one is repeated with the plain
-    recurrence and makes the domain back off.  It changes the Krylov trajectory, not the system or its tolerance (the
-    single-block path is preconditioned in the same spirit); ``False`` gives the reference's plain CG / BiCGStab.
+    Multi-block 2-D envs whose pressure CG runs on-chip (the cylinder family): the additive multilevel preconditioner of
+    ``MultiBlockDomain.set_pressure_multilevel``.  It changes the Krylov trajectory, not the system or its tolerance (the
+    single-block path is preconditioned in the same spirit); ``False`` gives the reference's plain CG.
+``pressure_multilevel_bicgstab`` (default False)
+    The same preconditioner, in kernel form, as right preconditioner of the pressure BiCGStab of the Airfoil2D envs -- a trial
+    (capped attempts verified on the true residual, plain fallback, exponential back-off) that cuts the pressure iterations
+    3x and the env step by a third.  Off by default: with it, identical envs of a batch come apart by 1-30 % in one run out
+    of five although every solve meets its tolerance on the true residual -- an open question, so it is
+    opt-in.
 
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` /
-``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` (read once at import).
+``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
+at import).
 """
 from __future__ import annotations
 
@@ -33,6 +38,7 @@ _POLICY: Dict[str, Any] = {
     "pressure_warm_start": os.environ.get("FLUIDGYM_AMD_PRESSURE_WARM_START", "0") not in ("0", "", "false", "False"),
     "pressure_stall_accept": float(os.environ.get("FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT", "0") or 0.0),
     "pressure_multilevel": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL", "1") not in ("0", "", "false", "False"),
+    "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "0") not in ("0", "", "false", "False"),
 }
 
 
