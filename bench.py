@@ -261,13 +261,18 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=F
     import fluidgym_amd
 
     old_policy = fluidgym_amd.set_solver_policy(pressure_multilevel_bicgstab=bool(multilevel_trial))
-    try:
+    env = None
+    try:   # (the policy is read when the domain is built, which happens in reset())
         env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=num_envs, initial_domain_steps=develop,
                                 randomize_initial_state=False, cuda_device=device)
+        env.reset(seed=0)
+    except Exception:
+        if env is not None:
+            env.close()
+        raise
     finally:
         fluidgym_amd.set_solver_policy(**old_policy)
     try:
-        env.reset(seed=0)
         gen = torch.Generator(device="cpu").manual_seed(11)
         act = lambda: (torch.rand((num_envs, 3), generator=gen) * 2 - 1).to(device)
         env.step(act())
