@@ -98,3 +98,40 @@ def test_tables_and_iteration_counts_on_the_cylinder_mesh():
     assert pre * 2.5 <= plain, (plain, pre)        # measured on this mesh: 63 against 193
     assert _pcg(P, b, M, 1e-3) < 600               # and it keeps converging on the non-symmetric matrix
     t.close()
+
+
+def test_coarse_operator_never_acts_on_the_constant():
+    """The coarse constant is the (approximate) null vector of the Galerkin operator; inverted it is a huge amplification of a
+    mode the pressure matrix annihilates -- the failure of the right-preconditioned BiCGStab before this was fixed.
+    On a matrix assembled in fp32 (row sums only ~1e-7 off) the tables must deflate it: A8^+ 1 = 0, 1^T A8^+ = 0, and P M keeps
+    its spectrum on the non-negative real axis with no eigenvalue thrown far from 0 by the constant."""
+    from tests import helpers_mb as H2
+
+    for fn in (H2.split_rotated_channel, H2.polar_ring):
+        spec = fn()
+        t = HostTables(spec)
+        N = t.N
+        sizes, off = [], 0
+        for c in spec.blocks:
+            nx, ny = c.shape[-1] - 1, c.shape[-2] - 1
+            sizes.append((nx, ny, off)); off += nx * ny
+        rng = np.random.default_rng(0)
+        P1 = _pressure_matrix(t, np.ones(N)).tolil()
+        # what fp32 assembly on the GPU does to the diagonal: relative perturbations of 1e-7, either sign
+        P1.setdiag(P1.diagonal() * (1.0 + 2e-7 * rng.standard_normal(N)))
+        P1 = P1.tocsr()
+        tab = multilevel_tables(P1, sizes, max_n4=65534, max_n8=2048)
+        one = np.ones(tab["n8"])
+        assert np.abs(tab["aci8"] @ one).max() < 1e-9 * np.abs(tab["aci8"]).max()
+        assert np.abs(one @ tab["aci8"]).max() < 1e-9 * np.abs(tab["aci8"]).max()
+        a4, p4 = tab["a4"], tab["parent4"]
+        P = _pressure_matrix(t, 0.03 * np.exp(0.3 * rng.standard_normal(N))).toarray()
+        diag = P.diagonal()
+        sinv = tab["geom_diag_sum"] / diag.sum()
+
+        def M(r):
+            r4 = np.bincount(a4, weights=r, minlength=tab["n4"]); r8 = np.bincount(p4, weights=r4, minlength=tab["n8"])
+            return r / diag + 0.5 * sinv * (r4 / tab["d4"])[a4] + sinv * (tab["aci8"] @ r8)[p4[a4]]
+
+        ev = np.linalg.eigvals(P @ np.stack([M(e) for e in np.eye(N)], 1))
+        assert ev.real.min() > -1e-6 and ev.real.max() < 4.0 and np.abs(ev.imag).max() < 1e-6, (fn.__name__, ev.real.min(), ev.real.max())
