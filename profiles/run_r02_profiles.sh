@@ -22,5 +22,10 @@ rocprofv3 --pmc WRITE_SIZE -d $O/p_p256w -o p256 -- python3 $R/profiles/micro_po
 python3 $R/profiles/summarize_pmc.py "$(find $O/p_p256w -name '*.db' | head -1)" > $O/r02_b_poisson256_pmc_write.csv
 rocprofv3 --kernel-trace --stats -d $O/p_air -o air -- python3 $R/profiles/airfoil_bench.py 16 1 40 > $O/p_air.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air -name '*.db' | head -1)" $O/r02_d_airfoil_kernel_stats.csv > /dev/null
-rm -rf $O/p_stats $O/p_fetch $O/p_write $O/p_p256 $O/p_cyl $O/p_p256f $O/p_p256w $O/p_air
+# the same leg with the opt-in multilevel trial of the pressure BiCGStab (policy read from the environment by the Python side)
+export FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB=1
+rocprofv3 --kernel-trace --stats -d $O/p_air2 -o air -- python3 $R/profiles/airfoil_bench.py 16 1 40 > $O/p_air2.log 2>&1
+unset FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB
+python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air2 -name '*.db' | head -1)" $O/r02_e_airfoil_trial_kernel_stats.csv > /dev/null
+rm -rf $O/p_stats $O/p_fetch $O/p_write $O/p_p256 $O/p_cyl $O/p_p256f $O/p_p256w $O/p_air $O/p_air2
 ls -la $O/r02_*
