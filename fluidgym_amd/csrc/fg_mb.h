@@ -105,6 +105,7 @@ struct fg_mb_state {
     // right-preconditioned pressure BiCGStab (kernel form): a trial with exponential back-off (mb_pressure_bicgstab): after a failed
     // attempt the next ml_bicg_skip solves run plain, the back-off doubles with every failure (up to 256) and halves with every success
     int ml_bicg_attempts = 0, ml_bicg_failures = 0, ml_bicg_skip = 0, ml_bicg_backoff = 4;
+    int dbg_ml_warmup = 0;   // FG_MB_ML_WARMUP: pressure solves a handle runs plain before its first multilevel attempt
     int ml_cap4 = 0, ml_cap8 = 0;   // capacity of the tables above (the on-chip CG takes at most 2048 / 512 aggregates, the kernel form 65535 / 2048)
     // work arrays of the kernel form (mb_ml_apply): aggregate sums [B][n4], coarse solution [B][n8], 1 / scale [B], M p and M s [B][N]
     float *ml_r4 = nullptr, *ml_z8 = nullptr, *ml_scale = nullptr, *ml_mp = nullptr, *ml_ms = nullptr;

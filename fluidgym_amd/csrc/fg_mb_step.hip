@@ -2474,6 +2474,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = e ? atoi(e) : 2;   // 0 five kernels, 1 s / t fused, 2 also p / v (default)
         e = getenv("FG_MB_PRED"); s->dbg_pred = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_ML_TRY_CAP"); if (e && atoi(e) > 0) s->dbg_ml_cap = atoi(e);
+        e = getenv("FG_MB_ML_WARMUP"); if (e && atoi(e) > 0) { s->dbg_ml_warmup = atoi(e); s->ml_bicg_skip = s->dbg_ml_warmup; }
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
