@@ -222,7 +222,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
                                   "samples": r["samples"], "launches": r["launches"], "est_total_ms": avg * r["launches"],
                                   "GBps": r["bytes"] / r["ms"] / 1e6, "frac_of_hbm_peak": r["bytes"] / r["ms"] / 1e6 / HBM_PEAK_GBS}
             return {"ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
-                    "pressure_warm_start": bool(env._sim.pressure_warm_start), "pressure_stall_accept": env._sim.pressure_stall_accept,
+                    "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "pressure_stall_accept": env._sim.pressure_stall_accept,
                     "solver_iterations": its, "mean_substeps_per_sim_step": round(its["piso_steps"] / max(n_steps * env.n_sim_steps, 1), 2),
                     "drag_coefficient_env0": float(info["drag"][0]), "kernels": rows, "cells_per_env": dom.n_cells,
                     "piso_steps_per_env_step": env.n_sim_steps}
@@ -233,7 +233,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
            "pressure_solver": "CG, cold-started (reference policy), additive multilevel preconditioner, whole solve per env on-chip",
            "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline)"}
     out.update(run(steps))
-    keep = ("value", "ms_per_step", "pressure_warm_start", "pressure_stall_accept", "solver_iterations", "drag_coefficient_env0")
+    keep = ("value", "ms_per_step", "pressure_warm_start", "advection_warm_start", "pressure_stall_accept", "solver_iterations", "drag_coefficient_env0")
     if not extra_modes:
         return out
 
@@ -247,7 +247,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
 
     # the reference's own recurrence (plain CG, cold start) and the opt-in warm start, same env, same policy of actions
     out["plain_cg_mode"] = mode(pressure_multilevel=False)
-    out["warm_start_mode"] = mode(pressure_warm_start=True, pressure_stall_accept=1.25)
+    out["warm_start_mode"] = mode(pressure_warm_start=True, advection_warm_start=True, pressure_stall_accept=1.25)
     return out
 
 
@@ -288,7 +288,7 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=F
                 "pressure_solver": "BiCGStab (fp32, mean-projected) with fp64 iterative refinement, tolerance 1e-7"
                                    + (" + multilevel right preconditioner as a capped, verified trial (opt-in policy)" if multilevel_trial else ""),
                 "multilevel_trial": env._domain.multilevel_status() if multilevel_trial else None,
-                "pressure_warm_start": bool(env._sim.pressure_warm_start), "solver_iterations": solver_iterations(env._domain),
+                "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": solver_iterations(env._domain),
                 "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
                 "drag_lift_env0": [float(info["drag"][0]), float(info["lift"][0])],
                 "note": f"state {develop} uncontrolled sim steps after an impulsive start; uniform random jets in [-1, 1]"}
@@ -344,7 +344,7 @@ def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing
         sim_steps = env.n_sim_steps
         return {"env_id": env_id, "envs": num_envs, "grid": [solver.nx, solver.ny, solver.nz], "doc": doc,
                 "piso_steps_per_env_step": sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
-                "pressure_warm_start": bool(env._sim.pressure_warm_start), "solver_iterations": its,
+                "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": its,
                 "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
                 "policy": "uniform samples of the action space",
                 "dominant_kernel": None if roof is None else {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
@@ -515,7 +515,7 @@ def main():
                        "forcing_amplitude": args.forcing,
                        "global_batch": n_total, "grid": [solver.nx, solver.ny, solver.nz],
                        "parallelism": f"env-sharded x{world} (RCCL: one broadcast + one all_gather per step, actions/obs only)",
-                       "pressure_warm_start": bool(env._sim.pressure_warm_start),
+                       "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start),
                        "pressure_solver": "CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)",
                        "solver_iterations": its,
                        "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2)},
@@ -539,9 +539,9 @@ def main():
             doc="headline workload without the body force: the laminar channel's pressure right-hand side sits at the "
                 "reference's absolute tolerance, the projections take 0-1 iterations")
         # the same workload in the opt-in performance mode: pressure solves started from the previous pressure
-        old = fluidgym_amd.set_solver_policy(pressure_warm_start=True)
+        old = fluidgym_amd.set_solver_policy(pressure_warm_start=True, advection_warm_start=True)
         leg("warm_start_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=max(2, args.steps // 2), warmup=2, seed=1234,
-            forcing=args.forcing, doc="headline workload with pressure_warm_start=True (not the reference's policy; reported separately)")
+            forcing=args.forcing, doc="headline workload with pressure_warm_start=True and advection_warm_start=True (not the reference's policy; reported separately)")
         fluidgym_amd.set_solver_policy(**old)
         leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=2, warmup=1,
             doc="BASELINE config 2 on one GPU: Rayleigh-Benard 512x128, 32 envs (256 across 8 GPUs)")

@@ -137,6 +137,7 @@ SIGNATURES = {
     "fg_max_velocity": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fg_set_fd_fast_transform": (c_int, [c_void_p, c_int, c_float]),
     "fg_set_return_best": (c_int, [c_void_p, c_int]),
+    "fg_set_advection_start": (c_int, [c_void_p, c_int]),
     "fg_boundary_flux_balance": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fg_step_diagnostics": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
     "fg_update_advective_boundary": (c_int, [c_void_p, c_int, POINTER(c_float), c_void_p, c_void_p]),
@@ -199,6 +200,7 @@ SIGNATURES = {
     "fg_mb_max_velocity": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
     "fg_mb_set_residual_projection": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_mb_set_stall_limit": (c_int, [c_void_p, c_int32]),
+    "fg_mb_set_advection_start": (c_int, [c_void_p, c_int]),
     "fg_mb_set_multilevel": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_float),
                                      POINTER(c_float), c_float, c_int32]),
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),

@@ -108,6 +108,7 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
     s->cg_return_best = 1;
+    s->adv_from_result = 1;
     FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMalloc(&s->cg_best.best_crit, sizeof(float) * g.B));
@@ -197,6 +198,12 @@ extern "C" int fg_set_return_best(fg_handle s, int on) {
     return FG_OK;
 }
 
+extern "C" int fg_set_advection_start(fg_handle s, int from_result) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    s->adv_from_result = from_result ? 1 : 0;
+    return FG_OK;
+}
+
 extern "C" int fg_max_velocity(fg_handle s, float* out_B, void* stream) {
     FG_REQUIRE(s && out_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, false)) return rc;
@@ -275,7 +282,7 @@ extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, floa
     a.dt = s->cur_dt;
     a.tol = tol; a.max_iterations = max_iterations;
     if (for_scalar) { a.x = s->scal_result; a.nc = 1; a.use_x0 = 0; }
-    else { a.x = s->vel_result; a.nc = s->grid.dims; a.use_x0 = 1; }
+    else { a.x = s->vel_result; a.nc = s->grid.dims; a.use_x0 = s->adv_from_result; }
     (void)channel;
     return fg_bicgstab_solve(s, a, info_host, (hipStream_t)stream);
 }
@@ -410,7 +417,7 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
     {
         FgBicgArgs a;
         a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->vel_result; a.nc = d;
-        a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 1;
+        a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = s->adv_from_result;
         if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
         stats[1] = max_iters(info.data(), B * d);
         s->ctr.add(1, info.data(), B * d);

@@ -423,6 +423,7 @@ struct fg_state {
     double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
     FgBest cg_best;               // best-iterate tracking of the CG (returnBestResult, cg_solver_kernel.cu:345-361)
     int cg_return_best;           // 1 (default): track; 0: never keep an iterate (fg_set_return_best)
+    int adv_from_result;          // 1 (default): velocity solve starts from velocityResult; 0: from zero (fg_set_advection_start)
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs

@@ -132,6 +132,7 @@ struct fg_mb_state {
     int32_t* env_fail_pinned = nullptr;
     std::vector<int32_t> env_status;   // [B] host, what fg_mb_env_status reports
     int cg_stall_limit = 400;  // fg_mb_set_stall_limit
+    int adv_from_result = 0;   // fg_mb_set_advection_start
     bool yproj_const = true;   // yproj is the constant 1/sqrt(N): kernels use the scalar instead of loading it
     float* red;        // [B] reductions (mean, max)
     float* red_pinned = nullptr;

@@ -2712,10 +2712,11 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         for (int no = 0; no < opt->advect_non_ortho_steps; ++no) {
             hipLaunchKernelGGL(k_mb_vrhs<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->velocity, s->ures, s->bvel, s->fb, s->source, s->rhs);
             int m = 0;
-            // initial guess: the velocity result buffer, i.e. the current velocity on the first non-orthogonal pass and the previous
-            // pass's result after that (advect_use_prev_result, PISOtorch_simulation.py:1436, 1689-1697)
+            // initial guess: zero on the first non-orthogonal pass, the previous pass's result after that (x = None if no_step == 0
+            // or not advect_non_ortho_reuse_result, PISOtorch_simulation.py:1735-1742; tests/golden/reference_split_step.json);
+            // fg_mb_set_advection_start(1): the current velocity on the first pass (opt-in)
             int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
-                                  opt->max_iterations, 1, &m, st, 0, 0, 0, no & 3);
+                                  opt->max_iterations, (no > 0 || s->adv_from_result) ? 1 : 0, &m, st, 0, 0, 0, no & 3);
             // ---- the reference's retry ladder (_linear_solve, PISOtorch_diff.py:410-476).  The advection solve runs without
             // returnBestResult, so "not solved" = any system unconverged (or non-finite); every rung starts from zero
             // ("do not start with a possibly corrupted result tensor", :429-431)
@@ -3169,6 +3170,11 @@ extern "C" int fg_mb_set_stall_limit(fg_mb_handle s, int32_t iterations) {
     FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_set_stall_limit: null handle");
     FG_REQUIRE(iterations >= 20, FG_ERR_INVALID_ARG, "fg_mb_set_stall_limit: at least one chunk of 20 iterations");
     s->cg_stall_limit = iterations;
+    return FG_OK;
+}
+extern "C" int fg_mb_set_advection_start(fg_mb_handle s, int from_result) {
+    FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_set_advection_start: null handle");
+    s->adv_from_result = from_result ? 1 : 0;
     return FG_OK;
 }
 // builds the pressure matrix for A = 1 into the P buffers (FG_MB_BUF_P_DIAG / P_OFF): the geometry-only matrix whose left

@@ -336,6 +336,11 @@ class NativeSolver:
         """``pressure_return_best_result`` of the reference's Simulation: keep / hand back the best CG iterate."""
         L.check(self.lib.fg_set_return_best(self.handle, int(on)))
 
+    def set_advection_start(self, from_result: bool = True):
+        """Start vector of the velocity solve: ``velocityResult`` (the reference's orthogonal branch) or zero (its non-orthogonal
+        branch, first pass) -- ``fg_set_advection_start``."""
+        L.check(self.lib.fg_set_advection_start(self.handle, int(from_result)))
+
     def profile_enable(self, on: bool = True):
         L.check(self.lib.fg_profile_enable(self.handle, int(on)))
 

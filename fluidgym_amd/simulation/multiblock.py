@@ -309,6 +309,10 @@ class MultiBlockDomain:
         """Iterations a CG solve may go without improving its kept iterate before it ends with it (default 400)."""
         L.check(self.lib.fg_mb_set_stall_limit(self.handle, int(iterations)))
 
+    def set_advection_start(self, from_result: bool = False) -> None:
+        """Start vector of the first velocity solve of a step: zero (the reference) or the current velocity (opt-in)."""
+        L.check(self.lib.fg_mb_set_advection_start(self.handle, int(from_result)))
+
     def boundary_tables(self):
         """(owner cell [NB], face [NB], Minv|det [NB, d*d+1]) of the boundary slots (host arrays)."""
         nb, tw = self.n_boundary_faces, self.dims * self.dims + 1
@@ -573,7 +577,8 @@ class MultiBlockSimulation:
                  pressure_use_BiCG: bool = False, outflow=None, outflow_velocity: Sequence[float] = (1.0, 0.0, 0.0),
                  outflow_tol: float = 5e-6, flux_balance_tol: float = 1e-5, pressure_warm_start: Optional[bool] = None,
                  pressure_project_mean: bool = True, pressure_stall_accept: Optional[float] = None,
-                 solver_double_fallback: bool = False, BiCG_precondition_fallback: bool = True):
+                 solver_double_fallback: bool = False, BiCG_precondition_fallback: bool = True,
+                 advection_warm_start: Optional[bool] = None):
         # the reference's retry ladder (Simulation attributes set by the envs, e.g. cylinder_env_base.py:326-328)
         self.solver_double_fallback, self.BiCG_precondition_fallback = bool(solver_double_fallback), bool(BiCG_precondition_fallback)
         from .policy import get_solver_policy
@@ -581,6 +586,9 @@ class MultiBlockSimulation:
         pol = get_solver_policy()   # reference behaviour unless asked otherwise: cold start, no stall acceptance
         self.pressure_warm_start = bool(pol["pressure_warm_start"] if pressure_warm_start is None else pressure_warm_start)
         self.pressure_stall_accept = float(pol["pressure_stall_accept"] if pressure_stall_accept is None else pressure_stall_accept)
+        # first velocity solve of a step from zero as the reference's non-orthogonal branch (policy.py), or from the current velocity
+        self.advection_warm_start = bool(pol["advection_warm_start"] if advection_warm_start is None else advection_warm_start)
+        domain.set_advection_start(self.advection_warm_start)
         self.pressure_project_mean = pressure_project_mean
         self.domain, self.time_step, self.adaptive_CFL, self.substeps = domain, float(dt), float(adaptive_CFL), substeps
         self.corrector_steps = corrector_steps

@@ -9,6 +9,12 @@ benchmark line can say which mode it ran in:
     ``:1877-1881``) and re-uses the previous result only for the later non-orthogonal pressure iterations of the same
     corrector.  ``True`` starts from the pressure field of the previous solve instead: same tolerance, same criterion,
     fewer iterations -- a performance mode, reported separately by ``bench.py``.
+``advection_warm_start`` (default False)
+    The reference's non-orthogonal branch -- cylinder and airfoil envs, and TCF / channel on their rectilinear grids -- starts the
+    velocity solve of the first non-orthogonal pass from zero (``x = None if (no_step == 0 or not advect_non_ortho_reuse_result)``,
+    ``PISOtorch_simulation.py:1735-1742``); its orthogonal branch (RBC) starts from ``velocityResult`` (``:1689-1693``).  Both
+    rules are recorded from the reference's own Python in ``tests/golden/reference_split_step.json``.  ``True`` starts every
+    velocity solve from the current velocity: same tolerance, fewer iterations -- a performance mode like ``pressure_warm_start``.
 ``pressure_stall_accept`` (default 0 = off)
     Multi-block CG only: a solve whose kept iterate is within this factor of the tolerance and has not improved for 20
     iterations ends with that iterate.  This loosens the effective tolerance by the factor, so it
@@ -25,7 +31,7 @@ benchmark line can say which mode it ran in:
     of five although every solve meets its tolerance on the true residual -- an open question, so it is
     opt-in.
 
-Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` /
+Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` / ``FLUIDGYM_AMD_ADVECTION_WARM_START`` /
 ``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
 at import).
 """
@@ -36,6 +42,7 @@ from typing import Any, Dict
 
 _POLICY: Dict[str, Any] = {
     "pressure_warm_start": os.environ.get("FLUIDGYM_AMD_PRESSURE_WARM_START", "0") not in ("0", "", "false", "False"),
+    "advection_warm_start": os.environ.get("FLUIDGYM_AMD_ADVECTION_WARM_START", "0") not in ("0", "", "false", "False"),
     "pressure_stall_accept": float(os.environ.get("FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT", "0") or 0.0),
     "pressure_multilevel": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL", "1") not in ("0", "", "false", "False"),
     "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "0") not in ("0", "", "false", "False"),

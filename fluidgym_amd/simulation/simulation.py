@@ -81,6 +81,7 @@ class Simulation:
         output_resampling_fill_max_steps: int = 0,
         buoyancy: Optional[tuple] = None,
         pressure_warm_start: Optional[bool] = None,
+        advection_warm_start: Optional[bool] = None,
         outflow: Optional[tuple] = None,
         **_ignored: Any,
     ):
@@ -123,6 +124,13 @@ class Simulation:
         # performance mode of simulation/policy.py
         self.pressure_warm_start = bool(get_solver_policy()["pressure_warm_start"] if pressure_warm_start is None
                                         else pressure_warm_start)
+        # start vector of the velocity solve: the reference's orthogonal branch starts from velocityResult
+        # (PISOtorch_simulation.py:1689-1693), its non-orthogonal branch -- which the TCF env runs on this kind of grid
+        # (tcf_env.py:497) -- from zero on its first (here only) non-orthogonal pass (:1735-1742).  The policy switch
+        # advection_warm_start (policy.py) starts from velocityResult in both
+        self.advection_warm_start = bool(get_solver_policy()["advection_warm_start"] if advection_warm_start is None
+                                         else advection_warm_start)
+        domain.solver.set_advection_start((not non_orthogonal) or self.advection_warm_start)
         if solver_double_fallback or not BiCG_precondition_fallback or preconditionBiCG:
             # accepted for signature compatibility; the orthogonal single-block systems of this path are solved by a
             # preconditioned CG / BiCGStab whose failure handling is native (returnBestResult), see DESIGN.md a19

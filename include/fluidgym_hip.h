@@ -128,6 +128,12 @@ int fg_set_fd_fast_transform(fg_handle h, int axis, float cell_width);
  * solve that ends unconverged hands back the best iterate it kept (within 2x of the lowest residual reached) instead
  * of the last one; off saves the occasional extra store pass over x. */
 int fg_set_return_best(fg_handle h, int on);
+/* Start vector of the velocity (advection) solve.  The reference's split step has two rules (recorded from its own Python in
+ * tests/golden/reference_split_step.json): its orthogonal branch starts from velocityResult (advect_use_prev_result,
+ * PISOtorch_simulation.py:1689-1693), its non-orthogonal branch -- which its TCF env also runs on a rectilinear grid
+ * (tcf_env.py:497) -- from zero on the first non-orthogonal pass (x=None, :1735-1742).  from_result 1 (default of a new handle): the
+ * orthogonal-branch rule; 0: zero.  Same converged answer within the tolerance, different iteration counts. */
+int fg_set_advection_start(fg_handle h, int from_result);
 
 /* ---- reductions used by the drivers --------------------------------------------------------- */
 /* Domain.getMaxVelocity(withBounds=True, computational=True) (domain_structs.cpp:1580-1611) */
@@ -449,6 +455,10 @@ int fg_mb_set_residual_projection(fg_mb_handle h, const float* y_host);
  * the reference has no such limit: its solves run to maxIterations and return the best result,
  * cg_solver_kernel.cu:345-361, PISOtorch_diff.py:266-371). */
 int fg_mb_set_stall_limit(fg_mb_handle h, int32_t iterations);
+/* Start vector of the first velocity solve of a step: 0 (default of a new handle) zero, the reference's non-orthogonal branch
+ * (x=None at no_step 0, PISOtorch_simulation.py:1735-1742); 1 the current velocity (opt-in: fewer iterations, same answer within
+ * the tolerance).  Later non-orthogonal passes always start from the previous pass's result as there. */
+int fg_mb_set_advection_start(fg_mb_handle h, int from_result);
 /* Additive multilevel preconditioner of the pressure solves on 2-D meshes: Jacobi + 1/2 x Jacobi on 4 x 4 aggregates + the
  * dense pseudo-inverse on 8 x 8 aggregates, all from the geometry-only (A = 1) matrix and scaled per env.  Host arrays: a4 [N]
  * (aggregate of every cell), parent4 [n4] (8 x 8 aggregate of every 4 x 4 one), rect4 (every 4 x 4 aggregate as a rectangle of

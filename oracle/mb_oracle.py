@@ -675,29 +675,52 @@ class Domain:
 
     # ------------------------------------------------------------------ one PISO step (SIM.py:1431-2002, non-orthogonal branch)
     def piso_step(self, u, p_result, dt, source=None, corrector_steps=2, advect_non_ortho_steps=1,
-                  pressure_non_ortho_steps=1, flags=NON_ORTHO_MODE, trace: Optional[dict] = None):
+                  pressure_non_ortho_steps=1, flags=NON_ORTHO_MODE, trace: Optional[dict] = None, calls: Optional[list] = None):
         """u [d, N], p_result [N] (pressure of the previous solve: the lagged corner terms of the first pressure
-        right-hand side read it, SIM.py:1841-1858).  Returns u_new, p_new."""
+        right-hand side read it, SIM.py:1841-1858).  Returns u_new, p_new.  ``calls`` (a list) receives the step's sequence of
+        operators and solves in the vocabulary of the reference's backend (the solves here are direct, so the start vector the
+        reference would pass is recorded, not used); ``tests/test_split_step_golden.py`` holds it against the sequence recorded
+        from the reference's own ``_PISO_split_step``."""
+        def log(op, **kw):
+            if calls is not None:
+                calls.append(dict(op=op, **kw))
+
+        log("SetupAdvectionMatrix", non_ortho_flags=flags, for_scalar=False)
         C = self.build_matrix(u, dt, flags)
         A = C[0]
+        log("CopyVelocityResultFromBlocks")
         u_res = u.copy()  # CopyVelocityResultFromBlocks (SIM.py:1707)
-        for _ in range(advect_non_ortho_steps):
+        for no in range(advect_non_ortho_steps):
+            log("SetupAdvectionVelocity", non_ortho_flags=flags, apply_pressure_gradient=False)
             rhs = self.velocity_rhs(u, u_res, dt, source, flags)
+            # x = None if no_step == 0 or not advect_non_ortho_reuse_result else velocityResult (SIM.py:1735-1742)
+            log("linear_solve", matrix="C", rhs="velocityRHS", x0=None if no == 0 else "velocityResult")
             u_res = self.solve(C, rhs)
+            log("setVelocityResult")
         if trace is not None:
             trace.update(C=C, rhs=rhs, u_star=u_res.copy())
         p = p_result.copy()
         for c in range(corrector_steps):
+            log("SetupPressureMatrix", non_ortho_flags=flags)
             P = self.build_pressure_matrix(A, flags)
             for ps in range(pressure_non_ortho_steps):
                 if ps == 0:
+                    log("SetupPressureRHS", non_ortho_flags=flags)
                     h = self.pressure_rhs_h(C, u, u_res, dt, source)
                     div = self.divergence(h)
+                else:
+                    log("SetupPressureRHSdiv", non_ortho_flags=flags)
                 b_rhs = div + self.pressure_nonortho(p, A, flags)
+                # x = None if pstep == 0 or not pressure_reuse_result else pressureResult (SIM.py:1877-1881)
+                log("linear_solve", matrix="P", rhs="pressureRHSdiv", x0=None if ps == 0 else "pressureResult")
                 p = self.solve(P, b_rhs, singular=True)
+                log("setPressureResult", mean_removed=True)   # solve(singular=True) returns the mean-free solution (SIM.py:1929-1932)
             if trace is not None and c == 0:
                 trace.update(P=P, h=h.copy(), div=div.copy(), prhs=b_rhs.copy(), p0=p.copy())
+            log("CopyPressureResultToBlocks")
+            log("CorrectVelocity")
             u_res = self.correct_velocity(h, p, A)
+        log("CopyVelocityResultToBlocks")
         return u_res, p
 
     def max_cfl_velocity(self, u):

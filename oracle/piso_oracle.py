@@ -726,6 +726,9 @@ class SolverOptions:
     normalize_pressure_result: bool = True
     advect_passive_scalar: bool = True
     direct: bool = True  # spsolve ground truth instead of Krylov iterations
+    # the reference's non-orthogonal branch run on this (rectilinear) grid, as its TCF env does (tcf_env.py:497): same
+    # discretisation here, but the velocity solve starts from zero instead of velocityResult (SIM.py:1735-1742 vs 1689-1693)
+    non_orthogonal: bool = False
     stats: Optional[dict] = None  # filled with iteration counts when not None
 
 
@@ -749,59 +752,96 @@ def _lin_solve(A, rhs, x0, tol, opts: SolverOptions, kind: str, singular=False, 
 
 
 def piso_split_step(dom: Domain, dt: float, opts: SolverOptions = SolverOptions(),
-                    prep_fn: Optional[Dict[str, List[Callable]]] = None) -> dict:
+                    prep_fn: Optional[Dict[str, List[Callable]]] = None, calls: Optional[list] = None) -> dict:
     """One ``_PISO_split_step(iterations=1, time_step=dt)`` in its orthogonal branch
     (SIM.py:1431-2002; ``non_orthogonal=False`` blocks :1515-1563, 1667-1705, 1779-1831).
     Hooks are called as ``fn(dom, dt)`` at PRE / PRE_VELOCITY_SETUP / POST.
 
-    Returns a dict of intermediates (A, rhs, h, div, p ...) for fixture generation.
+    Returns a dict of intermediates (A, rhs, h, div, p ...) for fixture generation.  ``calls`` (a list) receives the step's
+    sequence of operators, solves and hooks in the vocabulary of the reference's backend; ``tests/test_split_step_golden.py``
+    holds it against the sequence recorded from the reference's own ``_PISO_split_step``.
     """
     g = dom.grid
     out = {}
 
+    def log(op, **kw):
+        if calls is not None:
+            calls.append(dict(op=op, **kw))
+
     def run(name):
+        log("hook", name=name)
         if prep_fn and name in prep_fn:
             for fn in prep_fn[name]:
                 fn(dom, dt)
+
+    def solve(A, rhs, x0, tol, kind, names, **kw):
+        log("linear_solve", matrix=names[0], rhs=names[1], x0=None if x0 is None else names[2], use_BiCG=kind == "bicg", tol=tol,
+            return_best_result=bool(kw.get("return_best", False)))
+        return _lin_solve(A, rhs, x0, tol, opts, kind, **kw)
 
     run("PRE")
     # ---- passive scalar (SIM.py:1471-1644): matrix with scalar diffusivity from u^n fluxes
     if opts.advect_passive_scalar and dom.scalar is not None:
         Cn = dom.scalar.shape[0]
+        mats = []
+        for ch in range(Cn):   # (one matrix per channel: the reference shares channel 0's when the diffusivities allow, :1493-1513)
+            log("SetupAdvectionMatrix", for_scalar=True)
+            mats.append(build_advection_matrix(dom, dt, for_scalar=True, channel=ch)[0])
+        log("SetupAdvectionScalar")
         rhs_s = advection_rhs_scalar(dom, dt)
+        run("POST_SCALAR_SETUP")
         res = np.empty_like(dom.scalar)
         for ch in range(Cn):
-            Cs, _, _ = build_advection_matrix(dom, dt, for_scalar=True, channel=ch)
-            res[ch] = _lin_solve(Cs, rhs_s[ch], None, opts.advection_tol, opts, "bicg").reshape(g.shape)
+            res[ch] = solve(mats[ch], rhs_s[ch], None, opts.advection_tol, "bicg", ("C", "scalarRHS", None)).reshape(g.shape)
         out["scalar_rhs"] = rhs_s
+        log("setScalarResult")
         dom.scalar = res  # CopyScalarResultToBlocks (:1644)
+        log("CopyScalarResultToBlocks")
     run("PRE_VELOCITY_SETUP")
     # ---- velocity predictor (SIM.py:1646-1762)
+    log("SetupAdvectionMatrix", for_scalar=False)
     C, A, offs = build_advection_matrix(dom, dt)
+    log("SetupAdvectionVelocity", apply_pressure_gradient=False)
     rhs = advection_rhs_velocity(dom, dt)
+    run("POST_VELOCITY_SETUP")
     vel = np.empty_like(dom.velocity)
+    # advect_use_prev_result in the orthogonal branch (:1436, 1689-1693); the non-orthogonal branch starts its first pass from zero
+    # (:1735-1742).  One solve in the reference (all components in one block right-hand side), one per component here
+    log("linear_solve", matrix="C", rhs="velocityRHS", x0=None if opts.non_orthogonal else "velocityResult", use_BiCG=True,
+        tol=opts.advection_tol, return_best_result=False)
     for c in range(g.dims):
-        x0 = dom.velocity_result[c]  # advect_use_prev_result (:1436, 1689-1693)
+        x0 = None if opts.non_orthogonal else dom.velocity_result[c]
         vel[c] = _lin_solve(C, rhs[c], x0, opts.advection_tol, opts, "bicg").reshape(g.shape)
     dom.velocity_result = vel
+    log("setVelocityResult")
     out.update(A=A, C=C, C_offs=offs, velocity_rhs=rhs, velocity_pred=vel.copy())
-    # ---- correctors (SIM.py:1777-1972)
+    run("POST_PREDICTION")
+    # ---- correctors (SIM.py:1777-1972).  SetupPressureCorrection assembles matrix and right-hand side in every corrector; the
+    # matrix only depends on A, so it is built once here
     P, Pdiag, Poffs = build_pressure_matrix(dom, A)
     out.update(P=P, P_diag=Pdiag, P_offs=Poffs)
-    any_fixed = any(dom.is_fixed(f) for f in range(2 * g.dims))
     for cstep in range(opts.corrector_steps):
+        log("SetupPressureCorrection")
         h = pressure_rhs(dom, dt, A, offs, dom.velocity_result)
         div = divergence(dom, h)
-        p = _lin_solve(P, div, None, opts.pressure_tol, opts, "cg", singular=True,
-                       return_best=opts.pressure_return_best_result).reshape(g.shape)
+        run("POST_PRESSURE_SETUP")
+        p = solve(P, div, None, opts.pressure_tol, "cg", ("P", "pressureRHSdiv", None), singular=True,
+                  return_best=opts.pressure_return_best_result).reshape(g.shape)
         if opts.normalize_pressure_result:
             p = p - p.mean()  # SIM.py:1817-1820
+        log("setPressureResult", mean_removed=bool(opts.normalize_pressure_result))
         dom.pressure_result = p
+        run("POST_PRESSURE_RESULT")
+        run("POST_PRESSURE_NON_ORTHO")
         dom.pressure = p.copy()  # CopyPressureResultToBlocks (:1953)
+        log("CopyPressureResultToBlocks")
+        log("CorrectVelocity")
         dom.velocity_result = correct_velocity(dom, h, p, A)
+        run("POST_VELOCITY_CORRECTION")
         out[f"h{cstep}"], out[f"div{cstep}"], out[f"p{cstep}"] = h, div, p.copy()
         out[f"u{cstep}"] = dom.velocity_result.copy()
     dom.velocity = dom.velocity_result.copy()  # CopyVelocityResultToBlocks (:1974)
+    log("CopyVelocityResultToBlocks")
     run("POST")
     return out
 

@@ -12,6 +12,7 @@ rocprofv3 --pmc FETCH_SIZE -d $O/p_fetch -o bench -- $BENCH > $O/p_fetch.log 2>&
 python3 $R/profiles/summarize_pmc.py "$(find $O/p_fetch -name '*.db' | head -1)" > $O/r02_a_bench_pmc_fetch.csv
 rocprofv3 --pmc WRITE_SIZE -d $O/p_write -o bench -- $BENCH > $O/p_write.log 2>&1
 python3 $R/profiles/summarize_pmc.py "$(find $O/p_write -name '*.db' | head -1)" > $O/r02_a_bench_pmc_write.csv
+if [ "$1" = "headline" ]; then rm -rf $O/p_stats $O/p_fetch $O/p_write; ls -la $O/r02_*; exit 0; fi   # only the headline passes
 rocprofv3 --kernel-trace --stats -d $O/p_p256 -o p256 -- python3 $R/profiles/micro_poisson.py > $O/p_p256.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_p256 -name '*.db' | head -1)" $O/r02_b_poisson256_kernel_stats.csv > /dev/null
 rocprofv3 --kernel-trace --stats -d $O/p_cyl -o cyl -- python3 $R/profiles/cylinder_modes.py 64 2 1-0-1 > $O/p_cyl.log 2>&1

@@ -69,6 +69,9 @@ class StubSolver:
     def set_scalar_viscosity(self, ch, k):
         pass
 
+    def set_advection_start(self, from_result=True):
+        self.advection_from_result = bool(from_result)
+
     def set_return_best(self, on=True):
         pass
 

@@ -105,6 +105,33 @@ def test_scalar_assembly_and_solve(neumann):
         assert rel_err(res[b], x_ref) < SOLVE_TOL
 
 
+def test_velocity_solve_start_vector_follows_the_branch_rule():
+    """fg_set_advection_start: from velocityResult (the reference's orthogonal branch, PISOtorch_simulation.py:1689-1693; default of a
+    handle) or from zero (its non-orthogonal branch, :1735-1742, which its TCF env runs on such a grid).  Observable: solving the
+    same system again starts converged from velocityResult (0 iterations) and takes the full count again from zero."""
+    case = make_case(dims=2, n=(32, 24), fixed_axes=(1,), B=2, seed=5, vel_scale=0.3)
+    ns = case.native()
+    ns.setup_advection(0.02)
+    first = max(i.used_iterations for i in ns.solve_advection(tol=1e-6))
+    x1 = _np(ns.buffer(3, (case.B, case.dims) + case.shape))
+    again = max(i.used_iterations for i in ns.solve_advection(tol=1e-5))          # default: from velocityResult = the solution
+    ns.set_advection_start(False)
+    cold = max(i.used_iterations for i in ns.solve_advection(tol=1e-5))
+    x2 = _np(ns.buffer(3, (case.B, case.dims) + case.shape))
+    assert first > 0 and again <= 0 and 0 < cold <= first, (first, again, cold)      # (-1: converged before the first iteration)
+    assert rel_err(x2, x1) < 1e-4
+    # the fused step reads the same switch: both starts give the same step within the tolerance
+    out = {}
+    for from_result in (True, False):
+        n2 = case.native()
+        n2.set_advection_start(from_result)
+        ok, stats = n2.piso_step(0.02, advection_tol=1e-6, pressure_tol=1e-6)
+        out[from_result] = _np(n2.velocity)
+        n2.close()
+    assert rel_err(out[True], out[False]) < 1e-4
+    ns.close()
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_full_piso_step_intermediates(name):
     """One split step from identical state: predictor, h, div, p and corrected velocity."""
