@@ -694,7 +694,7 @@ class Domain:
             log("SetupAdvectionVelocity", non_ortho_flags=flags, apply_pressure_gradient=False)
             rhs = self.velocity_rhs(u, u_res, dt, source, flags)
             # x = None if no_step == 0 or not advect_non_ortho_reuse_result else velocityResult (SIM.py:1735-1742)
-            log("linear_solve", matrix="C", rhs="velocityRHS", x0=None if no == 0 else "velocityResult")
+            log("SolveLinear", matrix="C", rhs="velocityRHS", x0=None if no == 0 else "velocityResult")
             u_res = self.solve(C, rhs)
             log("setVelocityResult")
         if trace is not None:
@@ -712,7 +712,7 @@ class Domain:
                     log("SetupPressureRHSdiv", non_ortho_flags=flags)
                 b_rhs = div + self.pressure_nonortho(p, A, flags)
                 # x = None if pstep == 0 or not pressure_reuse_result else pressureResult (SIM.py:1877-1881)
-                log("linear_solve", matrix="P", rhs="pressureRHSdiv", x0=None if ps == 0 else "pressureResult")
+                log("SolveLinear", matrix="P", rhs="pressureRHSdiv", x0=None if ps == 0 else "pressureResult")
                 p = self.solve(P, b_rhs, singular=True)
                 log("setPressureResult", mean_removed=True)   # solve(singular=True) returns the mean-free solution (SIM.py:1929-1932)
             if trace is not None and c == 0:

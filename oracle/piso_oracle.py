@@ -775,7 +775,7 @@ def piso_split_step(dom: Domain, dt: float, opts: SolverOptions = SolverOptions(
                 fn(dom, dt)
 
     def solve(A, rhs, x0, tol, kind, names, **kw):
-        log("linear_solve", matrix=names[0], rhs=names[1], x0=None if x0 is None else names[2], use_BiCG=kind == "bicg", tol=tol,
+        log("SolveLinear", matrix=names[0], rhs=names[1], x0=None if x0 is None else names[2], use_BiCG=kind == "bicg", tol=tol,
             return_best_result=bool(kw.get("return_best", False)))
         return _lin_solve(A, rhs, x0, tol, opts, kind, **kw)
 
@@ -807,7 +807,7 @@ def piso_split_step(dom: Domain, dt: float, opts: SolverOptions = SolverOptions(
     vel = np.empty_like(dom.velocity)
     # advect_use_prev_result in the orthogonal branch (:1436, 1689-1693); the non-orthogonal branch starts its first pass from zero
     # (:1735-1742).  One solve in the reference (all components in one block right-hand side), one per component here
-    log("linear_solve", matrix="C", rhs="velocityRHS", x0=None if opts.non_orthogonal else "velocityResult", use_BiCG=True,
+    log("SolveLinear", matrix="C", rhs="velocityRHS", x0=None if opts.non_orthogonal else "velocityResult", use_BiCG=True,
         tol=opts.advection_tol, return_best_result=False)
     for c in range(g.dims):
         x0 = None if opts.non_orthogonal else dom.velocity_result[c]

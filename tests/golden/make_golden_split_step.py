@@ -1,14 +1,16 @@
-"""Call sequence of the reference's PISO split step, produced by the reference's OWN Python running HERE against recording
-stand-ins (no reference source is copied): ``Simulation._PISO_split_step`` (``pict/PISOtorch_simulation.py:1431-2002``) is run
-with a backend and a domain that only RECORD what is asked of them -- which compiled operator, with which non-orthogonal flags,
-which linear solve (matrix, right-hand side, start vector or none, solver kind, tolerance, best-result flag), which hook, in which
-order -- for the solver settings of the reference's four env families (channel / RBC: orthogonal branch; TCF, cylinder 2-D / 3-D,
-airfoil: non-orthogonal branch with their numbers of non-orthogonal passes).
+"""Call sequence and solver parameters of the reference's PISO split step, produced by the reference's OWN Python running HERE
+against recording stand-ins (no reference source is copied).  The chain that runs is the reference's: its real
+``Simulation.__init__`` (``pict/PISOtorch_simulation.py:489-597``) with the arguments its env families pass (copied here as data),
+its ``_PISO_split_step`` (``:1431-2002``), ``linear_solve`` / ``linear_solve_GPU`` (``:1080-1181``) and the real
+``_linear_solve_wrapper`` of ``pict/PISOtorch_diff.py`` (``:373-488``).  Only the compiled extension is replaced: a backend and a
+domain that RECORD what is asked of them -- which operator with which non-orthogonal flag word, which ``SolveLinear`` call
+(matrix, right-hand side, start vector or zeros, iteration cap, tolerance, criterion, solver kind, residual reset, best-result and
+preconditioner flags), which hook, in which order.
 
     python tests/golden/make_golden_split_step.py        ->  tests/golden/reference_split_step.json
 
-``tests/test_split_step_golden.py`` holds the oracle's step functions (``oracle/piso_oracle.py::piso_split_step``,
-``oracle/mb_oracle.py::Domain.piso_step``) against these sequences.
+``tests/test_split_step_golden.py`` holds the oracles' step functions (``oracle/piso_oracle.py::piso_split_step``,
+``oracle/mb_oracle.py::Domain.piso_step``) and the host's ``Simulation`` / ``MultiBlockSimulation`` settings against it.
 """
 import json
 import logging
@@ -33,7 +35,7 @@ class Tagged(torch.Tensor):
 
     @staticmethod
     def make(tag, n=N):
-        t = torch.zeros(n).as_subclass(Tagged)
+        t = torch.full((n,), 0.5).as_subclass(Tagged)       # non-zero: a given start vector differs from zeros_like(rhs)
         t.tag = tag
         return t
 
@@ -47,6 +49,19 @@ class RecordingDomain:
         self._log, self._scalar = log, scalar
         for name in ["C", "P", "velocityRHS", "scalarRHS", "pressureRHSdiv", "velocityResult", "pressureResult", "scalarResult"]:
             setattr(self, name, Tagged.make(name))
+
+    # what Simulation.__init__ and its property setters ask of a domain
+    def IsInitialized(self):
+        return True
+
+    def getNumBlocks(self):
+        return 1
+
+    def getBlock(self, i):
+        return types.SimpleNamespace(velocity=torch.zeros(1, dtype=torch.float32))
+
+    def getSpatialDims(self):
+        return 2
 
     # queries of the scalar branch (PISOtorch_simulation.py:1471-1486)
     def hasPassiveScalar(self):
@@ -119,48 +134,74 @@ class RecordingBackend:
         return op
 
 
-def run_case(sim_mod, name, scalar, **settings):
+class _Info:
+    """LinearSolverResultInfo of a converged solve (what the reporting code of the wrapper reads)"""
+    converged, isFiniteResidual, finalResidual, usedIterations = True, True, 1e-9, 7
+
+    def __getattr__(self, name):
+        return 0
+
+
+def run_case(sim_mod, diff_mod, name, scalar, ctor, after=None):
+    """ctor: keyword arguments of the reference env's Simulation(...) call that reach this class (the env-side wrapper
+    fluidgym/simulation/simulation.py passes them through, dt as time_step); after: attributes the env sets afterwards."""
     log = []
+    backend = RecordingBackend(log)
+    backend.Domain = RecordingDomain                       # isinstance check of the domain setter
+    backend.ConvergenceCriterion = types.SimpleNamespace(NORM2_NORMALIZED="NORM2_NORMALIZED")
+
+    def solve_linear(mat, rhs, result, maxit, tol, crit, use_bicg, rank_def, reset, transpose, print_res, best, BiCGwithPreconditioner=True):
+        log.append({"op": "SolveLinear", "matrix": tag_of(mat), "rhs": tag_of(rhs),
+                    "x0": None if bool(result.eq(0).all()) else tag_of(result), "dtype": str(rhs.dtype).replace("torch.", ""),
+                    "max_iterations": int(maxit[0]), "tol": float(tol[0]), "criterion": str(crit), "use_BiCG": bool(use_bicg),
+                    "matrix_rank_deficient": bool(rank_def), "residual_reset_step": int(reset), "transpose": bool(transpose),
+                    "return_best_result": bool(best), "BiCG_with_preconditioner": bool(BiCGwithPreconditioner)})
+        result.copy_(torch.arange(1.0, rhs.numel() + 1.0))    # NOT mean-free: setPressureResult shows whether the mean was removed
+        return [_Info()]
+
+    diff_mod.PISOtorch.SolveLinear = solve_linear
+    sim_mod.PISOtorch, sim_mod.PISOtorch_diff = backend, diff_mod        # the names Simulation.__init__ / linear_solve_GPU resolve
     dom = RecordingDomain(log, scalar)
-
-    def linear_solve(A, rhs, x=None, **kw):
-        log.append({"op": "linear_solve", "matrix": tag_of(A), "rhs": tag_of(rhs), "x0": tag_of(x),
-                    "use_BiCG": bool(kw.get("use_BiCG")), "tol": kw.get("tol"),
-                    "return_best_result": bool(kw.get("return_best_result", False)),
-                    "residual_reset_step": kw.get("residual_reset_step"), "matrix_rank_deficient": kw.get("matrix_rank_deficient")})
-        res = torch.arange(1.0, rhs.numel() + 1.0)          # NOT mean-free: setPressureResult shows whether the mean was removed
-        return res, True
-
-    me = types.SimpleNamespace(
-        domain=dom, differentiable=False, _velocity_corrector_version=0, convergence_tol=None, total_step=0, total_time=0.0,
-        advect_passive_scalar=True, exclude_advection_solve_gradients=True, exclude_pressure_solve_gradients=True,
-        scipy_solve_advection=False, scipy_solve_pressure=False, pressure_time_step_normalized=False,
-        _check_domain=lambda: None, _check_stop=lambda: False, linear_solve=linear_solve,
-        _run_prep_fn=lambda hook, **kw: log.append({"op": "hook", "name": hook}),
-        end_step=lambda time_step: log.append({"op": "end_step"}), **settings)
-    setattr(me, "_Simulation__backend", RecordingBackend(log))
-    # the flag word as Simulation.__init__ sets it (:739), from the class's own constant
-    mode = getattr(sim_mod.Simulation, "_Simulation__NON_ORTHO_MODE")
-    setattr(me, "_Simulation__non_ortho_flags", int(mode) if settings["non_orthogonal"] else 0)
-    setattr(me, "_Simulation__LOG", logging.getLogger("golden"))
-    ok = sim_mod.Simulation._PISO_split_step(me, 1, time_step=torch.tensor([0.05]))
-    return {"name": name, "settings": {k: v for k, v in settings.items()}, "passive_scalar": scalar, "ok": bool(ok), "calls": log}
+    sim = sim_mod.Simulation(domain=dom, **ctor)
+    for k, v in (after or {}).items():
+        setattr(sim, k, v)
+    sim._run_prep_fn = lambda hook, **kw: log.append({"op": "hook", "name": hook})
+    sim.end_step = lambda time_step: log.append({"op": "end_step"})
+    ok = sim._PISO_split_step(1, time_step=torch.tensor([0.05]))
+    derived = {"linear_solve_max_iterations": sim.linear_solve_max_iterations, "solver_double_fallback": sim.solver_double_fallback,
+               "preconditionBiCG": sim.preconditionBiCG, "BiCG_precondition_fallback": sim.BiCG_precondition_fallback,
+               "velocity_corrector_version": sim._velocity_corrector_version, "adaptive_CFL": sim.adaptive_CFL,
+               "substeps": sim.substeps, "corrector_steps": sim.corrector_steps}
+    return {"name": name, "constructor": ctor, "set_after_construction": after or {}, "passive_scalar": scalar, "ok": bool(ok),
+            "simulation_attributes": derived, "calls": log}
 
 
 def main():
+    logging.disable(logging.CRITICAL)
+    import make_golden_control as C                    # loader of the reference's real PISOtorch_diff (retry ladder pins)
+
+    diff_mod = C.load_diff_module(lambda *a, **k: [_Info()])
     sim_mod = G.load_reference_simulation_module()
-    base = dict(corrector_steps=2, advection_use_BiCG=True, pressure_use_BiCG=False, advection_tol=None, pressure_tol=None,
-                pressure_return_best_result=True, normalize_pressure_result=True)
+    # the Simulation(...) calls of the reference's env families, as data (cylinder_env_base.py:308-328, rbc_env_base.py:311-327,
+    # airfoil_env_base.py:265-284, tcf_env.py:483-503): the arguments that reach this class; dt / rendering arguments left out
+    common = dict(time_step=0.1, substeps="ADAPTIVE", corrector_steps=2, pressure_return_best_result=True, velocity_corrector="FD")
     cases = [
-        run_case(sim_mod, "channel_orthogonal", False, non_orthogonal=False, advect_non_ortho_steps=1, pressure_non_ortho_steps=1, **base),
-        run_case(sim_mod, "rbc_orthogonal_scalar", True, non_orthogonal=False, advect_non_ortho_steps=1, pressure_non_ortho_steps=1, **base),
-        run_case(sim_mod, "tcf_cylinder2d_nonorthogonal_1_1", False, non_orthogonal=True, advect_non_ortho_steps=1,
-                 pressure_non_ortho_steps=1, **base),
-        run_case(sim_mod, "cylinder3d_nonorthogonal_1_4", False, non_orthogonal=True, advect_non_ortho_steps=1,
-                 pressure_non_ortho_steps=4, **base),
-        run_case(sim_mod, "airfoil_nonorthogonal_2_4_bicg_pressure", False, non_orthogonal=True, advect_non_ortho_steps=2,
-                 pressure_non_ortho_steps=4, **{**base, "pressure_use_BiCG": True}),
-        run_case(sim_mod, "nonorthogonal_scalar_1_1", True, non_orthogonal=True, advect_non_ortho_steps=1, pressure_non_ortho_steps=1, **base),
+        run_case(sim_mod, diff_mod, "rbc", True, dict(common, adaptive_CFL=0.8, pressure_tol=1e-5, advect_non_ortho_steps=1,
+                                                      pressure_non_ortho_steps=1, non_orthogonal=False)),
+        run_case(sim_mod, diff_mod, "orthogonal_no_scalar", False, dict(common, non_orthogonal=False)),
+        run_case(sim_mod, diff_mod, "tcf", False, dict(common, advection_use_BiCG=True, advection_tol=1e-6, pressure_tol=1e-6, adaptive_CFL=0.8,
+                                                       advect_non_ortho_steps=1, pressure_non_ortho_steps=1, non_orthogonal=True),
+                 after=dict(solver_double_fallback=False, preconditionBiCG=False)),
+        run_case(sim_mod, diff_mod, "cylinder2d", False, dict(common, adaptive_CFL=0.8, pressure_tol=1e-5, advect_non_ortho_steps=1,
+                                                              pressure_non_ortho_steps=1, non_orthogonal=True),
+                 after=dict(solver_double_fallback=True, preconditionBiCG=False, BiCG_precondition_fallback=True)),
+        run_case(sim_mod, diff_mod, "cylinder3d", False, dict(common, adaptive_CFL=0.8, pressure_tol=5e-7, advect_non_ortho_steps=1,
+                                                              pressure_non_ortho_steps=4, non_orthogonal=True),
+                 after=dict(solver_double_fallback=True, preconditionBiCG=False, BiCG_precondition_fallback=True)),
+        run_case(sim_mod, diff_mod, "airfoil2d", False, dict(common, advection_tol=1e-6, pressure_tol=1e-7, advect_non_ortho_steps=2,
+                                                             pressure_non_ortho_steps=4, non_orthogonal=True),
+                 after=dict(solver_double_fallback=True, preconditionBiCG=False)),
+        run_case(sim_mod, diff_mod, "defaults_non_orthogonal", False, dict(time_step=0.1)),
     ]
     with open(os.path.join(OUT, "reference_split_step.json"), "w") as f:
         json.dump({"hooks": HOOKS, "cases": cases}, f, indent=1)

@@ -1,8 +1,10 @@
-"""The step structure of the oracles and the start-vector policy of the host against the call sequence of the reference's OWN
-``Simulation._PISO_split_step`` (``pict/PISOtorch_simulation.py:1431-2002``), recorded here by
-``tests/golden/make_golden_split_step.py`` with recording stand-ins for the compiled backend and domain
-(``tests/golden/reference_split_step.json``): which operator, which solve (matrix, right-hand side, start vector or none,
-solver kind, best-result flag), which hook, in which order, for the solver settings of the reference's env families."""
+"""The step structure of the oracles and the solver settings of the host against what the reference's OWN Python does, recorded
+here by ``tests/golden/make_golden_split_step.py`` (``tests/golden/reference_split_step.json``): the reference's real
+``Simulation.__init__`` with the arguments of its env families, its real ``_PISO_split_step`` (``pict/PISOtorch_simulation.py:
+1431-2002``), ``linear_solve`` / ``linear_solve_GPU`` (``:1080-1181``) and ``_linear_solve_wrapper`` (``pict/PISOtorch_diff.py:373-488``)
+run against a compiled backend and a domain that only record -- which operator, which ``SolveLinear`` call with which parameters
+(matrix, right-hand side, start vector or zeros, iteration cap, tolerance, criterion, solver kind, residual reset, best-result
+flag, preconditioner flag), which hook, in which order."""
 import json
 import os
 
@@ -20,7 +22,7 @@ CASES = {c["name"]: c for c in GOLD["cases"]}
 
 
 def _project(calls, fields):
-    """the records reduced to the fields a comparison is about (a field an oracle does not report is left out on both sides)"""
+    """the records reduced to the fields a comparison is about"""
     out = []
     for r in calls:
         if r["op"] == "end_step":            # time bookkeeping of the driver, outside the oracles' step functions
@@ -29,84 +31,140 @@ def _project(calls, fields):
     return out
 
 
+def _solves(case, matrix=None):
+    return [r for r in CASES[case]["calls"] if r["op"] == "SolveLinear" and (matrix is None or (r["matrix"] == matrix and r["rhs"] != "scalarRHS"))]
+
+
 def _single_block_domain(with_scalar):
     return make_case(dims=2, n=(8, 6), fixed_axes=(1,), B=1, n_scalars=1 if with_scalar else 0).oracle_domain(0)
 
 
-@pytest.mark.parametrize("case,scalar,non_orthogonal", [("channel_orthogonal", False, False), ("rbc_orthogonal_scalar", True, False)])
-def test_single_block_oracle_steps_like_the_reference_orthogonal_branch(case, scalar, non_orthogonal):
+@pytest.mark.parametrize("case,scalar", [("orthogonal_no_scalar", False), ("rbc", True)])
+def test_single_block_oracle_steps_like_the_reference_orthogonal_branch(case, scalar):
     ref = CASES[case]
-    dom = _single_block_domain(scalar)
     calls = []
-    opts = O.SolverOptions(corrector_steps=ref["settings"]["corrector_steps"], pressure_return_best_result=ref["settings"]["pressure_return_best_result"],
-                           normalize_pressure_result=ref["settings"]["normalize_pressure_result"], non_orthogonal=non_orthogonal)
-    O.piso_split_step(dom, 0.05, opts, calls=calls)
+    opts = O.SolverOptions(corrector_steps=ref["simulation_attributes"]["corrector_steps"],
+                           pressure_return_best_result=ref["constructor"]["pressure_return_best_result"], non_orthogonal=False)
+    O.piso_split_step(_single_block_domain(scalar), 0.05, opts, calls=calls)
     fields = {"hook": ("name",), "SetupAdvectionMatrix": ("for_scalar",), "SetupAdvectionVelocity": ("apply_pressure_gradient",),
-              "linear_solve": ("matrix", "rhs", "x0", "use_BiCG", "tol", "return_best_result"), "setPressureResult": ("mean_removed",)}
+              "SolveLinear": ("matrix", "rhs", "x0", "use_BiCG", "return_best_result"), "setPressureResult": ("mean_removed",)}
     assert _project(calls, fields) == _project(ref["calls"], fields)
 
 
 def test_single_block_oracle_non_orthogonal_flag_starts_the_velocity_solve_from_zero():
     """the reference's TCF env runs the non-orthogonal branch on a rectilinear grid (tcf_env.py:497): there the velocity solve
-    starts from zero, everything else of the step sequence that the orthogonal oracle logs stays in the same order"""
-    ref = [r for r in CASES["tcf_cylinder2d_nonorthogonal_1_1"]["calls"] if r["op"] == "linear_solve"]
+    starts from zero; the solves of the step are otherwise the same ones in the same order"""
     calls = []
     O.piso_split_step(_single_block_domain(False), 0.05, O.SolverOptions(non_orthogonal=True, pressure_return_best_result=True), calls=calls)
-    mine = [r for r in calls if r["op"] == "linear_solve"]
     key = lambda r: (r["matrix"], r["rhs"], r["x0"], r["use_BiCG"], r["return_best_result"])
-    assert [key(r) for r in mine] == [key(r) for r in ref]
+    mine = [r for r in calls if r["op"] == "SolveLinear"]
+    assert [key(r) for r in mine] == [key(r) for r in _solves("tcf")]
     assert mine[0]["x0"] is None
 
 
-@pytest.mark.parametrize("case", ["tcf_cylinder2d_nonorthogonal_1_1", "cylinder3d_nonorthogonal_1_4", "airfoil_nonorthogonal_2_4_bicg_pressure"])
+@pytest.mark.parametrize("case", ["tcf", "cylinder2d", "cylinder3d", "airfoil2d"])
 def test_multi_block_oracle_steps_like_the_reference_non_orthogonal_branch(case):
     ref = CASES[case]
-    st = ref["settings"]
+    st = ref["constructor"]
     dom = split_rotated_channel(nx=6, ny=4, cut=3).oracle()
     n = sum(b.ncells for b in dom.blocks)
-    u0 = np.vstack([np.ones(n), np.zeros(n)])
     calls = []
-    dom.piso_step(u0, np.zeros(n), 0.05, corrector_steps=st["corrector_steps"], advect_non_ortho_steps=st["advect_non_ortho_steps"],
-                  pressure_non_ortho_steps=st["pressure_non_ortho_steps"], calls=calls)
+    dom.piso_step(np.vstack([np.ones(n), np.zeros(n)]), np.zeros(n), 0.05, corrector_steps=st["corrector_steps"],
+                  advect_non_ortho_steps=st["advect_non_ortho_steps"], pressure_non_ortho_steps=st["pressure_non_ortho_steps"], calls=calls)
     fields = {"SetupAdvectionMatrix": ("non_ortho_flags", "for_scalar"), "SetupAdvectionVelocity": ("non_ortho_flags", "apply_pressure_gradient"),
               "SetupPressureMatrix": ("non_ortho_flags",), "SetupPressureRHS": ("non_ortho_flags",), "SetupPressureRHSdiv": ("non_ortho_flags",),
-              "linear_solve": ("matrix", "rhs", "x0"), "setPressureResult": ("mean_removed",)}
+              "SolveLinear": ("matrix", "rhs", "x0"), "setPressureResult": ("mean_removed",)}
     theirs = [r for r in ref["calls"] if r["op"] != "hook"]       # the multi-block oracle has no hook points
     assert _project(calls, fields) == _project(theirs, fields)
     assert MB.NON_ORTHO_MODE == next(r for r in ref["calls"] if r["op"] == "SetupAdvectionMatrix")["non_ortho_flags"]
 
 
-def test_host_start_vector_policy_is_the_recorded_one():
-    """What the host hands the native stepper: velocity solve from velocityResult in the orthogonal branch, from zero in the
-    non-orthogonal one; first pressure solve of a corrector from zero in both -- unless the opt-in policies say otherwise."""
-    import torch  # noqa: F401
+def test_every_solve_of_the_reference_uses_these_parameters():
+    """facts of the recorded SolveLinear calls that the native solvers are written to: RMS criterion, cap 5000, fp32, advection
+    BiCGStab without preconditioner, pressure CG with the best iterate kept, residual reset every 100 iterations only in the
+    non-orthogonal branch, first pressure solve of a corrector from zeros everywhere"""
+    for name, case in CASES.items():
+        for r in _solves(name):
+            assert (r["criterion"], r["max_iterations"], r["dtype"], r["transpose"], r["matrix_rank_deficient"]) == \
+                ("NORM2_NORMALIZED", 5000, "float32", False, False), (name, r)
+            assert r["BiCG_with_preconditioner"] is False
+            if r["matrix"] == "C":
+                assert r["use_BiCG"] is True and r["return_best_result"] is False and r["residual_reset_step"] == 0
+            else:
+                assert r["use_BiCG"] is False
+                assert r["residual_reset_step"] == (100 if case["constructor"].get("non_orthogonal", True) else 0)
+        p = _solves(name, "P")
+        per_corrector = len(p) // case["simulation_attributes"]["corrector_steps"]
+        for k, r in enumerate(p):
+            assert (r["x0"] is None) == (k % per_corrector == 0), (name, k)
+        assert case["simulation_attributes"]["velocity_corrector_version"] == 1       # "FD"
+    assert _solves("orthogonal_no_scalar", "C")[0]["x0"] == "velocityResult" and _solves("rbc", "C")[0]["x0"] == "velocityResult"
+    for name in ("tcf", "cylinder2d", "cylinder3d", "airfoil2d", "defaults_non_orthogonal"):
+        assert _solves(name, "C")[0]["x0"] is None
+    assert [r["x0"] for r in _solves("airfoil2d", "C")] == [None, "velocityResult"]
 
-    from fluidgym_amd.simulation.policy import get_solver_policy, set_solver_policy
-    from fluidgym_amd.simulation.simulation import Simulation
+
+def test_host_simulation_settings_resolve_like_the_reference():
+    """The host classes built with the SAME constructor arguments as the reference's env families end up with the recorded
+    tolerances, caps, fallback flags and start-vector policy (what they hand the native stepper)."""
+    import torch
+
     from fluidgym_amd.simulation.domain import Domain
+    from fluidgym_amd.simulation.multiblock import MultiBlockSimulation
+    from fluidgym_amd.simulation.policy import get_solver_policy, set_solver_policy
+    from fluidgym_amd.simulation.simulation import Simulation, get_solver_tolerance
     from tests.stub_solver import StubSolver
 
-    def make_stub_domain():        # a Domain whose native solver is the CPU stand-in of tests/stub_solver.py (nothing touches a GPU)
+    def stub_domain():        # a Domain whose native solver is the CPU stand-in of tests/stub_solver.py (nothing touches a GPU)
         dom = Domain.__new__(Domain)
         dom.solver, dom.batch, dom.dims = StubSolver([np.ones(4, np.float32), np.ones(3, np.float32)], 1), 1, 2
         return dom
 
-    def first(case, matrix):
-        return next(r for r in CASES[case]["calls"] if r["op"] == "linear_solve" and r["matrix"] == matrix and r["rhs"] != "scalarRHS")
+    class StubMb:              # what MultiBlockSimulation's constructor asks of a MultiBlockDomain
+        batch = 1
 
-    assert first("channel_orthogonal", "C")["x0"] == "velocityResult" and first("rbc_orthogonal_scalar", "C")["x0"] == "velocityResult"
-    assert first("tcf_cylinder2d_nonorthogonal_1_1", "C")["x0"] is None and first("airfoil_nonorthogonal_2_4_bicg_pressure", "C")["x0"] is None
-    for case in CASES:
-        assert first(case, "P")["x0"] is None
+        def set_advection_start(self, from_result):
+            self.advection_from_result = bool(from_result)
+
     assert get_solver_policy()["advection_warm_start"] is False and get_solver_policy()["pressure_warm_start"] is False
-    for non_orthogonal, expect_from_result in [(False, True), (True, False)]:
-        dom = make_stub_domain()
-        sim = Simulation(dom, 0.1, non_orthogonal=non_orthogonal)
-        assert dom.solver.advection_from_result is expect_from_result and sim.pressure_warm_start is False
-    old = set_solver_policy(advection_warm_start=True)
+    for name in ("rbc", "orthogonal_no_scalar", "tcf", "defaults_non_orthogonal"):       # single-block path
+        case = CASES[name]
+        kw = dict(case["constructor"])
+        dt = kw.pop("time_step")
+        dom = stub_domain()
+        sim = Simulation(dom, dt, **kw)
+        for k, v in case["set_after_construction"].items():
+            setattr(sim, k, v)
+        adv, prs = _solves(name, "C")[0], _solves(name, "P")[0]
+        assert np.float32(get_solver_tolerance(sim.advection_tol, torch.float32)) == np.float32(adv["tol"])
+        assert np.float32(get_solver_tolerance(sim.pressure_tol, torch.float32)) == np.float32(prs["tol"])
+        assert sim.linear_solve_max_iterations == adv["max_iterations"] and sim.corrector_steps == case["simulation_attributes"]["corrector_steps"]
+        assert bool(sim.pressure_return_best_result) == prs["return_best_result"]
+        assert dom.solver.advection_from_result is (adv["x0"] == "velocityResult")
+        assert sim.pressure_warm_start is (prs["x0"] is not None)
+        assert sim.adaptive_CFL == case["simulation_attributes"]["adaptive_CFL"]
+    for name in ("cylinder2d", "cylinder3d", "airfoil2d"):                                # multi-block path
+        case = CASES[name]
+        kw = {k: v for k, v in case["constructor"].items()
+              if k in ("substeps", "corrector_steps", "advection_tol", "pressure_tol", "advect_non_ortho_steps", "pressure_non_ortho_steps", "adaptive_CFL")}
+        dom = StubMb()
+        sim = MultiBlockSimulation(dom, dt=case["constructor"]["time_step"], **kw, **{k: v for k, v in case["set_after_construction"].items()
+                                                                                       if k in ("solver_double_fallback", "BiCG_precondition_fallback")})
+        adv, prs = _solves(name, "C")[0], _solves(name, "P")[0]
+        assert np.float32(sim.advection_tol) == np.float32(adv["tol"]) and np.float32(sim.pressure_tol) == np.float32(prs["tol"])
+        assert sim.max_iterations == adv["max_iterations"]
+        assert dom.advection_from_result is (adv["x0"] is not None) and sim.pressure_warm_start is (prs["x0"] is not None)
+        assert sim.solver_double_fallback == case["simulation_attributes"]["solver_double_fallback"]
+        assert sim.BiCG_precondition_fallback == case["simulation_attributes"]["BiCG_precondition_fallback"]
+        assert sim.adaptive_CFL == case["simulation_attributes"]["adaptive_CFL"]
+        assert (sim.advect_non_ortho_steps, sim.pressure_non_ortho_steps) == (len(_solves(name, "C")), len(_solves(name, "P")) // 2)
+    old = set_solver_policy(advection_warm_start=True)      # the opt-in
     try:
-        dom = make_stub_domain()
+        dom = stub_domain()
         Simulation(dom, 0.1, non_orthogonal=True)
         assert dom.solver.advection_from_result is True
+        mb = StubMb()
+        MultiBlockSimulation(mb, dt=0.1)
+        assert mb.advection_from_result is True
     finally:
         set_solver_policy(**old)
