@@ -47,8 +47,15 @@ def tag_of(x):
 class RecordingDomain:
     def __init__(self, log, scalar):
         self._log, self._scalar = log, scalar
-        for name in ["C", "P", "velocityRHS", "scalarRHS", "pressureRHSdiv", "velocityResult", "pressureResult", "scalarResult"]:
+        for name in ["A", "C", "P", "velocityRHS", "scalarRHS", "pressureRHSdiv", "velocityResult", "pressureResult", "scalarResult"]:
             setattr(self, name, Tagged.make(name))
+
+    # make_divergence_free (PISOtorch_simulation.py:1335-1355): A := 1, the velocity itself as the pressure right-hand side field
+    def setA(self, v):
+        self._log.append({"op": "setA", "all_ones": bool(torch.as_tensor(v).eq(1).all())})
+
+    def setPressureRHS(self, v):
+        self._log.append({"op": "setPressureRHS", "field": tag_of(v)})
 
     # what Simulation.__init__ and its property setters ask of a domain
     def IsInitialized(self):
@@ -166,14 +173,17 @@ def run_case(sim_mod, diff_mod, name, scalar, ctor, after=None):
     for k, v in (after or {}).items():
         setattr(sim, k, v)
     sim._run_prep_fn = lambda hook, **kw: log.append({"op": "hook", "name": hook})
-    sim.end_step = lambda time_step: log.append({"op": "end_step"})
+    sim.end_step = lambda time_step: log.append({"op": "end_step", "time_step": float(torch.as_tensor(time_step).reshape(-1)[0])})
     ok = sim._PISO_split_step(1, time_step=torch.tensor([0.05]))
+    n_step = len(log)
+    ok_mdf = sim.make_divergence_free()                 # (PISOtorch_simulation.py:1320-1429; the cylinder envs call it after set-up)
     derived = {"linear_solve_max_iterations": sim.linear_solve_max_iterations, "solver_double_fallback": sim.solver_double_fallback,
                "preconditionBiCG": sim.preconditionBiCG, "BiCG_precondition_fallback": sim.BiCG_precondition_fallback,
                "velocity_corrector_version": sim._velocity_corrector_version, "adaptive_CFL": sim.adaptive_CFL,
                "substeps": sim.substeps, "corrector_steps": sim.corrector_steps}
     return {"name": name, "constructor": ctor, "set_after_construction": after or {}, "passive_scalar": scalar, "ok": bool(ok),
-            "simulation_attributes": derived, "calls": log}
+            "simulation_attributes": derived, "calls": log[:n_step], "make_divergence_free_ok": bool(ok_mdf),
+            "make_divergence_free_calls": log[n_step:]}
 
 
 def main():

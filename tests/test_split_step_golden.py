@@ -168,3 +168,46 @@ def test_host_simulation_settings_resolve_like_the_reference():
         assert mb.advection_from_result is True
     finally:
         set_solver_policy(**old)
+
+
+def test_make_divergence_free_like_the_reference():
+    """``make_divergence_free`` (PISOtorch_simulation.py:1320-1429) recorded the same way: A := 1 and time step 1, the PRE hook, the
+    velocity itself as the right-hand-side field, ``pressure_non_ortho_steps`` solves capped at 1000 iterations (not 5000), the first
+    from zeros, at the env's pressure tolerance with the best iterate kept -- what the host hands the native entry."""
+    import inspect
+
+    from fluidgym_amd.simulation.multiblock import MultiBlockDomain, MultiBlockSimulation
+    from fluidgym_amd.simulation.simulation import Simulation
+
+    for name in ("cylinder2d", "cylinder3d", "airfoil2d"):
+        case = CASES[name]
+        calls = case["make_divergence_free_calls"]
+        ops = [r["op"] if r["op"] != "hook" else "hook:" + r["name"] for r in calls]
+        n_ps = case["constructor"]["pressure_non_ortho_steps"]
+        assert ops == (["setA", "hook:PRE", "CopyVelocityResultFromBlocks", "setPressureRHS", "SetupPressureMatrix"]
+                       + ["SetupPressureRHSdiv", "SolveLinear", "setPressureResult"] * n_ps
+                       + ["CopyPressureResultToBlocks", "CorrectVelocity", "CopyVelocityResultToBlocks", "end_step"])
+        assert calls[0]["all_ones"] and calls[3]["field"] == "velocityResult" and calls[-1]["time_step"] == 1.0
+        solves = [r for r in calls if r["op"] == "SolveLinear"]
+        assert [r["x0"] for r in solves] == [None] + ["pressureResult"] * (n_ps - 1)
+        assert all(r["max_iterations"] == 1000 and r["return_best_result"] and not r["use_BiCG"] for r in solves)
+        assert all(r["mean_removed"] for r in calls if r["op"] == "setPressureResult")
+
+        seen = {}
+
+        class StubMb:
+            batch = 1
+
+            def set_advection_start(self, from_result):
+                pass
+
+            def make_divergence_free(self, **kw):
+                seen.update(kw)
+                return True
+
+        kw = {k: v for k, v in case["constructor"].items() if k in ("pressure_tol", "pressure_non_ortho_steps")}
+        assert MultiBlockSimulation(StubMb(), dt=0.1, **kw).make_divergence_free() is True
+        assert np.float32(seen["pressure_tol"]) == np.float32(solves[0]["tol"]) and seen["pressure_non_ortho_steps"] == n_ps
+        assert "max_iterations" not in seen        # the entry's default applies:
+    assert inspect.signature(MultiBlockDomain.make_divergence_free).parameters["max_iterations"].default == 1000
+    assert inspect.signature(Simulation.make_divergence_free).parameters["max_iterations"].default == 1000
