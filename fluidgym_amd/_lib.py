@@ -12,7 +12,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfluidgym_hip.so")
+# FLUIDGYM_AMD_LIB: another build of the same library (the host-sanitizer build of tests/run_sanitizer_suite.sh); a path that does
+# not exist is an error like a missing default build
+LIB_PATH = os.environ.get("FLUIDGYM_AMD_LIB") or os.path.join(_HERE, "libfluidgym_hip.so")
 
 FG_MAX_SCALARS = 4
 FG_OK = 0
