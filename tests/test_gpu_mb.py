@@ -167,7 +167,7 @@ def test_first_velocity_solve_starts_from_zero_unless_asked():
     dom.set_advection_start(False)
     _load(dom, st)
     again = dom.piso_step(2e-3, **kw)
-    assert again[0] == cold[0]
+    assert abs(again[0] - cold[0]) <= 1 and again[0] > warm[0]      # (the dot products are summed with atomics: the count can move by one)
     dom.close()
 
 
