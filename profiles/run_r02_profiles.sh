@@ -6,6 +6,13 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-micro --steps 10 --warmup 3"
+if [ "$1" = "mb" ]; then   # only the kernel statistics of the cylinder and airfoil legs
+  rocprofv3 --kernel-trace --stats -d $O/p_cyl -o cyl -- python3 $R/profiles/cylinder_modes.py 64 2 1-0-1 > $O/p_cyl.log 2>&1
+  python3 $R/profiles/summarize_rocpd.py "$(find $O/p_cyl -name '*.db' | head -1)" $O/r02_c_cylinder_kernel_stats.csv > /dev/null
+  rocprofv3 --kernel-trace --stats -d $O/p_air -o air -- python3 $R/profiles/airfoil_bench.py 16 1 40 > $O/p_air.log 2>&1
+  python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air -name '*.db' | head -1)" $O/r02_d_airfoil_kernel_stats.csv > /dev/null
+  rm -rf $O/p_cyl $O/p_air; tail -2 $O/p_cyl.log $O/p_air.log; ls -la $O/r02_c_* $O/r02_d_*; exit 0
+fi
 rocprofv3 --kernel-trace --stats -d $O/p_stats -o bench -- $BENCH > $O/p_stats.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_stats -name '*.db' | head -1)" $O/r02_a_bench_kernel_stats.csv > /dev/null
 rocprofv3 --pmc FETCH_SIZE -d $O/p_fetch -o bench -- $BENCH > $O/p_fetch.log 2>&1
