@@ -27,7 +27,8 @@ def _run_one(args):
     inflow[0, :, 0] = prof
     bc = {0: O.FixedBC(inflow.copy()), 1: O.FixedBC(inflow.copy()), 2: O.FixedBC(np.zeros(2, dt)), 3: O.FixedBC(np.zeros(2, dt))}
     dom = O.Domain(g, dt.type(1.0 / CFG["reynolds_number"]), u, np.zeros((ny, nx), dt), bc)
-    opts = O.SolverOptions(direct=False, pressure_tol=1e-5, advection_tol=1e-5, pressure_return_best_result=True)
+    # same start vectors as the GPU leg: the channel env runs the reference's non-orthogonal branch (velocity solve from zero)
+    opts = O.SolverOptions(direct=False, pressure_tol=1e-5, advection_tol=1e-5, pressure_return_best_result=True, non_orthogonal=True)
     O.make_divergence_free(dom, O.SolverOptions(direct=False, pressure_tol=1e-5))
     velm = np.array([1.0, 0.0], dt)
     t0 = time.perf_counter()
