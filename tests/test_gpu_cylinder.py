@@ -224,3 +224,29 @@ def test_refined_bicgstab_gives_the_same_wake_as_cg():
     # CG (on-chip, no atomics) is deterministic: 2.5016; the BiCGStab's dot products are accumulated with atomics and its 40-step
     # drag scatters over 2.476 .. 2.572 from run to run (measured over 12 runs: up to 2.8 % from the CG value)
     assert abs(cds[0] - cds[1]) < 0.06 * abs(cds[0]), cds
+
+
+def test_parallel_env_wraps_the_multi_block_env_on_the_gpu():
+    """``ParallelFluidEnv`` over a multi-block env on the device (one rank = the shard a GPU would own; the two-rank protocol is
+    covered on gloo in tests/test_parallel_env_gloo.py): stacked observations, per-env flags and infos, same numbers as the env
+    stepped directly."""
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    kw = dict(KW, episode_length=2)
+    penv = ParallelFluidEnv("CylinderJet2D-easy-v0", cuda_ids=[0], num_envs=2, **kw)
+    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=2, **kw)
+    pobs, _ = penv.reset(seed=3)
+    obs, _ = env.reset(seed=3)
+    assert pobs["velocity"].shape == (2, 151, 2) and pobs["velocity"].is_cuda
+    assert torch.allclose(pobs["velocity"], obs["velocity"], rtol=1e-3, atol=1e-5)
+    act = torch.tensor([[0.5], [-0.5]], device="cuda")
+    for i in range(2):
+        pobs, prew, pterm, ptrunc, pinfo = penv.step(act)
+        obs, rew, term, trunc, info = env.step(act)
+        assert len(pterm) == 2 and len(ptrunc) == 2 and all(t == (i == 1) for t in ptrunc) and not any(pterm)
+        assert isinstance(pinfo, list) and len(pinfo) == 2 and set(pinfo[0]) == {"drag", "lift"}
+        # (two handles, dot products summed with atomics: equal within the solver tolerance's effect on the forces)
+        assert torch.allclose(prew, rew, rtol=2e-2, atol=1e-3)
+        assert abs(float(pinfo[1]["drag"]) - float(info["drag"][1])) < 2e-2 * abs(float(info["drag"][1]))
+    assert penv.sample_action().shape == (2, 1)
+    penv.close(); env.close()
