@@ -601,6 +601,9 @@ class MultiBlockSimulation:
         self.total_time, self.total_step, self.last_substeps, self.last_iterations = 0.0, 0, 0, (0, 0, 0)
 
     def make_divergence_free(self) -> bool:
+        # the reference ends the call with end_step(time_step = 1): the counters advance (PISOtorch_simulation.py:1334, 1427)
+        self.total_time += 1.0
+        self.total_step += 1
         return self.domain.make_divergence_free(pressure_tol=self.pressure_tol, pressure_non_ortho_steps=self.pressure_non_ortho_steps,
                                                 pressure_use_bicgstab=self.pressure_use_BiCG, outflow=self.outflow,
                                                 outflow_velocity=self.outflow_velocity, outflow_tol=self.outflow_tol,

@@ -349,6 +349,9 @@ class Simulation:
         """``make_divergence_free`` (PISOtorch_simulation.py:1320-1429)."""
         infos = self._solver.make_divergence_free(get_solver_tolerance(tol if tol is not None else self.pressure_tol),
                                                   max_iterations)
+        # the reference ends the call with end_step(time_step = 1): the counters advance (PISOtorch_simulation.py:1334, 1427)
+        self.total_step += 1
+        self.total_time += 1.0
         return all(i.converged for i in infos)
 
 

@@ -206,7 +206,9 @@ def test_make_divergence_free_like_the_reference():
                 return True
 
         kw = {k: v for k, v in case["constructor"].items() if k in ("pressure_tol", "pressure_non_ortho_steps")}
-        assert MultiBlockSimulation(StubMb(), dt=0.1, **kw).make_divergence_free() is True
+        sim = MultiBlockSimulation(StubMb(), dt=0.1, **kw)
+        assert sim.make_divergence_free() is True
+        assert (sim.total_step, sim.total_time) == (1, calls[-1]["time_step"])         # end_step(time_step = 1)
         assert np.float32(seen["pressure_tol"]) == np.float32(solves[0]["tol"]) and seen["pressure_non_ortho_steps"] == n_ps
         assert "max_iterations" not in seen        # the entry's default applies:
     assert inspect.signature(MultiBlockDomain.make_divergence_free).parameters["max_iterations"].default == 1000
