@@ -246,6 +246,7 @@ class CylinderEnvBase(FluidEnv):
         path = self._get_domain_dir(idx) / mode.value
         if not Path(str(path) + ".json").exists():
             return super().load_initial_domain(idx, mode)
+        self._pinned_initial = True      # (see FluidEnv.load_initial_domain)
         if self._domain is None:
             self._set_initial_state(randomize=False)
         loaded = load_multiblock_domain(str(path), device=self._cuda_device, batch=self._num_envs)

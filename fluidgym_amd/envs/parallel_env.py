@@ -138,6 +138,26 @@ class ParallelFluidEnv:
     def differentiable(self) -> bool:
         return False
 
+    # (parallel_env.py:70-113: answered by the reference from a dummy env; here from this rank's shard)
+    @property
+    def cuda_device(self) -> torch.device:
+        return self._env.cuda_device
+
+    @property
+    def episode_length(self) -> int:
+        return self._env.episode_length
+
+    @property
+    def metrics(self):
+        return self._env.metrics
+
+    @property
+    def use_marl(self) -> bool:
+        return self._env.use_marl
+
+    def render(self, save: bool = False, render_3d: bool = False, filename: Optional[str] = None, output_path: Any = None):
+        raise NotImplementedError("Rendering is not implemented for ParallelFluidEnv.")      # parallel_env.py:289-319
+
     @property
     def num_envs(self) -> int:
         return self._n_total

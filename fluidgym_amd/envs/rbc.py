@@ -81,6 +81,7 @@ class RBCEnvBase(FluidEnv):
     _n_sensors_per_heater: int = 4
     _n_sensors_y: int = 8
     _metrics = ["nusselt"]
+    _initial_domain_restart = True      # rbc_env_base.py:126: one development per mode
 
     def __init__(self, rayleigh_number, prandtl_number, n_heaters, resolution, dt, adaptive_cfl, step_length,
                  episode_length, ndims, local_obs_window=11, local_reward_weight=None, uniform_grid=False,
@@ -372,10 +373,14 @@ class RBCEnvBase(FluidEnv):
 
 
 class RBCEnv2D(RBCEnvBase):
+    _initial_domain_steps = 283      # rbc_env_2d.py:110 (uncontrolled env steps init() develops a state for)
+
     def __init__(self, **kw):
         super().__init__(ndims=2, **kw)
 
 
 class RBCEnv3D(RBCEnvBase):
+    _initial_domain_steps = 1500     # rbc_env_3d.py:118
+
     def __init__(self, **kw):
         super().__init__(ndims=3, **kw)

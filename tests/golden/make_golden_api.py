@@ -1,0 +1,88 @@
+"""Public API surface of the reference's classes on the drop-in boundary, extracted HERE from the reference's
+sources with ``ast`` (names, parameters, defaults -- no source text is stored): ``FluidEnv`` (``envs/fluid_env.py``),
+``ParallelFluidEnv`` (``envs/parallel_env.py``), the env-side ``Simulation`` (``simulation/simulation.py``), ``EnvMode`` /
+``FluidEnvLike`` (``types.py``) and the registry functions (``registry.py``).
+
+    python tests/golden/make_golden_api.py        ->  tests/golden/reference_api.json
+
+``tests/test_api_surface.py`` holds ``fluidgym_amd``'s classes against it.
+"""
+import ast
+import json
+import os
+
+REF = "/root/reference/src/fluidgym"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _params(fn: ast.FunctionDef):
+    a = fn.args
+    pos = list(a.posonlyargs) + list(a.args)
+    defaults = [None] * (len(pos) - len(a.defaults)) + list(a.defaults)
+    out = []
+    for arg, d in zip(pos, defaults):
+        if arg.arg in ("self", "cls"):
+            continue
+        out.append({"name": arg.arg, "kind": "positional", "has_default": d is not None, "default": None if d is None else ast.unparse(d)})
+    if a.vararg:
+        out.append({"name": a.vararg.arg, "kind": "var_positional", "has_default": False, "default": None})
+    for arg, d in zip(a.kwonlyargs, a.kw_defaults):
+        out.append({"name": arg.arg, "kind": "keyword_only", "has_default": d is not None, "default": None if d is None else ast.unparse(d)})
+    if a.kwarg:
+        out.append({"name": a.kwarg.arg, "kind": "var_keyword", "has_default": False, "default": None})
+    return out
+
+
+def _decorators(fn):
+    return [ast.unparse(d) for d in fn.decorator_list]
+
+
+def describe_class(path, name):
+    tree = ast.parse(open(path).read())
+    cls = next(n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name == name)
+    methods, properties, setters, attrs = {}, [], [], []
+    for n in cls.body:
+        if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef)):
+            decs = _decorators(n)
+            if "property" in decs:
+                properties.append(n.name)
+            elif any(d.endswith(".setter") for d in decs):
+                setters.append(n.name)
+            elif not n.name.startswith("_") or n.name in ("__init__", "__len__"):
+                methods[n.name] = {"params": _params(n), "abstract": "abstractmethod" in decs,
+                                   "static": "staticmethod" in decs, "classmethod": "classmethod" in decs}
+        elif isinstance(n, ast.AnnAssign) and isinstance(n.target, ast.Name) and not n.target.id.startswith("_"):
+            attrs.append(n.target.id)
+        elif isinstance(n, ast.Assign):
+            for t in n.targets:
+                if isinstance(t, ast.Name) and not t.id.startswith("_"):
+                    attrs.append(t.id)
+    return {"file": os.path.relpath(path, REF), "bases": [ast.unparse(b) for b in cls.bases], "methods": methods,
+            "properties": sorted(p for p in properties if not p.startswith("_")), "setters": sorted(set(setters)), "class_attributes": attrs}
+
+
+def describe_functions(path):
+    tree = ast.parse(open(path).read())
+    return {n.name: {"params": _params(n)} for n in tree.body if isinstance(n, ast.FunctionDef) and not n.name.startswith("_")}
+
+
+def main():
+    out = {
+        "FluidEnv": describe_class(f"{REF}/envs/fluid_env.py", "FluidEnv"),
+        "ParallelFluidEnv": describe_class(f"{REF}/envs/parallel_env.py", "ParallelFluidEnv"),
+        "Simulation": describe_class(f"{REF}/simulation/simulation.py", "Simulation"),
+        "EnvMode": describe_class(f"{REF}/types.py", "EnvMode"),
+        "FluidEnvLike": describe_class(f"{REF}/types.py", "FluidEnvLike"),
+        "registry": describe_functions(f"{REF}/registry.py"),
+    }
+    with open(os.path.join(OUT, "reference_api.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for k, v in out.items():
+        if "methods" in v:
+            print(k, len(v["methods"]), "methods,", len(v["properties"]), "properties")
+        else:
+            print(k, sorted(v))
+
+
+if __name__ == "__main__":
+    main()

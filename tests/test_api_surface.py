@@ -1,0 +1,103 @@
+"""The drop-in surface against the reference's own: every public method, property and registry function of
+the reference's ``FluidEnv`` / ``ParallelFluidEnv`` / ``Simulation`` / ``FluidEnvLike`` / ``EnvMode`` (extracted from its sources by
+``tests/golden/make_golden_api.py`` -> ``tests/golden/reference_api.json``) exists here with the same parameter names, order and
+defaults; what is deliberately different is listed with its reason."""
+import inspect
+import json
+import os
+
+import pytest
+
+import fluidgym_amd
+from fluidgym_amd.envs.fluid_env import FluidEnv
+from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+from fluidgym_amd.simulation.simulation import Simulation
+from fluidgym_amd.types import EnvMode, FluidEnvLike
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "reference_api.json")) as f:
+    API = json.load(f)
+
+MINE = {"FluidEnv": FluidEnv, "ParallelFluidEnv": ParallelFluidEnv, "Simulation": Simulation, "FluidEnvLike": FluidEnvLike}
+
+# members of the reference that are deliberately absent or different here, with the reason (everything else must match)
+NOT_BUILT = {
+}
+# parameters whose default differs on purpose
+DEFAULT_DIFFERS = {
+}
+
+
+def _mine_params(fn):
+    out = []
+    for p in inspect.signature(fn).parameters.values():
+        if p.name in ("self", "cls"):
+            continue
+        out.append(p)
+    return out
+
+
+@pytest.mark.parametrize("cls_name", list(MINE))
+def test_every_public_member_of_the_reference_exists(cls_name):
+    ref, mine = API[cls_name], MINE[cls_name]
+    missing = []
+    for m in ref["methods"]:
+        if (cls_name, m) in NOT_BUILT:
+            continue
+        if not callable(getattr(mine, m, None)):
+            missing.append(m + "()")
+    for p in ref["properties"]:
+        if (cls_name, p) in NOT_BUILT:
+            continue
+        if not hasattr(mine, p) and p not in getattr(mine, "__annotations__", {}):
+            missing.append(p)
+    assert not missing, f"{cls_name}: missing {missing}"
+
+
+@pytest.mark.parametrize("cls_name", ["FluidEnv", "ParallelFluidEnv", "Simulation"])
+def test_reference_parameters_are_accepted_with_the_same_names_and_defaults(cls_name):
+    ref, mine = API[cls_name], MINE[cls_name]
+    problems = []
+    for m, spec in ref["methods"].items():
+        if (cls_name, m) in NOT_BUILT or not callable(getattr(mine, m, None)):
+            continue
+        my = _mine_params(getattr(mine, m))
+        my_names = [p.name for p in my]
+        takes_kwargs = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in my)
+        last = -1
+        for rp in spec["params"]:
+            if rp["kind"] in ("var_positional", "var_keyword"):
+                continue
+            if rp["name"] not in my_names:
+                if not takes_kwargs:
+                    problems.append(f"{m}: parameter {rp['name']!r} not accepted")
+                continue
+            idx = my_names.index(rp["name"])
+            if rp["kind"] == "positional" and my[idx].kind is not inspect.Parameter.KEYWORD_ONLY:
+                if idx < last:
+                    problems.append(f"{m}: parameter {rp['name']!r} out of order")
+                last = idx
+            if rp["has_default"] and (cls_name, m, rp["name"]) not in DEFAULT_DIFFERS:
+                d = my[idx].default
+                if d is inspect.Parameter.empty:
+                    problems.append(f"{m}: {rp['name']!r} has a default in the reference ({rp['default']}), none here")
+                else:
+                    try:
+                        want = eval(rp["default"], {"EnvMode": EnvMode, "torch": __import__("torch")})
+                    except Exception:
+                        continue          # a default that is an expression of the reference's own modules: not comparable
+                    if callable(want) and callable(d):
+                        continue
+                    if want != d and not (want is None and d is None):
+                        problems.append(f"{m}: default of {rp['name']!r} is {d!r}, the reference's {rp['default']}")
+    assert not problems, f"{cls_name}:\n  " + "\n  ".join(problems)
+
+
+def test_env_mode_members_and_registry_functions():
+    assert [a for a in API["EnvMode"]["class_attributes"]] == [m.name for m in EnvMode]
+    for fn, spec in API["registry"].items():
+        mine = getattr(fluidgym_amd, fn)
+        names = [p.name for p in inspect.signature(mine).parameters.values()]
+        for rp in spec["params"]:
+            if rp["kind"] in ("var_positional", "var_keyword"):
+                continue
+            assert rp["name"] in names, (fn, rp["name"])

@@ -200,3 +200,46 @@ def test_load_multiblock_domain_reads_the_reference_written_file():
                 assert np.array_equal(blk.boundary(f)[0].cpu().numpy().reshape(-1), exp[f"mb_bvel{k}_{f}"][0].reshape(2, -1).reshape(-1))
     ref.close()
     dom.close()
+
+
+@pytest.mark.gpu
+def test_init_generates_the_initial_domains_and_resets_load_them(tmp_path, monkeypatch):
+    """``FluidEnv.init`` (fluid_env.py:1114-1190): for an index, every mode gets a developed state written in the reference's
+    layout (RBC develops each mode separately, seeds MODE_SEEDS[mode] + idx); afterwards resets of an env that asks for initial
+    domains load them like the reference's (index 0 without randomisation, a drawn index with it; a missing index is the
+    reference's "Initial domain not found")."""
+    import fluidgym_amd
+    from fluidgym_amd.envs import fluid_env as FE
+    from fluidgym_amd.types import EnvMode
+
+    monkeypatch.setenv("FLUIDGYM_DATA_PATH", str(tmp_path))
+    kw = dict(n_heaters=4, resolution=8, randomize_initial_state=False, load_initial_domain=True)
+    env = fluidgym_amd.make("RBC2D-easy-v0", num_envs=2, **kw)
+    env._initial_domain_steps = 3          # (283 in the reference: a development of minutes)
+    assert env._initial_domain_restart is True and not env._initial_domain_ids_on_disk()
+    env.reset(seed=1)                      # nothing on disk: generated state, no index drawn
+    generated = env._block.velocity.clone()
+    env.init(domain_idxs=[0])
+    base = tmp_path / "initial_domains" / env.initial_domain_id / "0"
+    assert sorted(p.name for p in base.iterdir()) == ["test.json", "test.npz", "train.json", "train.npz", "val.json", "val.npz"]
+    assert env._check_initial_domains_exists(idx=0) and not env._check_initial_domains_exists(idx=1)
+    assert env._enable_actions and env._load_domain_on_reset
+    # a reset now starts from the file of the current mode
+    states = {}
+    for mode in (EnvMode.TRAIN, EnvMode.VAL):
+        env.mode = mode
+        env.reset(seed=5, randomize=False)
+        states[mode] = env._block.velocity.clone()
+        probe = fluidgym_amd.make("RBC2D-easy-v0", num_envs=1, **dict(kw, load_initial_domain=False))
+        probe.seed(0)
+        probe.load_initial_domain(0, mode)
+        assert torch.equal(states[mode][0], probe._block.velocity[0]) and torch.equal(states[mode][1], probe._block.velocity[0])
+        probe.close()
+    assert not torch.equal(states[EnvMode.TRAIN], states[EnvMode.VAL])       # separate developments (different seeds)
+    assert not torch.equal(states[EnvMode.TRAIN], generated)
+    # with randomisation the index is drawn from the env's generator: only index 0 exists
+    drawn = int(np.random.default_rng(7).integers(0, FE.N_INITIAL_DOMAINS))
+    if drawn != 0:
+        with pytest.raises(RuntimeError, match="Initial domain not found"):
+            env.reset(seed=7, randomize=True)
+    env.close()
