@@ -28,6 +28,7 @@ def _lazy(module: str, cls: str):
 
         return getattr(importlib.import_module(module, __name__), cls)(**kw)
 
+    ctor.__name__ = ctor.__qualname__ = cls      # the registry shows the class the id stands for (fluidgym/__init__.py)
     return ctor
 
 
@@ -45,9 +46,15 @@ def _register_all():
     register("RBC2D-easy-v0", r2, R2)
     register("RBC2D-medium-v0", r2, R2, rayleigh_number=4e5, adaptive_cfl=0.5)
     register("RBC2D-hard-v0", r2, R2, rayleigh_number=8e5, adaptive_cfl=0.5)
-    register("RBC2D-wide-easy-v0", r2, R2, n_heaters=24, aspect_ratio=2.0)
+    register("RBC2D-wide-easy-v0", r2, R2, n_heaters=24, aspect_ratio=2)
+    register("RBC2D-wide-medium-v0", r2, R2, rayleigh_number=4e5, adaptive_cfl=0.5, n_heaters=24, aspect_ratio=2)
+    register("RBC2D-wide-hard-v0", r2, R2, rayleigh_number=8e5, adaptive_cfl=0.5, n_heaters=24, aspect_ratio=2)
     register("RBC2D-baseline-v0", r2, R2, n_heaters=64, resolution=8, aspect_ratio=2.55)  # 512x128 (BASELINE config 3)
-    register("RBC3D-easy-v0", r3, R3)
+    # 3-D: Ra 6e3 / 8e3 / 1e4, multi-agent by default (fluidgym/__init__.py; rbc_env_3d.py default config)
+    for tag, extra in (("", {}), ("wide-", dict(n_heaters=16, aspect_ratio=2))):
+        register(f"RBC3D-{tag}easy-v0", r3, R3, **extra)
+        register(f"RBC3D-{tag}medium-v0", r3, R3, rayleigh_number=8e3, **extra)
+        register(f"RBC3D-{tag}hard-v0", r3, R3, rayleigh_number=1e4, **extra)
     # reference ids (fluidgym/__init__.py:215-300): Small/Large x bottom/both x easy/medium/hard = Re_tau 180 / 330 / 550
     tcf = {"bottom": _lazy(".envs.tcf", "TCF3DBottomEnv"), "both": _lazy(".envs.tcf", "TCF3DBothEnv")}
     for size, cfg in (("Small", TS), ("Large", TL)):

@@ -52,20 +52,23 @@ RBC_2D_DEFAULT_CONFIG = {
     "aspect_ratio": 1.0,
     "use_marl": False,
     "dtype": torch.float32,
-    "load_initial_domain": False,
-    "load_domain_statistics": False,
+    "load_initial_domain": True,      # (as the reference; without files on disk the state is generated, fluid_env.py here)
+    "load_domain_statistics": True,
     "randomize_initial_state": True,
     "enable_actions": True,
     "differentiable": False,
 }
 
-RBC_3D_DEFAULT_CONFIG = {
+RBC_3D_DEFAULT_CONFIG = {          # rbc_env_3d.py's default config (held by tests/golden/reference_registry.json)
     **RBC_2D_DEFAULT_CONFIG,
-    "rayleigh_number": 2.5e3,
+    "rayleigh_number": 6e3,
     "n_heaters": 8,
-    "resolution": 4,
+    "resolution": 8,
     "adaptive_cfl": 0.5,
     "dt": 0.05,
+    "local_obs_window": 3,
+    "local_reward_weight": 0.0015,
+    "use_marl": True,
 }
 
 

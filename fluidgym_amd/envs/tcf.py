@@ -52,9 +52,11 @@ SMALL_TCF_3D_DEFAULT_CONFIG = {
     "local_reward_weight": 0.0,
     "use_marl": True,   # tcf_env.py:73
     "init_with_noise": True,
+    "C_smag": 0.0,            # (only 0 / False are built: tcf_env.py:441-474 is the Smagorinsky model)
+    "use_van_driest": False,
     "dtype": torch.float32,
-    "load_initial_domain": False,
-    "load_domain_statistics": False,
+    "load_initial_domain": True,
+    "load_domain_statistics": True,
     "randomize_initial_state": True,
     "enable_actions": True,
     "differentiable": False,

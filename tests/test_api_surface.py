@@ -6,6 +6,7 @@ import inspect
 import json
 import os
 
+import numpy as np
 import pytest
 
 import fluidgym_amd
@@ -101,3 +102,30 @@ def test_env_mode_members_and_registry_functions():
             if rp["kind"] in ("var_positional", "var_keyword"):
                 continue
             assert rp["name"] in names, (fn, rp["name"])
+
+
+def test_every_registered_id_of_the_reference_with_the_same_class_and_default_arguments():
+    """``tests/golden/reference_registry.json`` (made by ``make_golden_registry.py`` from ``fluidgym/__init__.py:28-352`` and the
+    ``*_DEFAULT_CONFIG`` dictionaries): every id the reference registers is registered here, for a class of the same name, and
+    ``make(id)`` hands that class the same keyword arguments (additional ones, e.g. ``initial_domain_steps``, are this package's)."""
+    import torch
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_registry.json")) as f:
+        ref = json.load(f)
+    specs = fluidgym_amd.registry.env_specs
+    problems = []
+    for env_id, want in ref.items():
+        if env_id not in specs:
+            problems.append(f"{env_id}: not registered")
+            continue
+        spec = specs[env_id]
+        if spec.entry_point.__name__ != want["entry_point"]:
+            problems.append(f"{env_id}: class {spec.entry_point.__name__}, the reference's {want['entry_point']}")
+        for k, text in want["kwargs"].items():
+            value = eval(text, {"torch": torch, "np": np})
+            if k not in spec.kwargs:
+                problems.append(f"{env_id}: default argument {k!r} missing (reference: {text})")
+            elif spec.kwargs[k] != value:
+                problems.append(f"{env_id}: {k} = {spec.kwargs[k]!r}, the reference's {text}")
+    assert not problems, "\n  " + "\n  ".join(problems)
+    assert len(ref) == 39

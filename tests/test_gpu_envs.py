@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 SMALL = {
     "ChannelJet2D-v0": dict(resolution_x=64, resolution_y=32),
     "RBC2D-easy-v0": dict(n_heaters=4, resolution=8),
-    "RBC3D-easy-v0": dict(n_heaters=2, resolution=4),
+    "RBC3D-easy-v0": dict(n_heaters=2, resolution=4, use_marl=False),       # (multi-agent by default, like the TCF ids)
     "TCFSmall3D-both-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False),
     "TCFSmall3D-bottom-easy-v0": dict(resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False),
 }
@@ -267,6 +267,8 @@ def test_multi_agent_contract(env_id, num_envs):
 # ---- the reference's own env tests (tests/env_utils/test_fluid_env.py, tests/envs/test_all_envs.py), restated for the
 # ids that are built here; grids shrunk through kwargs so the whole file stays within seconds -----------------------------
 REDUCED = {"ChannelJet": dict(resolution_x=64, resolution_y=32), "RBC2D": dict(n_heaters=4, resolution=8, local_obs_window=3),
+           # (the wide 3-D ids keep their aspect ratio of 2: four heaters so that the render grid is 13 high like the others)
+           "RBC3D-wide": dict(n_heaters=4, resolution=4, local_obs_window=1),
            "RBC3D": dict(n_heaters=2, resolution=4, local_obs_window=1), "TCF": dict(resolution_x_z=16, resolution_y=16, resolution_x=None, resolution_z=None)}
 
 
