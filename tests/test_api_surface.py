@@ -129,3 +129,18 @@ def test_every_registered_id_of_the_reference_with_the_same_class_and_default_ar
                 problems.append(f"{env_id}: {k} = {spec.kwargs[k]!r}, the reference's {text}")
     assert not problems, "\n  " + "\n  ".join(problems)
     assert len(ref) == 39
+
+
+def test_every_reference_id_constructs_with_its_default_arguments():
+    """``make(id)`` with nothing but the id -- the reference's own usage -- builds the env for every id it registers (construction
+    touches no GPU): the class accepts every default argument, the agent mode is the reference's default for that id."""
+    import torch
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_registry.json")) as f:
+        ref = json.load(f)
+    for env_id, want in ref.items():
+        env = fluidgym_amd.make(env_id, cuda_device=torch.device("cpu"))
+        assert env.use_marl is eval(want["kwargs"]["use_marl"]), env_id
+        assert isinstance(env.action_space, fluidgym_amd.spaces.Box) and isinstance(env.observation_space, fluidgym_amd.spaces.Dict)
+        assert env.episode_length == eval(want["kwargs"]["episode_length"]) and env.n_agents >= 1
+        assert env.id and env.initial_domain_id
