@@ -244,6 +244,9 @@ class RBCEnvBase(FluidEnv):
             control = self._smooth_profile(sz).view(self._num_envs, 1, self._x, 1, self._x)
         self._bottom_plate.setPassiveScalar(control)
 
+    def plot_actuation(self, *args, **kwargs) -> None:
+        raise NotImplementedError("plot_actuation: plotting is not part of fluidgym_amd")
+
     # ---- observation / reward -------------------------------------------------------------
     @property
     def render_shape(self):

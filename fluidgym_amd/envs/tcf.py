@@ -104,6 +104,26 @@ class TCF3DBottomEnv(FluidEnv):
         super().__init__(dt=(step_length / 10 if dt is None else dt), adaptive_cfl=adaptive_cfl, step_length=step_length,
                          episode_length=episode_length, ndims=3, **kw)
 
+    @property
+    def scale_actions(self) -> bool:
+        """Whether actions are scaled by u_wall (tcf_env.py:429-436)."""
+        return self._scale_actions
+
+    @scale_actions.setter
+    def scale_actions(self, value: bool) -> None:
+        self._scale_actions = value
+
+    # opposition-control baseline episodes next to the initial domains (tcf_env.py:1017-1062)
+    def save_opposition_control_episode(self, idx: int, mode, df) -> None:
+        path = self._get_domain_dir(idx=idx)
+        df.to_csv(path / f"{mode.value}_opposition_control_{self._actuation}_episode.csv", index=False)
+
+    def load_opposition_control_episode(self, idx: int, mode):
+        import pandas as pd
+
+        path = self._get_domain_dir(idx=idx)
+        return pd.read_csv(path / f"{mode.value}_opposition_control_{self._actuation}_episode.csv")
+
     # ---- unit conversions (tcf_env.py:323-341) ---------------------------------------------
     def _t_wall_to_t(self, t_wall: float) -> float:
         return t_wall * self._nu / self._u_wall ** 2

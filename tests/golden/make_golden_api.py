@@ -66,6 +66,36 @@ def describe_functions(path):
     return {n.name: {"params": _params(n)} for n in tree.body if isinstance(n, ast.FunctionDef) and not n.name.startswith("_")}
 
 
+def env_class_surfaces(entry_points):
+    """effective public surface of each registered env class: members of the class and of its bases inside the reference's env
+    package (bases resolved by name), constructor parameters of the class itself"""
+    import glob
+
+    classes = {}
+    for path in glob.glob(f"{REF}/envs/**/*.py", recursive=True):
+        for n in ast.parse(open(path).read()).body:
+            if isinstance(n, ast.ClassDef):
+                classes[n.name] = (path, n)
+    out = {}
+    for name in entry_points:
+        methods, props, order = {}, set(), []
+        todo = [name]
+        while todo:
+            c = todo.pop(0)
+            if c not in classes or c in order:
+                continue
+            order.append(c)
+            todo += [ast.unparse(b) for b in classes[c][1].bases]
+        for c in reversed(order):                    # most derived last: overrides win
+            d = describe_class(classes[c][0], c)
+            methods.update(d["methods"])
+            props.update(d["properties"])
+        init = describe_class(classes[name][0], name)["methods"].get("__init__")
+        out[name] = {"mro_in_package": order, "methods": sorted(m for m in methods if m != "__init__"), "properties": sorted(props),
+                     "init_params": None if init is None else init["params"]}
+    return out
+
+
 def main():
     out = {
         "FluidEnv": describe_class(f"{REF}/envs/fluid_env.py", "FluidEnv"),
@@ -74,12 +104,17 @@ def main():
         "EnvMode": describe_class(f"{REF}/types.py", "EnvMode"),
         "FluidEnvLike": describe_class(f"{REF}/types.py", "FluidEnvLike"),
         "registry": describe_functions(f"{REF}/registry.py"),
+        "env_classes": env_class_surfaces(["CylinderJetEnv2D", "CylinderRotEnv2D", "CylinderJetEnv3D", "AirfoilEnv2D", "AirfoilEnv3D",
+                                           "RBCEnv2D", "RBCEnv3D", "TCF3DBothEnv", "TCF3DBottomEnv"]),
     }
     with open(os.path.join(OUT, "reference_api.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out.items():
         if "methods" in v:
             print(k, len(v["methods"]), "methods,", len(v["properties"]), "properties")
+        elif k == "env_classes":
+            for c, d in v.items():
+                print(" ", c, d["mro_in_package"], len(d["methods"]), "methods,", len(d["properties"]), "properties")
         else:
             print(k, sorted(v))
 

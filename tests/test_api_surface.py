@@ -144,3 +144,47 @@ def test_every_reference_id_constructs_with_its_default_arguments():
         assert isinstance(env.action_space, fluidgym_amd.spaces.Box) and isinstance(env.observation_space, fluidgym_amd.spaces.Dict)
         assert env.episode_length == eval(want["kwargs"]["episode_length"]) and env.n_agents >= 1
         assert env.id and env.initial_domain_id
+
+
+def test_env_classes_have_the_reference_members_and_constructor_parameters():
+    """For each of the nine registered env classes: every public method / property of the reference's class (with its bases inside
+    the env package) exists on the class of the same name here, and the reference's constructor parameters are accepted."""
+    import importlib
+
+    where = {"Cylinder": "cylinder", "Airfoil": "airfoil", "RBC": "rbc", "TCF": "tcf"}
+    problems = []
+    for name, ref in API["env_classes"].items():
+        mod = next(m for k, m in where.items() if name.startswith(k))
+        cls = getattr(importlib.import_module(f"fluidgym_amd.envs.{mod}"), name)
+        for m in ref["methods"]:
+            if not callable(getattr(cls, m, None)):
+                problems.append(f"{name}.{m}() missing")
+        for p in ref["properties"]:
+            if not hasattr(cls, p):
+                problems.append(f"{name}.{p} missing")
+        if ref["init_params"] is not None:
+            mine = inspect.signature(cls.__init__).parameters
+            takes_kwargs = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in mine.values())
+            for rp in ref["init_params"]:
+                if rp["kind"] in ("var_positional", "var_keyword"):
+                    continue
+                if rp["name"] not in mine and not takes_kwargs:
+                    problems.append(f"{name}.__init__: parameter {rp['name']!r} not accepted")
+    assert not problems, "\n  " + "\n  ".join(sorted(problems))
+
+
+def test_tcf_opposition_control_episode_files_round_trip(tmp_path, monkeypatch):
+    """tcf_env.py:1017-1062: ``<mode>_opposition_control_<actuation>_episode.csv`` next to the initial domain of that index."""
+    import pandas as pd
+    import torch
+
+    monkeypatch.setenv("FLUIDGYM_DATA_PATH", str(tmp_path))
+    env = fluidgym_amd.make("TCFSmall3D-both-easy-v0", cuda_device=torch.device("cpu"))
+    env._get_domain_dir(2).mkdir(parents=True)
+    df = pd.DataFrame({"step": [0, 1, 2], "wall_stress": [1.0, 0.9, 0.85]})
+    env.save_opposition_control_episode(2, EnvMode.VAL, df)
+    assert (env._get_domain_dir(2) / "val_opposition_control_both_episode.csv").exists()
+    assert env.load_opposition_control_episode(2, EnvMode.VAL).equals(df)
+    assert env.scale_actions is True
+    env.scale_actions = False
+    assert env._scale_actions is False
