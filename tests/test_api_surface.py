@@ -54,7 +54,7 @@ def test_every_public_member_of_the_reference_exists(cls_name):
     assert not missing, f"{cls_name}: missing {missing}"
 
 
-@pytest.mark.parametrize("cls_name", ["FluidEnv", "ParallelFluidEnv", "Simulation"])
+@pytest.mark.parametrize("cls_name", ["FluidEnv", "ParallelFluidEnv", "Simulation", "FluidEnvLike"])
 def test_reference_parameters_are_accepted_with_the_same_names_and_defaults(cls_name):
     ref, mine = API[cls_name], MINE[cls_name]
     problems = []
