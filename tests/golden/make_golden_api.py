@@ -90,9 +90,23 @@ def env_class_surfaces(entry_points):
             d = describe_class(classes[c][0], c)
             methods.update(d["methods"])
             props.update(d["properties"])
+        consts = {}
+        for c in reversed(order):                    # class-level constants with literal values (most derived wins)
+            for n in classes[c][1].body:
+                tgt, val = None, None
+                if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name):
+                    tgt, val = n.targets[0].id, n.value
+                elif isinstance(n, ast.AnnAssign) and isinstance(n.target, ast.Name) and n.value is not None:
+                    tgt, val = n.target.id, n.value
+                if tgt is None:
+                    continue
+                try:
+                    consts[tgt] = ast.literal_eval(val)
+                except Exception:
+                    consts.pop(tgt, None)
         init = describe_class(classes[name][0], name)["methods"].get("__init__")
         out[name] = {"mro_in_package": order, "methods": sorted(m for m in methods if m != "__init__"), "properties": sorted(props),
-                     "init_params": None if init is None else init["params"]}
+                     "init_params": None if init is None else init["params"], "class_constants": consts}
     return out
 
 

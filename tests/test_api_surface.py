@@ -188,3 +188,23 @@ def test_tcf_opposition_control_episode_files_round_trip(tmp_path, monkeypatch):
     assert env.scale_actions is True
     env.scale_actions = False
     assert env._scale_actions is False
+
+
+def test_class_level_constants_shared_with_the_reference_have_its_values():
+    """class attributes with literal values (metrics, initial-domain lengths and restart flags, smoothing factors, jet geometry ...)
+    that exist under the same name on both sides carry the reference's value; ``_default_render_key`` is rendering."""
+    import importlib
+
+    where = {"Cylinder": "cylinder", "Airfoil": "airfoil", "RBC": "rbc", "TCF": "tcf"}
+    compared, problems = 0, []
+    for name, ref in API["env_classes"].items():
+        cls = getattr(importlib.import_module("fluidgym_amd.envs." + next(m for k, m in where.items() if name.startswith(k))), name)
+        for k, v in ref["class_constants"].items():
+            if k == "_default_render_key" or not hasattr(cls, k) or isinstance(getattr(cls, k), property):
+                continue
+            mine = getattr(cls, k)
+            compared += 1
+            if (list(mine) if isinstance(mine, tuple) else mine) != v:
+                problems.append(f"{name}.{k} = {mine!r}, the reference's {v!r}")
+    assert not problems, "\n  " + "\n  ".join(problems)
+    assert compared > 60
