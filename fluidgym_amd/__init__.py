@@ -17,6 +17,7 @@ from __future__ import annotations
 import numpy as np
 
 from .registry import make, register, registry  # noqa: F401
+from .config import config  # noqa: F401
 from .simulation.policy import get_solver_policy, set_solver_policy  # noqa: F401
 
 __version__ = "0.1.0"

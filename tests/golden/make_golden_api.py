@@ -118,6 +118,9 @@ def main():
         "EnvMode": describe_class(f"{REF}/types.py", "EnvMode"),
         "FluidEnvLike": describe_class(f"{REF}/types.py", "FluidEnvLike"),
         "registry": describe_functions(f"{REF}/registry.py"),
+        "Config": describe_class(f"{REF}/config.py", "Config"),
+        "package_all": ast.literal_eval(next(n.value for n in ast.parse(open(f"{REF}/__init__.py").read()).body
+                                             if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "__all__")),
         "env_classes": env_class_surfaces(["CylinderJetEnv2D", "CylinderRotEnv2D", "CylinderJetEnv3D", "AirfoilEnv2D", "AirfoilEnv3D",
                                            "RBCEnv2D", "RBCEnv3D", "TCF3DBothEnv", "TCF3DBottomEnv"]),
     }
@@ -129,8 +132,10 @@ def main():
         elif k == "env_classes":
             for c, d in v.items():
                 print(" ", c, d["mro_in_package"], len(d["methods"]), "methods,", len(d["properties"]), "properties")
-        else:
+        elif isinstance(v, dict):
             print(k, sorted(v))
+        else:
+            print(k, v)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,8 @@ from fluidgym_amd.types import EnvMode, FluidEnvLike
 with open(os.path.join(os.path.dirname(__file__), "golden", "reference_api.json")) as f:
     API = json.load(f)
 
-MINE = {"FluidEnv": FluidEnv, "ParallelFluidEnv": ParallelFluidEnv, "Simulation": Simulation, "FluidEnvLike": FluidEnvLike}
+MINE = {"FluidEnv": FluidEnv, "ParallelFluidEnv": ParallelFluidEnv, "Simulation": Simulation, "FluidEnvLike": FluidEnvLike,
+        "Config": type(fluidgym_amd.config)}
 
 # members of the reference that are deliberately absent or different here, with the reason (everything else must match)
 NOT_BUILT = {
@@ -54,7 +55,7 @@ def test_every_public_member_of_the_reference_exists(cls_name):
     assert not missing, f"{cls_name}: missing {missing}"
 
 
-@pytest.mark.parametrize("cls_name", ["FluidEnv", "ParallelFluidEnv", "Simulation", "FluidEnvLike"])
+@pytest.mark.parametrize("cls_name", ["FluidEnv", "ParallelFluidEnv", "Simulation", "FluidEnvLike", "Config"])
 def test_reference_parameters_are_accepted_with_the_same_names_and_defaults(cls_name):
     ref, mine = API[cls_name], MINE[cls_name]
     problems = []
@@ -208,3 +209,25 @@ def test_class_level_constants_shared_with_the_reference_have_its_values():
                 problems.append(f"{name}.{k} = {mine!r}, the reference's {v!r}")
     assert not problems, "\n  " + "\n  ".join(problems)
     assert compared > 60
+
+
+def test_package_exports_and_config_object(tmp_path):
+    """``fluidgym.__all__`` = config, make; the config object points the envs at their data directory like the reference's
+    (``config.update("local_data_path", ...)``, config.py:82-104) and rejects what the reference rejects."""
+    import torch
+
+    for name in API["package_all"]:
+        assert hasattr(fluidgym_amd, name), name
+    cfg = type(fluidgym_amd.config)()
+    assert cfg["dtype"] is torch.float32 and cfg.hf_intial_domains_repo_id == "safe-autonomous-systems/fluidgym-data"
+    cfg["local_data_path"] = str(tmp_path)
+    assert cfg.local_data_path == tmp_path.resolve() and cfg.initial_domains_path == tmp_path.resolve() / "initial_domains"
+    cfg.update("dtype", "FP64")
+    assert cfg.dtype is torch.float64
+    with pytest.raises(ValueError, match="not a valid configuration key"):
+        cfg.update("nonsense", "1")
+    with pytest.raises(ValueError, match="not a valid data type"):
+        cfg.update("dtype", "FP16")
+    with pytest.raises(ValueError, match="Unhandled configuration key"):
+        cfg.update("hf_intial_domains_repo_id", "x/y")
+    assert len(cfg.palette) == 8
