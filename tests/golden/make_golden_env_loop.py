@@ -237,7 +237,16 @@ def main():
         env.step(torch.zeros(2))
     except RuntimeError as e:
         errors["step_after_truncation"] = str(e)
-    out = {"init": cases, "step": {"episode_length": 3, "terminated_truncated": flags, "errors": errors, "n_sim_steps": env.n_sim_steps,
+    # sample_action: uniform in the action box from the env's device generator (fluid_env.py:360-381); CPU device here
+    env.seed(42)
+    samples = [env.sample_action().tolist() for _ in range(3)]
+    env2 = make_toy(mod, False, 0)(**dict(kw, randomize_initial_state=False))
+    try:
+        env2.sample_action()
+        unseeded = None
+    except RuntimeError as e:
+        unseeded = str(e)
+    out = {"sample_action": {"seed": 42, "samples": samples, "unseeded_error": unseeded}, "init": cases, "step": {"episode_length": 3, "terminated_truncated": flags, "errors": errors, "n_sim_steps": env.n_sim_steps,
                                    "time_passed_after_3": env.time_passed}}
     with open(os.path.join(OUT, "reference_env_loop.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-import fluidgym_amd
+import fluidgym_amd  # noqa: F401
 from fluidgym_amd import spaces
 from fluidgym_amd.envs import fluid_env as FE
 from fluidgym_amd.simulation import domain_io
@@ -154,7 +154,7 @@ def test_reset_reports_a_missing_initial_domain_like_the_reference(recording_io)
     env = _make_toy(events, False, 20)(**KW)
     env.init(domain_idxs=[0, 1])
     env.init(domain_idxs=[1, 2])
-    # (the golden's first resets ran with indices 0-2 on disk only in an earlier version of the script; the rule is what is held:
+    # (the rule is what is held here:
     # a drawn index without files raises the reference's message, index 0 is used without randomisation)
     drawn = int(np.random.default_rng(5).integers(0, FE.N_INITIAL_DOMAINS))
     assert drawn not in (0, 1, 2)
@@ -184,3 +184,16 @@ def test_step_bookkeeping_and_messages_are_the_reference_s(recording_io):
         env.step(torch.zeros(2))
     assert str(e.value) == ref["errors"]["step_after_truncation"]
     assert env.n_sim_steps == ref["n_sim_steps"] and env.time_passed == pytest.approx(ref["time_passed_after_3"])
+
+
+def test_sample_action_draws_like_the_reference(recording_io):
+    """fluid_env.py:360-381: ``low + (high - low) * torch.rand(shape, generator=<the env's device generator seeded by seed()>)``
+    -- the same numbers for the same seed on the same (CPU) device."""
+    ref = GOLD["sample_action"]
+    env = _make_toy(recording_io, False, 0)(**dict(KW, randomize_initial_state=False))
+    with pytest.raises(RuntimeError) as e:
+        env.sample_action()
+    assert str(e.value) == ref["unseeded_error"]
+    env.seed(ref["seed"])
+    for want in ref["samples"]:
+        assert env.sample_action().tolist() == want
