@@ -1,0 +1,85 @@
+"""Small pieces of arithmetic inside the reference's env classes, evaluated HERE by the reference's own code: the method is taken out
+of its source file with ``ast``, compiled as it stands and called with a stand-in ``self`` that carries the attributes it reads.
+Only inputs and outputs are stored (``tests/golden/reference_env_math.npz``); ``tests/test_env_math_golden.py`` holds the env classes
+of ``fluidgym_amd`` against them.
+
+* ``RBCEnvBase._compute_nusselt`` (``envs/rbc/rbc_env_base.py:491-513``): volume-weighted convective heat flux -> Nusselt number;
+* ``TCF3DBottomEnv._action_to_control`` (``envs/tcf/tcf_env.py:521-547``): actions -> wall-normal velocity of the actuated wall
+  (zero net mass flux, clipped at u_tau, actor patches), with and without ``scale_actions``;
+* ``TCF3DBottomEnv._t_to_t_wall`` / ``_t_wall_to_t`` (``:323-327``) with the reference's ``TCF_tools.t_star``.
+
+    python tests/golden/make_golden_env_math.py
+"""
+import ast
+import os
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src/fluidgym"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def method(path, cls, name, extra=None):
+    tree = ast.parse(open(path).read())
+    c = next(n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name == cls)
+    fn = next(n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    fn.decorator_list = []
+    fn.returns = None
+    for a in fn.args.args + fn.args.kwonlyargs:
+        a.annotation = None
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch, "np": np}
+    ns.update(extra or {})
+    exec(compile(ast.fix_missing_locations(mod), path, "exec"), ns)
+    return ns[name]
+
+
+def function(path, name, extra=None):
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    fn.returns = None
+    for a in fn.args.args:
+        a.annotation = None
+    ns = {"torch": torch, "np": np}
+    ns.update(extra or {})
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[fn], type_ignores=[])), path, "exec"), ns)
+    return ns[name]
+
+
+def main():
+    rng = np.random.default_rng(0)
+    out = {}
+    # ---- RBC Nusselt number
+    nusselt = method(f"{REF}/envs/rbc/rbc_env_base.py", "RBCEnvBase", "_compute_nusselt")
+    for tag, ndims, shape, batched in (("2d", 2, (6, 10), False), ("2d_batched", 2, (3, 6, 10), True), ("3d_batched", 3, (2, 4, 5, 6), True)):
+        me = types.SimpleNamespace(_ndims=ndims, _rayleigh_number=8e4, _prandtl_number=0.7)
+        T = torch.as_tensor(rng.random(shape), dtype=torch.float32)
+        uy = torch.as_tensor(rng.standard_normal(shape), dtype=torch.float32)
+        cs = torch.as_tensor(0.5 + rng.random(shape[1:] if batched else shape), dtype=torch.float32)
+        out[f"nusselt_{tag}_T"], out[f"nusselt_{tag}_uy"], out[f"nusselt_{tag}_cell_size"] = T.numpy(), uy.numpy(), cs.numpy()
+        out[f"nusselt_{tag}_out"] = np.asarray(nusselt(me, T, uy, cs))
+    out["nusselt_ra_pr"] = np.array([8e4, 0.7])
+    # ---- TCF wall actuation
+    to_control = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_action_to_control")
+    for tag, scale in (("scaled", True), ("raw", False)):
+        me = types.SimpleNamespace(_scale_actions=scale, _u_wall=0.0557, _z=8, _x=12, _actor_size=2, _cuda_device=torch.device("cpu"))
+        a = torch.as_tensor(2.5 * rng.standard_normal((6, 4)), dtype=torch.float32)          # [n_actors_x, n_actors_z], some |a| > 1
+        out[f"tcf_action_{tag}"] = a.numpy()
+        out[f"tcf_control_{tag}"] = to_control(me, a).numpy()                                 # [1, 3, Z, 1, X]
+    out["tcf_u_wall_actor_size"] = np.array([0.0557, 2])
+    # ---- TCF time units
+    t_star = function(f"{REF}/simulation/pict/data/TCF_tools.py", "t_star")
+    tools = types.SimpleNamespace(t_star=t_star)
+    to_wall = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_t_to_t_wall", {"TCF_tools": tools})
+    from_wall = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_t_wall_to_t", {"TCF_tools": tools})
+    me = types.SimpleNamespace(_viscosity=torch.tensor(3.1e-4), _u_wall=0.0557)
+    out["tcf_time_units"] = np.array([3.1e-4, 0.0557, to_wall(me, 0.37), from_wall(me, 0.6)])
+    np.savez(os.path.join(OUT, "reference_env_math.npz"), **out)
+    print({k: np.asarray(v).shape for k, v in out.items()})
+    print(out["tcf_time_units"], out["nusselt_2d_out"], out["nusselt_3d_batched_out"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Arithmetic inside the env classes against the reference's OWN methods evaluated on the same inputs
+(``tests/golden/make_golden_env_math.py`` takes the method out of the reference's source with ``ast`` and calls it;
+``tests/golden/reference_env_math.npz`` holds inputs and outputs): the RBC Nusselt number, the TCF wall actuation and its
+time units."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+import fluidgym_amd  # noqa: F401
+from fluidgym_amd.envs.rbc import RBCEnvBase
+from fluidgym_amd.envs.tcf import TCF3DBottomEnv
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_env_math.npz"))
+
+
+def test_rbc_nusselt_numbers_are_the_reference_s():
+    ra, pr = G["nusselt_ra_pr"]
+    me = SimpleNamespace(_rayleigh_number=float(ra), _prandtl_number=float(pr))
+    # global: one value per env from the fields on the simulation grid (compute_global_nusselt reads them off the block)
+    for tag, nd in (("2d_batched", 2), ("3d_batched", 3)):
+        T, uy, cs = (torch.as_tensor(G[f"nusselt_{tag}_{k}"]) for k in ("T", "uy", "cell_size"))
+        blk = SimpleNamespace(passiveScalar=T.unsqueeze(1), velocity=torch.stack([torch.zeros_like(uy), uy] + [torch.zeros_like(uy)] * (nd - 2), dim=1))
+        env = SimpleNamespace(_block=blk, _ndims=nd, _cell_size=cs, **vars(me))
+        got = RBCEnvBase.compute_global_nusselt(env)
+        assert np.allclose(got.numpy(), G[f"nusselt_{tag}_out"], rtol=2e-6, atol=1e-5), tag
+        # local (per-agent windows): the same formula with an agent axis
+        got = RBCEnvBase._local_nusselt(env, T.unsqueeze(1), uy.unsqueeze(1), cs)
+        assert np.allclose(got[:, 0].numpy(), G[f"nusselt_{tag}_out"], rtol=2e-6, atol=1e-5), tag
+    T, uy, cs = (torch.as_tensor(G[f"nusselt_2d_{k}"]) for k in ("T", "uy", "cell_size"))
+    blk = SimpleNamespace(passiveScalar=T[None, None], velocity=torch.stack([torch.zeros_like(uy), uy])[None])
+    got = RBCEnvBase.compute_global_nusselt(SimpleNamespace(_block=blk, _ndims=2, _cell_size=cs, **vars(me)))
+    assert np.allclose(got.numpy(), G["nusselt_2d_out"], rtol=2e-6)
+
+
+def test_tcf_wall_actuation_is_the_reference_s():
+    u_wall, actor = G["tcf_u_wall_actor_size"]
+    for tag, scale in (("scaled", True), ("raw", False)):
+        a = torch.as_tensor(G[f"tcf_action_{tag}"])
+        me = SimpleNamespace(_scale_actions=scale, _u_wall=float(u_wall), _actor_size=int(actor))
+        v = TCF3DBottomEnv._action_to_control(me, a[None])            # [B, Z, X]
+        want = G[f"tcf_control_{tag}"]                                # [1, 3, Z, 1, X]: only the wall-normal component is set
+        assert np.abs(want[0, 0]).max() == 0 and np.abs(want[0, 2]).max() == 0
+        assert np.allclose(v[0].numpy(), want[0, 1, :, 0, :], rtol=1e-6, atol=1e-8), tag
+        if scale:
+            assert abs(float(v.mean())) < 1e-8 and float(v.abs().max()) <= float(u_wall) * 1.5
+        # two envs of a batch are scaled independently, each like the reference's single env
+        both = TCF3DBottomEnv._action_to_control(me, torch.stack([a, -0.5 * a]))
+        assert np.allclose(both[0].numpy(), want[0, 1, :, 0, :], rtol=1e-6, atol=1e-8)
+
+
+def test_tcf_time_units_are_the_reference_s():
+    nu, u_wall, t_wall_of, t_of = G["tcf_time_units"]
+    me = SimpleNamespace(_nu=float(nu), _u_wall=float(u_wall))
+    assert np.isclose(TCF3DBottomEnv._t_to_t_wall(me, 0.37), t_wall_of, rtol=1e-6)
+    assert np.isclose(TCF3DBottomEnv._t_wall_to_t(me, 0.6), t_of, rtol=1e-6)
