@@ -6,6 +6,8 @@ of ``fluidgym_amd`` against them.
 * ``RBCEnvBase._compute_nusselt`` (``envs/rbc/rbc_env_base.py:491-513``): volume-weighted convective heat flux -> Nusselt number;
 * ``TCF3DBottomEnv._action_to_control`` (``envs/tcf/tcf_env.py:521-547``): actions -> wall-normal velocity of the actuated wall
   (zero net mass flux, clipped at u_tau, actor patches), with and without ``scale_actions``;
+* ``RBCEnv2D.__action_to_control`` / ``__smooth_action_profile_1d`` (``envs/rbc/rbc_env_2d.py:207-262``): heater actions ->
+  bottom-plate temperature profile (zero mean, limit, cubic blending between neighbouring heaters);
 * ``TCF3DBottomEnv._t_to_t_wall`` / ``_t_wall_to_t`` (``:323-327``) with the reference's ``TCF_tools.t_star``.
 
     python tests/golden/make_golden_env_math.py
@@ -76,6 +78,17 @@ def main():
     from_wall = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_t_wall_to_t", {"TCF_tools": tools})
     me = types.SimpleNamespace(_viscosity=torch.tensor(3.1e-4), _u_wall=0.0557)
     out["tcf_time_units"] = np.array([3.1e-4, 0.0557, to_wall(me, 0.37), from_wall(me, 0.6)])
+    # ---- RBC heaters: actions -> bottom-plate temperature profile (rbc_env_2d.py:207-262; private names are not mangled
+    # outside a class body, so the stand-in carries them literally)
+    smooth = method(f"{REF}/envs/rbc/rbc_env_2d.py", "RBCEnv2D", "__smooth_action_profile_1d")
+    control = method(f"{REF}/envs/rbc/rbc_env_2d.py", "RBCEnv2D", "__action_to_control")
+    for tag, n_heaters, hw in (("w8", 12, 8), ("w20", 6, 20), ("w4", 8, 4)):      # blend zones of 1, 2 and 0 cells
+        me = types.SimpleNamespace(_heater_width=hw, _x=n_heaters * hw, _heater_limit=0.75, _T_hot=1.0)
+        setattr(me, "__smooth_action_profile_1d", lambda T_action, me=me: smooth(me, T_action))
+        a = torch.as_tensor(1.5 * rng.standard_normal(n_heaters), dtype=torch.float32)
+        out[f"rbc_heater_{tag}_action"] = a.numpy()
+        out[f"rbc_heater_{tag}_control"] = control(me, a.clone()).numpy()
+    out["rbc_heater_limit_T_hot"] = np.array([0.75, 1.0])
     np.savez(os.path.join(OUT, "reference_env_math.npz"), **out)
     print({k: np.asarray(v).shape for k, v in out.items()})
     print(out["tcf_time_units"], out["nusselt_2d_out"], out["nusselt_3d_batched_out"])

@@ -55,3 +55,18 @@ def test_tcf_time_units_are_the_reference_s():
     me = SimpleNamespace(_nu=float(nu), _u_wall=float(u_wall))
     assert np.isclose(TCF3DBottomEnv._t_to_t_wall(me, 0.37), t_wall_of, rtol=1e-6)
     assert np.isclose(TCF3DBottomEnv._t_wall_to_t(me, 0.6), t_of, rtol=1e-6)
+
+
+def test_rbc_heater_profile_is_the_reference_s():
+    """actions -> temperature of the bottom plate (rbc_env_2d.py:207-262): mean removed, limited to +-0.75 around T_hot, blended
+    between neighbouring heaters over 10 % of a heater width (zones of 1, 2 and 0 cells here)."""
+    limit, t_hot = G["rbc_heater_limit_T_hot"]
+    for tag, hw in (("w8", 8), ("w20", 20), ("w4", 4)):
+        a = torch.as_tensor(G[f"rbc_heater_{tag}_action"])
+        x = a.numel() * hw
+        idx = torch.arange(x)
+        me = SimpleNamespace(_heater_width=hw, _x=x, _seg_id=idx // hw, _x_pos=idx % hw, _num_envs=2, _heater_limit=float(limit), _T_hot=float(t_hot))
+        T = RBCEnvBase._action_to_control(me, torch.stack([a, 0.3 * a]))             # two envs, each handled like the reference's one
+        prof = RBCEnvBase._smooth_profile(me, T)
+        assert np.allclose(prof[0].numpy(), G[f"rbc_heater_{tag}_control"], rtol=1e-6, atol=1e-7), tag
+        assert not np.allclose(prof[1].numpy(), prof[0].numpy())
