@@ -200,9 +200,17 @@ class RBCEnvBase(FluidEnv):
             T.copy_(torch.flip(T, dims=[-1]))
             u.copy_(torch.flip(u, dims=[-1]))
             u[:, 0] *= -1.0
+        if self._ndims == 3 and self._np_rng.uniform(0.0, 1.0) > 0.5:      # 3-D: the z axis too (rbc_env_base.py:350-353)
+            T.copy_(torch.flip(T, dims=[-3]))
+            u.copy_(torch.flip(u, dims=[-3]))
+            u[:, 2] *= -1.0
         shift = int(self._np_rng.integers(0, self._x))
         T.copy_(torch.roll(T, shifts=shift, dims=-1))
         u.copy_(torch.roll(u, shifts=shift, dims=-1))
+        if self._ndims == 3:                                                # (:359-362)
+            z_shift = int(self._np_rng.integers(0, self._x))
+            T.copy_(torch.roll(T, shifts=z_shift, dims=-3))
+            u.copy_(torch.roll(u, shifts=z_shift, dims=-3))
         T.add_(torch.randn(T.shape, device=T.device, generator=self._torch_rng_cuda) * 0.05).clamp_(self._T_cold, self._T_hot)
         u.add_(torch.randn(u.shape, device=u.device, generator=self._torch_rng_cuda) * 0.05)
         sim_time = self._np_rng.uniform(1.0, 2.0)

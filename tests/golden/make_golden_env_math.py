@@ -89,6 +89,22 @@ def main():
         out[f"rbc_heater_{tag}_action"] = a.numpy()
         out[f"rbc_heater_{tag}_control"] = control(me, a.clone()).numpy()
     out["rbc_heater_limit_T_hot"] = np.array([0.75, 1.0])
+    # ---- RBC randomisation of the initial state (rbc_env_base.py:335-398): flips, shifts, noise, 1-2 time units of simulation
+    randomize = method(f"{REF}/envs/rbc/rbc_env_base.py", "RBCEnvBase", "_randomize_domain")
+    for tag, ndims, shape in (("2d", 2, (5, 8)), ("3d", 3, (8, 5, 8))):
+        for seed in (3, 4, 6):
+            T0 = torch.as_tensor(rng.random((1, 1) + shape), dtype=torch.float32)
+            u0 = torch.as_tensor(0.2 * rng.standard_normal((1, ndims) + shape), dtype=torch.float32)
+            state, steps = {"T": T0.clone(), "u": u0.clone()}, []
+            block = types.SimpleNamespace(passiveScalar=state["T"], getVelocity=lambda with_bounds: state["u"],
+                                          setPassiveScalar=lambda v: state.__setitem__("T", v), setVelocity=lambda v: state.__setitem__("u", v))
+            me = types.SimpleNamespace(_block=block, _ndims=ndims, _x=8, _np_rng=np.random.default_rng(seed), _cuda_device=torch.device("cpu"),
+                                       _torch_rng_cuda=torch.Generator().manual_seed(seed), _dtype=torch.float32, _T_cold=0.0, _T_hot=1.0,
+                                       _dt=0.05, _sim=types.SimpleNamespace(single_step=lambda: steps.append(1)))
+            randomize(me)
+            out[f"rbc_rand_{tag}_{seed}_T0"], out[f"rbc_rand_{tag}_{seed}_u0"] = T0.numpy(), u0.numpy()
+            out[f"rbc_rand_{tag}_{seed}_T"], out[f"rbc_rand_{tag}_{seed}_u"] = state["T"].numpy(), state["u"].numpy()
+            out[f"rbc_rand_{tag}_{seed}_steps"] = np.array(len(steps))
     np.savez(os.path.join(OUT, "reference_env_math.npz"), **out)
     print({k: np.asarray(v).shape for k, v in out.items()})
     print(out["tcf_time_units"], out["nusselt_2d_out"], out["nusselt_3d_batched_out"])

@@ -70,3 +70,20 @@ def test_rbc_heater_profile_is_the_reference_s():
         prof = RBCEnvBase._smooth_profile(me, T)
         assert np.allclose(prof[0].numpy(), G[f"rbc_heater_{tag}_control"], rtol=1e-6, atol=1e-7), tag
         assert not np.allclose(prof[1].numpy(), prof[0].numpy())
+
+
+def test_rbc_randomisation_of_the_initial_state_is_the_reference_s():
+    """rbc_env_base.py:335-398 on the same fields with the same generators (CPU): x flip, in 3-D a z flip, x shift, in 3-D a z
+    shift, noise on T (clamped) and u, then 1-2 time units of simulation -- the same fields and the same number of steps."""
+    for tag, ndims in (("2d", 2), ("3d", 3)):
+        for seed in (3, 4, 6):
+            T = torch.as_tensor(G[f"rbc_rand_{tag}_{seed}_T0"]).clone()
+            u = torch.as_tensor(G[f"rbc_rand_{tag}_{seed}_u0"]).clone()
+            steps = []
+            me = SimpleNamespace(_block=SimpleNamespace(passiveScalar=T, velocity=u), _ndims=ndims, _x=8, _np_rng=np.random.default_rng(seed),
+                                 _torch_rng_cuda=torch.Generator().manual_seed(seed), _T_cold=0.0, _T_hot=1.0, _dt=0.05,
+                                 _sim=SimpleNamespace(single_step=lambda: steps.append(1)))
+            RBCEnvBase._randomize_domain(me)
+            assert np.allclose(T.numpy(), G[f"rbc_rand_{tag}_{seed}_T"], atol=1e-7), (tag, seed)
+            assert np.allclose(u.numpy(), G[f"rbc_rand_{tag}_{seed}_u"], atol=1e-7), (tag, seed)
+            assert len(steps) == int(G[f"rbc_rand_{tag}_{seed}_steps"])
