@@ -8,6 +8,7 @@ of ``fluidgym_amd`` against them.
   (zero net mass flux, clipped at u_tau, actor patches), with and without ``scale_actions``;
 * ``RBCEnv2D.__action_to_control`` / ``__smooth_action_profile_1d`` (``envs/rbc/rbc_env_2d.py:207-262``): heater actions ->
   bottom-plate temperature profile (zero mean, limit, cubic blending between neighbouring heaters);
+* ``RBCEnvBase._randomize_domain`` (``:335-398``) and ``TCF3DBottomEnv._get_global_obs`` / ``_get_local_obs`` (``:646-678, 918-992``);
 * ``TCF3DBottomEnv._t_to_t_wall`` / ``_t_wall_to_t`` (``:323-327``) with the reference's ``TCF_tools.t_star``.
 
     python tests/golden/make_golden_env_math.py
@@ -105,6 +106,25 @@ def main():
             out[f"rbc_rand_{tag}_{seed}_T0"], out[f"rbc_rand_{tag}_{seed}_u0"] = T0.numpy(), u0.numpy()
             out[f"rbc_rand_{tag}_{seed}_T"], out[f"rbc_rand_{tag}_{seed}_u"] = state["T"].numpy(), state["u"].numpy()
             out[f"rbc_rand_{tag}_{seed}_steps"] = np.array(len(steps))
+    # ---- TCF observations (tcf_env.py:646-678 global: volume-mean fluctuation on the sensing plane; :918-992 local: per-actuator
+    # windows, plane-mean fluctuation, the top wall's view flipped) with the reference's own window extraction
+    window = function(f"{REF}/envs/util/obs_extraction.py", "extract_moving_window_2d_x_z")
+    glob = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_get_global_obs", {"get_cell_size": lambda block: block.cell_size})
+    loc = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_get_local_obs", {"extract_moving_window_2d_x_z": window})
+    Z, Y, X, actor = 8, 6, 12, 2
+    u = torch.as_tensor(rng.standard_normal((1, 3, Z, Y, X)), dtype=torch.float32)
+    pr = torch.as_tensor(rng.standard_normal((1, 1, Z, Y, X)), dtype=torch.float32)
+    cs = torch.as_tensor(0.5 + rng.random((1, 1, Z, Y, X)), dtype=torch.float32)
+    block = types.SimpleNamespace(getVelocity=lambda with_bounds: u, pressure=pr, cell_size=cs)
+    out["tcf_obs_u"], out["tcf_obs_p"], out["tcf_obs_cell_size"] = u.numpy(), pr.numpy(), cs.numpy()
+    for W in (1, 3):
+        me = types.SimpleNamespace(_domain=types.SimpleNamespace(getBlock=lambda i: block), _y_obs_bottom_idx=1, _n_actors_x=X // actor,
+                                   _n_actors_z=Z // actor, _actor_size=actor, _local_obs_window=W)
+        g = glob(me)
+        out["tcf_global_velocity"], out["tcf_global_pressure"] = g["velocity"].numpy(), g["pressure"].numpy()
+        for flip, y_idx in ((False, 1), (True, Y - 2)):
+            l = loc(me, y_idx, flip)
+            out[f"tcf_local_w{W}_flip{int(flip)}_velocity"], out[f"tcf_local_w{W}_flip{int(flip)}_pressure"] = l["velocity"].numpy(), l["pressure"].numpy()
     np.savez(os.path.join(OUT, "reference_env_math.npz"), **out)
     print({k: np.asarray(v).shape for k, v in out.items()})
     print(out["tcf_time_units"], out["nusselt_2d_out"], out["nusselt_3d_batched_out"])

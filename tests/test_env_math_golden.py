@@ -87,3 +87,24 @@ def test_rbc_randomisation_of_the_initial_state_is_the_reference_s():
             assert np.allclose(T.numpy(), G[f"rbc_rand_{tag}_{seed}_T"], atol=1e-7), (tag, seed)
             assert np.allclose(u.numpy(), G[f"rbc_rand_{tag}_{seed}_u"], atol=1e-7), (tag, seed)
             assert len(steps) == int(G[f"rbc_rand_{tag}_{seed}_steps"])
+
+
+def test_tcf_observations_are_the_reference_s():
+    """tcf_env.py:646-678 (global: fluctuation about the volume-weighted mean on the sensing plane) and :918-992 (per-actuator
+    windows of the fluctuation about the plane mean; u_x padded by one column less than u_y / p; the top wall's view flipped and
+    u_y negated) -- the reference's methods with its own window extraction, on the same fields."""
+    u, p, cs = (torch.as_tensor(G[k]) for k in ("tcf_obs_u", "tcf_obs_p", "tcf_obs_cell_size"))
+    Z, Y, X = u.shape[2:]
+    actor = 2
+    blk = SimpleNamespace(velocity=torch.cat([u, 2.0 * u]), pressure=torch.cat([p, 2.0 * p]))     # two envs: the second must not leak
+    for W in (1, 3):
+        me = SimpleNamespace(_block=blk, _cell_size=cs[0, 0], _y_obs_bottom_idx=1, _n_actors_x=X // actor, _n_actors_z=Z // actor,
+                             _actor_size=actor, _local_obs_window=W)
+        g = TCF3DBottomEnv._plane_obs(me, 1)
+        assert np.allclose(g["velocity"][0].numpy(), G["tcf_global_velocity"], atol=2e-6)
+        assert np.allclose(g["pressure"][0].numpy(), G["tcf_global_pressure"], atol=2e-6)
+        for flip, y_idx in ((False, 1), (True, Y - 2)):
+            l = TCF3DBottomEnv._local_plane_obs(me, y_idx, flip)
+            assert np.allclose(l["velocity"][0].numpy(), G[f"tcf_local_w{W}_flip{int(flip)}_velocity"], atol=2e-6), (W, flip)
+            assert np.allclose(l["pressure"][0].numpy(), G[f"tcf_local_w{W}_flip{int(flip)}_pressure"], atol=2e-6), (W, flip)
+            assert np.allclose(l["velocity"][1].numpy(), 2.0 * G[f"tcf_local_w{W}_flip{int(flip)}_velocity"], atol=4e-6)
