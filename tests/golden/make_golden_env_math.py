@@ -90,6 +90,15 @@ def main():
         out[f"rbc_heater_{tag}_action"] = a.numpy()
         out[f"rbc_heater_{tag}_control"] = control(me, a.clone()).numpy()
     out["rbc_heater_limit_T_hot"] = np.array([0.75, 1.0])
+    # ---- RBC 3-D heaters: [n_heaters, n_heaters] actions -> temperature of the bottom plate [Z, X] (rbc_env_3d.py:201-262)
+    s1 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_1d")
+    s2 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_2d")
+    c3 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "_action_to_control")
+    me = types.SimpleNamespace(_heater_width=10, _x=40, _n_heaters=4, _heater_limit=0.75, _T_hot=1.0)
+    setattr(me, "__smooth_action_profile_1d", lambda T_action: s1(me, T_action))
+    setattr(me, "__smooth_action_profile_2d", lambda T_action: s2(me, T_action))
+    a = torch.as_tensor(1.5 * rng.standard_normal(16), dtype=torch.float32)
+    out["rbc3d_heater_action"], out["rbc3d_heater_control"] = a.numpy(), c3(me, a.clone()).numpy()
     # ---- RBC randomisation of the initial state (rbc_env_base.py:335-398): flips, shifts, noise, 1-2 time units of simulation
     randomize = method(f"{REF}/envs/rbc/rbc_env_base.py", "RBCEnvBase", "_randomize_domain")
     for tag, ndims, shape in (("2d", 2, (5, 8)), ("3d", 3, (8, 5, 8))):

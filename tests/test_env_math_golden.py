@@ -108,3 +108,20 @@ def test_tcf_observations_are_the_reference_s():
             assert np.allclose(l["velocity"][0].numpy(), G[f"tcf_local_w{W}_flip{int(flip)}_velocity"], atol=2e-6), (W, flip)
             assert np.allclose(l["pressure"][0].numpy(), G[f"tcf_local_w{W}_flip{int(flip)}_pressure"], atol=2e-6), (W, flip)
             assert np.allclose(l["velocity"][1].numpy(), 2.0 * G[f"tcf_local_w{W}_flip{int(flip)}_velocity"], atol=4e-6)
+
+
+def test_rbc_3d_heater_profile_is_the_reference_s():
+    """rbc_env_3d.py:201-262: the [n_heaters, n_heaters] actions (z-heater, x-heater) -> bottom-plate temperature [Z, X], blended
+    along both axes."""
+    limit, t_hot = G["rbc_heater_limit_T_hot"]
+    a = torch.as_tensor(G["rbc3d_heater_action"])
+    nh, hw = 4, 10
+    idx = torch.arange(nh * hw)
+    plate = SimpleNamespace(setPassiveScalar=lambda c: setattr(plate, "value", c))
+    me = SimpleNamespace(_heater_width=hw, _x=nh * hw, _n_heaters=nh, _seg_id=idx // hw, _x_pos=idx % hw, _num_envs=2, _ndims=3,
+                         _heater_limit=float(limit), _T_hot=float(t_hot), _bottom_plate=plate)
+    me._action_to_control = lambda action: RBCEnvBase._action_to_control(me, action)
+    me._smooth_profile = lambda T: RBCEnvBase._smooth_profile(me, T)
+    RBCEnvBase._apply_action(me, torch.stack([a, -a]))
+    assert plate.value.shape == (2, 1, nh * hw, 1, nh * hw)
+    assert np.allclose(plate.value[0, 0, :, 0, :].numpy(), G["rbc3d_heater_control"], rtol=1e-6, atol=1e-7)
