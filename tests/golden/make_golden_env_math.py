@@ -90,6 +90,17 @@ def main():
         out[f"rbc_heater_{tag}_action"] = a.numpy()
         out[f"rbc_heater_{tag}_control"] = control(me, a.clone()).numpy()
     out["rbc_heater_limit_T_hot"] = np.array([0.75, 1.0])
+    # ---- cylinder jets: velocity vectors of the two synthetic jets on the wall faces of the top / bottom block
+    # (jet_cylinder_env_2d.py:136-183), on the reference's own mesh (tests/golden/reference_cylinder_grid.npz, made by its generator)
+    jet_profile = function(f"{REF}/envs/util/profiles.py", "get_jet_profile")
+    jets = method(f"{REF}/envs/cylinder/jet_cylinder_env_2d.py", "CylinderJetEnv2D", "_get_boundary_velocities", {"get_jet_profile": jet_profile})
+    mesh = np.load(os.path.join(OUT, "reference_cylinder_grid.npz"))
+    for res in (8, 24):
+        coords = [torch.as_tensor(mesh[f"r{res}_block{b}"], dtype=torch.float32)[None] for b in range(5)]
+        me = types.SimpleNamespace(_domain=types.SimpleNamespace(getVertexCoordinates=lambda: coords), _top_block_idx=1, _bottom_block_idx=3,
+                                   _jet_angle=10.0, _dtype=torch.float32, _cuda_device=torch.device("cpu"))
+        top, bottom = jets(me)
+        out[f"cyl_jet_r{res}_top"], out[f"cyl_jet_r{res}_bottom"] = top.numpy(), bottom.numpy()          # [1, 2, 1, n_faces]
     # ---- RBC 3-D heaters: [n_heaters, n_heaters] actions -> temperature of the bottom plate [Z, X] (rbc_env_3d.py:201-262)
     s1 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_1d")
     s2 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_2d")

@@ -125,3 +125,21 @@ def test_rbc_3d_heater_profile_is_the_reference_s():
     RBCEnvBase._apply_action(me, torch.stack([a, -a]))
     assert plate.value.shape == (2, 1, nh * hw, 1, nh * hw)
     assert np.allclose(plate.value[0, 0, :, 0, :].numpy(), G["rbc3d_heater_control"], rtol=1e-6, atol=1e-7)
+
+
+def test_cylinder_jet_velocities_are_the_reference_s():
+    """jet_cylinder_env_2d.py:136-183 evaluated by the reference on its own mesh: the velocity vectors of the two synthetic jets on
+    the wall faces of the top / bottom block.  Here: the env's own mesh generator (pinned on the same reference mesh in
+    tests/test_cylinder_grid.py) and ``_jet_velocities``."""
+    from fluidgym_amd.envs.cylinder import BOTTOM, TOP, CylinderJetEnv2D, _face_vertices
+    from fluidgym_amd.envs.cylinder_grid import make_vortex_street_mesh
+
+    for res in (8, 24):
+        env = fluidgym_amd.make("CylinderJet2D-easy-v0", cuda_device=torch.device("cpu"), resolution=res)
+        env._mesh = make_vortex_street_mesh(env._circle_resolution_angular, env.H, env.L, env.cylinder_diameter / 2, env.cylinder_offset_y,
+                                            env.cylinder_diameter / 2, env.cylinder_diameter, env._vortex_street_refinement_base)   # as _get_domain (no GPU)
+        top = CylinderJetEnv2D._jet_velocities(env, _face_vertices(env._mesh, TOP, "-y"), True)
+        bottom = CylinderJetEnv2D._jet_velocities(env, _face_vertices(env._mesh, BOTTOM, "+y"), False)
+        assert np.allclose(top, G[f"cyl_jet_r{res}_top"][0, :, 0, :], atol=2e-6), res
+        assert np.allclose(bottom, G[f"cyl_jet_r{res}_bottom"][0, :, 0, :], atol=2e-6), res
+        assert np.abs(top).max() > 0.9
