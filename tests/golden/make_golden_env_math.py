@@ -101,6 +101,15 @@ def main():
                                    _jet_angle=10.0, _dtype=torch.float32, _cuda_device=torch.device("cpu"))
         top, bottom = jets(me)
         out[f"cyl_jet_r{res}_top"], out[f"cyl_jet_r{res}_bottom"] = top.numpy(), bottom.numpy()          # [1, 2, 1, n_faces]
+    # ---- airfoil jets: actions -> wall velocity of the top face from the base profiles (airfoil_env_2d.py:168-190)
+    af = method(f"{REF}/envs/airfoil/airfoil_env_2d.py", "AirfoilEnv2D", "_action_to_control")
+    base = torch.as_tensor(rng.standard_normal((1, 2, 1, 30)), dtype=torch.float32)
+    locs = [(3, 6), (12, 16), (22, 25)]
+    me = types.SimpleNamespace(_jet_locations_top=locs, _n_jets=3, _top_base_profile=base)
+    out["airfoil_base_profile"], out["airfoil_jet_locations"] = base.numpy(), np.array(locs)
+    for tag, a in (("small", [0.3, -0.2, 0.5]), ("large", [2.0, -1.0, 0.5]), ("equal", [0.7, 0.7, 0.7])):
+        act = torch.tensor(a, dtype=torch.float32)
+        out[f"airfoil_action_{tag}"], out[f"airfoil_control_{tag}"] = act.numpy(), af(me, act).numpy()
     # ---- RBC 3-D heaters: [n_heaters, n_heaters] actions -> temperature of the bottom plate [Z, X] (rbc_env_3d.py:201-262)
     s1 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_1d")
     s2 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_2d")

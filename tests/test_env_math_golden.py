@@ -143,3 +143,17 @@ def test_cylinder_jet_velocities_are_the_reference_s():
         assert np.allclose(top, G[f"cyl_jet_r{res}_top"][0, :, 0, :], atol=2e-6), res
         assert np.allclose(bottom, G[f"cyl_jet_r{res}_bottom"][0, :, 0, :], atol=2e-6), res
         assert np.abs(top).max() > 0.9
+
+
+def test_airfoil_jet_control_is_the_reference_s():
+    """airfoil_env_2d.py:168-190: mean removed, scaled to a maximum of 1 only when it exceeds 1, each jet's stretch of the base
+    profile multiplied by its action."""
+    from fluidgym_amd.envs.airfoil import AirfoilEnv2D
+
+    base = torch.as_tensor(G["airfoil_base_profile"])[0, :, 0, :]            # [2, nx]
+    locs = [tuple(int(v) for v in r) for r in G["airfoil_jet_locations"]]
+    me = SimpleNamespace(_top_base_profile=base, _jet_locations_top=locs, _num_envs=2)
+    for tag in ("small", "large", "equal"):
+        a = torch.as_tensor(G[f"airfoil_action_{tag}"])
+        got = AirfoilEnv2D._action_to_control(me, torch.stack([a, 0.1 * a]))
+        assert np.allclose(got[0].numpy(), G[f"airfoil_control_{tag}"][0, :, 0, :], atol=1e-6), tag
