@@ -72,6 +72,16 @@ def main():
         out[f"tcf_action_{tag}"] = a.numpy()
         out[f"tcf_control_{tag}"] = to_control(me, a).numpy()                                 # [1, 3, Z, 1, X]
     out["tcf_u_wall_actor_size"] = np.array([0.0557, 2])
+    # ---- TCF wall shear stress of both walls from the plane-mean streamwise velocity of the first / last cell row (tcf_env.py:564-584)
+    stress = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_get_wall_stress")
+    Zs, Ys, Xs = 4, 7, 5
+    yc = np.sort(rng.uniform(-0.98, 0.98, Ys)).astype(np.float32)                      # cell-centre heights between the walls at -1 / +1
+    cc = torch.as_tensor(np.broadcast_to(yc[None, :, None], (Zs, Ys, Xs)).copy())
+    vel = torch.as_tensor(rng.random((1, 3, Zs, Ys, Xs)), dtype=torch.float32)
+    blk = types.SimpleNamespace(getCellCoordinates=lambda: torch.stack([torch.zeros_like(cc), cc, torch.zeros_like(cc)])[None], velocity=vel)
+    me = types.SimpleNamespace(_domain=types.SimpleNamespace(getBlock=lambda i: blk, viscosity=torch.tensor([3.1e-4]), getDevice=lambda: torch.device("cpu")))
+    tb, tt = stress(me)
+    out["tcf_stress_y_centers"], out["tcf_stress_velocity"], out["tcf_stress_out"] = yc, vel.numpy(), np.array([float(tb), float(tt)])
     # ---- TCF time units
     t_star = function(f"{REF}/simulation/pict/data/TCF_tools.py", "t_star")
     tools = types.SimpleNamespace(t_star=t_star)

@@ -157,3 +157,13 @@ def test_airfoil_jet_control_is_the_reference_s():
         a = torch.as_tensor(G[f"airfoil_action_{tag}"])
         got = AirfoilEnv2D._action_to_control(me, torch.stack([a, 0.1 * a]))
         assert np.allclose(got[0].numpy(), G[f"airfoil_control_{tag}"][0, :, 0, :], atol=1e-6), tag
+
+
+def test_tcf_wall_stress_is_the_reference_s():
+    """tcf_env.py:564-584: nu x plane-mean streamwise velocity of the first / last cell row over its distance from the wall."""
+    yc = G["tcf_stress_y_centers"]
+    vel = torch.as_tensor(G["tcf_stress_velocity"])
+    me = SimpleNamespace(_block=SimpleNamespace(velocity=torch.cat([vel, 3.0 * vel])), _nu=3.1e-4, _d_wall=(float(1.0 + yc[0]), float(1.0 - yc[-1])))
+    bottom, top = TCF3DBottomEnv._get_wall_stress(me)
+    assert np.allclose([float(bottom[0]), float(top[0])], G["tcf_stress_out"], rtol=2e-6)
+    assert np.allclose([float(bottom[1]), float(top[1])], 3.0 * G["tcf_stress_out"], rtol=2e-6)
