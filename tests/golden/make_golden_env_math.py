@@ -120,6 +120,22 @@ def main():
     for tag, a in (("small", [0.3, -0.2, 0.5]), ("large", [2.0, -1.0, 0.5]), ("equal", [0.7, 0.7, 0.7])):
         act = torch.tensor(a, dtype=torch.float32)
         out[f"airfoil_action_{tag}"], out[f"airfoil_control_{tag}"] = act.numpy(), af(me, act).numpy()
+    # ---- RBC local rewards: nu_ref - Nusselt number over each agent's window of the simulation grid (rbc_env_2d.py:327-358)
+    import torch.nn.functional as F
+
+    win2d = function(f"{REF}/envs/util/obs_extraction.py", "extract_moving_window_2d", {"F": F})
+    local_r = method(f"{REF}/envs/rbc/rbc_env_2d.py", "RBCEnv2D", "_get_local_rewards",
+                     {"extract_moving_window_2d": win2d, "get_cell_size": lambda block: block.cell_size})
+    nh, hw, ny = 6, 4, 5
+    Tl = torch.as_tensor(rng.random((1, 1, ny, nh * hw)), dtype=torch.float32)
+    ul = torch.as_tensor(rng.standard_normal((1, 2, ny, nh * hw)), dtype=torch.float32)
+    csl = torch.as_tensor(0.5 + rng.random((ny, 1)) * np.ones((1, nh * hw)), dtype=torch.float32)     # cell sizes vary with y only (as on the env's grids)
+    out["rbc_local_T"], out["rbc_local_u"], out["rbc_local_cell_size"] = Tl.numpy(), ul.numpy(), csl.numpy()
+    for W in (1, 3):
+        me = types.SimpleNamespace(_block=types.SimpleNamespace(passiveScalar=Tl, getVelocity=lambda with_bounds: ul, cell_size=csl[None, None]),
+                                   _local_obs_window=W, _heater_width=hw, n_agents=nh, nu_ref=2.5, _ndims=2, _rayleigh_number=8e4, _prandtl_number=0.7)
+        me._compute_nusselt = lambda T, u_y, cell_size, me=me: nusselt(me, T, u_y, cell_size)
+        out[f"rbc_local_rewards_w{W}"] = local_r(me).numpy()
     # ---- RBC 3-D heaters: [n_heaters, n_heaters] actions -> temperature of the bottom plate [Z, X] (rbc_env_3d.py:201-262)
     s1 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_1d")
     s2 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_2d")

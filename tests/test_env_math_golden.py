@@ -167,3 +167,18 @@ def test_tcf_wall_stress_is_the_reference_s():
     bottom, top = TCF3DBottomEnv._get_wall_stress(me)
     assert np.allclose([float(bottom[0]), float(top[0])], G["tcf_stress_out"], rtol=2e-6)
     assert np.allclose([float(bottom[1]), float(top[1])], 3.0 * G["tcf_stress_out"], rtol=2e-6)
+
+
+def test_rbc_local_rewards_are_the_reference_s():
+    """rbc_env_2d.py:327-358: nu_ref minus the Nusselt number over each agent's window of the simulation grid (the reference's own
+    window extraction and Nusselt formula on the same fields), windows of one and three heaters."""
+    T, u, cs = (torch.as_tensor(G[k]) for k in ("rbc_local_T", "rbc_local_u", "rbc_local_cell_size"))
+    ra, pr = G["nusselt_ra_pr"]
+    for W in (1, 3):
+        blk = SimpleNamespace(passiveScalar=torch.cat([T, 0.5 * T]), velocity=torch.cat([u, u]))
+        me = SimpleNamespace(_block=blk, _cell_size=cs, _n_heaters=6, _heater_width=4, _local_obs_window=W, _ndims=2, nu_ref=2.5,
+                             _rayleigh_number=float(ra), _prandtl_number=float(pr))
+        me._local_nusselt = lambda lT, lu, lc, me=me: RBCEnvBase._local_nusselt(me, lT, lu, lc)
+        got = RBCEnvBase._get_local_rewards(me)
+        assert got.shape == (2, 6)
+        assert np.allclose(got[0].numpy(), G[f"rbc_local_rewards_w{W}"], rtol=1e-5, atol=1e-4), W
