@@ -136,6 +136,21 @@ def main():
                                    _local_obs_window=W, _heater_width=hw, n_agents=nh, nu_ref=2.5, _ndims=2, _rayleigh_number=8e4, _prandtl_number=0.7)
         me._compute_nusselt = lambda T, u_y, cell_size, me=me: nusselt(me, T, u_y, cell_size)
         out[f"rbc_local_rewards_w{W}"] = local_r(me).numpy()
+    # ---- the same in 3-D (rbc_env_3d.py:380-411): n_heaters x n_heaters agents, windows in x and z
+    win3d = function(f"{REF}/envs/util/obs_extraction.py", "extract_moving_window_3d", {"F": F})
+    local_r3 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "_get_local_rewards",
+                      {"extract_moving_window_3d": win3d, "get_cell_size": lambda block: block.cell_size})
+    nh3, hw3, ny3 = 3, 2, 4
+    T3 = torch.as_tensor(rng.random((1, 1, nh3 * hw3, ny3, nh3 * hw3)), dtype=torch.float32)
+    u3 = torch.as_tensor(rng.standard_normal((1, 3, nh3 * hw3, ny3, nh3 * hw3)), dtype=torch.float32)
+    cs3 = torch.as_tensor((0.5 + rng.random((1, ny3, 1))) * np.ones((nh3 * hw3, 1, nh3 * hw3)), dtype=torch.float32)
+    out["rbc3d_local_T"], out["rbc3d_local_u"], out["rbc3d_local_cell_size"] = T3.numpy(), u3.numpy(), cs3.numpy()
+    for W in (1, 3):
+        me = types.SimpleNamespace(_block=types.SimpleNamespace(passiveScalar=T3, getVelocity=lambda with_bounds: u3, cell_size=cs3[None, None]),
+                                   _local_obs_window=W, _heater_width=hw3, _n_heaters=nh3, nu_ref=2.5, _ndims=3, _rayleigh_number=8e4,
+                                   _prandtl_number=0.7)
+        me._compute_nusselt = lambda T, u_y, cell_size, me=me: nusselt(me, T, u_y, cell_size)
+        out[f"rbc3d_local_rewards_w{W}"] = local_r3(me).numpy()
     # ---- RBC 3-D heaters: [n_heaters, n_heaters] actions -> temperature of the bottom plate [Z, X] (rbc_env_3d.py:201-262)
     s1 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_1d")
     s2 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_2d")

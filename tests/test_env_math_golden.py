@@ -182,3 +182,17 @@ def test_rbc_local_rewards_are_the_reference_s():
         got = RBCEnvBase._get_local_rewards(me)
         assert got.shape == (2, 6)
         assert np.allclose(got[0].numpy(), G[f"rbc_local_rewards_w{W}"], rtol=1e-5, atol=1e-4), W
+
+
+def test_rbc_3d_local_rewards_are_the_reference_s():
+    """rbc_env_3d.py:380-411: the same over x-z windows of the n_heaters x n_heaters agents."""
+    T, u, cs = (torch.as_tensor(G[k]) for k in ("rbc3d_local_T", "rbc3d_local_u", "rbc3d_local_cell_size"))
+    ra, pr = G["nusselt_ra_pr"]
+    for W in (1, 3):
+        blk = SimpleNamespace(passiveScalar=torch.cat([T, T]), velocity=torch.cat([u, 2.0 * u]))
+        me = SimpleNamespace(_block=blk, _cell_size=cs, _n_heaters=3, _heater_width=2, _local_obs_window=W, _ndims=3, nu_ref=2.5,
+                             _rayleigh_number=float(ra), _prandtl_number=float(pr))
+        me._local_nusselt = lambda lT, lu, lc, me=me: RBCEnvBase._local_nusselt(me, lT, lu, lc)
+        got = RBCEnvBase._get_local_rewards(me)
+        assert got.shape == (2, 9)
+        assert np.allclose(got[0].numpy(), G[f"rbc3d_local_rewards_w{W}"], rtol=1e-5, atol=1e-4), W
