@@ -314,18 +314,25 @@ class CylinderJetEnv2D(CylinderEnvBase):
         dom.blocks[BOTTOM].boundary("+y").copy_(self._bottom_velocity[None] * a)
 
 
+def rotating_wall_velocities(mesh):
+    """Unit tangential velocity on the cylinder-wall faces of the four blocks around it, ``[(block, face, [2, n_faces])]``
+    (rotating_cylinder_env_2d.py:131-164)."""
+    out = []
+    for b, face in ((LEFT, "+x"), (TOP, "-y"), (RIGHT, "-x"), (BOTTOM, "+y")):
+        v = _face_vertices(mesh, b, face)
+        ctr = 0.5 * (v[:, :-1] + v[:, 1:])
+        th = np.arctan2(ctr[1], ctr[0])
+        out.append((b, face, np.stack([np.sin(th), -np.cos(th)]).astype(np.float32)))
+    return out
+
+
 class CylinderRotEnv2D(CylinderEnvBase):
     """The cylinder wall rotates with the commanded speed (rotating_cylinder_env_2d.py:121-176)."""
 
     def _additional_initialization(self) -> None:
         super()._additional_initialization()
         dev = self._domain.device
-        self._wall = []
-        for b, face in ((LEFT, "+x"), (TOP, "-y"), (RIGHT, "-x"), (BOTTOM, "+y")):
-            v = _face_vertices(self._mesh, b, face)
-            ctr = 0.5 * (v[:, :-1] + v[:, 1:])
-            th = np.arctan2(ctr[1], ctr[0])
-            self._wall.append((b, face, torch.as_tensor(np.stack([np.sin(th), -np.cos(th)]).astype(np.float32), device=dev)))
+        self._wall = [(b, face, torch.as_tensor(v, device=dev)) for b, face, v in rotating_wall_velocities(self._mesh)]
 
     def _apply_action(self, action: torch.Tensor) -> None:
         a = action.reshape(self._num_envs, 1, 1)

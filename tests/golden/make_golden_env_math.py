@@ -151,6 +151,15 @@ def main():
                                    _prandtl_number=0.7)
         me._compute_nusselt = lambda T, u_y, cell_size, me=me: nusselt(me, T, u_y, cell_size)
         out[f"rbc3d_local_rewards_w{W}"] = local_r3(me).numpy()
+    # ---- rotating cylinder: unit tangential velocity on the wall faces of the four blocks around it (rotating_cylinder_env_2d.py:131-164)
+    rot = method(f"{REF}/envs/cylinder/rotating_cylinder_env_2d.py", "CylinderRotEnv2D", "_get_boundary_velocities")
+    for res in (8, 24):
+        coords = [torch.as_tensor(mesh[f"r{res}_block{b}"], dtype=torch.float32)[None] for b in range(5)]
+        me = types.SimpleNamespace(_domain=types.SimpleNamespace(getVertexCoordinates=lambda: coords), _left_block_idx=0, _top_block_idx=1,
+                                   _right_block_idx=2, _bottom_block_idx=3)
+        left, top, bottom, right = rot(me)
+        for nm, v in (("left", left), ("top", top), ("bottom", bottom), ("right", right)):
+            out[f"cyl_rot_r{res}_{nm}"] = v.numpy().reshape(2, -1)
     # ---- RBC 3-D heaters: [n_heaters, n_heaters] actions -> temperature of the bottom plate [Z, X] (rbc_env_3d.py:201-262)
     s1 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_1d")
     s2 = method(f"{REF}/envs/rbc/rbc_env_3d.py", "RBCEnv3D", "__smooth_action_profile_2d")

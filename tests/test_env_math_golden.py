@@ -196,3 +196,20 @@ def test_rbc_3d_local_rewards_are_the_reference_s():
         got = RBCEnvBase._get_local_rewards(me)
         assert got.shape == (2, 9)
         assert np.allclose(got[0].numpy(), G[f"rbc3d_local_rewards_w{W}"], rtol=1e-5, atol=1e-4), W
+
+
+def test_rotating_cylinder_wall_velocities_are_the_reference_s():
+    """rotating_cylinder_env_2d.py:131-164 on the reference's own mesh: unit tangential velocity on the wall faces of the left, top,
+    right and bottom block, in the order of their face cells."""
+    from fluidgym_amd.envs.cylinder import BOTTOM, LEFT, RIGHT, TOP, rotating_wall_velocities
+    from fluidgym_amd.envs.cylinder_grid import make_vortex_street_mesh
+
+    for res in (8, 24):
+        env = fluidgym_amd.make("CylinderRot2D-easy-v0", cuda_device=torch.device("cpu"), resolution=res)
+        mesh = make_vortex_street_mesh(env._circle_resolution_angular, env.H, env.L, env.cylinder_diameter / 2, env.cylinder_offset_y,
+                                       env.cylinder_diameter / 2, env.cylinder_diameter, env._vortex_street_refinement_base)
+        names = {LEFT: "left", TOP: "top", RIGHT: "right", BOTTOM: "bottom"}
+        walls = rotating_wall_velocities(mesh)          # what CylinderRotEnv2D._additional_initialization uploads
+        assert [b for b, _, _ in walls] == [LEFT, TOP, RIGHT, BOTTOM]
+        for b, face, v in walls:
+            assert np.allclose(v, G[f"cyl_rot_r{res}_{names[b]}"], atol=3e-6), (res, names[b])
