@@ -105,6 +105,12 @@ class TCF3DBottomEnv(FluidEnv):
                          episode_length=episode_length, ndims=3, **kw)
 
     @property
+    def render_shape(self):
+        """(x, y, z) of the rendered domain (tcf_env.py:295-301)."""
+        x = 2 * self._x
+        return (x, int(x / self._L * self._H), int(x / self._L * self._D))
+
+    @property
     def scale_actions(self) -> bool:
         """Whether actions are scaled by u_wall (tcf_env.py:429-436)."""
         return self._scale_actions

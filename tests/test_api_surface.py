@@ -231,3 +231,13 @@ def test_package_exports_and_config_object(tmp_path):
     with pytest.raises(ValueError, match="Unhandled configuration key"):
         cfg.update("hf_intial_domains_repo_id", "x/y")
     assert len(cfg.palette) == 8
+
+
+def test_tcf_render_shape_formula():
+    """tcf_env.py:295-301: (2 x, int(2 x / L * H), int(2 x / L * D))."""
+    import torch
+
+    small = fluidgym_amd.make("TCFSmall3D-both-easy-v0", cuda_device=torch.device("cpu"))
+    large = fluidgym_amd.make("TCFLarge3D-bottom-hard-v0", cuda_device=torch.device("cpu"))
+    assert small.render_shape == (128, int(128 / np.pi * 2.0), int(128 / np.pi * (np.pi / 2)))
+    assert large.render_shape == (256, int(256 / (2 * np.pi) * 2.0), int(256 / (2 * np.pi) * np.pi))
