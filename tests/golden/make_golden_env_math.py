@@ -72,6 +72,17 @@ def main():
         out[f"tcf_action_{tag}"] = a.numpy()
         out[f"tcf_control_{tag}"] = to_control(me, a).numpy()                                 # [1, 3, Z, 1, X]
     out["tcf_u_wall_actor_size"] = np.array([0.0557, 2])
+    # ---- TCF, both walls actuated: first half of the agents drives the bottom wall, second half the top wall with the sign of the
+    # wall-normal velocity reversed (tcf_env.py:1143-1154)
+    both = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBothEnv", "_apply_action")
+    sent = {}
+    me = types.SimpleNamespace(n_agents=2 * 6 * 4, _n_actors_x=6, _n_actors_z=4, _scale_actions=True, _u_wall=0.0557, _z=8, _x=12, _actor_size=2,
+                               _cuda_device=torch.device("cpu"), _bottom_plate=types.SimpleNamespace(setVelocity=lambda v: sent.__setitem__("bottom", v)),
+                               _top_plate=types.SimpleNamespace(setVelocity=lambda v: sent.__setitem__("top", v)))
+    me._action_to_control = lambda a: to_control(me, a)
+    a_both = torch.as_tensor(2.0 * rng.standard_normal(48), dtype=torch.float32)
+    both(me, a_both)
+    out["tcf_both_action"], out["tcf_both_bottom"], out["tcf_both_top"] = a_both.numpy(), sent["bottom"].numpy(), sent["top"].numpy()
     # ---- TCF wall shear stress of both walls from the plane-mean streamwise velocity of the first / last cell row (tcf_env.py:564-584)
     stress = method(f"{REF}/envs/tcf/tcf_env.py", "TCF3DBottomEnv", "_get_wall_stress")
     Zs, Ys, Xs = 4, 7, 5

@@ -213,3 +213,27 @@ def test_rotating_cylinder_wall_velocities_are_the_reference_s():
         assert [b for b, _, _ in walls] == [LEFT, TOP, RIGHT, BOTTOM]
         for b, face, v in walls:
             assert np.allclose(v, G[f"cyl_rot_r{res}_{names[b]}"], atol=3e-6), (res, names[b])
+
+
+def test_tcf_both_walls_actuation_is_the_reference_s():
+    """tcf_env.py:1143-1154: the first half of the agents drives the bottom wall, the second half the top wall with the
+    wall-normal velocity reversed; each half scaled on its own."""
+    from fluidgym_amd.envs.tcf import TCF3DBothEnv
+
+    a = torch.as_tensor(G["tcf_both_action"])
+    u_wall, actor = G["tcf_u_wall_actor_size"]
+    walls = {}
+
+    class Plate:
+        def __init__(self, name):
+            self.velocity = torch.ones(2, 3, 8, 1, 12)
+            walls[name] = self
+
+    me = SimpleNamespace(_num_envs=2, _n_actors_x=6, _n_actors_z=4, _scale_actions=True, _u_wall=float(u_wall), _actor_size=int(actor),
+                         _bottom_plate=Plate("bottom"), _top_plate=Plate("top"))
+    me._action_to_control = lambda x: TCF3DBottomEnv._action_to_control(me, x)
+    me._set_wall = lambda plate, v: TCF3DBottomEnv._set_wall(me, plate, v)
+    TCF3DBothEnv._apply_action(me, torch.stack([a, -a]))
+    assert np.allclose(walls["bottom"].velocity[0].numpy(), G["tcf_both_bottom"][0], atol=1e-7)
+    assert np.allclose(walls["top"].velocity[0].numpy(), G["tcf_both_top"][0], atol=1e-7)
+    assert np.allclose(walls["bottom"].velocity[1].numpy(), -G["tcf_both_bottom"][0], atol=1e-7)
