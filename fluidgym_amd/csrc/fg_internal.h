@@ -374,7 +374,7 @@ struct FgCounters {
         for (int i = 0; i < count; ++i) {
             const int it = info[i].used_iterations;
             if (it < 0 && info[i].final_residual == 0.f) continue;   // masked-out env (dt <= 0)
-            const int v = it < 0 ? 0 : it;                           // -1: converged before the first iteration
+            const int v = it + 1;   // used_iterations is the 0-based index of the last iteration (-1: none was needed): a COUNT here
             sum[kind] += v; n[kind] += 1; max[kind] = v > max[kind] ? v : max[kind];
         }
     }
