@@ -49,6 +49,15 @@ class Command(IntEnum):
     SAMPLE_ACTION = 8
 
 
+def _free_port() -> int:
+    """A port the OS just handed out (29000 + pid % 2000 could collide between two drivers on one host)."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return int(sock.getsockname()[1])
+
+
 def _spawn_worker(rank: int, world: int, port: int, env_id: str, cuda_ids: List[int], num_envs: int,
                   env_kwargs: Dict[str, Any], backend: str):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -74,7 +83,7 @@ class ParallelFluidEnv:
             import torch.multiprocessing as mp
 
             world = len(cuda_ids)
-            port = int(os.environ.get("FLUIDGYM_MASTER_PORT", 29000 + (os.getpid() % 2000)))
+            port = int(os.environ.get("FLUIDGYM_MASTER_PORT", 0)) or _free_port()
             n_total = num_envs if num_envs is not None else world
             ctx = mp.get_context("spawn")
             for r in range(1, world):
@@ -109,14 +118,16 @@ class ParallelFluidEnv:
             kw["cuda_device"] = self._device
         self._env = make(env_id, num_envs=self._n_local, **kw)
         self._obs_keys = sorted(self._env.observation_space.keys())
-        # ONE message per command: int32 header [cmd, a, b, c] followed by the action block bit-cast to int32, so that a
+        # ONE message per command: header [cmd, a, b, c] (four int64 fields seen as eight int32 words, so that seeds of 2**31 and
+        # more travel: np.random.SeedSequence / getrandbits(32) produce them) followed by the action block bit-cast to int32, so that a
         # step costs one broadcast (header + actions) and one all_gather (obs | reward | terminated | truncated | info)
         self._a_shape = (self._n_total,) + tuple(self._env._zero_action.shape[1:])
         self._a_numel = int(np.prod(self._a_shape))
         self._msg = torch.zeros(self._HDR + self._a_numel, dtype=torch.int32, device=self._device)
         self._info_layout: Optional[List] = None
+        self._reset_info_layout: Optional[List] = None
 
-    _HDR = 4
+    _HDR = 8   # int32 words: four int64 header fields
 
     # ------------------------------------------------------------------ introspection
     def __getattr__(self, name: str) -> Any:
@@ -176,7 +187,7 @@ class ParallelFluidEnv:
         """The one broadcast of a command.  Driver: fills header (+ actions).  ``read_header=False`` (SPMD ranks that
         already know the command because they made the same call) skips the device->host read of the header."""
         if self.is_driver:
-            hdr = torch.tensor([int(cmd), int(a), int(b), int(c)], dtype=torch.int32)
+            hdr = torch.tensor([int(cmd), int(a), int(b), int(c)], dtype=torch.int64).view(torch.int32)
             self._msg[: self._HDR].copy_(hdr, non_blocking=True)
             if action is not None:
                 self._msg[self._HDR:].copy_(action.to(self._device, torch.float32).reshape(-1).view(torch.int32))
@@ -186,7 +197,7 @@ class ParallelFluidEnv:
         dist.broadcast(self._msg, src=0)
         if not read_header:
             return [int(cmd) if cmd is not None else -1, a, b, c]
-        return [int(v) for v in self._msg[: self._HDR].tolist()]
+        return [int(v) for v in self._msg[: self._HDR].cpu().view(torch.int64).tolist()]
 
     def _actions_from_msg(self) -> torch.Tensor:
         return self._msg[self._HDR:].view(torch.float32).reshape(self._a_shape)
@@ -213,17 +224,40 @@ class ParallelFluidEnv:
     def _pack(self, obs: Dict[str, torch.Tensor], reward: Optional[torch.Tensor], term=None, trunc=None,
               info: Optional[Dict[str, Any]] = None) -> torch.Tensor:
         parts = [obs[k].reshape(self._n_local, -1).float() for k in self._obs_keys]
+        if reward is None and info:
+            # reset: the reference returns one info dict per worker = per env (parallel_env.py:222-231)
+            if self._reset_info_layout is None:
+                self._reset_info_layout = self._layout_of(info)
+            parts += [self._per_env(info[k]) for k, _, _ in self._reset_info_layout]
         if reward is not None:
             parts.append(reward.reshape(self._n_local, -1).float())
             parts.append(self._per_env(term))
             parts.append(self._per_env(trunc))
             if self._info_layout is None:   # same keys / shapes on every rank (same env class and config)
-                self._info_layout = [(k, tuple(self._per_env(info[k]).shape[1:]),
-                                      tuple(torch.as_tensor(info[k]).shape[1:]) if torch.as_tensor(info[k]).dim() > 0
-                                      and torch.as_tensor(info[k]).shape[0] == self._n_local else None)
-                                     for k in sorted(info or {})]
+                self._info_layout = self._layout_of(info)
             parts += [self._per_env(info[k]) for k, _, _ in self._info_layout]
         return torch.cat(parts, dim=1)
+
+    def _layout_of(self, info: Optional[Dict[str, Any]]) -> List:
+        """(key, packed row shape, per-env shape or None for a per-shard value) of every numeric entry of an info dict."""
+        out = []
+        for k in sorted(info or {}):
+            try:
+                t = torch.as_tensor(info[k])
+            except (TypeError, ValueError, RuntimeError):
+                continue    # not numeric: stays on its shard
+            per_env = tuple(t.shape[1:]) if t.dim() > 0 and t.shape[0] == self._n_local else None
+            out.append((k, tuple(self._per_env(info[k]).shape[1:]), per_env))
+        return out
+
+    def _unpack_info(self, flat: torch.Tensor, off: int, layout: List) -> Dict[str, torch.Tensor]:
+        info, n = {}, flat.shape[0]
+        for k, w, shp in layout:
+            size = int(np.prod(w))
+            v = flat[:, off: off + size]
+            info[k] = v.reshape((n,) + shp) if shp is not None else v.reshape(n, -1)
+            off += size
+        return info
 
     def _unpack(self, flat: torch.Tensor, obs_like: Dict[str, torch.Tensor], with_reward: bool):
         out, off = {}, 0
@@ -234,20 +268,14 @@ class ParallelFluidEnv:
             out[k] = flat[:, off: off + size].reshape((n,) + tuple(shp))
             off += size
         if not with_reward:
-            return out, None, None, None, None
+            return out, None, None, None, self._unpack_info(flat, off, self._reset_info_layout or [])
         info_w = sum(int(np.prod(w)) for _, w, _ in self._info_layout)
         r_w = flat.shape[1] - off - 2 - info_w
         reward = flat[:, off: off + r_w].reshape(n, *(() if r_w == 1 else (-1,)))
         off += r_w
         term, trunc = flat[:, off] != 0, flat[:, off + 1] != 0
         off += 2
-        info = {}
-        for k, w, shp in self._info_layout:
-            size = int(np.prod(w))
-            v = flat[:, off: off + size]
-            info[k] = v.reshape((n,) + shp) if shp is not None else v.reshape(n, -1)
-            off += size
-        return out, reward, term, trunc, info
+        return out, reward, term, trunc, self._unpack_info(flat, off, self._info_layout)
 
     # ------------------------------------------------------------------ env API (collective)
     # Every public method is a COLLECTIVE call: all ranks that are not inside serve() must call it; the
@@ -257,17 +285,21 @@ class ParallelFluidEnv:
         self._env.seed(a + self.rank)
 
     def reset(self, seed: Optional[int] = None, randomize: Optional[bool] = None):
-        """All shards reset with seeds ``seed + rank`` (independent envs); returns the observations of
-        all ``num_envs`` envs stacked along dim 0 and a list of per-shard info dicts."""
+        """All shards reset with seeds ``seed + rank``; returns the observations of all ``num_envs`` envs stacked along dim 0
+        and one info dict per ENV gathered from all shards (the reference: one per worker = per env, parallel_env.py:222-231).
+        Departure: the reference hands the SAME seed to every worker (parallel_env.py:133-135, 226-228) -- its envs then differ
+        only when their initial domains are drawn differently; here a shard holds a batch whose envs draw from one generator,
+        so shards get ``seed + rank`` or every shard would replay the same batch."""
         _, a, b, _ = self._send(Command.RESET, -1 if seed is None else int(seed),
                                 -1 if randomize is None else int(randomize))
         return self._do_reset(None if a < 0 else a, None if b < 0 else bool(b))
 
     def _do_reset(self, seed, randomize):
         obs, info = self._env.reset(seed=None if seed is None else int(seed) + self.rank, randomize=randomize)
-        flat = self._all_gather(self._pack(obs, None))
-        obs_all = self._unpack(flat, obs, with_reward=False)[0]
-        return self._agents_to_rows(obs_all), [info for _ in range(self._n_total)]
+        flat = self._all_gather(self._pack(obs, None, info=info))
+        obs_all, _, _, _, info_all = self._unpack(flat, obs, with_reward=False)
+        infos = [{k: v[i].cpu() for k, v in info_all.items()} for i in range(self._n_total)]
+        return self._agents_to_rows(obs_all), infos
 
     def step(self, action: Optional[torch.Tensor] = None):
         """Driver: ``action [num_envs, ...]``.  Other ranks in SPMD mode pass ``None``.  Returns the reference's tuple

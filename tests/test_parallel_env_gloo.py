@@ -45,7 +45,7 @@ class ToyEnv:
             self._seed = seed
         g = torch.Generator().manual_seed(self._seed)
         self.state = torch.randn(self._num_envs, 3, generator=g)
-        return self._obs(), {}
+        return self._obs(), {"init_sum": self.state.sum(dim=1), "label": "not numeric: stays on its shard"}
 
     def step(self, action):
         assert action.shape == (self._num_envs, 3)
@@ -73,6 +73,9 @@ class ToyEnv:
 
     def close(self):
         pass
+
+
+BIG_SEED = 2 ** 32 - 1
 
 
 def _register():
@@ -105,7 +108,7 @@ def _worker(rank, world, port, mode, q):
         return
     from fluidgym_amd.types import EnvMode
 
-    penv.seed(5)
+    penv.seed(BIG_SEED)    # >= 2**31: must survive the command header (np.random.SeedSequence / getrandbits(32) give such seeds)
     sampled = penv.sample_action()          # a collective: hung in serve() mode before the command existed
     penv.load_initial_domain(3, EnvMode.TEST)
     loaded = penv.local_env.loaded
@@ -116,7 +119,8 @@ def _worker(rank, world, port, mode, q):
     mode_seen = penv.local_env.mode
     penv.close()
     if penv.is_driver:
-        extra = {"sampled": sampled.numpy().copy(), "loaded": loaded, "n_infos0": len(infos0), "term2": out2[2], "trunc2": out2[3],
+        extra = {"sampled": sampled.numpy().copy(), "loaded": loaded, "n_infos0": len(infos0),
+                 "init_sum": np.array([float(i["init_sum"]) for i in infos0]), "term2": out2[2], "trunc2": out2[3],
                  "info_m": np.array([float(i["m"]) for i in out2[4]]), "info_v": np.stack([i["v"].numpy() for i in out2[4]])}
         q.put((rank, {k: v.numpy().copy() for k, v in obs0.items()}, out[1].numpy().copy(), out2[1].numpy().copy(),
                {k: v.numpy().copy() for k, v in out2[0].items()}, mode_seen, extra))
@@ -127,16 +131,18 @@ def _worker(rank, world, port, mode, q):
 def _expected():
     envs = [ToyEnv(num_envs=2), ToyEnv(num_envs=2)]
     actions = torch.arange(12, dtype=torch.float32).reshape(4, 3) * 0.1
-    obs0 = [e.reset(seed=11 + r)[0] for r, e in enumerate(envs)]
+    res0 = [e.reset(seed=11 + r) for r, e in enumerate(envs)]
+    obs0 = [x[0] for x in res0]
     r1 = [e.step(actions[2 * r: 2 * r + 2])[1] for r, e in enumerate(envs)]
     o2r2 = [e.step(2 * actions[2 * r: 2 * r + 2]) for r, e in enumerate(envs)]
     cat = lambda ds: {k: torch.cat([d[k] for d in ds]) for k in ds[0]}
     extra = {"term2": torch.cat([x[2] for x in o2r2]).tolist(), "info_m": torch.cat([x[4]["m"] for x in o2r2]).numpy(),
              "info_v": torch.cat([x[4]["v"] for x in o2r2]).numpy()}
+    extra["init_sum"] = torch.cat([x[1]["init_sum"] for x in res0]).numpy()
     samp = []
     for r in range(2):
         e = ToyEnv(num_envs=2)
-        e.seed(5 + r)
+        e.seed(BIG_SEED + r)
         samp.append(e.sample_action())
     extra["sampled"] = torch.cat(samp).numpy()
     return cat(obs0), torch.cat(r1), torch.cat([x[1] for x in o2r2]), cat([x[0] for x in o2r2]), extra
@@ -166,6 +172,7 @@ def test_two_rank_gloo_matches_single_process(mode):
     # per-env terminated flags and info entries of EVERY shard (reference parallel_env.py:276-287), not the driver's copy
     assert got["term2"] == exp["term2"] and any(got["term2"]) and not all(got["term2"])
     assert got["trunc2"] == [False] * 4 and got["n_infos0"] == 4
+    assert np.allclose(got["init_sum"], exp["init_sum"])          # reset infos per ENV, gathered from every shard (parallel_env.py:222-231)
     assert np.allclose(got["info_m"], exp["info_m"]) and np.allclose(got["info_v"], exp["info_v"])
     assert np.allclose(got["sampled"], exp["sampled"])           # each shard sampled from its own generator (seed + rank)
     from fluidgym_amd.types import EnvMode
