@@ -168,3 +168,23 @@ def cylinder_3d_small(res=4, res_z=3, nu=0.01):
     s.connections = [(b1, F[f1], b2, F[f2], F[a1], F[a2]) for b1, f1, b2, f2, a1, a2 in m.connections]
     s.periodic = [(b, 2) for b, _ in m.periodic]
     return s
+
+
+def airfoil_spec(div=4, nu=1e-3):
+    """The airfoil envs' six-block C-mesh (envs/airfoil/grid.py:247-716 in the reference) at ``resolution_div = 4`` (4 110 cells,
+    small enough for the per-cell oracle): the mesh with cells of 1e-4 of the typical area where the blocks meet at the nose,
+    the one whose pressure matrix is visibly non-symmetric."""
+    from fluidgym_amd.envs.airfoil_grid import make_airfoil_mesh
+
+    m = make_airfoil_mesh(resolution_div=div, attack_angle_deg=10.0)
+    F = {"-x": 0, "+x": 1, "-y": 2, "+y": 3}
+    s = Spec(2, nu)
+    s.blocks = [c.astype(np.float64) for c in m.coords]
+    rng = np.random.default_rng(9)
+    s.fixed = []
+    for (b, f), v in m.fixed.items():
+        face_cells = s.blocks[b].shape[2 if F[f] >= 2 else 1] - 1
+        v = np.broadcast_to(np.asarray(v, np.float64).reshape(2, -1), (2, face_cells))
+        s.fixed.append((b, F[f], v + 0.1 * rng.standard_normal(v.shape)))
+    s.connections = [(b1, F[f1], b2, F[f2], F[ax]) for b1, f1, b2, f2, ax in m.connections]
+    return s

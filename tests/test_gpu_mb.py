@@ -111,7 +111,7 @@ def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     dom.close()
 
 
-@pytest.mark.parametrize("spec_fn", [H.skewed_pair, H.twisted_ring, H.cylinder_3d_small])
+@pytest.mark.parametrize("spec_fn", [H.skewed_pair, H.twisted_ring, H.cylinder_3d_small, H.airfoil_spec])
 def test_assembly_matches_oracle_on_strongly_skewed_meshes(spec_fn):
     """Matrices, right-hand sides, predictor, h and the pressure right-hand side with its lagged corner terms, on meshes
     where every cross-metric branch is active (walls with moving Dirichlet values, connections with shuffled axes, a
@@ -122,11 +122,29 @@ def test_assembly_matches_oracle_on_strongly_skewed_meshes(spec_fn):
     d = spec.oracle()
     B = 2
     dom = spec.native(batch=B)
-    dt = [0.05, 0.03]
+    # (the airfoil C-mesh -- airfoil/grid.py:629-707, cells down to 1e-4 of the typical area at the nose -- takes a time step
+    # of the size its env runs with; PISO_multiblock_cuda_kernel.cu:3616-3880, 4812-4978 are what is being compared)
+    dt = [2e-3, 1e-3] if spec_fn is H.airfoil_spec else [0.05, 0.03]
     states = [_state(d, 20 + b) for b in range(B)]
     _load(dom, states)
     dom.piso_step(dt, corrector_steps=1, advection_tol=1e-7, pressure_tol=1e-5, raise_on_failure=False, max_iterations=600)
     _assembly_parity(dom, d, states, dt, B, check_div=True)
+    dom.close()
+
+
+def test_airfoil_mesh_step_matches_the_oracle():
+    """One whole PISO step on the airfoil C-mesh (resolution_div 4) against the oracle's direct solves, with the solver the
+    airfoil env runs: mean-projected BiCGStab with fp64 refinement at the env's tolerance (airfoil_env_base.py:272)."""
+    spec = H.airfoil_spec()
+    d = spec.oracle()
+    dom = spec.native(batch=1)
+    st = [_state(d, 31)]
+    _load(dom, st)
+    dom.piso_step([1e-3], advection_tol=1e-7, pressure_tol=1e-7, pressure_use_bicgstab=2, pressure_project_mean=False,
+                  max_iterations=3000)
+    u_ref, p_ref = d.piso_step(st[0][0], st[0][1], 1e-3)
+    assert _rel(dom.velocity[0].cpu().numpy(), u_ref) < 2e-4
+    assert _rel(dom.pressure[0].cpu().numpy(), p_ref) < 2e-3
     dom.close()
 
 

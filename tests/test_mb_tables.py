@@ -27,6 +27,30 @@ def _cylinder_spec():
     return s
 
 
+def _recorded_airfoil_spec():
+    """The reference's OWN airfoil mesh at full resolution (45 k cells, NACA 0012 at 20 degrees; vertex coordinates, boundary
+    velocities and construction calls recorded off its make_airfoil_domain, tests/golden/make_golden_airfoil.py): the smallest
+    cells have 1e-7 of the typical area where front / top / bottom blocks meet."""
+    import os
+
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_airfoil_grid.npz"))
+    F = {"-x": 0, "+x": 1, "-y": 2, "+y": 3}
+    calls = [str(c).split() for c in G["aoa20_calls"]]
+    s = H.Spec(2, 0.3 / 1e3)
+    order = sorted(int(c[1]) for c in calls if c[0] == "block")
+    s.blocks = [G[f"aoa20_block{b}"].astype(np.float64) for b in order]
+    for c in calls:
+        if c[0] == "velocity":
+            b, f = int(c[1]), F[c[2]]
+            face_cells = s.blocks[b].shape[2 if f >= 2 else 1] - 1
+            v = G[f"aoa20_velocity_{b}_{c[2]}"].astype(np.float64)
+            v = v.reshape(2, -1) if v.size > 2 else v.reshape(2, 1)
+            s.fixed.append((b, f, np.ascontiguousarray(np.broadcast_to(v, (2, face_cells)))))
+        elif c[0] == "connect":
+            s.connections.append((int(c[1]), F[c[2]], int(c[3]), F[c[4]], F[c[5]]))
+    return s
+
+
 class HostTables:
     def __init__(self, spec, flags=25):
         self.lib = L.load()
@@ -58,7 +82,11 @@ class HostTables:
         self.lib.fg_mb_destroy(self.h)
 
 
-SPECS = [H.split_rotated_channel, H.skewed_pair, H.twisted_ring, H.skewed_pair_3d, _cylinder_spec, H.cylinder_3d_small]
+SPECS = [H.split_rotated_channel, H.skewed_pair, H.twisted_ring, H.skewed_pair_3d, _cylinder_spec, H.cylinder_3d_small, H.airfoil_spec]
+
+
+def test_tables_of_the_reference_airfoil_mesh_reproduce_the_oracle():
+    test_tables_reproduce_the_oracle(_recorded_airfoil_spec, 25)
 
 
 @pytest.mark.parametrize("flags", [25, 10])
