@@ -172,6 +172,8 @@ SIGNATURES = {
     "fg_mb_multilevel_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "fg_mb_multilevel_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fg_mb_debug_bicgstab": (c_int, [c_void_p, c_float, c_int32, c_int32, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_float), c_void_p]),
+    "fg_dacc_host_sum": (c_int, [POINTER(ctypes.c_double), c_int64, ctypes.c_double, POINTER(ctypes.c_double)]),
+    "fg_dacc_device_sum": (c_int, [POINTER(ctypes.c_double), c_int64, ctypes.c_double, c_int32, POINTER(ctypes.c_double), c_void_p]),
     "fg_coherence_litmus": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_int64), POINTER(ctypes.c_double), c_void_p]),
     "fg_profile_enable": (c_int, [c_void_p, c_int]),
     "fg_profile_kinds": (c_int, []),
@@ -208,6 +210,7 @@ SIGNATURES = {
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "fg_mb_ladder": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_debug_cycles": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
+    "fg_mb_solver_hints": (c_int, [c_void_p, POINTER(c_int32), c_int32]),
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_profile_iterations": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -94,8 +94,8 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(alloc(&s->scal_result, BN));
     for (int i = 0; i < 7; ++i) FG_HIP_CHECK(alloc(&s->w[i], BN * d));
     const size_t nsys = (size_t)g.B * d;
-    FG_HIP_CHECK(hipMalloc(&s->acc, sizeof(double) * nsys * FG_ACC_DOUBLES));
-    FG_HIP_CHECK(hipMemset(s->acc, 0, sizeof(double) * nsys * FG_ACC_DOUBLES));
+    FG_HIP_CHECK(hipMalloc(&s->acc, sizeof(FgDacc) * nsys * FG_ACC_DOUBLES));
+    FG_HIP_CHECK(hipMemset(s->acc, 0, sizeof(FgDacc) * nsys * FG_ACC_DOUBLES));
     FG_HIP_CHECK(hipMalloc(&s->flags, sizeof(int32_t) * nsys));
     FG_HIP_CHECK(hipMalloc(&s->info_dev, sizeof(fg_solve_info) * nsys));
     FG_HIP_CHECK(hipHostMalloc(&s->info_pinned, sizeof(fg_solve_info) * nsys));
@@ -109,8 +109,8 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     s->pred_bicg = 2; s->pred_cg = 1;
     s->cg_return_best = 1;
     s->adv_from_result = 1;
-    FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(double) * (size_t)g.B * 8 * 64));
-    FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(double) * (size_t)g.B * 8 * 64));
+    FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(FgDacc) * (size_t)g.B * 8 * 64));
+    FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(FgDacc) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMalloc(&s->cg_best.best_crit, sizeof(float) * g.B));
     FG_HIP_CHECK(hipMalloc(&s->cg_best.saved_crit, sizeof(float) * g.B));
     FG_HIP_CHECK(hipMalloc(&s->cg_best.save_at, sizeof(int32_t) * g.B));

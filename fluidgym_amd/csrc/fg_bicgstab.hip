@@ -68,7 +68,7 @@ __device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int
 struct BicgPtrs {
     const float* diag; const float* off; const float* rhs;
     float* x; float* r; float* rw; float* p; float* v; float* t;
-    double* acc; float* sc; int32_t* flags; fg_solve_info* info;
+    FgDacc* acc; float* sc; int32_t* flags; fg_solve_info* info;
     int nc; float tol;
 };
 
@@ -142,9 +142,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_init(FgGrid g, BicgPtrs q, in
         }
         fg_block_sum<1>(part, lds);
         if (threadIdx.x == 0) {
-            double* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-            atomicAdd(a + A_RHO, (double)part[0]);
-            atomicAdd(a + A_RR, (double)part[0]);
+            FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+            acc_add(a + A_RHO, (double)part[0]);
+            acc_add(a + A_RR, (double)part[0]);
         }
         __syncthreads();
     }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int i
         return;
     }
     if (f != 0) return;
-    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    FgDacc* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
     const float crit = fg_rms(acc_ld(a + (A_RR)), g.n);
     if (!(crit >= q.tol)) {
         if (s.leader) fg_mark(q.flags, q.info, s.sys, crit, it == 0 ? -1 : it);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_v(FgGrid g, BicgPtrs q, int i
             for (int e = 0; e < VEC; ++e) part[0] += rw.v[e] * y.v[e];
         }
         fg_block_sum<1>(part, lds);
-        if (threadIdx.x == 0) atomicAdd(q.acc + (size_t)sys * FG_ACC_DOUBLES + A_RV, (double)part[0]);
+        if (threadIdx.x == 0) acc_add(q.acc + (size_t)sys * FG_ACC_DOUBLES + A_RV, (double)part[0]);
         __syncthreads();  // lds reused by the next component
     }
 }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_s(FgGrid g, BicgPtrs q, int i
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
     if (flag_ld(q.flags + (s.sys)) != 0) return;
-    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    FgDacc* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
     const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
     const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
     if (s.leader) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_s(FgGrid g, BicgPtrs q, int i
         fg_store<VEC>(q.r + vb + c.idx, r);
     }
     fg_block_sum<1>(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + A_SS, (double)part[0]);
+    if (threadIdx.x == 0) acc_add(a + A_SS, (double)part[0]);
 }
 
 // K4_i: t = C s ; ts += t.s ; tt += t.t        (skipped when ||s|| already meets the tolerance; grid.y = 1)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int i
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
         if (flag_ld(q.flags + (sys)) != 0) continue;
-        double* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+        FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
         const float crit_s = fg_rms(acc_ld(a + (A_SS)), g.n);
         if (!(crit_s >= q.tol)) {
             // converged on s (bicgstab_solver_kernel.cu:305-329): flag 4 = "K5 applies x += alpha p, then done".
@@ -307,9 +307,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int i
         }
         fg_block_sum<2>(part, lds);
         if (threadIdx.x == 0) {
-            double* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-            atomicAdd(a + A_TS, (double)part[0]);
-            atomicAdd(a + A_TT, (double)part[1]);
+            FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+            acc_add(a + A_TS, (double)part[0]);
+            acc_add(a + A_TT, (double)part[1]);
         }
         __syncthreads();
     }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
     const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
     const int f = flag_ld(q.flags + (s.sys));  // stable during this launch: K5 never writes flags
     if (f != 0 && f != 4) return;
-    double* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
+    FgDacc* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
     const float alpha = sc_ld(q.sc + (s.sys * 2 + 0));
     const bool half = (f == 4);
     const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / acc_ld(a + (A_TT)));
@@ -360,12 +360,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
     if (half) return;
     fg_block_sum<2>(part, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RR, (double)part[0]);
-        atomicAdd(a + A_RHO + ((it + 1) & 1), (double)part[1]);
+        acc_add(a + A_RR, (double)part[0]);
+        acc_add(a + A_RHO + ((it + 1) & 1), (double)part[1]);
     }
 }
 
-__global__ void k_bicg_begin(const float* __restrict__ dt, double* __restrict__ acc, float* __restrict__ sc,
+__global__ void k_bicg_begin(const float* __restrict__ dt, FgDacc* __restrict__ acc, float* __restrict__ sc,
                              int32_t* __restrict__ flags, fg_solve_info* __restrict__ info, int nsys, int nc) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
@@ -379,7 +379,7 @@ __global__ void k_bicg_begin(const float* __restrict__ dt, double* __restrict__ 
     info[s].is_finite = 1;
 }
 
-__global__ void k_bicg_check(double* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+__global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
                              fg_solve_info* __restrict__ mirror, float tol, int it, int n, int nsys, int final_pass) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;

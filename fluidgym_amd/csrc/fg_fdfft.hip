@@ -23,7 +23,7 @@ struct DctArgs {
     const float2* rot;                      // [n]    (cos, sin)(pi k / 2n)
     float scale0, scale;                    // forward: s_k / sqrt(h); inverse: 1 / (s_k n sqrt(h))   (k = 0 | k > 0)
     const int32_t* flags;                   // env b skipped when flags[b] != 0
-    const float* dot_with; double* dot_acc; int dot_stride, dot_ns;   // inverse only: acc[b] += sum dst .* dot_with
+    const float* dot_with; FgDacc* dot_acc; int dot_stride, dot_ns;   // inverse only: acc[b] += sum dst .* dot_with
     long env_stride; int rows;
 };
 
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
         float part[1] = {dot};
         fg_block_sum<1>(part, red);
         if (threadIdx.x == 0)
-            atomicAdd(a.dot_acc + (size_t)b * a.dot_stride + (blockIdx.x & (unsigned)(a.dot_ns - 1)), (double)part[0]);
+            acc_add(a.dot_acc + (size_t)b * a.dot_stride + (blockIdx.x & (unsigned)(a.dot_ns - 1)), (double)part[0]);
     }
 }
 
@@ -182,7 +182,7 @@ int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st) {
     const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, G.B, 8.0 * G.n, 5.0 * G.n * log2((double)G.nx), st);
     return launch_dct<false>(s, G.nx, a, slot, st);
 }
-int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, double* dot_acc, int dot_stride,
+int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, FgDacc* dot_acc, int dot_stride,
                       int dot_ns, hipStream_t st) {
     const FgGrid& G = s->grid;
     DctArgs a = {};

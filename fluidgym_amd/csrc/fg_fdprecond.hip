@@ -20,7 +20,7 @@ struct GemmArgs {
     int M, N, K;
     const int32_t* flags;                     // batch b is skipped when flags[b] != 0
     const float* dot_with; long strideW;      // optional: acc[b] += sum C .* W  (W laid out like C)
-    double* dot_acc; int dot_stride; int dot_ns;  // slotted accumulator: dot_acc[b * dot_stride + (block & (ns-1))]
+    FgDacc* dot_acc; int dot_stride; int dot_ns;  // slotted accumulator: dot_acc[b * dot_stride + (block & (ns-1))]
 };
 
 // C = A * B, fp32 in / fp32 accumulate on MFMA 32x32x2.  256 threads = 4 waves in a 2 x 2 arrangement,
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g, int tiles_n, int t
         float part[1] = {dot};
         fg_block_sum<1>(part, lds);
         if (tid == 0)
-            atomicAdd(g.dot_acc + (size_t)b * g.dot_stride + ((unsigned)rem & (unsigned)(g.dot_ns - 1)),
+            acc_add(g.dot_acc + (size_t)b * g.dot_stride + ((unsigned)rem & (unsigned)(g.dot_ns - 1)),
                       (double)part[0]);
     }
 }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_gemm_sk(GemmArgs g, int tiles_n, int ti
         float part[1] = {dot};
         fg_block_sum<1>(part, lds);
         if (tid == 0)
-            atomicAdd(g.dot_acc + (size_t)b * g.dot_stride + ((unsigned)rem & (unsigned)(g.dot_ns - 1)), (double)part[0]);
+            acc_add(g.dot_acc + (size_t)b * g.dot_stride + ((unsigned)rem & (unsigned)(g.dot_ns - 1)), (double)part[0]);
     }
 }
 
@@ -465,12 +465,18 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expe
     // algorithmic traffic per env: A read + C written (+ the dot operand); the transform matrix stays in L2
     const double bytes = 4.0 * ((double)g.M * g.K + (double)g.M * g.N + (g.dot_with ? (double)g.M * g.N : 0.0));
     const long big_blocks = (long)((g.N + 127) / 128) * ((g.M + 127) / 128) * batch;
-    const bool tiled = big_blocks >= 512 || (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * expect_active >= 384;
+    // The kernel form is chosen from the BATCH, not from how many envs are still iterating: the two forms sum over k in different
+    // orders, and `expect_active` comes from the host's convergence polls, whose schedule depends on the solver's history -- a
+    // replayed state (get_state -> set_state -> step) would pick another form and round differently.  (Split-K is ~10 % faster
+    // once only a few envs of a large batch are left: B = 16 of 64 live 8.8 vs 10.1 us.)
+    (void)expect_active;
+    const long live_tiles = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * batch;
+    const bool tiled = big_blocks >= 512 || live_tiles >= 384;
     const int slot = fg_prof_slot(s, tiled ? FG_PK_GEMM : FG_PK_GEMM_SK, g.flags, batch, bytes, 2.0 * g.M * g.N * g.K, st);
     if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
         const int tn = (g.N + 127) / 128, tm = (g.M + 127) / 128;
         FG_LAUNCH_P(s, slot, (k_gemm_f32<2, 2, 16>), dim3((unsigned)(tn * tm * batch)), dim3(256), 0, st, g, tn, tm);
-    } else if ((long)((g.N + 63) / 64) * ((g.M + 63) / 64) * expect_active >= 384) {
+    } else if (live_tiles >= 384) {
         // enough live 64 x 64 tiles for ~1.5 workgroups per CU: the LDS-staged tile reads each operand half as often
         // (measured at 256 x 128, all envs live: B = 64 17.5 us vs 27 us split-K; B = 16 10.1 vs 8.8; B = 4 9.6 vs 6.5)
         const int tn = (g.N + 63) / 64, tm = (g.M + 63) / 64;
@@ -486,7 +492,7 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expe
 }
 
 // z = M^-1 r for all envs with flags == 0; optionally rz_acc[b * rz_stride] += r . z
-int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, int expect_active,
+int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st) {
     if (expect_active <= 0 || expect_active > s->grid.B) expect_active = s->grid.B;
     const FgGrid& G = s->grid;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <math.h>
 #include <stdint.h>
 #include <string>
 
@@ -32,6 +33,71 @@ template <typename T> __device__ __forceinline__ void fg_word_st(T* p, T v, bool
 }
 __device__ __forceinline__ double acc_ld(const double* p) { return fg_word_ld(p, (FG_ACC_ACCESS & 1) != 0); }
 __device__ __forceinline__ void acc_st(double* p, double v) { fg_word_st(p, v, (FG_ACC_ACCESS & 2) != 0); }
+
+// ------------------------------------------------------------------------------------------------
+// Order-independent reduction accumulator.  The dot products of the Krylov recurrences end in one contribution per
+// workgroup; added with fp64 atomics their order -- hence the rounded sum, hence every later iterate -- varied from run to
+// run (a replayed airfoil episode differed by 4-6 % in the forces after 17 env steps).  The reference's dots are cuBLAS
+// calls in a fixed order (cg_solver_kernel.cu:277,317), so its get_state -> set_state -> step replays exactly
+// (envs/fluid_env.py:1320-1363).  Here a contribution is split EXACTLY into four fixed-point words of 42 bits (units 2^34,
+// 2^-8, 2^-50, 2^-92) that are added with 64-bit INTEGER atomics: integer addition is associative, so the words -- and the
+// double they are read back as -- do not depend on the order of arrival.  Range: |contribution| < 2^75 (3.8e22), up to 2^20
+// contributions, resolution 2^-93; anything else (NaN, Inf, larger) sets the poison word and the accumulator reads as NaN,
+// which the solvers already treat as a non-finite solve.  `plain` carries a value stored with acc_st (0 to reset the
+// accumulator, or a scalar a leader parks between kernels); the value of an accumulator is plain + the sum of what was
+// added since.  All-zero bytes are an accumulator holding 0 (hipMemset works).  Kernel boundaries order stores, adds and
+// loads exactly as for the plain words above.
+// ------------------------------------------------------------------------------------------------
+struct alignas(64) FgDacc {
+    unsigned long long w[4];
+    unsigned long long poison;
+    double plain;
+    unsigned long long pad[2];
+};
+static_assert(sizeof(FgDacc) == 64, "one accumulator per 64-byte line segment");
+
+// the split of one contribution and the value of the words: shared by the device accessors and the host self-test
+// (fg_dacc_host_sum), so that what the CPU test checks is what the kernels run
+__host__ __device__ __forceinline__ bool fg_dacc_split(double v, long long k[4]) {
+    if (!(fabs(v) < 0x1p75)) return false;                      // NaN, Inf or out of range: poison
+    double r = v;
+    const double k0 = rint(r * 0x1p-34); r -= k0 * 0x1p34;      // exact: r keeps the bits of v below the word
+    const double k1 = rint(r * 0x1p8);   r -= k1 * 0x1p-8;
+    const double k2 = rint(r * 0x1p50);  r -= k2 * 0x1p-50;
+    const double k3 = rint(r * 0x1p92);                         // bits below 2^-93 are dropped (the same ones in any order)
+    k[0] = (long long)k0; k[1] = (long long)k1; k[2] = (long long)k2; k[3] = (long long)k3;
+    return true;
+}
+__host__ __device__ __forceinline__ double fg_dacc_value(unsigned long long w0, unsigned long long w1, unsigned long long w2,
+                                                         unsigned long long w3, unsigned long long poison, double plain) {
+    // smallest unit first; every conversion and addition is a fixed sequence on the same integer words
+    double t = (double)(long long)w3 * 0x1p-92;
+    t += (double)(long long)w2 * 0x1p-50;
+    t += (double)(long long)w1 * 0x1p-8;
+    t += (double)(long long)w0 * 0x1p34;
+    t += plain;
+    return poison ? (double)NAN : t;
+}
+inline double fg_dacc_host_value(const FgDacc& a) { return fg_dacc_value(a.w[0], a.w[1], a.w[2], a.w[3], a.poison, a.plain); }
+__device__ __forceinline__ void acc_st(FgDacc* p, double v) {
+    ulonglong2* q = reinterpret_cast<ulonglong2*>(p);
+    q[0] = make_ulonglong2(0ull, 0ull);
+    q[1] = make_ulonglong2(0ull, 0ull);
+    q[2] = make_ulonglong2(0ull, (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ double acc_ld(const FgDacc* p) {
+    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+    const ulonglong2 a = q[0], b = q[1], c = q[2];
+    return fg_dacc_value(a.x, a.y, b.x, b.y, c.x, __longlong_as_double((long long)c.y));
+}
+__device__ __forceinline__ void acc_add(FgDacc* p, double v) {
+    long long k[4];
+    if (!fg_dacc_split(v, k)) { atomicAdd(&p->poison, 1ull); return; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (k[i] != 0) atomicAdd(&p->w[i], (unsigned long long)k[i]);
+}
+
 __device__ __forceinline__ float sc_ld(const float* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
 __device__ __forceinline__ void sc_st(float* p, float v) { fg_word_st(p, v, (FG_FLAG_ACCESS & 2) != 0); }
 __device__ __forceinline__ int32_t flag_ld(const int32_t* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
@@ -413,14 +479,14 @@ struct fg_state {
     float* p_result;   // [B,N]
     float* scal_result;// [B,N]
     float* w[7];       // Krylov work vectors, each [B,d,N]
-    double* acc;       // [B*d][FG_ACC_DOUBLES] reduction accumulators
+    FgDacc* acc;       // [B*d][FG_ACC_DOUBLES] reduction accumulators (order-independent, FgDacc)
     int32_t* flags;    // [B*d] convergence flags (device)
     fg_solve_info* info_dev;   // [B*d]
     fg_solve_info* info_pinned;// [B*d] host-pinned mirror
     int32_t* flags_pinned;
     float* scratch_B;  // [B*(4+2d)] small per-env floats
     FgProf prof;
-    double* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
+    FgDacc* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
     FgBest cg_best;               // best-iterate tracking of the CG (returnBestResult, cg_solver_kernel.cu:345-361)
     int cg_return_best;           // 1 (default): track; 0: never keep an iterate (fg_set_return_best)
     int adv_from_result;          // 1 (default): velocity solve starts from velocityResult; 0: from zero (fg_set_advection_start)
@@ -530,7 +596,7 @@ int fg_zmarch_apply(const fg_state* s, const float* rA, const float* x, float* y
 int fg_zmarch_relax(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew, float omega,
                     int color, int zc, hipStream_t st);
 int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const float* p_in, float* p_out, float* Ap,
-                    double* acc, int32_t* flags, fg_solve_info* info, int prof_slot, float tol, int it, int first,
+                    FgDacc* acc, int32_t* flags, fg_solve_info* info, int prof_slot, float tol, int it, int first,
                     int ns, int num_base, int zc, hipStream_t st);
 // profiler (fg_profile.hip).  fg_prof_slot returns an event-pair slot when this launch is to be sampled (-1 otherwise);
 // flags == nullptr means all nsys systems are active; flags == FG_PROF_SELF means the sampled kernel itself adds
@@ -543,7 +609,7 @@ int fg_prof_collect(fg_state* s, hipStream_t st);
 void fg_prof_destroy(fg_state* s);
 bool fg_fd_dct_supported(int n);
 int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st);
-int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, double* dot_acc, int dot_stride,
+int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, FgDacc* dot_acc, int dot_stride,
                       int dot_ns, hipStream_t st);
 #define FG_LAUNCH_P(s, slot, kernel, grid, block, shmem, st, ...)                                              \
     do {                                                                                                       \
@@ -555,6 +621,6 @@ int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_wi
             hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                   \
     } while (0)
 // expect_active: the caller's estimate of envs still iterating (<= 0: all) -- only picks the GEMM tile shape
-int fg_fd_apply(fg_state* s, const float* r, float* z, double* rz_acc, int rz_stride, int rz_ns, int expect_active,
+int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

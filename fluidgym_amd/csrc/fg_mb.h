@@ -86,7 +86,7 @@ struct fg_mb_state {
     // work buffers
     float *cc, *fb, *Cdiag, *Coff, *rA, *rhs, *ures, *hvec, *div, *Pdiag, *Poff, *pres, *Sdiag, *Soff;
     float* w[8];   // Krylov work vectors: r, rw, p, v, t | s of the fused BiCGStab kernels | second p and v of their ping-pong pairs
-    double* acc;
+    FgDacc* acc;   // [B d][MB_ACC] order-independent reduction accumulators (fg_internal.h)
     float* sc;
     int32_t *flags, *best_it, *it_ctr;
     hipStream_t capture_stream = nullptr;
@@ -134,7 +134,8 @@ struct fg_mb_state {
     int cg_stall_limit = 400;  // fg_mb_set_stall_limit
     int adv_from_result = 0;   // fg_mb_set_advection_start
     bool yproj_const = true;   // yproj is the constant 1/sqrt(N): kernels use the scalar instead of loading it
-    float* red;        // [B] reductions (mean, max)
+    float* red;        // [B] reductions (max)
+    float* red8;       // [B][MB_SUM_WGS] per-workgroup partials of the pressure mean (summed in index order)
     float* red_pinned = nullptr;
     float *red2, *dt_dev;          // [2B] boundary flux sums, [B] time steps of the running substep
     float *red2_pinned = nullptr, *dt_pinned = nullptr;

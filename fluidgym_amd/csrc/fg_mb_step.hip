@@ -332,6 +332,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_maxvel(MbDev D, const float* __
     }
 }
 
+constexpr int MB_SUM_WGS = 8;
 __global__ void k_mb_sum(int N, const float* __restrict__ dt, const float* __restrict__ x, float* __restrict__ out) {
     const int b = blockIdx.y;
     if (!mb_active(dt, b)) return;
@@ -339,13 +340,14 @@ __global__ void k_mb_sum(int N, const float* __restrict__ dt, const float* __res
     for (int i = blockIdx.x * FG_BLOCK + threadIdx.x; i < N; i += gridDim.x * FG_BLOCK) s += x[(size_t)b * N + i];
     __shared__ float lds[4];
     s = mb_block_sum(s, lds);
-    if (threadIdx.x == 0) atomicAdd(out + b, s);
+    if (threadIdx.x == 0) out[b * MB_SUM_WGS + blockIdx.x] = s;   // one partial per workgroup, summed in index order by k_mb_sub_mean
 }
 __global__ void k_mb_sub_mean(int N, const float* __restrict__ dt, const float* __restrict__ sum, float* __restrict__ x,
                               float* __restrict__ copy) {
     const int b = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
     if (i >= N || !mb_active(dt, b)) return;
-    const float v = x[(size_t)b * N + i] - sum[b] / (float)N;
+    const float* ps = sum + b * MB_SUM_WGS;
+    const float v = x[(size_t)b * N + i] - (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / (float)N;
     x[(size_t)b * N + i] = v;
     if (copy) copy[(size_t)b * N + i] = v;
 }
@@ -364,7 +366,7 @@ __global__ void k_mb_copy(size_t per_env, const float* __restrict__ dt, const fl
 struct MbSolve {
     const float* diag; const float* off; const float* rhs;
     float* x; float* r; float* rw; float* p; float* v; float* t;
-    double* acc; float* sc; int32_t* flags; fg_solve_info* info;
+    FgDacc* acc; float* sc; int32_t* flags; fg_solve_info* info;
     int nc; float tol;
     // best-iterate tracking of the CG pressure solve (returnBestResult, cg_solver_kernel.cu:345-361): sc[2 sys] holds the
     // residual of the kept iterate, best_it the iteration it belongs to, best_x the iterate itself
@@ -411,7 +413,7 @@ __device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b
     const bool valid = i < N;                           \
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0); \
     const size_t vb = (size_t)sys * N;                  \
-    double* a = q.acc + (size_t)sys * MB_ACC;           \
+    FgDacc* a = q.acc + (size_t)sys * MB_ACC;           \
     __shared__ float lds[16];                           \
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
 
@@ -456,8 +458,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int u
     const float s = mb_block_sum(r * r, lds);
     const float s1 = sum_slot >= 0 ? mb_block_sum(valid ? r * (q.project ? 1.f : D.yproj[i]) : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
-        if (!defer_rho) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
-        if (sum_slot >= 0) atomicAdd(a + sum_slot, (double)s1);
+        if (!defer_rho) { acc_add(a + A_RHO, (double)s); acc_add(a + A_RR, (double)s); }
+        if (sum_slot >= 0) acc_add(a + sum_slot, (double)s1);
     }
 }
 
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_residual(MbDev D, MbSolve q, c
     const float s = mb_block_sum(r * r, lds);
     const float s1 = sum_slot >= 0 ? mb_block_sum(valid ? r : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
-        if (!defer_rho) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
-        if (sum_slot >= 0) atomicAdd(a + sum_slot, (double)s1);
+        if (!defer_rho) { acc_add(a + A_RHO, (double)s); acc_add(a + A_RR, (double)s); }
+        if (sum_slot >= 0) acc_add(a + sum_slot, (double)s1);
     }
 }
 
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_restore(int N, MbSolve q,
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
     if (flag_ld(q.flags + (sys)) != 0) return;
-    double* a = q.acc + (size_t)sys * MB_ACC;
+    FgDacc* a = q.acc + (size_t)sys * MB_ACC;
     const size_t vb = (size_t)sys * N;
     __shared__ float lds[4];
     const float m = (float)(acc_ld(a + (A_ST)) / (double)N);  // k_mbs_init left sum r in A_ST
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q)
         q.r[vb + i] = r; q.rw[vb + i] = r; q.p[vb + i] = r;
     }
     const float s = mb_block_sum(r * r, lds);
-    if (threadIdx.x == 0) { atomicAdd(a + A_RHO, (double)s); atomicAdd(a + A_RR, (double)s); }
+    if (threadIdx.x == 0) { acc_add(a + A_RHO, (double)s); acc_add(a + A_RR, (double)s); }
 }
 
 // ---- BiCGStab (same five-kernel recurrence as fg_bicgstab.hip)
@@ -604,8 +606,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) 
     part = mb_block_sum(part, lds);
     if (q.project) psum = mb_block_sum(psum, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RV, (double)part);
-        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+        acc_add(a + A_RV, (double)part);
+        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)psum);
     }
 }
 template <int DIMS>
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) 
         part = r * r;
     }
     part = mb_block_sum(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + A_SS, (double)part);
+    if (threadIdx.x == 0) acc_add(a + A_SS, (double)part);
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) {
@@ -646,9 +648,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
     ptt = mb_block_sum(ptt, lds);
     if (q.project) pst = mb_block_sum(pst, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_TS, (double)pt);
-        atomicAdd(a + A_TT, (double)ptt);
-        if (q.project) atomicAdd(a + A_ST, (double)pst);
+        acc_add(a + A_TS, (double)pt);
+        acc_add(a + A_TT, (double)ptt);
+        if (q.project) acc_add(a + A_ST, (double)pst);
     }
 }
 // "converged on s" (x += alpha p only, bicgstab_solver_kernel.cu:305-329).  With separate s and t kernels the t kernel has decided
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     if (half) return;
     float sums[2] = {prr, prho};
     mb_block_sums<2>(sums, lds);
-    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)sums[0]); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
+    if (threadIdx.x == 0) { acc_add(a + A_RR, (double)sums[0]); acc_add(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
 }
 
 // ---- the same five kernels with four consecutive cells per thread (N % 4 == 0): 128-bit loads / stores of the cell's own
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     const bool valid = i < N;                                     \
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);    \
     const size_t vb = (size_t)sys * N;                            \
-    double* a = q.acc + (size_t)sys * MB_ACC;                     \
+    FgDacc* a = q.acc + (size_t)sys * MB_ACC;                     \
     __shared__ float lds[16];                                     \
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -790,8 +792,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v4(MbDev D, MbSolve q, int it)
     part = mb_block_sum(part, lds);
     if (q.project) psum = mb_block_sum(psum, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RV, (double)part);
-        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)psum);
+        acc_add(a + A_RV, (double)part);
+        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)psum);
     }
 }
 template <int DIMS>
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s4(MbDev D, MbSolve q, int it)
         part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
     }
     part = mb_block_sum(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + A_SS, (double)part);
+    if (threadIdx.x == 0) acc_add(a + A_SS, (double)part);
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it) {
@@ -835,9 +837,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it)
     ptt = mb_block_sum(ptt, lds);
     if (q.project) pst = mb_block_sum(pst, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_TS, (double)pt);
-        atomicAdd(a + A_TT, (double)ptt);
-        if (q.project) atomicAdd(a + A_ST, (double)pst);
+        acc_add(a + A_TS, (double)pt);
+        acc_add(a + A_TT, (double)ptt);
+        if (q.project) acc_add(a + A_ST, (double)pst);
     }
 }
 template <int DIMS>
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     if (half) return;
     float sums[2] = {prr, prho};
     mb_block_sums<2>(sums, lds);
-    if (threadIdx.x == 0) { atomicAdd(a + A_RR, (double)sums[0]); atomicAdd(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
+    if (threadIdx.x == 0) { acc_add(a + A_RR, (double)sums[0]); acc_add(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
 }
 
 // ---- p and v in one launch: p_new = r + beta (p - omega (v - mean v)) for the own cell and, recomputed from r, p, v of the
@@ -921,8 +923,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv(MbDev D, MbSolve q, int it)
     float sums[2] = {part, psum};
     mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RV, (double)sums[0]);
-        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)sums[1]);
+        acc_add(a + A_RV, (double)sums[0]);
+        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)sums[1]);
     }
 }
 template <int DIMS>
@@ -975,8 +977,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it
     float sums[2] = {part, psum};
     mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_RV, (double)sums[0]);
-        if (q.project) atomicAdd(a + A_SV + 2 * (it & 1), (double)sums[1]);
+        acc_add(a + A_RV, (double)sums[0]);
+        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)sums[1]);
     }
 }
 
@@ -1011,10 +1013,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st(MbDev D, MbSolve q, int it)
     float sums[4] = {pss, pts, ptt, pst};
     mb_block_sums<4>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_SS, (double)sums[0]);
-        atomicAdd(a + A_TS, (double)sums[1]);
-        atomicAdd(a + A_TT, (double)sums[2]);
-        if (q.project) atomicAdd(a + A_ST, (double)sums[3]);
+        acc_add(a + A_SS, (double)sums[0]);
+        acc_add(a + A_TS, (double)sums[1]);
+        acc_add(a + A_TT, (double)sums[2]);
+        if (q.project) acc_add(a + A_ST, (double)sums[3]);
     }
 }
 template <int DIMS>
@@ -1043,10 +1045,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it
     float sums[4] = {pss, pts, ptt, pst};
     mb_block_sums<4>(sums, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + A_SS, (double)sums[0]);
-        atomicAdd(a + A_TS, (double)sums[1]);
-        atomicAdd(a + A_TT, (double)sums[2]);
-        if (q.project) atomicAdd(a + A_ST, (double)sums[3]);
+        acc_add(a + A_SS, (double)sums[0]);
+        acc_add(a + A_TS, (double)sums[1]);
+        acc_add(a + A_TT, (double)sums[2]);
+        if (q.project) acc_add(a + A_ST, (double)sums[3]);
     }
 }
 
@@ -1223,7 +1225,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
         part = pi * y;
     }
     part = mb_block_sum(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + C_PAP + (it & 1), (double)part);
+    if (threadIdx.x == 0) acc_add(a + C_PAP + (it & 1), (double)part);
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, const float* __restrict__ pA, const float* __restrict__ pB,
@@ -1248,8 +1250,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
     part = mb_block_sum(part, lds);
     if (project_mean) psum = mb_block_sum(psum, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + C_RHO + (it + 1) % 3, (double)part);
-        if (project_mean) atomicAdd(a + C_SUM + (it + 1) % 3, (double)psum);
+        acc_add(a + C_RHO + (it + 1) % 3, (double)part);
+        if (project_mean) acc_add(a + C_SUM + (it + 1) % 3, (double)psum);
     }
 }
 
@@ -1263,7 +1265,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
     const int sys = blockIdx.y, b = sys, N = D.N;
     const bool valid = i < N, leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
-    double* a = q.acc + (size_t)sys * MB_ACC;
+    FgDacc* a = q.acc + (size_t)sys * MB_ACC;
     __shared__ float lds[4];
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[0];
     if (leader && sys == 0) q.it_ctr[1] = it + 1;
@@ -1341,7 +1343,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
         part = pi[0] * y[0] + pi[1] * y[1] + pi[2] * y[2] + pi[3] * y[3];
     }
     part = mb_block_sum(part, lds);
-    if (threadIdx.x == 0) atomicAdd(a + C_PAP + (it & 1), (double)part);
+    if (threadIdx.x == 0) acc_add(a + C_PAP + (it & 1), (double)part);
 }
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, const float* __restrict__ pA, const float* __restrict__ pB,
                                                            int it_arg, int project_mean, const float* __restrict__ yp) {
@@ -1349,7 +1351,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, cons
     const int sys = blockIdx.y;
     const bool valid = i < N, leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
-    double* a = q.acc + (size_t)sys * MB_ACC;
+    FgDacc* a = q.acc + (size_t)sys * MB_ACC;
     __shared__ float lds[4];
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[1] - 1;
     if (leader && sys == 0) q.it_ctr[0] = it + 1;
@@ -1376,8 +1378,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, cons
     part = mb_block_sum(part, lds);
     if (project_mean) psum = mb_block_sum(psum, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(a + C_RHO + (it + 1) % 3, (double)part);
-        if (project_mean) atomicAdd(a + C_SUM + (it + 1) % 3, (double)psum);
+        acc_add(a + C_RHO + (it + 1) % 3, (double)part);
+        if (project_mean) acc_add(a + C_SUM + (it + 1) % 3, (double)psum);
     }
 }
 
@@ -1421,8 +1423,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, in
     const float s2 = mb_block_sum(r * r, lds);
     const float s1 = project_mean ? mb_block_sum(valid ? r * D.yproj[i] : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
-        atomicAdd(a + C_RHO + it % 3, (double)s2);
-        if (project_mean) atomicAdd(a + C_SUM + it % 3, (double)s1);
+        acc_add(a + C_RHO + it % 3, (double)s2);
+        if (project_mean) acc_add(a + C_SUM + it % 3, (double)s1);
     }
 }
 
@@ -2194,9 +2196,11 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     const int frc = mb_finish(s, nsys, nullptr, max_it);
     if (max_it && frc == FG_OK) pred = *max_it < 200 ? *max_it : 200;
     if (frc == FG_ERR_NOT_FINITE && s->dbg_fail) {   // rare path, FG_MB_TRACE_FAIL only: the recurrence scalars of the systems that broke down
+        std::vector<FgDacc> acc_raw((size_t)nsys * MB_ACC);
         std::vector<double> acc((size_t)nsys * MB_ACC);
         std::vector<float> sc((size_t)nsys * 2);
-        (void)hipMemcpy(acc.data(), s->acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(acc_raw.data(), s->acc, acc_raw.size() * sizeof(FgDacc), hipMemcpyDeviceToHost);
+        for (size_t k = 0; k < acc.size(); ++k) acc[k] = fg_dacc_host_value(acc_raw[k]);
         (void)hipMemcpy(sc.data(), s->sc, sc.size() * sizeof(float), hipMemcpyDeviceToHost);
         for (int i = 0; i < nsys; ++i) {
             if (s->info_pinned[i].is_finite) continue;
@@ -2607,6 +2611,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->flags, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->info_dev, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->red, B)) return rc;
+    if (int rc = mb_alloc(s, &s->red8, B * MB_SUM_WGS)) return rc;
     if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->yproj, N)) return rc;
     {
@@ -2786,9 +2791,8 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 }
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) { its[2 + c] = std::max(its[2 + c], m); s->ctr.add(2 + c, s->info_pinned, B); }
-                FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
-                hipLaunchKernelGGL(k_mb_sum, dim3(8, B), blk, 0, st, N, dt_B, s->pres, s->red);
-                hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, dt_B, s->red, s->pres, s->pressure);
+                hipLaunchKernelGGL(k_mb_sum, dim3(MB_SUM_WGS, B), blk, 0, st, N, dt_B, s->pres, s->red8);
+                hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, dt_B, s->red8, s->pres, s->pressure);
             }
             hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->hvec, s->pressure, s->ures);
         }
@@ -2936,8 +2940,20 @@ extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, float tol, int32_t max_itera
     }
     // the recurrence words as the last solve left them ([B d][12] accumulators, [B d][2] alpha / omega): with max_iterations = k
     // for k = 1, 2, ... this is the history of a (deterministic) solve
-    if (acc_out) FG_HIP_CHECK(hipMemcpy(acc_out, s->acc, sizeof(double) * MB_ACC * s->B * s->d, hipMemcpyDeviceToHost));
+    if (acc_out) {
+        std::vector<FgDacc> raw((size_t)MB_ACC * s->B * s->d);
+        FG_HIP_CHECK(hipMemcpy(raw.data(), s->acc, sizeof(FgDacc) * raw.size(), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < raw.size(); ++k) acc_out[k] = fg_dacc_host_value(raw[k]);
+    }
     if (sc_out) FG_HIP_CHECK(hipMemcpy(sc_out, s->sc, sizeof(float) * 2 * s->B * s->d, hipMemcpyDeviceToHost));
+    return FG_OK;
+}
+
+extern "C" int fg_mb_solver_hints(fg_mb_handle s, int32_t* hints36, int32_t set) {
+    FG_REQUIRE(s != nullptr && hints36 != nullptr, FG_ERR_INVALID_ARG, "fg_mb_solver_hints: bad argument");
+    int* trial[4] = {&s->ml_bicg_attempts, &s->ml_bicg_failures, &s->ml_bicg_skip, &s->ml_bicg_backoff};
+    for (int k = 0; k < 32; ++k) { if (set) s->pred_bicg[k] = hints36[k]; else hints36[k] = s->pred_bicg[k]; }
+    for (int k = 0; k < 4; ++k) { if (set) *trial[k] = hints36[32 + k]; else hints36[32 + k] = *trial[k]; }
     return FG_OK;
 }
 
@@ -3121,9 +3137,8 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
                                         opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
             if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;
             else if (prc != FG_OK) return prc;
-            FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * B, st));
-            hipLaunchKernelGGL(k_mb_sum, dim3(8, B), blk, 0, st, N, (const float*)nullptr, s->pres, s->red);
-            hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, (const float*)nullptr, s->red, s->pres, s->pressure);
+            hipLaunchKernelGGL(k_mb_sum, dim3(MB_SUM_WGS, B), blk, 0, st, N, (const float*)nullptr, s->pres, s->red8);
+            hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, (const float*)nullptr, s->red8, s->pres, s->pressure);
         }
         hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->hvec, s->pressure, s->velocity);
     });

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_buoyancy(const float* __restrict__
 
 // p -= mean(p) per env (PISOtorch_simulation.py:1817-1820), written to pressureResult and the block
 __global__ __launch_bounds__(FG_BLOCK) void k_sum_env(const float* __restrict__ dt, const float* __restrict__ p,
-                                                       double* __restrict__ sums, int n) {
+                                                       FgDacc* __restrict__ sums, int n) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
     const float* __restrict__ pb = p + (size_t)b * n;
@@ -516,14 +516,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_sum_env(const float* __restrict__ 
     __shared__ float lds[4];
     float v[1] = {acc};
     fg_block_sum<1>(v, lds);
-    if (threadIdx.x == 0) atomicAdd(sums + b, (double)v[0]);
+    if (threadIdx.x == 0) acc_add(sums + b, (double)v[0]);
 }
 __global__ __launch_bounds__(FG_BLOCK) void k_sub_mean(const float* __restrict__ dt, float* __restrict__ p,
-                                                        float* __restrict__ p_copy, const double* __restrict__ sums,
+                                                        float* __restrict__ p_copy, const FgDacc* __restrict__ sums,
                                                         int n) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
-    const float mean = (float)(sums[b] / (double)n);
+    const float mean = (float)(acc_ld(sums + b) / (double)n);
     float* __restrict__ pb = p + (size_t)b * n;
     float* __restrict__ cb = p_copy ? p_copy + (size_t)b * n : nullptr;
     const bool al = (n & 3) == 0 && (reinterpret_cast<size_t>(pb) & 15) == 0 && (!cb || (reinterpret_cast<size_t>(cb) & 15) == 0);
@@ -752,9 +752,9 @@ int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long 
 }
 
 int fg_launch_mean_sub(const fg_state* s, const float* dt, float* p, float* p_copy, hipStream_t st) {
-    double* sums = s->acc;  // first B doubles of the accumulator pool: free between solves, zeroed by k_cg_begin
+    FgDacc* sums = s->acc;  // first B accumulators of the pool: free between solves, zeroed by k_cg_begin
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
-    // every workgroup ends in one fp64 atomicAdd on its env's sum and same-address atomics serialise (~0.1 us each):
+    // every workgroup ends in atomics on its env's accumulator and same-address atomics serialise (~0.1 us each):
     // few workgroups per env for the reduction pass (fg_reduce_wgs)
     dim3 rgrid(grid.x > fg_reduce_wgs(s) ? fg_reduce_wgs(s) : grid.x, grid.y);
     hipLaunchKernelGGL(k_sum_env, rgrid, dim3(FG_BLOCK), 0, st, dt, p, sums, s->grid.n);

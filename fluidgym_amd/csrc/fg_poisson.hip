@@ -122,11 +122,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const floa
 
 __device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
 
-__device__ __forceinline__ double* fg_acc_ptr(double* acc, int b, int name) {
+__device__ __forceinline__ FgDacc* fg_acc_ptr(FgDacc* acc, int b, int name) {
     return acc + ((size_t)b * FG_CG_NAMES + name) * FG_CG_SLOTS;
 }
-// total of an accumulator; every lane of the calling wave gets the result
-__device__ __forceinline__ double fg_acc_total(const double* a, int ns) {
+// total of an accumulator; every lane of the calling wave gets the result.  Each slot is an order-independent FgDacc and
+// the slots are summed by a fixed shuffle tree: the total does not depend on the order in which the workgroups arrived.
+__device__ __forceinline__ double fg_acc_total(const FgDacc* a, int ns) {
     if (ns == 1) return acc_ld(a + (0));
     const int lane = threadIdx.x & 63;
     double v = (lane < ns) ? acc_ld(a + (lane)) : 0.0;
@@ -134,19 +135,19 @@ __device__ __forceinline__ double fg_acc_total(const double* a, int ns) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ void fg_acc_zero(double* a, int ns) {  // called by the first wave of the leader block
+__device__ __forceinline__ void fg_acc_zero(FgDacc* a, int ns) {  // called by the first wave of the leader block
     const int lane = threadIdx.x & 63;
     if (lane < ns) acc_st(a + (lane), 0.0);
 }
-__device__ __forceinline__ void fg_acc_add(double* a, int ns, unsigned tile, double v) {
-    atomicAdd(a + (tile & (unsigned)(ns - 1)), v);
+__device__ __forceinline__ void fg_acc_add(FgDacc* a, int ns, unsigned tile, double v) {
+    acc_add(a + (tile & (unsigned)(ns - 1)), v);
 }
 
 // r = b - P x (or r = b when x0 == 0), accumulates rr into ring name `name`
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float* __restrict__ rA_,
                                                            const float* __restrict__ b_, float* __restrict__ x_,
-                                                           float* __restrict__ r_, double* __restrict__ acc,
+                                                           float* __restrict__ r_, FgDacc* __restrict__ acc,
                                                            const int32_t* __restrict__ flags, int use_x0, int name,
                                                            int ns, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
@@ -189,7 +190,7 @@ template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __restrict__ rA_,
                                                      const float* __restrict__ z_, const float* __restrict__ pin_,
                                                      float* __restrict__ pout_, float* __restrict__ Ap_,
-                                                     double* __restrict__ acc, int32_t* __restrict__ flags,
+                                                     FgDacc* __restrict__ acc, int32_t* __restrict__ flags,
                                                      fg_solve_info* __restrict__ info, int32_t* __restrict__ prof_active,
                                                      FgBest best, float tol, int it, int first, int ns, int num_base,
                                                      int tiles_x, int tiles_y, int tiles) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* __restrict__ p_,
                                                          const float* __restrict__ Ap_, float* __restrict__ x_,
-                                                         float* __restrict__ r_, double* __restrict__ acc,
+                                                         float* __restrict__ r_, FgDacc* __restrict__ acc,
                                                          const int32_t* __restrict__ flags, FgBest best, float tol, int it,
                                                          int ns, int num_base, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
 // Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one wave per env.  `mirror` (optional) is the
 // host-pinned copy of info: thread 0 of every env writes its entry there, so a convergence poll is a stream
 // synchronise without a device-to-host copy (the copy kernel + its launch cost ~6 us per poll, 4-5 polls per PISO step).
-__global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+__global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
                            fg_solve_info* __restrict__ mirror, float tol, int it, int n, int B, int final_pass, int ns) {
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -327,15 +328,15 @@ __global__ void k_cg_check(double* __restrict__ acc, int32_t* __restrict__ flags
     if (mirror && threadIdx.x == 0) mirror[b] = info[b];
 }
 
-__global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ acc, int32_t* __restrict__ flags,
-                           fg_solve_info* __restrict__ info, double* __restrict__ mean_sums, FgBest best, int track_best,
-                           int B) {
+__global__ void k_cg_begin(const float* __restrict__ dt, FgDacc* __restrict__ acc, int32_t* __restrict__ flags,
+                           fg_solve_info* __restrict__ info, FgDacc* __restrict__ mean_sums, FgBest best, int track_best,
+                           int B, int ns) {
     const int b = blockIdx.x;
     if (b >= B) return;
-    for (int q = threadIdx.x; q < FG_CG_NAMES * FG_CG_SLOTS; q += blockDim.x)
-        acc_st(acc + ((size_t)b * FG_CG_NAMES * FG_CG_SLOTS + q), 0.0);
+    for (int q = threadIdx.x; q < FG_CG_NAMES * ns; q += blockDim.x)   // only the ns slots in use (64 B each)
+        acc_st(fg_acc_ptr(acc, b, q / ns) + q % ns, 0.0);
     if (threadIdx.x != 0) return;
-    mean_sums[b] = 0.0;  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
+    acc_st(mean_sums + b, 0.0);  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
     best.best_crit[b] = track_best ? INFINITY : 0.f;  // 0: no residual ever beats it, nothing is kept
     best.saved_crit[b] = INFINITY;
     best.save_at[b] = -1;
@@ -347,9 +348,9 @@ __global__ void k_cg_begin(const float* __restrict__ dt, double* __restrict__ ac
     info[b].is_finite = 1;
 }
 
-__global__ void k_zero_name(double* __restrict__ acc, int name, int B) {
+__global__ void k_zero_name(FgDacc* __restrict__ acc, int name, int B) {
     const int b = blockIdx.x;
-    if (b < B && threadIdx.x < FG_CG_SLOTS) fg_acc_ptr(acc, b, name)[threadIdx.x] = 0.0;
+    if (b < B && threadIdx.x < FG_CG_SLOTS) acc_st(fg_acc_ptr(acc, b, name) + threadIdx.x, 0.0);
 }
 
 // Unconverged envs get the best iterate seen back (returnBestResult): x = best_x where its residual beats the final one.
@@ -420,7 +421,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const bool zmarch = fg_zmarch_ok(s, &zc);
     int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
     while (ns < FG_CG_SLOTS && tiles_per_env / ns > 256) ns *= 2;
-    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, s->cg_best, s->cg_return_best, B);
+    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, s->cg_best, s->cg_return_best, B, ns);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,

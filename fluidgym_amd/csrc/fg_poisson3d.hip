@@ -163,12 +163,12 @@ struct Z3Args {
     float* y2;            // cg_ap: Ap
     float omega; int color;           // relax (color < 0: Jacobi)
     // cg_ap
-    double* acc; int32_t* flags; fg_solve_info* info; int32_t* prof_active; FgBest best;
+    FgDacc* acc; int32_t* flags; fg_solve_info* info; int32_t* prof_active; FgBest best;
     float tol; int it; int first; int ns; int num_base;
 };
 
-__device__ __forceinline__ double* z_acc_ptr(double* acc, int b, int name) { return acc + ((size_t)b * 8 + name) * 64; }
-__device__ __forceinline__ double z_acc_total(const double* a, int ns) {
+__device__ __forceinline__ FgDacc* z_acc_ptr(FgDacc* acc, int b, int name) { return acc + ((size_t)b * 8 + name) * 64; }
+__device__ __forceinline__ double z_acc_total(const FgDacc* a, int ns) {
     if (ns == 1) return acc_ld(a + (0));
     const int lane = threadIdx.x & 63;
     double v = (lane < ns) ? acc_ld(a + (lane)) : 0.0;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
     if constexpr (MODE == MODE_CG_AP) {
         float part[1] = {c.valid ? dot : 0.f};
         fg_block_sum<1>(part, red);
-        if (threadIdx.x == 0) atomicAdd(z_acc_ptr(a.acc, c.b, 3 + (a.it & 1)) + (tile_id & (unsigned)(a.ns - 1)), (double)part[0]);
+        if (threadIdx.x == 0) acc_add(z_acc_ptr(a.acc, c.b, 3 + (a.it & 1)) + (tile_id & (unsigned)(a.ns - 1)), (double)part[0]);
     }
 }
 
@@ -554,7 +554,7 @@ int fg_zmarch_relax(const fg_state* s, const float* rA, const float* b, const fl
     return launch_march<MODE_RELAX>(s, a, zc, st);
 }
 int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const float* p_in, float* p_out, float* Ap,
-                    double* acc, int32_t* flags, fg_solve_info* info, int prof_slot, float tol, int it, int first,
+                    FgDacc* acc, int32_t* flags, fg_solve_info* info, int prof_slot, float tol, int it, int first,
                     int ns, int num_base, int zc, hipStream_t st) {
     Z3Args a = {};
     a.rA = rA; a.x = z; a.x2 = p_in; a.y = p_out; a.y2 = Ap;

@@ -10,6 +10,8 @@
 
 #include <algorithm>
 
+#include <string.h>
+
 #include "fg_internal.h"
 
 namespace {
@@ -237,6 +239,56 @@ void litmus_run(LitArgs q, int nsys, int G, int iters, hipStream_t st) {
     }
 }
 }  // namespace
+
+// ---- order-independent accumulator (FgDacc, fg_internal.h): the host evaluation of the split / value code the kernels run, and
+// the same sum done on the device by one atomic contribution per thread in whatever order the hardware schedules them
+namespace {
+__global__ void k_dacc_selftest(const double* __restrict__ v, long long n, FgDacc* __restrict__ acc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc_add(acc, v[i]);
+}
+__global__ void k_dacc_read(FgDacc* __restrict__ acc, double* __restrict__ out, double plain) {
+    out[0] = acc_ld(acc);
+    acc_st(acc, plain);
+}
+}  // namespace
+
+extern "C" int fg_dacc_host_sum(const double* values, int64_t n, double plain, double* out_sum) {
+    FG_REQUIRE(values && n >= 0 && out_sum, FG_ERR_INVALID_ARG, "fg_dacc_host_sum: bad argument");
+    FgDacc a;
+    memset(&a, 0, sizeof(a));
+    a.plain = plain;
+    for (int64_t i = 0; i < n; ++i) {
+        long long k[4];
+        if (!fg_dacc_split(values[i], k)) { a.poison += 1; continue; }
+        for (int q = 0; q < 4; ++q) a.w[q] += (unsigned long long)k[q];
+    }
+    *out_sum = fg_dacc_host_value(a);
+    return FG_OK;
+}
+
+extern "C" int fg_dacc_device_sum(const double* values_host, int64_t n, double plain, int32_t reps, double* out_sums_host, void* stream) {
+    FG_REQUIRE(values_host && n > 0 && reps > 0 && out_sums_host, FG_ERR_INVALID_ARG, "fg_dacc_device_sum: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    double *v = nullptr, *out = nullptr;
+    FgDacc* acc = nullptr;
+    FG_HIP_CHECK(hipMalloc(&v, sizeof(double) * n));
+    FG_HIP_CHECK(hipMalloc(&out, sizeof(double)));
+    FG_HIP_CHECK(hipMalloc(&acc, sizeof(FgDacc)));
+    FG_HIP_CHECK(hipMemcpy(v, values_host, sizeof(double) * n, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemset(acc, 0, sizeof(FgDacc)));
+    hipLaunchKernelGGL(k_dacc_read, dim3(1), dim3(1), 0, st, acc, out, plain);   // parks `plain` through acc_st
+    for (int r = 0; r < reps; ++r) {
+        // different launch shapes per repetition: the arrival order of the contributions differs
+        const int blk = 64 << (r % 4);
+        hipLaunchKernelGGL(k_dacc_selftest, dim3((unsigned)((n + blk - 1) / blk)), dim3(blk), 0, st, v, (long long)n, acc);
+        hipLaunchKernelGGL(k_dacc_read, dim3(1), dim3(1), 0, st, acc, out, plain);
+        FG_HIP_CHECK(hipMemcpyAsync(out_sums_host + r, out, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(v); (void)hipFree(out); (void)hipFree(acc);
+    return FG_OK;
+}
 
 extern "C" int fg_stream_triad(float* a, const float* b, const float* c, float scalar, int64_t n, int32_t reps, float* ms_per_launch,
                                void* stream) {

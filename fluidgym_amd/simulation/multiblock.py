@@ -535,14 +535,24 @@ class MultiBlockDomain:
         return out
 
     # ---- what FluidEnv needs of a Domain
+    def solver_hints(self, values=None) -> torch.Tensor:
+        """The 36 words a handle remembers between solves (``fg_mb_solver_hints``): read, or written from ``values``."""
+        buf = (ctypes.c_int32 * 36)(*([0] * 36 if values is None else [int(v) for v in values]))
+        L.check(self.lib.fg_mb_solver_hints(self.handle, buf, 0 if values is None else 1))
+        return torch.tensor(list(buf), dtype=torch.int32)
+
     def Clone(self) -> dict:
+        """State snapshot of ``FluidEnv.get_state`` (reference ``Domain.Clone()``): the bound fields and the solver's hints, so
+        that ``set_state`` + ``step`` replays bit for bit (envs/fluid_env.py:1320-1363)."""
         return {"velocity": self.velocity.clone(), "pressure": self.pressure.clone(),
-                "boundary_velocity": self.boundary_velocity.clone()}
+                "boundary_velocity": self.boundary_velocity.clone(), "solver_hints": self.solver_hints()}
 
     def Restore(self, snap: dict) -> None:
         self.velocity.copy_(snap["velocity"])
         self.pressure.copy_(snap["pressure"])
         self.boundary_velocity.copy_(snap["boundary_velocity"])
+        if "solver_hints" in snap:
+            self.solver_hints(snap["solver_hints"].tolist())
 
     @property
     def solver(self):

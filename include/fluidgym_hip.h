@@ -284,6 +284,14 @@ int fg_stream_triad(float* a, const float* b, const float* c, float scalar, int6
  * first wrong value.  Synchronises. */
 int fg_coherence_litmus(int32_t atomic_access, int32_t nsys, int32_t cells, int32_t iterations, int64_t* bad_reads, double* bad_value,
                         void* stream);
+/* Order-independent reduction accumulator of the Krylov solvers (csrc/fg_internal.h FgDacc: every contribution split exactly into
+ * four 42-bit fixed-point words added with integer atomics, so a dot product does not depend on the arrival order of the
+ * workgroups -- what the reference gets from cuBLAS dots in a fixed order, cg_solver_kernel.cu:277,317).  fg_dacc_host_sum
+ * evaluates plain + sum(values) with the very split / read-back code the kernels run (no GPU needed); fg_dacc_device_sum does the
+ * same sum `reps` times on the device, one atomic contribution per thread with a different launch shape each time.  A value
+ * that is NaN, Inf or >= 2^75 in magnitude makes the sum NaN. */
+int fg_dacc_host_sum(const double* values, int64_t n, double plain, double* out_sum);
+int fg_dacc_device_sum(const double* values_host, int64_t n, double plain, int32_t reps, double* out_sums_host, void* stream);
 int fg_profile_enable(fg_handle h, int on);
 int fg_profile_kinds(void);
 const char* fg_profile_kind_name(int kind);
@@ -411,6 +419,11 @@ int fg_mb_ladder(fg_mb_handle h, int64_t* out4_host, int32_t force_mask);
 /* Tuning aid: with FG_MB_OC_VARIANT=256 in the environment at fg_mb_create, workgroup 0 of the on-chip CG counts shader-clock
  * cycles per phase of its loop; out12 = 11 phases + iterations of the last launch. */
 int fg_mb_debug_cycles(fg_mb_handle h, uint64_t* out12_host);
+/* What a handle remembers between solves besides the bound fields: where the previous solve of each place in the step finished
+ * (its next solve polls there first; a verified / refined BiCGStab re-opens and restarts at its polls, so the schedule is part of
+ * the arithmetic) and the back-off state of the multilevel trial.  get_state / set_state of the envs carry these 36 words so that
+ * a restored state replays bit for bit (reference: envs/fluid_env.py:1320-1363).  set = 0 reads, 1 writes. */
+int fg_mb_solver_hints(fg_mb_handle h, int32_t* hints36, int32_t set);
 /* as fg_solver_counters, for the multi-block path */
 int fg_mb_solver_counters(fg_mb_handle h, int64_t* out13_host, int32_t reset);
 /* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps

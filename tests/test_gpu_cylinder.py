@@ -221,8 +221,8 @@ def test_refined_bicgstab_gives_the_same_wake_as_cg():
         _, _, _, _, info = env.step(torch.zeros(1, 1, device="cuda"))
         cds.append(float(info["drag"][0]))
         env.close()
-    # CG (on-chip, no atomics) is deterministic: 2.5016; the BiCGStab's dot products are accumulated with atomics and its 40-step
-    # drag scatters over 2.476 .. 2.572 from run to run (measured over 12 runs: up to 2.8 % from the CG value)
+    # (both are deterministic now -- the BiCGStab's 40-step drag scattered over 2.476 .. 2.572 from run to run while its dot
+    # products were summed in arrival order; the two SOLVERS still differ by what their tolerances leave)
     assert abs(cds[0] - cds[1]) < 0.06 * abs(cds[0]), cds
 
 
@@ -238,15 +238,15 @@ def test_parallel_env_wraps_the_multi_block_env_on_the_gpu():
     pobs, _ = penv.reset(seed=3)
     obs, _ = env.reset(seed=3)
     assert pobs["velocity"].shape == (2, 151, 2) and pobs["velocity"].is_cuda
-    assert torch.allclose(pobs["velocity"], obs["velocity"], rtol=1e-3, atol=1e-5)
+    assert torch.equal(pobs["velocity"], obs["velocity"])
     act = torch.tensor([[0.5], [-0.5]], device="cuda")
     for i in range(2):
         pobs, prew, pterm, ptrunc, pinfo = penv.step(act)
         obs, rew, term, trunc, info = env.step(act)
         assert len(pterm) == 2 and len(ptrunc) == 2 and all(t == (i == 1) for t in ptrunc) and not any(pterm)
         assert isinstance(pinfo, list) and len(pinfo) == 2 and set(pinfo[0]) == {"drag", "lift"}
-        # (two handles, dot products summed with atomics: equal within the solver tolerance's effect on the forces)
-        assert torch.allclose(prew, rew, rtol=2e-2, atol=1e-3)
-        assert abs(float(pinfo[1]["drag"]) - float(info["drag"][1])) < 2e-2 * abs(float(info["drag"][1]))
+        # two handles, same inputs: bit-identical (order-independent reductions, csrc/fg_internal.h FgDacc)
+        assert torch.equal(prew, rew) and all(torch.equal(pobs[k], obs[k]) for k in obs)
+        assert float(pinfo[1]["drag"]) == float(info["drag"][1])
     assert penv.sample_action().shape == (2, 1)
     penv.close(); env.close()

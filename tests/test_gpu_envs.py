@@ -56,10 +56,11 @@ def test_reset_is_reproducible_and_state_roundtrip():
     r1 = env.step(a)
     env.set_state(s0)
     r2 = env.step(a)
-    assert torch.allclose(r1[1], r2[1], rtol=1e-4, atol=1e-6)
-    assert torch.allclose(r1[0]["velocity"], r2[0]["velocity"], rtol=1e-4, atol=1e-6)
+    # the replay is EXACT as in the reference (envs/fluid_env.py:1320-1363): order-independent reductions (FgDacc)
+    assert torch.equal(r1[1], r2[1])
+    assert torch.equal(r1[0]["velocity"], r2[0]["velocity"]) and torch.equal(r1[0]["pressure"], r2[0]["pressure"])
     o2, _ = env.reset(seed=11)
-    assert torch.allclose(o1["velocity"], o2["velocity"], rtol=1e-4, atol=1e-6)
+    assert torch.equal(o1["velocity"], o2["velocity"])
     env.close()
 
 
