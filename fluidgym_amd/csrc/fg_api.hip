@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "fg_internal.h"
 
 static thread_local std::string g_last_error;
@@ -92,7 +94,7 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(alloc(&s->div, BN));
     FG_HIP_CHECK(alloc(&s->p_result, BN));
     FG_HIP_CHECK(alloc(&s->scal_result, BN));
-    for (int i = 0; i < 7; ++i) FG_HIP_CHECK(alloc(&s->w[i], BN * d));
+    for (int i = 0; i < 8; ++i) FG_HIP_CHECK(alloc(&s->w[i], BN * d));
     const size_t nsys = (size_t)g.B * d;
     FG_HIP_CHECK(hipMalloc(&s->acc, sizeof(FgDacc) * nsys * FG_ACC_DOUBLES));
     FG_HIP_CHECK(hipMemset(s->acc, 0, sizeof(FgDacc) * nsys * FG_ACC_DOUBLES));
@@ -107,6 +109,8 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(float) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
+    s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr;
+    { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = (ev && ev[0] == '0') ? 0 : 1; }   // read once, never on the step path
     s->cg_return_best = 1;
     s->adv_from_result = 1;
     FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(FgDacc) * (size_t)g.B * 8 * 64));
@@ -125,7 +129,7 @@ extern "C" int fg_destroy(fg_handle s) {
     float* owned[] = {s->A, s->rA, s->Coff, s->adv_rhs, s->vel_result, s->hvec, s->div, s->p_result, s->scal_result,
                       s->scratch_B};
     for (float* p : owned) (void)hipFree(p);
-    for (int i = 0; i < 7; ++i) (void)hipFree(s->w[i]);
+    for (int i = 0; i < 8; ++i) (void)hipFree(s->w[i]);
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
     fg_prof_destroy(s);
@@ -134,6 +138,7 @@ extern "C" int fg_destroy(fg_handle s) {
     for (float* p : fd) if (p) (void)hipFree(p);
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc);
+    (void)hipFree(s->line_inv); (void)hipFree(s->line_cp);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
     return FG_OK;
@@ -201,6 +206,21 @@ extern "C" int fg_set_return_best(fg_handle s, int on) {
 extern "C" int fg_set_advection_start(fg_handle s, int from_result) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     s->adv_from_result = from_result ? 1 : 0;
+    return FG_OK;
+}
+
+extern "C" int fg_set_advection_preconditioner(fg_handle s, int mode) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    FG_REQUIRE(mode >= 0 && mode <= 2, FG_ERR_INVALID_ARG, "fg_set_advection_preconditioner: mode must be 0 (off), 1 (always) or 2 (fallback)");
+    if (mode != 0)
+        if (int rc = fg_line_alloc(s)) return rc;
+    s->adv_precond = mode;
+    return FG_OK;
+}
+extern "C" int fg_advection_retries(fg_handle s, int64_t* out, int32_t reset) {
+    FG_REQUIRE(s && out, FG_ERR_INVALID_ARG, "null argument");
+    *out = s->line_retries;
+    if (reset) s->line_retries = 0;
     return FG_OK;
 }
 
@@ -274,6 +294,8 @@ extern "C" int fg_setup_advection(fg_handle s, const float* dt_B, int for_scalar
     return fg_launch_adv_build(s, make_bounds(s, channel), a, (hipStream_t)stream);
 }
 
+static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st);
+
 extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, float tol, int max_iterations,
                                   fg_solve_info* info_host, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
@@ -284,7 +306,7 @@ extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, floa
     if (for_scalar) { a.x = s->scal_result; a.nc = 1; a.use_x0 = 0; }
     else { a.x = s->vel_result; a.nc = s->grid.dims; a.use_x0 = s->adv_from_result; }
     (void)channel;
-    return fg_bicgstab_solve(s, a, info_host, (hipStream_t)stream);
+    return advection_solve(s, a, info_host, (hipStream_t)stream);
 }
 
 extern "C" int fg_copy_scalar_result_to_blocks(fg_handle s, int channel, void* stream) {
@@ -367,6 +389,21 @@ static int max_iters(const fg_solve_info* info, int n) {
     return m;
 }
 
+// One advection-diffusion solve under the handle's preconditioner policy (fg_set_advection_preconditioner), the single-block
+// form of the reference's retry chain (_linear_solve, PISOtorch_diff.py:449-476): mode 1 preconditions every solve
+// (preconditionBiCG), mode 2 repeats a solve that ended unconverged or non-finite from zero WITH the preconditioner
+// (BiCG_precondition_fallback) -- the reference's preconditioner is cuSPARSE ILU(0), here the y-line solve of fg_linepre.hip.
+static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st) {
+    a.precond = (s->adv_precond == 1);
+    int rc = fg_bicgstab_solve(s, a, info, st);
+    if ((rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) && s->adv_precond == 2) {
+        s->line_retries += 1;
+        a.precond = 1; a.use_x0 = 0;
+        rc = fg_bicgstab_solve(s, a, info, st);
+    }
+    return rc;
+}
+
 extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
                             void* stream) {
     FG_REQUIRE(s && dt_B && opt, FG_ERR_INVALID_ARG, "null argument");
@@ -391,7 +428,7 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
             FgBicgArgs a;
             a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->scal_result; a.nc = 1;
             a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 0;
-            if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
+            if (int rc = soft(advection_solve(s, a, info.data(), st))) return rc;
             const int m = max_iters(info.data(), B);
             stats[0] = m > stats[0] ? m : stats[0];
             s->ctr.add(0, info.data(), B);
@@ -418,7 +455,7 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
         FgBicgArgs a;
         a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->vel_result; a.nc = d;
         a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = s->adv_from_result;
-        if (int rc = soft(fg_bicgstab_solve(s, a, info.data(), st))) return rc;
+        if (int rc = soft(advection_solve(s, a, info.data(), st))) return rc;
         stats[1] = max_iters(info.data(), B * d);
         s->ctr.add(1, info.data(), B * d);
     }

@@ -70,6 +70,9 @@ struct BicgPtrs {
     float* x; float* r; float* rw; float* p; float* v; float* t;
     FgDacc* acc; float* sc; int32_t* flags; fg_solve_info* info;
     int nc; float tol;
+    // right preconditioning (fg_linepre.hip): when set, v = C mp with mp = M^-1 p, t = C ms with ms = M^-1 s, and the iterate
+    // advances along mp / ms; r, s and every dot product are those of C M^-1, so r stays the true residual of C x = rhs
+    const float* mp; const float* ms;
 };
 
 // SpMV with the matrix held in registers: the (1 + 2 DIMS) coefficient fields belong to the env, not to the system,
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_v(FgGrid g, BicgPtrs q, int i
         const size_t vb = (size_t)sys * N;
         float part[1] = {0.f};
         if (c.valid) {
-            const FgVec<VEC> y = fg_apply_row<DIMS, VEC>(m, q.p + vb, c);
+            const FgVec<VEC> y = fg_apply_row<DIMS, VEC>(m, (q.mp ? q.mp : q.p) + vb, c);
             const FgVec<VEC> rw = fg_load<VEC>(q.rw + vb + c.idx);
             fg_store<VEC>(q.v + vb + c.idx, y);
 #pragma unroll
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int i
         const size_t vb = (size_t)sys * N;
         float part[2] = {0.f, 0.f};
         if (c.valid) {
-            const FgVec<VEC> t = fg_apply_row<DIMS, VEC>(m, q.r + vb, c);
+            const FgVec<VEC> t = fg_apply_row<DIMS, VEC>(m, (q.ms ? q.ms : q.r) + vb, c);
             const FgVec<VEC> sv = fg_load<VEC>(q.r + vb + c.idx);
             fg_store<VEC>(q.t + vb + c.idx, t);
 #pragma unroll
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
     float part[2] = {0.f, 0.f};
     if (c.valid) {
         FgVec<VEC> x = fg_load<VEC>(q.x + vb + c.idx);
-        const FgVec<VEC> p = fg_load<VEC>(q.p + vb + c.idx);
+        const FgVec<VEC> p = fg_load<VEC>((q.mp ? q.mp : q.p) + vb + c.idx);
         FgVec<VEC> r = fg_load<VEC>(q.r + vb + c.idx);
         if (half) {
 #pragma unroll
@@ -346,9 +349,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
         } else {
             const FgVec<VEC> t = fg_load<VEC>(q.t + vb + c.idx);
             const FgVec<VEC> rw = fg_load<VEC>(q.rw + vb + c.idx);
+            const FgVec<VEC> sd = q.ms ? fg_load<VEC>(q.ms + vb + c.idx) : r;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                x.v[e] += alpha * p.v[e] + omega * r.v[e];
+                x.v[e] += alpha * p.v[e] + omega * sd.v[e];
                 r.v[e] -= omega * t.v[e];
                 part[0] += r.v[e] * r.v[e];
                 part[1] += rw.v[e] * r.v[e];
@@ -363,6 +367,331 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
         acc_add(a + A_RR, (double)part[0]);
         acc_add(a + A_RHO + ((it + 1) & 1), (double)part[1]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two-kernel form of the same recurrence (default; FG_BICG_FUSED=0 at fg_create keeps the five kernels above).
+//
+// The five-kernel iteration has five global reductions and moves 96 B per cell and system; 87 launches of ~9 us made up a PISO
+// step of the headline workload.  Iteration i of BiCGStab,
+//     v_i = C p_i,  alpha_i = rho_i / rw.v_i,  s_i = r_i - alpha_i v_i,  t_i = C s_i,  omega_i = t_i.s_i / t_i.t_i,
+//     x_{i+1} = x_i + alpha_i p_i + omega_i s_i,  r_{i+1} = s_i - omega_i t_i,  rho_{i+1} = rw.r_{i+1},
+//     p_{i+1} = r_{i+1} + (rho_{i+1} / rho_i)(alpha_i / omega_i)(p_i - omega_i v_i),
+// needs only two of them once rho_{i+1} = rw.s_i - omega_i rw.t_i is taken from dot products of the t kernel:
+//   k_bicgf_b(i):  [r_i converged?]  s_i, t_i = C s_i   with s at the neighbours recomputed from r, v;   s.s, t.s, t.t, rw.s, rw.t
+//   k_bicgf_a(i+1): [s_i converged? -> x += alpha p]  x_{i+1}, r_{i+1}, p_{i+1}, v_{i+1} = C p_{i+1}  with p_{i+1} at the
+//                  neighbours recomputed from s, t, p, v;                                                      rw.v, r.r
+// 80 B per cell and system, two launches.  s, t, r and the p / v pairs live in separate buffers (the neighbours' old values must
+// survive a launch).  Same criterion (RMS residual), same iteration count bookkeeping, same breakdown guards as above: a
+// non-finite beta restarts the recurrence (rw = p = r, rho = r.r -- r.r completes in the launch that takes the decision, so the
+// decision is parked as a NaN in the rho slot and k_bicgf_b substitutes r.r), rw.v = 0 or t.t = 0 give alpha / omega = 0.
+// Accumulators (FgDacc, indexed with the parity e of the iteration that fills them so that a leader can reset the set nobody
+// reads in its launch): F_RV + e, F_RR + e by k_bicgf_a | F_SS.. F_RT + e by k_bicgf_b | F_RHOE + e the rho iteration e uses.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int F_RV = 0, F_RR = 2, F_SS = 4, F_TS = 6, F_TT = 8, F_RS = 10, F_RT = 12, F_RHOE = 14;
+static_assert(F_RHOE + 2 <= FG_ACC_DOUBLES, "fused BiCGStab accumulators");
+
+struct BicgFused {
+    float* s; float* p[2]; float* v[2];   // s buffer; p / v of iteration i in p[i & 1] / v[i & 1]
+};
+
+template <int DIMS, int VEC>
+__device__ __forceinline__ FgVec<VEC> fg_apply_nbr(const FgStencilRow<DIMS, VEC>& m, const FgNbr<DIMS, VEC>& X) {
+    FgVec<VEC> y;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        float v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
+                  m.o[3].v[e] * X.yp.v[e];
+        if constexpr (DIMS == 3) v += m.o[4].v[e] * X.zm.v[e] + m.o[5].v[e] * X.zp.v[e];
+        y.v[e] = v;
+    }
+    return y;
+}
+// out = a + ca * b at the cell and all its neighbours
+template <int DIMS, int VEC>
+__device__ __forceinline__ void fg_nbr_axpy(FgNbr<DIMS, VEC>& a, float cb, const FgNbr<DIMS, VEC>& b) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        a.c.v[e] += cb * b.c.v[e]; a.xm.v[e] += cb * b.xm.v[e]; a.xp.v[e] += cb * b.xp.v[e];
+        a.ym.v[e] += cb * b.ym.v[e]; a.yp.v[e] += cb * b.yp.v[e];
+        if constexpr (DIMS == 3) { a.zm.v[e] += cb * b.zm.v[e]; a.zp.v[e] += cb * b.zp.v[e]; }
+    }
+}
+template <int DIMS, int VEC>
+__device__ __forceinline__ void fg_nbr_scale_add(FgNbr<DIMS, VEC>& a, float ca, const FgNbr<DIMS, VEC>& b) {  // a = b + ca * a
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        a.c.v[e] = b.c.v[e] + ca * a.c.v[e]; a.xm.v[e] = b.xm.v[e] + ca * a.xm.v[e]; a.xp.v[e] = b.xp.v[e] + ca * a.xp.v[e];
+        a.ym.v[e] = b.ym.v[e] + ca * a.ym.v[e]; a.yp.v[e] = b.yp.v[e] + ca * a.yp.v[e];
+        if constexpr (DIMS == 3) { a.zm.v[e] = b.zm.v[e] + ca * a.zm.v[e]; a.zp.v[e] = b.zp.v[e] + ca * a.zp.v[e]; }
+    }
+}
+
+// init: r = rhs - C x0 ; rw = r ; p_0 = r ; rr_0 = r.r        (grid.y = 1: loops over the nc systems of the env)
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicgf_init(FgGrid g, BicgPtrs q, BicgFused w, int use_x0, int tiles_x, int tiles_y,
+                                                          int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const size_t N = g.n;
+    bool any = false;
+    for (int comp = 0; comp < q.nc; ++comp) any = any || (flag_ld(q.flags + (c.b * q.nc + comp)) == 0);
+    if (!any) return;
+    FgStencilRow<DIMS, VEC> m;
+    if (use_x0 && c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
+    __shared__ float lds[4];
+    for (int comp = 0; comp < q.nc; ++comp) {
+        const int sys = c.b * q.nc + comp;
+        if (flag_ld(q.flags + (sys)) != 0) continue;
+        const size_t vb = (size_t)sys * N;
+        float part[1] = {0.f};
+        if (c.valid) {
+            FgVec<VEC> r = fg_load<VEC>(q.rhs + vb + c.idx);
+            if (use_x0) {
+                const FgVec<VEC> y = fg_apply_row<DIMS, VEC>(m, q.x + vb, c);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r.v[e] -= y.v[e];
+            } else {
+                FgVec<VEC> z;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) z.v[e] = 0.f;
+                fg_store<VEC>(q.x + vb + c.idx, z);
+            }
+            fg_store<VEC>(q.r + vb + c.idx, r);
+            fg_store<VEC>(q.rw + vb + c.idx, r);
+            fg_store<VEC>(w.p[0] + vb + c.idx, r);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) part[0] += r.v[e] * r.v[e];
+        }
+        fg_block_sum<1>(part, lds);
+        if (threadIdx.x == 0) acc_add(q.acc + (size_t)sys * FG_ACC_DOUBLES + F_RR, (double)part[0]);
+        __syncthreads();
+    }
+}
+
+// k_bicgf_a(it): finish iteration it - 1 (x, r, p) and start iteration it (v = C p, rw.v, r.r)      (grid.y = 1)
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicgf_a(FgGrid g, BicgPtrs q, BicgFused w, int it, int tiles_x, int tiles_y,
+                                                       int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const size_t N = g.n;
+    const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
+    const int e = it & 1, pe = e ^ 1;
+    // per-system decisions, taken by every workgroup of the env from the same accumulator words
+    int mode[3] = {0, 0, 0};   // 0 skip | 1 full update | 2 converged on s: x += alpha p only | 3 first iteration: v = C p
+    float alpha[3], omega[3], beta[3];
+    bool restart[3];
+    bool any = false;
+    for (int comp = 0; comp < q.nc; ++comp) {
+        alpha[comp] = omega[comp] = beta[comp] = 0.f; restart[comp] = false;
+        const int sys = c.b * q.nc + comp;
+        const int f = flag_ld(q.flags + (sys));
+        // 4 = "converged on s" stored by this env's leader in THIS launch (k_bicgf_b turns every 4 into 1 before the next one):
+        // a workgroup that reads it decides the same from s.s below
+        if (f != 0 && f != 4) continue;
+        FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+        if (it == 0) {
+            const double rr0 = acc_ld(a + (F_RR + 0));
+            if (!(fg_rms(rr0, g.n) >= q.tol)) continue;   // the start vector already meets the tolerance: k_bicgf_b(0) marks it
+            if (leader) {
+                acc_st(a + (F_RHOE + 0), rr0);             // rho_0 = rw.r_0 = r_0.r_0
+                acc_st(a + (F_SS + 0), 0.0); acc_st(a + (F_TS + 0), 0.0); acc_st(a + (F_TT + 0), 0.0);
+                acc_st(a + (F_RS + 0), 0.0); acc_st(a + (F_RT + 0), 0.0);
+            }
+            mode[comp] = 3; any = true;
+            continue;
+        }
+        const float crit_s = fg_rms(acc_ld(a + (F_SS + pe)), g.n);
+        alpha[comp] = sc_ld(q.sc + (sys * 2 + 0));
+        if (!(crit_s >= q.tol)) {   // converged on s (bicgstab_solver_kernel.cu:305-329), or s.s not finite
+            const bool fin = isfinite(crit_s);
+            if (leader) {
+                fg_mark(q.flags, q.info, sys, crit_s, it - 1);
+                if (fin) flag_st(q.flags + (sys), 4);
+            }
+            if (fin) { mode[comp] = 2; any = true; }
+            continue;
+        }
+        const float omega_raw = (float)(acc_ld(a + (F_TS + pe)) / acc_ld(a + (F_TT + pe)));
+        omega[comp] = isfinite(omega_raw) ? omega_raw : 0.f;
+        const double rho_new = acc_ld(a + (F_RS + pe)) - (double)omega[comp] * acc_ld(a + (F_RT + pe));
+        beta[comp] = (float)(rho_new / acc_ld(a + (F_RHOE + pe))) * (alpha[comp] / omega[comp]);
+        restart[comp] = !isfinite(beta[comp]);   // rho of the previous iteration exactly 0, or omega 0: rw = p = r, rho = r.r
+        if (leader) {
+            sc_st(q.sc + (sys * 2 + 1), omega[comp]);
+            acc_st(a + (F_RHOE + e), restart[comp] ? (double)NAN : rho_new);   // NaN: k_bicgf_b takes r.r of this launch
+            acc_st(a + (F_SS + e), 0.0); acc_st(a + (F_TS + e), 0.0); acc_st(a + (F_TT + e), 0.0);
+            acc_st(a + (F_RS + e), 0.0); acc_st(a + (F_RT + e), 0.0);
+        }
+        mode[comp] = 1; any = true;
+    }
+    if (!any) return;
+    FgStencilRow<DIMS, VEC> m;
+    if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
+    __shared__ float lds[8];
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+        if (comp >= q.nc || mode[comp] == 0) continue;
+        const int sys = c.b * q.nc + comp;
+        const size_t vb = (size_t)sys * N;
+        if (mode[comp] == 2) {
+            if (c.valid) {
+                FgVec<VEC> x = fg_load<VEC>(q.x + vb + c.idx);
+                const FgVec<VEC> p = fg_load<VEC>(w.p[pe] + vb + c.idx);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) x.v[k] += alpha[comp] * p.v[k];
+                fg_store<VEC>(q.x + vb + c.idx, x);
+            }
+            continue;
+        }
+        float part[2] = {0.f, 0.f};
+        if (c.valid) {
+            FgNbr<DIMS, VEC> P;   // p of iteration `it` at the cell and its neighbours
+            FgVec<VEC> rwv = fg_load<VEC>(q.rw + vb + c.idx);
+            if (mode[comp] == 3) {
+                P = fg_gather<DIMS, VEC>(w.p[0] + vb, c);
+            } else {
+                const float al = alpha[comp], om = omega[comp], be = beta[comp];
+                // r_{it} = s - omega t at the cell and its neighbours
+                FgNbr<DIMS, VEC> R = fg_gather<DIMS, VEC>(w.s + vb, c);
+                {
+                    const FgNbr<DIMS, VEC> T = fg_gather<DIMS, VEC>(q.t + vb, c);
+                    FgVec<VEC> x = fg_load<VEC>(q.x + vb + c.idx);
+                    const FgVec<VEC> pold = fg_load<VEC>(w.p[pe] + vb + c.idx);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) x.v[k] += al * pold.v[k] + om * R.c.v[k];
+                    fg_store<VEC>(q.x + vb + c.idx, x);
+                    fg_nbr_axpy<DIMS, VEC>(R, -om, T);
+                }
+                fg_store<VEC>(q.r + vb + c.idx, R.c);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) part[1] += R.c.v[k] * R.c.v[k];
+                if (restart[comp]) {
+                    P = R;
+                    rwv = R.c;
+                    fg_store<VEC>(q.rw + vb + c.idx, rwv);
+                } else {
+                    // p_{it} = r + beta (p - omega v)
+                    P = fg_gather<DIMS, VEC>(w.p[pe] + vb, c);
+                    const FgNbr<DIMS, VEC> V = fg_gather<DIMS, VEC>(w.v[pe] + vb, c);
+                    fg_nbr_axpy<DIMS, VEC>(P, -om, V);
+                    fg_nbr_scale_add<DIMS, VEC>(P, be, R);
+                }
+                fg_store<VEC>(w.p[e] + vb + c.idx, P.c);
+            }
+            const FgVec<VEC> y = fg_apply_nbr<DIMS, VEC>(m, P);
+            fg_store<VEC>(w.v[e] + vb + c.idx, y);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) part[0] += rwv.v[k] * y.v[k];
+        }
+        fg_block_sum<2>(part, lds);
+        if (threadIdx.x == 0) {
+            FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+            acc_add(a + (F_RV + e), (double)part[0]);
+            if (mode[comp] == 1) acc_add(a + (F_RR + e), (double)part[1]);
+        }
+        __syncthreads();
+    }
+}
+
+// k_bicgf_b(it): convergence test on r_it, alpha, s = r - alpha v, t = C s, the five dot products      (grid.y = 1)
+template <int DIMS, int VEC>
+__global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, BicgFused w, int it, int tiles_x, int tiles_y,
+                                                       int tiles) {
+    const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    const size_t N = g.n;
+    const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
+    const int e = it & 1;
+    bool work[3] = {false, false, false};
+    float alpha[3] = {0.f, 0.f, 0.f};
+    bool any = false;
+    for (int comp = 0; comp < q.nc; ++comp) {
+        const int sys = c.b * q.nc + comp;
+        const int f = flag_ld(q.flags + (sys));
+        if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); continue; }   // k_bicgf_a applied x += alpha p: done
+        if (f != 0) continue;
+        FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+        const double rr = acc_ld(a + (F_RR + e));
+        const float crit = fg_rms(rr, g.n);
+        if (!(crit >= q.tol)) {
+            if (leader) fg_mark(q.flags, q.info, sys, crit, it == 0 ? -1 : it);
+            continue;
+        }
+        double rho = acc_ld(a + (F_RHOE + e));
+        if (isnan(rho)) rho = rr;                       // breakdown restart decided by k_bicgf_a: rw = r, rho = r.r
+        const float alpha_raw = (float)(rho / acc_ld(a + (F_RV + e)));
+        alpha[comp] = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
+        if (leader) {
+            q.info[sys].final_residual = crit;
+            q.info[sys].used_iterations = it - 1;
+            sc_st(q.sc + (sys * 2 + 0), alpha[comp]);
+            acc_st(a + (F_RHOE + e), rho);              // (a workgroup that reads it after this store finds the same value)
+            acc_st(a + (F_RV + (e ^ 1)), 0.0); acc_st(a + (F_RR + (e ^ 1)), 0.0);   // filled by k_bicgf_a(it + 1)
+        }
+        work[comp] = true; any = true;
+    }
+    if (!any) return;
+    FgStencilRow<DIMS, VEC> m;
+    if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
+    __shared__ float lds[20];
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+        if (comp >= q.nc || !work[comp]) continue;
+        const int sys = c.b * q.nc + comp;
+        const size_t vb = (size_t)sys * N;
+        float part[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c.valid) {
+            FgNbr<DIMS, VEC> S = fg_gather<DIMS, VEC>(q.r + vb, c);
+            {
+                const FgNbr<DIMS, VEC> V = fg_gather<DIMS, VEC>(w.v[e] + vb, c);
+                fg_nbr_axpy<DIMS, VEC>(S, -alpha[comp], V);
+            }
+            const FgVec<VEC> t = fg_apply_nbr<DIMS, VEC>(m, S);
+            const FgVec<VEC> rwv = fg_load<VEC>(q.rw + vb + c.idx);
+            fg_store<VEC>(w.s + vb + c.idx, S.c);
+            fg_store<VEC>(q.t + vb + c.idx, t);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                part[0] += S.c.v[k] * S.c.v[k];
+                part[1] += t.v[k] * S.c.v[k];
+                part[2] += t.v[k] * t.v[k];
+                part[3] += rwv.v[k] * S.c.v[k];
+                part[4] += rwv.v[k] * t.v[k];
+            }
+        }
+        fg_block_sum<5>(part, lds);
+        if (threadIdx.x == 0) {
+            FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
+            acc_add(a + (F_SS + e), (double)part[0]);
+            acc_add(a + (F_TS + e), (double)part[1]);
+            acc_add(a + (F_TT + e), (double)part[2]);
+            acc_add(a + (F_RS + e), (double)part[3]);
+            acc_add(a + (F_RT + e), (double)part[4]);
+        }
+        __syncthreads();
+    }
+}
+
+// poll after k_bicgf_a(it + 1), i.e. after iteration `it` completed: judges r_{it+1} exactly as k_bicg_check does (the next
+// k_bicgf_b would come to the same verdict from the same accumulator) and mirrors info for the host
+__global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+                              fg_solve_info* __restrict__ mirror, float tol, int it, int n, int nsys, int final_pass) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
+    if (flag_ld(flags + (s)) == 0) {
+        const float crit = (float)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + F_RR + ((it + 1) & 1))) / (double)n);
+        info[s].final_residual = crit;
+        info[s].used_iterations = it + 1;
+        if (!(crit >= tol)) {
+            const bool finite = isfinite(crit);
+            flag_st(flags + (s), finite ? 1 : 2);
+            info[s].converged = finite ? 1 : 0;
+            info[s].is_finite = finite ? 1 : 0;
+        } else if (final_pass) {
+            info[s].converged = 0;
+        }
+    }
+    mirror[s] = info[s];
 }
 
 __global__ void k_bicg_begin(const float* __restrict__ dt, FgDacc* __restrict__ acc, float* __restrict__ sc,
@@ -409,8 +738,15 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     q.r = s->w[0]; q.rw = s->w[1]; q.p = s->w[2]; q.v = s->w[3]; q.t = s->w[4];
     q.acc = s->acc; q.sc = s->scratch_B + 4 * B;  // scratch_B holds 4*B floats of env scalars first
     q.flags = s->flags; q.info = s->info_dev; q.nc = a.nc; q.tol = a.tol;
+    q.mp = nullptr; q.ms = nullptr;
+    if (a.precond) {
+        if (int rc = fg_line_alloc(s)) return rc;
+        q.mp = s->w[5]; q.ms = s->w[6];   // free during a BiCGStab solve (the CG's z and second p buffer)
+    }
     const dim3 sg((nsys + 63) / 64), sb(64);
     hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
+    if (a.precond)
+        if (int rc = fg_line_factor(s, a.diag, a.off, a.nc, st)) return rc;
 
 #define FG_BICG_LAUNCH_Y(NY, SLOT, KERNEL, ...)                                                                          \
     do {                                                                                                     \
@@ -434,20 +770,45 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     } while (0)
 
 #define FG_BICG_LAUNCH(SLOT, KERNEL, ...) FG_BICG_LAUNCH_Y(a.nc, SLOT, KERNEL, __VA_ARGS__)
-    FG_BICG_LAUNCH_Y(1, -1, k_bicg_init, a.use_x0);
     bool done = false, info_fresh = false;
     // first convergence poll where the previous solve finished (kernels of converged systems exit at once,
     // so over-launching costs ~2 us per kernel while every poll costs a stream sync), then every 2 iterations
     int next_poll = s->pred_bicg > 1 ? s->pred_bicg : 1;
+    const double cells = (double)n, mat = 4.0 * (1 + 2 * s->grid.dims) / a.nc, fl = 2.0 * (1 + 2 * s->grid.dims);
+    if (s->bicg_fused && !a.precond) {
+        // two-kernel iteration (k_bicgf_a / k_bicgf_b above): per system and cell, a reads x, p, s, t, v, rw + the matrix and writes
+        // x, r, p, v (40 + mat B); b reads r, v, rw + the matrix and writes s, t (20 + mat B)
+        BicgFused w;
+        w.s = s->w[7]; w.p[0] = s->w[2]; w.p[1] = s->w[5]; w.v[0] = s->w[3]; w.v[1] = s->w[6];
+        FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);
+        FG_BICG_LAUNCH_Y(1, -1, k_bicgf_a, w, 0);
+        for (int it = 0; it < a.max_iterations && !done; ++it) {
+            FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_B, q.flags, nsys, cells * (20.0 + mat), cells * (fl + 12.0), st), k_bicgf_b, w, it);
+            FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_A, q.flags, nsys, cells * (40.0 + mat), cells * (fl + 14.0), st), k_bicgf_a, w, it + 1);
+            if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
+                next_poll = it + 1 + 2;
+                const int final_pass = (it + 1 == a.max_iterations);
+                hipLaunchKernelGGL(k_bicgf_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass);
+                FG_HIP_CHECK(hipStreamSynchronize(st));
+                info_fresh = true;
+                done = true;
+                for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
+            }
+        }
+    } else {
+    FG_BICG_LAUNCH_Y(1, -1, k_bicg_init, a.use_x0);
     for (int it = 0; it < a.max_iterations && !done; ++it) {
         // algorithmic bytes per system and cell: Kp r,v,p -> p (16; the first iteration only checks) | Kv p,rw -> v + the
         // (1 + 2d) matrix fields shared by the nc right-hand sides | Ks r,v -> s (12) | Kt s -> t + matrix |
         // Kx x,p,s,t,rw -> x,r (28)
-        const double cells = (double)n, mat = 4.0 * (1 + 2 * s->grid.dims) / a.nc, fl = 2.0 * (1 + 2 * s->grid.dims);
         if (it > 0) FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_P, q.flags, nsys, cells * 16.0, cells * 4.0, st), k_bicg_p, it);
         else FG_BICG_LAUNCH(-1, k_bicg_p, it);
+        if (a.precond)
+            if (int rc = fg_line_apply(s, a.diag, a.off, a.nc, q.p, s->w[5], st)) return rc;
         FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICG_V, q.flags, nsys, cells * (12.0 + mat), cells * (fl + 2.0), st), k_bicg_v, it);
         FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_S, q.flags, nsys, cells * 12.0, cells * 4.0, st), k_bicg_s, it);
+        if (a.precond)
+            if (int rc = fg_line_apply(s, a.diag, a.off, a.nc, q.r, s->w[6], st)) return rc;
         FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICG_T, q.flags, nsys, cells * (8.0 + mat), cells * (fl + 4.0), st), k_bicg_t, it);
         FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_X, q.flags, nsys, cells * 28.0, cells * 10.0, st), k_bicg_x, it);
         if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
@@ -460,6 +821,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
             done = true;
             for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
         }
+    }
     }
 #undef FG_BICG_LAUNCH
 #undef FG_BICG_LAUNCH_Y

@@ -390,7 +390,7 @@ __device__ __forceinline__ void fg_block_sum(float (&v)[NV], float* lds /* >= NV
 // kernel snapshots how many systems were still iterating so the algorithmic bytes count only work done.
 enum FgProfKind {
     FG_PK_CG_AP = 0, FG_PK_CG_UPDATE, FG_PK_BICG_P, FG_PK_BICG_V, FG_PK_BICG_S, FG_PK_BICG_T, FG_PK_BICG_X,
-    FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_DCT, FG_PK_COUNT
+    FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_DCT, FG_PK_LINE, FG_PK_BICGF_A, FG_PK_BICGF_B, FG_PK_COUNT
 };
 #define FG_PROF_POOL 256
 struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };
@@ -478,7 +478,7 @@ struct fg_state {
     float* div;        // [B,N]     pressureRHSdiv
     float* p_result;   // [B,N]
     float* scal_result;// [B,N]
-    float* w[7];       // Krylov work vectors, each [B,d,N]
+    float* w[8];       // Krylov work vectors, each [B,d,N]
     FgDacc* acc;       // [B*d][FG_ACC_DOUBLES] reduction accumulators (order-independent, FgDacc)
     int32_t* flags;    // [B*d] convergence flags (device)
     fg_solve_info* info_dev;   // [B*d]
@@ -490,6 +490,12 @@ struct fg_state {
     FgBest cg_best;               // best-iterate tracking of the CG (returnBestResult, cg_solver_kernel.cu:345-361)
     int cg_return_best;           // 1 (default): track; 0: never keep an iterate (fg_set_return_best)
     int adv_from_result;          // 1 (default): velocity solve starts from velocityResult; 0: from zero (fg_set_advection_start)
+    // y-line right preconditioner of the advection BiCGStab (fg_linepre.hip; fg_set_advection_preconditioner): 0 never (the
+    // reference's first rung), 1 every solve (its preconditionBiCG), 2 only to repeat a solve that failed (its
+    // BiCG_precondition_fallback); line_retries counts the repeats.  Factors [B][N], allocated on first use
+    int adv_precond; long long line_retries;
+    int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
+    float* line_inv; float* line_cp;
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs
@@ -587,6 +593,7 @@ struct FgBicgArgs {
     int nc;
     const float* dt;
     float tol; int max_iterations; int use_x0;
+    int precond = 0;   // 1: right-preconditioned by the y-line solve of fg_linepre.hip (v = C M^-1 p, t = C M^-1 s)
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
 
@@ -623,4 +630,9 @@ int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_wi
 // expect_active: the caller's estimate of envs still iterating (<= 0: all) -- only picks the GEMM tile shape
 int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st);
+// y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
+// with a live system, z = M^-1 r for every live system
+int fg_line_alloc(fg_state* s);
+int fg_line_factor(fg_state* s, const float* diag, const float* off, int nc, hipStream_t st);
+int fg_line_apply(fg_state* s, const float* diag, const float* off, int nc, const float* r, float* z, hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

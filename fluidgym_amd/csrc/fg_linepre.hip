@@ -1,0 +1,321 @@
+// y-line (tridiagonal) right preconditioner of the batched BiCGStab on the stencil-form advection-diffusion matrix, gfx950.
+//
+// On wall-refined grids (RBC 512 x 128, TCF) the stiff part of C = I/dt + advection - nu Laplacian is the y-diffusion across the
+// thin wall cells: the plain recurrence of the reference (bicgstab_solver_kernel.cu:63-411) needs 20-35 iterations there.  The
+// reference's own answer is a preconditioned solve (cuSPARSE ILU(0), bicgstab_solver_kernel.cu:191-226, 288-293: preconditionBiCG
+// / BiCG_precondition_fallback of PISOtorch_diff.py:449-476).  Here M = the tridiagonal part of C along y (diagonal + the -y / +y
+// off-diagonals; a periodic wrap is ignored), factorised once per solve and env by the Thomas recurrence
+//   inv_j = 1 / (d_j - l_j c'_{j-1}),   c'_j = u_j inv_j
+// and applied per system as  y_j = (r_j - l_j y_{j-1}) inv_j,  z_j = y_j - c'_j z_{j+1}.
+// The recurrence is serial along y and parallel across the columns (x, z): a workgroup owns 64 consecutive columns, its four
+// waves stage the column block in LDS with float4 loads (rows contiguous in x: coalesced), wave 0 sweeps out of LDS in 16-row
+// register chunks (one dependent FMA per row), all waves store -- the scheme of k_tridiag_y_lds (fg_fdprecond.hip), with
+// per-env, per-cell coefficients.  Needs nx % 4 == 0 and 3 x roundup(ny, 16) x 256 B of LDS; otherwise a streaming kernel with one
+// thread per column.
+#include "fg_internal.h"
+
+namespace {
+
+constexpr int LP_CH = 16;
+
+struct LineArgs {
+    const float* diag;   // [B][N]
+    const float* off;    // [B][2 d][N], face order: 2 = -y, 3 = +y
+    float* inv;          // [B][N]
+    float* cp;           // [B][N]
+    int nx, ny, nz, dims, nc;
+    const int32_t* flags;  // per system (apply) -- a system whose flag is not 0 is skipped
+};
+
+// coordinates of the float4 a lane handles in a 64-column block: t4 = first column, a4 / c4 its x / z index
+struct LineCol { int lc, rsub; bool live; size_t col4; };
+__device__ __forceinline__ LineCol line_col(int nx, int ny, int nz) {
+    LineCol c;
+    const int lane = threadIdx.x & 63;
+    c.lc = 4 * (lane & 15);
+    c.rsub = lane >> 4;
+    int t4 = blockIdx.x * 64 + c.lc;
+    c.live = t4 < nx * nz;
+    if (!c.live) t4 = nx * nz - 4;
+    const int a4 = t4 % nx, c4 = t4 / nx;
+    c.col4 = (size_t)c4 * ny * nx + a4;
+    return c;
+}
+
+// factorisation: one launch per solve, grid (column blocks, B); active = any system of the env still has flag 0
+__global__ __launch_bounds__(256) void k_line_factor_y(LineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];   // d[nyp][64] | l[nyp][64] | u[nyp][64]
+    const int b = blockIdx.y;
+    bool any = false;
+    for (int comp = 0; comp < a.nc; ++comp) any = any || (a.flags[b * a.nc + comp] == 0);
+    if (!any) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nx = a.nx, ny = a.ny, last = ny - 1;
+    const int nyp = (ny + LP_CH - 1) / LP_CH * LP_CH;
+    const size_t N = (size_t)nx * ny * a.nz;
+    float* ds = tbuf;
+    float* ls = tbuf + (size_t)nyp * 64;
+    float* us = tbuf + (size_t)2 * nyp * 64;
+    const LineCol c = line_col(nx, ny, a.nz);
+    const float* __restrict__ d4 = a.diag + (size_t)b * N + c.col4;
+    const float* __restrict__ l4 = a.off + ((size_t)b * 2 * a.dims + 2) * N + c.col4;
+    const float* __restrict__ u4 = a.off + ((size_t)b * 2 * a.dims + 3) * N + c.col4;
+    for (int jb = wave * 32; jb < nyp; jb += 128) {
+        float4 vd[8], vl[8], vu[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = min(jb + 4 * q + c.rsub, last);
+            vd[q] = *reinterpret_cast<const float4*>(d4 + (size_t)j * nx);
+            vl[q] = *reinterpret_cast<const float4*>(l4 + (size_t)j * nx);
+            vu[q] = *reinterpret_cast<const float4*>(u4 + (size_t)j * nx);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = jb + 4 * q + c.rsub;
+            if (j < nyp) {
+                const int o = j * 64 + c.lc;
+                const bool pad = j > last;   // padding rows: the identity (d = 1, l = u = 0)
+                *reinterpret_cast<float4*>(ds + o) = pad ? make_float4(1.f, 1.f, 1.f, 1.f) : vd[q];
+                *reinterpret_cast<float4*>(ls + o) = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : vl[q];
+                *reinterpret_cast<float4*>(us + o) = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : vu[q];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float cprev = 0.f;
+        float* pd = ds + lane;
+        const float* pl = ls + lane;
+        float* pu = us + lane;
+        for (int j0 = 0; j0 < nyp; j0 += LP_CH, pd += LP_CH * 64, pl += LP_CH * 64, pu += LP_CH * 64) {
+            float ad[LP_CH], al[LP_CH], au[LP_CH];
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { ad[q] = pd[q * 64]; al[q] = pl[q * 64]; au[q] = pu[q * 64]; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) {
+                const float iv = 1.f / fmaf(-al[q], cprev, ad[q]);
+                cprev = au[q] * iv;
+                ad[q] = iv; au[q] = cprev;
+            }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { pd[q * 64] = ad[q]; pu[q * 64] = au[q]; }
+        }
+    }
+    __syncthreads();
+    if (c.live) {
+        float* __restrict__ i4 = a.inv + (size_t)b * N + c.col4;
+        float* __restrict__ c4 = a.cp + (size_t)b * N + c.col4;
+        for (int jb = wave * 32; jb < ny; jb += 128) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + 4 * q + c.rsub;
+                if (j <= last) {
+                    *reinterpret_cast<float4*>(i4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(ds + j * 64 + c.lc);
+                    *reinterpret_cast<float4*>(c4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(us + j * 64 + c.lc);
+                }
+            }
+        }
+    }
+}
+
+// z = M^-1 r for every system with flag 0; grid (column blocks, nsys)
+__global__ __launch_bounds__(256) void k_line_apply_y(LineArgs a, const float* __restrict__ r, float* __restrict__ z) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];   // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]
+    const int sys = blockIdx.y;
+    if (a.flags[sys] != 0) return;
+    const int b = sys / a.nc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nx = a.nx, ny = a.ny, last = ny - 1;
+    const int nyp = (ny + LP_CH - 1) / LP_CH * LP_CH;
+    const size_t N = (size_t)nx * ny * a.nz;
+    float* bs = tbuf;
+    float* ms = tbuf + (size_t)nyp * 64;
+    float* cs = tbuf + (size_t)2 * nyp * 64;
+    const LineCol c = line_col(nx, ny, a.nz);
+    const float* __restrict__ r4 = r + (size_t)sys * N + c.col4;
+    const float* __restrict__ i4 = a.inv + (size_t)b * N + c.col4;
+    const float* __restrict__ c4 = a.cp + (size_t)b * N + c.col4;
+    const float* __restrict__ l4 = a.off + ((size_t)b * 2 * a.dims + 2) * N + c.col4;
+    for (int jb = wave * 32; jb < nyp; jb += 128) {
+        float4 vr[8], vi[8], vc[8], vl[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = min(jb + 4 * q + c.rsub, last);
+            vr[q] = *reinterpret_cast<const float4*>(r4 + (size_t)j * nx);
+            vi[q] = *reinterpret_cast<const float4*>(i4 + (size_t)j * nx);
+            vc[q] = *reinterpret_cast<const float4*>(c4 + (size_t)j * nx);
+            vl[q] = *reinterpret_cast<const float4*>(l4 + (size_t)j * nx);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = jb + 4 * q + c.rsub;
+            if (j < nyp) {
+                const float m = (j > last) ? 0.f : 1.f;   // padding rows are neutral
+                const int o = j * 64 + c.lc;
+                *reinterpret_cast<float4*>(bs + o) =
+                    make_float4(vr[q].x * vi[q].x * m, vr[q].y * vi[q].y * m, vr[q].z * vi[q].z * m, vr[q].w * vi[q].w * m);
+                *reinterpret_cast<float4*>(ms + o) =
+                    make_float4(vl[q].x * vi[q].x * m, vl[q].y * vi[q].y * m, vl[q].z * vi[q].z * m, vl[q].w * vi[q].w * m);
+                *reinterpret_cast<float4*>(cs + o) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float prev = 0.f;   // y_{-1} = 0: a periodic wrap of the first row's -y coefficient is dropped here
+        float* px = bs + lane;
+        const float* pm = ms + lane;
+        for (int j0 = 0; j0 < nyp; j0 += LP_CH, px += LP_CH * 64, pm += LP_CH * 64) {
+            float ax[LP_CH], am[LP_CH];
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { ax[q] = px[q * 64]; am[q] = pm[q * 64]; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { prev = fmaf(-am[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) px[q * 64] = ax[q];
+        }
+        prev = 0.f;         // z_{ny} = 0: likewise for the last row's +y coefficient
+        px = bs + (size_t)(nyp - LP_CH) * 64 + lane;
+        const float* pc = cs + (size_t)(nyp - LP_CH) * 64 + lane;
+        for (int j0 = nyp - LP_CH; j0 >= 0; j0 -= LP_CH, px -= LP_CH * 64, pc -= LP_CH * 64) {
+            float ax[LP_CH], ac[LP_CH];
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { ax[q] = px[q * 64]; ac[q] = pc[q * 64]; }
+#pragma unroll
+            for (int q = LP_CH - 1; q >= 0; --q) { prev = fmaf(-ac[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) px[q * 64] = ax[q];
+        }
+    }
+    __syncthreads();
+    if (c.live) {
+        float* __restrict__ z4 = z + (size_t)sys * N + c.col4;
+        for (int jb = wave * 32; jb < ny; jb += 128) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + 4 * q + c.rsub;
+                if (j <= last)
+                    *reinterpret_cast<float4*>(z4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * 64 + c.lc);
+            }
+        }
+    }
+}
+
+// ---- streaming forms (any nx, ny): one thread per column, rows read in unrolled groups so that loads stay in flight
+__global__ __launch_bounds__(256) void k_line_factor_y_stream(LineArgs a) {
+    const int b = blockIdx.y;
+    bool any = false;
+    for (int comp = 0; comp < a.nc; ++comp) any = any || (a.flags[b * a.nc + comp] == 0);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (!any || t >= a.nx * a.nz) return;
+    const int nx = a.nx, ny = a.ny;
+    const size_t N = (size_t)nx * ny * a.nz;
+    const size_t col = (size_t)(t / nx) * ny * nx + (t % nx);
+    const float* d = a.diag + (size_t)b * N + col;
+    const float* l = a.off + ((size_t)b * 2 * a.dims + 2) * N + col;
+    const float* u = a.off + ((size_t)b * 2 * a.dims + 3) * N + col;
+    float* iv = a.inv + (size_t)b * N + col;
+    float* cp = a.cp + (size_t)b * N + col;
+    float cprev = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < ny; ++j) {
+        const size_t o = (size_t)j * nx;
+        const float inv = 1.f / fmaf(-l[o], cprev, d[o]);
+        cprev = u[o] * inv;
+        iv[o] = inv; cp[o] = cprev;
+    }
+}
+__global__ __launch_bounds__(256) void k_line_apply_y_stream(LineArgs a, const float* __restrict__ r, float* __restrict__ z) {
+    const int sys = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (a.flags[sys] != 0 || t >= a.nx * a.nz) return;
+    const int b = sys / a.nc;
+    const int nx = a.nx, ny = a.ny;
+    const size_t N = (size_t)nx * ny * a.nz;
+    const size_t col = (size_t)(t / nx) * ny * nx + (t % nx);
+    const float* rr = r + (size_t)sys * N + col;
+    float* zz = z + (size_t)sys * N + col;
+    const float* iv = a.inv + (size_t)b * N + col;
+    const float* cp = a.cp + (size_t)b * N + col;
+    const float* l = a.off + ((size_t)b * 2 * a.dims + 2) * N + col;
+    float prev = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < ny; ++j) {
+        const size_t o = (size_t)j * nx;
+        prev = (rr[o] - l[o] * prev) * iv[o];
+        zz[o] = prev;
+    }
+    prev = 0.f;
+#pragma unroll 8
+    for (int j = ny - 1; j >= 0; --j) {
+        const size_t o = (size_t)j * nx;
+        prev = zz[o] - cp[o] * prev;
+        zz[o] = prev;
+    }
+}
+
+bool line_lds_ready(size_t bytes) {   // dynamic LDS above 64 KB needs an explicit opt-in per kernel
+    static size_t granted = 0;
+    static bool failed = false;
+    if (bytes <= granted) return true;
+    if (failed) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_line_apply_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_line_factor_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        failed = true;
+        return false;
+    }
+    granted = bytes;
+    return true;
+}
+
+LineArgs line_args(const fg_state* s, const float* diag, const float* off, int nc) {
+    LineArgs a;
+    a.diag = diag; a.off = off; a.inv = s->line_inv; a.cp = s->line_cp;
+    a.nx = s->grid.nx; a.ny = s->grid.ny; a.nz = s->grid.nz; a.dims = s->grid.dims; a.nc = nc;
+    a.flags = s->flags;
+    return a;
+}
+
+size_t line_lds_bytes(const fg_state* s) {
+    const int nyp = (s->grid.ny + LP_CH - 1) / LP_CH * LP_CH;
+    return (size_t)3 * nyp * 64 * sizeof(float);
+}
+bool line_use_lds(const fg_state* s) {
+    const size_t bytes = line_lds_bytes(s);
+    return (s->grid.nx & 3) == 0 && bytes <= 160 * 1024 && line_lds_ready(bytes);
+}
+
+}  // namespace
+
+int fg_line_alloc(fg_state* s) {
+    if (s->line_inv) return FG_OK;
+    const size_t count = (size_t)s->grid.B * s->grid.n;
+    FG_HIP_CHECK(hipMalloc(&s->line_inv, sizeof(float) * count));
+    FG_HIP_CHECK(hipMalloc(&s->line_cp, sizeof(float) * count));
+    return FG_OK;
+}
+
+int fg_line_factor(fg_state* s, const float* diag, const float* off, int nc, hipStream_t st) {
+    const LineArgs a = line_args(s, diag, off, nc);
+    const int cols = s->grid.nx * s->grid.nz;
+    if (line_use_lds(s))
+        hipLaunchKernelGGL(k_line_factor_y, dim3((cols + 63) / 64, s->grid.B), dim3(256), line_lds_bytes(s), st, a);
+    else
+        hipLaunchKernelGGL(k_line_factor_y_stream, dim3((cols + 255) / 256, s->grid.B), dim3(256), 0, st, a);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_line_apply(fg_state* s, const float* diag, const float* off, int nc, const float* r, float* z, hipStream_t st) {
+    const LineArgs a = line_args(s, diag, off, nc);
+    const int cols = s->grid.nx * s->grid.nz, nsys = s->grid.B * nc;
+    // per system and cell: r, inv, c', l read + z written
+    const int slot = fg_prof_slot(s, FG_PK_LINE, s->flags, nsys, 20.0 * s->grid.n, 5.0 * s->grid.n, st);
+    if (line_use_lds(s))
+        FG_LAUNCH_P(s, slot, k_line_apply_y, dim3((cols + 63) / 64, nsys), dim3(256), line_lds_bytes(s), st, a, r, z);
+    else
+        FG_LAUNCH_P(s, slot, k_line_apply_y_stream, dim3((cols + 255) / 256, nsys), dim3(256), 0, st, a, r, z);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}

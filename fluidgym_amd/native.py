@@ -341,6 +341,17 @@ class NativeSolver:
         branch, first pass) -- ``fg_set_advection_start``."""
         L.check(self.lib.fg_set_advection_start(self.handle, int(from_result)))
 
+    def set_advection_preconditioner(self, mode: int = 0):
+        """Preconditioner policy of the advection-diffusion BiCGStab (``fg_set_advection_preconditioner``): 0 plain (the
+        reference's first rung), 1 every solve right-preconditioned by the y-line solve (its ``preconditionBiCG``), 2 only
+        to repeat a failed solve (its ``BiCG_precondition_fallback``)."""
+        L.check(self.lib.fg_set_advection_preconditioner(self.handle, int(mode)))
+
+    def advection_retries(self, reset: bool = False) -> int:
+        out = ctypes.c_int64()
+        L.check(self.lib.fg_advection_retries(self.handle, ctypes.byref(out), int(reset)))
+        return int(out.value)
+
     def profile_enable(self, on: bool = True):
         L.check(self.lib.fg_profile_enable(self.handle, int(on)))
 

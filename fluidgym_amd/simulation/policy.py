@@ -31,8 +31,16 @@ benchmark line can say which mode it ran in:
     of five although every solve meets its tolerance on the true residual -- an open question, so it is
     opt-in.
 
+``advection_line_preconditioner`` (default False)
+    Single-block path: on grids refined towards a y wall (largest / smallest y width >= 3: the RBC and TCF families) every
+    advection-diffusion BiCGStab is right-preconditioned by the tridiagonal part of its matrix along y (``csrc/fg_linepre.hip``)
+    instead of only the repeated ones (the reference's rule, ``BiCG_precondition_fallback``).  Off by default because it does
+    not pay on the registered grids: on RBC 512 x 128 the x and y diffusion numbers are comparable (5.7 and 1-14), the line
+    solve halves the iterations (44 -> 21 on a synthetic RBC matrix, 11 with an alternating x / y line solve) and costs as
+    much per iteration as it saves.  The ``preconditionBiCG`` / ``BiCG_precondition_fallback`` kwargs work either way.
+
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` / ``FLUIDGYM_AMD_ADVECTION_WARM_START`` /
-``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
+``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
 at import).
 """
 from __future__ import annotations
@@ -45,6 +53,7 @@ _POLICY: Dict[str, Any] = {
     "advection_warm_start": os.environ.get("FLUIDGYM_AMD_ADVECTION_WARM_START", "0") not in ("0", "", "false", "False"),
     "pressure_stall_accept": float(os.environ.get("FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT", "0") or 0.0),
     "pressure_multilevel": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL", "1") not in ("0", "", "false", "False"),
+    "advection_line_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER", "0") not in ("0", "", "false", "False"),
     "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "0") not in ("0", "", "false", "False"),
 }
 

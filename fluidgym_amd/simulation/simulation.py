@@ -131,11 +131,22 @@ class Simulation:
         self.advection_warm_start = bool(get_solver_policy()["advection_warm_start"] if advection_warm_start is None
                                          else advection_warm_start)
         domain.solver.set_advection_start((not non_orthogonal) or self.advection_warm_start)
-        if solver_double_fallback or not BiCG_precondition_fallback or preconditionBiCG:
-            # accepted for signature compatibility; the orthogonal single-block systems of this path are solved by a
-            # preconditioned CG / BiCGStab whose failure handling is native (returnBestResult), see DESIGN.md a19
-            _LOG.debug("solver_double_fallback=%s BiCG_precondition_fallback=%s preconditionBiCG=%s", solver_double_fallback,
-                       BiCG_precondition_fallback, preconditionBiCG)
+        # The reference's retry chain of the advection-diffusion solves (_linear_solve, PISOtorch_diff.py:449-476) on this path:
+        # preconditionBiCG preconditions every solve, BiCG_precondition_fallback repeats a failed one with the preconditioner
+        # (cuSPARSE ILU(0) there, the y-line solve of csrc/fg_linepre.hip here).  On top of that the policy switch
+        # advection_line_preconditioner (policy.py, default on) preconditions every solve on grids refined towards a y wall, where
+        # the plain recurrence needs 20-35 iterations (RBC 512 x 128): same system, same tolerance, another Krylov trajectory.
+        # solver_double_fallback (an fp64 re-solve) has no counterpart on this path: its systems are strictly diagonally
+        # dominant and fp32 BiCGStab reaches their tolerances; the kwarg is accepted.
+        self.preconditionBiCG = bool(preconditionBiCG)
+        self.BiCG_precondition_fallback = bool(BiCG_precondition_fallback)
+        self.solver_double_fallback = bool(solver_double_fallback)
+        solver = domain.solver
+        if hasattr(solver, "set_advection_preconditioner"):
+            hy = np.asarray(solver.widths[1], dtype=np.float64)
+            refined = bool(get_solver_policy()["advection_line_preconditioner"]) and float(hy.max() / hy.min()) >= 3.0
+            self.advection_preconditioner = 1 if (self.preconditionBiCG or refined) else (2 if self.BiCG_precondition_fallback else 0)
+            solver.set_advection_preconditioner(self.advection_preconditioner)
         # (bounds, velm, tol): advective-outflow PRE hook of the cylinder/airfoil envs (PISOtorch_simulation.py:
         # 228-393, wired in cylinder_env_base.py:280-300), kept as data so the native driver can run it
         self.outflow = outflow

@@ -161,6 +161,14 @@ int fg_setup_advection(fg_handle h, const float* dt_B, int for_scalar, int chann
  * info_host: d (or 1) * B entries, written after an internal stream sync. */
 int fg_solve_advection(fg_handle h, int for_scalar, int channel, float tol, int max_iterations,
                        fg_solve_info* info_host, void* stream);
+/* Preconditioner policy of the advection-diffusion solves (scalar and velocity), the reference's preconditionBiCG /
+ * BiCG_precondition_fallback (PISOtorch_simulation.py:503, 565; PISOtorch_diff.py:449-476; cuSPARSE ILU(0),
+ * bicgstab_solver_kernel.cu:191-226, 288-293): mode 0 = plain BiCGStab (the reference's first rung, default), 1 = every solve
+ * right-preconditioned, 2 = a solve that ends unconverged or non-finite is repeated from zero with the preconditioner.  The
+ * preconditioner here is the tridiagonal part of the matrix along y (csrc/fg_linepre.hip), factorised per solve and env.
+ * fg_advection_retries: number of repeated solves since the last reset. */
+int fg_set_advection_preconditioner(fg_handle h, int mode);
+int fg_advection_retries(fg_handle h, int64_t* out, int32_t reset);
 /* CopyScalarResultToBlocks (:6558-6746) */
 int fg_copy_scalar_result_to_blocks(fg_handle h, int channel, void* stream);
 /* SetupPressureMatrix (:5599-5615, kernel :4812-4978): rA = 1/A */

@@ -170,7 +170,17 @@ def cylinder_3d_small(res=4, res_z=3, nu=0.01):
     return s
 
 
-def airfoil_spec(div=4, nu=1e-3):
+def face_fluxes(d):
+    """Outward contravariant flux through every prescribed face of an oracle domain: {(block, face): flux}."""
+    out = {}
+    for b, pos in d.cells():
+        for f in range(2 * d.d):
+            if d.at_bound(b, pos, f) and d.is_empty(b, f):
+                out[(b, f)] = out.get((b, f), 0.0) + (1.0 if f & 1 else -1.0) * d.contra_bound(b, f, pos, f >> 1)
+    return out
+
+
+def airfoil_spec(div=4, nu=1e-3, noise=0.1, balanced=False):
     """The airfoil envs' six-block C-mesh (envs/airfoil/grid.py:247-716 in the reference) at ``resolution_div = 4`` (4 110 cells,
     small enough for the per-cell oracle): the mesh with cells of 1e-4 of the typical area where the blocks meet at the nose,
     the one whose pressure matrix is visibly non-symmetric."""
@@ -185,6 +195,13 @@ def airfoil_spec(div=4, nu=1e-3):
     for (b, f), v in m.fixed.items():
         face_cells = s.blocks[b].shape[2 if F[f] >= 2 else 1] - 1
         v = np.broadcast_to(np.asarray(v, np.float64).reshape(2, -1), (2, face_cells))
-        s.fixed.append((b, F[f], v + 0.1 * rng.standard_normal(v.shape)))
+        s.fixed.append((b, F[f], v + noise * rng.standard_normal(v.shape)))
     s.connections = [(b1, F[f1], b2, F[f2], F[ax]) for b1, f1, b2, f2, ax in m.connections]
+    if balanced:
+        # what balance_boundary_fluxes does for the env (PISOtorch_simulation.py:188-226): the two outflow faces (tail blocks,
+        # +x) are scaled so that the boundary fluxes sum to zero -- the pressure system is then consistent
+        fl = face_fluxes(s.oracle())
+        outflow = [(4, 1), (5, 1)]
+        k = -sum(v for key, v in fl.items() if key not in outflow) / sum(fl[key] for key in outflow)
+        s.fixed = [(b, f, v * k if (b, f) in outflow else v) for b, f, v in s.fixed]
     return s

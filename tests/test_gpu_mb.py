@@ -135,10 +135,13 @@ def test_assembly_matches_oracle_on_strongly_skewed_meshes(spec_fn):
 def test_airfoil_mesh_step_matches_the_oracle():
     """One whole PISO step on the airfoil C-mesh (resolution_div 4) against the oracle's direct solves, with the solver the
     airfoil env runs: mean-projected BiCGStab with fp64 refinement at the env's tolerance (airfoil_env_base.py:272)."""
-    spec = H.airfoil_spec()
+    spec = H.airfoil_spec(noise=0.02, balanced=True)
     d = spec.oracle()
+    assert abs(sum(H.face_fluxes(d).values())) < 1e-12
     dom = spec.native(batch=1)
-    st = [_state(d, 31)]
+    u0, p0 = _state(d, 31, scale=0.05)
+    u0[0] += 0.3                                  # the env's inflow speed (airfoil_env_base.py) + a perturbation
+    st = [(u0, p0)]
     _load(dom, st)
     dom.piso_step([1e-3], advection_tol=1e-7, pressure_tol=1e-7, pressure_use_bicgstab=2, pressure_project_mean=False,
                   max_iterations=3000)
