@@ -470,7 +470,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_init(FgGrid g, BicgPtrs q, B
 
 // k_bicgf_a(it): finish iteration it - 1 (x, r, p) and start iteration it (v = C p, rw.v, r.r)      (grid.y = 1)
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_bicgf_a(FgGrid g, BicgPtrs q, BicgFused w, int it, int tiles_x, int tiles_y,
+__global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS == 2 ? 4 : 3))) void k_bicgf_a(FgGrid g, BicgPtrs q, BicgFused w, int it, int tiles_x, int tiles_y,
                                                        int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     const size_t N = g.n;
@@ -527,7 +527,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_a(FgGrid g, BicgPtrs q, Bicg
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
-    __shared__ float lds[8];
+    // dot-product partials of all components, reduced across the workgroup ONCE after the loop (a reduction per component put a
+    // barrier between the components and kept the loads of one from overlapping the arithmetic of the other)
+    __shared__ float lds[24];
+    float part[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [comp][rw.v | r.r]
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
         if (comp >= q.nc || mode[comp] == 0) continue;
@@ -543,7 +546,6 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_a(FgGrid g, BicgPtrs q, Bicg
             }
             continue;
         }
-        float part[2] = {0.f, 0.f};
         if (c.valid) {
             FgNbr<DIMS, VEC> P;   // p of iteration `it` at the cell and its neighbours
             FgVec<VEC> rwv = fg_load<VEC>(q.rw + vb + c.idx);
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_a(FgGrid g, BicgPtrs q, Bicg
                 }
                 fg_store<VEC>(q.r + vb + c.idx, R.c);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) part[1] += R.c.v[k] * R.c.v[k];
+                for (int k = 0; k < VEC; ++k) part[2 * comp + 1] += R.c.v[k] * R.c.v[k];
                 if (restart[comp]) {
                     P = R;
                     rwv = R.c;
@@ -581,15 +583,18 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_a(FgGrid g, BicgPtrs q, Bicg
             const FgVec<VEC> y = fg_apply_nbr<DIMS, VEC>(m, P);
             fg_store<VEC>(w.v[e] + vb + c.idx, y);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) part[0] += rwv.v[k] * y.v[k];
+            for (int k = 0; k < VEC; ++k) part[2 * comp] += rwv.v[k] * y.v[k];
         }
-        fg_block_sum<2>(part, lds);
-        if (threadIdx.x == 0) {
-            FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-            acc_add(a + (F_RV + e), (double)part[0]);
-            if (mode[comp] == 1) acc_add(a + (F_RR + e), (double)part[1]);
+    }
+    fg_block_sum<6>(part, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {
+            if (comp >= q.nc || (mode[comp] != 1 && mode[comp] != 3)) continue;
+            FgDacc* a = q.acc + (size_t)(c.b * q.nc + comp) * FG_ACC_DOUBLES;
+            acc_add(a + (F_RV + e), (double)part[2 * comp]);
+            if (mode[comp] == 1) acc_add(a + (F_RR + e), (double)part[2 * comp + 1]);
         }
-        __syncthreads();
     }
 }
 
@@ -632,13 +637,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
-    __shared__ float lds[20];
+    __shared__ float lds[60];
+    float part[15];   // [comp][s.s | t.s | t.t | rw.s | rw.t], one workgroup reduction after the loop
+#pragma unroll
+    for (int k = 0; k < 15; ++k) part[k] = 0.f;
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
         if (comp >= q.nc || !work[comp]) continue;
         const int sys = c.b * q.nc + comp;
         const size_t vb = (size_t)sys * N;
-        float part[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         if (c.valid) {
             FgNbr<DIMS, VEC> S = fg_gather<DIMS, VEC>(q.r + vb, c);
             {
@@ -651,23 +658,26 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
             fg_store<VEC>(q.t + vb + c.idx, t);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                part[0] += S.c.v[k] * S.c.v[k];
-                part[1] += t.v[k] * S.c.v[k];
-                part[2] += t.v[k] * t.v[k];
-                part[3] += rwv.v[k] * S.c.v[k];
-                part[4] += rwv.v[k] * t.v[k];
+                part[5 * comp + 0] += S.c.v[k] * S.c.v[k];
+                part[5 * comp + 1] += t.v[k] * S.c.v[k];
+                part[5 * comp + 2] += t.v[k] * t.v[k];
+                part[5 * comp + 3] += rwv.v[k] * S.c.v[k];
+                part[5 * comp + 4] += rwv.v[k] * t.v[k];
             }
         }
-        fg_block_sum<5>(part, lds);
-        if (threadIdx.x == 0) {
-            FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-            acc_add(a + (F_SS + e), (double)part[0]);
-            acc_add(a + (F_TS + e), (double)part[1]);
-            acc_add(a + (F_TT + e), (double)part[2]);
-            acc_add(a + (F_RS + e), (double)part[3]);
-            acc_add(a + (F_RT + e), (double)part[4]);
+    }
+    fg_block_sum<15>(part, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {
+            if (comp >= q.nc || !work[comp]) continue;
+            FgDacc* a = q.acc + (size_t)(c.b * q.nc + comp) * FG_ACC_DOUBLES;
+            acc_add(a + (F_SS + e), (double)part[5 * comp + 0]);
+            acc_add(a + (F_TS + e), (double)part[5 * comp + 1]);
+            acc_add(a + (F_TT + e), (double)part[5 * comp + 2]);
+            acc_add(a + (F_RS + e), (double)part[5 * comp + 3]);
+            acc_add(a + (F_RT + e), (double)part[5 * comp + 4]);
         }
-        __syncthreads();
     }
 }
 
@@ -775,7 +785,9 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     // so over-launching costs ~2 us per kernel while every poll costs a stream sync), then every 2 iterations
     int next_poll = s->pred_bicg > 1 ? s->pred_bicg : 1;
     const double cells = (double)n, mat = 4.0 * (1 + 2 * s->grid.dims) / a.nc, fl = 2.0 * (1 + 2 * s->grid.dims);
-    if (s->bicg_fused && !a.precond) {
+    // (3-D: the neighbour recomputation of four fields across six faces costs more than the two saved passes -- measured on TCF
+    //  128 x 64 x 64: 299 us per iteration against 260 us -- so the five kernels stay there)
+    if (s->bicg_fused && !a.precond && (s->grid.dims == 2 || s->bicg_fused >= 2)) {
         // two-kernel iteration (k_bicgf_a / k_bicgf_b above): per system and cell, a reads x, p, s, t, v, rw + the matrix and writes
         // x, r, p, v (40 + mat B); b reads r, v, rw + the matrix and writes s, t (20 + mat B)
         BicgFused w;

@@ -143,8 +143,10 @@ def test_airfoil_mesh_step_matches_the_oracle():
     u0[0] += 0.3                                  # the env's inflow speed (airfoil_env_base.py) + a perturbation
     st = [(u0, p0)]
     _load(dom, st)
-    dom.piso_step([1e-3], advection_tol=1e-7, pressure_tol=1e-7, pressure_use_bicgstab=2, pressure_project_mean=False,
-                  max_iterations=3000)
+    its = dom.piso_step([1e-3], advection_tol=1e-7, pressure_tol=1e-7, pressure_use_bicgstab=2, pressure_project_mean=False,
+                        max_iterations=3000, raise_on_failure=False)
+    print("airfoil mesh step: iterations", its, "env status", dom.env_status())
+    assert (dom.env_status() <= 1).all()           # (1: a solve ended on its best iterate above 1e-7; 2 would be non-finite)
     u_ref, p_ref = d.piso_step(st[0][0], st[0][1], 1e-3)
     assert _rel(dom.velocity[0].cpu().numpy(), u_ref) < 2e-4
     assert _rel(dom.pressure[0].cpu().numpy(), p_ref) < 2e-3

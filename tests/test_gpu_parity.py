@@ -416,15 +416,15 @@ def test_live_profiler_samples_solver_kernels():
         ns.piso_step([0.05, 0.04, 0.03])
     prof = ns.profile_read()
     ns.profile_enable(False)
-    assert set(prof) >= {"k_cg_ap", "k_cg_update", "k_bicg_v", "k_bicg_t", "k_bicg_x"}
+    assert set(prof) >= {"k_cg_ap", "k_cg_update", "k_bicg_v", "k_bicg_t", "k_bicg_x", "k_bicgf_a", "k_bicgf_b"}
     n = int(np.prod(case.shape))
-    for name in ("k_bicg_v", "k_bicg_x"):
+    for name in ("k_bicgf_a", "k_bicgf_b"):      # (2-D: the two-kernel BiCGStab iteration is the default)
         r = prof[name]
         assert r["launches"] >= r["samples"] > 0
         assert 0.0 < r["ms"] / r["samples"] < 5.0
         # never more than the full batch of systems per launch
         per_launch = r["bytes"] / r["samples"]
-        assert 0 < per_launch <= 3 * 2 * n * 28.0 + 1
+        assert 0 < per_launch <= 3 * 2 * n * 60.0 + 1
     ns.close()
 
 
