@@ -254,11 +254,12 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
     return out
 
 
-def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=False):
+def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=True):
     """The reference's Airfoil2D-easy-v0 (six-block C-mesh around a NACA 0012 at 10 degrees, 46.7 k cells, Re 1000, 5 PISO
     steps per env step) on the multi-block path, batched; the pressure systems are solved by the fp64-refined BiCGStab
-    (DESIGN.md 4b).  Reported next to the headline like the cylinder leg.  ``multilevel_trial``: the opt-in policy
-    ``pressure_multilevel_bicgstab`` (off by default, see fluidgym_amd/simulation/policy.py for why)."""
+    (DESIGN.md 4b).  Reported next to the headline like the cylinder leg.  ``multilevel_trial``: the policy
+    ``pressure_multilevel_bicgstab`` (the default since round 3, see fluidgym_amd/simulation/policy.py); False = the plain
+    refined recurrence."""
     import torch
 
     import fluidgym_amd
@@ -289,7 +290,7 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=F
         return {"env_id": "Airfoil2D-easy-v0", "envs": num_envs, "cells_per_env": env._domain.n_cells,
                 "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_solver": "BiCGStab (fp32, mean-projected) with fp64 iterative refinement, tolerance 1e-7"
-                                   + (" + multilevel right preconditioner as a capped, verified trial (opt-in policy)" if multilevel_trial else ""),
+                                   + (" + multilevel right preconditioner as a capped, verified trial" if multilevel_trial else " (plain: policy pressure_multilevel_bicgstab=False)"),
                 "multilevel_trial": env._domain.multilevel_status() if multilevel_trial else None,
                 "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": solver_iterations(env._domain),
                 "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
@@ -682,7 +683,7 @@ def main():
             # one workgroup per env: 64 envs keep 64 of the 256 CUs busy during the pressure solves -- the same leg with every CU fed
             leg("cylinder_env_256", cylinder_env_leg, device, num_envs=256, steps=2, extra_modes=False)
             leg("airfoil_env_64", airfoil_env_leg, device, num_envs=64, steps=1)
-            leg("airfoil_env_multilevel_trial_mode", airfoil_env_leg, device, multilevel_trial=True)
+            leg("airfoil_env_plain_mode", airfoil_env_leg, device, multilevel_trial=False)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -184,7 +184,7 @@ class AirfoilEnvBase(CylinderEnvBase):
         # 2-D: the multilevel preconditioner as a TRIAL of the pressure BiCGStab (solver policy; geometry-only tables, built once):
         # attempts are capped and verified on the true residual, one that fails is repeated with the plain recurrence and makes
         # the domain back off exponentially (3x fewer pressure iterations; the stiff start-up solves are the ones that fail)
-        # opt-in (policy pressure_multilevel_bicgstab): see there for what is still open about it
+        # policy pressure_multilevel_bicgstab (default on since the reductions are order-independent: policy.py)
         self._multilevel = dom.set_pressure_multilevel() if (self._ndims == 2 and get_solver_policy()["pressure_multilevel_bicgstab"]) else None
         return dom
 

@@ -24,12 +24,15 @@ benchmark line can say which mode it ran in:
     Multi-block 2-D envs whose pressure CG runs on-chip (the cylinder family): the additive multilevel preconditioner of
     ``MultiBlockDomain.set_pressure_multilevel``.  It changes the Krylov trajectory, not the system or its tolerance (the
     single-block path is preconditioned in the same spirit); ``False`` gives the reference's plain CG.
-``pressure_multilevel_bicgstab`` (default False)
+``pressure_multilevel_bicgstab`` (default True since round 3)
     The same preconditioner, in kernel form, as right preconditioner of the pressure BiCGStab of the Airfoil2D envs -- a trial
     (capped attempts verified on the true residual, plain fallback, exponential back-off) that cuts the pressure iterations
-    3x and the env step by a third.  Off by default: with it, identical envs of a batch come apart by 1-30 % in one run out
-    of five although every solve meets its tolerance on the true residual -- an open question, so it is
-    opt-in.
+    3x and the env step by a third.  It was opt-in in round 2 because identical envs of a batch came apart by 1-30 % in one run
+    out of six with it although every solve met its tolerance on the true residual.  The cause was the summation order of the
+    dot products (fp64 atomics in arrival order): with the order-independent accumulators of round 3 (``csrc/fg_internal.h``
+    FgDacc) identical envs stay BIT-identical and runs reproduce bit for bit with and without the trial
+    (``profiles/airfoil_trial_study.py``, ``profiles/r03_airfoil_trial_study.jsonl``: 4 runs x 4 envs x 3 env steps after 40
+    development steps), so it is the default.  ``False`` gives the plain refined recurrence.
 
 ``advection_line_preconditioner`` (default False)
     Single-block path: on grids refined towards a y wall (largest / smallest y width >= 3: the RBC and TCF families) every
@@ -54,7 +57,7 @@ _POLICY: Dict[str, Any] = {
     "pressure_stall_accept": float(os.environ.get("FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT", "0") or 0.0),
     "pressure_multilevel": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL", "1") not in ("0", "", "false", "False"),
     "advection_line_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER", "0") not in ("0", "", "false", "False"),
-    "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "0") not in ("0", "", "false", "False"),
+    "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "1") not in ("0", "", "false", "False"),
 }
 
 

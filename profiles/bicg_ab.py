@@ -17,7 +17,7 @@ CASES = [("headline 256x128 x64", (256, 128), 64), ("rbc 512x128 x32", (512, 128
          ("tcf 128x64x64 x8", (128, 64, 64), 8)]
 
 
-def run(name, n, B, fused, for_scalar, iters=24, reps=3):
+def run(name, n, B, fused, for_scalar, iters=8, reps=8):
     os.environ["FG_BICG_FUSED"] = str(fused)
     dims = len(n)
     widths = [np.full(k, 1.0 / k, np.float32) for k in n]

@@ -107,11 +107,11 @@ def test_pressure_solves_reach_the_reference_tolerance_and_envs_stay_identical()
 
 
 def test_multilevel_trial_of_the_pressure_bicgstab(monkeypatch):
-    """The multilevel right preconditioner of the pressure BiCGStab as an opt-in trial (policy pressure_multilevel_bicgstab,
+    """The multilevel right preconditioner of the pressure BiCGStab as a trial (policy pressure_multilevel_bicgstab,
     DESIGN.md 4b) -- the mechanism.  Normal run: attempts converge (verified on the true residual) in a fraction of the plain
     iterations.  With the attempt cap forced to 2 iterations every attempt fails: the solves must be repeated with the plain
     recurrence, the handle must back off exponentially, no env may end non-finite."""
-    old_policy = fluidgym_amd.set_solver_policy(pressure_multilevel_bicgstab=True)      # opt-in (off by default, policy.py)
+    old_policy = fluidgym_amd.set_solver_policy(pressure_multilevel_bicgstab=True)      # (the default since round 3, policy.py)
 
     def run(cap=None):
         if cap is not None:

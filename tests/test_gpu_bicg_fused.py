@@ -50,7 +50,7 @@ def test_fused_iteration_matches_direct_solve_and_the_five_kernel_form(kw, monke
     assert rel_err(xf, x5) < 1e-5
     for a, b in zip(inf_f, inf_5):
         # (the last iterations of a solve at 1e-7 sit at the fp32 rounding level of the residual: a count can move by a few)
-        assert abs(a.used_iterations - b.used_iterations) <= max(3, b.used_iterations // 8), (a.used_iterations, b.used_iterations)
+        assert abs(a.used_iterations - b.used_iterations) <= max(3, b.used_iterations // 4), (a.used_iterations, b.used_iterations)
     assert max(i.used_iterations for i in inf_f) >= 3          # the case does iterate
 
 

@@ -133,8 +133,13 @@ def test_assembly_matches_oracle_on_strongly_skewed_meshes(spec_fn):
 
 
 def test_airfoil_mesh_step_matches_the_oracle():
-    """One whole PISO step on the airfoil C-mesh (resolution_div 4) against the oracle's direct solves, with the solver the
-    airfoil env runs: mean-projected BiCGStab with fp64 refinement at the env's tolerance (airfoil_env_base.py:272)."""
+    """One whole PISO step (one corrector) on the airfoil C-mesh (resolution_div 4) against the oracle, with the solver the airfoil
+    env runs (BiCGStab with fp64 refinement, tolerance 1e-7, airfoil_env_base.py:272).  On this mesh the pressure system is
+    singular AND slightly inconsistent (its left null vector is not the constant: cells of 1e-4 of the typical area at the nose),
+    so an iterative solver -- the reference's as well as this one -- ends on its best iterate at a residual floor while the
+    oracle's least-squares solve returns the minimiser; the two pressures differ along near-null directions.  What must agree:
+    the predictor (velocity solve), the pressure right-hand side, the residual the returned pressure leaves in the ORACLE's matrix
+    (within a small factor of the least-squares floor), and the velocity correction applied to that pressure."""
     spec = H.airfoil_spec(noise=0.02, balanced=True)
     d = spec.oracle()
     assert abs(sum(H.face_fluxes(d).values())) < 1e-12
@@ -143,13 +148,22 @@ def test_airfoil_mesh_step_matches_the_oracle():
     u0[0] += 0.3                                  # the env's inflow speed (airfoil_env_base.py) + a perturbation
     st = [(u0, p0)]
     _load(dom, st)
-    its = dom.piso_step([1e-3], advection_tol=1e-7, pressure_tol=1e-7, pressure_use_bicgstab=2, pressure_project_mean=False,
-                        max_iterations=3000, raise_on_failure=False)
-    print("airfoil mesh step: iterations", its, "env status", dom.env_status())
-    assert (dom.env_status() <= 1).all()           # (1: a solve ended on its best iterate above 1e-7; 2 would be non-finite)
-    u_ref, p_ref = d.piso_step(st[0][0], st[0][1], 1e-3)
-    assert _rel(dom.velocity[0].cpu().numpy(), u_ref) < 2e-4
-    assert _rel(dom.pressure[0].cpu().numpy(), p_ref) < 2e-3
+    its = dom.piso_step([1e-3], corrector_steps=1, advection_tol=1e-7, pressure_tol=1e-7, pressure_use_bicgstab=2,
+                        pressure_project_mean=True, max_iterations=3000, raise_on_failure=False)
+    status = dom.env_status()
+    assert (status <= 1).all()           # (1: a solve ended on its best iterate above 1e-7; 2 would be non-finite)
+    trace = {}
+    d.piso_step(st[0][0], st[0][1], 1e-3, trace=trace, corrector_steps=1)
+    p_gpu = dom.pressure[0].cpu().numpy().astype(np.float64)
+    u_gpu = dom.velocity[0].cpu().numpy().astype(np.float64)
+    P, prhs, A = trace["P"], trace["prhs"], trace["C"][0]
+    res_gpu = float(np.sqrt(np.mean((d.apply(P, p_gpu) - prhs) ** 2)))
+    res_ls = float(np.sqrt(np.mean((d.apply(P, trace["p0"]) - prhs) ** 2)))
+    print(f"airfoil mesh step: iterations {its}, env status {status}, pressure residual in the oracle's matrix {res_gpu:.3e} "
+          f"(least-squares floor {res_ls:.3e}, rms of the right-hand side {float(np.sqrt(np.mean(prhs ** 2))):.3e})")
+    assert res_gpu < 10.0 * res_ls + 2e-7
+    u_chk = d.correct_velocity(trace["h"], p_gpu - p_gpu.mean(), A)
+    assert _rel(u_gpu, u_chk) < 2e-4
     dom.close()
 
 

@@ -55,11 +55,10 @@ def test_tcf_pressure_system_needs_real_iterations_and_fdcg_solves_it_in_one_or_
               f"native FD-preconditioned CG {it_fd}")
         assert it_ref >= 3 and abs(it_cg - it_ref) <= max(3, it_ref // 10)
         assert 1 <= it_fd <= max(2, it_ref // 3)
-        scale = np.abs(x_ref).max()
-        x_ref = x_ref.reshape(g.shape)
-        # solutions of a singular system stopped at an ABSOLUTE residual of 1e-6 from a right-hand side of 7e-6: they agree to what
-        # that tolerance leaves (compare up to the constant)
-        for p in (p_fd, p_cg):
-            assert np.abs((p - p.mean()) - (x_ref - x_ref.mean())).max() < 0.25 * scale
+        # all three stop at an ABSOLUTE rms residual of 1e-6 from a right-hand side of 7e-6, so the pressures themselves agree only
+        # to what that tolerance leaves (tens of per cent); what is checked is that each of them solves the ORACLE's system to it
+        for name, p in (("oracle", x_ref.reshape(g.shape)), ("fdcg", p_fd), ("cg", p_cg)):
+            res = float(np.sqrt(np.mean((P @ p.ravel() - b.ravel()) ** 2)))
+            assert res < 1.5 * tol, (name, res)
     finally:
         env.close()
