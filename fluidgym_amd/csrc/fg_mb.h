@@ -119,8 +119,9 @@ struct fg_mb_state {
     // of the four-cell BiCGStab kernels: 1 p, 2 v, 4 s, 8 t, 16 x; default all), FG_MB_SCALAR_CG=1 (one-cell
     // CG kernels), FG_MB_GRAPH (CG chunks replayed as a hipGraph), FG_MB_TRACE (residual trace on stderr)
     int dbg_vec_mask = 0, dbg_scalar_cg = 0, dbg_graph = 0, dbg_trace = 0, dbg_fail = 0;   // dbg_fail: FG_MB_TRACE_FAIL
-    // iterations the last BiCGStab solve of the same place in the step took -- [0..3] velocity non-orthogonal pass, [4 + 8 c + ps]
-    // pressure solve ps of corrector c, [31] anything else: where the next solve of that place polls first
+    // iterations the last BiCGStab solve of the same place in the step took -- [0..3] velocity non-orthogonal pass,
+    // [4 + 4 (c & 1) + (ps & 3)] pressure solve ps of corrector c (+ 16 for its multilevel-preconditioned attempt), [31] anything
+    // else: where the next solve of that place polls first
     int pred_bicg[32] = {0};
     int dbg_ml_cap = 200;   // FG_MB_ML_TRY_CAP: iteration cap of a multilevel-preconditioned pressure BiCGStab attempt (tests: a tiny cap makes every attempt fail)
     int dbg_fuse_st = 2;   // FG_MB_BICG_FUSE: 0 five BiCGStab kernels, 1 s / t fused (k_mbb_st), 2 also p / v (k_mbb_pv; default)
@@ -135,6 +136,7 @@ struct fg_mb_state {
     int adv_from_result = 0;   // fg_mb_set_advection_start
     bool yproj_const = true;   // yproj is the constant 1/sqrt(N): kernels use the scalar instead of loading it
     float* red;        // [B] reductions (max)
+    float* pres_bak;   // [B][N] pressure at the start of a step (restored for envs whose step is dropped)
     float* red8;       // [B][MB_SUM_WGS] per-workgroup partials of the pressure mean (summed in index order)
     float* red_pinned = nullptr;
     float *red2, *dt_dev;          // [2B] boundary flux sums, [B] time steps of the running substep

@@ -1941,6 +1941,10 @@ __global__ void k_mb_fill(size_t n, float v, float* __restrict__ x) {
 
 // envs with a non-finite system leave the step: dt = 0 masks them out of every later kernel of the call (incl. the final
 // copy of the velocity result), so their state stays what it was before the step; status 2 is recorded
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_restore_failed(int N, const int32_t* __restrict__ fail, const float* __restrict__ src, float* __restrict__ dst) {
+    const int b = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (i < N && fail[b] == 2) dst[(size_t)b * N + i] = src[(size_t)b * N + i];
+}
 __global__ void k_mb_mask_failed(int B, int nc, const fg_solve_info* __restrict__ info, float* __restrict__ dt, int32_t* __restrict__ fail) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B || !(dt[b] > 0.f)) return;
@@ -2612,6 +2616,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->info_dev, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->red, B)) return rc;
     if (int rc = mb_alloc(s, &s->red8, B * MB_SUM_WGS)) return rc;
+    if (int rc = mb_alloc(s, &s->pres_bak, B * N)) return rc;
     if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->yproj, N)) return rc;
     {
@@ -2707,6 +2712,9 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
     auto mask_failed = [&](int nc) {
         hipLaunchKernelGGL(k_mb_mask_failed, dim3((B + 63) / 64), dim3(64), 0, st, B, nc, (const fg_solve_info*)s->info_dev, s->dt_step, s->env_fail);
     };
+    // pressure of the envs at the start of the step: a dropped env gets it back at the end (its velocity is never committed; its
+    // pressure is written by every corrector's mean removal, so a failure in corrector 1 would leave corrector 0's behind)
+    hipLaunchKernelGGL(k_mb_copy, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, (size_t)N, (const float*)nullptr, (const float*)s->pressure, s->pres_bak);
     const size_t vel_env = (size_t)d * N;
     const dim3 gcopy((unsigned)((vel_env + FG_BLOCK - 1) / FG_BLOCK), B);
     MB_DISPATCH(s, {
@@ -2802,7 +2810,8 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
     if (stats_host) for (int k = 0; k < 4; ++k) stats_host[k] = its[k];
     s->ctr.piso_steps += 1;
     for (int b = 0; b < B; ++b) s->env_status[b] = 0;
-    if (soft_rc == FG_ERR_NOT_FINITE) {   // rare path: which envs were dropped
+    if (soft_rc == FG_ERR_NOT_FINITE) {   // rare path: which envs were dropped; their pressure goes back to what it was
+        hipLaunchKernelGGL(k_mb_restore_failed, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, N, (const int32_t*)s->env_fail, (const float*)s->pres_bak, s->pressure);
         FG_HIP_CHECK(hipMemcpyAsync(s->env_fail_pinned, s->env_fail, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
         FG_HIP_CHECK(hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) s->env_status[b] = s->env_fail_pinned[b];

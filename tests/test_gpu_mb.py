@@ -298,6 +298,7 @@ def test_non_finite_solve_drops_only_that_env_and_leaves_its_state_intact():
     src[1, 0, d.N // 2] = float("nan")
     dom.set_velocity_source(src)
     before = dom.velocity[1].cpu().numpy().copy()
+    p_before = dom.pressure[1].cpu().numpy().copy()
     sim = MultiBlockSimulation(dom, dt=0.05, substeps=2, pressure_tol=1e-6, advection_tol=1e-6)
     ok = sim.single_step()
     assert ok is False
@@ -305,6 +306,7 @@ def test_non_finite_solve_drops_only_that_env_and_leaves_its_state_intact():
     after = dom.velocity.cpu().numpy()
     assert np.isfinite(after).all()
     assert np.array_equal(after[1], before)              # not committed
+    assert np.array_equal(dom.pressure[1].cpu().numpy(), p_before)   # nor is its pressure (restored from the start-of-step copy)
     assert _rel(after[0], u_ref) < 1e-5                   # the healthy env is not disturbed by its neighbour in the batch
     dom.close()
 
