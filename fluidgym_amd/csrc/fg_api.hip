@@ -110,6 +110,7 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr;
+    { const char* ev = getenv("FG_CG_WGS_PER_SLOT"); s->cg_wgs_per_slot = (ev && atoi(ev) > 0) ? atoi(ev) : 256; }
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
     s->cg_return_best = 1;
     s->adv_from_result = 1;

@@ -494,6 +494,7 @@ struct fg_state {
     // reference's first rung), 1 every solve (its preconditionBiCG), 2 only to repeat a solve that failed (its
     // BiCG_precondition_fallback); line_retries counts the repeats.  Factors [B][N], allocated on first use
     int adv_precond; long long line_retries;
+    int cg_wgs_per_slot;          // workgroups sharing one CG accumulator slot (256; FG_CG_WGS_PER_SLOT at fg_create: tuning)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
     float* line_inv; float* line_cp;
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)

@@ -420,7 +420,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     int zc = 0;
     const bool zmarch = fg_zmarch_ok(s, &zc);
     int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
-    while (ns < FG_CG_SLOTS && tiles_per_env / ns > 256) ns *= 2;
+    while (ns < FG_CG_SLOTS && tiles_per_env / ns > s->cg_wgs_per_slot) ns *= 2;
     hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, s->cg_best, s->cg_return_best, B, ns);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);

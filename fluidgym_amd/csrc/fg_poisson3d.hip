@@ -22,7 +22,8 @@ namespace {
 // form needed a 64-bit VGPR pair + v_lshl_add_u64 per distinct address (48 of them in the ISA) and pushed the
 // kernel to 160+ VGPRs.
 #ifndef Z_STORE_AUX
-#define Z_STORE_AUX 0  // 2 = nt stores: +8 % on the one-shot apply but -12 % on Jacobi ping-pong (measured at 256^3)
+#define Z_STORE_AUX 0  // 2 = nt stores: round 2 measured +8 % on the one-shot apply and -12 % on the Jacobi ping-pong at 256^3; round 3 (nt for
+                       // the apply mode only): 0.550 against 0.554-0.578 with plain stores, i.e. nothing -- left off
 #endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 using rsrc_t = __amdgpu_buffer_rsrc_t;
@@ -38,10 +39,11 @@ __device__ __forceinline__ FgVec<4> z_bload4(rsrc_t r, unsigned voff, unsigned s
 __device__ __forceinline__ float z_bload1(rsrc_t r, unsigned voff, unsigned soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+template <int AUX = Z_STORE_AUX>
 __device__ __forceinline__ void z_bstore4(rsrc_t r, unsigned voff, unsigned soff, const FgVec<4>& v) {
     u32x4_t u;
     u.x = __float_as_uint(v.v[0]); u.y = __float_as_uint(v.v[1]); u.z = __float_as_uint(v.v[2]); u.w = __float_as_uint(v.v[3]);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, Z_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, AUX);
 }
 
 // Tile shape: BXL lanes (x float4) along x, 256 / BXL rows along y.  64 x 16, 128 x 8 or 256 x 4 cells: wider
