@@ -99,6 +99,9 @@ KERNEL_DOC = {
     "k_bicg_s": "BiCGStab s = r - alpha v + s.s",
     "k_bicg_t": "BiCGStab t = C s + t.s + t.t",
     "k_bicg_x": "BiCGStab x/r update + r.r + rw.r",
+    "k_bicgf_a": "BiCGStab two-kernel form, first half: x, r, p updates + v = C p (p at the neighbours recomputed) + rw.v, r.r",
+    "k_bicgf_b": "BiCGStab two-kernel form, second half: s = r - alpha v, t = C s (s at the neighbours recomputed) + five dot products",
+    "k_line_y": "y-line (tridiagonal) right preconditioner of the advection BiCGStab: z = M^-1 r per column block in LDS",
     "k_gemm_f32": "fast-diagonalisation preconditioner: eigenbasis transform along x/z (fp32 MFMA 32x32x2)",
     "k_gemm_sk": "fast-diagonalisation preconditioner: eigenbasis transform, split-K 32x32 tiles (few live envs)",
     "k_dct_rows": "fast-diagonalisation preconditioner: cosine transform of every grid row (one FFT per row in LDS)",
@@ -110,10 +113,10 @@ KERNEL_DOC = {
 
 def pmc_traffic(kernel):
     """Memory-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r02_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
+    (profiles/r03_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
     fetch counter as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so this
     is the last profiled run, not this run; None when the file has no row for the kernel."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -126,7 +129,7 @@ def pmc_traffic(kernel):
     if isinstance(row, list):
         row = row[0]
     return {"fetch_bytes_per_launch": row["fetch_bytes"], "write_bytes_per_launch": row["write_bytes"],
-            "launches_averaged": row["launches"], "unit": "B", "source": "profiles/r02_traffic.json (rocprofv3 --pmc, "
+            "launches_averaged": row["launches"], "unit": "B", "source": "profiles/r03_traffic.json (rocprofv3 --pmc, "
             "separate FETCH_SIZE and WRITE_SIZE passes of bench.py; averages include launches that found every "
             "system converged; Infinity-Cache hits are counted)"}
 
@@ -226,7 +229,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
                                   "GBps": r["bytes"] / r["ms"] / 1e6, "frac_of_hbm_peak": r["bytes"] / r["ms"] / 1e6 / HBM_PEAK_GBS}
             return {"ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                     "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "pressure_stall_accept": env._sim.pressure_stall_accept,
-                    "solver_iterations": its, "mean_substeps_per_sim_step": round(its["piso_steps"] / max(n_steps * env.n_sim_steps, 1), 2),
+                    "solver_iterations": its, "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(n_steps * env.n_sim_steps, 1), 2),
                     "drag_coefficient_env0": float(info["drag"][0]), "kernels": rows, "cells_per_env": dom.n_cells,
                     "piso_steps_per_env_step": env.n_sim_steps}
         finally:
@@ -287,12 +290,14 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=T
             _, _, _, _, info = env.step(act())
         torch.cuda.synchronize(device)
         el = (time.perf_counter() - t0) / steps
+        its_leg = solver_iterations(env._domain)
         return {"env_id": "Airfoil2D-easy-v0", "envs": num_envs, "cells_per_env": env._domain.n_cells,
                 "piso_steps_per_env_step": env.n_sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_solver": "BiCGStab (fp32, mean-projected) with fp64 iterative refinement, tolerance 1e-7"
                                    + (" + multilevel right preconditioner as a capped, verified trial" if multilevel_trial else " (plain: policy pressure_multilevel_bicgstab=False)"),
                 "multilevel_trial": env._domain.multilevel_status() if multilevel_trial else None,
-                "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": solver_iterations(env._domain),
+                "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": its_leg,
+                "capped_solves": capped_solves(its_leg), "solves": int(sum(v["systems"] for v in its_leg.values() if isinstance(v, dict))),
                 "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
                 "drag_lift_env0": [float(info["drag"][0]), float(info["lift"][0])],
                 "note": f"state {develop} uncontrolled sim steps after an impulsive start; uniform random jets in [-1, 1]"}
@@ -308,10 +313,16 @@ def launches_per_piso_step(prof, its):
 
 def solver_iterations(solver) -> dict:
     c = solver.solver_counters()
-    out = {k: {"mean": (round(v["mean"], 2) if v["mean"] is not None else None), "max": v["max"]}
+    out = {k: {"mean": (round(v["mean"], 2) if v["mean"] is not None else None), "max": v["max"], "unconverged": v.get("unconverged", 0),
+               "systems": v["systems"]}
            for k, v in c.items() if isinstance(v, dict) and v["systems"]}
     out["piso_steps"] = c["piso_steps"]
     return out
+
+
+def capped_solves(its) -> int:
+    """Systems whose solve ended on its best iterate above the tolerance (iteration cap) during the timed region."""
+    return int(sum(v.get("unconverged", 0) for v in its.values() if isinstance(v, dict)))
 
 
 def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing=0.0, **env_kw):
@@ -355,7 +366,7 @@ def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing
         return {"env_id": env_id, "envs": num_envs, "grid": [solver.nx, solver.ny, solver.nz], "doc": doc,
                 "piso_steps_per_env_step": sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": its,
-                "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
+                "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
                 "policy": "uniform samples of the action space",
                 "dominant_kernel": None if roof is None else {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
                 "kernels": None if roof is None else {k: {kk: v[kk] for kk in ("avg_busy_launch_ms", "launches", "est_total_ms", "GBps", "TFLOPps")}
@@ -453,7 +464,8 @@ def compact_line(out, detail_path=DETAIL_PATH):
                       "iters_per_solve[mean,max]": _iters(cfg.get("solver_iterations")),
                       "iters_are": cfg.get("iters_are"),
                       "substeps_per_sim_step": cfg.get("mean_substeps_per_sim_step"),
-                      "launches_per_piso_step": _r(cfg.get("launches_per_piso_step"))}
+                      "capped_solves": cfg.get("capped_solves"),
+                      "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step"))}
     roof = out.get("roofline")
     if roof:
         tr = roof.get("traffic")
@@ -635,7 +647,7 @@ def main():
                        "parallelism": f"env-sharded x{world}, 1 bcast + 1 all_gather per step (RCCL)",
                        "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start),
                        "pressure_solver": "CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)",
-                       "solver_iterations": its,
+                       "solver_iterations": its, "capped_solves": capped_solves(its),
                        "iters_are": "iterations per solve (counts; 0 = initial residual met the tolerance)",
                        "launches_per_piso_step": launches_per_piso_step(prof, its),
                        "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2)},

@@ -211,6 +211,8 @@ SIGNATURES = {
     "fg_mb_ladder": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_debug_cycles": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
     "fg_mb_solver_hints": (c_int, [c_void_p, POINTER(c_int32), c_int32]),
+    "fg_mb_solver_unconverged": (c_int, [c_void_p, POINTER(c_int64)]),
+    "fg_solver_unconverged": (c_int, [c_void_p, POINTER(c_int64)]),
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_set_advection_preconditioner": (c_int, [c_void_p, c_int]),
     "fg_advection_retries": (c_int, [c_void_p, POINTER(c_int64), c_int32]),

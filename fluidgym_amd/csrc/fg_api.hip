@@ -480,6 +480,12 @@ extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_option
     return status;
 }
 
+extern "C" int fg_solver_unconverged(fg_handle s, int64_t* out4) {
+    FG_REQUIRE(s != nullptr && out4 != nullptr, FG_ERR_INVALID_ARG, "fg_solver_unconverged: bad argument");
+    for (int k = 0; k < 4; ++k) out4[k] = s->ctr.unconv[k];
+    return FG_OK;
+}
+
 extern "C" int fg_solver_counters(fg_handle s, int64_t* out13, int32_t reset) {
     FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_solver_counters: null handle");
     if (out13) s->ctr.write(out13);

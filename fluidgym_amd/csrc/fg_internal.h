@@ -435,6 +435,7 @@ __device__ __forceinline__ void fg_best_decide(const FgBest& best, int b, float 
 // sum / n = mean iterations per SYSTEM (env x component) that took part in a solve; piso_steps counts fg_piso_step calls.
 struct FgCounters {
     long long sum[4] = {0, 0, 0, 0}, n[4] = {0, 0, 0, 0}, piso_steps = 0;
+    long long unconv[4] = {0, 0, 0, 0};   // systems whose solve ended without meeting its tolerance (iteration cap / best iterate kept)
     int max[4] = {0, 0, 0, 0};
     void add(int kind, const fg_solve_info* info, int count) {
         for (int i = 0; i < count; ++i) {
@@ -442,6 +443,7 @@ struct FgCounters {
             if (it < 0 && info[i].final_residual == 0.f) continue;   // masked-out env (dt <= 0)
             const int v = it + 1;   // used_iterations is the 0-based index of the last iteration (-1: none was needed): a COUNT here
             sum[kind] += v; n[kind] += 1; max[kind] = v > max[kind] ? v : max[kind];
+            if (!info[i].converged) unconv[kind] += 1;
         }
     }
     void reset() { *this = FgCounters(); }

@@ -324,10 +324,13 @@ class NativeSolver:
     def solver_counters(self, reset: bool = False) -> dict:
         """Iterations of the linear solves since the last reset: per kind (scalar, velocity, pressure corrector 0 / 1) the
         mean and max per system (env x component) and the number of PISO steps (``fg_solver_counters``)."""
+        unconv = (ctypes.c_int64 * 4)()
+        L.check(self.lib.fg_solver_unconverged(self.handle, unconv))      # (read before the counters are cleared)
         out = (ctypes.c_int64 * 13)()
         L.check(self.lib.fg_solver_counters(self.handle, out, int(reset)))
         names = ("scalar", "velocity", "pressure0", "pressure1")
-        res = {n: {"mean": (out[k] / out[4 + k]) if out[4 + k] else None, "max": int(out[8 + k]), "systems": int(out[4 + k])}
+        res = {n: {"mean": (out[k] / out[4 + k]) if out[4 + k] else None, "max": int(out[8 + k]), "systems": int(out[4 + k]),
+                    "unconverged": int(unconv[k])}
                for k, n in enumerate(names)}
         res["piso_steps"] = int(out[12])
         return res

@@ -210,6 +210,9 @@ int fg_piso_step(fg_handle h, const float* dt_B, const fg_step_options* opt, int
  * PISO steps, kinds = {passive scalar, velocity, pressure corrector 0, pressure corrector 1}; a system = env x component.
  * reset != 0 clears them after the read. */
 int fg_solver_counters(fg_handle h, int64_t* out13_host, int32_t reset);
+/* per kind, the systems whose solve ended WITHOUT meeting its tolerance since the last reset of the counters (iteration cap
+ * reached, best iterate returned: LinearSolverResultInfo.converged == false); cleared together with fg_solver_counters */
+int fg_solver_unconverged(fg_handle h, int64_t* out4_host);
 /* Simulation.single_step entirely on the native side (simulation.py:206-280 + _PISO_adaptive_step,
  * PISOtorch_simulation.py:2004-2064): flux-balance guard, per-env adaptive substeps
  * ts = t_rem / ceil(t_rem / (CFL / max_vel)) recomputed before every substep, the advective-outflow PRE
@@ -434,6 +437,7 @@ int fg_mb_debug_cycles(fg_mb_handle h, uint64_t* out12_host);
 int fg_mb_solver_hints(fg_mb_handle h, int32_t* hints36, int32_t set);
 /* as fg_solver_counters, for the multi-block path */
 int fg_mb_solver_counters(fg_mb_handle h, int64_t* out13_host, int32_t reset);
+int fg_mb_solver_unconverged(fg_mb_handle h, int64_t* out4_host);   /* as fg_solver_unconverged */
 /* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps
  * (_PISO_adaptive_step, PISOtorch_simulation.py:2004-2064), the advective-outflow PRE hook on ONE FIXED face given as
  * a range of boundary slots (update_advective_boundaries + balance_boundary_fluxes, :188-393; count 0 = none) and

@@ -1,0 +1,68 @@
+"""CPU stand-in for the device half of ``fluidgym_amd.simulation.multiblock.MultiBlockDomain`` -- TEST INFRASTRUCTURE ONLY.
+
+The mesh tables of the multi-block path are built on the host by the native library (a handle created with device < 0 serves
+them without a GPU), so the REAL cylinder env -- mesh, boundary slots, jets -> boundary data, action smoothing, sensor gathers,
+wall-stress forces, reward, the ``MultiBlockSimulation`` driver -- runs on the CPU once the solve itself is replaced.  That is
+what this module does, so that ``ParallelFluidEnv`` can shard a multi-block env over two gloo ranks (tests/test_parallel_env_gloo.py).
+The "physics" is a deterministic relaxation of every env's velocity towards its own boundary data; nothing in
+``fluidgym_amd/`` imports this module."""
+import ctypes
+
+import numpy as np
+import torch
+
+from fluidgym_amd import _lib as L
+
+
+CALLS = [0]   # single_step calls of every stubbed domain of this process
+
+
+def install():
+    """Patch MultiBlockDomain in place; returns a function that restores it."""
+    import fluidgym_amd.simulation.multiblock as M
+
+    D = M.MultiBlockDomain
+    saved = {k: getattr(D, k) for k in ("__init__", "_bind", "single_step", "make_divergence_free", "set_pressure_multilevel",
+                                          "set_advection_start", "env_status", "solver_hints", "solver_counters", "boundary_flux_balance")}
+
+    def __init__(self, dims, viscosity, batch=1, device=None, reference_quirks=True, non_ortho_flags=25):
+        self.lib = L.load()
+        self.dims, self.batch = int(dims), int(batch)
+        self.device = torch.device("cpu")
+        self.viscosity = float(viscosity)
+        self.handle = ctypes.c_void_p()
+        L.check(self.lib.fg_mb_create(self.dims, self.batch, -1, ctypes.byref(self.handle)))    # host-only: tables, no compute
+        self.non_ortho_flags = int(non_ortho_flags)
+        self.blocks = []
+        self.prepared = False
+        self.velocity = self.pressure = self.boundary_velocity = self.velocity_source = None
+        self.n_cells = self.n_boundary_faces = 0
+        self._dt = None
+        self.multilevel = None
+        self.calls = 0
+
+    def single_step(self, time_step, **kw):
+        self.calls += 1
+        CALLS[0] += 1
+        target = self.boundary_velocity.mean(dim=2, keepdim=True)            # [B, d, 1]: env-local, deterministic
+        self.velocity.mul_(0.9).add_(0.1 * target)
+        self.velocity[:, 0] += 0.01 * torch.sin(torch.arange(self.n_cells, dtype=torch.float32) * 0.01)[None]
+        self.pressure.copy_(self.velocity[:, 0] * self.velocity[:, 1])
+        return 1, True, (1, 1, 1)
+
+    D.__init__ = __init__
+    D._bind = lambda self: None
+    D.single_step = single_step
+    D.make_divergence_free = lambda self, **kw: True
+    D.set_pressure_multilevel = lambda self, enable=True: None
+    D.set_advection_start = lambda self, from_result=False: None
+    D.env_status = lambda self: np.zeros(self.batch, np.int32)
+    D.solver_hints = lambda self, values=None: torch.zeros(36, dtype=torch.int32)
+    D.solver_counters = lambda self, reset=False: {"piso_steps": self.calls}
+    D.boundary_flux_balance = lambda self: np.zeros(self.batch, np.float32)
+
+    def restore():
+        for k, v in saved.items():
+            setattr(D, k, v)
+
+    return restore

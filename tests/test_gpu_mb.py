@@ -103,6 +103,8 @@ def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     p_gpu = dom.pressure.cpu().numpy()
     refs = _assembly_parity(dom, d, states, dt, B, check_div=False)
     for b in range(B):
+        print(f"MB_STEP_ERR {spec_fn.__name__} bicg={bicg} ptol={ptol:g} project={project} env {b}: velocity {_rel(u_gpu[b], refs[b][0]):.2e} "
+              f"pressure {_rel(p_gpu[b], refs[b][1]):.2e}")
         assert _rel(u_gpu[b], refs[b][0]) < 2e-4, (spec_fn.__name__, b)
         assert _rel(p_gpu[b], refs[b][1]) < 2e-3, (spec_fn.__name__, b)
     mv = dom.max_velocity()

@@ -331,3 +331,82 @@ def test_real_env_with_stubbed_solver_sharded_over_two_ranks():
     finally:
         torch.cuda.is_available = real_avail
         D.NativeSolver = real_solver
+
+
+# ---- a REAL multi-block env (CylinderJet2D: five-block mesh, jets -> boundary slots, action smoothing, sensor gathers, wall-stress
+# forces, reward, the MultiBlockSimulation driver) with the device half of its domain stubbed (tests/stub_mb.py; the mesh tables
+# come from the native library's host-only handle), sharded over two gloo ranks and compared with one 4-env process
+_MB_KW = dict(cuda_device="cpu", randomize_initial_state=False, initial_domain_steps=2, episode_length=3)
+
+
+def _mb_patches():
+    from tests import stub_mb
+
+    torch.cuda.is_available = lambda: True   # FluidEnv.reset's "FluidGym requires CUDA" guard; nothing here touches a GPU
+    return stub_mb.install()
+
+
+def _mb_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _mb_patches()
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    penv = ParallelFluidEnv("CylinderJet2D-easy-v0", num_envs=4, backend="gloo", **_MB_KW)
+    if not penv.is_driver:
+        penv.serve()
+        from tests import stub_mb
+        q.put((rank, stub_mb.CALLS[0]))
+        return
+    obs0, infos0 = penv.reset(seed=3)
+    g = torch.Generator().manual_seed(0)
+    outs = []
+    for _ in range(2):
+        a = torch.rand(4, 1, generator=g) * 2 - 1
+        o, r, term, trunc, info = penv.step(a)
+        outs.append(({k: v.numpy().copy() for k, v in o.items()}, r.numpy().copy(), term, trunc,
+                     np.array([float(i["drag"]) for i in info]), np.array([float(i["lift"]) for i in info])))
+    penv.close()
+    q.put((rank, {k: v.numpy().copy() for k, v in obs0.items()}, outs, len(infos0)))
+
+
+def test_multi_block_env_with_stubbed_solve_sharded_over_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    drv = [r for r in results if r[0] == 0][0]
+    worker = [r for r in results if r[0] == 1][0]
+    assert worker[1] > 0 and drv[3] == 4            # the worker's shard stepped; one reset info per env
+    real_avail = torch.cuda.is_available
+    restore = _mb_patches()
+    try:
+        import fluidgym_amd
+
+        env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=4, **_MB_KW)
+        obs0, _ = env.reset(seed=3)
+        for k in obs0:
+            assert drv[1][k].shape == tuple(obs0[k].shape) and np.allclose(drv[1][k], obs0[k].numpy(), atol=1e-6)
+        g = torch.Generator().manual_seed(0)
+        for step in range(2):
+            a = torch.rand(4, 1, generator=g) * 2 - 1
+            o, r, term, trunc, info = env.step(a)
+            po, pr, pterm, ptrunc, pdrag, plift = drv[2][step]
+            for k in o:
+                assert np.allclose(po[k], o[k].numpy(), atol=1e-6), k
+            assert np.allclose(pr, r.numpy(), atol=1e-6)
+            assert pterm == [bool(term)] * 4 and ptrunc == [bool(trunc)] * 4
+            assert np.allclose(pdrag, info["drag"].numpy(), atol=1e-6) and np.allclose(plift, info["lift"].numpy(), atol=1e-6)
+        # the jets of env 0 and env 3 differ: so do their forces (the actions reached the boundary slots of the right shard)
+        assert abs(drv[2][1][5][0] - drv[2][1][5][3]) > 1e-6
+        env.close()
+    finally:
+        torch.cuda.is_available = real_avail
+        restore()
