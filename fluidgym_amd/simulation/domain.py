@@ -251,7 +251,8 @@ class Domain:
     def __init__(self, spatialDims: int, viscosity, passiveScalarChannels: int = 0, name: str = "Domain",
                  device=None, dtype=torch.float32, batch: int = 1):
         if dtype != torch.float32:
-            raise NotImplementedError("the HIP path computes in fp32 (reference default, fluid_env.py:146)")
+            raise NotImplementedError("the HIP kernels are instantiated for fp32 fields only (the reference's default dtype, "
+                                      "fluid_env.py:146); dtype=torch.float64 is not built (DESIGN.md section 7)")
         self.dims = int(spatialDims)
         self.name = name
         self.dtype = dtype
@@ -269,7 +270,8 @@ class Domain:
     # ---- construction ---------------------------------------------------------------------
     def CreateBlock(self, vertexCoordinates: torch.Tensor, name: str = "Block") -> Block:
         if self.blocks:
-            raise NotImplementedError("multi-block domains (connected boundaries) are not built yet (SURVEY 8f-3)")
+            raise NotImplementedError("this class is the single-block (rectilinear) domain; connected curvilinear blocks are built "
+                                      "with fluidgym_amd.simulation.multiblock.MultiBlockDomain (SURVEY 8f-3)")
         b = Block(self, vertexCoordinates, name)
         self.blocks.append(b)
         return b

@@ -9,9 +9,11 @@ states, ``fluid_env.py:1044-1190``) load here and files written here load there:
   ``boundaries`` = 2d entries {``type``: FIXED | PERIODIC | CONNECTED | DIRICHLET | DIRICHLET_VARYING, ...}} where every
   tensor field holds the npz key as a string, and ``data_info`` (shape / dtype / device per key).
 
-What loads: one block on a rectilinear vertex grid with FIXED (also the two deprecated DIRICHLET spellings, as the
-reference maps them, ``:264-283``) and PERIODIC faces.  CONNECTED boundaries, several blocks, per-block viscosity
-fields or a non-rectilinear grid raise ``NotImplementedError`` (multi-block meshes are SURVEY 8f-3).  The files hold ONE
+What loads: ``load_domain`` -- one block on a rectilinear vertex grid with FIXED (also the two deprecated DIRICHLET spellings,
+as the reference maps them, ``:264-283``) and PERIODIC faces; ``load_multiblock_domain`` / ``save_multiblock_domain`` -- several
+curvilinear blocks with CONNECTED boundaries (``connectedBlock`` / ``axes``; the cylinder and airfoil envs' initial domains,
+SURVEY 8f-3).  Per-block viscosity fields raise ``NotImplementedError``; ``load_domain`` points at ``load_multiblock_domain``
+for a file that holds connected blocks.  The files hold ONE
 env (tensor batch 1); ``load_domain(..., batch=B)`` replicates it over the env axis and ``save_domain(..., env=b)`` writes
 one env of a batched domain.
 """
@@ -109,11 +111,12 @@ def load_domain(path: str, dtype=None, device=None, with_scalar: bool = True, ba
     dd, arrays = read_domain_file(path)
     data = [torch.from_numpy(a).to(torch.float32) for a in arrays]
     if dtype not in (None, torch.float32):
-        raise NotImplementedError("the HIP path computes in fp32")
+        raise NotImplementedError("the HIP kernels are instantiated for fp32 fields only; dtype=torch.float64 is not built")
     get = lambda d, name: data[int(d[name])] if name in d else None
 
     if len(dd["blocks"]) != 1:
-        raise NotImplementedError("multi-block domains (connected boundaries) are not built yet (SURVEY 8f-3)")
+        raise NotImplementedError("this file holds a multi-block domain (connected boundaries): load it with "
+                                  "load_multiblock_domain (SURVEY 8f-3)")
     n_scal = dd.get("passiveScalarChannels", 1) if with_scalar else 0
     dom = Domain(dd["spatialDims"], get(dd, "viscosity"), passiveScalarChannels=n_scal, name=dd["name"], device=device,
                  batch=batch)
@@ -135,7 +138,7 @@ def load_domain(path: str, dtype=None, device=None, with_scalar: bool = True, ba
         elif t == "PERIODIC":
             continue
         elif t == "CONNECTED":
-            raise NotImplementedError("CONNECTED boundaries need multi-block support (SURVEY 8f-3)")
+            raise NotImplementedError("CONNECTED boundary: this file holds a multi-block domain, load it with load_multiblock_domain")
         else:
             raise TypeError("Unknown boundary type: " + t)
     if not prepare:
