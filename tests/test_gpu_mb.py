@@ -83,7 +83,11 @@ def _assembly_parity(dom, d, states, dt, B, check_div):
                                                       # not a null vector of the matrix, so the mean projection the envs use changes
                                                       # the system)
                                                       (H.skewed_pair, 2, 2e-7, False), (H.skewed_pair_3d, 2, 2e-7, False),
-                                                      (H.polar_ring, 2, 2e-7, True)])
+                                                      (H.polar_ring, 2, 2e-7, True),
+                                                      # the same steps with the solves driven to 2e-8 (fp64-refined iterate): what is left is
+                                                      # the fp32 assembly and the fp32 velocity solve -- the north-star's 1e-5 per step
+                                                      (H.split_rotated_channel, 2, 2e-8, True), (H.odd_channel, 2, 2e-8, True),
+                                                      (H.polar_ring, 2, 2e-8, True), (H.skewed_pair, 2, 2e-8, False)])
 def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     """Whole step against the oracle's direct solves.  The pressure solver is CG as in the reference where the mesh is
     orthogonal (symmetric matrix); with strong cross metrics the matrix is not symmetric, CG stalls (there as here, see
@@ -95,7 +99,8 @@ def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     dt = [0.05, 0.03]
     states = [_state(d, 10 + b) for b in range(B)]
     _load(dom, states)
-    its = dom.piso_step(dt, advection_tol=1e-7, pressure_tol=ptol, pressure_use_bicgstab=bicg, pressure_project_mean=project)
+    tight = ptol < 1e-7
+    its = dom.piso_step(dt, advection_tol=3e-8 if tight else 1e-7, pressure_tol=ptol, pressure_use_bicgstab=bicg, pressure_project_mean=project)
     # (the refined solver verifies convergence on the true fp64 residual: after such a first projection the second corrector's
     # right-hand side can already meet the tolerance -- 0 iterations)
     assert its[0] > 0 and its[1] > 0 and (its[2] > 0 or bicg == 2)
@@ -105,8 +110,10 @@ def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
     for b in range(B):
         print(f"MB_STEP_ERR {spec_fn.__name__} bicg={bicg} ptol={ptol:g} project={project} env {b}: velocity {_rel(u_gpu[b], refs[b][0]):.2e} "
               f"pressure {_rel(p_gpu[b], refs[b][1]):.2e}")
-        assert _rel(u_gpu[b], refs[b][0]) < 2e-4, (spec_fn.__name__, b)
-        assert _rel(p_gpu[b], refs[b][1]) < 2e-3, (spec_fn.__name__, b)
+        # measured (round 3, MB_STEP_ERR lines of the GPU log): 0.9-13e-5 velocity / 0.3-22e-5 pressure at the envs' tolerances --
+        # the absolute pressure tolerance of 2e-6 .. 2e-7 is what is left; bounds = 2x the largest seen
+        assert _rel(u_gpu[b], refs[b][0]) < (3e-5 if tight else 2.5e-4), (spec_fn.__name__, b)
+        assert _rel(p_gpu[b], refs[b][1]) < (1e-4 if tight else 5e-4), (spec_fn.__name__, b)
     mv = dom.max_velocity()
     for b in range(B):
         assert np.isclose(mv[b], d.max_cfl_velocity(refs[b][0]), rtol=1e-3)
