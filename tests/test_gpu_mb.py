@@ -112,8 +112,9 @@ def test_piso_step_matches_oracle(spec_fn, bicg, ptol, project):
               f"pressure {_rel(p_gpu[b], refs[b][1]):.2e}")
         # measured (round 3, MB_STEP_ERR lines of the GPU log): 0.9-13e-5 velocity / 0.3-22e-5 pressure at the envs' tolerances --
         # the absolute pressure tolerance of 2e-6 .. 2e-7 is what is left; bounds = 2x the largest seen
-        assert _rel(u_gpu[b], refs[b][0]) < (3e-5 if tight else 2.5e-4), (spec_fn.__name__, b)
-        assert _rel(p_gpu[b], refs[b][1]) < (1e-4 if tight else 5e-4), (spec_fn.__name__, b)
+        # with the solves driven to 2e-8: 0.6-2.8e-6 velocity / 0.25-4.6e-6 pressure -- inside the north-star's 1e-5 per step
+        assert _rel(u_gpu[b], refs[b][0]) < (1e-5 if tight else 2.5e-4), (spec_fn.__name__, b)
+        assert _rel(p_gpu[b], refs[b][1]) < (2e-5 if tight else 5e-4), (spec_fn.__name__, b)
     mv = dom.max_velocity()
     for b in range(B):
         assert np.isclose(mv[b], d.max_cfl_velocity(refs[b][0]), rtol=1e-3)
