@@ -28,10 +28,11 @@ rocprofv3 --pmc FETCH_SIZE -d $O/p_p256f -o p256 -- python3 $R/profiles/micro_po
 python3 $R/profiles/summarize_pmc.py "$(find $O/p_p256f -name '*.db' | head -1)" > $O/r03_b_poisson256_pmc_fetch.csv
 rocprofv3 --pmc WRITE_SIZE -d $O/p_p256w -o p256 -- python3 $R/profiles/micro_poisson.py > $O/p_p256w.log 2>&1
 python3 $R/profiles/summarize_pmc.py "$(find $O/p_p256w -name '*.db' | head -1)" > $O/r03_b_poisson256_pmc_write.csv
+export FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB=0
 rocprofv3 --kernel-trace --stats -d $O/p_air -o air -- python3 $R/profiles/airfoil_bench.py 16 1 40 > $O/p_air.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air -name '*.db' | head -1)" $O/r03_d_airfoil_kernel_stats.csv > /dev/null
-# the same leg with the opt-in multilevel trial of the pressure BiCGStab (policy read from the environment by the Python side)
 export FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB=1
+# (r03_d: the plain refined recurrence, policy off; r03_e: the default since round 3 = with the multilevel trial)
 rocprofv3 --kernel-trace --stats -d $O/p_air2 -o air -- python3 $R/profiles/airfoil_bench.py 16 1 40 > $O/p_air2.log 2>&1
 unset FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air2 -name '*.db' | head -1)" $O/r03_e_airfoil_trial_kernel_stats.csv > /dev/null
