@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FLUIDGYM_AMD_LIB: another build of the same library (the host-sanitizer build of tests/run_sanitizer_suite.sh); a path that does
 # not exist is an error like a missing default build
 LIB_PATH = os.environ.get("FLUIDGYM_AMD_LIB") or os.path.join(_HERE, "libfluidgym_hip.so")
+# the fp64 build of the single-block entry points (fg_real = double, include/fluidgym_hip.h): FluidEnv(dtype=torch.float64)
+LIB_F64_PATH = os.environ.get("FLUIDGYM_AMD_LIB_F64") or os.path.join(_HERE, "libfluidgym_hip_f64.so")
 
 FG_MAX_SCALARS = 4
 FG_OK = 0
@@ -233,7 +235,46 @@ SIGNATURES = {
     "fg_mb_get_cell_transforms": (c_int, [c_void_p, POINTER(c_float)]),
 }
 
+# ---- the fp64 build: the single-block entry points with fg_real = double.  Same names, every float of a signature (by value,
+# by pointer, inside the option structures) becomes a double; the fp32-only entry points keep their types (they answer
+# FG_ERR_UNSUPPORTED there) and the multi-block / resampling symbols are not part of that library.
+def _f64_struct(cls):
+    fields = []
+    for name, tp in cls._fields_:
+        if tp is c_float:
+            tp = ctypes.c_double
+        elif isinstance(tp, type) and issubclass(tp, ctypes.Array) and tp._type_ is c_float:
+            tp = ctypes.c_double * tp._length_
+        elif isinstance(tp, type) and issubclass(tp, Structure) and tp in _F64_STRUCTS:
+            tp = _F64_STRUCTS[tp]
+        fields.append((name, tp))
+    return type(cls.__name__ + "F64", (Structure,), {"_fields_": fields})
+
+
+_F64_STRUCTS: dict = {}
+_F64_STRUCTS[FgStepOptions] = _f64_struct(FgStepOptions)
+_F64_STRUCTS[FgSimOptions] = _f64_struct(FgSimOptions)
+FgStepOptionsF64, FgSimOptionsF64 = _F64_STRUCTS[FgStepOptions], _F64_STRUCTS[FgSimOptions]
+_F64_KEEP_FLOAT = ("fg_set_fd_preconditioner", "fg_set_fd_fast_transform", "fg_coords_to_transforms", "fg_stream_triad")
+_F64_ABSENT_PREFIXES = ("fg_mb_", "fg_resampl", "fg_sparse_")
+
+
+def _f64_type(tp):
+    if tp is c_float:
+        return ctypes.c_double
+    if tp is POINTER(c_float):
+        return POINTER(ctypes.c_double)
+    for k, v in _F64_STRUCTS.items():
+        if tp is POINTER(k):
+            return POINTER(v)
+    return tp
+
+
+SIGNATURES_F64 = {name: ((res, args) if name in _F64_KEEP_FLOAT else (res, [_f64_type(a) for a in args]))
+                  for name, (res, args) in SIGNATURES.items() if not name.startswith(_F64_ABSENT_PREFIXES)}
+
 _lib = None
+_lib_f64 = None
 
 
 class NativeLibraryError(RuntimeError):
@@ -266,9 +307,32 @@ def load() -> ctypes.CDLL:
     return lib
 
 
-def check(rc: int, allow=()):
-    """Raise on a negative status (except those in ``allow``), with the library's message."""
+def load_f64() -> ctypes.CDLL:
+    """The fp64 build (``libfluidgym_hip_f64.so``), typed with ``SIGNATURES_F64``."""
+    global _lib_f64
+    if _lib_f64 is not None:
+        return _lib_f64
+    if not os.path.exists(LIB_F64_PATH):
+        raise NativeLibraryError(f"{LIB_F64_PATH} not found (dtype=torch.float64 needs the fp64 build: `make -C fluidgym_amd/csrc`). "
+                                 "fluidgym_amd has no CPU / PyTorch fallback.")
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_F64_PATH)
+    for name, (res, args) in SIGNATURES_F64.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fg_abi_version() != 1:
+        raise NativeLibraryError("libfluidgym_hip_f64.so ABI version mismatch")
+    _lib_f64 = lib
+    return lib
+
+
+def check(rc: int, allow=(), lib=None):
+    """Raise on a negative status (except those in ``allow``), with the message of the library that reported it."""
     if rc == FG_OK or rc in allow:
         return rc
-    msg = load().fg_last_error()
+    msg = (lib or load()).fg_last_error()
+    if not msg and lib is None and _lib_f64 is not None:
+        msg = _lib_f64.fg_last_error()
     raise NativeLibraryError(f"libfluidgym_hip call failed with status {rc}: {msg.decode() if msg else ''}")

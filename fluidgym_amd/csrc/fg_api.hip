@@ -38,7 +38,7 @@ static int check_bound(const fg_state* s, bool need_scalar) {
     return FG_OK;
 }
 
-extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy, const float* hz, fg_handle* out) {
+extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real* hy, const fg_real* hz, fg_handle* out) {
     FG_REQUIRE(cfg && out && hx && hy, FG_ERR_INVALID_ARG, "fg_create: null argument");
     FG_REQUIRE(cfg->dims == 2 || cfg->dims == 3, FG_ERR_INVALID_ARG, "dims must be 2 or 3");
     FG_REQUIRE(cfg->dims == 2 || hz, FG_ERR_INVALID_ARG, "hz required in 3-D");
@@ -61,28 +61,28 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     g.dims = cfg->dims; g.nx = cfg->nx; g.ny = cfg->ny; g.nz = cfg->nz;
     g.n = cfg->nx * cfg->ny * cfg->nz; g.B = cfg->batch;
     for (int f = 0; f < 6; ++f) g.fixed[f] = (f < 2 * cfg->dims) ? (cfg->face_type[f] == FG_FIXED) : 0;
-    s->vec = (cfg->nx % 4 == 0) ? 4 : 1;
+    s->vec = (!FG_F64 && cfg->nx % 4 == 0) ? 4 : 1;   // (the fp64 build runs scalar lanes: the float4 paths are fp32 idioms)
     s->viscosity = 0.f;
 
-    const float* hsrc[3] = {hx, hy, hz};
+    const fg_real* hsrc[3] = {hx, hy, hz};
     const int hn[3] = {cfg->nx, cfg->ny, cfg->nz};
     for (int a = 0; a < 3; ++a) {
-        std::vector<float> h(hn[a], 1.f), rh(hn[a], 1.f);
+        std::vector<fg_real> h(hn[a], 1.f), rh(hn[a], 1.f);
         if (a < cfg->dims)
             for (int i = 0; i < hn[a]; ++i) {
                 if (!(hsrc[a][i] > 0.f)) { delete s; fg_set_error("cell widths must be positive"); return FG_ERR_INVALID_ARG; }
                 h[i] = hsrc[a][i]; rh[i] = 1.f / hsrc[a][i];
             }
-        FG_HIP_CHECK(hipMalloc(&s->d_h[a], sizeof(float) * hn[a]));
-        FG_HIP_CHECK(hipMalloc(&s->d_rh[a], sizeof(float) * hn[a]));
-        FG_HIP_CHECK(hipMemcpy(s->d_h[a], h.data(), sizeof(float) * hn[a], hipMemcpyHostToDevice));
-        FG_HIP_CHECK(hipMemcpy(s->d_rh[a], rh.data(), sizeof(float) * hn[a], hipMemcpyHostToDevice));
+        FG_HIP_CHECK(hipMalloc(&s->d_h[a], sizeof(fg_real) * hn[a]));
+        FG_HIP_CHECK(hipMalloc(&s->d_rh[a], sizeof(fg_real) * hn[a]));
+        FG_HIP_CHECK(hipMemcpy(s->d_h[a], h.data(), sizeof(fg_real) * hn[a], hipMemcpyHostToDevice));
+        FG_HIP_CHECK(hipMemcpy(s->d_rh[a], rh.data(), sizeof(fg_real) * hn[a], hipMemcpyHostToDevice));
         g.h[a] = s->d_h[a]; g.rh[a] = s->d_rh[a];
     }
     const size_t BN = (size_t)g.B * g.n, d = g.dims;
-    auto alloc = [&](float** p, size_t count) -> hipError_t {
-        hipError_t e = hipMalloc(p, sizeof(float) * count);
-        if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * count);
+    auto alloc = [&](fg_real** p, size_t count) -> hipError_t {
+        hipError_t e = hipMalloc(p, sizeof(fg_real) * count);
+        if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(fg_real) * count);
         return e;
     };
     FG_HIP_CHECK(alloc(&s->A, BN));
@@ -103,10 +103,10 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     FG_HIP_CHECK(hipHostMalloc(&s->info_pinned, sizeof(fg_solve_info) * nsys));
     FG_HIP_CHECK(hipHostMalloc(&s->flags_pinned, sizeof(int32_t) * nsys));
     FG_HIP_CHECK(alloc(&s->scratch_B, (size_t)g.B * (4 + 2 * d)));
-    FG_HIP_CHECK(hipMalloc(&s->d_bvel_ptrs, sizeof(float*) * 6));
-    FG_HIP_CHECK(hipMemset(s->d_bvel_ptrs, 0, sizeof(float*) * 6));
-    FG_HIP_CHECK(hipHostMalloc(&s->diag_pinned, sizeof(float) * 2 * g.B));
-    FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(float) * g.B));
+    FG_HIP_CHECK(hipMalloc(&s->d_bvel_ptrs, sizeof(fg_real*) * 6));
+    FG_HIP_CHECK(hipMemset(s->d_bvel_ptrs, 0, sizeof(fg_real*) * 6));
+    FG_HIP_CHECK(hipHostMalloc(&s->diag_pinned, sizeof(fg_real) * 2 * g.B));
+    FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(fg_real) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr;
@@ -116,8 +116,8 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
     s->adv_from_result = 1;
     FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(FgDacc) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(FgDacc) * (size_t)g.B * 8 * 64));
-    FG_HIP_CHECK(hipMalloc(&s->cg_best.best_crit, sizeof(float) * g.B));
-    FG_HIP_CHECK(hipMalloc(&s->cg_best.saved_crit, sizeof(float) * g.B));
+    FG_HIP_CHECK(hipMalloc(&s->cg_best.best_crit, sizeof(fg_real) * g.B));
+    FG_HIP_CHECK(hipMalloc(&s->cg_best.saved_crit, sizeof(fg_real) * g.B));
     FG_HIP_CHECK(hipMalloc(&s->cg_best.save_at, sizeof(int32_t) * g.B));
     FG_HIP_CHECK(alloc(&s->cg_best.best_x, BN));
     *out = s;
@@ -127,9 +127,9 @@ extern "C" int fg_create(const fg_config* cfg, const float* hx, const float* hy,
 extern "C" int fg_destroy(fg_handle s) {
     if (!s) return FG_OK;
     for (int a = 0; a < 3; ++a) { (void)hipFree(s->d_h[a]); (void)hipFree(s->d_rh[a]); }
-    float* owned[] = {s->A, s->rA, s->Coff, s->adv_rhs, s->vel_result, s->hvec, s->div, s->p_result, s->scal_result,
+    fg_real* owned[] = {s->A, s->rA, s->Coff, s->adv_rhs, s->vel_result, s->hvec, s->div, s->p_result, s->scal_result,
                       s->scratch_B};
-    for (float* p : owned) (void)hipFree(p);
+    for (fg_real* p : owned) (void)hipFree(p);
     for (int i = 0; i < 8; ++i) (void)hipFree(s->w[i]);
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
@@ -146,7 +146,7 @@ extern "C" int fg_destroy(fg_handle s) {
 }
 
 static int sync_bvel_ptrs(fg_state* s);
-extern "C" int fg_bind(fg_handle s, int field, float* ptr) {
+extern "C" int fg_bind(fg_handle s, int field, fg_real* ptr) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (field == FG_VELOCITY) s->velocity = ptr;
     else if (field == FG_PRESSURE) s->pressure = ptr;
@@ -161,12 +161,12 @@ extern "C" int fg_bind(fg_handle s, int field, float* ptr) {
     return FG_OK;
 }
 
-extern "C" int fg_set_viscosity(fg_handle s, float v) {
+extern "C" int fg_set_viscosity(fg_handle s, fg_real v) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     s->viscosity = v;
     return FG_OK;
 }
-extern "C" int fg_set_scalar_viscosity(fg_handle s, int ch, float v) {
+extern "C" int fg_set_scalar_viscosity(fg_handle s, int ch, fg_real v) {
     FG_REQUIRE(s && ch >= 0 && ch < FG_MAX_SCALARS, FG_ERR_INVALID_ARG, "bad channel");
     s->scalar_viscosity[ch] = v;
     s->scalar_viscosity_set = true;
@@ -176,13 +176,17 @@ extern "C" int fg_set_scalar_viscosity(fg_handle s, int ch, float v) {
 extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const float* QxT, const float* Qz, const float* QzT,
                                         const float* lower, const float* inv, const float* cp) {
     FG_REQUIRE(s && Qx && QxT && lower && inv && cp, FG_ERR_INVALID_ARG, "null argument");
+#if FG_F64
+    fg_set_error("the fast-diagonalisation preconditioner is an fp32 kernel family: not part of the fp64 build (plain CG there)");
+    return FG_ERR_UNSUPPORTED;
+#else
     FG_REQUIRE(s->grid.fixed[2] && s->grid.fixed[3], FG_ERR_UNSUPPORTED, "FD preconditioner needs FIXED y faces");
     FG_REQUIRE(s->grid.dims == 2 || (Qz && QzT), FG_ERR_INVALID_ARG, "Qz required in 3-D");
     const size_t nx = s->grid.nx, ny = s->grid.ny, nz = s->grid.nz;
-    auto up = [&](float** dst, const float* src, size_t count) -> hipError_t {
+    auto up = [&](fg_real** dst, const fg_real* src, size_t count) -> hipError_t {
         if (*dst) (void)hipFree(*dst);
-        hipError_t e = hipMalloc(dst, sizeof(float) * count);
-        if (e == hipSuccess) e = hipMemcpy(*dst, src, sizeof(float) * count, hipMemcpyHostToDevice);
+        hipError_t e = hipMalloc(dst, sizeof(fg_real) * count);
+        if (e == hipSuccess) e = hipMemcpy(*dst, src, sizeof(fg_real) * count, hipMemcpyHostToDevice);
         return e;
     };
     FG_HIP_CHECK(up(&s->fd_Qx, Qx, nx * nx));
@@ -196,6 +200,7 @@ extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const floa
     FG_HIP_CHECK(up(&s->fd_cp, cp, nx * ny * nz));
     s->fd_dct_x = 0;  // fg_set_fd_fast_transform marks the axis again for the new basis
     return FG_OK;
+#endif
 }
 
 extern "C" int fg_set_return_best(fg_handle s, int on) {
@@ -225,51 +230,51 @@ extern "C" int fg_advection_retries(fg_handle s, int64_t* out, int32_t reset) {
     return FG_OK;
 }
 
-extern "C" int fg_max_velocity(fg_handle s, float* out_B, void* stream) {
+extern "C" int fg_max_velocity(fg_handle s, fg_real* out_B, void* stream) {
     FG_REQUIRE(s && out_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, false)) return rc;
     return fg_launch_max_velocity(s, make_bounds(s, 0), out_B, (hipStream_t)stream);
 }
-extern "C" int fg_boundary_flux_balance(fg_handle s, float* out_B, void* stream) {
+extern "C" int fg_boundary_flux_balance(fg_handle s, fg_real* out_B, void* stream) {
     FG_REQUIRE(s && out_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, false)) return rc;
     return fg_launch_flux_balance(s, make_bounds(s, 0), out_B, (hipStream_t)stream);
 }
 
-extern "C" int fg_step_diagnostics(fg_handle s, float* out_host, void* stream) {
+extern "C" int fg_step_diagnostics(fg_handle s, fg_real* out_host, void* stream) {
     FG_REQUIRE(s && out_host, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, false)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int B = s->grid.B;
-    float* d = s->scratch_B;  // [0..B) flux balance, [B..2B) max velocity
+    fg_real* d = s->scratch_B;  // [0..B) flux balance, [B..2B) max velocity
     const FgBounds bnd = make_bounds(s, 0);
     if (int rc = fg_launch_flux_balance(s, bnd, d, st)) return rc;
     if (int rc = fg_launch_max_velocity(s, bnd, d + B, st)) return rc;
-    FG_HIP_CHECK(hipMemcpyAsync(s->diag_pinned, d, sizeof(float) * 2 * B, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipMemcpyAsync(s->diag_pinned, d, sizeof(fg_real) * 2 * B, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
-    memcpy(out_host, s->diag_pinned, sizeof(float) * 2 * B);
+    memcpy(out_host, s->diag_pinned, sizeof(fg_real) * 2 * B);
     return FG_OK;
 }
 
 static int sync_bvel_ptrs(fg_state* s) {
-    FG_HIP_CHECK(hipMemcpy(s->d_bvel_ptrs, s->bvel, sizeof(float*) * 6, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->d_bvel_ptrs, s->bvel, sizeof(fg_real*) * 6, hipMemcpyHostToDevice));
     return FG_OK;
 }
 
-extern "C" int fg_update_advective_boundary(fg_handle s, int face, const float* velm, const float* dt_B, void* stream) {
+extern "C" int fg_update_advective_boundary(fg_handle s, int face, const fg_real* velm, const fg_real* dt_B, void* stream) {
     FG_REQUIRE(s && velm && dt_B && face >= 0 && face < 2 * s->grid.dims, FG_ERR_INVALID_ARG, "bad argument");
     FG_REQUIRE(s->grid.fixed[face] && s->bvel[face], FG_ERR_INVALID_ARG, "face is not a bound FIXED face");
     if (int rc = check_bound(s, false)) return rc;
     return fg_launch_outflow(s, face, velm[face >> 1], dt_B, (hipStream_t)stream);
 }
 
-extern "C" int fg_balance_boundary_fluxes(fg_handle s, int free_face_mask, float atol, const float* dt_B, void* stream) {
+extern "C" int fg_balance_boundary_fluxes(fg_handle s, int free_face_mask, fg_real atol, const fg_real* dt_B, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (int rc = check_bound(s, false)) return rc;
     return fg_launch_balance(s, make_bounds(s, 0), free_face_mask, atol, dt_B, (hipStream_t)stream);
 }
 
-extern "C" int fg_setup_advection(fg_handle s, const float* dt_B, int for_scalar, int channel, void* stream) {
+extern "C" int fg_setup_advection(fg_handle s, const fg_real* dt_B, int for_scalar, int channel, void* stream) {
     FG_REQUIRE(s && dt_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, for_scalar != 0)) return rc;
     FG_REQUIRE(!for_scalar || (channel >= 0 && channel < s->cfg.n_scalars), FG_ERR_INVALID_ARG, "bad scalar channel");
@@ -297,7 +302,7 @@ extern "C" int fg_setup_advection(fg_handle s, const float* dt_B, int for_scalar
 
 static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st);
 
-extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, float tol, int max_iterations,
+extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, fg_real tol, int max_iterations,
                                   fg_solve_info* info_host, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     FgBicgArgs a;
@@ -315,8 +320,8 @@ extern "C" int fg_copy_scalar_result_to_blocks(fg_handle s, int channel, void* s
     const int n = s->grid.n;
     if (s->cfg.n_scalars == 1) return fg_launch_copy_active(s, s->cur_dt, s->scal_result, s->scalar, 1, (hipStream_t)stream);
     // strided destination: channel `channel` of [B,C,N] (all envs)
-    FG_HIP_CHECK(hipMemcpy2DAsync(s->scalar + (size_t)channel * n, sizeof(float) * n * s->cfg.n_scalars, s->scal_result,
-                                  sizeof(float) * n, sizeof(float) * n, s->grid.B, hipMemcpyDeviceToDevice,
+    FG_HIP_CHECK(hipMemcpy2DAsync(s->scalar + (size_t)channel * n, sizeof(fg_real) * n * s->cfg.n_scalars, s->scal_result,
+                                  sizeof(fg_real) * n, sizeof(fg_real) * n, s->grid.B, hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
     return FG_OK;
 }
@@ -326,7 +331,7 @@ extern "C" int fg_setup_pressure_matrix(fg_handle s, void* stream) {
     return fg_launch_pressure_setup(s, s->cur_dt, (hipStream_t)stream);
 }
 
-extern "C" int fg_setup_pressure_rhs(fg_handle s, const float* dt_B, void* stream) {
+extern "C" int fg_setup_pressure_rhs(fg_handle s, const fg_real* dt_B, void* stream) {
     FG_REQUIRE(s && dt_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, false)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -334,7 +339,7 @@ extern "C" int fg_setup_pressure_rhs(fg_handle s, const float* dt_B, void* strea
     return fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st);
 }
 
-static int solve_pressure(fg_state* s, const float* dt, int method, float tol, int max_iterations, int use_previous,
+static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real tol, int max_iterations, int use_previous,
                           fg_solve_info* info_host, hipStream_t st, bool finalize = true) {
     int rc = FG_OK;
     if (method == FG_SOLVER_CG || method == FG_SOLVER_FDCG) {
@@ -359,7 +364,7 @@ static int solve_pressure(fg_state* s, const float* dt, int method, float tol, i
     return rc;
 }
 
-extern "C" int fg_solve_pressure(fg_handle s, int method, float tol, int max_iterations, int use_previous,
+extern "C" int fg_solve_pressure(fg_handle s, int method, fg_real tol, int max_iterations, int use_previous,
                                  fg_solve_info* info_host, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (int rc = check_bound(s, false)) return rc;
@@ -405,7 +410,7 @@ static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipSt
     return rc;
 }
 
-extern "C" int fg_piso_step(fg_handle s, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
+extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_options* opt, int32_t* stats_host,
                             void* stream) {
     FG_REQUIRE(s && dt_B && opt, FG_ERR_INVALID_ARG, "null argument");
     const bool scalar = opt->advect_scalar && s->cfg.n_scalars > 0;
@@ -496,7 +501,7 @@ extern "C" int fg_solver_counters(fg_handle s, int64_t* out13, int32_t reset) {
 // np.isclose(a, 0) with the default rtol=1e-5, atol=1e-8
 static inline bool is_close_zero(double a) { return std::fabs(a) <= 1e-8; }
 
-extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out, float* flux_host, void* stream) {
+extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out, fg_real* flux_host, void* stream) {
     FG_REQUIRE(s && o && out, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, o->step.advect_scalar && s->cfg.n_scalars > 0)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -523,10 +528,10 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             if (o->adaptive) { if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B)) return rc; }
             FG_HIP_CHECK(hipStreamSynchronize(st));
             if (first) {
-                float worst = 0.f;
+                fg_real worst = 0.f;
                 for (int b = 0; b < B; ++b) {
                     if (flux_host) flux_host[b] = s->diag_pinned[b];
-                    const float a = std::fabs(s->diag_pinned[b]);
+                    const fg_real a = std::fabs(s->diag_pinned[b]);
                     worst = (a > worst || a != a) ? a : worst;
                 }
                 if (!(worst <= o->flux_balance_tol)) {
@@ -536,7 +541,7 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             }
         }
         for (int b = 0; b < B; ++b) {
-            float ts = 0.f;
+            fg_real ts = 0.f;
             if (!o->adaptive) {
                 ts = o->time_step;
             } else if (t_rem[b] > 0 && !is_close_zero(t_rem[b])) {
@@ -546,11 +551,11 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
                 if (max_ts >= t_rem[b]) tsd = t_rem[b];
                 else tsd = t_rem[b] / (double)(long long)std::ceil(t_rem[b] / max_ts);
                 t_rem[b] -= tsd;
-                ts = (float)tsd;  // the reference rounds ts through the domain dtype (PISOtorch_simulation.py:2029-2031)
+                ts = (fg_real)tsd;  // the reference rounds ts through the domain dtype (PISOtorch_simulation.py:2029-2031)
             }
             s->dt_pinned[b] = ts;
         }
-        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * B, hipMemcpyHostToDevice, st));
+        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(fg_real) * B, hipMemcpyHostToDevice, st));
         // PRE hook: advective outflow + flux re-balancing (cylinder_env_base.py:280-300)
         if (o->outflow_mask) {
             for (int f = 0; f < 2 * s->grid.dims; ++f)
@@ -558,7 +563,7 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
                     FG_REQUIRE(s->grid.fixed[f], FG_ERR_INVALID_ARG, "outflow face is not FIXED");
                     if (int rc = fg_launch_outflow(s, f, o->outflow_velm[f >> 1], s->dt_dev, st)) return rc;
                 }
-            if (int rc = fg_launch_balance(s, bnd, o->outflow_mask, 0.01f * o->outflow_tol, s->dt_dev, st)) return rc;
+            if (int rc = fg_launch_balance(s, bnd, o->outflow_mask, (fg_real)0.01 * o->outflow_tol, s->dt_dev, st)) return rc;
         }
         int rc = fg_piso_step(s, s->dt_dev, &o->step, stats, stream);
         if (rc == FG_ERR_NOT_CONVERGED) all_ok = 0;
@@ -576,7 +581,7 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
     return FG_OK;
 }
 
-extern "C" int fg_make_divergence_free(fg_handle s, float tol, int max_iterations, fg_solve_info* info_host,
+extern "C" int fg_make_divergence_free(fg_handle s, fg_real tol, int max_iterations, fg_solve_info* info_host,
                                        void* stream) {
     // make_divergence_free (PISOtorch_simulation.py:1320-1429): A := 1, dt := 1, h := u
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
@@ -584,8 +589,8 @@ extern "C" int fg_make_divergence_free(fg_handle s, float tol, int max_iteration
     s->cur_dt = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const size_t BN = (size_t)s->grid.B * s->grid.n;
-    std::vector<float> ones(BN, 1.f);
-    FG_HIP_CHECK(hipMemcpyAsync(s->rA, ones.data(), sizeof(float) * BN, hipMemcpyHostToDevice, st));
+    std::vector<fg_real> ones(BN, 1.f);
+    FG_HIP_CHECK(hipMemcpyAsync(s->rA, ones.data(), sizeof(fg_real) * BN, hipMemcpyHostToDevice, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
     if (int rc = fg_launch_copy_active(s, nullptr, s->velocity, s->hvec, s->grid.dims, st)) return rc;
     if (int rc = fg_launch_div(s, make_bounds(s, 0), nullptr, s->hvec, s->div, st)) return rc;
@@ -598,11 +603,11 @@ extern "C" int fg_make_divergence_free(fg_handle s, float tol, int max_iteration
 
 extern "C" int fg_reset_solver_state(fg_handle s, void* stream) {
     FG_REQUIRE(s && s->velocity, FG_ERR_NOT_BOUND, "velocity not bound");
-    FG_HIP_CHECK(hipMemsetAsync(s->p_result, 0, sizeof(float) * (size_t)s->grid.B * s->grid.n, (hipStream_t)stream));
+    FG_HIP_CHECK(hipMemsetAsync(s->p_result, 0, sizeof(fg_real) * (size_t)s->grid.B * s->grid.n, (hipStream_t)stream));
     return fg_launch_copy_active(s, nullptr, s->velocity, s->vel_result, s->grid.dims, (hipStream_t)stream);
 }
 
-extern "C" int fg_get_buffer(fg_handle s, int which, float** out_ptr, int64_t* out_count) {
+extern "C" int fg_get_buffer(fg_handle s, int which, fg_real** out_ptr, int64_t* out_count) {
     FG_REQUIRE(s && out_ptr && out_count, FG_ERR_INVALID_ARG, "null argument");
     const int64_t BN = (int64_t)s->grid.B * s->grid.n, d = s->grid.dims;
     switch (which) {
@@ -619,34 +624,34 @@ extern "C" int fg_get_buffer(fg_handle s, int which, float** out_ptr, int64_t* o
     return FG_OK;
 }
 
-extern "C" int fg_read_buffer(fg_handle s, int which, float* dst, void* stream) {
-    float* src = nullptr;
+extern "C" int fg_read_buffer(fg_handle s, int which, fg_real* dst, void* stream) {
+    fg_real* src = nullptr;
     int64_t count = 0;
     if (int rc = fg_get_buffer(s, which, &src, &count)) return rc;
     FG_REQUIRE(dst, FG_ERR_INVALID_ARG, "null destination");
-    FG_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(float) * count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    FG_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(fg_real) * count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return FG_OK;
 }
 
 // ---- standalone Poisson entry points ------------------------------------------------------------
-extern "C" int fg_poisson_apply(fg_handle s, const float* rA, const float* x, float* y, void* stream) {
+extern "C" int fg_poisson_apply(fg_handle s, const fg_real* rA, const fg_real* x, fg_real* y, void* stream) {
     FG_REQUIRE(s && rA && x && y, FG_ERR_INVALID_ARG, "null argument");
     return fg_poisson_apply_launch(s, rA, x, y, (hipStream_t)stream);
 }
 
-extern "C" int fg_poisson_jacobi(fg_handle s, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+extern "C" int fg_poisson_jacobi(fg_handle s, const fg_real* rA, const fg_real* b, fg_real* x, int n_sweeps, fg_real omega,
                                  void* stream) {
     FG_REQUIRE(s && rA && b && x && n_sweeps >= 0, FG_ERR_INVALID_ARG, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    float* buf[2] = {x, s->w[5]};
+    fg_real* buf[2] = {x, s->w[5]};
     for (int i = 0; i < n_sweeps; ++i)
         if (int rc = fg_poisson_jacobi_launch(s, rA, b, buf[i & 1], buf[(i + 1) & 1], omega, st)) return rc;
     if (n_sweeps & 1)
-        FG_HIP_CHECK(hipMemcpyAsync(x, s->w[5], sizeof(float) * (size_t)s->grid.B * s->grid.n, hipMemcpyDeviceToDevice, st));
+        FG_HIP_CHECK(hipMemcpyAsync(x, s->w[5], sizeof(fg_real) * (size_t)s->grid.B * s->grid.n, hipMemcpyDeviceToDevice, st));
     return FG_OK;
 }
 
-extern "C" int fg_poisson_rbgs(fg_handle s, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+extern "C" int fg_poisson_rbgs(fg_handle s, const fg_real* rA, const fg_real* b, fg_real* x, int n_sweeps, fg_real omega,
                                void* stream) {
     FG_REQUIRE(s && rA && b && x && n_sweeps >= 0, FG_ERR_INVALID_ARG, "bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -657,7 +662,7 @@ extern "C" int fg_poisson_rbgs(fg_handle s, const float* rA, const float* b, flo
     return FG_OK;
 }
 
-extern "C" int fg_poisson_cg(fg_handle s, const float* rA, const float* b, float* x, float tol, int max_iterations,
+extern "C" int fg_poisson_cg(fg_handle s, const fg_real* rA, const fg_real* b, fg_real* x, fg_real tol, int max_iterations,
                              int use_x0, fg_solve_info* info_host, void* stream) {
     FG_REQUIRE(s && rA && b && x, FG_ERR_INVALID_ARG, "null argument");
     FgCgArgs a;
@@ -670,7 +675,7 @@ extern "C" int fg_poisson_cg(fg_handle s, const float* rA, const float* b, float
     return fg_cg_solve(s, a, info_host, (hipStream_t)stream);
 }
 
-extern "C" int fg_poisson_fdcg(fg_handle s, const float* rA, const float* b, float* x, float tol, int max_iterations,
+extern "C" int fg_poisson_fdcg(fg_handle s, const fg_real* rA, const fg_real* b, fg_real* x, fg_real tol, int max_iterations,
                                int use_x0, fg_solve_info* info_host, void* stream) {
     FG_REQUIRE(s && rA && b && x, FG_ERR_INVALID_ARG, "null argument");
     FgCgArgs a;
@@ -686,5 +691,10 @@ extern "C" int fg_poisson_fdcg(fg_handle s, const float* rA, const float* b, flo
 extern "C" int fg_coords_to_transforms(const float* coords, float* transforms, int dims, int nx, int ny, int nz,
                                        void* stream) {
     FG_REQUIRE(coords && transforms && (dims == 2 || dims == 3), FG_ERR_INVALID_ARG, "bad argument");
+#if FG_F64
+    fg_set_error("fg_coords_to_transforms is an fp32 entry point: use libfluidgym_hip.so");
+    return FG_ERR_UNSUPPORTED;
+#else
     return fg_metrics_launch(coords, transforms, dims, nx, ny, nz, (hipStream_t)stream);
+#endif
 }

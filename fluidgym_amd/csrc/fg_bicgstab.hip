@@ -20,8 +20,8 @@ constexpr int A_RHO = 0, A_RV = 2, A_SS = 3, A_TS = 4, A_TT = 5, A_RR = 6;
 constexpr int A_RHOE = 10;
 
 template <int DIMS, int VEC>
-__device__ __forceinline__ FgVec<VEC> fg_spmv(const float* __restrict__ diag, const float* __restrict__ off,
-                                              const float* __restrict__ x, const FgCtx<DIMS, VEC>& c, size_t N) {
+__device__ __forceinline__ FgVec<VEC> fg_spmv(const fg_real* __restrict__ diag, const fg_real* __restrict__ off,
+                                              const fg_real* __restrict__ x, const FgCtx<DIMS, VEC>& c, size_t N) {
     // diag/off already offset to the env; x offset to the system
     const FgNbr<DIMS, VEC> X = fg_gather<DIMS, VEC>(x, c);
     const FgVec<VEC> d = fg_load<VEC>(diag + c.idx);
@@ -31,7 +31,7 @@ __device__ __forceinline__ FgVec<VEC> fg_spmv(const float* __restrict__ diag, co
     FgVec<VEC> y;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        float v = d.v[e] * X.c.v[e] + o[0].v[e] * X.xm.v[e] + o[1].v[e] * X.xp.v[e] + o[2].v[e] * X.ym.v[e] +
+        fg_real v = d.v[e] * X.c.v[e] + o[0].v[e] * X.xm.v[e] + o[1].v[e] * X.xp.v[e] + o[2].v[e] * X.ym.v[e] +
                   o[3].v[e] * X.yp.v[e];
         if constexpr (DIMS == 3) v += o[4].v[e] * X.zm.v[e] + o[5].v[e] * X.zp.v[e];
         y.v[e] = v;
@@ -54,9 +54,9 @@ __device__ __forceinline__ SysCtx fg_sys(const FgCtx<DIMS, VEC>& c, int nc, int 
     return s;
 }
 
-__device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
+__device__ __forceinline__ fg_real fg_rms(double rr, int n) { return (fg_real)sqrt(rr / (double)n); }
 
-__device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int sys, float crit, int it) {
+__device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int sys, fg_real crit, int it) {
     const bool finite = isfinite(crit);
     flag_st(flags + (sys), finite ? 1 : 2);
     info[sys].final_residual = crit;
@@ -66,13 +66,13 @@ __device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int
 }
 
 struct BicgPtrs {
-    const float* diag; const float* off; const float* rhs;
-    float* x; float* r; float* rw; float* p; float* v; float* t;
-    FgDacc* acc; float* sc; int32_t* flags; fg_solve_info* info;
-    int nc; float tol;
+    const fg_real* diag; const fg_real* off; const fg_real* rhs;
+    fg_real* x; fg_real* r; fg_real* rw; fg_real* p; fg_real* v; fg_real* t;
+    FgDacc* acc; fg_real* sc; int32_t* flags; fg_solve_info* info;
+    int nc; fg_real tol;
     // right preconditioning (fg_linepre.hip): when set, v = C mp with mp = M^-1 p, t = C ms with ms = M^-1 s, and the iterate
     // advances along mp / ms; r, s and every dot product are those of C M^-1, so r stays the true residual of C x = rhs
-    const float* mp; const float* ms;
+    const fg_real* mp; const fg_real* ms;
 };
 
 // SpMV with the matrix held in registers: the (1 + 2 DIMS) coefficient fields belong to the env, not to the system,
@@ -84,8 +84,8 @@ struct FgStencilRow {
     FgVec<VEC> d, o[2 * DIMS];
 };
 template <int DIMS, int VEC>
-__device__ __forceinline__ FgStencilRow<DIMS, VEC> fg_load_row(const float* __restrict__ diag,
-                                                              const float* __restrict__ off,
+__device__ __forceinline__ FgStencilRow<DIMS, VEC> fg_load_row(const fg_real* __restrict__ diag,
+                                                              const fg_real* __restrict__ off,
                                                               const FgCtx<DIMS, VEC>& c, size_t N) {
     FgStencilRow<DIMS, VEC> m;
     m.d = fg_load<VEC>(diag + c.idx);
@@ -94,13 +94,13 @@ __device__ __forceinline__ FgStencilRow<DIMS, VEC> fg_load_row(const float* __re
     return m;
 }
 template <int DIMS, int VEC>
-__device__ __forceinline__ FgVec<VEC> fg_apply_row(const FgStencilRow<DIMS, VEC>& m, const float* __restrict__ x,
+__device__ __forceinline__ FgVec<VEC> fg_apply_row(const FgStencilRow<DIMS, VEC>& m, const fg_real* __restrict__ x,
                                                    const FgCtx<DIMS, VEC>& c) {
     const FgNbr<DIMS, VEC> X = fg_gather<DIMS, VEC>(x, c);
     FgVec<VEC> y;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        float v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
+        fg_real v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
                   m.o[3].v[e] * X.yp.v[e];
         if constexpr (DIMS == 3) v += m.o[4].v[e] * X.zm.v[e] + m.o[5].v[e] * X.zp.v[e];
         y.v[e] = v;
@@ -119,12 +119,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_init(FgGrid g, BicgPtrs q, in
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (use_x0 && c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
-    __shared__ float lds[4];
+    __shared__ fg_real lds[4];
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
         if (flag_ld(q.flags + (sys)) != 0) continue;
         const size_t vb = (size_t)sys * N;
-        float part[1] = {0.f};
+        fg_real part[1] = {0.f};
         if (c.valid) {
             FgVec<VEC> r = fg_load<VEC>(q.rhs + vb + c.idx);
             if (use_x0) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int i
     }
     if (f != 0) return;
     FgDacc* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float crit = fg_rms(acc_ld(a + (A_RR)), g.n);
+    const fg_real crit = fg_rms(acc_ld(a + (A_RR)), g.n);
     if (!(crit >= q.tol)) {
         if (s.leader) fg_mark(q.flags, q.info, s.sys, crit, it == 0 ? -1 : it);
         return;
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_p(FgGrid g, BicgPtrs q, int i
         q.info[s.sys].final_residual = crit;
         q.info[s.sys].used_iterations = it - 1;
     }
-    const float alpha = sc_ld(q.sc + (s.sys * 2 + 0)), omega = sc_ld(q.sc + (s.sys * 2 + 1));
+    const fg_real alpha = sc_ld(q.sc + (s.sys * 2 + 0)), omega = sc_ld(q.sc + (s.sys * 2 + 1));
     const double rho_now = acc_ld(a + (A_RHO + (it & 1)));
-    const float beta = it == 0 ? 0.f : (float)(rho_now / acc_ld(a + (A_RHOE + ((it + 1) & 1)))) * (alpha / omega);
+    const fg_real beta = it == 0 ? 0.f : (fg_real)(rho_now / acc_ld(a + (A_RHOE + ((it + 1) & 1)))) * (alpha / omega);
     const bool restart = it > 0 && !isfinite(beta);   // rho of the previous iteration exactly 0, or omega 0: rw = p = r, rho = r.r
     if (s.leader) acc_st(a + (A_RHOE + (it & 1)), restart ? acc_ld(a + (A_RR)) : rho_now);
     if (it == 0 || !c.valid) return;
@@ -207,12 +207,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_v(FgGrid g, BicgPtrs q, int i
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
-    __shared__ float lds[4];
+    __shared__ fg_real lds[4];
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
         if (flag_ld(q.flags + (sys)) != 0) continue;  // uniform over the workgroup
         const size_t vb = (size_t)sys * N;
-        float part[1] = {0.f};
+        fg_real part[1] = {0.f};
         if (c.valid) {
             const FgVec<VEC> y = fg_apply_row<DIMS, VEC>(m, (q.mp ? q.mp : q.p) + vb, c);
             const FgVec<VEC> rw = fg_load<VEC>(q.rw + vb + c.idx);
@@ -234,16 +234,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_s(FgGrid g, BicgPtrs q, int i
     const SysCtx s = fg_sys<DIMS, VEC>(c, q.nc, tiles);
     if (flag_ld(q.flags + (s.sys)) != 0) return;
     FgDacc* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
-    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
+    const fg_real alpha_raw = (fg_real)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const fg_real alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
     if (s.leader) {
         sc_st(q.sc + (s.sys * 2 + 0), alpha);
         acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0);  // rho slot of the next iteration
         acc_st(a + (A_RR), 0.0);                    // read by Kp_i / K2_i, re-accumulated by K5_i
     }
     const size_t vb = (size_t)s.sys * g.n;
-    __shared__ float lds[4];
-    float part[1] = {0.f};
+    __shared__ fg_real lds[4];
+    fg_real part[1] = {0.f};
     if (c.valid) {
         FgVec<VEC> r = fg_load<VEC>(q.r + vb + c.idx);
         const FgVec<VEC> v = fg_load<VEC>(q.v + vb + c.idx);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int i
         const int sys = c.b * q.nc + comp;
         if (flag_ld(q.flags + (sys)) != 0) continue;
         FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-        const float crit_s = fg_rms(acc_ld(a + (A_SS)), g.n);
+        const fg_real crit_s = fg_rms(acc_ld(a + (A_SS)), g.n);
         if (!(crit_s >= q.tol)) {
             // converged on s (bicgstab_solver_kernel.cu:305-329): flag 4 = "K5 applies x += alpha p, then done".
             // Nothing in THIS launch depends on the flag value written here (every workgroup of the env takes this
@@ -291,13 +291,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int i
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
-    __shared__ float lds[8];
+    __shared__ fg_real lds[8];
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
         if (comp >= q.nc || !work[comp]) continue;
         const int sys = c.b * q.nc + comp;
         const size_t vb = (size_t)sys * N;
-        float part[2] = {0.f, 0.f};
+        fg_real part[2] = {0.f, 0.f};
         if (c.valid) {
             const FgVec<VEC> t = fg_apply_row<DIMS, VEC>(m, (q.ms ? q.ms : q.r) + vb, c);
             const FgVec<VEC> sv = fg_load<VEC>(q.r + vb + c.idx);
@@ -327,17 +327,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
     const int f = flag_ld(q.flags + (s.sys));  // stable during this launch: K5 never writes flags
     if (f != 0 && f != 4) return;
     FgDacc* a = q.acc + (size_t)s.sys * FG_ACC_DOUBLES;
-    const float alpha = sc_ld(q.sc + (s.sys * 2 + 0));
+    const fg_real alpha = sc_ld(q.sc + (s.sys * 2 + 0));
     const bool half = (f == 4);
-    const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / acc_ld(a + (A_TT)));
-    const float omega = isfinite(omega_raw) ? omega_raw : 0.f;
+    const fg_real omega_raw = half ? 0.f : (fg_real)(acc_ld(a + (A_TS)) / acc_ld(a + (A_TT)));
+    const fg_real omega = isfinite(omega_raw) ? omega_raw : 0.f;
     if (s.leader) {
         sc_st(q.sc + (s.sys * 2 + 1), omega);
         acc_st(a + (A_RV), 0.0);
     }
     const size_t vb = (size_t)s.sys * g.n;
-    __shared__ float lds[8];
-    float part[2] = {0.f, 0.f};
+    __shared__ fg_real lds[8];
+    fg_real part[2] = {0.f, 0.f};
     if (c.valid) {
         FgVec<VEC> x = fg_load<VEC>(q.x + vb + c.idx);
         const FgVec<VEC> p = fg_load<VEC>((q.mp ? q.mp : q.p) + vb + c.idx);
@@ -392,7 +392,7 @@ constexpr int F_RV = 0, F_RR = 2, F_SS = 4, F_TS = 6, F_TT = 8, F_RS = 10, F_RT 
 static_assert(F_RHOE + 2 <= FG_ACC_DOUBLES, "fused BiCGStab accumulators");
 
 struct BicgFused {
-    float* s; float* p[2]; float* v[2];   // s buffer; p / v of iteration i in p[i & 1] / v[i & 1]
+    fg_real* s; fg_real* p[2]; fg_real* v[2];   // s buffer; p / v of iteration i in p[i & 1] / v[i & 1]
 };
 
 template <int DIMS, int VEC>
@@ -400,7 +400,7 @@ __device__ __forceinline__ FgVec<VEC> fg_apply_nbr(const FgStencilRow<DIMS, VEC>
     FgVec<VEC> y;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        float v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
+        fg_real v = m.d.v[e] * X.c.v[e] + m.o[0].v[e] * X.xm.v[e] + m.o[1].v[e] * X.xp.v[e] + m.o[2].v[e] * X.ym.v[e] +
                   m.o[3].v[e] * X.yp.v[e];
         if constexpr (DIMS == 3) v += m.o[4].v[e] * X.zm.v[e] + m.o[5].v[e] * X.zp.v[e];
         y.v[e] = v;
@@ -409,7 +409,7 @@ __device__ __forceinline__ FgVec<VEC> fg_apply_nbr(const FgStencilRow<DIMS, VEC>
 }
 // out = a + ca * b at the cell and all its neighbours
 template <int DIMS, int VEC>
-__device__ __forceinline__ void fg_nbr_axpy(FgNbr<DIMS, VEC>& a, float cb, const FgNbr<DIMS, VEC>& b) {
+__device__ __forceinline__ void fg_nbr_axpy(FgNbr<DIMS, VEC>& a, fg_real cb, const FgNbr<DIMS, VEC>& b) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         a.c.v[e] += cb * b.c.v[e]; a.xm.v[e] += cb * b.xm.v[e]; a.xp.v[e] += cb * b.xp.v[e];
@@ -418,7 +418,7 @@ __device__ __forceinline__ void fg_nbr_axpy(FgNbr<DIMS, VEC>& a, float cb, const
     }
 }
 template <int DIMS, int VEC>
-__device__ __forceinline__ void fg_nbr_scale_add(FgNbr<DIMS, VEC>& a, float ca, const FgNbr<DIMS, VEC>& b) {  // a = b + ca * a
+__device__ __forceinline__ void fg_nbr_scale_add(FgNbr<DIMS, VEC>& a, fg_real ca, const FgNbr<DIMS, VEC>& b) {  // a = b + ca * a
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         a.c.v[e] = b.c.v[e] + ca * a.c.v[e]; a.xm.v[e] = b.xm.v[e] + ca * a.xm.v[e]; a.xp.v[e] = b.xp.v[e] + ca * a.xp.v[e];
@@ -438,12 +438,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_init(FgGrid g, BicgPtrs q, B
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (use_x0 && c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
-    __shared__ float lds[4];
+    __shared__ fg_real lds[4];
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
         if (flag_ld(q.flags + (sys)) != 0) continue;
         const size_t vb = (size_t)sys * N;
-        float part[1] = {0.f};
+        fg_real part[1] = {0.f};
         if (c.valid) {
             FgVec<VEC> r = fg_load<VEC>(q.rhs + vb + c.idx);
             if (use_x0) {
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
     const int e = it & 1, pe = e ^ 1;
     // per-system decisions, taken by every workgroup of the env from the same accumulator words
     int mode[3] = {0, 0, 0};   // 0 skip | 1 full update | 2 converged on s: x += alpha p only | 3 first iteration: v = C p
-    float alpha[3], omega[3], beta[3];
+    fg_real alpha[3], omega[3], beta[3];
     bool restart[3];
     bool any = false;
     for (int comp = 0; comp < q.nc; ++comp) {
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
             mode[comp] = 3; any = true;
             continue;
         }
-        const float crit_s = fg_rms(acc_ld(a + (F_SS + pe)), g.n);
+        const fg_real crit_s = fg_rms(acc_ld(a + (F_SS + pe)), g.n);
         alpha[comp] = sc_ld(q.sc + (sys * 2 + 0));
         if (!(crit_s >= q.tol)) {   // converged on s (bicgstab_solver_kernel.cu:305-329), or s.s not finite
             const bool fin = isfinite(crit_s);
@@ -511,10 +511,10 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
             if (fin) { mode[comp] = 2; any = true; }
             continue;
         }
-        const float omega_raw = (float)(acc_ld(a + (F_TS + pe)) / acc_ld(a + (F_TT + pe)));
+        const fg_real omega_raw = (fg_real)(acc_ld(a + (F_TS + pe)) / acc_ld(a + (F_TT + pe)));
         omega[comp] = isfinite(omega_raw) ? omega_raw : 0.f;
         const double rho_new = acc_ld(a + (F_RS + pe)) - (double)omega[comp] * acc_ld(a + (F_RT + pe));
-        beta[comp] = (float)(rho_new / acc_ld(a + (F_RHOE + pe))) * (alpha[comp] / omega[comp]);
+        beta[comp] = (fg_real)(rho_new / acc_ld(a + (F_RHOE + pe))) * (alpha[comp] / omega[comp]);
         restart[comp] = !isfinite(beta[comp]);   // rho of the previous iteration exactly 0, or omega 0: rw = p = r, rho = r.r
         if (leader) {
             sc_st(q.sc + (sys * 2 + 1), omega[comp]);
@@ -529,8 +529,8 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
     // dot-product partials of all components, reduced across the workgroup ONCE after the loop (a reduction per component put a
     // barrier between the components and kept the loads of one from overlapping the arithmetic of the other)
-    __shared__ float lds[24];
-    float part[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [comp][rw.v | r.r]
+    __shared__ fg_real lds[24];
+    fg_real part[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [comp][rw.v | r.r]
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
         if (comp >= q.nc || mode[comp] == 0) continue;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
             if (mode[comp] == 3) {
                 P = fg_gather<DIMS, VEC>(w.p[0] + vb, c);
             } else {
-                const float al = alpha[comp], om = omega[comp], be = beta[comp];
+                const fg_real al = alpha[comp], om = omega[comp], be = beta[comp];
                 // r_{it} = s - omega t at the cell and its neighbours
                 FgNbr<DIMS, VEC> R = fg_gather<DIMS, VEC>(w.s + vb, c);
                 {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
     const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
     const int e = it & 1;
     bool work[3] = {false, false, false};
-    float alpha[3] = {0.f, 0.f, 0.f};
+    fg_real alpha[3] = {0.f, 0.f, 0.f};
     bool any = false;
     for (int comp = 0; comp < q.nc; ++comp) {
         const int sys = c.b * q.nc + comp;
@@ -616,14 +616,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
         if (f != 0) continue;
         FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
         const double rr = acc_ld(a + (F_RR + e));
-        const float crit = fg_rms(rr, g.n);
+        const fg_real crit = fg_rms(rr, g.n);
         if (!(crit >= q.tol)) {
             if (leader) fg_mark(q.flags, q.info, sys, crit, it == 0 ? -1 : it);
             continue;
         }
         double rho = acc_ld(a + (F_RHOE + e));
         if (isnan(rho)) rho = rr;                       // breakdown restart decided by k_bicgf_a: rw = r, rho = r.r
-        const float alpha_raw = (float)(rho / acc_ld(a + (F_RV + e)));
+        const fg_real alpha_raw = (fg_real)(rho / acc_ld(a + (F_RV + e)));
         alpha[comp] = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
         if (leader) {
             q.info[sys].final_residual = crit;
@@ -637,8 +637,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
-    __shared__ float lds[60];
-    float part[15];   // [comp][s.s | t.s | t.t | rw.s | rw.t], one workgroup reduction after the loop
+    __shared__ fg_real lds[60];
+    fg_real part[15];   // [comp][s.s | t.s | t.t | rw.s | rw.t], one workgroup reduction after the loop
 #pragma unroll
     for (int k = 0; k < 15; ++k) part[k] = 0.f;
 #pragma unroll
@@ -684,12 +684,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
 // poll after k_bicgf_a(it + 1), i.e. after iteration `it` completed: judges r_{it+1} exactly as k_bicg_check does (the next
 // k_bicgf_b would come to the same verdict from the same accumulator) and mirrors info for the host
 __global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                              fg_solve_info* __restrict__ mirror, float tol, int it, int n, int nsys, int final_pass) {
+                              fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
     if (flag_ld(flags + (s)) == 0) {
-        const float crit = (float)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + F_RR + ((it + 1) & 1))) / (double)n);
+        const fg_real crit = (fg_real)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + F_RR + ((it + 1) & 1))) / (double)n);
         info[s].final_residual = crit;
         info[s].used_iterations = it + 1;
         if (!(crit >= tol)) {
@@ -704,7 +704,7 @@ __global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ fl
     mirror[s] = info[s];
 }
 
-__global__ void k_bicg_begin(const float* __restrict__ dt, FgDacc* __restrict__ acc, float* __restrict__ sc,
+__global__ void k_bicg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict__ acc, fg_real* __restrict__ sc,
                              int32_t* __restrict__ flags, fg_solve_info* __restrict__ info, int nsys, int nc) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
@@ -719,12 +719,12 @@ __global__ void k_bicg_begin(const float* __restrict__ dt, FgDacc* __restrict__ 
 }
 
 __global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                             fg_solve_info* __restrict__ mirror, float tol, int it, int n, int nsys, int final_pass) {
+                             fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
     if (flag_ld(flags + (s)) == 0) {
-        const float crit = (float)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + A_RR)) / (double)n);
+        const fg_real crit = (fg_real)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + A_RR)) / (double)n);
         info[s].final_residual = crit;
         info[s].used_iterations = it + 1;
         if (!(crit >= tol)) {

@@ -1,0 +1,33 @@
+// fp64 build (libfluidgym_hip_f64.so, -DFG_REAL_DOUBLE) only: the kernels that exist in fp32 form alone -- the fast-diagonalisation
+// preconditioner with its MFMA basis changes and LDS FFT, the z-marching 3-D Poisson kernels, the y-line preconditioner -- are not
+// instantiated for double.  The core translation units call them through these definitions: "not available", and the callers fall
+// back to the generic kernels (plain CG, generic stencil kernels, unpreconditioned BiCGStab).
+#include "fg_internal.h"
+
+#if !FG_F64
+#error "fg_f64_stubs.hip belongs to the fp64 build only"
+#endif
+
+bool fg_zmarch_ok(const fg_state*, int*) { return false; }
+int fg_zmarch_apply(const fg_state*, const fg_real*, const fg_real*, fg_real*, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+int fg_zmarch_relax(const fg_state*, const fg_real*, const fg_real*, const fg_real*, fg_real*, fg_real, int, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+int fg_zmarch_cg_ap(const fg_state*, const fg_real*, const fg_real*, const fg_real*, fg_real*, fg_real*, FgDacc*, int32_t*, fg_solve_info*, int,
+                    fg_real, int, int, int, int, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+bool fg_fd_dct_supported(int) { return false; }
+int fg_fd_dct_forward(fg_state*, const fg_real*, fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+int fg_fd_dct_inverse(fg_state*, const fg_real*, fg_real*, const fg_real*, FgDacc*, int, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+int fg_fd_apply(fg_state*, const fg_real*, fg_real*, FgDacc*, int, int, int, hipStream_t) {
+    fg_set_error("the fast-diagonalisation preconditioner is an fp32 kernel family: not part of the fp64 build");
+    return FG_ERR_UNSUPPORTED;
+}
+int fg_line_alloc(fg_state*) {
+    fg_set_error("the y-line preconditioner is an fp32 kernel family: not part of the fp64 build");
+    return FG_ERR_UNSUPPORTED;
+}
+int fg_line_factor(fg_state*, const fg_real*, const fg_real*, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+int fg_line_apply(fg_state*, const fg_real*, const fg_real*, int, const fg_real*, fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+
+extern "C" int fg_set_fd_fast_transform(fg_handle, int, float) {
+    fg_set_error("the fast cosine transform belongs to the fp32 fast-diagonalisation preconditioner: not part of the fp64 build");
+    return FG_ERR_UNSUPPORTED;
+}

@@ -9,6 +9,23 @@
 
 #include "../../include/fluidgym_hip.h"
 
+// fg_real (include/fluidgym_hip.h): float in libfluidgym_hip.so, double in libfluidgym_hip_f64.so (-DFG_REAL_DOUBLE).  The fp32 build is
+// the product the benchmarks run; the fp64 build exists for FluidEnv(dtype=torch.float64) and compiles the core translation units only
+// (fg_api / fg_piso / fg_poisson / fg_bicgstab / fg_profile + fg_f64_stubs), scalar lanes (VEC = 1) throughout.
+#ifdef FG_REAL_DOUBLE
+struct alignas(16) fg_real4 { double x, y, z, w; };   // four consecutive reals (two 16-byte accesses)
+__host__ __device__ __forceinline__ fg_real4 make_fg_real4(double x, double y, double z, double w) { fg_real4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+#define FG_F64 1
+#define FG_FMAX fmax
+#define FG_FABS fabs
+#else
+typedef float4 fg_real4;
+#define make_fg_real4 make_float4
+#define FG_F64 0
+#define FG_FMAX fmaxf
+#define FG_FABS fabsf
+#endif
+
 // The recurrence words of the multi-kernel Krylov solvers (accumulators, alpha / omega, flags) are read and zeroed through
 // acc_ld / acc_st, sc_ld / sc_st, flag_ld / flag_st.  They are plain loads / stores: sums are accumulated with device-scope atomics
 // in one kernel and read in the next, zeroed by a leader workgroup for a later one -- kernel boundaries order all of it.  While the
@@ -58,23 +75,38 @@ static_assert(sizeof(FgDacc) == 64, "one accumulator per 64-byte line segment");
 
 // the split of one contribution and the value of the words: shared by the device accessors and the host self-test
 // (fg_dacc_host_sum), so that what the CPU test checks is what the kernels run
+// (the fp64 build shifts the window down by 2^-30: range 2^45, unit of the last word 2^-122 -- residuals of solves driven to
+//  1e-13 .. 1e-15 stay resolved; FG_REAL_DOUBLE is defined before this header is read)
+#ifdef FG_REAL_DOUBLE
+#define FG_DACC_U0 0x1p4
+#define FG_DACC_U1 0x1p-38
+#define FG_DACC_U2 0x1p-80
+#define FG_DACC_U3 0x1p-122
+#define FG_DACC_LIMIT 0x1p45
+#else
+#define FG_DACC_U0 0x1p34
+#define FG_DACC_U1 0x1p-8
+#define FG_DACC_U2 0x1p-50
+#define FG_DACC_U3 0x1p-92
+#define FG_DACC_LIMIT 0x1p75
+#endif
 __host__ __device__ __forceinline__ bool fg_dacc_split(double v, long long k[4]) {
-    if (!(fabs(v) < 0x1p75)) return false;                      // NaN, Inf or out of range: poison
+    if (!(fabs(v) < FG_DACC_LIMIT)) return false;               // NaN, Inf or out of range: poison
     double r = v;
-    const double k0 = rint(r * 0x1p-34); r -= k0 * 0x1p34;      // exact: r keeps the bits of v below the word
-    const double k1 = rint(r * 0x1p8);   r -= k1 * 0x1p-8;
-    const double k2 = rint(r * 0x1p50);  r -= k2 * 0x1p-50;
-    const double k3 = rint(r * 0x1p92);                         // bits below 2^-93 are dropped (the same ones in any order)
+    const double k0 = rint(r * (1.0 / FG_DACC_U0)); r -= k0 * FG_DACC_U0;      // exact: r keeps the bits of v below the word
+    const double k1 = rint(r * (1.0 / FG_DACC_U1)); r -= k1 * FG_DACC_U1;
+    const double k2 = rint(r * (1.0 / FG_DACC_U2)); r -= k2 * FG_DACC_U2;
+    const double k3 = rint(r * (1.0 / FG_DACC_U3));                            // bits below half the last unit are dropped (the same ones in any order)
     k[0] = (long long)k0; k[1] = (long long)k1; k[2] = (long long)k2; k[3] = (long long)k3;
     return true;
 }
 __host__ __device__ __forceinline__ double fg_dacc_value(unsigned long long w0, unsigned long long w1, unsigned long long w2,
                                                          unsigned long long w3, unsigned long long poison, double plain) {
     // smallest unit first; every conversion and addition is a fixed sequence on the same integer words
-    double t = (double)(long long)w3 * 0x1p-92;
-    t += (double)(long long)w2 * 0x1p-50;
-    t += (double)(long long)w1 * 0x1p-8;
-    t += (double)(long long)w0 * 0x1p34;
+    double t = (double)(long long)w3 * FG_DACC_U3;
+    t += (double)(long long)w2 * FG_DACC_U2;
+    t += (double)(long long)w1 * FG_DACC_U1;
+    t += (double)(long long)w0 * FG_DACC_U0;
     t += plain;
     return poison ? (double)NAN : t;
 }
@@ -98,8 +130,8 @@ __device__ __forceinline__ void acc_add(FgDacc* p, double v) {
         if (k[i] != 0) atomicAdd(&p->w[i], (unsigned long long)k[i]);
 }
 
-__device__ __forceinline__ float sc_ld(const float* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
-__device__ __forceinline__ void sc_st(float* p, float v) { fg_word_st(p, v, (FG_FLAG_ACCESS & 2) != 0); }
+__device__ __forceinline__ fg_real sc_ld(const fg_real* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
+__device__ __forceinline__ void sc_st(fg_real* p, fg_real v) { fg_word_st(p, v, (FG_FLAG_ACCESS & 2) != 0); }
 __device__ __forceinline__ int32_t flag_ld(const int32_t* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
 __device__ __forceinline__ void flag_st(int32_t* p, int32_t v) { fg_word_st(p, v, (FG_FLAG_ACCESS & 2) != 0); }
 
@@ -115,13 +147,13 @@ struct FgGrid {
     int n;        // cells per env
     int B;        // env batch
     int fixed[6]; // 1 = FIXED (prescribed) face, 0 = periodic
-    const float* h[3];  // cell widths per axis (device), length nx / ny / nz
-    const float* rh[3]; // reciprocals
+    const fg_real* h[3];  // cell widths per axis (device), length nx / ny / nz
+    const fg_real* rh[3]; // reciprocals
 };
 
 struct FgBounds {
-    const float* vel[6];    // [B,d,slab] or nullptr (periodic)
-    const float* scal[6];   // [B,C,slab] or nullptr
+    const fg_real* vel[6];    // [B,d,slab] or nullptr (periodic)
+    const fg_real* scal[6];   // [B,C,slab] or nullptr
     int scalar_bc[6];       // FG_DIRICHLET / FG_NEUMANN for the channel being processed
 };
 
@@ -158,11 +190,11 @@ inline FgLaunch fg_launch_geometry(const FgGrid& g) {
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
 struct FgVec {
-    float v[VEC];
+    fg_real v[VEC];
 };
 
 template <int VEC>
-__device__ __forceinline__ FgVec<VEC> fg_load(const float* __restrict__ p) {
+__device__ __forceinline__ FgVec<VEC> fg_load(const fg_real* __restrict__ p) {
     FgVec<VEC> r;
     if constexpr (VEC == 4) {
         const float4 t = *reinterpret_cast<const float4*>(p);
@@ -173,7 +205,7 @@ __device__ __forceinline__ FgVec<VEC> fg_load(const float* __restrict__ p) {
     return r;
 }
 template <int VEC>
-__device__ __forceinline__ void fg_store(float* __restrict__ p, const FgVec<VEC>& r) {
+__device__ __forceinline__ void fg_store(fg_real* __restrict__ p, const FgVec<VEC>& r) {
     if constexpr (VEC == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
     } else {
@@ -203,7 +235,7 @@ struct FgCtx {
     int ixm, ixp;   // linear index of the -x neighbour of element 0 / +x neighbour of element VEC-1
     int iym, iyp, izm, izp; // linear index of the vector start in the neighbouring rows
     // face masks (1 = face has a neighbour: interior or periodic; 0 = prescribed face)
-    float mxm, mxp, mym, myp, mzm, mzp;
+    fg_real mxm, mxp, mym, myp, mzm, mzp;
 };
 
 template <int DIMS, int VEC>
@@ -277,11 +309,11 @@ struct FgNbr {
 };
 
 template <int DIMS, int VEC>
-__device__ __forceinline__ FgNbr<DIMS, VEC> fg_gather(const float* __restrict__ q, const FgCtx<DIMS, VEC>& c) {
+__device__ __forceinline__ FgNbr<DIMS, VEC> fg_gather(const fg_real* __restrict__ q, const FgCtx<DIMS, VEC>& c) {
     FgNbr<DIMS, VEC> n;
     n.c = fg_load<VEC>(q + c.idx);
-    const float left = q[c.ixm];
-    const float right = q[c.ixp];
+    const fg_real left = q[c.ixm];
+    const fg_real right = q[c.ixp];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         n.xm.v[e] = (e == 0) ? left : n.c.v[e - 1];
@@ -298,12 +330,12 @@ __device__ __forceinline__ FgNbr<DIMS, VEC> fg_gather(const float* __restrict__ 
 
 // only the neighbours along one axis (used for fluxes of one velocity component)
 template <int DIMS, int VEC>
-__device__ __forceinline__ void fg_gather_axis(const float* __restrict__ q, const FgCtx<DIMS, VEC>& c, int axis,
+__device__ __forceinline__ void fg_gather_axis(const fg_real* __restrict__ q, const FgCtx<DIMS, VEC>& c, int axis,
                                                FgVec<VEC>& ctr, FgVec<VEC>& lo, FgVec<VEC>& hi) {
     ctr = fg_load<VEC>(q + c.idx);
     if (axis == 0) {
-        const float left = q[c.ixm];
-        const float right = q[c.ixp];
+        const fg_real left = q[c.ixm];
+        const fg_real right = q[c.ixp];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             lo.v[e] = (e == 0) ? left : ctr.v[e - 1];
@@ -323,10 +355,10 @@ __device__ __forceinline__ void fg_gather_axis(const float* __restrict__ q, cons
 // across each face.
 template <int DIMS, int VEC>
 struct FgMetric {
-    float hx[VEC], rhx[VEC];
-    float rhx_m, rhx_p;   // 1/hx of the -x neighbour of element 0 / +x neighbour of element VEC-1
-    float hy, rhy, rhy_m, rhy_p;
-    float hz, rhz, rhz_m, rhz_p;
+    fg_real hx[VEC], rhx[VEC];
+    fg_real rhx_m, rhx_p;   // 1/hx of the -x neighbour of element 0 / +x neighbour of element VEC-1
+    fg_real hy, rhy, rhy_m, rhy_p;
+    fg_real hz, rhz, rhz_m, rhz_p;
 };
 
 template <int DIMS, int VEC>
@@ -355,22 +387,22 @@ __device__ __forceinline__ FgMetric<DIMS, VEC> fg_metrics(const FgGrid& g, const
 }
 
 // wave64 + workgroup sum; result valid in thread 0
-__device__ __forceinline__ float fg_wave_sum(float v) {
+__device__ __forceinline__ fg_real fg_wave_sum(fg_real v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float fg_wave_max(float v) {
+__device__ __forceinline__ fg_real fg_wave_max(fg_real v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    for (int o = 32; o > 0; o >>= 1) v = FG_FMAX(v, __shfl_down(v, o, 64));
     return v;
 }
 template <int NV>
-__device__ __forceinline__ void fg_block_sum(float (&v)[NV], float* lds /* >= NV*4 floats */) {
+__device__ __forceinline__ void fg_block_sum(fg_real (&v)[NV], fg_real* lds /* >= NV*4 floats */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-        const float s = fg_wave_sum(v[q]);
+        const fg_real s = fg_wave_sum(v[q]);
         if (lane == 0) lds[q * 4 + wave] = s;
     }
     __syncthreads();
@@ -412,17 +444,17 @@ struct FgProf {
 // (k_cg_update of iteration it) writes the old x to best_x -- no extra read, one extra store per cell for the envs concerned.  A solve that ends
 // unconverged (max iterations, or fp32 stagnation followed by divergence) gets the kept iterate back (within 2x of the lowest residual reached).
 struct FgBest {
-    float* best_crit;   // [B] residual of the last kept iterate (leader-only state)
-    float* saved_crit;  // [B] residual of the iterate held in best_x (+inf: none)
+    fg_real* best_crit;   // [B] residual of the last kept iterate (leader-only state)
+    fg_real* saved_crit;  // [B] residual of the iterate held in best_x (+inf: none)
     int32_t* save_at;   // [B] iteration whose k_cg_update stores x before updating it
-    float* best_x;      // [B, N]
+    fg_real* best_x;      // [B, N]
 };
 #ifdef __HIPCC__
 // Called by the ONE leader thread of the stencil kernel of iteration `it`, which has just derived crit = RMS residual of
 // x_it: keep x_it when it beats the last kept iterate by a factor of two (a healthy solve then pays one extra store pass
 // every few iterations, not every iteration -- at 256^3 the every-improvement rule cost 11 % of the CG iteration -- and a
 // failed solve gets back an iterate within 2x of the lowest residual it reached).
-__device__ __forceinline__ void fg_best_decide(const FgBest& best, int b, float crit, int it) {
+__device__ __forceinline__ void fg_best_decide(const FgBest& best, int b, fg_real crit, int it) {
     if (it >= 1 && crit < 0.5f * best.best_crit[b]) {
         best.best_crit[b] = crit;
         best.saved_crit[b] = crit;
@@ -457,36 +489,36 @@ struct fg_state {
     fg_config cfg;
     FgGrid grid;
     int vec;  // 4 if nx % 4 == 0 else 1
-    float viscosity;
-    float scalar_viscosity[FG_MAX_SCALARS];
+    fg_real viscosity;
+    fg_real scalar_viscosity[FG_MAX_SCALARS];
     bool scalar_viscosity_set;
     // metrics (owned)
-    float* d_h[3];
-    float* d_rh[3];
+    fg_real* d_h[3];
+    fg_real* d_rh[3];
     // bound (borrowed) fields
-    float* velocity;
-    float* pressure;
-    float* scalar;
-    float* velocity_source;
-    float* bvel[6];
-    float* bscal[6];
+    fg_real* velocity;
+    fg_real* pressure;
+    fg_real* scalar;
+    fg_real* velocity_source;
+    fg_real* bvel[6];
+    fg_real* bscal[6];
     // owned solver workspace
-    float* A;          // [B,N]
-    float* rA;         // [B,N]
-    float* Coff;       // [B,2d,N]
-    float* adv_rhs;    // [B,d,N]
-    float* vel_result; // [B,d,N]
-    float* hvec;       // [B,d,N]   pressureRHS
-    float* div;        // [B,N]     pressureRHSdiv
-    float* p_result;   // [B,N]
-    float* scal_result;// [B,N]
-    float* w[8];       // Krylov work vectors, each [B,d,N]
+    fg_real* A;          // [B,N]
+    fg_real* rA;         // [B,N]
+    fg_real* Coff;       // [B,2d,N]
+    fg_real* adv_rhs;    // [B,d,N]
+    fg_real* vel_result; // [B,d,N]
+    fg_real* hvec;       // [B,d,N]   pressureRHS
+    fg_real* div;        // [B,N]     pressureRHSdiv
+    fg_real* p_result;   // [B,N]
+    fg_real* scal_result;// [B,N]
+    fg_real* w[8];       // Krylov work vectors, each [B,d,N]
     FgDacc* acc;       // [B*d][FG_ACC_DOUBLES] reduction accumulators (order-independent, FgDacc)
     int32_t* flags;    // [B*d] convergence flags (device)
     fg_solve_info* info_dev;   // [B*d]
     fg_solve_info* info_pinned;// [B*d] host-pinned mirror
     int32_t* flags_pinned;
-    float* scratch_B;  // [B*(4+2d)] small per-env floats
+    fg_real* scratch_B;  // [B*(4+2d)] small per-env floats
     FgProf prof;
     FgDacc* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
     FgBest cg_best;               // best-iterate tracking of the CG (returnBestResult, cg_solver_kernel.cu:345-361)
@@ -498,18 +530,18 @@ struct fg_state {
     int adv_precond; long long line_retries;
     int cg_wgs_per_slot;          // workgroups sharing one CG accumulator slot (256; FG_CG_WGS_PER_SLOT at fg_create: tuning)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
-    float* line_inv; float* line_cp;
+    fg_real* line_inv; fg_real* line_cp;
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
-    float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;
+    float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;   // (fp32 kernels only)
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs
     int fd_dct_x; float2* fd_dct_tw; float2* fd_dct_rot; float fd_dct_fwd[2]; float fd_dct_inv[2];
-    float** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
-    float* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
-    float* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
-    float* dt_dev;         // [B]
+    fg_real** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
+    fg_real* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
+    fg_real* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
+    fg_real* dt_dev;         // [B]
     int pred_bicg, pred_cg; // iterations the last solves needed (first convergence poll is scheduled there)
     FgCounters ctr;         // iterations per solve kind since the last reset (fg_solver_counters)
-    const float* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
+    const fg_real* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     size_t n_cells() const { return (size_t)grid.n; }
 };
 
@@ -532,6 +564,14 @@ void fg_set_error(const std::string& msg);
     } while (0)
 
 // dims / vector-width dispatch for templated launches; the body sees constexpr DIMS and VEC
+#if FG_F64
+// fp64 build: scalar lanes only (the float4 paths of fg_load / fg_store are fp32 idioms)
+#define FG_DISPATCH(s, ...)                                                       \
+    do {                                                                          \
+        if ((s)->grid.dims == 2) { constexpr int DIMS = 2, VEC = 1; __VA_ARGS__; } \
+        else { constexpr int DIMS = 3, VEC = 1; __VA_ARGS__; }                    \
+    } while (0)
+#else
 #define FG_DISPATCH(s, ...)                                                       \
     do {                                                                          \
         if ((s)->grid.dims == 2) {                                                \
@@ -542,48 +582,49 @@ void fg_set_error(const std::string& msg);
             else { constexpr int DIMS = 3, VEC = 1; __VA_ARGS__; }                \
         }                                                                         \
     } while (0)
+#endif
 
 // launchers implemented in the kernel translation units -----------------------------------------
 struct FgAdvArgs {
-    const float* vel;      // u^n [B,d,N]
-    const float* scal;     // T channel [B,?] base of the channel being advected (stride given)
+    const fg_real* vel;      // u^n [B,d,N]
+    const fg_real* scal;     // T channel [B,?] base of the channel being advected (stride given)
     long scal_env_stride;  // elements between envs in `scal`
-    const float* source;   // velocity source [B,d,N] or nullptr
-    const float* dt;       // [B]
-    float nu;              // viscosity (or scalar diffusivity)
+    const fg_real* source;   // velocity source [B,d,N] or nullptr
+    const fg_real* dt;       // [B]
+    fg_real nu;              // viscosity (or scalar diffusivity)
     int for_scalar;
     int channel, n_scalars;
-    float* A; float* Coff; float* rhs;
-    float* rA;             // optional: 1/A written alongside A (velocity system only)
+    fg_real* A; fg_real* Coff; fg_real* rhs;
+    fg_real* rA;             // optional: 1/A written alongside A (velocity system only)
 };
 int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
-int fg_launch_pressure_setup(const fg_state* s, const float* dt, hipStream_t st);  // rA = 1/A
-int fg_launch_h(const fg_state* s, const float* dt, const float* vel_result, hipStream_t st);
-int fg_launch_div(const fg_state* s, const FgBounds& bnd, const float* dt, const float* hvec, float* div, hipStream_t st);
-int fg_launch_correct(const fg_state* s, const float* dt, const float* rA, const float* hvec, const float* p,
-                      float* vel_out, hipStream_t st);
+int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t st);  // rA = 1/A
+int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st);
+int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, hipStream_t st);
+int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
+                      fg_real* vel_out, hipStream_t st);
 // mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be
 // scratch_B + B, whose next row holds the arrival counters)
-int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st, float* mirror_B = nullptr);
-int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st);
-int fg_launch_copy_active(const fg_state* s, const float* dt, const float* src, float* dst, int comps, hipStream_t st);
-int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long t_env_stride, float* source, int axis,
-                       float factor, hipStream_t st);
-int fg_launch_outflow(const fg_state* s, int face, float velm_axis, const float* dt, hipStream_t st);
-int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, float atol, const float* dt, hipStream_t st);
-int fg_launch_mean_sub(const fg_state* s, const float* active_dt, float* p, float* p_copy, hipStream_t st);
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B = nullptr);
+int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st);
+int fg_launch_copy_active(const fg_state* s, const fg_real* dt, const fg_real* src, fg_real* dst, int comps, hipStream_t st);
+int fg_launch_buoyancy(const fg_state* s, const fg_real* dt, const fg_real* T, long t_env_stride, fg_real* source, int axis,
+                       fg_real factor, hipStream_t st);
+int fg_launch_outflow(const fg_state* s, int face, fg_real velm_axis, const fg_real* dt, hipStream_t st);
+int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st);
+int fg_launch_mean_sub(const fg_state* s, const fg_real* active_dt, fg_real* p, fg_real* p_copy, hipStream_t st);
 
 // Poisson / CG (fg_poisson.hip)
-int fg_poisson_apply_launch(const fg_state* s, const float* rA, const float* x, float* y, hipStream_t st);
-int fg_poisson_jacobi_launch(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew,
-                             float omega, hipStream_t st);
-int fg_poisson_rbgs_launch(const fg_state* s, const float* rA, const float* b, float* x, float omega, int color,
+int fg_poisson_apply_launch(const fg_state* s, const fg_real* rA, const fg_real* x, fg_real* y, hipStream_t st);
+int fg_poisson_jacobi_launch(const fg_state* s, const fg_real* rA, const fg_real* b, const fg_real* x, fg_real* xnew,
+                             fg_real omega, hipStream_t st);
+int fg_poisson_rbgs_launch(const fg_state* s, const fg_real* rA, const fg_real* b, fg_real* x, fg_real omega, int color,
                            hipStream_t st);
 struct FgCgArgs {
-    const float* rA; const float* b; float* x;
-    float* r; float* p; float* Ap;
-    const float* dt;   // [B] activity mask (nullptr = all active)
-    float tol; int max_iterations; int use_x0; int reset_steps;
+    const fg_real* rA; const fg_real* b; fg_real* x;
+    fg_real* r; fg_real* p; fg_real* Ap;
+    const fg_real* dt;   // [B] activity mask (nullptr = all active)
+    fg_real tol; int max_iterations; int use_x0; int reset_steps;
     int check_every;
     int precond;   // 1: fast-diagonalisation preconditioned CG (needs fg_set_fd_preconditioner)
 };
@@ -591,22 +632,22 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
 
 // BiCGStab on the stencil-form advection matrix (fg_bicgstab.hip)
 struct FgBicgArgs {
-    const float* diag; const float* off;  // [B,N], [B,2d,N]
-    const float* rhs; float* x;           // [B,nc,N]
+    const fg_real* diag; const fg_real* off;  // [B,N], [B,2d,N]
+    const fg_real* rhs; fg_real* x;           // [B,nc,N]
     int nc;
-    const float* dt;
-    float tol; int max_iterations; int use_x0;
+    const fg_real* dt;
+    fg_real tol; int max_iterations; int use_x0;
     int precond = 0;   // 1: right-preconditioned by the y-line solve of fg_linepre.hip (v = C M^-1 p, t = C M^-1 s)
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
 
 // z-marching 3-D variants (fg_poisson3d.hip)
 bool fg_zmarch_ok(const fg_state* s, int* zc_out);
-int fg_zmarch_apply(const fg_state* s, const float* rA, const float* x, float* y, int zc, hipStream_t st);
-int fg_zmarch_relax(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew, float omega,
+int fg_zmarch_apply(const fg_state* s, const fg_real* rA, const fg_real* x, fg_real* y, int zc, hipStream_t st);
+int fg_zmarch_relax(const fg_state* s, const fg_real* rA, const fg_real* b, const fg_real* x, fg_real* xnew, fg_real omega,
                     int color, int zc, hipStream_t st);
-int fg_zmarch_cg_ap(const fg_state* s, const float* rA, const float* z, const float* p_in, float* p_out, float* Ap,
-                    FgDacc* acc, int32_t* flags, fg_solve_info* info, int prof_slot, float tol, int it, int first,
+int fg_zmarch_cg_ap(const fg_state* s, const fg_real* rA, const fg_real* z, const fg_real* p_in, fg_real* p_out, fg_real* Ap,
+                    FgDacc* acc, int32_t* flags, fg_solve_info* info, int prof_slot, fg_real tol, int it, int first,
                     int ns, int num_base, int zc, hipStream_t st);
 // profiler (fg_profile.hip).  fg_prof_slot returns an event-pair slot when this launch is to be sampled (-1 otherwise);
 // flags == nullptr means all nsys systems are active; flags == FG_PROF_SELF means the sampled kernel itself adds
@@ -618,8 +659,8 @@ int fg_prof_slot(const fg_state* s, int kind, const int32_t* flags, int nsys, do
 int fg_prof_collect(fg_state* s, hipStream_t st);
 void fg_prof_destroy(fg_state* s);
 bool fg_fd_dct_supported(int n);
-int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st);
-int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, FgDacc* dot_acc, int dot_stride,
+int fg_fd_dct_forward(fg_state* s, const fg_real* r, fg_real* out, hipStream_t st);
+int fg_fd_dct_inverse(fg_state* s, const fg_real* u, fg_real* z, const fg_real* dot_with, FgDacc* dot_acc, int dot_stride,
                       int dot_ns, hipStream_t st);
 #define FG_LAUNCH_P(s, slot, kernel, grid, block, shmem, st, ...)                                              \
     do {                                                                                                       \
@@ -631,11 +672,11 @@ int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_wi
             hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                   \
     } while (0)
 // expect_active: the caller's estimate of envs still iterating (<= 0: all) -- only picks the GEMM tile shape
-int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
+int fg_fd_apply(fg_state* s, const fg_real* r, fg_real* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st);
 // y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
 // with a live system, z = M^-1 r for every live system
 int fg_line_alloc(fg_state* s);
-int fg_line_factor(fg_state* s, const float* diag, const float* off, int nc, hipStream_t st);
-int fg_line_apply(fg_state* s, const float* diag, const float* off, int nc, const float* r, float* z, hipStream_t st);
+int fg_line_factor(fg_state* s, const fg_real* diag, const fg_real* off, int nc, hipStream_t st);
+int fg_line_apply(fg_state* s, const fg_real* diag, const fg_real* off, int nc, const fg_real* r, fg_real* z, hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

@@ -10,7 +10,7 @@
 namespace {
 
 template <int VEC>
-__device__ __forceinline__ float fg_elem_mask(int e, float lo_mask_or_hi, bool is_edge_elem) {
+__device__ __forceinline__ fg_real fg_elem_mask(int e, fg_real lo_mask_or_hi, bool is_edge_elem) {
     return is_edge_elem ? lo_mask_or_hi : 1.f;
 }
 
@@ -39,16 +39,16 @@ template <int DIMS, int VEC, bool SCALAR>
 __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, FgAdvArgs a, int tiles_x,
                                                          int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    const float dt = a.dt[c.b];
+    const fg_real dt = a.dt[c.b];
     if (!(dt > 0.f) || !c.valid) return;
     const size_t N = g.n;
-    const float* __restrict__ vel = a.vel + (size_t)c.b * DIMS * N;
+    const fg_real* __restrict__ vel = a.vel + (size_t)c.b * DIMS * N;
     const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
-    const float nu = a.nu;
-    const float rdt = 1.f / dt;
+    const fg_real nu = a.nu;
+    const fg_real rdt = 1.f / dt;
 
-    float J[VEC], diag[VEC], off[2 * DIMS][VEC];
-    float bsum[SCALAR ? 1 : DIMS][VEC];
+    fg_real J[VEC], diag[VEC], off[2 * DIMS][VEC];
+    fg_real bsum[SCALAR ? 1 : DIMS][VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         J[e] = m.hx[e] * m.hy * m.hz;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
         const int slab_n = fg_slab_size(g, ax);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float area, rh_p, rh_lo, rh_hi, mask_lo, mask_hi;
+            fg_real area, rh_p, rh_lo, rh_hi, mask_lo, mask_hi;
             if (ax == 0) {
                 area = m.hy * m.hz;
                 rh_p = m.rhx[e];
@@ -84,21 +84,21 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
                 rh_p = m.rhz; rh_lo = m.rhz_m; rh_hi = m.rhz_p;
                 mask_lo = c.mzm; mask_hi = c.mzp;
             }
-            const float Uc = u[ax].v[e] * area;
-            const float al_p = area * rh_p;
+            const fg_real Uc = u[ax].v[e] * area;
+            const fg_real al_p = area * rh_p;
             // ---- lower face (s = -1)
             if (mask_lo != 0.f) {
-                const float ff = -0.25f * (Uc + lo.v[e] * area);
-                const float visc = 0.5f * nu * (al_p + area * rh_lo);
+                const fg_real ff = -0.25f * (Uc + lo.v[e] * area);
+                const fg_real visc = 0.5f * nu * (al_p + area * rh_lo);
                 diag[e] += ff + visc;
                 off[f_lo][e] = ff - visc;
             } else {
                 off[f_lo][e] = 0.f;
                 const int bi = slab + ((ax == 0) ? 0 : e);
-                const float* bv = bnd.vel[f_lo] + (size_t)c.b * DIMS * slab_n;
-                const float Ub = bv[ax * slab_n + bi] * area;  // boundary contravariant flux (:1593-1599)
+                const fg_real* bv = bnd.vel[f_lo] + (size_t)c.b * DIMS * slab_n;
+                const fg_real Ub = bv[ax * slab_n + bi] * area;  // boundary contravariant flux (:1593-1599)
                 if constexpr (SCALAR) {
-                    const float tb = bnd.scal[f_lo][((size_t)c.b * a.n_scalars + a.channel) * slab_n + bi];
+                    const fg_real tb = bnd.scal[f_lo][((size_t)c.b * a.n_scalars + a.channel) * slab_n + bi];
                     const bool dir = bnd.scalar_bc[f_lo] == FG_DIRICHLET;
                     if (dir) diag[e] += 2.f * nu * al_p;
                     bsum[0][e] += tb * Ub + (dir ? tb * nu * 2.f * al_p : tb * nu);  // -T_b*(s U_b), s=-1
@@ -106,24 +106,24 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
                     diag[e] += 2.f * nu * al_p;
 #pragma unroll
                     for (int q = 0; q < DIMS; ++q) {
-                        const float ub = bv[q * slab_n + bi];
+                        const fg_real ub = bv[q * slab_n + bi];
                         bsum[q][e] += ub * Ub + ub * nu * 2.f * al_p;
                     }
                 }
             }
             // ---- upper face (s = +1)
             if (mask_hi != 0.f) {
-                const float ff = 0.25f * (Uc + hi.v[e] * area);
-                const float visc = 0.5f * nu * (al_p + area * rh_hi);
+                const fg_real ff = 0.25f * (Uc + hi.v[e] * area);
+                const fg_real visc = 0.5f * nu * (al_p + area * rh_hi);
                 diag[e] += ff + visc;
                 off[f_hi][e] = ff - visc;
             } else {
                 off[f_hi][e] = 0.f;
                 const int bi = slab + ((ax == 0) ? 0 : e);
-                const float* bv = bnd.vel[f_hi] + (size_t)c.b * DIMS * slab_n;
-                const float Ub = bv[ax * slab_n + bi] * area;
+                const fg_real* bv = bnd.vel[f_hi] + (size_t)c.b * DIMS * slab_n;
+                const fg_real Ub = bv[ax * slab_n + bi] * area;
                 if constexpr (SCALAR) {
-                    const float tb = bnd.scal[f_hi][((size_t)c.b * a.n_scalars + a.channel) * slab_n + bi];
+                    const fg_real tb = bnd.scal[f_hi][((size_t)c.b * a.n_scalars + a.channel) * slab_n + bi];
                     const bool dir = bnd.scalar_bc[f_hi] == FG_DIRICHLET;
                     if (dir) diag[e] += 2.f * nu * al_p;
                     bsum[0][e] += -tb * Ub + (dir ? tb * nu * 2.f * al_p : tb * nu);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
                     diag[e] += 2.f * nu * al_p;
 #pragma unroll
                     for (int q = 0; q < DIMS; ++q) {
-                        const float ub = bv[q * slab_n + bi];
+                        const fg_real ub = bv[q * slab_n + bi];
                         bsum[q][e] += -ub * Ub + ub * nu * 2.f * al_p;
                     }
                 }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
     }
     // ---- write A, off-diagonals, RHS
     FgVec<VEC> out;
-    float rJ[VEC];
+    fg_real rJ[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { rJ[e] = 1.f / J[e]; out.v[e] = diag[e] * rJ[e]; }
     fg_store<VEC>(a.A + (size_t)c.b * N + c.idx, out);
@@ -176,15 +176,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
 
 // rA = 1/A  (PISO_build_pressure_matrix reads Adiag, :4839,4871; we keep the reciprocal so the
 // Poisson operator needs no divisions)
-__global__ __launch_bounds__(FG_BLOCK) void k_reciprocal(const float* __restrict__ A, float* __restrict__ rA,
-                                                          const float* __restrict__ dt, int n, int n4) {
+__global__ __launch_bounds__(FG_BLOCK) void k_reciprocal(const fg_real* __restrict__ A, fg_real* __restrict__ rA,
+                                                          const fg_real* __restrict__ dt, int n, int n4) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
-    const float4* src = reinterpret_cast<const float4*>(A + (size_t)b * n);
-    float4* dst = reinterpret_cast<float4*>(rA + (size_t)b * n);
+    const fg_real4* src = reinterpret_cast<const fg_real4*>(A + (size_t)b * n);
+    fg_real4* dst = reinterpret_cast<fg_real4*>(rA + (size_t)b * n);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        const float4 v = src[i];
-        dst[i] = make_float4(1.f / v.x, 1.f / v.y, 1.f / v.z, 1.f / v.w);
+        const fg_real4 v = src[i];
+        dst[i] = make_fg_real4(1.f / v.x, 1.f / v.y, 1.f / v.z, 1.f / v.w);
     }
     if (blockIdx.x == 0) {
         for (int i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) rA[(size_t)b * n + i] = 1.f / A[(size_t)b * n + i];
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_reciprocal(const float* __restrict
 //   velocity RHS already holds u^n_c/dt + S_bnd/J + S_c (same terms, :4314-4387 vs :5165-5249).
 // ---------------------------------------------------------------------------------------------
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const float* __restrict__ dt,
-                                                 const float* __restrict__ rA_, const float* __restrict__ Coff,
-                                                 const float* __restrict__ rhs, const float* __restrict__ velr,
-                                                 float* __restrict__ hvec, int tiles_x, int tiles_y, int tiles) {
+__global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const fg_real* __restrict__ dt,
+                                                 const fg_real* __restrict__ rA_, const fg_real* __restrict__ Coff,
+                                                 const fg_real* __restrict__ rhs, const fg_real* __restrict__ velr,
+                                                 fg_real* __restrict__ hvec, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (!(dt[c.b] > 0.f) || !c.valid) return;
     const size_t N = g.n;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const float* __restric
         FgVec<VEC> out;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float H = off[0].v[e] * u.xm.v[e] + off[1].v[e] * u.xp.v[e] + off[2].v[e] * u.ym.v[e] +
+            fg_real H = off[0].v[e] * u.xm.v[e] + off[1].v[e] * u.xp.v[e] + off[2].v[e] * u.ym.v[e] +
                       off[3].v[e] * u.yp.v[e];
             if constexpr (DIMS == 3) H += off[4].v[e] * u.zm.v[e] + off[5].v[e] * u.zp.v[e];
             out.v[e] = rA.v[e] * (r.v[e] - H);
@@ -231,14 +231,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const float* __restric
 // :5389-5434; timeStepNorm = false)
 // ---------------------------------------------------------------------------------------------
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const float* __restrict__ dt,
-                                                   const float* __restrict__ hvec, float* __restrict__ div,
+__global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const fg_real* __restrict__ dt,
+                                                   const fg_real* __restrict__ hvec, fg_real* __restrict__ div,
                                                    int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if ((dt && !(dt[c.b] > 0.f)) || !c.valid) return;
     const size_t N = g.n;
     const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
-    float acc[VEC];
+    fg_real acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
 #pragma unroll
@@ -249,12 +249,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const 
         const int slab_n = fg_slab_size(g, ax);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float area, mask_lo, mask_hi;
+            fg_real area, mask_lo, mask_hi;
             if (ax == 0) { area = m.hy * m.hz; mask_lo = (e == 0) ? c.mxm : 1.f; mask_hi = (e == VEC - 1) ? c.mxp : 1.f; }
             else if (ax == 1) { area = m.hx[e] * m.hz; mask_lo = c.mym; mask_hi = c.myp; }
             else { area = m.hx[e] * m.hy; mask_lo = c.mzm; mask_hi = c.mzp; }
             const int bi = slab + ((ax == 0) ? 0 : e);
-            float F_hi, F_lo;
+            fg_real F_hi, F_lo;
             if (mask_hi != 0.f) F_hi = 0.5f * (ctr.v[e] + hi.v[e]) * area;
             else F_hi = bnd.vel[2 * ax + 1][((size_t)c.b * DIMS + ax) * slab_n + bi] * area;
             if (mask_lo != 0.f) F_lo = 0.5f * (ctr.v[e] + lo.v[e]) * area;
@@ -273,9 +273,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const 
 // times Minv (PISO_update_velocity :5962-5995; getPressureGradient :816-849)
 // ---------------------------------------------------------------------------------------------
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const float* __restrict__ dt,
-                                                       const float* __restrict__ rA_, const float* __restrict__ hvec,
-                                                       const float* __restrict__ p, float* __restrict__ vel_out,
+__global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const fg_real* __restrict__ dt,
+                                                       const fg_real* __restrict__ rA_, const fg_real* __restrict__ hvec,
+                                                       const fg_real* __restrict__ p, fg_real* __restrict__ vel_out,
                                                        int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if ((dt && !(dt[c.b] > 0.f)) || !c.valid) return;
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const float* __r
         FgVec<VEC> out;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float lo, hi, fac, rh;
+            fg_real lo, hi, fac, rh;
             if (q == 0) {
                 lo = P.xm.v[e]; hi = P.xp.v[e]; rh = m.rhx[e];
-                const float ml = (e == 0) ? c.mxm : 1.f, mh = (e == VEC - 1) ? c.mxp : 1.f;
+                const fg_real ml = (e == 0) ? c.mxm : 1.f, mh = (e == VEC - 1) ? c.mxp : 1.f;
                 fac = (ml == 0.f || mh == 0.f) ? 1.f : 0.5f;
             } else if (q == 1) {
                 lo = P.ym.v[e]; hi = P.yp.v[e]; rh = m.rhy;
@@ -314,37 +314,51 @@ __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const float* __r
 // Non-negative floats order like their bit patterns, so the reduction finishes with one integer
 // atomicMax per workgroup.
 // ---------------------------------------------------------------------------------------------
-// Per-env maximum across workgroups: atomicMax on the (non-negative) float bit pattern; the workgroup that arrives last
+// Per-env maximum across workgroups: atomicMax on the (non-negative) fg_real bit pattern; the workgroup that arrives last
 // (per-env arrival counter, zeroed with out_B) copies the final value into the host-pinned mirror, so the host reads the
 // CFL velocity after a stream synchronise without a device-to-host copy.  mirror_B == nullptr: plain atomicMax.
-__device__ __forceinline__ void fg_publish_max(float* out_B, int32_t* done_B, float* mirror_B, int b, float mx) {
+// (non-negative reals order like their bit patterns: int for fp32, long long for the fp64 build)
+#if FG_F64
+typedef long long fg_bits;
+__device__ __forceinline__ fg_bits fg_real_bits(fg_real v) { return __double_as_longlong(v); }
+__device__ __forceinline__ fg_real fg_bits_real(fg_bits b) { return __longlong_as_double(b); }
+#else
+typedef int fg_bits;
+__device__ __forceinline__ fg_bits fg_real_bits(fg_real v) { return __float_as_int(v); }
+__device__ __forceinline__ fg_real fg_bits_real(fg_bits b) { return __int_as_float(b); }
+#endif
+__device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx) {
     if (!mirror_B) {
-        atomicMax(reinterpret_cast<int*>(out_B) + b, __float_as_int(mx));
+        atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, fg_real_bits(mx));
         return;
     }
     // Order "my maximum is in" before "I have arrived" without a fence: the RETURNING atomicMax is consumed (the wave
     // waits for its result, i.e. until the device-scope atomic has been performed) before the arrival counter is bumped.
     // An agent-scope __threadfence() here writes back L2 in each of the 2048 workgroups: 14 us -> 45 us for this kernel.
-    int prev = atomicMax(reinterpret_cast<int*>(out_B) + b, __float_as_int(mx));
+    fg_bits prev = atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, fg_real_bits(mx));
+#if FG_F64
+    asm volatile("" ::"v"((int)(prev >> 32)), "v"((int)prev));
+#else
     asm volatile("" ::"v"(prev));
+#endif
     if (atomicAdd(done_B + b, 1) == (int)gridDim.x - 1)
-        mirror_B[b] = __int_as_float(atomicMax(reinterpret_cast<int*>(out_B) + b, 0));  // atomic read of the final value
+        mirror_B[b] = fg_bits_real(atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, (fg_bits)0));  // atomic read of the final value
 }
 
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bnd, const float* __restrict__ vel,
-                                                            float* __restrict__ out_B, int32_t* __restrict__ done_B,
-                                                            float* __restrict__ mirror_B) {
+__global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
+                                                            fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
+                                                            fg_real* __restrict__ mirror_B) {
     const int b = blockIdx.y;
     const size_t N = g.n;
-    float mx = 0.f;
+    fg_real mx = 0.f;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < g.n; idx += gridDim.x * blockDim.x) {
         const int i = idx % g.nx;
         const int j = (idx / g.nx) % g.ny;
         const int k = idx / (g.nx * g.ny);
-        const float rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
+        const fg_real rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
 #pragma unroll
-        for (int q = 0; q < DIMS; ++q) mx = fmaxf(mx, fabsf(vel[((size_t)b * DIMS + q) * N + idx] * rh[q]));
+        for (int q = 0; q < DIMS; ++q) mx = FG_FMAX(mx, FG_FABS(vel[((size_t)b * DIMS + q) * N + idx] * rh[q]));
     }
     {
         // boundary slabs: spread over ALL workgroups of the env.  With workgroup 0 scanning them alone the kernel's
@@ -361,49 +375,49 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
                 if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
                 else if (ax == 1) { j = edge; i = s % g.nx; k = s / g.nx; }
                 else { k = edge; i = s % g.nx; j = s / g.nx; }
-                const float rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
+                const fg_real rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
 #pragma unroll
                 for (int q = 0; q < DIMS; ++q)
-                    mx = fmaxf(mx, fabsf(bnd.vel[f][((size_t)b * DIMS + q) * slab_n + s] * rh[q]));
+                    mx = FG_FMAX(mx, FG_FABS(bnd.vel[f][((size_t)b * DIMS + q) * slab_n + s] * rh[q]));
             }
         }
     }
-    __shared__ float lds[4];
+    __shared__ fg_real lds[4];
     mx = fg_wave_max(mx);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+        mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
         fg_publish_max(out_B, done_B, mirror_B, b, mx);
     }
 }
 
-// Row-wise float4 variant (nx % 4 == 0): a wave walks whole rows, so there is no per-element integer division, the
-// x metrics come as one float4 per lane and the y/z metrics are wave-uniform (the element-wise form above spent
+// Row-wise fg_real4 variant (nx % 4 == 0): a wave walks whole rows, so there is no per-element integer division, the
+// x metrics come as one fg_real4 per lane and the y/z metrics are wave-uniform (the element-wise form above spent
 // 14 us on 16.8 MB at B = 64, 256 x 128).  Workgroup 0 of each env also scans the boundary slabs, as above.
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBounds bnd, const float* __restrict__ vel,
-                                                                 float* __restrict__ out_B, int32_t* __restrict__ done_B,
-                                                                 float* __restrict__ mirror_B, int rows_per_block) {
+__global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
+                                                                 fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
+                                                                 fg_real* __restrict__ mirror_B, int rows_per_block) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows = g.ny * g.nz, nx4 = g.nx >> 2;
     const int r_end = min(rows, (int)(blockIdx.x + 1) * rows_per_block);
-    float mx = 0.f;
+    fg_real mx = 0.f;
     for (int r = blockIdx.x * rows_per_block + wave; r < r_end; r += FG_BLOCK / 64) {
         const int k = r / g.ny, j = r - k * g.ny;
-        const float rhy = g.rh[1][j], rhz = (DIMS == 3) ? g.rh[2][k] : 1.f;
+        const fg_real rhy = g.rh[1][j], rhz = (DIMS == 3) ? g.rh[2][k] : 1.f;
         for (int i4 = lane; i4 < nx4; i4 += 64) {
-            const float4 rhx = *reinterpret_cast<const float4*>(g.rh[0] + 4 * i4);
+            const fg_real4 rhx = *reinterpret_cast<const fg_real4*>(g.rh[0] + 4 * i4);
             const size_t o = (size_t)r * g.nx + 4 * i4;
-            const float4 u = *reinterpret_cast<const float4*>(vel + ((size_t)b * DIMS + 0) * N + o);
-            const float4 v = *reinterpret_cast<const float4*>(vel + ((size_t)b * DIMS + 1) * N + o);
-            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(u.x * rhx.x), fabsf(u.y * rhx.y)), fmaxf(fabsf(u.z * rhx.z), fabsf(u.w * rhx.w))));
-            mx = fmaxf(mx, rhy * fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            const fg_real4 u = *reinterpret_cast<const fg_real4*>(vel + ((size_t)b * DIMS + 0) * N + o);
+            const fg_real4 v = *reinterpret_cast<const fg_real4*>(vel + ((size_t)b * DIMS + 1) * N + o);
+            mx = FG_FMAX(mx, FG_FMAX(FG_FMAX(FG_FABS(u.x * rhx.x), FG_FABS(u.y * rhx.y)), FG_FMAX(FG_FABS(u.z * rhx.z), FG_FABS(u.w * rhx.w))));
+            mx = FG_FMAX(mx, rhy * FG_FMAX(FG_FMAX(FG_FABS(v.x), FG_FABS(v.y)), FG_FMAX(FG_FABS(v.z), FG_FABS(v.w))));
             if constexpr (DIMS == 3) {
-                const float4 w = *reinterpret_cast<const float4*>(vel + ((size_t)b * DIMS + 2) * N + o);
-                mx = fmaxf(mx, rhz * fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
+                const fg_real4 w = *reinterpret_cast<const fg_real4*>(vel + ((size_t)b * DIMS + 2) * N + o);
+                mx = FG_FMAX(mx, rhz * FG_FMAX(FG_FMAX(FG_FABS(w.x), FG_FABS(w.y)), FG_FMAX(FG_FABS(w.z), FG_FABS(w.w))));
             }
         }
     }
@@ -422,19 +436,19 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
                 if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
                 else if (ax == 1) { j = edge; i = s % g.nx; k = s / g.nx; }
                 else { k = edge; i = s % g.nx; j = s / g.nx; }
-                const float rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
+                const fg_real rh[3] = {g.rh[0][i], g.rh[1][j], DIMS == 3 ? g.rh[2][k] : 1.f};
 #pragma unroll
                 for (int q = 0; q < DIMS; ++q)
-                    mx = fmaxf(mx, fabsf(bnd.vel[f][((size_t)b * DIMS + q) * slab_n + s] * rh[q]));
+                    mx = FG_FMAX(mx, FG_FABS(bnd.vel[f][((size_t)b * DIMS + q) * slab_n + s] * rh[q]));
             }
         }
     }
-    __shared__ float lds[4];
+    __shared__ fg_real lds[4];
     mx = fg_wave_max(mx);
     if (lane == 0) lds[wave] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+        mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
         fg_publish_max(out_B, done_B, mirror_B, b, mx);
     }
 }
@@ -442,7 +456,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
 // sum of FIXED-boundary contravariant fluxes, lower faces negated
 // (Domain::GetGlobalFluxBalance, domain_structs.cpp:2476-2509).  One workgroup per env, fp64 sum.
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bnd, float* __restrict__ out_B) {
+__global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bnd, fg_real* __restrict__ out_B) {
     const int b = blockIdx.x;
     double acc = 0.0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -455,11 +469,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bn
         // division per cell and the loads of a row are independent (the s % n, s / n form cost 26 us at 128 x 64 x 64)
         const int n0 = (ax == 0) ? g.ny : g.nx;
         const int n1 = (DIMS == 3) ? ((ax == 2) ? g.ny : g.nz) : 1;
-        const float* __restrict__ h0 = (ax == 0) ? g.h[1] : g.h[0];
-        const float* __restrict__ h1 = (DIMS == 3) ? ((ax == 2) ? g.h[1] : g.h[2]) : nullptr;
-        const float* __restrict__ v = bnd.vel[f] + ((size_t)b * DIMS + ax) * slab_n;
+        const fg_real* __restrict__ h0 = (ax == 0) ? g.h[1] : g.h[0];
+        const fg_real* __restrict__ h1 = (DIMS == 3) ? ((ax == 2) ? g.h[1] : g.h[2]) : nullptr;
+        const fg_real* __restrict__ v = bnd.vel[f] + ((size_t)b * DIMS + ax) * slab_n;
         for (int i1 = wave; i1 < n1; i1 += FG_BLOCK / 64) {
-            const float a1 = h1 ? h1[i1] : 1.f;
+            const fg_real a1 = h1 ? h1[i1] : 1.f;
             double row = 0.0;  // per-cell products in fp32 like the reference's flux, sums in fp64
             for (int i0 = lane; i0 < n0; i0 += 64) row += (double)(v[(size_t)i1 * n0 + i0] * (h0[i0] * a1));
             acc += sgn * row;
@@ -470,72 +484,72 @@ __global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bn
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out_B[b] = (float)(lds[0] + lds[1] + lds[2] + lds[3]);
+    if (threadIdx.x == 0) out_B[b] = (fg_real)(lds[0] + lds[1] + lds[2] + lds[3]);
 }
 
-// dst = src for active envs (Copy*ResultTo/FromBlocks, :6558-6746); float4 grid-stride rows
-__global__ __launch_bounds__(FG_BLOCK) void k_copy_active(const float* __restrict__ dt, const float* __restrict__ src,
-                                                           float* __restrict__ dst, long per_env) {
+// dst = src for active envs (Copy*ResultTo/FromBlocks, :6558-6746); fg_real4 grid-stride rows
+__global__ __launch_bounds__(FG_BLOCK) void k_copy_active(const fg_real* __restrict__ dt, const fg_real* __restrict__ src,
+                                                           fg_real* __restrict__ dst, long per_env) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
-    const float* s = src + (size_t)b * per_env;
-    float* d = dst + (size_t)b * per_env;
+    const fg_real* s = src + (size_t)b * per_env;
+    fg_real* d = dst + (size_t)b * per_env;
     const long n4 = (per_env % 4 == 0) ? per_env / 4 : 0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
-        reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+        reinterpret_cast<fg_real4*>(d)[i] = reinterpret_cast<const fg_real4*>(s)[i];
     if (blockIdx.x == 0)
         for (long i = n4 * 4 + threadIdx.x; i < per_env; i += blockDim.x) d[i] = s[i];
 }
 
 // RBC buoyancy hook fused natively: source[axis] = factor * T, other components 0
 // (rbc_env_base.py:285-297: velocitySource = cat([0, T*buoyancy_factor(, 0)]))
-__global__ __launch_bounds__(FG_BLOCK) void k_buoyancy(const float* __restrict__ dt, const float* __restrict__ T,
-                                                        long t_env_stride, float* __restrict__ source, int dims,
-                                                        int n, int axis, float factor) {
+__global__ __launch_bounds__(FG_BLOCK) void k_buoyancy(const fg_real* __restrict__ dt, const fg_real* __restrict__ T,
+                                                        long t_env_stride, fg_real* __restrict__ source, int dims,
+                                                        int n, int axis, fg_real factor) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float t = T[(size_t)b * t_env_stride + i];
+        const fg_real t = T[(size_t)b * t_env_stride + i];
         for (int q = 0; q < dims; ++q) source[((size_t)b * dims + q) * n + i] = (q == axis) ? factor * t : 0.f;
     }
 }
 
 // p -= mean(p) per env (PISOtorch_simulation.py:1817-1820), written to pressureResult and the block
-__global__ __launch_bounds__(FG_BLOCK) void k_sum_env(const float* __restrict__ dt, const float* __restrict__ p,
+__global__ __launch_bounds__(FG_BLOCK) void k_sum_env(const fg_real* __restrict__ dt, const fg_real* __restrict__ p,
                                                        FgDacc* __restrict__ sums, int n) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
-    const float* __restrict__ pb = p + (size_t)b * n;
-    float acc = 0.f;
-    const int n4 = ((n & 3) == 0 && (reinterpret_cast<size_t>(pb) & 15) == 0) ? n >> 2 : 0;  // float4 body, scalar tail
+    const fg_real* __restrict__ pb = p + (size_t)b * n;
+    fg_real acc = 0.f;
+    const int n4 = ((n & 3) == 0 && (reinterpret_cast<size_t>(pb) & 15) == 0) ? n >> 2 : 0;  // fg_real4 body, scalar tail
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(pb)[i];
+        const fg_real4 v = reinterpret_cast<const fg_real4*>(pb)[i];
         acc += (v.x + v.y) + (v.z + v.w);
     }
     for (int i = n4 * 4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += pb[i];
-    __shared__ float lds[4];
-    float v[1] = {acc};
+    __shared__ fg_real lds[4];
+    fg_real v[1] = {acc};
     fg_block_sum<1>(v, lds);
     if (threadIdx.x == 0) acc_add(sums + b, (double)v[0]);
 }
-__global__ __launch_bounds__(FG_BLOCK) void k_sub_mean(const float* __restrict__ dt, float* __restrict__ p,
-                                                        float* __restrict__ p_copy, const FgDacc* __restrict__ sums,
+__global__ __launch_bounds__(FG_BLOCK) void k_sub_mean(const fg_real* __restrict__ dt, fg_real* __restrict__ p,
+                                                        fg_real* __restrict__ p_copy, const FgDacc* __restrict__ sums,
                                                         int n) {
     const int b = blockIdx.y;
     if (dt && !(dt[b] > 0.f)) return;
-    const float mean = (float)(acc_ld(sums + b) / (double)n);
-    float* __restrict__ pb = p + (size_t)b * n;
-    float* __restrict__ cb = p_copy ? p_copy + (size_t)b * n : nullptr;
+    const fg_real mean = (fg_real)(acc_ld(sums + b) / (double)n);
+    fg_real* __restrict__ pb = p + (size_t)b * n;
+    fg_real* __restrict__ cb = p_copy ? p_copy + (size_t)b * n : nullptr;
     const bool al = (n & 3) == 0 && (reinterpret_cast<size_t>(pb) & 15) == 0 && (!cb || (reinterpret_cast<size_t>(cb) & 15) == 0);
     const int n4 = al ? n >> 2 : 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        float4 v = reinterpret_cast<float4*>(pb)[i];
+        fg_real4 v = reinterpret_cast<fg_real4*>(pb)[i];
         v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-        reinterpret_cast<float4*>(pb)[i] = v;
-        if (cb) reinterpret_cast<float4*>(cb)[i] = v;
+        reinterpret_cast<fg_real4*>(pb)[i] = v;
+        if (cb) reinterpret_cast<fg_real4*>(cb)[i] = v;
     }
     for (int i = n4 * 4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float v = pb[i] - mean;
+        const fg_real v = pb[i] - mean;
         pb[i] = v;
         if (cb) cb[i] = v;
     }
@@ -548,17 +562,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_sub_mean(const float* __restrict__
 // Rectilinear grid: Minv_row_n . u_m = u_m[axis] / h_axis(boundary cell).
 // ---------------------------------------------------------------------------------------------
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_outflow(FgGrid g, int face, float velm_axis, const float* __restrict__ dt,
-                                                       const float* __restrict__ vel, float* __restrict__ bvel,
-                                                       const float* __restrict__ scal, float* __restrict__ bscal,
+__global__ __launch_bounds__(FG_BLOCK) void k_outflow(FgGrid g, int face, fg_real velm_axis, const fg_real* __restrict__ dt,
+                                                       const fg_real* __restrict__ vel, fg_real* __restrict__ bvel,
+                                                       const fg_real* __restrict__ scal, fg_real* __restrict__ bscal,
                                                        int n_scalars) {
     const int b = blockIdx.y;
-    const float dtb = dt[b];
+    const fg_real dtb = dt[b];
     if (!(dtb > 0.f)) return;
     const int ax = face >> 1;
     const int slab_n = fg_slab_size(g, ax);
     const int edge = (face & 1) ? ((ax == 0) ? g.nx - 1 : (ax == 1) ? g.ny - 1 : g.nz - 1) : 0;
-    const float tcoef = 1.f - 1.f / (1.f + 2.f * dtb * velm_axis * g.rh[ax][edge]);
+    const fg_real tcoef = 1.f - 1.f / (1.f + 2.f * dtb * velm_axis * g.rh[ax][edge]);
     const size_t N = g.n;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < slab_n; s += gridDim.x * blockDim.x) {
         int i, j, k;
@@ -568,13 +582,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_outflow(FgGrid g, int face, float 
         const size_t cell = ((size_t)k * g.ny + j) * g.nx + i;
 #pragma unroll
         for (int q = 0; q < DIMS; ++q) {
-            float* pb = bvel + ((size_t)b * DIMS + q) * slab_n + s;
-            const float vb = *pb;
+            fg_real* pb = bvel + ((size_t)b * DIMS + q) * slab_n + s;
+            const fg_real vb = *pb;
             *pb = vb - tcoef * (vb - vel[((size_t)b * DIMS + q) * N + cell]);
         }
         for (int ch = 0; ch < n_scalars; ++ch) {
-            float* pb = bscal + ((size_t)b * n_scalars + ch) * slab_n + s;
-            const float sb = *pb;
+            fg_real* pb = bscal + ((size_t)b * n_scalars + ch) * slab_n + s;
+            const fg_real sb = *pb;
             *pb = sb - tcoef * (sb - scal[((size_t)b * n_scalars + ch) * N + cell]);
         }
     }
@@ -583,8 +597,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_outflow(FgGrid g, int face, float 
 // balance_boundary_fluxes (PISOtorch_simulation.py:188-224): per env, if |flux_fixed + flux_free| exceeds
 // atol scale the whole velocity of the free faces by -flux_fixed / flux_free.  One workgroup per env.
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds bnd, float* const* bvel_rw, int free_mask,
-                                                              float atol, const float* __restrict__ dt) {
+__global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds bnd, fg_real* const* bvel_rw, int free_mask,
+                                                              fg_real atol, const fg_real* __restrict__ dt) {
     const int b = blockIdx.x;
     if (dt && !(dt[b] > 0.f)) return;
     double fixed = 0.0, freef = 0.0;
@@ -599,7 +613,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds 
             if (ax == 0) { j = s % g.ny; k = s / g.ny; }
             else if (ax == 1) { i = s % g.nx; k = s / g.nx; }
             else { i = s % g.nx; j = s / g.nx; }
-            float area;
+            fg_real area;
             if (ax == 0) area = g.h[1][j] * (DIMS == 3 ? g.h[2][k] : 1.f);
             else if (ax == 1) area = g.h[0][i] * (DIMS == 3 ? g.h[2][k] : 1.f);
             else area = g.h[0][i] * g.h[1][j];
@@ -615,11 +629,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds 
     fixed = lds[0] + lds[1] + lds[2] + lds[3];
     freef = lds[4] + lds[5] + lds[6] + lds[7];
     if (!(fabs(fixed + freef) > (double)atol)) return;
-    const float scale = (float)(-fixed / freef);
+    const fg_real scale = (fg_real)(-fixed / freef);
     for (int f = 0; f < 2 * DIMS; ++f) {
         if (!((free_mask >> f) & 1) || !g.fixed[f]) continue;
         const int slab_n = fg_slab_size(g, f >> 1);
-        float* v = bvel_rw[f] + (size_t)b * DIMS * slab_n;
+        fg_real* v = bvel_rw[f] + (size_t)b * DIMS * slab_n;
         for (int s = threadIdx.x; s < DIMS * slab_n; s += blockDim.x) v[s] *= scale;
     }
 }
@@ -658,14 +672,14 @@ int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs&
     return FG_OK;
 }
 
-int fg_launch_pressure_setup(const fg_state* s, const float* dt, hipStream_t st) {
+int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t st) {
     const int n = s->grid.n;
     hipLaunchKernelGGL(k_reciprocal, stride_grid(s, n), dim3(FG_BLOCK), 0, st, s->A, s->rA, dt, n, (n % 4 == 0) ? n / 4 : 0);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
 
-int fg_launch_h(const fg_state* s, const float* dt, const float* vel_result, hipStream_t st) {
+int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st) {
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_h<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, s->rA, s->Coff, s->adv_rhs,
@@ -675,7 +689,7 @@ int fg_launch_h(const fg_state* s, const float* dt, const float* vel_result, hip
     return FG_OK;
 }
 
-int fg_launch_div(const fg_state* s, const FgBounds& bnd, const float* dt, const float* hvec, float* div,
+int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div,
                   hipStream_t st) {
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
@@ -686,8 +700,8 @@ int fg_launch_div(const fg_state* s, const FgBounds& bnd, const float* dt, const
     return FG_OK;
 }
 
-int fg_launch_correct(const fg_state* s, const float* dt, const float* rA, const float* hvec, const float* p,
-                      float* vel_out, hipStream_t st) {
+int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
+                      fg_real* vel_out, hipStream_t st) {
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out,
@@ -697,11 +711,11 @@ int fg_launch_correct(const fg_state* s, const float* dt, const float* rA, const
     return FG_OK;
 }
 
-int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st, float* mirror_B) {
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B) {
     // out_B [B] and the arrival counters right behind it (scratch_B rows 1 and 2) are zeroed together
     int32_t* done_B = reinterpret_cast<int32_t*>(out_B + s->grid.B);
     FG_REQUIRE(!mirror_B || out_B == s->scratch_B + s->grid.B, FG_ERR_INVALID_ARG, "mirror needs the scratch row as out_B");
-    FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(float) * s->grid.B * (mirror_B ? 2 : 1), st));
+    FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(fg_real) * s->grid.B * (mirror_B ? 2 : 1), st));
     if ((s->grid.nx & 3) == 0) {
         const int rows = s->grid.ny * s->grid.nz;
         int rpb = 4;  // rows per workgroup: one per wave, more when that still leaves >= 8 workgroups per CU ...
@@ -726,7 +740,7 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, float* out_B,
     return FG_OK;
 }
 
-int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, float* out_B, hipStream_t st) {
+int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st) {
     if (s->grid.dims == 2)
         hipLaunchKernelGGL(k_flux_balance<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, out_B);
     else
@@ -735,7 +749,7 @@ int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, float* out_B,
     return FG_OK;
 }
 
-int fg_launch_copy_active(const fg_state* s, const float* dt, const float* src, float* dst, int comps,
+int fg_launch_copy_active(const fg_state* s, const fg_real* dt, const fg_real* src, fg_real* dst, int comps,
                           hipStream_t st) {
     const long per_env = (long)comps * s->grid.n;
     hipLaunchKernelGGL(k_copy_active, stride_grid(s, per_env), dim3(FG_BLOCK), 0, st, dt, src, dst, per_env);
@@ -743,15 +757,15 @@ int fg_launch_copy_active(const fg_state* s, const float* dt, const float* src, 
     return FG_OK;
 }
 
-int fg_launch_buoyancy(const fg_state* s, const float* dt, const float* T, long t_env_stride, float* source, int axis,
-                       float factor, hipStream_t st) {
+int fg_launch_buoyancy(const fg_state* s, const fg_real* dt, const fg_real* T, long t_env_stride, fg_real* source, int axis,
+                       fg_real factor, hipStream_t st) {
     hipLaunchKernelGGL(k_buoyancy, stride_grid(s, (long)s->grid.n * 4), dim3(FG_BLOCK), 0, st, dt, T, t_env_stride,
                        source, s->grid.dims, s->grid.n, axis, factor);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
 
-int fg_launch_mean_sub(const fg_state* s, const float* dt, float* p, float* p_copy, hipStream_t st) {
+int fg_launch_mean_sub(const fg_state* s, const fg_real* dt, fg_real* p, fg_real* p_copy, hipStream_t st) {
     FgDacc* sums = s->acc;  // first B accumulators of the pool: free between solves, zeroed by k_cg_begin
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
     // every workgroup ends in atomics on its env's accumulator and same-address atomics serialise (~0.1 us each):
@@ -763,7 +777,7 @@ int fg_launch_mean_sub(const fg_state* s, const float* dt, float* p, float* p_co
     return FG_OK;
 }
 
-int fg_launch_outflow(const fg_state* s, int face, float velm_axis, const float* dt, hipStream_t st) {
+int fg_launch_outflow(const fg_state* s, int face, fg_real velm_axis, const fg_real* dt, hipStream_t st) {
     const int slab_n = (face >> 1) == 0 ? s->grid.ny * s->grid.nz : (face >> 1) == 1 ? s->grid.nx * s->grid.nz : s->grid.nx * s->grid.ny;
     dim3 grid((slab_n + FG_BLOCK - 1) / FG_BLOCK, s->grid.B);
     const int nsc = (s->scalar && s->bscal[face]) ? s->cfg.n_scalars : 0;
@@ -777,7 +791,7 @@ int fg_launch_outflow(const fg_state* s, int face, float velm_axis, const float*
     return FG_OK;
 }
 
-int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, float atol, const float* dt, hipStream_t st) {
+int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st) {
     if (s->grid.dims == 2)
         hipLaunchKernelGGL(k_balance_fluxes<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt);
     else

@@ -18,29 +18,29 @@ namespace {
 // face coefficients of the thread's cells from rA (+ neighbours) and rectilinear metrics
 template <int DIMS, int VEC>
 struct FgCoef {
-    float xm[VEC], xp[VEC], ym[VEC], yp[VEC], zm[VEC], zp[VEC];
+    fg_real xm[VEC], xp[VEC], ym[VEC], yp[VEC], zm[VEC], zp[VEC];
 };
 
 template <int DIMS, int VEC>
 __device__ __forceinline__ FgCoef<DIMS, VEC> fg_poisson_coef(const FgCtx<DIMS, VEC>& c, const FgMetric<DIMS, VEC>& m,
                                                              const FgNbr<DIMS, VEC>& rA) {
     FgCoef<DIMS, VEC> k;
-    const float ayz = m.hy * m.hz;
+    const fg_real ayz = m.hy * m.hz;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        const float rh_lo = (e == 0) ? m.rhx_m : m.rhx[e > 0 ? e - 1 : 0];
-        const float rh_hi = (e == VEC - 1) ? m.rhx_p : m.rhx[e < VEC - 1 ? e + 1 : VEC - 1];
-        const float ml = (e == 0) ? c.mxm : 1.f, mh = (e == VEC - 1) ? c.mxp : 1.f;
-        const float apx = ayz * m.rhx[e] * rA.c.v[e];
+        const fg_real rh_lo = (e == 0) ? m.rhx_m : m.rhx[e > 0 ? e - 1 : 0];
+        const fg_real rh_hi = (e == VEC - 1) ? m.rhx_p : m.rhx[e < VEC - 1 ? e + 1 : VEC - 1];
+        const fg_real ml = (e == 0) ? c.mxm : 1.f, mh = (e == VEC - 1) ? c.mxp : 1.f;
+        const fg_real apx = ayz * m.rhx[e] * rA.c.v[e];
         k.xm[e] = ml * 0.5f * (apx + ayz * rh_lo * rA.xm.v[e]);
         k.xp[e] = mh * 0.5f * (apx + ayz * rh_hi * rA.xp.v[e]);
-        const float axz = m.hx[e] * m.hz;
-        const float apy = axz * m.rhy * rA.c.v[e];
+        const fg_real axz = m.hx[e] * m.hz;
+        const fg_real apy = axz * m.rhy * rA.c.v[e];
         k.ym[e] = c.mym * 0.5f * (apy + axz * m.rhy_m * rA.ym.v[e]);
         k.yp[e] = c.myp * 0.5f * (apy + axz * m.rhy_p * rA.yp.v[e]);
         if constexpr (DIMS == 3) {
-            const float axy = m.hx[e] * m.hy;
-            const float apz = axy * m.rhz * rA.c.v[e];
+            const fg_real axy = m.hx[e] * m.hy;
+            const fg_real apz = axy * m.rhz * rA.c.v[e];
             k.zm[e] = c.mzm * 0.5f * (apz + axy * m.rhz_m * rA.zm.v[e]);
             k.zp[e] = c.mzp * 0.5f * (apz + axy * m.rhz_p * rA.zp.v[e]);
         } else {
@@ -51,8 +51,8 @@ __device__ __forceinline__ FgCoef<DIMS, VEC> fg_poisson_coef(const FgCtx<DIMS, V
 }
 
 template <int DIMS, int VEC>
-__device__ __forceinline__ float fg_apply_elem(const FgCoef<DIMS, VEC>& k, const FgNbr<DIMS, VEC>& x, int e) {
-    float y = k.xm[e] * (x.xm.v[e] - x.c.v[e]) + k.xp[e] * (x.xp.v[e] - x.c.v[e]) +
+__device__ __forceinline__ fg_real fg_apply_elem(const FgCoef<DIMS, VEC>& k, const FgNbr<DIMS, VEC>& x, int e) {
+    fg_real y = k.xm[e] * (x.xm.v[e] - x.c.v[e]) + k.xp[e] * (x.xp.v[e] - x.c.v[e]) +
               k.ym[e] * (x.ym.v[e] - x.c.v[e]) + k.yp[e] * (x.yp.v[e] - x.c.v[e]);
     if constexpr (DIMS == 3) y += k.zm[e] * (x.zm.v[e] - x.c.v[e]) + k.zp[e] * (x.zp.v[e] - x.c.v[e]);
     return y;
@@ -60,8 +60,8 @@ __device__ __forceinline__ float fg_apply_elem(const FgCoef<DIMS, VEC>& k, const
 
 // y = P x
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_poisson_apply(FgGrid g, const float* __restrict__ rA_,
-                                                             const float* __restrict__ x_, float* __restrict__ y_,
+__global__ __launch_bounds__(FG_BLOCK) void k_poisson_apply(FgGrid g, const fg_real* __restrict__ rA_,
+                                                             const fg_real* __restrict__ x_, fg_real* __restrict__ y_,
                                                              int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (!c.valid) return;
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson_apply(FgGrid g, const floa
 // damped Jacobi sweep: xnew = x + omega (b - P x) / diag,  diag = -sum_f off_f
 // RBGS (COLOR >= 0): same update, in place, only for cells with (i+j+k)&1 == COLOR
 template <int DIMS, int VEC, bool RB>
-__global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const float* __restrict__ rA_,
-                                                             const float* __restrict__ b_, const float* x_,
-                                                             float* xnew_, float omega, int color,
+__global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const fg_real* __restrict__ rA_,
+                                                             const fg_real* __restrict__ b_, const fg_real* x_,
+                                                             fg_real* xnew_, fg_real omega, int color,
                                                              int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (!c.valid) return;
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const floa
     FgVec<VEC> out;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        const float diag = -(k.xm[e] + k.xp[e] + k.ym[e] + k.yp[e] + k.zm[e] + k.zp[e]);
-        const float res = b.v[e] - fg_apply_elem<DIMS, VEC>(k, x, e);
-        float v = x.c.v[e] + omega * res / diag;
+        const fg_real diag = -(k.xm[e] + k.xp[e] + k.ym[e] + k.yp[e] + k.zm[e] + k.zp[e]);
+        const fg_real res = b.v[e] - fg_apply_elem<DIMS, VEC>(k, x, e);
+        fg_real v = x.c.v[e] + omega * res / diag;
         if constexpr (RB) {
             if (((c.i0 + e + c.j + c.k) & 1) != color) v = x.c.v[e];
         }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const floa
 #define FG_CG_SLOTS 64
 #define FG_CG_NAMES 8  // rr ring 0..2 | pAp ring 3..4 | r.z ring 5..7 (preconditioned CG)
 
-__device__ __forceinline__ float fg_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
+__device__ __forceinline__ fg_real fg_rms(double rr, int n) { return (fg_real)sqrt(rr / (double)n); }
 
 __device__ __forceinline__ FgDacc* fg_acc_ptr(FgDacc* acc, int b, int name) {
     return acc + ((size_t)b * FG_CG_NAMES + name) * FG_CG_SLOTS;
@@ -145,16 +145,16 @@ __device__ __forceinline__ void fg_acc_add(FgDacc* a, int ns, unsigned tile, dou
 
 // r = b - P x (or r = b when x0 == 0), accumulates rr into ring name `name`
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float* __restrict__ rA_,
-                                                           const float* __restrict__ b_, float* __restrict__ x_,
-                                                           float* __restrict__ r_, FgDacc* __restrict__ acc,
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const fg_real* __restrict__ rA_,
+                                                           const fg_real* __restrict__ b_, fg_real* __restrict__ x_,
+                                                           fg_real* __restrict__ r_, FgDacc* __restrict__ acc,
                                                            const int32_t* __restrict__ flags, int use_x0, int name,
                                                            int ns, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flag_ld(flags + (c.b)) != 0) return;
-    __shared__ float lds[4];
+    __shared__ fg_real lds[4];
     const size_t base = (size_t)c.b * g.n;
-    float part[1] = {0.f};
+    fg_real part[1] = {0.f};
     if (c.valid) {
         FgVec<VEC> r = fg_load<VEC>(b_ + base + c.idx);
         if (use_x0) {
@@ -187,19 +187,19 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_residual(FgGrid g, const float*
 // belong to other workgroups that rewrite p in this same launch, p is double-buffered:
 // pin_ = p of iteration it-1 (read with halo), pout_ = p of iteration it (written, centre only).
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __restrict__ rA_,
-                                                     const float* __restrict__ z_, const float* __restrict__ pin_,
-                                                     float* __restrict__ pout_, float* __restrict__ Ap_,
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const fg_real* __restrict__ rA_,
+                                                     const fg_real* __restrict__ z_, const fg_real* __restrict__ pin_,
+                                                     fg_real* __restrict__ pout_, fg_real* __restrict__ Ap_,
                                                      FgDacc* __restrict__ acc, int32_t* __restrict__ flags,
                                                      fg_solve_info* __restrict__ info, int32_t* __restrict__ prof_active,
-                                                     FgBest best, float tol, int it, int first, int ns, int num_base,
+                                                     FgBest best, fg_real tol, int it, int first, int ns, int num_base,
                                                      int tiles_x, int tiles_y, int tiles) {
     // z_ = preconditioned residual (= r when num_base == 0); beta = num_it / num_{it-1} with the numerator
     // ring num_base (0: r.r, 5: r.z).  Convergence is always judged on the r.r ring (RMS residual).
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flag_ld(flags + (c.b)) != 0) return;
     const double rr_new = fg_acc_total(fg_acc_ptr(acc, c.b, it % 3), ns);
-    const float crit = fg_rms(rr_new, g.n);
+    const fg_real crit = fg_rms(rr_new, g.n);
     const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
     const bool lead_block = (tile == 0);
     if (!(crit >= tol)) {  // converged (crit < tol) or NaN
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
             fg_best_decide(best, c.b, crit, it);
         }
     }
-    const float beta = first ? 0.f : (float)(num_new / num_old);
-    __shared__ float lds[4];
+    const fg_real beta = first ? 0.f : (fg_real)(num_new / num_old);
+    __shared__ fg_real lds[4];
     const size_t base = (size_t)c.b * g.n;
-    float part[1] = {0.f};
+    fg_real part[1] = {0.f};
     if (c.valid) {
         const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
         const FgNbr<DIMS, VEC> rA = fg_gather<DIMS, VEC>(rA_ + base, c);
@@ -264,10 +264,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_ap(FgGrid g, const float* __res
 
 // CG kernel 2:  alpha = rr / pAp ; x += alpha p ; r -= alpha Ap ; rr_next += r.r
 template <int DIMS, int VEC>
-__global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* __restrict__ p_,
-                                                         const float* __restrict__ Ap_, float* __restrict__ x_,
-                                                         float* __restrict__ r_, FgDacc* __restrict__ acc,
-                                                         const int32_t* __restrict__ flags, FgBest best, float tol, int it,
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const fg_real* __restrict__ p_,
+                                                         const fg_real* __restrict__ Ap_, fg_real* __restrict__ x_,
+                                                         fg_real* __restrict__ r_, FgDacc* __restrict__ acc,
+                                                         const int32_t* __restrict__ flags, FgBest best, fg_real tol, int it,
                                                          int ns, int num_base, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flag_ld(flags + (c.b)) != 0) return;
@@ -275,14 +275,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
     // best-iterate tracking (FgBest): the leader of k_cg_ap decided whether x_it (x on entry) is worth keeping
     const bool save = best.save_at[c.b] == it;
     const double pAp = fg_acc_total(fg_acc_ptr(acc, c.b, 3 + (it & 1)), ns);
-    const float alpha = (float)(rr / pAp);
+    const fg_real alpha = (fg_real)(rr / pAp);
     const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
     if (tile == 0 && threadIdx.x < 64) {
         fg_acc_zero(fg_acc_ptr(acc, c.b, 3 + ((it + 1) & 1)), ns);  // next pAp
     }
-    __shared__ float lds[4];
+    __shared__ fg_real lds[4];
     const size_t base = (size_t)c.b * g.n;
-    float part[1] = {0.f};
+    fg_real part[1] = {0.f};
     if (c.valid) {
         const FgVec<VEC> p = fg_load<VEC>(p_ + base + c.idx);
         const FgVec<VEC> Ap = fg_load<VEC>(Ap_ + base + c.idx);
@@ -306,11 +306,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const float* _
 // host-pinned copy of info: thread 0 of every env writes its entry there, so a convergence poll is a stream
 // synchronise without a device-to-host copy (the copy kernel + its launch cost ~6 us per poll, 4-5 polls per PISO step).
 __global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                           fg_solve_info* __restrict__ mirror, float tol, int it, int n, int B, int final_pass, int ns) {
+                           fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int B, int final_pass, int ns) {
     const int b = blockIdx.x;
     if (b >= B) return;
     if (flag_ld(flags + (b)) == 0) {
-        const float crit = fg_rms(fg_acc_total(fg_acc_ptr(acc, b, (it + 1) % 3), ns), n);
+        const fg_real crit = fg_rms(fg_acc_total(fg_acc_ptr(acc, b, (it + 1) % 3), ns), n);
         if (threadIdx.x == 0) {
             info[b].final_residual = crit;
             info[b].used_iterations = it;
@@ -328,7 +328,7 @@ __global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags
     if (mirror && threadIdx.x == 0) mirror[b] = info[b];
 }
 
-__global__ void k_cg_begin(const float* __restrict__ dt, FgDacc* __restrict__ acc, int32_t* __restrict__ flags,
+__global__ void k_cg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict__ acc, int32_t* __restrict__ flags,
                            fg_solve_info* __restrict__ info, FgDacc* __restrict__ mean_sums, FgBest best, int track_best,
                            int B, int ns) {
     const int b = blockIdx.x;
@@ -354,11 +354,11 @@ __global__ void k_zero_name(FgDacc* __restrict__ acc, int name, int B) {
 }
 
 // Unconverged envs get the best iterate seen back (returnBestResult): x = best_x where its residual beats the final one.
-__global__ __launch_bounds__(FG_BLOCK) void k_cg_restore_best(float* __restrict__ x, fg_solve_info* __restrict__ info,
+__global__ __launch_bounds__(FG_BLOCK) void k_cg_restore_best(fg_real* __restrict__ x, fg_solve_info* __restrict__ info,
                                                                fg_solve_info* __restrict__ mirror, FgBest best, int n) {
     const int b = blockIdx.y;
     const fg_solve_info I = info[b];
-    const float have = best.saved_crit[b];
+    const fg_real have = best.saved_crit[b];
     const bool worse = !(I.final_residual <= have);   // also true for a NaN final residual
     if (I.converged || !worse || !isfinite(have)) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_restore_best(float* __restrict_
 }  // namespace
 
 
-int fg_poisson_apply_launch(const fg_state* s, const float* rA, const float* x, float* y, hipStream_t st) {
+int fg_poisson_apply_launch(const fg_state* s, const fg_real* rA, const fg_real* x, fg_real* y, hipStream_t st) {
     int zc;
     if (fg_zmarch_ok(s, &zc)) return fg_zmarch_apply(s, rA, x, y, zc, st);
     FG_DISPATCH(s, {
@@ -384,8 +384,8 @@ int fg_poisson_apply_launch(const fg_state* s, const float* rA, const float* x, 
     return FG_OK;
 }
 
-int fg_poisson_jacobi_launch(const fg_state* s, const float* rA, const float* b, const float* x, float* xnew,
-                             float omega, hipStream_t st) {
+int fg_poisson_jacobi_launch(const fg_state* s, const fg_real* rA, const fg_real* b, const fg_real* x, fg_real* xnew,
+                             fg_real omega, hipStream_t st) {
     int zc;
     if (fg_zmarch_ok(s, &zc)) return fg_zmarch_relax(s, rA, b, x, xnew, omega, -1, zc, st);
     FG_DISPATCH(s, {
@@ -397,7 +397,7 @@ int fg_poisson_jacobi_launch(const fg_state* s, const float* rA, const float* b,
     return FG_OK;
 }
 
-int fg_poisson_rbgs_launch(const fg_state* s, const float* rA, const float* b, float* x, float omega, int color,
+int fg_poisson_rbgs_launch(const fg_state* s, const fg_real* rA, const fg_real* b, fg_real* x, fg_real omega, int color,
                            hipStream_t st) {
     int zc;
     if (fg_zmarch_ok(s, &zc)) return fg_zmarch_relax(s, rA, b, x, x, omega, color, zc, st);
@@ -414,7 +414,7 @@ int fg_poisson_rbgs_launch(const fg_state* s, const float* rA, const float* b, f
 int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st) {
     const int B = s->grid.B, n = s->grid.n;
     const dim3 sg(B), sb(64);
-    float* pbuf[2] = {a.p, s->w[6]};
+    fg_real* pbuf[2] = {a.p, s->w[6]};
     int tiles_per_env = 1;
     FG_DISPATCH(s, { tiles_per_env = fg_launch_geometry<DIMS, VEC>(s->grid).tiles; });
     int zc = 0;
@@ -430,7 +430,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const int check_every = a.check_every > 0 ? a.check_every : 16;
     const int nb = a.precond ? 5 : 0;
     const int acc_stride = FG_CG_NAMES * FG_CG_SLOTS;
-    float* zvec = a.precond ? s->w[5] : a.r;
+    fg_real* zvec = a.precond ? s->w[5] : a.r;
     if (a.precond) {
         if (!s->fd_Qx) { fg_set_error("preconditioned CG requested but fg_set_fd_preconditioner was not called"); return FG_ERR_INVALID_ARG; }
         // residual check of x0 (sets flags for already-converged envs), then z0 = M^-1 r0, r0.z0
@@ -454,8 +454,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             first = 1;
         }
         // p double buffer: read p_{it-1} from pbuf[(it+1)&1], write p_it to pbuf[it&1]
-        const float* p_in = pbuf[(it + 1) & 1];
-        float* p_out = pbuf[it & 1];
+        const fg_real* p_in = pbuf[(it + 1) & 1];
+        fg_real* p_out = pbuf[it & 1];
         // algorithmic bytes per env of k_cg_ap: z, rA read + p, Ap written (+ p_in read unless first); 2d+1-point
         // stencil = (4d + 1) flops + 2 (p update) + 2 (dot) per cell.  k_cg_update: x, r, p, Ap read + x, r written.
         const int slot_ap = fg_prof_slot(s, FG_PK_CG_AP, FG_PROF_SELF, B, (double)n * (first ? 16.0 : 20.0),

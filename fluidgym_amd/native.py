@@ -37,14 +37,24 @@ class NativeSolver:
 
     def __init__(self, widths: Sequence[np.ndarray], batch: int, fixed_faces: Sequence[int] = (),
                  n_scalars: int = 0, scalar_bc: Optional[Dict[int, Sequence[int]]] = None,
-                 device: Optional[torch.device] = None, allocate: bool = True):
+                 device: Optional[torch.device] = None, allocate: bool = True, dtype: torch.dtype = torch.float32):
         if not torch.cuda.is_available():
             raise L.NativeLibraryError("fluidgym_amd needs a ROCm GPU (MI355X); there is no CPU path")
-        self.lib = L.load()
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be torch.float32 or torch.float64")
+        # fp64 fields (the reference's FluidEnv(dtype=torch.float64), envs/fluid_env.py:146) run on the fp64 build of the same
+        # sources (libfluidgym_hip_f64.so: fg_real = double); its entry points take doubles wherever this one takes floats
+        self.dtype = dtype
+        self.f64 = dtype == torch.float64
+        self.lib = L.load_f64() if self.f64 else L.load()
+        self._np_real = np.float64 if self.f64 else np.float32
+        self._c_real = ctypes.c_double if self.f64 else ctypes.c_float
+        self._StepOptions = L.FgStepOptionsF64 if self.f64 else L.FgStepOptions
+        self._SimOptions = L.FgSimOptionsF64 if self.f64 else L.FgSimOptions
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.dims = len(widths)
         assert self.dims in (2, 3)
-        self.widths = [np.ascontiguousarray(w, dtype=np.float32) for w in widths]
+        self.widths = [np.ascontiguousarray(w, dtype=self._np_real) for w in widths]
         self.nx = len(self.widths[0])
         self.ny = len(self.widths[1])
         self.nz = len(self.widths[2]) if self.dims == 3 else 1
@@ -63,7 +73,7 @@ class NativeSolver:
             if scalar_bc and f in scalar_bc:
                 for ch, t in enumerate(scalar_bc[f]):
                     cfg.scalar_bc[f][ch] = int(t)
-        fp = ctypes.POINTER(ctypes.c_float)
+        fp = ctypes.POINTER(self._c_real)
         hz = self.widths[2].ctypes.data_as(fp) if self.dims == 3 else None
         handle = ctypes.c_void_p()
         L.check(self.lib.fg_create(ctypes.byref(cfg), self.widths[0].ctypes.data_as(fp),
@@ -75,12 +85,14 @@ class NativeSolver:
         self.velocity = self.pressure = self.scalar = self.velocity_source = None
         self.bvel: Dict[int, torch.Tensor] = {}
         self.bscal: Dict[int, torch.Tensor] = {}
-        self._dt = torch.zeros(self.B, dtype=torch.float32, device=self.device)
-        self._dt_host = torch.zeros(self.B, dtype=torch.float32).pin_memory()
-        self._out_B = torch.zeros(self.B, dtype=torch.float32, device=self.device)
-        # fast-diagonalisation preconditioner (needs FIXED y faces); default pressure solver when available
-        self.has_fd = bool(self.fixed[2] and self.fixed[3])
+        self._dt = torch.zeros(self.B, dtype=dtype, device=self.device)
+        self._dt_host = torch.zeros(self.B, dtype=dtype).pin_memory()
+        self._out_B = torch.zeros(self.B, dtype=dtype, device=self.device)
+        # fast-diagonalisation preconditioner (needs FIXED y faces); default pressure solver when available.  It is an fp32 kernel
+        # family (MFMA basis changes, LDS FFT): the fp64 build runs the reference's plain CG
+        self.has_fd = bool(self.fixed[2] and self.fixed[3]) and not self.f64
         if self.has_fd:
+            fp = ctypes.POINTER(ctypes.c_float)
             from .simulation.fd_precond import FDPreconditioner
 
             fd = FDPreconditioner(self.widths, [f for f in range(6) if self.fixed[f]])
@@ -90,7 +102,7 @@ class NativeSolver:
                                                       fpp(fd.inv), fpp(fd.cp)))
             if fd.x_cosine_width is not None and os.environ.get("FG_FD_NO_FFT", "0") == "0":
                 # the x basis is the DCT-II basis: apply it as a fast cosine transform instead of the dense GEMM
-                L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_cosine_width))
+                L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_cosine_width), lib=self.lib)
         self.default_method = L.FG_SOLVER_FDCG if self.has_fd else L.FG_SOLVER_CG
         if allocate:
             self.allocate_fields()
@@ -108,14 +120,14 @@ class NativeSolver:
     # ------------------------------------------------------------------ binding
     def bind(self, field: int, t: Optional[torch.Tensor]):
         if t is not None:
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "fields must be contiguous fp32 CUDA"
+            assert t.is_cuda and t.dtype == self.dtype and t.is_contiguous(), f"fields must be contiguous {self.dtype} CUDA tensors"
             self._bound[field] = t  # keep alive
         else:
             self._bound.pop(field, None)
-        L.check(self.lib.fg_bind(self.handle, field, _ptr(t)))
+        L.check(self.lib.fg_bind(self.handle, field, _ptr(t)), lib=self.lib)
 
     def allocate_fields(self):
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+        z = lambda *shape: torch.zeros(shape, dtype=self.dtype, device=self.device)
         self.set_velocity(z(self.B, self.dims, *self.spatial))
         self.set_pressure(z(self.B, 1, *self.spatial))
         if self.n_scalars:
@@ -152,10 +164,10 @@ class NativeSolver:
 
     def set_viscosity(self, nu: float):
         self.viscosity = float(nu)
-        L.check(self.lib.fg_set_viscosity(self.handle, float(nu)))
+        L.check(self.lib.fg_set_viscosity(self.handle, float(nu)), lib=self.lib)
 
     def set_scalar_viscosity(self, ch: int, k: float):
-        L.check(self.lib.fg_set_scalar_viscosity(self.handle, ch, float(k)))
+        L.check(self.lib.fg_set_scalar_viscosity(self.handle, ch, float(k)), lib=self.lib)
 
     # ------------------------------------------------------------------ helpers
     def dt_tensor(self, dt) -> torch.Tensor:
@@ -163,16 +175,16 @@ class NativeSolver:
         (``<= 0`` = env inactive for the call)."""
         if isinstance(dt, torch.Tensor) and dt.is_cuda:
             return dt
-        self._dt_host.copy_(torch.as_tensor(np.broadcast_to(np.asarray(dt, dtype=np.float32), (self.B,)).copy()))
+        self._dt_host.copy_(torch.as_tensor(np.broadcast_to(np.asarray(dt, dtype=self._np_real), (self.B,)).copy()))
         self._dt.copy_(self._dt_host, non_blocking=True)
         return self._dt
 
     def buffer(self, which: int, shape) -> torch.Tensor:
         """Copy of an internal solver vector (tests only)."""
         p, n = ctypes.c_void_p(), ctypes.c_int64()
-        L.check(self.lib.fg_get_buffer(self.handle, which, ctypes.byref(p), ctypes.byref(n)))
-        out = torch.empty(int(n.value), dtype=torch.float32, device=self.device)
-        L.check(self.lib.fg_read_buffer(self.handle, which, _ptr(out), _stream(self.device)))
+        L.check(self.lib.fg_get_buffer(self.handle, which, ctypes.byref(p), ctypes.byref(n)), lib=self.lib)
+        out = torch.empty(int(n.value), dtype=self.dtype, device=self.device)
+        L.check(self.lib.fg_read_buffer(self.handle, which, _ptr(out), _stream(self.device)), lib=self.lib)
         return out.view(*shape)
 
     def _infos(self, n):
@@ -180,23 +192,23 @@ class NativeSolver:
 
     # ------------------------------------------------------------------ reductions
     def max_velocity(self) -> torch.Tensor:
-        L.check(self.lib.fg_max_velocity(self.handle, _ptr(self._out_B), _stream(self.device)))
+        L.check(self.lib.fg_max_velocity(self.handle, _ptr(self._out_B), _stream(self.device)), lib=self.lib)
         return self._out_B.clone()
 
     def boundary_flux_balance(self) -> torch.Tensor:
-        L.check(self.lib.fg_boundary_flux_balance(self.handle, _ptr(self._out_B), _stream(self.device)))
+        L.check(self.lib.fg_boundary_flux_balance(self.handle, _ptr(self._out_B), _stream(self.device)), lib=self.lib)
         return self._out_B.clone()
 
     def step_diagnostics(self):
         """(flux_balance[B], max_velocity[B]) as NumPy arrays with a single device->host sync."""
-        buf = np.empty(2 * self.B, dtype=np.float32)
-        L.check(self.lib.fg_step_diagnostics(self.handle, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+        buf = np.empty(2 * self.B, dtype=self._np_real)
+        L.check(self.lib.fg_step_diagnostics(self.handle, buf.ctypes.data_as(ctypes.POINTER(self._c_real)),
                                              _stream(self.device)))
         return buf[: self.B], buf[self.B:]
 
     def update_advective_boundary(self, face: int, velm, dt):
-        v = np.ascontiguousarray(velm, dtype=np.float32).reshape(-1)
-        L.check(self.lib.fg_update_advective_boundary(self.handle, face, v.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+        v = np.ascontiguousarray(velm, dtype=self._np_real).reshape(-1)
+        L.check(self.lib.fg_update_advective_boundary(self.handle, face, v.ctypes.data_as(ctypes.POINTER(self._c_real)),
                                                       _ptr(self.dt_tensor(dt)), _stream(self.device)))
 
     def balance_boundary_fluxes(self, free_faces, atol: float, dt):
@@ -220,13 +232,13 @@ class NativeSolver:
         return list(info)
 
     def copy_scalar_result_to_blocks(self, channel=0):
-        L.check(self.lib.fg_copy_scalar_result_to_blocks(self.handle, channel, _stream(self.device)))
+        L.check(self.lib.fg_copy_scalar_result_to_blocks(self.handle, channel, _stream(self.device)), lib=self.lib)
 
     def setup_pressure_matrix(self):
-        L.check(self.lib.fg_setup_pressure_matrix(self.handle, _stream(self.device)))
+        L.check(self.lib.fg_setup_pressure_matrix(self.handle, _stream(self.device)), lib=self.lib)
 
     def setup_pressure_rhs(self, dt):
-        L.check(self.lib.fg_setup_pressure_rhs(self.handle, _ptr(self.dt_tensor(dt)), _stream(self.device)))
+        L.check(self.lib.fg_setup_pressure_rhs(self.handle, _ptr(self.dt_tensor(dt)), _stream(self.device)), lib=self.lib)
 
     def solve_pressure(self, tol=1e-5, max_iterations=5000, method=None, use_previous=False):
         method = self.default_method if method is None else method
@@ -237,19 +249,19 @@ class NativeSolver:
         return list(info)
 
     def correct_velocity(self):
-        L.check(self.lib.fg_correct_velocity(self.handle, _stream(self.device)))
+        L.check(self.lib.fg_correct_velocity(self.handle, _stream(self.device)), lib=self.lib)
 
     def copy_velocity_result_to_blocks(self):
-        L.check(self.lib.fg_copy_velocity_result_to_blocks(self.handle, _stream(self.device)))
+        L.check(self.lib.fg_copy_velocity_result_to_blocks(self.handle, _stream(self.device)), lib=self.lib)
 
     def copy_velocity_result_from_blocks(self):
-        L.check(self.lib.fg_copy_velocity_result_from_blocks(self.handle, _stream(self.device)))
+        L.check(self.lib.fg_copy_velocity_result_from_blocks(self.handle, _stream(self.device)), lib=self.lib)
 
     def piso_step(self, dt, corrector_steps=2, advect_scalar=True, advection_tol=1e-5, pressure_tol=1e-5,
                   max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0, method=None,
                   pressure_warm_start=False):
         method = self.default_method if method is None else method
-        opt = L.FgStepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol,
+        opt = self._StepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol,
                               pressure_tol, buoyancy_axis, buoyancy_factor, int(pressure_warm_start))
         stats = (ctypes.c_int32 * 4)()
         rc = self.lib.fg_piso_step(self.handle, _ptr(self.dt_tensor(dt)), ctypes.byref(opt), stats,
@@ -265,8 +277,8 @@ class NativeSolver:
                     method=None, pressure_warm_start=False, max_substeps=1000):
         """Native ``Simulation.single_step``; returns (all_converged, solver_stats[4], substeps)."""
         method = self.default_method if method is None else method
-        o = L.FgSimOptions()
-        o.step = L.FgStepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol, pressure_tol,
+        o = self._SimOptions()
+        o.step = self._StepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol, pressure_tol,
                                  buoyancy_axis, buoyancy_factor, int(pressure_warm_start))
         o.time_step, o.cfl, o.adaptive, o.substeps = float(time_step), float(cfl), int(adaptive), int(substeps)
         o.flux_balance_tol = float(flux_balance_tol)
@@ -279,7 +291,7 @@ class NativeSolver:
         o.outflow_tol = float(outflow_tol)
         o.max_substeps = int(max_substeps)
         out = (ctypes.c_int32 * 6)()
-        flux = (ctypes.c_float * self.B)()
+        flux = (self._c_real * self.B)()
         rc = self.lib.fg_single_step(self.handle, ctypes.byref(o), out, flux, _stream(self.device))
         if rc == L.FG_ERR_FLUX_BALANCE:
             raise RuntimeError(
@@ -291,7 +303,7 @@ class NativeSolver:
         return bool(out[5]), [int(out[i]) for i in range(4)], int(out[4])
 
     def reset_solver_state(self):
-        L.check(self.lib.fg_reset_solver_state(self.handle, _stream(self.device)))
+        L.check(self.lib.fg_reset_solver_state(self.handle, _stream(self.device)), lib=self.lib)
 
     def make_divergence_free(self, tol=1e-5, max_iterations=1000):
         info = self._infos(self.B)
@@ -302,15 +314,15 @@ class NativeSolver:
     # ------------------------------------------------------------------ standalone Poisson
     def poisson_apply(self, rA, x, y=None):
         y = torch.empty_like(x) if y is None else y
-        L.check(self.lib.fg_poisson_apply(self.handle, _ptr(rA), _ptr(x), _ptr(y), _stream(self.device)))
+        L.check(self.lib.fg_poisson_apply(self.handle, _ptr(rA), _ptr(x), _ptr(y), _stream(self.device)), lib=self.lib)
         return y
 
     def poisson_jacobi(self, rA, b, x, sweeps, omega=1.0):
-        L.check(self.lib.fg_poisson_jacobi(self.handle, _ptr(rA), _ptr(b), _ptr(x), sweeps, omega, _stream(self.device)))
+        L.check(self.lib.fg_poisson_jacobi(self.handle, _ptr(rA), _ptr(b), _ptr(x), sweeps, omega, _stream(self.device)), lib=self.lib)
         return x
 
     def poisson_rbgs(self, rA, b, x, sweeps, omega=1.0):
-        L.check(self.lib.fg_poisson_rbgs(self.handle, _ptr(rA), _ptr(b), _ptr(x), sweeps, omega, _stream(self.device)))
+        L.check(self.lib.fg_poisson_rbgs(self.handle, _ptr(rA), _ptr(b), _ptr(x), sweeps, omega, _stream(self.device)), lib=self.lib)
         return x
 
     def poisson_cg(self, rA, b, x, tol=1e-5, max_iterations=5000, use_x0=False):
@@ -325,9 +337,9 @@ class NativeSolver:
         """Iterations of the linear solves since the last reset: per kind (scalar, velocity, pressure corrector 0 / 1) the
         mean and max per system (env x component) and the number of PISO steps (``fg_solver_counters``)."""
         unconv = (ctypes.c_int64 * 4)()
-        L.check(self.lib.fg_solver_unconverged(self.handle, unconv))      # (read before the counters are cleared)
+        L.check(self.lib.fg_solver_unconverged(self.handle, unconv))      # (read before the counters are cleared, lib=self.lib)
         out = (ctypes.c_int64 * 13)()
-        L.check(self.lib.fg_solver_counters(self.handle, out, int(reset)))
+        L.check(self.lib.fg_solver_counters(self.handle, out, int(reset)), lib=self.lib)
         names = ("scalar", "velocity", "pressure0", "pressure1")
         res = {n: {"mean": (out[k] / out[4 + k]) if out[4 + k] else None, "max": int(out[8 + k]), "systems": int(out[4 + k]),
                     "unconverged": int(unconv[k])}
@@ -337,26 +349,28 @@ class NativeSolver:
 
     def set_return_best(self, on: bool = True):
         """``pressure_return_best_result`` of the reference's Simulation: keep / hand back the best CG iterate."""
-        L.check(self.lib.fg_set_return_best(self.handle, int(on)))
+        L.check(self.lib.fg_set_return_best(self.handle, int(on)), lib=self.lib)
 
     def set_advection_start(self, from_result: bool = True):
         """Start vector of the velocity solve: ``velocityResult`` (the reference's orthogonal branch) or zero (its non-orthogonal
         branch, first pass) -- ``fg_set_advection_start``."""
-        L.check(self.lib.fg_set_advection_start(self.handle, int(from_result)))
+        L.check(self.lib.fg_set_advection_start(self.handle, int(from_result)), lib=self.lib)
 
     def set_advection_preconditioner(self, mode: int = 0):
         """Preconditioner policy of the advection-diffusion BiCGStab (``fg_set_advection_preconditioner``): 0 plain (the
         reference's first rung), 1 every solve right-preconditioned by the y-line solve (its ``preconditionBiCG``), 2 only
         to repeat a failed solve (its ``BiCG_precondition_fallback``)."""
-        L.check(self.lib.fg_set_advection_preconditioner(self.handle, int(mode)))
+        if self.f64:
+            return    # the y-line preconditioner is an fp32 kernel family: the fp64 build keeps the plain recurrence (mode 0)
+        L.check(self.lib.fg_set_advection_preconditioner(self.handle, int(mode)), lib=self.lib)
 
     def advection_retries(self, reset: bool = False) -> int:
         out = ctypes.c_int64()
-        L.check(self.lib.fg_advection_retries(self.handle, ctypes.byref(out), int(reset)))
+        L.check(self.lib.fg_advection_retries(self.handle, ctypes.byref(out), int(reset)), lib=self.lib)
         return int(out.value)
 
     def profile_enable(self, on: bool = True):
-        L.check(self.lib.fg_profile_enable(self.handle, int(on)))
+        L.check(self.lib.fg_profile_enable(self.handle, int(on)), lib=self.lib)
 
     def profile_read(self):
         """{kernel name: dict(ms, samples, bytes, flops, full_ms, full_bytes, full_samples, launches)} of the sampled

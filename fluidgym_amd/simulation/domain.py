@@ -126,7 +126,7 @@ class Block:
         self.name = name
         self.vertexCoordinates = coords
         self.edges = grids.edges_from_vertex_grid(coords)
-        self.widths = [np.diff(e).astype(np.float32) for e in self.edges]
+        self.widths = [np.diff(e).astype(np.float64 if domain.dtype == torch.float64 else np.float32) for e in self.edges]
         d = domain.dims
         assert len(self.edges) == d
         self._fixed: Dict[int, FixedBoundary] = {}
@@ -237,7 +237,7 @@ class Block:
         d = len(centers)
         mesh = np.meshgrid(*[c for c in reversed(centers)], indexing="ij")
         c = np.stack([mesh[d - 1 - a] for a in range(d)], axis=0)[None]
-        return torch.from_numpy(c).to(self.domain.device, torch.float32)
+        return torch.from_numpy(c).to(self.domain.device, self.domain.dtype)
 
     def getCellSizes(self) -> torch.Tensor:
         """Cell volumes ``[1, 1, (Z,) Y, X]`` (the determinant of the cell transform)."""
@@ -250,9 +250,11 @@ class Domain:
 
     def __init__(self, spatialDims: int, viscosity, passiveScalarChannels: int = 0, name: str = "Domain",
                  device=None, dtype=torch.float32, batch: int = 1):
-        if dtype != torch.float32:
-            raise NotImplementedError("the HIP kernels are instantiated for fp32 fields only (the reference's default dtype, "
-                                      "fluid_env.py:146); dtype=torch.float64 is not built (DESIGN.md section 7)")
+        if dtype not in (torch.float32, torch.float64):
+            raise NotImplementedError("field dtype must be torch.float32 (the reference's default, fluid_env.py:146) or torch.float64")
+        # torch.float64: the fields, metrics and every kernel of the step run in fp64 on the fp64 build of the library
+        # (libfluidgym_hip_f64.so); the pressure solver is the reference's plain CG there (the fast-diagonalisation
+        # preconditioner is an fp32 kernel family)
         self.dims = int(spatialDims)
         self.name = name
         self.dtype = dtype
@@ -300,7 +302,7 @@ class Domain:
         fixed = sorted(blk._fixed.keys())
         scalar_bc = {f: blk._fixed[f].passiveScalarTypes for f in fixed} if self.n_scalars else None
         self.solver = NativeSolver(blk.widths, self.batch, fixed_faces=fixed, n_scalars=self.n_scalars,
-                                   scalar_bc=scalar_bc, device=self.device)
+                                   scalar_bc=scalar_bc, device=self.device, dtype=self.dtype)
         self.solver.set_viscosity(self._viscosity)
         if self._scalar_viscosity is not None:
             self.setScalarViscosity(self._scalar_viscosity)

@@ -79,15 +79,16 @@ class UniformResampler:
         self.handle = handle
 
     def __call__(self, data: torch.Tensor) -> torch.Tensor:
-        assert data.is_cuda and data.dtype == torch.float32 and data.dim() == self.dims + 2
+        assert data.is_cuda and data.dim() == self.dims + 2
         assert list(data.shape[2:]) == list(reversed(self.n_src)), "data does not match the block resolution"
-        data = data.contiguous()
+        in_dtype = data.dtype
+        data = data.to(torch.float32).contiguous()      # the gather is an fp32 kernel; fp64 fields are observed through a cast
         B, C = data.shape[:2]
         out = torch.empty((B, C) + tuple(reversed(self.out_shape)), dtype=torch.float32, device=data.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(data.device).cuda_stream)
         L.check(self.lib.fg_resample(self.handle, ctypes.c_void_p(data.data_ptr()), B, C, ctypes.c_void_p(out.data_ptr()),
                                      self.fill_max_steps, stream))
-        return out
+        return out if in_dtype == torch.float32 else out.to(in_dtype)
 
     def close(self):
         if getattr(self, "handle", None):

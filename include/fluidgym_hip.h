@@ -36,6 +36,17 @@ extern "C" {
 #endif
 
 #define FG_ABI_VERSION 1
+
+/* Scalar type of the fields, metrics and real-valued arguments of the SINGLE-BLOCK entry points (fg_create .. fg_poisson_fdcg).
+ * libfluidgym_hip.so is built with fg_real = float (the reference's default dtype, envs/fluid_env.py:146);
+ * libfluidgym_hip_f64.so is the same sources built with -DFG_REAL_DOUBLE: fg_real = double, for FluidEnv(dtype=torch.float64)
+ * (assembly, BiCGStab, CG and the step drivers; the fp32-only fast-diagonalisation / z-marching / line-preconditioner kernels and
+ * the multi-block path are not part of that build and their entry points return FG_ERR_UNSUPPORTED or are absent). */
+#ifdef FG_REAL_DOUBLE
+typedef double fg_real;
+#else
+typedef float fg_real;
+#endif
 #define FG_MAX_SCALARS 4
 
 /* status codes */
@@ -99,16 +110,16 @@ const char* fg_last_error(void);                 /* thread-local message of the 
 
 /* Domain()+CreateBlock()+PrepareSolve() (PISOtorch.cpp:420-500; domain_structs.cpp:2570-2693).
  * hx/hy/hz_host: per-axis cell widths (host arrays of nx/ny/nz floats; hz may be NULL in 2-D). */
-int fg_create(const fg_config* cfg, const float* hx_host, const float* hy_host, const float* hz_host,
+int fg_create(const fg_config* cfg, const fg_real* hx_host, const fg_real* hy_host, const fg_real* hz_host,
               fg_handle* out);
 int fg_destroy(fg_handle h);
 
 /* Block.setVelocity()/setPressure()/... + Domain.UpdateDomainData() (domain_structs.cpp:3047-3283):
  * bind (borrow) a caller-owned device buffer.  field = enum fg_field (+ face for boundaries). */
-int fg_bind(fg_handle h, int field, float* ptr);
+int fg_bind(fg_handle h, int field, fg_real* ptr);
 /* Domain.viscosity / Domain.setScalarViscosity (domain_structs.cpp:3070) */
-int fg_set_viscosity(fg_handle h, float viscosity);
-int fg_set_scalar_viscosity(fg_handle h, int channel, float viscosity);
+int fg_set_viscosity(fg_handle h, fg_real viscosity);
+int fg_set_scalar_viscosity(fg_handle h, int channel, fg_real viscosity);
 
 /* Fast-diagonalisation preconditioner factors for FG_SOLVER_FDCG (host arrays, copied to the device):
  * Qx [nx,nx] / QxT: H-orthonormal eigenbasis of the 1-D x operator and its transpose, Qz / QzT the same
@@ -137,29 +148,29 @@ int fg_set_advection_start(fg_handle h, int from_result);
 
 /* ---- reductions used by the drivers --------------------------------------------------------- */
 /* Domain.getMaxVelocity(withBounds=True, computational=True) (domain_structs.cpp:1580-1611) */
-int fg_max_velocity(fg_handle h, float* out_B, void* stream);
+int fg_max_velocity(fg_handle h, fg_real* out_B, void* stream);
 /* Domain.GetBoundaryFluxBalance (domain_structs.cpp:2476-2509) */
-int fg_boundary_flux_balance(fg_handle h, float* out_B, void* stream);
+int fg_boundary_flux_balance(fg_handle h, fg_real* out_B, void* stream);
 
 /* Both reductions with ONE device->host transfer and one stream sync: out_host[0..B) = flux balance,
  * out_host[B..2B) = max velocity (what Simulation.single_step + _PISO_adaptive_step read per substep,
  * simulation.py:223-231 and PISOtorch_simulation.py:2013-2014). */
-int fg_step_diagnostics(fg_handle h, float* out_host_2B, void* stream);
+int fg_step_diagnostics(fg_handle h, fg_real* out_host_2B, void* stream);
 /* update_advective_boundaries for one FIXED face with characteristic velocity velm (host, d floats)
  * (PISOtorch_simulation.py:282-389); envs with dt_B[b] <= 0 are skipped. */
-int fg_update_advective_boundary(fg_handle h, int face, const float* velm_host, const float* dt_B, void* stream);
+int fg_update_advective_boundary(fg_handle h, int face, const fg_real* velm_host, const fg_real* dt_B, void* stream);
 /* balance_boundary_fluxes (PISOtorch_simulation.py:188-224): free_face_mask bit f = face f is free. */
-int fg_balance_boundary_fluxes(fg_handle h, int free_face_mask, float atol, const float* dt_B, void* stream);
+int fg_balance_boundary_fluxes(fg_handle h, int free_face_mask, fg_real atol, const fg_real* dt_B, void* stream);
 
 /* ---- PISO building blocks (one call = the reference free function of the same role) --------- */
 /* SetupAdvectionMatrix (PISO_multiblock_cuda_kernel.cu:4525-4546, kernel :3616-3880) fused with
  * SetupAdvectionVelocity (:4692-4708, kernel :4296-4400) or, when for_scalar != 0, with
  * SetupAdvectionScalar (:4620-4637, kernel :4094-4198) for `channel`. */
-int fg_setup_advection(fg_handle h, const float* dt_B, int for_scalar, int channel, void* stream);
+int fg_setup_advection(fg_handle h, const fg_real* dt_B, int for_scalar, int channel, void* stream);
 /* SolveLinear(C, RHS, x, useBiCG=True) (:7085-7118; bicgstab_solver_kernel.cu:63-411) for the
  * velocity components (for_scalar = 0; x0 = previous velocityResult) or a scalar channel.
  * info_host: d (or 1) * B entries, written after an internal stream sync. */
-int fg_solve_advection(fg_handle h, int for_scalar, int channel, float tol, int max_iterations,
+int fg_solve_advection(fg_handle h, int for_scalar, int channel, fg_real tol, int max_iterations,
                        fg_solve_info* info_host, void* stream);
 /* Preconditioner policy of the advection-diffusion solves (scalar and velocity), the reference's preconditionBiCG /
  * BiCG_precondition_fallback (PISOtorch_simulation.py:503, 565; PISOtorch_diff.py:449-476; cuSPARSE ILU(0),
@@ -174,10 +185,10 @@ int fg_copy_scalar_result_to_blocks(fg_handle h, int channel, void* stream);
 /* SetupPressureMatrix (:5599-5615, kernel :4812-4978): rA = 1/A */
 int fg_setup_pressure_matrix(fg_handle h, void* stream);
 /* SetupPressureRHS (:5655-5672, kernels :5136-5255 + :5389-5434): h = H(u~), b = div h */
-int fg_setup_pressure_rhs(fg_handle h, const float* dt_B, void* stream);
+int fg_setup_pressure_rhs(fg_handle h, const fg_real* dt_B, void* stream);
 /* SolveLinear(P, div, x, useBiCG=False) + `p -= mean(p)` (PISOtorch_simulation.py:1804-1821) +
  * CopyPressureResultToBlocks.  method = FG_SOLVER_*.  info_host: B entries. */
-int fg_solve_pressure(fg_handle h, int method, float tol, int max_iterations, int use_previous,
+int fg_solve_pressure(fg_handle h, int method, fg_real tol, int max_iterations, int use_previous,
                       fg_solve_info* info_host, void* stream);
 /* CorrectVelocity(version=1) (:6220-6236, kernel :5962-5995 + :816-849) */
 int fg_correct_velocity(fg_handle h, void* stream);
@@ -194,16 +205,16 @@ typedef struct fg_step_options {
     int32_t advect_scalar;        /* solve passive scalars first */
     int32_t pressure_method;      /* FG_SOLVER_* */
     int32_t max_iterations;       /* 5000 (PISOtorch_simulation.py:564) */
-    float advection_tol;          /* RMS residual, 1e-5 default (PISOtorch_diff.py:247-253) */
-    float pressure_tol;
+    fg_real advection_tol;          /* RMS residual, 1e-5 default (PISOtorch_diff.py:247-253) */
+    fg_real pressure_tol;
     int32_t buoyancy_axis;        /* -1 = none */
-    float buoyancy_factor;
+    fg_real buoyancy_factor;
     int32_t pressure_warm_start;  /* 1: start each pressure solve from the previous pressureResult (the
                                      reference passes x=None in its orthogonal branch and pressureResult
                                      in its non-orthogonal branch, PISOtorch_simulation.py:1804-1812 vs
                                      :1878-1882; the converged answer is the same) */
 } fg_step_options;
-int fg_piso_step(fg_handle h, const float* dt_B, const fg_step_options* opt, int32_t* stats_host,
+int fg_piso_step(fg_handle h, const fg_real* dt_B, const fg_step_options* opt, int32_t* stats_host,
                  void* stream);
 /* Iteration statistics of the linear solves since the last reset (host bookkeeping of the LinearSolverResultInfo every
  * SolveLinear call returns, bicgstab_solver.h): out13 = sum of iterations [4] | systems solved [4] | max iterations [4] |
@@ -223,20 +234,20 @@ int fg_solver_unconverged(fg_handle h, int64_t* out4_host);
  * flux_balance_host (optional, B floats) receives the guard values. */
 typedef struct fg_sim_options {
     fg_step_options step;
-    float time_step;          /* physical time advanced per call */
-    float cfl;                /* adaptive_CFL */
+    fg_real time_step;          /* physical time advanced per call */
+    fg_real cfl;                /* adaptive_CFL */
     int32_t adaptive;         /* 1: substeps == -1 ("ADAPTIVE"); 0: `substeps` fixed steps of time_step */
     int32_t substeps;
-    float flux_balance_tol;   /* 1e-5 */
+    fg_real flux_balance_tol;   /* 1e-5 */
     int32_t outflow_mask;     /* bit f: FIXED face f is an advective outflow (0 = none) */
-    float outflow_velm[3];    /* characteristic velocity u_m */
-    float outflow_tol;        /* flux re-balancing triggers above 0.01 * outflow_tol */
+    fg_real outflow_velm[3];    /* characteristic velocity u_m */
+    fg_real outflow_tol;        /* flux re-balancing triggers above 0.01 * outflow_tol */
     int32_t max_substeps;     /* safety cap (reference warns above 1000) */
 } fg_sim_options;
-int fg_single_step(fg_handle h, const fg_sim_options* opt, int32_t* out_host_6, float* flux_balance_host,
+int fg_single_step(fg_handle h, const fg_sim_options* opt, int32_t* out_host_6, fg_real* flux_balance_host,
                    void* stream);
 /* make_divergence_free (PISOtorch_simulation.py:1320-1429) */
-int fg_make_divergence_free(fg_handle h, float tol, int max_iterations, fg_solve_info* info_host,
+int fg_make_divergence_free(fg_handle h, fg_real tol, int max_iterations, fg_solve_info* info_host,
                             void* stream);
 
 /* ---- access to solver vectors (tests / fixtures) -------------------------------------------- */
@@ -252,25 +263,25 @@ enum fg_buffer {
 };
 /* velocityResult := block velocity, pressureResult := 0 (call after re-initialising the fields) */
 int fg_reset_solver_state(fg_handle h, void* stream);
-int fg_get_buffer(fg_handle h, int which, float** out_ptr, int64_t* out_count);
+int fg_get_buffer(fg_handle h, int which, fg_real** out_ptr, int64_t* out_count);
 /* device-to-device copy of a solver vector into a caller buffer of fg_get_buffer's count */
-int fg_read_buffer(fg_handle h, int which, float* dst, void* stream);
+int fg_read_buffer(fg_handle h, int which, fg_real* dst, void* stream);
 
 /* ---- standalone pressure-Poisson kernels on caller arrays (micro-benchmark / tests) ----------
  * Operator: (P x)_c = sum_f off_f (x_N - x_c), off_f = (alpha_P rA_P + alpha_N rA_N)/2, no entry at
  * FIXED faces (PISO_multiblock_cuda_kernel.cu:4842-4889).  All arrays [B,N]. */
-int fg_poisson_apply(fg_handle h, const float* rA, const float* x, float* y, void* stream);
+int fg_poisson_apply(fg_handle h, const fg_real* rA, const fg_real* x, fg_real* y, void* stream);
 /* n_sweeps damped-Jacobi / red-black Gauss-Seidel sweeps on P x = b (x updated in place; Jacobi
  * uses the handle's scratch vector).  omega = relaxation factor. */
-int fg_poisson_jacobi(fg_handle h, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+int fg_poisson_jacobi(fg_handle h, const fg_real* rA, const fg_real* b, fg_real* x, int n_sweeps, fg_real omega,
                       void* stream);
-int fg_poisson_rbgs(fg_handle h, const float* rA, const float* b, float* x, int n_sweeps, float omega,
+int fg_poisson_rbgs(fg_handle h, const fg_real* rA, const fg_real* b, fg_real* x, int n_sweeps, fg_real omega,
                     void* stream);
 /* n_iterations of CG without convergence polling (timing) -- or a full solve when tol > 0. */
-int fg_poisson_cg(fg_handle h, const float* rA, const float* b, float* x, float tol, int max_iterations,
+int fg_poisson_cg(fg_handle h, const fg_real* rA, const fg_real* b, fg_real* x, fg_real tol, int max_iterations,
                   int use_x0, fg_solve_info* info_host, void* stream);
 /* same with the fast-diagonalisation preconditioner (FG_SOLVER_FDCG) */
-int fg_poisson_fdcg(fg_handle h, const float* rA, const float* b, float* x, float tol, int max_iterations,
+int fg_poisson_fdcg(fg_handle h, const fg_real* rA, const fg_real* b, fg_real* x, fg_real tol, int max_iterations,
                     int use_x0, fg_solve_info* info_host, void* stream);
 
 /* ---- live kernel timing for bench.py's roofline -----------------------------------------------

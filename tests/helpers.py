@@ -59,27 +59,30 @@ class Case:
             velocity_source=None if self.source is None else self.source[b].astype(np.float64),
         )
 
-    def native(self, device=None):
+    def native(self, device=None, dtype=None):
+        """``dtype=torch.float64``: the fp64 build of the library; the fields then carry the oracle's own fp64 values."""
         import torch
 
         from fluidgym_amd.native import NativeSolver
 
+        dtype = torch.float32 if dtype is None else dtype
+        npt = np.float64 if dtype == torch.float64 else np.float32
         ns = NativeSolver(self.widths, self.B, fixed_faces=self.fixed_faces,
                           n_scalars=0 if self.scalar is None else self.scalar.shape[1],
-                          scalar_bc=self.scalar_bc, device=device)
+                          scalar_bc=self.scalar_bc, device=device, dtype=dtype)
         dev = ns.device
         ns.set_viscosity(self.nu)
-        ns.velocity.copy_(torch.from_numpy(self.velocity.astype(np.float32)).to(dev))
+        ns.velocity.copy_(torch.from_numpy(self.velocity.astype(npt)).to(dev))
         for f in self.fixed_faces:
-            ns.bvel[f].copy_(torch.from_numpy(self.bvel[f].astype(np.float32)).to(dev))
+            ns.bvel[f].copy_(torch.from_numpy(self.bvel[f].astype(npt)).to(dev))
             if self.bscal is not None:
-                ns.bscal[f].copy_(torch.from_numpy(self.bscal[f].astype(np.float32)).to(dev))
+                ns.bscal[f].copy_(torch.from_numpy(self.bscal[f].astype(npt)).to(dev))
         if self.scalar is not None:
-            ns.scalar.copy_(torch.from_numpy(self.scalar.astype(np.float32)).to(dev))
+            ns.scalar.copy_(torch.from_numpy(self.scalar.astype(npt)).to(dev))
             for ch, k in enumerate(self.kappa or []):
                 ns.set_scalar_viscosity(ch, k)
         if self.source is not None:
-            ns.set_velocity_source(torch.from_numpy(self.source.astype(np.float32)).to(dev).contiguous())
+            ns.set_velocity_source(torch.from_numpy(self.source.astype(npt)).to(dev).contiguous())
         ns.copy_velocity_result_from_blocks()  # velocityResult starts as the block velocity
         return ns
 

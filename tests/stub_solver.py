@@ -12,7 +12,7 @@ import torch
 
 
 class StubSolver:
-    def __init__(self, widths, batch, fixed_faces=(), n_scalars=0, scalar_bc=None, device=None, allocate=True):
+    def __init__(self, widths, batch, fixed_faces=(), n_scalars=0, scalar_bc=None, device=None, allocate=True, dtype=torch.float32):
         self.device = torch.device("cpu")
         self.dims = len(widths)
         self.widths = [np.ascontiguousarray(w, dtype=np.float32) for w in widths]

@@ -1,0 +1,108 @@
+"""dtype=torch.float64: the fp64 build of the single-block path (libfluidgym_hip_f64.so, fg_real = double) against the fp64 oracle.
+
+The reference's envs take ``dtype`` (envs/fluid_env.py:146) and its retry chain re-solves in fp64 (PISOtorch_diff.py:418-445).  With
+fp64 fields the comparison with the oracle is no longer limited by fp32 rounding: assembly to 1e-12, quantities behind a Krylov
+solve (tolerance 1e-12) and whole PISO steps to 1e-9 -- four orders tighter than the fp32 gate, on the same kernels' source."""
+import numpy as np
+import pytest
+import torch
+
+from fluidgym_amd import _lib as L
+from oracle import piso_oracle as O
+from tests.helpers import make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+F64 = torch.float64
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+CASES = [dict(dims=2, n=(32, 24), fixed_axes=(1,), B=2, seed=5, with_source=True),
+         dict(dims=2, n=(30, 17), fixed_axes=(0, 1), B=2, seed=6, through_flow_axis=0),
+         dict(dims=3, n=(12, 10, 8), fixed_axes=(1,), B=2, seed=7),
+         dict(dims=2, n=(24, 16), fixed_axes=(1,), B=2, seed=8, n_scalars=1, neumann_faces=(3,))]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_fp64_assembly_and_solves_match_the_oracle(kw):
+    case = make_case(vel_scale=0.4, nu=0.03, **kw)
+    ns = case.native(dtype=F64)
+    assert ns.velocity.dtype == F64 and ns.f64
+    dt = 0.05
+    g = case.grid()
+    shape = (case.B, case.dims) + case.shape
+    ns.set_advection_start(False)
+    ns.setup_advection(dt)
+    A = _np(ns.buffer(L.FG_BUF_A, (case.B,) + case.shape))
+    rhs = _np(ns.buffer(L.FG_BUF_ADV_RHS, shape))
+    info = ns.solve_advection(tol=1e-13)
+    assert all(i.converged and i.is_finite for i in info)
+    x = _np(ns.buffer(L.FG_BUF_VEL_RESULT, shape))
+    for b in range(case.B):
+        dom = case.oracle_domain(b, g)
+        C, A_ref, _ = O.build_advection_matrix(dom, dt)
+        rhs_ref = O.advection_rhs_velocity(dom, dt)
+        assert rel_err(A[b], A_ref) < 1e-12
+        assert rel_err(rhs[b], rhs_ref) < 1e-12
+        for comp in range(case.dims):
+            assert rel_err(x[b, comp], O.solve_direct(C, rhs_ref[comp].ravel()).reshape(case.shape)) < 1e-10
+    ns.close()
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_fp64_piso_step_matches_the_oracle_to_1e9(kw):
+    """The whole split step (scalar, predictor, two correctors; pressure by the reference's plain CG in the fp64 build) from
+    identical state: max|diff| / max|ref| below 1e-9 for velocity, 1e-8 for pressure -- the fp32 gate is 1e-5."""
+    case = make_case(vel_scale=0.4, nu=0.03, **kw)
+    ns = case.native(dtype=F64)
+    dt = 0.03
+    ok, stats = ns.piso_step(dt, advection_tol=1e-13, pressure_tol=1e-13, max_iterations=20000)
+    assert ok, stats
+    g = case.grid()
+    for b in range(case.B):
+        dom = case.oracle_domain(b, g)
+        O.piso_split_step(dom, dt)
+        assert rel_err(_np(ns.velocity[b]), dom.velocity) < 1e-9, (b, stats)
+        p = _np(ns.pressure[b, 0])
+        assert rel_err(p - p.mean(), dom.pressure - dom.pressure.mean()) < 1e-8
+        if case.scalar is not None:
+            assert rel_err(_np(ns.scalar[b]), dom.scalar) < 1e-9
+    ns.close()
+
+
+def test_fp64_env_steps_like_the_fp32_env():
+    """FluidEnv(dtype=torch.float64) as in the reference: fp64 fields through make(); one env step agrees with the fp32 env to
+    what the envs' solver tolerances (1e-5) leave, and the fp64 env replays bit for bit."""
+    import fluidgym_amd
+
+    out = {}
+    for dtype in (torch.float32, F64):
+        env = fluidgym_amd.make("ChannelJet2D-v0", num_envs=2, resolution_x=64, resolution_y=32, dtype=dtype,
+                                randomize_initial_state=False)
+        obs, _ = env.reset(seed=3)
+        assert env._domain.solver.velocity.dtype == dtype
+        s0 = env.get_state()
+        a = torch.tensor([[0.5], [-0.25]], device="cuda")
+        o1, r1, *_ = env.step(a)
+        env.set_state(s0)
+        o2, r2, *_ = env.step(a)
+        assert torch.equal(r1, r2) and torch.equal(o1["velocity"], o2["velocity"])
+        out[dtype] = (env._domain.solver.velocity.double().clone(), r1.double().clone())
+        env.close()
+    u32, r32 = out[torch.float32]
+    u64, r64 = out[F64]
+    assert torch.isfinite(u64).all()
+    assert float((u32 - u64).abs().max() / u64.abs().max()) < 2e-3
+    assert torch.allclose(r32, r64, rtol=2e-2, atol=1e-4)
+
+
+def test_fp64_build_reports_what_it_does_not_carry():
+    case = make_case(dims=2, n=(16, 12), fixed_axes=(1,), B=1, seed=1)
+    ns = case.native(dtype=F64)
+    assert ns.has_fd is False and ns.default_method == L.FG_SOLVER_CG
+    rc = ns.lib.fg_set_advection_preconditioner(ns.handle, 1)          # the y-line preconditioner is an fp32 kernel family
+    assert rc == -4
+    ns.close()
