@@ -33,6 +33,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.fg_abi_version() == 1
 
 
+def test_fp64_build_exports_the_single_block_entry_points_with_double_signatures():
+    """libfluidgym_hip_f64.so (fg_real = double, include/fluidgym_hip.h): every single-block symbol of the header, typed with
+    doubles where the fp32 library takes floats; the multi-block / resampling symbols are not part of it."""
+    lib = L.load_f64()
+    declared = [n for n in _declared_symbols() if not n.startswith(("fg_mb_", "fg_resampl", "fg_sparse_"))]
+    assert set(L.SIGNATURES_F64) == set(declared)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert not hasattr(lib, "fg_mb_create")
+    assert lib.fg_abi_version() == 1
+    assert L.SIGNATURES_F64["fg_set_viscosity"][1][1] is ctypes.c_double
+    assert L.SIGNATURES_F64["fg_create"][1][1] is ctypes.POINTER(ctypes.c_double)
+    assert dict(L.FgSimOptionsF64._fields_)["time_step"] is ctypes.c_double
+    assert dict(L.FgStepOptionsF64._fields_)["advection_tol"] is ctypes.c_double
+    # error paths answer with codes there too
+    cfg = L.FgConfig()
+    cfg.dims, cfg.nx, cfg.ny, cfg.nz, cfg.batch = 4, 8, 8, 1, 1
+    h = ctypes.c_void_p()
+    w = np.ones(8, np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert lib.fg_create(ctypes.byref(cfg), w.ctypes.data_as(dp), w.ctypes.data_as(dp), None, ctypes.byref(h)) == -1
+    assert b"dims" in lib.fg_last_error()
+
+
 def test_invalid_arguments_return_status_codes():
     lib = L.load()
     cfg = L.FgConfig()

@@ -45,10 +45,11 @@ def test_fp64_assembly_and_solves_match_the_oracle(kw):
         dom = case.oracle_domain(b, g)
         C, A_ref, _ = O.build_advection_matrix(dom, dt)
         rhs_ref = O.advection_rhs_velocity(dom, dt)
+        ex = max(rel_err(x[b, comp], O.solve_direct(C, rhs_ref[comp].ravel()).reshape(case.shape)) for comp in range(case.dims))
+        print(f"F64_ERR assembly dims={case.dims} env {b}: A {rel_err(A[b], A_ref):.1e} rhs {rel_err(rhs[b], rhs_ref):.1e} solve {ex:.1e}")
         assert rel_err(A[b], A_ref) < 1e-12
         assert rel_err(rhs[b], rhs_ref) < 1e-12
-        for comp in range(case.dims):
-            assert rel_err(x[b, comp], O.solve_direct(C, rhs_ref[comp].ravel()).reshape(case.shape)) < 1e-10
+        assert ex < 1e-10
     ns.close()
 
 
@@ -65,9 +66,11 @@ def test_fp64_piso_step_matches_the_oracle_to_1e9(kw):
     for b in range(case.B):
         dom = case.oracle_domain(b, g)
         O.piso_split_step(dom, dt)
-        assert rel_err(_np(ns.velocity[b]), dom.velocity) < 1e-9, (b, stats)
         p = _np(ns.pressure[b, 0])
-        assert rel_err(p - p.mean(), dom.pressure - dom.pressure.mean()) < 1e-8
+        eu, ep = rel_err(_np(ns.velocity[b]), dom.velocity), rel_err(p - p.mean(), dom.pressure - dom.pressure.mean())
+        print(f"F64_ERR step dims={case.dims} env {b}: velocity {eu:.1e} pressure {ep:.1e} iterations {stats}")
+        assert eu < 1e-9, (b, stats)
+        assert ep < 1e-8
         if case.scalar is not None:
             assert rel_err(_np(ns.scalar[b]), dom.scalar) < 1e-9
     ns.close()
