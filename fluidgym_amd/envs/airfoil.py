@@ -171,6 +171,9 @@ class AirfoilEnvBase(CylinderEnvBase):
 
     # ---- domain and simulation (airfoil_env_base.py:216-311)
     def _get_domain(self):
+        if self._dtype != torch.float32:
+            raise NotImplementedError("dtype=torch.float64 is built for the single-block env families (channel, RBC, TCF: "
+                                      "libfluidgym_hip_f64.so); the multi-block kernels (cylinder, airfoil) are fp32 only")
         grow = 1.001 if (self._ndims == 3 and self._reynolds_number >= 5000) else 1.01      # airfoil_env_base.py:217-220
         self._mesh = self._mesh2d = make_airfoil_mesh(self.H, self.L, self.U_mean, self._attack_angle_deg, self._resolution_div,
                                                       grow, surface=self._surface)

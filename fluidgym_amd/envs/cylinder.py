@@ -124,6 +124,9 @@ class CylinderEnvBase(FluidEnv):
 
     # ---- domain and simulation (cylinder_env_base.py:233-329)
     def _get_domain(self) -> MultiBlockDomain:
+        if self._dtype != torch.float32:
+            raise NotImplementedError("dtype=torch.float64 is built for the single-block env families (channel, RBC, TCF: "
+                                      "libfluidgym_hip_f64.so); the multi-block kernels (cylinder, airfoil) are fp32 only")
         self._mesh = make_vortex_street_mesh(self._circle_resolution_angular, self.H, self.L, self.cylinder_diameter / 2,
                                              self.cylinder_offset_y, self.cylinder_diameter / 2, self.cylinder_diameter,
                                              self._vortex_street_refinement_base)

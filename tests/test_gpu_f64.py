@@ -113,3 +113,28 @@ def test_fp64_build_reports_what_it_does_not_carry():
     rc = ns.lib.fg_set_advection_preconditioner(ns.handle, 1)          # the y-line preconditioner is an fp32 kernel family
     assert rc == -4
     ns.close()
+
+
+@pytest.mark.parametrize("env_id,kw", [("RBC2D-easy-v0", dict(n_heaters=4, resolution=8)),
+                                       ("TCFSmall3D-both-easy-v0", dict(resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False))])
+def test_fp64_rbc_and_tcf_envs_run(env_id, kw):
+    """The other single-block families through make(dtype=torch.float64): fp64 fields, finite steps, observations through the
+    (fp32) resampling gather where the env uses it; the multi-block families refuse the dtype with the reason."""
+    import fluidgym_amd
+
+    env = fluidgym_amd.make(env_id, num_envs=2, dtype=F64, **kw)
+    obs, _ = env.reset(seed=1)
+    sol = env._domain.solver
+    assert sol.f64 and sol.velocity.dtype == F64 and sol.pressure.dtype == F64
+    o, r, term, trunc, info = env.step(env.sample_action())
+    assert torch.isfinite(r).all() and all(torch.isfinite(v).all() for v in o.values())
+    assert torch.isfinite(sol.velocity).all()
+    env.close()
+
+
+def test_fp64_is_refused_by_the_multi_block_envs():
+    import fluidgym_amd
+
+    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=1, dtype=F64)
+    with pytest.raises(NotImplementedError, match="single-block"):
+        env.reset(seed=0)
