@@ -217,6 +217,7 @@ SIGNATURES = {
     "fg_solver_unconverged": (c_int, [c_void_p, POINTER(c_int64)]),
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_set_advection_preconditioner": (c_int, [c_void_p, c_int]),
+    "fg_set_fd_helmholtz": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_advection_retries": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_profile_iterations": (c_int, [c_void_p, POINTER(c_int64)]),
@@ -255,7 +256,7 @@ _F64_STRUCTS: dict = {}
 _F64_STRUCTS[FgStepOptions] = _f64_struct(FgStepOptions)
 _F64_STRUCTS[FgSimOptions] = _f64_struct(FgSimOptions)
 FgStepOptionsF64, FgSimOptionsF64 = _F64_STRUCTS[FgStepOptions], _F64_STRUCTS[FgSimOptions]
-_F64_KEEP_FLOAT = ("fg_set_fd_preconditioner", "fg_set_fd_fast_transform", "fg_coords_to_transforms", "fg_stream_triad")
+_F64_KEEP_FLOAT = ("fg_set_fd_preconditioner", "fg_set_fd_fast_transform", "fg_set_fd_helmholtz", "fg_coords_to_transforms", "fg_stream_triad")
 _F64_ABSENT_PREFIXES = ("fg_mb_", "fg_resampl", "fg_sparse_")
 
 

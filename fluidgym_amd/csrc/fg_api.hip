@@ -110,6 +110,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr;
+    s->fd_lam = nullptr; s->helm_diag = s->helm_lower = s->helm_upper = s->helm_tmp = nullptr;
     { const char* ev = getenv("FG_CG_WGS_PER_SLOT"); s->cg_wgs_per_slot = (ev && atoi(ev) > 0) ? atoi(ev) : 256; }
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
     s->cg_return_best = 1;
@@ -140,6 +141,7 @@ extern "C" int fg_destroy(fg_handle s) {
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp);
+    (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
     return FG_OK;
@@ -217,7 +219,8 @@ extern "C" int fg_set_advection_start(fg_handle s, int from_result) {
 
 extern "C" int fg_set_advection_preconditioner(fg_handle s, int mode) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
-    FG_REQUIRE(mode >= 0 && mode <= 2, FG_ERR_INVALID_ARG, "fg_set_advection_preconditioner: mode must be 0 (off), 1 (always) or 2 (fallback)");
+    FG_REQUIRE(mode >= 0 && mode <= 3, FG_ERR_INVALID_ARG, "fg_set_advection_preconditioner: mode must be 0 (off), 1 (line, always), 2 (line, fallback) or 3 (Helmholtz, always)");
+    FG_REQUIRE(mode != 3 || s->fd_lam != nullptr, FG_ERR_INVALID_ARG, "fg_set_advection_preconditioner: mode 3 needs fg_set_fd_helmholtz");
     if (mode != 0)
         if (int rc = fg_line_alloc(s)) return rc;
     s->adv_precond = mode;
@@ -300,7 +303,7 @@ extern "C" int fg_setup_advection(fg_handle s, const fg_real* dt_B, int for_scal
     return fg_launch_adv_build(s, make_bounds(s, channel), a, (hipStream_t)stream);
 }
 
-static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st);
+static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st, int for_scalar = 0, int channel = 0);
 
 extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, fg_real tol, int max_iterations,
                                   fg_solve_info* info_host, void* stream) {
@@ -311,8 +314,7 @@ extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, fg_r
     a.tol = tol; a.max_iterations = max_iterations;
     if (for_scalar) { a.x = s->scal_result; a.nc = 1; a.use_x0 = 0; }
     else { a.x = s->vel_result; a.nc = s->grid.dims; a.use_x0 = s->adv_from_result; }
-    (void)channel;
-    return advection_solve(s, a, info_host, (hipStream_t)stream);
+    return advection_solve(s, a, info_host, (hipStream_t)stream, for_scalar, channel);
 }
 
 extern "C" int fg_copy_scalar_result_to_blocks(fg_handle s, int channel, void* stream) {
@@ -399,8 +401,13 @@ static int max_iters(const fg_solve_info* info, int n) {
 // form of the reference's retry chain (_linear_solve, PISOtorch_diff.py:449-476): mode 1 preconditions every solve
 // (preconditionBiCG), mode 2 repeats a solve that ended unconverged or non-finite from zero WITH the preconditioner
 // (BiCG_precondition_fallback) -- the reference's preconditioner is cuSPARSE ILU(0), here the y-line solve of fg_linepre.hip.
-static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st) {
-    a.precond = (s->adv_precond == 1);
+static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st, int for_scalar, int channel) {
+    a.precond = (s->adv_precond == 1) ? 1 : (s->adv_precond == 3 ? 2 : 0);
+    if (a.precond == 2) {   // Helmholtz (fast-diagonalisation) preconditioner: the diffusivity and wall treatment of THIS solve
+        a.nu = for_scalar ? (s->scalar_viscosity_set ? s->scalar_viscosity[channel] : s->viscosity) : s->viscosity;
+        a.wall_lo = for_scalar ? (s->cfg.scalar_bc[2][channel] == FG_DIRICHLET) : 1;
+        a.wall_hi = for_scalar ? (s->cfg.scalar_bc[3][channel] == FG_DIRICHLET) : 1;
+    }
     int rc = fg_bicgstab_solve(s, a, info, st);
     if ((rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) && s->adv_precond == 2) {
         s->line_retries += 1;
@@ -434,7 +441,7 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
             FgBicgArgs a;
             a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->scal_result; a.nc = 1;
             a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 0;
-            if (int rc = soft(advection_solve(s, a, info.data(), st))) return rc;
+            if (int rc = soft(advection_solve(s, a, info.data(), st, 1, ch))) return rc;
             const int m = max_iters(info.data(), B);
             stats[0] = m > stats[0] ? m : stats[0];
             s->ctr.add(0, info.data(), B);

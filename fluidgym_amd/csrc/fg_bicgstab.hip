@@ -755,8 +755,15 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     }
     const dim3 sg((nsys + 63) / 64), sb(64);
     hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
-    if (a.precond)
+    if (a.precond == 2) {
+        FG_REQUIRE(s->fd_lam != nullptr, FG_ERR_INVALID_ARG, "Helmholtz preconditioner requested but fg_set_fd_helmholtz was not called");
+        if (int rc = fg_helm_factor(s, a.dt, a.nu, a.wall_lo, a.wall_hi, a.nc, st)) return rc;
+    } else if (a.precond) {
         if (int rc = fg_line_factor(s, a.diag, a.off, a.nc, st)) return rc;
+    }
+    auto precondition = [&](const fg_real* in, fg_real* out) -> int {
+        return a.precond == 2 ? fg_fd_helmholtz_apply(s, a.nc, in, out, st) : fg_line_apply(s, a.diag, a.off, a.nc, in, out, st);
+    };
 
 #define FG_BICG_LAUNCH_Y(NY, SLOT, KERNEL, ...)                                                                          \
     do {                                                                                                     \
@@ -816,11 +823,11 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         if (it > 0) FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_P, q.flags, nsys, cells * 16.0, cells * 4.0, st), k_bicg_p, it);
         else FG_BICG_LAUNCH(-1, k_bicg_p, it);
         if (a.precond)
-            if (int rc = fg_line_apply(s, a.diag, a.off, a.nc, q.p, s->w[5], st)) return rc;
+            if (int rc = precondition(q.p, s->w[5])) return rc;
         FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICG_V, q.flags, nsys, cells * (12.0 + mat), cells * (fl + 2.0), st), k_bicg_v, it);
         FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_S, q.flags, nsys, cells * 12.0, cells * 4.0, st), k_bicg_s, it);
         if (a.precond)
-            if (int rc = fg_line_apply(s, a.diag, a.off, a.nc, q.r, s->w[6], st)) return rc;
+            if (int rc = precondition(q.r, s->w[6])) return rc;
         FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICG_T, q.flags, nsys, cells * (8.0 + mat), cells * (fl + 4.0), st), k_bicg_t, it);
         FG_BICG_LAUNCH(fg_prof_slot(s, FG_PK_BICG_X, q.flags, nsys, cells * 28.0, cells * 10.0, st), k_bicg_x, it);
         if (it + 1 >= next_poll || it + 1 == a.max_iterations) {

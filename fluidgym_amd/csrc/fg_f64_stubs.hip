@@ -24,10 +24,17 @@ int fg_line_alloc(fg_state*) {
     fg_set_error("the y-line preconditioner is an fp32 kernel family: not part of the fp64 build");
     return FG_ERR_UNSUPPORTED;
 }
+int fg_helm_alloc(fg_state*) { return FG_ERR_UNSUPPORTED; }
+int fg_helm_factor(fg_state*, const fg_real*, fg_real, int, int, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+int fg_fd_helmholtz_apply(fg_state*, int, const fg_real*, fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }
 int fg_line_factor(fg_state*, const fg_real*, const fg_real*, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
 int fg_line_apply(fg_state*, const fg_real*, const fg_real*, int, const fg_real*, fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }
 
 extern "C" int fg_set_fd_fast_transform(fg_handle, int, float) {
     fg_set_error("the fast cosine transform belongs to the fp32 fast-diagonalisation preconditioner: not part of the fp64 build");
+    return FG_ERR_UNSUPPORTED;
+}
+extern "C" int fg_set_fd_helmholtz(fg_handle, const float*) {
+    fg_set_error("the Helmholtz preconditioner belongs to the fp32 fast-diagonalisation kernels: not part of the fp64 build");
     return FG_ERR_UNSUPPORTED;
 }

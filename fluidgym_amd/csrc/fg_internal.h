@@ -533,6 +533,9 @@ struct fg_state {
     fg_real* line_inv; fg_real* line_cp;
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;   // (fp32 kernels only)
+    // separable Helmholtz preconditioner of the advection-diffusion solves (fg_set_fd_helmholtz): eigenvalue sums lam [nz][nx] of the
+    // transform axes, per-solve coefficient arrays [B][N] and a [B][d][N] temporary of the basis changes
+    float* fd_lam; float* helm_diag; float* helm_lower; float* helm_upper; float* helm_tmp;
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs
     int fd_dct_x; float2* fd_dct_tw; float2* fd_dct_rot; float fd_dct_fwd[2]; float fd_dct_inv[2];
     fg_real** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
@@ -637,7 +640,9 @@ struct FgBicgArgs {
     int nc;
     const fg_real* dt;
     fg_real tol; int max_iterations; int use_x0;
-    int precond = 0;   // 1: right-preconditioned by the y-line solve of fg_linepre.hip (v = C M^-1 p, t = C M^-1 s)
+    int precond = 0;   // 1: right-preconditioned by the y-line solve of fg_linepre.hip (v = C M^-1 p, t = C M^-1 s); 2: by the
+                       // separable Helmholtz operator I/dt - nu Laplacian (fast diagonalisation, fg_fd_helmholtz_apply)
+    fg_real nu = 0; int wall_lo = 1, wall_hi = 1;   // precond == 2: diffusivity of this solve; the variable is prescribed at the -y / +y wall
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
 
@@ -677,6 +682,11 @@ int fg_fd_apply(fg_state* s, const fg_real* r, fg_real* z, FgDacc* rz_acc, int r
 // y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
 // with a live system, z = M^-1 r for every live system
 int fg_line_alloc(fg_state* s);
+int fg_helm_alloc(fg_state* s);
+int fg_helm_factor(fg_state* s, const fg_real* dt, fg_real nu, int wall_lo, int wall_hi, int nc, hipStream_t st);
+// z = M^-1 r with M the separable Helmholtz operator factorised by fg_helm_factor: basis change along x (and z), tridiagonal solve
+// along y per mode and env, basis change back (fg_fdprecond.hip)
+int fg_fd_helmholtz_apply(fg_state* s, int nc, const fg_real* r, fg_real* z, hipStream_t st);
 int fg_line_factor(fg_state* s, const fg_real* diag, const fg_real* off, int nc, hipStream_t st);
 int fg_line_apply(fg_state* s, const fg_real* diag, const fg_real* off, int nc, const fg_real* r, fg_real* z, hipStream_t st);
 int fg_metrics_launch(const float* coords, float* transforms, int dims, int nx, int ny, int nz, hipStream_t st);

@@ -20,7 +20,9 @@ constexpr int LP_CH = 16;
 
 struct LineArgs {
     const float* diag;   // [B][N]
-    const float* off;    // [B][2 d][N], face order: 2 = -y, 3 = +y
+    const float* lower;  // -y coefficient of every cell, env b at lower + b * lu_stride
+    const float* upper;  // +y coefficient
+    size_t lu_stride;
     float* inv;          // [B][N]
     float* cp;           // [B][N]
     int nx, ny, nz, dims, nc;
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(256) void k_line_factor_y(LineArgs a) {
     float* us = tbuf + (size_t)2 * nyp * 64;
     const LineCol c = line_col(nx, ny, a.nz);
     const float* __restrict__ d4 = a.diag + (size_t)b * N + c.col4;
-    const float* __restrict__ l4 = a.off + ((size_t)b * 2 * a.dims + 2) * N + c.col4;
-    const float* __restrict__ u4 = a.off + ((size_t)b * 2 * a.dims + 3) * N + c.col4;
+    const float* __restrict__ l4 = a.lower + (size_t)b * a.lu_stride + c.col4;
+    const float* __restrict__ u4 = a.upper + (size_t)b * a.lu_stride + c.col4;
     for (int jb = wave * 32; jb < nyp; jb += 128) {
         float4 vd[8], vl[8], vu[8];
 #pragma unroll
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void k_line_apply_y(LineArgs a, const float* _
     const float* __restrict__ r4 = r + (size_t)sys * N + c.col4;
     const float* __restrict__ i4 = a.inv + (size_t)b * N + c.col4;
     const float* __restrict__ c4 = a.cp + (size_t)b * N + c.col4;
-    const float* __restrict__ l4 = a.off + ((size_t)b * 2 * a.dims + 2) * N + c.col4;
+    const float* __restrict__ l4 = a.lower + (size_t)b * a.lu_stride + c.col4;
     for (int jb = wave * 32; jb < nyp; jb += 128) {
         float4 vr[8], vi[8], vc[8], vl[8];
 #pragma unroll
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(256) void k_line_factor_y_stream(LineArgs a) {
     const size_t N = (size_t)nx * ny * a.nz;
     const size_t col = (size_t)(t / nx) * ny * nx + (t % nx);
     const float* d = a.diag + (size_t)b * N + col;
-    const float* l = a.off + ((size_t)b * 2 * a.dims + 2) * N + col;
-    const float* u = a.off + ((size_t)b * 2 * a.dims + 3) * N + col;
+    const float* l = a.lower + (size_t)b * a.lu_stride + col;
+    const float* u = a.upper + (size_t)b * a.lu_stride + col;
     float* iv = a.inv + (size_t)b * N + col;
     float* cp = a.cp + (size_t)b * N + col;
     float cprev = 0.f;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void k_line_apply_y_stream(LineArgs a, const f
     float* zz = z + (size_t)sys * N + col;
     const float* iv = a.inv + (size_t)b * N + col;
     const float* cp = a.cp + (size_t)b * N + col;
-    const float* l = a.off + ((size_t)b * 2 * a.dims + 2) * N + col;
+    const float* l = a.lower + (size_t)b * a.lu_stride + col;
     float prev = 0.f;
 #pragma unroll 8
     for (int j = 0; j < ny; ++j) {
@@ -252,6 +254,28 @@ __global__ __launch_bounds__(256) void k_line_apply_y_stream(LineArgs a, const f
         prev = zz[o] - cp[o] * prev;
         zz[o] = prev;
     }
+}
+
+// ---- coefficients of the separable Helmholtz operator  M = I/dt - nu (Dxx + Dyy + Dzz)  in the eigenbasis of the transform axes
+// (fg_fd_helmholtz_apply, fg_fdprecond.hip): per env b, mode (a, c) and row j the tridiagonal system along y
+//   diag = (1/dt_b - nu lam[c][a] + nu (sum of its y-face coefficients)) / s,   lower / upper = -nu / (hy_j (hy_j + hy_{j-+1}) / 2) / s,
+// s = hx hz (the library's eigenvectors are H-orthonormal: Q^T H Q = I, so Q T^-1 Q^T r carries a factor 1/(hx hz)).  A FIXED y
+// face contributes the one-sided coefficient 2 / hy_j^2 when the variable is prescribed there (velocity; Dirichlet scalar) and
+// nothing for a Neumann scalar -- exactly the diffusion part of k_adv_build's matrix (PISO_multiblock_cuda_kernel.cu:3616-3880).
+__global__ __launch_bounds__(256) void k_helm_coeffs(FgGrid g, const float* __restrict__ dt, const float* __restrict__ lam, float nu,
+                                                      int wall_lo, int wall_hi, float* __restrict__ diag, float* __restrict__ lower,
+                                                      float* __restrict__ upper) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.n || !(dt[b] > 0.f)) return;
+    const int a = idx % g.nx, j = (idx / g.nx) % g.ny, c = idx / (g.nx * g.ny);
+    const float hy = g.h[1][j], rs = g.rh[0][0] * (g.dims == 3 ? g.rh[2][0] : 1.f);   // uniform transform axes
+    const float lo = j > 0 ? 1.f / (hy * 0.5f * (hy + g.h[1][j - 1])) : (wall_lo ? 2.f / (hy * hy) : 0.f);
+    const float hi = j < g.ny - 1 ? 1.f / (hy * 0.5f * (hy + g.h[1][j + 1])) : (wall_hi ? 2.f / (hy * hy) : 0.f);
+    const size_t o = (size_t)b * g.n + idx;
+    diag[o] = (1.f / dt[b] - nu * lam[c * g.nx + a] + nu * (lo + hi)) * rs;
+    lower[o] = j > 0 ? -nu * lo * rs : 0.f;
+    upper[o] = j < g.ny - 1 ? -nu * hi * rs : 0.f;
 }
 
 bool line_lds_ready(size_t bytes) {   // dynamic LDS above 64 KB needs an explicit opt-in per kernel
@@ -271,7 +295,12 @@ bool line_lds_ready(size_t bytes) {   // dynamic LDS above 64 KB needs an explic
 
 LineArgs line_args(const fg_state* s, const float* diag, const float* off, int nc) {
     LineArgs a;
-    a.diag = diag; a.off = off; a.inv = s->line_inv; a.cp = s->line_cp;
+    a.diag = diag; a.inv = s->line_inv; a.cp = s->line_cp;
+    if (off) {   // the tridiagonal part of the stencil matrix itself: faces 2 / 3 of [B][2 d][N]
+        a.lower = off + (size_t)2 * s->grid.n; a.upper = off + (size_t)3 * s->grid.n; a.lu_stride = (size_t)2 * s->grid.dims * s->grid.n;
+    } else {     // synthesized coefficients of the Helmholtz preconditioner (k_helm_coeffs): [B][N] each
+        a.lower = s->helm_lower; a.upper = s->helm_upper; a.lu_stride = (size_t)s->grid.n;
+    }
     a.nx = s->grid.nx; a.ny = s->grid.ny; a.nz = s->grid.nz; a.dims = s->grid.dims; a.nc = nc;
     a.flags = s->flags;
     return a;
@@ -294,6 +323,24 @@ int fg_line_alloc(fg_state* s) {
     FG_HIP_CHECK(hipMalloc(&s->line_inv, sizeof(float) * count));
     FG_HIP_CHECK(hipMalloc(&s->line_cp, sizeof(float) * count));
     return FG_OK;
+}
+
+int fg_helm_alloc(fg_state* s) {
+    if (int rc = fg_line_alloc(s)) return rc;
+    if (s->helm_diag) return FG_OK;
+    const size_t count = (size_t)s->grid.B * s->grid.n;
+    FG_HIP_CHECK(hipMalloc(&s->helm_diag, sizeof(float) * count));
+    FG_HIP_CHECK(hipMalloc(&s->helm_lower, sizeof(float) * count));
+    FG_HIP_CHECK(hipMalloc(&s->helm_upper, sizeof(float) * count));
+    FG_HIP_CHECK(hipMalloc(&s->helm_tmp, sizeof(float) * count * s->grid.dims));
+    return FG_OK;
+}
+
+// coefficients + Thomas factorisation of the Helmholtz preconditioner for this solve (dt per env, nu of the solve)
+int fg_helm_factor(fg_state* s, const float* dt, float nu, int wall_lo, int wall_hi, int nc, hipStream_t st) {
+    hipLaunchKernelGGL(k_helm_coeffs, dim3((s->grid.n + 255) / 256, s->grid.B), dim3(256), 0, st, s->grid, dt, (const float*)s->fd_lam, nu,
+                       wall_lo, wall_hi, s->helm_diag, s->helm_lower, s->helm_upper);
+    return fg_line_factor(s, s->helm_diag, nullptr, nc, st);
 }
 
 int fg_line_factor(fg_state* s, const float* diag, const float* off, int nc, hipStream_t st) {

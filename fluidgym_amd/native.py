@@ -91,6 +91,7 @@ class NativeSolver:
         # fast-diagonalisation preconditioner (needs FIXED y faces); default pressure solver when available.  It is an fp32 kernel
         # family (MFMA basis changes, LDS FFT): the fp64 build runs the reference's plain CG
         self.has_fd = bool(self.fixed[2] and self.fixed[3]) and not self.f64
+        self.has_helmholtz = False
         if self.has_fd:
             fp = ctypes.POINTER(ctypes.c_float)
             from .simulation.fd_precond import FDPreconditioner
@@ -103,6 +104,11 @@ class NativeSolver:
             if fd.x_cosine_width is not None and os.environ.get("FG_FD_NO_FFT", "0") == "0":
                 # the x basis is the DCT-II basis: apply it as a fast cosine transform instead of the dense GEMM
                 L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_cosine_width), lib=self.lib)
+            # Helmholtz preconditioner of the advection-diffusion solves (mode 3 of set_advection_preconditioner): available when
+            # the transform axes are periodic and uniform (RBC, TCF)
+            self.has_helmholtz = bool(fd.transform_axes_periodic_uniform and fd.x_cosine_width is None)
+            if self.has_helmholtz:
+                L.check(self.lib.fg_set_fd_helmholtz(self.handle, fpp(fd.lam)), lib=self.lib)
         self.default_method = L.FG_SOLVER_FDCG if self.has_fd else L.FG_SOLVER_CG
         if allocate:
             self.allocate_fields()
@@ -359,7 +365,8 @@ class NativeSolver:
     def set_advection_preconditioner(self, mode: int = 0):
         """Preconditioner policy of the advection-diffusion BiCGStab (``fg_set_advection_preconditioner``): 0 plain (the
         reference's first rung), 1 every solve right-preconditioned by the y-line solve (its ``preconditionBiCG``), 2 only
-        to repeat a failed solve (its ``BiCG_precondition_fallback``)."""
+        to repeat a failed solve (its ``BiCG_precondition_fallback``), 3 every solve right-preconditioned by the separable
+        Helmholtz operator (fast diagonalisation; needs ``has_helmholtz``)."""
         if self.f64:
             return    # the y-line preconditioner is an fp32 kernel family: the fp64 build keeps the plain recurrence (mode 0)
         L.check(self.lib.fg_set_advection_preconditioner(self.handle, int(mode)), lib=self.lib)

@@ -101,6 +101,12 @@ class FDPreconditioner:
         else:
             Qz, lz = np.ones((1, 1)), np.zeros(1)
         lam = lz[:, None] + lx[None, :]  # [nz, nx] mode eigenvalue sums
+        # for the Helmholtz preconditioner of the advection-diffusion solves (csrc/fg_fdprecond.hip fg_fd_helmholtz_apply): the
+        # eigenvalue sums themselves, and whether the transform axes are periodic and uniform (then velocity and pressure share
+        # the 1-D operators of those axes -- a FIXED axis has different boundary rows for a Dirichlet variable)
+        self.lam = np.ascontiguousarray(lam, dtype=np.float32)
+        self.transform_axes_periodic_uniform = bool((not fixed_axis[0]) and is_uniform(h[0]) and
+                                                    (d == 2 or ((not fixed_axis[2]) and is_uniform(h[2]))))
         Ty = axis_operator(h[1], True)
         # The mode that is constant along every transform axis has lambda = 0 and meets the singular Neumann
         # operator Ty (constant null space of the all-Neumann/periodic pressure system).  Its last pivot

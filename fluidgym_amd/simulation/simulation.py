@@ -146,6 +146,13 @@ class Simulation:
             hy = np.asarray(solver.widths[1], dtype=np.float64)
             refined = bool(get_solver_policy()["advection_line_preconditioner"]) and float(hy.max() / hy.min()) >= 3.0
             self.advection_preconditioner = 1 if (self.preconditionBiCG or refined) else (2 if self.BiCG_precondition_fallback else 0)
+            # policy advection_fd_preconditioner (default on): where the grid allows it -- periodic, uniform x (and z), walls in y:
+            # the RBC and TCF families -- every advection-diffusion solve is right-preconditioned by the exact inverse of its
+            # diffusion part (separable Helmholtz operator, fast diagonalisation).  2-D only by default: in 3-D the four basis
+            # changes per application cost what the 2-3 saved iterations of a 4-iteration solve give back
+            fd_pol = get_solver_policy()["advection_fd_preconditioner"]
+            if getattr(solver, "has_helmholtz", False) and not self.preconditionBiCG and (fd_pol == "always" or (fd_pol == "auto" and solver.dims == 2)):
+                self.advection_preconditioner = 3
             solver.set_advection_preconditioner(self.advection_preconditioner)
         # (bounds, velm, tol): advective-outflow PRE hook of the cylinder/airfoil envs (PISOtorch_simulation.py:
         # 228-393, wired in cylinder_env_base.py:280-300), kept as data so the native driver can run it

@@ -179,6 +179,12 @@ int fg_solve_advection(fg_handle h, int for_scalar, int channel, fg_real tol, in
  * preconditioner here is the tridiagonal part of the matrix along y (csrc/fg_linepre.hip), factorised per solve and env.
  * fg_advection_retries: number of repeated solves since the last reset. */
 int fg_set_advection_preconditioner(fg_handle h, int mode);
+/* mode 3 of fg_set_advection_preconditioner: every advection-diffusion solve right-preconditioned by the separable Helmholtz
+ * operator I/dt - nu Laplacian (the matrix without its advective part), inverted by fast diagonalisation: basis change along the
+ * PERIODIC, uniform transform axes (x, z; the eigenvectors of fg_set_fd_preconditioner), one tridiagonal solve along y per mode
+ * and env.  lam_host [nz][nx]: sum of the transform axes' eigenvalues per mode (fluidgym_amd/simulation/fd_precond.py).  No
+ * reference counterpart (its preconditioner for these solves is ILU(0), off by default); fp32 library only. */
+int fg_set_fd_helmholtz(fg_handle h, const float* lam_host);
 int fg_advection_retries(fg_handle h, int64_t* out, int32_t reset);
 /* CopyScalarResultToBlocks (:6558-6746) */
 int fg_copy_scalar_result_to_blocks(fg_handle h, int channel, void* stream);
