@@ -105,8 +105,10 @@ class FDPreconditioner:
         # eigenvalue sums themselves, and whether the transform axes are periodic and uniform (then velocity and pressure share
         # the 1-D operators of those axes -- a FIXED axis has different boundary rows for a Dirichlet variable)
         self.lam = np.ascontiguousarray(lam, dtype=np.float32)
-        self.transform_axes_periodic_uniform = bool((not fixed_axis[0]) and is_uniform(h[0]) and
-                                                    (d == 2 or ((not fixed_axis[2]) and is_uniform(h[2]))))
+        # (uniform to 1e-3: vertex coordinates that went through fp32 differ by 1e-5 of a width, and a preconditioner does not
+        #  care -- the eigenvectors above are those of the widths as they are)
+        self.transform_axes_periodic_uniform = bool((not fixed_axis[0]) and is_uniform(h[0], rtol=1e-3) and
+                                                    (d == 2 or ((not fixed_axis[2]) and is_uniform(h[2], rtol=1e-3))))
         Ty = axis_operator(h[1], True)
         # The mode that is constant along every transform axis has lambda = 0 and meets the singular Neumann
         # operator Ty (constant null space of the all-Neumann/periodic pressure system).  Its last pivot
