@@ -27,7 +27,11 @@ struct DctArgs {
     long env_stride; int rows;
 };
 
-template <int N, bool INVERSE>
+// PERIODIC = false: the cosine transforms above (FIXED axis).  PERIODIC = true: the real Fourier basis of a periodic uniform axis,
+//   q_0 = 1/sqrt(n),  q_k = sqrt(2/n) cos(2 pi k i / n),  q_{n-k} = sqrt(2/n) sin(2 pi k i / n)  (0 < k < n/2),  q_{n/2} = (-1)^i / sqrt(n),
+// all / sqrt(h); mode m has the eigenvalue of k = min(m, n - m).  Forward: V = FFT_n(x), X_k = s_k Re V_k, X_{n-k} = -s_k Im V_k.
+// Inverse: W_0 = g_0 Y_0, W_{n/2} = g_0 Y_{n/2}, W_k = g/2 (Y_k - i Y_{n-k}), W_{n-k} = conj(W_k); x = Re FFT^-1_n(W) (unnormalised).
+template <int N, bool INVERSE, bool PERIODIC = false>
 __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     constexpr int EPL = N / 64;             // elements per lane
     __shared__ float2 buf[2][4][N];
@@ -46,12 +50,25 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) xin[e] = a.src[off + e];
     if (!INVERSE) {
-        // v_j = x_2j, v_{n-1-j} = x_{2j+1}
+        // v_j = x_2j, v_{n-1-j} = x_{2j+1}  (periodic: v = x)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = lane * EPL + e;
-            const int j = (i & 1) ? N - 1 - (i >> 1) : (i >> 1);
+            const int j = PERIODIC ? i : ((i & 1) ? N - 1 - (i >> 1) : (i >> 1));
             x[j] = make_float2(xin[e], 0.f);
+        }
+    } else if (PERIODIC) {
+        float* stage = reinterpret_cast<float*>(y);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) stage[lane * EPL + e] = xin[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int k = lane * EPL + e;
+            const float yk = stage[k], ym = stage[(N - k) & (N - 1)];
+            if (k == 0 || k == N / 2) x[k] = make_float2(a.scale0 * yk, 0.f);
+            else if (k < N / 2) x[k] = make_float2(0.5f * a.scale * yk, -0.5f * a.scale * ym);
+            else x[k] = make_float2(0.5f * a.scale * ym, 0.5f * a.scale * yk);
         }
     } else {
         // stage the row so that Y_{n-k} is reachable, then V_k = g_k (Y_k - i Y_{n-k}) e^{+i theta_k},  Y_n := 0
@@ -122,7 +139,14 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
         float2* tmp = x; x = y; y = tmp;
     }
     float out[EPL];
-    if (!INVERSE) {
+    if (!INVERSE && PERIODIC) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int m = lane * EPL + e;
+            const float2 V = x[m <= N / 2 ? m : N - m];
+            out[e] = (m == 0 || m == N / 2) ? a.scale0 * V.x : (m < N / 2 ? a.scale * V.x : -a.scale * V.y);
+        }
+    } else if (!INVERSE) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int k = lane * EPL + e;
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = lane * EPL + e;
-            out[e] = x[(i & 1) ? N - 1 - (i >> 1) : (i >> 1)].x;
+            out[e] = x[PERIODIC ? i : ((i & 1) ? N - 1 - (i >> 1) : (i >> 1))].x;
         }
     }
     float dot = 0.f;
@@ -153,18 +177,22 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     }
 }
 
-template <bool INVERSE>
-int launch_dct(const fg_state* s, int n, const DctArgs& a, int slot, hipStream_t st) {
-    const dim3 grid((a.rows + 3) / 4, s->grid.B);
+template <bool INVERSE, bool PERIODIC>
+int launch_dct_mode(const fg_state* s, int n, const DctArgs& a, int slot, int batch, hipStream_t st) {
+    const dim3 grid((a.rows + 3) / 4, batch);
     switch (n) {
-        case 64: FG_LAUNCH_P(s, slot, (k_dct_rows<64, INVERSE>), grid, dim3(256), 0, st, a); break;
-        case 128: FG_LAUNCH_P(s, slot, (k_dct_rows<128, INVERSE>), grid, dim3(256), 0, st, a); break;
-        case 256: FG_LAUNCH_P(s, slot, (k_dct_rows<256, INVERSE>), grid, dim3(256), 0, st, a); break;
-        case 512: FG_LAUNCH_P(s, slot, (k_dct_rows<512, INVERSE>), grid, dim3(256), 0, st, a); break;
-        default: fg_set_error("fast cosine transform: unsupported length"); return FG_ERR_UNSUPPORTED;
+        case 64: FG_LAUNCH_P(s, slot, (k_dct_rows<64, INVERSE, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 128: FG_LAUNCH_P(s, slot, (k_dct_rows<128, INVERSE, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 256: FG_LAUNCH_P(s, slot, (k_dct_rows<256, INVERSE, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 512: FG_LAUNCH_P(s, slot, (k_dct_rows<512, INVERSE, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        default: fg_set_error("fast transform: unsupported length"); return FG_ERR_UNSUPPORTED;
     }
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
+}
+template <bool INVERSE>
+int launch_dct(const fg_state* s, int n, const DctArgs& a, int slot, int batch, hipStream_t st) {
+    return s->fd_dct_x == 2 ? launch_dct_mode<INVERSE, true>(s, n, a, slot, batch, st) : launch_dct_mode<INVERSE, false>(s, n, a, slot, batch, st);
 }
 
 }  // namespace
@@ -172,35 +200,38 @@ int launch_dct(const fg_state* s, int n, const DctArgs& a, int slot, hipStream_t
 bool fg_fd_dct_supported(int n) { return n == 64 || n == 128 || n == 256 || n == 512; }
 
 // x-axis transforms of fg_fd_apply when the axis is marked as DCT (fd_dct_x): rows = ny * nz per env, length nx.
-int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st) {
+int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st, int batch) {
     const FgGrid& G = s->grid;
+    if (batch <= 0) batch = G.B;
     DctArgs a = {};
     a.src = r; a.dst = out; a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot;
     a.scale0 = s->fd_dct_fwd[0]; a.scale = s->fd_dct_fwd[1];
     a.flags = s->flags; a.env_stride = G.n; a.rows = G.ny * G.nz;
     // per env: the row read + written; ~5 n log2 n flops per row
-    const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, G.B, 8.0 * G.n, 5.0 * G.n * log2((double)G.nx), st);
-    return launch_dct<false>(s, G.nx, a, slot, st);
+    const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, batch, 8.0 * G.n, 5.0 * G.n * log2((double)G.nx), st);
+    return launch_dct<false>(s, G.nx, a, slot, batch, st);
 }
 int fg_fd_dct_inverse(fg_state* s, const float* u, float* z, const float* dot_with, FgDacc* dot_acc, int dot_stride,
-                      int dot_ns, hipStream_t st) {
+                      int dot_ns, hipStream_t st, int batch) {
     const FgGrid& G = s->grid;
+    if (batch <= 0) batch = G.B;
     DctArgs a = {};
     a.src = u; a.dst = z; a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot;
     a.scale0 = s->fd_dct_inv[0]; a.scale = s->fd_dct_inv[1];
     a.flags = s->flags; a.env_stride = G.n; a.rows = G.ny * G.nz;
     a.dot_with = dot_acc ? dot_with : nullptr; a.dot_acc = dot_acc; a.dot_stride = dot_stride; a.dot_ns = dot_ns;
-    const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, G.B, (dot_acc ? 12.0 : 8.0) * G.n, 5.0 * G.n * log2((double)G.nx), st);
-    return launch_dct<true>(s, G.nx, a, slot, st);
+    const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, batch, (dot_acc ? 12.0 : 8.0) * G.n, 5.0 * G.n * log2((double)G.nx), st);
+    return launch_dct<true>(s, G.nx, a, slot, batch, st);
 }
 
 extern "C" int fg_set_fd_fast_transform(fg_handle s, int axis, float cell_width) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     FG_REQUIRE(axis == 0, FG_ERR_UNSUPPORTED, "fast transforms are built for the x axis only");
     const int n = s->grid.nx;
-    FG_REQUIRE(fg_fd_dct_supported(n), FG_ERR_UNSUPPORTED, "fast cosine transform needs nx in {64, 128, 256, 512}");
-    FG_REQUIRE(s->grid.fixed[0] && s->grid.fixed[1] && cell_width > 0.f, FG_ERR_INVALID_ARG,
-               "fast cosine transform needs FIXED x faces and a uniform positive cell width");
+    FG_REQUIRE(fg_fd_dct_supported(n), FG_ERR_UNSUPPORTED, "fast transform needs nx in {64, 128, 256, 512}");
+    FG_REQUIRE(cell_width > 0.f && (s->grid.fixed[0] != 0) == (s->grid.fixed[1] != 0), FG_ERR_INVALID_ARG,
+               "fast transform needs a uniform positive cell width");
+    const bool periodic = !s->grid.fixed[0];   // FIXED x: cosine basis (DCT-II / III); PERIODIC x: real Fourier basis
     std::vector<float2> tw(n), rot(n);
     for (int j = 0; j < n; ++j) tw[j] = make_float2((float)cos(2.0 * M_PI * j / n), (float)sin(2.0 * M_PI * j / n));
     for (int k = 0; k < n; ++k) rot[k] = make_float2((float)cos(M_PI * k / (2.0 * n)), (float)sin(M_PI * k / (2.0 * n)));
@@ -211,7 +242,11 @@ extern "C" int fg_set_fd_fast_transform(fg_handle s, int axis, float cell_width)
     FG_HIP_CHECK(hipMemcpy(s->fd_dct_rot, rot.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
     const double rs = 1.0 / sqrt((double)cell_width);
     s->fd_dct_fwd[0] = (float)(sqrt(1.0 / n) * rs); s->fd_dct_fwd[1] = (float)(sqrt(2.0 / n) * rs);
-    s->fd_dct_inv[0] = (float)(rs / (sqrt(1.0 / n) * n)); s->fd_dct_inv[1] = (float)(rs / (sqrt(2.0 / n) * n));
-    s->fd_dct_x = 1;
+    if (periodic) {   // x = Re FFT^-1(W) with the basis factors inside W: g_0 = rs / sqrt(n), g = rs sqrt(2 / n)
+        s->fd_dct_inv[0] = (float)(rs * sqrt(1.0 / n)); s->fd_dct_inv[1] = (float)(rs * sqrt(2.0 / n));
+    } else {
+        s->fd_dct_inv[0] = (float)(rs / (sqrt(1.0 / n) * n)); s->fd_dct_inv[1] = (float)(rs / (sqrt(2.0 / n) * n));
+    }
+    s->fd_dct_x = periodic ? 2 : 1;
     return FG_OK;
 }

@@ -570,7 +570,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_st
 // ---------------------------------------------------------------------------------------------------------------------------
 extern "C" int fg_set_fd_helmholtz(fg_handle s, const float* lam_host) {
     FG_REQUIRE(s && lam_host, FG_ERR_INVALID_ARG, "fg_set_fd_helmholtz: null argument");
-    FG_REQUIRE(s->fd_Qx && !s->fd_dct_x, FG_ERR_INVALID_ARG, "fg_set_fd_helmholtz: call fg_set_fd_preconditioner first (GEMM basis along x)");
+    FG_REQUIRE(s->fd_Qx && s->fd_dct_x != 1, FG_ERR_INVALID_ARG, "fg_set_fd_helmholtz: call fg_set_fd_preconditioner first (periodic x basis)");
     FG_REQUIRE(!s->grid.fixed[0] && !s->grid.fixed[1] && s->grid.fixed[2] && s->grid.fixed[3] && (s->grid.dims == 2 || (!s->grid.fixed[4] && !s->grid.fixed[5])),
                FG_ERR_UNSUPPORTED, "fg_set_fd_helmholtz: needs PERIODIC transform axes (x, z) and FIXED y faces");
     const size_t count = (size_t)s->grid.nx * s->grid.nz;
@@ -587,12 +587,16 @@ int fg_fd_helmholtz_apply(fg_state* s, int nc, const float* r, float* z, hipStre
     float* t2 = s->helm_tmp;
     GemmArgs g;
     g.flags = s->flags; g.dot_with = nullptr; g.strideW = 0; g.dot_acc = nullptr; g.dot_stride = 0; g.dot_ns = 1;
-    // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]
-    g.A = r; g.lda = nx; g.strideA = N;
-    g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_QxT; g.ldbt = nx;
-    g.C = t1; g.ldc = nx; g.strideC = N;
-    g.M = ny * nz; g.N = nx; g.K = nx;
-    if (int rc = launch_gemm(s, g, nsys, nsys, st)) return rc;
+    // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]  (periodic x marked as a fast-transform axis: one real FFT per row)
+    if (s->fd_dct_x == 2) {
+        if (int rc = fg_fd_dct_forward(s, r, t1, st, nsys)) return rc;
+    } else {
+        g.A = r; g.lda = nx; g.strideA = N;
+        g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_QxT; g.ldbt = nx;
+        g.C = t1; g.ldc = nx; g.strideC = N;
+        g.M = ny * nz; g.N = nx; g.K = nx;
+        if (int rc = launch_gemm(s, g, nsys, nsys, st)) return rc;
+    }
     float* cur = t1;
     if (G.dims == 3) {
         g.A = s->fd_QzT; g.lda = nz; g.strideA = 0;
@@ -612,6 +616,7 @@ int fg_fd_helmholtz_apply(fg_state* s, int nc, const float* r, float* z, hipStre
         cur = t1;
     }
     // inverse x: z[rows, i] = sum_a cur[rows, a] QxT[a, i]
+    if (s->fd_dct_x == 2) return fg_fd_dct_inverse(s, cur, z, nullptr, nullptr, 0, 1, st, nsys);
     g.A = cur; g.lda = nx; g.strideA = N;
     g.B = s->fd_QxT; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_Qx; g.ldbt = nx;
     g.C = z; g.ldc = nx; g.strideC = N;

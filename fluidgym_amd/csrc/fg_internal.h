@@ -664,9 +664,9 @@ int fg_prof_slot(const fg_state* s, int kind, const int32_t* flags, int nsys, do
 int fg_prof_collect(fg_state* s, hipStream_t st);
 void fg_prof_destroy(fg_state* s);
 bool fg_fd_dct_supported(int n);
-int fg_fd_dct_forward(fg_state* s, const fg_real* r, fg_real* out, hipStream_t st);
+int fg_fd_dct_forward(fg_state* s, const fg_real* r, fg_real* out, hipStream_t st, int batch = 0);   // batch 0: the env batch
 int fg_fd_dct_inverse(fg_state* s, const fg_real* u, fg_real* z, const fg_real* dot_with, FgDacc* dot_acc, int dot_stride,
-                      int dot_ns, hipStream_t st);
+                      int dot_ns, hipStream_t st, int batch = 0);
 #define FG_LAUNCH_P(s, slot, kernel, grid, block, shmem, st, ...)                                              \
     do {                                                                                                       \
         const int slot__ = (slot);                                                                             \

@@ -106,7 +106,10 @@ class NativeSolver:
                 L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_cosine_width), lib=self.lib)
             # Helmholtz preconditioner of the advection-diffusion solves (mode 3 of set_advection_preconditioner): available when
             # the transform axes are periodic and uniform (RBC, TCF)
-            self.has_helmholtz = bool(fd.transform_axes_periodic_uniform and fd.x_cosine_width is None)
+            if fd.x_fourier_width is not None and os.environ.get("FG_FD_NO_FFT", "0") == "0":
+                # periodic uniform x: the real Fourier basis, applied as one FFT per row
+                L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_fourier_width), lib=self.lib)
+            self.has_helmholtz = bool(fd.transform_axes_periodic_uniform)
             if self.has_helmholtz:
                 L.check(self.lib.fg_set_fd_helmholtz(self.handle, fpp(fd.lam)), lib=self.lib)
         self.default_method = L.FG_SOLVER_FDCG if self.has_fd else L.FG_SOLVER_CG

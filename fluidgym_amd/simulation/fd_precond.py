@@ -63,6 +63,22 @@ def cosine_basis(n: int, h: float):
     return Q, lam
 
 
+def fourier_basis(n: int, h: float):
+    """Eigenpairs of a PERIODIC axis with uniform width ``h`` in the order a real FFT produces them: mode 0 the constant,
+    modes ``k`` and ``n - k`` (``0 < k < n/2``) the cosine and the sine of wavenumber ``k``, mode ``n/2`` the alternating vector;
+    ``Q^T H Q = I`` and ``lam_m = -(2 - 2 cos(2 pi k / n)) / h^2`` with ``k = min(m, n - m)``.  The device applies this basis as
+    one FFT per row (``csrc/fg_fdfft.hip``, ``PERIODIC`` form) instead of the dense n x n GEMM."""
+    i = np.arange(n)[:, None]
+    m = np.arange(n)[None, :]
+    k = np.minimum(m, n - m)
+    ang = 2.0 * np.pi * k * i / n
+    Q = np.where(m <= n // 2, np.cos(ang), np.sin(ang)) * np.sqrt(2.0 / n)
+    Q[:, 0] = np.sqrt(1.0 / n)
+    Q[:, n // 2] = np.sqrt(1.0 / n) * (1.0 - 2.0 * (np.arange(n) % 2))
+    lam = -(2.0 - 2.0 * np.cos(2.0 * np.pi * k[0] / n)) / (h * h)
+    return Q / np.sqrt(h), lam
+
+
 def is_uniform(h: np.ndarray, rtol: float = 1e-6) -> bool:
     h = np.asarray(h, dtype=np.float64)
     return bool(np.abs(h - h[0]).max() <= rtol * abs(h[0]))
@@ -91,9 +107,15 @@ class FDPreconditioner:
         nz = len(h[2]) if d == 3 else 1
         # uniform FIXED x axis of a power-of-two length: cosine basis in DCT order, the device applies it as an FFT
         self.x_cosine_width: Optional[float] = None
+        self.x_fourier_width: Optional[float] = None
         if fixed_axis[0] and is_uniform(h[0]) and nx in (64, 128, 256, 512):
             self.x_cosine_width = float(np.float32(widths[0][0]))
             Qx, lx = cosine_basis(nx, float(h[0][0]))
+        elif (not fixed_axis[0]) and is_uniform(h[0], rtol=1e-3) and nx in (64, 128, 256, 512):
+            # periodic uniform x (RBC, TCF): real Fourier basis in FFT order (uniform to 1e-3: vertex coordinates that went through
+            # fp32 differ by 1e-5 of a width; the mean width defines the basis, and a preconditioner does not care)
+            self.x_fourier_width = float(np.float32(h[0].mean()))
+            Qx, lx = fourier_basis(nx, float(h[0].mean()))
         else:
             Qx, lx = generalized_eig(axis_operator(h[0], fixed_axis[0]), h[0])
         if d == 3:
