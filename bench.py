@@ -107,7 +107,7 @@ KERNEL_DOC = {
     "k_line_y": "y-line (tridiagonal) right preconditioner of the advection BiCGStab: z = M^-1 r per column block in LDS",
     "k_gemm_f32": "fast-diagonalisation preconditioner: eigenbasis transform along x/z (fp32 MFMA 32x32x2)",
     "k_gemm_sk": "fast-diagonalisation preconditioner: eigenbasis transform, split-K 32x32 tiles (few live envs)",
-    "k_dct_rows": "fast-diagonalisation preconditioner: cosine transform of every grid row (one FFT per row in LDS)",
+    "k_dct_rows": "fast-diagonalisation preconditioners: cosine / real Fourier transform of every grid row (one FFT per row in LDS)",
     "k_tridiag_y": "fast-diagonalisation preconditioner: per-mode tridiagonal sweep along y",
     "k_mbc_ap": "multi-block CG: p = r + beta p on the fly, v = P p over the neighbour table, p.Pp",
     "k_mbc_update": "multi-block CG: x/r update + r.r + sum r",
