@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void k_line_factor_y(LineArgs a) {
 }
 
 // z = M^-1 r for every system with flag 0; grid (column blocks, nsys)
-__global__ __launch_bounds__(256) void k_line_apply_y(LineArgs a, const float* __restrict__ r, float* __restrict__ z) {
+// (r and z may be the same array: every row is staged in LDS before the first store -- no __restrict__ on the two)
+__global__ __launch_bounds__(256) void k_line_apply_y(LineArgs a, const float* r, float* z) {
     extern __shared__ __attribute__((aligned(16))) float tbuf[];   // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]
     const int sys = blockIdx.y;
     if (a.flags[sys] != 0) return;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_line_apply_y(LineArgs a, const float* _
     float* ms = tbuf + (size_t)nyp * 64;
     float* cs = tbuf + (size_t)2 * nyp * 64;
     const LineCol c = line_col(nx, ny, a.nz);
-    const float* __restrict__ r4 = r + (size_t)sys * N + c.col4;
+    const float* r4 = r + (size_t)sys * N + c.col4;
     const float* __restrict__ i4 = a.inv + (size_t)b * N + c.col4;
     const float* __restrict__ c4 = a.cp + (size_t)b * N + c.col4;
     const float* __restrict__ l4 = a.lower + (size_t)b * a.lu_stride + c.col4;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void k_line_apply_y(LineArgs a, const float* _
     }
     __syncthreads();
     if (c.live) {
-        float* __restrict__ z4 = z + (size_t)sys * N + c.col4;
+        float* z4 = z + (size_t)sys * N + c.col4;
         for (int jb = wave * 32; jb < ny; jb += 128) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void k_line_factor_y_stream(LineArgs a) {
         iv[o] = inv; cp[o] = cprev;
     }
 }
-__global__ __launch_bounds__(256) void k_line_apply_y_stream(LineArgs a, const float* __restrict__ r, float* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_line_apply_y_stream(LineArgs a, const float* r, float* z) {
     const int sys = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (a.flags[sys] != 0 || t >= a.nx * a.nz) return;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void k_line_apply_y_stream(LineArgs a, const f
 
 // ---- coefficients of the separable Helmholtz operator  M = I/dt - nu (Dxx + Dyy + Dzz)  in the eigenbasis of the transform axes
 // (fg_fd_helmholtz_apply, fg_fdprecond.hip): per env b, mode (a, c) and row j the tridiagonal system along y
-//   diag = (1/dt_b - nu lam[c][a] + nu (sum of its y-face coefficients)) / s,   lower / upper = -nu / (hy_j (hy_j + hy_{j-+1}) / 2) / s,
+//   diag = (1/dt_b - nu lam[c][a] + nu (sum of its y-face coefficients)) / s,   lower / upper = -nu (1/hy_j + 1/hy_{j-+1}) / (2 hy_j) / s,
 // s = hx hz (the library's eigenvectors are H-orthonormal: Q^T H Q = I, so Q T^-1 Q^T r carries a factor 1/(hx hz)).  A FIXED y
 // face contributes the one-sided coefficient 2 / hy_j^2 when the variable is prescribed there (velocity; Dirichlet scalar) and
 // nothing for a Neumann scalar -- exactly the diffusion part of k_adv_build's matrix (PISO_multiblock_cuda_kernel.cu:3616-3880).
@@ -269,9 +270,11 @@ __global__ __launch_bounds__(256) void k_helm_coeffs(FgGrid g, const float* __re
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= g.n || !(dt[b] > 0.f)) return;
     const int a = idx % g.nx, j = (idx / g.nx) % g.ny, c = idx / (g.nx * g.ny);
-    const float hy = g.h[1][j], rs = g.rh[0][0] * (g.dims == 3 ? g.rh[2][0] : 1.f);   // uniform transform axes
-    const float lo = j > 0 ? 1.f / (hy * 0.5f * (hy + g.h[1][j - 1])) : (wall_lo ? 2.f / (hy * hy) : 0.f);
-    const float hi = j < g.ny - 1 ? 1.f / (hy * 0.5f * (hy + g.h[1][j + 1])) : (wall_hi ? 2.f / (hy * hy) : 0.f);
+    const float rs = g.rh[0][0] * (g.dims == 3 ? g.rh[2][0] : 1.f);   // uniform transform axes
+    // face coefficient = mean of the two cells' alpha = J / h^2 (getLaplaceCoefficientOrthogonal, K.cu:1224-1239), over the cell volume
+    const float ry = g.rh[1][j];
+    const float lo = j > 0 ? 0.5f * (ry + g.rh[1][j - 1]) * ry : (wall_lo ? 2.f * ry * ry : 0.f);
+    const float hi = j < g.ny - 1 ? 0.5f * (ry + g.rh[1][j + 1]) * ry : (wall_hi ? 2.f * ry * ry : 0.f);
     const size_t o = (size_t)b * g.n + idx;
     diag[o] = (1.f / dt[b] - nu * lam[c * g.nx + a] + nu * (lo + hi)) * rs;
     lower[o] = j > 0 ? -nu * lo * rs : 0.f;

@@ -135,7 +135,8 @@ def test_rbc_env_uses_the_line_solve_and_steps_like_the_plain_solver():
 
     out = {}
     for on in (True, False):
-        old = fluidgym_amd.set_solver_policy(advection_line_preconditioner=on)
+        # (the Helmholtz preconditioner, which the RBC grids get by default, is switched off: this test is about the line rungs)
+        old = fluidgym_amd.set_solver_policy(advection_line_preconditioner=on, advection_fd_preconditioner="never")
         try:
             env = fluidgym_amd.make("RBC2D-easy-v0", num_envs=2, n_heaters=4, resolution=8)
             env._non_uniform_grid_base = 1.3       # 20 rows: 1.3^9 = 10.6 (the registered base 1.02 refines by 1.2 only at this size)
