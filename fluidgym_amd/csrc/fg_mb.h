@@ -110,6 +110,19 @@ struct fg_mb_state {
     // work arrays of the kernel form (mb_ml_apply): aggregate sums [B][n4], coarse solution [B][n8], 1 / scale [B], M p and M s [B][N]
     float *ml_r4 = nullptr, *ml_z8 = nullptr, *ml_scale = nullptr, *ml_mp = nullptr, *ml_ms = nullptr;
     float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
+    // aggregate-owned layout of the on-chip CG (k_mbc_onchip<AGG>, built by fg_mb_set_multilevel when the mesh has at most 256
+    // 8 x 8 aggregates of at most four 4 x 4 children of at most 16 cells): thread t = 4 * (8 x 8 aggregate) + child owns the
+    // cells of that child, member m (row-major in its rectangle) lives in slot t + 1024 m of a 16 384-slot index space
+    static constexpr int OC_SLOTS = 16 * 1024;
+    int32_t* oc_slot_cell = nullptr;   // [OC_SLOTS] cell of a slot, -1 = hole
+    uint16_t* oc_cell_slot = nullptr;  // [N] slot of a cell
+    uint2* oc_nbr = nullptr;           // [OC_SLOTS] the four neighbour SLOTS of a slot's cell, 16 bits each, 0xFFFF = prescribed face
+    float* oc_d4g = nullptr;           // [1024] 1 / diag(Z4^T S Z4) of the thread's aggregate (0: the thread owns none)
+    int32_t* oc_cnt = nullptr;         // [1024] cells the thread owns
+    float *Poff4s = nullptr, *Pdiag_s = nullptr, *oc_bestx = nullptr;   // [B][OC_SLOTS][4], [B][OC_SLOTS], [B][OC_SLOTS]: slot order; holes stay 0
+    bool oc_agg = false;               // tables above installed
+    bool oc_matrix_stale = true;       // no k_mb_pmatrix launch has written the slot-ordered matrix since the tables were installed
+    int dbg_oc_agg = 1;                // FG_MB_OC_AGG=0: keep the cell-ordered on-chip kernel
     int oc_variant = 0;        // FG_MB_OC_VARIANT (tuning switches of the on-chip CG)
     unsigned long long* oc_dbg = nullptr;   // per-phase cycle counts (fg_mb_debug_cycles)
     int onchip_mode = 1;       // FG_MB_ONCHIP: 0 never, 1 when the mesh fits one workgroup's LDS / registers (default)

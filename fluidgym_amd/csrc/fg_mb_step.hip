@@ -160,12 +160,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_vrhs(MbDev D, const float* __re
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* __restrict__ dt, const float* __restrict__ rA,
                                                           float* __restrict__ Pdiag, float* __restrict__ Poff,
-                                                          float* __restrict__ Poff4) {
+                                                          float* __restrict__ Poff4, const uint16_t* __restrict__ cell_slot = nullptr,
+                                                          float* __restrict__ Poff4s = nullptr, float* __restrict__ Pdiag_s = nullptr) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     constexpr int F = 2 * DIMS;
     const float* ra = rA + (size_t)b * N;
-    float o4[4] = {0.f, 0.f, 0.f, 0.f};
+    float o4[4] = {0.f, 0.f, 0.f, 0.f}, dv = 0.f;
     const float rp = ra[i];
     float rn[F];
 #pragma unroll
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* _
             const size_t q = ((size_t)g * F + f) * N + i;
             v += D.KPp[q] * rp + D.KPn[q] * rn[f];
         }
-        if (g == 0) Pdiag[(size_t)b * N + i] = v;
+        if (g == 0) { Pdiag[(size_t)b * N + i] = v; dv = v; }
         else {
             const float o = (D.nbr[(size_t)(g - 1) * N + i] >= 0) ? v : 0.f;
             Poff[((size_t)b * F + (g - 1)) * N + i] = o;
@@ -190,6 +191,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* _
     }
     // the same off-diagonals once more, interleaved per cell: the on-chip CG fetches a cell's four with one 16-byte load
     if (DIMS == 2 && Poff4) *reinterpret_cast<float4*>(Poff4 + ((size_t)b * N + i) * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    // ... and in the slot order of the aggregate-owned on-chip CG (fg_mb.h: OC_SLOTS), diagonal included
+    if (DIMS == 2 && cell_slot) {
+        const size_t sl = (size_t)b * fg_mb_state::OC_SLOTS + cell_slot[i];
+        *reinterpret_cast<float4*>(Poff4s + sl * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        Pdiag_s[sl] = dv;
+    }
 }
 
 // h = (u_old/dt - H u* + S) / A   (PISO_build_pressure_rhs): grid.z = component
@@ -1486,6 +1493,9 @@ __global__ void k_mbs_restore_best(int N, MbSolve q) {
 // Same recurrence, same projection of the residual, same restart / best-iterate / stall rules as mb_cg's kernels; only
 // the summation order of the dot products differs (per-thread partials, wave shuffle, 16 wave sums added in fp64).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef OC_AGG_GROUP
+#define OC_AGG_GROUP 2   // members of the aggregate-owned stencil pass loaded per batch
+#endif
 constexpr int OC_MAX_WAVES = 16;   // workgroups of 1024 or 512 threads (NT): 512 threads get 256 registers each
 
 // Two-level-plus additive preconditioner of the on-chip CG (fg_mb_set_multilevel): M r = D^-1 r + 1/2 Z4 D4^-1 Z4^T r + Z8 A8^+ Z8^T r with
@@ -1503,8 +1513,25 @@ struct OcPre {
     float geom_diag_sum;       // sum_i S_ii: the env's scale is sum_i P_ii / geom_diag_sum (P = S / A with A nearly constant)
 };
 
+// Aggregate-owned layout (AGG): thread t = 4 * (8 x 8 aggregate) + child owns the (up to 16) cells of one 4 x 4 aggregate; its
+// member m sits in slot t + 1024 m.  Restriction to the 4 x 4 level is then a sum over the thread's own registers, the 8 x 8 level
+// a sum over the four lanes of a quad, prolongation a register broadcast: the residual copy to LDS, the two gather passes, the
+// correction table and three of the six barriers of the cell-ordered preconditioner pass go away, and so do its table loads
+// (rectangles, children, parents, aggregate ids).  Matrix, neighbour table and kept iterate live in slot order (k_mb_pmatrix
+// writes the first; fg_mb_set_multilevel builds the second), so every per-iteration access is coalesced as before.
+struct OcAgg {
+    const int32_t* slot_cell;   // [16384] cell of a slot, -1 = hole
+    const uint2* nbr;           // [16384] neighbour slots
+    const float* d4g;           // [1024]
+    const int32_t* cnt;         // [1024]
+    const float* off4;          // [B][16384][4]
+    const float* diag;          // [B][16384]
+    float* bestx;               // [B][16384]
+};
+
 struct OcParams {
     OcPre pre;
+    OcAgg agg;
     const uint32_t* nbr16;   // [N][F/2] words: one 8-byte load per cell in 2-D
     const float* off4;       // [B][N][4] off-diagonals interleaved per cell (2-D), or null: q.off [B][F][N] is read instead
     int fence;               // compiler fence every four cells of the stencil pass (bounds the loads in flight)
@@ -1531,7 +1558,7 @@ __device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[2][OC
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) { sa += slot[0][w]; sb += slot[1][w]; }
     if (!RING) __syncthreads();   // single slot: nobody may rewrite it before everybody has read it
-    A = sa; B = sb;
+    A = sa; B = sb;   // (marking the sums wave-uniform with v_readfirstlane was measured: 16.4 -> 18.2 us per preconditioned iteration, 11.5 -> 20.6 plain)
 }
 
 // y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory: per cell
@@ -1591,20 +1618,103 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
     }
 }
 
-template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true, bool PRE = false>
+// Buffer-resource addressing for the slot-ordered arrays (cdna_hip_programming.md T8): one descriptor in SGPRs per array, ONE
+// per-thread byte offset, the member offset k NT as the scalar offset -- a flat pointer costs a 64-bit VGPR pair per member.
+typedef unsigned int oc_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int oc_u32x2 __attribute__((ext_vector_type(2)));
+using oc_rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ oc_rsrc oc_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// the same for the aggregate-owned layout: every index is a slot, a thread's first `cnt` members are cells.  Unconditional: a
+// hole's matrix row is all zeros and its neighbour word all ones.  The loads of G members are issued as ONE batch (explicit
+// arrays + a scheduling barrier): left to itself the compiler, short of registers, loads and waits member by member -- sixteen
+// serial L2 round trips per stencil pass, 13 of the 28 us of a preconditioned iteration (knock-out builds, -DFG_MB_OC_KNOCK).
+template <int CPT, int NT, int G>
+__device__ __forceinline__ float oc_spmv_agg(const OcParams& o, int sys, unsigned tl, const float* __restrict__ v_lds, float* __restrict__ y_lds) {
+    static_assert(CPT % G == 0, "member groups");
+    float part = 0.f;   // this thread's share of v . (M v)
+    constexpr unsigned S = CPT * NT;
+    const oc_rsrc R_off = oc_make_rsrc(o.agg.off4 + (size_t)sys * S * 4, S * 16u);
+    const oc_rsrc R_dg = oc_make_rsrc(o.agg.diag + (size_t)sys * S, S * 4u);
+    const oc_rsrc R_nb = oc_make_rsrc(o.agg.nbr, S * 8u);
+#pragma unroll
+    for (int k0 = 0; k0 < CPT; k0 += G) {
+        oc_u32x2 ub[G];
+        oc_u32x4 cb[G];
+        float dd[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned so = (unsigned)(k0 + g) * NT;
+#if defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 2)
+            const unsigned i = tl + so;
+            ub[g].x = (i ^ 1u) | ((i ^ 2u) << 16); ub[g].y = (i ^ 4u) | ((i ^ 8u) << 16);
+            cb[g].x = cb[g].y = cb[g].z = cb[g].w = __float_as_uint(-0.2f);
+            dd[g] = 1.f;
+#else
+            ub[g] = __builtin_amdgcn_raw_buffer_load_b64(R_nb, tl * 8u, so * 8u, 0);
+            cb[g] = __builtin_amdgcn_raw_buffer_load_b128(R_off, tl * 16u, so * 16u, 0);
+            dd[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R_dg, tl * 4u, so * 4u, 0));
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned i = tl + (unsigned)(k0 + g) * NT;
+            const uint32_t n0 = ub[g].x & 0xffffu, n1 = ub[g].x >> 16, n2 = ub[g].y & 0xffffu, n3 = ub[g].y >> 16;
+            const float vc = v_lds[i];
+#if defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 4)
+            const float v0 = vc, v1 = vc, v2 = vc, v3 = vc;
+#else
+            const float v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
+            const float v2 = v_lds[n2 != 0xffffu ? n2 : i], v3 = v_lds[n3 != 0xffffu ? n3 : i];
+#endif
+            // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
+            float acc = dd[g] * vc;
+            acc += n0 != 0xffffu ? __uint_as_float(cb[g].x) * v0 : 0.f;
+            acc += n1 != 0xffffu ? __uint_as_float(cb[g].y) * v1 : 0.f;
+            acc += n2 != 0xffffu ? __uint_as_float(cb[g].z) * v2 : 0.f;
+            acc += n3 != 0xffffu ? __uint_as_float(cb[g].w) * v3 : 0.f;
+            y_lds[i] = acc;
+            part += vc * acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return part;
+}
+
+template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true, bool PRE = false, bool AGG = false>
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
+    static_assert(!AGG || (PRE && DIMS == 2 && CPT == 16 && NT == 1024 && PM != 2 && !DG_REGS && !NBR), "aggregate-owned layout: 16 slots x 1024 threads, preconditioned, 2-D");
     __shared__ float v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
-    __shared__ float l_r4[PRE ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1];
+    __shared__ float l_r4[(PRE && !AGG) ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1];
     // r - mean r of the preconditioner pass, where the aggregate sums gather it; once they have, the same memory holds the
     // per-wave partial sums of the coarse solve
-    constexpr int RT = PRE ? (CPT * NT > OC_MAX_WAVES * OC_N8 ? CPT * NT : OC_MAX_WAVES * OC_N8) : 1;
+    constexpr int LP8 = AGG ? 256 : OC_N8;   // AGG: 4 n8 <= 1024 threads
+    constexpr int RT = PRE ? ((!AGG && CPT * NT > OC_MAX_WAVES * LP8) ? CPT * NT : OC_MAX_WAVES * LP8) : 1;
     __shared__ __attribute__((aligned(16))) float l_rt[RT];
-    float (*l_part)[OC_N8] = reinterpret_cast<float (*)[OC_N8]>(l_rt);
+    float (*l_part)[LP8] = reinterpret_cast<float (*)[LP8]>(l_rt);
+    // AGG: M p (and, before the stencil pass, z) lives in LDS instead of 16 registers per thread -- the cell-ordered preconditioned
+    // instance spills ~100 registers, and what that costs is the stencil pass: its 48 loads per thread no longer overlap
+    // (knock-out builds, -DFG_MB_OC_KNOCK: 13 of 28 us per iteration are those loads, against 11.5 us for the whole plain iteration)
+    __shared__ float ap_lds[AGG ? CPT * NT : 1];
+#define OC_AP(k, i) (*(AGG ? &ap_lds[i] : &ap[k]))
     static_assert(!PRE || NT == 1024, "the coarse solve of the preconditioner gives every one of the 16 waves its own set of columns");
     int phase = 0;
     const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
     const size_t vb = (size_t)sys * N;
+    // AGG: indices are slots; the thread's members k < cnt are cells.  Otherwise cell i = t + k NT < N.
+    const int cnt = AGG ? o.agg.cnt[t] : 0;
+    const float d4g_t = AGG ? o.agg.d4g[t] : 0.f;
+    // AGG: every slot is valid memory and holes hold zeros (matrix, kept iterate, LDS vectors), so nothing that touches memory is
+    // conditional -- a per-member branch `k < cnt` around the loads of the stencil pass serialises their latencies (16 round
+    // trips instead of one batch); only the values that would not be zero by themselves (r - mean, z) are masked with a select
+#define OC_OK(k, i) (AGG || ((i) < (unsigned)N))
+#define OC_M(k) (!AGG || ((k) < cnt))
+    const size_t sb = AGG ? (size_t)sys * (CPT * NT) : vb;                      // base of the per-iteration arrays of this env
+    const float* __restrict__ diag_it = AGG ? o.agg.diag + sb : q.diag + vb;    // diagonal in the index space of the iteration
     if (!mb_active(o.dt, sys)) {
         if (t == 0) {
             flag_st(q.flags + (sys), 3);
@@ -1626,14 +1736,17 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     }
     const float rsqn = rsqrtf((float)N);
     const float* __restrict__ rhs = q.rhs + vb;
-    float* __restrict__ bestx = q.best_x + vb;
+    float* __restrict__ bestx = AGG ? o.agg.bestx + sb : q.best_x + vb;
     // ---- start: x = x0 or 0, r = rhs (- M x0 through a residual pass)
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const unsigned i = t + (unsigned)k * NT;
-        x[k] = (i < (unsigned)N && o.use_x0) ? q.x[vb + i] : 0.f;
-        r[k] = i < (unsigned)N ? rhs[i] : 0.f;
-        dg[k] = (DG_REGS && i < (unsigned)N) ? q.diag[vb + i] : 0.f;
+        const bool ok = AGG ? (k < cnt) : (i < (unsigned)N);
+        const unsigned cell = (AGG && ok) ? (unsigned)o.agg.slot_cell[i] : i;   // rhs and x are in cell order: a gather, once per solve
+        x[k] = (ok && o.use_x0) ? q.x[vb + cell] : 0.f;
+        r[k] = ok ? rhs[cell] : 0.f;
+        if (AGG) { v_lds[i] = 0.f; ap_lds[i] = 0.f; }   // holes stay zero: only their owner ever reads them
+        dg[k] = (DG_REGS && ok) ? q.diag[vb + i] : 0.f;
         ap[k] = 0.f;
     }
     double rr = 0.0, sr = 0.0;
@@ -1641,7 +1754,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     if (PRE) {
         float sd = 0.f;
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { const unsigned i = t + (unsigned)k * NT; if (i < (unsigned)N) sd += q.diag[vb + i]; }
+        for (int k = 0; k < CPT; ++k) { const unsigned i = t + (unsigned)k * NT; if (OC_OK(k, i)) sd += diag_it[i]; }
         double dsum, unused0;
         oc_reduce2<NT, RING>(sd, 0.f, red, phase, dsum, unused0);
         inv_s = (float)((double)o.pre.geom_diag_sum / dsum);
@@ -1651,7 +1764,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = t + (unsigned)k * NT;
-            if (i < (unsigned)N) { s2 += r[k] * r[k]; s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn); }
+            if (OC_OK(k, i)) { s2 += r[k] * r[k]; s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn); }
         }
         oc_reduce2<NT, RING>(s2, s1, red, phase, rr, sr);
         if (PM == 0) sr = 0.0;
@@ -1689,7 +1802,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     const unsigned i = tl + (unsigned)k * NT;
-                    if (i < (unsigned)N) { const float v = bestx[i]; x[k] = isfinite(v) ? v : 0.f; }
+                    if (OC_OK(k, i)) { const float v = bestx[i]; x[k] = isfinite(v) ? v : 0.f; }
                 }
                 residual_pass = true; recovering = true;
             } else {
@@ -1698,7 +1811,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 if (it == 0 || crit < 0.5f * best || (crit < o.accept_factor * o.tol && crit < best)) {
                     best = crit; best_it = it;
 #pragma unroll
-                    for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (i < (unsigned)N) bestx[i] = x[k]; }
+                    for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (OC_OK(k, i)) bestx[i] = x[k]; }
                 }
                 if (it > 0 && it % o.check_every == 0) {   // the cadence of k_mbs_check in the chunked solver
                     if (o.accept_factor > 0.f && best <= o.accept_factor * o.tol && (it - 1) - best_it >= o.accept_window) { outcome = 3; break; }
@@ -1714,7 +1827,64 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
             restarted = false;
             beta = fresh ? 0.f : (float)(rho / rho_prev);
             cy = (float)sr;
-            if (PRE) {
+            if (PRE && AGG) {
+                // ---- z = M (r - mean r), aggregate-owned: the 4 x 4 sum is a sum over the thread's registers (members in the
+                // row-major order the gather of the cell-ordered form walks), the 8 x 8 sum the sum of a quad's lanes in child order
+                const float rm = PM == 1 ? cy * rsqn : 0.f;
+                const int n8 = o.pre.n8;
+                float r4 = 0.f;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) r4 += (k < cnt) ? r[k] - rm : 0.f;
+                {
+                    const int q0 = (t & 63) & ~3;
+                    const float c0 = __shfl(r4, q0, 64), c1 = __shfl(r4, q0 + 1, 64), c2 = __shfl(r4, q0 + 2, 64), c3 = __shfl(r4, q0 + 3, 64);
+                    if ((t & 3) == 0 && (t >> 2) < n8) l_r8[t >> 2] = ((c0 + c1) + c2) + c3;
+                }
+                __syncthreads();
+                {
+                    const int ld = (n8 + 3) & ~3, nq = ld >> 2, grp = t >> 6;
+                    for (int qd = t & 63; qd < nq; qd += 64) {
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#if !(defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 1))
+#pragma unroll 8
+                        for (int c = grp; c < n8; c += OC_MAX_WAVES) {
+                            const float4 a = *reinterpret_cast<const float4*>(o.pre.aci8 + (unsigned)c * (unsigned)ld + 4u * (unsigned)qd);
+                            const float rc = l_r8[c];
+                            acc.x += a.x * rc; acc.y += a.y * rc; acc.z += a.z * rc; acc.w += a.w * rc;
+                        }
+#endif
+                        *reinterpret_cast<float4*>(&l_part[grp][4 * qd]) = acc;
+                    }
+                }
+                __syncthreads();
+                const oc_rsrc R_dg = oc_make_rsrc(diag_it, (unsigned)(CPT * NT) * 4u);
+                float corr = 0.f;
+                if (cnt > 0) {
+                    float e = 0.f;
+#pragma unroll
+                    for (int g = 0; g < OC_MAX_WAVES; ++g) e += l_part[g][t >> 2];
+                    corr = inv_s * (0.5f * r4 * d4g_t + e);
+                }
+                float s_rz = 0.f, s_z = 0.f;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const unsigned i = tl + (unsigned)k * NT;
+                    const float rt = (k < cnt) ? r[k] - rm : 0.f;
+#if defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 8)
+                    const float z = (k < cnt) ? rt + corr : 0.f;
+#else
+                    const float dk = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R_dg, tl * 4u, (unsigned)k * NT * 4u, 0));
+                    const float z = (k < cnt) ? rt * __builtin_amdgcn_rcpf(dk) + corr : 0.f;
+#endif
+                    OC_AP(k, i) = z;
+                    s_rz += rt * z; s_z += z;
+                }
+                double zsum;
+                oc_reduce2<NT, RING>(s_rz, s_z, red, phase, rz, zsum);   // its barrier also orders the reads of l_part before the next pass writes it
+                zbar = PM == 1 ? (float)(zsum / (double)N) : 0.f;
+                beta = fresh ? 0.f : (float)(rz / rz_prev);
+                OC_PHASE(6);
+            } else if (PRE) {
                 // ---- z = M (r - mean r): restrict to the 4 x 4 and 8 x 8 aggregates (LDS atomics), dense coarse solve by the
                 // waves (one row per wave and pass, lanes over the columns), corrections summed top-down into l_r4
                 const float rm = PM == 1 ? cy * rsqn : 0.f;
@@ -1800,12 +1970,12 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = tl + (unsigned)k * NT;
-            if (i < (unsigned)N) {
+            if (OC_OK(k, i)) {
                 float v;
                 if (residual_pass) v = x[k];
                 else {
                     v = PM == 0 ? r[k] : (PM == 1 ? r[k] - cy * rsqn : r[k] - cy * o.yp[i]);
-                    if (PRE) v = ap[k] - zbar;   // z of this cell, parked in ap by the preconditioner pass
+                    if (PRE) v = OC_M(k) ? OC_AP(k, i) - zbar : 0.f;   // z of this cell, parked in ap by the preconditioner pass
                     if (!fresh) v += beta * v_lds[i];
                 }
                 v_lds[i] = v;
@@ -1813,15 +1983,17 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         }
         __syncthreads();
         OC_PHASE(7);   // direction update
-        oc_spmv<DIMS, CPT, DG_REGS, NB_REGS, NT>(q, o, sys, N, tl, v_lds, dg, nbk, ap);
+        float part = 0.f;
+        if constexpr (AGG) part = oc_spmv_agg<CPT, NT, OC_AGG_GROUP>(o, sys, tl, v_lds, ap_lds);
+        else oc_spmv<DIMS, CPT, DG_REGS, NB_REGS, NT>(q, o, sys, N, tl, v_lds, dg, nbk, ap);
         OC_PHASE(8);   // stencil pass
         float s2 = 0.f, s1 = 0.f;
         if (residual_pass) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 const unsigned i = tl + (unsigned)k * NT;
-                if (i < (unsigned)N) {
-                    r[k] = rhs[i] - ap[k];
+                if (AGG ? (k < cnt) : (i < (unsigned)N)) {
+                    r[k] = rhs[AGG ? (unsigned)o.agg.slot_cell[i] : i] - OC_AP(k, i);
                     s2 += r[k] * r[k];
                     s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
                 }
@@ -1831,9 +2003,10 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
             residual_pass = false; fresh = true; restarted = true;
             continue;
         }
-        float part = 0.f;
+        if (!AGG) {
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (i < (unsigned)N) part += v_lds[i] * ap[k]; }
+            for (int k = 0; k < CPT; ++k) { const unsigned i = tl + (unsigned)k * NT; if (OC_OK(k, i)) part += v_lds[i] * ap[k]; }
+        }
         double pap, unused;
         oc_reduce2<NT, RING>(part, 0.f, red, phase, pap, unused);
         OC_PHASE(9);   // p.Pp reduction
@@ -1841,9 +2014,9 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = tl + (unsigned)k * NT;
-            if (i < (unsigned)N) {
+            if (OC_OK(k, i)) {
                 x[k] += alpha * v_lds[i];
-                r[k] -= alpha * ap[k];
+                r[k] -= alpha * OC_AP(k, i);
                 s2 += r[k] * r[k];
                 s1 += r[k] * (PM == 2 ? o.yp[i] : rsqn);
             }
@@ -1868,8 +2041,11 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const unsigned i = t + (unsigned)k * NT;
-        if (i < (unsigned)N) q.x[vb + i] = use_best ? bestx[i] : x[k];
+        if (AGG ? (k < cnt) : (i < (unsigned)N)) q.x[vb + (AGG ? (unsigned)o.agg.slot_cell[i] : i)] = use_best ? bestx[i] : x[k];
     }
+#undef OC_OK
+#undef OC_M
+#undef OC_AP
     if (t == 0) {
         flag_st(q.flags + (sys), outcome == 2 ? 2 : (outcome == 3 ? 5 : 1));
         q.info[sys].final_residual = use_best ? best : crit;
@@ -2282,8 +2458,16 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     o.pre.a4 = s->ml_a4; o.pre.parent4 = s->ml_parent4; o.pre.d4g = s->ml_d4g; o.pre.aci8 = s->ml_aci8;
     o.pre.rect4 = s->ml_rect4; o.pre.child8 = s->ml_child8;
     o.pre.n4 = s->ml_n4; o.pre.n8 = s->ml_n8; o.pre.geom_diag_sum = s->ml_geom_diag_sum;
+    // the aggregate-owned layout (fg_mb.h) when its tables are installed and the matrix is the pressure matrix k_mb_pmatrix wrote
+    const bool agg = pre && s->oc_agg && s->dbg_oc_agg && !s->oc_matrix_stale && diag == s->Pdiag && off == s->Poff;
+    o.agg.slot_cell = s->oc_slot_cell; o.agg.nbr = s->oc_nbr; o.agg.d4g = s->oc_d4g; o.agg.cnt = s->oc_cnt;
+    o.agg.off4 = s->Poff4s; o.agg.diag = s->Pdiag_s; o.agg.bestx = s->oc_bestx;
 #define OC_LAUNCH_PRE(CPT_, DGR_, NBR_) do { if (pre) OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, true); else OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, false); } while (0)
-    if (n <= 4 * 1024) OC_LAUNCH_PRE(4, true, true);
+#ifndef OC_AGG_RING
+#define OC_AGG_RING false
+#endif
+    if (agg) OC_LAUNCH_PM(16, false, 1024, false, OC_AGG_RING, true, true);
+    else if (n <= 4 * 1024) OC_LAUNCH_PRE(4, true, true);
     else if (n <= 8 * 1024) OC_LAUNCH_PRE(8, true, true);
     else if (n <= 16 * 1024) OC_LAUNCH_PRE(16, false, false);
     else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024, false, false, false);
@@ -2487,6 +2671,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_OC_AGG"); s->dbg_oc_agg = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_VARIANT"); s->oc_variant = e ? atoi(e) : 0;   // bit 0: no compiler fences in the stencil pass; bit 1: split [F][N] coefficient layout
     }
     *out = s;
@@ -2756,7 +2941,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         }
         // ---- correctors (SIM.py:1777-1972)
         for (int c = 0; c < opt->corrector_steps; ++c) {
-            hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4);
+            hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;
             for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
                 if (ps == 0) {
                     hipLaunchKernelGGL(k_mb_h<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->rA, s->Coff, s->velocity, s->ures,
@@ -2902,6 +3087,65 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
     FG_HIP_CHECK(hipMemcpy(s->ml_d4g, rd4.data(), sizeof(float) * n4, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_aci8, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
     s->ml_n4 = n4; s->ml_n8 = n8; s->ml_geom_diag_sum = geom_diag_sum; s->ml_on = enable != 0;
+    // ---- aggregate-owned layout of the on-chip CG (fg_mb.h): thread 4 A + c owns child c of 8 x 8 aggregate A
+    s->oc_agg = false;
+    bool fits = s->d == 2 && s->nbr16 != nullptr && 4 * n8 <= 1024 && s->N <= fg_mb_state::OC_SLOTS;
+    for (int a = 0; a < n4 && fits; ++a) fits = rect4_host[4 * a + 1] * rect4_host[4 * a + 2] <= 16;
+    if (fits) {
+        constexpr int S = fg_mb_state::OC_SLOTS;
+        std::vector<int32_t> slot_cell(S, -1), cnt(1024, 0);
+        std::vector<uint16_t> cell_slot(s->N, 0xffff);
+        std::vector<float> d4t(1024, 0.f);
+        for (int A = 0; A < n8; ++A) {
+            const unsigned words[2] = {child[A].x, child[A].y};
+            for (int c = 0; c < 4; ++c) {
+                const unsigned a = (words[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+                if (a == 0xffffu) continue;
+                const int t = 4 * A + c;
+                const int first = rect4_host[4 * a], w = rect4_host[4 * a + 1], h = rect4_host[4 * a + 2], stride = rect4_host[4 * a + 3];
+                cnt[t] = w * h;
+                d4t[t] = rd4[a];
+                for (int dy = 0; dy < h; ++dy)
+                    for (int dx = 0; dx < w; ++dx) {
+                        const int cell = first + dy * stride + dx, slot = t + 1024 * (dy * w + dx);
+                        slot_cell[slot] = cell;
+                        cell_slot[cell] = (uint16_t)slot;
+                    }
+            }
+        }
+        for (int i = 0; i < s->N && fits; ++i) fits = cell_slot[i] != 0xffff;   // every cell owned (0xFFFF is no slot: 16383 is the last)
+        if (fits) {
+            std::vector<uint2> nbr(S, make_uint2(0xffffffffu, 0xffffffffu));
+            for (int sl = 0; sl < S; ++sl) {
+                const int cell = slot_cell[sl];
+                if (cell < 0) continue;
+                unsigned v[4];
+                for (int f = 0; f < 4; ++f) { const int32_t n = s->h_nbr[(size_t)f * s->N + cell]; v[f] = n >= 0 ? cell_slot[n] : 0xffffu; }
+                nbr[sl] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+            }
+            if (!s->oc_slot_cell) {
+                if (int rc = mb_alloc(s, &s->oc_slot_cell, (size_t)S)) return rc;
+                if (int rc = mb_alloc(s, &s->oc_cell_slot, (size_t)s->N)) return rc;
+                if (int rc = mb_alloc(s, &s->oc_nbr, (size_t)S)) return rc;
+                if (int rc = mb_alloc(s, &s->oc_d4g, (size_t)1024)) return rc;
+                if (int rc = mb_alloc(s, &s->oc_cnt, (size_t)1024)) return rc;
+                if (int rc = mb_alloc(s, &s->Poff4s, (size_t)s->B * S * 4)) return rc;
+                if (int rc = mb_alloc(s, &s->Pdiag_s, (size_t)s->B * S)) return rc;
+                if (int rc = mb_alloc(s, &s->oc_bestx, (size_t)s->B * S)) return rc;
+            }
+            // holes stay zero for good: k_mb_pmatrix and the solver write the slots of cells only
+            FG_HIP_CHECK(hipMemset(s->Poff4s, 0, sizeof(float) * (size_t)s->B * S * 4));
+            FG_HIP_CHECK(hipMemset(s->Pdiag_s, 0, sizeof(float) * (size_t)s->B * S));
+            FG_HIP_CHECK(hipMemset(s->oc_bestx, 0, sizeof(float) * (size_t)s->B * S));
+            FG_HIP_CHECK(hipMemcpy(s->oc_slot_cell, slot_cell.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
+            FG_HIP_CHECK(hipMemcpy(s->oc_cell_slot, cell_slot.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
+            FG_HIP_CHECK(hipMemcpy(s->oc_nbr, nbr.data(), sizeof(uint2) * S, hipMemcpyHostToDevice));
+            FG_HIP_CHECK(hipMemcpy(s->oc_d4g, d4t.data(), sizeof(float) * 1024, hipMemcpyHostToDevice));
+            FG_HIP_CHECK(hipMemcpy(s->oc_cnt, cnt.data(), sizeof(int32_t) * 1024, hipMemcpyHostToDevice));
+            s->oc_agg = true;
+            s->oc_matrix_stale = true;   // the slot-ordered copy of the matrix does not exist yet (fg_mb_step.hip: mb_cg_onchip)
+        }
+    }
     return FG_OK;
 }
 
@@ -3141,7 +3385,7 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
     hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, (const float*)nullptr, s->velocity, s->hvec);
     MB_DISPATCH(s, {
         hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, (const float*)nullptr, s->hvec, s->bvel, s->cc, s->fb);
-        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4);
+        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;
         for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
             hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
             int m = 0;
@@ -3216,7 +3460,7 @@ extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
     const size_t BN = (size_t)s->B * s->N;
     hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), dim3(FG_BLOCK), 0, st, BN, 1.f, s->rA);
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, dim3((s->N + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st, s->dev,
-                                      (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4););
+                                      (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;);
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }

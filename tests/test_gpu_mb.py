@@ -435,6 +435,40 @@ def test_multilevel_preconditioned_onchip_cg_reaches_the_same_answer_in_fewer_it
     assert c_m["pressure0"]["mean"] > 3       # it did iterate
 
 
+def test_aggregate_owned_onchip_cg_is_the_cell_ordered_one(monkeypatch):
+    """The aggregate-owned layout of the preconditioned on-chip CG (k_mbc_onchip<AGG>: thread = one 4 x 4 aggregate, restriction and
+    prolongation in registers, matrix in slot order, stencil loads batched) against the cell-ordered kernel (FG_MB_OC_AGG=0) on the
+    reference's cylinder mesh: the same recurrence with another summation order of the dot products, so the iteration counts of
+    every solve may differ by one or two and the projected velocities agree to what two Krylov trajectories at that tolerance
+    do.  A mesh the layout does not fit (an aggregate table with more than 256 8 x 8 aggregates) keeps the cell-ordered kernel:
+    covered by the other multilevel tests, which run meshes of both kinds."""
+    from fluidgym_amd.envs.cylinder_grid import build_domain, make_vortex_street_mesh
+
+    mesh = make_vortex_street_mesh(24)
+    out = {}
+    for agg in ("0", "1"):
+        monkeypatch.setenv("FG_MB_OC_AGG", agg)
+        dom = build_domain(mesh, 0.01, batch=3)
+        dom.set_stall_limit(5000)
+        assert dom.set_pressure_multilevel() == {"n4": 912, "n8": 228}
+        g = torch.Generator(device="cpu").manual_seed(11)
+        dom.velocity.copy_((0.3 * torch.randn(dom.velocity.shape, generator=g)).to(dom.device))
+        dom.velocity[:, 0] += 1.0
+        dom.solver_counters(reset=True)
+        dom.make_divergence_free(pressure_tol=1e-7, max_iterations=5000, pressure_project_mean=True)
+        u0 = dom.velocity.cpu().numpy().copy()
+        for _ in range(3):
+            dom.piso_step([0.01, 0.02, 0.0], pressure_tol=1e-7, advection_tol=1e-7, pressure_project_mean=True)   # env 2 inactive
+        out[agg] = (u0, dom.velocity.cpu().numpy().copy(), dom.pressure.cpu().numpy().copy(), dom.solver_counters())
+        dom.close()
+    (u0_c, u_c, p_c, c_c), (u0_a, u_a, p_a, c_a) = out["0"], out["1"]
+    assert np.isfinite(u_a).all() and np.isfinite(p_a).all()
+    assert _rel(u0_a, u0_c) < 2e-5 and _rel(u_a, u_c) < 5e-5, (_rel(u0_a, u0_c), _rel(u_a, u_c))
+    for k in ("pressure0", "pressure1"):
+        assert abs(c_a[k]["mean"] - c_c[k]["mean"]) <= 2.0 and c_a[k]["unconverged"] == 0, (c_c, c_a)
+    np.testing.assert_array_equal(u_a[2], u0_a[2])   # the inactive env is untouched
+
+
 @pytest.mark.parametrize("spec_fn", [H.polar_ring, H.split_rotated_channel, H.odd_channel])
 def test_multilevel_preconditioned_step_matches_the_oracle(spec_fn):
     """Whole PISO step with the preconditioned on-chip CG against the oracle's DIRECT solves, on the meshes where CG is a valid
