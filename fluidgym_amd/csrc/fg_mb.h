@@ -116,7 +116,7 @@ struct fg_mb_state {
     static constexpr int OC_SLOTS = 16 * 1024;
     int32_t* oc_slot_cell = nullptr;   // [OC_SLOTS] cell of a slot, -1 = hole
     uint16_t* oc_cell_slot = nullptr;  // [N] slot of a cell
-    uint2* oc_nbr = nullptr;           // [OC_SLOTS] the four neighbour SLOTS of a slot's cell, 16 bits each, 0xFFFF = prescribed face
+    uint2* oc_nbr = nullptr;           // [OC_SLOTS] the four neighbour slots of a slot's cell as byte offsets (slot * 4), 16 bits each; prescribed face = the slot itself
     float* oc_d4g = nullptr;           // [1024] 1 / diag(Z4^T S Z4) of the thread's aggregate (0: the thread owns none)
     int32_t* oc_cnt = nullptr;         // [1024] cells the thread owns
     float *Poff4s = nullptr, *Pdiag_s = nullptr, *oc_bestx = nullptr;   // [B][OC_SLOTS][4], [B][OC_SLOTS], [B][OC_SLOTS]: slot order; holes stay 0

@@ -1496,6 +1496,9 @@ __global__ void k_mbs_restore_best(int N, MbSolve q) {
 #ifndef OC_AGG_GROUP
 #define OC_AGG_GROUP 2   // members of the aggregate-owned stencil pass loaded per batch
 #endif
+#ifndef OC_AGG_PIPE
+#define OC_AGG_PIPE 0    // ... double-buffered (measured: 16.2-16.9 us per iteration either way; G = 4 spills: 20.9)
+#endif
 constexpr int OC_MAX_WAVES = 16;   // workgroups of 1024 or 512 threads (NT): 512 threads get 256 registers each
 
 // Two-level-plus additive preconditioner of the on-chip CG (fg_mb_set_multilevel): M r = D^-1 r + 1/2 Z4 D4^-1 Z4^T r + Z8 A8^+ Z8^T r with
@@ -1634,48 +1637,60 @@ __device__ __forceinline__ oc_rsrc oc_make_rsrc(const void* p, unsigned bytes) {
 template <int CPT, int NT, int G>
 __device__ __forceinline__ float oc_spmv_agg(const OcParams& o, int sys, unsigned tl, const float* __restrict__ v_lds, float* __restrict__ y_lds) {
     static_assert(CPT % G == 0, "member groups");
+    constexpr int NB = CPT / G;
     float part = 0.f;   // this thread's share of v . (M v)
     constexpr unsigned S = CPT * NT;
     const oc_rsrc R_off = oc_make_rsrc(o.agg.off4 + (size_t)sys * S * 4, S * 16u);
     const oc_rsrc R_dg = oc_make_rsrc(o.agg.diag + (size_t)sys * S, S * 4u);
     const oc_rsrc R_nb = oc_make_rsrc(o.agg.nbr, S * 8u);
-#pragma unroll
-    for (int k0 = 0; k0 < CPT; k0 += G) {
-        oc_u32x2 ub[G];
-        oc_u32x4 cb[G];
-        float dd[G];
+    // two batches of G members: batch b + 1 is requested before batch b is consumed (OC_AGG_PIPE), so one L2 round trip is exposed
+    // per stencil pass instead of one per batch
+    oc_u32x2 ub[2][G];
+    oc_u32x4 cb[2][G];
+    float dd[2][G];
+    auto request = [&](int b, int buf) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const unsigned so = (unsigned)(k0 + g) * NT;
+            const unsigned so = (unsigned)(b * G + g) * NT;
 #if defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 2)
             const unsigned i = tl + so;
-            ub[g].x = (i ^ 1u) | ((i ^ 2u) << 16); ub[g].y = (i ^ 4u) | ((i ^ 8u) << 16);
-            cb[g].x = cb[g].y = cb[g].z = cb[g].w = __float_as_uint(-0.2f);
-            dd[g] = 1.f;
+            ub[buf][g].x = ((i ^ 1u) * 4u) | (((i ^ 2u) * 4u) << 16); ub[buf][g].y = ((i ^ 4u) * 4u) | (((i ^ 8u) * 4u) << 16);
+            cb[buf][g].x = cb[buf][g].y = cb[buf][g].z = cb[buf][g].w = __float_as_uint(-0.2f);
+            dd[buf][g] = 1.f;
 #else
-            ub[g] = __builtin_amdgcn_raw_buffer_load_b64(R_nb, tl * 8u, so * 8u, 0);
-            cb[g] = __builtin_amdgcn_raw_buffer_load_b128(R_off, tl * 16u, so * 16u, 0);
-            dd[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R_dg, tl * 4u, so * 4u, 0));
+            ub[buf][g] = __builtin_amdgcn_raw_buffer_load_b64(R_nb, tl * 8u, so * 8u, 0);
+            cb[buf][g] = __builtin_amdgcn_raw_buffer_load_b128(R_off, tl * 16u, so * 16u, 0);
+            dd[buf][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R_dg, tl * 4u, so * 4u, 0));
 #endif
         }
+    };
+    if (OC_AGG_PIPE) request(0, 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int buf = OC_AGG_PIPE ? (b & 1) : 0;
+        if (OC_AGG_PIPE) { if (b + 1 < NB) request(b + 1, (b + 1) & 1); }
+        else request(b, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const unsigned i = tl + (unsigned)(k0 + g) * NT;
-            const uint32_t n0 = ub[g].x & 0xffffu, n1 = ub[g].x >> 16, n2 = ub[g].y & 0xffffu, n3 = ub[g].y >> 16;
+            const unsigned i = tl + (unsigned)(b * G + g) * NT;
+            // the table holds BYTE offsets into the LDS vector (slot * 4 <= 65 532), and a prescribed face points at the cell itself
+            // with the zero coefficient k_mb_pmatrix wrote for it: no shifts, compares or selects -- the kernel is VALU-bound
+            // (~130 vector instructions per member and iteration at four waves per SIMD), so every one of them counts
+            const uint32_t a0 = ub[buf][g].x & 0xffffu, a1 = ub[buf][g].x >> 16, a2 = ub[buf][g].y & 0xffffu, a3 = ub[buf][g].y >> 16;
+            const char* vb_ = reinterpret_cast<const char*>(v_lds);
             const float vc = v_lds[i];
 #if defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 4)
             const float v0 = vc, v1 = vc, v2 = vc, v3 = vc;
 #else
-            const float v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
-            const float v2 = v_lds[n2 != 0xffffu ? n2 : i], v3 = v_lds[n3 != 0xffffu ? n3 : i];
+            const float v0 = *reinterpret_cast<const float*>(vb_ + a0), v1 = *reinterpret_cast<const float*>(vb_ + a1);
+            const float v2 = *reinterpret_cast<const float*>(vb_ + a2), v3 = *reinterpret_cast<const float*>(vb_ + a3);
 #endif
-            // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
-            float acc = dd[g] * vc;
-            acc += n0 != 0xffffu ? __uint_as_float(cb[g].x) * v0 : 0.f;
-            acc += n1 != 0xffffu ? __uint_as_float(cb[g].y) * v1 : 0.f;
-            acc += n2 != 0xffffu ? __uint_as_float(cb[g].z) * v2 : 0.f;
-            acc += n3 != 0xffffu ? __uint_as_float(cb[g].w) * v3 : 0.f;
+            float acc = dd[buf][g] * vc;
+            acc += __uint_as_float(cb[buf][g].x) * v0;
+            acc += __uint_as_float(cb[buf][g].y) * v1;
+            acc += __uint_as_float(cb[buf][g].z) * v2;
+            acc += __uint_as_float(cb[buf][g].w) * v3;
             y_lds[i] = acc;
             part += vc * acc;
         }
@@ -2868,6 +2883,57 @@ extern "C" int fg_mb_bind(fg_mb_handle s, float* velocity, float* pressure_resul
     return FG_OK;
 }
 
+// ---- drag / lift on a closed wall (envs/util/forces.py:193-377 of the reference, compute_forces_2d / _3d): traction
+// (2 nu S - p I) n on every wall face, S from the one-sided normal derivative (cell - wall) / distance and a central tangential
+// derivative over the ring of wall-adjacent cells, times the face length (area), summed over the ring.  One workgroup per (layer,
+// env); the host code did this with ~40 tensor ops per sim step (290 us of host time against a 1.4 ms PISO step).
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_wall_forces(int d, int N, int NB, int n, int layers, const float* __restrict__ u,
+                                                              const float* __restrict__ ub, const float* __restrict__ p,
+                                                              const int32_t* __restrict__ cell_index, const int32_t* __restrict__ slot_index,
+                                                              const float* __restrict__ geom, float area_scale, float nu,
+                                                              float* __restrict__ out) {
+    __shared__ float lds[8];
+    const int layer = blockIdx.x, b = blockIdx.y;
+    const float* ue = u + (size_t)b * d * N;
+    const float* ube = ub + (size_t)b * d * NB;
+    const float* pe = p + (size_t)b * N;
+    const int32_t* ci = cell_index + (size_t)layer * n;
+    const int32_t* si = slot_index + (size_t)layer * n;
+    float f[2] = {0.f, 0.f};
+    for (int j = threadIdx.x; j < n; j += FG_BLOCK) {
+        const int c = ci[j], cl = ci[j + 1 == n ? 0 : j + 1], cr = ci[j == 0 ? n - 1 : j - 1], sl = si[j];   // roll(-1) = "left", roll(+1) = "right"
+        const float nx = geom[j], ny = geom[n + j], tl = geom[2 * n + j], wd = geom[3 * n + j], fl = geom[4 * n + j] * area_scale;
+        const float tx = ny, ty = -nx;
+        float dn[2], dt[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            dn[q] = (ue[(size_t)q * N + c] - ube[(size_t)q * NB + sl]) / wd;
+            dt[q] = (ue[(size_t)q * N + cr] - ue[(size_t)q * N + cl]) / (2.f * tl);
+        }
+        const float du_dx = dn[0] * nx + dt[0] * tx, du_dy = dn[0] * ny + dt[0] * ty;
+        const float dv_dx = dn[1] * nx + dt[1] * tx, dv_dy = dn[1] * ny + dt[1] * ty;
+        const float sxy = 0.5f * (du_dy + dv_dx), two_nu = 2.f * nu, pc = pe[c];
+        f[0] += ((two_nu * du_dx - pc) * nx + two_nu * sxy * ny) * fl;
+        f[1] += (two_nu * sxy * nx + (two_nu * dv_dy - pc) * ny) * fl;
+    }
+    mb_block_sums<2>(f, lds);
+    if (threadIdx.x == 0) {
+        out[((size_t)b * 2 + 0) * layers + layer] = f[0];
+        out[((size_t)b * 2 + 1) * layers + layer] = f[1];
+    }
+}
+
+extern "C" int fg_mb_wall_forces(fg_mb_handle s, const int32_t* cell_index, const int32_t* slot_index, const float* geom, int32_t n,
+                                 int32_t layers, float area_scale, float viscosity, float* out, void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity && s->pressure && s->bvel, FG_ERR_NOT_BOUND, "fg_mb_wall_forces: fields not bound");
+    FG_REQUIRE(cell_index && slot_index && geom && out && n > 0 && layers > 0, FG_ERR_INVALID_ARG, "fg_mb_wall_forces: bad argument");
+    hipLaunchKernelGGL(k_mb_wall_forces, dim3(layers, s->B), dim3(FG_BLOCK), 0, (hipStream_t)stream, s->d, s->N, s->NB, n, layers,
+                       (const float*)s->velocity, (const float*)s->bvel, (const float*)s->pressure, cell_index, slot_index, geom, area_scale,
+                       viscosity, out);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
 extern "C" int fg_mb_set_viscosity(fg_mb_handle s, float nu) {
     FG_REQUIRE(s && nu > 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_viscosity: viscosity must be positive");
     s->nu = nu;
@@ -3115,12 +3181,16 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
         }
         for (int i = 0; i < s->N && fits; ++i) fits = cell_slot[i] != 0xffff;   // every cell owned (0xFFFF is no slot: 16383 is the last)
         if (fits) {
-            std::vector<uint2> nbr(S, make_uint2(0xffffffffu, 0xffffffffu));
+            // neighbours as BYTE offsets into the LDS vector (slot * 4); a prescribed face -- and every face of a hole -- points at
+            // the slot itself (its coefficient is zero: k_mb_pmatrix)
+            std::vector<uint2> nbr(S);
             for (int sl = 0; sl < S; ++sl) {
                 const int cell = slot_cell[sl];
-                if (cell < 0) continue;
                 unsigned v[4];
-                for (int f = 0; f < 4; ++f) { const int32_t n = s->h_nbr[(size_t)f * s->N + cell]; v[f] = n >= 0 ? cell_slot[n] : 0xffffu; }
+                for (int f = 0; f < 4; ++f) {
+                    const int32_t n = cell >= 0 ? s->h_nbr[(size_t)f * s->N + cell] : -1;
+                    v[f] = 4u * (unsigned)(n >= 0 ? cell_slot[n] : sl);
+                }
                 nbr[sl] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
             }
             if (!s->oc_slot_cell) {

@@ -119,9 +119,24 @@ class WallRing:
         self.vertices, self.centers = vc, ctr
         self.wall_distances, self.wall_normals = dist.to(**f32), normals.to(**f32)
         self.tangent_lengths, self.face_lengths = tl.to(**f32), fl.to(**f32)
+        self._native = None   # int32 index tables + packed geometry of fg_mb_wall_forces, built on first use
 
     def forces(self, domain, viscosity: float, layer_height: float = 1.0) -> torch.Tensor:
-        """[B, 2] force on the wall from the domain's current fields; [B, 2, NZ] per spanwise layer in 3-D."""
+        """[B, 2] force on the wall from the domain's current fields; [B, 2, NZ] per spanwise layer in 3-D.  One launch of
+        ``fg_mb_wall_forces`` on the domain's bound fields (the tensor form below -- :func:`compute_forces_2d`, pinned on the
+        reference's own function in tests/test_env_math_golden.py -- costs ~40 launches per sim step and is what the kernel is
+        tested against)."""
+        if self._native is None:
+            i32 = dict(dtype=torch.int32, device=self.cell_index.device)
+            geom = torch.stack([self.wall_normals[0], self.wall_normals[1], self.tangent_lengths, self.wall_distances,
+                                self.face_lengths]).contiguous()
+            self._native = (self.cell_index.reshape(self.nz, -1).to(**i32).contiguous(),
+                            self.slot_index.reshape(self.nz, -1).to(**i32).contiguous(), geom)
+        out = domain.wall_forces(*self._native, float(layer_height) if self.dims == 3 else 1.0, float(viscosity))   # [B, 2, NZ]
+        return out if self.dims == 3 else out[:, :, 0]
+
+    def forces_tensor_form(self, domain, viscosity: float, layer_height: float = 1.0) -> torch.Tensor:
+        """The same through :func:`compute_forces_2d` / :func:`compute_forces_3d` (the reference's arithmetic, op by op)."""
         u_cell = domain.velocity[:, :, self.cell_index]
         u_b = domain.boundary_velocity[:, :, self.slot_index]
         p = domain.pressure[:, self.cell_index]

@@ -525,6 +525,13 @@ int fg_mb_multilevel_apply(fg_mb_handle h, const float* r_BN, float* z_BN, void*
  * out3 = current back-off in solves (0: no tables; 4: every attempt converges; up to 256), attempts, failed attempts (each repeated
  * with the plain recurrence). */
 int fg_mb_multilevel_status(fg_mb_handle h, int32_t* out3);
+/* Force on a closed wall from the bound fields: replaces the tensor arithmetic of the reference's envs/util/forces.py
+ * (compute_forces_2d :193-276, compute_forces_3d :278-377) behind CylinderEnvBase._get_drag_and_lift (cylinder_env_base.py:676-700).
+ * cell_index / slot_index [layers][n]: the wall-adjacent cell and the boundary slot of every wall face in ring order (device);
+ * geom [5][n]: outward normal x, y, tangential spacing, wall distance, face length (device); out [B][2][layers] (device) =
+ * sum over the ring of ((2 nu S - p I) n) * face length * area_scale.  Asynchronous on `stream`. */
+int fg_mb_wall_forces(fg_mb_handle h, const int32_t* cell_index, const int32_t* slot_index, const float* geom, int32_t n,
+                      int32_t layers, float area_scale, float viscosity, float* out, void* stream);
 int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their

@@ -23,7 +23,7 @@ def install():
 
     D = M.MultiBlockDomain
     saved = {k: getattr(D, k) for k in ("__init__", "_bind", "single_step", "make_divergence_free", "set_pressure_multilevel",
-                                          "set_advection_start", "env_status", "solver_hints", "solver_counters", "boundary_flux_balance")}
+                                          "set_advection_start", "env_status", "solver_hints", "solver_counters", "boundary_flux_balance", "wall_forces")}
 
     def __init__(self, dims, viscosity, batch=1, device=None, reference_quirks=True, non_ortho_flags=25):
         self.lib = L.load()
@@ -50,7 +50,17 @@ def install():
         self.pressure.copy_(self.velocity[:, 0] * self.velocity[:, 1])
         return 1, True, (1, 1, 1)
 
+    def wall_forces(self, cell_index, slot_index, geom, area_scale, viscosity):
+        """The tensor form (the reference's arithmetic) on the CPU fields, in the kernel's argument and result layout."""
+        from fluidgym_amd.envs.forces import compute_forces_2d
+
+        ci, si = cell_index.long(), slot_index.long()                                   # [layers, n]
+        u, ub, p = self.velocity[:, :2][:, :, ci], self.boundary_velocity[:, :2][:, :, si], self.pressure[:, ci]   # [B, 2, L, n], [B, L, n]
+        f = compute_forces_2d(u.transpose(1, 2), ub.transpose(1, 2), p, geom[:2], geom[2], geom[3], geom[4] * area_scale, viscosity)
+        return f.transpose(1, 2).contiguous()                                           # [B, L, 2] -> [B, 2, L]
+
     D.__init__ = __init__
+    D.wall_forces = wall_forces
     D._bind = lambda self: None
     D.single_step = single_step
     D.make_divergence_free = lambda self, **kw: True

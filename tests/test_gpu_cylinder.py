@@ -250,3 +250,33 @@ def test_parallel_env_wraps_the_multi_block_env_on_the_gpu():
         assert float(pinfo[1]["drag"]) == float(info["drag"][1])
     assert penv.sample_action().shape == (2, 1)
     penv.close(); env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["CylinderJet2D-easy-v0", "CylinderJet3D-easy-v0"])
+def test_wall_force_kernel_is_the_tensor_form(env_id):
+    """``fg_mb_wall_forces`` (one launch on the bound fields) against the tensor form of the same arithmetic
+    (``forces.compute_forces_2d`` / ``_3d``, which tests/test_env_math_golden.py pins on the reference's own function): same
+    formulas in fp32, another summation order over the ring."""
+    import fluidgym_amd
+
+    kw = dict(num_envs=2, initial_domain_steps=3, randomize_initial_state=False)
+    if "3D" in env_id:
+        kw["resolution"] = 8
+    env = fluidgym_amd.make(env_id, **kw)
+    env.reset(seed=0)
+    act = torch.full_like(env._zero_action, 0.5)
+    act[1] = -0.5
+    env.step(act)
+    dom, ring = env._domain, env._ring
+    g = torch.Generator(device="cpu").manual_seed(3)
+    dom.velocity.add_((0.2 * torch.randn(dom.velocity.shape, generator=g)).cuda())       # a field with real wall gradients
+    dom.pressure.add_((0.5 * torch.randn(dom.pressure.shape, generator=g)).cuda())
+    lh = env.D / env._circle_resolution_angular
+    got = ring.forces(dom, env._nu, layer_height=lh)
+    ref = ring.forces_tensor_form(dom, env._nu, layer_height=lh)
+    assert got.shape == ref.shape and got.shape[0] == 2
+    scale = ref.abs().max().item()
+    assert scale > 1e-3
+    assert (got - ref).abs().max().item() <= 2e-5 * scale, ((got - ref).abs().max().item(), scale)
+    env.close()
