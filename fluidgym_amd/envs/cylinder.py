@@ -215,17 +215,30 @@ class CylinderEnvBase(FluidEnv):
 
     def _step_impl(self, action: torch.Tensor):
         target = action.reshape(self._num_envs, self._n_controls)
-        cds, cls = [], []
-        for _ in range(self._n_sim_steps):
-            control = self._last_control + self._action_smoothing_alpha * (target - self._last_control)
-            self._last_control = control
+        n = self._n_sim_steps
+        # The smoothed control of every sim step (cylinder_env_base.py:560-566: c <- c + alpha (target - c)) is a recurrence on a
+        # [B, n_controls] tensor: evaluated once on the host in the same fp32 operations (separately rounded multiply and add,
+        # as the per-step tensor expression) and uploaded in one copy, instead of three tiny launches per sim step.
+        c = self._last_control.cpu()
+        t_host, alpha, controls = target.cpu(), self._action_smoothing_alpha, []
+        for _ in range(n):
+            c = c + alpha * (t_host - c)
+            controls.append(c)
+        controls = torch.stack(controls).to(self._last_control.device, non_blocking=False)      # [n, B, n_controls]
+        # raw wall forces of every sim step land in one buffer; normalised and averaged once (elementwise division, then the
+        # mean over the stack: what torch.stack of the per-step coefficients gave)
+        raw = torch.empty(n, self._num_envs, 2, self._ring.nz, dtype=torch.float32, device=self._last_control.device)
+        for k in range(n):
+            self._last_control = controls[k]
             if self._enable_actions:
-                self._apply_action(control)
+                self._apply_action(controls[k])
             self._sim.single_step()
-            cd, cl = self._get_drag_and_lift()
-            cds.append(cd); cls.append(cl)
+            self._ring.forces(self._domain, self._nu, layer_height=self.D / self._circle_resolution_angular, out=raw[k])
         obs = self._get_global_obs()
-        cd, cl = torch.stack(cds).mean(0), torch.stack(cls).mean(0)
+        coeff = raw / (0.5 * self._U_mean ** 2 * self.cylinder_diameter)
+        if self._ndims == 2:
+            coeff = coeff[..., 0]
+        cd, cl = coeff[:, :, 0].mean(0), coeff[:, :, 1].mean(0)
         if self._ndims == 3:   # summed over the span here; CylinderJetEnv3D divides by D (:765-768)
             reward = self._cd_ref - cd.sum(-1) - self._lift_penalty * cl.sum(-1).abs()
         else:

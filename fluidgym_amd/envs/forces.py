@@ -121,8 +121,9 @@ class WallRing:
         self.tangent_lengths, self.face_lengths = tl.to(**f32), fl.to(**f32)
         self._native = None   # int32 index tables + packed geometry of fg_mb_wall_forces, built on first use
 
-    def forces(self, domain, viscosity: float, layer_height: float = 1.0) -> torch.Tensor:
-        """[B, 2] force on the wall from the domain's current fields; [B, 2, NZ] per spanwise layer in 3-D.  One launch of
+    def forces(self, domain, viscosity: float, layer_height: float = 1.0, out: torch.Tensor = None) -> torch.Tensor:
+        """[B, 2] force on the wall from the domain's current fields; [B, 2, NZ] per spanwise layer in 3-D (``out``: a contiguous
+        float32 ``[B, 2, NZ]`` tensor to write into).  One launch of
         ``fg_mb_wall_forces`` on the domain's bound fields (the tensor form below -- :func:`compute_forces_2d`, pinned on the
         reference's own function in tests/test_env_math_golden.py -- costs ~40 launches per sim step and is what the kernel is
         tested against)."""
@@ -132,7 +133,7 @@ class WallRing:
                                 self.face_lengths]).contiguous()
             self._native = (self.cell_index.reshape(self.nz, -1).to(**i32).contiguous(),
                             self.slot_index.reshape(self.nz, -1).to(**i32).contiguous(), geom)
-        out = domain.wall_forces(*self._native, float(layer_height) if self.dims == 3 else 1.0, float(viscosity))   # [B, 2, NZ]
+        out = domain.wall_forces(*self._native, float(layer_height) if self.dims == 3 else 1.0, float(viscosity), out=out)   # [B, 2, NZ]
         return out if self.dims == 3 else out[:, :, 0]
 
     def forces_tensor_form(self, domain, viscosity: float, layer_height: float = 1.0) -> torch.Tensor:

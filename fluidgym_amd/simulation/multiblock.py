@@ -465,12 +465,15 @@ class MultiBlockDomain:
         return self.multilevel
 
     def wall_forces(self, cell_index: torch.Tensor, slot_index: torch.Tensor, geom: torch.Tensor, area_scale: float,
-                    viscosity: float) -> torch.Tensor:
+                    viscosity: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``[B, 2, layers]`` force on a closed wall from the current fields (``fg_mb_wall_forces``): ``cell_index`` /
         ``slot_index`` int32 ``[layers, n]`` in ring order, ``geom`` float32 ``[5, n]`` (normal x, y, tangential spacing, wall
         distance, face length).  Asynchronous on the current stream."""
         layers, n = cell_index.shape
-        out = torch.empty(self.batch, 2, layers, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(self.batch, 2, layers, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (self.batch, 2, layers) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("wall_forces: out must be a contiguous float32 [B, 2, layers] tensor on the domain's device")
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_wall_forces(self.handle, ctypes.c_void_p(cell_index.data_ptr()), ctypes.c_void_p(slot_index.data_ptr()),
                                            ctypes.c_void_p(geom.data_ptr()), int(n), int(layers), float(area_scale), float(viscosity),

@@ -50,14 +50,15 @@ def install():
         self.pressure.copy_(self.velocity[:, 0] * self.velocity[:, 1])
         return 1, True, (1, 1, 1)
 
-    def wall_forces(self, cell_index, slot_index, geom, area_scale, viscosity):
+    def wall_forces(self, cell_index, slot_index, geom, area_scale, viscosity, out=None):
         """The tensor form (the reference's arithmetic) on the CPU fields, in the kernel's argument and result layout."""
         from fluidgym_amd.envs.forces import compute_forces_2d
 
         ci, si = cell_index.long(), slot_index.long()                                   # [layers, n]
         u, ub, p = self.velocity[:, :2][:, :, ci], self.boundary_velocity[:, :2][:, :, si], self.pressure[:, ci]   # [B, 2, L, n], [B, L, n]
         f = compute_forces_2d(u.transpose(1, 2), ub.transpose(1, 2), p, geom[:2], geom[2], geom[3], geom[4] * area_scale, viscosity)
-        return f.transpose(1, 2).contiguous()                                           # [B, L, 2] -> [B, 2, L]
+        f = f.transpose(1, 2).contiguous()                                              # [B, L, 2] -> [B, 2, L]
+        return f if out is None else out.copy_(f)
 
     D.__init__ = __init__
     D.wall_forces = wall_forces
