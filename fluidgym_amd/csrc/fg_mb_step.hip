@@ -1544,6 +1544,8 @@ struct OcParams {
     const float* yp;         // [N] projection vector (PM == 2)
     int use_x0, project_mean, restart_every, check_every, max_iterations, stall_limit, accept_window;
     float accept_factor, tol;
+    fg_solve_info* info_host;   // pinned host mirrors of info[] and of the iterations run: written by the kernel itself, so the
+    int32_t* its_host;          // host needs one stream synchronisation after the launch and no device-to-host copies
 };
 
 // block sum of two values in fp64.  `red` is a ring of three slot pairs used in turn (`phase` advances per call): a wave that
@@ -1734,6 +1736,8 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         if (t == 0) {
             flag_st(q.flags + (sys), 3);
             q.info[sys].final_residual = 0.f; q.info[sys].used_iterations = -1; q.info[sys].converged = 1; q.info[sys].is_finite = 1;
+            o.info_host[sys] = q.info[sys];
+            o.its_host[sys] = 0;
         }
         return;
     }
@@ -2068,6 +2072,8 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         q.info[sys].converged = (outcome == 1 || outcome == 3) ? 1 : 0;
         q.info[sys].is_finite = outcome != 2 ? 1 : 0;
         q.best_it[sys] = it;   // total iterations run (profiling: the host sums them)
+        o.info_host[sys] = q.info[sys];
+        o.its_host[sys] = it;
     }
 }
 
@@ -2464,6 +2470,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     o.max_iterations = ((max_iterations + CG_CHUNK - 1) / CG_CHUNK) * CG_CHUNK;
     o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
     o.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; o.tol = tol;
+    o.info_host = s->info_pinned; o.its_host = s->flags_pinned;
     const bool ev = s->prof_on != 0;
     // Instances, chosen by measurement on the cylinder mesh (profiles/r02_onchip_variants.txt; 64 envs x 14 232 cells, us per
     // iteration): 16 cells per thread with the two-barrier reduction 11.7-11.8; the same with the one-barrier ring 14.5; 14
@@ -2488,9 +2495,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024, false, false, false);
     else OC_LAUNCH_PM(28, false, 1024, false, false, false);
 #undef OC_LAUNCH_PRE
-    FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
-    FG_HIP_CHECK(hipMemcpyAsync(s->flags_pinned, s->best_it, sizeof(int32_t) * nsys, hipMemcpyDeviceToHost, st));  // iterations run
-    FG_HIP_CHECK(hipStreamSynchronize(st));
+    FG_HIP_CHECK(hipStreamSynchronize(st));   // info_pinned / flags_pinned (iterations run) were written by the kernel
     if (ev) {
         float ms = 0.f;
         FG_HIP_CHECK(hipEventElapsedTime(&ms, s->prof_ev_oc[0], s->prof_ev_oc[1]));
