@@ -527,7 +527,7 @@ def main():
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
-    ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 16 leg (about 10 s)")
+    ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 64 leg (about 18 s)")
     ap.add_argument("--all-legs", action="store_true", help="also run the opt-in modes and the 256 / 64-env multi-block legs")
     ap.add_argument("--leg-budget", type=float, default=60.0, help="seconds after which no further extra leg is started")
     ap.add_argument("--forcing", type=float, default=2.0,
@@ -688,7 +688,9 @@ def main():
             doc="BASELINE config 3: turbulent channel 128x64x64, 8 envs")
         leg("cylinder_env", cylinder_env_leg, device, extra_modes=args.all_legs)
         if not args.no_airfoil_leg:
-            leg("airfoil_env", airfoil_env_leg, device)
+            # BASELINE config 4 ("batch=512 across 8 GPUs"): 64 envs are one GPU's share (rounds 1-3 quoted 16 envs: `airfoil_env_16`
+            # under --all-legs; the kernels are launch-latency-bound at 16 x 46.7 k cells, so the larger batch costs little more time)
+            leg("airfoil_env", airfoil_env_leg, device, num_envs=64, steps=1)
         if args.all_legs:
             # the same workload in the opt-in performance mode: pressure solves started from the previous pressure
             old = fluidgym_amd.set_solver_policy(pressure_warm_start=True, advection_warm_start=True)
@@ -697,8 +699,8 @@ def main():
             fluidgym_amd.set_solver_policy(**old)
             # one workgroup per env: 64 envs keep 64 of the 256 CUs busy during the pressure solves -- the same leg with every CU fed
             leg("cylinder_env_256", cylinder_env_leg, device, num_envs=256, steps=2, extra_modes=False)
-            leg("airfoil_env_64", airfoil_env_leg, device, num_envs=64, steps=1)
-            leg("airfoil_env_plain_mode", airfoil_env_leg, device, multilevel_trial=False)
+            leg("airfoil_env_16", airfoil_env_leg, device, num_envs=16, steps=2)
+            leg("airfoil_env_plain_mode", airfoil_env_leg, device, num_envs=16, multilevel_trial=False)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -8,7 +8,7 @@ import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEGS = ("quiescent_mode", "warm_start_mode", "rbc_env", "tcf_env", "cylinder_env", "cylinder_env_256", "airfoil_env",
-        "airfoil_env_64", "airfoil_env_multilevel_trial_mode")
+        "airfoil_env_16", "airfoil_env_multilevel_trial_mode")
 
 
 def _canned():
