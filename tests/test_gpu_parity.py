@@ -402,7 +402,7 @@ for b in range(2):
 print("OK")
 """
     env = dict(os.environ, FG_FORCE_ZMARCH=str(zc))
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)   # a fresh box pages torch in for minutes under load
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 

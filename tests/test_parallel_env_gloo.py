@@ -156,7 +156,7 @@ def test_two_rank_gloo_matches_single_process(mode):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -299,7 +299,7 @@ def test_real_env_with_stubbed_solver_sharded_over_two_ranks():
     procs = [ctx.Process(target=_stub_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in procs]
+    results = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -378,7 +378,7 @@ def test_multi_block_env_with_stubbed_solve_sharded_over_two_ranks():
     procs = [ctx.Process(target=_mb_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in procs]
+    results = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
