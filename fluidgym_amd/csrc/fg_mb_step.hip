@@ -3012,7 +3012,9 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
         }
         // ---- correctors (SIM.py:1777-1972)
         for (int c = 0; c < opt->corrector_steps; ++c) {
-            hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;
+            // P depends on A = diag(C) and the mesh only: the same matrix in every corrector of a step (the reference rebuilds it,
+            // SetupPressureMatrix inside the loop, PISOtorch_simulation.py:1790-1800, to the same values)
+            if (c == 0) { hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false; }
             for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
                 if (ps == 0) {
                     hipLaunchKernelGGL(k_mb_h<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->rA, s->Coff, s->velocity, s->ures,
