@@ -173,7 +173,7 @@ def roofline_from_profile(prof, solver):
             "launches": d["launches"], "avg_bytes_per_launch": d["avg_bytes_per_launch"],
             "kernels": rows,
             "note": "durations are the kernels' own dispatch timestamps (hipExtLaunchKernelGGL start/stop events on the "
-                    "solver's stream, every 8th launch of each kind inside the timed region). avg_launch_ms averages every "
+                    "solver's stream, every 32nd launch of each kind inside the timed region). avg_launch_ms averages every "
                     "sampled launch (what rocprofv3 --stats averages); achieved = bytes (flops) / time over the launches "
                     "that had live systems (avg_busy_launch_ms), counting only the systems still iterating. The working set of this "
                     "workload (64 envs x 32768 cells x ~20 fields = 170 MB) is Infinity-Cache resident, so cache-"

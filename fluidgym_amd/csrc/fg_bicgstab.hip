@@ -808,6 +808,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
                 next_poll = it + 1 + 2;
                 const int final_pass = (it + 1 == a.max_iterations);
                 hipLaunchKernelGGL(k_bicgf_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass);
+                fg_prof_prefetch(s, st);
                 FG_HIP_CHECK(hipStreamSynchronize(st));
                 info_fresh = true;
                 done = true;
@@ -835,6 +836,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
             const int final_pass = (it + 1 == a.max_iterations);
             hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass);
             // one read-back serves the poll and the result (nothing is launched after the last poll)
+            fg_prof_prefetch(s, st);
             FG_HIP_CHECK(hipStreamSynchronize(st));
             info_fresh = true;
             done = true;

@@ -428,6 +428,7 @@ enum FgProfKind {
 struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };
 struct FgProf {
     int on, used, period;
+    int prefetched;           // slots whose counts a poll already copied to the host (fg_prof_prefetch)
     hipEvent_t ev[2 * FG_PROF_POOL];
     FgProfMeta meta[FG_PROF_POOL];
     int32_t* active_dev;      // [FG_PROF_POOL] active systems of each sampled launch
@@ -662,6 +663,10 @@ int fg_zmarch_cg_ap(const fg_state* s, const fg_real* rA, const fg_real* z, cons
 int fg_prof_slot(const fg_state* s, int kind, const int32_t* flags, int nsys, double bytes_per_sys,
                  double flops_per_sys, hipStream_t st);
 int fg_prof_collect(fg_state* s, hipStream_t st);
+// Called right before a solver poll waits for the stream: the counts of the samples taken so far ride along with that wait, so
+// the collect that follows a poll which ends the solve needs neither a copy nor a second stream synchronisation (that second
+// round trip per solve was most of what live profiling cost the timed region: 2 700 -> 2 900 env-steps/s on the headline)
+void fg_prof_prefetch(fg_state* s, hipStream_t st);
 void fg_prof_destroy(fg_state* s);
 bool fg_fd_dct_supported(int n);
 int fg_fd_dct_forward(fg_state* s, const fg_real* r, fg_real* out, hipStream_t st, int batch = 0);   // batch 0: the env batch

@@ -492,6 +492,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             // The poll comes BEFORE the preconditioner of the next iteration: polls are scheduled where the previous solve
             // finished, so they usually end the solve, and three kernels of M^-1 that would find every env converged
             // cost more than the idle round trip of a poll that does not.
+            fg_prof_prefetch(s, st);
             FG_HIP_CHECK(hipStreamSynchronize(st));
             info_fresh = true;
             done = true;

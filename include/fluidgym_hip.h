@@ -291,7 +291,7 @@ int fg_poisson_fdcg(fg_handle h, const fg_real* rA, const fg_real* b, fg_real* x
                     int use_x0, fg_solve_info* info_host, void* stream);
 
 /* ---- live kernel timing for bench.py's roofline -----------------------------------------------
- * When enabled, every FG_PROF_PERIOD-th launch (default 8) of each solver kernel kind is issued with a
+ * When enabled, every FG_PROF_PERIOD-th launch (default 32) of each solver kernel kind is issued with a
  * start/stop event pair on the solve's stream (kernel-accurate timestamps), and the systems still
  * iterating in that launch are counted on the device.  Kinds are 0 .. fg_profile_kinds()-1, named by
  * fg_profile_kind_name (k_cg_ap, k_cg_update, k_bicg_p/v/s/t/x, k_gemm_f32, k_gemm_sk, k_tridiag_y).
