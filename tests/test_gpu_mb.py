@@ -459,6 +459,10 @@ def test_aggregate_owned_onchip_cg_is_the_cell_ordered_one(monkeypatch):
         u0 = dom.velocity.cpu().numpy().copy()
         for _ in range(3):
             dom.piso_step([0.01, 0.02, 0.0], pressure_tol=1e-7, advection_tol=1e-7, pressure_project_mean=True)   # env 2 inactive
+        # solves started from an iterate (the second non-orthogonal pass of a corrector, and the warm-start policy): the kernel's
+        # residual pass r = rhs - P x0 through the slot-ordered matrix
+        dom.piso_step([0.01, 0.02, 0.0], pressure_tol=1e-7, advection_tol=1e-7, pressure_project_mean=True, pressure_non_ortho_steps=2,
+                      pressure_warm_start=True)
         out[agg] = (u0, dom.velocity.cpu().numpy().copy(), dom.pressure.cpu().numpy().copy(), dom.solver_counters())
         dom.close()
     (u0_c, u_c, p_c, c_c), (u0_a, u_a, p_a, c_a) = out["0"], out["1"]
