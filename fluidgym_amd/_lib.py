@@ -237,9 +237,9 @@ SIGNATURES = {
     "fg_mb_get_cell_transforms": (c_int, [c_void_p, POINTER(c_float)]),
 }
 
-# ---- the fp64 build: the single-block entry points with fg_real = double.  Same names, every float of a signature (by value,
-# by pointer, inside the option structures) becomes a double; the fp32-only entry points keep their types (they answer
-# FG_ERR_UNSUPPORTED there) and the multi-block / resampling symbols are not part of that library.
+# ---- the fp64 build: the single-block AND (since round 3) the multi-block entry points with fg_real = double.  Same names, every
+# float of a signature (by value, by pointer, inside the option structures) becomes a double; the fp32-only entry points keep
+# their types (they answer FG_ERR_UNSUPPORTED there) and the resampling symbols are not part of that library.
 def _f64_struct(cls):
     fields = []
     for name, tp in cls._fields_:
@@ -256,9 +256,12 @@ def _f64_struct(cls):
 _F64_STRUCTS: dict = {}
 _F64_STRUCTS[FgStepOptions] = _f64_struct(FgStepOptions)
 _F64_STRUCTS[FgSimOptions] = _f64_struct(FgSimOptions)
+_F64_STRUCTS[FgMbStepOptions] = _f64_struct(FgMbStepOptions)
+_F64_STRUCTS[FgMbSimOptions] = _f64_struct(FgMbSimOptions)
 FgStepOptionsF64, FgSimOptionsF64 = _F64_STRUCTS[FgStepOptions], _F64_STRUCTS[FgSimOptions]
+FgMbStepOptionsF64, FgMbSimOptionsF64 = _F64_STRUCTS[FgMbStepOptions], _F64_STRUCTS[FgMbSimOptions]
 _F64_KEEP_FLOAT = ("fg_set_fd_preconditioner", "fg_set_fd_fast_transform", "fg_set_fd_helmholtz", "fg_coords_to_transforms", "fg_stream_triad")
-_F64_ABSENT_PREFIXES = ("fg_mb_", "fg_resampl", "fg_sparse_")
+_F64_ABSENT_PREFIXES = ("fg_resampl", "fg_sparse_")
 
 
 def _f64_type(tp):

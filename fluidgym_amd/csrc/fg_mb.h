@@ -16,6 +16,24 @@
 
 #include "fg_internal.h"
 
+// fp64 build (libfluidgym_hip_f64.so, -DFG_REAL_DOUBLE): the multi-block translation units are written in `float` throughout --
+// fields, tables, recurrence scalars, C ABI -- and every one of them becomes a double by renaming the keyword for these two files
+// (after every system header has been read; the public header declares the same entry points with fg_real).  What is written for
+// 32-bit words -- the four-cells-per-thread kernels (float4), the on-chip CG, the multilevel preconditioner -- stays compiled and is
+// switched off at run time in that build (fg_mb_create / fg_mb_finalize / fg_mb_set_multilevel); fg_f32 is a float in both builds.
+typedef float fg_f32;
+#ifdef FG_REAL_DOUBLE
+#define float double
+#define fabsf fabs
+#define fmaxf fmax
+#define fminf fmin
+#define sqrtf sqrt
+#define rsqrtf rsqrt
+#define FG_MB_F64 1
+#else
+#define FG_MB_F64 0
+#endif
+
 #define FG_MB_FIXED 0
 #define FG_MB_CONNECTED 1
 #define FG_MB_PERIODIC 2

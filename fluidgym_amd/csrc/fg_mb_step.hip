@@ -335,7 +335,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_maxvel(MbDev D, const float* __
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+#if FG_MB_F64
+        atomicMax(reinterpret_cast<unsigned long long*>(out) + b, (unsigned long long)__double_as_longlong(m));  // non-negative doubles order like their bits
+#else
         atomicMax(reinterpret_cast<int*>(out) + b, __float_as_int(m));  // non-negative floats order like ints
+#endif
     }
 }
 
@@ -2456,6 +2460,11 @@ bool mb_onchip_ok(const fg_mb_state* s, int pm_mode) {
 // the whole CG solve of every env in one launch (k_mbc_onchip); same arguments and results as mb_cg
 int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
                  int max_iterations, int use_x0, int pm_mode, float stall_accept, int* max_it, hipStream_t st) {
+#if FG_MB_F64
+    (void)dt; (void)diag; (void)off; (void)rhs; (void)x; (void)tol; (void)max_iterations; (void)use_x0; (void)pm_mode; (void)stall_accept; (void)max_it; (void)st;
+    fg_set_error("the on-chip CG is not part of the fp64 build");   // (never reached: fg_mb_create switches it off there)
+    return FG_ERR_UNSUPPORTED;
+#else
     const int nsys = s->B, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);
     q.best_x = s->w[4]; q.best_it = s->best_it;
@@ -2497,7 +2506,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
 #undef OC_LAUNCH_PRE
     FG_HIP_CHECK(hipStreamSynchronize(st));   // info_pinned / flags_pinned (iterations run) were written by the kernel
     if (ev) {
-        float ms = 0.f;
+        fg_f32 ms = 0.f;
         FG_HIP_CHECK(hipEventElapsedTime(&ms, s->prof_ev_oc[0], s->prof_ev_oc[1]));
         long long its = 0;
         for (int i = 0; i < nsys; ++i) its += s->flags_pinned[i] > 0 ? s->flags_pinned[i] : 0;
@@ -2509,6 +2518,7 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
         s->prof_its += its;
     }
     return mb_finish(s, nsys, nullptr, max_it);
+#endif
 }
 
 // project_mean: every residual is used with its mean removed.  For a symmetric matrix with the constant null space (an
@@ -2541,7 +2551,7 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
     int active_now = 0;  // systems still iterating, from the poll before this chunk (all active ones at chunk 0)
     auto prof_collect = [&]() -> int {
         for (int k = 0; k < s->prof_used; ++k) {
-            float ms = 0.f;
+            fg_f32 ms = 0.f;
             FG_HIP_CHECK(hipEventElapsedTime(&ms, s->prof_ev[2 * k], s->prof_ev[2 * k + 1]));
             const int kind = s->prof_kind[k];
             if (s->prof_active[k] > 0) {
@@ -2694,6 +2704,11 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_OC_AGG"); s->dbg_oc_agg = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_VARIANT"); s->oc_variant = e ? atoi(e) : 0;   // bit 0: no compiler fences in the stencil pass; bit 1: split [F][N] coefficient layout
     }
+#if FG_MB_F64
+    // the fp64 build runs the one-cell-per-thread kernels: the four-cell forms (float4), the on-chip CG and the multilevel
+    // preconditioner are written for 32-bit words (fg_mb.h)
+    s->dbg_vec_mask = 0; s->dbg_scalar_cg = 1; s->onchip_mode = 0; s->dbg_oc_agg = 0;
+#endif
     *out = s;
     return FG_OK;
 }
@@ -2849,7 +2864,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
             }
         if (int rc = mb_alloc(s, &s->nbr16, packed.size())) return rc;
         FG_HIP_CHECK(hipMemcpy(s->nbr16, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice));
-        if (d == 2 && N <= (size_t)28 * 1024)
+        if (d == 2 && N <= (size_t)28 * 1024 && !FG_MB_F64)
             if (int rc = mb_alloc(s, &s->Poff4, B * N * 4)) return rc;
     }
     s->env_status.assign(B, 0);
@@ -3098,6 +3113,7 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
                                     const int32_t* rect4_host, const float* d4g_host, const float* aci8_host, float geom_diag_sum,
                                     int32_t enable) {
     FG_REQUIRE(s && s->finalized && !s->host_only, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: domain not finalized (or host-only)");
+    FG_REQUIRE(!FG_MB_F64, FG_ERR_UNSUPPORTED, "fg_mb_set_multilevel: the multilevel preconditioner is not part of the fp64 build (plain recurrences there)");
     if (!a4_host) { s->ml_on = enable && s->ml_a4 != nullptr; return FG_OK; }   // switch only
     FG_REQUIRE(s->d == 2 && n4 > 0 && n4 < 65535 && n8 > 0 && n8 <= ML_N8_MAX && parent4_host && rect4_host && d4g_host && aci8_host &&
                    geom_diag_sum != 0.f,

@@ -171,16 +171,13 @@ class AirfoilEnvBase(CylinderEnvBase):
 
     # ---- domain and simulation (airfoil_env_base.py:216-311)
     def _get_domain(self):
-        if self._dtype != torch.float32:
-            raise NotImplementedError("dtype=torch.float64 is built for the single-block env families (channel, RBC, TCF: "
-                                      "libfluidgym_hip_f64.so); the multi-block kernels (cylinder, airfoil) are fp32 only")
         grow = 1.001 if (self._ndims == 3 and self._reynolds_number >= 5000) else 1.01      # airfoil_env_base.py:217-220
         self._mesh = self._mesh2d = make_airfoil_mesh(self.H, self.L, self.U_mean, self._attack_angle_deg, self._resolution_div,
                                                       grow, surface=self._surface)
         if self._ndims == 3:   # grid.py:601-617: res_z layers over z in [-H/2, H/2]
             self._mesh = extrude_mesh(self._mesh2d, self._res_z, -self.H / 2, self.H / 2)
         dom = build_domain(self._mesh, self._nu, batch=self._num_envs, device=self._cuda_device,
-                           non_ortho_flags=self._non_ortho_flags)
+                           non_ortho_flags=self._non_ortho_flags, dtype=self._dtype)   # float64: the fp64 build (plain recurrences)
         # the pressure system of this mesh has a residual floor (2-4e-5) far above the reference's tolerance (1e-7): every
         # solve ends on its best iterate after ``stall_limit`` iterations without improvement ("Airfoil")
         dom.set_stall_limit(self._stall_limit)
@@ -209,16 +206,16 @@ class AirfoilEnvBase(CylinderEnvBase):
             self._sensors = self._resampler.sensor_gather(self._sensor_locations.T)
         self._deflation_cos = dom.set_pressure_deflation() if self._pressure_deflation else 1.0
         self._initial_boundary = dom.boundary_velocity.clone()
-        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
+        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device, dtype=self._dtype)
         self._jet_locations_top = self._get_jet_locations()
-        self._top_base_profile = torch.as_tensor(self._get_base_jet_profiles(), device=dom.device)      # [2, nx_top]
+        self._top_base_profile = torch.as_tensor(self._get_base_jet_profiles(), device=dom.device).to(self._dtype)      # [2, nx_top]
         # outward flux of every boundary slot per unit velocity component: s_f det Minv[axis, :]
         _, face, T = dom.boundary_tables()
         d = dom.dims
         axis, sign = face >> 1, np.where(face & 1, 1.0, -1.0)
         Minv = T[:, : d * d].reshape(-1, d, d)
         w = sign[:, None] * T[:, d * d][:, None] * Minv[np.arange(len(face)), axis, :]
-        self._flux_w = torch.as_tensor(w.T.astype(np.float32), device=dom.device)                        # [d, NB]
+        self._flux_w = torch.as_tensor(w.T.astype(np.float32), device=dom.device).to(self._dtype)         # [d, NB]
         free = np.zeros(len(face), bool)
         for b, f in list(self._mesh.outflows) + [(TOP, "-y")]:
             blk = dom.blocks[b]
@@ -256,7 +253,7 @@ class AirfoilEnvBase(CylinderEnvBase):
                 self._sim.single_step()
             self._developed = dom.Clone()
         dom.Restore(self._developed)
-        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
+        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device, dtype=self._dtype)
 
     def _randomize_domain(self) -> None:
         """airfoil_env_base.py:327-332."""
@@ -432,8 +429,8 @@ class AirfoilEnv3D(AirfoilEnvBase):
     def _get_global_obs(self) -> Dict[str, torch.Tensor]:
         dom = self._domain
         B, nz, n = self._num_envs, self._n_sensors_z, self._sensor_locations.shape[-1]
-        u = self._sensors(dom.velocity)      # [B, 3, nz * n]
-        p = self._sensors(dom.pressure)
+        u = self._sensors(dom.velocity).to(self._dtype)      # [B, 3, nz * n]
+        p = self._sensors(dom.pressure).to(self._dtype)
         if self._local_2d_obs:
             u = u[:, :2]
         vd = u.shape[1]

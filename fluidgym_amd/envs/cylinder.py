@@ -124,16 +124,15 @@ class CylinderEnvBase(FluidEnv):
 
     # ---- domain and simulation (cylinder_env_base.py:233-329)
     def _get_domain(self) -> MultiBlockDomain:
-        if self._dtype != torch.float32:
-            raise NotImplementedError("dtype=torch.float64 is built for the single-block env families (channel, RBC, TCF: "
-                                      "libfluidgym_hip_f64.so); the multi-block kernels (cylinder, airfoil) are fp32 only")
         self._mesh = make_vortex_street_mesh(self._circle_resolution_angular, self.H, self.L, self.cylinder_diameter / 2,
                                              self.cylinder_offset_y, self.cylinder_diameter / 2, self.cylinder_diameter,
                                              self._vortex_street_refinement_base)
         if self._ndims == 3:   # grid.py:281-294: res_z = resolution, z in [-2, 2]
             self._mesh = extrude_mesh(self._mesh, self._circle_resolution_angular, -self.D / 2, self.D / 2)
+        # dtype=torch.float64: the fp64 build of the multi-block path (plain recurrences, one cell per thread; observations are
+        # resampled in float32 and handed back in the env's dtype)
         return build_domain(self._mesh, self._nu, batch=self._num_envs, device=self._cuda_device,
-                            non_ortho_flags=self._non_ortho_flags)
+                            non_ortho_flags=self._non_ortho_flags, dtype=self._dtype)
 
     def _get_simulation(self, domain, prep_fn):
         sim = MultiBlockSimulation(domain, dt=self._dt, adaptive_CFL=self._adaptive_cfl, substeps="ADAPTIVE", corrector_steps=2,
@@ -158,7 +157,7 @@ class CylinderEnvBase(FluidEnv):
         self._multilevel = dom.set_pressure_multilevel() if (get_solver_policy()["pressure_multilevel"] and not self._pressure_deflation
                                                               and not self._pressure_use_bicg) else None
         self._initial_boundary = dom.boundary_velocity.clone()  # inflow / outflow profile, walls at rest
-        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
+        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device, dtype=self._dtype)
 
     _n_controls = 1
 
@@ -176,7 +175,7 @@ class CylinderEnvBase(FluidEnv):
                 self._sim.single_step()
             self._developed = dom.Clone()
         dom.Restore(self._developed)
-        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device)
+        self._last_control = torch.zeros(self._num_envs, self._n_controls, device=dom.device, dtype=self._dtype)
 
     def _randomize_domain(self) -> None:
         """cylinder_env_base.py:364-404."""
@@ -193,8 +192,8 @@ class CylinderEnvBase(FluidEnv):
     # ---- observations, forces, step (cylinder_env_base.py:541-776)
     def _get_global_obs(self) -> Dict[str, torch.Tensor]:
         dom = self._domain
-        u = self._sensors(dom.velocity)   # [B, 2, S]
-        p = self._sensors(dom.pressure)      # [B, S]
+        u = self._sensors(dom.velocity).to(self._dtype)   # [B, 2, S]
+        p = self._sensors(dom.pressure).to(self._dtype)      # [B, S]
         return {"velocity": u.permute(0, 2, 1).contiguous(), "pressure": p}
 
     def get_velocity(self) -> torch.Tensor:
@@ -227,7 +226,7 @@ class CylinderEnvBase(FluidEnv):
         controls = torch.stack(controls).to(self._last_control.device, non_blocking=False)      # [n, B, n_controls]
         # raw wall forces of every sim step land in one buffer; normalised and averaged once (elementwise division, then the
         # mean over the stack: what torch.stack of the per-step coefficients gave)
-        raw = torch.empty(n, self._num_envs, 2, self._ring.nz, dtype=torch.float32, device=self._last_control.device)
+        raw = torch.empty(n, self._num_envs, 2, self._ring.nz, dtype=self._dtype, device=self._last_control.device)
         for k in range(n):
             self._last_control = controls[k]
             if self._enable_actions:
@@ -320,8 +319,8 @@ class CylinderJetEnv2D(CylinderEnvBase):
     def _additional_initialization(self) -> None:
         super()._additional_initialization()
         dev = self._domain.device
-        self._top_velocity = torch.as_tensor(self._jet_velocities(_face_vertices(self._mesh, TOP, "-y"), True), device=dev)
-        self._bottom_velocity = torch.as_tensor(self._jet_velocities(_face_vertices(self._mesh, BOTTOM, "+y"), False), device=dev)
+        self._top_velocity = torch.as_tensor(self._jet_velocities(_face_vertices(self._mesh, TOP, "-y"), True), device=dev).to(self._dtype)
+        self._bottom_velocity = torch.as_tensor(self._jet_velocities(_face_vertices(self._mesh, BOTTOM, "+y"), False), device=dev).to(self._dtype)
 
     def _apply_action(self, action: torch.Tensor) -> None:
         a = action.reshape(self._num_envs, 1, 1)
@@ -349,7 +348,7 @@ class CylinderRotEnv2D(CylinderEnvBase):
     def _additional_initialization(self) -> None:
         super()._additional_initialization()
         dev = self._domain.device
-        self._wall = [(b, face, torch.as_tensor(v, device=dev)) for b, face, v in rotating_wall_velocities(self._mesh)]
+        self._wall = [(b, face, torch.as_tensor(v, device=dev).to(self._dtype)) for b, face, v in rotating_wall_velocities(self._mesh)]
 
     def _apply_action(self, action: torch.Tensor) -> None:
         a = action.reshape(self._num_envs, 1, 1)
@@ -444,8 +443,8 @@ class CylinderJetEnv3D(CylinderJetEnv2D):
     def _get_global_obs(self) -> Dict[str, torch.Tensor]:
         dom = self._domain
         B, nz, n = self._num_envs, self._n_sensors_z, self._n_sensors_x_y
-        u = self._sensors(dom.velocity)       # [B, 3, nz * 151]
-        p = self._sensors(dom.pressure)          # [B, nz * 151]
+        u = self._sensors(dom.velocity).to(self._dtype)       # [B, 3, nz * 151]
+        p = self._sensors(dom.pressure).to(self._dtype)          # [B, nz * 151]
         if self._local_2d_obs:
             u = u[:, :2]
         vd = u.shape[1]

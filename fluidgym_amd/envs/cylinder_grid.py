@@ -191,12 +191,15 @@ def extrude_mesh(mesh: CylinderMesh, res_z: int, z0: float = -2.0, z1: float = 2
 
 
 def build_domain(mesh: CylinderMesh, viscosity: float, batch: int = 1, device=None, reference_quirks: bool = True,
-                 non_ortho_flags: int = 25):
-    """The mesh as a ``MultiBlockDomain`` on the GPU (``make_vortex_street_domain`` + ``PrepareSolve``)."""
+                 non_ortho_flags: int = 25, dtype=None):
+    """The mesh as a ``MultiBlockDomain`` on the GPU (``make_vortex_street_domain`` + ``PrepareSolve``); ``dtype``: torch.float32
+    (default) or torch.float64 (the fp64 build)."""
+    import torch
+
     from ..simulation.multiblock import MultiBlockDomain
 
     dom = MultiBlockDomain(mesh.dims, viscosity, batch=batch, device=device, reference_quirks=reference_quirks,
-                           non_ortho_flags=non_ortho_flags)
+                           non_ortho_flags=non_ortho_flags, dtype=dtype or torch.float32)
     blocks = [dom.CreateBlock(c, name=n) for c, n in zip(mesh.coords, mesh.names)]
     for (b, face), vel in mesh.fixed.items():
         blocks[b].CloseBoundary(face, vel)

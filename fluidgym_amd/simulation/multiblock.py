@@ -48,7 +48,7 @@ class MBBlock:
         f = face_index(face)
         if velocity is not None:
             self._pending_velocity[f] = np.asarray(
-                velocity.detach().cpu().numpy() if isinstance(velocity, torch.Tensor) else velocity, dtype=np.float32)
+                velocity.detach().cpu().numpy() if isinstance(velocity, torch.Tensor) else velocity, dtype=self.domain._np)
 
     def ConnectBlock(self, face, other: "MBBlock", other_face, axis1, axis2="-z"):
         lib = self.domain.lib
@@ -181,10 +181,10 @@ class MultiBlockDomain:
     """``PISOtorch.Domain`` for connected curvilinear blocks, batched over envs."""
 
     def __init__(self, dims: int, viscosity: float, batch: int = 1, device: Optional[torch.device] = None,
-                 reference_quirks: bool = True, non_ortho_flags: int = 25):
+                 reference_quirks: bool = True, non_ortho_flags: int = 25, dtype: torch.dtype = torch.float32):
         if not torch.cuda.is_available():
             raise L.NativeLibraryError("fluidgym_amd needs a GPU: the multi-block path has no CPU fallback")
-        self.lib = L.load()
+        self._set_dtype(dtype)
         self.dims, self.batch = int(dims), int(batch)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.viscosity = float(viscosity)
@@ -202,16 +202,30 @@ class MultiBlockDomain:
         self._dt = None
         self.multilevel = None   # aggregate counts once set_pressure_multilevel has installed the preconditioner
 
+    def _set_dtype(self, dtype: torch.dtype) -> None:
+        """float32: ``libfluidgym_hip.so``; float64: the fp64 build (``libfluidgym_hip_f64.so``), in which every float of the
+        multi-block C ABI is a double (csrc/fg_mb.h) -- the one-cell-per-thread kernels and the plain recurrences only: no
+        on-chip CG, no multilevel preconditioner there."""
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be torch.float32 or torch.float64")
+        f64 = dtype == torch.float64
+        self.dtype = dtype
+        self.lib = L.load_f64() if f64 else L.load()
+        self._np = np.float64 if f64 else np.float32
+        self._cf = ctypes.c_double if f64 else ctypes.c_float
+        self._step_opt_t = L.FgMbStepOptionsF64 if f64 else L.FgMbStepOptions
+        self._sim_opt_t = L.FgMbSimOptionsF64 if f64 else L.FgMbSimOptions
+
     def CreateBlock(self, vertexCoordinates, name: str = "") -> MBBlock:
         c = vertexCoordinates.detach().cpu().numpy() if isinstance(vertexCoordinates, torch.Tensor) else np.asarray(vertexCoordinates)
         if c.ndim == self.dims + 2:  # reference layout [1, d, ...]
             c = c[0]
-        c = np.ascontiguousarray(c, dtype=np.float32)
+        c = np.ascontiguousarray(c, dtype=self._np)
         if c.shape[0] != self.dims or c.ndim != self.dims + 1:
             raise ValueError("vertexCoordinates must be [d, (nz+1,) ny+1, nx+1]")
         size = [c.shape[-1 - a] - 1 for a in range(self.dims)] + [1] * (3 - self.dims)
         bid = ctypes.c_int32(-1)
-        L.check(self.lib.fg_mb_add_block(self.handle, c.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), size[0], size[1],
+        L.check(self.lib.fg_mb_add_block(self.handle, c.ctypes.data_as(ctypes.POINTER(self._cf)), size[0], size[1],
                                          size[2], ctypes.byref(bid)))
         blk = MBBlock(self, bid.value, c, name or f"block{bid.value}")
         self.blocks.append(blk)
@@ -230,7 +244,7 @@ class MultiBlockDomain:
             blk.cell_offset = off.value
             blk.boundary_slot0 = [slots[f] for f in range(2 * self.dims)]
         B, d = self.batch, self.dims
-        kw = dict(dtype=torch.float32, device=self.device)
+        kw = dict(dtype=self.dtype, device=self.device)
         self.velocity = torch.zeros(B, d, self.n_cells, **kw)
         self.pressure = torch.zeros(B, self.n_cells, **kw)
         self.boundary_velocity = torch.zeros(B, d, max(self.n_boundary_faces, 1), **kw)
@@ -254,7 +268,7 @@ class MultiBlockDomain:
                                     ctypes.c_void_p(src.data_ptr()) if src is not None else None))
 
     def set_velocity_source(self, source: Optional[torch.Tensor]):
-        self.velocity_source = None if source is None else source.to(self.device, torch.float32).contiguous()
+        self.velocity_source = None if source is None else source.to(self.device, self.dtype).contiguous()
         self._bind()
 
     def neighbors(self) -> np.ndarray:
@@ -272,8 +286,8 @@ class MultiBlockDomain:
         solver iterations (velocity, pressure corrector 0, pressure corrector 1)."""
         if not self.prepared:
             raise RuntimeError("PrepareSolve() first")
-        self._dt.copy_(torch.as_tensor(dt, dtype=torch.float32).expand(self.batch))
-        opt = L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
+        self._dt.copy_(torch.as_tensor(dt, dtype=self.dtype).expand(self.batch))
+        opt = self._step_opt_t(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
                                 advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
                                 int(pressure_project_mean), 0.0, int(solver_double_fallback), int(bicg_precondition_fallback))
         stats = (ctypes.c_int32 * 4)()
@@ -284,26 +298,26 @@ class MultiBlockDomain:
         return stats[1], stats[2], stats[3]
 
     def max_velocity(self) -> np.ndarray:
-        out = (ctypes.c_float * self.batch)()
+        out = (self._cf * self.batch)()
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_max_velocity(self.handle, out, ctypes.c_void_p(st)))
-        return np.array(out[:], dtype=np.float32)
+        return np.array(out[:], dtype=self._np)
 
     def buffer(self, which: int) -> torch.Tensor:
         """Copy of an intermediate buffer of the last step (tests)."""
         ptr, cnt = ctypes.c_void_p(), ctypes.c_int64()
         L.check(self.lib.fg_mb_get_buffer(self.handle, which, ctypes.byref(ptr), ctypes.byref(cnt)))
-        out = torch.empty(cnt.value, dtype=torch.float32, device=self.device)
+        out = torch.empty(cnt.value, dtype=self.dtype, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_read_buffer(self.handle, which, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st)))
         return out
 
     # ---- Simulation.single_step / make_divergence_free
     def boundary_flux_balance(self) -> np.ndarray:
-        out = (ctypes.c_float * self.batch)()
+        out = (self._cf * self.batch)()
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_boundary_flux_balance(self.handle, out, ctypes.c_void_p(st)))
-        return np.array(out[:], dtype=np.float32)
+        return np.array(out[:], dtype=self._np)
 
     def set_stall_limit(self, iterations: int) -> None:
         """Iterations a CG solve may go without improving its kept iterate before it ends with it (default 400)."""
@@ -318,22 +332,22 @@ class MultiBlockDomain:
         nb, tw = self.n_boundary_faces, self.dims * self.dims + 1
         cell = np.zeros(max(nb, 1), np.int32)
         face = np.zeros(max(nb, 1), np.int32)
-        T = np.zeros((max(nb, 1), tw), np.float32)
-        i32, f32 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)
+        T = np.zeros((max(nb, 1), tw), self._np)
+        i32, f32 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(self._cf)
         L.check(self.lib.fg_mb_get_boundary_tables(self.handle, cell.ctypes.data_as(i32), face.ctypes.data_as(i32),
                                                    T.ctypes.data_as(f32)))
         return cell[:nb], face[:nb], T[:nb]
 
     def cell_transforms(self) -> np.ndarray:
-        T = np.zeros((self.n_cells, self.dims * self.dims + 1), np.float32)
-        L.check(self.lib.fg_mb_get_cell_transforms(self.handle, T.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        T = np.zeros((self.n_cells, self.dims * self.dims + 1), self._np)
+        L.check(self.lib.fg_mb_get_cell_transforms(self.handle, T.ctypes.data_as(ctypes.POINTER(self._cf))))
         return T
 
     def _step_options(self, corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
                       pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start=False,
                       pressure_project_mean=False, pressure_stall_accept=0.0, solver_double_fallback=False,
                       bicg_precondition_fallback=False):
-        return L.FgMbStepOptions(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
+        return self._step_opt_t(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, max_iterations,
                                  advection_tol, pressure_tol, int(pressure_use_bicgstab), int(pressure_warm_start),
                                  int(pressure_project_mean), float(pressure_stall_accept), int(solver_double_fallback),
                                  int(bicg_precondition_fallback))
@@ -358,7 +372,7 @@ class MultiBlockDomain:
                                   tol: float = 5e-6):
         """``update_advective_boundaries`` + ``balance_boundary_fluxes`` for one face (the envs' PRE hook)."""
         (s0, n), (s1, n1) = self._outflow_ranges(outflow)
-        v = (ctypes.c_float * 3)(*(list(outflow_velocity) + [0.0] * 3)[:3])
+        v = (self._cf * 3)(*(list(outflow_velocity) + [0.0] * 3)[:3])
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_update_advective_boundary(self.handle, float(dt), s0, n, s1, n1, v, float(tol), ctypes.c_void_p(st)))
 
@@ -385,7 +399,7 @@ class MultiBlockDomain:
                     bicg_precondition_fallback: bool = False):
         """``Simulation.single_step`` on the native side.  ``outflow``: (block, face) of the FIXED face that follows the
         convective outflow condition.  Returns (substeps, all solves converged, max iterations of the last substep)."""
-        o = L.FgMbSimOptions()
+        o = self._sim_opt_t()
         o.step = self._step_options(corrector_steps, advect_non_ortho_steps, pressure_non_ortho_steps, advection_tol,
                                     pressure_tol, max_iterations, pressure_use_bicgstab, pressure_warm_start,
                                     pressure_project_mean, pressure_stall_accept, solver_double_fallback,
@@ -444,7 +458,7 @@ class MultiBlockDomain:
         BiCGStab of larger 2-D meshes (Airfoil2D: 46.7 k cells) takes it as a right preconditioner in kernel form (three launches
         per application, csrc/fg_mb_step.hip::mb_ml_apply), up to 2048 coarse aggregates.  Returns the aggregate counts, or None
         when the mesh does not qualify (3-D, or too many aggregates; nothing is installed)."""
-        if self.dims != 2:
+        if self.dims != 2 or self.dtype != torch.float32:   # (the fp64 build runs the plain recurrences)
             return None
         if not enable:
             L.check(self.lib.fg_mb_set_multilevel(self.handle, 0, 0, None, None, None, None, None, 0.0, 0))
@@ -471,9 +485,10 @@ class MultiBlockDomain:
         distance, face length).  Asynchronous on the current stream."""
         layers, n = cell_index.shape
         if out is None:
-            out = torch.empty(self.batch, 2, layers, dtype=torch.float32, device=self.device)
-        elif tuple(out.shape) != (self.batch, 2, layers) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
-            raise ValueError("wall_forces: out must be a contiguous float32 [B, 2, layers] tensor on the domain's device")
+            out = torch.empty(self.batch, 2, layers, dtype=self.dtype, device=self.device)
+        elif tuple(out.shape) != (self.batch, 2, layers) or out.dtype != self.dtype or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("wall_forces: out must be a contiguous [B, 2, layers] tensor of the domain's dtype on its device")
+        geom = geom if geom.dtype == self.dtype else geom.to(self.dtype)
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_wall_forces(self.handle, ctypes.c_void_p(cell_index.data_ptr()), ctypes.c_void_p(slot_index.data_ptr()),
                                            ctypes.c_void_p(geom.data_ptr()), int(n), int(layers), float(area_scale), float(viscosity),
@@ -489,7 +504,7 @@ class MultiBlockDomain:
 
     def multilevel_apply(self, r: torch.Tensor) -> torch.Tensor:
         """``z = M r`` [B, N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled."""
-        r = r.to(self.device, torch.float32).contiguous()
+        r = r.to(self.device, self.dtype).contiguous()
         z = torch.empty_like(r)
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fg_mb_multilevel_apply(self.handle, ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(st)))
@@ -517,8 +532,8 @@ class MultiBlockDomain:
         res = np.linalg.norm(P.T @ y) / max(abs(P).max(), 1e-30)
         if not np.isfinite(res) or res > 1e-3:
             y = np.ones(N) / np.sqrt(N)
-        y32 = np.ascontiguousarray(y, dtype=np.float32)
-        L.check(self.lib.fg_mb_set_residual_projection(self.handle, y32.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        y32 = np.ascontiguousarray(y, dtype=self._np)
+        L.check(self.lib.fg_mb_set_residual_projection(self.handle, y32.ctypes.data_as(ctypes.POINTER(self._cf))))
         return float(y.sum() / np.sqrt(N))
 
     def solver_counters(self, reset: bool = False) -> dict:

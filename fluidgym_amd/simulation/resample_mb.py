@@ -277,6 +277,8 @@ class SensorGather:
             return (field[..., self.idx] * self.w).sum(-1)
         lead = field.shape[:-1]
         flat = field.reshape(-1, field.shape[-1])
+        if flat.dtype != torch.float32:   # float64 domains: observations are resampled in float32 (the kernels' word size)
+            flat = flat.to(torch.float32)
         if not flat.is_contiguous():
             flat = flat.contiguous()
         S, K = self._idx32.shape
@@ -312,7 +314,7 @@ class MultiBlockResampler3D:
         """field [..., N] -> [..., oz, oy, ox]."""
         pl = self.plan
         lead = field.shape[:-1]
-        flat = field.reshape(-1, field.shape[-1])
+        flat = field.reshape(-1, field.shape[-1]).to(torch.float32)
         out = torch.zeros(flat.shape[0], pl.n_pixels + 1, dtype=torch.float32, device=self.device)
         out.index_add_(1, self._pix, flat[:, self._cell] * self._w)
         out[:, :-1] *= self._inv

@@ -377,7 +377,7 @@ int fg_resample(fg_resampler r, const float* src, int batch, int channels, float
 typedef struct fg_mb_state* fg_mb_handle;
 int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_handle* out);
 int fg_mb_destroy(fg_mb_handle h);
-int fg_mb_add_block(fg_mb_handle h, const float* vertex_coords_host, int32_t nx, int32_t ny, int32_t nz, int32_t* block_id);
+int fg_mb_add_block(fg_mb_handle h, const fg_real* vertex_coords_host, int32_t nx, int32_t ny, int32_t nz, int32_t* block_id);
 int fg_mb_connect(fg_mb_handle h, int32_t block1, int32_t face1, int32_t block2, int32_t face2, int32_t axis1, int32_t axis2);
 int fg_mb_make_periodic(fg_mb_handle h, int32_t block, int32_t axis);
 int fg_mb_set_reference_quirks(fg_mb_handle h, int32_t connected_diagonal_offset, int32_t first_layer_rule);
@@ -394,15 +394,15 @@ int fg_mb_get_neighbors(fg_mb_handle h, int32_t* out_host /* [2d*N]: neighbour c
  * out may be NULL to query the count).  A handle created with device < 0 is host-only: it builds and serves these tables
  * without touching a GPU (CPU parity tests of the topology code), every compute entry point refuses it. */
 int fg_mb_get_host_table(fg_mb_handle h, int32_t which, void* out, int64_t* count);
-int fg_mb_bind(fg_mb_handle h, float* velocity, float* pressure_result, float* boundary_velocity, const float* source);
-int fg_mb_set_viscosity(fg_mb_handle h, float nu);
+int fg_mb_bind(fg_mb_handle h, fg_real* velocity, fg_real* pressure_result, fg_real* boundary_velocity, const fg_real* source);
+int fg_mb_set_viscosity(fg_mb_handle h, fg_real nu);
 typedef struct fg_mb_step_options {
     int32_t corrector_steps;           /* 2 */
     int32_t advect_non_ortho_steps;    /* 1 (airfoil 2) */
     int32_t pressure_non_ortho_steps;  /* 1 (cylinder 3-D and airfoil 4) */
     int32_t max_iterations;            /* 5000 */
-    float advection_tol;               /* RMS residual */
-    float pressure_tol;
+    fg_real advection_tol;               /* RMS residual */
+    fg_real pressure_tol;
     int32_t pressure_use_bicgstab;     /* 0: CG as the reference (pressure_use_BiCG=False, simulation.py:136) -- with the
                                           cross-metric terms the pressure matrix is not symmetric, CG only works while the
                                           mesh is close to orthogonal; 1: BiCGStab (restarted every 200 iterations);
@@ -415,7 +415,7 @@ typedef struct fg_mb_step_options {
     int32_t pressure_project_mean;     /* 1: CG works on residuals with their mean removed -- identical on orthogonal meshes,
                                           and what keeps the solve from stalling on the constant residual component that the
                                           cross-metric terms feed (1^T P != 0); 0: the reference's plain recurrence */
-    float pressure_stall_accept;       /* > 1: a CG solve whose best iterate is within this factor of pressure_tol and has
+    fg_real pressure_stall_accept;       /* > 1: a CG solve whose best iterate is within this factor of pressure_tol and has
                                           not improved for 20 iterations ends with that iterate: the reference's
                                           pressure matrix has a near-null LEFT vector y that is not constant, so a
                                           flux-balanced right-hand side keeps a component (y.b) y no iteration can remove
@@ -434,7 +434,7 @@ typedef struct fg_mb_step_options {
  * {-, velocity, pressure corrector 0, pressure corrector 1}.  Returns FG_ERR_NOT_CONVERGED / FG_ERR_NOT_FINITE when a
  * solve failed (unconverged: fields updated from the best iterate, as with returnBestResult; non-finite: the envs concerned
  * are left as they were, see fg_mb_env_status), other negative codes on errors. */
-int fg_mb_piso_step(fg_mb_handle h, const float* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream);
+int fg_mb_piso_step(fg_mb_handle h, const fg_real* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream);
 /* Per-env outcome of the last fg_mb_piso_step / fg_mb_single_step, host array [B]: 0 ok; 1 a solve of the batch ended
  * unconverged (best iterate used, returnBestResult); 2 a solve of THIS env was non-finite -- its step was not committed
  * (velocity as before the step, like solve_ok=False before CopyVelocityResultToBlocks, PISOtorch_simulation.py:1752-1757,
@@ -462,37 +462,37 @@ int fg_mb_solver_unconverged(fg_mb_handle h, int64_t* out4_host);   /* as fg_sol
  * [4] substeps taken, [5] 1 if every solve converged; flux_host (optional, [B]) the boundary flux balance found. */
 typedef struct fg_mb_sim_options {
     fg_mb_step_options step;
-    float time_step;
-    float cfl;
+    fg_real time_step;
+    fg_real cfl;
     int32_t adaptive;          /* 1: substeps from the CFL condition; 0: `substeps` equal steps */
     int32_t substeps;
-    float flux_balance_tol;
+    fg_real flux_balance_tol;
     int32_t outflow_slot0;
     int32_t outflow_count;
-    float outflow_velm[3];     /* characteristic velocity of the convective condition */
-    float outflow_tol;         /* tol of update_advective_boundaries (balance threshold = 0.01 tol) */
+    fg_real outflow_velm[3];     /* characteristic velocity of the convective condition */
+    fg_real outflow_tol;         /* tol of update_advective_boundaries (balance threshold = 0.01 tol) */
     int32_t max_substeps;      /* safety bound, 0 = none */
     int32_t outflow_slot0_b;   /* a second outflow face (the airfoil mesh has two: airfoil/grid.py:708-714); count 0 = none */
     int32_t outflow_count_b;
 } fg_mb_sim_options;
-int fg_mb_single_step(fg_mb_handle h, const fg_mb_sim_options* opt, int32_t* out_host, float* flux_host, void* stream);
+int fg_mb_single_step(fg_mb_handle h, const fg_mb_sim_options* opt, int32_t* out_host, fg_real* flux_host, void* stream);
 /* the PRE hook alone, same dt for every env (make_divergence_free runs it with dt = 1, PISOtorch_simulation.py:1334-1345) */
-int fg_mb_update_advective_boundary(fg_mb_handle h, float dt, int32_t slot0, int32_t count, int32_t slot0_b, int32_t count_b,
-                                    const float* velm, float tol, void* stream);
+int fg_mb_update_advective_boundary(fg_mb_handle h, fg_real dt, int32_t slot0, int32_t count, int32_t slot0_b, int32_t count_b,
+                                    const fg_real* velm, fg_real tol, void* stream);
 /* Simulation.make_divergence_free (PISOtorch_simulation.py:1318-1429), without its PRE hook */
 int fg_mb_make_divergence_free(fg_mb_handle h, const fg_mb_step_options* opt, void* stream);
 /* Domain.GetBoundaryFluxBalance per env; synchronises */
-int fg_mb_boundary_flux_balance(fg_mb_handle h, float* out_B_host, void* stream);
+int fg_mb_boundary_flux_balance(fg_mb_handle h, fg_real* out_B_host, void* stream);
 /* host copies of the mesh tables: per boundary slot the owner cell, its face and Minv | det of the face
  * (k_CoordsToFaceTransforms, grid_gen.cu:398-470); per cell Minv | det (k_CoordsToTransforms, :298-354) */
-int fg_mb_get_boundary_tables(fg_mb_handle h, int32_t* cell, int32_t* face, float* transform);
-int fg_mb_get_cell_transforms(fg_mb_handle h, float* transform);
+int fg_mb_get_boundary_tables(fg_mb_handle h, int32_t* cell, int32_t* face, fg_real* transform);
+int fg_mb_get_cell_transforms(fg_mb_handle h, fg_real* transform);
 /* max |Minv u| over cells and boundary faces per env (Domain.getMaxVelocity(True, True)); synchronises */
-int fg_mb_max_velocity(fg_mb_handle h, float* out_B_host, void* stream);
+int fg_mb_max_velocity(fg_mb_handle h, fg_real* out_B_host, void* stream);
 /* pressure_project_mean keeps the CG residuals orthogonal to a unit vector: the constant by default, or y_host [N] (any scale).
  * fg_mb_unit_pressure_matrix leaves the pressure matrix for A = 1 in the P buffers so that a host routine can compute its left
  * near-null vector, the choice that removes the residual floor of non-orthogonal meshes */
-int fg_mb_set_residual_projection(fg_mb_handle h, const float* y_host);
+int fg_mb_set_residual_projection(fg_mb_handle h, const fg_real* y_host);
 /* Iterations a CG solve may go without improving its kept iterate before it ends with that iterate (default 400;
  * the reference has no such limit: its solves run to maxIterations and return the best result,
  * cg_solver_kernel.cu:345-361, PISOtorch_diff.py:266-371). */
@@ -510,17 +510,17 @@ int fg_mb_set_advection_start(fg_mb_handle h, int from_result);
  * (enable).  The reference's CG / BiCGStab run without one (cg_solver_kernel.cu; its ILU0 is the fallback rung only); converged
  * answers agree to the solver tolerance, iteration counts drop 3-9x. */
 int fg_mb_set_multilevel(fg_mb_handle h, int32_t n4, int32_t n8, const int32_t* a4_host, const int32_t* parent4_host,
-                         const int32_t* rect4_host /* [n4][4]: first cell, width, height, row stride */, const float* d4g_host,
-                         const float* aci8_host, float geom_diag_sum, int32_t enable);
+                         const int32_t* rect4_host /* [n4][4]: first cell, width, height, row stride */, const fg_real* d4g_host,
+                         const fg_real* aci8_host, fg_real geom_diag_sum, int32_t enable);
 /* Stress harness of the multi-block velocity BiCGStab: solves the d systems per env held in the assembly buffers (FG_MB_BUF_A,
  * _C_OFF, _RHS, e.g. loaded from a dumped failing step) `reps` times from zero; out4 = solves, solves with a non-finite system,
  * unconverged solves, max iterations; acc_out / sc_out receive the recurrence words (accumulators, alpha / omega) as the last solve
  * left them.  Debugging aid (profiles/bicg_stress.py), not on any step path. */
-int fg_mb_debug_bicgstab(fg_mb_handle h, float tol, int32_t max_iterations, int32_t reps, int64_t* out4,
-                         double* acc_out /* [B d][12] or NULL */, float* sc_out /* [B d][2] or NULL */, void* stream);
+int fg_mb_debug_bicgstab(fg_mb_handle h, fg_real tol, int32_t max_iterations, int32_t reps, int64_t* out4,
+                         double* acc_out /* [B d][12] or NULL */, fg_real* sc_out /* [B d][2] or NULL */, void* stream);
 /* z = M r [B,N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled (unit test of
  * the three kernels behind the preconditioned pressure BiCGStab; synchronises). */
-int fg_mb_multilevel_apply(fg_mb_handle h, const float* r_BN, float* z_BN, void* stream);
+int fg_mb_multilevel_apply(fg_mb_handle h, const fg_real* r_BN, fg_real* z_BN, void* stream);
 /* The multilevel right preconditioner of the pressure BiCGStab is a trial with exponential back-off per handle:
  * out3 = current back-off in solves (0: no tables; 4: every attempt converges; up to 256), attempts, failed attempts (each repeated
  * with the plain recurrence). */
@@ -530,8 +530,8 @@ int fg_mb_multilevel_status(fg_mb_handle h, int32_t* out3);
  * cell_index / slot_index [layers][n]: the wall-adjacent cell and the boundary slot of every wall face in ring order (device);
  * geom [5][n]: outward normal x, y, tangential spacing, wall distance, face length (device); out [B][2][layers] (device) =
  * sum over the ring of ((2 nu S - p I) n) * face length * area_scale.  Asynchronous on `stream`. */
-int fg_mb_wall_forces(fg_mb_handle h, const int32_t* cell_index, const int32_t* slot_index, const float* geom, int32_t n,
-                      int32_t layers, float area_scale, float viscosity, float* out, void* stream);
+int fg_mb_wall_forces(fg_mb_handle h, const int32_t* cell_index, const int32_t* slot_index, const fg_real* geom, int32_t n,
+                      int32_t layers, fg_real area_scale, fg_real viscosity, fg_real* out, void* stream);
 int fg_mb_unit_pressure_matrix(fg_mb_handle h, void* stream);
 /* live timing of the CG kernel pair (kind 0: stencil kernel k_mbc_ap, 1: update kernel k_mbc_update): every fourth chunk of
  * iterations has its first pair issued with start/stop events; sums over sampled launches with live systems, their
@@ -552,8 +552,8 @@ int fg_mb_profile_iterations(fg_mb_handle h, int64_t* iterations);
 #define FG_MB_BUF_P_OFF 6
 #define FG_MB_BUF_VELOCITY_RESULT 7
 #define FG_MB_BUF_KRYLOV0 8          /* 8..12: the five Krylov work vectors [B,d,N] as the last solve left them (debugging) */
-int fg_mb_get_buffer(fg_mb_handle h, int32_t which, const float** ptr, int64_t* count);
-int fg_mb_read_buffer(fg_mb_handle h, int32_t which, float* dst_device, void* stream); /* device copy, synchronises */
+int fg_mb_get_buffer(fg_mb_handle h, int32_t which, const fg_real** ptr, int64_t* count);
+int fg_mb_read_buffer(fg_mb_handle h, int32_t which, fg_real* dst_device, void* stream); /* device copy, synchronises */
 
 /* ---- grid metrics --------------------------------------------------------------------------- */
 /* CoordsToTransforms (grid_gen.cu:298-390): vertex coords [d,(nz+1,)ny+1,nx+1] ->

@@ -26,11 +26,15 @@ class Spec:
         d.finalize()
         return d
 
-    def native(self, batch=1, reference_quirks=True, non_ortho_flags=25):
+    def native(self, batch=1, reference_quirks=True, non_ortho_flags=25, dtype=None):
+        import torch
+
         from fluidgym_amd.simulation.multiblock import MultiBlockDomain
 
-        dom = MultiBlockDomain(self.dims, self.nu, batch=batch, reference_quirks=reference_quirks, non_ortho_flags=non_ortho_flags)
-        blks = [dom.CreateBlock(c.astype(np.float32)) for c in self.blocks]
+        dom = MultiBlockDomain(self.dims, self.nu, batch=batch, reference_quirks=reference_quirks, non_ortho_flags=non_ortho_flags,
+                               dtype=dtype or torch.float32)
+        # (fp64 build: the vertex coordinates as they are -- the oracle computes from the same doubles)
+        blks = [dom.CreateBlock(c.astype(np.float64 if dtype == torch.float64 else np.float32)) for c in self.blocks]
         for b, f, v in self.fixed:
             blks[b].CloseBoundary(f, v)
         for b, a in self.periodic:

@@ -25,7 +25,10 @@ def install():
     saved = {k: getattr(D, k) for k in ("__init__", "_bind", "single_step", "make_divergence_free", "set_pressure_multilevel",
                                           "set_advection_start", "env_status", "solver_hints", "solver_counters", "boundary_flux_balance", "wall_forces")}
 
-    def __init__(self, dims, viscosity, batch=1, device=None, reference_quirks=True, non_ortho_flags=25):
+    def __init__(self, dims, viscosity, batch=1, device=None, reference_quirks=True, non_ortho_flags=25, dtype=torch.float32):
+        assert dtype == torch.float32
+        self.dtype, self._np, self._cf = torch.float32, np.float32, ctypes.c_float
+        self._step_opt_t, self._sim_opt_t = L.FgMbStepOptions, L.FgMbSimOptions
         self.lib = L.load()
         self.dims, self.batch = int(dims), int(batch)
         self.device = torch.device("cpu")

@@ -34,14 +34,27 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_fp64_build_exports_the_single_block_entry_points_with_double_signatures():
-    """libfluidgym_hip_f64.so (fg_real = double, include/fluidgym_hip.h): every single-block symbol of the header, typed with
-    doubles where the fp32 library takes floats; the multi-block / resampling symbols are not part of it."""
+    """libfluidgym_hip_f64.so (fg_real = double, include/fluidgym_hip.h): every single-block and multi-block symbol of the header,
+    typed with doubles where the fp32 library takes floats; the resampling symbols are not part of it."""
     lib = L.load_f64()
-    declared = [n for n in _declared_symbols() if not n.startswith(("fg_mb_", "fg_resampl", "fg_sparse_"))]
+    declared = [n for n in _declared_symbols() if not n.startswith(("fg_resampl", "fg_sparse_"))]
     assert set(L.SIGNATURES_F64) == set(declared)
     for name in declared:
         assert hasattr(lib, name), name
-    assert not hasattr(lib, "fg_mb_create")
+    assert not hasattr(lib, "fg_resample")
+    assert L.SIGNATURES_F64["fg_mb_set_viscosity"][1][1] is ctypes.c_double
+    assert dict(L.FgMbSimOptionsF64._fields_)["cfl"] is ctypes.c_double
+    # a host-only handle of the fp64 build builds its tables from double coordinates
+    h2 = ctypes.c_void_p()
+    assert lib.fg_mb_create(2, 1, -1, ctypes.byref(h2)) == 0
+    c = np.stack(np.meshgrid(np.linspace(0, 1, 4), np.linspace(0, 1, 5), indexing="xy")).astype(np.float64)   # [2, ny+1, nx+1]
+    bid = ctypes.c_int32(-1)
+    assert lib.fg_mb_add_block(h2, np.ascontiguousarray(c).ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 3, 4, 1, ctypes.byref(bid)) == 0
+    assert lib.fg_mb_finalize(h2) == 0
+    T = np.zeros((12, 5), np.float64)
+    assert lib.fg_mb_get_cell_transforms(h2, T.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+    assert np.allclose(T[:, 4], (1 / 3) * (1 / 4), rtol=1e-14)     # det = cell area, to double precision
+    assert lib.fg_mb_destroy(h2) == 0
     assert lib.fg_abi_version() == 1
     assert L.SIGNATURES_F64["fg_set_viscosity"][1][1] is ctypes.c_double
     assert L.SIGNATURES_F64["fg_create"][1][1] is ctypes.POINTER(ctypes.c_double)
