@@ -132,9 +132,11 @@ def test_fp64_rbc_and_tcf_envs_run(env_id, kw):
     env.close()
 
 
-def test_fp64_is_refused_by_the_multi_block_envs():
+def test_fp64_reaches_the_multi_block_envs_too():
+    """(Round 3 refused the dtype there; the multi-block translation units are part of the fp64 build now: tests/test_gpu_mb_f64.py.)"""
     import fluidgym_amd
 
-    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=1, dtype=F64)
-    with pytest.raises(NotImplementedError, match="single-block"):
-        env.reset(seed=0)
+    env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=1, dtype=F64, initial_domain_steps=1, randomize_initial_state=False)
+    obs, _ = env.reset(seed=0)
+    assert env._domain.velocity.dtype == F64 and all(v.dtype == F64 for v in obs.values())
+    env.close()

@@ -64,6 +64,41 @@ def test_fp64_piso_step_matches_the_oracle(spec_fn, bicg):
     dom.close()
 
 
+@pytest.mark.parametrize("spec_fn", [H.cylinder_3d_small, H.airfoil_spec, H.twisted_ring])
+def test_fp64_assembly_on_the_reference_meshes(spec_fn):
+    """Advection matrix, right-hand side, pressure matrix, h and the pressure right-hand side (with its lagged corner terms) on the
+    extruded cylinder mesh and on the airfoil C-mesh (cells down to 1e-4 of the typical area at the nose), independent of how the
+    solves converge: fp32 leaves 2e-5 .. 2e-4 there (tests/test_gpu_mb.py), the fp64 build the rounding of a different summation order."""
+    from fluidgym_amd import _lib as L
+
+    spec = spec_fn()
+    d = spec.oracle()
+    B = 2
+    dom = spec.native(batch=B, dtype=torch.float64)
+    dt = [2e-3, 1e-3] if spec_fn is H.airfoil_spec else [0.05, 0.03]
+    states = [_state(d, 20 + b) for b in range(B)]
+    for b, (u, p) in enumerate(states):
+        dom.velocity[b] = torch.as_tensor(u, dtype=torch.float64)
+        dom.pressure[b] = torch.as_tensor(p, dtype=torch.float64)
+    dom.piso_step(dt, corrector_steps=1, advection_tol=1e-13, pressure_tol=1e-9, raise_on_failure=False, max_iterations=3000, pressure_use_bicgstab=True)
+    nd = d.d
+    buf = lambda k, *shape: dom.buffer(k).view(B, *shape).cpu().numpy()
+    A, Coff, rhs = buf(L.FG_MB_BUF_A, -1), buf(L.FG_MB_BUF_C_OFF, 2 * nd, -1), buf(L.FG_MB_BUF_RHS, nd, -1)
+    Pd, Po = buf(L.FG_MB_BUF_P_DIAG, -1), buf(L.FG_MB_BUF_P_OFF, 2 * nd, -1)
+    h, div = buf(L.FG_MB_BUF_H, nd, -1), buf(L.FG_MB_BUF_DIV, -1)
+    for b in range(B):
+        trace = {}
+        d.piso_step(states[b][0], states[b][1], dt[b], trace=trace, corrector_steps=1)
+        errs = {"A": _rel(A[b], trace["C"][0]), "Coff": _rel(Coff[b], trace["C"][1]), "rhs": _rel(rhs[b], trace["rhs"]),
+                "Pdiag": _rel(Pd[b], trace["P"][0]), "Poff": _rel(Po[b], trace["P"][1]), "h": _rel(h[b], trace["h"]),
+                "prhs": _rel(div[b], trace["prhs"])}
+        print(f"MB_F64_ASM {spec_fn.__name__} env {b}: " + " ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+        for k in ("A", "Coff", "rhs", "Pdiag", "Poff"):
+            assert errs[k] < 1e-11, (k, errs)
+        assert errs["h"] < 1e-8 and errs["prhs"] < 1e-7, errs      # behind the velocity solve (tolerance 1e-13 RMS)
+    dom.close()
+
+
 def test_fp64_domain_refuses_what_the_build_does_not_hold():
     spec = H.polar_ring()
     dom = spec.native(batch=1, dtype=torch.float64)
