@@ -7,7 +7,7 @@
 // after that).  Makhoul's mapping onto ONE n-point complex FFT per row:
 //     v_j = x_{2j},  v_{n-1-j} = x_{2j+1};   V = FFT_n(v);   X_k = s_k Re(e^{-i pi k / 2n} V_k)
 // and backwards  V_k = (Y_k - i Y_{n-k}) e^{+i pi k / 2n},  v = FFT^-1(V),  x_{2j} = v_j, x_{2j+1} = v_{n-1-j}.
-// One wave per row, four rows per workgroup, radix-4 (+ one radix-2) Stockham stages ping-ponging between two LDS buffers;
+// One wave per PAIR of rows (two real rows per complex transform), four waves per workgroup, radix-4 (+ one radix-2) Stockham stages ping-ponging between two LDS buffers;
 // twiddles come from a table built in double precision on the host (fg_set_fd_fast_transform), staged in LDS per workgroup.
 #include <math.h>
 
@@ -31,9 +31,16 @@ struct DctArgs {
 //   q_0 = 1/sqrt(n),  q_k = sqrt(2/n) cos(2 pi k i / n),  q_{n-k} = sqrt(2/n) sin(2 pi k i / n)  (0 < k < n/2),  q_{n/2} = (-1)^i / sqrt(n),
 // all / sqrt(h); mode m has the eigenvalue of k = min(m, n - m).  Forward: V = FFT_n(x), X_k = s_k Re V_k, X_{n-k} = -s_k Im V_k.
 // Inverse: W_0 = g_0 Y_0, W_{n/2} = g_0 Y_{n/2}, W_k = g/2 (Y_k - i Y_{n-k}), W_{n-k} = conj(W_k); x = Re FFT^-1_n(W) (unnormalised).
+// TWO rows per complex FFT: the rows are real, so rows a and b travel as z = a + i b through one transform and come apart by the
+// symmetry of a real sequence's spectrum, V^a_k = (Z_k + conj Z_{N-k}) / 2, V^b_k = (Z_k - conj Z_{N-k}) / 2i; backwards the
+// two Hermitian spectra are added as W^a + i W^b and the rows are the real and imaginary part of the result.  Half the butterflies,
+// LDS traffic and wave barriers per row of the one-row-per-transform form of rounds 1-3 (identities checked in NumPy for all four
+// modes).  Measured: it leaves the kernel's duration where it was (RBC 512-point rows: 10-11.6 us, half the workgroups) -- a build
+// without the butterflies (-DFG_DCT_KNOCK) still takes 7 of the 9 us of the 256-point kernel: load, staging barrier, store and
+// launch are the floor at these sizes, not the transform.
 template <int N, bool INVERSE, bool PERIODIC = false>
 __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
-    constexpr int EPL = N / 64;             // elements per lane
+    constexpr int EPL = N / 64;             // elements per lane and row
     __shared__ float2 buf[2][4][N];
     __shared__ float2 twl[N];                // W^k = (cos, sin)(2 pi k / N), k < N
     __shared__ float red[4];
@@ -41,48 +48,50 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     if (a.flags && a.flags[b] != 0) return;
     for (int k = threadIdx.x; k < N; k += 256) twl[k] = a.tw[k];   // visible after the barrier that follows the row staging
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    const bool live = row < a.rows;
-    const size_t off = (size_t)b * a.env_stride + (size_t)(live ? row : 0) * N + lane * EPL;
+    const int row0 = 2 * (blockIdx.x * 4 + wave), row1 = row0 + 1;
+    const bool live0 = row0 < a.rows, live1 = row1 < a.rows;
+    const size_t off0 = (size_t)b * a.env_stride + (size_t)(live0 ? row0 : 0) * N + lane * EPL;
+    const size_t off1 = (size_t)b * a.env_stride + (size_t)(live1 ? row1 : 0) * N + lane * EPL;
     float2* x = buf[0][wave];
     float2* y = buf[1][wave];
-    float xin[EPL];
+    float xa[EPL], xb[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) xin[e] = a.src[off + e];
+    for (int e = 0; e < EPL; ++e) { xa[e] = live0 ? a.src[off0 + e] : 0.f; xb[e] = live1 ? a.src[off1 + e] : 0.f; }
     if (!INVERSE) {
-        // v_j = x_2j, v_{n-1-j} = x_{2j+1}  (periodic: v = x)
+        // v_j = x_2j, v_{n-1-j} = x_{2j+1}  (periodic: v = x); row a in the real, row b in the imaginary part
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = lane * EPL + e;
             const int j = PERIODIC ? i : ((i & 1) ? N - 1 - (i >> 1) : (i >> 1));
-            x[j] = make_float2(xin[e], 0.f);
-        }
-    } else if (PERIODIC) {
-        float* stage = reinterpret_cast<float*>(y);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) stage[lane * EPL + e] = xin[e];
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int k = lane * EPL + e;
-            const float yk = stage[k], ym = stage[(N - k) & (N - 1)];
-            if (k == 0 || k == N / 2) x[k] = make_float2(a.scale0 * yk, 0.f);
-            else if (k < N / 2) x[k] = make_float2(0.5f * a.scale * yk, -0.5f * a.scale * ym);
-            else x[k] = make_float2(0.5f * a.scale * ym, 0.5f * a.scale * yk);
+            x[j] = make_float2(xa[e], xb[e]);
         }
     } else {
-        // stage the row so that Y_{n-k} is reachable, then V_k = g_k (Y_k - i Y_{n-k}) e^{+i theta_k},  Y_n := 0
-        float* stage = reinterpret_cast<float*>(y);
+        // stage both rows so that Y_{n-k} is reachable (the second buffer holds 2 N floats), then Z_k = W^a_k + i W^b_k with
+        //   cosine basis:  W_k = g_k (Y_k - i Y_{n-k}) e^{+i theta_k},  Y_n := 0
+        //   Fourier basis: W_0 = g_0 Y_0, W_{n/2} = g_0 Y_{n/2}, W_k = g/2 (Y_k - i Y_{n-k}), W_{n-k} = conj W_k
+        float* sa = reinterpret_cast<float*>(y);
+        float* sb = sa + N;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) stage[lane * EPL + e] = xin[e];
+        for (int e = 0; e < EPL; ++e) { sa[lane * EPL + e] = xa[e]; sb[lane * EPL + e] = xb[e]; }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int k = lane * EPL + e;
-            const float yk = stage[k], ym = (k == 0) ? 0.f : stage[N - k];
-            const float2 r = a.rot[k];
-            const float g = (k == 0) ? a.scale0 : a.scale;
-            x[k] = make_float2(g * (yk * r.x + ym * r.y), g * (yk * r.y - ym * r.x));
+            float2 wa, wb;
+            if (PERIODIC) {
+                const int km = (N - k) & (N - 1);
+                const float ya = sa[k], yam = sa[km], yb = sb[k], ybm = sb[km];
+                if (k == 0 || k == N / 2) { wa = make_float2(a.scale0 * ya, 0.f); wb = make_float2(a.scale0 * yb, 0.f); }
+                else if (k < N / 2) { wa = make_float2(0.5f * a.scale * ya, -0.5f * a.scale * yam); wb = make_float2(0.5f * a.scale * yb, -0.5f * a.scale * ybm); }
+                else { wa = make_float2(0.5f * a.scale * yam, 0.5f * a.scale * ya); wb = make_float2(0.5f * a.scale * ybm, 0.5f * a.scale * yb); }
+            } else {
+                const float ya = sa[k], yam = (k == 0) ? 0.f : sa[N - k], yb = sb[k], ybm = (k == 0) ? 0.f : sb[N - k];
+                const float2 r = a.rot[k];
+                const float g = (k == 0) ? a.scale0 : a.scale;
+                wa = make_float2(g * (ya * r.x + yam * r.y), g * (ya * r.y - yam * r.x));
+                wb = make_float2(g * (yb * r.x + ybm * r.y), g * (yb * r.y - ybm * r.x));
+            }
+            x[k] = make_float2(wa.x - wb.y, wa.y + wb.x);
         }
     }
     __syncthreads();
@@ -105,6 +114,9 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     int rem = N;
 #pragma unroll
     for (int st = 0; st < 5; ++st) {
+#ifdef FG_DCT_KNOCK
+        break;   // timing floor of the kernel without its butterflies (profiling build only)
+#endif
         if (rem % 4 != 0) break;
         const int sm = (1 << sft) - 1;
         for (int t = lane; t < N / 4; t += 64) {
@@ -138,35 +150,49 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
         wave_sync();
         float2* tmp = x; x = y; y = tmp;
     }
-    float out[EPL];
-    if (!INVERSE && PERIODIC) {
+    float oa[EPL], ob[EPL];
+    if (!INVERSE) {
+        // split the spectrum of z = a + i b:  V^a = (Z_k + conj Z_{n-k}) / 2,  V^b = (Z_k - conj Z_{n-k}) / 2i
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int m = lane * EPL + e;
-            const float2 V = x[m <= N / 2 ? m : N - m];
-            out[e] = (m == 0 || m == N / 2) ? a.scale0 * V.x : (m < N / 2 ? a.scale * V.x : -a.scale * V.y);
-        }
-    } else if (!INVERSE) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int k = lane * EPL + e;
-            const float2 r = a.rot[k], V = x[k];
-            out[e] = ((k == 0) ? a.scale0 : a.scale) * (r.x * V.x + r.y * V.y);   // Re(e^{-i theta} V)
+            const int k = PERIODIC ? (m <= N / 2 ? m : N - m) : m;
+            const float2 Z = x[k], M = x[(N - k) & (N - 1)];
+            const float2 Va = make_float2(0.5f * (Z.x + M.x), 0.5f * (Z.y - M.y));
+            const float2 Vb = make_float2(0.5f * (Z.y + M.y), -0.5f * (Z.x - M.x));
+            if (PERIODIC) {   // X_k = s_k Re V_k, X_{n-k} = -s_k Im V_k
+                oa[e] = (m == 0 || m == N / 2) ? a.scale0 * Va.x : (m < N / 2 ? a.scale * Va.x : -a.scale * Va.y);
+                ob[e] = (m == 0 || m == N / 2) ? a.scale0 * Vb.x : (m < N / 2 ? a.scale * Vb.x : -a.scale * Vb.y);
+            } else {          // X_k = s_k Re(e^{-i theta_k} V_k)
+                const float2 r = a.rot[k];
+                const float g = (k == 0) ? a.scale0 : a.scale;
+                oa[e] = g * (r.x * Va.x + r.y * Va.y);
+                ob[e] = g * (r.x * Vb.x + r.y * Vb.y);
+            }
         }
     } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = lane * EPL + e;
-            out[e] = x[PERIODIC ? i : ((i & 1) ? N - 1 - (i >> 1) : (i >> 1))].x;
+            const float2 v = x[PERIODIC ? i : ((i & 1) ? N - 1 - (i >> 1) : (i >> 1))];
+            oa[e] = v.x; ob[e] = v.y;
         }
     }
     float dot = 0.f;
-    if (live) {
+    if (live0) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) a.dst[off + e] = out[e];
+        for (int e = 0; e < EPL; ++e) a.dst[off0 + e] = oa[e];
         if (INVERSE && a.dot_with) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) dot += out[e] * a.dot_with[off + e];
+            for (int e = 0; e < EPL; ++e) dot += oa[e] * a.dot_with[off0 + e];
+        }
+    }
+    if (live1) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) a.dst[off1 + e] = ob[e];
+        if (INVERSE && a.dot_with) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dot += ob[e] * a.dot_with[off1 + e];
         }
     }
     if (INVERSE && a.dot_with) {
@@ -179,7 +205,7 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
 
 template <bool INVERSE, bool PERIODIC>
 int launch_dct_mode(const fg_state* s, int n, const DctArgs& a, int slot, int batch, hipStream_t st) {
-    const dim3 grid((a.rows + 3) / 4, batch);
+    const dim3 grid(((a.rows + 1) / 2 + 3) / 4, batch);   // a wave takes a PAIR of rows, four waves per workgroup
     switch (n) {
         case 64: FG_LAUNCH_P(s, slot, (k_dct_rows<64, INVERSE, PERIODIC>), grid, dim3(256), 0, st, a); break;
         case 128: FG_LAUNCH_P(s, slot, (k_dct_rows<128, INVERSE, PERIODIC>), grid, dim3(256), 0, st, a); break;
