@@ -111,7 +111,8 @@ def load_domain(path: str, dtype=None, device=None, with_scalar: bool = True, ba
     dd, arrays = read_domain_file(path)
     data = [torch.from_numpy(a).to(torch.float32) for a in arrays]
     if dtype not in (None, torch.float32):
-        raise NotImplementedError("the HIP kernels are instantiated for fp32 fields only; dtype=torch.float64 is not built")
+        raise NotImplementedError("load_domain builds fp32 single-block domains; for float64 construct Domain(dtype=torch.float64) "
+                                  "and copy the loaded fields in")
     get = lambda d, name: data[int(d[name])] if name in d else None
 
     if len(dd["blocks"]) != 1:
@@ -167,9 +168,11 @@ def save_multiblock_domain(domain, path: str, env: int = 0, name: str = "Domain"
     """``save_domain`` for env ``env`` of a prepared :class:`~fluidgym_amd.simulation.multiblock.MultiBlockDomain`."""
     data = []
 
+    real = getattr(domain, "dtype", torch.float32)      # float64 domains are stored as float64 (the reference stores the tensors' dtype)
+
     def add(t, d: dict, key: str):
         d[key] = str(len(data))
-        data.append(torch.as_tensor(t).detach().cpu().contiguous().to(torch.float32))
+        data.append(torch.as_tensor(t).detach().cpu().contiguous().to(real))
 
     dims = domain.dims
     dd = {"name": name, "spatialDims": dims}
@@ -194,25 +197,29 @@ def save_multiblock_domain(domain, path: str, env: int = 0, name: str = "Domain"
                 add(blk.boundary(f)[env: env + 1].reshape(shape), e, "velocity")
             bd["boundaries"].append(e)
         dd["blocks"].append(bd)
-    dd["data_info"] = {str(i): {"shape": list(t.shape), "dtype": "float32", "device": "cpu"} for i, t in enumerate(data)}
+    dd["data_info"] = {str(i): {"shape": list(t.shape), "dtype": "float64" if real == torch.float64 else "float32", "device": "cpu"}
+                       for i, t in enumerate(data)}
     np.savez_compressed(path + ".npz", **{str(i): t.numpy() for i, t in enumerate(data)})
     with open(path + ".json", "w") as fh:
         json.dump(dd, fh)
 
 
-def load_multiblock_domain(path: str, device=None, batch: int = 1, reference_quirks: bool = True):
+def load_multiblock_domain(path: str, device=None, batch: int = 1, reference_quirks: bool = True, dtype=None):
     """``load_domain`` for a domain with CONNECTED boundaries: builds and prepares a ``MultiBlockDomain`` holding the stored
-    state replicated over ``batch`` envs."""
+    state replicated over ``batch`` envs.  ``dtype``: torch.float32 / torch.float64; None = the dtype the file was written in."""
     from .multiblock import MultiBlockDomain
 
     dd, arrays = read_domain_file(path)
-    data = [np.asarray(a, dtype=np.float32) for a in arrays]
+    if dtype is None:
+        dtype = torch.float64 if all(np.asarray(a).dtype == np.float64 for a in arrays) else torch.float32
+    npt = np.float64 if dtype == torch.float64 else np.float32
+    data = [np.asarray(a, dtype=npt) for a in arrays]
     get = lambda d, key: data[int(d[key])] if key in d else None
     dims = int(dd["spatialDims"])
     if dd.get("passiveScalarChannels", 0):
         raise NotImplementedError("passive scalars on multi-block domains are not built")
     nu = float(np.asarray(get(dd, "viscosity")).reshape(-1)[0])
-    dom = MultiBlockDomain(dims, nu, batch=batch, device=device, reference_quirks=reference_quirks)
+    dom = MultiBlockDomain(dims, nu, batch=batch, device=device, reference_quirks=reference_quirks, dtype=dtype)
     blocks = []
     for bd in dd["blocks"]:
         if "vertexCoordinates" not in bd:

@@ -130,3 +130,36 @@ def test_fp64_multi_block_envs_step(env_id):
     # different Krylov trajectories (preconditioned on-chip CG / refined BiCGStab against the plain recurrences) to the envs'
     # absolute tolerances, right after an impulsive start
     assert dv < 5e-2 and dd < 5e-2
+
+
+def test_fp64_env_state_replays_bit_for_bit_and_files_keep_the_dtype(tmp_path, monkeypatch):
+    """``get_state -> set_state -> step`` on a float64 multi-block env is bit-identical (order-independent reductions there too), and an
+    initial domain written by a float64 env is stored as float64 and comes back exactly."""
+    import json
+
+    import fluidgym_amd
+    from fluidgym_amd.envs.fluid_env import EnvMode
+
+    monkeypatch.setenv("FLUIDGYM_DATA_PATH", str(tmp_path))
+    kw = dict(num_envs=2, dtype=torch.float64, initial_domain_steps=2, randomize_initial_state=False, resolution=8)
+    env = fluidgym_amd.make("CylinderJet2D-easy-v0", **kw)
+    env.reset(seed=1)
+    a = torch.tensor([[0.6], [-0.4]], device="cuda", dtype=torch.float64)
+    env.step(a)
+    s0 = env.get_state()
+    r1 = env.step(a)
+    u1 = env._domain.velocity.clone()
+    env.set_state(s0)
+    r2 = env.step(a)
+    assert torch.equal(u1, env._domain.velocity) and torch.equal(r1[1], r2[1]) and torch.equal(r1[0]["velocity"], r2[0]["velocity"])
+    env._save_initial_domain(EnvMode.TRAIN, 0, env=1)
+    base = tmp_path / "initial_domains" / env.initial_domain_id / "0" / "train"
+    dd = json.load(open(str(base) + ".json"))
+    assert {v["dtype"] for v in dd["data_info"].values()} == {"float64"}
+    want = env._domain.Clone()
+    env2 = fluidgym_amd.make("CylinderJet2D-easy-v0", **kw)
+    env2.load_initial_domain(0, EnvMode.TRAIN)
+    env2.reset(seed=0, randomize=False)
+    for b in range(2):
+        assert torch.equal(env2._domain.velocity[b], want["velocity"][1]) and torch.equal(env2._domain.pressure[b], want["pressure"][1])
+    env.close(); env2.close()
