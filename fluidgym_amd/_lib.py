@@ -218,6 +218,7 @@ SIGNATURES = {
     "fg_solver_unconverged": (c_int, [c_void_p, POINTER(c_int64)]),
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_set_advection_preconditioner": (c_int, [c_void_p, c_int]),
+    "fg_debug_apply_preconditioner": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fg_set_fd_helmholtz": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_advection_retries": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),

@@ -109,7 +109,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(fg_real) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
-    s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr;
+    s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr; s->ilu_d = nullptr;
     s->fd_lam = nullptr; s->helm_diag = s->helm_lower = s->helm_upper = s->helm_tmp = nullptr;
     { const char* ev = getenv("FG_CG_WGS_PER_SLOT"); s->cg_wgs_per_slot = (ev && atoi(ev) > 0) ? atoi(ev) : 256; }
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
@@ -140,7 +140,7 @@ extern "C" int fg_destroy(fg_handle s) {
     for (float* p : fd) if (p) (void)hipFree(p);
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc);
-    (void)hipFree(s->line_inv); (void)hipFree(s->line_cp);
+    (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
     (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
@@ -219,11 +219,29 @@ extern "C" int fg_set_advection_start(fg_handle s, int from_result) {
 
 extern "C" int fg_set_advection_preconditioner(fg_handle s, int mode) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
-    FG_REQUIRE(mode >= 0 && mode <= 3, FG_ERR_INVALID_ARG, "fg_set_advection_preconditioner: mode must be 0 (off), 1 (line, always), 2 (line, fallback) or 3 (Helmholtz, always)");
+    FG_REQUIRE(mode >= 0 && mode <= 5, FG_ERR_INVALID_ARG, "fg_set_advection_preconditioner: mode must be 0 (off), 1 (line, always), 2 (line, fallback), 3 (Helmholtz, always), 4 (ILU(0), always) or 5 (ILU(0), fallback)");
     FG_REQUIRE(mode != 3 || s->fd_lam != nullptr, FG_ERR_INVALID_ARG, "fg_set_advection_preconditioner: mode 3 needs fg_set_fd_helmholtz");
-    if (mode != 0)
+    if (mode >= 4) { if (int rc = fg_ilu_alloc(s)) return rc; }
+    else if (mode != 0)
         if (int rc = fg_line_alloc(s)) return rc;
     s->adv_precond = mode;
+    return FG_OK;
+}
+extern "C" int fg_debug_apply_preconditioner(fg_handle s, int mode, int nc, const fg_real* r, fg_real* z, void* stream) {
+    FG_REQUIRE(s && r && z && nc >= 1 && nc <= s->grid.dims && (mode == 1 || mode == 4), FG_ERR_INVALID_ARG,
+               "fg_debug_apply_preconditioner: mode 1 (y-line) or 4 (ILU(0)), 1 <= nc <= dims");
+    hipStream_t st = (hipStream_t)stream;
+    FG_HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int32_t) * (size_t)s->grid.B * s->grid.dims, st));
+    if (mode == 4) {
+        if (int rc = fg_ilu_alloc(s)) return rc;
+        if (int rc = fg_ilu_factor(s, s->A, s->Coff, st)) return rc;
+        if (int rc = fg_ilu_apply(s, s->A, s->Coff, nc, r, z, st)) return rc;
+    } else {
+        if (int rc = fg_line_alloc(s)) return rc;
+        if (int rc = fg_line_factor(s, s->A, s->Coff, nc, st)) return rc;
+        if (int rc = fg_line_apply(s, s->A, s->Coff, nc, r, z, st)) return rc;
+    }
+    FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }
 extern "C" int fg_advection_retries(fg_handle s, int64_t* out, int32_t reset) {
@@ -402,16 +420,16 @@ static int max_iters(const fg_solve_info* info, int n) {
 // (preconditionBiCG), mode 2 repeats a solve that ended unconverged or non-finite from zero WITH the preconditioner
 // (BiCG_precondition_fallback) -- the reference's preconditioner is cuSPARSE ILU(0), here the y-line solve of fg_linepre.hip.
 static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st, int for_scalar, int channel) {
-    a.precond = (s->adv_precond == 1) ? 1 : (s->adv_precond == 3 ? 2 : 0);
+    a.precond = (s->adv_precond == 1) ? 1 : (s->adv_precond == 3 ? 2 : (s->adv_precond == 4 ? 3 : 0));
     if (a.precond == 2) {   // Helmholtz (fast-diagonalisation) preconditioner: the diffusivity and wall treatment of THIS solve
         a.nu = for_scalar ? (s->scalar_viscosity_set ? s->scalar_viscosity[channel] : s->viscosity) : s->viscosity;
         a.wall_lo = for_scalar ? (s->cfg.scalar_bc[2][channel] == FG_DIRICHLET) : 1;
         a.wall_hi = for_scalar ? (s->cfg.scalar_bc[3][channel] == FG_DIRICHLET) : 1;
     }
     int rc = fg_bicgstab_solve(s, a, info, st);
-    if ((rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) && s->adv_precond == 2) {
+    if ((rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) && (s->adv_precond == 2 || s->adv_precond == 5)) {
         s->line_retries += 1;
-        a.precond = 1; a.use_x0 = 0;
+        a.precond = s->adv_precond == 5 ? 3 : 1; a.use_x0 = 0;
         rc = fg_bicgstab_solve(s, a, info, st);
     }
     return rc;

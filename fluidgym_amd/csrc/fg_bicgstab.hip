@@ -750,7 +750,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     q.flags = s->flags; q.info = s->info_dev; q.nc = a.nc; q.tol = a.tol;
     q.mp = nullptr; q.ms = nullptr;
     if (a.precond) {
-        if (int rc = fg_line_alloc(s)) return rc;
+        if (int rc = (a.precond == 3 ? fg_ilu_alloc(s) : fg_line_alloc(s))) return rc;
         q.mp = s->w[5]; q.ms = s->w[6];   // free during a BiCGStab solve (the CG's z and second p buffer)
     }
     const dim3 sg((nsys + 63) / 64), sb(64);
@@ -758,10 +758,13 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     if (a.precond == 2) {
         FG_REQUIRE(s->fd_lam != nullptr, FG_ERR_INVALID_ARG, "Helmholtz preconditioner requested but fg_set_fd_helmholtz was not called");
         if (int rc = fg_helm_factor(s, a.dt, a.nu, a.wall_lo, a.wall_hi, a.nc, st)) return rc;
+    } else if (a.precond == 3) {
+        if (int rc = fg_ilu_factor(s, a.diag, a.off, st)) return rc;
     } else if (a.precond) {
         if (int rc = fg_line_factor(s, a.diag, a.off, a.nc, st)) return rc;
     }
     auto precondition = [&](const fg_real* in, fg_real* out) -> int {
+        if (a.precond == 3) return fg_ilu_apply(s, a.diag, a.off, a.nc, in, out, st);
         return a.precond == 2 ? fg_fd_helmholtz_apply(s, a.nc, in, out, st) : fg_line_apply(s, a.diag, a.off, a.nc, in, out, st);
     };
 

@@ -532,6 +532,7 @@ struct fg_state {
     int cg_wgs_per_slot;          // workgroups sharing one CG accumulator slot (256; FG_CG_WGS_PER_SLOT at fg_create: tuning)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
     fg_real* line_inv; fg_real* line_cp;
+    fg_real* ilu_d;               // [B,N] modified diagonal of the ILU(0) preconditioner (fg_ilu0.hip), built per solve
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;   // (fp32 kernels only)
     // separable Helmholtz preconditioner of the advection-diffusion solves (fg_set_fd_helmholtz): eigenvalue sums lam [nz][nx] of the
@@ -641,7 +642,8 @@ struct FgBicgArgs {
     int nc;
     const fg_real* dt;
     fg_real tol; int max_iterations; int use_x0;
-    int precond = 0;   // 1: right-preconditioned by the y-line solve of fg_linepre.hip (v = C M^-1 p, t = C M^-1 s); 2: by the
+    int precond = 0;   // 3: by ILU(0) of the matrix (fg_ilu0.hip, the reference's preconditioner);
+                       // 1: right-preconditioned by the y-line solve of fg_linepre.hip (v = C M^-1 p, t = C M^-1 s); 2: by the
                        // separable Helmholtz operator I/dt - nu Laplacian (fast diagonalisation, fg_fd_helmholtz_apply)
     fg_real nu = 0; int wall_lo = 1, wall_hi = 1;   // precond == 2: diffusivity of this solve; the variable is prescribed at the -y / +y wall
 };
@@ -687,6 +689,10 @@ int fg_fd_apply(fg_state* s, const fg_real* r, fg_real* z, FgDacc* rz_acc, int r
 // y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
 // with a live system, z = M^-1 r for every live system
 int fg_line_alloc(fg_state* s);
+// ILU(0) of the stencil-form matrix (fg_ilu0.hip): the reference's own preconditioner of the BiCGStab rungs
+int fg_ilu_alloc(fg_state* s);
+int fg_ilu_factor(fg_state* s, const fg_real* diag, const fg_real* off, hipStream_t st);
+int fg_ilu_apply(fg_state* s, const fg_real* diag, const fg_real* off, int nc, const fg_real* r, fg_real* z, hipStream_t st);
 int fg_helm_alloc(fg_state* s);
 int fg_helm_factor(fg_state* s, const fg_real* dt, fg_real nu, int wall_lo, int wall_hi, int nc, hipStream_t st);
 // z = M^-1 r with M the separable Helmholtz operator factorised by fg_helm_factor: basis change along x (and z), tridiagonal solve

@@ -369,10 +369,20 @@ class NativeSolver:
         """Preconditioner policy of the advection-diffusion BiCGStab (``fg_set_advection_preconditioner``): 0 plain (the
         reference's first rung), 1 every solve right-preconditioned by the y-line solve (its ``preconditionBiCG``), 2 only
         to repeat a failed solve (its ``BiCG_precondition_fallback``), 3 every solve right-preconditioned by the separable
-        Helmholtz operator (fast diagonalisation; needs ``has_helmholtz``)."""
+        Helmholtz operator (fast diagonalisation; needs ``has_helmholtz``), 4 / 5 like 1 / 2 with the reference's own preconditioner,
+        ILU(0) of the matrix (``csrc/fg_ilu0.hip``; hyperplane sweeps: correct and slow, ~1 ms per application)."""
         if self.f64:
-            return    # the y-line preconditioner is an fp32 kernel family: the fp64 build keeps the plain recurrence (mode 0)
+            return    # the preconditioners are fp32 kernel families: the fp64 build keeps the plain recurrence (mode 0)
         L.check(self.lib.fg_set_advection_preconditioner(self.handle, int(mode)), lib=self.lib)
+
+    def apply_advection_preconditioner(self, mode: int, r: torch.Tensor) -> torch.Tensor:
+        """``z = M^-1 r`` for ``r [B, nc, *grid]`` with the preconditioner of ``mode`` (1 y-line, 4 ILU(0)) built from the matrix
+        ``setup_advection`` assembled last (``fg_debug_apply_preconditioner``; tests)."""
+        r = r.to(self.device, torch.float32).contiguous()
+        z = torch.empty_like(r)
+        L.check(self.lib.fg_debug_apply_preconditioner(self.handle, int(mode), int(r.shape[1]), ctypes.c_void_p(r.data_ptr()),
+                                                       ctypes.c_void_p(z.data_ptr()), _stream(self.device)), lib=self.lib)
+        return z
 
     def advection_retries(self, reset: bool = False) -> int:
         out = ctypes.c_int64()

@@ -42,6 +42,14 @@ benchmark line can say which mode it ran in:
     solve halves the iterations (44 -> 21 on a synthetic RBC matrix, 11 with an alternating x / y line solve) and costs as
     much per iteration as it saves.  The ``preconditionBiCG`` / ``BiCG_precondition_fallback`` kwargs work either way.
 
+``advection_rung_preconditioner`` (default ``"line"``)
+    Single-block path: which preconditioner the reference's rungs use -- ``preconditionBiCG`` (every solve) and
+    ``BiCG_precondition_fallback`` (a failed solve is repeated with it).  ``"line"``: the tridiagonal part of the matrix along y
+    (``csrc/fg_linepre.hip``, ~15 us per application).  ``"ilu0"``: the reference's own preconditioner, ILU(0) of the matrix
+    (``csrc/fg_ilu0.hip``: the closed form on the stencil, swept hyperplane by hyperplane by one workgroup per system -- what
+    cuSPARSE's level-scheduled triangular solves do for this matrix; 0.5-1 ms per application on the bench grids).  Same
+    systems, same tolerances either way; the default is the fast one.
+
 ``advection_fd_preconditioner`` (default ``"auto"``)
     Single-block path, grids with periodic uniform x (and z) and walls in y (the RBC and TCF families): every advection-diffusion
     BiCGStab is right-preconditioned by the separable Helmholtz operator ``I/dt - nu Laplacian`` -- its matrix without the advective
@@ -67,6 +75,7 @@ _POLICY: Dict[str, Any] = {
     "pressure_multilevel": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL", "1") not in ("0", "", "false", "False"),
     "advection_line_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER", "0") not in ("0", "", "false", "False"),
     "advection_fd_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_FD_PRECONDITIONER", "auto"),
+    "advection_rung_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_RUNG_PRECONDITIONER", "line"),
     "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "1") not in ("0", "", "false", "False"),
 }
 

@@ -146,6 +146,9 @@ class Simulation:
             hy = np.asarray(solver.widths[1], dtype=np.float64)
             refined = bool(get_solver_policy()["advection_line_preconditioner"]) and float(hy.max() / hy.min()) >= 3.0
             self.advection_preconditioner = 1 if (self.preconditionBiCG or refined) else (2 if self.BiCG_precondition_fallback else 0)
+            # policy advection_rung_preconditioner = "ilu0": the rungs use the reference's own preconditioner (ILU(0), modes 4 / 5)
+            if get_solver_policy()["advection_rung_preconditioner"] == "ilu0" and min(len(w) for w in solver.widths[:solver.dims]) >= 4 and not refined:
+                self.advection_preconditioner = {1: 4, 2: 5}.get(self.advection_preconditioner, self.advection_preconditioner)
             # policy advection_fd_preconditioner (default on): where the grid allows it -- periodic, uniform x (and z), walls in y:
             # the RBC and TCF families -- every advection-diffusion solve is right-preconditioned by the exact inverse of its
             # diffusion part (separable Helmholtz operator, fast diagonalisation).  2-D only by default: in 3-D the four basis

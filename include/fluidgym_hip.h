@@ -176,9 +176,14 @@ int fg_solve_advection(fg_handle h, int for_scalar, int channel, fg_real tol, in
  * BiCG_precondition_fallback (PISOtorch_simulation.py:503, 565; PISOtorch_diff.py:449-476; cuSPARSE ILU(0),
  * bicgstab_solver_kernel.cu:191-226, 288-293): mode 0 = plain BiCGStab (the reference's first rung, default), 1 = every solve
  * right-preconditioned, 2 = a solve that ends unconverged or non-finite is repeated from zero with the preconditioner.  The
- * preconditioner here is the tridiagonal part of the matrix along y (csrc/fg_linepre.hip), factorised per solve and env.
+ * preconditioner of modes 1 / 2 is the tridiagonal part of the matrix along y (csrc/fg_linepre.hip), factorised per solve and env;
+ * 3 = every solve preconditioned by the separable Helmholtz operator (fg_set_fd_helmholtz); 4 / 5 = like 1 / 2 with the reference's
+ * own preconditioner, ILU(0) of the matrix (csrc/fg_ilu0.hip: closed form on the stencil, hyperplane sweeps; every axis >= 4 cells).
  * fg_advection_retries: number of repeated solves since the last reset. */
 int fg_set_advection_preconditioner(fg_handle h, int mode);
+/* Test / diagnosis entry, never on a step path: z = M^-1 r [B, nc, N] with the preconditioner of `mode` (1: y-line, 4: ILU(0)) built from
+ * the advection-diffusion matrix currently assembled (fg_setup_advection).  Synchronises. */
+int fg_debug_apply_preconditioner(fg_handle h, int mode, int nc, const fg_real* r, fg_real* z, void* stream);
 /* mode 3 of fg_set_advection_preconditioner: every advection-diffusion solve right-preconditioned by the separable Helmholtz
  * operator I/dt - nu Laplacian (the matrix without its advective part), inverted by fast diagonalisation: basis change along the
  * PERIODIC, uniform transform axes (x, z; the eigenvectors of fg_set_fd_preconditioner), one tridiagonal solve along y per mode
