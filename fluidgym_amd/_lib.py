@@ -173,6 +173,7 @@ SIGNATURES = {
     "fg_stream_triad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, POINTER(c_float), c_void_p]),
     "fg_mb_multilevel_status": (c_int, [c_void_p, POINTER(c_int32)]),
     "fg_mb_multilevel_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fg_mb_debug_ilu_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fg_mb_wall_forces": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p]),
     "fg_mb_debug_bicgstab": (c_int, [c_void_p, c_float, c_int32, c_int32, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(c_float), c_void_p]),
     "fg_dacc_host_sum": (c_int, [POINTER(ctypes.c_double), c_int64, ctypes.c_double, POINTER(ctypes.c_double)]),

@@ -128,6 +128,15 @@ struct fg_mb_state {
     // work arrays of the kernel form (mb_ml_apply): aggregate sums [B][n4], coarse solution [B][n8], 1 / scale [B], M p and M s [B][N]
     float *ml_r4 = nullptr, *ml_z8 = nullptr, *ml_scale = nullptr, *ml_mp = nullptr, *ml_ms = nullptr;
     float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
+    // ILU(0) of the velocity matrix as the right preconditioner of the preconditioned rung (mb_ilu_*, fg_mb_step.hip): level
+    // schedules of the two triangular solves from the neighbour table (host, once per mesh), factors and M p / M s per env
+    int32_t *ilu_order_f = nullptr, *ilu_order_b = nullptr;   // [N] cells sorted by forward / backward level
+    std::vector<int32_t> ilu_start_f, ilu_start_b;            // [levels + 1] first position of every level in the order
+    int32_t *ilu_start_f_dev = nullptr, *ilu_start_b_dev = nullptr;
+    float *ilu_w = nullptr, *ilu_ud = nullptr;                 // [B][F][N] modified off-diagonals (l_ik below, u_ij above the diagonal), [B][N] u_ii
+    float *ilu_mp = nullptr, *ilu_ms = nullptr;                // [B][d][N]
+    int ilu_state = 0;         // 0 not tried, 1 schedules built, -1 the mesh does not qualify (a cell with the same neighbour across two faces)
+    int dbg_rung_ilu = 1;      // FG_MB_RUNG_ILU=0: the preconditioned rung keeps the right diagonal scaling of rounds 1-3
     // aggregate-owned layout of the on-chip CG (k_mbc_onchip<AGG>, built by fg_mb_set_multilevel when the mesh has at most 256
     // 8 x 8 aggregates of at most four 4 x 4 children of at most 16 cells): thread t = 4 * (8 x 8 aggregate) + child owns the
     // cells of that child, member m (row-major in its rectangle) lives in slot t + 1024 m of a 16 384-slot index space

@@ -2081,6 +2081,99 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ILU(0) of an ELL matrix on the mesh's neighbour table: the reference's preconditioner of the BiCG_precondition_fallback rung
+// (cusparseScsrilu02 + two cusparseSpSV, bicgstab_solver_kernel.cu:191-226, 288-293).  General pattern (at an interior vertex shared by
+// three cells two lower neighbours of a cell are neighbours of each other and an elimination step does update an off-diagonal),
+// IKJ elimination row by row; rows are processed level by level (a row depends on its lower neighbours: the schedule comes from
+// the neighbour table, host, once per mesh -- mb_ilu_prepare), one workgroup per env (factor) / per system (solves), a barrier
+// between levels.  Sequential by nature -- it runs on the rung that repeats a FAILED solve, not on the step's fast path.
+// W[f][i] = l_ik (neighbour across face f below i) or u_ij (above); ud[i] = u_ii.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DIMS>
+__global__ __launch_bounds__(1024) void k_mb_ilu_factor(MbDev D, const float* __restrict__ dt, const float* __restrict__ diag,
+                                                         const float* __restrict__ off, const int32_t* __restrict__ order,
+                                                         const int32_t* __restrict__ start, int levels, float* __restrict__ W,
+                                                         float* __restrict__ ud) {
+    constexpr int F = 2 * DIMS;
+    const int b = blockIdx.x, N = D.N;
+    if (!mb_active(dt, b)) return;
+    const float* dg = diag + (size_t)b * N;
+    const float* of = off + (size_t)b * F * N;
+    float* w_ = W + (size_t)b * F * N;
+    float* u_ = ud + (size_t)b * N;
+    for (int lv = 0; lv < levels; ++lv) {
+        for (int pos = start[lv] + (int)threadIdx.x; pos < start[lv + 1]; pos += (int)blockDim.x) {
+            const int i = order[pos];
+            int nb[F];
+            float w[F];
+            float d = dg[i];
+#pragma unroll
+            for (int f = 0; f < F; ++f) { nb[f] = D.nbr[(size_t)f * N + i]; w[f] = nb[f] >= 0 ? of[(size_t)f * N + i] : 0.f; }
+            int last = -1;
+            for (int round = 0; round < F; ++round) {          // lower neighbours in increasing order of their index
+                int k = 0x7fffffff, fk = -1;
+#pragma unroll
+                for (int f = 0; f < F; ++f) if (nb[f] >= 0 && nb[f] < i && nb[f] > last && nb[f] < k) { k = nb[f]; fk = f; }
+                if (fk < 0) break;
+                last = k;
+                const float l = w[fk] / u_[k];
+                w[fk] = l;
+#pragma unroll
+                for (int g = 0; g < F; ++g) {                  // row k above its diagonal
+                    const int j = D.nbr[(size_t)g * N + k];
+                    if (j <= k) continue;
+                    const float ukj = w_[(size_t)g * N + k];
+                    if (j == i) d -= l * ukj;
+                    else {
+#pragma unroll
+                        for (int f2 = 0; f2 < F; ++f2) if (nb[f2] == j) w[f2] -= l * ukj;
+                    }
+                }
+            }
+            u_[i] = d;
+#pragma unroll
+            for (int f = 0; f < F; ++f) w_[(size_t)f * N + i] = w[f];
+        }
+        __syncthreads();
+    }
+}
+
+// out = U^-1 L^-1 in for every system still iterating; grid = (nc, B)
+template <int DIMS>
+__global__ __launch_bounds__(1024) void k_mb_ilu_solve(MbDev D, int nc, const int32_t* __restrict__ flags, const int32_t* __restrict__ order_f,
+                                                        const int32_t* __restrict__ start_f, int levels_f, const int32_t* __restrict__ order_b,
+                                                        const int32_t* __restrict__ start_b, int levels_b, const float* __restrict__ W,
+                                                        const float* __restrict__ ud, const float* __restrict__ in, float* __restrict__ out) {
+    constexpr int F = 2 * DIMS;
+    const int b = blockIdx.y, sys = b * nc + (int)blockIdx.x, N = D.N;
+    if (flag_ld(flags + sys) != 0) return;
+    const float* w_ = W + (size_t)b * F * N;
+    const float* u_ = ud + (size_t)b * N;
+    const float* r = in + (size_t)sys * N;
+    float* y = out + (size_t)sys * N;
+    for (int lv = 0; lv < levels_f; ++lv) {
+        for (int pos = start_f[lv] + (int)threadIdx.x; pos < start_f[lv + 1]; pos += (int)blockDim.x) {
+            const int i = order_f[pos];
+            float v = r[i];
+#pragma unroll
+            for (int f = 0; f < F; ++f) { const int k = D.nbr[(size_t)f * N + i]; if (k >= 0 && k < i) v -= w_[(size_t)f * N + i] * y[k]; }
+            y[i] = v;
+        }
+        __syncthreads();
+    }
+    for (int lv = 0; lv < levels_b; ++lv) {
+        for (int pos = start_b[lv] + (int)threadIdx.x; pos < start_b[lv + 1]; pos += (int)blockDim.x) {
+            const int i = order_b[pos];
+            float v = y[i];
+#pragma unroll
+            for (int f = 0; f < F; ++f) { const int j = D.nbr[(size_t)f * N + i]; if (j > i) v -= w_[(size_t)f * N + i] * y[j]; }
+            y[i] = v / u_[i];
+        }
+        __syncthreads();
+    }
+}
+
 // ---- boundary bookkeeping of Simulation.single_step (simulation.py:206-280) on the flat boundary slots --------------
 // update_advective_boundaries (PISOtorch_simulation.py:228-393): u_b <- u_b - t (u_b - u_cell), t = 1 - 1/(1 + 2 dt Minv_b[axis].velm)
 template <int DIMS>
@@ -2268,6 +2361,61 @@ void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, 
     hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out);
 }
 
+// level schedules of the ILU(0) sweeps from the neighbour table (once per mesh); false: the mesh does not qualify
+bool mb_ilu_prepare(fg_mb_state* s) {
+    if (s->ilu_state != 0) return s->ilu_state > 0;
+    s->ilu_state = -1;
+    const int N = s->N, F = s->F;
+    std::vector<int> lf(N, 0), lb(N, 0);
+    for (int i = 0; i < N; ++i) {
+        int lv = 0;
+        for (int f = 0; f < F; ++f) {
+            const int k = s->h_nbr[(size_t)f * N + i];
+            for (int g = 0; g < f; ++g) if (k >= 0 && s->h_nbr[(size_t)g * N + i] == k) return false;   // the same neighbour across two faces
+            if (k == i) return false;
+            if (k >= 0 && k < i) lv = std::max(lv, lf[k] + 1);
+        }
+        lf[i] = lv;
+    }
+    for (int i = N - 1; i >= 0; --i) {
+        int lv = 0;
+        for (int f = 0; f < F; ++f) { const int j = s->h_nbr[(size_t)f * N + i]; if (j > i) lv = std::max(lv, lb[j] + 1); }
+        lb[i] = lv;
+    }
+    auto schedule = [&](const std::vector<int>& lev, std::vector<int32_t>& start, int32_t** order_dev, int32_t** start_dev) -> int {
+        const int nl = *std::max_element(lev.begin(), lev.end()) + 1;
+        start.assign(nl + 1, 0);
+        for (int i = 0; i < N; ++i) start[lev[i] + 1]++;
+        for (int l = 0; l < nl; ++l) start[l + 1] += start[l];
+        std::vector<int32_t> order(N), fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < N; ++i) order[fill[lev[i]]++] = i;
+        if (int rc = mb_alloc(s, order_dev, (size_t)N)) return rc;
+        if (int rc = mb_alloc(s, start_dev, start.size())) return rc;
+        FG_HIP_CHECK(hipMemcpy(*order_dev, order.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+        FG_HIP_CHECK(hipMemcpy(*start_dev, start.data(), sizeof(int32_t) * start.size(), hipMemcpyHostToDevice));
+        return FG_OK;
+    };
+    if (schedule(lf, s->ilu_start_f, &s->ilu_order_f, &s->ilu_start_f_dev) != FG_OK) return false;
+    if (schedule(lb, s->ilu_start_b, &s->ilu_order_b, &s->ilu_start_b_dev) != FG_OK) return false;
+    const size_t BN = (size_t)s->B * N;
+    if (mb_alloc(s, &s->ilu_w, BN * F) != FG_OK || mb_alloc(s, &s->ilu_ud, BN) != FG_OK || mb_alloc(s, &s->ilu_mp, BN * s->d) != FG_OK ||
+        mb_alloc(s, &s->ilu_ms, BN * s->d) != FG_OK)
+        return false;
+    s->ilu_state = 1;
+    return true;
+}
+
+void mb_ilu_factor(fg_mb_state* s, const float* dt, const float* diag, const float* off, hipStream_t st) {
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_ilu_factor<DIMS>, dim3(s->B), dim3(1024), 0, st, s->dev, dt, diag, off, (const int32_t*)s->ilu_order_f,
+                                      (const int32_t*)s->ilu_start_f_dev, (int)s->ilu_start_f.size() - 1, s->ilu_w, s->ilu_ud););
+}
+void mb_ilu_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st) {
+    MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_ilu_solve<DIMS>, dim3(q.nc, s->B), dim3(1024), 0, st, s->dev, q.nc, (const int32_t*)q.flags,
+                                      (const int32_t*)s->ilu_order_f, (const int32_t*)s->ilu_start_f_dev, (int)s->ilu_start_f.size() - 1,
+                                      (const int32_t*)s->ilu_order_b, (const int32_t*)s->ilu_start_b_dev, (int)s->ilu_start_b.size() - 1,
+                                      (const float*)s->ilu_w, (const float*)s->ilu_ud, in, out););
+}
+
 int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, int nc,
                 float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0, int multilevel = 0,
                 int pred_slot = 31) {
@@ -2275,8 +2423,13 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     q.project = project ? 1 : 0;
     // multilevel right preconditioning of the pressure solve: the recurrence runs on P M, the iterate advances along M p, M s
-    const bool ml = multilevel && nc == 1 && s->ml_on && s->ml_a4 != nullptr && s->ml_mp != nullptr;
-    if (ml) {
+    // multilevel == 2: right preconditioning by ILU(0) of the matrix itself (the reference's preconditioned rung; mb_ilu_*)
+    const bool ilu = multilevel == 2 && s->ilu_state > 0;
+    const bool ml = ilu || (multilevel == 1 && nc == 1 && s->ml_on && s->ml_a4 != nullptr && s->ml_mp != nullptr);
+    if (ilu) {
+        q.mp = s->ilu_mp; q.ms = s->ilu_ms;
+        mb_ilu_factor(s, dt, diag, off, st);
+    } else if (ml) {
         q.mp = s->ml_mp; q.ms = s->ml_ms;
         hipLaunchKernelGGL(k_ml_scale, dim3(s->B), dim3(1024), 0, st, diag, n, s->ml_geom_diag_sum, s->ml_scale);
     }
@@ -2342,14 +2495,16 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
                 if ((vec_mask & 3) == 3) hipLaunchKernelGGL(k_mbb_pv4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_pv<DIMS>, grid, blk, 0, st, s->dev, q, li);
             } else {
             if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st);
+            if (ilu) mb_ilu_apply(s, q, q.p, s->ilu_mp, st);
+            else if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st);
             if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
             }
             if (fused_st) {
                 if ((vec_mask & 12) == 12) hipLaunchKernelGGL(k_mbb_st4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_st<DIMS>, grid, blk, 0, st, s->dev, q, li);
             } else {
                 if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
-                if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st);
+                if (ilu) mb_ilu_apply(s, q, q.r, s->ilu_ms, st);
+                else if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st);
                 if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
             }
             if (vec_mask & 16) hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
@@ -2702,6 +2857,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_AGG"); s->dbg_oc_agg = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_RUNG_ILU"); s->dbg_rung_ilu = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_VARIANT"); s->oc_variant = e ? atoi(e) : 0;   // bit 0: no compiler fences in the stencil pass; bit 1: split [F][N] coefficient layout
     }
 #if FG_MB_F64
@@ -3011,11 +3167,16 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol, opt->max_iterations, 0, &m, st, 0, 1);
                 if ((s->ladder_force & 4) && vrc == FG_OK) vrc = FG_ERR_NOT_CONVERGED;
             }
-            if (v_failed(vrc) && opt->bicg_precondition_fallback) {   // preconditioned rung: (C D^-1) y = b, x = D^-1 y
+            if (v_failed(vrc) && opt->bicg_precondition_fallback) {
                 ++s->ladder[1];
-                hipLaunchKernelGGL(k_mb_scale_cols<DIMS>, gn, blk, 0, st, D, dt_B, s->Cdiag, s->Coff, s->Sdiag, s->Soff);
-                vrc = mb_bicgstab(s, dt_B, s->Sdiag, s->Soff, s->rhs, s->ures, d, opt->advection_tol, opt->max_iterations, 0, &m, st);
-                hipLaunchKernelGGL(k_mb_unscale, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B * d), blk, 0, st, N, d, dt_B, (const float*)s->Cdiag, s->ures);
+                if (s->dbg_rung_ilu && !FG_MB_F64 && mb_ilu_prepare(s)) {
+                    // preconditioned rung as in the reference: BiCGStab right-preconditioned by ILU(0) of the matrix
+                    vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol, opt->max_iterations, 0, &m, st, 0, 0, 2);
+                } else {   // meshes the schedule does not cover, the fp64 build: right diagonal scaling, (C D^-1) y = b, x = D^-1 y
+                    hipLaunchKernelGGL(k_mb_scale_cols<DIMS>, gn, blk, 0, st, D, dt_B, s->Cdiag, s->Coff, s->Sdiag, s->Soff);
+                    vrc = mb_bicgstab(s, dt_B, s->Sdiag, s->Soff, s->rhs, s->ures, d, opt->advection_tol, opt->max_iterations, 0, &m, st);
+                    hipLaunchKernelGGL(k_mb_unscale, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B * d), blk, 0, st, N, d, dt_B, (const float*)s->Cdiag, s->ures);
+                }
             }
             if (vrc == FG_ERR_NOT_FINITE) {
                 fg_set_error("fg_mb_piso_step: the velocity (BiCGStab) solve produced a non-finite residual");
@@ -3256,6 +3417,21 @@ extern "C" int fg_mb_multilevel_status(fg_mb_handle s, int32_t* out3) {
     out3[0] = (s->ml_on && s->ml_a4 != nullptr) ? s->ml_bicg_backoff : 0;
     out3[1] = s->ml_bicg_attempts;
     out3[2] = s->ml_bicg_failures;
+    return FG_OK;
+}
+
+// z = U^-1 L^-1 r with ILU(0) of the velocity matrix currently assembled (the last step's), d systems per env: unit entry of the
+// preconditioned rung's preconditioner (tests/test_gpu_mb.py), not on any step path.
+extern "C" int fg_mb_debug_ilu_apply(fg_mb_handle s, const float* r_BdN, float* z_BdN, void* stream) {
+    FG_REQUIRE(s && s->finalized && !s->host_only && r_BdN && z_BdN, FG_ERR_INVALID_ARG, "fg_mb_debug_ilu_apply: bad argument");
+    FG_REQUIRE(!FG_MB_F64, FG_ERR_UNSUPPORTED, "fg_mb_debug_ilu_apply: not part of the fp64 build");
+    FG_REQUIRE(mb_ilu_prepare(s), FG_ERR_UNSUPPORTED, "fg_mb_debug_ilu_apply: the mesh does not qualify (a cell with the same neighbour across two faces)");
+    hipStream_t st = (hipStream_t)stream;
+    MbSolve q = mb_solve_ptrs(s, s->Cdiag, s->Coff, nullptr, nullptr, s->d, 0.f);
+    FG_HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int32_t) * s->B * s->d, st));
+    mb_ilu_factor(s, nullptr, s->Cdiag, s->Coff, st);
+    mb_ilu_apply(s, q, r_BdN, z_BdN, st);
+    FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }
 

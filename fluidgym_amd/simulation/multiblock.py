@@ -502,6 +502,15 @@ class MultiBlockDomain:
         L.check(self.lib.fg_mb_multilevel_status(self.handle, out))
         return {"backoff": int(out[0]), "attempts": int(out[1]), "failed_attempts": int(out[2])}
 
+    def ilu_apply(self, r: torch.Tensor) -> torch.Tensor:
+        """``z = U^-1 L^-1 r`` [B, d, N] with ILU(0) of the velocity matrix the last step assembled (``fg_mb_debug_ilu_apply``): the
+        preconditioner of the ``BiCG_precondition_fallback`` rung (tests)."""
+        r = r.to(self.device, self.dtype).contiguous()
+        z = torch.empty_like(r)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fg_mb_debug_ilu_apply(self.handle, ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(st)), lib=self.lib)
+        return z
+
     def multilevel_apply(self, r: torch.Tensor) -> torch.Tensor:
         """``z = M r`` [B, N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled."""
         r = r.to(self.device, self.dtype).contiguous()

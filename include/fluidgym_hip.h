@@ -526,6 +526,11 @@ int fg_mb_debug_bicgstab(fg_mb_handle h, fg_real tol, int32_t max_iterations, in
 /* z = M r [B,N] with the kernel form of the multilevel preconditioner on the pressure matrix currently assembled (unit test of
  * the three kernels behind the preconditioned pressure BiCGStab; synchronises). */
 int fg_mb_multilevel_apply(fg_mb_handle h, const fg_real* r_BN, fg_real* z_BN, void* stream);
+/* z = U^-1 L^-1 r [B,d,N] with ILU(0) of the velocity matrix assembled by the last step: the preconditioner of the multi-block
+ * BiCG_precondition_fallback rung (cuSPARSE ILU(0) in the reference, bicgstab_solver_kernel.cu:191-226; level-scheduled on the
+ * mesh's neighbour table here).  Test entry (synchronises); FG_ERR_UNSUPPORTED in the fp64 build and on meshes in which a cell
+ * meets the same neighbour across two faces (the rung keeps right diagonal scaling there). */
+int fg_mb_debug_ilu_apply(fg_mb_handle h, const fg_real* r_BdN, fg_real* z_BdN, void* stream);
 /* The multilevel right preconditioner of the pressure BiCGStab is a trial with exponential back-off per handle:
  * out3 = current back-off in solves (0: no tables; 4: every attempt converges; up to 256), attempts, failed attempts (each repeated
  * with the plain recurrence). */
