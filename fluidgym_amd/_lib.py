@@ -25,7 +25,7 @@ FG_ERR_NOT_FINITE = -6
 FG_ERR_FLUX_BALANCE = -7
 FG_PERIODIC, FG_FIXED = 0, 1
 FG_DIRICHLET, FG_NEUMANN = 0, 1
-FG_VELOCITY, FG_PRESSURE, FG_SCALAR, FG_VELOCITY_SOURCE = 0, 1, 2, 3
+FG_VELOCITY, FG_PRESSURE, FG_SCALAR, FG_VELOCITY_SOURCE, FG_VISCOSITY_FIELD = 0, 1, 2, 3, 4
 FG_BOUND_VELOCITY, FG_BOUND_SCALAR = 8, 16
 FG_SOLVER_CG, FG_SOLVER_JACOBI, FG_SOLVER_RBGS, FG_SOLVER_MGCG, FG_SOLVER_FDCG = 0, 1, 2, 3, 4
 (FG_BUF_A, FG_BUF_C_OFF, FG_BUF_ADV_RHS, FG_BUF_VEL_RESULT, FG_BUF_H, FG_BUF_DIV, FG_BUF_P_RESULT,
@@ -220,6 +220,7 @@ SIGNATURES = {
     "fg_mb_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_set_advection_preconditioner": (c_int, [c_void_p, c_int]),
     "fg_debug_apply_preconditioner": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fg_sgs_smagorinsky": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "fg_set_fd_helmholtz": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_advection_retries": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),

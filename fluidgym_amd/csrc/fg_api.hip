@@ -154,6 +154,7 @@ extern "C" int fg_bind(fg_handle s, int field, fg_real* ptr) {
     else if (field == FG_PRESSURE) s->pressure = ptr;
     else if (field == FG_SCALAR) s->scalar = ptr;
     else if (field == FG_VELOCITY_SOURCE) s->velocity_source = ptr;
+    else if (field == FG_VISCOSITY_FIELD) s->visc_field = ptr;
     else if (field >= FG_BOUND_VELOCITY && field < FG_BOUND_VELOCITY + 6) {
         s->bvel[field - FG_BOUND_VELOCITY] = ptr;
         return sync_bvel_ptrs(s);
@@ -244,6 +245,11 @@ extern "C" int fg_debug_apply_preconditioner(fg_handle s, int mode, int nc, cons
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }
+extern "C" int fg_sgs_smagorinsky(fg_handle s, fg_real coefficient, fg_real* out_BN, void* stream) {
+    FG_REQUIRE(s && out_BN, FG_ERR_INVALID_ARG, "fg_sgs_smagorinsky: null argument");
+    if (int rc = check_bound(s, false)) return rc;
+    return fg_launch_sgs(s, make_bounds(s, 0), coefficient, out_BN, (hipStream_t)stream);
+}
 extern "C" int fg_advection_retries(fg_handle s, int64_t* out, int32_t reset) {
     FG_REQUIRE(s && out, FG_ERR_INVALID_ARG, "null argument");
     *out = s->line_retries;
@@ -315,6 +321,7 @@ extern "C" int fg_setup_advection(fg_handle s, const fg_real* dt_B, int for_scal
         a.nu = s->scalar_viscosity_set ? s->scalar_viscosity[channel] : s->viscosity;
     } else {
         a.source = s->velocity_source;
+        a.visc = s->visc_field;
         a.nu = s->viscosity;
         a.rA = s->rA;
     }
@@ -421,6 +428,7 @@ static int max_iters(const fg_solve_info* info, int n) {
 // (BiCG_precondition_fallback) -- the reference's preconditioner is cuSPARSE ILU(0), here the y-line solve of fg_linepre.hip.
 static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipStream_t st, int for_scalar, int channel) {
     a.precond = (s->adv_precond == 1) ? 1 : (s->adv_precond == 3 ? 2 : (s->adv_precond == 4 ? 3 : 0));
+    if (a.precond == 2 && !for_scalar && s->visc_field) a.precond = 0;   // the Helmholtz operator is built for ONE viscosity
     if (a.precond == 2) {   // Helmholtz (fast-diagonalisation) preconditioner: the diffusivity and wall treatment of THIS solve
         a.nu = for_scalar ? (s->scalar_viscosity_set ? s->scalar_viscosity[channel] : s->viscosity) : s->viscosity;
         a.wall_lo = for_scalar ? (s->cfg.scalar_bc[2][channel] == FG_DIRICHLET) : 1;

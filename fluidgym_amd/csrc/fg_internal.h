@@ -18,12 +18,14 @@ __host__ __device__ __forceinline__ fg_real4 make_fg_real4(double x, double y, d
 #define FG_F64 1
 #define FG_FMAX fmax
 #define FG_FABS fabs
+#define FG_SQRT sqrt
 #else
 typedef float4 fg_real4;
 #define make_fg_real4 make_float4
 #define FG_F64 0
 #define FG_FMAX fmaxf
 #define FG_FABS fabsf
+#define FG_SQRT sqrtf
 #endif
 
 // The recurrence words of the multi-kernel Krylov solvers (accumulators, alpha / omega, flags) are read and zeroed through
@@ -501,6 +503,7 @@ struct fg_state {
     fg_real* pressure;
     fg_real* scalar;
     fg_real* velocity_source;
+    fg_real* visc_field;          // [B,N] per-cell viscosity of the velocity system (FG_VISCOSITY_FIELD) or nullptr
     fg_real* bvel[6];
     fg_real* bscal[6];
     // owned solver workspace
@@ -597,12 +600,14 @@ struct FgAdvArgs {
     const fg_real* source;   // velocity source [B,d,N] or nullptr
     const fg_real* dt;       // [B]
     fg_real nu;              // viscosity (or scalar diffusivity)
+    const fg_real* visc;     // optional per-cell viscosity [B,N] of the velocity system (Block.setViscosity: SGS models); nullptr = nu
     int for_scalar;
     int channel, n_scalars;
     fg_real* A; fg_real* Coff; fg_real* rhs;
     fg_real* rA;             // optional: 1/A written alongside A (velocity system only)
 };
 int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
+int fg_launch_sgs(const fg_state* s, const FgBounds& bnd, fg_real coefficient, fg_real* out, hipStream_t st);
 int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t st);  // rA = 1/A
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st);
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, hipStream_t st);

@@ -35,7 +35,10 @@ __device__ __forceinline__ int fg_slab_size(const FgGrid& g, int a) {
 //   rhs_c = [ J q_c/dt + sum_FIXED q_b,c ( -s_f U_b + (1-slip) nu 2 alpha_b ) ]/J + S_c
 // Rectilinear grid: U_a = u_a * (J/h_a), alpha_a = (J/h_a)/h_a, boundary transform == adjacent cell.
 // ---------------------------------------------------------------------------------------------
-template <int DIMS, int VEC, bool SCALAR>
+// VISC: a per-cell viscosity field (getViscosityBlock, K.cu:1816-1837; Block.setViscosity of the SGS hook, tcf_env.py:441-474): the
+// face coefficient becomes (alpha_P nu_P + alpha_N nu_N) / 2 (:3745) and a prescribed face takes the adjacent cell's value
+// (getViscosityFixedBoundary, :1840-1843).  A separate instance: the default path is the scalar-nu kernel, bit for bit.
+template <int DIMS, int VEC, bool SCALAR, bool VISC = false>
 __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, FgAdvArgs a, int tiles_x,
                                                          int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
@@ -62,6 +65,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
     for (int ax = 0; ax < DIMS; ++ax) {
         FgVec<VEC> lo, hi;
         fg_gather_axis<DIMS, VEC>(vel + ax * N, c, ax, u[ax], lo, hi);
+        FgVec<VEC> nu_c, nu_lo, nu_hi;
+        if constexpr (VISC) fg_gather_axis<DIMS, VEC>(a.visc + (size_t)c.b * N, c, ax, nu_c, nu_lo, nu_hi);
         const int f_lo = 2 * ax, f_hi = 2 * ax + 1;
         const int slab = fg_slab_index<DIMS, VEC>(g, c, ax);
         const int slab_n = fg_slab_size(g, ax);
@@ -86,10 +91,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
             }
             const fg_real Uc = u[ax].v[e] * area;
             const fg_real al_p = area * rh_p;
+            const fg_real nu_p = VISC ? nu_c.v[e] : nu;   // (the code below reads nu_p where the scalar kernel read nu)
             // ---- lower face (s = -1)
             if (mask_lo != 0.f) {
                 const fg_real ff = -0.25f * (Uc + lo.v[e] * area);
-                const fg_real visc = 0.5f * nu * (al_p + area * rh_lo);
+                fg_real visc;
+                if constexpr (VISC) visc = 0.5f * (nu_p * al_p + nu_lo.v[e] * (area * rh_lo));
+                else visc = 0.5f * nu * (al_p + area * rh_lo);
                 diag[e] += ff + visc;
                 off[f_lo][e] = ff - visc;
             } else {
@@ -103,18 +111,20 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
                     if (dir) diag[e] += 2.f * nu * al_p;
                     bsum[0][e] += tb * Ub + (dir ? tb * nu * 2.f * al_p : tb * nu);  // -T_b*(s U_b), s=-1
                 } else {
-                    diag[e] += 2.f * nu * al_p;
+                    diag[e] += 2.f * nu_p * al_p;
 #pragma unroll
                     for (int q = 0; q < DIMS; ++q) {
                         const fg_real ub = bv[q * slab_n + bi];
-                        bsum[q][e] += ub * Ub + ub * nu * 2.f * al_p;
+                        bsum[q][e] += ub * Ub + ub * nu_p * 2.f * al_p;
                     }
                 }
             }
             // ---- upper face (s = +1)
             if (mask_hi != 0.f) {
                 const fg_real ff = 0.25f * (Uc + hi.v[e] * area);
-                const fg_real visc = 0.5f * nu * (al_p + area * rh_hi);
+                fg_real visc;
+                if constexpr (VISC) visc = 0.5f * (nu_p * al_p + nu_hi.v[e] * (area * rh_hi));
+                else visc = 0.5f * nu * (al_p + area * rh_hi);
                 diag[e] += ff + visc;
                 off[f_hi][e] = ff - visc;
             } else {
@@ -128,11 +138,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
                     if (dir) diag[e] += 2.f * nu * al_p;
                     bsum[0][e] += -tb * Ub + (dir ? tb * nu * 2.f * al_p : tb * nu);
                 } else {
-                    diag[e] += 2.f * nu * al_p;
+                    diag[e] += 2.f * nu_p * al_p;
 #pragma unroll
                     for (int q = 0; q < DIMS; ++q) {
                         const fg_real ub = bv[q * slab_n + bi];
-                        bsum[q][e] += -ub * Ub + ub * nu * 2.f * al_p;
+                        bsum[q][e] += -ub * Ub + ub * nu_p * 2.f * al_p;
                     }
                 }
             }
@@ -664,10 +674,79 @@ int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs&
         if (a.for_scalar)
             hipLaunchKernelGGL((k_adv_build<DIMS, VEC, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
                                L.tiles_y, L.tiles);
+        else if (a.visc)
+            hipLaunchKernelGGL((k_adv_build<DIMS, VEC, false, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
+                               L.tiles_y, L.tiles);
         else
             hipLaunchKernelGGL((k_adv_build<DIMS, VEC, false>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
                                L.tiles_y, L.tiles);
     });
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+// SGSviscosityIncompressibleSmagorinsky (K.cu:6913-6966) on the rectilinear block: nu_t = C Delta^2 |S|,  |S| = sqrt(2 S:S),
+// S = sym(grad u) from getBlockDataGradient (K.cu:2997-3040): (value above - value below) / distance along every axis, where a
+// neighbour across a periodic or interior face is the cell (distance contribution 1) and a FIXED face contributes its (Dirichlet)
+// boundary value at half a cell (0.5); then times Minv = 1 / h.  Delta^2 = max_a h_a^2 (squared column lengths of M; the kernel
+// never takes the root, :6959).  One cell per thread: a PRE-hook kernel, once per step.
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_sgs_smagorinsky(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel, fg_real coefficient,
+                                                               fg_real* __restrict__ out) {
+    const int b = blockIdx.y, c = blockIdx.x * FG_BLOCK + threadIdx.x;
+    if (c >= g.n) return;
+    const int ext[3] = {g.nx, g.ny, DIMS == 3 ? g.nz : 1};
+    const int pos[3] = {c % g.nx, (c / g.nx) % g.ny, c / (g.nx * g.ny)};
+    const int stride[3] = {1, g.nx, g.nx * g.ny};
+    const fg_real* u = vel + (size_t)b * DIMS * g.n;
+    fg_real grad[DIMS][DIMS];   // [component][axis]
+    fg_real delta = 0.f;
+#pragma unroll
+    for (int a = 0; a < DIMS; ++a) {
+        const fg_real h = g.h[a][pos[a]];
+        delta = FG_FMAX(delta, h * h);
+        fg_real dist = 2.f;
+        fg_real diff[DIMS];
+#pragma unroll
+        for (int q = 0; q < DIMS; ++q) diff[q] = 0.f;
+#pragma unroll
+        for (int up = 0; up < 2; ++up) {
+            const int f = 2 * a + up;
+            const bool at = up ? (pos[a] + 1 == ext[a]) : (pos[a] == 0);
+            if (at && g.fixed[f]) {
+                // slab index of this cell on face f: the remaining axes, lowest fastest
+                int si = 0, mul = 1;
+#pragma unroll
+                for (int t = 0; t < DIMS; ++t) if (t != a) { si += pos[t] * mul; mul *= ext[t]; }
+                const fg_real* bv = bnd.vel[f] + (size_t)b * DIMS * mul;
+#pragma unroll
+                for (int q = 0; q < DIMS; ++q) diff[q] += (up ? 1.f : -1.f) * bv[q * mul + si];
+                dist -= 0.5f;
+            } else {
+                const int n = at ? (up ? c - (ext[a] - 1) * stride[a] : c + (ext[a] - 1) * stride[a]) : (up ? c + stride[a] : c - stride[a]);
+#pragma unroll
+                for (int q = 0; q < DIMS; ++q) diff[q] += (up ? 1.f : -1.f) * u[(size_t)q * g.n + n];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < DIMS; ++q) grad[q][a] = diff[q] / dist * g.rh[a][pos[a]];
+    }
+    fg_real d = 0.f;
+#pragma unroll
+    for (int i = 0; i < DIMS; ++i)
+#pragma unroll
+        for (int j = i; j < DIMS; ++j) {
+            fg_real sij = 0.5f * (grad[i][j] + grad[j][i]);
+            sij *= sij;
+            d += (i != j) ? 2.f * sij : sij;
+        }
+    out[(size_t)b * g.n + c] = coefficient * delta * FG_SQRT(2.f * d);
+}
+
+int fg_launch_sgs(const fg_state* s, const FgBounds& bnd, fg_real coefficient, fg_real* out, hipStream_t st) {
+    const dim3 grid((s->grid.n + FG_BLOCK - 1) / FG_BLOCK, s->grid.B);
+    if (s->grid.dims == 2) hipLaunchKernelGGL(k_sgs_smagorinsky<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, (const fg_real*)s->velocity, coefficient, out);
+    else hipLaunchKernelGGL(k_sgs_smagorinsky<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, (const fg_real*)s->velocity, coefficient, out);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

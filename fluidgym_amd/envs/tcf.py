@@ -21,8 +21,9 @@ Mirrors ``envs/tcf/tcf_env.py`` (``TCF3DBottomEnv`` :94-1063, ``TCF3DBothEnv`` :
 * solver: adaptive CFL 0.1, advection and pressure tol 1e-6, 2 correctors (``:478-500``).
 
 Deviations: the reference's curl-simplex-noise initial perturbation (a separate CUDA extension, ``extensions/noise``)
-is replaced by Gaussian noise made discretely divergence-free; Smagorinsky SGS viscosity (``C_smag != 0``, off in every
-registered id) is not built; no published initial domains / statistics (no network).
+is replaced by Gaussian noise made discretely divergence-free; no published initial domains / statistics (no network).
+The Smagorinsky sub-grid viscosity (``C_smag != 0``, ``use_van_driest``: off in every registered id) runs as the reference's ``PRE``
+hook on ``fg_sgs_smagorinsky`` and a per-cell viscosity field (``Block.setViscosity``).
 """
 from __future__ import annotations
 
@@ -52,7 +53,7 @@ SMALL_TCF_3D_DEFAULT_CONFIG = {
     "local_reward_weight": 0.0,
     "use_marl": True,   # tcf_env.py:73
     "init_with_noise": True,
-    "C_smag": 0.0,            # (only 0 / False are built: tcf_env.py:441-474 is the Smagorinsky model)
+    "C_smag": 0.0,            # Smagorinsky coefficient (tcf_env.py:441-474); 0 = no sub-grid model (every registered id)
     "use_van_driest": False,
     "dtype": torch.float32,
     "load_initial_domain": True,
@@ -83,8 +84,8 @@ class TCF3DBottomEnv(FluidEnv):
     def __init__(self, resolution_y, resolution_x_z, actor_size, L, D, reynolds_number_wall, adaptive_cfl, step_length,
                  episode_length, init_with_noise=True, resolution_x=None, resolution_z=None, C_smag: float = 0.0,
                  use_van_driest: bool = False, local_obs_window: int = 1, local_reward_weight: float = 0.0, dt=None, **kw):
-        if C_smag != 0.0 or use_van_driest:
-            raise NotImplementedError("Smagorinsky SGS viscosity (tcf_env.py:441-474) is not built")
+        # Smagorinsky sub-grid viscosity (tcf_env.py:441-474): off in every registered id (C_smag = 0); built since round 3
+        self._C_smag, self._use_van_driest = float(C_smag), bool(use_van_driest)
         self._L, self._D = float(L), float(D)
         self._re_wall = float(reynolds_number_wall)
         self._re_center = (self._re_wall / 0.116) ** (1 / 0.88)   # TCF_tools.Re_wall_to_cl
@@ -206,7 +207,23 @@ class TCF3DBottomEnv(FluidEnv):
             tau_b, tau_t = self._get_wall_stress()   # [B] each
             self._block.velocitySource[:, 0] = (0.5 * (tau_b + tau_t)).view(-1, 1, 1, 1)
 
-        return {"PRE": [forcing]}
+        hooks = [forcing]
+        if self._C_smag != 0.0:
+            # tcf_env.py:441-474: every (sub)step the block's viscosity = nu + C Delta^2 |S| (x the squared van Driest damping
+            # (1 - exp(-y+ / 25))^2 of the wall distance, util.py:75-125), computed from the current velocity
+            cache = {}
+
+            def add_block_sgs_viscosity(domain, **kw):
+                visc = domain.solver.sgs_smagorinsky(self._C_smag)
+                if self._use_van_driest:
+                    if "vd2" not in cache:      # (the cell centres exist once _additional_initialization has run)
+                        y_plus = (1.0 - self._y_centers.abs()) * (self._u_wall / self._nu)                      # [Y]
+                        cache["vd2"] = ((1.0 - torch.exp(-y_plus / 25.0)) ** 2).to(visc.dtype).view(1, 1, -1, 1)   # over [B, Z, Y, X]
+                    visc = visc * cache["vd2"]
+                self._block.setViscosity(visc + self._nu)
+
+            hooks.append(add_block_sgs_viscosity)
+        return {"PRE": hooks}
 
     def _get_simulation(self, domain, prep_fn) -> Simulation:
         return Simulation(domain=domain, prep_fn=prep_fn, substeps="ADAPTIVE", adaptive_CFL=self._adaptive_cfl,

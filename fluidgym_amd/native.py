@@ -83,6 +83,7 @@ class NativeSolver:
         self.viscosity = 0.0
         # fields
         self.velocity = self.pressure = self.scalar = self.velocity_source = None
+        self.viscosity_field = None
         self.bvel: Dict[int, torch.Tensor] = {}
         self.bscal: Dict[int, torch.Tensor] = {}
         self._dt = torch.zeros(self.B, dtype=dtype, device=self.device)
@@ -162,6 +163,19 @@ class NativeSolver:
     def set_velocity_source(self, t):
         self.velocity_source = t
         self.bind(L.FG_VELOCITY_SOURCE, t)
+
+    def set_viscosity_field(self, t: Optional[torch.Tensor]):
+        """Per-cell viscosity ``[B, *grid]`` of the velocity system (``Block.setViscosity``: the SGS hook of the TCF env), or None
+        for the global one.  The tensor is bound, not copied: writing into it changes the next step's matrix."""
+        self.viscosity_field = t
+        self.bind(L.FG_VISCOSITY_FIELD, t)
+
+    def sgs_smagorinsky(self, coefficient: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``SGSviscosityIncompressibleSmagorinsky`` of the bound velocity: ``[B, *grid]`` (``fg_sgs_smagorinsky``)."""
+        if out is None:
+            out = torch.empty((self.B,) + tuple(self.spatial), dtype=self.dtype, device=self.device)
+        L.check(self.lib.fg_sgs_smagorinsky(self.handle, float(coefficient), _ptr(out), _stream(self.device)), lib=self.lib)
+        return out
 
     def set_boundary_velocity(self, face, t):
         self.bvel[face] = t

@@ -214,6 +214,27 @@ class Block:
             sol.set_velocity_source(torch.zeros_like(sol.velocity))
         _bcast_into(sol.velocity_source, s)
 
+    def setViscosity(self, visc: Optional[torch.Tensor]):
+        """``Block.setViscosity``: a per-cell viscosity of the velocity system, ``[1 | B, 1, (Z,) Y, X]`` (the reference's layout) or
+        ``[B, (Z,) Y, X]``; None returns to the domain's viscosity.  Used by the Smagorinsky hook of the TCF env
+        (tcf_env.py:441-474; the kernels read it through getViscosityBlock, PISO_multiblock_cuda_kernel.cu:1816-1837)."""
+        sol = self.domain.solver
+        if sol is None:
+            raise RuntimeError("setViscosity: PrepareSolve() first")
+        if visc is None:
+            sol.set_viscosity_field(None)
+            return
+        if getattr(sol, "viscosity_field", None) is None:
+            sol.set_viscosity_field(torch.empty((sol.B,) + tuple(sol.spatial), dtype=sol.dtype, device=sol.device))
+        v = visc.to(sol.device, sol.dtype)
+        if v.dim() == len(sol.spatial) + 2:      # NCDHW with C = 1
+            v = v[:, 0]
+        sol.viscosity_field.copy_(v.expand_as(sol.viscosity_field))
+
+    @property
+    def viscosity(self) -> Optional[torch.Tensor]:
+        return getattr(self.domain.solver, "viscosity_field", None)
+
     # ---- geometry -------------------------------------------------------------------------
     def getSizes(self):
         s = self.domain.solver

@@ -72,6 +72,8 @@ enum fg_field {
     FG_PRESSURE = 1,       /* block.pressure           [B,N]                        */
     FG_SCALAR = 2,         /* block.passiveScalar      [B,C,N]                      */
     FG_VELOCITY_SOURCE = 3,/* block.velocitySource     [B,d,N] (NULL = none)        */
+    FG_VISCOSITY_FIELD = 4,/* block.viscosity          [B,N] per-cell viscosity of the velocity system (NULL = the global one): Block.setViscosity
+                              of the reference's SGS hook (tcf_env.py:441-474; getViscosityBlock, PISO_multiblock_cuda_kernel.cu:1816-1837) */
     FG_BOUND_VELOCITY = 8, /* + face: FixedBoundary.velocity      [B,d,slab]        */
     FG_BOUND_SCALAR = 16   /* + face: FixedBoundary.passiveScalar [B,C,slab]        */
 };
@@ -181,6 +183,10 @@ int fg_solve_advection(fg_handle h, int for_scalar, int channel, fg_real tol, in
  * own preconditioner, ILU(0) of the matrix (csrc/fg_ilu0.hip: closed form on the stencil, hyperplane sweeps; every axis >= 4 cells).
  * fg_advection_retries: number of repeated solves since the last reset. */
 int fg_set_advection_preconditioner(fg_handle h, int mode);
+/* SGSviscosityIncompressibleSmagorinsky (PISO_multiblock_cuda_kernel.cu:6913-6966): out[B,N] = coefficient * Delta^2 * |S| with
+ * |S| = sqrt(2 S:S) from the gradients of the bound velocity (getBlockDataGradient, :2997-3040: central differences, a Dirichlet face
+ * counts as half a cell) and Delta^2 = the largest squared cell extent.  Asynchronous on `stream`. */
+int fg_sgs_smagorinsky(fg_handle h, fg_real coefficient, fg_real* out_BN, void* stream);
 /* Test / diagnosis entry, never on a step path: z = M^-1 r [B, nc, N] with the preconditioner of `mode` (1: y-line, 4: ILU(0)) built from
  * the advection-diffusion matrix currently assembled (fg_setup_advection).  Synchronises. */
 int fg_debug_apply_preconditioner(fg_handle h, int mode, int nc, const fg_real* r, fg_real* z, void* stream);

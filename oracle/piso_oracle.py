@@ -252,6 +252,8 @@ class Domain:
     scalar: Optional[np.ndarray] = None  # [C, cells]
     scalar_viscosity: Optional[Sequence[float]] = None  # per channel (or length 1)
     velocity_source: Optional[np.ndarray] = None  # [d] or [d, cells]
+    # per-cell viscosity of the velocity system (Block.setViscosity; getViscosityBlock, K.cu:1816-1837): [cells] or None = `viscosity`
+    viscosity_field: Optional[np.ndarray] = None
     # solver vectors kept between steps (domain.velocityResult / pressureResult)
     velocity_result: Optional[np.ndarray] = None
     pressure_result: Optional[np.ndarray] = None
@@ -428,6 +430,8 @@ def build_advection_matrix(dom: Domain, dt: float, for_scalar: bool = False, cha
     """
     g = dom.grid
     nu = dom.kappa(channel) if for_scalar else dom.viscosity
+    if not for_scalar and dom.viscosity_field is not None:   # per-cell viscosity of the velocity system (:3698, 3742)
+        nu = np.asarray(dom.viscosity_field, dtype=g.det.dtype).reshape(g.shape)
     F = compute_fluxes(dom, dom.velocity)
     diag = g.det / dt
     offs, valid = [], []
@@ -436,7 +440,7 @@ def build_advection_matrix(dom: Domain, dt: float, for_scalar: bool = False, cha
         al_p = g.alpha(a)
         al_n = _nbr(al_p, a, s)
         presc = _prescribed(dom, f)
-        visc = 0.5 * (al_p * nu + al_n * nu)
+        visc = 0.5 * (al_p * nu + al_n * (_nbr(nu, a, s) if isinstance(nu, np.ndarray) else nu))   # (:3745)
         ff = s * 0.5 * F[f]
         if dom.is_fixed(f):
             if for_scalar:
@@ -480,7 +484,9 @@ def _boundary_source_velocity(dom: Domain) -> np.ndarray:
         flux = g.contravariant_b(ub, f) * s
         alpha = g.alpha_b(f)
         slip = 0.0
-        term = -ub * flux + ub * (1.0 - slip) * dom.viscosity * 2.0 * alpha
+        # getViscosityFixedBoundary = the adjacent cell's viscosity (K.cu:1840-1843, 4342)
+        nu_b = dom.viscosity if dom.viscosity_field is None else _cells_slab(g, f, np.asarray(dom.viscosity_field).reshape(g.shape))
+        term = -ub * flux + ub * (1.0 - slip) * nu_b * 2.0 * alpha
         acc = acc + _slab_to_cells(g, f, term)
     return acc
 
@@ -844,6 +850,44 @@ def piso_split_step(dom: Domain, dt: float, opts: SolverOptions = SolverOptions(
     log("CopyVelocityResultToBlocks")
     run("POST")
     return out
+
+
+def velocity_gradient(dom: Domain) -> np.ndarray:
+    """``getBlockDataGradient`` for the velocity components (K.cu:2997-3040): ``grad[i, a]`` = d u_i / d x_a per cell.  Along
+    every axis (value above - value below) / distance in index space -- a neighbour cell counts 1, a FIXED (Dirichlet) face its
+    boundary value at 0.5 -- then ``dataGrad @ Minv`` (rectilinear: / h_a)."""
+    g = dom.grid
+    d = g.dims
+    grad = np.zeros((d, d) + g.shape, dtype=dom.velocity.dtype)
+    u = dom.velocity.reshape((d,) + g.shape)
+    for a in range(d):
+        diff = np.zeros_like(u)
+        dist = np.full(g.shape, 2.0)
+        for up in (0, 1):
+            f, s = 2 * a + up, (1 if up else -1)
+            val = _nbr(u, a, s)                                   # [d, cells]: the neighbour cell (periodic wrap)
+            if dom.is_fixed(f):
+                at = _at_bound(g, f)
+                val = np.where(at, _slab_to_cells(g, f, dom.bvel(f)), val)
+                dist = dist - 0.5 * at
+            diff = diff + s * val
+        grad[:, a] = diff / dist * g.Minv[..., a, a]      # dataGrad @ Minv with a diagonal Minv
+    return grad
+
+
+def sgs_smagorinsky(dom: Domain, coefficient: float) -> np.ndarray:
+    """``SGSviscosityIncompressibleSmagorinsky`` (K.cu:6913-6966): ``C * Delta^2 * sqrt(2 S:S)``, ``Delta^2`` the largest squared
+    column length of the cell's M (its extents on a rectilinear grid; the kernel never takes the root)."""
+    g = dom.grid
+    d = g.dims
+    grad = velocity_gradient(dom)
+    acc = np.zeros(g.shape, dtype=dom.velocity.dtype)
+    for i in range(d):
+        for j in range(i, d):
+            sij = (0.5 * (grad[i, j] + grad[j, i])) ** 2
+            acc = acc + (2.0 * sij if i != j else sij)
+    delta = np.max(np.stack([np.sum(g.M[..., :, a] ** 2, axis=-1) for a in range(d)]), axis=0)   # squared column lengths of M
+    return coefficient * delta * np.sqrt(2.0 * acc)
 
 
 def max_velocity(dom: Domain) -> float:
