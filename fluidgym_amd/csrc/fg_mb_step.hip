@@ -2645,7 +2645,9 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
     o.pre.rect4 = s->ml_rect4; o.pre.child8 = s->ml_child8;
     o.pre.n4 = s->ml_n4; o.pre.n8 = s->ml_n8; o.pre.geom_diag_sum = s->ml_geom_diag_sum;
     // the aggregate-owned layout (fg_mb.h) when its tables are installed and the matrix is the pressure matrix k_mb_pmatrix wrote
-    const bool agg = pre && s->oc_agg && s->dbg_oc_agg && !s->oc_matrix_stale && diag == s->Pdiag && off == s->Poff;
+    // (sixteen members per thread whatever the mesh: below 8 k cells the cell-ordered instances with four / eight cells per thread
+    //  are faster -- measured per iteration: 1 984 cells 8.2 against 12.8 us, 6 192 cells 11.7 against 13.6, 14 232 cells 26.9 against 14.6)
+    const bool agg = pre && s->oc_agg && s->dbg_oc_agg && !s->oc_matrix_stale && diag == s->Pdiag && off == s->Poff && n > 8 * 1024;
     o.agg.slot_cell = s->oc_slot_cell; o.agg.nbr = s->oc_nbr; o.agg.d4g = s->oc_d4g; o.agg.cnt = s->oc_cnt;
     o.agg.off4 = s->Poff4s; o.agg.diag = s->Pdiag_s; o.agg.bestx = s->oc_bestx;
 #define OC_LAUNCH_PRE(CPT_, DGR_, NBR_) do { if (pre) OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, true); else OC_LAUNCH_PM(CPT_, DGR_, 1024, NBR_, false, false); } while (0)
