@@ -54,7 +54,7 @@ class CylinderEnvBase(FluidEnv):
 
     def __init__(self, reynolds_number: float, resolution: int, dt: float, adaptive_cfl: float, step_length: float,
                  episode_length: int, lift_penalty: float = 1.0, ndims: int = 2, initial_domain_steps: Optional[int] = None,
-                 drag_reference: float = 0.0, pressure_use_BiCG: bool = False, pressure_deflation: bool = False,
+                 drag_reference: float = 0.0, pressure_use_BiCG=None, pressure_deflation: bool = False,
                  non_ortho_mode: str = "matrix", **kw):
         if ndims not in (2, 3):
             raise ValueError("ndims must be 2 or 3")
@@ -135,6 +135,11 @@ class CylinderEnvBase(FluidEnv):
                             non_ortho_flags=self._non_ortho_flags, dtype=self._dtype)
 
     def _get_simulation(self, domain, prep_fn):
+        # solver policy pressure_bicgstab_large_meshes: beyond the preconditioned on-chip CG's reach (16 384 cells) the pressure
+        # systems go to the fp64-refined BiCGStab unless the caller chose (policy.py)
+        from ..simulation.policy import get_solver_policy
+        if self._pressure_use_bicg is None:     # (None = not chosen by the caller; False = the reference's CG, 1 / 2 = BiCGStab / refined)
+            self._pressure_use_bicg = 2 if (get_solver_policy()["pressure_bicgstab_large_meshes"] and domain.n_cells > 16384) else False
         sim = MultiBlockSimulation(domain, dt=self._dt, adaptive_CFL=self._adaptive_cfl, substeps="ADAPTIVE", corrector_steps=2,
                                    pressure_tol=1e-5 if self._ndims == 2 else 5e-7, advect_non_ortho_steps=1,
                                    pressure_non_ortho_steps=1 if self._ndims == 2 else 4,

@@ -42,6 +42,13 @@ benchmark line can say which mode it ran in:
     solve halves the iterations (44 -> 21 on a synthetic RBC matrix, 11 with an alternating x / y line solve) and costs as
     much per iteration as it saves.  The ``preconditionBiCG`` / ``BiCG_precondition_fallback`` kwargs work either way.
 
+``pressure_bicgstab_large_meshes`` (default True)
+    Cylinder envs on meshes beyond the preconditioned on-chip CG (more than 16 384 cells: the ``medium`` / ``hard`` 2-D ids at
+    resolution 32 and every 3-D id): the pressure systems are solved by the fp64-refined BiCGStab (the airfoil envs' solver,
+    ``pressure_use_BiCG = 2``) instead of the reference's plain CG -- same systems, same tolerance; CG needs 100-220 iterations per
+    solve there and BiCGStab 37-44 (``CylinderJet2D-medium-v0`` x 64: 103 -> 245 env-steps/s, ``-hard``: 123 -> 248,
+    ``CylinderJet3D-easy-v0`` x 4: 3.2 -> 4.4).  ``False``, or ``pressure_use_BiCG`` given explicitly to the env, keeps the choice.
+
 ``advection_rung_preconditioner`` (default ``"line"``)
     Single-block path: which preconditioner the reference's rungs use -- ``preconditionBiCG`` (every solve) and
     ``BiCG_precondition_fallback`` (a failed solve is repeated with it).  ``"line"``: the tridiagonal part of the matrix along y
@@ -76,6 +83,7 @@ _POLICY: Dict[str, Any] = {
     "advection_line_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER", "0") not in ("0", "", "false", "False"),
     "advection_fd_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_FD_PRECONDITIONER", "auto"),
     "advection_rung_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_RUNG_PRECONDITIONER", "line"),
+    "pressure_bicgstab_large_meshes": os.environ.get("FLUIDGYM_AMD_PRESSURE_BICGSTAB_LARGE_MESHES", "1") not in ("0", "", "false", "False"),
     "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "1") not in ("0", "", "false", "False"),
 }
 

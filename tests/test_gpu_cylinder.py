@@ -280,3 +280,56 @@ def test_wall_force_kernel_is_the_tensor_form(env_id):
     assert scale > 1e-3
     assert (got - ref).abs().max().item() <= 2e-5 * scale, ((got - ref).abs().max().item(), scale)
     env.close()
+
+
+@pytest.mark.gpu
+def test_large_cylinder_meshes_take_the_refined_bicgstab_unless_told_otherwise():
+    """Solver policy ``pressure_bicgstab_large_meshes``: beyond the preconditioned on-chip CG (16 384 cells: resolution 32, the
+    medium / hard ids) the pressure solver is the fp64-refined BiCGStab; the easy id (resolution 24) and an explicit
+    ``pressure_use_BiCG=False`` keep the reference's CG.  Held from ONE common state, one sim step each way, against the same
+    step solved 100x tighter: at the envs' own tolerance (1e-5, the reference's) either solver leaves the step 0.3-0.6 % from
+    the tight one (measured: CG 2.6e-3, BiCGStab 5.7e-3), which is what separates them from each other; solved tightly the two
+    agree to 1.3e-4."""
+    import fluidgym_amd
+
+    kw = dict(num_envs=2, initial_domain_steps=40, randomize_initial_state=False)
+    env = fluidgym_amd.make("CylinderJet2D-easy-v0", **kw)
+    env.reset(seed=0)
+    assert env._sim.pressure_use_BiCG is False and env._domain.n_cells <= 16384
+    env.close()
+    envs = {}
+    for name, choice, tol in (("cg", False, None), ("bicg", None, None), ("cg_tight", False, 1e-7), ("bicg_tight", None, 1e-7)):
+        env = fluidgym_amd.make("CylinderJet2D-medium-v0", **kw, **({} if choice is None else {"pressure_use_BiCG": choice}))
+        env.reset(seed=0)
+        assert env._domain.n_cells > 16384 and env._sim.pressure_use_BiCG == (2 if choice is None else False)
+        if tol is not None:
+            env._sim.pressure_tol = tol
+        envs[name] = env
+    state = envs["cg"].get_state()
+    its = {}
+    for name, env in envs.items():
+        env.set_state(state)
+        env._domain.solver_counters(reset=True)
+        assert env._sim.single_step()
+        c = env._domain.solver_counters()
+        assert c["pressure0"]["unconverged"] == 0, name
+        its[name] = c["pressure0"]["mean"]
+    ref = envs["cg_tight"]._domain.velocity
+
+    def dist(name):
+        return float((envs[name]._domain.velocity - ref).abs().max() / ref.abs().max())
+
+    assert its["bicg"] < 0.6 * its["cg"], its                                            # far fewer iterations
+    assert dist("bicg_tight") < 1e-3, dist("bicg_tight")
+    assert dist("cg") < 1e-2 and dist("bicg") < 4 * dist("cg") + 1e-3, (dist("cg"), dist("bicg"))
+    for env in envs.values():
+        env.close()
+    kw["initial_domain_steps"] = 2
+    old = fluidgym_amd.set_solver_policy(pressure_bicgstab_large_meshes=False)
+    try:
+        env = fluidgym_amd.make("CylinderJet2D-medium-v0", **kw)
+        env.reset(seed=0)
+        assert env._sim.pressure_use_BiCG is False
+        env.close()
+    finally:
+        fluidgym_amd.set_solver_policy(**old)
