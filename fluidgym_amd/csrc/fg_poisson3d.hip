@@ -179,8 +179,11 @@ __device__ __forceinline__ double z_acc_total(const FgDacc* a, int ns) {
     return v;
 }
 
-template <int MODE, int BXL, int PPB>
-__global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 2 && PPB == 1 ? 4 : 1))) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
+// SB (PPB == 1 only): one barrier per plane instead of two -- the ring has a fourth slot, plane k+2 is committed into the slot
+// nobody reads during step k (it held plane k-2), and the barrier that ends the step both publishes it and retires plane k-1.
+// 50 KB of LDS per workgroup: three workgroups per CU, so the launch geometry aims at 768 workgroups per round (launch_march).
+template <int MODE, int BXL, int PPB, bool SB = false>
+__global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == 2 && PPB == 1 && !SB ? 4 : 1))) void k_poisson3_march(FgGrid g, Z3Args a, int tiles_x, int tiles_y, int zchunks,
                                                               int ZC) {
     constexpr int TY = ZT<BXL>::TY, LP = ZT<BXL>::LP, LROWS = ZT<BXL>::LROWS;
     const ZCtx c = z_make_ctx<BXL>(g, tiles_x, tiles_y, zchunks, ZC);
@@ -228,8 +231,9 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
     // (register pressure decides occupancy here: the register-plane variant needed 164 VGPRs = 3 waves/SIMD).  PPB = 2 halves
     // the barriers per plane and doubles the bytes a thread has in flight; plane q of a chunk lives in slot (q - k0 + 1) % NS.
     constexpr int NS = PPB + 2;
-    __shared__ __attribute__((aligned(16))) float ring_p[NS][LROWS * LP];
-    __shared__ __attribute__((aligned(16))) float ring_a[NS][LROWS * LP];
+    constexpr int NSLOT = NS + (SB ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) float ring_p[NSLOT][LROWS * LP];
+    __shared__ __attribute__((aligned(16))) float ring_a[NSLOT][LROWS * LP];
     __shared__ float red[4];
 
     const size_t env = (size_t)c.b * g.n;
@@ -425,7 +429,8 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
         }
     };
     if constexpr (PPB == 1) {   // one plane per barrier pair: three rotating slot indices, one staged plane
-        int sm = 0, sc = 1, sp = 2;
+        int sm = 0, sc = 1, sp = 2, sf = 3;
+        (void)sf;
 #pragma unroll 1
         for (int k = c.k0; k < c.k1; ++k) {
             const bool more = (k + 1 < c.k1);
@@ -438,10 +443,16 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
             __builtin_amdgcn_sched_barrier(0);
             plane(k, sm, sc, sp, bvec[0]);
             if (!more) break;
-            __syncthreads();            // every wave is done reading slot sm (plane k-1)
-            commit(sm, nxt);            // plane k+2 takes its place
-            __syncthreads();
-            const int t3 = sm; sm = sc; sc = sp; sp = t3;
+            if constexpr (SB) {
+                commit(sf, nxt);        // the free slot: last read as plane k-2, a barrier ago
+                __syncthreads();        // plane k+2 is visible; every wave is done with plane k-1
+                const int t3 = sm; sm = sc; sc = sp; sp = sf; sf = t3;
+            } else {
+                __syncthreads();            // every wave is done reading slot sm (plane k-1)
+                commit(sm, nxt);            // plane k+2 takes its place
+                __syncthreads();
+                const int t3 = sm; sm = sc; sc = sp; sp = t3;
+            }
             if constexpr (MODE == MODE_RELAX) bvec[0] = bnext;
         }
     } else
@@ -537,6 +548,37 @@ static int launch_march(const fg_state* s, const Z3Args& a, int zc, hipStream_t 
     // measured at 256^3 (profiles/zmarch_sweep.sh, r02): the Jacobi / RB-GS sweep is fastest with two planes per barrier pair
     // (55.5 us against 58.8), apply and the CG kernel with one (registers: 152-170 with two)
     constexpr int PPB = (MODE == MODE_RELAX) ? 2 : 1;
+    // Single-barrier ring (SB) for the sweep and the CG kernel: three workgroups fit a CU (50 KB of LDS each), so it pays when the
+    // launch is ONE round of 3 x CUs workgroups with balanced chunks -- 256^3: 64 tiles x 12 chunks of 22 planes = 768 workgroups,
+    // Jacobi 56.0 -> 52.2 us, CG iteration 153-155 -> 143-148 us; with any other chunk length (a second, partial round) it loses
+    // (20 planes: 72 us, 24: 55 us), and the bare apply (one round of 1024 already) gains nothing from it (49 us against 46).
+    // Most of the gain is the geometry (one full round, 9 % z-halo planes instead of 25 %); two planes in flight per thread on
+    // top of it: nothing (Jacobi 53.7 us), and in the two-barrier apply it spills (124 VGPRs at four waves already).
+    // FG_ZMARCH_SB: bit MODE forces it on with the caller's chunk length, 0 = never; unset = the rule above.
+    static const int sb_mask = [] { const char* e = getenv("FG_ZMARCH_SB"); return e ? atoi(e) : -1; }();
+    bool sb = sb_mask >= 0 && ((sb_mask >> MODE) & 1);
+    if (sb_mask < 0 && MODE != MODE_APPLY) {
+        static const int slots = [] {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+            return 3 * cus;
+        }();
+        const long layer = (long)tx * ty * g.B;                       // workgroups per layer of chunks
+        const int chunks = layer > 0 ? (int)(slots / layer) : 0;
+        if (chunks >= 2 && layer * chunks == slots) {                 // fills the round exactly
+            const int zc_sb = (g.nz + chunks - 1) / chunks;
+            if (zc_sb >= 16 && (g.nz + zc_sb - 1) / zc_sb == chunks) { sb = true; zc = zc_sb; }
+        }
+    }
+    if (sb) {
+        const int zch = (g.nz + zc - 1) / zc;
+        const dim3 grid((unsigned)(tx * ty * zch * g.B));
+        if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16, 1, true>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+        else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32, 1, true>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+        else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64, 1, true>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
+        FG_HIP_CHECK(hipGetLastError());
+        return FG_OK;
+    }
     if (bxl == 16) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 16, PPB>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
     else if (bxl == 32) FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 32, PPB>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);
     else FG_LAUNCH_P(s, slot, (k_poisson3_march<MODE, 64, PPB>), grid, dim3(FG_BLOCK), 0, st, g, a, tx, ty, zch, zc);

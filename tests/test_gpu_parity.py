@@ -356,10 +356,12 @@ def test_fd_preconditioner_matches_numpy_application():
         assert rel_err(got - got.mean(), z - z.mean()) < 2e-5
 
 
-@pytest.mark.parametrize("shape,fixed,zc", [((64, 32, 32), (1,), 8), ((128, 16, 40), (0, 1, 2), 16), ((64, 16, 33), (1, 2), 32)])
-def test_zmarch_3d_kernels_match_brick_kernels_and_oracle(shape, fixed, zc):
+@pytest.mark.parametrize("shape,fixed,zc,sb", [((64, 32, 32), (1,), 8, 0), ((128, 16, 40), (0, 1, 2), 16, 0), ((64, 16, 33), (1, 2), 32, 0),
+                                               ((64, 32, 32), (1,), 8, 7), ((128, 16, 40), (0, 1, 2), 11, 7), ((256, 8, 33), (1, 2), 32, 7), ((256, 8, 33), (1, 2), 32, 0)])
+def test_zmarch_3d_kernels_match_brick_kernels_and_oracle(shape, fixed, zc, sb):
     """The z-marching LDS/register-plane variants (fg_poisson3d.hip) against the oracle matrix: apply, Jacobi,
-    RB-GS and the CG solve.  FG_FORCE_ZMARCH makes small grids take the path that 256^3 takes by itself."""
+    RB-GS and the CG solve.  FG_FORCE_ZMARCH makes small grids take the path that 256^3 takes by itself; FG_ZMARCH_SB=7 the
+    single-barrier ring (what the sweep and the CG kernel run at 256^3) in all three modes, 0 the two-barrier one."""
     import os
     import subprocess
     import sys
@@ -398,10 +400,11 @@ for b in range(2):
     assert info[b].converged
     got = xc[b].cpu().numpy().astype(np.float64).ravel()
     res = bb - P @ got   # (no 3-D direct solve: residual of the GPU solution under the ORACLE's matrix)
-    assert np.sqrt((res ** 2).mean()) < 1e-5, "cg"
+    # (256 x 8 x 33: 2 294 iterations, over which the fp32 recurrence residual (1e-6) drifts from the true one: 1.6e-5 in either ring form)
+    assert np.sqrt((res ** 2).mean()) < (1e-5 if info[b].used_iterations < 1000 else 5e-5), ("cg", np.sqrt((res ** 2).mean()), info[b].used_iterations, info[b].final_residual)
 print("OK")
 """
-    env = dict(os.environ, FG_FORCE_ZMARCH=str(zc))
+    env = dict(os.environ, FG_FORCE_ZMARCH=str(zc), FG_ZMARCH_SB=str(sb))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)   # a fresh box pages torch in for minutes under load
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
