@@ -1103,6 +1103,77 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* 
         for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
     M.r4[(size_t)sys * M.n4 + a] = sum;
 }
+// The restriction fused with the vector update that feeds it (the preconditioned BiCGStab applies M to p and to s right after
+// forming them): the thread of an aggregate forms p (k_mbb_p4's update, convergence test and leader bookkeeping) or s (k_mbb_s4's)
+// at its own cells, stores it and sums it -- one launch instead of two, twice per iteration.  The cells of an aggregate are a
+// partition of the mesh (checked in fg_mb_set_multilevel), so every cell is written exactly once.
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, MlDev M, int it) {
+    const int ag = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y, N = D.N;
+    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+    const size_t vb = (size_t)sys * N;
+    FgDacc* a = q.acc + (size_t)sys * MB_ACC;
+    const int f = flag_ld(q.flags + (sys));
+    if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
+    if (f != 0) return;
+    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
+    if (leader) {
+        acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
+        q.info[sys].final_residual = crit;
+        q.info[sys].used_iterations = it + q.it_base - 1;
+    }
+    MB_BETA
+    if (ag >= M.n4) return;
+    const float mv = (q.project && it > 0) ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
+    const uint2 rc = M.rect4[ag];
+    const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
+    float sum = 0.f;
+    for (int dy = 0; dy < h; ++dy)
+        for (int dx = 0; dx < w; ++dx) {
+            const size_t c = vb + rc.x + dy * stride + dx;
+            float pv;
+            if (it == 0) pv = q.p[c];                       // p = r was laid down by the initialisation
+            else {
+                const float r = q.r[c];
+                if (restart) { q.rw[c] = r; pv = r; }
+                else pv = r + beta * (q.p[c] - omega * (q.v[c] - mv));
+                q.p[c] = pv;
+            }
+            sum += pv;
+        }
+    M.r4[(size_t)sys * M.n4 + ag] = sum;
+}
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, MlDev M, int it) {
+    const int ag = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y, N = D.N;
+    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+    const size_t vb = (size_t)sys * N;
+    FgDacc* a = q.acc + (size_t)sys * MB_ACC;
+    __shared__ float lds[16];
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
+    if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
+    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    float part = 0.f;
+    if (ag < M.n4) {
+        const uint2 rc = M.rect4[ag];
+        const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
+        float sum = 0.f;
+        for (int dy = 0; dy < h; ++dy)
+            for (int dx = 0; dx < w; ++dx) {
+                const size_t c = vb + rc.x + dy * stride + dx;
+                const float sv = q.r[c] - alpha * (q.v[c] - mv);
+                q.r[c] = sv;
+                part += sv * sv;
+                sum += sv;
+            }
+        M.r4[(size_t)sys * M.n4 + ag] = sum;
+    }
+    part = mb_block_sum(part, lds);
+    if (threadIdx.x == 0) acc_add(a + A_SS, (double)part);
+}
 constexpr int ML_N8_MAX = 2048, ML_SB = 4, ML_ROWS = 16, ML_CG = 64;   // coarse solve: systems and rows per workgroup, column groups
 // One workgroup = 16 rows of A8^+ x ML_SB systems; its 1024 threads are 16 rows x 64 column groups (a thread streams 1 / 64 of its
 // row -- by columns, the matrix is symmetric --: 12 loads at Airfoil2D's 771 aggregates, all in flight at once), partial sums meet
@@ -2350,13 +2421,23 @@ template <typename T>
 int mb_alloc(fg_mb_state* s, T** p, size_t count);
 
 // z = M in for every system still iterating (kernel form of the multilevel preconditioner; pressure systems, nc == 1)
-void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st) {
+MlDev mb_ml_dev(const fg_mb_state* s) {
     MlDev M;
     M.a4 = s->ml_a4; M.parent4 = s->ml_parent4; M.rect4 = s->ml_rect4; M.child8 = s->ml_child8; M.rd4 = s->ml_d4g; M.aci8 = s->ml_aci8;
     M.n4 = s->ml_n4; M.n8 = s->ml_n8; M.ld8 = (s->ml_n8 + 3) & ~3;
     M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale;
+    return M;
+}
+// fused = 0: z = M in.  1 / 2: `in` is q.p / q.r and its update (k_mbb_p4 / k_mbb_s4) happens inside the restriction
+// (k_ml_restrict_p / _s), iteration index `it`.
+void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st, int fused = 0, int it = 0) {
+    const MlDev M = mb_ml_dev(s);
     const int nsys = s->B * q.nc, n = s->N;
-    hipLaunchKernelGGL(k_ml_restrict, dim3((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
+    const dim3 rgrid((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
+    if (fused == 1) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_p<DIMS>, rgrid, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
+    else if (fused == 2) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_s<DIMS>, rgrid, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
+    else
+    hipLaunchKernelGGL(k_ml_restrict, rgrid, dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
     hipLaunchKernelGGL(k_ml_coarse, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + ML_SB - 1) / ML_SB), dim3(ML_ROWS * ML_CG), 0, st, M, q.nc, nsys, (const int32_t*)q.flags);
     hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out);
 }
@@ -2451,6 +2532,11 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // s and t in one launch unless the recurrence is right-preconditioned (t = A M s needs all of s first); FG_MB_BICG_FUSE=0
     // (read at create) keeps the two kernels
     const bool fused_st = !ml && s->dbg_fuse_st >= 1, fused_pv = !ml && s->dbg_fuse_st >= 2;
+    // multilevel: p and s are formed inside the restriction that follows them -- two launches fewer per iteration, which pays
+    // while the launches are latency-sized (Airfoil2D x 16: 32.3-33.9 -> 34.7-34.8 env-steps/s) and not once they carry bytes
+    // (x 64: 63.0 -> 62.4; an aggregate's thread walks its 4 x 4 cells in 16-byte pieces).  So: up to 32 systems.
+    // FG_MB_ML_FUSE=0 never, 2 always.
+    const bool ml_fused = ml && !ilu && (s->dbg_ml_fuse == 2 || (s->dbg_ml_fuse == 1 && nsys <= 32));
     if (fused_st) q.sbuf = s->w[5];
     const bool verify = ml || refine;
     int verify_rounds = 0;
@@ -2494,17 +2580,19 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             if (fused_pv) {
                 if ((vec_mask & 3) == 3) hipLaunchKernelGGL(k_mbb_pv4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_pv<DIMS>, grid, blk, 0, st, s->dev, q, li);
             } else {
-            if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (ml_fused) {}   // p is formed inside the restriction (mb_ml_apply below)
+            else if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
             if (ilu) mb_ilu_apply(s, q, q.p, s->ilu_mp, st);
-            else if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st);
+            else if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st, ml_fused ? 1 : 0, li);
             if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
             }
             if (fused_st) {
                 if ((vec_mask & 12) == 12) hipLaunchKernelGGL(k_mbb_st4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_st<DIMS>, grid, blk, 0, st, s->dev, q, li);
             } else {
-                if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                if (ml_fused) {}   // s is formed inside the restriction
+                else if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
                 if (ilu) mb_ilu_apply(s, q, q.r, s->ilu_ms, st);
-                else if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st);
+                else if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st, ml_fused ? 2 : 0, li);
                 if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
             }
             if (vec_mask & 16) hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
@@ -2852,6 +2940,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
         e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = e ? atoi(e) : 2;   // 0 five kernels, 1 s / t fused, 2 also p / v (default)
         e = getenv("FG_MB_PRED"); s->dbg_pred = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_ML_FUSE"); s->dbg_ml_fuse = e ? atoi(e) : 1;
         e = getenv("FG_MB_ML_TRY_CAP"); if (e && atoi(e) > 0) s->dbg_ml_cap = atoi(e);
         e = getenv("FG_MB_ML_WARMUP"); if (e && atoi(e) > 0) { s->dbg_ml_warmup = atoi(e); s->ml_bicg_skip = s->dbg_ml_warmup; }
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;

@@ -141,6 +141,31 @@ def test_multilevel_trial_of_the_pressure_bicgstab(monkeypatch):
     assert np.isfinite(drag).all() and np.isfinite(drag2).all()    # (the forces of the two runs are NOT compared: policy.py)
 
 
+def test_restriction_fused_with_the_vector_updates_is_the_separate_launches(monkeypatch):
+    """Preconditioned pressure BiCGStab: p and s formed inside the restriction of the multilevel preconditioner
+    (k_ml_restrict_p / _s, the default up to 32 systems) against k_mbb_p4 / _s4 followed by k_ml_restrict (FG_MB_ML_FUSE=0, what
+    larger batches run).  p and the restricted sums are the same numbers; only s.s is summed in another grouping, so the two runs
+    agree to the solver tolerance, with the same number of attempts and nearly the same iteration counts."""
+    out = {}
+    for fuse in ("0", "2"):
+        monkeypatch.setenv("FG_MB_ML_FUSE", fuse)        # read once per handle, at fg_mb_create
+        env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=2, **dict(KW, initial_domain_steps=4))
+        env.reset(seed=3)
+        env._domain.solver_counters(reset=True)
+        _, _, _, _, info = env.step(torch.zeros(2, 3, device="cuda"))
+        out[fuse] = (env._domain.velocity.clone(), env._domain.pressure.clone(), env._domain.solver_counters(), env._domain.multilevel_status(),
+                     info["drag"].clone(), env._domain.env_status().copy())
+        env.close()
+    (u0, p0, c0, st0, d0, s0), (u1, p1, c1, st1, d1, s1) = out["0"], out["2"]
+    assert (s0 == 0).all() and (s1 == 0).all()
+    assert st0["attempts"] == st1["attempts"] > 10 and st1["failed_attempts"] <= 4, (st0, st1)
+    for k in ("pressure0", "pressure1"):
+        assert c1[k]["unconverged"] == 0 and abs(c1[k]["mean"] - c0[k]["mean"]) < 0.1 * c0[k]["mean"], (c0[k], c1[k])
+    assert float((u1 - u0).abs().max() / u0.abs().max()) < 1e-3
+    assert float((p1 - p0).abs().max() / p0.abs().max()) < 1e-2
+    assert torch.allclose(d0, d1, rtol=2e-3)
+
+
 KW3 = dict(initial_domain_steps=4, randomize_initial_state=False, episode_length=2, resolution_div=4, res_z=8, n_agents=4)
 
 
