@@ -166,6 +166,7 @@ struct fg_mb_state {
     int dbg_ml_cap = 200;   // FG_MB_ML_TRY_CAP: iteration cap of a multilevel-preconditioned pressure BiCGStab attempt (tests: a tiny cap makes every attempt fail)
     int dbg_fuse_st = 2;   // FG_MB_BICG_FUSE: 0 five BiCGStab kernels, 1 s / t fused (k_mbb_st), 2 also p / v (k_mbb_pv; default)
     int dbg_ml_fuse = 1;   // FG_MB_ML_FUSE: multilevel BiCGStab forms p / s inside the restriction -- 0 never, 1 up to 32 systems (default), 2 always
+    int dbg_ml_sb = 0;     // FG_MB_ML_SB: systems per workgroup of k_ml_coarse (4 / 8; 0 = 8 from 32 systems on)
     int dbg_pred = 1;      // FG_MB_PRED=0: first convergence poll after two iterations instead of where the previous solve finished
     // per-env outcome of the last fg_mb_piso_step / fg_mb_single_step: 0 ok, 1 a solve ended unconverged (best iterate used),
     // 2 a solve was non-finite: that env's step was NOT committed (state as before the step), the other envs completed

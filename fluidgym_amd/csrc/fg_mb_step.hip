@@ -1174,21 +1174,27 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, 
     part = mb_block_sum(part, lds);
     if (threadIdx.x == 0) acc_add(a + A_SS, (double)part);
 }
-constexpr int ML_N8_MAX = 2048, ML_SB = 4, ML_ROWS = 16, ML_CG = 64;   // coarse solve: systems and rows per workgroup, column groups
-// One workgroup = 16 rows of A8^+ x ML_SB systems; its 1024 threads are 16 rows x 64 column groups (a thread streams 1 / 64 of its
+constexpr int ML_N8_MAX = 2048, ML_ROWS = 16, ML_CG = 64;   // coarse solve: rows per workgroup, column groups
+// One workgroup = 16 rows of A8^+ x SB systems; its 1024 threads are 16 rows x 64 column groups (a thread streams 1 / 64 of its
 // row -- by columns, the matrix is symmetric --: 12 loads at Airfoil2D's 771 aggregates, all in flight at once), partial sums meet
 // in LDS.  49 x 4 workgroups at 771 aggregates x 16 envs; with 64 rows per workgroup (13 x 4 workgroups, 49 dependent-latency
 // loads per thread) the kernel took 12.3 us and was the largest single item of the preconditioned airfoil step.
-__global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags) {
-    __shared__ float l_r8[ML_SB][ML_N8_MAX];
-    __shared__ float l_part[ML_CG][ML_SB][ML_ROWS];
-    const int sys0 = blockIdx.y * ML_SB, r = threadIdx.x & (ML_ROWS - 1), cg = threadIdx.x / ML_ROWS;
-    bool on[ML_SB], any = false;
+// SB systems per workgroup (template): the matrix rows a workgroup streams serve SB right-hand sides, so 8 halve the L2 traffic of
+// 4 once there are enough systems to fill the chip either way (mb_ml_apply picks).  LDS is sized to the mesh (n8p = n8 rounded up):
+// r8 [SB][n8p] (re-used by the second folding stage, which needs 4 SB ROWS floats) and the partial sums [CG][SB][ROWS].
+template <int SB>
+__global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags, int n8p) {
+    extern __shared__ float l_dyn[];
+    float* l_r8 = l_dyn;
+    const int r8_words = SB * n8p > 4 * SB * ML_ROWS ? SB * n8p : 4 * SB * ML_ROWS;
+    float* l_part = l_dyn + r8_words;                  // [ML_CG][SB][ML_ROWS]
+    const int sys0 = blockIdx.y * SB, r = threadIdx.x & (ML_ROWS - 1), cg = threadIdx.x / ML_ROWS;
+    bool on[SB], any = false;
 #pragma unroll
-    for (int k = 0; k < ML_SB; ++k) { on[k] = sys0 + k < nsys && flag_ld(flags + sys0 + k) == 0; any = any || on[k]; }
+    for (int k = 0; k < SB; ++k) { on[k] = sys0 + k < nsys && flag_ld(flags + sys0 + k) == 0; any = any || on[k]; }
     if (!any) return;
 #pragma unroll
-    for (int k = 0; k < ML_SB; ++k) {
+    for (int k = 0; k < SB; ++k) {
         const float* r4 = M.r4 + (size_t)(sys0 + k) * M.n4;
         for (int g = threadIdx.x; g < M.n8; g += ML_ROWS * ML_CG) {
             float sum = 0.f;
@@ -1198,40 +1204,42 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
 #pragma unroll
                 for (int c = 0; c < 4; ++c) if (ids[c] != 0xffffu) sum += r4[ids[c]];
             }
-            l_r8[k][g] = sum;
+            l_r8[k * n8p + g] = sum;
         }
     }
     __syncthreads();
     const int row = blockIdx.x * ML_ROWS + r;
-    float acc[ML_SB] = {0.f, 0.f, 0.f, 0.f};
+    float acc[SB];
+#pragma unroll
+    for (int k = 0; k < SB; ++k) acc[k] = 0.f;
     if (row < M.n8) {
         const float* col = M.aci8 + row;
 #pragma unroll 4
         for (int j = cg; j < M.n8; j += ML_CG) {      // column groups interleave: a wave's four groups read four adjacent matrix rows
             const float m = col[(size_t)j * M.ld8];
 #pragma unroll
-            for (int k = 0; k < ML_SB; ++k) acc[k] += m * l_r8[k][j];
+            for (int k = 0; k < SB; ++k) acc[k] += m * l_r8[k * n8p + j];
         }
     }
 #pragma unroll
-    for (int k = 0; k < ML_SB; ++k) l_part[cg][k][r] = acc[k];
+    for (int k = 0; k < SB; ++k) l_part[(cg * SB + k) * ML_ROWS + r] = acc[k];
     __syncthreads();
-    // 64 partial sums per (system, row), folded in two stages: thread t < 256 = (quarter t / 64, system t / 16 % 4, row t % 16)
-    if (threadIdx.x < ML_SB * ML_ROWS * 4) {
-        const int rr = threadIdx.x & (ML_ROWS - 1), k = (threadIdx.x / ML_ROWS) & (ML_SB - 1), quarter = threadIdx.x / (ML_SB * ML_ROWS);
+    // 64 partial sums per (system, row), folded in two stages: thread t < 4 SB ROWS = (quarter t / (SB ROWS), system t / ROWS % SB, row t % ROWS)
+    if (threadIdx.x < SB * ML_ROWS * 4) {
+        const int rr = threadIdx.x & (ML_ROWS - 1), k = (threadIdx.x / ML_ROWS) & (SB - 1), quarter = threadIdx.x / (SB * ML_ROWS);
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < ML_CG / 4; ++w) t += l_part[quarter * (ML_CG / 4) + w][k][rr];
-        l_r8[0][threadIdx.x] = t;     // second stage in the (now free) r8 buffer: [quarter][system][row] = thread index
+        for (int w = 0; w < ML_CG / 4; ++w) t += l_part[((quarter * (ML_CG / 4) + w) * SB + k) * ML_ROWS + rr];
+        l_r8[threadIdx.x] = t;     // second stage in the (now free) r8 buffer: [quarter][system][row] = thread index
     }
     __syncthreads();
-    if (threadIdx.x < ML_SB * ML_ROWS) {
+    if (threadIdx.x < SB * ML_ROWS) {
         const int rr = threadIdx.x & (ML_ROWS - 1), k = threadIdx.x / ML_ROWS;
         const int orow = blockIdx.x * ML_ROWS + rr;
-        constexpr int Q = ML_SB * ML_ROWS;
-        if (orow < M.n8 && on[k])
+        constexpr int Q = SB * ML_ROWS;
+        if (orow < M.n8 && sys0 + k < nsys && flag_ld(flags + sys0 + k) == 0)
             M.z8[(size_t)(sys0 + k) * M.n8 + orow] =
-                (l_r8[0][threadIdx.x] + l_r8[0][Q + threadIdx.x] + l_r8[0][2 * Q + threadIdx.x] + l_r8[0][3 * Q + threadIdx.x]) * M.scale_inv[(sys0 + k) / nc];
+                (l_r8[threadIdx.x] + l_r8[Q + threadIdx.x] + l_r8[2 * Q + threadIdx.x] + l_r8[3 * Q + threadIdx.x]) * M.scale_inv[(sys0 + k) / nc];
     }
 }
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const float* __restrict__ in, const float* __restrict__ diag, int N, int nc,
@@ -2438,7 +2446,16 @@ void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, 
     else if (fused == 2) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_s<DIMS>, rgrid, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
     else
     hipLaunchKernelGGL(k_ml_restrict, rgrid, dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
-    hipLaunchKernelGGL(k_ml_coarse, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + ML_SB - 1) / ML_SB), dim3(ML_ROWS * ML_CG), 0, st, M, q.nc, nsys, (const int32_t*)q.flags);
+    {
+        // systems per workgroup: 8 when that still leaves >= 2 workgroups per CU-pair of work (>= 32 systems) and the LDS fits 64 KB
+        const int n8p = (M.n8 + 3) & ~3;
+        const auto words = [&](int sb) { return (sb * n8p > 4 * sb * ML_ROWS ? sb * n8p : 4 * sb * ML_ROWS) + ML_CG * sb * ML_ROWS; };
+        const int want = s->dbg_ml_sb ? s->dbg_ml_sb : (nsys >= 32 ? 8 : 4);
+        if (want == 8 && words(8) * 4 <= 64 * 1024)
+            hipLaunchKernelGGL(k_ml_coarse<8>, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + 7) / 8), dim3(ML_ROWS * ML_CG), (size_t)words(8) * 4, st, M, q.nc, nsys, (const int32_t*)q.flags, n8p);
+        else
+            hipLaunchKernelGGL(k_ml_coarse<4>, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + 3) / 4), dim3(ML_ROWS * ML_CG), (size_t)words(4) * 4, st, M, q.nc, nsys, (const int32_t*)q.flags, n8p);
+    }
     hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out);
 }
 
@@ -2941,6 +2958,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = e ? atoi(e) : 2;   // 0 five kernels, 1 s / t fused, 2 also p / v (default)
         e = getenv("FG_MB_PRED"); s->dbg_pred = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_ML_FUSE"); s->dbg_ml_fuse = e ? atoi(e) : 1;
+        e = getenv("FG_MB_ML_SB"); s->dbg_ml_sb = e ? atoi(e) : 0;   // systems per workgroup of k_ml_coarse: 4 / 8, 0 = by batch size
         e = getenv("FG_MB_ML_TRY_CAP"); if (e && atoi(e) > 0) s->dbg_ml_cap = atoi(e);
         e = getenv("FG_MB_ML_WARMUP"); if (e && atoi(e) > 0) { s->dbg_ml_warmup = atoi(e); s->ml_bicg_skip = s->dbg_ml_warmup; }
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
