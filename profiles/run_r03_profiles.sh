@@ -10,8 +10,8 @@ if [ "$1" = "mb" ]; then   # only the kernel statistics of the cylinder and airf
   rocprofv3 --kernel-trace --stats -d $O/p_cyl -o cyl -- python3 $R/profiles/cylinder_modes.py 64 2 1-0-1 > $O/p_cyl.log 2>&1
   python3 $R/profiles/summarize_rocpd.py "$(find $O/p_cyl -name '*.db' | head -1)" $O/r03_c_cylinder_kernel_stats.csv > /dev/null
   rocprofv3 --kernel-trace --stats -d $O/p_air -o air -- python3 $R/profiles/airfoil_bench.py 16 1 40 > $O/p_air.log 2>&1
-  python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air -name '*.db' | head -1)" $O/r03_d_airfoil_kernel_stats.csv > /dev/null
-  rm -rf $O/p_cyl $O/p_air; tail -2 $O/p_cyl.log $O/p_air.log; ls -la $O/r03_c_* $O/r03_d_*; exit 0
+  python3 $R/profiles/summarize_rocpd.py "$(find $O/p_air -name '*.db' | head -1)" $O/r03_e_airfoil_trial_kernel_stats.csv > /dev/null   # (default policy = with the trial: the r03_e file)
+  rm -rf $O/p_cyl $O/p_air; tail -n 2 $O/p_cyl.log; tail -n 2 $O/p_air.log; ls -la $O/r03_c_* $O/r03_e_*; exit 0
 fi
 rocprofv3 --kernel-trace --stats -d $O/p_stats -o bench -- $BENCH > $O/p_stats.log 2>&1
 python3 $R/profiles/summarize_rocpd.py "$(find $O/p_stats -name '*.db' | head -1)" $O/r03_a_bench_kernel_stats.csv > /dev/null
