@@ -1107,9 +1107,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* 
 // forming them): the thread of an aggregate forms p (k_mbb_p4's update, convergence test and leader bookkeeping) or s (k_mbb_s4's)
 // at its own cells, stores it and sums it -- one launch instead of two, twice per iteration.  The cells of an aggregate are a
 // partition of the mesh (checked in fg_mb_set_multilevel), so every cell is written exactly once.
+// (four threads per aggregate, one per row of its rectangle: a thread's cells are one contiguous run, and the four row sums meet in a
+//  fixed order)
+__device__ __forceinline__ float ml_quad_sum(float v) {
+    const int base = (threadIdx.x & 63) & ~3;
+    const float s0 = __shfl(v, base, 64), s1 = __shfl(v, base + 1, 64), s2 = __shfl(v, base + 2, 64), s3 = __shfl(v, base + 3, 64);
+    return ((s0 + s1) + s2) + s3;
+}
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, MlDev M, int it) {
-    const int ag = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y, N = D.N;
+    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, ag = tq >> 2, row = tq & 3, sys = blockIdx.y, N = D.N;
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
@@ -1124,29 +1131,31 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, 
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
     MB_BETA
-    if (ag >= M.n4) return;
     const float mv = (q.project && it > 0) ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
-    const uint2 rc = M.rect4[ag];
-    const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
     float sum = 0.f;
-    for (int dy = 0; dy < h; ++dy)
-        for (int dx = 0; dx < w; ++dx) {
-            const size_t c = vb + rc.x + dy * stride + dx;
-            float pv;
-            if (it == 0) pv = q.p[c];                       // p = r was laid down by the initialisation
-            else {
-                const float r = q.r[c];
-                if (restart) { q.rw[c] = r; pv = r; }
-                else pv = r + beta * (q.p[c] - omega * (q.v[c] - mv));
-                q.p[c] = pv;
+    if (ag < M.n4) {
+        const uint2 rc = M.rect4[ag];
+        const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
+        for (int dy = row; dy < h; dy += 4)
+            for (int dx = 0; dx < w; ++dx) {
+                const size_t c = vb + rc.x + dy * stride + dx;
+                float pv;
+                if (it == 0) pv = q.p[c];                       // p = r was laid down by the initialisation
+                else {
+                    const float r = q.r[c];
+                    if (restart) { q.rw[c] = r; pv = r; }
+                    else pv = r + beta * (q.p[c] - omega * (q.v[c] - mv));
+                    q.p[c] = pv;
+                }
+                sum += pv;
             }
-            sum += pv;
-        }
-    M.r4[(size_t)sys * M.n4 + ag] = sum;
+    }
+    sum = ml_quad_sum(sum);
+    if (ag < M.n4 && row == 0) M.r4[(size_t)sys * M.n4 + ag] = sum;
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, MlDev M, int it) {
-    const int ag = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y, N = D.N;
+    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, ag = tq >> 2, row = tq & 3, sys = blockIdx.y, N = D.N;
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
@@ -1156,12 +1165,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, 
     const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
     const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
-    float part = 0.f;
+    float part = 0.f, sum = 0.f;
     if (ag < M.n4) {
         const uint2 rc = M.rect4[ag];
         const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
-        float sum = 0.f;
-        for (int dy = 0; dy < h; ++dy)
+        for (int dy = row; dy < h; dy += 4)
             for (int dx = 0; dx < w; ++dx) {
                 const size_t c = vb + rc.x + dy * stride + dx;
                 const float sv = q.r[c] - alpha * (q.v[c] - mv);
@@ -1169,8 +1177,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, 
                 part += sv * sv;
                 sum += sv;
             }
-        M.r4[(size_t)sys * M.n4 + ag] = sum;
     }
+    sum = ml_quad_sum(sum);
+    if (ag < M.n4 && row == 0) M.r4[(size_t)sys * M.n4 + ag] = sum;
     part = mb_block_sum(part, lds);
     if (threadIdx.x == 0) acc_add(a + A_SS, (double)part);
 }
@@ -2441,9 +2450,9 @@ MlDev mb_ml_dev(const fg_mb_state* s) {
 void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st, int fused = 0, int it = 0) {
     const MlDev M = mb_ml_dev(s);
     const int nsys = s->B * q.nc, n = s->N;
-    const dim3 rgrid((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
-    if (fused == 1) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_p<DIMS>, rgrid, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
-    else if (fused == 2) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_s<DIMS>, rgrid, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
+    const dim3 rgrid((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys), rgrid4((4 * M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
+    if (fused == 1) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_p<DIMS>, rgrid4, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
+    else if (fused == 2) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_s<DIMS>, rgrid4, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
     else
     hipLaunchKernelGGL(k_ml_restrict, rgrid, dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
     {
@@ -2550,8 +2559,8 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     // (read at create) keeps the two kernels
     const bool fused_st = !ml && s->dbg_fuse_st >= 1, fused_pv = !ml && s->dbg_fuse_st >= 2;
     // multilevel: p and s are formed inside the restriction that follows them -- two launches fewer per iteration, which pays
-    // while the launches are latency-sized (Airfoil2D x 16: 32.3-33.9 -> 34.7-34.8 env-steps/s) and not once they carry bytes
-    // (x 64: 63.0 -> 62.4; an aggregate's thread walks its 4 x 4 cells in 16-byte pieces).  So: up to 32 systems.
+    // while the launches are latency-sized (Airfoil2D x 16: 32.3-33.9 -> 34.7-34.8 env-steps/s; rocprofv3: p + restriction 10.1 -> 7.3 us, s + restriction
+    // 10.4 -> 7.1 us with four threads per aggregate) and not once they carry bytes (x 64: 16.0 -> 17.4 us, 15.2 -> 14.3 us).  So: up to 32 systems.
     // FG_MB_ML_FUSE=0 never, 2 always.
     const bool ml_fused = ml && !ilu && (s->dbg_ml_fuse == 2 || (s->dbg_ml_fuse == 1 && nsys <= 32));
     if (fused_st) q.sbuf = s->w[5];
