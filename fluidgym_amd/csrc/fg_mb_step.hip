@@ -1075,6 +1075,9 @@ struct MlDev {
     const uint16_t* a4; const uint16_t* parent4; const uint2* rect4; const uint2* child8; const float* rd4; const float* aci8;
     int n4, n8, ld8;
     float* r4; float* z8; const float* scale_inv;   // work arrays [nsys][n4], [nsys][n8]; 1 / s per env
+    // r4 a second time in the order the coarse kernel wants it -- [nsys][n8][4], slot pos4[a] = 4 parent + child index -- so that
+    // its r8 is one coalesced 16-byte load instead of a child table followed by four gathers
+    const uint32_t* pos4; float* r4c;
 };
 // 1 / s per env: trace(S_geom) / trace(P_env); one workgroup per env
 __global__ __launch_bounds__(1024) void k_ml_scale(const float* __restrict__ diag, int N, float geom_diag_sum, float* __restrict__ scale_inv) {
@@ -1102,6 +1105,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* 
     for (int dy = 0; dy < h; ++dy)
         for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
     M.r4[(size_t)sys * M.n4 + a] = sum;
+    M.r4c[(size_t)sys * 4 * M.n8 + M.pos4[a]] = sum;
 }
 // The restriction fused with the vector update that feeds it (the preconditioned BiCGStab applies M to p and to s right after
 // forming them): the thread of an aggregate forms p (k_mbb_p4's update, convergence test and leader bookkeeping) or s (k_mbb_s4's)
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, 
             }
     }
     sum = ml_quad_sum(sum);
-    if (ag < M.n4 && row == 0) M.r4[(size_t)sys * M.n4 + ag] = sum;
+    if (ag < M.n4 && row == 0) { M.r4[(size_t)sys * M.n4 + ag] = sum; M.r4c[(size_t)sys * 4 * M.n8 + M.pos4[ag]] = sum; }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, MlDev M, int it) {
@@ -1179,7 +1183,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, 
             }
     }
     sum = ml_quad_sum(sum);
-    if (ag < M.n4 && row == 0) M.r4[(size_t)sys * M.n4 + ag] = sum;
+    if (ag < M.n4 && row == 0) { M.r4[(size_t)sys * M.n4 + ag] = sum; M.r4c[(size_t)sys * 4 * M.n8 + M.pos4[ag]] = sum; }
     part = mb_block_sum(part, lds);
     if (threadIdx.x == 0) acc_add(a + A_SS, (double)part);
 }
@@ -1204,14 +1208,12 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
     if (!any) return;
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
-        const float* r4 = M.r4 + (size_t)(sys0 + k) * M.n4;
+        const float4* r4c = reinterpret_cast<const float4*>(M.r4c + (size_t)(sys0 + k) * 4 * M.n8);
         for (int g = threadIdx.x; g < M.n8; g += ML_ROWS * ML_CG) {
             float sum = 0.f;
             if (on[k]) {
-                const uint2 ch = M.child8[g];
-                const unsigned ids[4] = {ch.x & 0xffffu, ch.x >> 16, ch.y & 0xffffu, ch.y >> 16};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if (ids[c] != 0xffffu) sum += r4[ids[c]];
+                const float4 c = r4c[g];               // the (at most four) children in child order, absent ones 0
+                sum = ((c.x + c.y) + c.z) + c.w;
             }
             l_r8[k * n8p + g] = sum;
         }
@@ -2442,7 +2444,7 @@ MlDev mb_ml_dev(const fg_mb_state* s) {
     MlDev M;
     M.a4 = s->ml_a4; M.parent4 = s->ml_parent4; M.rect4 = s->ml_rect4; M.child8 = s->ml_child8; M.rd4 = s->ml_d4g; M.aci8 = s->ml_aci8;
     M.n4 = s->ml_n4; M.n8 = s->ml_n8; M.ld8 = (s->ml_n8 + 3) & ~3;
-    M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale;
+    M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale; M.pos4 = s->ml_pos4; M.r4c = s->ml_r4c;
     return M;
 }
 // fused = 0: z = M in.  1 / 2: `in` is q.p / q.r and its update (k_mbb_p4 / k_mbb_s4) happens inside the restriction
@@ -3403,6 +3405,7 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
     // every aggregate must be the rectangle it is declared as (the kernel sums it by its shape), and an 8 x 8 aggregate has at
     // most four children
     std::vector<uint2> rect(n4), child(n8, make_uint2(0xffffffffu, 0xffffffffu));
+    std::vector<uint32_t> pos4(n4);
     {
         std::vector<int> count(n4, 0);
         for (int i = 0; i < s->N; ++i) count[a4[i]]++;
@@ -3420,6 +3423,7 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
         for (int a = 0; a < n4; ++a) {
             const int p = p4[a], k = nch[p]++;
             FG_REQUIRE(k < 4, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: an 8 x 8 aggregate has more than four children");
+            pos4[a] = 4u * (unsigned)p + (unsigned)k;
             unsigned* words = &child[p].x;
             unsigned& wref = words[k >> 1];
             wref = (k & 1) ? ((wref & 0x0000ffffu) | ((unsigned)a << 16)) : ((wref & 0xffff0000u) | (unsigned)a);
@@ -3435,6 +3439,8 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
         if (int rc = mb_alloc(s, &s->ml_aci8, (size_t)c8 * ((c8 + 3) & ~3))) return rc;   // rows padded to a multiple of four
         if (int rc = mb_alloc(s, &s->ml_r4, (size_t)s->B * c4)) return rc;
         if (int rc = mb_alloc(s, &s->ml_z8, (size_t)s->B * c8)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_r4c, (size_t)s->B * 4 * c8)) return rc;
+        if (int rc = mb_alloc(s, &s->ml_pos4, (size_t)c4)) return rc;
         if (!s->ml_scale) {
             if (int rc = mb_alloc(s, &s->ml_scale, (size_t)s->B)) return rc;
             if (int rc = mb_alloc(s, &s->ml_mp, (size_t)s->B * s->N)) return rc;
@@ -3446,6 +3452,8 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
     FG_HIP_CHECK(hipMemcpy(s->ml_parent4, p4.data(), sizeof(uint16_t) * n4, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_rect4, rect.data(), sizeof(uint2) * n4, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_child8, child.data(), sizeof(uint2) * n8, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_pos4, pos4.data(), sizeof(uint32_t) * n4, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemset(s->ml_r4c, 0, sizeof(float) * (size_t)s->B * 4 * s->ml_cap8));   // the slots of absent children are never written
     std::vector<float> rd4(n4);
     for (int a = 0; a < n4; ++a) { FG_REQUIRE(d4g_host[a] != 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: zero Galerkin diagonal"); rd4[a] = 1.f / d4g_host[a]; }
     const int ld = (n8 + 3) & ~3;
