@@ -127,6 +127,7 @@ struct fg_mb_state {
     int ml_cap4 = 0, ml_cap8 = 0;   // capacity of the tables above (the on-chip CG takes at most 2048 / 512 aggregates, the kernel form 65535 / 2048)
     // work arrays of the kernel form (mb_ml_apply): aggregate sums [B][n4], coarse solution [B][n8], 1 / scale [B], M p and M s [B][N]
     float *ml_r4 = nullptr, *ml_z8 = nullptr, *ml_scale = nullptr, *ml_mp = nullptr, *ml_ms = nullptr;
+    uint16_t* ml_p8c = nullptr;   // the 8 x 8 aggregate of every CELL (parent4[a4[i]]): one table level less in the prolongation
     float* ml_r4c = nullptr; uint32_t* ml_pos4 = nullptr;   // r4 once more, ordered by parent: [B][n8][4] (absent children stay 0), and the slot of every aggregate in it
     float* Poff4 = nullptr;    // [B][N][4] pressure off-diagonals interleaved per cell (2-D), written by k_mb_pmatrix next to Poff
     // ILU(0) of the velocity matrix as the right preconditioner of the preconditioned rung (mb_ilu_*, fg_mb_step.hip): level

@@ -1078,6 +1078,7 @@ struct MlDev {
     // r4 a second time in the order the coarse kernel wants it -- [nsys][n8][4], slot pos4[a] = 4 parent + child index -- so that
     // its r8 is one coalesced 16-byte load instead of a child table followed by four gathers
     const uint32_t* pos4; float* r4c;
+    const uint16_t* p8c;   // parent4[a4[i]] per cell
 };
 // 1 / s per env: trace(S_geom) / trace(P_env); one workgroup per env
 __global__ __launch_bounds__(1024) void k_ml_scale(const float* __restrict__ diag, int N, float geom_diag_sum, float* __restrict__ scale_inv) {
@@ -1261,7 +1262,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const float* _
     const unsigned a = M.a4[i];
     const float half_s = 0.5f * M.scale_inv[b];
     out[(size_t)sys * N + i] = in[(size_t)sys * N + i] * __builtin_amdgcn_rcpf(diag[(size_t)b * N + i]) +
-                               half_s * M.rd4[a] * M.r4[(size_t)sys * M.n4 + a] + M.z8[(size_t)sys * M.n8 + M.parent4[a]];
+                               half_s * M.rd4[a] * M.r4[(size_t)sys * M.n4 + a] + M.z8[(size_t)sys * M.n8 + M.p8c[i]];
 }
 
 // ---- CG (cgSolveGPU recurrence, cg_solver_kernel.cu:129-471) in two kernels per iteration.  The search direction is
@@ -2444,7 +2445,7 @@ MlDev mb_ml_dev(const fg_mb_state* s) {
     MlDev M;
     M.a4 = s->ml_a4; M.parent4 = s->ml_parent4; M.rect4 = s->ml_rect4; M.child8 = s->ml_child8; M.rd4 = s->ml_d4g; M.aci8 = s->ml_aci8;
     M.n4 = s->ml_n4; M.n8 = s->ml_n8; M.ld8 = (s->ml_n8 + 3) & ~3;
-    M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale; M.pos4 = s->ml_pos4; M.r4c = s->ml_r4c;
+    M.r4 = s->ml_r4; M.z8 = s->ml_z8; M.scale_inv = s->ml_scale; M.pos4 = s->ml_pos4; M.r4c = s->ml_r4c; M.p8c = s->ml_p8c;
     return M;
 }
 // fused = 0: z = M in.  1 / 2: `in` is q.p / q.r and its update (k_mbb_p4 / k_mbb_s4) happens inside the restriction
@@ -3433,6 +3434,7 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
         const int c4 = n4 > OC_N4 ? n4 : OC_N4, c8 = n8 > OC_N8 ? n8 : OC_N8;
         if (int rc = mb_alloc(s, &s->ml_rect4, (size_t)c4)) return rc;
         if (int rc = mb_alloc(s, &s->ml_child8, (size_t)c8)) return rc;
+        if (!s->ml_p8c) if (int rc = mb_alloc(s, &s->ml_p8c, (size_t)s->N)) return rc;
         if (!s->ml_a4) if (int rc = mb_alloc(s, &s->ml_a4, (size_t)s->N)) return rc;
         if (int rc = mb_alloc(s, &s->ml_parent4, (size_t)c4)) return rc;
         if (int rc = mb_alloc(s, &s->ml_d4g, (size_t)c4)) return rc;
@@ -3453,6 +3455,11 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
     FG_HIP_CHECK(hipMemcpy(s->ml_rect4, rect.data(), sizeof(uint2) * n4, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_child8, child.data(), sizeof(uint2) * n8, hipMemcpyHostToDevice));
     FG_HIP_CHECK(hipMemcpy(s->ml_pos4, pos4.data(), sizeof(uint32_t) * n4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint16_t> p8c(s->N);
+        for (int i = 0; i < s->N; ++i) p8c[i] = p4[a4[i]];
+        FG_HIP_CHECK(hipMemcpy(s->ml_p8c, p8c.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
+    }
     FG_HIP_CHECK(hipMemset(s->ml_r4c, 0, sizeof(float) * (size_t)s->B * 4 * s->ml_cap8));   // the slots of absent children are never written
     std::vector<float> rd4(n4);
     for (int a = 0; a < n4; ++a) { FG_REQUIRE(d4g_host[a] != 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: zero Galerkin diagonal"); rd4[a] = 1.f / d4g_host[a]; }
