@@ -1096,22 +1096,6 @@ __global__ __launch_bounds__(1024) void k_ml_scale(const float* __restrict__ dia
         scale_inv[b] = (float)((double)geom_diag_sum / t);
     }
 }
-__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* __restrict__ in, int N, const int32_t* __restrict__ flags) {
-    const int a = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
-    if (a >= M.n4 || flag_ld(flags + sys) != 0) return;
-    const uint2 rc = M.rect4[a];
-    const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
-    const float* src = in + (size_t)sys * N + rc.x;
-    float sum = 0.f;
-    for (int dy = 0; dy < h; ++dy)
-        for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
-    M.r4[(size_t)sys * M.n4 + a] = sum;
-    M.r4c[(size_t)sys * 4 * M.n8 + M.pos4[a]] = sum;
-}
-// The restriction fused with the vector update that feeds it (the preconditioned BiCGStab applies M to p and to s right after
-// forming them): the thread of an aggregate forms p (k_mbb_p4's update, convergence test and leader bookkeeping) or s (k_mbb_s4's)
-// at its own cells, stores it and sums it -- one launch instead of two, twice per iteration.  The cells of an aggregate are a
-// partition of the mesh (checked in fg_mb_set_multilevel), so every cell is written exactly once.
 // (four threads per aggregate, one per row of its rectangle: a thread's cells are one contiguous run, and the four row sums meet in a
 //  fixed order)
 __device__ __forceinline__ float ml_quad_sum(float v) {
@@ -1119,6 +1103,24 @@ __device__ __forceinline__ float ml_quad_sum(float v) {
     const float s0 = __shfl(v, base, 64), s1 = __shfl(v, base + 1, 64), s2 = __shfl(v, base + 2, 64), s3 = __shfl(v, base + 3, 64);
     return ((s0 + s1) + s2) + s3;
 }
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* __restrict__ in, int N, const int32_t* __restrict__ flags) {
+    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, a = tq >> 2, row = tq & 3, sys = blockIdx.y;
+    if (flag_ld(flags + sys) != 0) return;
+    float sum = 0.f;
+    if (a < M.n4) {
+        const uint2 rc = M.rect4[a];
+        const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
+        const float* src = in + (size_t)sys * N + rc.x;
+        for (int dy = row; dy < h; dy += 4)
+            for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
+    }
+    sum = ml_quad_sum(sum);
+    if (a < M.n4 && row == 0) { M.r4[(size_t)sys * M.n4 + a] = sum; M.r4c[(size_t)sys * 4 * M.n8 + M.pos4[a]] = sum; }
+}
+// The restriction fused with the vector update that feeds it (the preconditioned BiCGStab applies M to p and to s right after
+// forming them): the thread of an aggregate forms p (k_mbb_p4's update, convergence test and leader bookkeeping) or s (k_mbb_s4's)
+// at its own cells, stores it and sums it -- one launch instead of two, twice per iteration.  The cells of an aggregate are a
+// partition of the mesh (checked in fg_mb_set_multilevel), so every cell is written exactly once.
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, MlDev M, int it) {
     const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, ag = tq >> 2, row = tq & 3, sys = blockIdx.y, N = D.N;
@@ -2453,11 +2455,11 @@ MlDev mb_ml_dev(const fg_mb_state* s) {
 void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st, int fused = 0, int it = 0) {
     const MlDev M = mb_ml_dev(s);
     const int nsys = s->B * q.nc, n = s->N;
-    const dim3 rgrid((M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys), rgrid4((4 * M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys);
+    const dim3 rgrid4((4 * M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys);   // four threads per aggregate
     if (fused == 1) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_p<DIMS>, rgrid4, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
     else if (fused == 2) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_s<DIMS>, rgrid4, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
     else
-    hipLaunchKernelGGL(k_ml_restrict, rgrid, dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
+    hipLaunchKernelGGL(k_ml_restrict, rgrid4, dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
     {
         // systems per workgroup: 8 when that still leaves >= 2 workgroups per CU-pair of work (>= 32 systems) and the LDS fits 64 KB
         const int n8p = (M.n8 + 3) & ~3;
