@@ -424,9 +424,8 @@ def _r(x, nd=4):
 
 
 def _iters(its):
-    """{"velocity": {"mean", "max"}, ...} -> {"velocity": [mean, max], ...}.  The native counters hold the 0-based index of a
-    solve's last iteration; the compact line reports COUNTS of iterations per solve (index + 1; a solve that met the tolerance
-    on its initial residual has count 0 and is stored as -1 by the kernels' bookkeeping -> clamped to 0)."""
+    """{"velocity": {"mean", "max"}, ...} -> {"velocity": [mean, max], ...}.  The native counters (FgCounters::add) already hold
+    COUNTS of iterations per solve (0 = the initial residual met the tolerance); nothing is converted here."""
     if not its:
         return None
     out = {}

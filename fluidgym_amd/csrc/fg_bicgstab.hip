@@ -56,13 +56,16 @@ __device__ __forceinline__ SysCtx fg_sys(const FgCtx<DIMS, VEC>& c, int nc, int 
 
 __device__ __forceinline__ fg_real fg_rms(double rr, int n) { return (fg_real)sqrt(rr / (double)n); }
 
-__device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int sys, fg_real crit, int it) {
+// ok_flag: the value a finite verdict stores (1 done; 4 = converged on s, the x kernel still owes x += alpha p).  The flag is
+// stored ONCE, after the info words: other workgroups of the env read it in the same launch, and a transient 1 before the 4
+// would let one of them skip its half update.
+__device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int sys, fg_real crit, int it, int ok_flag = 1) {
     const bool finite = isfinite(crit);
-    flag_st(flags + (sys), finite ? 1 : 2);
     info[sys].final_residual = crit;
     info[sys].used_iterations = it;
     info[sys].converged = finite ? 1 : 0;
     info[sys].is_finite = finite ? 1 : 0;
+    flag_st(flags + (sys), finite ? ok_flag : 2);
 }
 
 struct BicgPtrs {
@@ -276,10 +279,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_t(FgGrid g, BicgPtrs q, int i
             // converged on s (bicgstab_solver_kernel.cu:305-329): flag 4 = "K5 applies x += alpha p, then done".
             // Nothing in THIS launch depends on the flag value written here (every workgroup of the env takes this
             // branch from the same accumulator value, and reads flags only above).
-            if (leader) {
-                fg_mark(q.flags, q.info, sys, crit_s, it);
-                if (isfinite(crit_s)) flag_st(q.flags + (sys), 4);
-            }
+            if (leader) fg_mark(q.flags, q.info, sys, crit_s, it, 4);
             continue;
         }
         work[comp] = true;
@@ -504,10 +504,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
         alpha[comp] = sc_ld(q.sc + (sys * 2 + 0));
         if (!(crit_s >= q.tol)) {   // converged on s (bicgstab_solver_kernel.cu:305-329), or s.s not finite
             const bool fin = isfinite(crit_s);
-            if (leader) {
-                fg_mark(q.flags, q.info, sys, crit_s, it - 1);
-                if (fin) flag_st(q.flags + (sys), 4);
-            }
+            if (leader) fg_mark(q.flags, q.info, sys, crit_s, it - 1, 4);
             if (fin) { mode[comp] = 2; any = true; }
             continue;
         }

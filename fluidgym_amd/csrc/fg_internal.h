@@ -93,7 +93,11 @@ static_assert(sizeof(FgDacc) == 64, "one accumulator per 64-byte line segment");
 #define FG_DACC_LIMIT 0x1p75
 #endif
 __host__ __device__ __forceinline__ bool fg_dacc_split(double v, long long k[4]) {
-    if (!(fabs(v) < FG_DACC_LIMIT)) return false;               // NaN, Inf or out of range: poison
+    if (!(fabs(v) <= 1.79769313486231570815e308)) return false;  // NaN, Inf: poison
+    // a finite contribution beyond the window SATURATES (each contribution on its own, so the sum stays order-independent):
+    // a diverging but finite solve keeps reading as a large finite residual -- return-best / the retry ladder then see
+    // "not converged", not "not finite" (the poison word is for NaN / Inf only)
+    if (!(fabs(v) < FG_DACC_LIMIT)) v = v < 0 ? -FG_DACC_LIMIT * (1.0 - 0x1p-30) : FG_DACC_LIMIT * (1.0 - 0x1p-30);
     double r = v;
     const double k0 = rint(r * (1.0 / FG_DACC_U0)); r -= k0 * FG_DACC_U0;      // exact: r keeps the bits of v below the word
     const double k1 = rint(r * (1.0 / FG_DACC_U1)); r -= k1 * FG_DACC_U1;

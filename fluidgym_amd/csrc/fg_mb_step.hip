@@ -430,13 +430,15 @@ __device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b
 
 // accumulator / scalar / flag words: only through acc_ld / acc_st, sc_ld / sc_st, flag_ld / flag_st (fg_internal.h)
 __device__ __forceinline__ float mb_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
-__device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, float crit, int it) {
+// ok_flag: what a finite verdict stores (1 done; 4 = converged on s, the x kernel still owes x += alpha p) -- ONE store of the
+// flag, after the info words (other workgroups of the env read it in the same launch)
+__device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, float crit, int it, int ok_flag = 1) {
     const bool finite = isfinite(crit);
-    flag_st(q.flags + (sys), finite ? 1 : 2);
     q.info[sys].final_residual = crit;
     q.info[sys].used_iterations = it;
     q.info[sys].converged = finite ? 1 : 0;
     q.info[sys].is_finite = finite ? 1 : 0;
+    flag_st(q.flags + (sys), finite ? ok_flag : 2);
 }
 
 __global__ void k_mbs_begin(const float* __restrict__ dt, MbSolve q, int nsys) {
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
     if (flag_ld(q.flags + (sys)) != 0) return;
     const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);
     if (!(crit_s >= q.tol)) {  // converged on s (bicgstab_solver_kernel.cu:305-329): k_mbb_x applies x += alpha p
-        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) flag_st(q.flags + (sys), 4); }
+        if (leader) mb_mark(q, sys, crit_s, it, 4);
         return;
     }
     float pt = 0.f, ptt = 0.f, pst = 0.f;
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it)
     if (flag_ld(q.flags + (sys)) != 0) return;
     const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);
     if (!(crit_s >= q.tol)) {
-        if (leader) { mb_mark(q, sys, crit_s, it); if (isfinite(crit_s)) flag_st(q.flags + (sys), 4); }
+        if (leader) mb_mark(q, sys, crit_s, it, 4);
         return;
     }
     float pt = 0.f, ptt = 0.f, pst = 0.f;

@@ -301,7 +301,12 @@ class AirfoilEnvBase(CylinderEnvBase):
             cd, cl = self._get_drag_and_lift()
             cds.append(cd); cls.append(cl)
         obs = self._get_global_obs()
-        cd, cl = torch.stack(cds).mean(0), torch.stack(cls).mean(0)
+        # mean over the sim steps as adds in step order (mean(0) of the stack picks its summation order per column: identical envs
+        # then differ in the last bit of drag / lift)
+        cd, cl = cds[0].clone(), cls[0].clone()
+        for k in range(1, len(cds)):
+            cd += cds[k]; cl += cls[k]
+        cd /= len(cds); cl /= len(cls)
         return obs, cl / cd - self._cl_cd_ref, False, {"drag": cd, "lift": cl}
 
     def _save_initial_domain(self, mode, idx: int, env: int = 0) -> None:

@@ -223,11 +223,15 @@ class CylinderEnvBase(FluidEnv):
         # The smoothed control of every sim step (cylinder_env_base.py:560-566: c <- c + alpha (target - c)) is a recurrence on a
         # [B, n_controls] tensor: evaluated once on the host in the same fp32 operations (separately rounded multiply and add,
         # as the per-step tensor expression) and uploaded in one copy, instead of three tiny launches per sim step.
-        c = self._last_control.cpu()
+        # The host keeps its own copy of the last control (valid while `_last_control` is the tensor this method left there), so the
+        # only read-back of a step is the action itself -- none when the caller hands over a host tensor.
+        mirror = getattr(self, "_last_control_mirror", None)
+        c = mirror[1] if mirror is not None and mirror[0] is self._last_control else self._last_control.cpu()
         t_host, alpha, controls = target.cpu(), self._action_smoothing_alpha, []
         for _ in range(n):
             c = c + alpha * (t_host - c)
             controls.append(c)
+        c_last = c
         controls = torch.stack(controls).to(self._last_control.device, non_blocking=False)      # [n, B, n_controls]
         # raw wall forces of every sim step land in one buffer; normalised and averaged once (elementwise division, then the
         # mean over the stack: what torch.stack of the per-step coefficients gave)
@@ -238,11 +242,18 @@ class CylinderEnvBase(FluidEnv):
                 self._apply_action(controls[k])
             self._sim.single_step()
             self._ring.forces(self._domain, self._nu, layer_height=self.D / self._circle_resolution_angular, out=raw[k])
+        self._last_control_mirror = (self._last_control, c_last)
         obs = self._get_global_obs()
         coeff = raw / (0.5 * self._U_mean ** 2 * self.cylinder_diameter)
         if self._ndims == 2:
             coeff = coeff[..., 0]
-        cd, cl = coeff[:, :, 0].mean(0), coeff[:, :, 1].mean(0)
+        # mean over the sim steps as a loop of adds in step order: `mean(0)` picks its summation order per column, and identical
+        # envs of a batch then report drag / lift (hence rewards) that differ in the last bit
+        acc = coeff[0].clone()
+        for k in range(1, n):
+            acc += coeff[k]
+        acc /= n
+        cd, cl = acc[:, 0], acc[:, 1]
         if self._ndims == 3:   # summed over the span here; CylinderJetEnv3D divides by D (:765-768)
             reward = self._cd_ref - cd.sum(-1) - self._lift_penalty * cl.sum(-1).abs()
         else:

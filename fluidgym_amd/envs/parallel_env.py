@@ -68,7 +68,8 @@ def _spawn_worker(rank: int, world: int, port: int, env_id: str, cuda_ids: List[
 
 class ParallelFluidEnv:
     def __init__(self, env_id: str, cuda_ids: Optional[Sequence[int]] = None, num_envs: Optional[int] = None,
-                 backend: Optional[str] = None, _spawned: bool = False, **env_kwargs: Any):
+                 backend: Optional[str] = None, _spawned: bool = False, collective_timeout_s: Optional[float] = None,
+                 force_collectives: Optional[bool] = None, **env_kwargs: Any):
         if env_kwargs.get("differentiable", False):
             raise ValueError("ParallelFluidEnv does not support differentiable environments.")
         self._env_id = env_id
@@ -94,14 +95,30 @@ class ParallelFluidEnv:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE=str(world),
                               LOCAL_RANK="0")
             launched = True
+        # A rank that dies leaves the others inside a collective: with a timeout the survivors raise instead of hanging (the
+        # reference's Pipe.recv hangs, parallel_env.py:233-287).  FLUIDGYM_COLLECTIVE_TIMEOUT_S / collective_timeout_s, default 600 s
+        # (an env step of the largest 3-D ids takes seconds; first-call RCCL setup tens of seconds).
+        if collective_timeout_s is None:
+            collective_timeout_s = float(os.environ.get("FLUIDGYM_COLLECTIVE_TIMEOUT_S", 600))
+        self._timeout_s = float(collective_timeout_s)
+        # force_collectives: issue the broadcast / all_gather of every command at world size 1 too (one-GPU boxes exercise the
+        # RCCL branch with it: tests/test_gpu_rccl.py; FLUIDGYM_FORCE_COLLECTIVES=1).  Needs a process group, i.e. a launched rank.
+        if force_collectives is None:
+            force_collectives = os.environ.get("FLUIDGYM_FORCE_COLLECTIVES", "0") not in ("", "0")
+        self._force = bool(force_collectives)
         if launched:
             if not dist.is_initialized():
-                dist.init_process_group(backend=backend, init_method="env://")
+                from datetime import timedelta
+
+                dist.init_process_group(backend=backend, init_method="env://", timeout=timedelta(seconds=self._timeout_s))
                 self._owns_group = True
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
         else:
             self.rank, self.world = 0, 1
         local = int(os.environ.get("LOCAL_RANK", self.rank))
+        if self._force and not (launched and dist.is_initialized()):
+            raise RuntimeError("force_collectives needs a torch.distributed process group (launch the rank with torch.distributed.run)")
+        self._collective = self._force or self.world > 1
         if backend == "nccl":
             dev_index = cuda_ids[local] if cuda_ids is not None else local
             self._device = torch.device("cuda", int(dev_index))
@@ -191,7 +208,7 @@ class ParallelFluidEnv:
             self._msg[: self._HDR].copy_(hdr, non_blocking=True)
             if action is not None:
                 self._msg[self._HDR:].copy_(action.to(self._device, torch.float32).reshape(-1).view(torch.int32))
-            if self.world > 1:
+            if self._collective:
                 dist.broadcast(self._msg, src=0)
             return [int(cmd), int(a), int(b), int(c)]
         dist.broadcast(self._msg, src=0)
@@ -203,7 +220,7 @@ class ParallelFluidEnv:
         return self._msg[self._HDR:].view(torch.float32).reshape(self._a_shape)
 
     def _all_gather(self, local: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if not self._collective:
             return local
         out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         try:
@@ -224,10 +241,11 @@ class ParallelFluidEnv:
     def _pack(self, obs: Dict[str, torch.Tensor], reward: Optional[torch.Tensor], term=None, trunc=None,
               info: Optional[Dict[str, Any]] = None) -> torch.Tensor:
         parts = [obs[k].reshape(self._n_local, -1).float() for k in self._obs_keys]
-        if reward is None and info:
-            # reset: the reference returns one info dict per worker = per env (parallel_env.py:222-231)
-            if self._reset_info_layout is None:
-                self._reset_info_layout = self._layout_of(info)
+        if reward is None:
+            # reset: the reference returns one info dict per worker = per env (parallel_env.py:222-231).  The layout is taken
+            # from THIS reset's dict (a cached one would mis-slice the gathered block when a later reset -- another mode, a
+            # randomised state -- reports another key set; same env class and call on every rank, so the ranks agree)
+            self._reset_info_layout = self._layout_of(info)
             parts += [self._per_env(info[k]) for k, _, _ in self._reset_info_layout]
         if reward is not None:
             parts.append(reward.reshape(self._n_local, -1).float())
@@ -298,7 +316,8 @@ class ParallelFluidEnv:
         obs, info = self._env.reset(seed=None if seed is None else int(seed) + self.rank, randomize=randomize)
         flat = self._all_gather(self._pack(obs, None, info=info))
         obs_all, _, _, _, info_all = self._unpack(flat, obs, with_reward=False)
-        infos = [{k: v[i].cpu() for k, v in info_all.items()} for i in range(self._n_total)]
+        host = {k: v.cpu() for k, v in info_all.items()}       # one copy per key, sliced per env on the host
+        infos = [{k: v[i] for k, v in host.items()} for i in range(self._n_total)]
         return self._agents_to_rows(obs_all), infos
 
     def step(self, action: Optional[torch.Tensor] = None):
@@ -402,7 +421,7 @@ class ParallelFluidEnv:
         self._shutdown()
 
     def close(self) -> None:
-        if self.world > 1:
+        if self._collective:
             self._send(Command.CLOSE, read_header=False)
         self._shutdown()
         for p in self._workers:

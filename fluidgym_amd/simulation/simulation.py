@@ -134,7 +134,7 @@ class Simulation:
         # The reference's retry chain of the advection-diffusion solves (_linear_solve, PISOtorch_diff.py:449-476) on this path:
         # preconditionBiCG preconditions every solve, BiCG_precondition_fallback repeats a failed one with the preconditioner
         # (cuSPARSE ILU(0) there, the y-line solve of csrc/fg_linepre.hip here).  On top of that the policy switch
-        # advection_line_preconditioner (policy.py, default on) preconditions every solve on grids refined towards a y wall, where
+        # advection_line_preconditioner (policy.py, default OFF) preconditions every solve on grids refined towards a y wall, where
         # the plain recurrence needs 20-35 iterations (RBC 512 x 128): same system, same tolerance, another Krylov trajectory.
         # solver_double_fallback (an fp64 re-solve) has no counterpart on this path: its systems are strictly diagonally
         # dominant and fp32 BiCGStab reaches their tolerances; the kwarg is accepted.

@@ -193,6 +193,95 @@ def test_single_process_world_of_one():
     penv.close()
 
 
+def test_forced_collectives_at_world_size_one():
+    """The CPU twin of tests/test_gpu_rccl.py: one rank under torch.distributed.run, every command through the group's
+    broadcast / all_gather (gloo here, RCCL there), equal to the plain env."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "rccl_child.py"), "gloo", "ToyCPU-v0", "3"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    rep = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rep["backend"] == "gloo" and rep["world"] == 1 and rep["checks"] >= 8
+    # without a process group the switch is refused instead of silently skipping the collectives
+    _register()
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    os.environ.pop("RANK", None)
+    with pytest.raises(RuntimeError, match="force_collectives needs"):
+        ParallelFluidEnv("ToyCPU-v0", num_envs=2, backend="gloo", force_collectives=True)
+
+
+class ToyShiftingInfoEnv(ToyEnv):
+    """Reports another key set at every reset (a randomised reset of a real env may: ADVICE r3)."""
+
+    def reset(self, seed=None, randomize=None):
+        obs, info = super().reset(seed, randomize)
+        self._n_resets = getattr(self, "_n_resets", 0) + 1
+        if self._n_resets > 1:
+            info = {"aaa_first": self.state[:, :2], "init_sum": info["init_sum"]}
+        return obs, info
+
+
+def test_reset_info_layout_follows_the_reset():
+    import fluidgym_amd
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    if "ToyShift-v0" not in fluidgym_amd.registry.ids:
+        fluidgym_amd.register("ToyShift-v0", ToyShiftingInfoEnv, {"gain": 1.0})
+    os.environ.pop("RANK", None)
+    penv = ParallelFluidEnv("ToyShift-v0", num_envs=3, backend="gloo")
+    _, i1 = penv.reset(seed=1)
+    assert set(i1[0]) == {"init_sum"}
+    _, i2 = penv.reset(seed=2)
+    assert set(i2[0]) == {"aaa_first", "init_sum"} and i2[1]["aaa_first"].shape == (2,)
+    st = penv.local_env.state
+    assert np.allclose([float(i["init_sum"]) for i in i2], st.sum(dim=1).numpy())     # not mis-sliced by the first reset's layout
+    assert np.allclose(np.stack([i["aaa_first"].numpy() for i in i2]), st[:, :2].numpy())
+    penv.close()
+
+
+def _dying_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    _register()
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    penv = ParallelFluidEnv("ToyCPU-v0", num_envs=4, backend="gloo", collective_timeout_s=8)
+    penv.reset(seed=1)
+    if rank == 1:
+        os._exit(0)                      # dies between two commands
+    import time
+
+    t0 = time.time()
+    try:
+        penv.step(torch.zeros(4, 3))
+        q.put(("hung-or-ok", time.time() - t0))
+    except Exception as e:                # noqa: BLE001 -- any backend error is the point
+        q.put(("raised", time.time() - t0, type(e).__name__))
+
+
+def test_dead_rank_raises_instead_of_hanging():
+    """A dead rank must not hang the others (the reference's Pipe.recv does, parallel_env.py:233-287): the group is created
+    with a timeout (`collective_timeout_s` / FLUIDGYM_COLLECTIVE_TIMEOUT_S)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dying_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=30)
+    assert res[0] == "raised" and res[1] < 60, res
+
+
 def test_num_envs_must_divide_world():
     _register()
     from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
