@@ -112,6 +112,11 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr; s->ilu_d = nullptr;
     s->fd_lam = nullptr; s->helm_diag = s->helm_lower = s->helm_upper = s->helm_tmp = nullptr;
     { const char* ev = getenv("FG_CG_WGS_PER_SLOT"); s->cg_wgs_per_slot = (ev && atoi(ev) > 0) ? atoi(ev) : 256; }
+    // FG_BICG3: z-marching two-kernel BiCGStab in 3-D (fg_bicgstab3d.hip): 0 never | > 0 always, with that z-chunk length (tests on
+    // small grids) | unset: when the grid fits the tiles and fills the chip.  FG_BICG3_BXL: 16 / 32 float4 lanes along x (tile shape)
+    { const char* ev = getenv("FG_BICG3"); s->bicg3_force = ev ? atoi(ev) : -1; }
+    { const char* ev = getenv("FG_BICG3_BXL"); s->bicg3_bxl = ev ? atoi(ev) : 0; }
+    { const char* ev = getenv("FG_BICG3_MIX"); s->bicg3_mix = ev ? atoi(ev) : 3; }   // bit 0: kernel a, bit 1: kernel b as z-march (debugging)
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
     s->cg_return_best = 1;
     s->adv_from_result = 1;
@@ -254,6 +259,25 @@ extern "C" int fg_advection_retries(fg_handle s, int64_t* out, int32_t reset) {
     FG_REQUIRE(s && out, FG_ERR_INVALID_ARG, "null argument");
     *out = s->line_retries;
     if (reset) s->line_retries = 0;
+    return FG_OK;
+}
+
+#if !FG_F64
+bool fg_bicg3_ok(const fg_state* s, int nc, int* zc_out);
+#endif
+extern "C" int fg_advection_solver_form(fg_handle s, int nc, int32_t* out) {
+    FG_REQUIRE(s && out, FG_ERR_INVALID_ARG, "null argument");
+    int form = 0;
+    if (s->bicg_fused) {
+        int zc = 0;
+#if !FG_F64
+        if (s->grid.dims == 3 && (s->bicg3_mix & 3) == 3 && fg_bicg3_ok(s, nc, &zc)) form = 2;
+        else
+#endif
+        if (s->grid.dims == 2 || s->bicg_fused >= 2) form = 1;
+        (void)zc;
+    }
+    *out = form;
     return FG_OK;
 }
 
@@ -652,7 +676,9 @@ extern "C" int fg_get_buffer(fg_handle s, int which, fg_real** out_ptr, int64_t*
         case FG_BUF_DIV: *out_ptr = s->div; *out_count = BN; break;
         case FG_BUF_P_RESULT: *out_ptr = s->p_result; *out_count = BN; break;
         case FG_BUF_SCALAR_RESULT: *out_ptr = s->scal_result; *out_count = BN; break;
-        default: FG_REQUIRE(false, FG_ERR_INVALID_ARG, "unknown buffer id");
+        default:
+            if (which >= 100 && which < 108) { *out_ptr = s->w[which - 100]; *out_count = BN * d; break; }   // Krylov work vectors (tests)
+            FG_REQUIRE(false, FG_ERR_INVALID_ARG, "unknown buffer id");
     }
     return FG_OK;
 }

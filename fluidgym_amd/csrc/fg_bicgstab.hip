@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include "fg_internal.h"
+#include "fg_bicg.h"
 
 namespace {
 
@@ -53,30 +54,6 @@ __device__ __forceinline__ SysCtx fg_sys(const FgCtx<DIMS, VEC>& c, int nc, int 
     s.leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
     return s;
 }
-
-__device__ __forceinline__ fg_real fg_rms(double rr, int n) { return (fg_real)sqrt(rr / (double)n); }
-
-// ok_flag: the value a finite verdict stores (1 done; 4 = converged on s, the x kernel still owes x += alpha p).  The flag is
-// stored ONCE, after the info words: other workgroups of the env read it in the same launch, and a transient 1 before the 4
-// would let one of them skip its half update.
-__device__ __forceinline__ void fg_mark(int32_t* flags, fg_solve_info* info, int sys, fg_real crit, int it, int ok_flag = 1) {
-    const bool finite = isfinite(crit);
-    info[sys].final_residual = crit;
-    info[sys].used_iterations = it;
-    info[sys].converged = finite ? 1 : 0;
-    info[sys].is_finite = finite ? 1 : 0;
-    flag_st(flags + (sys), finite ? ok_flag : 2);
-}
-
-struct BicgPtrs {
-    const fg_real* diag; const fg_real* off; const fg_real* rhs;
-    fg_real* x; fg_real* r; fg_real* rw; fg_real* p; fg_real* v; fg_real* t;
-    FgDacc* acc; fg_real* sc; int32_t* flags; fg_solve_info* info;
-    int nc; fg_real tol;
-    // right preconditioning (fg_linepre.hip): when set, v = C mp with mp = M^-1 p, t = C ms with ms = M^-1 s, and the iterate
-    // advances along mp / ms; r, s and every dot product are those of C M^-1, so r stays the true residual of C x = rhs
-    const fg_real* mp; const fg_real* ms;
-};
 
 // SpMV with the matrix held in registers: the (1 + 2 DIMS) coefficient fields belong to the env, not to the system,
 // so one workgroup applies them to ALL nc right-hand sides of its tile.  With one workgroup per (tile, component) the
@@ -388,13 +365,6 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicg_x(FgGrid g, BicgPtrs q, int i
 // Accumulators (FgDacc, indexed with the parity e of the iteration that fills them so that a leader can reset the set nobody
 // reads in its launch): F_RV + e, F_RR + e by k_bicgf_a | F_SS.. F_RT + e by k_bicgf_b | F_RHOE + e the rho iteration e uses.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int F_RV = 0, F_RR = 2, F_SS = 4, F_TS = 6, F_TT = 8, F_RS = 10, F_RT = 12, F_RHOE = 14;
-static_assert(F_RHOE + 2 <= FG_ACC_DOUBLES, "fused BiCGStab accumulators");
-
-struct BicgFused {
-    fg_real* s; fg_real* p[2]; fg_real* v[2];   // s buffer; p / v of iteration i in p[i & 1] / v[i & 1]
-};
-
 template <int DIMS, int VEC>
 __device__ __forceinline__ FgVec<VEC> fg_apply_nbr(const FgStencilRow<DIMS, VEC>& m, const FgNbr<DIMS, VEC>& X) {
     FgVec<VEC> y;
@@ -794,15 +764,40 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     const double cells = (double)n, mat = 4.0 * (1 + 2 * s->grid.dims) / a.nc, fl = 2.0 * (1 + 2 * s->grid.dims);
     // (3-D: the neighbour recomputation of four fields across six faces costs more than the two saved passes -- measured on TCF
     //  128 x 64 x 64: 299 us per iteration against 260 us -- so the five kernels stay there)
-    if (s->bicg_fused && !a.precond && (s->grid.dims == 2 || s->bicg_fused >= 2)) {
+    int zc3 = 0;
+#if FG_F64
+    const bool zmarch3 = false; (void)zc3;
+#else
+    // 3-D: the two-kernel form as z-marching LDS-ring kernels (fg_bicgstab3d.hip) when the grid fits its tiles and fills the chip
+    const bool zmarch3 = s->bicg_fused && !a.precond && s->grid.dims == 3 && fg_bicg3_ok(s, a.nc, &zc3);
+#endif
+    if (s->bicg_fused && !a.precond && (s->grid.dims == 2 || s->bicg_fused >= 2 || zmarch3)) {
         // two-kernel iteration (k_bicgf_a / k_bicgf_b above): per system and cell, a reads x, p, s, t, v, rw + the matrix and writes
         // x, r, p, v (40 + mat B); b reads r, v, rw + the matrix and writes s, t (20 + mat B)
         BicgFused w;
         w.s = s->w[7]; w.p[0] = s->w[2]; w.p[1] = s->w[5]; w.v[0] = s->w[3]; w.v[1] = s->w[6];
-        FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);
+        w.fold0 = 0;
+#if !FG_F64
+        const bool za = zmarch3 && (s->bicg3_mix & 1), zb = zmarch3 && (s->bicg3_mix & 2);   // (FG_BICG3_MIX: the two forms share buffers and accumulators)
+        // start vector zero on the z-marching kernels: r_0 = p_0 = rw = rhs, no init kernel (fg_bicg.h BicgFused::fold0; FG_BICG3_MIX & 4 keeps it)
+        w.fold0 = (za && zb && !a.use_x0 && !(s->bicg3_mix & 4)) ? 1 : 0;
+#endif
+        if (!w.fold0) FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);
+#if !FG_F64
+        if (za) { if (int rc = fg_bicg3_launch_a(s, q, w, 0, zc3, -1, st)) return rc; }
+        else
+#endif
         FG_BICG_LAUNCH_Y(1, -1, k_bicgf_a, w, 0);
         for (int it = 0; it < a.max_iterations && !done; ++it) {
+#if !FG_F64
+            if (zb) { if (int rc = fg_bicg3_launch_b(s, q, w, it, zc3, fg_prof_slot(s, FG_PK_BICGF_B, q.flags, nsys, cells * (20.0 + mat), cells * (fl + 12.0), st), st)) return rc; }
+            else
+#endif
             FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_B, q.flags, nsys, cells * (20.0 + mat), cells * (fl + 12.0), st), k_bicgf_b, w, it);
+#if !FG_F64
+            if (za) { if (int rc = fg_bicg3_launch_a(s, q, w, it + 1, zc3, fg_prof_slot(s, FG_PK_BICGF_A, q.flags, nsys, cells * (40.0 + mat), cells * (fl + 14.0), st), st)) return rc; }
+            else
+#endif
             FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_A, q.flags, nsys, cells * (40.0 + mat), cells * (fl + 14.0), st), k_bicgf_a, w, it + 1);
             if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
                 next_poll = it + 1 + 2;

@@ -537,6 +537,7 @@ struct fg_state {
     // BiCG_precondition_fallback); line_retries counts the repeats.  Factors [B][N], allocated on first use
     int adv_precond; long long line_retries;
     int cg_wgs_per_slot;          // workgroups sharing one CG accumulator slot (256; FG_CG_WGS_PER_SLOT at fg_create: tuning)
+    int bicg3_force, bicg3_bxl, bicg3_mix;   // FG_BICG3 / FG_BICG3_BXL at fg_create (fg_bicgstab3d.hip)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
     fg_real* line_inv; fg_real* line_cp;
     fg_real* ilu_d;               // [B,N] modified diagonal of the ILU(0) preconditioner (fg_ilu0.hip), built per solve

@@ -403,6 +403,12 @@ class NativeSolver:
         L.check(self.lib.fg_advection_retries(self.handle, ctypes.byref(out), int(reset)), lib=self.lib)
         return int(out.value)
 
+    def advection_solver_form(self, nc: Optional[int] = None) -> str:
+        """Kernels of the next un-preconditioned advection-diffusion solve: 'five' | 'two-brick' | 'two-zmarch'."""
+        out = ctypes.c_int32()
+        L.check(self.lib.fg_advection_solver_form(self.handle, int(self.dims if nc is None else nc), ctypes.byref(out)), lib=self.lib)
+        return ("five", "two-brick", "two-zmarch")[out.value]
+
     def profile_enable(self, on: bool = True):
         L.check(self.lib.fg_profile_enable(self.handle, int(on)), lib=self.lib)
 

@@ -197,6 +197,11 @@ int fg_debug_apply_preconditioner(fg_handle h, int mode, int nc, const fg_real* 
  * reference counterpart (its preconditioner for these solves is ILU(0), off by default); fp32 library only. */
 int fg_set_fd_helmholtz(fg_handle h, const float* lam_host);
 int fg_advection_retries(fg_handle h, int64_t* out, int32_t reset);
+/* Which kernels the NEXT un-preconditioned advection-diffusion solve of `nc` right-hand sides will run (tests, bench reports):
+ * 0 = five kernels per BiCGStab iteration, 1 = two brick kernels (csrc/fg_bicgstab.hip k_bicgf_a / _b), 2 = two z-marching
+ * LDS-ring kernels (csrc/fg_bicgstab3d.hip: 3-D grids that fit the tiles and fill the chip).  Replaces nothing in the reference
+ * (bicgstab_solver_kernel.cu:63-411 has one form). */
+int fg_advection_solver_form(fg_handle h, int nc, int32_t* out);
 /* CopyScalarResultToBlocks (:6558-6746) */
 int fg_copy_scalar_result_to_blocks(fg_handle h, int channel, void* stream);
 /* SetupPressureMatrix (:5599-5615, kernel :4812-4978): rA = 1/A */

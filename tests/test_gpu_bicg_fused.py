@@ -92,3 +92,100 @@ def test_fused_step_is_bit_reproducible(monkeypatch):
         outs.append((ns.velocity.clone(), ns.pressure.clone()))
         ns.close()
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
+# ---- 3-D: the two-kernel iteration as z-marching LDS-ring kernels (csrc/fg_bicgstab3d.hip; the default in 3-D when the grid
+# fits the tiles and fills the chip, forced here on small grids with FG_BICG3 = planes per z-chunk)
+def _solve3(case, dt, mode, monkeypatch, zc=4, bxl=None, **kw):
+    """mode: 'zmarch' | 'brick' (two-kernel brick form) | 'five'."""
+    monkeypatch.setenv("FG_BICG3", str(zc) if mode == "zmarch" else "0")
+    if bxl:
+        monkeypatch.setenv("FG_BICG3_BXL", str(bxl))
+    else:
+        monkeypatch.delenv("FG_BICG3_BXL", raising=False)
+    return _solve(case, dt, mode != "five", monkeypatch, **kw)
+
+
+ZCASES = [
+    # (case kwargs, planes per chunk, tile lanes): walls in y / periodic everywhere / walls in z and x / ragged last chunk
+    (dict(dims=3, n=(64, 16, 8), fixed_axes=(1,), B=2, seed=21), 4, None),
+    (dict(dims=3, n=(64, 32, 9), fixed_axes=(), B=2, seed=22), 4, None),
+    (dict(dims=3, n=(128, 16, 6), fixed_axes=(0, 2), B=3, seed=23), 3, None),
+    (dict(dims=3, n=(128, 16, 8), fixed_axes=(1,), B=2, seed=24), 8, 32),
+    (dict(dims=3, n=(128, 32, 12), fixed_axes=(2,), B=1, seed=25), 5, 16),
+]
+
+
+@pytest.mark.parametrize("kw,zc,bxl", ZCASES)
+def test_zmarch_iteration_matches_direct_solve_and_the_brick_kernels(kw, zc, bxl, monkeypatch):
+    case = make_case(vel_scale=0.4, nu=0.03, **kw)
+    dt = 0.08
+    xz, inf_z = _solve3(case, dt, "zmarch", monkeypatch, zc=zc, bxl=bxl)
+    x5, inf_5 = _solve3(case, dt, "five", monkeypatch)
+    assert all(i.converged and i.is_finite for i in inf_z) and all(i.converged for i in inf_5)
+    g = case.grid()
+    for b in range(case.B):
+        dom = case.oracle_domain(b, g)
+        C, _, _ = O.build_advection_matrix(dom, dt)
+        rhs = O.advection_rhs_velocity(dom, dt)
+        for comp in range(case.dims):
+            x_ref = O.solve_direct(C, rhs[comp].ravel()).reshape(case.shape)
+            assert rel_err(xz[b, comp], x_ref) < 3e-5, (b, comp)
+    assert rel_err(xz, x5) < 1e-5
+    for a, b in zip(inf_z, inf_5):
+        assert abs(a.used_iterations - b.used_iterations) <= max(3, b.used_iterations // 4), (a.used_iterations, b.used_iterations)
+    assert max(i.used_iterations for i in inf_z) >= 3
+
+
+def test_zmarch_cap_warm_start_scalar_and_uneven_convergence(monkeypatch):
+    case = make_case(dims=3, n=(64, 16, 8), fixed_axes=(1,), B=3, seed=31, vel_scale=0.4, nu=0.03, n_scalars=1)
+    # iteration cap: same two iterations, same report as the five kernels
+    xz, inf_z = _solve3(case, 0.08, "zmarch", monkeypatch, max_iterations=2)
+    x5, inf_5 = _solve3(case, 0.08, "five", monkeypatch, max_iterations=2)
+    assert [i.used_iterations for i in inf_z] == [i.used_iterations for i in inf_5] == [2] * (case.B * 3)
+    assert not any(i.converged for i in inf_z) and rel_err(xz, x5) < 1e-5
+    assert np.allclose([i.final_residual for i in inf_z], [i.final_residual for i in inf_5], rtol=1e-3)
+    # passive scalar: one system per env (the nc = 1 instance)
+    xz, inf_z = _solve3(case, 0.08, "zmarch", monkeypatch, for_scalar=True)
+    x5, inf_5 = _solve3(case, 0.08, "five", monkeypatch, for_scalar=True)
+    assert all(i.converged for i in inf_z) and rel_err(xz, x5) < 1e-5
+    # a loose tolerance: the systems of an env end in different iterations (the slow path of the kernels: per-system modes,
+    # converged-on-s half updates) and still agree with the five kernels
+    case.velocity[:, 2] *= 1e-3              # (an absolute tolerance: the small component and the slow env finish early)
+    case.velocity[1] *= 0.05
+    xz, inf_z = _solve3(case, 0.08, "zmarch", monkeypatch, tol=2e-4)
+    x5, inf_5 = _solve3(case, 0.08, "five", monkeypatch, tol=2e-4)
+    assert all(i.converged for i in inf_z)
+    assert len({i.used_iterations for i in inf_z}) > 1, [i.used_iterations for i in inf_z]
+    assert all(abs(a.used_iterations - b.used_iterations) <= 2 for a, b in zip(inf_z, inf_5))
+    assert np.abs(xz - x5).max() < 2e-4 * 0.08 * 10            # both within the tolerance of the same answer (x ~ dt rhs)
+    # the same with the init kernel kept (FG_BICG3_MIX = 7: no folded start) -- the folded start is the same recurrence
+    monkeypatch.setenv("FG_BICG3_MIX", "7")
+    xk, inf_k = _solve3(case, 0.08, "zmarch", monkeypatch, tol=2e-4)
+    monkeypatch.delenv("FG_BICG3_MIX")
+    assert all(abs(a.used_iterations - b.used_iterations) <= 2 for a, b in zip(inf_k, inf_z))
+    assert np.abs(xk - xz).max() < 2e-4 * 0.08 * 10
+    # start vector = the solution: no iteration
+    monkeypatch.setenv("FG_BICG3", "4")
+    ns = case.native()
+    ns.setup_advection(0.08)
+    ns.set_advection_start(False)
+    first = ns.solve_advection(tol=1e-6)
+    ns.set_advection_start(True)
+    again = ns.solve_advection(tol=1e-5)
+    assert all(i.used_iterations > 0 for i in first) and all(i.used_iterations == -1 and i.converged for i in again)
+    ns.close()
+
+
+def test_zmarch_step_is_bit_reproducible_and_batch_independent(monkeypatch):
+    monkeypatch.setenv("FG_BICG3", "4")
+    case = make_case(dims=3, n=(64, 16, 8), fixed_axes=(1,), B=3, seed=33, vel_scale=0.4, with_source=True)
+    outs = []
+    for _ in range(2):
+        ns = case.native()
+        for _ in range(2):
+            ok, stats = ns.piso_step(0.03, advection_tol=1e-6, pressure_tol=1e-6)
+            assert ok
+        outs.append((ns.velocity.clone(), ns.pressure.clone()))
+        ns.close()
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
