@@ -31,11 +31,11 @@ constexpr int A_RHOE = 10;
     const int N = D.N;                                  \
     const bool valid = i < N;
 
-__device__ __forceinline__ bool mb_active(const float* dt, int b) { return dt == nullptr || dt[b] > 0.f; }
+__device__ __forceinline__ bool mb_active(const mb_real* dt, int b) { return dt == nullptr || dt[b] > 0.f; }
 
 template <int DIMS>
-__device__ __forceinline__ void mb_load_T(const float* __restrict__ T, int i, float (&mi)[DIMS * DIMS], float& det) {
-    const float* t = T + (size_t)i * (DIMS * DIMS + 1);
+__device__ __forceinline__ void mb_load_T(const mb_real* __restrict__ T, int i, mb_real (&mi)[DIMS * DIMS], mb_real& det) {
+    const mb_real* t = T + (size_t)i * (DIMS * DIMS + 1);
 #pragma unroll
     for (int q = 0; q < DIMS * DIMS; ++q) mi[q] = t[q];
     det = t[DIMS * DIMS];
@@ -43,30 +43,30 @@ __device__ __forceinline__ void mb_load_T(const float* __restrict__ T, int i, fl
 
 // contravariant components det * Minv u of the cells, and of the boundary faces along their own axis
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_contra(MbDev D, const float* __restrict__ dt, const float* __restrict__ u,
-                                                         const float* __restrict__ ub, float* __restrict__ cc,
-                                                         float* __restrict__ fb) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_contra(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ u,
+                                                         const mb_real* __restrict__ ub, mb_real* __restrict__ cc,
+                                                         mb_real* __restrict__ fb) {
     MB_CELL
     if (!mb_active(dt, b)) return;
     if (valid) {
-        float mi[DIMS * DIMS], det;
+        mb_real mi[DIMS * DIMS], det;
         mb_load_T<DIMS>(D.T, i, mi, det);
-        float v[DIMS];
+        mb_real v[DIMS];
 #pragma unroll
         for (int c = 0; c < DIMS; ++c) v[c] = u[((size_t)b * DIMS + c) * N + i];
 #pragma unroll
         for (int a = 0; a < DIMS; ++a) {
-            float s = 0.f;
+            mb_real s = 0.f;
 #pragma unroll
             for (int c = 0; c < DIMS; ++c) s += mi[a * DIMS + c] * v[c];
             cc[((size_t)b * DIMS + a) * N + i] = det * s;
         }
     }
     if (fb != nullptr && i < D.NB) {
-        float mi[DIMS * DIMS], det;
+        mb_real mi[DIMS * DIMS], det;
         mb_load_T<DIMS>(D.Tb, i, mi, det);
         const int axis = D.bface[i] >> 1;
-        float s = 0.f;
+        mb_real s = 0.f;
 #pragma unroll
         for (int c = 0; c < DIMS; ++c) s += mi[axis * DIMS + c] * ub[((size_t)b * DIMS + c) * D.NB + i];
         fb[(size_t)b * D.NB + i] = det * s;
@@ -75,33 +75,33 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_contra(MbDev D, const float* __
 
 // face flux, not multiplied by the face sign (computeFluxesNDLoop, K.cu:1568-1645)
 template <int DIMS>
-__device__ __forceinline__ float mb_flux(const MbDev& D, const float* __restrict__ cc_b, const float* __restrict__ fb_b,
+__device__ __forceinline__ mb_real mb_flux(const MbDev& D, const mb_real* __restrict__ cc_b, const mb_real* __restrict__ fb_b,
                                          int f, int i) {
     const int n = D.nbr[(size_t)f * D.N + i];
     if (n < 0) return fb_b[-1 - n];
     const int code = D.fcode[(size_t)f * D.N + i];
-    const float vn = cc_b[(size_t)(code & 3) * D.N + n];
+    const mb_real vn = cc_b[(size_t)(code & 3) * D.N + n];
     return 0.5f * (((code & 4) ? -vn : vn) + cc_b[(size_t)(f >> 1) * D.N + i]);
 }
 
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_matrix(MbDev D, const float* __restrict__ dt, float nu,
-                                                         const float* __restrict__ cc, const float* __restrict__ fb,
-                                                         float* __restrict__ Cdiag, float* __restrict__ Coff,
-                                                         float* __restrict__ rA) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_matrix(MbDev D, const mb_real* __restrict__ dt, mb_real nu,
+                                                         const mb_real* __restrict__ cc, const mb_real* __restrict__ fb,
+                                                         mb_real* __restrict__ Cdiag, mb_real* __restrict__ Coff,
+                                                         mb_real* __restrict__ rA) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     constexpr int F = 2 * DIMS;
-    const float det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
-    const float* cc_b = cc + (size_t)b * DIMS * N;
-    const float* fb_b = fb + (size_t)b * D.NB;
-    float diag = det / dt[b] + nu * D.Vdiag[i];
-    const float rdet = 1.f / det;
+    const mb_real det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
+    const mb_real* cc_b = cc + (size_t)b * DIMS * N;
+    const mb_real* fb_b = fb + (size_t)b * D.NB;
+    mb_real diag = det / dt[b] + nu * D.Vdiag[i];
+    const mb_real rdet = 1.f / det;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        float o = 0.f;
+        mb_real o = 0.f;
         if (D.nbr[(size_t)f * N + i] >= 0) {
-            const float ff = ((f & 1) ? 0.5f : -0.5f) * mb_flux<DIMS>(D, cc_b, fb_b, f, i);
+            const mb_real ff = ((f & 1) ? 0.5f : -0.5f) * mb_flux<DIMS>(D, cc_b, fb_b, f, i);
             diag += ff;
             o = (ff + nu * D.Voff[(size_t)f * N + i]) * rdet;
         }
@@ -114,20 +114,20 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_matrix(MbDev D, const float* __
 
 // boundary sources of one cell and component: -u_b flux_b n + 2 nu alpha_b u_b over its prescribed faces
 template <int DIMS>
-__device__ __forceinline__ float mb_boundary_source(const MbDev& D, const float* __restrict__ ub_c,
-                                                    const float* __restrict__ fb_b, float nu, int i) {
-    float s = 0.f;
+__device__ __forceinline__ mb_real mb_boundary_source(const MbDev& D, const mb_real* __restrict__ ub_c,
+                                                    const mb_real* __restrict__ fb_b, mb_real nu, int i) {
+    mb_real s = 0.f;
 #pragma unroll
     for (int f = 0; f < 2 * DIMS; ++f) {
         const int n = D.nbr[(size_t)f * D.N + i];
         if (n >= 0) continue;
         const int k = -1 - n;
-        const float* t = D.Tb + (size_t)k * (DIMS * DIMS + 1);
-        float a = 0.f;
+        const mb_real* t = D.Tb + (size_t)k * (DIMS * DIMS + 1);
+        mb_real a = 0.f;
 #pragma unroll
         for (int q = 0; q < DIMS; ++q) a += t[(f >> 1) * DIMS + q] * t[(f >> 1) * DIMS + q];
         a *= t[DIMS * DIMS];
-        const float vel = ub_c[k];
+        const mb_real vel = ub_c[k];
         s += vel * (2.f * nu * a - ((f & 1) ? fb_b[k] : -fb_b[k]));
     }
     return s;
@@ -135,19 +135,19 @@ __device__ __forceinline__ float mb_boundary_source(const MbDev& D, const float*
 
 // velocity right-hand side (kPISO_build_advection_RHS): grid.z = component
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_vrhs(MbDev D, const float* __restrict__ dt, float nu,
-                                                       const float* __restrict__ u_old, const float* __restrict__ u_res,
-                                                       const float* __restrict__ ub, const float* __restrict__ fb,
-                                                       const float* __restrict__ src, float* __restrict__ rhs) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_vrhs(MbDev D, const mb_real* __restrict__ dt, mb_real nu,
+                                                       const mb_real* __restrict__ u_old, const mb_real* __restrict__ u_res,
+                                                       const mb_real* __restrict__ ub, const mb_real* __restrict__ fb,
+                                                       const mb_real* __restrict__ src, mb_real* __restrict__ rhs) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     const int c = blockIdx.z;
     const size_t vb = ((size_t)b * DIMS + c) * N;
-    const float* ub_c = ub + ((size_t)b * DIMS + c) * D.NB;
-    const float det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
-    float r = det * u_old[vb + i] / dt[b];
+    const mb_real* ub_c = ub + ((size_t)b * DIMS + c) * D.NB;
+    const mb_real det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
+    mb_real r = det * u_old[vb + i] / dt[b];
     r += mb_boundary_source<DIMS>(D, ub_c, fb + (size_t)b * D.NB, nu, i);
-    float S = 0.f;
+    mb_real S = 0.f;
     for (int k = 0; k < D.KC; ++k) S += D.SVc_w[(size_t)k * N + i] * u_res[vb + D.SVc_idx[(size_t)k * N + i]];
     for (int k = 0; k < D.KB; ++k) S += D.SVb_w[(size_t)k * N + i] * ub_c[D.SVb_idx[(size_t)k * N + i]];
     r -= nu * S;
@@ -158,17 +158,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_vrhs(MbDev D, const float* __re
 
 // pressure matrix from the coefficient pairs (PISO_build_pressure_matrix)
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* __restrict__ dt, const float* __restrict__ rA,
-                                                          float* __restrict__ Pdiag, float* __restrict__ Poff,
-                                                          float* __restrict__ Poff4, const uint16_t* __restrict__ cell_slot = nullptr,
-                                                          float* __restrict__ Poff4s = nullptr, float* __restrict__ Pdiag_s = nullptr) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ rA,
+                                                          mb_real* __restrict__ Pdiag, mb_real* __restrict__ Poff,
+                                                          mb_real* __restrict__ Poff4, const uint16_t* __restrict__ cell_slot = nullptr,
+                                                          mb_real* __restrict__ Poff4s = nullptr, mb_real* __restrict__ Pdiag_s = nullptr) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     constexpr int F = 2 * DIMS;
-    const float* ra = rA + (size_t)b * N;
-    float o4[4] = {0.f, 0.f, 0.f, 0.f}, dv = 0.f;
-    const float rp = ra[i];
-    float rn[F];
+    const mb_real* ra = rA + (size_t)b * N;
+    mb_real o4[4] = {0.f, 0.f, 0.f, 0.f}, dv = 0.f;
+    const mb_real rp = ra[i];
+    mb_real rn[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const int n = D.nbr[(size_t)f * N + i];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* _
     }
 #pragma unroll
     for (int g = 0; g <= F; ++g) {
-        float v = 0.f;
+        mb_real v = 0.f;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const size_t q = ((size_t)g * F + f) * N + i;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* _
         }
         if (g == 0) { Pdiag[(size_t)b * N + i] = v; dv = v; }
         else {
-            const float o = (D.nbr[(size_t)(g - 1) * N + i] >= 0) ? v : 0.f;
+            const mb_real o = (D.nbr[(size_t)(g - 1) * N + i] >= 0) ? v : 0.f;
             Poff[((size_t)b * F + (g - 1)) * N + i] = o;
             if (DIMS == 2) o4[(g - 1) & 3] = o;
         }
@@ -201,48 +201,48 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const float* _
 
 // h = (u_old/dt - H u* + S) / A   (PISO_build_pressure_rhs): grid.z = component
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_h(MbDev D, const float* __restrict__ dt, float nu,
-                                                    const float* __restrict__ rA, const float* __restrict__ Coff,
-                                                    const float* __restrict__ u_old, const float* __restrict__ u_star,
-                                                    const float* __restrict__ ub, const float* __restrict__ fb,
-                                                    const float* __restrict__ src, float* __restrict__ h) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_h(MbDev D, const mb_real* __restrict__ dt, mb_real nu,
+                                                    const mb_real* __restrict__ rA, const mb_real* __restrict__ Coff,
+                                                    const mb_real* __restrict__ u_old, const mb_real* __restrict__ u_star,
+                                                    const mb_real* __restrict__ ub, const mb_real* __restrict__ fb,
+                                                    const mb_real* __restrict__ src, mb_real* __restrict__ h) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     constexpr int F = 2 * DIMS;
     const int c = blockIdx.z;
     const size_t vb = ((size_t)b * DIMS + c) * N;
-    const float det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
-    float H = 0.f;
+    const mb_real det = D.T[(size_t)i * (DIMS * DIMS + 1) + DIMS * DIMS];
+    mb_real H = 0.f;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const int n = D.nbr[(size_t)f * N + i];
         if (n >= 0) H += Coff[((size_t)b * F + f) * N + i] * u_star[vb + n];
     }
-    float S = mb_boundary_source<DIMS>(D, ub + ((size_t)b * DIMS + c) * D.NB, fb + (size_t)b * D.NB, nu, i) / det;
+    mb_real S = mb_boundary_source<DIMS>(D, ub + ((size_t)b * DIMS + c) * D.NB, fb + (size_t)b * D.NB, nu, i) / det;
     if (src) S += src[vb + i];
     h[vb + i] = rA[(size_t)b * N + i] * (u_old[vb + i] / dt[b] - H + S);
 }
 
 // div of the flux of h, plus the lagged corner terms of the pressure (add_corner != 0)
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_div(MbDev D, const float* __restrict__ dt, const float* __restrict__ cc,
-                                                      const float* __restrict__ fb, const float* __restrict__ rA,
-                                                      const float* __restrict__ p, int add_corner,
-                                                      float* __restrict__ div) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_div(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ cc,
+                                                      const mb_real* __restrict__ fb, const mb_real* __restrict__ rA,
+                                                      const mb_real* __restrict__ p, int add_corner,
+                                                      mb_real* __restrict__ div) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
-    const float* cc_b = cc + (size_t)b * DIMS * N;
-    const float* fb_b = fb + (size_t)b * D.NB;
-    float s = 0.f;
+    const mb_real* cc_b = cc + (size_t)b * DIMS * N;
+    const mb_real* fb_b = fb + (size_t)b * D.NB;
+    mb_real s = 0.f;
 #pragma unroll
     for (int a = 0; a < DIMS; ++a) s += mb_flux<DIMS>(D, cc_b, fb_b, 2 * a + 1, i) - mb_flux<DIMS>(D, cc_b, fb_b, 2 * a, i);
     if (add_corner) {
-        const float* ra = rA + (size_t)b * N;
-        const float* pb = p + (size_t)b * N;
-        const float rp = ra[i];
+        const mb_real* ra = rA + (size_t)b * N;
+        const mb_real* pb = p + (size_t)b * N;
+        const mb_real rp = ra[i];
         for (int k = 0; k < D.KPN; ++k) {
             const size_t q = (size_t)k * N + i;
-            const float wp = D.SP_wp[q], wn = D.SP_wn[q];
+            const mb_real wp = D.SP_wp[q], wn = D.SP_wn[q];
             if (wp == 0.f && wn == 0.f) continue;
             const int n = D.nbr[(size_t)D.SP_face[q] * N + i];
             s += (wp * rp + wn * (n >= 0 ? ra[n] : 0.f)) * pb[D.SP_idx[q]];
@@ -253,25 +253,25 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_div(MbDev D, const float* __res
 
 // u = h - (1/A) Minv^T grad_xi p   (PISO_update_velocity + getPressureGradient, K.cu:816-849)
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_correct(MbDev D, const float* __restrict__ dt, const float* __restrict__ rA,
-                                                          const float* __restrict__ h, const float* __restrict__ p,
-                                                          float* __restrict__ u) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_correct(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ rA,
+                                                          const mb_real* __restrict__ h, const mb_real* __restrict__ p,
+                                                          mb_real* __restrict__ u) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
-    const float* pb = p + (size_t)b * N;
-    float mi[DIMS * DIMS], det;
+    const mb_real* pb = p + (size_t)b * N;
+    mb_real mi[DIMS * DIMS], det;
     mb_load_T<DIMS>(D.T, i, mi, det);
-    float g[DIMS];
+    mb_real g[DIMS];
 #pragma unroll
     for (int a = 0; a < DIMS; ++a) {
         const int nl = D.nbr[(size_t)(2 * a) * N + i], nh = D.nbr[(size_t)(2 * a + 1) * N + i];
-        const float fac = (nl < 0 || nh < 0) ? 1.f : 0.5f;
+        const mb_real fac = (nl < 0 || nh < 0) ? 1.f : 0.5f;
         g[a] = (pb[nh < 0 ? i : nh] - pb[nl < 0 ? i : nl]) * fac;
     }
-    const float ra = rA[(size_t)b * N + i];
+    const mb_real ra = rA[(size_t)b * N + i];
 #pragma unroll
     for (int c = 0; c < DIMS; ++c) {
-        float gp = 0.f;
+        mb_real gp = 0.f;
 #pragma unroll
         for (int a = 0; a < DIMS; ++a) gp += g[a] * mi[a * DIMS + c];
         const size_t q = ((size_t)b * DIMS + c) * N + i;
@@ -279,18 +279,18 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_correct(MbDev D, const float* _
     }
 }
 
-__device__ __forceinline__ float mb_block_sum(float v, float* lds) {
+__device__ __forceinline__ mb_real mb_block_sum(mb_real v, mb_real* lds) {
     v = fg_wave_sum(v);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float r = lds[0] + lds[1] + lds[2] + lds[3];
+    const mb_real r = lds[0] + lds[1] + lds[2] + lds[3];
     __syncthreads();
     return r;
 }
 // NV sums with ONE barrier pair (lds: NV * 4 floats): in the launch-bound Krylov kernels the reduction tail is a visible
 // share of the run time, and four sums one after the other are eight barriers
 template <int NV>
-__device__ __forceinline__ void mb_block_sums(float (&v)[NV], float* lds) {
+__device__ __forceinline__ void mb_block_sums(mb_real (&v)[NV], mb_real* lds) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = fg_wave_sum(v[k]);
     if ((threadIdx.x & 63) == 0) {
@@ -305,36 +305,36 @@ __device__ __forceinline__ void mb_block_sums(float (&v)[NV], float* lds) {
 
 // max |Minv u| over cells and boundary faces (Block::getMaxVelocity, domain_structs.cpp:1580-1611)
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_maxvel(MbDev D, const float* __restrict__ u, const float* __restrict__ ub,
-                                                         float* __restrict__ out) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_maxvel(MbDev D, const mb_real* __restrict__ u, const mb_real* __restrict__ ub,
+                                                         mb_real* __restrict__ out) {
     MB_CELL
-    float m = 0.f;
+    mb_real m = 0.f;
     if (valid) {
-        const float* t = D.T + (size_t)i * (DIMS * DIMS + 1);
+        const mb_real* t = D.T + (size_t)i * (DIMS * DIMS + 1);
 #pragma unroll
         for (int a = 0; a < DIMS; ++a) {
-            float s = 0.f;
+            mb_real s = 0.f;
 #pragma unroll
             for (int c = 0; c < DIMS; ++c) s += t[a * DIMS + c] * u[((size_t)b * DIMS + c) * N + i];
-            m = fmaxf(m, fabsf(s));
+            m = mb_fmax(m, mb_fabs(s));
         }
     }
     if (i < D.NB) {
-        const float* t = D.Tb + (size_t)i * (DIMS * DIMS + 1);
+        const mb_real* t = D.Tb + (size_t)i * (DIMS * DIMS + 1);
 #pragma unroll
         for (int a = 0; a < DIMS; ++a) {
-            float s = 0.f;
+            mb_real s = 0.f;
 #pragma unroll
             for (int c = 0; c < DIMS; ++c) s += t[a * DIMS + c] * ub[((size_t)b * DIMS + c) * D.NB + i];
-            m = fmaxf(m, fabsf(s));
+            m = mb_fmax(m, mb_fabs(s));
         }
     }
     m = fg_wave_max(m);
-    __shared__ float lds[4];
+    __shared__ mb_real lds[4];
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+        m = mb_fmax(mb_fmax(lds[0], lds[1]), mb_fmax(lds[2], lds[3]));
 #if FG_MB_F64
         atomicMax(reinterpret_cast<unsigned long long*>(out) + b, (unsigned long long)__double_as_longlong(m));  // non-negative doubles order like their bits
 #else
@@ -344,25 +344,25 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_maxvel(MbDev D, const float* __
 }
 
 constexpr int MB_SUM_WGS = 8;
-__global__ void k_mb_sum(int N, const float* __restrict__ dt, const float* __restrict__ x, float* __restrict__ out) {
+__global__ void k_mb_sum(int N, const mb_real* __restrict__ dt, const mb_real* __restrict__ x, mb_real* __restrict__ out) {
     const int b = blockIdx.y;
     if (!mb_active(dt, b)) return;
-    float s = 0.f;
+    mb_real s = 0.f;
     for (int i = blockIdx.x * FG_BLOCK + threadIdx.x; i < N; i += gridDim.x * FG_BLOCK) s += x[(size_t)b * N + i];
-    __shared__ float lds[4];
+    __shared__ mb_real lds[4];
     s = mb_block_sum(s, lds);
     if (threadIdx.x == 0) out[b * MB_SUM_WGS + blockIdx.x] = s;   // one partial per workgroup, summed in index order by k_mb_sub_mean
 }
-__global__ void k_mb_sub_mean(int N, const float* __restrict__ dt, const float* __restrict__ sum, float* __restrict__ x,
-                              float* __restrict__ copy) {
+__global__ void k_mb_sub_mean(int N, const mb_real* __restrict__ dt, const mb_real* __restrict__ sum, mb_real* __restrict__ x,
+                              mb_real* __restrict__ copy) {
     const int b = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
     if (i >= N || !mb_active(dt, b)) return;
-    const float* ps = sum + b * MB_SUM_WGS;
-    const float v = x[(size_t)b * N + i] - (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / (float)N;
+    const mb_real* ps = sum + b * MB_SUM_WGS;
+    const mb_real v = x[(size_t)b * N + i] - (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / (mb_real)N;
     x[(size_t)b * N + i] = v;
     if (copy) copy[(size_t)b * N + i] = v;
 }
-__global__ void k_mb_copy(size_t per_env, const float* __restrict__ dt, const float* __restrict__ src, float* __restrict__ dst) {
+__global__ void k_mb_copy(size_t per_env, const mb_real* __restrict__ dt, const mb_real* __restrict__ src, mb_real* __restrict__ dst) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * FG_BLOCK + threadIdx.x;
     if (i >= per_env || !mb_active(dt, b)) return;
@@ -375,39 +375,39 @@ __global__ void k_mb_copy(size_t per_env, const float* __restrict__ dt, const fl
 // solvers (fg_bicgstab.hip, fg_poisson.hip), so the host only polls convergence.
 // ---------------------------------------------------------------------------------------------------------------
 struct MbSolve {
-    const float* diag; const float* off; const float* rhs;
-    float* x; float* r; float* rw; float* p; float* v; float* t;
-    FgDacc* acc; float* sc; int32_t* flags; fg_solve_info* info;
-    int nc; float tol;
+    const mb_real* diag; const mb_real* off; const mb_real* rhs;
+    mb_real* x; mb_real* r; mb_real* rw; mb_real* p; mb_real* v; mb_real* t;
+    FgDacc* acc; mb_real* sc; int32_t* flags; fg_solve_info* info;
+    int nc; mb_real tol;
     // best-iterate tracking of the CG pressure solve (returnBestResult, cg_solver_kernel.cu:345-361): sc[2 sys] holds the
     // residual of the kept iterate, best_it the iteration it belongs to, best_x the iterate itself
-    float* best_x; int32_t* best_it; int stall_limit;
+    mb_real* best_x; int32_t* best_it; int stall_limit;
     // device-side iteration index of the graph-replayed CG: ctr[0] read by k_mbc_ap*, ctr[1] - 1 by k_mbc_update*
     int32_t* it_ctr; int max_iterations;
     int it_base;  // BiCGStab: iteration index of the last restart (kernels run on the index since then, reports add this)
     // stall acceptance (off when 0): a system whose kept iterate is within accept_factor * tol and has not improved for
     // accept_window iterations ends with that iterate and counts as converged
-    float accept_factor; int accept_window;
+    mb_real accept_factor; int accept_window;
     // BiCGStab on the singular pressure system: 1 = iterate on Q P with Q = I - 1 1^T / N (all vectors mean-free), which removes
     // the null space the plain recurrence breaks down on
     int project;
     // right preconditioning (multilevel, mb_ml_apply): when set, v = A mp with mp = M p, t = A ms with ms = M s, and the iterate
     // advances along mp / ms; the recurrence itself (p, s, r and all dot products) is the one of A M
-    const float* mp; const float* ms;
+    const mb_real* mp; const mb_real* ms;
     // fused s / t kernel (k_mbb_st*): s lives in its own buffer (the neighbours' s is recomputed from r and v, which must still be
     // there), k_mbb_x reads it from here and takes over the convergence-on-s decision; null = the separate s and t kernels
-    float* sbuf;
+    mb_real* sbuf;
     // fused p / v kernel (k_mbb_pv*): p and v of the previous iteration (the neighbours' new p is recomputed from them, so the new p
     // and v go to the other buffer of a pair); q.p / q.v are the current ones.  Null = the separate p and v kernels
-    const float* p_prev; const float* v_prev;
+    const mb_real* p_prev; const mb_real* v_prev;
 };
 
 struct MbGraphKey { MbSolve q; int vec4, project_mean; hipStream_t stream; };
 
 template <int DIMS>
-__device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b, const float* __restrict__ x, int i) {
+__device__ __forceinline__ mb_real mb_spmv(const MbDev& D, const MbSolve& q, int b, const mb_real* __restrict__ x, int i) {
     constexpr int F = 2 * DIMS;
-    float y = q.diag[(size_t)b * D.N + i] * x[i];
+    mb_real y = q.diag[(size_t)b * D.N + i] * x[i];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const int n = D.nbr[(size_t)f * D.N + i];
@@ -425,14 +425,14 @@ __device__ __forceinline__ float mb_spmv(const MbDev& D, const MbSolve& q, int b
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0); \
     const size_t vb = (size_t)sys * N;                  \
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;           \
-    __shared__ float lds[16];                           \
+    __shared__ mb_real lds[16];                           \
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
 
 // accumulator / scalar / flag words: only through acc_ld / acc_st, sc_ld / sc_st, flag_ld / flag_st (fg_internal.h)
-__device__ __forceinline__ float mb_rms(double rr, int n) { return (float)sqrt(rr / (double)n); }
+__device__ __forceinline__ mb_real mb_rms(double rr, int n) { return (mb_real)sqrt(rr / (double)n); }
 // ok_flag: what a finite verdict stores (1 done; 4 = converged on s, the x kernel still owes x += alpha p) -- ONE store of the
 // flag, after the info words (other workgroups of the env read it in the same launch)
-__device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, float crit, int it, int ok_flag = 1) {
+__device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, mb_real crit, int it, int ok_flag = 1) {
     const bool finite = isfinite(crit);
     q.info[sys].final_residual = crit;
     q.info[sys].used_iterations = it;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void mb_mark(const MbSolve& q, int sys, float crit, i
     flag_st(q.flags + (sys), finite ? ok_flag : 2);
 }
 
-__global__ void k_mbs_begin(const float* __restrict__ dt, MbSolve q, int nsys) {
+__global__ void k_mbs_begin(const mb_real* __restrict__ dt, MbSolve q, int nsys) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     for (int k = 0; k < MB_ACC; ++k) acc_st(q.acc + ((size_t)s * MB_ACC + k), 0.0);
@@ -459,7 +459,7 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int use_x0, int sum_slot, int defer_rho) {
     MB_SYS
     if (flag_ld(q.flags + (sys)) != 0) return;
-    float r = 0.f;
+    mb_real r = 0.f;
     if (valid) {
         r = q.rhs[vb + i];
         if (use_x0) r -= mb_spmv<DIMS>(D, q, b, q.x + vb, i);
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbs_init(MbDev D, MbSolve q, int u
         if (q.rw) q.rw[vb + i] = r;
         q.p[vb + i] = r;
     }
-    const float s = mb_block_sum(r * r, lds);
-    const float s1 = sum_slot >= 0 ? mb_block_sum(valid ? r * (q.project ? 1.f : D.yproj[i]) : 0.f, lds) : 0.f;
+    const mb_real s = mb_block_sum(r * r, lds);
+    const mb_real s1 = sum_slot >= 0 ? mb_block_sum(valid ? r * (q.project ? 1.f : D.yproj[i]) : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
         if (!defer_rho) { acc_add(a + A_RHO, (double)s); acc_add(a + A_RR, (double)s); }
         if (sum_slot >= 0) acc_add(a + sum_slot, (double)s1);
@@ -499,13 +499,13 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_fold(int N, MbSolve q, double*
     if (mode == 0) { x64[k] = 0.0; return; }                        // cold start
     if (mode == 1) { x64[k] = (double)q.x[k]; q.x[k] = 0.f; return; }  // warm start from the caller's x
     if (mode == 2) { if (flag_ld(q.flags + (sys)) == 0) { x64[k] += (double)q.x[k]; q.x[k] = 0.f; } return; }  // restart
-    q.x[k] = (float)(x64[k] + (double)q.x[k]);                       // mode 3: hand back the sum
+    q.x[k] = (mb_real)(x64[k] + (double)q.x[k]);                       // mode 3: hand back the sum
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbr_residual(MbDev D, MbSolve q, const double* __restrict__ x64, int sum_slot, int defer_rho) {
     MB_SYS
     if (flag_ld(q.flags + (sys)) != 0) return;
-    float r = 0.f;
+    mb_real r = 0.f;
     if (valid) {
         constexpr int F = 2 * DIMS;
         const double* x = x64 + vb;
@@ -515,12 +515,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_residual(MbDev D, MbSolve q, c
             const int n = D.nbr[(size_t)f * N + i];
             if (n >= 0) y += (double)q.off[((size_t)b * F + f) * N + i] * x[n];
         }
-        r = (float)((double)q.rhs[vb + i] - y);
+        r = (mb_real)((double)q.rhs[vb + i] - y);
         q.x[vb + i] = 0.f;
         q.r[vb + i] = r; q.rw[vb + i] = r; q.p[vb + i] = r;
     }
-    const float s = mb_block_sum(r * r, lds);
-    const float s1 = sum_slot >= 0 ? mb_block_sum(valid ? r : 0.f, lds) : 0.f;
+    const mb_real s = mb_block_sum(r * r, lds);
+    const mb_real s1 = sum_slot >= 0 ? mb_block_sum(valid ? r : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
         if (!defer_rho) { acc_add(a + A_RHO, (double)s); acc_add(a + A_RR, (double)s); }
         if (sum_slot >= 0) acc_add(a + sum_slot, (double)s1);
@@ -531,12 +531,12 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_residual(MbDev D, MbSolve q, c
 // k_mbb_project_init), so the fp64 iterate with the smallest one is kept and handed back when a solve ends unconverged --
 // BiCGStab's residual is far from monotone (spikes of two orders of magnitude on these systems) and without this an
 // unconverged solve returned whatever the last iteration happened to hold.
-__global__ void k_mbr_best_decide(MbSolve q, float* __restrict__ best_res, int32_t* __restrict__ keep, int n, int nsys, int first) {
+__global__ void k_mbr_best_decide(MbSolve q, mb_real* __restrict__ best_res, int32_t* __restrict__ keep, int n, int nsys, int first) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     keep[s] = 0;
     if (flag_ld(q.flags + (s)) != 0) return;
-    const float crit = (float)sqrt(acc_ld(q.acc + ((size_t)s * MB_ACC + A_RR)) / (double)n);
+    const mb_real crit = (mb_real)sqrt(acc_ld(q.acc + ((size_t)s * MB_ACC + A_RR)) / (double)n);
     if (first) best_res[s] = 3.0e38f;
     if (isfinite(crit) && crit < best_res[s]) { best_res[s] = crit; keep[s] = 1; }
 }
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_copy(int N, const int32_t
 }
 // systems that ended without converging (or non-finite): x64 <- kept iterate, fp32 correction dropped, residual reported
 __global__ __launch_bounds__(FG_BLOCK) void k_mbr_best_restore(int N, MbSolve q, double* __restrict__ x64, const double* __restrict__ best,
-                                                                const float* __restrict__ best_res) {
+                                                                const mb_real* __restrict__ best_res) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
     if (flag_ld(q.flags + (sys)) == 3 || flag_ld(q.flags + (sys)) == 0 || (q.info[sys].converged && q.info[sys].is_finite)) return;
     if (!(best_res[sys] < 3.0e38f)) return;   // nothing kept (non-finite from the start): leave it to the caller's fallback
@@ -562,14 +562,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q)
     if (flag_ld(q.flags + (sys)) != 0) return;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
     const size_t vb = (size_t)sys * N;
-    __shared__ float lds[4];
-    const float m = (float)(acc_ld(a + (A_ST)) / (double)N);  // k_mbs_init left sum r in A_ST
-    float r = 0.f;
+    __shared__ mb_real lds[4];
+    const mb_real m = (mb_real)(acc_ld(a + (A_ST)) / (double)N);  // k_mbs_init left sum r in A_ST
+    mb_real r = 0.f;
     if (i < N) {
         r = q.r[vb + i] - m;
         q.r[vb + i] = r; q.rw[vb + i] = r; q.p[vb + i] = r;
     }
-    const float s = mb_block_sum(r * r, lds);
+    const mb_real s = mb_block_sum(r * r, lds);
     if (threadIdx.x == 0) { acc_add(a + A_RHO, (double)s); acc_add(a + A_RR, (double)s); }
 }
 
@@ -581,9 +581,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_project_init(int N, MbSolve q)
 // residual half); a non-finite beta (rho of the previous iteration 0, omega 0) restarts the recurrence HERE from the current
 // residual: rw = p = r, rho = r.r.  Every workgroup of a system decides from the same words, so the decision is uniform.
 #define MB_BETA                                                                                                                   \
-    const float alpha = sc_ld(q.sc + (sys * 2)), omega = sc_ld(q.sc + (sys * 2 + 1));                                             \
+    const mb_real alpha = sc_ld(q.sc + (sys * 2)), omega = sc_ld(q.sc + (sys * 2 + 1));                                             \
     const double rho_now = acc_ld(a + (A_RHO + (it & 1)));                                                                         \
-    const float beta = it == 0 ? 0.f : (float)(rho_now / acc_ld(a + (A_RHOE + ((it + 1) & 1)))) * (alpha / omega);                \
+    const mb_real beta = it == 0 ? 0.f : (mb_real)(rho_now / acc_ld(a + (A_RHOE + ((it + 1) & 1)))) * (alpha / omega);                \
     const bool restart = it > 0 && !isfinite(beta);                                                                                \
     if (leader) acc_st(a + (A_RHOE + (it & 1)), restart ? acc_ld(a + (A_RR)) : rho_now);
 template <int DIMS>
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) 
     const int f = flag_ld(q.flags + (sys));
     if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
     if (f != 0) return;
-    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    const mb_real crit = mb_rms(acc_ld(a + (A_RR)), N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
         acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
@@ -601,17 +601,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p(MbDev D, MbSolve q, int it) 
     }
     MB_BETA
     if (it == 0 || !valid) return;
-    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;  // sum v of the previous iteration (slots 7 / 9 alternate)
-    if (restart) { const float r = q.r[vb + i]; q.rw[vb + i] = r; q.p[vb + i] = r; }
+    const mb_real mv = q.project ? (mb_real)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;  // sum v of the previous iteration (slots 7 / 9 alternate)
+    if (restart) { const mb_real r = q.r[vb + i]; q.rw[vb + i] = r; q.p[vb + i] = r; }
     else q.p[vb + i] = q.r[vb + i] + beta * (q.p[vb + i] - omega * (q.v[vb + i] - mv));
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) {
     MB_SYS
     if (flag_ld(q.flags + (sys)) != 0) return;
-    float part = 0.f, psum = 0.f;
+    mb_real part = 0.f, psum = 0.f;
     if (valid) {
-        const float y = mb_spmv<DIMS>(D, q, b, (q.mp ? q.mp : q.p) + vb, i);
+        const mb_real y = mb_spmv<DIMS>(D, q, b, (q.mp ? q.mp : q.p) + vb, i);
         q.v[vb + i] = y;
         part = q.rw[vb + i] * y;  // rw is mean-free: rw . (v - mean v) = rw . v
         psum = y;
@@ -627,13 +627,13 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) {
     MB_SYS
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
-    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
+    const mb_real alpha_raw = (mb_real)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const mb_real alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
-    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
-    float part = 0.f;
+    const mb_real mv = q.project ? (mb_real)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    mb_real part = 0.f;
     if (valid) {
-        const float r = q.r[vb + i] - alpha * (q.v[vb + i] - mv);
+        const mb_real r = q.r[vb + i] - alpha * (q.v[vb + i] - mv);
         q.r[vb + i] = r;
         part = r * r;
     }
@@ -644,14 +644,14 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) {
     MB_SYS
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);
+    const mb_real crit_s = mb_rms(acc_ld(a + (A_SS)), N);
     if (!(crit_s >= q.tol)) {  // converged on s (bicgstab_solver_kernel.cu:305-329): k_mbb_x applies x += alpha p
         if (leader) mb_mark(q, sys, crit_s, it, 4);
         return;
     }
-    float pt = 0.f, ptt = 0.f, pst = 0.f;
+    mb_real pt = 0.f, ptt = 0.f, pst = 0.f;
     if (valid) {
-        const float t = mb_spmv<DIMS>(D, q, b, (q.ms ? q.ms : q.r) + vb, i);
+        const mb_real t = mb_spmv<DIMS>(D, q, b, (q.ms ? q.ms : q.r) + vb, i);
         q.t[vb + i] = t;
         pt = t * q.r[vb + i];  // s is mean-free: (t - mean t) . s = t . s
         ptt = t * t;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
 #define MB_HALF                                                                                                           \
     bool half = (f == 4);                                                                                                 \
     if (q.sbuf) {                                                                                                         \
-        const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);                                                               \
+        const mb_real crit_s = mb_rms(acc_ld(a + (A_SS)), N);                                                               \
         half = !(crit_s >= q.tol);                                                                                        \
         if (half) {                                                                                                       \
             const bool fin = isfinite(crit_s);                                                                            \
@@ -691,29 +691,29 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     MB_SYS
     const int f = flag_ld(q.flags + (sys));
     if (f != 0 && f != 4) return;
-    const float alpha = sc_ld(q.sc + (sys * 2));
+    const mb_real alpha = sc_ld(q.sc + (sys * 2));
     MB_HALF
     const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
-    const float mt = (float)(st / (double)N);
-    const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
-    const float omega = isfinite(omega_raw) ? omega_raw : 0.f;
+    const mb_real mt = (mb_real)(st / (double)N);
+    const mb_real omega_raw = half ? 0.f : (mb_real)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    const mb_real omega = isfinite(omega_raw) ? omega_raw : 0.f;
     if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
-    float prr = 0.f, prho = 0.f;
+    mb_real prr = 0.f, prho = 0.f;
     if (valid) {
-        const float pd = (q.mp ? q.mp : q.p)[vb + i];
+        const mb_real pd = (q.mp ? q.mp : q.p)[vb + i];
         if (half) {
             q.x[vb + i] += alpha * pd;
         } else {
-            const float sv = (q.sbuf ? q.sbuf : q.r)[vb + i];
+            const mb_real sv = (q.sbuf ? q.sbuf : q.r)[vb + i];
             q.x[vb + i] += alpha * pd + omega * (q.ms ? q.ms[vb + i] : sv);
-            const float r = sv - omega * (q.t[vb + i] - mt);
+            const mb_real r = sv - omega * (q.t[vb + i] - mt);
             q.r[vb + i] = r;
             prr = r * r;
             prho = q.rw[vb + i] * r;
         }
     }
     if (half) return;
-    float sums[2] = {prr, prho};
+    mb_real sums[2] = {prr, prho};
     mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) { acc_add(a + A_RR, (double)sums[0]); acc_add(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
 }
@@ -730,30 +730,30 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);    \
     const size_t vb = (size_t)sys * N;                            \
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;                     \
-    __shared__ float lds[16];                                     \
+    __shared__ mb_real lds[16];                                     \
     (void)b; (void)leader; (void)a; (void)lds; (void)valid;
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+__device__ __forceinline__ float4 ld4(const mb_real* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(mb_real* p, mb_real a, mb_real b, mb_real c, mb_real d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
 // y = A x for the thread's four cells: xi = the vector at the own cells, gather(n) = the vector at any other cell
 template <int DIMS, typename G>
-__device__ __forceinline__ void mb_spmv4_core(const MbDev& D, const MbSolve& q, int b, int i, const float xi[4], G gather, float y[4]) {
+__device__ __forceinline__ void mb_spmv4_core(const MbDev& D, const MbSolve& q, int b, int i, const mb_real xi[4], G gather, mb_real y[4]) {
     constexpr int F = 2 * DIMS;
     const int N = D.N;
     const float4 d4 = ld4(q.diag + (size_t)b * N + i);
     y[0] = d4.x * xi[0]; y[1] = d4.y * xi[1]; y[2] = d4.z * xi[2]; y[3] = d4.w * xi[3];
     const int lane = threadIdx.x & 63;
-    const float from_prev = __shfl_up(xi[3], 1), from_next = __shfl_down(xi[0], 1);
+    const mb_real from_prev = __shfl_up(xi[3], 1), from_next = __shfl_down(xi[0], 1);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const int4 n4 = *reinterpret_cast<const int4*>(D.nbr + (size_t)f * N + i);
         const float4 o4 = ld4(q.off + ((size_t)b * F + f) * N + i);
         const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
-        const float oo[4] = {o4.x, o4.y, o4.z, o4.w};
+        const mb_real oo[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int n = nn[e];
             if (n < 0) continue;  // prescribed face: no matrix entry (as mb_spmv; 0 * x would turn a non-finite x into NaN)
-            float xn;
+            mb_real xn;
             if (f == 0 && n == i + e - 1 && (e > 0 || lane > 0)) xn = e > 0 ? xi[e > 0 ? e - 1 : 0] : from_prev;
             else if (f == 1 && n == i + e + 1 && (e < 3 || lane < 63)) xn = e < 3 ? xi[e < 3 ? e + 1 : 3] : from_next;
             else xn = gather(n);
@@ -762,9 +762,9 @@ __device__ __forceinline__ void mb_spmv4_core(const MbDev& D, const MbSolve& q, 
     }
 }
 template <int DIMS>
-__device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b, const float* __restrict__ x, int i, float y[4]) {
+__device__ __forceinline__ void mb_spmv4(const MbDev& D, const MbSolve& q, int b, const mb_real* __restrict__ x, int i, mb_real y[4]) {
     const float4 x4 = ld4(x + i);
-    const float xi[4] = {x4.x, x4.y, x4.z, x4.w};
+    const mb_real xi[4] = {x4.x, x4.y, x4.z, x4.w};
     mb_spmv4_core<DIMS>(D, q, b, i, xi, [x](int n) { return x[n]; }, y);
 }
 template <int DIMS>
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p4(MbDev D, MbSolve q, int it)
     const int f = flag_ld(q.flags + (sys));
     if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
     if (f != 0) return;
-    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    const mb_real crit = mb_rms(acc_ld(a + (A_RR)), N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
         acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_p4(MbDev D, MbSolve q, int it)
     }
     MB_BETA
     if (it == 0 || !valid) return;
-    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
+    const mb_real mv = q.project ? (mb_real)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
     const float4 r = ld4(q.r + vb + i);
     if (restart) { st4(q.rw + vb + i, r.x, r.y, r.z, r.w); st4(q.p + vb + i, r.x, r.y, r.z, r.w); return; }
     const float4 p = ld4(q.p + vb + i), v = ld4(q.v + vb + i);
@@ -793,9 +793,9 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v4(MbDev D, MbSolve q, int it) {
     MB_SYS4
     if (flag_ld(q.flags + (sys)) != 0) return;
-    float part = 0.f, psum = 0.f;
+    mb_real part = 0.f, psum = 0.f;
     if (valid) {
-        float y[4];
+        mb_real y[4];
         mb_spmv4<DIMS>(D, q, b, (q.mp ? q.mp : q.p) + vb, i, y);
         st4(q.v + vb + i, y[0], y[1], y[2], y[3]);
         const float4 w = ld4(q.rw + vb + i);
@@ -813,14 +813,14 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s4(MbDev D, MbSolve q, int it) {
     MB_SYS4
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
-    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
+    const mb_real alpha_raw = (mb_real)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const mb_real alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
-    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
-    float part = 0.f;
+    const mb_real mv = q.project ? (mb_real)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    mb_real part = 0.f;
     if (valid) {
         const float4 r = ld4(q.r + vb + i), v = ld4(q.v + vb + i);
-        const float s0 = r.x - alpha * (v.x - mv), s1 = r.y - alpha * (v.y - mv), s2 = r.z - alpha * (v.z - mv), s3 = r.w - alpha * (v.w - mv);
+        const mb_real s0 = r.x - alpha * (v.x - mv), s1 = r.y - alpha * (v.y - mv), s2 = r.z - alpha * (v.z - mv), s3 = r.w - alpha * (v.w - mv);
         st4(q.r + vb + i, s0, s1, s2, s3);
         part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
     }
@@ -831,14 +831,14 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it) {
     MB_SYS4
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float crit_s = mb_rms(acc_ld(a + (A_SS)), N);
+    const mb_real crit_s = mb_rms(acc_ld(a + (A_SS)), N);
     if (!(crit_s >= q.tol)) {
         if (leader) mb_mark(q, sys, crit_s, it, 4);
         return;
     }
-    float pt = 0.f, ptt = 0.f, pst = 0.f;
+    mb_real pt = 0.f, ptt = 0.f, pst = 0.f;
     if (valid) {
-        float t[4];
+        mb_real t[4];
         mb_spmv4<DIMS>(D, q, b, (q.ms ? q.ms : q.r) + vb, i, t);
         st4(q.t + vb + i, t[0], t[1], t[2], t[3]);
         const float4 sv = ld4(q.r + vb + i);
@@ -860,14 +860,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     MB_SYS4
     const int f = flag_ld(q.flags + (sys));
     if (f != 0 && f != 4) return;
-    const float alpha = sc_ld(q.sc + (sys * 2));
+    const mb_real alpha = sc_ld(q.sc + (sys * 2));
     MB_HALF
     const double st = q.project ? acc_ld(a + (A_ST)) : 0.0;
-    const float mt = (float)(st / (double)N);
-    const float omega_raw = half ? 0.f : (float)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
-    const float omega = isfinite(omega_raw) ? omega_raw : 0.f;
+    const mb_real mt = (mb_real)(st / (double)N);
+    const mb_real omega_raw = half ? 0.f : (mb_real)(acc_ld(a + (A_TS)) / (acc_ld(a + (A_TT)) - st * st / (double)N));
+    const mb_real omega = isfinite(omega_raw) ? omega_raw : 0.f;
     if (leader) { sc_st(q.sc + (sys * 2 + 1), omega); acc_st(a + (A_RV), 0.0); }
-    float prr = 0.f, prho = 0.f;
+    mb_real prr = 0.f, prho = 0.f;
     if (valid) {
         const float4 x = ld4(q.x + vb + i), p = ld4((q.mp ? q.mp : q.p) + vb + i);
         if (half) {
@@ -877,14 +877,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
             const float4 sd = q.ms ? ld4(q.ms + vb + i) : sv;
             st4(q.x + vb + i, x.x + alpha * p.x + omega * sd.x, x.y + alpha * p.y + omega * sd.y, x.z + alpha * p.z + omega * sd.z,
                 x.w + alpha * p.w + omega * sd.w);
-            const float r0 = sv.x - omega * (t.x - mt), r1 = sv.y - omega * (t.y - mt), r2 = sv.z - omega * (t.z - mt), r3 = sv.w - omega * (t.w - mt);
+            const mb_real r0 = sv.x - omega * (t.x - mt), r1 = sv.y - omega * (t.y - mt), r2 = sv.z - omega * (t.z - mt), r3 = sv.w - omega * (t.w - mt);
             st4(q.r + vb + i, r0, r1, r2, r3);
             prr = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
             prho = w.x * r0 + w.y * r1 + w.z * r2 + w.w * r3;
         }
     }
     if (half) return;
-    float sums[2] = {prr, prho};
+    mb_real sums[2] = {prr, prho};
     mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) { acc_add(a + A_RR, (double)sums[0]); acc_add(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
 }
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv(MbDev D, MbSolve q, int it)
     const int f = flag_ld(q.flags + (sys));
     if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
     if (f != 0) return;
-    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    const mb_real crit = mb_rms(acc_ld(a + (A_RR)), N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
         acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
@@ -907,33 +907,33 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv(MbDev D, MbSolve q, int it)
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
     MB_BETA
-    const float mv = (q.project && it > 0) ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
-    float part = 0.f, psum = 0.f;
+    const mb_real mv = (q.project && it > 0) ? (mb_real)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
+    mb_real part = 0.f, psum = 0.f;
     if (valid) {
-        const float* __restrict__ r = q.r + vb;
-        const float* __restrict__ pp = q.p_prev + vb;
-        const float* __restrict__ vp = q.v_prev + vb;
+        const mb_real* __restrict__ r = q.r + vb;
+        const mb_real* __restrict__ pp = q.p_prev + vb;
+        const mb_real* __restrict__ vp = q.v_prev + vb;
         // it == 0: p = r was laid down by the initialisation in the CURRENT p buffer
-        auto pnew = [&](int c) -> float {
+        auto pnew = [&](int c) -> mb_real {
             if (it == 0) return q.p[vb + c];
             if (restart) return r[c];
             return r[c] + beta * (pp[c] - omega * (vp[c] - mv));
         };
-        const float pc = pnew(i);
-        float y = q.diag[(size_t)b * N + i] * pc;
+        const mb_real pc = pnew(i);
+        mb_real y = q.diag[(size_t)b * N + i] * pc;
 #pragma unroll
         for (int ff = 0; ff < F; ++ff) {
             const int n = D.nbr[(size_t)ff * N + i];
             if (n >= 0) y += q.off[((size_t)b * F + ff) * N + i] * pnew(n);
         }
-        float rwv = q.rw[vb + i];
+        mb_real rwv = q.rw[vb + i];
         if (restart) { rwv = r[i]; q.rw[vb + i] = rwv; }
         if (it > 0) q.p[vb + i] = pc;
         q.v[vb + i] = y;
         part = rwv * y;
         psum = y;
     }
-    float sums[2] = {part, psum};
+    mb_real sums[2] = {part, psum};
     mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) {
         acc_add(a + A_RV, (double)sums[0]);
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it
     const int f = flag_ld(q.flags + (sys));
     if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
     if (f != 0) return;
-    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    const mb_real crit = mb_rms(acc_ld(a + (A_RR)), N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
         acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
@@ -954,14 +954,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
     MB_BETA
-    const float mv = (q.project && it > 0) ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
-    float part = 0.f, psum = 0.f;
+    const mb_real mv = (q.project && it > 0) ? (mb_real)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
+    mb_real part = 0.f, psum = 0.f;
     if (valid) {
-        const float* __restrict__ r = q.r + vb;
-        const float* __restrict__ pp = q.p_prev + vb;
-        const float* __restrict__ vp = q.v_prev + vb;
-        const float* __restrict__ pcur = q.p + vb;
-        float pc[4];
+        const mb_real* __restrict__ r = q.r + vb;
+        const mb_real* __restrict__ pp = q.p_prev + vb;
+        const mb_real* __restrict__ vp = q.v_prev + vb;
+        const mb_real* __restrict__ pcur = q.p + vb;
+        mb_real pc[4];
         if (it == 0) {
             const float4 p4 = ld4(pcur + i);
             pc[0] = p4.x; pc[1] = p4.y; pc[2] = p4.z; pc[3] = p4.w;
@@ -974,8 +974,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it
                 pc[2] = r4.z + beta * (p4.z - omega * (v4.z - mv)); pc[3] = r4.w + beta * (p4.w - omega * (v4.w - mv));
             }
         }
-        float y[4];
-        mb_spmv4_core<DIMS>(D, q, b, i, pc, [=](int n) -> float {
+        mb_real y[4];
+        mb_spmv4_core<DIMS>(D, q, b, i, pc, [=](int n) -> mb_real {
             if (it == 0) return pcur[n];
             if (restart) return r[n];
             return r[n] + beta * (pp[n] - omega * (vp[n] - mv));
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it
         part = w.x * y[0] + w.y * y[1] + w.z * y[2] + w.w * y[3];
         psum = y[0] + y[1] + y[2] + y[3];
     }
-    float sums[2] = {part, psum};
+    mb_real sums[2] = {part, psum};
     mb_block_sums<2>(sums, lds);
     if (threadIdx.x == 0) {
         acc_add(a + A_RV, (double)sums[0]);
@@ -1004,16 +1004,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st(MbDev D, MbSolve q, int it)
     MB_SYS
     constexpr int F = 2 * DIMS;
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
-    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
+    const mb_real alpha_raw = (mb_real)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const mb_real alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
-    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
-    float pss = 0.f, pts = 0.f, ptt = 0.f, pst = 0.f;
+    const mb_real mv = q.project ? (mb_real)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    mb_real pss = 0.f, pts = 0.f, ptt = 0.f, pst = 0.f;
     if (valid) {
-        const float* __restrict__ r = q.r + vb;
-        const float* __restrict__ v = q.v + vb;
-        const float sv = r[i] - alpha * (v[i] - mv);
-        float t = q.diag[(size_t)b * N + i] * sv;
+        const mb_real* __restrict__ r = q.r + vb;
+        const mb_real* __restrict__ v = q.v + vb;
+        const mb_real sv = r[i] - alpha * (v[i] - mv);
+        mb_real t = q.diag[(size_t)b * N + i] * sv;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int n = D.nbr[(size_t)f * N + i];
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st(MbDev D, MbSolve q, int it)
         q.t[vb + i] = t;
         pss = sv * sv; pts = t * sv; ptt = t * t; pst = t;
     }
-    float sums[4] = {pss, pts, ptt, pst};
+    mb_real sums[4] = {pss, pts, ptt, pst};
     mb_block_sums<4>(sums, lds);
     if (threadIdx.x == 0) {
         acc_add(a + A_SS, (double)sums[0]);
@@ -1036,17 +1036,17 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it) {
     MB_SYS4
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
-    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;
+    const mb_real alpha_raw = (mb_real)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const mb_real alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
-    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
-    float pss = 0.f, pts = 0.f, ptt = 0.f, pst = 0.f;
+    const mb_real mv = q.project ? (mb_real)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    mb_real pss = 0.f, pts = 0.f, ptt = 0.f, pst = 0.f;
     if (valid) {
-        const float* __restrict__ r = q.r + vb;
-        const float* __restrict__ v = q.v + vb;
+        const mb_real* __restrict__ r = q.r + vb;
+        const mb_real* __restrict__ v = q.v + vb;
         const float4 r4 = ld4(r + i), v4 = ld4(v + i);
-        const float sv[4] = {r4.x - alpha * (v4.x - mv), r4.y - alpha * (v4.y - mv), r4.z - alpha * (v4.z - mv), r4.w - alpha * (v4.w - mv)};
-        float t[4];
+        const mb_real sv[4] = {r4.x - alpha * (v4.x - mv), r4.y - alpha * (v4.y - mv), r4.z - alpha * (v4.z - mv), r4.w - alpha * (v4.w - mv)};
+        mb_real t[4];
         mb_spmv4_core<DIMS>(D, q, b, i, sv, [r, v, alpha, mv](int n) { return r[n] - alpha * (v[n] - mv); }, t);
         st4(q.sbuf + vb + i, sv[0], sv[1], sv[2], sv[3]);
         st4(q.t + vb + i, t[0], t[1], t[2], t[3]);
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it
         ptt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
         pst = t[0] + t[1] + t[2] + t[3];
     }
-    float sums[4] = {pss, pts, ptt, pst};
+    mb_real sums[4] = {pss, pts, ptt, pst};
     mb_block_sums<4>(sums, lds);
     if (threadIdx.x == 0) {
         acc_add(a + A_SS, (double)sums[0]);
@@ -1074,16 +1074,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it
 //                  columns; 16 rows x 64 column groups x 4 systems per workgroup                             -> z8 [sys][n8]
 //   k_ml_prolong   z = r / diag + (1/2s) r4 / d4 + z8 at the cell's aggregates                              -> z  [sys][N]
 struct MlDev {
-    const uint16_t* a4; const uint16_t* parent4; const uint2* rect4; const uint2* child8; const float* rd4; const float* aci8;
+    const uint16_t* a4; const uint16_t* parent4; const uint2* rect4; const uint2* child8; const mb_real* rd4; const mb_real* aci8;
     int n4, n8, ld8;
-    float* r4; float* z8; const float* scale_inv;   // work arrays [nsys][n4], [nsys][n8]; 1 / s per env
+    mb_real* r4; mb_real* z8; const mb_real* scale_inv;   // work arrays [nsys][n4], [nsys][n8]; 1 / s per env
     // r4 a second time in the order the coarse kernel wants it -- [nsys][n8][4], slot pos4[a] = 4 parent + child index -- so that
     // its r8 is one coalesced 16-byte load instead of a child table followed by four gathers
-    const uint32_t* pos4; float* r4c;
+    const uint32_t* pos4; mb_real* r4c;
     const uint16_t* p8c;   // parent4[a4[i]] per cell
 };
 // 1 / s per env: trace(S_geom) / trace(P_env); one workgroup per env
-__global__ __launch_bounds__(1024) void k_ml_scale(const float* __restrict__ diag, int N, float geom_diag_sum, float* __restrict__ scale_inv) {
+__global__ __launch_bounds__(1024) void k_ml_scale(const mb_real* __restrict__ diag, int N, mb_real geom_diag_sum, mb_real* __restrict__ scale_inv) {
     const int b = blockIdx.x;
     __shared__ double part[16];
     double acc = 0.0;
@@ -1095,24 +1095,24 @@ __global__ __launch_bounds__(1024) void k_ml_scale(const float* __restrict__ dia
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t += part[w];
-        scale_inv[b] = (float)((double)geom_diag_sum / t);
+        scale_inv[b] = (mb_real)((double)geom_diag_sum / t);
     }
 }
 // (four threads per aggregate, one per row of its rectangle: a thread's cells are one contiguous run, and the four row sums meet in a
 //  fixed order)
-__device__ __forceinline__ float ml_quad_sum(float v) {
+__device__ __forceinline__ mb_real ml_quad_sum(mb_real v) {
     const int base = (threadIdx.x & 63) & ~3;
-    const float s0 = __shfl(v, base, 64), s1 = __shfl(v, base + 1, 64), s2 = __shfl(v, base + 2, 64), s3 = __shfl(v, base + 3, 64);
+    const mb_real s0 = __shfl(v, base, 64), s1 = __shfl(v, base + 1, 64), s2 = __shfl(v, base + 2, 64), s3 = __shfl(v, base + 3, 64);
     return ((s0 + s1) + s2) + s3;
 }
-__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const float* __restrict__ in, int N, const int32_t* __restrict__ flags) {
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const mb_real* __restrict__ in, int N, const int32_t* __restrict__ flags) {
     const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, a = tq >> 2, row = tq & 3, sys = blockIdx.y;
     if (flag_ld(flags + sys) != 0) return;
-    float sum = 0.f;
+    mb_real sum = 0.f;
     if (a < M.n4) {
         const uint2 rc = M.rect4[a];
         const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
-        const float* src = in + (size_t)sys * N + rc.x;
+        const mb_real* src = in + (size_t)sys * N + rc.x;
         for (int dy = row; dy < h; dy += 4)
             for (int dx = 0; dx < w; ++dx) sum += src[dy * stride + dx];
     }
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, 
     const int f = flag_ld(q.flags + (sys));
     if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); return; }
     if (f != 0) return;
-    const float crit = mb_rms(acc_ld(a + (A_RR)), N);
+    const mb_real crit = mb_rms(acc_ld(a + (A_RR)), N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, (it == 0 && q.it_base == 0) ? -1 : it + q.it_base); return; }
     if (leader) {
         acc_st(a + (A_SS), 0.0); acc_st(a + (A_TS), 0.0); acc_st(a + (A_TT), 0.0); acc_st(a + (A_ST), 0.0);
@@ -1140,18 +1140,18 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, 
         q.info[sys].used_iterations = it + q.it_base - 1;
     }
     MB_BETA
-    const float mv = (q.project && it > 0) ? (float)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
-    float sum = 0.f;
+    const mb_real mv = (q.project && it > 0) ? (mb_real)(acc_ld(a + (A_SV + 2 * ((it + 1) & 1))) / (double)N) : 0.f;
+    mb_real sum = 0.f;
     if (ag < M.n4) {
         const uint2 rc = M.rect4[ag];
         const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
         for (int dy = row; dy < h; dy += 4)
             for (int dx = 0; dx < w; ++dx) {
                 const size_t c = vb + rc.x + dy * stride + dx;
-                float pv;
+                mb_real pv;
                 if (it == 0) pv = q.p[c];                       // p = r was laid down by the initialisation
                 else {
-                    const float r = q.r[c];
+                    const mb_real r = q.r[c];
                     if (restart) { q.rw[c] = r; pv = r; }
                     else pv = r + beta * (q.p[c] - omega * (q.v[c] - mv));
                     q.p[c] = pv;
@@ -1168,20 +1168,20 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, 
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
-    __shared__ float lds[16];
+    __shared__ mb_real lds[16];
     if (flag_ld(q.flags + (sys)) != 0) return;
-    const float alpha_raw = (float)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
-    const float alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
+    const mb_real alpha_raw = (mb_real)(acc_ld(a + (A_RHOE + (it & 1))) / acc_ld(a + (A_RV)));
+    const mb_real alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0: see MB_BETA
     if (leader) { sc_st(q.sc + (sys * 2), alpha); acc_st(a + (A_RHO + ((it + 1) & 1)), 0.0); acc_st(a + (A_RR), 0.0); acc_st(a + (A_SV + 2 * ((it + 1) & 1)), 0.0); }
-    const float mv = q.project ? (float)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
-    float part = 0.f, sum = 0.f;
+    const mb_real mv = q.project ? (mb_real)(acc_ld(a + (A_SV + 2 * (it & 1))) / (double)N) : 0.f;
+    mb_real part = 0.f, sum = 0.f;
     if (ag < M.n4) {
         const uint2 rc = M.rect4[ag];
         const int w = rc.y & 255, h = (rc.y >> 8) & 255, stride = rc.y >> 16;
         for (int dy = row; dy < h; dy += 4)
             for (int dx = 0; dx < w; ++dx) {
                 const size_t c = vb + rc.x + dy * stride + dx;
-                const float sv = q.r[c] - alpha * (q.v[c] - mv);
+                const mb_real sv = q.r[c] - alpha * (q.v[c] - mv);
                 q.r[c] = sv;
                 part += sv * sv;
                 sum += sv;
@@ -1202,10 +1202,10 @@ constexpr int ML_N8_MAX = 2048, ML_ROWS = 16, ML_CG = 64;   // coarse solve: row
 // r8 [SB][n8p] (re-used by the second folding stage, which needs 4 SB ROWS floats) and the partial sums [CG][SB][ROWS].
 template <int SB>
 __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags, int n8p) {
-    extern __shared__ float l_dyn[];
-    float* l_r8 = l_dyn;
+    extern __shared__ mb_real l_dyn[];
+    mb_real* l_r8 = l_dyn;
     const int r8_words = SB * n8p > 4 * SB * ML_ROWS ? SB * n8p : 4 * SB * ML_ROWS;
-    float* l_part = l_dyn + r8_words;                  // [ML_CG][SB][ML_ROWS]
+    mb_real* l_part = l_dyn + r8_words;                  // [ML_CG][SB][ML_ROWS]
     const int sys0 = blockIdx.y * SB, r = threadIdx.x & (ML_ROWS - 1), cg = threadIdx.x / ML_ROWS;
     bool on[SB], any = false;
 #pragma unroll
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
     for (int k = 0; k < SB; ++k) {
         const float4* r4c = reinterpret_cast<const float4*>(M.r4c + (size_t)(sys0 + k) * 4 * M.n8);
         for (int g = threadIdx.x; g < M.n8; g += ML_ROWS * ML_CG) {
-            float sum = 0.f;
+            mb_real sum = 0.f;
             if (on[k]) {
                 const float4 c = r4c[g];               // the (at most four) children in child order, absent ones 0
                 sum = ((c.x + c.y) + c.z) + c.w;
@@ -1225,14 +1225,14 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
     }
     __syncthreads();
     const int row = blockIdx.x * ML_ROWS + r;
-    float acc[SB];
+    mb_real acc[SB];
 #pragma unroll
     for (int k = 0; k < SB; ++k) acc[k] = 0.f;
     if (row < M.n8) {
-        const float* col = M.aci8 + row;
+        const mb_real* col = M.aci8 + row;
 #pragma unroll 4
         for (int j = cg; j < M.n8; j += ML_CG) {      // column groups interleave: a wave's four groups read four adjacent matrix rows
-            const float m = col[(size_t)j * M.ld8];
+            const mb_real m = col[(size_t)j * M.ld8];
 #pragma unroll
             for (int k = 0; k < SB; ++k) acc[k] += m * l_r8[k * n8p + j];
         }
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
     // 64 partial sums per (system, row), folded in two stages: thread t < 4 SB ROWS = (quarter t / (SB ROWS), system t / ROWS % SB, row t % ROWS)
     if (threadIdx.x < SB * ML_ROWS * 4) {
         const int rr = threadIdx.x & (ML_ROWS - 1), k = (threadIdx.x / ML_ROWS) & (SB - 1), quarter = threadIdx.x / (SB * ML_ROWS);
-        float t = 0.f;
+        mb_real t = 0.f;
 #pragma unroll
         for (int w = 0; w < ML_CG / 4; ++w) t += l_part[((quarter * (ML_CG / 4) + w) * SB + k) * ML_ROWS + rr];
         l_r8[threadIdx.x] = t;     // second stage in the (now free) r8 buffer: [quarter][system][row] = thread index
@@ -1258,13 +1258,13 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
                 (l_r8[threadIdx.x] + l_r8[Q + threadIdx.x] + l_r8[2 * Q + threadIdx.x] + l_r8[3 * Q + threadIdx.x]) * M.scale_inv[(sys0 + k) / nc];
     }
 }
-__global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const float* __restrict__ in, const float* __restrict__ diag, int N, int nc,
-                                                         const int32_t* __restrict__ flags, float* __restrict__ out) {
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const mb_real* __restrict__ in, const mb_real* __restrict__ diag, int N, int nc,
+                                                         const int32_t* __restrict__ flags, mb_real* __restrict__ out) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
     if (i >= N || flag_ld(flags + sys) != 0) return;
     const int b = sys / nc;
     const unsigned a = M.a4[i];
-    const float half_s = 0.5f * M.scale_inv[b];
+    const mb_real half_s = 0.5f * M.scale_inv[b];
     out[(size_t)sys * N + i] = in[(size_t)sys * N + i] * __builtin_amdgcn_rcpf(diag[(size_t)b * N + i]) +
                                half_s * M.rd4[a] * M.r4[(size_t)sys * M.n4 + a] + M.z8[(size_t)sys * M.n8 + M.p8c[i]];
 }
@@ -1278,22 +1278,22 @@ constexpr int C_RHO = 0, C_PAP = 3, C_SUM = 8;  // C_SUM ring 8..10: yp . r_k (r
 // PM: how the residual is projected -- 0 not at all, 1 onto the complement of the constant (yp = 1/sqrt(N): no loads of
 // yp at all), 2 onto the complement of a general unit vector yp (gathered with every neighbour)
 template <int PM>
-__device__ __forceinline__ float mb_yp(const float* __restrict__ yp, int i, float yc) { return PM == 2 ? yp[i] : yc; }
+__device__ __forceinline__ mb_real mb_yp(const mb_real* __restrict__ yp, int i, mb_real yc) { return PM == 2 ? yp[i] : yc; }
 template <int DIMS, int PM>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* __restrict__ pA, float* __restrict__ pB, int it_arg,
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, mb_real* __restrict__ pA, mb_real* __restrict__ pB, int it_arg,
                                                       int project_mean) {
     MB_SYS
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[0];
     if (leader && sys == 0) q.it_ctr[1] = it + 1;
-    const float* p_old = (it & 1) ? pA : pB;
-    float* p_new = (it & 1) ? pB : pA;
+    const mb_real* p_old = (it & 1) ? pA : pB;
+    mb_real* p_new = (it & 1) ? pB : pA;
     if (flag_ld(q.flags + (sys)) != 0) return;
     // residual with its mean removed (project_mean): rho = |r|^2 - (sum r)^2 / N
     // residual with its component along the projection vector yp removed (|yp| = 1): rho = |r|^2 - (yp.r)^2
     const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
-    const float cy = (float)sum_r;
+    const mb_real cy = (mb_real)sum_r;
     const double rho = acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r;
-    const float crit = mb_rms(rho, N);
+    const mb_real crit = mb_rms(rho, N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
     double rho_prev = 1.0;
     if (it > 0) {
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
         rho_prev = acc_ld(a + (C_RHO + (it + 2) % 3)) - sp * sp;
     }
     const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
-    const float beta = fresh ? 0.f : (float)(rho / rho_prev);
+    const mb_real beta = fresh ? 0.f : (mb_real)(rho / rho_prev);
     if (leader) {
         q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
         acc_st(a + (C_RHO + (it + 1) % 3), 0.0);  // accumulated by k_mbc_update of this iteration; nobody reads it here
@@ -1311,16 +1311,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
             sc_st(q.sc + (sys * 2), crit); q.best_it[sys] = it;
         }
     }
-    float part = 0.f;
+    mb_real part = 0.f;
     if (valid) {
         constexpr int F = 2 * DIMS;
-        const float* r = q.r + vb;
-        const float* po = p_old + vb;
-        const float* yp = D.yproj;
-        const float yc = PM == 1 ? cy * rsqrtf((float)N) : 0.f;   // cy * yp for the constant vector
+        const mb_real* r = q.r + vb;
+        const mb_real* po = p_old + vb;
+        const mb_real* yp = D.yproj;
+        const mb_real yc = PM == 1 ? cy * mb_rsqrt((mb_real)N) : 0.f;   // cy * yp for the constant vector
         auto proj = [&](int c) { return PM == 0 ? r[c] : (PM == 1 ? r[c] - yc : r[c] - cy * yp[c]); };
-        const float pi = fresh ? proj(i) : proj(i) + beta * po[i];
-        float y = q.diag[(size_t)b * N + i] * pi;
+        const mb_real pi = fresh ? proj(i) : proj(i) + beta * po[i];
+        mb_real y = q.diag[(size_t)b * N + i] * pi;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int n = D.nbr[(size_t)f * N + i];
@@ -1334,21 +1334,21 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap(MbDev D, MbSolve q, float* 
     if (threadIdx.x == 0) acc_add(a + C_PAP + (it & 1), (double)part);
 }
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, const float* __restrict__ pA, const float* __restrict__ pB,
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, const mb_real* __restrict__ pA, const mb_real* __restrict__ pB,
                                                           int it_arg, int project_mean) {
     MB_SYS
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[1] - 1;
     if (leader && sys == 0) q.it_ctr[0] = it + 1;
-    const float* p = (it & 1) ? pB : pA;
+    const mb_real* p = (it & 1) ? pB : pA;
     if (flag_ld(q.flags + (sys)) != 0) return;
     const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
-    const float alpha = (float)((acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r) / acc_ld(a + (C_PAP + (it & 1))));
+    const mb_real alpha = (mb_real)((acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r) / acc_ld(a + (C_PAP + (it & 1))));
     if (leader) acc_st(a + (C_PAP + ((it + 1) & 1)), 0.0);  // k_mbc_ap of the next iteration accumulates it; not read here
-    float part = 0.f, psum = 0.f;
+    mb_real part = 0.f, psum = 0.f;
     if (valid) {
         if (q.best_x && q.best_it[sys] == it) q.best_x[vb + i] = q.x[vb + i];
         q.x[vb + i] += alpha * p[vb + i];
-        const float r = q.r[vb + i] - alpha * q.v[vb + i];
+        const mb_real r = q.r[vb + i] - alpha * q.v[vb + i];
         q.r[vb + i] = r;
         part = r * r;
         psum = r * D.yproj[i];
@@ -1365,24 +1365,24 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
 // 2 x 2d x 4 neighbour gathers of a thread are independent and overlap, and a quarter of the workgroups is launched --
 // at 14 k cells x 64 envs the scalar kernels were bound by gather latency and workgroup turnover, not by bytes.
 template <int DIMS, int PM>
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float* __restrict__ pA, float* __restrict__ pB,
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, mb_real* __restrict__ pA, mb_real* __restrict__ pB,
                                                        int it_arg, int project_mean) {
     const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;
     const int sys = blockIdx.y, b = sys, N = D.N;
     const bool valid = i < N, leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
-    __shared__ float lds[4];
+    __shared__ mb_real lds[4];
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[0];
     if (leader && sys == 0) q.it_ctr[1] = it + 1;
-    const float* p_old = (it & 1) ? pA : pB;
-    float* p_new = (it & 1) ? pB : pA;
+    const mb_real* p_old = (it & 1) ? pA : pB;
+    mb_real* p_new = (it & 1) ? pB : pA;
     if (flag_ld(q.flags + (sys)) != 0) return;
     // residual with its component along the projection vector yp removed (|yp| = 1): rho = |r|^2 - (yp.r)^2
     const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
-    const float cy = (float)sum_r;
+    const mb_real cy = (mb_real)sum_r;
     const double rho = acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r;
-    const float crit = mb_rms(rho, N);
+    const mb_real crit = mb_rms(rho, N);
     if (!(crit >= q.tol)) { if (leader) mb_mark(q, sys, crit, it); return; }
     double rho_prev = 1.0;
     if (it > 0) {
@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
         rho_prev = acc_ld(a + (C_RHO + (it + 2) % 3)) - sp * sp;
     }
     const bool fresh = (it == q.it_ctr[2]);  // first iteration after the start or a restart: p = r
-    const float beta = fresh ? 0.f : (float)(rho / rho_prev);
+    const mb_real beta = fresh ? 0.f : (mb_real)(rho / rho_prev);
     if (leader) {
         q.info[sys].final_residual = crit; q.info[sys].used_iterations = it;
         acc_st(a + (C_RHO + (it + 1) % 3), 0.0);
@@ -1399,15 +1399,15 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
             sc_st(q.sc + (sys * 2), crit); q.best_it[sys] = it;
         }
     }
-    float part = 0.f;
+    mb_real part = 0.f;
     if (valid) {
         constexpr int F = 2 * DIMS;
-        const float* r = q.r + vb;
-        const float* po = p_old + vb;
+        const mb_real* r = q.r + vb;
+        const mb_real* po = p_old + vb;
         const float4 r4 = *reinterpret_cast<const float4*>(r + i);
-        const float* yp = D.yproj;
-        const float yc = PM == 1 ? cy * rsqrtf((float)N) : 0.f;   // cy * yp for the constant vector
-        float pi[4] = {r4.x - yc, r4.y - yc, r4.z - yc, r4.w - yc};
+        const mb_real* yp = D.yproj;
+        const mb_real yc = PM == 1 ? cy * mb_rsqrt((mb_real)N) : 0.f;   // cy * yp for the constant vector
+        mb_real pi[4] = {r4.x - yc, r4.y - yc, r4.z - yc, r4.w - yc};
         if (PM == 2) {
             const float4 y4 = *reinterpret_cast<const float4*>(yp + i);
             pi[0] = r4.x - cy * y4.x; pi[1] = r4.y - cy * y4.y; pi[2] = r4.z - cy * y4.z; pi[3] = r4.w - cy * y4.w;
@@ -1417,14 +1417,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
             pi[0] += beta * p4.x; pi[1] += beta * p4.y; pi[2] += beta * p4.z; pi[3] += beta * p4.w;
         }
         const float4 d4 = *reinterpret_cast<const float4*>(q.diag + (size_t)b * N + i);
-        float y[4] = {d4.x * pi[0], d4.y * pi[1], d4.z * pi[2], d4.w * pi[3]};
+        mb_real y[4] = {d4.x * pi[0], d4.y * pi[1], d4.z * pi[2], d4.w * pi[3]};
         // the direction value of a neighbour is the same expression as the cell's own (pi): inside a block row the -x / +x
         // neighbours are the adjacent cells, i.e. this thread's other three cells or the first / last cell of the adjacent
         // lane -- taken from registers / a lane shuffle instead of two gathers each (a third to a half of all gathers)
         const int lane = threadIdx.x & 63;
-        const float from_prev = __shfl_up(pi[3], 1), from_next = __shfl_down(pi[0], 1);
+        const mb_real from_prev = __shfl_up(pi[3], 1), from_next = __shfl_down(pi[0], 1);
         auto gather = [&](int n) {
-            float pn = PM == 2 ? r[n] - cy * yp[n] : r[n] - yc;
+            mb_real pn = PM == 2 ? r[n] - cy * yp[n] : r[n] - yc;
             if (!fresh) pn += beta * po[n];
             return pn;
         };
@@ -1433,11 +1433,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
             const int4 n4 = *reinterpret_cast<const int4*>(D.nbr + (size_t)f * N + i);
             const float4 o4 = *reinterpret_cast<const float4*>(q.off + ((size_t)b * F + f) * N + i);
             const int nn[4] = {n4.x, n4.y, n4.z, n4.w};
-            const float oo[4] = {o4.x, o4.y, o4.z, o4.w};
+            const mb_real oo[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = nn[e] >= 0 ? nn[e] : i;  // prescribed face: coefficient is 0, read something valid
-                float pn;
+                mb_real pn;
                 if (f == 0 && n == i + e - 1 && (e > 0 || lane > 0)) pn = e > 0 ? pi[e > 0 ? e - 1 : 0] : from_prev;
                 else if (f == 1 && n == i + e + 1 && (e < 3 || lane < 63)) pn = e < 3 ? pi[e < 3 ? e + 1 : 3] : from_next;
                 else pn = gather(n);
@@ -1451,22 +1451,22 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_ap4(MbDev D, MbSolve q, float*
     part = mb_block_sum(part, lds);
     if (threadIdx.x == 0) acc_add(a + C_PAP + (it & 1), (double)part);
 }
-__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, const float* __restrict__ pA, const float* __restrict__ pB,
-                                                           int it_arg, int project_mean, const float* __restrict__ yp) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, const mb_real* __restrict__ pA, const mb_real* __restrict__ pB,
+                                                           int it_arg, int project_mean, const mb_real* __restrict__ yp) {
     const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;
     const int sys = blockIdx.y;
     const bool valid = i < N, leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
-    __shared__ float lds[4];
+    __shared__ mb_real lds[4];
     const int it = it_arg >= 0 ? it_arg : q.it_ctr[1] - 1;
     if (leader && sys == 0) q.it_ctr[0] = it + 1;
-    const float* p = (it & 1) ? pB : pA;
+    const mb_real* p = (it & 1) ? pB : pA;
     if (flag_ld(q.flags + (sys)) != 0) return;
     const double sum_r = project_mean ? acc_ld(a + (C_SUM + it % 3)) : 0.0;
-    const float alpha = (float)((acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r) / acc_ld(a + (C_PAP + (it & 1))));
+    const mb_real alpha = (mb_real)((acc_ld(a + (C_RHO + it % 3)) - sum_r * sum_r) / acc_ld(a + (C_PAP + (it & 1))));
     if (leader) acc_st(a + (C_PAP + ((it + 1) & 1)), 0.0);
-    float part = 0.f, psum = 0.f;
+    mb_real part = 0.f, psum = 0.f;
     if (valid) {
         float4 x4 = *reinterpret_cast<const float4*>(q.x + vb + i);
         if (q.best_x && q.best_it[sys] == it) *reinterpret_cast<float4*>(q.best_x + vb + i) = x4;
@@ -1506,7 +1506,7 @@ __global__ void k_mbs_recover(int N, MbSolve q) {
     const int sys = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
     if (flag_ld(q.flags + (sys)) != 2) return;
     if (i < N) {
-        const float v = q.best_x[(size_t)sys * N + i];
+        const mb_real v = q.best_x[(size_t)sys * N + i];
         q.x[(size_t)sys * N + i] = isfinite(v) ? v : 0.f;
     }
 }
@@ -1521,13 +1521,13 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, int it, int project_mean) {
     MB_SYS
     if (flag_ld(q.flags + (sys)) != 0) return;
-    float r = 0.f;
+    mb_real r = 0.f;
     if (valid) {
         r = q.rhs[vb + i] - mb_spmv<DIMS>(D, q, b, q.x + vb, i);
         q.r[vb + i] = r;
     }
-    const float s2 = mb_block_sum(r * r, lds);
-    const float s1 = project_mean ? mb_block_sum(valid ? r * D.yproj[i] : 0.f, lds) : 0.f;
+    const mb_real s2 = mb_block_sum(r * r, lds);
+    const mb_real s1 = project_mean ? mb_block_sum(valid ? r * D.yproj[i] : 0.f, lds) : 0.f;
     if (threadIdx.x == 0) {
         acc_add(a + C_RHO + it % 3, (double)s2);
         if (project_mean) acc_add(a + C_SUM + it % 3, (double)s1);
@@ -1548,7 +1548,7 @@ __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32
     if (flag_ld(q.flags + (s)) == 0) {
         double rr = acc_ld(q.acc + ((size_t)s * MB_ACC + rr_slot));
         if (sum_slot >= 0) { const double sr = acc_ld(q.acc + ((size_t)s * MB_ACC + sum_slot)); rr -= sr * sr; }
-        const float crit = (float)sqrt(rr / (double)n);
+        const mb_real crit = (mb_real)sqrt(rr / (double)n);
         q.info[s].final_residual = crit;
         q.info[s].used_iterations = it + 1;
         if (!(crit >= q.tol)) {
@@ -1609,10 +1609,10 @@ struct OcPre {
     const uint16_t* parent4;   // [n4]  8 x 8 aggregate of every 4 x 4 aggregate
     const uint2* rect4;        // [n4]  the aggregate as a rectangle of cells: .x = first cell, .y = width | height << 8 | row stride << 16
     const uint2* child8;       // [n8]  the (up to four) 4 x 4 aggregates of an 8 x 8 aggregate, 16 bits each, 0xFFFF = none
-    const float* d4g;          // [n4]  1 / diag(Z4^T S Z4)
-    const float* aci8;         // [n8][ld] pseudo-inverse of Z8^T S Z8, row pitch ld = n8 rounded up to a multiple of 4
+    const mb_real* d4g;          // [n4]  1 / diag(Z4^T S Z4)
+    const mb_real* aci8;         // [n8][ld] pseudo-inverse of Z8^T S Z8, row pitch ld = n8 rounded up to a multiple of 4
     int n4, n8;
-    float geom_diag_sum;       // sum_i S_ii: the env's scale is sum_i P_ii / geom_diag_sum (P = S / A with A nearly constant)
+    mb_real geom_diag_sum;       // sum_i S_ii: the env's scale is sum_i P_ii / geom_diag_sum (P = S / A with A nearly constant)
 };
 
 // Aggregate-owned layout (AGG): thread t = 4 * (8 x 8 aggregate) + child owns the (up to 16) cells of one 4 x 4 aggregate; its
@@ -1624,25 +1624,25 @@ struct OcPre {
 struct OcAgg {
     const int32_t* slot_cell;   // [16384] cell of a slot, -1 = hole
     const uint2* nbr;           // [16384] neighbour slots
-    const float* d4g;           // [1024]
+    const mb_real* d4g;           // [1024]
     const int32_t* cnt;         // [1024]
-    const float* off4;          // [B][16384][4]
-    const float* diag;          // [B][16384]
-    float* bestx;               // [B][16384]
+    const mb_real* off4;          // [B][16384][4]
+    const mb_real* diag;          // [B][16384]
+    mb_real* bestx;               // [B][16384]
 };
 
 struct OcParams {
     OcPre pre;
     OcAgg agg;
     const uint32_t* nbr16;   // [N][F/2] words: one 8-byte load per cell in 2-D
-    const float* off4;       // [B][N][4] off-diagonals interleaved per cell (2-D), or null: q.off [B][F][N] is read instead
+    const mb_real* off4;       // [B][N][4] off-diagonals interleaved per cell (2-D), or null: q.off [B][F][N] is read instead
     int fence;               // compiler fence every four cells of the stencil pass (bounds the loads in flight)
     int dbg;                 // FG_MB_OC_VARIANT >> 8: bit 0 = per-phase cycle counts of workgroup 0 into dbg_out (fg_mb_debug_cycles)
     unsigned long long* dbg_out;   // [16] cycles per phase, summed over the iterations of the launch
-    const float* dt;         // [B] or null
-    const float* yp;         // [N] projection vector (PM == 2)
+    const mb_real* dt;         // [B] or null
+    const mb_real* yp;         // [N] projection vector (PM == 2)
     int use_x0, project_mean, restart_every, check_every, max_iterations, stall_limit, accept_window;
-    float accept_factor, tol;
+    mb_real accept_factor, tol;
     fg_solve_info* info_host;   // pinned host mirrors of info[] and of the iterations run: written by the kernel itself, so the
     int32_t* its_host;          // host needs one stream synchronisation after the launch and no device-to-host copies
 };
@@ -1651,7 +1651,7 @@ struct OcParams {
 // already runs ahead into the next reduction writes another slot, so ONE barrier per reduction is enough (a slot is rewritten
 // three reductions later, with two barriers in between).
 template <int NT, bool RING = true>
-__device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[2][OC_MAX_WAVES], int& phase, double& A, double& B) {
+__device__ __forceinline__ void oc_reduce2(mb_real a, mb_real b, double (*red)[2][OC_MAX_WAVES], int& phase, double& A, double& B) {
     a = fg_wave_sum(a);
     b = fg_wave_sum(b);
     double(*slot)[OC_MAX_WAVES] = red[RING ? phase : 0];
@@ -1668,11 +1668,11 @@ __device__ __forceinline__ void oc_reduce2(float a, float b, double (*red)[2][OC
 // y_k = (M v)(cell k of this thread) for the vector v held in LDS; off-diagonals and neighbours stream from memory: per cell
 // one 8-byte load (four packed neighbour indices) and one 16-byte load (four coefficients) in 2-D.
 template <int DIMS, int CPT, bool DG_REGS, bool NB_REGS, int NT>
-__device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int sys, int N, unsigned tl, const float* __restrict__ v_lds,
-                                        const float (&dg)[CPT], const uint2 (&nbk)[NB_REGS ? CPT : 1], float (&y)[CPT]) {
+__device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int sys, int N, unsigned tl, const mb_real* __restrict__ v_lds,
+                                        const mb_real (&dg)[CPT], const uint2 (&nbk)[NB_REGS ? CPT : 1], mb_real (&y)[CPT]) {
     constexpr int F = 2 * DIMS;
-    const float* __restrict__ off = q.off + (size_t)sys * F * N;
-    const float* __restrict__ diag = q.diag + (size_t)sys * N;
+    const mb_real* __restrict__ off = q.off + (size_t)sys * F * N;
+    const mb_real* __restrict__ diag = q.diag + (size_t)sys * N;
     const unsigned un = (unsigned)N;
     if (DIMS == 2 && o.off4 != nullptr) {
         const float4* __restrict__ off4 = reinterpret_cast<const float4*>(o.off4) + (size_t)sys * N;
@@ -1680,15 +1680,15 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = tl + (unsigned)k * NT;
-            float acc = 0.f;
+            mb_real acc = 0.f;
             if (i < un) {
                 const uint2 u = NB_REGS ? nbk[NB_REGS ? k : 0] : nb2[i];
                 const float4 c = off4[i];
-                const float d = DG_REGS ? dg[k] : diag[i];
+                const mb_real d = DG_REGS ? dg[k] : diag[i];
                 const uint32_t n0 = u.x & 0xffffu, n1 = u.x >> 16, n2 = u.y & 0xffffu, n3 = u.y >> 16;
                 // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
-                const float v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
-                const float v2 = v_lds[n2 != 0xffffu ? n2 : i], v3 = v_lds[n3 != 0xffffu ? n3 : i];
+                const mb_real v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
+                const mb_real v2 = v_lds[n2 != 0xffffu ? n2 : i], v3 = v_lds[n3 != 0xffffu ? n3 : i];
                 acc = d * v_lds[i];
                 acc += n0 != 0xffffu ? c.x * v0 : 0.f;
                 acc += n1 != 0xffffu ? c.y * v1 : 0.f;
@@ -1704,15 +1704,15 @@ __device__ __forceinline__ void oc_spmv(const MbSolve& q, const OcParams& o, int
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const unsigned i = tl + (unsigned)k * NT;
-        float acc = 0.f;
+        mb_real acc = 0.f;
         if (i < un) {
             acc = (DG_REGS ? dg[k] : diag[i]) * v_lds[i];
 #pragma unroll
             for (int w = 0; w < DIMS; ++w) {
                 const uint32_t u = nb[i * (unsigned)DIMS + (unsigned)w];
                 const uint32_t n0 = u & 0xffffu, n1 = u >> 16;
-                const float c0 = off[(unsigned)(2 * w) * un + i], c1 = off[(unsigned)(2 * w + 1) * un + i];
-                const float v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
+                const mb_real c0 = off[(unsigned)(2 * w) * un + i], c1 = off[(unsigned)(2 * w + 1) * un + i];
+                const mb_real v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
                 acc += n0 != 0xffffu ? c0 * v0 : 0.f;
                 acc += n1 != 0xffffu ? c1 * v1 : 0.f;
             }
@@ -1736,10 +1736,10 @@ __device__ __forceinline__ oc_rsrc oc_make_rsrc(const void* p, unsigned bytes) {
 // arrays + a scheduling barrier): left to itself the compiler, short of registers, loads and waits member by member -- sixteen
 // serial L2 round trips per stencil pass, 13 of the 28 us of a preconditioned iteration (knock-out builds, -DFG_MB_OC_KNOCK).
 template <int CPT, int NT, int G>
-__device__ __forceinline__ float oc_spmv_agg(const OcParams& o, int sys, unsigned tl, const float* __restrict__ v_lds, float* __restrict__ y_lds) {
+__device__ __forceinline__ mb_real oc_spmv_agg(const OcParams& o, int sys, unsigned tl, const mb_real* __restrict__ v_lds, mb_real* __restrict__ y_lds) {
     static_assert(CPT % G == 0, "member groups");
     constexpr int NB = CPT / G;
-    float part = 0.f;   // this thread's share of v . (M v)
+    mb_real part = 0.f;   // this thread's share of v . (M v)
     constexpr unsigned S = CPT * NT;
     const oc_rsrc R_off = oc_make_rsrc(o.agg.off4 + (size_t)sys * S * 4, S * 16u);
     const oc_rsrc R_dg = oc_make_rsrc(o.agg.diag + (size_t)sys * S, S * 4u);
@@ -1748,7 +1748,7 @@ __device__ __forceinline__ float oc_spmv_agg(const OcParams& o, int sys, unsigne
     // per stencil pass instead of one per batch
     oc_u32x2 ub[2][G];
     oc_u32x4 cb[2][G];
-    float dd[2][G];
+    mb_real dd[2][G];
     auto request = [&](int b, int buf) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -1780,14 +1780,14 @@ __device__ __forceinline__ float oc_spmv_agg(const OcParams& o, int sys, unsigne
             // (~130 vector instructions per member and iteration at four waves per SIMD), so every one of them counts
             const uint32_t a0 = ub[buf][g].x & 0xffffu, a1 = ub[buf][g].x >> 16, a2 = ub[buf][g].y & 0xffffu, a3 = ub[buf][g].y >> 16;
             const char* vb_ = reinterpret_cast<const char*>(v_lds);
-            const float vc = v_lds[i];
+            const mb_real vc = v_lds[i];
 #if defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 4)
-            const float v0 = vc, v1 = vc, v2 = vc, v3 = vc;
+            const mb_real v0 = vc, v1 = vc, v2 = vc, v3 = vc;
 #else
-            const float v0 = *reinterpret_cast<const float*>(vb_ + a0), v1 = *reinterpret_cast<const float*>(vb_ + a1);
-            const float v2 = *reinterpret_cast<const float*>(vb_ + a2), v3 = *reinterpret_cast<const float*>(vb_ + a3);
+            const mb_real v0 = *reinterpret_cast<const mb_real*>(vb_ + a0), v1 = *reinterpret_cast<const mb_real*>(vb_ + a1);
+            const mb_real v2 = *reinterpret_cast<const mb_real*>(vb_ + a2), v3 = *reinterpret_cast<const mb_real*>(vb_ + a3);
 #endif
-            float acc = dd[buf][g] * vc;
+            mb_real acc = dd[buf][g] * vc;
             acc += __uint_as_float(cb[buf][g].x) * v0;
             acc += __uint_as_float(cb[buf][g].y) * v1;
             acc += __uint_as_float(cb[buf][g].z) * v2;
@@ -1803,19 +1803,19 @@ __device__ __forceinline__ float oc_spmv_agg(const OcParams& o, int sys, unsigne
 template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true, bool PRE = false, bool AGG = false>
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
     static_assert(!AGG || (PRE && DIMS == 2 && CPT == 16 && NT == 1024 && PM != 2 && !DG_REGS && !NBR), "aggregate-owned layout: 16 slots x 1024 threads, preconditioned, 2-D");
-    __shared__ float v_lds[CPT * NT];
+    __shared__ mb_real v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
-    __shared__ float l_r4[(PRE && !AGG) ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1];
+    __shared__ mb_real l_r4[(PRE && !AGG) ? OC_N4 : 1], l_r8[PRE ? OC_N8 : 1];
     // r - mean r of the preconditioner pass, where the aggregate sums gather it; once they have, the same memory holds the
     // per-wave partial sums of the coarse solve
     constexpr int LP8 = AGG ? 256 : OC_N8;   // AGG: 4 n8 <= 1024 threads
     constexpr int RT = PRE ? ((!AGG && CPT * NT > OC_MAX_WAVES * LP8) ? CPT * NT : OC_MAX_WAVES * LP8) : 1;
-    __shared__ __attribute__((aligned(16))) float l_rt[RT];
-    float (*l_part)[LP8] = reinterpret_cast<float (*)[LP8]>(l_rt);
+    __shared__ __attribute__((aligned(16))) mb_real l_rt[RT];
+    mb_real (*l_part)[LP8] = reinterpret_cast<mb_real (*)[LP8]>(l_rt);
     // AGG: M p (and, before the stencil pass, z) lives in LDS instead of 16 registers per thread -- the cell-ordered preconditioned
     // instance spills ~100 registers, and what that costs is the stencil pass: its 48 loads per thread no longer overlap
     // (knock-out builds, -DFG_MB_OC_KNOCK: 13 of 28 us per iteration are those loads, against 11.5 us for the whole plain iteration)
-    __shared__ float ap_lds[AGG ? CPT * NT : 1];
+    __shared__ mb_real ap_lds[AGG ? CPT * NT : 1];
 #define OC_AP(k, i) (*(AGG ? &ap_lds[i] : &ap[k]))
     static_assert(!PRE || NT == 1024, "the coarse solve of the preconditioner gives every one of the 16 waves its own set of columns");
     int phase = 0;
@@ -1823,14 +1823,14 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     const size_t vb = (size_t)sys * N;
     // AGG: indices are slots; the thread's members k < cnt are cells.  Otherwise cell i = t + k NT < N.
     const int cnt = AGG ? o.agg.cnt[t] : 0;
-    const float d4g_t = AGG ? o.agg.d4g[t] : 0.f;
+    const mb_real d4g_t = AGG ? o.agg.d4g[t] : 0.f;
     // AGG: every slot is valid memory and holes hold zeros (matrix, kept iterate, LDS vectors), so nothing that touches memory is
     // conditional -- a per-member branch `k < cnt` around the loads of the stencil pass serialises their latencies (16 round
     // trips instead of one batch); only the values that would not be zero by themselves (r - mean, z) are masked with a select
 #define OC_OK(k, i) (AGG || ((i) < (unsigned)N))
 #define OC_M(k) (!AGG || ((k) < cnt))
     const size_t sb = AGG ? (size_t)sys * (CPT * NT) : vb;                      // base of the per-iteration arrays of this env
-    const float* __restrict__ diag_it = AGG ? o.agg.diag + sb : q.diag + vb;    // diagonal in the index space of the iteration
+    const mb_real* __restrict__ diag_it = AGG ? o.agg.diag + sb : q.diag + vb;    // diagonal in the index space of the iteration
     if (!mb_active(o.dt, sys)) {
         if (t == 0) {
             flag_st(q.flags + (sys), 3);
@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         }
         return;
     }
-    float r[CPT], x[CPT], ap[CPT], dg[CPT];
+    mb_real r[CPT], x[CPT], ap[CPT], dg[CPT];
     // the packed neighbour indices of the thread's cells never change: kept in registers when they fit (2-D, interleaved
     // coefficient layout), which also takes the index load out of the stencil's dependency chain (index -> LDS address)
     constexpr bool NB_REGS = NBR && (DIMS == 2 && CPT * (NT / 512) <= 32);   // 2 registers per cell: up to 16 (32) cells at 1024 (512) threads
@@ -1852,9 +1852,9 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
             nbk[k] = i < (unsigned)N ? reinterpret_cast<const uint2*>(o.nbr16)[i] : make_uint2(0xffffffffu, 0xffffffffu);
         }
     }
-    const float rsqn = rsqrtf((float)N);
-    const float* __restrict__ rhs = q.rhs + vb;
-    float* __restrict__ bestx = AGG ? o.agg.bestx + sb : q.best_x + vb;
+    const mb_real rsqn = mb_rsqrt((mb_real)N);
+    const mb_real* __restrict__ rhs = q.rhs + vb;
+    mb_real* __restrict__ bestx = AGG ? o.agg.bestx + sb : q.best_x + vb;
     // ---- start: x = x0 or 0, r = rhs (- M x0 through a residual pass)
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -1868,17 +1868,17 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         ap[k] = 0.f;
     }
     double rr = 0.0, sr = 0.0;
-    float inv_s = 1.f;   // 1 / (scale of this env's matrix against the geometry-only one)
+    mb_real inv_s = 1.f;   // 1 / (scale of this env's matrix against the geometry-only one)
     if (PRE) {
-        float sd = 0.f;
+        mb_real sd = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) { const unsigned i = t + (unsigned)k * NT; if (OC_OK(k, i)) sd += diag_it[i]; }
         double dsum, unused0;
         oc_reduce2<NT, RING>(sd, 0.f, red, phase, dsum, unused0);
-        inv_s = (float)((double)o.pre.geom_diag_sum / dsum);
+        inv_s = (mb_real)((double)o.pre.geom_diag_sum / dsum);
     }
     if (!o.use_x0) {
-        float s2 = 0.f, s1 = 0.f;
+        mb_real s2 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = t + (unsigned)k * NT;
@@ -1891,7 +1891,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     // One loop, ONE stencil pass per trip: a trip is either a CG iteration (vector in LDS = the new search direction) or a
     // residual pass r = rhs - M x (vector in LDS = x: start from x0, the restart every 100 iterations, a recovery).
     int it = 0, best_it = 0, recoveries = 0, outcome = 0;   // outcome: 1 converged, 2 non-finite, 3 accepted on the kept iterate, 4 out of iterations / stalled
-    float best = 3.0e38f, crit = 0.f;
+    mb_real best = 3.0e38f, crit = 0.f;
     bool fresh = true, restarted = true, residual_pass = o.use_x0 != 0, recovering = false;
     double rho = 0.0, rho_prev = 1.0;
     // per-phase cycle counters: a BUILD switch (-DFG_MB_OC_CYCLES, profiles/onchip_micro.py variant 256) -- as a run-time switch
@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         // compiler otherwise hoists all of them out of it (CPT x 8 register pairs) and spills them
         unsigned tl = t;
         asm volatile("" : "+v"(tl));
-        float beta = 0.f, cy = 0.f;
+        mb_real beta = 0.f, cy = 0.f;
         if (!residual_pass) {
             rho = rr - sr * sr;   // |r - (yp.r) yp|^2
             crit = mb_rms(rho, N);
@@ -1920,7 +1920,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     const unsigned i = tl + (unsigned)k * NT;
-                    if (OC_OK(k, i)) { const float v = bestx[i]; x[k] = isfinite(v) ? v : 0.f; }
+                    if (OC_OK(k, i)) { const mb_real v = bestx[i]; x[k] = isfinite(v) ? v : 0.f; }
                 }
                 residual_pass = true; recovering = true;
             } else {
@@ -1939,23 +1939,23 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 if (it > 0 && it % o.restart_every == 0 && !restarted) residual_pass = true;   // residualResetSteps (cg_solver_kernel.cu:281-300)
             }
         }
-        float zbar = 0.f;
+        mb_real zbar = 0.f;
         OC_PHASE(0);   // checks, best-iterate store
         if (!residual_pass) {
             restarted = false;
-            beta = fresh ? 0.f : (float)(rho / rho_prev);
-            cy = (float)sr;
+            beta = fresh ? 0.f : (mb_real)(rho / rho_prev);
+            cy = (mb_real)sr;
             if (PRE && AGG) {
                 // ---- z = M (r - mean r), aggregate-owned: the 4 x 4 sum is a sum over the thread's registers (members in the
                 // row-major order the gather of the cell-ordered form walks), the 8 x 8 sum the sum of a quad's lanes in child order
-                const float rm = PM == 1 ? cy * rsqn : 0.f;
+                const mb_real rm = PM == 1 ? cy * rsqn : 0.f;
                 const int n8 = o.pre.n8;
-                float r4 = 0.f;
+                mb_real r4 = 0.f;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) r4 += (k < cnt) ? r[k] - rm : 0.f;
                 {
                     const int q0 = (t & 63) & ~3;
-                    const float c0 = __shfl(r4, q0, 64), c1 = __shfl(r4, q0 + 1, 64), c2 = __shfl(r4, q0 + 2, 64), c3 = __shfl(r4, q0 + 3, 64);
+                    const mb_real c0 = __shfl(r4, q0, 64), c1 = __shfl(r4, q0 + 1, 64), c2 = __shfl(r4, q0 + 2, 64), c3 = __shfl(r4, q0 + 3, 64);
                     if ((t & 3) == 0 && (t >> 2) < n8) l_r8[t >> 2] = ((c0 + c1) + c2) + c3;
                 }
                 __syncthreads();
@@ -1967,7 +1967,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll 8
                         for (int c = grp; c < n8; c += OC_MAX_WAVES) {
                             const float4 a = *reinterpret_cast<const float4*>(o.pre.aci8 + (unsigned)c * (unsigned)ld + 4u * (unsigned)qd);
-                            const float rc = l_r8[c];
+                            const mb_real rc = l_r8[c];
                             acc.x += a.x * rc; acc.y += a.y * rc; acc.z += a.z * rc; acc.w += a.w * rc;
                         }
 #endif
@@ -1976,39 +1976,39 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 }
                 __syncthreads();
                 const oc_rsrc R_dg = oc_make_rsrc(diag_it, (unsigned)(CPT * NT) * 4u);
-                float corr = 0.f;
+                mb_real corr = 0.f;
                 if (cnt > 0) {
-                    float e = 0.f;
+                    mb_real e = 0.f;
 #pragma unroll
                     for (int g = 0; g < OC_MAX_WAVES; ++g) e += l_part[g][t >> 2];
                     corr = inv_s * (0.5f * r4 * d4g_t + e);
                 }
-                float s_rz = 0.f, s_z = 0.f;
+                mb_real s_rz = 0.f, s_z = 0.f;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     const unsigned i = tl + (unsigned)k * NT;
-                    const float rt = (k < cnt) ? r[k] - rm : 0.f;
+                    const mb_real rt = (k < cnt) ? r[k] - rm : 0.f;
 #if defined(FG_MB_OC_KNOCK) && (FG_MB_OC_KNOCK & 8)
-                    const float z = (k < cnt) ? rt + corr : 0.f;
+                    const mb_real z = (k < cnt) ? rt + corr : 0.f;
 #else
-                    const float dk = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R_dg, tl * 4u, (unsigned)k * NT * 4u, 0));
-                    const float z = (k < cnt) ? rt * __builtin_amdgcn_rcpf(dk) + corr : 0.f;
+                    const mb_real dk = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R_dg, tl * 4u, (unsigned)k * NT * 4u, 0));
+                    const mb_real z = (k < cnt) ? rt * __builtin_amdgcn_rcpf(dk) + corr : 0.f;
 #endif
                     OC_AP(k, i) = z;
                     s_rz += rt * z; s_z += z;
                 }
                 double zsum;
                 oc_reduce2<NT, RING>(s_rz, s_z, red, phase, rz, zsum);   // its barrier also orders the reads of l_part before the next pass writes it
-                zbar = PM == 1 ? (float)(zsum / (double)N) : 0.f;
-                beta = fresh ? 0.f : (float)(rz / rz_prev);
+                zbar = PM == 1 ? (mb_real)(zsum / (double)N) : 0.f;
+                beta = fresh ? 0.f : (mb_real)(rz / rz_prev);
                 OC_PHASE(6);
             } else if (PRE) {
                 // ---- z = M (r - mean r): restrict to the 4 x 4 and 8 x 8 aggregates (LDS atomics), dense coarse solve by the
                 // waves (one row per wave and pass, lanes over the columns), corrections summed top-down into l_r4
-                const float rm = PM == 1 ? cy * rsqn : 0.f;
+                const mb_real rm = PM == 1 ? cy * rsqn : 0.f;
                 const int n4 = o.pre.n4, n8 = o.pre.n8;
                 // restriction as GATHERS: every aggregate is a rectangle of cells of one block, so one thread sums it out of the
-                // LDS copy of the residual; 8 x 8 aggregates sum their (up to four) children.  LDS float atomics did this first
+                // LDS copy of the residual; 8 x 8 aggregates sum their (up to four) children.  LDS mb_real atomics did this first
                 // and cost 21 us per application (14 k atomics on 912 addresses)
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
@@ -2020,7 +2020,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 for (int a = t; a < n4; a += NT) {
                     const uint2 rc = o.pre.rect4[a];
                     const unsigned w = rc.y & 0xffu, h = (rc.y >> 8) & 0xffu, stride = rc.y >> 16;
-                    float sum = 0.f;
+                    mb_real sum = 0.f;
                     for (unsigned dy = 0; dy < h; ++dy)
                         for (unsigned dx = 0; dx < w; ++dx) sum += l_rt[rc.x + dy * stride + dx];
                     l_r4[a] = sum;
@@ -2047,7 +2047,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 #pragma unroll 8
                         for (int c = grp; c < n8; c += OC_MAX_WAVES) {
                             const float4 a = *reinterpret_cast<const float4*>(o.pre.aci8 + (unsigned)c * (unsigned)ld + 4u * (unsigned)qd);
-                            const float rc = l_r8[c];
+                            const mb_real rc = l_r8[c];
                             acc.x += a.x * rc; acc.y += a.y * rc; acc.z += a.z * rc; acc.w += a.w * rc;
                         }
                         *reinterpret_cast<float4*>(&l_part[grp][4 * qd]) = acc;
@@ -2059,28 +2059,28 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 // parent (the 16 per-wave partial sums are added here, by every child: one barrier less than a separate pass)
                 for (int a = t; a < n4; a += NT) {
                     const int row = o.pre.parent4[a];
-                    float e = 0.f;
+                    mb_real e = 0.f;
 #pragma unroll
                     for (int g = 0; g < OC_MAX_WAVES; ++g) e += l_part[g][row];
                     l_r4[a] = inv_s * (0.5f * l_r4[a] * o.pre.d4g[a] + e);   // d4g holds reciprocals
                 }
                 __syncthreads();
                 OC_PHASE(5);   // correction table
-                float s_rz = 0.f, s_z = 0.f;
+                mb_real s_rz = 0.f, s_z = 0.f;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     const unsigned i = tl + (unsigned)k * NT;
                     if (i < (unsigned)N) {
-                        const float rt = r[k] - rm;
-                        const float z = rt * __builtin_amdgcn_rcpf(DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]];   // v_rcp_f32: a preconditioner needs no IEEE division
+                        const mb_real rt = r[k] - rm;
+                        const mb_real z = rt * __builtin_amdgcn_rcpf(DG_REGS ? dg[k] : q.diag[vb + i]) + l_r4[o.pre.a4[i]];   // v_rcp_f32: a preconditioner needs no IEEE division
                         ap[k] = z;   // ap is free until the stencil pass rewrites it
                         s_rz += rt * z; s_z += z;
                     }
                 }
                 double zsum;
                 oc_reduce2<NT, RING>(s_rz, s_z, red, phase, rz, zsum);
-                zbar = PM == 1 ? (float)(zsum / (double)N) : 0.f;
-                beta = fresh ? 0.f : (float)(rz / rz_prev);
+                zbar = PM == 1 ? (mb_real)(zsum / (double)N) : 0.f;
+                beta = fresh ? 0.f : (mb_real)(rz / rz_prev);
                 OC_PHASE(6);   // z pass + r.z reduction
             }
         }
@@ -2089,7 +2089,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = tl + (unsigned)k * NT;
             if (OC_OK(k, i)) {
-                float v;
+                mb_real v;
                 if (residual_pass) v = x[k];
                 else {
                     v = PM == 0 ? r[k] : (PM == 1 ? r[k] - cy * rsqn : r[k] - cy * o.yp[i]);
@@ -2101,11 +2101,11 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         }
         __syncthreads();
         OC_PHASE(7);   // direction update
-        float part = 0.f;
+        mb_real part = 0.f;
         if constexpr (AGG) part = oc_spmv_agg<CPT, NT, OC_AGG_GROUP>(o, sys, tl, v_lds, ap_lds);
         else oc_spmv<DIMS, CPT, DG_REGS, NB_REGS, NT>(q, o, sys, N, tl, v_lds, dg, nbk, ap);
         OC_PHASE(8);   // stencil pass
-        float s2 = 0.f, s1 = 0.f;
+        mb_real s2 = 0.f, s1 = 0.f;
         if (residual_pass) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
@@ -2128,7 +2128,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         double pap, unused;
         oc_reduce2<NT, RING>(part, 0.f, red, phase, pap, unused);
         OC_PHASE(9);   // p.Pp reduction
-        const float alpha = (float)((PRE ? rz : rho) / pap);
+        const mb_real alpha = (mb_real)((PRE ? rz : rho) / pap);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const unsigned i = tl + (unsigned)k * NT;
@@ -2186,23 +2186,23 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 // W[f][i] = l_ik (neighbour across face f below i) or u_ij (above); ud[i] = u_ii.
 // ---------------------------------------------------------------------------------------------------------------
 template <int DIMS>
-__global__ __launch_bounds__(1024) void k_mb_ilu_factor(MbDev D, const float* __restrict__ dt, const float* __restrict__ diag,
-                                                         const float* __restrict__ off, const int32_t* __restrict__ order,
-                                                         const int32_t* __restrict__ start, int levels, float* __restrict__ W,
-                                                         float* __restrict__ ud) {
+__global__ __launch_bounds__(1024) void k_mb_ilu_factor(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ diag,
+                                                         const mb_real* __restrict__ off, const int32_t* __restrict__ order,
+                                                         const int32_t* __restrict__ start, int levels, mb_real* __restrict__ W,
+                                                         mb_real* __restrict__ ud) {
     constexpr int F = 2 * DIMS;
     const int b = blockIdx.x, N = D.N;
     if (!mb_active(dt, b)) return;
-    const float* dg = diag + (size_t)b * N;
-    const float* of = off + (size_t)b * F * N;
-    float* w_ = W + (size_t)b * F * N;
-    float* u_ = ud + (size_t)b * N;
+    const mb_real* dg = diag + (size_t)b * N;
+    const mb_real* of = off + (size_t)b * F * N;
+    mb_real* w_ = W + (size_t)b * F * N;
+    mb_real* u_ = ud + (size_t)b * N;
     for (int lv = 0; lv < levels; ++lv) {
         for (int pos = start[lv] + (int)threadIdx.x; pos < start[lv + 1]; pos += (int)blockDim.x) {
             const int i = order[pos];
             int nb[F];
-            float w[F];
-            float d = dg[i];
+            mb_real w[F];
+            mb_real d = dg[i];
 #pragma unroll
             for (int f = 0; f < F; ++f) { nb[f] = D.nbr[(size_t)f * N + i]; w[f] = nb[f] >= 0 ? of[(size_t)f * N + i] : 0.f; }
             int last = -1;
@@ -2212,13 +2212,13 @@ __global__ __launch_bounds__(1024) void k_mb_ilu_factor(MbDev D, const float* __
                 for (int f = 0; f < F; ++f) if (nb[f] >= 0 && nb[f] < i && nb[f] > last && nb[f] < k) { k = nb[f]; fk = f; }
                 if (fk < 0) break;
                 last = k;
-                const float l = w[fk] / u_[k];
+                const mb_real l = w[fk] / u_[k];
                 w[fk] = l;
 #pragma unroll
                 for (int g = 0; g < F; ++g) {                  // row k above its diagonal
                     const int j = D.nbr[(size_t)g * N + k];
                     if (j <= k) continue;
-                    const float ukj = w_[(size_t)g * N + k];
+                    const mb_real ukj = w_[(size_t)g * N + k];
                     if (j == i) d -= l * ukj;
                     else {
 #pragma unroll
@@ -2238,19 +2238,19 @@ __global__ __launch_bounds__(1024) void k_mb_ilu_factor(MbDev D, const float* __
 template <int DIMS>
 __global__ __launch_bounds__(1024) void k_mb_ilu_solve(MbDev D, int nc, const int32_t* __restrict__ flags, const int32_t* __restrict__ order_f,
                                                         const int32_t* __restrict__ start_f, int levels_f, const int32_t* __restrict__ order_b,
-                                                        const int32_t* __restrict__ start_b, int levels_b, const float* __restrict__ W,
-                                                        const float* __restrict__ ud, const float* __restrict__ in, float* __restrict__ out) {
+                                                        const int32_t* __restrict__ start_b, int levels_b, const mb_real* __restrict__ W,
+                                                        const mb_real* __restrict__ ud, const mb_real* __restrict__ in, mb_real* __restrict__ out) {
     constexpr int F = 2 * DIMS;
     const int b = blockIdx.y, sys = b * nc + (int)blockIdx.x, N = D.N;
     if (flag_ld(flags + sys) != 0) return;
-    const float* w_ = W + (size_t)b * F * N;
-    const float* u_ = ud + (size_t)b * N;
-    const float* r = in + (size_t)sys * N;
-    float* y = out + (size_t)sys * N;
+    const mb_real* w_ = W + (size_t)b * F * N;
+    const mb_real* u_ = ud + (size_t)b * N;
+    const mb_real* r = in + (size_t)sys * N;
+    mb_real* y = out + (size_t)sys * N;
     for (int lv = 0; lv < levels_f; ++lv) {
         for (int pos = start_f[lv] + (int)threadIdx.x; pos < start_f[lv + 1]; pos += (int)blockDim.x) {
             const int i = order_f[pos];
-            float v = r[i];
+            mb_real v = r[i];
 #pragma unroll
             for (int f = 0; f < F; ++f) { const int k = D.nbr[(size_t)f * N + i]; if (k >= 0 && k < i) v -= w_[(size_t)f * N + i] * y[k]; }
             y[i] = v;
@@ -2260,7 +2260,7 @@ __global__ __launch_bounds__(1024) void k_mb_ilu_solve(MbDev D, int nc, const in
     for (int lv = 0; lv < levels_b; ++lv) {
         for (int pos = start_b[lv] + (int)threadIdx.x; pos < start_b[lv + 1]; pos += (int)blockDim.x) {
             const int i = order_b[pos];
-            float v = y[i];
+            mb_real v = y[i];
 #pragma unroll
             for (int f = 0; f < F; ++f) { const int j = D.nbr[(size_t)f * N + i]; if (j > i) v -= w_[(size_t)f * N + i] * y[j]; }
             y[i] = v / u_[i];
@@ -2272,18 +2272,18 @@ __global__ __launch_bounds__(1024) void k_mb_ilu_solve(MbDev D, int nc, const in
 // ---- boundary bookkeeping of Simulation.single_step (simulation.py:206-280) on the flat boundary slots --------------
 // update_advective_boundaries (PISOtorch_simulation.py:228-393): u_b <- u_b - t (u_b - u_cell), t = 1 - 1/(1 + 2 dt Minv_b[axis].velm)
 template <int DIMS>
-__global__ void k_mb_outflow(MbDev D, const float* __restrict__ dt, const float* __restrict__ u, float* __restrict__ ub,
-                             int slot0, int count, float v0, float v1, float v2) {
+__global__ void k_mb_outflow(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ u, mb_real* __restrict__ ub,
+                             int slot0, int count, mb_real v0, mb_real v1, mb_real v2) {
     const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count || !mb_active(dt, b)) return;
     const int sl = slot0 + k;
-    const float* t = D.Tb + (size_t)sl * (DIMS * DIMS + 1);
+    const mb_real* t = D.Tb + (size_t)sl * (DIMS * DIMS + 1);
     const int axis = D.bface[sl] >> 1;
-    const float velm[3] = {v0, v1, v2};
-    float adv = 0.f;
+    const mb_real velm[3] = {v0, v1, v2};
+    mb_real adv = 0.f;
 #pragma unroll
     for (int c = 0; c < DIMS; ++c) adv += t[axis * DIMS + c] * velm[c];
-    const float w = 1.f - 1.f / (1.f + 2.f * dt[b] * adv);
+    const mb_real w = 1.f - 1.f / (1.f + 2.f * dt[b] * adv);
     const int cell = D.bcell[sl];
 #pragma unroll
     for (int c = 0; c < DIMS; ++c) {
@@ -2293,48 +2293,48 @@ __global__ void k_mb_outflow(MbDev D, const float* __restrict__ dt, const float*
 }
 // signed boundary fluxes (get_fixed_boundary_fluxes, :88-105): out[b][0] = slots outside [slot0, slot0+count), out[b][1] = inside
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_bflux(MbDev D, const float* __restrict__ ub, int slot0, int count, int slot0b, int countb,
-                                                        float* __restrict__ out) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_bflux(MbDev D, const mb_real* __restrict__ ub, int slot0, int count, int slot0b, int countb,
+                                                        mb_real* __restrict__ out) {
     const int b = blockIdx.x;
-    float fx = 0.f, fr = 0.f;
+    mb_real fx = 0.f, fr = 0.f;
     for (int sl = threadIdx.x; sl < D.NB; sl += FG_BLOCK) {
-        const float* t = D.Tb + (size_t)sl * (DIMS * DIMS + 1);
+        const mb_real* t = D.Tb + (size_t)sl * (DIMS * DIMS + 1);
         const int f = D.bface[sl], axis = f >> 1;
-        float s = 0.f;
+        mb_real s = 0.f;
 #pragma unroll
         for (int c = 0; c < DIMS; ++c) s += t[axis * DIMS + c] * ub[((size_t)b * DIMS + c) * D.NB + sl];
         s *= t[DIMS * DIMS] * ((f & 1) ? 1.f : -1.f);
         if ((sl >= slot0 && sl < slot0 + count) || (sl >= slot0b && sl < slot0b + countb)) fr += s; else fx += s;
     }
-    __shared__ float lds[4];
+    __shared__ mb_real lds[4];
     fx = mb_block_sum(fx, lds);
     fr = mb_block_sum(fr, lds);
     if (threadIdx.x == 0) { out[2 * b] = fx; out[2 * b + 1] = fr; }
 }
 // balance_boundary_fluxes (:188-224): scale the free boundary so that the total flux vanishes
 template <int DIMS>
-__global__ void k_mb_balance(MbDev D, const float* __restrict__ dt, const float* __restrict__ sums, float atol,
-                             float* __restrict__ ub, int slot0, int count) {
+__global__ void k_mb_balance(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ sums, mb_real atol,
+                             mb_real* __restrict__ ub, int slot0, int count) {
     const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count || !mb_active(dt, b)) return;
-    const float fx = sums[2 * b], fr = sums[2 * b + 1];
-    if (fabsf(fx + fr) <= atol) return;
-    const float scale = -fx / fr;
+    const mb_real fx = sums[2 * b], fr = sums[2 * b + 1];
+    if (mb_fabs(fx + fr) <= atol) return;
+    const mb_real scale = -fx / fr;
 #pragma unroll
     for (int c = 0; c < DIMS; ++c) ub[((size_t)b * DIMS + c) * D.NB + slot0 + k] *= scale;
 }
-__global__ void k_mb_fill(size_t n, float v, float* __restrict__ x) {
+__global__ void k_mb_fill(size_t n, mb_real v, mb_real* __restrict__ x) {
     const size_t i = (size_t)blockIdx.x * FG_BLOCK + threadIdx.x;
     if (i < n) x[i] = v;
 }
 
 // envs with a non-finite system leave the step: dt = 0 masks them out of every later kernel of the call (incl. the final
 // copy of the velocity result), so their state stays what it was before the step; status 2 is recorded
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_restore_failed(int N, const int32_t* __restrict__ fail, const float* __restrict__ src, float* __restrict__ dst) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_restore_failed(int N, const int32_t* __restrict__ fail, const mb_real* __restrict__ src, mb_real* __restrict__ dst) {
     const int b = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
     if (i < N && fail[b] == 2) dst[(size_t)b * N + i] = src[(size_t)b * N + i];
 }
-__global__ void k_mb_mask_failed(int B, int nc, const fg_solve_info* __restrict__ info, float* __restrict__ dt, int32_t* __restrict__ fail) {
+__global__ void k_mb_mask_failed(int B, int nc, const fg_solve_info* __restrict__ info, mb_real* __restrict__ dt, int32_t* __restrict__ fail) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B || !(dt[b] > 0.f)) return;
     bool bad = false;
@@ -2344,8 +2344,8 @@ __global__ void k_mb_mask_failed(int B, int nc, const fg_solve_info* __restrict_
 
 // right diagonal scaling for the preconditioned BiCGStab rung: M' = M D^-1 (unit diagonal), solved for y = D x
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_scale_cols(MbDev D, const float* __restrict__ dt, const float* __restrict__ diag,
-                                                             const float* __restrict__ off, float* __restrict__ diag_s, float* __restrict__ off_s) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_scale_cols(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ diag,
+                                                             const mb_real* __restrict__ off, mb_real* __restrict__ diag_s, mb_real* __restrict__ off_s) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     constexpr int F = 2 * DIMS;
@@ -2356,7 +2356,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_scale_cols(MbDev D, const float
         off_s[((size_t)b * F + f) * N + i] = n >= 0 ? off[((size_t)b * F + f) * N + i] / diag[(size_t)b * N + n] : 0.f;
     }
 }
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_unscale(int N, int nc, const float* __restrict__ dt, const float* __restrict__ diag, float* __restrict__ x) {
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_unscale(int N, int nc, const mb_real* __restrict__ dt, const mb_real* __restrict__ diag, mb_real* __restrict__ x) {
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y, b = sys / nc;
     if (i >= N || !mb_active(dt, b)) return;
     x[(size_t)sys * N + i] /= diag[(size_t)b * N + i];
@@ -2394,7 +2394,7 @@ __global__ void k_mbb_reopen(MbSolve q, int32_t* __restrict__ verified, int nsys
 __global__ void k_mbb_verify(MbSolve q, int32_t* __restrict__ verified, int n, int nsys, int last_round) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys || verified[s] != 2) return;
-    const float crit = (float)sqrt(acc_ld(q.acc + ((size_t)s * MB_ACC + A_RR)) / (double)n);   // the recomputed residual
+    const mb_real crit = (mb_real)sqrt(acc_ld(q.acc + ((size_t)s * MB_ACC + A_RR)) / (double)n);   // the recomputed residual
     if (crit < q.tol || last_round) {   // last round: ends here either way, reported as what it is
         verified[s] = 1;
         q.info[s].final_residual = crit;
@@ -2428,7 +2428,7 @@ int mb_finish(fg_mb_state* s, int nsys, fg_solve_info* info_host, int* max_it) {
     return rc;
 }
 
-MbSolve mb_solve_ptrs(fg_mb_state* s, const float* diag, const float* off, const float* rhs, float* x, int nc, float tol) {
+MbSolve mb_solve_ptrs(fg_mb_state* s, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, int nc, mb_real tol) {
     MbSolve q;
     memset(&q, 0, sizeof(q));  // the struct doubles as (part of) the key of the cached CG graph: no stray padding bytes
     q.diag = diag; q.off = off; q.rhs = rhs; q.x = x;
@@ -2454,7 +2454,7 @@ MlDev mb_ml_dev(const fg_mb_state* s) {
 }
 // fused = 0: z = M in.  1 / 2: `in` is q.p / q.r and its update (k_mbb_p4 / k_mbb_s4) happens inside the restriction
 // (k_ml_restrict_p / _s), iteration index `it`.
-void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st, int fused = 0, int it = 0) {
+void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const mb_real* in, mb_real* out, hipStream_t st, int fused = 0, int it = 0) {
     const MlDev M = mb_ml_dev(s);
     const int nsys = s->B * q.nc, n = s->N;
     const dim3 rgrid4((4 * M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys);   // four threads per aggregate
@@ -2519,19 +2519,19 @@ bool mb_ilu_prepare(fg_mb_state* s) {
     return true;
 }
 
-void mb_ilu_factor(fg_mb_state* s, const float* dt, const float* diag, const float* off, hipStream_t st) {
+void mb_ilu_factor(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, hipStream_t st) {
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_ilu_factor<DIMS>, dim3(s->B), dim3(1024), 0, st, s->dev, dt, diag, off, (const int32_t*)s->ilu_order_f,
                                       (const int32_t*)s->ilu_start_f_dev, (int)s->ilu_start_f.size() - 1, s->ilu_w, s->ilu_ud););
 }
-void mb_ilu_apply(fg_mb_state* s, const MbSolve& q, const float* in, float* out, hipStream_t st) {
+void mb_ilu_apply(fg_mb_state* s, const MbSolve& q, const mb_real* in, mb_real* out, hipStream_t st) {
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_ilu_solve<DIMS>, dim3(q.nc, s->B), dim3(1024), 0, st, s->dev, q.nc, (const int32_t*)q.flags,
                                       (const int32_t*)s->ilu_order_f, (const int32_t*)s->ilu_start_f_dev, (int)s->ilu_start_f.size() - 1,
                                       (const int32_t*)s->ilu_order_b, (const int32_t*)s->ilu_start_b_dev, (int)s->ilu_start_b.size() - 1,
-                                      (const float*)s->ilu_w, (const float*)s->ilu_ud, in, out););
+                                      (const mb_real*)s->ilu_w, (const mb_real*)s->ilu_ud, in, out););
 }
 
-int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, int nc,
-                float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0, int multilevel = 0,
+int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, int nc,
+                mb_real tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0, int multilevel = 0,
                 int pred_slot = 31) {
     const int nsys = s->B * nc, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
@@ -2635,8 +2635,8 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
             hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
             if (int rc = mb_poll(s, nsys, st, done)) return rc;
             if (nc == 1 && s->dbg_trace) {
-                float lo = 1e30f, hi = 0.f; int active = 0;
-                for (int i = 0; i < nsys; ++i) { const float c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
+                mb_real lo = 1e30f, hi = 0.f; int active = 0;
+                for (int i = 0; i < nsys; ++i) { const mb_real c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
                 fprintf(stderr, "[mb_bicg] it %4d residual min %.3e max %.3e active %d\n", it + 1, lo, hi, active);
             }
             if (done && verify && verify_rounds < 3 && it + 1 < max_iterations) {   // see k_mbb_reopen
@@ -2669,7 +2669,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
         }
     }
     if (refine) {
-        hipLaunchKernelGGL(k_mbr_best_restore, grid, blk, 0, st, n, q, s->x64, (const double*)s->x64_best, (const float*)s->best_res);
+        hipLaunchKernelGGL(k_mbr_best_restore, grid, blk, 0, st, n, q, s->x64, (const double*)s->x64_best, (const mb_real*)s->best_res);
         hipLaunchKernelGGL(k_mbr_fold, grid, blk, 0, st, n, q, s->x64, 3);
         FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * nsys, hipMemcpyDeviceToHost, st));
         FG_HIP_CHECK(hipStreamSynchronize(st));
@@ -2679,10 +2679,10 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
     if (frc == FG_ERR_NOT_FINITE && s->dbg_fail) {   // rare path, FG_MB_TRACE_FAIL only: the recurrence scalars of the systems that broke down
         std::vector<FgDacc> acc_raw((size_t)nsys * MB_ACC);
         std::vector<double> acc((size_t)nsys * MB_ACC);
-        std::vector<float> sc((size_t)nsys * 2);
+        std::vector<mb_real> sc((size_t)nsys * 2);
         (void)hipMemcpy(acc_raw.data(), s->acc, acc_raw.size() * sizeof(FgDacc), hipMemcpyDeviceToHost);
         for (size_t k = 0; k < acc.size(); ++k) acc[k] = fg_dacc_host_value(acc_raw[k]);
-        (void)hipMemcpy(sc.data(), s->sc, sc.size() * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sc.data(), s->sc, sc.size() * sizeof(mb_real), hipMemcpyDeviceToHost);
         for (int i = 0; i < nsys; ++i) {
             if (s->info_pinned[i].is_finite) continue;
             fprintf(stderr, "[mb_bicg] non-finite system %d (nc %d, vec_mask %d, project %d, refine %d): it %d residual %g alpha %g omega %g acc",
@@ -2700,7 +2700,7 @@ int mb_bicgstab(fg_mb_state* s, const float* dt, const float* diag, const float*
 // sensible cap), so the attempt is capped (200 iterations), a failed attempt is repeated with the plain recurrence (from the kept
 // iterate; from zero after a non-finite one), and the handle backs off: the next `backoff` solves run plain, the back-off doubles
 // with every failure (4 ... 256) and halves with every success.
-int mb_pressure_bicgstab(fg_mb_state* s, const float* dt, float tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project,
+int mb_pressure_bicgstab(fg_mb_state* s, const mb_real* dt, mb_real tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project,
                          int refine, int pred_slot) {
     const bool have_ml = s->ml_on && s->ml_a4 != nullptr && s->ml_mp != nullptr && s->d == 2;
     if (have_ml && s->ml_bicg_skip > 0) --s->ml_bicg_skip;
@@ -2734,8 +2734,8 @@ bool mb_onchip_ok(const fg_mb_state* s, int pm_mode) {
 }
 
 // the whole CG solve of every env in one launch (k_mbc_onchip); same arguments and results as mb_cg
-int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
-                 int max_iterations, int use_x0, int pm_mode, float stall_accept, int* max_it, hipStream_t st) {
+int mb_cg_onchip(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, mb_real tol,
+                 int max_iterations, int use_x0, int pm_mode, mb_real stall_accept, int* max_it, hipStream_t st) {
 #if FG_MB_F64
     (void)dt; (void)diag; (void)off; (void)rhs; (void)x; (void)tol; (void)max_iterations; (void)use_x0; (void)pm_mode; (void)stall_accept; (void)max_it; (void)st;
     fg_set_error("the on-chip CG is not part of the fp64 build");   // (never reached: fg_mb_create switches it off there)
@@ -2803,8 +2803,8 @@ int mb_cg_onchip(fg_mb_state* s, const float* dt, const float* diag, const float
 // orthogonal mesh) that changes nothing; with cross-metric terms 1^T P != 0, the plain recurrence accumulates a constant
 // residual component that no search direction can reduce (the solve stalls just above the envs' tolerance and cannot be
 // warm-started), and removing it is what makes the singular system consistent.
-int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, const float* rhs, float* x, float tol,
-          int max_iterations, int use_x0, int project_mean, float stall_accept, int* max_it, hipStream_t st) {
+int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, mb_real tol,
+          int max_iterations, int use_x0, int project_mean, mb_real stall_accept, int* max_it, hipStream_t st) {
     const int nsys = s->B, n = s->N;
     {
         const int pm = project_mean ? (s->yproj_const ? 1 : 2) : 0;
@@ -2859,18 +2859,18 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
                 if (vec4) {
                     if (ev) {
                         hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap4<DIMS, PM>), grid4, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                        hipExtLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean, s->dev.yproj);
+                        hipExtLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, n, q, (const mb_real*)s->w[1], (const mb_real*)s->w[2], -1, project_mean, s->dev.yproj);
                     } else {
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap4<DIMS, PM>), grid4, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                        hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean, s->dev.yproj);
+                        hipLaunchKernelGGL(k_mbc_update4, grid4, blk, 0, st, n, q, (const mb_real*)s->w[1], (const mb_real*)s->w[2], -1, project_mean, s->dev.yproj);
                     }
                 } else {
                     if (ev) {
                         hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap<DIMS, PM>), grid, blk, 0, st, s->prof_ev[2 * e0], s->prof_ev[2 * e0 + 1], 0, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                        hipExtLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                        hipExtLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->prof_ev[2 * e0 + 2], s->prof_ev[2 * e0 + 3], 0, s->dev, q, (const mb_real*)s->w[1], (const mb_real*)s->w[2], -1, project_mean);
                     } else {
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_ap<DIMS, PM>), grid, blk, 0, st, s->dev, q, s->w[1], s->w[2], -1, project_mean);
-                        hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const float*)s->w[1], (const float*)s->w[2], -1, project_mean);
+                        hipLaunchKernelGGL(k_mbc_update<DIMS>, grid, blk, 0, st, s->dev, q, (const mb_real*)s->w[1], (const mb_real*)s->w[2], -1, project_mean);
                     }
                 }
             }
@@ -2929,8 +2929,8 @@ int mb_cg(fg_mb_state* s, const float* dt, const float* diag, const float* off, 
             done = false;
         }
         if (trace) {
-            float lo = 1e30f, hi = 0.f; int active = 0;
-            for (int i = 0; i < nsys; ++i) { const float c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
+            mb_real lo = 1e30f, hi = 0.f; int active = 0;
+            for (int i = 0; i < nsys; ++i) { const mb_real c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
             fprintf(stderr, "[mb_cg] it %4d residual min %.3e max %.3e active %d\n", it + CG_CHUNK, lo, hi, active);
         }
     }
@@ -3011,7 +3011,7 @@ extern "C" int fg_mb_destroy(fg_mb_handle s) {
     return FG_OK;
 }
 
-extern "C" int fg_mb_add_block(fg_mb_handle s, const float* coords, int32_t nx, int32_t ny, int32_t nz, int32_t* block_id) {
+extern "C" int fg_mb_add_block(fg_mb_handle s, const mb_real* coords, int32_t nx, int32_t ny, int32_t nz, int32_t* block_id) {
     FG_REQUIRE(s && coords, FG_ERR_INVALID_ARG, "fg_mb_add_block: null argument");
     FG_REQUIRE(!s->finalized, FG_ERR_INVALID_ARG, "fg_mb_add_block: domain already finalized");
     if (s->d == 2) nz = 1;
@@ -3121,8 +3121,8 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     if (int rc = mb_alloc(s, &s->best_it, B * d)) return rc;
     if (int rc = mb_alloc(s, &s->yproj, N)) return rc;
     {
-        std::vector<float> ones(N, 1.f / std::sqrt((float)N));
-        FG_HIP_CHECK(hipMemcpy(s->yproj, ones.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+        std::vector<mb_real> ones(N, 1.f / std::sqrt((mb_real)N));
+        FG_HIP_CHECK(hipMemcpy(s->yproj, ones.data(), sizeof(mb_real) * N, hipMemcpyHostToDevice));
         s->dev.yproj = s->yproj;
     }
     if (int rc = mb_alloc(s, &s->red2, 2 * B)) return rc;
@@ -3151,9 +3151,9 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     s->env_status.assign(B, 0);
     FG_HIP_CHECK(hipHostMalloc((void**)&s->env_fail_pinned, sizeof(int32_t) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
-    FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(float) * B, hipHostMallocDefault));
-    FG_HIP_CHECK(hipHostMalloc((void**)&s->red2_pinned, sizeof(float) * 2 * B, hipHostMallocDefault));
-    FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(float) * B, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(mb_real) * B, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->red2_pinned, sizeof(mb_real) * 2 * B, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(mb_real) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->flags_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
     if (int rc = mb_alloc(s, &s->verified, (size_t)B * d)) return rc;
     s->finalized = true;
@@ -3176,7 +3176,7 @@ extern "C" int fg_mb_block_info(fg_mb_handle s, int32_t block, int32_t* cell_off
     return FG_OK;
 }
 
-extern "C" int fg_mb_bind(fg_mb_handle s, float* velocity, float* pressure_result, float* boundary_velocity, const float* source) {
+extern "C" int fg_mb_bind(fg_mb_handle s, mb_real* velocity, mb_real* pressure_result, mb_real* boundary_velocity, const mb_real* source) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_bind: domain not finalized");
     FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_bind: this handle was created host-only (device < 0): tables only, no compute");
     FG_REQUIRE(velocity && pressure_result && (boundary_velocity || s->NB == 0), FG_ERR_INVALID_ARG, "fg_mb_bind: null field");
@@ -3188,32 +3188,32 @@ extern "C" int fg_mb_bind(fg_mb_handle s, float* velocity, float* pressure_resul
 // (2 nu S - p I) n on every wall face, S from the one-sided normal derivative (cell - wall) / distance and a central tangential
 // derivative over the ring of wall-adjacent cells, times the face length (area), summed over the ring.  One workgroup per (layer,
 // env); the host code did this with ~40 tensor ops per sim step (290 us of host time against a 1.4 ms PISO step).
-__global__ __launch_bounds__(FG_BLOCK) void k_mb_wall_forces(int d, int N, int NB, int n, int layers, const float* __restrict__ u,
-                                                              const float* __restrict__ ub, const float* __restrict__ p,
+__global__ __launch_bounds__(FG_BLOCK) void k_mb_wall_forces(int d, int N, int NB, int n, int layers, const mb_real* __restrict__ u,
+                                                              const mb_real* __restrict__ ub, const mb_real* __restrict__ p,
                                                               const int32_t* __restrict__ cell_index, const int32_t* __restrict__ slot_index,
-                                                              const float* __restrict__ geom, float area_scale, float nu,
-                                                              float* __restrict__ out) {
-    __shared__ float lds[8];
+                                                              const mb_real* __restrict__ geom, mb_real area_scale, mb_real nu,
+                                                              mb_real* __restrict__ out) {
+    __shared__ mb_real lds[8];
     const int layer = blockIdx.x, b = blockIdx.y;
-    const float* ue = u + (size_t)b * d * N;
-    const float* ube = ub + (size_t)b * d * NB;
-    const float* pe = p + (size_t)b * N;
+    const mb_real* ue = u + (size_t)b * d * N;
+    const mb_real* ube = ub + (size_t)b * d * NB;
+    const mb_real* pe = p + (size_t)b * N;
     const int32_t* ci = cell_index + (size_t)layer * n;
     const int32_t* si = slot_index + (size_t)layer * n;
-    float f[2] = {0.f, 0.f};
+    mb_real f[2] = {0.f, 0.f};
     for (int j = threadIdx.x; j < n; j += FG_BLOCK) {
         const int c = ci[j], cl = ci[j + 1 == n ? 0 : j + 1], cr = ci[j == 0 ? n - 1 : j - 1], sl = si[j];   // roll(-1) = "left", roll(+1) = "right"
-        const float nx = geom[j], ny = geom[n + j], tl = geom[2 * n + j], wd = geom[3 * n + j], fl = geom[4 * n + j] * area_scale;
-        const float tx = ny, ty = -nx;
-        float dn[2], dt[2];
+        const mb_real nx = geom[j], ny = geom[n + j], tl = geom[2 * n + j], wd = geom[3 * n + j], fl = geom[4 * n + j] * area_scale;
+        const mb_real tx = ny, ty = -nx;
+        mb_real dn[2], dt[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             dn[q] = (ue[(size_t)q * N + c] - ube[(size_t)q * NB + sl]) / wd;
             dt[q] = (ue[(size_t)q * N + cr] - ue[(size_t)q * N + cl]) / (2.f * tl);
         }
-        const float du_dx = dn[0] * nx + dt[0] * tx, du_dy = dn[0] * ny + dt[0] * ty;
-        const float dv_dx = dn[1] * nx + dt[1] * tx, dv_dy = dn[1] * ny + dt[1] * ty;
-        const float sxy = 0.5f * (du_dy + dv_dx), two_nu = 2.f * nu, pc = pe[c];
+        const mb_real du_dx = dn[0] * nx + dt[0] * tx, du_dy = dn[0] * ny + dt[0] * ty;
+        const mb_real dv_dx = dn[1] * nx + dt[1] * tx, dv_dy = dn[1] * ny + dt[1] * ty;
+        const mb_real sxy = 0.5f * (du_dy + dv_dx), two_nu = 2.f * nu, pc = pe[c];
         f[0] += ((two_nu * du_dx - pc) * nx + two_nu * sxy * ny) * fl;
         f[1] += (two_nu * sxy * nx + (two_nu * dv_dy - pc) * ny) * fl;
     }
@@ -3224,24 +3224,24 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_wall_forces(int d, int N, int N
     }
 }
 
-extern "C" int fg_mb_wall_forces(fg_mb_handle s, const int32_t* cell_index, const int32_t* slot_index, const float* geom, int32_t n,
-                                 int32_t layers, float area_scale, float viscosity, float* out, void* stream) {
+extern "C" int fg_mb_wall_forces(fg_mb_handle s, const int32_t* cell_index, const int32_t* slot_index, const mb_real* geom, int32_t n,
+                                 int32_t layers, mb_real area_scale, mb_real viscosity, mb_real* out, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity && s->pressure && s->bvel, FG_ERR_NOT_BOUND, "fg_mb_wall_forces: fields not bound");
     FG_REQUIRE(cell_index && slot_index && geom && out && n > 0 && layers > 0, FG_ERR_INVALID_ARG, "fg_mb_wall_forces: bad argument");
     hipLaunchKernelGGL(k_mb_wall_forces, dim3(layers, s->B), dim3(FG_BLOCK), 0, (hipStream_t)stream, s->d, s->N, s->NB, n, layers,
-                       (const float*)s->velocity, (const float*)s->bvel, (const float*)s->pressure, cell_index, slot_index, geom, area_scale,
+                       (const mb_real*)s->velocity, (const mb_real*)s->bvel, (const mb_real*)s->pressure, cell_index, slot_index, geom, area_scale,
                        viscosity, out);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
 
-extern "C" int fg_mb_set_viscosity(fg_mb_handle s, float nu) {
+extern "C" int fg_mb_set_viscosity(fg_mb_handle s, mb_real nu) {
     FG_REQUIRE(s && nu > 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_viscosity: viscosity must be positive");
     s->nu = nu;
     return FG_OK;
 }
 
-extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream) {
+extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_step_options* opt, int32_t* stats_host, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity, FG_ERR_NOT_BOUND, "fg_mb_piso_step: fields not bound");
     FG_REQUIRE(dt_B && opt, FG_ERR_INVALID_ARG, "fg_mb_piso_step: null argument");
     FG_REQUIRE(s->nu > 0.f, FG_ERR_INVALID_ARG, "fg_mb_piso_step: viscosity not set");
@@ -3258,7 +3258,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
     };
     int its[4] = {0, 0, 0, 0};
     // working copy of dt: envs whose solve turns out non-finite are masked out of the rest of the step (k_mb_mask_failed)
-    FG_HIP_CHECK(hipMemcpyAsync(s->dt_step, dt_B, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
+    FG_HIP_CHECK(hipMemcpyAsync(s->dt_step, dt_B, sizeof(mb_real) * B, hipMemcpyDeviceToDevice, st));
     FG_HIP_CHECK(hipMemsetAsync(s->env_fail, 0, sizeof(int32_t) * B, st));
     dt_B = s->dt_step;
     auto mask_failed = [&](int nc) {
@@ -3266,7 +3266,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
     };
     // pressure of the envs at the start of the step: a dropped env gets it back at the end (its velocity is never committed; its
     // pressure is written by every corrector's mean removal, so a failure in corrector 1 would leave corrector 0's behind)
-    hipLaunchKernelGGL(k_mb_copy, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, (size_t)N, (const float*)nullptr, (const float*)s->pressure, s->pres_bak);
+    hipLaunchKernelGGL(k_mb_copy, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, (size_t)N, (const mb_real*)nullptr, (const mb_real*)s->pressure, s->pres_bak);
     const size_t vel_env = (size_t)d * N;
     const dim3 gcopy((unsigned)((vel_env + FG_BLOCK - 1) / FG_BLOCK), B);
     MB_DISPATCH(s, {
@@ -3300,7 +3300,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 } else {   // meshes the schedule does not cover, the fp64 build: right diagonal scaling, (C D^-1) y = b, x = D^-1 y
                     hipLaunchKernelGGL(k_mb_scale_cols<DIMS>, gn, blk, 0, st, D, dt_B, s->Cdiag, s->Coff, s->Sdiag, s->Soff);
                     vrc = mb_bicgstab(s, dt_B, s->Sdiag, s->Soff, s->rhs, s->ures, d, opt->advection_tol, opt->max_iterations, 0, &m, st);
-                    hipLaunchKernelGGL(k_mb_unscale, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B * d), blk, 0, st, N, d, dt_B, (const float*)s->Cdiag, s->ures);
+                    hipLaunchKernelGGL(k_mb_unscale, dim3((N + FG_BLOCK - 1) / FG_BLOCK, B * d), blk, 0, st, N, d, dt_B, (const mb_real*)s->Cdiag, s->ures);
                 }
             }
             if (vrc == FG_ERR_NOT_FINITE) {
@@ -3320,7 +3320,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
                 if (ps == 0) {
                     hipLaunchKernelGGL(k_mb_h<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->rA, s->Coff, s->velocity, s->ures,
                                        s->bvel, s->fb, s->source, s->hvec);
-                    hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, dt_B, s->hvec, s->bvel, s->cc, (float*)nullptr);
+                    hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, dt_B, s->hvec, s->bvel, s->cc, (mb_real*)nullptr);
                 }
                 hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, dt_B, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
                 int m = 0;
@@ -3370,7 +3370,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const float* dt_B, const fg_mb_st
     s->ctr.piso_steps += 1;
     for (int b = 0; b < B; ++b) s->env_status[b] = 0;
     if (soft_rc == FG_ERR_NOT_FINITE) {   // rare path: which envs were dropped; their pressure goes back to what it was
-        hipLaunchKernelGGL(k_mb_restore_failed, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, N, (const int32_t*)s->env_fail, (const float*)s->pres_bak, s->pressure);
+        hipLaunchKernelGGL(k_mb_restore_failed, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, N, (const int32_t*)s->env_fail, (const mb_real*)s->pres_bak, s->pressure);
         FG_HIP_CHECK(hipMemcpyAsync(s->env_fail_pinned, s->env_fail, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
         FG_HIP_CHECK(hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) s->env_status[b] = s->env_fail_pinned[b];
@@ -3396,7 +3396,7 @@ extern "C" int fg_mb_solver_counters(fg_mb_handle s, int64_t* out13, int32_t res
 // Tables of the multilevel preconditioner of the on-chip pressure CG (built on the host from the geometry-only pressure matrix,
 // simulation/multiblock.py::set_pressure_multilevel); a4 / parent4 as int32 on the host, stored as 16-bit on the device.
 extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, const int32_t* a4_host, const int32_t* parent4_host,
-                                    const int32_t* rect4_host, const float* d4g_host, const float* aci8_host, float geom_diag_sum,
+                                    const int32_t* rect4_host, const mb_real* d4g_host, const mb_real* aci8_host, mb_real geom_diag_sum,
                                     int32_t enable) {
     FG_REQUIRE(s && s->finalized && !s->host_only, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: domain not finalized (or host-only)");
     FG_REQUIRE(!FG_MB_F64, FG_ERR_UNSUPPORTED, "fg_mb_set_multilevel: the multilevel preconditioner is not part of the fp64 build (plain recurrences there)");
@@ -3464,15 +3464,15 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
         for (int i = 0; i < s->N; ++i) p8c[i] = p4[a4[i]];
         FG_HIP_CHECK(hipMemcpy(s->ml_p8c, p8c.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
     }
-    FG_HIP_CHECK(hipMemset(s->ml_r4c, 0, sizeof(float) * (size_t)s->B * 4 * s->ml_cap8));   // the slots of absent children are never written
-    std::vector<float> rd4(n4);
+    FG_HIP_CHECK(hipMemset(s->ml_r4c, 0, sizeof(mb_real) * (size_t)s->B * 4 * s->ml_cap8));   // the slots of absent children are never written
+    std::vector<mb_real> rd4(n4);
     for (int a = 0; a < n4; ++a) { FG_REQUIRE(d4g_host[a] != 0.f, FG_ERR_INVALID_ARG, "fg_mb_set_multilevel: zero Galerkin diagonal"); rd4[a] = 1.f / d4g_host[a]; }
     const int ld = (n8 + 3) & ~3;
-    std::vector<float> padded((size_t)n8 * ld, 0.f);
+    std::vector<mb_real> padded((size_t)n8 * ld, 0.f);
     for (int r = 0; r < n8; ++r)
         for (int c = 0; c < n8; ++c) padded[(size_t)r * ld + c] = aci8_host[(size_t)r * n8 + c];
-    FG_HIP_CHECK(hipMemcpy(s->ml_d4g, rd4.data(), sizeof(float) * n4, hipMemcpyHostToDevice));
-    FG_HIP_CHECK(hipMemcpy(s->ml_aci8, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_d4g, rd4.data(), sizeof(mb_real) * n4, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->ml_aci8, padded.data(), sizeof(mb_real) * padded.size(), hipMemcpyHostToDevice));
     s->ml_n4 = n4; s->ml_n8 = n8; s->ml_geom_diag_sum = geom_diag_sum; s->ml_on = enable != 0;
     // ---- aggregate-owned layout of the on-chip CG (fg_mb.h): thread 4 A + c owns child c of 8 x 8 aggregate A
     s->oc_agg = false;
@@ -3482,7 +3482,7 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
         constexpr int S = fg_mb_state::OC_SLOTS;
         std::vector<int32_t> slot_cell(S, -1), cnt(1024, 0);
         std::vector<uint16_t> cell_slot(s->N, 0xffff);
-        std::vector<float> d4t(1024, 0.f);
+        std::vector<mb_real> d4t(1024, 0.f);
         for (int A = 0; A < n8; ++A) {
             const unsigned words[2] = {child[A].x, child[A].y};
             for (int c = 0; c < 4; ++c) {
@@ -3525,13 +3525,13 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
                 if (int rc = mb_alloc(s, &s->oc_bestx, (size_t)s->B * S)) return rc;
             }
             // holes stay zero for good: k_mb_pmatrix and the solver write the slots of cells only
-            FG_HIP_CHECK(hipMemset(s->Poff4s, 0, sizeof(float) * (size_t)s->B * S * 4));
-            FG_HIP_CHECK(hipMemset(s->Pdiag_s, 0, sizeof(float) * (size_t)s->B * S));
-            FG_HIP_CHECK(hipMemset(s->oc_bestx, 0, sizeof(float) * (size_t)s->B * S));
+            FG_HIP_CHECK(hipMemset(s->Poff4s, 0, sizeof(mb_real) * (size_t)s->B * S * 4));
+            FG_HIP_CHECK(hipMemset(s->Pdiag_s, 0, sizeof(mb_real) * (size_t)s->B * S));
+            FG_HIP_CHECK(hipMemset(s->oc_bestx, 0, sizeof(mb_real) * (size_t)s->B * S));
             FG_HIP_CHECK(hipMemcpy(s->oc_slot_cell, slot_cell.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
             FG_HIP_CHECK(hipMemcpy(s->oc_cell_slot, cell_slot.data(), sizeof(uint16_t) * s->N, hipMemcpyHostToDevice));
             FG_HIP_CHECK(hipMemcpy(s->oc_nbr, nbr.data(), sizeof(uint2) * S, hipMemcpyHostToDevice));
-            FG_HIP_CHECK(hipMemcpy(s->oc_d4g, d4t.data(), sizeof(float) * 1024, hipMemcpyHostToDevice));
+            FG_HIP_CHECK(hipMemcpy(s->oc_d4g, d4t.data(), sizeof(mb_real) * 1024, hipMemcpyHostToDevice));
             FG_HIP_CHECK(hipMemcpy(s->oc_cnt, cnt.data(), sizeof(int32_t) * 1024, hipMemcpyHostToDevice));
             s->oc_agg = true;
             s->oc_matrix_stale = true;   // the slot-ordered copy of the matrix does not exist yet (fg_mb_step.hip: mb_cg_onchip)
@@ -3559,7 +3559,7 @@ extern "C" int fg_mb_multilevel_status(fg_mb_handle s, int32_t* out3) {
 
 // z = U^-1 L^-1 r with ILU(0) of the velocity matrix currently assembled (the last step's), d systems per env: unit entry of the
 // preconditioned rung's preconditioner (tests/test_gpu_mb.py), not on any step path.
-extern "C" int fg_mb_debug_ilu_apply(fg_mb_handle s, const float* r_BdN, float* z_BdN, void* stream) {
+extern "C" int fg_mb_debug_ilu_apply(fg_mb_handle s, const mb_real* r_BdN, mb_real* z_BdN, void* stream) {
     FG_REQUIRE(s && s->finalized && !s->host_only && r_BdN && z_BdN, FG_ERR_INVALID_ARG, "fg_mb_debug_ilu_apply: bad argument");
     FG_REQUIRE(!FG_MB_F64, FG_ERR_UNSUPPORTED, "fg_mb_debug_ilu_apply: not part of the fp64 build");
     FG_REQUIRE(mb_ilu_prepare(s), FG_ERR_UNSUPPORTED, "fg_mb_debug_ilu_apply: the mesh does not qualify (a cell with the same neighbour across two faces)");
@@ -3574,13 +3574,13 @@ extern "C" int fg_mb_debug_ilu_apply(fg_mb_handle s, const float* r_BdN, float* 
 
 // z = M r with the kernel form of the multilevel preconditioner, for every env, on the pressure matrix currently assembled
 // (fg_mb_unit_pressure_matrix or the last step): the unit test of mb_ml_apply (tests/test_gpu_mb.py), not on any step path.
-extern "C" int fg_mb_multilevel_apply(fg_mb_handle s, const float* r_BN, float* z_BN, void* stream) {
+extern "C" int fg_mb_multilevel_apply(fg_mb_handle s, const mb_real* r_BN, mb_real* z_BN, void* stream) {
     FG_REQUIRE(s && s->finalized && !s->host_only && r_BN && z_BN, FG_ERR_INVALID_ARG, "fg_mb_multilevel_apply: bad argument");
     FG_REQUIRE(s->ml_a4 != nullptr && s->ml_mp != nullptr, FG_ERR_UNSUPPORTED, "fg_mb_multilevel_apply: no tables installed (fg_mb_set_multilevel)");
     hipStream_t st = (hipStream_t)stream;
     MbSolve q = mb_solve_ptrs(s, s->Pdiag, s->Poff, nullptr, nullptr, 1, 0.f);
     FG_HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int32_t) * s->B, st));
-    hipLaunchKernelGGL(k_ml_scale, dim3(s->B), dim3(1024), 0, st, (const float*)s->Pdiag, s->N, s->ml_geom_diag_sum, s->ml_scale);
+    hipLaunchKernelGGL(k_ml_scale, dim3(s->B), dim3(1024), 0, st, (const mb_real*)s->Pdiag, s->N, s->ml_geom_diag_sum, s->ml_scale);
     mb_ml_apply(s, q, r_BN, z_BN, st);
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
@@ -3589,8 +3589,8 @@ extern "C" int fg_mb_multilevel_apply(fg_mb_handle s, const float* r_BN, float* 
 // Stress harness of the velocity BiCGStab (profiles/bicg_stress.py): solves the systems currently held in the assembly buffers
 // (diagonal, off-diagonals, right-hand side; FG_MB_BUF_A / _C_OFF / _RHS) `reps` times from zero, exactly as fg_mb_piso_step's first
 // attempt does, and counts the outcomes: [0] solves, [1] with a non-finite system, [2] unconverged, [3] max iterations seen.
-extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, float tol, int32_t max_iterations, int32_t reps, int64_t* out4, double* acc_out,
-                                    float* sc_out, void* stream) {
+extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, mb_real tol, int32_t max_iterations, int32_t reps, int64_t* out4, double* acc_out,
+                                    mb_real* sc_out, void* stream) {
     FG_REQUIRE(s && s->finalized && !s->host_only && out4 && reps > 0, FG_ERR_INVALID_ARG, "fg_mb_debug_bicgstab: bad argument");
     hipStream_t st = (hipStream_t)stream;
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
@@ -3610,7 +3610,7 @@ extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, float tol, int32_t max_itera
         FG_HIP_CHECK(hipMemcpy(raw.data(), s->acc, sizeof(FgDacc) * raw.size(), hipMemcpyDeviceToHost));
         for (size_t k = 0; k < raw.size(); ++k) acc_out[k] = fg_dacc_host_value(raw[k]);
     }
-    if (sc_out) FG_HIP_CHECK(hipMemcpy(sc_out, s->sc, sizeof(float) * 2 * s->B * s->d, hipMemcpyDeviceToHost));
+    if (sc_out) FG_HIP_CHECK(hipMemcpy(sc_out, s->sc, sizeof(mb_real) * 2 * s->B * s->d, hipMemcpyDeviceToHost));
     return FG_OK;
 }
 
@@ -3637,21 +3637,21 @@ extern "C" int fg_mb_env_status(fg_mb_handle s, int32_t* out_B_host) {
 
 
 
-extern "C" int fg_mb_max_velocity(fg_mb_handle s, float* out_B_host, void* stream) {
+extern "C" int fg_mb_max_velocity(fg_mb_handle s, mb_real* out_B_host, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_max_velocity: fields not bound");
     hipStream_t st = (hipStream_t)stream;
     const int cells = std::max(s->N, s->NB);
-    FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(float) * s->B, st));
+    FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(mb_real) * s->B, st));
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_maxvel<DIMS>, dim3((cells + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st,
                                       s->dev, s->velocity, s->bvel, s->red););
-    FG_HIP_CHECK(hipMemcpyAsync(s->red_pinned, s->red, sizeof(float) * s->B, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipMemcpyAsync(s->red_pinned, s->red, sizeof(mb_real) * s->B, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < s->B; ++b) out_B_host[b] = s->red_pinned[b];
     return FG_OK;
 }
 
-static int mb_outflow_pre(fg_mb_state* s, const float* dt_dev, int slot0, int count, int slot0b, int countb, const float* velm,
-                          float tol, hipStream_t st) {
+static int mb_outflow_pre(fg_mb_state* s, const mb_real* dt_dev, int slot0, int count, int slot0b, int countb, const mb_real* velm,
+                          mb_real tol, hipStream_t st) {
     const int r0[2] = {slot0, slot0b}, rn[2] = {count, countb};
     MB_DISPATCH(s, {
         for (int k = 0; k < 2; ++k)
@@ -3670,14 +3670,14 @@ static int mb_outflow_pre(fg_mb_state* s, const float* dt_dev, int slot0, int co
 
 // update_advective_boundaries + balance_boundary_fluxes for one FIXED face with the same dt for every env (the PRE hook as
 // make_divergence_free runs it, with time_step = 1: PISOtorch_simulation.py:1334-1345)
-extern "C" int fg_mb_update_advective_boundary(fg_mb_handle s, float dt, int32_t slot0, int32_t count, int32_t slot0_b, int32_t count_b,
-                                               const float* velm, float tol, void* stream) {
+extern "C" int fg_mb_update_advective_boundary(fg_mb_handle s, mb_real dt, int32_t slot0, int32_t count, int32_t slot0_b, int32_t count_b,
+                                               const mb_real* velm, mb_real tol, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity && velm, FG_ERR_NOT_BOUND, "fg_mb_update_advective_boundary: fields not bound");
     FG_REQUIRE(slot0 >= 0 && count > 0 && slot0 + count <= s->NB && count_b >= 0 && (count_b == 0 || (slot0_b >= 0 && slot0_b + count_b <= s->NB)),
                FG_ERR_INVALID_ARG, "fg_mb_update_advective_boundary: slots out of range");
     hipStream_t st = (hipStream_t)stream;
     for (int b = 0; b < s->B; ++b) s->dt_pinned[b] = dt;
-    FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * s->B, hipMemcpyHostToDevice, st));
+    FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(mb_real) * s->B, hipMemcpyHostToDevice, st));
     if (int rc = mb_outflow_pre(s, s->dt_dev, slot0, count, slot0_b, count_b, velm, tol, st)) return rc;
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
@@ -3685,17 +3685,17 @@ extern "C" int fg_mb_update_advective_boundary(fg_mb_handle s, float dt, int32_t
 
 static bool mb_close_zero(double v) { return std::fabs(v) <= 1e-8; }  // np.isclose(v, 0) defaults
 
-extern "C" int fg_mb_boundary_flux_balance(fg_mb_handle s, float* out_B_host, void* stream) {
+extern "C" int fg_mb_boundary_flux_balance(fg_mb_handle s, mb_real* out_B_host, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_boundary_flux_balance: fields not bound");
     hipStream_t st = (hipStream_t)stream;
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, 0, 0, 0, 0, s->red2););
-    FG_HIP_CHECK(hipMemcpyAsync(s->red2_pinned, s->red2, sizeof(float) * 2 * s->B, hipMemcpyDeviceToHost, st));
+    FG_HIP_CHECK(hipMemcpyAsync(s->red2_pinned, s->red2, sizeof(mb_real) * 2 * s->B, hipMemcpyDeviceToHost, st));
     FG_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < s->B; ++b) out_B_host[b] = s->red2_pinned[2 * b] + s->red2_pinned[2 * b + 1];
     return FG_OK;
 }
 
-extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int32_t* out, float* flux_host, void* stream) {
+extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int32_t* out, mb_real* flux_host, void* stream) {
     FG_REQUIRE(s && s->finalized && s->velocity, FG_ERR_NOT_BOUND, "fg_mb_single_step: fields not bound");
     FG_REQUIRE(o && out, FG_ERR_INVALID_ARG, "fg_mb_single_step: null argument");
     FG_REQUIRE((o->outflow_count == 0 || (o->outflow_slot0 >= 0 && o->outflow_slot0 + o->outflow_count <= s->NB)) &&
@@ -3706,12 +3706,12 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
     const int B = s->B;
     // flux-balance guard (simulation.py:221-229)
     {
-        std::vector<float> fl(B);
+        std::vector<mb_real> fl(B);
         if (int rc = fg_mb_boundary_flux_balance(s, fl.data(), stream)) return rc;
-        float worst = 0.f;
+        mb_real worst = 0.f;
         for (int b = 0; b < B; ++b) {
             if (flux_host) flux_host[b] = fl[b];
-            const float a = std::fabs(fl[b]);
+            const mb_real a = std::fabs(fl[b]);
             worst = (a > worst || a != a) ? a : worst;
         }
         if (!(worst <= o->flux_balance_tol)) {
@@ -3720,7 +3720,7 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
         }
     }
     std::vector<double> t_rem(B, (double)o->time_step);
-    std::vector<float> mv(B, 0.f);
+    std::vector<mb_real> mv(B, 0.f);
     std::vector<int32_t> status(B, 0);
     int32_t stats[4] = {-1, -1, -1, -1};
     int substeps = 0, all_ok = 1;
@@ -3734,22 +3734,22 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
             if (int rc = fg_mb_max_velocity(s, mv.data(), stream)) return rc;
         // _PISO_adaptive_step (PISOtorch_simulation.py:2004-2064): ts = t_rem / ceil(t_rem / (CFL / max_vel)), per env
         for (int b = 0; b < B; ++b) {
-            float ts = 0.f;
+            mb_real ts = 0.f;
             if (status[b] == 2) {
                 ts = 0.f;   // dropped out of this step (non-finite solve or state)
             } else if (!o->adaptive) {
-                ts = o->time_step / (float)(o->substeps > 0 ? o->substeps : 1);
+                ts = o->time_step / (mb_real)(o->substeps > 0 ? o->substeps : 1);
             } else if (t_rem[b] > 0 && !mb_close_zero(t_rem[b]) && !std::isfinite(mv[b])) {
                 status[b] = 2; t_rem[b] = 0.0;   // a state that is already non-finite: nothing to step
             } else if (t_rem[b] > 0 && !mb_close_zero(t_rem[b])) {
                 const double max_ts = mb_close_zero(mv[b]) ? t_rem[b] : (double)o->cfl / (double)mv[b];
                 const double tsd = (max_ts >= t_rem[b]) ? t_rem[b] : t_rem[b] / (double)(long long)std::ceil(t_rem[b] / max_ts);
                 t_rem[b] -= tsd;
-                ts = (float)tsd;
+                ts = (mb_real)tsd;
             }
             s->dt_pinned[b] = ts;
         }
-        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(float) * B, hipMemcpyHostToDevice, st));
+        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(mb_real) * B, hipMemcpyHostToDevice, st));
         if (o->outflow_count > 0)  // PRE hook of the cylinder / airfoil envs (cylinder_env_base.py:280-300)
             if (int rc = mb_outflow_pre(s, s->dt_dev, o->outflow_slot0, o->outflow_count, o->outflow_slot0_b, o->outflow_count_b,
                                         o->outflow_velm, o->outflow_tol, st))
@@ -3788,12 +3788,12 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
     const MbDev& D = s->dev;
     int soft_rc = FG_OK;
     hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), blk, 0, st, BN, 1.f, s->rA);
-    hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, (const float*)nullptr, s->velocity, s->hvec);
+    hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, (const mb_real*)nullptr, s->velocity, s->hvec);
     MB_DISPATCH(s, {
-        hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, (const float*)nullptr, s->hvec, s->bvel, s->cc, s->fb);
-        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;
+        hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, (const mb_real*)nullptr, s->hvec, s->bvel, s->cc, s->fb);
+        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const mb_real*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;
         for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
-            hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
+            hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, (const mb_real*)nullptr, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
             int m = 0;
             const int prc = opt->pressure_use_bicgstab
                                 ? mb_pressure_bicgstab(s, nullptr, opt->pressure_tol, opt->max_iterations, ps > 0, &m, st, opt->pressure_project_mean,
@@ -3802,17 +3802,17 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
                                         opt->pressure_project_mean, opt->pressure_stall_accept, &m, st);
             if (prc == FG_ERR_NOT_CONVERGED || prc == FG_ERR_NOT_FINITE) soft_rc = prc;
             else if (prc != FG_OK) return prc;
-            hipLaunchKernelGGL(k_mb_sum, dim3(MB_SUM_WGS, B), blk, 0, st, N, (const float*)nullptr, s->pres, s->red8);
-            hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, (const float*)nullptr, s->red8, s->pres, s->pressure);
+            hipLaunchKernelGGL(k_mb_sum, dim3(MB_SUM_WGS, B), blk, 0, st, N, (const mb_real*)nullptr, s->pres, s->red8);
+            hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, (const mb_real*)nullptr, s->red8, s->pres, s->pressure);
         }
-        hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, (const float*)nullptr, s->rA, s->hvec, s->pressure, s->velocity);
+        hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, (const mb_real*)nullptr, s->rA, s->hvec, s->pressure, s->velocity);
     });
     FG_HIP_CHECK(hipGetLastError());
     return soft_rc;
 }
 
 // host copies of the boundary-slot tables: owner cell, face, Minv | det
-extern "C" int fg_mb_get_boundary_tables(fg_mb_handle s, int32_t* cell, int32_t* face, float* transform) {
+extern "C" int fg_mb_get_boundary_tables(fg_mb_handle s, int32_t* cell, int32_t* face, mb_real* transform) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_get_boundary_tables: domain not finalized");
     const int tw = s->d * s->d + 1;
     for (int k = 0; k < s->NB; ++k) {
@@ -3822,7 +3822,7 @@ extern "C" int fg_mb_get_boundary_tables(fg_mb_handle s, int32_t* cell, int32_t*
     }
     return FG_OK;
 }
-extern "C" int fg_mb_get_cell_transforms(fg_mb_handle s, float* transform /* [N][d*d+1] Minv | det */) {
+extern "C" int fg_mb_get_cell_transforms(fg_mb_handle s, mb_real* transform /* [N][d*d+1] Minv | det */) {
     FG_REQUIRE(s && s->finalized && transform, FG_ERR_INVALID_ARG, "fg_mb_get_cell_transforms: bad argument");
     std::copy(s->h_T.begin(), s->h_T.end(), transform);
     return FG_OK;
@@ -3830,16 +3830,16 @@ extern "C" int fg_mb_get_cell_transforms(fg_mb_handle s, float* transform /* [N]
 
 // Vector the CG residuals are kept orthogonal to (pressure_project_mean): default the constant; the left near-null vector of
 // the pressure matrix removes the residual floor the constant leaves on non-orthogonal meshes.  Host array [N].
-extern "C" int fg_mb_set_residual_projection(fg_mb_handle s, const float* y_host) {
+extern "C" int fg_mb_set_residual_projection(fg_mb_handle s, const mb_real* y_host) {
     FG_REQUIRE(s && s->finalized, FG_ERR_INVALID_ARG, "fg_mb_set_residual_projection: domain not finalized");
     FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_set_residual_projection: host-only handle");
-    std::vector<float> y(s->N);
+    std::vector<mb_real> y(s->N);
     double nrm = 0.0;
     for (int i = 0; i < s->N; ++i) { y[i] = y_host ? y_host[i] : 1.f; nrm += (double)y[i] * y[i]; }
     FG_REQUIRE(nrm > 0.0 && std::isfinite(nrm), FG_ERR_INVALID_ARG, "fg_mb_set_residual_projection: zero or non-finite vector");
-    const float sc = (float)(1.0 / std::sqrt(nrm));
+    const mb_real sc = (mb_real)(1.0 / std::sqrt(nrm));
     for (int i = 0; i < s->N; ++i) y[i] *= sc;
-    FG_HIP_CHECK(hipMemcpy(s->yproj, y.data(), sizeof(float) * s->N, hipMemcpyHostToDevice));
+    FG_HIP_CHECK(hipMemcpy(s->yproj, y.data(), sizeof(mb_real) * s->N, hipMemcpyHostToDevice));
     s->yproj_const = (y_host == nullptr);
     return FG_OK;
 }
@@ -3866,7 +3866,7 @@ extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
     const size_t BN = (size_t)s->B * s->N;
     hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), dim3(FG_BLOCK), 0, st, BN, 1.f, s->rA);
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, dim3((s->N + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st, s->dev,
-                                      (const float*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;);
+                                      (const mb_real*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;);
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }
@@ -3901,7 +3901,7 @@ extern "C" int fg_mb_profile_read(fg_mb_handle s, int32_t kind, double* ms_sum, 
 }
 
 // intermediate buffers for the parity tests
-extern "C" int fg_mb_get_buffer(fg_mb_handle s, int32_t which, const float** ptr, int64_t* count) {
+extern "C" int fg_mb_get_buffer(fg_mb_handle s, int32_t which, const mb_real** ptr, int64_t* count) {
     FG_REQUIRE(s && s->finalized && ptr && count, FG_ERR_INVALID_ARG, "fg_mb_get_buffer: bad argument");
     FG_REQUIRE(!s->host_only, FG_ERR_UNSUPPORTED, "fg_mb_get_buffer: host-only handle");
     const int64_t B = s->B, N = s->N, d = s->d, F = s->F;
@@ -3921,12 +3921,12 @@ extern "C" int fg_mb_get_buffer(fg_mb_handle s, int32_t which, const float** ptr
     return FG_OK;
 }
 
-extern "C" int fg_mb_read_buffer(fg_mb_handle s, int32_t which, float* dst_device, void* stream) {
-    const float* p = nullptr;
+extern "C" int fg_mb_read_buffer(fg_mb_handle s, int32_t which, mb_real* dst_device, void* stream) {
+    const mb_real* p = nullptr;
     int64_t n = 0;
     if (int rc = fg_mb_get_buffer(s, which, &p, &n)) return rc;
     FG_REQUIRE(dst_device != nullptr, FG_ERR_INVALID_ARG, "fg_mb_read_buffer: null destination");
-    FG_HIP_CHECK(hipMemcpyAsync(dst_device, p, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    FG_HIP_CHECK(hipMemcpyAsync(dst_device, p, sizeof(mb_real) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     FG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return FG_OK;
 }

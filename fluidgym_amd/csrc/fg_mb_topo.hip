@@ -327,7 +327,7 @@ int fg_mb_build_tables(fg_mb_state* s) {
     s->h_bcell.assign(NB ? NB : 1, 0);
     s->h_bface.assign(NB ? NB : 1, 0);
     std::vector<double> Tb_d((size_t)(NB ? NB : 1) * tw, 0.0);
-    std::vector<float>&Vdiag = s->h_Vdiag, &Voff = s->h_Voff, &KPp = s->h_KPp, &KPn = s->h_KPn;
+    std::vector<mb_real>&Vdiag = s->h_Vdiag, &Voff = s->h_Voff, &KPp = s->h_KPp, &KPn = s->h_KPn;
     Vdiag.assign(N, 0.f); Voff.assign((size_t)F * N, 0.f);
     KPp.assign((size_t)(F + 1) * F * N, 0.f); KPn.assign((size_t)(F + 1) * F * N, 0.f);
     struct CellTerm { int idx; double w; };
@@ -347,8 +347,8 @@ int fg_mb_build_tables(fg_mb_state* s) {
     for_cells([&](int b, const Pos& p) {
         const int g = tp.gidx(b, p);
         const double* mi = tp.Minv(b, p);
-        for (int q = 0; q < d * d; ++q) s->h_T[(size_t)g * tw + q] = (float)mi[q];
-        s->h_T[(size_t)g * tw + d * d] = (float)tp.det(b, p);
+        for (int q = 0; q < d * d; ++q) s->h_T[(size_t)g * tw + q] = (mb_real)mi[q];
+        s->h_T[(size_t)g * tw + d * d] = (mb_real)tp.det(b, p);
         for (int f = 0; f < F; ++f) {
             const int axis = f >> 1;
             if (tp.at_bound(b, p, f) && tp.is_empty(b, f)) {
@@ -372,7 +372,7 @@ int fg_mb_build_tables(fg_mb_state* s) {
             s->h_fcode[(size_t)f * N + g] = code;
         }
     });
-    for (size_t q = 0; q < Tb_d.size(); ++q) s->h_Tb[q] = (float)Tb_d[q];
+    for (size_t q = 0; q < Tb_d.size(); ++q) s->h_Tb[q] = (mb_real)Tb_d[q];
     auto alpha_b = [&](int k, int c1, int c2) {
         const double* m = &Tb_d[(size_t)k * tw];
         double v = 0;
@@ -383,8 +383,8 @@ int fg_mb_build_tables(fg_mb_state* s) {
     for_cells([&](int b, const Pos& p) {
         const int g = tp.gidx(b, p);
         double vdiag = 0, voff[6] = {0};
-        auto kp = [&](int slotg, int f) -> float* { return &KPp[((size_t)slotg * F + f) * N + g]; };
-        auto kn = [&](int slotg, int f) -> float* { return &KPn[((size_t)slotg * F + f) * N + g]; };
+        auto kp = [&](int slotg, int f) -> mb_real* { return &KPp[((size_t)slotg * F + f) * N + g]; };
+        auto kn = [&](int slotg, int f) -> mb_real* { return &KPn[((size_t)slotg * F + f) * N + g]; };
         for (int f = 0; f < F; ++f) {
             const int dim = f >> 1;
             const double fs = (f & 1) ? 1.0 : -1.0;
@@ -415,8 +415,8 @@ int fg_mb_build_tables(fg_mb_state* s) {
             // orthogonal diffusion (K.cu:3717-3747) and pressure Laplacian (K.cu:4849-4885)
             vdiag += 0.5 * (aP + aN);
             voff[f] -= 0.5 * (aP + aN);
-            *kp(0, f) -= (float)(0.5 * aP); *kn(0, f) -= (float)(0.5 * aN);
-            *kp(1 + f, f) += (float)(0.5 * aP); *kn(1 + f, f) += (float)(0.5 * aN);
+            *kp(0, f) -= (mb_real)(0.5 * aP); *kn(0, f) -= (mb_real)(0.5 * aN);
+            *kp(1 + f, f) += (mb_real)(0.5 * aP); *kn(1 + f, f) += (mb_real)(0.5 * aN);
             for (int i = 1; i < d; ++i) {
                 const int t = (dim + i) % d;
                 // ---- matrices: centre + direct neighbours (K.cu:3749-3805, 4887-4936)
@@ -432,17 +432,17 @@ int fg_mb_build_tables(fg_mb_state* s) {
                         if (c.num < 1) {
                             // velocity: Dirichlet value on the right-hand side, nothing here; pressure: one-sided
                             const double q = fs * tfs * 0.25;
-                            *kp(0, f) += (float)(3 * q * 0.5 * xP); *kn(0, f) += (float)(3 * q * 0.5 * xN);
-                            *kp(1 + f, f) += (float)(3 * q * 0.5 * xP); *kn(1 + f, f) += (float)(3 * q * 0.5 * xN);
-                            if (has_to) { *kp(1 + (tf ^ 1), f) -= (float)(q * 0.5 * xP); *kn(1 + (tf ^ 1), f) -= (float)(q * 0.5 * xN); }
+                            *kp(0, f) += (mb_real)(3 * q * 0.5 * xP); *kn(0, f) += (mb_real)(3 * q * 0.5 * xN);
+                            *kp(1 + f, f) += (mb_real)(3 * q * 0.5 * xP); *kn(1 + f, f) += (mb_real)(3 * q * 0.5 * xN);
+                            if (has_to) { *kp(1 + (tf ^ 1), f) -= (mb_real)(q * 0.5 * xP); *kn(1 + (tf ^ 1), f) -= (mb_real)(q * 0.5 * xN); }
                         } else {
                             const double q = fs * tfs / (double)c.num;
                             vdiag -= q * a;
                             voff[f] -= q * a;
                             if (has_t) voff[tf] -= q * a;
-                            *kp(0, f) += (float)(q * 0.5 * xP); *kn(0, f) += (float)(q * 0.5 * xN);
-                            *kp(1 + f, f) += (float)(q * 0.5 * xP); *kn(1 + f, f) += (float)(q * 0.5 * xN);
-                            if (has_t) { *kp(1 + tf, f) += (float)(q * 0.5 * xP); *kn(1 + tf, f) += (float)(q * 0.5 * xN); }
+                            *kp(0, f) += (mb_real)(q * 0.5 * xP); *kn(0, f) += (mb_real)(q * 0.5 * xN);
+                            *kp(1 + f, f) += (mb_real)(q * 0.5 * xP); *kn(1 + f, f) += (mb_real)(q * 0.5 * xN);
+                            if (has_t) { *kp(1 + tf, f) += (mb_real)(q * 0.5 * xP); *kn(1 + tf, f) += (mb_real)(q * 0.5 * xN); }
                         }
                     }
                 }
@@ -477,8 +477,8 @@ int fg_mb_build_tables(fg_mb_state* s) {
                 }
             }
         }
-        Vdiag[g] = (float)vdiag;
-        for (int f = 0; f < F; ++f) Voff[(size_t)f * N + g] = (s->h_nbr[(size_t)f * N + g] >= 0) ? (float)voff[f] : 0.f;
+        Vdiag[g] = (mb_real)vdiag;
+        for (int f = 0; f < F; ++f) Voff[(size_t)f * N + g] = (s->h_nbr[(size_t)f * N + g] >= 0) ? (mb_real)voff[f] : 0.f;
     });
     // ---- merge duplicate targets, drop zeros, pad to ELL
     auto merge = [](std::vector<CellTerm>& v) {
@@ -498,15 +498,15 @@ int fg_mb_build_tables(fg_mb_state* s) {
         KPN = std::max(KPN, (int)spn[g].size());
     }
     std::vector<int32_t>&c_idx = s->h_SVc_idx, &b_idx = s->h_SVb_idx, &p_idx = s->h_SP_idx, &p_face = s->h_SP_face;
-    std::vector<float>&c_w = s->h_SVc_w, &b_w = s->h_SVb_w, &p_wp = s->h_SP_wp, &p_wn = s->h_SP_wn;
+    std::vector<mb_real>&c_w = s->h_SVc_w, &b_w = s->h_SVb_w, &p_wp = s->h_SP_wp, &p_wn = s->h_SP_wn;
     c_idx.assign((size_t)KC * N, 0); b_idx.assign((size_t)KB * N, 0); p_idx.assign((size_t)KPN * N, 0); p_face.assign((size_t)KPN * N, 0);
     c_w.assign((size_t)KC * N, 0.f); b_w.assign((size_t)KB * N, 0.f); p_wp.assign((size_t)KPN * N, 0.f); p_wn.assign((size_t)KPN * N, 0.f);
     for (int g = 0; g < N; ++g) {
-        for (size_t k = 0; k < svc[g].size(); ++k) { c_idx[k * N + g] = svc[g][k].idx; c_w[k * N + g] = (float)svc[g][k].w; }
-        for (size_t k = 0; k < svb[g].size(); ++k) { b_idx[k * N + g] = svb[g][k].idx; b_w[k * N + g] = (float)svb[g][k].w; }
+        for (size_t k = 0; k < svc[g].size(); ++k) { c_idx[k * N + g] = svc[g][k].idx; c_w[k * N + g] = (mb_real)svc[g][k].w; }
+        for (size_t k = 0; k < svb[g].size(); ++k) { b_idx[k * N + g] = svb[g][k].idx; b_w[k * N + g] = (mb_real)svb[g][k].w; }
         for (size_t k = 0; k < spn[g].size(); ++k) {
             p_idx[k * N + g] = spn[g][k].idx; p_face[k * N + g] = spn[g][k].face;
-            p_wp[k * N + g] = (float)spn[g][k].wp; p_wn[k * N + g] = (float)spn[g][k].wn;
+            p_wp[k * N + g] = (mb_real)spn[g][k].wp; p_wn[k * N + g] = (mb_real)spn[g][k].wn;
         }
     }
     MbDev& D = s->dev;
