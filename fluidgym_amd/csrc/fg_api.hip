@@ -110,6 +110,8 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     s->pred_bicg = 2; s->pred_cg = 1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr; s->ilu_d = nullptr;
+    s->double_fallback = 0; s->ladder_force = 0; s->r64_buf = nullptr; s->r64_acc = nullptr;
+    for (int k = 0; k < 4; ++k) s->rung_count[k] = 0;
     s->fd_lam = nullptr; s->helm_diag = s->helm_lower = s->helm_upper = s->helm_tmp = nullptr;
     { const char* ev = getenv("FG_CG_WGS_PER_SLOT"); s->cg_wgs_per_slot = (ev && atoi(ev) > 0) ? atoi(ev) : 256; }
     // FG_BICG3: z-marching two-kernel BiCGStab in 3-D (fg_bicgstab3d.hip): 0 never | > 0 always, with that z-chunk length (tests on
@@ -146,6 +148,7 @@ extern "C" int fg_destroy(fg_handle s) {
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
+    (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc);
     (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
@@ -231,6 +234,17 @@ extern "C" int fg_set_advection_preconditioner(fg_handle s, int mode) {
     else if (mode != 0)
         if (int rc = fg_line_alloc(s)) return rc;
     s->adv_precond = mode;
+    return FG_OK;
+}
+extern "C" int fg_set_double_fallback(fg_handle s, int on) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    s->double_fallback = on ? 1 : 0;     // (the fp64 build accepts it: nothing to fall back to there, as in the reference for fp64 fields)
+    return FG_OK;
+}
+extern "C" int fg_ladder(fg_handle s, int64_t* out4, int32_t force_mask) {
+    FG_REQUIRE(s && out4, FG_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < 4; ++k) out4[k] = s->rung_count[k];
+    if (force_mask >= 0) s->ladder_force = force_mask;
     return FG_OK;
 }
 extern "C" int fg_debug_apply_preconditioner(fg_handle s, int mode, int nc, const fg_real* r, fg_real* z, void* stream) {
@@ -402,6 +416,17 @@ static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real to
         a.precond = (method == FG_SOLVER_FDCG);
         a.check_every = a.precond ? 2 : 16;
         rc = fg_cg_solve(s, a, info_host, st);
+#if !FG_F64
+        // pressure solves run with returnBestResult: only a NON-FINITE solve counts as failed and is repeated in fp64
+        // (solver_double_fallback, PISOtorch_diff.py:410-445)
+        if (s->double_fallback && (rc == FG_ERR_NOT_FINITE || (s->ladder_force & 2))) {
+            std::vector<fg_solve_info> tmp;
+            fg_solve_info* info = info_host;
+            if (!info) { tmp.assign(s->info_pinned, s->info_pinned + s->grid.B); info = tmp.data(); }
+            s->rung_count[2] += 1;
+            rc = fg_rung64_cg(s, a, info, (s->ladder_force & 2) != 0, st);
+        }
+#endif
     } else {
         fg_set_error("fg_solve_pressure: only FG_SOLVER_CG drives the PISO step (Jacobi/RBGS are smoothers)");
         return FG_ERR_UNSUPPORTED;
@@ -458,12 +483,27 @@ static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipSt
         a.wall_lo = for_scalar ? (s->cfg.scalar_bc[2][channel] == FG_DIRICHLET) : 1;
         a.wall_hi = for_scalar ? (s->cfg.scalar_bc[3][channel] == FG_DIRICHLET) : 1;
     }
+    // The reference's ladder (_linear_solve_wrapper, PISOtorch_diff.py:410-476), in its order: the plain solve; if it failed (these
+    // solves run without returnBestResult: "not converged" fails them) and solver_double_fallback is on, the same system in fp64
+    // from a cleared result (fg_rung64.h); if that failed too and BiCG_precondition_fallback is on, the preconditioned solve from zero.
     int rc = fg_bicgstab_solve(s, a, info, st);
-    if ((rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) && (s->adv_precond == 2 || s->adv_precond == 5)) {
+    const int nsys = s->grid.B * a.nc;
+    bool failed = (rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) || (s->ladder_force & 1);
+#if !FG_F64
+    if (failed && s->double_fallback && rc != FG_ERR_HIP) {
+        s->rung_count[0] += 1;
+        rc = fg_rung64_bicgstab(s, a, info, (s->ladder_force & 1) != 0, st);
+        if (rc != FG_OK && rc != FG_ERR_NOT_CONVERGED && rc != FG_ERR_NOT_FINITE) return rc;
+        failed = (rc != FG_OK) || (s->ladder_force & 4);
+    }
+#endif
+    if (failed && (s->adv_precond == 2 || s->adv_precond == 5)) {
         s->line_retries += 1;
+        s->rung_count[1] += 1;
         a.precond = s->adv_precond == 5 ? 3 : 1; a.use_x0 = 0;
         rc = fg_bicgstab_solve(s, a, info, st);
     }
+    (void)nsys;
     return rc;
 }
 

@@ -9,9 +9,12 @@
 // accumulators per system (fp64): 0,1 rho ring | 2 rw.v | 3 s.s | 4 t.s | 5 t.t | 6 r.r
 // derived scalars per system (fp32, `sc`): 0 alpha | 1 omega
 #include <math.h>
+#include <cmath>
+#include <vector>
 
 #include "fg_internal.h"
 #include "fg_bicg.h"
+#include "fg_rung64.h"
 
 namespace {
 
@@ -858,3 +861,102 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     FG_HIP_CHECK(hipGetLastError());
     return rc;
 }
+
+#if !FG_F64
+// ---------------------------------------------------------------------------------------------------------------------------
+// fp64 repeat of a failed advection-diffusion solve (fg_rung64.h; the reference's solver_double_fallback, PISOtorch_diff.py:418-445)
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+// y = C x for ONE system in double: the fp32 matrix entries promoted (csrMat.toType(dp)); grid of one env
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k64_adv_apply(FgGrid g, const float* __restrict__ diag, const float* __restrict__ off,
+                                                          const double* __restrict__ x, double* __restrict__ y, int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, 1> c = fg_make_ctx<DIMS, 1>(g, tiles_x, tiles_y, tiles);
+    if (!c.valid) return;
+    const FgStencilRow<DIMS, 1> m = fg_load_row<DIMS, 1>(diag, off, c, (size_t)g.n);
+    const R64Nbr<DIMS> X = r64_gather<DIMS>(x, c);
+    double v = (double)m.d.v[0] * X.c + (double)m.o[0].v[0] * X.xm + (double)m.o[1].v[0] * X.xp + (double)m.o[2].v[0] * X.ym +
+               (double)m.o[3].v[0] * X.yp;
+    if constexpr (DIMS == 3) v += (double)m.o[4].v[0] * X.zm + (double)m.o[5].v[0] * X.zp;
+    y[c.idx] = v;
+}
+}  // namespace
+
+int fg_rung64_bicgstab(fg_state* s, const FgBicgArgs& a, fg_solve_info* info, bool all_systems, hipStream_t st) {
+    R64 w;
+    if (int rc = w.init(s, st)) return rc;
+    const int B = s->grid.B, n = s->grid.n, d = s->grid.dims;
+    FgGrid g1 = s->grid; g1.B = 1;
+    double *r = w.v[0], *rw = w.v[1], *p = w.v[2], *v = w.v[3], *sv = w.v[4], *t = w.v[5], *x = w.v[6];
+    auto apply = [&](int b, const double* in, double* out) {
+        const float* diag = a.diag + (size_t)b * n;
+        const float* off = a.off + (size_t)b * 2 * d * n;
+        if (d == 2) { FgLaunch L = fg_launch_geometry<2, 1>(g1); hipLaunchKernelGGL((k64_adv_apply<2>), L.grid, dim3(FG_BLOCK), 0, st, g1, diag, off, in, out, L.tiles_x, L.tiles_y, L.tiles); }
+        else { FgLaunch L = fg_launch_geometry<3, 1>(g1); hipLaunchKernelGGL((k64_adv_apply<3>), L.grid, dim3(FG_BLOCK), 0, st, g1, diag, off, in, out, L.tiles_x, L.tiles_y, L.tiles); }
+    };
+    auto rms = [&](double q) { return sqrt(q / (double)n); };
+    std::vector<float> dt_host;
+    if (a.dt) { dt_host.resize(B); FG_HIP_CHECK(hipMemcpyAsync(dt_host.data(), a.dt, sizeof(float) * B, hipMemcpyDeviceToHost, st)); FG_HIP_CHECK(hipStreamSynchronize(st)); }
+    int rc_all = FG_OK;
+    for (int b = 0; b < B; ++b) {
+        if (a.dt && !(dt_host[b] > 0.f)) continue;      // masked env
+        bool failed = all_systems;
+        for (int comp = 0; comp < a.nc; ++comp) failed = failed || !info[b * a.nc + comp].converged;
+        if (!failed) continue;
+        for (int comp = 0; comp < a.nc; ++comp) {       // the reference repeats the whole SolveLinear call: every right-hand side of the env
+            const int sys = b * a.nc + comp;
+            const size_t vb = (size_t)sys * n;
+            fg_solve_info& I = info[sys];
+            w.load(r, a.rhs + vb);                      // x_0 = 0 ("do not start with a possibly corrupted result tensor"): r_0 = rhs
+            w.zero(x);
+            w.axpby(rw, 1.0, r, 0.0, r);
+            w.axpby(p, 1.0, r, 0.0, r);
+            double rho = w.dot(r, r), rr = rho, alpha = 1.0, omega = 1.0;
+            I.used_iterations = -1; I.converged = 0; I.is_finite = 1; I.final_residual = (float)rms(rr);
+            for (int it = 0; it < a.max_iterations; ++it) {
+                if (!(rms(rr) >= (double)a.tol)) { I.converged = std::isfinite(rr) ? 1 : 0; I.is_finite = std::isfinite(rr) ? 1 : 0; break; }
+                apply(b, p, v);
+                const double rv = w.dot(rw, v);
+                alpha = rho / rv;
+                if (!std::isfinite(alpha)) alpha = 0.0;
+                w.axpby(sv, 1.0, r, -alpha, v);
+                const double ss = w.dot(sv, sv);
+                if (!(rms(ss) >= (double)a.tol)) {      // converged on s (bicgstab_solver_kernel.cu:305-329)
+                    w.axpby(x, 1.0, x, alpha, p);
+                    I.used_iterations = it; I.final_residual = (float)rms(ss);
+                    I.converged = std::isfinite(ss) ? 1 : 0; I.is_finite = std::isfinite(ss) ? 1 : 0;
+                    rr = ss;
+                    break;
+                }
+                apply(b, sv, t);
+                const double ts = w.dot(t, sv), tt = w.dot(t, t);
+                omega = ts / tt;
+                if (!std::isfinite(omega)) omega = 0.0;
+                w.axpby(x, 1.0, x, alpha, p);
+                w.axpby(x, 1.0, x, omega, sv);
+                w.axpby(r, 1.0, sv, -omega, t);
+                rr = w.dot(r, r);
+                const double rho_new = w.dot(rw, r);
+                double beta = (rho_new / rho) * (alpha / omega);
+                I.used_iterations = it + 1; I.final_residual = (float)rms(rr);
+                if (!std::isfinite(beta)) {             // breakdown: restart the recurrence (rw = p = r, rho = r.r)
+                    w.axpby(rw, 1.0, r, 0.0, r); w.axpby(p, 1.0, r, 0.0, r); rho = rr;
+                } else {
+                    w.axpby(p, 1.0, p, -omega, v);
+                    w.axpby(p, beta, p, 1.0, r);
+                    rho = rho_new;
+                }
+                if (it + 1 == a.max_iterations && !(rms(rr) >= (double)a.tol)) { I.converged = 1; }
+                if (!std::isfinite(rr)) { I.is_finite = 0; break; }
+            }
+            if (w.err) return w.err;
+            w.store(a.x + vb, x);
+            if (!I.is_finite) rc_all = FG_ERR_NOT_FINITE;
+            else if (!I.converged && rc_all == FG_OK) rc_all = FG_ERR_NOT_CONVERGED;
+        }
+    }
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    FG_HIP_CHECK(hipGetLastError());
+    return rc_all;
+}
+#endif

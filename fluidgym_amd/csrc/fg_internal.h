@@ -541,6 +541,11 @@ struct fg_state {
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
     fg_real* line_inv; fg_real* line_cp;
     fg_real* ilu_d;               // [B,N] modified diagonal of the ILU(0) preconditioner (fg_ilu0.hip), built per solve
+    // the reference's retry ladder on this path (fg_set_double_fallback, fg_ladder; fg_rung64.h): double_fallback = repeat a failed
+    // solve in fp64 before the preconditioned rung; rung_count: velocity / scalar fp64, preconditioned, pressure fp64 repeats;
+    // ladder_force (tests): first attempts count as failed (1 advection, 2 pressure, 4 also the advection fp64 rung)
+    int double_fallback; int ladder_force; long long rung_count[4];
+    double* r64_buf; FgDacc* r64_acc;
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;   // (fp32 kernels only)
     // separable Helmholtz preconditioner of the advection-diffusion solves (fg_set_fd_helmholtz): eigenvalue sums lam [nz][nx] of the
@@ -658,6 +663,10 @@ struct FgBicgArgs {
     fg_real nu = 0; int wall_lo = 1, wall_hi = 1;   // precond == 2: diffusivity of this solve; the variable is prescribed at the -y / +y wall
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
+// fp64 repeats of failed solves (fg_rung64.h; fp32 library only): every system of an env that has a failed one (BiCGStab: not
+// converged; CG: non-finite), info_host updated in place; returns the status of the repeated solves
+int fg_rung64_bicgstab(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, bool all_systems, hipStream_t st);
+int fg_rung64_cg(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, bool all_envs, hipStream_t st);
 
 // z-marching 3-D variants (fg_poisson3d.hip)
 bool fg_zmarch_ok(const fg_state* s, int* zc_out);

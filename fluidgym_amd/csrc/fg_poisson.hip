@@ -10,8 +10,11 @@
 // + x again is the same stream) -> 16; CG kernel 1 (r, p, rA -> p, Ap) 20; CG kernel 2 (p, Ap, x, r
 // -> x, r) 24.  See DESIGN.md "roofline".
 #include <math.h>
+#include <cmath>
+#include <vector>
 
 #include "fg_internal.h"
+#include "fg_rung64.h"
 
 namespace {
 
@@ -536,3 +539,80 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     FG_HIP_CHECK(hipGetLastError());
     return rc;
 }
+
+#if !FG_F64
+// ---------------------------------------------------------------------------------------------------------------------------
+// fp64 repeat of a pressure solve that ended non-finite (fg_rung64.h; the reference's solver_double_fallback on a solve that runs with
+// returnBestResult, PISOtorch_diff.py:410-445): plain CG in double on the fp32 matrix entries, from zero, same criterion / cap.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k64_papply(FgGrid g, const float* __restrict__ rA_, const double* __restrict__ x, double* __restrict__ y,
+                                                       int tiles_x, int tiles_y, int tiles) {
+    const FgCtx<DIMS, 1> c = fg_make_ctx<DIMS, 1>(g, tiles_x, tiles_y, tiles);
+    if (!c.valid) return;
+    const FgMetric<DIMS, 1> m = fg_metrics<DIMS, 1>(g, c);
+    const FgNbr<DIMS, 1> rA = fg_gather<DIMS, 1>(rA_, c);
+    const FgCoef<DIMS, 1> k = fg_poisson_coef<DIMS, 1>(c, m, rA);      // the matrix entries as the fp32 solver forms them, promoted below
+    const R64Nbr<DIMS> X = r64_gather<DIMS>(x, c);
+    double v = (double)k.xm[0] * (X.xm - X.c) + (double)k.xp[0] * (X.xp - X.c) + (double)k.ym[0] * (X.ym - X.c) + (double)k.yp[0] * (X.yp - X.c);
+    if constexpr (DIMS == 3) v += (double)k.zm[0] * (X.zm - X.c) + (double)k.zp[0] * (X.zp - X.c);
+    y[c.idx] = v;
+}
+}  // namespace
+
+int fg_rung64_cg(fg_state* s, const FgCgArgs& a, fg_solve_info* info, bool all_envs, hipStream_t st) {
+    R64 w;
+    if (int rc = w.init(s, st)) return rc;
+    const int B = s->grid.B, n = s->grid.n, d = s->grid.dims;
+    FgGrid g1 = s->grid; g1.B = 1;
+    double *r = w.v[0], *p = w.v[1], *Ap = w.v[2], *x = w.v[3], *bb = w.v[4];
+    auto apply = [&](int b, const double* in, double* out) {
+        const float* rA = a.rA + (size_t)b * n;
+        if (d == 2) { FgLaunch L = fg_launch_geometry<2, 1>(g1); hipLaunchKernelGGL((k64_papply<2>), L.grid, dim3(FG_BLOCK), 0, st, g1, rA, in, out, L.tiles_x, L.tiles_y, L.tiles); }
+        else { FgLaunch L = fg_launch_geometry<3, 1>(g1); hipLaunchKernelGGL((k64_papply<3>), L.grid, dim3(FG_BLOCK), 0, st, g1, rA, in, out, L.tiles_x, L.tiles_y, L.tiles); }
+    };
+    auto rms = [&](double q) { return sqrt(q / (double)n); };
+    std::vector<float> dt_host;
+    if (a.dt) { dt_host.resize(B); FG_HIP_CHECK(hipMemcpyAsync(dt_host.data(), a.dt, sizeof(float) * B, hipMemcpyDeviceToHost, st)); FG_HIP_CHECK(hipStreamSynchronize(st)); }
+    int rc_all = FG_OK;
+    for (int b = 0; b < B; ++b) {
+        if (a.dt && !(dt_host[b] > 0.f)) continue;
+        fg_solve_info& I = info[b];
+        if (!all_envs && I.is_finite) continue;
+        w.load(bb, a.b + (size_t)b * n);
+        w.zero(x);
+        w.axpby(r, 1.0, bb, 0.0, bb);
+        w.axpby(p, 1.0, r, 0.0, r);
+        double rr = w.dot(r, r);
+        I.used_iterations = -1; I.converged = 0; I.is_finite = 1; I.final_residual = (float)rms(rr);
+        for (int it = 0; it < a.max_iterations; ++it) {
+            if (!(rms(rr) >= (double)a.tol)) { I.converged = std::isfinite(rr) ? 1 : 0; break; }
+            if (a.reset_steps > 0 && it > 0 && (it + 1) % a.reset_steps == 0) {      // residual restart (cg_solver_kernel.cu:281-302)
+                apply(b, x, Ap);
+                w.axpby(r, 1.0, bb, -1.0, Ap);
+                w.axpby(p, 1.0, r, 0.0, r);
+                rr = w.dot(r, r);
+            }
+            apply(b, p, Ap);
+            const double pAp = w.dot(p, Ap);
+            const double alpha = rr / pAp;
+            w.axpby(x, 1.0, x, alpha, p);
+            w.axpby(r, 1.0, r, -alpha, Ap);
+            const double rr_new = w.dot(r, r);
+            w.axpby(p, rr_new / rr, p, 1.0, r);
+            rr = rr_new;
+            I.used_iterations = it; I.final_residual = (float)rms(rr);
+            if (!std::isfinite(rr)) { I.is_finite = 0; break; }
+            if (it + 1 == a.max_iterations && !(rms(rr) >= (double)a.tol)) I.converged = 1;
+        }
+        if (w.err) return w.err;
+        w.store(a.x + (size_t)b * n, x);
+        if (!I.is_finite) rc_all = FG_ERR_NOT_FINITE;
+        else if (!I.converged && rc_all == FG_OK) rc_all = FG_ERR_NOT_CONVERGED;
+    }
+    FG_HIP_CHECK(hipStreamSynchronize(st));
+    FG_HIP_CHECK(hipGetLastError());
+    return rc_all;
+}
+#endif

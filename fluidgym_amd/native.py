@@ -403,6 +403,17 @@ class NativeSolver:
         L.check(self.lib.fg_advection_retries(self.handle, ctypes.byref(out), int(reset)), lib=self.lib)
         return int(out.value)
 
+    def set_double_fallback(self, on: bool = True) -> None:
+        """``solver_double_fallback`` of the reference's linear-solve ladder (PISOtorch_diff.py:418-445): see ``fg_set_double_fallback``."""
+        L.check(self.lib.fg_set_double_fallback(self.handle, int(bool(on))), lib=self.lib)
+
+    def ladder(self, force_mask: int = -1) -> Dict[str, int]:
+        """How often each rung of the retry ladder ran (``fg_ladder``); ``force_mask`` >= 0 (tests) makes first attempts count as
+        failed: 1 advection, 2 pressure, 4 also the advection fp64 rung."""
+        out = (ctypes.c_int64 * 4)()
+        L.check(self.lib.fg_ladder(self.handle, out, int(force_mask)), lib=self.lib)
+        return {"advection_fp64": int(out[0]), "advection_preconditioned": int(out[1]), "pressure_fp64": int(out[2])}
+
     def advection_solver_form(self, nc: Optional[int] = None) -> str:
         """Kernels of the next un-preconditioned advection-diffusion solve: 'five' | 'two-brick' | 'two-zmarch'."""
         out = ctypes.c_int32()

@@ -136,12 +136,15 @@ class Simulation:
         # (cuSPARSE ILU(0) there, the y-line solve of csrc/fg_linepre.hip here).  On top of that the policy switch
         # advection_line_preconditioner (policy.py, default OFF) preconditions every solve on grids refined towards a y wall, where
         # the plain recurrence needs 20-35 iterations (RBC 512 x 128): same system, same tolerance, another Krylov trajectory.
-        # solver_double_fallback (an fp64 re-solve) has no counterpart on this path: its systems are strictly diagonally
-        # dominant and fp32 BiCGStab reaches their tolerances; the kwarg is accepted.
+        # solver_double_fallback (PISOtorch_diff.py:418-445): a solve that failed in fp32 is repeated in fp64 on the same matrix and
+        # right-hand side from a cleared result, BEFORE the preconditioned rung (csrc/fg_rung64.h; round 4 -- until then the kwarg
+        # was accepted and ignored on this path).
         self.preconditionBiCG = bool(preconditionBiCG)
         self.BiCG_precondition_fallback = bool(BiCG_precondition_fallback)
         self.solver_double_fallback = bool(solver_double_fallback)
         solver = domain.solver
+        if hasattr(solver, "set_double_fallback"):
+            solver.set_double_fallback(self.solver_double_fallback)
         if hasattr(solver, "set_advection_preconditioner"):
             hy = np.asarray(solver.widths[1], dtype=np.float64)
             refined = bool(get_solver_policy()["advection_line_preconditioner"]) and float(hy.max() / hy.min()) >= 3.0

@@ -197,6 +197,14 @@ int fg_debug_apply_preconditioner(fg_handle h, int mode, int nc, const fg_real* 
  * reference counterpart (its preconditioner for these solves is ILU(0), off by default); fp32 library only. */
 int fg_set_fd_helmholtz(fg_handle h, const float* lam_host);
 int fg_advection_retries(fg_handle h, int64_t* out, int32_t reset);
+/* The reference's retry ladder of a linear solve (_linear_solve_wrapper, pict/PISOtorch_diff.py:410-476) on the single-block path.
+ * fg_set_double_fallback(on): `solver_double_fallback` -- a solve that failed in fp32 (advection-diffusion BiCGStab: not converged;
+ * pressure CG, which runs with returnBestResult: non-finite) is repeated in fp64 on the same fp32 matrix and right-hand side from a
+ * cleared result (csrMat.toType(dp), rhs.to(dp)), BEFORE the preconditioned rung of fg_set_advection_preconditioner (modes 2 / 5).
+ * fg_ladder: out4 = how often each rung ran since fg_create {advection fp64, advection preconditioned, pressure fp64, 0};
+ * force_mask >= 0 (tests) makes first attempts count as failed: 1 advection, 2 pressure, 4 also the advection fp64 rung; -1 = only read. */
+int fg_set_double_fallback(fg_handle h, int on);
+int fg_ladder(fg_handle h, int64_t* out4, int32_t force_mask);
 /* Which kernels the NEXT un-preconditioned advection-diffusion solve of `nc` right-hand sides will run (tests, bench reports):
  * 0 = five kernels per BiCGStab iteration, 1 = two brick kernels (csrc/fg_bicgstab.hip k_bicgf_a / _b), 2 = two z-marching
  * LDS-ring kernels (csrc/fg_bicgstab3d.hip: 3-D grids that fit the tiles and fill the chip).  Replaces nothing in the reference
