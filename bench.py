@@ -308,6 +308,17 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=T
         env.close()
 
 
+def step_gbps(prof, elapsed_s):
+    """Whole-step effective bandwidth of the SOLVER kernels: algorithmic bytes of every sampled kind (mean bytes per sampled launch
+    x launches in the timed region) / wall time of the timed region.  Assembly / corrector kernels are not in the native profile, so
+    this is a lower bound of what the step moves."""
+    tot = 0.0
+    for r in prof.values():
+        if r.get("all_samples", 0) > 0:
+            tot += r["bytes"] / max(r["samples"], 1) * r["launches"] * (r["samples"] / r["all_samples"])
+    return tot / elapsed_s / 1e9 if tot > 0 else None
+
+
 def launches_per_piso_step(prof, its):
     """Solver-kernel launches (the kinds the native profile counts: Krylov + preconditioner kernels) per PISO step."""
     n = sum(r["launches"] for r in prof.values())
@@ -404,11 +415,11 @@ def cpu_baseline():
     from oracle import cpu_bench
 
     n_sim = max(1, int(CFG["step_length"] / CFG["dt"]))
-    r1, rall, cores, dtype, steps_all = cpu_bench.run(budget_1=8.0, budget_all=12.0, dtype="float32")
+    r1, rall, cores, dtype, steps_all = cpu_bench.run(budget_1=4.0, budget_all=8.0, dtype="float32")
     return {"value": rall / n_sim, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "one_thread_value": r1 / n_sim, "cpu_model": cpu_bench.cpu_model(), "dtype": dtype,
-            "sample": f"{cores} envs of the {CFG['resolution_x']}x{CFG['resolution_y']} channel, one per core for 12 s "
-                      f"({steps_all} PISO steps = {steps_all / n_sim:.1f} env steps in total), and one env on one thread for 8 s; "
+            "sample": f"{cores} envs of the {CFG['resolution_x']}x{CFG['resolution_y']} channel, one per core for 8 s "
+                      f"({steps_all} PISO steps = {steps_all / n_sim:.1f} env steps in total), and one env on one thread for 4 s; "
                       "NumPy/SciPy oracle with the reference's CG / BiCGStab recurrences (cold-started, tolerance 1e-5)"}
 
 
@@ -459,6 +470,8 @@ def compact_line(out, detail_path=DETAIL_PATH):
     keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")
     line = {k: _r(out[k], 6) for k in keys}
+    if out.get("value_unforced") is not None:
+        line["value_unforced"] = _r(out["value_unforced"], 6)
     cfg = out["config"]
     line["config"] = {"workload": cfg["workload"], "global_batch": cfg["global_batch"], "grid": cfg["grid"],
                       "parallelism": cfg["parallelism"], "workload_modified": cfg.get("workload_modified"),
@@ -467,7 +480,8 @@ def compact_line(out, detail_path=DETAIL_PATH):
                       "iters_are": cfg.get("iters_are"),
                       "substeps_per_sim_step": cfg.get("mean_substeps_per_sim_step"),
                       "capped_solves": cfg.get("capped_solves"),
-                      "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step"))}
+                      "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step")),
+                      "step_GBps": _r(cfg.get("step_GBps")), "advection_solver_form": cfg.get("advection_solver_form")}
     roof = out.get("roofline")
     if roof:
         tr = roof.get("traffic")
@@ -528,7 +542,7 @@ def main():
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 64 leg (about 18 s)")
     ap.add_argument("--all-legs", action="store_true", help="also run the opt-in modes and the 256 / 64-env multi-block legs")
-    ap.add_argument("--leg-budget", type=float, default=60.0, help="seconds after which no further extra leg is started")
+    ap.add_argument("--leg-budget", type=float, default=75.0, help="seconds after which no further extra leg is started")
     ap.add_argument("--forcing", type=float, default=2.0,
                     help="amplitude of the random body force (velocity source N(0, forcing), redrawn every env step); 0 = quiescent channel")
     args = ap.parse_args()
@@ -575,13 +589,15 @@ def main():
     # (block.velocitySource, a feature of the reference's solver: PISO_multiblock_cuda_kernel.cu:2256-2267) ~ N(0, forcing) per
     # cell and component, redrawn every env step, so that BOTH pressure solves of EVERY PISO step have a divergence to remove.
     blk0 = env._domain.getBlock(0)
-    if args.forcing > 0:
+    single_block = hasattr(blk0, "setVelocitySource")     # the body force is a feature of the single-block Domain; the reference's
+    forcing = args.forcing if single_block else 0.0       # own multi-block envs (--env-id CylinderJet2D-easy-v0, ...) run as they are
+    if forcing > 0:
         blk0.setVelocitySource(torch.zeros_like(blk0.velocity))
     force_gen = torch.Generator(device=device).manual_seed(4321 + rank)
 
     def perturb():
-        if args.forcing > 0:
-            blk0.velocitySource.normal_(0.0, args.forcing, generator=force_gen)
+        if forcing > 0:
+            blk0.velocitySource.normal_(0.0, forcing, generator=force_gen)
 
     def one_step():
         perturb()
@@ -614,8 +630,9 @@ def main():
     its = solver_iterations(solver)
     n_sim = env._n_sim_steps
 
+    grid_desc = [solver.nx, solver.ny, solver.nz] if single_block else {"cells_per_env": int(solver.n_cells), "blocks": len(solver.blocks)}
     if rank == 0:
-        roof = roofline_from_profile(prof, solver)
+        roof = roofline_from_profile(prof, solver) if single_block else None
         triad = None
         if not args.no_micro:
             try:
@@ -642,16 +659,19 @@ def main():
             "config": {"workload": f"{args.env_id}"
                                    + (" (2D channel stand-in for 'cylinder Re=100 256x128')" if args.env_id == ENV_ID else "")
                                    + f", {args.envs_per_gpu} envs/GPU, {n_sim} PISO steps/env step, random jets"
-                                   + (f", stirred by a body force N(0,{args.forcing}) redrawn every env step" if args.forcing > 0 else ", quiescent"),
-                       "workload_modified": args.forcing > 0,
-                       "forcing_amplitude": args.forcing,
-                       "global_batch": n_total, "grid": [solver.nx, solver.ny, solver.nz],
+                                   + (f", stirred by a body force N(0,{forcing}) redrawn every env step" if forcing > 0 else (", quiescent" if single_block else ", the reference's own multi-block mesh")),
+                       "workload_modified": forcing > 0,
+                       "forcing_amplitude": forcing,
+                       "global_batch": n_total, "grid": grid_desc,
                        "parallelism": f"env-sharded x{world}, 1 bcast + 1 all_gather per step (RCCL)",
                        "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start),
-                       "pressure_solver": "CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)",
+                       "pressure_solver": ("CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)"
+                                           if single_block else "multi-block path (fg_mb_*): see the cylinder_env / airfoil_env legs"),
+                       "advection_solver_form": solver.advection_solver_form() if single_block else None,
                        "solver_iterations": its, "capped_solves": capped_solves(its),
                        "iters_are": "iterations per solve (counts; 0 = initial residual met the tolerance)",
-                       "launches_per_piso_step": launches_per_piso_step(prof, its),
+                       "launches_per_piso_step": launches_per_piso_step(prof, its) if single_block else None,
+                       "step_GBps": step_gbps(prof, elapsed) if single_block else None,
                        "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2)},
             "roofline": roof,
             "legs": {},
@@ -675,21 +695,21 @@ def main():
 
         import fluidgym_amd
 
-        half = max(2, min(args.steps // 2, 5))
+        half = max(5, min(args.steps // 2, 8))
         leg("quiescent_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=half, warmup=2, seed=1234,
             doc="headline workload without the body force: the laminar channel's pressure right-hand side sits at the "
                 "reference's absolute tolerance, the projections take 0-1 iterations")
-        leg("large_env", env_leg, "ChannelJet2D-large-v0", 64, device, steps=2, warmup=1, seed=1234, forcing=args.forcing,
+        leg("large_env", env_leg, "ChannelJet2D-large-v0", 64, device, steps=5, warmup=1, seed=1234, forcing=args.forcing,
             doc="BASELINE config 5's per-GPU share: 512x256 x 64 envs (working set > Infinity Cache: the HBM-resident 2-D case)")
-        leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=2, warmup=1,
+        leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=8, warmup=1,
             doc="BASELINE config 2 on one GPU: Rayleigh-Benard 512x128, 32 envs (256 across 8 GPUs)")
-        leg("tcf_env", env_leg, "TCF3D-baseline-v0", 8, device, steps=2, warmup=1,
+        leg("tcf_env", env_leg, "TCF3D-baseline-v0", 8, device, steps=8, warmup=1,
             doc="BASELINE config 3: turbulent channel 128x64x64, 8 envs")
-        leg("cylinder_env", cylinder_env_leg, device, extra_modes=args.all_legs)
+        leg("cylinder_env", cylinder_env_leg, device, steps=6, extra_modes=args.all_legs)
         if not args.no_airfoil_leg:
             # BASELINE config 4 ("batch=512 across 8 GPUs"): 64 envs are one GPU's share (rounds 1-3 quoted 16 envs: `airfoil_env_16`
             # under --all-legs; the kernels are launch-latency-bound at 16 x 46.7 k cells, so the larger batch costs little more time)
-            leg("airfoil_env", airfoil_env_leg, device, num_envs=64, steps=1)
+            leg("airfoil_env", airfoil_env_leg, device, num_envs=64, steps=3)
         if args.all_legs:
             # the same workload in the opt-in performance mode: pressure solves started from the previous pressure
             old = fluidgym_amd.set_solver_policy(pressure_warm_start=True, advection_warm_start=True)
@@ -701,6 +721,8 @@ def main():
             leg("airfoil_env_16", airfoil_env_leg, device, num_envs=16, steps=2)
             leg("airfoil_env_plain_mode", airfoil_env_leg, device, num_envs=16, multilevel_trial=False)
     if rank == 0:
+        q = out["legs"].get("quiescent_mode")
+        out["value_unforced"] = q.get("value") if isinstance(q, dict) else None     # the same workload without the body force
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         write_detail(out)

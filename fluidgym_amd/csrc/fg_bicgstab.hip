@@ -556,14 +556,13 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
             for (int k = 0; k < VEC; ++k) part[2 * comp] += rwv.v[k] * y.v[k];
         }
     }
-    fg_block_sum<6>(part, lds);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp) {
-            if (comp >= q.nc || (mode[comp] != 1 && mode[comp] != 3)) continue;
+    const fg_real tot = fg_block_sum_lanes<6>(part, lds);      // thread t < 6 holds value t: [comp][rw.v | r.r]
+    if (threadIdx.x < 6) {
+        const int comp = threadIdx.x >> 1, kind = threadIdx.x & 1;
+        const int md = comp == 0 ? mode[0] : (comp == 1 ? mode[1] : mode[2]);
+        if (comp < q.nc && (md == 1 || (md == 3 && kind == 0))) {
             FgDacc* a = q.acc + (size_t)(c.b * q.nc + comp) * FG_ACC_DOUBLES;
-            acc_add(a + (F_RV + e), (double)part[2 * comp]);
-            if (mode[comp] == 1) acc_add(a + (F_RR + e), (double)part[2 * comp + 1]);
+            acc_add(a + ((kind ? F_RR : F_RV) + e), (double)tot);
         }
     }
 }
@@ -636,17 +635,22 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
             }
         }
     }
-    fg_block_sum<15>(part, lds);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp) {
-            if (comp >= q.nc || !work[comp]) continue;
+    // (-DFG_KNOCK_B=1: no accumulator atomics, =2: no workgroup reduction either -- timing knock-outs, profiles/micro_bicg2d.py)
+#if defined(FG_KNOCK_B) && FG_KNOCK_B >= 2
+    if (part[0] == 12345.678f) q.sc[0] = part[1] + part[2] + part[3] + part[4] + part[5] + part[6] + part[7] + part[8] + part[9];
+    return;
+#endif
+    const fg_real tot = fg_block_sum_lanes<15>(part, lds);     // thread t < 15 holds value t: [comp][s.s | t.s | t.t | rw.s | rw.t]
+#if defined(FG_KNOCK_B) && FG_KNOCK_B == 1
+    if (threadIdx.x == 0 && tot == 12345.678f) q.sc[0] = tot;
+    return;
+#endif
+    if (threadIdx.x < 15) {
+        const int comp = threadIdx.x / 5, kind = threadIdx.x - 5 * comp;
+        const bool wk = comp == 0 ? work[0] : (comp == 1 ? work[1] : work[2]);
+        if (comp < q.nc && wk) {
             FgDacc* a = q.acc + (size_t)(c.b * q.nc + comp) * FG_ACC_DOUBLES;
-            acc_add(a + (F_SS + e), (double)part[5 * comp + 0]);
-            acc_add(a + (F_TS + e), (double)part[5 * comp + 1]);
-            acc_add(a + (F_TT + e), (double)part[5 * comp + 2]);
-            acc_add(a + (F_RS + e), (double)part[5 * comp + 3]);
-            acc_add(a + (F_RT + e), (double)part[5 * comp + 4]);
+            acc_add(a + (F_SS + 2 * kind + e), (double)tot);      // F_SS, F_TS, F_TT, F_RS, F_RT are two apart
         }
     }
 }

@@ -249,15 +249,14 @@ __device__ __forceinline__ void b3_a_body(const FgGrid& g, const BicgPtrs& q, co
         __syncthreads();                                                                     // the plane ahead is visible; the plane behind retired
         const int t3 = sm; sm = sc; sc = sp; sp = sf; sf = t3;
     }
-    fg_block_sum<2 * NC>(part, red);
-    if (threadIdx.x == 0) {
+    const float tot = fg_block_sum_lanes<2 * NC>(part, red);    // thread t < 2 NC holds value t: [comp][rw.v | r.r]
+    if (threadIdx.x < 2 * NC) {
+        const int comp = threadIdx.x >> 1, kind = threadIdx.x & 1;
+        bool on = false;
 #pragma unroll
-        for (int comp = 0; comp < NC; ++comp) {
-            if (!m1(comp) && !m3(comp)) continue;
-            FgDacc* a = q.acc + (size_t)(c.b * NC + comp) * FG_ACC_DOUBLES;
-            acc_add(a + (F_RV + e), (double)part[2 * comp]);
-            if (m1(comp) || (m3(comp) && fold)) acc_add(a + (F_RR + e), (double)part[2 * comp + 1]);
-        }
+        for (int k = 0; k < NC; ++k)
+            if (k == comp) on = kind == 0 ? (m1(k) || m3(k)) : (m1(k) || (m3(k) && fold));
+        if (on) acc_add(q.acc + (size_t)(c.b * NC + comp) * FG_ACC_DOUBLES + ((kind ? F_RR : F_RV) + e), (double)tot);
     }
 }
 
@@ -397,18 +396,14 @@ __device__ __forceinline__ void b3_b_body(const FgGrid& g, const BicgPtrs& q, co
         const int t3 = sm; sm = sc; sc = sp; sp = sf; sf = t3;
         mcur = mnxt;
     }
-    fg_block_sum<5 * NC>(part, red);
-    if (threadIdx.x == 0) {
+    const float tot = fg_block_sum_lanes<5 * NC>(part, red);    // thread t < 5 NC holds value t: [comp][s.s | t.s | t.t | rw.s | rw.t]
+    if (threadIdx.x < 5 * NC) {
+        const int comp = threadIdx.x / 5, kind = threadIdx.x - 5 * comp;
+        bool on = false;
 #pragma unroll
-        for (int comp = 0; comp < NC; ++comp) {
-            if (!wk(comp)) continue;
-            FgDacc* a = q.acc + (size_t)(c.b * NC + comp) * FG_ACC_DOUBLES;
-            acc_add(a + (F_SS + e), (double)part[5 * comp + 0]);
-            acc_add(a + (F_TS + e), (double)part[5 * comp + 1]);
-            acc_add(a + (F_TT + e), (double)part[5 * comp + 2]);
-            acc_add(a + (F_RS + e), (double)part[5 * comp + 3]);
-            acc_add(a + (F_RT + e), (double)part[5 * comp + 4]);
-        }
+        for (int k = 0; k < NC; ++k)
+            if (k == comp) on = wk(k);
+        if (on) acc_add(q.acc + (size_t)(c.b * NC + comp) * FG_ACC_DOUBLES + (F_SS + 2 * kind + e), (double)tot);
     }
 }
 

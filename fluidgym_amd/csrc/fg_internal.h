@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 
 #include "../../include/fluidgym_hip.h"
 
@@ -71,28 +72,30 @@ struct alignas(64) FgDacc {
     unsigned long long w[4];
     unsigned long long poison;
     double plain;
-    unsigned long long pad[2];
+    unsigned long long w4;     // fifth word: fp64 build only (FG_DACC_WORDS == 5)
+    unsigned long long pad;
 };
 static_assert(sizeof(FgDacc) == 64, "one accumulator per 64-byte line segment");
 
 // the split of one contribution and the value of the words: shared by the device accessors and the host self-test
-// (fg_dacc_host_sum), so that what the CPU test checks is what the kernels run
-// (the fp64 build shifts the window down by 2^-30: range 2^45, unit of the last word 2^-122 -- residuals of solves driven to
-//  1e-13 .. 1e-15 stay resolved; FG_REAL_DOUBLE is defined before this header is read)
+// (fg_dacc_host_sum), so that what the CPU test checks is what the kernels run.
+// fp32 build: four words, units 2^34 .. 2^-92, range 2^75.  fp64 build (FG_REAL_DOUBLE is defined before this header is read):
+// FIVE words, the same range with a last unit of 2^-134, so that residuals of solves driven to 1e-13 .. 1e-15 stay resolved.  (Rounds
+// 2-3 gave the fp64 build four words shifted down by 2^-30 -- range 2^45 = 3.5e13.  Round 4: the impulsive start of the fp64
+// airfoil env exceeds that -- the tiny cells at the nose give residual components ~1e7 --, so its sums were poisoned until
+// round 3 and saturated after the ADVICE-r3 change; with five words neither happens.)
 #ifdef FG_REAL_DOUBLE
-#define FG_DACC_U0 0x1p4
-#define FG_DACC_U1 0x1p-38
-#define FG_DACC_U2 0x1p-80
-#define FG_DACC_U3 0x1p-122
-#define FG_DACC_LIMIT 0x1p45
+#define FG_DACC_WORDS 5
 #else
+#define FG_DACC_WORDS 4
+#endif
 #define FG_DACC_U0 0x1p34
 #define FG_DACC_U1 0x1p-8
 #define FG_DACC_U2 0x1p-50
 #define FG_DACC_U3 0x1p-92
+#define FG_DACC_U4 0x1p-134
 #define FG_DACC_LIMIT 0x1p75
-#endif
-__host__ __device__ __forceinline__ bool fg_dacc_split(double v, long long k[4]) {
+__host__ __device__ __forceinline__ bool fg_dacc_split(double v, long long k[5]) {
     if (!(fabs(v) <= 1.79769313486231570815e308)) return false;  // NaN, Inf: poison
     // a finite contribution beyond the window SATURATES (each contribution on its own, so the sum stays order-independent):
     // a diverging but finite solve keeps reading as a large finite residual -- return-best / the retry ladder then see
@@ -102,38 +105,59 @@ __host__ __device__ __forceinline__ bool fg_dacc_split(double v, long long k[4])
     const double k0 = rint(r * (1.0 / FG_DACC_U0)); r -= k0 * FG_DACC_U0;      // exact: r keeps the bits of v below the word
     const double k1 = rint(r * (1.0 / FG_DACC_U1)); r -= k1 * FG_DACC_U1;
     const double k2 = rint(r * (1.0 / FG_DACC_U2)); r -= k2 * FG_DACC_U2;
-    const double k3 = rint(r * (1.0 / FG_DACC_U3));                            // bits below half the last unit are dropped (the same ones in any order)
+    const double k3 = rint(r * (1.0 / FG_DACC_U3));                            // (4 words: bits below half the last unit are dropped, the same ones in any order)
     k[0] = (long long)k0; k[1] = (long long)k1; k[2] = (long long)k2; k[3] = (long long)k3;
+    k[4] = 0;
+#if FG_DACC_WORDS == 5
+    r -= k3 * FG_DACC_U3;
+    k[4] = (long long)rint(r * (1.0 / FG_DACC_U4));
+#endif
     return true;
 }
 __host__ __device__ __forceinline__ double fg_dacc_value(unsigned long long w0, unsigned long long w1, unsigned long long w2,
-                                                         unsigned long long w3, unsigned long long poison, double plain) {
+                                                         unsigned long long w3, unsigned long long poison, double plain,
+                                                         unsigned long long w4 = 0ull) {
     // smallest unit first; every conversion and addition is a fixed sequence on the same integer words
-    double t = (double)(long long)w3 * FG_DACC_U3;
+    double t = 0.0;
+#if FG_DACC_WORDS == 5
+    t = (double)(long long)w4 * FG_DACC_U4;
+#endif
+    t += (double)(long long)w3 * FG_DACC_U3;
     t += (double)(long long)w2 * FG_DACC_U2;
     t += (double)(long long)w1 * FG_DACC_U1;
     t += (double)(long long)w0 * FG_DACC_U0;
     t += plain;
     return poison ? (double)NAN : t;
 }
-inline double fg_dacc_host_value(const FgDacc& a) { return fg_dacc_value(a.w[0], a.w[1], a.w[2], a.w[3], a.poison, a.plain); }
+inline double fg_dacc_host_value(const FgDacc& a) { return fg_dacc_value(a.w[0], a.w[1], a.w[2], a.w[3], a.poison, a.plain, a.w4); }
 __device__ __forceinline__ void acc_st(FgDacc* p, double v) {
     ulonglong2* q = reinterpret_cast<ulonglong2*>(p);
     q[0] = make_ulonglong2(0ull, 0ull);
     q[1] = make_ulonglong2(0ull, 0ull);
     q[2] = make_ulonglong2(0ull, (unsigned long long)__double_as_longlong(v));
+#if FG_DACC_WORDS == 5
+    q[3] = make_ulonglong2(0ull, 0ull);
+#endif
 }
 __device__ __forceinline__ double acc_ld(const FgDacc* p) {
     const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
     const ulonglong2 a = q[0], b = q[1], c = q[2];
+#if FG_DACC_WORDS == 5
+    const ulonglong2 d = q[3];
+    return fg_dacc_value(a.x, a.y, b.x, b.y, c.x, __longlong_as_double((long long)c.y), d.x);
+#else
     return fg_dacc_value(a.x, a.y, b.x, b.y, c.x, __longlong_as_double((long long)c.y));
+#endif
 }
 __device__ __forceinline__ void acc_add(FgDacc* p, double v) {
-    long long k[4];
+    long long k[5];
     if (!fg_dacc_split(v, k)) { atomicAdd(&p->poison, 1ull); return; }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (k[i] != 0) atomicAdd(&p->w[i], (unsigned long long)k[i]);
+#if FG_DACC_WORDS == 5
+    if (k[4] != 0) atomicAdd(&p->w4, (unsigned long long)k[4]);
+#endif
 }
 
 __device__ __forceinline__ fg_real sc_ld(const fg_real* p) { return fg_word_ld(p, (FG_FLAG_ACCESS & 1) != 0); }
@@ -314,12 +338,43 @@ struct FgNbr {
     FgVec<VEC> c, xm, xp, ym, yp, zm, zp;
 };
 
+// x neighbours of a thread's vector: the cell left of element 0 is element VEC-1 of the lane before, the cell right of element VEC-1
+// is element 0 of the lane after -- inside a tile row (16 consecutive lanes = one DPP row with VEC = 4) they come from a DPP row
+// shift, and only the lanes at a tile or grid edge load them.  Until round 4 EVERY lane loaded both scalars: two wave-wide 4-byte
+// gathers per field that pull the same sixteen cache lines through the L1 as the 16-byte centre load (PMC round 4: the stencil
+// kernels of the headline sit 57-59 % of their wave cycles in s_waitcnt with ~3.5x their algorithmic bytes going through the L1).
+#if !FG_F64
+__device__ __forceinline__ float fg_dpp_from_lane_before(float v) {   // row_shr:1 -- lane i receives lane i-1 (of its row of 16)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float fg_dpp_from_lane_after(float v) {    // row_shl:1 -- lane i receives lane i+1
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+}
+#endif
+template <int DIMS, int VEC>
+__device__ __forceinline__ void fg_x_neighbours(const fg_real* __restrict__ q, const FgCtx<DIMS, VEC>& c, const FgVec<VEC>& ctr,
+                                                fg_real& left, fg_real& right) {
+#if !FG_F64
+    if constexpr (VEC == 4) {
+        // (callers run this under `c.valid`: the lanes before / after a valid interior lane of the same row are valid too)
+        const int lx = threadIdx.x & 15;
+        left = fg_dpp_from_lane_before(ctr.v[3]);
+        right = fg_dpp_from_lane_after(ctr.v[0]);
+        if (lx == 0 || c.ixm != c.idx - 1) left = q[c.ixm];
+        if (lx == 15 || c.ixp != c.idx + VEC) right = q[c.ixp];
+        return;
+    }
+#endif
+    left = q[c.ixm];
+    right = q[c.ixp];
+}
+
 template <int DIMS, int VEC>
 __device__ __forceinline__ FgNbr<DIMS, VEC> fg_gather(const fg_real* __restrict__ q, const FgCtx<DIMS, VEC>& c) {
     FgNbr<DIMS, VEC> n;
     n.c = fg_load<VEC>(q + c.idx);
-    const fg_real left = q[c.ixm];
-    const fg_real right = q[c.ixp];
+    fg_real left, right;
+    fg_x_neighbours<DIMS, VEC>(q, c, n.c, left, right);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         n.xm.v[e] = (e == 0) ? left : n.c.v[e - 1];
@@ -340,8 +395,8 @@ __device__ __forceinline__ void fg_gather_axis(const fg_real* __restrict__ q, co
                                                FgVec<VEC>& ctr, FgVec<VEC>& lo, FgVec<VEC>& hi) {
     ctr = fg_load<VEC>(q + c.idx);
     if (axis == 0) {
-        const fg_real left = q[c.ixm];
-        const fg_real right = q[c.ixp];
+        fg_real left, right;
+        fg_x_neighbours<DIMS, VEC>(q, c, ctr, left, right);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             lo.v[e] = (e == 0) ? left : ctr.v[e - 1];
@@ -392,16 +447,68 @@ __device__ __forceinline__ FgMetric<DIMS, VEC> fg_metrics(const FgGrid& g, const
     return m;
 }
 
-// wave64 + workgroup sum; result valid in thread 0
-__device__ __forceinline__ fg_real fg_wave_sum(fg_real v) {
+// wave64 sum / max; result valid in EVERY lane.  fp32: on the VALU alone -- DPP quad permutes, row rotations and row broadcasts (the
+// rocPRIM sequence) and one v_readlane; until round 4 these were six dependent __shfl_down = ds_bpermute trips through the LDS
+// crossbar per value.  Every lane of the wave must be active (all call sites sit next to a __syncthreads()).
+#if !FG_F64
+template <typename OP>
+__device__ __forceinline__ float fg_wave_reduce_dpp(float v, OP op) {
+    // (masked rows keep `old`, which is the neutral element handed in through the first operand of update_dpp)
+#define FG_DPP(x, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, 0xf, false))
+    v = op(v, FG_DPP(v, 0xb1, 0xf));     // quad_perm [1,0,3,2]
+    v = op(v, FG_DPP(v, 0x4e, 0xf));     // quad_perm [2,3,0,1]
+    v = op(v, FG_DPP(v, 0x124, 0xf));    // row_ror:4
+    v = op(v, FG_DPP(v, 0x128, 0xf));    // row_ror:8  -> every lane holds its row's result
+    float t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+    v = ((threadIdx.x >> 4) & 1) ? op(v, t) : v;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xc, 0xf, false));         // row_bcast:31 into rows 2, 3
+    v = ((threadIdx.x >> 5) & 1) ? op(v, t) : v;
+#undef FG_DPP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#ifdef FG_WAVE_SHFL   // (-DFG_WAVE_SHFL: the shuffle form of rounds 1-3, for A/B runs)
+__device__ __forceinline__ float fg_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    return __shfl(v, 0, 64);
 }
-__device__ __forceinline__ fg_real fg_wave_max(fg_real v) {
+__device__ __forceinline__ float fg_wave_max(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = FG_FMAX(v, __shfl_down(v, o, 64));
-    return v;
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return __shfl(v, 0, 64);
+}
+#else
+__device__ __forceinline__ float fg_wave_sum(float v) { return fg_wave_reduce_dpp(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float fg_wave_max(float v) { return fg_wave_reduce_dpp(v, [](float a, float b) { return fmaxf(a, b); }); }
+#endif
+#endif
+__device__ __forceinline__ double fg_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+__device__ __forceinline__ double fg_wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return __shfl(v, 0, 64);
+}
+// Round 4, k_bicgf_b at the headline size: 15 values per thread through fg_block_sum (shuffle form) + ONE thread splitting and adding
+// them all cost 11.7 of the kernel's 36.9 us (knock-out builds, profiles/micro_bicg2d.py) -- every workgroup of these launches is
+// resident at once, so a serial per-workgroup tail is exposed.
+// Workgroup sum of NV values with the result of value q returned to THREAD q (q < NV): the per-value tails (accumulator split +
+// atomics) then run in NV lanes side by side instead of one after the other in thread 0.
+template <int NV>
+__device__ __forceinline__ fg_real fg_block_sum_lanes(fg_real (&v)[NV], fg_real* lds /* >= NV*4 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const fg_real s = fg_wave_sum(v[q]);
+        if (lane == 0) lds[q * 4 + wave] = s;
+    }
+    __syncthreads();
+    fg_real r = 0;
+    if (threadIdx.x < NV) { const int t = threadIdx.x; r = lds[t * 4] + lds[t * 4 + 1] + lds[t * 4 + 2] + lds[t * 4 + 3]; }
+    return r;
 }
 template <int NV>
 __device__ __forceinline__ void fg_block_sum(fg_real (&v)[NV], fg_real* lds /* >= NV*4 floats */) {

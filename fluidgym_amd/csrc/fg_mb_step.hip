@@ -303,6 +303,21 @@ __device__ __forceinline__ void mb_block_sums(mb_real (&v)[NV], mb_real* lds) {
     __syncthreads();
 }
 
+// The accumulator adds of a reduction tail with one LANE per value (threads 0 .. NV-1 side by side) instead of thread 0 doing them
+// one after the other: the exact split of a value into the FgDacc words and its atomics are a dependent chain of ~100
+// instructions, and in launches whose workgroups are all resident at once that per-workgroup tail is exposed (round 4: 11.7 of
+// 36.9 us in the single-block k_bicgf_b, profiles/micro_bicg2d.py).
+template <int NV>
+__device__ __forceinline__ void mb_acc_tail(FgDacc* a, const int (&slot)[NV], const mb_real (&val)[NV], const bool (&on)[NV]) {
+    if (threadIdx.x < NV) {
+        int sl = slot[0]; mb_real v = val[0]; bool o = on[0];
+#pragma unroll
+        for (int k = 1; k < NV; ++k)
+            if ((int)threadIdx.x == k) { sl = slot[k]; v = val[k]; o = on[k]; }
+        if (o) acc_add(a + sl, (double)v);
+    }
+}
+
 // max |Minv u| over cells and boundary faces (Block::getMaxVelocity, domain_structs.cpp:1580-1611)
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mb_maxvel(MbDev D, const mb_real* __restrict__ u, const mb_real* __restrict__ ub,
@@ -618,10 +633,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v(MbDev D, MbSolve q, int it) 
     }
     part = mb_block_sum(part, lds);
     if (q.project) psum = mb_block_sum(psum, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_RV, (double)part);
-        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)psum);
-    }
+    { const int sl[2] = {A_RV, A_SV + 2 * (it & 1)}; const mb_real vv[2] = {part, psum}; const bool on[2] = {true, (bool)q.project}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s(MbDev D, MbSolve q, int it) {
@@ -660,11 +672,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t(MbDev D, MbSolve q, int it) 
     pt = mb_block_sum(pt, lds);
     ptt = mb_block_sum(ptt, lds);
     if (q.project) pst = mb_block_sum(pst, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_TS, (double)pt);
-        acc_add(a + A_TT, (double)ptt);
-        if (q.project) acc_add(a + A_ST, (double)pst);
-    }
+    { const int sl[3] = {A_TS, A_TT, A_ST}; const mb_real vv[3] = {pt, ptt, pst}; const bool on[3] = {true, true, (bool)q.project}; mb_acc_tail<3>(a, sl, vv, on); }
 }
 // "converged on s" (x += alpha p only, bicgstab_solver_kernel.cu:305-329).  With separate s and t kernels the t kernel has decided
 // (flag 4).  With the fused kernel the decision is taken HERE from the complete s.s -- every workgroup of the system computes the
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
     if (half) return;
     mb_real sums[2] = {prr, prho};
     mb_block_sums<2>(sums, lds);
-    if (threadIdx.x == 0) { acc_add(a + A_RR, (double)sums[0]); acc_add(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
+    { const int sl[2] = {A_RR, A_RHO + ((it + 1) & 1)}; const mb_real vv[2] = {sums[0], sums[1]}; const bool on[2] = {true, true}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 
 // ---- the same five kernels with four consecutive cells per thread (N % 4 == 0): 128-bit loads / stores of the cell's own
@@ -804,10 +812,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_v4(MbDev D, MbSolve q, int it)
     }
     part = mb_block_sum(part, lds);
     if (q.project) psum = mb_block_sum(psum, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_RV, (double)part);
-        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)psum);
-    }
+    { const int sl[2] = {A_RV, A_SV + 2 * (it & 1)}; const mb_real vv[2] = {part, psum}; const bool on[2] = {true, (bool)q.project}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_s4(MbDev D, MbSolve q, int it) {
@@ -849,11 +854,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_t4(MbDev D, MbSolve q, int it)
     pt = mb_block_sum(pt, lds);
     ptt = mb_block_sum(ptt, lds);
     if (q.project) pst = mb_block_sum(pst, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_TS, (double)pt);
-        acc_add(a + A_TT, (double)ptt);
-        if (q.project) acc_add(a + A_ST, (double)pst);
-    }
+    { const int sl[3] = {A_TS, A_TT, A_ST}; const mb_real vv[3] = {pt, ptt, pst}; const bool on[3] = {true, true, (bool)q.project}; mb_acc_tail<3>(a, sl, vv, on); }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it) {
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x4(MbDev D, MbSolve q, int it)
     if (half) return;
     mb_real sums[2] = {prr, prho};
     mb_block_sums<2>(sums, lds);
-    if (threadIdx.x == 0) { acc_add(a + A_RR, (double)sums[0]); acc_add(a + A_RHO + ((it + 1) & 1), (double)sums[1]); }
+    { const int sl[2] = {A_RR, A_RHO + ((it + 1) & 1)}; const mb_real vv[2] = {sums[0], sums[1]}; const bool on[2] = {true, true}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 
 // ---- p and v in one launch: p_new = r + beta (p - omega (v - mean v)) for the own cell and, recomputed from r, p, v of the
@@ -935,10 +936,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv(MbDev D, MbSolve q, int it)
     }
     mb_real sums[2] = {part, psum};
     mb_block_sums<2>(sums, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_RV, (double)sums[0]);
-        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)sums[1]);
-    }
+    { const int sl[2] = {A_RV, A_SV + 2 * (it & 1)}; const mb_real vv[2] = {sums[0], sums[1]}; const bool on[2] = {true, (bool)q.project}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it) {
@@ -989,10 +987,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_pv4(MbDev D, MbSolve q, int it
     }
     mb_real sums[2] = {part, psum};
     mb_block_sums<2>(sums, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_RV, (double)sums[0]);
-        if (q.project) acc_add(a + A_SV + 2 * (it & 1), (double)sums[1]);
-    }
+    { const int sl[2] = {A_RV, A_SV + 2 * (it & 1)}; const mb_real vv[2] = {sums[0], sums[1]}; const bool on[2] = {true, (bool)q.project}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 
 // ---- s and t in one launch (five kernels per iteration -> four): s = r - alpha (v - mean v) for the own cell and, recomputed
@@ -1025,12 +1020,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st(MbDev D, MbSolve q, int it)
     }
     mb_real sums[4] = {pss, pts, ptt, pst};
     mb_block_sums<4>(sums, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_SS, (double)sums[0]);
-        acc_add(a + A_TS, (double)sums[1]);
-        acc_add(a + A_TT, (double)sums[2]);
-        if (q.project) acc_add(a + A_ST, (double)sums[3]);
-    }
+    { const int sl[4] = {A_SS, A_TS, A_TT, A_ST}; const mb_real vv[4] = {sums[0], sums[1], sums[2], sums[3]}; const bool on[4] = {true, true, true, (bool)q.project}; mb_acc_tail<4>(a, sl, vv, on); }
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it) {
@@ -1057,12 +1047,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_st4(MbDev D, MbSolve q, int it
     }
     mb_real sums[4] = {pss, pts, ptt, pst};
     mb_block_sums<4>(sums, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + A_SS, (double)sums[0]);
-        acc_add(a + A_TS, (double)sums[1]);
-        acc_add(a + A_TT, (double)sums[2]);
-        if (q.project) acc_add(a + A_ST, (double)sums[3]);
-    }
+    { const int sl[4] = {A_SS, A_TS, A_TT, A_ST}; const mb_real vv[4] = {sums[0], sums[1], sums[2], sums[3]}; const bool on[4] = {true, true, true, (bool)q.project}; mb_acc_tail<4>(a, sl, vv, on); }
 }
 
 // ---- the additive multilevel preconditioner as kernels (meshes too large for the on-chip CG; right preconditioner of the
@@ -1355,10 +1340,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update(MbDev D, MbSolve q, con
     }
     part = mb_block_sum(part, lds);
     if (project_mean) psum = mb_block_sum(psum, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + C_RHO + (it + 1) % 3, (double)part);
-        if (project_mean) acc_add(a + C_SUM + (it + 1) % 3, (double)psum);
-    }
+    { const int sl[2] = {C_RHO + (it + 1) % 3, C_SUM + (it + 1) % 3}; const mb_real vv[2] = {part, psum}; const bool on[2] = {true, (bool)project_mean}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 
 // ---- the same two kernels with four consecutive cells per thread (N % 4 == 0): own-cell data moves as 128-bit loads, the
@@ -1483,10 +1465,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_update4(int N, MbSolve q, cons
     }
     part = mb_block_sum(part, lds);
     if (project_mean) psum = mb_block_sum(psum, lds);
-    if (threadIdx.x == 0) {
-        acc_add(a + C_RHO + (it + 1) % 3, (double)part);
-        if (project_mean) acc_add(a + C_SUM + (it + 1) % 3, (double)psum);
-    }
+    { const int sl[2] = {C_RHO + (it + 1) % 3, C_SUM + (it + 1) % 3}; const mb_real vv[2] = {part, psum}; const bool on[2] = {true, (bool)project_mean}; mb_acc_tail<2>(a, sl, vv, on); }
 }
 
 // restart of the CG recurrence (the reference recomputes r = b - A x and resets p = r every residualResetSteps = 100

@@ -29,12 +29,13 @@ __device__ __forceinline__ void z_metrics(const FgGrid& g, const ZCtx& c, FgMetr
     m.rhy_m = g.rh[1][(j == 0) ? g.ny - 1 : j - 1];
     m.rhy_p = g.rh[1][(j == g.ny - 1) ? 0 : j + 1];
 }
-__device__ __forceinline__ void z_metrics_plane(const FgGrid& g, int k, FgMetric<3, 4>& m, FgCtx<3, 4>& fc) {
-    m.hz = g.h[2][k]; m.rhz = g.rh[2][k];
-    m.rhz_m = g.rh[2][(k == 0) ? g.nz - 1 : k - 1];
-    m.rhz_p = g.rh[2][(k == g.nz - 1) ? 0 : k + 1];
-    fc.mzm = (k == 0 && g.fixed[4]) ? 0.f : 1.f;
-    fc.mzp = (k == g.nz - 1 && g.fixed[5]) ? 0.f : 1.f;
+// p: PHYSICAL plane; flip: the chunk marches downward, i.e. its logical -z / +z neighbours are the physical +z / -z ones
+__device__ __forceinline__ void z_metrics_plane(const FgGrid& g, int p, bool flip, FgMetric<3, 4>& m, FgCtx<3, 4>& fc) {
+    m.hz = g.h[2][p]; m.rhz = g.rh[2][p];
+    const float rh_lo = g.rh[2][(p == 0) ? g.nz - 1 : p - 1], rh_hi = g.rh[2][(p == g.nz - 1) ? 0 : p + 1];
+    const float m_lo = (p == 0 && g.fixed[4]) ? 0.f : 1.f, m_hi = (p == g.nz - 1 && g.fixed[5]) ? 0.f : 1.f;
+    m.rhz_m = flip ? rh_hi : rh_lo; m.rhz_p = flip ? rh_lo : rh_hi;
+    fc.mzm = flip ? m_hi : m_lo; fc.mzp = flip ? m_lo : m_hi;
 }
 
 enum { MODE_APPLY = 0, MODE_RELAX = 1, MODE_CG_AP = 2 };
@@ -69,6 +70,12 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
                                                               int ZC) {
     constexpr int TY = ZT<BXL>::TY, LP = ZT<BXL>::LP, LROWS = ZT<BXL>::LROWS;
     const ZCtx c = z_make_ctx<BXL>(g, tiles_x, tiles_y, zchunks, ZC);
+    // Odd z-chunks march DOWNWARD (round 4, as fg_bicgstab3d.hip): a chunk and its neighbour then touch the planes they share --
+    // each other's z halo, 2 / ZC of the loads -- at the same time, and the second reader finds them in the XCD's L2.  The march
+    // itself runs in logical plane indices k0 .. k1-1 as before; phys() maps a logical plane (halo planes k0-1 and k1 included)
+    // to the plane in memory, and z_metrics_plane swaps the roles of the z neighbours.
+    const bool flip = ((c.k0 / ZC) & 1) != 0;
+    auto phys = [&](int k) { return flip ? (c.k0 + c.k1 - 1 - k) : k; };
     float beta = 0.f;
     bool use_prev = false;
     unsigned tile_id = 0;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
     struct Staged { FgVec<4> p, a; Halo hp, ha; };
     auto stage = [&](int k) -> Staged {  // global loads of one plane (centre + this thread's halo duty)
         Staged r;
-        const unsigned so = (unsigned)z_plane(g, k) * plane_b;
+        const unsigned so = (unsigned)z_plane(g, phys(k)) * plane_b;
         r.p = z_bload4(R_x, vo_c, so);
         r.hp = z_load_halo<BXL>(c, R_x, vo_hy, vo_hx, so);
         if constexpr (MODE == MODE_CG_AP) {
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
     FgVec<4> bvec[PPB];
     if constexpr (MODE == MODE_RELAX) {
 #pragma unroll
-        for (int u = 0; u < PPB; ++u) bvec[u] = z_bload4(R_x2, vo_c, (unsigned)min(c.k0 + u, g.nz - 1) * plane_b);
+        for (int u = 0; u < PPB; ++u) bvec[u] = z_bload4(R_x2, vo_c, (unsigned)phys(min(c.k0 + u, c.k1 - 1)) * plane_b);
     }
     __syncthreads();
     float dot = 0.f;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
     float gz_c[4], face_zm[4];
     bool have_carry = false;
     auto plane = [&](int k, int sm, int sc, int sp, const FgVec<4>& bv) {
-        z_metrics_plane(g, k, m, fc);
+        z_metrics_plane(g, phys(k), flip, m, fc);
         const float4 P_c = *reinterpret_cast<const float4*>(&ring_p[sc][cen]);
         const float4 A_c = *reinterpret_cast<const float4*>(&ring_a[sc][cen]);
         float pcv[4] = {P_c.x, P_c.y, P_c.z, P_c.w};
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
         for (int e = 0; e < 4; ++e) {
             if constexpr (MODE == MODE_RELAX) {
                 float v = pcv[e] + a.omega * (bv.v[e] - y[e]) * __builtin_amdgcn_rcpf(dg[e]);  // v_rcp_f32 (1 ulp): the IEEE division was ~10 VALU ops per cell in a VALU-bound kernel
-                if (a.color >= 0 && (((c.i0 + e + c.j + k) & 1) != a.color)) v = pcv[e];
+                if (a.color >= 0 && (((c.i0 + e + c.j + phys(k)) & 1) != a.color)) v = pcv[e];
                 out.v[e] = v;
             } else {
                 out.v[e] = y[e];
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
             }
         }
         if (c.valid) {
-            const unsigned so = (unsigned)k * plane_b;
+            const unsigned so = (unsigned)phys(k) * plane_b;
             if constexpr (MODE == MODE_CG_AP) {
                 z_bstore4(R_y2, vo_c, so, out);  // Ap
                 FgVec<4> pc_;
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
             FgVec<4> bnext;
             if (more) {
                 nxt = stage(k + 2);
-                if constexpr (MODE == MODE_RELAX) bnext = z_bload4(R_x2, vo_c, (unsigned)(k + 1) * plane_b);
+                if constexpr (MODE == MODE_RELAX) bnext = z_bload4(R_x2, vo_c, (unsigned)phys(k + 1) * plane_b);
             }
             __builtin_amdgcn_sched_barrier(0);
             plane(k, sm, sc, sp, bvec[0]);
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
 #pragma unroll
             for (int u = 0; u < PPB; ++u) {
                 nxt[u] = stage(k + PPB + 1 + u);
-                if constexpr (MODE == MODE_RELAX) bnext[u] = z_bload4(R_x2, vo_c, (unsigned)min(k + PPB + u, g.nz - 1) * plane_b);
+                if constexpr (MODE == MODE_RELAX) bnext[u] = z_bload4(R_x2, vo_c, (unsigned)phys(min(k + PPB + u, c.k1 - 1)) * plane_b);
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -271,9 +271,10 @@ extern "C" int fg_dacc_host_sum(const double* values, int64_t n, double plain, d
     memset(&a, 0, sizeof(a));
     a.plain = plain;
     for (int64_t i = 0; i < n; ++i) {
-        long long k[4];
+        long long k[5];
         if (!fg_dacc_split(values[i], k)) { a.poison += 1; continue; }
         for (int q = 0; q < 4; ++q) a.w[q] += (unsigned long long)k[q];
+        a.w4 += (unsigned long long)k[4];
     }
     *out_sum = fg_dacc_host_value(a);
     return FG_OK;

@@ -1,0 +1,64 @@
+"""BASELINE config 3 at its full per-GPU size -- "2D Rayleigh-Benard convection, 512x128, batch=256 sharded across 8 GPUs" = 32 envs of
+512 x 128 per GPU (``RBC2D-baseline-v0``): one native PISO step of the whole batch (passive scalar, buoyancy hook, heater profile on
+the bottom plate) from the env's randomised state, envs 0 and 31 against the oracle's direct solves with the reference's
+PRE_VELOCITY_SETUP hook (rbc_env_base.py:285-297); then one ``env.step`` with the iteration counts of its solves (Helmholtz-
+preconditioned BiCGStab, FD-preconditioned CG) reported."""
+import numpy as np
+import pytest
+import torch
+
+import fluidgym_amd
+from oracle import piso_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+B = 32
+
+
+def test_rbc_full_batch_step_matches_oracle_and_env_steps():
+    env = fluidgym_amd.make("RBC2D-baseline-v0", num_envs=B)
+    try:
+        env.reset(seed=4)
+        ns = env._domain.solver
+        assert (ns.nx, ns.ny, ns.B) == (512, 128, B)
+        env.step(env.sample_action())                         # heaters on, a developing state
+        g = torch.Generator(device="cpu").manual_seed(5)
+        u0 = (ns.velocity.cpu() + 0.02 * torch.randn(ns.velocity.shape, generator=g)).contiguous()
+        T0 = ns.scalar.cpu().clone()
+        ns.velocity.copy_(u0.to(ns.device))
+        ns.copy_velocity_result_from_blocks()
+        bscal = {f: ns.bscal[f].cpu().numpy().astype(np.float64) for f in (2, 3)}
+        assert float(np.abs(bscal[2][0] - bscal[2][B - 1]).max()) > 0 or float((T0[0] - T0[B - 1]).abs().max()) > 0   # envs differ
+        dt = 0.5 * float(env._dt)
+        ok, stats = ns.piso_step(dt, advection_tol=1e-7, pressure_tol=1e-7, buoyancy_axis=1, buoyancy_factor=float(env._buoyancy_factor))
+        assert ok, stats
+        vel, T = ns.velocity.cpu().numpy().astype(np.float64), ns.scalar.cpu().numpy().astype(np.float64)
+        edges = [np.concatenate([[0.0], np.cumsum(np.asarray(w, np.float64))]) for w in ns.widths[:2]]
+        grid = O.Grid(O.rectilinear_coords(edges))
+
+        def buoyancy(d, _dt):
+            s = np.zeros_like(d.velocity)
+            s[1] = float(env._buoyancy_factor) * d.scalar[0]
+            d.velocity_source = s
+
+        for b in (0, B - 1):
+            bc = {f: O.FixedBC(velocity=np.zeros(2), scalar=bscal[f][b], scalar_types=[O.DIRICHLET]) for f in (2, 3)}
+            ref = O.Domain(grid, float(env._nu), u0[b].numpy().astype(np.float64), np.zeros(grid.shape), bc,
+                           scalar=T0[b].numpy().astype(np.float64), scalar_viscosity=[float(env._kappa)])
+            O.piso_split_step(ref, dt, prep_fn={"PRE_VELOCITY_SETUP": [buoyancy]})
+            # (the velocity is small in this developing state, |u| ~ 1e-2, while the buoyancy term the projection has to cancel is
+            # O(dt T): the error scale is the larger of the two, as in tests/test_gpu_parity.py::test_buoyancy_fused_rbc_like_step)
+            scale = max(float(np.abs(ref.velocity).max()), dt * float(env._buoyancy_factor) * float(np.abs(T0[b].numpy()).max()))
+            es, ev = rel_err(T[b], ref.scalar), float(np.abs(vel[b] - ref.velocity).max()) / scale
+            print(f"RBC_B32_ERR env {b}: scalar {es:.2e} velocity {ev:.2e} (max|u| {np.abs(ref.velocity).max():.2e}, forcing scale {scale:.2e})")
+            assert es < 3e-5 and ev < 1e-4, (b, es, ev)
+        ns.solver_counters(reset=True)
+        obs, reward, term, trunc, info = env.step(env.sample_action())
+        c = ns.solver_counters()
+        assert torch.isfinite(reward).all() and all(torch.isfinite(v).all() for v in obs.values())
+        assert c["scalar"]["mean"] > 0 and c["velocity"]["mean"] > 0 and c["velocity"]["max"] < 30 and c["pressure0"]["max"] < 100
+        assert sum(v.get("unconverged", 0) for v in c.values() if isinstance(v, dict)) == 0
+        print("RBC2D-baseline-v0 x 32 iterations per solve:", {k: (v["mean"], v["max"]) for k, v in c.items() if isinstance(v, dict) and v["systems"]})
+    finally:
+        env.close()

@@ -17,17 +17,19 @@ from tests.helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 
-ENV_ID, B = "ChannelJet2D-large-v0", 64
+B = 64
 
 
-def test_large_channel_batch_step_matches_oracle_and_env_steps():
-    env = fluidgym_amd.make(ENV_ID, num_envs=B)
+# BASELINE config 5's share (512 x 256) and config 2 at its full size (256 x 128: the headline workload of bench.py), 64 envs each
+@pytest.mark.parametrize("env_id,grid", [("ChannelJet2D-large-v0", (512, 256)), ("ChannelJet2D-v0", (256, 128))])
+def test_large_channel_batch_step_matches_oracle_and_env_steps(env_id, grid):
+    env = fluidgym_amd.make(env_id, num_envs=B)
     try:
         env.reset(seed=3, randomize=False)
         dom = env._domain
         blk = dom.getBlock(0)
         nx, ny = env._x, env._y
-        assert (nx, ny) == (512, 256) and blk.velocity.shape == (B, 2, ny, nx)
+        assert (nx, ny) == grid and blk.velocity.shape == (B, 2, ny, nx)
         # perturbed state, different per env; jets blowing at different strengths
         g = torch.Generator(device="cpu").manual_seed(11)
         noise = 0.05 * torch.randn((B, 2, ny, nx), generator=g)
@@ -69,6 +71,6 @@ def test_large_channel_batch_step_matches_oracle_and_env_steps():
         assert c["piso_steps"] >= env.n_sim_steps
         assert c["velocity"]["mean"] > 0 and c["velocity"]["max"] < 50
         assert c["pressure0"]["max"] < 200
-        print("config 5 iterations per solve:", {k: (v["mean"], v["max"]) for k, v in c.items() if isinstance(v, dict) and v["systems"]})
+        print(f"{env_id} x {B} iterations per solve:", {k: (v["mean"], v["max"]) for k, v in c.items() if isinstance(v, dict) and v["systems"]})
     finally:
         env.close()
