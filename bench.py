@@ -116,14 +116,19 @@ KERNEL_DOC = {
 
 def pmc_traffic(kernel):
     """Memory-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r03_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
+    (profiles/r04_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
     fetch counter as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so this
     is the last profiled run, not this run; None when the file has no row for the kernel."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-    except (OSError, ValueError):
+    t = None
+    for name in ("r04_traffic.json", "r03_traffic.json"):      # (the newest committed profile of this command)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            src = name
+            break
+        except (OSError, ValueError):
+            continue
+    if t is None:
         return None
     key = {"k_tridiag_y": "k_tridiag_y_lds"}.get(kernel, kernel)
     row = t["kernels"].get(key)
@@ -132,7 +137,7 @@ def pmc_traffic(kernel):
     if isinstance(row, list):
         row = row[0]
     return {"fetch_bytes_per_launch": row["fetch_bytes"], "write_bytes_per_launch": row["write_bytes"],
-            "launches_averaged": row["launches"], "unit": "B", "source": "profiles/r03_traffic.json (rocprofv3 --pmc, "
+            "launches_averaged": row["launches"], "unit": "B", "source": f"profiles/{src} (rocprofv3 --pmc, "
             "separate FETCH_SIZE and WRITE_SIZE passes of bench.py; averages include launches that found every "
             "system converged; Infinity-Cache hits are counted)"}
 
@@ -461,6 +466,12 @@ def _leg_summary(leg):
     for k in ("capped_solves", "launches_per_piso_step", "oracle_iters", "busy_cus"):
         if leg.get(k) is not None:
             s[k] = _r(leg[k])
+    # adaptive-CFL sub-steps make an env step as long as the flow is fast (RBC: 1.35 sub-steps per sim step two env steps after a
+    # reset, 2.9 eight steps later): PISO steps per second is the figure that compares across states
+    sub, n_sim = leg.get("mean_substeps_per_sim_step"), leg.get("piso_steps_per_env_step")
+    if sub is not None and n_sim and leg.get("ms_per_step"):
+        s["substeps"] = _r(sub, 3)
+        s["piso_steps_per_s"] = _r(leg.get("envs", 1) * n_sim * sub / (leg["ms_per_step"] * 1e-3), 4)
     return s
 
 

@@ -473,7 +473,13 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expe
     const long live_tiles = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * batch;
     const bool tiled = big_blocks >= 512 || live_tiles >= 384;
     const int slot = fg_prof_slot(s, tiled ? FG_PK_GEMM : FG_PK_GEMM_SK, g.flags, batch, bytes, 2.0 * g.M * g.N * g.K, st);
-    if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
+    if (g.M <= 64 && g.K == 64 && (long)((g.N + 127) / 128) * batch >= 256) {
+        // the z transform of a 64-plane grid (TCF 128 x 64 x 64: M = K = nz = 64, N = ny nx): a 64 x 128 tile with the WHOLE K in one
+        // stage -- the 128 x 128 tile below spent half its MFMAs on padding rows and four barrier pairs on a K of 64 (round 4:
+        // 21 us per transform at 24 TFLOP/s; the transform moves 34 MB per launch, i.e. ~7 us of traffic)
+        const int tn = (g.N + 127) / 128;
+        FG_LAUNCH_P(s, slot, (k_gemm_f32<1, 2, 64>), dim3((unsigned)(tn * batch)), dim3(256), 0, st, g, tn, 1);
+    } else if (big_blocks >= 512) {  // >= 2 workgroups per CU with the 128 x 128 tile
         const int tn = (g.N + 127) / 128, tm = (g.M + 127) / 128;
         FG_LAUNCH_P(s, slot, (k_gemm_f32<2, 2, 16>), dim3((unsigned)(tn * tm * batch)), dim3(256), 0, st, g, tn, tm);
     } else if (live_tiles >= 384) {

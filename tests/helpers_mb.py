@@ -174,6 +174,31 @@ def cylinder_3d_small(res=4, res_z=3, nu=0.01):
     return s
 
 
+def cylinder_2d(res=8, nu=0.01, noise=0.02):
+    """The reference's five-block cylinder mesh (envs/cylinder/grid.py) in 2-D at a small resolution (``resolution 8``), inflow /
+    outflow / wall values perturbed a little; the outflow face is rescaled so that the boundary fluxes balance (what
+    balance_boundary_fluxes does for the env)."""
+    from fluidgym_amd.envs.cylinder_grid import make_vortex_street_mesh
+
+    m = make_vortex_street_mesh(res)
+    F = {"-x": 0, "+x": 1, "-y": 2, "+y": 3}
+    s = Spec(2, nu)
+    s.blocks = [c.astype(np.float64) for c in m.coords]
+    rng = np.random.default_rng(16)
+    s.fixed = []
+    for (b, f), v in m.fixed.items():
+        face_cells = s.blocks[b].shape[2 if F[f] >= 2 else 1] - 1
+        v = np.broadcast_to(np.asarray(v, np.float64).reshape(2, -1), (2, face_cells))
+        s.fixed.append((b, F[f], v + noise * rng.standard_normal(v.shape)))
+    s.connections = [(c[0], F[c[1]], c[2], F[c[3]], F[c[4]]) for c in m.connections]
+    fl = face_fluxes(s.oracle())
+    # the face with the largest outward flux is the outflow: scale it so that everything balances
+    out_key = max(fl, key=lambda k: fl[k])
+    k = -sum(v for key, v in fl.items() if key != out_key) / fl[out_key]
+    s.fixed = [(b, f, v * k if (b, f) == out_key else v) for b, f, v in s.fixed]
+    return s
+
+
 def face_fluxes(d):
     """Outward contravariant flux through every prescribed face of an oracle domain: {(block, face): flux}."""
     out = {}

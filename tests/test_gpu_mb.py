@@ -142,7 +142,57 @@ def test_assembly_matches_oracle_on_strongly_skewed_meshes(spec_fn):
     dom.close()
 
 
-AIRFOIL_U_BOUND, AIRFOIL_P_BOUND = 1.0, 1.0     # (set from the measured figures: see the AIRFOIL_STEP_ERR line of the GPU log)
+AIRFOIL_U_BOUND, AIRFOIL_P_BOUND = 2e-4, 2e-4     # measured 3.9e-5 / 4.8e-5 (the AIRFOIL_STEP_ERR line of the GPU log)
+
+
+def _projected_field_errors(d, trace, p_gpu, u_gpu, res_gpu, A, label):
+    """Velocity and pressure of a whole step against the oracle's with the ill-determined directions of the oracle's pressure matrix
+    removed from the pressure DIFFERENCE (see test_airfoil_mesh_step_matches_the_oracle); prints the raw figures too."""
+    P, prhs, u_ref = trace["P"], trace["prhs"], trace["u_new"]
+    err_u = _rel(u_gpu, u_ref)
+    err_u_l2 = float(np.sqrt(np.mean((u_gpu - u_ref) ** 2)) / np.sqrt(np.mean(u_ref ** 2)))
+    U, S, Vt = np.linalg.svd(d.dense(P))
+    nz = S > 1e-13 * S[0]                                     # (an exactly singular matrix: its null space takes no part)
+    p_star = Vt[nz].T @ ((U[:, nz].T @ prhs) / S[nz])
+    sig_cut = max(res_gpu, 1e-9) * np.sqrt(len(S)) / (1e-2 * np.abs(p_star - p_star.mean()).max())
+    keep = S >= sig_cut
+    proj = lambda x: Vt[keep].T @ (Vt[keep] @ x)
+    delta = p_gpu - p_star
+    err_p = float(np.abs(proj(delta)).max() / np.abs(proj(p_star)).max())
+    u_fix = d.correct_velocity(trace["h"], p_gpu - (delta - proj(delta)), A)
+    err_u_fix = _rel(u_fix, u_ref)
+    print(f"{label} velocity max-norm {err_u:.2e} rms {err_u_l2:.2e}; with the pressure difference along the {int((~keep).sum())} of {len(S)} "
+          f"directions below sigma {sig_cut:.2e} (sigma_max {S[0]:.2e}, sigma_min {S[-1]:.2e}) removed: velocity {err_u_fix:.2e}, pressure {err_p:.2e}; "
+          f"max|p*| {np.abs(p_star - p_star.mean()).max():.2e}, GPU residual {res_gpu:.2e}")
+    return err_u, err_u_fix, err_p
+
+
+def test_cylinder_mesh_step_fields_match_the_oracle():
+    """The same field comparison on the reference's cylinder mesh at resolution 8 (five blocks, a cycle of connections around the
+    cylinder): one corrector, refined BiCGStab at 1e-7 -- here the raw velocity must agree as well (the mesh has no 1e-4-area cells)."""
+    spec = H.cylinder_2d(8)
+    d = spec.oracle()
+    assert abs(sum(H.face_fluxes(d).values())) < 1e-10
+    dom = spec.native(batch=1)
+    u0, p0 = _state(d, 33, scale=0.05)
+    u0[0] += 1.0
+    st = [(u0, p0)]
+    _load(dom, st)
+    its = dom.piso_step([5e-3], corrector_steps=1, advection_tol=1e-7, pressure_tol=1e-7, pressure_use_bicgstab=2,
+                        pressure_project_mean=True, max_iterations=3000, raise_on_failure=False)
+    assert (dom.env_status() <= 1).all()
+    trace = {}
+    trace["u_new"], _ = d.piso_step(st[0][0], st[0][1], 5e-3, trace=trace, corrector_steps=1)
+    p_gpu = dom.pressure[0].cpu().numpy().astype(np.float64)
+    u_gpu = dom.velocity[0].cpu().numpy().astype(np.float64)
+    res_gpu = float(np.sqrt(np.mean((d.apply(trace["P"], p_gpu) - trace["prhs"]) ** 2)))
+    err_u, err_u_fix, err_p = _projected_field_errors(d, trace, p_gpu, u_gpu, res_gpu, trace["C"][0], f"CYLINDER8_STEP_ERR (iterations {its})")
+    assert err_u_fix < 2e-4 and err_p < 2e-4 and err_u < CYLINDER8_RAW_U_BOUND
+    dom.close()
+
+
+CYLINDER8_RAW_U_BOUND = 5e-2     # measured 1.3e-2 (the refined BiCGStab ends at a residual of 3.5e-5 on this mesh after 383 iterations)
+
 
 
 def test_airfoil_mesh_step_matches_the_oracle():
@@ -187,21 +237,22 @@ def test_airfoil_mesh_step_matches_the_oracle():
     worst = int(np.abs(u_gpu - u_ref).max(axis=0).argmax())
     D = d.dense(P)
     U, S, Vt = np.linalg.svd(D)
-    # a residual difference e moves the pressure by e / sigma along a singular direction: keep the directions along which the
-    # two residual levels (GPU 5e-6, oracle's mean-removed least-squares solution 1e-3 rms) cannot move it by more than 1 % of max|p|
-    p_ls = trace["p0"] - trace["p0"].mean()
-    sig_cut = max(res_gpu, res_ls) * np.sqrt(len(S)) / (1e-2 * np.abs(p_ls).max())
+    # The matrix is not exactly singular on this mesh (sigma_min / sigma_max ~ 3e-6, the constant is not its null vector), so the
+    # system has ONE solution p* = V S^-1 U^T b, and a residual e moves the pressure by (u_i . e) / sigma_i along singular direction
+    # i.  The GPU's iterate leaves res_gpu; the directions along which that residual level cannot move the pressure by more than
+    # 1 % of max|p*| are the ones a comparison can hold -- the others (the near-constant mode and the modes living on the 1e-4-area
+    # cells at the nose) are removed from the pressure DIFFERENCE, in the pressure and in the velocity correction it drives.
+    p_star = Vt.T @ ((U.T @ prhs) / S)
+    sig_cut = res_gpu * np.sqrt(len(S)) / (1e-2 * np.abs(p_star - p_star.mean()).max())
     keep = S >= sig_cut
     proj = lambda x: Vt[keep].T @ (Vt[keep] @ x)
-    pg, po = proj(p_gpu - p_gpu.mean()), proj(p_ls)
-    err_p = float(np.abs(pg - po).max() / np.abs(po).max())
-    # the velocity with the same directions removed from the pressure difference: u_gpu + (1/A) grad(delta_null)
-    delta = (p_gpu - p_gpu.mean()) - p_ls
-    u_fix = d.correct_velocity(trace["h"], (p_gpu - p_gpu.mean()) - (delta - proj(delta)), A)
+    delta = p_gpu - p_star
+    err_p = float(np.abs(proj(delta)).max() / np.abs(proj(p_star)).max())
+    u_fix = d.correct_velocity(trace["h"], p_gpu - (delta - proj(delta)), A)
     err_u_fix = _rel(u_fix, u_ref)
     print(f"AIRFOIL_STEP_ERR velocity max-norm {err_u:.2e} (worst cell {worst}) rms {err_u_l2:.2e}; with the pressure difference along the "
           f"{int((~keep).sum())} of {len(S)} directions below sigma {sig_cut:.2e} (sigma_max {S[0]:.2e}, sigma_min {S[-1]:.2e}) removed: velocity {err_u_fix:.2e}, "
-          f"pressure {err_p:.2e}; max|p| {np.abs(p_ls).max():.2e}")
+          f"pressure {err_p:.2e}; max|p*| {np.abs(p_star - p_star.mean()).max():.2e}, GPU residual {res_gpu:.2e}")
     assert err_u_fix < AIRFOIL_U_BOUND and err_p < AIRFOIL_P_BOUND
     dom.close()
 
