@@ -482,11 +482,24 @@ __global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bn
         const fg_real* __restrict__ h0 = (ax == 0) ? g.h[1] : g.h[0];
         const fg_real* __restrict__ h1 = (DIMS == 3) ? ((ax == 2) ? g.h[1] : g.h[2]) : nullptr;
         const fg_real* __restrict__ v = bnd.vel[f] + ((size_t)b * DIMS + ax) * slab_n;
-        for (int i1 = wave; i1 < n1; i1 += FG_BLOCK / 64) {
-            const fg_real a1 = h1 ? h1[i1] : 1.f;
-            double row = 0.0;  // per-cell products in fp32 like the reference's flux, sums in fp64
-            for (int i0 = lane; i0 < n0; i0 += 64) row += (double)(v[(size_t)i1 * n0 + i0] * (h0[i0] * a1));
-            acc += sgn * row;
+        // rows in groups of four per wave with all their loads requested together: one workgroup per env walks the whole slab, so
+        // the loop is a latency chain (TCF 128 x 64 x 64: 31 us with one row in flight per wave; the sum order per thread -- row by
+        // row, products in fp32, sums in fp64 -- is unchanged)
+        constexpr int RU = 4, WV = FG_BLOCK / 64;
+        for (int i1b = wave; i1b < n1; i1b += WV * RU) {
+            for (int i0 = lane; i0 < n0; i0 += 64) {
+                fg_real val[RU], a1[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int i1 = i1b + u * WV;
+                    const bool ok = i1 < n1;
+                    a1[u] = ok ? (h1 ? h1[i1] : (fg_real)1) : (fg_real)0;
+                    val[u] = ok ? v[(size_t)i1 * n0 + i0] : (fg_real)0;
+                }
+                const fg_real w0 = h0[i0];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) acc += sgn * (double)(val[u] * (w0 * a1[u]));
+            }
         }
     }
     __shared__ double lds[4];
