@@ -47,11 +47,16 @@ struct BicgFused {
 // k_bicgf_a / k_bicgf_b (fg_bicgstab.hip), shared with the z-marching kernels; the results are made wave-uniform (SGPRs) so that
 // the branches on them are scalar branches.
 __device__ __forceinline__ float fg_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double fg_uniform(double v) {
+    const long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ int fg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 struct BicgDecA {
     int mode[3];   // 0 skip | 1 full update | 2 converged on s: x += alpha p only | 3 first iteration: v = C p
-    float alpha[3], omega[3], beta[3];
+    fg_real alpha[3], omega[3], beta[3];
     bool restart[3];
     bool any;
 };
@@ -61,13 +66,13 @@ __device__ __forceinline__ BicgDecA fg_bicgf_decide_a(const FgGrid& g, const Bic
     D.any = false;
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
-        D.mode[comp] = 0; D.alpha[comp] = D.omega[comp] = D.beta[comp] = 0.f; D.restart[comp] = false;
+        D.mode[comp] = 0; D.alpha[comp] = D.omega[comp] = D.beta[comp] = 0; D.restart[comp] = false;
         if (comp >= q.nc) continue;
         const int sys = b * q.nc + comp;
         const int f = flag_ld(q.flags + (sys));
         if (f != 0 && f != 4) continue;      // (4: stored by this env's leader in THIS launch; s.s below gives the same verdict)
         FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-        int mode = 0; float alpha = 0.f, omega = 0.f, beta = 0.f; bool restart = false;
+        int mode = 0; fg_real alpha = 0, omega = 0, beta = 0; bool restart = false;
         if (it == 0 && fold0) {
             // r_0.r_0 is summed by this very launch: rho_0 is parked as NaN (kernel b(0) substitutes r.r, as after a restart) and
             // kernel b(0) judges the start vector
@@ -88,16 +93,16 @@ __device__ __forceinline__ BicgDecA fg_bicgf_decide_a(const FgGrid& g, const Bic
                 mode = 3;
             }
         } else {
-            const float crit_s = fg_rms(acc_ld(a + (F_SS + pe)), g.n);
+            const fg_real crit_s = fg_rms(acc_ld(a + (F_SS + pe)), g.n);
             alpha = sc_ld(q.sc + (sys * 2 + 0));
             if (!(crit_s >= q.tol)) {   // converged on s (bicgstab_solver_kernel.cu:305-329), or s.s not finite
                 if (leader) fg_mark(q.flags, q.info, sys, crit_s, it - 1, 4);
                 if (isfinite(crit_s)) mode = 2;
             } else {
-                const float omega_raw = (float)(acc_ld(a + (F_TS + pe)) / acc_ld(a + (F_TT + pe)));
-                omega = isfinite(omega_raw) ? omega_raw : 0.f;
+                const fg_real omega_raw = (fg_real)(acc_ld(a + (F_TS + pe)) / acc_ld(a + (F_TT + pe)));
+                omega = isfinite(omega_raw) ? omega_raw : (fg_real)0;
                 const double rho_new = acc_ld(a + (F_RS + pe)) - (double)omega * acc_ld(a + (F_RT + pe));
-                beta = (float)(rho_new / acc_ld(a + (F_RHOE + pe))) * (alpha / omega);
+                beta = (fg_real)(rho_new / acc_ld(a + (F_RHOE + pe))) * (alpha / omega);
                 restart = !isfinite(beta);   // rho of the previous iteration exactly 0, or omega 0: rw = p = r, rho = r.r
                 if (leader) {
                     sc_st(q.sc + (sys * 2 + 1), omega);
@@ -118,7 +123,7 @@ __device__ __forceinline__ BicgDecA fg_bicgf_decide_a(const FgGrid& g, const Bic
 
 struct BicgDecB {
     bool work[3];
-    float alpha[3];
+    fg_real alpha[3];
     bool any;
 };
 __device__ __forceinline__ BicgDecB fg_bicgf_decide_b(const FgGrid& g, const BicgPtrs& q, int b, int it, bool leader) {
@@ -127,7 +132,7 @@ __device__ __forceinline__ BicgDecB fg_bicgf_decide_b(const FgGrid& g, const Bic
     D.any = false;
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
-        D.work[comp] = false; D.alpha[comp] = 0.f;
+        D.work[comp] = false; D.alpha[comp] = 0;
         if (comp >= q.nc) continue;
         const int sys = b * q.nc + comp;
         const int f = flag_ld(q.flags + (sys));
@@ -135,15 +140,15 @@ __device__ __forceinline__ BicgDecB fg_bicgf_decide_b(const FgGrid& g, const Bic
         if (f != 0) continue;
         FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
         const double rr = acc_ld(a + (F_RR + e));
-        const float crit = fg_rms(rr, g.n);
-        bool work = false; float alpha = 0.f;
+        const fg_real crit = fg_rms(rr, g.n);
+        bool work = false; fg_real alpha = 0;
         if (!(crit >= q.tol)) {
             if (leader) fg_mark(q.flags, q.info, sys, crit, it == 0 ? -1 : it);
         } else {
             double rho = acc_ld(a + (F_RHOE + e));
             if (isnan(rho)) rho = rr;                       // breakdown restart decided by kernel a: rw = r, rho = r.r
-            const float alpha_raw = (float)(rho / acc_ld(a + (F_RV + e)));
-            alpha = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
+            const fg_real alpha_raw = (fg_real)(rho / acc_ld(a + (F_RV + e)));
+            alpha = isfinite(alpha_raw) ? alpha_raw : (fg_real)0;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
             if (leader) {
                 q.info[sys].final_residual = crit;
                 q.info[sys].used_iterations = it - 1;

@@ -449,51 +449,16 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
     const size_t N = g.n;
     const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
     const int e = it & 1, pe = e ^ 1;
-    // per-system decisions, taken by every workgroup of the env from the same accumulator words
-    int mode[3] = {0, 0, 0};   // 0 skip | 1 full update | 2 converged on s: x += alpha p only | 3 first iteration: v = C p
-    fg_real alpha[3], omega[3], beta[3];
-    bool restart[3];
-    bool any = false;
-    for (int comp = 0; comp < q.nc; ++comp) {
-        alpha[comp] = omega[comp] = beta[comp] = 0.f; restart[comp] = false;
-        const int sys = c.b * q.nc + comp;
-        const int f = flag_ld(q.flags + (sys));
-        // 4 = "converged on s" stored by this env's leader in THIS launch (k_bicgf_b turns every 4 into 1 before the next one):
-        // a workgroup that reads it decides the same from s.s below
-        if (f != 0 && f != 4) continue;
-        FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-        if (it == 0) {
-            const double rr0 = acc_ld(a + (F_RR + 0));
-            if (!(fg_rms(rr0, g.n) >= q.tol)) continue;   // the start vector already meets the tolerance: k_bicgf_b(0) marks it
-            if (leader) {
-                acc_st(a + (F_RHOE + 0), rr0);             // rho_0 = rw.r_0 = r_0.r_0
-                acc_st(a + (F_SS + 0), 0.0); acc_st(a + (F_TS + 0), 0.0); acc_st(a + (F_TT + 0), 0.0);
-                acc_st(a + (F_RS + 0), 0.0); acc_st(a + (F_RT + 0), 0.0);
-            }
-            mode[comp] = 3; any = true;
-            continue;
-        }
-        const fg_real crit_s = fg_rms(acc_ld(a + (F_SS + pe)), g.n);
-        alpha[comp] = sc_ld(q.sc + (sys * 2 + 0));
-        if (!(crit_s >= q.tol)) {   // converged on s (bicgstab_solver_kernel.cu:305-329), or s.s not finite
-            const bool fin = isfinite(crit_s);
-            if (leader) fg_mark(q.flags, q.info, sys, crit_s, it - 1, 4);
-            if (fin) { mode[comp] = 2; any = true; }
-            continue;
-        }
-        const fg_real omega_raw = (fg_real)(acc_ld(a + (F_TS + pe)) / acc_ld(a + (F_TT + pe)));
-        omega[comp] = isfinite(omega_raw) ? omega_raw : 0.f;
-        const double rho_new = acc_ld(a + (F_RS + pe)) - (double)omega[comp] * acc_ld(a + (F_RT + pe));
-        beta[comp] = (fg_real)(rho_new / acc_ld(a + (F_RHOE + pe))) * (alpha[comp] / omega[comp]);
-        restart[comp] = !isfinite(beta[comp]);   // rho of the previous iteration exactly 0, or omega 0: rw = p = r, rho = r.r
-        if (leader) {
-            sc_st(q.sc + (sys * 2 + 1), omega[comp]);
-            acc_st(a + (F_RHOE + e), restart[comp] ? (double)NAN : rho_new);   // NaN: k_bicgf_b takes r.r of this launch
-            acc_st(a + (F_SS + e), 0.0); acc_st(a + (F_TS + e), 0.0); acc_st(a + (F_TT + e), 0.0);
-            acc_st(a + (F_RS + e), 0.0); acc_st(a + (F_RT + e), 0.0);
-        }
-        mode[comp] = 1; any = true;
-    }
+    // per-system decisions, taken by every workgroup of the env from the same accumulator words (fg_bicg.h: shared with the
+    // z-marching kernels).  mode: 0 skip | 1 full update | 2 converged on s: x += alpha p only | 3 first iteration: v = C p
+    const bool fold = w.fold0 != 0;
+    const BicgDecA D = fg_bicgf_decide_a(g, q, c.b, it, leader, fold);
+    const int (&mode)[3] = D.mode;
+    const fg_real (&alpha)[3] = D.alpha; const fg_real (&omega)[3] = D.omega; const fg_real (&beta)[3] = D.beta;
+    const bool (&restart)[3] = D.restart;
+    const bool any = D.any;
+    // p of the previous iteration; with a folded start (zero start vector: r_0 = p_0 = rw = rhs, no init kernel) p_0 IS the right-hand side
+    const fg_real* __restrict__ p_prev = (fold && it <= 1) ? q.rhs : (it == 0 ? w.p[0] : w.p[pe]);
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
@@ -509,7 +474,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
         if (mode[comp] == 2) {
             if (c.valid) {
                 FgVec<VEC> x = fg_load<VEC>(q.x + vb + c.idx);
-                const FgVec<VEC> p = fg_load<VEC>(w.p[pe] + vb + c.idx);
+                const FgVec<VEC> p = fg_load<VEC>(p_prev + vb + c.idx);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) x.v[k] += alpha[comp] * p.v[k];
                 fg_store<VEC>(q.x + vb + c.idx, x);
@@ -518,9 +483,18 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
         }
         if (c.valid) {
             FgNbr<DIMS, VEC> P;   // p of iteration `it` at the cell and its neighbours
-            FgVec<VEC> rwv = fg_load<VEC>(q.rw + vb + c.idx);
+            FgVec<VEC> rwv;
+            if (!(mode[comp] == 3 && fold)) rwv = fg_load<VEC>(q.rw + vb + c.idx);
             if (mode[comp] == 3) {
-                P = fg_gather<DIMS, VEC>(w.p[0] + vb, c);
+                P = fg_gather<DIMS, VEC>(p_prev + vb, c);
+                if (fold) {   // rw = r_0 = rhs, x_0 = 0, r.r (what the init kernel would have done)
+                    rwv = P.c;
+                    fg_store<VEC>(q.rw + vb + c.idx, P.c);
+                    FgVec<VEC> z0;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) { z0.v[k] = 0; part[2 * comp + 1] += P.c.v[k] * P.c.v[k]; }
+                    fg_store<VEC>(q.x + vb + c.idx, z0);
+                }
             } else {
                 const fg_real al = alpha[comp], om = omega[comp], be = beta[comp];
                 // r_{it} = s - omega t at the cell and its neighbours
@@ -528,7 +502,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
                 {
                     const FgNbr<DIMS, VEC> T = fg_gather<DIMS, VEC>(q.t + vb, c);
                     FgVec<VEC> x = fg_load<VEC>(q.x + vb + c.idx);
-                    const FgVec<VEC> pold = fg_load<VEC>(w.p[pe] + vb + c.idx);
+                    const FgVec<VEC> pold = fg_load<VEC>(p_prev + vb + c.idx);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) x.v[k] += al * pold.v[k] + om * R.c.v[k];
                     fg_store<VEC>(q.x + vb + c.idx, x);
@@ -543,7 +517,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
                     fg_store<VEC>(q.rw + vb + c.idx, rwv);
                 } else {
                     // p_{it} = r + beta (p - omega v)
-                    P = fg_gather<DIMS, VEC>(w.p[pe] + vb, c);
+                    P = fg_gather<DIMS, VEC>(p_prev + vb, c);
                     const FgNbr<DIMS, VEC> V = fg_gather<DIMS, VEC>(w.v[pe] + vb, c);
                     fg_nbr_axpy<DIMS, VEC>(P, -om, V);
                     fg_nbr_scale_add<DIMS, VEC>(P, be, R);
@@ -560,7 +534,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(DIMS =
     if (threadIdx.x < 6) {
         const int comp = threadIdx.x >> 1, kind = threadIdx.x & 1;
         const int md = comp == 0 ? mode[0] : (comp == 1 ? mode[1] : mode[2]);
-        if (comp < q.nc && (md == 1 || (md == 3 && kind == 0))) {
+        if (comp < q.nc && (md == 1 || (md == 3 && (kind == 0 || fold)))) {
             FgDacc* a = q.acc + (size_t)(c.b * q.nc + comp) * FG_ACC_DOUBLES;
             acc_add(a + ((kind ? F_RR : F_RV) + e), (double)tot);
         }
@@ -575,34 +549,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
     const size_t N = g.n;
     const bool leader = (threadIdx.x == 0) && ((fg_xcd_remap(blockIdx.x, gridDim.x) % tiles) == 0);
     const int e = it & 1;
-    bool work[3] = {false, false, false};
-    fg_real alpha[3] = {0.f, 0.f, 0.f};
-    bool any = false;
-    for (int comp = 0; comp < q.nc; ++comp) {
-        const int sys = c.b * q.nc + comp;
-        const int f = flag_ld(q.flags + (sys));
-        if (f == 4) { if (leader) flag_st(q.flags + (sys), 1); continue; }   // k_bicgf_a applied x += alpha p: done
-        if (f != 0) continue;
-        FgDacc* a = q.acc + (size_t)sys * FG_ACC_DOUBLES;
-        const double rr = acc_ld(a + (F_RR + e));
-        const fg_real crit = fg_rms(rr, g.n);
-        if (!(crit >= q.tol)) {
-            if (leader) fg_mark(q.flags, q.info, sys, crit, it == 0 ? -1 : it);
-            continue;
-        }
-        double rho = acc_ld(a + (F_RHOE + e));
-        if (isnan(rho)) rho = rr;                       // breakdown restart decided by k_bicgf_a: rw = r, rho = r.r
-        const fg_real alpha_raw = (fg_real)(rho / acc_ld(a + (F_RV + e)));
-        alpha[comp] = isfinite(alpha_raw) ? alpha_raw : 0.f;   // rw.v == 0 exactly: the iteration keeps its minimal-residual half
-        if (leader) {
-            q.info[sys].final_residual = crit;
-            q.info[sys].used_iterations = it - 1;
-            sc_st(q.sc + (sys * 2 + 0), alpha[comp]);
-            acc_st(a + (F_RHOE + e), rho);              // (a workgroup that reads it after this store finds the same value)
-            acc_st(a + (F_RV + (e ^ 1)), 0.0); acc_st(a + (F_RR + (e ^ 1)), 0.0);   // filled by k_bicgf_a(it + 1)
-        }
-        work[comp] = true; any = true;
-    }
+    const BicgDecB D = fg_bicgf_decide_b(g, q, c.b, it, leader);     // (fg_bicg.h: shared with the z-marching kernels)
+    const bool (&work)[3] = D.work;
+    const fg_real (&alpha)[3] = D.alpha;
+    const bool any = D.any;
+    const fg_real* __restrict__ r_src = (w.fold0 && it == 0) ? q.rhs : q.r;      // folded start: r_0 is the right-hand side
     if (!any) return;
     FgStencilRow<DIMS, VEC> m;
     if (c.valid) m = fg_load_row<DIMS, VEC>(q.diag + (size_t)c.b * N, q.off + (size_t)c.b * 2 * DIMS * N, c, N);
@@ -616,7 +567,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
         const int sys = c.b * q.nc + comp;
         const size_t vb = (size_t)sys * N;
         if (c.valid) {
-            FgNbr<DIMS, VEC> S = fg_gather<DIMS, VEC>(q.r + vb, c);
+            FgNbr<DIMS, VEC> S = fg_gather<DIMS, VEC>(r_src + vb, c);
             {
                 const FgNbr<DIMS, VEC> V = fg_gather<DIMS, VEC>(w.v[e] + vb, c);
                 fg_nbr_axpy<DIMS, VEC>(S, -alpha[comp], V);
@@ -783,11 +734,11 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         // x, r, p, v (40 + mat B); b reads r, v, rw + the matrix and writes s, t (20 + mat B)
         BicgFused w;
         w.s = s->w[7]; w.p[0] = s->w[2]; w.p[1] = s->w[5]; w.v[0] = s->w[3]; w.v[1] = s->w[6];
-        w.fold0 = 0;
+        w.fold0 = a.use_x0 ? 0 : 1;      // zero start vector: r_0 = p_0 = rw = rhs, no init kernel (fg_bicg.h BicgFused::fold0)
 #if !FG_F64
         const bool za = zmarch3 && (s->bicg3_mix & 1), zb = zmarch3 && (s->bicg3_mix & 2);   // (FG_BICG3_MIX: the two forms share buffers and accumulators)
         // start vector zero on the z-marching kernels: r_0 = p_0 = rw = rhs, no init kernel (fg_bicg.h BicgFused::fold0; FG_BICG3_MIX & 4 keeps it)
-        w.fold0 = (za && zb && !a.use_x0 && !(s->bicg3_mix & 4)) ? 1 : 0;
+        w.fold0 = (!a.use_x0 && !(s->bicg3_mix & 4) && (za == zb)) ? 1 : 0;     // (brick and z-marching kernels alike; not when the two are mixed)
 #endif
         if (!w.fold0) FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);
 #if !FG_F64
