@@ -14,9 +14,9 @@ int fg_zmarch_relax(const fg_state*, const fg_real*, const fg_real*, const fg_re
 int fg_zmarch_cg_ap(const fg_state*, const fg_real*, const fg_real*, const fg_real*, fg_real*, fg_real*, FgDacc*, int32_t*, fg_solve_info*, int,
                     fg_real, int, int, int, int, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
 bool fg_fd_dct_supported(int) { return false; }
-int fg_fd_dct_forward(fg_state*, const fg_real*, fg_real*, hipStream_t, int) { return FG_ERR_UNSUPPORTED; }
+int fg_fd_dct_forward(fg_state*, const fg_real*, fg_real*, hipStream_t, int, const FgCgJudge*) { return FG_ERR_UNSUPPORTED; }
 int fg_fd_dct_inverse(fg_state*, const fg_real*, fg_real*, const fg_real*, FgDacc*, int, int, hipStream_t, int) { return FG_ERR_UNSUPPORTED; }
-int fg_fd_apply(fg_state*, const fg_real*, fg_real*, FgDacc*, int, int, int, hipStream_t) {
+int fg_fd_apply(fg_state*, const fg_real*, fg_real*, FgDacc*, int, int, int, hipStream_t, const FgCgJudge*) {
     fg_set_error("the fast-diagonalisation preconditioner is an fp32 kernel family: not part of the fp64 build");
     return FG_ERR_UNSUPPORTED;
 }

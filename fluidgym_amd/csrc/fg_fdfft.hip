@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "fg_internal.h"
+#include "fg_cg.h"
 
 namespace {
 
@@ -25,6 +26,7 @@ struct DctArgs {
     const int32_t* flags;                   // env b skipped when flags[b] != 0
     const float* dot_with; FgDacc* dot_acc; int dot_stride, dot_ns;   // inverse only: acc[b] += sum dst .* dot_with
     long env_stride; int rows;
+    FgCgJudge judge;                        // forward only, optional (judge.acc != nullptr): fg_cg.h
 };
 
 // PERIODIC = false: the cosine transforms above (FIXED axis).  PERIODIC = true: the real Fourier basis of a periodic uniform axis,
@@ -46,6 +48,9 @@ __global__ __launch_bounds__(256) void k_dct_rows(DctArgs a) {
     __shared__ float red[4];
     const int b = blockIdx.y;
     if (a.flags && a.flags[b] != 0) return;
+    if constexpr (!INVERSE) {
+        if (a.judge.acc && fg_cg_judge(a.judge, b, blockIdx.x == 0 && threadIdx.x == 0)) return;
+    }
     for (int k = threadIdx.x; k < N; k += 256) twl[k] = a.tw[k];   // visible after the barrier that follows the row staging
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = 2 * (blockIdx.x * 4 + wave), row1 = row0 + 1;
@@ -226,13 +231,14 @@ int launch_dct(const fg_state* s, int n, const DctArgs& a, int slot, int batch, 
 bool fg_fd_dct_supported(int n) { return n == 64 || n == 128 || n == 256 || n == 512; }
 
 // x-axis transforms of fg_fd_apply when the axis is marked as DCT (fd_dct_x): rows = ny * nz per env, length nx.
-int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st, int batch) {
+int fg_fd_dct_forward(fg_state* s, const float* r, float* out, hipStream_t st, int batch, const FgCgJudge* judge) {
     const FgGrid& G = s->grid;
     if (batch <= 0) batch = G.B;
     DctArgs a = {};
     a.src = r; a.dst = out; a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot;
     a.scale0 = s->fd_dct_fwd[0]; a.scale = s->fd_dct_fwd[1];
     a.flags = s->flags; a.env_stride = G.n; a.rows = G.ny * G.nz;
+    if (judge) a.judge = *judge;
     // per env: the row read + written; ~5 n log2 n flops per row
     const int slot = fg_prof_slot(s, FG_PK_DCT, s->flags, batch, 8.0 * G.n, 5.0 * G.n * log2((double)G.nx), st);
     return launch_dct<false>(s, G.nx, a, slot, batch, st);

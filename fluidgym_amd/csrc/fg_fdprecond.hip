@@ -6,6 +6,7 @@
 // 64 cycles / 4096 MACs per wave, bitwise an fmaf chain, cdna_hip_programming.md section 3); the
 // tridiagonal sweep streams the per-mode LU factors precomputed on the host.
 #include "fg_internal.h"
+#include "fg_cg.h"
 
 namespace {
 
@@ -21,6 +22,7 @@ struct GemmArgs {
     const int32_t* flags;                     // batch b is skipped when flags[b] != 0
     const float* dot_with; long strideW;      // optional: acc[b] += sum C .* W  (W laid out like C)
     FgDacc* dot_acc; int dot_stride; int dot_ns;  // slotted accumulator: dot_acc[b * dot_stride + (block & (ns-1))]
+    FgCgJudge judge;                          // optional (judge.acc != nullptr): residual verdict before any work, fg_cg.h
 };
 
 // C = A * B, fp32 in / fp32 accumulate on MFMA 32x32x2.  256 threads = 4 waves in a 2 x 2 arrangement,
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g, int tiles_n, int t
     const int b = id / per_b;
     if (g.flags && g.flags[b] != 0) return;
     const int rem = id - b * per_b, tile_m = rem / tiles_n, tile_n = rem - tile_m * tiles_n;
+    if (g.judge.acc && fg_cg_judge(g.judge, b, rem == 0 && threadIdx.x == 0)) return;
     __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
     const float* __restrict__ A = g.A + (size_t)b * g.strideA;
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(256) void k_gemm_sk(GemmArgs g, int tiles_n, int ti
     const int b = id / per_b;
     if (g.flags && g.flags[b] != 0) return;
     const int rem = id - b * per_b, tm = rem / tiles_n, tn = rem - tm * tiles_n;
+    if (g.judge.acc && fg_cg_judge(g.judge, b, rem == 0 && threadIdx.x == 0)) return;
     const int m0 = tm * 32, n0 = tn * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const float* __restrict__ A = g.A + (size_t)b * g.strideA;
@@ -499,25 +503,28 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expe
 
 // z = M^-1 r for all envs with flags == 0; optionally rz_acc[b * rz_stride] += r . z
 int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
-                hipStream_t st) {
+                hipStream_t st, const FgCgJudge* judge) {
     if (expect_active <= 0 || expect_active > s->grid.B) expect_active = s->grid.B;
     const FgGrid& G = s->grid;
     const int nx = G.nx, ny = G.ny, nz = G.nz, B = G.B;
     const long N = G.n;
     float* t1 = s->w[3];
     float* t2 = s->w[4];
-    GemmArgs g;
+    GemmArgs g = {};
     g.flags = s->flags; g.dot_with = nullptr; g.strideW = 0; g.dot_acc = nullptr; g.dot_stride = 0; g.dot_ns = 1;
+    g.judge = FgCgJudge{};
     if (s->fd_dct_x) {
         // uniform FIXED x axis: the basis is the DCT-II basis, applied as an FFT per row (fg_fdfft.hip)
-        if (int rc = fg_fd_dct_forward(s, r, t1, st)) return rc;
+        if (int rc = fg_fd_dct_forward(s, r, t1, st, 0, judge)) return rc;
     } else {
+        if (judge) g.judge = *judge;     // (the first kernel of the application only)
         // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]
         g.A = r; g.lda = nx; g.strideA = N;
         g.B = s->fd_Qx; g.ldb = nx; g.strideB = 0; g.Bt = s->fd_QxT; g.ldbt = nx;
         g.C = t1; g.ldc = nx; g.strideC = N;
         g.M = ny * nz; g.N = nx; g.K = nx;
         if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
+        g.judge = FgCgJudge{};
     }
     float* cur = t1;
     if (G.dims == 3) {
@@ -591,7 +598,7 @@ int fg_fd_helmholtz_apply(fg_state* s, int nc, const float* r, float* z, hipStre
     const long N = G.n;
     float* t1 = s->w[7];          // free in the five-kernel BiCGStab
     float* t2 = s->helm_tmp;
-    GemmArgs g;
+    GemmArgs g = {};
     g.flags = s->flags; g.dot_with = nullptr; g.strideW = 0; g.dot_acc = nullptr; g.dot_stride = 0; g.dot_ns = 1;
     // forward x: t1[rows, a] = sum_i r[rows, i] Qx[i, a]  (periodic x marked as a fast-transform axis: one real FFT per row)
     if (s->fd_dct_x == 2) {

@@ -797,7 +797,8 @@ int fg_prof_collect(fg_state* s, hipStream_t st);
 void fg_prof_prefetch(fg_state* s, hipStream_t st);
 void fg_prof_destroy(fg_state* s);
 bool fg_fd_dct_supported(int n);
-int fg_fd_dct_forward(fg_state* s, const fg_real* r, fg_real* out, hipStream_t st, int batch = 0);   // batch 0: the env batch
+struct FgCgJudge;   // fg_cg.h: residual verdict folded into the first kernel of a preconditioner application (nullptr: none)
+int fg_fd_dct_forward(fg_state* s, const fg_real* r, fg_real* out, hipStream_t st, int batch = 0, const FgCgJudge* judge = nullptr);   // batch 0: the env batch
 int fg_fd_dct_inverse(fg_state* s, const fg_real* u, fg_real* z, const fg_real* dot_with, FgDacc* dot_acc, int dot_stride,
                       int dot_ns, hipStream_t st, int batch = 0);
 #define FG_LAUNCH_P(s, slot, kernel, grid, block, shmem, st, ...)                                              \
@@ -811,7 +812,7 @@ int fg_fd_dct_inverse(fg_state* s, const fg_real* u, fg_real* z, const fg_real* 
     } while (0)
 // expect_active: the caller's estimate of envs still iterating (<= 0: all) -- only picks the GEMM tile shape
 int fg_fd_apply(fg_state* s, const fg_real* r, fg_real* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
-                hipStream_t st);
+                hipStream_t st, const FgCgJudge* judge = nullptr);
 // y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
 // with a live system, z = M^-1 r for every live system
 int fg_line_alloc(fg_state* s);

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "fg_internal.h"
+#include "fg_cg.h"
 #include "fg_rung64.h"
 
 namespace {
@@ -120,31 +121,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_poisson_relax(FgGrid g, const fg_r
 // iteration through cublasTdot/nrm2, cg_solver_kernel.cu:277,317,332,431).
 // flags[b]: 0 running, 1 converged, 2 non-finite residual, 3 inactive env.
 // ---------------------------------------------------------------------------------------------
-#define FG_CG_SLOTS 64
-#define FG_CG_NAMES 8  // rr ring 0..2 | pAp ring 3..4 | r.z ring 5..7 (preconditioned CG)
-
 __device__ __forceinline__ fg_real fg_rms(double rr, int n) { return (fg_real)sqrt(rr / (double)n); }
-
-__device__ __forceinline__ FgDacc* fg_acc_ptr(FgDacc* acc, int b, int name) {
-    return acc + ((size_t)b * FG_CG_NAMES + name) * FG_CG_SLOTS;
-}
-// total of an accumulator; every lane of the calling wave gets the result.  Each slot is an order-independent FgDacc and
-// the slots are summed by a fixed shuffle tree: the total does not depend on the order in which the workgroups arrived.
-__device__ __forceinline__ double fg_acc_total(const FgDacc* a, int ns) {
-    if (ns == 1) return acc_ld(a + (0));
-    const int lane = threadIdx.x & 63;
-    double v = (lane < ns) ? acc_ld(a + (lane)) : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ void fg_acc_zero(FgDacc* a, int ns) {  // called by the first wave of the leader block
-    const int lane = threadIdx.x & 63;
-    if (lane < ns) acc_st(a + (lane), 0.0);
-}
-__device__ __forceinline__ void fg_acc_add(FgDacc* a, int ns, unsigned tile, double v) {
-    acc_add(a + (tile & (unsigned)(ns - 1)), v);
-}
+// (FG_CG_SLOTS / FG_CG_NAMES, fg_acc_ptr / fg_acc_total / fg_acc_zero / fg_acc_add: fg_cg.h)
 
 // r = b - P x (or r = b when x0 == 0), accumulates rr into ring name `name`
 template <int DIMS, int VEC>
@@ -434,11 +412,14 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const int nb = a.precond ? 5 : 0;
     const int acc_stride = FG_CG_NAMES * FG_CG_SLOTS;
     fg_real* zvec = a.precond ? s->w[5] : a.r;
+    FgCgJudge judge;
+    judge.acc = s->cg_acc; judge.flags = s->flags; judge.info = s->info_dev; judge.tol = a.tol; judge.it = -1; judge.n = n; judge.ns = ns;
     if (a.precond) {
         if (!s->fd_Qx) { fg_set_error("preconditioned CG requested but fg_set_fd_preconditioner was not called"); return FG_ERR_INVALID_ARG; }
-        // residual check of x0 (sets flags for already-converged envs), then z0 = M^-1 r0, r0.z0
-        hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, (fg_solve_info*)nullptr, a.tol, -1, n, B, 0, ns);
-        if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, B, st)) return rc;
+        // z0 = M^-1 r0, r0.z0; the residual check of x0 (flags for already-converged envs) is taken by the first kernel of the
+        // application (FgCgJudge, fg_cg.h) -- as is the one after every iteration below: no k_cg_check launch outside the polls
+        judge.it = -1;
+        if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + 0) * FG_CG_SLOTS, acc_stride, ns, B, st, &judge)) return rc;
     }
     bool done = false, info_fresh = false;
     int active_est = (B + 3) / 4;  // envs expected to still iterate after the first iteration, refreshed by every poll
@@ -484,7 +465,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         });
         const bool poll = (it + 1 >= next_poll || it + 1 == a.max_iterations);
         if (poll) next_poll = it + 1 + check_every;
-        if (a.precond || poll) {
+        if (poll) {
             const int final_pass = (it + 1 == a.max_iterations);
             hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, poll ? s->info_pinned : nullptr, a.tol, it,
                                n, B, final_pass, ns);
@@ -510,7 +491,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         }
         if (a.precond && it + 1 < a.max_iterations) {
             // z = M^-1 r and r.z of the next iteration (envs that just converged are skipped via flags)
-            if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + (it + 1) % 3) * FG_CG_SLOTS, acc_stride, ns, active_est, st))
+            judge.it = it;
+            if (int rc = fg_fd_apply(s, a.r, zvec, s->cg_acc + (size_t)(nb + (it + 1) % 3) * FG_CG_SLOTS, acc_stride, ns, active_est, st, &judge))
                 return rc;
         }
     }
