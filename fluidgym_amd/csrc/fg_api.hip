@@ -251,6 +251,7 @@ extern "C" int fg_debug_apply_preconditioner(fg_handle s, int mode, int nc, cons
     FG_REQUIRE(s && r && z && nc >= 1 && nc <= s->grid.dims && (mode == 1 || mode == 4), FG_ERR_INVALID_ARG,
                "fg_debug_apply_preconditioner: mode 1 (y-line) or 4 (ILU(0)), 1 <= nc <= dims");
     hipStream_t st = (hipStream_t)stream;
+    s->bicg_ready_nc = 0; s->cg_ready_ns = 0;
     FG_HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int32_t) * (size_t)s->grid.B * s->grid.dims, st));
     if (mode == 4) {
         if (int rc = fg_ilu_alloc(s)) return rc;
@@ -572,11 +573,13 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
                                          info.data(), st, last)))
             return rc;
         if (c < 2) { stats[2 + c] = max_iters(info.data(), B); s->ctr.add(2 + c, info.data(), B); }
-        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, last ? s->pressure : s->p_result, s->vel_result, st))
+        // the last corrector also writes the block velocity of active envs: CopyVelocityResultToBlocks (:1974)
+        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, last ? s->pressure : s->p_result, s->vel_result, st,
+                                       last ? s->velocity : nullptr))
             return rc;
     }
-    // CopyVelocityResultToBlocks (:1974)
-    if (int rc = fg_launch_copy_active(s, dt_B, s->vel_result, s->velocity, d, st)) return rc;
+    if (opt->corrector_steps <= 0)
+        if (int rc = fg_launch_copy_active(s, dt_B, s->vel_result, s->velocity, d, st)) return rc;
     if (stats_host) memcpy(stats_host, stats, sizeof(stats));
     s->ctr.piso_steps += 1;
     return status;

@@ -633,14 +633,8 @@ __global__ void k_bicg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict_
                              int32_t* __restrict__ flags, fg_solve_info* __restrict__ info, int nsys, int nc) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
-    for (int q = 0; q < FG_ACC_DOUBLES; ++q) acc_st(acc + ((size_t)s * FG_ACC_DOUBLES + q), 0.0);
-    sc_st(sc + (s * 2), 1.f); sc_st(sc + (s * 2 + 1), 1.f);
-    const bool active = (dt == nullptr) || (dt[s / nc] > 0.f);
-    flag_st(flags + (s), active ? 0 : 3);
-    info[s].final_residual = 0.f;
-    info[s].used_iterations = -1;
-    info[s].converged = active ? 0 : 1;
-    info[s].is_finite = 1;
+    const FgBicgBegin q = {acc, sc, flags, info, nc};
+    fg_bicg_begin_sys(q, dt, s);     // (fg_internal.h: shared with k_adv_build, which prepares the solve that follows an assembly)
 }
 
 __global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
@@ -679,7 +673,11 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         q.mp = s->w[5]; q.ms = s->w[6];   // free during a BiCGStab solve (the CG's z and second p buffer)
     }
     const dim3 sg((nsys + 63) / 64), sb(64);
-    hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
+    {   // state already prepared by the k_adv_build that assembled this system (FgBicgBegin, fg_internal.h)?
+        const bool ready = s->bicg_ready_nc == a.nc && s->bicg_ready_dt == a.dt;
+        s->bicg_ready_nc = 0; s->cg_ready_ns = 0;
+        if (!ready) hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
+    }
     if (a.precond == 2) {
         FG_REQUIRE(s->fd_lam != nullptr, FG_ERR_INVALID_ARG, "Helmholtz preconditioner requested but fg_set_fd_helmholtz was not called");
         if (int rc = fg_helm_factor(s, a.dt, a.nu, a.wall_lo, a.wall_hi, a.nc, st)) return rc;

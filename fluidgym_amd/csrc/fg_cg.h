@@ -29,6 +29,29 @@ __device__ __forceinline__ void fg_acc_add(FgDacc* a, int ns, unsigned tile, dou
 }
 #endif
 
+// State of the pressure CG that follows a right-hand side, prepared by the kernel that builds it (k_div) -- what a k_cg_begin launch
+// does: the ns accumulator slots in use, the mean accumulator of the p -= mean(p) pass, best-iterate state, flags from the activity
+// mask, info cleared.  acc == nullptr: not folded.  All threads of ONE workgroup per env call fg_cg_begin_env.
+struct FgCgBegin { FgDacc* acc; int32_t* flags; fg_solve_info* info; FgDacc* mean_sums; FgBest best; int track_best, ns; };
+int fg_cg_slots(const fg_state* s);   // accumulator slots of this grid's CG launches (fg_poisson.hip)
+#ifdef __HIPCC__
+__device__ __forceinline__ void fg_cg_begin_env(const FgCgBegin& q, const fg_real* __restrict__ dt, int b) {
+    for (int k = threadIdx.x; k < FG_CG_NAMES * q.ns; k += blockDim.x)   // only the ns slots in use (64 B each)
+        acc_st(fg_acc_ptr(q.acc, b, k / q.ns) + k % q.ns, 0.0);
+    if (threadIdx.x != 0) return;
+    acc_st(q.mean_sums + b, 0.0);  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
+    q.best.best_crit[b] = q.track_best ? INFINITY : 0.f;  // 0: no residual ever beats it, nothing is kept
+    q.best.saved_crit[b] = INFINITY;
+    q.best.save_at[b] = -1;
+    const bool active = (dt == nullptr) || (dt[b] > 0.f);
+    flag_st(q.flags + (b), active ? 0 : 3);
+    q.info[b].final_residual = 0.f;
+    q.info[b].used_iterations = -1;
+    q.info[b].converged = active ? 0 : 1;
+    q.info[b].is_finite = 1;
+}
+#endif
+
 // The verdict on rr_{it+1} that a k_cg_check launch between k_cg_update(it) and the preconditioner used to give, taken instead by
 // EVERY workgroup of the preconditioner's first kernel from the same accumulator words (whole waves must call: the slot sum is a
 // wave shuffle tree); the env's leader thread stores the flag and the info words.  An env found converged (or non-finite) is

@@ -667,6 +667,11 @@ struct fg_state {
     int pred_bicg, pred_cg; // iterations the last solves needed (first convergence poll is scheduled there)
     FgCounters ctr;         // iterations per solve kind since the last reset (fg_solver_counters)
     const fg_real* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
+    // solver state already prepared by the kernel launched just before the solve (k_adv_build: FgBicgBegin, k_div: FgCgBegin) --
+    // the solve then skips its own begin launch.  Consumed (and the other one dropped) by the next solve of either kind.
+    mutable int maxvel_clean;     // scratch_B rows 1-2 (CFL maximum + arrival counters) are zero: left so by the mirrored k_max_velocity
+    mutable int bicg_ready_nc; mutable const fg_real* bicg_ready_dt;
+    mutable int cg_ready_ns, cg_ready_best; mutable const fg_real* cg_ready_dt;
     size_t n_cells() const { return (size_t)grid.n; }
 };
 
@@ -710,6 +715,21 @@ void fg_set_error(const std::string& msg);
 #endif
 
 // launchers implemented in the kernel translation units -----------------------------------------
+// State of the BiCGStab solve that follows an assembly, prepared by the assembly kernel itself (what a k_bicg_begin launch does:
+// accumulators and scalars reset, flags from the activity mask, info cleared); acc == nullptr: not folded.
+struct FgBicgBegin { FgDacc* acc; fg_real* sc; int32_t* flags; fg_solve_info* info; int nc; };
+#ifdef __HIPCC__
+__device__ __forceinline__ void fg_bicg_begin_sys(const FgBicgBegin& q, const fg_real* __restrict__ dt, int sys) {
+    for (int k = 0; k < FG_ACC_DOUBLES; ++k) acc_st(q.acc + ((size_t)sys * FG_ACC_DOUBLES + k), 0.0);
+    sc_st(q.sc + (sys * 2), 1.f); sc_st(q.sc + (sys * 2 + 1), 1.f);
+    const bool active = (dt == nullptr) || (dt[sys / q.nc] > 0.f);
+    flag_st(q.flags + (sys), active ? 0 : 3);
+    q.info[sys].final_residual = 0.f;
+    q.info[sys].used_iterations = -1;
+    q.info[sys].converged = active ? 0 : 1;
+    q.info[sys].is_finite = 1;
+}
+#endif
 struct FgAdvArgs {
     const fg_real* vel;      // u^n [B,d,N]
     const fg_real* scal;     // T channel [B,?] base of the channel being advected (stride given)
@@ -722,6 +742,7 @@ struct FgAdvArgs {
     int channel, n_scalars;
     fg_real* A; fg_real* Coff; fg_real* rhs;
     fg_real* rA;             // optional: 1/A written alongside A (velocity system only)
+    FgBicgBegin begin;       // optional (begin.acc != nullptr): the leader workgroup of every env prepares the solve that follows
 };
 int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
 int fg_launch_sgs(const fg_state* s, const FgBounds& bnd, fg_real coefficient, fg_real* out, hipStream_t st);
@@ -729,7 +750,7 @@ int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t s
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st);
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, hipStream_t st);
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
-                      fg_real* vel_out, hipStream_t st);
+                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy = nullptr);
 // mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be
 // scratch_B + B, whose next row holds the arrival counters)
 int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B = nullptr);

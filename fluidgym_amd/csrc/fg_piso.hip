@@ -6,6 +6,7 @@
 // kept as diag (= A) + 2d off-diagonal fields in face order, and the pressure matrix is applied
 // matrix-free from rA = 1/A (fg_poisson.hip).
 #include "fg_internal.h"
+#include "fg_cg.h"
 
 namespace {
 
@@ -42,6 +43,10 @@ template <int DIMS, int VEC, bool SCALAR, bool VISC = false>
 __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, FgAdvArgs a, int tiles_x,
                                                          int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    if (a.begin.acc) {   // the BiCGStab solve on this system comes next: the first workgroup of the env prepares its state
+        if (fg_xcd_remap(blockIdx.x, gridDim.x) % (unsigned)tiles == 0 && (int)threadIdx.x < a.begin.nc)
+            fg_bicg_begin_sys(a.begin, a.dt, c.b * a.begin.nc + threadIdx.x);
+    }
     const fg_real dt = a.dt[c.b];
     if (!(dt > 0.f) || !c.valid) return;
     const size_t N = g.n;
@@ -242,9 +247,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const fg_real* __restr
 // ---------------------------------------------------------------------------------------------
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const fg_real* __restrict__ dt,
-                                                   const fg_real* __restrict__ hvec, fg_real* __restrict__ div,
+                                                   const fg_real* __restrict__ hvec, fg_real* __restrict__ div, FgCgBegin begin,
                                                    int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    // the pressure solve on this right-hand side comes next: the first workgroup of the env prepares its state (fg_cg.h)
+    if (begin.acc && fg_xcd_remap(blockIdx.x, gridDim.x) % (unsigned)tiles == 0) fg_cg_begin_env(begin, dt, c.b);
     if ((dt && !(dt[c.b] > 0.f)) || !c.valid) return;
     const size_t N = g.n;
     const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
@@ -286,7 +293,9 @@ template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const fg_real* __restrict__ dt,
                                                        const fg_real* __restrict__ rA_, const fg_real* __restrict__ hvec,
                                                        const fg_real* __restrict__ p, fg_real* __restrict__ vel_out,
-                                                       int tiles_x, int tiles_y, int tiles) {
+                                                       fg_real* __restrict__ vel_copy, int tiles_x, int tiles_y, int tiles) {
+    // vel_copy (optional): the block velocity of active envs, written alongside the result by the last corrector of a step
+    // (CopyVelocityResultToBlocks, PISOtorch_simulation.py:1974, without a pass of its own)
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if ((dt && !(dt[c.b] > 0.f)) || !c.valid) return;
     const size_t N = g.n;
@@ -315,6 +324,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const fg_real* _
             out.v[e] = h.v[e] - rA.v[e] * ((hi - lo) * fac * rh);
         }
         fg_store<VEC>(vel_out + base + c.idx, out);
+        if (vel_copy) fg_store<VEC>(vel_copy + base + c.idx, out);
     }
 }
 
@@ -351,8 +361,12 @@ __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, 
 #else
     asm volatile("" ::"v"(prev));
 #endif
-    if (atomicAdd(done_B + b, 1) == (int)gridDim.x - 1)
-        mirror_B[b] = fg_bits_real(atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, (fg_bits)0));  // atomic read of the final value
+    if (atomicAdd(done_B + b, 1) == (int)gridDim.x - 1) {
+        // the last workgroup of the env: atomic read of the final value, which also leaves the maximum and the arrival counter
+        // zeroed for the next launch (fg_launch_max_velocity then needs no memset in front of it)
+        mirror_B[b] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + b, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        atomicExch(done_B + b, 0);
+    }
 }
 
 template <int DIMS>
@@ -681,7 +695,13 @@ inline dim3 stride_grid(const fg_state* s, long per_env_elems) {
 }  // namespace
 
 
-int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st) {
+int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a_in, hipStream_t st) {
+    // the state of the BiCGStab solve that follows is prepared by this launch (FgBicgBegin, fg_internal.h; fg_bicgstab_solve skips its
+    // k_bicg_begin when the record matches its own arguments)
+    FgAdvArgs a = a_in;
+    a.begin.acc = s->acc; a.begin.sc = s->scratch_B + 4 * s->grid.B; a.begin.flags = s->flags; a.begin.info = s->info_dev;
+    a.begin.nc = a.for_scalar ? 1 : s->grid.dims;
+    s->bicg_ready_nc = a.begin.nc; s->bicg_ready_dt = a.dt; s->cg_ready_ns = 0;
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         if (a.for_scalar)
@@ -783,9 +803,13 @@ int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result,
 
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div,
                   hipStream_t st) {
+    FgCgBegin begin;
+    begin.acc = s->cg_acc; begin.flags = s->flags; begin.info = s->info_dev; begin.mean_sums = s->acc; begin.best = s->cg_best;
+    begin.track_best = s->cg_return_best; begin.ns = fg_cg_slots(s);
+    s->cg_ready_ns = begin.ns; s->cg_ready_best = begin.track_best; s->cg_ready_dt = dt; s->bicg_ready_nc = 0;
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_div<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, dt, hvec, div, L.tiles_x,
+        hipLaunchKernelGGL((k_div<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, dt, hvec, div, begin, L.tiles_x,
                            L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
@@ -793,10 +817,10 @@ int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, con
 }
 
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
-                      fg_real* vel_out, hipStream_t st) {
+                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy) {
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out,
+        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out, vel_copy,
                            L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
@@ -807,7 +831,9 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_
     // out_B [B] and the arrival counters right behind it (scratch_B rows 1 and 2) are zeroed together
     int32_t* done_B = reinterpret_cast<int32_t*>(out_B + s->grid.B);
     FG_REQUIRE(!mirror_B || out_B == s->scratch_B + s->grid.B, FG_ERR_INVALID_ARG, "mirror needs the scratch row as out_B");
-    FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(fg_real) * s->grid.B * (mirror_B ? 2 : 1), st));
+    // (the mirrored form cleans up after itself: the memset is only needed after something else used the rows)
+    if (!mirror_B || !s->maxvel_clean) FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(fg_real) * s->grid.B * (mirror_B ? 2 : 1), st));
+    s->maxvel_clean = mirror_B ? 1 : 0;
     if ((s->grid.nx & 3) == 0) {
         const int rows = s->grid.ny * s->grid.nz;
         int rpb = 4;  // rows per workgroup: one per wave, more when that still leaves >= 8 workgroups per CU ...

@@ -309,24 +309,8 @@ __global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags
     if (mirror && threadIdx.x == 0) mirror[b] = info[b];
 }
 
-__global__ void k_cg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict__ acc, int32_t* __restrict__ flags,
-                           fg_solve_info* __restrict__ info, FgDacc* __restrict__ mean_sums, FgBest best, int track_best,
-                           int B, int ns) {
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    for (int q = threadIdx.x; q < FG_CG_NAMES * ns; q += blockDim.x)   // only the ns slots in use (64 B each)
-        acc_st(fg_acc_ptr(acc, b, q / ns) + q % ns, 0.0);
-    if (threadIdx.x != 0) return;
-    acc_st(mean_sums + b, 0.0);  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
-    best.best_crit[b] = track_best ? INFINITY : 0.f;  // 0: no residual ever beats it, nothing is kept
-    best.saved_crit[b] = INFINITY;
-    best.save_at[b] = -1;
-    const bool active = (dt == nullptr) || (dt[b] > 0.f);
-    flag_st(flags + (b), active ? 0 : 3);
-    info[b].final_residual = 0.f;
-    info[b].used_iterations = -1;
-    info[b].converged = active ? 0 : 1;
-    info[b].is_finite = 1;
+__global__ void k_cg_begin(const fg_real* __restrict__ dt, FgCgBegin q, int B) {
+    if ((int)blockIdx.x < B) fg_cg_begin_env(q, dt, blockIdx.x);
 }
 
 __global__ void k_zero_name(FgDacc* __restrict__ acc, int name, int B) {
@@ -392,6 +376,14 @@ int fg_poisson_rbgs_launch(const fg_state* s, const fg_real* rA, const fg_real* 
 }
 
 // Host driver of the batched CG.  p is double-buffered: a.p is buffer 0, s->w[6] buffer 1.
+int fg_cg_slots(const fg_state* s) {   // ~cg_wgs_per_slot workgroups per accumulator slot, power of two
+    int tiles_per_env = 1;
+    FG_DISPATCH(s, { tiles_per_env = fg_launch_geometry<DIMS, VEC>(s->grid).tiles; });
+    int ns = 1;
+    while (ns < FG_CG_SLOTS && tiles_per_env / ns > s->cg_wgs_per_slot) ns *= 2;
+    return ns;
+}
+
 int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st) {
     const int B = s->grid.B, n = s->grid.n;
     const dim3 sg(B), sb(64);
@@ -400,9 +392,18 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     FG_DISPATCH(s, { tiles_per_env = fg_launch_geometry<DIMS, VEC>(s->grid).tiles; });
     int zc = 0;
     const bool zmarch = fg_zmarch_ok(s, &zc);
-    int ns = 1;  // accumulator slots: ~256 workgroups per slot, power of two
-    while (ns < FG_CG_SLOTS && tiles_per_env / ns > s->cg_wgs_per_slot) ns *= 2;
-    hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, s->cg_acc, s->flags, s->info_dev, s->acc, s->cg_best, s->cg_return_best, B, ns);
+    const int ns = fg_cg_slots(s);
+    (void)tiles_per_env;
+    {   // state already prepared by the k_div that built this right-hand side (FgCgBegin, fg_cg.h)?
+        const bool ready = s->cg_ready_ns == ns && s->cg_ready_best == s->cg_return_best && s->cg_ready_dt == a.dt;
+        s->cg_ready_ns = 0; s->bicg_ready_nc = 0;
+        if (!ready) {
+            FgCgBegin q;
+            q.acc = s->cg_acc; q.flags = s->flags; q.info = s->info_dev; q.mean_sums = s->acc; q.best = s->cg_best;
+            q.track_best = s->cg_return_best; q.ns = ns;
+            hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, q, B);
+        }
+    }
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,
