@@ -108,6 +108,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipHostMalloc(&s->diag_pinned, sizeof(fg_real) * 2 * g.B));
     FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(fg_real) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
+    if (int rc = fg_poll_create(&s->poll, (int)(nsys > 2 * (size_t)g.B ? nsys : 2 * (size_t)g.B))) return rc;
     s->pred_bicg = 2; s->pred_cg = 1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr; s->ilu_d = nullptr;
     s->double_fallback = 0; s->ladder_force = 0; s->r64_buf = nullptr; s->r64_acc = nullptr;
@@ -142,6 +143,7 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipFree(s->acc); (void)hipFree(s->flags); (void)hipFree(s->info_dev);
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
     fg_prof_destroy(s);
+    fg_poll_destroy(&s->poll);
     (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned); (void)hipHostFree(s->dt_pinned); (void)hipFree(s->dt_dev);
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
@@ -624,9 +626,14 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             // one transfer: [0..B) boundary flux balance, [B..2B) max |Minv u| (CFL velocity)
             // both kernels publish straight into the host-pinned diag_pinned (one workgroup per env writes the flux
             // balance; the last workgroup of each env mirrors the max velocity): the read-back is a stream synchronise
-            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st)) return rc; }
-            if (o->adaptive) { if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B)) return rc; }
-            FG_HIP_CHECK(hipStreamSynchronize(st));
+            // (the host waits on the sequence words the two kernels publish behind their results: FgPoll, fg_internal.h)
+            const FgPollOut po = fg_poll_next(&s->poll);
+            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, po)) return rc; }
+            if (o->adaptive) {
+                if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B, po.seq ? FgPollOut{po.seq + B, po.value} : po))
+                    return rc;
+            }
+            if (int rc = fg_poll_wait(&s->poll, po, first ? 0 : B, (first ? B : 0) + (o->adaptive ? B : 0), st)) return rc;
             if (first) {
                 fg_real worst = 0.f;
                 for (int b = 0; b < B; ++b) {

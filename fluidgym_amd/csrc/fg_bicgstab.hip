@@ -609,7 +609,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
 // poll after k_bicgf_a(it + 1), i.e. after iteration `it` completed: judges r_{it+1} exactly as k_bicg_check does (the next
 // k_bicgf_b would come to the same verdict from the same accumulator) and mirrors info for the host
 __global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                              fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass) {
+                              fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass, FgPollOut poll) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
@@ -627,6 +627,7 @@ __global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ fl
         }
     }
     mirror[s] = info[s];
+    fg_poll_publish(poll, s);      // (after the entry: the host spins on this word instead of synchronising the stream)
 }
 
 __global__ void k_bicg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict__ acc, fg_real* __restrict__ sc,
@@ -638,7 +639,7 @@ __global__ void k_bicg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict_
 }
 
 __global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                             fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass) {
+                             fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass, FgPollOut poll) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
@@ -655,7 +656,8 @@ __global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ fla
             info[s].converged = 0;
         }
     }
-    mirror[s] = info[s];  // host-pinned copy: the poll that follows is a stream synchronise, no device-to-host copy
+    mirror[s] = info[s];  // host-pinned copy: the poll that follows needs no device-to-host copy
+    fg_poll_publish(poll, s);
 }
 
 }  // namespace
@@ -758,9 +760,10 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
             if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
                 next_poll = it + 1 + 2;
                 const int final_pass = (it + 1 == a.max_iterations);
-                hipLaunchKernelGGL(k_bicgf_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass);
-                fg_prof_prefetch(s, st);
-                FG_HIP_CHECK(hipStreamSynchronize(st));
+                fg_prof_prefetch(s, st);       // (in front of the polled kernel: its completion then covers the copy)
+                const FgPollOut po = fg_poll_next(&s->poll);
+                hipLaunchKernelGGL(k_bicgf_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass, po);
+                if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
                 info_fresh = true;
                 done = true;
                 for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
@@ -785,10 +788,11 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
             next_poll = it + 1 + 2;
             const int final_pass = (it + 1 == a.max_iterations);
-            hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass);
             // one read-back serves the poll and the result (nothing is launched after the last poll)
             fg_prof_prefetch(s, st);
-            FG_HIP_CHECK(hipStreamSynchronize(st));
+            const FgPollOut po = fg_poll_next(&s->poll);
+            hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass, po);
+            if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
             info_fresh = true;
             done = true;
             for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);

@@ -557,6 +557,27 @@ struct FgProf {
 // iterate x_it is less than half that of the last kept iterate (it >= 1), the kernel that is about to overwrite x
 // (k_cg_update of iteration it) writes the old x to best_x -- no extra read, one extra store per cell for the envs concerned.  A solve that ends
 // unconverged (max iterations, or fp32 stagnation followed by divergence) gets the kept iterate back (within 2x of the lowest residual reached).
+// Host polls without hipStreamSynchronize (fg_poll.hip).  A kernel whose results the host waits for -- the convergence checks, the
+// flux balance and CFL maximum of fg_single_step -- stores them into host-pinned memory and then, with a system-scope release, the
+// poll's sequence number into a pinned word per entry; the host spins on those words.  Measured on MI355X (profiles/scratch/
+// poll_latency.hip): kernel -> host -> next kernel costs 6 us this way against 11.5 us through hipStreamSynchronize, 4-5 times per
+// PISO step.  Streams are in order, so "the polled kernel has finished" still means everything launched before it has.
+struct FgPollOut { int32_t* seq; int32_t value; };     // seq == nullptr: no word is written (the caller synchronises the stream)
+#ifdef __HIPCC__
+__device__ __forceinline__ void fg_poll_publish(const FgPollOut& p, int i) {
+    if (p.seq) __hip_atomic_store(p.seq + i, p.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+struct FgPoll {
+    int32_t* seq;      // pinned [n]
+    int n; int32_t epoch; int spin;    // spin == 0 (FG_POLL_SPIN=0): hipStreamSynchronize, as before
+};
+int fg_poll_create(FgPoll* P, int n);
+void fg_poll_destroy(FgPoll* P);
+FgPollOut fg_poll_next(FgPoll* P);     // the words and sequence number of the next poll ({nullptr, 0} when spinning is off)
+// waits until words [first, first + count) carry out.value (or, without words / after 50 ms of spinning, for the stream)
+int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st);
+
 struct FgBest {
     fg_real* best_crit;   // [B] residual of the last kept iterate (leader-only state)
     fg_real* saved_crit;  // [B] residual of the iterate held in best_x (+inf: none)
@@ -669,6 +690,7 @@ struct fg_state {
     const fg_real* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     // solver state already prepared by the kernel launched just before the solve (k_adv_build: FgBicgBegin, k_div: FgCgBegin) --
     // the solve then skips its own begin launch.  Consumed (and the other one dropped) by the next solve of either kind.
+    FgPoll poll;                  // host polls of this handle (fg_poll.hip)
     mutable int maxvel_clean;     // scratch_B rows 1-2 (CFL maximum + arrival counters) are zero: left so by the mirrored k_max_velocity
     mutable int bicg_ready_nc; mutable const fg_real* bicg_ready_dt;
     mutable int cg_ready_ns, cg_ready_best; mutable const fg_real* cg_ready_dt;
@@ -753,8 +775,10 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
                       fg_real* vel_out, hipStream_t st, fg_real* vel_copy = nullptr);
 // mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be
 // scratch_B + B, whose next row holds the arrival counters)
-int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B = nullptr);
-int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st);
+// poll (optional): sequence words published per env after the host-pinned result (FgPollOut above)
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B = nullptr,
+                           FgPollOut poll = FgPollOut{nullptr, 0});
+int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, FgPollOut poll = FgPollOut{nullptr, 0});
 int fg_launch_copy_active(const fg_state* s, const fg_real* dt, const fg_real* src, fg_real* dst, int comps, hipStream_t st);
 int fg_launch_buoyancy(const fg_state* s, const fg_real* dt, const fg_real* T, long t_env_stride, fg_real* source, int axis,
                        fg_real factor, hipStream_t st);

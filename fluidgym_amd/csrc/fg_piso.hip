@@ -347,7 +347,7 @@ typedef int fg_bits;
 __device__ __forceinline__ fg_bits fg_real_bits(fg_real v) { return __float_as_int(v); }
 __device__ __forceinline__ fg_real fg_bits_real(fg_bits b) { return __int_as_float(b); }
 #endif
-__device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx) {
+__device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx, const FgPollOut& poll) {
     if (!mirror_B) {
         atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, fg_real_bits(mx));
         return;
@@ -366,13 +366,14 @@ __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, 
         // zeroed for the next launch (fg_launch_max_velocity then needs no memset in front of it)
         mirror_B[b] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + b, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         atomicExch(done_B + b, 0);
+        fg_poll_publish(poll, b);
     }
 }
 
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
                                                             fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
-                                                            fg_real* __restrict__ mirror_B) {
+                                                            fg_real* __restrict__ mirror_B, FgPollOut poll) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     fg_real mx = 0.f;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
     __syncthreads();
     if (threadIdx.x == 0) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll);
     }
 }
 
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
                                                                  fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
-                                                                 fg_real* __restrict__ mirror_B, int rows_per_block) {
+                                                                 fg_real* __restrict__ mirror_B, int rows_per_block, FgPollOut poll) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -473,14 +474,14 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
     __syncthreads();
     if (threadIdx.x == 0) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll);
     }
 }
 
 // sum of FIXED-boundary contravariant fluxes, lower faces negated
 // (Domain::GetGlobalFluxBalance, domain_structs.cpp:2476-2509).  One workgroup per env, fp64 sum.
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bnd, fg_real* __restrict__ out_B) {
+__global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bnd, fg_real* __restrict__ out_B, FgPollOut poll) {
     const int b = blockIdx.x;
     double acc = 0.0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -521,7 +522,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bn
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out_B[b] = (fg_real)(lds[0] + lds[1] + lds[2] + lds[3]);
+    if (threadIdx.x == 0) {
+        out_B[b] = (fg_real)(lds[0] + lds[1] + lds[2] + lds[3]);
+        fg_poll_publish(poll, b);      // (out_B may be host-pinned: the host then spins on this word, fg_single_step)
+    }
 }
 
 // dst = src for active envs (Copy*ResultTo/FromBlocks, :6558-6746); fg_real4 grid-stride rows
@@ -827,7 +831,7 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
     return FG_OK;
 }
 
-int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B) {
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B, FgPollOut poll) {
     // out_B [B] and the arrival counters right behind it (scratch_B rows 1 and 2) are zeroed together
     int32_t* done_B = reinterpret_cast<int32_t*>(out_B + s->grid.B);
     FG_REQUIRE(!mirror_B || out_B == s->scratch_B + s->grid.B, FG_ERR_INVALID_ARG, "mirror needs the scratch row as out_B");
@@ -842,27 +846,27 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_
         dim3 grid((rows + rpb - 1) / rpb, s->grid.B);
         if (s->grid.dims == 2)
             hipLaunchKernelGGL(k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb);
+                               mirror_B, rpb, poll);
         else
             hipLaunchKernelGGL(k_max_velocity_rows<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb);
+                               mirror_B, rpb, poll);
         FG_HIP_CHECK(hipGetLastError());
         return FG_OK;
     }
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
     if (s->grid.dims == 2)
-        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B);
+        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll);
     else
-        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B);
+        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
 
-int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st) {
+int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, FgPollOut poll) {
     if (s->grid.dims == 2)
-        hipLaunchKernelGGL(k_flux_balance<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, out_B);
+        hipLaunchKernelGGL(k_flux_balance<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, out_B, poll);
     else
-        hipLaunchKernelGGL(k_flux_balance<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, out_B);
+        hipLaunchKernelGGL(k_flux_balance<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, out_B, poll);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const fg_real*
 // host-pinned copy of info: thread 0 of every env writes its entry there, so a convergence poll is a stream
 // synchronise without a device-to-host copy (the copy kernel + its launch cost ~6 us per poll, 4-5 polls per PISO step).
 __global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                           fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int B, int final_pass, int ns) {
+                           fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int B, int final_pass, int ns,
+                           FgPollOut poll = FgPollOut{nullptr, 0}) {
     const int b = blockIdx.x;
     if (b >= B) return;
     if (flag_ld(flags + (b)) == 0) {
@@ -306,7 +307,10 @@ __global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags
             }
         }
     }
-    if (mirror && threadIdx.x == 0) mirror[b] = info[b];
+    if (mirror && threadIdx.x == 0) {
+        mirror[b] = info[b];
+        fg_poll_publish(poll, b);      // (after the entry: the host spins on this word instead of synchronising the stream)
+    }
 }
 
 __global__ void k_cg_begin(const fg_real* __restrict__ dt, FgCgBegin q, int B) {
@@ -468,17 +472,16 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         if (poll) next_poll = it + 1 + check_every;
         if (poll) {
             const int final_pass = (it + 1 == a.max_iterations);
-            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, poll ? s->info_pinned : nullptr, a.tol, it,
-                               n, B, final_pass, ns);
-        }
-        if (poll) {
+            fg_prof_prefetch(s, st);       // (in front of the polled kernel: its completion then covers the copy)
+            const FgPollOut po = fg_poll_next(&s->poll);
+            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
+                               n, B, final_pass, ns, po);
             // one read-back serves the poll and the result: k_cg_check above mirrored info (converged / is_finite of every
             // env) into the pinned host copy, and nothing is launched between the last poll and the end of the solve.
             // The poll comes BEFORE the preconditioner of the next iteration: polls are scheduled where the previous solve
             // finished, so they usually end the solve, and three kernels of M^-1 that would find every env converged
             // cost more than the idle round trip of a poll that does not.
-            fg_prof_prefetch(s, st);
-            FG_HIP_CHECK(hipStreamSynchronize(st));
+            if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
             info_fresh = true;
             done = true;
             active_est = 0;

@@ -1,0 +1,49 @@
+// Host polls on pinned sequence words instead of hipStreamSynchronize (FgPoll, fg_internal.h).
+#include <chrono>
+#include <cstdlib>
+
+#include "fg_internal.h"
+
+int fg_poll_create(FgPoll* P, int n) {
+    P->n = n; P->epoch = 0;
+    const char* e = getenv("FG_POLL_SPIN");
+    P->spin = !(e && atoi(e) == 0);
+    FG_HIP_CHECK(hipHostMalloc(&P->seq, sizeof(int32_t) * (size_t)n));
+    for (int i = 0; i < n; ++i) P->seq[i] = 0;
+    return FG_OK;
+}
+
+void fg_poll_destroy(FgPoll* P) {
+    if (P->seq) (void)hipHostFree(P->seq);
+    P->seq = nullptr;
+}
+
+FgPollOut fg_poll_next(FgPoll* P) {
+    if (!P->spin || !P->seq) return FgPollOut{nullptr, 0};
+    if (++P->epoch == 0) ++P->epoch;      // 0 is what the words start with
+    return FgPollOut{P->seq, P->epoch};
+}
+
+int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st) {
+    if (!out.seq) { FG_HIP_CHECK(hipStreamSynchronize(st)); return FG_OK; }
+    if (first < 0 || first + count > P->n) { fg_set_error("fg_poll_wait: range outside the sequence words"); return FG_ERR_INVALID_ARG; }
+    const auto t0 = std::chrono::steady_clock::now();
+    int i = first;
+    unsigned spins = 0;
+    while (i < first + count) {
+        if (__atomic_load_n(out.seq + i, __ATOMIC_ACQUIRE) == out.value) { ++i; continue; }
+        __builtin_ia32_pause();
+        if ((++spins & 0xfff) == 0 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 50.0) {
+            // a long kernel queue, or a fault: let the runtime wait (and report)
+            FG_HIP_CHECK(hipStreamSynchronize(st));
+            for (int k = first; k < first + count; ++k)
+                if (__atomic_load_n(out.seq + k, __ATOMIC_ACQUIRE) != out.value) {
+                    fg_set_error("fg_poll_wait: the polled kernel finished without publishing its sequence word");
+                    return FG_ERR_HIP;
+                }
+            return FG_OK;
+        }
+    }
+    return FG_OK;
+}
