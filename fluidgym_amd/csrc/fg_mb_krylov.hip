@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, in
 }
 
 __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32_t* __restrict__ flag_mirror, int rr_slot,
-                            int it, int n, int nsys, int final_pass, int sum_slot = -1) {
+                            int it, int n, int nsys, int final_pass, int sum_slot = -1, FgPollOut poll = FgPollOut{nullptr, 0}) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsys) return;
     if (it < 0) {  // graph-replayed CG: iteration index and accumulator slots from the device counter
@@ -1133,6 +1133,7 @@ __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32
     }
     mirror[s] = q.info[s];
     flag_mirror[s] = flag_ld(q.flags + (s));
+    fg_poll_publish(poll, s);      // (after both mirrors: the host spins on this word instead of synchronising the stream)
 }
 
 // hand back the kept iterate of the systems that ended unconverged
@@ -1269,8 +1270,8 @@ __global__ void k_mbb_verify(MbSolve q, int32_t* __restrict__ verified, int n, i
     }
 }
 
-int mb_poll(fg_mb_state* s, int nsys, hipStream_t st, bool& done) {
-    FG_HIP_CHECK(hipStreamSynchronize(st));
+int mb_poll(fg_mb_state* s, int nsys, hipStream_t st, bool& done, const FgPollOut& po) {
+    if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
     done = true;
     for (int i = 0; i < nsys; ++i) done = done && s->flags_pinned[i] != 0;
     return FG_OK;
@@ -1499,8 +1500,9 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
         });
         if (it + 1 >= next_poll || it + 1 == max_iterations) {
             next_poll = it + 1 + (it < 20 ? 2 : 10);   // long (pressure) solves: fewer host round trips
-            hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations));
-            if (int rc = mb_poll(s, nsys, st, done)) return rc;
+            FgPollOut po = fg_poll_next(&s->poll);
+            hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations), -1, po);
+            if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
             if (nc == 1 && s->dbg_trace) {
                 mb_real lo = 1e30f, hi = 0.f; int active = 0;
                 for (int i = 0; i < nsys; ++i) { const mb_real c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
@@ -1523,8 +1525,9 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
                     if (project) hipLaunchKernelGGL(k_mbb_project_init, grid, blk, 0, st, n, q);
                     hipLaunchKernelGGL(k_mbb_verify, sg, sb, 0, st, q, s->verified, n, nsys, (int)(verify_rounds == 3));
                     if (refine) keep_best(0);
-                    hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, 0);
-                    if (int rc = mb_poll(s, nsys, st, done)) return rc;
+                    po = fg_poll_next(&s->poll);
+                    hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, 0, -1, po);
+                    if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
                     next_poll = it + 1 + 2;
                     if (nc == 1 && s->dbg_trace) {
                         int open = 0;
@@ -1631,7 +1634,7 @@ int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real*
         return FG_OK;
     };
     const int pm_mode = project_mean ? (s->yproj_const ? 1 : 2) : 0;
-    auto enqueue_chunk = [&](bool sample) {
+    auto enqueue_chunk = [&](bool sample, FgPollOut po) {   // po: sequence words of the poll that follows ({nullptr, 0} inside a captured graph)
         MB_DISPATCH_PM(s, pm_mode, {
             for (int k = 0; k < CG_CHUNK; ++k) {
                 const bool ev = sample && k == 0 && s->prof_used + 2 <= 32;
@@ -1661,7 +1664,7 @@ int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real*
                 }
             }
         });
-        hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, 0, -1, n, nsys, 0, project_mean ? 0 : -1);
+        hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, 0, -1, n, nsys, 0, project_mean ? 0 : -1, po);
     };
     // the chunk can be replayed as a hipGraph (FG_MB_GRAPH=1); since the four-cells-per-thread kernels the loop is no
     // longer enqueue-bound and plain launches are as fast, so that is the default (and what the live profiler samples)
@@ -1682,7 +1685,7 @@ int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real*
             const hipStream_t run_stream = st;
             st = s->capture_stream;
             FG_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            enqueue_chunk(false);
+            enqueue_chunk(false, FgPollOut{nullptr, 0});
             FG_HIP_CHECK(hipStreamEndCapture(st, &graph));
             st = run_stream;
             FG_HIP_CHECK(hipGraphInstantiate(&s->cg_graph_exec, graph, nullptr, nullptr, 0));
@@ -1699,9 +1702,10 @@ int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real*
             MB_DISPATCH(s, hipLaunchKernelGGL(k_mbc_restart<DIMS>, grid, blk, 0, st, s->dev, q, it, project_mean););
         }
         if (it == 0) { active_now = 0; for (int i = 0; i < nsys; ++i) active_now += 1; }  // inactive envs exit in k_mbs_begin's flags; counted below after the first poll
+        const FgPollOut po = use_graph ? FgPollOut{nullptr, 0} : fg_poll_next(&s->poll);
         if (use_graph) FG_HIP_CHECK(hipGraphLaunch(s->cg_graph_exec, st));
-        else enqueue_chunk(s->prof_on && (s->prof_chunk++ % 4 == 0));
-        if (int rc = mb_poll(s, nsys, st, done)) return rc;
+        else enqueue_chunk(s->prof_on && (s->prof_chunk++ % 4 == 0), po);
+        if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
         active_now = 0;
         for (int i = 0; i < nsys; ++i) active_now += s->flags_pinned[i] == 0;
         if (s->prof_used) if (int rc = prof_collect()) return rc;

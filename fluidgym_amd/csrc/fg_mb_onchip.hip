@@ -77,7 +77,8 @@ struct OcParams {
     int use_x0, project_mean, restart_every, check_every, max_iterations, stall_limit, accept_window;
     mb_real accept_factor, tol;
     fg_solve_info* info_host;   // pinned host mirrors of info[] and of the iterations run: written by the kernel itself, so the
-    int32_t* its_host;          // host needs one stream synchronisation after the launch and no device-to-host copies
+    int32_t* its_host;          // host needs one wait after the launch and no device-to-host copies
+    FgPollOut poll;             // sequence word per env behind the mirrors (fg_internal.h FgPoll)
 };
 
 // block sum of two values in fp64.  `red` is a ring of three slot pairs used in turn (`phase` advances per call): a wave that
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
             q.info[sys].final_residual = 0.f; q.info[sys].used_iterations = -1; q.info[sys].converged = 1; q.info[sys].is_finite = 1;
             o.info_host[sys] = q.info[sys];
             o.its_host[sys] = 0;
+            fg_poll_publish(o.poll, sys);
         }
         return;
     }
@@ -606,6 +608,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
         q.best_it[sys] = it;   // total iterations run (profiling: the host sums them)
         o.info_host[sys] = q.info[sys];
         o.its_host[sys] = it;
+        fg_poll_publish(o.poll, sys);      // (after the mirrors: the host spins on this word instead of synchronising the stream)
     }
 }
 
@@ -649,6 +652,7 @@ int mb_cg_onchip(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const m
     o.stall_limit = s->cg_stall_limit; o.accept_window = 20;
     o.accept_factor = stall_accept > 1.f ? stall_accept : 0.f; o.tol = tol;
     o.info_host = s->info_pinned; o.its_host = s->flags_pinned;
+    o.poll = fg_poll_next(&s->poll);
     const bool ev = s->prof_on != 0;
     // Instances, chosen by measurement on the cylinder mesh (profiles/r02_onchip_variants.txt; 64 envs x 14 232 cells, us per
     // iteration): 16 cells per thread with the two-barrier reduction 11.7-11.8; the same with the one-barrier ring 14.5; 14
@@ -675,7 +679,8 @@ int mb_cg_onchip(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const m
     else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024, false, false, false);
     else OC_LAUNCH_PM(28, false, 1024, false, false, false);
 #undef OC_LAUNCH_PRE
-    FG_HIP_CHECK(hipStreamSynchronize(st));   // info_pinned / flags_pinned (iterations run) were written by the kernel
+    // info_pinned / flags_pinned (iterations run) were written by the kernel; with profiling events the stream is synchronised
+    if (int rc = fg_poll_wait(&s->poll, ev ? FgPollOut{nullptr, 0} : o.poll, 0, nsys, st)) return rc;
     if (ev) {
         fg_f32 ms = 0.f;
         FG_HIP_CHECK(hipEventElapsedTime(&ms, s->prof_ev_oc[0], s->prof_ev_oc[1]));

@@ -481,6 +481,7 @@ extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (s->info_pinned) (void)hipHostFree(s->info_pinned);
     if (s->red_pinned) (void)hipHostFree(s->red_pinned);
     if (s->flags_pinned) (void)hipHostFree(s->flags_pinned);
+    fg_poll_destroy(&s->poll);
     if (s->red2_pinned) (void)hipHostFree(s->red2_pinned);
     if (s->dt_pinned) (void)hipHostFree(s->dt_pinned);
     if (s->env_fail_pinned) (void)hipHostFree(s->env_fail_pinned);
@@ -632,6 +633,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red2_pinned, sizeof(mb_real) * 2 * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(mb_real) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->flags_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
+    if (int rc = fg_poll_create(&s->poll, B * d > 2 * B ? B * d : 2 * B)) return rc;
     if (int rc = mb_alloc(s, &s->verified, (size_t)B * d)) return rc;
     s->finalized = true;
     return FG_OK;
