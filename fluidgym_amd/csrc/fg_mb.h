@@ -151,6 +151,8 @@ struct fg_mb_state {
     uint2* oc_nbr = nullptr;           // [OC_SLOTS] the four neighbour slots of a slot's cell as byte offsets (slot * 4), 16 bits each; prescribed face = the slot itself
     mb_real* oc_d4g = nullptr;           // [1024] 1 / diag(Z4^T S Z4) of the thread's aggregate (0: the thread owns none)
     int32_t* oc_cnt = nullptr;         // [1024] cells the thread owns
+    int oc_rtg_nt = 1024;               // FG_MB_OC_RTG_NT: workgroup size of that instance (1024 x 24 cells or 512 x 48 cells per thread)
+    mb_real* oc_rt_scratch = nullptr;   // [B][N] r - mean r of the on-chip preconditioner pass on meshes of 16-24 k cells (fg_mb_onchip.hip RTG)
     mb_real *Poff4s = nullptr, *Pdiag_s = nullptr, *oc_bestx = nullptr;   // [B][OC_SLOTS][4], [B][OC_SLOTS], [B][OC_SLOTS]: slot order; holes stay 0
     bool oc_agg = false;               // tables above installed
     bool oc_matrix_stale = true;       // no k_mb_pmatrix launch has written the slot-ordered matrix since the tables were installed

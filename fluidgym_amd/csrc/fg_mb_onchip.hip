@@ -79,6 +79,7 @@ struct OcParams {
     fg_solve_info* info_host;   // pinned host mirrors of info[] and of the iterations run: written by the kernel itself, so the
     int32_t* its_host;          // host needs one wait after the launch and no device-to-host copies
     FgPollOut poll;             // sequence word per env behind the mirrors (fg_internal.h FgPoll)
+    mb_real* rt_scratch;          // [B][N] r - mean r of the preconditioner pass (RTG instances: meshes beyond the LDS budget)
 };
 
 // block sum of two values in fp64.  `red` is a ring of three slot pairs used in turn (`phase` advances per call): a wave that
@@ -234,8 +235,11 @@ __device__ __forceinline__ mb_real oc_spmv_agg(const OcParams& o, int sys, unsig
     return part;
 }
 
-template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true, bool PRE = false, bool AGG = false>
+// RTG (cell-ordered preconditioned form, meshes of 16-24 k cells: the cylinder's `medium` / `hard` ids): the copy of r - mean r
+// that the 4 x 4 aggregate sums gather lives in a per-env global scratch vector (L2) instead of LDS -- p alone is 96 KB there.
+template <int DIMS, int CPT, int PM, bool DG_REGS, int NT, bool NBR = true, bool RING = true, bool PRE = false, bool AGG = false, bool RTG = false>
 __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams o) {
+    static_assert(!RTG || (PRE && !AGG), "global residual copy: cell-ordered preconditioned form only");
     static_assert(!AGG || (PRE && DIMS == 2 && CPT == 16 && NT == 1024 && PM != 2 && !DG_REGS && !NBR), "aggregate-owned layout: 16 slots x 1024 threads, preconditioned, 2-D");
     __shared__ mb_real v_lds[CPT * NT];
     __shared__ double red[3][2][OC_MAX_WAVES];
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     // r - mean r of the preconditioner pass, where the aggregate sums gather it; once they have, the same memory holds the
     // per-wave partial sums of the coarse solve
     constexpr int LP8 = AGG ? 256 : OC_N8;   // AGG: 4 n8 <= 1024 threads
-    constexpr int RT = PRE ? ((!AGG && CPT * NT > OC_MAX_WAVES * LP8) ? CPT * NT : OC_MAX_WAVES * LP8) : 1;
+    constexpr int RT = PRE ? ((!AGG && !RTG && CPT * NT > OC_MAX_WAVES * LP8) ? CPT * NT : OC_MAX_WAVES * LP8) : 1;
     __shared__ __attribute__((aligned(16))) mb_real l_rt[RT];
     mb_real (*l_part)[LP8] = reinterpret_cast<mb_real (*)[LP8]>(l_rt);
     // AGG: M p (and, before the stencil pass, z) lives in LDS instead of 16 registers per thread -- the cell-ordered preconditioned
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     // (knock-out builds, -DFG_MB_OC_KNOCK: 13 of 28 us per iteration are those loads, against 11.5 us for the whole plain iteration)
     __shared__ mb_real ap_lds[AGG ? CPT * NT : 1];
 #define OC_AP(k, i) (*(AGG ? &ap_lds[i] : &ap[k]))
-    static_assert(!PRE || NT == 1024, "the coarse solve of the preconditioner gives every one of the 16 waves its own set of columns");
+    static_assert(!AGG || NT == 1024, "aggregate-owned coarse solve: sixteen waves");   // (the cell-ordered form gives every one of its NT / 64 waves its own set of columns)
     int phase = 0;
     const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
     const size_t vb = (size_t)sys * N;
@@ -445,19 +449,35 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                 // restriction as GATHERS: every aggregate is a rectangle of cells of one block, so one thread sums it out of the
                 // LDS copy of the residual; 8 x 8 aggregates sum their (up to four) children.  LDS mb_real atomics did this first
                 // and cost 21 us per application (14 k atomics on 912 addresses)
+                mb_real* __restrict__ rt_g = RTG ? o.rt_scratch + vb : nullptr;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     const unsigned i = tl + (unsigned)k * NT;
-                    if (i < (unsigned)N) l_rt[i] = r[k] - rm;
+                    if (i < (unsigned)N) { if constexpr (RTG) rt_g[i] = r[k] - rm; else l_rt[i] = r[k] - rm; }
                 }
-                __syncthreads();
+                __syncthreads();   // (RTG: the waves of a workgroup share the CU's L1, which the stores above went through)
                 OC_PHASE(1);   // residual copy to LDS
                 for (int a = t; a < n4; a += NT) {
                     const uint2 rc = o.pre.rect4[a];
                     const unsigned w = rc.y & 0xffu, h = (rc.y >> 8) & 0xffu, stride = rc.y >> 16;
                     mb_real sum = 0.f;
-                    for (unsigned dy = 0; dy < h; ++dy)
-                        for (unsigned dx = 0; dx < w; ++dx) sum += l_rt[rc.x + dy * stride + dx];
+                    if constexpr (RTG) {
+                        // all (up to 16) loads of the rectangle requested at once: clamped addresses, zero weight outside it --
+                        // same order of the sum as the loop of the LDS form
+                        mb_real val[4][4];
+#pragma unroll
+                        for (unsigned dy = 0; dy < 4; ++dy)
+#pragma unroll
+                            for (unsigned dx = 0; dx < 4; ++dx)
+                                val[dy][dx] = rt_g[rc.x + (dy < h ? dy : h - 1) * stride + (dx < w ? dx : w - 1)];
+#pragma unroll
+                        for (unsigned dy = 0; dy < 4; ++dy)
+#pragma unroll
+                            for (unsigned dx = 0; dx < 4; ++dx) sum += (dy < h && dx < w) ? val[dy][dx] : 0.f;
+                    } else {
+                        for (unsigned dy = 0; dy < h; ++dy)
+                            for (unsigned dx = 0; dx < w; ++dx) sum += l_rt[rc.x + dy * stride + dx];
+                    }
                     l_r4[a] = sum;
                 }
                 __syncthreads();
@@ -480,7 +500,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     for (int qd = t & 63; qd < nq; qd += 64) {
                         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-                        for (int c = grp; c < n8; c += OC_MAX_WAVES) {
+                        for (int c = grp; c < n8; c += (NT / 64)) {
                             const float4 a = *reinterpret_cast<const float4*>(o.pre.aci8 + (unsigned)c * (unsigned)ld + 4u * (unsigned)qd);
                             const mb_real rc = l_r8[c];
                             acc.x += a.x * rc; acc.y += a.y * rc; acc.z += a.z * rc; acc.w += a.w * rc;
@@ -496,7 +516,7 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
                     const int row = o.pre.parent4[a];
                     mb_real e = 0.f;
 #pragma unroll
-                    for (int g = 0; g < OC_MAX_WAVES; ++g) e += l_part[g][row];
+                    for (int g = 0; g < (NT / 64); ++g) e += l_part[g][row];
                     l_r4[a] = inv_s * (0.5f * l_r4[a] * o.pre.d4g[a] + e);   // d4g holds reciprocals
                 }
                 __syncthreads();
@@ -612,6 +632,283 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same preconditioned solve for meshes of 16-24 k cells (the cylinder's `medium` / `hard` ids, 23 k cells): at that size p alone
+// takes 96 of the 160 KB of LDS and the register-resident form above spills a third of its state (68 us per iteration, measured).
+// Here only the search direction p lives in the CU (LDS, where the stencil gathers hit it); x, r and M p / z are per-env vectors in
+// global memory that never leave L2 (64 envs x 3 x 92 KB), always read and written by the thread that owns the cell (cell i = thread
+// + k 1024, members in batches of four so that a batch's loads are in flight together), so the loops need no register arrays, and
+// the 4 x 4 aggregate sums gather r straight from that vector (sum(r - mean) = sum(r) - mean * cells: no residual copy).  Per
+// iteration and cell ~74 B cross the CU's L1 (stencil 32, update 20, z pass 14, direction 4, aggregate sums 4).  Recurrence, projection,
+// restart / best-iterate / stall rules and preconditioner are those of k_mbc_onchip<PRE, !AGG>, statement by statement.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int OC_L2_CELLS = 24 * 1024;
+template <int PM>
+__global__ __launch_bounds__(1024) void k_mbc_l2(MbDev D, MbSolve q, OcParams o) {
+    static_assert(PM != 2, "mean projection or none");
+    constexpr int NT = 1024, G = 4, NW = NT / 64;
+    __shared__ mb_real v_lds[OC_L2_CELLS];
+    __shared__ double red[3][2][OC_MAX_WAVES];
+    __shared__ mb_real l_r4[OC_N4], l_r8[OC_N8];
+    __shared__ __attribute__((aligned(16))) mb_real l_rt[NW * OC_N8];
+    mb_real (*l_part)[OC_N8] = reinterpret_cast<mb_real (*)[OC_N8]>(l_rt);
+    int phase = 0;
+    const int sys = blockIdx.x, N = D.N, t = threadIdx.x;
+    const unsigned un = (unsigned)N, ut = (unsigned)t;
+    const size_t vb = (size_t)sys * N;
+    if (!mb_active(o.dt, sys)) {
+        if (t == 0) {
+            flag_st(q.flags + (sys), 3);
+            q.info[sys].final_residual = 0.f; q.info[sys].used_iterations = -1; q.info[sys].converged = 1; q.info[sys].is_finite = 1;
+            o.info_host[sys] = q.info[sys];
+            o.its_host[sys] = 0;
+            fg_poll_publish(o.poll, sys);
+        }
+        return;
+    }
+    const mb_real rsqn = mb_rsqrt((mb_real)N);
+    const mb_real* __restrict__ rhs = q.rhs + vb;
+    const mb_real* __restrict__ diag = q.diag + vb;
+    const float4* __restrict__ off4 = reinterpret_cast<const float4*>(o.off4) + (size_t)sys * N;
+    const uint2* __restrict__ nb2 = reinterpret_cast<const uint2*>(o.nbr16);
+    mb_real* xg = q.x + vb;       // (no __restrict__: the vectors are re-read after they were written)
+    mb_real* rg = q.r + vb;
+    mb_real* ag = q.v + vb;       // M p of the stencil pass; before it, z of the preconditioner pass
+    mb_real* bestx = q.best_x + vb;
+    // batches of G members: the loads of a batch are requested together (out-of-range members read cell 0 and contribute nothing)
+#define L2_BATCHES(i0) for (unsigned i0 = ut; i0 < un; i0 += G * NT)
+#define L2_MEMBERS(g, i, ok, i0) _Pragma("unroll") for (int g = 0; g < G; ++g) if (const unsigned i = (i0) + (unsigned)g * NT; true) if (const bool ok = i < un; true)
+    // ---- start: x = x0 or 0, r = rhs (- M x0 through a residual pass)
+    double rr = 0.0, sr = 0.0;
+    mb_real inv_s = 1.f;
+    {
+        mb_real sd = 0.f, s2 = 0.f, s1 = 0.f;
+        L2_BATCHES(i0) {
+            mb_real rv[G], dv[G];
+            L2_MEMBERS(g, i, ok, i0) { rv[g] = rhs[ok ? i : 0]; dv[g] = diag[ok ? i : 0]; }
+            L2_MEMBERS(g, i, ok, i0) {
+                if (ok) {
+                    rg[i] = rv[g];
+                    if (!o.use_x0) xg[i] = 0.f;
+                    sd += dv[g]; s2 += rv[g] * rv[g]; s1 += rv[g] * rsqn;
+                }
+            }
+        }
+        double dsum, unused0;
+        oc_reduce2<NT, false>(sd, 0.f, red, phase, dsum, unused0);
+        inv_s = (mb_real)((double)o.pre.geom_diag_sum / dsum);
+        if (!o.use_x0) {
+            oc_reduce2<NT, false>(s2, s1, red, phase, rr, sr);
+            if (PM == 0) sr = 0.0;
+        }
+    }
+    double rz = 0.0, rz_prev = 1.0;
+    int it = 0, best_it = 0, recoveries = 0, outcome = 0;   // outcome: 1 converged, 2 non-finite, 3 accepted on the kept iterate, 4 out of iterations / stalled
+    mb_real best = 3.0e38f, crit = 0.f;
+    bool fresh = true, restarted = true, residual_pass = o.use_x0 != 0, recovering = false;
+    double rho = 0.0;
+    const int n4 = o.pre.n4, n8 = o.pre.n8;
+    for (;;) {
+        mb_real beta = 0.f, cy = 0.f;
+        if (!residual_pass) {
+            rho = rr - sr * sr;   // |r - (yp.r) yp|^2
+            crit = mb_rms(rho, N);
+            if (!(crit >= o.tol)) {
+                if (isfinite(crit)) { outcome = 1; break; }
+                // the recurrence broke down: back to the kept iterate
+                if (recovering || recoveries >= 3 || it + o.check_every >= o.max_iterations) { outcome = 2; break; }
+                ++recoveries;
+                L2_BATCHES(i0) {
+                    mb_real bv[G];
+                    L2_MEMBERS(g, i, ok, i0) bv[g] = bestx[ok ? i : 0];
+                    L2_MEMBERS(g, i, ok, i0) if (ok) xg[i] = isfinite(bv[g]) ? bv[g] : 0.f;
+                }
+                residual_pass = true; recovering = true;
+            } else {
+                recovering = false;
+                // keep x_it when it beats the kept iterate by 2x (or at all inside the acceptance band): returnBestResult
+                if (it == 0 || crit < 0.5f * best || (crit < o.accept_factor * o.tol && crit < best)) {
+                    best = crit; best_it = it;
+                    L2_BATCHES(i0) {
+                        mb_real xv[G];
+                        L2_MEMBERS(g, i, ok, i0) xv[g] = xg[ok ? i : 0];
+                        L2_MEMBERS(g, i, ok, i0) if (ok) bestx[i] = xv[g];
+                    }
+                }
+                if (it > 0 && it % o.check_every == 0) {   // the cadence of k_mbs_check in the chunked solver
+                    if (o.accept_factor > 0.f && best <= o.accept_factor * o.tol && (it - 1) - best_it >= o.accept_window) { outcome = 3; break; }
+                    if (o.stall_limit > 0 && (it - 1) - best_it > o.stall_limit) { outcome = 4; break; }
+                }
+                if (it >= o.max_iterations) { outcome = 4; break; }
+                if (it > 0 && it % o.restart_every == 0 && !restarted) residual_pass = true;   // residualResetSteps (cg_solver_kernel.cu:281-300)
+            }
+        }
+        mb_real zbar = 0.f;
+        if (!residual_pass) {
+            restarted = false;
+            cy = (mb_real)sr;
+            // ---- z = M (r - mean r): 4 x 4 aggregate sums gathered from r (every aggregate is a rectangle of cells of one block),
+            // 8 x 8 sums of their children, dense coarse solve by the waves, corrections summed top-down into l_r4
+            const mb_real rm = PM == 1 ? cy * rsqn : 0.f;
+            for (int a = t; a < n4; a += NT) {
+                const uint2 rc = o.pre.rect4[a];
+                const unsigned w = rc.y & 0xffu, h = (rc.y >> 8) & 0xffu, stride = rc.y >> 16;
+                mb_real val[4][4];
+#pragma unroll
+                for (unsigned dy = 0; dy < 4; ++dy)
+#pragma unroll
+                    for (unsigned dx = 0; dx < 4; ++dx) val[dy][dx] = rg[rc.x + (dy < h ? dy : h - 1) * stride + (dx < w ? dx : w - 1)];
+                mb_real sum = 0.f;
+#pragma unroll
+                for (unsigned dy = 0; dy < 4; ++dy)
+#pragma unroll
+                    for (unsigned dx = 0; dx < 4; ++dx) sum += (dy < h && dx < w) ? val[dy][dx] - rm : 0.f;
+                l_r4[a] = sum;
+            }
+            __syncthreads();
+            for (int a = t; a < n8; a += NT) {
+                const uint2 ch = o.pre.child8[a];
+                const unsigned c0 = ch.x & 0xffffu, c1 = ch.x >> 16, c2 = ch.y & 0xffffu, c3 = ch.y >> 16;
+                l_r8[a] = (c0 != 0xffffu ? l_r4[c0] : 0.f) + (c1 != 0xffffu ? l_r4[c1] : 0.f) + (c2 != 0xffffu ? l_r4[c2] : 0.f) +
+                          (c3 != 0xffffu ? l_r4[c3] : 0.f);
+            }
+            __syncthreads();
+            {   // e8 = A8^+ r8: wave g takes the columns c = g, g + 16, ..., lane q the four rows 4q .. 4q+3 (k_mbc_onchip)
+                const int ld = (n8 + 3) & ~3, nq = ld >> 2, grp = t >> 6;
+                for (int qd = t & 63; qd < nq; qd += 64) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                    for (int c = grp; c < n8; c += NW) {
+                        const float4 a = *reinterpret_cast<const float4*>(o.pre.aci8 + (unsigned)c * (unsigned)ld + 4u * (unsigned)qd);
+                        const mb_real rc = l_r8[c];
+                        acc.x += a.x * rc; acc.y += a.y * rc; acc.z += a.z * rc; acc.w += a.w * rc;
+                    }
+                    *reinterpret_cast<float4*>(&l_part[grp][4 * qd]) = acc;
+                }
+            }
+            __syncthreads();
+            for (int a = t; a < n4; a += NT) {
+                const int row = o.pre.parent4[a];
+                mb_real e = 0.f;
+#pragma unroll
+                for (int g = 0; g < NW; ++g) e += l_part[g][row];
+                l_r4[a] = inv_s * (0.5f * l_r4[a] * o.pre.d4g[a] + e);   // d4g holds reciprocals
+            }
+            __syncthreads();
+            mb_real s_rz = 0.f, s_z = 0.f;
+            L2_BATCHES(i0) {
+                mb_real rv[G], dv[G]; unsigned av[G];
+                L2_MEMBERS(g, i, ok, i0) { rv[g] = rg[ok ? i : 0]; dv[g] = diag[ok ? i : 0]; av[g] = o.pre.a4[ok ? i : 0]; }
+                L2_MEMBERS(g, i, ok, i0) {
+                    if (ok) {
+                        const mb_real rt = rv[g] - rm;
+                        const mb_real z = rt * __builtin_amdgcn_rcpf(dv[g]) + l_r4[av[g]];   // v_rcp_f32: a preconditioner needs no IEEE division
+                        ag[i] = z;
+                        s_rz += rt * z; s_z += z;
+                    }
+                }
+            }
+            double zsum;
+            oc_reduce2<NT, false>(s_rz, s_z, red, phase, rz, zsum);
+            zbar = PM == 1 ? (mb_real)(zsum / (double)N) : 0.f;
+            beta = fresh ? 0.f : (mb_real)(rz / rz_prev);
+        }
+        // ---- the vector the stencil is applied to: x, or p = (z - mean z) + beta p (every thread rewrites its own cells)
+        L2_BATCHES(i0) {
+            mb_real sv[G];
+            L2_MEMBERS(g, i, ok, i0) sv[g] = residual_pass ? xg[ok ? i : 0] : ag[ok ? i : 0];
+            L2_MEMBERS(g, i, ok, i0) {
+                if (ok) {
+                    mb_real v = sv[g];
+                    if (!residual_pass) { v -= zbar; if (!fresh) v += beta * v_lds[i]; }
+                    v_lds[i] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stencil pass: M p (or M x) of the thread's cells, p . M p
+        mb_real part = 0.f, s2 = 0.f, s1 = 0.f;
+        L2_BATCHES(i0) {
+            uint2 ub[G]; float4 cb[G]; mb_real dd[G], rh[G];
+            L2_MEMBERS(g, i, ok, i0) {
+                ub[g] = nb2[ok ? i : 0]; cb[g] = off4[ok ? i : 0]; dd[g] = diag[ok ? i : 0];
+                if (residual_pass) rh[g] = rhs[ok ? i : 0];
+            }
+            L2_MEMBERS(g, i, ok, i0) {
+                if (ok) {
+                    const uint32_t n0 = ub[g].x & 0xffffu, n1 = ub[g].x >> 16, n2 = ub[g].y & 0xffffu, n3 = ub[g].y >> 16;
+                    // prescribed face (0xFFFF): no matrix entry; the gather reads the cell itself so that it stays in bounds
+                    const mb_real vc = v_lds[i];
+                    const mb_real v0 = v_lds[n0 != 0xffffu ? n0 : i], v1 = v_lds[n1 != 0xffffu ? n1 : i];
+                    const mb_real v2 = v_lds[n2 != 0xffffu ? n2 : i], v3 = v_lds[n3 != 0xffffu ? n3 : i];
+                    mb_real acc = dd[g] * vc;
+                    acc += n0 != 0xffffu ? cb[g].x * v0 : 0.f;
+                    acc += n1 != 0xffffu ? cb[g].y * v1 : 0.f;
+                    acc += n2 != 0xffffu ? cb[g].z * v2 : 0.f;
+                    acc += n3 != 0xffffu ? cb[g].w * v3 : 0.f;
+                    if (residual_pass) {
+                        const mb_real rnew = rh[g] - acc;
+                        rg[i] = rnew;
+                        s2 += rnew * rnew; s1 += rnew * rsqn;
+                    } else {
+                        ag[i] = acc;
+                        part += vc * acc;
+                    }
+                }
+            }
+        }
+        if (residual_pass) {
+            oc_reduce2<NT, false>(s2, s1, red, phase, rr, sr);
+            if (PM == 0) sr = 0.0;
+            residual_pass = false; fresh = true; restarted = true;
+            continue;
+        }
+        double pap, unused;
+        oc_reduce2<NT, false>(part, 0.f, red, phase, pap, unused);
+        const mb_real alpha = (mb_real)(rz / pap);
+        L2_BATCHES(i0) {
+            mb_real xv[G], rv[G], av[G];
+            L2_MEMBERS(g, i, ok, i0) { xv[g] = xg[ok ? i : 0]; rv[g] = rg[ok ? i : 0]; av[g] = ag[ok ? i : 0]; }
+            L2_MEMBERS(g, i, ok, i0) {
+                if (ok) {
+                    xg[i] = xv[g] + alpha * v_lds[i];
+                    const mb_real rnew = rv[g] - alpha * av[g];
+                    rg[i] = rnew;
+                    s2 += rnew * rnew; s1 += rnew * rsqn;
+                }
+            }
+        }
+        oc_reduce2<NT, false>(s2, s1, red, phase, rr, sr);   // (its barriers also order this pass's stores of r before the aggregate gathers of the next)
+        if (PM == 0) sr = 0.0;
+        rz_prev = rz;
+        fresh = false;
+        ++it;
+    }
+    // ---- hand back: the last iterate when converged (it is in place), the kept one otherwise (k_mbs_restore_best)
+    const bool use_best = (outcome == 3 || outcome == 4 || (outcome == 2 && best < 3.0e38f));
+    if (use_best) {
+        L2_BATCHES(i0) {
+            mb_real bv[G];
+            L2_MEMBERS(g, i, ok, i0) bv[g] = bestx[ok ? i : 0];
+            L2_MEMBERS(g, i, ok, i0) if (ok) xg[i] = bv[g];
+        }
+    }
+#undef L2_BATCHES
+#undef L2_MEMBERS
+    if (t == 0) {
+        flag_st(q.flags + (sys), outcome == 2 ? 2 : (outcome == 3 ? 5 : 1));
+        q.info[sys].final_residual = use_best ? best : crit;
+        q.info[sys].used_iterations = use_best ? best_it : it;
+        q.info[sys].converged = (outcome == 1 || outcome == 3) ? 1 : 0;
+        q.info[sys].is_finite = outcome != 2 ? 1 : 0;
+        q.best_it[sys] = it;   // total iterations run (profiling: the host sums them)
+        o.info_host[sys] = q.info[sys];
+        o.its_host[sys] = it;
+        fg_poll_publish(o.poll, sys);
+    }
+}
+
 }  // namespace
 
 #define OC_FIRST(a, ...) a
@@ -658,7 +955,13 @@ int mb_cg_onchip(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const m
     // iteration): 16 cells per thread with the two-barrier reduction 11.7-11.8; the same with the one-barrier ring 14.5; 14
     // cells per thread 15.8-16.3; neighbour indices in registers 17.4; 512 threads x 256 registers 18.3 -- what the
     // compiler's schedule makes of each form decides, not the instruction count.  Small meshes keep the indices in registers.
-    const bool pre = s->ml_on && s->ml_a4 != nullptr && n <= 16 * 1024 && s->ml_n4 <= OC_N4 && s->ml_n8 <= OC_N8;   // LDS: p, r - mean r and the aggregate tables
+    // LDS: p, r - mean r and the aggregate tables; 16-24 k cells: r - mean r in a global scratch vector (RTG instance)
+    const bool pre = s->ml_on && s->ml_a4 != nullptr && n <= 24 * 1024 && s->ml_n4 <= OC_N4 && s->ml_n8 <= OC_N8;
+    o.rt_scratch = nullptr;
+    if (pre && n > 16 * 1024) {
+        if (!s->oc_rt_scratch) { if (int rc = mb_alloc(s, &s->oc_rt_scratch, (size_t)s->B * s->N)) return rc; }
+        o.rt_scratch = s->oc_rt_scratch;
+    }
     o.pre.a4 = s->ml_a4; o.pre.parent4 = s->ml_parent4; o.pre.d4g = s->ml_d4g; o.pre.aci8 = s->ml_aci8;
     o.pre.rect4 = s->ml_rect4; o.pre.child8 = s->ml_child8;
     o.pre.n4 = s->ml_n4; o.pre.n8 = s->ml_n8; o.pre.geom_diag_sum = s->ml_geom_diag_sum;
@@ -676,6 +979,17 @@ int mb_cg_onchip(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const m
     else if (n <= 4 * 1024) OC_LAUNCH_PRE(4, true, true);
     else if (n <= 8 * 1024) OC_LAUNCH_PRE(8, true, true);
     else if (n <= 16 * 1024) OC_LAUNCH_PRE(16, false, false);
+    else if (n <= OC_L2_CELLS && pre && o.off4 != nullptr && s->oc_rtg_nt != 1) {
+        // 16-24 k cells: vectors in L2, p in LDS (k_mbc_l2; FG_MB_OC_RTG_NT=1 picks the register-resident form with its residual copy in global memory)
+        if (ev) {
+            if (pm_mode == 0) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_l2<0>), dim3(nsys), dim3(1024), 0, st, s->prof_ev_oc[0], s->prof_ev_oc[1], 0, s->dev, q, o);
+            else hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_l2<1>), dim3(nsys), dim3(1024), 0, st, s->prof_ev_oc[0], s->prof_ev_oc[1], 0, s->dev, q, o);
+        } else {
+            if (pm_mode == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_l2<0>), dim3(nsys), dim3(1024), 0, st, s->dev, q, o);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbc_l2<1>), dim3(nsys), dim3(1024), 0, st, s->dev, q, o);
+        }
+    }
+    else if (n <= 24 * 1024 && pre) OC_LAUNCH_PM(24, false, 1024, false, false, true, false, true);
     else if (n <= 24 * 1024) OC_LAUNCH_PM(24, false, 1024, false, false, false);
     else OC_LAUNCH_PM(28, false, 1024, false, false, false);
 #undef OC_LAUNCH_PRE

@@ -456,6 +456,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_ML_WARMUP"); if (e && atoi(e) > 0) { s->dbg_ml_warmup = atoi(e); s->ml_bicg_skip = s->dbg_ml_warmup; }
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
+        if (const char* e = getenv("FG_MB_OC_RTG_NT")) s->oc_rtg_nt = atoi(e);   // 1: the register-resident form on 16-24 k cells instead of k_mbc_l2
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_AGG"); s->dbg_oc_agg = (e && e[0] == '0') ? 0 : 1;

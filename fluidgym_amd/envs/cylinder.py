@@ -38,6 +38,9 @@ CYLINDER_JET_2D_DEFAULT_CONFIG = {
 CYLINDER_ROT_2D_DEFAULT_CONFIG = dict(CYLINDER_JET_2D_DEFAULT_CONFIG)
 
 
+ONCHIP_PCG_MAX_CELLS = 24 * 1024   # the multilevel-preconditioned on-chip CG (2-D): fg_mb_onchip.hip OC_L2_CELLS
+
+
 class CylinderEnvBase(FluidEnv):
     _supports_marl = False
     _action_smoothing_alpha: float = 0.1
@@ -135,11 +138,13 @@ class CylinderEnvBase(FluidEnv):
                             non_ortho_flags=self._non_ortho_flags, dtype=self._dtype)
 
     def _get_simulation(self, domain, prep_fn):
-        # solver policy pressure_bicgstab_large_meshes: beyond the preconditioned on-chip CG's reach (16 384 cells) the pressure
-        # systems go to the fp64-refined BiCGStab unless the caller chose (policy.py)
+        # solver policy pressure_bicgstab_large_meshes: beyond the preconditioned on-chip CG's reach (2-D meshes of up to 24 576 cells:
+        # every 2-D id; csrc/fg_mb_onchip.hip k_mbc_onchip / k_mbc_l2) the pressure systems go to the fp64-refined BiCGStab unless
+        # the caller chose (policy.py)
         from ..simulation.policy import get_solver_policy
         if self._pressure_use_bicg is None:     # (None = not chosen by the caller; False = the reference's CG, 1 / 2 = BiCGStab / refined)
-            self._pressure_use_bicg = 2 if (get_solver_policy()["pressure_bicgstab_large_meshes"] and domain.n_cells > 16384) else False
+            self._pressure_use_bicg = 2 if (get_solver_policy()["pressure_bicgstab_large_meshes"]
+                                            and (self._ndims == 3 or domain.n_cells > ONCHIP_PCG_MAX_CELLS)) else False
         sim = MultiBlockSimulation(domain, dt=self._dt, adaptive_CFL=self._adaptive_cfl, substeps="ADAPTIVE", corrector_steps=2,
                                    pressure_tol=1e-5 if self._ndims == 2 else 5e-7, advect_non_ortho_steps=1,
                                    pressure_non_ortho_steps=1 if self._ndims == 2 else 4,

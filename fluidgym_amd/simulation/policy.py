@@ -43,11 +43,12 @@ benchmark line can say which mode it ran in:
     much per iteration as it saves.  The ``preconditionBiCG`` / ``BiCG_precondition_fallback`` kwargs work either way.
 
 ``pressure_bicgstab_large_meshes`` (default True)
-    Cylinder envs on meshes beyond the preconditioned on-chip CG (more than 16 384 cells: the ``medium`` / ``hard`` 2-D ids at
-    resolution 32 and every 3-D id): the pressure systems are solved by the fp64-refined BiCGStab (the airfoil envs' solver,
-    ``pressure_use_BiCG = 2``) instead of the reference's plain CG -- same systems, same tolerance; CG needs 100-220 iterations per
-    solve there and BiCGStab 37-44 (``CylinderJet2D-medium-v0`` x 64: 103 -> 245 env-steps/s, ``-hard``: 123 -> 248,
-    ``CylinderJet3D-easy-v0`` x 4: 3.2 -> 4.4).  ``False``, or ``pressure_use_BiCG`` given explicitly to the env, keeps the choice.
+    Cylinder envs on meshes beyond the preconditioned on-chip CG (every 3-D id, and 2-D meshes of more than 24 576 cells): the
+    pressure systems are solved by the fp64-refined BiCGStab (the airfoil envs' solver, ``pressure_use_BiCG = 2``) instead of the
+    reference's plain CG -- same systems, same tolerance; plain CG needs 100-220 iterations per solve there and BiCGStab 37-44
+    (``CylinderJet3D-easy-v0`` x 4: 3.2 -> 4.4).  ``False``, or ``pressure_use_BiCG`` given explicitly to the env, keeps the choice.
+    Rounds 2-3 also sent the ``medium`` / ``hard`` 2-D ids (resolution 32, 23 k cells) this way (103 -> 245 env-steps/s at 64 envs);
+    since round 4 the multilevel-preconditioned on-chip CG reaches them (``k_mbc_l2``: 16 iterations per solve, 527 env-steps/s).
 
 ``advection_rung_preconditioner`` (default ``"line"``)
     Single-block path: which preconditioner the reference's rungs use -- ``preconditionBiCG`` (every solve) and
