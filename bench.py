@@ -185,18 +185,18 @@ def roofline_from_profile(prof, solver):
                     "resident kernels can exceed the HBM figure; poisson_256 is the HBM-resident case"}
 
 
-def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
+def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True, env_id="CylinderJet2D-easy-v0"):
     """The reference's own cylinder env (CylinderJet2D-easy-v0: five-block curvilinear mesh, 14 232 cells, Re 100, 25 PISO
     steps per env step) on the multi-block path, batched like the headline workload and driven by the same random policy.
     Pressure solves: CG, cold-started as in the reference; at this mesh size the whole solve of an env runs inside one
-    workgroup (k_mbc_onchip).  ``warm_start_mode`` = the opt-in performance mode (previous pressure as initial guess,
-    stall acceptance 1.25) of the same leg."""
+    workgroup (k_mbc_onchip; on the ``medium`` / ``hard`` meshes of 23 k cells its vectors live in L2 and only p in LDS: k_mbc_l2).
+    ``warm_start_mode`` = the opt-in performance mode (previous pressure as initial guess, stall acceptance 1.25) of the same leg."""
     import torch
 
     import fluidgym_amd
 
     def run(n_steps):
-        env = fluidgym_amd.make("CylinderJet2D-easy-v0", num_envs=num_envs, initial_domain_steps=100,
+        env = fluidgym_amd.make(env_id, num_envs=num_envs, initial_domain_steps=100,
                                 randomize_initial_state=False, cuda_device=device)
         try:
             env.reset(seed=0)
@@ -243,7 +243,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True):
         finally:
             env.close()
 
-    out = {"env_id": "CylinderJet2D-easy-v0", "envs": num_envs, "policy": "uniform random jets in [-1, 1] (as the headline)",
+    out = {"env_id": env_id, "envs": num_envs, "policy": "uniform random jets in [-1, 1] (as the headline)",
            "pressure_solver": "CG, cold-started (reference policy), additive multilevel preconditioner, whole solve per env on-chip",
            "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline)"}
     out.update(run(steps))
@@ -717,6 +717,7 @@ def main():
         leg("tcf_env", env_leg, "TCF3D-baseline-v0", 8, device, steps=8, warmup=1,
             doc="BASELINE config 3: turbulent channel 128x64x64, 8 envs")
         leg("cylinder_env", cylinder_env_leg, device, steps=6, extra_modes=args.all_legs)
+        leg("cylinder_medium_env", cylinder_env_leg, device, steps=3, extra_modes=False, env_id="CylinderJet2D-medium-v0")
         if not args.no_airfoil_leg:
             # BASELINE config 4 ("batch=512 across 8 GPUs"): 64 envs are one GPU's share (rounds 1-3 quoted 16 envs: `airfoil_env_16`
             # under --all-legs; the kernels are launch-latency-bound at 16 x 46.7 k cells, so the larger batch costs little more time)
