@@ -626,14 +626,17 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             // one transfer: [0..B) boundary flux balance, [B..2B) max |Minv u| (CFL velocity)
             // both kernels publish straight into the host-pinned diag_pinned (one workgroup per env writes the flux
             // balance; the last workgroup of each env mirrors the max velocity): the read-back is a stream synchronise
-            // (the host waits on the sequence words the two kernels publish behind their results: FgPoll, fg_internal.h)
+            // The host waits on sequence words published behind the results (FgPoll, fg_internal.h): ONE word behind the CFL maxima
+            // (fg_publish_max), which the in-order stream also puts behind the flux balances of the kernel in front of it; without the
+            // CFL kernel, one word per env behind the flux balance.
             const FgPollOut po = fg_poll_next(&s->poll);
-            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, po)) return rc; }
+            const FgPollOut none = FgPollOut{nullptr, 0};
+            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, o->adaptive ? none : po)) return rc; }
             if (o->adaptive) {
                 if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B, po.seq ? FgPollOut{po.seq + B, po.value} : po))
                     return rc;
             }
-            if (int rc = fg_poll_wait(&s->poll, po, first ? 0 : B, (first ? B : 0) + (o->adaptive ? B : 0), st)) return rc;
+            if (int rc = fg_poll_wait(&s->poll, po, o->adaptive ? B : 0, o->adaptive ? 1 : B, st)) return rc;
             if (first) {
                 fg_real worst = 0.f;
                 for (int b = 0; b < B; ++b) {

@@ -347,26 +347,41 @@ typedef int fg_bits;
 __device__ __forceinline__ fg_bits fg_real_bits(fg_real v) { return __float_as_int(v); }
 __device__ __forceinline__ fg_real fg_bits_real(fg_bits b) { return __int_as_float(b); }
 #endif
-__device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx, const FgPollOut& poll) {
-    if (!mirror_B) {
-        atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, fg_real_bits(mx));
-        return;
-    }
-    // Order "my maximum is in" before "I have arrived" without a fence: the RETURNING atomicMax is consumed (the wave
-    // waits for its result, i.e. until the device-scope atomic has been performed) before the arrival counter is bumped.
-    // An agent-scope __threadfence() here writes back L2 in each of the 2048 workgroups: 14 us -> 45 us for this kernel.
-    fg_bits prev = atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, fg_real_bits(mx));
+// Called by the whole FIRST WAVE of the workgroup (lane 0 carries the workgroup's maximum).
+__device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx, const FgPollOut& poll, int B) {
+    const int lane = threadIdx.x & 63;
+    int last_of_all = 0;
+    if (lane == 0) {
+        if (!mirror_B) {
+            atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, fg_real_bits(mx));
+        } else {
+            // Order "my maximum is in" before "I have arrived" without a fence: the RETURNING atomicMax is consumed (the wave
+            // waits for its result, i.e. until the device-scope atomic has been performed) before the arrival counter is bumped.
+            // An agent-scope __threadfence() here writes back L2 in each of the 2048 workgroups: 14 us -> 45 us for this kernel.
+            fg_bits prev = atomicMax(reinterpret_cast<fg_bits*>(out_B) + b, fg_real_bits(mx));
 #if FG_F64
-    asm volatile("" ::"v"((int)(prev >> 32)), "v"((int)prev));
+            asm volatile("" ::"v"((int)(prev >> 32)), "v"((int)prev));
 #else
-    asm volatile("" ::"v"(prev));
+            asm volatile("" ::"v"(prev));
 #endif
-    if (atomicAdd(done_B + b, 1) == (int)gridDim.x - 1) {
-        // the last workgroup of the env: atomic read of the final value, which also leaves the maximum and the arrival counter
-        // zeroed for the next launch (fg_launch_max_velocity then needs no memset in front of it)
-        mirror_B[b] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + b, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        atomicExch(done_B + b, 0);
-        fg_poll_publish(poll, b);
+            // the last workgroup of the env bumps the counter of finished envs (behind the per-env counters: done_B[B])
+            if (atomicAdd(done_B + b, 1) == (int)gridDim.x - 1) last_of_all = (atomicAdd(done_B + B, 1) == B - 1);
+        }
+    }
+    if (!mirror_B) return;
+    // The workgroup that finishes the LAST env hands everything to the host: atomic reads of the final values (which also leave the
+    // maxima and every counter zeroed for the next launch: no memset in front of it), the host-pinned mirror, and ONE sequence
+    // word behind it -- one L2 write-back at the very end of the kernel (64 of them, one per env, while the other workgroups
+    // were still streaming, cost 10 us: fg_poll_publish).
+    if (__shfl(last_of_all, 0, 64)) {
+        for (int e = lane; e < B; e += 64) {
+            mirror_B[e] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            atomicExch(done_B + e, 0);
+        }
+        if (lane == 0) {
+            atomicExch(done_B + B, 0);
+            fg_poll_publish(poll, 0);
+        }
     }
 }
 
@@ -411,9 +426,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
     mx = fg_wave_max(mx);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y);
     }
 }
 
@@ -472,9 +487,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
     mx = fg_wave_max(mx);
     if (lane == 0) lds[wave] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y);
     }
 }
 
@@ -835,8 +850,10 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_
     // out_B [B] and the arrival counters right behind it (scratch_B rows 1 and 2) are zeroed together
     int32_t* done_B = reinterpret_cast<int32_t*>(out_B + s->grid.B);
     FG_REQUIRE(!mirror_B || out_B == s->scratch_B + s->grid.B, FG_ERR_INVALID_ARG, "mirror needs the scratch row as out_B");
-    // (the mirrored form cleans up after itself: the memset is only needed after something else used the rows)
-    if (!mirror_B || !s->maxvel_clean) FG_HIP_CHECK(hipMemsetAsync(out_B, 0, sizeof(fg_real) * s->grid.B * (mirror_B ? 2 : 1), st));
+    // (the mirrored form cleans up after itself: the memset -- maxima, per-env counters and the counter of finished envs behind
+    // them -- is only needed after something else used the rows)
+    if (!mirror_B || !s->maxvel_clean)
+        FG_HIP_CHECK(hipMemsetAsync(out_B, 0, mirror_B ? sizeof(fg_real) * s->grid.B + sizeof(int32_t) * (s->grid.B + 1) : sizeof(fg_real) * s->grid.B, st));
     s->maxvel_clean = mirror_B ? 1 : 0;
     if ((s->grid.nx & 3) == 0) {
         const int rows = s->grid.ny * s->grid.nz;

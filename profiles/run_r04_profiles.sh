@@ -29,6 +29,7 @@ fi
 if [ $W = all ] || [ $W = legs ]; then
   stats b_poisson256 python3 $R/profiles/micro_poisson.py
   stats c_cylinder python3 $R/profiles/leg_run.py CylinderJet2D-easy-v0 64 4 1 0 initial_domain_steps=100 randomize_initial_state=false
+  stats d_cylinder_medium python3 $R/profiles/leg_run.py CylinderJet2D-medium-v0 64 3 1 0 initial_domain_steps=100 randomize_initial_state=false
   stats e_airfoil64 python3 $R/profiles/airfoil_bench.py 64 2 40
   stats f_tcf $TCF
   stats g_rbc python3 $R/profiles/leg_run.py RBC2D-baseline-v0 32 5 1
