@@ -189,3 +189,58 @@ def test_zmarch_step_is_bit_reproducible_and_batch_independent(monkeypatch):
         outs.append((ns.velocity.clone(), ns.pressure.clone()))
         ns.close()
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
+def test_solver_state_prepared_by_the_assembly_kernels_survives_foreign_calls_in_between(monkeypatch):
+    """Round 4: the state of a solve (accumulators, flags, info) is prepared by the kernel launched in front of it -- k_adv_build for the
+    BiCGStab solve, k_div for the pressure CG (FgBicgBegin / FgCgBegin) -- and the solver skips its own begin launch when the record of
+    who prepared what matches.  The two solvers share flags and info, so a call of the OTHER solver between assembly and solve must
+    drop the record: setup_pressure_rhs -> solve_pressure gives bit for bit the same pressure with and without an advection solve
+    in between (the right-hand side was built before it), and setup_advection -> solve_advection the same velocity with and without
+    a pressure solve in between; repeated solves on one assembly (the ladder's situation) are bit-identical too."""
+    import torch
+
+    case = make_case(dims=2, n=(64, 32), fixed_axes=(1,), B=3, seed=21, vel_scale=0.4, nu=0.03)
+    dt = 0.05
+    shape_v = (case.B, case.dims) + case.shape
+    shape_p = (case.B,) + case.shape
+
+    def pressure(with_foreign_call):
+        ns = case.native()
+        ns.setup_advection(dt)
+        assert all(i.converged for i in ns.solve_advection(tol=1e-7))
+        ns.setup_pressure_matrix()
+        ns.setup_pressure_rhs(dt)
+        if with_foreign_call:
+            assert all(i.converged for i in ns.solve_advection(tol=1e-7))      # BiCGStab on the same assembly: rewrites flags / info
+        info = ns.solve_pressure(tol=1e-7)
+        p = ns.buffer(6, shape_p).clone()
+        info2 = ns.solve_pressure(tol=1e-7)                                    # a second solve on the same right-hand side
+        p2 = ns.buffer(6, shape_p).clone()
+        ns.close()
+        return p, p2, info, info2
+
+    p_a, p_a2, info_a, info_a2 = pressure(False)
+    p_b, p_b2, info_b, _ = pressure(True)
+    assert all(i.converged and i.is_finite for i in info_a + info_b + info_a2)
+    assert [i.used_iterations for i in info_a] == [i.used_iterations for i in info_b] == [i.used_iterations for i in info_a2]
+    assert torch.equal(p_a, p_b) and torch.equal(p_a, p_a2) and torch.equal(p_b, p_b2)
+    assert float(p_a.abs().max()) > 0
+
+    def velocity(with_foreign_call):
+        ns = case.native()
+        ns.setup_advection(dt)
+        if with_foreign_call:
+            ns.setup_pressure_matrix()
+            ns.setup_pressure_rhs(dt)                                          # k_div prepares the CG's state over the BiCGStab's
+            ns.solve_pressure(tol=1e-7)
+        info = ns.solve_advection(tol=1e-7)
+        u = ns.buffer(3, shape_v).clone()
+        ns.close()
+        return u, info
+
+    u_a, inf_a = velocity(False)
+    u_b, inf_b = velocity(True)
+    assert all(i.converged for i in inf_a + inf_b)
+    assert [i.used_iterations for i in inf_a] == [i.used_iterations for i in inf_b]
+    assert torch.equal(u_a, u_b)
