@@ -669,11 +669,15 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
         // PRE hook: advective outflow + flux re-balancing (cylinder_env_base.py:280-300)
         if (o->outflow_mask) {
             for (int f = 0; f < 2 * s->grid.dims; ++f)
-                if ((o->outflow_mask >> f) & 1) {
-                    FG_REQUIRE(s->grid.fixed[f], FG_ERR_INVALID_ARG, "outflow face is not FIXED");
-                    if (int rc = fg_launch_outflow(s, f, o->outflow_velm[f >> 1], s->dt_dev, st)) return rc;
-                }
-            if (int rc = fg_launch_balance(s, bnd, o->outflow_mask, (fg_real)0.01 * o->outflow_tol, s->dt_dev, st)) return rc;
+                if ((o->outflow_mask >> f) & 1) FG_REQUIRE(s->grid.fixed[f], FG_ERR_INVALID_ARG, "outflow face is not FIXED");
+            const bool folded = fg_outflow_folds(s, o->outflow_mask);     // small slabs: the update rides in the balance launch
+            if (!folded)
+                for (int f = 0; f < 2 * s->grid.dims; ++f)
+                    if ((o->outflow_mask >> f) & 1)
+                        if (int rc = fg_launch_outflow(s, f, o->outflow_velm[f >> 1], s->dt_dev, st)) return rc;
+            fg_real velm3[3] = {o->outflow_velm[0], o->outflow_velm[1], o->outflow_velm[2]};
+            if (int rc = fg_launch_balance(s, bnd, o->outflow_mask, (fg_real)0.01 * o->outflow_tol, s->dt_dev, st, folded ? o->outflow_mask : 0, velm3))
+                return rc;
         }
         int rc = fg_piso_step(s, s->dt_dev, &o->step, stats, stream);
         if (rc == FG_ERR_NOT_CONVERGED) all_ok = 0;

@@ -787,7 +787,9 @@ int fg_launch_copy_active(const fg_state* s, const fg_real* dt, const fg_real* s
 int fg_launch_buoyancy(const fg_state* s, const fg_real* dt, const fg_real* T, long t_env_stride, fg_real* source, int axis,
                        fg_real factor, hipStream_t st);
 int fg_launch_outflow(const fg_state* s, int face, fg_real velm_axis, const fg_real* dt, hipStream_t st);
-int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st);
+int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st,
+                      int outflow_mask = 0, const fg_real* outflow_velm = nullptr);   // outflow_mask: faces whose convective update rides in this launch
+bool fg_outflow_folds(const fg_state* s, int outflow_mask);
 int fg_launch_mean_sub(const fg_state* s, const fg_real* active_dt, fg_real* p, fg_real* p_copy, hipStream_t st);
 
 // Poisson / CG (fg_poisson.hip)

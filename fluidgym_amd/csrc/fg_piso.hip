@@ -652,11 +652,50 @@ __global__ __launch_bounds__(FG_BLOCK) void k_outflow(FgGrid g, int face, fg_rea
 
 // balance_boundary_fluxes (PISOtorch_simulation.py:188-224): per env, if |flux_fixed + flux_free| exceeds
 // atol scale the whole velocity of the free faces by -flux_fixed / flux_free.  One workgroup per env.
+// fold (optional, fold.mask != 0): the convective update of the masked faces (k_outflow's body, same expressions) by this env's
+// workgroup in front of the balance -- fg_single_step's PRE hook as ONE launch when the slabs are small.
+struct FgOutflowFold {
+    int mask;                       // faces updated first (0: none)
+    fg_real velm[3];                // mean outflow velocity per axis
+    const fg_real* vel; const fg_real* scal;
+    fg_real* bscal[6]; int nsc[6];
+};
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds bnd, fg_real* const* bvel_rw, int free_mask,
-                                                              fg_real atol, const fg_real* __restrict__ dt) {
+                                                              fg_real atol, const fg_real* __restrict__ dt, FgOutflowFold fold) {
     const int b = blockIdx.x;
     if (dt && !(dt[b] > 0.f)) return;
+    if (fold.mask) {
+        const fg_real dtb = dt[b];
+        for (int face = 0; face < 2 * DIMS; ++face) {
+            if (!((fold.mask >> face) & 1)) continue;
+            const int ax = face >> 1;
+            const int slab_n = fg_slab_size(g, ax);
+            const int edge = (face & 1) ? ((ax == 0) ? g.nx - 1 : (ax == 1) ? g.ny - 1 : g.nz - 1) : 0;
+            const fg_real tcoef = 1.f - 1.f / (1.f + 2.f * dtb * fold.velm[ax] * g.rh[ax][edge]);
+            const size_t N = g.n;
+            fg_real* bvel = bvel_rw[face];
+            for (int s = threadIdx.x; s < slab_n; s += blockDim.x) {
+                int i, j, k;
+                if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
+                else if (ax == 1) { j = edge; i = s % g.nx; k = s / g.nx; }
+                else { k = edge; i = s % g.nx; j = s / g.nx; }
+                const size_t cell = ((size_t)k * g.ny + j) * g.nx + i;
+#pragma unroll
+                for (int q = 0; q < DIMS; ++q) {
+                    fg_real* pb = bvel + ((size_t)b * DIMS + q) * slab_n + s;
+                    const fg_real vb = *pb;
+                    *pb = vb - tcoef * (vb - fold.vel[((size_t)b * DIMS + q) * N + cell]);
+                }
+                for (int ch = 0; ch < fold.nsc[face]; ++ch) {
+                    fg_real* pb = fold.bscal[face] + ((size_t)b * fold.nsc[face] + ch) * slab_n + s;
+                    const fg_real sb = *pb;
+                    *pb = sb - tcoef * (sb - fold.scal[((size_t)b * fold.nsc[face] + ch) * N + cell]);
+                }
+            }
+        }
+        __syncthreads();     // the balance below reads what this workgroup just wrote (one CU, one L1)
+    }
     double fixed = 0.0, freef = 0.0;
     for (int f = 0; f < 2 * DIMS; ++f) {
         if (!g.fixed[f]) continue;
@@ -930,11 +969,30 @@ int fg_launch_outflow(const fg_state* s, int face, fg_real velm_axis, const fg_r
     return FG_OK;
 }
 
-int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st) {
+int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st,
+                      int outflow_mask, const fg_real* outflow_velm) {
+    FgOutflowFold fold;
+    fold = FgOutflowFold{};
+    if (outflow_mask) {     // (the caller checked the slab sizes: fg_outflow_folds)
+        fold.mask = outflow_mask; fold.vel = s->velocity; fold.scal = s->scalar;
+        for (int a = 0; a < 3; ++a) fold.velm[a] = outflow_velm[a];
+        for (int f = 0; f < 6; ++f) { fold.bscal[f] = s->bscal[f]; fold.nsc[f] = (s->scalar && s->bscal[f]) ? s->cfg.n_scalars : 0; }
+    }
     if (s->grid.dims == 2)
-        hipLaunchKernelGGL(k_balance_fluxes<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt);
+        hipLaunchKernelGGL(k_balance_fluxes<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt, fold);
     else
-        hipLaunchKernelGGL(k_balance_fluxes<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt);
+        hipLaunchKernelGGL(k_balance_fluxes<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt, fold);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
+}
+
+// the convective update of these faces can ride in the balance launch: slabs of at most four rounds of the env's one workgroup
+bool fg_outflow_folds(const fg_state* s, int outflow_mask) {
+    for (int f = 0; f < 2 * s->grid.dims; ++f) {
+        if (!((outflow_mask >> f) & 1)) continue;
+        const int ax = f >> 1;
+        const long slab_n = ax == 0 ? (long)s->grid.ny * s->grid.nz : ax == 1 ? (long)s->grid.nx * s->grid.nz : (long)s->grid.nx * s->grid.ny;
+        if (slab_n > 4 * FG_BLOCK) return false;
+    }
+    return outflow_mask != 0;
 }
