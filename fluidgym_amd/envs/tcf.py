@@ -284,8 +284,11 @@ class TCF3DBottomEnv(FluidEnv):
 
     def _get_wall_stress(self):
         """(bottom, top) wall shear stress per env ``[B]`` (tcf_env.py:564-584)."""
-        mean_u = self._block.velocity[:, 0].mean(dim=(1, 3))   # [B, Y]
-        return self._nu * mean_u[:, 0] / self._d_wall[0], self._nu * mean_u[:, -1] / self._d_wall[1]
+        # (only the two wall-adjacent cell layers are needed: the mean over the whole field read 17 MB twice per sim step at
+        #  128 x 64 x 64 x 8 envs -- 2 % of the TCF leg -- for two of its 64 rows)
+        ux = self._block.velocity[:, 0]                          # [B, Z, Y, X]
+        mean_lo, mean_hi = ux[:, :, 0, :].mean(dim=(1, 2)), ux[:, :, -1, :].mean(dim=(1, 2))
+        return self._nu * mean_lo / self._d_wall[0], self._nu * mean_hi / self._d_wall[1]
 
     def _plane_obs(self, y_idx: int):
         u = self._block.velocity                                   # [B, 3, Z, Y, X]
