@@ -110,6 +110,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     if (int rc = fg_poll_create(&s->poll, (int)(nsys > 2 * (size_t)g.B ? nsys : 2 * (size_t)g.B))) return rc;
     s->pred_bicg = 2; s->pred_cg = 1;
+    s->wall_forcing_axis = -1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr; s->ilu_d = nullptr;
     s->double_fallback = 0; s->ladder_force = 0; s->r64_buf = nullptr; s->r64_acc = nullptr;
     for (int k = 0; k < 4; ++k) s->rung_count[k] = 0;
@@ -150,7 +151,7 @@ extern "C" int fg_destroy(fg_handle s) {
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
-    (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc);
+    (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->force_uniform);
     (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
@@ -225,6 +226,20 @@ extern "C" int fg_set_return_best(fg_handle s, int on) {
 extern "C" int fg_set_advection_start(fg_handle s, int from_result) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     s->adv_from_result = from_result ? 1 : 0;
+    return FG_OK;
+}
+
+extern "C" int fg_set_wall_stress_forcing(fg_handle s, int axis, fg_real coef_lo, fg_real coef_hi) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    FG_REQUIRE(axis < s->grid.dims, FG_ERR_INVALID_ARG, "fg_set_wall_stress_forcing: bad axis");
+    if (axis >= 0) {
+        FG_REQUIRE(s->grid.fixed[2] && s->grid.fixed[3], FG_ERR_UNSUPPORTED, "fg_set_wall_stress_forcing: needs FIXED y faces (walls)");
+        if (!s->force_uniform) {
+            FG_HIP_CHECK(hipMalloc(&s->force_uniform, sizeof(fg_real) * (size_t)s->grid.B * s->grid.dims));
+            FG_HIP_CHECK(hipMemset(s->force_uniform, 0, sizeof(fg_real) * (size_t)s->grid.B * s->grid.dims));
+        }
+    }
+    s->wall_forcing_axis = axis; s->wall_forcing_coef[0] = coef_lo; s->wall_forcing_coef[1] = coef_hi;
     return FG_OK;
 }
 
@@ -362,6 +377,7 @@ extern "C" int fg_setup_advection(fg_handle s, const fg_real* dt_B, int for_scal
         a.nu = s->scalar_viscosity_set ? s->scalar_viscosity[channel] : s->viscosity;
     } else {
         a.source = s->velocity_source;
+        a.force = s->wall_forcing_axis >= 0 ? s->force_uniform : nullptr;
         a.visc = s->visc_field;
         a.nu = s->viscosity;
         a.rA = s->rA;
@@ -527,6 +543,9 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         if (rc == FG_ERR_NOT_CONVERGED) { status = rc; return FG_OK; }
         return rc;
     };
+    // ---- PRE hook fused: wall-stress forcing of the turbulent-channel env (fg_set_wall_stress_forcing; tcf_env.py, grid.py:147-176)
+    if (s->wall_forcing_axis >= 0)
+        if (int rc = fg_launch_wall_forcing(s, st)) return rc;
     // ---- passive scalars (:1471-1644)
     if (scalar) {
         for (int ch = 0; ch < s->cfg.n_scalars; ++ch) {

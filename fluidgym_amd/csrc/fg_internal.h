@@ -669,6 +669,7 @@ struct fg_state {
     // BiCG_precondition_fallback); line_retries counts the repeats.  Factors [B][N], allocated on first use
     int adv_precond; long long line_retries;
     int cg_wgs_per_slot;          // workgroups sharing one CG accumulator slot (256; FG_CG_WGS_PER_SLOT at fg_create: tuning)
+    int wall_forcing_axis; fg_real wall_forcing_coef[2]; fg_real* force_uniform;   // fg_set_wall_stress_forcing: [B, dims] uniform body force (device)
     int bicg3_force, bicg3_bxl, bicg3_mix;   // FG_BICG3 / FG_BICG3_BXL at fg_create (fg_bicgstab3d.hip)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
     fg_real* line_inv; fg_real* line_cp;
@@ -761,6 +762,7 @@ struct FgAdvArgs {
     const fg_real* scal;     // T channel [B,?] base of the channel being advected (stride given)
     long scal_env_stride;  // elements between envs in `scal`
     const fg_real* source;   // velocity source [B,d,N] or nullptr
+    const fg_real* force;    // uniform body force per env [B,d] or nullptr (fg_set_wall_stress_forcing): added like a source of that value
     const fg_real* dt;       // [B]
     fg_real nu;              // viscosity (or scalar diffusivity)
     const fg_real* visc;     // optional per-cell viscosity [B,N] of the velocity system (Block.setViscosity: SGS models); nullptr = nu
@@ -771,6 +773,7 @@ struct FgAdvArgs {
     FgBicgBegin begin;       // optional (begin.acc != nullptr): the leader workgroup of every env prepares the solve that follows
 };
 int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
+int fg_launch_wall_forcing(const fg_state* s, hipStream_t st);   // force_uniform from the wall-adjacent layers of s->velocity
 int fg_launch_sgs(const fg_state* s, const FgBounds& bnd, fg_real coefficient, fg_real* out, hipStream_t st);
 int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t st);  // rA = 1/A
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st);

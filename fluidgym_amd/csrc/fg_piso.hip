@@ -181,9 +181,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
         for (int q = 0; q < DIMS; ++q) {
             FgVec<VEC> S;
             if (a.source) S = fg_load<VEC>(a.source + ((size_t)c.b * DIMS + q) * N + c.idx);
+            const fg_real F = a.force ? a.force[c.b * DIMS + q] : 0.f;     // uniform body force of the env (the native wall-stress forcing)
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
-                out.v[e] = (J[e] * u[q].v[e] * rdt + bsum[q][e]) * rJ[e] + (a.source ? S.v[e] : 0.f);
+                out.v[e] = (J[e] * u[q].v[e] * rdt + bsum[q][e]) * rJ[e] + ((a.source ? S.v[e] : 0.f) + F);
             fg_store<VEC>(a.rhs + ((size_t)c.b * DIMS + q) * N + c.idx, out);
         }
     }
@@ -832,6 +833,42 @@ __global__ __launch_bounds__(FG_BLOCK) void k_sgs_smagorinsky(FgGrid g, FgBounds
             d += (i != j) ? 2.f * sij : sij;
         }
     out[(size_t)b * g.n + c] = coefficient * delta * FG_SQRT(2.f * d);
+}
+
+// Wall-stress forcing of the turbulent-channel env (tcf_env.py PRE hook, grid.py:147-176): per env the mean of u[axis] over the cell
+// layer next to the -y wall and over the one next to the +y wall, G = 1/2 (coef_lo mean_lo + coef_hi mean_hi) -> force[b][axis],
+// the other components 0.  One workgroup of 1024 threads per env; rows in a fixed order, sums in fp64.
+__global__ __launch_bounds__(1024) void k_wall_forcing(FgGrid g, const fg_real* __restrict__ vel, int axis, fg_real coef_lo, fg_real coef_hi,
+                                                        fg_real* __restrict__ force, int dims) {
+    const int b = blockIdx.x;
+    const size_t N = g.n;
+    const fg_real* __restrict__ u = vel + ((size_t)b * dims + axis) * N;
+    double lo = 0.0, hi = 0.0;
+    const int rows = g.nz;       // one (z) row of nx cells per layer and z
+    for (int idx = threadIdx.x; idx < rows * g.nx; idx += blockDim.x) {
+        const int k = idx / g.nx, i = idx - k * g.nx;
+        lo += (double)u[((size_t)k * g.ny + 0) * g.nx + i];
+        hi += (double)u[((size_t)k * g.ny + (g.ny - 1)) * g.nx + i];
+    }
+    __shared__ double lds[2][16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo += __shfl_down(lo, o, 64); hi += __shfl_down(hi, o, 64); }
+    if ((threadIdx.x & 63) == 0) { lds[0][threadIdx.x >> 6] = lo; lds[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sl = 0.0, sh = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { sl += lds[0][w]; sh += lds[1][w]; }
+        const double n = (double)rows * g.nx;
+        const fg_real tau_lo = coef_lo * (fg_real)(sl / n), tau_hi = coef_hi * (fg_real)(sh / n);
+        for (int q = 0; q < dims; ++q) force[b * dims + q] = (q == axis) ? (fg_real)0.5 * (tau_lo + tau_hi) : (fg_real)0;
+    }
+}
+
+int fg_launch_wall_forcing(const fg_state* s, hipStream_t st) {
+    hipLaunchKernelGGL(k_wall_forcing, dim3(s->grid.B), dim3(1024), 0, st, s->grid, (const fg_real*)s->velocity, s->wall_forcing_axis,
+                       s->wall_forcing_coef[0], s->wall_forcing_coef[1], s->force_uniform, s->grid.dims);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
 }
 
 int fg_launch_sgs(const fg_state* s, const FgBounds& bnd, fg_real coefficient, fg_real* out, hipStream_t st) {

@@ -187,7 +187,12 @@ class TCF3DBottomEnv(FluidEnv):
         blk = dom.CreateBlock(vertexCoordinates=grids.vertex_grid(edges), name="ChannelBlock")
         blk.CloseBoundary("-y")
         dom.PrepareSolve()
-        blk.setVelocitySource(torch.zeros(1, 3, *dom.solver.spatial))
+        # dynamic forcing: natively (a uniform body force per env, fg_set_wall_stress_forcing) unless a sub-grid-scale hook keeps the
+        # step in the interpreter anyway or the policy says no -- then through the block's velocity source, as in the reference
+        from ..simulation.policy import get_solver_policy
+        self._native_forcing = bool(get_solver_policy()["native_wall_forcing"]) and self._C_smag == 0.0
+        if not self._native_forcing:
+            blk.setVelocitySource(torch.zeros(1, 3, *dom.solver.spatial))
         return dom
 
     def _additional_initialization(self) -> None:
@@ -207,7 +212,7 @@ class TCF3DBottomEnv(FluidEnv):
             tau_b, tau_t = self._get_wall_stress()   # [B] each
             self._block.velocitySource[:, 0] = (0.5 * (tau_b + tau_t)).view(-1, 1, 1, 1)
 
-        hooks = [forcing]
+        hooks = [] if self._native_forcing else [forcing]
         if self._C_smag != 0.0:
             # tcf_env.py:441-474: every (sub)step the block's viscosity = nu + C Delta^2 |S| (x the squared van Driest damping
             # (1 - exp(-y+ / 25))^2 of the wall distance, util.py:75-125), computed from the current velocity
@@ -226,7 +231,12 @@ class TCF3DBottomEnv(FluidEnv):
         return {"PRE": hooks}
 
     def _get_simulation(self, domain, prep_fn) -> Simulation:
-        return Simulation(domain=domain, prep_fn=prep_fn, substeps="ADAPTIVE", adaptive_CFL=self._adaptive_cfl,
+        wall_forcing = None
+        if self._native_forcing:
+            e = domain.getBlock(0).edges[1]
+            ycen = 0.5 * (e[1:] + e[:-1])
+            wall_forcing = (0, self._nu / float(1.0 + ycen[0]), self._nu / float(1.0 - ycen[-1]))   # grid.py:147-176
+        return Simulation(domain=domain, prep_fn=prep_fn, wall_forcing=wall_forcing, substeps="ADAPTIVE", adaptive_CFL=self._adaptive_cfl,
                           dt=self._dt, corrector_steps=2, advection_tol=1e-6, pressure_tol=1e-6, advect_non_ortho_steps=1,
                           pressure_non_ortho_steps=1, pressure_return_best_result=True, velocity_corrector="FD",
                           non_orthogonal=True, solver_double_fallback=False)

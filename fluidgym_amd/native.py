@@ -379,6 +379,11 @@ class NativeSolver:
         branch, first pass) -- ``fg_set_advection_start``."""
         L.check(self.lib.fg_set_advection_start(self.handle, int(from_result)), lib=self.lib)
 
+    def set_wall_stress_forcing(self, axis: int, coef_lo: float = 0.0, coef_hi: float = 0.0) -> None:
+        """Native form of the turbulent-channel env's PRE hook (``fg_set_wall_stress_forcing``): before every PISO step the uniform
+        body force ``1/2 (coef_lo <u_axis>_{-y layer} + coef_hi <u_axis>_{+y layer})`` per env along ``axis``; ``axis < 0`` = off."""
+        L.check(self.lib.fg_set_wall_stress_forcing(self.handle, int(axis), float(coef_lo), float(coef_hi)), lib=self.lib)
+
     def set_advection_preconditioner(self, mode: int = 0):
         """Preconditioner policy of the advection-diffusion BiCGStab (``fg_set_advection_preconditioner``): 0 plain (the
         reference's first rung), 1 every solve right-preconditioned by the y-line solve (its ``preconditionBiCG``), 2 only

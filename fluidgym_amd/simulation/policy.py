@@ -50,6 +50,12 @@ benchmark line can say which mode it ran in:
     Rounds 2-3 also sent the ``medium`` / ``hard`` 2-D ids (resolution 32, 23 k cells) this way (103 -> 245 env-steps/s at 64 envs);
     since round 4 the multilevel-preconditioned on-chip CG reaches them (``k_mbc_l2``: 16 iterations per solve, 527 env-steps/s).
 
+``native_wall_forcing`` (default True)
+    Turbulent-channel envs without a sub-grid-scale hook: the dynamic forcing of the ``PRE`` hook (``G_x`` = mean of the two wall
+    shear stresses) is computed natively before every PISO step (``fg_set_wall_stress_forcing``) and added to the velocity
+    right-hand side as a uniform body force, so the whole ``single_step`` runs in ``fg_single_step`` and no source field is
+    streamed.  ``False``: the Python hook writes the block's velocity source, as the reference's does.
+
 ``advection_rung_preconditioner`` (default ``"line"``)
     Single-block path: which preconditioner the reference's rungs use -- ``preconditionBiCG`` (every solve) and
     ``BiCG_precondition_fallback`` (a failed solve is repeated with it).  ``"line"``: the tridiagonal part of the matrix along y
@@ -85,6 +91,7 @@ _POLICY: Dict[str, Any] = {
     "advection_fd_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_FD_PRECONDITIONER", "auto"),
     "advection_rung_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_RUNG_PRECONDITIONER", "line"),
     "pressure_bicgstab_large_meshes": os.environ.get("FLUIDGYM_AMD_PRESSURE_BICGSTAB_LARGE_MESHES", "1") not in ("0", "", "false", "False"),
+    "native_wall_forcing": os.environ.get("FLUIDGYM_AMD_NATIVE_WALL_FORCING", "1") not in ("0", "", "false", "False"),
     "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "1") not in ("0", "", "false", "False"),
 }
 

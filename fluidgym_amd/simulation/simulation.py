@@ -80,6 +80,7 @@ class Simulation:
         output_resampling_shape=None,
         output_resampling_fill_max_steps: int = 0,
         buoyancy: Optional[tuple] = None,
+        wall_forcing: Optional[tuple] = None,
         pressure_warm_start: Optional[bool] = None,
         advection_warm_start: Optional[bool] = None,
         outflow: Optional[tuple] = None,
@@ -118,6 +119,11 @@ class Simulation:
         self.advect_passive_scalar = advect_passive_scalar
         self.non_orthogonal = non_orthogonal  # identical results on orthogonal grids
         self.buoyancy = buoyancy  # (axis, factor): native form of the RBC PRE_VELOCITY_SETUP hook
+        # (axis, coef_lo, coef_hi): native form of the turbulent-channel env's PRE hook -- a uniform body force along `axis` equal to
+        # the mean of the two wall shear stresses, recomputed before every PISO step (fg_set_wall_stress_forcing)
+        self.wall_forcing = wall_forcing
+        if wall_forcing is not None:
+            domain.solver.set_wall_stress_forcing(*wall_forcing)
         # the reference starts every pressure solve of this path from zero (orthogonal branch x=None,
         # PISOtorch_simulation.py:1804-1807; non-orthogonal branch x=None at pstep 0, :1877-1881, and this path runs
         # pressure_non_ortho_steps == 1): that is the default.  Starting from the previous pressure is the opt-in

@@ -147,6 +147,11 @@ int fg_set_return_best(fg_handle h, int on);
  * (tcf_env.py:497) -- from zero on the first non-orthogonal pass (x=None, :1735-1742).  from_result 1 (default of a new handle): the
  * orthogonal-branch rule; 0: zero.  Same converged answer within the tolerance, different iteration counts. */
 int fg_set_advection_start(fg_handle h, int from_result);
+/* Native form of the turbulent-channel env's PRE hook (tcf_env.py "dynamic forcing", grid.py:147-176): before every PISO step a
+ * uniform body force along `axis`, per env  G = 1/2 (coef_lo <u_axis>_lo + coef_hi <u_axis>_hi), the means taken over the cell
+ * layers next to the -y / +y walls (coef = nu / wall distance of the layer: the two wall shear stresses), is added to the velocity
+ * right-hand side as a velocity source of that value would be.  axis < 0 switches it off.  Needs FIXED y faces. */
+int fg_set_wall_stress_forcing(fg_handle h, int axis, fg_real coef_lo, fg_real coef_hi);
 
 /* ---- reductions used by the drivers --------------------------------------------------------- */
 /* Domain.getMaxVelocity(withBounds=True, computational=True) (domain_structs.cpp:1580-1611) */

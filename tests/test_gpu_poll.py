@@ -44,3 +44,38 @@ def test_spinning_polls_leave_every_bit_of_a_run_where_it_was(env_id, kw, monkey
     for a, b in zip(r_spin, r_sync):
         assert torch.equal(a, b)
     assert any(float(o[k].abs().max()) > 0 for o in obs_spin for k in o)
+
+
+def test_native_wall_stress_forcing_is_the_python_hook(monkeypatch):
+    """Policy ``native_wall_forcing`` (round 4): the turbulent-channel env's PRE hook -- G_x = mean of the two wall shear stresses
+    written into the block's velocity source (tcf_env.py, grid.py:147-176) -- runs natively (``fg_set_wall_stress_forcing``: a
+    uniform body force per env recomputed before every PISO step, the whole single_step inside fg_single_step).  Held against the
+    interpreter's hook on the same env over two env steps: the forcing value is a mean taken in a different order (fp64 sums
+    against torch's fp32 tree), so fields agree to rounding, not to the bit."""
+    import fluidgym_amd
+
+    kw = dict(num_envs=2, randomize_initial_state=False, resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False)
+    outs = {}
+    for native in (True, False):
+        old = fluidgym_amd.set_solver_policy(native_wall_forcing=native)
+        try:
+            env = fluidgym_amd.make("TCFSmall3D-both-easy-v0", **kw)
+            env.reset(seed=3)                                    # (the domain is built here: the policy is read then)
+        finally:
+            fluidgym_amd.set_solver_policy(**old)
+        try:
+            assert env._native_forcing is native
+            assert env._sim._native_ok() is native               # (the Python hook keeps the step in the interpreter)
+            assert (env._block.velocitySource is None) == native
+            a = torch.zeros_like(env.sample_action())
+            for _ in range(2):
+                _, r, _, _, info = env.step(a)
+            outs[native] = (env._block.velocity.clone(), env._block.pressure.clone(), torch.as_tensor(info["wall_stress"]).clone())
+        finally:
+            env.close()
+    (u_n, p_n, tau_n), (u_p, p_p, tau_p) = outs[True], outs[False]
+    scale = float(u_p.abs().max())
+    assert float((u_n - u_p).abs().max()) < 2e-5 * scale, float((u_n - u_p).abs().max()) / scale
+    assert float((p_n - p_p).abs().max()) < 2e-4 * float(p_p.abs().max()) + 1e-7
+    assert torch.allclose(tau_n.float(), tau_p.float(), rtol=2e-5, atol=1e-9)
+    assert float(tau_p.abs().max()) > 0

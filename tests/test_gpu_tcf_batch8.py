@@ -59,7 +59,15 @@ def test_tcf_full_batch_step_matches_the_reference_recurrences(monkeypatch):
             assert env._sim.single_step()
         blk = env._domain.getBlock(0)
         u0 = blk.velocity.clone()
-        src = ns.velocity_source.clone() if ns.velocity_source is not None else torch.zeros_like(u0)
+        if ns.velocity_source is not None:
+            src = ns.velocity_source.clone()
+        else:
+            # native wall-stress forcing (policy native_wall_forcing, fg_set_wall_stress_forcing): no source field is bound; the
+            # body force of the state is what the reference's PRE hook would write -- uniform G_x = mean of the wall shear stresses
+            assert env._native_forcing and env._sim.wall_forcing is not None
+            tau_b, tau_t = env._get_wall_stress()
+            src = torch.zeros_like(u0)
+            src[:, 0] = (0.5 * (tau_b + tau_t)).view(-1, 1, 1, 1)
         assert float(src.abs().max()) > 0                                  # the env's body force is on
         assert float((u0[0] - u0[B - 1]).abs().max()) > 1e-3            # the envs of the batch differ
         dt = 0.25 * float(env._dt)
