@@ -338,3 +338,32 @@ def test_medium_cylinder_mesh_takes_the_preconditioned_onchip_cg():
         env.close()
     finally:
         fluidgym_amd.set_solver_policy(**old)
+
+
+def test_medium_mesh_at_the_bench_batch_every_env_identical_and_converged():
+    """``CylinderJet2D-medium-v0`` x 64 (the ``cylinder_medium_env`` bench leg): one workgroup per env runs the whole preconditioned
+    pressure solve (``k_mbc_l2``).  From one state and one action every env must stay bit-identical to env 0 -- the kernel's
+    reductions run in a fixed order inside the workgroup and nothing is shared between workgroups -- every solve meets its
+    tolerance, and the iteration counts are those of a preconditioned solve."""
+    import fluidgym_amd
+
+    env = fluidgym_amd.make("CylinderJet2D-medium-v0", num_envs=64, initial_domain_steps=10, randomize_initial_state=False)
+    try:
+        env.reset(seed=0)
+        assert env._sim.pressure_use_BiCG is False and env._multilevel is not None
+        dom = env._domain
+        dom.solver_counters(reset=True)
+        a = torch.full_like(env.sample_action(), 0.3)
+        for _ in range(2):
+            obs, r, _, _, info = env.step(a)
+        c = dom.solver_counters()
+        for kind in ("velocity", "pressure0", "pressure1"):
+            assert c[kind]["unconverged"] == 0, (kind, c[kind])
+        assert 5 <= c["pressure0"]["mean"] <= 40 and c["pressure0"]["max"] <= 60, c["pressure0"]
+        u, p = dom.velocity, dom.pressure
+        assert torch.isfinite(u).all() and torch.isfinite(p).all()
+        assert torch.equal(u, u[:1].expand_as(u)) and torch.equal(p, p[:1].expand_as(p))
+        assert torch.equal(torch.as_tensor(r), torch.as_tensor(r)[:1].expand_as(torch.as_tensor(r)))
+        assert float(u.abs().max()) > 0.5
+    finally:
+        env.close()
