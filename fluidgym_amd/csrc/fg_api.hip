@@ -650,11 +650,14 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             // CFL kernel, one word per env behind the flux balance.
             const FgPollOut po = fg_poll_next(&s->poll);
             const FgPollOut none = FgPollOut{nullptr, 0};
-            if (first) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, o->adaptive ? none : po)) return rc; }
+            // (with the CFL kernel in the step, the guard is computed by workgroup 0 of every env of THAT launch: one kernel, one word)
+            if (first && !o->adaptive) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, po)) return rc; }
             if (o->adaptive) {
-                if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B, po.seq ? FgPollOut{po.seq + B, po.value} : po))
+                if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B, po.seq ? FgPollOut{po.seq + B, po.value} : po,
+                                                    first ? s->scratch_B : nullptr, first ? s->diag_pinned : nullptr))
                     return rc;
             }
+            (void)none;
             if (int rc = fg_poll_wait(&s->poll, po, o->adaptive ? B : 0, o->adaptive ? 1 : B, st)) return rc;
             if (first) {
                 fg_real worst = 0.f;
@@ -684,18 +687,21 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             }
             s->dt_pinned[b] = ts;
         }
-        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(fg_real) * B, hipMemcpyHostToDevice, st));
         // PRE hook: advective outflow + flux re-balancing (cylinder_env_base.py:280-300)
+        const bool folded = o->outflow_mask && fg_outflow_folds(s, o->outflow_mask);     // small slabs: the update rides in the balance launch
+        // the time steps reach the device as kernel arguments of that launch (up to 64 envs) instead of through a copy in front of it
+        const bool dt_by_value = folded && B <= 64;
+        if (!dt_by_value) FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(fg_real) * B, hipMemcpyHostToDevice, st));
         if (o->outflow_mask) {
             for (int f = 0; f < 2 * s->grid.dims; ++f)
                 if ((o->outflow_mask >> f) & 1) FG_REQUIRE(s->grid.fixed[f], FG_ERR_INVALID_ARG, "outflow face is not FIXED");
-            const bool folded = fg_outflow_folds(s, o->outflow_mask);     // small slabs: the update rides in the balance launch
             if (!folded)
                 for (int f = 0; f < 2 * s->grid.dims; ++f)
                     if ((o->outflow_mask >> f) & 1)
                         if (int rc = fg_launch_outflow(s, f, o->outflow_velm[f >> 1], s->dt_dev, st)) return rc;
             fg_real velm3[3] = {o->outflow_velm[0], o->outflow_velm[1], o->outflow_velm[2]};
-            if (int rc = fg_launch_balance(s, bnd, o->outflow_mask, (fg_real)0.01 * o->outflow_tol, s->dt_dev, st, folded ? o->outflow_mask : 0, velm3))
+            if (int rc = fg_launch_balance(s, bnd, o->outflow_mask, (fg_real)0.01 * o->outflow_tol, s->dt_dev, st, folded ? o->outflow_mask : 0, velm3,
+                                           dt_by_value ? s->dt_pinned : nullptr))
                 return rc;
         }
         int rc = fg_piso_step(s, s->dt_dev, &o->step, stats, stream);

@@ -545,7 +545,8 @@ struct FgProf {
     hipEvent_t ev[2 * FG_PROF_POOL];
     FgProfMeta meta[FG_PROF_POOL];
     int32_t* active_dev;      // [FG_PROF_POOL] active systems of each sampled launch
-    int32_t* active_pinned;
+    int32_t* active_pinned;   // host-pinned: the count kernel writes it directly; only self-counted slots (active_dev) are copied
+    unsigned char self_counted[FG_PROF_POOL];
     double ms[FG_PK_COUNT], bytes[FG_PK_COUNT], flops[FG_PK_COUNT], full_ms[FG_PK_COUNT], full_bytes[FG_PK_COUNT];
     long long n[FG_PK_COUNT], full_n[FG_PK_COUNT], launches[FG_PK_COUNT];
     double all_ms[FG_PK_COUNT];   // every sampled launch, including those that found all systems converged
@@ -784,14 +785,15 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
 // scratch_B + B, whose next row holds the arrival counters)
 // poll (optional): sequence words published per env after the host-pinned result (FgPollOut above)
 int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B = nullptr,
-                           FgPollOut poll = FgPollOut{nullptr, 0});
+                           FgPollOut poll = FgPollOut{nullptr, 0}, fg_real* flux_B = nullptr, fg_real* flux_mirror = nullptr);   // flux_B: device [B] scratch, the flux-balance guard computed in the same launch and mirrored to flux_mirror (host-pinned)
 int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, FgPollOut poll = FgPollOut{nullptr, 0});
 int fg_launch_copy_active(const fg_state* s, const fg_real* dt, const fg_real* src, fg_real* dst, int comps, hipStream_t st);
 int fg_launch_buoyancy(const fg_state* s, const fg_real* dt, const fg_real* T, long t_env_stride, fg_real* source, int axis,
                        fg_real factor, hipStream_t st);
 int fg_launch_outflow(const fg_state* s, int face, fg_real velm_axis, const fg_real* dt, hipStream_t st);
 int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st,
-                      int outflow_mask = 0, const fg_real* outflow_velm = nullptr);   // outflow_mask: faces whose convective update rides in this launch
+                      int outflow_mask = 0, const fg_real* outflow_velm = nullptr,    // outflow_mask: faces whose convective update rides in this launch
+                      const fg_real* dt_host_values = nullptr);                       // B <= 64 time steps by value: the kernel fills s->dt_dev (no copy in front of it)
 bool fg_outflow_folds(const fg_state* s, int outflow_mask);
 int fg_launch_mean_sub(const fg_state* s, const fg_real* active_dt, fg_real* p, fg_real* p_copy, hipStream_t st);
 

@@ -348,8 +348,56 @@ typedef int fg_bits;
 __device__ __forceinline__ fg_bits fg_real_bits(fg_real v) { return __float_as_int(v); }
 __device__ __forceinline__ fg_real fg_bits_real(fg_bits b) { return __int_as_float(b); }
 #endif
+// sum of FIXED-boundary contravariant fluxes, lower faces negated
+// (Domain::GetGlobalFluxBalance, domain_structs.cpp:2476-2509).  One workgroup per env, fp64 sum; the result is valid in thread 0.
+template <int DIMS>
+__device__ __forceinline__ double fg_flux_balance_block(const FgGrid& g, const FgBounds& bnd, int b) {
+    double acc = 0.0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int f = 0; f < 2 * DIMS; ++f) {
+        if (!g.fixed[f]) continue;
+        const int ax = f >> 1;
+        const int slab_n = fg_slab_size(g, ax);
+        const double sgn = (f & 1) ? 1.0 : -1.0;
+        // slab index s = i0 + n0 * i1 over the two tangential axes; waves take rows i1, lanes run along i0: no integer
+        // division per cell and the loads of a row are independent (the s % n, s / n form cost 26 us at 128 x 64 x 64)
+        const int n0 = (ax == 0) ? g.ny : g.nx;
+        const int n1 = (DIMS == 3) ? ((ax == 2) ? g.ny : g.nz) : 1;
+        const fg_real* __restrict__ h0 = (ax == 0) ? g.h[1] : g.h[0];
+        const fg_real* __restrict__ h1 = (DIMS == 3) ? ((ax == 2) ? g.h[1] : g.h[2]) : nullptr;
+        const fg_real* __restrict__ v = bnd.vel[f] + ((size_t)b * DIMS + ax) * slab_n;
+        // rows in groups of four per wave with all their loads requested together: one workgroup per env walks the whole slab, so
+        // the loop is a latency chain (TCF 128 x 64 x 64: 31 us with one row in flight per wave; the sum order per thread -- row by
+        // row, products in fp32, sums in fp64 -- is unchanged)
+        constexpr int RU = 4, WV = FG_BLOCK / 64;
+        for (int i1b = wave; i1b < n1; i1b += WV * RU) {
+            for (int i0 = lane; i0 < n0; i0 += 64) {
+                fg_real val[RU], a1[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int i1 = i1b + u * WV;
+                    const bool ok = i1 < n1;
+                    a1[u] = ok ? (h1 ? h1[i1] : (fg_real)1) : (fg_real)0;
+                    val[u] = ok ? v[(size_t)i1 * n0 + i0] : (fg_real)0;
+                }
+                const fg_real w0 = h0[i0];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) acc += sgn * (double)(val[u] * (w0 * a1[u]));
+            }
+        }
+    }
+    __shared__ double lds_fb[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) lds_fb[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return lds_fb[0] + lds_fb[1] + lds_fb[2] + lds_fb[3];
+}
 // Called by the whole FIRST WAVE of the workgroup (lane 0 carries the workgroup's maximum).
-__device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx, const FgPollOut& poll, int B) {
+// flux_B / flux_mirror (optional): the flux balances workgroup 0 of every env left in flux_B (fg_flux_balance_block, in the same launch)
+// are mirrored with the maxima.
+__device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx, const FgPollOut& poll, int B,
+                                               fg_real* flux_B = nullptr, fg_real* flux_mirror = nullptr) {
     const int lane = threadIdx.x & 63;
     int last_of_all = 0;
     if (lane == 0) {
@@ -377,6 +425,7 @@ __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, 
     if (__shfl(last_of_all, 0, 64)) {
         for (int e = lane; e < B; e += 64) {
             mirror_B[e] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (flux_B) flux_mirror[e] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(flux_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             atomicExch(done_B + e, 0);
         }
         if (lane == 0) {
@@ -389,7 +438,7 @@ __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, 
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
                                                             fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
-                                                            fg_real* __restrict__ mirror_B, FgPollOut poll) {
+                                                            fg_real* __restrict__ mirror_B, FgPollOut poll, fg_real* flux_B, fg_real* flux_mirror) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     fg_real mx = 0.f;
@@ -427,9 +476,23 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
     mx = fg_wave_max(mx);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
     __syncthreads();
+    if (flux_B && blockIdx.x == 0) {
+        // the flux-balance guard of the step rides in this launch: workgroup 0 of the env computes it exactly as k_flux_balance does and
+        // leaves it in flux_B with a RETURNING atomic, consumed before this workgroup's arrival below (fg_publish_max: the same ordering
+        // as for the maxima); the workgroup that finishes the last env mirrors it to the host with the maxima
+        const double total = fg_flux_balance_block<DIMS>(g, bnd, b);
+        if (threadIdx.x == 0) {
+            fg_bits prevf = __hip_atomic_exchange(reinterpret_cast<fg_bits*>(flux_B) + b, fg_real_bits((fg_real)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if FG_F64
+            asm volatile("" ::"v"((int)(prevf >> 32)), "v"((int)prevf));
+#else
+            asm volatile("" ::"v"(prevf));
+#endif
+        }
+    }
     if (threadIdx.x < 64) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y, flux_B, flux_mirror);
     }
 }
 
@@ -439,7 +502,8 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
                                                                  fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
-                                                                 fg_real* __restrict__ mirror_B, int rows_per_block, FgPollOut poll) {
+                                                                 fg_real* __restrict__ mirror_B, int rows_per_block, FgPollOut poll,
+                                                                 fg_real* flux_B, fg_real* flux_mirror) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -488,58 +552,32 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
     mx = fg_wave_max(mx);
     if (lane == 0) lds[wave] = mx;
     __syncthreads();
+    if (flux_B && blockIdx.x == 0) {
+        // the flux-balance guard of the step rides in this launch: workgroup 0 of the env computes it exactly as k_flux_balance does and
+        // leaves it in flux_B with a RETURNING atomic, consumed before this workgroup's arrival below (fg_publish_max: the same ordering
+        // as for the maxima); the workgroup that finishes the last env mirrors it to the host with the maxima
+        const double total = fg_flux_balance_block<DIMS>(g, bnd, b);
+        if (threadIdx.x == 0) {
+            fg_bits prevf = __hip_atomic_exchange(reinterpret_cast<fg_bits*>(flux_B) + b, fg_real_bits((fg_real)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if FG_F64
+            asm volatile("" ::"v"((int)(prevf >> 32)), "v"((int)prevf));
+#else
+            asm volatile("" ::"v"(prevf));
+#endif
+        }
+    }
     if (threadIdx.x < 64) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y, flux_B, flux_mirror);
     }
 }
 
-// sum of FIXED-boundary contravariant fluxes, lower faces negated
-// (Domain::GetGlobalFluxBalance, domain_structs.cpp:2476-2509).  One workgroup per env, fp64 sum.
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_flux_balance(FgGrid g, FgBounds bnd, fg_real* __restrict__ out_B, FgPollOut poll) {
     const int b = blockIdx.x;
-    double acc = 0.0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int f = 0; f < 2 * DIMS; ++f) {
-        if (!g.fixed[f]) continue;
-        const int ax = f >> 1;
-        const int slab_n = fg_slab_size(g, ax);
-        const double sgn = (f & 1) ? 1.0 : -1.0;
-        // slab index s = i0 + n0 * i1 over the two tangential axes; waves take rows i1, lanes run along i0: no integer
-        // division per cell and the loads of a row are independent (the s % n, s / n form cost 26 us at 128 x 64 x 64)
-        const int n0 = (ax == 0) ? g.ny : g.nx;
-        const int n1 = (DIMS == 3) ? ((ax == 2) ? g.ny : g.nz) : 1;
-        const fg_real* __restrict__ h0 = (ax == 0) ? g.h[1] : g.h[0];
-        const fg_real* __restrict__ h1 = (DIMS == 3) ? ((ax == 2) ? g.h[1] : g.h[2]) : nullptr;
-        const fg_real* __restrict__ v = bnd.vel[f] + ((size_t)b * DIMS + ax) * slab_n;
-        // rows in groups of four per wave with all their loads requested together: one workgroup per env walks the whole slab, so
-        // the loop is a latency chain (TCF 128 x 64 x 64: 31 us with one row in flight per wave; the sum order per thread -- row by
-        // row, products in fp32, sums in fp64 -- is unchanged)
-        constexpr int RU = 4, WV = FG_BLOCK / 64;
-        for (int i1b = wave; i1b < n1; i1b += WV * RU) {
-            for (int i0 = lane; i0 < n0; i0 += 64) {
-                fg_real val[RU], a1[RU];
-#pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const int i1 = i1b + u * WV;
-                    const bool ok = i1 < n1;
-                    a1[u] = ok ? (h1 ? h1[i1] : (fg_real)1) : (fg_real)0;
-                    val[u] = ok ? v[(size_t)i1 * n0 + i0] : (fg_real)0;
-                }
-                const fg_real w0 = h0[i0];
-#pragma unroll
-                for (int u = 0; u < RU; ++u) acc += sgn * (double)(val[u] * (w0 * a1[u]));
-            }
-        }
-    }
-    __shared__ double lds[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    const double total = fg_flux_balance_block<DIMS>(g, bnd, b);
     if (threadIdx.x == 0) {
-        out_B[b] = (fg_real)(lds[0] + lds[1] + lds[2] + lds[3]);
+        out_B[b] = (fg_real)total;
         fg_poll_publish(poll, b);      // (out_B may be host-pinned: the host then spins on this word, fg_single_step)
     }
 }
@@ -656,6 +694,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_outflow(FgGrid g, int face, fg_rea
 // fold (optional, fold.mask != 0): the convective update of the masked faces (k_outflow's body, same expressions) by this env's
 // workgroup in front of the balance -- fg_single_step's PRE hook as ONE launch when the slabs are small.
 struct FgOutflowFold {
+    // dt_n > 0: the time steps of the substep arrive BY VALUE (dt_v, batches of up to 64 envs) and this kernel -- the first of the
+    // substep -- stores them into the device array every later kernel reads: no host-to-device copy in front of it
+    int dt_n; fg_real dt_v[64]; fg_real* dt_out;
     int mask;                       // faces updated first (0: none)
     fg_real velm[3];                // mean outflow velocity per axis
     const fg_real* vel; const fg_real* scal;
@@ -665,9 +706,10 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds bnd, fg_real* const* bvel_rw, int free_mask,
                                                               fg_real atol, const fg_real* __restrict__ dt, FgOutflowFold fold) {
     const int b = blockIdx.x;
-    if (dt && !(dt[b] > 0.f)) return;
+    const fg_real dtb = fold.dt_n ? fold.dt_v[b] : (dt ? dt[b] : (fg_real)1);
+    if (fold.dt_n && threadIdx.x == 0) fold.dt_out[b] = dtb;
+    if ((dt || fold.dt_n) && !(dtb > 0.f)) return;
     if (fold.mask) {
-        const fg_real dtb = dt[b];
         for (int face = 0; face < 2 * DIMS; ++face) {
             if (!((fold.mask >> face) & 1)) continue;
             const int ax = face >> 1;
@@ -922,7 +964,9 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
     return FG_OK;
 }
 
-int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B, FgPollOut poll) {
+int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B, FgPollOut poll,
+                           fg_real* flux_B, fg_real* flux_mirror) {
+    FG_REQUIRE(!flux_B || (mirror_B && flux_mirror), FG_ERR_INVALID_ARG, "the flux balance rides in the mirrored form only");
     // out_B [B] and the arrival counters right behind it (scratch_B rows 1 and 2) are zeroed together
     int32_t* done_B = reinterpret_cast<int32_t*>(out_B + s->grid.B);
     FG_REQUIRE(!mirror_B || out_B == s->scratch_B + s->grid.B, FG_ERR_INVALID_ARG, "mirror needs the scratch row as out_B");
@@ -939,18 +983,18 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_
         dim3 grid((rows + rpb - 1) / rpb, s->grid.B);
         if (s->grid.dims == 2)
             hipLaunchKernelGGL(k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb, poll);
+                               mirror_B, rpb, poll, flux_B, flux_mirror);
         else
             hipLaunchKernelGGL(k_max_velocity_rows<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb, poll);
+                               mirror_B, rpb, poll, flux_B, flux_mirror);
         FG_HIP_CHECK(hipGetLastError());
         return FG_OK;
     }
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
     if (s->grid.dims == 2)
-        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll);
+        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll, flux_B, flux_mirror);
     else
-        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll);
+        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll, flux_B, flux_mirror);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
@@ -1007,9 +1051,13 @@ int fg_launch_outflow(const fg_state* s, int face, fg_real velm_axis, const fg_r
 }
 
 int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_real atol, const fg_real* dt, hipStream_t st,
-                      int outflow_mask, const fg_real* outflow_velm) {
+                      int outflow_mask, const fg_real* outflow_velm, const fg_real* dt_host_values) {
     FgOutflowFold fold;
     fold = FgOutflowFold{};
+    if (dt_host_values) {       // (the caller checked B <= 64)
+        fold.dt_n = s->grid.B; fold.dt_out = s->dt_dev;
+        for (int b = 0; b < s->grid.B; ++b) fold.dt_v[b] = dt_host_values[b];
+    }
     if (outflow_mask) {     // (the caller checked the slab sizes: fg_outflow_folds)
         fold.mask = outflow_mask; fold.vel = s->velocity; fold.scal = s->scalar;
         for (int a = 0; a < 3; ++a) fold.velm[a] = outflow_velm[a];

@@ -33,26 +33,29 @@ int fg_prof_slot(const fg_state* cs, int kind, const int32_t* flags, int nsys, d
     if (P.used >= FG_PROF_POOL || (k % P.period) != 0) return -1;
     const int slot = P.used++;
     P.meta[slot] = FgProfMeta{kind, nsys, bytes_per_sys, flops_per_sys};
+    // the count goes straight into the host-pinned word (no device-to-host copy per poll: those copies were 2.6 of the headline's
+    // 57 launches per PISO step); only a kernel that counts itself (atomics) uses the device word, copied by fg_prof_prefetch
+    P.self_counted[slot] = (flags == FG_PROF_SELF);
     if (flags == FG_PROF_SELF) (void)hipMemsetAsync(P.active_dev + slot, 0, sizeof(int32_t), st);  // kernel counts
-    else if (flags) hipLaunchKernelGGL(k_prof_count, dim3(1), dim3(64), 0, st, flags, nsys, P.active_dev + slot);
-    else (void)hipMemsetAsync(P.active_dev + slot, 0xff, sizeof(int32_t), st);  // -1 = "all active"
+    else if (flags) hipLaunchKernelGGL(k_prof_count, dim3(1), dim3(64), 0, st, flags, nsys, P.active_pinned + slot);
+    else P.active_pinned[slot] = -1;   // "all active" (the slot's previous sample was collected before the pool index came round again)
     return slot;
 }
 
 void fg_prof_prefetch(fg_state* s, hipStream_t st) {
     FgProf& P = s->prof;
     if (!P.on || P.used <= P.prefetched) return;
-    if (hipMemcpyAsync(P.active_pinned + P.prefetched, P.active_dev + P.prefetched, sizeof(int32_t) * (P.used - P.prefetched),
-                       hipMemcpyDeviceToHost, st) == hipSuccess)
-        P.prefetched = P.used;
+    for (int i = P.prefetched; i < P.used; ++i)
+        if (P.self_counted[i]) (void)hipMemcpyAsync(P.active_pinned + i, P.active_dev + i, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    P.prefetched = P.used;
 }
 
 int fg_prof_collect(fg_state* s, hipStream_t st) {
     FgProf& P = s->prof;
     if (!P.used) return FG_OK;
-    if (P.prefetched < P.used) {   // samples taken after the last poll (or no poll at all): copy and wait here
-        FG_HIP_CHECK(hipMemcpyAsync(P.active_pinned + P.prefetched, P.active_dev + P.prefetched, sizeof(int32_t) * (P.used - P.prefetched),
-                                    hipMemcpyDeviceToHost, st));
+    if (P.prefetched < P.used) {   // samples taken after the last poll (or no poll at all): copy the self-counted ones and wait here
+        for (int i = P.prefetched; i < P.used; ++i)
+            if (P.self_counted[i]) FG_HIP_CHECK(hipMemcpyAsync(P.active_pinned + i, P.active_dev + i, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         FG_HIP_CHECK(hipStreamSynchronize(st));
     }
     P.prefetched = 0;
