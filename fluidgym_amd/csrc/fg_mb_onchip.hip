@@ -709,6 +709,7 @@ __global__ __launch_bounds__(1024) void k_mbc_l2(MbDev D, MbSolve q, OcParams o)
     bool fresh = true, restarted = true, residual_pass = o.use_x0 != 0, recovering = false;
     double rho = 0.0;
     const int n4 = o.pre.n4, n8 = o.pre.n8;
+    const int ngrp = min(NW, NT / (((n8 + 3) & ~3) >> 2));    // column groups of the coarse solve (l_part holds NW rows)
     for (;;) {
         mb_real beta = 0.f, cy = 0.f;
         if (!residual_pass) {
@@ -775,11 +776,15 @@ __global__ __launch_bounds__(1024) void k_mbc_l2(MbDev D, MbSolve q, OcParams o)
             }
             __syncthreads();
             {   // e8 = A8^+ r8: wave g takes the columns c = g, g + 16, ..., lane q the four rows 4q .. 4q+3 (k_mbc_onchip)
-                const int ld = (n8 + 3) & ~3, nq = ld >> 2, grp = t >> 6;
-                for (int qd = t & 63; qd < nq; qd += 64) {
+                // (here thread = (row quad qd, column group grp) with ngrp = 1024 / quads groups, so that one round keeps nearly every
+                //  thread busy: 90 quads x 11 groups of 33 columns at 360 aggregates, against two rounds of 23 with 26 of 64 lanes in the
+                //  second -- per-phase cycle counts of a -DFG_MB_OC_CYCLES build: 30.0 k -> 21.5 k cycles per iteration)
+                const int ld = (n8 + 3) & ~3, nq = ld >> 2;
+                const int qd = t % nq, grp = t / nq;
+                if (grp < ngrp) {
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-                    for (int c = grp; c < n8; c += NW) {
+#pragma unroll 12
+                    for (int c = grp; c < n8; c += ngrp) {
                         const float4 a = *reinterpret_cast<const float4*>(o.pre.aci8 + (unsigned)c * (unsigned)ld + 4u * (unsigned)qd);
                         const mb_real rc = l_r8[c];
                         acc.x += a.x * rc; acc.y += a.y * rc; acc.z += a.z * rc; acc.w += a.w * rc;
@@ -791,8 +796,7 @@ __global__ __launch_bounds__(1024) void k_mbc_l2(MbDev D, MbSolve q, OcParams o)
             for (int a = t; a < n4; a += NT) {
                 const int row = o.pre.parent4[a];
                 mb_real e = 0.f;
-#pragma unroll
-                for (int g = 0; g < NW; ++g) e += l_part[g][row];
+                for (int g = 0; g < ngrp; ++g) e += l_part[g][row];
                 l_r4[a] = inv_s * (0.5f * l_r4[a] * o.pre.d4g[a] + e);   // d4g holds reciprocals
             }
             __syncthreads();
