@@ -190,6 +190,7 @@ struct fg_mb_state {
     mb_real* red_pinned = nullptr;
     mb_real *red2, *dt_dev;          // [2B] boundary flux sums, [B] time steps of the running substep
     mb_real *red2_pinned = nullptr, *dt_pinned = nullptr;
+    int dt_slot = 0;              // half of dt_pinned the current sub-step's time steps were written to
     // live timing of the CG pair for bench.py's roofline (fg_mb_profile_*): the first iteration of sampled chunks is issued
     // with start/stop events on the kernels' own dispatch packets; active systems are known from the poll before the chunk
     int prof_on = 0, prof_used = 0, prof_chunk = 0;

@@ -632,7 +632,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     FG_HIP_CHECK(hipHostMalloc((void**)&s->info_pinned, sizeof(fg_solve_info) * B * d, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red_pinned, sizeof(mb_real) * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red2_pinned, sizeof(mb_real) * 2 * B, hipHostMallocDefault));
-    FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(mb_real) * B, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(mb_real) * 2 * B, hipHostMallocDefault));   // two halves (fg_mb_single_step)
     FG_HIP_CHECK(hipHostMalloc((void**)&s->flags_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
     if (int rc = fg_poll_create(&s->poll, B * d > 2 * B ? B * d : 2 * B)) return rc;
     if (int rc = mb_alloc(s, &s->verified, (size_t)B * d)) return rc;
@@ -1117,14 +1117,21 @@ extern "C" int fg_mb_env_status(fg_mb_handle s, int32_t* out_B_host) {
 
 
 
-extern "C" int fg_mb_max_velocity(fg_mb_handle s, mb_real* out_B_host, void* stream) {
-    FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_max_velocity: fields not bound");
-    hipStream_t st = (hipStream_t)stream;
+// the CFL maxima into red_pinned, enqueued without a wait (the caller synchronises: fg_mb_single_step reads the flux-balance guard
+// of the step and the first maxima behind ONE wait)
+static int mb_enqueue_max_velocity(fg_mb_state* s, hipStream_t st) {
     const int cells = std::max(s->N, s->NB);
     FG_HIP_CHECK(hipMemsetAsync(s->red, 0, sizeof(mb_real) * s->B, st));
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_maxvel<DIMS>, dim3((cells + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st,
                                       s->dev, s->velocity, s->bvel, s->red););
     FG_HIP_CHECK(hipMemcpyAsync(s->red_pinned, s->red, sizeof(mb_real) * s->B, hipMemcpyDeviceToHost, st));
+    return FG_OK;
+}
+
+extern "C" int fg_mb_max_velocity(fg_mb_handle s, mb_real* out_B_host, void* stream) {
+    FG_REQUIRE(s && s->finalized && s->velocity && out_B_host, FG_ERR_NOT_BOUND, "fg_mb_max_velocity: fields not bound");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mb_enqueue_max_velocity(s, st)) return rc;
     FG_HIP_CHECK(hipStreamSynchronize(st));
     for (int b = 0; b < s->B; ++b) out_B_host[b] = s->red_pinned[b];
     return FG_OK;
@@ -1184,10 +1191,16 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
                "fg_mb_single_step: outflow slots out of range");
     hipStream_t st = (hipStream_t)stream;
     const int B = s->B;
-    // flux-balance guard (simulation.py:221-229)
+    // flux-balance guard (simulation.py:221-229); with adaptive sub-steps the CFL maxima of the first sub-step are enqueued behind it
+    // and both come back behind ONE wait
+    bool maxvel_ready = false;
     {
         std::vector<mb_real> fl(B);
-        if (int rc = fg_mb_boundary_flux_balance(s, fl.data(), stream)) return rc;
+        MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, 0, 0, 0, 0, s->red2););
+        FG_HIP_CHECK(hipMemcpyAsync(s->red2_pinned, s->red2, sizeof(mb_real) * 2 * s->B, hipMemcpyDeviceToHost, st));
+        if (o->adaptive) { if (int rc = mb_enqueue_max_velocity(s, st)) return rc; maxvel_ready = true; }
+        FG_HIP_CHECK(hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) fl[b] = s->red2_pinned[2 * b] + s->red2_pinned[2 * b + 1];
         mb_real worst = 0.f;
         for (int b = 0; b < B; ++b) {
             if (flux_host) flux_host[b] = fl[b];
@@ -1210,9 +1223,13 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
         if (o->adaptive) for (int b = 0; b < B; ++b) any = any || (t_rem[b] > 0 && !mb_close_zero(t_rem[b]));
         else any = fixed_left > 0;
         if (!any) break;
-        if (o->adaptive)
-            if (int rc = fg_mb_max_velocity(s, mv.data(), stream)) return rc;
+        if (o->adaptive) {
+            if (maxvel_ready) { for (int b = 0; b < B; ++b) mv[b] = s->red_pinned[b]; maxvel_ready = false; }   // (read with the guard above)
+            else if (int rc = fg_mb_max_velocity(s, mv.data(), stream)) return rc;
+        }
         // _PISO_adaptive_step (PISOtorch_simulation.py:2004-2064): ts = t_rem / ceil(t_rem / (CFL / max_vel)), per env
+        s->dt_slot ^= 1;
+        mb_real* dt_slot = s->dt_pinned + (size_t)s->dt_slot * B;     // two halves used in turn (see the end of the loop)
         for (int b = 0; b < B; ++b) {
             mb_real ts = 0.f;
             if (status[b] == 2) {
@@ -1227,9 +1244,9 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
                 t_rem[b] -= tsd;
                 ts = (mb_real)tsd;
             }
-            s->dt_pinned[b] = ts;
+            dt_slot[b] = ts;
         }
-        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(mb_real) * B, hipMemcpyHostToDevice, st));
+        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, dt_slot, sizeof(mb_real) * B, hipMemcpyHostToDevice, st));
         if (o->outflow_count > 0)  // PRE hook of the cylinder / airfoil envs (cylinder_env_base.py:280-300)
             if (int rc = mb_outflow_pre(s, s->dt_dev, o->outflow_slot0, o->outflow_count, o->outflow_slot0_b, o->outflow_count_b,
                                         o->outflow_velm, o->outflow_tol, st))
@@ -1244,7 +1261,8 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
                 if (s->env_status[b] == 2) t_rem[b] = 0.0;
             }
         } else if (rc != FG_OK) return rc;
-        FG_HIP_CHECK(hipStreamSynchronize(st));  // dt_pinned is rewritten next round
+        // (no wait here: the time steps of the next sub-step go into the OTHER half of dt_pinned, and the wait for its CFL maxima
+        //  -- or for the next step's guard -- comes before this half is written again)
         ++substeps;
         if (!o->adaptive) --fixed_left;
         if (substeps >= (o->max_substeps > 0 ? o->max_substeps : 100000)) break;
