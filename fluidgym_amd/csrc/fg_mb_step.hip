@@ -1196,8 +1196,8 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
     bool maxvel_ready = false;
     {
         std::vector<mb_real> fl(B);
-        MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, 0, 0, 0, 0, s->red2););
-        FG_HIP_CHECK(hipMemcpyAsync(s->red2_pinned, s->red2, sizeof(mb_real) * 2 * s->B, hipMemcpyDeviceToHost, st));
+        // (one workgroup per env writes its two sums: straight into the host-pinned words, no device-to-host copy)
+        MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_bflux<DIMS>, dim3(s->B), dim3(FG_BLOCK), 0, st, s->dev, s->bvel, 0, 0, 0, 0, s->red2_pinned););
         if (o->adaptive) { if (int rc = mb_enqueue_max_velocity(s, st)) return rc; maxvel_ready = true; }
         FG_HIP_CHECK(hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) fl[b] = s->red2_pinned[2 * b] + s->red2_pinned[2 * b + 1];
