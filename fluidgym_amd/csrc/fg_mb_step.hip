@@ -737,9 +737,10 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
         return rc;
     };
     int its[4] = {0, 0, 0, 0};
-    // working copy of dt: envs whose solve turns out non-finite are masked out of the rest of the step (k_mb_mask_failed)
-    FG_HIP_CHECK(hipMemcpyAsync(s->dt_step, dt_B, sizeof(mb_real) * B, hipMemcpyDeviceToDevice, st));
-    FG_HIP_CHECK(hipMemsetAsync(s->env_fail, 0, sizeof(int32_t) * B, st));
+    // working copy of dt: envs whose solve turns out non-finite are masked out of the rest of the step (k_mb_mask_failed).
+    // (fg_mb_single_step uploads its time steps straight into the working copy; env_fail is all zeros between steps: the rare path
+    //  below that reads it clears it again -- two launches per PISO step less)
+    if (dt_B != s->dt_step) FG_HIP_CHECK(hipMemcpyAsync(s->dt_step, dt_B, sizeof(mb_real) * B, hipMemcpyDeviceToDevice, st));
     dt_B = s->dt_step;
     auto mask_failed = [&](int nc) {
         hipLaunchKernelGGL(k_mb_mask_failed, dim3((B + 63) / 64), dim3(64), 0, st, B, nc, (const fg_solve_info*)s->info_dev, s->dt_step, s->env_fail);
@@ -852,6 +853,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
     if (soft_rc == FG_ERR_NOT_FINITE) {   // rare path: which envs were dropped; their pressure goes back to what it was
         hipLaunchKernelGGL(k_mb_restore_failed, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, N, (const int32_t*)s->env_fail, (const mb_real*)s->pres_bak, s->pressure);
         FG_HIP_CHECK(hipMemcpyAsync(s->env_fail_pinned, s->env_fail, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+        FG_HIP_CHECK(hipMemsetAsync(s->env_fail, 0, sizeof(int32_t) * B, st));
         FG_HIP_CHECK(hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) s->env_status[b] = s->env_fail_pinned[b];
     } else if (soft_rc == FG_ERR_NOT_CONVERGED) {
@@ -1246,12 +1248,12 @@ extern "C" int fg_mb_single_step(fg_mb_handle s, const fg_mb_sim_options* o, int
             }
             dt_slot[b] = ts;
         }
-        FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, dt_slot, sizeof(mb_real) * B, hipMemcpyHostToDevice, st));
+        FG_HIP_CHECK(hipMemcpyAsync(s->dt_step, dt_slot, sizeof(mb_real) * B, hipMemcpyHostToDevice, st));   // (the step's working copy)
         if (o->outflow_count > 0)  // PRE hook of the cylinder / airfoil envs (cylinder_env_base.py:280-300)
-            if (int rc = mb_outflow_pre(s, s->dt_dev, o->outflow_slot0, o->outflow_count, o->outflow_slot0_b, o->outflow_count_b,
+            if (int rc = mb_outflow_pre(s, s->dt_step, o->outflow_slot0, o->outflow_count, o->outflow_slot0_b, o->outflow_count_b,
                                         o->outflow_velm, o->outflow_tol, st))
                 return rc;
-        const int rc = fg_mb_piso_step(s, s->dt_dev, &o->step, stats, stream);
+        const int rc = fg_mb_piso_step(s, s->dt_step, &o->step, stats, stream);
         if (rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) {
             all_ok = 0;
             for (int b = 0; b < B; ++b) {
