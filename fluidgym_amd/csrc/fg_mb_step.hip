@@ -246,7 +246,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_div(MbDev D, const mb_real* __r
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mb_correct(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ rA,
                                                           const mb_real* __restrict__ h, const mb_real* __restrict__ p,
-                                                          mb_real* __restrict__ u) {
+                                                          mb_real* __restrict__ u, mb_real* __restrict__ u_copy = nullptr) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     const mb_real* pb = p + (size_t)b * N;
@@ -266,7 +266,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_correct(MbDev D, const mb_real*
 #pragma unroll
         for (int a = 0; a < DIMS; ++a) gp += g[a] * mi[a * DIMS + c];
         const size_t q = ((size_t)b * DIMS + c) * N + i;
-        u[q] = h[q] - ra * gp;
+        const mb_real uc = h[q] - ra * gp;
+        u[q] = uc;
+        if (u_copy) u_copy[q] = uc;
     }
 }
 
@@ -322,9 +324,13 @@ __global__ void k_mb_sum(int N, const mb_real* __restrict__ dt, const mb_real* _
     if (threadIdx.x == 0) out[b * MB_SUM_WGS + blockIdx.x] = s;   // one partial per workgroup, summed in index order by k_mb_sub_mean
 }
 __global__ void k_mb_sub_mean(int N, const mb_real* __restrict__ dt, const mb_real* __restrict__ sum, mb_real* __restrict__ x,
-                              mb_real* __restrict__ copy) {
+                              mb_real* __restrict__ copy, mb_real* __restrict__ copy_backup = nullptr) {
     const int b = blockIdx.y, i = blockIdx.x * FG_BLOCK + threadIdx.x;
-    if (i >= N || !mb_active(dt, b)) return;
+    if (i >= N) return;
+    // copy_backup (the first mean removal of a PISO step): what `copy` held before this kernel overwrites it, for EVERY env -- the
+    // pressure a dropped env gets back at the end of the step (an env masked out earlier in the step still has it in `copy`)
+    if (copy_backup) copy_backup[(size_t)b * N + i] = copy[(size_t)b * N + i];
+    if (!mb_active(dt, b)) return;
     const mb_real* ps = sum + b * MB_SUM_WGS;
     const mb_real v = x[(size_t)b * N + i] - (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / (mb_real)N;
     x[(size_t)b * N + i] = v;
@@ -746,8 +752,9 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
         hipLaunchKernelGGL(k_mb_mask_failed, dim3((B + 63) / 64), dim3(64), 0, st, B, nc, (const fg_solve_info*)s->info_dev, s->dt_step, s->env_fail);
     };
     // pressure of the envs at the start of the step: a dropped env gets it back at the end (its velocity is never committed; its
-    // pressure is written by every corrector's mean removal, so a failure in corrector 1 would leave corrector 0's behind)
-    hipLaunchKernelGGL(k_mb_copy, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, (size_t)N, (const mb_real*)nullptr, (const mb_real*)s->pressure, s->pres_bak);
+    // pressure is written by every corrector's mean removal, so a failure in corrector 1 would leave corrector 0's behind).  The
+    // first mean removal of the step saves it while it overwrites it (k_mb_sub_mean: no copy launch of its own)
+    bool pressure_saved = false;
     const size_t vel_env = (size_t)d * N;
     const dim3 gcopy((unsigned)((vel_env + FG_BLOCK - 1) / FG_BLOCK), B);
     MB_DISPATCH(s, {
@@ -840,11 +847,15 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
                 if (int rc = soft(prc)) return rc;
                 if (c < 2) { its[2 + c] = std::max(its[2 + c], m); s->ctr.add(2 + c, s->info_pinned, B); }
                 hipLaunchKernelGGL(k_mb_sum, dim3(MB_SUM_WGS, B), blk, 0, st, N, dt_B, s->pres, s->red8);
-                hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, dt_B, s->red8, s->pres, s->pressure);
+                hipLaunchKernelGGL(k_mb_sub_mean, gn, blk, 0, st, N, dt_B, s->red8, s->pres, s->pressure, pressure_saved ? (mb_real*)nullptr : s->pres_bak);
+                pressure_saved = true;
             }
-            hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->hvec, s->pressure, s->ures);
+            // the last corrector also writes the block velocity of active envs: CopyVelocityResultToBlocks without a pass of its own
+            hipLaunchKernelGGL(k_mb_correct<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->hvec, s->pressure, s->ures,
+                               (c + 1 == opt->corrector_steps) ? s->velocity : (mb_real*)nullptr);
         }
-        hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, dt_B, s->ures, s->velocity);  // CopyVelocityResultToBlocks
+        if (opt->corrector_steps <= 0) hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, dt_B, s->ures, s->velocity);  // CopyVelocityResultToBlocks
+        if (!pressure_saved) hipLaunchKernelGGL(k_mb_copy, dim3((unsigned)((N + FG_BLOCK - 1) / FG_BLOCK), B), blk, 0, st, (size_t)N, (const mb_real*)nullptr, (const mb_real*)s->pressure, s->pres_bak);
     });
     FG_HIP_CHECK(hipGetLastError());
     if (stats_host) for (int k = 0; k < 4; ++k) stats_host[k] = its[k];
