@@ -609,9 +609,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_bicgf_b(FgGrid g, BicgPtrs q, Bicg
 // poll after k_bicgf_a(it + 1), i.e. after iteration `it` completed: judges r_{it+1} exactly as k_bicg_check does (the next
 // k_bicgf_b would come to the same verdict from the same accumulator) and mirrors info for the host
 __global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                              fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass, FgPollOut poll) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsys) return;
+                              fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass, FgPollOut poll,
+                              int sys0 = 0) {
+    // systems sys0 .. sys0 + nsys - 1 (a sub-batch of envs: the systems behind it have not started and must not be judged)
+    const int s = sys0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= sys0 + nsys) return;
     if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
     if (flag_ld(flags + (s)) == 0) {
         const fg_real crit = (fg_real)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + F_RR + ((it + 1) & 1))) / (double)n);
@@ -693,23 +695,24 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         return a.precond == 2 ? fg_fd_helmholtz_apply(s, a.nc, in, out, st) : fg_line_apply(s, a.diag, a.off, a.nc, in, out, st);
     };
 
+    FgGrid gsub = s->grid;     // the envs a launch covers: all of them, or a sub-batch (b0, B) in the two-kernel 2-D form below
 #define FG_BICG_LAUNCH_Y(NY, SLOT, KERNEL, ...)                                                                          \
     do {                                                                                                     \
         if (s->grid.dims == 2) {                                                                             \
             if (s->vec == 4) {                                                                               \
-                FgLaunch L = fg_launch_geometry<2, 4>(s->grid); L.grid.y = (NY);                             \
-                FG_LAUNCH_P(s, SLOT, (KERNEL<2, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FgLaunch L = fg_launch_geometry<2, 4>(gsub); L.grid.y = (NY);                             \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<2, 4>), L.grid, dim3(FG_BLOCK), 0, st, gsub, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             } else {                                                                                         \
-                FgLaunch L = fg_launch_geometry<2, 1>(s->grid); L.grid.y = (NY);                             \
-                FG_LAUNCH_P(s, SLOT, (KERNEL<2, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FgLaunch L = fg_launch_geometry<2, 1>(gsub); L.grid.y = (NY);                             \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<2, 1>), L.grid, dim3(FG_BLOCK), 0, st, gsub, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             }                                                                                                \
         } else {                                                                                             \
             if (s->vec == 4) {                                                                               \
-                FgLaunch L = fg_launch_geometry<3, 4>(s->grid); L.grid.y = (NY);                             \
-                FG_LAUNCH_P(s, SLOT, (KERNEL<3, 4>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FgLaunch L = fg_launch_geometry<3, 4>(gsub); L.grid.y = (NY);                             \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<3, 4>), L.grid, dim3(FG_BLOCK), 0, st, gsub, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             } else {                                                                                         \
-                FgLaunch L = fg_launch_geometry<3, 1>(s->grid); L.grid.y = (NY);                             \
-                FG_LAUNCH_P(s, SLOT, (KERNEL<3, 1>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
+                FgLaunch L = fg_launch_geometry<3, 1>(gsub); L.grid.y = (NY);                             \
+                FG_LAUNCH_P(s, SLOT, (KERNEL<3, 1>), L.grid, dim3(FG_BLOCK), 0, st, gsub, q, __VA_ARGS__, L.tiles_x, L.tiles_y, L.tiles); \
             }                                                                                                \
         }                                                                                                    \
     } while (0)
@@ -740,6 +743,32 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         // start vector zero on the z-marching kernels: r_0 = p_0 = rw = rhs, no init kernel (fg_bicg.h BicgFused::fold0; FG_BICG3_MIX & 4 keeps it)
         w.fold0 = (!a.use_x0 && !(s->bicg3_mix & 4) && (za == zb)) ? 1 : 0;     // (brick and z-marching kernels alike; not when the two are mixed)
 #endif
+        // Sub-batches of envs (2-D brick kernels): when the working set of the solve -- nine vectors per system, the matrix, the
+        // right-hand sides -- is far beyond the 256 MB Infinity Cache, the envs are solved in groups whose set fits it (the systems are
+        // independent), so that the iterations of a group stream from the cache instead of HBM: `large_env` (512 x 256 x 64, 839 MB)
+        // runs its launches at the headline's size and efficiency (k_bicgf_a 0.56 -> ~0.68 of the HBM figure) -- FG_BICG_SUB=0 / N
+        int nb_sub = B;
+#if !FG_F64
+        if (s->grid.dims == 2 && !za && !zb) {
+#else
+        if (s->grid.dims == 2) {
+#endif
+            const double per_env = (double)n * sizeof(fg_real) * (a.nc * 9.0 + (1 + 2 * s->grid.dims) + a.nc);
+            if (s->bicg_sub > 0) nb_sub = s->bicg_sub < B ? s->bicg_sub : B;
+            else if (s->bicg_sub < 0 && per_env * B > 400e6) {
+                nb_sub = (int)(220e6 / per_env);
+                const int tiles_env = (int)((n / (s->vec == 4 ? 4 : 1) + FG_BLOCK - 1) / FG_BLOCK);
+                while (nb_sub < B && (long)nb_sub * tiles_env < 1024) ++nb_sub;     // keep the chip filled
+                if (nb_sub < 1) nb_sub = 1;
+                if (nb_sub >= B) nb_sub = B;
+                else nb_sub = (B + (B + nb_sub - 1) / nb_sub - 1) / ((B + nb_sub - 1) / nb_sub);   // even groups
+            }
+        }
+        const int pred0 = next_poll;
+        for (int b0 = 0; b0 < B; b0 += nb_sub) {
+        gsub.b0 = b0; gsub.B = (b0 + nb_sub <= B) ? nb_sub : B - b0;
+        const int sys0 = b0 * a.nc, nsys_sub = gsub.B * a.nc;
+        done = false; next_poll = pred0;
         if (!w.fold0) FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);
 #if !FG_F64
         if (za) { if (int rc = fg_bicg3_launch_a(s, q, w, 0, zc3, -1, st)) return rc; }
@@ -748,27 +777,30 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         FG_BICG_LAUNCH_Y(1, -1, k_bicgf_a, w, 0);
         for (int it = 0; it < a.max_iterations && !done; ++it) {
 #if !FG_F64
-            if (zb) { if (int rc = fg_bicg3_launch_b(s, q, w, it, zc3, fg_prof_slot(s, FG_PK_BICGF_B, q.flags, nsys, cells * (20.0 + mat), cells * (fl + 12.0), st), st)) return rc; }
+            if (zb) { if (int rc = fg_bicg3_launch_b(s, q, w, it, zc3, fg_prof_slot(s, FG_PK_BICGF_B, q.flags + sys0, nsys_sub, cells * (20.0 + mat), cells * (fl + 12.0), st), st)) return rc; }
             else
 #endif
-            FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_B, q.flags, nsys, cells * (20.0 + mat), cells * (fl + 12.0), st), k_bicgf_b, w, it);
+            FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_B, q.flags + sys0, nsys_sub, cells * (20.0 + mat), cells * (fl + 12.0), st), k_bicgf_b, w, it);
 #if !FG_F64
-            if (za) { if (int rc = fg_bicg3_launch_a(s, q, w, it + 1, zc3, fg_prof_slot(s, FG_PK_BICGF_A, q.flags, nsys, cells * (40.0 + mat), cells * (fl + 14.0), st), st)) return rc; }
+            if (za) { if (int rc = fg_bicg3_launch_a(s, q, w, it + 1, zc3, fg_prof_slot(s, FG_PK_BICGF_A, q.flags + sys0, nsys_sub, cells * (40.0 + mat), cells * (fl + 14.0), st), st)) return rc; }
             else
 #endif
-            FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_A, q.flags, nsys, cells * (40.0 + mat), cells * (fl + 14.0), st), k_bicgf_a, w, it + 1);
+            FG_BICG_LAUNCH_Y(1, fg_prof_slot(s, FG_PK_BICGF_A, q.flags + sys0, nsys_sub, cells * (40.0 + mat), cells * (fl + 14.0), st), k_bicgf_a, w, it + 1);
             if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
                 next_poll = it + 1 + 2;
                 const int final_pass = (it + 1 == a.max_iterations);
                 fg_prof_prefetch(s, st);       // (in front of the polled kernel: its completion then covers the copy)
                 const FgPollOut po = fg_poll_next(&s->poll);
-                hipLaunchKernelGGL(k_bicgf_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass, po);
-                if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
+                hipLaunchKernelGGL(k_bicgf_check, dim3((nsys_sub + 63) / 64), sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys_sub,
+                                   final_pass, po, sys0);
+                if (int rc = fg_poll_wait(&s->poll, po, sys0, nsys_sub, st)) return rc;
                 info_fresh = true;
                 done = true;
-                for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
+                for (int i = sys0; i < sys0 + nsys_sub; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
             }
         }
+        }   // sub-batches
+        gsub = s->grid;
     } else {
     FG_BICG_LAUNCH_Y(1, -1, k_bicg_init, a.use_x0);
     for (int it = 0; it < a.max_iterations && !done; ++it) {

@@ -176,6 +176,7 @@ struct FgGrid {
     int nx, ny, nz;
     int n;        // cells per env
     int B;        // env batch
+    int b0;       // first env of the launch (0 except in a launch over a sub-batch of envs: fg_bicgstab_solve)
     int fixed[6]; // 1 = FIXED (prescribed) face, 0 = periodic
     const fg_real* h[3];  // cell widths per axis (device), length nx / ny / nz
     const fg_real* rh[3]; // reciprocals
@@ -275,6 +276,7 @@ __device__ __forceinline__ FgCtx<DIMS, VEC> fg_make_ctx(const FgGrid& g, int til
     const unsigned bid = fg_xcd_remap(blockIdx.x, gridDim.x);
     c.b = bid / tiles;
     int t = bid - c.b * tiles;
+    c.b += g.b0;
     int tix, tiy, tiz;
     if (DIMS == 3 && (tiles_y & 7) == 0 && gridDim.x == (unsigned)tiles) {
         // One big env (e.g. 256^3): the XCD remap hands each XCD a contiguous eighth of the tile ids.  Order the
@@ -671,6 +673,7 @@ struct fg_state {
     int adv_precond; long long line_retries;
     int cg_wgs_per_slot;          // workgroups sharing one CG accumulator slot (256; FG_CG_WGS_PER_SLOT at fg_create: tuning)
     int wall_forcing_axis; fg_real wall_forcing_coef[2]; fg_real* force_uniform;   // fg_set_wall_stress_forcing: [B, dims] uniform body force (device)
+    int bicg_sub;                 // FG_BICG_SUB: envs per sub-batch of the 2-D two-kernel BiCGStab (-1 = by the working set, 0 = never)
     int bicg3_force, bicg3_bxl, bicg3_mix;   // FG_BICG3 / FG_BICG3_BXL at fg_create (fg_bicgstab3d.hip)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
     fg_real* line_inv; fg_real* line_cp;
