@@ -765,16 +765,19 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
             }
         }
         const int pred0 = next_poll;
+        int started_b0 = -1;      // group whose first kernels were launched ahead, behind the previous group's poll (see below)
         for (int b0 = 0; b0 < B; b0 += nb_sub) {
         gsub.b0 = b0; gsub.B = (b0 + nb_sub <= B) ? nb_sub : B - b0;
         const int sys0 = b0 * a.nc, nsys_sub = gsub.B * a.nc;
         done = false; next_poll = pred0;
+        if (started_b0 != b0) {
         if (!w.fold0) FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);
 #if !FG_F64
         if (za) { if (int rc = fg_bicg3_launch_a(s, q, w, 0, zc3, -1, st)) return rc; }
         else
 #endif
         FG_BICG_LAUNCH_Y(1, -1, k_bicgf_a, w, 0);
+        }
         for (int it = 0; it < a.max_iterations && !done; ++it) {
 #if !FG_F64
             if (zb) { if (int rc = fg_bicg3_launch_b(s, q, w, it, zc3, fg_prof_slot(s, FG_PK_BICGF_B, q.flags + sys0, nsys_sub, cells * (20.0 + mat), cells * (fl + 12.0), st), st)) return rc; }
@@ -793,6 +796,16 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
                 const FgPollOut po = fg_poll_next(&s->poll);
                 hipLaunchKernelGGL(k_bicgf_check, dim3((nsys_sub + 63) / 64), sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys_sub,
                                    final_pass, po, sys0);
+                if (nb_sub < B && b0 + nb_sub < B && started_b0 != b0 + nb_sub) {
+                    // the next group's first kernels go out behind this group's check, so that the GPU has work during the host's round
+                    // trip (polls are placed where solves usually end); the groups share nothing, whatever this poll says
+                    const FgGrid keep = gsub;
+                    gsub.b0 = b0 + nb_sub; gsub.B = (gsub.b0 + nb_sub <= B) ? nb_sub : B - gsub.b0;
+                    if (!w.fold0) FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);
+                    FG_BICG_LAUNCH_Y(1, -1, k_bicgf_a, w, 0);
+                    gsub = keep;
+                    started_b0 = b0 + nb_sub;
+                }
                 if (int rc = fg_poll_wait(&s->poll, po, sys0, nsys_sub, st)) return rc;
                 info_fresh = true;
                 done = true;
