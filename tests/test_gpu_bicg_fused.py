@@ -244,3 +244,43 @@ def test_solver_state_prepared_by_the_assembly_kernels_survives_foreign_calls_in
     assert all(i.converged for i in inf_a + inf_b)
     assert [i.used_iterations for i in inf_a] == [i.used_iterations for i in inf_b]
     assert torch.equal(u_a, u_b)
+
+
+def test_subbatched_solve_is_the_whole_batch_solve_bit_for_bit(monkeypatch):
+    """Round 4 (FG_BICG_SUB, fg_bicgstab_solve): when the working set of the 2-D two-kernel BiCGStab is far beyond the Infinity Cache
+    the envs are solved in cache-sized groups, each group through all its iterations and polls before the next (FgGrid::b0; the
+    check kernel judges the group's systems only; the next group's first kernels go out behind the current group's check).  The
+    systems are independent and the per-system arithmetic does not change: forced groups of 2 envs (5 envs: 2 + 2 + 1) give the
+    whole-batch solve bit for bit, iteration counts included -- with envs that converge at different iterations, from zero and
+    from a start vector, velocity and scalar systems."""
+    import torch
+
+    case = make_case(dims=2, n=(64, 32), fixed_axes=(1,), B=5, seed=31, vel_scale=0.4, nu=0.03, n_scalars=1)
+    scale = torch.tensor([0.2, 1.0, 0.5, 1.5, 0.8]).view(5, 1, 1, 1)
+
+    def solve(sub, from_result, for_scalar):
+        monkeypatch.setenv("FG_BICG_SUB", str(sub))           # read at fg_create
+        ns = case.native()
+        ns.velocity.mul_(scale.to(ns.velocity.device))           # envs of different stiffness: different iteration counts
+        ns.set_advection_start(from_result)
+        ns.setup_advection(0.08, for_scalar=for_scalar, channel=0)
+        if from_result:
+            ns.solve_advection(for_scalar=for_scalar, tol=1e-3)   # leaves a start vector behind
+        info = ns.solve_advection(for_scalar=for_scalar, tol=1e-7)
+        shape = (case.B,) + case.shape if for_scalar else (case.B, case.dims) + case.shape
+        x = ns.buffer(7 if for_scalar else 3, shape).clone()
+        form = ns.advection_solver_form()
+        ns.close()
+        return x, [i.used_iterations for i in info], all(i.converged for i in info), form
+
+    for from_result in (False, True):
+        for for_scalar in (False, True):
+            if for_scalar and from_result:
+                continue                                          # (scalar solves always start from zero)
+            x0, it0, ok0, form = solve(0, from_result, for_scalar)
+            x2, it2, ok2, _ = solve(2, from_result, for_scalar)
+            assert form == "two-brick" and ok0 and ok2
+            assert it0 == it2, (it0, it2)
+            assert torch.equal(x0, x2)
+            if not for_scalar:
+                assert len(set(it0)) > 1, it0                     # the groups do end at different iterations
