@@ -113,6 +113,9 @@ struct fg_mb_state {
     hipGraphExec_t cg_graph_exec = nullptr;   // one chunk of CG iterations + convergence check (fg_mb_step.hip::mb_cg)
     unsigned char cg_graph_key_storage[256] = {0};
     int32_t* flags_pinned = nullptr;
+    int32_t* sys_map_dev = nullptr;    // [B d] systems of a compacted launch (mb_bicgstab: MbSolve::sys_map); host copy in sys_map_pinned
+    int32_t* sys_map_pinned = nullptr;
+    int dbg_compact = 1;               // FG_MB_COMPACT=0: every launch over all systems
     FgPoll poll = {};             // host polls on pinned sequence words (fg_internal.h FgPoll; created with the pinned mirrors)
     int32_t* verified = nullptr;   // [B d] BiCGStab convergence verification (mb_bicgstab): 0 open, 1 true residual checked, 2 being checked
     fg_solve_info *info_dev, *info_pinned = nullptr;

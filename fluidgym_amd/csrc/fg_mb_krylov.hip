@@ -31,7 +31,7 @@ __device__ __forceinline__ mb_real mb_spmv(const MbDev& D, const MbSolve& q, int
 
 #define MB_SYS                                          \
     const int i = blockIdx.x * FG_BLOCK + threadIdx.x;  \
-    const int sys = blockIdx.y;                         \
+    const int sys = q.sys_map ? q.sys_map[blockIdx.y] : (int)blockIdx.y;   /* (compacted launches: MbSolve::sys_map) */ \
     const int b = sys / q.nc;                           \
     const int N = D.N;                                  \
     const bool valid = i < N;                           \
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbb_x(MbDev D, MbSolve q, int it) 
 // 16 envs x 46.7 k cells the one-cell kernels took 51 us per iteration, 2-3x what their bytes need.
 #define MB_SYS4                                                   \
     const int i = (blockIdx.x * FG_BLOCK + threadIdx.x) * 4;      \
-    const int sys = blockIdx.y;                                   \
+    const int sys = q.sys_map ? q.sys_map[blockIdx.y] : (int)blockIdx.y;   \
     const int b = sys / q.nc;                                     \
     const int N = D.N;                                            \
     const bool valid = i < N;                                     \
@@ -676,8 +676,9 @@ __device__ __forceinline__ mb_real ml_quad_sum(mb_real v) {
     const mb_real s0 = __shfl(v, base, 64), s1 = __shfl(v, base + 1, 64), s2 = __shfl(v, base + 2, 64), s3 = __shfl(v, base + 3, 64);
     return ((s0 + s1) + s2) + s3;
 }
-__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const mb_real* __restrict__ in, int N, const int32_t* __restrict__ flags) {
-    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, a = tq >> 2, row = tq & 3, sys = blockIdx.y;
+__global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const mb_real* __restrict__ in, int N, const int32_t* __restrict__ flags,
+                                                          const int32_t* __restrict__ sys_map) {
+    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, a = tq >> 2, row = tq & 3, sys = sys_map ? sys_map[blockIdx.y] : (int)blockIdx.y;
     if (flag_ld(flags + sys) != 0) return;
     mb_real sum = 0.f;
     if (a < M.n4) {
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict(MlDev M, const mb_real
 // partition of the mesh (checked in fg_mb_set_multilevel), so every cell is written exactly once.
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, MlDev M, int it) {
-    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, ag = tq >> 2, row = tq & 3, sys = blockIdx.y, N = D.N;
+    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, ag = tq >> 2, row = tq & 3, sys = q.sys_map ? q.sys_map[blockIdx.y] : (int)blockIdx.y, N = D.N;
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_p(MbDev D, MbSolve q, 
 }
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, MlDev M, int it) {
-    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, ag = tq >> 2, row = tq & 3, sys = blockIdx.y, N = D.N;
+    const int tq = blockIdx.x * FG_BLOCK + threadIdx.x, ag = tq >> 2, row = tq & 3, sys = q.sys_map ? q.sys_map[blockIdx.y] : (int)blockIdx.y, N = D.N;
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const size_t vb = (size_t)sys * N;
     FgDacc* a = q.acc + (size_t)sys * MB_ACC;
@@ -771,7 +772,10 @@ __global__ __launch_bounds__(FG_BLOCK) void k_ml_restrict_s(MbDev D, MbSolve q, 
 // 4 once there are enough systems to fill the chip either way (mb_ml_apply picks).  LDS is sized to the mesh (n8p = n8 rounded up):
 // r8 [SB][n8p] (re-used by the second folding stage, which needs 4 SB ROWS floats) and the partial sums [CG][SB][ROWS].
 template <int SB>
-__global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags, int n8p) {
+__global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, int nsys, const int32_t* __restrict__ flags, int n8p,
+                                                               const int32_t* __restrict__ sys_map) {
+    // (nsys: systems of the launch -- all of them, or the sys_map entries of a compacted launch)
+#define ML_SYSK(k) (sys_map ? sys_map[min(sys0 + (k), nsys - 1)] : sys0 + (k))
     extern __shared__ mb_real l_dyn[];
     mb_real* l_r8 = l_dyn;
     const int r8_words = SB * n8p > 4 * SB * ML_ROWS ? SB * n8p : 4 * SB * ML_ROWS;
@@ -779,11 +783,11 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
     const int sys0 = blockIdx.y * SB, r = threadIdx.x & (ML_ROWS - 1), cg = threadIdx.x / ML_ROWS;
     bool on[SB], any = false;
 #pragma unroll
-    for (int k = 0; k < SB; ++k) { on[k] = sys0 + k < nsys && flag_ld(flags + sys0 + k) == 0; any = any || on[k]; }
+    for (int k = 0; k < SB; ++k) { on[k] = sys0 + k < nsys && flag_ld(flags + ML_SYSK(k)) == 0; any = any || on[k]; }
     if (!any) return;
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
-        const float4* r4c = reinterpret_cast<const float4*>(M.r4c + (size_t)(sys0 + k) * 4 * M.n8);
+        const float4* r4c = reinterpret_cast<const float4*>(M.r4c + (size_t)(on[k] ? ML_SYSK(k) : 0) * 4 * M.n8);
         for (int g = threadIdx.x; g < M.n8; g += ML_ROWS * ML_CG) {
             mb_real sum = 0.f;
             if (on[k]) {
@@ -823,14 +827,15 @@ __global__ __launch_bounds__(ML_ROWS * ML_CG) void k_ml_coarse(MlDev M, int nc, 
         const int rr = threadIdx.x & (ML_ROWS - 1), k = threadIdx.x / ML_ROWS;
         const int orow = blockIdx.x * ML_ROWS + rr;
         constexpr int Q = SB * ML_ROWS;
-        if (orow < M.n8 && sys0 + k < nsys && flag_ld(flags + sys0 + k) == 0)
-            M.z8[(size_t)(sys0 + k) * M.n8 + orow] =
-                (l_r8[threadIdx.x] + l_r8[Q + threadIdx.x] + l_r8[2 * Q + threadIdx.x] + l_r8[3 * Q + threadIdx.x]) * M.scale_inv[(sys0 + k) / nc];
+        if (orow < M.n8 && sys0 + k < nsys && flag_ld(flags + ML_SYSK(k)) == 0)
+            M.z8[(size_t)ML_SYSK(k) * M.n8 + orow] =
+                (l_r8[threadIdx.x] + l_r8[Q + threadIdx.x] + l_r8[2 * Q + threadIdx.x] + l_r8[3 * Q + threadIdx.x]) * M.scale_inv[ML_SYSK(k) / nc];
     }
+#undef ML_SYSK
 }
 __global__ __launch_bounds__(FG_BLOCK) void k_ml_prolong(MlDev M, const mb_real* __restrict__ in, const mb_real* __restrict__ diag, int N, int nc,
-                                                         const int32_t* __restrict__ flags, mb_real* __restrict__ out) {
-    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = blockIdx.y;
+                                                         const int32_t* __restrict__ flags, mb_real* __restrict__ out, const int32_t* __restrict__ sys_map) {
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, sys = sys_map ? sys_map[blockIdx.y] : (int)blockIdx.y;
     if (i >= N || flag_ld(flags + sys) != 0) return;
     const int b = sys / nc;
     const unsigned a = M.a4[i];
@@ -1324,23 +1329,23 @@ void mb_ml_scale(fg_mb_state* s, const mb_real* diag, hipStream_t st) {
 
 void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const mb_real* in, mb_real* out, hipStream_t st, int fused, int it) {
     const MlDev M = mb_ml_dev(s);
-    const int nsys = s->B * q.nc, n = s->N;
+    const int nsys = q.sys_map ? q.n_map : s->B * q.nc, n = s->N;    // (systems of the launch: compacted when only a few still iterate)
     const dim3 rgrid4((4 * M.n4 + FG_BLOCK - 1) / FG_BLOCK, nsys);   // four threads per aggregate
     if (fused == 1) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_p<DIMS>, rgrid4, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
     else if (fused == 2) { MB_DISPATCH(s, hipLaunchKernelGGL(k_ml_restrict_s<DIMS>, rgrid4, dim3(FG_BLOCK), 0, st, s->dev, q, M, it);); }
     else
-    hipLaunchKernelGGL(k_ml_restrict, rgrid4, dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags);
+    hipLaunchKernelGGL(k_ml_restrict, rgrid4, dim3(FG_BLOCK), 0, st, M, in, n, (const int32_t*)q.flags, q.sys_map);
     {
         // systems per workgroup: 8 when that still leaves >= 2 workgroups per CU-pair of work (>= 32 systems) and the LDS fits 64 KB
         const int n8p = (M.n8 + 3) & ~3;
         const auto words = [&](int sb) { return (sb * n8p > 4 * sb * ML_ROWS ? sb * n8p : 4 * sb * ML_ROWS) + ML_CG * sb * ML_ROWS; };
         const int want = s->dbg_ml_sb ? s->dbg_ml_sb : (nsys >= 32 ? 8 : 4);
         if (want == 8 && words(8) * 4 <= 64 * 1024)
-            hipLaunchKernelGGL(k_ml_coarse<8>, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + 7) / 8), dim3(ML_ROWS * ML_CG), (size_t)words(8) * 4, st, M, q.nc, nsys, (const int32_t*)q.flags, n8p);
+            hipLaunchKernelGGL(k_ml_coarse<8>, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + 7) / 8), dim3(ML_ROWS * ML_CG), (size_t)words(8) * 4, st, M, q.nc, nsys, (const int32_t*)q.flags, n8p, q.sys_map);
         else
-            hipLaunchKernelGGL(k_ml_coarse<4>, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + 3) / 4), dim3(ML_ROWS * ML_CG), (size_t)words(4) * 4, st, M, q.nc, nsys, (const int32_t*)q.flags, n8p);
+            hipLaunchKernelGGL(k_ml_coarse<4>, dim3((M.n8 + ML_ROWS - 1) / ML_ROWS, (nsys + 3) / 4), dim3(ML_ROWS * ML_CG), (size_t)words(4) * 4, st, M, q.nc, nsys, (const int32_t*)q.flags, n8p, q.sys_map);
     }
-    hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out);
+    hipLaunchKernelGGL(k_ml_prolong, dim3((n + FG_BLOCK - 1) / FG_BLOCK, nsys), dim3(FG_BLOCK), 0, st, M, in, q.diag, n, q.nc, (const int32_t*)q.flags, out, q.sys_map);
 }
 
 // level schedules of the ILU(0) sweeps from the neighbour table (once per mesh); false: the mesh does not qualify
@@ -1458,6 +1463,24 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
     int& pred = s->pred_bicg[pred_slot & 31];
     int next_poll = (pred > 2 && s->dbg_pred) ? pred : 2;
     const int BICG_RESTART = refine ? 100 : 200;
+    int n_map = 0;      // systems of the compacted per-iteration launches (0: all systems, identity)
+    auto update_map = [&]() -> int {     // after a poll: the systems that still iterate (flags_pinned == 0), when they are few
+        if (!s->dbg_compact || ilu) return FG_OK;
+        int act = 0;
+        for (int i = 0; i < nsys; ++i) act += s->flags_pinned[i] == 0;
+        if (act == 0 || act > 16 || 4 * act > nsys) { n_map = 0; return FG_OK; }
+        bool same = (act == n_map);
+        int k = 0;
+        for (int i = 0; i < nsys; ++i)
+            if (s->flags_pinned[i] == 0) { same = same && s->sys_map_pinned[k] == i; ++k; }
+        if (same) return FG_OK;
+        k = 0;
+        for (int i = 0; i < nsys; ++i) if (s->flags_pinned[i] == 0) s->sys_map_pinned[k++] = i;
+        // (the previous upload has executed: the poll that just returned was enqueued behind it)
+        FG_HIP_CHECK(hipMemcpyAsync(s->sys_map_dev, s->sys_map_pinned, sizeof(int32_t) * act, hipMemcpyHostToDevice, st));
+        n_map = act;
+        return FG_OK;
+    };
     for (int it = 0; it < max_iterations && !done; ++it) {
         if (it > 0 && it % BICG_RESTART == 0) {
             q.it_base = it;
@@ -1477,32 +1500,40 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
             q.p = (li & 1) ? s->w[6] : s->w[2]; q.p_prev = (li & 1) ? s->w[2] : s->w[6];
             q.v = (li & 1) ? s->w[7] : s->w[3]; q.v_prev = (li & 1) ? s->w[3] : s->w[7];
         }
+        // Compacted launches: while only a few systems of the batch still iterate (envs differ: the slowest of 64 pressure systems
+        // needs 2-3x the mean), the kernels of an iteration are launched over those systems only -- grid.y = n_map, system =
+        // sys_map[blockIdx.y] -- instead of over all of them with most workgroups leaving at once (Airfoil2D x 64 with random actions:
+        // 47 % of all launched iterations ran for 1-3 systems, ~5.5 us per launch against ~2.5)
+        MbSolve qi = q;
+        dim3 gi = grid, gi4 = grid4;
+        if (n_map > 0) { qi.sys_map = s->sys_map_dev; qi.n_map = n_map; gi.y = gi4.y = (unsigned)n_map; }
         MB_DISPATCH(s, {   // vec_mask: which of the five kernels run in their four-cell form
             if (fused_pv) {
-                if ((vec_mask & 3) == 3) hipLaunchKernelGGL(k_mbb_pv4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_pv<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                if ((vec_mask & 3) == 3) hipLaunchKernelGGL(k_mbb_pv4<DIMS>, gi4, blk, 0, st, s->dev, qi, li); else hipLaunchKernelGGL(k_mbb_pv<DIMS>, gi, blk, 0, st, s->dev, qi, li);
             } else {
             if (ml_fused) {}   // p is formed inside the restriction (mb_ml_apply below)
-            else if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, grid, blk, 0, st, s->dev, q, li);
-            if (ilu) mb_ilu_apply(s, q, q.p, s->ilu_mp, st);
-            else if (ml) mb_ml_apply(s, q, q.p, s->ml_mp, st, ml_fused ? 1 : 0, li);
-            if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            else if (vec_mask & 1) hipLaunchKernelGGL(k_mbb_p4<DIMS>, gi4, blk, 0, st, s->dev, qi, li); else hipLaunchKernelGGL(k_mbb_p<DIMS>, gi, blk, 0, st, s->dev, qi, li);
+            if (ilu) mb_ilu_apply(s, qi, qi.p, s->ilu_mp, st);
+            else if (ml) mb_ml_apply(s, qi, qi.p, s->ml_mp, st, ml_fused ? 1 : 0, li);
+            if (vec_mask & 2) hipLaunchKernelGGL(k_mbb_v4<DIMS>, gi4, blk, 0, st, s->dev, qi, li); else hipLaunchKernelGGL(k_mbb_v<DIMS>, gi, blk, 0, st, s->dev, qi, li);
             }
             if (fused_st) {
-                if ((vec_mask & 12) == 12) hipLaunchKernelGGL(k_mbb_st4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_st<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                if ((vec_mask & 12) == 12) hipLaunchKernelGGL(k_mbb_st4<DIMS>, gi4, blk, 0, st, s->dev, qi, li); else hipLaunchKernelGGL(k_mbb_st<DIMS>, gi, blk, 0, st, s->dev, qi, li);
             } else {
                 if (ml_fused) {}   // s is formed inside the restriction
-                else if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, grid, blk, 0, st, s->dev, q, li);
-                if (ilu) mb_ilu_apply(s, q, q.r, s->ilu_ms, st);
-                else if (ml) mb_ml_apply(s, q, q.r, s->ml_ms, st, ml_fused ? 2 : 0, li);
-                if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, grid, blk, 0, st, s->dev, q, li);
+                else if (vec_mask & 4) hipLaunchKernelGGL(k_mbb_s4<DIMS>, gi4, blk, 0, st, s->dev, qi, li); else hipLaunchKernelGGL(k_mbb_s<DIMS>, gi, blk, 0, st, s->dev, qi, li);
+                if (ilu) mb_ilu_apply(s, qi, qi.r, s->ilu_ms, st);
+                else if (ml) mb_ml_apply(s, qi, qi.r, s->ml_ms, st, ml_fused ? 2 : 0, li);
+                if (vec_mask & 8) hipLaunchKernelGGL(k_mbb_t4<DIMS>, gi4, blk, 0, st, s->dev, qi, li); else hipLaunchKernelGGL(k_mbb_t<DIMS>, gi, blk, 0, st, s->dev, qi, li);
             }
-            if (vec_mask & 16) hipLaunchKernelGGL(k_mbb_x4<DIMS>, grid4, blk, 0, st, s->dev, q, li); else hipLaunchKernelGGL(k_mbb_x<DIMS>, grid, blk, 0, st, s->dev, q, li);
+            if (vec_mask & 16) hipLaunchKernelGGL(k_mbb_x4<DIMS>, gi4, blk, 0, st, s->dev, qi, li); else hipLaunchKernelGGL(k_mbb_x<DIMS>, gi, blk, 0, st, s->dev, qi, li);
         });
         if (it + 1 >= next_poll || it + 1 == max_iterations) {
             next_poll = it + 1 + (it < 20 ? 2 : 10);   // long (pressure) solves: fewer host round trips
             FgPollOut po = fg_poll_next(&s->poll);
             hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations), -1, po);
             if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
+            if (int rc = update_map()) return rc;
             if (nc == 1 && s->dbg_trace) {
                 mb_real lo = 1e30f, hi = 0.f; int active = 0;
                 for (int i = 0; i < nsys; ++i) { const mb_real c = s->info_pinned[i].final_residual; lo = c < lo ? c : lo; hi = c > hi ? c : hi; active += s->flags_pinned[i] == 0; }
@@ -1528,6 +1559,7 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
                     po = fg_poll_next(&s->poll);
                     hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, 0, -1, po);
                     if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
+                    if (int rc = update_map()) return rc;
                     next_poll = it + 1 + 2;
                     if (nc == 1 && s->dbg_trace) {
                         int open = 0;

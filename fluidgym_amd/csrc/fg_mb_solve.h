@@ -46,6 +46,9 @@ struct MbSolve {
     // fused p / v kernel (k_mbb_pv*): p and v of the previous iteration (the neighbours' new p is recomputed from them, so the new p
     // and v go to the other buffer of a pair); q.p / q.v are the current ones.  Null = the separate p and v kernels
     const mb_real* p_prev; const mb_real* v_prev;
+    // compacted launches (mb_bicgstab): when few systems of a batch still iterate, the per-iteration kernels are launched over those
+    // only -- grid.y = n_map and the system of a workgroup row is sys_map[blockIdx.y] (nullptr: the identity, grid.y = all systems)
+    const int32_t* sys_map; int n_map;
 };
 
 // accumulator / scalar / flag words: only through acc_ld / acc_st, sc_ld / sc_st, flag_ld / flag_st (fg_internal.h)

@@ -462,6 +462,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_ML_WARMUP"); if (e && atoi(e) > 0) { s->dbg_ml_warmup = atoi(e); s->ml_bicg_skip = s->dbg_ml_warmup; }
         s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
+        if (const char* e = getenv("FG_MB_COMPACT")) s->dbg_compact = atoi(e);
         if (const char* e = getenv("FG_MB_OC_RTG_NT")) s->oc_rtg_nt = atoi(e);   // 1: the register-resident form on 16-24 k cells instead of k_mbc_l2
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
@@ -489,6 +490,7 @@ extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (s->red_pinned) (void)hipHostFree(s->red_pinned);
     if (s->flags_pinned) (void)hipHostFree(s->flags_pinned);
     fg_poll_destroy(&s->poll);
+    if (s->sys_map_pinned) (void)hipHostFree(s->sys_map_pinned);
     if (s->red2_pinned) (void)hipHostFree(s->red2_pinned);
     if (s->dt_pinned) (void)hipHostFree(s->dt_pinned);
     if (s->env_fail_pinned) (void)hipHostFree(s->env_fail_pinned);
@@ -641,6 +643,8 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(mb_real) * 2 * B, hipHostMallocDefault));   // two halves (fg_mb_single_step)
     FG_HIP_CHECK(hipHostMalloc((void**)&s->flags_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
     if (int rc = fg_poll_create(&s->poll, B * d > 2 * B ? B * d : 2 * B)) return rc;
+    if (int rc = mb_alloc(s, &s->sys_map_dev, (size_t)B * d)) return rc;
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->sys_map_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
     if (int rc = mb_alloc(s, &s->verified, (size_t)B * d)) return rc;
     s->finalized = true;
     return FG_OK;

@@ -79,3 +79,35 @@ def test_native_wall_stress_forcing_is_the_python_hook(monkeypatch):
     assert float((p_n - p_p).abs().max()) < 2e-4 * float(p_p.abs().max()) + 1e-7
     assert torch.allclose(tau_n.float(), tau_p.float(), rtol=2e-5, atol=1e-9)
     assert float(tau_p.abs().max()) > 0
+
+
+def test_compacted_krylov_launches_leave_every_bit_where_it_was(monkeypatch):
+    """Round 4 (MbSolve::sys_map, mb_bicgstab): while only a few systems of a batch still iterate, the kernels of an iteration are
+    launched over those systems only.  The per-system arithmetic does not change, so an airfoil batch whose envs are driven apart
+    by different actions (their pressure solves end at different iterations: the compaction does engage) steps to the same bits
+    with FG_MB_COMPACT=0 (every launch over all systems, read at fg_mb_create)."""
+    import fluidgym_amd
+
+    def run(compact):
+        if compact:
+            monkeypatch.delenv("FG_MB_COMPACT", raising=False)
+        else:
+            monkeypatch.setenv("FG_MB_COMPACT", "0")
+        env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=8, initial_domain_steps=6, randomize_initial_state=False, episode_length=3, resolution_div=2)
+        try:
+            env.reset(seed=0)
+            gen = torch.Generator().manual_seed(9)
+            for _ in range(2):
+                a = (torch.rand(tuple(env.sample_action().shape), generator=gen) * 2 - 1).to(env.cuda_device)
+                _, r, _, _, info = env.step(a)
+            c = env._domain.solver_counters()
+            return env._domain.velocity.clone(), env._domain.pressure.clone(), torch.as_tensor(r).clone(), c["pressure0"]
+        finally:
+            env.close()
+
+    u1, p1, r1, c1 = run(True)
+    u0, p0, r0, c0 = run(False)
+    assert torch.equal(u1, u0) and torch.equal(p1, p0) and torch.equal(r1, r0)
+    assert c1["mean"] == c0["mean"] and c1["max"] == c0["max"]
+    assert c1["max"] > 1.3 * c1["mean"], c1                      # the solves of the batch do end at different iterations
+    assert float((u1[0] - u1[-1]).abs().max()) > 0               # and the envs differ
