@@ -589,7 +589,7 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
     for (int c = 0; c < opt->corrector_steps; ++c) {
         const bool last = (c + 1 == opt->corrector_steps);
         if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
-        if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st)) return rc;
+        if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st, !opt->pressure_warm_start)) return rc;
         if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations,
                                          opt->pressure_warm_start ? 1 : 0,
                                          info.data(), st, last)))

@@ -52,6 +52,11 @@ __device__ __forceinline__ void fg_cg_begin_env(const FgCgBegin& q, const fg_rea
 }
 #endif
 
+// Start of a pressure CG from the zero vector, folded into the kernel that writes its right-hand side (k_div; the state was
+// prepared by the kernel in front of it, k_h): r = b, x = 0 and r.r into ring entry 0 -- what k_cg_residual<use_x0 = 0> does in a
+// launch of its own.  Same per-workgroup partial sums, same accumulator: the same bits.  acc == nullptr: not folded.
+struct FgCgStart { FgDacc* acc; fg_real* r; fg_real* x; int ns; };
+
 // The verdict on rr_{it+1} that a k_cg_check launch between k_cg_update(it) and the preconditioner used to give, taken instead by
 // EVERY workgroup of the preconditioner's first kernel from the same accumulator words (whole waves must call: the slot sum is a
 // wave shuffle tree); the env's leader thread stores the flag and the info words.  An env found converged (or non-finite) is

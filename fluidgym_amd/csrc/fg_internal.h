@@ -703,6 +703,7 @@ struct fg_state {
     mutable int maxvel_clean;     // scratch_B rows 1-2 (CFL maximum + arrival counters) are zero: left so by the mirrored k_max_velocity
     mutable int bicg_ready_nc; mutable const fg_real* bicg_ready_dt;
     mutable int cg_ready_ns, cg_ready_best; mutable const fg_real* cg_ready_dt;
+    mutable int cg_start_ready;   // k_div also started the CG from zero (r = b in w[0], x = 0 in p_result, r.r in ring entry 0)
     size_t n_cells() const { return (size_t)grid.n; }
 };
 
@@ -781,7 +782,8 @@ int fg_launch_wall_forcing(const fg_state* s, hipStream_t st);   // force_unifor
 int fg_launch_sgs(const fg_state* s, const FgBounds& bnd, fg_real coefficient, fg_real* out, hipStream_t st);
 int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t st);  // rA = 1/A
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st);
-int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, hipStream_t st);
+int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, hipStream_t st,
+                  bool cg_from_zero = false);   // true: the kernel also starts the pressure CG that follows from zero (FgCgStart, fg_cg.h)
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
                       fg_real* vel_out, hipStream_t st, fg_real* vel_copy = nullptr);
 // mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be

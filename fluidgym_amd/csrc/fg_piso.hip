@@ -216,8 +216,11 @@ template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const fg_real* __restrict__ dt,
                                                  const fg_real* __restrict__ rA_, const fg_real* __restrict__ Coff,
                                                  const fg_real* __restrict__ rhs, const fg_real* __restrict__ velr,
-                                                 fg_real* __restrict__ hvec, int tiles_x, int tiles_y, int tiles) {
+                                                 fg_real* __restrict__ hvec, FgCgBegin begin, int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
+    // the pressure solve on the right-hand side built from this h comes next: the first workgroup of the env prepares its state
+    // (fg_cg.h; here and not in k_div, which ALSO starts the solve -- r = b, x = 0, r.r -- and must find the accumulators zeroed)
+    if (begin.acc && fg_xcd_remap(blockIdx.x, gridDim.x) % (unsigned)tiles == 0) fg_cg_begin_env(begin, dt, c.b);
     if (!(dt[c.b] > 0.f) || !c.valid) return;
     const size_t N = g.n;
     const FgVec<VEC> rA = fg_load<VEC>(rA_ + (size_t)c.b * N + c.idx);
@@ -248,12 +251,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_h(FgGrid g, const fg_real* __restr
 // ---------------------------------------------------------------------------------------------
 template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const fg_real* __restrict__ dt,
-                                                   const fg_real* __restrict__ hvec, fg_real* __restrict__ div, FgCgBegin begin,
+                                                   const fg_real* __restrict__ hvec, fg_real* __restrict__ div, FgCgStart start,
                                                    int tiles_x, int tiles_y, int tiles) {
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
-    // the pressure solve on this right-hand side comes next: the first workgroup of the env prepares its state (fg_cg.h)
-    if (begin.acc && fg_xcd_remap(blockIdx.x, gridDim.x) % (unsigned)tiles == 0) fg_cg_begin_env(begin, dt, c.b);
-    if ((dt && !(dt[c.b] > 0.f)) || !c.valid) return;
+    if (dt && !(dt[c.b] > 0.f)) return;
+    if (!c.valid && !start.acc) return;
     const size_t N = g.n;
     const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
     fg_real acc[VEC];
@@ -283,7 +285,24 @@ __global__ __launch_bounds__(FG_BLOCK) void k_div(FgGrid g, FgBounds bnd, const 
     FgVec<VEC> out;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) out.v[e] = acc[e];
-    fg_store<VEC>(div + (size_t)c.b * N + c.idx, out);
+    if (c.valid) fg_store<VEC>(div + (size_t)c.b * N + c.idx, out);
+    if (start.acc) {
+        // the start of the CG that follows from the zero vector (FgCgStart, fg_cg.h): r = b, x = 0, r.r -- k_cg_residual's arithmetic
+        __shared__ fg_real lds[4];
+        fg_real part[1] = {0.f};
+        if (c.valid) {
+            FgVec<VEC> z;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { z.v[e] = 0.f; part[0] += out.v[e] * out.v[e]; }
+            fg_store<VEC>(start.x + (size_t)c.b * N + c.idx, z);
+            fg_store<VEC>(start.r + (size_t)c.b * N + c.idx, out);
+        }
+        fg_block_sum<1>(part, lds);
+        if (threadIdx.x == 0) {
+            const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
+            fg_acc_add(fg_acc_ptr(start.acc, c.b, 0), start.ns, tile, (double)part[0]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -929,24 +948,35 @@ int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t s
 }
 
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st) {
+    // the state of the pressure CG that follows is prepared by this launch (FgCgBegin, fg_cg.h; fg_cg_solve skips its k_cg_begin when
+    // the record matches its own arguments)
+    FgCgBegin begin;
+    begin.acc = s->cg_acc; begin.flags = s->flags; begin.info = s->info_dev; begin.mean_sums = s->acc; begin.best = s->cg_best;
+    begin.track_best = s->cg_return_best; begin.ns = fg_cg_slots(s);
+    s->cg_ready_ns = begin.ns; s->cg_ready_best = begin.track_best; s->cg_ready_dt = dt; s->bicg_ready_nc = 0; s->cg_start_ready = 0;
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_h<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, s->rA, s->Coff, s->adv_rhs,
-                           vel_result, s->hvec, L.tiles_x, L.tiles_y, L.tiles);
+                           vel_result, s->hvec, begin, L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }
 
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div,
-                  hipStream_t st) {
-    FgCgBegin begin;
-    begin.acc = s->cg_acc; begin.flags = s->flags; begin.info = s->info_dev; begin.mean_sums = s->acc; begin.best = s->cg_best;
-    begin.track_best = s->cg_return_best; begin.ns = fg_cg_slots(s);
-    s->cg_ready_ns = begin.ns; s->cg_ready_best = begin.track_best; s->cg_ready_dt = dt; s->bicg_ready_nc = 0;
+                  hipStream_t st, bool cg_from_zero) {
+    // cg_from_zero: the pressure CG on this right-hand side starts from the zero vector and its state was prepared by the k_h in
+    // front of this launch -- then this kernel also starts it (FgCgStart: r = b into w[0], x = 0 into p_result, r.r) and fg_cg_solve
+    // finds the record and skips k_cg_residual
+    FgCgStart start = {nullptr, nullptr, nullptr, 1};
+    s->cg_start_ready = 0;
+    if (cg_from_zero && dt != nullptr && s->cg_ready_ns > 0 && s->cg_ready_dt == dt && div == s->div) {
+        start.acc = s->cg_acc; start.r = s->w[0]; start.x = s->p_result; start.ns = s->cg_ready_ns;
+        s->cg_start_ready = 1;
+    }
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_div<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, dt, hvec, div, begin, L.tiles_x,
+        hipLaunchKernelGGL((k_div<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, dt, hvec, div, start, L.tiles_x,
                            L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());

@@ -398,9 +398,11 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const bool zmarch = fg_zmarch_ok(s, &zc);
     const int ns = fg_cg_slots(s);
     (void)tiles_per_env;
+    bool start_ready = false;      // k_div started this solve (FgCgStart): no k_cg_residual launch
     {   // state already prepared by the k_div that built this right-hand side (FgCgBegin, fg_cg.h)?
         const bool ready = s->cg_ready_ns == ns && s->cg_ready_best == s->cg_return_best && s->cg_ready_dt == a.dt;
-        s->cg_ready_ns = 0; s->bicg_ready_nc = 0;
+        start_ready = ready && s->cg_start_ready && !a.use_x0 && a.b == s->div && a.r == s->w[0] && a.x == s->p_result;
+        s->cg_ready_ns = 0; s->bicg_ready_nc = 0; s->cg_start_ready = 0;
         if (!ready) {
             FgCgBegin q;
             q.acc = s->cg_acc; q.flags = s->flags; q.info = s->info_dev; q.mean_sums = s->acc; q.best = s->cg_best;
@@ -408,6 +410,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, q, B);
         }
     }
+    if (!start_ready)
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x, a.r,
