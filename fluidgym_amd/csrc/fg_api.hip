@@ -340,10 +340,7 @@ extern "C" int fg_step_diagnostics(fg_handle s, fg_real* out_host, void* stream)
     return FG_OK;
 }
 
-static int sync_bvel_ptrs(fg_state* s) {
-    FG_HIP_CHECK(hipMemcpy(s->d_bvel_ptrs, s->bvel, sizeof(fg_real*) * 6, hipMemcpyHostToDevice));
-    return FG_OK;
-}
+static int sync_bvel_ptrs(fg_state*) { return FG_OK; }   // (the boundary pointers travel as kernel arguments: re-binding one costs nothing on the device)
 
 extern "C" int fg_update_advective_boundary(fg_handle s, int face, const fg_real* velm, const fg_real* dt_B, void* stream) {
     FG_REQUIRE(s && velm && dt_B && face >= 0 && face < 2 * s->grid.dims, FG_ERR_INVALID_ARG, "bad argument");

@@ -721,8 +721,9 @@ struct FgOutflowFold {
     const fg_real* vel; const fg_real* scal;
     fg_real* bscal[6]; int nsc[6];
 };
+struct FgBvelRw { fg_real* p[6]; };      // the writable boundary velocities, by value (no device-side pointer table: re-binding a boundary is host-only)
 template <int DIMS>
-__global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds bnd, fg_real* const* bvel_rw, int free_mask,
+__global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds bnd, FgBvelRw bvel_rw_, int free_mask,
                                                               fg_real atol, const fg_real* __restrict__ dt, FgOutflowFold fold) {
     const int b = blockIdx.x;
     const fg_real dtb = fold.dt_n ? fold.dt_v[b] : (dt ? dt[b] : (fg_real)1);
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds 
             const int edge = (face & 1) ? ((ax == 0) ? g.nx - 1 : (ax == 1) ? g.ny - 1 : g.nz - 1) : 0;
             const fg_real tcoef = 1.f - 1.f / (1.f + 2.f * dtb * fold.velm[ax] * g.rh[ax][edge]);
             const size_t N = g.n;
-            fg_real* bvel = bvel_rw[face];
+            fg_real* bvel = bvel_rw_.p[face];
             for (int s = threadIdx.x; s < slab_n; s += blockDim.x) {
                 int i, j, k;
                 if (ax == 0) { i = edge; j = s % g.ny; k = s / g.ny; }
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds 
     for (int f = 0; f < 2 * DIMS; ++f) {
         if (!((free_mask >> f) & 1) || !g.fixed[f]) continue;
         const int slab_n = fg_slab_size(g, f >> 1);
-        fg_real* v = bvel_rw[f] + (size_t)b * DIMS * slab_n;
+        fg_real* v = bvel_rw_.p[f] + (size_t)b * DIMS * slab_n;
         for (int s = threadIdx.x; s < DIMS * slab_n; s += blockDim.x) v[s] *= scale;
     }
 }
@@ -1093,10 +1094,12 @@ int fg_launch_balance(const fg_state* s, const FgBounds& bnd, int free_mask, fg_
         for (int a = 0; a < 3; ++a) fold.velm[a] = outflow_velm[a];
         for (int f = 0; f < 6; ++f) { fold.bscal[f] = s->bscal[f]; fold.nsc[f] = (s->scalar && s->bscal[f]) ? s->cfg.n_scalars : 0; }
     }
+    FgBvelRw rw;
+    for (int f = 0; f < 6; ++f) rw.p[f] = s->bvel[f];
     if (s->grid.dims == 2)
-        hipLaunchKernelGGL(k_balance_fluxes<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt, fold);
+        hipLaunchKernelGGL(k_balance_fluxes<2>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, rw, free_mask, atol, dt, fold);
     else
-        hipLaunchKernelGGL(k_balance_fluxes<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, s->d_bvel_ptrs, free_mask, atol, dt, fold);
+        hipLaunchKernelGGL(k_balance_fluxes<3>, dim3(s->grid.B), dim3(FG_BLOCK), 0, st, s->grid, bnd, rw, free_mask, atol, dt, fold);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

@@ -85,7 +85,7 @@ extern "C" int fg_profile_enable(fg_handle s, int on) {
     FG_HIP_CHECK(hipDeviceSynchronize());
     P.on = on; P.used = 0; P.prefetched = 0;
     const char* e = getenv("FG_PROF_PERIOD");
-    P.period = e && atoi(e) > 0 ? atoi(e) : 32;   // every 32nd launch of a kind is timed (8 cost the timed region ~5 %: a count kernel + two events per sample)
+    P.period = e && atoi(e) > 0 ? atoi(e) : 64;   // every 64th launch of a kind is timed (8 cost the timed region ~5 %: a count kernel + two events per sample; 32 until round 4)
     for (int k = 0; k < FG_PK_COUNT; ++k) {
         P.ms[k] = P.bytes[k] = P.flops[k] = P.full_ms[k] = P.full_bytes[k] = 0.0;
         P.n[k] = P.full_n[k] = P.launches[k] = P.all_n[k] = 0;

@@ -122,11 +122,6 @@ class ChannelJetEnv2D(FluidEnv):
         jp = torch.from_numpy(jet_profile(self._jet_cells).astype(np.float32)).to(dev) * self._jet_max
         self._jet_shape = torch.zeros(1, 2, 1, self._x, device=dev)
         self._jet_shape[0, 1, 0, self._jet_start: self._jet_start + self._jet_cells] = jp
-        # the two jet walls live in ONE tensor [2, B, 2, 1, X] (bound once, here): a sim step's action is then one copy, not two
-        sol = self._domain.solver
-        self._walls = torch.zeros(2, *sol.bvel[2].shape, device=dev, dtype=sol.bvel[2].dtype)
-        sol.set_boundary_velocity(2, self._walls[0])
-        sol.set_boundary_velocity(3, self._walls[1])
         self._velm = np.array([self._U_mean, 0.0], dtype=np.float32)  # host: characteristic outflow velocity
         # sensor probes: nearest cell centre of a regular lattice in the downstream 3/4 of the channel
         ix = np.linspace(self._x // 4, self._x - 1, self._n_sensors_x).round().astype(np.int64)
@@ -201,9 +196,14 @@ class ChannelJetEnv2D(FluidEnv):
             decay = (1.0 - self._action_smoothing_alpha) ** torch.arange(1, n + 1, device=target.device, dtype=target.dtype)
             controls = target[None] + (self._current_action - target)[None] * decay.view(n, 1, 1)       # [n, B, 1]
             jets = self._jet_shape[None] * controls.reshape(n, self._num_envs, 1, 1, 1)                   # [n, B, 2, 1, X]
+            sol = self._domain.solver
+            self._jets = jets          # (the walls stay bound to its last slice after the step)
         for k in range(n):
             if self._enable_actions:
-                self._walls.copy_(jets[k][None].expand_as(self._walls))      # both walls (the same wall-normal velocity: zero net flux)
+                # both walls are BOUND to this sim step's slice (the same wall-normal velocity on both: zero net flux) -- a pointer
+                # update on the host, no copy launch (the library takes boundary pointers as kernel arguments)
+                sol.set_boundary_velocity(2, jets[k])
+                sol.set_boundary_velocity(3, jets[k])
             if not self._sim.single_step():
                 raise RuntimeError("simulation step failed")
         if self._enable_actions:
