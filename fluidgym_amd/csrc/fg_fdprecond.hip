@@ -362,10 +362,14 @@ __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const f
 //   3. all four waves store the result with float4s.
 // Measured 7.8 us at B = 64 (256 x 128), 4.5k / 6.1k / 1.5k clocks for the three phases.  Needs nx % 4 == 0 and
 // 3 x roundup(ny, 16) x 256 B of LDS (ny <= 208).
+// TWO = true (ny beyond 208: the 512 x 256 grid of `large_env`): only two arrays fit the 160 KB -- c' is staged into the ms region
+// AFTER the forward sweep has used it up (one more load phase and barrier in the middle; the streaming kernel it replaces there took
+// 32 us per application).
+template <bool TWO>
 __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, const float* __restrict__ inv,
                                                        const float* __restrict__ cp, const float* __restrict__ lower,
                                                        const int32_t* __restrict__ flags, int nx, int ny, int nz) {
-    extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]  (TWO: cs shares ms)
     const int b = blockIdx.y;
     if (flags && flags[b] != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
     const int nyp = (ny + CH - 1) / CH * CH, last = ny - 1;
     float* bs = tbuf;
     float* ms = tbuf + (size_t)nyp * 64;
-    float* cs = tbuf + (size_t)2 * nyp * 64;
+    float* cs = TWO ? ms : tbuf + (size_t)2 * nyp * 64;
     const int lc = 4 * (lane & 15), rsub = lane >> 4;
     int t4 = blockIdx.x * 64 + lc;
     const bool live = t4 < nx * nz;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
             const int j = min(jb + 4 * q + rsub, last);
             vx[q] = *reinterpret_cast<const float4*>(xb4 + (size_t)j * nx);
             vi[q] = *reinterpret_cast<const float4*>(iv4 + (size_t)j * nx);
-            vc[q] = *reinterpret_cast<const float4*>(cp4 + (size_t)j * nx);
+            if (!TWO) vc[q] = *reinterpret_cast<const float4*>(cp4 + (size_t)j * nx);
             vl[q] = lower[j];
         }
 #pragma unroll
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
                 *reinterpret_cast<float4*>(bs + o) =
                     make_float4(vx[q].x * vi[q].x * m, vx[q].y * vi[q].y * m, vx[q].z * vi[q].z * m, vx[q].w * vi[q].w * m);
                 *reinterpret_cast<float4*>(ms + o) = make_float4(l * vi[q].x, l * vi[q].y, l * vi[q].z, l * vi[q].w);
-                *reinterpret_cast<float4*>(cs + o) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
+                if (!TWO) *reinterpret_cast<float4*>(cs + o) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
             }
         }
     }
@@ -422,8 +426,27 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
 #pragma unroll
             for (int q = 0; q < CH; ++q) px[q * 64] = ax[q];
         }
-        prev = 0.f;
-        px = bs + (size_t)(nyp - CH) * 64 + lane;
+    }
+    if (TWO) {
+        __syncthreads();       // the forward sweep is through with ms: c' takes its place
+        for (int jb = wave * 32; jb < nyp; jb += 128) {
+            float4 vc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vc[q] = *reinterpret_cast<const float4*>(cp4 + (size_t)min(jb + 4 * q + rsub, last) * nx);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + 4 * q + rsub;
+                if (j < nyp) {
+                    const float m = (j > last) ? 0.f : 1.f;
+                    *reinterpret_cast<float4*>(cs + j * 64 + lc) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float prev = 0.f;
+        float* px = bs + (size_t)(nyp - CH) * 64 + lane;
         const float* pc = cs + (size_t)(nyp - CH) * 64 + lane;
         for (int j0 = nyp - CH; j0 >= 0; j0 -= CH, px -= CH * 64, pc -= CH * 64) {
             float ax[CH], ac[CH];
@@ -455,8 +478,8 @@ static bool tridiag_lds_ready(size_t bytes) {
     static bool failed = false;
     if (bytes <= granted) return true;
     if (failed) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tridiag_y_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tridiag_y_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_tridiag_y_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
         (void)hipGetLastError();
         failed = true;
         return false;
@@ -541,8 +564,12 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_st
         dim3 grid((nx * nz + 63) / 64, B);
         const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
         const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
+        const size_t lds_two = lds_coop / 3 * 2;      // two arrays: c' staged after the forward sweep (ny up to 320)
         if ((nx & 3) == 0 && lds_coop <= 160 * 1024 && tridiag_lds_ready(lds_coop)) {
-            FG_LAUNCH_P(s, slot, k_tridiag_y_lds, grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+            FG_LAUNCH_P(s, slot, k_tridiag_y_lds<false>, grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                        s->flags, nx, ny, nz);
+        } else if ((nx & 3) == 0 && lds_two <= 160 * 1024 && tridiag_lds_ready(lds_two)) {
+            FG_LAUNCH_P(s, slot, k_tridiag_y_lds<true>, grid, dim3(256), lds_two, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
                         s->flags, nx, ny, nz);
         } else {
             FG_LAUNCH_P(s, slot, k_tridiag_y, grid, dim3(64), (size_t)((ny + 63) / 64 * 64) * 64 * sizeof(float), st, cur,
