@@ -712,3 +712,45 @@ def test_recurrence_words_read_back_exactly():
         val = (ctypes.c_double * 12)()
         L.check(L.load().fg_coherence_litmus(access, 32, 46664, 3000, bad, val, None))
         assert sum(bad) == 0, (access, list(bad), list(val))
+
+
+def test_l2_form_onchip_cg_is_the_register_resident_one(monkeypatch):
+    """Round 4: meshes of 16-24 k cells (the cylinder's ``medium`` / ``hard`` ids, resolution 32: 23 424 cells) run the preconditioned
+    pressure CG of an env in one workgroup with ONLY the search direction in LDS and x, r, M p / z as per-env vectors in L2
+    (``k_mbc_l2``, csrc/fg_mb_onchip.hip) -- against the register-resident cell-ordered kernel with its residual copy in global
+    memory (``k_mbc_onchip<..., RTG>``, FG_MB_OC_RTG_NT=1, read at fg_mb_create): the same recurrence, preconditioner, restart and
+    best-iterate rules with another summation order of the dot products, so iteration counts may differ by one or two and the
+    projected velocities agree to what two Krylov trajectories at that tolerance do.  Covers the start from zero, the start from an
+    iterate (second non-orthogonal pass, warm-start policy: the kernel's residual pass) and an inactive env."""
+    from fluidgym_amd.envs.cylinder_grid import build_domain, make_vortex_street_mesh
+
+    mesh = make_vortex_street_mesh(32)
+    out = {}
+    for form in ("1", "0"):
+        if form == "1":
+            monkeypatch.setenv("FG_MB_OC_RTG_NT", "1")
+        else:
+            monkeypatch.delenv("FG_MB_OC_RTG_NT", raising=False)
+        dom = build_domain(mesh, 0.01, batch=3)
+        assert 16384 < dom.n_cells <= 24576
+        dom.set_stall_limit(5000)
+        ml = dom.set_pressure_multilevel()
+        assert ml is not None and ml["n4"] <= 2048 and ml["n8"] <= 512, ml
+        g = torch.Generator(device="cpu").manual_seed(11)
+        dom.velocity.copy_((0.3 * torch.randn(dom.velocity.shape, generator=g)).to(dom.device))
+        dom.velocity[:, 0] += 1.0
+        dom.solver_counters(reset=True)
+        dom.make_divergence_free(pressure_tol=1e-7, max_iterations=5000, pressure_project_mean=True)
+        u0 = dom.velocity.cpu().numpy().copy()
+        for _ in range(2):
+            dom.piso_step([0.01, 0.02, 0.0], pressure_tol=1e-7, advection_tol=1e-7, pressure_project_mean=True)   # env 2 inactive
+        dom.piso_step([0.01, 0.02, 0.0], pressure_tol=1e-7, advection_tol=1e-7, pressure_project_mean=True, pressure_non_ortho_steps=2,
+                      pressure_warm_start=True)
+        out[form] = (u0, dom.velocity.cpu().numpy().copy(), dom.pressure.cpu().numpy().copy(), dom.solver_counters())
+        dom.close()
+    (u0_r, u_r, p_r, c_r), (u0_l, u_l, p_l, c_l) = out["1"], out["0"]
+    assert np.isfinite(u_l).all() and np.isfinite(p_l).all()
+    assert _rel(u0_l, u0_r) < 2e-5 and _rel(u_l, u_r) < 5e-5, (_rel(u0_l, u0_r), _rel(u_l, u_r))
+    for k in ("pressure0", "pressure1"):
+        assert abs(c_l[k]["mean"] - c_r[k]["mean"]) <= 2.0 and c_l[k]["unconverged"] == 0 and c_l[k]["mean"] < 200, (c_r, c_l)     # (1e-7 on a rough random field: ~90 iterations)
+    np.testing.assert_array_equal(u_l[2], u0_l[2])   # the inactive env is untouched
