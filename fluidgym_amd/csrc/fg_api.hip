@@ -121,6 +121,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     { const char* ev = getenv("FG_BICG3"); s->bicg3_force = ev ? atoi(ev) : -1; }
     { const char* ev = getenv("FG_BICG3_BXL"); s->bicg3_bxl = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("FG_BICG_SUB"); s->bicg_sub = ev ? atoi(ev) : -1; }
+    { const char* ev = getenv("FG_REDUCE_WGS"); s->reduce_wgs = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("FG_BICG3_MIX"); s->bicg3_mix = ev ? atoi(ev) : 3; }   // bit 0: kernel a, bit 1: kernel b as z-march (debugging)
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
     s->cg_return_best = 1;

@@ -673,6 +673,7 @@ struct fg_state {
     int adv_precond; long long line_retries;
     int cg_wgs_per_slot;          // workgroups sharing one CG accumulator slot (256; FG_CG_WGS_PER_SLOT at fg_create: tuning)
     int wall_forcing_axis; fg_real wall_forcing_coef[2]; fg_real* force_uniform;   // fg_set_wall_stress_forcing: [B, dims] uniform body force (device)
+    int reduce_wgs;               // FG_REDUCE_WGS: workgroups per env of the reduction kernels (0 = the rule of fg_reduce_wgs)
     int bicg_sub;                 // FG_BICG_SUB: envs per sub-batch of the 2-D two-kernel BiCGStab (-1 = by the working set, 0 = never)
     int bicg3_force, bicg3_bxl, bicg3_mix;   // FG_BICG3 / FG_BICG3_BXL at fg_create (fg_bicgstab3d.hip)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels

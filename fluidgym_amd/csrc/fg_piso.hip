@@ -801,6 +801,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_balance_fluxes(FgGrid g, FgBounds 
 // (measured: B = 64, 256 x 128: 32 -> 8 per env takes the max-velocity pass 18.5 -> 7.3 us; B = 8, 128 x 64 x 64:
 // 256 -> 32 per env 31 -> 21 us, 8 per env 66 us).
 inline unsigned fg_reduce_wgs(const fg_state* s) {
+    if (s->reduce_wgs > 0) return (unsigned)s->reduce_wgs;      // FG_REDUCE_WGS (tuning runs)
     const unsigned per_env = (512 + s->grid.B - 1) / s->grid.B;
     return per_env < 8 ? 8 : (per_env > 64 ? 64 : per_env);
 }
