@@ -141,6 +141,7 @@ SIGNATURES = {
     "fg_max_velocity": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fg_set_fd_fast_transform": (c_int, [c_void_p, c_int, c_float]),
     "fg_set_return_best": (c_int, [c_void_p, c_int]),
+    "fg_set_cg_reset_steps": (c_int, [c_void_p, c_int]),
     "fg_set_advection_start": (c_int, [c_void_p, c_int]),
     "fg_set_wall_stress_forcing": (c_int, [c_void_p, c_int, c_float, c_float]),
     "fg_boundary_flux_balance": (c_int, [c_void_p, c_void_p, c_void_p]),

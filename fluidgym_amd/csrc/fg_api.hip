@@ -124,7 +124,15 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     { const char* ev = getenv("FG_REDUCE_WGS"); s->reduce_wgs = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("FG_BICG3_MIX"); s->bicg3_mix = ev ? atoi(ev) : 3; }   // bit 0: kernel a, bit 1: kernel b as z-march (debugging)
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
+    { const char* ev = getenv("FG_CG_FUSED"); s->cg_fused = ev ? atoi(ev) : 1; }       // 0: five-kernel preconditioned CG iteration (fg_poisson.hip)
+    { const char* ev = getenv("FG_BICG_PFUSED"); s->bicg_pfused = ev ? atoi(ev) : 1; } // 0: eleven-launch Helmholtz-preconditioned BiCGStab iteration
+    FG_HIP_CHECK(hipMalloc(&s->fcg_alpha, sizeof(double) * 2 * (size_t)g.B));
+    FG_HIP_CHECK(hipMemset(s->fcg_alpha, 0, sizeof(double) * 2 * (size_t)g.B));
+    FG_HIP_CHECK(hipMalloc(&s->fcg_xsum, sizeof(FgDacc) * 2 * (size_t)g.B));
+    FG_HIP_CHECK(hipMemset(s->fcg_xsum, 0, sizeof(FgDacc) * 2 * (size_t)g.B));
+    s->fcg_mean_ready = 0;
     s->cg_return_best = 1;
+    s->cg_reset_steps = 100;
     s->adv_from_result = 1;
     FG_HIP_CHECK(hipMalloc(&s->cg_acc, sizeof(FgDacc) * (size_t)g.B * 8 * 64));
     FG_HIP_CHECK(hipMemset(s->cg_acc, 0, sizeof(FgDacc) * (size_t)g.B * 8 * 64));
@@ -151,7 +159,7 @@ extern "C" int fg_destroy(fg_handle s) {
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
-    (void)hipFree(s->cg_acc);
+    (void)hipFree(s->cg_acc); (void)hipFree(s->fcg_alpha); (void)hipFree(s->fcg_xsum);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
     (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->force_uniform);
     (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp);
@@ -222,6 +230,12 @@ extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const floa
 extern "C" int fg_set_return_best(fg_handle s, int on) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     s->cg_return_best = on ? 1 : 0;
+    return FG_OK;
+}
+
+extern "C" int fg_set_cg_reset_steps(fg_handle s, int steps) {
+    FG_REQUIRE(s && steps >= 0, FG_ERR_INVALID_ARG, "fg_set_cg_reset_steps: null handle or negative step count");
+    s->cg_reset_steps = steps;
     return FG_OK;
 }
 
@@ -376,6 +390,11 @@ extern "C" int fg_setup_advection(fg_handle s, const fg_real* dt_B, int for_scal
         a.nu = s->scalar_viscosity_set ? s->scalar_viscosity[channel] : s->viscosity;
     } else {
         a.source = s->velocity_source;
+        // wall-stress forcing (fg_set_wall_stress_forcing; the env's PRE hook, tcf_env.py / grid.py:147-176): recomputed from u^n for
+        // EVERY velocity assembly -- the fused step and the hook-by-hook path (Simulation._split_step_hooked) alike; u^n does not change
+        // between the PRE hook and this point of the step
+        if (s->wall_forcing_axis >= 0)
+            if (int rc = fg_launch_wall_forcing(s, (hipStream_t)stream)) return rc;
         a.force = s->wall_forcing_axis >= 0 ? s->force_uniform : nullptr;
         a.visc = s->visc_field;
         a.nu = s->viscosity;
@@ -430,7 +449,7 @@ static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real to
         a.rA = s->rA; a.b = s->div; a.x = s->p_result;
         a.r = s->w[0]; a.p = s->w[1]; a.Ap = s->w[2];
         a.dt = dt; a.tol = tol; a.max_iterations = max_iterations; a.use_x0 = use_previous;
-        a.reset_steps = 100;  // residual_reset_step=100 (PISOtorch_simulation.py:1913)
+        a.reset_steps = s->cg_reset_steps;  // residual_reset_step=100 (PISOtorch_simulation.py:1913; fg_set_cg_reset_steps)
         a.precond = (method == FG_SOLVER_FDCG);
         a.check_every = a.precond ? 2 : 16;
         rc = fg_cg_solve(s, a, info_host, st);
@@ -504,8 +523,10 @@ static int advection_solve(fg_state* s, FgBicgArgs a, fg_solve_info* info, hipSt
     // The reference's ladder (_linear_solve_wrapper, PISOtorch_diff.py:410-476), in its order: the plain solve; if it failed (these
     // solves run without returnBestResult: "not converged" fails them) and solver_double_fallback is on, the same system in fp64
     // from a cleared result (fg_rung64.h); if that failed too and BiCG_precondition_fallback is on, the preconditioned solve from zero.
-    int rc = fg_bicgstab_solve(s, a, info, st);
     const int nsys = s->grid.B * a.nc;
+    std::vector<fg_solve_info> info_own;
+    if (!info) { info_own.resize(nsys); info = info_own.data(); }      // (the rungs below read and update the solve infos in place)
+    int rc = fg_bicgstab_solve(s, a, info, st);
     bool failed = (rc == FG_ERR_NOT_CONVERGED || rc == FG_ERR_NOT_FINITE) || (s->ladder_force & 1);
 #if !FG_F64
     if (failed && s->double_fallback && rc != FG_ERR_HIP) {
@@ -542,9 +563,7 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         if (rc == FG_ERR_NOT_CONVERGED) { status = rc; return FG_OK; }
         return rc;
     };
-    // ---- PRE hook fused: wall-stress forcing of the turbulent-channel env (fg_set_wall_stress_forcing; tcf_env.py, grid.py:147-176)
-    if (s->wall_forcing_axis >= 0)
-        if (int rc = fg_launch_wall_forcing(s, st)) return rc;
+    // (PRE hook fused: the wall-stress forcing of the turbulent-channel env is computed by the velocity fg_setup_advection below)
     // ---- passive scalars (:1471-1644)
     if (scalar) {
         for (int ch = 0; ch < s->cfg.n_scalars; ++ch) {
@@ -588,14 +607,21 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         const bool last = (c + 1 == opt->corrector_steps);
         if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
         if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st, !opt->pressure_warm_start)) return rc;
+        // The mean removal + block copy of the last corrector's pressure (setPressureResult, CopyPressureResultToBlocks: :1922-1925, 1953):
+        // when the solver left sum(p) behind (fused CG, fg_fftcg.hip) the corrector does both where it reads p for the gradient --
+        // pressureResult then keeps its constant, which nothing downstream sees (grad p; the next solve starts from zero or from it)
         if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations,
                                          opt->pressure_warm_start ? 1 : 0,
-                                         info.data(), st, last)))
+                                         info.data(), st, false)))
             return rc;
         if (c < 2) { stats[2 + c] = max_iters(info.data(), B); s->ctr.add(2 + c, info.data(), B); }
+        const bool mean_folded = last && s->fcg_mean_ready;
+        if (last && !mean_folded)
+            if (int rc = fg_launch_mean_sub(s, dt_B, s->p_result, s->pressure, st)) return rc;
+        const FgMeanRef mean = {s->fcg_xsum, s->info_dev, s->pressure};
         // the last corrector also writes the block velocity of active envs: CopyVelocityResultToBlocks (:1974)
-        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, last ? s->pressure : s->p_result, s->vel_result, st,
-                                       last ? s->velocity : nullptr))
+        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, (last && !mean_folded) ? s->pressure : s->p_result, s->vel_result, st,
+                                       last ? s->velocity : nullptr, mean_folded ? &mean : nullptr))
             return rc;
     }
     if (opt->corrector_steps <= 0)

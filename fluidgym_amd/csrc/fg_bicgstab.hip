@@ -15,6 +15,7 @@
 #include "fg_internal.h"
 #include "fg_bicg.h"
 #include "fg_rung64.h"
+#include "fg_fftbicg.h"
 
 namespace {
 
@@ -814,7 +815,44 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         }
         }   // sub-batches
         gsub = s->grid;
-    } else {
+    }
+#if !FG_F64
+    else if (a.precond == 2 && fg_fbicg_ok(s)) {
+        // Helmholtz-preconditioned iteration in SIX launches (fg_fftbicg.hip): the vector updates ride in the forward transforms, the
+        // matrix is applied by the inverse transforms, decisions and accumulators are those of the two-kernel form (fg_bicg.h)
+        BicgFused w;
+        w.s = q.r; w.p[0] = q.p; w.p[1] = q.p; w.v[0] = q.v; w.v[1] = q.v;
+        w.fold0 = a.use_x0 ? 0 : 1;
+        float* t1 = s->w[7];
+        if (!w.fold0) FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);      // r = rhs - C x0, rw = p_0 = r, r.r
+        if (int rc = fg_fbicg_forward(s, q, 1, 0, w.fold0, st)) return rc;
+        if (int rc = fg_line_apply(s, s->helm_diag, nullptr, a.nc, t1, t1, st)) return rc;
+        if (int rc = fg_fbicg_inverse(s, q, 1, 0, st)) return rc;
+        for (int it = 0; it < a.max_iterations && !done; ++it) {
+            if (int rc = fg_fbicg_forward(s, q, 0, it, w.fold0, st)) return rc;
+            if (int rc = fg_line_apply(s, s->helm_diag, nullptr, a.nc, t1, t1, st)) return rc;
+            if (int rc = fg_fbicg_inverse(s, q, 0, it, st)) return rc;
+            if (int rc = fg_fbicg_forward(s, q, 1, it + 1, w.fold0, st)) return rc;
+            if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
+                next_poll = it + 1 + 2;
+                const int final_pass = (it + 1 == a.max_iterations);
+                fg_prof_prefetch(s, st);
+                const FgPollOut po = fg_poll_next(&s->poll);
+                hipLaunchKernelGGL(k_bicgf_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass, po, 0);
+                if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
+                info_fresh = true;
+                done = true;
+                for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
+                if (done) break;
+            }
+            if (it + 1 < a.max_iterations) {
+                if (int rc = fg_line_apply(s, s->helm_diag, nullptr, a.nc, t1, t1, st)) return rc;
+                if (int rc = fg_fbicg_inverse(s, q, 1, it + 1, st)) return rc;
+            }
+        }
+    }
+#endif
+    else {
     FG_BICG_LAUNCH_Y(1, -1, k_bicg_init, a.use_x0);
     for (int it = 0; it < a.max_iterations && !done; ++it) {
         // algorithmic bytes per system and cell: Kp r,v,p -> p (16; the first iteration only checks) | Kv p,rw -> v + the

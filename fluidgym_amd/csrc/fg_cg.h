@@ -32,7 +32,8 @@ __device__ __forceinline__ void fg_acc_add(FgDacc* a, int ns, unsigned tile, dou
 // State of the pressure CG that follows a right-hand side, prepared by the kernel that builds it (k_div) -- what a k_cg_begin launch
 // does: the ns accumulator slots in use, the mean accumulator of the p -= mean(p) pass, best-iterate state, flags from the activity
 // mask, info cleared.  acc == nullptr: not folded.  All threads of ONE workgroup per env call fg_cg_begin_env.
-struct FgCgBegin { FgDacc* acc; int32_t* flags; fg_solve_info* info; FgDacc* mean_sums; FgBest best; int track_best, ns; };
+struct FgCgBegin { FgDacc* acc; int32_t* flags; fg_solve_info* info; FgDacc* mean_sums; FgBest best; int track_best, ns;
+                   FgDacc* xsum; };   // xsum (optional): [B][2] sum(x) accumulators of the fused CG (fg_fftcg.hip)
 int fg_cg_slots(const fg_state* s);   // accumulator slots of this grid's CG launches (fg_poisson.hip)
 #ifdef __HIPCC__
 __device__ __forceinline__ void fg_cg_begin_env(const FgCgBegin& q, const fg_real* __restrict__ dt, int b) {
@@ -40,6 +41,7 @@ __device__ __forceinline__ void fg_cg_begin_env(const FgCgBegin& q, const fg_rea
         acc_st(fg_acc_ptr(q.acc, b, k / q.ns) + k % q.ns, 0.0);
     if (threadIdx.x != 0) return;
     acc_st(q.mean_sums + b, 0.0);  // accumulator of the p -= mean(p) pass that follows the solve (fg_launch_mean_sub)
+    if (q.xsum) { acc_st(q.xsum + 2 * b, 0.0); acc_st(q.xsum + 2 * b + 1, 0.0); }
     q.best.best_crit[b] = q.track_best ? INFINITY : 0.f;  // 0: no residual ever beats it, nothing is kept
     q.best.saved_crit[b] = INFINITY;
     q.best.save_at[b] = -1;
@@ -81,5 +83,35 @@ __device__ __forceinline__ bool fg_cg_judge(const FgCgJudge& j, int b, bool lead
         flag_st(j.flags + (b), finite ? 1 : 2);
     }
     return true;
+}
+#endif
+
+// Fused CG (fg_fftcg.hip): the tridiagonal kernel of the preconditioner application that follows iteration `judge.it` is the first
+// kernel to see rr_{it+1} complete.  EVERY workgroup takes the verdict (fg_cg_judge's rule); the env's leader workgroup stores it,
+// or -- for an env that iterates on -- does what the leader of k_cg_ap did: progress words, the best-iterate decision on
+// x_{it+1} (FgBest), and the reset of the r.r ring entry the next update kernel accumulates into.
+struct FgCgLead { FgCgJudge judge; FgBest best; };      // judge.acc == nullptr: none
+#ifdef __HIPCC__
+__device__ __forceinline__ bool fg_cg_lead(const FgCgLead& q, int b, bool lead_block) {   // true: env b needs no further work
+    const FgCgJudge& j = q.judge;
+    const double rr = fg_acc_total(fg_acc_ptr(j.acc, b, (j.it + 1) % 3), j.ns);
+    const fg_real crit = (fg_real)sqrt(rr / (double)j.n);
+    const bool done = !(crit >= j.tol);
+    if (lead_block && threadIdx.x < 64) {
+        if (!done) fg_acc_zero(fg_acc_ptr(j.acc, b, (j.it + 2) % 3), j.ns);
+        if (threadIdx.x == 0) {
+            j.info[b].final_residual = crit;
+            j.info[b].used_iterations = j.it;
+            if (done) {
+                const bool finite = isfinite(crit);
+                j.info[b].converged = finite ? 1 : 0;
+                j.info[b].is_finite = finite ? 1 : 0;
+                flag_st(j.flags + (b), finite ? 1 : 2);
+            } else {
+                fg_best_decide(q.best, b, crit, j.it + 1);
+            }
+        }
+    }
+    return done;
 }
 #endif

@@ -277,10 +277,11 @@ constexpr int TRI_NB = 4;    // chunk buffers: TRI_NB - 1 chunks (48 rows) of lo
 // later chunks in flight with counted s_waitcnt (a branchy form compiled to 36 x vmcnt(0) drains).
 __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const float* __restrict__ inv,
                                                    const float* __restrict__ cp, const float* __restrict__ lower,
-                                                   const int32_t* __restrict__ flags, int nx, int ny, int nz) {
+                                                   const int32_t* __restrict__ flags, int nx, int ny, int nz, FgCgLead lead) {
     extern __shared__ __attribute__((aligned(16))) float ybuf[];  // [ny padded to TRI_CH * TRI_NB][64]
     const int b = blockIdx.y;
     if (flags && flags[b] != 0) return;
+    if (lead.judge.acc && fg_cg_lead(lead, b, blockIdx.x == 0)) return;
     const int lane = threadIdx.x;
     int t = blockIdx.x * 64 + lane;
     const bool live = t < nx * nz;
@@ -368,10 +369,12 @@ __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const f
 template <bool TWO>
 __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, const float* __restrict__ inv,
                                                        const float* __restrict__ cp, const float* __restrict__ lower,
-                                                       const int32_t* __restrict__ flags, int nx, int ny, int nz) {
+                                                       const int32_t* __restrict__ flags, int nx, int ny, int nz, FgCgLead lead) {
     extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]  (TWO: cs shares ms)
     const int b = blockIdx.y;
     if (flags && flags[b] != 0) return;
+    // fused CG (fg_fftcg.hip): the verdict on the residual this application preconditions, and the leader's bookkeeping, ride here
+    if (lead.judge.acc && fg_cg_lead(lead, b, blockIdx.x == 0)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int CH = 16;
     const int nyp = (ny + CH - 1) / CH * CH, last = ny - 1;
@@ -524,6 +527,33 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expe
     return FG_OK;
 }
 
+// per-mode Thomas solve along y of the transformed field `cur` (in place), all envs with flags == 0; lead (optional): the fused CG's
+// verdict / leader bookkeeping taken by this launch (FgCgLead, fg_cg.h)
+int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead) {
+    const FgGrid& G = s->grid;
+    const int nx = G.nx, ny = G.ny, nz = G.nz, B = G.B;
+    const long N = G.n;
+    FgCgLead ld = {};
+    if (lead) ld = *lead;
+    // per env: x read + written, inv + c' read (shared by all envs, so they come from L2 after the first env)
+    dim3 grid((nx * nz + 63) / 64, B);
+    const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
+    const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
+    const size_t lds_two = lds_coop / 3 * 2;      // two arrays: c' staged after the forward sweep (ny up to 320)
+    if ((nx & 3) == 0 && lds_coop <= 160 * 1024 && tridiag_lds_ready(lds_coop)) {
+        FG_LAUNCH_P(s, slot, k_tridiag_y_lds<false>, grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                    s->flags, nx, ny, nz, ld);
+    } else if ((nx & 3) == 0 && lds_two <= 160 * 1024 && tridiag_lds_ready(lds_two)) {
+        FG_LAUNCH_P(s, slot, k_tridiag_y_lds<true>, grid, dim3(256), lds_two, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                    s->flags, nx, ny, nz, ld);
+    } else {
+        FG_LAUNCH_P(s, slot, k_tridiag_y, grid, dim3(64), (size_t)((ny + 63) / 64 * 64) * 64 * sizeof(float), st, cur,
+                    s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz, ld);
+    }
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
 // z = M^-1 r for all envs with flags == 0; optionally rz_acc[b * rz_stride] += r . z
 int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st, const FgCgJudge* judge) {
@@ -559,23 +589,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_st
         if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
         cur = t2;
     }
-    {
-        // per env: x read + written, inv + c' read (shared by all envs, so they come from L2 after the first env)
-        dim3 grid((nx * nz + 63) / 64, B);
-        const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
-        const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
-        const size_t lds_two = lds_coop / 3 * 2;      // two arrays: c' staged after the forward sweep (ny up to 320)
-        if ((nx & 3) == 0 && lds_coop <= 160 * 1024 && tridiag_lds_ready(lds_coop)) {
-            FG_LAUNCH_P(s, slot, k_tridiag_y_lds<false>, grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                        s->flags, nx, ny, nz);
-        } else if ((nx & 3) == 0 && lds_two <= 160 * 1024 && tridiag_lds_ready(lds_two)) {
-            FG_LAUNCH_P(s, slot, k_tridiag_y_lds<true>, grid, dim3(256), lds_two, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                        s->flags, nx, ny, nz);
-        } else {
-            FG_LAUNCH_P(s, slot, k_tridiag_y, grid, dim3(64), (size_t)((ny + 63) / 64 * 64) * 64 * sizeof(float), st, cur,
-                        s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz);
-        }
-    }
+    if (int rc = fg_fd_tridiag(s, cur, st, nullptr)) return rc;
     if (G.dims == 3) {
         // inverse z: t1[k, m] = sum_c Qz[k, c] t2[c, m]
         g.A = s->fd_Qz; g.lda = nz; g.strideA = 0;

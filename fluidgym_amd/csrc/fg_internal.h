@@ -537,7 +537,8 @@ __device__ __forceinline__ void fg_block_sum(fg_real (&v)[NV], fg_real* lds /* >
 // kernel snapshots how many systems were still iterating so the algorithmic bytes count only work done.
 enum FgProfKind {
     FG_PK_CG_AP = 0, FG_PK_CG_UPDATE, FG_PK_BICG_P, FG_PK_BICG_V, FG_PK_BICG_S, FG_PK_BICG_T, FG_PK_BICG_X,
-    FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_DCT, FG_PK_LINE, FG_PK_BICGF_A, FG_PK_BICGF_B, FG_PK_COUNT
+    FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_DCT, FG_PK_LINE, FG_PK_BICGF_A, FG_PK_BICGF_B, FG_PK_FCG_UPD, FG_PK_FCG_INV,
+    FG_PK_FBICG_FWD, FG_PK_FBICG_INV, FG_PK_COUNT
 };
 #define FG_PROF_POOL 256
 struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };
@@ -666,6 +667,7 @@ struct fg_state {
     FgDacc* cg_acc;               // [B][FG_CG_NAMES=8][FG_CG_SLOTS=64] slotted CG accumulators
     FgBest cg_best;               // best-iterate tracking of the CG (returnBestResult, cg_solver_kernel.cu:345-361)
     int cg_return_best;           // 1 (default): track; 0: never keep an iterate (fg_set_return_best)
+    int cg_reset_steps;           // residual restart period of the pressure CG inside the PISO step (100; fg_set_cg_reset_steps)
     int adv_from_result;          // 1 (default): velocity solve starts from velocityResult; 0: from zero (fg_set_advection_start)
     // y-line right preconditioner of the advection BiCGStab (fg_linepre.hip; fg_set_advection_preconditioner): 0 never (the
     // reference's first rung), 1 every solve (its preconditionBiCG), 2 only to repeat a solve that failed (its
@@ -677,6 +679,10 @@ struct fg_state {
     int bicg_sub;                 // FG_BICG_SUB: envs per sub-batch of the 2-D two-kernel BiCGStab (-1 = by the working set, 0 = never)
     int bicg3_force, bicg3_bxl, bicg3_mix;   // FG_BICG3 / FG_BICG3_BXL at fg_create (fg_bicgstab3d.hip)
     int bicg_fused;               // 1 (default): two-kernel BiCGStab iteration (fg_bicgstab.hip); FG_BICG_FUSED=0 at fg_create: five kernels
+    // fused row kernels (fg_fftcg.hip / fg_fftbicg.hip): cg_fused 1 (default) = three-launch preconditioned pressure CG on 2-D grids
+    // with a fast x transform, FG_CG_FUSED=0 at fg_create keeps the five kernels; alpha_k per env and parity; sum(x_k) per env and parity
+    int cg_fused, bicg_pfused; double* fcg_alpha; FgDacc* fcg_xsum;
+    mutable int fcg_mean_ready;   // the last pressure solve left sum(x) of its result in fcg_xsum[b][used_iterations & 1] (consumed by k_correct)
     fg_real* line_inv; fg_real* line_cp;
     fg_real* ilu_d;               // [B,N] modified diagonal of the ILU(0) preconditioner (fg_ilu0.hip), built per solve
     // the reference's retry ladder on this path (fg_set_double_fallback, fg_ladder; fg_rung64.h): double_fallback = repeat a failed
@@ -785,8 +791,12 @@ int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t s
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st);
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, hipStream_t st,
                   bool cg_from_zero = false);   // true: the kernel also starts the pressure CG that follows from zero (FgCgStart, fg_cg.h)
+// mean (optional): the corrector also writes p - mean(p) of active envs to p_copy (the block pressure: setPressureResult +
+// CopyPressureResultToBlocks, PISOtorch_simulation.py:1922-1925, 1953, without the two passes of fg_launch_mean_sub), the sum of
+// env b's pressure being sums[2 b + (info[b].used_iterations & 1)] (0 for a solve that took no iteration: x = 0)
+struct FgMeanRef { const FgDacc* sums; const fg_solve_info* info; fg_real* p_copy; };
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
-                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy = nullptr);
+                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy = nullptr, const FgMeanRef* mean = nullptr);
 // mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be
 // scratch_B + B, whose next row holds the arrival counters)
 // poll (optional): sequence words published per env after the host-pinned result (FgPollOut above)
@@ -875,6 +885,8 @@ int fg_fd_dct_inverse(fg_state* s, const fg_real* u, fg_real* z, const fg_real* 
 // expect_active: the caller's estimate of envs still iterating (<= 0: all) -- only picks the GEMM tile shape
 int fg_fd_apply(fg_state* s, const fg_real* r, fg_real* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st, const FgCgJudge* judge = nullptr);
+struct FgCgLead;    // fg_cg.h
+int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead);   // the per-mode Thomas solve of fg_fd_apply alone (in place)
 // y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
 // with a live system, z = M^-1 r for every live system
 int fg_line_alloc(fg_state* s);

@@ -313,7 +313,7 @@ template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const fg_real* __restrict__ dt,
                                                        const fg_real* __restrict__ rA_, const fg_real* __restrict__ hvec,
                                                        const fg_real* __restrict__ p, fg_real* __restrict__ vel_out,
-                                                       fg_real* __restrict__ vel_copy, int tiles_x, int tiles_y, int tiles) {
+                                                       fg_real* __restrict__ vel_copy, FgMeanRef mean, int tiles_x, int tiles_y, int tiles) {
     // vel_copy (optional): the block velocity of active envs, written alongside the result by the last corrector of a step
     // (CopyVelocityResultToBlocks, PISOtorch_simulation.py:1974, without a pass of its own)
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
@@ -322,6 +322,16 @@ __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const fg_real* _
     const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
     const FgVec<VEC> rA = fg_load<VEC>(rA_ + (size_t)c.b * N + c.idx);
     const FgNbr<DIMS, VEC> P = fg_gather<DIMS, VEC>(p + (size_t)c.b * N, c);
+    if (mean.sums) {
+        // p - mean(p) to the block (PISOtorch_simulation.py:1922-1925, 1953): the solver's update kernels summed the iterate they
+        // left (FgMeanRef, fg_internal.h)
+        const int used = mean.info[c.b].used_iterations;
+        const fg_real mu = used < 0 ? (fg_real)0 : (fg_real)(acc_ld(mean.sums + (2 * c.b + (used & 1))) / (double)g.n);
+        FgVec<VEC> pc;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) pc.v[e] = P.c.v[e] - mu;
+        fg_store<VEC>(mean.p_copy + (size_t)c.b * N + c.idx, pc);
+    }
 #pragma unroll
     for (int q = 0; q < DIMS; ++q) {
         const size_t base = ((size_t)c.b * DIMS + q) * N;
@@ -954,7 +964,7 @@ int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result,
     // the record matches its own arguments)
     FgCgBegin begin;
     begin.acc = s->cg_acc; begin.flags = s->flags; begin.info = s->info_dev; begin.mean_sums = s->acc; begin.best = s->cg_best;
-    begin.track_best = s->cg_return_best; begin.ns = fg_cg_slots(s);
+    begin.track_best = s->cg_return_best; begin.ns = fg_cg_slots(s); begin.xsum = s->fcg_xsum;
     s->cg_ready_ns = begin.ns; s->cg_ready_best = begin.track_best; s->cg_ready_dt = dt; s->bicg_ready_nc = 0; s->cg_start_ready = 0;
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
@@ -986,10 +996,11 @@ int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, con
 }
 
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
-                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy) {
+                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy, const FgMeanRef* mean) {
+    const FgMeanRef mr = mean ? *mean : FgMeanRef{nullptr, nullptr, nullptr};
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out, vel_copy,
+        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out, vel_copy, mr,
                            L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());

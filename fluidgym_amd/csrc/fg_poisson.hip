@@ -16,6 +16,7 @@
 #include "fg_internal.h"
 #include "fg_cg.h"
 #include "fg_rung64.h"
+#include "fg_fftcg.h"
 
 namespace {
 
@@ -406,7 +407,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         if (!ready) {
             FgCgBegin q;
             q.acc = s->cg_acc; q.flags = s->flags; q.info = s->info_dev; q.mean_sums = s->acc; q.best = s->cg_best;
-            q.track_best = s->cg_return_best; q.ns = ns;
+            q.track_best = s->cg_return_best; q.ns = ns; q.xsum = s->fcg_xsum;
             hipLaunchKernelGGL(k_cg_begin, sg, sb, 0, st, a.dt, q, B);
         }
     }
@@ -422,7 +423,13 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     fg_real* zvec = a.precond ? s->w[5] : a.r;
     FgCgJudge judge;
     judge.acc = s->cg_acc; judge.flags = s->flags; judge.info = s->info_dev; judge.tol = a.tol; judge.it = -1; judge.n = n; judge.ns = ns;
-    if (a.precond) {
+    s->fcg_mean_ready = 0;
+#if !FG_F64
+    const bool fused = a.precond && s->fd_Qx && fg_fcg_ok(s);
+#else
+    const bool fused = false;
+#endif
+    if (a.precond && !fused) {
         if (!s->fd_Qx) { fg_set_error("preconditioned CG requested but fg_set_fd_preconditioner was not called"); return FG_ERR_INVALID_ARG; }
         // z0 = M^-1 r0, r0.z0; the residual check of x0 (flags for already-converged envs) is taken by the first kernel of the
         // application (FgCgJudge, fg_cg.h) -- as is the one after every iteration below: no k_cg_check launch outside the polls
@@ -433,6 +440,62 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     int active_est = (B + 3) / 4;  // envs expected to still iterate after the first iteration, refreshed by every poll
     int next_poll = a.precond ? (s->pred_cg + 1 > 1 ? s->pred_cg + 1 : 1) : check_every;
     int it = 0;
+#if !FG_F64
+    if (fused) {
+        // Three launches per iteration (fg_fftcg.hip): F'(it) = vector updates + forward transform, L = verdict + per-mode Thomas solve,
+        // I'(it + 1) = inverse transform + operator + dot products.  Polls sit behind F' exactly where they sat behind k_cg_update.
+        FcgVectors v;
+        v.x = a.x; v.r = a.r; v.t1 = s->w[3]; v.z = zvec; v.w = s->w[4]; v.p = a.p; v.s = a.Ap;
+        FgCgLead lead;
+        lead.best = s->cg_best;
+        judge.it = -1;
+        if (int rc = fg_fd_dct_forward(s, a.r, v.t1, st, 0, &judge)) return rc;      // u = Qx^T r_0 (the verdict on x_0 rides here)
+        lead.judge = judge;
+        if (int rc = fg_fd_tridiag(s, v.t1, st, &lead)) return rc;
+        if (int rc = fg_fcg_inv_apply(s, v, a.rA, 0, ns, st)) return rc;
+        int first = 1;
+        for (; it < a.max_iterations && !done; ++it) {
+            if (int rc = fg_fcg_update_fwd(s, v, it, first, ns, st)) return rc;
+            if (first) {      // p_it = z_it, s_it = w_it: the buffers change roles instead of being copied
+                fg_real* t = v.p; v.p = v.z; v.z = t;
+                t = v.s; v.s = v.w; v.w = t;
+                first = 0;
+            }
+            const bool poll = (it + 1 >= next_poll || it + 1 == a.max_iterations);
+            if (poll) {
+                next_poll = it + 1 + check_every;
+                const int final_pass = (it + 1 == a.max_iterations);
+                fg_prof_prefetch(s, st);
+                const FgPollOut po = fg_poll_next(&s->poll);
+                hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
+                                   n, B, final_pass, ns, po);
+                if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
+                info_fresh = true;
+                done = true;
+                for (int b = 0; b < B; ++b) done = done && (s->info_pinned[b].converged || !s->info_pinned[b].is_finite);
+                if (done) break;
+            }
+            if (it + 1 < a.max_iterations) {
+                judge.it = it;
+                if (a.reset_steps > 0 && (it + 2) % a.reset_steps == 0) {
+                    // residual restart (cg_solver_kernel.cu:281-302): r = b - P x, then the recurrence starts over (beta = 0)
+                    hipLaunchKernelGGL(k_zero_name, sg, sb, 0, st, s->cg_acc, (it + 1) % 3, B);
+                    FG_DISPATCH(s, {
+                        const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
+                        hipLaunchKernelGGL((k_cg_residual<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, a.rA, a.b, a.x,
+                                           a.r, s->cg_acc, s->flags, 1, (it + 1) % 3, ns, L.tiles_x, L.tiles_y, L.tiles);
+                    });
+                    if (int rc = fg_fd_dct_forward(s, a.r, v.t1, st, 0, nullptr)) return rc;
+                    first = 1;
+                }
+                lead.judge = judge;
+                if (int rc = fg_fd_tridiag(s, v.t1, st, &lead)) return rc;
+                if (int rc = fg_fcg_inv_apply(s, v, a.rA, it + 1, ns, st)) return rc;
+            }
+        }
+        s->fcg_mean_ready = a.use_x0 ? 0 : 1;     // (sum(x) of a solve that takes no iteration is only known for x_0 = 0)
+    } else
+#endif
     for (; it < a.max_iterations && !done; ++it) {
         int first = (it == 0);
         if (a.reset_steps > 0 && it > 0 && (it + 1) % a.reset_steps == 0) {
@@ -511,6 +574,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     bool failed = false;
     for (int b = 0; b < B; ++b) failed = failed || !s->info_pinned[b].converged;
     if (failed) {  // rare path: hand back the best iterate instead of the last one (results land in the pinned mirror)
+        s->fcg_mean_ready = 0;     // (x may be replaced: its sum is no longer the one the update kernels left)
         hipLaunchKernelGGL(k_cg_restore_best, dim3(32, B), dim3(FG_BLOCK), 0, st, a.x, s->info_dev, s->info_pinned, s->cg_best, n);
         FG_HIP_CHECK(hipStreamSynchronize(st));
     }

@@ -1,6 +1,7 @@
 // Host polls on pinned sequence words instead of hipStreamSynchronize (FgPoll, fg_internal.h).
 #include <chrono>
 #include <cstdlib>
+#include <sched.h>
 
 #include "fg_internal.h"
 
@@ -32,7 +33,15 @@ int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStrea
     unsigned spins = 0;
     while (i < first + count) {
         if (__atomic_load_n(out.seq + i, __ATOMIC_ACQUIRE) == out.value) { ++i; continue; }
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        sched_yield();
+#endif
+        // the kernels polled here take 5-50 us; past ~100-200 us of spinning (a long queue in front of the polled kernel) the core is
+        // handed back between looks, so that several ranks per host -- one per GPU under ParallelFluidEnv -- or a CPU-limited
+        // container do not starve the threads that launch (FG_POLL_SPIN=0 takes the spin away altogether: hipStreamSynchronize)
+        if (spins > 0x1000) sched_yield();
         if ((++spins & 0xfff) == 0 &&
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 50.0) {
             // a long kernel queue, or a fault: let the runtime wait (and report)

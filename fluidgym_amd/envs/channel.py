@@ -195,15 +195,17 @@ class ChannelJetEnv2D(FluidEnv):
             # instead of six per sim step (same values to rounding; the per-step loop only copies them in)
             decay = (1.0 - self._action_smoothing_alpha) ** torch.arange(1, n + 1, device=target.device, dtype=target.dtype)
             controls = target[None] + (self._current_action - target)[None] * decay.view(n, 1, 1)       # [n, B, 1]
-            jets = self._jet_shape[None] * controls.reshape(n, self._num_envs, 1, 1, 1)                   # [n, B, 2, 1, X]
+            # [n, wall, B, 2, 1, X]: each wall gets its OWN slice (the reference keeps two independent boundary tensors; an in-place
+            # write to one wall -- setVelocity, a loaded state -- must not reach the other)
+            jets = (self._jet_shape[None] * controls.reshape(n, self._num_envs, 1, 1, 1)).unsqueeze(1).repeat(1, 2, 1, 1, 1, 1)
             sol = self._domain.solver
-            self._jets = jets          # (the walls stay bound to its last slice after the step)
+            self._jets = jets          # (the walls stay bound to their last slices after the step)
         for k in range(n):
             if self._enable_actions:
-                # both walls are BOUND to this sim step's slice (the same wall-normal velocity on both: zero net flux) -- a pointer
+                # the walls are BOUND to this sim step's slices (the same wall-normal velocity on both: zero net flux) -- a pointer
                 # update on the host, no copy launch (the library takes boundary pointers as kernel arguments)
-                sol.set_boundary_velocity(2, jets[k])
-                sol.set_boundary_velocity(3, jets[k])
+                sol.set_boundary_velocity(2, jets[k, 0])
+                sol.set_boundary_velocity(3, jets[k, 1])
             if not self._sim.single_step():
                 raise RuntimeError("simulation step failed")
         if self._enable_actions:

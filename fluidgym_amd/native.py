@@ -374,6 +374,10 @@ class NativeSolver:
         """``pressure_return_best_result`` of the reference's Simulation: keep / hand back the best CG iterate."""
         L.check(self.lib.fg_set_return_best(self.handle, int(on)), lib=self.lib)
 
+    def set_cg_reset_steps(self, steps: int = 100):
+        """``residualResetSteps`` of the pressure CG (``cg_solver_kernel.cu:281-302``); 0 = never."""
+        L.check(self.lib.fg_set_cg_reset_steps(self.handle, int(steps)), lib=self.lib)
+
     def set_advection_start(self, from_result: bool = True):
         """Start vector of the velocity solve: ``velocityResult`` (the reference's orthogonal branch) or zero (its non-orthogonal
         branch, first pass) -- ``fg_set_advection_start``."""

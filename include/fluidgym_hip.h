@@ -141,6 +141,10 @@ int fg_set_fd_fast_transform(fg_handle h, int axis, float cell_width);
  * solve that ends unconverged hands back the best iterate it kept (within 2x of the lowest residual reached) instead
  * of the last one; off saves the occasional extra store pass over x. */
 int fg_set_return_best(fg_handle h, int on);
+/* residualResetSteps of the pressure CG (SolveLinear(..., residualResetSteps), cg_solver_kernel.cu:281-302): every `steps`
+ * iterations the residual is recomputed from the iterate, r = b - P x, and the recurrence restarts from it.  Default 100, the value
+ * the reference's non-orthogonal branch passes (PISOtorch_simulation.py:1913); 0 = never. */
+int fg_set_cg_reset_steps(fg_handle h, int steps);
 /* Start vector of the velocity (advection) solve.  The reference's split step has two rules (recorded from its own Python in
  * tests/golden/reference_split_step.json): its orthogonal branch starts from velocityResult (advect_use_prev_result,
  * PISOtorch_simulation.py:1689-1693), its non-orthogonal branch -- which its TCF env also runs on a rectilinear grid

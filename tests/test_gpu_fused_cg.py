@@ -1,0 +1,159 @@
+"""The three-launch preconditioned pressure CG (csrc/fg_fftcg.hip: k_fcg_update_fwd, k_fcg_inv_apply + the verdict inside
+k_tridiag_y_lds) against the oracle's direct solve and against the five-kernel iteration it replaces (FG_CG_FUSED=0), through the
+C ABI.  Replaces cgSolveGPU (cg_solver_kernel.cu:129-471) on the matrix of PISO_build_pressure_matrix
+(PISO_multiblock_cuda_kernel.cu:4812-4978); tolerance / criterion as the reference's (cg_solver_kernel.cu:100-106)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import piso_oracle as O
+from tests.helpers import make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _uniform_x(case):
+    """x widths made uniform (the fast transforms need that); y keeps its stretching."""
+    nx = len(case.widths[0])
+    w = np.full(nx, np.float32(2.0 / nx), np.float32)
+    case.widths[0] = w
+    case.edges[0] = np.concatenate([[0.0], np.cumsum(w.astype(np.float64))])
+    return case
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def _oracle_poisson(case, g, rA):
+    dom = case.oracle_domain(0, g)
+    P, _, _ = O.build_pressure_matrix(dom, 1.0 / rA)
+    return P
+
+
+GRIDS = [((64, 24), (0, 1)), ((128, 40), (0, 1)), ((256, 19), (0, 1)), ((128, 33), (1,)), ((512, 16), (1,)), ((64, 8), (1,))]
+
+
+@pytest.mark.parametrize("n,fixed_axes", GRIDS)
+def test_fused_cg_matches_the_direct_solve_and_the_five_kernels(n, fixed_axes, monkeypatch):
+    """cosine basis (FIXED x) and real Fourier basis (periodic x), row counts that are not multiples of the eight rows a workgroup
+    transforms, three envs with different coefficient fields."""
+    case = _uniform_x(make_case(dims=2, n=n, fixed_axes=fixed_axes, B=3, seed=5, stretch=0.4))
+    g = case.grid()
+    rng = np.random.default_rng(11)
+    rA = (1.0 / (100.0 * rng.uniform(0.8, 1.35, size=(case.B,) + case.shape))).astype(np.float32)
+    b_ = rng.standard_normal((case.B,) + case.shape)
+    b_ -= b_.mean(axis=(1, 2), keepdims=True)
+    b_ = b_.astype(np.float32)
+    tol = 2e-6
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FG_CG_FUSED", mode)
+        ns = case.native()
+        assert ns.has_fd
+        x = torch.zeros((case.B,) + case.shape, device="cuda")
+        info = ns.poisson_fdcg(torch.from_numpy(rA).cuda(), torch.from_numpy(b_).cuda(), x, tol=tol)
+        torch.cuda.synchronize()
+        out[mode] = (_np(x), [(i.used_iterations, i.final_residual, i.converged) for i in info])
+        ns.close()
+    for b in range(case.B):
+        P = _oracle_poisson(case, g, rA[b].astype(np.float64))
+        ref = O.solve_direct(P, b_[b].astype(np.float64).ravel(), singular=True).reshape(case.shape)
+        ref -= ref.mean()
+        true_res = {}
+        for mode in ("1", "0"):
+            got, info = out[mode]
+            it, res, conv = info[b]
+            assert conv and res < tol, (mode, info[b])
+            assert rel_err(got[b] - got[b].mean(), ref) < 1e-4, (mode, b)
+            true_res[mode] = np.sqrt(np.mean((P @ got[b].ravel() - b_[b].astype(np.float64).ravel()) ** 2))
+        # the residual the solver reports is the residual of what it returns: up to the fp32 round-off of the recurrence, which the
+        # five-kernel iteration shows on the same system
+        print(f"{n} env {b}: iterations {out['1'][1][b][0]} / {out['0'][1][b][0]}, true residual fused {true_res['1']:.2e}, five kernels {true_res['0']:.2e}")
+        assert true_res["1"] < max(3 * tol, 2.0 * true_res["0"]), (b, true_res)
+        assert abs(out["1"][1][b][0] - out["0"][1][b][0]) <= 1, (out["1"][1][b], out["0"][1][b])
+        assert rel_err(out["1"][0][b] - out["1"][0][b].mean(), out["0"][0][b] - out["0"][0][b].mean()) < 5e-5
+
+
+def _channel_case(n, B=3, seed=2):
+    return _uniform_x(make_case(dims=2, n=n, fixed_axes=(0, 1), B=B, seed=seed, stretch=0.3, with_source=True, vel_scale=0.3,
+                                through_flow_axis=0))
+
+
+@pytest.mark.parametrize("n", [(64, 24), (128, 36)])
+def test_piso_step_with_the_fused_cg_is_the_step_of_the_five_kernels_and_of_the_oracle(n, monkeypatch):
+    """fg_piso_step end to end: the fused solver, the mean removal folded into the last corrector (the block pressure is mean-free and
+    equals the five-kernel path's), one env masked out (dt = 0) left untouched."""
+    case = _channel_case(n)
+    g = case.grid()
+    dt = [0.02, 0.0, 0.03]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FG_CG_FUSED", mode)
+        ns = case.native()
+        v0 = ns.velocity.clone()
+        ok, stats = ns.piso_step(dt, advection_tol=1e-7, pressure_tol=1e-7)
+        torch.cuda.synchronize()
+        assert ok, stats
+        res[mode] = (_np(ns.velocity), _np(ns.pressure), stats)
+        assert torch.equal(ns.velocity[1], v0[1])     # masked env
+        ns.close()
+    for b in (0, 2):
+        dom = case.oracle_domain(b, g)
+        O.piso_split_step(dom, dt[b])
+        for mode in ("1", "0"):
+            u, p, _ = res[mode]
+            assert rel_err(u[b], dom.velocity) < 3e-5, (mode, b)
+            assert abs(p[b].mean()) < 1e-5 * np.abs(p[b]).max(), (mode, b, p[b].mean())
+            assert rel_err(p[b, 0], dom.pressure) < 2e-4, (mode, b)
+        assert rel_err(res["1"][0][b], res["0"][0][b]) < 1e-5
+        assert rel_err(res["1"][1][b], res["0"][1][b]) < 5e-5
+
+
+def test_residual_restart_inside_the_fused_loop():
+    """reset_steps = 3: the recurrence is restarted from r = b - P x in the middle of a solve (cg_solver_kernel.cu:281-302) and still
+    lands on the oracle's step; repeated steps are bit-identical (order-independent accumulators)."""
+    case = _channel_case((128, 36), B=2, seed=9)
+    g = case.grid()
+    ns = case.native()
+    ns.set_cg_reset_steps(3)
+    state = ns.velocity.clone()
+    ok, stats = ns.piso_step(0.05, advection_tol=1e-7, pressure_tol=2e-8)
+    torch.cuda.synchronize()
+    assert stats[2] >= 3, stats       # (0-based index of the last iteration: at least one restart happened)
+    u1 = ns.velocity.clone()
+    for b in range(case.B):
+        dom = case.oracle_domain(b, g)
+        O.piso_split_step(dom, 0.05)
+        assert rel_err(_np(u1[b]), dom.velocity) < 3e-5
+    ns.velocity.copy_(state)
+    ns.copy_velocity_result_from_blocks()
+    ns.reset_solver_state()
+    ns.piso_step(0.05, advection_tol=1e-7, pressure_tol=2e-8)
+    torch.cuda.synchronize()
+    assert torch.equal(ns.velocity, u1)
+    ns.close()
+
+
+def test_unconverged_fused_solve_hands_back_its_best_iterate():
+    """iteration cap below what the tolerance needs: FG_ERR_NOT_CONVERGED is reported in-band, the result is finite and is a CG
+    iterate of the system (returnBestResult, cg_solver_kernel.cu:345-361: best-iterate bookkeeping as in the five-kernel path)."""
+    case = _uniform_x(make_case(dims=2, n=(128, 40), fixed_axes=(0, 1), B=2, seed=5, stretch=0.4))
+    g = case.grid()
+    rng = np.random.default_rng(1)
+    rA = (1.0 / (100.0 * rng.uniform(0.5, 2.0, size=(case.B,) + case.shape))).astype(np.float32)
+    b_ = rng.standard_normal((case.B,) + case.shape)
+    b_ -= b_.mean(axis=(1, 2), keepdims=True)
+    b_ = b_.astype(np.float32)
+    ns = case.native()
+    x = torch.zeros((case.B,) + case.shape, device="cuda")
+    info = ns.poisson_fdcg(torch.from_numpy(rA).cuda(), torch.from_numpy(b_).cuda(), x, tol=1e-12, max_iterations=3)
+    torch.cuda.synchronize()
+    got = _np(x)
+    assert np.isfinite(got).all()
+    for b in range(case.B):
+        assert not info[b].converged and info[b].is_finite
+        P = _oracle_poisson(case, g, rA[b].astype(np.float64))
+        true_res = np.sqrt(np.mean((P @ got[b].ravel() - b_[b].astype(np.float64).ravel()) ** 2))
+        assert true_res < 0.2 * np.sqrt(np.mean(b_[b].astype(np.float64) ** 2)), (b, true_res)     # (three iterations on coefficients 0.5 .. 2)
+    ns.close()

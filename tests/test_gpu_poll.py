@@ -81,6 +81,36 @@ def test_native_wall_stress_forcing_is_the_python_hook(monkeypatch):
     assert float(tau_p.abs().max()) > 0
 
 
+def test_native_wall_forcing_also_drives_the_hook_by_hook_path():
+    """with a hook that keeps the step out of the fused driver (here a do-nothing POST_PREDICTION hook) the step goes
+    through the stepwise entry points -- fg_setup_advection must then compute the wall-stress body force itself (before round 5
+    it bound force_uniform as the last fused step had left it: zero or stale, silently)."""
+    import fluidgym_amd
+
+    kw = dict(num_envs=2, randomize_initial_state=False, resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False)
+    outs = {}
+    for hooked in (False, True):
+        env = fluidgym_amd.make("TCFSmall3D-both-easy-v0", **kw)
+        env.reset(seed=3)
+        try:
+            assert env._native_forcing is True
+            calls = []
+            if hooked:
+                env._sim.prep_fn = {**env._sim.prep_fn, "POST_PREDICTION": [lambda *a, **k: calls.append(1)]}
+                assert not env._sim._fused_ok()
+            a = torch.zeros_like(env.sample_action())
+            for _ in range(2):
+                _, r, _, _, info = env.step(a)
+            assert bool(calls) == hooked
+            outs[hooked] = (env._block.velocity.clone(), torch.as_tensor(info["wall_stress"]).clone())
+        finally:
+            env.close()
+    (u_f, tau_f), (u_h, tau_h) = outs[False], outs[True]
+    scale = float(u_f.abs().max())
+    assert float((u_h - u_f).abs().max()) < 2e-5 * scale, float((u_h - u_f).abs().max()) / scale
+    assert torch.allclose(tau_h.float(), tau_f.float(), rtol=2e-5, atol=1e-9) and float(tau_f.abs().max()) > 0
+
+
 def test_compacted_krylov_launches_leave_every_bit_where_it_was(monkeypatch):
     """Round 4 (MbSolve::sys_map, mb_bicgstab): while only a few systems of a batch still iterate, the kernels of an iteration are
     launched over those systems only.  The per-system arithmetic does not change, so an airfoil batch whose envs are driven apart
