@@ -493,6 +493,8 @@ def compact_line(out, detail_path=DETAIL_PATH):
                       "capped_solves": cfg.get("capped_solves"),
                       "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step")),
                       "step_GBps": _r(cfg.get("step_GBps")), "advection_solver_form": cfg.get("advection_solver_form")}
+    if cfg.get("per_rank"):
+        line["config"]["per_rank"] = cfg["per_rank"]
     roof = out.get("roofline")
     if roof:
         tr = roof.get("traffic")
@@ -626,16 +628,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    penv.time_shards = world > 1      # per-rank time of the shard's own step (one sync per step, in front of the all_gather that waits anyway)
+    penv.shard_seconds = 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what each rank spent in its OWN shard's steps and how many adaptive sub-steps its envs took: the imbalance SURVEY 8e names
+        # as the scaling risk (a step ends with its slowest shard) is then visible next to the max-over-ranks figure
+        c_r = solver.solver_counters()
+        mine = torch.tensor([penv.shard_seconds, float(c_r["piso_steps"])], dtype=torch.float64, device=device)
+        allr = torch.empty((world, 2), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().tolist()
+        ms = [1e3 * r[0] / args.steps for r in allr]
+        per_rank = {"shard_ms_per_step": [round(v, 3) for v in ms], "min_ms": round(min(ms), 3), "max_ms": round(max(ms), 3),
+                    "imbalance": round(max(ms) / max(min(ms), 1e-9), 3),
+                    "mean_substeps_per_sim_step": [round(r[1] / max(args.steps * env._n_sim_steps, 1), 2) for r in allr]}
     prof = solver.profile_read()
     solver.profile_enable(False)
     its = solver_iterations(solver)
@@ -683,7 +699,8 @@ def main():
                        "iters_are": "iterations per solve (counts; 0 = initial residual met the tolerance)",
                        "launches_per_piso_step": launches_per_piso_step(prof, its) if single_block else None,
                        "step_GBps": step_gbps(prof, elapsed) if single_block else None,
-                       "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2)},
+                       "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2),
+                       "per_rank": per_rank},
             "roofline": roof,
             "legs": {},
         }

@@ -109,7 +109,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(fg_real) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
     if (int rc = fg_poll_create(&s->poll, (int)(nsys > 2 * (size_t)g.B ? nsys : 2 * (size_t)g.B))) return rc;
-    s->pred_bicg = 2; s->pred_cg = 1;
+    for (int k = 0; k < 4; ++k) { s->pred_bicg[k] = 2; s->pred_cg[k] = 1; }
     s->wall_forcing_axis = -1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr; s->ilu_d = nullptr;
     s->double_fallback = 0; s->ladder_force = 0; s->r64_buf = nullptr; s->r64_acc = nullptr;
@@ -124,6 +124,9 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     { const char* ev = getenv("FG_REDUCE_WGS"); s->reduce_wgs = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("FG_BICG3_MIX"); s->bicg3_mix = ev ? atoi(ev) : 3; }   // bit 0: kernel a, bit 1: kernel b as z-march (debugging)
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
+    { const char* ev = getenv("FG_TRIDIAG_CB"); s->tridiag_cb = ev ? atoi(ev) : 64; }      // 32: half-width column blocks in k_tridiag_y_lds (measured: no gain)
+    { const char* ev = getenv("FG_HELM_CB"); s->helm_cb_pref = ev ? atoi(ev) : 32; }
+    { const char* ev = getenv("FG_HELM_ROWFORM"); s->helm_rowform_off = (ev && atoi(ev) == 0) ? 1 : 0; }   // 0: k_helm_coeffs + the array-form line kernels
     { const char* ev = getenv("FG_CG_FUSED"); s->cg_fused = ev ? atoi(ev) : 1; }       // 0: five-kernel preconditioned CG iteration (fg_poisson.hip)
     { const char* ev = getenv("FG_BICG_PFUSED"); s->bicg_pfused = ev ? atoi(ev) : 1; } // 0: eleven-launch Helmholtz-preconditioned BiCGStab iteration
     FG_HIP_CHECK(hipMalloc(&s->fcg_alpha, sizeof(double) * 2 * (size_t)g.B));
@@ -162,7 +165,7 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipFree(s->cg_acc); (void)hipFree(s->fcg_alpha); (void)hipFree(s->fcg_xsum);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
     (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->force_uniform);
-    (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp);
+    (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp); (void)hipFree(s->helm_lower_row);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
     return FG_OK;
@@ -370,7 +373,12 @@ extern "C" int fg_balance_boundary_fluxes(fg_handle s, int free_face_mask, fg_re
     return fg_launch_balance(s, make_bounds(s, 0), free_face_mask, atol, dt_B, (hipStream_t)stream);
 }
 
+static int setup_advection(fg_handle s, const fg_real* dt_B, int for_scalar, int channel, void* stream, int buoy_axis, fg_real buoy_factor);
 extern "C" int fg_setup_advection(fg_handle s, const fg_real* dt_B, int for_scalar, int channel, void* stream) {
+    return setup_advection(s, dt_B, for_scalar, channel, stream, -1, 0);
+}
+// buoy_axis >= 0 (velocity system): the buoyancy hook rides in the assembly (FgAdvArgs::buoy_T)
+static int setup_advection(fg_handle s, const fg_real* dt_B, int for_scalar, int channel, void* stream, int buoy_axis, fg_real buoy_factor) {
     FG_REQUIRE(s && dt_B, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, for_scalar != 0)) return rc;
     FG_REQUIRE(!for_scalar || (channel >= 0 && channel < s->cfg.n_scalars), FG_ERR_INVALID_ARG, "bad scalar channel");
@@ -399,6 +407,10 @@ extern "C" int fg_setup_advection(fg_handle s, const fg_real* dt_B, int for_scal
         a.visc = s->visc_field;
         a.nu = s->viscosity;
         a.rA = s->rA;
+        if (buoy_axis >= 0) {
+            a.buoy_T = s->scalar; a.buoy_stride = (long)s->cfg.n_scalars * s->grid.n; a.buoy_axis = buoy_axis; a.buoy_factor = buoy_factor;
+            a.source_w = s->velocity_source;
+        }
     }
     return fg_launch_adv_build(s, make_bounds(s, channel), a, (hipStream_t)stream);
 }
@@ -412,7 +424,7 @@ extern "C" int fg_solve_advection(fg_handle s, int for_scalar, int channel, fg_r
     a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs;
     a.dt = s->cur_dt;
     a.tol = tol; a.max_iterations = max_iterations;
-    if (for_scalar) { a.x = s->scal_result; a.nc = 1; a.use_x0 = 0; }
+    if (for_scalar) { a.x = s->scal_result; a.nc = 1; a.use_x0 = 0; a.kind = 0; }
     else { a.x = s->vel_result; a.nc = s->grid.dims; a.use_x0 = s->adv_from_result; }
     return advection_solve(s, a, info_host, (hipStream_t)stream, for_scalar, channel);
 }
@@ -442,7 +454,7 @@ extern "C" int fg_setup_pressure_rhs(fg_handle s, const fg_real* dt_B, void* str
 }
 
 static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real tol, int max_iterations, int use_previous,
-                          fg_solve_info* info_host, hipStream_t st, bool finalize = true) {
+                          fg_solve_info* info_host, hipStream_t st, bool finalize = true, int kind = 2) {
     int rc = FG_OK;
     if (method == FG_SOLVER_CG || method == FG_SOLVER_FDCG) {
         FgCgArgs a;
@@ -451,6 +463,7 @@ static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real to
         a.dt = dt; a.tol = tol; a.max_iterations = max_iterations; a.use_x0 = use_previous;
         a.reset_steps = s->cg_reset_steps;  // residual_reset_step=100 (PISOtorch_simulation.py:1913; fg_set_cg_reset_steps)
         a.precond = (method == FG_SOLVER_FDCG);
+        a.kind = kind;
         a.check_every = a.precond ? 2 : 16;
         rc = fg_cg_solve(s, a, info_host, st);
 #if !FG_F64
@@ -570,7 +583,7 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
             if (int rc = fg_setup_advection(s, dt_B, 1, ch, stream)) return rc;
             FgBicgArgs a;
             a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->scal_result; a.nc = 1;
-            a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 0;
+            a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = 0; a.kind = 0;
             if (int rc = soft(advection_solve(s, a, info.data(), st, 1, ch))) return rc;
             const int m = max_iters(info.data(), B);
             stats[0] = m > stats[0] ? m : stats[0];
@@ -587,13 +600,10 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         }
     }
     // ---- PRE_VELOCITY_SETUP hook fused: RBC buoyancy (rbc_env_base.py:285-297)
-    if (opt->buoyancy_axis >= 0) {
-        if (int rc = fg_launch_buoyancy(s, dt_B, s->scalar, (long)s->cfg.n_scalars * s->grid.n, s->velocity_source,
-                                        opt->buoyancy_axis, opt->buoyancy_factor, st))
-            return rc;
-    }
+    //      (folded into the assembly that reads the source: FgAdvArgs::buoy_T -- no k_buoyancy launch, the source field is written, not
+    //      written and read back)
     // ---- velocity predictor (:1646-1762)
-    if (int rc = fg_setup_advection(s, dt_B, 0, 0, stream)) return rc;
+    if (int rc = setup_advection(s, dt_B, 0, 0, stream, opt->buoyancy_axis, opt->buoyancy_factor)) return rc;
     {
         FgBicgArgs a;
         a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->vel_result; a.nc = d;
@@ -606,13 +616,15 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
     for (int c = 0; c < opt->corrector_steps; ++c) {
         const bool last = (c + 1 == opt->corrector_steps);
         if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
-        if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st, !opt->pressure_warm_start)) return rc;
+        if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st, !opt->pressure_warm_start,
+                                   opt->pressure_method == FG_SOLVER_FDCG && s->fd_Qx != nullptr))
+            return rc;
         // The mean removal + block copy of the last corrector's pressure (setPressureResult, CopyPressureResultToBlocks: :1922-1925, 1953):
         // when the solver left sum(p) behind (fused CG, fg_fftcg.hip) the corrector does both where it reads p for the gradient --
         // pressureResult then keeps its constant, which nothing downstream sees (grad p; the next solve starts from zero or from it)
         if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations,
                                          opt->pressure_warm_start ? 1 : 0,
-                                         info.data(), st, false)))
+                                         info.data(), st, false, c == 0 ? 0 : 1)))
             return rc;
         if (c < 2) { stats[2 + c] = max_iters(info.data(), B); s->ctr.add(2 + c, info.data(), B); }
         const bool mean_folded = last && s->fcg_mean_ready;

@@ -722,7 +722,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     bool done = false, info_fresh = false;
     // first convergence poll where the previous solve finished (kernels of converged systems exit at once,
     // so over-launching costs ~2 us per kernel while every poll costs a stream sync), then every 2 iterations
-    int next_poll = s->pred_bicg > 1 ? s->pred_bicg : 1;
+    int next_poll = s->pred_bicg[a.kind & 3] > 1 ? s->pred_bicg[a.kind & 3] : 1;
     const double cells = (double)n, mat = 4.0 * (1 + 2 * s->grid.dims) / a.nc, fl = 2.0 * (1 + 2 * s->grid.dims);
     // (3-D: the neighbour recomputation of four fields across six faces costs more than the two saved passes -- measured on TCF
     //  128 x 64 x 64: 299 us per iteration against 260 us -- so the five kernels stay there)
@@ -826,11 +826,11 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         float* t1 = s->w[7];
         if (!w.fold0) FG_BICG_LAUNCH_Y(1, -1, k_bicgf_init, w, a.use_x0);      // r = rhs - C x0, rw = p_0 = r, r.r
         if (int rc = fg_fbicg_forward(s, q, 1, 0, w.fold0, st)) return rc;
-        if (int rc = fg_line_apply(s, s->helm_diag, nullptr, a.nc, t1, t1, st)) return rc;
+        if (int rc = fg_helm_apply(s, a.nc, t1, t1, st)) return rc;
         if (int rc = fg_fbicg_inverse(s, q, 1, 0, st)) return rc;
         for (int it = 0; it < a.max_iterations && !done; ++it) {
             if (int rc = fg_fbicg_forward(s, q, 0, it, w.fold0, st)) return rc;
-            if (int rc = fg_line_apply(s, s->helm_diag, nullptr, a.nc, t1, t1, st)) return rc;
+            if (int rc = fg_helm_apply(s, a.nc, t1, t1, st)) return rc;
             if (int rc = fg_fbicg_inverse(s, q, 0, it, st)) return rc;
             if (int rc = fg_fbicg_forward(s, q, 1, it + 1, w.fold0, st)) return rc;
             if (it + 1 >= next_poll || it + 1 == a.max_iterations) {
@@ -846,7 +846,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
                 if (done) break;
             }
             if (it + 1 < a.max_iterations) {
-                if (int rc = fg_line_apply(s, s->helm_diag, nullptr, a.nc, t1, t1, st)) return rc;
+                if (int rc = fg_helm_apply(s, a.nc, t1, t1, st)) return rc;
                 if (int rc = fg_fbicg_inverse(s, q, 1, it + 1, st)) return rc;
             }
         }
@@ -892,7 +892,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     int rc = FG_OK;
     int used_max = 0;
     for (int i = 0; i < nsys; ++i) used_max = s->info_pinned[i].used_iterations > used_max ? s->info_pinned[i].used_iterations : used_max;
-    s->pred_bicg = used_max;
+    s->pred_bicg[a.kind & 3] = used_max;
     for (int i = 0; i < nsys; ++i) {
         if (info_host) info_host[i] = s->info_pinned[i];
         if (!s->info_pinned[i].is_finite) rc = FG_ERR_NOT_FINITE;

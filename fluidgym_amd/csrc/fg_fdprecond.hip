@@ -366,11 +366,14 @@ __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const f
 // TWO = true (ny beyond 208: the 512 x 256 grid of `large_env`): only two arrays fit the 160 KB -- c' is staged into the ms region
 // AFTER the forward sweep has used it up (one more load phase and barrier in the middle; the streaming kernel it replaces there took
 // 32 us per application).
-template <bool TWO>
+template <bool TWO, int CB>
 __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, const float* __restrict__ inv,
                                                        const float* __restrict__ cp, const float* __restrict__ lower,
                                                        const int32_t* __restrict__ flags, int nx, int ny, int nz, FgCgLead lead) {
-    extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]  (TWO: cs shares ms)
+    // CB = columns per workgroup: 64 (one float4 row segment per 16 lanes) or 32 (half the LDS: at ny = 128 two to three workgroups per
+    // CU instead of one -- round 5: the whole launch resident at once on the 2-D env grids)
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][CB] | ms[nyp][CB] | cs[nyp][CB]  (TWO: cs shares ms)
+    constexpr int CBL = CB / 4, RPW = 64 / CBL, UQ = 32 / RPW;    // lanes per row | rows per wave access | accesses per wave and round (32 rows)
     const int b = blockIdx.y;
     if (flags && flags[b] != 0) return;
     // fused CG (fg_fftcg.hip): the verdict on the residual this application preconditions, and the leader's bookkeeping, ride here
@@ -379,10 +382,10 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
     constexpr int CH = 16;
     const int nyp = (ny + CH - 1) / CH * CH, last = ny - 1;
     float* bs = tbuf;
-    float* ms = tbuf + (size_t)nyp * 64;
-    float* cs = TWO ? ms : tbuf + (size_t)2 * nyp * 64;
-    const int lc = 4 * (lane & 15), rsub = lane >> 4;
-    int t4 = blockIdx.x * 64 + lc;
+    float* ms = tbuf + (size_t)nyp * CB;
+    float* cs = TWO ? ms : tbuf + (size_t)2 * nyp * CB;
+    const int lc = 4 * (lane % CBL), rsub = lane / CBL;
+    int t4 = blockIdx.x * CB + lc;
     const bool live = t4 < nx * nz;
     if (!live) t4 = nx * nz - 4;
     const int a4 = t4 % nx, c4 = t4 / nx;
@@ -390,24 +393,24 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
     float* __restrict__ xb4 = x + (size_t)b * nx * ny * nz + col4;
     const float* __restrict__ iv4 = inv + col4;
     const float* __restrict__ cp4 = cp + col4;
-    for (int jb = wave * 32; jb < nyp; jb += 128) {  // 32 rows per wave per round = 8 instructions per array
-        float4 vx[8], vi[8], vc[8];
-        float vl[8];
+    for (int jb = wave * 32; jb < nyp; jb += 128) {  // 32 rows per wave per round
+        float4 vx[UQ], vi[UQ], vc[UQ];
+        float vl[UQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = min(jb + 4 * q + rsub, last);
+        for (int q = 0; q < UQ; ++q) {
+            const int j = min(jb + RPW * q + rsub, last);
             vx[q] = *reinterpret_cast<const float4*>(xb4 + (size_t)j * nx);
             vi[q] = *reinterpret_cast<const float4*>(iv4 + (size_t)j * nx);
             if (!TWO) vc[q] = *reinterpret_cast<const float4*>(cp4 + (size_t)j * nx);
             vl[q] = lower[j];
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = jb + 4 * q + rsub;
+        for (int q = 0; q < UQ; ++q) {
+            const int j = jb + RPW * q + rsub;
             if (j < nyp) {
                 const float m = (j > last) ? 0.f : 1.f;
                 const float l = vl[q] * m;
-                const int o = j * 64 + lc;
+                const int o = j * CB + lc;
                 *reinterpret_cast<float4*>(bs + o) =
                     make_float4(vx[q].x * vi[q].x * m, vx[q].y * vi[q].y * m, vx[q].z * vi[q].z * m, vx[q].w * vi[q].w * m);
                 *reinterpret_cast<float4*>(ms + o) = make_float4(l * vi[q].x, l * vi[q].y, l * vi[q].z, l * vi[q].w);
@@ -416,59 +419,59 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
         }
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && lane < CB) {
         float prev = 0.f;
         float* px = bs + lane;
         const float* pm = ms + lane;
-        for (int j0 = 0; j0 < nyp; j0 += CH, px += CH * 64, pm += CH * 64) {
+        for (int j0 = 0; j0 < nyp; j0 += CH, px += CH * CB, pm += CH * CB) {
             float ax[CH], am[CH];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) { ax[q] = px[q * 64]; am[q] = pm[q * 64]; }
+            for (int q = 0; q < CH; ++q) { ax[q] = px[q * CB]; am[q] = pm[q * CB]; }
 #pragma unroll
             for (int q = 0; q < CH; ++q) { prev = fmaf(-am[q], prev, ax[q]); ax[q] = prev; }
 #pragma unroll
-            for (int q = 0; q < CH; ++q) px[q * 64] = ax[q];
+            for (int q = 0; q < CH; ++q) px[q * CB] = ax[q];
         }
     }
     if (TWO) {
         __syncthreads();       // the forward sweep is through with ms: c' takes its place
         for (int jb = wave * 32; jb < nyp; jb += 128) {
-            float4 vc[8];
+            float4 vc[UQ];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) vc[q] = *reinterpret_cast<const float4*>(cp4 + (size_t)min(jb + 4 * q + rsub, last) * nx);
+            for (int q = 0; q < UQ; ++q) vc[q] = *reinterpret_cast<const float4*>(cp4 + (size_t)min(jb + RPW * q + rsub, last) * nx);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = jb + 4 * q + rsub;
+            for (int q = 0; q < UQ; ++q) {
+                const int j = jb + RPW * q + rsub;
                 if (j < nyp) {
                     const float m = (j > last) ? 0.f : 1.f;
-                    *reinterpret_cast<float4*>(cs + j * 64 + lc) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
+                    *reinterpret_cast<float4*>(cs + j * CB + lc) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
                 }
             }
         }
         __syncthreads();
     }
-    if (wave == 0) {
+    if (wave == 0 && lane < CB) {
         float prev = 0.f;
-        float* px = bs + (size_t)(nyp - CH) * 64 + lane;
-        const float* pc = cs + (size_t)(nyp - CH) * 64 + lane;
-        for (int j0 = nyp - CH; j0 >= 0; j0 -= CH, px -= CH * 64, pc -= CH * 64) {
+        float* px = bs + (size_t)(nyp - CH) * CB + lane;
+        const float* pc = cs + (size_t)(nyp - CH) * CB + lane;
+        for (int j0 = nyp - CH; j0 >= 0; j0 -= CH, px -= CH * CB, pc -= CH * CB) {
             float ax[CH], ac[CH];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) { ax[q] = px[q * 64]; ac[q] = pc[q * 64]; }
+            for (int q = 0; q < CH; ++q) { ax[q] = px[q * CB]; ac[q] = pc[q * CB]; }
 #pragma unroll
             for (int q = CH - 1; q >= 0; --q) { prev = fmaf(-ac[q], prev, ax[q]); ax[q] = prev; }
 #pragma unroll
-            for (int q = 0; q < CH; ++q) px[q * 64] = ax[q];
+            for (int q = 0; q < CH; ++q) px[q * CB] = ax[q];
         }
     }
     __syncthreads();
     if (live)
         for (int jb = wave * 32; jb < ny; jb += 128) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = jb + 4 * q + rsub;
+            for (int q = 0; q < UQ; ++q) {
+                const int j = jb + RPW * q + rsub;
                 if (j <= last)
-                    *reinterpret_cast<float4*>(xb4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * 64 + lc);
+                    *reinterpret_cast<float4*>(xb4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * CB + lc);
             }
         }
 }
@@ -481,12 +484,14 @@ static bool tridiag_lds_ready(size_t bytes) {
     static bool failed = false;
     if (bytes <= granted) return true;
     if (failed) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tridiag_y_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_tridiag_y_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        failed = true;
-        return false;
-    }
+    const void* fns[4] = {reinterpret_cast<const void*>(k_tridiag_y_lds<false, 64>), reinterpret_cast<const void*>(k_tridiag_y_lds<true, 64>),
+                          reinterpret_cast<const void*>(k_tridiag_y_lds<false, 32>), reinterpret_cast<const void*>(k_tridiag_y_lds<true, 32>)};
+    for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            failed = true;
+            return false;
+        }
     granted = bytes;
     return true;
 }
@@ -540,12 +545,24 @@ int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead)
     const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
     const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
     const size_t lds_two = lds_coop / 3 * 2;      // two arrays: c' staged after the forward sweep (ny up to 320)
+    // FG_TRIDIAG_CB=32 at fg_create: 32-column workgroups (half the LDS per workgroup, two to three resident per CU).  Measured round 5:
+    // RBC 512 x 128 x 32 8.1 us against 7.0 us with 64 columns, headline unchanged -- the serial sweep of wave 0 is the floor, and
+    // half-width blocks only halve its lanes; 64 stays the default
+    const bool cb32 = s->tridiag_cb == 32 && nz == 1 && (nx & 31) == 0 && (long)((nx + 63) / 64) * B <= 1024;
     if ((nx & 3) == 0 && lds_coop <= 160 * 1024 && tridiag_lds_ready(lds_coop)) {
-        FG_LAUNCH_P(s, slot, k_tridiag_y_lds<false>, grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                    s->flags, nx, ny, nz, ld);
+        if (cb32)
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 32>), dim3(nx / 32, B), dim3(256), lds_coop / 2, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                        s->flags, nx, ny, nz, ld);
+        else
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 64>), grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                        s->flags, nx, ny, nz, ld);
     } else if ((nx & 3) == 0 && lds_two <= 160 * 1024 && tridiag_lds_ready(lds_two)) {
-        FG_LAUNCH_P(s, slot, k_tridiag_y_lds<true>, grid, dim3(256), lds_two, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                    s->flags, nx, ny, nz, ld);
+        if (cb32)
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 32>), dim3(nx / 32, B), dim3(256), lds_two / 2, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                        s->flags, nx, ny, nz, ld);
+        else
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 64>), grid, dim3(256), lds_two, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
+                        s->flags, nx, ny, nz, ld);
     } else {
         FG_LAUNCH_P(s, slot, k_tridiag_y, grid, dim3(64), (size_t)((ny + 63) / 64 * 64) * 64 * sizeof(float), st, cur,
                     s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz, ld);
@@ -660,7 +677,7 @@ int fg_fd_helmholtz_apply(fg_state* s, int nc, const float* r, float* z, hipStre
         if (int rc = launch_gemm(s, g, nsys, nsys, st)) return rc;
         cur = t2;
     }
-    if (int rc = fg_line_apply(s, s->helm_diag, nullptr, nc, cur, cur, st)) return rc;   // per-mode Thomas solve, in place
+    if (int rc = fg_helm_apply(s, nc, cur, cur, st)) return rc;   // per-mode Thomas solve, in place
     if (G.dims == 3) {
         g.A = s->fd_Qz; g.lda = nz; g.strideA = 0;
         g.B = t2; g.ldb = (long)ny * nx; g.strideB = N; g.Bt = nullptr; g.ldbt = 0;

@@ -27,7 +27,16 @@ struct FcgInvArgs {
     const float* hy; const float* rhy; const float* hx; const float* rhx; int fixed_x;
 };
 
+struct FcgDivArgs {
+    const float* h; float* div; float* r; float* x; float* t1;
+    const float* bvel[4];
+    const float2* tw; const float2* rot; float fs0, fs;
+    const float* dt; FgDacc* acc; int ns, rows; long n;
+    const float* hx; const float* hy; int fixed_x;
+};
+
 #if !FG_F64
+int fg_fcg_div_fwd(fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, int ns, hipStream_t st);
 bool fg_fcg_ok(const fg_state* s);     // the grid / preconditioner setup the fused kernels cover (and FG_CG_FUSED != 0)
 int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int ns, hipStream_t st);
 int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it, int ns, hipStream_t st);

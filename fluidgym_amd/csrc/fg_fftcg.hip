@@ -244,6 +244,102 @@ __global__ __launch_bounds__(320) void k_fcg_inv_apply(FcgInvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// D(0): the right-hand side of the pressure system AND the start of its solve in one row kernel -- b = div of the fluxes of h
+// (k_div of fg_piso.hip term by term: k_computePressureRHSdivergenceFromFlux, PISO_multiblock_cuda_kernel.cu:5389-5434; prescribed
+// faces take the boundary-velocity flux, computeFluxesNDLoop :1567-1645), r_0 = b, x_0 = 0, r.r, u = Qx^T r_0.  Replaces k_div +
+// the stand-alone forward transform in front of the first tridiagonal solve.  The divergence only needs h (written by k_h in the
+// launch before): the x neighbours of a row sit in the row, the y neighbours are two more row loads.  grid (ceil(rows / 8), B).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int N, bool PERIODIC>
+__global__ __launch_bounds__(256) void k_fcg_div_fwd(FcgDivArgs a) {
+    constexpr int EPL = N / 64;
+    using M = Map<N>;
+    constexpr int VW = M::VW;
+    __shared__ __attribute__((aligned(16))) float2 buf[2][4][N];
+    __shared__ __attribute__((aligned(16))) float2 twl[N];
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    if (a.dt && !(a.dt[b] > 0.f)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < N; k += 256) twl[k] = a.tw[k];
+    const int row0 = 2 * (blockIdx.x * 4 + wave);
+    const size_t hb0 = ((size_t)b * 2 + 0) * a.n, hb1 = ((size_t)b * 2 + 1) * a.n;
+    // x component of h for the wave's two rows, staged so that the row neighbours are reachable
+    float* sx = reinterpret_cast<float*>(buf[1][wave]);      // [row a | row b], natural order
+    float da[EPL], db[EPL];
+    float part[1] = {0.f};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int j = row0 + half;
+        const bool live = j < a.rows;
+        const int jc = live ? j : 0;
+        float h0[EPL];
+        fgfft::load_row<N>(a.h + hb0 + (size_t)jc * N, lane, h0);
+#pragma unroll
+        for (int q = 0; q < M::NG; ++q) fgfft::stv<VW>(sx + half * N + q * 64 * VW + lane * VW, &h0[q * VW]);
+    }
+    fgfft::wave_sync();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int j = row0 + half;
+        const bool live = j < a.rows;
+        const int jc = live ? j : 0;
+        const float hy = a.hy[jc];
+        const bool at_lo = jc == 0, at_hi = jc == a.rows - 1;      // y faces are FIXED (the tridiagonal axis)
+        const float* sr = sx + half * N;
+        float* out = half ? db : da;
+#pragma unroll
+        for (int q = 0; q < M::NG; ++q) {
+            const int i0 = q * 64 * VW + lane * VW;
+            float hc[VW], v1[VW], vu[VW], vd[VW], hx[VW], bl[VW], bh[VW];
+            fgfft::ldv<VW>(sr + i0, hc);
+            fgfft::ldv<VW>(a.h + hb1 + (size_t)jc * N + i0, v1);
+            fgfft::ldv<VW>(a.h + hb1 + (size_t)(at_lo ? jc : jc - 1) * N + i0, vu);
+            fgfft::ldv<VW>(a.h + hb1 + (size_t)(at_hi ? jc : jc + 1) * N + i0, vd);
+            fgfft::ldv<VW>(a.hx + i0, hx);
+            if (at_lo) fgfft::ldv<VW>(a.bvel[2] + ((size_t)b * 2 + 1) * N + i0, bl);
+            if (at_hi) fgfft::ldv<VW>(a.bvel[3] + ((size_t)b * 2 + 1) * N + i0, bh);
+            const float hl = sr[(i0 == 0) ? N - 1 : i0 - 1], hr = sr[(i0 + VW == N) ? 0 : i0 + VW];
+            const bool xlo = (i0 == 0) && a.fixed_x, xhi = (i0 + VW == N) && a.fixed_x;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const float h_l = (e == 0) ? hl : hc[e > 0 ? e - 1 : 0], h_r = (e == VW - 1) ? hr : hc[e < VW - 1 ? e + 1 : VW - 1];
+                float acc = 0.f;
+                {   // x faces: area = hy (hz = 1)
+                    const float area = hy;
+                    const float F_hi = (e == VW - 1 && xhi) ? a.bvel[1][((size_t)b * 2 + 0) * a.rows + jc] * area : 0.5f * (hc[e] + h_r) * area;
+                    const float F_lo = (e == 0 && xlo) ? a.bvel[0][((size_t)b * 2 + 0) * a.rows + jc] * area : 0.5f * (hc[e] + h_l) * area;
+                    acc += F_hi - F_lo;
+                }
+                {   // y faces: area = hx
+                    const float area = hx[e];
+                    const float F_hi = at_hi ? bh[e] * area : 0.5f * (v1[e] + vd[e]) * area;
+                    const float F_lo = at_lo ? bl[e] * area : 0.5f * (v1[e] + vu[e]) * area;
+                    acc += F_hi - F_lo;
+                }
+                out[q * VW + e] = live ? acc : 0.f;
+            }
+        }
+        if (live) {
+            float z0[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { z0[e] = 0.f; part[0] += out[e] * out[e]; }
+            const size_t o = (size_t)b * a.n + (size_t)j * N;
+            fgfft::store_row<N>(a.div + o, lane, half ? db : da);
+            fgfft::store_row<N>(a.r + o, lane, half ? db : da);
+            fgfft::store_row<N>(a.x + o, lane, z0);
+        }
+    }
+    __syncthreads();      // twiddle table staged (and every lane is through with the staged rows)
+    float oa[EPL], ob[EPL];
+    fgfft::forward_rows<N, PERIODIC>(da, db, oa, ob, buf[0][wave], buf[1][wave], twl, a.rot, fgfft::Scales{a.fs0, a.fs}, lane);
+    if (row0 < a.rows) fgfft::store_row<N>(a.t1 + (size_t)b * a.n + (size_t)row0 * N, lane, oa);
+    if (row0 + 1 < a.rows) fgfft::store_row<N>(a.t1 + (size_t)b * a.n + (size_t)(row0 + 1) * N, lane, ob);
+    fg_block_sum<1>(part, red);
+    if (threadIdx.x == 0) fg_acc_add(fg_acc_ptr(a.acc, b, 0), a.ns, blockIdx.x, (double)part[0]);
+}
+
 template <bool PERIODIC>
 int launch_upd(const fg_state* s, int slot, int n, const FcgUpdArgs& a, dim3 grid, hipStream_t st) {
     switch (n) {
@@ -262,6 +358,18 @@ int launch_inv(const fg_state* s, int slot, int n, const FcgInvArgs& a, dim3 gri
         case 128: FG_LAUNCH_P(s, slot, (k_fcg_inv_apply<128, PERIODIC>), grid, dim3(320), 0, st, a); break;
         case 256: FG_LAUNCH_P(s, slot, (k_fcg_inv_apply<256, PERIODIC>), grid, dim3(320), 0, st, a); break;
         case 512: FG_LAUNCH_P(s, slot, (k_fcg_inv_apply<512, PERIODIC>), grid, dim3(320), 0, st, a); break;
+        default: fg_set_error("fused CG: unsupported row length"); return FG_ERR_UNSUPPORTED;
+    }
+    return FG_OK;
+}
+
+template <bool PERIODIC>
+int launch_div(const fg_state* s, int n, const FcgDivArgs& a, dim3 grid, hipStream_t st) {
+    switch (n) {
+        case 64: hipLaunchKernelGGL((k_fcg_div_fwd<64, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 128: hipLaunchKernelGGL((k_fcg_div_fwd<128, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 256: hipLaunchKernelGGL((k_fcg_div_fwd<256, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 512: hipLaunchKernelGGL((k_fcg_div_fwd<512, PERIODIC>), grid, dim3(256), 0, st, a); break;
         default: fg_set_error("fused CG: unsupported row length"); return FG_ERR_UNSUPPORTED;
     }
     return FG_OK;
@@ -301,6 +409,20 @@ int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it
     // per env: u, rA, r read; z, w written (the halo rows come from L2)
     const int slot = fg_prof_slot(s, FG_PK_FCG_INV, s->flags, G.B, 20.0 * G.n, (14.0 + 5.0 * log2((double)G.nx)) * G.n, st);
     if (int rc = (s->fd_dct_x == 2 ? launch_inv<true>(s, slot, G.nx, a, grid, st) : launch_inv<false>(s, slot, G.nx, a, grid, st))) return rc;
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+// right-hand side + start of the solve + first forward transform (k_fcg_div_fwd): div, r = w[0], x = p_result, u = w[3], r.r in ring entry 0
+int fg_fcg_div_fwd(fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, int ns, hipStream_t st) {
+    const FgGrid& G = s->grid;
+    FcgDivArgs a = {};
+    a.h = hvec; a.div = div; a.r = s->w[0]; a.x = s->p_result; a.t1 = s->w[3];
+    for (int f = 0; f < 4; ++f) a.bvel[f] = bnd.vel[f];
+    a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot; a.fs0 = s->fd_dct_fwd[0]; a.fs = s->fd_dct_fwd[1];
+    a.dt = dt; a.acc = s->cg_acc; a.ns = ns; a.rows = G.ny; a.n = G.n;
+    a.hx = G.h[0]; a.hy = G.h[1]; a.fixed_x = G.fixed[0];
+    const dim3 grid((G.ny + 7) / 8, G.B);
+    if (int rc = (s->fd_dct_x == 2 ? launch_div<true>(s, G.nx, a, grid, st) : launch_div<false>(s, G.nx, a, grid, st))) return rc;
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

@@ -695,13 +695,21 @@ struct fg_state {
     // separable Helmholtz preconditioner of the advection-diffusion solves (fg_set_fd_helmholtz): eigenvalue sums lam [nz][nx] of the
     // transform axes, per-solve coefficient arrays [B][N] and a [B][d][N] temporary of the basis changes
     float* fd_lam; float* helm_diag; float* helm_lower; float* helm_upper; float* helm_tmp;
+    // row form of the 2-D Helmholtz factors (fg_linepre.hip k_helm_factor_y / k_helm_apply_y): lower_j per env and row, 1 / (hx hz),
+    // columns per workgroup the last fg_helm_factor chose (0 = the array form), FG_HELM_ROWFORM=0 at fg_create
+    float* helm_lower_row; float helm_rs; int helm_cb, helm_rowform_off, helm_cb_pref;
+    int tridiag_cb;               // FG_TRIDIAG_CB at fg_create: 64 keeps 64-column workgroups in k_tridiag_y_lds (default: 32 where they divide)
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs
     int fd_dct_x; float2* fd_dct_tw; float2* fd_dct_rot; float fd_dct_fwd[2]; float fd_dct_inv[2];
     fg_real** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
     fg_real* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
     fg_real* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
     fg_real* dt_dev;         // [B]
-    int pred_bicg, pred_cg; // iterations the last solves needed (first convergence poll is scheduled there)
+    // iterations the last solve of each KIND needed (the first convergence poll of the next one is scheduled there): advection kinds
+    // 0 scalar, 1 velocity; pressure kinds 0 first corrector, 1 later correctors, 2 stand-alone calls.  Until round 5 one predictor per
+    // solver served all kinds: the RBC env's second corrector (0-1 iterations) then launched the first corrector's three iterations
+    // before its first poll, and the first corrector polled twice
+    int pred_bicg[4], pred_cg[4];
     FgCounters ctr;         // iterations per solve kind since the last reset (fg_solver_counters)
     const fg_real* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     // solver state already prepared by the kernel launched just before the solve (k_adv_build: FgBicgBegin, k_div: FgCgBegin) --
@@ -783,6 +791,10 @@ struct FgAdvArgs {
     fg_real* A; fg_real* Coff; fg_real* rhs;
     fg_real* rA;             // optional: 1/A written alongside A (velocity system only)
     FgBicgBegin begin;       // optional (begin.acc != nullptr): the leader workgroup of every env prepares the solve that follows
+    // optional (buoy_T != nullptr, velocity system): the RBC envs' PRE_VELOCITY_SETUP hook folded in -- the source is
+    // S[axis] = factor * T, S[other] = 0 (rbc_env_base.py:285-297), used here AND written to `source_w` (the block's velocitySource
+    // keeps the value the hook would have left) instead of being materialised by a k_buoyancy launch and read back
+    const fg_real* buoy_T; long buoy_stride; int buoy_axis; fg_real buoy_factor; fg_real* source_w;
 };
 int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
 int fg_launch_wall_forcing(const fg_state* s, hipStream_t st);   // force_uniform from the wall-adjacent layers of s->velocity
@@ -790,7 +802,8 @@ int fg_launch_sgs(const fg_state* s, const FgBounds& bnd, fg_real coefficient, f
 int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t st);  // rA = 1/A
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st);
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, hipStream_t st,
-                  bool cg_from_zero = false);   // true: the kernel also starts the pressure CG that follows from zero (FgCgStart, fg_cg.h)
+                  bool cg_from_zero = false,    // true: the kernel also starts the pressure CG that follows from zero (FgCgStart, fg_cg.h)
+                  bool fused_fwd = false);      // true (with cg_from_zero): the solve is the FD-preconditioned CG -- where the fused row kernels cover the grid, right-hand side, start and first forward transform are ONE launch (k_fcg_div_fwd)
 // mean (optional): the corrector also writes p - mean(p) of active envs to p_copy (the block pressure: setPressureResult +
 // CopyPressureResultToBlocks, PISOtorch_simulation.py:1922-1925, 1953, without the two passes of fg_launch_mean_sub), the sum of
 // env b's pressure being sums[2 b + (info[b].used_iterations & 1)] (0 for a solve that took no iteration: x = 0)
@@ -826,6 +839,7 @@ struct FgCgArgs {
     fg_real tol; int max_iterations; int use_x0; int reset_steps;
     int check_every;
     int precond;   // 1: fast-diagonalisation preconditioned CG (needs fg_set_fd_preconditioner)
+    int kind = 2;  // which poll predictor the solve reads and updates (fg_state::pred_cg)
 };
 int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st);
 
@@ -840,6 +854,7 @@ struct FgBicgArgs {
                        // 1: right-preconditioned by the y-line solve of fg_linepre.hip (v = C M^-1 p, t = C M^-1 s); 2: by the
                        // separable Helmholtz operator I/dt - nu Laplacian (fast diagonalisation, fg_fd_helmholtz_apply)
     fg_real nu = 0; int wall_lo = 1, wall_hi = 1;   // precond == 2: diffusivity of this solve; the variable is prescribed at the -y / +y wall
+    int kind = 1;      // which poll predictor the solve reads and updates (fg_state::pred_bicg): 0 scalar, 1 velocity
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
 // fp64 repeats of failed solves (fg_rung64.h; fp32 library only): every system of an env that has a failed one (BiCGStab: not
@@ -896,6 +911,7 @@ int fg_ilu_factor(fg_state* s, const fg_real* diag, const fg_real* off, hipStrea
 int fg_ilu_apply(fg_state* s, const fg_real* diag, const fg_real* off, int nc, const fg_real* r, fg_real* z, hipStream_t st);
 int fg_helm_alloc(fg_state* s);
 int fg_helm_factor(fg_state* s, const fg_real* dt, fg_real nu, int wall_lo, int wall_hi, int nc, hipStream_t st);
+int fg_helm_apply(fg_state* s, int nc, const float* r, float* z, hipStream_t st);   // z = M^-1 r with the factors of the last fg_helm_factor (r == z allowed)
 // z = M^-1 r with M the separable Helmholtz operator factorised by fg_helm_factor: basis change along x (and z), tridiagonal solve
 // along y per mode and env, basis change back (fg_fdprecond.hip)
 int fg_fd_helmholtz_apply(fg_state* s, int nc, const fg_real* r, fg_real* z, hipStream_t st);

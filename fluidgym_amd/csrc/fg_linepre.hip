@@ -281,6 +281,154 @@ __global__ __launch_bounds__(256) void k_helm_coeffs(FgGrid g, const float* __re
     upper[o] = j < g.ny - 1 ? -nu * hi * rs : 0.f;
 }
 
+// ---- Helmholtz preconditioner on 2-D grids, row form (round 5).  The tridiagonal systems of the separable operator have the SAME
+// off-diagonals for every mode of an env -- lower_j, upper_j depend on the row only -- and diag_j(a) = base_j + sigma_a, so
+//  * the coefficients need no arrays: k_helm_factor_y synthesises them in the wave that runs the Thomas factorisation (one launch
+//    instead of k_helm_coeffs + k_line_factor_y, no [B][N] coefficient traffic), and
+//  * the application reads r, inv, c' (16 B per cell and system instead of 20) with lower_j as a per-row scalar.
+// CB = columns per workgroup of the application: 64 columns x ny rows x 3 arrays is 96 KB of LDS at ny = 128, i.e. ONE workgroup per
+// CU and two rounds of latency-bound workgroups for RBC 512 x 128 x 32 (11.4 us per application, rocprofv3 round 5); 32 columns is
+// 48 KB, three workgroups per CU, every workgroup of the launch resident at once.
+struct HelmArgs {
+    const float* dt; const float* lam; const float* rhy;     // [B] | [nx] eigenvalues of the periodic x operator | 1 / hy [ny]
+    float nu, rs; int wall_lo, wall_hi;
+    float* inv; float* cp; float* lower_row;                  // [B][N] | [B][N] | [B][ny]
+    int nx, ny, nc;
+    const int32_t* flags;
+};
+__device__ __forceinline__ void helm_row(const HelmArgs& a, int j, float& lo, float& hi) {
+    // face coefficient = mean of the two cells' alpha = J / h^2 (getLaplaceCoefficientOrthogonal, K.cu:1224-1239), over the cell volume;
+    // a wall where the variable is prescribed adds the one-sided coefficient (k_adv_build's matrix, K.cu:3616-3880)
+    const float ry = a.rhy[j];
+    lo = j > 0 ? 0.5f * (ry + a.rhy[j - 1]) * ry : (a.wall_lo ? 2.f * ry * ry : 0.f);
+    hi = j < a.ny - 1 ? 0.5f * (ry + a.rhy[j + 1]) * ry : (a.wall_hi ? 2.f * ry * ry : 0.f);
+}
+// one wave per 64 modes and env: inv_j = 1 / (d_j - l_j c'_{j-1}), c'_j = u_j inv_j with d, l, u of k_helm_coeffs.  The per-row
+// coefficients are formed once, in parallel, and parked in LDS: the serial loop then has no global load in it (a first version read
+// rhy[j-1 .. j+1] inside the loop -- a dependent scalar-load round trip per row, 32 us for 128 rows; IEEE division on top).  The
+// reciprocal is v_rcp_f32 (1 ulp): these are the factors of a PRECONDITIONER.
+constexpr int HELM_MAX_NY = 256;
+__global__ __launch_bounds__(64) void k_helm_factor_y(HelmArgs a) {
+    __shared__ float sl[HELM_MAX_NY], su[HELM_MAX_NY], sb[HELM_MAX_NY];
+    const int b = blockIdx.y;
+    bool any = false;
+    for (int comp = 0; comp < a.nc; ++comp) any = any || (a.flags[b * a.nc + comp] == 0);
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (!any || !(a.dt[b] > 0.f)) return;
+    for (int j = threadIdx.x; j < a.ny; j += 64) {
+        float lo, hi;
+        helm_row(a, j, lo, hi);
+        const float l = j > 0 ? -a.nu * lo * a.rs : 0.f;
+        sl[j] = l;
+        su[j] = j < a.ny - 1 ? -a.nu * hi * a.rs : 0.f;
+        sb[j] = a.nu * (lo + hi);
+        if (blockIdx.x == 0) a.lower_row[b * a.ny + j] = l;
+    }
+    __syncthreads();
+    const bool live = col < a.nx;
+    const float sig = 1.f / a.dt[b] - a.nu * a.lam[live ? col : 0];
+    const size_t N = (size_t)a.nx * a.ny;
+    float* __restrict__ iv = a.inv + (size_t)b * N + (live ? col : 0);
+    float* __restrict__ cp = a.cp + (size_t)b * N + (live ? col : 0);
+    float cprev = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < a.ny; ++j) {
+        const float d = (sig + sb[j]) * a.rs;
+        const float inv = __builtin_amdgcn_rcpf(fmaf(-sl[j], cprev, d));
+        cprev = su[j] * inv;
+        if (live) { iv[(size_t)j * a.nx] = inv; cp[(size_t)j * a.nx] = cprev; }
+    }
+}
+
+// z = M^-1 r for every system with flag 0; grid (nx / CB, nsys); r and z may be the same array
+template <int CB>
+__global__ __launch_bounds__(256) void k_helm_apply_y(HelmArgs a, const float* r, float* z) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];   // bs[nyp][CB] | ms[nyp][CB] | cs[nyp][CB]
+    constexpr int CBL = CB / 4, RPW = 64 / CBL, UQ = 32 / RPW;    // lanes per row | rows per wave access | accesses per wave and round (32 rows)
+    const int sys = blockIdx.y;
+    if (a.flags[sys] != 0) return;
+    const int b = sys / a.nc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nx = a.nx, ny = a.ny, last = ny - 1;
+    const int nyp = (ny + LP_CH - 1) / LP_CH * LP_CH;
+    const size_t N = (size_t)nx * ny;
+    float* bs = tbuf;
+    float* ms = tbuf + (size_t)nyp * CB;
+    float* cs = tbuf + (size_t)2 * nyp * CB;
+    const int lc = 4 * (lane % CBL), rsub = lane / CBL;
+    int t4 = blockIdx.x * CB + lc;
+    const bool live = t4 < nx;
+    if (!live) t4 = nx - 4;
+    const float* r4 = r + (size_t)sys * N + t4;
+    const float* __restrict__ i4 = a.inv + (size_t)b * N + t4;
+    const float* __restrict__ c4 = a.cp + (size_t)b * N + t4;
+    const float* __restrict__ lrow = a.lower_row + (size_t)b * ny;
+    for (int jb = wave * 32; jb < nyp; jb += 128) {
+        float4 vr[UQ], vi[UQ], vc[UQ];
+        float vl[UQ];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int j = min(jb + RPW * q + rsub, last);
+            vr[q] = *reinterpret_cast<const float4*>(r4 + (size_t)j * nx);
+            vi[q] = *reinterpret_cast<const float4*>(i4 + (size_t)j * nx);
+            vc[q] = *reinterpret_cast<const float4*>(c4 + (size_t)j * nx);
+            vl[q] = lrow[j];
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int j = jb + RPW * q + rsub;
+            if (j < nyp) {
+                const float m = (j > last) ? 0.f : 1.f;   // padding rows are neutral
+                const float l = vl[q] * m;
+                const int o = j * CB + lc;
+                *reinterpret_cast<float4*>(bs + o) =
+                    make_float4(vr[q].x * vi[q].x * m, vr[q].y * vi[q].y * m, vr[q].z * vi[q].z * m, vr[q].w * vi[q].w * m);
+                *reinterpret_cast<float4*>(ms + o) = make_float4(l * vi[q].x, l * vi[q].y, l * vi[q].z, l * vi[q].w);
+                *reinterpret_cast<float4*>(cs + o) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < CB) {
+        float prev = 0.f;
+        float* px = bs + lane;
+        const float* pm = ms + lane;
+        for (int j0 = 0; j0 < nyp; j0 += LP_CH, px += LP_CH * CB, pm += LP_CH * CB) {
+            float ax[LP_CH], am[LP_CH];
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { ax[q] = px[q * CB]; am[q] = pm[q * CB]; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { prev = fmaf(-am[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) px[q * CB] = ax[q];
+        }
+        prev = 0.f;
+        px = bs + (size_t)(nyp - LP_CH) * CB + lane;
+        const float* pc = cs + (size_t)(nyp - LP_CH) * CB + lane;
+        for (int j0 = nyp - LP_CH; j0 >= 0; j0 -= LP_CH, px -= LP_CH * CB, pc -= LP_CH * CB) {
+            float ax[LP_CH], ac[LP_CH];
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { ax[q] = px[q * CB]; ac[q] = pc[q * CB]; }
+#pragma unroll
+            for (int q = LP_CH - 1; q >= 0; --q) { prev = fmaf(-ac[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) px[q * CB] = ax[q];
+        }
+    }
+    __syncthreads();
+    if (live) {
+        float* z4 = z + (size_t)sys * N + t4;
+        for (int jb = wave * 32; jb < ny; jb += 128) {
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) {
+                const int j = jb + RPW * q + rsub;
+                if (j <= last)
+                    *reinterpret_cast<float4*>(z4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * CB + lc);
+            }
+        }
+    }
+}
+
 bool line_lds_ready(size_t bytes) {   // dynamic LDS above 64 KB needs an explicit opt-in per kernel
     static size_t granted = 0;
     static bool failed = false;
@@ -336,14 +484,67 @@ int fg_helm_alloc(fg_state* s) {
     FG_HIP_CHECK(hipMalloc(&s->helm_lower, sizeof(float) * count));
     FG_HIP_CHECK(hipMalloc(&s->helm_upper, sizeof(float) * count));
     FG_HIP_CHECK(hipMalloc(&s->helm_tmp, sizeof(float) * count * s->grid.dims));
+    FG_HIP_CHECK(hipMalloc(&s->helm_lower_row, sizeof(float) * (size_t)s->grid.B * s->grid.ny));
+    {   // 1 / (hx hz) of the uniform transform axes (the H-orthonormal eigenvectors carry it: k_helm_coeffs)
+        float rx = 1.f, rz = 1.f;
+        FG_HIP_CHECK(hipMemcpy(&rx, s->d_rh[0], sizeof(float), hipMemcpyDeviceToHost));
+        if (s->grid.dims == 3) FG_HIP_CHECK(hipMemcpy(&rz, s->d_rh[2], sizeof(float), hipMemcpyDeviceToHost));
+        s->helm_rs = rx * rz;
+    }
     return FG_OK;
+}
+
+// row form (k_helm_factor_y / k_helm_apply_y above): 2-D, nx a multiple of 4 and of the column block, the column block in LDS
+static int helm_cb(const fg_state* s) {      // columns per workgroup of the application, 0 = the array form (k_helm_coeffs + line kernels)
+    if (s->grid.dims != 2 || (s->grid.nx & 63) != 0 || s->grid.ny > HELM_MAX_NY || s->helm_rowform_off) return 0;
+    const int nyp = (s->grid.ny + LP_CH - 1) / LP_CH * LP_CH;
+    const int cb = s->helm_cb_pref == 64 ? 64 : 32;
+    const size_t bytes = (size_t)3 * nyp * cb * sizeof(float);
+    if (bytes > 160 * 1024) return 0;
+    static size_t granted = 0;
+    if (bytes > granted) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_helm_apply_y<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_helm_apply_y<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        granted = bytes;
+    }
+    return cb;
 }
 
 // coefficients + Thomas factorisation of the Helmholtz preconditioner for this solve (dt per env, nu of the solve)
 int fg_helm_factor(fg_state* s, const float* dt, float nu, int wall_lo, int wall_hi, int nc, hipStream_t st) {
+    s->helm_cb = helm_cb(s);
+    if (s->helm_cb) {
+        HelmArgs a = {};
+        a.dt = dt; a.lam = s->fd_lam; a.rhy = s->grid.rh[1]; a.nu = nu; a.wall_lo = wall_lo; a.wall_hi = wall_hi;
+        a.rs = s->helm_rs;
+        a.inv = s->line_inv; a.cp = s->line_cp; a.lower_row = s->helm_lower_row; a.nx = s->grid.nx; a.ny = s->grid.ny; a.nc = nc; a.flags = s->flags;
+        hipLaunchKernelGGL(k_helm_factor_y, dim3((s->grid.nx + 63) / 64, s->grid.B), dim3(64), 0, st, a);
+        FG_HIP_CHECK(hipGetLastError());
+        return FG_OK;
+    }
     hipLaunchKernelGGL(k_helm_coeffs, dim3((s->grid.n + 255) / 256, s->grid.B), dim3(256), 0, st, s->grid, dt, (const float*)s->fd_lam, nu,
                        wall_lo, wall_hi, s->helm_diag, s->helm_lower, s->helm_upper);
     return fg_line_factor(s, s->helm_diag, nullptr, nc, st);
+}
+
+// z = M^-1 r (the per-mode Thomas solves of the Helmholtz operator factorised by the last fg_helm_factor), nc systems per env
+int fg_helm_apply(fg_state* s, int nc, const float* r, float* z, hipStream_t st) {
+    if (!s->helm_cb) return fg_line_apply(s, s->helm_diag, nullptr, nc, r, z, st);
+    HelmArgs a = {};
+    a.inv = s->line_inv; a.cp = s->line_cp; a.lower_row = s->helm_lower_row; a.nx = s->grid.nx; a.ny = s->grid.ny; a.nc = nc; a.flags = s->flags;
+    const int nsys = s->grid.B * nc;
+    // per system and cell: r, inv, c' read + z written
+    const int slot = fg_prof_slot(s, FG_PK_LINE, s->flags, nsys, 16.0 * s->grid.n, 5.0 * s->grid.n, st);
+    const int nyp = (s->grid.ny + LP_CH - 1) / LP_CH * LP_CH;
+    if (s->helm_cb == 64)
+        FG_LAUNCH_P(s, slot, k_helm_apply_y<64>, dim3(s->grid.nx / 64, nsys), dim3(256), (size_t)3 * nyp * 64 * sizeof(float), st, a, r, z);
+    else
+        FG_LAUNCH_P(s, slot, k_helm_apply_y<32>, dim3(s->grid.nx / 32, nsys), dim3(256), (size_t)3 * nyp * 32 * sizeof(float), st, a, r, z);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
 }
 
 int fg_line_factor(fg_state* s, const float* diag, const float* off, int nc, hipStream_t st) {

@@ -7,6 +7,7 @@
 // matrix-free from rA = 1/A (fg_poisson.hip).
 #include "fg_internal.h"
 #include "fg_cg.h"
+#include "fg_fftcg.h"
 
 namespace {
 
@@ -180,11 +181,22 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
 #pragma unroll
         for (int q = 0; q < DIMS; ++q) {
             FgVec<VEC> S;
-            if (a.source) S = fg_load<VEC>(a.source + ((size_t)c.b * DIMS + q) * N + c.idx);
+            const bool have_s = a.source != nullptr || a.buoy_T != nullptr;
+            if (a.buoy_T) {      // folded buoyancy hook (FgAdvArgs): S = factor * T along the buoyancy axis, 0 elsewhere
+                if (q == a.buoy_axis) {
+                    S = fg_load<VEC>(a.buoy_T + (size_t)c.b * a.buoy_stride + c.idx);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) S.v[e] = a.buoy_factor * S.v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) S.v[e] = 0.f;
+                }
+                fg_store<VEC>(a.source_w + ((size_t)c.b * DIMS + q) * N + c.idx, S);
+            } else if (a.source) S = fg_load<VEC>(a.source + ((size_t)c.b * DIMS + q) * N + c.idx);
             const fg_real F = a.force ? a.force[c.b * DIMS + q] : 0.f;     // uniform body force of the env (the native wall-stress forcing)
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
-                out.v[e] = (J[e] * u[q].v[e] * rdt + bsum[q][e]) * rJ[e] + ((a.source ? S.v[e] : 0.f) + F);
+                out.v[e] = (J[e] * u[q].v[e] * rdt + bsum[q][e]) * rJ[e] + ((have_s ? S.v[e] : 0.f) + F);
             fg_store<VEC>(a.rhs + ((size_t)c.b * DIMS + q) * N + c.idx, out);
         }
     }
@@ -976,13 +988,21 @@ int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result,
 }
 
 int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div,
-                  hipStream_t st, bool cg_from_zero) {
+                  hipStream_t st, bool cg_from_zero, bool fused_fwd) {
     // cg_from_zero: the pressure CG on this right-hand side starts from the zero vector and its state was prepared by the k_h in
     // front of this launch -- then this kernel also starts it (FgCgStart: r = b into w[0], x = 0 into p_result, r.r) and fg_cg_solve
     // finds the record and skips k_cg_residual
     FgCgStart start = {nullptr, nullptr, nullptr, 1};
     s->cg_start_ready = 0;
     if (cg_from_zero && dt != nullptr && s->cg_ready_ns > 0 && s->cg_ready_dt == dt && div == s->div) {
+#if !FG_F64
+        if (fused_fwd && fg_fcg_ok(s)) {
+            // fused CG on a fast-transform grid: one row kernel writes the right-hand side, starts the solve AND transforms r_0
+            // (k_fcg_div_fwd, fg_fftcg.hip); fg_cg_solve finds the record (2) and goes straight to the tridiagonal solve
+            s->cg_start_ready = 2;
+            return fg_fcg_div_fwd(const_cast<fg_state*>(s), bnd, dt, hvec, div, s->cg_ready_ns, st);
+        }
+#endif
         start.acc = s->cg_acc; start.r = s->w[0]; start.x = s->p_result; start.ns = s->cg_ready_ns;
         s->cg_start_ready = 1;
     }

@@ -400,9 +400,11 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     const int ns = fg_cg_slots(s);
     (void)tiles_per_env;
     bool start_ready = false;      // k_div started this solve (FgCgStart): no k_cg_residual launch
+    bool start_fwd = false;
     {   // state already prepared by the k_div that built this right-hand side (FgCgBegin, fg_cg.h)?
         const bool ready = s->cg_ready_ns == ns && s->cg_ready_best == s->cg_return_best && s->cg_ready_dt == a.dt;
         start_ready = ready && s->cg_start_ready && !a.use_x0 && a.b == s->div && a.r == s->w[0] && a.x == s->p_result;
+        start_fwd = start_ready && s->cg_start_ready == 2;      // ... and w[3] holds Qx^T r_0 (k_fcg_div_fwd)
         s->cg_ready_ns = 0; s->bicg_ready_nc = 0; s->cg_start_ready = 0;
         if (!ready) {
             FgCgBegin q;
@@ -438,7 +440,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     }
     bool done = false, info_fresh = false;
     int active_est = (B + 3) / 4;  // envs expected to still iterate after the first iteration, refreshed by every poll
-    int next_poll = a.precond ? (s->pred_cg + 1 > 1 ? s->pred_cg + 1 : 1) : check_every;
+    int next_poll = a.precond ? (s->pred_cg[a.kind & 3] + 1 > 1 ? s->pred_cg[a.kind & 3] + 1 : 1) : check_every;
     int it = 0;
 #if !FG_F64
     if (fused) {
@@ -449,7 +451,8 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         FgCgLead lead;
         lead.best = s->cg_best;
         judge.it = -1;
-        if (int rc = fg_fd_dct_forward(s, a.r, v.t1, st, 0, &judge)) return rc;      // u = Qx^T r_0 (the verdict on x_0 rides here)
+        if (!(start_ready && start_fwd))      // (k_fcg_div_fwd already transformed r_0: the verdict on x_0 is the tridiagonal kernel's alone)
+            if (int rc = fg_fd_dct_forward(s, a.r, v.t1, st, 0, &judge)) return rc;      // u = Qx^T r_0 (the verdict on x_0 rides here)
         lead.judge = judge;
         if (int rc = fg_fd_tridiag(s, v.t1, st, &lead)) return rc;
         if (int rc = fg_fcg_inv_apply(s, v, a.rA, 0, ns, st)) return rc;
@@ -582,7 +585,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     if (a.precond) {
         int used_max = 0;
         for (int b = 0; b < B; ++b) used_max = s->info_pinned[b].used_iterations > used_max ? s->info_pinned[b].used_iterations : used_max;
-        s->pred_cg = used_max;
+        s->pred_cg[a.kind & 3] = used_max;
     }
     for (int b = 0; b < B; ++b) {
         if (info_host) info_host[b] = s->info_pinned[b];

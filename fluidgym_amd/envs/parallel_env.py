@@ -123,15 +123,21 @@ class ParallelFluidEnv:
             dev_index = cuda_ids[local] if cuda_ids is not None else local
             self._device = torch.device("cuda", int(dev_index))
             torch.cuda.set_device(self._device)
+        elif cuda_ids is not None and torch.cuda.is_available():
+            # gloo with GPU envs (host-staged collectives): the shard steps on its GPU, the command / result blocks cross the
+            # process group through host memory -- several ranks may share one GPU this way (tests/test_gpu_two_ranks.py)
+            self._device = torch.device("cuda", int(cuda_ids[local]))
+            torch.cuda.set_device(self._device)
         else:
             self._device = torch.device("cpu")
+        self._comm_device = self._device if backend == "nccl" else torch.device("cpu")
         n_total = num_envs if num_envs is not None else self.world
         if n_total % self.world:
             raise ValueError(f"num_envs={n_total} must be divisible by the number of GPUs ({self.world})")
         self._n_total = int(n_total)
         self._n_local = self._n_total // self.world
         kw = dict(env_kwargs)
-        if backend == "nccl":
+        if self._device.type == "cuda":
             kw["cuda_device"] = self._device
         self._env = make(env_id, num_envs=self._n_local, **kw)
         self._obs_keys = sorted(self._env.observation_space.keys())
@@ -140,9 +146,11 @@ class ParallelFluidEnv:
         # step costs one broadcast (header + actions) and one all_gather (obs | reward | terminated | truncated | info)
         self._a_shape = (self._n_total,) + tuple(self._env._zero_action.shape[1:])
         self._a_numel = int(np.prod(self._a_shape))
-        self._msg = torch.zeros(self._HDR + self._a_numel, dtype=torch.int32, device=self._device)
+        self._msg = torch.zeros(self._HDR + self._a_numel, dtype=torch.int32, device=self._comm_device)
         self._info_layout: Optional[List] = None
         self._reset_info_layout: Optional[List] = None
+        self.time_shards = False      # accumulate the wall time of this rank's own env.step calls in shard_seconds (a sync per step)
+        self.shard_seconds = 0.0
 
     _HDR = 8   # int32 words: four int64 header fields
 
@@ -207,7 +215,7 @@ class ParallelFluidEnv:
             hdr = torch.tensor([int(cmd), int(a), int(b), int(c)], dtype=torch.int64).view(torch.int32)
             self._msg[: self._HDR].copy_(hdr, non_blocking=True)
             if action is not None:
-                self._msg[self._HDR:].copy_(action.to(self._device, torch.float32).reshape(-1).view(torch.int32))
+                self._msg[self._HDR:].copy_(action.to(self._comm_device, torch.float32).reshape(-1).view(torch.int32))
             if self._collective:
                 dist.broadcast(self._msg, src=0)
             return [int(cmd), int(a), int(b), int(c)]
@@ -217,11 +225,13 @@ class ParallelFluidEnv:
         return [int(v) for v in self._msg[: self._HDR].cpu().view(torch.int64).tolist()]
 
     def _actions_from_msg(self) -> torch.Tensor:
-        return self._msg[self._HDR:].view(torch.float32).reshape(self._a_shape)
+        return self._msg[self._HDR:].view(torch.float32).reshape(self._a_shape).to(self._device)
 
     def _all_gather(self, local: torch.Tensor) -> torch.Tensor:
         if not self._collective:
             return local
+        back = local.device
+        local = local.to(self._comm_device)      # (host-staged when the group is gloo and the envs live on a GPU)
         out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         try:
             dist.all_gather_into_tensor(out, local.contiguous())
@@ -229,7 +239,7 @@ class ParallelFluidEnv:
             parts = [torch.empty_like(local) for _ in range(self.world)]
             dist.all_gather(parts, local.contiguous())
             out = torch.stack(parts)
-        return out.reshape((-1,) + tuple(local.shape[1:]))
+        return out.reshape((-1,) + tuple(local.shape[1:])).to(back)
 
     def _per_env(self, v) -> torch.Tensor:
         """A per-shard scalar / bool or a per-env tensor as one float row per local env."""
@@ -251,8 +261,9 @@ class ParallelFluidEnv:
             parts.append(reward.reshape(self._n_local, -1).float())
             parts.append(self._per_env(term))
             parts.append(self._per_env(trunc))
-            if self._info_layout is None:   # same keys / shapes on every rank (same env class and config)
-                self._info_layout = self._layout_of(info)
+            # taken from THIS step's dict, like the reset layout (a cached layout mis-slices the gathered block once a
+            # step reports another key set -- a mode switch, a failure flag); same env class and call on every rank, so the ranks agree
+            self._info_layout = self._layout_of(info)
             parts += [self._per_env(info[k]) for k, _, _ in self._info_layout]
         return torch.cat(parts, dim=1)
 
@@ -334,12 +345,26 @@ class ParallelFluidEnv:
         self._send(Command.STEP, action=action, read_header=False)
         return self._do_step()
 
-    def _do_step(self):
+    def _do_step(self, lists: bool = True):
+        """``lists=False`` (workers inside ``serve()``): nobody reads this rank's return value, so the device -> host read of the
+        flags and the per-env dicts are skipped -- only the driver needs the Python lists of the reference's return type."""
         full = self._actions_from_msg()
         mine = full[self.rank * self._n_local: (self.rank + 1) * self._n_local]
+        if self.time_shards:       # (bench.py --gpus N: this rank's own step time, so that load imbalance between shards is visible)
+            import time
+
+            if self._device.type == "cuda":
+                torch.cuda.synchronize(self._device)
+            t0 = time.perf_counter()
         obs, reward, term, trunc, info = self._env.step(mine)
+        if self.time_shards:
+            if self._device.type == "cuda":
+                torch.cuda.synchronize(self._device)
+            self.shard_seconds += time.perf_counter() - t0
         flat = self._all_gather(self._pack(obs, reward, term, trunc, info))  # everything a step returns: one collective
         obs_all, reward_all, term_all, trunc_all, info_all = self._unpack(flat, obs, with_reward=True)
+        if not lists:
+            return None
         obs_all = self._agents_to_rows(obs_all)
         flags = torch.stack([term_all, trunc_all]).cpu().tolist()
         infos = [{k: v[i] for k, v in info_all.items()} for i in range(self._n_total)]
@@ -401,7 +426,7 @@ class ParallelFluidEnv:
         while True:
             cmd, a, b, _ = self._send()
             if cmd == Command.STEP:
-                self._do_step()
+                self._do_step(lists=False)
             elif cmd == Command.RESET:
                 self._do_reset(None if a < 0 else a, None if b < 0 else bool(b))
             elif cmd == Command.SEED:

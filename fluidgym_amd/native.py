@@ -61,6 +61,8 @@ class NativeSolver:
         self.n = self.nx * self.ny * self.nz
         self.B = int(batch)
         self.n_scalars = int(n_scalars)
+        self.scalar_bc = {int(f): [int(t) for t in v] for f, v in (scalar_bc or {}).items()}
+        self.scalar_viscosities: Dict[int, float] = {}
         self.fixed = [f in fixed_faces for f in range(6)]
         cfg = L.FgConfig()
         cfg.dims, cfg.nx, cfg.ny, cfg.nz = self.dims, self.nx, self.ny, self.nz
@@ -190,6 +192,7 @@ class NativeSolver:
         L.check(self.lib.fg_set_viscosity(self.handle, float(nu)), lib=self.lib)
 
     def set_scalar_viscosity(self, ch: int, k: float):
+        self.scalar_viscosities[int(ch)] = float(k)
         L.check(self.lib.fg_set_scalar_viscosity(self.handle, ch, float(k)), lib=self.lib)
 
     # ------------------------------------------------------------------ helpers

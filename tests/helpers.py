@@ -135,3 +135,37 @@ def rel_err(a: np.ndarray, b: np.ndarray) -> float:
     """max |a-b| / max |b|  (the gate of SURVEY.md section 8d)."""
     scale = max(float(np.abs(b).max()), 1e-30)
     return float(np.abs(a - b).max()) / scale
+
+
+def f64_twin(ns, envs, velocity, scalar=None, with_source=False):
+    """The fp64 build of the library (``libfluidgym_hip_f64.so``) set up as the twin of the fp32 ``NativeSolver`` ``ns`` for its envs
+    ``envs``: the same grid (the fp32 widths promoted, which is what the oracle sees), boundary data, viscosities, and the given
+    start state ``velocity [B, d, ...]`` / ``scalar [B, C, ...]`` (CPU or GPU tensors of the WHOLE batch).  Used by the full-size
+    tests to show that a loose fp32 bound is fp32 round-off and solver tolerance, not an error of the kernels: the same state through
+    the same kernels in double lands on the fp64 oracle to ~1e-9."""
+    import torch
+
+    from fluidgym_amd.native import NativeSolver
+
+    idx = list(envs)
+    fixed = [f for f in range(2 * ns.dims) if ns.fixed[f]]
+    t = NativeSolver([np.asarray(w, np.float64) for w in ns.widths], len(idx), fixed_faces=fixed, n_scalars=ns.n_scalars,
+                     scalar_bc=ns.scalar_bc or None, device=ns.device, dtype=torch.float64)
+    t.set_viscosity(ns.viscosity)
+    for ch, k in ns.scalar_viscosities.items():
+        t.set_scalar_viscosity(ch, k)
+    dev = t.device
+    pick = lambda a: torch.as_tensor(a)[idx].to(dev).double().contiguous()
+    t.velocity.copy_(pick(velocity))
+    if scalar is not None:
+        t.scalar.copy_(pick(scalar))
+    for f in fixed:
+        bv = ns.bvel[f]
+        t.bvel[f].copy_(bv[idx].double() if bv.shape[0] == ns.B else bv.double().expand_as(t.bvel[f]))
+        if ns.n_scalars:
+            bs = ns.bscal[f]
+            t.bscal[f].copy_(bs[idx].double() if bs.shape[0] == ns.B else bs.double().expand_as(t.bscal[f]))
+    if with_source:
+        t.set_velocity_source(torch.zeros_like(t.velocity))
+    t.copy_velocity_result_from_blocks()
+    return t

@@ -9,7 +9,7 @@ import torch
 
 import fluidgym_amd
 from oracle import piso_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import f64_twin, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,13 @@ def test_rbc_full_batch_step_matches_oracle_and_env_steps():
             s[1] = float(env._buoyancy_factor) * d.scalar[0]
             d.velocity_source = s
 
-        for b in (0, B - 1):
+        # the same two states through the fp64 build of the same kernels (plain recurrences there), solved far below the fp32 tolerances
+        twin = f64_twin(ns, (0, B - 1), u0, T0, with_source=True)
+        ok64, stats64 = twin.piso_step(dt, advection_tol=1e-13, pressure_tol=1e-13, max_iterations=50000, buoyancy_axis=1,
+                                       buoyancy_factor=float(env._buoyancy_factor))
+        vel64, T64 = twin.velocity.cpu().numpy(), twin.scalar.cpu().numpy()
+        twin.close()
+        for k, b in enumerate((0, B - 1)):
             bc = {f: O.FixedBC(velocity=np.zeros(2), scalar=bscal[f][b], scalar_types=[O.DIRICHLET]) for f in (2, 3)}
             ref = O.Domain(grid, float(env._nu), u0[b].numpy().astype(np.float64), np.zeros(grid.shape), bc,
                            scalar=T0[b].numpy().astype(np.float64), scalar_viscosity=[float(env._kappa)])
@@ -52,8 +58,12 @@ def test_rbc_full_batch_step_matches_oracle_and_env_steps():
             scale = max(float(np.abs(ref.velocity).max()), dt * float(env._buoyancy_factor) * float(np.abs(T0[b].numpy()).max()))
             es, ev = rel_err(T[b], ref.scalar), float(np.abs(vel[b] - ref.velocity).max()) / scale
             print(f"RBC_B32_ERR env {b}: scalar {es:.2e} velocity {ev:.2e} (max|u| {np.abs(ref.velocity).max():.2e}, forcing scale {scale:.2e})")
-            # (velocity behind two pressure solves at an ABSOLUTE residual of 1e-7 on a 40:1 wall-refined grid: measured 5e-4)
-            assert es < 3e-5 and ev < 2e-3, (b, es, ev)
+            es64, ev64 = rel_err(T64[k], ref.scalar), float(np.abs(vel64[k] - ref.velocity).max()) / scale
+            print(f"RBC_B32_F64 env {b}: scalar {es64:.2e} velocity {ev64:.2e} (fp64 build, iterations {stats64})")
+            # the fp64 build of the same assembly / operator / corrector kernels lands on the oracle: what is left in fp32 is the
+            # ABSOLUTE residual tolerance of 1e-7 of two pressure solves on a 40:1 wall-refined grid (measured 5-7e-4; bound = 2x)
+            assert es64 < 1e-9 and ev64 < 1e-9, (b, es64, ev64)
+            assert es < 3e-5 and ev < 1.5e-3, (b, es, ev)
         ns.solver_counters(reset=True)
         obs, reward, term, trunc, info = env.step(env.sample_action())
         c = ns.solver_counters()

@@ -13,7 +13,7 @@ import torch
 import fluidgym_amd
 from fluidgym_amd.simulation import Simulation
 from oracle import piso_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import f64_twin, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,13 @@ def test_large_channel_batch_step_matches_oracle_and_env_steps(env_id, grid):
         outflow0 = out.velocity.cpu().numpy().astype(np.float64)
         lo = blk.getBoundary("-y").velocity.cpu().numpy().astype(np.float64)          # [B, 2, 1, nx]
         hi = blk.getBoundary("+y").velocity.cpu().numpy().astype(np.float64)
+        # the twin in the fp64 build BEFORE the fp32 step moves the boundary data: same grid, state and boundary values for envs 0 / 63
+        twin = f64_twin(dom.solver, (0, B - 1), u0)
         assert sim.single_step()
+        ok64, stats64, sub64 = twin.single_step(dt, 0.8, adaptive=True, outflow_faces=(1,), outflow_velm=[float(v) for v in velm], outflow_tol=1e-5,
+                                                advection_tol=1e-13, pressure_tol=1e-13, max_iterations=50000)
+        vel64, prs64 = twin.velocity.cpu().numpy(), twin.pressure.cpu().numpy()
+        twin.close()
         vel = dom.solver.velocity.cpu().numpy().astype(np.float64)
         prs = dom.solver.pressure.cpu().numpy().astype(np.float64)
         assert np.isfinite(vel).all() and np.isfinite(prs).all()
@@ -60,8 +66,13 @@ def test_large_channel_batch_step_matches_oracle_and_env_steps(env_id, grid):
                   2: O.FixedBC(lo[b].copy()), 3: O.FixedBC(hi[b].copy())}
             ref = O.Domain(grid, env._nu, u0[b].numpy().astype(np.float64), np.zeros((ny, nx)), bc)
             O.piso_adaptive_step(ref, dt, 0.8, prep_fn=hooks)
-            assert rel_err(vel[b], ref.velocity) < 1e-4, b
-            assert rel_err(prs[b, 0], ref.pressure) < 5e-3, b
+            k = 0 if b == 0 else 1
+            e32 = (rel_err(vel[b], ref.velocity), rel_err(prs[b, 0], ref.pressure))
+            e64 = (rel_err(vel64[k], ref.velocity), rel_err(prs64[k, 0] - prs64[k, 0].mean(), ref.pressure - ref.pressure.mean()))
+            print(f"CHANNEL_{nx}x{ny}_ERR env {b}: fp32 velocity {e32[0]:.2e} pressure {e32[1]:.2e} | fp64 build velocity {e64[0]:.2e} pressure {e64[1]:.2e} (iterations {stats64}, substeps {sub64})")
+            # the fp64 build of the same kernels lands on the oracle; the fp32 figures are solver tolerance (1e-7 absolute) x conditioning
+            assert e64[0] < 1e-9 and e64[1] < 1e-8, (b, e64)
+            assert e32[0] < 1e-4 and e32[1] < 5e-3, (b, e32)
         # the env's own step (25 PISO steps, its tolerances) on the batch
         solver = dom.solver
         solver.solver_counters(reset=True)
