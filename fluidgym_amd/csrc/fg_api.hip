@@ -165,7 +165,7 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipFree(s->cg_acc); (void)hipFree(s->fcg_alpha); (void)hipFree(s->fcg_xsum);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
     (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->force_uniform);
-    (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp); (void)hipFree(s->helm_lower_row);
+    (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp); (void)hipFree(s->helm_lower_row); (void)hipFree(s->helm_lower_row2); (void)hipFree(s->line_inv2); (void)hipFree(s->line_cp2);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
     return FG_OK;
@@ -577,6 +577,15 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         return rc;
     };
     // (PRE hook fused: the wall-stress forcing of the turbulent-channel env is computed by the velocity fg_setup_advection below)
+#if !FG_F64
+    // Helmholtz-preconditioned solves (RBC): the factors of the scalar AND the velocity system depend on dt, the diffusivities and
+    // the wall conditions only -- one launch for both, ahead of the assemblies (fg_helm_factor_pair; the solves find the record)
+    if (scalar && s->cfg.n_scalars == 1 && s->adv_precond == 3 && s->fd_lam && !s->visc_field) {
+        const float nu2[2] = {s->scalar_viscosity_set ? s->scalar_viscosity[0] : s->viscosity, s->viscosity};
+        const int wlo[2] = {s->cfg.scalar_bc[2][0] == FG_DIRICHLET, 1}, whi[2] = {s->cfg.scalar_bc[3][0] == FG_DIRICHLET, 1};
+        if (int rc = fg_helm_factor_pair(s, dt_B, nu2, wlo, whi, st)) return rc;
+    }
+#endif
     // ---- passive scalars (:1471-1644)
     if (scalar) {
         for (int ch = 0; ch < s->cfg.n_scalars; ++ch) {

@@ -685,7 +685,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     }
     if (a.precond == 2) {
         FG_REQUIRE(s->fd_lam != nullptr, FG_ERR_INVALID_ARG, "Helmholtz preconditioner requested but fg_set_fd_helmholtz was not called");
-        if (int rc = fg_helm_factor(s, a.dt, a.nu, a.wall_lo, a.wall_hi, a.nc, st)) return rc;
+        if (int rc = fg_helm_factor(s, a.dt, a.nu, a.wall_lo, a.wall_hi, a.nc, st, a.kind)) return rc;
     } else if (a.precond == 3) {
         if (int rc = fg_ilu_factor(s, a.diag, a.off, st)) return rc;
     } else if (a.precond) {

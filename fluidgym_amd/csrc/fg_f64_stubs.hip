@@ -28,7 +28,7 @@ int fg_helm_alloc(fg_state*) { return FG_ERR_UNSUPPORTED; }
 int fg_ilu_alloc(fg_state*) { fg_set_error("the ILU(0) preconditioner is not part of the fp64 build"); return FG_ERR_UNSUPPORTED; }
 int fg_ilu_factor(fg_state*, const fg_real*, const fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }
 int fg_ilu_apply(fg_state*, const fg_real*, const fg_real*, int, const fg_real*, fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }
-int fg_helm_factor(fg_state*, const fg_real*, fg_real, int, int, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
+int fg_helm_factor(fg_state*, const fg_real*, fg_real, int, int, int, hipStream_t, int) { return FG_ERR_UNSUPPORTED; }
 int fg_fd_helmholtz_apply(fg_state*, int, const fg_real*, fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }
 int fg_line_factor(fg_state*, const fg_real*, const fg_real*, int, hipStream_t) { return FG_ERR_UNSUPPORTED; }
 int fg_line_apply(fg_state*, const fg_real*, const fg_real*, int, const fg_real*, fg_real*, hipStream_t) { return FG_ERR_UNSUPPORTED; }

@@ -698,6 +698,9 @@ struct fg_state {
     // row form of the 2-D Helmholtz factors (fg_linepre.hip k_helm_factor_y / k_helm_apply_y): lower_j per env and row, 1 / (hx hz),
     // columns per workgroup the last fg_helm_factor chose (0 = the array form), FG_HELM_ROWFORM=0 at fg_create
     float* helm_lower_row; float helm_rs; int helm_cb, helm_rowform_off, helm_cb_pref;
+    // second factor set + the record of a factorisation made ahead of the solves (fg_helm_factor_pair): which sets are valid, for which
+    // dt array / diffusivity / wall conditions; helm_set = the set the last fg_helm_factor selected for fg_helm_apply
+    float* line_inv2; float* line_cp2; float* helm_lower_row2; int helm_pre_mask; const fg_real* helm_pre_dt; float helm_pre_nu[2]; int helm_pre_walls[2][2]; int helm_set;
     int tridiag_cb;               // FG_TRIDIAG_CB at fg_create: 64 keeps 64-column workgroups in k_tridiag_y_lds (default: 32 where they divide)
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs
     int fd_dct_x; float2* fd_dct_tw; float2* fd_dct_rot; float fd_dct_fwd[2]; float fd_dct_inv[2];
@@ -910,7 +913,8 @@ int fg_ilu_alloc(fg_state* s);
 int fg_ilu_factor(fg_state* s, const fg_real* diag, const fg_real* off, hipStream_t st);
 int fg_ilu_apply(fg_state* s, const fg_real* diag, const fg_real* off, int nc, const fg_real* r, fg_real* z, hipStream_t st);
 int fg_helm_alloc(fg_state* s);
-int fg_helm_factor(fg_state* s, const fg_real* dt, fg_real nu, int wall_lo, int wall_hi, int nc, hipStream_t st);
+int fg_helm_factor(fg_state* s, const fg_real* dt, fg_real nu, int wall_lo, int wall_hi, int nc, hipStream_t st, int kind = -1);
+int fg_helm_factor_pair(fg_state* s, const float* dt, const float nu[2], const int wall_lo[2], const int wall_hi[2], hipStream_t st);
 int fg_helm_apply(fg_state* s, int nc, const float* r, float* z, hipStream_t st);   // z = M^-1 r with the factors of the last fg_helm_factor (r == z allowed)
 // z = M^-1 r with M the separable Helmholtz operator factorised by fg_helm_factor: basis change along x (and z), tridiagonal solve
 // along y per mode and env, basis change back (fg_fdprecond.hip)

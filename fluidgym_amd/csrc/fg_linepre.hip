@@ -294,7 +294,10 @@ struct HelmArgs {
     float nu, rs; int wall_lo, wall_hi;
     float* inv; float* cp; float* lower_row;                  // [B][N] | [B][N] | [B][ny]
     int nx, ny, nc;
-    const int32_t* flags;
+    const int32_t* flags;                                     // nullptr (factorisation ahead of the solves): every env with dt > 0
+    // second parameter set (blockIdx.z == 1 of the factorisation): the scalar and the velocity system of a PISO step differ in their
+    // diffusivity and wall condition only, so both factorisations are ONE launch at the start of the step (fg_helm_factor_pair)
+    float nu2; int wall_lo2, wall_hi2; float* inv2; float* cp2; float* lower_row2;
 };
 __device__ __forceinline__ void helm_row(const HelmArgs& a, int j, float& lo, float& hi) {
     // face coefficient = mean of the two cells' alpha = J / h^2 (getLaplaceCoefficientOrthogonal, K.cu:1224-1239), over the cell volume;
@@ -311,8 +314,9 @@ constexpr int HELM_MAX_NY = 256;
 __global__ __launch_bounds__(64) void k_helm_factor_y(HelmArgs a) {
     __shared__ float sl[HELM_MAX_NY], su[HELM_MAX_NY], sb[HELM_MAX_NY];
     const int b = blockIdx.y;
-    bool any = false;
-    for (int comp = 0; comp < a.nc; ++comp) any = any || (a.flags[b * a.nc + comp] == 0);
+    if (blockIdx.z == 1) { a.nu = a.nu2; a.wall_lo = a.wall_lo2; a.wall_hi = a.wall_hi2; a.inv = a.inv2; a.cp = a.cp2; a.lower_row = a.lower_row2; }
+    bool any = a.flags == nullptr;
+    if (a.flags) for (int comp = 0; comp < a.nc; ++comp) any = any || (a.flags[b * a.nc + comp] == 0);
     const int col = blockIdx.x * 64 + threadIdx.x;
     if (!any || !(a.dt[b] > 0.f)) return;
     for (int j = threadIdx.x; j < a.ny; j += 64) {
@@ -485,6 +489,9 @@ int fg_helm_alloc(fg_state* s) {
     FG_HIP_CHECK(hipMalloc(&s->helm_upper, sizeof(float) * count));
     FG_HIP_CHECK(hipMalloc(&s->helm_tmp, sizeof(float) * count * s->grid.dims));
     FG_HIP_CHECK(hipMalloc(&s->helm_lower_row, sizeof(float) * (size_t)s->grid.B * s->grid.ny));
+    FG_HIP_CHECK(hipMalloc(&s->helm_lower_row2, sizeof(float) * (size_t)s->grid.B * s->grid.ny));
+    FG_HIP_CHECK(hipMalloc(&s->line_inv2, sizeof(float) * count));
+    FG_HIP_CHECK(hipMalloc(&s->line_cp2, sizeof(float) * count));
     {   // 1 / (hx hz) of the uniform transform axes (the H-orthonormal eigenvectors carry it: k_helm_coeffs)
         float rx = 1.f, rz = 1.f;
         FG_HIP_CHECK(hipMemcpy(&rx, s->d_rh[0], sizeof(float), hipMemcpyDeviceToHost));
@@ -513,9 +520,34 @@ static int helm_cb(const fg_state* s) {      // columns per workgroup of the app
     return cb;
 }
 
-// coefficients + Thomas factorisation of the Helmholtz preconditioner for this solve (dt per env, nu of the solve)
-int fg_helm_factor(fg_state* s, const float* dt, float nu, int wall_lo, int wall_hi, int nc, hipStream_t st) {
+// both factorisations of a PISO step with a passive scalar (set 0: scalar, set 1: velocity) in one launch, ahead of the solves;
+// fg_helm_factor then finds the record and launches nothing.  Row form only (returns FG_OK without a record otherwise).
+int fg_helm_factor_pair(fg_state* s, const float* dt, const float nu[2], const int wall_lo[2], const int wall_hi[2], hipStream_t st) {
+    s->helm_pre_mask = 0;
+    if (!helm_cb(s) || !s->line_inv2) return FG_OK;
+    HelmArgs a = {};
+    a.dt = dt; a.lam = s->fd_lam; a.rhy = s->grid.rh[1]; a.rs = s->helm_rs; a.nx = s->grid.nx; a.ny = s->grid.ny; a.nc = 1; a.flags = nullptr;
+    a.nu = nu[0]; a.wall_lo = wall_lo[0]; a.wall_hi = wall_hi[0]; a.inv = s->line_inv; a.cp = s->line_cp; a.lower_row = s->helm_lower_row;
+    a.nu2 = nu[1]; a.wall_lo2 = wall_lo[1]; a.wall_hi2 = wall_hi[1]; a.inv2 = s->line_inv2; a.cp2 = s->line_cp2; a.lower_row2 = s->helm_lower_row2;
+    hipLaunchKernelGGL(k_helm_factor_y, dim3((s->grid.nx + 63) / 64, s->grid.B, 2), dim3(64), 0, st, a);
+    FG_HIP_CHECK(hipGetLastError());
+    s->helm_pre_mask = 3; s->helm_pre_dt = dt;
+    for (int k = 0; k < 2; ++k) { s->helm_pre_nu[k] = nu[k]; s->helm_pre_walls[k][0] = wall_lo[k]; s->helm_pre_walls[k][1] = wall_hi[k]; }
+    return FG_OK;
+}
+
+// coefficients + Thomas factorisation of the Helmholtz preconditioner for this solve (dt per env, nu of the solve); kind = the
+// factor set a record of fg_helm_factor_pair may already hold (0 scalar, 1 velocity)
+int fg_helm_factor(fg_state* s, const float* dt, float nu, int wall_lo, int wall_hi, int nc, hipStream_t st, int kind) {
     s->helm_cb = helm_cb(s);
+    s->helm_set = 0;
+    if (s->helm_cb && kind >= 0 && kind < 2 && ((s->helm_pre_mask >> kind) & 1) && s->helm_pre_dt == dt && s->helm_pre_nu[kind] == nu &&
+        s->helm_pre_walls[kind][0] == wall_lo && s->helm_pre_walls[kind][1] == wall_hi) {
+        s->helm_pre_mask &= ~(1 << kind);
+        s->helm_set = kind;
+        return FG_OK;
+    }
+    if (kind >= 0 && kind < 2) s->helm_pre_mask &= ~1;      // (set 0 is overwritten below)
     if (s->helm_cb) {
         HelmArgs a = {};
         a.dt = dt; a.lam = s->fd_lam; a.rhy = s->grid.rh[1]; a.nu = nu; a.wall_lo = wall_lo; a.wall_hi = wall_hi;
@@ -534,7 +566,8 @@ int fg_helm_factor(fg_state* s, const float* dt, float nu, int wall_lo, int wall
 int fg_helm_apply(fg_state* s, int nc, const float* r, float* z, hipStream_t st) {
     if (!s->helm_cb) return fg_line_apply(s, s->helm_diag, nullptr, nc, r, z, st);
     HelmArgs a = {};
-    a.inv = s->line_inv; a.cp = s->line_cp; a.lower_row = s->helm_lower_row; a.nx = s->grid.nx; a.ny = s->grid.ny; a.nc = nc; a.flags = s->flags;
+    a.inv = s->helm_set ? s->line_inv2 : s->line_inv; a.cp = s->helm_set ? s->line_cp2 : s->line_cp;
+    a.lower_row = s->helm_set ? s->helm_lower_row2 : s->helm_lower_row; a.nx = s->grid.nx; a.ny = s->grid.ny; a.nc = nc; a.flags = s->flags;
     const int nsys = s->grid.B * nc;
     // per system and cell: r, inv, c' read + z written
     const int slot = fg_prof_slot(s, FG_PK_LINE, s->flags, nsys, 16.0 * s->grid.n, 5.0 * s->grid.n, st);

@@ -52,13 +52,16 @@ def test_large_channel_batch_step_matches_oracle_and_env_steps(env_id, grid):
         twin = f64_twin(dom.solver, (0, B - 1), u0)
         assert sim.single_step()
         ok64, stats64, sub64 = twin.single_step(dt, 0.8, adaptive=True, outflow_faces=(1,), outflow_velm=[float(v) for v in velm], outflow_tol=1e-5,
-                                                advection_tol=1e-13, pressure_tol=1e-13, max_iterations=50000)
+                                                advection_tol=1e-13, pressure_tol=1e-13, max_iterations=250000)
         vel64, prs64 = twin.velocity.cpu().numpy(), twin.pressure.cpu().numpy()
         twin.close()
         vel = dom.solver.velocity.cpu().numpy().astype(np.float64)
         prs = dom.solver.pressure.cpu().numpy().astype(np.float64)
         assert np.isfinite(vel).all() and np.isfinite(prs).all()
-        edges = [np.linspace(0.0, env.L, nx + 1), np.linspace(-env.H / 2, env.H / 2, ny + 1)]
+        # the oracle's grid = the widths the library holds (fp32 values of L / nx, H / ny), promoted: fp32 path, fp64 twin and oracle then
+        # see the same metrics to the last bit (exact linspace edges differ from them by 6e-8 relative, which is 1e-6 in the velocity)
+        w = [np.asarray(x, np.float64) for x in dom.solver.widths[:2]]
+        edges = [np.concatenate([[0.0], np.cumsum(w[0])]), -env.H / 2 + np.concatenate([[0.0], np.cumsum(w[1])])]
         grid = O.Grid(O.rectilinear_coords(edges))
         hooks = {"PRE": [lambda d, ts: O.update_advective_boundaries(d, [1], velm.astype(np.float64), ts, tol=1e-5)]}
         for b in (0, B - 1):
@@ -71,8 +74,9 @@ def test_large_channel_batch_step_matches_oracle_and_env_steps(env_id, grid):
             e64 = (rel_err(vel64[k], ref.velocity), rel_err(prs64[k, 0] - prs64[k, 0].mean(), ref.pressure - ref.pressure.mean()))
             print(f"CHANNEL_{nx}x{ny}_ERR env {b}: fp32 velocity {e32[0]:.2e} pressure {e32[1]:.2e} | fp64 build velocity {e64[0]:.2e} pressure {e64[1]:.2e} (iterations {stats64}, substeps {sub64})")
             # the fp64 build of the same kernels lands on the oracle; the fp32 figures are solver tolerance (1e-7 absolute) x conditioning
-            assert e64[0] < 1e-9 and e64[1] < 1e-8, (b, e64)
-            assert e32[0] < 1e-4 and e32[1] < 5e-3, (b, e32)
+            # (plain CG in double at an ABSOLUTE residual of 1e-13: what is left is that tolerance x the conditioning of the grid)
+            assert e64[0] < 1e-7 and e64[1] < 1e-7, (b, e64)
+            assert e32[0] < 6e-5 and e32[1] < 3e-5, (b, e32)      # measured 6e-6 .. 2.5e-5 / 3e-6 .. 1e-5: bound = 2x
         # the env's own step (25 PISO steps, its tolerances) on the batch
         solver = dom.solver
         solver.solver_counters(reset=True)
