@@ -250,7 +250,9 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const fg_real*
                                                          const fg_real* __restrict__ Ap_, fg_real* __restrict__ x_,
                                                          fg_real* __restrict__ r_, FgDacc* __restrict__ acc,
                                                          const int32_t* __restrict__ flags, FgBest best, fg_real tol, int it,
-                                                         int ns, int num_base, int tiles_x, int tiles_y, int tiles) {
+                                                         int ns, int num_base, FgDacc* __restrict__ xsum, int tiles_x, int tiles_y, int tiles) {
+    // xsum (optional): sum(x_{it+1}) per env into xsum[2 b + (it & 1)], so that the mean removal of the pressure needs no pass of its
+    // own (FgMeanRef, fg_internal.h: k_correct subtracts it where it copies the pressure to the block) -- as the fused CG's update does
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
     if (flag_ld(flags + (c.b)) != 0) return;
     const double rr = fg_acc_total(fg_acc_ptr(acc, c.b, num_base + it % 3), ns);  // r.r or r.z
@@ -261,10 +263,11 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const fg_real*
     const unsigned tile = fg_xcd_remap(blockIdx.x, gridDim.x) % tiles;
     if (tile == 0 && threadIdx.x < 64) {
         fg_acc_zero(fg_acc_ptr(acc, c.b, 3 + ((it + 1) & 1)), ns);  // next pAp
+        if (xsum && threadIdx.x == 0) acc_st(xsum + (2 * c.b + ((it + 1) & 1)), 0.0);      // filled by the update of iteration it + 1
     }
-    __shared__ fg_real lds[4];
+    __shared__ fg_real lds[8];
     const size_t base = (size_t)c.b * g.n;
-    fg_real part[1] = {0.f};
+    fg_real part[2] = {0.f, 0.f};
     if (c.valid) {
         const FgVec<VEC> p = fg_load<VEC>(p_ + base + c.idx);
         const FgVec<VEC> Ap = fg_load<VEC>(Ap_ + base + c.idx);
@@ -276,12 +279,19 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const fg_real*
             x.v[e] += alpha * p.v[e];
             r.v[e] -= alpha * Ap.v[e];
             part[0] += r.v[e] * r.v[e];
+            part[1] += x.v[e];
         }
         fg_store<VEC>(x_ + base + c.idx, x);
         fg_store<VEC>(r_ + base + c.idx, r);
     }
-    fg_block_sum<1>(part, lds);
-    if (threadIdx.x == 0) fg_acc_add(fg_acc_ptr(acc, c.b, (it + 1) % 3), ns, tile, (double)part[0]);
+    if (xsum) {
+        const fg_real tot = fg_block_sum_lanes<2>(part, lds);      // thread q holds value q (same per-wave sums and order as fg_block_sum)
+        if (threadIdx.x == 0) fg_acc_add(fg_acc_ptr(acc, c.b, (it + 1) % 3), ns, tile, (double)tot);
+        if (threadIdx.x == 1) acc_add(xsum + (2 * c.b + (it & 1)), (double)tot);
+    } else {
+        fg_block_sum<1>(*reinterpret_cast<fg_real (*)[1]>(part), lds);
+        if (threadIdx.x == 0) fg_acc_add(fg_acc_ptr(acc, c.b, (it + 1) % 3), ns, tile, (double)part[0]);
+    }
 }
 
 // Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one wave per env.  `mirror` (optional) is the
@@ -441,6 +451,9 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     bool done = false, info_fresh = false;
     int active_est = (B + 3) / 4;  // envs expected to still iterate after the first iteration, refreshed by every poll
     int next_poll = a.precond ? (s->pred_cg[a.kind & 3] + 1 > 1 ? s->pred_cg[a.kind & 3] + 1 : 1) : check_every;
+    // sum(x) rides in the update kernels when the solve starts from zero inside the PISO step (a.x = pressureResult): the mean removal
+    // then needs no pass of its own (fcg_mean_ready, consumed by fg_piso_step's last corrector)
+    FgDacc* mean_sums = (!a.use_x0 && a.x == s->p_result && s->fcg_xsum) ? s->fcg_xsum : nullptr;
     int it = 0;
 #if !FG_F64
     if (fused) {
@@ -535,7 +548,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         FG_DISPATCH(s, {
             const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
             FG_LAUNCH_P(s, slot_up, (k_cg_update<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, p_out, a.Ap, a.x,
-                        a.r, s->cg_acc, s->flags, s->cg_best, a.tol, it, ns, nb, L.tiles_x, L.tiles_y, L.tiles);
+                        a.r, s->cg_acc, s->flags, s->cg_best, a.tol, it, ns, nb, mean_sums, L.tiles_x, L.tiles_y, L.tiles);
         });
         const bool poll = (it + 1 >= next_poll || it + 1 == a.max_iterations);
         if (poll) next_poll = it + 1 + check_every;
@@ -569,6 +582,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 return rc;
         }
     }
+    if (!fused && mean_sums) s->fcg_mean_ready = 1;      // (a residual restart recomputes r only: the sums of x stay valid)
     if (!info_fresh) {
         FG_HIP_CHECK(hipMemcpyAsync(s->info_pinned, s->info_dev, sizeof(fg_solve_info) * B, hipMemcpyDeviceToHost, st));
         FG_HIP_CHECK(hipStreamSynchronize(st));
