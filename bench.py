@@ -239,7 +239,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True, e
                     "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "pressure_stall_accept": env._sim.pressure_stall_accept,
                     "solver_iterations": its, "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(n_steps * env.n_sim_steps, 1), 2),
                     "drag_coefficient_env0": float(info["drag"][0]), "kernels": rows, "cells_per_env": dom.n_cells,
-                    "piso_steps_per_env_step": env.n_sim_steps}
+                    "piso_steps_per_env_step": env.n_sim_steps, "switches": solver_switches(dom)}
         finally:
             env.close()
 
@@ -308,7 +308,8 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=T
                 "capped_solves": capped_solves(its_leg), "solves": int(sum(v["systems"] for v in its_leg.values() if isinstance(v, dict))),
                 "last_sim_step": {"substeps": env._sim.last_substeps, "iterations[velocity, pressure0, pressure1]": list(env._sim.last_iterations)},
                 "drag_lift_env0": [float(info["drag"][0]), float(info["lift"][0])],
-                "note": f"state {develop} uncontrolled sim steps after an impulsive start; uniform random jets in [-1, 1]"}
+                "note": f"state {develop} uncontrolled sim steps after an impulsive start; uniform random jets in [-1, 1]",
+                "switches": solver_switches(env._domain)}
     finally:
         env.close()
 
@@ -328,6 +329,14 @@ def launches_per_piso_step(prof, its):
     """Solver-kernel launches (the kinds the native profile counts: Krylov + preconditioner kernels) per PISO step."""
     n = sum(r["launches"] for r in prof.values())
     return round(n / max(its["piso_steps"], 1), 1) if n else None
+
+
+def solver_switches(solver):
+    """fg_config_dump / fg_mb_config_dump of the handle a leg ran on (stored with the leg in profiles/bench_detail.json)."""
+    try:
+        return solver.config_dump()
+    except Exception as exc:      # (a leg's number must not be lost to its metadata)
+        return {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
 
 def solver_iterations(solver) -> dict:
@@ -386,7 +395,7 @@ def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing
                 "piso_steps_per_env_step": sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": its,
                 "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
-                "policy": "uniform samples of the action space",
+                "policy": "uniform samples of the action space", "switches": solver_switches(solver),
                 "dominant_kernel": None if roof is None else {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
                 "kernels": None if roof is None else {k: {kk: v[kk] for kk in ("avg_busy_launch_ms", "launches", "est_total_ms", "GBps", "TFLOPps")}
                                                       for k, v in roof["kernels"].items()}}
@@ -700,7 +709,7 @@ def main():
                        "launches_per_piso_step": launches_per_piso_step(prof, its) if single_block else None,
                        "step_GBps": step_gbps(prof, elapsed) if single_block else None,
                        "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2),
-                       "per_rank": per_rank},
+                       "per_rank": per_rank, "switches": solver_switches(solver)},
             "roofline": roof,
             "legs": {},
         }

@@ -194,6 +194,8 @@ SIGNATURES = {
     "fg_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fg_mb_create": (c_int, [c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "fg_mb_destroy": (c_int, [c_void_p]),
+    "fg_config_dump": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
+    "fg_mb_config_dump": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
     "fg_mb_add_block": (c_int, [c_void_p, POINTER(c_float), c_int32, c_int32, c_int32, POINTER(c_int32)]),
     "fg_mb_connect": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "fg_mb_make_periodic": (c_int, [c_void_p, c_int32, c_int32]),

@@ -1,6 +1,7 @@
 // C-ABI entry points of libfluidgym_hip.so (declared in include/fluidgym_hip.h): handle lifetime,
 // field binding and the PISO step drivers.  Host code only; kernels live in fg_piso.hip,
 // fg_poisson.hip, fg_bicgstab.hip, fg_metrics.hip.
+#include <stdio.h>
 #include <string.h>
 
 #include <cmath>
@@ -127,6 +128,8 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     { const char* ev = getenv("FG_TRIDIAG_CB"); s->tridiag_cb = ev ? atoi(ev) : 64; }      // 32: half-width column blocks in k_tridiag_y_lds (measured: no gain)
     { const char* ev = getenv("FG_HELM_CB"); s->helm_cb_pref = ev ? atoi(ev) : 32; }
     { const char* ev = getenv("FG_HELM_ROWFORM"); s->helm_rowform_off = (ev && atoi(ev) == 0) ? 1 : 0; }   // 0: k_helm_coeffs + the array-form line kernels
+    { const char* ev = getenv("FG_FD_ROWMEAN"); s->fd_rowmean = ev ? atoi(ev) : 1; }     // 0: the fused CG keeps the grid's A = 1 factors
+    s->fd_row_epoch = -1; s->rA_epoch = 0; s->fd_row_part_epoch = -1;
     { const char* ev = getenv("FG_CG_FUSED"); s->cg_fused = ev ? atoi(ev) : 1; }       // 0: five-kernel preconditioned CG iteration (fg_poisson.hip)
     { const char* ev = getenv("FG_BICG_PFUSED"); s->bicg_pfused = ev ? atoi(ev) : 1; } // 0: eleven-launch Helmholtz-preconditioned BiCGStab iteration
     FG_HIP_CHECK(hipMalloc(&s->fcg_alpha, sizeof(double) * 2 * (size_t)g.B));
@@ -163,6 +166,7 @@ extern "C" int fg_destroy(fg_handle s) {
     for (float* p : fd) if (p) (void)hipFree(p);
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc); (void)hipFree(s->fcg_alpha); (void)hipFree(s->fcg_xsum);
+    (void)hipFree(s->fd_row_part); (void)hipFree(s->fd_lam_x); (void)hipFree(s->fd_row_inv); (void)hipFree(s->fd_row_cp); (void)hipFree(s->fd_row_lower);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
     (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->force_uniform);
     (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp); (void)hipFree(s->helm_lower_row); (void)hipFree(s->helm_lower_row2); (void)hipFree(s->line_inv2); (void)hipFree(s->line_cp2);
@@ -407,6 +411,14 @@ static int setup_advection(fg_handle s, const fg_real* dt_B, int for_scalar, int
         a.visc = s->visc_field;
         a.nu = s->viscosity;
         a.rA = s->rA;
+        s->rA_epoch++;
+#if !FG_F64
+        if (fg_fd_rowmean_ok(s) && s->vec == 4 && (s->grid.nx & 63) == 0) {      // row sums of 1/A for the row-mean preconditioner ride in the assembly
+            if (!s->fd_row_part) FG_HIP_CHECK(hipMalloc(&s->fd_row_part, sizeof(float) * (size_t)s->grid.B * s->grid.ny * (s->grid.nx / 64)));
+            a.row_part = s->fd_row_part;
+            s->fd_row_part_epoch = s->rA_epoch;
+        }
+#endif
         if (buoy_axis >= 0) {
             a.buoy_T = s->scalar; a.buoy_stride = (long)s->cfg.n_scalars * s->grid.n; a.buoy_axis = buoy_axis; a.buoy_factor = buoy_factor;
             a.source_w = s->velocity_source;
@@ -442,6 +454,7 @@ extern "C" int fg_copy_scalar_result_to_blocks(fg_handle s, int channel, void* s
 
 extern "C" int fg_setup_pressure_matrix(fg_handle s, void* stream) {
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    s->rA_epoch++;
     return fg_launch_pressure_setup(s, s->cur_dt, (hipStream_t)stream);
 }
 
@@ -652,6 +665,23 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
     return status;
 }
 
+extern "C" int fg_config_dump(fg_handle s, char* buf, int n) {
+    FG_REQUIRE(s && buf && n > 0, FG_ERR_INVALID_ARG, "fg_config_dump: bad argument");
+    char tmp[1536];
+    const int len = snprintf(tmp, sizeof(tmp),
+        "{\"build\": \"%s\", \"FG_CG_FUSED\": %d, \"FG_BICG_PFUSED\": %d, \"FG_BICG_FUSED\": %d, \"FG_BICG_SUB\": %d, \"FG_BICG3\": %d, "
+        "\"FG_BICG3_BXL\": %d, \"FG_BICG3_MIX\": %d, \"FG_REDUCE_WGS\": %d, \"FG_CG_WGS_PER_SLOT\": %d, \"FG_TRIDIAG_CB\": %d, \"FG_HELM_CB\": %d, "
+        "\"FG_HELM_ROWFORM\": %d, \"FG_FD_ROWMEAN\": %d, \"FG_POLL_SPIN\": %d, \"FG_PROF_PERIOD\": %d, \"fast_transform_x\": %d, \"fd_preconditioner\": %d, "
+        "\"helmholtz\": %d, \"advection_preconditioner\": %d, \"advection_from_result\": %d, \"return_best\": %d, \"cg_reset_steps\": %d, "
+        "\"double_fallback\": %d, \"wall_forcing_axis\": %d}",
+        FG_F64 ? "f64" : "f32", s->cg_fused, s->bicg_pfused, s->bicg_fused, s->bicg_sub, s->bicg3_force, s->bicg3_bxl, s->bicg3_mix, s->reduce_wgs,
+        s->cg_wgs_per_slot, s->tridiag_cb, s->helm_cb_pref, s->helm_rowform_off ? 0 : 1, s->fd_rowmean, s->poll.spin, s->prof.period, s->fd_dct_x, s->fd_Qx ? 1 : 0,
+        s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis);
+    if (len >= n) return len + 1;
+    memcpy(buf, tmp, (size_t)len + 1);
+    return FG_OK;
+}
+
 extern "C" int fg_solver_unconverged(fg_handle s, int64_t* out4) {
     FG_REQUIRE(s != nullptr && out4 != nullptr, FG_ERR_INVALID_ARG, "fg_solver_unconverged: bad argument");
     for (int k = 0; k < 4; ++k) out4[k] = s->ctr.unconv[k];
@@ -776,6 +806,7 @@ extern "C" int fg_make_divergence_free(fg_handle s, fg_real tol, int max_iterati
     const size_t BN = (size_t)s->grid.B * s->grid.n;
     std::vector<fg_real> ones(BN, 1.f);
     FG_HIP_CHECK(hipMemcpyAsync(s->rA, ones.data(), sizeof(fg_real) * BN, hipMemcpyHostToDevice, st));
+    s->rA_epoch++;
     FG_HIP_CHECK(hipStreamSynchronize(st));
     if (int rc = fg_launch_copy_active(s, nullptr, s->velocity, s->hvec, s->grid.dims, st)) return rc;
     if (int rc = fg_launch_div(s, make_bounds(s, 0), nullptr, s->hvec, s->div, st)) return rc;

@@ -280,5 +280,16 @@ extern "C" int fg_set_fd_fast_transform(fg_handle s, int axis, float cell_width)
         s->fd_dct_inv[0] = (float)(rs / (sqrt(1.0 / n) * n)); s->fd_dct_inv[1] = (float)(rs / (sqrt(2.0 / n) * n));
     }
     s->fd_dct_x = periodic ? 2 : 1;
+    // eigenvalues of the 1-D operator in the order the transform produces the modes (fd_precond.cosine_basis / fourier_basis): the
+    // row-mean preconditioner synthesises its per-env tridiagonal systems from them (fg_fdprecond.hip k_fd_rowmean_factor)
+    std::vector<float> lam(n);
+    for (int m = 0; m < n; ++m) {
+        const int k = periodic ? (m <= n / 2 ? m : n - m) : m;
+        const double ang = periodic ? 2.0 * M_PI * k / n : M_PI * k / n;
+        lam[m] = (float)(-(2.0 - 2.0 * cos(ang)) / ((double)cell_width * (double)cell_width));
+    }
+    if (s->fd_lam_x) (void)hipFree(s->fd_lam_x);
+    FG_HIP_CHECK(hipMalloc(&s->fd_lam_x, sizeof(float) * n));
+    FG_HIP_CHECK(hipMemcpy(s->fd_lam_x, lam.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     return FG_OK;
 }

@@ -369,7 +369,10 @@ __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const f
 template <bool TWO, int CB>
 __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, const float* __restrict__ inv,
                                                        const float* __restrict__ cp, const float* __restrict__ lower,
-                                                       const int32_t* __restrict__ flags, int nx, int ny, int nz, FgCgLead lead) {
+                                                       const int32_t* __restrict__ flags, int nx, int ny, int nz, FgCgLead lead,
+                                                       long fac_stride, int lower_stride) {
+    // fac_stride / lower_stride: 0 = the grid's factors (A = 1 operator, shared by all envs); N / ny = per-env factors of the
+    // row-mean operator (k_fd_rowmean_factor below)
     // CB = columns per workgroup: 64 (one float4 row segment per 16 lanes) or 32 (half the LDS: at ny = 128 two to three workgroups per
     // CU instead of one -- round 5: the whole launch resident at once on the 2-D env grids)
     extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][CB] | ms[nyp][CB] | cs[nyp][CB]  (TWO: cs shares ms)
@@ -391,8 +394,9 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
     const int a4 = t4 % nx, c4 = t4 / nx;
     const size_t col4 = (size_t)c4 * ny * nx + a4;
     float* __restrict__ xb4 = x + (size_t)b * nx * ny * nz + col4;
-    const float* __restrict__ iv4 = inv + col4;
-    const float* __restrict__ cp4 = cp + col4;
+    const float* __restrict__ iv4 = inv + (size_t)b * fac_stride + col4;
+    const float* __restrict__ cp4 = cp + (size_t)b * fac_stride + col4;
+    lower += (size_t)b * lower_stride;
     for (int jb = wave * 32; jb < nyp; jb += 128) {  // 32 rows per wave per round
         float4 vx[UQ], vi[UQ], vc[UQ];
         float vl[UQ];
@@ -476,6 +480,103 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-mean preconditioner (round 5).  M = the pressure operator with the coefficient 1/A replaced by its MEAN ALONG x per row and
+// env, a_j = mean_i (1/A)_{ij}: still separable -- the x basis is the grid's (cosine / Fourier, eigenvalues lam_a), and mode a of env
+// b solves the tridiagonal system
+//     (a_j hy_j lam_a - c_{j-1/2} - c_{j+1/2}) u_j + c_{j-1/2} u_{j-1} + c_{j+1/2} u_{j+1} = r^_j,   c_{j+1/2} = (a_j / hy_j + a_{j+1} / hy_{j+1}) / 2
+// (the A = 1 operator of simulation/fd_precond.py with a_j in place of 1).  It follows the part of 1/A that varies ACROSS the channel
+// -- the mean profile in the channel stand-ins, the 40 : 1 wall refinement in RBC -- exactly, which the A = 1 operator cannot:
+// measured on the oracle's matrices of the stirred 256 x 128 channel (profiles/scratch/precond_rowmean_exp.py) the residual after
+// ONE iteration is 7-8e-6 against 1.2-1.3e-5, i.e. under the reference's tolerance of 1e-5 instead of just over it -- one CG iteration
+// per solve instead of two.  The factors depend on the env's A: one factorisation per PISO step (both correctors share A).
+// One wave per 64 modes and env; the row means are taken by the same wave first (the env's 1/A rows from L2).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int ROW_MAX_NY = 320;
+__global__ __launch_bounds__(64) void k_fd_rowmean_factor(const float* __restrict__ rA, const float* __restrict__ lam, const float* __restrict__ hy,
+                                                          const float* __restrict__ rhy, const float* __restrict__ dt, float* __restrict__ inv,
+                                                          float* __restrict__ cp, float* __restrict__ lower_out, int nx, int ny,
+                                                          const float* __restrict__ row_part, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float se[ROW_MAX_NY], sd[ROW_MAX_NY], sl[ROW_MAX_NY], su[ROW_MAX_NY], sz[ROW_MAX_NY];
+    __shared__ float sa[ROW_MAX_NY];
+    const int b = blockIdx.y, lane = threadIdx.x;
+    if (dt && !(dt[b] > 0.f)) return;
+    const size_t N = (size_t)nx * ny;
+    const float* __restrict__ ra = rA + (size_t)b * N;
+    // a_j = mean over x of 1/A: from the per-tile row sums the assembly left (k_adv_build, fixed order), or -- 1/A fields that did
+    // not come from it -- taken here (float4 loads, eight rows in flight per round: a lone wave streaming the env's field, slow)
+    const float rn = 1.f / (float)nx;
+    if (row_part) {
+        for (int j = lane; j < ny; j += 64) {
+            const float* __restrict__ pp = row_part + ((size_t)b * ny + j) * tiles_x;
+            float acc = 0.f;
+            for (int t = 0; t < tiles_x; ++t) acc += pp[t];
+            sa[j] = acc * rn;
+        }
+    } else
+    for (int j0 = 0; j0 < ny; j0 += 8) {
+        float part[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = min(j0 + q, ny - 1);
+            float acc = 0.f;
+            for (int i = 4 * lane; i < nx; i += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(ra + (size_t)j * nx + i);
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+            part[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float tot = fg_wave_sum(part[q]);
+            if (lane == 0 && j0 + q < ny) sa[j0 + q] = tot * rn;
+        }
+    }
+    __syncthreads();
+    const int nyp = (ny + 7) & ~7;
+    for (int j = lane; j < nyp; j += 64) {
+        if (j < ny) {
+            const float aj = sa[j];
+            const float cm = j > 0 ? 0.5f * (sa[j - 1] * rhy[j - 1] + aj * rhy[j]) : 0.f;
+            const float cpl = j < ny - 1 ? 0.5f * (aj * rhy[j] + sa[j + 1] * rhy[j + 1]) : 0.f;
+            sl[j] = cm; su[j] = cpl; sd[j] = -(cm + cpl); se[j] = aj * hy[j];
+            // the mode that is constant along x meets the singular Neumann operator along y: its last pivot is shifted by the row's own
+            // diagonal (fd_precond.py: a rank-one change along the null space, which CG never sees)
+            sz[j] = (j == ny - 1) ? -(cm + cpl) : 0.f;
+            if (blockIdx.x == 0) lower_out[(size_t)b * ny + j] = cm;
+        } else { sl[j] = 0.f; su[j] = 0.f; sd[j] = 1.f; se[j] = 0.f; sz[j] = 0.f; }      // padding rows: the identity
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 64 + lane;                  // (nx is a multiple of 64: every lane owns a mode)
+    const float lm = lam[col];
+    const float zm = (col == 0) ? 1.f : 0.f;
+    float* __restrict__ iv = inv + (size_t)b * N + col;
+    float* __restrict__ cq = cp + (size_t)b * N + col;
+    float cprev = 0.f;
+    // eight rows per trip: their coefficients come out of LDS in one batch, then the dependent chain fma -> rcp -> mul runs from
+    // registers (a first version read LDS and branched on `live` inside every step: one exposed LDS round trip per row, 17 us for 128 rows)
+    for (int j0 = 0; j0 < nyp; j0 += 8) {
+        float e8[8], d8[8], l8[8], u8[8], z8[8], pv[8], cv[8];
+        {   // (128-bit LDS reads: ten per trip instead of forty)
+            auto ld8 = [&](const float* a, float (&o)[8]) {
+                const float4 x0 = *reinterpret_cast<const float4*>(a + j0), x1 = *reinterpret_cast<const float4*>(a + j0 + 4);
+                o[0] = x0.x; o[1] = x0.y; o[2] = x0.z; o[3] = x0.w; o[4] = x1.x; o[5] = x1.y; o[6] = x1.z; o[7] = x1.w;
+            };
+            ld8(se, e8); ld8(sd, d8); ld8(sl, l8); ld8(su, u8); ld8(sz, z8);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float d = fmaf(zm, z8[q], fmaf(e8[q], lm, d8[q]));
+            pv[q] = __builtin_amdgcn_rcpf(fmaf(-l8[q], cprev, d));
+            cprev = u8[q] * pv[q];
+            cv[q] = cprev;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q < ny) { iv[(size_t)(j0 + q) * nx] = pv[q]; cq[(size_t)(j0 + q) * nx] = cv[q]; }
+    }
+}
+
 }  // namespace
 
 // dynamic LDS above 64 KB needs an explicit opt-in per kernel (once per process and size class)
@@ -532,9 +633,27 @@ static int launch_gemm(const fg_state* s, const GemmArgs& g, int batch, int expe
     return FG_OK;
 }
 
+// factors of the row-mean operator for the envs' current 1/A (rA [B][N]); 2-D grids with a fast x transform only
+bool fg_fd_rowmean_ok(const fg_state* s) {
+    return s->fd_rowmean && s->fd_dct_x != 0 && s->grid.dims == 2 && s->grid.ny <= ROW_MAX_NY && (s->grid.nx & 63) == 0 && s->fd_lam_x != nullptr;
+}
+int fg_fd_rowmean_factor(fg_state* s, const float* rA, const float* dt, hipStream_t st, const float* row_part, int tiles_x) {
+    const FgGrid& G = s->grid;
+    const size_t BN = (size_t)G.B * G.n;
+    if (!s->fd_row_inv) {
+        FG_HIP_CHECK(hipMalloc(&s->fd_row_inv, sizeof(float) * BN));
+        FG_HIP_CHECK(hipMalloc(&s->fd_row_cp, sizeof(float) * BN));
+        FG_HIP_CHECK(hipMalloc(&s->fd_row_lower, sizeof(float) * (size_t)G.B * G.ny));
+    }
+    hipLaunchKernelGGL(k_fd_rowmean_factor, dim3((G.nx + 63) / 64, G.B), dim3(64), 0, st, rA, (const float*)s->fd_lam_x, G.h[1], G.rh[1], dt,
+                       s->fd_row_inv, s->fd_row_cp, s->fd_row_lower, G.nx, G.ny, row_part, tiles_x);
+    FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
 // per-mode Thomas solve along y of the transformed field `cur` (in place), all envs with flags == 0; lead (optional): the fused CG's
 // verdict / leader bookkeeping taken by this launch (FgCgLead, fg_cg.h)
-int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead) {
+int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean) {
     const FgGrid& G = s->grid;
     const int nx = G.nx, ny = G.ny, nz = G.nz, B = G.B;
     const long N = G.n;
@@ -545,24 +664,31 @@ int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead)
     const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
     const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
     const size_t lds_two = lds_coop / 3 * 2;      // two arrays: c' staged after the forward sweep (ny up to 320)
+    // per-env factors of the row-mean operator (fg_fd_rowmean_factor) when the caller asked for them and the LDS kernels run
+    const bool rowf = use_rowmean && s->fd_row_inv && (nx & 3) == 0 && lds_two <= 160 * 1024;
+    const float* f_inv = rowf ? s->fd_row_inv : s->fd_inv;
+    const float* f_cp = rowf ? s->fd_row_cp : s->fd_cp;
+    const float* f_lower = rowf ? s->fd_row_lower : s->fd_lower;
+    const long fstride = rowf ? N : 0;
+    const int lstride = rowf ? ny : 0;
     // FG_TRIDIAG_CB=32 at fg_create: 32-column workgroups (half the LDS per workgroup, two to three resident per CU).  Measured round 5:
     // RBC 512 x 128 x 32 8.1 us against 7.0 us with 64 columns, headline unchanged -- the serial sweep of wave 0 is the floor, and
     // half-width blocks only halve its lanes; 64 stays the default
     const bool cb32 = s->tridiag_cb == 32 && nz == 1 && (nx & 31) == 0 && (long)((nx + 63) / 64) * B <= 1024;
     if ((nx & 3) == 0 && lds_coop <= 160 * 1024 && tridiag_lds_ready(lds_coop)) {
         if (cb32)
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 32>), dim3(nx / 32, B), dim3(256), lds_coop / 2, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                        s->flags, nx, ny, nz, ld);
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 32>), dim3(nx / 32, B), dim3(256), lds_coop / 2, st, cur, f_inv, f_cp, f_lower,
+                        s->flags, nx, ny, nz, ld, fstride, lstride);
         else
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 64>), grid, dim3(256), lds_coop, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                        s->flags, nx, ny, nz, ld);
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 64>), grid, dim3(256), lds_coop, st, cur, f_inv, f_cp, f_lower,
+                        s->flags, nx, ny, nz, ld, fstride, lstride);
     } else if ((nx & 3) == 0 && lds_two <= 160 * 1024 && tridiag_lds_ready(lds_two)) {
         if (cb32)
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 32>), dim3(nx / 32, B), dim3(256), lds_two / 2, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                        s->flags, nx, ny, nz, ld);
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 32>), dim3(nx / 32, B), dim3(256), lds_two / 2, st, cur, f_inv, f_cp, f_lower,
+                        s->flags, nx, ny, nz, ld, fstride, lstride);
         else
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 64>), grid, dim3(256), lds_two, st, cur, s->fd_inv, s->fd_cp, s->fd_lower,
-                        s->flags, nx, ny, nz, ld);
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 64>), grid, dim3(256), lds_two, st, cur, f_inv, f_cp, f_lower,
+                        s->flags, nx, ny, nz, ld, fstride, lstride);
     } else {
         FG_LAUNCH_P(s, slot, k_tridiag_y, grid, dim3(64), (size_t)((ny + 63) / 64 * 64) * 64 * sizeof(float), st, cur,
                     s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz, ld);
@@ -606,7 +732,7 @@ int fg_fd_apply(fg_state* s, const float* r, float* z, FgDacc* rz_acc, int rz_st
         if (int rc = launch_gemm(s, g, B, expect_active, st)) return rc;
         cur = t2;
     }
-    if (int rc = fg_fd_tridiag(s, cur, st, nullptr)) return rc;
+    if (int rc = fg_fd_tridiag(s, cur, st, nullptr, false)) return rc;
     if (G.dims == 3) {
         // inverse z: t1[k, m] = sum_c Qz[k, c] t2[c, m]
         g.A = s->fd_Qz; g.lda = nz; g.strideA = 0;

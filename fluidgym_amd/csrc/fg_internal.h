@@ -704,6 +704,11 @@ struct fg_state {
     int tridiag_cb;               // FG_TRIDIAG_CB at fg_create: 64 keeps 64-column workgroups in k_tridiag_y_lds (default: 32 where they divide)
     // x axis marked as a cosine-transform axis (uniform width, FIXED ends): fg_fdfft.hip replaces the two x GEMMs
     int fd_dct_x; float2* fd_dct_tw; float2* fd_dct_rot; float fd_dct_fwd[2]; float fd_dct_inv[2];
+    // row-mean preconditioner of the fused pressure CG (fg_fdprecond.hip k_fd_rowmean_factor): eigenvalues of the x basis [nx], per-env
+    // factors [B][N] / [B][ny], FG_FD_ROWMEAN at fg_create (1), epoch of the 1/A field the factors were made from (rA_epoch: bumped by
+    // everything that rewrites s->rA)
+    float* fd_lam_x; float* fd_row_inv; float* fd_row_cp; float* fd_row_lower; int fd_rowmean; long fd_row_epoch; mutable long rA_epoch;
+    float* fd_row_part; long fd_row_part_epoch;   // per-tile row sums of 1/A written by k_adv_build, and the rA epoch they belong to
     fg_real** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
     fg_real* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
     fg_real* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
@@ -798,6 +803,7 @@ struct FgAdvArgs {
     // S[axis] = factor * T, S[other] = 0 (rbc_env_base.py:285-297), used here AND written to `source_w` (the block's velocitySource
     // keeps the value the hook would have left) instead of being materialised by a k_buoyancy launch and read back
     const fg_real* buoy_T; long buoy_stride; int buoy_axis; fg_real buoy_factor; fg_real* source_w;
+    fg_real* row_part;       // optional (2-D, float4 lanes): per-tile row sums of 1/A, [B][ny][tiles_x] (row-mean preconditioner, fg_fdprecond.hip)
 };
 int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs& a, hipStream_t st);
 int fg_launch_wall_forcing(const fg_state* s, hipStream_t st);   // force_uniform from the wall-adjacent layers of s->velocity
@@ -904,7 +910,9 @@ int fg_fd_dct_inverse(fg_state* s, const fg_real* u, fg_real* z, const fg_real* 
 int fg_fd_apply(fg_state* s, const fg_real* r, fg_real* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st, const FgCgJudge* judge = nullptr);
 struct FgCgLead;    // fg_cg.h
-int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead);   // the per-mode Thomas solve of fg_fd_apply alone (in place)
+int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean = false);   // the per-mode Thomas solve of fg_fd_apply alone (in place); use_rowmean: the per-env factors of fg_fd_rowmean_factor
+bool fg_fd_rowmean_ok(const fg_state* s);
+int fg_fd_rowmean_factor(fg_state* s, const float* rA, const float* dt, hipStream_t st, const float* row_part = nullptr, int tiles_x = 0);
 // y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
 // with a live system, z = M^-1 r for every live system
 int fg_line_alloc(fg_state* s);

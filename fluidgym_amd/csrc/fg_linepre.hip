@@ -312,35 +312,51 @@ __device__ __forceinline__ void helm_row(const HelmArgs& a, int j, float& lo, fl
 // reciprocal is v_rcp_f32 (1 ulp): these are the factors of a PRECONDITIONER.
 constexpr int HELM_MAX_NY = 256;
 __global__ __launch_bounds__(64) void k_helm_factor_y(HelmArgs a) {
-    __shared__ float sl[HELM_MAX_NY], su[HELM_MAX_NY], sb[HELM_MAX_NY];
+    __shared__ __attribute__((aligned(16))) float sl[HELM_MAX_NY], su[HELM_MAX_NY], sb[HELM_MAX_NY];
     const int b = blockIdx.y;
     if (blockIdx.z == 1) { a.nu = a.nu2; a.wall_lo = a.wall_lo2; a.wall_hi = a.wall_hi2; a.inv = a.inv2; a.cp = a.cp2; a.lower_row = a.lower_row2; }
     bool any = a.flags == nullptr;
     if (a.flags) for (int comp = 0; comp < a.nc; ++comp) any = any || (a.flags[b * a.nc + comp] == 0);
     const int col = blockIdx.x * 64 + threadIdx.x;
     if (!any || !(a.dt[b] > 0.f)) return;
-    for (int j = threadIdx.x; j < a.ny; j += 64) {
-        float lo, hi;
-        helm_row(a, j, lo, hi);
-        const float l = j > 0 ? -a.nu * lo * a.rs : 0.f;
-        sl[j] = l;
-        su[j] = j < a.ny - 1 ? -a.nu * hi * a.rs : 0.f;
-        sb[j] = a.nu * (lo + hi);
-        if (blockIdx.x == 0) a.lower_row[b * a.ny + j] = l;
+    const int nyp = (a.ny + 7) & ~7;
+    for (int j = threadIdx.x; j < nyp; j += 64) {
+        if (j < a.ny) {
+            float lo, hi;
+            helm_row(a, j, lo, hi);
+            const float l = j > 0 ? -a.nu * lo * a.rs : 0.f;
+            sl[j] = l;
+            su[j] = j < a.ny - 1 ? -a.nu * hi * a.rs : 0.f;
+            sb[j] = a.nu * (lo + hi);
+            if (blockIdx.x == 0) a.lower_row[b * a.ny + j] = l;
+        } else { sl[j] = 0.f; su[j] = 0.f; sb[j] = 0.f; }      // padding rows (never stored)
     }
     __syncthreads();
-    const bool live = col < a.nx;
-    const float sig = 1.f / a.dt[b] - a.nu * a.lam[live ? col : 0];
+    const float sig = 1.f / a.dt[b] - a.nu * a.lam[col];       // (nx is a multiple of 64: every lane owns a mode)
     const size_t N = (size_t)a.nx * a.ny;
-    float* __restrict__ iv = a.inv + (size_t)b * N + (live ? col : 0);
-    float* __restrict__ cp = a.cp + (size_t)b * N + (live ? col : 0);
+    float* __restrict__ iv = a.inv + (size_t)b * N + col;
+    float* __restrict__ cp = a.cp + (size_t)b * N + col;
     float cprev = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < a.ny; ++j) {
-        const float d = (sig + sb[j]) * a.rs;
-        const float inv = __builtin_amdgcn_rcpf(fmaf(-sl[j], cprev, d));
-        cprev = su[j] * inv;
-        if (live) { iv[(size_t)j * a.nx] = inv; cp[(size_t)j * a.nx] = cprev; }
+    // eight rows per trip: coefficients out of LDS in one batch, then the dependent chain fma -> rcp -> mul from registers
+    for (int j0 = 0; j0 < nyp; j0 += 8) {
+        float b8[8], l8[8], u8[8], pv[8], cv[8];
+        {
+            auto ld8 = [&](const float* a8, float (&o)[8]) {
+                const float4 x0 = *reinterpret_cast<const float4*>(a8 + j0), x1 = *reinterpret_cast<const float4*>(a8 + j0 + 4);
+                o[0] = x0.x; o[1] = x0.y; o[2] = x0.z; o[3] = x0.w; o[4] = x1.x; o[5] = x1.y; o[6] = x1.z; o[7] = x1.w;
+            };
+            ld8(sb, b8); ld8(sl, l8); ld8(su, u8);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float d = (sig + b8[q]) * a.rs;
+            pv[q] = __builtin_amdgcn_rcpf(fmaf(-l8[q], cprev, d));
+            cprev = u8[q] * pv[q];
+            cv[q] = cprev;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q < a.ny) { iv[(size_t)(j0 + q) * a.nx] = pv[q]; cp[(size_t)(j0 + q) * a.nx] = cv[q]; }
     }
 }
 

@@ -479,6 +479,21 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
     return FG_OK;
 }
 
+extern "C" int fg_mb_config_dump(fg_mb_handle s, char* buf, int n) {
+    FG_REQUIRE(s && buf && n > 0, FG_ERR_INVALID_ARG, "fg_mb_config_dump: bad argument");
+    char tmp[1024];
+    const int len = snprintf(tmp, sizeof(tmp),
+        "{\"FG_MB_BICG_VEC4\": %d, \"FG_MB_SCALAR_CG\": %d, \"FG_MB_BICG_FUSE\": %d, \"FG_MB_PRED\": %d, \"FG_MB_ML_FUSE\": %d, \"FG_MB_ML_SB\": %d, "
+        "\"FG_MB_ML_TRY_CAP\": %d, \"FG_MB_ML_WARMUP\": %d, \"FG_MB_GRAPH\": %d, \"FG_MB_TRACE\": %d, \"FG_MB_COMPACT\": %d, \"FG_MB_OC_RTG_NT\": %d, "
+        "\"FG_MB_ONCHIP\": %d, \"FG_MB_OC_AGG\": %d, \"FG_MB_RUNG_ILU\": %d, \"FG_MB_OC_VARIANT\": %d}",
+        (int)s->dbg_vec_mask, (int)s->dbg_scalar_cg, (int)s->dbg_fuse_st, (int)s->dbg_pred, (int)s->dbg_ml_fuse, (int)s->dbg_ml_sb, (int)s->dbg_ml_cap,
+        (int)s->dbg_ml_warmup, (int)s->dbg_graph, (int)s->dbg_trace, (int)s->dbg_compact, (int)s->oc_rtg_nt, (int)s->onchip_mode, (int)s->dbg_oc_agg,
+        (int)s->dbg_rung_ilu, (int)s->oc_variant);
+    if (len >= n) return len + 1;
+    memcpy(buf, tmp, (size_t)len + 1);
+    return FG_OK;
+}
+
 extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (!s) return FG_OK;
     if (s->cg_graph_exec) (void)hipGraphExecDestroy(s->cg_graph_exec);

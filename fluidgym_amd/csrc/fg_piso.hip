@@ -165,6 +165,23 @@ __global__ __launch_bounds__(FG_BLOCK) void k_adv_build(FgGrid g, FgBounds bnd, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) r.v[e] = 1.f / out.v[e];
         fg_store<VEC>(a.rA + (size_t)c.b * N + c.idx, r);
+#if !FG_F64
+        if constexpr (DIMS == 2 && VEC == 4) {
+            // row sums of 1/A for the row-mean preconditioner of the pressure CG (k_fd_rowmean_factor, fg_fdprecond.hip): the 16 lanes
+            // of a tile row add up their 64 cells on the VALU (DPP) and the tile's partial goes to its own slot [b][j][x-tile] -- no
+            // atomics, so the factorisation sums the partials in a fixed order (bit-reproducible steps)
+            if (a.row_part) {
+                float v = (r.v[0] + r.v[1]) + (r.v[2] + r.v[3]);
+#define FG_DPP16(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, 0xf, 0xf, false))
+                v += FG_DPP16(v, 0xb1);      // quad_perm [1,0,3,2]
+                v += FG_DPP16(v, 0x4e);      // quad_perm [2,3,0,1]
+                v += FG_DPP16(v, 0x124);     // row_ror:4
+                v += FG_DPP16(v, 0x128);     // row_ror:8  -> every lane of the 16-lane row holds the row's sum
+#undef FG_DPP16
+                if ((threadIdx.x & 15) == 0) a.row_part[((size_t)c.b * g.ny + c.j) * tiles_x + c.i0 / 64] = v;
+            }
+        }
+#endif
     }
 #pragma unroll
     for (int f = 0; f < 2 * DIMS; ++f) {

@@ -463,11 +463,19 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         v.x = a.x; v.r = a.r; v.t1 = s->w[3]; v.z = zvec; v.w = s->w[4]; v.p = a.p; v.s = a.Ap;
         FgCgLead lead;
         lead.best = s->cg_best;
+        // preconditioner of this solve: the row-mean operator (per-env factors, made once per 1/A field: both correctors of a PISO
+        // step share them) where it applies, the grid's A = 1 operator otherwise
+        const bool rowm = fg_fd_rowmean_ok(s);
+        if (rowm && !(a.rA == s->rA && s->fd_row_epoch == s->rA_epoch)) {
+            const bool parts = a.rA == s->rA && s->fd_row_part && s->fd_row_part_epoch == s->rA_epoch;      // the assembly left the row sums
+            if (int rc = fg_fd_rowmean_factor(s, a.rA, a.dt, st, parts ? s->fd_row_part : nullptr, (s->grid.nx + 63) / 64)) return rc;
+            s->fd_row_epoch = (a.rA == s->rA) ? s->rA_epoch : -1;
+        }
         judge.it = -1;
         if (!(start_ready && start_fwd))      // (k_fcg_div_fwd already transformed r_0: the verdict on x_0 is the tridiagonal kernel's alone)
             if (int rc = fg_fd_dct_forward(s, a.r, v.t1, st, 0, &judge)) return rc;      // u = Qx^T r_0 (the verdict on x_0 rides here)
         lead.judge = judge;
-        if (int rc = fg_fd_tridiag(s, v.t1, st, &lead)) return rc;
+        if (int rc = fg_fd_tridiag(s, v.t1, st, &lead, rowm)) return rc;
         if (int rc = fg_fcg_inv_apply(s, v, a.rA, 0, ns, st)) return rc;
         int first = 1;
         for (; it < a.max_iterations && !done; ++it) {
@@ -505,7 +513,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                     first = 1;
                 }
                 lead.judge = judge;
-                if (int rc = fg_fd_tridiag(s, v.t1, st, &lead)) return rc;
+                if (int rc = fg_fd_tridiag(s, v.t1, st, &lead, rowm)) return rc;
                 if (int rc = fg_fcg_inv_apply(s, v, a.rA, it + 1, ns, st)) return rc;
             }
         }

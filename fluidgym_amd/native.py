@@ -373,6 +373,17 @@ class NativeSolver:
         res["piso_steps"] = int(out[12])
         return res
 
+    def config_dump(self) -> dict:
+        """The switches this handle runs under (``fg_config_dump``: the FG_* variables read at create time + the solver policies set
+        through the API) plus the process environment's FG_* / FLUIDGYM_AMD_* variables."""
+        import json
+
+        buf = ctypes.create_string_buffer(4096)
+        L.check(self.lib.fg_config_dump(self.handle, buf, 4096), lib=self.lib)
+        out = json.loads(buf.value.decode())
+        out["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("FG_", "FLUIDGYM_"))}
+        return out
+
     def set_return_best(self, on: bool = True):
         """``pressure_return_best_result`` of the reference's Simulation: keep / hand back the best CG iterate."""
         L.check(self.lib.fg_set_return_best(self.handle, int(on)), lib=self.lib)

@@ -559,6 +559,17 @@ class MultiBlockDomain:
         res["piso_steps"] = int(out[12])
         return res
 
+    def config_dump(self) -> dict:
+        """The switches this handle runs under (``fg_mb_config_dump``) plus the process environment's FG_* / FLUIDGYM_* variables."""
+        import json
+        import os
+
+        buf = ctypes.create_string_buffer(4096)
+        L.check(self.lib.fg_mb_config_dump(self.handle, buf, 4096))
+        out = json.loads(buf.value.decode())
+        out["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("FG_", "FLUIDGYM_"))}
+        return out
+
     # ---- live kernel timing (bench.py)
     def profile_enable(self, on: bool = True) -> None:
         L.check(self.lib.fg_mb_profile_enable(self.handle, int(on)))

@@ -487,6 +487,12 @@ int fg_mb_debug_cycles(fg_mb_handle h, uint64_t* out12_host);
 int fg_mb_solver_hints(fg_mb_handle h, int32_t* hints36, int32_t set);
 /* as fg_solver_counters, for the multi-block path */
 int fg_mb_solver_counters(fg_mb_handle h, int64_t* out13_host, int32_t reset);
+/* The tuning / diagnosis switches a handle runs under (the FG_* environment variables read ONCE at create time, docs/SWITCHES.md,
+ * and the solver policies set through the API), as one JSON object written to buf (NUL-terminated, at most n bytes; returns the
+ * length needed when the buffer is too small, a negative status on error).  bench.py stores it with every result, so a number can
+ * be traced to the code paths that produced it.  (No counterpart in the reference: its solver has no such switches.) */
+int fg_config_dump(fg_handle h, char* buf, int n);
+int fg_mb_config_dump(fg_mb_handle h, char* buf, int n);
 int fg_mb_solver_unconverged(fg_mb_handle h, int64_t* out4_host);   /* as fg_solver_unconverged */
 /* Simulation.single_step for such a domain (simulation.py:206-280): boundary-flux guard, per-env adaptive substeps
  * (_PISO_adaptive_step, PISOtorch_simulation.py:2004-2064), the advective-outflow PRE hook on ONE FIXED face given as

@@ -1,0 +1,129 @@
+"""Generates docs/SWITCHES.md: every environment switch of the package, FROM THE SOURCE (getenv / os.environ sites), with where it is
+read, its default, and whether it can change results.  The "results" and "what" columns are annotations kept here; a switch found in
+the source without an annotation (or annotated but gone from the source) fails the run, so the table cannot rot:
+    python profiles/gen_switch_table.py            # rewrite docs/SWITCHES.md
+    python profiles/gen_switch_table.py --check    # exit 1 if the committed table is stale (tests/test_switch_table.py)"""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# name -> (changes results?, what it does).  "bits" = same converged answer, different rounding / iteration trajectory;
+# "no" = timing / diagnosis only; "policy" = a documented departure from (or return to) the reference's solver policy
+NOTES = {
+    "FG_CG_FUSED": ("bits", "1 (default): three-launch preconditioned pressure CG on 2-D fast-transform grids (fg_fftcg.hip); 0: the five kernels"),
+    "FG_BICG_PFUSED": ("bits", "1 (default): six-launch Helmholtz-preconditioned BiCGStab (fg_fftbicg.hip); 0: eleven launches per iteration"),
+    "FG_BICG_FUSED": ("bits", "1 (default): two-kernel BiCGStab iteration in 2-D; 0: five kernels; 2: two kernels in 3-D bricks too"),
+    "FG_BICG_SUB": ("no", "envs per sub-batch of the 2-D two-kernel BiCGStab (unset: by working set; 0: never)"),
+    "FG_BICG3": ("bits", "z-marching 3-D BiCGStab: 0 never, N always with z-chunk N (tests), unset by the rule"),
+    "FG_BICG3_BXL": ("no", "tile lanes along x of the z-marching BiCGStab (16 / 32)"),
+    "FG_BICG3_MIX": ("bits", "debugging: bit 0 kernel a, bit 1 kernel b as z-march, bit 2 keep the init kernel"),
+    "FG_CG_WGS_PER_SLOT": ("no", "workgroups sharing one CG accumulator slot (256)"),
+    "FG_REDUCE_WGS": ("no", "workgroups per env of the reduction kernels (0 = rule)"),
+    "FG_TRIDIAG_CB": ("no", "columns per workgroup of k_tridiag_y_lds: 64 (default) / 32"),
+    "FG_HELM_CB": ("no", "columns per workgroup of k_helm_apply_y: 32 (default) / 64"),
+    "FG_HELM_ROWFORM": ("bits", "0: Helmholtz factors through k_helm_coeffs + the array-form line kernels (IEEE division instead of v_rcp)"),
+    "FG_FD_ROWMEAN": ("bits", "1 (default): the fused pressure CG is preconditioned by the row-mean operator (per-env factors, one factorisation per PISO step); 0: the grid's A = 1 factors"),
+    "FG_FORCE_ZMARCH": ("bits", "z-march chunk length of the 3-D Poisson kernels (tests on small grids; -1 = brick kernels)"),
+    "FG_ZMARCH_BXL": ("no", "tile shape of the z-march Poisson kernels (16 / 32 / 64 float4 lanes)"),
+    "FG_ZMARCH_SB": ("no", "single-barrier ring of the z-march kernels: bit per mode, 0 never, unset = rule"),
+    "FG_POLL_SPIN": ("no", "0: host polls wait with hipStreamSynchronize instead of spinning on pinned sequence words"),
+    "FG_PROF_PERIOD": ("no", "sampling period of the live kernel timing (64)"),
+    "FG_FD_NO_FFT": ("bits", "1: the x basis change of the FD preconditioner as dense GEMM instead of the row FFT (tests)"),
+    "FG_MB_BICG_VEC4": ("no", "bit per multi-block BiCGStab kernel: four-cell form (31 = all)"),
+    "FG_MB_BICG_FUSE": ("bits", "multi-block BiCGStab: 0 five kernels, 1 s/t fused, 2 (default) also p/v"),
+    "FG_MB_PRED": ("no", "0: first convergence poll after two iterations instead of where the previous solve ended"),
+    "FG_MB_ML_FUSE": ("bits", "multilevel BiCGStab forms p / s inside the restriction: 0 never, 1 up to 32 systems, 2 always"),
+    "FG_MB_ML_SB": ("no", "systems per workgroup of k_ml_coarse (4 / 8; 0 = by batch)"),
+    "FG_MB_ML_TRY_CAP": ("policy", "iteration cap of an attempt of the multilevel trial (200; tests force 2)"),
+    "FG_MB_ML_WARMUP": ("policy", "pressure solves a handle runs plain before its first multilevel attempt"),
+    "FG_MB_GRAPH": ("no", "chunked CG replayed as a hipGraph"),
+    "FG_MB_TRACE": ("no", "residual / verification trace of the pressure BiCGStab on stderr"),
+    "FG_MB_TRACE_FAIL": ("no", "recurrence words of a system that ends non-finite"),
+    "FG_MB_COMPACT": ("no", "0: every multi-block Krylov launch covers all systems of the batch"),
+    "FG_MB_OC_RTG_NT": ("bits", "register-resident on-chip CG with a global residual copy on 16-24 k-cell meshes instead of k_mbc_l2"),
+    "FG_MB_ONCHIP": ("bits", "0: no whole-solve on-chip CG (chunked CG kernels)"),
+    "FG_MB_OC_AGG": ("bits", "0: cell-ordered on-chip CG instead of the aggregate-owned one"),
+    "FG_MB_OC_VARIANT": ("no", "on-chip CG variant bits (fences / coefficient layout)"),
+    "FG_MB_RUNG_ILU": ("bits", "0: column-scaled preconditioned rung instead of ILU(0)"),
+    "FG_MB_SCALAR_CG": ("bits", "1: one-cell chunked CG"),
+    "FLUIDGYM_AMD_LIB": ("no", "path of libfluidgym_hip.so (sanitizer build: tests/run_sanitizer_suite.sh)"),
+    "FLUIDGYM_AMD_LIB_F64": ("no", "path of libfluidgym_hip_f64.so"),
+    "FLUIDGYM_AMD_ADVECTION_FD_PRECONDITIONER": ("bits", "policy advection_fd_preconditioner: auto (2-D periodic-x grids) / always / never"),
+    "FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER": ("bits", "policy advection_line_preconditioner (off)"),
+    "FLUIDGYM_AMD_ADVECTION_RUNG_PRECONDITIONER": ("bits", "preconditioner of the BiCG_precondition_fallback rung: line / ilu"),
+    "FLUIDGYM_AMD_ADVECTION_WARM_START": ("policy", "1: velocity solve starts from the current velocity in both branches (reference: branch rule)"),
+    "FLUIDGYM_AMD_PRESSURE_WARM_START": ("policy", "1: pressure solves start from the previous pressure (reference: zero)"),
+    "FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT": ("policy", "accept a stalled pressure solve within a factor of the tolerance (off)"),
+    "FLUIDGYM_AMD_PRESSURE_MULTILEVEL": ("bits", "multilevel preconditioner of the multi-block pressure CG"),
+    "FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB": ("bits", "multilevel trial of the airfoil's refined BiCGStab"),
+    "FLUIDGYM_AMD_PRESSURE_BICGSTAB_LARGE_MESHES": ("bits", "3-D multi-block ids take the refined BiCGStab"),
+    "FLUIDGYM_AMD_NATIVE_WALL_FORCING": ("bits", "policy native_wall_forcing: the TCF forcing hook runs inside the library"),
+    "FLUIDGYM_COLLECTIVE_TIMEOUT_S": ("no", "timeout of ParallelFluidEnv's process group (600 s)"),
+    "FLUIDGYM_FORCE_COLLECTIVES": ("no", "ParallelFluidEnv issues its collectives at world size 1 too (tests)"),
+    "FLUIDGYM_MASTER_PORT": ("no", "rendezvous port of the reference-style ParallelFluidEnv(cuda_ids=...) entry"),
+    "FLUIDGYM_DATA_PATH": ("no", "local data path (initial domains), as config.update('local_data_path', ...)"),
+}
+IGNORE = {"RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "PYTHONPATH", "OMP_NUM_THREADS",
+          "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "TMPDIR", "GRAFT_REPO_ROOT"}
+
+
+def scan():
+    found = {}
+    for base, _, files in os.walk(os.path.join(ROOT, "fluidgym_amd")):
+        if "_san" in base or "_f64" in base or "_var" in base or "__pycache__" in base:
+            continue
+        for fn in files:
+            if not fn.endswith((".hip", ".h", ".py")):
+                continue
+            path = os.path.join(base, fn)
+            rel = os.path.relpath(path, ROOT)
+            for no, line in enumerate(open(path, errors="replace"), 1):
+                for m in re.finditer(r'getenv\("([A-Z][A-Z0-9_]+)"\)', line):
+                    found.setdefault(m.group(1), []).append(f"{rel}:{no}")
+                for m in re.finditer(r'environ(?:\.get)?[\[(]\s*"([A-Z][A-Z0-9_]+)"', line):
+                    found.setdefault(m.group(1), []).append(f"{rel}:{no}")
+    return {k: v for k, v in found.items() if k not in IGNORE}
+
+
+def render(found):
+    lines = ["# Environment switches of fluidgym_amd", "",
+             "Generated by `python profiles/gen_switch_table.py` from the `getenv` / `os.environ` sites of the source; `tests/test_switch_table.py`",
+             "fails when this file is stale.  The native library reads its variables ONCE, at `fg_create` / `fg_mb_create` (never on a step",
+             "path); `fg_config_dump` / `fg_mb_config_dump` report the values a handle runs under and `bench.py` stores them with every leg",
+             "(`profiles/bench_detail.json`).  None is needed in normal operation.", "",
+             "*results*: **no** = timing / diagnosis only; **bits** = the same converged answer through another kernel form (rounding and",
+             "iteration trajectories differ); **policy** = a documented departure from (or return to) the reference's solver policy.", "",
+             "| variable | results | read at | what |", "|---|---|---|---|"]
+    for name in sorted(found):
+        res, what = NOTES[name]
+        where = ", ".join(f"`{w}`" for w in found[name][:2]) + (" ..." if len(found[name]) > 2 else "")
+        lines.append(f"| `{name}` | {res} | {where} | {what} |")
+    lines += ["", "Build-time defines (profiling builds only): `-DFG_ACC_ACCESS`, `-DFG_FLAG_ACCESS`, `-DFG_MB_OC_CYCLES`, `-DFG_KNOCK_B`, `-DFG_WAVE_SHFL`,",
+              "`-DFG_DCT_KNOCK` -- see the comments where they are tested.", ""]
+    return "\n".join(lines)
+
+
+def main():
+    found = scan()
+    missing = sorted(set(found) - set(NOTES))
+    gone = sorted(set(NOTES) - set(found))
+    if missing or gone:
+        print(f"switch table out of date: in the source without a note {missing}; noted but not in the source {gone}")
+        return 1
+    text = render(found)
+    path = os.path.join(ROOT, "docs", "SWITCHES.md")
+    if "--check" in sys.argv:
+        # line numbers move with every edit: compare names and annotations only
+        cur = open(path).read() if os.path.exists(path) else ""
+        strip = lambda t: re.sub(r"\| `[^|]*:\d+`[^|]*\|", "| |", t)
+        return 0 if strip(cur) == strip(text) else 1
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    open(path, "w").write(text)
+    print(f"wrote {path}: {len(found)} switches")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -13,7 +13,7 @@ import torch
 
 import fluidgym_amd
 from oracle import piso_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import f64_twin, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -75,8 +75,20 @@ def test_tcf_full_batch_step_matches_the_reference_recurrences(monkeypatch):
         v5, p5, st_5 = _native_step(env, u0, src, dt, monkeypatch, "five")
         print("TCF x 8 one PISO step, iterations [velocity, pressure0, pressure1]: z-march", st_z, "five kernels", st_5)
         assert rel_err(vz.cpu().numpy(), v5.cpu().numpy()) < 2e-5
-        g = O.Grid(O.rectilinear_coords([np.asarray(e, np.float64) for e in env._block.edges]))
-        opts = O.SolverOptions(direct=False, advection_tol=1e-10, pressure_tol=1e-10, non_orthogonal=True, stats={})
+        # envs 0 and 7 through the fp64 build of the library (brick kernels, plain recurrences) far below the fp32 tolerances
+        twin = f64_twin(ns, (0, B - 1), u0)
+        for f in (2, 3):
+            twin.bvel[f].zero_()
+        twin.set_velocity_source(src[[0, B - 1]].double().contiguous())
+        twin.set_advection_start(False)
+        ok64, st64 = twin.piso_step(dt, advection_tol=1e-13, pressure_tol=1e-13, max_iterations=50000)
+        v64, p64 = twin.velocity.cpu().numpy(), twin.pressure.cpu().numpy()
+        twin.close()
+        # (the oracle's grid = the fp32 widths the library holds, promoted: fp32 path, fp64 twin and oracle see the same metrics)
+        g = O.Grid(O.rectilinear_coords([np.concatenate([[0.0], np.cumsum(np.asarray(w, np.float64))]) for w in ns.widths]))
+        # (round 5: 1e-13 instead of 1e-10 -- this flow's pressure right-hand side has an rms of 7e-6, and at 1e-10 the ORACLE's own
+        #  pressure was only good to 1.3e-3: the fp64 build of the library, driven to 1e-12, showed the same 'error' as the fp32 path)
+        opts = O.SolverOptions(direct=False, advection_tol=1e-13, pressure_tol=1e-13, non_orthogonal=True, stats={})
         for b in (0, B - 1):
             bc = {2: O.FixedBC(np.zeros(3)), 3: O.FixedBC(np.zeros(3))}
             ref = O.Domain(g, float(ns.viscosity), u0[b].cpu().numpy().astype(np.float64), np.zeros(g.shape), bc)
@@ -87,8 +99,14 @@ def test_tcf_full_batch_step_matches_the_reference_recurrences(monkeypatch):
             pg = pz[b, 0].cpu().numpy().astype(np.float64)
             ep = rel_err(pg - pg.mean(), pr)
             print(f"TCF_B8_ERR env {b}: velocity {ev:.2e} pressure {ep:.2e}; oracle iterations {opts.stats}")
-            # (pressure in the max norm, fp32 solve against the fp64 recurrence: measured 6e-3; the velocity is what the step hands on)
-            assert ev < 3e-5 and ep < 2e-2, (b, ev, ep)
+            k = 0 if b == 0 else 1
+            p6 = p64[k, 0] - p64[k, 0].mean()
+            ev64, ep64 = rel_err(v64[k], ref.velocity), rel_err(p6, pr)
+            print(f"TCF_B8_F64 env {b}: velocity {ev64:.2e} pressure {ep64:.2e} (fp64 build, iterations {st64})")
+            # the fp64 build of the same assembly / operator / corrector kernels agrees with the fp64 recurrence to the oracle's own
+            # solver tolerance: the fp32 pressure figure (max norm, measured 1.3-1.7e-3) is fp32 solver tolerance x conditioning
+            assert ev64 < 1e-7 and ep64 < 1e-5, (b, ev64, ep64)
+            assert ev < 3e-5 and ep < 4e-3, (b, ev, ep)
         # the env's own step on the batch (its tolerances, its hooks)
         ns.solver_counters(reset=True)
         obs, reward, term, trunc, info = env.step(env.sample_action())
