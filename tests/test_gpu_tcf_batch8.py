@@ -103,10 +103,11 @@ def test_tcf_full_batch_step_matches_the_reference_recurrences(monkeypatch):
             p6 = p64[k, 0] - p64[k, 0].mean()
             ev64, ep64 = rel_err(v64[k], ref.velocity), rel_err(p6, pr)
             print(f"TCF_B8_F64 env {b}: velocity {ev64:.2e} pressure {ep64:.2e} (fp64 build, iterations {st64})")
-            # the fp64 build of the same assembly / operator / corrector kernels agrees with the fp64 recurrence to the oracle's own
-            # solver tolerance: the fp32 pressure figure (max norm, measured 1.3-1.7e-3) is fp32 solver tolerance x conditioning
+            # measured (round 5, oracle driven to 1e-13): fp32 velocity 4-5e-7, pressure 6-8e-5 (max norm); fp64 build 7-8e-10 / 2-3e-6.
+            # (Rounds 3-4 read a pressure "error" of 1.3-1.7e-3 here: that was the ORACLE's pressure, stopped at 1e-10 on a right-hand
+            #  side of rms 7e-6 -- the fp64 twin exposed it by showing the same figure.)  fp32 bounds = 2x measured
             assert ev64 < 1e-7 and ep64 < 1e-5, (b, ev64, ep64)
-            assert ev < 3e-5 and ep < 4e-3, (b, ev, ep)
+            assert ev < 3e-6 and ep < 2e-4, (b, ev, ep)
         # the env's own step on the batch (its tolerances, its hooks)
         ns.solver_counters(reset=True)
         obs, reward, term, trunc, info = env.step(env.sample_action())
