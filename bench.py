@@ -565,6 +565,9 @@ def main():
     ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 64 leg (about 18 s)")
     ap.add_argument("--all-legs", action="store_true", help="also run the opt-in modes and the 256 / 64-env multi-block legs")
     ap.add_argument("--leg-budget", type=float, default=75.0, help="seconds after which no further extra leg is started")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="dry run of the N > 1 path on a ONE-GPU box: every rank steps its shard on cuda:0 and the collectives go through gloo "
+                         "(host-staged); the value it prints is NOT a scaling figure (tests/test_gpu_two_ranks.py)")
     ap.add_argument("--forcing", type=float, default=2.0,
                     help="amplitude of the random body force (velocity source N(0, forcing), redrawn every env step); 0 = quiescent channel")
     args = ap.parse_args()
@@ -592,11 +595,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = torch.device("cpu") if args.share_gpu else device      # where the bench's own collectives live
 
     n_total = args.envs_per_gpu * world
-    penv = ParallelFluidEnv(args.env_id, num_envs=n_total)
+    if args.share_gpu:
+        penv = ParallelFluidEnv(args.env_id, num_envs=n_total, backend="gloo", cuda_ids=[0] * world)
+    else:
+        penv = ParallelFluidEnv(args.env_id, num_envs=n_total)
     env = penv.local_env
     penv.reset(seed=1234, randomize=True)
     gen = torch.Generator(device="cpu").manual_seed(7)
@@ -647,16 +655,16 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # what each rank spent in its OWN shard's steps and how many adaptive sub-steps its envs took: the imbalance SURVEY 8e names
         # as the scaling risk (a step ends with its slowest shard) is then visible next to the max-over-ranks figure
         c_r = solver.solver_counters()
-        mine = torch.tensor([penv.shard_seconds, float(c_r["piso_steps"])], dtype=torch.float64, device=device)
-        allr = torch.empty((world, 2), dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(allr, mine)
-        allr = allr.cpu().tolist()
+        mine = torch.tensor([penv.shard_seconds, float(c_r["piso_steps"])], dtype=torch.float64, device=coll_device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        allr = torch.stack(parts).cpu().tolist()
         ms = [1e3 * r[0] / args.steps for r in allr]
         per_rank = {"shard_ms_per_step": [round(v, 3) for v in ms], "min_ms": round(min(ms), 3), "max_ms": round(max(ms), 3),
                     "imbalance": round(max(ms) / max(min(ms), 1e-9), 3),
@@ -699,7 +707,7 @@ def main():
                        "workload_modified": forcing > 0,
                        "forcing_amplitude": forcing,
                        "global_batch": n_total, "grid": grid_desc,
-                       "parallelism": f"env-sharded x{world}, 1 bcast + 1 all_gather per step (RCCL)",
+                       "parallelism": f"env-sharded x{world}, 1 bcast + 1 all_gather per step ({'gloo, ALL RANKS ON ONE GPU: dry run, not a scaling figure' if args.share_gpu else 'RCCL'})",
                        "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start),
                        "pressure_solver": ("CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)"
                                            if single_block else "multi-block path (fg_mb_*): see the cylinder_env / airfoil_env legs"),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/r05_*: per-leg kernel statistics (every bench leg, VERDICT r4 "missing 2": PMC for every leg) and the FETCH_SIZE /
 # WRITE_SIZE PMC passes (separate runs, no tracing domains mixed in) of the headline command, the 256^3 micro-benchmark and the TCF leg.
-#   bash profiles/run_r05_profiles.sh [all | headline | legs | pmc | rbc]
+#   bash profiles/run_r05_profiles.sh [all | headline | legs | pmc | rbc | refresh]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
@@ -41,6 +41,18 @@ CYL="python3 $R/profiles/leg_run.py CylinderJet2D-easy-v0 64 4 1 0 initial_domai
 AIR="python3 $R/profiles/airfoil_bench.py 64 1 40"
 if [ $W = rbc ]; then
   stats g_rbc $RBC
+fi
+if [ $W = refresh ]; then      # the legs whose kernels changed late in the round
+  stats a_bench $BENCH
+  pmc a_bench FETCH_SIZE $BENCH
+  pmc a_bench WRITE_SIZE $BENCH
+  stats g_rbc $RBC
+  pmc g_rbc FETCH_SIZE $RBC
+  pmc g_rbc WRITE_SIZE $RBC
+  stats h_large $LARGE
+  pmc h_large FETCH_SIZE $LARGE
+  pmc h_large WRITE_SIZE $LARGE
+  stats f_tcf $TCF
 fi
 if [ $W = all ] || [ $W = pmc ]; then
   pmc b_poisson256 FETCH_SIZE python3 $R/profiles/micro_poisson.py

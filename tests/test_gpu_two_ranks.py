@@ -70,3 +70,24 @@ def test_two_ranks_on_one_gpu_reproduce_two_independent_shards(env_id, kv, kw, t
         finally:
             plain.close()
     assert checks >= 12
+
+
+def test_bench_world_2_path_runs_on_one_gpu():
+    """``bench.py --gpus 2 --share-gpu``: the N > 1 branch of the bench -- barrier, max-over-ranks time, per-rank shard times and
+    sub-steps -- as a dry run on the one GPU (gloo, both ranks on cuda:0).  What SCALE will run with RCCL on a real node; the value is
+    not a scaling figure and says so."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "4",
+           "--no-micro", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, f"bench failed:\n{run.stdout[-3000:]}\n{run.stderr[-6000:]}"
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    pr = line["config"]["per_rank"]
+    assert len(pr["shard_ms_per_step"]) == 2 and pr["min_ms"] > 0 and pr["imbalance"] >= 1.0
+    assert len(pr["mean_substeps_per_sim_step"]) == 2
+    assert "dry run" in line["config"]["parallelism"]
