@@ -104,6 +104,8 @@ KERNEL_DOC = {
     "k_bicg_x": "BiCGStab x/r update + r.r + rw.r",
     "k_bicgf_a": "BiCGStab two-kernel form, first half: x, r, p updates + v = C p (p at the neighbours recomputed) + rw.v, r.r",
     "k_bicgf_b": "BiCGStab two-kernel form, second half: s = r - alpha v, t = C s (s at the neighbours recomputed) + five dot products",
+    "k_jac_pass": "velocity systems, point-Jacobi sweeps with the region on chip (fg_jacobi.hip): matrix (5), b (2), x (2) read once and x (2) "
+                  "written for 4-8 sweeps; algorithmic bytes = 11 floats per cell and pass, the halo rows a region re-reads are overhead",
     "k_line_y": "y-line (tridiagonal) right preconditioner of the advection BiCGStab: z = M^-1 r per column block in LDS",
     "k_gemm_f32": "fast-diagonalisation preconditioner: eigenbasis transform along x/z (fp32 MFMA 32x32x2)",
     "k_gemm_sk": "fast-diagonalisation preconditioner: eigenbasis transform, split-K 32x32 tiles (few live envs)",
@@ -339,6 +341,18 @@ def solver_switches(solver):
         return {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
 
+def velocity_solver_desc(env, solver) -> str:
+    """Which iteration solved the velocity systems of the timed region (policy advection_jacobi, csrc/fg_jacobi.hip)."""
+    try:
+        c = solver.advection_jacobi_counts()
+    except Exception:
+        return "BiCGStab"
+    if not getattr(env._sim, "advection_jacobi", False) or (c["settled_by_sweeps"] == 0 and c["handed_to_bicgstab"] == 0):
+        return "BiCGStab (the reference's solver)"
+    return (f"on-chip Jacobi sweeps (policy advection_jacobi; {c['settled_by_sweeps']} solves settled by them, {c['handed_to_bicgstab']} handed to "
+            "BiCGStab; the velocity 'iterations' are sweeps); krylov_mode leg = BiCGStab")
+
+
 def solver_iterations(solver) -> dict:
     c = solver.solver_counters()
     out = {k: {"mean": (round(v["mean"], 2) if v["mean"] is not None else None), "max": v["max"], "unconverged": v.get("unconverged", 0),
@@ -395,7 +409,7 @@ def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing
                 "piso_steps_per_env_step": sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": its,
                 "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
-                "policy": "uniform samples of the action space", "switches": solver_switches(solver),
+                "policy": "uniform samples of the action space", "switches": solver_switches(solver), "velocity_solver": velocity_solver_desc(env, solver),
                 "dominant_kernel": None if roof is None else {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
                 "kernels": None if roof is None else {k: {kk: v[kk] for kk in ("avg_busy_launch_ms", "launches", "est_total_ms", "GBps", "TFLOPps")}
                                                       for k, v in roof["kernels"].items()}}
@@ -501,7 +515,8 @@ def compact_line(out, detail_path=DETAIL_PATH):
                       "substeps_per_sim_step": cfg.get("mean_substeps_per_sim_step"),
                       "capped_solves": cfg.get("capped_solves"),
                       "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step")),
-                      "step_GBps": _r(cfg.get("step_GBps")), "advection_solver_form": cfg.get("advection_solver_form")}
+                      "step_GBps": _r(cfg.get("step_GBps")), "advection_solver_form": cfg.get("advection_solver_form"),
+                      "velocity_solver": cfg.get("velocity_solver")}
     if cfg.get("per_rank"):
         line["config"]["per_rank"] = cfg["per_rank"]
     roof = out.get("roofline")
@@ -712,6 +727,7 @@ def main():
                        "pressure_solver": ("CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)"
                                            if single_block else "multi-block path (fg_mb_*): see the cylinder_env / airfoil_env legs"),
                        "advection_solver_form": solver.advection_solver_form() if single_block else None,
+                       "velocity_solver": velocity_solver_desc(env, solver) if single_block else None,
                        "solver_iterations": its, "capped_solves": capped_solves(its),
                        "iters_are": "iterations per solve (counts; 0 = initial residual met the tolerance)",
                        "launches_per_piso_step": launches_per_piso_step(prof, its) if single_block else None,
@@ -744,6 +760,12 @@ def main():
         leg("quiescent_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=half, warmup=2, seed=1234,
             doc="headline workload without the body force: the laminar channel's pressure right-hand side sits at the "
                 "reference's absolute tolerance, the projections take 0-1 iterations")
+        # the same workload with the reference's solver for the velocity systems (policy advection_jacobi off: two-kernel BiCGStab)
+        old = fluidgym_amd.set_solver_policy(advection_jacobi=False)
+        leg("krylov_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=half, warmup=2, seed=1234, forcing=args.forcing,
+            doc="headline workload with advection_jacobi=False: the velocity systems by BiCGStab (the reference's solver) instead of the "
+                "on-chip Jacobi sweeps -- same systems, same tolerance")
+        fluidgym_amd.set_solver_policy(**old)
         leg("large_env", env_leg, "ChannelJet2D-large-v0", 64, device, steps=5, warmup=1, seed=1234, forcing=args.forcing,
             doc="BASELINE config 5's per-GPU share: 512x256 x 64 envs (working set > Infinity Cache: the HBM-resident 2-D case)")
         leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=8, warmup=1,

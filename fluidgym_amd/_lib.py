@@ -229,6 +229,8 @@ SIGNATURES = {
     "fg_advection_retries": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_advection_solver_form": (c_int, [c_void_p, c_int, POINTER(c_int32)]),
     "fg_set_double_fallback": (c_int, [c_void_p, c_int]),
+    "fg_set_advection_jacobi": (c_int, [c_void_p, c_int]),
+    "fg_advection_jacobi_counts": (c_int, [c_void_p, POINTER(c_int64)]),
     "fg_ladder": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_solver_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
     "fg_mb_profile_iterations": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -132,6 +132,12 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     s->fd_row_epoch = -1; s->rA_epoch = 0; s->fd_row_part_epoch = -1;
     { const char* ev = getenv("FG_CG_FUSED"); s->cg_fused = ev ? atoi(ev) : 1; }       // 0: five-kernel preconditioned CG iteration (fg_poisson.hip)
     { const char* ev = getenv("FG_BICG_PFUSED"); s->bicg_pfused = ev ? atoi(ev) : 1; } // 0: eleven-launch Helmholtz-preconditioned BiCGStab iteration
+    // FG_ADV_JACOBI: 1 = the velocity systems of uniform 2-D grids go to the Jacobi sweeps first (fg_jacobi.hip) | 0 = never | unset: off
+    // until fg_set_advection_jacobi turns it on (the Python Simulation does, policy advection_jacobi)
+    { const char* ev = getenv("FG_ADV_JACOBI"); s->adv_jacobi = ev ? atoi(ev) : 0; s->adv_jacobi_env = ev ? 1 : 0; }
+    for (int k = 0; k < 4; ++k) s->jac_hist[k] = FgJacHist{0, 0, 0};
+    s->jac_solves = s->jac_fallbacks = 0;
+    FG_HIP_CHECK(hipHostMalloc(&s->jac_prev, sizeof(float) * nsys));
     FG_HIP_CHECK(hipMalloc(&s->fcg_alpha, sizeof(double) * 2 * (size_t)g.B));
     FG_HIP_CHECK(hipMemset(s->fcg_alpha, 0, sizeof(double) * 2 * (size_t)g.B));
     FG_HIP_CHECK(hipMalloc(&s->fcg_xsum, sizeof(FgDacc) * 2 * (size_t)g.B));
@@ -166,6 +172,7 @@ extern "C" int fg_destroy(fg_handle s) {
     for (float* p : fd) if (p) (void)hipFree(p);
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
     (void)hipFree(s->cg_acc); (void)hipFree(s->fcg_alpha); (void)hipFree(s->fcg_xsum);
+    if (s->jac_prev) (void)hipHostFree(s->jac_prev);
     (void)hipFree(s->fd_row_part); (void)hipFree(s->fd_lam_x); (void)hipFree(s->fd_row_inv); (void)hipFree(s->fd_row_cp); (void)hipFree(s->fd_row_lower);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
     (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->force_uniform);
@@ -274,6 +281,18 @@ extern "C" int fg_set_advection_preconditioner(fg_handle s, int mode) {
     else if (mode != 0)
         if (int rc = fg_line_alloc(s)) return rc;
     s->adv_precond = mode;
+    return FG_OK;
+}
+extern "C" int fg_set_advection_jacobi(fg_handle s, int on) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    // (FG_ADV_JACOBI in the environment wins: A/B runs of whole envs; the fp64 build accepts the call and keeps the Krylov solver)
+    if (!s->adv_jacobi_env) s->adv_jacobi = on ? 1 : 0;
+    for (int k = 0; k < 4; ++k) s->jac_hist[k] = FgJacHist{0, 0, 0};
+    return FG_OK;
+}
+extern "C" int fg_advection_jacobi_counts(fg_handle s, int64_t* out2) {
+    FG_REQUIRE(s && out2, FG_ERR_INVALID_ARG, "null argument");
+    out2[0] = s->jac_solves; out2[1] = s->jac_fallbacks;
     return FG_OK;
 }
 extern "C" int fg_set_double_fallback(fg_handle s, int on) {
@@ -673,10 +692,10 @@ extern "C" int fg_config_dump(fg_handle s, char* buf, int n) {
         "\"FG_BICG3_BXL\": %d, \"FG_BICG3_MIX\": %d, \"FG_REDUCE_WGS\": %d, \"FG_CG_WGS_PER_SLOT\": %d, \"FG_TRIDIAG_CB\": %d, \"FG_HELM_CB\": %d, "
         "\"FG_HELM_ROWFORM\": %d, \"FG_FD_ROWMEAN\": %d, \"FG_POLL_SPIN\": %d, \"FG_PROF_PERIOD\": %d, \"fast_transform_x\": %d, \"fd_preconditioner\": %d, "
         "\"helmholtz\": %d, \"advection_preconditioner\": %d, \"advection_from_result\": %d, \"return_best\": %d, \"cg_reset_steps\": %d, "
-        "\"double_fallback\": %d, \"wall_forcing_axis\": %d}",
+        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d}",
         FG_F64 ? "f64" : "f32", s->cg_fused, s->bicg_pfused, s->bicg_fused, s->bicg_sub, s->bicg3_force, s->bicg3_bxl, s->bicg3_mix, s->reduce_wgs,
         s->cg_wgs_per_slot, s->tridiag_cb, s->helm_cb_pref, s->helm_rowform_off ? 0 : 1, s->fd_rowmean, s->poll.spin, s->prof.period, s->fd_dct_x, s->fd_Qx ? 1 : 0,
-        s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis);
+        s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis, s->adv_jacobi);
     if (len >= n) return len + 1;
     memcpy(buf, tmp, (size_t)len + 1);
     return FG_OK;

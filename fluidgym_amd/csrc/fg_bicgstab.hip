@@ -665,7 +665,32 @@ __global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ fla
 
 }  // namespace
 
+static int bicgstab_krylov(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, bool begun);
+
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st) {
+#if !FG_F64
+    // velocity systems of the uniform 2-D grids: Jacobi sweeps first (fg_jacobi.hip); what they do not settle goes to BiCGStab from a
+    // cleared start vector, with the solve state prepared afresh
+    if (fg_jacobi_ok(s, a)) {
+        const int nsys = s->grid.B * a.nc;
+        const bool ready = s->bicg_ready_nc == a.nc && s->bicg_ready_dt == a.dt;
+        s->bicg_ready_nc = 0; s->cg_ready_ns = 0;
+        if (!ready)
+            hipLaunchKernelGGL(k_bicg_begin, dim3((nsys + 63) / 64), dim3(64), 0, st, a.dt, s->acc, s->scratch_B + 4 * s->grid.B, s->flags, s->info_dev, nsys, a.nc);
+        int outcome = 0;
+        if (int rc = fg_jacobi_solve(s, a, info_host, st, &outcome)) return rc;
+        if (outcome == 1) { s->jac_solves += 1; return FG_OK; }
+        if (outcome == 0) return bicgstab_krylov(s, a, info_host, st, true);   // (not tried: the prepared state is untouched)
+        s->jac_fallbacks += 1;
+        FgBicgArgs a2 = a;
+        a2.use_x0 = 0;
+        return bicgstab_krylov(s, a2, info_host, st, false);
+    }
+#endif
+    return bicgstab_krylov(s, a, info_host, st, false);
+}
+
+static int bicgstab_krylov(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, bool begun) {
     const int B = s->grid.B, n = s->grid.n, nsys = B * a.nc;
     BicgPtrs q;
     q.diag = a.diag; q.off = a.off; q.rhs = a.rhs; q.x = a.x;
@@ -679,7 +704,7 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
     }
     const dim3 sg((nsys + 63) / 64), sb(64);
     {   // state already prepared by the k_adv_build that assembled this system (FgBicgBegin, fg_internal.h)?
-        const bool ready = s->bicg_ready_nc == a.nc && s->bicg_ready_dt == a.dt;
+        const bool ready = begun || (s->bicg_ready_nc == a.nc && s->bicg_ready_dt == a.dt);
         s->bicg_ready_nc = 0; s->cg_ready_ns = 0;
         if (!ready) hipLaunchKernelGGL(k_bicg_begin, sg, sb, 0, st, a.dt, q.acc, q.sc, q.flags, q.info, nsys, a.nc);
     }

@@ -538,7 +538,7 @@ __device__ __forceinline__ void fg_block_sum(fg_real (&v)[NV], fg_real* lds /* >
 enum FgProfKind {
     FG_PK_CG_AP = 0, FG_PK_CG_UPDATE, FG_PK_BICG_P, FG_PK_BICG_V, FG_PK_BICG_S, FG_PK_BICG_T, FG_PK_BICG_X,
     FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_DCT, FG_PK_LINE, FG_PK_BICGF_A, FG_PK_BICGF_B, FG_PK_FCG_UPD, FG_PK_FCG_INV,
-    FG_PK_FBICG_FWD, FG_PK_FBICG_INV, FG_PK_COUNT
+    FG_PK_FBICG_FWD, FG_PK_FBICG_INV, FG_PK_JAC_PASS, FG_PK_COUNT
 };
 #define FG_PROF_POOL 256
 struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };
@@ -566,6 +566,7 @@ struct FgProf {
 // poll's sequence number into a pinned word per entry; the host spins on those words.  Measured on MI355X (profiles/scratch/
 // poll_latency.hip): kernel -> host -> next kernel costs 6 us this way against 11.5 us through hipStreamSynchronize, 4-5 times per
 // PISO step.  Streams are in order, so "the polled kernel has finished" still means everything launched before it has.
+struct FgJacHist { int sweeps, skip, fails; };
 struct FgPollOut { int32_t* seq; int32_t value; };     // seq == nullptr: no word is written (the caller synchronises the stream)
 #ifdef __HIPCC__
 __device__ __forceinline__ void fg_poll_publish(const FgPollOut& p, int i) {
@@ -718,6 +719,10 @@ struct fg_state {
     // solver served all kinds: the RBC env's second corrector (0-1 iterations) then launched the first corrector's three iterations
     // before its first poll, and the first corrector polled twice
     int pred_bicg[4], pred_cg[4];
+    // Jacobi sweeps for the velocity systems of the uniform 2-D grids (fg_jacobi.hip): switch (FG_ADV_JACOBI / fg_set_advection_jacobi),
+    // per-kind history (sweeps the last solve needed; solves still to skip after a failure), pinned residuals of the pass before the last
+    int adv_jacobi, adv_jacobi_env; FgJacHist jac_hist[4]; float* jac_prev;
+    long long jac_solves, jac_fallbacks;
     FgCounters ctr;         // iterations per solve kind since the last reset (fg_solver_counters)
     const fg_real* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     // solver state already prepared by the kernel launched just before the solve (k_adv_build: FgBicgBegin, k_div: FgCgBegin) --
@@ -866,6 +871,12 @@ struct FgBicgArgs {
     int kind = 1;      // which poll predictor the solve reads and updates (fg_state::pred_bicg): 0 scalar, 1 velocity
 };
 int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st);
+#if !FG_F64
+// stationary sweeps instead of the Krylov iteration where the rows are diagonally dominant (fg_jacobi.hip); *outcome: 0 not tried,
+// 1 solved, 2 given up -- then the caller runs BiCGStab from a cleared start vector behind a fresh k_bicg_begin
+bool fg_jacobi_ok(const fg_state* s, const FgBicgArgs& a);
+int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, int* outcome);
+#endif
 // fp64 repeats of failed solves (fg_rung64.h; fp32 library only): every system of an env that has a failed one (BiCGStab: not
 // converged; CG: non-finite), info_host updated in place; returns the status of the repeated solves
 int fg_rung64_bicgstab(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, bool all_systems, hipStream_t st);

@@ -1,0 +1,404 @@
+// Point-Jacobi sweeps, several per pass over the field, for the velocity systems of the 2-D uniform-grid envs (the channel family).
+//
+// The advection-diffusion matrix of a PISO step is A = D + O with D = 1/dt + (diffusive and advective face sums) and O the four
+// neighbour coefficients (k_adv_build, fg_piso.hip; reference PISO_build_advection_matrix :4170-4312).  On the channel grids at
+// the envs' time steps the rows are strongly diagonally dominant -- sum|O| / D = 0.34 (256 x 128) and 0.63 (512 x 256), measured
+// on the bench states -- and the reference's BiCGStab (bicgstab_solver_kernel.cu) needs 4-5 / 7-8 iterations of two
+// matrix applications each, every one a full pass over x, r, p, v, s, t and the matrix in HBM (~48 floats per cell and iteration
+// for the two components).  The stationary iteration x <- D^-1 (b - O x) contracts the residual by 0.18 / 0.47 per sweep on
+// the same systems (11 / 24 sweeps to the reference's criterion, RMS residual < tol; profiles/scratch/jacobi_exp*.py) and needs NO
+// dot product between sweeps, so S sweeps run on one tile that stays on chip:
+//
+//   * a workgroup owns a region of 8192 cells = ROWS full rows of the grid (no halo in x: the row is complete; periodic x wraps
+//     inside it, FIXED x has zero coefficients there), of which the outer S rows towards a neighbouring region are halo: after
+//     S sweeps the inner rows are exact sweeps of the global iteration.  Regions at a y wall need no halo on that side.
+//   * each of the 512 threads keeps a strip of 4 rows x 4 columns in registers: the pre-scaled coefficients O/D (16 x 4), the
+//     right-hand sides b/D and the iterates of BOTH components (the matrix is shared by them);
+//     x neighbours come from the neighbouring lanes (ds_bpermute), y neighbours across strips from a ping-pong LDS array that
+//     holds only the top and bottom row of every strip (64 KB).  One barrier per sweep.
+//   * the last sweep of a pass also gives the residual of the iterate it started from: b - A x_k = D (x_{k+1} - x_k).  Its sum of
+//     squares over the region's output rows goes to the system's accumulator ring (FgDacc, order-independent); the NEXT pass -- or
+//     the check kernel behind the last enqueued pass -- takes the verdict from it with the rule of the Krylov kernels
+//     (RMS residual < tol; not finite = failed), per env: both components stop together.
+//
+// Per pass and cell: 9 floats read (5 matrix, 2 b, 2 x; x (ROWS_loaded / ny) for the halo rows) and 2 written for S sweeps, against
+// ~24 floats per matrix application of the two-kernel BiCGStab.  The host enqueues the number of passes the previous solve of the
+// same kind needed, then k_jac_check and one poll; what it learns there (contraction per pass) sizes what follows.  A solve that
+// does not contract (rows not dominant enough: refined grids, large time steps) is handed to BiCGStab from a cleared start
+// vector, and the kind backs off from trying again for a while.  Same system, same tolerance, same criterion: another iteration,
+// like the preconditioners of the other solves (fluidgym_amd/simulation/policy.py: advection_jacobi).
+//
+// fp32 library only (the fp64 build keeps the plain recurrences).
+#include "fg_internal.h"
+#include "fg_bicg.h"
+
+#if !FG_F64
+namespace {
+
+constexpr int JAC_THREADS = 512;
+constexpr int JAC_CELLS = 8192;
+constexpr int JAC_MAX_PASSES = 24;
+
+struct JacArgs {
+    const float* diag; const float* off; const float* rhs;   // [B,N], [B,4,N], [B,2,N]
+    const float* xin; float* xout;                            // [B,2,N] (xin unused in a pass that starts from zero)
+    FgDacc* acc; int32_t* flags; fg_solve_info* info;
+    float tol;
+    int pass, sweeps, zero_start, ny, n, tiles;
+};
+
+__device__ __forceinline__ void jac_mark(const JacArgs& a, int sys, float crit, int sweeps_done) {
+    const bool finite = isfinite(crit);
+    a.info[sys].final_residual = crit;
+    a.info[sys].used_iterations = sweeps_done;
+    a.info[sys].converged = (finite && crit < a.tol) ? 1 : 0;
+    a.info[sys].is_finite = finite ? 1 : 0;
+    flag_st(a.flags + sys, finite ? 1 : 2);
+}
+
+// verdict on the pass before `pass` for env b (both systems): true = the env needs no further work.  Every workgroup of the env
+// comes to it from the same accumulator words; `leader` stores it (or, for an env that goes on, resets the ring entry pass + 1).
+__device__ __forceinline__ bool jac_verdict(const JacArgs& a, int b, int pass, bool leader) {
+    const int sys0 = 2 * b;
+    if (flag_ld(a.flags + sys0) != 0 && flag_ld(a.flags + sys0 + 1) != 0) return true;
+    if (pass == 0) return false;
+    FgDacc* A0 = a.acc + (size_t)sys0 * FG_ACC_DOUBLES;
+    FgDacc* A1 = A0 + FG_ACC_DOUBLES;
+    const int e = (pass - 1) % 3;
+    const float c0 = fg_rms(acc_ld(A0 + e), a.n), c1 = fg_rms(acc_ld(A1 + e), a.n);
+    const bool bad = !isfinite(c0) || !isfinite(c1);
+    const bool done = bad || (c0 < a.tol && c1 < a.tol);
+    if (leader) {
+        if (done) {
+            jac_mark(a, sys0, c0, pass * a.sweeps - 1);      // (used_iterations: the 0-based index of the last sweep, as the Krylov solvers count)
+            jac_mark(a, sys0 + 1, c1, pass * a.sweeps - 1);
+        } else {
+            acc_st(A0 + (pass + 1) % 3, 0.0);
+            acc_st(A1 + (pass + 1) % 3, 0.0);
+        }
+    }
+    return done;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float el(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+template <int NX>
+__global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
+    constexpr int Q = NX / 4;                  // column quads per row
+    constexpr int STRIPS = JAC_THREADS / Q;    // strips of 4 rows
+    constexpr int ROWS = 4 * STRIPS;
+    static_assert(Q * STRIPS == JAC_THREADS && ROWS * NX == JAC_CELLS, "region shape");
+    constexpr bool SPLIT = Q > 64;             // a row spans several waves: the x neighbours at the wave seams go through LDS
+    constexpr int WPR = SPLIT ? Q / 64 : 1;    // waves per row
+    // dynamic LDS (64 KB + the seams: above the static limit, fg_jacobi_lds_ready):
+    //   edge [buffer][comp][2 * strip + (0 top | 1 bottom row of the strip)][column]
+    //   seam [buffer][comp][row][2 * wave-of-row + (0 first | 1 last cell of the wave's part of the row)]   (SPLIT only)
+    extern __shared__ __attribute__((aligned(16))) float jac_lds[];
+    float (*edge)[2][2 * STRIPS][NX] = reinterpret_cast<float (*)[2][2 * STRIPS][NX]>(jac_lds);
+    float (*seam)[2][ROWS][2 * WPR] = reinterpret_cast<float (*)[2][ROWS][2 * WPR]>(jac_lds + 2 * 2 * 2 * STRIPS * NX);
+    __shared__ float red[2][JAC_THREADS / 64];
+    const int b = blockIdx.y, tile = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    if (jac_verdict(a, b, a.pass, tile == 0 && t == 0)) return;
+    const int S = a.sweeps, TY = ROWS - 2 * S;
+    int start = 0, out0 = 0, out1 = a.ny;
+    if (a.tiles > 1) {
+        out0 = tile == 0 ? 0 : (ROWS - S) + (tile - 1) * TY;
+        out1 = tile == a.tiles - 1 ? a.ny : (ROWS - S) + tile * TY;
+        start = tile == 0 ? 0 : out0 - S;
+        if (start > a.ny - ROWS) start = a.ny - ROWS;
+    }
+    const int col = t % Q, strip = t / Q;
+    const int row0 = 4 * strip;               // first region row of the strip
+    const size_t cell0 = (size_t)(start + row0) * NX + 4 * col;
+    const size_t n = (size_t)a.n;
+    // ---- the strip's part of the system: all loads first, then the scaling
+    float4 of[4][4], bp[2][4], xo[2][4];
+    {
+    float4 dg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dg[r] = ld4(a.diag + (size_t)b * n + cell0 + (size_t)r * NX);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) of[f][r] = ld4(a.off + ((size_t)b * 4 + f) * n + cell0 + (size_t)r * NX);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bp[c][r] = ld4(a.rhs + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * NX);
+            xo[c][r] = a.zero_start ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(a.xin + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * NX);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 rd = make_float4(1.f / dg[r].x, 1.f / dg[r].y, 1.f / dg[r].z, 1.f / dg[r].w);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { of[f][r].x *= rd.x; of[f][r].y *= rd.y; of[f][r].z *= rd.z; of[f][r].w *= rd.w; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { bp[c][r].x *= rd.x; bp[c][r].y *= rd.y; bp[c][r].z *= rd.z; bp[c][r].w *= rd.w; }
+    }
+    }
+    // lanes that hold the x neighbours of this thread's quad (same row: the quads of a row are consecutive threads)
+    const int lane_l = SPLIT ? ((lane + 63) & 63) : (lane - (col) + ((col + Q - 1) % Q));
+    const int lane_r = SPLIT ? ((lane + 1) & 63) : (lane - (col) + ((col + 1) % Q));
+    const int wrow = SPLIT ? (col >> 6) : 0;              // which wave of the row this thread sits in
+    const int up_row = strip > 0 ? 2 * (strip - 1) + 1 : 0;                 // bottom row of the strip above (clamped: rows outside the
+    const int dn_row = strip < STRIPS - 1 ? 2 * (strip + 1) : 2 * strip + 1;  // region are a wall -- zero coefficient -- or halo)
+    float part[2] = {0.f, 0.f};
+    for (int k = 0; k < S; ++k) {
+        const int cur = k & 1;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            *reinterpret_cast<float4*>(&edge[cur][c][2 * strip][4 * col]) = xo[c][0];
+            *reinterpret_cast<float4*>(&edge[cur][c][2 * strip + 1][4 * col]) = xo[c][3];
+            if constexpr (SPLIT) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) seam[cur][c][row0 + r][2 * wrow] = xo[c][r].x;
+                }
+                if (lane == 63) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) seam[cur][c][row0 + r][2 * wrow + 1] = xo[c][r].w;
+                }
+            }
+        }
+        __syncthreads();
+        const bool last = (k == S - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 upq = *reinterpret_cast<const float4*>(&edge[cur][c][up_row][4 * col]);
+            const float4 dnq = *reinterpret_cast<const float4*>(&edge[cur][c][dn_row][4 * col]);
+            float4 xn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float xl = __shfl(xo[c][r].w, lane_l, 64), xr = __shfl(xo[c][r].x, lane_r, 64);
+                if constexpr (SPLIT) {
+                    if (lane == 0) xl = seam[cur][c][row0 + r][2 * ((wrow + WPR - 1) % WPR) + 1];
+                    if (lane == 63) xr = seam[cur][c][row0 + r][2 * ((wrow + 1) % WPR)];
+                }
+                const float4 up = r == 0 ? upq : xo[c][r > 0 ? r - 1 : 0];
+                const float4 dn = r == 3 ? dnq : xo[c][r < 3 ? r + 1 : 3];
+                const float4 x = xo[c][r];
+                float4 v;
+                v.x = bp[c][r].x - of[0][r].x * xl - of[1][r].x * x.y - of[2][r].x * up.x - of[3][r].x * dn.x;
+                v.y = bp[c][r].y - of[0][r].y * x.x - of[1][r].y * x.z - of[2][r].y * up.y - of[3][r].y * dn.y;
+                v.z = bp[c][r].z - of[0][r].z * x.y - of[1][r].z * x.w - of[2][r].z * up.z - of[3][r].z * dn.z;
+                v.w = bp[c][r].w - of[0][r].w * x.z - of[1][r].w * xr - of[2][r].w * up.w - of[3][r].w * dn.w;
+                xn[r] = v;
+            }
+            if (last) {
+                // residual of the iterate this sweep started from, on the rows this region answers for (the diagonal is read again
+                // here -- from L2 -- instead of living in 16 registers through the sweeps)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = start + row0 + r;
+                    if (g >= out0 && g < out1) {
+                        const float4 d4 = ld4(a.diag + (size_t)b * n + cell0 + (size_t)r * NX);
+                        const float r0 = d4.x * (xn[r].x - xo[c][r].x), r1 = d4.y * (xn[r].y - xo[c][r].y);
+                        const float r2 = d4.z * (xn[r].z - xo[c][r].z), r3 = d4.w * (xn[r].w - xo[c][r].w);
+                        part[c] += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xo[c][r] = xn[r];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int g = start + row0 + r;
+            if (g >= out0 && g < out1) *reinterpret_cast<float4*>(a.xout + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * NX) = xo[c][r];
+        }
+        const float s = fg_wave_sum(part[c]);
+        if (lane == 0) red[c][t >> 6] = s;
+    }
+    __syncthreads();
+    if (t < 2) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < JAC_THREADS / 64; ++w) s += red[t][w];
+        acc_add(a.acc + (size_t)(2 * b + t) * FG_ACC_DOUBLES + a.pass % 3, (double)s);
+    }
+}
+
+// behind the last enqueued pass: its verdict (what the next pass would have found), the info mirror and the poll words; for envs
+// that go on, the residual of the pass before rides along so that the host can size what it enqueues next
+__global__ void k_jac_check(JacArgs a, fg_solve_info* __restrict__ mirror, float* __restrict__ prev, int B, FgPollOut poll) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int sys0 = 2 * b;
+    // a.pass = number of passes enqueued so far: the verdict pass number a.pass would take
+    const FgDacc* A0 = a.acc + (size_t)sys0 * FG_ACC_DOUBLES;
+    const FgDacc* A1 = A0 + FG_ACC_DOUBLES;
+    float p0 = -1.f, p1 = -1.f;      // (read before the verdict: an env that goes on resets this ring entry for pass a.pass + 1)
+    if (a.pass >= 2) { const int e2 = (a.pass - 2) % 3; p0 = fg_rms(acc_ld(A0 + e2), a.n); p1 = fg_rms(acc_ld(A1 + e2), a.n); }
+    const bool done = jac_verdict(a, b, a.pass, true);
+    if (!done) {
+        const int e = (a.pass - 1) % 3;
+        a.info[sys0].final_residual = fg_rms(acc_ld(A0 + e), a.n); a.info[sys0 + 1].final_residual = fg_rms(acc_ld(A1 + e), a.n);
+        a.info[sys0].used_iterations = a.info[sys0 + 1].used_iterations = a.pass * a.sweeps - 1;
+        a.info[sys0].converged = a.info[sys0 + 1].converged = 0;
+    }
+    prev[sys0] = p0; prev[sys0 + 1] = p1;
+    mirror[sys0] = a.info[sys0]; mirror[sys0 + 1] = a.info[sys0 + 1];
+    fg_poll_publish(poll, sys0);
+    fg_poll_publish(poll, sys0 + 1);
+}
+
+// envs whose last iterate was written to the work buffer: into the result.  Pass p wrote the result vector iff (p & 1) == last_parity;
+// an env that stopped with the verdict of pass q + 1 has the output of pass q = (used + 1) / S - 1 (the host launches this only when its
+// copy of the sweep counts says some env needs it)
+__global__ __launch_bounds__(256) void k_jac_settle(const float* __restrict__ work, float* __restrict__ x, const fg_solve_info* __restrict__ info,
+                                                    int sweeps, int last_parity, int n2 /* floats per env: 2 n */) {
+    const int b = blockIdx.y;
+    const int used = info[2 * b].used_iterations + 1;
+    if (used <= 0 || ((used / sweeps - 1) & 1) == last_parity) return;
+    const float4* src = reinterpret_cast<const float4*>(work + (size_t)b * n2);
+    float4* dst = reinterpret_cast<float4*>(x + (size_t)b * n2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2 / 4; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int jac_tiles(int ny, int rows, int sweeps) {
+    if (ny == rows) return 1;
+    const int ty = rows - 2 * sweeps, rest = ny - 2 * (rows - sweeps);
+    return 2 + (rest > 0 ? (rest + ty - 1) / ty : 0);
+}
+
+constexpr size_t JAC_LDS = sizeof(float) * (2 * 2 * 2 * (JAC_CELLS / 4) + 2 * 2 * 128 * 2);   // edge rows + seams (<= 128 row-waves)
+
+// dynamic LDS above 64 KB needs an explicit opt-in per kernel (once per process)
+bool jac_lds_ready() {
+    static int state = 0;      // 0 not tried, 1 granted, -1 refused
+    if (state == 0) {
+        const void* fns[4] = {reinterpret_cast<const void*>(k_jac_pass<64>), reinterpret_cast<const void*>(k_jac_pass<128>),
+                              reinterpret_cast<const void*>(k_jac_pass<256>), reinterpret_cast<const void*>(k_jac_pass<512>)};
+        state = 1;
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JAC_LDS) != hipSuccess) { (void)hipGetLastError(); state = -1; }
+    }
+    return state == 1;
+}
+
+int launch_pass(const fg_state* s, int slot, const JacArgs& a, hipStream_t st) {
+    const dim3 grid(a.tiles, s->grid.B), block(JAC_THREADS);
+    switch (s->grid.nx) {
+        case 64: FG_LAUNCH_P(s, slot, k_jac_pass<64>, grid, block, JAC_LDS, st, a); break;
+        case 128: FG_LAUNCH_P(s, slot, k_jac_pass<128>, grid, block, JAC_LDS, st, a); break;
+        case 256: FG_LAUNCH_P(s, slot, k_jac_pass<256>, grid, block, JAC_LDS, st, a); break;
+        case 512: FG_LAUNCH_P(s, slot, k_jac_pass<512>, grid, block, JAC_LDS, st, a); break;
+        default: fg_set_error("Jacobi sweeps: unsupported row length"); return FG_ERR_UNSUPPORTED;
+    }
+    return FG_OK;
+}
+
+}  // namespace
+
+bool fg_jacobi_ok(const fg_state* s, const FgBicgArgs& a) {
+    const FgGrid& G = s->grid;
+    if (!s->adv_jacobi || a.precond || a.nc != 2 || G.dims != 2) return false;
+    if (!(G.nx == 64 || G.nx == 128 || G.nx == 256 || G.nx == 512)) return false;
+    const int rows = JAC_CELLS / G.nx;
+    return G.fixed[2] && G.fixed[3] && G.ny >= rows && s->jac_prev != nullptr && jac_lds_ready();
+}
+
+// *outcome: 0 = not tried (the kind is backing off: the prepared solve state is untouched), 1 = solved here, 2 = tried and given up --
+// the caller then runs BiCGStab from a cleared start vector behind a fresh k_bicg_begin
+int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, int* outcome) {
+    *outcome = 0;
+    FgJacHist& H = s->jac_hist[a.kind & 3];
+    if (H.skip > 0) { --H.skip; return FG_OK; }
+    *outcome = 2;
+    const FgGrid& G = s->grid;
+    const int B = G.B, n = G.n, nsys = 2 * B, rows = JAC_CELLS / G.nx;
+    const int s_max = (rows - 4) / 2 < 8 ? (rows - 4) / 2 : 8;
+    // sweeps per pass: what moves the fewest bytes for the sweep count of the previous solve of this kind
+    int S = s_max < 4 ? s_max : 4, P = 2;
+    if (H.sweeps > 0) {
+        double best = 1e30;
+        for (int c = 2; c <= s_max; ++c) {
+            const int p = (H.sweeps + c - 1) / c;
+            const double cost = p * (9.0 * jac_tiles(G.ny, rows, c) * rows / G.ny + 2.0) + 0.5 * p;   // (+ launch and fill of a pass)
+            if (cost < best) { best = cost; S = c; P = p; }
+        }
+    }
+    JacArgs q = {};
+    q.diag = a.diag; q.off = a.off; q.rhs = a.rhs; q.acc = s->acc; q.flags = s->flags; q.info = s->info_dev; q.tol = a.tol;
+    q.sweeps = S; q.ny = G.ny; q.n = n; q.tiles = jac_tiles(G.ny, rows, S);
+    float* work = s->w[0];
+    const double bytes_sys = 0.5 * 4.0 * n * 11.0, flops_sys = 0.5 * n * 2.0 * 9.0 * S;
+    int passes = 0;
+    // pass p writes the result vector when p has the parity of the last planned pass (a start from a.x reads it in pass 0,
+    // so that pass has to write the work buffer)
+    int last_parity = (P - 1) & 1;
+    if (a.use_x0 && last_parity == 0) last_parity = 1;
+    auto enqueue = [&](int count) -> int {
+        for (int k = 0; k < count; ++k, ++passes) {
+            q.pass = passes; q.zero_start = (passes == 0 && !a.use_x0) ? 1 : 0;
+            const bool to_x = ((passes & 1) == last_parity);
+            q.xin = to_x ? work : a.x; q.xout = to_x ? a.x : work;
+            const int slot = fg_prof_slot(s, FG_PK_JAC_PASS, s->flags, nsys, q.zero_start ? bytes_sys * 9.0 / 11.0 : bytes_sys, flops_sys, st);
+            if (int rc = launch_pass(s, slot, q, st)) return rc;
+        }
+        return FG_OK;
+    };
+    auto check = [&]() -> int {
+        fg_prof_prefetch(s, st);
+        const FgPollOut po = fg_poll_next(&s->poll);
+        q.pass = passes;
+        hipLaunchKernelGGL(k_jac_check, dim3((B + 63) / 64), dim3(64), 0, st, q, s->info_pinned, s->jac_prev, B, po);
+        return fg_poll_wait(&s->poll, po, 0, nsys, st);
+    };
+    const int max_passes = (a.max_iterations / S) < JAC_MAX_PASSES ? (a.max_iterations / S > 0 ? a.max_iterations / S : 1) : JAC_MAX_PASSES;
+    if (P > max_passes) P = max_passes;
+    if (int rc = enqueue(P)) return rc;
+    bool ok = false, failed = false;
+    for (;;) {
+        if (int rc = check()) return rc;
+        bool all = true;
+        double need = 0.0;      // passes still to go, from the contraction of the last pass
+        for (int i = 0; i < nsys; ++i) {
+            const fg_solve_info& I = s->info_pinned[i];
+            if (!I.is_finite) failed = true;
+            if (I.converged || !I.is_finite) continue;
+            all = false;
+            const double r1 = I.final_residual, r0 = s->jac_prev[i];
+            if (r0 > 0.0) {
+                const double c = r1 / r0;
+                if (!(c < 0.7)) failed = true;      // less than a factor 0.7 per pass: not the regime this is for
+                else { const double m = log((double)a.tol / r1) / log(c); need = m > need ? m : need; }
+            } else {
+                need = need > 1.0 ? need : 1.0;
+            }
+        }
+        if (all && !failed) { ok = true; break; }
+        if (failed) break;
+        int more = (int)ceil(need);
+        if (more < 1) more = 1;
+        more += more & 1;                        // in pairs: the last pass of every batch writes the result vector
+        if (passes + more > max_passes) { failed = true; break; }
+        if (int rc = enqueue(more)) return rc;
+    }
+    if (int prc = fg_prof_collect(s, st)) return prc;
+    if (!ok) {
+        // not the regime of the sweeps (or a non-finite system): the Krylov solver decides, and this kind waits before it tries again
+        H.fails += 1; H.skip = H.fails > 6 ? 512 : (4 << H.fails); H.sweeps = 0;
+        return FG_OK;
+    }
+    // where did every env's last iterate land?  pass p wrote the result vector iff (p & 1) == last_parity; an env that stopped with
+    // the verdict of pass q + 1 has the output of pass q = (used + 1) / S - 1
+    int used_max = 0, settle = 0;
+    for (int b = 0; b < B; ++b) {
+        const int used = s->info_pinned[2 * b].used_iterations + 1;
+        if (used > 0) { settle |= (((used / S - 1) & 1) != last_parity) ? 1 : 0; used_max = used > used_max ? used : used_max; }
+    }
+    if (settle)
+        hipLaunchKernelGGL(k_jac_settle, dim3(32, B), dim3(256), 0, st, (const float*)work, a.x, (const fg_solve_info*)s->info_dev, S, last_parity, 2 * n);
+    H.fails = 0;
+    H.sweeps = used_max > 0 ? used_max : S;
+    for (int i = 0; i < nsys; ++i)
+        if (info_host) info_host[i] = s->info_pinned[i];
+    FG_HIP_CHECK(hipGetLastError());
+    *outcome = 1;
+    return FG_OK;
+}
+#endif

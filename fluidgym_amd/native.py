@@ -430,6 +430,16 @@ class NativeSolver:
         """``solver_double_fallback`` of the reference's linear-solve ladder (PISOtorch_diff.py:418-445): see ``fg_set_double_fallback``."""
         L.check(self.lib.fg_set_double_fallback(self.handle, int(bool(on))), lib=self.lib)
 
+    def set_advection_jacobi(self, on: bool = True) -> None:
+        """Velocity systems of uniform 2-D grids with walls in y: point-Jacobi sweeps, several per pass with the tile on chip
+        (``csrc/fg_jacobi.hip``), before the reference's BiCGStab -- see ``fg_set_advection_jacobi`` and the policy ``advection_jacobi``."""
+        L.check(self.lib.fg_set_advection_jacobi(self.handle, int(bool(on))), lib=self.lib)
+
+    def advection_jacobi_counts(self) -> Dict[str, int]:
+        out = (ctypes.c_int64 * 2)()
+        L.check(self.lib.fg_advection_jacobi_counts(self.handle, out), lib=self.lib)
+        return {"settled_by_sweeps": int(out[0]), "handed_to_bicgstab": int(out[1])}
+
     def ladder(self, force_mask: int = -1) -> Dict[str, int]:
         """How often each rung of the retry ladder ran (``fg_ladder``); ``force_mask`` >= 0 (tests) makes first attempts count as
         failed: 1 advection, 2 pressure, 4 also the advection fp64 rung."""

@@ -73,6 +73,17 @@ benchmark line can say which mode it ran in:
     4-iteration solves), ``"always"`` / ``"never"`` force it.  Same systems, same tolerances, another Krylov trajectory -- like
     ``pressure_multilevel``; the reference's own preconditioner for these solves is ILU(0), off by default.
 
+``advection_jacobi`` (default True)
+    Single-block path, velocity systems of 2-D grids with walls in y whose rows are 64 / 128 / 256 / 512 cells (the channel family:
+    the headline workload): point-Jacobi sweeps x <- D^-1 (b - O x), 2-8 per pass over the field with the tile kept on chip
+    (``csrc/fg_jacobi.hip``), instead of the reference's BiCGStab.  On these grids at the envs' time steps the rows are strongly
+    diagonally dominant (sum |O| / D = 0.34 at 256 x 128, 0.63 at 512 x 256) and the sweeps reach the reference's criterion -- RMS
+    residual below ``advection_tol``, measured as D (x_new - x) = b - A x -- in 11 / 24 sweeps = 2-6 passes over the matrix, where
+    BiCGStab takes 4-8 iterations of two matrix applications and six vector passes each.  A solve the sweeps do not settle (no
+    contraction by 0.7 per pass: refined grids, large time steps) is handed to BiCGStab from a cleared start vector and the solver
+    backs off from trying.  Same systems, same tolerance, same criterion, another iteration -- like the preconditioners above;
+    ``False`` = BiCGStab always (``bench.py`` reports that mode as the ``krylov_mode`` leg).
+
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` / ``FLUIDGYM_AMD_ADVECTION_WARM_START`` /
 ``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
 at import).
@@ -92,6 +103,7 @@ _POLICY: Dict[str, Any] = {
     "advection_rung_preconditioner": os.environ.get("FLUIDGYM_AMD_ADVECTION_RUNG_PRECONDITIONER", "line"),
     "pressure_bicgstab_large_meshes": os.environ.get("FLUIDGYM_AMD_PRESSURE_BICGSTAB_LARGE_MESHES", "1") not in ("0", "", "false", "False"),
     "native_wall_forcing": os.environ.get("FLUIDGYM_AMD_NATIVE_WALL_FORCING", "1") not in ("0", "", "false", "False"),
+    "advection_jacobi": os.environ.get("FLUIDGYM_AMD_ADVECTION_JACOBI", "1") not in ("0", "", "false", "False"),
     "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "1") not in ("0", "", "false", "False"),
 }
 

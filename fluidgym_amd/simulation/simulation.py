@@ -166,6 +166,11 @@ class Simulation:
             if getattr(solver, "has_helmholtz", False) and not self.preconditionBiCG and (fd_pol == "always" or (fd_pol == "auto" and solver.dims == 2)):
                 self.advection_preconditioner = 3
             solver.set_advection_preconditioner(self.advection_preconditioner)
+        # policy advection_jacobi (default on): un-preconditioned velocity solves of uniform 2-D grids go to the on-chip Jacobi
+        # sweeps first (csrc/fg_jacobi.hip); the library checks per solve whether the grid qualifies and whether they contract
+        self.advection_jacobi = bool(get_solver_policy()["advection_jacobi"])
+        if hasattr(solver, "set_advection_jacobi"):
+            solver.set_advection_jacobi(self.advection_jacobi)
         # (bounds, velm, tol): advective-outflow PRE hook of the cylinder/airfoil envs (PISOtorch_simulation.py:
         # 228-393, wired in cylinder_env_base.py:280-300), kept as data so the native driver can run it
         self.outflow = outflow

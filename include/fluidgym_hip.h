@@ -213,6 +213,14 @@ int fg_advection_retries(fg_handle h, int64_t* out, int32_t reset);
  * fg_ladder: out4 = how often each rung ran since fg_create {advection fp64, advection preconditioned, pressure fp64, 0};
  * force_mask >= 0 (tests) makes first attempts count as failed: 1 advection, 2 pressure, 4 also the advection fp64 rung; -1 = only read. */
 int fg_set_double_fallback(fg_handle h, int on);
+/* fg_set_advection_jacobi(on): the velocity systems of uniform 2-D grids with walls in y (the channel family) are solved by point-Jacobi
+ * sweeps, several per pass over the field with the tile kept on chip (csrc/fg_jacobi.hip), instead of the reference's BiCGStab
+ * (bicgstab_solver_kernel.cu, called from PISOtorch_simulation.py:1735-1742) -- same system, same criterion (RMS residual < tol), another
+ * iteration; a solve the sweeps do not settle goes to BiCGStab from a cleared start vector.  Off until called (the Python Simulation
+ * calls it, policy `advection_jacobi`); FG_ADV_JACOBI=0/1 in the environment overrides.  fg_advection_jacobi_counts: solves settled
+ * by the sweeps, solves handed on to BiCGStab. */
+int fg_set_advection_jacobi(fg_handle h, int on);
+int fg_advection_jacobi_counts(fg_handle h, int64_t* out2);
 int fg_ladder(fg_handle h, int64_t* out4, int32_t force_mask);
 /* Which kernels the NEXT un-preconditioned advection-diffusion solve of `nc` right-hand sides will run (tests, bench reports):
  * 0 = five kernels per BiCGStab iteration, 1 = two brick kernels (csrc/fg_bicgstab.hip k_bicgf_a / _b), 2 = two z-marching

@@ -1,0 +1,141 @@
+"""The on-chip Jacobi sweeps of the velocity systems (csrc/fg_jacobi.hip: k_jac_pass / k_jac_check / k_jac_settle, switched by
+fg_set_advection_jacobi) against the oracle's direct solve and against the BiCGStab they stand in for (bicgstabSolveGPU,
+bicgstab_solver_kernel.cu:63-411, called for the velocity systems at PISOtorch_simulation.py:1735-1742), through the C ABI: every
+row length the kernel is instantiated for (64 / 128 / 256 / 512: four region shapes, the last with rows that span two waves),
+ragged last regions, periodic and FIXED x, a masked env, the hand-over of a system the sweeps do not contract on, reproducible bits,
+and a whole PISO step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import piso_oracle as O
+from tests.helpers import make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def _solve(case, dt, jacobi, tol=1e-6, from_result=False, max_iterations=5000):
+    ns = case.native()
+    ns.set_advection_jacobi(jacobi)
+    ns.set_advection_start(from_result)
+    ns.setup_advection(dt)
+    info = ns.solve_advection(tol=tol, max_iterations=max_iterations)
+    torch.cuda.synchronize()
+    x = _np(ns.buffer(3, (case.B, case.dims) + case.shape))
+    counts = ns.advection_jacobi_counts()
+    ns.close()
+    return x, info, counts
+
+
+def _true_residual_rms(case, dt, b, x):
+    """RMS of b - A x per component, the criterion of both solvers, evaluated in double on the oracle's matrix"""
+    dom = case.oracle_domain(b, case.grid())
+    C, _, _ = O.build_advection_matrix(dom, dt)
+    rhs = O.advection_rhs_velocity(dom, dt)
+    return [float(np.sqrt(np.mean((rhs[c].ravel() - C @ x[b, c].ravel()) ** 2))) for c in range(2)], C, rhs
+
+
+@pytest.mark.parametrize("n, fixed", [((64, 130), (0, 1)), ((128, 64), (0, 1)), ((128, 75), (1,)), ((256, 128), (0, 1)), ((256, 37), (1,)),
+                                      ((512, 16), (0, 1)), ((512, 45), (1,))])
+def test_sweeps_reach_the_solution_of_the_direct_solve(n, fixed):
+    """uniform grids; per env its own dt with CFL <= ~0.8 and diffusion numbers ~0.1 (the regime of the channel envs: cell Peclet
+    numbers above 2, rows dominated by 1/dt).  The tolerance is scaled like the envs' 1e-5 at 1/dt = 100 -- an fp32 iterate
+    cannot bring the residual of a row with diagonal D below ~4e-8 D |x|."""
+    h = min(2.0 / n[0], 1.0 / n[1])
+    case = make_case(dims=2, n=n, fixed_axes=fixed, B=3, seed=3, stretch=0.0, nu=0.25 * h, vel_scale=0.5)
+    dt = [0.2 * h, 0.4 * h, 0.1 * h]
+    tol = 2e-7 / min(dt)
+    xj, ij, cj = _solve(case, dt, True, tol)
+    xb, ib, cb = _solve(case, dt, False, tol)
+    assert cj == {"settled_by_sweeps": 1, "handed_to_bicgstab": 0} and cb == {"settled_by_sweeps": 0, "handed_to_bicgstab": 0}
+    assert all(i.converged and i.is_finite for i in ij), [(i.used_iterations, i.final_residual) for i in ij]
+    print(f"JACOBI {n} fixed axes {fixed}: sweeps {[i.used_iterations for i in ij]}, BiCGStab iterations {[i.used_iterations for i in ib]}")
+    for b in range(case.B):
+        res, C, rhs = _true_residual_rms(case, dt[b], b, xj)
+        resb, _, _ = _true_residual_rms(case, dt[b], b, xb)
+        for c in range(2):
+            # the criterion is met on the TRUE residual (the sweeps measure the residual of the iterate before the last sweep: margin)
+            assert res[c] < 1.5 * tol, (b, c, res, resb)
+            x_ref = O.solve_direct(C, rhs[c].ravel()).reshape(case.shape)
+            assert rel_err(xj[b, c], x_ref) < 3e-6, (b, c, rel_err(xj[b, c], x_ref), rel_err(xb[b, c], x_ref))
+            assert rel_err(xb[b, c], x_ref) < 3e-5       # (BiCGStab stops on its recurrence residual: the looser of the two)
+
+
+def test_masked_env_and_start_from_result():
+    case = make_case(dims=2, n=(256, 70), fixed_axes=(0, 1), B=3, seed=8, stretch=0.0, nu=2e-3, vel_scale=0.5)
+    dt = [1.5e-3, 0.0, 3e-3]     # env 1 masked out
+    for from_result in (False, True):
+        xj, ij, cj = _solve(case, dt, True, 1e-4, from_result)
+        xb, ib, _ = _solve(case, dt, False, 1e-4, from_result)
+        assert cj["settled_by_sweeps"] == 1
+        assert ij[2].used_iterations == -1 and ij[3].used_iterations == -1 and ib[2].used_iterations == -1
+        for b in (0, 2):
+            assert rel_err(xj[b], xb[b]) < 1e-5
+        # the masked env keeps what its result vector held (the start state from the blocks)
+        assert np.array_equal(xj[1], xb[1])
+        if from_result:
+            # a start from the previous velocity needs fewer sweeps than the start from zero (1/dt u is most of the right-hand side)
+            assert max(i.used_iterations for i in ij) <= zero_sweeps
+        zero_sweeps = max(i.used_iterations for i in ij)
+
+
+def test_system_without_diagonal_dominance_goes_to_bicgstab():
+    """a time step 500 x larger: diffusion number ~40, the sweeps contract by less than 0.7 per pass -> BiCGStab from a cleared start,
+    the same answer as without the sweeps, and the solver backs off from trying again"""
+    case = make_case(dims=2, n=(256, 64), fixed_axes=(0, 1), B=2, seed=5, stretch=0.0, nu=0.05, vel_scale=0.5)
+    dt = 0.05
+    ns = case.native()
+    ns.set_advection_jacobi(True)
+    ns.setup_advection(dt)
+    info = ns.solve_advection(tol=1e-6)
+    x1 = _np(ns.buffer(3, (case.B, 2) + case.shape))
+    assert all(i.converged for i in info)
+    assert ns.advection_jacobi_counts() == {"settled_by_sweeps": 0, "handed_to_bicgstab": 1}
+    ns.setup_advection(dt)
+    info2 = ns.solve_advection(tol=1e-6)       # backing off: straight to BiCGStab
+    assert ns.advection_jacobi_counts() == {"settled_by_sweeps": 0, "handed_to_bicgstab": 1}
+    x2 = _np(ns.buffer(3, (case.B, 2) + case.shape))
+    ns.close()
+    xb, ib, _ = _solve(case, dt, False, 1e-6)
+    assert np.array_equal(x1, xb) and np.array_equal(x2, xb)
+    assert [i.used_iterations for i in info] == [i.used_iterations for i in ib] == [i.used_iterations for i in info2]
+
+
+def test_bits_reproduce_and_envs_do_not_see_each_other():
+    case = make_case(dims=2, n=(256, 128), fixed_axes=(0, 1), B=4, seed=11, stretch=0.0, nu=2e-3, vel_scale=0.5)
+    dt = [1e-3, 3e-3, 5e-4, 2e-3]
+    x1, i1, _ = _solve(case, dt, True, 2e-4)
+    x2, i2, _ = _solve(case, dt, True, 2e-4)
+    assert np.array_equal(x1, x2)
+    assert [(i.used_iterations, i.final_residual) for i in i1] == [(i.used_iterations, i.final_residual) for i in i2]
+    # env 1 alone (other envs masked): the same bits as inside the batch, although the batch went on sweeping for the slower envs
+    x3, i3, _ = _solve(case, [0.0, 3e-3, 0.0, 0.0], True, 2e-4)
+    assert np.array_equal(x3[1], x1[1])
+    assert (i3[2].used_iterations, i3[2].final_residual) == (i1[2].used_iterations, i1[2].final_residual)
+
+
+def test_whole_piso_step_with_the_sweeps():
+    case = make_case(dims=2, n=(256, 64), fixed_axes=(0, 1), B=2, seed=2, stretch=0.0, nu=2e-3, vel_scale=0.4, wall_motion=0.2,
+                     through_flow_axis=0)
+    out = {}
+    dt = [3e-3, 2e-3]
+    for jac in (True, False):
+        ns = case.native()
+        ns.set_advection_jacobi(jac)
+        ok, stats = ns.piso_step(dt, advection_tol=5e-5, pressure_tol=1e-7)
+        torch.cuda.synchronize()
+        assert ok, stats
+        out[jac] = (_np(ns.velocity), _np(ns.pressure), stats, ns.advection_jacobi_counts())
+        ns.close()
+    assert out[True][3]["settled_by_sweeps"] == 1 and out[False][3]["settled_by_sweeps"] == 0
+    print("PISO step: sweeps", out[True][2], "BiCGStab", out[False][2])
+    assert rel_err(out[True][0], out[False][0]) < 2e-5
+    g = case.grid()
+    for b in range(case.B):
+        dom = case.oracle_domain(b, g)
+        O.piso_split_step(dom, dt[b])
+        assert rel_err(out[True][0][b], dom.velocity) < 2e-5
