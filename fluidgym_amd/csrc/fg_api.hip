@@ -718,6 +718,7 @@ extern "C" int fg_solver_counters(fg_handle s, int64_t* out13, int32_t reset) {
 static inline bool is_close_zero(double a) { return std::fabs(a) <= 1e-8; }
 
 extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out, fg_real* flux_host, void* stream) {
+    fg_htrace("single_step_in");
     FG_REQUIRE(s && o && out, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, o->step.advect_scalar && s->cfg.n_scalars > 0)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -753,7 +754,9 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
                     return rc;
             }
             (void)none;
+            fg_htrace("maxvel_launched");
             if (int rc = fg_poll_wait(&s->poll, po, o->adaptive ? B : 0, o->adaptive ? 1 : B, st)) return rc;
+            fg_htrace("maxvel_poll_done");
             if (first) {
                 fg_real worst = 0.f;
                 for (int b = 0; b < B; ++b) {
@@ -809,6 +812,7 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
         if (!o->adaptive) --fixed_left;
         if (substeps >= (o->max_substeps > 0 ? o->max_substeps : 100000)) break;
     }
+    fg_htrace("single_step_out");
     for (int i = 0; i < 4; ++i) out[i] = stats[i];
     out[4] = substeps;
     out[5] = all_ok;

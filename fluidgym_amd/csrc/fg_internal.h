@@ -586,6 +586,7 @@ void fg_poll_destroy(FgPoll* P);
 FgPollOut fg_poll_next(FgPoll* P);     // the words and sequence number of the next poll ({nullptr, 0} when spinning is off)
 // waits until words [first, first + count) carry out.value (or, without words / after 50 ms of spinning, for the stream)
 int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st);
+void fg_htrace(const char* tag);      // FG_HTRACE=1: host time stamps (fg_poll.hip); a no-op otherwise
 
 struct FgBest {
     fg_real* best_crit;   // [B] residual of the last kept iterate (leader-only state)

@@ -346,7 +346,10 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
         const FgPollOut po = fg_poll_next(&s->poll);
         q.pass = passes;
         hipLaunchKernelGGL(k_jac_check, dim3((B + 63) / 64), dim3(64), 0, st, q, s->info_pinned, s->jac_prev, B, po);
-        return fg_poll_wait(&s->poll, po, 0, nsys, st);
+        fg_htrace("jac_check_launched");
+        const int rc = fg_poll_wait(&s->poll, po, 0, nsys, st);
+        fg_htrace("jac_poll_done");
+        return rc;
     };
     const int max_passes = (a.max_iterations / S) < JAC_MAX_PASSES ? (a.max_iterations / S > 0 ? a.max_iterations / S : 1) : JAC_MAX_PASSES;
     if (P > max_passes) P = max_passes;
@@ -366,6 +369,8 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
                 const double c = r1 / r0;
                 if (!(c < 0.7)) failed = true;      // less than a factor 0.7 per pass: not the regime this is for
                 else { const double m = log((double)a.tol / r1) / log(c); need = m > need ? m : need; }
+                // (beyond ~48 sweeps in all the Krylov iteration is the cheaper one: BiCGStab takes 10-15 iterations on such systems)
+                if ((passes + need) * S > 48.0) failed = true;
             } else {
                 need = need > 1.0 ? need : 1.0;
             }
@@ -398,6 +403,7 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     for (int i = 0; i < nsys; ++i)
         if (info_host) info_host[i] = s->info_pinned[i];
     FG_HIP_CHECK(hipGetLastError());
+    fg_htrace("jac_return");
     *outcome = 1;
     return FG_OK;
 }

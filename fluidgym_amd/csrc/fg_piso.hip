@@ -991,6 +991,7 @@ int fg_launch_pressure_setup(const fg_state* s, const fg_real* dt, hipStream_t s
 int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result, hipStream_t st) {
     // the state of the pressure CG that follows is prepared by this launch (FgCgBegin, fg_cg.h; fg_cg_solve skips its k_cg_begin when
     // the record matches its own arguments)
+    fg_htrace("h_launch_in");
     FgCgBegin begin;
     begin.acc = s->cg_acc; begin.flags = s->flags; begin.info = s->info_dev; begin.mean_sums = s->acc; begin.best = s->cg_best;
     begin.track_best = s->cg_return_best; begin.ns = fg_cg_slots(s); begin.xsum = s->fcg_xsum;
@@ -1001,6 +1002,7 @@ int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result,
                            vel_result, s->hvec, begin, L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
+    fg_htrace("h_launch_out");
     return FG_OK;
 }
 
@@ -1034,6 +1036,7 @@ int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, con
 
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
                       fg_real* vel_out, hipStream_t st, fg_real* vel_copy, const FgMeanRef* mean) {
+    fg_htrace("correct_in");
     const FgMeanRef mr = mean ? *mean : FgMeanRef{nullptr, nullptr, nullptr};
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
@@ -1041,6 +1044,7 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
                            L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
+    fg_htrace("correct_out");
     return FG_OK;
 }
 

@@ -499,7 +499,9 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 const FgPollOut po = fg_poll_next(&s->poll);
                 hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
                                    n, B, final_pass, ns, po);
+                fg_htrace("cg_check_launched");
                 if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
+                fg_htrace("cg_poll_done");
                 info_fresh = true;
                 done = true;
                 for (int b = 0; b < B; ++b) done = done && (s->info_pinned[b].converged || !s->info_pinned[b].is_finite);

@@ -56,3 +56,32 @@ int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStrea
     }
     return FG_OK;
 }
+
+// ---- FG_HTRACE=1: host-side time stamps around the polls (diagnosis of the idle time between a polled kernel and the launch that
+// follows it); the deltas between consecutive tags are summed per pair and printed when the process ends
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+namespace {
+struct HTrace {
+    bool on; const char* last; std::chrono::steady_clock::time_point t;
+    std::map<std::string, std::pair<long long, double>> sum;
+    HTrace() : on(false), last(nullptr) { const char* e = getenv("FG_HTRACE"); on = e && atoi(e) != 0; }
+    ~HTrace() {
+        if (!on) return;
+        for (const auto& kv : sum) fprintf(stderr, "FG_HTRACE %-44s n %8lld  avg_us %8.2f\n", kv.first.c_str(), kv.second.first, kv.second.second / kv.second.first);
+    }
+};
+HTrace g_htrace;
+}  // namespace
+void fg_htrace(const char* tag) {
+    HTrace& H = g_htrace;
+    if (!H.on) return;
+    const auto now = std::chrono::steady_clock::now();
+    if (H.last) {
+        auto& e = H.sum[std::string(H.last) + " -> " + tag];
+        e.first += 1; e.second += std::chrono::duration<double, std::micro>(now - H.t).count();
+    }
+    H.last = tag; H.t = now;
+}

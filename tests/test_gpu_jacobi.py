@@ -90,6 +90,7 @@ def test_system_without_diagonal_dominance_goes_to_bicgstab():
     dt = 0.05
     ns = case.native()
     ns.set_advection_jacobi(True)
+    ns.set_advection_start(False)
     ns.setup_advection(dt)
     info = ns.solve_advection(tol=1e-6)
     x1 = _np(ns.buffer(3, (case.B, 2) + case.shape))
