@@ -19,6 +19,9 @@ struct FcgUpdArgs {
     const float2* tw; const float2* rot; float fs0, fs;
     const int32_t* flags; FgDacc* acc; double* alpha; FgDacc* xsum; FgBest best;
     int ns, rows, it, first; long env_stride;
+    // first update of a solve started by k_fcg_div_fwd: x_0 = 0 and r_0 = b were never stored -- r_0 is read from the right-hand side,
+    // x_0 is not read, and an env whose start vector already met the tolerance gets its zeros here
+    const float* r0; int x_zero;
 };
 struct FcgInvArgs {
     const float* u; const float* r; const float* rA; float* z; float* w;
@@ -38,6 +41,6 @@ struct FcgDivArgs {
 #if !FG_F64
 int fg_fcg_div_fwd(fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, int ns, hipStream_t st);
 bool fg_fcg_ok(const fg_state* s);     // the grid / preconditioner setup the fused kernels cover (and FG_CG_FUSED != 0)
-int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int ns, hipStream_t st);
+int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int ns, hipStream_t st, const fg_real* r0 = nullptr);
 int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it, int ns, hipStream_t st);
 #endif

@@ -45,8 +45,19 @@ __global__ __launch_bounds__(256) void k_fcg_update_fwd(FcgUpdArgs a) {
     __shared__ __attribute__((aligned(16))) float2 twl[N];
     __shared__ float red[8];
     const int b = blockIdx.y;
-    if (a.flags[b] != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.flags[b] != 0) {
+        if (a.x_zero && (a.flags[b] == 1 || a.flags[b] == 2)) {
+            // the start vector of this env met the tolerance (or its right-hand side is not finite): x_0 = 0 is its result
+            float z0[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) z0[e] = 0.f;
+            const int r0 = 2 * (blockIdx.x * 4 + wave);
+            if (r0 < a.rows) fgfft::store_row<N>(a.x + (size_t)b * a.env_stride + (size_t)r0 * N, lane, z0);
+            if (r0 + 1 < a.rows) fgfft::store_row<N>(a.x + (size_t)b * a.env_stride + (size_t)(r0 + 1) * N, lane, z0);
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < N; k += 256) twl[k] = a.tw[k];
     // scalars of the iteration, derived by every workgroup from the same accumulator words
     const int it = a.it;
@@ -83,8 +94,14 @@ __global__ __launch_bounds__(256) void k_fcg_update_fwd(FcgUpdArgs a) {
             fgfft::load_row<N>(a.p + o0, lane, pa); fgfft::load_row<N>(a.p + o1, lane, pb);
             fgfft::load_row<N>(a.s + o0, lane, sa); fgfft::load_row<N>(a.s + o1, lane, sb);
         }
-        fgfft::load_row<N>(a.x + o0, lane, xa); fgfft::load_row<N>(a.x + o1, lane, xb);
-        fgfft::load_row<N>(a.r + o0, lane, ra); fgfft::load_row<N>(a.r + o1, lane, rb);
+        if (a.x_zero) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { xa[e] = 0.f; xb[e] = 0.f; }
+        } else {
+            fgfft::load_row<N>(a.x + o0, lane, xa); fgfft::load_row<N>(a.x + o1, lane, xb);
+        }
+        const float* rsrc = a.r0 ? a.r0 : a.r;
+        fgfft::load_row<N>(rsrc + o0, lane, ra); fgfft::load_row<N>(rsrc + o1, lane, rb);
         if (save) {
             if (live0) fgfft::store_row<N>(a.best.best_x + o0, lane, xa);
             if (live1) fgfft::store_row<N>(a.best.best_x + o1, lane, xb);
@@ -322,13 +339,11 @@ __global__ __launch_bounds__(256) void k_fcg_div_fwd(FcgDivArgs a) {
             }
         }
         if (live) {
-            float z0[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) { z0[e] = 0.f; part[0] += out[e] * out[e]; }
+            for (int e = 0; e < EPL; ++e) part[0] += out[e] * out[e];
             const size_t o = (size_t)b * a.n + (size_t)j * N;
             fgfft::store_row<N>(a.div + o, lane, half ? db : da);
-            fgfft::store_row<N>(a.r + o, lane, half ? db : da);
-            fgfft::store_row<N>(a.x + o, lane, z0);
+            // (r_0 = b and x_0 = 0 are not stored: the first update kernel of the solve reads b and knows the zero, FcgUpdArgs::r0)
         }
     }
     __syncthreads();      // twiddle table staged (and every lane is through with the staged rows)
@@ -383,16 +398,17 @@ bool fg_fcg_ok(const fg_state* s) {
            s->fcg_alpha != nullptr;
 }
 
-int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int ns, hipStream_t st) {
+int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int ns, hipStream_t st, const fg_real* r0) {
     const FgGrid& G = s->grid;
     FcgUpdArgs a = {};
+    a.r0 = r0; a.x_zero = r0 ? 1 : 0;
     a.z = v.z; a.w = v.w; a.p = v.p; a.s = v.s; a.x = v.x; a.r = v.r; a.t1 = v.t1;
     a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot; a.fs0 = s->fd_dct_fwd[0]; a.fs = s->fd_dct_fwd[1];
     a.flags = s->flags; a.acc = s->cg_acc; a.alpha = s->fcg_alpha; a.xsum = s->fcg_xsum; a.best = s->cg_best;
     a.ns = ns; a.rows = G.ny; a.it = it; a.first = first; a.env_stride = G.n;
     const dim3 grid((G.ny + 7) / 8, G.B);
     // per env: z, w, x, r (+ p, s) read; x, r, t1 (+ p, s) written
-    const int slot = fg_prof_slot(s, FG_PK_FCG_UPD, s->flags, G.B, (first ? 28.0 : 44.0) * G.n, (10.0 + 5.0 * log2((double)G.nx)) * G.n, st);
+    const int slot = fg_prof_slot(s, FG_PK_FCG_UPD, s->flags, G.B, (first ? (r0 ? 24.0 : 28.0) : 44.0) * G.n, (10.0 + 5.0 * log2((double)G.nx)) * G.n, st);
     if (int rc = (s->fd_dct_x == 2 ? launch_upd<true>(s, slot, G.nx, a, grid, st) : launch_upd<false>(s, slot, G.nx, a, grid, st))) return rc;
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;

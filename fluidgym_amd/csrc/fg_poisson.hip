@@ -476,7 +476,14 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             if (int rc = fg_fd_dct_forward(s, a.r, v.t1, st, 0, &judge)) return rc;      // u = Qx^T r_0 (the verdict on x_0 rides here)
         lead.judge = judge;
         if (int rc = fg_fd_tridiag(s, v.t1, st, &lead, rowm)) return rc;
-        if (int rc = fg_fcg_inv_apply(s, v, a.rA, 0, ns, st)) return rc;
+        // a solve started by k_fcg_div_fwd never stored r_0 = b and x_0 = 0: until the first update has written r and x, r is the
+        // right-hand side itself and x is known
+        const fg_real* r0 = (start_ready && start_fwd) ? a.b : nullptr;
+        {
+            FcgVectors v0 = v;
+            if (r0) v0.r = const_cast<fg_real*>(r0);      // (read only by the inverse kernel)
+            if (int rc = fg_fcg_inv_apply(s, v0, a.rA, 0, ns, st)) return rc;
+        }
         int first = 1;
         // restart period of THIS recurrence: s = P p is carried by a recurrence of its own here (s = w + beta s), so r and the true
         // residual drift apart faster than in the classic form once a solve stagnates at fp32 round-off (a solve asked for more than
@@ -485,7 +492,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         // true residual is therefore recomputed every ten iterations at the latest; solves of the envs take one to three.
         const int fused_reset = (a.reset_steps > 0 && a.reset_steps < 10) ? a.reset_steps : 10;
         for (; it < a.max_iterations && !done; ++it) {
-            if (int rc = fg_fcg_update_fwd(s, v, it, first, ns, st)) return rc;
+            if (int rc = fg_fcg_update_fwd(s, v, it, first, ns, st, it == 0 ? r0 : nullptr)) return rc;      // (first is 1 again after a restart: x and r exist by then)
             if (first) {      // p_it = z_it, s_it = w_it: the buffers change roles instead of being copied
                 fg_real* t = v.p; v.p = v.z; v.z = t;
                 t = v.s; v.s = v.w; v.w = t;

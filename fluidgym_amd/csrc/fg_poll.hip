@@ -61,16 +61,23 @@ int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStrea
 // follows it); the deltas between consecutive tags are summed per pair and printed when the process ends
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
+#include <vector>
 #include <string>
 namespace {
 struct HTrace {
     bool on; const char* last; std::chrono::steady_clock::time_point t;
-    std::map<std::string, std::pair<long long, double>> sum;
+    struct Row { long long n = 0; double sum = 0, mn = 1e30; std::vector<float> v; };
+    std::map<std::string, Row> sum;
     HTrace() : on(false), last(nullptr) { const char* e = getenv("FG_HTRACE"); on = e && atoi(e) != 0; }
     ~HTrace() {
         if (!on) return;
-        for (const auto& kv : sum) fprintf(stderr, "FG_HTRACE %-44s n %8lld  avg_us %8.2f\n", kv.first.c_str(), kv.second.first, kv.second.second / kv.second.first);
+        for (auto& kv : sum) {
+            Row& r = kv.second;
+            std::sort(r.v.begin(), r.v.end());
+            fprintf(stderr, "FG_HTRACE %-44s n %8lld  avg_us %8.2f  min %8.2f  median %8.2f\n", kv.first.c_str(), r.n, r.sum / r.n, r.mn, r.v.empty() ? 0.0 : (double)r.v[r.v.size() / 2]);
+        }
     }
 };
 HTrace g_htrace;
@@ -81,7 +88,9 @@ void fg_htrace(const char* tag) {
     const auto now = std::chrono::steady_clock::now();
     if (H.last) {
         auto& e = H.sum[std::string(H.last) + " -> " + tag];
-        e.first += 1; e.second += std::chrono::duration<double, std::micro>(now - H.t).count();
+        const double us = std::chrono::duration<double, std::micro>(now - H.t).count();
+        e.n += 1; e.sum += us; e.mn = us < e.mn ? us : e.mn;
+        if (e.v.size() < (1u << 20)) e.v.push_back((float)us);
     }
     H.last = tag; H.t = now;
 }

@@ -190,3 +190,23 @@ def test_rowmean_preconditioner_is_exact_for_row_constant_coefficients(monkeypat
     # (used_iterations is the 0-based index of the last iteration: one or, where the fp32 round-off of the transforms leaves the first
     #  residual just above 1e-5 of a unit right-hand side, two iterations against eight or nine)
     assert max(its["1"]) <= 1 and min(its["0"]) >= 5, its
+
+
+def test_env_whose_start_vector_meets_the_tolerance_gets_a_zero_pressure():
+    """k_fcg_div_fwd starts the solve without storing x_0 = 0 and r_0 = b; the first update kernel writes x and r -- and, for an env
+    the verdict on x_0 already stopped (right-hand side below the tolerance: a fluid at rest), the zeros of its result.  Two steps:
+    the first leaves a pressure field in pressureResult, then env 1 is put at rest and must come back with exactly zero pressure."""
+    case = _uniform_x(make_case(dims=2, n=(128, 32), fixed_axes=(0, 1), B=3, seed=4, stretch=0.2, vel_scale=0.3, wall_motion=0.0))
+    ns = case.native()
+    ok, stats = ns.piso_step(0.02, advection_tol=1e-7, pressure_tol=1e-6)
+    assert ok and float(ns.pressure[1].abs().max()) > 0
+    ns.velocity[1].zero_()
+    ns.copy_velocity_result_from_blocks()
+    ok, stats = ns.piso_step(0.02, advection_tol=1e-7, pressure_tol=1e-6)
+    torch.cuda.synchronize()
+    assert ok, stats
+    c = ns.solver_counters()
+    assert float(ns.pressure[1].abs().max()) == 0.0 and float(ns.velocity[1].abs().max()) == 0.0
+    assert float(ns.pressure[0].abs().max()) > 0 and float(ns.pressure[2].abs().max()) > 0
+    g = case.grid()
+    ns.close()
