@@ -140,3 +140,34 @@ def test_whole_piso_step_with_the_sweeps():
         dom = case.oracle_domain(b, g)
         O.piso_split_step(dom, dt[b])
         assert rel_err(out[True][0][b], dom.velocity) < 2e-5
+
+
+def test_env_trajectory_with_the_sweeps_stays_on_the_trajectory_of_bicgstab():
+    """ChannelJet2D-v0 (the headline env, 256 x 128) x 3 envs, three env steps = 75 PISO steps with random jets: the policy
+    `advection_jacobi` changes the iteration of the velocity solves, not their systems or tolerance -- velocity, pressure, observations and
+    rewards of the two runs agree to a few solver tolerances; every velocity solve of the first run is settled by the sweeps."""
+    import fluidgym_amd
+
+    out = {}
+    for jac in (True, False):
+        old = fluidgym_amd.set_solver_policy(advection_jacobi=jac)
+        try:
+            env = fluidgym_amd.make("ChannelJet2D-v0", num_envs=3)
+            env.reset(seed=11)
+            g = torch.Generator(device="cpu").manual_seed(3)
+            rewards = []
+            for _ in range(3):
+                obs, r, _, _, info = env.step((torch.rand(3, 1, generator=g) * 2 - 1).cuda())
+                rewards.append(_np(r))
+            ns = env._domain.solver
+            out[jac] = (_np(ns.velocity), _np(ns.pressure), _np(obs["velocity"]), np.stack(rewards), ns.advection_jacobi_counts(), ns.solver_counters())
+            env.close()
+        finally:
+            fluidgym_amd.set_solver_policy(**old)
+    cj, cb = out[True][4], out[False][4]
+    assert cj["settled_by_sweeps"] >= 75 and cj["handed_to_bicgstab"] == 0 and cb["settled_by_sweeps"] == 0
+    print("sweeps per solve", out[True][5]["velocity"], "BiCGStab iterations per solve", out[False][5]["velocity"])
+    assert rel_err(out[True][0], out[False][0]) < 2e-5      # velocity after 75 PISO steps
+    assert rel_err(out[True][2], out[False][2]) < 2e-5      # observations
+    assert rel_err(out[True][1], out[False][1]) < 2e-3      # pressure (a Lagrange multiplier of the step: second differences of u / dt)
+    assert np.abs(out[True][3] - out[False][3]).max() < 1e-4 * np.abs(out[False][3]).max() + 1e-7
