@@ -310,17 +310,14 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     *outcome = 2;
     const FgGrid& G = s->grid;
     const int B = G.B, n = G.n, nsys = 2 * B, rows = JAC_CELLS / G.nx;
-    const int s_max = (rows - 4) / 2 < 8 ? (rows - 4) / 2 : 8;
-    // sweeps per pass: what moves the fewest bytes for the sweep count of the previous solve of this kind
-    int S = s_max < 4 ? s_max : 4, P = 2;
-    if (H.sweeps > 0) {
-        double best = 1e30;
-        for (int c = 2; c <= s_max; ++c) {
-            const int p = (H.sweeps + c - 1) / c;
-            const double cost = p * (9.0 * jac_tiles(G.ny, rows, c) * rows / G.ny + 2.0) + 0.5 * p;   // (+ launch and fill of a pass)
-            if (cost < best) { best = cost; S = c; P = p; }
-        }
-    }
+    // Sweeps per pass: fixed by the region shape, NOT by the history of the handle -- an env stops at the first pass boundary where
+    // the verdict holds, so with S fixed its iterate (its bits) does not depend on how many passes were enqueued ahead, and a
+    // replayed step (get_state -> set_state -> step) repeats exactly.  6 sweeps on 32-row regions (256 columns: 1.5 x the rows
+    // loaded at 128 rows, 12 sweeps = 2 passes at the headline), 4 on 16-row regions (512 columns), 8 on the tall ones.
+    const int S = rows <= 16 ? 4 : (rows <= 32 ? 6 : 8);
+    // passes to enqueue before the first check: what the previous solve of this kind needed (the history only decides how much is
+    // enqueued ahead of the poll)
+    int P = H.sweeps > 0 ? (H.sweeps + S - 1) / S : 2;
     JacArgs q = {};
     q.diag = a.diag; q.off = a.off; q.rhs = a.rhs; q.acc = s->acc; q.flags = s->flags; q.info = s->info_dev; q.tol = a.tol;
     q.sweeps = S; q.ny = G.ny; q.n = n; q.tiles = jac_tiles(G.ny, rows, S);
