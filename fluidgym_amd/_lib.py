@@ -159,6 +159,7 @@ SIGNATURES = {
     "fg_copy_velocity_result_from_blocks": (c_int, [c_void_p, c_void_p]),
     "fg_piso_step": (c_int, [c_void_p, c_void_p, POINTER(FgStepOptions), POINTER(c_int32), c_void_p]),
     "fg_single_step": (c_int, [c_void_p, POINTER(FgSimOptions), POINTER(c_int32), POINTER(c_float), c_void_p]),
+    "fg_multi_step": (c_int, [c_void_p, POINTER(FgSimOptions), c_int32, POINTER(c_void_p), POINTER(c_int32), POINTER(c_float), POINTER(c_int32), c_void_p]),
     "fg_make_divergence_free": (c_int, [c_void_p, c_float, c_int, POINTER(FgSolveInfo), c_void_p]),
     "fg_reset_solver_state": (c_int, [c_void_p, c_void_p]),
     "fg_get_buffer": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),

@@ -714,6 +714,22 @@ extern "C" int fg_solver_counters(fg_handle s, int64_t* out13, int32_t reset) {
     return FG_OK;
 }
 
+extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out, fg_real* flux_host, void* stream);
+extern "C" int fg_multi_step(fg_handle s, const fg_sim_options* o, int32_t n, const fg_real* const* bvel_schedule, int32_t* out_6n,
+                             fg_real* flux_host, int32_t* steps_done, void* stream) {
+    FG_REQUIRE(s && o && out_6n && n >= 0, FG_ERR_INVALID_ARG, "fg_multi_step: bad argument");
+    if (steps_done) *steps_done = 0;
+    for (int k = 0; k < n; ++k) {
+        if (bvel_schedule)
+            for (int f = 0; f < 2 * s->grid.dims; ++f)
+                if (const fg_real* p = bvel_schedule[(size_t)k * 6 + f])
+                    if (int rc = fg_bind(s, FG_BOUND_VELOCITY + f, const_cast<fg_real*>(p))) return rc;
+        if (int rc = fg_single_step(s, o, out_6n + 6 * (size_t)k, flux_host, stream)) return rc;
+        if (steps_done) *steps_done = k + 1;
+    }
+    return FG_OK;
+}
+
 // np.isclose(a, 0) with the default rtol=1e-5, atol=1e-8
 static inline bool is_close_zero(double a) { return std::fabs(a) <= 1e-8; }
 

@@ -198,16 +198,11 @@ class ChannelJetEnv2D(FluidEnv):
             # [n, wall, B, 2, 1, X]: each wall gets its OWN slice (the reference keeps two independent boundary tensors; an in-place
             # write to one wall -- setVelocity, a loaded state -- must not reach the other)
             jets = (self._jet_shape[None] * controls.reshape(n, self._num_envs, 1, 1, 1)).unsqueeze(1).repeat(1, 2, 1, 1, 1, 1)
-            sol = self._domain.solver
             self._jets = jets          # (the walls stay bound to their last slices after the step)
-        for k in range(n):
-            if self._enable_actions:
-                # the walls are BOUND to this sim step's slices (the same wall-normal velocity on both: zero net flux) -- a pointer
-                # update on the host, no copy launch (the library takes boundary pointers as kernel arguments)
-                sol.set_boundary_velocity(2, jets[k, 0])
-                sol.set_boundary_velocity(3, jets[k, 1])
-            if not self._sim.single_step():
-                raise RuntimeError("simulation step failed")
+        # the n sim steps of this env step in one native call (fg_multi_step): before sim step k the walls are BOUND to that step's
+        # slices (the same wall-normal velocity on both: zero net flux) -- a pointer update, no copy launch
+        if not self._sim.multi_step(n, {2: jets[:, 0], 3: jets[:, 1]} if self._enable_actions else None):
+            raise RuntimeError("simulation step failed")
         if self._enable_actions:
             self._current_action = controls[n - 1]
         cross, shear = self._metrics_now()

@@ -297,11 +297,10 @@ class NativeSolver:
         L.check(rc, allow=(L.FG_ERR_NOT_CONVERGED,))
         return rc == L.FG_OK, list(stats)
 
-    def single_step(self, time_step, cfl, adaptive=True, substeps=1, flux_balance_tol=1e-5, outflow_faces=(),
-                    outflow_velm=(0.0, 0.0, 0.0), outflow_tol=1e-5, corrector_steps=2, advect_scalar=True,
-                    advection_tol=1e-5, pressure_tol=1e-5, max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0,
-                    method=None, pressure_warm_start=False, max_substeps=1000):
-        """Native ``Simulation.single_step``; returns (all_converged, solver_stats[4], substeps)."""
+    def _sim_options(self, time_step, cfl, adaptive=True, substeps=1, flux_balance_tol=1e-5, outflow_faces=(),
+                     outflow_velm=(0.0, 0.0, 0.0), outflow_tol=1e-5, corrector_steps=2, advect_scalar=True,
+                     advection_tol=1e-5, pressure_tol=1e-5, max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0,
+                     method=None, pressure_warm_start=False, max_substeps=1000):
         method = self.default_method if method is None else method
         o = self._SimOptions()
         o.step = self._StepOptions(corrector_steps, int(advect_scalar), method, max_iterations, advection_tol, pressure_tol,
@@ -316,6 +315,16 @@ class NativeSolver:
             o.outflow_velm[i] = float(outflow_velm[i]) if i < len(outflow_velm) else 0.0
         o.outflow_tol = float(outflow_tol)
         o.max_substeps = int(max_substeps)
+        return o
+
+    def single_step(self, time_step, cfl, adaptive=True, substeps=1, flux_balance_tol=1e-5, outflow_faces=(),
+                    outflow_velm=(0.0, 0.0, 0.0), outflow_tol=1e-5, corrector_steps=2, advect_scalar=True,
+                    advection_tol=1e-5, pressure_tol=1e-5, max_iterations=5000, buoyancy_axis=-1, buoyancy_factor=0.0,
+                    method=None, pressure_warm_start=False, max_substeps=1000):
+        """Native ``Simulation.single_step``; returns (all_converged, solver_stats[4], substeps)."""
+        o = self._sim_options(time_step, cfl, adaptive, substeps, flux_balance_tol, outflow_faces, outflow_velm, outflow_tol, corrector_steps,
+                              advect_scalar, advection_tol, pressure_tol, max_iterations, buoyancy_axis, buoyancy_factor, method,
+                              pressure_warm_start, max_substeps)
         out = (ctypes.c_int32 * 6)()
         flux = (self._c_real * self.B)()
         rc = self.lib.fg_single_step(self.handle, ctypes.byref(o), out, flux, _stream(self.device))
@@ -327,6 +336,37 @@ class NativeSolver:
             raise LinsolveError("linear solve produced a non-finite residual")
         L.check(rc)
         return bool(out[5]), [int(out[i]) for i in range(4)], int(out[4])
+
+    def multi_step(self, n, time_step, cfl, boundary_schedule=None, **kw):
+        """``n`` native ``single_step`` calls in one C call (``fg_multi_step``): the sim steps of an env step without a return to the
+        interpreter in between.  ``boundary_schedule``: {face: tensor [n, B, d, ...]} -- slice k is bound to the face before sim step
+        k (what ``set_boundary_velocity(face, t[k])`` in front of every step does).  Keyword arguments as :meth:`single_step`.
+        Returns a list of (all_converged, solver_stats[4], substeps), one per step."""
+        o = self._sim_options(time_step, cfl, **kw)
+        sched = None
+        if boundary_schedule:
+            sched = (ctypes.c_void_p * (6 * n))()
+            for face, t in boundary_schedule.items():
+                # (t may be a strided view along the step axis -- the channel keeps [n, wall, ...] -- as long as every slice is dense)
+                assert t.shape[0] == n and t[0].is_contiguous() and t.dtype == self.dtype and t.device == self.device
+                base, step_bytes = t.data_ptr(), t.stride(0) * t.element_size()
+                for k in range(n):
+                    sched[6 * k + int(face)] = base + k * step_bytes
+        out = (ctypes.c_int32 * (6 * n))()
+        flux = (self._c_real * self.B)()
+        done = ctypes.c_int32(0)
+        rc = self.lib.fg_multi_step(self.handle, ctypes.byref(o), int(n), sched, out, flux, ctypes.byref(done), _stream(self.device))
+        if boundary_schedule:
+            for face, t in boundary_schedule.items():      # what the handle is bound to now
+                self.bvel[int(face)] = t[max(min(done.value, n - 1), 0)]
+        if rc == L.FG_ERR_FLUX_BALANCE:
+            raise RuntimeError(
+                "Domain boundary fluxes not balanced, cannot proceed with simulation step. "
+                f"Flux balance: {list(flux)}, flux_balance_tol: {kw.get('flux_balance_tol', 1e-5)}")
+        if rc == L.FG_ERR_NOT_FINITE:
+            raise LinsolveError("linear solve produced a non-finite residual")
+        L.check(rc)
+        return [(bool(out[6 * k + 5]), [int(out[6 * k + i]) for i in range(4)], int(out[6 * k + 4])) for k in range(n)]
 
     def reset_solver_state(self):
         L.check(self.lib.fg_reset_solver_state(self.handle, _stream(self.device)), lib=self.lib)

@@ -18,6 +18,8 @@ already covered the requested time span are masked out with ``dt = 0``.
 """
 from __future__ import annotations
 
+import os
+
 import logging
 from typing import Any, Callable, Dict, List, Optional, Sequence, Union
 
@@ -271,6 +273,47 @@ class Simulation:
             _LOG.error("linear solve did not converge (iterations %s)", stats)
             return False
         return True
+
+    def multi_step(self, n: int, boundary_schedule=None) -> bool:
+        """``n`` calls of :meth:`single_step` -- in ONE native call when every hook has a native equivalent (``fg_multi_step``): the
+        sim steps of an env step (``FluidEnv.step``, fluid_env.py:788-800) then run without the interpreter in between.
+        ``boundary_schedule``: {face: tensor [n, ...]}, slice k bound to the face's boundary velocity before sim step k (the
+        smoothed jet control changes every sim step).  Same arithmetic, same order, same results as the loop."""
+        s = self._solver
+        if not (self._native_ok() and hasattr(s, "multi_step")) or os.environ.get("FLUIDGYM_AMD_MULTI_STEP", "1") == "0":
+            for k in range(n):
+                for face, t in (boundary_schedule or {}).items():
+                    s.set_boundary_velocity(face, t[k])
+                if not self.single_step():
+                    return False
+            return True
+        bax, bfac = self.buoyancy if self.buoyancy is not None else (-1, 0.0)
+        faces, velm, otol = (), (0.0, 0.0, 0.0), 1e-5
+        if self.outflow is not None:
+            bounds, velm_t, otol = self.outflow
+            faces = [b.face for b in bounds]
+            velm = np.asarray(velm_t.detach().cpu() if isinstance(velm_t, torch.Tensor) else velm_t, dtype=np.float64).reshape(-1)
+        try:
+            res = s.multi_step(
+                n, self.time_step, self.adaptive_CFL, boundary_schedule, adaptive=(self.substeps == -1), substeps=max(self.substeps, 1),
+                flux_balance_tol=self.flux_balance_tol, outflow_faces=faces, outflow_velm=velm,
+                outflow_tol=get_solver_tolerance(otol), corrector_steps=self.corrector_steps,
+                advect_scalar=self.advect_passive_scalar and self.domain.hasPassiveScalar(),
+                advection_tol=get_solver_tolerance(self.advection_tol), pressure_tol=get_solver_tolerance(self.pressure_tol),
+                max_iterations=self.linear_solve_max_iterations, buoyancy_axis=bax, buoyancy_factor=bfac,
+                pressure_warm_start=self.pressure_warm_start)
+        except LinsolveError:
+            _LOG.exception("Simulation failed in step (total step %d):", self.total_step)
+            return False
+        good = True
+        for ok, stats, n_sub in res:
+            self.last_stats, self.substep_count = stats, n_sub
+            self.total_step += n_sub
+            self.total_time += self.time_step if self.substeps == -1 else self.time_step * max(self.substeps, 1)
+            if not ok and not self.pressure_return_best_result:
+                _LOG.error("linear solve did not converge (iterations %s)", stats)
+                good = False
+        return good
 
     def _PISO_adaptive_step(self, CFL_cond: Optional[float] = None, max_substeps: int = 1000) -> bool:
         """Per-env version of ``_PISO_adaptive_step`` (PISOtorch_simulation.py:2004-2064): before every

@@ -293,6 +293,13 @@ typedef struct fg_sim_options {
 } fg_sim_options;
 int fg_single_step(fg_handle h, const fg_sim_options* opt, int32_t* out_host_6, fg_real* flux_balance_host,
                    void* stream);
+/* fg_multi_step: `n` calls of fg_single_step in one C call -- the sim steps of one env step (FluidEnv.step runs
+ * int(step_length / dt) of them, fluid_env.py:840-842) without a return to the interpreter in between.  bvel_schedule (optional,
+ * n x 6 pointers, step-major): boundary velocity tensor bound to face f before sim step k, NULL = keep what is bound (the
+ * smoothed control of the jets changes every sim step, cylinder_env_base.py:748-753).  out_host_6n receives the six words of
+ * every step; steps_done the number of steps completed (n unless a step returned an error, which is passed on). */
+int fg_multi_step(fg_handle h, const fg_sim_options* opt, int32_t n, const fg_real* const* bvel_schedule, int32_t* out_host_6n,
+                  fg_real* flux_balance_host, int32_t* steps_done, void* stream);
 /* make_divergence_free (PISOtorch_simulation.py:1320-1429) */
 int fg_make_divergence_free(fg_handle h, fg_real tol, int max_iterations, fg_solve_info* info_host,
                             void* stream);

