@@ -44,7 +44,7 @@ struct JacArgs {
     const float* xin; float* xout;                            // [B,2,N] (xin unused in a pass that starts from zero)
     FgDacc* acc; int32_t* flags; fg_solve_info* info;
     float tol;
-    int pass, sweeps, zero_start, ny, n, tiles;
+    int pass, sweeps, zero_start, nx, ny, n, tiles;
 };
 
 __device__ __forceinline__ void jac_mark(const JacArgs& a, int sys, float crit, int sweeps_done) {
@@ -81,15 +81,26 @@ __device__ __forceinline__ bool jac_verdict(const JacArgs& a, int b, int pass, b
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// value of the lane below / above within the 16-lane DPP row (row_shr:1 / row_shl:1); the first / last lane of a row keeps its own
+__device__ __forceinline__ float dpp_from_below(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_above(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x101, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float el(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
-template <int NX>
+// XT = false: the region is ROWS full rows (4 Q = nx columns), regions tile the y axis.  XT = true: the region is ALL rows (ROWS = ny)
+// of a band of 4 Q columns, regions tile the x axis (FIXED x faces only: the band's lane wrap-around is halo, never the periodic
+// neighbour) -- the better shape for wide grids, where a full-row region is only 16 rows high and half of what it loads is halo.
+template <int Q, bool XT>
 __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
-    constexpr int Q = NX / 4;                  // column quads per row
+    constexpr int NX = 4 * Q;                  // columns of the region
     constexpr int STRIPS = JAC_THREADS / Q;    // strips of 4 rows
     constexpr int ROWS = 4 * STRIPS;
     static_assert(Q * STRIPS == JAC_THREADS && ROWS * NX == JAC_CELLS, "region shape");
     constexpr bool SPLIT = Q > 64;             // a row spans several waves: the x neighbours at the wave seams go through LDS
+    static_assert(!(SPLIT && XT), "bands are at most one wave wide");
     constexpr int WPR = SPLIT ? Q / 64 : 1;    // waves per row
     // dynamic LDS (64 KB + the seams: above the static limit, fg_jacobi_lds_ready):
     //   edge [buffer][comp][2 * strip + (0 top | 1 bottom row of the strip)][column]
@@ -100,31 +111,39 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
     __shared__ float red[2][JAC_THREADS / 64];
     const int b = blockIdx.y, tile = blockIdx.x, t = threadIdx.x, lane = t & 63;
     if (jac_verdict(a, b, a.pass, tile == 0 && t == 0)) return;
-    const int S = a.sweeps, TY = ROWS - 2 * S;
-    int start = 0, out0 = 0, out1 = a.ny;
+    // tiles along the tiled axis (y for full-row regions, x for bands): `span` cells per region, of which the outer S towards a
+    // neighbouring region are halo
+    constexpr int SPAN = XT ? NX : ROWS;
+    const int extent = XT ? a.nx : a.ny;
+    const int S = a.sweeps, TY = SPAN - 2 * S;
+    int start = 0, out0 = 0, out1 = extent;
     if (a.tiles > 1) {
-        out0 = tile == 0 ? 0 : (ROWS - S) + (tile - 1) * TY;
-        out1 = tile == a.tiles - 1 ? a.ny : (ROWS - S) + tile * TY;
+        out0 = tile == 0 ? 0 : (SPAN - S) + (tile - 1) * TY;
+        out1 = tile == a.tiles - 1 ? extent : (SPAN - S) + tile * TY;
         start = tile == 0 ? 0 : out0 - S;
-        if (start > a.ny - ROWS) start = a.ny - ROWS;
+        if (start > extent - SPAN) start = extent - SPAN;
     }
     const int col = t % Q, strip = t / Q;
     const int row0 = 4 * strip;               // first region row of the strip
-    const size_t cell0 = (size_t)(start + row0) * NX + 4 * col;
+    const size_t ld = (size_t)a.nx;           // row pitch of the fields
+    const size_t cell0 = XT ? (size_t)row0 * ld + (size_t)(start + 4 * col) : (size_t)(start + row0) * ld + (size_t)(4 * col);
     const size_t n = (size_t)a.n;
+    // which of the thread's cells the region answers for: rows of the strip (full-row regions) or columns of the quad (bands)
+    const int lo = out0 - (XT ? start + 4 * col : start + row0), hi = out1 - (XT ? start + 4 * col : start + row0);   // cell k of 0..3 is inside iff lo <= k < hi
+    auto inside = [&](int r, int e) { const int k = XT ? e : r; return k >= lo && k < hi; };
     // ---- the strip's part of the system: all loads first, then the scaling
     float4 of[4][4], bp[2][4], xo[2][4];
     {
     float4 dg[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        dg[r] = ld4(a.diag + (size_t)b * n + cell0 + (size_t)r * NX);
+        dg[r] = ld4(a.diag + (size_t)b * n + cell0 + (size_t)r * ld);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) of[f][r] = ld4(a.off + ((size_t)b * 4 + f) * n + cell0 + (size_t)r * NX);
+        for (int f = 0; f < 4; ++f) of[f][r] = ld4(a.off + ((size_t)b * 4 + f) * n + cell0 + (size_t)r * ld);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            bp[c][r] = ld4(a.rhs + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * NX);
-            xo[c][r] = a.zero_start ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(a.xin + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * NX);
+            bp[c][r] = ld4(a.rhs + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * ld);
+            xo[c][r] = a.zero_start ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(a.xin + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * ld);
         }
     }
 #pragma unroll
@@ -169,7 +188,15 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
             float4 xn[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float xl = __shfl(xo[c][r].w, lane_l, 64), xr = __shfl(xo[c][r].x, lane_r, 64);
+                float xl, xr;
+                if constexpr (XT && Q <= 16) {
+                    // narrow bands (a band row is 8 or 16 lanes = at most one 16-lane DPP row): what comes in over a band's edge is halo
+                    // (or meets a zero coefficient at a wall), so the neighbour lanes of the DPP row will do -- a VALU move instead of
+                    // a trip through the LDS crossbar
+                    xl = dpp_from_below(xo[c][r].w); xr = dpp_from_above(xo[c][r].x);
+                } else {
+                    xl = __shfl(xo[c][r].w, lane_l, 64); xr = __shfl(xo[c][r].x, lane_r, 64);
+                }
                 if constexpr (SPLIT) {
                     if (lane == 0) xl = seam[cur][c][row0 + r][2 * ((wrow + WPR - 1) % WPR) + 1];
                     if (lane == 63) xr = seam[cur][c][row0 + r][2 * ((wrow + 1) % WPR)];
@@ -185,16 +212,15 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
                 xn[r] = v;
             }
             if (last) {
-                // residual of the iterate this sweep started from, on the rows this region answers for (the diagonal is read again
+                // residual of the iterate this sweep started from, on the cells this region answers for (the diagonal is read again
                 // here -- from L2 -- instead of living in 16 registers through the sweeps)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int g = start + row0 + r;
-                    if (g >= out0 && g < out1) {
-                        const float4 d4 = ld4(a.diag + (size_t)b * n + cell0 + (size_t)r * NX);
+                    if (XT ? (hi > 0 && lo < 4) : inside(r, 0)) {
+                        const float4 d4 = ld4(a.diag + (size_t)b * n + cell0 + (size_t)r * ld);
                         const float r0 = d4.x * (xn[r].x - xo[c][r].x), r1 = d4.y * (xn[r].y - xo[c][r].y);
                         const float r2 = d4.z * (xn[r].z - xo[c][r].z), r3 = d4.w * (xn[r].w - xo[c][r].w);
-                        part[c] += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+                        part[c] += (inside(r, 0) ? r0 * r0 : 0.f) + (inside(r, 1) ? r1 * r1 : 0.f) + (inside(r, 2) ? r2 * r2 : 0.f) + (inside(r, 3) ? r3 * r3 : 0.f);
                     }
                 }
             }
@@ -206,8 +232,14 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int g = start + row0 + r;
-            if (g >= out0 && g < out1) *reinterpret_cast<float4*>(a.xout + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * NX) = xo[c][r];
+            float* dst = a.xout + ((size_t)b * 2 + c) * n + cell0 + (size_t)r * ld;
+            if (inside(r, 0) && inside(r, 3)) *reinterpret_cast<float4*>(dst) = xo[c][r];
+            else if (XT) {      // a band's output range ends inside this quad
+                if (inside(r, 0)) dst[0] = xo[c][r].x;
+                if (inside(r, 1)) dst[1] = xo[c][r].y;
+                if (inside(r, 2)) dst[2] = xo[c][r].z;
+                if (inside(r, 3)) dst[3] = xo[c][r].w;
+            }
         }
         const float s = fg_wave_sum(part[c]);
         if (lane == 0) red[c][t >> 6] = s;
@@ -266,39 +298,71 @@ int jac_tiles(int ny, int rows, int sweeps) {
 
 constexpr size_t JAC_LDS = sizeof(float) * (2 * 2 * 2 * (JAC_CELLS / 4) + 2 * 2 * 128 * 2);   // edge rows + seams (<= 128 row-waves)
 
+#define JAC_FOR_EACH_KERNEL(X) X(16, false) X(32, false) X(64, false) X(128, false) X(8, true) X(16, true) X(32, true) X(64, true)
+
 // dynamic LDS above 64 KB needs an explicit opt-in per kernel (once per process)
 bool jac_lds_ready() {
     static int state = 0;      // 0 not tried, 1 granted, -1 refused
     if (state == 0) {
-        const void* fns[4] = {reinterpret_cast<const void*>(k_jac_pass<64>), reinterpret_cast<const void*>(k_jac_pass<128>),
-                              reinterpret_cast<const void*>(k_jac_pass<256>), reinterpret_cast<const void*>(k_jac_pass<512>)};
         state = 1;
-        for (const void* f : fns)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JAC_LDS) != hipSuccess) { (void)hipGetLastError(); state = -1; }
+#define JAC_OPT_IN(Q, XT)                                                                                                              \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_jac_pass<Q, XT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)JAC_LDS) != hipSuccess) { \
+            (void)hipGetLastError(); state = -1;                                                                                       \
+        }
+        JAC_FOR_EACH_KERNEL(JAC_OPT_IN)
+#undef JAC_OPT_IN
     }
     return state == 1;
 }
 
-int launch_pass(const fg_state* s, int slot, const JacArgs& a, hipStream_t st) {
-    const dim3 grid(a.tiles, s->grid.B), block(JAC_THREADS);
-    switch (s->grid.nx) {
-        case 64: FG_LAUNCH_P(s, slot, k_jac_pass<64>, grid, block, JAC_LDS, st, a); break;
-        case 128: FG_LAUNCH_P(s, slot, k_jac_pass<128>, grid, block, JAC_LDS, st, a); break;
-        case 256: FG_LAUNCH_P(s, slot, k_jac_pass<256>, grid, block, JAC_LDS, st, a); break;
-        case 512: FG_LAUNCH_P(s, slot, k_jac_pass<512>, grid, block, JAC_LDS, st, a); break;
-        default: fg_set_error("Jacobi sweeps: unsupported row length"); return FG_ERR_UNSUPPORTED;
+// Region shape of a grid: full rows tiling y, or bands of all rows tiling x (FIXED x only) -- whichever loads fewer rows / columns per
+// sweep.  A function of the grid alone (never of the handle's history): the iterate of an env must not depend on it.
+struct JacPlan { bool ok, xt; int q, span, sweeps, tiles; double cost; };
+// sweeps per pass by region depth along the tiled axis.  Bands take more: their halo costs columns of ALL rows, and a pass of 12 sweeps
+// over 64-column bands (1.5 x the columns loaded) settles the headline's systems in ONE pass over the matrix (measured, same box:
+// 7 100-7 170 env-steps/s against 6 400-6 780 with two passes of 6 over full rows); 8 on 32-column bands (512 x 256: 1 834 against
+// 1 466 with full rows of 16)
+int jac_sweeps_for(int span, bool xt) { return xt ? (span <= 32 ? 8 : 12) : (span <= 16 ? 4 : (span <= 32 ? 6 : 8)); }
+JacPlan jac_plan(const FgGrid& G) {
+    JacPlan best = {false, false, 0, 0, 0, 0, 1e30};
+    if (G.dims != 2 || !(G.fixed[2] && G.fixed[3])) return best;
+    // FG_JAC_SHAPE (A/B runs): 1 = full rows only, 2 = bands only; FG_JAC_SWEEPS = sweeps per pass (clamped to what the region allows)
+    static const int force_shape = [] { const char* e = getenv("FG_JAC_SHAPE"); return e ? atoi(e) : 0; }();
+    static const int force_sweeps = [] { const char* e = getenv("FG_JAC_SWEEPS"); return e ? atoi(e) : 0; }();
+    auto sweeps_of = [&](int span, bool xt) { int S = force_sweeps > 0 ? force_sweeps : jac_sweeps_for(span, xt); const int cap = (span - 4) / 2; return S > cap ? cap : (S < 1 ? 1 : S); };
+    if (force_shape != 2 && (G.nx == 64 || G.nx == 128 || G.nx == 256 || G.nx == 512)) {
+        const int rows = JAC_CELLS / G.nx;
+        if (G.ny >= rows) {
+            const int S = sweeps_of(rows, false), tiles = jac_tiles(G.ny, rows, S);
+            const double cost = (9.0 * tiles * rows / G.ny + 2.0) / S;
+            if (cost < best.cost) best = JacPlan{true, false, G.nx / 4, rows, S, tiles, cost};
+        }
     }
-    return FG_OK;
+    if (force_shape != 1 && G.fixed[0] && G.fixed[1] && (G.ny == 32 || G.ny == 64 || G.ny == 128 || G.ny == 256)) {
+        const int w = JAC_CELLS / G.ny;
+        if (G.nx >= w && (G.nx & 3) == 0) {
+            const int S = sweeps_of(w, true), tiles = jac_tiles(G.nx, w, S);
+            const double cost = (9.0 * tiles * w / G.nx + 2.0) / S;
+            if (cost < best.cost) best = JacPlan{true, true, w / 4, w, S, tiles, cost};
+        }
+    }
+    return best;
+}
+
+int launch_pass(const fg_state* s, int slot, const JacPlan& P, const JacArgs& a, hipStream_t st) {
+    const dim3 grid(a.tiles, s->grid.B), block(JAC_THREADS);
+#define JAC_CASE(Q, XT) if (P.q == Q && P.xt == XT) { FG_LAUNCH_P(s, slot, (k_jac_pass<Q, XT>), grid, block, JAC_LDS, st, a); return FG_OK; }
+    JAC_FOR_EACH_KERNEL(JAC_CASE)
+#undef JAC_CASE
+    fg_set_error("Jacobi sweeps: unsupported region shape");
+    return FG_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
 bool fg_jacobi_ok(const fg_state* s, const FgBicgArgs& a) {
-    const FgGrid& G = s->grid;
-    if (!s->adv_jacobi || a.precond || a.nc != 2 || G.dims != 2) return false;
-    if (!(G.nx == 64 || G.nx == 128 || G.nx == 256 || G.nx == 512)) return false;
-    const int rows = JAC_CELLS / G.nx;
-    return G.fixed[2] && G.fixed[3] && G.ny >= rows && s->jac_prev != nullptr && jac_lds_ready();
+    if (!s->adv_jacobi || a.precond || a.nc != 2 || s->jac_prev == nullptr) return false;
+    return jac_plan(s->grid).ok && jac_lds_ready();
 }
 
 // *outcome: 0 = not tried (the kind is backing off: the prepared solve state is untouched), 1 = solved here, 2 = tried and given up --
@@ -309,18 +373,18 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     if (H.skip > 0) { --H.skip; return FG_OK; }
     *outcome = 2;
     const FgGrid& G = s->grid;
-    const int B = G.B, n = G.n, nsys = 2 * B, rows = JAC_CELLS / G.nx;
-    // Sweeps per pass: fixed by the region shape, NOT by the history of the handle -- an env stops at the first pass boundary where
-    // the verdict holds, so with S fixed its iterate (its bits) does not depend on how many passes were enqueued ahead, and a
-    // replayed step (get_state -> set_state -> step) repeats exactly.  6 sweeps on 32-row regions (256 columns: 1.5 x the rows
-    // loaded at 128 rows, 12 sweeps = 2 passes at the headline), 4 on 16-row regions (512 columns), 8 on the tall ones.
-    const int S = rows <= 16 ? 4 : (rows <= 32 ? 6 : 8);
+    const int B = G.B, n = G.n, nsys = 2 * B;
+    // Region shape and sweeps per pass: fixed by the grid, NOT by the history of the handle -- an env stops at the first pass boundary
+    // where the verdict holds, so its iterate (its bits) does not depend on how many passes were enqueued ahead, and a replayed step
+    // (get_state -> set_state -> step) repeats exactly (jac_sweeps_for).
+    const JacPlan plan = jac_plan(G);
+    const int S = plan.sweeps;
     // passes to enqueue before the first check: what the previous solve of this kind needed (the history only decides how much is
     // enqueued ahead of the poll)
     int P = H.sweeps > 0 ? (H.sweeps + S - 1) / S : 2;
     JacArgs q = {};
     q.diag = a.diag; q.off = a.off; q.rhs = a.rhs; q.acc = s->acc; q.flags = s->flags; q.info = s->info_dev; q.tol = a.tol;
-    q.sweeps = S; q.ny = G.ny; q.n = n; q.tiles = jac_tiles(G.ny, rows, S);
+    q.sweeps = S; q.nx = G.nx; q.ny = G.ny; q.n = n; q.tiles = plan.tiles;
     float* work = s->w[0];
     const double bytes_sys = 0.5 * 4.0 * n * 11.0, flops_sys = 0.5 * n * 2.0 * 9.0 * S;
     int passes = 0;
@@ -334,7 +398,7 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
             const bool to_x = ((passes & 1) == last_parity);
             q.xin = to_x ? work : a.x; q.xout = to_x ? a.x : work;
             const int slot = fg_prof_slot(s, FG_PK_JAC_PASS, s->flags, nsys, q.zero_start ? bytes_sys * 9.0 / 11.0 : bytes_sys, flops_sys, st);
-            if (int rc = launch_pass(s, slot, q, st)) return rc;
+            if (int rc = launch_pass(s, slot, plan, q, st)) return rc;
         }
         return FG_OK;
     };

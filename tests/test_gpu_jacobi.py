@@ -1,8 +1,8 @@
 """The on-chip Jacobi sweeps of the velocity systems (csrc/fg_jacobi.hip: k_jac_pass / k_jac_check / k_jac_settle, switched by
 fg_set_advection_jacobi) against the oracle's direct solve and against the BiCGStab they stand in for (bicgstabSolveGPU,
 bicgstab_solver_kernel.cu:63-411, called for the velocity systems at PISOtorch_simulation.py:1735-1742), through the C ABI: every
-row length the kernel is instantiated for (64 / 128 / 256 / 512: four region shapes, the last with rows that span two waves),
-ragged last regions, periodic and FIXED x, a masked env, the hand-over of a system the sweeps do not contract on, reproducible bits,
+region shape the kernel is instantiated for (full rows of 64 / 128 / 256 / 512 cells tiling y, the last with rows that span two waves;
+bands of all 256 / 128 / 64 / 32 rows tiling x), ragged last regions, periodic and FIXED x, a masked env, the hand-over of a system the sweeps do not contract on, reproducible bits,
 and a whole PISO step."""
 import numpy as np
 import pytest
@@ -40,7 +40,10 @@ def _true_residual_rms(case, dt, b, x):
 
 
 @pytest.mark.parametrize("n, fixed", [((64, 130), (0, 1)), ((128, 64), (0, 1)), ((128, 75), (1,)), ((256, 128), (0, 1)), ((256, 37), (1,)),
-                                      ((512, 16), (0, 1)), ((512, 45), (1,))])
+                                      ((512, 16), (0, 1)), ((512, 45), (1,)),
+                                      # bands (all rows of 8192 / ny columns, regions tile x; FIXED x only): 8 / 16 / 32 / 64 quads wide, a row
+                                      # length that is no power of two, output ranges that end inside a quad
+                                      ((512, 256), (0, 1)), ((200, 128), (0, 1)), ((256, 64), (0, 1)), ((320, 32), (0, 1))])
 def test_sweeps_reach_the_solution_of_the_direct_solve(n, fixed):
     """uniform grids; per env its own dt with CFL <= ~0.8 and diffusion numbers ~0.1 (the regime of the channel envs: cell Peclet
     numbers above 2, rows dominated by 1/dt).  The tolerance is scaled like the envs' 1e-5 at 1/dt = 100 -- an fp32 iterate
