@@ -179,38 +179,46 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
                 }
             }
         }
+        // one cell row of the strip: x neighbours from the neighbouring lanes, y neighbours `up` / `dn` (the thread's own rows, or the
+        // strip edges of the neighbours from LDS for rows 0 and 3)
+        auto row_update = [&](int c, int r, const float4& up, const float4& dn) -> float4 {
+            float xl, xr;
+            if constexpr (XT && Q <= 16) {
+                // narrow bands (a band row is 8 or 16 lanes = at most one 16-lane DPP row): what comes in over a band's edge is halo
+                // (or meets a zero coefficient at a wall), so the neighbour lanes of the DPP row will do -- a VALU move instead of
+                // a trip through the LDS crossbar
+                xl = dpp_from_below(xo[c][r].w); xr = dpp_from_above(xo[c][r].x);
+            } else {
+                xl = __shfl(xo[c][r].w, lane_l, 64); xr = __shfl(xo[c][r].x, lane_r, 64);
+            }
+            if constexpr (SPLIT) {
+                if (lane == 0) xl = seam[cur][c][row0 + r][2 * ((wrow + WPR - 1) % WPR) + 1];
+                if (lane == 63) xr = seam[cur][c][row0 + r][2 * ((wrow + 1) % WPR)];
+            }
+            const float4 x = xo[c][r];
+            float4 v;
+            v.x = bp[c][r].x - of[0][r].x * xl - of[1][r].x * x.y - of[2][r].x * up.x - of[3][r].x * dn.x;
+            v.y = bp[c][r].y - of[0][r].y * x.x - of[1][r].y * x.z - of[2][r].y * up.y - of[3][r].y * dn.y;
+            v.z = bp[c][r].z - of[0][r].z * x.y - of[1][r].z * x.w - of[2][r].z * up.z - of[3][r].z * dn.z;
+            v.w = bp[c][r].w - of[0][r].w * x.z - of[1][r].w * xr - of[2][r].w * up.w - of[3][r].w * dn.w;
+            return v;
+        };
+        float4 xn[2][4];
+        // the two inner rows of the strip need nothing from LDS: they are updated while the strip edges are on their way (with two
+        // waves per SIMD nothing else would fill the wait for the barrier); rows that span several waves read their seams after it
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { xn[c][1] = row_update(c, 1, xo[c][0], xo[c][2]); xn[c][2] = row_update(c, 2, xo[c][1], xo[c][3]); }
+        }
         __syncthreads();
         const bool last = (k == S - 1);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4 upq = *reinterpret_cast<const float4*>(&edge[cur][c][up_row][4 * col]);
             const float4 dnq = *reinterpret_cast<const float4*>(&edge[cur][c][dn_row][4 * col]);
-            float4 xn[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float xl, xr;
-                if constexpr (XT && Q <= 16) {
-                    // narrow bands (a band row is 8 or 16 lanes = at most one 16-lane DPP row): what comes in over a band's edge is halo
-                    // (or meets a zero coefficient at a wall), so the neighbour lanes of the DPP row will do -- a VALU move instead of
-                    // a trip through the LDS crossbar
-                    xl = dpp_from_below(xo[c][r].w); xr = dpp_from_above(xo[c][r].x);
-                } else {
-                    xl = __shfl(xo[c][r].w, lane_l, 64); xr = __shfl(xo[c][r].x, lane_r, 64);
-                }
-                if constexpr (SPLIT) {
-                    if (lane == 0) xl = seam[cur][c][row0 + r][2 * ((wrow + WPR - 1) % WPR) + 1];
-                    if (lane == 63) xr = seam[cur][c][row0 + r][2 * ((wrow + 1) % WPR)];
-                }
-                const float4 up = r == 0 ? upq : xo[c][r > 0 ? r - 1 : 0];
-                const float4 dn = r == 3 ? dnq : xo[c][r < 3 ? r + 1 : 3];
-                const float4 x = xo[c][r];
-                float4 v;
-                v.x = bp[c][r].x - of[0][r].x * xl - of[1][r].x * x.y - of[2][r].x * up.x - of[3][r].x * dn.x;
-                v.y = bp[c][r].y - of[0][r].y * x.x - of[1][r].y * x.z - of[2][r].y * up.y - of[3][r].y * dn.y;
-                v.z = bp[c][r].z - of[0][r].z * x.y - of[1][r].z * x.w - of[2][r].z * up.z - of[3][r].z * dn.z;
-                v.w = bp[c][r].w - of[0][r].w * x.z - of[1][r].w * xr - of[2][r].w * up.w - of[3][r].w * dn.w;
-                xn[r] = v;
-            }
+            if constexpr (SPLIT) { xn[c][1] = row_update(c, 1, xo[c][0], xo[c][2]); xn[c][2] = row_update(c, 2, xo[c][1], xo[c][3]); }
+            xn[c][0] = row_update(c, 0, upq, xo[c][1]);
+            xn[c][3] = row_update(c, 3, xo[c][2], dnq);
             if (last) {
                 // residual of the iterate this sweep started from, on the cells this region answers for (the diagonal is read again
                 // here -- from L2 -- instead of living in 16 registers through the sweeps)
@@ -218,14 +226,14 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     if (XT ? (hi > 0 && lo < 4) : inside(r, 0)) {
                         const float4 d4 = ld4(a.diag + (size_t)b * n + cell0 + (size_t)r * ld);
-                        const float r0 = d4.x * (xn[r].x - xo[c][r].x), r1 = d4.y * (xn[r].y - xo[c][r].y);
-                        const float r2 = d4.z * (xn[r].z - xo[c][r].z), r3 = d4.w * (xn[r].w - xo[c][r].w);
+                        const float r0 = d4.x * (xn[c][r].x - xo[c][r].x), r1 = d4.y * (xn[c][r].y - xo[c][r].y);
+                        const float r2 = d4.z * (xn[c][r].z - xo[c][r].z), r3 = d4.w * (xn[c][r].w - xo[c][r].w);
                         part[c] += (inside(r, 0) ? r0 * r0 : 0.f) + (inside(r, 1) ? r1 * r1 : 0.f) + (inside(r, 2) ? r2 * r2 : 0.f) + (inside(r, 3) ? r3 * r3 : 0.f);
                     }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xo[c][r] = xn[r];
+            for (int r = 0; r < 4; ++r) xo[c][r] = xn[c][r];
         }
     }
 #pragma unroll
