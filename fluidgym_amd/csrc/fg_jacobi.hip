@@ -6,7 +6,7 @@
 // on the bench states -- and the reference's BiCGStab (bicgstab_solver_kernel.cu) needs 4-5 / 7-8 iterations of two
 // matrix applications each, every one a full pass over x, r, p, v, s, t and the matrix in HBM (~48 floats per cell and iteration
 // for the two components).  The stationary iteration x <- D^-1 (b - O x) contracts the residual by 0.18 / 0.47 per sweep on
-// the same systems (11 / 24 sweeps to the reference's criterion, RMS residual < tol; profiles/scratch/jacobi_exp*.py) and needs NO
+// the same systems (11 / 24 sweeps to the reference's criterion, RMS residual < tol; profiles/jacobi_exp_*.py) and needs NO
 // dot product between sweeps, so S sweeps run on one tile that stays on chip:
 //
 //   * a workgroup owns a region of 8192 cells = ROWS full rows of the grid (no halo in x: the row is complete; periodic x wraps
