@@ -214,6 +214,8 @@ SIGNATURES = {
     "fg_mb_set_residual_projection": (c_int, [c_void_p, POINTER(c_float)]),
     "fg_mb_set_stall_limit": (c_int, [c_void_p, c_int32]),
     "fg_mb_set_advection_start": (c_int, [c_void_p, c_int]),
+    "fg_mb_set_advection_jacobi": (c_int, [c_void_p, c_int]),
+    "fg_mb_advection_jacobi_counts": (c_int, [c_void_p, POINTER(c_int64)]),
     "fg_mb_set_multilevel": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_float),
                                      POINTER(c_float), c_float, c_int32]),
     "fg_mb_env_status": (c_int, [c_void_p, POINTER(c_int32)]),

@@ -186,6 +186,12 @@ struct fg_mb_state {
     std::vector<int32_t> env_status;   // [B] host, what fg_mb_env_status reports
     int cg_stall_limit = 400;  // fg_mb_set_stall_limit
     int adv_from_result = 0;   // fg_mb_set_advection_start
+    // Jacobi sweeps for the velocity systems (mb_jacobi, fg_mb_krylov.hip): switch (fg_mb_set_advection_jacobi / FG_ADV_JACOBI), per
+    // non-orthogonal pass the sweeps the last solve needed and the solves still to skip after a failure, pinned residuals of the check
+    int adv_jacobi = 0, adv_jacobi_env = 0;
+    int jac_sweeps[4] = {0, 0, 0, 0}, jac_skip[4] = {0, 0, 0, 0}, jac_fails[4] = {0, 0, 0, 0};
+    mb_real* jac_res_pinned = nullptr;   // [B d][2]: residual at the last / the previous measuring sweep
+    long long jac_solves = 0, jac_fallbacks = 0;
     bool yproj_const = true;   // yproj is the constant 1/sqrt(N): kernels use the scalar instead of loading it
     mb_real* red;        // [B] reductions (max)
     mb_real* pres_bak;   // [B][N] pressure at the start of a step (restored for envs whose step is dropped)

@@ -1596,6 +1596,208 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
     return frc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Point-Jacobi sweeps for the velocity systems (policy advection_jacobi, as csrc/fg_jacobi.hip on the single-block path).  The rows of
+// the advection-diffusion matrix of the cylinder meshes are dominated by 1/dt at the envs' time steps: x <- D^-1 (b - O x) contracts
+// the residual by ~0.2 per sweep there (profiles/jacobi_exp_multiblock.py: 12 sweeps to the criterion, where BiCGStab takes 5-6
+// iterations of three launches with two matrix applications).  A sweep is one launch over the neighbour table -- one matrix pass, no
+// dot product; the sweeps that are followed by a check also sum the residual of the iterate they started from, D (x_new - x) = b - C x.
+// The airfoil's systems contract by 0.8 per sweep: the first check sees that and hands the solve to BiCGStab.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int DIMS>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbj_sweep(MbDev D, MbSolve q, const mb_real* __restrict__ xin, mb_real* __restrict__ xout, int from_zero,
+                                                        int measure_slot) {
+    MB_SYS
+    if (flag_ld(q.flags + (sys)) != 0) return;
+    constexpr int F = 2 * DIMS;
+    mb_real part = 0.f;
+    if (valid) {
+        const mb_real dg = q.diag[(size_t)b * N + i];
+        mb_real acc = q.rhs[vb + i];
+        mb_real xold = 0.f;
+        if (!from_zero) {
+            xold = xin[vb + i];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const int nb = D.nbr[(size_t)f * N + i];
+                if (nb >= 0) acc -= q.off[((size_t)b * F + f) * N + i] * xin[vb + nb];
+            }
+        }
+        const mb_real xn = acc / dg;
+        xout[vb + i] = xn;
+        const mb_real r = dg * (xn - xold);
+        part = r * r;
+    }
+    if (measure_slot >= 0) {
+        part = mb_block_sum(part, lds);
+        if (threadIdx.x == 0) acc_add(a + measure_slot, (double)part);
+    }
+}
+
+// the same sweep for ALL components of an env in one thread: they share the matrix row and the neighbour indices (grid.y = env; a
+// component whose system has stopped keeps its iterate)
+template <int DIMS, int NC>
+__global__ __launch_bounds__(FG_BLOCK) void k_mbj_sweep_env(MbDev D, MbSolve q, const mb_real* __restrict__ xin, mb_real* __restrict__ xout, int from_zero,
+                                                            int measure_slot) {
+    constexpr int F = 2 * DIMS;
+    const int i = blockIdx.x * FG_BLOCK + threadIdx.x, b = blockIdx.y, N = D.N;
+    __shared__ mb_real lds[16];
+    bool live[NC], any = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { live[c] = flag_ld(q.flags + (b * NC + c)) == 0; any = any || live[c]; }
+    if (!any) return;
+    mb_real part[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) part[c] = 0.f;
+    if (i < N) {
+        const mb_real dg = q.diag[(size_t)b * N + i];
+        const mb_real rd = (mb_real)1 / dg;
+        mb_real acc[NC], xold[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { acc[c] = q.rhs[((size_t)b * NC + c) * N + i]; xold[c] = from_zero ? (mb_real)0 : xin[((size_t)b * NC + c) * N + i]; }
+        if (!from_zero) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const int nb = D.nbr[(size_t)f * N + i];
+                if (nb >= 0) {
+                    const mb_real o = q.off[((size_t)b * F + f) * N + i];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[c] -= o * xin[((size_t)b * NC + c) * N + nb];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (!live[c]) continue;
+            const mb_real xn = acc[c] * rd;
+            xout[((size_t)b * NC + c) * N + i] = xn;
+            const mb_real r = dg * (xn - xold[c]);
+            part[c] = r * r;
+        }
+    }
+    if (measure_slot >= 0) {
+        mb_block_sums<NC>(part, lds);
+        if (threadIdx.x < NC && live[threadIdx.x < NC ? threadIdx.x : 0]) {
+            mb_real v = part[0];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) if ((int)threadIdx.x == c) v = part[c];
+            acc_add(q.acc + (size_t)(b * NC + threadIdx.x) * MB_ACC + measure_slot, (double)v);
+        }
+    }
+}
+
+// verdict behind a measuring sweep (k_mbs_check's rule on the sweep's own sum), mirrors, and both measured residuals for the host
+__global__ void k_mbj_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32_t* __restrict__ flag_mirror, mb_real* __restrict__ res2,
+                            int slot_now, int slot_prev, int sweeps, int n, int nsys, FgPollOut poll) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    mb_real now = -1.f, prev = -1.f;
+    if (flag_ld(q.flags + (s)) == 0) {
+        now = mb_rms(acc_ld(q.acc + ((size_t)s * MB_ACC + slot_now)), n);
+        if (slot_prev >= 0) prev = mb_rms(acc_ld(q.acc + ((size_t)s * MB_ACC + slot_prev)), n);
+        q.info[s].final_residual = now;
+        q.info[s].used_iterations = sweeps;
+        if (!(now >= q.tol)) {
+            const bool finite = isfinite(now);
+            flag_st(q.flags + (s), finite ? 1 : 2);
+            q.info[s].converged = finite ? 1 : 0;
+            q.info[s].is_finite = finite ? 1 : 0;
+        }
+    }
+    res2[2 * s] = now; res2[2 * s + 1] = prev;
+    mirror[s] = q.info[s];
+    flag_mirror[s] = flag_ld(q.flags + (s));
+    fg_poll_publish(poll, s);
+}
+}  // namespace
+
+int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, int nc, mb_real tol,
+              int use_x0, int* max_it, hipStream_t st, int pred_slot, int* outcome) {
+    *outcome = 0;
+    const int ps = pred_slot & 3;
+    if (s->jac_skip[ps] > 0) { --s->jac_skip[ps]; return FG_OK; }
+    *outcome = 2;
+    constexpr int MAX_SWEEPS = 32;      // (beyond that BiCGStab is the cheaper iteration: the airfoil meshes need 40-55 sweeps)
+    const int nsys = s->B * nc, n = s->N;
+    MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
+    const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
+    hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
+    mb_real* buf[2] = {x, s->w[0]};
+    int sweeps = 0, measures = 0, slot_now = -1, slot_prev = -1;
+    // first batch: what the previous solve of this pass needed (8 without a history); every batch ends with the result vector as the
+    // target of its last sweep, so a system that stops at a check has its iterate there and needs no copy
+    int batch = s->jac_sweeps[ps] > 0 ? s->jac_sweeps[ps] : 8;
+    if (batch > MAX_SWEEPS) batch = MAX_SWEEPS;
+    if (use_x0 && (batch & 1)) ++batch;      // (sweep 0 reads the result vector, so it writes the work buffer: an even batch ends in x)
+    int target = (batch - 1) & 1;            // sweep k writes buf[(k + target) & 1]: the last sweep of the first batch writes buf[0] = x
+    if (use_x0) target = 1;
+    auto enqueue = [&](int count) {
+        for (int k = 0; k < count; ++k, ++sweeps) {
+            // the last sweep of a batch and the one two before it measure: two points give the host the contraction per sweep
+            int slot = -1;
+            if (k == count - 1 || k == count - 3) { slot = measures % MB_ACC; ++measures; slot_prev = slot_now; slot_now = slot; }
+            const int w = (sweeps + target) & 1;
+            const int fz = (sweeps == 0 && !use_x0) ? 1 : 0;
+            if (nc == s->d) {      // the velocity systems: all components of an env in one thread
+                const dim3 genv(grid.x, s->B);
+                if (s->d == 2) hipLaunchKernelGGL((k_mbj_sweep_env<2, 2>), genv, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot);
+                else hipLaunchKernelGGL((k_mbj_sweep_env<3, 3>), genv, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot);
+            } else {
+                MB_DISPATCH(s, hipLaunchKernelGGL(k_mbj_sweep<DIMS>, grid, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot););
+            }
+        }
+    };
+    bool ok = false;
+    for (;;) {
+        if (batch < 3) slot_prev = -1;
+        enqueue(batch);
+        const FgPollOut po = fg_poll_next(&s->poll);
+        hipLaunchKernelGGL(k_mbj_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, s->jac_res_pinned, slot_now, batch >= 3 ? slot_prev : -1,
+                           sweeps, n, nsys, po);
+        bool done = false;
+        if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
+        bool bad = false;
+        double need = 0.0;
+        for (int i = 0; i < nsys; ++i) {
+            if (!s->info_pinned[i].is_finite) bad = true;
+            if (s->flags_pinned[i] != 0) continue;
+            const double r1 = s->jac_res_pinned[2 * i], r0 = s->jac_res_pinned[2 * i + 1];
+            if (r0 > 0.0 && r1 > 0.0) {
+                const double c = sqrt(r1 / r0);      // per sweep (the two measuring sweeps are two apart)
+                if (!(c < 0.85)) bad = true;
+                else { const double m = log((double)tol / r1) / log(c); need = m > need ? m : need; }
+            } else {
+                need = need > 4.0 ? need : 4.0;
+            }
+        }
+        if (done && !bad) { ok = true; break; }
+        if (bad) break;
+        int more = (int)ceil(need) + 1;
+        if (more < 4) more = 4;
+        more += more & 1;                        // even: the batch ends in the result vector again
+        if (measures + 2 > MB_ACC || sweeps + more > MAX_SWEEPS) break;
+        batch = more;
+    }
+    if (!ok) {
+        // handed over: 3 = every iterate is finite (BiCGStab may start from it), 2 = start from zero
+        bool finite = true;
+        for (int i = 0; i < nsys; ++i) finite = finite && s->info_pinned[i].is_finite && std::isfinite((double)s->jac_res_pinned[2 * i]);
+        *outcome = finite ? 3 : 2;
+        s->jac_fails[ps] += 1;
+        s->jac_skip[ps] = s->jac_fails[ps] > 6 ? 512 : (4 << s->jac_fails[ps]);
+        s->jac_sweeps[ps] = 0;
+        return FG_OK;
+    }
+    s->jac_fails[ps] = 0;
+    const int frc = mb_finish(s, nsys, nullptr, max_it);
+    int used = 0;
+    for (int i = 0; i < nsys; ++i) used = std::max(used, (int)s->info_pinned[i].used_iterations);
+    s->jac_sweeps[ps] = used > 0 ? used : 8;
+    *outcome = 1;
+    return frc;
+}
+
 // Pressure BiCGStab with the multilevel right preconditioner as a TRIAL.  On the Airfoil2D mesh the attempt converges in a third
 // of the plain iterations (17 against 55-63), verified on the true residual -- but a geometry-only symmetric coarse operator is no
 // safe preconditioner for that non-symmetric matrix in every state (the stiff solves right after an impulsive start exceed any

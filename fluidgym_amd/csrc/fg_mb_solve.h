@@ -148,6 +148,11 @@ void mb_ml_apply(fg_mb_state* s, const MbSolve& q, const mb_real* in, mb_real* o
 int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, int nc,
                 mb_real tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project = 0, int refine = 0, int multilevel = 0,
                 int pred_slot = 31);
+// point-Jacobi sweeps for the velocity systems where their rows are diagonally dominant (the cylinder meshes: 12 sweeps); *outcome: 0 not
+// tried (backing off), 1 solved, 2 / 3 given up -- then the caller runs BiCGStab, from a cleared start vector (2) or from the sweeps' last
+// iterate, which sits in x (3)
+int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, int nc, mb_real tol,
+              int use_x0, int* max_it, hipStream_t st, int pred_slot, int* outcome);
 int mb_pressure_bicgstab(fg_mb_state* s, const mb_real* dt, mb_real tol, int max_iterations, int use_x0, int* max_it, hipStream_t st, int project,
                          int refine, int pred_slot);
 int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, mb_real tol,

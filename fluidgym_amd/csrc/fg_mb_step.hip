@@ -456,6 +456,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
         e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = e ? atoi(e) : 2;   // 0 five kernels, 1 s / t fused, 2 also p / v (default)
         e = getenv("FG_MB_PRED"); s->dbg_pred = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_ADV_JACOBI"); s->adv_jacobi = e ? atoi(e) : 0; s->adv_jacobi_env = e ? 1 : 0;      // (as on the single-block path: fg_api.hip)
         e = getenv("FG_MB_ML_FUSE"); s->dbg_ml_fuse = e ? atoi(e) : 1;
         e = getenv("FG_MB_ML_SB"); s->dbg_ml_sb = e ? atoi(e) : 0;   // systems per workgroup of k_ml_coarse: 4 / 8, 0 = by batch size
         e = getenv("FG_MB_ML_TRY_CAP"); if (e && atoi(e) > 0) s->dbg_ml_cap = atoi(e);
@@ -504,6 +505,7 @@ extern "C" int fg_mb_destroy(fg_mb_handle s) {
     if (s->info_pinned) (void)hipHostFree(s->info_pinned);
     if (s->red_pinned) (void)hipHostFree(s->red_pinned);
     if (s->flags_pinned) (void)hipHostFree(s->flags_pinned);
+    if (s->jac_res_pinned) (void)hipHostFree(s->jac_res_pinned);
     fg_poll_destroy(&s->poll);
     if (s->sys_map_pinned) (void)hipHostFree(s->sys_map_pinned);
     if (s->red2_pinned) (void)hipHostFree(s->red2_pinned);
@@ -657,6 +659,7 @@ extern "C" int fg_mb_finalize(fg_mb_handle s) {
     FG_HIP_CHECK(hipHostMalloc((void**)&s->red2_pinned, sizeof(mb_real) * 2 * B, hipHostMallocDefault));
     FG_HIP_CHECK(hipHostMalloc((void**)&s->dt_pinned, sizeof(mb_real) * 2 * B, hipHostMallocDefault));   // two halves (fg_mb_single_step)
     FG_HIP_CHECK(hipHostMalloc((void**)&s->flags_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
+    FG_HIP_CHECK(hipHostMalloc((void**)&s->jac_res_pinned, sizeof(mb_real) * 2 * B * d, hipHostMallocDefault));
     if (int rc = fg_poll_create(&s->poll, B * d > 2 * B ? B * d : 2 * B)) return rc;
     if (int rc = mb_alloc(s, &s->sys_map_dev, (size_t)B * d)) return rc;
     FG_HIP_CHECK(hipHostMalloc((void**)&s->sys_map_pinned, sizeof(int32_t) * B * d, hipHostMallocDefault));
@@ -787,8 +790,17 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
             // initial guess: zero on the first non-orthogonal pass, the previous pass's result after that (x = None if no_step == 0
             // or not advect_non_ortho_reuse_result, PISOtorch_simulation.py:1735-1742; tests/golden/reference_split_step.json);
             // fg_mb_set_advection_start(1): the current velocity on the first pass (opt-in)
-            int vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
-                                  opt->max_iterations, (no > 0 || s->adv_from_result) ? 1 : 0, &m, st, 0, 0, 0, no & 3);
+            int vrc = FG_OK, jac = 0;
+            const int start_x0 = (no > 0 || s->adv_from_result) ? 1 : 0;
+            // policy advection_jacobi: the sweeps first (mb_jacobi); what they do not settle goes to BiCGStab from a cleared start vector
+            if (s->adv_jacobi && s->jac_res_pinned) {
+                vrc = mb_jacobi(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol, start_x0, &m, st, no & 3, &jac);
+                if (jac == 1) s->jac_solves += 1;
+                else if (jac >= 2) s->jac_fallbacks += 1;
+            }
+            if (jac != 1)      // (after sweeps that gave up: from their last iterate when it is finite -- closer than either start vector)
+                vrc = mb_bicgstab(s, dt_B, s->Cdiag, s->Coff, s->rhs, s->ures, d, opt->advection_tol,
+                                  opt->max_iterations, jac == 2 ? 0 : (jac == 3 ? 1 : start_x0), &m, st, 0, 0, 0, no & 3);
             // ---- the reference's retry ladder (_linear_solve, PISOtorch_diff.py:410-476).  The advection solve runs without
             // returnBestResult, so "not solved" = any system unconverged (or non-finite); every rung starts from zero
             // ("do not start with a possibly corrupted result tensor", :429-431)
@@ -1380,6 +1392,17 @@ extern "C" int fg_mb_set_stall_limit(fg_mb_handle s, int32_t iterations) {
     FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_set_stall_limit: null handle");
     FG_REQUIRE(iterations >= 20, FG_ERR_INVALID_ARG, "fg_mb_set_stall_limit: at least one chunk of 20 iterations");
     s->cg_stall_limit = iterations;
+    return FG_OK;
+}
+extern "C" int fg_mb_set_advection_jacobi(fg_mb_handle s, int on) {
+    FG_REQUIRE(s != nullptr, FG_ERR_INVALID_ARG, "fg_mb_set_advection_jacobi: null handle");
+    if (!s->adv_jacobi_env) s->adv_jacobi = on ? 1 : 0;      // (FG_ADV_JACOBI in the environment wins: A/B runs of whole envs)
+    for (int k = 0; k < 4; ++k) { s->jac_sweeps[k] = 0; s->jac_skip[k] = 0; s->jac_fails[k] = 0; }
+    return FG_OK;
+}
+extern "C" int fg_mb_advection_jacobi_counts(fg_mb_handle s, int64_t* out2) {
+    FG_REQUIRE(s != nullptr && out2 != nullptr, FG_ERR_INVALID_ARG, "fg_mb_advection_jacobi_counts: bad argument");
+    out2[0] = s->jac_solves; out2[1] = s->jac_fallbacks;
     return FG_OK;
 }
 extern "C" int fg_mb_set_advection_start(fg_mb_handle s, int from_result) {

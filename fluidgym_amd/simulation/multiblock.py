@@ -327,6 +327,15 @@ class MultiBlockDomain:
         """Start vector of the first velocity solve of a step: zero (the reference) or the current velocity (opt-in)."""
         L.check(self.lib.fg_mb_set_advection_start(self.handle, int(from_result)))
 
+    def set_advection_jacobi(self, on: bool = True) -> None:
+        """Velocity systems by point-Jacobi sweeps before BiCGStab (``fg_mb_set_advection_jacobi``; policy ``advection_jacobi``)."""
+        L.check(self.lib.fg_mb_set_advection_jacobi(self.handle, int(bool(on))))
+
+    def advection_jacobi_counts(self) -> dict:
+        out = (ctypes.c_int64 * 2)()
+        L.check(self.lib.fg_mb_advection_jacobi_counts(self.handle, out))
+        return {"settled_by_sweeps": int(out[0]), "handed_to_bicgstab": int(out[1])}
+
     def boundary_tables(self):
         """(owner cell [NB], face [NB], Minv|det [NB, d*d+1]) of the boundary slots (host arrays)."""
         nb, tw = self.n_boundary_faces, self.dims * self.dims + 1
@@ -653,6 +662,10 @@ class MultiBlockSimulation:
         # first velocity solve of a step from zero as the reference's non-orthogonal branch (policy.py), or from the current velocity
         self.advection_warm_start = bool(pol["advection_warm_start"] if advection_warm_start is None else advection_warm_start)
         domain.set_advection_start(self.advection_warm_start)
+        # policy advection_jacobi (default on): the velocity systems go to the Jacobi sweeps first (mb_jacobi); meshes they do not
+        # contract on (the airfoil's) are handed to BiCGStab after the first check and the handle backs off
+        self.advection_jacobi = bool(pol["advection_jacobi"])
+        domain.set_advection_jacobi(self.advection_jacobi)
         self.pressure_project_mean = pressure_project_mean
         self.domain, self.time_step, self.adaptive_CFL, self.substeps = domain, float(dt), float(adaptive_CFL), substeps
         self.corrector_steps = corrector_steps

@@ -555,6 +555,13 @@ int fg_mb_set_stall_limit(fg_mb_handle h, int32_t iterations);
  * (x=None at no_step 0, PISOtorch_simulation.py:1735-1742); 1 the current velocity (opt-in: fewer iterations, same answer within
  * the tolerance).  Later non-orthogonal passes always start from the previous pass's result as there. */
 int fg_mb_set_advection_start(fg_mb_handle h, int from_result);
+/* fg_mb_set_advection_jacobi(on): the velocity systems by point-Jacobi sweeps over the neighbour table (mb_jacobi, csrc/fg_mb_krylov.hip)
+ * before the reference's BiCGStab (bicgstab_solver_kernel.cu:63-411 at PISOtorch_simulation.py:1735-1742) -- the single-block policy
+ * `advection_jacobi` on the multi-block path: same systems, same criterion; a system the sweeps do not contract on (the airfoil meshes)
+ * is handed to BiCGStab from a cleared start vector after the first check.  fg_mb_advection_jacobi_counts: solves settled by the
+ * sweeps, solves handed on. */
+int fg_mb_set_advection_jacobi(fg_mb_handle h, int on);
+int fg_mb_advection_jacobi_counts(fg_mb_handle h, int64_t* out2);
 /* Additive multilevel preconditioner of the pressure solves on 2-D meshes: Jacobi + 1/2 x Jacobi on 4 x 4 aggregates + the
  * dense pseudo-inverse on 8 x 8 aggregates, all from the geometry-only (A = 1) matrix and scaled per env.  Host arrays: a4 [N]
  * (aggregate of every cell), parent4 [n4] (8 x 8 aggregate of every 4 x 4 one), rect4 (every 4 x 4 aggregate as a rectangle of
