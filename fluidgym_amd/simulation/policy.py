@@ -83,6 +83,9 @@ benchmark line can say which mode it ran in:
     contraction by 0.7 per pass: refined grids, large time steps) is handed to BiCGStab from a cleared start vector and the solver
     backs off from trying.  Same systems, same tolerance, same criterion, another iteration -- like the preconditioners above;
     ``False`` = BiCGStab always (``bench.py`` reports that mode as the ``krylov_mode`` leg).
+    Multi-block path: the same sweeps over the neighbour table, one launch per sweep (``mb_jacobi``, ``csrc/fg_mb_krylov.hip``): the
+    cylinder meshes take 12-16 sweeps where BiCGStab took 5-6 iterations of three launches; the airfoil meshes contract by 0.8 per
+    sweep, which the first check sees -- BiCGStab takes over from the sweeps' iterate and the handle backs off.
 
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` / ``FLUIDGYM_AMD_ADVECTION_WARM_START`` /
 ``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
