@@ -137,7 +137,8 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     { const char* ev = getenv("FG_ADV_JACOBI"); s->adv_jacobi = ev ? atoi(ev) : 0; s->adv_jacobi_env = ev ? 1 : 0; }
     for (int k = 0; k < 4; ++k) s->jac_hist[k] = FgJacHist{0, 0, 0};
     s->jac_solves = s->jac_fallbacks = 0;
-    FG_HIP_CHECK(hipHostMalloc(&s->jac_prev, sizeof(float) * nsys));
+    FG_HIP_CHECK(hipHostMalloc(&s->jac_prev, sizeof(float) * 2 * nsys));
+    s->jac_rA_epoch = -1;
     FG_HIP_CHECK(hipMalloc(&s->fcg_alpha, sizeof(double) * 2 * (size_t)g.B));
     FG_HIP_CHECK(hipMemset(s->fcg_alpha, 0, sizeof(double) * 2 * (size_t)g.B));
     FG_HIP_CHECK(hipMalloc(&s->fcg_xsum, sizeof(FgDacc) * 2 * (size_t)g.B));
@@ -431,6 +432,7 @@ static int setup_advection(fg_handle s, const fg_real* dt_B, int for_scalar, int
         a.nu = s->viscosity;
         a.rA = s->rA;
         s->rA_epoch++;
+        s->jac_rA_epoch = s->rA_epoch;      // (rA = 1 / A of THIS velocity matrix: what the streaming Jacobi sweeps read, fg_jacobi.hip)
 #if !FG_F64
         if (fg_fd_rowmean_ok(s) && s->vec == 4 && (s->grid.nx & 63) == 0) {      // row sums of 1/A for the row-mean preconditioner ride in the assembly
             if (!s->fd_row_part) FG_HIP_CHECK(hipMalloc(&s->fd_row_part, sizeof(float) * (size_t)s->grid.B * s->grid.ny * (s->grid.nx / 64)));

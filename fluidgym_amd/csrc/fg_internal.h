@@ -724,6 +724,7 @@ struct fg_state {
     // per-kind history (sweeps the last solve needed; solves still to skip after a failure), pinned residuals of the pass before the last
     int adv_jacobi, adv_jacobi_env; FgJacHist jac_hist[4]; float* jac_prev;
     long long jac_solves, jac_fallbacks;
+    long jac_rA_epoch;      // rA_epoch at which rA = 1 / A was written for the velocity system in s->A (the streaming sweeps read it)
     FgCounters ctr;         // iterations per solve kind since the last reset (fg_solver_counters)
     const fg_real* cur_dt;  // dt_B of the last fg_setup_advection: activity mask of the stepwise entry points
     // solver state already prepared by the kernel launched just before the solve (k_adv_build: FgBicgBegin, k_div: FgCgBegin) --

@@ -1718,43 +1718,47 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
     const int ps = pred_slot & 3;
     if (s->jac_skip[ps] > 0) { --s->jac_skip[ps]; return FG_OK; }
     *outcome = 2;
-    constexpr int MAX_SWEEPS = 32;      // (beyond that BiCGStab is the cheaper iteration: the airfoil meshes need 40-55 sweeps)
+    // Check points at FIXED sweep counts -- 12, 16, ... 32 (beyond that BiCGStab is the cheaper iteration: the airfoil meshes need
+    // 40-55 sweeps) -- each with a verdict on the device: a system stops at the first check point where its residual is below the
+    // tolerance, whatever the host enqueued ahead.  The history of the handle only decides how far ahead that is (where the first
+    // poll sits), so an env's iterate does not depend on it and replays repeat exactly.
+    constexpr int FIRST = 12, STEP = 4, CHECKS = 6;
     const int nsys = s->B * nc, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
     hipLaunchKernelGGL(k_mbs_begin, sg, sb, 0, st, dt, q, nsys);
-    mb_real* buf[2] = {x, s->w[0]};
-    int sweeps = 0, measures = 0, slot_now = -1, slot_prev = -1;
-    // first batch: what the previous solve of this pass needed (8 without a history); every batch ends with the result vector as the
-    // target of its last sweep, so a system that stops at a check has its iterate there and needs no copy
-    int batch = s->jac_sweeps[ps] > 0 ? s->jac_sweeps[ps] : 8;
-    if (batch > MAX_SWEEPS) batch = MAX_SWEEPS;
-    if (use_x0 && (batch & 1)) ++batch;      // (sweep 0 reads the result vector, so it writes the work buffer: an even batch ends in x)
-    int target = (batch - 1) & 1;            // sweep k writes buf[(k + target) & 1]: the last sweep of the first batch writes buf[0] = x
-    if (use_x0) target = 1;
-    auto enqueue = [&](int count) {
-        for (int k = 0; k < count; ++k, ++sweeps) {
-            // the last sweep of a batch and the one two before it measure: two points give the host the contraction per sweep
-            int slot = -1;
-            if (k == count - 1 || k == count - 3) { slot = measures % MB_ACC; ++measures; slot_prev = slot_now; slot_now = slot; }
-            const int w = (sweeps + target) & 1;
-            const int fz = (sweeps == 0 && !use_x0) ? 1 : 0;
-            if (nc == s->d) {      // the velocity systems: all components of an env in one thread
-                const dim3 genv(grid.x, s->B);
-                if (s->d == 2) hipLaunchKernelGGL((k_mbj_sweep_env<2, 2>), genv, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot);
-                else hipLaunchKernelGGL((k_mbj_sweep_env<3, 3>), genv, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot);
-            } else {
-                MB_DISPATCH(s, hipLaunchKernelGGL(k_mbj_sweep<DIMS>, grid, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot););
+    mb_real* buf[2] = {x, s->w[0]};      // sweep k writes buf[(k + 1) & 1]: the check points are even counts, so each ends in x
+    int sweeps = 0, checks = 0;
+    auto run_to_check = [&](int upto, const FgPollOut& po_last) {      // sweeps and checks up to check point number `upto` (1-based)
+        while (checks < upto) {
+            const int target = FIRST + STEP * checks;
+            for (; sweeps < target; ++sweeps) {
+                // the last sweep in front of a check and the one two before it measure (two points: the contraction per sweep)
+                const int slot = (sweeps == target - 1) ? 2 * checks + 1 : (sweeps == target - 3 ? 2 * checks : -1);
+                const int w = (sweeps + 1) & 1;
+                const int fz = (sweeps == 0 && !use_x0) ? 1 : 0;
+                if (nc == s->d) {      // the velocity systems: all components of an env in one thread
+                    const dim3 genv(grid.x, s->B);
+                    if (s->d == 2) hipLaunchKernelGGL((k_mbj_sweep_env<2, 2>), genv, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot);
+                    else hipLaunchKernelGGL((k_mbj_sweep_env<3, 3>), genv, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot);
+                } else {
+                    MB_DISPATCH(s, hipLaunchKernelGGL(k_mbj_sweep<DIMS>, grid, blk, 0, st, s->dev, q, (const mb_real*)buf[w ^ 1], buf[w], fz, slot););
+                }
             }
+            ++checks;
+            hipLaunchKernelGGL(k_mbj_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, s->jac_res_pinned, 2 * checks - 1, 2 * checks - 2,
+                               sweeps, n, nsys, checks == upto ? po_last : FgPollOut{nullptr, 0});
         }
     };
+    static_assert(2 * CHECKS <= MB_ACC, "two measuring sweeps per check point");
+    // first poll at the check point the previous solve of this pass ended at
+    int upto = 1;
+    if (s->jac_sweeps[ps] > FIRST) upto = 1 + (s->jac_sweeps[ps] - FIRST + STEP - 1) / STEP;
+    if (upto > CHECKS) upto = CHECKS;
     bool ok = false;
     for (;;) {
-        if (batch < 3) slot_prev = -1;
-        enqueue(batch);
         const FgPollOut po = fg_poll_next(&s->poll);
-        hipLaunchKernelGGL(k_mbj_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, s->jac_res_pinned, slot_now, batch >= 3 ? slot_prev : -1,
-                           sweeps, n, nsys, po);
+        run_to_check(upto, po);
         bool done = false;
         if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
         bool bad = false;
@@ -1773,11 +1777,9 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
         }
         if (done && !bad) { ok = true; break; }
         if (bad) break;
-        int more = (int)ceil(need) + 1;
-        if (more < 4) more = 4;
-        more += more & 1;                        // even: the batch ends in the result vector again
-        if (measures + 2 > MB_ACC || sweeps + more > MAX_SWEEPS) break;
-        batch = more;
+        const int more = 1 + (int)(ceil(need) - 1) / STEP;      // check points still to go at that contraction
+        if (checks + more > CHECKS) break;
+        upto = checks + (more < 1 ? 1 : more);
     }
     if (!ok) {
         // handed over: 3 = every iterate is finite (BiCGStab may start from it), 2 = start from zero
@@ -1793,7 +1795,7 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
     const int frc = mb_finish(s, nsys, nullptr, max_it);
     int used = 0;
     for (int i = 0; i < nsys; ++i) used = std::max(used, (int)s->info_pinned[i].used_iterations);
-    s->jac_sweeps[ps] = used > 0 ? used : 8;
+    s->jac_sweeps[ps] = used > 0 ? used : FIRST;
     *outcome = 1;
     return frc;
 }

@@ -221,3 +221,30 @@ def test_multi_block_airfoil_hands_the_velocity_systems_to_bicgstab():
     # two valid solver paths on this mesh differ by what the tolerance leaves: the systems are volume-integrated (diagonal ~ J / dt ~ 0.1),
     # so a residual of 1e-5 is ~1e-4 of the velocity, per solve (measured 3e-4 after one sim step = 14 solves, 1.4e-3 after five)
     assert rel_err(a[0], b[0]) < 1e-2
+
+
+@pytest.mark.parametrize("n, fixed, dims", [((32, 16, 12), (1,), 3), ((24, 20, 8), (0, 1, 2), 3), ((40, 24), (), 2), ((36, 18), (0, 1), 2)])
+def test_streaming_sweeps_on_grids_without_a_region_shape(n, fixed, dims):
+    """3-D (the turbulent channel's path) and 2-D grids no on-chip region fits: one launch per sweep (k_jac_stream), all components of a cell
+    in one thread, against the oracle's direct solve and BiCGStab; three envs with their own dt, one of them masked in a second call."""
+    h = min(L / m for L, m in zip((2.0, 1.0, 1.5), n))
+    case = make_case(dims=dims, n=n, fixed_axes=fixed, B=3, seed=7, stretch=0.2, nu=0.25 * h, vel_scale=0.5)
+    dt = [0.2 * h, 0.1 * h, 0.15 * h]
+    tol = 2e-7 / min(dt)
+    xj, ij, cj = _solve(case, dt, True, tol)
+    xb, ib, cb = _solve(case, dt, False, tol)
+    assert cj == {"settled_by_sweeps": 1, "handed_to_bicgstab": 0}
+    assert all(i.converged and i.is_finite for i in ij), [(i.used_iterations, i.final_residual) for i in ij]
+    print(f"STREAM {n} fixed axes {fixed}: sweeps {[i.used_iterations + 1 for i in ij]}, BiCGStab iterations {[i.used_iterations + 1 for i in ib]}")
+    g = case.grid()
+    for b in range(case.B):
+        dom = case.oracle_domain(b, g)
+        C, _, _ = O.build_advection_matrix(dom, dt[b])
+        rhs = O.advection_rhs_velocity(dom, dt[b])
+        for c in range(dims):
+            res = float(np.sqrt(np.mean((rhs[c].ravel() - C @ xj[b, c].ravel()) ** 2)))
+            assert res < 1.5 * tol, (b, c, res)
+            x_ref = O.solve_direct(C, rhs[c].ravel()).reshape(case.shape)
+            assert rel_err(xj[b, c], x_ref) < 3e-6, (b, c)
+    xm, im, _ = _solve(case, [dt[0], 0.0, dt[2]], True, tol)
+    assert np.array_equal(xm[0], xj[0]) and np.array_equal(xm[2], xj[2]) and all(i.used_iterations == -1 for i in im[dims:2 * dims])
