@@ -106,6 +106,8 @@ KERNEL_DOC = {
     "k_bicgf_b": "BiCGStab two-kernel form, second half: s = r - alpha v, t = C s (s at the neighbours recomputed) + five dot products",
     "k_jac_pass": "velocity systems, point-Jacobi sweeps with the region on chip (fg_jacobi.hip): matrix (5), b (2), x (2) read once and x (2) "
                   "written for 4-8 sweeps; algorithmic bytes = 11 floats per cell and pass, the halo rows a region re-reads are overhead",
+    "k_jac_stream": "velocity systems, one point-Jacobi sweep per launch (3-D: fg_jacobi.hip): rA, 2d off-diagonals, d right-hand sides and d iterates read, "
+                    "d iterates written -- k_h's traffic; at 8 envs x 128 x 64 x 64 the working set (268 MB) is partly Infinity-Cache resident",
     "k_line_y": "y-line (tridiagonal) right preconditioner of the advection BiCGStab: z = M^-1 r per column block in LDS",
     "k_gemm_f32": "fast-diagonalisation preconditioner: eigenbasis transform along x/z (fp32 MFMA 32x32x2)",
     "k_gemm_sk": "fast-diagonalisation preconditioner: eigenbasis transform, split-K 32x32 tiles (few live envs)",

@@ -608,13 +608,16 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     return FG_OK;
 }
 
-// the streaming form's driver.  Check points at FIXED sweep counts (6, 8, ... 20), each with a verdict on the device: an env stops at
+// the streaming form's driver.  Check points at FIXED sweep counts (5, 7, ... 19), each with a verdict on the device: an env stops at
 // the first one where all its systems are below the tolerance (or their fp32 floor), whatever was enqueued ahead -- the handle's
 // history only decides where the first poll sits, so the iterate does not depend on it.  Every odd sweep from the fourth on sums the
 // residual of the iterate it started from (a check reads the last two: the contraction per sweep for the host); sweep k writes
-// buf[(k + 1) & 1], so every check point (an even count) ends in the result vector.
+// the buffer that makes every check point end in the result vector.
 static int jacobi_stream_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, int* outcome) {
-    constexpr int FIRST = 6, STEP = 2, CHECKS = 8;
+    // (a check judges the iterate its last sweep STARTED from, so odd counts -- 5, 7, ... -- from a zero start, where sweep 0 may write the
+    //  result vector; a start from the result vector has to write the work buffer first: even counts)
+    const int FIRST = a.use_x0 ? 6 : 5;
+    constexpr int STEP = 2, CHECKS = 8;
     FgJacHist& H = s->jac_hist[a.kind & 3];
     const FgGrid& G = s->grid;
     const int B = G.B, n = G.n, nc = a.nc, nsys = B * nc;
@@ -628,11 +631,13 @@ static int jacobi_stream_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* 
         while (checks < upto) {
             const int target = FIRST + STEP * checks;
             for (; sweeps < target; ++sweeps) {
-                const int w = (sweeps + 1) & 1;
+                const int w = (sweeps + (a.use_x0 ? 1 : 0)) & 1;
                 q.xin = buf[w ^ 1]; q.xout = buf[w]; q.from_zero = (sweeps == 0 && !a.use_x0) ? 1 : 0;
-                q.measure_slot = (sweeps >= 3 && (sweeps & 1)) ? (sweeps - 3) / 2 : -1;
+                q.measure_slot = (sweeps >= FIRST - 3 && ((sweeps - (FIRST - 3)) & 1) == 0) ? (sweeps - (FIRST - 3)) / 2 : -1;
                 q.ax_slot = (sweeps == FIRST - 1) ? 12 : -1;
-                const int pslot = fg_prof_slot(s, FG_PK_JAC_PASS, s->flags, nsys, bytes_sys, flops_sys, st);
+                // (the first sweep of a zero start reads no x and no off-diagonals: it is not sampled, which also keeps the sampling period
+                //  from locking onto one sweep index of the solves)
+                const int pslot = q.from_zero ? -1 : fg_prof_slot(s, FG_PK_JAC_STREAM, s->flags, nsys, bytes_sys, flops_sys, st);
                 FG_DISPATCH(s, {
                     const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
                     FG_LAUNCH_P(s, pslot, (k_jac_stream<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, q, L.tiles_x, L.tiles_y, L.tiles);
@@ -641,7 +646,7 @@ static int jacobi_stream_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* 
             ++checks;
             if (checks == upto) fg_prof_prefetch(s, st);
             hipLaunchKernelGGL(k_jac_stream_check, dim3((B + 63) / 64), dim3(64), 0, st, s->acc, s->flags, s->info_dev, s->info_pinned, s->jac_prev, a.tol, nc,
-                               (target - 4) / 2, (target - 6) / 2, 12, sweeps, n, B, checks == upto ? po_last : FgPollOut{nullptr, 0});
+                               (target - FIRST + 2) / 2, (target - FIRST) / 2, 12, sweeps, n, B, checks == upto ? po_last : FgPollOut{nullptr, 0});
         }
         FG_HIP_CHECK(hipGetLastError());
         return FG_OK;
