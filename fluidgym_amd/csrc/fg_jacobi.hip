@@ -45,6 +45,7 @@ struct JacArgs {
     FgDacc* acc; int32_t* flags; fg_solve_info* info;
     float tol;
     int pass, sweeps, zero_start, nx, ny, n, tiles;
+    int xcd_remap;      // FG_JAC_XCD (default 1): regions of an env on one XCD
 };
 
 __device__ __forceinline__ void jac_mark(const JacArgs& a, int sys, float crit, int sweeps_done) {
@@ -109,7 +110,11 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
     float (*edge)[2][2 * STRIPS][NX] = reinterpret_cast<float (*)[2][2 * STRIPS][NX]>(jac_lds);
     float (*seam)[2][ROWS][2 * WPR] = reinterpret_cast<float (*)[2][ROWS][2 * WPR]>(jac_lds + 2 * 2 * 2 * STRIPS * NX);
     __shared__ float red[2][JAC_THREADS / 64];
-    const int b = blockIdx.y, tile = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    // XCD-aware order: the hardware places workgroup id on XCD id % 8; every XCD gets a contiguous run of (env, region) pairs, so that
+    // neighbouring regions of an env -- which share their halo rows / columns and, in narrow bands, halves of 128-byte lines -- run on
+    // one XCD at about the same time and find each other's loads in its L2
+    const unsigned lid = a.xcd_remap ? fg_xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y) : blockIdx.x + gridDim.x * blockIdx.y;
+    const int b = (int)(lid / gridDim.x), tile = (int)(lid % gridDim.x), t = threadIdx.x, lane = t & 63;
     if (jac_verdict(a, b, a.pass, tile == 0 && t == 0)) return;
     // tiles along the tiled axis (y for full-row regions, x for bands): `span` cells per region, of which the outer S towards a
     // neighbouring region are halo
@@ -524,6 +529,7 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     JacArgs q = {};
     q.diag = a.diag; q.off = a.off; q.rhs = a.rhs; q.acc = s->acc; q.flags = s->flags; q.info = s->info_dev; q.tol = a.tol;
     q.sweeps = S; q.nx = G.nx; q.ny = G.ny; q.n = n; q.tiles = plan.tiles;
+    { static const int xr = [] { const char* e = getenv("FG_JAC_XCD"); return e ? atoi(e) : 1; }(); q.xcd_remap = xr; }
     float* work = s->w[0];
     const double bytes_sys = 0.5 * 4.0 * n * 11.0, flops_sys = 0.5 * n * 2.0 * 9.0 * S;
     int passes = 0;
