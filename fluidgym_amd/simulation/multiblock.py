@@ -665,7 +665,8 @@ class MultiBlockSimulation:
         # policy advection_jacobi (default on): the velocity systems go to the Jacobi sweeps first (mb_jacobi); meshes they do not
         # contract on (the airfoil's) are handed to BiCGStab after the first check and the handle backs off
         self.advection_jacobi = bool(pol["advection_jacobi"])
-        domain.set_advection_jacobi(self.advection_jacobi)
+        if hasattr(domain, "set_advection_jacobi"):
+            domain.set_advection_jacobi(self.advection_jacobi)
         self.pressure_project_mean = pressure_project_mean
         self.domain, self.time_step, self.adaptive_CFL, self.substeps = domain, float(dt), float(adaptive_CFL), substeps
         self.corrector_steps = corrector_steps
