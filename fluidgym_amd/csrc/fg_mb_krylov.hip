@@ -1718,11 +1718,12 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
     const int ps = pred_slot & 3;
     if (s->jac_skip[ps] > 0) { --s->jac_skip[ps]; return FG_OK; }
     *outcome = 2;
-    // Check points at FIXED sweep counts -- 12, 16, ... 32 (beyond that BiCGStab is the cheaper iteration: the airfoil meshes need
+    // Check points at FIXED sweep counts -- 12, 14, ... 32 (beyond that BiCGStab is the cheaper iteration: the airfoil meshes need
     // 40-55 sweeps) -- each with a verdict on the device: a system stops at the first check point where its residual is below the
     // tolerance, whatever the host enqueued ahead.  The history of the handle only decides how far ahead that is (where the first
-    // poll sits), so an env's iterate does not depend on it and replays repeat exactly.
-    constexpr int FIRST = 12, STEP = 4, CHECKS = 6;
+    // poll sits), so an env's iterate does not depend on it and replays repeat exactly.  Every odd sweep from the tenth on sums the
+    // residual of the iterate it started from; a check reads the last two sums (the contraction per sweep, for the host).
+    constexpr int FIRST = 12, STEP = 2, CHECKS = 11;
     const int nsys = s->B * nc, n = s->N;
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, nc, tol);
     const dim3 sg((nsys + 63) / 64), sb(64), grid((n + FG_BLOCK - 1) / FG_BLOCK, nsys), blk(FG_BLOCK);
@@ -1733,8 +1734,7 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
         while (checks < upto) {
             const int target = FIRST + STEP * checks;
             for (; sweeps < target; ++sweeps) {
-                // the last sweep in front of a check and the one two before it measure (two points: the contraction per sweep)
-                const int slot = (sweeps == target - 1) ? 2 * checks + 1 : (sweeps == target - 3 ? 2 * checks : -1);
+                const int slot = (sweeps >= FIRST - 3 && (sweeps & 1)) ? (sweeps - (FIRST - 3)) / 2 : -1;      // sweeps 9, 11, ... -> slots 0, 1, ...
                 const int w = (sweeps + 1) & 1;
                 const int fz = (sweeps == 0 && !use_x0) ? 1 : 0;
                 if (nc == s->d) {      // the velocity systems: all components of an env in one thread
@@ -1746,11 +1746,12 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
                 }
             }
             ++checks;
-            hipLaunchKernelGGL(k_mbj_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, s->jac_res_pinned, 2 * checks - 1, 2 * checks - 2,
+            const int now = (target - 1 - (FIRST - 3)) / 2;      // the sum of sweep target - 1; the one before it is two sweeps older
+            hipLaunchKernelGGL(k_mbj_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, s->jac_res_pinned, now, now - 1,
                                sweeps, n, nsys, checks == upto ? po_last : FgPollOut{nullptr, 0});
         }
     };
-    static_assert(2 * CHECKS <= MB_ACC, "two measuring sweeps per check point");
+    static_assert((FIRST + STEP * (CHECKS - 1) - 1 - (FIRST - 3)) / 2 < MB_ACC, "one accumulator per measuring sweep");
     // first poll at the check point the previous solve of this pass ended at
     int upto = 1;
     if (s->jac_sweeps[ps] > FIRST) upto = 1 + (s->jac_sweeps[ps] - FIRST + STEP - 1) / STEP;
