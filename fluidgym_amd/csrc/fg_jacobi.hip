@@ -1,4 +1,5 @@
-// Point-Jacobi sweeps, several per pass over the field, for the velocity systems of the 2-D uniform-grid envs (the channel family).
+// Point-Jacobi sweeps for the velocity systems: several per pass over the field with the region on chip (2-D uniform-grid envs: the
+// channel family), one per launch elsewhere (3-D: the turbulent channel).
 //
 // The advection-diffusion matrix of a PISO step is A = D + O with D = 1/dt + (diffusive and advective face sums) and O the four
 // neighbour coefficients (k_adv_build, fg_piso.hip; reference PISO_build_advection_matrix :4170-4312).  On the channel grids at
@@ -9,13 +10,16 @@
 // the same systems (11 / 24 sweeps to the reference's criterion, RMS residual < tol; profiles/jacobi_exp_*.py) and needs NO
 // dot product between sweeps, so S sweeps run on one tile that stays on chip:
 //
-//   * a workgroup owns a region of 8192 cells = ROWS full rows of the grid (no halo in x: the row is complete; periodic x wraps
-//     inside it, FIXED x has zero coefficients there), of which the outer S rows towards a neighbouring region are halo: after
-//     S sweeps the inner rows are exact sweeps of the global iteration.  Regions at a y wall need no halo on that side.
+//   * a workgroup owns a region of 8192 cells: ROWS full rows of the grid tiling y (no halo in x: the row is complete; periodic x
+//     wraps inside it, FIXED x has zero coefficients there), or a band of ALL rows, 8192 / ny columns wide, tiling x (FIXED x only);
+//     of a region the outer S cells towards a neighbouring region are halo: after S sweeps the inner ones are exact sweeps of the
+//     global iteration.  Regions at a wall need no halo on that side.  Shape and S depend on the grid alone (jac_plan).
 //   * each of the 512 threads keeps a strip of 4 rows x 4 columns in registers: the pre-scaled coefficients O/D (16 x 4), the
 //     right-hand sides b/D and the iterates of BOTH components (the matrix is shared by them);
-//     x neighbours come from the neighbouring lanes (ds_bpermute), y neighbours across strips from a ping-pong LDS array that
-//     holds only the top and bottom row of every strip (64 KB).  One barrier per sweep.
+//     x neighbours come from the neighbouring lanes (DPP row shifts in narrow bands, ds_bpermute otherwise), y neighbours across
+//     strips from a ping-pong LDS array that holds only the top and bottom row of every strip (64 KB).  One barrier per sweep; the
+//     two inner rows of a strip are updated in front of it.
+//   * workgroups are numbered so that the regions of an env run on one XCD (fg_xcd_remap): their halo loads meet in its L2.
 //   * the last sweep of a pass also gives the residual of the iterate it started from: b - A x_k = D (x_{k+1} - x_k).  Its sum of
 //     squares over the region's output rows goes to the system's accumulator ring (FgDacc, order-independent); the NEXT pass -- or
 //     the check kernel behind the last enqueued pass -- takes the verdict from it with the rule of the Krylov kernels
@@ -28,6 +32,7 @@
 // vector, and the kind backs off from trying again for a while.  Same system, same tolerance, same criterion: another iteration,
 // like the preconditioners of the other solves (fluidgym_amd/simulation/policy.py: advection_jacobi).
 //
+// Grids without a region shape (3-D) get the same sweeps one launch at a time (k_jac_stream, below).
 // fp32 library only (the fp64 build keeps the plain recurrences).
 #include "fg_internal.h"
 #include "fg_bicg.h"
@@ -89,7 +94,6 @@ __device__ __forceinline__ float dpp_from_below(float v) {
 __device__ __forceinline__ float dpp_from_above(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x101, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float el(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 // XT = false: the region is ROWS full rows (4 Q = nx columns), regions tile the y axis.  XT = true: the region is ALL rows (ROWS = ny)
 // of a band of 4 Q columns, regions tile the x axis (FIXED x faces only: the band's lane wrap-around is halo, never the periodic
