@@ -1783,10 +1783,17 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
         upto = checks + (more < 1 ? 1 : more);
     }
     if (!ok) {
-        // handed over: 3 = every iterate is finite (BiCGStab may start from it), 2 = start from zero
-        bool finite = true;
-        for (int i = 0; i < nsys; ++i) finite = finite && s->info_pinned[i].is_finite && std::isfinite((double)s->jac_res_pinned[2 * i]);
-        *outcome = finite ? 3 : 2;
+        // handed over: 3 = BiCGStab may start from the sweeps' iterate, 2 = it starts from zero.  From the iterate only when every
+        // system still iterating is finite and well above the tolerance: sweeps that stall just above it sit at fp32's attainable
+        // accuracy, the residual of such an iterate is rounding noise, and a BiCGStab recurrence started on noise has been seen to
+        // report convergence on a wrong iterate (Airfoil2D, resolution_div 2: one env's drag -5.0 for 0.34).
+        bool from_iterate = true;
+        for (int i = 0; i < nsys; ++i) {
+            const double r1 = (double)s->jac_res_pinned[2 * i];
+            from_iterate = from_iterate && s->info_pinned[i].is_finite && std::isfinite(r1);
+            if (s->flags_pinned[i] == 0 && !(r1 > 8.0 * (double)tol)) from_iterate = false;
+        }
+        *outcome = from_iterate ? 3 : 2;
         s->jac_fails[ps] += 1;
         s->jac_skip[ps] = s->jac_fails[ps] > 6 ? 512 : (4 << s->jac_fails[ps]);
         s->jac_sweeps[ps] = 0;
