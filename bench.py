@@ -113,6 +113,11 @@ KERNEL_DOC = {
     "k_gemm_sk": "fast-diagonalisation preconditioner: eigenbasis transform, split-K 32x32 tiles (few live envs)",
     "k_dct_rows": "fast-diagonalisation preconditioners: cosine / real Fourier transform of every grid row (one FFT per row in LDS)",
     "k_tridiag_y": "fast-diagonalisation preconditioner: per-mode tridiagonal sweep along y",
+    "k_fcg_inv_apply": "fused pressure CG, I'(k) (fg_fftcg.hip): inverse row transform of the tridiagonal kernel's output, the matrix-free pressure "
+                       "operator on the rows in LDS, r.z and z.Pz (first iteration: also the three sums the first-iterate verdict needs); "
+                       "u, rA, r read, z and P z written = 20 B per cell",
+    "k_fcg_update_fwd": "fused pressure CG, F'(k): p, s, x, r updates + r.r + sum(x) + forward row transform of the new residual "
+                        "(24-44 B per cell); not launched at all when every env ends on its first iterate",
     "k_mbc_ap": "multi-block CG: p = r + beta p on the fly, v = P p over the neighbour table, p.Pp",
     "k_mbc_update": "multi-block CG: x/r update + r.r + sum r",
 }

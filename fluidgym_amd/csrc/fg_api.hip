@@ -143,6 +143,10 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipMemset(s->fcg_alpha, 0, sizeof(double) * 2 * (size_t)g.B));
     FG_HIP_CHECK(hipMalloc(&s->fcg_xsum, sizeof(FgDacc) * 2 * (size_t)g.B));
     FG_HIP_CHECK(hipMemset(s->fcg_xsum, 0, sizeof(FgDacc) * 2 * (size_t)g.B));
+    FG_HIP_CHECK(hipMalloc(&s->fcg_lazy, sizeof(int32_t) * (size_t)g.B));
+    FG_HIP_CHECK(hipMemset(s->fcg_lazy, 0, sizeof(int32_t) * (size_t)g.B));
+    s->fcg_check0_ran = 0; s->fcg_lazy_on = 0; s->fcg_lazy_z = nullptr; s->fcg_unstored = 0; s->fcg_first_polls = 0;
+    { const char* e = getenv("FG_FCG_FIRST"); s->fcg_first = (e && atoi(e) == 0) ? 0 : 1; }
     s->fcg_mean_ready = 0;
     s->cg_return_best = 1;
     s->cg_reset_steps = 100;
@@ -172,7 +176,7 @@ extern "C" int fg_destroy(fg_handle s) {
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
-    (void)hipFree(s->cg_acc); (void)hipFree(s->fcg_alpha); (void)hipFree(s->fcg_xsum);
+    (void)hipFree(s->cg_acc); (void)hipFree(s->fcg_alpha); (void)hipFree(s->fcg_xsum); (void)hipFree(s->fcg_lazy);
     if (s->jac_prev) (void)hipHostFree(s->jac_prev);
     (void)hipFree(s->fd_row_part); (void)hipFree(s->fd_lam_x); (void)hipFree(s->fd_row_inv); (void)hipFree(s->fd_row_cp); (void)hipFree(s->fd_row_lower);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
@@ -499,6 +503,7 @@ static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real to
         a.precond = (method == FG_SOLVER_FDCG);
         a.kind = kind;
         a.check_every = a.precond ? 2 : 16;
+        a.lazy_ok = finalize ? 0 : 1;      // (the fused step's correctors read the result through FgLazyRef)
         rc = fg_cg_solve(s, a, info_host, st);
 #if !FG_F64
         // pressure solves run with returnBestResult: only a NON-FINITE solve counts as failed and is repeated in fp64
@@ -508,6 +513,7 @@ static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real to
             fg_solve_info* info = info_host;
             if (!info) { tmp.assign(s->info_pinned, s->info_pinned + s->grid.B); info = tmp.data(); }
             s->rung_count[2] += 1;
+            s->fcg_lazy_on = 0; s->fcg_check0_ran = 0; s->fcg_mean_ready = 0;      // (the repeat stores its result in p_result)
             rc = fg_rung64_cg(s, a, info, (s->ladder_force & 2) != 0, st);
         }
 #endif
@@ -673,10 +679,15 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         const bool mean_folded = last && s->fcg_mean_ready;
         if (last && !mean_folded)
             if (int rc = fg_launch_mean_sub(s, dt_B, s->p_result, s->pressure, st)) return rc;
-        const FgMeanRef mean = {s->fcg_xsum, s->info_dev, s->pressure};
+        const FgMeanRef mean = {s->fcg_xsum, s->info_dev, s->pressure, s->fcg_check0_ran ? s->fcg_lazy : nullptr, s->fcg_alpha};
+        // the solve ended on the first iterate of every env and stored no pressure: the corrector reads alpha z (FgLazyRef; the last
+        // one also stores pressureResult)
+        const bool lazy_p = s->fcg_lazy_on && (!last || mean_folded);
+        FG_REQUIRE(!s->fcg_lazy_on || lazy_p, FG_ERR_UNSUPPORTED, "fg_piso_step: an unmaterialised pressure without its folded mean");
+        const FgLazyRef lazy = {s->fcg_lazy, s->fcg_alpha, last ? s->p_result : nullptr};
         // the last corrector also writes the block velocity of active envs: CopyVelocityResultToBlocks (:1974)
-        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, (last && !mean_folded) ? s->pressure : s->p_result, s->vel_result, st,
-                                       last ? s->velocity : nullptr, mean_folded ? &mean : nullptr))
+        if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, lazy_p ? s->fcg_lazy_z : ((last && !mean_folded) ? s->pressure : s->p_result),
+                                       s->vel_result, st, last ? s->velocity : nullptr, mean_folded ? &mean : nullptr, lazy_p ? &lazy : nullptr))
             return rc;
     }
     if (opt->corrector_steps <= 0)
@@ -694,10 +705,11 @@ extern "C" int fg_config_dump(fg_handle s, char* buf, int n) {
         "\"FG_BICG3_BXL\": %d, \"FG_BICG3_MIX\": %d, \"FG_REDUCE_WGS\": %d, \"FG_CG_WGS_PER_SLOT\": %d, \"FG_TRIDIAG_CB\": %d, \"FG_HELM_CB\": %d, "
         "\"FG_HELM_ROWFORM\": %d, \"FG_FD_ROWMEAN\": %d, \"FG_POLL_SPIN\": %d, \"FG_PROF_PERIOD\": %d, \"fast_transform_x\": %d, \"fd_preconditioner\": %d, "
         "\"helmholtz\": %d, \"advection_preconditioner\": %d, \"advection_from_result\": %d, \"return_best\": %d, \"cg_reset_steps\": %d, "
-        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d}",
+        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d, \"FG_FCG_FIRST\": %d, \"first_iterate_polls\": %ld, \"unstored_pressure_solves\": %ld}",
         FG_F64 ? "f64" : "f32", s->cg_fused, s->bicg_pfused, s->bicg_fused, s->bicg_sub, s->bicg3_force, s->bicg3_bxl, s->bicg3_mix, s->reduce_wgs,
         s->cg_wgs_per_slot, s->tridiag_cb, s->helm_cb_pref, s->helm_rowform_off ? 0 : 1, s->fd_rowmean, s->poll.spin, s->prof.period, s->fd_dct_x, s->fd_Qx ? 1 : 0,
-        s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis, s->adv_jacobi);
+        s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis, s->adv_jacobi, s->fcg_first,
+        s->fcg_first_polls, s->fcg_unstored);
     if (len >= n) return len + 1;
     memcpy(buf, tmp, (size_t)len + 1);
     return FG_OK;

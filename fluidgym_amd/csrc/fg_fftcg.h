@@ -22,12 +22,16 @@ struct FcgUpdArgs {
     // first update of a solve started by k_fcg_div_fwd: x_0 = 0 and r_0 = b were never stored -- r_0 is read from the right-hand side,
     // x_0 is not read, and an env whose start vector already met the tolerance gets its zeros here
     const float* r0; int x_zero;
+    const int32_t* lazy;      // envs whose first iterate met the tolerance (k_fcg_check0): only x = x_0 + alpha z is written
 };
 struct FcgInvArgs {
     const float* u; const float* r; const float* rA; float* z; float* w;
     const float2* tw; const float2* rot; float is0, is;
     const int32_t* flags; FgDacc* acc; int ns, rows, it; long env_stride;
     const float* hy; const float* rhy; const float* hx; const float* rhx; int fixed_x;
+    // I'(0) of a solve: also d.w, w.w, d.d (d = r - w) and sum(z) (ring names FCG_GAMMA + 2, FCG_DELTA + 1, r.r ring entry 2,
+    // xsum[2 b + 1] -- all idle until the second iteration), from which k_fcg_check0 knows |r_1| before any vector is updated
+    FgDacc* xsum; int extras;
 };
 
 struct FcgDivArgs {
@@ -42,5 +46,7 @@ struct FcgDivArgs {
 int fg_fcg_div_fwd(fg_state* s, const FgBounds& bnd, const fg_real* dt, const fg_real* hvec, fg_real* div, int ns, hipStream_t st);
 bool fg_fcg_ok(const fg_state* s);     // the grid / preconditioner setup the fused kernels cover (and FG_CG_FUSED != 0)
 int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int ns, hipStream_t st, const fg_real* r0 = nullptr);
-int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it, int ns, hipStream_t st);
+int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it, int ns, hipStream_t st, int extras = 0);
+// verdict on the FIRST iterate from the dot products of I'(0) (k_fcg_check0): flags / info / alpha / lazy marks
+int fg_fcg_check0(fg_state* s, fg_real tol, int ns, hipStream_t st, FgPollOut poll);
 #endif

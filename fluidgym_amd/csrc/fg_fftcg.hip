@@ -47,7 +47,28 @@ __global__ __launch_bounds__(256) void k_fcg_update_fwd(FcgUpdArgs a) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (a.flags[b] != 0) {
-        if (a.x_zero && (a.flags[b] == 1 || a.flags[b] == 2)) {
+        if (a.lazy && a.lazy[b] == 1) {
+            // the first iterate of this env met the tolerance (k_fcg_check0): x_1 = x_0 + alpha z is all that is left to write
+            const float alpha = (float)a.alpha[b * 2];
+            const int row0 = 2 * (blockIdx.x * 4 + wave);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int row = row0 + half;
+                if (row >= a.rows) continue;
+                const size_t o = (size_t)b * a.env_stride + (size_t)row * N;
+                float zv[EPL], xv[EPL];
+                fgfft::load_row<N>(a.z + o, lane, zv);
+                if (a.x_zero) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) xv[e] = 0.f;
+                } else {
+                    fgfft::load_row<N>(a.x + o, lane, xv);
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) xv[e] += alpha * zv[e];
+                fgfft::store_row<N>(a.x + o, lane, xv);
+            }
+        } else if (a.x_zero && (a.flags[b] == 1 || a.flags[b] == 2)) {
             // the start vector of this env met the tolerance (or its right-hand side is not finite): x_0 = 0 is its result
             float z0[EPL];
 #pragma unroll
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(320) void k_fcg_inv_apply(FcgInvArgs a) {
     constexpr int VW = M::VW;
     __shared__ __attribute__((aligned(16))) float2 buf[2][5][N];
     __shared__ __attribute__((aligned(16))) float2 twl[N];
-    __shared__ float red[10];
+    __shared__ float red[30];
     const int b = blockIdx.y;
     if (a.flags[b] != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(320) void k_fcg_inv_apply(FcgInvArgs a) {
     }
     __syncthreads();
     float part[2] = {0.f, 0.f};     // r.z | z.Pz
+    float ext[4] = {0.f, 0.f, 0.f, 0.f};      // d.w | w.w | sum z | d.d with d = r - w (I'(0) only: FcgInvArgs::extras)
     if (wave < 4) {
         // every wave's result landed in the same one of its two buffers: wave w' has its rows at zr + (w' - wave) * 2N floats
         const float* zup = (wave == 0) ? zr + 4 * 2 * N : zr - 2 * N + N;           // row above row a: halo wave's row a | wave - 1's row b
@@ -244,6 +266,14 @@ __global__ __launch_bounds__(320) void k_fcg_inv_apply(FcgInvArgs a) {
             if (livea) { part[0] += ra[e] * za[e]; part[1] += za[e] * wa[e]; }
             if (liveb) { part[0] += rb[e] * zb[e]; part[1] += zb[e] * wb[e]; }
         }
+        if (a.extras) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const float da = ra[e] - wa[e], db = rb[e] - wb[e];
+                if (livea) { ext[0] += da * wa[e]; ext[1] += wa[e] * wa[e]; ext[2] += za[e]; ext[3] += da * da; }
+                if (liveb) { ext[0] += db * wb[e]; ext[1] += wb[e] * wb[e]; ext[2] += zb[e]; ext[3] += db * db; }
+            }
+        }
         if (livea) { fgfft::store_row<N>(a.z + oa, lane, za); fgfft::store_row<N>(a.w + oa, lane, wa); }
         if (liveb) { fgfft::store_row<N>(a.z + ob, lane, zb); fgfft::store_row<N>(a.w + ob, lane, wb); }
     }
@@ -253,11 +283,69 @@ __global__ __launch_bounds__(320) void k_fcg_inv_apply(FcgInvArgs a) {
         const float sv = fg_wave_sum(part[q]);
         if (lane == 0) red[q * 5 + wave] = sv;
     }
+    if (a.extras) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float sv = fg_wave_sum(ext[q]);
+            if (lane == 0) red[10 + q * 5 + wave] = sv;
+        }
+    }
     __syncthreads();
+    if (a.extras && threadIdx.x >= 64 && threadIdx.x < 68) {
+        const int q = threadIdx.x - 64;
+        const float* rq = red + 10 + q * 5;
+        const float tot = ((rq[0] + rq[1]) + (rq[2] + rq[3])) + rq[4];
+        if (q == 2) acc_add(a.xsum + (b * 2 + 1), (double)tot);
+        else fg_acc_add(fg_acc_ptr(a.acc, b, q == 0 ? FCG_GAMMA + 2 : (q == 1 ? FCG_DELTA + 1 : 2)), a.ns, blockIdx.x, (double)tot);
+    }
     if (threadIdx.x < 2) {
         const int q = threadIdx.x;
         const float tot = ((red[q * 5] + red[q * 5 + 1]) + (red[q * 5 + 2] + red[q * 5 + 3])) + red[q * 5 + 4];
         fg_acc_add(fg_acc_ptr(a.acc, b, q == 0 ? FCG_GAMMA + a.it % 3 : FCG_DELTA + (a.it & 1)), a.ns, blockIdx.x, (double)tot);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// C(0): the verdict on the FIRST iterate, before any vector is updated.  The first step of the recurrence is x_1 = x_0 + alpha z_0,
+// r_1 = r_0 - alpha w_0 with alpha = gamma_0 / delta_0.  With d = r_0 - w_0 (small: the preconditioner is close to the inverse, so
+// w_0 = P M^-1 r_0 is close to r_0 and alpha to 1) r_1 = d + (1 - alpha) w_0 and |r_1|^2 = d.d + 2 (1 - alpha) d.w + (1 - alpha)^2 w.w
+// is a sum of three SMALL terms that I'(0) accumulates -- r.r - 2 alpha r.w + alpha^2 w.w cancels to the rounding of its fp32
+// partial sums, 3e-4 |r_0|, and reported 1.5e-4 for an env whose first residual is 3e-6 -- with alpha rounded to fp32 as the update
+// applies it.  An env that
+// meets the tolerance (the RMS criterion of cg_solver_kernel.cu:100-106 on that number) is marked: its result is x_0 + alpha z_0,
+// which F'(0) writes without touching r -- or which nobody writes at all when EVERY env of the batch ends here (the PISO pressure
+// systems of the channel family: 99 % of the solves) and the caller reads the pressure as alpha z (FgLazyRef).  One wave per env.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void k_fcg_check0(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+                             fg_solve_info* __restrict__ mirror, double* __restrict__ alpha, int32_t* __restrict__ lazy, float tol,
+                             int n, int B, int ns, FgPollOut poll) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    int lz = 0;
+    if (flag_ld(flags + (b)) == 0) {
+        const double g = fg_acc_total(fg_acc_ptr(acc, b, FCG_GAMMA), ns), d = fg_acc_total(fg_acc_ptr(acc, b, FCG_DELTA), ns);
+        const double dd = fg_acc_total(fg_acc_ptr(acc, b, 2), ns);
+        const double dw = fg_acc_total(fg_acc_ptr(acc, b, FCG_GAMMA + 2), ns), ww = fg_acc_total(fg_acc_ptr(acc, b, FCG_DELTA + 1), ns);
+        const double alpha_d = g / d;
+        const double e1 = 1.0 - (double)(float)alpha_d;
+        double rr1 = dd + 2.0 * e1 * dw + e1 * e1 * ww;
+        if (rr1 < 0.0) rr1 = 0.0;      // (a NaN stays one)
+        const float crit = (float)sqrt(rr1 / (double)n);
+        if (threadIdx.x == 0) {
+            info[b].final_residual = crit;
+            info[b].used_iterations = 0;
+            if (!(crit >= tol)) {
+                const bool finite = isfinite(crit);
+                flag_st(flags + (b), finite ? 1 : 2);
+                info[b].converged = finite ? 1 : 0;
+                info[b].is_finite = finite ? 1 : 0;
+                if (finite) { alpha[b * 2] = alpha_d; lz = 1; }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        lazy[b] = lz;
+        if (mirror) { mirror[b] = info[b]; fg_poll_publish(poll, b); }
     }
 }
 
@@ -402,6 +490,7 @@ int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int n
     const FgGrid& G = s->grid;
     FcgUpdArgs a = {};
     a.r0 = r0; a.x_zero = r0 ? 1 : 0;
+    a.lazy = (it == 0 && s->fcg_check0_ran) ? s->fcg_lazy : nullptr;
     a.z = v.z; a.w = v.w; a.p = v.p; a.s = v.s; a.x = v.x; a.r = v.r; a.t1 = v.t1;
     a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot; a.fs0 = s->fd_dct_fwd[0]; a.fs = s->fd_dct_fwd[1];
     a.flags = s->flags; a.acc = s->cg_acc; a.alpha = s->fcg_alpha; a.xsum = s->fcg_xsum; a.best = s->cg_best;
@@ -414,18 +503,27 @@ int fg_fcg_update_fwd(fg_state* s, const FcgVectors& v, int it, int first, int n
     return FG_OK;
 }
 
-int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it, int ns, hipStream_t st) {
+int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it, int ns, hipStream_t st, int extras) {
     const FgGrid& G = s->grid;
     FcgInvArgs a = {};
     a.u = v.t1; a.r = v.r; a.rA = rA; a.z = v.z; a.w = v.w;
     a.tw = s->fd_dct_tw; a.rot = s->fd_dct_rot; a.is0 = s->fd_dct_inv[0]; a.is = s->fd_dct_inv[1];
     a.flags = s->flags; a.acc = s->cg_acc; a.ns = ns; a.rows = G.ny; a.it = it; a.env_stride = G.n;
+    a.xsum = s->fcg_xsum; a.extras = (extras && it == 0) ? 1 : 0;
     a.hy = G.h[1]; a.rhy = G.rh[1]; a.hx = G.h[0]; a.rhx = G.rh[0]; a.fixed_x = G.fixed[0];
     const dim3 grid((G.ny + 7) / 8, G.B);
     // per env: u, rA, r read; z, w written (the halo rows come from L2)
     const int slot = fg_prof_slot(s, FG_PK_FCG_INV, s->flags, G.B, 20.0 * G.n, (14.0 + 5.0 * log2((double)G.nx)) * G.n, st);
     if (int rc = (s->fd_dct_x == 2 ? launch_inv<true>(s, slot, G.nx, a, grid, st) : launch_inv<false>(s, slot, G.nx, a, grid, st))) return rc;
     FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+int fg_fcg_check0(fg_state* s, fg_real tol, int ns, hipStream_t st, FgPollOut poll) {
+    const FgGrid& G = s->grid;
+    hipLaunchKernelGGL(k_fcg_check0, dim3(G.B), dim3(64), 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, s->fcg_alpha, s->fcg_lazy,
+                       tol, G.n, G.B, ns, poll);
+    FG_HIP_CHECK(hipGetLastError());
+    s->fcg_check0_ran = 1;
     return FG_OK;
 }
 // right-hand side + start of the solve + first forward transform (k_fcg_div_fwd): div, r = w[0], x = p_result, u = w[3], r.r in ring entry 0

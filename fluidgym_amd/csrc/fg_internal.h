@@ -684,6 +684,12 @@ struct fg_state {
     // fused row kernels (fg_fftcg.hip / fg_fftbicg.hip): cg_fused 1 (default) = three-launch preconditioned pressure CG on 2-D grids
     // with a fast x transform, FG_CG_FUSED=0 at fg_create keeps the five kernels; alpha_k per env and parity; sum(x_k) per env and parity
     int cg_fused, bicg_pfused; double* fcg_alpha; FgDacc* fcg_xsum;
+    // First iterate of the fused CG left unmaterialised (fg_fftcg.hip, k_fcg_check0): fcg_lazy[b] = 1 for an env whose FIRST iterate
+    // from zero met the tolerance -- its result is x = alpha_0 z_0.  fcg_check0_ran: the marks belong to the last pressure solve;
+    // fcg_lazy_on: that solve ended with EVERY env so (or stopped at its start vector) and wrote no x at all: the corrector reads
+    // fcg_lazy_z scaled by fcg_alpha[2 b] instead (FgLazyRef).  fcg_first: 0 switches the whole scheme off (FG_FCG_FIRST=0).
+    int32_t* fcg_lazy; mutable int fcg_check0_ran, fcg_lazy_on; mutable const fg_real* fcg_lazy_z; int fcg_first;
+    mutable long fcg_unstored, fcg_first_polls;      // solves that stored no x | solves whose first iterate was polled (fg_config_dump)
     mutable int fcg_mean_ready;   // the last pressure solve left sum(x) of its result in fcg_xsum[b][used_iterations & 1] (consumed by k_correct)
     fg_real* line_inv; fg_real* line_cp;
     fg_real* ilu_d;               // [B,N] modified diagonal of the ILU(0) preconditioner (fg_ilu0.hip), built per solve
@@ -823,9 +829,13 @@ int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, con
 // mean (optional): the corrector also writes p - mean(p) of active envs to p_copy (the block pressure: setPressureResult +
 // CopyPressureResultToBlocks, PISOtorch_simulation.py:1922-1925, 1953, without the two passes of fg_launch_mean_sub), the sum of
 // env b's pressure being sums[2 b + (info[b].used_iterations & 1)] (0 for a solve that took no iteration: x = 0)
-struct FgMeanRef { const FgDacc* sums; const fg_solve_info* info; fg_real* p_copy; };
+// lazy / alpha (optional, FgLazyRef below): an env marked lazy took ONE iteration from zero, x = alpha z, and its sum is alpha * sums[2 b + 1]
+struct FgMeanRef { const FgDacc* sums; const fg_solve_info* info; fg_real* p_copy; const int32_t* lazy; const double* alpha; };
+// The pressure the corrector reads is not stored: `p` is z_0 of the fused CG and env b's pressure is alpha[2 b] * z (lazy[b] == 1) or
+// zero (lazy[b] == 0: the env stopped at its start vector).  p_res (optional): the corrector also stores it (pressureResult).
+struct FgLazyRef { const int32_t* lazy; const double* alpha; fg_real* p_res; };
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
-                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy = nullptr, const FgMeanRef* mean = nullptr);
+                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy = nullptr, const FgMeanRef* mean = nullptr, const FgLazyRef* lazy = nullptr);
 // mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be
 // scratch_B + B, whose next row holds the arrival counters)
 // poll (optional): sequence words published per env after the host-pinned result (FgPollOut above)
@@ -856,6 +866,7 @@ struct FgCgArgs {
     int check_every;
     int precond;   // 1: fast-diagonalisation preconditioned CG (needs fg_set_fd_preconditioner)
     int kind = 2;  // which poll predictor the solve reads and updates (fg_state::pred_cg)
+    int lazy_ok = 0;   // the caller reads the result through FgLazyRef when fg_state::fcg_lazy_on comes back set (the fused PISO step)
 };
 int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStream_t st);
 

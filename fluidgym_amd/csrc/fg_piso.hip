@@ -342,7 +342,7 @@ template <int DIMS, int VEC>
 __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const fg_real* __restrict__ dt,
                                                        const fg_real* __restrict__ rA_, const fg_real* __restrict__ hvec,
                                                        const fg_real* __restrict__ p, fg_real* __restrict__ vel_out,
-                                                       fg_real* __restrict__ vel_copy, FgMeanRef mean, int tiles_x, int tiles_y, int tiles) {
+                                                       fg_real* __restrict__ vel_copy, FgMeanRef mean, FgLazyRef lazy, int tiles_x, int tiles_y, int tiles) {
     // vel_copy (optional): the block velocity of active envs, written alongside the result by the last corrector of a step
     // (CopyVelocityResultToBlocks, PISOtorch_simulation.py:1974, without a pass of its own)
     const FgCtx<DIMS, VEC> c = fg_make_ctx<DIMS, VEC>(g, tiles_x, tiles_y, tiles);
@@ -350,12 +350,26 @@ __global__ __launch_bounds__(FG_BLOCK) void k_correct(FgGrid g, const fg_real* _
     const size_t N = g.n;
     const FgMetric<DIMS, VEC> m = fg_metrics<DIMS, VEC>(g, c);
     const FgVec<VEC> rA = fg_load<VEC>(rA_ + (size_t)c.b * N + c.idx);
-    const FgNbr<DIMS, VEC> P = fg_gather<DIMS, VEC>(p + (size_t)c.b * N, c);
+    FgNbr<DIMS, VEC> P = fg_gather<DIMS, VEC>(p + (size_t)c.b * N, c);
+    if (lazy.lazy) {
+        // `p` is z_0 of the fused CG: this env's pressure is alpha z (or zero: it stopped at its start vector) -- FgLazyRef
+        const bool on = lazy.lazy[c.b] == 1;
+        const fg_real sc = on ? (fg_real)lazy.alpha[2 * c.b] : (fg_real)0;
+        auto scale = [&](FgVec<VEC>& v) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = on ? sc * v.v[e] : (fg_real)0;
+        };
+        scale(P.c); scale(P.xm); scale(P.xp); scale(P.ym); scale(P.yp);
+        if constexpr (DIMS == 3) { scale(P.zm); scale(P.zp); }
+        if (lazy.p_res) fg_store<VEC>(lazy.p_res + (size_t)c.b * N + c.idx, P.c);
+    }
     if (mean.sums) {
         // p - mean(p) to the block (PISOtorch_simulation.py:1922-1925, 1953): the solver's update kernels summed the iterate they
-        // left (FgMeanRef, fg_internal.h)
+        // left (FgMeanRef, fg_internal.h); an env that ended on its first iterate from zero has sum(x) = alpha sum(z)
         const int used = mean.info[c.b].used_iterations;
-        const fg_real mu = used < 0 ? (fg_real)0 : (fg_real)(acc_ld(mean.sums + (2 * c.b + (used & 1))) / (double)g.n);
+        const bool first_only = mean.lazy && mean.lazy[c.b] == 1;
+        const fg_real mu = first_only ? (fg_real)(mean.alpha[2 * c.b] * acc_ld(mean.sums + (2 * c.b + 1)) / (double)g.n)
+                           : used < 0 ? (fg_real)0 : (fg_real)(acc_ld(mean.sums + (2 * c.b + (used & 1))) / (double)g.n);
         FgVec<VEC> pc;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) pc.v[e] = P.c.v[e] - mu;
@@ -1035,12 +1049,13 @@ int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, con
 }
 
 int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, const fg_real* hvec, const fg_real* p,
-                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy, const FgMeanRef* mean) {
+                      fg_real* vel_out, hipStream_t st, fg_real* vel_copy, const FgMeanRef* mean, const FgLazyRef* lazy) {
     fg_htrace("correct_in");
-    const FgMeanRef mr = mean ? *mean : FgMeanRef{nullptr, nullptr, nullptr};
+    const FgMeanRef mr = mean ? *mean : FgMeanRef{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const FgLazyRef lz = lazy ? *lazy : FgLazyRef{nullptr, nullptr, nullptr};
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out, vel_copy, mr,
+        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out, vel_copy, mr, lz,
                            L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());

@@ -415,6 +415,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         const bool ready = s->cg_ready_ns == ns && s->cg_ready_best == s->cg_return_best && s->cg_ready_dt == a.dt;
         start_ready = ready && s->cg_start_ready && !a.use_x0 && a.b == s->div && a.r == s->w[0] && a.x == s->p_result;
         start_fwd = start_ready && s->cg_start_ready == 2;      // ... and w[3] holds Qx^T r_0 (k_fcg_div_fwd)
+        (void)start_fwd;
         s->cg_ready_ns = 0; s->bicg_ready_nc = 0; s->cg_start_ready = 0;
         if (!ready) {
             FgCgBegin q;
@@ -436,6 +437,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     FgCgJudge judge;
     judge.acc = s->cg_acc; judge.flags = s->flags; judge.info = s->info_dev; judge.tol = a.tol; judge.it = -1; judge.n = n; judge.ns = ns;
     s->fcg_mean_ready = 0;
+    s->fcg_check0_ran = 0; s->fcg_lazy_on = 0;
 #if !FG_F64
     const bool fused = a.precond && s->fd_Qx && fg_fcg_ok(s);
 #else
@@ -482,7 +484,38 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         {
             FcgVectors v0 = v;
             if (r0) v0.r = const_cast<fg_real*>(r0);      // (read only by the inverse kernel)
-            if (int rc = fg_fcg_inv_apply(s, v0, a.rA, 0, ns, st)) return rc;
+            if (int rc = fg_fcg_inv_apply(s, v0, a.rA, 0, ns, st, s->fcg_first)) return rc;
+        }
+        if (s->fcg_first && a.max_iterations >= 1) {
+            // C(0): the first iterate is judged from I'(0)'s dot products (k_fcg_check0).  Polled when the previous solve of this kind
+            // ended after one iteration: if every env ends here nothing is left to do but write x_1 = alpha z -- or not even that
+            // (lazy_ok: the corrector reads alpha z itself)
+            const bool poll0 = next_poll <= 1;
+            const FgPollOut po = poll0 ? fg_poll_next(&s->poll) : FgPollOut{nullptr, 0};
+            if (poll0) fg_prof_prefetch(s, st);
+            if (int rc = fg_fcg_check0(s, a.tol, ns, st, po)) return rc;
+            if (poll0) {
+                fg_htrace("cg_check_launched");
+                if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
+                fg_htrace("cg_poll_done");
+                info_fresh = true;
+                s->fcg_first_polls += 1;
+                bool all = true, all_ok = true;
+                for (int b = 0; b < B; ++b) {
+                    all = all && (s->info_pinned[b].converged || !s->info_pinned[b].is_finite);
+                    all_ok = all_ok && s->info_pinned[b].converged && s->info_pinned[b].is_finite;
+                }
+                if (all) {
+                    if (a.lazy_ok && r0 && all_ok && mean_sums) {
+                        s->fcg_lazy_on = 1; s->fcg_lazy_z = v.z; s->fcg_unstored += 1;
+                    } else {
+                        if (int rc = fg_fcg_update_fwd(s, v, 0, 1, ns, st, r0)) return rc;      // (every env takes the short path)
+                    }
+                    done = true;
+                } else {
+                    next_poll = 2;
+                }
+            }
         }
         int first = 1;
         // restart period of THIS recurrence: s = P p is carried by a recurrence of its own here (s = w + beta s), so r and the true
