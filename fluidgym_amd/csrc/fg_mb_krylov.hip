@@ -1578,6 +1578,11 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
     }
     const int frc = mb_finish(s, nsys, nullptr, max_it);
     if (max_it && frc == FG_OK) pred = *max_it < 200 ? *max_it : 200;
+    if (frc == FG_ERR_NOT_CONVERGED && s->dbg_fail)      // FG_MB_TRACE_FAIL: how far from the tolerance a capped solve ended
+        for (int i = 0; i < nsys; ++i)
+            if (!s->info_pinned[i].converged)
+                fprintf(stderr, "[mb_bicg] capped system %d (nc %d, ilu %d, project %d, refine %d): it %d residual %g tol %g\n", i, nc, ilu, project, refine,
+                        (int)s->info_pinned[i].used_iterations, (double)s->info_pinned[i].final_residual, (double)tol);
     if (frc == FG_ERR_NOT_FINITE && s->dbg_fail) {   // rare path, FG_MB_TRACE_FAIL only: the recurrence scalars of the systems that broke down
         std::vector<FgDacc> acc_raw((size_t)nsys * MB_ACC);
         std::vector<double> acc((size_t)nsys * MB_ACC);

@@ -644,10 +644,13 @@ __global__ __launch_bounds__(NT) void k_mbc_onchip(MbDev D, MbSolve q, OcParams 
 // restart / best-iterate / stall rules and preconditioner are those of k_mbc_onchip<PRE, !AGG>, statement by statement.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int OC_L2_CELLS = 24 * 1024;
+#ifndef OC_L2_G
+#define OC_L2_G 4      // members per batch of loads in flight together (-DOC_L2_G=8: A/B builds)
+#endif
 template <int PM>
 __global__ __launch_bounds__(1024) void k_mbc_l2(MbDev D, MbSolve q, OcParams o) {
     static_assert(PM != 2, "mean projection or none");
-    constexpr int NT = 1024, G = 4, NW = NT / 64;
+    constexpr int NT = 1024, G = OC_L2_G, NW = NT / 64;
     __shared__ mb_real v_lds[OC_L2_CELLS];
     __shared__ double red[3][2][OC_MAX_WAVES];
     __shared__ mb_real l_r4[OC_N4], l_r8[OC_N8];
