@@ -689,6 +689,7 @@ struct fg_state {
     // fcg_lazy_on: that solve ended with EVERY env so (or stopped at its start vector) and wrote no x at all: the corrector reads
     // fcg_lazy_z scaled by fcg_alpha[2 b] instead (FgLazyRef).  fcg_first: 0 switches the whole scheme off (FG_FCG_FIRST=0).
     int32_t* fcg_lazy; mutable int fcg_check0_ran, fcg_lazy_on; mutable const fg_real* fcg_lazy_z; int fcg_first;
+    int jac_warm;      // the Jacobi sweeps of the velocity systems start from the block velocity: 1 always, 0 never (the BiCGStab start vector), -1 (default) on the grids where that saves a pass (fg_jacobi.hip: jac_warm_start)
     mutable long fcg_unstored, fcg_first_polls;      // solves that stored no x | solves whose first iterate was polled (fg_config_dump)
     mutable int fcg_mean_ready;   // the last pressure solve left sum(x) of its result in fcg_xsum[b][used_iterations & 1] (consumed by k_correct)
     fg_real* line_inv; fg_real* line_cp;

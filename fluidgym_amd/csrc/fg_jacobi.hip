@@ -505,6 +505,17 @@ static bool jac_onchip_ok(const fg_state* s, const FgBicgArgs& a) { return a.nc 
 // the streaming form takes the velocity systems of everything else (3-D; 2-D grids no region shape fits), where rA = 1 / diag is at hand
 static bool jac_stream_ok(const fg_state* s, const FgBicgArgs& a) { return a.nc == s->grid.dims && a.diag == s->A && s->rA != nullptr && s->rA_epoch == s->jac_rA_epoch; }
 
+// The sweeps start from the block velocity (the velocity systems of a step: the result goes to velocityResult).  A static rule, so
+// that an env's bits do not depend on the handle's history: it pays where a cold start needs more than two passes -- the 512 x 256
+// grid contracts by 0.47 per sweep, 24 sweeps from zero, 16.6 from u^n (`large_env` 2 065 / 2 100 -> 2 292 / 2 287 env-steps/s, same
+// box) -- and costs where one pass suffices anyway (256 x 128: the same 12 sweeps plus 17 MB more to read, 7 553 / 7 672 -> 7 384 /
+// 7 199) or sweeps are cheap to add (the streaming form: 7 sweeps either way).  Default: on-chip grids of 2^17 cells and more.
+static bool jac_warm_start(const fg_state* s, const FgBicgArgs& a, bool onchip) {
+    if (!(a.x == s->vel_result && a.nc == s->grid.dims && s->velocity != nullptr)) return false;
+    if (s->jac_warm >= 0) return s->jac_warm != 0;
+    return onchip && s->grid.n >= (1 << 17);
+}
+
 bool fg_jacobi_ok(const fg_state* s, const FgBicgArgs& a) {
     if (!s->adv_jacobi || a.precond || s->jac_prev == nullptr) return false;
     return jac_onchip_ok(s, a) || jac_stream_ok(s, a);
@@ -539,13 +550,20 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     int passes = 0;
     // pass p writes the result vector when p has the parity of the last planned pass (a start from a.x reads it in pass 0,
     // so that pass has to write the work buffer)
+    // Start vector.  The sweeps are this library's own iteration, so their start is not the reference's BiCGStab start (zero on the
+    // non-orthogonal branch): the first pass reads the BLOCK velocity, u^n -- an O(dt) distance from the solution -- straight from
+    // where it lives (velocityResult is not read, so pass 0 may write it and no parity is lost).  FG_JAC_WARM=0 / other systems:
+    // a.use_x0 as BiCGStab has it.
+    const bool warm = jac_warm_start(s, a, true);
+    const bool from_x = a.use_x0 && !warm;
     int last_parity = (P - 1) & 1;
-    if (a.use_x0 && last_parity == 0) last_parity = 1;
+    if (from_x && last_parity == 0) last_parity = 1;
     auto enqueue = [&](int count) -> int {
         for (int k = 0; k < count; ++k, ++passes) {
-            q.pass = passes; q.zero_start = (passes == 0 && !a.use_x0) ? 1 : 0;
+            q.pass = passes; q.zero_start = (passes == 0 && !from_x && !warm) ? 1 : 0;
             const bool to_x = ((passes & 1) == last_parity);
             q.xin = to_x ? work : a.x; q.xout = to_x ? a.x : work;
+            if (warm && passes == 0) q.xin = s->velocity;
             const int slot = fg_prof_slot(s, FG_PK_JAC_PASS, s->flags, nsys, q.zero_start ? bytes_sys * 9.0 / 11.0 : bytes_sys, flops_sys, st);
             if (int rc = launch_pass(s, slot, plan, q, st)) return rc;
         }
@@ -626,7 +644,10 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
 static int jacobi_stream_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, int* outcome) {
     // (a check judges the iterate its last sweep STARTED from, so odd counts -- 5, 7, ... -- from a zero start, where sweep 0 may write the
     //  result vector; a start from the result vector has to write the work buffer first: even counts)
-    const int FIRST = a.use_x0 ? 6 : 5;
+    // (from the block velocity -- jac_warm_start -- nothing but the measuring sweeps bounds the first check: 3, 5, ...)
+    const bool warm = jac_warm_start(s, a, false);
+    const bool from_x = a.use_x0 && !warm;
+    const int FIRST = warm ? 3 : (from_x ? 6 : 5);
     constexpr int STEP = 2, CHECKS = 8;
     FgJacHist& H = s->jac_hist[a.kind & 3];
     const FgGrid& G = s->grid;
@@ -641,8 +662,9 @@ static int jacobi_stream_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* 
         while (checks < upto) {
             const int target = FIRST + STEP * checks;
             for (; sweeps < target; ++sweeps) {
-                const int w = (sweeps + (a.use_x0 ? 1 : 0)) & 1;
-                q.xin = buf[w ^ 1]; q.xout = buf[w]; q.from_zero = (sweeps == 0 && !a.use_x0) ? 1 : 0;
+                const int w = (sweeps + (from_x ? 1 : 0)) & 1;
+                q.xin = buf[w ^ 1]; q.xout = buf[w]; q.from_zero = (sweeps == 0 && !from_x && !warm) ? 1 : 0;
+                if (warm && sweeps == 0) q.xin = s->velocity;
                 q.measure_slot = (sweeps >= FIRST - 3 && ((sweeps - (FIRST - 3)) & 1) == 0) ? (sweeps - (FIRST - 3)) / 2 : -1;
                 q.ax_slot = (sweeps == FIRST - 1) ? 12 : -1;
                 // (the first sweep of a zero start reads no x and no off-diagonals: it is not sampled, which also keeps the sampling period

@@ -248,3 +248,42 @@ def test_streaming_sweeps_on_grids_without_a_region_shape(n, fixed, dims):
             assert rel_err(xj[b, c], x_ref) < 3e-6, (b, c)
     xm, im, _ = _solve(case, [dt[0], 0.0, dt[2]], True, tol)
     assert np.array_equal(xm[0], xj[0]) and np.array_equal(xm[2], xj[2]) and all(i.used_iterations == -1 for i in im[dims:2 * dims])
+
+
+@pytest.mark.parametrize("n", [(256, 128), (128, 64, 16)])
+def test_sweeps_started_from_the_block_velocity(n, monkeypatch):
+    """FG_JAC_WARM=1: the first pass / sweep reads the block velocity u^n instead of starting from zero (the default on the large
+    on-chip grids, where it saves a pass: jac_warm_start, fg_jacobi.hip).  Same system, same criterion: both starts meet the direct
+    solve, on the region form and on the streaming form, with a masked env left alone."""
+    dims = len(n)
+    h = min(2.0 / n[0], 1.0 / n[1])
+    case = make_case(dims=dims, n=n, fixed_axes=(0, 1) if dims == 2 else (1,), B=3, seed=6, stretch=0.0, nu=0.25 * h, vel_scale=0.5)
+    dt = [0.2 * h, 0.0, 0.1 * h]
+    tol = 2e-7 / 0.1 / h
+    out = {}
+    for warm in ("1", "0"):
+        monkeypatch.setenv("FG_JAC_WARM", warm)
+        ns = case.native()
+        assert ns.config_dump()["FG_JAC_WARM"] == int(warm)
+        ns.set_advection_jacobi(True)
+        ns.set_advection_start(False)
+        ns.setup_advection(dt)
+        before = ns.buffer(3, (case.B, dims) + case.shape).clone()
+        info = ns.solve_advection(tol=tol)
+        torch.cuda.synchronize()
+        x = ns.buffer(3, (case.B, dims) + case.shape)
+        assert ns.advection_jacobi_counts() == {"settled_by_sweeps": 1, "handed_to_bicgstab": 0}
+        assert torch.equal(x[1], before[1])      # masked env
+        out[warm] = (_np(x), [(i.used_iterations, i.final_residual, i.converged) for i in info])
+        ns.close()
+    for warm in ("1", "0"):
+        x, info = out[warm]
+        for b in (0, 2):
+            dom = case.oracle_domain(b, case.grid())
+            C, _, _ = O.build_advection_matrix(dom, dt[b])
+            rhs = O.advection_rhs_velocity(dom, dt[b])
+            for c in range(dims):
+                res = float(np.sqrt(np.mean((rhs[c].ravel() - C @ x[b, c].ravel()) ** 2)))
+                assert info[dims * b + c][2] and res < 2.5 * tol, (warm, b, c, res, tol)
+    assert rel_err(out["1"][0][[0, 2]], out["0"][0][[0, 2]]) < 1e-5
+    print("JACOBI warm / cold sweeps:", [i[0] for i in out["1"][1]], [i[0] for i in out["0"][1]])
