@@ -147,6 +147,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipMemset(s->fcg_lazy, 0, sizeof(int32_t) * (size_t)g.B));
     s->fcg_check0_ran = 0; s->fcg_lazy_on = 0; s->fcg_lazy_z = nullptr; s->fcg_unstored = 0; s->fcg_first_polls = 0;
     { const char* e = getenv("FG_FCG_FIRST"); s->fcg_first = (e && atoi(e) == 0) ? 0 : 1; }
+    { const char* e = getenv("FG_JAC_PREFACTOR"); s->jac_prefactor = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("FG_JAC_WARM"); s->jac_warm = e ? (atoi(e) != 0 ? 1 : 0) : -1; }      // (-1: where it pays, jac_warm_start)
     s->fcg_mean_ready = 0;
     s->cg_return_best = 1;

@@ -689,6 +689,7 @@ struct fg_state {
     // fcg_lazy_on: that solve ended with EVERY env so (or stopped at its start vector) and wrote no x at all: the corrector reads
     // fcg_lazy_z scaled by fcg_alpha[2 b] instead (FgLazyRef).  fcg_first: 0 switches the whole scheme off (FG_FCG_FIRST=0).
     int32_t* fcg_lazy; mutable int fcg_check0_ran, fcg_lazy_on; mutable const fg_real* fcg_lazy_z; int fcg_first;
+    int jac_prefactor;      // FG_JAC_PREFACTOR (default 1): fg_fd_rowmean_prefactor behind the sweeps' check kernel
     int jac_warm;      // the Jacobi sweeps of the velocity systems start from the block velocity: 1 always, 0 never (the BiCGStab start vector), -1 (default) on the grids where that saves a pass (fg_jacobi.hip: jac_warm_start)
     mutable long fcg_unstored, fcg_first_polls;      // solves that stored no x | solves whose first iterate was polled (fg_config_dump)
     mutable int fcg_mean_ready;   // the last pressure solve left sum(x) of its result in fcg_xsum[b][used_iterations & 1] (consumed by k_correct)
@@ -938,6 +939,10 @@ struct FgCgLead;    // fg_cg.h
 int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean = false);   // the per-mode Thomas solve of fg_fd_apply alone (in place); use_rowmean: the per-env factors of fg_fd_rowmean_factor
 bool fg_fd_rowmean_ok(const fg_state* s);
 int fg_fd_rowmean_factor(fg_state* s, const float* rA, const float* dt, hipStream_t st, const float* row_part = nullptr, int tiles_x = 0);
+// the factors for the CURRENT 1/A field ahead of the pressure solves that will want them (fg_cg_solve then finds them made): launched
+// behind a polled kernel, the factorisation -- 14 us, latency-sized, independent of the velocity solve -- runs while the host turns the
+// poll around instead of in front of the first tridiagonal solve.  A no-op where the fused CG / the row-mean operator do not apply.
+int fg_fd_rowmean_prefactor(fg_state* s, const fg_real* dt, hipStream_t st);
 // y-line preconditioner (fg_linepre.hip): buffers, Thomas factorisation of the tridiagonal part of (diag, off) along y for every env
 // with a live system, z = M^-1 r for every live system
 int fg_line_alloc(fg_state* s);

@@ -574,6 +574,8 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
         const FgPollOut po = fg_poll_next(&s->poll);
         q.pass = passes;
         hipLaunchKernelGGL(k_jac_check, dim3((B + 63) / 64), dim3(64), 0, st, q, s->info_pinned, s->jac_prev, B, po);
+        // (something for the GPU to do while the host turns the poll around: the pressure preconditioner's factors for this 1/A)
+        if (a.diag == s->A && s->jac_prefactor) if (int rc = fg_fd_rowmean_prefactor(s, a.dt, st)) return rc;
         fg_htrace("jac_check_launched");
         const int rc = fg_poll_wait(&s->poll, po, 0, nsys, st);
         fg_htrace("jac_poll_done");

@@ -391,6 +391,18 @@ int fg_poisson_rbgs_launch(const fg_state* s, const fg_real* rA, const fg_real* 
 }
 
 // Host driver of the batched CG.  p is double-buffered: a.p is buffer 0, s->w[6] buffer 1.
+int fg_fd_rowmean_prefactor(fg_state* s, const fg_real* dt, hipStream_t st) {
+#if !FG_F64
+    if (!(s->fd_Qx && fg_fcg_ok(s) && fg_fd_rowmean_ok(s)) || s->fd_row_epoch == s->rA_epoch || dt == nullptr) return FG_OK;
+    const bool parts = s->fd_row_part && s->fd_row_part_epoch == s->rA_epoch;      // the assembly left the row sums
+    if (int rc = fg_fd_rowmean_factor(s, s->rA, dt, st, parts ? s->fd_row_part : nullptr, (s->grid.nx + 63) / 64)) return rc;
+    s->fd_row_epoch = s->rA_epoch;
+#else
+    (void)s; (void)dt; (void)st;
+#endif
+    return FG_OK;
+}
+
 int fg_cg_slots(const fg_state* s) {   // ~cg_wgs_per_slot workgroups per accumulator slot, power of two
     int tiles_per_env = 1;
     FG_DISPATCH(s, { tiles_per_env = fg_launch_geometry<DIMS, VEC>(s->grid).tiles; });
