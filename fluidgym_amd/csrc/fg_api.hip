@@ -147,6 +147,8 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipMemset(s->fcg_lazy, 0, sizeof(int32_t) * (size_t)g.B));
     s->fcg_check0_ran = 0; s->fcg_lazy_on = 0; s->fcg_lazy_z = nullptr; s->fcg_unstored = 0; s->fcg_first_polls = 0;
     { const char* e = getenv("FG_FCG_FIRST"); s->fcg_first = (e && atoi(e) == 0) ? 0 : 1; }
+    { const char* e = getenv("FG_FCG_SPEC"); s->fcg_spec = (e && atoi(e) == 0) ? 0 : 1; }
+    s->fcg_spec_fn = nullptr; s->fcg_spec_ctx = nullptr; s->fcg_spec_done = 0;
     { const char* e = getenv("FG_JAC_PREFACTOR"); s->jac_prefactor = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("FG_JAC_WARM"); s->jac_warm = e ? (atoi(e) != 0 ? 1 : 0) : -1; }      // (-1: where it pays, jac_warm_start)
     s->fcg_mean_ready = 0;
@@ -493,6 +495,16 @@ extern "C" int fg_setup_pressure_rhs(fg_handle s, const fg_real* dt_B, void* str
     return fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st);
 }
 
+// the corrector of fg_piso_step in its unstored-pressure form (FgLazyRef), launched by fg_cg_solve behind k_fcg_check0 (fg_state::fcg_spec_fn)
+struct SpecCorrect { fg_state* s; const fg_real* dt; bool last; hipStream_t st; };
+static int spec_correct(void* p) {
+    const SpecCorrect* c = static_cast<const SpecCorrect*>(p);
+    fg_state* s = c->s;
+    const FgMeanRef mean = {s->fcg_xsum, s->info_dev, s->pressure, s->fcg_lazy, s->fcg_alpha};
+    const FgLazyRef lazy = {s->fcg_lazy, s->fcg_alpha, c->last ? s->p_result : nullptr};
+    return fg_launch_correct(s, c->dt, s->rA, s->hvec, s->fcg_lazy_z, s->vel_result, c->st, c->last ? s->velocity : nullptr, c->last ? &mean : nullptr, &lazy);
+}
+
 static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real tol, int max_iterations, int use_previous,
                           fg_solve_info* info_host, hipStream_t st, bool finalize = true, int kind = 2) {
     int rc = FG_OK;
@@ -515,7 +527,7 @@ static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real to
             fg_solve_info* info = info_host;
             if (!info) { tmp.assign(s->info_pinned, s->info_pinned + s->grid.B); info = tmp.data(); }
             s->rung_count[2] += 1;
-            s->fcg_lazy_on = 0; s->fcg_check0_ran = 0; s->fcg_mean_ready = 0;      // (the repeat stores its result in p_result)
+            s->fcg_lazy_on = 0; s->fcg_check0_ran = 0; s->fcg_mean_ready = 0; s->fcg_spec_done = 0;      // (the repeat stores its result in p_result)
             rc = fg_rung64_cg(s, a, info, (s->ladder_force & 2) != 0, st);
         }
 #endif
@@ -673,10 +685,13 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         // The mean removal + block copy of the last corrector's pressure (setPressureResult, CopyPressureResultToBlocks: :1922-1925, 1953):
         // when the solver left sum(p) behind (fused CG, fg_fftcg.hip) the corrector does both where it reads p for the gradient --
         // pressureResult then keeps its constant, which nothing downstream sees (grad p; the next solve starts from zero or from it)
-        if (int rc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations,
-                                         opt->pressure_warm_start ? 1 : 0,
-                                         info.data(), st, false, c == 0 ? 0 : 1)))
-            return rc;
+        SpecCorrect spec_ctx = {s, dt_B, last, st};
+        s->fcg_spec_fn = spec_correct; s->fcg_spec_ctx = &spec_ctx;
+        const int prc = soft(solve_pressure(s, dt_B, opt->pressure_method, opt->pressure_tol, opt->max_iterations,
+                                            opt->pressure_warm_start ? 1 : 0,
+                                            info.data(), st, false, c == 0 ? 0 : 1));
+        s->fcg_spec_fn = nullptr; s->fcg_spec_ctx = nullptr;
+        if (prc) return prc;
         if (c < 2) { stats[2 + c] = max_iters(info.data(), B); s->ctr.add(2 + c, info.data(), B); }
         const bool mean_folded = last && s->fcg_mean_ready;
         if (last && !mean_folded)
@@ -688,6 +703,7 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         FG_REQUIRE(!s->fcg_lazy_on || lazy_p, FG_ERR_UNSUPPORTED, "fg_piso_step: an unmaterialised pressure without its folded mean");
         const FgLazyRef lazy = {s->fcg_lazy, s->fcg_alpha, last ? s->p_result : nullptr};
         // the last corrector also writes the block velocity of active envs: CopyVelocityResultToBlocks (:1974)
+        if (s->fcg_spec_done && lazy_p) continue;      // (this very launch already ran behind the verdict kernel: spec_correct)
         if (int rc = fg_launch_correct(s, dt_B, s->rA, s->hvec, lazy_p ? s->fcg_lazy_z : ((last && !mean_folded) ? s->pressure : s->p_result),
                                        s->vel_result, st, last ? s->velocity : nullptr, mean_folded ? &mean : nullptr, lazy_p ? &lazy : nullptr))
             return rc;
@@ -701,7 +717,7 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
 
 extern "C" int fg_config_dump(fg_handle s, char* buf, int n) {
     FG_REQUIRE(s && buf && n > 0, FG_ERR_INVALID_ARG, "fg_config_dump: bad argument");
-    char tmp[1536];
+    char tmp[3072];
     const int len = snprintf(tmp, sizeof(tmp),
         "{\"build\": \"%s\", \"FG_CG_FUSED\": %d, \"FG_BICG_PFUSED\": %d, \"FG_BICG_FUSED\": %d, \"FG_BICG_SUB\": %d, \"FG_BICG3\": %d, "
         "\"FG_BICG3_BXL\": %d, \"FG_BICG3_MIX\": %d, \"FG_REDUCE_WGS\": %d, \"FG_CG_WGS_PER_SLOT\": %d, \"FG_TRIDIAG_CB\": %d, \"FG_HELM_CB\": %d, "

@@ -689,6 +689,11 @@ struct fg_state {
     // fcg_lazy_on: that solve ended with EVERY env so (or stopped at its start vector) and wrote no x at all: the corrector reads
     // fcg_lazy_z scaled by fcg_alpha[2 b] instead (FgLazyRef).  fcg_first: 0 switches the whole scheme off (FG_FCG_FIRST=0).
     int32_t* fcg_lazy; mutable int fcg_check0_ran, fcg_lazy_on; mutable const fg_real* fcg_lazy_z; int fcg_first;
+    // The corrector launched BEHIND k_fcg_check0, before the host knows the verdict (fg_piso_step sets the hook): when every env ends on
+    // its first iterate -- the common case -- the corrector has then already run while the host turned the poll around
+    // (fcg_spec_done); otherwise its output is overwritten by the corrector that follows the finished solve (same inputs: it reads
+    // h, 1/A and z / x, writes the velocity result and, in the last corrector, the block fields nothing reads in between).
+    int (*fcg_spec_fn)(void*); void* fcg_spec_ctx; mutable int fcg_spec_done; int fcg_spec;      // fcg_spec: FG_FCG_SPEC (default 1)
     int jac_prefactor;      // FG_JAC_PREFACTOR (default 1): fg_fd_rowmean_prefactor behind the sweeps' check kernel
     int jac_warm;      // the Jacobi sweeps of the velocity systems start from the block velocity: 1 always, 0 never (the BiCGStab start vector), -1 (default) on the grids where that saves a pass (fg_jacobi.hip: jac_warm_start)
     mutable long fcg_unstored, fcg_first_polls;      // solves that stored no x | solves whose first iterate was polled (fg_config_dump)

@@ -449,7 +449,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
     FgCgJudge judge;
     judge.acc = s->cg_acc; judge.flags = s->flags; judge.info = s->info_dev; judge.tol = a.tol; judge.it = -1; judge.n = n; judge.ns = ns;
     s->fcg_mean_ready = 0;
-    s->fcg_check0_ran = 0; s->fcg_lazy_on = 0;
+    s->fcg_check0_ran = 0; s->fcg_lazy_on = 0; s->fcg_spec_done = 0;
 #if !FG_F64
     const bool fused = a.precond && s->fd_Qx && fg_fcg_ok(s);
 #else
@@ -506,6 +506,13 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             const FgPollOut po = poll0 ? fg_poll_next(&s->poll) : FgPollOut{nullptr, 0};
             if (poll0) fg_prof_prefetch(s, st);
             if (int rc = fg_fcg_check0(s, a.tol, ns, st, po)) return rc;
+            bool spec = false;
+            if (poll0 && s->fcg_spec && s->fcg_spec_fn && a.lazy_ok && r0 && mean_sums) {
+                // the corrector in its unstored-pressure form, behind the verdict kernel: it runs while the host waits (fg_internal.h)
+                s->fcg_lazy_z = v.z;
+                if (int rc = s->fcg_spec_fn(s->fcg_spec_ctx)) return rc;
+                spec = true;
+            }
             if (poll0) {
                 fg_htrace("cg_check_launched");
                 if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
@@ -519,7 +526,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 }
                 if (all) {
                     if (a.lazy_ok && r0 && all_ok && mean_sums) {
-                        s->fcg_lazy_on = 1; s->fcg_lazy_z = v.z; s->fcg_unstored += 1;
+                        s->fcg_lazy_on = 1; s->fcg_lazy_z = v.z; s->fcg_unstored += 1; s->fcg_spec_done = spec ? 1 : 0;
                     } else {
                         if (int rc = fg_fcg_update_fwd(s, v, 0, 1, ns, st, r0)) return rc;      // (every env takes the short path)
                     }
