@@ -28,5 +28,7 @@ c = solver.solver_counters()
 print(json.dumps({"env": env_id, "envs": B, "env_steps": steps, "resets": resets, "finite": finite, "seconds": round(time.time() - t0, 1),
                   "jacobi": solver.advection_jacobi_counts(),
                   "velocity": {k: c["velocity"][k] for k in ("mean", "max", "unconverged", "systems")},
-                  "pressure_unconverged": [c[k]["unconverged"] for k in ("pressure0", "pressure1")]}))
+                  "pressure_unconverged": [c[k]["unconverged"] for k in ("pressure0", "pressure1")],
+                  "pressure_mean_iterations": [c[k]["mean"] for k in ("pressure0", "pressure1")],
+                  "first_iterate": ({k: solver.config_dump().get(k) for k in ("first_iterate_polls", "unstored_pressure_solves")} if hasattr(solver, "config_dump") else None)}))
 env.close()
