@@ -301,3 +301,40 @@ def test_piso_step_that_never_stores_its_pressure(monkeypatch):
         assert scale > 0 and float((p1 - p0).abs().max()) <= 2e-6 * scale
         for b in (0, 2, 3):
             assert abs(float(p1[b].double().mean())) < 1e-5 * float(p1[b].abs().max())
+
+
+def test_corrector_launched_behind_the_verdict_kernel_changes_no_bit(monkeypatch):
+    """FG_FCG_SPEC: the corrector in its unstored-pressure form is launched behind k_fcg_check0, before the host has seen the verdict;
+    when an env turns out to iterate on, the corrector that follows the finished solve overwrites what it wrote.  Tolerances on both
+    sides of the envs' first residuals (every solve ends on the first iterate / some envs go on / the start vector already does):
+    velocity, block pressure and pressureResult bit for bit against FG_FCG_SPEC=0, a masked env untouched."""
+    import fluidgym_amd._lib as L
+    case = _channel_case((128, 36), B=4)
+    dt = [0.02, 0.0, 0.03, 0.02]
+    ns = case.native()
+    ok, _ = ns.piso_step(dt, corrector_steps=1, advection_tol=1e-7, pressure_tol=1e-7)
+    div = ns.buffer(L.FG_BUF_DIV, (case.B,) + case.shape)
+    rms = min(float(div[b].double().pow(2).mean().sqrt()) for b in (0, 2, 3))
+    ns.close()
+    for mult in (0.5, 0.05, 0.005, 5.0):
+        res = {}
+        for spec in ("1", "0"):
+            monkeypatch.setenv("FG_FCG_SPEC", spec)
+            ns = case.native()
+            v0 = ns.velocity.clone()
+            its = []
+            for _ in range(3):
+                ok, stats = ns.piso_step(dt, advection_tol=1e-7, pressure_tol=mult * rms)
+                assert ok, stats
+                its.append(tuple(stats))
+            torch.cuda.synchronize()
+            res[spec] = (ns.velocity.clone(), ns.pressure.clone(), ns.buffer(L.FG_BUF_P_RESULT, (case.B,) + case.shape).clone(), its,
+                         ns.config_dump()["unstored_pressure_solves"])
+            assert torch.equal(ns.velocity[1], v0[1])
+            ns.close()
+        a, b = res["1"], res["0"]
+        assert a[3] == b[3] and a[4] == b[4], (mult, a[3], b[3], a[4], b[4])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), mult
+        for e in (0, 2, 3):
+            assert torch.equal(a[2][e], b[2][e]), (mult, e)
+        print("SPEC", mult, "iterations", a[3], "unstored solves", a[4])
