@@ -147,6 +147,8 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipMemset(s->fcg_lazy, 0, sizeof(int32_t) * (size_t)g.B));
     s->fcg_check0_ran = 0; s->fcg_lazy_on = 0; s->fcg_lazy_z = nullptr; s->fcg_unstored = 0; s->fcg_first_polls = 0;
     { const char* e = getenv("FG_FCG_FIRST"); s->fcg_first = (e && atoi(e) == 0) ? 0 : 1; }
+    { const char* e = getenv("FG_JAC_SPEC"); s->jac_spec = (e && atoi(e) == 0) ? 0 : 1; }
+    s->jac_spec_fn = nullptr; s->jac_spec_ctx = nullptr; s->jac_spec_done = 0; s->jac_spec_missed = 0;
     { const char* e = getenv("FG_FCG_SPEC"); s->fcg_spec = (e && atoi(e) == 0) ? 0 : 1; }
     s->fcg_spec_fn = nullptr; s->fcg_spec_ctx = nullptr; s->fcg_spec_done = 0;
     { const char* e = getenv("FG_JAC_PREFACTOR"); s->jac_prefactor = (e && atoi(e) == 0) ? 0 : 1; }
@@ -495,6 +497,16 @@ extern "C" int fg_setup_pressure_rhs(fg_handle s, const fg_real* dt_B, void* str
     return fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st);
 }
 
+// k_h and the divergence kernel of corrector 0, launched by fg_jacobi_solve behind its check kernel (fg_state::jac_spec_fn)
+struct SpecH { fg_state* s; const fg_real* dt; const fg_step_options* opt; hipStream_t st; };
+static int spec_h(void* p) {
+    const SpecH* c = static_cast<const SpecH*>(p);
+    fg_state* s = c->s;
+    if (int rc = fg_launch_h(s, c->dt, s->vel_result, c->st)) return rc;
+    return fg_launch_div(s, make_bounds(s, 0), c->dt, s->hvec, s->div, c->st, !c->opt->pressure_warm_start,
+                         c->opt->pressure_method == FG_SOLVER_FDCG && s->fd_Qx != nullptr);
+}
+
 // the corrector of fg_piso_step in its unstored-pressure form (FgLazyRef), launched by fg_cg_solve behind k_fcg_check0 (fg_state::fcg_spec_fn)
 struct SpecCorrect { fg_state* s; const fg_real* dt; bool last; hipStream_t st; };
 static int spec_correct(void* p) {
@@ -671,17 +683,25 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         FgBicgArgs a;
         a.diag = s->A; a.off = s->Coff; a.rhs = s->adv_rhs; a.x = s->vel_result; a.nc = d;
         a.dt = dt_B; a.tol = opt->advection_tol; a.max_iterations = opt->max_iterations; a.use_x0 = s->adv_from_result;
-        if (int rc = soft(advection_solve(s, a, info.data(), st))) return rc;
+        SpecH spec_h_ctx = {s, dt_B, opt, st};
+        s->jac_spec_done = 0;
+        if (opt->corrector_steps > 0) { s->jac_spec_fn = spec_h; s->jac_spec_ctx = &spec_h_ctx; }
+        const int arc = soft(advection_solve(s, a, info.data(), st));
+        s->jac_spec_fn = nullptr; s->jac_spec_ctx = nullptr;
+        if (arc) return arc;
         stats[1] = max_iters(info.data(), B * d);
         s->ctr.add(1, info.data(), B * d);
     }
     // ---- correctors (:1777-1972); rA = 1/A was written by the velocity fg_setup_advection above
     for (int c = 0; c < opt->corrector_steps; ++c) {
         const bool last = (c + 1 == opt->corrector_steps);
-        if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
-        if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st, !opt->pressure_warm_start,
-                                   opt->pressure_method == FG_SOLVER_FDCG && s->fd_Qx != nullptr))
-            return rc;
+        if (!(c == 0 && s->jac_spec_done)) {      // (corrector 0: these two may already run behind the sweeps' check kernel, spec_h)
+            if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
+            if (int rc = fg_launch_div(s, make_bounds(s, 0), dt_B, s->hvec, s->div, st, !opt->pressure_warm_start,
+                                       opt->pressure_method == FG_SOLVER_FDCG && s->fd_Qx != nullptr))
+                return rc;
+        }
+        s->jac_spec_done = 0;
         // The mean removal + block copy of the last corrector's pressure (setPressureResult, CopyPressureResultToBlocks: :1922-1925, 1953):
         // when the solver left sum(p) behind (fused CG, fg_fftcg.hip) the corrector does both where it reads p for the gradient --
         // pressureResult then keeps its constant, which nothing downstream sees (grad p; the next solve starts from zero or from it)
@@ -723,11 +743,11 @@ extern "C" int fg_config_dump(fg_handle s, char* buf, int n) {
         "\"FG_BICG3_BXL\": %d, \"FG_BICG3_MIX\": %d, \"FG_REDUCE_WGS\": %d, \"FG_CG_WGS_PER_SLOT\": %d, \"FG_TRIDIAG_CB\": %d, \"FG_HELM_CB\": %d, "
         "\"FG_HELM_ROWFORM\": %d, \"FG_FD_ROWMEAN\": %d, \"FG_POLL_SPIN\": %d, \"FG_PROF_PERIOD\": %d, \"fast_transform_x\": %d, \"fd_preconditioner\": %d, "
         "\"helmholtz\": %d, \"advection_preconditioner\": %d, \"advection_from_result\": %d, \"return_best\": %d, \"cg_reset_steps\": %d, "
-        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d, \"FG_FCG_FIRST\": %d, \"FG_JAC_WARM\": %d, \"first_iterate_polls\": %ld, \"unstored_pressure_solves\": %ld}",
+        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d, \"FG_FCG_FIRST\": %d, \"FG_JAC_WARM\": %d, \"first_iterate_polls\": %ld, \"unstored_pressure_solves\": %ld, \"FG_JAC_SPEC\": %d, \"FG_FCG_SPEC\": %d, \"jacobi_speculation_misses\": %ld}",
         FG_F64 ? "f64" : "f32", s->cg_fused, s->bicg_pfused, s->bicg_fused, s->bicg_sub, s->bicg3_force, s->bicg3_bxl, s->bicg3_mix, s->reduce_wgs,
         s->cg_wgs_per_slot, s->tridiag_cb, s->helm_cb_pref, s->helm_rowform_off ? 0 : 1, s->fd_rowmean, s->poll.spin, s->prof.period, s->fd_dct_x, s->fd_Qx ? 1 : 0,
         s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis, s->adv_jacobi, s->fcg_first, s->jac_warm,
-        s->fcg_first_polls, s->fcg_unstored);
+        s->fcg_first_polls, s->fcg_unstored, s->jac_spec, s->fcg_spec, s->jac_spec_missed);
     if (len >= n) return len + 1;
     memcpy(buf, tmp, (size_t)len + 1);
     return FG_OK;

@@ -679,6 +679,16 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
             hipLaunchKernelGGL(k_bicg_begin, dim3((nsys + 63) / 64), dim3(64), 0, st, a.dt, s->acc, s->scratch_B + 4 * s->grid.B, s->flags, s->info_dev, nsys, a.nc);
         int outcome = 0;
         if (int rc = fg_jacobi_solve(s, a, info_host, st, &outcome)) return rc;
+        if (outcome == 5) {      // (kernels launched behind the check on speculation overwrote the solve's state: the solve again, without them)
+            s->jac_spec_missed += 1;
+            int (*const fn)(void*) = s->jac_spec_fn;
+            s->jac_spec_fn = nullptr;
+            hipLaunchKernelGGL(k_bicg_begin, dim3((nsys + 63) / 64), dim3(64), 0, st, a.dt, s->acc, s->scratch_B + 4 * s->grid.B, s->flags, s->info_dev, nsys, a.nc);
+            outcome = 0;
+            const int rc = fg_jacobi_solve(s, a, info_host, st, &outcome);
+            s->jac_spec_fn = fn;
+            if (rc) return rc;
+        }
         if (outcome == 1) { s->jac_solves += 1; return FG_OK; }
         if (outcome == 0) return bicgstab_krylov(s, a, info_host, st, true);   // (not tried: the prepared state is untouched)
         s->jac_fallbacks += 1;

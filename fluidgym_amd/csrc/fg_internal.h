@@ -694,6 +694,12 @@ struct fg_state {
     // (fcg_spec_done); otherwise its output is overwritten by the corrector that follows the finished solve (same inputs: it reads
     // h, 1/A and z / x, writes the velocity result and, in the last corrector, the block fields nothing reads in between).
     int (*fcg_spec_fn)(void*); void* fcg_spec_ctx; mutable int fcg_spec_done; int fcg_spec;      // fcg_spec: FG_FCG_SPEC (default 1)
+    // The first kernels of the corrector -- k_h, the divergence kernel -- launched BEHIND the sweeps' check kernel, before the host
+    // knows the verdict (fg_piso_step sets the hook; on-chip form, one planned pass writing the result vector): they read what the
+    // sweeps left and write h, the right-hand side and the CG's start, so the velocity solve's own device state (flags, sums) is gone
+    // once they ran -- a verdict that does not end the solve there (never seen: profiles/r05_jacobi_soak.jsonl) sends the whole solve
+    // round again without the speculation (outcome 5 of fg_jacobi_solve, jac_spec_missed).  FG_JAC_SPEC=0 switches it off.
+    int (*jac_spec_fn)(void*); void* jac_spec_ctx; mutable int jac_spec_done; int jac_spec; long jac_spec_missed;
     int jac_prefactor;      // FG_JAC_PREFACTOR (default 1): fg_fd_rowmean_prefactor behind the sweeps' check kernel
     int jac_warm;      // the Jacobi sweeps of the velocity systems start from the block velocity: 1 always, 0 never (the BiCGStab start vector), -1 (default) on the grids where that saves a pass (fg_jacobi.hip: jac_warm_start)
     mutable long fcg_unstored, fcg_first_polls;      // solves that stored no x | solves whose first iterate was polled (fg_config_dump)

@@ -569,6 +569,7 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
         }
         return FG_OK;
     };
+    bool spec = false, spec_tried = false;
     auto check = [&]() -> int {
         fg_prof_prefetch(s, st);
         const FgPollOut po = fg_poll_next(&s->poll);
@@ -576,6 +577,12 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
         hipLaunchKernelGGL(k_jac_check, dim3((B + 63) / 64), dim3(64), 0, st, q, s->info_pinned, s->jac_prev, B, po);
         // (something for the GPU to do while the host turns the poll around: the pressure preconditioner's factors for this 1/A)
         if (a.diag == s->A && s->jac_prefactor) if (int rc = fg_fd_rowmean_prefactor(s, a.dt, st)) return rc;
+        // (and the corrector's first kernels, when this check is expected to end the solve with the iterate in the result vector)
+        if (!spec_tried && s->jac_spec && s->jac_spec_fn && P == 1 && passes == 1 && last_parity == 0 && a.diag == s->A) {
+            if (int rc = s->jac_spec_fn(s->jac_spec_ctx)) return rc;
+            spec = true;
+        }
+        spec_tried = true;
         fg_htrace("jac_check_launched");
         const int rc = fg_poll_wait(&s->poll, po, 0, nsys, st);
         fg_htrace("jac_poll_done");
@@ -606,6 +613,11 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
             }
         }
         if (all && !failed) { ok = true; break; }
+        if (spec) {      // the speculated kernels ran on an iterate that is not the result and reset this solve's device state: once more, without
+            if (int prc = fg_prof_collect(s, st)) return prc;
+            *outcome = 5;
+            return FG_OK;
+        }
         if (failed) break;
         int more = (int)ceil(need);
         if (more < 1) more = 1;
@@ -625,6 +637,10 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     for (int b = 0; b < B; ++b) {
         const int used = s->info_pinned[2 * b].used_iterations + 1;
         if (used > 0) { settle |= (((used / S - 1) & 1) != last_parity) ? 1 : 0; used_max = used > used_max ? used : used_max; }
+    }
+    if (spec) {
+        if (settle) { fg_set_error("fg_jacobi_solve: speculated corrector kernels with an iterate outside the result vector"); return FG_ERR_HIP; }
+        s->jac_spec_done = 1;
     }
     if (settle)
         hipLaunchKernelGGL(k_jac_settle, dim3(32, B), dim3(256), 0, st, (const float*)work, a.x, (const fg_solve_info*)s->info_dev, S, last_parity, 2 * n);

@@ -32,6 +32,7 @@ NOTES = {
     "FG_JAC_WARM": ("bits", "start vector of the Jacobi sweeps of a step's velocity systems: 1 the block velocity, 0 the BiCGStab start vector (zero on the non-orthogonal branch); unset: the block velocity on on-chip grids of 2^17 cells and more (where it saves a pass)"),
     "FG_JAC_PREFACTOR": ("no", "0: the row-mean factors of the pressure preconditioner are made in front of the first tridiagonal solve instead of behind the sweeps' check kernel (A/B runs)"),
     "FG_FCG_SPEC": ("no", "0: the corrector waits for the verdict on the first iterate instead of being launched behind the verdict kernel (A/B runs)"),
+    "FG_JAC_SPEC": ("no", "0: k_h and the divergence kernel of the first corrector wait for the verdict on the velocity sweeps instead of being launched behind the check kernel (A/B runs)"),
     "FG_JAC_XCD": ("no", "0: the on-chip Jacobi regions in launch order instead of one XCD per run of an env's regions (A/B runs)"),
     "FG_JAC_SHAPE": ("bits", "A/B runs of the Jacobi sweeps: 1 full-row regions only, 2 bands only (unset: the cheaper of the two for the grid)"),
     "FG_JAC_SWEEPS": ("bits", "A/B runs: sweeps per pass of the Jacobi sweeps (unset: 4 / 6 / 8 for full rows, 8 / 12 for bands, by region depth)"),

@@ -287,3 +287,40 @@ def test_sweeps_started_from_the_block_velocity(n, monkeypatch):
                 assert info[dims * b + c][2] and res < 2.5 * tol, (warm, b, c, res, tol)
     assert rel_err(out["1"][0][[0, 2]], out["0"][0][[0, 2]]) < 1e-5
     print("JACOBI warm / cold sweeps:", [i[0] for i in out["1"][1]], [i[0] for i in out["0"][1]])
+
+
+def test_corrector_kernels_launched_behind_the_sweeps_check(monkeypatch):
+    """FG_JAC_SPEC: when the sweeps are expected to end after their one planned pass, k_h and the divergence kernel of the first
+    corrector are launched behind the check kernel, before the host has the verdict.  A step whose velocity systems then need a
+    SECOND pass (the tolerance is tightened after the handle has learnt "one pass") is a miss: the solve runs again without the
+    speculation.  Hit or miss, every field is the one of FG_JAC_SPEC=0, bit for bit."""
+    import fluidgym_amd._lib as L
+    h = 1.0 / 128
+    case = make_case(dims=2, n=(256, 128), fixed_axes=(0, 1), B=3, seed=8, stretch=0.0, nu=0.25 * h, vel_scale=0.5, with_source=True, through_flow_axis=0)
+    w = np.full(256, np.float32(2.0 / 256), np.float32)
+    case.widths[0] = w
+    case.edges[0] = np.concatenate([[0.0], np.cumsum(w.astype(np.float64))])
+    dt = [0.2 * h, 0.0, 0.3 * h]
+    res = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("FG_JAC_SPEC", spec)
+        ns = case.native()
+        ns.set_advection_jacobi(True)
+        ns.set_advection_start(False)      # (the channel envs' start: zero, so that the one planned pass writes the result vector)
+        v0 = ns.velocity.clone()
+        its = []
+        for tol in (1e-2, 1e-2, 1e-2, 1e-6, 1e-6, 1e-2):      # loose: one pass of sweeps; tight: more than one
+            ok, stats = ns.piso_step(dt, advection_tol=tol, pressure_tol=1e-6)
+            assert ok, stats
+            its.append(stats[1])
+        torch.cuda.synchronize()
+        cfg = ns.config_dump()
+        res[spec] = (ns.velocity.clone(), ns.pressure.clone(), its, cfg["jacobi_speculation_misses"], ns.advection_jacobi_counts())
+        assert torch.equal(ns.velocity[1], v0[1])
+        ns.close()
+    a, b = res["1"], res["0"]
+    print("JACSPEC sweeps", a[2], "misses", a[3], a[4])
+    assert a[2] == b[2] and a[4] == b[4] and b[3] == 0
+    assert a[3] >= 1, a      # (the step that tightened the tolerance)
+    assert max(a[2]) > min(a[2])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
