@@ -87,7 +87,10 @@ benchmark line can say which mode it ran in:
     (TCF: 8 sweeps, contraction 0.03 per sweep at CFL 0.1).
     Multi-block path: the same sweeps over the neighbour table, one launch per sweep (``mb_jacobi``, ``csrc/fg_mb_krylov.hip``): the
     cylinder meshes take 12-16 sweeps where BiCGStab took 5-6 iterations of three launches; the airfoil meshes contract by 0.8 per
-    sweep, which the first check sees -- BiCGStab takes over from the sweeps' iterate and the handle backs off.
+    sweep, which the first check sees -- BiCGStab takes over (from the sweeps' iterate while that is well above the tolerance, from
+    zero otherwise) and the handle backs off.
+    Start vector of the sweeps: zero, like the BiCGStab they stand in for, except on on-chip grids of 2^17 cells and more (512 x 256),
+    where the first pass reads the block velocity -- 16.6 sweeps instead of 24 (``FG_JAC_WARM``, docs/SWITCHES.md).
 
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` / ``FLUIDGYM_AMD_ADVECTION_WARM_START`` /
 ``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
