@@ -697,7 +697,7 @@ struct fg_state {
     // The first kernels of the corrector -- k_h, the divergence kernel -- launched BEHIND the sweeps' check kernel, before the host
     // knows the verdict (fg_piso_step sets the hook; on-chip form, one planned pass writing the result vector): they read what the
     // sweeps left and write h, the right-hand side and the CG's start, so the velocity solve's own device state (flags, sums) is gone
-    // once they ran -- a verdict that does not end the solve there (never seen: profiles/r05_jacobi_soak.jsonl) sends the whole solve
+    // once they ran -- a verdict that does not end the solve there (0.6 % of the soak's solves: profiles/r05_soak_first_iterate.jsonl) sends the whole solve
     // round again without the speculation (outcome 5 of fg_jacobi_solve, jac_spec_missed).  FG_JAC_SPEC=0 switches it off.
     int (*jac_spec_fn)(void*); void* jac_spec_ctx; mutable int jac_spec_done; int jac_spec; long jac_spec_missed;
     int jac_prefactor;      // FG_JAC_PREFACTOR (default 1): fg_fd_rowmean_prefactor behind the sweeps' check kernel

@@ -30,5 +30,5 @@ print(json.dumps({"env": env_id, "envs": B, "env_steps": steps, "resets": resets
                   "velocity": {k: c["velocity"][k] for k in ("mean", "max", "unconverged", "systems")},
                   "pressure_unconverged": [c[k]["unconverged"] for k in ("pressure0", "pressure1")],
                   "pressure_mean_iterations": [c[k]["mean"] for k in ("pressure0", "pressure1")],
-                  "first_iterate": ({k: solver.config_dump().get(k) for k in ("first_iterate_polls", "unstored_pressure_solves")} if hasattr(solver, "config_dump") else None)}))
+                  "first_iterate": ({k: solver.config_dump().get(k) for k in ("first_iterate_polls", "unstored_pressure_solves", "jacobi_speculation_misses")} if hasattr(solver, "config_dump") else None)}))
 env.close()
