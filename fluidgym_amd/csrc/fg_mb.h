@@ -36,6 +36,8 @@ __host__ __device__ __forceinline__ mb_real mb_fmin(mb_real a, mb_real b) { retu
 __device__ __forceinline__ mb_real mb_rsqrt(mb_real x) { return FG_MB_F64 ? (mb_real)rsqrt((double)x) : (mb_real)rsqrtf((float)x); }
 __host__ __device__ __forceinline__ mb_real mb_sqrt(mb_real x) { return FG_MB_F64 ? (mb_real)sqrt((double)x) : (mb_real)sqrtf((float)x); }
 
+#define FG_CL_G 4   // workgroups per cluster of the cluster CG (fg_mb_cluster.hip)
+
 #define FG_MB_FIXED 0
 #define FG_MB_CONNECTED 1
 #define FG_MB_PERIODIC 2
@@ -163,6 +165,25 @@ struct fg_mb_state {
     int oc_variant = 0;        // FG_MB_OC_VARIANT (tuning switches of the on-chip CG)
     unsigned long long* oc_dbg = nullptr;   // per-phase cycle counts (fg_mb_debug_cycles)
     int onchip_mode = 1;       // FG_MB_ONCHIP: 0 never, 1 when the mesh fits one workgroup's LDS / registers (default)
+    // cluster CG (fg_mb_cluster.hip, round 6): FG_CL_G workgroups per env, each owning a contiguous range of the 8 x 8 aggregates;
+    // slot s of workgroup g = thread + NT * member.  Tables built by mb_cluster_build behind fg_mb_set_multilevel
+    int cl_mode = 1;           // FG_MB_CLUSTER: 0 never, 1 meshes beyond 8 k cells (default), 2 every mesh the tables fit
+    int cl_force_cpt = 0;      // FG_MB_CL_CPT=4: four members per thread in 1024 threads where the mesh allows it (default: eight in 512; A/B runs)
+    int cl_near = 1;           // FG_MB_CL_NEAR=0: granule stores always write through (sc1), also when a cluster's workgroups share an XCD
+    int cl_max_clusters = 0;   // FG_MB_CL_MAXCL: cap on the clusters of a launch (tests: envs beyond it queue inside the kernel)
+    bool cl_on = false;        // tables installed
+    bool cl_matrix_stale = true;   // no k_mb_pmatrix launch has written the cluster-ordered matrix since
+    int cl_cpt = 0, cl_nt = 0, cl_S = 0, cl_W = 0, cl_n8g_max = 0, cl_n_out_max = 0, cl_n_halo_max = 0, cl_cus = 0;
+    int cl_first[FG_CL_G + 1] = {0}, cl_n_out[FG_CL_G] = {0}, cl_n_halo[FG_CL_G] = {0};
+    int32_t *cl_slot_cell = nullptr, *cl_out_slot = nullptr;
+    uint16_t* cl_cell_slot = nullptr;     // [N] g * S + slot
+    uint2* cl_nbr = nullptr;
+    uint32_t *cl_tinfo = nullptr, *cl_halo_src = nullptr, *cl_epoch = nullptr, *cl_abort = nullptr;
+    mb_real *cl_d4g = nullptr, *cl_cnt8 = nullptr, *cl_aci8 = nullptr, *cl_off4 = nullptr, *cl_diag = nullptr, *cl_bestx = nullptr;
+    unsigned long long* cl_box = nullptr;
+    uint16_t* cl_aci16 = nullptr; mb_real cl_aci16_unscale = 1.f;   // the coarse inverse as fp16 behind a power-of-two scale (meshes whose fp32 rows do not fit LDS)
+    int cl_half = 1;           // FG_MB_CL_HALF=0: such meshes stream the fp32 rows from L2 instead
+    long long cl_solves = 0, cl_fallbacks = 0;   // launches that solved / that a workgroup gave up on (repeated by the one-workgroup kernels)
     double* x64_best = nullptr; mb_real* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
     double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2)
     // debug switches, read ONCE from the environment at fg_mb_create (never on the step path): FG_MB_BICG_VEC4 (per-kernel mask

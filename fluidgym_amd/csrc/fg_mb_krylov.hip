@@ -1846,6 +1846,11 @@ int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real*
     const int nsys = s->B, n = s->N;
     {
         const int pm = project_mean ? (s->yproj_const ? 1 : 2) : 0;
+        if (mb_cluster_ok(s, pm, diag, off)) {
+            bool fell_back = false;
+            const int rc = mb_cg_cluster(s, dt, rhs, x, tol, max_iterations, use_x0, pm, stall_accept, max_it, st, &fell_back);
+            if (!fell_back) return rc;
+        }
         if (mb_onchip_ok(s, pm)) return mb_cg_onchip(s, dt, diag, off, rhs, x, tol, max_iterations, use_x0, pm, stall_accept, max_it, st);
     }
     MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 1, tol);

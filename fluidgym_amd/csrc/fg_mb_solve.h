@@ -139,6 +139,12 @@ int mb_finish(fg_mb_state* s, int nsys, fg_solve_info* info_host, int* max_it);
 bool mb_onchip_ok(const fg_mb_state* s, int pm_mode);
 int mb_cg_onchip(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, mb_real tol,
                  int max_iterations, int use_x0, int pm_mode, mb_real stall_accept, int* max_it, hipStream_t st);
+// fg_mb_cluster.hip: the same solve by a cluster of workgroups per env (k_mbc_cluster); tables built behind fg_mb_set_multilevel
+int mb_cluster_build(fg_mb_state* s, int n4, int n8, const int32_t* rect4_host, const uint16_t* parent4, const uint2* child8, const mb_real* rd4,
+                     const mb_real* aci8_padded);
+bool mb_cluster_ok(const fg_mb_state* s, int pm_mode, const mb_real* diag, const mb_real* off);
+int mb_cg_cluster(fg_mb_state* s, const mb_real* dt, const mb_real* rhs, mb_real* x, mb_real tol, int max_iterations, int use_x0, int pm_mode,
+                  mb_real stall_accept, int* max_it, hipStream_t st, bool* fell_back);
 constexpr int ML_N8_MAX = 2048, ML_ROWS = 16, ML_CG = 64;   // multilevel coarse solve: rows per workgroup, column groups
 void mb_ml_scale(fg_mb_state* s, const mb_real* diag, hipStream_t st);
 bool mb_ilu_prepare(fg_mb_state* s);

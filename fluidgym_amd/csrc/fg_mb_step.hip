@@ -152,7 +152,8 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const mb_real* __restrict__ dt, const mb_real* __restrict__ rA,
                                                           mb_real* __restrict__ Pdiag, mb_real* __restrict__ Poff,
                                                           mb_real* __restrict__ Poff4, const uint16_t* __restrict__ cell_slot = nullptr,
-                                                          mb_real* __restrict__ Poff4s = nullptr, mb_real* __restrict__ Pdiag_s = nullptr) {
+                                                          mb_real* __restrict__ Poff4s = nullptr, mb_real* __restrict__ Pdiag_s = nullptr,
+                                                          int slot_stride = fg_mb_state::OC_SLOTS) {
     MB_CELL
     if (!valid || !mb_active(dt, b)) return;
     constexpr int F = 2 * DIMS;
@@ -182,13 +183,29 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mb_pmatrix(MbDev D, const mb_real*
     }
     // the same off-diagonals once more, interleaved per cell: the on-chip CG fetches a cell's four with one 16-byte load
     if (DIMS == 2 && Poff4) *reinterpret_cast<float4*>(Poff4 + ((size_t)b * N + i) * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-    // ... and in the slot order of the aggregate-owned on-chip CG (fg_mb.h: OC_SLOTS), diagonal included
+    // ... and in the slot order of the aggregate-owned on-chip CG (fg_mb.h: OC_SLOTS) or of the cluster CG (fg_mb_cluster.hip),
+    // diagonal included
     if (DIMS == 2 && cell_slot) {
-        const size_t sl = (size_t)b * fg_mb_state::OC_SLOTS + cell_slot[i];
+        const size_t sl = (size_t)b * slot_stride + cell_slot[i];
         *reinterpret_cast<float4*>(Poff4s + sl * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
         Pdiag_s[sl] = dv;
     }
 }
+
+// which slot-ordered copy of the pressure matrix k_mb_pmatrix writes beside the cell-ordered one: the cluster CG's (when its
+// tables are installed and the mesh is one it takes), else the aggregate-owned on-chip CG's, else none
+struct MbSlots { const uint16_t* cell_slot; mb_real* off4; mb_real* diag; int stride; };
+static bool mb_cluster_wanted(const fg_mb_state* s) { return s->cl_on && (s->cl_mode == 2 || s->N > 8 * 1024); }
+static MbSlots mb_slots(const fg_mb_state* s) {
+    if (mb_cluster_wanted(s)) return MbSlots{s->cl_cell_slot, s->cl_off4, s->cl_diag, FG_CL_G * s->cl_S};
+    if (s->oc_agg) return MbSlots{s->oc_cell_slot, s->Poff4s, s->Pdiag_s, fg_mb_state::OC_SLOTS};
+    return MbSlots{nullptr, nullptr, nullptr, 0};
+}
+static void mb_slots_written(fg_mb_state* s) {
+    if (mb_cluster_wanted(s)) s->cl_matrix_stale = false;
+    else s->oc_matrix_stale = false;
+}
+#define SLOTS mb_slots(s)
 
 // h = (u_old/dt - H u* + S) / A   (PISO_build_pressure_rhs): grid.z = component
 template <int DIMS>
@@ -468,13 +485,18 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_AGG"); s->dbg_oc_agg = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_CL_CPT"); s->cl_force_cpt = e ? atoi(e) : 0;
+        e = getenv("FG_MB_CL_HALF"); s->cl_half = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_CL_NEAR"); s->cl_near = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("FG_MB_CL_MAXCL"); s->cl_max_clusters = e ? atoi(e) : 0;
+        e = getenv("FG_MB_CLUSTER"); s->cl_mode = e ? atoi(e) : 1;   // 0 never, 1 meshes beyond 8 k cells (default), 2 every mesh its tables fit
         e = getenv("FG_MB_RUNG_ILU"); s->dbg_rung_ilu = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_VARIANT"); s->oc_variant = e ? atoi(e) : 0;   // bit 0: no compiler fences in the stencil pass; bit 1: split [F][N] coefficient layout
     }
 #if FG_MB_F64
     // the fp64 build runs the one-cell-per-thread kernels: the four-cell forms (float4), the on-chip CG and the multilevel
     // preconditioner are written for 32-bit words (fg_mb.h)
-    s->dbg_vec_mask = 0; s->dbg_scalar_cg = 1; s->onchip_mode = 0; s->dbg_oc_agg = 0;
+    s->dbg_vec_mask = 0; s->dbg_scalar_cg = 1; s->onchip_mode = 0; s->dbg_oc_agg = 0; s->cl_mode = 0;
 #endif
     *out = s;
     return FG_OK;
@@ -482,14 +504,16 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
 
 extern "C" int fg_mb_config_dump(fg_mb_handle s, char* buf, int n) {
     FG_REQUIRE(s && buf && n > 0, FG_ERR_INVALID_ARG, "fg_mb_config_dump: bad argument");
-    char tmp[1024];
+    char tmp[2048];
     const int len = snprintf(tmp, sizeof(tmp),
         "{\"FG_MB_BICG_VEC4\": %d, \"FG_MB_SCALAR_CG\": %d, \"FG_MB_BICG_FUSE\": %d, \"FG_MB_PRED\": %d, \"FG_MB_ML_FUSE\": %d, \"FG_MB_ML_SB\": %d, "
         "\"FG_MB_ML_TRY_CAP\": %d, \"FG_MB_ML_WARMUP\": %d, \"FG_MB_GRAPH\": %d, \"FG_MB_TRACE\": %d, \"FG_MB_COMPACT\": %d, \"FG_MB_OC_RTG_NT\": %d, "
-        "\"FG_MB_ONCHIP\": %d, \"FG_MB_OC_AGG\": %d, \"FG_MB_RUNG_ILU\": %d, \"FG_MB_OC_VARIANT\": %d}",
+        "\"FG_MB_ONCHIP\": %d, \"FG_MB_OC_AGG\": %d, \"FG_MB_RUNG_ILU\": %d, \"FG_MB_OC_VARIANT\": %d, \"FG_MB_CLUSTER\": %d, "
+        "\"cluster_on\": %d, \"cluster_members_per_thread\": %d, \"cluster_threads\": %d, \"cluster_halo_max\": %d, \"cluster_solves\": %lld, \"cluster_fallbacks\": %lld}",
         (int)s->dbg_vec_mask, (int)s->dbg_scalar_cg, (int)s->dbg_fuse_st, (int)s->dbg_pred, (int)s->dbg_ml_fuse, (int)s->dbg_ml_sb, (int)s->dbg_ml_cap,
         (int)s->dbg_ml_warmup, (int)s->dbg_graph, (int)s->dbg_trace, (int)s->dbg_compact, (int)s->oc_rtg_nt, (int)s->onchip_mode, (int)s->dbg_oc_agg,
-        (int)s->dbg_rung_ilu, (int)s->oc_variant);
+        (int)s->dbg_rung_ilu, (int)s->oc_variant, (int)s->cl_mode, (int)(mb_cluster_wanted(s) ? 1 : 0), (int)s->cl_cpt, (int)s->cl_nt, (int)s->cl_n_halo_max,
+        s->cl_solves, s->cl_fallbacks);
     if (len >= n) return len + 1;
     memcpy(buf, tmp, (size_t)len + 1);
     return FG_OK;
@@ -834,7 +858,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
         for (int c = 0; c < opt->corrector_steps; ++c) {
             // P depends on A = diag(C) and the mesh only: the same matrix in every corrector of a step (the reference rebuilds it,
             // SetupPressureMatrix inside the loop, PISOtorch_simulation.py:1790-1800, to the same values)
-            if (c == 0) { hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false; }
+            if (c == 0) { hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4, SLOTS.cell_slot, SLOTS.off4, SLOTS.diag, SLOTS.stride); mb_slots_written(s); }
             for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
                 if (ps == 0) {
                     hipLaunchKernelGGL(k_mb_h<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->rA, s->Coff, s->velocity, s->ures,
@@ -1061,7 +1085,8 @@ extern "C" int fg_mb_set_multilevel(fg_mb_handle s, int32_t n4, int32_t n8, cons
             s->oc_matrix_stale = true;   // the slot-ordered copy of the matrix does not exist yet (fg_mb_step.hip: mb_cg_onchip)
         }
     }
-    return FG_OK;
+    // ---- cluster layout of the cluster CG (fg_mb_cluster.hip)
+    return mb_cluster_build(s, n4, n8, rect4_host, p4.data(), child.data(), rd4.data(), padded.data());
 }
 
 // cycle counts per phase of the on-chip CG (workgroup 0 of the last launch; FG_MB_OC_VARIANT=256): [0..10] phases, [11] iterations
@@ -1333,7 +1358,7 @@ extern "C" int fg_mb_make_divergence_free(fg_mb_handle s, const fg_mb_step_optio
     hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, (const mb_real*)nullptr, s->velocity, s->hvec);
     MB_DISPATCH(s, {
         hipLaunchKernelGGL(k_mb_contra<DIMS>, gc, blk, 0, st, D, (const mb_real*)nullptr, s->hvec, s->bvel, s->cc, s->fb);
-        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const mb_real*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;
+        hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, (const mb_real*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, SLOTS.cell_slot, SLOTS.off4, SLOTS.diag, SLOTS.stride); mb_slots_written(s);
         for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
             hipLaunchKernelGGL(k_mb_div<DIMS>, gn, blk, 0, st, D, (const mb_real*)nullptr, s->cc, s->fb, s->rA, s->pressure, 1, s->div);
             int m = 0;
@@ -1419,7 +1444,7 @@ extern "C" int fg_mb_unit_pressure_matrix(fg_mb_handle s, void* stream) {
     const size_t BN = (size_t)s->B * s->N;
     hipLaunchKernelGGL(k_mb_fill, dim3((unsigned)((BN + FG_BLOCK - 1) / FG_BLOCK)), dim3(FG_BLOCK), 0, st, BN, 1.f, s->rA);
     MB_DISPATCH(s, hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, dim3((s->N + FG_BLOCK - 1) / FG_BLOCK, s->B), dim3(FG_BLOCK), 0, st, s->dev,
-                                      (const mb_real*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, s->oc_agg ? s->oc_cell_slot : nullptr, s->Poff4s, s->Pdiag_s); s->oc_matrix_stale = false;);
+                                      (const mb_real*)nullptr, s->rA, s->Pdiag, s->Poff, s->Poff4, SLOTS.cell_slot, SLOTS.off4, SLOTS.diag, SLOTS.stride); mb_slots_written(s););
     FG_HIP_CHECK(hipStreamSynchronize(st));
     return FG_OK;
 }

@@ -57,6 +57,11 @@ NOTES = {
     "FG_MB_OC_RTG_NT": ("bits", "register-resident on-chip CG with a global residual copy on 16-24 k-cell meshes instead of k_mbc_l2"),
     "FG_MB_ONCHIP": ("bits", "0: no whole-solve on-chip CG (chunked CG kernels)"),
     "FG_MB_OC_AGG": ("bits", "0: cell-ordered on-chip CG instead of the aggregate-owned one"),
+    "FG_MB_CLUSTER": ("bits", "pressure CG of an env by a cluster of four workgroups (fg_mb_cluster.hip): 0 never (the one-workgroup kernels), 1 (default) meshes beyond 8 k cells, 2 every mesh its tables fit (tests)"),
+    "FG_MB_CL_CPT": ("no", "reserved (members per thread of the cluster CG; eight is the one instance built -- four in 1024 threads measured 12.8 against 8.6 us per iteration)"),
+    "FG_MB_CL_HALF": ("bits", "0: meshes whose rows of the coarse inverse do not fit LDS as fp32 stream them from L2 instead of holding them as fp16 (A/B runs: 19.7 against 16.8 us per iteration on 23 k cells)"),
+    "FG_MB_CL_MAXCL": ("no", "cap on the clusters of one launch of the cluster CG (tests: envs beyond it queue inside the kernel; same bits)"),
+    "FG_MB_CL_NEAR": ("no", "0: granule stores of the cluster CG always write through (sc1), also when a cluster's workgroups reported one XCD (A/B runs: 10.0 against 8.6 us per iteration)"),
     "FG_MB_OC_VARIANT": ("no", "on-chip CG variant bits (fences / coefficient layout)"),
     "FG_MB_RUNG_ILU": ("bits", "0: column-scaled preconditioned rung instead of ILU(0)"),
     "FG_MB_SCALAR_CG": ("bits", "1: one-cell chunked CG"),
