@@ -183,6 +183,9 @@ struct fg_mb_state {
     unsigned long long* cl_box = nullptr;
     uint16_t* cl_aci16 = nullptr; mb_real cl_aci16_unscale = 1.f;   // the coarse inverse as fp16 behind a power-of-two scale (meshes whose fp32 rows do not fit LDS)
     int cl_half = 1;           // FG_MB_CL_HALF=0: such meshes stream the fp32 rows from L2 instead
+    int cl_WJ = 0; unsigned long long* cl_jbox = nullptr; uint32_t *cl_jepoch = nullptr, *cl_jabort = nullptr;   // granule boxes of the cluster sweeps (k_mbj_cluster)
+    int cl_jacobi = 1;         // FG_MB_CL_JACOBI=0: the velocity sweeps stay one launch per sweep (k_mbj_sweep_env)
+    long long cl_jacobi_solves = 0;
     long long cl_solves = 0, cl_fallbacks = 0;   // launches that solved / that a workgroup gave up on (repeated by the one-workgroup kernels)
     double* x64_best = nullptr; mb_real* best_res = nullptr; int32_t* best_keep = nullptr;   // its best refinement point
     double* x64 = nullptr;     // fp64 iterate of the refined BiCGStab (pressure_use_bicgstab = 2)

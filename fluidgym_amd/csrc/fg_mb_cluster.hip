@@ -619,6 +619,272 @@ __global__ __launch_bounds__(NT) void k_mbc_cluster(MbSolve q, ClParams o) {
     }
 }
 
+// (k_mbs_begin of fg_mb_krylov.hip, for this translation unit: the flags and info words of the systems of a solve)
+__global__ void k_mbs_begin_cl(const mb_real* __restrict__ dt, MbSolve q, int nsys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    for (int k = 0; k < MB_ACC; ++k) acc_st(q.acc + ((size_t)s * MB_ACC + k), 0.0);
+    sc_st(q.sc + (s * 2), 1.f); sc_st(q.sc + (s * 2 + 1), 1.f);
+    const bool active = mb_active(dt, s / q.nc);
+    flag_st(q.flags + (s), active ? 0 : 3);
+    q.info[s].final_residual = 0.f;
+    q.info[s].used_iterations = -1;
+    q.info[s].converged = active ? 0 : 1;
+    q.info[s].is_finite = 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The velocity systems' Jacobi sweeps (mb_jacobi, fg_mb_krylov.hip: k_mbj_sweep_env, one launch per sweep over the neighbour table,
+// 12 us each at 64 envs x 14 k cells -- 18 % of a cylinder step) by the same clusters: a workgroup keeps the matrix row, the
+// right-hand sides and the iterate of its cells (both components: they share the row) in registers, the iterate it gathers from in
+// LDS with the halo behind it, and ONE exchange per sweep carries the halo -- and, behind a measuring sweep, the residual sums the
+// verdict is taken from.  Same sweep, same arithmetic per cell (x = (b - sum_f o_f x_f) / d in face order, the residual of the
+// iterate a sweep started from as d (x_new - x_old)), same check points (12, 14, ... 32 sweeps), same verdict per system, so an
+// env's iterate is what the launched sweeps give it; the give-up rule the host applies to the batch (contraction per sweep above
+// 0.85, or more than 32 sweeps needed) is applied per env here, and the host hands the batch to BiCGStab when any env gave up.
+// ---------------------------------------------------------------------------------------------------------------
+struct ClJParams {
+    const int32_t* slot_cell; const uint2* nbr; const uint32_t* tinfo; const int32_t* out_slot; const uint32_t* halo_src;
+    int n_out[CL_G], n_halo[CL_G];
+    int n_out_max, n_halo_max, WJ;       // WJ: granules of one box = 2 n_out_max + CL_NSC
+    cl_u64* box; uint32_t* epoch; uint32_t* abort_at;
+    int B, N, n_clusters, allow_near, use_x0;
+    mb_real tol;
+    fg_solve_info* info_host; int32_t* flags_host; mb_real* res2_host; FgPollOut poll;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_mbj_cluster(MbSolve q, ClJParams o) {
+    constexpr int CPT = 8, S = CPT * NT, HCAP = NT, NW = NT / 64, NC = 2, F = 4;
+    constexpr int FIRST = 12, STEP = 2, CHECKS = 11;     // mb_jacobi's check points
+    static_assert(S + HCAP <= 16383, "16-bit byte offsets into the LDS vectors");
+    __shared__ __attribute__((aligned(16))) mb_real xl[NC][S + HCAP];
+    __shared__ double l_wave[NC][NW];
+    __shared__ double l_tot[NC];
+    __shared__ uint32_t l_xcc[CL_G];
+    __shared__ int l_fail;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int cluster, g;
+    {
+        const int b = blockIdx.x, ncl = o.n_clusters;
+        if ((ncl & 7) == 0) { const int xcd = b & 7, j = b >> 3; cluster = (j / CL_G) * 8 + xcd; g = j % CL_G; }
+        else { cluster = b / CL_G; g = b % CL_G; }
+    }
+    const int N = o.N;
+    const uint32_t vmask = o.tinfo[g * NT + t] & 0xffu;
+    uint2 nb[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) nb[k] = o.nbr[(size_t)g * S + t + k * NT];
+    const int n_out = o.n_out[g], n_halo = o.n_halo[g];
+    const int out_sl = t < n_out ? o.out_slot[g * o.n_out_max + t] : 0;
+    uint32_t halo_at = 0;
+    if (t < n_halo) { const uint32_t src = o.halo_src[g * o.n_halo_max + t]; halo_at = (src >> 16) * (uint32_t)o.WJ + 2u * (src & 0xffffu); }
+    const int sc_at = 2 * o.n_out_max;
+    const uint32_t my_xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xfu;
+
+    for (int b = cluster; b < o.B; b += o.n_clusters) {
+        // systems b NC + c; k_mbs_begin has set their flags (0 live, 3 the env sits out) and cleared their info
+        bool live[NC], any = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { live[c] = flag_ld(q.flags + (b * NC + c)) == 0; any = any || live[c]; }
+        if (!any) {
+            if (g == 0 && t < NC) {
+                const int sy = b * NC + t;
+                o.info_host[sy] = q.info[sy]; o.flags_host[sy] = flag_ld(q.flags + sy); o.res2_host[2 * sy] = -1.f; o.res2_host[2 * sy + 1] = -1.f;
+                fg_poll_publish(o.poll, sy);
+            }
+            continue;
+        }
+        const uint32_t base = __hip_atomic_load(o.epoch + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t epoch = 0;
+        bool near = false;
+        cl_u64* const box_env = o.box + (size_t)b * 2 * CL_G * o.WJ;
+        if (t == 0) l_fail = 0;
+        // ---- matrix row (cell order: gathered once per solve), right-hand sides, start vector
+        mb_real off[CPT][F], dg[CPT], rd[CPT], rhs[CPT][NC], x[CPT][NC];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const bool ok = (vmask >> k) & 1u;
+            const int cell = ok ? o.slot_cell[(size_t)g * S + t + k * NT] : 0;
+            const uint32_t self = 4u * (uint32_t)(t + k * NT);
+            const uint32_t na[F] = {nb[k].x & 0xffffu, nb[k].x >> 16, nb[k].y & 0xffffu, nb[k].y >> 16};
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const mb_real v = ok ? q.off[((size_t)b * F + f) * N + cell] : 0.f;
+                off[k][f] = (ok && na[f] != self) ? v : 0.f;      // a prescribed face points at the cell itself: no matrix entry (k_mbj_sweep_env skips it)
+            }
+            dg[k] = ok ? q.diag[(size_t)b * N + cell] : 1.f;
+            rd[k] = (mb_real)1 / dg[k];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                rhs[k][c] = ok ? q.rhs[((size_t)b * NC + c) * N + cell] : 0.f;
+                x[k][c] = (ok && o.use_x0) ? q.x[((size_t)b * NC + c) * N + cell] : 0.f;
+            }
+        }
+        __syncthreads();
+        int sweeps = 0, checks = 0, used[NC] = {0, 0}, outcome = 0;     // outcome: 1 every live system settled, 2 gave up, 5 a granule never came
+        double res_now[NC] = {-1.0, -1.0}, res_prev[NC] = {-1.0, -1.0};
+        bool fin[NC] = {true, true}, conv[NC] = {false, false};
+        for (;;) {
+            int tl = t;
+            asm volatile("" : "+v"(tl));
+            const bool from_zero = sweeps == 0 && !o.use_x0;
+            // what the sweep before this one measured goes out with this sweep's halo
+            const bool measured = sweeps >= FIRST - 2 && !(sweeps & 1);     // sweeps 9, 11, ... measure; their sums travel at sweep counts 10, 12, ...
+            if (!from_zero) {
+                // ---- the exchange: x of the boundary cells (both components), the sums of the last measuring sweep
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) { xl[0][t + k * NT] = x[k][0]; xl[1][t + k * NT] = x[k][1]; }
+                ++epoch;
+                const uint32_t tag = base + epoch;
+                cl_u64* const bx = box_env + (size_t)(epoch & 1u) * CL_G * o.WJ;
+                cl_u64* const mine = bx + (size_t)g * o.WJ;
+                __syncthreads();
+                if (tl < n_out) { cl_store(mine + 2 * tl, tag, __float_as_uint(xl[0][out_sl]), near); cl_store(mine + 2 * tl + 1, tag, __float_as_uint(xl[1][out_sl]), near); }
+                const bool sc_wave = wave == NW - 1;
+                const int sc_v = (lane >> 4) & 1, sc_w = lane & 15;
+                double own = 0.0;
+                if (sc_wave && measured && lane < 32) {
+                    own = sc_w < NW ? l_wave[sc_v][sc_w] : 0.0;
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) own += __shfl_xor(own, m, 64);
+                    const cl_u64 bits = (cl_u64)__double_as_longlong(own);
+                    if (sc_w < 2) cl_store(mine + sc_at + 2 * sc_v + sc_w, tag, (uint32_t)(sc_w ? (bits >> 32) : bits), near);
+                }
+                if (!near && tl == NT - 65) { cl_store(mine + sc_at + 8, tag, my_xcc, near); l_xcc[g] = my_xcc; }
+                bool ok = true;
+                if (tl < n_halo) {
+                    uint32_t v0 = 0, v1 = 0;
+                    ok &= cl_poll(bx + halo_at, tag, o.abort_at + b, base, v0);
+                    ok &= cl_poll(bx + halo_at + 1, tag, o.abort_at + b, base, v1);
+                    xl[0][S + tl] = __uint_as_float(v0); xl[1][S + tl] = __uint_as_float(v1);
+                }
+                if (sc_wave && measured && lane < 32) {
+                    double part = own;
+                    if (sc_w < CL_G && sc_w != g) {
+                        const cl_u64* src = bx + (size_t)sc_w * o.WJ + sc_at + 2 * sc_v;
+                        unsigned spins = 0;
+                        for (;;) {
+                            const cl_u64 lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const cl_u64 hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)(lo >> 32) == tag && (uint32_t)(hi >> 32) == tag) {
+                                part = __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins >= CL_SPIN_LIMIT || ((spins & 255u) == 0u && __hip_atomic_load(o.abort_at + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == base)) { ok = false; break; }
+                        }
+                    }
+                    double sum = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CL_G; ++c) sum += __shfl(part, (lane & 16) + c, 64);
+                    if (sc_w == 0) l_tot[sc_v] = sum;
+                }
+                if (!near && tl == NT - 65) {
+#pragma unroll
+                    for (int c = 0; c < CL_G; ++c)
+                        if (c != g) { uint32_t v = 0; ok &= cl_poll(bx + (size_t)c * o.WJ + sc_at + 8, tag, o.abort_at + b, base, v); l_xcc[c] = v; }
+                }
+                if (!ok) l_fail = 1;
+                __syncthreads();
+                if (!near && o.allow_near) {
+                    bool same = true;
+#pragma unroll
+                    for (int c = 0; c < CL_G; ++c) same = same && l_xcc[c] == my_xcc;
+                    near = same;
+                }
+                if (l_fail) { outcome = 5; break; }
+                // ---- behind a measuring sweep: its residual; at a check point (12, 14, ... sweeps done) the verdict per system
+                if (measured) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (live[c]) { res_prev[c] = res_now[c]; res_now[c] = (double)mb_rms(cl_uni(l_tot[c]), N); }
+                    if (sweeps >= FIRST) {
+                        ++checks;
+                        bool all = true, bad = false;
+                        double need = 0.0;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            if (!live[c]) continue;
+                            const mb_real now = (mb_real)res_now[c];
+                            used[c] = sweeps;
+                            if (!(now >= o.tol)) { live[c] = false; fin[c] = isfinite(now); conv[c] = fin[c]; continue; }
+                            all = false;
+                            // mb_jacobi's rule for going on, per env: the contraction per sweep from the two measuring sweeps (two apart)
+                            const double r1 = res_now[c], r0 = res_prev[c];
+                            if (r0 > 0.0 && r1 > 0.0) {
+                                const double cs = sqrt(r1 / r0);
+                                if (!(cs < 0.85)) bad = true;
+                                else { const double m = log((double)o.tol / r1) / log(cs); need = m > need ? m : need; }
+                            } else need = need > 4.0 ? need : 4.0;
+                        }
+                        if (all) { outcome = 1; break; }
+                        if (bad || !(need < 1.0e6)) { outcome = 2; break; }
+                        const int more = 1 + (int)(ceil(need) - 1) / STEP;
+                        if (checks + more > CHECKS) { outcome = 2; break; }
+                    }
+                }
+            }
+            // ---- the sweep: x = (b - sum_f o_f x_f) / d, the residual of the iterate it started from as d (x_new - x_old)
+            const bool measure = sweeps >= FIRST - 3 && (sweeps & 1);
+            mb_real part[NC] = {0.f, 0.f};
+            const char* b0 = reinterpret_cast<const char*>(xl[0]);
+            const char* b1 = reinterpret_cast<const char*>(xl[1]);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                mb_real acc0 = rhs[k][0], acc1 = rhs[k][1];
+                if (!from_zero) {
+                    const uint32_t na[F] = {nb[k].x & 0xffffu, nb[k].x >> 16, nb[k].y & 0xffffu, nb[k].y >> 16};
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        acc0 -= off[k][f] * *reinterpret_cast<const mb_real*>(b0 + na[f]);
+                        acc1 -= off[k][f] * *reinterpret_cast<const mb_real*>(b1 + na[f]);
+                    }
+                }
+                const bool ok = (vmask >> k) & 1u;
+                if (live[0] && ok) { const mb_real xn = acc0 * rd[k]; const mb_real r = dg[k] * (xn - x[k][0]); part[0] += r * r; x[k][0] = xn; }
+                if (live[1] && ok) { const mb_real xn = acc1 * rd[k]; const mb_real r = dg[k] * (xn - x[k][1]); part[1] += r * r; x[k][1] = xn; }
+            }
+            if (measure) {
+                const mb_real w0 = fg_wave_sum(part[0]), w1 = fg_wave_sum(part[1]);
+                if (lane == 0) { l_wave[0][wave] = (double)w0; l_wave[1][wave] = (double)w1; }
+            }
+            ++sweeps;
+            __syncthreads();   // every gather of this sweep is done before the next sweep's iterate overwrites the LDS vectors
+        }
+        // ---- hand back: the iterate of every system (a system that stopped kept its own)
+        if (outcome != 5) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+                if ((vmask >> k) & 1u) {
+                    const int cell = o.slot_cell[(size_t)g * S + t + k * NT];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) q.x[((size_t)b * NC + c) * N + cell] = x[k][c];
+                }
+        }
+        if (t == 0) {
+            __hip_atomic_fetch_max(o.epoch + b, base + epoch + 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (outcome == 5) __hip_atomic_store(o.abort_at + b, base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (g == 0 && t < NC) {
+            const int c = t, sy = b * NC + c;
+            const bool was_live = flag_ld(q.flags + sy) == 0;
+            if (was_live) {
+                const bool stopped = c == 0 ? !live[0] : !live[1];
+                const bool f_ = c == 0 ? fin[0] : fin[1], cv = c == 0 ? conv[0] : conv[1];
+                q.info[sy].final_residual = (mb_real)(c == 0 ? res_now[0] : res_now[1]);
+                q.info[sy].used_iterations = stopped ? (c == 0 ? used[0] : used[1]) : sweeps;
+                if (stopped) { q.info[sy].converged = cv ? 1 : 0; q.info[sy].is_finite = f_ ? 1 : 0; flag_st(q.flags + sy, f_ ? 1 : 2); }
+            }
+            o.info_host[sy] = q.info[sy];
+            o.flags_host[sy] = outcome == 5 ? -77 : flag_ld(q.flags + sy);
+            o.res2_host[2 * sy] = (mb_real)(c == 0 ? res_now[0] : res_now[1]); o.res2_host[2 * sy + 1] = (mb_real)(c == 0 ? res_prev[0] : res_prev[1]);
+            fg_poll_publish(o.poll, sy);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -822,6 +1088,11 @@ int mb_cluster_build(fg_mb_state* s, int n4, int n8, const int32_t* rect4_host, 
     if (int rc = mb_alloc(s, &s->cl_bestx, (size_t)s->B * G * S)) return rc;
     if (int rc = mb_alloc(s, &s->cl_box, (size_t)s->B * 2 * G * W)) return rc;
     if (int rc = mb_alloc(s, &s->cl_epoch, (size_t)s->B)) return rc;
+    s->cl_WJ = 2 * n_out_max + CL_NSC;
+    if (int rc = mb_alloc(s, &s->cl_jbox, (size_t)s->B * 2 * G * s->cl_WJ)) return rc;
+    if (int rc = mb_alloc(s, &s->cl_jepoch, (size_t)s->B)) return rc;
+    if (int rc = mb_alloc(s, &s->cl_jabort, (size_t)s->B)) return rc;
+    FG_HIP_CHECK(hipMemset(s->cl_jabort, 0xff, sizeof(uint32_t) * s->B));
     if (int rc = mb_alloc(s, &s->cl_abort, (size_t)s->B)) return rc;
     FG_HIP_CHECK(hipMemset(s->cl_abort, 0xff, sizeof(uint32_t) * s->B));   // no launch has base 0xFFFFFFFF
     FG_HIP_CHECK(hipMemcpy(s->cl_slot_cell, slot_cell.data(), sizeof(int32_t) * slot_cell.size(), hipMemcpyHostToDevice));
@@ -923,5 +1194,50 @@ int mb_cg_cluster(fg_mb_state* s, const mb_real* dt, const mb_real* rhs, mb_real
         s->prof_its += its;
     }
     return mb_finish(s, nsys, nullptr, max_it);
+#endif
+}
+
+// mb_jacobi's sweeps by the clusters (k_mbj_cluster): the 2-D velocity systems of the meshes the cluster CG takes.  *fell_back: a
+// workgroup gave up on a granule (nothing was solved: the caller runs the launch-per-sweep path); otherwise *done says whether every
+// system settled -- when not, the pinned mirrors hold the flags and the last two measured residuals of every system, as mb_jacobi's
+// check kernel leaves them.
+bool mb_jacobi_cluster_ok(const fg_mb_state* s, int nc) {
+    return s->cl_on && s->cl_jacobi && (s->cl_mode == 2 || s->N > 8 * 1024) && nc == 2 && s->d == 2 && s->cl_cus >= CL_G && s->cl_jbox != nullptr;
+}
+int mb_jacobi_cluster(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, mb_real tol,
+                      int use_x0, hipStream_t st, bool* fell_back, bool* done) {
+    *fell_back = false; *done = false;
+#if FG_MB_F64
+    (void)dt; (void)diag; (void)off; (void)rhs; (void)x; (void)tol; (void)use_x0; (void)st;
+    fg_set_error("the cluster sweeps are not part of the fp64 build");
+    return FG_ERR_UNSUPPORTED;
+#else
+    const int nsys = s->B * 2;
+    MbSolve q = mb_solve_ptrs(s, diag, off, rhs, x, 2, tol);
+    hipLaunchKernelGGL(k_mbs_begin_cl, dim3((nsys + 63) / 64), dim3(64), 0, st, dt, q, nsys);
+    ClJParams o;
+    memset(&o, 0, sizeof(o));
+    o.slot_cell = s->cl_slot_cell; o.nbr = s->cl_nbr; o.tinfo = s->cl_tinfo; o.out_slot = s->cl_out_slot; o.halo_src = s->cl_halo_src;
+    for (int g = 0; g < CL_G; ++g) { o.n_out[g] = s->cl_n_out[g]; o.n_halo[g] = s->cl_n_halo[g]; }
+    o.n_out_max = s->cl_n_out_max; o.n_halo_max = s->cl_n_halo_max; o.WJ = s->cl_WJ;
+    o.box = reinterpret_cast<cl_u64*>(s->cl_jbox); o.epoch = s->cl_jepoch; o.abort_at = s->cl_jabort;
+    o.B = s->B; o.N = s->N; o.allow_near = s->cl_near; o.use_x0 = use_x0; o.tol = tol;
+    o.n_clusters = std::max(1, std::min(s->B, s->cl_cus / CL_G));
+    if (s->cl_max_clusters > 0) o.n_clusters = std::min(o.n_clusters, s->cl_max_clusters);
+    o.info_host = s->info_pinned; o.flags_host = s->flags_pinned; o.res2_host = s->jac_res_pinned;
+    o.poll = fg_poll_next(&s->poll);
+    const dim3 grid(o.n_clusters * CL_G);
+    if (s->cl_nt == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbj_cluster<512>), grid, dim3(512), 0, st, q, o);
+    else if (s->cl_nt == 768) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbj_cluster<768>), grid, dim3(768), 0, st, q, o);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mbj_cluster<1024>), grid, dim3(1024), 0, st, q, o);
+    if (int rc = fg_poll_wait(&s->poll, o.poll, 0, nsys, st)) return rc;
+    bool all = true;
+    for (int i = 0; i < nsys; ++i) {
+        if (s->flags_pinned[i] == -77) { *fell_back = true; ++s->cl_fallbacks; return FG_OK; }
+        all = all && s->flags_pinned[i] != 0;
+    }
+    ++s->cl_jacobi_solves;
+    *done = all;
+    return FG_OK;
 #endif
 }

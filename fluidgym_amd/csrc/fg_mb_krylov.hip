@@ -1761,8 +1761,20 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
     int upto = 1;
     if (s->jac_sweeps[ps] > FIRST) upto = 1 + (s->jac_sweeps[ps] - FIRST + STEP - 1) / STEP;
     if (upto > CHECKS) upto = CHECKS;
-    bool ok = false;
-    for (;;) {
+    bool ok = false, by_cluster = false;
+    // the sweeps of an env by a cluster of workgroups, one launch per solve (k_mbj_cluster, fg_mb_cluster.hip): the same sweeps, check
+    // points and verdicts; its give-up rule is this loop's, applied per env
+    if (mb_jacobi_cluster_ok(s, nc)) {
+        bool fell_back = false, done = false;
+        if (int rc = mb_jacobi_cluster(s, dt, diag, off, rhs, x, tol, use_x0, st, &fell_back, &done)) return rc;
+        if (!fell_back) {
+            by_cluster = true;
+            bool bad = false;
+            for (int i = 0; i < nsys; ++i) bad = bad || !s->info_pinned[i].is_finite;
+            ok = done && !bad;
+        }
+    }
+    while (!by_cluster) {
         const FgPollOut po = fg_poll_next(&s->poll);
         run_to_check(upto, po);
         bool done = false;

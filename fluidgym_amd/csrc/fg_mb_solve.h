@@ -145,6 +145,9 @@ int mb_cluster_build(fg_mb_state* s, int n4, int n8, const int32_t* rect4_host, 
 bool mb_cluster_ok(const fg_mb_state* s, int pm_mode, const mb_real* diag, const mb_real* off);
 int mb_cg_cluster(fg_mb_state* s, const mb_real* dt, const mb_real* rhs, mb_real* x, mb_real tol, int max_iterations, int use_x0, int pm_mode,
                   mb_real stall_accept, int* max_it, hipStream_t st, bool* fell_back);
+bool mb_jacobi_cluster_ok(const fg_mb_state* s, int nc);
+int mb_jacobi_cluster(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real* off, const mb_real* rhs, mb_real* x, mb_real tol,
+                      int use_x0, hipStream_t st, bool* fell_back, bool* done);
 constexpr int ML_N8_MAX = 2048, ML_ROWS = 16, ML_CG = 64;   // multilevel coarse solve: rows per workgroup, column groups
 void mb_ml_scale(fg_mb_state* s, const mb_real* diag, hipStream_t st);
 bool mb_ilu_prepare(fg_mb_state* s);

@@ -486,6 +486,7 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_AGG"); s->dbg_oc_agg = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_CL_CPT"); s->cl_force_cpt = e ? atoi(e) : 0;
+        e = getenv("FG_MB_CL_JACOBI"); s->cl_jacobi = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_CL_HALF"); s->cl_half = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_CL_NEAR"); s->cl_near = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_CL_MAXCL"); s->cl_max_clusters = e ? atoi(e) : 0;
@@ -509,11 +510,11 @@ extern "C" int fg_mb_config_dump(fg_mb_handle s, char* buf, int n) {
         "{\"FG_MB_BICG_VEC4\": %d, \"FG_MB_SCALAR_CG\": %d, \"FG_MB_BICG_FUSE\": %d, \"FG_MB_PRED\": %d, \"FG_MB_ML_FUSE\": %d, \"FG_MB_ML_SB\": %d, "
         "\"FG_MB_ML_TRY_CAP\": %d, \"FG_MB_ML_WARMUP\": %d, \"FG_MB_GRAPH\": %d, \"FG_MB_TRACE\": %d, \"FG_MB_COMPACT\": %d, \"FG_MB_OC_RTG_NT\": %d, "
         "\"FG_MB_ONCHIP\": %d, \"FG_MB_OC_AGG\": %d, \"FG_MB_RUNG_ILU\": %d, \"FG_MB_OC_VARIANT\": %d, \"FG_MB_CLUSTER\": %d, "
-        "\"cluster_on\": %d, \"cluster_members_per_thread\": %d, \"cluster_threads\": %d, \"cluster_halo_max\": %d, \"cluster_solves\": %lld, \"cluster_fallbacks\": %lld}",
+        "\"cluster_on\": %d, \"cluster_members_per_thread\": %d, \"cluster_threads\": %d, \"cluster_halo_max\": %d, \"cluster_solves\": %lld, \"cluster_fallbacks\": %lld, \"cluster_jacobi_solves\": %lld}",
         (int)s->dbg_vec_mask, (int)s->dbg_scalar_cg, (int)s->dbg_fuse_st, (int)s->dbg_pred, (int)s->dbg_ml_fuse, (int)s->dbg_ml_sb, (int)s->dbg_ml_cap,
         (int)s->dbg_ml_warmup, (int)s->dbg_graph, (int)s->dbg_trace, (int)s->dbg_compact, (int)s->oc_rtg_nt, (int)s->onchip_mode, (int)s->dbg_oc_agg,
         (int)s->dbg_rung_ilu, (int)s->oc_variant, (int)s->cl_mode, (int)(mb_cluster_wanted(s) ? 1 : 0), (int)s->cl_cpt, (int)s->cl_nt, (int)s->cl_n_halo_max,
-        s->cl_solves, s->cl_fallbacks);
+        s->cl_solves, s->cl_fallbacks, s->cl_jacobi_solves);
     if (len >= n) return len + 1;
     memcpy(buf, tmp, (size_t)len + 1);
     return FG_OK;

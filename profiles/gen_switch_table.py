@@ -59,6 +59,7 @@ NOTES = {
     "FG_MB_OC_AGG": ("bits", "0: cell-ordered on-chip CG instead of the aggregate-owned one"),
     "FG_MB_CLUSTER": ("bits", "pressure CG of an env by a cluster of four workgroups (fg_mb_cluster.hip): 0 never (the one-workgroup kernels), 1 (default) meshes beyond 8 k cells, 2 every mesh its tables fit (tests)"),
     "FG_MB_CL_CPT": ("no", "reserved (members per thread of the cluster CG; eight is the one instance built -- four in 1024 threads measured 12.8 against 8.6 us per iteration)"),
+    "FG_MB_CL_JACOBI": ("bits", "0: the velocity sweeps of the meshes the cluster CG takes stay one launch per sweep (k_mbj_sweep_env) instead of one launch per solve by the clusters (k_mbj_cluster; A/B runs: 2 552 against 3 045 env-steps/s on the cylinder mesh)"),
     "FG_MB_CL_HALF": ("bits", "0: meshes whose rows of the coarse inverse do not fit LDS as fp32 stream them from L2 instead of holding them as fp16 (A/B runs: 19.7 against 16.8 us per iteration on 23 k cells)"),
     "FG_MB_CL_MAXCL": ("no", "cap on the clusters of one launch of the cluster CG (tests: envs beyond it queue inside the kernel; same bits)"),
     "FG_MB_CL_NEAR": ("no", "0: granule stores of the cluster CG always write through (sc1), also when a cluster's workgroups reported one XCD (A/B runs: 10.0 against 8.6 us per iteration)"),

@@ -101,3 +101,36 @@ def test_cluster_cg_at_the_bench_batch(monkeypatch):
         assert c[k]["unconverged"] == 0
     for b in range(1, 63):
         np.testing.assert_array_equal(u[b], u[0])
+
+
+def _sweeps_run(monkeypatch, cl_jacobi, env_id, steps=2, B=3, **kw):
+    import fluidgym_amd
+
+    monkeypatch.setenv("FG_MB_CL_JACOBI", cl_jacobi)
+    env = fluidgym_amd.make(env_id, num_envs=B, randomize_initial_state=False, **kw)
+    env.reset(seed=0)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    na = tuple(env._zero_action.shape[1:])
+    for _ in range(steps):
+        env.step((torch.rand((B,) + na, generator=g) * 2 - 1).cuda())
+    dom = env._domain
+    out = (dom.velocity.cpu().numpy().copy(), dom.pressure.cpu().numpy().copy(), dom.advection_jacobi_counts(), dom.solver_counters(), dom.config_dump())
+    env.close()
+    return out
+
+
+@pytest.mark.parametrize("env_id", ["CylinderJet2D-easy-v0", "CylinderJet2D-medium-v0"])
+def test_cluster_sweeps_are_the_launched_sweeps(monkeypatch, env_id):
+    """The velocity systems' Jacobi sweeps by the clusters (``k_mbj_cluster``, one launch per solve) against one launch per sweep
+    (``k_mbj_sweep_env``, FG_MB_CL_JACOBI=0): the same arithmetic per cell, the same check points, the same verdict per system --
+    only the residual sums the verdict reads are added in another order, so a system whose residual sits at the tolerance at a check
+    point may stop one check point apart (seen: one system of 502 on the medium mesh).  Two env steps (50 PISO steps) with random
+    jets: every solve settled by the sweeps either way, the same sweeps per solve to a hundredth, fields equal to what two sweeps more
+    or less leave."""
+    a = _sweeps_run(monkeypatch, "1", env_id, initial_domain_steps=20)
+    b = _sweeps_run(monkeypatch, "0", env_id, initial_domain_steps=20)
+    assert a[4]["cluster_jacobi_solves"] >= 50 and b[4]["cluster_jacobi_solves"] == 0 and a[4]["cluster_fallbacks"] == 0
+    assert a[2] == b[2] and a[2]["handed_to_bicgstab"] == 0, (a[2], b[2])
+    va, vb = a[3]["velocity"], b[3]["velocity"]
+    assert va["systems"] == vb["systems"] and va["unconverged"] == vb["unconverged"] == 0 and abs(va["mean"] - vb["mean"]) < 0.05, (va, vb)
+    assert _rel(a[0], b[0]) < 5e-5 and _rel(a[1], b[1]) < 2e-3, (_rel(a[0], b[0]), _rel(a[1], b[1]))
