@@ -230,15 +230,15 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True, e
                     continue
                 if name == "k_mbc_onchip":
                     per_it = r["ms"] / max(r["iterations"] / num_envs, 1)
-                    rows[name] = {"doc": "whole CG solve of one env per workgroup: r, x, P p in registers, p in LDS; off-diagonals and "
-                                         "packed neighbour table streamed from L2 every iteration",
+                    rows[name] = {"doc": "whole CG solve of one env in one launch: by a cluster of four workgroups since round 6 (k_mbc_cluster: state in "
+                                         "registers, two granule exchanges per iteration; csrc/fg_mb_cluster.hip), by one workgroup when FG_MB_CLUSTER=0 "
+                                         "(k_mbc_onchip / k_mbc_l2) -- see `switches`",
                                   "launches": r["launches"], "total_ms": r["ms"], "avg_launch_ms": r["ms"] / r["samples"],
                                   "iterations_per_env_and_solve": r["iterations"] / num_envs / r["launches"],
                                   "us_per_iteration": 1e3 * per_it,
                                   "L2_side_streamed_GBps": r["bytes"] / r["ms"] / 1e6,
-                                  "note": "bytes = iterations x cells x 24 B (16 B coefficients + 8 B neighbours) + 20 B per cell and solve; "
-                                          "they come from L2 / Infinity Cache, not HBM: this kernel is bound by per-CU load latency and "
-                                          "L2 bandwidth (64 of 256 CUs busy at 64 envs), not by the HBM roofline"}
+                                  "note": "latency-bound by construction (two cross-workgroup exchanges per iteration, ~1.5-2 us each): the figure to "
+                                          "read is us_per_iteration, not a bandwidth"}
                 else:
                     avg = r["ms"] / r["samples"]
                     rows[name] = {"doc": KERNEL_DOC.get(name, ""), "traffic": pmc_traffic(name + "4"), "avg_busy_launch_ms": avg,
@@ -253,7 +253,7 @@ def cylinder_env_leg(device, num_envs=ENVS_PER_GPU, steps=2, extra_modes=True, e
             env.close()
 
     out = {"env_id": env_id, "envs": num_envs, "policy": "uniform random jets in [-1, 1] (as the headline)",
-           "pressure_solver": "CG, cold-started (reference policy), additive multilevel preconditioner, whole solve per env on-chip",
+           "pressure_solver": "CG, cold-started (reference policy), additive multilevel preconditioner, whole solve of an env in one launch by a cluster of four workgroups",
            "note": "state 100 uncontrolled sim steps after an impulsive start (no published initial domains offline)"}
     out.update(run(steps))
     keep = ("value", "ms_per_step", "pressure_warm_start", "advection_warm_start", "pressure_stall_accept", "solver_iterations", "drag_coefficient_env0")
@@ -324,7 +324,7 @@ def airfoil_env_leg(device, num_envs=16, steps=2, develop=60, multilevel_trial=T
 
 
 def step_gbps(prof, elapsed_s):
-    """Whole-step effective bandwidth of the SOLVER kernels: algorithmic bytes of every sampled kind (mean bytes per sampled launch
+    """Effective bandwidth of the SOLVER kernels only (`solver_kernels_GBps`; printed as `step_GBps` until round 5): algorithmic bytes of every sampled kind (mean bytes per sampled launch
     x launches in the timed region) / wall time of the timed region.  Assembly / corrector kernels are not in the native profile, so
     this is a lower bound of what the step moves."""
     tot = 0.0
@@ -332,6 +332,24 @@ def step_gbps(prof, elapsed_s):
         if r.get("all_samples", 0) > 0:
             tot += r["bytes"] / max(r["samples"], 1) * r["launches"] * (r["samples"] / r["all_samples"])
     return tot / elapsed_s / 1e9 if tot > 0 else None
+
+
+def whole_step_gbps_model(prof, elapsed_s, its, solver):
+    """The SOLVER kernels' sampled bytes (solver_kernels_GBps: until round 5 printed as `step_GBps`) plus, for the kernels the
+    native profile does not time, DESIGN.md section 4's algorithmic bytes per cell and launch: per PISO step one assembly
+    (k_adv_build: 44 B in 2-D, 56 B in 3-D) and per corrector k_h (52 / 68), the divergence / start kernel (28) and k_correct (28 / 36).
+    A model, not a measurement: what the whole step moves at least, over the wall time of the timed regions."""
+    try:
+        cells = float(solver.nx) * float(solver.ny) * float(max(solver.nz, 1)) * float(solver.B)
+        three_d = solver.nz > 1
+    except Exception:
+        return None
+    per_piso = (56.0 if three_d else 44.0) + 2.0 * ((68.0 if three_d else 52.0) + 28.0 + (36.0 if three_d else 28.0))
+    tot = per_piso * cells * float(its["piso_steps"])
+    for r in prof.values():
+        if r.get("all_samples", 0) > 0:
+            tot += r["bytes"] / max(r["samples"], 1) * r["launches"] * (r["samples"] / r["all_samples"])
+    return tot / elapsed_s / 1e9 if elapsed_s > 0 else None
 
 
 def launches_per_piso_step(prof, its):
@@ -412,16 +430,67 @@ def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing
         its = solver_iterations(solver)
         roof = roofline_from_profile(prof, solver)
         sim_steps = env.n_sim_steps
+        sw = solver_switches(solver)
         return {"env_id": env_id, "envs": num_envs, "grid": [solver.nx, solver.ny, solver.nz], "doc": doc,
+                # velocity systems the streaming sweeps ended on their fp32-floor rule (measured residual >= tolerance, < 8 x tolerance;
+                # csrc/fg_jacobi.hip k_jac_stream_check) since the handle was created: reported beside capped_solves, not hidden in it
+                "floor_released_solves": sw.get("jacobi_floor_released") if isinstance(sw, dict) else None,
                 "piso_steps_per_env_step": sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": its,
                 "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
-                "policy": "uniform samples of the action space", "switches": solver_switches(solver), "velocity_solver": velocity_solver_desc(env, solver),
+                "policy": "uniform samples of the action space", "switches": sw, "velocity_solver": velocity_solver_desc(env, solver),
                 "dominant_kernel": None if roof is None else {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
                 "kernels": None if roof is None else {k: {kk: v[kk] for kk in ("avg_busy_launch_ms", "launches", "est_total_ms", "GBps", "TFLOPps")}
                                                       for k, v in roof["kernels"].items()}}
     finally:
         env.close()
+
+
+def cylinder_sharded(world, rank, device, coll_device, share_gpu, envs_per_gpu=ENVS_PER_GPU, steps=4, repeats=3):
+    """N > 1 only: the env `north_star`'s scaling target names -- the reference's own CylinderJet2D-easy-v0 (five-block mesh, 14 232
+    cells, 25 PISO steps per env step) -- weak-scaled like the headline: `envs_per_gpu` envs per rank behind ParallelFluidEnv (one
+    broadcast + one all_gather per step over RCCL), random jets, max-over-ranks time of the median of `repeats` regions of `steps`
+    steps.  Every rank calls this; rank 0 returns the summary (reference behaviour: parallel_env.py:233-287)."""
+    import torch
+    import torch.distributed as dist
+
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    n_total = envs_per_gpu * world
+    kw = dict(initial_domain_steps=40, randomize_initial_state=False)
+    penv = ParallelFluidEnv("CylinderJet2D-easy-v0", num_envs=n_total, backend="gloo", cuda_ids=[0] * world, **kw) if share_gpu \
+        else ParallelFluidEnv("CylinderJet2D-easy-v0", num_envs=n_total, **kw)
+    try:
+        env = penv.local_env
+        penv.reset(seed=0)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        a_shape = (n_total,) + tuple(env._zero_action.shape[1:])
+        act = lambda: (torch.rand(a_shape, generator=gen) * 2 - 1).to(device) if penv.is_driver else None
+
+        def fence():
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+        penv.step(act())
+        regions = []
+        for _ in range(repeats):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                penv.step(act())
+            fence()
+            regions.append(time.perf_counter() - t0)
+        t = torch.tensor(regions, dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions = sorted(float(v) for v in t.cpu().tolist())
+        el = regions[len(regions) // 2]
+        return {"env_id": "CylinderJet2D-easy-v0", "value": round(n_total * steps / el, 2), "unit": "env-steps/s", "n_gpus": world,
+                "envs_per_gpu": envs_per_gpu, "ms_per_step": round(1e3 * el / steps, 3), "scaling": "weak",
+                "min": round(n_total * steps / regions[-1], 2), "max": round(n_total * steps / regions[0], 2),
+                "collective_backend": dist.get_backend(), "collective_world_size": dist.get_world_size()}
+    finally:
+        penv.close()
 
 
 def stream_triad(device, n=1 << 28, reps=10):
@@ -493,7 +562,7 @@ def _leg_summary(leg):
     dk = leg.get("dominant_kernel")
     if dk:
         s["dom"] = [dk["kernel"].split(":")[0], _r(dk["frac"], 3)]
-    for k in ("capped_solves", "launches_per_piso_step", "oracle_iters", "busy_cus"):
+    for k in ("capped_solves", "floor_released_solves", "launches_per_piso_step", "oracle_iters", "busy_cus"):
         if leg.get(k) is not None:
             s[k] = _r(leg[k])
     # adaptive-CFL sub-steps make an env step as long as the flow is fast (RBC: 1.35 sub-steps per sim step two env steps after a
@@ -511,6 +580,11 @@ def compact_line(out, detail_path=DETAIL_PATH):
     keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")
     line = {k: _r(out[k], 6) for k in keys}
+    if out.get("value_spread"):
+        line["repeats"] = out.get("repeats")
+        line["value_spread"] = {k: _r(out["value_spread"][k], 6) for k in ("median", "min", "max")}
+    if out.get("cylinder_sharded"):
+        line["cylinder_sharded"] = out["cylinder_sharded"]
     if out.get("value_unforced") is not None:
         line["value_unforced"] = _r(out["value_unforced"], 6)
     cfg = out["config"]
@@ -518,21 +592,23 @@ def compact_line(out, detail_path=DETAIL_PATH):
                       "parallelism": cfg["parallelism"], "workload_modified": cfg.get("workload_modified"),
                       "forcing_amplitude": cfg.get("forcing_amplitude"),
                       "iters_per_solve[mean,max]": _iters(cfg.get("solver_iterations")),
-                      "iters_are": cfg.get("iters_are"),
                       "substeps_per_sim_step": cfg.get("mean_substeps_per_sim_step"),
-                      "capped_solves": cfg.get("capped_solves"),
+                      "capped_solves": cfg.get("capped_solves"), "floor_released_solves": cfg.get("floor_released_solves"),
                       "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step")),
-                      "step_GBps": _r(cfg.get("step_GBps")), "advection_solver_form": cfg.get("advection_solver_form"),
-                      "velocity_solver": cfg.get("velocity_solver")}
+                      "solver_kernels_GBps": _r(cfg.get("solver_kernels_GBps")), "whole_step_GBps_model": _r(cfg.get("whole_step_GBps_model")),
+                      "GBps_doc": "solver_kernels_GBps = r5's step_GBps (solver kernels only); _model adds DESIGN 4's bytes of assembly + correctors",
+                      "advection_solver_form": cfg.get("advection_solver_form"),
+                      "velocity_solver": (cfg.get("velocity_solver") or "")[:120]}
     if cfg.get("per_rank"):
         line["config"]["per_rank"] = cfg["per_rank"]
+    line["config"]["collective"] = [cfg.get("collective_backend"), cfg.get("collective_world_size")]
     roof = out.get("roofline")
     if roof:
         tr = roof.get("traffic")
         line["roofline"] = {"bound": roof["bound"], "kernel": roof["kernel"].split(":")[0], "achieved": _r(roof["achieved"]),
                             "peak": roof["peak"], "unit": roof["unit"], "frac": _r(roof["frac"], 3),
                             "traffic": None if not tr else _r(tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"]),
-                            "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, last profiled run)",
+                            "traffic_unit": "B/launch (--pmc FETCH_SIZE x2 + WRITE_SIZE, last profiled run)",
                             "algorithmic_bytes_per_launch": _r(roof.get("avg_bytes_per_launch")),
                             "avg_launch_us": _r(1e3 * roof["avg_launch_ms"]), "launches": roof["launches"],
                             "share_of_solver_kernel_time": _r(roof.get("share_of_gpu_time"), 3)}
@@ -557,7 +633,7 @@ def compact_line(out, detail_path=DETAIL_PATH):
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                "one_thread_value": _r(cb.get("one_thread_value")), "sample": cb["sample"][:200]}
+                                "one_thread_value": _r(cb.get("one_thread_value")), "sample": cb["sample"][:120]}
     line["detail"] = detail_path
     text = json.dumps(line, separators=(",", ":"))
     if len(text) >= LINE_LIMIT:   # never let an extra leg push the headline off the driver's tail
@@ -585,6 +661,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of --steps steps is run this many times back to back (each bracketed by its own fence); the line "
+                         "reports the MEDIAN region and the spread (boxes and runs differ by a few per cent: VERDICT r5, bench method)")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -627,6 +706,11 @@ def main():
     device = torch.device("cuda", dev_index)
     coll_device = torch.device("cpu") if args.share_gpu else device      # where the bench's own collectives live
 
+    if world > 1 and not dist.is_initialized():
+        # the group outlives the headline's ParallelFluidEnv (which would otherwise own and destroy it): the sharded cylinder run uses it too
+        from datetime import timedelta
+
+        dist.init_process_group(backend="gloo" if args.share_gpu else "nccl", init_method="env://", timeout=timedelta(seconds=600))
     n_total = args.envs_per_gpu * world
     if args.share_gpu:
         penv = ParallelFluidEnv(args.env_id, num_envs=n_total, backend="gloo", cuda_ids=[0] * world)
@@ -674,17 +758,28 @@ def main():
 
     penv.time_shards = world > 1      # per-rank time of the shard's own step (one sync per step, in front of the all_gather that waits anyway)
     penv.shard_seconds = 0.0
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    regions = []
+    n_rep = max(1, args.repeats)
+    for k_rep in range(n_rep):
+        if env._n_steps + args.steps > env.episode_length:
+            # an episode is 80 env steps: a region never straddles its end -- a new episode (and its warm-up) starts outside the timed region
+            penv.reset(seed=1234 + k_rep, randomize=True)
+            for _ in range(args.warmup):
+                one_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        fence()
+        regions.append(time.perf_counter() - t0)
     per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor(regions, dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every region: the slowest rank's time
+        regions = [float(v) for v in t.cpu().tolist()]
+    elapsed = sorted(regions)[len(regions) // 2]      # the median region of --steps steps
+    total_elapsed = sum(regions)
+    if world > 1:
         # what each rank spent in its OWN shard's steps and how many adaptive sub-steps its envs took: the imbalance SURVEY 8e names
         # as the scaling risk (a step ends with its slowest shard) is then visible next to the max-over-ranks figure
         c_r = solver.solver_counters()
@@ -692,10 +787,10 @@ def main():
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         allr = torch.stack(parts).cpu().tolist()
-        ms = [1e3 * r[0] / args.steps for r in allr]
+        ms = [1e3 * r[0] / (args.steps * n_rep) for r in allr]
         per_rank = {"shard_ms_per_step": [round(v, 3) for v in ms], "min_ms": round(min(ms), 3), "max_ms": round(max(ms), 3),
                     "imbalance": round(max(ms) / max(min(ms), 1e-9), 3),
-                    "mean_substeps_per_sim_step": [round(r[1] / max(args.steps * env._n_sim_steps, 1), 2) for r in allr]}
+                    "mean_substeps_per_sim_step": [round(r[1] / max(args.steps * n_rep * env._n_sim_steps, 1), 2) for r in allr]}
     prof = solver.profile_read()
     solver.profile_enable(False)
     its = solver_iterations(solver)
@@ -722,6 +817,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "repeats": n_rep,
+            "value_spread": {"median": n_total * args.steps / elapsed, "min": n_total * args.steps / max(regions), "max": n_total * args.steps / min(regions),
+                             "regions_ms": [round(1e3 * v, 3) for v in regions],
+                             "doc": "value = the median of `repeats` back-to-back timed regions of `steps` steps each"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -741,10 +840,12 @@ def main():
                        "advection_solver_form": solver.advection_solver_form() if single_block else None,
                        "velocity_solver": velocity_solver_desc(env, solver) if single_block else None,
                        "solver_iterations": its, "capped_solves": capped_solves(its),
+                       "floor_released_solves": (solver_switches(solver) or {}).get("jacobi_floor_released") if single_block else None,
                        "iters_are": "iterations per solve (counts; 0 = initial residual met the tolerance)",
                        "launches_per_piso_step": launches_per_piso_step(prof, its) if single_block else None,
-                       "step_GBps": step_gbps(prof, elapsed) if single_block else None,
-                       "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_sim, 1), 2),
+                       "solver_kernels_GBps": step_gbps(prof, total_elapsed) if single_block else None,
+                       "whole_step_GBps_model": whole_step_gbps_model(prof, total_elapsed, its, solver) if single_block else None,
+                       "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_rep * n_sim, 1), 2),
                        "per_rank": per_rank, "switches": solver_switches(solver)},
             "roofline": roof,
             "legs": {},
@@ -752,6 +853,17 @@ def main():
         if not args.no_micro:
             out["poisson_256"] = poisson_micro(device)
     penv.close()
+    if world > 1:
+        # the multi-GPU run also times the env the 7x scaling target names (every rank takes part; rank 0 prints it in the same line)
+        try:
+            cyl = cylinder_sharded(world, rank, device, coll_device, args.share_gpu, envs_per_gpu=args.envs_per_gpu)
+        except Exception as exc:      # (the headline line must survive)
+            cyl = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if rank == 0:
+            out["cylinder_sharded"] = cyl
+    if rank == 0:
+        out["config"]["collective_backend"] = dist.get_backend() if dist.is_initialized() else None
+        out["config"]["collective_world_size"] = dist.get_world_size() if dist.is_initialized() else 1
     if rank == 0 and world == 1 and not args.no_micro:
         t_legs = time.perf_counter()
 
@@ -807,6 +919,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         write_detail(out)
         print(compact_line(out), flush=True)
+    if world > 1 and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

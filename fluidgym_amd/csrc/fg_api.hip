@@ -743,11 +743,11 @@ extern "C" int fg_config_dump(fg_handle s, char* buf, int n) {
         "\"FG_BICG3_BXL\": %d, \"FG_BICG3_MIX\": %d, \"FG_REDUCE_WGS\": %d, \"FG_CG_WGS_PER_SLOT\": %d, \"FG_TRIDIAG_CB\": %d, \"FG_HELM_CB\": %d, "
         "\"FG_HELM_ROWFORM\": %d, \"FG_FD_ROWMEAN\": %d, \"FG_POLL_SPIN\": %d, \"FG_PROF_PERIOD\": %d, \"fast_transform_x\": %d, \"fd_preconditioner\": %d, "
         "\"helmholtz\": %d, \"advection_preconditioner\": %d, \"advection_from_result\": %d, \"return_best\": %d, \"cg_reset_steps\": %d, "
-        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d, \"FG_FCG_FIRST\": %d, \"FG_JAC_WARM\": %d, \"first_iterate_polls\": %ld, \"unstored_pressure_solves\": %ld, \"FG_JAC_SPEC\": %d, \"FG_FCG_SPEC\": %d, \"jacobi_speculation_misses\": %ld}",
+        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d, \"FG_FCG_FIRST\": %d, \"FG_JAC_WARM\": %d, \"first_iterate_polls\": %ld, \"unstored_pressure_solves\": %ld, \"FG_JAC_SPEC\": %d, \"FG_FCG_SPEC\": %d, \"jacobi_speculation_misses\": %ld, \"jacobi_floor_released\": %ld}",
         FG_F64 ? "f64" : "f32", s->cg_fused, s->bicg_pfused, s->bicg_fused, s->bicg_sub, s->bicg3_force, s->bicg3_bxl, s->bicg3_mix, s->reduce_wgs,
         s->cg_wgs_per_slot, s->tridiag_cb, s->helm_cb_pref, s->helm_rowform_off ? 0 : 1, s->fd_rowmean, s->poll.spin, s->prof.period, s->fd_dct_x, s->fd_Qx ? 1 : 0,
         s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis, s->adv_jacobi, s->fcg_first, s->jac_warm,
-        s->fcg_first_polls, s->fcg_unstored, s->jac_spec, s->fcg_spec, s->jac_spec_missed);
+        s->fcg_first_polls, s->fcg_unstored, s->jac_spec, s->fcg_spec, s->jac_spec_missed, s->jac_floor_released);
     if (len >= n) return len + 1;
     memcpy(buf, tmp, (size_t)len + 1);
     return FG_OK;

@@ -700,6 +700,7 @@ struct fg_state {
     // once they ran -- a verdict that does not end the solve there (0.6 % of the soak's solves: profiles/r05_soak_first_iterate.jsonl) sends the whole solve
     // round again without the speculation (outcome 5 of fg_jacobi_solve, jac_spec_missed).  FG_JAC_SPEC=0 switches it off.
     int (*jac_spec_fn)(void*); void* jac_spec_ctx; mutable int jac_spec_done; int jac_spec; long jac_spec_missed;
+    long jac_floor_released = 0;   // systems the streaming sweeps ended on the fp32-floor rule (measured residual above the tolerance): fg_config_dump
     int jac_prefactor;      // FG_JAC_PREFACTOR (default 1): fg_fd_rowmean_prefactor behind the sweeps' check kernel
     int jac_warm;      // the Jacobi sweeps of the velocity systems start from the block velocity: 1 always, 0 never (the BiCGStab start vector), -1 (default) on the grids where that saves a pass (fg_jacobi.hip: jac_warm_start)
     mutable long fcg_unstored, fcg_first_polls;      // solves that stored no x | solves whose first iterate was polled (fg_config_dump)

@@ -409,7 +409,8 @@ __global__ void k_jac_stream_check(FgDacc* __restrict__ acc, int32_t* __restrict
         for (int q = 0; q < nc; ++q) {
             const float now = fg_rms(acc_ld(acc + (size_t)(b * nc + q) * FG_ACC_DOUBLES + slot_now), n);
             const float floor32 = ax_slot >= 0 ? 1.1920929e-7f * fg_rms(acc_ld(acc + (size_t)(b * nc + q) * FG_ACC_DOUBLES + ax_slot), n) : 0.f;
-            bad = bad || !isfinite(now); all = all && (now < tol || now < floor32);
+            // (the floor rule is capped at 8 x the tolerance: beyond that the measure is not rounding, the system is not solved -- ADVICE r5)
+            bad = bad || !isfinite(now); all = all && (now < tol || (now < floor32 && now < 8.f * tol));
         }
         for (int q = 0; q < nc; ++q) {
             const int sys = b * nc + q;
@@ -741,6 +742,8 @@ static int jacobi_stream_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* 
     for (int i = 0; i < nsys; ++i) {
         used_max = s->info_pinned[i].used_iterations + 1 > used_max ? s->info_pinned[i].used_iterations + 1 : used_max;
         if (info_host) info_host[i] = s->info_pinned[i];
+        // released by the fp32-floor rule: converged with a measured residual at or above the tolerance (reported, not hidden: fg_config_dump)
+        if (s->info_pinned[i].converged && s->info_pinned[i].used_iterations >= 0 && s->info_pinned[i].final_residual >= a.tol) s->jac_floor_released += 1;
     }
     H.fails = 0; H.sweeps = used_max > 0 ? used_max : FIRST;
     *outcome = 1;
