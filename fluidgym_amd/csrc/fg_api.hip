@@ -137,7 +137,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     { const char* ev = getenv("FG_ADV_JACOBI"); s->adv_jacobi = ev ? atoi(ev) : 0; s->adv_jacobi_env = ev ? 1 : 0; }
     for (int k = 0; k < 4; ++k) s->jac_hist[k] = FgJacHist{0, 0, 0};
     s->jac_solves = s->jac_fallbacks = 0;
-    FG_HIP_CHECK(hipHostMalloc(&s->jac_prev, sizeof(float) * 2 * nsys));
+    FG_HIP_CHECK(hipHostMalloc(&s->jac_prev, sizeof(float) * 4 * nsys));   // (on-chip form: [nsys] previous residual | [nsys][2] residuals of passes 0 and 1; streaming form: [nsys][2])
     s->jac_rA_epoch = -1;
     FG_HIP_CHECK(hipMalloc(&s->fcg_alpha, sizeof(double) * 2 * (size_t)g.B));
     FG_HIP_CHECK(hipMemset(s->fcg_alpha, 0, sizeof(double) * 2 * (size_t)g.B));
@@ -778,6 +778,9 @@ extern "C" int fg_multi_step(fg_handle s, const fg_sim_options* o, int32_t n, co
                     if (int rc = fg_bind(s, FG_BOUND_VELOCITY + f, const_cast<fg_real*>(p))) return rc;
         if (int rc = fg_single_step(s, o, out_6n + 6 * (size_t)k, flux_host, stream)) return rc;
         if (steps_done) *steps_done = k + 1;
+        // the loop this call stands in for (Simulation.multi_step) stops at the first step whose solves did not converge unless the
+        // best iterate is accepted (pressure_return_best_result): so does this one -- *steps_done says how far it got
+        if (out_6n[6 * (size_t)k + 5] == 0 && !s->cg_return_best) break;
     }
     return FG_OK;
 }
@@ -910,8 +913,22 @@ extern "C" int fg_make_divergence_free(fg_handle s, fg_real tol, int max_iterati
 
 extern "C" int fg_reset_solver_state(fg_handle s, void* stream) {
     FG_REQUIRE(s && s->velocity, FG_ERR_NOT_BOUND, "velocity not bound");
+    for (int k = 0; k < 4; ++k) s->jac_hist[k] = FgJacHist{0, 0, 0};   // the sweeps' back-off decides WHICH solver runs: not carried across a reset
     FG_HIP_CHECK(hipMemsetAsync(s->p_result, 0, sizeof(fg_real) * (size_t)s->grid.B * s->grid.n, (hipStream_t)stream));
     return fg_launch_copy_active(s, nullptr, s->velocity, s->vel_result, s->grid.dims, (hipStream_t)stream);
+}
+
+// What a handle remembers between solves besides the bound fields and decides which iteration runs: per solve kind the sweeps the
+// last Jacobi solve needed (where the next one polls first), the solves still to skip after a failure and the failures in a row
+// (fg_jacobi.hip).  get_state / set_state carry these 12 words so that a restored state replays bit for bit.
+extern "C" int fg_solver_hints(fg_handle s, int32_t* hints12, int32_t set) {
+    FG_REQUIRE(s != nullptr && hints12 != nullptr, FG_ERR_INVALID_ARG, "fg_solver_hints: bad argument");
+    for (int k = 0; k < 4; ++k) {
+        FgJacHist& H = s->jac_hist[k];
+        if (set) { H.sweeps = hints12[3 * k]; H.skip = hints12[3 * k + 1]; H.fails = hints12[3 * k + 2]; }
+        else { hints12[3 * k] = H.sweeps; hints12[3 * k + 1] = H.skip; hints12[3 * k + 2] = H.fails; }
+    }
+    return FG_OK;
 }
 
 extern "C" int fg_get_buffer(fg_handle s, int which, fg_real** out_ptr, int64_t* out_count) {

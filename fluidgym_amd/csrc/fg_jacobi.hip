@@ -34,6 +34,8 @@
 //
 // Grids without a region shape (3-D) get the same sweeps one launch at a time (k_jac_stream, below).
 // fp32 library only (the fp64 build keeps the plain recurrences).
+#include <mutex>
+
 #include "fg_internal.h"
 #include "fg_bicg.h"
 
@@ -79,6 +81,13 @@ __device__ __forceinline__ bool jac_verdict(const JacArgs& a, int b, int pass, b
             jac_mark(a, sys0, c0, pass * a.sweeps - 1);      // (used_iterations: the 0-based index of the last sweep, as the Krylov solvers count)
             jac_mark(a, sys0 + 1, c1, pass * a.sweeps - 1);
         } else {
+            // (the sums of passes 0 and 1 outlive the ring in slots 3 and 4: the give-up rule of the host reads THEM, whatever it has
+            //  enqueued ahead -- ADVICE r5: which solver runs must not depend on the handle's history)
+            if (pass == 2 || pass == 3) {      // (a check and the pass behind it both come here: the second finds the entry already cleared)
+                const double v0 = acc_ld(A0 + (pass + 1) % 3), v1 = acc_ld(A1 + (pass + 1) % 3);
+                if (v0 != 0.0) acc_st(A0 + 1 + pass, v0);
+                if (v1 != 0.0) acc_st(A1 + 1 + pass, v1);
+            }
             acc_st(A0 + (pass + 1) % 3, 0.0);
             acc_st(A1 + (pass + 1) % 3, 0.0);
         }
@@ -281,6 +290,12 @@ __global__ void k_jac_check(JacArgs a, fg_solve_info* __restrict__ mirror, float
     const FgDacc* A1 = A0 + FG_ACC_DOUBLES;
     float p0 = -1.f, p1 = -1.f;      // (read before the verdict: an env that goes on resets this ring entry for pass a.pass + 1)
     if (a.pass >= 2) { const int e2 = (a.pass - 2) % 3; p0 = fg_rms(acc_ld(A0 + e2), a.n); p1 = fg_rms(acc_ld(A1 + e2), a.n); }
+    // the residuals passes 0 and 1 measured (ring entries 0 and 1 until passes 2 and 3 moved them to slots 3 and 4)
+    float f00 = -1.f, f01 = -1.f, f10 = -1.f, f11 = -1.f;
+    if (a.pass >= 2) {
+        f00 = fg_rms(acc_ld(A0 + (a.pass >= 3 ? 3 : 0)), a.n); f10 = fg_rms(acc_ld(A1 + (a.pass >= 3 ? 3 : 0)), a.n);
+        f01 = fg_rms(acc_ld(A0 + (a.pass >= 4 ? 4 : 1)), a.n); f11 = fg_rms(acc_ld(A1 + (a.pass >= 4 ? 4 : 1)), a.n);
+    }
     const bool done = jac_verdict(a, b, a.pass, true);
     if (!done) {
         const int e = (a.pass - 1) % 3;
@@ -289,6 +304,8 @@ __global__ void k_jac_check(JacArgs a, fg_solve_info* __restrict__ mirror, float
         a.info[sys0].converged = a.info[sys0 + 1].converged = 0;
     }
     prev[sys0] = p0; prev[sys0 + 1] = p1;
+    float* first2 = prev + 2 * B;      // [2 B][2]
+    first2[2 * sys0] = f00; first2[2 * sys0 + 1] = f01; first2[2 * (sys0 + 1)] = f10; first2[2 * (sys0 + 1) + 1] = f11;
     mirror[sys0] = a.info[sys0]; mirror[sys0 + 1] = a.info[sys0 + 1];
     fg_poll_publish(poll, sys0);
     fg_poll_publish(poll, sys0 + 1);
@@ -442,9 +459,15 @@ constexpr size_t JAC_LDS = sizeof(float) * (2 * 2 * 2 * (JAC_CELLS / 4) + 2 * 2 
 
 #define JAC_FOR_EACH_KERNEL(X) X(16, false) X(32, false) X(64, false) X(128, false) X(8, true) X(16, true) X(32, true) X(64, true)
 
-// dynamic LDS above 64 KB needs an explicit opt-in per kernel (once per process)
+// dynamic LDS above 64 KB needs an explicit opt-in per kernel -- and per DEVICE: the attribute belongs to the device that is current
+// when it is set (a process with handles on two GPUs launched k_jac_pass on the second one without it)
 bool jac_lds_ready() {
-    static int state = 0;      // 0 not tried, 1 granted, -1 refused
+    static std::mutex mu;
+    static int states[64] = {0};      // per device: 0 not tried, 1 granted, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lock(mu);
+    int& state = states[dev];
     if (state == 0) {
         state = 1;
 #define JAC_OPT_IN(Q, XT)                                                                                                              \
@@ -596,21 +619,23 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
     for (;;) {
         if (int rc = check()) return rc;
         bool all = true;
-        double need = 0.0;      // passes still to go, from the contraction of the last pass
+        double need = 0.0;      // passes still to go, from the contraction of the last pass: sizes what is enqueued next, nothing else
         for (int i = 0; i < nsys; ++i) {
             const fg_solve_info& I = s->info_pinned[i];
             if (!I.is_finite) failed = true;
             if (I.converged || !I.is_finite) continue;
             all = false;
             const double r1 = I.final_residual, r0 = s->jac_prev[i];
-            if (r0 > 0.0) {
-                const double c = r1 / r0;
-                if (!(c < 0.7)) failed = true;      // less than a factor 0.7 per pass: not the regime this is for
-                else { const double m = log((double)a.tol / r1) / log(c); need = m > need ? m : need; }
-                // (beyond ~48 sweeps in all the Krylov iteration is the cheaper one: BiCGStab takes 10-15 iterations on such systems)
-                if ((passes + need) * S > 48.0) failed = true;
-            } else {
-                need = need > 1.0 ? need : 1.0;
+            if (r0 > 0.0 && r1 > 0.0 && r1 < r0) { const double m = log((double)a.tol / r1) / log(r1 / r0); need = m > need ? m : need; }
+            else need = need > 1.0 ? need : 1.0;
+            // GIVE UP from the residuals passes 0 and 1 measured -- a function of the system, not of how many passes the previous
+            // solve of the kind made this one enqueue ahead: less than a factor 0.7 per pass is not the regime this is for, and beyond
+            // ~48 sweeps in all the Krylov iteration is the cheaper one (BiCGStab takes 10-15 iterations on such systems)
+            const double f0 = s->jac_prev[nsys + 2 * i], f1 = s->jac_prev[nsys + 2 * i + 1];
+            if (f0 > 0.0 && f1 > 0.0) {
+                const double c = f1 / f0;
+                if (!(c < 0.7)) failed = true;
+                else if ((2.0 + log((double)a.tol / f1) / log(c)) * S > 48.0) failed = true;
             }
         }
         if (all && !failed) { ok = true; break; }
@@ -623,7 +648,8 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
         int more = (int)ceil(need);
         if (more < 1) more = 1;
         more += more & 1;                        // in pairs: the last pass of every batch writes the result vector
-        if (passes + more > max_passes) { failed = true; break; }
+        if (passes >= max_passes) { failed = true; break; }      // out of passes (a fixed bound: a.max_iterations)
+        if (passes + more > max_passes) more = ((max_passes - passes) & ~1) > 0 ? ((max_passes - passes) & ~1) : 2;
         if (int rc = enqueue(more)) return rc;
     }
     if (int prc = fg_prof_collect(s, st)) return prc;

@@ -12,6 +12,7 @@
 // register chunks (one dependent FMA per row), all waves store -- the scheme of k_tridiag_y_lds (fg_fdprecond.hip), with
 // per-env, per-cell coefficients.  Needs nx % 4 == 0 and 3 x roundup(ny, 16) x 256 B of LDS; otherwise a streaming kernel with one
 // thread per column.
+#include <mutex>
 #include "fg_internal.h"
 
 namespace {
@@ -449,9 +450,15 @@ __global__ __launch_bounds__(256) void k_helm_apply_y(HelmArgs a, const float* r
     }
 }
 
-bool line_lds_ready(size_t bytes) {   // dynamic LDS above 64 KB needs an explicit opt-in per kernel
-    static size_t granted = 0;
-    static bool failed = false;
+bool line_lds_ready(size_t bytes) {   // dynamic LDS above 64 KB needs an explicit opt-in per kernel and per device
+    static std::mutex mu;
+    static size_t granted_dev[64] = {0};
+    static bool failed_dev[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& granted = granted_dev[dev];
+    bool& failed = failed_dev[dev];
     if (bytes <= granted) return true;
     if (failed) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_line_apply_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess ||
@@ -524,7 +531,12 @@ static int helm_cb(const fg_state* s) {      // columns per workgroup of the app
     const int cb = s->helm_cb_pref == 64 ? 64 : 32;
     const size_t bytes = (size_t)3 * nyp * cb * sizeof(float);
     if (bytes > 160 * 1024) return 0;
-    static size_t granted = 0;
+    static std::mutex mu;
+    static size_t granted_dev[64] = {0};      // per device: the attribute belongs to the device current when it is set
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& granted = granted_dev[dev];
     if (bytes > granted) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_helm_apply_y<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_helm_apply_y<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {

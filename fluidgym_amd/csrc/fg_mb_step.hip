@@ -1164,11 +1164,16 @@ extern "C" int fg_mb_debug_bicgstab(fg_mb_handle s, mb_real tol, int32_t max_ite
     return FG_OK;
 }
 
-extern "C" int fg_mb_solver_hints(fg_mb_handle s, int32_t* hints36, int32_t set) {
-    FG_REQUIRE(s != nullptr && hints36 != nullptr, FG_ERR_INVALID_ARG, "fg_mb_solver_hints: bad argument");
+extern "C" int fg_mb_solver_hints(fg_mb_handle s, int32_t* hints48, int32_t set) {
+    FG_REQUIRE(s != nullptr && hints48 != nullptr, FG_ERR_INVALID_ARG, "fg_mb_solver_hints: bad argument");
     int* trial[4] = {&s->ml_bicg_attempts, &s->ml_bicg_failures, &s->ml_bicg_skip, &s->ml_bicg_backoff};
-    for (int k = 0; k < 32; ++k) { if (set) s->pred_bicg[k] = hints36[k]; else hints36[k] = s->pred_bicg[k]; }
-    for (int k = 0; k < 4; ++k) { if (set) *trial[k] = hints36[32 + k]; else hints36[32 + k] = *trial[k]; }
+    for (int k = 0; k < 32; ++k) { if (set) s->pred_bicg[k] = hints48[k]; else hints48[k] = s->pred_bicg[k]; }
+    for (int k = 0; k < 4; ++k) { if (set) *trial[k] = hints48[32 + k]; else hints48[32 + k] = *trial[k]; }
+    // the velocity sweeps' back-off (mb_jacobi): whether a solve goes through the sweeps or straight to BiCGStab
+    for (int k = 0; k < 4; ++k) {
+        if (set) { s->jac_skip[k] = hints48[36 + k]; s->jac_fails[k] = hints48[40 + k]; s->jac_sweeps[k] = hints48[44 + k]; }
+        else { hints48[36 + k] = s->jac_skip[k]; hints48[40 + k] = s->jac_fails[k]; hints48[44 + k] = s->jac_sweeps[k]; }
+    }
     return FG_OK;
 }
 

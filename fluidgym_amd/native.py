@@ -359,6 +359,9 @@ class NativeSolver:
         if boundary_schedule:
             for face, t in boundary_schedule.items():      # what the handle is bound to now
                 self.bvel[int(face)] = t[max(min(done.value, n - 1), 0)]
+        # the steps that completed (all of them, or up to a failure): kept on the handle so that a caller that catches the exception
+        # below can still account for them (Simulation.multi_step advances its step / time counters from this)
+        self.last_multi_results = [(bool(out[6 * k + 5]), [int(out[6 * k + i]) for i in range(4)], int(out[6 * k + 4])) for k in range(min(done.value, n))]
         if rc == L.FG_ERR_FLUX_BALANCE:
             raise RuntimeError(
                 "Domain boundary fluxes not balanced, cannot proceed with simulation step. "
@@ -366,7 +369,14 @@ class NativeSolver:
         if rc == L.FG_ERR_NOT_FINITE:
             raise LinsolveError("linear solve produced a non-finite residual")
         L.check(rc)
-        return [(bool(out[6 * k + 5]), [int(out[6 * k + i]) for i in range(4)], int(out[6 * k + 4])) for k in range(n)]
+        return self.last_multi_results
+
+    def solver_hints(self, values=None):
+        """The 12 words the handle remembers between solves and that decide which iteration runs (``fg_solver_hints``): read as a
+        list, or written from ``values``."""
+        buf = (ctypes.c_int32 * 12)(*([0] * 12 if values is None else [int(v) for v in values]))
+        L.check(self.lib.fg_solver_hints(self.handle, buf, 0 if values is None else 1), lib=self.lib)
+        return list(buf)
 
     def reset_solver_state(self):
         L.check(self.lib.fg_reset_solver_state(self.handle, _stream(self.device)), lib=self.lib)

@@ -400,6 +400,8 @@ class Domain:
             snap["velocity_source"] = s.velocity_source.clone()
         snap["bvel"] = {f: t.clone() for f, t in s.bvel.items()}
         snap["bscal"] = {f: t.clone() for f, t in s.bscal.items()}
+        if hasattr(s, "solver_hints"):     # which iteration the next solves run (the sweeps' back-off): part of a bit-exact replay
+            snap["solver_hints"] = s.solver_hints()
         return snap
 
     def Restore(self, snap: dict):
@@ -414,4 +416,6 @@ class Domain:
             s.bvel[f].copy_(t)
         for f, t in snap["bscal"].items():
             s.bscal[f].copy_(t)
+        if "solver_hints" in snap and hasattr(s, "solver_hints"):
+            s.solver_hints(snap["solver_hints"])
         s.copy_velocity_result_from_blocks()

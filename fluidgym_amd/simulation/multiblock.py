@@ -599,8 +599,10 @@ class MultiBlockDomain:
 
     # ---- what FluidEnv needs of a Domain
     def solver_hints(self, values=None) -> torch.Tensor:
-        """The 36 words a handle remembers between solves (``fg_mb_solver_hints``): read, or written from ``values``."""
-        buf = (ctypes.c_int32 * 36)(*([0] * 36 if values is None else [int(v) for v in values]))
+        """The 48 words a handle remembers between solves (``fg_mb_solver_hints``): read, or written from ``values`` (a 36-word
+        snapshot of rounds 3-5 is padded: the sweeps' back-off starts cleared)."""
+        vals = [0] * 48 if values is None else ([int(v) for v in values] + [0] * 48)[:48]
+        buf = (ctypes.c_int32 * 48)(*vals)
         L.check(self.lib.fg_mb_solver_hints(self.handle, buf, 0 if values is None else 1))
         return torch.tensor(list(buf), dtype=torch.int32)
 

@@ -293,6 +293,18 @@ class Simulation:
             bounds, velm_t, otol = self.outflow
             faces = [b.face for b in bounds]
             velm = np.asarray(velm_t.detach().cpu() if isinstance(velm_t, torch.Tensor) else velm_t, dtype=np.float64).reshape(-1)
+        def account(results):
+            good_ = True
+            for ok, stats, n_sub in results:
+                self.last_stats, self.substep_count = stats, n_sub
+                self.total_step += n_sub
+                self.total_time += self.time_step if self.substeps == -1 else self.time_step * max(self.substeps, 1)
+                if not ok and not self.pressure_return_best_result:
+                    _LOG.error("linear solve did not converge (iterations %s)", stats)
+                    good_ = False
+            return good_
+
+        s.last_multi_results = []
         try:
             res = s.multi_step(
                 n, self.time_step, self.adaptive_CFL, boundary_schedule, adaptive=(self.substeps == -1), substeps=max(self.substeps, 1),
@@ -303,17 +315,13 @@ class Simulation:
                 max_iterations=self.linear_solve_max_iterations, buoyancy_axis=bax, buoyancy_factor=bfac,
                 pressure_warm_start=self.pressure_warm_start)
         except LinsolveError:
+            account(getattr(s, "last_multi_results", []))      # the steps that did complete: fields and counters stay in step
             _LOG.exception("Simulation failed in step (total step %d):", self.total_step)
             return False
-        good = True
-        for ok, stats, n_sub in res:
-            self.last_stats, self.substep_count = stats, n_sub
-            self.total_step += n_sub
-            self.total_time += self.time_step if self.substeps == -1 else self.time_step * max(self.substeps, 1)
-            if not ok and not self.pressure_return_best_result:
-                _LOG.error("linear solve did not converge (iterations %s)", stats)
-                good = False
-        return good
+        except RuntimeError:                                   # the flux-balance guard: the same accounting, then the caller's problem
+            account(getattr(s, "last_multi_results", []))
+            raise
+        return account(res)
 
     def _PISO_adaptive_step(self, CFL_cond: Optional[float] = None, max_substeps: int = 1000) -> bool:
         """Per-env version of ``_PISO_adaptive_step`` (PISOtorch_simulation.py:2004-2064): before every

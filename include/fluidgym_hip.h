@@ -317,6 +317,10 @@ enum fg_buffer {
 };
 /* velocityResult := block velocity, pressureResult := 0 (call after re-initialising the fields) */
 int fg_reset_solver_state(fg_handle h, void* stream);
+/* The single-block handle's counterpart of fg_mb_solver_hints: per solve kind (4) the sweeps the last Jacobi solve needed, the
+ * solves still to skip after a failure, the failures in a row (csrc/fg_jacobi.hip) -- 12 words that decide which iteration runs.
+ * Domain.Clone / Restore carry them (reference: envs/fluid_env.py:1320-1363); fg_reset_solver_state clears them.  set = 0 reads. */
+int fg_solver_hints(fg_handle h, int32_t* hints12, int32_t set);
 int fg_get_buffer(fg_handle h, int which, fg_real** out_ptr, int64_t* out_count);
 /* device-to-device copy of a solver vector into a caller buffer of fg_get_buffer's count */
 int fg_read_buffer(fg_handle h, int which, fg_real* dst, void* stream);
@@ -497,9 +501,10 @@ int fg_mb_ladder(fg_mb_handle h, int64_t* out4_host, int32_t force_mask);
 int fg_mb_debug_cycles(fg_mb_handle h, uint64_t* out12_host);
 /* What a handle remembers between solves besides the bound fields: where the previous solve of each place in the step finished
  * (its next solve polls there first; a verified / refined BiCGStab re-opens and restarts at its polls, so the schedule is part of
- * the arithmetic) and the back-off state of the multilevel trial.  get_state / set_state of the envs carry these 36 words so that
- * a restored state replays bit for bit (reference: envs/fluid_env.py:1320-1363).  set = 0 reads, 1 writes. */
-int fg_mb_solver_hints(fg_mb_handle h, int32_t* hints36, int32_t set);
+ * the arithmetic), the back-off state of the multilevel trial and (round 6) the back-off of the velocity sweeps -- skip, failures,
+ * sweeps per non-orthogonal pass -- which decides whether a solve runs the sweeps or BiCGStab.  get_state / set_state of the envs
+ * carry these 48 words so that a restored state replays bit for bit (reference: envs/fluid_env.py:1320-1363).  set = 0 reads, 1 writes. */
+int fg_mb_solver_hints(fg_mb_handle h, int32_t* hints48, int32_t set);
 /* as fg_solver_counters, for the multi-block path */
 int fg_mb_solver_counters(fg_mb_handle h, int64_t* out13_host, int32_t reset);
 /* The tuning / diagnosis switches a handle runs under (the FG_* environment variables read ONCE at create time, docs/SWITCHES.md,

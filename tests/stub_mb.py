@@ -71,7 +71,7 @@ def install():
     D.set_pressure_multilevel = lambda self, enable=True: None
     D.set_advection_start = lambda self, from_result=False: None
     D.env_status = lambda self: np.zeros(self.batch, np.int32)
-    D.solver_hints = lambda self, values=None: torch.zeros(36, dtype=torch.int32)
+    D.solver_hints = lambda self, values=None: torch.zeros(48, dtype=torch.int32)
     D.solver_counters = lambda self, reset=False: {"piso_steps": self.calls}
     D.boundary_flux_balance = lambda self: np.zeros(self.batch, np.float32)
 

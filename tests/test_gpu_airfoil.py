@@ -207,3 +207,33 @@ def test_3d_env_single_and_multi_agent():
     wall = menv._domain.blocks[2].boundary("-y").reshape(1, 3, 8, -1)
     assert float(wall[0, :, :2].abs().max()) > 1e-3 and float(wall[0, :, 2:].abs().max()) < 1e-6
     menv.close()
+
+
+def test_replay_across_a_retry_of_the_velocity_sweeps():
+    """the velocity sweeps fail on this mesh (contraction 0.8 per sweep) and back off -- the handle skips 8, 16, ... solves
+    before it tries them again, and a retry that lands in one run and not in the other changes which solver ran.  The back-off
+    words travel with ``get_state`` now (``fg_mb_solver_hints``: 48 words), so a replay that crosses a retry repeats bit for bit:
+    three env steps (>= 30 velocity solves) from a snapshot taken with a back-off pending."""
+    # (the full-resolution mesh 40 sim steps after the impulsive start: where tests/test_gpu_jacobi.py sees the sweeps fail)
+    env = fluidgym_amd.make("Airfoil2D-easy-v0", num_envs=2, initial_domain_steps=40, randomize_initial_state=False, episode_length=10)
+    env.reset(seed=5)
+    a = torch.tensor([[0.3, -0.1, 0.2], [0.3, -0.1, 0.2]], device="cuda")
+    env.step(a)
+    hints = env._domain.solver_hints().tolist()
+    assert len(hints) == 48 and (any(hints[36:40]) or any(hints[40:44])), hints      # a back-off is pending
+    hints[36:40] = [3] * 4                                                             # ... and is made short: the next retry is three solves away
+    hints[40:44] = [1] * 4
+    env._domain.solver_hints(hints)
+    s0 = env.get_state()
+    c0 = env._domain.advection_jacobi_counts()
+    for _ in range(3):
+        r1 = env.step(a)
+    u1, p1 = env._domain.velocity.clone(), env._domain.pressure.clone()
+    c1 = env._domain.advection_jacobi_counts()
+    assert c1["handed_to_bicgstab"] > c0["handed_to_bicgstab"], (c0, c1)                # ... and a retry happened inside the replayed span
+    env.set_state(s0)
+    for _ in range(3):
+        r2 = env.step(a)
+    assert torch.equal(env._domain.velocity, u1) and torch.equal(env._domain.pressure, p1)
+    assert torch.equal(r1[1], r2[1])
+    env.close()

@@ -109,6 +109,36 @@ def test_system_without_diagonal_dominance_goes_to_bicgstab():
     assert [i.used_iterations for i in info] == [i.used_iterations for i in ib] == [i.used_iterations for i in info2]
 
 
+@pytest.mark.parametrize("dt, handed", [(0.05, 1), (0.004, None)])
+def test_which_solver_runs_does_not_depend_on_the_handles_history(dt, handed):
+    """the give-up rule of the on-chip sweeps (less than a factor 0.7 per pass, or more than ~48 sweeps needed) used the
+    residuals of the last two passes the host happened to have enqueued -- a count it takes from the previous solve of the kind.
+    It reads the residuals of passes 0 and 1 now (kept beside the ring by the passes that would overwrite them), so a handle that
+    remembers a 12-sweep solve and one that remembers a 48-sweep solve (``fg_solver_hints``) take the same decision and deliver
+    the same bits: a system the sweeps give up on (dt 0.05), and a slowly contracting one near the boundary of the rule (dt 0.004)."""
+    case = make_case(dims=2, n=(256, 64), fixed_axes=(0, 1), B=2, seed=5, stretch=0.0, nu=0.05, vel_scale=0.5)
+    out = []
+    for remembered in (0, 12, 48):
+        ns = case.native()
+        ns.set_advection_jacobi(True)
+        ns.set_advection_start(False)
+        h = ns.solver_hints()
+        assert len(h) == 12
+        ns.solver_hints([remembered, 0, 0] * 4)
+        assert ns.solver_hints() == [remembered, 0, 0] * 4
+        ns.setup_advection(dt)
+        info = ns.solve_advection(tol=1e-6)
+        out.append((_np(ns.buffer(3, (case.B, 2) + case.shape)), ns.advection_jacobi_counts(), [i.used_iterations for i in info], ns.solver_hints()))
+        ns.reset_solver_state()
+        assert ns.solver_hints() == [0] * 12          # the back-off does not survive a reset
+        ns.close()
+    for x, counts, its, hints in out[1:]:
+        assert counts == out[0][1], (counts, out[0][1])
+        assert np.array_equal(x, out[0][0]) and its == out[0][2]
+    if handed is not None:
+        assert out[0][1]["handed_to_bicgstab"] == handed and any(out[0][3][1::3])      # it backs off (the skip word of its solve kind)
+
+
 def test_bits_reproduce_and_envs_do_not_see_each_other():
     case = make_case(dims=2, n=(256, 128), fixed_axes=(0, 1), B=4, seed=11, stretch=0.0, nu=2e-3, vel_scale=0.5)
     dt = [1e-3, 3e-3, 5e-4, 2e-3]
