@@ -80,6 +80,13 @@ def poisson_micro(device, n=256, iters=20):
     ms = timed(lambda: ns.poisson_jacobi(rA, b, x, iters, 0.8), 3) / iters
     out["jacobi_sweep"] = {"ms": ms, "bytes_per_cell": 16, "GBps": 16 * cells / ms / 1e6,
                            "frac": 16 * cells / ms / 1e6 / HBM_PEAK_GBS}
+    # red-black Gauss-Seidel (the other relaxation `north_star` names): one sweep = two colour passes of the same z-marching kernel,
+    # in place; each pass reads rA and x in full and b / writes x for its colour: 2 x (4 + 4) + 4 + 4 = 24 B per cell and sweep
+    x.zero_()
+    ms = timed(lambda: ns.poisson_rbgs(rA, b, x, iters, 1.0), 3) / iters
+    out["rbgs_sweep"] = {"ms": ms, "bytes_per_cell": 24, "GBps": 24 * cells / ms / 1e6, "frac": 24 * cells / ms / 1e6 / HBM_PEAK_GBS,
+                         "note": "two colour passes per sweep (k_poisson3_march<1>, in place)"}
+    x.zero_()
     y = torch.empty_like(x)
     ms = timed(lambda: ns.poisson_apply(rA, b, y), 10)
     out["apply"] = {"ms": ms, "bytes_per_cell": 12, "GBps": 12 * cells / ms / 1e6, "frac": 12 * cells / ms / 1e6 / HBM_PEAK_GBS}

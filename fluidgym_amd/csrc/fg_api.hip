@@ -116,7 +116,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     s->double_fallback = 0; s->ladder_force = 0; s->r64_buf = nullptr; s->r64_acc = nullptr;
     for (int k = 0; k < 4; ++k) s->rung_count[k] = 0;
     s->fd_lam = nullptr; s->helm_diag = s->helm_lower = s->helm_upper = s->helm_tmp = nullptr;
-    { const char* ev = getenv("FG_CG_WGS_PER_SLOT"); s->cg_wgs_per_slot = (ev && atoi(ev) > 0) ? atoi(ev) : 256; }
+    s->cg_wgs_per_slot = 256;      // (FG_CG_WGS_PER_SLOT until round 5: never changed by a test or a bench leg -- a constant since round 6)
     // FG_BICG3: z-marching two-kernel BiCGStab in 3-D (fg_bicgstab3d.hip): 0 never | > 0 always, with that z-chunk length (tests on
     // small grids) | unset: when the grid fits the tiles and fills the chip.  FG_BICG3_BXL: 16 / 32 float4 lanes along x (tile shape)
     { const char* ev = getenv("FG_BICG3"); s->bicg3_force = ev ? atoi(ev) : -1; }
@@ -125,8 +125,8 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     { const char* ev = getenv("FG_REDUCE_WGS"); s->reduce_wgs = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("FG_BICG3_MIX"); s->bicg3_mix = ev ? atoi(ev) : 3; }   // bit 0: kernel a, bit 1: kernel b as z-march (debugging)
     { const char* ev = getenv("FG_BICG_FUSED"); s->bicg_fused = ev ? atoi(ev) : 1; }   // 0 five kernels | 1 two kernels in 2-D (default) | 2 two kernels in 3-D as well   // read once, never on the step path
-    { const char* ev = getenv("FG_TRIDIAG_CB"); s->tridiag_cb = ev ? atoi(ev) : 64; }      // 32: half-width column blocks in k_tridiag_y_lds (measured: no gain)
-    { const char* ev = getenv("FG_HELM_CB"); s->helm_cb_pref = ev ? atoi(ev) : 32; }
+    s->tridiag_cb = 64;            // (FG_TRIDIAG_CB until round 5; 32 = half-width column blocks in k_tridiag_y_lds: measured, no gain)
+    s->helm_cb_pref = 32;          // (FG_HELM_CB until round 5; 64-column workgroups of k_helm_apply_y: 8.1 against 7.0 us)
     { const char* ev = getenv("FG_HELM_ROWFORM"); s->helm_rowform_off = (ev && atoi(ev) == 0) ? 1 : 0; }   // 0: k_helm_coeffs + the array-form line kernels
     { const char* ev = getenv("FG_FD_ROWMEAN"); s->fd_rowmean = ev ? atoi(ev) : 1; }     // 0: the fused CG keeps the grid's A = 1 factors
     s->fd_row_epoch = -1; s->rA_epoch = 0; s->fd_row_part_epoch = -1;

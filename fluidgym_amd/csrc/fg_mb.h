@@ -168,7 +168,6 @@ struct fg_mb_state {
     // cluster CG (fg_mb_cluster.hip, round 6): FG_CL_G workgroups per env, each owning a contiguous range of the 8 x 8 aggregates;
     // slot s of workgroup g = thread + NT * member.  Tables built by mb_cluster_build behind fg_mb_set_multilevel
     int cl_mode = 1;           // FG_MB_CLUSTER: 0 never, 1 meshes beyond 8 k cells (default), 2 every mesh the tables fit
-    int cl_force_cpt = 0;      // FG_MB_CL_CPT=4: four members per thread in 1024 threads where the mesh allows it (default: eight in 512; A/B runs)
     int cl_near = 1;           // FG_MB_CL_NEAR=0: granule stores always write through (sc1), also when a cluster's workgroups share an XCD
     int cl_max_clusters = 0;   // FG_MB_CL_MAXCL: cap on the clusters of a launch (tests: envs beyond it queue inside the kernel)
     bool cl_on = false;        // tables installed

@@ -470,22 +470,20 @@ extern "C" int fg_mb_create(int32_t dims, int32_t batch, int32_t device, fg_mb_h
     {   // debug switches: the only getenv calls of this path, never on the step path
         const char* e = getenv("FG_MB_BICG_VEC4");
         s->dbg_vec_mask = !e ? 31 : ((e[0] == '1' && e[1] == 0) ? 31 : atoi(e));   // bit per kernel: 1 p, 2 v, 4 s, 8 t, 16 x
-        e = getenv("FG_MB_SCALAR_CG"); s->dbg_scalar_cg = (e && e[0] == '1') ? 1 : 0;
+        s->dbg_scalar_cg = 0;      // (FG_MB_SCALAR_CG until round 5: the one-cell CG kernels are what the fp64 build runs, set below)
         e = getenv("FG_MB_BICG_FUSE"); s->dbg_fuse_st = e ? atoi(e) : 2;   // 0 five kernels, 1 s / t fused, 2 also p / v (default)
-        e = getenv("FG_MB_PRED"); s->dbg_pred = (e && e[0] == '0') ? 0 : 1;
+        s->dbg_pred = 1;           // (FG_MB_PRED until round 5)
         e = getenv("FG_ADV_JACOBI"); s->adv_jacobi = e ? atoi(e) : 0; s->adv_jacobi_env = e ? 1 : 0;      // (as on the single-block path: fg_api.hip)
         e = getenv("FG_MB_ML_FUSE"); s->dbg_ml_fuse = e ? atoi(e) : 1;
-        e = getenv("FG_MB_ML_SB"); s->dbg_ml_sb = e ? atoi(e) : 0;   // systems per workgroup of k_ml_coarse: 4 / 8, 0 = by batch size
+        s->dbg_ml_sb = 0;          // (FG_MB_ML_SB until round 5) systems per workgroup of k_ml_coarse: by batch size
         e = getenv("FG_MB_ML_TRY_CAP"); if (e && atoi(e) > 0) s->dbg_ml_cap = atoi(e);
-        e = getenv("FG_MB_ML_WARMUP"); if (e && atoi(e) > 0) { s->dbg_ml_warmup = atoi(e); s->ml_bicg_skip = s->dbg_ml_warmup; }
-        s->dbg_graph = getenv("FG_MB_GRAPH") != nullptr;
+        s->dbg_graph = 0;          // (FG_MB_GRAPH until round 5: the chunked CG replayed as a hipGraph -- no mesh of the envs takes the chunked CG any more)
         s->dbg_trace = getenv("FG_MB_TRACE") != nullptr;
         if (const char* e = getenv("FG_MB_COMPACT")) s->dbg_compact = atoi(e);
         if (const char* e = getenv("FG_MB_OC_RTG_NT")) s->oc_rtg_nt = atoi(e);   // 1: the register-resident form on 16-24 k cells instead of k_mbc_l2
         s->dbg_fail = getenv("FG_MB_TRACE_FAIL") != nullptr;
         e = getenv("FG_MB_ONCHIP"); s->onchip_mode = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_OC_AGG"); s->dbg_oc_agg = (e && e[0] == '0') ? 0 : 1;
-        e = getenv("FG_MB_CL_CPT"); s->cl_force_cpt = e ? atoi(e) : 0;
         e = getenv("FG_MB_CL_JACOBI"); s->cl_jacobi = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_CL_HALF"); s->cl_half = (e && e[0] == '0') ? 0 : 1;
         e = getenv("FG_MB_CL_NEAR"); s->cl_near = (e && e[0] == '0') ? 0 : 1;

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(FG_BLOCK) __attribute__((amdgpu_waves_per_eu(MODE =
 
 // geometry -----------------------------------------------------------------------------------------
 static int z_shape() {  // lanes along x: 16 (64 x 16 tile), 32 (128 x 8), 64 (256 x 4); FG_ZMARCH_BXL overrides
-    static const int v = [] { const char* e = getenv("FG_ZMARCH_BXL"); return e ? atoi(e) : 0; }();
+    static const int v = 0;      // (FG_ZMARCH_BXL until round 5: the tile width follows the grid)
     return v;
 }
 static int z_pick_bxl(const FgGrid& g) {

@@ -1,7 +1,7 @@
 """Micro-benchmark of the cluster pressure CG (k_mbc_cluster, csrc/fg_mb_cluster.hip) against the one-workgroup kernels on the
 reference's cylinder meshes: fixed iteration count (tolerance 0), time per iteration per launch from the live profiler
 (fg_mb_profile_*), and -- with a -DFG_CL_CYCLES build (FLUIDGYM_AMD_LIB) -- cycles per phase of workgroup 0 of env 0.
-    python profiles/cluster_micro.py [envs=64] [iterations=200] [res=24] [configs: cluster:cpt:near, ...]"""
+    python profiles/cluster_micro.py [envs=64] [iterations=200] [res=24] [configs: cluster:half:near, ...]"""
 import ctypes
 import json
 import os
@@ -17,11 +17,11 @@ from fluidgym_amd.envs.cylinder_grid import build_domain, make_vortex_street_mes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 res = int(sys.argv[3]) if len(sys.argv) > 3 else 24
-configs = (sys.argv[4] if len(sys.argv) > 4 else "0:0:1,1:0:1,1:4:1,1:0:0").split(",")
+configs = (sys.argv[4] if len(sys.argv) > 4 else "0:1:1,1:1:1,1:0:1,1:1:0").split(",")
 mesh = make_vortex_street_mesh(res)
 for cfg in configs:
-    cluster, cpt, near = cfg.split(":")
-    os.environ["FG_MB_CLUSTER"], os.environ["FG_MB_CL_CPT"], os.environ["FG_MB_CL_NEAR"] = cluster, cpt, near
+    cluster, half, near = cfg.split(":")
+    os.environ["FG_MB_CLUSTER"], os.environ["FG_MB_CL_HALF"], os.environ["FG_MB_CL_NEAR"] = cluster, half, near
     dom = build_domain(mesh, 0.01, batch=B)
     dom.set_stall_limit(100000)
     dom.set_pressure_multilevel()
@@ -36,7 +36,7 @@ for cfg in configs:
     k = p["k_mbc_onchip"]
     c = dom.config_dump()
     row = {"cluster": int(cluster), "cpt": c["cluster_members_per_thread"] if c["cluster_on"] else 0, "threads": c["cluster_threads"] if c["cluster_on"] else 0,
-           "near": int(near), "envs": B, "cells": dom.n_cells, "halo_max": c["cluster_halo_max"],
+           "near": int(near), "half": int(half), "envs": B, "cells": dom.n_cells, "halo_max": c["cluster_halo_max"],
            "us_per_iteration": round(1e3 * k["ms"] / max(k["iterations"] / B, 1), 3), "launches": k["launches"],
            "cluster_solves": c["cluster_solves"], "fallbacks": c["cluster_fallbacks"]}
     if int(cluster) and os.environ.get("FLUIDGYM_AMD_LIB", "").endswith("cyc.so"):

@@ -19,10 +19,7 @@ NOTES = {
     "FG_BICG3": ("bits", "z-marching 3-D BiCGStab: 0 never, N always with z-chunk N (tests), unset by the rule"),
     "FG_BICG3_BXL": ("no", "tile lanes along x of the z-marching BiCGStab (16 / 32)"),
     "FG_BICG3_MIX": ("bits", "debugging: bit 0 kernel a, bit 1 kernel b as z-march, bit 2 keep the init kernel"),
-    "FG_CG_WGS_PER_SLOT": ("no", "workgroups sharing one CG accumulator slot (256)"),
     "FG_REDUCE_WGS": ("no", "workgroups per env of the reduction kernels (0 = rule)"),
-    "FG_TRIDIAG_CB": ("no", "columns per workgroup of k_tridiag_y_lds: 64 (default) / 32"),
-    "FG_HELM_CB": ("no", "columns per workgroup of k_helm_apply_y: 32 (default) / 64"),
     "FG_HELM_ROWFORM": ("bits", "0: Helmholtz factors through k_helm_coeffs + the array-form line kernels (IEEE division instead of v_rcp)"),
     "FG_FD_ROWMEAN": ("bits", "1 (default): the fused pressure CG is preconditioned by the row-mean operator (per-env factors, one factorisation per PISO step); 0: the grid's A = 1 factors"),
     "FG_ADV_JACOBI": ("bits", "velocity systems of uniform 2-D grids: 1 Jacobi sweeps first (fg_jacobi.hip), 0 BiCGStab always; unset = what fg_set_advection_jacobi says (the Simulation turns it on: policy advection_jacobi)"),
@@ -38,19 +35,14 @@ NOTES = {
     "FG_JAC_SWEEPS": ("bits", "A/B runs: sweeps per pass of the Jacobi sweeps (unset: 4 / 6 / 8 for full rows, 8 / 12 for bands, by region depth)"),
     "FG_HTRACE": ("no", "1: host time stamps around the polls and the launches behind them (fg_poll.hip), per-pair averages printed at exit"),
     "FG_FORCE_ZMARCH": ("bits", "z-march chunk length of the 3-D Poisson kernels (tests on small grids; -1 = brick kernels)"),
-    "FG_ZMARCH_BXL": ("no", "tile shape of the z-march Poisson kernels (16 / 32 / 64 float4 lanes)"),
     "FG_ZMARCH_SB": ("no", "single-barrier ring of the z-march kernels: bit per mode, 0 never, unset = rule"),
     "FG_POLL_SPIN": ("no", "0: host polls wait with hipStreamSynchronize instead of spinning on pinned sequence words"),
     "FG_PROF_PERIOD": ("no", "sampling period of the live kernel timing (64)"),
     "FG_FD_NO_FFT": ("bits", "1: the x basis change of the FD preconditioner as dense GEMM instead of the row FFT (tests)"),
     "FG_MB_BICG_VEC4": ("no", "bit per multi-block BiCGStab kernel: four-cell form (31 = all)"),
     "FG_MB_BICG_FUSE": ("bits", "multi-block BiCGStab: 0 five kernels, 1 s/t fused, 2 (default) also p/v"),
-    "FG_MB_PRED": ("no", "0: first convergence poll after two iterations instead of where the previous solve ended"),
     "FG_MB_ML_FUSE": ("bits", "multilevel BiCGStab forms p / s inside the restriction: 0 never, 1 up to 32 systems, 2 always"),
-    "FG_MB_ML_SB": ("no", "systems per workgroup of k_ml_coarse (4 / 8; 0 = by batch)"),
     "FG_MB_ML_TRY_CAP": ("policy", "iteration cap of an attempt of the multilevel trial (200; tests force 2)"),
-    "FG_MB_ML_WARMUP": ("policy", "pressure solves a handle runs plain before its first multilevel attempt"),
-    "FG_MB_GRAPH": ("no", "chunked CG replayed as a hipGraph"),
     "FG_MB_TRACE": ("no", "residual / verification trace of the pressure BiCGStab on stderr"),
     "FG_MB_TRACE_FAIL": ("no", "recurrence words of a system that ends non-finite"),
     "FG_MB_COMPACT": ("no", "0: every multi-block Krylov launch covers all systems of the batch"),
@@ -58,14 +50,12 @@ NOTES = {
     "FG_MB_ONCHIP": ("bits", "0: no whole-solve on-chip CG (chunked CG kernels)"),
     "FG_MB_OC_AGG": ("bits", "0: cell-ordered on-chip CG instead of the aggregate-owned one"),
     "FG_MB_CLUSTER": ("bits", "pressure CG of an env by a cluster of four workgroups (fg_mb_cluster.hip): 0 never (the one-workgroup kernels), 1 (default) meshes beyond 8 k cells, 2 every mesh its tables fit (tests)"),
-    "FG_MB_CL_CPT": ("no", "reserved (members per thread of the cluster CG; eight is the one instance built -- four in 1024 threads measured 12.8 against 8.6 us per iteration)"),
     "FG_MB_CL_JACOBI": ("bits", "0: the velocity sweeps of the meshes the cluster CG takes stay one launch per sweep (k_mbj_sweep_env) instead of one launch per solve by the clusters (k_mbj_cluster; A/B runs: 2 552 against 3 045 env-steps/s on the cylinder mesh)"),
     "FG_MB_CL_HALF": ("bits", "0: meshes whose rows of the coarse inverse do not fit LDS as fp32 stream them from L2 instead of holding them as fp16 (A/B runs: 19.7 against 16.8 us per iteration on 23 k cells)"),
     "FG_MB_CL_MAXCL": ("no", "cap on the clusters of one launch of the cluster CG (tests: envs beyond it queue inside the kernel; same bits)"),
     "FG_MB_CL_NEAR": ("no", "0: granule stores of the cluster CG always write through (sc1), also when a cluster's workgroups reported one XCD (A/B runs: 10.0 against 8.6 us per iteration)"),
     "FG_MB_OC_VARIANT": ("no", "on-chip CG variant bits (fences / coefficient layout)"),
     "FG_MB_RUNG_ILU": ("bits", "0: column-scaled preconditioned rung instead of ILU(0)"),
-    "FG_MB_SCALAR_CG": ("bits", "1: one-cell chunked CG"),
     "FLUIDGYM_AMD_LIB": ("no", "path of libfluidgym_hip.so (sanitizer build: tests/run_sanitizer_suite.sh)"),
     "FLUIDGYM_AMD_LIB_F64": ("no", "path of libfluidgym_hip_f64.so"),
     "FLUIDGYM_AMD_ADVECTION_FD_PRECONDITIONER": ("bits", "policy advection_fd_preconditioner: auto (2-D periodic-x grids) / always / never"),

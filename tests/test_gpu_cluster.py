@@ -17,7 +17,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def _run(monkeypatch, mode, resolution, batch=3, maxcl=None, cpt=None, tol=1e-7):
+def _run(monkeypatch, mode, resolution, batch=3, maxcl=None, half=None, tol=1e-7):
     from fluidgym_amd.envs.cylinder_grid import build_domain, make_vortex_street_mesh
 
     monkeypatch.setenv("FG_MB_CLUSTER", mode)      # read once per handle at fg_mb_create
@@ -25,10 +25,10 @@ def _run(monkeypatch, mode, resolution, batch=3, maxcl=None, cpt=None, tol=1e-7)
         monkeypatch.delenv("FG_MB_CL_MAXCL", raising=False)
     else:
         monkeypatch.setenv("FG_MB_CL_MAXCL", str(maxcl))
-    if cpt is None:
-        monkeypatch.delenv("FG_MB_CL_CPT", raising=False)
+    if half is None:
+        monkeypatch.delenv("FG_MB_CL_HALF", raising=False)
     else:
-        monkeypatch.setenv("FG_MB_CL_CPT", str(cpt))
+        monkeypatch.setenv("FG_MB_CL_HALF", str(half))
     mesh = make_vortex_street_mesh(resolution)
     dom = build_domain(mesh, 0.01, batch=batch)
     dom.set_stall_limit(5000)
@@ -52,16 +52,14 @@ def _run(monkeypatch, mode, resolution, batch=3, maxcl=None, cpt=None, tol=1e-7)
     return out
 
 
-@pytest.mark.parametrize("resolution,cpt", [(24, None), (32, None)])
-def test_cluster_cg_is_the_one_workgroup_cg(monkeypatch, resolution, cpt):
+@pytest.mark.parametrize("resolution,half", [(24, None), (32, None), (32, 0)])
+def test_cluster_cg_is_the_one_workgroup_cg(monkeypatch, resolution, half):
     """14 232 cells (eight members per thread in 512 threads, the workgroup's rows of the coarse inverse in LDS as fp32) and 23 424
-    cells (768 threads, the rows as fp16): start from zero, start from an iterate, an inactive env; identical envs stay
-    bit-identical."""
+    cells (768 threads, the rows as fp16 -- or, FG_MB_CL_HALF=0, streamed from L2 as fp32): start from zero, start from an iterate,
+    an inactive env; identical envs stay bit-identical."""
     u0_c, u_c, p_c, c_c, cfg_c = _run(monkeypatch, "0", resolution)
-    u0_k, u_k, p_k, c_k, cfg_k = _run(monkeypatch, "1", resolution, cpt=cpt)
+    u0_k, u_k, p_k, c_k, cfg_k = _run(monkeypatch, "1", resolution, half=half)
     assert cfg_c["cluster_solves"] == 0 and cfg_k["cluster_on"] == 1 and cfg_k["cluster_solves"] > 0 and cfg_k["cluster_fallbacks"] == 0, (cfg_c, cfg_k)
-    if cpt is not None:
-        assert cfg_k["cluster_members_per_thread"] == cpt
     assert np.isfinite(u_k).all() and np.isfinite(p_k).all()
     assert _rel(u0_k, u0_c) < 2e-5 and _rel(u_k, u_c) < 5e-5, (_rel(u0_k, u0_c), _rel(u_k, u_c))
     for k in ("pressure0", "pressure1"):
