@@ -128,6 +128,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     s->tridiag_cb = 64;            // (FG_TRIDIAG_CB until round 5; 32 = half-width column blocks in k_tridiag_y_lds: measured, no gain)
     s->helm_cb_pref = 32;          // (FG_HELM_CB until round 5; 64-column workgroups of k_helm_apply_y: 8.1 against 7.0 us)
     { const char* ev = getenv("FG_HELM_ROWFORM"); s->helm_rowform_off = (ev && atoi(ev) == 0) ? 1 : 0; }   // 0: k_helm_coeffs + the array-form line kernels
+    { const char* ev = getenv("FG_FD_FACFUSE"); s->fd_facfuse = ev ? atoi(ev) : 1; }
     { const char* ev = getenv("FG_FD_ROWMEAN"); s->fd_rowmean = ev ? atoi(ev) : 1; }     // 0: the fused CG keeps the grid's A = 1 factors
     s->fd_row_epoch = -1; s->rA_epoch = 0; s->fd_row_part_epoch = -1;
     { const char* ev = getenv("FG_CG_FUSED"); s->cg_fused = ev ? atoi(ev) : 1; }       // 0: five-kernel preconditioned CG iteration (fg_poisson.hip)

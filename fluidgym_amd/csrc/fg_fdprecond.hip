@@ -5,6 +5,8 @@
 // eigenbasis) and run on the matrix cores with the exact-fp32 MFMA v_mfma_f32_32x32x2_f32 (gfx950:
 // 64 cycles / 4096 MACs per wave, bitwise an fmaf chain, cdna_hip_programming.md section 3); the
 // tridiagonal sweep streams the per-mode LU factors precomputed on the host.
+#include <mutex>
+
 #include "fg_internal.h"
 #include "fg_cg.h"
 
@@ -366,11 +368,22 @@ __global__ __launch_bounds__(64) void k_tridiag_y(float* __restrict__ x, const f
 // TWO = true (ny beyond 208: the 512 x 256 grid of `large_env`): only two arrays fit the 160 KB -- c' is staged into the ms region
 // AFTER the forward sweep has used it up (one more load phase and barrier in the middle; the streaming kernel it replaces there took
 // 32 us per application).
-template <bool TWO, int CB>
+// FAC (round 6): the launch also MAKES the per-env factors of the row-mean operator it solves with -- k_fd_rowmean_factor's
+// arithmetic (same row means from the assembly's per-tile sums in the same order, same pivots: identical bits), run by wave 0 inside
+// its forward sweep, where the factor chain (fma -> rcp -> mul per row) and the solve chain (one fma per row) interleave.  The
+// separate factorisation launch was 26 us of a 287 us PISO step for 0.6 MB fetched: one wave per CU on a 128-row dependent chain.
+// The factors go to `inv_out` / `cp_out` / `lower_out` for the later applications of the PISO step (both correctors share 1/A).
+// An env the verdict stops before its first application (x_0 already good) still gets its factors: the next solve needs them.
+struct FgFacArgs {
+    const float* row_part; int tiles_x;      // per-tile row sums of 1/A the assembly left ([B][ny][tiles_x])
+    const float* lam; const float* hy; const float* rhy; const float* dt;
+    float* inv_out; float* cp_out; float* lower_out;
+};
+template <bool TWO, int CB, bool FAC = false>
 __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, const float* __restrict__ inv,
                                                        const float* __restrict__ cp, const float* __restrict__ lower,
                                                        const int32_t* __restrict__ flags, int nx, int ny, int nz, FgCgLead lead,
-                                                       long fac_stride, int lower_stride) {
+                                                       long fac_stride, int lower_stride, FgFacArgs fa = FgFacArgs{}) {
     // fac_stride / lower_stride: 0 = the grid's factors (A = 1 operator, shared by all envs); N / ny = per-env factors of the
     // row-mean operator (k_fd_rowmean_factor below)
     // CB = columns per workgroup: 64 (one float4 row segment per 16 lanes) or 32 (half the LDS: at ny = 128 two to three workgroups per
@@ -378,15 +391,42 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
     extern __shared__ __attribute__((aligned(16))) float tbuf[];  // bs[nyp][CB] | ms[nyp][CB] | cs[nyp][CB]  (TWO: cs shares ms)
     constexpr int CBL = CB / 4, RPW = 64 / CBL, UQ = 32 / RPW;    // lanes per row | rows per wave access | accesses per wave and round (32 rows)
     const int b = blockIdx.y;
-    if (flags && flags[b] != 0) return;
+    bool solve = true;      // FAC: an env may need its factors without a solve
+    if (flags && flags[b] != 0) { if (!FAC || !(fa.dt == nullptr || fa.dt[b] > 0.f)) return; solve = false; }
     // fused CG (fg_fftcg.hip): the verdict on the residual this application preconditions, and the leader's bookkeeping, ride here
-    if (lead.judge.acc && fg_cg_lead(lead, b, blockIdx.x == 0)) return;
+    if (solve && lead.judge.acc && fg_cg_lead(lead, b, blockIdx.x == 0)) { if (!FAC) return; solve = false; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int CH = 16;
     const int nyp = (ny + CH - 1) / CH * CH, last = ny - 1;
     float* bs = tbuf;
     float* ms = tbuf + (size_t)nyp * CB;
     float* cs = TWO ? ms : tbuf + (size_t)2 * nyp * CB;
+    // FAC: the env's row coefficients behind the column arrays: e = a hy | d | l | u | z (k_fd_rowmean_factor), a = row mean of 1/A
+    float* rc = tbuf + (size_t)(TWO ? 2 : 3) * nyp * CB;
+    if (FAC) {
+        float* sa = rc + 5 * nyp;
+        const float rn = 1.f / (float)nx;
+        for (int j = threadIdx.x; j < ny; j += 256) {
+            const float* __restrict__ pp = fa.row_part + ((size_t)b * ny + j) * fa.tiles_x;
+            float acc = 0.f;
+            for (int t = 0; t < fa.tiles_x; ++t) acc += pp[t];
+            sa[j] = acc * rn;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < nyp; j += 256) {
+            float e = 0.f, d = 1.f, l = 0.f, u = 0.f, z = 0.f;      // padding rows: the identity
+            if (j < ny) {
+                const float aj = sa[j];
+                const float cm = j > 0 ? 0.5f * (sa[j - 1] * fa.rhy[j - 1] + aj * fa.rhy[j]) : 0.f;
+                const float cpl = j < ny - 1 ? 0.5f * (aj * fa.rhy[j] + sa[j + 1] * fa.rhy[j + 1]) : 0.f;
+                l = cm; u = cpl; d = -(cm + cpl); e = aj * fa.hy[j];
+                z = (j == ny - 1) ? -(cm + cpl) : 0.f;      // the mode constant along x: its last pivot is shifted (k_fd_rowmean_factor)
+                if (blockIdx.x == 0) fa.lower_out[(size_t)b * ny + j] = cm;
+            }
+            rc[j] = e; rc[nyp + j] = d; rc[2 * nyp + j] = l; rc[3 * nyp + j] = u; rc[4 * nyp + j] = z;
+        }
+        // (the barrier behind the load phase below orders these writes before wave 0 reads them)
+    }
     const int lc = 4 * (lane % CBL), rsub = lane / CBL;
     int t4 = blockIdx.x * CB + lc;
     const bool live = t4 < nx * nz;
@@ -397,6 +437,23 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
     const float* __restrict__ iv4 = inv + (size_t)b * fac_stride + col4;
     const float* __restrict__ cp4 = cp + (size_t)b * fac_stride + col4;
     lower += (size_t)b * lower_stride;
+    if (FAC) {
+        // only the right-hand side is loaded: bs = b (the factors are made below)
+        if (solve)
+            for (int jb = wave * 32; jb < nyp; jb += 128) {
+                float4 vx[UQ];
+#pragma unroll
+                for (int q = 0; q < UQ; ++q) vx[q] = *reinterpret_cast<const float4*>(xb4 + (size_t)min(jb + RPW * q + rsub, last) * nx);
+#pragma unroll
+                for (int q = 0; q < UQ; ++q) {
+                    const int j = jb + RPW * q + rsub;
+                    if (j < nyp) {
+                        const float m = (j > last) ? 0.f : 1.f;
+                        *reinterpret_cast<float4*>(bs + j * CB + lc) = make_float4(vx[q].x * m, vx[q].y * m, vx[q].z * m, vx[q].w * m);
+                    }
+                }
+            }
+    } else
     for (int jb = wave * 32; jb < nyp; jb += 128) {  // 32 rows per wave per round
         float4 vx[UQ], vi[UQ], vc[UQ];
         float vl[UQ];
@@ -423,6 +480,50 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
         }
     }
     __syncthreads();
+    if (FAC) {
+        if (wave == 0 && lane < CB) {
+            // factor chain and solve chain side by side: p_j = 1 / (d_j - l_j c'_{j-1}), c'_j = u_j p_j (k_fd_rowmean_factor, same
+            // operations); y_j = b_j p_j - (l_j p_j) y_{j-1} (the folded form of the load phase above: bs = b inv, ms = l inv)
+            const int col = (blockIdx.x * CB + lane) % nx;
+            const float lm = fa.lam[col];
+            const float zm = (col == 0) ? 1.f : 0.f;
+            float prev = 0.f, cprev = 0.f;
+            float* px = bs + lane;
+            float* pm = ms + lane;                          // !TWO: p (to be stored as inv); TWO: c'
+            float* pc = cs + lane;                          // c' of the back sweep
+            float* iv = fa.inv_out + (size_t)b * fac_stride + (size_t)(blockIdx.x * CB + lane);      // TWO: p goes straight to memory
+            for (int j0 = 0; j0 < nyp; j0 += CH, px += CH * CB, pm += CH * CB, pc += CH * CB) {
+                float ax[CH], e8[CH], d8[CH], l8[CH], u8[CH], z8[CH], pv[CH], cv[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) ax[q] = solve ? px[q * CB] : 0.f;
+                auto ldc = [&](const float* a, float (&o)[CH]) {
+#pragma unroll
+                    for (int q4 = 0; q4 < CH / 4; ++q4) {
+                        const float4 v = *reinterpret_cast<const float4*>(a + j0 + 4 * q4);
+                        o[4 * q4] = v.x; o[4 * q4 + 1] = v.y; o[4 * q4 + 2] = v.z; o[4 * q4 + 3] = v.w;
+                    }
+                };
+                ldc(rc, e8); ldc(rc + nyp, d8); ldc(rc + 2 * nyp, l8); ldc(rc + 3 * nyp, u8); ldc(rc + 4 * nyp, z8);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const float d = fmaf(zm, z8[q], fmaf(e8[q], lm, d8[q]));
+                    pv[q] = __builtin_amdgcn_rcpf(fmaf(-l8[q], cprev, d));
+                    cprev = u8[q] * pv[q];
+                    cv[q] = cprev;
+                    const float m = (j0 + q > last) ? 0.f : 1.f;
+                    prev = fmaf(-((l8[q] * m) * pv[q]), prev, ax[q] * pv[q]);
+                    ax[q] = prev;
+                }
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    px[q * CB] = ax[q];
+                    const float m = (j0 + q > last) ? 0.f : 1.f;
+                    if (TWO) { pm[q * CB] = cv[q] * m; if (j0 + q <= last) iv[(size_t)(j0 + q) * nx] = pv[q]; }
+                    else { pm[q * CB] = pv[q]; pc[q * CB] = cv[q] * m; }
+                }
+            }
+        }
+    } else
     if (wave == 0 && lane < CB) {
         float prev = 0.f;
         float* px = bs + lane;
@@ -437,7 +538,7 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
             for (int q = 0; q < CH; ++q) px[q * CB] = ax[q];
         }
     }
-    if (TWO) {
+    if (TWO && !FAC) {
         __syncthreads();       // the forward sweep is through with ms: c' takes its place
         for (int jb = wave * 32; jb < nyp; jb += 128) {
             float4 vc[UQ];
@@ -454,7 +555,7 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
         }
         __syncthreads();
     }
-    if (wave == 0 && lane < CB) {
+    if (solve && wave == 0 && lane < CB) {
         float prev = 0.f;
         float* px = bs + (size_t)(nyp - CH) * CB + lane;
         const float* pc = cs + (size_t)(nyp - CH) * CB + lane;
@@ -474,8 +575,15 @@ __global__ __launch_bounds__(256) void k_tridiag_y_lds(float* __restrict__ x, co
 #pragma unroll
             for (int q = 0; q < UQ; ++q) {
                 const int j = jb + RPW * q + rsub;
-                if (j <= last)
-                    *reinterpret_cast<float4*>(xb4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * CB + lc);
+                if (j <= last) {
+                    if (solve) *reinterpret_cast<float4*>(xb4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * CB + lc);
+                    if (FAC) {      // the factors wave 0 left in LDS, for the later applications of this 1/A
+                        float* io = fa.inv_out + (size_t)b * fac_stride + col4 + (size_t)j * nx;
+                        float* co = fa.cp_out + (size_t)b * fac_stride + col4 + (size_t)j * nx;
+                        if (!TWO) *reinterpret_cast<float4*>(io) = *reinterpret_cast<const float4*>(ms + j * CB + lc);
+                        *reinterpret_cast<float4*>(co) = *reinterpret_cast<const float4*>(cs + j * CB + lc);
+                    }
+                }
             }
         }
 }
@@ -580,14 +688,20 @@ __global__ __launch_bounds__(64) void k_fd_rowmean_factor(const float* __restric
 }  // namespace
 
 // dynamic LDS above 64 KB needs an explicit opt-in per kernel (once per process and size class)
-static bool tridiag_lds_ready(size_t bytes) {
-    static size_t granted = 0;
-    static bool failed = false;
+static bool tridiag_lds_ready(size_t bytes, bool fac = false) {
+    static std::mutex mu;
+    static size_t granted_dev[64][2] = {{0}};      // per device (the attribute belongs to the device current when it is set) and kernel family
+    static bool failed_dev[64][2] = {{false}};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& granted = granted_dev[dev][fac ? 1 : 0];
+    bool& failed = failed_dev[dev][fac ? 1 : 0];
     if (bytes <= granted) return true;
     if (failed) return false;
-    const void* fns[4] = {reinterpret_cast<const void*>(k_tridiag_y_lds<false, 64>), reinterpret_cast<const void*>(k_tridiag_y_lds<true, 64>),
-                          reinterpret_cast<const void*>(k_tridiag_y_lds<false, 32>), reinterpret_cast<const void*>(k_tridiag_y_lds<true, 32>)};
-    for (const void* f : fns)
+    const void* plain[2] = {reinterpret_cast<const void*>(k_tridiag_y_lds<false, 64>), reinterpret_cast<const void*>(k_tridiag_y_lds<true, 64>)};
+    const void* facs[2] = {reinterpret_cast<const void*>(k_tridiag_y_lds<false, 64, true>), reinterpret_cast<const void*>(k_tridiag_y_lds<true, 64, true>)};
+    for (const void* f : (fac ? facs : plain))
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
             (void)hipGetLastError();
             failed = true;
@@ -653,7 +767,20 @@ int fg_fd_rowmean_factor(fg_state* s, const float* rA, const float* dt, hipStrea
 
 // per-mode Thomas solve along y of the transformed field `cur` (in place), all envs with flags == 0; lead (optional): the fused CG's
 // verdict / leader bookkeeping taken by this launch (FgCgLead, fg_cg.h)
-int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean) {
+// the tridiagonal launches that can make the row-mean factors themselves (k_tridiag_y_lds<.., 64, FAC>): LDS for the column arrays
+// plus the env's six row arrays
+bool fg_fd_tridiag_can_factor(const fg_state* s) {
+    const FgGrid& G = s->grid;
+    if (!s->fd_facfuse || G.dims != 2 || G.nz != 1 || (G.nx & 63) != 0) return false;
+    const size_t nyp = (size_t)(G.ny + 15) / 16 * 16;
+    const size_t lds_three = (size_t)3 * nyp * 64 * sizeof(float) + 6 * nyp * sizeof(float), lds_two = (size_t)2 * nyp * 64 * sizeof(float) + 6 * nyp * sizeof(float);
+    return lds_three <= 160 * 1024 || lds_two <= 160 * 1024;
+}
+
+// per-mode Thomas solve along y of the transformed field `cur` (in place), all envs with flags == 0; lead (optional): the fused CG's
+// verdict / leader bookkeeping taken by this launch (FgCgLead, fg_cg.h); factor_from (optional): the launch also makes the per-env
+// row-mean factors from these per-tile row sums of 1/A (fg_fd_tridiag_can_factor)
+int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean, const float* factor_from, const float* factor_dt) {
     const FgGrid& G = s->grid;
     const int nx = G.nx, ny = G.ny, nz = G.nz, B = G.B;
     const long N = G.n;
@@ -664,6 +791,27 @@ int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead,
     const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
     const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
     const size_t lds_two = lds_coop / 3 * 2;      // two arrays: c' staged after the forward sweep (ny up to 320)
+    if (factor_from) {
+        const size_t rows = (size_t)6 * ((ny + 15) / 16 * 16) * sizeof(float);
+        if (!s->fd_row_inv) {
+            const size_t BN = (size_t)B * N;
+            FG_HIP_CHECK(hipMalloc(&s->fd_row_inv, sizeof(float) * BN));
+            FG_HIP_CHECK(hipMalloc(&s->fd_row_cp, sizeof(float) * BN));
+            FG_HIP_CHECK(hipMalloc(&s->fd_row_lower, sizeof(float) * (size_t)B * ny));
+        }
+        FgFacArgs fa;
+        fa.row_part = factor_from; fa.tiles_x = (nx + 63) / 64; fa.lam = s->fd_lam_x; fa.hy = G.h[1]; fa.rhy = G.rh[1]; fa.dt = factor_dt;
+        fa.inv_out = s->fd_row_inv; fa.cp_out = s->fd_row_cp; fa.lower_out = s->fd_row_lower;
+        if (lds_coop + rows <= 160 * 1024 && tridiag_lds_ready(lds_coop + rows, true))
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 64, true>), grid, dim3(256), lds_coop + rows, st, cur, (const float*)nullptr, (const float*)nullptr,
+                        (const float*)nullptr, s->flags, nx, ny, nz, ld, N, ny, fa);
+        else if (lds_two + rows <= 160 * 1024 && tridiag_lds_ready(lds_two + rows, true))
+            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 64, true>), grid, dim3(256), lds_two + rows, st, cur, (const float*)nullptr, (const float*)nullptr,
+                        (const float*)nullptr, s->flags, nx, ny, nz, ld, N, ny, fa);
+        else { fg_set_error("fg_fd_tridiag: no LDS for the factoring launch (fg_fd_tridiag_can_factor said otherwise)"); return FG_ERR_HIP; }
+        FG_HIP_CHECK(hipGetLastError());
+        return FG_OK;
+    }
     // per-env factors of the row-mean operator (fg_fd_rowmean_factor) when the caller asked for them and the LDS kernels run
     const bool rowf = use_rowmean && s->fd_row_inv && (nx & 3) == 0 && lds_two <= 160 * 1024;
     const float* f_inv = rowf ? s->fd_row_inv : s->fd_inv;
@@ -671,24 +819,12 @@ int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead,
     const float* f_lower = rowf ? s->fd_row_lower : s->fd_lower;
     const long fstride = rowf ? N : 0;
     const int lstride = rowf ? ny : 0;
-    // FG_TRIDIAG_CB=32 at fg_create: 32-column workgroups (half the LDS per workgroup, two to three resident per CU).  Measured round 5:
-    // RBC 512 x 128 x 32 8.1 us against 7.0 us with 64 columns, headline unchanged -- the serial sweep of wave 0 is the floor, and
-    // half-width blocks only halve its lanes; 64 stays the default
-    const bool cb32 = s->tridiag_cb == 32 && nz == 1 && (nx & 31) == 0 && (long)((nx + 63) / 64) * B <= 1024;
     if ((nx & 3) == 0 && lds_coop <= 160 * 1024 && tridiag_lds_ready(lds_coop)) {
-        if (cb32)
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 32>), dim3(nx / 32, B), dim3(256), lds_coop / 2, st, cur, f_inv, f_cp, f_lower,
-                        s->flags, nx, ny, nz, ld, fstride, lstride);
-        else
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 64>), grid, dim3(256), lds_coop, st, cur, f_inv, f_cp, f_lower,
-                        s->flags, nx, ny, nz, ld, fstride, lstride);
+        FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<false, 64>), grid, dim3(256), lds_coop, st, cur, f_inv, f_cp, f_lower,
+                    s->flags, nx, ny, nz, ld, fstride, lstride, FgFacArgs{});
     } else if ((nx & 3) == 0 && lds_two <= 160 * 1024 && tridiag_lds_ready(lds_two)) {
-        if (cb32)
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 32>), dim3(nx / 32, B), dim3(256), lds_two / 2, st, cur, f_inv, f_cp, f_lower,
-                        s->flags, nx, ny, nz, ld, fstride, lstride);
-        else
-            FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 64>), grid, dim3(256), lds_two, st, cur, f_inv, f_cp, f_lower,
-                        s->flags, nx, ny, nz, ld, fstride, lstride);
+        FG_LAUNCH_P(s, slot, (k_tridiag_y_lds<true, 64>), grid, dim3(256), lds_two, st, cur, f_inv, f_cp, f_lower,
+                    s->flags, nx, ny, nz, ld, fstride, lstride, FgFacArgs{});
     } else {
         FG_LAUNCH_P(s, slot, k_tridiag_y, grid, dim3(64), (size_t)((ny + 63) / 64 * 64) * 64 * sizeof(float), st, cur,
                     s->fd_inv, s->fd_cp, s->fd_lower, s->flags, nx, ny, nz, ld);

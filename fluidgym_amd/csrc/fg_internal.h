@@ -730,6 +730,7 @@ struct fg_state {
     // factors [B][N] / [B][ny], FG_FD_ROWMEAN at fg_create (1), epoch of the 1/A field the factors were made from (rA_epoch: bumped by
     // everything that rewrites s->rA)
     float* fd_lam_x; float* fd_row_inv; float* fd_row_cp; float* fd_row_lower; int fd_rowmean; long fd_row_epoch; mutable long rA_epoch;
+    int fd_facfuse;               // FG_FD_FACFUSE (default 1): the first tridiagonal solve after 1/A changed makes the row-mean factors itself (0: k_fd_rowmean_factor, a launch of its own)
     float* fd_row_part; long fd_row_part_epoch;   // per-tile row sums of 1/A written by k_adv_build, and the rA epoch they belong to
     fg_real** d_bvel_ptrs;   // device copy of bvel[6] (writable pointers for the flux balancing kernel)
     fg_real* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
@@ -948,7 +949,8 @@ int fg_fd_dct_inverse(fg_state* s, const fg_real* u, fg_real* z, const fg_real* 
 int fg_fd_apply(fg_state* s, const fg_real* r, fg_real* z, FgDacc* rz_acc, int rz_stride, int rz_ns, int expect_active,
                 hipStream_t st, const FgCgJudge* judge = nullptr);
 struct FgCgLead;    // fg_cg.h
-int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean = false);   // the per-mode Thomas solve of fg_fd_apply alone (in place); use_rowmean: the per-env factors of fg_fd_rowmean_factor
+int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean = false, const float* factor_from = nullptr, const float* factor_dt = nullptr);
+bool fg_fd_tridiag_can_factor(const fg_state* s);      // the tridiagonal launch can make the row-mean factors itself (round 6)   // the per-mode Thomas solve of fg_fd_apply alone (in place); use_rowmean: the per-env factors of fg_fd_rowmean_factor
 bool fg_fd_rowmean_ok(const fg_state* s);
 int fg_fd_rowmean_factor(fg_state* s, const float* rA, const float* dt, hipStream_t st, const float* row_part = nullptr, int tiles_x = 0);
 // the factors for the CURRENT 1/A field ahead of the pressure solves that will want them (fg_cg_solve then finds them made): launched

@@ -395,6 +395,7 @@ int fg_fd_rowmean_prefactor(fg_state* s, const fg_real* dt, hipStream_t st) {
 #if !FG_F64
     if (!(s->fd_Qx && fg_fcg_ok(s) && fg_fd_rowmean_ok(s)) || s->fd_row_epoch == s->rA_epoch || dt == nullptr) return FG_OK;
     const bool parts = s->fd_row_part && s->fd_row_part_epoch == s->rA_epoch;      // the assembly left the row sums
+    if (parts && fg_fd_tridiag_can_factor(s)) return FG_OK;      // round 6: the first tridiagonal solve makes the factors itself
     if (int rc = fg_fd_rowmean_factor(s, s->rA, dt, st, parts ? s->fd_row_part : nullptr, (s->grid.nx + 63) / 64)) return rc;
     s->fd_row_epoch = s->rA_epoch;
 #else
@@ -480,16 +481,18 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
         // preconditioner of this solve: the row-mean operator (per-env factors, made once per 1/A field: both correctors of a PISO
         // step share them) where it applies, the grid's A = 1 operator otherwise
         const bool rowm = fg_fd_rowmean_ok(s);
+        const float* factor_from = nullptr;      // != nullptr: the first tridiagonal launch of this solve makes the factors (round 6)
         if (rowm && !(a.rA == s->rA && s->fd_row_epoch == s->rA_epoch)) {
             const bool parts = a.rA == s->rA && s->fd_row_part && s->fd_row_part_epoch == s->rA_epoch;      // the assembly left the row sums
-            if (int rc = fg_fd_rowmean_factor(s, a.rA, a.dt, st, parts ? s->fd_row_part : nullptr, (s->grid.nx + 63) / 64)) return rc;
+            if (parts && fg_fd_tridiag_can_factor(s)) factor_from = s->fd_row_part;
+            else if (int rc = fg_fd_rowmean_factor(s, a.rA, a.dt, st, parts ? s->fd_row_part : nullptr, (s->grid.nx + 63) / 64)) return rc;
             s->fd_row_epoch = (a.rA == s->rA) ? s->rA_epoch : -1;
         }
         judge.it = -1;
         if (!(start_ready && start_fwd))      // (k_fcg_div_fwd already transformed r_0: the verdict on x_0 is the tridiagonal kernel's alone)
             if (int rc = fg_fd_dct_forward(s, a.r, v.t1, st, 0, &judge)) return rc;      // u = Qx^T r_0 (the verdict on x_0 rides here)
         lead.judge = judge;
-        if (int rc = fg_fd_tridiag(s, v.t1, st, &lead, rowm)) return rc;
+        if (int rc = fg_fd_tridiag(s, v.t1, st, &lead, rowm, factor_from, a.dt)) return rc;
         // a solve started by k_fcg_div_fwd never stored r_0 = b and x_0 = 0: until the first update has written r and x, r is the
         // right-hand side itself and x is known
         const fg_real* r0 = (start_ready && start_fwd) ? a.b : nullptr;

@@ -21,6 +21,7 @@ NOTES = {
     "FG_BICG3_MIX": ("bits", "debugging: bit 0 kernel a, bit 1 kernel b as z-march, bit 2 keep the init kernel"),
     "FG_REDUCE_WGS": ("no", "workgroups per env of the reduction kernels (0 = rule)"),
     "FG_HELM_ROWFORM": ("bits", "0: Helmholtz factors through k_helm_coeffs + the array-form line kernels (IEEE division instead of v_rcp)"),
+    "FG_FD_FACFUSE": ("no", "1 (default): the first tridiagonal solve after 1/A changed makes the per-env row-mean factors itself (k_tridiag_y_lds<.., FAC>: same arithmetic, same bits); 0: k_fd_rowmean_factor as a launch of its own (A/B runs)"),
     "FG_FD_ROWMEAN": ("bits", "1 (default): the fused pressure CG is preconditioned by the row-mean operator (per-env factors, one factorisation per PISO step); 0: the grid's A = 1 factors"),
     "FG_ADV_JACOBI": ("bits", "velocity systems of uniform 2-D grids: 1 Jacobi sweeps first (fg_jacobi.hip), 0 BiCGStab always; unset = what fg_set_advection_jacobi says (the Simulation turns it on: policy advection_jacobi)"),
     "FLUIDGYM_AMD_ADVECTION_JACOBI": ("policy", "policy advection_jacobi (default 1): the Simulation asks for the Jacobi sweeps of fg_jacobi.hip on the grids that qualify"),

@@ -338,3 +338,39 @@ def test_corrector_launched_behind_the_verdict_kernel_changes_no_bit(monkeypatch
         for e in (0, 2, 3):
             assert torch.equal(a[2][e], b[2][e]), (mult, e)
         print("SPEC", mult, "iterations", a[3], "unstored solves", a[4])
+
+
+@pytest.mark.parametrize("n", [(128, 36), (256, 128), (512, 256)])
+def test_factors_made_by_the_first_tridiagonal_solve_are_the_factor_kernels(n, monkeypatch):
+    """Round 6: the per-env factors of the row-mean preconditioner are made by the first tridiagonal solve after 1/A changed
+    (``k_tridiag_y_lds<.., FAC>``: k_fd_rowmean_factor's arithmetic inside wave 0's forward sweep) instead of by a launch of their
+    own (FG_FD_FACFUSE=0).  Same row means, same pivots, the same folded solve: every field bit for bit over three PISO steps,
+    tolerances on both sides of the first residuals (an env the verdict stops before its first application still gets its factors for
+    the second corrector), a masked env untouched; 128 rows (three LDS arrays) and 256 rows (two: c' written over the forward sweep's
+    multipliers)."""
+    import fluidgym_amd._lib as L
+    case = _channel_case(n, B=4)
+    dt = [0.02, 0.0, 0.03, 0.02]
+    ns = case.native()
+    ok, _ = ns.piso_step(dt, corrector_steps=1, advection_tol=1e-7, pressure_tol=1e-7)
+    div = ns.buffer(L.FG_BUF_DIV, (case.B,) + case.shape)
+    rms = min(float(div[b].double().pow(2).mean().sqrt()) for b in (0, 2, 3))
+    ns.close()
+    for mult in (0.05, 5.0, 0.5):
+        res = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("FG_FD_FACFUSE", fuse)
+            ns = case.native()
+            v0 = ns.velocity.clone()
+            its = []
+            for _ in range(3):
+                ok, stats = ns.piso_step(dt, advection_tol=1e-7, pressure_tol=mult * rms)
+                assert ok, stats
+                its.append(tuple(stats))
+            torch.cuda.synchronize()
+            res[fuse] = (ns.velocity.clone(), ns.pressure.clone(), ns.buffer(L.FG_BUF_P_RESULT, (case.B,) + case.shape).clone(), its)
+            assert torch.equal(ns.velocity[1], v0[1])
+            ns.close()
+        a, b = res["1"], res["0"]
+        assert a[3] == b[3], (mult, a[3], b[3])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), mult
