@@ -132,11 +132,11 @@ KERNEL_DOC = {
 
 def pmc_traffic(kernel):
     """Memory-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r05_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
+    (profiles/r06_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 x2 correction on the
     fetch counter as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so this
     is the last profiled run, not this run; None when the file has no row for the kernel."""
     t = None
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):      # (the newest committed profile of this command)
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"):      # (the newest committed profile of this command)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)

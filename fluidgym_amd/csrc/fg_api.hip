@@ -655,6 +655,7 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
 #endif
     // ---- passive scalars (:1471-1644)
     if (scalar) {
+        FgRange range_scalar("scalar_advection");
         for (int ch = 0; ch < s->cfg.n_scalars; ++ch) {
             if (int rc = fg_setup_advection(s, dt_B, 1, ch, stream)) return rc;
             FgBicgArgs a;
@@ -679,6 +680,8 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
     //      (folded into the assembly that reads the source: FgAdvArgs::buoy_T -- no k_buoyancy launch, the source field is written, not
     //      written and read back)
     // ---- velocity predictor (:1646-1762)
+    fg_range_push("velocity_assembly_and_solve");
+    struct PopOnce { bool armed = true; void fire() { if (armed) { fg_range_pop(); armed = false; } } ~PopOnce() { fire(); } } range_velocity;
     if (int rc = setup_advection(s, dt_B, 0, 0, stream, opt->buoyancy_axis, opt->buoyancy_factor)) return rc;
     {
         FgBicgArgs a;
@@ -694,7 +697,9 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
         s->ctr.add(1, info.data(), B * d);
     }
     // ---- correctors (:1777-1972); rA = 1/A was written by the velocity fg_setup_advection above
+    range_velocity.fire();
     for (int c = 0; c < opt->corrector_steps; ++c) {
+        FgRange range_corr(c == 0 ? "pressure_corrector_0" : "pressure_corrector_1+");
         const bool last = (c + 1 == opt->corrector_steps);
         if (!(c == 0 && s->jac_spec_done)) {      // (corrector 0: these two may already run behind the sweeps' check kernel, spec_h)
             if (int rc = fg_launch_h(s, dt_B, s->vel_result, st)) return rc;
@@ -791,6 +796,7 @@ static inline bool is_close_zero(double a) { return std::fabs(a) <= 1e-8; }
 
 extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out, fg_real* flux_host, void* stream) {
     fg_htrace("single_step_in");
+    FgRange range_sim("fg_single_step");
     FG_REQUIRE(s && o && out, FG_ERR_INVALID_ARG, "null argument");
     if (int rc = check_bound(s, o->step.advect_scalar && s->cfg.n_scalars > 0)) return rc;
     hipStream_t st = (hipStream_t)stream;

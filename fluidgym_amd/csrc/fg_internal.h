@@ -587,6 +587,10 @@ FgPollOut fg_poll_next(FgPoll* P);     // the words and sequence number of the n
 // waits until words [first, first + count) carry out.value (or, without words / after 50 ms of spinning, for the stream)
 int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st);
 void fg_htrace(const char* tag);      // FG_HTRACE=1: host time stamps (fg_poll.hip); a no-op otherwise
+// FG_ROCTX=1: named ranges around the phases of a step for rocprofv3 --marker-trace (fg_poll.hip; a no-op otherwise)
+void fg_range_push(const char* name);
+void fg_range_pop();
+struct FgRange { explicit FgRange(const char* name) { fg_range_push(name); } ~FgRange() { fg_range_pop(); } FgRange(const FgRange&) = delete; FgRange& operator=(const FgRange&) = delete; };
 
 struct FgBest {
     fg_real* best_crit;   // [B] residual of the last kept iterate (leader-only state)

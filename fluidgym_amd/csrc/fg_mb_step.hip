@@ -808,6 +808,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
         hipLaunchKernelGGL(k_mb_matrix<DIMS>, gn, blk, 0, st, D, dt_B, s->nu, s->cc, s->fb, s->Cdiag, s->Coff, s->rA);
         hipLaunchKernelGGL(k_mb_copy, gcopy, blk, 0, st, vel_env, dt_B, s->velocity, s->ures);  // CopyVelocityResultFromBlocks
         for (int no = 0; no < opt->advect_non_ortho_steps; ++no) {
+            FgRange range_vel("mb_velocity_solve");
             hipLaunchKernelGGL(k_mb_vrhs<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->velocity, s->ures, s->bvel, s->fb, s->source, s->rhs);
             int m = 0;
             // initial guess: zero on the first non-orthogonal pass, the previous pass's result after that (x = None if no_step == 0
@@ -859,6 +860,7 @@ extern "C" int fg_mb_piso_step(fg_mb_handle s, const mb_real* dt_B, const fg_mb_
             // SetupPressureMatrix inside the loop, PISOtorch_simulation.py:1790-1800, to the same values)
             if (c == 0) { hipLaunchKernelGGL(k_mb_pmatrix<DIMS>, gn, blk, 0, st, D, dt_B, s->rA, s->Pdiag, s->Poff, s->Poff4, SLOTS.cell_slot, SLOTS.off4, SLOTS.diag, SLOTS.stride); mb_slots_written(s); }
             for (int ps = 0; ps < opt->pressure_non_ortho_steps; ++ps) {
+                FgRange range_p("mb_pressure_solve");
                 if (ps == 0) {
                     hipLaunchKernelGGL(k_mb_h<DIMS>, gv, blk, 0, st, D, dt_B, s->nu, s->rA, s->Coff, s->velocity, s->ures,
                                        s->bvel, s->fb, s->source, s->hvec);

@@ -94,3 +94,31 @@ void fg_htrace(const char* tag) {
     }
     H.last = tag; H.t = now;
 }
+
+// ---- FG_ROCTX=1: named ranges for rocprofv3 --marker-trace (in place of the reference's profiling.py scopes,
+// /root/reference .../pict/util/profiling.py:48-499).  The roctx library is resolved at run time (dlopen), so the build and a run
+// without the switch do not depend on it.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    bool on = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("FG_ROCTX");
+        if (!(e && atoi(e) != 0)) return;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) { on = true; return; }
+        }
+        fprintf(stderr, "FG_ROCTX=1 but no roctx library could be loaded: ranges are off\n");
+    }
+};
+Roctx g_roctx;
+}  // namespace
+void fg_range_push(const char* name) { if (g_roctx.on) (void)g_roctx.push(name); }
+void fg_range_pop() { if (g_roctx.on) (void)g_roctx.pop(); }
+

@@ -34,6 +34,7 @@ NOTES = {
     "FG_JAC_XCD": ("no", "0: the on-chip Jacobi regions in launch order instead of one XCD per run of an env's regions (A/B runs)"),
     "FG_JAC_SHAPE": ("bits", "A/B runs of the Jacobi sweeps: 1 full-row regions only, 2 bands only (unset: the cheaper of the two for the grid)"),
     "FG_JAC_SWEEPS": ("bits", "A/B runs: sweeps per pass of the Jacobi sweeps (unset: 4 / 6 / 8 for full rows, 8 / 12 for bands, by region depth)"),
+    "FG_ROCTX": ("no", "1: named roctx ranges around the phases of a step (fg_single_step, scalar / velocity assembly and solve, pressure correctors; mb_velocity_solve, mb_pressure_solve) for rocprofv3 --marker-trace; the library is dlopen'ed, off by default"),
     "FG_HTRACE": ("no", "1: host time stamps around the polls and the launches behind them (fg_poll.hip), per-pair averages printed at exit"),
     "FG_FORCE_ZMARCH": ("bits", "z-march chunk length of the 3-D Poisson kernels (tests on small grids; -1 = brick kernels)"),
     "FG_ZMARCH_SB": ("no", "single-barrier ring of the z-march kernels: bit per mode, 0 never, unset = rule"),
