@@ -163,6 +163,7 @@ SIGNATURES = {
     "fg_make_divergence_free": (c_int, [c_void_p, c_float, c_int, POINTER(FgSolveInfo), c_void_p]),
     "fg_reset_solver_state": (c_int, [c_void_p, c_void_p]),
     "fg_solver_hints": (c_int, [c_void_p, POINTER(c_int32), c_int32]),
+    "fg_set_pressure_refinement": (c_int, [c_void_p, c_int32, c_float, c_float]),
     "fg_get_buffer": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)]),
     "fg_read_buffer": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "fg_poisson_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

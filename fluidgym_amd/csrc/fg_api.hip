@@ -114,6 +114,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     s->wall_forcing_axis = -1;
     s->adv_precond = 0; s->line_retries = 0; s->line_inv = nullptr; s->line_cp = nullptr; s->ilu_d = nullptr;
     s->double_fallback = 0; s->ladder_force = 0; s->r64_buf = nullptr; s->r64_acc = nullptr;
+    s->ref64_outer = 0; s->ref64_tol = 0.f; s->ref64_inner = 1e-4f; s->ref64_x = nullptr; s->ref64_corrections = 0;
     for (int k = 0; k < 4; ++k) s->rung_count[k] = 0;
     s->fd_lam = nullptr; s->helm_diag = s->helm_lower = s->helm_upper = s->helm_tmp = nullptr;
     s->cg_wgs_per_slot = 256;      // (FG_CG_WGS_PER_SLOT until round 5: never changed by a test or a bench leg -- a constant since round 6)
@@ -187,7 +188,7 @@ extern "C" int fg_destroy(fg_handle s) {
     if (s->jac_prev) (void)hipHostFree(s->jac_prev);
     (void)hipFree(s->fd_row_part); (void)hipFree(s->fd_lam_x); (void)hipFree(s->fd_row_inv); (void)hipFree(s->fd_row_cp); (void)hipFree(s->fd_row_lower);
     (void)hipFree(s->line_inv); (void)hipFree(s->line_cp); (void)hipFree(s->ilu_d);
-    (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->force_uniform);
+    (void)hipFree(s->r64_buf); (void)hipFree(s->r64_acc); (void)hipFree(s->ref64_x); (void)hipFree(s->force_uniform);
     (void)hipFree(s->fd_lam); (void)hipFree(s->helm_diag); (void)hipFree(s->helm_lower); (void)hipFree(s->helm_upper); (void)hipFree(s->helm_tmp); (void)hipFree(s->helm_lower_row); (void)hipFree(s->helm_lower_row2); (void)hipFree(s->line_inv2); (void)hipFree(s->line_cp2);
     (void)hipFree(s->cg_best.best_crit); (void)hipFree(s->cg_best.saved_crit); (void)hipFree(s->cg_best.save_at); (void)hipFree(s->cg_best.best_x);
     delete s;
@@ -531,8 +532,16 @@ static int solve_pressure(fg_state* s, const fg_real* dt, int method, fg_real to
         a.kind = kind;
         a.check_every = a.precond ? 2 : 16;
         a.lazy_ok = finalize ? 0 : 1;      // (the fused step's correctors read the result through FgLazyRef)
+#if !FG_F64
+        if (s->ref64_outer > 0) a.lazy_ok = 0;      // (the refinement below starts from the STORED fp32 result)
+#endif
         rc = fg_cg_solve(s, a, info_host, st);
 #if !FG_F64
+        // opt-in: fp64 residual, fp32 corrections (fg_refine64_pressure) -- the solve then ends on the fp64 residual's own verdict
+        if (s->ref64_outer > 0 && (rc == FG_OK || rc == FG_ERR_NOT_CONVERGED)) {
+            s->fcg_lazy_on = 0; s->fcg_check0_ran = 0; s->fcg_mean_ready = 0; s->fcg_spec_done = 0;      // (the result is rewritten in p_result)
+            rc = fg_refine64_pressure(s, a, info_host, st);
+        }
         // pressure solves run with returnBestResult: only a NON-FINITE solve counts as failed and is repeated in fp64
         // (solver_double_fallback, PISOtorch_diff.py:410-445)
         if (s->double_fallback && (rc == FG_ERR_NOT_FINITE || (s->ladder_force & 2))) {
@@ -562,6 +571,16 @@ extern "C" int fg_solve_pressure(fg_handle s, int method, fg_real tol, int max_i
     FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
     if (int rc = check_bound(s, false)) return rc;
     return solve_pressure(s, s->cur_dt, method, tol, max_iterations, use_previous, info_host, (hipStream_t)stream);
+}
+
+extern "C" int fg_set_pressure_refinement(fg_handle s, int32_t max_corrections, fg_real target_tol, fg_real inner_relative_tol) {
+    FG_REQUIRE(s, FG_ERR_INVALID_ARG, "null handle");
+    FG_REQUIRE(!FG_F64 || max_corrections <= 0, FG_ERR_UNSUPPORTED, "fg_set_pressure_refinement: the fp64 build solves in fp64 already");
+    FG_REQUIRE(max_corrections <= 0 || (target_tol > 0 && inner_relative_tol > 0 && inner_relative_tol < 1), FG_ERR_INVALID_ARG,
+               "fg_set_pressure_refinement: tolerances must be positive, the relative one below 1");
+    s->ref64_outer = max_corrections > 0 ? max_corrections : 0;
+    s->ref64_tol = (float)target_tol; s->ref64_inner = (float)inner_relative_tol;
+    return FG_OK;
 }
 
 extern "C" int fg_correct_velocity(fg_handle s, void* stream) {
@@ -749,11 +768,11 @@ extern "C" int fg_config_dump(fg_handle s, char* buf, int n) {
         "\"FG_BICG3_BXL\": %d, \"FG_BICG3_MIX\": %d, \"FG_REDUCE_WGS\": %d, \"FG_CG_WGS_PER_SLOT\": %d, \"FG_TRIDIAG_CB\": %d, \"FG_HELM_CB\": %d, "
         "\"FG_HELM_ROWFORM\": %d, \"FG_FD_ROWMEAN\": %d, \"FG_POLL_SPIN\": %d, \"FG_PROF_PERIOD\": %d, \"fast_transform_x\": %d, \"fd_preconditioner\": %d, "
         "\"helmholtz\": %d, \"advection_preconditioner\": %d, \"advection_from_result\": %d, \"return_best\": %d, \"cg_reset_steps\": %d, "
-        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d, \"FG_FCG_FIRST\": %d, \"FG_JAC_WARM\": %d, \"first_iterate_polls\": %ld, \"unstored_pressure_solves\": %ld, \"FG_JAC_SPEC\": %d, \"FG_FCG_SPEC\": %d, \"jacobi_speculation_misses\": %ld, \"jacobi_floor_released\": %ld}",
+        "\"double_fallback\": %d, \"wall_forcing_axis\": %d, \"FG_ADV_JACOBI\": %d, \"FG_FCG_FIRST\": %d, \"FG_JAC_WARM\": %d, \"first_iterate_polls\": %ld, \"unstored_pressure_solves\": %ld, \"FG_JAC_SPEC\": %d, \"FG_FCG_SPEC\": %d, \"jacobi_speculation_misses\": %ld, \"jacobi_floor_released\": %ld, \"pressure_refinement_corrections\": %ld}",
         FG_F64 ? "f64" : "f32", s->cg_fused, s->bicg_pfused, s->bicg_fused, s->bicg_sub, s->bicg3_force, s->bicg3_bxl, s->bicg3_mix, s->reduce_wgs,
         s->cg_wgs_per_slot, s->tridiag_cb, s->helm_cb_pref, s->helm_rowform_off ? 0 : 1, s->fd_rowmean, s->poll.spin, s->prof.period, s->fd_dct_x, s->fd_Qx ? 1 : 0,
         s->fd_lam ? 1 : 0, s->adv_precond, s->adv_from_result, s->cg_return_best, s->cg_reset_steps, s->double_fallback, s->wall_forcing_axis, s->adv_jacobi, s->fcg_first, s->jac_warm,
-        s->fcg_first_polls, s->fcg_unstored, s->jac_spec, s->fcg_spec, s->jac_spec_missed, s->jac_floor_released);
+        s->fcg_first_polls, s->fcg_unstored, s->jac_spec, s->fcg_spec, s->jac_spec_missed, s->jac_floor_released, s->ref64_corrections);
     if (len >= n) return len + 1;
     memcpy(buf, tmp, (size_t)len + 1);
     return FG_OK;

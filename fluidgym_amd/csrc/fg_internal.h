@@ -716,6 +716,9 @@ struct fg_state {
     // ladder_force (tests): first attempts count as failed (1 advection, 2 pressure, 4 also the advection fp64 rung)
     int double_fallback; int ladder_force; long long rung_count[4];
     double* r64_buf; FgDacc* r64_acc;
+    // opt-in mixed-precision refinement of the pressure solve (fg_set_pressure_refinement, fg_poisson.hip): outer corrections allowed (0 = off),
+    // target RMS of the fp64 residual, relative tolerance of the fp32 correction solves; fp64 iterate [B][n]; corrections run so far
+    int ref64_outer; float ref64_tol, ref64_inner; double* ref64_x; long ref64_corrections;
     // fast-diagonalisation preconditioner factors (device copies; null = not configured)
     float* fd_Qx; float* fd_QxT; float* fd_Qz; float* fd_QzT; float* fd_lower; float* fd_inv; float* fd_cp;   // (fp32 kernels only)
     // separable Helmholtz preconditioner of the advection-diffusion solves (fg_set_fd_helmholtz): eigenvalue sums lam [nz][nx] of the
@@ -956,6 +959,7 @@ struct FgCgLead;    // fg_cg.h
 int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead, bool use_rowmean = false, const float* factor_from = nullptr, const float* factor_dt = nullptr);
 bool fg_fd_tridiag_can_factor(const fg_state* s);      // the tridiagonal launch can make the row-mean factors itself (round 6)   // the per-mode Thomas solve of fg_fd_apply alone (in place); use_rowmean: the per-env factors of fg_fd_rowmean_factor
 bool fg_fd_rowmean_ok(const fg_state* s);
+int fg_refine64_pressure(fg_state* s, const FgCgArgs& a0, fg_solve_info* info_host, hipStream_t st);   // fg_poisson.hip (fp32 library only)
 int fg_fd_rowmean_factor(fg_state* s, const float* rA, const float* dt, hipStream_t st, const float* row_part = nullptr, int tiles_x = 0);
 // the factors for the CURRENT 1/A field ahead of the pressure solves that will want them (fg_cg_solve then finds them made): launched
 // behind a polled kernel, the factorisation -- 14 us, latency-sized, independent of the velocity solve -- runs while the host turns the

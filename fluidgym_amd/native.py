@@ -371,6 +371,11 @@ class NativeSolver:
         L.check(rc)
         return self.last_multi_results
 
+    def set_pressure_refinement(self, max_corrections: int = 3, target_tol: float = 1e-10, inner_relative_tol: float = 1e-4):
+        """Opt-in accuracy mode (``fg_set_pressure_refinement``): fp64 residual, fp32 corrections, at most ``max_corrections`` per
+        pressure solve or until the fp64 residual's RMS is below ``target_tol``; 0 switches it off."""
+        L.check(self.lib.fg_set_pressure_refinement(self.handle, int(max_corrections), self._c_real(target_tol), self._c_real(inner_relative_tol)), lib=self.lib)
+
     def solver_hints(self, values=None):
         """The 12 words the handle remembers between solves and that decide which iteration runs (``fg_solver_hints``): read as a
         list, or written from ``values``."""

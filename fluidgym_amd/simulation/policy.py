@@ -92,6 +92,16 @@ benchmark line can say which mode it ran in:
     Start vector of the sweeps: zero, like the BiCGStab they stand in for, except on on-chip grids of 2^17 cells and more (512 x 256),
     where the first pass reads the block velocity -- 16.6 sweeps instead of 24 (``FG_JAC_WARM``, docs/SWITCHES.md).
 
+``pressure_refinement`` (default 0 = off)
+    Single-block path, an ACCURACY mode: every pressure solve is followed by up to this many corrections of a mixed-precision
+    iterative refinement -- the iterate is kept in fp64, ``r = b - P x`` is formed in fp64 with the fp32 matrix entries promoted (as
+    the reference's fp64 fallback promotes its CSR values, ``PISOtorch_diff.py:418-445``), each correction is solved by the fp32
+    FD-preconditioned CG to a relative tolerance of 1e-4 (``fg_set_pressure_refinement``, ``csrc/fg_poisson.hip``), until the fp64
+    residual is 1000 x below the env's pressure tolerance.  What it buys: the fp32 path's distance from the fp64 answer on refined
+    grids is the ABSOLUTE residual tolerance of its pressure solves, not kernel error -- RBC 512 x 128: velocity 2.4e-5 of the forcing
+    scale without it, 9e-7 with two corrections (``tests/test_gpu_config3.py``), i.e. inside ``north_star``'s 1e-5.  Per env a few
+    launches and two host reads per correction: not a fast path.
+
 Set with :func:`set_solver_policy` or the environment variables ``FLUIDGYM_AMD_PRESSURE_WARM_START`` / ``FLUIDGYM_AMD_ADVECTION_WARM_START`` /
 ``FLUIDGYM_AMD_PRESSURE_STALL_ACCEPT`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL`` / ``FLUIDGYM_AMD_ADVECTION_LINE_PRECONDITIONER`` / ``FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB`` (read once
 at import).
@@ -113,6 +123,7 @@ _POLICY: Dict[str, Any] = {
     "native_wall_forcing": os.environ.get("FLUIDGYM_AMD_NATIVE_WALL_FORCING", "1") not in ("0", "", "false", "False"),
     "advection_jacobi": os.environ.get("FLUIDGYM_AMD_ADVECTION_JACOBI", "1") not in ("0", "", "false", "False"),
     "pressure_multilevel_bicgstab": os.environ.get("FLUIDGYM_AMD_PRESSURE_MULTILEVEL_BICGSTAB", "1") not in ("0", "", "false", "False"),
+    "pressure_refinement": int(os.environ.get("FLUIDGYM_AMD_PRESSURE_REFINEMENT", "0") or 0),
 }
 
 

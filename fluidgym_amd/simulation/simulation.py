@@ -173,6 +173,11 @@ class Simulation:
         self.advection_jacobi = bool(get_solver_policy()["advection_jacobi"])
         if hasattr(solver, "set_advection_jacobi"):
             solver.set_advection_jacobi(self.advection_jacobi)
+        # policy pressure_refinement (default 0 = off): the opt-in accuracy mode of the single-block pressure solves -- fp64 residual,
+        # fp32 corrections (fg_set_pressure_refinement); fp32 library only
+        self.pressure_refinement = int(get_solver_policy()["pressure_refinement"])
+        if self.pressure_refinement > 0 and hasattr(solver, "set_pressure_refinement") and not getattr(solver, "f64", False):
+            solver.set_pressure_refinement(self.pressure_refinement, target_tol=1e-3 * get_solver_tolerance(pressure_tol), inner_relative_tol=1e-4)
         # (bounds, velm, tol): advective-outflow PRE hook of the cylinder/airfoil envs (PISOtorch_simulation.py:
         # 228-393, wired in cylinder_env_base.py:280-300), kept as data so the native driver can run it
         self.outflow = outflow

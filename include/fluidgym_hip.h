@@ -237,6 +237,11 @@ int fg_setup_pressure_rhs(fg_handle h, const fg_real* dt_B, void* stream);
  * CopyPressureResultToBlocks.  method = FG_SOLVER_*.  info_host: B entries. */
 int fg_solve_pressure(fg_handle h, int method, fg_real tol, int max_iterations, int use_previous,
                       fg_solve_info* info_host, void* stream);
+/* Opt-in accuracy mode of the pressure solves of this handle (round 6): mixed-precision iterative refinement -- the iterate is kept
+ * in fp64, r = b - P x is formed in fp64 with the fp32 matrix entries promoted (what the reference's fp64 fallback does with its CSR
+ * values, PISOtorch_diff.py:418-445), each correction P d = r / |r| is solved by the fp32 solver to `inner_relative_tol`, at most
+ * `max_corrections` times or until RMS(r) < target_tol.  0 corrections = off (default).  fp32 library only. */
+int fg_set_pressure_refinement(fg_handle h, int32_t max_corrections, fg_real target_tol, fg_real inner_relative_tol);
 /* CorrectVelocity(version=1) (:6220-6236, kernel :5962-5995 + :816-849) */
 int fg_correct_velocity(fg_handle h, void* stream);
 /* CopyVelocityResultToBlocks / FromBlocks (:6558-6746) */

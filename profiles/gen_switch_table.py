@@ -25,6 +25,7 @@ NOTES = {
     "FG_FD_ROWMEAN": ("bits", "1 (default): the fused pressure CG is preconditioned by the row-mean operator (per-env factors, one factorisation per PISO step); 0: the grid's A = 1 factors"),
     "FG_ADV_JACOBI": ("bits", "velocity systems of uniform 2-D grids: 1 Jacobi sweeps first (fg_jacobi.hip), 0 BiCGStab always; unset = what fg_set_advection_jacobi says (the Simulation turns it on: policy advection_jacobi)"),
     "FLUIDGYM_AMD_ADVECTION_JACOBI": ("policy", "policy advection_jacobi (default 1): the Simulation asks for the Jacobi sweeps of fg_jacobi.hip on the grids that qualify"),
+    "FLUIDGYM_AMD_PRESSURE_REFINEMENT": ("bits", "policy pressure_refinement (default 0 = off): up to N mixed-precision corrections behind every single-block pressure solve (fp64 residual, fp32 corrections: fg_set_pressure_refinement) -- an accuracy mode"),
     "FLUIDGYM_AMD_MULTI_STEP": ("no", "0: the sim steps of an env step are issued one by one from Python instead of through fg_multi_step (A/B runs; same bits)"),
     "FG_FCG_FIRST": ("bits", "1 (default): the fused CG judges its first iterate from I'(0)'s dot products (k_fcg_check0) and stores no pressure when every env ends there; 0: the verdict on the updated residual (A/B runs, tests)"),
     "FG_JAC_WARM": ("bits", "start vector of the Jacobi sweeps of a step's velocity systems: 1 the block velocity, 0 the BiCGStab start vector (zero on the non-orthogonal branch); unset: the block velocity on on-chip grids of 2^17 cells and more (where it saves a pass)"),

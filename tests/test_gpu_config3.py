@@ -74,3 +74,56 @@ def test_rbc_full_batch_step_matches_oracle_and_env_steps():
         print("RBC2D-baseline-v0 x 32 iterations per solve:", {k: (v["mean"], v["max"]) for k, v in c.items() if isinstance(v, dict) and v["systems"]})
     finally:
         env.close()
+
+
+def test_rbc_step_with_the_refinement_rung_reaches_north_stars_1e_5():
+    """the fp32 bound of this config (velocity 5-7e-4 of the forcing scale) is the ABSOLUTE residual tolerance
+    of two fp32 pressure solves on a 40 : 1 wall-refined grid, not a kernel error (the fp64 twins).  With the opt-in mixed-precision
+    refinement of the pressure solve (``fg_set_pressure_refinement``: fp64 residual with the fp32 matrix promoted, fp32 FD-CG
+    corrections) the same step of the same 512 x 128 state lands within ``north_star``'s 1e-5 of the oracle's direct solves in
+    velocity; with the rung off the bound of the test above is unchanged."""
+    Bs = 4
+    env = fluidgym_amd.make("RBC2D-baseline-v0", num_envs=Bs)
+    try:
+        env.reset(seed=4)
+        ns = env._domain.solver
+        assert (ns.nx, ns.ny, ns.B) == (512, 128, Bs)
+        env.step(env.sample_action())
+        g = torch.Generator(device="cpu").manual_seed(5)
+        u0 = (ns.velocity.cpu() + 0.02 * torch.randn(ns.velocity.shape, generator=g)).contiguous()
+        T0 = ns.scalar.cpu().clone()
+        p0 = ns.pressure.cpu().clone()
+        bscal = {f: ns.bscal[f].cpu().numpy().astype(np.float64) for f in (2, 3)}
+        dt = 0.5 * float(env._dt)
+        edges = [np.concatenate([[0.0], np.cumsum(np.asarray(w, np.float64))]) for w in ns.widths[:2]]
+        grid = O.Grid(O.rectilinear_coords(edges))
+
+        def buoyancy(d, _dt):
+            s = np.zeros_like(d.velocity)
+            s[1] = float(env._buoyancy_factor) * d.scalar[0]
+            d.velocity_source = s
+
+        errs = {}
+        for rung in (0, 4):
+            ns.velocity.copy_(u0.to(ns.device)); ns.scalar.copy_(T0.to(ns.device)); ns.pressure.copy_(p0.to(ns.device))
+            ns.copy_velocity_result_from_blocks()
+            ns.reset_solver_state()
+            ns.set_pressure_refinement(rung, target_tol=2e-11, inner_relative_tol=1e-4)
+            ok, stats = ns.piso_step(dt, advection_tol=1e-7, pressure_tol=1e-7, buoyancy_axis=1, buoyancy_factor=float(env._buoyancy_factor))
+            assert ok, stats
+            vel = ns.velocity.cpu().numpy().astype(np.float64)
+            worst = 0.0
+            for b in (0, Bs - 1):
+                bc = {f: O.FixedBC(velocity=np.zeros(2), scalar=bscal[f][b], scalar_types=[O.DIRICHLET]) for f in (2, 3)}
+                ref = O.Domain(grid, float(env._nu), u0[b].numpy().astype(np.float64), np.zeros(grid.shape), bc,
+                               scalar=T0[b].numpy().astype(np.float64), scalar_viscosity=[float(env._kappa)])
+                O.piso_split_step(ref, dt, prep_fn={"PRE_VELOCITY_SETUP": [buoyancy]})
+                scale = max(float(np.abs(ref.velocity).max()), dt * float(env._buoyancy_factor) * float(np.abs(T0[b].numpy()).max()))
+                worst = max(worst, float(np.abs(vel[b] - ref.velocity).max()) / scale)
+            errs[rung] = worst
+            print(f"RBC_REFINE rung {rung}: velocity {worst:.2e} of the forcing scale, corrections so far {ns.config_dump()['pressure_refinement_corrections']}")
+        ns.set_pressure_refinement(0)
+        assert errs[0] < 1.2e-3                     # the bound of the fp32 path, unchanged
+        assert errs[4] <= 1e-5, errs                # north_star's rtol with the rung on
+    finally:
+        env.close()
