@@ -130,6 +130,9 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     s->helm_cb_pref = 32;          // (FG_HELM_CB until round 5; 64-column workgroups of k_helm_apply_y: 8.1 against 7.0 us)
     { const char* ev = getenv("FG_HELM_ROWFORM"); s->helm_rowform_off = (ev && atoi(ev) == 0) ? 1 : 0; }   // 0: k_helm_coeffs + the array-form line kernels
     { const char* ev = getenv("FG_FD_FACFUSE"); s->fd_facfuse = ev ? atoi(ev) : 1; }
+    // (default OFF: built for VERDICT r5 item 6 and measured on the RBC leg -- at the bench state's sub-step (0.02, not the 0.0125 the
+    //  round-5 experiment costed) the velocity systems take 16-17 sweeps and the scalar systems do not contract by 0.7: 775 against 793 env-steps/s)
+    { const char* ev = getenv("FG_ADV_LINESWEEP"); s->adv_linesweep = ev ? atoi(ev) : 0; }
     { const char* ev = getenv("FG_FD_ROWMEAN"); s->fd_rowmean = ev ? atoi(ev) : 1; }     // 0: the fused CG keeps the grid's A = 1 factors
     s->fd_row_epoch = -1; s->rA_epoch = 0; s->fd_row_part_epoch = -1;
     { const char* ev = getenv("FG_CG_FUSED"); s->cg_fused = ev ? atoi(ev) : 1; }       // 0: five-kernel preconditioned CG iteration (fg_poisson.hip)
@@ -666,7 +669,10 @@ extern "C" int fg_piso_step(fg_handle s, const fg_real* dt_B, const fg_step_opti
 #if !FG_F64
     // Helmholtz-preconditioned solves (RBC): the factors of the scalar AND the velocity system depend on dt, the diffusivities and
     // the wall conditions only -- one launch for both, ahead of the assemblies (fg_helm_factor_pair; the solves find the record)
-    if (scalar && s->cfg.n_scalars == 1 && s->adv_precond == 3 && s->fd_lam && !s->visc_field) {
+    // (not when the line sweeps are expected to settle both systems: the BiCGStab that needs the factors then never runs -- a solve the
+    //  sweeps hand over makes its own, fg_helm_factor)
+    const bool sweeps_first = s->adv_linesweep && s->grid.dims == 2 && s->jac_hist[0].skip == 0 && s->jac_hist[1].skip == 0;
+    if (scalar && s->cfg.n_scalars == 1 && s->adv_precond == 3 && s->fd_lam && !s->visc_field && !sweeps_first) {
         const float nu2[2] = {s->scalar_viscosity_set ? s->scalar_viscosity[0] : s->viscosity, s->viscosity};
         const int wlo[2] = {s->cfg.scalar_bc[2][0] == FG_DIRICHLET, 1}, whi[2] = {s->cfg.scalar_bc[3][0] == FG_DIRICHLET, 1};
         if (int rc = fg_helm_factor_pair(s, dt_B, nu2, wlo, whi, st)) return rc;

@@ -696,6 +696,23 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
         a2.use_x0 = 0;
         return bicgstab_krylov(s, a2, info_host, st, false);
     }
+    // the Helmholtz-preconditioned family (wall-refined 2-D grids: RBC): line sweeps first (fg_linepre.hip); what they do not settle
+    // goes to the preconditioned BiCGStab from a cleared start vector, with the solve state prepared afresh
+    if (fg_linesweep_ok(s, a)) {
+        const int nsys = s->grid.B * a.nc;
+        const bool ready = s->bicg_ready_nc == a.nc && s->bicg_ready_dt == a.dt;
+        s->bicg_ready_nc = 0; s->cg_ready_ns = 0;
+        if (!ready)
+            hipLaunchKernelGGL(k_bicg_begin, dim3((nsys + 63) / 64), dim3(64), 0, st, a.dt, s->acc, s->scratch_B + 4 * s->grid.B, s->flags, s->info_dev, nsys, a.nc);
+        int outcome = 0;
+        if (int rc = fg_linesweep_solve(s, a, info_host, st, &outcome)) return rc;
+        if (outcome == 1) { s->jac_solves += 1; return FG_OK; }
+        if (outcome == 0) return bicgstab_krylov(s, a, info_host, st, true);
+        s->jac_fallbacks += 1;
+        FgBicgArgs a2 = a;
+        a2.use_x0 = 0;
+        return bicgstab_krylov(s, a2, info_host, st, false);
+    }
 #endif
     return bicgstab_krylov(s, a, info_host, st, false);
 }

@@ -751,6 +751,7 @@ struct fg_state {
     // Jacobi sweeps for the velocity systems of the uniform 2-D grids (fg_jacobi.hip): switch (FG_ADV_JACOBI / fg_set_advection_jacobi),
     // per-kind history (sweeps the last solve needed; solves still to skip after a failure), pinned residuals of the pass before the last
     int adv_jacobi, adv_jacobi_env; FgJacHist jac_hist[4]; float* jac_prev;
+    int adv_linesweep;            // FG_ADV_LINESWEEP (default 1): line sweeps instead of the Helmholtz-preconditioned BiCGStab where they contract (fg_linepre.hip)
     long long jac_solves, jac_fallbacks;
     long jac_rA_epoch;      // rA_epoch at which rA = 1 / A was written for the velocity system in s->A (the streaming sweeps read it)
     FgCounters ctr;         // iterations per solve kind since the last reset (fg_solver_counters)
@@ -910,6 +911,9 @@ int fg_bicgstab_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host
 // stationary sweeps instead of the Krylov iteration where the rows are diagonally dominant (fg_jacobi.hip); *outcome: 0 not tried,
 // 1 solved, 2 given up -- then the caller runs BiCGStab from a cleared start vector behind a fresh k_bicg_begin
 bool fg_jacobi_ok(const fg_state* s, const FgBicgArgs& a);
+// line sweeps x <- (D + O_y)^-1 (b - O_x x) for the Helmholtz-preconditioned family (wall-refined 2-D grids: RBC); fg_linepre.hip, round 6
+bool fg_linesweep_ok(const fg_state* s, const FgBicgArgs& a);
+int fg_linesweep_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, int* outcome);
 int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, int* outcome);
 #endif
 // fp64 repeats of failed solves (fg_rung64.h; fp32 library only): every system of an env that has a failed one (BiCGStab: not

@@ -205,6 +205,168 @@ __global__ __launch_bounds__(256) void k_line_apply_y(LineArgs a, const float* r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// LINE SWEEPS (round 6): the stationary iteration x <- (D + O_y)^-1 (b - O_x x) for the advection-diffusion systems of wall-refined
+// 2-D grids (the RBC family), in place of the Helmholtz-preconditioned BiCGStab (bicgstabSolveGPU, bicgstab_solver_kernel.cu:63-411,
+// at rbc_env_base.py:318's tolerance).  Point sweeps do not contract there (the y part of a row sums to 0.78 of its diagonal at the
+// env's sub-step), line sweeps do: the x part is 0.18, measured contraction 0.23 per sweep (profiles/line_sweep_rbc.txt: 8 sweeps
+// from u^n, 10 from zero, to 1e-5).  One sweep is ONE launch of the y-line solve above with the x stencil folded into its load phase:
+// 36 B per cell (b, x and its two x neighbours, the two x coefficients, inv, c', l read; x written) against the ~80 us of a
+// six-launch preconditioned BiCGStab iteration.  A measuring sweep also sums the residual b - C x of the iterate it STARTED from
+// (diag, the +y coefficient and the rows above and below read on top).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LineSweepArgs {
+    const float* off;      // [B][4][N]: faces -x, +x, -y, +y
+    const float* rhs;      // [B][nc][N]
+    const float* xin; float* xout;   // [B][nc][N]; xin == nullptr: the sweep from zero
+    FgDacc* acc; int slot;           // slot >= 0: sum of squares of b - C x_in into acc[sys][slot]
+};
+template <bool MEASURE>
+__global__ __launch_bounds__(256) void k_line_sweep_y(LineArgs a, LineSweepArgs w) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];   // bs[nyp][64] | ms[nyp][64] | cs[nyp][64]
+    __shared__ float red[4];
+    const int sys = blockIdx.y;
+    if (a.flags[sys] != 0) return;
+    const int b = sys / a.nc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nx = a.nx, ny = a.ny, last = ny - 1;
+    const int nyp = (ny + LP_CH - 1) / LP_CH * LP_CH;
+    const size_t N = (size_t)nx * ny;
+    float* bs = tbuf;
+    float* ms = tbuf + (size_t)nyp * 64;
+    float* cs = tbuf + (size_t)2 * nyp * 64;
+    const LineCol c = line_col(nx, ny, 1);
+    const int i0 = (int)(c.col4 % (size_t)nx);                  // first of the lane's four columns
+    const int il = i0 == 0 ? nx - 1 : i0 - 1, ir = i0 + 4 >= nx ? 0 : i0 + 4;      // (a periodic wrap; at a wall the coefficient is zero)
+    const float* __restrict__ r4 = w.rhs + (size_t)sys * N + c.col4;
+    const float* __restrict__ x0 = w.xin ? w.xin + (size_t)sys * N : nullptr;
+    const float* __restrict__ i4 = a.inv + (size_t)b * N + c.col4;
+    const float* __restrict__ c4 = a.cp + (size_t)b * N + c.col4;
+    const float* __restrict__ l4 = a.lower + (size_t)b * a.lu_stride + c.col4;
+    const float* __restrict__ u4 = a.upper + (size_t)b * a.lu_stride + c.col4;
+    const float* __restrict__ d4 = a.diag + (size_t)b * N + c.col4;
+    const float* __restrict__ om4 = w.off + (size_t)b * 4 * N + c.col4;
+    const float* __restrict__ op4 = om4 + N;
+    float part = 0.f;
+    for (int jb = wave * 32; jb < nyp; jb += 128) {
+        float4 vr[8], vi[8], vc[8], vl[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = min(jb + 4 * q + c.rsub, last);
+            float4 rv = *reinterpret_cast<const float4*>(r4 + (size_t)j * nx);
+            vi[q] = *reinterpret_cast<const float4*>(i4 + (size_t)j * nx);
+            vc[q] = *reinterpret_cast<const float4*>(c4 + (size_t)j * nx);
+            vl[q] = *reinterpret_cast<const float4*>(l4 + (size_t)j * nx);
+            if (x0) {
+                const float* xr = x0 + (size_t)j * nx;
+                const float4 xc = *reinterpret_cast<const float4*>(xr + i0);
+                const float xl = xr[il], xrr = xr[ir];
+                const float4 om = *reinterpret_cast<const float4*>(om4 + (size_t)j * nx), op = *reinterpret_cast<const float4*>(op4 + (size_t)j * nx);
+                rv.x -= om.x * xl + op.x * xc.y;
+                rv.y -= om.y * xc.x + op.y * xc.z;
+                rv.z -= om.z * xc.y + op.z * xc.w;
+                rv.w -= om.w * xc.z + op.w * xrr;
+                if (MEASURE && jb + 4 * q + c.rsub <= last && c.live) {
+                    // b - C x = (b - O_x x) - (d x + l x[j - 1] + u x[j + 1]); l / u are zero at the walls
+                    const float4 dv = *reinterpret_cast<const float4*>(d4 + (size_t)j * nx), uv = *reinterpret_cast<const float4*>(u4 + (size_t)j * nx);
+                    const float4 xd = *reinterpret_cast<const float4*>(x0 + (size_t)(j > 0 ? j - 1 : j) * nx + i0);
+                    const float4 xu = *reinterpret_cast<const float4*>(x0 + (size_t)(j < last ? j + 1 : j) * nx + i0);
+                    const float e0 = rv.x - (dv.x * xc.x + vl[q].x * xd.x + uv.x * xu.x), e1 = rv.y - (dv.y * xc.y + vl[q].y * xd.y + uv.y * xu.y);
+                    const float e2 = rv.z - (dv.z * xc.z + vl[q].z * xd.z + uv.z * xu.z), e3 = rv.w - (dv.w * xc.w + vl[q].w * xd.w + uv.w * xu.w);
+                    part += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+                }
+            } else if (MEASURE && jb + 4 * q + c.rsub <= last && c.live) {
+                part += (rv.x * rv.x + rv.y * rv.y) + (rv.z * rv.z + rv.w * rv.w);      // x = 0: the residual is b
+            }
+            vr[q] = rv;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = jb + 4 * q + c.rsub;
+            if (j < nyp) {
+                const float m = (j > last) ? 0.f : 1.f;   // padding rows are neutral
+                const int o = j * 64 + c.lc;
+                *reinterpret_cast<float4*>(bs + o) =
+                    make_float4(vr[q].x * vi[q].x * m, vr[q].y * vi[q].y * m, vr[q].z * vi[q].z * m, vr[q].w * vi[q].w * m);
+                *reinterpret_cast<float4*>(ms + o) =
+                    make_float4(vl[q].x * vi[q].x * m, vl[q].y * vi[q].y * m, vl[q].z * vi[q].z * m, vl[q].w * vi[q].w * m);
+                *reinterpret_cast<float4*>(cs + o) = make_float4(vc[q].x * m, vc[q].y * m, vc[q].z * m, vc[q].w * m);
+            }
+        }
+    }
+    if (MEASURE) {
+        const float sv = fg_wave_sum(part);
+        if (lane == 0) red[wave] = sv;
+    }
+    __syncthreads();
+    if (MEASURE && threadIdx.x == 64) acc_add(w.acc + (size_t)sys * FG_ACC_DOUBLES + w.slot, (double)((red[0] + red[1]) + (red[2] + red[3])));
+    if (wave == 0) {
+        float prev = 0.f;
+        float* px = bs + lane;
+        const float* pm = ms + lane;
+        for (int j0 = 0; j0 < nyp; j0 += LP_CH, px += LP_CH * 64, pm += LP_CH * 64) {
+            float ax[LP_CH], am[LP_CH];
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { ax[q] = px[q * 64]; am[q] = pm[q * 64]; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { prev = fmaf(-am[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) px[q * 64] = ax[q];
+        }
+        prev = 0.f;
+        px = bs + (size_t)(nyp - LP_CH) * 64 + lane;
+        const float* pc = cs + (size_t)(nyp - LP_CH) * 64 + lane;
+        for (int j0 = nyp - LP_CH; j0 >= 0; j0 -= LP_CH, px -= LP_CH * 64, pc -= LP_CH * 64) {
+            float ax[LP_CH], ac[LP_CH];
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) { ax[q] = px[q * 64]; ac[q] = pc[q * 64]; }
+#pragma unroll
+            for (int q = LP_CH - 1; q >= 0; --q) { prev = fmaf(-ac[q], prev, ax[q]); ax[q] = prev; }
+#pragma unroll
+            for (int q = 0; q < LP_CH; ++q) px[q * 64] = ax[q];
+        }
+    }
+    __syncthreads();
+    if (c.live) {
+        float* z4 = w.xout + (size_t)sys * N + c.col4;
+        for (int jb = wave * 32; jb < ny; jb += 128) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + 4 * q + c.rsub;
+                if (j <= last)
+                    *reinterpret_cast<float4*>(z4 + (size_t)j * nx) = *reinterpret_cast<const float4*>(bs + j * 64 + c.lc);
+            }
+        }
+    }
+}
+
+// verdict behind a measuring sweep, per system (k_bicg_check's rule on the sweep's own sum), mirrors, and for the host the last two
+// measured residuals plus those of the FIRST two measuring sweeps (its give-up rule reads fixed sweeps, whatever it enqueued ahead)
+__global__ void k_line_sweep_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info, fg_solve_info* __restrict__ mirror,
+                                   float* __restrict__ res, float tol, int slot_now, int slot_prev, int sweeps, int n, int nsys, FgPollOut poll) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsys) return;
+    float now = -1.f, prev = -1.f;
+    if (flag_ld(flags + s) == 0) {
+        const FgDacc* A = acc + (size_t)s * FG_ACC_DOUBLES;
+        now = (float)sqrt(acc_ld(A + slot_now) / (double)n);
+        if (slot_prev >= 0) prev = (float)sqrt(acc_ld(A + slot_prev) / (double)n);
+        info[s].final_residual = now;
+        info[s].used_iterations = sweeps;
+        if (!(now >= tol)) {
+            const bool finite = isfinite(now);
+            flag_st(flags + s, finite ? 1 : 2);
+            info[s].converged = finite ? 1 : 0;
+            info[s].is_finite = finite ? 1 : 0;
+        }
+        res[2 * nsys + 2 * s] = (float)sqrt(acc_ld(A + 0) / (double)n);
+        res[2 * nsys + 2 * s + 1] = slot_now >= 1 ? (float)sqrt(acc_ld(A + 1) / (double)n) : -1.f;
+    }
+    res[2 * s] = now; res[2 * s + 1] = prev;
+    mirror[s] = info[s];
+    fg_poll_publish(poll, s);
+}
+
 // ---- streaming forms (any nx, ny): one thread per column, rows read in unrolled groups so that loads stay in flight
 __global__ __launch_bounds__(256) void k_line_factor_y_stream(LineArgs a) {
     const int b = blockIdx.y;
@@ -629,5 +791,94 @@ int fg_line_apply(fg_state* s, const float* diag, const float* off, int nc, cons
     else
         FG_LAUNCH_P(s, slot, k_line_apply_y_stream, dim3((cols + 255) / 256, nsys), dim3(256), 0, st, a, r, z);
     FG_HIP_CHECK(hipGetLastError());
+    return FG_OK;
+}
+
+// ---- line sweeps: driver.  *outcome: 0 not tried (the kind is backing off), 1 solved, 2 given up (the caller runs its Krylov solver
+// from a cleared start vector behind a fresh k_bicg_begin).  Check points at FIXED sweep counts (6, 8, ... 20) with the verdict on the
+// device, per system; the host's give-up rule reads the residuals the FIRST two measuring sweeps left (sweeps 3 and 5), so which
+// solver runs is a function of the system, not of where the previous solve of the kind made this one poll first.
+bool fg_linesweep_ok(const fg_state* s, const FgBicgArgs& a) {
+    return s->adv_linesweep && a.precond == 2 && s->grid.dims == 2 && s->grid.nz == 1 && a.nc <= 2 && s->jac_prev != nullptr && (s->grid.nx & 3) == 0 &&
+           line_lds_bytes(s) <= 160 * 1024;
+}
+int fg_linesweep_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, hipStream_t st, int* outcome) {
+    *outcome = 0;
+    FgJacHist& H = s->jac_hist[a.kind & 3];
+    if (H.skip > 0) { --H.skip; return FG_OK; }
+    *outcome = 2;
+    if (!line_use_lds(s)) return FG_OK;
+    if (int rc = fg_line_alloc(s)) return rc;
+    constexpr int FIRST = 6, STEP = 2, CHECKS = 8;
+    const FgGrid& G = s->grid;
+    const int B = G.B, n = G.n, nc = a.nc, nsys = B * nc, cols = G.nx;
+    if (int rc = fg_line_factor(s, a.diag, a.off, nc, st)) return rc;      // (D + O_y) = L U per env, once per solve
+    const LineArgs la = line_args(s, a.diag, a.off, nc);
+    float* buf[2] = {a.x, s->w[0]};      // sweep k writes buf[(k + 1) & 1]: the check points are even counts, so each ends in a.x
+    LineSweepArgs w;
+    w.off = a.off; w.rhs = a.rhs; w.acc = s->acc;
+    int sweeps = 0, checks = 0;
+    const double bytes_sys = 36.0 * n, flops_sys = 12.0 * n;
+    auto run_to_check = [&](int upto, const FgPollOut& po_last) -> int {
+        while (checks < upto) {
+            const int target = FIRST + STEP * checks;
+            for (; sweeps < target; ++sweeps) {
+                const int o = (sweeps + 1) & 1;
+                w.xin = (sweeps == 0 && !a.use_x0) ? nullptr : buf[o ^ 1];
+                w.xout = buf[o];
+                w.slot = (sweeps >= FIRST - 3 && (sweeps & 1)) ? (sweeps - (FIRST - 3)) / 2 : -1;      // sweeps 3, 5, ... -> slots 0, 1, ...
+                const int pslot = fg_prof_slot(s, FG_PK_LINE, s->flags, nsys, bytes_sys, flops_sys, st);
+                if (w.slot >= 0) FG_LAUNCH_P(s, pslot, (k_line_sweep_y<true>), dim3((cols + 63) / 64, nsys), dim3(256), line_lds_bytes(s), st, la, w);
+                else FG_LAUNCH_P(s, pslot, (k_line_sweep_y<false>), dim3((cols + 63) / 64, nsys), dim3(256), line_lds_bytes(s), st, la, w);
+            }
+            ++checks;
+            const int now = (target - 1 - (FIRST - 3)) / 2;
+            if (checks == upto) fg_prof_prefetch(s, st);
+            hipLaunchKernelGGL(k_line_sweep_check, dim3((nsys + 63) / 64), dim3(64), 0, st, s->acc, s->flags, s->info_dev, s->info_pinned, s->jac_prev, a.tol,
+                               now, now - 1, sweeps, n, nsys, checks == upto ? po_last : FgPollOut{nullptr, 0});
+        }
+        FG_HIP_CHECK(hipGetLastError());
+        return FG_OK;
+    };
+    int upto = 1;
+    if (H.sweeps > FIRST) upto = 1 + (H.sweeps - FIRST + STEP - 1) / STEP;
+    if (upto > CHECKS) upto = CHECKS;
+    bool ok = false;
+    for (;;) {
+        const FgPollOut po = fg_poll_next(&s->poll);
+        if (int rc = run_to_check(upto, po)) return rc;
+        if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
+        bool all = true, bad = false;
+        double need = 0.0;
+        for (int i = 0; i < nsys; ++i) {
+            const fg_solve_info& I = s->info_pinned[i];
+            if (!I.is_finite) bad = true;
+            const double r1 = s->jac_prev[2 * i], r0 = s->jac_prev[2 * i + 1];
+            if (I.converged || !I.is_finite || r1 < 0.0) continue;      // (settled here or at an earlier check point, or inactive)
+            all = false;
+            if (r0 > 0.0 && r1 > 0.0 && r1 < r0) { const double m = log((double)a.tol / r1) / log(sqrt(r1 / r0)); need = m > need ? m : need; }
+            else need = need > 2.0 ? need : 2.0;
+            // give up from the residuals of sweeps 3 and 5 (two sweeps apart): less than 0.7 per sweep is not the regime this is for
+            const double f0 = s->jac_prev[2 * nsys + 2 * i], f1 = s->jac_prev[2 * nsys + 2 * i + 1];
+            if (f0 > 0.0 && f1 > 0.0 && !(sqrt(f1 / f0) < 0.7)) bad = true;
+        }
+        if (all && !bad) { ok = true; break; }
+        if (bad) break;
+        const int more = 1 + (int)(ceil(need > 1.0 ? need : 1.0) - 1) / STEP;
+        if (checks >= CHECKS) break;
+        upto = checks + more > CHECKS ? CHECKS : checks + more;
+    }
+    if (int prc = fg_prof_collect(s, st)) return prc;
+    if (!ok) {
+        H.fails += 1; H.skip = H.fails > 6 ? 512 : (4 << H.fails); H.sweeps = 0;
+        return FG_OK;
+    }
+    int used_max = 0;
+    for (int i = 0; i < nsys; ++i) {
+        used_max = s->info_pinned[i].used_iterations > used_max ? s->info_pinned[i].used_iterations : used_max;
+        if (info_host) info_host[i] = s->info_pinned[i];
+    }
+    H.fails = 0; H.sweeps = used_max > 0 ? used_max : FIRST;
+    *outcome = 1;
     return FG_OK;
 }

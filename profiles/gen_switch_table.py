@@ -21,6 +21,7 @@ NOTES = {
     "FG_BICG3_MIX": ("bits", "debugging: bit 0 kernel a, bit 1 kernel b as z-march, bit 2 keep the init kernel"),
     "FG_REDUCE_WGS": ("no", "workgroups per env of the reduction kernels (0 = rule)"),
     "FG_HELM_ROWFORM": ("bits", "0: Helmholtz factors through k_helm_coeffs + the array-form line kernels (IEEE division instead of v_rcp)"),
+    "FG_ADV_LINESWEEP": ("bits", "1: the advection-diffusion systems of the Helmholtz-preconditioned family (wall-refined 2-D grids: RBC) go to line sweeps x <- (D + O_y)^-1 (b - O_x x) first (k_line_sweep_y, fg_linepre.hip), BiCGStab takes what they do not settle; 0 (default): the preconditioned BiCGStab always -- measured on the RBC leg: 16-17 sweeps per velocity solve at the bench state's sub-step, 775 against 793 env-steps/s"),
     "FG_FD_FACFUSE": ("no", "1 (default): the first tridiagonal solve after 1/A changed makes the per-env row-mean factors itself (k_tridiag_y_lds<.., FAC>: same arithmetic, same bits); 0: k_fd_rowmean_factor as a launch of its own (A/B runs)"),
     "FG_FD_ROWMEAN": ("bits", "1 (default): the fused pressure CG is preconditioned by the row-mean operator (per-env factors, one factorisation per PISO step); 0: the grid's A = 1 factors"),
     "FG_ADV_JACOBI": ("bits", "velocity systems of uniform 2-D grids: 1 Jacobi sweeps first (fg_jacobi.hip), 0 BiCGStab always; unset = what fg_set_advection_jacobi says (the Simulation turns it on: policy advection_jacobi)"),

@@ -119,3 +119,35 @@ def test_rbc_like_piso_step_with_both_fused_solvers(monkeypatch):
         O.piso_split_step(dom, [0.04, 0.025][b], prep_fn={"PRE_VELOCITY_SETUP": [buoy]})
         assert rel_err(t1[b], dom.scalar) < 1e-5
         assert rel_err(u1[b], dom.velocity) < 1e-4      # (error scale = the buoyancy forcing the projection cancels, as in test_buoyancy_fused_rbc_like_step)
+
+
+@pytest.mark.parametrize("from_result", [False, True])
+def test_line_sweeps_reach_the_direct_solve_and_hand_over_what_they_cannot(from_result, monkeypatch):
+    """Round 6 (opt-in: FG_ADV_LINESWEEP=1): the velocity systems of a wall-refined periodic-x grid by line sweeps
+    x <- (D + O_y)^-1 (b - O_x x) (``k_line_sweep_y``, csrc/fg_linepre.hip: the y-line solve with the x stencil folded into its load
+    phase) instead of the Helmholtz-preconditioned BiCGStab.  Small time steps (x part of a row well below its diagonal): settled by
+    the sweeps, the direct solve's answer to the solver tolerance.  A time step 40 x larger: the sweeps do not contract by 0.7, the
+    first check sees it from the residuals of sweeps 3 and 5, BiCGStab solves the system from a cleared start and the kind backs off."""
+    case = _wall_refined(make_case(dims=2, n=(128, 32), fixed_axes=(1,), B=3, seed=4, nu=0.05, vel_scale=0.3, stretch=0.0), ratio=12.0)
+    monkeypatch.setenv("FG_ADV_LINESWEEP", "1")
+    for dt, settled in (([0.002, 0.001, 0.003], True), ([0.08, 0.04, 0.12], False)):
+        ns = case.native()
+        ns.set_advection_start(from_result)
+        ns.set_advection_preconditioner(3)
+        ns.setup_advection(dt)
+        info = ns.solve_advection(tol=2e-6 / min(dt))      # (a residual fp32 can show: the right-hand side is u / dt ~ 300, its rounding ~4e-4)
+        torch.cuda.synchronize()
+        assert all(i.converged and i.is_finite for i in info), [(i.used_iterations, i.final_residual) for i in info]
+        counts = ns.advection_jacobi_counts()
+        x = _np(ns.buffer(3, (case.B, 2) + case.shape))
+        ns.close()
+        assert counts == ({"settled_by_sweeps": 1, "handed_to_bicgstab": 0} if settled else {"settled_by_sweeps": 0, "handed_to_bicgstab": 1}), (dt, counts)
+        print(f"LINE-SWEEPS dt {dt} from_result={from_result}: {counts}, iterations {[i.used_iterations for i in info]}")
+        g = case.grid()
+        for b in range(case.B):
+            dom = case.oracle_domain(b, g)
+            C, _, _ = O.build_advection_matrix(dom, dt[b])
+            rhs = O.advection_rhs_velocity(dom, dt[b])
+            for comp in range(2):
+                x_ref = O.solve_direct(C, rhs[comp].ravel()).reshape(case.shape)
+                assert rel_err(x[b, comp], x_ref) < 1e-4, (dt, b, comp)
