@@ -43,6 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
 ENVS_PER_GPU = 64
 ENV_ID = "ChannelJet2D-v0"
+LANES = 2             # sub-batches per GPU stepped concurrently on their own HIP streams (ParallelFluidEnv(lanes=...); --lanes 1 = one batch)
 
 
 def poisson_micro(device, n=256, iters=20):
@@ -347,7 +348,7 @@ def whole_step_gbps_model(prof, elapsed_s, its, solver):
     (k_adv_build: 44 B in 2-D, 56 B in 3-D) and per corrector k_h (52 / 68), the divergence / start kernel (28) and k_correct (28 / 36).
     A model, not a measurement: what the whole step moves at least, over the wall time of the timed regions."""
     try:
-        cells = float(solver.nx) * float(solver.ny) * float(max(solver.nz, 1)) * float(solver.B)
+        cells = float(solver.nx) * float(solver.ny) * float(max(solver.nz, 1)) * float(solver.B)      # (per handle: its["piso_steps"] sums the lanes)
         three_d = solver.nz > 1
     except Exception:
         return None
@@ -383,6 +384,32 @@ def velocity_solver_desc(env, solver) -> str:
         return "BiCGStab (the reference's solver)"
     return (f"on-chip Jacobi sweeps (policy advection_jacobi; {c['settled_by_sweeps']} solves settled by them, {c['handed_to_bicgstab']} handed to "
             "BiCGStab; the velocity 'iterations' are sweeps); krylov_mode leg = BiCGStab")
+
+
+def merge_profiles(profs):
+    """Sum of the native profiles of the lanes of one GPU (every field is a sum over launches or samples)."""
+    out = {}
+    for p in profs:
+        for name, r in p.items():
+            o = out.setdefault(name, dict.fromkeys(r, 0))
+            for k, v in r.items():
+                o[k] += v
+    return out
+
+
+def merge_iterations(items):
+    """solver_iterations of the lanes of one GPU as one table: systems / unconverged / piso_steps summed, max of the maxima, means
+    weighted by systems."""
+    if len(items) == 1:
+        return items[0]
+    out = {"piso_steps": sum(i["piso_steps"] for i in items)}
+    for k in sorted({k for i in items for k in i if k != "piso_steps"}):
+        rows = [i[k] for i in items if k in i]
+        n = sum(r["systems"] for r in rows)
+        means = [r for r in rows if r["mean"] is not None]
+        out[k] = {"mean": round(sum(r["mean"] * r["systems"] for r in means) / max(sum(r["systems"] for r in means), 1), 2) if means else None,
+                  "max": max(r["max"] for r in rows), "unconverged": sum(r.get("unconverged", 0) for r in rows), "systems": n}
+    return out
 
 
 def solver_iterations(solver) -> dict:
@@ -673,6 +700,9 @@ def main():
                          "reports the MEDIAN region and the spread (boxes and runs differ by a few per cent: VERDICT r5, bench method)")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--env-id", default=ENV_ID)
+    ap.add_argument("--lanes", type=int, default=LANES,
+                    help="sub-shards of a GPU's env batch stepped concurrently on their own HIP streams by their own host threads "
+                         "(ParallelFluidEnv(lanes=...)): the step is bound by host round trips, a second lane's kernels fill the gaps; 1 = one batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--no-airfoil-leg", action="store_true", help="skip the Airfoil2D-easy-v0 x 64 leg (about 18 s)")
@@ -720,32 +750,37 @@ def main():
         dist.init_process_group(backend="gloo" if args.share_gpu else "nccl", init_method="env://", timeout=timedelta(seconds=600))
     n_total = args.envs_per_gpu * world
     if args.share_gpu:
-        penv = ParallelFluidEnv(args.env_id, num_envs=n_total, backend="gloo", cuda_ids=[0] * world)
+        penv = ParallelFluidEnv(args.env_id, num_envs=n_total, backend="gloo", cuda_ids=[0] * world, lanes=args.lanes)
     else:
-        penv = ParallelFluidEnv(args.env_id, num_envs=n_total)
-    env = penv.local_env
+        penv = ParallelFluidEnv(args.env_id, num_envs=n_total, lanes=args.lanes)
+    env = penv.local_env            # (with lanes: the lane group; attributes that are the same for every lane come from lane 0)
+    lane_envs = penv.lane_envs
     penv.reset(seed=1234, randomize=True)
-    gen = torch.Generator(device="cpu").manual_seed(7)
+    # the policy's actions are drawn ON the GPU: the contract times the step with its inputs resident in HBM (until round 5 they were
+    # drawn on the host and copied: 0.27 ms of a 7.2 ms step, profiles/headline_glue.py)
+    gen = torch.Generator(device=device).manual_seed(7)
     a_shape = (n_total,) + tuple(env._zero_action.shape[1:])  # [envs, (agents,) *per-agent action shape]
 
     def actions():
-        return (torch.rand(a_shape, generator=gen) * 2 - 1).to(device) if penv.is_driver else None
+        return (torch.rand(a_shape, generator=gen, device=device) * 2 - 1) if penv.is_driver else None
 
     # Synthetic unsteadiness.  The laminar Re = 100 channel settles to a state whose pressure right-hand side sits AT the
     # reference's absolute tolerance (RMS 1e-5 of the volume-integrated divergence), so its projections take 0-1 iterations
     # (`quiescent_mode` below).  To time the path the metric is named after, the flow is stirred: a random body force
     # (block.velocitySource, a feature of the reference's solver: PISO_multiblock_cuda_kernel.cu:2256-2267) ~ N(0, forcing) per
     # cell and component, redrawn every env step, so that BOTH pressure solves of EVERY PISO step have a divergence to remove.
-    blk0 = env._domain.getBlock(0)
-    single_block = hasattr(blk0, "setVelocitySource")     # the body force is a feature of the single-block Domain; the reference's
+    blks = [e._domain.getBlock(0) for e in lane_envs]
+    single_block = hasattr(blks[0], "setVelocitySource")  # the body force is a feature of the single-block Domain; the reference's
     forcing = args.forcing if single_block else 0.0       # own multi-block envs (--env-id CylinderJet2D-easy-v0, ...) run as they are
     if forcing > 0:
-        blk0.setVelocitySource(torch.zeros_like(blk0.velocity))
+        for b in blks:
+            b.setVelocitySource(torch.zeros_like(b.velocity))
     force_gen = torch.Generator(device=device).manual_seed(4321 + rank)
 
     def perturb():
         if forcing > 0:
-            blk0.velocitySource.normal_(0.0, forcing, generator=force_gen)
+            for b in blks:
+                b.velocitySource.normal_(0.0, forcing, generator=force_gen)
 
     def one_step():
         perturb()
@@ -753,9 +788,11 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    solver = env._domain.solver
-    solver.solver_counters(reset=True)
-    solver.profile_enable(True)
+    solvers = [e._domain.solver for e in lane_envs]
+    solver = solvers[0]
+    for sv in solvers:
+        sv.solver_counters(reset=True)
+        sv.profile_enable(True)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -798,9 +835,11 @@ def main():
         per_rank = {"shard_ms_per_step": [round(v, 3) for v in ms], "min_ms": round(min(ms), 3), "max_ms": round(max(ms), 3),
                     "imbalance": round(max(ms) / max(min(ms), 1e-9), 3),
                     "mean_substeps_per_sim_step": [round(r[1] / max(args.steps * n_rep * env._n_sim_steps, 1), 2) for r in allr]}
-    prof = solver.profile_read()
-    solver.profile_enable(False)
-    its = solver_iterations(solver)
+    prof = merge_profiles([sv.profile_read() for sv in solvers])
+    for sv in solvers:
+        sv.profile_enable(False)
+    its = merge_iterations([solver_iterations(sv) for sv in solvers])      # (piso_steps: summed over the lanes)
+    n_lanes = len(solvers)
     n_sim = env._n_sim_steps
 
     grid_desc = [solver.nx, solver.ny, solver.nz] if single_block else {"cells_per_env": int(solver.n_cells), "blocks": len(solver.blocks)}
@@ -840,6 +879,10 @@ def main():
                        "workload_modified": forcing > 0,
                        "forcing_amplitude": forcing,
                        "global_batch": n_total, "grid": grid_desc,
+                       "lanes_per_gpu": n_lanes,
+                       "lanes_doc": (f"{n_lanes} sub-batches of {args.envs_per_gpu // n_lanes} envs per GPU, each its own solver handle, stepped concurrently by "
+                                     f"{n_lanes} host threads on {n_lanes} HIP streams (fluidgym_amd/envs/parallel_env.py 'Lanes'): kernel durations in `roofline` "
+                                     "are each lane's own launches, timed while the other lane's kernels share the GPU") if n_lanes > 1 else None,
                        "parallelism": f"env-sharded x{world}, 1 bcast + 1 all_gather per step ({'gloo, ALL RANKS ON ONE GPU: dry run, not a scaling figure' if args.share_gpu else 'RCCL'})",
                        "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start),
                        "pressure_solver": ("CG preconditioned by the separable constant-coefficient operator (cosine transform + tridiagonal sweep)"
@@ -847,12 +890,12 @@ def main():
                        "advection_solver_form": solver.advection_solver_form() if single_block else None,
                        "velocity_solver": velocity_solver_desc(env, solver) if single_block else None,
                        "solver_iterations": its, "capped_solves": capped_solves(its),
-                       "floor_released_solves": (solver_switches(solver) or {}).get("jacobi_floor_released") if single_block else None,
+                       "floor_released_solves": sum(int((solver_switches(sv) or {}).get("jacobi_floor_released") or 0) for sv in solvers) if single_block else None,
                        "iters_are": "iterations per solve (counts; 0 = initial residual met the tolerance)",
                        "launches_per_piso_step": launches_per_piso_step(prof, its) if single_block else None,
                        "solver_kernels_GBps": step_gbps(prof, total_elapsed) if single_block else None,
                        "whole_step_GBps_model": whole_step_gbps_model(prof, total_elapsed, its, solver) if single_block else None,
-                       "mean_substeps_per_sim_step": round(its["piso_steps"] / max(args.steps * n_rep * n_sim, 1), 2),
+                       "mean_substeps_per_sim_step": round(its["piso_steps"] / n_lanes / max(args.steps * n_rep * n_sim, 1), 2),
                        "per_rank": per_rank, "switches": solver_switches(solver)},
             "roofline": roof,
             "legs": {},

@@ -195,6 +195,9 @@ SIGNATURES = {
                                     POINTER(ctypes.c_float), c_int, c_int, POINTER(c_void_p)]),
     "fg_resampler_destroy": (c_int, [c_void_p]),
     "fg_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "fg_envglue_jet_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fg_envglue_channel_observe": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fg_mb_create": (c_int, [c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "fg_mb_destroy": (c_int, [c_void_p]),
     "fg_config_dump": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
@@ -278,7 +281,7 @@ _F64_STRUCTS[FgMbSimOptions] = _f64_struct(FgMbSimOptions)
 FgStepOptionsF64, FgSimOptionsF64 = _F64_STRUCTS[FgStepOptions], _F64_STRUCTS[FgSimOptions]
 FgMbStepOptionsF64, FgMbSimOptionsF64 = _F64_STRUCTS[FgMbStepOptions], _F64_STRUCTS[FgMbSimOptions]
 _F64_KEEP_FLOAT = ("fg_set_fd_preconditioner", "fg_set_fd_fast_transform", "fg_set_fd_helmholtz", "fg_coords_to_transforms", "fg_stream_triad")
-_F64_ABSENT_PREFIXES = ("fg_resampl", "fg_sparse_")
+_F64_ABSENT_PREFIXES = ("fg_resampl", "fg_sparse_", "fg_envglue_")
 
 
 def _f64_type(tp):

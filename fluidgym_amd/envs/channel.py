@@ -21,6 +21,7 @@ on a single block; what is missing is the body (multi-block connections, SURVEY 
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -129,6 +130,11 @@ class ChannelJetEnv2D(FluidEnv):
         flat = (iy[None, :] * self._x + ix[:, None]).reshape(-1)
         self._sensor_idx = torch.from_numpy(flat).to(dev)
         self._hy = float(self.H / self._y)
+        # the glue either side of the sim steps as two native launches (csrc/fg_envglue.hip) instead of ~25 elementwise torch launches;
+        # FLUIDGYM_AMD_ENV_GLUE=0 keeps the torch expressions below (the A/B switch; they are also what a CPU test stub runs)
+        self._native_glue = (dev.type == "cuda" and self._dtype == torch.float32 and self._x % 4 == 0
+                             and os.environ.get("FLUIDGYM_AMD_ENV_GLUE", "1") != "0")
+        self._decay = None
 
     def _get_simulation(self, domain: Domain, prep_fn: Dict[str, Any]) -> Simulation:
         return Simulation(
@@ -186,7 +192,38 @@ class ChannelJetEnv2D(FluidEnv):
         shear = self._nu * (u[:, 0, 0, :].mean(dim=1) + u[:, 0, -1, :].mean(dim=1)) / (0.5 * self._hy)
         return cross, shear
 
+    def _step_native(self, action: torch.Tensor):
+        """``_step_impl`` with the schedule and the observation by ``fg_envglue_*`` (same values: the schedule to the bit, the means to
+        fp32 rounding of a different summation order)."""
+        from .. import _lib as L
+        B, n, X, S = self._num_envs, self._n_sim_steps, self._x, int(self._sensor_idx.numel())
+        dev, lib = self._cuda_device, L.load()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self._enable_actions:
+            if self._decay is None or self._decay.numel() != n:
+                self._decay = ((1.0 - self._action_smoothing_alpha) ** torch.arange(1, n + 1, device=dev, dtype=torch.float32)).contiguous()
+                self._jet_rows = self._jet_shape.reshape(2, X).contiguous()
+            target = action.reshape(B).contiguous()
+            jets = torch.empty(n, 2, B, 2, 1, X, device=dev)
+            last = torch.empty(B, 1, device=dev)
+            L.check(lib.fg_envglue_jet_schedule(target.data_ptr(), self._current_action.contiguous().data_ptr(), self._decay.data_ptr(),
+                                                self._jet_rows.data_ptr(), n, B, X, jets.data_ptr(), last.data_ptr(), stream))
+            self._jets = jets
+        if not self._sim.multi_step(n, {2: jets[:, 0], 3: jets[:, 1]} if self._enable_actions else None):
+            raise RuntimeError("simulation step failed")
+        if self._enable_actions:
+            self._current_action = last
+        u, p = self._block.velocity, self._block.pressure
+        obs_u, obs_p = torch.empty(B, S, 2, device=dev), torch.empty(B, S, device=dev)
+        out = torch.empty(3, B, device=dev)
+        L.check(lib.fg_envglue_channel_observe(u.data_ptr(), p.data_ptr(), self._sensor_idx.data_ptr(), S, B, self._y, X,
+                                               float(self._nu / (0.5 * self._hy)), float(self._lift_penalty), obs_u.data_ptr(),
+                                               obs_p.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), stream))
+        return {"velocity": obs_u, "pressure": obs_p}, out[2], False, {"cross_flow_energy": out[0], "wall_shear": out[1]}
+
     def _step_impl(self, action: torch.Tensor):
+        if self._native_glue and self._block.velocity.is_contiguous() and self._block.pressure.is_contiguous():
+            return self._step_native(action)
         target = action.reshape(self._num_envs, 1)
         n = self._n_sim_steps
         if self._enable_actions:

@@ -13,6 +13,15 @@ collective; the collectives run on RCCL's own stream, ranks that already know th
 read the header back to the host, and the only host read of a step is the per-env terminated / truncated
 flags the reference's return type (Python lists) asks for.
 
+Lanes (``lanes=L``, round 6): a rank's shard may itself be split into L sub-shards ("lanes"), each its own env batch and solver
+handle, stepped CONCURRENTLY by L host threads on L HIP streams of the one GPU.  The single-block step is bound by host round trips
+(polls of convergence words, launch latency: the GPU idles ~22 % of a 64-env headline step), and a second lane's kernels fill exactly
+those gaps: 2 x 32 envs give 1.2x the env-steps/s of 1 x 64 on the same GPU (profiles/headline_two_streams.sh).  It is the in-process
+form of what the reference allows as ``cuda_ids=[0, 0]`` (two workers on one GPU, parallel_env.py:115-160).  Lane l of rank r acts as
+virtual rank ``r * L + l`` everywhere a rank number enters (seeds, initial-domain indices), so ``world=1, lanes=2`` runs the envs of
+``world=2, lanes=1``.  NOT for the multi-block cluster solvers (csrc/fg_mb_cluster.hip): their workgroups spin on each other and need
+the whole GPU co-resident, two such kernels at once can starve each other into the time-out path; those envs refuse ``lanes > 1``.
+
 Two ways to run it:
 
 * SPMD (``torchrun`` / ``python -m torch.distributed.run``): every rank constructs the object and
@@ -66,10 +75,134 @@ def _spawn_worker(rank: int, world: int, port: int, env_id: str, cuda_ids: List[
     env.serve()
 
 
+class _Lanes:
+    """L sub-shards of one rank behind the FluidEnv calls ParallelFluidEnv makes (module docstring, "Lanes").  Every call fans out to
+    the lanes -- lane 0 on the calling thread, the others on a thread pool, each under its own HIP stream -- and the per-lane results
+    are concatenated along the env axis on the caller's stream.  Stream order: a lane's stream first waits for an event recorded on the
+    caller's stream (the actions are produced there, and memory a lane frees is only reused after what the caller enqueued), the
+    caller's stream then waits for every lane's end event before it concatenates."""
+
+    def __init__(self, env_id: str, n_local: int, lanes: int, device: torch.device, kw: Dict[str, Any]):
+        from concurrent.futures import ThreadPoolExecutor
+
+        if n_local % lanes:
+            raise ValueError(f"{n_local} envs per GPU are not divisible by lanes={lanes}")
+        self.n_lane, self.n_lanes, self._device = n_local // lanes, lanes, device
+        self.envs = [make(env_id, num_envs=self.n_lane, **kw) for _ in range(lanes)]
+        self._cuda = device.type == "cuda"
+        self._streams = [torch.cuda.Stream(device) for _ in range(lanes)] if self._cuda else [None] * lanes
+        self._pool = ThreadPoolExecutor(max_workers=max(lanes - 1, 1), thread_name_prefix="fluidgym-lane")
+        z = self.envs[0]._zero_action
+        self._zero_action = z.new_zeros((n_local,) + tuple(z.shape[1:]))
+        self._check_solvers()
+
+    def __getattr__(self, name: str) -> Any:      # spaces, episode length, counters ...: every lane is the same env class and options
+        return getattr(self.envs[0], name)
+
+    def _check_solvers(self) -> None:
+        from .cylinder import CylinderEnvBase      # (cylinder and airfoil ids: the multi-block path, fg_mb_*)
+
+        if self._cuda and isinstance(self.envs[0], CylinderEnvBase):
+            raise ValueError("lanes > 1 is for the single-block solver path: the multi-block cluster kernels need the whole GPU "
+                             "co-resident (fluidgym_amd/envs/parallel_env.py, 'Lanes')")
+
+    def _fan(self, fn):
+        """``fn(lane, env)`` on every lane concurrently; the list of results in lane order."""
+        if not self._cuda:
+            futs = [self._pool.submit(fn, l, self.envs[l]) for l in range(1, self.n_lanes)]
+            return [fn(0, self.envs[0])] + [f.result() for f in futs]
+        main = torch.cuda.current_stream(self._device)
+        start = torch.cuda.Event()
+        start.record(main)
+
+        def task(l):
+            torch.cuda.set_device(self._device)
+            st = self._streams[l]
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                out = fn(l, self.envs[l])
+            end = torch.cuda.Event()
+            end.record(st)
+            return out, end
+
+        futs = [self._pool.submit(task, l) for l in range(1, self.n_lanes)]
+        first = task(0)
+        done = [first] + [f.result() for f in futs]
+        for _, end in done:
+            main.wait_event(end)
+        return [out for out, _ in done]
+
+    def _rows(self, v) -> torch.Tensor:
+        """A lane's per-env tensor, or its per-shard value repeated for each of its envs."""
+        t = v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
+        if t.dim() > 0 and t.shape[0] == self.n_lane:
+            return t
+        return t.reshape((1,) + tuple(t.shape)).expand((self.n_lane,) + tuple(t.shape))
+
+    def _cat_info(self, infos: List[Dict[str, Any]]) -> Dict[str, Any]:
+        out = {}
+        for k in infos[0]:
+            try:
+                parts = [self._rows(i[k]) for i in infos]
+                out[k] = torch.cat([q.to(parts[0].device) for q in parts], dim=0)
+            except (TypeError, ValueError, RuntimeError):
+                out[k] = infos[0][k]      # not numeric: lane 0's (it stays on its shard, like in _layout_of)
+        return out
+
+    @staticmethod
+    def _cat_obs(obs: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
+        return {k: torch.cat([o[k] for o in obs], dim=0) for k in obs[0]}
+
+    def _flag(self, vals):
+        if all(not isinstance(v, torch.Tensor) for v in vals) and len({bool(v) for v in vals}) == 1:
+            return bool(vals[0])
+        return torch.cat([self._rows(v).reshape(self.n_lane, -1)[:, 0].to(self._device) != 0 for v in vals])
+
+    # ---- the FluidEnv calls of ParallelFluidEnv; ``base`` is the virtual rank of lane 0 (rank * lanes)
+    def reset(self, seed=None, randomize=None, base: int = 0):
+        res = self._fan(lambda l, e: e.reset(seed=None if seed is None else int(seed) + base + l, randomize=randomize))
+        return self._cat_obs([r[0] for r in res]), self._cat_info([r[1] for r in res])
+
+    def step(self, action: torch.Tensor):
+        n = self.n_lane
+        res = self._fan(lambda l, e: e.step(action[l * n: (l + 1) * n]))
+        obs = self._cat_obs([r[0] for r in res])
+        reward = torch.cat([r[1].reshape((n,) + tuple(r[1].shape[1:])) for r in res], dim=0)
+        return obs, reward, self._flag([r[2] for r in res]), self._flag([r[3] for r in res]), self._cat_info([r[4] for r in res])
+
+    def seed(self, seed: int, base: int = 0) -> None:
+        for l, e in enumerate(self.envs):
+            e.seed(int(seed) + base + l)
+
+    def sample_action(self) -> torch.Tensor:
+        return torch.cat([e.sample_action().to(self._device) for e in self.envs], dim=0)
+
+    def load_initial_domain(self, idx: int, mode=None, base: int = 0, stride: int = 1) -> None:
+        for l, e in enumerate(self.envs):
+            e.load_initial_domain(idx * stride + base + l, mode)
+
+    def train(self) -> None:
+        for e in self.envs:
+            e.train()
+
+    def val(self) -> None:
+        for e in self.envs:
+            e.val()
+
+    def test(self) -> None:
+        for e in self.envs:
+            e.test()
+
+    def close(self) -> None:
+        for e in self.envs:
+            e.close()
+        self._pool.shutdown(wait=True)
+
+
 class ParallelFluidEnv:
     def __init__(self, env_id: str, cuda_ids: Optional[Sequence[int]] = None, num_envs: Optional[int] = None,
                  backend: Optional[str] = None, _spawned: bool = False, collective_timeout_s: Optional[float] = None,
-                 force_collectives: Optional[bool] = None, **env_kwargs: Any):
+                 force_collectives: Optional[bool] = None, lanes: Optional[int] = None, **env_kwargs: Any):
         if env_kwargs.get("differentiable", False):
             raise ValueError("ParallelFluidEnv does not support differentiable environments.")
         self._env_id = env_id
@@ -89,7 +222,7 @@ class ParallelFluidEnv:
             ctx = mp.get_context("spawn")
             for r in range(1, world):
                 p = ctx.Process(target=_spawn_worker,
-                                args=(r, world, port, env_id, list(cuda_ids), n_total, env_kwargs, backend), daemon=True)
+                                args=(r, world, port, env_id, list(cuda_ids), n_total, dict(env_kwargs, lanes=lanes), backend), daemon=True)
                 p.start()
                 self._workers.append(p)
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE=str(world),
@@ -139,7 +272,12 @@ class ParallelFluidEnv:
         kw = dict(env_kwargs)
         if self._device.type == "cuda":
             kw["cuda_device"] = self._device
-        self._env = make(env_id, num_envs=self._n_local, **kw)
+        # lanes: sub-shards of this rank stepped concurrently on their own HIP streams (module docstring); FLUIDGYM_AMD_LANES
+        if lanes is None:
+            lanes = int(os.environ.get("FLUIDGYM_AMD_LANES", "1") or 1)
+        self._lanes = max(1, int(lanes))
+        self._env = make(env_id, num_envs=self._n_local, **kw) if self._lanes == 1 else \
+            _Lanes(env_id, self._n_local, self._lanes, self._device, kw)
         self._obs_keys = sorted(self._env.observation_space.keys())
         # ONE message per command: header [cmd, a, b, c] (four int64 fields seen as eight int32 words, so that seeds of 2**31 and
         # more travel: np.random.SeedSequence / getrandbits(32) produce them) followed by the action block bit-cast to int32, so that a
@@ -205,6 +343,11 @@ class ParallelFluidEnv:
     @property
     def local_env(self):
         return self._env
+
+    @property
+    def lane_envs(self) -> List[Any]:
+        """The env batches this rank steps: one, or ``lanes`` of them (module docstring)."""
+        return [self._env] if self._lanes == 1 else list(self._env.envs)
 
     # ------------------------------------------------------------------ collectives
     def _send(self, cmd: Optional[Command] = None, a: int = 0, b: int = 0, c: int = 0,
@@ -311,7 +454,19 @@ class ParallelFluidEnv:
     # driver's arguments win (they travel in the command broadcast).
     def seed(self, seed: int = 0) -> None:
         _, a, _, _ = self._send(Command.SEED, int(seed))
-        self._env.seed(a + self.rank)
+        self._seed_shard(a)
+
+    def _seed_shard(self, seed: int) -> None:
+        if self._lanes == 1:
+            self._env.seed(seed + self.rank)
+        else:
+            self._env.seed(seed, base=self.rank * self._lanes)
+
+    def _load_shard(self, idx: int, mode) -> None:
+        if self._lanes == 1:
+            self._env.load_initial_domain(idx * self.world + self.rank, mode)
+        else:
+            self._env.load_initial_domain(idx, mode, base=self.rank * self._lanes, stride=self.world * self._lanes)
 
     def reset(self, seed: Optional[int] = None, randomize: Optional[bool] = None):
         """All shards reset with seeds ``seed + rank``; returns the observations of all ``num_envs`` envs stacked along dim 0
@@ -324,7 +479,10 @@ class ParallelFluidEnv:
         return self._do_reset(None if a < 0 else a, None if b < 0 else bool(b))
 
     def _do_reset(self, seed, randomize):
-        obs, info = self._env.reset(seed=None if seed is None else int(seed) + self.rank, randomize=randomize)
+        if self._lanes == 1:
+            obs, info = self._env.reset(seed=None if seed is None else int(seed) + self.rank, randomize=randomize)
+        else:
+            obs, info = self._env.reset(seed=seed, randomize=randomize, base=self.rank * self._lanes)
         flat = self._all_gather(self._pack(obs, None, info=info))
         obs_all, _, _, _, info_all = self._unpack(flat, obs, with_reward=False)
         host = {k: v.cpu() for k, v in info_all.items()}       # one copy per key, sliced per env on the host
@@ -342,8 +500,30 @@ class ParallelFluidEnv:
             if action is None or action.shape[0] not in ok:
                 raise ValueError(f"Expected action batch size {ok[-1]}, but got "
                                  f"{None if action is None else action.shape[0]}")
+        if not self._collective:
+            return self._step_local(action)
         self._send(Command.STEP, action=action, read_header=False)
         return self._do_step()
+
+    def _step_local(self, action: torch.Tensor):
+        """World size 1 without forced collectives: nothing to broadcast or gather, so the step is the shard's own ``env.step`` and
+        the reference's return type is built from its results directly -- no message buffer, no packed block, no device read of flags
+        the env already holds as Python values (round 6: the wrapper cost 0.36 ms of a 7.2 ms headline step, most of it 128 tensor
+        slices for the per-env info dicts and host-to-device copies of two booleans)."""
+        n = self._n_total
+        obs, reward, term, trunc, info = self._env.step(action.to(self._device).reshape(self._a_shape))
+
+        def flags(v) -> List[bool]:
+            if isinstance(v, torch.Tensor):
+                vals = v.reshape(-1).cpu().tolist()
+                return [bool(x) for x in (vals if len(vals) == n else vals * n)]
+            return [bool(v)] * n
+
+        cols = {}
+        for k, v in info.items():
+            cols[k] = v.unbind(0) if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else (v,) * n
+        infos = [{k: c[i] for k, c in cols.items()} for i in range(n)]
+        return self._agents_to_rows(obs), reward, flags(term), flags(trunc), infos
 
     def _do_step(self, lists: bool = True):
         """``lists=False`` (workers inside ``serve()``): nobody reads this rank's return value, so the device -> host read of the
@@ -402,7 +582,7 @@ class ParallelFluidEnv:
 
     def load_initial_domain(self, idx: int = 0, mode=None) -> None:
         _, a, b, _ = self._send(Command.LOAD_INITIAL_DOMAIN, int(idx), self._MODES.index(mode))
-        self._env.load_initial_domain(a * self.world + self.rank, self._MODES[b])
+        self._load_shard(a, self._MODES[b])
 
     def get_state(self) -> Any:
         raise NotImplementedError("get_state is not implemented for ParallelFluidEnv.")   # parallel_env.py:370-378
@@ -430,7 +610,7 @@ class ParallelFluidEnv:
             elif cmd == Command.RESET:
                 self._do_reset(None if a < 0 else a, None if b < 0 else bool(b))
             elif cmd == Command.SEED:
-                self._env.seed(a + self.rank)
+                self._seed_shard(a)
             elif cmd == Command.TRAIN:
                 self._env.train()
             elif cmd == Command.VAL:
@@ -440,7 +620,7 @@ class ParallelFluidEnv:
             elif cmd == Command.SAMPLE_ACTION:
                 self._do_sample()
             elif cmd == Command.LOAD_INITIAL_DOMAIN:
-                self._env.load_initial_domain(a * self.world + self.rank, self._MODES[b])
+                self._load_shard(a, self._MODES[b])
             elif cmd == Command.CLOSE:
                 break
         self._shutdown()

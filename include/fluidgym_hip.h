@@ -409,6 +409,22 @@ int fg_resampler_destroy(fg_resampler r);
 int fg_resample(fg_resampler r, const float* src, int batch, int channels, float* dst, int fill_max_steps,
                 void* stream);
 
+/* ---- env glue either side of the n sim steps of an env step (fp32 library only) ------------------------------
+ * fg_envglue_jet_schedule: the action smoothing of the reference's jet envs (cylinder_env_base.py:748-753, a_k = a_{k-1} +
+ * alpha (target - a_{k-1}) before every sim step) for the n sim steps of one env step at once: control[k][b] = target[b] +
+ * (current[b] - target[b]) * decay[k] (decay[k] = (1 - alpha)^(k+1), device array of n), jets[k][wall][b][c][0][x] =
+ * shape[c][x] * control[k][b] (two walls, two components, nx % 4 == 0), last[b] = control[n-1][b].  The slabs are what
+ * fg_multi_step binds as the wall velocities of sim step k.
+ * fg_envglue_channel_observe: what step() returns after them (fluid_env.py:749-800) for the channel env: cross[b] = mean(v^2),
+ * shear[b] = shear_scale * (mean_x u[y=0] + mean_x u[y=ny-1]), reward[b] = -(shear + penalty * cross), the sensor gather
+ * obs_velocity[b][s][c] = velocity[b][c][sensor[s]], obs_pressure[b][s] = pressure[b][sensor[s]] (sensor: flat cell indices,
+ * int64, device).  One workgroup per env and a fixed summation tree: an env's result does not depend on the batch. */
+int fg_envglue_jet_schedule(const float* target, const float* current, const float* decay, const float* shape, int32_t n,
+                            int32_t batch, int32_t nx, float* jets, float* last, void* stream);
+int fg_envglue_channel_observe(const float* velocity, const float* pressure, const int64_t* sensor, int32_t n_sensors,
+                               int32_t batch, int32_t ny, int32_t nx, float shear_scale, float penalty, float* obs_velocity,
+                               float* obs_pressure, float* cross, float* shear, float* reward, void* stream);
+
 /* ---- multi-block, non-orthogonal domains -------------------------------------------
  * The reference's general Domain: several structured blocks of curvilinear cells (vertex coordinates ->
  * CoordsToTransforms, grid_gen.cu:298-390), joined by ConnectedBoundary with shuffled / inverted axes

@@ -35,9 +35,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_fp64_build_exports_the_single_block_entry_points_with_double_signatures():
     """libfluidgym_hip_f64.so (fg_real = double, include/fluidgym_hip.h): every single-block and multi-block symbol of the header,
-    typed with doubles where the fp32 library takes floats; the resampling symbols are not part of it."""
+    typed with doubles where the fp32 library takes floats; the resampling and env-glue symbols are not part of it."""
     lib = L.load_f64()
-    declared = [n for n in _declared_symbols() if not n.startswith(("fg_resampl", "fg_sparse_"))]
+    declared = [n for n in _declared_symbols() if not n.startswith(L._F64_ABSENT_PREFIXES)]
     assert set(L.SIGNATURES_F64) == set(declared)
     for name in declared:
         assert hasattr(lib, name), name

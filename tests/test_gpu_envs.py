@@ -64,6 +64,72 @@ def test_reset_is_reproducible_and_state_roundtrip():
     env.close()
 
 
+def test_native_env_glue_gives_the_torch_expressions_values(monkeypatch):
+    """The schedule + observation kernels (csrc/fg_envglue.hip) against the elementwise torch expressions they replace
+    (FLUIDGYM_AMD_ENV_GLUE=0): the controls and jets to the bit (so the fields are the same to the bit), the means and the reward
+    to fp32 rounding of another summation order."""
+    kw = dict(resolution_x=64, resolution_y=32, randomize_initial_state=False, num_envs=3)
+    envN = fluidgym_amd.make("ChannelJet2D-v0", **kw)
+    envN.reset(seed=5)
+    monkeypatch.setenv("FLUIDGYM_AMD_ENV_GLUE", "0")      # (read when the env builds its domain: at its first reset)
+    envT = fluidgym_amd.make("ChannelJet2D-v0", **kw)
+    envT.reset(seed=5)
+    assert envN._native_glue and not envT._native_glue
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(3):
+        a = torch.rand(3, 1, device="cuda", generator=gen) * 2 - 1
+        oN, rN, tN, uN, iN = envN.step(a)
+        oT, rT, tT, uT, iT = envT.step(a)
+        assert torch.equal(envN._block.velocity, envT._block.velocity) and torch.equal(envN._block.pressure, envT._block.pressure)
+        assert torch.equal(envN._current_action, envT._current_action) and torch.equal(envN._jets, envT._jets)
+        assert torch.equal(oN["velocity"], oT["velocity"]) and torch.equal(oN["pressure"], oT["pressure"])
+        assert oN["velocity"].shape == oT["velocity"].shape and rN.shape == rT.shape
+        torch.testing.assert_close(rN, rT, rtol=2e-6, atol=1e-9)
+        for k in iT:
+            assert iN[k].shape == iT[k].shape
+            torch.testing.assert_close(iN[k], iT[k], rtol=2e-6, atol=1e-9)
+        assert (tN, uN) == (tT, uT)
+    envN.close()
+    envT.close()
+
+
+def test_two_lanes_on_two_streams_are_two_independent_shards():
+    """``ParallelFluidEnv(lanes=2)``: two 3-env batches of one rank stepped concurrently by two host threads on two HIP streams
+    (envs/parallel_env.py, "Lanes") give, bit for bit, what the two batches give stepped alone one after the other (seeds ``seed`` and
+    ``seed + 1``: lane l acts as virtual rank l), several steps in a row -- stream order between the caller's stream, the lanes' streams and
+    the concatenation included.  The multi-block cluster solvers refuse lanes."""
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    kw = dict(resolution_x=64, resolution_y=32)
+    penv = ParallelFluidEnv("ChannelJet2D-v0", num_envs=6, lanes=2, **kw)
+    assert [e.num_envs for e in penv.lane_envs] == [3, 3]
+    obs, infos = penv.reset(seed=21, randomize=True)
+    plain = [fluidgym_amd.make("ChannelJet2D-v0", num_envs=3, **kw) for _ in range(2)]
+    ref = [e.reset(seed=21 + r, randomize=True) for r, e in enumerate(plain)]
+    for k in obs:
+        assert torch.equal(obs[k], torch.cat([r[0][k] for r in ref]))
+    assert len(infos) == 6
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for step in range(4):
+        a = torch.rand(6, 1, device="cuda", generator=gen) * 2 - 1
+        o, r, term, trunc, info = penv.step(a)
+        outs = [e.step(a[3 * i: 3 * i + 3]) for i, e in enumerate(plain)]
+        for k in o:
+            assert torch.equal(o[k], torch.cat([x[0][k] for x in outs])), (step, k)
+        assert torch.equal(r, torch.cat([x[1] for x in outs])) and r.shape == (6,)
+        assert term == [False] * 6 and trunc == [bool(outs[0][3])] * 6 and len(info) == 6
+        for i in range(6):
+            assert torch.equal(info[i]["wall_shear"], outs[i // 3][4]["wall_shear"][i % 3])
+        for e, q in zip(penv.lane_envs, plain):
+            assert torch.equal(e._block.velocity, q._block.velocity) and torch.equal(e._block.pressure, q._block.pressure)
+    assert torch.equal(penv.sample_action().shape and torch.tensor(penv.sample_action().shape), torch.tensor([6, 1]))
+    penv.close()
+    for e in plain:
+        e.close()
+    with pytest.raises(ValueError, match="single-block solver path"):
+        ParallelFluidEnv("CylinderJet2D-easy-v0", num_envs=2, lanes=2)
+
+
 def test_batched_env_equals_independent_envs():
     """Env b of a batch evolves exactly as if it were alone (no cross-talk through the batched solvers)."""
     kw = dict(resolution_x=64, resolution_y=32, randomize_initial_state=False)

@@ -193,6 +193,42 @@ def test_single_process_world_of_one():
     penv.close()
 
 
+def test_two_lanes_of_one_rank_are_the_two_ranks_of_a_world_of_two():
+    """``lanes=2`` at world size 1 (two sub-shards of the rank stepped by two threads, on the GPU on two HIP streams) runs the envs of
+    ``world=2``: lane l acts as virtual rank l for seeds, sampled actions and initial-domain indices, and the results come back
+    concatenated in lane order."""
+    _register()
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+    from fluidgym_amd.types import EnvMode
+
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    penv = ParallelFluidEnv("ToyCPU-v0", num_envs=4, backend="gloo", lanes=2)
+    assert penv.world == 1 and penv.num_envs == 4 and [e._num_envs for e in penv.lane_envs] == [2, 2]
+    actions = torch.arange(12, dtype=torch.float32).reshape(4, 3) * 0.1
+    penv.seed(BIG_SEED)
+    sampled = penv.sample_action()
+    penv.load_initial_domain(3, EnvMode.TEST)
+    assert [e.loaded for e in penv.lane_envs] == [(3 * 2 + 0, EnvMode.TEST), (3 * 2 + 1, EnvMode.TEST)]
+    obs0, infos0 = penv.reset(seed=11)
+    penv.val()
+    assert [e.mode for e in penv.lane_envs] == ["val", "val"]
+    out = penv.step(actions)
+    out2 = penv.step(actions * 2)
+    e_obs0, e_r1, e_r2, e_o2, exp = _expected()
+    for k in e_obs0:
+        assert torch.equal(obs0[k], e_obs0[k]) and torch.equal(out2[0][k], e_o2[k])
+    assert torch.equal(out[1], e_r1) and torch.equal(out2[1], e_r2)
+    assert out2[2] == exp["term2"] and out2[3] == [False] * 4 and len(infos0) == 4
+    assert np.allclose([float(i["init_sum"]) for i in infos0], exp["init_sum"])
+    assert np.allclose([float(i["m"]) for i in out2[4]], exp["info_m"])
+    assert np.allclose(np.stack([i["v"].numpy() for i in out2[4]]), exp["info_v"])
+    assert np.allclose(sampled.numpy(), exp["sampled"])
+    penv.close()
+    with pytest.raises(ValueError, match="not divisible by lanes"):
+        ParallelFluidEnv("ToyCPU-v0", num_envs=3, backend="gloo", lanes=2)
+
+
 def test_forced_collectives_at_world_size_one():
     """The CPU twin of tests/test_gpu_rccl.py: one rank under torch.distributed.run, every command through the group's
     broadcast / all_gather (gloo here, RCCL there), equal to the plain env."""
