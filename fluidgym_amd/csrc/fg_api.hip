@@ -850,15 +850,23 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             const FgPollOut po = fg_poll_next(&s->poll);
             const FgPollOut none = FgPollOut{nullptr, 0};
             // (with the CFL kernel in the step, the guard is computed by workgroup 0 of every env of THAT launch: one kernel, one word)
-            if (first && !o->adaptive) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, po)) return rc; }
+            if (first && !o->adaptive) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, FgPollOut{po.seq, po.value})) return rc; }
             if (o->adaptive) {
-                if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B, po.seq ? FgPollOut{po.seq + B, po.value} : po,
+                // (fp32 build: the maxima and the flux balances travel in the polled result words themselves -- FgPollOut::gran,
+                //  words [B, 2 B) and [0, B) -- and are unpacked to where the mirror form leaves them)
+                if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B, po.seq ? FgPollOut{po.seq + B, po.value, po.gran} : po,
                                                     first ? s->scratch_B : nullptr, first ? s->diag_pinned : nullptr))
                     return rc;
             }
             (void)none;
             fg_htrace("maxvel_launched");
-            if (int rc = fg_poll_wait(&s->poll, po, o->adaptive ? B : 0, o->adaptive ? 1 : B, st)) return rc;
+            if (o->adaptive && po.gran) {
+                if (int rc = fg_poll_wait_words(&s->poll, po, first ? 0 : B, first ? 2 * B : B, st)) return rc;
+                for (int b = 0; b < B; ++b) {
+                    s->diag_pinned[B + b] = fg_poll_word_float(&s->poll, B + b);
+                    if (first) s->diag_pinned[b] = fg_poll_word_float(&s->poll, b);
+                }
+            } else if (int rc = fg_poll_wait(&s->poll, po, o->adaptive ? B : 0, o->adaptive ? 1 : B, st)) return rc;
             fg_htrace("maxvel_poll_done");
             if (first) {
                 fg_real worst = 0.f;

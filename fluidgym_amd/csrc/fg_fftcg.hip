@@ -316,13 +316,16 @@ __global__ __launch_bounds__(320) void k_fcg_inv_apply(FcgInvArgs a) {
 // which F'(0) writes without touching r -- or which nobody writes at all when EVERY env of the batch ends here (the PISO pressure
 // systems of the channel family: 99 % of the solves) and the caller reads the pressure as alpha z (FgLazyRef).  One wave per env.
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ void k_fcg_check0(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                             fg_solve_info* __restrict__ mirror, double* __restrict__ alpha, int32_t* __restrict__ lazy, float tol,
-                             int n, int B, int ns, FgPollOut poll) {
-    const int b = blockIdx.x;
-    if (b >= B) return;
+constexpr int CHECK_WAVES = 16;      // envs per workgroup of the verdict kernels: their result words leave as one 256-byte run
+__global__ __launch_bounds__(64 * CHECK_WAVES) void k_fcg_check0(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+                                                                 fg_solve_info* __restrict__ mirror, double* __restrict__ alpha, int32_t* __restrict__ lazy,
+                                                                 float tol, int n, int B, int ns, FgPollOut poll) {
+    __shared__ uint32_t stage[CHECK_WAVES * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * CHECK_WAVES, b = b0 + wave;      // one wave per env (fg_acc_total is a wave's shuffle tree)
+    const bool valid = b < B;
     int lz = 0;
-    if (flag_ld(flags + (b)) == 0) {
+    if (valid && flag_ld(flags + (b)) == 0) {
         const double g = fg_acc_total(fg_acc_ptr(acc, b, FCG_GAMMA), ns), d = fg_acc_total(fg_acc_ptr(acc, b, FCG_DELTA), ns);
         const double dd = fg_acc_total(fg_acc_ptr(acc, b, 2), ns);
         const double dw = fg_acc_total(fg_acc_ptr(acc, b, FCG_GAMMA + 2), ns), ww = fg_acc_total(fg_acc_ptr(acc, b, FCG_DELTA + 1), ns);
@@ -331,7 +334,7 @@ __global__ void k_fcg_check0(FgDacc* __restrict__ acc, int32_t* __restrict__ fla
         double rr1 = dd + 2.0 * e1 * dw + e1 * e1 * ww;
         if (rr1 < 0.0) rr1 = 0.0;      // (a NaN stays one)
         const float crit = (float)sqrt(rr1 / (double)n);
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             info[b].final_residual = crit;
             info[b].used_iterations = 0;
             if (!(crit >= tol)) {
@@ -343,10 +346,14 @@ __global__ void k_fcg_check0(FgDacc* __restrict__ acc, int32_t* __restrict__ fla
             }
         }
     }
-    if (threadIdx.x == 0) {
-        lazy[b] = lz;
-        if (mirror) { mirror[b] = info[b]; fg_poll_publish(poll, b); }
-    }
+    if (valid && lane == 0) lazy[b] = lz;
+    if (!mirror) return;
+    if (poll.gran) {      // (the verdicts travel in the words the host spins on: no release, no L2 write-back -- FgPollOut, fg_internal.h)
+        uint32_t w[2] = {0u, 0u};
+        const bool writer = valid && lane == 0;
+        if (writer) { const fg_solve_info v = info[b]; w[0] = __float_as_uint(v.final_residual); w[1] = fg_info_word(v); }
+        fg_poll_publish_records<2>(poll, b0, min(CHECK_WAVES, B - b0), wave, w, writer, stage);
+    } else if (valid && lane == 0) { mirror[b] = info[b]; fg_poll_publish(poll, b); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -520,7 +527,7 @@ int fg_fcg_inv_apply(fg_state* s, const FcgVectors& v, const fg_real* rA, int it
 }
 int fg_fcg_check0(fg_state* s, fg_real tol, int ns, hipStream_t st, FgPollOut poll) {
     const FgGrid& G = s->grid;
-    hipLaunchKernelGGL(k_fcg_check0, dim3(G.B), dim3(64), 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, s->fcg_alpha, s->fcg_lazy,
+    hipLaunchKernelGGL(k_fcg_check0, dim3((G.B + CHECK_WAVES - 1) / CHECK_WAVES), dim3(64 * CHECK_WAVES), 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, s->fcg_alpha, s->fcg_lazy,
                        tol, G.n, G.B, ns, poll);
     FG_HIP_CHECK(hipGetLastError());
     s->fcg_check0_ran = 1;

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <stdint.h>
+#include <cstring>
 #include <string>
 #include <type_traits>
 
@@ -567,8 +568,34 @@ struct FgProf {
 // poll_latency.hip): kernel -> host -> next kernel costs 6 us this way against 11.5 us through hipStreamSynchronize, 4-5 times per
 // PISO step.  Streams are in order, so "the polled kernel has finished" still means everything launched before it has.
 struct FgJacHist { int sweeps, skip, fails; };
-struct FgPollOut { int32_t* seq; int32_t value; };     // seq == nullptr: no word is written (the caller synchronises the stream)
+// Round 6: result WORDS.  A kernel that publishes through the release above pays a write-back of its XCD's L2 (the 4-5 us the one-wave
+// verdict kernels took were that write-back, and the host saw the verdict that much later).  A result that fits 32 bits can instead
+// travel IN the word the host spins on: one 8-byte system-scope store {payload, sequence number} per result -- a single store is
+// its own ordering, so nothing has to be fenced against anything (the "granule" form of fg_mb_cluster.hip's exchanges).  `gran` is
+// the pinned array of such words (nullptr: the fp64 build, or FG_POLL_SPIN=0 -- the kernels then use the mirror + release form).
+struct FgPollOut { int32_t* seq; int32_t value; unsigned long long* gran = nullptr; };     // seq == nullptr: no word is written (the caller synchronises the stream)
 #ifdef __HIPCC__
+__device__ __forceinline__ void fg_poll_publish_word(const FgPollOut& p, int i, uint32_t payload) {
+    __hip_atomic_store(p.gran + i, ((unsigned long long)(uint32_t)p.value << 32) | (unsigned long long)payload, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// a solve info as two result words: the residual's bits | (used_iterations + 1) << 2 | converged << 1 | is_finite
+__device__ __forceinline__ uint32_t fg_info_word(const fg_solve_info& v) {
+    return ((uint32_t)(v.used_iterations + 1) << 2) | (v.converged ? 2u : 0u) | (v.is_finite ? 1u : 0u);
+}
+// Records of W words per entry, written by a whole workgroup (EVERY thread calls): the writers (`valid`) put the record of entry
+// first + slot into LDS, then the n entries of the workgroup are stored as one run of consecutive words, 64 per wave instruction -- the
+// words cross PCIe as full lines.  (One 8-byte store per workgroup or thread, uncoalesced, made the verdict kernels SLOWER than the
+// release form: 128-640 partial-line writes into host memory per poll.)  `stage`: n * W words of LDS.
+template <int W>
+__device__ __forceinline__ void fg_poll_publish_records(const FgPollOut& p, int first, int n, int slot, const uint32_t (&w)[W], bool valid,
+                                                        uint32_t* stage) {
+    if (valid)
+#pragma unroll
+        for (int k = 0; k < W; ++k) stage[slot * W + k] = w[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * W; i += blockDim.x) fg_poll_publish_word(p, first * W + i, stage[i]);
+}
 __device__ __forceinline__ void fg_poll_publish(const FgPollOut& p, int i) {
     // system-scope release: the results stored before it (by this thread, or by threads it synchronised with) are visible to the
     // host once the word is.  It writes the L2 back, so a kernel calls it from as few threads as possible, and after all its
@@ -580,12 +607,22 @@ __device__ __forceinline__ void fg_poll_publish(const FgPollOut& p, int i) {
 struct FgPoll {
     int32_t* seq;      // pinned [n]
     int n; int32_t epoch; int spin;    // spin == 0 (FG_POLL_SPIN=0): hipStreamSynchronize, as before
+    unsigned long long* gran; int n_gran;      // pinned result words {payload, sequence number} (FgPollOut::gran): 8 per sequence word
 };
 int fg_poll_create(FgPoll* P, int n);
 void fg_poll_destroy(FgPoll* P);
 FgPollOut fg_poll_next(FgPoll* P);     // the words and sequence number of the next poll ({nullptr, 0} when spinning is off)
 // waits until words [first, first + count) carry out.value (or, without words / after 50 ms of spinning, for the stream)
 int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st);
+// the same for result words [first, first + count) of out.gran; fg_poll_word / fg_poll_info read them afterwards
+int fg_poll_wait_words(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st);
+inline uint32_t fg_poll_word(const FgPoll* P, int i) { return (uint32_t)(__atomic_load_n(P->gran + i, __ATOMIC_RELAXED) & 0xffffffffull); }
+inline float fg_poll_word_float(const FgPoll* P, int i) { const uint32_t u = fg_poll_word(P, i); float f; memcpy(&f, &u, 4); return f; }
+inline void fg_poll_info(const FgPoll* P, int sys, fg_solve_info* out) {
+    const uint32_t w = fg_poll_word(P, 2 * sys + 1);
+    out->final_residual = fg_poll_word_float(P, 2 * sys);
+    out->used_iterations = (int32_t)(w >> 2) - 1; out->converged = (w >> 1) & 1; out->is_finite = w & 1;
+}
 void fg_htrace(const char* tag);      // FG_HTRACE=1: host time stamps (fg_poll.hip); a no-op otherwise
 // FG_ROCTX=1: named ranges around the phases of a step for rocprofv3 --marker-trace (fg_poll.hip; a no-op otherwise)
 void fg_range_push(const char* name);

@@ -282,33 +282,49 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac_pass(JacArgs a) {
 // behind the last enqueued pass: its verdict (what the next pass would have found), the info mirror and the poll words; for envs
 // that go on, the residual of the pass before rides along so that the host can size what it enqueues next
 __global__ void k_jac_check(JacArgs a, fg_solve_info* __restrict__ mirror, float* __restrict__ prev, int B, FgPollOut poll) {
+    __shared__ uint32_t stage[64 * 10];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int sys0 = 2 * b;
-    // a.pass = number of passes enqueued so far: the verdict pass number a.pass would take
-    const FgDacc* A0 = a.acc + (size_t)sys0 * FG_ACC_DOUBLES;
-    const FgDacc* A1 = A0 + FG_ACC_DOUBLES;
-    float p0 = -1.f, p1 = -1.f;      // (read before the verdict: an env that goes on resets this ring entry for pass a.pass + 1)
-    if (a.pass >= 2) { const int e2 = (a.pass - 2) % 3; p0 = fg_rms(acc_ld(A0 + e2), a.n); p1 = fg_rms(acc_ld(A1 + e2), a.n); }
-    // the residuals passes 0 and 1 measured (ring entries 0 and 1 until passes 2 and 3 moved them to slots 3 and 4)
-    float f00 = -1.f, f01 = -1.f, f10 = -1.f, f11 = -1.f;
-    if (a.pass >= 2) {
-        f00 = fg_rms(acc_ld(A0 + (a.pass >= 3 ? 3 : 0)), a.n); f10 = fg_rms(acc_ld(A1 + (a.pass >= 3 ? 3 : 0)), a.n);
-        f01 = fg_rms(acc_ld(A0 + (a.pass >= 4 ? 4 : 1)), a.n); f11 = fg_rms(acc_ld(A1 + (a.pass >= 4 ? 4 : 1)), a.n);
+    const bool valid = b < B;
+    uint32_t w[10] = {};
+    if (valid) {
+        const int sys0 = 2 * b;
+        // a.pass = number of passes enqueued so far: the verdict pass number a.pass would take
+        const FgDacc* A0 = a.acc + (size_t)sys0 * FG_ACC_DOUBLES;
+        const FgDacc* A1 = A0 + FG_ACC_DOUBLES;
+        float p0 = -1.f, p1 = -1.f;      // (read before the verdict: an env that goes on resets this ring entry for pass a.pass + 1)
+        if (a.pass >= 2) { const int e2 = (a.pass - 2) % 3; p0 = fg_rms(acc_ld(A0 + e2), a.n); p1 = fg_rms(acc_ld(A1 + e2), a.n); }
+        // the residuals passes 0 and 1 measured (ring entries 0 and 1 until passes 2 and 3 moved them to slots 3 and 4)
+        float f00 = -1.f, f01 = -1.f, f10 = -1.f, f11 = -1.f;
+        if (a.pass >= 2) {
+            f00 = fg_rms(acc_ld(A0 + (a.pass >= 3 ? 3 : 0)), a.n); f10 = fg_rms(acc_ld(A1 + (a.pass >= 3 ? 3 : 0)), a.n);
+            f01 = fg_rms(acc_ld(A0 + (a.pass >= 4 ? 4 : 1)), a.n); f11 = fg_rms(acc_ld(A1 + (a.pass >= 4 ? 4 : 1)), a.n);
+        }
+        const bool done = jac_verdict(a, b, a.pass, true);
+        if (!done) {
+            const int e = (a.pass - 1) % 3;
+            a.info[sys0].final_residual = fg_rms(acc_ld(A0 + e), a.n); a.info[sys0 + 1].final_residual = fg_rms(acc_ld(A1 + e), a.n);
+            a.info[sys0].used_iterations = a.info[sys0 + 1].used_iterations = a.pass * a.sweeps - 1;
+            a.info[sys0].converged = a.info[sys0 + 1].converged = 0;
+        }
+        if (poll.gran) {
+            // result words (FgPollOut, fg_internal.h), ten per env: the two infos, the residuals of the pass before, those of passes 0 / 1
+            const fg_solve_info i0 = a.info[sys0], i1 = a.info[sys0 + 1];
+            w[0] = __float_as_uint(i0.final_residual); w[1] = fg_info_word(i0); w[2] = __float_as_uint(i1.final_residual); w[3] = fg_info_word(i1);
+            w[4] = __float_as_uint(p0); w[5] = __float_as_uint(p1);
+            w[6] = __float_as_uint(f00); w[7] = __float_as_uint(f01); w[8] = __float_as_uint(f10); w[9] = __float_as_uint(f11);
+        } else {
+            prev[sys0] = p0; prev[sys0 + 1] = p1;
+            float* first2 = prev + 2 * B;      // [2 B][2]
+            first2[2 * sys0] = f00; first2[2 * sys0 + 1] = f01; first2[2 * (sys0 + 1)] = f10; first2[2 * (sys0 + 1) + 1] = f11;
+            mirror[sys0] = a.info[sys0]; mirror[sys0 + 1] = a.info[sys0 + 1];
+            fg_poll_publish(poll, sys0);
+            fg_poll_publish(poll, sys0 + 1);
+        }
     }
-    const bool done = jac_verdict(a, b, a.pass, true);
-    if (!done) {
-        const int e = (a.pass - 1) % 3;
-        a.info[sys0].final_residual = fg_rms(acc_ld(A0 + e), a.n); a.info[sys0 + 1].final_residual = fg_rms(acc_ld(A1 + e), a.n);
-        a.info[sys0].used_iterations = a.info[sys0 + 1].used_iterations = a.pass * a.sweeps - 1;
-        a.info[sys0].converged = a.info[sys0 + 1].converged = 0;
+    if (poll.gran) {      // (every lane: the wave publishes together, the writers' records first -- no lane may run ahead of them)
+        const int first = blockIdx.x * blockDim.x;
+        fg_poll_publish_records<10>(poll, first, min((int)blockDim.x, B - first), threadIdx.x, w, valid, stage);
     }
-    prev[sys0] = p0; prev[sys0 + 1] = p1;
-    float* first2 = prev + 2 * B;      // [2 B][2]
-    first2[2 * sys0] = f00; first2[2 * sys0 + 1] = f01; first2[2 * (sys0 + 1)] = f10; first2[2 * (sys0 + 1) + 1] = f11;
-    mirror[sys0] = a.info[sys0]; mirror[sys0 + 1] = a.info[sys0 + 1];
-    fg_poll_publish(poll, sys0);
-    fg_poll_publish(poll, sys0 + 1);
 }
 
 // envs whose last iterate was written to the work buffer: into the result.  Pass p wrote the result vector iff (p & 1) == last_parity;
@@ -608,7 +624,22 @@ int fg_jacobi_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* info_host, 
         }
         spec_tried = true;
         fg_htrace("jac_check_launched");
-        const int rc = fg_poll_wait(&s->poll, po, 0, nsys, st);
+        int rc;
+        if (po.gran) {      // (the verdicts arrive in the polled words themselves: unpacked to where the mirror form leaves them)
+            rc = fg_poll_wait_words(&s->poll, po, 0, 10 * B, st);
+            if (rc == FG_OK)
+                for (int b = 0; b < B; ++b)
+                    for (int c = 0; c < 2; ++c) {
+                        const int i = 2 * b + c;
+                        fg_solve_info& I = s->info_pinned[i];
+                        const uint32_t w = fg_poll_word(&s->poll, 10 * b + 2 * c + 1);
+                        I.final_residual = fg_poll_word_float(&s->poll, 10 * b + 2 * c);
+                        I.used_iterations = (int32_t)(w >> 2) - 1; I.converged = (w >> 1) & 1; I.is_finite = w & 1;
+                        s->jac_prev[i] = fg_poll_word_float(&s->poll, 10 * b + 4 + c);
+                        s->jac_prev[nsys + 2 * i] = fg_poll_word_float(&s->poll, 10 * b + 6 + 2 * c);
+                        s->jac_prev[nsys + 2 * i + 1] = fg_poll_word_float(&s->poll, 10 * b + 7 + 2 * c);
+                    }
+        } else rc = fg_poll_wait(&s->poll, po, 0, nsys, st);
         fg_htrace("jac_poll_done");
         return rc;
     };

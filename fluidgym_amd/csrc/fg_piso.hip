@@ -495,6 +495,19 @@ __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, 
     // word behind it -- one L2 write-back at the very end of the kernel (64 of them, one per env, while the other workgroups
     // were still streaming, cost 10 us: fg_poll_publish).
     if (__shfl(last_of_all, 0, 64)) {
+#if !FG_F64
+        if (poll.gran) {
+            // result words (fg_internal.h FgPollOut): the maxima as words [B, 2 B), the flux balances as [0, B) -- no mirror, no release,
+            // no write-back of this XCD's L2 at the end of the kernel
+            for (int e = lane; e < B; e += 64) {
+                fg_poll_publish_word(poll, B + e, __hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (flux_B) fg_poll_publish_word(poll, e, __hip_atomic_exchange(reinterpret_cast<fg_bits*>(flux_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                atomicExch(done_B + e, 0);
+            }
+            if (lane == 0) atomicExch(done_B + B, 0);
+            return;
+        }
+#endif
         for (int e = lane; e < B; e += 64) {
             mirror_B[e] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (flux_B) flux_mirror[e] = fg_bits_real(__hip_atomic_exchange(reinterpret_cast<fg_bits*>(flux_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

@@ -297,14 +297,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_cg_update(FgGrid g, const fg_real*
 // Bookkeeping after the last launched iteration `it` (evaluates rr_{it+1}); one wave per env.  `mirror` (optional) is the
 // host-pinned copy of info: thread 0 of every env writes its entry there, so a convergence poll is a stream
 // synchronise without a device-to-host copy (the copy kernel + its launch cost ~6 us per poll, 4-5 polls per PISO step).
-__global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
-                           fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int B, int final_pass, int ns,
-                           FgPollOut poll = FgPollOut{nullptr, 0}) {
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    if (flag_ld(flags + (b)) == 0) {
+constexpr int CG_CHECK_WAVES = 16;      // envs per workgroup: their result words leave as one 256-byte run (FgPollOut, fg_internal.h)
+__global__ __launch_bounds__(64 * CG_CHECK_WAVES) void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
+                                                                  fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int B, int final_pass, int ns,
+                                                                  FgPollOut poll = FgPollOut{nullptr, 0}) {
+    __shared__ uint32_t stage[CG_CHECK_WAVES * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * CG_CHECK_WAVES, b = b0 + wave;      // one wave per env (fg_acc_total is a wave's shuffle tree)
+    const bool valid = b < B;
+    if (valid && flag_ld(flags + (b)) == 0) {
         const fg_real crit = fg_rms(fg_acc_total(fg_acc_ptr(acc, b, (it + 1) % 3), ns), n);
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             info[b].final_residual = crit;
             info[b].used_iterations = it;
             if (!(crit >= tol)) {
@@ -318,10 +321,23 @@ __global__ void k_cg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags
             }
         }
     }
-    if (mirror && threadIdx.x == 0) {
+    if (!mirror) return;
+    const bool writer = valid && lane == 0;
+    if (poll.gran) {
+        uint32_t w[2] = {0u, 0u};
+        if (writer) { const fg_solve_info v = info[b]; w[0] = __float_as_uint((float)v.final_residual); w[1] = fg_info_word(v); }
+        fg_poll_publish_records<2>(poll, b0, min(CG_CHECK_WAVES, B - b0), wave, w, writer, stage);
+    } else if (writer) {
         mirror[b] = info[b];
         fg_poll_publish(poll, b);      // (after the entry: the host spins on this word instead of synchronising the stream)
     }
+}
+// the host side of a polled k_cg_check / k_fcg_check0: wait for the verdicts and leave them in info_pinned
+static int cg_wait_infos(fg_state* s, const FgPollOut& po, int B, hipStream_t st) {
+    if (!po.gran) return fg_poll_wait(&s->poll, po, 0, B, st);
+    if (int rc = fg_poll_wait_words(&s->poll, po, 0, 2 * B, st)) return rc;
+    for (int b = 0; b < B; ++b) fg_poll_info(&s->poll, b, s->info_pinned + b);
+    return FG_OK;
 }
 
 __global__ void k_cg_begin(const fg_real* __restrict__ dt, FgCgBegin q, int B) {
@@ -518,7 +534,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             }
             if (poll0) {
                 fg_htrace("cg_check_launched");
-                if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
+                if (int rc = cg_wait_infos(s, po, B, st)) return rc;
                 fg_htrace("cg_poll_done");
                 info_fresh = true;
                 s->fcg_first_polls += 1;
@@ -559,10 +575,10 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 const int final_pass = (it + 1 == a.max_iterations);
                 fg_prof_prefetch(s, st);
                 const FgPollOut po = fg_poll_next(&s->poll);
-                hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
+                hipLaunchKernelGGL(k_cg_check, dim3((B + CG_CHECK_WAVES - 1) / CG_CHECK_WAVES), dim3(64 * CG_CHECK_WAVES), 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
                                    n, B, final_pass, ns, po);
                 fg_htrace("cg_check_launched");
-                if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
+                if (int rc = cg_wait_infos(s, po, B, st)) return rc;
                 fg_htrace("cg_poll_done");
                 info_fresh = true;
                 done = true;
@@ -634,14 +650,14 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             const int final_pass = (it + 1 == a.max_iterations);
             fg_prof_prefetch(s, st);       // (in front of the polled kernel: its completion then covers the copy)
             const FgPollOut po = fg_poll_next(&s->poll);
-            hipLaunchKernelGGL(k_cg_check, sg, sb, 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
+            hipLaunchKernelGGL(k_cg_check, dim3((B + CG_CHECK_WAVES - 1) / CG_CHECK_WAVES), dim3(64 * CG_CHECK_WAVES), 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
                                n, B, final_pass, ns, po);
             // one read-back serves the poll and the result: k_cg_check above mirrored info (converged / is_finite of every
             // env) into the pinned host copy, and nothing is launched between the last poll and the end of the solve.
             // The poll comes BEFORE the preconditioner of the next iteration: polls are scheduled where the previous solve
             // finished, so they usually end the solve, and three kernels of M^-1 that would find every env converged
             // cost more than the idle round trip of a poll that does not.
-            if (int rc = fg_poll_wait(&s->poll, po, 0, B, st)) return rc;
+            if (int rc = cg_wait_infos(s, po, B, st)) return rc;
             info_fresh = true;
             done = true;
             active_est = 0;

@@ -11,28 +11,37 @@ int fg_poll_create(FgPoll* P, int n) {
     P->spin = !(e && atoi(e) == 0);
     FG_HIP_CHECK(hipHostMalloc(&P->seq, sizeof(int32_t) * (size_t)n));
     for (int i = 0; i < n; ++i) P->seq[i] = 0;
+    P->gran = nullptr; P->n_gran = 0;
+#if !FG_F64
+    // FG_POLL_WORDS=0: the mirror + release form everywhere (the A/B switch of the result words)
+    const char* w = getenv("FG_POLL_WORDS");
+    if (!P->spin || (w && atoi(w) == 0)) return FG_OK;
+    P->n_gran = 8 * n;
+    FG_HIP_CHECK(hipHostMalloc(&P->gran, sizeof(unsigned long long) * (size_t)P->n_gran));
+    for (int i = 0; i < P->n_gran; ++i) P->gran[i] = 0ull;
+#endif
     return FG_OK;
 }
 
 void fg_poll_destroy(FgPoll* P) {
     if (P->seq) (void)hipHostFree(P->seq);
-    P->seq = nullptr;
+    if (P->gran) (void)hipHostFree(P->gran);
+    P->seq = nullptr; P->gran = nullptr;
 }
 
 FgPollOut fg_poll_next(FgPoll* P) {
     if (!P->spin || !P->seq) return FgPollOut{nullptr, 0};
     if (++P->epoch == 0) ++P->epoch;      // 0 is what the words start with
-    return FgPollOut{P->seq, P->epoch};
+    return FgPollOut{P->seq, P->epoch, P->gran};
 }
 
-int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st) {
-    if (!out.seq) { FG_HIP_CHECK(hipStreamSynchronize(st)); return FG_OK; }
-    if (first < 0 || first + count > P->n) { fg_set_error("fg_poll_wait: range outside the sequence words"); return FG_ERR_INVALID_ARG; }
+template <typename Ready>
+static int poll_spin(int first, int count, hipStream_t st, Ready ready) {
     const auto t0 = std::chrono::steady_clock::now();
     int i = first;
     unsigned spins = 0;
     while (i < first + count) {
-        if (__atomic_load_n(out.seq + i, __ATOMIC_ACQUIRE) == out.value) { ++i; continue; }
+        if (ready(i)) { ++i; continue; }
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
 #else
@@ -47,7 +56,7 @@ int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStrea
             // a long kernel queue, or a fault: let the runtime wait (and report)
             FG_HIP_CHECK(hipStreamSynchronize(st));
             for (int k = first; k < first + count; ++k)
-                if (__atomic_load_n(out.seq + k, __ATOMIC_ACQUIRE) != out.value) {
+                if (!ready(k)) {
                     fg_set_error("fg_poll_wait: the polled kernel finished without publishing its sequence word");
                     return FG_ERR_HIP;
                 }
@@ -55,6 +64,19 @@ int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStrea
         }
     }
     return FG_OK;
+}
+
+int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st) {
+    if (!out.seq) { FG_HIP_CHECK(hipStreamSynchronize(st)); return FG_OK; }
+    if (first < 0 || first + count > P->n) { fg_set_error("fg_poll_wait: range outside the sequence words"); return FG_ERR_INVALID_ARG; }
+    return poll_spin(first, count, st, [&](int i) { return __atomic_load_n(out.seq + i, __ATOMIC_ACQUIRE) == out.value; });
+}
+
+int fg_poll_wait_words(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st) {
+    if (!out.gran) { fg_set_error("fg_poll_wait_words: no result words (the caller must use the mirror form)"); return FG_ERR_INVALID_ARG; }
+    if (first < 0 || first + count > P->n_gran) { fg_set_error("fg_poll_wait_words: range outside the result words"); return FG_ERR_INVALID_ARG; }
+    const unsigned long long tag = (unsigned long long)(uint32_t)out.value;
+    return poll_spin(first, count, st, [&](int i) { return (__atomic_load_n(out.gran + i, __ATOMIC_ACQUIRE) >> 32) == tag; });
 }
 
 // ---- FG_HTRACE=1: host-side time stamps around the polls (diagnosis of the idle time between a polled kernel and the launch that
