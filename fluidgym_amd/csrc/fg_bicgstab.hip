@@ -613,10 +613,11 @@ __global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ fl
                               fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass, FgPollOut poll,
                               int sys0 = 0) {
     // systems sys0 .. sys0 + nsys - 1 (a sub-batch of envs: the systems behind it have not started and must not be judged)
-    const int s = sys0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= sys0 + nsys) return;
-    if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
-    if (flag_ld(flags + (s)) == 0) {
+    __shared__ uint32_t stage[2 * 64];
+    const int first = sys0 + blockIdx.x * blockDim.x, s = first + threadIdx.x;
+    const bool valid = s < sys0 + nsys;
+    if (valid && flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
+    if (valid && flag_ld(flags + (s)) == 0) {
         const fg_real crit = (fg_real)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + F_RR + ((it + 1) & 1))) / (double)n);
         info[s].final_residual = crit;
         info[s].used_iterations = it + 1;
@@ -629,8 +630,7 @@ __global__ void k_bicgf_check(FgDacc* __restrict__ acc, int32_t* __restrict__ fl
             info[s].converged = 0;
         }
     }
-    mirror[s] = info[s];
-    fg_poll_publish(poll, s);      // (after the entry: the host spins on this word instead of synchronising the stream)
+    fg_poll_publish_infos(poll, mirror, info, s, valid, first, min((int)blockDim.x, sys0 + nsys - first), stage);
 }
 
 __global__ void k_bicg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict__ acc, fg_real* __restrict__ sc,
@@ -643,10 +643,11 @@ __global__ void k_bicg_begin(const fg_real* __restrict__ dt, FgDacc* __restrict_
 
 __global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info,
                              fg_solve_info* __restrict__ mirror, fg_real tol, int it, int n, int nsys, int final_pass, FgPollOut poll) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsys) return;
-    if (flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
-    if (flag_ld(flags + (s)) == 0) {
+    __shared__ uint32_t stage[2 * 64];
+    const int first = blockIdx.x * blockDim.x, s = first + threadIdx.x;
+    const bool valid = s < nsys;
+    if (valid && flag_ld(flags + (s)) == 4) flag_st(flags + (s), 1);
+    if (valid && flag_ld(flags + (s)) == 0) {
         const fg_real crit = (fg_real)sqrt(acc_ld(acc + ((size_t)s * FG_ACC_DOUBLES + A_RR)) / (double)n);
         info[s].final_residual = crit;
         info[s].used_iterations = it + 1;
@@ -659,8 +660,7 @@ __global__ void k_bicg_check(FgDacc* __restrict__ acc, int32_t* __restrict__ fla
             info[s].converged = 0;
         }
     }
-    mirror[s] = info[s];  // host-pinned copy: the poll that follows needs no device-to-host copy
-    fg_poll_publish(poll, s);
+    fg_poll_publish_infos(poll, mirror, info, s, valid, first, min((int)blockDim.x, nsys - first), stage);
 }
 
 }  // namespace
@@ -859,7 +859,7 @@ static int bicgstab_krylov(fg_state* s, const FgBicgArgs& a, fg_solve_info* info
                     gsub = keep;
                     started_b0 = b0 + nb_sub;
                 }
-                if (int rc = fg_poll_wait(&s->poll, po, sys0, nsys_sub, st)) return rc;
+                if (int rc = fg_poll_wait_infos(&s->poll, po, sys0, nsys_sub, s->info_pinned, st)) return rc;
                 info_fresh = true;
                 done = true;
                 for (int i = sys0; i < sys0 + nsys_sub; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
@@ -891,7 +891,7 @@ static int bicgstab_krylov(fg_state* s, const FgBicgArgs& a, fg_solve_info* info
                 fg_prof_prefetch(s, st);
                 const FgPollOut po = fg_poll_next(&s->poll);
                 hipLaunchKernelGGL(k_bicgf_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass, po, 0);
-                if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
+                if (int rc = fg_poll_wait_infos(&s->poll, po, 0, nsys, s->info_pinned, st)) return rc;
                 info_fresh = true;
                 done = true;
                 for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);
@@ -927,7 +927,7 @@ static int bicgstab_krylov(fg_state* s, const FgBicgArgs& a, fg_solve_info* info
             fg_prof_prefetch(s, st);
             const FgPollOut po = fg_poll_next(&s->poll);
             hipLaunchKernelGGL(k_bicg_check, sg, sb, 0, st, q.acc, q.flags, q.info, s->info_pinned, a.tol, it, n, nsys, final_pass, po);
-            if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
+            if (int rc = fg_poll_wait_infos(&s->poll, po, 0, nsys, s->info_pinned, st)) return rc;
             info_fresh = true;
             done = true;
             for (int i = 0; i < nsys; ++i) done = done && (s->info_pinned[i].converged || !s->info_pinned[i].is_finite);

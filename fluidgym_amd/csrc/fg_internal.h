@@ -596,6 +596,21 @@ __device__ __forceinline__ void fg_poll_publish_records(const FgPollOut& p, int 
     __syncthreads();
     for (int i = threadIdx.x; i < n * W; i += blockDim.x) fg_poll_publish_word(p, first * W + i, stage[i]);
 }
+__device__ __forceinline__ void fg_poll_publish(const FgPollOut& p, int i);
+// the end of a verdict kernel with one THREAD per system (every thread of the workgroup calls, `valid` = the thread has a system):
+// the infos of systems first .. first + n - 1 leave as result words (two per system, fg_poll_wait_infos unpacks them) or, without
+// result words, through the mirror + release form.  `stage`: 2 * blockDim.x words of LDS.
+__device__ __forceinline__ void fg_poll_publish_infos(const FgPollOut& p, fg_solve_info* mirror, const fg_solve_info* info, int sys, bool valid,
+                                                      int first, int n, uint32_t* stage) {
+    if (p.gran) {
+        uint32_t w[2] = {0u, 0u};
+        if (valid) { const fg_solve_info v = info[sys]; w[0] = __float_as_uint((float)v.final_residual); w[1] = fg_info_word(v); }
+        fg_poll_publish_records<2>(p, first, n, sys - first, w, valid, stage);
+    } else if (valid) {
+        mirror[sys] = info[sys];      // host-pinned copy: the poll that follows needs no device-to-host copy
+        fg_poll_publish(p, sys);      // (after the entry: the host spins on this word instead of synchronising the stream)
+    }
+}
 __device__ __forceinline__ void fg_poll_publish(const FgPollOut& p, int i) {
     // system-scope release: the results stored before it (by this thread, or by threads it synchronised with) are visible to the
     // host once the word is.  It writes the L2 back, so a kernel calls it from as few threads as possible, and after all its
@@ -616,6 +631,8 @@ FgPollOut fg_poll_next(FgPoll* P);     // the words and sequence number of the n
 int fg_poll_wait(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st);
 // the same for result words [first, first + count) of out.gran; fg_poll_word / fg_poll_info read them afterwards
 int fg_poll_wait_words(FgPoll* P, const FgPollOut& out, int first, int count, hipStream_t st);
+// infos of systems [first, first + count) into `pinned` (where the mirror form leaves them): result words when the poll has them
+int fg_poll_wait_infos(FgPoll* P, const FgPollOut& out, int first, int count, fg_solve_info* pinned, hipStream_t st);
 inline uint32_t fg_poll_word(const FgPoll* P, int i) { return (uint32_t)(__atomic_load_n(P->gran + i, __ATOMIC_RELAXED) & 0xffffffffull); }
 inline float fg_poll_word_float(const FgPoll* P, int i) { const uint32_t u = fg_poll_word(P, i); float f; memcpy(&f, &u, 4); return f; }
 inline void fg_poll_info(const FgPoll* P, int sys, fg_solve_info* out) {

@@ -433,36 +433,55 @@ __global__ __launch_bounds__(FG_BLOCK) void k_jac_stream(FgGrid g, JacStreamArgs
 __global__ void k_jac_stream_check(FgDacc* __restrict__ acc, int32_t* __restrict__ flags, fg_solve_info* __restrict__ info, fg_solve_info* __restrict__ mirror,
                                    float* __restrict__ res2, float tol, int nc, int slot_now, int slot_prev, int ax_slot, int sweeps, int n, int B,
                                    FgPollOut poll) {
+    __shared__ uint32_t stage[64 * 12];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    bool running = false;
-    for (int q = 0; q < nc; ++q) running = running || flag_ld(flags + (b * nc + q)) == 0;
-    if (running) {
-        bool bad = false, all = true;
-        for (int q = 0; q < nc; ++q) {
-            const float now = fg_rms(acc_ld(acc + (size_t)(b * nc + q) * FG_ACC_DOUBLES + slot_now), n);
-            const float floor32 = ax_slot >= 0 ? 1.1920929e-7f * fg_rms(acc_ld(acc + (size_t)(b * nc + q) * FG_ACC_DOUBLES + ax_slot), n) : 0.f;
-            // (the floor rule is capped at 8 x the tolerance: beyond that the measure is not rounding, the system is not solved -- ADVICE r5)
-            bad = bad || !isfinite(now); all = all && (now < tol || (now < floor32 && now < 8.f * tol));
-        }
-        for (int q = 0; q < nc; ++q) {
-            const int sys = b * nc + q;
-            const float now = fg_rms(acc_ld(acc + (size_t)sys * FG_ACC_DOUBLES + slot_now), n);
-            const float prev = slot_prev >= 0 ? fg_rms(acc_ld(acc + (size_t)sys * FG_ACC_DOUBLES + slot_prev), n) : -1.f;
-            res2[2 * sys] = now; res2[2 * sys + 1] = prev;
-            info[sys].final_residual = now;
-            info[sys].used_iterations = sweeps - 1;
-            if (bad || all) {
-                const bool finite = isfinite(now);
-                info[sys].converged = (finite && all) ? 1 : 0;
-                info[sys].is_finite = finite ? 1 : 0;
-                flag_st(flags + sys, finite ? 1 : 2);
+    const bool valid = b < B;
+    // result words (FgPollOut, fg_internal.h), twelve per env: per component the info (2), the residual measured now, the one before
+    uint32_t w[12] = {};
+    float rnow[3] = {-1.f, -1.f, -1.f}, rprev[3] = {-1.f, -1.f, -1.f};
+    if (valid) {
+        bool running = false;
+        for (int q = 0; q < nc; ++q) running = running || flag_ld(flags + (b * nc + q)) == 0;
+        if (running) {
+            bool bad = false, all = true;
+            for (int q = 0; q < nc; ++q) {
+                const float now = fg_rms(acc_ld(acc + (size_t)(b * nc + q) * FG_ACC_DOUBLES + slot_now), n);
+                const float floor32 = ax_slot >= 0 ? 1.1920929e-7f * fg_rms(acc_ld(acc + (size_t)(b * nc + q) * FG_ACC_DOUBLES + ax_slot), n) : 0.f;
+                // (the floor rule is capped at 8 x the tolerance: beyond that the measure is not rounding, the system is not solved -- ADVICE r5)
+                bad = bad || !isfinite(now); all = all && (now < tol || (now < floor32 && now < 8.f * tol));
+            }
+            for (int q = 0; q < nc; ++q) {
+                const int sys = b * nc + q;
+                const float now = fg_rms(acc_ld(acc + (size_t)sys * FG_ACC_DOUBLES + slot_now), n);
+                const float prev = slot_prev >= 0 ? fg_rms(acc_ld(acc + (size_t)sys * FG_ACC_DOUBLES + slot_prev), n) : -1.f;
+                if (q < 3) { rnow[q] = now; rprev[q] = prev; }
+                info[sys].final_residual = now;
+                info[sys].used_iterations = sweeps - 1;
+                if (bad || all) {
+                    const bool finite = isfinite(now);
+                    info[sys].converged = (finite && all) ? 1 : 0;
+                    info[sys].is_finite = finite ? 1 : 0;
+                    flag_st(flags + sys, finite ? 1 : 2);
+                }
             }
         }
-    } else {
-        for (int q = 0; q < nc; ++q) { res2[2 * (b * nc + q)] = -1.f; res2[2 * (b * nc + q) + 1] = -1.f; }
+        if (poll.gran) {
+            for (int q = 0; q < nc && q < 3; ++q) {
+                const fg_solve_info v = info[b * nc + q];
+                w[4 * q] = __float_as_uint(v.final_residual); w[4 * q + 1] = fg_info_word(v);
+                w[4 * q + 2] = __float_as_uint(rnow[q]); w[4 * q + 3] = __float_as_uint(rprev[q]);
+            }
+        } else {
+            for (int q = 0; q < nc; ++q) {
+                res2[2 * (b * nc + q)] = q < 3 ? rnow[q] : -1.f; res2[2 * (b * nc + q) + 1] = q < 3 ? rprev[q] : -1.f;
+                mirror[b * nc + q] = info[b * nc + q]; fg_poll_publish(poll, b * nc + q);
+            }
+        }
     }
-    for (int q = 0; q < nc; ++q) { mirror[b * nc + q] = info[b * nc + q]; fg_poll_publish(poll, b * nc + q); }
+    if (poll.gran) {      // (every lane: the wave publishes together)
+        const int first = blockIdx.x * blockDim.x;
+        fg_poll_publish_records<12>(poll, first, min((int)blockDim.x, B - first), threadIdx.x, w, valid, stage);
+    }
 }
 
 int jac_tiles(int ny, int rows, int sweeps) {
@@ -766,7 +785,19 @@ static int jacobi_stream_solve(fg_state* s, const FgBicgArgs& a, fg_solve_info* 
     for (;;) {
         const FgPollOut po = fg_poll_next(&s->poll);
         if (int rc = run_to_check(upto, po)) return rc;
-        if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
+        if (po.gran) {      // (the verdicts and both measured residuals arrive in the polled words: unpacked to where the mirror form leaves them)
+            if (int rc = fg_poll_wait_words(&s->poll, po, 0, 12 * B, st)) return rc;
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < nc; ++c) {
+                    const int i = b * nc + c;
+                    fg_solve_info& I = s->info_pinned[i];
+                    const uint32_t wd = fg_poll_word(&s->poll, 12 * b + 4 * c + 1);
+                    I.final_residual = fg_poll_word_float(&s->poll, 12 * b + 4 * c);
+                    I.used_iterations = (int32_t)(wd >> 2) - 1; I.converged = (wd >> 1) & 1; I.is_finite = wd & 1;
+                    s->jac_prev[2 * i] = fg_poll_word_float(&s->poll, 12 * b + 4 * c + 2);
+                    s->jac_prev[2 * i + 1] = fg_poll_word_float(&s->poll, 12 * b + 4 * c + 3);
+                }
+        } else if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
         bool all = true, bad = false;
         double need = 0.0;
         for (int i = 0; i < nsys; ++i) {

@@ -332,13 +332,6 @@ __global__ __launch_bounds__(64 * CG_CHECK_WAVES) void k_cg_check(FgDacc* __rest
         fg_poll_publish(poll, b);      // (after the entry: the host spins on this word instead of synchronising the stream)
     }
 }
-// the host side of a polled k_cg_check / k_fcg_check0: wait for the verdicts and leave them in info_pinned
-static int cg_wait_infos(fg_state* s, const FgPollOut& po, int B, hipStream_t st) {
-    if (!po.gran) return fg_poll_wait(&s->poll, po, 0, B, st);
-    if (int rc = fg_poll_wait_words(&s->poll, po, 0, 2 * B, st)) return rc;
-    for (int b = 0; b < B; ++b) fg_poll_info(&s->poll, b, s->info_pinned + b);
-    return FG_OK;
-}
 
 __global__ void k_cg_begin(const fg_real* __restrict__ dt, FgCgBegin q, int B) {
     if ((int)blockIdx.x < B) fg_cg_begin_env(q, dt, blockIdx.x);
@@ -534,7 +527,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             }
             if (poll0) {
                 fg_htrace("cg_check_launched");
-                if (int rc = cg_wait_infos(s, po, B, st)) return rc;
+                if (int rc = fg_poll_wait_infos(&s->poll, po, 0, B, s->info_pinned, st)) return rc;
                 fg_htrace("cg_poll_done");
                 info_fresh = true;
                 s->fcg_first_polls += 1;
@@ -578,7 +571,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
                 hipLaunchKernelGGL(k_cg_check, dim3((B + CG_CHECK_WAVES - 1) / CG_CHECK_WAVES), dim3(64 * CG_CHECK_WAVES), 0, st, s->cg_acc, s->flags, s->info_dev, s->info_pinned, a.tol, it,
                                    n, B, final_pass, ns, po);
                 fg_htrace("cg_check_launched");
-                if (int rc = cg_wait_infos(s, po, B, st)) return rc;
+                if (int rc = fg_poll_wait_infos(&s->poll, po, 0, B, s->info_pinned, st)) return rc;
                 fg_htrace("cg_poll_done");
                 info_fresh = true;
                 done = true;
@@ -657,7 +650,7 @@ int fg_cg_solve(fg_state* s, const FgCgArgs& a, fg_solve_info* info_host, hipStr
             // The poll comes BEFORE the preconditioner of the next iteration: polls are scheduled where the previous solve
             // finished, so they usually end the solve, and three kernels of M^-1 that would find every env converged
             // cost more than the idle round trip of a poll that does not.
-            if (int rc = cg_wait_infos(s, po, B, st)) return rc;
+            if (int rc = fg_poll_wait_infos(&s->poll, po, 0, B, s->info_pinned, st)) return rc;
             info_fresh = true;
             done = true;
             active_est = 0;

@@ -79,6 +79,13 @@ int fg_poll_wait_words(FgPoll* P, const FgPollOut& out, int first, int count, hi
     return poll_spin(first, count, st, [&](int i) { return (__atomic_load_n(out.gran + i, __ATOMIC_ACQUIRE) >> 32) == tag; });
 }
 
+int fg_poll_wait_infos(FgPoll* P, const FgPollOut& out, int first, int count, fg_solve_info* pinned, hipStream_t st) {
+    if (!out.gran) return fg_poll_wait(P, out, first, count, st);
+    if (int rc = fg_poll_wait_words(P, out, 2 * first, 2 * count, st)) return rc;
+    for (int i = first; i < first + count; ++i) fg_poll_info(P, i, pinned + i);
+    return FG_OK;
+}
+
 // ---- FG_HTRACE=1: host-side time stamps around the polls (diagnosis of the idle time between a polled kernel and the launch that
 // follows it); the deltas between consecutive tags are summed per pair and printed when the process ends
 #include <cstdio>
