@@ -426,32 +426,44 @@ def capped_solves(its) -> int:
     return int(sum(v.get("unconverged", 0) for v in its.values() if isinstance(v, dict)))
 
 
-def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing=0.0, **env_kw):
+def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing=0.0, lanes=1, **env_kw):
     """One single-block env at full size, batched on this GPU: env-steps/s, iterations per solve over the timed region,
-    substeps, the live roofline table of its solver kernels."""
+    substeps, the live roofline table of its solver kernels.  lanes > 1: the batch as that many sub-batches stepped concurrently on
+    their own HIP streams (ParallelFluidEnv(lanes=...))."""
     import torch
 
     import fluidgym_amd
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
 
-    env = fluidgym_amd.make(env_id, num_envs=num_envs, cuda_device=device, **env_kw)
+    if lanes > 1:
+        env = ParallelFluidEnv(env_id, num_envs=num_envs, lanes=lanes, cuda_ids=[device.index or 0], **env_kw)
+        lane_envs = env.lane_envs
+    else:
+        env = fluidgym_amd.make(env_id, num_envs=num_envs, cuda_device=device, **env_kw)
+        lane_envs = [env]
+    group = env
     try:
         env.reset(seed=seed)
         env.seed(seed)
-        blk0 = env._domain.getBlock(0)
+        blks = [e._domain.getBlock(0) for e in lane_envs]
         if forcing > 0:
-            blk0.setVelocitySource(torch.zeros_like(blk0.velocity))
+            for b in blks:
+                b.setVelocitySource(torch.zeros_like(b.velocity))
         force_gen = torch.Generator(device=device).manual_seed(4321)
 
         def perturb():
             if forcing > 0:
-                blk0.velocitySource.normal_(0.0, forcing, generator=force_gen)
+                for b in blks:
+                    b.velocitySource.normal_(0.0, forcing, generator=force_gen)
 
         for _ in range(warmup):
             perturb()
             env.step(env.sample_action())
-        solver = env._domain.solver
-        solver.solver_counters(reset=True)
-        solver.profile_enable(True)
+        solvers = [e._domain.solver for e in lane_envs]
+        solver = solvers[0]
+        for sv in solvers:
+            sv.solver_counters(reset=True)
+            sv.profile_enable(True)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -459,25 +471,27 @@ def env_leg(env_id, num_envs, device, steps=2, warmup=1, seed=5, doc="", forcing
             env.step(env.sample_action())
         torch.cuda.synchronize(device)
         el = (time.perf_counter() - t0) / steps
-        prof = solver.profile_read()
-        solver.profile_enable(False)
-        its = solver_iterations(solver)
+        prof = merge_profiles([sv.profile_read() for sv in solvers])
+        for sv in solvers:
+            sv.profile_enable(False)
+        its = merge_iterations([solver_iterations(sv) for sv in solvers])
         roof = roofline_from_profile(prof, solver)
-        sim_steps = env.n_sim_steps
+        sim_steps = lane_envs[0].n_sim_steps
         sw = solver_switches(solver)
-        return {"env_id": env_id, "envs": num_envs, "grid": [solver.nx, solver.ny, solver.nz], "doc": doc,
+        env = lane_envs[0] if lanes > 1 else env      # (below: attributes every lane shares; the group is closed in `finally`)
+        return {"env_id": env_id, "envs": num_envs, "lanes": lanes, "grid": [solver.nx, solver.ny, solver.nz], "doc": doc,
                 # velocity systems the streaming sweeps ended on their fp32-floor rule (measured residual >= tolerance, < 8 x tolerance;
                 # csrc/fg_jacobi.hip k_jac_stream_check) since the handle was created: reported beside capped_solves, not hidden in it
                 "floor_released_solves": sw.get("jacobi_floor_released") if isinstance(sw, dict) else None,
                 "piso_steps_per_env_step": sim_steps, "ms_per_step": 1e3 * el, "value": num_envs / el, "unit": "env-steps/s",
                 "pressure_warm_start": bool(env._sim.pressure_warm_start), "advection_warm_start": bool(env._sim.advection_warm_start), "solver_iterations": its,
-                "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(steps * sim_steps, 1), 2),
+                "capped_solves": capped_solves(its), "mean_substeps_per_sim_step": round(its["piso_steps"] / max(lanes, 1) / max(steps * sim_steps, 1), 2),
                 "policy": "uniform samples of the action space", "switches": sw, "velocity_solver": velocity_solver_desc(env, solver),
                 "dominant_kernel": None if roof is None else {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")},
                 "kernels": None if roof is None else {k: {kk: v[kk] for kk in ("avg_busy_launch_ms", "launches", "est_total_ms", "GBps", "TFLOPps")}
                                                       for k, v in roof["kernels"].items()}}
     finally:
-        env.close()
+        group.close()
 
 
 def cylinder_sharded(world, rank, device, coll_device, share_gpu, envs_per_gpu=ENVS_PER_GPU, steps=4, repeats=3):
@@ -596,6 +610,8 @@ def _leg_summary(leg):
     dk = leg.get("dominant_kernel")
     if dk:
         s["dom"] = [dk["kernel"].split(":")[0], _r(dk["frac"], 3)]
+    if (leg.get("lanes") or 1) > 1:
+        s["lanes"] = leg["lanes"]
     for k in ("capped_solves", "floor_released_solves", "launches_per_piso_step", "oracle_iters", "busy_cus"):
         if leg.get(k) is not None:
             s[k] = _r(leg[k])
@@ -623,14 +639,14 @@ def compact_line(out, detail_path=DETAIL_PATH):
         line["value_unforced"] = _r(out["value_unforced"], 6)
     cfg = out["config"]
     line["config"] = {"workload": cfg["workload"], "global_batch": cfg["global_batch"], "grid": cfg["grid"],
-                      "parallelism": cfg["parallelism"], "workload_modified": cfg.get("workload_modified"),
+                      "parallelism": cfg["parallelism"], "lanes_per_gpu": cfg.get("lanes_per_gpu"), "workload_modified": cfg.get("workload_modified"),
                       "forcing_amplitude": cfg.get("forcing_amplitude"),
                       "iters_per_solve[mean,max]": _iters(cfg.get("solver_iterations")),
                       "substeps_per_sim_step": cfg.get("mean_substeps_per_sim_step"),
                       "capped_solves": cfg.get("capped_solves"), "floor_released_solves": cfg.get("floor_released_solves"),
                       "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step")),
                       "solver_kernels_GBps": _r(cfg.get("solver_kernels_GBps")), "whole_step_GBps_model": _r(cfg.get("whole_step_GBps_model")),
-                      "GBps_doc": "solver_kernels_GBps = r5's step_GBps (solver kernels only); _model adds DESIGN 4's bytes of assembly + correctors",
+                      "GBps_doc": "solver kernels only (r5: step_GBps); _model adds DESIGN 4's assembly + corrector bytes",
                       "advection_solver_form": cfg.get("advection_solver_form"),
                       "velocity_solver": (cfg.get("velocity_solver") or "")[:120]}
     if cfg.get("per_rank"):
@@ -651,6 +667,8 @@ def compact_line(out, detail_path=DETAIL_PATH):
             # VALU / LDS work on resident data, so the HBM fraction of its ALGORITHMIC bytes is bounded by that split
             line["roofline"]["note"] = ("loads once, then 8-12 on-chip sweeps per launch: ~half the launch is VALU/LDS work on resident data; "
                                         "krylov_mode leg = the streaming kernels it replaced (k_bicgf_a at ~0.68)")
+        if (cfg.get("lanes_per_gpu") or 1) > 1:
+            line["roofline"]["lanes_note"] = "each lane's own launches, timed while the other lane's kernels share the GPU (--lanes 1: alone)"
         triad = roof.get("measured_stream_triad")
         if triad and "GBps" in triad:
             line["roofline"]["triad_GBps"] = _r(triad["GBps"])
@@ -940,9 +958,11 @@ def main():
             doc="headline workload with advection_jacobi=False: the velocity systems by BiCGStab (the reference's solver) instead of the "
                 "on-chip Jacobi sweeps -- same systems, same tolerance")
         fluidgym_amd.set_solver_policy(**old)
-        leg("large_env", env_leg, "ChannelJet2D-large-v0", 64, device, steps=5, warmup=1, seed=1234, forcing=args.forcing,
+        # (lanes: measured per leg, profiles/legs_lanes.py -- two lanes give +15 % on the large channel and +8 % on RBC; the 8-env TCF batch is
+        #  too small to split: -7 %)
+        leg("large_env", env_leg, "ChannelJet2D-large-v0", 64, device, steps=5, warmup=1, seed=1234, forcing=args.forcing, lanes=min(args.lanes, 2),
             doc="BASELINE config 5's per-GPU share: 512x256 x 64 envs (working set > Infinity Cache: the HBM-resident 2-D case)")
-        leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=8, warmup=1,
+        leg("rbc_env", env_leg, "RBC2D-baseline-v0", 32, device, steps=8, warmup=1, lanes=min(args.lanes, 2),
             doc="BASELINE config 2 on one GPU: Rayleigh-Benard 512x128, 32 envs (256 across 8 GPUs)")
         leg("tcf_env", env_leg, "TCF3D-baseline-v0", 8, device, steps=8, warmup=1,
             doc="BASELINE config 3: turbulent channel 128x64x64, 8 envs")

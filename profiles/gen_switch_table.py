@@ -41,6 +41,9 @@ NOTES = {
     "FG_FORCE_ZMARCH": ("bits", "z-march chunk length of the 3-D Poisson kernels (tests on small grids; -1 = brick kernels)"),
     "FG_ZMARCH_SB": ("no", "single-barrier ring of the z-march kernels: bit per mode, 0 never, unset = rule"),
     "FG_POLL_SPIN": ("no", "0: host polls wait with hipStreamSynchronize instead of spinning on pinned sequence words"),
+    "FG_POLL_WORDS": ("no", "0: polled verdicts through the host-pinned mirror + a system-scope release (one L2 write-back per verdict kernel) instead of travelling in the 8-byte result words the host spins on (A/B runs: 8 790 against 9 600 env-steps/s on the headline, one lane)"),
+    "FLUIDGYM_AMD_ENV_GLUE": ("bits", "0: ChannelJet2D's action schedule and reward / observation as elementwise torch launches instead of the two native kernels of fg_envglue.hip (A/B runs; the schedule is bit-identical, the means differ by fp32 rounding of the summation order)"),
+    "FLUIDGYM_AMD_LANES": ("no", "default of ParallelFluidEnv(lanes=...): sub-batches of a rank's env batch, each its own solver handle, stepped concurrently by that many host threads on their own HIP streams (1 = one batch; bench.py passes --lanes 2).  Same bits per env as the sub-batches stepped alone"),
     "FG_PROF_PERIOD": ("no", "sampling period of the live kernel timing (64)"),
     "FG_FD_NO_FFT": ("bits", "1: the x basis change of the FD preconditioner as dense GEMM instead of the row FFT (tests)"),
     "FG_MB_BICG_VEC4": ("no", "bit per multi-block BiCGStab kernel: four-cell form (31 = all)"),
