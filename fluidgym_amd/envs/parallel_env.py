@@ -110,7 +110,13 @@ class _Lanes:
         """``fn(lane, env)`` on every lane concurrently; the list of results in lane order."""
         if not self._cuda:
             futs = [self._pool.submit(fn, l, self.envs[l]) for l in range(1, self.n_lanes)]
-            return [fn(0, self.envs[0])] + [f.result() for f in futs]
+            try:
+                first = fn(0, self.envs[0])
+            finally:
+                from concurrent.futures import wait
+
+                wait(futs)
+            return [first] + [f.result() for f in futs]
         main = torch.cuda.current_stream(self._device)
         start = torch.cuda.Event()
         start.record(main)
@@ -126,7 +132,12 @@ class _Lanes:
             return out, end
 
         futs = [self._pool.submit(task, l) for l in range(1, self.n_lanes)]
-        first = task(0)
+        try:
+            first = task(0)
+        finally:      # (a lane that raised must not leave the others stepping behind the caller's back)
+            from concurrent.futures import wait
+
+            wait(futs)
         done = [first] + [f.result() for f in futs]
         for _, end in done:
             main.wait_event(end)
