@@ -120,7 +120,10 @@ KERNEL_DOC = {
     "k_gemm_f32": "fast-diagonalisation preconditioner: eigenbasis transform along x/z (fp32 MFMA 32x32x2)",
     "k_gemm_sk": "fast-diagonalisation preconditioner: eigenbasis transform, split-K 32x32 tiles (few live envs)",
     "k_dct_rows": "fast-diagonalisation preconditioners: cosine / real Fourier transform of every grid row (one FFT per row in LDS)",
-    "k_tridiag_y": "fast-diagonalisation preconditioner: per-mode tridiagonal sweep along y",
+    "k_tridiag_y": "fast-diagonalisation preconditioner: per-mode tridiagonal sweep along y (x read + written; with the row-mean operator the env's own "
+                   "factors are read too: 16 B per cell)",
+    "k_tridiag_y_fac": "the same sweep in the launch that also MAKES the env's row-mean factors (x read + written, both factor arrays written: 16 B per cell; "
+                       "wave 0 runs the factor chain beside its forward sweep)",
     "k_fcg_inv_apply": "fused pressure CG, I'(k) (fg_fftcg.hip): inverse row transform of the tridiagonal kernel's output, the matrix-free pressure "
                        "operator on the rows in LDS, r.z and z.Pz (first iteration: also the three sums the first-iterate verdict needs); "
                        "u, rA, r read, z and P z written = 20 B per cell",
@@ -147,7 +150,7 @@ def pmc_traffic(kernel):
             continue
     if t is None:
         return None
-    key = {"k_tridiag_y": "k_tridiag_y_lds"}.get(kernel, kernel)
+    key = {"k_tridiag_y": "k_tridiag_y_lds", "k_tridiag_y_fac": "k_tridiag_y_lds"}.get(kernel, kernel)
     row = t["kernels"].get(key)
     if row is None:
         return None

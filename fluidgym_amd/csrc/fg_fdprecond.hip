@@ -786,9 +786,12 @@ int fg_fd_tridiag(fg_state* s, float* cur, hipStream_t st, const FgCgLead* lead,
     const long N = G.n;
     FgCgLead ld = {};
     if (lead) ld = *lead;
-    // per env: x read + written, inv + c' read (shared by all envs, so they come from L2 after the first env)
+    // per env: x read + written; inv + c' read -- the grid's factors are shared by all envs (they come from L2 after the first env: not
+    // counted), the row-mean operator's are the env's own (8 more bytes per cell); the factoring launch writes them instead (a kind of its
+    // own in the live profile: it also runs the factor chain)
     dim3 grid((nx * nz + 63) / 64, B);
-    const int slot = fg_prof_slot(s, FG_PK_TRIDIAG, s->flags, B, 8.0 * N, 5.0 * N, st);
+    const bool own_factors = factor_from || (use_rowmean && s->fd_row_inv && (nx & 3) == 0 && (size_t)2 * ((ny + 15) / 16 * 16) * 64 * sizeof(float) <= 160 * 1024);
+    const int slot = fg_prof_slot(s, factor_from ? FG_PK_TRIDIAG_FAC : FG_PK_TRIDIAG, s->flags, B, (own_factors ? 16.0 : 8.0) * N, (factor_from ? 9.0 : 5.0) * N, st);
     const size_t lds_coop = (size_t)3 * ((ny + 15) / 16 * 16) * 64 * sizeof(float);
     const size_t lds_two = lds_coop / 3 * 2;      // two arrays: c' staged after the forward sweep (ny up to 320)
     if (factor_from) {
