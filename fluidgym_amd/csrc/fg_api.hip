@@ -109,6 +109,11 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     FG_HIP_CHECK(hipHostMalloc(&s->diag_pinned, sizeof(fg_real) * 2 * g.B));
     FG_HIP_CHECK(hipHostMalloc(&s->dt_pinned, sizeof(fg_real) * g.B));
     FG_HIP_CHECK(alloc(&s->dt_dev, g.B));
+    s->t_rem_dev = nullptr;
+#if !FG_F64
+    FG_HIP_CHECK(hipMalloc(&s->t_rem_dev, sizeof(double) * g.B));
+    FG_HIP_CHECK(hipMemset(s->t_rem_dev, 0, sizeof(double) * g.B));
+#endif
     if (int rc = fg_poll_create(&s->poll, (int)(nsys > 2 * (size_t)g.B ? nsys : 2 * (size_t)g.B))) return rc;
     for (int k = 0; k < 4; ++k) { s->pred_bicg[k] = 2; s->pred_cg[k] = 1; }
     s->wall_forcing_axis = -1;
@@ -130,6 +135,7 @@ extern "C" int fg_create(const fg_config* cfg, const fg_real* hx, const fg_real*
     s->helm_cb_pref = 32;          // (FG_HELM_CB until round 5; 64-column workgroups of k_helm_apply_y: 8.1 against 7.0 us)
     { const char* ev = getenv("FG_HELM_ROWFORM"); s->helm_rowform_off = (ev && atoi(ev) == 0) ? 1 : 0; }   // 0: k_helm_coeffs + the array-form line kernels
     { const char* ev = getenv("FG_FD_FACFUSE"); s->fd_facfuse = ev ? atoi(ev) : 1; }
+    { const char* ev = getenv("FG_DEV_DT"); s->dev_dt = ev ? atoi(ev) : 1; }
     // (default OFF: built for VERDICT r5 item 6 and measured on the RBC leg -- at the bench state's sub-step (0.02, not the 0.0125 the
     //  round-5 experiment costed) the velocity systems take 16-17 sweeps and the scalar systems do not contract by 0.7: 775 against 793 env-steps/s)
     { const char* ev = getenv("FG_ADV_LINESWEEP"); s->adv_linesweep = ev ? atoi(ev) : 0; }
@@ -183,7 +189,7 @@ extern "C" int fg_destroy(fg_handle s) {
     (void)hipHostFree(s->info_pinned); (void)hipHostFree(s->flags_pinned);
     fg_prof_destroy(s);
     fg_poll_destroy(&s->poll);
-    (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned); (void)hipHostFree(s->dt_pinned); (void)hipFree(s->dt_dev);
+    (void)hipFree(s->d_bvel_ptrs); (void)hipHostFree(s->diag_pinned); (void)hipHostFree(s->dt_pinned); (void)hipFree(s->dt_dev); (void)hipFree(s->t_rem_dev);
     float* fd[] = {s->fd_Qx, s->fd_QxT, s->fd_Qz, s->fd_QzT, s->fd_lower, s->fd_inv, s->fd_cp};
     for (float* p : fd) if (p) (void)hipFree(p);
     if (s->fd_dct_tw) { (void)hipFree(s->fd_dct_tw); (void)hipFree(s->fd_dct_rot); }
@@ -840,6 +846,37 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             any = fixed_left > 0;
         }
         if (!any) break;
+        // the reference's sub-step rule for env b from its CFL maximum (PISOtorch_simulation.py:2013-2031)
+        auto advance = [&](int b, fg_real max_vel) -> fg_real {
+            fg_real ts = 0.f;
+            if (!o->adaptive) {
+                ts = o->time_step;
+            } else if (t_rem[b] > 0 && !is_close_zero(t_rem[b])) {
+                const double mv = (double)max_vel;
+                const double max_ts = is_close_zero(mv) ? t_rem[b] : (double)o->cfl / mv;
+                double tsd;
+                if (max_ts >= t_rem[b]) tsd = t_rem[b];
+                else tsd = t_rem[b] / (double)(long long)std::ceil(t_rem[b] / max_ts);
+                t_rem[b] -= tsd;
+                ts = (fg_real)tsd;  // the reference rounds ts through the domain dtype (PISOtorch_simulation.py:2029-2031)
+            }
+            return ts;
+        };
+        auto flux_guard = [&]() -> int {
+            fg_real worst = 0.f;
+            for (int b = 0; b < B; ++b) {
+                if (flux_host) flux_host[b] = s->diag_pinned[b];
+                const fg_real a = std::fabs(s->diag_pinned[b]);
+                worst = (a > worst || a != a) ? a : worst;
+            }
+            if (!(worst <= o->flux_balance_tol)) {
+                fg_set_error("Domain boundary fluxes not balanced, cannot proceed with simulation step.");
+                return FG_ERR_FLUX_BALANCE;
+            }
+            return FG_OK;
+        };
+        bool deferred = false;      // the CFL maxima are read AFTER the PISO step: its sub-steps were taken on the device (FgDtRule)
+        FgPollOut po_cfl = FgPollOut{nullptr, 0};
         if (o->adaptive || first) {
             // one transfer: [0..B) boundary flux balance, [B..2B) max |Minv u| (CFL velocity)
             // both kernels publish straight into the host-pinned diag_pinned (one workgroup per env writes the flux
@@ -848,59 +885,42 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
             // (fg_publish_max), which the in-order stream also puts behind the flux balances of the kernel in front of it; without the
             // CFL kernel, one word per env behind the flux balance.
             const FgPollOut po = fg_poll_next(&s->poll);
-            const FgPollOut none = FgPollOut{nullptr, 0};
+            po_cfl = po;
             // (with the CFL kernel in the step, the guard is computed by workgroup 0 of every env of THAT launch: one kernel, one word)
             if (first && !o->adaptive) { if (int rc = fg_launch_flux_balance(s, bnd, s->diag_pinned, st, FgPollOut{po.seq, po.value})) return rc; }
             if (o->adaptive) {
                 // (fp32 build: the maxima and the flux balances travel in the polled result words themselves -- FgPollOut::gran,
-                //  words [B, 2 B) and [0, B) -- and are unpacked to where the mirror form leaves them)
+                //  words [12 B, 13 B) and [13 B, 14 B), out of reach of the polls of the step -- and are unpacked to where the mirror form
+                //  leaves them.  With them the sub-steps are taken on the device by the kernel itself and the host reads the maxima after
+                //  the PISO step, for its loop control: no round trip between the CFL kernel and the step -- FgDtRule, FG_DEV_DT=0 = before)
+                deferred = po.gran != nullptr && s->dev_dt && s->t_rem_dev != nullptr;
+                const FgDtRule rule = deferred ? FgDtRule{s->t_rem_dev, s->dt_dev, (float)o->cfl, (double)o->time_step, first ? 1 : 0}
+                                               : FgDtRule{nullptr, nullptr, 0.f, 0.0, 0};
                 if (int rc = fg_launch_max_velocity(s, bnd, s->scratch_B + B, st, s->diag_pinned + B, po.seq ? FgPollOut{po.seq + B, po.value, po.gran} : po,
-                                                    first ? s->scratch_B : nullptr, first ? s->diag_pinned : nullptr))
+                                                    first ? s->scratch_B : nullptr, first ? s->diag_pinned : nullptr, rule))
                     return rc;
             }
-            (void)none;
             fg_htrace("maxvel_launched");
-            if (o->adaptive && po.gran) {
-                if (int rc = fg_poll_wait_words(&s->poll, po, first ? 0 : B, first ? 2 * B : B, st)) return rc;
-                for (int b = 0; b < B; ++b) {
-                    s->diag_pinned[B + b] = fg_poll_word_float(&s->poll, B + b);
-                    if (first) s->diag_pinned[b] = fg_poll_word_float(&s->poll, b);
-                }
-            } else if (int rc = fg_poll_wait(&s->poll, po, o->adaptive ? B : 0, o->adaptive ? 1 : B, st)) return rc;
-            fg_htrace("maxvel_poll_done");
-            if (first) {
-                fg_real worst = 0.f;
-                for (int b = 0; b < B; ++b) {
-                    if (flux_host) flux_host[b] = s->diag_pinned[b];
-                    const fg_real a = std::fabs(s->diag_pinned[b]);
-                    worst = (a > worst || a != a) ? a : worst;
-                }
-                if (!(worst <= o->flux_balance_tol)) {
-                    fg_set_error("Domain boundary fluxes not balanced, cannot proceed with simulation step.");
-                    return FG_ERR_FLUX_BALANCE;
-                }
+            if (!deferred) {
+                if (o->adaptive && po.gran) {
+                    if (int rc = fg_poll_wait_words(&s->poll, po, 12 * B, first ? 2 * B : B, st)) return rc;
+                    for (int b = 0; b < B; ++b) {
+                        s->diag_pinned[B + b] = fg_poll_word_float(&s->poll, 12 * B + b);
+                        if (first) s->diag_pinned[b] = fg_poll_word_float(&s->poll, 13 * B + b);
+                    }
+                } else if (int rc = fg_poll_wait(&s->poll, po, o->adaptive ? B : 0, o->adaptive ? 1 : B, st)) return rc;
+                fg_htrace("maxvel_poll_done");
+                if (first) if (int rc = flux_guard()) return rc;
             }
         }
-        for (int b = 0; b < B; ++b) {
-            fg_real ts = 0.f;
-            if (!o->adaptive) {
-                ts = o->time_step;
-            } else if (t_rem[b] > 0 && !is_close_zero(t_rem[b])) {
-                const double mv = (double)s->diag_pinned[B + b];
-                const double max_ts = is_close_zero(mv) ? t_rem[b] : (double)o->cfl / mv;
-                double tsd;
-                if (max_ts >= t_rem[b]) tsd = t_rem[b];
-                else tsd = t_rem[b] / (double)(long long)std::ceil(t_rem[b] / max_ts);
-                t_rem[b] -= tsd;
-                ts = (fg_real)tsd;  // the reference rounds ts through the domain dtype (PISOtorch_simulation.py:2029-2031)
-            }
-            s->dt_pinned[b] = ts;
-        }
+        if (!deferred)
+            for (int b = 0; b < B; ++b) s->dt_pinned[b] = advance(b, o->adaptive ? s->diag_pinned[B + b] : (fg_real)0);
         // PRE hook: advective outflow + flux re-balancing (cylinder_env_base.py:280-300)
         const bool folded = o->outflow_mask && fg_outflow_folds(s, o->outflow_mask);     // small slabs: the update rides in the balance launch
         // the time steps reach the device as kernel arguments of that launch (up to 64 envs) instead of through a copy in front of it
-        const bool dt_by_value = folded && B <= 64;
-        if (!dt_by_value) FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(fg_real) * B, hipMemcpyHostToDevice, st));
+        // (deferred: they are in dt_dev already, written by the CFL kernel)
+        const bool dt_by_value = folded && B <= 64 && !deferred;
+        if (!dt_by_value && !deferred) FG_HIP_CHECK(hipMemcpyAsync(s->dt_dev, s->dt_pinned, sizeof(fg_real) * B, hipMemcpyHostToDevice, st));
         if (o->outflow_mask) {
             for (int f = 0; f < 2 * s->grid.dims; ++f)
                 if ((o->outflow_mask >> f) & 1) FG_REQUIRE(s->grid.fixed[f], FG_ERR_INVALID_ARG, "outflow face is not FIXED");
@@ -918,6 +938,18 @@ extern "C" int fg_single_step(fg_handle s, const fg_sim_options* o, int32_t* out
         else if (rc != FG_OK) return rc;
         // dt_pinned must not be rewritten before the H2D copy above has executed: fg_piso_step's solver polls
         // synchronise the stream, so the copy is complete here.
+        if (deferred) {
+            // the maxima the device took its sub-steps from (published long ago): the host repeats the rule for its loop control, and the
+            // flux-balance guard of the sim step's first sub-step is judged here -- the error is the same, only raised after a PISO step
+            // on the unbalanced domain instead of before it
+            if (int rc2 = fg_poll_wait_words(&s->poll, po_cfl, 12 * B, first ? 2 * B : B, st)) return rc2;
+            for (int b = 0; b < B; ++b) {
+                s->diag_pinned[B + b] = fg_poll_word_float(&s->poll, 12 * B + b);
+                if (first) s->diag_pinned[b] = fg_poll_word_float(&s->poll, 13 * B + b);
+            }
+            if (first) if (int rc2 = flux_guard()) return rc2;
+            for (int b = 0; b < B; ++b) s->dt_pinned[b] = advance(b, s->diag_pinned[B + b]);
+        }
         ++substeps;
         first = false;
         if (!o->adaptive) --fixed_left;

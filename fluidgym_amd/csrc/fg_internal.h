@@ -797,6 +797,8 @@ struct fg_state {
     fg_real* diag_pinned;    // [2B] host-pinned: flux balance | max velocity
     fg_real* dt_pinned;      // [B] host-pinned per-env substep sizes of fg_single_step
     fg_real* dt_dev;         // [B]
+    double* t_rem_dev;       // [B] FgDtRule::t_rem (fp32 build)
+    int dev_dt;              // FG_DEV_DT (default 1): the adaptive sub-step is taken on the device behind the CFL kernel
     // iterations the last solve of each KIND needed (the first convergence poll of the next one is scheduled there): advection kinds
     // 0 scalar, 1 velocity; pressure kinds 0 first corrector, 1 later correctors, 2 stand-alone calls.  Until round 5 one predictor per
     // solver served all kinds: the RBC env's second corrector (0-1 iterations) then launched the first corrector's three iterations
@@ -916,8 +918,15 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
 // mirror_B: optional host-pinned [B] the last workgroup of each env publishes the result to (out_B must then be
 // scratch_B + B, whose next row holds the arrival counters)
 // poll (optional): sequence words published per env after the host-pinned result (FgPollOut above)
+// FgDtRule (round 6): the adaptive sub-step of fg_single_step taken ON THE DEVICE by the workgroup that finishes the CFL maxima (the
+// reference's rule, PISOtorch_simulation.py:2013-2031, in the same doubles the host uses -- which repeats it from the published maxima
+// for its own bookkeeping): t_rem [B] the time an env still has to cover in this sim step (reset to time_step when `reset`), dt_out [B]
+// the sub-step the kernels of the PISO step read.  The host then needs the maxima only AFTER the PISO step (loop control), not
+// before it: no round trip between the CFL kernel and the step's first kernels.  t_rem == nullptr: off.
+struct FgDtRule { double* t_rem; fg_real* dt_out; float cfl; double time_step; int reset; };
 int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B = nullptr,
-                           FgPollOut poll = FgPollOut{nullptr, 0}, fg_real* flux_B = nullptr, fg_real* flux_mirror = nullptr);   // flux_B: device [B] scratch, the flux-balance guard computed in the same launch and mirrored to flux_mirror (host-pinned)
+                           FgPollOut poll = FgPollOut{nullptr, 0}, fg_real* flux_B = nullptr, fg_real* flux_mirror = nullptr,   // flux_B: device [B] scratch, the flux-balance guard computed in the same launch and mirrored to flux_mirror (host-pinned)
+                           FgDtRule rule = FgDtRule{nullptr, nullptr, 0.f, 0.0, 0});
 int fg_launch_flux_balance(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, FgPollOut poll = FgPollOut{nullptr, 0});
 int fg_launch_copy_active(const fg_state* s, const fg_real* dt, const fg_real* src, fg_real* dst, int comps, hipStream_t st);
 int fg_launch_buoyancy(const fg_state* s, const fg_real* dt, const fg_real* T, long t_env_stride, fg_real* source, int axis,

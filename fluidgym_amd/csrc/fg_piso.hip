@@ -469,7 +469,7 @@ __device__ __forceinline__ double fg_flux_balance_block(const FgGrid& g, const F
 // flux_B / flux_mirror (optional): the flux balances workgroup 0 of every env left in flux_B (fg_flux_balance_block, in the same launch)
 // are mirrored with the maxima.
 __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, fg_real* mirror_B, int b, fg_real mx, const FgPollOut& poll, int B,
-                                               fg_real* flux_B = nullptr, fg_real* flux_mirror = nullptr) {
+                                               fg_real* flux_B = nullptr, fg_real* flux_mirror = nullptr, const FgDtRule& rule = FgDtRule{nullptr, nullptr, 0.f, 0.0, 0}) {
     const int lane = threadIdx.x & 63;
     int last_of_all = 0;
     if (lane == 0) {
@@ -497,11 +497,27 @@ __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, 
     if (__shfl(last_of_all, 0, 64)) {
 #if !FG_F64
         if (poll.gran) {
-            // result words (fg_internal.h FgPollOut): the maxima as words [B, 2 B), the flux balances as [0, B) -- no mirror, no release,
+            // result words (fg_internal.h FgPollOut): the maxima as words [12 B, 13 B), the flux balances as [13 B, 14 B) -- no mirror, no release,
             // no write-back of this XCD's L2 at the end of the kernel
             for (int e = lane; e < B; e += 64) {
-                fg_poll_publish_word(poll, B + e, __hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (flux_B) fg_poll_publish_word(poll, e, __hip_atomic_exchange(reinterpret_cast<fg_bits*>(flux_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const fg_bits mbits = __hip_atomic_exchange(reinterpret_cast<fg_bits*>(out_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rule.t_rem) {
+                    // the sub-step of env e (FgDtRule): fg_single_step's host loop statement by statement, in doubles
+                    double tr = rule.reset ? rule.time_step : rule.t_rem[e];
+                    float ts = 0.f;
+                    if (tr > 0.0 && !(fabs(tr) <= 1e-8)) {
+                        const double mv = (double)__uint_as_float(mbits);
+                        const double max_ts = (fabs(mv) <= 1e-8) ? tr : (double)rule.cfl / mv;
+                        const double tsd = (max_ts >= tr) ? tr : tr / (double)(long long)ceil(tr / max_ts);
+                        tr -= tsd;
+                        ts = (float)tsd;
+                    }
+                    rule.t_rem[e] = tr;
+                    rule.dt_out[e] = ts;
+                }
+                // (words [12 B, 14 B): nothing else the step polls reaches them, so the host may read them after the PISO step)
+                fg_poll_publish_word(poll, 12 * B + e, mbits);
+                if (flux_B) fg_poll_publish_word(poll, 13 * B + e, __hip_atomic_exchange(reinterpret_cast<fg_bits*>(flux_B) + e, (fg_bits)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 atomicExch(done_B + e, 0);
             }
             if (lane == 0) atomicExch(done_B + B, 0);
@@ -523,7 +539,7 @@ __device__ __forceinline__ void fg_publish_max(fg_real* out_B, int32_t* done_B, 
 template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
                                                             fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
-                                                            fg_real* __restrict__ mirror_B, FgPollOut poll, fg_real* flux_B, fg_real* flux_mirror) {
+                                                            fg_real* __restrict__ mirror_B, FgPollOut poll, fg_real* flux_B, fg_real* flux_mirror, FgDtRule rule) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     fg_real mx = 0.f;
@@ -577,7 +593,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity(FgGrid g, FgBounds bn
     }
     if (threadIdx.x < 64) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y, flux_B, flux_mirror);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y, flux_B, flux_mirror, rule);
     }
 }
 
@@ -588,7 +604,7 @@ template <int DIMS>
 __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBounds bnd, const fg_real* __restrict__ vel,
                                                                  fg_real* __restrict__ out_B, int32_t* __restrict__ done_B,
                                                                  fg_real* __restrict__ mirror_B, int rows_per_block, FgPollOut poll,
-                                                                 fg_real* flux_B, fg_real* flux_mirror) {
+                                                                 fg_real* flux_B, fg_real* flux_mirror, FgDtRule rule) {
     const int b = blockIdx.y;
     const size_t N = g.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -653,7 +669,7 @@ __global__ __launch_bounds__(FG_BLOCK) void k_max_velocity_rows(FgGrid g, FgBoun
     }
     if (threadIdx.x < 64) {
         mx = FG_FMAX(FG_FMAX(lds[0], lds[1]), FG_FMAX(lds[2], lds[3]));
-        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y, flux_B, flux_mirror);
+        fg_publish_max(out_B, done_B, mirror_B, b, mx, poll, (int)gridDim.y, flux_B, flux_mirror, rule);
     }
 }
 
@@ -1077,7 +1093,8 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
 }
 
 int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_B, hipStream_t st, fg_real* mirror_B, FgPollOut poll,
-                           fg_real* flux_B, fg_real* flux_mirror) {
+                           fg_real* flux_B, fg_real* flux_mirror, FgDtRule rule) {
+    FG_REQUIRE(!rule.t_rem || (poll.gran && mirror_B && !FG_F64), FG_ERR_INVALID_ARG, "the device-side sub-step rule needs the result-word form");
     FG_REQUIRE(!flux_B || (mirror_B && flux_mirror), FG_ERR_INVALID_ARG, "the flux balance rides in the mirrored form only");
     // out_B [B] and the arrival counters right behind it (scratch_B rows 1 and 2) are zeroed together
     int32_t* done_B = reinterpret_cast<int32_t*>(out_B + s->grid.B);
@@ -1095,18 +1112,18 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_
         dim3 grid((rows + rpb - 1) / rpb, s->grid.B);
         if (s->grid.dims == 2)
             hipLaunchKernelGGL(k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb, poll, flux_B, flux_mirror);
+                               mirror_B, rpb, poll, flux_B, flux_mirror, rule);
         else
             hipLaunchKernelGGL(k_max_velocity_rows<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb, poll, flux_B, flux_mirror);
+                               mirror_B, rpb, poll, flux_B, flux_mirror, rule);
         FG_HIP_CHECK(hipGetLastError());
         return FG_OK;
     }
     dim3 grid = stride_grid(s, (long)s->grid.n * 4);
     if (s->grid.dims == 2)
-        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll, flux_B, flux_mirror);
+        hipLaunchKernelGGL(k_max_velocity<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll, flux_B, flux_mirror, rule);
     else
-        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll, flux_B, flux_mirror);
+        hipLaunchKernelGGL(k_max_velocity<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B, mirror_B, poll, flux_B, flux_mirror, rule);
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
 }

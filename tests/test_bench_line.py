@@ -62,3 +62,21 @@ def test_detail_file_is_written(tmp_path):
     target = tmp_path / "detail.json"
     bench.write_detail(out, str(target))
     assert json.loads(target.read_text())["roofline"]["kernels"]
+
+
+def test_lane_profiles_and_iteration_tables_merge_like_one_handle():
+    """Two lanes = two solver handles: the live profiles add field by field, the iteration tables add systems / unconverged / PISO steps,
+    take the maximum of the maxima and weight the means by systems (bench.merge_profiles / merge_iterations)."""
+    a = {"k_x": dict(ms=1.0, samples=2, bytes=10.0, flops=1.0, full_ms=0.5, full_bytes=5.0, full_samples=1, launches=16, all_ms=1.5, all_samples=3)}
+    b = {"k_x": dict(ms=3.0, samples=4, bytes=30.0, flops=2.0, full_ms=1.5, full_bytes=15.0, full_samples=3, launches=32, all_ms=3.5, all_samples=5),
+         "k_y": dict(ms=1.0, samples=1, bytes=1.0, flops=0.0, full_ms=0.0, full_bytes=0.0, full_samples=0, launches=8, all_ms=1.0, all_samples=1)}
+    m = bench.merge_profiles([a, b])
+    assert m["k_x"]["ms"] == 4.0 and m["k_x"]["samples"] == 6 and m["k_x"]["launches"] == 48 and m["k_x"]["all_samples"] == 8
+    assert m["k_y"] == b["k_y"] and a["k_x"]["ms"] == 1.0      # (the inputs are left alone)
+    i0 = {"piso_steps": 10, "velocity": {"mean": 12.0, "max": 12, "unconverged": 0, "systems": 100}, "pressure0": {"mean": 1.0, "max": 2, "unconverged": 1, "systems": 50}}
+    i1 = {"piso_steps": 12, "velocity": {"mean": 6.0, "max": 14, "unconverged": 2, "systems": 300}}
+    it = bench.merge_iterations([i0, i1])
+    assert it["piso_steps"] == 22
+    assert it["velocity"] == {"mean": 7.5, "max": 14, "unconverged": 2, "systems": 400}
+    assert it["pressure0"] == {"mean": 1.0, "max": 2, "unconverged": 1, "systems": 50}
+    assert bench.merge_iterations([i0]) is i0

@@ -46,6 +46,36 @@ def test_spinning_polls_leave_every_bit_of_a_run_where_it_was(env_id, kw, monkey
     assert any(float(o[k].abs().max()) > 0 for o in obs_spin for k in o)
 
 
+def _run_switch(env_id, monkeypatch, name, value, steps=3, **kw):
+    monkeypatch.delenv("FG_POLL_SPIN", raising=False)
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, value)
+    try:
+        return _run(env_id, monkeypatch, True, steps=steps, **kw)
+    finally:
+        monkeypatch.delenv(name, raising=False)
+
+
+@pytest.mark.parametrize("env_id,kw", [("ChannelJet2D-v0", dict(num_envs=3)), ("RBC2D-baseline-v0", dict(num_envs=2)),
+                                       ("TCFSmall3D-both-easy-v0", dict(num_envs=2, resolution_x_z=16, resolution_y=16, step_length=0.6, use_marl=False))])
+@pytest.mark.parametrize("switch", ["FG_POLL_WORDS", "FG_DEV_DT"])
+def test_result_words_and_the_device_side_sub_step_leave_every_bit_where_it_was(env_id, kw, switch, monkeypatch):
+    """Round 6: (a) the polled verdicts, CFL maxima and flux balances travel IN the 8-byte words the host spins on (FgPollOut::gran)
+    instead of through a host-pinned mirror behind a system-scope release -- the same values, unpacked to where the mirror form left them
+    (FG_POLL_WORDS=0 = the mirror form); (b) the adaptive sub-step is taken on the device by the CFL kernel, in the doubles the host
+    uses, and the host reads the maxima after the PISO step (FgDtRule; FG_DEV_DT=0 = before it).  Neither may move a bit of a run
+    (read at fg_create): env steps with random actions, adaptive sub-steps that differ per env."""
+    on = _run_switch(env_id, monkeypatch, switch, None, **kw)
+    off = _run_switch(env_id, monkeypatch, switch, "0", **kw)
+    for a, b in zip(on[0], off[0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (switch, k)
+    for a, b in zip(on[1], off[1]):
+        assert torch.equal(a, b)
+
+
 def test_native_wall_stress_forcing_is_the_python_hook(monkeypatch):
     """Policy ``native_wall_forcing`` (round 4): the turbulent-channel env's PRE hook -- G_x = mean of the two wall shear stresses
     written into the block's velocity source (tcf_env.py, grid.py:147-176) -- runs natively (``fg_set_wall_stress_forcing``: a
