@@ -154,8 +154,10 @@ def pmc_traffic(kernel):
     row = t["kernels"].get(key)
     if row is None:
         return None
-    if isinstance(row, list):
-        row = row[0]
+    if isinstance(row, list):      # (template instances of one kernel: the factoring tridiagonal launch ends in "true>")
+        fac = [r for r in row if r["symbol"].replace(" ", "").endswith(",true>")]
+        plain = [r for r in row if r not in fac]
+        row = (fac or row)[0] if kernel == "k_tridiag_y_fac" else (plain or row)[0]
     return {"fetch_bytes_per_launch": row["fetch_bytes"], "write_bytes_per_launch": row["write_bytes"],
             "launches_averaged": row["launches"], "unit": "B", "source": f"profiles/{src} (rocprofv3 --pmc, "
             "separate FETCH_SIZE and WRITE_SIZE passes of bench.py; averages include launches that found every "
