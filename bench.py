@@ -651,9 +651,9 @@ def compact_line(out, detail_path=DETAIL_PATH):
                       "capped_solves": cfg.get("capped_solves"), "floor_released_solves": cfg.get("floor_released_solves"),
                       "solver_launches_per_piso_step": _r(cfg.get("launches_per_piso_step")),
                       "solver_kernels_GBps": _r(cfg.get("solver_kernels_GBps")), "whole_step_GBps_model": _r(cfg.get("whole_step_GBps_model")),
-                      "GBps_doc": "solver kernels only (r5: step_GBps); _model adds DESIGN 4's assembly + corrector bytes",
+                      "GBps_doc": "solver kernels only; _model adds DESIGN 4's assembly + corrector bytes",
                       "advection_solver_form": cfg.get("advection_solver_form"),
-                      "velocity_solver": (cfg.get("velocity_solver") or "")[:120]}
+                      "velocity_solver": (cfg.get("velocity_solver") or "")[:72]}
     if cfg.get("per_rank"):
         line["config"]["per_rank"] = cfg["per_rank"]
     line["config"]["collective"] = [cfg.get("collective_backend"), cfg.get("collective_world_size")]
@@ -663,7 +663,7 @@ def compact_line(out, detail_path=DETAIL_PATH):
         line["roofline"] = {"bound": roof["bound"], "kernel": roof["kernel"].split(":")[0], "achieved": _r(roof["achieved"]),
                             "peak": roof["peak"], "unit": roof["unit"], "frac": _r(roof["frac"], 3),
                             "traffic": None if not tr else _r(tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"]),
-                            "traffic_unit": "B/launch (--pmc FETCH_SIZE x2 + WRITE_SIZE, last profiled run)",
+                            "traffic_unit": "B/launch, pmc FETCH x2 + WRITE, last profiled run",
                             "algorithmic_bytes_per_launch": _r(roof.get("avg_bytes_per_launch")),
                             "avg_launch_us": _r(1e3 * roof["avg_launch_ms"]), "launches": roof["launches"],
                             "share_of_solver_kernel_time": _r(roof.get("share_of_gpu_time"), 3)}
@@ -673,7 +673,7 @@ def compact_line(out, detail_path=DETAIL_PATH):
             line["roofline"]["note"] = ("loads once, then 8-12 on-chip sweeps per launch: ~half the launch is VALU/LDS work on resident data; "
                                         "krylov_mode leg = the streaming kernels it replaced (k_bicgf_a at ~0.68)")
         if (cfg.get("lanes_per_gpu") or 1) > 1:
-            line["roofline"]["lanes_note"] = "each lane's own launches, timed while the other lane's kernels share the GPU (--lanes 1: alone)"
+            line["roofline"]["lanes_note"] = "timed while the other lane's kernels share the GPU (--lanes 1: alone, DESIGN 8.3b)"
         triad = roof.get("measured_stream_triad")
         if triad and "GBps" in triad:
             line["roofline"]["triad_GBps"] = _r(triad["GBps"])
@@ -690,7 +690,7 @@ def compact_line(out, detail_path=DETAIL_PATH):
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                "one_thread_value": _r(cb.get("one_thread_value")), "sample": cb["sample"][:120]}
+                                "one_thread_value": _r(cb.get("one_thread_value")), "sample": cb["sample"][:96]}
     line["detail"] = detail_path
     text = json.dumps(line, separators=(",", ":"))
     if len(text) >= LINE_LIMIT:   # never let an extra leg push the headline off the driver's tail
