@@ -10,11 +10,19 @@ from __future__ import annotations
 import torch
 
 
+_INDEX_CACHE: dict = {}
+
+
 def _window_index(n_agents: int, window: int, pad: int, device) -> torch.Tensor:
-    """``idx[i, k] = (i - pad + k) mod n``: the agents seen by agent ``i`` (circular)."""
-    i = torch.arange(n_agents, device=device).view(-1, 1)
-    k = torch.arange(window, device=device).view(1, -1)
-    return (i - pad + k) % n_agents
+    """``idx[i, k] = (i - pad + k) mod n``: the agents seen by agent ``i`` (circular).  Static per layout: made once per
+    (layout, device) -- an env step of the turbulent-channel ids asked for it 24 times (four launches each)."""
+    key = (int(n_agents), int(window), int(pad), str(device))
+    idx = _INDEX_CACHE.get(key)
+    if idx is None:
+        i = torch.arange(n_agents, device=device).view(-1, 1)
+        k = torch.arange(window, device=device).view(1, -1)
+        idx = _INDEX_CACHE[key] = (i - pad + k) % n_agents
+    return idx
 
 
 def extract_moving_window_2d(field: torch.Tensor, n_agents: int, agent_width: int, n_agents_per_window: int) -> torch.Tensor:
