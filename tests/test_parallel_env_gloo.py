@@ -229,6 +229,58 @@ def test_two_lanes_of_one_rank_are_the_two_ranks_of_a_world_of_two():
         ParallelFluidEnv("ToyCPU-v0", num_envs=3, backend="gloo", lanes=2)
 
 
+def _lanes_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    _register()
+    from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
+
+    penv = ParallelFluidEnv("ToyCPU-v0", num_envs=8, backend="gloo", lanes=2)
+    assert penv.world == 2 and [e._num_envs for e in penv.lane_envs] == [2, 2]
+    actions = torch.arange(24, dtype=torch.float32).reshape(8, 3) * 0.05
+    penv.seed(7)
+    sampled = penv.sample_action()
+    obs0, infos0 = penv.reset(seed=11)
+    out = penv.step(actions if penv.is_driver else None)
+    out2 = penv.step(actions * 2 if penv.is_driver else None)
+    penv.close()
+    if penv.is_driver:
+        q.put({"obs0": {k: v.numpy().copy() for k, v in obs0.items()}, "r1": out[1].numpy().copy(), "r2": out2[1].numpy().copy(),
+               "o2": {k: v.numpy().copy() for k, v in out2[0].items()}, "term2": out2[2], "n_infos": len(out2[4]),
+               "info_m": np.array([float(i["m"]) for i in out2[4]]), "sampled": sampled.numpy().copy()})
+
+
+def test_two_ranks_of_two_lanes_are_four_shards():
+    """world 2 x lanes 2 (what ``bench.py --gpus N`` runs on every rank): lane l of rank r is virtual rank 2 r + l -- the packed block of
+    a rank is its lanes' rows in lane order, the one all_gather puts the ranks in rank order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lanes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    envs = [ToyEnv(num_envs=2) for _ in range(4)]
+    actions = torch.arange(24, dtype=torch.float32).reshape(8, 3) * 0.05
+    res0 = [e.reset(seed=11 + v) for v, e in enumerate(envs)]
+    r1 = [e.step(actions[2 * v: 2 * v + 2])[1] for v, e in enumerate(envs)]
+    o2r2 = [e.step(2 * actions[2 * v: 2 * v + 2]) for v, e in enumerate(envs)]
+    for k in res0[0][0]:
+        assert np.allclose(got["obs0"][k], torch.cat([x[0][k] for x in res0]).numpy())
+        assert np.allclose(got["o2"][k], torch.cat([x[0][k] for x in o2r2]).numpy())
+    assert np.allclose(got["r1"], torch.cat(r1).numpy()) and np.allclose(got["r2"], torch.cat([x[1] for x in o2r2]).numpy())
+    assert got["term2"] == torch.cat([x[2] for x in o2r2]).tolist() and got["n_infos"] == 8
+    assert np.allclose(got["info_m"], torch.cat([x[4]["m"] for x in o2r2]).numpy())
+    samp = []
+    for v in range(4):
+        e = ToyEnv(num_envs=2)
+        e.seed(7 + v)
+        samp.append(e.sample_action())
+    assert np.allclose(got["sampled"], torch.cat(samp).numpy())
+
+
 def test_forced_collectives_at_world_size_one():
     """The CPU twin of tests/test_gpu_rccl.py: one rank under torch.distributed.run, every command through the group's
     broadcast / all_gather (gloo here, RCCL there), equal to the plain env."""
