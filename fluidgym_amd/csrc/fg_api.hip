@@ -236,17 +236,14 @@ extern "C" int fg_set_scalar_viscosity(fg_handle s, int ch, fg_real v) {
 extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const float* QxT, const float* Qz, const float* QzT,
                                         const float* lower, const float* inv, const float* cp) {
     FG_REQUIRE(s && Qx && QxT && lower && inv && cp, FG_ERR_INVALID_ARG, "null argument");
-#if FG_F64
-    fg_set_error("the fast-diagonalisation preconditioner is an fp32 kernel family: not part of the fp64 build (plain CG there)");
-    return FG_ERR_UNSUPPORTED;
-#else
+    // (the arrays are floats in both builds: the fp64 library's plain kernels promote them on load, fg_f64_fd.hip)
     FG_REQUIRE(s->grid.fixed[2] && s->grid.fixed[3], FG_ERR_UNSUPPORTED, "FD preconditioner needs FIXED y faces");
     FG_REQUIRE(s->grid.dims == 2 || (Qz && QzT), FG_ERR_INVALID_ARG, "Qz required in 3-D");
     const size_t nx = s->grid.nx, ny = s->grid.ny, nz = s->grid.nz;
-    auto up = [&](fg_real** dst, const fg_real* src, size_t count) -> hipError_t {
+    auto up = [&](float** dst, const float* src, size_t count) -> hipError_t {
         if (*dst) (void)hipFree(*dst);
-        hipError_t e = hipMalloc(dst, sizeof(fg_real) * count);
-        if (e == hipSuccess) e = hipMemcpy(*dst, src, sizeof(fg_real) * count, hipMemcpyHostToDevice);
+        hipError_t e = hipMalloc(dst, sizeof(float) * count);
+        if (e == hipSuccess) e = hipMemcpy(*dst, src, sizeof(float) * count, hipMemcpyHostToDevice);
         return e;
     };
     FG_HIP_CHECK(up(&s->fd_Qx, Qx, nx * nx));
@@ -260,7 +257,6 @@ extern "C" int fg_set_fd_preconditioner(fg_handle s, const float* Qx, const floa
     FG_HIP_CHECK(up(&s->fd_cp, cp, nx * ny * nz));
     s->fd_dct_x = 0;  // fg_set_fd_fast_transform marks the axis again for the new basis
     return FG_OK;
-#endif
 }
 
 extern "C" int fg_set_return_best(fg_handle s, int on) {

@@ -1,5 +1,5 @@
 // fp64 build (libfluidgym_hip_f64.so, -DFG_REAL_DOUBLE) only: the kernels that exist in fp32 form alone -- the fast-diagonalisation
-// preconditioner with its MFMA basis changes and LDS FFT, the z-marching 3-D Poisson kernels, the y-line preconditioner -- are not
+// preconditioner's MFMA basis changes and LDS FFT (its operator itself runs in doubles since round 6: fg_f64_fd.hip), the z-marching 3-D Poisson kernels, the y-line preconditioner -- are not
 // instantiated for double.  The core translation units call them through these definitions: "not available", and the callers fall
 // back to the generic kernels (plain CG, generic stencil kernels, unpreconditioned BiCGStab).
 #include "fg_internal.h"
@@ -16,10 +16,7 @@ int fg_zmarch_cg_ap(const fg_state*, const fg_real*, const fg_real*, const fg_re
 bool fg_fd_dct_supported(int) { return false; }
 int fg_fd_dct_forward(fg_state*, const fg_real*, fg_real*, hipStream_t, int, const FgCgJudge*) { return FG_ERR_UNSUPPORTED; }
 int fg_fd_dct_inverse(fg_state*, const fg_real*, fg_real*, const fg_real*, FgDacc*, int, int, hipStream_t, int) { return FG_ERR_UNSUPPORTED; }
-int fg_fd_apply(fg_state*, const fg_real*, fg_real*, FgDacc*, int, int, int, hipStream_t, const FgCgJudge*) {
-    fg_set_error("the fast-diagonalisation preconditioner is an fp32 kernel family: not part of the fp64 build");
-    return FG_ERR_UNSUPPORTED;
-}
+// (fg_fd_apply: fg_f64_fd.hip -- the preconditioner's operator in doubles, plain kernels; round 6)
 int fg_line_alloc(fg_state*) {
     fg_set_error("the y-line preconditioner is an fp32 kernel family: not part of the fp64 build");
     return FG_ERR_UNSUPPORTED;

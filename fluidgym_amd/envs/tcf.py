@@ -307,7 +307,8 @@ class TCF3DBottomEnv(FluidEnv):
         # only: (u * cs).sum() / cs.sum() and (u - mean)[plane] made three full-field passes (a 50 MB product, its sum, a 50 MB
         # difference) for a [B, 2, Z, X] slice
         B = u.shape[0]
-        mean_u = (u[:, :2].reshape(B * 2, -1) @ cs.reshape(-1)).reshape(B, 2, 1, 1) / cs.sum()
+        w = cs.reshape(-1).to(u.dtype)
+        mean_u = (u[:, :2].reshape(B * 2, -1) @ w).reshape(B, 2, 1, 1) / w.sum()
         return {"velocity": u[:, :2, :, y_idx, :] - mean_u, "pressure": self._block.pressure[:, 0, :, y_idx, :]}
 
     def _get_global_obs(self):

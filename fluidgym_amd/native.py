@@ -91,9 +91,11 @@ class NativeSolver:
         self._dt = torch.zeros(self.B, dtype=dtype, device=self.device)
         self._dt_host = torch.zeros(self.B, dtype=dtype).pin_memory()
         self._out_B = torch.zeros(self.B, dtype=dtype, device=self.device)
-        # fast-diagonalisation preconditioner (needs FIXED y faces); default pressure solver when available.  It is an fp32 kernel
-        # family (MFMA basis changes, LDS FFT): the fp64 build runs the reference's plain CG
-        self.has_fd = bool(self.fixed[2] and self.fixed[3]) and not self.f64
+        # fast-diagonalisation preconditioner (needs FIXED y faces); default pressure solver when available.  The fp32 library applies it
+        # with MFMA basis changes / LDS FFTs; the fp64 library applies the same operator with plain kernels in doubles (round 6,
+        # csrc/fg_f64_fd.hip: until then it ran the reference's plain CG -- 250 000 iterations per solve on the refined 512 x 256 grid)
+        # (FLUIDGYM_AMD_F64_FD=0: the fp64 library's plain CG, as before -- A/B runs)
+        self.has_fd = bool(self.fixed[2] and self.fixed[3]) and not (self.f64 and os.environ.get("FLUIDGYM_AMD_F64_FD", "1") == "0")
         self.has_helmholtz = False
         if self.has_fd:
             fp = ctypes.POINTER(ctypes.c_float)
@@ -104,15 +106,16 @@ class NativeSolver:
             qz, qzt = (fpp(fd.Qz), fpp(fd.QzT)) if self.dims == 3 else (None, None)
             L.check(self.lib.fg_set_fd_preconditioner(self.handle, fpp(fd.Qx), fpp(fd.QxT), qz, qzt, fpp(fd.lower),
                                                       fpp(fd.inv), fpp(fd.cp)))
-            if fd.x_cosine_width is not None and os.environ.get("FG_FD_NO_FFT", "0") == "0":
+            no_fft = self.f64 or os.environ.get("FG_FD_NO_FFT", "0") != "0"      # (the row FFTs and the Helmholtz operator are fp32 kernels)
+            if fd.x_cosine_width is not None and not no_fft:
                 # the x basis is the DCT-II basis: apply it as a fast cosine transform instead of the dense GEMM
                 L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_cosine_width), lib=self.lib)
             # Helmholtz preconditioner of the advection-diffusion solves (mode 3 of set_advection_preconditioner): available when
             # the transform axes are periodic and uniform (RBC, TCF)
-            if fd.x_fourier_width is not None and os.environ.get("FG_FD_NO_FFT", "0") == "0":
+            if fd.x_fourier_width is not None and not no_fft:
                 # periodic uniform x: the real Fourier basis, applied as one FFT per row
                 L.check(self.lib.fg_set_fd_fast_transform(self.handle, 0, fd.x_fourier_width), lib=self.lib)
-            self.has_helmholtz = bool(fd.transform_axes_periodic_uniform)
+            self.has_helmholtz = bool(fd.transform_axes_periodic_uniform) and not self.f64
             if self.has_helmholtz:
                 L.check(self.lib.fg_set_fd_helmholtz(self.handle, fpp(fd.lam)), lib=self.lib)
         self.default_method = L.FG_SOLVER_FDCG if self.has_fd else L.FG_SOLVER_CG

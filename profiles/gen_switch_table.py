@@ -43,6 +43,7 @@ NOTES = {
     "FG_POLL_SPIN": ("no", "0: host polls wait with hipStreamSynchronize instead of spinning on pinned sequence words"),
     "FG_POLL_WORDS": ("no", "0: polled verdicts through the host-pinned mirror + a system-scope release (one L2 write-back per verdict kernel) instead of travelling in the 8-byte result words the host spins on (A/B runs: 8 790 against 9 600 env-steps/s on the headline, one lane)"),
     "FG_DEV_DT": ("no", "0: fg_single_step waits for the CFL maxima and computes the adaptive sub-steps on the host before the PISO step, instead of the CFL kernel's last workgroup taking them on the device (FgDtRule: same doubles, same bits) and the host reading the maxima after the step (A/B runs)"),
+    "FLUIDGYM_AMD_F64_FD": ("bits", "0: the fp64 library solves the pressure systems with the reference's plain CG instead of the CG preconditioned by the fast-diagonalisation operator in doubles (csrc/fg_f64_fd.hip; A/B runs: iterations per solve)"),
     "FLUIDGYM_AMD_ENV_GLUE": ("bits", "0: ChannelJet2D's action schedule and reward / observation as elementwise torch launches instead of the two native kernels of fg_envglue.hip (A/B runs; the schedule is bit-identical, the means differ by fp32 rounding of the summation order)"),
     "FLUIDGYM_AMD_LANES": ("no", "default of ParallelFluidEnv(lanes=...): sub-batches of a rank's env batch, each its own solver handle, stepped concurrently by that many host threads on their own HIP streams (1 = one batch; bench.py passes --lanes 2).  Same bits per env as the sub-batches stepped alone"),
     "FG_PROF_PERIOD": ("no", "sampling period of the live kernel timing (64)"),

@@ -106,12 +106,56 @@ def test_fp64_env_steps_like_the_fp32_env():
     assert torch.allclose(r32, r64, rtol=2e-2, atol=1e-4)
 
 
-def test_fp64_build_reports_what_it_does_not_carry():
+def test_fp64_build_reports_what_it_does_not_carry(monkeypatch):
     case = make_case(dims=2, n=(16, 12), fixed_axes=(1,), B=1, seed=1)
     ns = case.native(dtype=F64)
-    assert ns.has_fd is False and ns.default_method == L.FG_SOLVER_CG
+    # round 6: the pressure CG of the fp64 build is preconditioned too (the fast-diagonalisation operator in doubles, csrc/fg_f64_fd.hip)
+    assert ns.has_fd is True and ns.default_method == L.FG_SOLVER_FDCG and ns.has_helmholtz is False
     rc = ns.lib.fg_set_advection_preconditioner(ns.handle, 1)          # the y-line preconditioner is an fp32 kernel family
     assert rc == -4
+    ns.close()
+    monkeypatch.setenv("FLUIDGYM_AMD_F64_FD", "0")                      # (the plain CG of rounds 2-5: A/B runs)
+    ns = case.native(dtype=F64)
+    assert ns.has_fd is False and ns.default_method == L.FG_SOLVER_CG
+    ns.close()
+
+
+@pytest.mark.parametrize("kw", [dict(dims=2, n=(64, 48), fixed_axes=(1,)), dict(dims=2, n=(40, 33), fixed_axes=(0, 1)),
+                                dict(dims=3, n=(20, 18, 12), fixed_axes=(1,)), dict(dims=3, n=(16, 12, 10), fixed_axes=(0, 1, 2))])
+def test_fp64_pressure_cg_is_preconditioned_by_the_fast_diagonalisation_operator(kw):
+    """``fg_poisson_fdcg`` of the fp64 build (round 6, csrc/fg_f64_fd.hip: the operator Qx (Qz) T^-1 (Qz^T) Qx^T in doubles, plain kernels)
+    on wall-refined grids with a variable coefficient: the direct solve's answer to 1e-9, an order of magnitude fewer iterations than the
+    plain CG the fp64 build ran until then (VERDICT r5 "missing 2": 250 000 iterations per solve on the refined 512 x 256 grid), and the
+    residual it reports is the true one."""
+    case = make_case(**kw, B=2, seed=23, stretch=0.8)
+    ns = case.native(dtype=F64)
+    assert ns.has_fd and ns.f64
+    g = case.grid()
+    rng = np.random.default_rng(5)
+    rA = 1.0 / (100.0 * rng.uniform(0.85, 1.3, size=(case.B,) + case.shape))
+    b_ = rng.standard_normal((case.B,) + case.shape)
+    b_ -= b_.mean(axis=tuple(range(1, b_.ndim)), keepdims=True)
+    tol = 1e-11
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x = torch.zeros((case.B,) + case.shape, device="cuda", dtype=F64)
+    info = ns.poisson_fdcg(dev(rA), dev(b_), x, tol=tol, max_iterations=200)
+    xc = torch.zeros_like(x)
+    info_cg = ns.poisson_cg(dev(rA), dev(b_), xc, tol=tol, max_iterations=20000)
+    torch.cuda.synchronize()
+    from tests.test_gpu_parity import _oracle_poisson
+
+    for b in range(case.B):
+        assert info[b].converged and info[b].is_finite and info[b].final_residual < tol, (info[b].used_iterations, info[b].final_residual)
+        assert info_cg[b].converged
+        print(f"F64_FDCG {kw}: env {b} preconditioned {info[b].used_iterations + 1} iterations, plain {info_cg[b].used_iterations + 1}")
+        assert info[b].used_iterations <= 40 and 5 * (info[b].used_iterations + 1) < info_cg[b].used_iterations + 1
+        P = _oracle_poisson(case, g, rA[b])
+        got = _np(x[b])
+        res = b_[b].ravel() - P @ got.ravel()
+        assert float(np.sqrt(np.mean(res ** 2))) < 3 * tol
+        ref = O.solve_direct(P, b_[b].ravel(), singular=True).reshape(case.shape)
+        assert rel_err(got - got.mean(), ref - ref.mean()) < 1e-9
+        assert rel_err(got - got.mean(), _np(xc[b]) - _np(xc[b]).mean()) < 1e-8
     ns.close()
 
 
