@@ -274,8 +274,8 @@ class Domain:
         if dtype not in (torch.float32, torch.float64):
             raise NotImplementedError("field dtype must be torch.float32 (the reference's default, fluid_env.py:146) or torch.float64")
         # torch.float64: the fields, metrics and every kernel of the step run in fp64 on the fp64 build of the library
-        # (libfluidgym_hip_f64.so); the pressure solver is the reference's plain CG there (the fast-diagonalisation
-        # preconditioner is an fp32 kernel family)
+        # (libfluidgym_hip_f64.so); the pressure CG is preconditioned by the fast-diagonalisation operator there as well (plain
+        # kernels in doubles, csrc/fg_f64_fd.hip), the fp32-tuned kernel families are not part of that build
         self.dims = int(spatialDims)
         self.name = name
         self.dtype = dtype
