@@ -475,11 +475,13 @@ int launch_inv(const fg_state* s, int slot, int n, const FcgInvArgs& a, dim3 gri
 
 template <bool PERIODIC>
 int launch_div(const fg_state* s, int n, const FcgDivArgs& a, dim3 grid, hipStream_t st) {
+    // live profile (kind k_div): h (2) read, div, r, u written + the halo rows: 28 B per cell as the stand-alone divergence kernel it replaces
+    const int slot = fg_prof_slot(s, FG_PK_DIV, nullptr, s->grid.B, 28.0 * (double)s->grid.n, (8.0 + 5.0 * log2((double)n)) * (double)s->grid.n, st);
     switch (n) {
-        case 64: hipLaunchKernelGGL((k_fcg_div_fwd<64, PERIODIC>), grid, dim3(256), 0, st, a); break;
-        case 128: hipLaunchKernelGGL((k_fcg_div_fwd<128, PERIODIC>), grid, dim3(256), 0, st, a); break;
-        case 256: hipLaunchKernelGGL((k_fcg_div_fwd<256, PERIODIC>), grid, dim3(256), 0, st, a); break;
-        case 512: hipLaunchKernelGGL((k_fcg_div_fwd<512, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 64: FG_LAUNCH_P(s, slot, (k_fcg_div_fwd<64, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 128: FG_LAUNCH_P(s, slot, (k_fcg_div_fwd<128, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 256: FG_LAUNCH_P(s, slot, (k_fcg_div_fwd<256, PERIODIC>), grid, dim3(256), 0, st, a); break;
+        case 512: FG_LAUNCH_P(s, slot, (k_fcg_div_fwd<512, PERIODIC>), grid, dim3(256), 0, st, a); break;
         default: fg_set_error("fused CG: unsupported row length"); return FG_ERR_UNSUPPORTED;
     }
     return FG_OK;

@@ -539,7 +539,9 @@ __device__ __forceinline__ void fg_block_sum(fg_real (&v)[NV], fg_real* lds /* >
 enum FgProfKind {
     FG_PK_CG_AP = 0, FG_PK_CG_UPDATE, FG_PK_BICG_P, FG_PK_BICG_V, FG_PK_BICG_S, FG_PK_BICG_T, FG_PK_BICG_X,
     FG_PK_GEMM, FG_PK_GEMM_SK, FG_PK_TRIDIAG, FG_PK_DCT, FG_PK_LINE, FG_PK_BICGF_A, FG_PK_BICGF_B, FG_PK_FCG_UPD, FG_PK_FCG_INV,
-    FG_PK_FBICG_FWD, FG_PK_FBICG_INV, FG_PK_JAC_PASS, FG_PK_JAC_STREAM, FG_PK_TRIDIAG_FAC, FG_PK_COUNT
+    FG_PK_FBICG_FWD, FG_PK_FBICG_INV, FG_PK_JAC_PASS, FG_PK_JAC_STREAM, FG_PK_TRIDIAG_FAC,
+    // round 6: the streaming kernels of the PISO step around the solves (all envs of the batch counted as live)
+    FG_PK_ADV_BUILD, FG_PK_H, FG_PK_DIV, FG_PK_CORRECT, FG_PK_MAXVEL, FG_PK_COUNT
 };
 #define FG_PROF_POOL 256
 struct FgProfMeta { int kind; int nsys; double bytes_per_sys; double flops_per_sys; };

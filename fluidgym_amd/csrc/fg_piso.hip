@@ -906,17 +906,20 @@ int fg_launch_adv_build(const fg_state* s, const FgBounds& bnd, const FgAdvArgs&
     a.begin.acc = s->acc; a.begin.sc = s->scratch_B + 4 * s->grid.B; a.begin.flags = s->flags; a.begin.info = s->info_dev;
     a.begin.nc = a.for_scalar ? 1 : s->grid.dims;
     s->bicg_ready_nc = a.begin.nc; s->bicg_ready_dt = a.dt; s->cg_ready_ns = 0;
+    // live profile: u (d) + the matrix (1 + 2 d) + the right-hand sides (d) written, u and the source read: 44 B per cell in 2-D, 56 in 3-D
+    const double nd = (double)s->grid.n;
+    const int slot = fg_prof_slot(s, FG_PK_ADV_BUILD, nullptr, s->grid.B, (s->grid.dims == 3 ? 56.0 : 44.0) * nd, 30.0 * nd, st);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
         if (a.for_scalar)
-            hipLaunchKernelGGL((k_adv_build<DIMS, VEC, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
-                               L.tiles_y, L.tiles);
+            FG_LAUNCH_P(s, slot, (k_adv_build<DIMS, VEC, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
+                        L.tiles_y, L.tiles);
         else if (a.visc)
-            hipLaunchKernelGGL((k_adv_build<DIMS, VEC, false, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
-                               L.tiles_y, L.tiles);
+            FG_LAUNCH_P(s, slot, (k_adv_build<DIMS, VEC, false, true>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
+                        L.tiles_y, L.tiles);
         else
-            hipLaunchKernelGGL((k_adv_build<DIMS, VEC, false>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
-                               L.tiles_y, L.tiles);
+            FG_LAUNCH_P(s, slot, (k_adv_build<DIMS, VEC, false>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, a, L.tiles_x,
+                        L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
@@ -1039,10 +1042,11 @@ int fg_launch_h(const fg_state* s, const fg_real* dt, const fg_real* vel_result,
     begin.acc = s->cg_acc; begin.flags = s->flags; begin.info = s->info_dev; begin.mean_sums = s->acc; begin.best = s->cg_best;
     begin.track_best = s->cg_return_best; begin.ns = fg_cg_slots(s); begin.xsum = s->fcg_xsum;
     s->cg_ready_ns = begin.ns; s->cg_ready_best = begin.track_best; s->cg_ready_dt = dt; s->bicg_ready_nc = 0; s->cg_start_ready = 0;
+    const int slot_h = fg_prof_slot(s, FG_PK_H, nullptr, s->grid.B, (s->grid.dims == 3 ? 68.0 : 52.0) * (double)s->grid.n, 6.0 * s->grid.dims * s->grid.dims * (double)s->grid.n, st);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_h<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, s->rA, s->Coff, s->adv_rhs,
-                           vel_result, s->hvec, begin, L.tiles_x, L.tiles_y, L.tiles);
+        FG_LAUNCH_P(s, slot_h, (k_h<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, s->rA, s->Coff, s->adv_rhs,
+                    vel_result, s->hvec, begin, L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
     fg_htrace("h_launch_out");
@@ -1068,10 +1072,11 @@ int fg_launch_div(const fg_state* s, const FgBounds& bnd, const fg_real* dt, con
         start.acc = s->cg_acc; start.r = s->w[0]; start.x = s->p_result; start.ns = s->cg_ready_ns;
         s->cg_start_ready = 1;
     }
+    const int slot_d = fg_prof_slot(s, FG_PK_DIV, nullptr, s->grid.B, 28.0 * (double)s->grid.n, 4.0 * s->grid.dims * (double)s->grid.n, st);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_div<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, dt, hvec, div, start, L.tiles_x,
-                           L.tiles_y, L.tiles);
+        FG_LAUNCH_P(s, slot_d, (k_div<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, dt, hvec, div, start, L.tiles_x,
+                    L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
     return FG_OK;
@@ -1082,10 +1087,13 @@ int fg_launch_correct(const fg_state* s, const fg_real* dt, const fg_real* rA, c
     fg_htrace("correct_in");
     const FgMeanRef mr = mean ? *mean : FgMeanRef{nullptr, nullptr, nullptr, nullptr, nullptr};
     const FgLazyRef lz = lazy ? *lazy : FgLazyRef{nullptr, nullptr, nullptr};
+    // live profile: rA, h (d), p read, u (d) written -- plus the block copy / pressure the last corrector also writes
+    const double cb = (s->grid.dims == 3 ? 36.0 : 28.0) + (vel_copy ? 4.0 * s->grid.dims : 0.0) + ((mean && mean->sums) || (lazy && lazy->p_res) ? 4.0 : 0.0);
+    const int slot_c = fg_prof_slot(s, FG_PK_CORRECT, nullptr, s->grid.B, cb * (double)s->grid.n, 5.0 * s->grid.dims * (double)s->grid.n, st);
     FG_DISPATCH(s, {
         const FgLaunch L = fg_launch_geometry<DIMS, VEC>(s->grid);
-        hipLaunchKernelGGL((k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out, vel_copy, mr, lz,
-                           L.tiles_x, L.tiles_y, L.tiles);
+        FG_LAUNCH_P(s, slot_c, (k_correct<DIMS, VEC>), L.grid, dim3(FG_BLOCK), 0, st, s->grid, dt, rA, hvec, p, vel_out, vel_copy, mr, lz,
+                    L.tiles_x, L.tiles_y, L.tiles);
     });
     FG_HIP_CHECK(hipGetLastError());
     fg_htrace("correct_out");
@@ -1110,12 +1118,13 @@ int fg_launch_max_velocity(const fg_state* s, const FgBounds& bnd, fg_real* out_
         while ((long)((rows + 2 * rpb - 1) / (2 * rpb)) * s->grid.B >= 2048) rpb *= 2;
         while ((rows + rpb - 1) / rpb > (int)fg_reduce_wgs(s)) rpb *= 2;  // ... and few per env: they meet in same-address atomics
         dim3 grid((rows + rpb - 1) / rpb, s->grid.B);
+        const int slot_m = fg_prof_slot(s, FG_PK_MAXVEL, nullptr, s->grid.B, 4.0 * s->grid.dims * (double)s->grid.n, 2.0 * s->grid.dims * (double)s->grid.n, st);
         if (s->grid.dims == 2)
-            hipLaunchKernelGGL(k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb, poll, flux_B, flux_mirror, rule);
+            FG_LAUNCH_P(s, slot_m, k_max_velocity_rows<2>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
+                        mirror_B, rpb, poll, flux_B, flux_mirror, rule);
         else
-            hipLaunchKernelGGL(k_max_velocity_rows<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
-                               mirror_B, rpb, poll, flux_B, flux_mirror, rule);
+            FG_LAUNCH_P(s, slot_m, k_max_velocity_rows<3>, grid, dim3(FG_BLOCK), 0, st, s->grid, bnd, s->velocity, out_B, done_B,
+                        mirror_B, rpb, poll, flux_B, flux_mirror, rule);
         FG_HIP_CHECK(hipGetLastError());
         return FG_OK;
     }

@@ -23,7 +23,8 @@ __global__ void k_prof_count(const int32_t* __restrict__ flags, int nsys, int32_
 }
 const char* const kNames[FG_PK_COUNT] = {"k_cg_ap", "k_cg_update", "k_bicg_p", "k_bicg_v", "k_bicg_s", "k_bicg_t",
                                          "k_bicg_x", "k_gemm_f32", "k_gemm_sk", "k_tridiag_y", "k_dct_rows", "k_line_y", "k_bicgf_a", "k_bicgf_b",
-                                         "k_fcg_update_fwd", "k_fcg_inv_apply", "k_fbicg_fwd", "k_fbicg_inv", "k_jac_pass", "k_jac_stream", "k_tridiag_y_fac"};
+                                         "k_fcg_update_fwd", "k_fcg_inv_apply", "k_fbicg_fwd", "k_fbicg_inv", "k_jac_pass", "k_jac_stream", "k_tridiag_y_fac",
+                                         "k_adv_build", "k_h", "k_div", "k_correct", "k_max_velocity"};
 }  // namespace
 
 int fg_prof_slot(const fg_state* cs, int kind, const int32_t* flags, int nsys, double bytes_per_sys,
