@@ -1104,16 +1104,17 @@ __global__ __launch_bounds__(FG_BLOCK) void k_mbc_restart(MbDev D, MbSolve q, in
 
 __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32_t* __restrict__ flag_mirror, int rr_slot,
                             int it, int n, int nsys, int final_pass, int sum_slot = -1, FgPollOut poll = FgPollOut{nullptr, 0}) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsys) return;
+    __shared__ uint32_t stage[64 * 3];
+    const int first = blockIdx.x * blockDim.x, s = first + threadIdx.x;
+    const bool valid = s < nsys;
     if (it < 0) {  // graph-replayed CG: iteration index and accumulator slots from the device counter
         it = q.it_ctr[0] - 1;
         rr_slot = C_RHO + (it + 1) % 3;
         if (sum_slot != -1) sum_slot = C_SUM + (it + 1) % 3;
         final_pass = (it + 1 >= q.max_iterations);
     }
-    if (flag_ld(q.flags + (s)) == 4) flag_st(q.flags + (s), 1);
-    if (flag_ld(q.flags + (s)) == 0) {
+    if (valid && flag_ld(q.flags + (s)) == 4) flag_st(q.flags + (s), 1);
+    if (valid && flag_ld(q.flags + (s)) == 0) {
         double rr = acc_ld(q.acc + ((size_t)s * MB_ACC + rr_slot));
         if (sum_slot >= 0) { const double sr = acc_ld(q.acc + ((size_t)s * MB_ACC + sum_slot)); rr -= sr * sr; }
         const mb_real crit = (mb_real)sqrt(rr / (double)n);
@@ -1136,6 +1137,17 @@ __global__ void k_mbs_check(MbSolve q, fg_solve_info* __restrict__ mirror, int32
             flag_st(q.flags + (s), 1);
         }
     }
+#if !FG_MB_F64
+    if (poll.gran) {
+        // result words (FgPollOut, fg_internal.h), three per system: residual, info word, flag -- the verdicts travel in the words the host
+        // spins on, no release and no write-back of this XCD's L2 (mb_poll unpacks them to where the mirrors leave them)
+        uint32_t w[3] = {0u, 0u, 0u};
+        if (valid) { const fg_solve_info v = q.info[s]; w[0] = __float_as_uint((float)v.final_residual); w[1] = fg_info_word(v); w[2] = (uint32_t)flag_ld(q.flags + (s)); }
+        fg_poll_publish_records<3>(poll, first, min((int)blockDim.x, nsys - first), threadIdx.x, w, valid, stage);
+        return;
+    }
+#endif
+    if (!valid) return;
     mirror[s] = q.info[s];
     flag_mirror[s] = flag_ld(q.flags + (s));
     fg_poll_publish(poll, s);      // (after both mirrors: the host spins on this word instead of synchronising the stream)
@@ -1275,8 +1287,18 @@ __global__ void k_mbb_verify(MbSolve q, int32_t* __restrict__ verified, int n, i
     }
 }
 
-int mb_poll(fg_mb_state* s, int nsys, hipStream_t st, bool& done, const FgPollOut& po) {
-    if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
+int mb_poll(fg_mb_state* s, int nsys, hipStream_t st, bool& done, const FgPollOut& po, bool words) {
+    // words: the polled kernel was k_mbs_check, whose verdicts arrive in the result words when the poll has them
+    if (words && po.gran) {
+        if (int rc = fg_poll_wait_words(&s->poll, po, 0, 3 * nsys, st)) return rc;
+        for (int i = 0; i < nsys; ++i) {
+            fg_solve_info& I = s->info_pinned[i];
+            const uint32_t wd = fg_poll_word(&s->poll, 3 * i + 1);
+            I.final_residual = fg_poll_word_float(&s->poll, 3 * i);
+            I.used_iterations = (int32_t)(wd >> 2) - 1; I.converged = (wd >> 1) & 1; I.is_finite = wd & 1;
+            s->flags_pinned[i] = (int32_t)fg_poll_word(&s->poll, 3 * i + 2);
+        }
+    } else if (int rc = fg_poll_wait(&s->poll, po, 0, nsys, st)) return rc;
     done = true;
     for (int i = 0; i < nsys; ++i) done = done && s->flags_pinned[i] != 0;
     return FG_OK;
@@ -1532,7 +1554,7 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
             next_poll = it + 1 + (it < 20 ? 2 : 10);   // long (pressure) solves: fewer host round trips
             FgPollOut po = fg_poll_next(&s->poll);
             hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, (int)(it + 1 == max_iterations), -1, po);
-            if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
+            if (int rc = mb_poll(s, nsys, st, done, po, true)) return rc;
             if (int rc = update_map()) return rc;
             if (nc == 1 && s->dbg_trace) {
                 mb_real lo = 1e30f, hi = 0.f; int active = 0;
@@ -1558,7 +1580,7 @@ int mb_bicgstab(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb
                     if (refine) keep_best(0);
                     po = fg_poll_next(&s->poll);
                     hipLaunchKernelGGL(k_mbs_check, sg, sb, 0, st, q, s->info_pinned, s->flags_pinned, A_RR, it, n, nsys, 0, -1, po);
-                    if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
+                    if (int rc = mb_poll(s, nsys, st, done, po, true)) return rc;
                     if (int rc = update_map()) return rc;
                     next_poll = it + 1 + 2;
                     if (nc == 1 && s->dbg_trace) {
@@ -1778,7 +1800,7 @@ int mb_jacobi(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_r
         const FgPollOut po = fg_poll_next(&s->poll);
         run_to_check(upto, po);
         bool done = false;
-        if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
+        if (int rc = mb_poll(s, nsys, st, done, po, false)) return rc;
         bool bad = false;
         double need = 0.0;
         for (int i = 0; i < nsys; ++i) {
@@ -1971,7 +1993,7 @@ int mb_cg(fg_mb_state* s, const mb_real* dt, const mb_real* diag, const mb_real*
         const FgPollOut po = use_graph ? FgPollOut{nullptr, 0} : fg_poll_next(&s->poll);
         if (use_graph) FG_HIP_CHECK(hipGraphLaunch(s->cg_graph_exec, st));
         else enqueue_chunk(s->prof_on && (s->prof_chunk++ % 4 == 0), po);
-        if (int rc = mb_poll(s, nsys, st, done, po)) return rc;
+        if (int rc = mb_poll(s, nsys, st, done, po, true)) return rc;
         active_now = 0;
         for (int i = 0; i < nsys; ++i) active_now += s->flags_pinned[i] == 0;
         if (s->prof_used) if (int rc = prof_collect()) return rc;
