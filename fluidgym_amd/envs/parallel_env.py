@@ -97,6 +97,8 @@ class _Lanes:
         self._check_solvers()
 
     def __getattr__(self, name: str) -> Any:      # spaces, episode length, counters ...: every lane is the same env class and options
+        if name in ("envs", "_pool", "_streams"):      # (not built yet: a failed constructor must not recurse through this hook)
+            raise AttributeError(name)
         return getattr(self.envs[0], name)
 
     def _check_solvers(self) -> None:
@@ -205,9 +207,11 @@ class _Lanes:
             e.test()
 
     def close(self) -> None:
-        for e in self.envs:
+        for e in self.__dict__.get("envs", []):
             e.close()
-        self._pool.shutdown(wait=True)
+        pool = self.__dict__.get("_pool")
+        if pool is not None:
+            pool.shutdown(wait=True)
 
 
 class ParallelFluidEnv:
@@ -305,6 +309,8 @@ class ParallelFluidEnv:
 
     # ------------------------------------------------------------------ introspection
     def __getattr__(self, name: str) -> Any:
+        if name == "_env":      # (not built yet: a constructor that raised must not recurse through this hook)
+            raise AttributeError(name)
         return getattr(self._env, name)
 
     @property
