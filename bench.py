@@ -634,12 +634,12 @@ def _leg_summary(leg):
     if (leg.get("lanes") or 1) > 1:
         s["lanes"] = leg["lanes"]
     for k in ("capped_solves", "floor_released_solves", "launches_per_piso_step", "oracle_iters", "busy_cus"):
-        if leg.get(k) is not None:
+        if leg.get(k) is not None and not (k in ("capped_solves", "floor_released_solves") and leg[k] == 0):      # (zero counts: see legs_doc)
             s[k] = _r(leg[k])
     # adaptive-CFL sub-steps make an env step as long as the flow is fast (RBC: 1.35 sub-steps per sim step two env steps after a
     # reset, 2.9 eight steps later): PISO steps per second is the figure that compares across states
     sub, n_sim = leg.get("mean_substeps_per_sim_step"), leg.get("piso_steps_per_env_step")
-    if sub is not None and n_sim and leg.get("ms_per_step"):
+    if sub is not None and n_sim and leg.get("ms_per_step") and abs(sub - 1.0) > 0.02:      # (only where sub-steps make env steps incomparable)
         s["substeps"] = _r(sub, 3)
         s["piso_steps_per_s"] = _r(leg.get("envs", 1) * n_sim * sub / (leg["ms_per_step"] * 1e-3), 4)
     return s
@@ -703,6 +703,7 @@ def compact_line(out, detail_path=DETAIL_PATH):
     legs = {k: _leg_summary(v) for k, v in out.get("legs", {}).items()}
     if legs:
         line["legs"] = legs
+        line["legs_doc"] = "capped_solves / floor_released_solves of a leg are printed when > 0"
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -970,6 +971,10 @@ def main():
         import fluidgym_amd
 
         half = max(5, min(args.steps // 2, 8))
+        if args.lanes > 1:
+            # the headline's kernels ALONE on the GPU: what `roofline` above would read without the other lane's kernels sharing the CUs
+            leg("one_lane_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=half, warmup=2, seed=1234, forcing=args.forcing,
+                doc="headline workload as ONE batch of 64 envs (--lanes 1): env-steps/s and the dominant kernel's roofline fraction with the GPU to itself")
         leg("quiescent_mode", env_leg, args.env_id, args.envs_per_gpu, device, steps=half, warmup=2, seed=1234,
             doc="headline workload without the body force: the laminar channel's pressure right-hand side sits at the "
                 "reference's absolute tolerance, the projections take 0-1 iterations")
