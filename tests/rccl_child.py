@@ -16,6 +16,38 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+class _PlainLanes:
+    """L plain env batches stepped one after the other, seeds ``seed + l``: what ``ParallelFluidEnv(lanes=L)`` must reproduce."""
+
+    def __init__(self, envs):
+        self.envs = envs
+        self.action_space = envs[0].action_space
+        z = envs[0]._zero_action
+        self._zero_action = z.new_zeros((len(envs) * z.shape[0],) + tuple(z.shape[1:]))
+
+    def seed(self, s):
+        for l, e in enumerate(self.envs):
+            e.seed(s + l)
+
+    def reset(self, seed):
+        res = [e.reset(seed=seed + l) for l, e in enumerate(self.envs)]
+        return {k: torch.cat([r[0][k] for r in res]) for k in res[0][0]}, [r[1] for r in res]
+
+    def sample_action(self):
+        return torch.cat([e.sample_action() for e in self.envs])
+
+    def step(self, a):
+        n = a.shape[0] // len(self.envs)
+        res = [e.step(a[l * n: (l + 1) * n]) for l, e in enumerate(self.envs)]
+        info = {k: torch.cat([torch.as_tensor(r[4][k]) for r in res]) for k in res[0][4]
+                if isinstance(res[0][4][k], torch.Tensor) and res[0][4][k].dim() > 0}
+        return {k: torch.cat([r[0][k] for r in res]) for k in res[0][0]}, torch.cat([r[1] for r in res]), res[0][2], res[0][3], info
+
+    def close(self):
+        for e in self.envs:
+            e.close()
+
+
 def main() -> int:
     backend, env_id, num_envs = sys.argv[1], sys.argv[2], int(sys.argv[3])
     kw = {}
@@ -30,13 +62,17 @@ def main() -> int:
     import fluidgym_amd
     from fluidgym_amd.envs.parallel_env import ParallelFluidEnv
 
-    penv = ParallelFluidEnv(env_id, num_envs=num_envs, backend=backend, force_collectives=True, **kw)
+    lanes = int(kw.pop("lanes", 1))      # lanes=L: the rank's shard as L sub-batches on their own HIP streams (ParallelFluidEnv "Lanes")
+    penv = ParallelFluidEnv(env_id, num_envs=num_envs, backend=backend, force_collectives=True, lanes=lanes, **kw)
     assert dist.is_initialized() and dist.get_backend() == backend and penv.world == 1 and penv._collective
     plain_kw = dict(kw)
     if backend == "nccl":
         plain_kw["cuda_device"] = penv._device
-    plain = fluidgym_amd.make(env_id, num_envs=num_envs, **plain_kw)
-    report = {"backend": dist.get_backend(), "world": penv.world, "device": str(penv._device), "checks": 0}
+    if lanes > 1:
+        plain = _PlainLanes([fluidgym_amd.make(env_id, num_envs=num_envs // lanes, **plain_kw) for _ in range(lanes)])
+    else:
+        plain = fluidgym_amd.make(env_id, num_envs=num_envs, **plain_kw)
+    report = {"backend": dist.get_backend(), "world": penv.world, "device": str(penv._device), "checks": 0, "lanes": lanes}
 
     def same(a, b, what):
         assert torch.equal(a.to(b.device), b), what

@@ -41,3 +41,12 @@ def _run_child(backend, env_id, num_envs, *kv, timeout=900):
 def test_rccl_broadcast_and_all_gather_reproduce_the_plain_env(env_id, kv):
     rep = _run_child("nccl", env_id, 4, *kv)
     assert rep["backend"] == "nccl" and rep["world"] == 1 and rep["device"].startswith("cuda") and rep["checks"] >= 10, rep
+
+
+def test_rccl_collectives_carry_the_lanes_of_a_rank():
+    """``lanes=2`` under the RCCL branch (what every rank of ``bench.py --gpus N`` runs): the shard's two sub-batches are stepped on
+    their own HIP streams, packed in lane order and carried by the group's broadcast / all_gather -- equal, bit for bit, to the two
+    batches stepped alone with seeds ``seed`` and ``seed + 1``."""
+    rep = _run_child("nccl", "ChannelJet2D-v0", 4, "resolution_x=64", "resolution_y=32", "randomize_initial_state=false", "lanes=2")
+    assert rep["backend"] == "nccl" and rep["world"] == 1 and rep["lanes"] == 2 and rep["checks"] >= 10, rep
+
